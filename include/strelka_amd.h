@@ -1,0 +1,206 @@
+/*
+ * strelka_amd.h -- C-ABI of the MI355X-native Strelka2 hot path.
+ *
+ * Every entry point replaces one call site of the reference (Illumina/strelka v2.9.x); the reference has no FFI
+ * seam of its own, so the seam is introduced directly below the `starling_pos_processor_base`
+ * class surface, at the call sites cited on each function.  `L/` = `src/c++/lib/` of the reference tree.
+ *
+ * Conventions
+ *  - plain C: POD structs, pointers and sizes only.  No C++/torch types cross this boundary.
+ *  - every function returns 0 on success, non-zero on failure; `sk_last_error()` gives the message.  Nothing throws or
+ *    aborts across the ABI (the reference throws `blt_exception`; the host adapter in INTEGRATION.md converts).
+ *  - batches are flat SoA with CSR offsets for ragged dimensions (reads->candidate alignments->ops, loci->calls,
+ *    indels->reads).  The caller owns every buffer; the library retains no pointer after a call returns.
+ *  - `*_dev` variants take DEVICE pointers inside the same batch structs plus a `hipStream_t` (as `void*`) and only
+ *    enqueue work; the plain variants take HOST pointers, stage through library-owned device buffers, and block.
+ *  - one host thread per process (as in the reference); many processes may share one GPU.
+ *
+ * The product path has no CPU fallback: if the HIP runtime or a gfx950 device is missing `sk_init` fails.
+ */
+#ifndef STRELKA_AMD_H
+#define STRELKA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SK_VERSION 100
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * lifecycle
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+/** Select `device`, build the host-side q-score/likelihood tables with the host libm (exactly the expressions of
+ *  L/blt_util/qscore_cache.cpp:34-50 and the memoised tables of
+ *  L/applications/strelka/position_somatic_snv_strand_grid_lhood_cached.cpp:41-234) and upload them.
+ *  Idempotent for the same device. */
+int sk_init(int device);
+void sk_shutdown(void);
+const char* sk_last_error(void);
+int sk_version(void);
+/** 1 when sk_init succeeded on a gfx950 device. */
+int sk_is_initialized(void);
+
+/** Host copies of the q-score tables the kernels use (71 entries each, Q0..Q70; L/blt_util/qscore_cache.hh:66-68). */
+int sk_get_qscore_tables(double* q2p, double* q2lncompe, double* q2lne);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Hot path A: candidate-alignment scoring
+ *   replaces the loop at L/starling_common/starling_read_align.cpp:1568-1569 calling
+ *   scoreCandidateAlignment (L/starling_common/starling_read_align_score.cpp:261-499).
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+/** BAM 4-bit base codes, one per byte (L/htsapi/bam_seq.hh:30-50). */
+enum { SK_BAM_REF = 0, SK_BAM_A = 1, SK_BAM_C = 2, SK_BAM_G = 4, SK_BAM_T = 8, SK_BAM_ANY = 15 };
+
+/** Scoring op kinds: a candidate alignment's CIGAR + indel keys flattened in path order by
+ *  sk_flatten_candidate_alignment (host adapter).  Read offset advances by `length` for MATCH/INSERT/SOFT_CLIP. */
+enum {
+    SK_OP_MATCH = 0,     /* score read[ro+i] against ref window [src+i]          (scoreMatchSegment :144-170)  */
+    SK_OP_INSERT = 1,    /* score read[ro+i] against insert pool [src+i]         (scoreInsertSegment :110-137) */
+    SK_OP_SOFT_CLIP = 2, /* lnp += length * ln(0.25)                             (:453-454)                    */
+    SK_OP_NOBASE = 3     /* DELETE/SKIP/HARD_CLIP: no base term, only the optional penalty (:419-460)          */
+};
+/** flags bit 0: add ln(1e-5) after this op (its indel is not a candidate, :471-487). */
+enum { SK_OPFLAG_NONCANDIDATE_PENALTY = 1 };
+
+typedef struct sk_score_op {
+    uint16_t length;
+    uint8_t kind;
+    uint8_t flags;
+    int32_t src; /* MATCH: offset into this read's reference window; INSERT: offset into ins_code pool */
+} sk_score_op;
+
+typedef struct sk_align_batch {
+    int32_t n_reads;
+    int32_t n_cals;           /* total candidate alignments = cal_off[n_reads] */
+    int64_t n_ops;            /* = op_off[n_cals] */
+    const int64_t* read_off;  /* [n_reads+1] into read_code/read_qual */
+    const uint8_t* read_code; /* BAM 4-bit codes, 1/byte */
+    const uint8_t* read_qual; /* phred, must be <= 70 */
+    const int64_t* ref_off;   /* [n_reads+1] per-read reference window into ref_code */
+    const uint8_t* ref_code;  /* BAM 4-bit codes of the reference window ('N'/outside contig segment = 15) */
+    const int32_t* cal_off;   /* [n_reads+1] candidate-alignment range of each read */
+    const int64_t* op_off;    /* [n_cals+1] op range of each candidate alignment */
+    const sk_score_op* ops;   /* [n_ops] */
+    const uint8_t* ins_code;  /* insert-sequence pool (BAM 4-bit codes) */
+    int64_t n_ins;            /* size of ins_code in bytes */
+} sk_align_batch;
+
+/** out_lnp[n_cals]: ln P(read | alignment), double, bit-identical to the reference's sequential accumulation. */
+int sk_score_alignments(const sk_align_batch* host_batch, double* out_lnp);
+int sk_score_alignments_dev(const sk_align_batch* dev_batch, double* dev_out_lnp, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Hot path B (germline SNV): dependent error probabilities + diploid genotype likelihoods
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+/** 16-bit packed basecall, identical bit layout to the reference's `base_call` bitfield
+ *  (L/blt_common/snp_pos_info.hh:109-117, GCC little-endian allocation):
+ *  bits 0-5 qscore, 6-9 base_id (0..3 = ACGT), 10 is_fwd_strand, 11 is_neighbor_mismatch, 12 is_call_filter,
+ *  13 is_tier_specific_call_filter. */
+#define SK_CALL_Q(c) ((unsigned)((c) & 0x3f))
+#define SK_CALL_BASE(c) ((unsigned)(((c) >> 6) & 0xf))
+#define SK_CALL_FWD(c) ((unsigned)(((c) >> 10) & 1))
+#define SK_CALL_NMM(c) ((unsigned)(((c) >> 11) & 1))
+#define SK_CALL_FILTER(c) ((unsigned)(((c) >> 12) & 1))
+#define SK_CALL_TSCF(c) ((unsigned)(((c) >> 13) & 1))
+#define SK_MAKE_CALL(q, base, fwd, nmm, filt, tscf) \
+    ((uint16_t)(((q) & 0x3f) | (((base) & 0xf) << 6) | (((fwd) & 1) << 10) | (((nmm) & 1) << 11) | (((filt) & 1) << 12) | (((tscf) & 1) << 13)))
+
+typedef struct sk_pileup_batch {
+    int32_t n_loci;
+    const int64_t* call_off; /* [n_loci+1] into calls/de */
+    const uint16_t* calls;   /* cleaned pileup (PileupCleaner::CleanPileupFilter output), pileup order */
+    const float* de;         /* dependent error prob per call (epi.de); may be NULL only for sk_dependent_eprob */
+    const uint8_t* ref_base; /* [n_loci] base id 0..3, 4 = 'N' */
+    const uint8_t* ploidy;   /* [n_loci] 0,1,2; NULL = all diploid (dgt.ploidy, position_snp_call_pprob_digt.hh:100) */
+} sk_pileup_batch;
+
+/** Options of the germline SNV model (defaults: L/applications/starling/starling_shared.hh:34-39,
+ *  L/blt_common/blt_shared.hh:82-84). */
+typedef struct sk_germline_options {
+    double bsnp_diploid_theta;    /* 0.001 */
+    double bsnp_ssd_no_mismatch;  /* 0.35 */
+    double bsnp_ssd_one_mismatch; /* 0.6 */
+    int32_t is_min_vexp;          /* 1 */
+    double min_vexp;              /* 0.25 */
+} sk_germline_options;
+void sk_germline_options_default(sk_germline_options* opt);
+
+/** a9: replaces adjust_joint_eprob at L/starling_common/PileupCleaner.cpp:73 (L/blt_common/adjust_joint_eprob.cpp:201-243).
+ *  out_de[total calls]. */
+int sk_dependent_eprob(const sk_pileup_batch* host_batch, const sk_germline_options* opt, float* out_de);
+int sk_dependent_eprob_dev(const sk_pileup_batch* dev_batch, const sk_germline_options* opt, float* dev_out_de,
+                           void* hip_stream);
+
+typedef struct sk_digt_result_set { /* diploid_genotype::result_set, position_snp_call_pprob_digt.hh:72-91 */
+    double ref_pprob;
+    uint32_t max_gt;
+    int32_t snp_qphred;
+    int32_t max_gt_qphred;
+    int32_t _pad;
+} sk_digt_result_set;
+
+typedef struct sk_digt_call { /* diploid_genotype + the raw likelihoods */
+    float lhood[10];           /* get_diploid_gt_lhood, DIGT order AA,CC,GG,TT,AC,AG,AT,CG,CT,GT */
+    uint32_t phredLoghood[10]; /* PLs (:499-511); entries >= 4 are 0 for haploid loci */
+    sk_digt_result_set genome; /* genomic prior */
+    sk_digt_result_set poly;   /* polymorphic-site prior */
+    double strand_bias;        /* :520-538 */
+    uint32_t ref_gt;
+    uint32_t is_called;        /* 0 when the reference returns early (ref base 'N', :481) */
+} sk_digt_call;
+
+/** a10: replaces pprob_digt_caller::position_snp_call_pprob_digt(opt, epi, dgt, is_always_test=true) at
+ *  L/applications/starling/starling_pos_processor.cpp:265-266 (L/blt_common/position_snp_call_pprob_digt.cpp:473-539).
+ *  out[n_loci]. */
+int sk_site_digt_call(const sk_pileup_batch* host_batch, const sk_germline_options* opt, sk_digt_call* out);
+int sk_site_digt_call_dev(const sk_pileup_batch* dev_batch, const sk_germline_options* opt, sk_digt_call* dev_out,
+                          void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Hot path B (somatic SNV): 30-state frequency-grid likelihoods + 3x2 posterior
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+enum { SK_SOM_PRESTRAND = 21, SK_SOM_STATES = 30 };
+
+typedef struct sk_somatic_snv_options { /* L/applications/strelka/strelka_shared.hh; workflow overrides in
+                                           src/python/bin/configureStrelkaSomaticWorkflow.py.ini */
+    double bsnp_diploid_theta;                      /* 0.001 */
+    double somatic_snv_rate;                        /* ssnvPrior 1e-4 */
+    double shared_site_error_rate;                  /* ssnvNoise 5e-10 */
+    double shared_site_error_strand_bias_fraction;  /* 0 */
+    double ssnv_contam_tolerance;                   /* 0.15 */
+} sk_somatic_snv_options;
+void sk_somatic_snv_options_default(sk_somatic_snv_options* opt);
+
+typedef struct sk_somatic_snv_call { /* snv_result_set, L/applications/strelka/somatic_result_set.hh:32-54 */
+    float normal_lhood[SK_SOM_STATES]; /* entries 21..29 unused (0) for the normal sample */
+    float tumor_lhood[SK_SOM_STATES];
+    uint32_t max_gt;
+    int32_t qphred;            /* QSS */
+    int32_t from_ntype_qphred; /* QSS_NT */
+    uint32_t ntype;            /* SOMATIC_DIGT index of the most likely normal genotype (pre NTYPE remap) */
+    float strand_bias;
+    uint32_t is_called;        /* 0 = early-out (ref 'N' or both pileups all-ref, :251-254) */
+    uint32_t normal_alt_id;
+    uint32_t tumor_alt_id;
+} sk_somatic_snv_call;
+
+/** a12+a13: replaces somatic_snv_caller_strand_grid::position_somatic_snv_call (single tier) at
+ *  L/applications/strelka/strelka_pos_processor.cpp:213-219
+ *  (L/applications/strelka/position_somatic_snv_strand_grid.cpp:230-363, qscore_calculator.cpp:47-209).
+ *  normal/tumor batches must have the same n_loci and ref_base; `de` is ignored (raw error_prob(q) is used). */
+int sk_somatic_snv_call_batch(const sk_pileup_batch* host_normal, const sk_pileup_batch* host_tumor,
+                              const sk_somatic_snv_options* opt, int is_forced_output, sk_somatic_snv_call* out);
+int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* dev_normal, const sk_pileup_batch* dev_tumor,
+                                  const sk_somatic_snv_options* opt, int is_forced_output,
+                                  sk_somatic_snv_call* dev_out, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRELKA_AMD_H */

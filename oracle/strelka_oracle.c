@@ -1,0 +1,961 @@
+/*
+ * strelka_oracle.c -- CPU restatement of the Strelka2 hot path.  TEST INFRASTRUCTURE ONLY (see strelka_oracle.h).
+ *
+ * Every function cites the reference lines it follows (L/ = /root/reference/src/c++/lib/).  Float/double mixing is
+ * restated literally (blt_float_t == float, L/blt_util/blt_types.hh:27): where the reference's C++ expression
+ * promotes to double (a `1.` or `0.5` literal) the restatement does too.
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -fPIC -shared strelka_oracle.c -lm   (no FMA contraction: the reference
+ * is built for baseline x86-64, which has none).
+ */
+#define _GNU_SOURCE
+#include "strelka_oracle.h"
+
+#include <assert.h>
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------ scalar helpers */
+
+/* L/blt_util/math_util.hh:33-48 (double) */
+double sko_log1p_switch(double x)
+{
+    if (fabs(x) < 0.01) return log1p(x);
+    return log(1 + x);
+}
+
+/* L/blt_util/math_util.hh:33-48 (float instantiation: smallx_thresh is float(0.01)) */
+static float log1p_switch_f(float x)
+{
+    static const float smallx_thresh = 0.01f;
+    if (fabsf(x) < smallx_thresh) return log1pf(x);
+    return logf(1 + x);
+}
+
+/* L/blt_util/logSumUtil.hh:33-41 */
+double sko_log_sum2(double x1, double x2)
+{
+    if (x1 < x2) { double t = x1; x1 = x2; x2 = t; }
+    return x1 + sko_log1p_switch(exp(x2 - x1));
+}
+
+float sko_log_sum2f(float x1, float x2)
+{
+    if (x1 < x2) { float t = x1; x1 = x2; x2 = t; }
+    return x1 + log1p_switch_f(expf(x2 - x1));
+}
+
+/* L/blt_util/qscore.hh:40-47,60-66 (double) */
+int sko_error_prob_to_qphred(double prob)
+{
+    static const double minlog10 = (double)DBL_MIN_10_EXP;
+    const double l = log10(prob);
+    const double m = (minlog10 < l) ? l : minlog10; /* std::max(minlog10, l) */
+    const double phred = -10. * m;
+    return (int)floor(phred + 0.5);
+}
+
+/* L/blt_util/qscore.hh:49-57,68-74 (float): ln10 = logf(10), division and max in float, `-10.*` in double, result
+ * narrowed to float by the FloatType return, `+0.5` in double. */
+int sko_ln_error_prob_to_qphred_f(float lnProb)
+{
+    static const float minlog10 = (float)FLT_MIN_10_EXP;
+    const float ln10 = logf(10.f);
+    const float q = lnProb / ln10;
+    const float m = (minlog10 < q) ? q : minlog10;
+    const float phred = (float)(-10. * m);
+    return (int)floor(phred + 0.5);
+}
+
+/* ------------------------------------------------------------------------------------------------ q-score tables */
+
+enum { MAX_QSCORE = 70 };
+static double g_q2p[MAX_QSCORE + 1], g_q2lncompe[MAX_QSCORE + 1], g_q2lne[MAX_QSCORE + 1];
+static int g_tables_ready = 0;
+
+/* L/blt_util/qscore_cache.cpp:34-50 */
+static void init_tables(void)
+{
+    if (g_tables_ready) return;
+    const double q2lnp = -log(10.) / 10.;
+    for (int i = 0; i <= MAX_QSCORE; ++i) {
+        g_q2p[i] = pow(10., -((double)i) / 10.); /* phred_to_error_prob, qscore.hh:77-82 */
+        g_q2lncompe[i] = sko_log1p_switch(-g_q2p[i]);
+        g_q2lne[i] = (double)i * q2lnp;
+    }
+    g_tables_ready = 1;
+}
+
+void sko_get_qscore_tables(double* q2p, double* q2lncompe, double* q2lne)
+{
+    init_tables();
+    memcpy(q2p, g_q2p, sizeof(g_q2p));
+    memcpy(q2lncompe, g_q2lncompe, sizeof(g_q2lncompe));
+    memcpy(q2lne, g_q2lne, sizeof(g_q2lne));
+}
+
+/* packed base_call accessors (layout: include/strelka_amd.h; L/blt_common/snp_pos_info.hh:109-117) */
+#define C_Q(c) ((unsigned)((c) & 0x3f))
+#define C_BASE(c) ((unsigned)(((c) >> 6) & 0xf))
+#define C_FWD(c) ((unsigned)(((c) >> 10) & 1))
+#define C_NMM(c) ((unsigned)(((c) >> 11) & 1))
+#define C_FILTER(c) ((unsigned)(((c) >> 12) & 1))
+
+/* ------------------------------------------------------------------------------ libstdc++ std::sort, restated
+ * GCC 11 bits/stl_algo.h: __sort = __introsort_loop(first,last,2*lg(n)) + __final_insertion_sort, threshold 16;
+ * bits/stl_heap.h for the depth-limit fallback.  comp(a,b) := key[a] > key[b]
+ * (sort_icall_by_eprob, L/blt_common/adjust_joint_eprob.cpp:41-53). */
+
+#define SCMP(a, b) (key[(a)] > key[(b)])
+
+static void s_unguarded_linear_insert(uint32_t* last, const uint16_t* key)
+{
+    uint32_t val = *last;
+    uint32_t* next = last - 1;
+    while (SCMP(val, *next)) {
+        *last = *next;
+        last = next;
+        --next;
+    }
+    *last = val;
+}
+
+static void s_insertion_sort(uint32_t* first, uint32_t* last, const uint16_t* key)
+{
+    if (first == last) return;
+    for (uint32_t* i = first + 1; i != last; ++i) {
+        if (SCMP(*i, *first)) {
+            uint32_t val = *i;
+            memmove(first + 1, first, (size_t)(i - first) * sizeof(uint32_t));
+            *first = val;
+        } else {
+            s_unguarded_linear_insert(i, key);
+        }
+    }
+}
+
+static void s_push_heap(uint32_t* first, long hole, long top, uint32_t value, const uint16_t* key)
+{
+    long parent = (hole - 1) / 2;
+    while (hole > top && SCMP(first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+
+static void s_adjust_heap(uint32_t* first, long hole, long len, uint32_t value, const uint16_t* key)
+{
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (SCMP(first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    s_push_heap(first, hole, top, value, key);
+}
+
+static void s_heap_sort(uint32_t* first, uint32_t* last, const uint16_t* key)
+{
+    /* __partial_sort(first,last,last) = __heap_select (make_heap only, as middle==last) + __sort_heap */
+    const long len = last - first;
+    if (len >= 2) {
+        long parent = (len - 2) / 2;
+        for (;;) {
+            uint32_t value = first[parent];
+            s_adjust_heap(first, parent, len, value, key);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    while (last - first > 1) {
+        --last;
+        uint32_t value = *last;
+        *last = *first;
+        s_adjust_heap(first, 0, last - first, value, key);
+    }
+}
+
+static void s_move_median_to_first(uint32_t* result, uint32_t* a, uint32_t* b, uint32_t* c, const uint16_t* key)
+{
+    uint32_t* pick;
+    if (SCMP(*a, *b)) {
+        if (SCMP(*b, *c)) pick = b;
+        else if (SCMP(*a, *c)) pick = c;
+        else pick = a;
+    } else if (SCMP(*a, *c)) pick = a;
+    else if (SCMP(*b, *c)) pick = c;
+    else pick = b;
+    uint32_t t = *result; *result = *pick; *pick = t;
+}
+
+static uint32_t* s_unguarded_partition(uint32_t* first, uint32_t* last, uint32_t* pivot, const uint16_t* key)
+{
+    for (;;) {
+        while (SCMP(*first, *pivot)) ++first;
+        --last;
+        while (SCMP(*pivot, *last)) --last;
+        if (!(first < last)) return first;
+        uint32_t t = *first; *first = *last; *last = t;
+        ++first;
+    }
+}
+
+static void s_introsort_loop(uint32_t* first, uint32_t* last, long depth_limit, const uint16_t* key)
+{
+    while (last - first > 16) {
+        if (depth_limit == 0) {
+            s_heap_sort(first, last, key);
+            return;
+        }
+        --depth_limit;
+        uint32_t* mid = first + (last - first) / 2;
+        s_move_median_to_first(first, first + 1, mid, last - 1, key);
+        uint32_t* cut = s_unguarded_partition(first + 1, last, first, key);
+        s_introsort_loop(cut, last, depth_limit, key);
+        last = cut;
+    }
+}
+
+void sko_sort_idx_by_key_desc(uint32_t* idx, int n, const uint16_t* key)
+{
+    if (n <= 0) return;
+    long lg = 0;
+    for (unsigned long m = (unsigned long)n; m > 1; m >>= 1) ++lg; /* std::__lg */
+    s_introsort_loop(idx, idx + n, lg * 2, key);
+    if (n > 16) {
+        s_insertion_sort(idx, idx + 16, key);
+        for (uint32_t* i = idx + 16; i != idx + n; ++i) s_unguarded_linear_insert(i, key);
+    } else {
+        s_insertion_sort(idx, idx + n, key);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ hot path A */
+
+static int is_align_match(uint32_t t) { return t == SKO_MATCH || t == SKO_SEQ_MATCH || t == SKO_SEQ_MISMATCH; }
+static int is_type_indel(uint32_t t) { return t == SKO_INSERT || t == SKO_DELETE; }
+
+/* L/blt_util/align_path.cpp:868-895 */
+static int is_segment_swap_start(const sko_path_seg* path, int n, int i)
+{
+    int is_insert = 0, is_delete = 0;
+    for (; i < n; ++i) {
+        if (path[i].type == SKO_INSERT) is_insert = 1;
+        else if (path[i].type == SKO_DELETE) is_delete = 1;
+        else break;
+    }
+    return is_insert && is_delete;
+}
+
+/* L/htsapi/bam_seq.hh:73-92 */
+static uint8_t bam_code_of_char(char c)
+{
+    switch (c) {
+    case '=': return 0;
+    case 'A': return 1;
+    case 'C': return 2;
+    case 'G': return 4;
+    case 'T': return 8;
+    default: return 15;
+    }
+}
+
+typedef struct seq_view {
+    const char* s;
+    int32_t offset; /* genomic position of s[0] (0 for insert sequences) */
+    int32_t len;
+} seq_view;
+
+/* string_bam_seq / rc_segment_bam_seq ::get_code (L/htsapi/bam_seq.hh:250-300,
+ * L/blt_util/reference_contig_segment.hh:46-51): out of range -> 'N' */
+static uint8_t seq_code(const seq_view* v, int32_t pos)
+{
+    if (pos < v->offset || pos >= v->offset + v->len) return 15;
+    return bam_code_of_char(v->s[pos - v->offset]);
+}
+
+/* scoreMatchSegment / scoreInsertSegment (L/starling_common/starling_read_align_score.cpp:110-170; identical bodies) */
+static void score_segment(unsigned seg_length, const uint8_t* read_code, int32_t read_len, const uint8_t* qual,
+                          unsigned read_offset, const seq_view* ref, int32_t ref_head_pos, double* lnp)
+{
+    const double lnthird = -log(3.);
+    for (unsigned i = 0; i < seg_length; ++i) {
+        const int32_t readPos = (int32_t)(read_offset + i);
+        const uint8_t sbase = (readPos >= 0 && readPos < read_len) ? read_code[readPos] : 15; /* bam_seq::get_code */
+        if (sbase == 15) continue;
+        const uint8_t qscore = qual[readPos];
+        int is_ref = (sbase == 0);
+        if (!is_ref) {
+            const int32_t refPos = ref_head_pos + (int32_t)i;
+            is_ref = (sbase == seq_code(ref, refPos));
+        }
+        *lnp += (is_ref ? g_q2lncompe[qscore] : g_q2lne[qscore] + lnthird);
+    }
+}
+
+/* getMatchingIndelKey (L/starling_common/starling_read_align_score.cpp:177-228) */
+static const sko_indel* get_matching_indel(const sko_cal* cal, int32_t ref_head_pos, unsigned delete_length,
+                                           unsigned insert_length, int ends_first, int ends_second, int path_index)
+{
+    if (path_index < ends_first) return &cal->leading;
+    if (path_index > ends_second) return &cal->trailing;
+    const sko_indel* found = NULL;
+    for (int k = 0; k < cal->n_indels; ++k) {
+        const sko_indel* ci = &cal->indels[k];
+        if (ci->pos == ref_head_pos && (ci->type == SKO_INDEL_INDEL || ci->type == SKO_INDEL_MISMATCH) &&
+            ci->del_len == delete_length && ci->ins_len == insert_length) {
+            assert(found == NULL);
+            found = ci;
+        } else if (ci->pos > ref_head_pos) {
+            break;
+        }
+    }
+    assert(found != NULL);
+    return found;
+}
+
+/* scoreCandidateAlignment (L/starling_common/starling_read_align_score.cpp:261-499) */
+double sko_score_candidate_alignment(const uint8_t* read_code, const uint8_t* read_qual, int32_t read_len,
+                                     const sko_cal* cal, const char* ref_seq, int32_t ref_offset, int32_t ref_len)
+{
+    init_tables();
+    double lnp = 0.;
+    const seq_view ref = { ref_seq, ref_offset, ref_len };
+    const sko_path_seg* path = cal->path;
+    const int aps = cal->n_seg;
+
+    unsigned read_offset = 0;
+    int32_t ref_head_pos = cal->pos;
+
+    /* get_match_edge_segments (L/blt_util/align_path.cpp:735-752) */
+    int ends_first = aps, ends_second = aps;
+    {
+        int is_first_match = 0;
+        for (int i = 0; i < aps; ++i) {
+            if (is_align_match(path[i].type)) {
+                if (!is_first_match) ends_first = i;
+                is_first_match = 1;
+                ends_second = i;
+            }
+        }
+    }
+
+    int path_index = 0;
+    while (path_index < aps) {
+        const int is_swap_start = is_segment_swap_start(path, aps, path_index);
+        unsigned n_seg = 1;
+        const sko_path_seg* ps = &path[path_index];
+        const sko_indel* indelKey = NULL;
+
+        if (is_swap_start || ps->type == SKO_SEQ_MISMATCH) {
+            unsigned deleteLength, insertLength;
+            if (ps->type == SKO_SEQ_MISMATCH) {
+                deleteLength = ps->length;
+                insertLength = ps->length;
+            } else {
+                /* swap_info (L/blt_util/align_path_util.hh:75-106) */
+                int k = path_index;
+                insertLength = 0;
+                deleteLength = 0;
+                for (; k < aps && is_type_indel(path[k].type); ++k) {
+                    if (path[k].type == SKO_INSERT) insertLength += path[k].length;
+                    else deleteLength += path[k].length;
+                }
+                n_seg = (unsigned)(k - path_index);
+            }
+            indelKey = get_matching_indel(cal, ref_head_pos, deleteLength, insertLength, ends_first, ends_second,
+                                          path_index);
+            const seq_view ins = { indelKey->ins_seq, 0, (int32_t)indelKey->ins_len };
+            int32_t insert_seq_head_pos = 0;
+            if (path_index < ends_first) insert_seq_head_pos = (int32_t)ins.len - (int32_t)ps->length;
+            score_segment(insertLength, read_code, read_len, read_qual, read_offset, &ins, insert_seq_head_pos, &lnp);
+        } else if (is_align_match(ps->type)) {
+            score_segment(ps->length, read_code, read_len, read_qual, read_offset, &ref, ref_head_pos, &lnp);
+        } else if (ps->type == SKO_INSERT) {
+            indelKey = get_matching_indel(cal, ref_head_pos, 0, ps->length, ends_first, ends_second, path_index);
+            const seq_view ins = { indelKey->ins_seq, 0, (int32_t)indelKey->ins_len };
+            int32_t insert_seq_head_pos = 0;
+            if (path_index < ends_first) insert_seq_head_pos = (int32_t)ins.len - (int32_t)ps->length;
+            score_segment(ps->length, read_code, read_len, read_qual, read_offset, &ins, insert_seq_head_pos, &lnp);
+        } else if (ps->type == SKO_DELETE || ps->type == SKO_SKIP) {
+            if (ps->type == SKO_DELETE)
+                indelKey = get_matching_indel(cal, ref_head_pos, ps->length, 0, ends_first, ends_second, path_index);
+        } else if (ps->type == SKO_SOFT_CLIP) {
+            const double unalignedBasecallLogLikelihood = log(0.25);
+            lnp += (ps->length * unalignedBasecallLogLikelihood);
+        } else if (ps->type == SKO_HARD_CLIP) {
+            /* nothing */
+        } else {
+            assert(0 && "Can't handle cigar code");
+        }
+
+        if (indelKey != NULL && indelKey->type != SKO_INDEL_NONE) {
+            if (!indelKey->is_candidate) {
+                const double nonCandidateIndelPenalty = log(1e-5);
+                lnp += nonCandidateIndelPenalty;
+            }
+        }
+
+        /* increment_path (L/blt_util/align_path_util.hh:38-68) */
+        for (unsigned i = 0; i < n_seg; ++i) {
+            const sko_path_seg* s = &path[path_index];
+            if (is_align_match(s->type)) {
+                read_offset += s->length;
+                ref_head_pos += (int32_t)s->length;
+            } else if (s->type == SKO_DELETE || s->type == SKO_SKIP) {
+                ref_head_pos += (int32_t)s->length;
+            } else if (s->type == SKO_INSERT || s->type == SKO_SOFT_CLIP) {
+                read_offset += s->length;
+            }
+            path_index++;
+        }
+    }
+    return lnp;
+}
+
+/* ------------------------------------------------------------------------------------ hot path B: dependent eprob */
+
+/* get_dependent_eprob (L/blt_common/adjust_joint_eprob.cpp:58-69); all blt_float_t, std::pow(float,float)=powf */
+static float get_dependent_eprob(unsigned qscore, float vexp)
+{
+    static const float dep_converge_prob = 0.75f;
+    const float eprob = (float)g_q2p[qscore];
+    const float val = powf(eprob, vexp);
+    const float frac = (1 - val) / (1 - eprob);
+    const float dep = frac * val + (1 - frac) * dep_converge_prob;
+    return (eprob < dep) ? dep : eprob; /* std::max(eprob, dep) */
+}
+
+/* adjust_icalls_eprob (L/blt_common/adjust_joint_eprob.cpp:92-194).  `dpc` (dependent_prob_cache) is only ever filled at
+ * vexp == min_vexp (is_min_vexp becomes true exactly when vexp is clamped to min_vexp, :170-174), so the cache is the
+ * pure function get_dependent_eprob(q, (float)min_vexp). */
+static void adjust_icalls_eprob(const sko_germline_options* opt, uint32_t* ic, int ic_size, const uint16_t* calls,
+                                const uint16_t* qkey, float* de)
+{
+    float vexp_frac;
+    {
+        const float lnran = (float)log(0.75);
+        float num = 0, den = 0;
+        for (int i = 0; i < ic_size; ++i) {
+            const uint16_t bi = calls[ic[i]];
+            const float weight = (float)(lnran - g_q2lne[C_Q(bi)]); /* float - double -> double -> float */
+            den += weight;
+            if (C_NMM(bi)) num += weight;
+        }
+        float mismatch_frac = 0;
+        if (ic_size && (den > 0.)) mismatch_frac = (num / den);
+        vexp_frac = (float)((1 - mismatch_frac) * opt->bsnp_ssd_no_mismatch + mismatch_frac * opt->bsnp_ssd_one_mismatch);
+    }
+    const int is_limit_vexp = opt->is_min_vexp;
+    const float min_vexp = (float)opt->min_vexp;
+    int is_min_vexp = 0;
+
+    sko_sort_idx_by_key_desc(ic, ic_size, qkey);
+    float vexp = 1.f;
+    for (int i = 0; i < ic_size; ++i) {
+        const uint16_t bi = calls[ic[i]];
+        if (!is_min_vexp) {
+            de[ic[i]] = get_dependent_eprob(C_Q(bi), vexp);
+            float next_vexp = vexp;
+            next_vexp *= (1 - vexp_frac);
+            if (is_limit_vexp) {
+                is_min_vexp = (next_vexp <= min_vexp);
+                vexp = (min_vexp < next_vexp) ? next_vexp : min_vexp; /* std::max(min_vexp,next_vexp) */
+            } else {
+                vexp = next_vexp;
+            }
+        } else {
+            de[ic[i]] = get_dependent_eprob(C_Q(bi), vexp);
+        }
+    }
+}
+
+/* adjust_joint_eprob (L/blt_common/adjust_joint_eprob.cpp:201-243); is_dependent_eprob() assumed true when either
+ * ssd parameter > 0 (L/blt_common/blt_shared.hh:75-80, germline: is_bsnp_diploid) */
+void sko_adjust_joint_eprob(const uint16_t* calls, int32_t n_calls, const sko_germline_options* opt, float* de)
+{
+    init_tables();
+    for (int i = 0; i < n_calls; ++i) de[i] = (float)g_q2p[C_Q(calls[i])];
+    if (!(opt->bsnp_ssd_no_mismatch > 0. || opt->bsnp_ssd_one_mismatch > 0)) return;
+    if (n_calls == 0) return;
+
+    uint32_t* ic = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n_calls);
+    uint16_t* qkey = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)n_calls);
+    for (int i = 0; i < n_calls; ++i) qkey[i] = (uint16_t)C_Q(calls[i]);
+    for (unsigned g = 0; g < 8; ++g) {
+        int n = 0;
+        for (int i = 0; i < n_calls; ++i) {
+            const uint16_t b = calls[i];
+            if (C_FILTER(b)) continue;
+            if (C_Q(b) < 3) continue;
+            const unsigned group_index = C_FWD(b) + 2 * C_BASE(b);
+            if (group_index == g) ic[n++] = (uint32_t)i;
+        }
+        adjust_icalls_eprob(opt, ic, n, calls, qkey, de);
+    }
+    free(ic);
+    free(qkey);
+}
+
+/* ------------------------------------------------------------------------------------ hot path B: germline lhood */
+
+/* DIGT::expect2 (L/blt_util/digt.hh:126-146) */
+static const uint8_t DIGT_EXPECT2[10][4] = { { 2, 0, 0, 0 }, { 0, 2, 0, 0 }, { 0, 0, 2, 0 }, { 0, 0, 0, 2 }, { 1, 1, 0, 0 },
+                                             { 1, 0, 1, 0 }, { 1, 0, 0, 1 }, { 0, 1, 1, 0 }, { 0, 1, 0, 1 }, { 0, 0, 1, 1 } };
+/* DIGT::expect (L/blt_util/digt.hh:100-120) as 2*frequency */
+#define DIGT_IS_HET(gt) ((gt) >= 4)
+
+/* get_diploid_gt_lhood (L/blt_common/position_snp_call_pprob_digt.cpp:328-385), useHetVariantFrequencyExtension=false */
+void sko_diploid_gt_lhood(const uint16_t* calls, const float* de, int32_t n_calls, uint32_t ref_gt,
+                          int is_strand_specific, int is_ss_fwd, float* lhood)
+{
+    init_tables();
+    const float one_third = (float)(1. / 3.);
+    const float log_one_third = logf(one_third);
+    const float one_half = (float)(1. / 2.);
+    const float log_one_half = logf(one_half);
+
+    for (unsigned gt = 0; gt < 10; ++gt) lhood[gt] = 0.f;
+    for (int i = 0; i < n_calls; ++i) {
+        const uint16_t bc = calls[i];
+        const float eprob = de[i];
+        const float ceprob = (float)(1. - g_q2p[C_Q(bc)]);
+        const float lnce = (float)g_q2lncompe[C_Q(bc)];
+        float val[3];
+        val[0] = logf(eprob) + log_one_third;
+        val[1] = (float)(log((ceprob) + ((1. - ceprob) * one_third)) + log_one_half);
+        val[2] = lnce;
+        const int is_force_ref = (is_strand_specific && (is_ss_fwd != (int)C_FWD(bc)));
+        const unsigned obs_id = C_BASE(bc);
+        for (unsigned gt = 0; gt < 10; ++gt) lhood[gt] += val[DIGT_EXPECT2[is_force_ref ? ref_gt : gt][obs_id]];
+    }
+}
+
+typedef struct prior_set {
+    float genome[10], poly[10];
+} prior_set;
+
+/* priors (L/blt_common/position_snp_call_pprob_digt.cpp:50-258) */
+static void build_priors(float theta, prior_set lnprior[5], prior_set lnprior_haploid[5])
+{
+    const float one_third = (float)(1. / 3.);
+    memset(lnprior, 0, sizeof(prior_set) * 5);
+    memset(lnprior_haploid, 0, sizeof(prior_set) * 5);
+    for (unsigned ref_gt = 0; ref_gt < 4; ++ref_gt) {
+        { /* get_genomic_prior :50-74 */
+            float* prior = lnprior[ref_gt].genome;
+            float prior_sum = 0.f;
+            for (unsigned gt = 0; gt < 10; ++gt) {
+                if (gt == ref_gt) continue;
+                prior[gt] = (theta * one_third);
+                if (DIGT_IS_HET(gt)) {
+                    if (DIGT_EXPECT2[gt][ref_gt] == 0) prior[gt] *= theta;
+                } else {
+                    prior[gt] = (float)(prior[gt] * .5);
+                }
+                prior_sum += prior[gt];
+            }
+            prior[ref_gt] = (float)(1. - prior_sum);
+        }
+        { /* get_poly_prior :105-138 */
+            float* prior = lnprior[ref_gt].poly;
+            const float ctheta = (float)(1. - theta);
+            for (unsigned gt = 0; gt < 10; ++gt) {
+                if (gt == ref_gt) prior[gt] = (float)(0.25 * (ctheta));
+                else if (DIGT_IS_HET(gt)) {
+                    if (DIGT_EXPECT2[gt][ref_gt] == 0) prior[gt] = theta * one_third;
+                    else prior[gt] = (float)(0.5 * one_third * ctheta);
+                } else prior[gt] = (float)(0.25 * one_third * ctheta);
+            }
+        }
+        { /* get_haploid_genomic_prior :78-101 */
+            float* prior = lnprior_haploid[ref_gt].genome;
+            float prior_sum = 0.f;
+            for (unsigned gt = 0; gt < 10; ++gt) {
+                if (gt == ref_gt) continue;
+                if (DIGT_IS_HET(gt)) prior[gt] = 0;
+                else prior[gt] = (theta * one_third);
+                prior_sum += prior[gt];
+            }
+            prior[ref_gt] = (float)(1. - prior_sum);
+        }
+        { /* get_haploid_poly_prior :142-167 */
+            float* prior = lnprior_haploid[ref_gt].poly;
+            for (unsigned gt = 0; gt < 10; ++gt) {
+                if (gt == ref_gt) prior[gt] = 0.5f;
+                else if (DIGT_IS_HET(gt)) prior[gt] = 0;
+                else prior[gt] = (float)(0.5 * one_third);
+            }
+        }
+    }
+    /* finish_prior :214-237 */
+    for (int h = 0; h < 2; ++h) {
+        prior_set* P = h ? lnprior_haploid : lnprior;
+        for (unsigned i = 0; i < 4; ++i)
+            for (unsigned gt = 0; gt < 10; ++gt) {
+                P[4].genome[gt] += P[i].genome[gt];
+                P[4].poly[gt] += P[i].poly[gt];
+            }
+        for (int w = 0; w < 2; ++w) { /* norm_gt :184-198 */
+            float* x = w ? P[4].poly : P[4].genome;
+            float sum = 0;
+            for (unsigned gt = 0; gt < 10; ++gt) sum += x[gt];
+            sum = (float)(1. / sum);
+            for (unsigned gt = 0; gt < 10; ++gt) x[gt] *= sum;
+        }
+        for (unsigned i = 0; i < 5; ++i)
+            for (unsigned gt = 0; gt < 10; ++gt) {
+                P[i].genome[gt] = logf(P[i].genome[gt]);
+                P[i].poly[gt] = logf(P[i].poly[gt]);
+            }
+    }
+}
+
+void sko_germline_lnpriors(double theta, float* out /* [2][5][2][10]: haploid?, ref, genome/poly, gt */)
+{
+    prior_set a[5], b[5];
+    build_priors((float)theta, a, b);
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 5; ++r) {
+            const prior_set* p = h ? &b[r] : &a[r];
+            memcpy(out + ((h * 5 + r) * 2 + 0) * 10, p->genome, sizeof(float) * 10);
+            memcpy(out + ((h * 5 + r) * 2 + 1) * 10, p->poly, sizeof(float) * 10);
+        }
+}
+
+/* calculate_result_set (L/blt_common/position_snp_call_pprob_digt.cpp:412-433) with normalizeLogDistro and prob_comp
+ * (L/blt_util/prob_util.hh:177-237) */
+static void calculate_result_set(const float* lhood, const float* lnprior, unsigned ref_gt, sko_digt_result_set* rs)
+{
+    double pprob[10];
+    for (unsigned gt = 0; gt < 10; ++gt) pprob[gt] = lhood[gt] + lnprior[gt]; /* float add, widened */
+    unsigned max_idx = 0;
+    double max = pprob[0];
+    for (unsigned i = 1; i < 10; ++i)
+        if (pprob[i] > max) { max = pprob[i]; max_idx = i; }
+    double sum = 0.;
+    for (unsigned i = 0; i < 10; ++i) { pprob[i] = exp(pprob[i] - max); sum += pprob[i]; }
+    sum = 1. / sum;
+    for (unsigned i = 0; i < 10; ++i) pprob[i] *= sum;
+    rs->max_gt = max_idx;
+    rs->ref_pprob = pprob[ref_gt];
+    rs->snp_qphred = sko_error_prob_to_qphred(pprob[ref_gt]);
+    double comp = 0.;
+    for (unsigned i = 0; i < 10; ++i) { if (i == max_idx) continue; comp = comp + pprob[i]; }
+    rs->max_gt_qphred = sko_error_prob_to_qphred(comp);
+    rs->_pad = 0;
+}
+
+/* position_snp_call_pprob_digt (L/blt_common/position_snp_call_pprob_digt.cpp:471-539), is_always_test=true,
+ * hetVariantFrequencyExtension=0 */
+void sko_position_snp_call_pprob_digt(const uint16_t* calls, const float* de, int32_t n_calls, uint32_t ref_base_id,
+                                      int ploidy, const sko_germline_options* opt, sko_digt_call* out)
+{
+    static prior_set lnprior[5], lnprior_haploid[5];
+    static double cached_theta = -1;
+    if (cached_theta != opt->bsnp_diploid_theta) {
+        build_priors((float)opt->bsnp_diploid_theta, lnprior, lnprior_haploid);
+        cached_theta = opt->bsnp_diploid_theta;
+    }
+    memset(out, 0, sizeof(*out));
+    if (ref_base_id >= 4) return; /* 'N' :481 */
+    out->is_called = 1;
+    out->ref_gt = ref_base_id;
+    const int is_haploid = (ploidy == 1);
+
+    float* lhood = out->lhood;
+    sko_diploid_gt_lhood(calls, de, n_calls, ref_base_id, 0, 0, lhood);
+    {
+        unsigned gtcount = 10;
+        if (is_haploid) gtcount = 4;
+        unsigned maxIndex = 0;
+        for (unsigned gt = 1; gt < gtcount; ++gt)
+            if (lhood[gt] > lhood[maxIndex]) maxIndex = gt;
+        for (unsigned gt = 0; gt < gtcount; ++gt)
+            out->phredLoghood[gt] = (uint32_t)sko_ln_error_prob_to_qphred_f(lhood[gt] - lhood[maxIndex]);
+    }
+    const prior_set* P = is_haploid ? lnprior_haploid : lnprior;
+    calculate_result_set(lhood, P[ref_base_id].genome, ref_base_id, &out->genome);
+    calculate_result_set(lhood, P[ref_base_id].poly, ref_base_id, &out->poly);
+
+    if (out->genome.snp_qphred != 0) {
+        float lhood_fwd[10], lhood_rev[10];
+        sko_diploid_gt_lhood(calls, de, n_calls, ref_base_id, 1, 1, lhood_fwd);
+        sko_diploid_gt_lhood(calls, de, n_calls, ref_base_id, 1, 0, lhood_rev);
+        const unsigned tgt = out->genome.max_gt;
+        const float m = (lhood_fwd[tgt] < lhood_rev[tgt]) ? lhood_rev[tgt] : lhood_fwd[tgt];
+        out->strand_bias = m - lhood[tgt]; /* float subtraction, widened */
+    } else {
+        out->strand_bias = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ hot path B: somatic SNV */
+
+enum { SOM_REF = 0, SOM_HOM = 1, SOM_HET = 2, SOM_SIZE = 3, HET_RES = 9, PRESTRAND = 21, GRID = 30 };
+
+/* DIGT_GRID::get_fraction_from_index (L/applications/strelka/strelka_digt_states.cpp:33-41) */
+static float get_fraction_from_index(int index)
+{
+    const float RATIO_INCREMENT = 0.5f / (float)(HET_RES + 1);
+    if (index == SOM_REF) return 0.f;
+    if (index == SOM_HOM) return 1.f;
+    if (index == SOM_HET) return 0.5f;
+    if (index < SOM_SIZE + HET_RES) return RATIO_INCREMENT * (index - SOM_SIZE + 1);
+    return RATIO_INCREMENT * (index - SOM_SIZE + 2);
+}
+
+void sko_somatic_sample_lhood(const uint16_t* calls, int32_t n_calls, uint32_t ref_gt, int with_strand, float* lhood)
+{
+    init_tables();
+    const float one_third = (float)(1. / 3.);
+    const float ln_one_third = logf(one_third);
+    const float one_half = (float)(1. / 2.);
+    const float ln_one_half = logf(one_half);
+    const float RATIO_INCREMENT = 0.5f / (float)(HET_RES + 1);
+
+    for (int i = 0; i < GRID; ++i) lhood[i] = 0.f;
+
+    /* get_diploid_gt_lhood_cached_simple (…_lhood_cached.cpp:41-84) */
+    for (int i = 0; i < n_calls; ++i) {
+        const uint16_t bc = calls[i];
+        const unsigned q = C_Q(bc);
+        const float eprob = (float)g_q2p[q];
+        const float ceprob = (1 - eprob);
+        const float lne = (float)g_q2lne[q];
+        const float lnce = (float)g_q2lncompe[q];
+        const float v0 = lne + ln_one_third;
+        const float v1 = logf((ceprob) + ((eprob)*one_third)) + ln_one_half;
+        const float v2 = lnce;
+        if (C_BASE(bc) == ref_gt) {
+            lhood[SOM_REF] += v2;
+            lhood[SOM_HET] += v1;
+            lhood[SOM_HOM] += v0;
+        } else {
+            lhood[SOM_REF] += v0;
+            lhood[SOM_HET] += v1;
+            lhood[SOM_HOM] += v2;
+        }
+    }
+
+    /* get_diploid_het_grid_lhood_cached (:133-153) + get_high_low_het_ratio_lhood_cached (:86-131) */
+    float* grid = lhood + SOM_SIZE;
+    const unsigned totalHetRatios = HET_RES * 2;
+    for (unsigned hetIndex = 0; hetIndex < HET_RES; ++hetIndex) {
+        const float het_ratio = (hetIndex + 1) * RATIO_INCREMENT;
+        const float chet_ratio = (float)(1. - het_ratio);
+        float* lhood_high = grid + (totalHetRatios - (hetIndex + 1));
+        float* lhood_low = grid + hetIndex;
+        for (int i = 0; i < n_calls; ++i) {
+            const uint16_t bc = calls[i];
+            const float eprob = (float)g_q2p[C_Q(bc)];
+            const float ceprob = (1 - eprob);
+            const float c0 = logf((ceprob)*het_ratio + ((eprob)*one_third) * chet_ratio);
+            const float c1 = logf((ceprob)*chet_ratio + ((eprob)*one_third) * het_ratio);
+            if (C_BASE(bc) == ref_gt) {
+                *lhood_high += c0;
+                *lhood_low += c1;
+            } else {
+                *lhood_high += c1;
+                *lhood_low += c0;
+            }
+        }
+    }
+
+    if (!with_strand) return;
+    /* get_diploid_strand_grid_lhood_spi (position_somatic_snv_strand_grid.cpp:63-83) +
+     * get_strand_ratio_lhood_spi (…_lhood_cached.cpp:164-234) */
+    for (unsigned r = 0; r < HET_RES; ++r) {
+        const float het_ratio = (r + 1) * RATIO_INCREMENT;
+        const float chet_ratio = (float)(1. - het_ratio);
+        float lhood_fwd = 0, lhood_rev = 0;
+        for (int i = 0; i < n_calls; ++i) {
+            const uint16_t bc = calls[i];
+            const unsigned q = C_Q(bc);
+            const float eprob = (float)g_q2p[q];
+            const float ceprob = (float)(1. - eprob);
+            const float c0 = (logf((ceprob)*chet_ratio + ((eprob)*one_third) * het_ratio));
+            const float c1 = (logf((ceprob)*het_ratio + ((eprob)*one_third) * chet_ratio));
+            if (C_BASE(bc) == ref_gt) {
+                const float val_off_strand = (float)g_q2lncompe[q];
+                lhood_fwd += (C_FWD(bc) ? c0 : val_off_strand);
+                lhood_rev += (C_FWD(bc) ? val_off_strand : c0);
+            } else {
+                const float val_off_strand = (float)(g_q2lne[q] + ln_one_third);
+                lhood_fwd += (C_FWD(bc) ? c1 : val_off_strand);
+                lhood_rev += (C_FWD(bc) ? val_off_strand : c1);
+            }
+        }
+        lhood[PRESTRAND + r] = sko_log_sum2f(lhood_fwd, lhood_rev) + ln_one_half;
+    }
+}
+
+/* calculate_result_set_grid (L/applications/strelka/qscore_calculator.cpp:47-209) */
+void sko_calculate_result_set_grid(float contam_tolerance, float logSharedErrorRate, float logSharedErrorRateComplement,
+                                   const float* normal_lhood, const float* tumor_lhood,
+                                   const float* germlineGenotypeLogPrior, float lnmatch, float lnmismatch,
+                                   uint32_t* out_max_gt, int32_t* out_qphred, int32_t* out_from_ntype_qphred,
+                                   uint32_t* out_ntype)
+{
+    const float neg_inf = -INFINITY;
+    const float ln_one_half = (float)log(1. / 2.);
+    const float log_error_mod = (float)(-log((double)(PRESTRAND - 1)));
+    const float RATIO_INCREMENT = 0.5f / (float)(HET_RES + 1);
+
+    double log_post_prob[SOM_SIZE][2];
+    double max_log_prob = neg_inf;
+    uint32_t max_gt = 0;
+
+    for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) {
+        for (unsigned tgt = 0; tgt < 2; ++tgt) {
+            double max_log_sum = neg_inf;
+            double log_sum[PRESTRAND * PRESTRAND];
+            int index = 0;
+            for (unsigned tfi = 0; tfi < PRESTRAND; ++tfi) {
+                const float tumor_freq = get_fraction_from_index((int)tfi);
+                const int consider_norm_contam = (contam_tolerance * tumor_freq >= RATIO_INCREMENT);
+                for (unsigned nfi = 0; nfi < PRESTRAND; ++nfi) {
+                    double lprior_freq;
+                    if (tgt == 0) {
+                        if (nfi != tfi) continue;
+                        lprior_freq = (nfi == ngt) ? logSharedErrorRateComplement : logSharedErrorRate + log_error_mod;
+                    } else {
+                        if (nfi == tfi) continue;
+                        if (ngt != SOM_REF) {
+                            if (nfi != ngt) continue;
+                            lprior_freq = log_error_mod;
+                        } else {
+                            if (!consider_norm_contam) {
+                                if (nfi == 0) lprior_freq = log_error_mod;
+                                else continue;
+                            } else {
+                                if ((nfi == ngt) || (nfi == SOM_SIZE)) lprior_freq = log_error_mod + ln_one_half;
+                                else continue;
+                            }
+                        }
+                    }
+                    const double lsum = lprior_freq + normal_lhood[nfi] + tumor_lhood[tfi];
+                    log_sum[index++] = lsum;
+                    if (lsum > max_log_sum) max_log_sum = lsum;
+                }
+            }
+            double sum = 0.0;
+            for (int i = 0; i < index; ++i) sum += exp(log_sum[i] - max_log_sum);
+            const double log_genotype_prior = germlineGenotypeLogPrior[ngt] + ((tgt == 0) ? lnmatch : lnmismatch);
+            log_post_prob[ngt][tgt] = log_genotype_prior + max_log_sum + log(sum);
+            if (log_post_prob[ngt][tgt] > max_log_prob) {
+                max_log_prob = log_post_prob[ngt][tgt];
+                max_gt = ngt * 2 + tgt; /* DDIGT::get_state (strelka_digt_states.hh) */
+            }
+        }
+    }
+
+    double sum_prob = 0.0;
+    for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt)
+        for (unsigned tgt = 0; tgt < 2; ++tgt) sum_prob += exp(log_post_prob[ngt][tgt] - max_log_prob);
+    const double log_sum_prob = log(sum_prob);
+    double min_not_somfrom_sum = INFINITY;
+    double nonsom_prob = 0.0;
+    int32_t from_ntype_qphred = 0;
+    uint32_t ntype = 0;
+    for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) {
+        double som_prob_given_ngt = 0;
+        for (unsigned tgt = 0; tgt < 2; ++tgt) {
+            const double pp = exp(log_post_prob[ngt][tgt] - max_log_prob - log_sum_prob);
+            if (tgt == 0) nonsom_prob += pp;
+            else som_prob_given_ngt += pp;
+        }
+        const double err_som_and_ngt = 1.0 - som_prob_given_ngt;
+        if (err_som_and_ngt < min_not_somfrom_sum) {
+            min_not_somfrom_sum = err_som_and_ngt;
+            from_ntype_qphred = sko_error_prob_to_qphred(err_som_and_ngt);
+            ntype = ngt;
+        }
+    }
+    *out_max_gt = max_gt;
+    *out_qphred = sko_error_prob_to_qphred(nonsom_prob);
+    *out_from_ntype_qphred = from_ntype_qphred;
+    *out_ntype = ntype;
+}
+
+/* snp_pos_info::get_most_frequent_alt_id (L/blt_common/snp_pos_info.hh:164-190) */
+static unsigned most_frequent_alt_id(const uint16_t* calls, int32_t n, unsigned ref_gt)
+{
+    unsigned alt_count[5] = { 0, 0, 0, 0, 0 };
+    for (int i = 0; i < n; ++i) {
+        const unsigned obs = C_BASE(calls[i]);
+        if (obs == ref_gt || obs == 4) continue;
+        ++alt_count[obs];
+    }
+    unsigned alt_id = ref_gt, max_count = 0;
+    for (unsigned b = 0; b < 5; ++b) {
+        if (alt_count[b] > max_count) {
+            if (b == ref_gt) continue;
+            max_count = alt_count[b];
+            alt_id = b;
+        }
+    }
+    return alt_id;
+}
+
+/* position_somatic_snv_call, tier1 only (L/applications/strelka/position_somatic_snv_strand_grid.cpp:230-363) with the
+ * constructor's derived parameters (:42-54) and the sb part of the wrapper (:216-225) */
+void sko_position_somatic_snv_call(const uint16_t* ncalls, int32_t n_n, const uint16_t* tcalls, int32_t n_t,
+                                   uint32_t ref_base_id, const sko_somatic_snv_options* opt, int is_forced_output,
+                                   sko_somatic_snv_call* out)
+{
+    memset(out, 0, sizeof(*out));
+    if (ref_base_id >= 4) return;
+    if (!is_forced_output) {
+        int allref = 1;
+        for (int i = 0; i < n_n && allref; ++i) if (C_BASE(ncalls[i]) != ref_base_id) allref = 0;
+        for (int i = 0; i < n_t && allref; ++i) if (C_BASE(tcalls[i]) != ref_base_id) allref = 0;
+        if (allref) return;
+    }
+    out->is_called = 1;
+
+    const float contam_tolerance = (float)opt->ssnv_contam_tolerance;
+    const float ln_csse_rate = (float)sko_log1p_switch(-opt->shared_site_error_rate);
+    const float ln_som_match = (float)sko_log1p_switch(-opt->somatic_snv_rate);
+    const float ln_som_mismatch = (float)log(opt->somatic_snv_rate);
+    float lnprior[3]; /* calculateGermlineGenotypeLogPrior, qscore_calculator.cpp:35-43 */
+    lnprior[SOM_REF] = (float)sko_log1p_switch(-(3. * opt->bsnp_diploid_theta) / 2.);
+    lnprior[SOM_HOM] = (float)log(opt->bsnp_diploid_theta / 2.);
+    lnprior[SOM_HET] = (float)log(opt->bsnp_diploid_theta);
+    const float strand_sse_rate = (float)(opt->shared_site_error_rate * opt->shared_site_error_strand_bias_fraction);
+    const float nostrand_sse_rate = (float)(opt->shared_site_error_rate - strand_sse_rate);
+    const float ln_sse_rate = logf(nostrand_sse_rate);
+
+    sko_somatic_sample_lhood(ncalls, n_n, ref_base_id, 0, out->normal_lhood);
+    sko_somatic_sample_lhood(tcalls, n_t, ref_base_id, 1, out->tumor_lhood);
+
+    sko_calculate_result_set_grid(contam_tolerance, ln_sse_rate, ln_csse_rate, out->normal_lhood, out->tumor_lhood,
+                                  lnprior, ln_som_match, ln_som_mismatch, &out->max_gt, &out->qphred,
+                                  &out->from_ntype_qphred, &out->ntype);
+    out->normal_alt_id = most_frequent_alt_id(ncalls, n_n, ref_base_id);
+    out->tumor_alt_id = most_frequent_alt_id(tcalls, n_t, ref_base_id);
+    if (!is_forced_output && out->qphred == 0) {
+        /* wrapper returns before the strand-bias block (:184) and the caller drops the site (:315-319) */
+        out->strand_bias = 0;
+        return;
+    }
+    {
+        float symm = out->tumor_lhood[SOM_SIZE];
+        for (int i = SOM_SIZE; i < PRESTRAND; ++i) if (symm < out->tumor_lhood[i]) symm = out->tumor_lhood[i];
+        float strand = out->tumor_lhood[PRESTRAND];
+        for (int i = PRESTRAND; i < GRID; ++i) if (strand < out->tumor_lhood[i]) strand = out->tumor_lhood[i];
+        const float d = strand - symm;
+        out->strand_bias = (0.f < d) ? d : 0.f;
+    }
+}

@@ -1,0 +1,131 @@
+/*
+ * strelka_oracle.h -- CPU restatement of the Strelka2 hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (strelka_amd/) never links, imports or calls it.
+ *
+ * Each function restates one reference function (file:line cited at the definition in strelka_oracle.c;
+ * `L/` = /root/reference/src/c++/lib/) in plain C with the reference's own data model (CIGAR path segments + indel
+ * keys, pileup `base_call`s), NOT the flattened layout of the product's C-ABI -- so a parity test compares
+ * "reference algorithm on reference-shaped input" against "host flattener + HIP kernel".
+ *
+ * Pinning: oracle/ref/ builds the reference's own translation units (oracle/_ref/libstrelka_ref.so) and
+ * tests/test_oracle_vs_ref.py + tests/golden/ check this restatement against them.
+ */
+#ifndef STRELKA_ORACLE_H
+#define STRELKA_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- q-score tables (L/blt_util/qscore_cache.cpp:34-50) ---- */
+void sko_get_qscore_tables(double* q2p, double* q2lncompe, double* q2lne); /* 71 each */
+int sko_error_prob_to_qphred(double p);         /* L/blt_util/qscore.hh:60-66 (double) */
+int sko_ln_error_prob_to_qphred_f(float lnp);   /* L/blt_util/qscore.hh:68-74 (float instantiation) */
+double sko_log1p_switch(double x);              /* L/blt_util/math_util.hh:33-48 */
+double sko_log_sum2(double a, double b);        /* L/blt_util/logSumUtil.hh:33-41 */
+float sko_log_sum2f(float a, float b);
+
+/* ---- libstdc++ std::sort restated (introsort + final insertion sort), descending-q comparator of
+ *      L/blt_common/adjust_joint_eprob.cpp:41-53.  idx[n] is permuted in place; key[] is indexed by idx values. */
+void sko_sort_idx_by_key_desc(uint32_t* idx, int n, const uint16_t* key);
+
+/* ---- hot path A: scoreCandidateAlignment (L/starling_common/starling_read_align_score.cpp:261-499) ---- */
+enum { SKO_NONE = 0, SKO_MATCH, SKO_INSERT, SKO_DELETE, SKO_SKIP, SKO_SOFT_CLIP, SKO_HARD_CLIP, SKO_PAD, SKO_SEQ_MATCH,
+       SKO_SEQ_MISMATCH }; /* ALIGNPATH::align_t, L/blt_util/align_path.hh:36-48 */
+enum { SKO_INDEL_NONE = 0, SKO_INDEL_INDEL, SKO_INDEL_MISMATCH, SKO_INDEL_BP_LEFT, SKO_INDEL_BP_RIGHT };
+
+typedef struct sko_path_seg {
+    uint32_t type;
+    uint32_t length;
+} sko_path_seg;
+
+typedef struct sko_indel { /* IndelKey (L/starling_common/IndelKey.hh:39-199) + its candidate status */
+    int32_t pos;
+    int32_t type;
+    uint32_t del_len;
+    uint32_t ins_len;
+    const char* ins_seq; /* insert sequence (for breakpoints: the breakpoint insert sequence), ACGTN chars */
+    int32_t is_candidate;
+} sko_indel;
+
+typedef struct sko_cal { /* CandidateAlignment (L/starling_common/CandidateAlignment.hh:35-78) */
+    int32_t pos;         /* al.pos */
+    int32_t n_seg;
+    const sko_path_seg* path;
+    int32_t n_indels;
+    const sko_indel* indels; /* IndelKey-sorted indel set of the alignment */
+    sko_indel leading;       /* type SKO_INDEL_NONE when absent */
+    sko_indel trailing;
+} sko_cal;
+
+/* read_code: BAM 4-bit code per byte; ref_seq: reference contig segment chars starting at genomic ref_offset */
+double sko_score_candidate_alignment(const uint8_t* read_code, const uint8_t* read_qual, int32_t read_len,
+                                     const sko_cal* cal, const char* ref_seq, int32_t ref_offset, int32_t ref_len);
+
+/* ---- hot path B, germline ---- */
+typedef struct sko_germline_options {
+    double bsnp_diploid_theta, bsnp_ssd_no_mismatch, bsnp_ssd_one_mismatch;
+    int32_t is_min_vexp;
+    double min_vexp;
+} sko_germline_options;
+
+/* adjust_joint_eprob (L/blt_common/adjust_joint_eprob.cpp:201-243); calls = packed base_call (include/strelka_amd.h) */
+void sko_adjust_joint_eprob(const uint16_t* calls, int32_t n_calls, const sko_germline_options* opt, float* de);
+
+/* get_diploid_gt_lhood (L/blt_common/position_snp_call_pprob_digt.cpp:328-385), no het-frequency extension */
+void sko_diploid_gt_lhood(const uint16_t* calls, const float* de, int32_t n_calls, uint32_t ref_gt,
+                          int is_strand_specific, int is_ss_fwd, float* lhood);
+
+typedef struct sko_digt_result_set {
+    double ref_pprob;
+    uint32_t max_gt;
+    int32_t snp_qphred, max_gt_qphred, _pad;
+} sko_digt_result_set;
+typedef struct sko_digt_call {
+    float lhood[10];
+    uint32_t phredLoghood[10];
+    sko_digt_result_set genome, poly;
+    double strand_bias;
+    uint32_t ref_gt, is_called;
+} sko_digt_call;
+
+/* position_snp_call_pprob_digt(..., is_always_test=true) (L/blt_common/position_snp_call_pprob_digt.cpp:473-539) */
+void sko_position_snp_call_pprob_digt(const uint16_t* calls, const float* de, int32_t n_calls, uint32_t ref_base_id,
+                                      int ploidy, const sko_germline_options* opt, sko_digt_call* out);
+
+/* ---- hot path B, somatic SNV ---- */
+typedef struct sko_somatic_snv_options {
+    double bsnp_diploid_theta, somatic_snv_rate, shared_site_error_rate, shared_site_error_strand_bias_fraction,
+        ssnv_contam_tolerance;
+} sko_somatic_snv_options;
+typedef struct sko_somatic_snv_call {
+    float normal_lhood[30], tumor_lhood[30];
+    uint32_t max_gt;
+    int32_t qphred, from_ntype_qphred;
+    uint32_t ntype;
+    float strand_bias;
+    uint32_t is_called, normal_alt_id, tumor_alt_id;
+} sko_somatic_snv_call;
+
+/* 21 prestrand states (+9 strand states when with_strand) of one sample
+ * (L/applications/strelka/position_somatic_snv_strand_grid_lhood_cached.cpp:41-234, position_somatic_snv_strand_grid.cpp:63-83) */
+void sko_somatic_sample_lhood(const uint16_t* calls, int32_t n_calls, uint32_t ref_gt, int with_strand, float* lhood);
+
+/* calculate_result_set_grid (L/applications/strelka/qscore_calculator.cpp:47-209) */
+void sko_calculate_result_set_grid(float contam_tolerance, float ln_sse_rate, float ln_csse_rate,
+                                   const float* normal_lhood, const float* tumor_lhood, const float* lnprior3,
+                                   float lnmatch, float lnmismatch, uint32_t* max_gt, int32_t* qphred,
+                                   int32_t* from_ntype_qphred, uint32_t* ntype);
+
+/* position_somatic_snv_call, tier1 only, isComputeNonSomatic=false
+ * (L/applications/strelka/position_somatic_snv_strand_grid.cpp:230-363) */
+void sko_position_somatic_snv_call(const uint16_t* ncalls, int32_t n_n, const uint16_t* tcalls, int32_t n_t,
+                                   uint32_t ref_base_id, const sko_somatic_snv_options* opt, int is_forced_output,
+                                   sko_somatic_snv_call* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
