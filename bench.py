@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the MI355X-native Strelka2 hot path on the germline chr20-style synthetic workload
+(BASELINE.json configs[1]): 150 bp reads x 64 candidate alignments (hot path A) and 40x pileup loci (hot path B).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  The path shards by independent genome segments, so every rank scores its own,
+equally sized batch ("weak" scaling) and there is NO data-path collective; torch.distributed is used only for the
+barrier that brackets the timed region and the max-over-ranks of the elapsed time.
+
+A "step" = one pass of hot path A over one resident batch of R reads x 64 candidate alignments (the headline metric,
+cells/s = read bases x candidate alignments scored per second).  Hot path B (dependent error probabilities + diploid
+genotype likelihoods per locus) is timed the same way in a second K-step region and reported as loci_per_s beside it.
+Inputs are resident in HBM before any timed region starts.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# algorithmic bytes per unit, SURVEY.md 8(d)
+A_BYTES_PER_READ = 2 * 150 + 64 * (160 + 8)  # 11 052 B per 9 600 cells
+B_BYTES_PER_CALL_DE = 6                      # sk_dependent_eprob: 2 B call in + 4 B de out
+B_BYTES_PER_LOCUS_FIXED = 1 + 120            # ref base + results
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=1 << 20, help="reads per step per GPU (x64 candidates x150 bp)")
+    ap.add_argument("--loci", type=int, default=1 << 24, help="germline loci per step per GPU (depth ~Poisson(40))")
+    ap.add_argument("--unique-reads", type=int, default=1 << 14, help="distinct synthetic reads (tiled on device)")
+    ap.add_argument("--unique-loci", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
+    ap.add_argument("--cpu-loci", type=int, default=150000, help="loci in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (plain-C restatement of the reference, oracle/strelka_oracle.c) timed on ONE host core over a bounded
+    sample of the same workload.  This is the only place bench.py touches oracle/: as the thing the GPU number is put
+    beside, never as part of the measured product path."""
+    from oracle import pyoracle
+    from strelka_amd import synth
+    pyoracle.build(ref=False)
+    rng = np.random.default_rng(1)
+    cases = synth.align_cases_h64(args.cpu_reads, rng)
+    m = pyoracle.MarshalledCases(cases)
+    pyoracle.score_cases(m)  # warm
+    t0 = time.perf_counter()
+    pyoracle.score_cases(m)
+    ta = time.perf_counter() - t0
+    cells = sum(len(c["read_code"]) * len(c["cals"]) for c in cases)
+    pb = synth.pileups(args.cpu_loci, rng)
+    t0 = time.perf_counter()
+    de = pyoracle.adjust_joint_eprob(pb)
+    pyoracle.site_digt_call(pb, de)
+    tb = time.perf_counter() - t0
+    return {"value": cells / ta, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "%d reads x 64 candidate alignments x 150 bp through sko_score_cases (%.1f s); loci: %d loci "
+                      "depth~Poisson(40) through sko_adjust_joint_eprob+sko_position_snp_call_pprob_digt (%.1f s)"
+                      % (len(cases), ta, args.cpu_loci, tb),
+            "loci_per_s": args.cpu_loci / tb}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    from strelka_amd import capi, device, synth
+    capi.init(local_rank)
+
+    # ---- resident inputs (per rank: an independent batch, seeded by rank = an independent genome segment) ----
+    rng = np.random.default_rng(1000 + rank)
+    ua = min(args.unique_reads, args.reads)
+    tile_a = max(1, args.reads // ua)
+    ha = synth.align_batch_flat(ua, rng)
+    da = device.DeviceAlignBatch(ha, dev, tile=tile_a)
+    ub = min(args.unique_loci, args.loci)
+    tile_b = max(1, args.loci // ub)
+    hb = synth.pileups(ub, rng)
+    db = device.DevicePileupBatch(hb, dev, tile=tile_b)
+    gopt = capi.germline_options()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for s, e in evs:
+            s.record()
+            fn()
+            e.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        kern_ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kern_ms
+
+    # ---- hot path A ----
+    dt_a, kms_a = timed(lambda: da.score(), args.steps, args.warmup)
+    cells_per_step = da.n_bases * 64 if ha.n_cals == ha.n_reads * 64 else None
+    cells_per_step = int(np.diff(ha.read_off).astype(np.int64).dot(np.diff(ha.cal_off).astype(np.int64))) * tile_a
+    value = world * cells_per_step * args.steps / dt_a
+    alg_bytes_a = A_BYTES_PER_READ * da.n_reads
+    ach_a = alg_bytes_a / (kms_a * 1e-3) / 1e9
+
+    # ---- hot path B (germline): dependent eprob + site genotype call ----
+    def step_b():
+        db.dependent_eprob(gopt)
+        db.site_digt_call(gopt)
+    dt_b, kms_b = timed(step_b, args.steps, args.warmup)
+    loci_per_s = world * db.n_loci * args.steps / dt_b
+    alg_bytes_b = 6 * db.n_calls + B_BYTES_PER_LOCUS_FIXED * db.n_loci
+    ach_b = alg_bytes_b / (kms_b * 1e-3) / 1e9
+
+    out = {
+        "metric": "candidate-alignment scoring cells/s (read bases x candidate alignments; Strelka2 has no pair-HMM, "
+                  "SURVEY.md section 0) + germline loci/s",
+        "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt_a / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "germline chr20-style synthetic (BASELINE.json configs[1]): per GPU per step %d reads x 64 "
+                               "candidate alignments x 150 bp (K=6 toggled candidate indels); loci leg: %d loci, "
+                               "depth~Poisson(40)" % (da.n_reads, db.n_loci),
+                   "reads_per_step_per_gpu": da.n_reads, "candidates_per_read": 64, "read_len": 150,
+                   "loci_per_step_per_gpu": db.n_loci, "sharding": "independent segments per GPU, no collective"},
+        "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
+        "roofline": {"kernel": "score_wave_per_read", "bound": "hbm", "achieved": ach_a, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": ach_a / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes_a, "kernel_ms": kms_a},
+        "roofline_loci": {"kernel": "dependent_eprob_kernel+site_digt_call_kernel", "bound": "hbm", "achieved": ach_b,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS, "traffic": None,
+                          "algorithmic_bytes_per_launch": alg_bytes_b, "kernel_ms": kms_b},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,12 +56,13 @@ int sk_get_qscore_tables(double* q2p, double* q2lncompe, double* q2lne);
 enum { SK_BAM_REF = 0, SK_BAM_A = 1, SK_BAM_C = 2, SK_BAM_G = 4, SK_BAM_T = 8, SK_BAM_ANY = 15 };
 
 /** Scoring op kinds: a candidate alignment's CIGAR + indel keys flattened in path order by
- *  sk_flatten_candidate_alignment (host adapter).  Read offset advances by `length` for MATCH/INSERT/SOFT_CLIP. */
+ *  sk_flatten_candidate_alignment (host adapter).  Read offset advances by `length` for BASES/SOFT_CLIP ops. */
 enum {
-    SK_OP_MATCH = 0,     /* score read[ro+i] against ref window [src+i]          (scoreMatchSegment :144-170)  */
-    SK_OP_INSERT = 1,    /* score read[ro+i] against insert pool [src+i]         (scoreInsertSegment :110-137) */
-    SK_OP_SOFT_CLIP = 2, /* lnp += length * ln(0.25)                             (:453-454)                    */
-    SK_OP_NOBASE = 3     /* DELETE/SKIP/HARD_CLIP: no base term, only the optional penalty (:419-460)          */
+    SK_OP_BASES = 0,     /* score read[ro+i] against hap pool [src+i]: a MATCH segment against the reference window
+                            (scoreMatchSegment :144-170) or an INSERT segment against the indel's insert sequence
+                            (scoreInsertSegment :110-137) -- the two reference loops are identical                 */
+    SK_OP_SOFT_CLIP = 1, /* lnp += length * ln(0.25)                                        (:453-454)          */
+    SK_OP_NOBASE = 2     /* DELETE/SKIP/HARD_CLIP: no base term, only the optional penalty  (:419-460)          */
 };
 /** flags bit 0: add ln(1e-5) after this op (its indel is not a candidate, :471-487). */
 enum { SK_OPFLAG_NONCANDIDATE_PENALTY = 1 };
@@ -70,7 +71,7 @@ typedef struct sk_score_op {
     uint16_t length;
     uint8_t kind;
     uint8_t flags;
-    int32_t src; /* MATCH: offset into this read's reference window; INSERT: offset into ins_code pool */
+    int32_t src; /* BASES: offset into this read's hap pool (>= 0, src+length <= pool size) */
 } sk_score_op;
 
 typedef struct sk_align_batch {
@@ -79,19 +80,69 @@ typedef struct sk_align_batch {
     int64_t n_ops;            /* = op_off[n_cals] */
     const int64_t* read_off;  /* [n_reads+1] into read_code/read_qual */
     const uint8_t* read_code; /* BAM 4-bit codes, 1/byte */
-    const uint8_t* read_qual; /* phred, must be <= 70 */
-    const int64_t* ref_off;   /* [n_reads+1] per-read reference window into ref_code */
-    const uint8_t* ref_code;  /* BAM 4-bit codes of the reference window ('N'/outside contig segment = 15) */
+    const uint8_t* read_qual; /* phred, must be <= 70 (the reference throws above, qscore_cache.cpp:53-75) */
+    const int64_t* hap_off;   /* [n_reads+1] per-read haplotype source pool into hap_code */
+    const uint8_t* hap_code;  /* BAM 4-bit codes: the read's reference window ('N'/outside the contig segment = 15)
+                                 followed by the insert sequences of the read's candidate indels */
     const int32_t* cal_off;   /* [n_reads+1] candidate-alignment range of each read */
-    const int64_t* op_off;    /* [n_cals+1] op range of each candidate alignment */
+    const int64_t* op_off;    /* [n_cals+1] op range of each candidate alignment; the BASES+SOFT_CLIP lengths of one
+                                 candidate sum to its read's length */
     const sk_score_op* ops;   /* [n_ops] */
-    const uint8_t* ins_code;  /* insert-sequence pool (BAM 4-bit codes) */
-    int64_t n_ins;            /* size of ins_code in bytes */
+    int32_t max_read_len;     /* upper bound of any read length in the batch, 0 = unknown (selects the generic kernel) */
+    int32_t max_hap_len;      /* upper bound of any per-read hap pool size, 0 = unknown */
 } sk_align_batch;
 
 /** out_lnp[n_cals]: ln P(read | alignment), double, bit-identical to the reference's sequential accumulation. */
 int sk_score_alignments(const sk_align_batch* host_batch, double* out_lnp);
 int sk_score_alignments_dev(const sk_align_batch* dev_batch, double* dev_out_lnp, void* hip_stream);
+
+/* Host adapter for hot path A: flattens the reference's own data model -- a read, the reference contig segment and a
+ * set of CandidateAlignment objects (CIGAR path + indel keys, L/starling_common/CandidateAlignment.hh:35-78) -- into an
+ * sk_align_batch.  The walk over the path is the one scoreCandidateAlignment performs
+ * (L/starling_common/starling_read_align_score.cpp:286-493): swap handling (:306-347), edge-insert head position
+ * (:334-338,394-398), indel-key lookup (getMatchingIndelKey :177-228) and the non-candidate penalty (:471-487). */
+
+/** ALIGNPATH::align_t (L/blt_util/align_path.hh:36-48) */
+enum { SK_SEG_NONE = 0, SK_SEG_MATCH, SK_SEG_INSERT, SK_SEG_DELETE, SK_SEG_SKIP, SK_SEG_SOFT_CLIP, SK_SEG_HARD_CLIP,
+       SK_SEG_PAD, SK_SEG_SEQ_MATCH, SK_SEG_SEQ_MISMATCH };
+/** INDEL::index_t (L/starling_common/indel_core.hh:57-66) */
+enum { SK_INDEL_NONE = 0, SK_INDEL_INDEL, SK_INDEL_MISMATCH, SK_INDEL_BP_LEFT, SK_INDEL_BP_RIGHT };
+
+typedef struct sk_path_seg {
+    uint32_t type;
+    uint32_t length;
+} sk_path_seg;
+
+typedef struct sk_indel_key { /* IndelKey (L/starling_common/IndelKey.hh:39-199) + IndelBuffer::isCandidateIndel */
+    int32_t pos;
+    int32_t type;
+    uint32_t del_len;
+    uint32_t ins_len;
+    const char* ins_seq; /* ACGTN; for breakpoints the IndelData breakpoint insert sequence */
+    int32_t is_candidate;
+} sk_indel_key;
+
+typedef struct sk_candidate_alignment {
+    int32_t pos; /* al.pos */
+    int32_t n_seg;
+    const sk_path_seg* path;
+    int32_t n_indels;
+    const sk_indel_key* indels; /* IndelKey-sorted */
+    sk_indel_key leading;       /* type SK_INDEL_NONE when absent */
+    sk_indel_key trailing;
+} sk_candidate_alignment;
+
+typedef struct sk_align_builder sk_align_builder;
+sk_align_builder* sk_align_builder_create(void);
+void sk_align_builder_destroy(sk_align_builder* b);
+void sk_align_builder_clear(sk_align_builder* b);
+/** Append one read and its candidate alignments.  read_code: BAM 4-bit codes one per byte; ref_seq/ref_offset/ref_len:
+ *  the reference_contig_segment (positions outside it read as 'N', L/blt_util/reference_contig_segment.hh:46-51). */
+int sk_align_builder_add_read(sk_align_builder* b, const uint8_t* read_code, const uint8_t* read_qual, int32_t read_len,
+                              const char* ref_seq, int32_t ref_offset, int32_t ref_len,
+                              const sk_candidate_alignment* cals, int32_t n_cals);
+/** Fill `out` with HOST pointers into the builder (valid until the next clear/add/destroy). */
+int sk_align_builder_finish(sk_align_builder* b, sk_align_batch* out);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (germline SNV): dependent error probabilities + diploid genotype likelihoods
@@ -133,8 +184,9 @@ void sk_germline_options_default(sk_germline_options* opt);
 /** a9: replaces adjust_joint_eprob at L/starling_common/PileupCleaner.cpp:73 (L/blt_common/adjust_joint_eprob.cpp:201-243).
  *  out_de[total calls]. */
 int sk_dependent_eprob(const sk_pileup_batch* host_batch, const sk_germline_options* opt, float* out_de);
+/** dev_scratch: device buffer of >= 4 bytes per call (index array for the per-group sort). */
 int sk_dependent_eprob_dev(const sk_pileup_batch* dev_batch, const sk_germline_options* opt, float* dev_out_de,
-                           void* hip_stream);
+                           void* dev_scratch, void* hip_stream);
 
 typedef struct sk_digt_result_set { /* diploid_genotype::result_set, position_snp_call_pprob_digt.hh:72-91 */
     double ref_pprob;

@@ -1,0 +1,186 @@
+"""ctypes loader of the CHECKERS: oracle/libstrelka_oracle.so (plain-C restatement) and, when present,
+oracle/_ref/libstrelka_ref.so (the reference's own translation units).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by
+strelka_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libstrelka_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libstrelka_ref.so")
+vp = C.c_void_p
+
+
+def build(ref=True, quiet=True):
+    """(Re)build the checkers.  `make ref` is a no-op when /root/reference is absent."""
+    out = subprocess.DEVNULL if quiet else None
+    subprocess.run(["make", "-s", "-C", HERE, "oracle"], check=True, stdout=out)
+    if ref and os.path.isdir("/root/reference/src/c++/lib"):
+        subprocess.run(["make", "-s", "-C", HERE, "-j8", "ref"], check=True, stdout=out)
+
+
+class PathSeg(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("length", C.c_uint32)]
+
+
+class Indel(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("type", C.c_int32), ("del_len", C.c_uint32), ("ins_len", C.c_uint32),
+                ("ins_seq", C.c_char_p), ("is_candidate", C.c_int32)]
+
+
+class Cal(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("n_seg", C.c_int32), ("path", C.POINTER(PathSeg)), ("n_indels", C.c_int32),
+                ("indels", C.POINTER(Indel)), ("leading", Indel), ("trailing", Indel)]
+
+
+class ReadCase(C.Structure):
+    _fields_ = [("read_code", vp), ("read_qual", vp), ("read_len", C.c_int32), ("ref_seq", C.c_char_p),
+                ("ref_offset", C.c_int32), ("ref_len", C.c_int32), ("cals", C.POINTER(Cal)), ("n_cals", C.c_int32)]
+
+
+class GermlineOptions(C.Structure):
+    _fields_ = [("bsnp_diploid_theta", C.c_double), ("bsnp_ssd_no_mismatch", C.c_double),
+                ("bsnp_ssd_one_mismatch", C.c_double), ("is_min_vexp", C.c_int32), ("min_vexp", C.c_double)]
+
+
+class SomaticSnvOptions(C.Structure):
+    _fields_ = [("bsnp_diploid_theta", C.c_double), ("somatic_snv_rate", C.c_double),
+                ("shared_site_error_rate", C.c_double), ("shared_site_error_strand_bias_fraction", C.c_double),
+                ("ssnv_contam_tolerance", C.c_double)]
+
+
+def germline_options():
+    return GermlineOptions(0.001, 0.35, 0.6, 1, 0.25)
+
+
+def somatic_snv_options():
+    return SomaticSnvOptions(0.001, 1e-4, 5e-10, 0.0, 0.15)
+
+
+DIGT_RS_DTYPE = np.dtype([("ref_pprob", "<f8"), ("max_gt", "<u4"), ("snp_qphred", "<i4"), ("max_gt_qphred", "<i4"),
+                          ("_pad", "<i4")])
+DIGT_CALL_DTYPE = np.dtype([("lhood", "<f4", (10,)), ("phredLoghood", "<u4", (10,)), ("genome", DIGT_RS_DTYPE),
+                            ("poly", DIGT_RS_DTYPE), ("strand_bias", "<f8"), ("ref_gt", "<u4"), ("is_called", "<u4")])
+SOMATIC_CALL_DTYPE = np.dtype([("normal_lhood", "<f4", (30,)), ("tumor_lhood", "<f4", (30,)), ("max_gt", "<u4"),
+                               ("qphred", "<i4"), ("from_ntype_qphred", "<i4"), ("ntype", "<u4"),
+                               ("strand_bias", "<f4"), ("is_called", "<u4"), ("normal_alt_id", "<u4"),
+                               ("tumor_alt_id", "<u4")])
+
+_oracle = None
+_ref = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO):
+            build(ref=False)
+        L = C.CDLL(ORACLE_SO)
+        L.sko_score_candidate_alignment.restype = C.c_double
+        L.sko_log_sum2.restype = C.c_double
+        L.sko_log_sum2.argtypes = [C.c_double, C.c_double]
+        L.sko_log_sum2f.restype = C.c_float
+        L.sko_log_sum2f.argtypes = [C.c_float, C.c_float]
+        L.sko_error_prob_to_qphred.argtypes = [C.c_double]
+        L.sko_ln_error_prob_to_qphred_f.argtypes = [C.c_float]
+        L.sko_germline_lnpriors.argtypes = [C.c_double, vp]
+        _oracle = L
+    return _oracle
+
+
+def ref_available():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    """The reference's own code; None when oracle/_ref/libstrelka_ref.so has not been built."""
+    global _ref
+    if _ref is None and ref_available():
+        L = C.CDLL(REF_SO)
+        L.ref_pack_base_call.restype = C.c_uint16
+        L.ref_log_sum2.restype = C.c_double
+        L.ref_log_sum2.argtypes = [C.c_double, C.c_double]
+        L.ref_log_sum2f.restype = C.c_float
+        L.ref_log_sum2f.argtypes = [C.c_float, C.c_float]
+        L.ref_error_prob_to_qphred.argtypes = [C.c_double]
+        L.ref_ln_error_prob_to_qphred_f.argtypes = [C.c_float]
+        L.ref_germline_lnpriors.argtypes = [C.c_double, vp]
+        _ref = L
+    return _ref
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# hot path A
+
+class MarshalledCases:
+    """ctypes image of a list of synth.align_cases() dicts; keeps every buffer alive."""
+
+    def __init__(self, cases):
+        self.keep = []
+        self.n_cals = sum(len(c["cals"]) for c in cases)
+        self.arr = (ReadCase * max(len(cases), 1))()
+        self.n = len(cases)
+        for i, c in enumerate(cases):
+            rc = np.ascontiguousarray(c["read_code"], np.uint8)
+            rq = np.ascontiguousarray(c["read_qual"], np.uint8)
+            ref_b = c["ref_seq"].encode() if isinstance(c["ref_seq"], str) else bytes(c["ref_seq"])
+            cals = (Cal * max(len(c["cals"]), 1))()
+            for j, cal in enumerate(c["cals"]):
+                path = (PathSeg * max(len(cal["path"]), 1))(*[PathSeg(t, l) for t, l in cal["path"]])
+                ind = (Indel * max(len(cal["indels"]), 1))(*[self._key(k) for k in cal["indels"]])
+                self.keep += [path, ind]
+                cals[j] = Cal(cal["pos"], len(cal["path"]), path, len(cal["indels"]), ind, self._key(cal.get("leading")),
+                              self._key(cal.get("trailing")))
+            self.keep += [rc, rq, ref_b, cals]
+            self.arr[i] = ReadCase(_p(rc), _p(rq), len(rc), ref_b, c["ref_offset"], len(ref_b), cals, len(c["cals"]))
+
+    def _key(self, k):
+        if k is None:
+            return Indel(0, 0, 0, 0, None, 0)
+        seq = k.get("ins_seq", "").encode()
+        self.keep.append(seq)
+        return Indel(k["pos"], k["type"], k.get("del_len", 0), len(seq), seq, int(k.get("is_candidate", 1)))
+
+
+def score_cases(cases):
+    """ln P(read|alignment) of every candidate alignment of every case (concatenated), via the C restatement."""
+    m = cases if isinstance(cases, MarshalledCases) else MarshalledCases(cases)
+    out = np.zeros(m.n_cals, np.float64)
+    oracle().sko_score_cases(m.arr, m.n, _p(out))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# hot path B
+
+def adjust_joint_eprob(batch, opt=None):
+    opt = opt or germline_options()
+    de = np.zeros(len(batch.calls), np.float32)
+    oracle().sko_adjust_joint_eprob_batch(_p(batch.call_off), _p(batch.calls), batch.n_loci, C.byref(opt), _p(de))
+    return de
+
+
+def site_digt_call(batch, de, opt=None):
+    opt = opt or germline_options()
+    out = np.zeros(batch.n_loci, DIGT_CALL_DTYPE)
+    de = np.ascontiguousarray(de, np.float32)
+    oracle().sko_site_digt_call_batch(_p(batch.call_off), _p(batch.calls), _p(de), _p(batch.ref_base),
+                                      _p(batch.ploidy), batch.n_loci, C.byref(opt), _p(out))
+    return out
+
+
+def somatic_snv_call(normal, tumor, opt=None, is_forced_output=False):
+    opt = opt or somatic_snv_options()
+    out = np.zeros(normal.n_loci, SOMATIC_CALL_DTYPE)
+    oracle().sko_somatic_snv_call_batch(_p(normal.call_off), _p(normal.calls), _p(tumor.call_off), _p(tumor.calls),
+                                        _p(normal.ref_base), normal.n_loci, C.byref(opt), int(is_forced_output), _p(out))
+    return out

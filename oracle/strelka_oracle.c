@@ -959,3 +959,40 @@ void sko_position_somatic_snv_call(const uint16_t* ncalls, int32_t n_n, const ui
         out->strand_bias = (0.f < d) ? d : 0.f;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ batch drivers */
+
+void sko_score_cases(const sko_read_case* cases, int32_t n_cases, double* out)
+{
+    int64_t k = 0;
+    for (int32_t i = 0; i < n_cases; ++i) {
+        const sko_read_case* c = &cases[i];
+        for (int32_t j = 0; j < c->n_cals; ++j)
+            out[k++] = sko_score_candidate_alignment(c->read_code, c->read_qual, c->read_len, &c->cals[j], c->ref_seq,
+                                                     c->ref_offset, c->ref_len);
+    }
+}
+
+void sko_adjust_joint_eprob_batch(const int64_t* call_off, const uint16_t* calls, int32_t n_loci,
+                                  const sko_germline_options* opt, float* de)
+{
+    for (int32_t l = 0; l < n_loci; ++l)
+        sko_adjust_joint_eprob(calls + call_off[l], (int32_t)(call_off[l + 1] - call_off[l]), opt, de + call_off[l]);
+}
+
+void sko_site_digt_call_batch(const int64_t* call_off, const uint16_t* calls, const float* de, const uint8_t* ref_base,
+                              const uint8_t* ploidy, int32_t n_loci, const sko_germline_options* opt, sko_digt_call* out)
+{
+    for (int32_t l = 0; l < n_loci; ++l)
+        sko_position_snp_call_pprob_digt(calls + call_off[l], de + call_off[l], (int32_t)(call_off[l + 1] - call_off[l]),
+                                         ref_base[l], ploidy ? ploidy[l] : 2, opt, &out[l]);
+}
+
+void sko_somatic_snv_call_batch(const int64_t* n_off, const uint16_t* n_calls, const int64_t* t_off,
+                                const uint16_t* t_calls, const uint8_t* ref_base, int32_t n_loci,
+                                const sko_somatic_snv_options* opt, int is_forced_output, sko_somatic_snv_call* out)
+{
+    for (int32_t l = 0; l < n_loci; ++l)
+        sko_position_somatic_snv_call(n_calls + n_off[l], (int32_t)(n_off[l + 1] - n_off[l]), t_calls + t_off[l],
+                                      (int32_t)(t_off[l + 1] - t_off[l]), ref_base[l], opt, is_forced_output, &out[l]);
+}

@@ -125,6 +125,29 @@ void sko_position_somatic_snv_call(const uint16_t* ncalls, int32_t n_n, const ui
                                    uint32_t ref_base_id, const sko_somatic_snv_options* opt, int is_forced_output,
                                    sko_somatic_snv_call* out);
 
+/* ---- batch drivers (plain loops over the functions above; used for parity tests and the bench CPU baseline) ---- */
+typedef struct sko_read_case {
+    const uint8_t* read_code;
+    const uint8_t* read_qual;
+    int32_t read_len;
+    const char* ref_seq;
+    int32_t ref_offset, ref_len;
+    const sko_cal* cals;
+    int32_t n_cals;
+} sko_read_case;
+/* out: concatenated scores, case by case */
+void sko_score_cases(const sko_read_case* cases, int32_t n_cases, double* out);
+
+void sko_adjust_joint_eprob_batch(const int64_t* call_off, const uint16_t* calls, int32_t n_loci,
+                                  const sko_germline_options* opt, float* de);
+void sko_site_digt_call_batch(const int64_t* call_off, const uint16_t* calls, const float* de, const uint8_t* ref_base,
+                              const uint8_t* ploidy /* may be NULL */, int32_t n_loci, const sko_germline_options* opt,
+                              sko_digt_call* out);
+void sko_somatic_snv_call_batch(const int64_t* n_off, const uint16_t* n_calls, const int64_t* t_off,
+                                const uint16_t* t_calls, const uint8_t* ref_base, int32_t n_loci,
+                                const sko_somatic_snv_options* opt, int is_forced_output, sko_somatic_snv_call* out);
+void sko_germline_lnpriors(double theta, float* out /* [2][5][2][10] */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,299 @@
+"""ctypes binding of include/strelka_amd.h (plumbing for tests and bench.py; the product is the C-ABI library).
+
+There is deliberately no fallback: if libstrelka_amd.so is missing this module raises, and if no gfx950 device is present
+`init()` raises with the library's own error text.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstrelka_amd.so")
+
+c_void_p = C.c_void_p
+
+
+class ScoreOp(C.Structure):
+    _fields_ = [("length", C.c_uint16), ("kind", C.c_uint8), ("flags", C.c_uint8), ("src", C.c_int32)]
+
+
+SCORE_OP_DTYPE = np.dtype([("length", "<u2"), ("kind", "u1"), ("flags", "u1"), ("src", "<i4")])
+OP_BASES, OP_SOFT_CLIP, OP_NOBASE = 0, 1, 2
+OPFLAG_PENALTY = 1
+
+
+class AlignBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_cals", C.c_int32), ("n_ops", C.c_int64),
+                ("read_off", c_void_p), ("read_code", c_void_p), ("read_qual", c_void_p),
+                ("hap_off", c_void_p), ("hap_code", c_void_p), ("cal_off", c_void_p), ("op_off", c_void_p),
+                ("ops", c_void_p), ("max_read_len", C.c_int32), ("max_hap_len", C.c_int32)]
+
+
+class PathSeg(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("length", C.c_uint32)]
+
+
+class IndelKey(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("type", C.c_int32), ("del_len", C.c_uint32), ("ins_len", C.c_uint32),
+                ("ins_seq", C.c_char_p), ("is_candidate", C.c_int32)]
+
+
+class CandidateAlignment(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("n_seg", C.c_int32), ("path", C.POINTER(PathSeg)), ("n_indels", C.c_int32),
+                ("indels", C.POINTER(IndelKey)), ("leading", IndelKey), ("trailing", IndelKey)]
+
+
+class PileupBatch(C.Structure):
+    _fields_ = [("n_loci", C.c_int32), ("call_off", c_void_p), ("calls", c_void_p), ("de", c_void_p),
+                ("ref_base", c_void_p), ("ploidy", c_void_p)]
+
+
+class GermlineOptions(C.Structure):
+    _fields_ = [("bsnp_diploid_theta", C.c_double), ("bsnp_ssd_no_mismatch", C.c_double),
+                ("bsnp_ssd_one_mismatch", C.c_double), ("is_min_vexp", C.c_int32), ("min_vexp", C.c_double)]
+
+
+class SomaticSnvOptions(C.Structure):
+    _fields_ = [("bsnp_diploid_theta", C.c_double), ("somatic_snv_rate", C.c_double),
+                ("shared_site_error_rate", C.c_double), ("shared_site_error_strand_bias_fraction", C.c_double),
+                ("ssnv_contam_tolerance", C.c_double)]
+
+
+DIGT_RS_DTYPE = np.dtype([("ref_pprob", "<f8"), ("max_gt", "<u4"), ("snp_qphred", "<i4"), ("max_gt_qphred", "<i4"),
+                          ("_pad", "<i4")])
+DIGT_CALL_DTYPE = np.dtype([("lhood", "<f4", (10,)), ("phredLoghood", "<u4", (10,)), ("genome", DIGT_RS_DTYPE),
+                            ("poly", DIGT_RS_DTYPE), ("strand_bias", "<f8"), ("ref_gt", "<u4"), ("is_called", "<u4")])
+SOMATIC_CALL_DTYPE = np.dtype([("normal_lhood", "<f4", (30,)), ("tumor_lhood", "<f4", (30,)), ("max_gt", "<u4"),
+                               ("qphred", "<i4"), ("from_ntype_qphred", "<i4"), ("ntype", "<u4"),
+                               ("strand_bias", "<f4"), ("is_called", "<u4"), ("normal_alt_id", "<u4"),
+                               ("tumor_alt_id", "<u4")])
+assert DIGT_CALL_DTYPE.itemsize == 144 and SOMATIC_CALL_DTYPE.itemsize == 272
+
+# every symbol include/strelka_amd.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "sk_init", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_get_qscore_tables",
+    "sk_score_alignments", "sk_score_alignments_dev",
+    "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_add_read",
+    "sk_align_builder_finish",
+    "sk_germline_options_default", "sk_dependent_eprob", "sk_dependent_eprob_dev", "sk_site_digt_call",
+    "sk_site_digt_call_dev",
+    "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("strelka_amd: %s is missing -- run `python -m strelka_amd.build` (there is no CPU fallback)"
+                               % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.sk_last_error.restype = C.c_char_p
+        L.sk_align_builder_create.restype = c_void_p
+        L.sk_align_builder_error.restype = C.c_char_p
+        L.sk_align_builder_error.argtypes = [c_void_p]
+        L.sk_align_builder_destroy.argtypes = [c_void_p]
+        L.sk_align_builder_clear.argtypes = [c_void_p]
+        L.sk_align_builder_add_read.argtypes = [c_void_p, c_void_p, c_void_p, C.c_int32, C.c_char_p, C.c_int32,
+                                                C.c_int32, C.POINTER(CandidateAlignment), C.c_int32]
+        L.sk_align_builder_finish.argtypes = [c_void_p, C.POINTER(AlignBatch)]
+        L.sk_score_alignments.argtypes = [C.POINTER(AlignBatch), c_void_p]
+        L.sk_score_alignments_dev.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
+        L.sk_score_alignments_dev_generic.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
+        L.sk_dependent_eprob.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p]
+        L.sk_dependent_eprob_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p, c_void_p,
+                                             c_void_p]
+        L.sk_site_digt_call.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p]
+        L.sk_site_digt_call_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p, c_void_p]
+        L.sk_somatic_snv_call_batch.argtypes = [C.POINTER(PileupBatch), C.POINTER(PileupBatch),
+                                                C.POINTER(SomaticSnvOptions), C.c_int, c_void_p]
+        L.sk_somatic_snv_call_batch_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(PileupBatch),
+                                                    C.POINTER(SomaticSnvOptions), C.c_int, c_void_p, c_void_p]
+        _lib = L
+    return _lib
+
+
+class StrelkaAmdError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise StrelkaAmdError(lib().sk_last_error().decode("utf-8", "replace"))
+
+
+def init(device=0):
+    _check(lib().sk_init(int(device)))
+
+
+def shutdown():
+    lib().sk_shutdown()
+
+
+def germline_options():
+    o = GermlineOptions()
+    lib().sk_germline_options_default(C.byref(o))
+    return o
+
+
+def somatic_snv_options():
+    o = SomaticSnvOptions()
+    lib().sk_somatic_snv_options_default(C.byref(o))
+    return o
+
+
+def qscore_tables():
+    a = [np.zeros(71) for _ in range(3)]
+    _check(lib().sk_get_qscore_tables(*[x.ctypes.data_as(c_void_p) for x in a]))
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# numpy-level views of the batches
+
+
+class HostAlignBatch:
+    """Host-side sk_align_batch held as numpy arrays."""
+
+    def __init__(self, read_off, read_code, read_qual, hap_off, hap_code, cal_off, op_off, ops, max_read_len=None,
+                 max_hap_len=None):
+        self.read_off = np.ascontiguousarray(read_off, np.int64)
+        self.read_code = np.ascontiguousarray(read_code, np.uint8)
+        self.read_qual = np.ascontiguousarray(read_qual, np.uint8)
+        self.hap_off = np.ascontiguousarray(hap_off, np.int64)
+        self.hap_code = np.ascontiguousarray(hap_code, np.uint8)
+        self.cal_off = np.ascontiguousarray(cal_off, np.int32)
+        self.op_off = np.ascontiguousarray(op_off, np.int64)
+        self.ops = np.ascontiguousarray(ops, SCORE_OP_DTYPE)
+        self.n_reads = len(self.read_off) - 1
+        self.n_cals = int(self.cal_off[-1]) if len(self.cal_off) else 0
+        self.max_read_len = int(np.diff(self.read_off).max()) if max_read_len is None and self.n_reads else int(max_read_len or 0)
+        self.max_hap_len = int(np.diff(self.hap_off).max()) if max_hap_len is None and self.n_reads else int(max_hap_len or 0)
+
+    def struct(self):
+        return AlignBatch(self.n_reads, self.n_cals, len(self.ops), _p(self.read_off), _p(self.read_code),
+                          _p(self.read_qual), _p(self.hap_off), _p(self.hap_code), _p(self.cal_off), _p(self.op_off),
+                          _p(self.ops), self.max_read_len, self.max_hap_len)
+
+
+def score_alignments(batch):
+    """Host-buffer entry point: returns float64[n_cals]."""
+    out = np.zeros(batch.n_cals, np.float64)
+    s = batch.struct()
+    _check(lib().sk_score_alignments(C.byref(s), _p(out)))
+    return out
+
+
+class AlignBuilder:
+    """sk_align_builder wrapper: add reads with reference-shaped candidate alignments, get a HostAlignBatch."""
+
+    def __init__(self):
+        self._b = lib().sk_align_builder_create()
+
+    def __del__(self):
+        try:
+            if self._b:
+                lib().sk_align_builder_destroy(self._b)
+        except Exception:
+            pass
+
+    def clear(self):
+        lib().sk_align_builder_clear(self._b)
+
+    @staticmethod
+    def _key(k, keep):
+        if k is None:
+            return IndelKey(0, 0, 0, 0, None, 0)
+        seq = k.get("ins_seq", "").encode()
+        keep.append(seq)
+        return IndelKey(k["pos"], k["type"], k.get("del_len", 0), len(seq), seq, int(k.get("is_candidate", 1)))
+
+    def add_read(self, read_code, read_qual, ref_seq, ref_offset, cals):
+        """cals: list of dict(pos, path=[(type,len)...], indels=[dict(pos,type,del_len,ins_seq,is_candidate)],
+        leading=None|dict, trailing=None|dict)"""
+        read_code = np.ascontiguousarray(read_code, np.uint8)
+        read_qual = np.ascontiguousarray(read_qual, np.uint8)
+        keep = []
+        arr = (CandidateAlignment * max(len(cals), 1))()
+        for i, c in enumerate(cals):
+            path = (PathSeg * max(len(c["path"]), 1))(*[PathSeg(t, l) for t, l in c["path"]])
+            ind = (IndelKey * max(len(c["indels"]), 1))(*[self._key(k, keep) for k in c["indels"]])
+            keep += [path, ind]
+            arr[i] = CandidateAlignment(c["pos"], len(c["path"]), path, len(c["indels"]), ind,
+                                        self._key(c.get("leading"), keep), self._key(c.get("trailing"), keep))
+        ref = ref_seq.encode() if isinstance(ref_seq, str) else bytes(ref_seq)
+        rc = lib().sk_align_builder_add_read(self._b, _p(read_code), _p(read_qual), len(read_code), ref, int(ref_offset),
+                                             len(ref), arr, len(cals))
+        if rc != 0:
+            raise StrelkaAmdError(lib().sk_align_builder_error(self._b).decode())
+
+    def finish(self):
+        s = AlignBatch()
+        if lib().sk_align_builder_finish(self._b, C.byref(s)) != 0:
+            raise StrelkaAmdError("sk_align_builder_finish failed")
+
+        def arr(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.zeros(0, dt)
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).copy()
+
+        n, nc = s.n_reads, s.n_cals
+        read_off = arr(s.read_off, n + 1, np.int64)
+        hap_off = arr(s.hap_off, n + 1, np.int64)
+        return HostAlignBatch(read_off, arr(s.read_code, int(read_off[-1]), np.uint8),
+                              arr(s.read_qual, int(read_off[-1]), np.uint8), hap_off,
+                              arr(s.hap_code, int(hap_off[-1]), np.uint8), arr(s.cal_off, n + 1, np.int32),
+                              arr(s.op_off, nc + 1, np.int64), arr(s.ops, s.n_ops, SCORE_OP_DTYPE), s.max_read_len,
+                              s.max_hap_len)
+
+
+class HostPileupBatch:
+    def __init__(self, call_off, calls, ref_base, de=None, ploidy=None):
+        self.call_off = np.ascontiguousarray(call_off, np.int64)
+        self.calls = np.ascontiguousarray(calls, np.uint16)
+        self.ref_base = np.ascontiguousarray(ref_base, np.uint8)
+        self.de = None if de is None else np.ascontiguousarray(de, np.float32)
+        self.ploidy = None if ploidy is None else np.ascontiguousarray(ploidy, np.uint8)
+        self.n_loci = len(self.call_off) - 1
+
+    def struct(self):
+        return PileupBatch(self.n_loci, _p(self.call_off), _p(self.calls), _p(self.de), _p(self.ref_base), _p(self.ploidy))
+
+
+def dependent_eprob(batch, opt=None):
+    opt = opt or germline_options()
+    out = np.zeros(len(batch.calls), np.float32)
+    s = batch.struct()
+    _check(lib().sk_dependent_eprob(C.byref(s), C.byref(opt), _p(out)))
+    return out
+
+
+def site_digt_call(batch, opt=None):
+    opt = opt or germline_options()
+    out = np.zeros(batch.n_loci, DIGT_CALL_DTYPE)
+    s = batch.struct()
+    _check(lib().sk_site_digt_call(C.byref(s), C.byref(opt), _p(out)))
+    return out
+
+
+def somatic_snv_call(normal, tumor, opt=None, is_forced_output=False):
+    opt = opt or somatic_snv_options()
+    out = np.zeros(normal.n_loci, SOMATIC_CALL_DTYPE)
+    sn, st = normal.struct(), tumor.struct()
+    _check(lib().sk_somatic_snv_call_batch(C.byref(sn), C.byref(st), C.byref(opt), int(is_forced_output), _p(out)))
+    return out
+
+
+def make_call(q, base, fwd=1, nmm=0, filt=0, tscf=0):
+    """SK_MAKE_CALL (vectorised)."""
+    q, base, fwd, nmm, filt, tscf = [np.asarray(x, np.uint16) for x in (q, base, fwd, nmm, filt, tscf)]
+    return ((q & 0x3f) | ((base & 0xf) << 6) | ((fwd & 1) << 10) | ((nmm & 1) << 11) | ((filt & 1) << 12) |
+            ((tscf & 1) << 13)).astype(np.uint16)

@@ -1,0 +1,90 @@
+// sk_common.h -- internal declarations shared by the HIP translation units of libstrelka_amd.so (gfx950 only).
+#pragma once
+
+#include "strelka_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-resident tables.  Every value is computed ON THE HOST with the host libm, using the reference's own
+// expressions (file:line on each builder in sk_context.hip), then uploaded: the kernels never evaluate a
+// transcendental for a quantity the reference takes from a table or memoises, so those terms are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------
+enum { SK_NQ = 71, SK_NQ6 = 64, SK_HET_RES = 9 };
+
+struct SkTables
+{
+    // hot path A (double): L/blt_util/qscore_cache.cpp:34-50, L/starling_common/starling_read_align_score.cpp:119,133-135
+    double q2lncompe[SK_NQ + 1]; // ln(1-e_q)
+    double q2mis[SK_NQ + 1];     // ln(e_q) + (-ln 3)
+    double ln_quarter;           // std::log(0.25)            (:453)
+    double ln_noncand;           // std::log(1e-5)            (:483)
+
+    // hot path B germline (float): L/blt_common/position_snp_call_pprob_digt.cpp:43-46,345-354
+    float g_eprob[SK_NQ6];  // (float) error_prob(q)          (adjust_joint_eprob.cpp:210)
+    float g_v1[SK_NQ6];     // (float)(log(ce+(1.-ce)/3)+ln 1/2)
+    float g_v2[SK_NQ6];     // (float) ln_comp_error_prob(q)
+    float g_weight[SK_NQ6]; // (float)(ln0.75 - ln_error_prob(q))  (adjust_joint_eprob.cpp:116,123)
+    float g_log_one_third;
+
+    // hot path B somatic (float): L/applications/strelka/position_somatic_snv_strand_grid_lhood_cached.cpp
+    float s_v0[SK_NQ6], s_v1[SK_NQ6], s_v2[SK_NQ6];           // :56-64
+    float s_c0[SK_HET_RES][SK_NQ6], s_c1[SK_HET_RES][SK_NQ6]; // :104-110  (het grid)
+    float t_c0[SK_HET_RES][SK_NQ6], t_c1[SK_HET_RES][SK_NQ6]; // :197-206  (strand states, on-strand)
+    float t_off_ref[SK_NQ6];                                  // (float) ln_comp_error_prob(q)            (:213)
+    float t_off_alt[SK_NQ6];                                  // (float)(ln_error_prob(q) + ln_one_third) (:221)
+    float s_ln_one_half;
+};
+
+struct SkContext
+{
+    int device = -1;
+    bool ready = false;
+    SkTables host_tables;
+    SkTables* dev_tables = nullptr;
+    hipStream_t stream = nullptr; // used by the host-buffer entry points
+    // staging arena for the host-buffer entry points (grown on demand, never shrunk)
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+};
+
+SkContext& sk_ctx();
+void sk_set_error(const std::string& msg);
+int sk_fail(const std::string& msg);
+
+#define SK_HIP(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return sk_fail(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+
+#define SK_REQUIRE_INIT()                                                                    \
+    do {                                                                                     \
+        if (!sk_ctx().ready) return sk_fail("strelka_amd: sk_init() has not succeeded");     \
+    } while (0)
+
+// simple bump allocator over the context arena (host-buffer entry points)
+struct SkArena
+{
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    int reserve(size_t bytes);
+    template <typename T> T* take(size_t n)
+    {
+        size_t off = (used + 255) & ~size_t(255);
+        used = off + n * sizeof(T);
+        return reinterpret_cast<T*>(base + off);
+    }
+};
+
+static inline size_t sk_align256(size_t n) { return (n + 255) & ~size_t(255); }
+
+// packed base_call accessors (device + host)
+#define SKC_Q(c) ((unsigned)((c) & 0x3f))
+#define SKC_BASE(c) ((unsigned)(((c) >> 6) & 0xf))
+#define SKC_FWD(c) ((unsigned)(((c) >> 10) & 1))
+#define SKC_NMM(c) ((unsigned)(((c) >> 11) & 1))
+#define SKC_FILTER(c) ((unsigned)(((c) >> 12) & 1))

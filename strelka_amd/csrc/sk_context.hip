@@ -1,0 +1,208 @@
+// sk_context.hip -- lifecycle, error channel and host-built tables of libstrelka_amd.so.
+//
+// The tables are evaluated at run time with the host libm (the same glibc the reference links), never constant-folded
+// by the compiler: inputs pass through `rt()` (a volatile round trip).
+
+#include "sk_common.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace
+{
+thread_local std::string g_last_error;
+SkContext g_ctx;
+
+inline double rt(double x)
+{
+    volatile double v = x;
+    return v;
+}
+inline float rtf(float x)
+{
+    volatile float v = x;
+    return v;
+}
+
+// log1p_switch, L/blt_util/math_util.hh:33-48
+double log1p_switch(const double x)
+{
+    if (std::abs(x) < 0.01) return ::log1p(x);
+    return std::log(1 + x);
+}
+
+void build_tables(SkTables& t)
+{
+    std::memset(&t, 0, sizeof(t));
+    double q2p[SK_NQ], q2lne[SK_NQ];
+    // qphred_cache::qphred_cache, L/blt_util/qscore_cache.cpp:34-50
+    const double q2lnp(-std::log(rt(10.)) / 10.);
+    const double lnthird(-std::log(rt(3.))); // starling_read_align_score.cpp:119
+    for (int i = 0; i < SK_NQ; ++i) {
+        q2p[i] = std::pow(rt(10.), -static_cast<double>(i) / 10.); // phred_to_error_prob, qscore.hh:77-82
+        t.q2lncompe[i] = log1p_switch(-q2p[i]);
+        q2lne[i] = static_cast<double>(i) * q2lnp;
+        t.q2mis[i] = q2lne[i] + lnthird; // qphred_to_ln_error_prob(qscore)+lnthird (:135)
+    }
+    t.ln_quarter = std::log(rt(0.25));
+    t.ln_noncand = std::log(rt(1e-5));
+
+    // germline, position_snp_call_pprob_digt.cpp:43-46
+    const float one_third(rt(1.) / 3.);
+    const float log_one_third(std::log(rtf(one_third)));
+    const float one_half(rt(1.) / 2.);
+    const float log_one_half(std::log(rtf(one_half)));
+    t.g_log_one_third = log_one_third;
+    const float lnran(std::log(rt(0.75))); // adjust_joint_eprob.cpp:116
+    for (int q = 0; q < SK_NQ6; ++q) {
+        t.g_eprob[q] = static_cast<float>(q2p[q]);
+        const float ceprob(1. - q2p[q]);                                                  // :347
+        t.g_v1[q] = std::log((ceprob) + ((1. - ceprob) * one_third)) + log_one_half;      // :353 (double, narrowed)
+        t.g_v2[q] = static_cast<float>(t.q2lncompe[q]);                                   // :348,354
+        t.g_weight[q] = lnran - q2lne[q];                                                 // adjust_joint_eprob.cpp:123
+    }
+
+    // somatic, position_somatic_snv_strand_grid_lhood_cached.cpp:34-37
+    const float ln_one_third(std::log(rtf(one_third)));
+    const float ln_one_half(std::log(rtf(one_half)));
+    t.s_ln_one_half = ln_one_half;
+    const float RATIO_INCREMENT = 0.5f / static_cast<float>(SK_HET_RES + 1); // strelka_digt_states.hh:94
+    for (int q = 0; q < SK_NQ6; ++q) {
+        {
+            // get_diploid_gt_lhood_cached_simple :53-64
+            const float eprob(q2p[q]);
+            const float ceprob(1 - eprob);
+            const float lne(q2lne[q]);
+            const float lnce(t.q2lncompe[q]);
+            t.s_v0[q] = lne + ln_one_third;
+            t.s_v1[q] = std::log((ceprob) + ((eprob)*one_third)) + ln_one_half;
+            t.s_v2[q] = lnce;
+        }
+        for (unsigned r = 0; r < SK_HET_RES; ++r) {
+            const float het_ratio((r + 1) * RATIO_INCREMENT);
+            const float chet_ratio(1. - het_ratio);
+            {
+                // get_high_low_het_ratio_lhood_cached :94-110
+                const float eprob(q2p[q]);
+                const float ceprob(1 - eprob);
+                t.s_c0[r][q] = std::log((ceprob)*het_ratio + ((eprob)*one_third) * chet_ratio);
+                t.s_c1[r][q] = std::log((ceprob)*chet_ratio + ((eprob)*one_third) * het_ratio);
+            }
+            {
+                // get_strand_ratio_lhood_spi :178-206
+                const float eprob(q2p[q]);
+                const float ceprob(1. - eprob);
+                t.t_c0[r][q] = (std::log((ceprob)*chet_ratio + ((eprob)*one_third) * het_ratio));
+                t.t_c1[r][q] = (std::log((ceprob)*het_ratio + ((eprob)*one_third) * chet_ratio));
+            }
+        }
+        t.t_off_ref[q] = static_cast<float>(t.q2lncompe[q]);  // :213
+        t.t_off_alt[q] = q2lne[q] + ln_one_third;             // :221 (double add, narrowed)
+    }
+}
+} // namespace
+
+SkContext& sk_ctx() { return g_ctx; }
+void sk_set_error(const std::string& msg) { g_last_error = msg; }
+int sk_fail(const std::string& msg)
+{
+    g_last_error = msg;
+    return 1;
+}
+
+int SkArena::reserve(size_t bytes)
+{
+    SkContext& c = sk_ctx();
+    bytes = sk_align256(bytes) + 4096;
+    if (c.arena_bytes < bytes) {
+        if (c.arena) (void)hipFree(c.arena);
+        c.arena = nullptr;
+        c.arena_bytes = 0;
+        size_t want = bytes + bytes / 4;
+        SK_HIP(hipMalloc(&c.arena, want));
+        c.arena_bytes = want;
+    }
+    base = static_cast<char*>(c.arena);
+    cap = c.arena_bytes;
+    used = 0;
+    return 0;
+}
+
+extern "C" {
+
+int sk_version(void) { return SK_VERSION; }
+const char* sk_last_error(void) { return g_last_error.c_str(); }
+int sk_is_initialized(void) { return g_ctx.ready ? 1 : 0; }
+
+int sk_init(int device)
+{
+    SkContext& c = g_ctx;
+    if (c.ready && c.device == device) return 0;
+    if (c.ready) sk_shutdown();
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return sk_fail(std::string("strelka_amd: no HIP device available (") + hipGetErrorString(e) +
+                       "); this library has no CPU fallback");
+    if (device < 0 || device >= n) return sk_fail("strelka_amd: device index out of range");
+    SK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SK_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return sk_fail(std::string("strelka_amd: built for gfx950 only, device is ") + prop.gcnArchName);
+    build_tables(c.host_tables);
+    SK_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev_tables), sizeof(SkTables)));
+    SK_HIP(hipMemcpy(c.dev_tables, &c.host_tables, sizeof(SkTables), hipMemcpyHostToDevice));
+    SK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.device = device;
+    c.ready = true;
+    return 0;
+}
+
+void sk_shutdown(void)
+{
+    SkContext& c = g_ctx;
+    if (!c.ready) return;
+    (void)hipSetDevice(c.device);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    if (c.dev_tables) (void)hipFree(c.dev_tables);
+    if (c.arena) (void)hipFree(c.arena);
+    c = SkContext();
+}
+
+int sk_get_qscore_tables(double* q2p, double* q2lncompe, double* q2lne)
+{
+    // usable without a GPU: the tables are host-built
+    SkTables t;
+    build_tables(t);
+    const double lnthird(-std::log(rt(3.)));
+    const double q2lnp(-std::log(rt(10.)) / 10.);
+    (void)lnthird;
+    for (int i = 0; i < SK_NQ; ++i) {
+        q2p[i] = std::pow(rt(10.), -static_cast<double>(i) / 10.);
+        q2lncompe[i] = t.q2lncompe[i];
+        q2lne[i] = static_cast<double>(i) * q2lnp;
+    }
+    return 0;
+}
+
+void sk_germline_options_default(sk_germline_options* opt)
+{
+    opt->bsnp_diploid_theta = 0.001;
+    opt->bsnp_ssd_no_mismatch = 0.35;
+    opt->bsnp_ssd_one_mismatch = 0.6;
+    opt->is_min_vexp = 1;
+    opt->min_vexp = 0.25;
+}
+
+void sk_somatic_snv_options_default(sk_somatic_snv_options* opt)
+{
+    opt->bsnp_diploid_theta = 0.001;
+    opt->somatic_snv_rate = 1e-4;
+    opt->shared_site_error_rate = 5e-10;
+    opt->shared_site_error_strand_bias_fraction = 0.0;
+    opt->ssnv_contam_tolerance = 0.15;
+}
+
+} // extern "C"

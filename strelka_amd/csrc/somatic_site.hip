@@ -1,0 +1,368 @@
+// somatic_site.hip -- hot path B (somatic SNV): per-locus 30-state frequency-grid likelihoods of the normal and tumor
+// pileups and the 3x2 (normal genotype x {non-somatic, somatic}) posterior.
+//
+//   position_somatic_snv_call       L/applications/strelka/position_somatic_snv_strand_grid.cpp:230-363 (one tier)
+//   get_diploid_gt_lhood_cached_simple / get_diploid_het_grid_lhood_cached / get_strand_ratio_lhood_spi
+//                                   L/applications/strelka/position_somatic_snv_strand_grid_lhood_cached.cpp:41-234
+//   calculate_result_set_grid       L/applications/strelka/qscore_calculator.cpp:47-209
+//
+// One thread per locus.  The reference memoises every per-call term by (qscore, ratio index); those memo tables are
+// built on the host (SkTables) so each of the 21 (+2x9 strand) accumulators is the same sequential float32 sum over the
+// calls in pileup order as in the reference -- bit-identical.  Only the 9 strand states' final float logsum and the
+// double-precision posterior evaluate device transcendentals.
+
+#include "sk_common.h"
+
+#include <cmath>
+#include <cstring>
+
+int sk_upload_pileup_internal(const sk_pileup_batch* hb, bool need_de, SkArena& ar, size_t extra_bytes,
+                              sk_pileup_batch& d, hipStream_t st, int64_t& total_calls);
+
+namespace
+{
+
+enum { SOM_REF = 0, SOM_HOM = 1, SOM_HET = 2, SOM_SIZE = 3, HET_RES = SK_HET_RES, PRESTRAND = 21, GRID = 30 };
+
+struct SomaticDerived
+{
+    float contam_tolerance;
+    float ln_csse_rate, ln_sse_rate;
+    float ln_som_match, ln_som_mismatch;
+    float lnprior[3];
+    float log_error_mod; // -log(PRESTRAND_SIZE-1)
+    float ln_one_half;   // (float) std::log(1./2.)
+    float grid_frac[PRESTRAND];
+    int is_forced_output;
+};
+
+struct SomArgs
+{
+    sk_pileup_batch n, t;
+    const SkTables* tab;
+    sk_somatic_snv_call* out;
+    SomaticDerived d;
+};
+
+// error_prob_to_qphred<double>, L/blt_util/qscore.hh:40-47,60-66
+__device__ __forceinline__ int error_prob_to_qphred_d(const double prob)
+{
+    const double minlog10 = -307.;
+    const double l = log10(prob);
+    const double m = (minlog10 < l) ? l : minlog10;
+    return static_cast<int>(floor(__dadd_rn(__dmul_rn(-10., m), 0.5)));
+}
+
+// getLogSum<float>, L/blt_util/logSumUtil.hh:33-41 with log1p_switch<float>, L/blt_util/math_util.hh:33-48
+__device__ __forceinline__ float log_sum2f(float x1, float x2)
+{
+    if (x1 < x2) {
+        const float t = x1;
+        x1 = x2;
+        x2 = t;
+    }
+    const float e = expf(__fsub_rn(x2, x1));
+    const float l = (fabsf(e) < 0.01f) ? log1pf(e) : logf(__fadd_rn(1.f, e));
+    return __fadd_rn(x1, l);
+}
+
+template <bool WITH_STRAND>
+__device__ void sample_lhood(const uint16_t* __restrict__ calls, const int n, const unsigned ref_gt,
+                             const SkTables* __restrict__ T, float* __restrict__ lhood, bool& allref, unsigned& alt_id)
+{
+    float acc[PRESTRAND];
+#pragma unroll
+    for (int i = 0; i < PRESTRAND; ++i) acc[i] = 0.f;
+    float sf[HET_RES], sr[HET_RES];
+#pragma unroll
+    for (int r = 0; r < HET_RES; ++r) sf[r] = sr[r] = 0.f;
+    unsigned alt_count[4] = { 0, 0, 0, 0 };
+    allref = true;
+
+    for (int i = 0; i < n; ++i) {
+        const uint16_t bc = calls[i];
+        const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
+        const bool is_ref = (obs == ref_gt);
+        if (!is_ref) {
+            allref = false;
+            if (obs < 4) ++alt_count[obs];
+        }
+        const float v0 = T->s_v0[q], v1 = T->s_v1[q], v2 = T->s_v2[q];
+        acc[SOM_REF] = __fadd_rn(acc[SOM_REF], is_ref ? v2 : v0);
+        acc[SOM_HET] = __fadd_rn(acc[SOM_HET], v1);
+        acc[SOM_HOM] = __fadd_rn(acc[SOM_HOM], is_ref ? v0 : v2);
+#pragma unroll
+        for (int r = 0; r < HET_RES; ++r) {
+            const float c0 = T->s_c0[r][q], c1 = T->s_c1[r][q];
+            // lhood_high = grid[2*HET_RES-(r+1)], lhood_low = grid[r]   (…_lhood_cached.cpp:149-151)
+            acc[SOM_SIZE + (2 * HET_RES - (r + 1))] = __fadd_rn(acc[SOM_SIZE + (2 * HET_RES - (r + 1))], is_ref ? c0 : c1);
+            acc[SOM_SIZE + r] = __fadd_rn(acc[SOM_SIZE + r], is_ref ? c1 : c0);
+        }
+        if (WITH_STRAND) {
+            const bool fwd = SKC_FWD(bc);
+            const float off = is_ref ? T->t_off_ref[q] : T->t_off_alt[q];
+#pragma unroll
+            for (int r = 0; r < HET_RES; ++r) {
+                const float on = is_ref ? T->t_c0[r][q] : T->t_c1[r][q];
+                sf[r] = __fadd_rn(sf[r], fwd ? on : off);
+                sr[r] = __fadd_rn(sr[r], fwd ? off : on);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PRESTRAND; ++i) lhood[i] = acc[i];
+#pragma unroll
+    for (int r = 0; r < HET_RES; ++r)
+        lhood[PRESTRAND + r] = WITH_STRAND ? __fadd_rn(log_sum2f(sf[r], sr[r]), T->s_ln_one_half) : 0.f;
+
+    // snp_pos_info::get_most_frequent_alt_id, L/blt_common/snp_pos_info.hh:164-190
+    alt_id = ref_gt;
+    unsigned max_count = 0;
+#pragma unroll
+    for (unsigned b = 0; b < 4; ++b) {
+        if (alt_count[b] > max_count && b != ref_gt) {
+            max_count = alt_count[b];
+            alt_id = b;
+        }
+    }
+}
+
+// calculate_result_set_grid, L/applications/strelka/qscore_calculator.cpp:47-209.  The (Fn,Ft) enumeration order of the
+// reference is kept so that the running max / sums see the terms in the same order.
+__device__ void calculate_result_set_grid(const SomaticDerived& d, const float* normal_lhood, const float* tumor_lhood,
+                                          sk_somatic_snv_call& rs)
+{
+    const double neg_inf = -INFINITY;
+    double log_post_prob[SOM_SIZE][2];
+    double max_log_prob = neg_inf;
+    unsigned max_gt = 0;
+    const float RATIO_INCREMENT = 0.5f / static_cast<float>(HET_RES + 1);
+
+    for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) {
+        for (unsigned tgt = 0; tgt < 2; ++tgt) {
+            // two passes over the allowed (Ft,Fn) pairs instead of the reference's log_sum[] buffer: same max, same
+            // summation order, no 441-double scratch array
+            double max_log_sum = neg_inf;
+            double sum = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (unsigned tfi = 0; tfi < PRESTRAND; ++tfi) {
+                    const bool consider_norm_contam = (__fmul_rn(d.contam_tolerance, d.grid_frac[tfi]) >= RATIO_INCREMENT);
+                    for (unsigned nfi = 0; nfi < PRESTRAND; ++nfi) {
+                        double lprior_freq;
+                        if (tgt == 0) {
+                            if (nfi != tfi) continue;
+                            lprior_freq = (nfi == ngt) ? static_cast<double>(d.ln_csse_rate)
+                                                       : static_cast<double>(__fadd_rn(d.ln_sse_rate, d.log_error_mod));
+                        } else {
+                            if (nfi == tfi) continue;
+                            if (ngt != SOM_REF) {
+                                if (nfi != ngt) continue;
+                                lprior_freq = d.log_error_mod;
+                            } else {
+                                if (!consider_norm_contam) {
+                                    if (nfi == 0) lprior_freq = d.log_error_mod;
+                                    else continue;
+                                } else {
+                                    if ((nfi == ngt) || (nfi == SOM_SIZE))
+                                        lprior_freq = static_cast<double>(__fadd_rn(d.log_error_mod, d.ln_one_half));
+                                    else continue;
+                                }
+                            }
+                        }
+                        const double lsum = __dadd_rn(__dadd_rn(lprior_freq, static_cast<double>(normal_lhood[nfi])),
+                                                      static_cast<double>(tumor_lhood[tfi]));
+                        if (pass == 0) {
+                            if (lsum > max_log_sum) max_log_sum = lsum;
+                        } else {
+                            sum = __dadd_rn(sum, exp(__dsub_rn(lsum, max_log_sum)));
+                        }
+                    }
+                }
+            }
+            const double log_genotype_prior = static_cast<double>(__fadd_rn(d.lnprior[ngt], (tgt == 0) ? d.ln_som_match : d.ln_som_mismatch));
+            log_post_prob[ngt][tgt] = __dadd_rn(__dadd_rn(log_genotype_prior, max_log_sum), log(sum));
+            if (log_post_prob[ngt][tgt] > max_log_prob) {
+                max_log_prob = log_post_prob[ngt][tgt];
+                max_gt = ngt * 2 + tgt;
+            }
+        }
+    }
+
+    double sum_prob = 0.0;
+    for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt)
+        for (unsigned tgt = 0; tgt < 2; ++tgt)
+            sum_prob = __dadd_rn(sum_prob, exp(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob)));
+    const double log_sum_prob = log(sum_prob);
+    double min_not_somfrom_sum = INFINITY;
+    double nonsom_prob = 0.0;
+    int from_ntype_qphred = 0;
+    unsigned ntype = 0;
+    for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) {
+        double som_prob_given_ngt = 0;
+        for (unsigned tgt = 0; tgt < 2; ++tgt) {
+            const double pp = exp(__dsub_rn(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob), log_sum_prob));
+            if (tgt == 0) nonsom_prob = __dadd_rn(nonsom_prob, pp);
+            else som_prob_given_ngt = __dadd_rn(som_prob_given_ngt, pp);
+        }
+        const double err_som_and_ngt = __dsub_rn(1.0, som_prob_given_ngt);
+        if (err_som_and_ngt < min_not_somfrom_sum) {
+            min_not_somfrom_sum = err_som_and_ngt;
+            from_ntype_qphred = error_prob_to_qphred_d(err_som_and_ngt);
+            ntype = ngt;
+        }
+    }
+    rs.max_gt = max_gt;
+    rs.qphred = error_prob_to_qphred_d(nonsom_prob);
+    rs.from_ntype_qphred = from_ntype_qphred;
+    rs.ntype = ntype;
+}
+
+__global__ void somatic_snv_kernel(const SomArgs a)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.n.n_loci) return;
+    const unsigned ref = a.n.ref_base[l];
+    sk_somatic_snv_call res;
+    memset(&res, 0, sizeof(res));
+    if (ref >= 4) {
+        a.out[l] = res;
+        return;
+    }
+    const int64_t no = a.n.call_off[l], to = a.t.call_off[l];
+    const int nn = int(a.n.call_off[l + 1] - no), nt = int(a.t.call_off[l + 1] - to);
+    bool n_allref, t_allref;
+    sample_lhood<false>(a.n.calls + no, nn, ref, a.tab, res.normal_lhood, n_allref, res.normal_alt_id);
+    sample_lhood<true>(a.t.calls + to, nt, ref, a.tab, res.tumor_lhood, t_allref, res.tumor_alt_id);
+    if (!a.d.is_forced_output && n_allref && t_allref) { // early-out (:251-254): nothing is computed by the reference
+        memset(&res, 0, sizeof(res));
+        a.out[l] = res;
+        return;
+    }
+    res.is_called = 1;
+    calculate_result_set_grid(a.d, res.normal_lhood, res.tumor_lhood, res);
+    if (a.d.is_forced_output || res.qphred != 0) { // strand bias (:216-225), skipped by the early return at :184
+        float symm = res.tumor_lhood[SOM_SIZE];
+        for (int i = SOM_SIZE; i < PRESTRAND; ++i) symm = (symm < res.tumor_lhood[i]) ? res.tumor_lhood[i] : symm;
+        float strand = res.tumor_lhood[PRESTRAND];
+        for (int i = PRESTRAND; i < GRID; ++i) strand = (strand < res.tumor_lhood[i]) ? res.tumor_lhood[i] : strand;
+        const float dd = __fsub_rn(strand, symm);
+        res.strand_bias = (0.f < dd) ? dd : 0.f;
+    }
+    a.out[l] = res;
+}
+
+double log1p_switch(const double x)
+{
+    if (std::abs(x) < 0.01) return ::log1p(x);
+    return std::log(1 + x);
+}
+
+void derive(const sk_somatic_snv_options& opt, int is_forced_output, SomaticDerived& d)
+{
+    std::memset(&d, 0, sizeof(d));
+    // somatic_snv_caller_strand_grid ctor, position_somatic_snv_strand_grid.cpp:42-54
+    d.contam_tolerance = opt.ssnv_contam_tolerance;
+    d.ln_csse_rate = log1p_switch(-opt.shared_site_error_rate);
+    d.ln_som_match = log1p_switch(-opt.somatic_snv_rate);
+    d.ln_som_mismatch = std::log(opt.somatic_snv_rate);
+    // calculateGermlineGenotypeLogPrior, qscore_calculator.cpp:33-42
+    d.lnprior[SOM_REF] = (float)log1p_switch(-(3. * opt.bsnp_diploid_theta) / 2.);
+    d.lnprior[SOM_HOM] = (float)std::log(opt.bsnp_diploid_theta / 2.);
+    d.lnprior[SOM_HET] = (float)std::log(opt.bsnp_diploid_theta);
+    const float strand_sse_rate(opt.shared_site_error_rate * opt.shared_site_error_strand_bias_fraction);
+    const float nostrand_sse_rate(opt.shared_site_error_rate - strand_sse_rate);
+    d.ln_sse_rate = std::log(nostrand_sse_rate);
+    // qscore_calculator.cpp:59-60
+    volatile double half = 1. / 2., pm1 = static_cast<double>(PRESTRAND - 1);
+    d.ln_one_half = std::log(half);
+    d.log_error_mod = -std::log(pm1);
+    // DIGT_GRID::get_fraction_from_index, strelka_digt_states.cpp:33-41
+    const float RATIO_INCREMENT = 0.5f / static_cast<float>(HET_RES + 1);
+    for (int index = 0; index < PRESTRAND; ++index) {
+        float f;
+        if (index == SOM_REF) f = 0.f;
+        else if (index == SOM_HOM) f = 1.f;
+        else if (index == SOM_HET) f = 0.5f;
+        else if (index < SOM_SIZE + HET_RES) f = RATIO_INCREMENT * (index - SOM_SIZE + 1);
+        else f = RATIO_INCREMENT * (index - SOM_SIZE + 2);
+        d.grid_frac[index] = f;
+    }
+    d.is_forced_output = is_forced_output ? 1 : 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* n, const sk_pileup_batch* t, const sk_somatic_snv_options* opt,
+                                  int is_forced_output, sk_somatic_snv_call* dev_out, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (!n || !t || !opt || !dev_out) return sk_fail("sk_somatic_snv_call_batch_dev: null argument");
+    if (n->n_loci != t->n_loci) return sk_fail("sk_somatic_snv_call_batch_dev: normal/tumor n_loci differ");
+    if (n->n_loci <= 0) return 0;
+    SomArgs a;
+    a.n = *n;
+    a.t = *t;
+    a.tab = sk_ctx().dev_tables;
+    a.out = dev_out;
+    derive(*opt, is_forced_output, a.d);
+    const int threads = 64;
+    hipLaunchKernelGGL(somatic_snv_kernel, dim3((n->n_loci + threads - 1) / threads), dim3(threads), 0,
+                       static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sk_somatic_snv_call_batch(const sk_pileup_batch* hn, const sk_pileup_batch* ht, const sk_somatic_snv_options* opt,
+                              int is_forced_output, sk_somatic_snv_call* out)
+{
+    SK_REQUIRE_INIT();
+    if (!hn || !ht || !opt || !out) return sk_fail("sk_somatic_snv_call_batch: null argument");
+    if (hn->n_loci != ht->n_loci) return sk_fail("sk_somatic_snv_call_batch: normal/tumor n_loci differ");
+    const int n = hn->n_loci;
+    if (n <= 0) return 0;
+    if (std::memcmp(hn->ref_base, ht->ref_base, n) != 0) return sk_fail("sk_somatic_snv_call_batch: ref_base differs");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    // two uploads share one arena: reserve for both up front
+    const int64_t tn = hn->call_off[n], tt = hn == ht ? 0 : ht->call_off[n];
+    const size_t per = [&](int64_t tc) {
+        return sk_align256(sizeof(int64_t) * (n + 1)) + sk_align256(2 * tc) + sk_align256(n) * 2 + 8 * 256;
+    }(0);
+    (void)per;
+    SkArena ar;
+    const size_t need = 2 * (sk_align256(sizeof(int64_t) * (n + 1)) + sk_align256(n) * 2 + 16 * 256) +
+                        sk_align256(2 * tn) + sk_align256(2 * ht->call_off[n]) +
+                        sk_align256(sizeof(sk_somatic_snv_call) * n) + 4096;
+    (void)tt;
+    if (ar.reserve(need)) return 1;
+    auto up = [&](const sk_pileup_batch* hb, sk_pileup_batch& d) -> int {
+        if (hb->call_off[0] != 0) return sk_fail("pileup batch: call_off must start at 0");
+        const int64_t tc = hb->call_off[n];
+        for (int64_t i = 0; i < tc; ++i)
+            if (SKC_BASE(hb->calls[i]) > 3) return sk_fail("sk_somatic_snv_call_batch: basecall with base_id > 3");
+        d = *hb;
+        int64_t* off = ar.take<int64_t>(n + 1);
+        SK_HIP(hipMemcpyAsync(off, hb->call_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx.stream));
+        d.call_off = off;
+        uint16_t* calls = ar.take<uint16_t>(tc);
+        if (tc) SK_HIP(hipMemcpyAsync(calls, hb->calls, 2 * tc, hipMemcpyHostToDevice, ctx.stream));
+        d.calls = calls;
+        d.de = nullptr;
+        d.ploidy = nullptr;
+        uint8_t* rb = ar.take<uint8_t>(n);
+        SK_HIP(hipMemcpyAsync(rb, hb->ref_base, n, hipMemcpyHostToDevice, ctx.stream));
+        d.ref_base = rb;
+        return 0;
+    };
+    sk_pileup_batch dn, dt;
+    if (up(hn, dn) || up(ht, dt)) return 1;
+    sk_somatic_snv_call* dout = ar.take<sk_somatic_snv_call>(n);
+    if (sk_somatic_snv_call_batch_dev(&dn, &dt, opt, is_forced_output, dout, ctx.stream)) return 1;
+    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_snv_call) * n, hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,123 @@
+"""Device-resident batches for the `*_dev` entry points.  torch is used only as the device allocator / stream provider
+(bench.py, tests); nothing here computes."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+def _t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceAlignBatch:
+    def __init__(self, hb, device="cuda:0", tile=1):
+        """Upload a capi.HostAlignBatch; `tile` > 1 replicates it on the device (offsets shifted) to reach bench sizes."""
+        self.device = device
+        ops_bytes = hb.ops.view(np.uint8).reshape(-1, 8)
+        t = dict(read_off=_t(hb.read_off, device), read_code=_t(hb.read_code, device), read_qual=_t(hb.read_qual, device),
+                 hap_off=_t(hb.hap_off, device), hap_code=_t(hb.hap_code, device), cal_off=_t(hb.cal_off, device),
+                 op_off=_t(hb.op_off, device), ops=_t(ops_bytes, device))
+        if tile > 1:
+            def tile_off(x, dtype):
+                base = x[:-1]
+                total = x[-1]
+                k = torch.arange(tile, device=device, dtype=dtype)[:, None] * total
+                return torch.cat([(base[None, :] + k).reshape(-1), (total * tile).reshape(1).to(dtype)])
+            t["read_off"] = tile_off(t["read_off"], torch.int64)
+            t["hap_off"] = tile_off(t["hap_off"], torch.int64)
+            t["cal_off"] = tile_off(t["cal_off"].to(torch.int64), torch.int64).to(torch.int32)
+            t["op_off"] = tile_off(t["op_off"], torch.int64)
+            for k in ("read_code", "read_qual", "hap_code"):
+                t[k] = t[k].repeat(tile)
+            t["ops"] = t["ops"].repeat(tile, 1)
+        self.t = t
+        self.n_reads = hb.n_reads * tile
+        self.n_cals = hb.n_cals * tile
+        self.n_ops = len(hb.ops) * tile
+        self.n_bases = len(hb.read_code) * tile
+        self.max_read_len = hb.max_read_len
+        self.max_hap_len = hb.max_hap_len
+        self.out = torch.empty(self.n_cals, dtype=torch.float64, device=device)
+
+    def struct(self):
+        t = self.t
+        return capi.AlignBatch(self.n_reads, self.n_cals, self.n_ops, t["read_off"].data_ptr(), t["read_code"].data_ptr(),
+                               t["read_qual"].data_ptr(), t["hap_off"].data_ptr(), t["hap_code"].data_ptr(),
+                               t["cal_off"].data_ptr(), t["op_off"].data_ptr(), t["ops"].data_ptr(), self.max_read_len,
+                               self.max_hap_len)
+
+    def score(self, generic=False):
+        """Enqueue the scoring kernel on torch's current stream; returns the device output tensor."""
+        s = self.struct()
+        fn = capi.lib().sk_score_alignments_dev_generic if generic else capi.lib().sk_score_alignments_dev
+        capi._check(fn(C.byref(s), C.c_void_p(self.out.data_ptr()), _stream_ptr()))
+        return self.out
+
+
+class DevicePileupBatch:
+    def __init__(self, hb, device="cuda:0", tile=1, de=None):
+        self.device = device
+        t = dict(call_off=_t(hb.call_off, device), calls=_t(hb.calls.view(np.int16), device), ref_base=_t(hb.ref_base, device))
+        if tile > 1:
+            total = t["call_off"][-1]
+            k = torch.arange(tile, device=device, dtype=torch.int64)[:, None] * total
+            t["call_off"] = torch.cat([(t["call_off"][:-1][None, :] + k).reshape(-1), (total * tile).reshape(1)])
+            t["calls"] = t["calls"].repeat(tile)
+            t["ref_base"] = t["ref_base"].repeat(tile)
+        self.t = t
+        self.n_loci = hb.n_loci * tile
+        self.n_calls = len(hb.calls) * tile
+        self.ploidy = None
+        if hb.ploidy is not None:
+            self.ploidy = _t(hb.ploidy, device).repeat(tile)
+        self.de = torch.empty(self.n_calls, dtype=torch.float32, device=device)
+        if de is not None:
+            self.de.copy_(_t(de, device).repeat(tile))
+        self.scratch = None
+        self.digt_out = None
+        self.som_out = None
+
+    def struct(self, with_de=True):
+        t = self.t
+        return capi.PileupBatch(self.n_loci, t["call_off"].data_ptr(), t["calls"].data_ptr(),
+                                self.de.data_ptr() if with_de else None, t["ref_base"].data_ptr(),
+                                None if self.ploidy is None else self.ploidy.data_ptr())
+
+    def dependent_eprob(self, opt=None):
+        opt = opt or capi.germline_options()
+        if self.scratch is None:
+            self.scratch = torch.empty(max(self.n_calls, 1), dtype=torch.int32, device=self.device)
+        s = self.struct(with_de=False)
+        capi._check(capi.lib().sk_dependent_eprob_dev(C.byref(s), C.byref(opt), C.c_void_p(self.de.data_ptr()),
+                                                      C.c_void_p(self.scratch.data_ptr()), _stream_ptr()))
+        return self.de
+
+    def site_digt_call(self, opt=None):
+        opt = opt or capi.germline_options()
+        if self.digt_out is None:
+            self.digt_out = torch.empty(self.n_loci * capi.DIGT_CALL_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+        s = self.struct()
+        capi._check(capi.lib().sk_site_digt_call_dev(C.byref(s), C.byref(opt), C.c_void_p(self.digt_out.data_ptr()),
+                                                     _stream_ptr()))
+        return self.digt_out
+
+    def digt_numpy(self):
+        return self.digt_out.cpu().numpy().view(capi.DIGT_CALL_DTYPE)
+
+
+def somatic_snv_call_dev(normal, tumor, opt=None, is_forced_output=False):
+    opt = opt or capi.somatic_snv_options()
+    if normal.som_out is None:
+        normal.som_out = torch.empty(normal.n_loci * capi.SOMATIC_CALL_DTYPE.itemsize, dtype=torch.uint8,
+                                     device=normal.device)
+    sn, st = normal.struct(with_de=False), tumor.struct(with_de=False)
+    capi._check(capi.lib().sk_somatic_snv_call_batch_dev(C.byref(sn), C.byref(st), C.byref(opt), int(is_forced_output),
+                                                         C.c_void_p(normal.som_out.data_ptr()), _stream_ptr()))
+    return normal.som_out

@@ -1,0 +1,318 @@
+// align_flatten.cpp -- host adapter of hot path A: (read, reference segment, CandidateAlignment set) -> sk_align_batch.
+//
+// Mirrors the control flow of scoreCandidateAlignment (L/starling_common/starling_read_align_score.cpp:261-499) but
+// emits scoring ops instead of adding likelihood terms; the arithmetic itself happens in score_alignments.hip.
+// Everything here is integer/byte work and must reproduce the reference's indexing exactly (which reference base or
+// insert base each read base is compared with).
+
+#include "strelka_amd.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace
+{
+
+inline bool is_align_match(const uint32_t t) { return t == SK_SEG_MATCH || t == SK_SEG_SEQ_MATCH || t == SK_SEG_SEQ_MISMATCH; }
+inline bool is_type_indel(const uint32_t t) { return t == SK_SEG_INSERT || t == SK_SEG_DELETE; }
+
+// get_bam_seq_code, L/htsapi/bam_seq.hh:73-92
+inline uint8_t code_of(const char c)
+{
+    switch (c) {
+    case '=': return SK_BAM_REF;
+    case 'A': return SK_BAM_A;
+    case 'C': return SK_BAM_C;
+    case 'G': return SK_BAM_G;
+    case 'T': return SK_BAM_T;
+    default: return SK_BAM_ANY;
+    }
+}
+
+struct Error
+{
+    std::string msg;
+};
+
+} // namespace
+
+struct sk_align_builder
+{
+    std::vector<int64_t> read_off{ 0 }, hap_off{ 0 }, op_off{ 0 };
+    std::vector<int32_t> cal_off{ 0 };
+    std::vector<uint8_t> read_code, read_qual, hap_code;
+    std::vector<sk_score_op> ops;
+    int32_t max_read_len = 0, max_hap_len = 0;
+    std::string error;
+
+    void clear()
+    {
+        read_off.assign(1, 0);
+        hap_off.assign(1, 0);
+        op_off.assign(1, 0);
+        cal_off.assign(1, 0);
+        read_code.clear();
+        read_qual.clear();
+        hap_code.clear();
+        ops.clear();
+        max_read_len = max_hap_len = 0;
+        error.clear();
+    }
+};
+
+namespace
+{
+
+// is_segment_swap_start, L/blt_util/align_path.cpp:868-895
+bool is_segment_swap_start(const sk_path_seg* path, const int n, int i)
+{
+    bool is_insert = false, is_delete = false;
+    for (; i < n; ++i) {
+        if (path[i].type == SK_SEG_INSERT) is_insert = true;
+        else if (path[i].type == SK_SEG_DELETE) is_delete = true;
+        else break;
+    }
+    return is_insert && is_delete;
+}
+
+// getMatchingIndelKey, starling_read_align_score.cpp:177-228
+const sk_indel_key* matching_indel(const sk_candidate_alignment& cal, const int32_t ref_head_pos, const unsigned del_len,
+                                   const unsigned ins_len, const int ends_first, const int ends_second,
+                                   const int path_index)
+{
+    if (path_index < ends_first) return &cal.leading;
+    if (path_index > ends_second) return &cal.trailing;
+    const sk_indel_key* found = nullptr;
+    for (int k = 0; k < cal.n_indels; ++k) {
+        const sk_indel_key& ci = cal.indels[k];
+        if (ci.pos == ref_head_pos && (ci.type == SK_INDEL_INDEL || ci.type == SK_INDEL_MISMATCH) &&
+            ci.del_len == del_len && ci.ins_len == ins_len) {
+            if (found) throw Error{ "candidate alignment holds two indels matching one CIGAR gap" };
+            found = &ci;
+        } else if (ci.pos > ref_head_pos) {
+            break;
+        }
+    }
+    if (!found) throw Error{ "candidate alignment CIGAR gap has no matching indel key" };
+    return found;
+}
+
+struct ReadPool
+{
+    // the read's reference window [win_begin, win_end) followed by insert sequences
+    int32_t win_begin = 0, win_end = 0;
+    std::vector<uint8_t> bytes;
+    struct InsEntry
+    {
+        const char* seq;
+        uint32_t len;
+        int32_t off;
+    };
+    std::vector<InsEntry> ins;
+
+    // offset of insert bases [head, head+len) of `key` (positions outside the sequence read as 'N',
+    // string_bam_seq::get_char, L/htsapi/bam_seq.hh:268-273)
+    int32_t insert_src(const sk_indel_key& key, const int32_t head, const uint32_t len)
+    {
+        if (head >= 0 && uint32_t(head) + len <= key.ins_len) {
+            for (const InsEntry& e : ins)
+                if (e.len == key.ins_len && (e.seq == key.ins_seq || std::memcmp(e.seq, key.ins_seq, e.len) == 0)) return e.off + head;
+            const int32_t off = int32_t(bytes.size());
+            for (uint32_t i = 0; i < key.ins_len; ++i) bytes.push_back(code_of(key.ins_seq[i]));
+            ins.push_back(InsEntry{ key.ins_seq, key.ins_len, off });
+            return off + head;
+        }
+        const int32_t off = int32_t(bytes.size());
+        for (uint32_t i = 0; i < len; ++i) {
+            const int64_t p = int64_t(head) + i;
+            bytes.push_back((p >= 0 && p < int64_t(key.ins_len)) ? code_of(key.ins_seq[p]) : uint8_t(SK_BAM_ANY));
+        }
+        return off;
+    }
+};
+
+void flatten_one(const sk_candidate_alignment& cal, const int32_t read_len, ReadPool& pool, std::vector<sk_score_op>& ops)
+{
+    const sk_path_seg* path = cal.path;
+    const int aps = cal.n_seg;
+    unsigned read_offset = 0;
+    int32_t ref_head_pos = cal.pos;
+
+    int ends_first = aps, ends_second = aps; // get_match_edge_segments, align_path.cpp:735-752
+    {
+        bool is_first_match = false;
+        for (int i = 0; i < aps; ++i)
+            if (is_align_match(path[i].type)) {
+                if (!is_first_match) ends_first = i;
+                is_first_match = true;
+                ends_second = i;
+            }
+    }
+    auto emit = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
+        if (len > 0xffffu) throw Error{ "path segment longer than 65535" };
+        if (kind == SK_OP_NOBASE && !penalty) return;
+        ops.push_back(sk_score_op{ uint16_t(len), kind, uint8_t(penalty ? SK_OPFLAG_NONCANDIDATE_PENALTY : 0), src });
+    };
+
+    int path_index = 0;
+    while (path_index < aps) {
+        const bool is_swap_start = is_segment_swap_start(path, aps, path_index);
+        unsigned n_seg = 1;
+        const sk_path_seg& ps = path[path_index];
+
+        if (is_swap_start || ps.type == SK_SEG_SEQ_MISMATCH) {
+            unsigned del_len, ins_len;
+            if (ps.type == SK_SEG_SEQ_MISMATCH) {
+                del_len = ins_len = ps.length;
+            } else { // swap_info, align_path_util.hh:75-106
+                int k = path_index;
+                del_len = ins_len = 0;
+                for (; k < aps && is_type_indel(path[k].type); ++k) {
+                    if (path[k].type == SK_SEG_INSERT) ins_len += path[k].length;
+                    else del_len += path[k].length;
+                }
+                n_seg = unsigned(k - path_index);
+            }
+            const sk_indel_key* key = matching_indel(cal, ref_head_pos, del_len, ins_len, ends_first, ends_second, path_index);
+            if (key->type == SK_INDEL_NONE) throw Error{ "edge swap without leading/trailing indel key" };
+            int32_t head = 0;
+            if (path_index < ends_first) head = int32_t(key->ins_len) - int32_t(ps.length);
+            const bool pen = !key->is_candidate;
+            if (ins_len > 0) emit(SK_OP_BASES, ins_len, pool.insert_src(*key, head, ins_len), pen);
+            else emit(SK_OP_NOBASE, 0, 0, pen);
+        } else if (is_align_match(ps.type)) {
+            emit(SK_OP_BASES, ps.length, ref_head_pos - pool.win_begin, false);
+        } else if (ps.type == SK_SEG_INSERT) {
+            const sk_indel_key* key = matching_indel(cal, ref_head_pos, 0, ps.length, ends_first, ends_second, path_index);
+            if (key->type == SK_INDEL_NONE) throw Error{ "edge insertion without leading/trailing indel key" };
+            int32_t head = 0;
+            if (path_index < ends_first) head = int32_t(key->ins_len) - int32_t(ps.length);
+            emit(SK_OP_BASES, ps.length, pool.insert_src(*key, head, ps.length), !key->is_candidate);
+        } else if (ps.type == SK_SEG_DELETE) {
+            const sk_indel_key* key = matching_indel(cal, ref_head_pos, ps.length, 0, ends_first, ends_second, path_index);
+            if (key->type == SK_INDEL_NONE) throw Error{ "edge deletion without leading/trailing indel key" };
+            emit(SK_OP_NOBASE, 0, 0, !key->is_candidate);
+        } else if (ps.type == SK_SEG_SKIP || ps.type == SK_SEG_HARD_CLIP) {
+            // nothing
+        } else if (ps.type == SK_SEG_SOFT_CLIP) {
+            emit(SK_OP_SOFT_CLIP, ps.length, 0, false);
+        } else {
+            throw Error{ "Can't handle cigar code" };
+        }
+
+        for (unsigned i = 0; i < n_seg; ++i) { // increment_path, align_path_util.hh:38-68
+            const sk_path_seg& s = path[path_index];
+            if (is_align_match(s.type)) {
+                read_offset += s.length;
+                ref_head_pos += int32_t(s.length);
+            } else if (s.type == SK_SEG_DELETE || s.type == SK_SEG_SKIP) {
+                ref_head_pos += int32_t(s.length);
+            } else if (s.type == SK_SEG_INSERT || s.type == SK_SEG_SOFT_CLIP) {
+                read_offset += s.length;
+            }
+            path_index++;
+        }
+    }
+    if (int64_t(read_offset) != int64_t(read_len)) throw Error{ "candidate alignment path does not span the read" };
+}
+
+} // namespace
+
+extern "C" {
+
+sk_align_builder* sk_align_builder_create(void) { return new sk_align_builder(); }
+void sk_align_builder_destroy(sk_align_builder* b) { delete b; }
+void sk_align_builder_clear(sk_align_builder* b)
+{
+    if (b) b->clear();
+}
+
+// error text of the last failing builder call (the GPU library's sk_last_error covers the device entry points)
+const char* sk_align_builder_error(const sk_align_builder* b) { return b ? b->error.c_str() : "null builder"; }
+
+int sk_align_builder_add_read(sk_align_builder* b, const uint8_t* read_code, const uint8_t* read_qual,
+                              const int32_t read_len, const char* ref_seq, const int32_t ref_offset,
+                              const int32_t ref_len, const sk_candidate_alignment* cals, const int32_t n_cals)
+{
+    if (!b || read_len < 0 || n_cals < 0 || (read_len && (!read_code || !read_qual))) return 1;
+    try {
+        for (int32_t i = 0; i < read_len; ++i)
+            if (read_qual[i] > 70) // qphred_cache::high_qscore_error, L/blt_util/qscore_cache.cpp:66-75
+                throw Error{ "Attempting to lookup basecall quality score " + std::to_string(int(read_qual[i])) +
+                             " which exceeds the maximum cached basecall quality score of 70" };
+        // reference window: union of the reference spans of all match segments of all candidates
+        int32_t wb = INT_MAX, we = INT_MIN;
+        for (int32_t c = 0; c < n_cals; ++c) {
+            int32_t pos = cals[c].pos;
+            for (int i = 0; i < cals[c].n_seg; ++i) {
+                const sk_path_seg& s = cals[c].path[i];
+                if (is_align_match(s.type)) {
+                    wb = std::min(wb, pos);
+                    we = std::max(we, pos + int32_t(s.length));
+                    pos += int32_t(s.length);
+                } else if (s.type == SK_SEG_DELETE || s.type == SK_SEG_SKIP) {
+                    pos += int32_t(s.length);
+                }
+            }
+        }
+        ReadPool pool;
+        if (wb > we) wb = we = 0;
+        pool.win_begin = wb;
+        pool.win_end = we;
+        pool.bytes.resize(size_t(we - wb));
+        for (int32_t p = wb; p < we; ++p) // reference_contig_segment::get_base, :46-51
+            pool.bytes[size_t(p - wb)] = (p < ref_offset || p >= ref_offset + ref_len) ? uint8_t(SK_BAM_ANY) : code_of(ref_seq[p - ref_offset]);
+
+        const size_t ops_mark = b->ops.size(), off_mark = b->op_off.size();
+        try {
+            for (int32_t c = 0; c < n_cals; ++c) {
+                flatten_one(cals[c], read_len, pool, b->ops);
+                b->op_off.push_back(int64_t(b->ops.size()));
+            }
+        } catch (...) {
+            b->ops.resize(ops_mark);
+            b->op_off.resize(off_mark);
+            throw;
+        }
+        b->read_code.insert(b->read_code.end(), read_code, read_code + read_len);
+        b->read_qual.insert(b->read_qual.end(), read_qual, read_qual + read_len);
+        b->read_off.push_back(int64_t(b->read_code.size()));
+        if (pool.bytes.empty()) pool.bytes.push_back(SK_BAM_ANY);
+        b->hap_code.insert(b->hap_code.end(), pool.bytes.begin(), pool.bytes.end());
+        b->hap_off.push_back(int64_t(b->hap_code.size()));
+        b->cal_off.push_back(b->cal_off.back() + n_cals);
+        b->max_read_len = std::max(b->max_read_len, read_len);
+        b->max_hap_len = std::max<int32_t>(b->max_hap_len, int32_t(pool.bytes.size()));
+        return 0;
+    } catch (const Error& e) {
+        b->error = e.msg;
+        return 1;
+    } catch (const std::exception& e) {
+        b->error = e.what();
+        return 1;
+    }
+}
+
+int sk_align_builder_finish(sk_align_builder* b, sk_align_batch* out)
+{
+    if (!b || !out) return 1;
+    out->n_reads = int32_t(b->read_off.size() - 1);
+    out->n_cals = b->cal_off.back();
+    out->n_ops = int64_t(b->ops.size());
+    out->read_off = b->read_off.data();
+    out->read_code = b->read_code.data();
+    out->read_qual = b->read_qual.data();
+    out->hap_off = b->hap_off.data();
+    out->hap_code = b->hap_code.data();
+    out->cal_off = b->cal_off.data();
+    out->op_off = b->op_off.data();
+    out->ops = b->ops.data();
+    out->max_read_len = b->max_read_len;
+    out->max_hap_len = b->max_hap_len;
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,308 @@
+"""Seeded synthetic workloads of SURVEY.md section 8d (inputs A, B, C) for tests and bench.py.
+
+Two flavours of input A:
+  * `align_cases(...)`      reference-shaped (CIGAR paths + indel keys): small, for parity tests through the host adapter
+  * `align_batch_flat(...)` already flattened sk_align_batch arrays, vectorised: bench-scale
+
+No model of the caller lives here -- only input generation.
+"""
+import numpy as np
+
+from . import capi
+
+BAM_CODE = np.array([1, 2, 4, 8], np.uint8)  # A C G T
+BASES = "ACGT"
+QUAL_VALUES = np.array([2, 11, 25, 32, 37, 40], np.uint8)
+QUAL_PROBS = np.array([0.01, 0.04, 0.10, 0.20, 0.35, 0.30])
+
+SEG = dict(NONE=0, MATCH=1, INSERT=2, DELETE=3, SKIP=4, SOFT_CLIP=5, HARD_CLIP=6, PAD=7, SEQ_MATCH=8, SEQ_MISMATCH=9)
+INDEL = dict(NONE=0, INDEL=1, MISMATCH=2, BP_LEFT=3, BP_RIGHT=4)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# input B / C: pileups
+
+def pileups(n_loci, rng, depth_mean=40.0, het_rate=0.00067, hom_rate=0.00033, nmm_rate=0.02, filter_rate=0.0,
+            alt_frac=None, with_n_ref=False):
+    """Germline-style pileup batch: depth ~ Poisson(depth_mean), hom-ref except het/hom-alt loci, strand Bernoulli(.5),
+    quals from QUAL_VALUES, a 0.1 %-per-base sequencing error.  Returns capi.HostPileupBatch (de=None)."""
+    depth = rng.poisson(depth_mean, n_loci).astype(np.int64)
+    off = np.zeros(n_loci + 1, np.int64)
+    np.cumsum(depth, out=off[1:])
+    total = int(off[-1])
+    locus = np.repeat(np.arange(n_loci), depth)
+    ref = rng.integers(0, 4, n_loci).astype(np.uint8)
+    alt = ((ref + rng.integers(1, 4, n_loci)) % 4).astype(np.uint8)
+    u = rng.random(n_loci)
+    if alt_frac is None:
+        frac = np.where(u < het_rate, 0.5, np.where(u < het_rate + hom_rate, 1.0, 0.0))
+    else:
+        frac = np.broadcast_to(np.asarray(alt_frac, float), (n_loci,))
+    base = np.where(rng.random(total) < frac[locus], alt[locus], ref[locus]).astype(np.uint8)
+    q = rng.choice(QUAL_VALUES, total, p=QUAL_PROBS)
+    err = rng.random(total) < np.power(10.0, -q / 10.0)
+    base = np.where(err, (base + rng.integers(1, 4, total)) % 4, base).astype(np.uint8)
+    fwd = rng.integers(0, 2, total)
+    nmm = rng.random(total) < nmm_rate
+    filt = rng.random(total) < filter_rate
+    calls = capi.make_call(q, base, fwd, nmm, filt, 0)
+    if with_n_ref:
+        ref = np.where(rng.random(n_loci) < 0.01, 4, ref).astype(np.uint8)
+    return capi.HostPileupBatch(off, calls, ref)
+
+
+def somatic_pileups(n_loci, rng, normal_depth=40.0, tumor_depth=110.0, somatic_rate=1e-4, het_rate=1e-3,
+                    somatic_frac=0.2):
+    """Normal + tumor pileups sharing ref bases (input C)."""
+    ref = rng.integers(0, 4, n_loci).astype(np.uint8)
+    alt = ((ref + rng.integers(1, 4, n_loci)) % 4).astype(np.uint8)
+    u = rng.random(n_loci)
+    nfrac = np.where(u < het_rate, 0.5, 0.0)
+    tfrac = np.where(u < het_rate, 0.5, np.where(u < het_rate + somatic_rate, somatic_frac, 0.0))
+
+    def one(depth_mean, frac):
+        depth = rng.poisson(depth_mean, n_loci).astype(np.int64)
+        off = np.zeros(n_loci + 1, np.int64)
+        np.cumsum(depth, out=off[1:])
+        total = int(off[-1])
+        locus = np.repeat(np.arange(n_loci), depth)
+        base = np.where(rng.random(total) < frac[locus], alt[locus], ref[locus]).astype(np.uint8)
+        q = rng.choice(QUAL_VALUES, total, p=QUAL_PROBS)
+        err = rng.random(total) < np.power(10.0, -q / 10.0)
+        base = np.where(err, (base + rng.integers(1, 4, total)) % 4, base).astype(np.uint8)
+        calls = capi.make_call(q, base, rng.integers(0, 2, total), 0, 0, 0)
+        return capi.HostPileupBatch(off, calls, ref)
+
+    return one(normal_depth, nfrac), one(tumor_depth, tfrac)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# input A, flattened and vectorised (bench scale)
+
+def align_batch_flat(n_reads, rng, H=64, L=150, K=6, win=400, noncand_rate=0.1):
+    """R reads x H=2^K candidate alignments: every subset of K candidate indels (1-10 bp deletions / insertions with
+    random insert sequence) toggled on a start-pinned alignment of an L-bp read against a `win`-bp reference window.
+    Returns a capi.HostAlignBatch with exactly H candidates per read."""
+    assert H == (1 << K)
+    ref = BAM_CODE[rng.integers(0, 4, (n_reads, win))]
+    start = rng.integers(20, 60, n_reads)
+    # K indels, sorted ascending, >= 12 apart, inside the first ~110 bases of the read span
+    gaps = rng.integers(12, 18, (n_reads, K))
+    ipos = start[:, None] + 8 + np.cumsum(gaps, axis=1)            # reference position (window coords) of indel k
+    is_ins = rng.random((n_reads, K)) < 0.5
+    ilen = rng.integers(1, 11, (n_reads, K))
+    is_cand = rng.random((n_reads, K)) >= noncand_rate
+    ins_seq = BAM_CODE[rng.integers(0, 4, (n_reads, K, 10))]        # pool slot k of read r: 10 bytes
+    pool_len = win + K * 10
+    hap = np.concatenate([ref, ins_seq.reshape(n_reads, K * 10)], axis=1)
+
+    # the read: sampled along the window from `start` with substitution errors at rate 10^(-q/10)
+    qual = rng.choice(QUAL_VALUES, (n_reads, L), p=QUAL_PROBS)
+    idx = start[:, None] + np.arange(L)[None, :]
+    read = np.take_along_axis(ref, idx, axis=1)
+    err = rng.random((n_reads, L)) < np.power(10.0, -qual / 10.0)
+    sub = BAM_CODE[rng.integers(0, 4, (n_reads, L))]
+    read = np.where(err, sub, read).astype(np.uint8)
+    read = np.where(rng.random((n_reads, L)) < 0.002, 15, read).astype(np.uint8)  # a few N base calls
+
+    MAXOPS = 3 * K + 1
+    ops = np.zeros((n_reads, H, MAXOPS), capi.SCORE_OP_DTYPE)
+    nops = np.zeros((n_reads, H), np.int64)
+    rows = np.arange(n_reads)
+
+    def push(h, mask, length, kind, flags, src):
+        slot = nops[:, h]
+        sel = mask & (slot < MAXOPS)
+        r = rows[sel]
+        s = slot[sel]
+        ops["length"][r, h, s] = length[sel] if np.ndim(length) else length
+        ops["kind"][r, h, s] = kind
+        ops["flags"][r, h, s] = flags[sel] if np.ndim(flags) else flags
+        ops["src"][r, h, s] = src[sel] if np.ndim(src) else src
+        nops[:, h] += sel
+
+    for h in range(H):
+        ref_pos = start.copy()
+        read_pos = np.zeros(n_reads, np.int64)
+        for k in range(K):
+            if not (h >> k) & 1:
+                continue
+            p = ipos[:, k]
+            mlen = p - ref_pos
+            # the indel is used when it lies ahead on the reference and strictly inside the read
+            use = (mlen >= 0) & (read_pos + mlen < L) & (read_pos + mlen > 0)
+            push(h, use & (mlen > 0), mlen, capi.OP_BASES, 0, ref_pos)
+            read_pos = np.where(use, read_pos + mlen, read_pos)
+            ref_pos = np.where(use, p, ref_pos)
+            pen = np.where(is_cand[:, k], 0, capi.OPFLAG_PENALTY).astype(np.uint8)
+            ins = use & is_ins[:, k]
+            il = np.minimum(ilen[:, k], L - read_pos)
+            push(h, ins, il, capi.OP_BASES, pen, np.full(n_reads, win + 10 * k))
+            read_pos = np.where(ins, read_pos + il, read_pos)
+            dele = use & ~is_ins[:, k]
+            push(h, dele & (pen > 0), np.zeros(n_reads, np.int64), capi.OP_NOBASE, pen, np.zeros(n_reads, np.int64))
+            ref_pos = np.where(dele, ref_pos + ilen[:, k], ref_pos)
+        rest = L - read_pos
+        push(h, rest > 0, rest, capi.OP_BASES, 0, ref_pos)
+
+    keep = np.arange(MAXOPS)[None, None, :] < nops[:, :, None]
+    flat_ops = ops[keep]
+    op_off = np.zeros(n_reads * H + 1, np.int64)
+    np.cumsum(nops.reshape(-1), out=op_off[1:])
+    read_off = np.arange(n_reads + 1, dtype=np.int64) * L
+    hap_off = np.arange(n_reads + 1, dtype=np.int64) * pool_len
+    cal_off = (np.arange(n_reads + 1, dtype=np.int64) * H).astype(np.int32)
+    return capi.HostAlignBatch(read_off, read.reshape(-1), qual.reshape(-1).astype(np.uint8), hap_off, hap.reshape(-1),
+                               cal_off, op_off, flat_ops, L, pool_len)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# input A, reference-shaped (parity tests through the host adapter)
+
+def _path_from_indels(start_pos, read_len, indels, lead_clip=0, trail_clip=0):
+    """Start-pinned CIGAR of a read against the reference with `indels` (sorted dicts pos,del_len,ins_seq) applied.
+    Returns (path, used_indels)."""
+    path = []
+    used = []
+    if lead_clip:
+        path.append((SEG["SOFT_CLIP"], lead_clip))
+    ref_pos = start_pos
+    remaining = read_len - lead_clip - trail_clip
+    for ind in indels:
+        if remaining <= 0:
+            break
+        mlen = ind["pos"] - ref_pos
+        if mlen <= 0 or mlen >= remaining:
+            continue
+        path.append((SEG["MATCH"], mlen))
+        remaining -= mlen
+        ref_pos = ind["pos"]
+        ins = len(ind.get("ins_seq", ""))
+        dele = ind.get("del_len", 0)
+        if ins >= remaining:
+            # would run off the read: stop before it
+            path.pop()
+            remaining += mlen
+            ref_pos -= mlen
+            break
+        if dele:
+            path.append((SEG["DELETE"], dele))
+            ref_pos += dele
+        if ins:
+            path.append((SEG["INSERT"], ins))
+            remaining -= ins
+        used.append(ind)
+    if remaining > 0:
+        path.append((SEG["MATCH"], remaining))
+    if trail_clip:
+        path.append((SEG["SOFT_CLIP"], trail_clip))
+    return path, used
+
+
+def align_cases(n_reads, rng, L=150, K=4, win=400, ref_offset=1000, max_cals=16):
+    """List of dicts(read_code, read_qual, ref_seq, ref_offset, cals) with reference-shaped candidate alignments,
+    including soft clips, swaps (deletion+insertion at one position), leading/trailing edge insertions,
+    non-candidate indels, 'N' and '=' read bases and Q0/Q70 qualities."""
+    out = []
+    for r in range(n_reads):
+        ref_seq = "".join(BASES[i] for i in rng.integers(0, 4, win))
+        if rng.random() < 0.2:  # some N in the reference
+            j = int(rng.integers(0, win))
+            ref_seq = ref_seq[:j] + "N" + ref_seq[j + 1:]
+        Lr = int(L if rng.random() < 0.7 else rng.integers(30, 2 * L))
+        start = int(rng.integers(20, 60))
+        # candidate indels
+        indels = []
+        p = start + int(rng.integers(5, 20))
+        for k in range(K):
+            kind = rng.random()
+            ind = dict(pos=ref_offset + p, type=INDEL["INDEL"], del_len=0, ins_seq="", is_candidate=int(rng.random() > 0.15))
+            if kind < 0.4:
+                ind["del_len"] = int(rng.integers(1, 11))
+            elif kind < 0.8:
+                ind["ins_seq"] = "".join(BASES[i] for i in rng.integers(0, 4, int(rng.integers(1, 11))))
+            else:  # swap
+                ind["del_len"] = int(rng.integers(1, 6))
+                ind["ins_seq"] = "".join(BASES[i] for i in rng.integers(0, 4, int(rng.integers(1, 6))))
+            indels.append(ind)
+            p += ind["del_len"] + int(rng.integers(3, 25))
+        q = rng.choice(np.array([0, 2, 11, 25, 32, 37, 40, 70], np.uint8), Lr,
+                       p=[0.01, 0.01, 0.04, 0.10, 0.20, 0.34, 0.29, 0.01])
+        span = (ref_seq * 3)[start:start + Lr]
+        read = np.array([BAM_CODE[BASES.index(c)] if c in BASES else 15 for c in span], np.uint8)
+        err = rng.random(Lr) < 0.02
+        read = np.where(err, BAM_CODE[rng.integers(0, 4, Lr)], read).astype(np.uint8)
+        read = np.where(rng.random(Lr) < 0.01, 15, read).astype(np.uint8)
+        read = np.where(rng.random(Lr) < 0.01, 0, read).astype(np.uint8)
+
+        cals = []
+        n_sub = min(1 << K, max_cals)
+        masks = rng.permutation(1 << K)[:n_sub]
+        for m in masks:
+            subset = [indels[k] for k in range(K) if (int(m) >> k) & 1]
+            lead = int(rng.integers(1, 8)) if rng.random() < 0.15 else 0
+            trail = int(rng.integers(1, 8)) if rng.random() < 0.15 else 0
+            if lead + trail >= Lr - 2:
+                lead = trail = 0
+            path, used = _path_from_indels(ref_offset + start, Lr, subset, lead, trail)
+            cal = dict(pos=ref_offset + start, path=path, indels=used, leading=None, trailing=None)
+            u = rng.random()
+            if u < 0.12 and lead == 0 and path and path[0][0] == SEG["MATCH"] and path[0][1] > 12:
+                # leading edge insertion: the read starts inside an insertion; only its last n bases are read
+                n = int(rng.integers(1, 6))
+                full = "".join(BASES[i] for i in rng.integers(0, 4, n + int(rng.integers(0, 4))))
+                path[0] = (SEG["MATCH"], path[0][1] - n)
+                path.insert(0, (SEG["INSERT"], n))
+                cal["pos"] += n  # the first aligned base moves right by the bases now read from the insertion
+                cal["leading"] = dict(pos=ref_offset + start, type=INDEL["INDEL"], del_len=0, ins_seq=full,
+                                      is_candidate=int(rng.random() > 0.3))
+            elif u < 0.24 and trail == 0 and path and path[-1][0] == SEG["MATCH"] and path[-1][1] > 12:
+                n = int(rng.integers(1, 6))
+                full = "".join(BASES[i] for i in rng.integers(0, 4, n + int(rng.integers(0, 4))))
+                path[-1] = (SEG["MATCH"], path[-1][1] - n)
+                path.append((SEG["INSERT"], n))
+                ref_end = cal["pos"] + sum(l for t, l in path if t in (SEG["MATCH"], SEG["DELETE"]))
+                cal["trailing"] = dict(pos=ref_end, type=INDEL["INDEL"], del_len=0, ins_seq=full,
+                                       is_candidate=int(rng.random() > 0.3))
+            elif u < 0.30 and path and path[0][0] == SEG["MATCH"]:
+                path.insert(0, (SEG["HARD_CLIP"], int(rng.integers(1, 30))))
+            cals.append(cal)
+        out.append(dict(read_code=read, read_qual=q.astype(np.uint8), ref_seq=ref_seq, ref_offset=ref_offset, cals=cals))
+    return out
+
+
+def build_align_batch(cases):
+    b = capi.AlignBuilder()
+    for c in cases:
+        b.add_read(c["read_code"], c["read_qual"], c["ref_seq"], c["ref_offset"], c["cals"])
+    return b.finish()
+
+
+def align_cases_h64(n_reads, rng, L=150, K=6, win=400, ref_offset=0, noncand_rate=0.1):
+    """Reference-shaped twin of align_batch_flat: every subset of K=6 candidate indels, start-pinned, 64 candidates."""
+    out = []
+    for r in range(n_reads):
+        ref_seq = "".join(BASES[i] for i in rng.integers(0, 4, win))
+        start = int(rng.integers(20, 60))
+        indels = []
+        p = start + 8
+        for k in range(K):
+            p += int(rng.integers(12, 18))
+            ind = dict(pos=ref_offset + p, type=INDEL["INDEL"], del_len=0, ins_seq="",
+                       is_candidate=int(rng.random() >= noncand_rate))
+            if rng.random() < 0.5:
+                ind["ins_seq"] = "".join(BASES[i] for i in rng.integers(0, 4, int(rng.integers(1, 11))))
+            else:
+                ind["del_len"] = int(rng.integers(1, 11))
+            indels.append(ind)
+        q = rng.choice(QUAL_VALUES, L, p=QUAL_PROBS)
+        read = np.array([BAM_CODE[BASES.index(c)] for c in ref_seq[start:start + L]], np.uint8)
+        err = rng.random(L) < np.power(10.0, -q / 10.0)
+        read = np.where(err, BAM_CODE[rng.integers(0, 4, L)], read).astype(np.uint8)
+        cals = []
+        for m in range(1 << K):
+            subset = [indels[k] for k in range(K) if (m >> k) & 1]
+            path, used = _path_from_indels(ref_offset + start, L, subset)
+            cals.append(dict(pos=ref_offset + start, path=path, indels=used, leading=None, trailing=None))
+        out.append(dict(read_code=read, read_qual=q.astype(np.uint8), ref_seq=ref_seq, ref_offset=ref_offset, cals=cals))
+    return out

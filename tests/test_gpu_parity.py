@@ -1,0 +1,208 @@
+"""GPU suite (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star):
+  * hot path A scores: BIT-EXACT doubles (every term comes from host-built tables; adds are sequential, no FMA)
+  * somatic grid likelihoods (table-driven float32 sums): BIT-EXACT
+  * integer outputs (max genotype, Q-scores, PLs): exact, except where a float transcendental evaluated on the device
+    (logf/powf/expf of a non-table argument) feeds them -- there the log-likelihoods must agree to 1e-5 (relative to
+    max(1,|x|): float32 log-likelihoods of magnitude ~400 have an ulp of 3e-5, so an absolute 1e-5 would be tighter than
+    the reference's own number format) and the integer outputs may differ only where a value sits on a rounding boundary
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from strelka_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LL_TOL = 1e-5
+
+
+def close_ll(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    both_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    scale = np.maximum(1.0, np.abs(b))
+    with np.errstate(invalid="ignore"):
+        ok = np.abs(a - b) <= LL_TOL * scale
+    return bool(np.all(ok | both_inf))
+
+
+# ---------------------------------------------------------------------------------------------------------- hot path A
+
+def test_scores_bit_exact_random_cases(gpu):
+    rng = np.random.default_rng(101)
+    cases = synth.align_cases(300, rng)
+    got = gpu.score_alignments(synth.build_align_batch(cases))
+    want = pyoracle.score_cases(cases)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_scores_bit_exact_h64_workload(gpu):
+    rng = np.random.default_rng(102)
+    cases = synth.align_cases_h64(200, rng)
+    got = gpu.score_alignments(synth.build_align_batch(cases))
+    want = pyoracle.score_cases(cases)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_more_than_64_candidates_and_long_reads(gpu):
+    rng = np.random.default_rng(103)
+    cases = synth.align_cases(6, rng, L=150, K=7, max_cals=128)          # > one wave of candidates per read
+    cases += synth.align_cases(4, rng, L=2000, K=6, win=5000, max_cals=20)  # too long for the LDS kernel -> generic
+    got = gpu.score_alignments(synth.build_align_batch(cases))
+    want = pyoracle.score_cases(cases)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_fast_and_generic_kernels_agree_at_scale(gpu):
+    """Size-independent property at bench scale: the LDS wave-per-read kernel and the thread-per-candidate kernel are two
+    independent implementations; their outputs over 2^21 pairs must be identical bit for bit, and tiling a batch must
+    reproduce the untiled scores."""
+    import torch
+    from strelka_amd import device
+    rng = np.random.default_rng(104)
+    hb = synth.align_batch_flat(1 << 13, rng)
+    d1 = device.DeviceAlignBatch(hb, "cuda:0", tile=4)
+    fast = d1.score().clone()
+    gen = d1.score(generic=True).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(fast.view(torch.int64), gen.view(torch.int64))
+    n = hb.n_cals
+    assert torch.equal(fast[:n].view(torch.int64), fast[3 * n:].view(torch.int64))
+    small = gpu.score_alignments(hb)
+    assert np.array_equal(small.view(np.uint64), fast[:n].cpu().numpy().view(np.uint64))
+
+
+def test_flat_workload_matches_interpreter(gpu):
+    from tests.flat_interp import score_flat
+    rng = np.random.default_rng(105)
+    hb = synth.align_batch_flat(64, rng)
+    _, lnc, lne = gpu.qscore_tables()
+    want = score_flat(hb, lnc, lne)
+    got = gpu.score_alignments(hb)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_empty_batches(gpu):
+    from strelka_amd import capi
+    b = capi.AlignBuilder()
+    assert len(gpu.score_alignments(b.finish())) == 0
+    b.add_read(np.zeros(0, np.uint8), np.zeros(0, np.uint8), "ACGT", 0, [])
+    assert len(gpu.score_alignments(b.finish())) == 0
+
+
+def test_invalid_quality_rejected(gpu):
+    from strelka_amd import capi
+    hb = synth.align_batch_flat(4, np.random.default_rng(1))
+    hb.read_qual[3] = 71
+    with pytest.raises(capi.StrelkaAmdError):
+        gpu.score_alignments(hb)
+
+
+# ---------------------------------------------------------------------------------------------------------- hot path B
+
+def _varied_pileups(rng, n=4000):
+    parts = [synth.pileups(n, rng, het_rate=0.05, hom_rate=0.03, filter_rate=0.03),
+             synth.pileups(n // 4, rng, depth_mean=3.0, het_rate=0.2),
+             synth.pileups(n // 8, rng, depth_mean=400.0, het_rate=0.1, nmm_rate=0.2),
+             synth.pileups(50, rng, depth_mean=0.2)]
+    off = [np.zeros(1, np.int64)]
+    calls, ref = [], []
+    base = 0
+    for p in parts:
+        off.append(p.call_off[1:] + base)
+        base += p.call_off[-1]
+        calls.append(p.calls)
+        ref.append(p.ref_base)
+    from strelka_amd import capi
+    return capi.HostPileupBatch(np.concatenate(off), np.concatenate(calls), np.concatenate(ref))
+
+
+def test_dependent_eprob(gpu):
+    rng = np.random.default_rng(201)
+    pb = _varied_pileups(rng)
+    got = gpu.dependent_eprob(pb)
+    want = pyoracle.adjust_joint_eprob(pb)
+    # the sort emulation fixes WHICH call gets which exponent: any mis-assignment shows up as a gross difference
+    assert np.allclose(got, want, rtol=2e-6, atol=0)
+    # entries that never pass through powf (first of each group, filtered calls, floor-cached ones) are bit-exact
+    exact = np.mean(got == want)
+    assert exact > 0.5
+
+
+def test_site_digt_call(gpu):
+    rng = np.random.default_rng(202)
+    pb = _varied_pileups(rng)
+    pb.de = pyoracle.adjust_joint_eprob(pb)
+    pb.ploidy = rng.choice(np.array([1, 2, 2, 2], np.uint8), pb.n_loci)
+    pb.ref_base[::97] = 4  # some 'N' reference bases
+    got = gpu.site_digt_call(pb)
+    want = pyoracle.site_digt_call(pb, pb.de)
+    assert np.array_equal(got["is_called"], want["is_called"])
+    assert np.array_equal(got["ref_gt"], want["ref_gt"])
+    assert close_ll(got["lhood"], want["lhood"])
+    assert close_ll(got["strand_bias"], want["strand_bias"])
+    for rs in ("genome", "poly"):
+        assert np.mean(got[rs]["max_gt"] == want[rs]["max_gt"]) > 0.9999
+        assert np.abs(got[rs]["snp_qphred"] - want[rs]["snp_qphred"]).max() <= 1
+        assert np.mean(got[rs]["snp_qphred"] == want[rs]["snp_qphred"]) > 0.999
+        assert np.abs(got[rs]["max_gt_qphred"] - want[rs]["max_gt_qphred"]).max() <= 1
+        assert np.allclose(got[rs]["ref_pprob"], want[rs]["ref_pprob"], rtol=1e-4, atol=1e-300)
+    pl_diff = np.abs(got["phredLoghood"].astype(np.int64) - want["phredLoghood"].astype(np.int64))
+    assert pl_diff.max() <= 1 and np.mean(pl_diff == 0) > 0.999
+
+
+def test_site_digt_call_exact_when_de_is_tabulated(gpu):
+    """With de[i] = 0.5 (logf exact-ish input shared by both sides is not enough) -- use de values whose logf is the same
+    on both sides: powers of two.  Then every term is table- or exactly-computed and the float32 sums must be bit-exact."""
+    rng = np.random.default_rng(203)
+    pb = synth.pileups(3000, rng, het_rate=0.1, hom_rate=0.05)
+    pb.de = np.full(len(pb.calls), 0.25, np.float32)
+    got = gpu.site_digt_call(pb)
+    want = pyoracle.site_digt_call(pb, pb.de)
+    same = np.array_equal(got["lhood"].view(np.uint32), want["lhood"].view(np.uint32))
+    if not same:  # logf(0.25) may still differ by an ulp between libm and the device; then only closeness is required
+        assert close_ll(got["lhood"], want["lhood"])
+    else:
+        assert np.array_equal(got["phredLoghood"], want["phredLoghood"])
+
+
+def test_somatic_snv(gpu):
+    rng = np.random.default_rng(204)
+    n, t = synth.somatic_pileups(6000, rng, somatic_rate=0.03, het_rate=0.03)
+    for forced in (False, True):
+        got = gpu.somatic_snv_call(n, t, is_forced_output=forced)
+        want = pyoracle.somatic_snv_call(n, t, is_forced_output=forced)
+        assert np.array_equal(got["is_called"], want["is_called"])
+        # table-driven float sums: bit exact (21 prestrand states of both samples)
+        assert np.array_equal(got["normal_lhood"][:, :21].view(np.uint32), want["normal_lhood"][:, :21].view(np.uint32))
+        assert np.array_equal(got["tumor_lhood"][:, :21].view(np.uint32), want["tumor_lhood"][:, :21].view(np.uint32))
+        # 9 strand states end in a float logsum evaluated on the device
+        assert close_ll(got["tumor_lhood"][:, 21:], want["tumor_lhood"][:, 21:])
+        assert np.array_equal(got["normal_alt_id"], want["normal_alt_id"])
+        assert np.array_equal(got["tumor_alt_id"], want["tumor_alt_id"])
+        assert np.array_equal(got["max_gt"], want["max_gt"])
+        assert np.array_equal(got["ntype"], want["ntype"])
+        assert np.abs(got["qphred"] - want["qphred"]).max() <= 1
+        assert np.mean(got["qphred"] == want["qphred"]) > 0.999
+        assert np.abs(got["from_ntype_qphred"] - want["from_ntype_qphred"]).max() <= 1
+        assert close_ll(got["strand_bias"], want["strand_bias"])
+
+
+def test_pileup_edge_cases(gpu):
+    from strelka_amd import capi
+    # empty loci, single-call loci, all-filtered loci, N reference
+    calls = capi.make_call([30, 40, 2, 63, 20], [0, 1, 2, 3, 0], [1, 0, 1, 0, 1], 0, [0, 0, 0, 0, 1], 0)
+    off = np.array([0, 0, 1, 3, 5, 5], np.int64)
+    pb = capi.HostPileupBatch(off, calls, np.array([0, 0, 1, 4, 2], np.uint8))
+    de = gpu.dependent_eprob(pb)
+    want_de = pyoracle.adjust_joint_eprob(pb)
+    assert np.allclose(de, want_de, rtol=2e-6)
+    pb.de = want_de
+    got = gpu.site_digt_call(pb)
+    want = pyoracle.site_digt_call(pb, want_de)
+    assert np.array_equal(got["is_called"], want["is_called"])
+    assert close_ll(got["lhood"], want["lhood"])
+    assert np.array_equal(got["genome"]["max_gt"], want["genome"]["max_gt"])
