@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--unique-loci", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
-    ap.add_argument("--cpu-loci", type=int, default=150000, help="loci in the CPU-baseline sample")
+    ap.add_argument("--cpu-loci", type=int, default=2000000, help="loci in the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time spent on the alignment-scoring sample")
     return ap.parse_args()
 
 
@@ -61,18 +62,21 @@ def cpu_baseline(args):
     m = pyoracle.MarshalledCases(cases)
     pyoracle.score_cases(m)  # warm
     t0 = time.perf_counter()
-    pyoracle.score_cases(m)
+    reps = 0
+    while time.perf_counter() - t0 < args.cpu_seconds:  # repeated passes over the (cache-resident) sample
+        pyoracle.score_cases(m)
+        reps += 1
     ta = time.perf_counter() - t0
-    cells = sum(len(c["read_code"]) * len(c["cals"]) for c in cases)
+    cells = reps * sum(len(c["read_code"]) * len(c["cals"]) for c in cases)
     pb = synth.pileups(args.cpu_loci, rng)
     t0 = time.perf_counter()
     de = pyoracle.adjust_joint_eprob(pb)
     pyoracle.site_digt_call(pb, de)
     tb = time.perf_counter() - t0
     return {"value": cells / ta, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "%d reads x 64 candidate alignments x 150 bp through sko_score_cases (%.1f s); loci: %d loci "
+            "sample": "%d reads x 64 candidate alignments x 150 bp, %d passes through sko_score_cases (%.1f s); loci: %d loci "
                       "depth~Poisson(40) through sko_adjust_joint_eprob+sko_position_snp_call_pprob_digt (%.1f s)"
-                      % (len(cases), ta, args.cpu_loci, tb),
+                      % (len(cases), reps, ta, args.cpu_loci, tb),
             "loci_per_s": args.cpu_loci / tb}
 
 

@@ -90,6 +90,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("strelka_amd: %s is missing -- run `python -m strelka_amd.build` (there is no CPU fallback)"
                                % LIB_PATH)
+        try:
+            # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same soname as /opt/rocm's).  When
+            # torch is going to be used in this process (bench.py, device.py) it must be loaded FIRST so that this
+            # library binds to the runtime torch initialises; loading /opt/rocm's copy first leaves torch without GPUs.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.sk_last_error.restype = C.c_char_p
         L.sk_align_builder_create.restype = c_void_p

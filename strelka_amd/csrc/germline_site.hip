@@ -51,6 +51,10 @@ __device__ __forceinline__ int ln_error_prob_to_qphred_f(const float lnProb, con
     return static_cast<int>(floor(__dadd_rn(static_cast<double>(phred), 0.5)));
 }
 
+// glibc's logf computes in double and rounds once; so does this (agrees except when the double result sits within
+// its own error of a float rounding boundary)
+__device__ __forceinline__ float logf_via_double(const float x) { return static_cast<float>(log(static_cast<double>(x))); }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // libstdc++ std::sort on an index array with comp(a,b) = q[a] > q[b]   (adjust_joint_eprob.cpp:41-53,145)
 // (GCC bits/stl_algo.h __introsort_loop/__final_insertion_sort, threshold 16; bits/stl_heap.h for the depth fallback)
@@ -206,7 +210,7 @@ __device__ void std_sort_emulated(uint32_t* idx, const int n, const SortKey& key
 __device__ __forceinline__ float get_dependent_eprob(const float eprob, const float vexp)
 {
     const float dep_converge_prob = 0.75f;
-    const float val = powf(eprob, vexp);
+    const float val = static_cast<float>(pow(static_cast<double>(eprob), static_cast<double>(vexp))); // glibc powf is evaluated in double and rounded once
     const float frac = __fdiv_rn(__fsub_rn(1.f, val), __fsub_rn(1.f, eprob));
     const float dep = __fadd_rn(__fmul_rn(frac, val), __fmul_rn(__fsub_rn(1.f, frac), dep_converge_prob));
     return (eprob < dep) ? dep : eprob;
@@ -383,7 +387,7 @@ __global__ void site_digt_call_kernel(const SiteArgs a)
     for (int i = 0; i < n; ++i) {
         const uint16_t bc = calls[i];
         const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
-        const float v0 = __fadd_rn(logf(de[i]), log_one_third); // val[0] (:352)
+        const float v0 = __fadd_rn(logf_via_double(de[i]), log_one_third); // val[0] (:352)
         const float v1 = T->g_v1[q];                             // val[1] (:353)
         const float v2 = T->g_v2[q];                             // val[2] (:354)
 #pragma unroll
@@ -415,7 +419,7 @@ __global__ void site_digt_call_kernel(const SiteArgs a)
         for (int i = 0; i < n; ++i) {
             const uint16_t bc = calls[i];
             const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
-            const float v0 = __fadd_rn(logf(de[i]), log_one_third);
+            const float v0 = __fadd_rn(logf_via_double(de[i]), log_one_third);
             const float v1 = T->g_v1[q];
             const float v2 = T->g_v2[q];
             const float val_ref = (obs == ref) ? v2 : v0; // expect2(obs, ref_gt): ref_gt is homozygous

@@ -33,42 +33,53 @@ namespace
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int WAVE = 64;
+constexpr int OPS_CAP = 512;   // scoring ops staged in LDS per wave per pass of 64 candidates
+constexpr int ROW_BYTES = 48;  // per read position: {A, C, G, T, other, 0.0} doubles
+constexpr int ZERO_COL = 40;   // byte offset of the 0.0 column
 
 __device__ __forceinline__ double dadd(double a, double b) { return __dadd_rn(a, b); }
+
+// BAM 4-bit code of a haplotype base -> byte offset of its column in a table row
+__device__ __forceinline__ unsigned hap_col_offset(const unsigned code)
+{
+    return code == SK_BAM_A ? 0u : code == SK_BAM_C ? 8u : code == SK_BAM_G ? 16u : code == SK_BAM_T ? 24u : 32u;
+}
 
 struct ScoreArgs
 {
     sk_align_batch b;
     const SkTables* tab;
     double* out;
-    int lds_mx_doubles; // per wave: 3 * maxL doubles
-    int lds_rc_bytes;   // per wave: align16(maxL)
-    int lds_hap_bytes;  // per wave: align16(max(maxPool, maxL))
+    int lds_tab_bytes; // per wave: ROW_BYTES * maxL
+    int lds_hap_bytes; // per wave: align16(max(maxPool, maxL))
 };
 
+// Kernel A1.  LDS slab per wave: [table rows][hap column offsets][staged ops]
 __global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(const ScoreArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x / WAVE;
-    const size_t per_wave = size_t(a.lds_mx_doubles) * 8 + a.lds_rc_bytes + a.lds_hap_bytes;
+    const size_t per_wave = size_t(a.lds_tab_bytes) + a.lds_hap_bytes + OPS_CAP * sizeof(sk_score_op);
     unsigned char* slab = smem + per_wave * wave;
-    double* mx = reinterpret_cast<double*>(slab);
-    unsigned char* rcl = slab + size_t(a.lds_mx_doubles) * 8;
-    unsigned char* hap = rcl + a.lds_rc_bytes;
+    unsigned char* tabb = slab;
+    unsigned char* hap = slab + a.lds_tab_bytes;
+    sk_score_op* lops = reinterpret_cast<sk_score_op*>(hap + a.lds_hap_bytes);
 
     const int r = blockIdx.x * WAVES_PER_BLOCK + wave;
-    const bool live = (r < a.b.n_reads);
+    if (r >= a.b.n_reads) return; // whole wave; waves never synchronise with each other
 
-    int L = 0, P = 0, cal_begin = 0, cal_end = 0;
-    if (live) {
-        const int64_t ro = a.b.read_off[r];
-        L = int(a.b.read_off[r + 1] - ro);
-        const int64_t ho = a.b.hap_off[r];
-        P = int(a.b.hap_off[r + 1] - ho);
-        cal_begin = a.b.cal_off[r];
-        cal_end = a.b.cal_off[r + 1];
+    const int64_t ro = a.b.read_off[r];
+    const int L = int(a.b.read_off[r + 1] - ro);
+    const int64_t ho = a.b.hap_off[r];
+    const int P = int(a.b.hap_off[r + 1] - ho);
+    const int cal_begin = a.b.cal_off[r], cal_end = a.b.cal_off[r + 1];
+    {
+        // per-position table: row[col] = the term added when the haplotype base of that column faces read base i
+        //   'N' read base -> 0.0 everywhere (the reference `continue`s, :125/:158)
+        //   '=' read base -> M everywhere   (always a match, :127/:160)
         const SkTables* __restrict__ T = a.tab;
+        double* tab = reinterpret_cast<double*>(tabb);
         for (int j = lane; j < L; j += WAVE) {
             const unsigned rc = a.b.read_code[ro + j];
             unsigned q = a.b.read_qual[ro + j];
@@ -76,56 +87,85 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(con
             const bool any = (rc == SK_BAM_ANY);
             const double M = any ? 0.0 : T->q2lncompe[q];
             const double X = any ? 0.0 : (rc == SK_BAM_REF ? M : T->q2mis[q]);
-            mx[3 * j + 0] = M;
-            mx[3 * j + 1] = X;
-            mx[3 * j + 2] = 0.0;
-            rcl[j] = (unsigned char)rc;
+            double* row = tab + 6 * j;
+            row[0] = (rc == SK_BAM_A) ? M : X;
+            row[1] = (rc == SK_BAM_C) ? M : X;
+            row[2] = (rc == SK_BAM_G) ? M : X;
+            row[3] = (rc == SK_BAM_T) ? M : X;
+            row[4] = X; // haplotype 'N'/other never equals a non-N read code
+            row[5] = 0.0;
         }
-        for (int j = lane; j < P; j += WAVE) hap[j] = a.b.hap_code[ho + j];
+        for (int j = lane; j < P; j += WAVE) hap[j] = (unsigned char)hap_col_offset(a.b.hap_code[ho + j]);
+        for (int j = P + lane; j < a.lds_hap_bytes; j += WAVE) hap[j] = 32;
     }
-    __syncthreads();
-    if (!live) return;
 
     const double ln_quarter = a.tab->ln_quarter;
     const double ln_noncand = a.tab->ln_noncand;
+    const sk_score_op* __restrict__ gops = a.b.ops;
 
     for (int cbase = cal_begin; cbase < cal_end; cbase += WAVE) {
         const int c = cbase + lane;
         const bool has_cal = (c < cal_end);
-        const sk_score_op* __restrict__ ops = a.b.ops;
-        int64_t k = 0, kend = 0;
-        if (has_cal) {
-            k = a.b.op_off[c];
-            kend = a.b.op_off[c + 1];
+        const int clast = (cbase + WAVE < cal_end) ? cbase + WAVE : cal_end;
+        const int64_t kbase = a.b.op_off[cbase];
+        const int nstage = int(a.b.op_off[clast] - kbase);
+        const bool in_lds = (nstage <= OPS_CAP);
+        __builtin_amdgcn_wave_barrier();
+        if (in_lds) {
+            // consecutive candidates' ops are contiguous: one coalesced copy for the whole wave
+            const uint2* __restrict__ src = reinterpret_cast<const uint2*>(gops + kbase);
+            uint2* dst = reinterpret_cast<uint2*>(lops);
+            for (int j = lane; j < nstage; j += WAVE) dst[j] = src[j];
         }
-        double lnp = 0.0;
-        int op_end = 0;   // read position at which the current op ends
-        int delta = 0;    // hap index = delta + i while inside a BASES op
-        int selM = 16, selX = 16; // byte offset inside {M,X,0} selected on match / mismatch
-        unsigned cur_flags = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // advance(): finish the current op (penalty), start following ops until one that spans read bases
+        int k = 0, kend = 0; // op cursor relative to kbase
+        if (has_cal) {
+            k = int(a.b.op_off[c] - kbase);
+            kend = int(a.b.op_off[c + 1] - kbase);
+        }
+        auto load_op = [&](const int kk) -> uint2 {
+            if (kk >= kend) return make_uint2(0u, 0u);
+            return in_lds ? reinterpret_cast<const uint2*>(lops)[kk] : reinterpret_cast<const uint2*>(gops + kbase)[kk];
+        };
+        double lnp = 0.0;
+        double pend = 0.0;  // term of the previous read position, not yet added (software pipeline of depth 1)
+        int op_end = 0;     // read position at which the current op ends
+        int delta = 0;      // hap index = delta + i inside a BASES op
+        unsigned colmin = ZERO_COL; // 0 inside a BASES op, ZERO_COL otherwise (max() forces the 0.0 column)
+        unsigned cur_flags = 0;
+        uint2 nop = load_op(k); // the next op, prefetched one transition ahead
+
+        // advance(): finish the current op (penalty), start following ops until one that spans read bases.
+        // Called by exactly the lanes whose current op ends at read position i.
         auto advance = [&](const int i) {
+            lnp = dadd(lnp, pend); // the last base term of the finished op precedes its penalty
+            pend = 0.0;
             for (;;) {
                 if (cur_flags & SK_OPFLAG_NONCANDIDATE_PENALTY) lnp = dadd(lnp, ln_noncand);
                 cur_flags = 0;
                 if (k >= kend) {
                     op_end = 0x7fffffff;
-                    selM = selX = 16;
-                    delta = -i; // keep idle lanes' hap address in range (hap[0])
+                    colmin = ZERO_COL;
+                    delta = -i; // keeps the (ignored) hap read of an idle lane in range
                     return;
                 }
-                const sk_score_op op = ops[k++];
-                cur_flags = op.flags;
-                int len = op.length;
-                if (op.kind == SK_OP_BASES) {
-                    selM = 0;
-                    selX = 8;
-                    delta = op.src - i;
+                const unsigned w0 = nop.x;
+                const int src = int(nop.y);
+                ++k;
+                nop = load_op(k);
+                cur_flags = (w0 >> 24) & 0xffu;
+                const unsigned kind = (w0 >> 16) & 0xffu;
+                int len = int(w0 & 0xffffu);
+                if (kind == SK_OP_BASES) {
+                    colmin = 0;
+                    delta = src - i;
                 } else {
-                    selM = selX = 16;
-                    delta = 0;
-                    if (op.kind == SK_OP_SOFT_CLIP) {
+                    colmin = ZERO_COL;
+                    delta = -i;
+                    if (kind == SK_OP_SOFT_CLIP) {
                         lnp = dadd(lnp, __dmul_rn(double(unsigned(len)), ln_quarter));
                     } else {
                         len = 0;
@@ -136,17 +176,23 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(con
             }
         };
 
-        const unsigned char* mxb = reinterpret_cast<const unsigned char*>(mx);
-#pragma unroll 4
+        if (op_end == 0) advance(0);
+        unsigned col_next = (L > 0) ? hap[delta] : 0u;
+#pragma unroll 2
         for (int i = 0; i < L; ++i) {
-            if (op_end == i) advance(i);
-            const unsigned rc = rcl[i];        // wave-uniform LDS broadcast
-            const unsigned h = hap[delta + i]; // per-lane haplotype base
-            const int sel = (h == rc) ? selM : selX;
-            const double v = *reinterpret_cast<const double*>(mxb + 24 * i + sel);
-            lnp = dadd(lnp, v);
+            if (op_end == i && i > 0) { // a lane leaves the lock-step sweep only at its own op boundaries
+                advance(i);
+                col_next = hap[delta + i];
+            }
+            unsigned col = col_next;
+            col = col > colmin ? col : colmin;
+            const double v = *reinterpret_cast<const double*>(tabb + ROW_BYTES * i + col);
+            col_next = hap[delta + i + 1]; // prefetch (hap slab is padded by 16 bytes beyond max(P, L))
+            lnp = dadd(lnp, pend);
+            pend = v;
         }
-        if (op_end == L || op_end == 0) advance(L); // trailing penalty / NOBASE ops (op_end==0 only when L==0)
+        if (op_end == L && L > 0) advance(L); // trailing penalty / NOBASE ops
+        lnp = dadd(lnp, pend);
         if (has_cal) a.out[c] = lnp;
     }
 }
@@ -204,10 +250,9 @@ extern "C" int sk_score_alignments_dev(const sk_align_batch* b, double* dev_out_
     a.tab = sk_ctx().dev_tables;
     a.out = dev_out_lnp;
     const int maxL = b->max_read_len, maxP = b->max_hap_len;
-    a.lds_mx_doubles = 3 * std::max(maxL, 1);
-    a.lds_rc_bytes = align16(std::max(maxL, 1));
-    a.lds_hap_bytes = align16(std::max(std::max(maxP, maxL), 1));
-    const size_t per_wave = size_t(a.lds_mx_doubles) * 8 + a.lds_rc_bytes + a.lds_hap_bytes;
+    a.lds_tab_bytes = ROW_BYTES * std::max(maxL, 1);
+    a.lds_hap_bytes = align16(std::max(std::max(maxP, maxL), 1)) + 16; // +16: the sweep prefetches one byte ahead
+    const size_t per_wave = size_t(a.lds_tab_bytes) + a.lds_hap_bytes + OPS_CAP * sizeof(sk_score_op);
     const size_t lds = per_wave * WAVES_PER_BLOCK;
     // fast path when 4 waves' slabs leave room for >= 2 workgroups per CU (160 KiB LDS)
     if (maxL > 0 && maxP > 0 && lds <= 64 * 1024) {
@@ -232,7 +277,7 @@ extern "C" int sk_score_alignments_dev_generic(const sk_align_batch* b, double* 
     a.b = *b;
     a.tab = sk_ctx().dev_tables;
     a.out = dev_out_lnp;
-    a.lds_mx_doubles = a.lds_rc_bytes = a.lds_hap_bytes = 0;
+    a.lds_tab_bytes = a.lds_hap_bytes = 0;
     const int threads = 256;
     hipLaunchKernelGGL(score_thread_per_cal, dim3((b->n_cals + threads - 1) / threads), dim3(threads), 0,
                        static_cast<hipStream_t>(hip_stream), a);

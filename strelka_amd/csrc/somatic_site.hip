@@ -61,8 +61,10 @@ __device__ __forceinline__ float log_sum2f(float x1, float x2)
         x1 = x2;
         x2 = t;
     }
-    const float e = expf(__fsub_rn(x2, x1));
-    const float l = (fabsf(e) < 0.01f) ? log1pf(e) : logf(__fadd_rn(1.f, e));
+    // expf/log1pf/logf of glibc are evaluated in double and rounded once; so are these
+    const float e = static_cast<float>(exp(static_cast<double>(__fsub_rn(x2, x1))));
+    const float l = (fabsf(e) < 0.01f) ? static_cast<float>(log1p(static_cast<double>(e)))
+                                       : static_cast<float>(log(static_cast<double>(__fadd_rn(1.f, e))));
     return __fadd_rn(x1, l);
 }
 

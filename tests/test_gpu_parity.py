@@ -126,10 +126,13 @@ def test_dependent_eprob(gpu):
     got = gpu.dependent_eprob(pb)
     want = pyoracle.adjust_joint_eprob(pb)
     # the sort emulation fixes WHICH call gets which exponent: any mis-assignment shows up as a gross difference
-    assert np.allclose(got, want, rtol=2e-6, atol=0)
-    # entries that never pass through powf (first of each group, filtered calls, floor-cached ones) are bit-exact
-    exact = np.mean(got == want)
-    assert exact > 0.5
+    # de = max(e, frac*val + (1-frac)*0.75) with frac = (1-val)/(1-e), val = powf(e, v): a 1-ulp difference between the
+    # device's pow and glibc's powf is amplified ~50x by the cancellation in (1-frac) when val is small, hence 1e-5 here;
+    # a mis-assigned exponent (wrong tie order) would be off by orders of magnitude more
+    assert np.allclose(got, want, rtol=1e-5, atol=0)
+    # entries that never pass through powf (first of each group, filtered calls, floor-cached ones) are bit-exact, and
+    # with pow evaluated in double and rounded once nearly all others are too
+    assert np.mean(got == want) > 0.999
 
 
 def test_site_digt_call(gpu):
@@ -143,7 +146,9 @@ def test_site_digt_call(gpu):
     assert np.array_equal(got["is_called"], want["is_called"])
     assert np.array_equal(got["ref_gt"], want["ref_gt"])
     assert close_ll(got["lhood"], want["lhood"])
-    assert close_ll(got["strand_bias"], want["strand_bias"])
+    # strand_bias = max(lhood_fwd, lhood_rev)[gt] - lhood[gt]: a difference of log-likelihoods, so its error scale is theirs
+    scale = np.maximum(1.0, np.abs(want["lhood"]).max(axis=1, initial=0.0, where=np.isfinite(want["lhood"])))
+    assert np.all(np.abs(got["strand_bias"] - want["strand_bias"]) <= LL_TOL * scale)
     for rs in ("genome", "poly"):
         assert np.mean(got[rs]["max_gt"] == want[rs]["max_gt"]) > 0.9999
         assert np.abs(got[rs]["snp_qphred"] - want[rs]["snp_qphred"]).max() <= 1
@@ -199,7 +204,7 @@ def test_pileup_edge_cases(gpu):
     pb = capi.HostPileupBatch(off, calls, np.array([0, 0, 1, 4, 2], np.uint8))
     de = gpu.dependent_eprob(pb)
     want_de = pyoracle.adjust_joint_eprob(pb)
-    assert np.allclose(de, want_de, rtol=2e-6)
+    assert np.allclose(de, want_de, rtol=1e-5)
     pb.de = want_de
     got = gpu.site_digt_call(pb)
     want = pyoracle.site_digt_call(pb, want_de)
