@@ -33,7 +33,7 @@ namespace
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int WAVE = 64;
-constexpr int OPS_CAP = 512;   // scoring ops staged in LDS per wave per pass of 64 candidates
+constexpr int OPS_CAP = 0;     // >0: stage up to this many scoring ops per wave per pass in LDS (0: prefetch from global)
 constexpr int ROW_BYTES = 48;  // per read position: {A, C, G, T, other, 0.0} doubles
 constexpr int ZERO_COL = 40;   // byte offset of the 0.0 column
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(con
         const int clast = (cbase + WAVE < cal_end) ? cbase + WAVE : cal_end;
         const int64_t kbase = a.b.op_off[cbase];
         const int nstage = int(a.b.op_off[clast] - kbase);
-        const bool in_lds = (nstage <= OPS_CAP);
+        const bool in_lds = (OPS_CAP > 0) && (nstage <= OPS_CAP);
         __builtin_amdgcn_wave_barrier();
         if (in_lds) {
             // consecutive candidates' ops are contiguous: one coalesced copy for the whole wave
