@@ -146,8 +146,7 @@ def main():
 
     # ---- hot path B (germline): dependent eprob + site genotype call ----
     def step_b():
-        db.dependent_eprob(gopt)
-        db.site_digt_call(gopt)
+        db.site_digt_call_fused(gopt)
     dt_b, kms_b = timed(step_b, args.steps, args.warmup)
     loci_per_s = world * db.n_loci * args.steps / dt_b
     alg_bytes_b = 6 * db.n_calls + B_BYTES_PER_LOCUS_FIXED * db.n_loci
@@ -168,7 +167,7 @@ def main():
         "roofline": {"kernel": "score_wave_per_read", "bound": "hbm", "achieved": ach_a, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach_a / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes_a, "kernel_ms": kms_a},
-        "roofline_loci": {"kernel": "dependent_eprob_kernel+site_digt_call_kernel", "bound": "hbm", "achieved": ach_b,
+        "roofline_loci": {"kernel": "germline_site_fused_kernel", "bound": "hbm", "achieved": ach_b,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS, "traffic": None,
                           "algorithmic_bytes_per_launch": alg_bytes_b, "kernel_ms": kms_b},
     }

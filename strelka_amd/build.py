@@ -17,6 +17,7 @@ HIP_SOURCES = [
     "csrc/sk_context.hip",
     "csrc/score_alignments.hip",
     "csrc/germline_site.hip",
+    "csrc/germline_fused.hip",
     "csrc/somatic_site.hip",
 ]
 HOST_SOURCES = [
@@ -37,7 +38,7 @@ def _stale(target, deps):
 
 def build_all(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
-    deps = _sources() + [os.path.join(ROOT, "include", "strelka_amd.h"), os.path.join(PKG, "csrc", "sk_common.h"),
+    deps = _sources() + [os.path.join(ROOT, "include", "strelka_amd.h"), os.path.join(PKG, "csrc", "sk_common.h"), os.path.join(PKG, "csrc", "germline_common.h"),
                          os.path.abspath(__file__)]
     if not force and not _stale(LIB_PATH, deps):
         return LIB_PATH

@@ -77,7 +77,7 @@ EXPORTS = [
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_add_read",
     "sk_align_builder_finish",
     "sk_germline_options_default", "sk_dependent_eprob", "sk_dependent_eprob_dev", "sk_site_digt_call",
-    "sk_site_digt_call_dev",
+    "sk_site_digt_call_dev", "sk_site_digt_call_fused", "sk_site_digt_call_fused_dev",
     "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
 ]
 
@@ -115,6 +115,9 @@ def lib():
                                              c_void_p]
         L.sk_site_digt_call.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p]
         L.sk_site_digt_call_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p, c_void_p]
+        L.sk_site_digt_call_fused.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p, c_void_p]
+        L.sk_site_digt_call_fused_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p, c_void_p,
+                                                  C.c_int, c_void_p, c_void_p]
         L.sk_somatic_snv_call_batch.argtypes = [C.POINTER(PileupBatch), C.POINTER(PileupBatch),
                                                 C.POINTER(SomaticSnvOptions), C.c_int, c_void_p]
         L.sk_somatic_snv_call_batch_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(PileupBatch),
@@ -289,6 +292,16 @@ def site_digt_call(batch, opt=None):
     s = batch.struct()
     _check(lib().sk_site_digt_call(C.byref(s), C.byref(opt), _p(out)))
     return out
+
+
+def site_digt_call_fused(batch, opt=None, want_de=False):
+    """a9+a10 in one pass; returns (calls, de or None)."""
+    opt = opt or germline_options()
+    out = np.zeros(batch.n_loci, DIGT_CALL_DTYPE)
+    de = np.zeros(len(batch.calls), np.float32) if want_de else None
+    s = batch.struct()
+    _check(lib().sk_site_digt_call_fused(C.byref(s), C.byref(opt), _p(out), _p(de)))
+    return out, de
 
 
 def somatic_snv_call(normal, tumor, opt=None, is_forced_output=False):

@@ -108,6 +108,18 @@ class DevicePileupBatch:
                                                      _stream_ptr()))
         return self.digt_out
 
+    def site_digt_call_fused(self, opt=None, want_de=False):
+        opt = opt or capi.germline_options()
+        if self.digt_out is None:
+            self.digt_out = torch.empty(self.n_loci * capi.DIGT_CALL_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+        if self.scratch is None:
+            self.scratch = torch.empty(max(self.n_calls, 1), dtype=torch.int32, device=self.device)
+        s = self.struct(with_de=False)
+        capi._check(capi.lib().sk_site_digt_call_fused_dev(C.byref(s), C.byref(opt), C.c_void_p(self.digt_out.data_ptr()),
+                                                           C.c_void_p(self.de.data_ptr()), int(want_de),
+                                                           C.c_void_p(self.scratch.data_ptr()), _stream_ptr()))
+        return self.digt_out
+
     def digt_numpy(self):
         return self.digt_out.cpu().numpy().view(capi.DIGT_CALL_DTYPE)
 

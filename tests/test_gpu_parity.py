@@ -174,6 +174,61 @@ def test_site_digt_call_exact_when_de_is_tabulated(gpu):
         assert np.array_equal(got["phredLoghood"], want["phredLoghood"])
 
 
+def test_site_digt_call_fused_equals_two_step(gpu):
+    """The fused LDS kernel (a9+a10 in one pass, de never materialised) must reproduce the two separate kernels bit for
+    bit: same arithmetic, different data movement.  Includes loci deeper than the LDS path allows (>1023 calls) and a
+    span larger than one LDS sub-batch."""
+    rng = np.random.default_rng(207)
+    parts = [_varied_pileups(rng), synth.pileups(40, rng, depth_mean=1500.0, het_rate=0.2),
+             synth.pileups(300, rng, depth_mean=150.0, het_rate=0.1), synth.pileups(1, rng, depth_mean=9000.0)]
+    off = [np.zeros(1, np.int64)]
+    calls, ref = [], []
+    base = 0
+    for p in parts:
+        off.append(p.call_off[1:] + base)
+        base += p.call_off[-1]
+        calls.append(p.calls)
+        ref.append(p.ref_base)
+    pb = gpu.HostPileupBatch(np.concatenate(off), np.concatenate(calls), np.concatenate(ref))
+    pb.ploidy = rng.choice(np.array([1, 2, 2], np.uint8), pb.n_loci)
+    pb.ref_base[::53] = 4
+    de2 = gpu.dependent_eprob(pb)
+    pb.de = de2
+    two = gpu.site_digt_call(pb)
+    fused, de1 = gpu.site_digt_call_fused(pb, want_de=True)
+    assert np.array_equal(de1.view(np.uint32), de2.view(np.uint32))
+    assert fused.tobytes() == two.tobytes()
+    fused_no_de, none = gpu.site_digt_call_fused(pb)
+    assert none is None and fused_no_de.tobytes() == two.tobytes()
+    # and against the oracle
+    want = pyoracle.site_digt_call(pb, pyoracle.adjust_joint_eprob(pb))
+    assert close_ll(fused["lhood"], want["lhood"])
+    assert np.mean(fused["genome"]["max_gt"] == want["genome"]["max_gt"]) > 0.9999
+    assert np.abs(fused["genome"]["snp_qphred"] - want["genome"]["snp_qphred"]).max() <= 1
+
+
+def test_site_digt_call_fused_nondefault_options(gpu):
+    rng = np.random.default_rng(208)
+    pb = synth.pileups(3000, rng, het_rate=0.1, nmm_rate=0.3)
+    for kw in (dict(bsnp_ssd_no_mismatch=0.05, bsnp_ssd_one_mismatch=0.1), dict(is_min_vexp=0),
+               dict(bsnp_ssd_no_mismatch=0.0, bsnp_ssd_one_mismatch=0.0), dict(min_vexp=0.6, bsnp_diploid_theta=0.01)):
+        opt = gpu.germline_options()
+        oopt = pyoracle.germline_options()
+        for k, v in kw.items():
+            setattr(opt, k, v)
+            setattr(oopt, k, v)
+        de2 = gpu.dependent_eprob(pb, opt)
+        pb.de = de2
+        two = gpu.site_digt_call(pb, opt)
+        fused, de1 = gpu.site_digt_call_fused(pb, opt, want_de=True)
+        assert np.array_equal(de1.view(np.uint32), de2.view(np.uint32)), kw
+        assert fused.tobytes() == two.tobytes(), kw
+        want_de = pyoracle.adjust_joint_eprob(pb, oopt)
+        assert np.allclose(de1, want_de, rtol=1e-5, atol=0), kw
+        want = pyoracle.site_digt_call(pb, want_de, oopt)
+        assert close_ll(fused["lhood"], want["lhood"]), kw
+
+
 def test_somatic_snv(gpu):
     rng = np.random.default_rng(204)
     n, t = synth.somatic_pileups(6000, rng, somatic_rate=0.03, het_rate=0.03)
