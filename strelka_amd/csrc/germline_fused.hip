@@ -27,10 +27,13 @@ namespace
 
 constexpr int LOCI_PER_BLOCK = 128;
 constexpr int FUSED_THREADS = 128;
-constexpr int CAP_CALLS = 6144;       // LDS budget: 4 B/call -> 24 KiB per block, 6 blocks per CU
-constexpr int MAX_PACKED_DEPTH = 1023; // index fits 10 bits beside the 6-bit q in a u16 sort key
+constexpr int CAP_CALLS = 5632;       // LDS budget: 4 B/call -> 22 KiB (+12 KiB of per-locus ranked-call terms) per block
+constexpr int MAX_RANK = 4;           // ranked calls per group on the LDS path (defaults need <= 4: 1, .65, .4225, .2746)
+constexpr int V0R_PER_LOCUS = 8 * (MAX_RANK - 1); // val[0] of ranks 2..MAX_RANK of each group (rank 1 has de == e_q)
+constexpr int MAX_PACKED_DEPTH = 1022; // index fits 10 bits beside the 6-bit q in a u16 sort key
 constexpr unsigned RANK_SHIFT = 13;    // bits 13..15 of the LDS basecall copy hold the rank (bit 13 = tscf, unused here)
 constexpr unsigned CALL_MASK = 0x1fffu;
+constexpr uint32_t NEEDS_GLOBAL_PASS = 0xffffffffu; // sentinel in sk_digt_call::is_called between the two passes
 
 struct FusedArgs
 {
@@ -116,23 +119,24 @@ __device__ void k_heap_sort(uint16_t* first, uint16_t* last)
     }
 }
 
-__device__ void k_std_sort(uint16_t* idx, const int n)
+constexpr int SORT_STACK = 6; // pending left parts kept per thread (LDS); deeper recursion -> caller falls back
+
+// returns false when the pending-part stack would overflow (n in the hundreds with adversarial splits)
+__device__ bool k_std_sort(uint16_t* idx, const int n, uint32_t* stack)
 {
     if (n <= 16) {
         k_insertion_sort(idx, idx + n);
-        return;
+        return true;
     }
     int lg = 0;
     for (unsigned m = unsigned(n); m > 1; m >>= 1) ++lg;
-    // n <= 1023 -> depth limit <= 18: the pending-left-part stack never holds more than that many entries
-    short st_first[20], st_last[20], st_depth[20];
+    // entry = first | last << 10 | depth << 20   (n <= 1023, depth <= 18)
     int sp = 1;
-    st_first[0] = 0;
-    st_last[0] = short(n);
-    st_depth[0] = short(lg * 2);
+    stack[0] = 0u | (unsigned(n) << 10) | (unsigned(lg * 2) << 20);
     while (sp > 0) {
         --sp;
-        int first = st_first[sp], last = st_last[sp], depth = st_depth[sp];
+        const uint32_t ent = stack[sp];
+        int first = int(ent & 0x3ffu), last = int((ent >> 10) & 0x3ffu), depth = int(ent >> 20);
         while (last - first > 16) {
             if (depth == 0) {
                 k_heap_sort(idx + first, idx + last);
@@ -169,15 +173,15 @@ __device__ void k_std_sort(uint16_t* idx, const int n)
                 ++lo;
             }
             const int cut = int(lo - idx);
-            st_first[sp] = short(first);
-            st_last[sp] = short(cut);
-            st_depth[sp] = short(depth);
+            if (sp >= SORT_STACK) return false;
+            stack[sp] = unsigned(first) | (unsigned(cut) << 10) | (unsigned(depth) << 20);
             ++sp;
             first = cut;
         }
     }
     k_insertion_sort(idx, idx + 16);
     for (uint16_t* i = idx + 16; i != idx + n; ++i) k_unguarded_linear_insert(i);
+    return true;
 }
 
 // exponent of the call with rank r (1-based) in a group with fraction f: the chain of adjust_icalls_eprob :146-178
@@ -211,26 +215,38 @@ __device__ __forceinline__ float call_de(const uint16_t c, const float (&vfrac)[
     return get_dependent_eprob(T->g_eprob[q], vexp_of_rank(rank, select8(vfrac, g), D));
 }
 
-// val[0] = logf(de) + ln(1/3) of one call
-__device__ __forceinline__ float call_v0(const uint16_t c, const float (&vfrac)[8], const SkTables* __restrict__ T,
-                                         const GermlineDerived& D)
+// val[0] = logf(de) + ln(1/3) of one call: a table value unless the call is one of the few ranked ones, whose terms
+// phase 1 left in LDS (v0r).  Branch-free: lanes of a wave hit ranked calls at different loop iterations.
+__device__ __forceinline__ float call_v0(const uint16_t c, const float* v0r, const GermlineDerived& D)
 {
     const unsigned q = SKC_Q(c), rank = c >> RANK_SHIFT;
-    if (!D.is_dependent_eprob || SKC_FILTER(c) || q < 3) return D.v0e[q];
-    if (rank == 0) return D.v0min[q];
+    const bool raw = (!D.is_dependent_eprob) || SKC_FILTER(c) || q < 3 || rank == 1; // de == (float)error_prob(q)
     const unsigned g = SKC_FWD(c) + 2 * SKC_BASE(c);
-    const float de = get_dependent_eprob(T->g_eprob[q], vexp_of_rank(rank, select8(vfrac, g), D));
-    return __fadd_rn(logf_via_double(de), T->g_log_one_third);
+    const unsigned slot = (rank >= 2) ? (g * (MAX_RANK - 1) + rank - 2) : 0u;
+    const float ranked = v0r[slot];
+    const float tab = raw ? D.v0e[q] : D.v0min[q];
+    return (rank >= 2 && !raw) ? ranked : tab;
 }
 
-// phase 1 for one locus in LDS.  Returns false when a group needs more than 7 ranked calls (caller falls back).
+// phase 1 for one locus in LDS.  Returns false when a group needs more than MAX_RANK ranked calls (caller falls back).
 __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, const SkTables* __restrict__ T,
-                                 const GermlineDerived& D, float (&vfrac)[8])
+                                 const GermlineDerived& D, float (&vfrac)[8], float* v0r, uint32_t* sort_stack)
 {
 #pragma unroll
     for (int g = 0; g < 8; ++g) vfrac[g] = 0.f;
     if (!D.is_dependent_eprob) return true;
-    for (unsigned g = 0; g < 8; ++g) {
+    // which (strand, base) groups are present
+    unsigned present = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint16_t b = calls[i];
+        if (SKC_FILTER(b) || SKC_Q(b) < 3) continue;
+        present |= 1u << (SKC_FWD(b) + 2 * SKC_BASE(b));
+    }
+    bool ok = true;
+    // lanes walk their k-th present group together (groups are independent; ascending order as in the reference)
+    while (present) {
+        const unsigned g = __builtin_ctz(present);
+        present &= present - 1;
         int gs = 0;
         float num = 0.f, den = 0.f;
         for (int i = 0; i < n; ++i) {
@@ -242,26 +258,35 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
             den = __fadd_rn(den, weight);
             if (SKC_NMM(b)) num = __fadd_rn(num, weight);
         }
-        if (gs == 0) continue;
         float mismatch_frac = 0.f;
         if (den > 0.) mismatch_frac = __fdiv_rn(num, den);
         const float vexp_frac = static_cast<float>(
             __dadd_rn(__dmul_rn(static_cast<double>(__fsub_rn(1.f, mismatch_frac)), D.ssd_no_mismatch),
                       __dmul_rn(static_cast<double>(mismatch_frac), D.ssd_one_mismatch)));
-        // select8() in phase 2 needs compile-time indices
 #pragma unroll
         for (unsigned k = 0; k < 8; ++k)
             if (k == g) vfrac[k] = vexp_frac;
 
-        k_std_sort(keys, gs);
+        if (!k_std_sort(keys, gs, sort_stack)) {
+            ok = false;
+            break;
+        }
 
         bool is_min = false;
         float vexp = 1.f;
         const float m = __fsub_rn(1.f, vexp_frac);
         for (int i = 0; i < gs && !is_min; ++i) {
-            if (i >= 7) return false;
+            if (i >= MAX_RANK) {
+                ok = false;
+                break;
+            }
             const unsigned ci = keys[i] & 0x3ffu;
-            calls[ci] = uint16_t(calls[ci] | ((unsigned(i) + 1u) << RANK_SHIFT));
+            const uint16_t c = calls[ci];
+            calls[ci] = uint16_t(c | ((unsigned(i) + 1u) << RANK_SHIFT));
+            if (i >= 1) { // rank 1 has vexp == 1 -> de == e_q exactly, a table term
+                const float de = get_dependent_eprob(T->g_eprob[SKC_Q(c)], vexp);
+                v0r[g * (MAX_RANK - 1) + i - 1] = __fadd_rn(logf_via_double(de), T->g_log_one_third);
+            }
             const float next_vexp = __fmul_rn(vexp, m);
             if (D.is_min_vexp) {
                 is_min = (next_vexp <= D.min_vexp);
@@ -271,12 +296,12 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
             }
         }
     }
-    return true;
+    return ok;
 }
 
 // phase 2 for one locus in LDS
 __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigned ref, const int ploidy,
-                               const float (&vfrac)[8], const SkTables* __restrict__ T, const GermlineDerived& D,
+                               const float* v0r, const SkTables* __restrict__ T, const GermlineDerived& D,
                                sk_digt_call& res)
 {
     memset(&res, 0, sizeof(res));
@@ -291,7 +316,7 @@ __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigne
     for (int i = 0; i < n; ++i) {
         const uint16_t bc = calls[i];
         const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
-        const float v0 = call_v0(bc, vfrac, T, D);
+        const float v0 = call_v0(bc, v0r, D);
         const float v1 = T->g_v1[q];
         const float v2 = T->g_v2[q];
 #pragma unroll
@@ -303,11 +328,13 @@ __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigne
     for (int gt = 0; gt < 10; ++gt) res.lhood[gt] = lh[gt];
     {
         const int gtcount = is_haploid ? 4 : 10;
-        int maxIndex = 0;
-        for (int gt = 1; gt < gtcount; ++gt)
-            if (lh[gt] > lh[maxIndex]) maxIndex = gt;
-        for (int gt = 0; gt < gtcount; ++gt)
-            res.phredLoghood[gt] = unsigned(ln_error_prob_to_qphred_f(__fsub_rn(lh[gt], lh[maxIndex]), D.ln10f));
+        float best = lh[0]; // lhood[maxIndex]: first maximum, strict > as in the reference
+#pragma unroll
+        for (int gt = 1; gt < 10; ++gt)
+            if (gt < gtcount && lh[gt] > best) best = lh[gt];
+#pragma unroll
+        for (int gt = 0; gt < 10; ++gt)
+            res.phredLoghood[gt] = (gt < gtcount) ? unsigned(ln_error_prob_to_qphred_f(__fsub_rn(lh[gt], best), D.ln10f)) : 0u;
     }
     calculate_result_set(lh, D.lnprior[is_haploid ? 1 : 0][ref][0], ref, res.genome);
     calculate_result_set(lh, D.lnprior[is_haploid ? 1 : 0][ref][1], ref, res.poly);
@@ -319,7 +346,7 @@ __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigne
         for (int i = 0; i < n; ++i) {
             const uint16_t bc = calls[i];
             const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
-            const float v0 = call_v0(bc, vfrac, T, D);
+            const float v0 = call_v0(bc, v0r, D);
             const float v1 = T->g_v1[q];
             const float v2 = T->g_v2[q];
             const float val_ref = (obs == ref) ? v2 : v0;
@@ -329,7 +356,10 @@ __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigne
             lr = __fadd_rn(lr, fwd ? val_ref : val_tgt);
         }
         const float m = (lf < lr) ? lr : lf;
-        res.strand_bias = static_cast<double>(__fsub_rn(m, lh[tgt]));
+        float lht = lh[0];
+#pragma unroll
+        for (int gt = 1; gt < 10; ++gt) lht = (tgt == unsigned(gt)) ? lh[gt] : lht;
+        res.strand_bias = static_cast<double>(__fsub_rn(m, lht));
     }
 }
 
@@ -338,6 +368,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
     __shared__ uint16_t s_calls[CAP_CALLS];
     __shared__ uint16_t s_keys[CAP_CALLS];
     __shared__ int64_t s_off[LOCI_PER_BLOCK + 1];
+    __shared__ float s_v0r[LOCI_PER_BLOCK * V0R_PER_LOCUS];
+    __shared__ uint32_t s_stack[FUSED_THREADS * SORT_STACK];
 
     const int tid = threadIdx.x;
     const int l0 = blockIdx.x * LOCI_PER_BLOCK;
@@ -353,11 +385,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
         const bool fits = (tid >= s) && (tid < nl) && (s_off[tid + 1] - c0 <= CAP_CALLS);
         const int cnt = __syncthreads_count(fits);
         if (cnt == 0) {
-            // a single locus deeper than the LDS budget: global-memory routines, one thread
-            if (tid == 0) {
-                locus_dependent_eprob_global(a.b, T, a.d, a.de_tmp, a.scratch, l0 + s);
-                locus_site_digt_call_global(a.b, a.de_tmp, T, a.d, a.out, l0 + s);
-            }
+            // a single locus deeper than the LDS budget: left to the global-memory pass
+            if (tid == 0) a.out[l0 + s].is_called = NEEDS_GLOBAL_PASS;
             s += 1;
             __syncthreads();
             continue;
@@ -377,23 +406,34 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
             const int ploidy = a.b.ploidy ? int(a.b.ploidy[l]) : 2;
             float vfrac[8];
             bool ok = (n <= MAX_PACKED_DEPTH);
-            if (ok) ok = locus_rank_calls(s_calls + off, s_keys + off, n, T, a.d, vfrac);
+            float* v0r = s_v0r + tid * V0R_PER_LOCUS;
+            if (ok) ok = locus_rank_calls(s_calls + off, s_keys + off, n, T, a.d, vfrac, v0r, s_stack + tid * SORT_STACK);
             if (ok) {
                 sk_digt_call res;
-                locus_call_lds(s_calls + off, n, ref, ploidy, vfrac, T, a.d, res);
+                locus_call_lds(s_calls + off, n, ref, ploidy, v0r, T, a.d, res);
                 a.out[l] = res;
                 if (a.want_de) {
                     float* __restrict__ de = a.de_tmp + s_off[t];
                     for (int i = 0; i < n; ++i) de[i] = call_de(s_calls[off + i], vfrac, T, a.d);
                 }
             } else {
-                locus_dependent_eprob_global(a.b, T, a.d, a.de_tmp, a.scratch, l);
-                locus_site_digt_call_global(a.b, a.de_tmp, T, a.d, a.out, l);
+                a.out[l].is_called = NEEDS_GLOBAL_PASS;
             }
         }
         s = e;
         __syncthreads();
     }
+}
+
+// second pass: the few loci the LDS kernel declined (deeper than 1022 calls / the LDS budget, or needing more ranked
+// calls / sort stack than the fast path holds) through the global-memory routines -- same arithmetic
+__global__ void germline_site_global_pass_kernel(const FusedArgs a)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.b.n_loci) return;
+    if (a.out[l].is_called != NEEDS_GLOBAL_PASS) return;
+    locus_dependent_eprob_global(a.b, a.tab, a.d, a.de_tmp, a.scratch, l);
+    locus_site_digt_call_global(a.b, a.de_tmp, a.tab, a.d, a.out, l);
 }
 
 } // namespace
@@ -419,6 +459,8 @@ int sk_site_digt_call_fused_dev(const sk_pileup_batch* b, const sk_germline_opti
     derive(*opt, a.d);
     const int blocks = (b->n_loci + LOCI_PER_BLOCK - 1) / LOCI_PER_BLOCK;
     hipLaunchKernelGGL(germline_site_fused_kernel, dim3(blocks), dim3(FUSED_THREADS), 0,
+                       static_cast<hipStream_t>(hip_stream), a);
+    hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3((b->n_loci + 255) / 256), dim3(256), 0,
                        static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());
     return 0;

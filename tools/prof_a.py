@@ -15,5 +15,5 @@ else:
     db = device.DevicePileupBatch(hb, "cuda:0", tile=4)
     g = capi.germline_options()
     for _ in range(3):
-        db.dependent_eprob(g); db.site_digt_call(g)
+        db.site_digt_call_fused(g)
 torch.cuda.synchronize()
