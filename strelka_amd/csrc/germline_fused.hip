@@ -22,18 +22,29 @@
 
 #include "germline_common.h"
 
+#include <cstdlib>
+
 namespace
 {
 
 constexpr int LOCI_PER_BLOCK = 128;
 constexpr int FUSED_THREADS = 128;
-constexpr int CAP_CALLS = 5632;       // LDS budget: 4 B/call -> 22 KiB (+12 KiB of per-locus ranked-call terms) per block
+constexpr int CAP_CALLS = 5312;       // LDS budget: 4 B/call -> 22 KiB (+12 KiB of per-locus ranked-call terms) per block
 constexpr int MAX_RANK = 4;           // ranked calls per group on the LDS path (defaults need <= 4: 1, .65, .4225, .2746)
-constexpr int V0R_PER_LOCUS = 8 * (MAX_RANK - 1); // val[0] of ranks 2..MAX_RANK of each group (rank 1 has de == e_q)
+constexpr int V0R_PER_LOCUS = 12;    // LDS floats per locus for val[0] of ranks 2..MAX_RANK (rank 1 has de == e_q), packed
+                                     // group after group; a locus needing more takes the global pass
 constexpr int MAX_PACKED_DEPTH = 1022; // index fits 10 bits beside the 6-bit q in a u16 sort key
 constexpr unsigned RANK_SHIFT = 13;    // bits 13..15 of the LDS basecall copy hold the rank (bit 13 = tscf, unused here)
 constexpr unsigned CALL_MASK = 0x1fffu;
 constexpr uint32_t NEEDS_GLOBAL_PASS = 0xffffffffu; // sentinel in sk_digt_call::is_called between the two passes
+
+// per-q float tables, copied into LDS once per block: the per-call loops index them with a data-dependent q, and an
+// LDS read costs a fraction of a (cached) global load's latency
+struct QTab
+{
+    float4 v[SK_NQ6]; // {v0e, v0min, v1, v2}: one ds_read_b128 per call in the likelihood loop
+    float weight[SK_NQ6], eprob[SK_NQ6], depmin[SK_NQ6];
+};
 
 struct FusedArgs
 {
@@ -119,7 +130,7 @@ __device__ void k_heap_sort(uint16_t* first, uint16_t* last)
     }
 }
 
-constexpr int SORT_STACK = 6; // pending left parts kept per thread (LDS); deeper recursion -> caller falls back
+constexpr int SORT_STACK = 4; // pending left parts kept per thread (LDS); deeper recursion -> caller falls back
 
 // returns false when the pending-part stack would overflow (n in the hundreds with adversarial splits)
 __device__ bool k_std_sort(uint16_t* idx, const int n, uint32_t* stack)
@@ -205,33 +216,37 @@ __device__ __forceinline__ float select8(const float (&f)[8], const unsigned g)
 }
 
 // de of one call (adjust_joint_eprob semantics) from its LDS copy
-__device__ __forceinline__ float call_de(const uint16_t c, const float (&vfrac)[8], const SkTables* __restrict__ T,
+__device__ __forceinline__ float call_de(const uint16_t c, const float (&vfrac)[8], const QTab& Q,
                                          const GermlineDerived& D)
 {
     const unsigned q = SKC_Q(c), rank = c >> RANK_SHIFT;
-    if (!D.is_dependent_eprob || SKC_FILTER(c) || q < 3) return T->g_eprob[q];
-    if (rank == 0) return D.depmin[q];
+    if (!D.is_dependent_eprob || SKC_FILTER(c) || q < 3) return Q.eprob[q];
+    if (rank == 0) return Q.depmin[q];
     const unsigned g = SKC_FWD(c) + 2 * SKC_BASE(c);
-    return get_dependent_eprob(T->g_eprob[q], vexp_of_rank(rank, select8(vfrac, g), D));
+    return get_dependent_eprob(Q.eprob[q], vexp_of_rank(rank, select8(vfrac, g), D));
 }
 
 // val[0] = logf(de) + ln(1/3) of one call: a table value unless the call is one of the few ranked ones, whose terms
 // phase 1 left in LDS (v0r).  Branch-free: lanes of a wave hit ranked calls at different loop iterations.
-__device__ __forceinline__ float call_v0(const uint16_t c, const float* v0r, const GermlineDerived& D)
+__device__ __forceinline__ float call_v0(const uint16_t c, const float4 qv, const float* v0r, const unsigned gbase,
+                                         const GermlineDerived& D)
 {
     const unsigned q = SKC_Q(c), rank = c >> RANK_SHIFT;
     const bool raw = (!D.is_dependent_eprob) || SKC_FILTER(c) || q < 3 || rank == 1; // de == (float)error_prob(q)
     const unsigned g = SKC_FWD(c) + 2 * SKC_BASE(c);
-    const unsigned slot = (rank >= 2) ? (g * (MAX_RANK - 1) + rank - 2) : 0u;
+    const unsigned slot = (rank >= 2) ? (((gbase >> (4 * g)) & 15u) + rank - 2) : 0u; // gbase: 4-bit slot base per group
     const float ranked = v0r[slot];
-    const float tab = raw ? D.v0e[q] : D.v0min[q];
+    const float tab = raw ? qv.x : qv.y;
     return (rank >= 2 && !raw) ? ranked : tab;
 }
 
 // phase 1 for one locus in LDS.  Returns false when a group needs more than MAX_RANK ranked calls (caller falls back).
 __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, const SkTables* __restrict__ T,
-                                 const GermlineDerived& D, float (&vfrac)[8], float* v0r, uint32_t* sort_stack)
+                                 const GermlineDerived& D, const QTab& Q, float (&vfrac)[8], float* v0r,
+                                 unsigned& gbase, uint32_t* sort_stack)
 {
+    gbase = 0;
+    unsigned nslots = 0;
 #pragma unroll
     for (int g = 0; g < 8; ++g) vfrac[g] = 0.f;
     if (!D.is_dependent_eprob) return true;
@@ -254,7 +269,7 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
             if (SKC_FILTER(b) || SKC_Q(b) < 3) continue;
             if (SKC_FWD(b) + 2 * SKC_BASE(b) != g) continue;
             keys[gs++] = uint16_t((SKC_Q(b) << 10) | unsigned(i));
-            const float weight = T->g_weight[SKC_Q(b)];
+            const float weight = Q.weight[SKC_Q(b)];
             den = __fadd_rn(den, weight);
             if (SKC_NMM(b)) num = __fadd_rn(num, weight);
         }
@@ -275,8 +290,9 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
         bool is_min = false;
         float vexp = 1.f;
         const float m = __fsub_rn(1.f, vexp_frac);
+        gbase |= nslots << (4 * g);
         for (int i = 0; i < gs && !is_min; ++i) {
-            if (i >= MAX_RANK) {
+            if (i >= MAX_RANK || (i >= 1 && nslots >= unsigned(V0R_PER_LOCUS))) {
                 ok = false;
                 break;
             }
@@ -284,8 +300,8 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
             const uint16_t c = calls[ci];
             calls[ci] = uint16_t(c | ((unsigned(i) + 1u) << RANK_SHIFT));
             if (i >= 1) { // rank 1 has vexp == 1 -> de == e_q exactly, a table term
-                const float de = get_dependent_eprob(T->g_eprob[SKC_Q(c)], vexp);
-                v0r[g * (MAX_RANK - 1) + i - 1] = __fadd_rn(logf_via_double(de), T->g_log_one_third);
+                const float de = get_dependent_eprob(Q.eprob[SKC_Q(c)], vexp);
+                v0r[nslots++] = __fadd_rn(logf_via_double(de), T->g_log_one_third);
             }
             const float next_vexp = __fmul_rn(vexp, m);
             if (D.is_min_vexp) {
@@ -301,8 +317,8 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
 
 // phase 2 for one locus in LDS
 __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigned ref, const int ploidy,
-                               const float* v0r, const SkTables* __restrict__ T, const GermlineDerived& D,
-                               sk_digt_call& res)
+                               const float* v0r, const unsigned gbase, const SkTables* __restrict__ T,
+                               const GermlineDerived& D, const QTab& Q, sk_digt_call& res)
 {
     memset(&res, 0, sizeof(res));
     if (ref >= 4) return;
@@ -316,9 +332,10 @@ __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigne
     for (int i = 0; i < n; ++i) {
         const uint16_t bc = calls[i];
         const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
-        const float v0 = call_v0(bc, v0r, D);
-        const float v1 = T->g_v1[q];
-        const float v2 = T->g_v2[q];
+        const float4 qv = Q.v[q];
+        const float v0 = call_v0(bc, qv, v0r, gbase, D);
+        const float v1 = qv.z;
+        const float v2 = qv.w;
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt) lh[gt] = __fadd_rn(lh[gt], (obs == unsigned(gt)) ? v2 : v0);
 #pragma unroll
@@ -346,9 +363,10 @@ __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigne
         for (int i = 0; i < n; ++i) {
             const uint16_t bc = calls[i];
             const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
-            const float v0 = call_v0(bc, v0r, D);
-            const float v1 = T->g_v1[q];
-            const float v2 = T->g_v2[q];
+            const float4 qv = Q.v[q];
+            const float v0 = call_v0(bc, qv, v0r, gbase, D);
+            const float v1 = qv.z;
+            const float v2 = qv.w;
             const float val_ref = (obs == ref) ? v2 : v0;
             const float val_tgt = (tgt < 4) ? ((obs == tgt) ? v2 : v0) : ((obs == t0 || obs == t1) ? v1 : v0);
             const bool fwd = SKC_FWD(bc);
@@ -370,11 +388,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
     __shared__ int64_t s_off[LOCI_PER_BLOCK + 1];
     __shared__ float s_v0r[LOCI_PER_BLOCK * V0R_PER_LOCUS];
     __shared__ uint32_t s_stack[FUSED_THREADS * SORT_STACK];
+    __shared__ QTab s_q;
 
     const int tid = threadIdx.x;
     const int l0 = blockIdx.x * LOCI_PER_BLOCK;
     const int nl = min(LOCI_PER_BLOCK, a.b.n_loci - l0);
     for (int j = tid; j <= nl; j += FUSED_THREADS) s_off[j] = a.b.call_off[l0 + j];
+    for (int q = tid; q < SK_NQ6; q += FUSED_THREADS) {
+        s_q.v[q] = make_float4(a.d.v0e[q], a.d.v0min[q], a.tab->g_v1[q], a.tab->g_v2[q]);
+        s_q.weight[q] = a.tab->g_weight[q];
+        s_q.eprob[q] = a.tab->g_eprob[q];
+        s_q.depmin[q] = a.d.depmin[q];
+    }
     __syncthreads();
 
     const SkTables* __restrict__ T = a.tab;
@@ -407,14 +432,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
             float vfrac[8];
             bool ok = (n <= MAX_PACKED_DEPTH);
             float* v0r = s_v0r + tid * V0R_PER_LOCUS;
-            if (ok) ok = locus_rank_calls(s_calls + off, s_keys + off, n, T, a.d, vfrac, v0r, s_stack + tid * SORT_STACK);
+            unsigned gbase = 0;
+            if (ok) ok = locus_rank_calls(s_calls + off, s_keys + off, n, T, a.d, s_q, vfrac, v0r, gbase, s_stack + tid * SORT_STACK);
             if (ok) {
                 sk_digt_call res;
-                locus_call_lds(s_calls + off, n, ref, ploidy, v0r, T, a.d, res);
+                locus_call_lds(s_calls + off, n, ref, ploidy, v0r, gbase, T, a.d, s_q, res);
                 a.out[l] = res;
                 if (a.want_de) {
                     float* __restrict__ de = a.de_tmp + s_off[t];
-                    for (int i = 0; i < n; ++i) de[i] = call_de(s_calls[off + i], vfrac, T, a.d);
+                    for (int i = 0; i < n; ++i) de[i] = call_de(s_calls[off + i], vfrac, s_q, a.d);
                 }
             } else {
                 a.out[l].is_called = NEEDS_GLOBAL_PASS;
@@ -460,8 +486,9 @@ int sk_site_digt_call_fused_dev(const sk_pileup_batch* b, const sk_germline_opti
     const int blocks = (b->n_loci + LOCI_PER_BLOCK - 1) / LOCI_PER_BLOCK;
     hipLaunchKernelGGL(germline_site_fused_kernel, dim3(blocks), dim3(FUSED_THREADS), 0,
                        static_cast<hipStream_t>(hip_stream), a);
-    hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3((b->n_loci + 255) / 256), dim3(256), 0,
-                       static_cast<hipStream_t>(hip_stream), a);
+    if (!getenv("SK_DEBUG_SKIP_GLOBAL_PASS")) // debugging aid: leaves the sentinel visible in is_called
+        hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3((b->n_loci + 255) / 256), dim3(256), 0,
+                           static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());
     return 0;
 }

@@ -23,7 +23,7 @@ INDEL = dict(NONE=0, INDEL=1, MISMATCH=2, BP_LEFT=3, BP_RIGHT=4)
 # input B / C: pileups
 
 def pileups(n_loci, rng, depth_mean=40.0, het_rate=0.00067, hom_rate=0.00033, nmm_rate=0.02, filter_rate=0.0,
-            alt_frac=None, with_n_ref=False):
+            alt_frac=None, with_n_ref=False, noise=0.0):
     """Germline-style pileup batch: depth ~ Poisson(depth_mean), hom-ref except het/hom-alt loci, strand Bernoulli(.5),
     quals from QUAL_VALUES, a 0.1 %-per-base sequencing error.  Returns capi.HostPileupBatch (de=None)."""
     depth = rng.poisson(depth_mean, n_loci).astype(np.int64)
@@ -40,8 +40,10 @@ def pileups(n_loci, rng, depth_mean=40.0, het_rate=0.00067, hom_rate=0.00033, nm
         frac = np.broadcast_to(np.asarray(alt_frac, float), (n_loci,))
     base = np.where(rng.random(total) < frac[locus], alt[locus], ref[locus]).astype(np.uint8)
     q = rng.choice(QUAL_VALUES, total, p=QUAL_PROBS)
-    err = rng.random(total) < np.power(10.0, -q / 10.0)
+    err = rng.random(total) < np.power(10.0, -q.astype(np.float64) / 10.0)
     base = np.where(err, (base + rng.integers(1, 4, total)) % 4, base).astype(np.uint8)
+    if noise > 0:  # stress case for tests: many bases present at one locus (all eight strand/base groups populated)
+        base = np.where(rng.random(total) < noise, rng.integers(0, 4, total), base).astype(np.uint8)
     fwd = rng.integers(0, 2, total)
     nmm = rng.random(total) < nmm_rate
     filt = rng.random(total) < filter_rate
@@ -68,7 +70,7 @@ def somatic_pileups(n_loci, rng, normal_depth=40.0, tumor_depth=110.0, somatic_r
         locus = np.repeat(np.arange(n_loci), depth)
         base = np.where(rng.random(total) < frac[locus], alt[locus], ref[locus]).astype(np.uint8)
         q = rng.choice(QUAL_VALUES, total, p=QUAL_PROBS)
-        err = rng.random(total) < np.power(10.0, -q / 10.0)
+        err = rng.random(total) < np.power(10.0, -q.astype(np.float64) / 10.0)
         base = np.where(err, (base + rng.integers(1, 4, total)) % 4, base).astype(np.uint8)
         calls = capi.make_call(q, base, rng.integers(0, 2, total), 0, 0, 0)
         return capi.HostPileupBatch(off, calls, ref)
@@ -100,7 +102,7 @@ def align_batch_flat(n_reads, rng, H=64, L=150, K=6, win=400, noncand_rate=0.1):
     qual = rng.choice(QUAL_VALUES, (n_reads, L), p=QUAL_PROBS)
     idx = start[:, None] + np.arange(L)[None, :]
     read = np.take_along_axis(ref, idx, axis=1)
-    err = rng.random((n_reads, L)) < np.power(10.0, -qual / 10.0)
+    err = rng.random((n_reads, L)) < np.power(10.0, -qual.astype(np.float64) / 10.0)
     sub = BAM_CODE[rng.integers(0, 4, (n_reads, L))]
     read = np.where(err, sub, read).astype(np.uint8)
     read = np.where(rng.random((n_reads, L)) < 0.002, 15, read).astype(np.uint8)  # a few N base calls
@@ -297,7 +299,7 @@ def align_cases_h64(n_reads, rng, L=150, K=6, win=400, ref_offset=0, noncand_rat
             indels.append(ind)
         q = rng.choice(QUAL_VALUES, L, p=QUAL_PROBS)
         read = np.array([BAM_CODE[BASES.index(c)] for c in ref_seq[start:start + L]], np.uint8)
-        err = rng.random(L) < np.power(10.0, -q / 10.0)
+        err = rng.random(L) < np.power(10.0, -q.astype(np.float64) / 10.0)
         read = np.where(err, BAM_CODE[rng.integers(0, 4, L)], read).astype(np.uint8)
         cals = []
         for m in range(1 << K):

@@ -107,6 +107,7 @@ def _varied_pileups(rng, n=4000):
     parts = [synth.pileups(n, rng, het_rate=0.05, hom_rate=0.03, filter_rate=0.03),
              synth.pileups(n // 4, rng, depth_mean=3.0, het_rate=0.2),
              synth.pileups(n // 8, rng, depth_mean=400.0, het_rate=0.1, nmm_rate=0.2),
+             synth.pileups(n // 2, rng, noise=0.6, nmm_rate=0.1),
              synth.pileups(50, rng, depth_mean=0.2)]
     off = [np.zeros(1, np.int64)]
     calls, ref = [], []
