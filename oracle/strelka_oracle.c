@@ -960,6 +960,202 @@ void sko_position_somatic_snv_call(const uint16_t* ncalls, int32_t n_n, const ui
     }
 }
 
+/* ------------------------------------------------------------------------------------ hot path B: indels */
+
+/* get_het_observed_allele_ratio, L/starling_common/starling_indel_call_pprob_digt.cpp:40-71 */
+void sko_het_observed_allele_ratio(unsigned read_length, unsigned min_overlap, unsigned del_len, unsigned ins_len,
+                                   double het_allele_ratio, double* log_ref_prob, double* log_indel_prob)
+{
+    const unsigned base_expect = ((read_length + 1) < (2 * min_overlap)) ? 0 : (read_length + 1) - (2 * min_overlap);
+    const double ref_path_expect = base_expect + ((del_len < base_expect) ? del_len : base_expect);
+    const double indel_path_expect = base_expect + ((ins_len < base_expect) ? ins_len : base_expect);
+    const double ref_path_term = (1 - het_allele_ratio) * ref_path_expect;
+    const double indel_path_term = het_allele_ratio * indel_path_expect;
+    const double total_path_term = ref_path_term + indel_path_term;
+    if (total_path_term > 0) {
+        const double indel_prob = indel_path_term / total_path_term;
+        *log_ref_prob = log(1. - indel_prob);
+        *log_indel_prob = log(indel_prob);
+    }
+}
+
+/* integrateOutMappingStatus, L/starling_common/readMappingAdjustmentUtil.hh:29-56 */
+double sko_integrate_out_mapping_status(double randomBaseMatchLogProb, unsigned nonAmbiguousBasesInRead, double lnp)
+{
+    const double correctMappingLogPrior = log(1.7e-10); /* starling_base_shared.cpp:64 */
+    return sko_log_sum2(lnp + correctMappingLogPrior, randomBaseMatchLogProb * nonAmbiguousBasesInRead);
+}
+
+void sko_indel_grid_lhood(int32_t n_reads, const float* ref_lnp, const float* indel_lnp, const float* alt_lnp,
+                          const uint16_t* non_ambig, const uint16_t* read_length, const uint8_t* is_tier1,
+                          unsigned del_len, unsigned ins_len, int is_breakpoint, int min_read_bp_flank,
+                          double randomBaseMatchProb, int is_include_tier2, int is_use_alt_indel, double* lhood)
+{
+    const double rbm = log(randomBaseMatchProb); /* starling_base_shared.cpp:42 */
+    const float RATIO_INCREMENT = 0.5f / (float)(HET_RES + 1);
+    for (int i = 0; i < PRESTRAND; ++i) lhood[i] = 0.;
+
+    /* get_indel_digt_lhood :240-310 : STAR_DIINDEL NOINDEL=0, HOM=1, HET=2 (== SOMATIC_DIGT REF, HOM, HET) */
+    const double loghalf = -log(2.);
+    for (int r = 0; r < n_reads; ++r) {
+        if ((!is_include_tier2) && (!is_tier1[r])) continue;
+        double alt_path_lnp = ref_lnp[r];
+        if (is_use_alt_indel && alt_lnp[r] == alt_lnp[r] && alt_lnp[r] > alt_path_lnp) alt_path_lnp = alt_lnp[r];
+        const double noindel_lnp = alt_path_lnp;
+        const double hom_lnp = indel_lnp[r];
+        double log_ref_prob = loghalf, log_indel_prob = loghalf;
+        if (!is_breakpoint)
+            sko_het_observed_allele_ratio(read_length[r], (unsigned)min_read_bp_flank, del_len, ins_len, 0.5,
+                                          &log_ref_prob, &log_indel_prob);
+        const double het_lnp = sko_log_sum2(noindel_lnp + log_ref_prob, hom_lnp + log_indel_prob);
+        lhood[SOM_REF] += sko_integrate_out_mapping_status(rbm, non_ambig[r], noindel_lnp);
+        lhood[SOM_HOM] += sko_integrate_out_mapping_status(rbm, non_ambig[r], hom_lnp);
+        lhood[SOM_HET] += sko_integrate_out_mapping_status(rbm, non_ambig[r], het_lnp);
+    }
+
+    /* get_indel_het_grid_lhood (somatic_indel_grid.cpp:66-89) over get_high_low_het_ratio_lhood (:75-155) */
+    double* grid = lhood + SOM_SIZE;
+    const unsigned lsize = HET_RES * 2;
+    for (unsigned i = 0; i < HET_RES; ++i) {
+        const double het_ratio = (i + 1) * RATIO_INCREMENT; /* unsigned * float -> float, widened */
+        const double chet_ratio = 1. - het_ratio;
+        const double log_het_ratio = log(het_ratio);
+        const double log_chet_ratio = log(chet_ratio);
+        double het_lhood_high = 0, het_lhood_low = 0;
+        for (int r = 0; r < n_reads; ++r) {
+            if ((!is_include_tier2) && (!is_tier1[r])) continue;
+            double alt_path_lnp = ref_lnp[r];
+            if (is_use_alt_indel && alt_lnp[r] == alt_lnp[r] && alt_lnp[r] > alt_path_lnp) alt_path_lnp = alt_lnp[r];
+            const double noindel_lnp = alt_path_lnp;
+            const double hom_lnp = indel_lnp[r];
+            {
+                double log_ref_prob = log_chet_ratio, log_indel_prob = log_het_ratio;
+                if (!is_breakpoint)
+                    sko_het_observed_allele_ratio(read_length[r], (unsigned)min_read_bp_flank, del_len, ins_len,
+                                                  het_ratio, &log_ref_prob, &log_indel_prob);
+                const double het_lnp = sko_log_sum2(noindel_lnp + log_ref_prob, hom_lnp + log_indel_prob);
+                het_lhood_low += sko_integrate_out_mapping_status(rbm, non_ambig[r], het_lnp);
+            }
+            {
+                double log_ref_prob = log_het_ratio, log_indel_prob = log_chet_ratio;
+                if (!is_breakpoint)
+                    sko_het_observed_allele_ratio(read_length[r], (unsigned)min_read_bp_flank, del_len, ins_len,
+                                                  chet_ratio, &log_ref_prob, &log_indel_prob);
+                const double het_lnp = sko_log_sum2(noindel_lnp + log_ref_prob, hom_lnp + log_indel_prob);
+                het_lhood_high += sko_integrate_out_mapping_status(rbm, non_ambig[r], het_lnp);
+            }
+        }
+        grid[lsize - (i + 1)] = het_lhood_high;
+        grid[i] = het_lhood_low;
+    }
+}
+
+void sko_allele_group_genotype_lhoods(int32_t n_reads, int32_t n_alt, const float* ref_lnp, const float* allele_lnp,
+                                      const uint16_t* non_ambig, const uint16_t* read_length, const uint8_t* is_tier1,
+                                      const uint8_t* is_fwd, const uint32_t* del_len, const uint32_t* ins_len,
+                                      int ploidy, int min_read_bp_flank, double randomBaseMatchProb,
+                                      double readSupportThreshold, double* out_lhood, uint32_t* out_counts)
+{
+    const double rbm = log(randomBaseMatchProb);
+    const int full = n_alt + 1;
+    const int gcount = (ploidy == 1) ? full : full * (full + 1) / 2;
+    for (int g = 0; g < gcount; ++g) out_lhood[g] = 0.;
+    memset(out_counts, 0, sizeof(uint32_t) * 2 * (size_t)(n_alt + 2));
+    if (n_alt <= 0) return;
+    double L[8], Lm[8];
+    assert(full <= 8);
+    for (int r = 0; r < n_reads; ++r) {
+        /* getAlleleGroupIntersectionReadIds (OrthogonalVariantAlleleCandidateGroupUtil.cpp:64-113), tier1 only:
+         * the read must be scored for every allele of the group */
+        int present = 0;
+        for (int a = 0; a < n_alt; ++a) {
+            const float s = allele_lnp[r * n_alt + a];
+            if (s == s && is_tier1[r]) ++present;
+        }
+        if (present < n_alt) continue;
+        /* getAlleleLogLhoodFromRead (:132-197) */
+        for (int a = 0; a < n_alt; ++a) {
+            const double rl = (double)ref_lnp[r * n_alt + a];
+            if (a == 0) L[0] = rl;
+            else L[0] = (L[0] < rl) ? rl : L[0];
+            L[a + 1] = allele_lnp[r * n_alt + a];
+        }
+        /* updateGenotypeLogLhoodFromAlleleLogLhood (AlleleGroupGenotype.cpp:36-114) */
+        if (ploidy == 1) {
+            for (int a0 = 0; a0 < full; ++a0) out_lhood[a0] += sko_integrate_out_mapping_status(rbm, non_ambig[r], L[a0]);
+        } else {
+            for (int a1 = 0; a1 < full; ++a1) {
+                for (int a0 = 0; a0 <= a1; ++a0) {
+                    const int gi = a0 + (a1 * (a1 + 1) / 2);
+                    double raw = 0;
+                    if (a0 != a1) {
+                        const double loghalf = log(0.5);
+                        double lp0 = loghalf, lp1 = loghalf;
+                        sko_het_observed_allele_ratio(read_length[r], (unsigned)min_read_bp_flank, del_len[a1 - 1],
+                                                      ins_len[a1 - 1], 0.5, &lp0, &lp1);
+                        if (a0 > 0) {
+                            double logRefPrior = loghalf;
+                            lp0 = loghalf;
+                            sko_het_observed_allele_ratio(read_length[r], (unsigned)min_read_bp_flank, del_len[a0 - 1],
+                                                          ins_len[a0 - 1], 0.5, &logRefPrior, &lp0);
+                            const double norm = sko_log_sum2(lp0, lp1);
+                            lp0 -= norm;
+                            lp1 -= norm;
+                        }
+                        raw = sko_log_sum2(L[a0] + lp0, L[a1] + lp1);
+                    } else {
+                        raw = L[a0];
+                    }
+                    out_lhood[gi] += sko_integrate_out_mapping_status(rbm, non_ambig[r], raw);
+                }
+            }
+        }
+        /* updateSupportingReadStats (:125-155) */
+        for (int a = 0; a < full; ++a) Lm[a] = sko_integrate_out_mapping_status(rbm, non_ambig[r], L[a]);
+        {
+            double mx = Lm[0];
+            for (int a = 1; a < full; ++a) if (Lm[a] > mx) mx = Lm[a];
+            double sum = 0.;
+            for (int a = 0; a < full; ++a) { Lm[a] = exp(Lm[a] - mx); sum += Lm[a]; }
+            sum = 1. / sum;
+            for (int a = 0; a < full; ++a) Lm[a] *= sum;
+        }
+        uint32_t* cnt = out_counts + (is_fwd[r] ? 0 : 1) * (n_alt + 2);
+        int found = 0;
+        for (int a = 0; a < full; ++a) {
+            if (Lm[a] < readSupportThreshold) continue;
+            cnt[a]++;
+            found = 1;
+            break;
+        }
+        if (!found) cnt[n_alt + 1]++;
+    }
+}
+
+void sko_somatic_indel_result(const double* normal_lhood, const double* tumor_lhood, double indelToRefErrorProb,
+                              double shared_indel_error_factor, double indel_contam_tolerance, double somatic_indel_rate,
+                              double bindel_diploid_theta, uint32_t* max_gt, int32_t* qphred, int32_t* from_ntype_qphred,
+                              uint32_t* ntype)
+{
+    float nf[PRESTRAND], tf[PRESTRAND];
+    for (int j = 0; j < PRESTRAND; ++j) {
+        nf[j] = (float)normal_lhood[j];
+        tf[j] = (float)tumor_lhood[j];
+    }
+    const double sharedIndelErrorRate = pow(indelToRefErrorProb, shared_indel_error_factor);
+    const double logSharedIndelErrorRate = log(sharedIndelErrorRate);
+    const double logSharedIndelErrorRateComplement = sko_log1p_switch(-sharedIndelErrorRate);
+    float lnprior[3]; /* somatic_indel_caller_grid ctor :58-64 */
+    lnprior[SOM_REF] = (float)sko_log1p_switch(-(3. * bindel_diploid_theta) / 2.);
+    lnprior[SOM_HOM] = (float)log(bindel_diploid_theta / 2.);
+    lnprior[SOM_HET] = (float)log(bindel_diploid_theta);
+    const float ln_som_match = (float)sko_log1p_switch(-somatic_indel_rate);
+    const float ln_som_mismatch = (float)log(somatic_indel_rate);
+    sko_calculate_result_set_grid((float)indel_contam_tolerance, (float)logSharedIndelErrorRate,
+                                  (float)logSharedIndelErrorRateComplement, nf, tf, lnprior, ln_som_match,
+                                  ln_som_mismatch, max_gt, qphred, from_ntype_qphred, ntype);
+}
+
 /* ------------------------------------------------------------------------------------------------ batch drivers */
 
 void sko_score_cases(const sko_read_case* cases, int32_t n_cases, double* out)

@@ -125,6 +125,40 @@ void sko_position_somatic_snv_call(const uint16_t* ncalls, int32_t n_n, const ui
                                    uint32_t ref_base_id, const sko_somatic_snv_options* opt, int is_forced_output,
                                    sko_somatic_snv_call* out);
 
+/* ---- hot path B, indels ---- */
+/* get_het_observed_allele_ratio (L/starling_common/starling_indel_call_pprob_digt.cpp:40-71); outputs untouched when
+ * the total path term is 0 */
+void sko_het_observed_allele_ratio(unsigned read_length, unsigned min_overlap, unsigned del_len, unsigned ins_len,
+                                   double het_allele_ratio, double* log_ref_prob, double* log_indel_prob);
+/* integrateOutMappingStatus (L/starling_common/readMappingAdjustmentUtil.hh:29-56) with
+ * correctMappingLogPrior = log(1.7e-10) (L/starling_common/starling_base_shared.cpp:64) */
+double sko_integrate_out_mapping_status(double randomBaseMatchLogProb, unsigned nonAmbiguousBasesInRead, double lnp);
+
+/* 21 somatic-grid states of one sample for one indel: get_indel_digt_lhood (:240-336) for REF/HOM/HET and
+ * get_indel_het_grid_lhood (L/applications/strelka/somatic_indel_grid.cpp:66-89) -> get_high_low_het_ratio_lhood
+ * (:75-155) for the 18 grid ratios.  alt_lnp[r] = best alternate-indel score of read r, NaN when it has none. */
+void sko_indel_grid_lhood(int32_t n_reads, const float* ref_lnp, const float* indel_lnp, const float* alt_lnp,
+                          const uint16_t* non_ambig, const uint16_t* read_length, const uint8_t* is_tier1,
+                          unsigned del_len, unsigned ins_len, int is_breakpoint, int min_read_bp_flank,
+                          double randomBaseMatchProb, int is_include_tier2, int is_use_alt_indel, double* lhood21);
+
+/* getVariantAlleleGroupGenotypeLhoodsForSample (L/starling_common/AlleleGroupGenotype.cpp:185-258), empty contrast
+ * group.  ref_lnp/allele_lnp: [n_reads][n_alt], allele_lnp NaN = read not scored for that allele.
+ * out_lhood: ploidy 1 -> n_alt+1, ploidy 2 -> (n_alt+1)(n_alt+2)/2 (VcfGenotypeUtil order).
+ * out_counts: [2 strands: fwd, rev][n_alt+2]: confident count per allele (ref first), then non-confident. */
+void sko_allele_group_genotype_lhoods(int32_t n_reads, int32_t n_alt, const float* ref_lnp, const float* allele_lnp,
+                                      const uint16_t* non_ambig, const uint16_t* read_length, const uint8_t* is_tier1,
+                                      const uint8_t* is_fwd, const uint32_t* del_len, const uint32_t* ins_len,
+                                      int ploidy, int min_read_bp_flank, double randomBaseMatchProb,
+                                      double readSupportThreshold, double* out_lhood, uint32_t* out_counts);
+
+/* somatic indel call from the two samples' 21-state likelihoods (get_somatic_indel :243-291, one tier, no multi-indel
+ * filter): float cast, shared error rate = indelToRefErrorProb^shared_indel_error_factor, calculate_result_set_grid */
+void sko_somatic_indel_result(const double* normal_lhood21, const double* tumor_lhood21, double indelToRefErrorProb,
+                              double shared_indel_error_factor, double indel_contam_tolerance, double somatic_indel_rate,
+                              double bindel_diploid_theta, uint32_t* max_gt, int32_t* qphred, int32_t* from_ntype_qphred,
+                              uint32_t* ntype);
+
 /* ---- batch drivers (plain loops over the functions above; used for parity tests and the bench CPU baseline) ---- */
 typedef struct sko_read_case {
     const uint8_t* read_code;
