@@ -262,6 +262,102 @@ int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* dev_normal, const sk_pi
                                   const sk_somatic_snv_options* opt, int is_forced_output,
                                   sk_somatic_snv_call* dev_out, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Hot path B (indels): per-read likelihood reductions over IndelSampleData::read_path_lnp
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+enum { SK_MAX_ALT = 3, SK_MAX_INDEL_GT = 10 };
+/** read_flags bits */
+enum { SK_READ_TIER1 = 1, SK_READ_FWD = 2 };
+
+typedef struct sk_indel_options { /* starling_base_options / starling_sample_options / Tier2Options */
+    int32_t min_read_bp_flank;        /* 5 germline & tumor; normal sample in somatic mode: 1
+                                         (L/starling_common/starling_base_shared.hh:108, strelka_shared.hh:159) */
+    double random_base_match_prob;    /* 0.25 germline, 0.5 somatic (starling_base_shared.hh:177, strelka_shared.hh:74) */
+    double tier2_random_base_match_prob; /* 0.25 (L/starling_common/Tier2Options.hh:50): used for every read of a tier2 pass */
+    double read_confident_support_threshold; /* 0.51 (starling_base_shared.hh:245) */
+    int32_t is_use_alt_indel;         /* 1 */
+} sk_indel_options;
+void sk_indel_options_default(sk_indel_options* opt, int is_somatic);
+
+/** indels -> reads (CSR): one row per (indel, sample); the per-read fields are ReadPathScores (L/starling_common/IndelData.hh:64-116) */
+typedef struct sk_readscore_batch {
+    int32_t n_indels;
+    const int64_t* read_off;      /* [n_indels+1] */
+    const float* ref_lnp;         /* ReadPathScores::ref */
+    const float* indel_lnp;       /* ReadPathScores::indel */
+    const float* alt_lnp;         /* max over ReadPathScores::alt_indel, NaN when the read has none; NULL = no alts */
+    const uint16_t* non_ambig;    /* nonAmbiguousBasesInRead */
+    const uint16_t* read_length;
+    const uint8_t* read_flags;    /* SK_READ_TIER1 | SK_READ_FWD */
+    const uint32_t* del_len;      /* [n_indels] IndelKey::delete_length() */
+    const uint32_t* ins_len;      /* [n_indels] IndelKey::insert_length() */
+    const uint8_t* is_breakpoint; /* [n_indels] or NULL */
+} sk_readscore_batch;
+
+/** a14 (likelihood half): the 21 somatic-grid states of one sample per indel: get_indel_digt_lhood
+ *  (L/starling_common/starling_indel_call_pprob_digt.cpp:240-336) + get_indel_het_grid_lhood
+ *  (L/applications/strelka/somatic_indel_grid.cpp:66-89).  out_lhood[n_indels][21], double. */
+int sk_indel_grid_lhood(const sk_readscore_batch* host_batch, const sk_indel_options* opt, int is_include_tier2,
+                        double* out_lhood);
+int sk_indel_grid_lhood_dev(const sk_readscore_batch* dev_batch, const sk_indel_options* opt, int is_include_tier2,
+                            double* dev_out_lhood, void* hip_stream);
+
+typedef struct sk_somatic_indel_options { /* L/applications/strelka/strelka_shared.hh:126-151, workflow .ini overrides */
+    double bindel_diploid_theta;      /* 1e-4 */
+    double somatic_indel_rate;        /* sindelPrior 1e-6 */
+    double shared_indel_error_factor; /* sindelNoiseFactor 2.2 */
+    double indel_contam_tolerance;    /* 0.15 */
+} sk_somatic_indel_options;
+void sk_somatic_indel_options_default(sk_somatic_indel_options* opt);
+
+typedef struct sk_somatic_indel_call { /* indel_result_set, somatic_result_set.hh:32-54 */
+    double normal_lhood[SK_SOM_PRESTRAND];
+    double tumor_lhood[SK_SOM_PRESTRAND];
+    uint32_t max_gt;
+    int32_t qphred;            /* QSI */
+    int32_t from_ntype_qphred; /* QSI_NT */
+    uint32_t ntype;
+} sk_somatic_indel_call;
+
+/** a14: replaces the likelihood + posterior part of somatic_indel_caller_grid::get_somatic_indel for one tier
+ *  (L/applications/strelka/somatic_indel_grid.cpp:243-291) at L/applications/strelka/strelka_pos_processor.cpp:343-349.
+ *  indel_to_ref_error_prob[n_indels]: tumorIndelSampleData.getErrorRates().indelToRefErrorProb (:273).
+ *  The multi-indel-allele filter (:102-177) and the tier combination (:293-361) stay with the host adapter. */
+int sk_somatic_indel_call_batch(const sk_readscore_batch* host_normal, const sk_readscore_batch* host_tumor,
+                                const sk_indel_options* normal_opt, const sk_indel_options* tumor_opt,
+                                const sk_somatic_indel_options* sopt, const double* indel_to_ref_error_prob,
+                                int is_include_tier2, sk_somatic_indel_call* out);
+
+/** allele groups -> reads (CSR): getVariantAlleleGroupGenotypeLhoodsForSample's input after the host adapter resolved
+ *  read ids (L/starling_common/AlleleGroupGenotype.cpp:185-258; empty contrast group) */
+typedef struct sk_allele_group_batch {
+    int32_t n_groups;
+    const int64_t* read_off;   /* [n_groups+1]; reads in ascending read-id order (std::set iteration order) */
+    const uint8_t* n_alt;      /* [n_groups] non-reference allele count, 1..SK_MAX_ALT */
+    const uint8_t* ploidy;     /* [n_groups] 1 or 2 */
+    const uint32_t* del_len;   /* [n_groups][SK_MAX_ALT] */
+    const uint32_t* ins_len;   /* [n_groups][SK_MAX_ALT] */
+    const float* ref_lnp;      /* [reads][SK_MAX_ALT] ReadPathScores::ref of the read in each allele's map */
+    const float* allele_lnp;   /* [reads][SK_MAX_ALT] ReadPathScores::indel; NaN = the read is not in that allele's map */
+    const uint16_t* non_ambig; /* [reads] */
+    const uint16_t* read_length;
+    const uint8_t* read_flags;
+} sk_allele_group_batch;
+
+typedef struct sk_allele_group_call {
+    double lhood[SK_MAX_INDEL_GT];           /* VcfGenotypeUtil::getGenotypeIndex order */
+    uint32_t counts[2][SK_MAX_ALT + 2];      /* [fwd,rev][ref, alt.., non-confident] LocusSupportingReadStats */
+    uint32_t n_genotypes;
+    uint32_t n_reads_used;
+} sk_allele_group_call;
+
+/** a11: replaces getVariantAlleleGroupGenotypeLhoodsForSample at L/applications/starling/starling_pos_processor.cpp:1384-1386 */
+int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* host_batch, const sk_indel_options* opt,
+                                    sk_allele_group_call* out);
+int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* dev_batch, const sk_indel_options* opt,
+                                        sk_allele_group_call* dev_out, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,3 +184,72 @@ def somatic_snv_call(normal, tumor, opt=None, is_forced_output=False):
     oracle().sko_somatic_snv_call_batch(_p(normal.call_off), _p(normal.calls), _p(tumor.call_off), _p(tumor.calls),
                                         _p(normal.ref_base), normal.n_loci, C.byref(opt), int(is_forced_output), _p(out))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# hot path B, indels
+
+def indel_grid_lhood(batch, min_read_bp_flank, random_base_match_prob, is_include_tier2, is_use_alt_indel=True):
+    """batch: strelka_amd.capi.HostReadScoreBatch -> float64 [n_indels][21] (pass the EFFECTIVE random-base-match
+    probability of the pass: the tier2 value for tier2 passes)."""
+    out = np.zeros((batch.n_indels, 21))
+    alt = batch.alt_lnp if batch.alt_lnp is not None else np.full(len(batch.ref_lnp), np.nan, np.float32)
+    for i in range(batch.n_indels):
+        s, e = int(batch.read_off[i]), int(batch.read_off[i + 1])
+        t1 = np.ascontiguousarray(batch.read_flags[s:e] & 1)
+        bp = 0 if batch.is_breakpoint is None else int(batch.is_breakpoint[i])
+        args = [np.ascontiguousarray(x[s:e]) for x in (batch.ref_lnp, batch.indel_lnp, alt, batch.non_ambig, batch.read_length)]
+        row = np.zeros(21)
+        oracle().sko_indel_grid_lhood(e - s, *[_p(x) for x in args], _p(t1), int(batch.del_len[i]), int(batch.ins_len[i]),
+                                      bp, int(min_read_bp_flank), C.c_double(random_base_match_prob),
+                                      int(is_include_tier2), int(is_use_alt_indel), _p(row))
+        out[i] = row
+    return out
+
+
+def somatic_indel_result(normal_lhood, tumor_lhood, indel_to_ref_error_prob, shared_indel_error_factor=2.2,
+                         indel_contam_tolerance=0.15, somatic_indel_rate=1e-6, bindel_diploid_theta=1e-4):
+    n = len(normal_lhood)
+    out = np.zeros(n, np.dtype([("max_gt", "<u4"), ("qphred", "<i4"), ("from_ntype_qphred", "<i4"), ("ntype", "<u4")]))
+    for i in range(n):
+        mg, q, fq, nt = C.c_uint32(), C.c_int32(), C.c_int32(), C.c_uint32()
+        nl = np.ascontiguousarray(normal_lhood[i], np.float64)
+        tl = np.ascontiguousarray(tumor_lhood[i], np.float64)
+        oracle().sko_somatic_indel_result(_p(nl), _p(tl), C.c_double(indel_to_ref_error_prob[i]),
+                                          C.c_double(shared_indel_error_factor), C.c_double(indel_contam_tolerance),
+                                          C.c_double(somatic_indel_rate), C.c_double(bindel_diploid_theta), C.byref(mg),
+                                          C.byref(q), C.byref(fq), C.byref(nt))
+        out[i] = (mg.value, q.value, fq.value, nt.value)
+    return out
+
+
+def allele_group_genotype_lhoods(batch, min_read_bp_flank=5, random_base_match_prob=0.25, threshold=0.51):
+    """batch: strelka_amd.capi.HostAlleleGroupBatch -> (lhood [n][10], counts [n][2][5], n_genotypes [n])"""
+    n = batch.n_groups
+    lh = np.zeros((n, 10))
+    counts = np.zeros((n, 2, 5), np.uint32)
+    ng = np.zeros(n, np.uint32)
+    for g in range(n):
+        s, e = int(batch.read_off[g]), int(batch.read_off[g + 1])
+        A = int(batch.n_alt[g])
+        pl = int(batch.ploidy[g])
+        G = A + 1 if pl == 1 else (A + 1) * (A + 2) // 2
+        refl = np.ascontiguousarray(batch.ref_lnp[s:e, :A])
+        al = np.ascontiguousarray(batch.allele_lnp[s:e, :A])
+        t1 = np.ascontiguousarray(batch.read_flags[s:e] & 1)
+        fw = np.ascontiguousarray((batch.read_flags[s:e] >> 1) & 1)
+        na = np.ascontiguousarray(batch.non_ambig[s:e])
+        rl = np.ascontiguousarray(batch.read_length[s:e])
+        dl = np.ascontiguousarray(batch.del_len[g, :A])
+        il = np.ascontiguousarray(batch.ins_len[g, :A])
+        ol = np.zeros(G)
+        oc = np.zeros(2 * (A + 2), np.uint32)
+        oracle().sko_allele_group_genotype_lhoods(e - s, A, _p(refl), _p(al), _p(na), _p(rl), _p(t1), _p(fw), _p(dl), _p(il),
+                                                  pl, int(min_read_bp_flank), C.c_double(random_base_match_prob),
+                                                  C.c_double(threshold), _p(ol), _p(oc))
+        lh[g, :G] = ol
+        oc = oc.reshape(2, A + 2)
+        counts[g, :, :A + 1] = oc[:, :A + 1]
+        counts[g, :, A + 1] = oc[:, A + 1]
+        ng[g] = G
+    return lh, counts, ng

@@ -19,6 +19,7 @@ HIP_SOURCES = [
     "csrc/germline_site.hip",
     "csrc/germline_fused.hip",
     "csrc/somatic_site.hip",
+    "csrc/indel_lhood.hip",
 ]
 HOST_SOURCES = [
     "host/align_flatten.cpp",
@@ -38,7 +39,7 @@ def _stale(target, deps):
 
 def build_all(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
-    deps = _sources() + [os.path.join(ROOT, "include", "strelka_amd.h"), os.path.join(PKG, "csrc", "sk_common.h"), os.path.join(PKG, "csrc", "germline_common.h"),
+    deps = _sources() + [os.path.join(ROOT, "include", "strelka_amd.h"), os.path.join(PKG, "csrc", "sk_common.h"), os.path.join(PKG, "csrc", "germline_common.h"), os.path.join(PKG, "csrc", "somatic_common.h"),
                          os.path.abspath(__file__)]
     if not force and not _stale(LIB_PATH, deps):
         return LIB_PATH

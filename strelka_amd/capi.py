@@ -60,6 +60,36 @@ class SomaticSnvOptions(C.Structure):
                 ("ssnv_contam_tolerance", C.c_double)]
 
 
+class IndelOptions(C.Structure):
+    _fields_ = [("min_read_bp_flank", C.c_int32), ("random_base_match_prob", C.c_double),
+                ("tier2_random_base_match_prob", C.c_double), ("read_confident_support_threshold", C.c_double),
+                ("is_use_alt_indel", C.c_int32)]
+
+
+class SomaticIndelOptions(C.Structure):
+    _fields_ = [("bindel_diploid_theta", C.c_double), ("somatic_indel_rate", C.c_double),
+                ("shared_indel_error_factor", C.c_double), ("indel_contam_tolerance", C.c_double)]
+
+
+class ReadScoreBatch(C.Structure):
+    _fields_ = [("n_indels", C.c_int32), ("read_off", c_void_p), ("ref_lnp", c_void_p), ("indel_lnp", c_void_p),
+                ("alt_lnp", c_void_p), ("non_ambig", c_void_p), ("read_length", c_void_p), ("read_flags", c_void_p),
+                ("del_len", c_void_p), ("ins_len", c_void_p), ("is_breakpoint", c_void_p)]
+
+
+class AlleleGroupBatch(C.Structure):
+    _fields_ = [("n_groups", C.c_int32), ("read_off", c_void_p), ("n_alt", c_void_p), ("ploidy", c_void_p),
+                ("del_len", c_void_p), ("ins_len", c_void_p), ("ref_lnp", c_void_p), ("allele_lnp", c_void_p),
+                ("non_ambig", c_void_p), ("read_length", c_void_p), ("read_flags", c_void_p)]
+
+
+MAX_ALT, MAX_INDEL_GT = 3, 10
+SOMATIC_INDEL_CALL_DTYPE = np.dtype([("normal_lhood", "<f8", (21,)), ("tumor_lhood", "<f8", (21,)), ("max_gt", "<u4"),
+                                     ("qphred", "<i4"), ("from_ntype_qphred", "<i4"), ("ntype", "<u4")])
+ALLELE_GROUP_CALL_DTYPE = np.dtype([("lhood", "<f8", (MAX_INDEL_GT,)), ("counts", "<u4", (2, MAX_ALT + 2)),
+                                    ("n_genotypes", "<u4"), ("n_reads_used", "<u4")])
+assert SOMATIC_INDEL_CALL_DTYPE.itemsize == 352 and ALLELE_GROUP_CALL_DTYPE.itemsize == 128
+
 DIGT_RS_DTYPE = np.dtype([("ref_pprob", "<f8"), ("max_gt", "<u4"), ("snp_qphred", "<i4"), ("max_gt_qphred", "<i4"),
                           ("_pad", "<i4")])
 DIGT_CALL_DTYPE = np.dtype([("lhood", "<f4", (10,)), ("phredLoghood", "<u4", (10,)), ("genome", DIGT_RS_DTYPE),
@@ -79,6 +109,8 @@ EXPORTS = [
     "sk_germline_options_default", "sk_dependent_eprob", "sk_dependent_eprob_dev", "sk_site_digt_call",
     "sk_site_digt_call_dev", "sk_site_digt_call_fused", "sk_site_digt_call_fused_dev",
     "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
+    "sk_indel_options_default", "sk_somatic_indel_options_default", "sk_indel_grid_lhood", "sk_indel_grid_lhood_dev",
+    "sk_somatic_indel_call_batch", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
 ]
 
 _lib = None
@@ -122,6 +154,14 @@ def lib():
                                                 C.POINTER(SomaticSnvOptions), C.c_int, c_void_p]
         L.sk_somatic_snv_call_batch_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(PileupBatch),
                                                     C.POINTER(SomaticSnvOptions), C.c_int, c_void_p, c_void_p]
+        L.sk_indel_grid_lhood.argtypes = [C.POINTER(ReadScoreBatch), C.POINTER(IndelOptions), C.c_int, c_void_p]
+        L.sk_indel_grid_lhood_dev.argtypes = [C.POINTER(ReadScoreBatch), C.POINTER(IndelOptions), C.c_int, c_void_p, c_void_p]
+        L.sk_somatic_indel_call_batch.argtypes = [C.POINTER(ReadScoreBatch), C.POINTER(ReadScoreBatch),
+                                                  C.POINTER(IndelOptions), C.POINTER(IndelOptions),
+                                                  C.POINTER(SomaticIndelOptions), c_void_p, C.c_int, c_void_p]
+        L.sk_allele_group_genotype_lhoods.argtypes = [C.POINTER(AlleleGroupBatch), C.POINTER(IndelOptions), c_void_p]
+        L.sk_allele_group_genotype_lhoods_dev.argtypes = [C.POINTER(AlleleGroupBatch), C.POINTER(IndelOptions), c_void_p,
+                                                          c_void_p]
         _lib = L
     return _lib
 
@@ -317,3 +357,90 @@ def make_call(q, base, fwd=1, nmm=0, filt=0, tscf=0):
     q, base, fwd, nmm, filt, tscf = [np.asarray(x, np.uint16) for x in (q, base, fwd, nmm, filt, tscf)]
     return ((q & 0x3f) | ((base & 0xf) << 6) | ((fwd & 1) << 10) | ((nmm & 1) << 11) | ((filt & 1) << 12) |
             ((tscf & 1) << 13)).astype(np.uint16)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# indels
+
+def indel_options(is_somatic=False):
+    o = IndelOptions()
+    lib().sk_indel_options_default(C.byref(o), int(is_somatic))
+    return o
+
+
+def somatic_indel_options():
+    o = SomaticIndelOptions()
+    lib().sk_somatic_indel_options_default(C.byref(o))
+    return o
+
+
+class HostReadScoreBatch:
+    def __init__(self, read_off, ref_lnp, indel_lnp, alt_lnp, non_ambig, read_length, read_flags, del_len, ins_len,
+                 is_breakpoint=None):
+        self.read_off = np.ascontiguousarray(read_off, np.int64)
+        self.ref_lnp = np.ascontiguousarray(ref_lnp, np.float32)
+        self.indel_lnp = np.ascontiguousarray(indel_lnp, np.float32)
+        self.alt_lnp = None if alt_lnp is None else np.ascontiguousarray(alt_lnp, np.float32)
+        self.non_ambig = np.ascontiguousarray(non_ambig, np.uint16)
+        self.read_length = np.ascontiguousarray(read_length, np.uint16)
+        self.read_flags = np.ascontiguousarray(read_flags, np.uint8)
+        self.del_len = np.ascontiguousarray(del_len, np.uint32)
+        self.ins_len = np.ascontiguousarray(ins_len, np.uint32)
+        self.is_breakpoint = None if is_breakpoint is None else np.ascontiguousarray(is_breakpoint, np.uint8)
+        self.n_indels = len(self.read_off) - 1
+
+    def struct(self):
+        return ReadScoreBatch(self.n_indels, _p(self.read_off), _p(self.ref_lnp), _p(self.indel_lnp), _p(self.alt_lnp),
+                              _p(self.non_ambig), _p(self.read_length), _p(self.read_flags), _p(self.del_len),
+                              _p(self.ins_len), _p(self.is_breakpoint))
+
+
+def indel_grid_lhood(batch, opt=None, is_include_tier2=False):
+    opt = opt or indel_options(True)
+    out = np.zeros((batch.n_indels, 21), np.float64)
+    s = batch.struct()
+    _check(lib().sk_indel_grid_lhood(C.byref(s), C.byref(opt), int(is_include_tier2), _p(out)))
+    return out
+
+
+def somatic_indel_call(normal, tumor, indel_to_ref_error_prob, normal_opt=None, tumor_opt=None, sopt=None,
+                       is_include_tier2=False):
+    if normal_opt is None:
+        normal_opt = indel_options(True)
+        normal_opt.min_read_bp_flank = 1
+    tumor_opt = tumor_opt or indel_options(True)
+    sopt = sopt or somatic_indel_options()
+    out = np.zeros(normal.n_indels, SOMATIC_INDEL_CALL_DTYPE)
+    err = np.ascontiguousarray(indel_to_ref_error_prob, np.float64)
+    sn, st = normal.struct(), tumor.struct()
+    _check(lib().sk_somatic_indel_call_batch(C.byref(sn), C.byref(st), C.byref(normal_opt), C.byref(tumor_opt),
+                                             C.byref(sopt), _p(err), int(is_include_tier2), _p(out)))
+    return out
+
+
+class HostAlleleGroupBatch:
+    def __init__(self, read_off, n_alt, ploidy, del_len, ins_len, ref_lnp, allele_lnp, non_ambig, read_length, read_flags):
+        self.read_off = np.ascontiguousarray(read_off, np.int64)
+        self.n_alt = np.ascontiguousarray(n_alt, np.uint8)
+        self.ploidy = np.ascontiguousarray(ploidy, np.uint8)
+        self.del_len = np.ascontiguousarray(del_len, np.uint32).reshape(-1, MAX_ALT)
+        self.ins_len = np.ascontiguousarray(ins_len, np.uint32).reshape(-1, MAX_ALT)
+        self.ref_lnp = np.ascontiguousarray(ref_lnp, np.float32).reshape(-1, MAX_ALT)
+        self.allele_lnp = np.ascontiguousarray(allele_lnp, np.float32).reshape(-1, MAX_ALT)
+        self.non_ambig = np.ascontiguousarray(non_ambig, np.uint16)
+        self.read_length = np.ascontiguousarray(read_length, np.uint16)
+        self.read_flags = np.ascontiguousarray(read_flags, np.uint8)
+        self.n_groups = len(self.read_off) - 1
+
+    def struct(self):
+        return AlleleGroupBatch(self.n_groups, _p(self.read_off), _p(self.n_alt), _p(self.ploidy), _p(self.del_len),
+                                _p(self.ins_len), _p(self.ref_lnp), _p(self.allele_lnp), _p(self.non_ambig),
+                                _p(self.read_length), _p(self.read_flags))
+
+
+def allele_group_genotype_lhoods(batch, opt=None):
+    opt = opt or indel_options(False)
+    out = np.zeros(batch.n_groups, ALLELE_GROUP_CALL_DTYPE)
+    s = batch.struct()
+    _check(lib().sk_allele_group_genotype_lhoods(C.byref(s), C.byref(opt), _p(out)))
+    return out

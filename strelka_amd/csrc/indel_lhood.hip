@@ -1,0 +1,594 @@
+// indel_lhood.hip -- hot path B (indels): reductions over IndelSampleData::read_path_lnp.
+//
+//   I1 `indel_grid_lhood_kernel`      : get_indel_digt_lhood (L/starling_common/starling_indel_call_pprob_digt.cpp:240-336)
+//                                       + get_indel_het_grid_lhood (L/applications/strelka/somatic_indel_grid.cpp:66-89)
+//                                       = the 21 somatic-grid states of one sample per indel
+//   I2 `somatic_indel_posterior_kernel`: float cast + calculate_result_set_grid with the indel priors
+//                                       (somatic_indel_grid.cpp:264-287, qscore_calculator.cpp:47-209)
+//   I3 `allele_group_kernel`          : getVariantAlleleGroupGenotypeLhoodsForSample
+//                                       (L/starling_common/AlleleGroupGenotype.cpp:185-258)
+//
+// Mapping: one 64-lane wavefront per indel / allele group.  The reference adds one double term per read to each state
+// (sequentially, in read-id order); the TERMS are independent, so lanes evaluate them for 64 reads at a time (each costs
+// several exp/log/log1p evaluations) into LDS, then one lane per state performs the adds in read order -- the order
+// and rounding of every add is the reference's.
+//
+// Double exp/log/log1p are the device library's; they differ from glibc's in the last ulp now and then, so likelihoods
+// agree with the oracle to ~1e-15 relative, not bit-for-bit.
+
+#include "somatic_common.h"
+
+#include <vector>
+
+namespace
+{
+
+constexpr int WAVE = 64;
+constexpr int N_STATES = 21;
+
+// log1p_switch / getLogSum, L/blt_util/math_util.hh:33-48, L/blt_util/logSumUtil.hh:33-41 (double)
+__device__ __forceinline__ double log1p_switch_d(const double x) { return (fabs(x) < 0.01) ? log1p(x) : log(__dadd_rn(1., x)); }
+__device__ __forceinline__ double log_sum2(double x1, double x2)
+{
+    if (x1 < x2) {
+        const double t = x1;
+        x1 = x2;
+        x2 = t;
+    }
+    return __dadd_rn(x1, log1p_switch_d(exp(__dsub_rn(x2, x1))));
+}
+
+struct MapParams
+{
+    double correct_mapping_log_prior; // log(1.7e-10), starling_base_shared.cpp:64
+    double random_base_match_log_prob; // log(randomBaseMatchProb) of the pass (tier2 passes use the tier2 value)
+};
+
+// integrateOutMappingStatus, L/starling_common/readMappingAdjustmentUtil.hh:29-56
+__device__ __forceinline__ double integrate_out_mapping(const MapParams& m, const unsigned non_ambig, const double lnp)
+{
+    return log_sum2(__dadd_rn(lnp, m.correct_mapping_log_prior), __dmul_rn(m.random_base_match_log_prob, double(non_ambig)));
+}
+
+// get_het_observed_allele_ratio, starling_indel_call_pprob_digt.cpp:40-71
+__device__ __forceinline__ void het_observed_allele_ratio(const unsigned read_length, const unsigned min_overlap,
+                                                          const unsigned del_len, const unsigned ins_len,
+                                                          const double het_allele_ratio, double& log_ref_prob,
+                                                          double& log_indel_prob)
+{
+    const unsigned base_expect = ((read_length + 1) < (2 * min_overlap)) ? 0 : (read_length + 1) - (2 * min_overlap);
+    const double ref_path_expect = double(base_expect + min(del_len, base_expect));
+    const double indel_path_expect = double(base_expect + min(ins_len, base_expect));
+    const double ref_path_term = __dmul_rn(__dsub_rn(1., het_allele_ratio), ref_path_expect);
+    const double indel_path_term = __dmul_rn(het_allele_ratio, indel_path_expect);
+    const double total_path_term = __dadd_rn(ref_path_term, indel_path_term);
+    if (total_path_term > 0) {
+        const double indel_prob = __ddiv_rn(indel_path_term, total_path_term);
+        log_ref_prob = log(__dsub_rn(1., indel_prob));
+        log_indel_prob = log(indel_prob);
+    }
+}
+
+struct GridArgs
+{
+    sk_readscore_batch b;
+    MapParams map;
+    int min_read_bp_flank;
+    int is_include_tier2;
+    int is_use_alt_indel;
+    double* out; // [n_indels][21]
+    double het_ratio[SK_HET_RES], chet_ratio[SK_HET_RES], log_het_ratio[SK_HET_RES], log_chet_ratio[SK_HET_RES];
+    double loghalf;
+};
+
+__global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a)
+{
+    __shared__ double s_term[N_STATES][WAVE];
+    const int ind = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t r0 = a.b.read_off[ind];
+    const int n = int(a.b.read_off[ind + 1] - r0);
+    const unsigned del_len = a.b.del_len[ind], ins_len = a.b.ins_len[ind];
+    const bool is_breakpoint = a.b.is_breakpoint ? (a.b.is_breakpoint[ind] != 0) : false;
+    const unsigned flank = unsigned(a.min_read_bp_flank);
+
+    double acc = 0.; // lanes 0..20: the running sum of state `lane`
+    for (int base = 0; base < n; base += WAVE) {
+        const int r = base + lane;
+        const int cnt = min(WAVE, n - base);
+        if (r < n) {
+            const int64_t g = r0 + r;
+            const unsigned flags = a.b.read_flags[g];
+            const bool use = a.is_include_tier2 || (flags & SK_READ_TIER1);
+            if (!use) {
+#pragma unroll
+                for (int s = 0; s < N_STATES; ++s) s_term[s][lane] = 0.; // skipped read: x + 0.0 == x
+            } else {
+                double alt_path_lnp = double(a.b.ref_lnp[g]);
+                if (a.is_use_alt_indel && a.b.alt_lnp) {
+                    const float al = a.b.alt_lnp[g];
+                    if (al == al && double(al) > alt_path_lnp) alt_path_lnp = double(al);
+                }
+                const double noindel_lnp = alt_path_lnp;
+                const double hom_lnp = double(a.b.indel_lnp[g]);
+                const unsigned na = a.b.non_ambig[g];
+                const unsigned rl = a.b.read_length[g];
+                // SOMATIC_DIGT / STAR_DIINDEL: 0 = REF/NOINDEL, 1 = HOM, 2 = HET
+                s_term[0][lane] = integrate_out_mapping(a.map, na, noindel_lnp);
+                s_term[1][lane] = integrate_out_mapping(a.map, na, hom_lnp);
+                {
+                    double lr = a.loghalf, li = a.loghalf;
+                    if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, 0.5, lr, li);
+                    s_term[2][lane] = integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li)));
+                }
+                for (int i = 0; i < SK_HET_RES; ++i) {
+                    { // het_lhood_low -> grid[i]
+                        double lr = a.log_chet_ratio[i], li = a.log_het_ratio[i];
+                        if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, a.het_ratio[i], lr, li);
+                        s_term[3 + i][lane] =
+                            integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li)));
+                    }
+                    { // het_lhood_high -> grid[2*HET_RES-(i+1)]
+                        double lr = a.log_het_ratio[i], li = a.log_chet_ratio[i];
+                        if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, a.chet_ratio[i], lr, li);
+                        s_term[3 + (2 * SK_HET_RES - (i + 1))][lane] =
+                            integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li)));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (lane < N_STATES)
+            for (int j = 0; j < cnt; ++j) acc = __dadd_rn(acc, s_term[lane][j]);
+        __syncthreads();
+    }
+    if (lane < N_STATES) a.out[size_t(ind) * N_STATES + lane] = acc;
+}
+
+struct PostArgs
+{
+    const double* normal_lhood; // [n][21]
+    const double* tumor_lhood;
+    const float* ln_sse;  // [n] (float) log(indelToRef^factor)
+    const float* ln_csse; // [n] (float) log1p_switch(-indelToRef^factor)
+    sk_somatic_indel_call* out;
+    int n;
+    SomaticDerived d;
+};
+
+__global__ void somatic_indel_posterior_kernel(const PostArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    sk_somatic_indel_call res;
+    float nf[30], tf[30];
+#pragma unroll
+    for (int j = 0; j < N_STATES; ++j) {
+        res.normal_lhood[j] = a.normal_lhood[size_t(i) * N_STATES + j];
+        res.tumor_lhood[j] = a.tumor_lhood[size_t(i) * N_STATES + j];
+        nf[j] = static_cast<float>(res.normal_lhood[j]); // "temporary solution" float cast, somatic_indel_grid.cpp:264-270
+        tf[j] = static_cast<float>(res.tumor_lhood[j]);
+    }
+    SomaticDerived d = a.d;
+    d.ln_sse_rate = a.ln_sse[i];
+    d.ln_csse_rate = a.ln_csse[i];
+    calculate_result_set_grid(d, nf, tf, res);
+    a.out[i] = res;
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+
+struct GroupArgs
+{
+    sk_allele_group_batch b;
+    MapParams map;
+    int min_read_bp_flank;
+    double support_threshold;
+    double loghalf;
+    sk_allele_group_call* out;
+};
+
+__global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
+{
+    __shared__ double s_term[SK_MAX_INDEL_GT][WAVE];
+    __shared__ unsigned char s_support[WAVE]; // 0xff = read not used; else fwd<<4 | (allele index, or 15 = non-confident)
+    const int grp = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t r0 = a.b.read_off[grp];
+    const int n = int(a.b.read_off[grp + 1] - r0);
+    const int n_alt = a.b.n_alt[grp];
+    const int ploidy = a.b.ploidy[grp];
+    const int full = n_alt + 1;
+    const int gcount = (ploidy == 1) ? full : full * (full + 1) / 2;
+    const unsigned flank = unsigned(a.min_read_bp_flank);
+    unsigned del_len[SK_MAX_ALT], ins_len[SK_MAX_ALT];
+#pragma unroll
+    for (int k = 0; k < SK_MAX_ALT; ++k) {
+        del_len[k] = a.b.del_len[size_t(grp) * SK_MAX_ALT + k];
+        ins_len[k] = a.b.ins_len[size_t(grp) * SK_MAX_ALT + k];
+    }
+
+    double acc = 0.;
+    unsigned cnt_f[SK_MAX_ALT + 2], cnt_r[SK_MAX_ALT + 2]; // lane 0 only
+#pragma unroll
+    for (int k = 0; k < SK_MAX_ALT + 2; ++k) cnt_f[k] = cnt_r[k] = 0;
+    unsigned used = 0;
+
+    for (int base = 0; base < n; base += WAVE) {
+        const int r = base + lane;
+        const int cnt = min(WAVE, n - base);
+        if (r < n) {
+            const int64_t g = r0 + r;
+            const unsigned flags = a.b.read_flags[g];
+            // intersection of the tier1 reads scored for every allele (OrthogonalVariantAlleleCandidateGroupUtil.cpp:64-113)
+            bool use = (flags & SK_READ_TIER1) != 0;
+            double L[SK_MAX_ALT + 1];
+            L[0] = 0.;
+#pragma unroll
+            for (int k = 0; k < SK_MAX_ALT; ++k) {
+                L[k + 1] = 0.;
+                if (k < n_alt) {
+                    const float s = a.b.allele_lnp[g * SK_MAX_ALT + k];
+                    if (!(s == s)) use = false;
+                    const double rl = double(a.b.ref_lnp[g * SK_MAX_ALT + k]);
+                    L[0] = (k == 0) ? rl : ((L[0] < rl) ? rl : L[0]); // getAlleleLogLhoodFromRead :159-167
+                    L[k + 1] = double(s);
+                }
+            }
+            if (!use) {
+#pragma unroll
+                for (int gi = 0; gi < SK_MAX_INDEL_GT; ++gi) s_term[gi][lane] = 0.;
+                s_support[lane] = 0xff;
+            } else {
+                const unsigned na = a.b.non_ambig[g];
+                const unsigned rlen = a.b.read_length[g];
+                // updateGenotypeLogLhoodFromAlleleLogLhood, AlleleGroupGenotype.cpp:36-114
+                if (ploidy == 1) {
+#pragma unroll
+                    for (int a0 = 0; a0 <= SK_MAX_ALT; ++a0)
+                        if (a0 < full) s_term[a0][lane] = integrate_out_mapping(a.map, na, L[a0]);
+                } else {
+#pragma unroll
+                    for (int a1 = 0; a1 <= SK_MAX_ALT; ++a1) {
+#pragma unroll
+                        for (int a0 = 0; a0 <= a1; ++a0) {
+                            if (a1 >= full) continue;
+                            const int gi = a0 + (a1 * (a1 + 1) / 2);
+                            double raw;
+                            if (a0 != a1) {
+                                double lp0 = a.loghalf, lp1 = a.loghalf;
+                                het_observed_allele_ratio(rlen, flank, del_len[a1 - 1], ins_len[a1 - 1], 0.5, lp0, lp1);
+                                if (a0 > 0) {
+                                    double log_ref_prior = a.loghalf;
+                                    lp0 = a.loghalf;
+                                    het_observed_allele_ratio(rlen, flank, del_len[a0 - 1], ins_len[a0 - 1], 0.5, log_ref_prior, lp0);
+                                    const double norm = log_sum2(lp0, lp1);
+                                    lp0 = __dsub_rn(lp0, norm);
+                                    lp1 = __dsub_rn(lp1, norm);
+                                }
+                                raw = log_sum2(__dadd_rn(L[a0], lp0), __dadd_rn(L[a1], lp1));
+                            } else {
+                                raw = L[a0];
+                            }
+                            s_term[gi][lane] = integrate_out_mapping(a.map, na, raw);
+                        }
+                    }
+                }
+                // updateSupportingReadStats, :125-155 (normalizeLogDistro: first maximum, exp, 1/sum)
+                double Lm[SK_MAX_ALT + 1];
+                double mx = 0.;
+#pragma unroll
+                for (int k = 0; k <= SK_MAX_ALT; ++k) {
+                    Lm[k] = (k < full) ? integrate_out_mapping(a.map, na, L[k]) : 0.;
+                    if (k < full) mx = (k == 0) ? Lm[0] : ((Lm[k] > mx) ? Lm[k] : mx);
+                }
+                double sum = 0.;
+#pragma unroll
+                for (int k = 0; k <= SK_MAX_ALT; ++k)
+                    if (k < full) {
+                        Lm[k] = exp(__dsub_rn(Lm[k], mx));
+                        sum = __dadd_rn(sum, Lm[k]);
+                    }
+                sum = __ddiv_rn(1., sum);
+                unsigned which = 15;
+#pragma unroll
+                for (int k = SK_MAX_ALT; k >= 0; --k)
+                    if (k < full && !(__dmul_rn(Lm[k], sum) < a.support_threshold)) which = unsigned(k); // first such allele
+                s_support[lane] = (unsigned char)(((flags & SK_READ_FWD) ? 0x10 : 0) | which);
+            }
+        }
+        __syncthreads();
+        if (lane < gcount)
+            for (int j = 0; j < cnt; ++j) acc = __dadd_rn(acc, s_term[lane][j]);
+        if (lane == 0) {
+            for (int j = 0; j < cnt; ++j) {
+                const unsigned s = s_support[j];
+                if (s == 0xff) continue;
+                ++used;
+                const unsigned which = s & 15u;
+                const unsigned slot = (which == 15u) ? unsigned(n_alt + 1) : which;
+#pragma unroll
+                for (unsigned k = 0; k < SK_MAX_ALT + 2; ++k) {
+                    if (k == slot) {
+                        if (s & 0x10) ++cnt_f[k]; else ++cnt_r[k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    sk_allele_group_call* o = a.out + grp;
+    if (lane < SK_MAX_INDEL_GT) o->lhood[lane] = (lane < gcount) ? acc : 0.;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < SK_MAX_ALT + 2; ++k) {
+            o->counts[0][k] = cnt_f[k];
+            o->counts[1][k] = cnt_r[k];
+        }
+        o->n_genotypes = unsigned(gcount);
+        o->n_reads_used = used;
+    }
+}
+
+double h_log1p_switch(const double x)
+{
+    if (std::abs(x) < 0.01) return ::log1p(x);
+    return std::log(1 + x);
+}
+
+MapParams make_map(const sk_indel_options& opt, const bool tier2_pass)
+{
+    MapParams m;
+    volatile double p = 1.7e-10;
+    m.correct_mapping_log_prior = std::log(p);
+    volatile double rb = tier2_pass ? opt.tier2_random_base_match_prob : opt.random_base_match_prob;
+    m.random_base_match_log_prob = std::log(rb);
+    return m;
+}
+
+} // namespace
+
+extern "C" {
+
+void sk_indel_options_default(sk_indel_options* opt, int is_somatic)
+{
+    opt->min_read_bp_flank = 5;
+    opt->random_base_match_prob = is_somatic ? 0.5 : 0.25;
+    opt->tier2_random_base_match_prob = 0.25;
+    opt->read_confident_support_threshold = 0.51;
+    opt->is_use_alt_indel = 1;
+}
+
+void sk_somatic_indel_options_default(sk_somatic_indel_options* opt)
+{
+    opt->bindel_diploid_theta = 1e-4;
+    opt->somatic_indel_rate = 1e-6;
+    opt->shared_indel_error_factor = 2.2;
+    opt->indel_contam_tolerance = 0.15;
+}
+
+int sk_indel_grid_lhood_dev(const sk_readscore_batch* b, const sk_indel_options* opt, int is_include_tier2,
+                            double* dev_out_lhood, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (!b || !opt || !dev_out_lhood) return sk_fail("sk_indel_grid_lhood_dev: null argument");
+    if (b->n_indels <= 0) return 0;
+    GridArgs a;
+    a.b = *b;
+    a.map = make_map(*opt, is_include_tier2 != 0);
+    a.min_read_bp_flank = opt->min_read_bp_flank;
+    a.is_include_tier2 = is_include_tier2 ? 1 : 0;
+    a.is_use_alt_indel = opt->is_use_alt_indel ? 1 : 0;
+    a.out = dev_out_lhood;
+    const float RATIO_INCREMENT = 0.5f / static_cast<float>(SK_HET_RES + 1);
+    for (unsigned i = 0; i < SK_HET_RES; ++i) {
+        // get_indel_het_grid_lhood :79 / get_high_low_het_ratio_lhood :88-91
+        const double het_ratio((i + 1) * RATIO_INCREMENT);
+        volatile double hr = het_ratio;
+        const double chet_ratio(1. - hr);
+        volatile double chr = chet_ratio;
+        a.het_ratio[i] = hr;
+        a.chet_ratio[i] = chet_ratio;
+        a.log_het_ratio[i] = std::log(hr);
+        a.log_chet_ratio[i] = std::log(chr);
+    }
+    volatile double two = 2.;
+    a.loghalf = -std::log(two); // :251
+    hipLaunchKernelGGL(indel_grid_lhood_kernel, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+static int upload_readscores(const sk_readscore_batch* hb, SkArena& ar, sk_readscore_batch& d, hipStream_t st)
+{
+    const int n = hb->n_indels;
+    if (hb->read_off[0] != 0) return sk_fail("readscore batch: read_off must start at 0");
+    const int64_t tr = hb->read_off[n];
+    d = *hb;
+#define UPA(field, T, count, optional)                                                                  \
+    if (hb->field) {                                                                                    \
+        T* p = ar.take<T>(count);                                                                       \
+        if (count) SK_HIP(hipMemcpyAsync(p, hb->field, sizeof(T) * (count), hipMemcpyHostToDevice, st)); \
+        d.field = p;                                                                                    \
+    } else if (!(optional)) {                                                                           \
+        return sk_fail("readscore batch: missing array " #field);                                      \
+    }
+    UPA(read_off, int64_t, size_t(n + 1), false);
+    UPA(ref_lnp, float, size_t(tr), false);
+    UPA(indel_lnp, float, size_t(tr), false);
+    UPA(alt_lnp, float, size_t(tr), true);
+    UPA(non_ambig, uint16_t, size_t(tr), false);
+    UPA(read_length, uint16_t, size_t(tr), false);
+    UPA(read_flags, uint8_t, size_t(tr), false);
+    UPA(del_len, uint32_t, size_t(n), false);
+    UPA(ins_len, uint32_t, size_t(n), false);
+    UPA(is_breakpoint, uint8_t, size_t(n), true);
+#undef UPA
+    return 0;
+}
+
+static size_t readscore_bytes(const sk_readscore_batch* hb)
+{
+    const int64_t tr = hb->read_off[hb->n_indels];
+    return sk_align256(8 * (hb->n_indels + 1)) + 3 * sk_align256(4 * tr) + 2 * sk_align256(2 * tr) + sk_align256(tr) +
+           2 * sk_align256(4 * hb->n_indels) + sk_align256(hb->n_indels) + 16 * 256;
+}
+
+int sk_indel_grid_lhood(const sk_readscore_batch* hb, const sk_indel_options* opt, int is_include_tier2, double* out_lhood)
+{
+    SK_REQUIRE_INIT();
+    if (!hb || !opt || !out_lhood) return sk_fail("sk_indel_grid_lhood: null argument");
+    if (hb->n_indels <= 0) return 0;
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    SkArena ar;
+    const size_t out_bytes = sizeof(double) * N_STATES * size_t(hb->n_indels);
+    if (ar.reserve(readscore_bytes(hb) + sk_align256(out_bytes) + 1024)) return 1;
+    sk_readscore_batch d;
+    if (upload_readscores(hb, ar, d, ctx.stream)) return 1;
+    double* dout = ar.take<double>(size_t(hb->n_indels) * N_STATES);
+    if (sk_indel_grid_lhood_dev(&d, opt, is_include_tier2, dout, ctx.stream)) return 1;
+    SK_HIP(hipMemcpyAsync(out_lhood, dout, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
+int sk_somatic_indel_call_batch(const sk_readscore_batch* hn, const sk_readscore_batch* ht, const sk_indel_options* nopt,
+                                const sk_indel_options* topt, const sk_somatic_indel_options* sopt,
+                                const double* indel_to_ref_error_prob, int is_include_tier2, sk_somatic_indel_call* out)
+{
+    SK_REQUIRE_INIT();
+    if (!hn || !ht || !nopt || !topt || !sopt || !indel_to_ref_error_prob || !out)
+        return sk_fail("sk_somatic_indel_call_batch: null argument");
+    if (hn->n_indels != ht->n_indels) return sk_fail("sk_somatic_indel_call_batch: normal/tumor n_indels differ");
+    const int n = hn->n_indels;
+    if (n <= 0) return 0;
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    SkArena ar;
+    const size_t lh_bytes = sizeof(double) * N_STATES * size_t(n);
+    if (ar.reserve(readscore_bytes(hn) + readscore_bytes(ht) + 2 * sk_align256(lh_bytes) + 2 * sk_align256(4 * n) +
+                   sk_align256(sizeof(sk_somatic_indel_call) * n) + 4096))
+        return 1;
+    sk_readscore_batch dn, dt;
+    if (upload_readscores(hn, ar, dn, ctx.stream) || upload_readscores(ht, ar, dt, ctx.stream)) return 1;
+    double* dnl = ar.take<double>(size_t(n) * N_STATES);
+    double* dtl = ar.take<double>(size_t(n) * N_STATES);
+    if (sk_indel_grid_lhood_dev(&dn, nopt, is_include_tier2, dnl, ctx.stream)) return 1;
+    if (sk_indel_grid_lhood_dev(&dt, topt, is_include_tier2, dtl, ctx.stream)) return 1;
+
+    // per-indel shared error rate, host libm (somatic_indel_grid.cpp:273-275)
+    std::vector<float> ln_sse(n), ln_csse(n);
+    for (int i = 0; i < n; ++i) {
+        const double sharedIndelErrorRate(std::pow(indel_to_ref_error_prob[i], sopt->shared_indel_error_factor));
+        ln_sse[i] = (float)std::log(sharedIndelErrorRate);
+        ln_csse[i] = (float)h_log1p_switch(-sharedIndelErrorRate);
+    }
+    float* dsse = ar.take<float>(n);
+    float* dcsse = ar.take<float>(n);
+    SK_HIP(hipMemcpyAsync(dsse, ln_sse.data(), 4 * n, hipMemcpyHostToDevice, ctx.stream));
+    SK_HIP(hipMemcpyAsync(dcsse, ln_csse.data(), 4 * n, hipMemcpyHostToDevice, ctx.stream));
+    sk_somatic_indel_call* dout = ar.take<sk_somatic_indel_call>(n);
+
+    PostArgs p;
+    p.normal_lhood = dnl;
+    p.tumor_lhood = dtl;
+    p.ln_sse = dsse;
+    p.ln_csse = dcsse;
+    p.out = dout;
+    p.n = n;
+    std::memset(&p.d, 0, sizeof(p.d));
+    // somatic_indel_caller_grid ctor, somatic_indel_grid.cpp:58-64
+    p.d.contam_tolerance = (float)sopt->indel_contam_tolerance;
+    p.d.ln_som_match = h_log1p_switch(-sopt->somatic_indel_rate);
+    p.d.ln_som_mismatch = std::log(sopt->somatic_indel_rate);
+    p.d.lnprior[SOM_REF] = (float)h_log1p_switch(-(3. * sopt->bindel_diploid_theta) / 2.);
+    p.d.lnprior[SOM_HOM] = (float)std::log(sopt->bindel_diploid_theta / 2.);
+    p.d.lnprior[SOM_HET] = (float)std::log(sopt->bindel_diploid_theta);
+    {
+        volatile double half = 1. / 2., pm1 = static_cast<double>(PRESTRAND - 1);
+        p.d.ln_one_half = std::log(half);
+        p.d.log_error_mod = -std::log(pm1);
+        const float RATIO_INCREMENT = 0.5f / static_cast<float>(HET_RES + 1);
+        for (int index = 0; index < PRESTRAND; ++index) {
+            float f;
+            if (index == SOM_REF) f = 0.f;
+            else if (index == SOM_HOM) f = 1.f;
+            else if (index == SOM_HET) f = 0.5f;
+            else if (index < SOM_SIZE + HET_RES) f = RATIO_INCREMENT * (index - SOM_SIZE + 1);
+            else f = RATIO_INCREMENT * (index - SOM_SIZE + 2);
+            p.d.grid_frac[index] = f;
+        }
+    }
+    hipLaunchKernelGGL(somatic_indel_posterior_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx.stream, p);
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_indel_call) * n, hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
+int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* b, const sk_indel_options* opt,
+                                        sk_allele_group_call* dev_out, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (!b || !opt || !dev_out) return sk_fail("sk_allele_group_genotype_lhoods_dev: null argument");
+    if (b->n_groups <= 0) return 0;
+    GroupArgs a;
+    a.b = *b;
+    a.map = make_map(*opt, false); // isTier2Pass(false), AlleleGroupGenotype.cpp:46
+    a.min_read_bp_flank = opt->min_read_bp_flank;
+    a.support_threshold = opt->read_confident_support_threshold;
+    volatile double half = 0.5;
+    a.loghalf = std::log(half); // :75
+    a.out = dev_out;
+    hipLaunchKernelGGL(allele_group_kernel, dim3(b->n_groups), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* hb, const sk_indel_options* opt, sk_allele_group_call* out)
+{
+    SK_REQUIRE_INIT();
+    if (!hb || !opt || !out) return sk_fail("sk_allele_group_genotype_lhoods: null argument");
+    const int n = hb->n_groups;
+    if (n <= 0) return 0;
+    if (hb->read_off[0] != 0) return sk_fail("allele group batch: read_off must start at 0");
+    for (int g = 0; g < n; ++g) {
+        if (hb->n_alt[g] < 1 || hb->n_alt[g] > SK_MAX_ALT) return sk_fail("allele group batch: n_alt must be 1..SK_MAX_ALT");
+        if (hb->ploidy[g] != 1 && hb->ploidy[g] != 2) return sk_fail("Unexpected ploidy value"); // AlleleGroupGenotype.cpp:112
+    }
+    const int64_t tr = hb->read_off[n];
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    SkArena ar;
+    if (ar.reserve(sk_align256(8 * (n + 1)) + 2 * sk_align256(n) + 2 * sk_align256(4 * SK_MAX_ALT * n) +
+                   2 * sk_align256(4 * SK_MAX_ALT * tr) + 2 * sk_align256(2 * tr) + sk_align256(tr) +
+                   sk_align256(sizeof(sk_allele_group_call) * n) + 16 * 256))
+        return 1;
+    sk_allele_group_batch d = *hb;
+    hipStream_t st = ctx.stream;
+#define UPG(field, T, count)                                                                            \
+    {                                                                                                   \
+        T* p = ar.take<T>(count);                                                                       \
+        if (count) SK_HIP(hipMemcpyAsync(p, hb->field, sizeof(T) * (count), hipMemcpyHostToDevice, st)); \
+        d.field = p;                                                                                    \
+    }
+    UPG(read_off, int64_t, size_t(n + 1));
+    UPG(n_alt, uint8_t, size_t(n));
+    UPG(ploidy, uint8_t, size_t(n));
+    UPG(del_len, uint32_t, size_t(n) * SK_MAX_ALT);
+    UPG(ins_len, uint32_t, size_t(n) * SK_MAX_ALT);
+    UPG(ref_lnp, float, size_t(tr) * SK_MAX_ALT);
+    UPG(allele_lnp, float, size_t(tr) * SK_MAX_ALT);
+    UPG(non_ambig, uint16_t, size_t(tr));
+    UPG(read_length, uint16_t, size_t(tr));
+    UPG(read_flags, uint8_t, size_t(tr));
+#undef UPG
+    sk_allele_group_call* dout = ar.take<sk_allele_group_call>(n);
+    if (sk_allele_group_genotype_lhoods_dev(&d, opt, dout, st)) return 1;
+    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_allele_group_call) * n, hipMemcpyDeviceToHost, st));
+    SK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+} // extern "C"

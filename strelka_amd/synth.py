@@ -308,3 +308,49 @@ def align_cases_h64(n_reads, rng, L=150, K=6, win=400, ref_offset=0, noncand_rat
             cals.append(dict(pos=ref_offset + start, path=path, indels=used, leading=None, trailing=None))
         out.append(dict(read_code=read, read_qual=q.astype(np.uint8), ref_seq=ref_seq, ref_offset=ref_offset, cals=cals))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# input D: per-(indel, read) ReadPathScores
+
+def _read_fields(total, rng, tier1_rate=0.9):
+    non_ambig = rng.integers(60, 151, total).astype(np.uint16)
+    read_length = np.where(rng.random(total) < 0.85, 150, rng.integers(8, 200, total)).astype(np.uint16)
+    flags = ((rng.random(total) < tier1_rate).astype(np.uint8) * 1) | (rng.integers(0, 2, total).astype(np.uint8) * 2)
+    return non_ambig, read_length, flags.astype(np.uint8)
+
+
+def readscore_batch(n_indels, rng, depth_mean=40.0, alt_rate=0.2, breakpoint_rate=0.0):
+    """ref, indel ~ N(-5,3) clipped at 0 (SURVEY.md 8d input D), some reads with an alternate-indel score."""
+    depth = rng.poisson(depth_mean, n_indels).astype(np.int64)
+    off = np.zeros(n_indels + 1, np.int64)
+    np.cumsum(depth, out=off[1:])
+    total = int(off[-1])
+    ref = np.minimum(0, rng.normal(-5, 3, total)).astype(np.float32)
+    ind = np.minimum(0, rng.normal(-5, 3, total)).astype(np.float32)
+    alt = np.where(rng.random(total) < alt_rate, np.minimum(0, rng.normal(-4, 3, total)), np.nan).astype(np.float32)
+    na, rl, fl = _read_fields(total, rng)
+    is_del = rng.random(n_indels) < 0.5
+    ln = rng.integers(1, 30, n_indels)
+    del_len = np.where(is_del, ln, 0).astype(np.uint32)
+    ins_len = np.where(is_del, np.where(rng.random(n_indels) < 0.1, rng.integers(1, 5, n_indels), 0), ln).astype(np.uint32)
+    bp = (rng.random(n_indels) < breakpoint_rate).astype(np.uint8) if breakpoint_rate > 0 else None
+    return capi.HostReadScoreBatch(off, ref, ind, alt, na, rl, fl, del_len, ins_len, bp)
+
+
+def allele_group_batch(n_groups, rng, depth_mean=40.0, missing_rate=0.05):
+    depth = rng.poisson(depth_mean, n_groups).astype(np.int64)
+    off = np.zeros(n_groups + 1, np.int64)
+    np.cumsum(depth, out=off[1:])
+    total = int(off[-1])
+    n_alt = rng.integers(1, capi.MAX_ALT + 1, n_groups).astype(np.uint8)
+    ploidy = rng.choice(np.array([1, 2, 2, 2], np.uint8), n_groups)
+    is_del = rng.random((n_groups, capi.MAX_ALT)) < 0.5
+    ln = rng.integers(1, 30, (n_groups, capi.MAX_ALT))
+    del_len = np.where(is_del, ln, 0).astype(np.uint32)
+    ins_len = np.where(is_del, 0, ln).astype(np.uint32)
+    refl = np.minimum(0, rng.normal(-5, 3, (total, capi.MAX_ALT))).astype(np.float32)
+    al = np.minimum(0, rng.normal(-5, 3, (total, capi.MAX_ALT))).astype(np.float32)
+    al = np.where(rng.random((total, capi.MAX_ALT)) < missing_rate, np.nan, al).astype(np.float32)
+    na, rl, fl = _read_fields(total, rng)
+    return capi.HostAlleleGroupBatch(off, n_alt, ploidy, del_len, ins_len, refl, al, na, rl, fl)

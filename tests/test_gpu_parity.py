@@ -267,3 +267,72 @@ def test_pileup_edge_cases(gpu):
     assert np.array_equal(got["is_called"], want["is_called"])
     assert close_ll(got["lhood"], want["lhood"])
     assert np.array_equal(got["genome"]["max_gt"], want["genome"]["max_gt"])
+
+
+# ---------------------------------------------------------------------------------------------------- hot path B, indels
+
+DBL_TOL = 1e-12  # double exp/log/log1p of the device library vs glibc: last-ulp differences, summed over ~100 reads
+
+
+def test_indel_grid_lhood(gpu):
+    rng = np.random.default_rng(301)
+    rb = synth.readscore_batch(400, rng, depth_mean=110.0, breakpoint_rate=0.05)
+    for tier2 in (False, True):
+        opt = gpu.indel_options(True)
+        got = gpu.indel_grid_lhood(rb, opt, tier2)
+        want = pyoracle.indel_grid_lhood(rb, opt.min_read_bp_flank, 0.25 if tier2 else 0.5, tier2)
+        assert np.allclose(got, want, rtol=DBL_TOL, atol=0)
+    # empty and single-read rows
+    rb2 = synth.readscore_batch(50, rng, depth_mean=0.7)
+    opt = gpu.indel_options(True)
+    opt.min_read_bp_flank = 1
+    got = gpu.indel_grid_lhood(rb2, opt, False)
+    want = pyoracle.indel_grid_lhood(rb2, 1, 0.5, False)
+    assert np.allclose(got, want, rtol=DBL_TOL, atol=0)
+
+
+def test_somatic_indel_call(gpu):
+    rng = np.random.default_rng(302)
+    n = 500
+    normal = synth.readscore_batch(n, rng, depth_mean=40.0)
+    tumor = synth.readscore_batch(n, rng, depth_mean=110.0)
+    tumor.del_len, tumor.ins_len = normal.del_len, normal.ins_len
+    # make a fraction of them look somatic / germline
+    k = len(tumor.indel_lnp)
+    boost = np.repeat(rng.random(n) < 0.4, np.diff(tumor.read_off))
+    tumor.indel_lnp = np.where(boost & (rng.random(k) < 0.3), 0.0, tumor.indel_lnp).astype(np.float32)
+    tumor.ref_lnp = np.where(boost, np.minimum(tumor.ref_lnp, -1.0), tumor.ref_lnp).astype(np.float32)
+    err = rng.choice([5e-5, 1e-4, 3e-3, 2e-2], n)
+    got = gpu.somatic_indel_call(normal, tumor, err)
+    nl = pyoracle.indel_grid_lhood(normal, 1, 0.5, False)
+    tl = pyoracle.indel_grid_lhood(tumor, 5, 0.5, False)
+    assert np.allclose(got["normal_lhood"], nl, rtol=DBL_TOL, atol=0)
+    assert np.allclose(got["tumor_lhood"], tl, rtol=DBL_TOL, atol=0)
+    # the posterior is evaluated from the float-cast likelihoods: feed the oracle the device's own likelihoods so that a
+    # last-ulp difference upstream cannot flip a float rounding, then demand exact integer outputs
+    want = pyoracle.somatic_indel_result(got["normal_lhood"], got["tumor_lhood"], err)
+    assert np.array_equal(got["max_gt"], want["max_gt"])
+    assert np.array_equal(got["ntype"], want["ntype"])
+    assert np.abs(got["qphred"] - want["qphred"]).max() <= 1
+    assert np.mean(got["qphred"] == want["qphred"]) > 0.995
+    assert np.abs(got["from_ntype_qphred"] - want["from_ntype_qphred"]).max() <= 1
+    assert (got["qphred"] > 0).sum() > 5  # the test data does contain calls
+
+
+def test_allele_group_genotype_lhoods(gpu):
+    rng = np.random.default_rng(303)
+    ab = synth.allele_group_batch(600, rng, depth_mean=45.0)
+    got = gpu.allele_group_genotype_lhoods(ab)
+    lh, counts, ng = pyoracle.allele_group_genotype_lhoods(ab)
+    assert np.array_equal(got["n_genotypes"], ng)
+    assert np.allclose(got["lhood"], lh, rtol=DBL_TOL, atol=0)
+    # supporting-read counts: integer outputs of a threshold on a normalised posterior (0.51): exact except where a
+    # posterior sits within an ulp of the threshold
+    assert np.mean(got["counts"] == counts) > 0.9999
+    assert np.abs(got["counts"].astype(np.int64) - counts.astype(np.int64)).max() <= 1
+    # deep group (> one 64-read chunk) and an empty one
+    ab2 = synth.allele_group_batch(8, rng, depth_mean=300.0)
+    got2 = gpu.allele_group_genotype_lhoods(ab2)
+    lh2, counts2, _ = pyoracle.allele_group_genotype_lhoods(ab2)
+    assert np.allclose(got2["lhood"], lh2, rtol=DBL_TOL, atol=0)
+    assert np.array_equal(got2["counts"], counts2)
