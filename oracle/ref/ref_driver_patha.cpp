@@ -1,0 +1,207 @@
+// ref_driver_patha.cpp -- C entry points over the REFERENCE's own read-realignment code (hot path A).
+//
+// TEST INFRASTRUCTURE ONLY; contains no reference code.  Like the reference's own unit test
+// (L/starling_common/test/starling_read_align_test.cpp:22) this TU #includes starling_read_align.cpp where it lies to
+// reach its file-static functions (make_start_pos_alignment, get_end_pin_start_pos, getCandidateAlignments,
+// scoreCandidateAlignments ...).
+
+#include "starling_common/starling_read_align.cpp"
+
+#include "htsapi/align_path_bam_util.hh"
+#include "starling_common/starling_read.hh"
+#include "starling_common/starling_read_align_score.hh"
+#include "test/starling_base_options_test.hh"
+
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace
+{
+
+struct RefIndel
+{
+    int32_t pos;
+    int32_t type;
+    uint32_t del_len;
+    uint32_t ins_len;
+    const char* ins_seq;
+    int32_t is_candidate;
+};
+
+IndelKey to_key(const RefIndel& r)
+{
+    return IndelKey(r.pos, static_cast<INDEL::index_t>(r.type), r.del_len, r.ins_seq ? std::string(r.ins_seq, r.ins_len).c_str() : "");
+}
+
+void from_key(const IndelKey& k, int32_t* pos, int32_t* type, uint32_t* del_len, char* ins, int ins_cap)
+{
+    *pos = k.pos;
+    *type = k.type;
+    *del_len = k.deletionLength;
+    std::strncpy(ins, k.insertSequence.c_str(), ins_cap - 1);
+    ins[ins_cap - 1] = 0;
+}
+
+struct Session
+{
+    starling_base_options_test opt;
+    std::unique_ptr<starling_base_deriv_options> dopt;
+    std::unique_ptr<starling_sample_options> sopt;
+    reference_contig_segment ref;
+    std::unique_ptr<IndelBuffer> buffer;
+    depth_buffer db, db2;
+    unsigned next_read_id = 1;
+};
+
+} // namespace
+
+extern "C" {
+
+/// make_start_pos_alignment (starling_read_align.cpp:394-584).  Returns 0 on success, 1 when the reference throws.
+int ref_make_start_pos_alignment(int ref_start_pos, int read_start_pos, int is_fwd, unsigned read_length, int n_indels,
+                                 const RefIndel* indels, int* out_pos, char* out_cigar, int cigar_cap, int32_t* lead,
+                                 char* lead_ins, int32_t* trail, char* trail_ins, int ins_cap)
+{
+    try {
+        indel_set_t iset;
+        for (int i = 0; i < n_indels; ++i) iset.insert(to_key(indels[i]));
+        const CandidateAlignment cal(make_start_pos_alignment(ref_start_pos, read_start_pos, is_fwd != 0, read_length, iset));
+        *out_pos = cal.al.pos;
+        const std::string cigar(ALIGNPATH::apath_to_cigar(cal.al.path));
+        std::strncpy(out_cigar, cigar.c_str(), cigar_cap - 1);
+        out_cigar[cigar_cap - 1] = 0;
+        uint32_t dl;
+        from_key(cal.leading_indel_key, &lead[0], &lead[1], &dl, lead_ins, ins_cap);
+        lead[2] = int32_t(dl);
+        from_key(cal.trailing_indel_key, &trail[0], &trail[1], &dl, trail_ins, ins_cap);
+        trail[2] = int32_t(dl);
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+/// get_end_pin_start_pos (starling_read_align.cpp:594-719)
+int ref_get_end_pin_start_pos(int n_indels, const RefIndel* indels, unsigned read_length, int ref_end_pos,
+                              int read_end_pos, int* ref_start_pos, int* read_start_pos)
+{
+    try {
+        indel_set_t iset;
+        for (int i = 0; i < n_indels; ++i) iset.insert(to_key(indels[i]));
+        pos_t rsp(0), rdp(0);
+        get_end_pin_start_pos(iset, read_length, ref_end_pos, read_end_pos, rsp, rdp);
+        *ref_start_pos = rsp;
+        *read_start_pos = rdp;
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+/// a reference segment + an IndelBuffer with one sample, as in starling_read_align_test.cpp:345-372
+void* ref_session_create(const char* ref_seq, int ref_offset, int is_somatic)
+{
+    Session* s = new Session();
+    if (is_somatic) s->opt.randomBaseMatchProb = 0.5;
+    s->opt.is_candidate_indel_signal_test = false;
+    s->opt.isHaplotypingEnabled = false;
+    s->dopt.reset(new starling_base_deriv_options(s->opt));
+    s->sopt.reset(new starling_sample_options(s->opt));
+    s->ref.seq() = ref_seq;
+    s->ref.set_offset(ref_offset);
+    s->buffer.reset(new IndelBuffer(s->opt, *s->dopt, s->ref));
+    s->buffer->registerSample(s->db, s->db2, false);
+    s->buffer->finalizeSamples();
+    return s;
+}
+
+void ref_session_destroy(void* p) { delete static_cast<Session*>(p); }
+
+/// insert an indel and force its candidate status (IndelData::status is the cache isCandidateIndel consults,
+/// IndelBuffer.hh:153-164)
+int ref_session_add_indel(void* p, const RefIndel* ind)
+{
+    Session* s = static_cast<Session*>(p);
+    try {
+        IndelObservation obs;
+        obs.key = to_key(*ind);
+        obs.data.is_external_candidate = (ind->is_candidate != 0);
+        obs.data.iat = INDEL_ALIGN_TYPE::GENOME_TIER1_READ;
+        obs.data.id = 1000000 + s->next_read_id++;
+        s->buffer->addIndelObservation(0, obs);
+        const IndelData* idp(s->buffer->getIndelDataPtr(obs.key));
+        if (!idp) return 1;
+        idp->status.is_candidate_indel = (ind->is_candidate != 0);
+        idp->status.is_candidate_indel_cached = true;
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+/// the error rates the reference attached to an indel (IndelData::initializeAuxInfo): refToIndel, indelToRef
+int ref_session_indel_error_rates(void* p, const RefIndel* ind, double* ref_to_indel, double* indel_to_ref)
+{
+    Session* s = static_cast<Session*>(p);
+    const IndelData* idp(s->buffer->getIndelDataPtr(to_key(*ind)));
+    if (!idp) return 1;
+    const auto& er(idp->getSampleData(0).getErrorRates());
+    *ref_to_indel = er.refToIndelErrorProb.getValue();
+    *indel_to_ref = er.indelToRefErrorProb.getValue();
+    return 0;
+}
+
+struct RefPathSeg
+{
+    uint32_t type, length;
+};
+struct RefCal
+{
+    int32_t pos;
+    int32_t n_seg;
+    const RefPathSeg* path;
+    int32_t n_indels;
+    const RefIndel* indels;
+    RefIndel leading, trailing;
+};
+
+/// scoreCandidateAlignment (starling_read_align_score.cpp:261-499) for one candidate alignment of one read.
+/// read_seq: ACGTN= characters.  Every indel of the alignment must have been added to the session.
+int ref_session_score_cal(void* p, const char* read_seq, const uint8_t* qual, int read_len, const RefCal* c, double* out)
+{
+    Session* s = static_cast<Session*>(p);
+    try {
+        bam_record bamRead;
+        bamRead.set_qname("R");
+        bamRead.set_readqual(read_seq, qual);
+        alignment al;
+        al.pos = c->pos;
+        for (int i = 0; i < c->n_seg; ++i)
+            al.path.push_back(ALIGNPATH::path_segment(static_cast<ALIGNPATH::align_t>(c->path[i].type), c->path[i].length));
+        // the bam record only supplies sequence/qualities here; give it a trivially valid alignment
+        alignment bal;
+        bal.pos = c->pos;
+        bal.path.push_back(ALIGNPATH::path_segment(ALIGNPATH::MATCH, unsigned(read_len)));
+        bam1_t& br(*(bamRead.get_data()));
+        br.core.pos = bal.pos;
+        edit_bam_cigar(bal.path, br);
+        starling_read sread(bamRead, bal, MAPLEVEL::TIER1_MAPPED, 0);
+        read_segment& rseg(sread.get_full_segment());
+
+        CandidateAlignment cal;
+        cal.al = al;
+        indel_set_t iset;
+        for (int i = 0; i < c->n_indels; ++i) iset.insert(to_key(c->indels[i]));
+        cal.setIndels(iset);
+        if (c->leading.type != INDEL::NONE) cal.leading_indel_key = to_key(c->leading);
+        if (c->trailing.type != INDEL::NONE) cal.trailing_indel_key = to_key(c->trailing);
+        *out = scoreCandidateAlignment(s->opt, *s->buffer, rseg, cal, s->ref);
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+} // extern "C"
