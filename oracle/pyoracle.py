@@ -253,3 +253,68 @@ def allele_group_genotype_lhoods(batch, min_read_bp_flank=5, random_base_match_p
         counts[g, :, A + 1] = oc[:, A + 1]
         ng[g] = G
     return lh, counts, ng
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference's own hot path A (oracle/_ref), for pinning the restatement
+
+class RefIndel(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("type", C.c_int32), ("del_len", C.c_uint32), ("ins_len", C.c_uint32),
+                ("ins_seq", C.c_char_p), ("is_candidate", C.c_int32)]
+
+
+class RefCal(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("n_seg", C.c_int32), ("path", C.POINTER(PathSeg)), ("n_indels", C.c_int32),
+                ("indels", C.POINTER(RefIndel)), ("leading", RefIndel), ("trailing", RefIndel)]
+
+
+_CODE2CHAR = {0: "=", 1: "A", 2: "C", 4: "G", 8: "T", 15: "N"}
+
+
+def _ref_indel(k):
+    if k is None:
+        return RefIndel(0, 0, 0, 0, None, 0)
+    seq = k.get("ins_seq", "").encode()
+    return RefIndel(k["pos"], k["type"], k.get("del_len", 0), len(seq), seq, int(k.get("is_candidate", 1)))
+
+
+def ref_score_cases(cases, is_somatic=False):
+    """scoreCandidateAlignment of the REFERENCE for every candidate alignment of synth.align_cases()-style cases.
+    Each case gets its own IndelBuffer session holding exactly the indels its candidates mention."""
+    L = ref()
+    L.ref_session_create.restype = vp
+    L.ref_session_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.ref_session_destroy.argtypes = [vp]
+    L.ref_session_add_indel.argtypes = [vp, C.POINTER(RefIndel)]
+    L.ref_session_score_cal.argtypes = [vp, C.c_char_p, vp, C.c_int, C.POINTER(RefCal), C.POINTER(C.c_double)]
+    out = []
+    for c in cases:
+        ref_b = c["ref_seq"].encode() if isinstance(c["ref_seq"], str) else bytes(c["ref_seq"])
+        s = L.ref_session_create(ref_b, int(c["ref_offset"]), int(is_somatic))
+        try:
+            seen = set()
+            for cal in c["cals"]:
+                for k in list(cal["indels"]) + [cal.get("leading"), cal.get("trailing")]:
+                    if k is None:
+                        continue
+                    ident = (k["pos"], k["type"], k.get("del_len", 0), k.get("ins_seq", ""))
+                    if ident in seen:
+                        continue
+                    seen.add(ident)
+                    ri = _ref_indel(k)
+                    if L.ref_session_add_indel(s, C.byref(ri)) != 0:
+                        raise RuntimeError("reference rejected indel %r" % (ident,))
+            read = "".join(_CODE2CHAR.get(int(x), "N") for x in c["read_code"]).encode()
+            qual = np.ascontiguousarray(c["read_qual"], np.uint8)
+            for cal in c["cals"]:
+                path = (PathSeg * max(len(cal["path"]), 1))(*[PathSeg(t, l) for t, l in cal["path"]])
+                ind = (RefIndel * max(len(cal["indels"]), 1))(*[_ref_indel(k) for k in cal["indels"]])
+                rc = RefCal(cal["pos"], len(cal["path"]), path, len(cal["indels"]), ind, _ref_indel(cal.get("leading")),
+                            _ref_indel(cal.get("trailing")))
+                v = C.c_double()
+                if L.ref_session_score_cal(s, read, _p(qual), len(qual), C.byref(rc), C.byref(v)) != 0:
+                    raise RuntimeError("reference threw while scoring %r" % (cal,))
+                out.append(v.value)
+        finally:
+            L.ref_session_destroy(s)
+    return np.array(out)

@@ -44,11 +44,33 @@ void from_key(const IndelKey& k, int32_t* pos, int32_t* type, uint32_t* del_len,
     ins[ins_cap - 1] = 0;
 }
 
-struct Session
+// options + derived options are built once per mode (their construction parses the built-in indel error / theta models)
+struct Mode
 {
     starling_base_options_test opt;
     std::unique_ptr<starling_base_deriv_options> dopt;
+    explicit Mode(const bool is_somatic)
+    {
+        if (is_somatic) opt.randomBaseMatchProb = 0.5;
+        opt.is_candidate_indel_signal_test = false;
+        opt.isHaplotypingEnabled = false;
+        dopt.reset(new starling_base_deriv_options(opt));
+    }
+};
+
+Mode& mode(const bool is_somatic)
+{
+    static Mode germline(false), somatic(true);
+    return is_somatic ? somatic : germline;
+}
+
+struct Session
+{
+    Mode& m;
+    starling_base_options_test& opt;
+    std::unique_ptr<starling_base_deriv_options>& dopt;
     std::unique_ptr<starling_sample_options> sopt;
+    explicit Session(const bool is_somatic) : m(mode(is_somatic)), opt(m.opt), dopt(m.dopt) {}
     reference_contig_segment ref;
     std::unique_ptr<IndelBuffer> buffer;
     depth_buffer db, db2;
@@ -103,11 +125,7 @@ int ref_get_end_pin_start_pos(int n_indels, const RefIndel* indels, unsigned rea
 /// a reference segment + an IndelBuffer with one sample, as in starling_read_align_test.cpp:345-372
 void* ref_session_create(const char* ref_seq, int ref_offset, int is_somatic)
 {
-    Session* s = new Session();
-    if (is_somatic) s->opt.randomBaseMatchProb = 0.5;
-    s->opt.is_candidate_indel_signal_test = false;
-    s->opt.isHaplotypingEnabled = false;
-    s->dopt.reset(new starling_base_deriv_options(s->opt));
+    Session* s = new Session(is_somatic != 0);
     s->sopt.reset(new starling_sample_options(s->opt));
     s->ref.seq() = ref_seq;
     s->ref.set_offset(ref_offset);

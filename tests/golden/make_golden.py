@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz|*.pkl: outputs of the REFERENCE ITSELF (oracle/_ref/libstrelka_ref.so, i.e. the
+reference's own translation units compiled by oracle/Makefile) on seeded inputs.
+
+Run in the build container (needs /root/reference):  python tests/golden/make_golden.py
+The fixtures travel with the repo, so the oracle restatement stays pinned to reference outputs where /root/reference
+does not exist (the GPU box)."""
+import ctypes as C
+import os
+import pickle
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import pyoracle  # noqa: E402
+from strelka_amd import capi, synth  # noqa: E402
+
+vp = C.c_void_p
+
+
+def _p(a):
+    return a.ctypes.data_as(vp)
+
+
+def main():
+    pyoracle.build(ref=True)
+    R = pyoracle.ref()
+    assert R is not None, "oracle/_ref/libstrelka_ref.so missing"
+    rng = np.random.default_rng(20240925)
+    out = {}
+
+    # ---- scalar helpers / tables
+    tabs = [np.zeros(71) for _ in range(3)]
+    R.ref_get_qscore_tables(*[_p(t) for t in tabs])
+    out["q2p"], out["q2lncompe"], out["q2lne"] = tabs
+    out["mapped_q"] = np.array([[R.ref_mapped_qscore(q, m) for q in range(71)] for m in range(0, 91, 5)], np.int32)
+    probs = np.concatenate([10.0 ** -rng.uniform(0, 320, 200), rng.random(100)])
+    out["qphred_in"] = probs
+    out["qphred_out"] = np.array([R.ref_error_prob_to_qphred(C.c_double(p)) for p in probs], np.int32)
+    lnp = (-rng.uniform(0, 120, 300)).astype(np.float32)
+    out["lnqphred_in"] = lnp
+    out["lnqphred_out"] = np.array([R.ref_ln_error_prob_to_qphred_f(C.c_float(x)) for x in lnp], np.int32)
+    pairs = (-rng.uniform(0, 60, (300, 2)))
+    out["logsum_in"] = pairs
+    out["logsum_out"] = np.array([R.ref_log_sum2(C.c_double(a), C.c_double(b)) for a, b in pairs])
+    out["logsumf_out"] = np.array([R.ref_log_sum2f(C.c_float(a), C.c_float(b)) for a, b in pairs.astype(np.float32)], np.float32)
+    pri = np.zeros(200, np.float32)
+    R.ref_germline_lnpriors(C.c_double(0.001), _p(pri))
+    out["germline_lnpriors_theta0.001"] = pri
+
+    # ---- std::sort tie order
+    keys, perms = [], []
+    for n in list(range(0, 36)) + [50, 64, 100, 257, 1000]:
+        for rep in range(3):
+            key = rng.integers(0, int(rng.integers(1, 64)), size=max(n, 1)).astype(np.uint16)
+            idx = np.arange(n, dtype=np.uint32)
+            R.ref_sort_idx_by_key_desc(_p(idx), n, _p(key))
+            keys.append(key[:n].copy())
+            perms.append(idx)
+    out["sort_keys"] = np.array(keys, dtype=object)
+    out["sort_perms"] = np.array(perms, dtype=object)
+
+    # ---- germline: adjust_joint_eprob + position_snp_call_pprob_digt
+    parts = [synth.pileups(150, rng, het_rate=0.1, hom_rate=0.05, filter_rate=0.03),
+             synth.pileups(60, rng, depth_mean=3.0, het_rate=0.2), synth.pileups(30, rng, depth_mean=120.0, nmm_rate=0.3),
+             synth.pileups(60, rng, noise=0.6, nmm_rate=0.1)]
+    off = [np.zeros(1, np.int64)]
+    calls, refb = [], []
+    base = 0
+    for p in parts:
+        off.append(p.call_off[1:] + base)
+        base += p.call_off[-1]
+        calls.append(p.calls)
+        refb.append(p.ref_base)
+    pb = capi.HostPileupBatch(np.concatenate(off), np.concatenate(calls), np.concatenate(refb))
+    pb.ref_base[::37] = 4
+    ploidy = rng.choice(np.array([1, 2, 2], np.uint8), pb.n_loci)
+    de = np.zeros(len(pb.calls), np.float32)
+    digt = np.zeros(pb.n_loci, pyoracle.DIGT_CALL_DTYPE)
+    for l in range(pb.n_loci):
+        s, e = int(pb.call_off[l]), int(pb.call_off[l + 1])
+        c = np.ascontiguousarray(pb.calls[s:e])
+        d = np.zeros(e - s, np.float32)
+        R.ref_adjust_joint_eprob(_p(c), e - s, C.c_double(.35), C.c_double(.6), 1, C.c_double(.25), _p(d))
+        de[s:e] = d
+        # the caller consumes the CLEANED pileup (filtered calls removed, PileupCleaner.cpp:28-66)
+        keep = ((c >> 12) & 1) == 0
+        cc, dd = np.ascontiguousarray(c[keep]), np.ascontiguousarray(d[keep])
+        row = np.zeros(1, pyoracle.DIGT_CALL_DTYPE)
+        R.ref_position_snp_call_pprob_digt(_p(cc), _p(dd), len(cc), int(pb.ref_base[l]), int(ploidy[l]), C.c_double(0.001), _p(row))
+        digt[l] = row[0]
+    out.update(g_call_off=pb.call_off, g_calls=pb.calls, g_ref_base=pb.ref_base, g_ploidy=ploidy, g_de=de,
+               g_digt=digt.view(np.uint8).reshape(pb.n_loci, -1))
+
+    # ---- somatic SNV: sample likelihoods + posterior
+    n, t = synth.somatic_pileups(250, rng, somatic_rate=0.1, het_rate=0.1)
+    nl = np.zeros((n.n_loci, 30), np.float32)
+    tl = np.zeros((n.n_loci, 30), np.float32)
+    res = np.zeros((n.n_loci, 4), np.int64)
+    lnp3 = np.zeros(3, np.float32)
+    R.ref_germline_genotype_log_prior(C.c_double(0.001), _p(lnp3))
+    import math
+    for l in range(n.n_loci):
+        for b, dst, strand in ((n, nl, 0), (t, tl, 1)):
+            s, e = int(b.call_off[l]), int(b.call_off[l + 1])
+            c = np.ascontiguousarray(b.calls[s:e])
+            row = np.zeros(30, np.float32)
+            R.ref_somatic_sample_lhood(_p(c), e - s, int(n.ref_base[l]), strand, _p(row))
+            dst[l] = row
+        mg, q, fq, nt = C.c_uint32(), C.c_int32(), C.c_int32(), C.c_uint32()
+        R.ref_calculate_result_set_grid(C.c_float(0.15), C.c_float(math.log(5e-10)), C.c_float(math.log1p(-5e-10)),
+                                        _p(nl[l]), _p(tl[l]), _p(lnp3), C.c_float(math.log1p(-1e-4)),
+                                        C.c_float(math.log(1e-4)), C.byref(mg), C.byref(q), C.byref(fq), C.byref(nt))
+        res[l] = (mg.value, q.value, fq.value, nt.value)
+    out.update(s_n_off=n.call_off, s_n_calls=n.calls, s_t_off=t.call_off, s_t_calls=t.calls, s_ref_base=n.ref_base,
+               s_normal_lhood=nl, s_tumor_lhood=tl, s_result=res, s_lnprior3=lnp3)
+
+    # ---- indels: 21-state grid likelihoods + allele-group genotype likelihoods
+    rb = synth.readscore_batch(80, rng, depth_mean=60.0)
+    bases = "ACGT"
+    grid = np.zeros((2, rb.n_indels, 21))
+    for i in range(rb.n_indels):
+        s, e = int(rb.read_off[i]), int(rb.read_off[i + 1])
+        ins = ("A" * int(rb.ins_len[i])).encode()
+        for t2 in (0, 1):
+            row = np.zeros(21)
+            args = [np.ascontiguousarray(x[s:e]) for x in (rb.ref_lnp, rb.indel_lnp, rb.alt_lnp, rb.non_ambig, rb.read_length)]
+            t1 = np.ascontiguousarray(rb.read_flags[s:e] & 1)
+            R.ref_indel_grid_lhood(e - s, *[_p(x) for x in args], _p(t1), int(rb.del_len[i]), ins, 5, C.c_double(0.5), t2, 1, _p(row))
+            grid[t2, i] = row
+    out.update(i_read_off=rb.read_off, i_ref=rb.ref_lnp, i_indel=rb.indel_lnp, i_alt=rb.alt_lnp, i_na=rb.non_ambig,
+               i_rl=rb.read_length, i_flags=rb.read_flags, i_del=rb.del_len, i_ins=rb.ins_len, i_grid=grid)
+    ab = synth.allele_group_batch(120, rng, depth_mean=45.0)
+    glh = np.zeros((ab.n_groups, 10))
+    gcnt = np.zeros((ab.n_groups, 2, 5), np.uint32)
+    for g in range(ab.n_groups):
+        s, e = int(ab.read_off[g]), int(ab.read_off[g + 1])
+        A, pl = int(ab.n_alt[g]), int(ab.ploidy[g])
+        G = A + 1 if pl == 1 else (A + 1) * (A + 2) // 2
+        refl = np.ascontiguousarray(ab.ref_lnp[s:e, :A])
+        al = np.ascontiguousarray(ab.allele_lnp[s:e, :A])
+        t1 = np.ascontiguousarray(ab.read_flags[s:e] & 1)
+        fw = np.ascontiguousarray((ab.read_flags[s:e] >> 1) & 1)
+        inss = (C.c_char_p * A)(*[("C" * int(ab.ins_len[g, k])).encode() for k in range(A)])
+        dl = np.ascontiguousarray(ab.del_len[g, :A])
+        ol, oc = np.zeros(G), np.zeros(2 * (A + 2), np.uint32)
+        R.ref_allele_group_genotype_lhoods(e - s, A, _p(refl), _p(al), _p(np.ascontiguousarray(ab.non_ambig[s:e])),
+                                           _p(np.ascontiguousarray(ab.read_length[s:e])), _p(t1), _p(fw), _p(dl), inss, pl,
+                                           5, C.c_double(0.25), _p(ol), _p(oc))
+        glh[g, :G] = ol
+        oc = oc.reshape(2, A + 2)
+        gcnt[g, :, :A + 1] = oc[:, :A + 1]
+        gcnt[g, :, A + 1] = oc[:, A + 1]
+    out.update(a_read_off=ab.read_off, a_n_alt=ab.n_alt, a_ploidy=ab.ploidy, a_del=ab.del_len, a_ins=ab.ins_len,
+               a_ref=ab.ref_lnp, a_allele=ab.allele_lnp, a_na=ab.non_ambig, a_rl=ab.read_length, a_flags=ab.read_flags,
+               a_lhood=glh, a_counts=gcnt)
+
+    np.savez_compressed(os.path.join(HERE, "pathb_reference.npz"), **out)
+
+    # ---- hot path A: scoreCandidateAlignment of the reference on reference-shaped candidate alignments
+    cases = synth.align_cases(48, rng) + synth.align_cases_h64(4, rng)
+    scores = pyoracle.ref_score_cases(cases)
+    with open(os.path.join(HERE, "patha_scores_reference.pkl"), "wb") as f:
+        pickle.dump(dict(cases=cases, scores=scores), f, protocol=4)
+    print("wrote", sorted(os.listdir(HERE)))
+
+
+if __name__ == "__main__":
+    main()
