@@ -143,6 +143,129 @@ int sk_align_builder_add_read(sk_align_builder* b, const uint8_t* read_code, con
                               const sk_candidate_alignment* cals, int32_t n_cals);
 /** Fill `out` with HOST pointers into the builder (valid until the next clear/add/destroy). */
 int sk_align_builder_finish(sk_align_builder* b, sk_align_batch* out);
+/** error text of the last failing builder call */
+const char* sk_align_builder_error(const sk_align_builder* b);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Hot path A, whole read: realignAndScoreRead (L/starling_common/starling_read_align.cpp:2026-2126) as a batched job
+ *
+ *   stage 1 (host)  add_read : the gate (check_for_candidate_indel_overlap :219-270), input normalisation (:1998-2057),
+ *                              candidate-alignment enumeration (candidate_alignment_search :859-1277 with
+ *                              make_start_pos_alignment :394-584 / get_end_pin_start_pos :594-719) and flattening
+ *   stage 2 (GPU)            : scoreCandidateAlignment for every (read, candidate alignment) of the job in one launch
+ *   stage 3 (host)  finish   : max / smooth-pool selection with the reference's exact tie rules
+ *                              (scoreCandidateAlignments :1536-1741), edge soft-clipping of ambiguous pools
+ *                              (starling_read_align_clipper.cpp:343-424) and per-indel read support
+ *                              (score_indels, starling_read_align_score_indels.cpp:455-1079)
+ *   sk_realign_job_run = get_batch -> sk_score_alignments -> finish.
+ *
+ * Replaces the per-read call at L/starling_common/starling_pos_processor_base.cpp:752: the adapter queues the reads
+ * buffered at the READ_BUFFER stage, runs the job, then writes `rseg.realignment/is_realigned` and
+ * `IndelSampleData::read_path_lnp[readId]` from the results.
+ * DNA reads only: spliced (RNA) read segments with pinned exon edges are not handled (north_star: germline/somatic DNA).
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+enum { SK_MAX_SAMPLES = 4 };
+/** MAPLEVEL::index_t (L/blt_common/map_level.hh:32-39) */
+enum { SK_MAPLEVEL_UNKNOWN = 0, SK_MAPLEVEL_TIER1 = 1, SK_MAPLEVEL_TIER2 = 2, SK_MAPLEVEL_SUB = 3, SK_MAPLEVEL_UNMAPPED = 4 };
+
+typedef struct sk_realign_options { /* L/starling_common/starling_base_shared.hh */
+    int32_t max_read_indel_toggle;        /* 5    (:139) */
+    double max_candidate_indel_density;   /* 0.15 (:145) */
+    uint32_t max_realignment_candidates;  /* 5000 (:160) */
+    uint32_t max_indel_size;              /* 49   (:124) */
+    int32_t is_smoothed_alignments;       /* 1    (:170) */
+    double smoothed_lnp_range;            /* ln 10 (:171) */
+    uint32_t upstream_oligo_size;         /* 0    (:206) */
+    int32_t is_haplotyping_enabled;       /* germline 1, somatic 0 (:98, starling_shared.hh:52) */
+    int32_t min_read_bp_flank;            /* 5; normal sample of a somatic run 1 */
+    int32_t sample_count;                 /* 1..SK_MAX_SAMPLES */
+} sk_realign_options;
+void sk_realign_options_default(sk_realign_options* opt);
+
+/** One entry of the IndelBuffer (IndelKey + the IndelData fields the path consults). */
+typedef struct sk_indel_info {
+    sk_indel_key key;                 /* key.is_candidate = IndelBuffer::isCandidateIndel */
+    double ref_to_indel_log_prob;     /* getErrorRates().refToIndelErrorProb.getLogValue() of the read's sample */
+    double indel_to_ref_log_prob;     /* getErrorRates().indelToRefErrorProb.getLogValue() */
+    int32_t active_region_id;         /* IndelData::activeRegionId, < 0 = none */
+    int8_t haplotype_id[SK_MAX_SAMPLES];            /* IndelSampleData::haplotypeId */
+    uint8_t is_haplotyping_bypassed[SK_MAX_SAMPLES];/* IndelSampleData::isHaplotypingBypassed */
+    uint8_t is_forced_output;         /* IndelData::isForcedOutput */
+    uint8_t not_discovered_from_reads;/* IndelData::status.notDiscoveredFromReads */
+} sk_indel_info;
+
+typedef struct sk_read_input {
+    const uint8_t* read_code;   /* BAM 4-bit codes, one per byte */
+    const uint8_t* read_qual;
+    int32_t read_len;
+    int32_t pos;                /* input alignment (already left-normalised by the caller, as rseg.getInputAlignment()) */
+    int32_t n_seg;
+    const sk_path_seg* path;
+    int32_t is_fwd_strand;
+    int32_t map_level;          /* SK_MAPLEVEL_* (tier1/tier2 reads get indel scores) */
+    int32_t sample_index;
+    int32_t realign_begin, realign_end; /* realign_buffer_range */
+    int32_t n_observed;         /* indels of the table this read was observed to support in its sample */
+    const int32_t* observed;    /* (is_usable_indel :289-305): indices into the job's indel table (as given) */
+} sk_read_input;
+
+typedef struct sk_read_path_scores { /* ReadPathScores, L/starling_common/IndelData.hh:64-116 */
+    int32_t indel;              /* index into the job's indel table (as given to set_indels) */
+    float ref_lnp, indel_lnp;
+    uint16_t non_ambig, read_length;
+    uint8_t is_tier1_read, is_fwd_strand;
+    int16_t read_pos, distance_from_closest_read_edge;
+    int32_t n_alt;              /* <= 2 */
+    int32_t alt_indel[2];
+    float alt_lnp[2];
+} sk_read_path_scores;
+
+typedef struct sk_read_result {
+    int32_t n_candidate_alignments; /* 0 = the read left at the gate (not realignable / no candidate overlap) */
+    int32_t is_realigned;
+    int32_t realign_pos;
+    int32_t realign_n_seg;
+    const sk_path_seg* realign_path;
+    double max_score;               /* score of the max candidate alignment */
+    int32_t n_scores;
+    const sk_read_path_scores* scores;
+    int32_t n_suboverlap;           /* indels whose breakpoint the read overlaps by 0 < bp < min_read_bp_flank */
+    const int32_t* suboverlap;      /* (suboverlap_tier{1,2}_read_ids, score_indels :616-626) */
+    int32_t warn_origin_skip, warn_max_toggle_depth;
+} sk_read_result;
+
+typedef struct sk_realign_job sk_realign_job;
+sk_realign_job* sk_realign_job_create(const sk_realign_options* opt);
+void sk_realign_job_destroy(sk_realign_job* job);
+const char* sk_realign_job_error(const sk_realign_job* job);
+/** reference_contig_segment: positions outside [offset, offset+len) read as 'N' */
+int sk_realign_job_set_reference(sk_realign_job* job, const char* ref_seq, int32_t ref_offset, int32_t ref_len);
+/** the indels visible to the job's reads (any order; sorted internally in IndelKey order) */
+int sk_realign_job_set_indels(sk_realign_job* job, const sk_indel_info* indels, int32_t n_indels);
+/** stage 1 for one read; returns the read's index in the job or -1 */
+int sk_realign_job_add_read(sk_realign_job* job, const sk_read_input* read);
+/** the flattened (read, candidate alignment) pairs of all reads added so far (host pointers owned by the job) */
+int sk_realign_job_get_batch(sk_realign_job* job, sk_align_batch* out);
+/** stage 3 from host scores laid out as get_batch's candidate alignments */
+int sk_realign_job_finish(sk_realign_job* job, const double* scores);
+/** stages 2+3 on the GPU */
+int sk_realign_job_run(sk_realign_job* job);
+int sk_realign_job_n_reads(const sk_realign_job* job);
+int sk_realign_job_read_result(const sk_realign_job* job, int32_t read_index, sk_read_result* out);
+/** drop reads and results, keep reference/indels/options */
+void sk_realign_job_clear_reads(sk_realign_job* job);
+
+/* building blocks, exposed for known-answer tests against the reference's own unit tests
+ * (L/starling_common/test/starling_read_align_test.cpp:67-335) */
+/** make_start_pos_alignment: out_path capacity >= 2*n_indels+3; returns the number of path segments or -1.
+ *  out_leading/out_trailing: index into `indels` or -1. */
+int sk_make_start_pos_alignment(int32_t ref_start_pos, int32_t read_start_pos, int32_t is_fwd_strand, uint32_t read_length,
+                                const sk_indel_key* indels, int32_t n_indels, int32_t* out_pos, sk_path_seg* out_path,
+                                int32_t path_cap, int32_t* out_leading, int32_t* out_trailing);
+/** get_end_pin_start_pos */
+int sk_get_end_pin_start_pos(const sk_indel_key* indels, int32_t n_indels, uint32_t read_length, int32_t ref_end_pos,
+                             int32_t read_end_pos, int32_t* out_ref_start_pos, int32_t* out_read_start_pos);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (germline SNV): dependent error probabilities + diploid genotype likelihoods

@@ -318,3 +318,89 @@ def ref_score_cases(cases, is_somatic=False):
         finally:
             L.ref_session_destroy(s)
     return np.array(out)
+
+
+class RefReadScore(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("type", C.c_int32), ("del_len", C.c_uint32), ("ins_len", C.c_uint32),
+                ("ins", C.c_char * 64), ("ref_lnp", C.c_float), ("indel_lnp", C.c_float), ("non_ambig", C.c_uint16),
+                ("read_length", C.c_uint16), ("is_tier1_read", C.c_int32), ("is_fwd_strand", C.c_int32),
+                ("read_pos", C.c_int32), ("edge_dist", C.c_int32), ("n_alt", C.c_int32), ("alt_pos", C.c_int32 * 2),
+                ("alt_type", C.c_int32 * 2), ("alt_del_len", C.c_uint32 * 2), ("alt_ins", (C.c_char * 64) * 2),
+                ("alt_lnp", C.c_float * 2), ("is_suboverlap", C.c_int32)]
+
+
+def ref_realign_scenarios(scenarios, is_somatic=False):
+    """realignAndScoreRead of the REFERENCE on synth.realign_scenarios()-style input (one IndelBuffer session per
+    scenario).  Fills each indel's log error rates (`r2i`, `i2r`) as the reference's IndelBuffer computed them and
+    returns, per scenario, the list of per-read results:
+    dict(threw, is_realigned, pos, cigar, scores=[dict(key=(pos,type,del_len,ins), ...)], suboverlap=[key...])."""
+    L = ref()
+    L.ref_session_create.restype = vp
+    L.ref_session_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.ref_session_destroy.argtypes = [vp]
+    L.ref_session_add_indel.argtypes = [vp, C.POINTER(RefIndel)]
+    L.ref_session_add_indel_observed.argtypes = [vp, C.POINTER(RefIndel), C.c_uint]
+    L.ref_session_set_indel_haplotype.argtypes = [vp, C.POINTER(RefIndel)] + [C.c_int] * 5
+    L.ref_session_indel_log_error_rates.argtypes = [vp, C.POINTER(RefIndel), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ref_session_realign.argtypes = [vp, C.c_char_p, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PathSeg), C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.c_char_p, C.c_int]
+    L.ref_session_read_scores.argtypes = [vp, C.c_uint, C.POINTER(RefReadScore), C.c_int]
+    out = []
+    for sc in scenarios:
+        s = L.ref_session_create(sc["ref_seq"].encode(), int(sc["ref_offset"]), int(is_somatic))
+        try:
+            for d in sc["indels"]:
+                ri = _ref_indel(d)
+                if L.ref_session_add_indel(s, C.byref(ri)) != 0:
+                    raise RuntimeError("reference rejected indel %r" % (d,))
+            for rid, rd in enumerate(sc["reads"]):
+                for o in rd["observed"]:
+                    ri = _ref_indel(sc["indels"][o])
+                    if L.ref_session_add_indel_observed(s, C.byref(ri), rid + 1) != 0:
+                        raise RuntimeError("reference rejected indel observation")
+            for d in sc["indels"]:
+                ri = _ref_indel(d)
+                a, b = C.c_double(), C.c_double()
+                if L.ref_session_indel_log_error_rates(s, C.byref(ri), C.byref(a), C.byref(b)) != 0:
+                    raise RuntimeError("indel missing from the reference session")
+                d["r2i"], d["i2r"] = a.value, b.value
+                if "arid" in d:
+                    L.ref_session_set_indel_haplotype(s, C.byref(ri), d["arid"], d["hap"], d["bypass"], d["forced"], d["ndfr"])
+            res = []
+            for rid, rd in enumerate(sc["reads"]):
+                read = "".join(_CODE2CHAR.get(int(x), "N") for x in rd["code"]).encode()
+                qual = np.ascontiguousarray(rd["qual"], np.uint8)
+                path = (PathSeg * len(rd["path"]))(*[PathSeg(t, l) for t, l in rd["path"]])
+                isr, pos = C.c_int(), C.c_int()
+                cig = C.create_string_buffer(512)
+                rc = L.ref_session_realign(s, read, _p(qual), len(qual), rd["pos"], len(rd["path"]), path, int(rd["is_fwd"]),
+                                           rd["map_level"], rd["realign_range"][0], rd["realign_range"][1], rid + 1,
+                                           int(sc.get("is_haplotyping_enabled", 0)), int(sc.get("min_read_bp_flank", 5)),
+                                           C.byref(isr), C.byref(pos), cig, 512)
+                if rc != 0:
+                    res.append(dict(threw=True))
+                    continue
+                buf = (RefReadScore * 64)()
+                n = L.ref_session_read_scores(s, rid + 1, buf, 64)
+                if n < 0:
+                    raise RuntimeError("score buffer overflow")
+                scores, sub = [], []
+                for i in range(n):
+                    b = buf[i]
+                    key = (b.pos, b.type, b.del_len, b.ins.decode())
+                    if b.is_suboverlap:
+                        sub.append(key)
+                        continue
+                    scores.append(dict(key=key, ref_lnp=float(b.ref_lnp), indel_lnp=float(b.indel_lnp),
+                                       non_ambig=b.non_ambig, read_length=b.read_length,
+                                       is_tier1_read=b.is_tier1_read, is_fwd_strand=b.is_fwd_strand, read_pos=b.read_pos,
+                                       edge_dist=b.edge_dist,
+                                       alt=[((b.alt_pos[a], b.alt_type[a], b.alt_del_len[a], b.alt_ins[a].value.decode()),
+                                             float(b.alt_lnp[a])) for a in range(b.n_alt)]))
+                res.append(dict(threw=False, is_realigned=bool(isr.value), pos=pos.value, cigar=cig.value.decode(),
+                                scores=scores, suboverlap=sub))
+            out.append(res)
+        finally:
+            L.ref_session_destroy(s)
+    return out

@@ -222,4 +222,156 @@ int ref_session_score_cal(void* p, const char* read_seq, const uint8_t* qual, in
     }
 }
 
+
+/// as ref_session_add_indel, but the observation is attributed to read `read_id` (tier1_map_read_ids of sample 0), so
+/// that is_usable_indel (starling_read_align.cpp:289-305) accepts it for that read even when it is not a candidate
+int ref_session_add_indel_observed(void* p, const RefIndel* ind, unsigned read_id)
+{
+    Session* s = static_cast<Session*>(p);
+    try {
+        IndelObservation obs;
+        obs.key = to_key(*ind);
+        obs.data.is_external_candidate = false;
+        obs.data.iat = INDEL_ALIGN_TYPE::GENOME_TIER1_READ;
+        obs.data.id = read_id;
+        s->buffer->addIndelObservation(0, obs);
+        const IndelData* idp(s->buffer->getIndelDataPtr(obs.key));
+        if (!idp) return 1;
+        idp->status.is_candidate_indel = (ind->is_candidate != 0);
+        idp->status.is_candidate_indel_cached = true;
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+/// haplotyping annotations of an indel already in the session (sample 0)
+int ref_session_set_indel_haplotype(void* p, const RefIndel* ind, int active_region_id, int haplotype_id,
+                                    int is_haplotyping_bypassed, int is_forced_output, int not_discovered_from_reads)
+{
+    Session* s = static_cast<Session*>(p);
+    IndelData* idp(s->buffer->getIndelDataPtr(to_key(*ind)));
+    if (!idp) return 1;
+    idp->activeRegionId = active_region_id;
+    idp->getSampleData(0).haplotypeId = uint8_t(haplotype_id);
+    idp->getSampleData(0).isHaplotypingBypassed = (is_haplotyping_bypassed != 0);
+    idp->isForcedOutput = (is_forced_output != 0);
+    idp->status.notDiscoveredFromReads = (not_discovered_from_reads != 0);
+    return 0;
+}
+
+/// log error rates as score_indels reads them (getLogValue)
+int ref_session_indel_log_error_rates(void* p, const RefIndel* ind, double* ref_to_indel, double* indel_to_ref)
+{
+    Session* s = static_cast<Session*>(p);
+    const IndelData* idp(s->buffer->getIndelDataPtr(to_key(*ind)));
+    if (!idp) return 1;
+    const auto& er(idp->getSampleData(0).getErrorRates());
+    *ref_to_indel = er.refToIndelErrorProb.getLogValue();
+    *indel_to_ref = er.indelToRefErrorProb.getLogValue();
+    return 0;
+}
+
+/// realignAndScoreRead (starling_read_align.cpp:2026-2126) on one read of sample 0.
+/// Returns 0 ok, 1 when the reference throws.  Scores are left in the session's IndelBuffer (ref_session_read_scores).
+int ref_session_realign(void* p, const char* read_seq, const uint8_t* qual, int read_len, int pos, int n_seg,
+                        const RefPathSeg* path, int is_fwd, int map_level, int realign_begin, int realign_end,
+                        unsigned read_id, int is_haplotyping_enabled, int min_read_bp_flank, int* is_realigned,
+                        int* out_pos, char* out_cigar, int cigar_cap)
+{
+    Session* s = static_cast<Session*>(p);
+    try {
+        bam_record bamRead;
+        bamRead.set_qname("R");
+        bamRead.set_readqual(read_seq, qual);
+        alignment al;
+        al.pos = pos;
+        al.is_fwd_strand = (is_fwd != 0);
+        for (int i = 0; i < n_seg; ++i)
+            al.path.push_back(ALIGNPATH::path_segment(static_cast<ALIGNPATH::align_t>(path[i].type), path[i].length));
+        bam1_t& br(*(bamRead.get_data()));
+        br.core.pos = al.pos;
+        if (!is_fwd) br.core.flag |= BAM_FLAG::STRAND;
+        edit_bam_cigar(al.path, br);
+        (void)read_len;
+        starling_read sread(bamRead, al, static_cast<MAPLEVEL::index_t>(map_level), read_id);
+        read_segment& rseg(sread.get_full_segment());
+
+        s->opt.isHaplotypingEnabled = (is_haplotyping_enabled != 0);
+        s->sopt->min_read_bp_flank = min_read_bp_flank;
+        const known_pos_range realign_range(realign_begin, realign_end);
+        realignAndScoreRead(s->opt, *s->dopt, *s->sopt, s->ref, realign_range, 0, rseg, *s->buffer);
+        *is_realigned = rseg.is_realigned ? 1 : 0;
+        *out_pos = rseg.is_realigned ? rseg.realignment.pos : 0;
+        const std::string cigar(rseg.is_realigned ? ALIGNPATH::apath_to_cigar(rseg.realignment.path) : std::string());
+        std::strncpy(out_cigar, cigar.c_str(), cigar_cap - 1);
+        out_cigar[cigar_cap - 1] = 0;
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+struct RefReadScore
+{
+    int32_t pos, type;
+    uint32_t del_len, ins_len;
+    char ins[64];
+    float ref_lnp, indel_lnp;
+    uint16_t non_ambig, read_length;
+    int32_t is_tier1_read, is_fwd_strand;
+    int32_t read_pos, edge_dist;
+    int32_t n_alt;
+    int32_t alt_pos[2], alt_type[2];
+    uint32_t alt_del_len[2];
+    char alt_ins[2][64];
+    float alt_lnp[2];
+    int32_t is_suboverlap; // 1: the read is only in suboverlap_tier{1,2}_read_ids of this indel
+};
+
+/// everything score_indels stored for read `read_id`: read_path_lnp entries and suboverlap memberships, in IndelKey order
+int ref_session_read_scores(void* p, unsigned read_id, RefReadScore* out, int cap)
+{
+    Session* s = static_cast<Session*>(p);
+    int n = 0;
+    const auto range(s->buffer->rangeIterator(-1000000, 1000000000));
+    for (auto it(range.first); it != range.second; ++it) {
+        const IndelKey& k(it->first);
+        const IndelSampleData& sd(it->second.getSampleData(0));
+        const auto f(sd.read_path_lnp.find(read_id));
+        const bool sub = (sd.suboverlap_tier1_read_ids.count(read_id) > 0) || (sd.suboverlap_tier2_read_ids.count(read_id) > 0);
+        if (f == sd.read_path_lnp.end() && !sub) continue;
+        if (n >= cap) return -1;
+        RefReadScore& o(out[n++]);
+        std::memset(&o, 0, sizeof(o));
+        o.pos = k.pos;
+        o.type = k.type;
+        o.del_len = k.deletionLength;
+        o.ins_len = k.insertSequence.size();
+        std::strncpy(o.ins, k.insertSequence.c_str(), 63);
+        if (f == sd.read_path_lnp.end()) {
+            o.is_suboverlap = 1;
+            continue;
+        }
+        const ReadPathScores& r(f->second);
+        o.ref_lnp = r.ref;
+        o.indel_lnp = r.indel;
+        o.non_ambig = r.nonAmbiguousBasesInRead;
+        o.read_length = r.read_length;
+        o.is_tier1_read = r.is_tier1_read;
+        o.is_fwd_strand = r.is_fwd_strand;
+        o.read_pos = r.read_pos;
+        o.edge_dist = r.distanceFromClosestReadEdge;
+        o.n_alt = int32_t(r.alt_indel.size());
+        for (int a = 0; a < o.n_alt && a < 2; ++a) {
+            o.alt_pos[a] = r.alt_indel[a].first.pos;
+            o.alt_type[a] = r.alt_indel[a].first.type;
+            o.alt_del_len[a] = r.alt_indel[a].first.deletionLength;
+            std::strncpy(o.alt_ins[a], r.alt_indel[a].first.insertSequence.c_str(), 63);
+            o.alt_lnp[a] = r.alt_indel[a].second;
+        }
+    }
+    return n;
+}
+
 } // extern "C"

@@ -23,6 +23,7 @@ HIP_SOURCES = [
 ]
 HOST_SOURCES = [
     "host/align_flatten.cpp",
+    "host/read_realign.cpp",
 ]
 
 

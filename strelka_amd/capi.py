@@ -44,6 +44,50 @@ class CandidateAlignment(C.Structure):
                 ("indels", C.POINTER(IndelKey)), ("leading", IndelKey), ("trailing", IndelKey)]
 
 
+MAX_SAMPLES = 4
+SEG = dict(NONE=0, MATCH=1, INSERT=2, DELETE=3, SKIP=4, SOFT_CLIP=5, HARD_CLIP=6, PAD=7, SEQ_MATCH=8, SEQ_MISMATCH=9)
+CIGAR_CHARS = "?MIDNSHP=X"
+INDEL = dict(NONE=0, INDEL=1, MISMATCH=2, BP_LEFT=3, BP_RIGHT=4)
+MAPLEVEL = dict(UNKNOWN=0, TIER1=1, TIER2=2, SUB=3, UNMAPPED=4)
+
+
+class RealignOptions(C.Structure):
+    _fields_ = [("max_read_indel_toggle", C.c_int32), ("max_candidate_indel_density", C.c_double),
+                ("max_realignment_candidates", C.c_uint32), ("max_indel_size", C.c_uint32),
+                ("is_smoothed_alignments", C.c_int32), ("smoothed_lnp_range", C.c_double),
+                ("upstream_oligo_size", C.c_uint32), ("is_haplotyping_enabled", C.c_int32),
+                ("min_read_bp_flank", C.c_int32), ("sample_count", C.c_int32)]
+
+
+class IndelInfo(C.Structure):
+    _fields_ = [("key", IndelKey), ("ref_to_indel_log_prob", C.c_double), ("indel_to_ref_log_prob", C.c_double),
+                ("active_region_id", C.c_int32), ("haplotype_id", C.c_int8 * MAX_SAMPLES),
+                ("is_haplotyping_bypassed", C.c_uint8 * MAX_SAMPLES), ("is_forced_output", C.c_uint8),
+                ("not_discovered_from_reads", C.c_uint8)]
+
+
+class ReadInput(C.Structure):
+    _fields_ = [("read_code", c_void_p), ("read_qual", c_void_p), ("read_len", C.c_int32), ("pos", C.c_int32),
+                ("n_seg", C.c_int32), ("path", C.POINTER(PathSeg)), ("is_fwd_strand", C.c_int32),
+                ("map_level", C.c_int32), ("sample_index", C.c_int32), ("realign_begin", C.c_int32),
+                ("realign_end", C.c_int32), ("n_observed", C.c_int32), ("observed", C.POINTER(C.c_int32))]
+
+
+class ReadPathScores(C.Structure):
+    _fields_ = [("indel", C.c_int32), ("ref_lnp", C.c_float), ("indel_lnp", C.c_float), ("non_ambig", C.c_uint16),
+                ("read_length", C.c_uint16), ("is_tier1_read", C.c_uint8), ("is_fwd_strand", C.c_uint8),
+                ("read_pos", C.c_int16), ("distance_from_closest_read_edge", C.c_int16), ("n_alt", C.c_int32),
+                ("alt_indel", C.c_int32 * 2), ("alt_lnp", C.c_float * 2)]
+
+
+class ReadResult(C.Structure):
+    _fields_ = [("n_candidate_alignments", C.c_int32), ("is_realigned", C.c_int32), ("realign_pos", C.c_int32),
+                ("realign_n_seg", C.c_int32), ("realign_path", C.POINTER(PathSeg)), ("max_score", C.c_double),
+                ("n_scores", C.c_int32), ("scores", C.POINTER(ReadPathScores)), ("n_suboverlap", C.c_int32),
+                ("suboverlap", C.POINTER(C.c_int32)), ("warn_origin_skip", C.c_int32),
+                ("warn_max_toggle_depth", C.c_int32)]
+
+
 class PileupBatch(C.Structure):
     _fields_ = [("n_loci", C.c_int32), ("call_off", c_void_p), ("calls", c_void_p), ("de", c_void_p),
                 ("ref_base", c_void_p), ("ploidy", c_void_p)]
@@ -105,7 +149,11 @@ EXPORTS = [
     "sk_init", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_get_qscore_tables",
     "sk_score_alignments", "sk_score_alignments_dev",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_add_read",
-    "sk_align_builder_finish",
+    "sk_align_builder_finish", "sk_align_builder_error",
+    "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
+    "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_get_batch",
+    "sk_realign_job_finish", "sk_realign_job_run", "sk_realign_job_n_reads", "sk_realign_job_read_result",
+    "sk_realign_job_clear_reads", "sk_make_start_pos_alignment", "sk_get_end_pin_start_pos",
     "sk_germline_options_default", "sk_dependent_eprob", "sk_dependent_eprob_dev", "sk_site_digt_call",
     "sk_site_digt_call_dev", "sk_site_digt_call_fused", "sk_site_digt_call_fused_dev",
     "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
@@ -139,6 +187,26 @@ def lib():
         L.sk_align_builder_add_read.argtypes = [c_void_p, c_void_p, c_void_p, C.c_int32, C.c_char_p, C.c_int32,
                                                 C.c_int32, C.POINTER(CandidateAlignment), C.c_int32]
         L.sk_align_builder_finish.argtypes = [c_void_p, C.POINTER(AlignBatch)]
+        L.sk_realign_options_default.argtypes = [C.POINTER(RealignOptions)]
+        L.sk_realign_job_create.restype = c_void_p
+        L.sk_realign_job_create.argtypes = [C.POINTER(RealignOptions)]
+        L.sk_realign_job_destroy.argtypes = [c_void_p]
+        L.sk_realign_job_error.restype = C.c_char_p
+        L.sk_realign_job_error.argtypes = [c_void_p]
+        L.sk_realign_job_set_reference.argtypes = [c_void_p, C.c_char_p, C.c_int32, C.c_int32]
+        L.sk_realign_job_set_indels.argtypes = [c_void_p, C.POINTER(IndelInfo), C.c_int32]
+        L.sk_realign_job_add_read.argtypes = [c_void_p, C.POINTER(ReadInput)]
+        L.sk_realign_job_get_batch.argtypes = [c_void_p, C.POINTER(AlignBatch)]
+        L.sk_realign_job_finish.argtypes = [c_void_p, c_void_p]
+        L.sk_realign_job_run.argtypes = [c_void_p]
+        L.sk_realign_job_n_reads.argtypes = [c_void_p]
+        L.sk_realign_job_read_result.argtypes = [c_void_p, C.c_int32, C.POINTER(ReadResult)]
+        L.sk_realign_job_clear_reads.argtypes = [c_void_p]
+        L.sk_make_start_pos_alignment.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(IndelKey),
+                                                  C.c_int32, C.POINTER(C.c_int32), C.POINTER(PathSeg), C.c_int32,
+                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.sk_get_end_pin_start_pos.argtypes = [C.POINTER(IndelKey), C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
+                                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.sk_score_alignments.argtypes = [C.POINTER(AlignBatch), c_void_p]
         L.sk_score_alignments_dev.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
         L.sk_score_alignments_dev_generic.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
@@ -288,21 +356,24 @@ class AlignBuilder:
         s = AlignBatch()
         if lib().sk_align_builder_finish(self._b, C.byref(s)) != 0:
             raise StrelkaAmdError("sk_align_builder_finish failed")
+        return _host_batch_from_struct(s)
 
-        def arr(ptr, n, dt):
-            if n == 0 or not ptr:
-                return np.zeros(0, dt)
-            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
-            return np.frombuffer(buf, dtype=dt).copy()
 
-        n, nc = s.n_reads, s.n_cals
-        read_off = arr(s.read_off, n + 1, np.int64)
-        hap_off = arr(s.hap_off, n + 1, np.int64)
-        return HostAlignBatch(read_off, arr(s.read_code, int(read_off[-1]), np.uint8),
-                              arr(s.read_qual, int(read_off[-1]), np.uint8), hap_off,
-                              arr(s.hap_code, int(hap_off[-1]), np.uint8), arr(s.cal_off, n + 1, np.int32),
-                              arr(s.op_off, nc + 1, np.int64), arr(s.ops, s.n_ops, SCORE_OP_DTYPE), s.max_read_len,
-                              s.max_hap_len)
+def _host_batch_from_struct(s):
+    def arr(ptr, n, dt):
+        if n == 0 or not ptr:
+            return np.zeros(0, dt)
+        buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    n, nc = s.n_reads, s.n_cals
+    read_off = arr(s.read_off, n + 1, np.int64)
+    hap_off = arr(s.hap_off, n + 1, np.int64)
+    return HostAlignBatch(read_off, arr(s.read_code, int(read_off[-1]), np.uint8),
+                          arr(s.read_qual, int(read_off[-1]), np.uint8), hap_off,
+                          arr(s.hap_code, int(hap_off[-1]), np.uint8), arr(s.cal_off, n + 1, np.int32),
+                          arr(s.op_off, nc + 1, np.int64), arr(s.ops, s.n_ops, SCORE_OP_DTYPE), s.max_read_len,
+                          s.max_hap_len)
 
 
 class HostPileupBatch:
@@ -444,3 +515,157 @@ def allele_group_genotype_lhoods(batch, opt=None):
     s = batch.struct()
     _check(lib().sk_allele_group_genotype_lhoods(C.byref(s), C.byref(opt), _p(out)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- realign job
+
+def cigar_to_path(cigar):
+    out, num = [], ""
+    for ch in cigar:
+        if ch.isdigit():
+            num += ch
+        else:
+            out.append((CIGAR_CHARS.index(ch), int(num)))
+            num = ""
+    return out
+
+
+def path_to_cigar(path):
+    return "".join("%d%s" % (l, CIGAR_CHARS[t]) for t, l in path)
+
+
+def realign_options(**kw):
+    o = RealignOptions()
+    lib().sk_realign_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _ckeys(keys, keep):
+    arr = (IndelKey * max(len(keys), 1))()
+    for i, k in enumerate(keys):
+        arr[i] = AlignBuilder._key(k, keep)
+    return arr
+
+
+def make_start_pos_alignment(ref_start_pos, read_start_pos, is_fwd, read_length, indels):
+    """-> dict(pos, path, leading, trailing) (indices into `indels`) or None when the arguments are rejected"""
+    keep = []
+    arr = _ckeys(indels, keep)
+    cap = 2 * len(indels) + 4
+    path = (PathSeg * cap)()
+    pos, lead, trail = C.c_int32(), C.c_int32(), C.c_int32()
+    n = lib().sk_make_start_pos_alignment(ref_start_pos, read_start_pos, int(is_fwd), read_length, arr, len(indels),
+                                          C.byref(pos), path, cap, C.byref(lead), C.byref(trail))
+    if n < 0:
+        return None
+    return dict(pos=pos.value, path=[(path[i].type, path[i].length) for i in range(n)], leading=lead.value,
+                trailing=trail.value)
+
+
+def get_end_pin_start_pos(indels, read_length, ref_end_pos, read_end_pos):
+    keep = []
+    arr = _ckeys(indels, keep)
+    a, b = C.c_int32(), C.c_int32()
+    if lib().sk_get_end_pin_start_pos(arr, len(indels), read_length, ref_end_pos, read_end_pos, C.byref(a), C.byref(b)):
+        return None
+    return a.value, b.value
+
+
+class RealignJob:
+    """sk_realign_job wrapper (realignAndScoreRead as a batched job)."""
+
+    def __init__(self, opt=None):
+        self.opt = opt or realign_options()
+        self._j = lib().sk_realign_job_create(C.byref(self.opt))
+        if not self._j:
+            raise StrelkaAmdError("sk_realign_job_create failed")
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if self._j:
+                lib().sk_realign_job_destroy(self._j)
+        except Exception:
+            pass
+
+    def _err(self):
+        return StrelkaAmdError(lib().sk_realign_job_error(self._j).decode())
+
+    def set_reference(self, seq, offset=0):
+        b = seq.encode()
+        if lib().sk_realign_job_set_reference(self._j, b, offset, len(b)):
+            raise self._err()
+
+    def set_indels(self, indels):
+        """indels: dicts(pos,type,del_len,ins_seq,is_candidate, r2i, i2r [, arid, hap, bypass, forced, ndfr])"""
+        keep = []
+        arr = (IndelInfo * max(len(indels), 1))()
+        for i, d in enumerate(indels):
+            a = arr[i]
+            a.key = AlignBuilder._key(d, keep)
+            a.ref_to_indel_log_prob = d.get("r2i", 0.0)
+            a.indel_to_ref_log_prob = d.get("i2r", 0.0)
+            a.active_region_id = d.get("arid", -1)
+            hap = d.get("hap", 0)
+            byp = d.get("bypass", 0)
+            for s in range(MAX_SAMPLES):
+                a.haplotype_id[s] = hap[s] if isinstance(hap, (list, tuple)) else hap
+                a.is_haplotyping_bypassed[s] = byp[s] if isinstance(byp, (list, tuple)) else byp
+            a.is_forced_output = int(d.get("forced", 0))
+            a.not_discovered_from_reads = int(d.get("ndfr", 0))
+        if lib().sk_realign_job_set_indels(self._j, arr, len(indels)):
+            raise self._err()
+
+    def add_read(self, read_code, read_qual, pos, path, is_fwd=True, map_level=1, sample=0, realign_range=(0, 1 << 30),
+                 observed=()):
+        code = np.ascontiguousarray(read_code, np.uint8)
+        qual = np.ascontiguousarray(read_qual, np.uint8)
+        segs = (PathSeg * max(len(path), 1))(*[PathSeg(t, l) for t, l in path])
+        obs = (C.c_int32 * max(len(observed), 1))(*observed)
+        r = ReadInput(_p(code), _p(qual), len(code), pos, len(path), segs, int(is_fwd), map_level, sample,
+                      realign_range[0], realign_range[1], len(observed), obs)
+        i = lib().sk_realign_job_add_read(self._j, C.byref(r))
+        if i < 0:
+            raise self._err()
+        return i
+
+    def batch(self):
+        s = AlignBatch()
+        if lib().sk_realign_job_get_batch(self._j, C.byref(s)):
+            raise self._err()
+        return _host_batch_from_struct(s)
+
+    def finish(self, scores):
+        scores = np.ascontiguousarray(scores, np.float64)
+        if lib().sk_realign_job_finish(self._j, _p(scores)):
+            raise self._err()
+
+    def run(self):
+        if lib().sk_realign_job_run(self._j):
+            raise self._err()
+
+    def n_reads(self):
+        return lib().sk_realign_job_n_reads(self._j)
+
+    def clear_reads(self):
+        lib().sk_realign_job_clear_reads(self._j)
+
+    def result(self, i):
+        r = ReadResult()
+        if lib().sk_realign_job_read_result(self._j, i, C.byref(r)):
+            raise StrelkaAmdError("bad read index")
+        scores = []
+        for q in range(r.n_scores):
+            s = r.scores[q]
+            scores.append(dict(indel=s.indel, ref_lnp=s.ref_lnp, indel_lnp=s.indel_lnp, non_ambig=s.non_ambig,
+                               read_length=s.read_length, is_tier1_read=s.is_tier1_read, is_fwd_strand=s.is_fwd_strand,
+                               read_pos=s.read_pos, edge_dist=s.distance_from_closest_read_edge,
+                               alt=[(s.alt_indel[a], s.alt_lnp[a]) for a in range(s.n_alt)]))
+        return dict(n_cals=r.n_candidate_alignments, is_realigned=bool(r.is_realigned), pos=r.realign_pos,
+                    path=[(r.realign_path[i].type, r.realign_path[i].length) for i in range(r.realign_n_seg)],
+                    max_score=r.max_score, scores=scores, suboverlap=[r.suboverlap[i] for i in range(r.n_suboverlap)],
+                    warn_origin_skip=bool(r.warn_origin_skip), warn_max_toggle_depth=bool(r.warn_max_toggle_depth))

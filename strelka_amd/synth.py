@@ -354,3 +354,176 @@ def allele_group_batch(n_groups, rng, depth_mean=40.0, missing_rate=0.05):
     al = np.where(rng.random((total, capi.MAX_ALT)) < missing_rate, np.nan, al).astype(np.float32)
     na, rl, fl = _read_fields(total, rng)
     return capi.HostAlleleGroupBatch(off, n_alt, ploidy, del_len, ins_len, refl, al, na, rl, fl)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# whole-read realignment scenarios (realignAndScoreRead inputs): a reference window, an indel table, reads with input
+# alignments of the kinds a mapper produces (true gapped, gapless anchored either end, soft-clipped, edge inserts)
+
+_BASES = "ACGT"
+_CODE = {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15}
+
+
+def _random_ref(L, rng):
+    """random sequence with homopolymer and short-tandem-repeat stretches (so that equivalent indel placements exist)"""
+    out = []
+    while len(out) < L:
+        r = rng.random()
+        if r < 0.08:
+            out += [_BASES[int(rng.integers(4))]] * int(rng.integers(4, 12))
+        elif r < 0.14:
+            unit = [_BASES[int(x)] for x in rng.integers(0, 4, int(rng.integers(2, 4)))]
+            out += unit * int(rng.integers(3, 7))
+        else:
+            out += [_BASES[int(x)] for x in rng.integers(0, 4, int(rng.integers(5, 30)))]
+    return "".join(out[:L])
+
+
+def _conflict(a, b):
+    """is_indel_conflict for plain indels: closed ranges [pos, pos+del] intersect"""
+    return a["pos"] <= b["pos"] + b["del_len"] and b["pos"] <= a["pos"] + a["del_len"]
+
+
+def realign_scenarios(n, rng, reads_per=6, haplotyping_rate=0.25, max_indels=6):
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(160, 360))
+        off = int(rng.choice([0, 0, 1000, 25000]))
+        ref = _random_ref(L, rng)
+        n_ind = int(rng.integers(1, max_indels + 1))
+        indels = []
+        for _k in range(n_ind * 3):
+            if len(indels) >= n_ind:
+                break
+            p = off + int(rng.integers(25, L - 25))
+            r = rng.random()
+            if indels and rng.random() < 0.3:  # a shifted copy of an existing indel (same type/size, nearby)
+                src = indels[int(rng.integers(len(indels)))]
+                d = dict(src)
+                d["pos"] = src["pos"] + int(rng.integers(-3, 4))
+                if d["ins_seq"]:
+                    i0 = d["pos"] - off
+                    if rng.random() < 0.7 and 0 <= i0 and i0 + len(d["ins_seq"]) <= L:
+                        d["ins_seq"] = ref[i0:i0 + len(d["ins_seq"])]
+            elif r < 0.45:
+                d = dict(pos=p, type=INDEL["INDEL"], del_len=int(rng.choice([1, 1, 2, 3, 5, 8, 15, 30])), ins_seq="")
+            elif r < 0.9:
+                ln = int(rng.choice([1, 1, 2, 3, 4, 6, 10]))
+                if rng.random() < 0.5:
+                    seq = ref[p - off:p - off + ln]
+                else:
+                    seq = "".join(_BASES[int(x)] for x in rng.integers(0, 4, ln))
+                d = dict(pos=p, type=INDEL["INDEL"], del_len=0, ins_seq=seq)
+            else:
+                ln = int(rng.integers(1, 5))
+                d = dict(pos=p, type=INDEL["INDEL"], del_len=int(rng.integers(1, 6)),
+                         ins_seq="".join(_BASES[int(x)] for x in rng.integers(0, 4, ln)))
+            if d["pos"] < off + 10 or d["pos"] + d["del_len"] > off + L - 10:
+                continue
+            if any((d["pos"], d["del_len"], d["ins_seq"]) == (e["pos"], e["del_len"], e["ins_seq"]) for e in indels):
+                continue
+            d["is_candidate"] = int(rng.random() < 0.8)
+            indels.append(d)
+        is_hap = rng.random() < haplotyping_rate
+        for d in indels:
+            if is_hap and rng.random() < 0.8:
+                d["arid"] = int(rng.integers(0, 2))
+                d["hap"] = int(rng.integers(0, 4))
+                d["bypass"] = int(rng.random() < 0.2)
+                d["forced"] = int(rng.random() < 0.1)
+                d["ndfr"] = int(rng.random() < 0.15)
+        reads = []
+        for _r in range(reads_per):
+            # haplotype = a non-conflicting subset of the indels
+            hap = []
+            for i in rng.permutation(len(indels)):
+                if rng.random() < 0.5 and not any(_conflict(indels[i], indels[j]) for j in hap):
+                    hap.append(int(i))
+            hap.sort(key=lambda i: (indels[i]["pos"], indels[i]["del_len"]))
+            rl = int(rng.integers(40, 101))
+            start = off + int(rng.integers(0, max(1, L - rl - 35)))
+            # walk the haplotype from `start`
+            seq, path, used, p, hi = [], [], [], start, 0
+            while hi < len(hap) and indels[hap[hi]]["pos"] <= start:
+                hi += 1
+
+            def push(t, ln):
+                if ln <= 0:
+                    return
+                if path and path[-1][0] == t:
+                    path[-1] = (t, path[-1][1] + ln)
+                else:
+                    path.append((t, ln))
+            fixed = set()  # read positions that belong to inserted sequence (kept free of mismatches)
+            while len(seq) < rl:
+                nxt = indels[hap[hi]]["pos"] if hi < len(hap) else off + L
+                m = min(nxt - p, rl - len(seq), off + L - p)
+                if m > 0:
+                    seq += list(ref[p - off:p - off + m])
+                    push(SEG["MATCH"], m)
+                    p += m
+                if len(seq) >= rl or p >= off + L or hi >= len(hap):
+                    if p >= off + L:
+                        break
+                    if hi >= len(hap) and len(seq) < rl:
+                        continue
+                    break
+                d = indels[hap[hi]]
+                hi += 1
+                used.append(hap[hi - 1])
+                if d["del_len"]:
+                    push(SEG["DELETE"], d["del_len"])
+                    p += d["del_len"]
+                if d["ins_seq"]:
+                    k = min(len(d["ins_seq"]), rl - len(seq))
+                    fixed.update(range(len(seq), len(seq) + k))
+                    seq += list(d["ins_seq"][:k])
+                    push(SEG["INSERT"], k)
+            rl = len(seq)
+            if rl < 20:
+                continue
+            while path and path[-1][0] == SEG["DELETE"]:
+                path.pop()
+            for i in range(rl):
+                if i not in fixed and rng.random() < 0.015:
+                    seq[i] = _BASES[(_BASES.index(seq[i]) + int(rng.integers(1, 4))) % 4]
+                if i not in fixed and rng.random() < 0.004:
+                    seq[i] = "N"
+            code = np.array([_CODE[c] for c in seq], np.uint8)
+            qual = rng.integers(2, 41, rl).astype(np.uint8)
+            ref_len = sum(l for t, l in path if t in (SEG["MATCH"], SEG["DELETE"]))
+            kind = rng.random()
+            observed = list(used)
+            if kind < 0.45:
+                in_pos, in_path = start, list(path)
+            elif kind < 0.6:   # gapless, anchored at the read start
+                in_pos, in_path, observed = start, [(SEG["MATCH"], rl)], []
+            elif kind < 0.75:  # gapless, anchored at the read end
+                in_pos, in_path, observed = start + ref_len - rl, [(SEG["MATCH"], rl)], []
+            else:              # true alignment up to the first indel, the rest soft-clipped (either side)
+                observed = []
+                if len(path) == 1:
+                    c = int(rng.integers(1, 12))
+                    in_pos, in_path = start, [(SEG["MATCH"], rl - c), (SEG["SOFT_CLIP"], c)]
+                elif rng.random() < 0.5:
+                    m0 = path[0][1]
+                    in_pos, in_path = start, [(SEG["MATCH"], m0), (SEG["SOFT_CLIP"], rl - m0)]
+                else:
+                    m1 = path[-1][1] if path[-1][0] == SEG["MATCH"] else 0
+                    if m1 == 0:
+                        in_pos, in_path = start, list(path)
+                        observed = list(used)
+                    else:
+                        in_pos, in_path = start + ref_len - m1, [(SEG["SOFT_CLIP"], rl - m1), (SEG["MATCH"], m1)]
+            if in_pos < 0:
+                continue
+            lvl = rng.random()
+            rr = (max(0, off - 60), off + L + 60)
+            if rng.random() < 0.08:
+                rr = (max(0, start - int(rng.integers(0, 12))), start + ref_len + int(rng.integers(0, 12)))
+            reads.append(dict(code=code, qual=qual, pos=int(in_pos), path=in_path, is_fwd=bool(rng.random() < 0.5),
+                              map_level=1 if lvl < 0.8 else (2 if lvl < 0.93 else 3), observed=observed,
+                              realign_range=rr))
+        out.append(dict(ref_seq=ref, ref_offset=off, indels=indels, reads=reads, is_haplotyping_enabled=int(is_hap),
+                        min_read_bp_flank=int(rng.choice([5, 5, 5, 1]))))
+    return out

@@ -169,5 +169,24 @@ def main():
     print("wrote", sorted(os.listdir(HERE)))
 
 
+def realign_golden():
+    """hot path A, whole read: realignAndScoreRead of the reference on seeded scenarios (reference window + indel table +
+    reads); the fixture keeps inputs (with the error rates the reference's IndelBuffer attached) and per-read outputs"""
+    pyoracle.build(ref=True)
+    rng = np.random.default_rng(20240926)
+    scenarios = synth.realign_scenarios(70, rng) + synth.realign_scenarios(12, rng, max_indels=14)
+    expect = pyoracle.ref_realign_scenarios(scenarios)
+    with open(os.path.join(HERE, "patha_realign_reference.pkl"), "wb") as f:
+        pickle.dump(dict(scenarios=scenarios, expect=expect), f, protocol=4)
+    n = sum(len(e) for e in expect)
+    print("realign golden: %d scenarios, %d reads, %d realigned, %d indel scores" % (
+        len(scenarios), n, sum(r.get("is_realigned", False) for e in expect for r in e),
+        sum(len(r.get("scores", [])) for e in expect for r in e)))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "realign":
+        realign_golden()
+    else:
+        main()
+        realign_golden()
