@@ -17,6 +17,7 @@ Inputs are resident in HBM before any timed region starts.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -80,6 +81,22 @@ def cpu_baseline(args):
             "loci_per_s": args.cpu_loci / tb}
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes over this same command, tools/gpu_round.sh) -- used only when that run had the same
+    per-launch workload as this one; PMC counters cannot be collected from inside the timed run itself."""
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return {}
+    with open(files[-1]) as f:
+        d = json.load(f)
+    w = d.get("workload", {})
+    if (w.get("reads_per_step_per_gpu"), w.get("loci_per_step_per_gpu"), w.get("unique_reads"), w.get("unique_loci")) != \
+            (args.reads, args.loci, args.unique_reads, args.unique_loci):
+        return {}
+    return {k: v["hbm_bytes_per_launch"] for k, v in d.get("kernels", {}).items()}
+
+
 def main():
     args = parse()
     import torch
@@ -96,7 +113,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
-    from strelka_amd import capi, device, synth
+    from strelka_amd import capi, device, shard, synth
     capi.init(local_rank)
 
     # ---- resident inputs (per rank: an independent batch, seeded by rank = an independent genome segment) ----
@@ -112,46 +129,32 @@ def main():
     gopt = capi.germline_options()
     torch.cuda.synchronize()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    region = shard.Region(dist, world, torch.cuda.synchronize,
+                          lambda v: torch.tensor(v, dtype=torch.float64, device=dev))
 
-    def timed(fn, steps, warmup):
-        for _ in range(warmup):
-            fn()
+    def timed(fn, steps, warmup, units_per_step):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        barrier()
-        t0 = time.perf_counter()
-        for s, e in evs:
-            s.record()
-            fn()
-            e.record()
-        barrier()
-        dt = time.perf_counter() - t0
+        dt, units = region.timed(fn, steps, warmup, units_per_step,
+                                 on_step=lambda i, before: evs[i][0 if before else 1].record())
         kern_ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, kern_ms
+        return dt, units, kern_ms
 
     # ---- hot path A ----
-    dt_a, kms_a = timed(lambda: da.score(), args.steps, args.warmup)
-    cells_per_step = da.n_bases * 64 if ha.n_cals == ha.n_reads * 64 else None
     cells_per_step = int(np.diff(ha.read_off).astype(np.int64).dot(np.diff(ha.cal_off).astype(np.int64))) * tile_a
-    value = world * cells_per_step * args.steps / dt_a
+    dt_a, cells, kms_a = timed(lambda: da.score(), args.steps, args.warmup, cells_per_step)
+    value = cells / dt_a
     alg_bytes_a = A_BYTES_PER_READ * da.n_reads
     ach_a = alg_bytes_a / (kms_a * 1e-3) / 1e9
 
     # ---- hot path B (germline): dependent eprob + site genotype call ----
     def step_b():
         db.site_digt_call_fused(gopt)
-    dt_b, kms_b = timed(step_b, args.steps, args.warmup)
-    loci_per_s = world * db.n_loci * args.steps / dt_b
+    dt_b, loci, kms_b = timed(step_b, args.steps, args.warmup, db.n_loci)
+    loci_per_s = loci / dt_b
     alg_bytes_b = 6 * db.n_calls + B_BYTES_PER_LOCUS_FIXED * db.n_loci
     ach_b = alg_bytes_b / (kms_b * 1e-3) / 1e9
 
+    traffic = pmc_traffic(args)
     out = {
         "metric": "candidate-alignment scoring cells/s (read bases x candidate alignments; Strelka2 has no pair-HMM, "
                   "SURVEY.md section 0) + germline loci/s",
@@ -165,10 +168,12 @@ def main():
                    "loci_per_step_per_gpu": db.n_loci, "sharding": "independent segments per GPU, no collective"},
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
         "roofline": {"kernel": "score_wave_per_read", "bound": "hbm", "achieved": ach_a, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": ach_a / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": ach_a / HBM_PEAK_GBS,
+                     "traffic": traffic.get("score_wave_per_read"),
                      "algorithmic_bytes_per_launch": alg_bytes_a, "kernel_ms": kms_a},
         "roofline_loci": {"kernel": "germline_site_fused_kernel", "bound": "hbm", "achieved": ach_b,
-                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS, "traffic": None,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS,
+                          "traffic": traffic.get("germline_site_fused_kernel"),
                           "algorithmic_bytes_per_launch": alg_bytes_b, "kernel_ms": kms_b},
     }
     if rank == 0:
