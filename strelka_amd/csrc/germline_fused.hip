@@ -33,7 +33,7 @@ constexpr int CAP_CALLS = 5312;       // LDS budget: 4 B/call -> 22 KiB (+12 KiB
 constexpr int MAX_RANK = 4;           // ranked calls per group on the LDS path (defaults need <= 4: 1, .65, .4225, .2746)
 constexpr int V0R_PER_LOCUS = 12;    // LDS floats per locus for val[0] of ranks 2..MAX_RANK (rank 1 has de == e_q), packed
                                      // group after group; a locus needing more takes the global pass
-constexpr int MAX_PACKED_DEPTH = 1022; // index fits 10 bits beside the 6-bit q in a u16 sort key
+constexpr int MAX_PACKED_DEPTH = 511;  // sort key u16 = q << 10 | neighbor-mismatch << 9 | 9-bit call index
 constexpr unsigned RANK_SHIFT = 13;    // bits 13..15 of the LDS basecall copy hold the rank (bit 13 = tscf, unused here)
 constexpr unsigned CALL_MASK = 0x1fffu;
 constexpr uint32_t NEEDS_GLOBAL_PASS = 0xffffffffu; // sentinel in sk_digt_call::is_called between the two passes
@@ -130,33 +130,35 @@ __device__ void k_heap_sort(uint16_t* first, uint16_t* last)
     }
 }
 
-constexpr int SORT_STACK = 4; // pending left parts kept per thread (LDS); deeper recursion -> caller falls back
-
-// returns false when the pending-part stack would overflow (n in the hundreds with adversarial splits)
-__device__ bool k_std_sort(uint16_t* idx, const int n, uint32_t* stack)
+// The first `need` (<= MAX_RANK) elements of std::sort(keys, keys+n, q descending) WITHOUT sorting.
+//
+// libstdc++'s std::sort = __introsort_loop (median-of-3 pivot, unguarded partition, recursing into the RIGHT part and
+// looping on the left, ranges of <= 16 left alone) followed by one insertion sort over the whole array.  That insertion
+// sort is stable (strict comparisons), and after the partitioning every element of an earlier final range compares >=
+// every element of a later one, so the sorted array is the concatenation of the stably sorted final ranges.  Its first
+// elements therefore need only (a) the partition steps along the LEFTMOST chain of ranges -- partitioning a range never
+// touches elements outside it, so the right parts can be left unpartitioned until they are reached -- and (b) a stable
+// top-k selection inside each final range reached.  Both are emulated step for step (the tie order decides which calls
+// get the first exponents).
+// Returns false when the reference would enter its heap-sort fallback (depth limit) or the chain is deeper than the
+// 4-entry boundary stack: the caller then takes the full emulation in the global-memory pass.
+__device__ bool k_top_ranked(uint16_t* keys, const int n, const int need, uint16_t (&res)[MAX_RANK], int& nres)
 {
-    if (n <= 16) {
-        k_insertion_sort(idx, idx + n);
-        return true;
-    }
+    nres = 0;
     int lg = 0;
     for (unsigned m = unsigned(n); m > 1; m >>= 1) ++lg;
-    // entry = first | last << 10 | depth << 20   (n <= 1023, depth <= 18)
+    // pending range ends, innermost in the low 16 bits: entry = last | depth_limit << 10
+    uint64_t stack = uint64_t(unsigned(n) | (unsigned(2 * lg) << 10));
     int sp = 1;
-    stack[0] = 0u | (unsigned(n) << 10) | (unsigned(lg * 2) << 20);
-    while (sp > 0) {
-        --sp;
-        const uint32_t ent = stack[sp];
-        int first = int(ent & 0x3ffu), last = int((ent >> 10) & 0x3ffu), depth = int(ent >> 20);
+    int first = 0;
+    while (nres < need && first < n) {
+        int last = int(stack & 0x3ffu), depth = int((stack >> 10) & 0x3fu);
         while (last - first > 16) {
-            if (depth == 0) {
-                k_heap_sort(idx + first, idx + last);
-                break;
-            }
+            if (depth == 0) return false;
             --depth;
-            uint16_t* a = idx + first + 1;
-            uint16_t* b = idx + first + (last - first) / 2;
-            uint16_t* c = idx + last - 1;
+            uint16_t* a = keys + first + 1;
+            uint16_t* b = keys + first + (last - first) / 2;
+            uint16_t* c = keys + last - 1;
             uint16_t* pick;
             if (kgt(*a, *b)) {
                 if (kgt(*b, *c)) pick = b;
@@ -166,13 +168,13 @@ __device__ bool k_std_sort(uint16_t* idx, const int n, uint32_t* stack)
             else if (kgt(*b, *c)) pick = c;
             else pick = b;
             {
-                const uint16_t t = idx[first];
-                idx[first] = *pick;
+                const uint16_t t = keys[first];
+                keys[first] = *pick;
                 *pick = t;
             }
-            uint16_t* lo = idx + first + 1;
-            uint16_t* hi = idx + last;
-            const uint16_t pivot = idx[first];
+            uint16_t* lo = keys + first + 1;
+            uint16_t* hi = keys + last;
+            const uint16_t pivot = keys[first];
             for (;;) {
                 while (kgt(*lo, pivot)) ++lo;
                 --hi;
@@ -183,15 +185,39 @@ __device__ bool k_std_sort(uint16_t* idx, const int n, uint32_t* stack)
                 *hi = t;
                 ++lo;
             }
-            const int cut = int(lo - idx);
-            if (sp >= SORT_STACK) return false;
-            stack[sp] = unsigned(first) | (unsigned(cut) << 10) | (unsigned(depth) << 20);
+            const int cut = int(lo - keys);
+            if (sp >= 4) return false;
+            // the right part [cut, last) keeps the decremented depth limit; descend into the left part
+            stack = ((stack & ~uint64_t(0xffffu)) | uint64_t(unsigned(last) | (unsigned(depth) << 10))) << 16 |
+                    uint64_t(unsigned(cut) | (unsigned(depth) << 10));
             ++sp;
-            first = cut;
+            last = cut;
         }
+        // final range [first, last): stable selection of its best (need - nres) keys; q >= 3 for every real key, so a
+        // zero key never displaces one
+        uint16_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        for (int i = first; i < last; ++i) {
+            const uint16_t x = keys[i];
+            const bool c0 = kgt(x, t0), c1 = kgt(x, t1), c2 = kgt(x, t2), c3 = kgt(x, t3);
+            t3 = c2 ? t2 : (c3 ? x : t3);
+            t2 = c1 ? t1 : (c2 ? x : t2);
+            t1 = c0 ? t0 : (c1 ? x : t1);
+            t0 = c0 ? x : t0;
+        }
+        const int take = min(last - first, need - nres);
+        const uint16_t sel[4] = { t0, t1, t2, t3 };
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < take) {
+#pragma unroll
+                for (int r = 0; r < MAX_RANK; ++r)
+                    if (r == nres + k) res[r] = sel[k];
+            }
+        nres += take;
+        first = last;
+        stack >>= 16;
+        --sp;
     }
-    k_insertion_sort(idx, idx + 16);
-    for (uint16_t* i = idx + 16; i != idx + n; ++i) k_unguarded_linear_insert(i);
     return true;
 }
 
@@ -240,38 +266,75 @@ __device__ __forceinline__ float call_v0(const uint16_t c, const float4 qv, cons
     return (rank >= 2 && !raw) ? ranked : tab;
 }
 
-// phase 1 for one locus in LDS.  Returns false when a group needs more than MAX_RANK ranked calls (caller falls back).
+// phase 1 for one locus in LDS.  Returns false when the locus needs the full emulation (caller falls back).
+//   pass A  count the members of the eight (strand, base) groups           (16-bit fields of two 64-bit registers)
+//   pass B  write every member's sort key into its group's slice of `keys` (pileup order inside a group)
+//   then per present group: mismatch fraction -> exponent chain length -> the first ranked calls -> their val[0] terms
 __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, const SkTables* __restrict__ T,
                                  const GermlineDerived& D, const QTab& Q, float (&vfrac)[8], float* v0r,
-                                 unsigned& gbase, uint32_t* sort_stack)
+                                 unsigned& gbase)
 {
     gbase = 0;
     unsigned nslots = 0;
 #pragma unroll
     for (int g = 0; g < 8; ++g) vfrac[g] = 0.f;
     if (!D.is_dependent_eprob) return true;
-    // which (strand, base) groups are present
-    unsigned present = 0;
+
+    uint64_t cntA = 0, cntB = 0; // groups 0-3 / 4-7
     for (int i = 0; i < n; ++i) {
         const uint16_t b = calls[i];
-        if (SKC_FILTER(b) || SKC_Q(b) < 3) continue;
-        present |= 1u << (SKC_FWD(b) + 2 * SKC_BASE(b));
+        const bool valid = !(SKC_FILTER(b) || SKC_Q(b) < 3);
+        const unsigned g = SKC_FWD(b) + 2 * SKC_BASE(b);
+        const uint64_t inc = valid ? (uint64_t(1) << (16 * (g & 3))) : 0;
+        cntA += (g < 4) ? inc : 0;
+        cntB += (g >= 4) ? inc : 0;
     }
+    // exclusive prefix sums of the eight counts, same packing (no field overflows: n <= 511)
+    const uint64_t inclA = cntA + (cntA << 16) + (cntA << 32) + (cntA << 48);
+    const uint64_t inclB = cntB + (cntB << 16) + (cntB << 32) + (cntB << 48);
+    const uint64_t totalA = inclA >> 48;
+    uint64_t posA = inclA << 16, posB = (inclB << 16) + totalA * 0x0001000100010001ull;
+    for (int i = 0; i < n; ++i) {
+        const uint16_t b = calls[i];
+        const bool valid = !(SKC_FILTER(b) || SKC_Q(b) < 3);
+        const unsigned g = SKC_FWD(b) + 2 * SKC_BASE(b);
+        const unsigned sh = 16 * (g & 3);
+        const unsigned off = unsigned(((g < 4) ? posA : posB) >> sh) & 0xffffu;
+        if (valid) keys[off] = uint16_t((SKC_Q(b) << 10) | (SKC_NMM(b) << 9) | unsigned(i));
+        const uint64_t inc = valid ? (uint64_t(1) << sh) : 0;
+        posA += (g < 4) ? inc : 0;
+        posB += (g >= 4) ? inc : 0;
+    }
+    // posA/posB now hold the END offset of every group's slice
+
     bool ok = true;
-    // lanes walk their k-th present group together (groups are independent; ascending order as in the reference)
+    // Groups are independent, so the order in which a locus visits them is free.  Lanes visit their groups LARGEST FIRST:
+    // the lanes of a wave then work on groups of similar size at the same time (the two big reference-base groups,
+    // then the one- or two-call error groups) instead of pairing one lane's 20-call group with another's single call.
+    unsigned present = 0;
+#pragma unroll
+    for (unsigned g = 0; g < 8; ++g)
+        if ((((g < 4) ? cntA : cntB) >> (16 * (g & 3))) & 0xffffu) present |= 1u << g;
     while (present) {
-        const unsigned g = __builtin_ctz(present);
-        present &= present - 1;
-        int gs = 0;
-        float num = 0.f, den = 0.f;
-        for (int i = 0; i < n; ++i) {
-            const uint16_t b = calls[i];
-            if (SKC_FILTER(b) || SKC_Q(b) < 3) continue;
-            if (SKC_FWD(b) + 2 * SKC_BASE(b) != g) continue;
-            keys[gs++] = uint16_t((SKC_Q(b) << 10) | unsigned(i));
-            const float weight = Q.weight[SKC_Q(b)];
+        unsigned g = 0, best = 0;
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) {
+            const unsigned ck = unsigned(((k < 4) ? cntA : cntB) >> (16 * (k & 3))) & 0xffffu;
+            const bool take = ((present >> k) & 1u) && ck > best;
+            g = take ? k : g;
+            best = take ? ck : best;
+        }
+        present &= ~(1u << g);
+        const unsigned sh = 16 * (g & 3);
+        const int gs = int(((g < 4) ? cntA : cntB) >> sh) & 0xffff;
+        uint16_t* gk = keys + ((int(((g < 4) ? posA : posB) >> sh) & 0xffff) - gs);
+
+        float num = 0.f, den = 0.f; // adjust_icalls_eprob :110-127, pileup order
+        for (int i = 0; i < gs; ++i) {
+            const unsigned k = gk[i];
+            const float weight = Q.weight[k >> 10];
             den = __fadd_rn(den, weight);
-            if (SKC_NMM(b)) num = __fadd_rn(num, weight);
+            if (k & 0x200u) num = __fadd_rn(num, weight);
         }
         float mismatch_frac = 0.f;
         if (den > 0.) mismatch_frac = __fdiv_rn(num, den);
@@ -282,33 +345,51 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
         for (unsigned k = 0; k < 8; ++k)
             if (k == g) vfrac[k] = vexp_frac;
 
-        if (!k_std_sort(keys, gs, sort_stack)) {
+        // how many calls of the sorted group get an exponent above the floor (:146-178): those need their rank
+        const float m = __fsub_rn(1.f, vexp_frac);
+        int nrank = 0;
+        {
+            float vexp = 1.f;
+            bool is_min = false;
+            while (!is_min && nrank < gs && nrank <= MAX_RANK) {
+                ++nrank;
+                const float next_vexp = __fmul_rn(vexp, m);
+                if (D.is_min_vexp) {
+                    is_min = (next_vexp <= D.min_vexp);
+                    vexp = (D.min_vexp < next_vexp) ? next_vexp : D.min_vexp;
+                } else {
+                    vexp = next_vexp;
+                }
+            }
+        }
+        if (nrank > MAX_RANK) {
             ok = false;
             break;
         }
-
-        bool is_min = false;
-        float vexp = 1.f;
-        const float m = __fsub_rn(1.f, vexp_frac);
+        uint16_t top[MAX_RANK];
+        int ntop = 0;
+        if (!k_top_ranked(gk, gs, nrank, top, ntop)) {
+            ok = false;
+            break;
+        }
         gbase |= nslots << (4 * g);
-        for (int i = 0; i < gs && !is_min; ++i) {
-            if (i >= MAX_RANK || (i >= 1 && nslots >= unsigned(V0R_PER_LOCUS))) {
-                ok = false;
-                break;
-            }
-            const unsigned ci = keys[i] & 0x3ffu;
-            const uint16_t c = calls[ci];
-            calls[ci] = uint16_t(c | ((unsigned(i) + 1u) << RANK_SHIFT));
-            if (i >= 1) { // rank 1 has vexp == 1 -> de == e_q exactly, a table term
-                const float de = get_dependent_eprob(Q.eprob[SKC_Q(c)], vexp);
-                v0r[nslots++] = __fadd_rn(logf_via_double(de), T->g_log_one_third);
-            }
-            const float next_vexp = __fmul_rn(vexp, m);
-            if (D.is_min_vexp) {
-                is_min = (next_vexp <= D.min_vexp);
-                vexp = (D.min_vexp < next_vexp) ? next_vexp : D.min_vexp;
-            } else {
-                vexp = next_vexp;
+        if (nslots + unsigned(ntop > 1 ? ntop - 1 : 0) > unsigned(V0R_PER_LOCUS)) {
+            ok = false;
+            break;
+        }
+        float vexp = 1.f;
+#pragma unroll
+        for (int i = 0; i < MAX_RANK; ++i) {
+            if (i < ntop) {
+                const unsigned ci = top[i] & 0x1ffu;
+                const uint16_t c = calls[ci];
+                calls[ci] = uint16_t(c | ((unsigned(i) + 1u) << RANK_SHIFT));
+                if (i >= 1) { // rank 1 has vexp == 1 -> de == e_q exactly, a table term
+                    const float de = get_dependent_eprob(Q.eprob[SKC_Q(c)], vexp);
+                    v0r[nslots++] = __fadd_rn(logf_via_double(de), T->g_log_one_third);
+                }
+                const float next_vexp = __fmul_rn(vexp, m);
+                vexp = D.is_min_vexp ? ((D.min_vexp < next_vexp) ? next_vexp : D.min_vexp) : next_vexp;
             }
         }
     }
@@ -387,7 +468,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
     __shared__ uint16_t s_keys[CAP_CALLS];
     __shared__ int64_t s_off[LOCI_PER_BLOCK + 1];
     __shared__ float s_v0r[LOCI_PER_BLOCK * V0R_PER_LOCUS];
-    __shared__ uint32_t s_stack[FUSED_THREADS * SORT_STACK];
     __shared__ QTab s_q;
 
     const int tid = threadIdx.x;
@@ -433,7 +513,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
             bool ok = (n <= MAX_PACKED_DEPTH);
             float* v0r = s_v0r + tid * V0R_PER_LOCUS;
             unsigned gbase = 0;
-            if (ok) ok = locus_rank_calls(s_calls + off, s_keys + off, n, T, a.d, s_q, vfrac, v0r, gbase, s_stack + tid * SORT_STACK);
+            if (ok) ok = locus_rank_calls(s_calls + off, s_keys + off, n, T, a.d, s_q, vfrac, v0r, gbase);
             if (ok) {
                 sk_digt_call res;
                 locus_call_lds(s_calls + off, n, ref, ploidy, v0r, gbase, T, a.d, s_q, res);
