@@ -339,12 +339,13 @@ int sk_site_digt_call_dev(const sk_pileup_batch* dev_batch, const sk_germline_op
 /** a9+a10 fused: CleanPileupErrorProb followed by position_snp_call_pprob_digt for every locus in one pass
  *  (L/applications/starling/starling_pos_processor.cpp:146-196 calls them back to back per locus).  The pileup is staged
  *  once through LDS; `de` never travels through HBM unless `out_de` is non-NULL.  batch.de is ignored.
- *  dev variant: dev_scratch >= 4 bytes per call and dev_de_tmp >= 4 bytes per call are used only by loci too deep for
- *  the LDS path (and dev_de_tmp doubles as the `de` output when want_de != 0). */
+ *  dev variant: dev_de_tmp >= 4 bytes per call and dev_scratch >= 4 * (n_calls + n_loci + 4) bytes (n_calls = the
+ *  batch's call_off[n_loci], which the host knows) serve the few loci that leave the LDS path -- sort scratch, then a
+ *  work-list of their indices; dev_de_tmp doubles as the `de` output when want_de != 0. */
 int sk_site_digt_call_fused(const sk_pileup_batch* host_batch, const sk_germline_options* opt, sk_digt_call* out,
                             float* out_de /* may be NULL */);
 int sk_site_digt_call_fused_dev(const sk_pileup_batch* dev_batch, const sk_germline_options* opt, sk_digt_call* dev_out,
-                                float* dev_de_tmp, int want_de, void* dev_scratch, void* hip_stream);
+                                float* dev_de_tmp, int want_de, void* dev_scratch, int64_t n_calls, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (somatic SNV): 30-state frequency-grid likelihoods + 3x2 posterior

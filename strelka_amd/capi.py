@@ -217,7 +217,7 @@ def lib():
         L.sk_site_digt_call_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p, c_void_p]
         L.sk_site_digt_call_fused.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p, c_void_p]
         L.sk_site_digt_call_fused_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p, c_void_p,
-                                                  C.c_int, c_void_p, c_void_p]
+                                                  C.c_int, c_void_p, C.c_int64, c_void_p]
         L.sk_somatic_snv_call_batch.argtypes = [C.POINTER(PileupBatch), C.POINTER(PileupBatch),
                                                 C.POINTER(SomaticSnvOptions), C.c_int, c_void_p]
         L.sk_somatic_snv_call_batch_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(PileupBatch),

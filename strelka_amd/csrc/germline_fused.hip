@@ -22,6 +22,7 @@
 
 #include "germline_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace
@@ -36,7 +37,7 @@ constexpr int V0R_PER_LOCUS = 12;    // LDS floats per locus for val[0] of ranks
 constexpr int MAX_PACKED_DEPTH = 511;  // sort key u16 = q << 10 | neighbor-mismatch << 9 | 9-bit call index
 constexpr unsigned RANK_SHIFT = 13;    // bits 13..15 of the LDS basecall copy hold the rank (bit 13 = tscf, unused here)
 constexpr unsigned CALL_MASK = 0x1fffu;
-constexpr uint32_t NEEDS_GLOBAL_PASS = 0xffffffffu; // sentinel in sk_digt_call::is_called between the two passes
+constexpr uint32_t NEEDS_GLOBAL_PASS = 0xffffffffu; // is_called of a locus queued for the global-memory pass
 
 // per-q float tables, copied into LDS once per block: the per-call loops index them with a data-dependent q, and an
 // LDS read costs a fraction of a (cached) global load's latency
@@ -53,6 +54,8 @@ struct FusedArgs
     sk_digt_call* out;
     float* de_tmp;      // global de (output when want_de, scratch for the deep-locus path)
     uint32_t* scratch;  // global sort scratch for the deep-locus path
+    uint32_t* work_count; // number of loci left to the global-memory pass, and their indices
+    uint32_t* worklist;
     int want_de;
     GermlineDerived d;
 };
@@ -140,63 +143,22 @@ __device__ void k_heap_sort(uint16_t* first, uint16_t* last)
 // touches elements outside it, so the right parts can be left unpartitioned until they are reached -- and (b) a stable
 // top-k selection inside each final range reached.  Both are emulated step for step (the tie order decides which calls
 // get the first exponents).
-// Returns false when the reference would enter its heap-sort fallback (depth limit) or the chain is deeper than the
-// 4-entry boundary stack: the caller then takes the full emulation in the global-memory pass.
+// A right part is only ever entered when the left part beside it holds fewer elements than are still needed (then that
+// left part is at most 3 elements, i.e. already a final range), so no stack of pending ranges is required.
+// Returns false when the reference would enter its heap-sort fallback (depth limit exhausted): the caller then takes
+// the full emulation in the global-memory pass.
 __device__ bool k_top_ranked(uint16_t* keys, const int n, const int need, uint16_t (&res)[MAX_RANK], int& nres)
 {
     nres = 0;
     int lg = 0;
     for (unsigned m = unsigned(n); m > 1; m >>= 1) ++lg;
-    // pending range ends, innermost in the low 16 bits: entry = last | depth_limit << 10
-    uint64_t stack = uint64_t(unsigned(n) | (unsigned(2 * lg) << 10));
-    int sp = 1;
-    int first = 0;
-    while (nres < need && first < n) {
-        int last = int(stack & 0x3ffu), depth = int((stack >> 10) & 0x3fu);
-        while (last - first > 16) {
-            if (depth == 0) return false;
-            --depth;
-            uint16_t* a = keys + first + 1;
-            uint16_t* b = keys + first + (last - first) / 2;
-            uint16_t* c = keys + last - 1;
-            uint16_t* pick;
-            if (kgt(*a, *b)) {
-                if (kgt(*b, *c)) pick = b;
-                else if (kgt(*a, *c)) pick = c;
-                else pick = a;
-            } else if (kgt(*a, *c)) pick = a;
-            else if (kgt(*b, *c)) pick = c;
-            else pick = b;
-            {
-                const uint16_t t = keys[first];
-                keys[first] = *pick;
-                *pick = t;
-            }
-            uint16_t* lo = keys + first + 1;
-            uint16_t* hi = keys + last;
-            const uint16_t pivot = keys[first];
-            for (;;) {
-                while (kgt(*lo, pivot)) ++lo;
-                --hi;
-                while (kgt(pivot, *hi)) --hi;
-                if (!(lo < hi)) break;
-                const uint16_t t = *lo;
-                *lo = *hi;
-                *hi = t;
-                ++lo;
-            }
-            const int cut = int(lo - keys);
-            if (sp >= 4) return false;
-            // the right part [cut, last) keeps the decremented depth limit; descend into the left part
-            stack = ((stack & ~uint64_t(0xffffu)) | uint64_t(unsigned(last) | (unsigned(depth) << 10))) << 16 |
-                    uint64_t(unsigned(cut) | (unsigned(depth) << 10));
-            ++sp;
-            last = cut;
-        }
-        // final range [first, last): stable selection of its best (need - nres) keys; q >= 3 for every real key, so a
-        // zero key never displaces one
+    int depth = 2 * lg;
+    int first = 0, last = n;
+    // stable selection of the best `want` keys of the final range [lo, hi) appended to res; q >= 3 for every real key,
+    // so a zero key never displaces one
+    auto take_from = [&](const int lo, const int hi, const int want) {
         uint16_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        for (int i = first; i < last; ++i) {
+        for (int i = lo; i < hi; ++i) {
             const uint16_t x = keys[i];
             const bool c0 = kgt(x, t0), c1 = kgt(x, t1), c2 = kgt(x, t2), c3 = kgt(x, t3);
             t3 = c2 ? t2 : (c3 ? x : t3);
@@ -204,7 +166,7 @@ __device__ bool k_top_ranked(uint16_t* keys, const int n, const int need, uint16
             t1 = c0 ? t0 : (c1 ? x : t1);
             t0 = c0 ? x : t0;
         }
-        const int take = min(last - first, need - nres);
+        const int take = min(hi - lo, want);
         const uint16_t sel[4] = { t0, t1, t2, t3 };
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -214,10 +176,48 @@ __device__ bool k_top_ranked(uint16_t* keys, const int n, const int need, uint16
                     if (r == nres + k) res[r] = sel[k];
             }
         nres += take;
-        first = last;
-        stack >>= 16;
-        --sp;
+    };
+    while (last - first > 16) {
+        if (depth == 0) return false;
+        --depth;
+        uint16_t* a = keys + first + 1;
+        uint16_t* b = keys + first + (last - first) / 2;
+        uint16_t* c = keys + last - 1;
+        uint16_t* pick;
+        if (kgt(*a, *b)) {
+            if (kgt(*b, *c)) pick = b;
+            else if (kgt(*a, *c)) pick = c;
+            else pick = a;
+        } else if (kgt(*a, *c)) pick = a;
+        else if (kgt(*b, *c)) pick = c;
+        else pick = b;
+        {
+            const uint16_t t = keys[first];
+            keys[first] = *pick;
+            *pick = t;
+        }
+        uint16_t* lo = keys + first + 1;
+        uint16_t* hi = keys + last;
+        const uint16_t pivot = keys[first];
+        for (;;) {
+            while (kgt(*lo, pivot)) ++lo;
+            --hi;
+            while (kgt(pivot, *hi)) --hi;
+            if (!(lo < hi)) break;
+            const uint16_t t = *lo;
+            *lo = *hi;
+            *hi = t;
+            ++lo;
+        }
+        const int cut = int(lo - keys);
+        if (cut - first >= need - nres) {
+            last = cut; // everything still needed lies in the left part
+        } else {
+            take_from(first, cut, need - nres); // a final range of < 4 elements; then on into the right part
+            first = cut;
+        }
     }
+    if (nres < need) take_from(first, last, need - nres);
     return true;
 }
 
@@ -491,7 +491,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
         const int cnt = __syncthreads_count(fits);
         if (cnt == 0) {
             // a single locus deeper than the LDS budget: left to the global-memory pass
-            if (tid == 0) a.out[l0 + s].is_called = NEEDS_GLOBAL_PASS;
+            if (tid == 0) {
+                a.out[l0 + s].is_called = NEEDS_GLOBAL_PASS;
+                a.worklist[atomicAdd(a.work_count, 1u)] = unsigned(l0 + s);
+            }
             s += 1;
             __syncthreads();
             continue;
@@ -524,6 +527,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
                 }
             } else {
                 a.out[l].is_called = NEEDS_GLOBAL_PASS;
+                a.worklist[atomicAdd(a.work_count, 1u)] = unsigned(l);
             }
         }
         s = e;
@@ -535,11 +539,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
 // calls / sort stack than the fast path holds) through the global-memory routines -- same arithmetic
 __global__ void germline_site_global_pass_kernel(const FusedArgs a)
 {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= a.b.n_loci) return;
-    if (a.out[l].is_called != NEEDS_GLOBAL_PASS) return;
-    locus_dependent_eprob_global(a.b, a.tab, a.d, a.de_tmp, a.scratch, l);
-    locus_site_digt_call_global(a.b, a.de_tmp, a.tab, a.d, a.out, l);
+    const unsigned n = *a.work_count;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int l = int(a.worklist[i]);
+        locus_dependent_eprob_global(a.b, a.tab, a.d, a.de_tmp, a.scratch, l);
+        locus_site_digt_call_global(a.b, a.de_tmp, a.tab, a.d, a.out, l);
+    }
 }
 
 } // namespace
@@ -550,24 +555,28 @@ int sk_upload_pileup_internal(const sk_pileup_batch* hb, bool need_de, SkArena& 
 extern "C" {
 
 int sk_site_digt_call_fused_dev(const sk_pileup_batch* b, const sk_germline_options* opt, sk_digt_call* dev_out,
-                                float* dev_de_tmp, int want_de, void* dev_scratch, void* hip_stream)
+                                float* dev_de_tmp, int want_de, void* dev_scratch, int64_t n_calls, void* hip_stream)
 {
     SK_REQUIRE_INIT();
     if (!b || !opt || !dev_out || !dev_de_tmp || !dev_scratch) return sk_fail("sk_site_digt_call_fused_dev: null argument");
     if (b->n_loci <= 0) return 0;
+    if (n_calls < 0) return sk_fail("sk_site_digt_call_fused_dev: negative n_calls");
     FusedArgs a;
     a.b = *b;
     a.tab = sk_ctx().dev_tables;
     a.out = dev_out;
     a.de_tmp = dev_de_tmp;
     a.scratch = static_cast<uint32_t*>(dev_scratch);
+    a.work_count = a.scratch + n_calls;
+    a.worklist = a.work_count + 4;
     a.want_de = want_de ? 1 : 0;
     derive(*opt, a.d);
     const int blocks = (b->n_loci + LOCI_PER_BLOCK - 1) / LOCI_PER_BLOCK;
+    SK_HIP(hipMemsetAsync(a.work_count, 0, sizeof(uint32_t), static_cast<hipStream_t>(hip_stream)));
     hipLaunchKernelGGL(germline_site_fused_kernel, dim3(blocks), dim3(FUSED_THREADS), 0,
                        static_cast<hipStream_t>(hip_stream), a);
     if (!getenv("SK_DEBUG_SKIP_GLOBAL_PASS")) // debugging aid: leaves the sentinel visible in is_called
-        hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3((b->n_loci + 255) / 256), dim3(256), 0,
+        hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3(std::min(2048, (b->n_loci + 63) / 64)), dim3(64), 0,
                            static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());
     return 0;
@@ -586,13 +595,13 @@ int sk_site_digt_call_fused(const sk_pileup_batch* hb, const sk_germline_options
     SkArena ar;
     sk_pileup_batch d;
     int64_t total = 0;
-    if (sk_upload_pileup_internal(hb, false, ar, sk_align256(sizeof(sk_digt_call) * hb->n_loci) + 2 * sk_align256(4 * tc) + 1024,
+    if (sk_upload_pileup_internal(hb, false, ar, sk_align256(sizeof(sk_digt_call) * hb->n_loci) + 2 * sk_align256(4 * tc) + sk_align256(4 * (int64_t(hb->n_loci) + 4)) + 1024,
                                   d, ctx.stream, total))
         return 1;
     sk_digt_call* dout = ar.take<sk_digt_call>(hb->n_loci);
     float* dde = ar.take<float>(total);
-    uint32_t* scratch = ar.take<uint32_t>(total);
-    if (sk_site_digt_call_fused_dev(&d, opt, dout, dde, out_de ? 1 : 0, scratch, ctx.stream)) return 1;
+    uint32_t* scratch = ar.take<uint32_t>(total + hb->n_loci + 4);
+    if (sk_site_digt_call_fused_dev(&d, opt, dout, dde, out_de ? 1 : 0, scratch, total, ctx.stream)) return 1;
     SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_digt_call) * hb->n_loci, hipMemcpyDeviceToHost, ctx.stream));
     if (out_de && total) SK_HIP(hipMemcpyAsync(out_de, dde, 4 * total, hipMemcpyDeviceToHost, ctx.stream));
     SK_HIP(hipStreamSynchronize(ctx.stream));

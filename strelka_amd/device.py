@@ -93,7 +93,7 @@ class DevicePileupBatch:
     def dependent_eprob(self, opt=None):
         opt = opt or capi.germline_options()
         if self.scratch is None:
-            self.scratch = torch.empty(max(self.n_calls, 1), dtype=torch.int32, device=self.device)
+            self.scratch = torch.empty(self.n_calls + self.n_loci + 4, dtype=torch.int32, device=self.device)
         s = self.struct(with_de=False)
         capi._check(capi.lib().sk_dependent_eprob_dev(C.byref(s), C.byref(opt), C.c_void_p(self.de.data_ptr()),
                                                       C.c_void_p(self.scratch.data_ptr()), _stream_ptr()))
@@ -113,11 +113,11 @@ class DevicePileupBatch:
         if self.digt_out is None:
             self.digt_out = torch.empty(self.n_loci * capi.DIGT_CALL_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
         if self.scratch is None:
-            self.scratch = torch.empty(max(self.n_calls, 1), dtype=torch.int32, device=self.device)
+            self.scratch = torch.empty(self.n_calls + self.n_loci + 4, dtype=torch.int32, device=self.device)
         s = self.struct(with_de=False)
         capi._check(capi.lib().sk_site_digt_call_fused_dev(C.byref(s), C.byref(opt), C.c_void_p(self.digt_out.data_ptr()),
                                                            C.c_void_p(self.de.data_ptr()), int(want_de),
-                                                           C.c_void_p(self.scratch.data_ptr()), _stream_ptr()))
+                                                           C.c_void_p(self.scratch.data_ptr()), self.n_calls, _stream_ptr()))
         return self.digt_out
 
     def digt_numpy(self):
