@@ -268,6 +268,74 @@ int sk_get_end_pin_start_pos(const sk_indel_key* indels, int32_t n_indels, uint3
                              int32_t read_end_pos, int32_t* out_ref_start_pos, int32_t* out_read_start_pos);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Row a8: pileup of aligned reads into per-locus basecall columns
+ *
+ * Replaces, for a batch of reads, the per-read calls of starling_pos_processor_base::pileup_read_segment
+ * (L/starling_common/starling_pos_processor_base.cpp:1127-1421, called from pileup_pos_reads :1107-1123 at stage
+ * READ_BUFFER) including the mismatch-density filter (create_mismatch_filter_map, L/starling_common/starling_read_util.cpp:
+ * 121-213), the MAPQ-adjusted basecall quality (qphred_to_mapped_qphred, L/blt_util/qscore.hh:104-121) and the ambiguous
+ * read-end trim (getReadAmbiguousEndLength, L/htsapi/bam_seq_read_util.cpp:29-54); the columns come out as the CSR
+ * sk_pileup_batch the path-B entry points consume -- raw, or already cleaned as PileupCleaner::CleanPileupFilter
+ * (L/starling_common/PileupCleaner.cpp:28-66) would.  Calls of a locus appear in read order (the order of `reads`,
+ * = the read buffer's order), as insert_pos_basecall appends them.
+ * Not produced: the EVS feature accumulators (updateGermlineScoringMetrics / updateSomaticScoringMetrics) and the MAPQ
+ * tracker -- scoring-model inputs, outside the likelihood path.
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+typedef struct sk_pileup_options {
+    int32_t min_basecall_qscore;              /* blt_options::minBasecallErrorPhredProb: 17 germline (blt_shared.hh:107), 0 somatic */
+    int32_t mismatch_density_flank_size;      /* 20 (starling_shared.hh:37); 0 = filter off */
+    int32_t mismatch_density_max_count;       /* 2 germline (starling_shared.hh:36), 3 somatic (strelka_shared.hh:70) */
+    int32_t use_tier2_evidence;               /* somatic 1 (strelka_shared.hh:78) */
+    int32_t tier2_mismatch_density_max_count; /* opt.tier2.mismatchDensityFilterMaxMismatchCount */
+    int32_t is_mapq_adjust;                   /* isBasecallQualAdjustedForMapq, 1 (starling_base_shared.hh:225) */
+    int32_t min_distance_from_read_edge;      /* 0 (:252) */
+    int32_t largest_total_indel_ref_span_per_read; /* the processor's running value, >= maxIndelSize (49) */
+    int32_t report_begin, report_end;         /* _reportRange; locus index = ref position - report_begin */
+} sk_pileup_options;
+void sk_pileup_options_default(sk_pileup_options* opt);
+
+/** reads with their best alignment (the realignment when the read was realigned, else the input alignment) */
+typedef struct sk_read_batch {
+    int32_t n_reads;
+    const int64_t* read_off;    /* [n_reads+1] */
+    const uint8_t* read_code;   /* BAM 4-bit codes, one per byte: '=',A,C,G,T,N only */
+    const uint8_t* read_qual;
+    const int64_t* path_off;    /* [n_reads+1] */
+    const sk_path_seg* path;
+    const int32_t* pos;         /* best_al.pos */
+    const uint8_t* is_fwd;      /* best_al.is_fwd_strand */
+    const uint8_t* mapq;        /* rseg.map_qual() */
+    const uint8_t* map_level;   /* SK_MAPLEVEL_* */
+    const char* ref_seq;        /* reference_contig_segment; positions outside read as 'N' */
+    int32_t ref_offset, ref_len;
+    const uint8_t* cand_snv_mask; /* optional [ref_len]: bit b set = base id b is a candidate SNV of an active region
+                                     at that position (CandidateSnvBuffer::isCandidateSnvAnySample); NULL = none */
+} sk_read_batch;
+
+enum { SK_PILEUP_RAW_TIER1 = 0,   /* snp_pos_info::calls */
+       SK_PILEUP_RAW_TIER2 = 1,   /* snp_pos_info::tier2_calls */
+       SK_PILEUP_CLEAN_TIER1 = 2, /* CleanPileupFilter(pi, false) */
+       SK_PILEUP_CLEAN_TIER2 = 3  /* CleanPileupFilter(pi, true): tier1 calls (tier-specific filter waived) then tier2 calls */ };
+
+typedef struct sk_pileup_columns {
+    int32_t n_loci;           /* in: report_end - report_begin */
+    int64_t capacity;         /* in: entries available in `calls` (total read bases always suffices; twice that for
+                                 SK_PILEUP_CLEAN_TIER2) */
+    int64_t* call_off;        /* out [n_loci+1] */
+    uint16_t* calls;          /* out */
+    uint32_t* spandel_count;  /* out [n_loci]: spanningDeletionReadCount; may be NULL */
+    uint32_t* submapped_count;/* out [n_loci]: submappedReadCount; may be NULL */
+} sk_pileup_columns;
+
+/** host arrays in and out */
+int sk_pileup_reads(const sk_read_batch* host_reads, const sk_pileup_options* opt, int mode, sk_pileup_columns* host_out);
+/** device arrays in and out (ref_seq/cand_snv_mask device pointers too); dev_scratch >= sk_pileup_scratch_bytes() */
+int64_t sk_pileup_scratch_bytes(int32_t n_reads, int64_t n_bases, int32_t n_loci);
+int sk_pileup_reads_dev(const sk_read_batch* dev_reads, int64_t n_bases, const sk_pileup_options* opt, int mode,
+                        sk_pileup_columns* dev_out, void* dev_scratch, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (germline SNV): dependent error probabilities + diploid genotype likelihoods
  * ---------------------------------------------------------------------------------------------------------------- */
 

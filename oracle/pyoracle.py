@@ -404,3 +404,124 @@ def ref_realign_scenarios(scenarios, is_somatic=False):
         finally:
             L.ref_session_destroy(s)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# row a8: pileup
+
+class PileupOptions(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("min_basecall_qscore", "mismatch_density_flank_size", "mismatch_density_max_count",
+                                         "use_tier2_evidence", "tier2_mismatch_density_max_count", "is_mapq_adjust",
+                                         "min_distance_from_read_edge", "largest_total_indel_ref_span_per_read",
+                                         "report_begin", "report_end")]
+
+
+def pileup_options(**kw):
+    o = PileupOptions(17, 20, 2, 0, 10, 1, 0, 49, 0, 0)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+class ReadBatchStruct(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("read_off", vp), ("read_code", vp), ("read_qual", vp), ("path_off", vp),
+                ("path", vp), ("pos", vp), ("is_fwd", vp), ("mapq", vp), ("map_level", vp), ("ref_seq", C.c_char_p),
+                ("ref_offset", C.c_int32), ("ref_len", C.c_int32), ("cand_snv_mask", vp)]
+
+
+def read_batch_struct(rb, keep):
+    ref = rb.ref_seq.encode()
+    keep.append(ref)
+    return ReadBatchStruct(rb.n_reads, _p(rb.read_off), _p(rb.read_code), _p(rb.read_qual), _p(rb.path_off), _p(rb.path),
+                           _p(rb.pos), _p(rb.is_fwd), _p(rb.mapq), _p(rb.map_level), ref, rb.ref_offset, len(ref),
+                           None if rb.cand_snv_mask is None else _p(rb.cand_snv_mask))
+
+
+def pileup_reads(rb, opt, mode):
+    """oracle restatement of pileup_read_segment over a strelka_amd.synth.ReadBatch -> (call_off, calls, spandel, submapped)"""
+    L = oracle()
+    L.sko_pileup_reads.restype = C.c_int64
+    L.sko_pileup_reads.argtypes = [C.POINTER(ReadBatchStruct), C.POINTER(PileupOptions), C.c_int, vp, vp, C.c_int64, vp, vp]
+    n_loci = opt.report_end - opt.report_begin
+    keep = []
+    s = read_batch_struct(rb, keep)
+    cap = 2 * rb.n_bases + 1
+    call_off = np.zeros(n_loci + 1, np.int64)
+    calls = np.zeros(cap, np.uint16)
+    sd = np.zeros(max(n_loci, 1), np.uint32)
+    sm = np.zeros(max(n_loci, 1), np.uint32)
+    n = L.sko_pileup_reads(C.byref(s), C.byref(opt), mode, _p(call_off), _p(calls), cap, _p(sd), _p(sm))
+    if n < 0:
+        raise RuntimeError("sko_pileup_reads failed")
+    return call_off, calls[:n].copy(), sd[:n_loci], sm[:n_loci]
+
+
+def mapped_qscore_table():
+    L = oracle()
+    return np.array([[L.sko_mapped_qscore(q, m) for q in range(71)] for m in range(91)], np.int32)
+
+
+def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=()):
+    """The REFERENCE's position processor end to end (oracle/ref/ref_driver_pileup.cpp): reads (dicts as produced by
+    synth.pileup_reads, position-sorted) -> read buffer -> realignment -> pileup.
+    Returns (finals, columns): finals = per piled read, in pileup order, dict(read_id = index into `reads`, is_realigned,
+    pos, is_fwd, cigar, skipped); columns = {pos: dict(calls, tier2_calls, spandel, submapped)}."""
+    L = ref()
+    L.refpp_create.restype = vp
+    L.refpp_create.argtypes = [C.c_char_p] + [C.c_int] * 10
+    L.refpp_destroy.argtypes = [vp]
+    L.refpp_add_read.argtypes = [vp, C.c_char_p, vp, C.c_int, C.c_int, C.POINTER(PathSeg), C.c_int, C.c_int, C.c_int]
+    L.refpp_add_candidate_indel.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.refpp_finish.argtypes = [vp]
+    L.refpp_n_columns.argtypes = [vp]
+    L.refpp_column_info.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int32)] * 3 + [C.POINTER(C.c_uint32)] * 2
+    L.refpp_column_calls.argtypes = [vp, C.c_int, vp, vp]
+    L.refpp_n_finals.argtypes = [vp]
+    L.refpp_final.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)] + [C.POINTER(C.c_int32)] * 4 + [C.c_char_p, C.c_int]
+    s = L.refpp_create(ref_seq.encode(), ref_offset, opt.report_begin, opt.report_end, opt.min_basecall_qscore,
+                       opt.mismatch_density_flank_size, opt.mismatch_density_max_count, opt.use_tier2_evidence,
+                       opt.tier2_mismatch_density_max_count, opt.is_mapq_adjust, opt.min_distance_from_read_edge)
+    if not s:
+        raise RuntimeError("refpp_create failed")
+    try:
+        events = [(c["pos"], 0, c) for c in candidate_indels] + [(r["pos"], 1, i) for i, r in enumerate(reads)]
+        events.sort(key=lambda e: (e[0], e[1]))
+        id_of = {}
+        for _, kind, x in events:
+            if kind == 0:
+                if L.refpp_add_candidate_indel(s, x["pos"], x.get("del_len", 0), x.get("ins_seq", "").encode()):
+                    raise RuntimeError("reference rejected candidate indel")
+                continue
+            r = reads[x]
+            seq = "".join(_CODE2CHAR.get(int(c), "N") for c in r["code"]).encode()
+            qual = np.ascontiguousarray(r["qual"], np.uint8)
+            path = (PathSeg * len(r["path"]))(*[PathSeg(t, l) for t, l in r["path"]])
+            rid = L.refpp_add_read(s, seq, _p(qual), r["pos"], len(r["path"]), path, int(r["is_fwd"]), r["mapq"], r["map_level"])
+            if rid == -2:
+                raise RuntimeError("reference threw while inserting read %d" % x)
+            if rid >= 0:
+                id_of[rid] = x
+        if L.refpp_finish(s):
+            raise RuntimeError("reference threw in reset()")
+        finals = []
+        for i in range(L.refpp_n_finals(s)):
+            rid, a, b, c, d = C.c_uint32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            buf = C.create_string_buffer(1024)
+            L.refpp_final(s, i, rid, a, b, c, d, buf, 1024)
+            finals.append(dict(read_id=id_of[rid.value], is_realigned=bool(a.value), pos=b.value, is_fwd=bool(c.value),
+                               skipped=bool(d.value), cigar=buf.value.decode()))
+        cols = {}
+        for i in range(L.refpp_n_columns(s)):
+            pos, n, n2 = C.c_int32(), C.c_int32(), C.c_int32()
+            sd, sm = C.c_uint32(), C.c_uint32()
+            L.refpp_column_info(s, i, pos, n, n2, sd, sm)
+            calls = np.zeros(max(n.value, 1), np.uint16)
+            t2 = np.zeros(max(n2.value, 1), np.uint16)
+            L.refpp_column_calls(s, i, _p(calls), _p(t2))
+            cols[pos.value] = dict(calls=calls[:n.value].copy(), tier2_calls=t2[:n2.value].copy(), spandel=sd.value,
+                                   submapped=sm.value)
+        return finals, cols
+    finally:
+        L.refpp_destroy(s)

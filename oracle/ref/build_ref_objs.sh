@@ -18,7 +18,7 @@ comp() {
 export -f comp; export L INC OUT
 rm -f $OUT/skipped.txt
 (cd $L; ls blt_util/*.cpp blt_common/*.cpp common/*.cpp htsapi/*.cpp starling_common/*.cpp strelka_common/*.cpp alignment/*.cpp \
-    calibration/*.cpp options/*.cpp applications/strelka/*.cpp applications/starling/*.cpp 2>/dev/null) | xargs -P ${JOBS:-8} -I{} bash -c 'comp {}'
+    calibration/*.cpp options/*.cpp appstats/*.cpp assembly/*.cpp applications/strelka/*.cpp applications/starling/*.cpp 2>/dev/null) | xargs -P ${JOBS:-8} -I{} bash -c 'comp {}'
 rm -f $OUT/libreftus.a
 ar rcs $OUT/libreftus.a $OUT/obj/*.o
 echo "archived $(ls $OUT/obj/*.o | wc -l) reference objects; skipped $(wc -l < $OUT/skipped.txt 2>/dev/null || echo 0)"

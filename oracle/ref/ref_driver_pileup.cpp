@@ -1,0 +1,261 @@
+// ref_driver_pileup.cpp -- the REFERENCE's own position processor, end to end, for pinning rows a1-a8:
+// reads -> read buffer -> realignAndScoreRead (stage READ_BUFFER) -> pileup_read_segment -> per-position pileup columns.
+//
+// TEST INFRASTRUCTURE ONLY; contains no reference code.  A minimal subclass of starling_pos_processor_base
+// (L/starling_common/starling_pos_processor_base.hh:86) supplies the one pure virtual (process_pos_variants_impl, called
+// at stage POST_ALIGN for every reportable position) and uses it to snapshot what the germline/somatic callers would
+// see: the position's snp_pos_info (calls, tier2 calls, spanning-deletion and submapped counts) and the final alignment
+// of every read buffered at that position.
+
+#include "appstats/RunStats.hh"
+#include "appstats/RunStatsManager.hh"
+#include "htsapi/align_path_bam_util.hh"
+#include "starling_common/normalizeAlignment.hh"
+#include "starling_common/starling_pos_processor_base.hh"
+#include "starling_common/starling_streams_base.hh"
+#include "test/starling_base_options_test.hh"
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+// appstats/RunStats.cpp needs Boost.Serialization's XML archives and is not built; its only symbol reached from here is
+// the stats writer, which RunStatsManager calls only when given an output file name (never, in this driver)
+void RunStats::save(std::ostream&) const {}
+
+namespace
+{
+
+struct Column
+{
+    int32_t pos;
+    std::vector<uint16_t> calls, tier2_calls;
+    uint32_t spandel, submapped;
+};
+
+struct FinalAlignment
+{
+    uint32_t read_id;
+    int32_t is_realigned, pos, is_fwd, skipped;
+    std::string cigar;
+};
+
+struct Streams : public starling_streams_base
+{
+    explicit Streams(const unsigned n) : starling_streams_base(n) {}
+};
+
+struct PP : public starling_pos_processor_base
+{
+    PP(const starling_base_options& opt, const starling_base_deriv_options& dopt, const reference_contig_segment& ref,
+       const Streams& streams, RunStatsManager& stats)
+        : starling_pos_processor_base(opt, dopt, ref, streams, 1, stats)
+    {
+        // as the application processors do (L/applications/starling/starling_pos_processor.cpp:62-68)
+        sample_info& sif(sample(0));
+        getIndelBuffer().registerSample(sif.estdepth_buff, sif.estdepth_buff_tier2, true);
+        getIndelBuffer().finalizeSamples();
+    }
+
+    void resetRegion(const std::string& chrom, const known_pos_range2& range) { resetRegionBase(chrom, range); }
+
+    void process_pos_variants_impl(const pos_t pos, const bool /*isPosPrecedingReportableRange*/) override
+    {
+        static_assert(sizeof(base_call) == 2, "base_call is a 16-bit bitfield");
+        const snp_pos_info& pi(sample(0).basecallBuffer.get_pos(pos));
+        Column c;
+        c.pos = pos;
+        for (const base_call& bc : pi.calls) {
+            uint16_t v;
+            std::memcpy(&v, &bc, 2);
+            c.calls.push_back(v);
+        }
+        for (const base_call& bc : pi.tier2_calls) {
+            uint16_t v;
+            std::memcpy(&v, &bc, 2);
+            c.tier2_calls.push_back(v);
+        }
+        c.spandel = pi.spanningDeletionReadCount;
+        c.submapped = pi.submappedReadCount;
+        if (!(c.calls.empty() && c.tier2_calls.empty() && c.spandel == 0 && c.submapped == 0)) columns.push_back(c);
+
+    }
+
+    // called at stage POST_ALIGN for EVERY position (reportable or not), after the reads buffered at `pos` were realigned
+    // and piled up (stage READ_BUFFER) and before the read buffer is cleared: record their final alignments, in the
+    // order pileup_pos_reads visited them
+    void post_align_clear_pos(const pos_t pos) override
+    {
+        read_segment_iter ri(sample(0).readBuffer.get_pos_read_segment_iter(pos));
+        for (read_segment_iter::ret_val r; true; ri.next()) {
+            r = ri.get_ptr();
+            if (nullptr == r.first) break;
+            const read_segment& rseg(r.first->get_segment(r.second));
+            FinalAlignment fa;
+            fa.read_id = rseg.getReadIndex();
+            fa.is_realigned = rseg.is_realigned ? 1 : 0;
+            const alignment& al(rseg.is_realigned ? rseg.realignment : rseg.getInputAlignment());
+            fa.pos = al.pos;
+            fa.is_fwd = al.is_fwd_strand;
+            fa.cigar = ALIGNPATH::apath_to_cigar(al.path);
+            fa.skipped = (!rseg.is_realigned && !rseg.is_any_nonovermax(_opt.maxIndelSize)) ||
+                         (rseg.is_realigned && rseg.is_invalid_realignment);
+            finals.push_back(fa);
+        }
+    }
+
+    std::vector<Column> columns;
+    std::vector<FinalAlignment> finals;
+};
+
+struct Session
+{
+    starling_base_options_test opt;
+    std::unique_ptr<starling_base_deriv_options> dopt;
+    reference_contig_segment ref;
+    std::unique_ptr<Streams> streams;
+    std::unique_ptr<RunStatsManager> stats;
+    std::unique_ptr<PP> pp;
+};
+
+struct RefPathSeg
+{
+    uint32_t type, length;
+};
+
+} // namespace
+
+extern "C" {
+
+/// one position processor over [report_begin, report_end) of a reference segment
+void* refpp_create(const char* ref_seq, int ref_offset, int report_begin, int report_end, int min_basecall_qscore,
+                   int mdf_flank, int mdf_max_count, int use_tier2, int tier2_mdf_max_count, int is_mapq_adjust,
+                   int min_dist_from_read_edge)
+{
+    try {
+        Session* s = new Session();
+        s->opt.isHaplotypingEnabled = false;
+        s->opt.minBasecallErrorPhredProb = min_basecall_qscore;
+        s->opt.mismatchDensityFilterFlankSize = mdf_flank;
+        s->opt.mismatchDensityFilterMaxMismatchCount = mdf_max_count;
+        s->opt.useTier2Evidence = (use_tier2 != 0);
+        s->opt.tier2.mismatchDensityFilterMaxMismatchCount = tier2_mdf_max_count;
+        s->opt.isBasecallQualAdjustedForMapq = (is_mapq_adjust != 0);
+        s->opt.minDistanceFromReadEdge = min_dist_from_read_edge;
+        s->dopt.reset(new starling_base_deriv_options(s->opt));
+        s->ref.seq() = ref_seq;
+        s->ref.set_offset(ref_offset);
+        s->streams.reset(new Streams(1));
+        s->stats.reset(new RunStatsManager(""));
+        s->pp.reset(new PP(s->opt, *s->dopt, s->ref, *s->streams, *s->stats));
+        s->pp->resetRegion("chrT", known_pos_range2(report_begin, report_end));
+        return s;
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+void refpp_destroy(void* p) { delete static_cast<Session*>(p); }
+
+/// processInputReadAlignment's tail (L/starling_common/starling_pos_processor_util.cpp:395-440): left-normalise, then
+/// insert_read.  Reads must arrive in position order (set_head_pos is advanced as starling_run.cpp:127 does).
+/// Returns the read id (>= 0), -1 if the processor declined the read, -2 on exception.
+int refpp_add_read(void* p, const char* read_seq, const uint8_t* qual, int pos, int n_seg, const RefPathSeg* path,
+                   int is_fwd, int mapq, int map_level)
+{
+    Session* s = static_cast<Session*>(p);
+    try {
+        s->pp->set_head_pos(pos - 1);
+        bam_record br;
+        br.set_qname("R");
+        br.set_readqual(read_seq, qual);
+        alignment al;
+        al.pos = pos;
+        al.is_fwd_strand = (is_fwd != 0);
+        for (int i = 0; i < n_seg; ++i)
+            al.path.push_back(ALIGNPATH::path_segment(static_cast<ALIGNPATH::align_t>(path[i].type), path[i].length));
+        bam1_t& b(*(br.get_data()));
+        b.core.pos = al.pos;
+        b.core.qual = uint8_t(mapq);
+        if (!is_fwd) b.core.flag |= BAM_FLAG::STRAND;
+        edit_bam_cigar(al.path, b);
+        {
+            const rc_segment_bam_seq refBamSeq(s->ref);
+            const bam_seq readBamSeq(br.get_bam_read());
+            normalizeAlignment(refBamSeq, readBamSeq, al);
+        }
+        const boost::optional<align_id_t> id(s->pp->insert_read(br, al, "chrT", static_cast<MAPLEVEL::index_t>(map_level), 0));
+        return id ? int(*id) : -1;
+    } catch (...) {
+        return -2;
+    }
+}
+
+/// an externally supplied candidate indel (as a --candidate-indel-input-vcf record would be)
+int refpp_add_candidate_indel(void* p, int pos, int del_len, const char* ins_seq)
+{
+    Session* s = static_cast<Session*>(p);
+    try {
+        s->pp->set_head_pos(pos - 1);
+        IndelObservation obs;
+        obs.key = IndelKey(pos, INDEL::INDEL, del_len, ins_seq ? ins_seq : "");
+        obs.data.is_external_candidate = true;
+        s->pp->insert_indel(obs, 0);
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+/// flush every stage (starling_pos_processor_base::reset)
+int refpp_finish(void* p)
+{
+    Session* s = static_cast<Session*>(p);
+    try {
+        s->pp->reset();
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+int refpp_n_columns(void* p) { return int(static_cast<Session*>(p)->pp->columns.size()); }
+
+int refpp_column_info(void* p, int i, int32_t* pos, int32_t* n_calls, int32_t* n_tier2, uint32_t* spandel, uint32_t* submapped)
+{
+    const Column& c(static_cast<Session*>(p)->pp->columns[i]);
+    *pos = c.pos;
+    *n_calls = int32_t(c.calls.size());
+    *n_tier2 = int32_t(c.tier2_calls.size());
+    *spandel = c.spandel;
+    *submapped = c.submapped;
+    return 0;
+}
+
+int refpp_column_calls(void* p, int i, uint16_t* calls, uint16_t* tier2_calls)
+{
+    const Column& c(static_cast<Session*>(p)->pp->columns[i]);
+    if (!c.calls.empty()) std::memcpy(calls, c.calls.data(), 2 * c.calls.size());
+    if (!c.tier2_calls.empty()) std::memcpy(tier2_calls, c.tier2_calls.data(), 2 * c.tier2_calls.size());
+    return 0;
+}
+
+int refpp_n_finals(void* p) { return int(static_cast<Session*>(p)->pp->finals.size()); }
+
+int refpp_final(void* p, int i, uint32_t* read_id, int32_t* is_realigned, int32_t* pos, int32_t* is_fwd, int32_t* skipped,
+                char* cigar, int cap)
+{
+    const FinalAlignment& f(static_cast<Session*>(p)->pp->finals[i]);
+    *read_id = f.read_id;
+    *is_realigned = f.is_realigned;
+    *pos = f.pos;
+    *is_fwd = f.is_fwd;
+    *skipped = f.skipped;
+    std::strncpy(cigar, f.cigar.c_str(), cap - 1);
+    cigar[cap - 1] = 0;
+    return 0;
+}
+
+} // extern "C"

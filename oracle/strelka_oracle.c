@@ -1192,3 +1192,272 @@ void sko_somatic_snv_call_batch(const int64_t* n_off, const uint16_t* n_calls, c
         sko_position_somatic_snv_call(n_calls + n_off[l], (int32_t)(n_off[l + 1] - n_off[l]), t_calls + t_off[l],
                                       (int32_t)(t_off[l + 1] - t_off[l]), ref_base[l], opt, is_forced_output, &out[l]);
 }
+
+/* ---------------------------------------------------------------------------------------------------- row a8: pileup */
+
+/* qphred_cache::mappedq, L/blt_util/qscore_cache.cpp:46-49 with phred_to_mapped_error_prob (qscore.hh:104-113) */
+int sko_mapped_qscore(int basecall_q, int mapq)
+{
+    if (mapq > 90) mapq = 90; /* MAX_MAP, qscore_cache.hh:129-132 */
+    const double be = pow(10., -((double)basecall_q) / 10.);
+    const double me = pow(10., -((double)mapq) / 10.);
+    return sko_error_prob_to_qphred(((1. - me) * be) + (me * 0.75));
+}
+
+static int pl_seg_match(uint32_t t) { return t == 1 || t == 8 || t == 9; }              /* is_segment_align_match */
+static int pl_seg_read_len(uint32_t t) { return pl_seg_match(t) || t == 2 || t == 5; }   /* MATCH-likes, INSERT, SOFT_CLIP */
+static int pl_seg_ref_len(uint32_t t) { return pl_seg_match(t) || t == 3 || t == 4; }    /* MATCH-likes, DELETE, SKIP */
+
+static char pl_ref_char(const sko_read_batch* b, int p)
+{
+    if (p < b->ref_offset || p >= b->ref_offset + b->ref_len) return 'N'; /* reference_contig_segment::get_base */
+    return b->ref_seq[p - b->ref_offset];
+}
+static char pl_code_char(uint8_t c)
+{
+    switch (c) {
+    case 0: return '=';
+    case 1: return 'A';
+    case 2: return 'C';
+    case 4: return 'G';
+    case 8: return 'T';
+    default: return 'N';
+    }
+}
+
+typedef struct pl_col {
+    uint16_t* v;
+    int32_t n, cap;
+} pl_col;
+static int pl_push(pl_col* c, uint16_t x)
+{
+    if (c->n == c->cap) {
+        const int32_t nc = c->cap ? 2 * c->cap : 16;
+        uint16_t* nv = (uint16_t*)realloc(c->v, sizeof(uint16_t) * (size_t)nc);
+        if (!nv) return 1;
+        c->v = nv;
+        c->cap = nc;
+    }
+    c->v[c->n++] = x;
+    return 0;
+}
+
+int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* o, int mode, int64_t* call_off,
+                         uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count)
+{
+    const int32_t n_loci = o->report_end - o->report_begin;
+    pl_col* t1 = (pl_col*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col));
+    pl_col* t2 = (pl_col*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col));
+    int* delta = NULL;
+    unsigned char* is_mm = NULL;
+    int64_t result = -1;
+    int bad = 0;
+    if (spandel_count) memset(spandel_count, 0, sizeof(uint32_t) * (size_t)n_loci);
+    if (submapped_count) memset(submapped_count, 0, sizeof(uint32_t) * (size_t)n_loci);
+
+    for (int32_t r = 0; r < b->n_reads && !bad; ++r) { /* pileup_pos_reads: read after read, buffer order */
+        const int64_t ro = b->read_off[r];
+        const int L = (int)(b->read_off[r + 1] - ro);
+        const sko_path_seg* path = b->path + b->path_off[r];
+        const int nseg = (int)(b->path_off[r + 1] - b->path_off[r]);
+        const uint8_t* code = b->read_code + ro;
+        const uint8_t* qual = b->read_qual + ro;
+        const int pos = b->pos[r];
+        const int fwd = b->is_fwd[r] != 0;
+        if (nseg == 0) continue; /* best_al.empty() :1148-1165 */
+
+        int ref_len = 0, plen = 0, first_match = nseg, last_match = nseg; /* get_match_edge_segments */
+        for (int i = 0; i < nseg; ++i) {
+            if (pl_seg_ref_len(path[i].type)) ref_len += (int)path[i].length;
+            if (pl_seg_read_len(path[i].type)) plen += (int)path[i].length;
+            if (pl_seg_match(path[i].type)) {
+                if (first_match == nseg) first_match = i;
+                last_match = i;
+            }
+        }
+        if (plen != L) { bad = 1; break; }
+        const unsigned mapq = b->mapq[r];
+        const unsigned adj_mapq = mapq < 5 ? 5 : mapq;                         /* :1181-1184 */
+        const int is_mapq_adjust = o->is_mapq_adjust && (adj_mapq <= 80);
+        if (ref_len > L + o->largest_total_indel_ref_span_per_read) continue; /* :1186-1191 */
+        if (pos >= o->report_end) continue;                                   /* :1194-1198 */
+        if (pos + ref_len <= o->report_begin) continue;
+
+        int amb = 0; /* getReadAmbiguousEndLength, bam_seq_read_util.cpp:29-54 */
+        if (fwd) {
+            int e = L;
+            while (e > 0 && pl_code_char(code[e - 1]) == 'N') --e;
+            amb = L - e;
+        } else {
+            int s = 0;
+            while (s < L && pl_code_char(code[s]) == 'N') ++s;
+            amb = s;
+        }
+        int read_begin = 0, read_end = L;
+        if (amb > 0) {
+            if (fwd) read_end -= amb;
+            else read_begin += amb;
+        }
+        if (o->min_distance_from_read_edge > 0) { /* :1220-1233 */
+            read_begin += o->min_distance_from_read_edge;
+            if (o->min_distance_from_read_edge <= read_end) read_end -= o->min_distance_from_read_edge;
+            else read_end = 0;
+            if (read_end <= read_begin) continue;
+        }
+        const unsigned level = b->map_level[r];
+        const int is_submapped = !(level == 1 || level == 2);
+        const int is_tier1 = (level == 1);
+        const int mdf = o->mismatch_density_flank_size > 0;
+        const int fs = o->mismatch_density_flank_size, fs2 = 2 * fs;
+        const int delta_size = ((1 + fs2 > L) ? 1 + fs2 : L) - fs2;
+
+        if (!is_submapped && mdf) { /* create_mismatch_filter_map, starling_read_util.cpp:121-213 */
+            delta = (int*)realloc(delta, sizeof(int) * (size_t)(delta_size + 1));
+            is_mm = (unsigned char*)realloc(is_mm, (size_t)(L + 1));
+            memset(delta, 0, sizeof(int) * (size_t)delta_size);
+            memset(is_mm, 0, (size_t)L);
+#define PL_INC(start, length)                                                                  \
+    do {                                                                                       \
+        delta[((fs2 > (start)) ? fs2 : (start)) - fs2] += 1;                                   \
+        if (((start) + (length)) < delta_size) delta[(start) + (length)] -= 1;                 \
+    } while (0)
+            int read_head = 0, ref_head = pos;
+            for (int i = 0; i < nseg; ++i) {
+                const uint32_t t = path[i].type;
+                const int len = (int)path[i].length;
+                const int edge = (i < first_match) || (i > last_match);
+                if (t == 2) {
+                    if (!edge) PL_INC(read_head, len);
+                    read_head += len;
+                } else if (t == 3) {
+                    if (!edge) PL_INC(read_head, 0);
+                    ref_head += len;
+                } else if (pl_seg_match(t)) {
+                    for (int j = 0; j < len; ++j) {
+                        const int rp = read_head + j;
+                        if (rp < read_begin || rp >= read_end) continue;
+                        const int refp = ref_head + j;
+                        const char rc = pl_code_char(code[rp]);
+                        if (rc != pl_ref_char(b, refp)) {
+                            int cand = 0; /* CandidateSnvBuffer::isCandidateSnvAnySample */
+                            if (b->cand_snv_mask && refp >= b->ref_offset && refp < b->ref_offset + b->ref_len) {
+                                const int id = rc == 'A' ? 0 : rc == 'C' ? 1 : rc == 'G' ? 2 : rc == 'T' ? 3 : 4;
+                                cand = id < 4 && ((b->cand_snv_mask[refp - b->ref_offset] >> id) & 1);
+                            }
+                            if (!cand) {
+                                is_mm[rp] = 1;
+                                PL_INC(rp, 1);
+                            }
+                        }
+                    }
+                    read_head += len;
+                    ref_head += len;
+                } else if (t == 5) {
+                    read_head += len;
+                } else if (t == 4) {
+                    ref_head += len;
+                }
+            }
+            for (int i = 1; i < delta_size; ++i) delta[i] += delta[i - 1]; /* ddata::total */
+        }
+
+        int read_head = 0, ref_head = pos;
+        for (int i = 0; i < nseg && !bad; ++i) {
+            const uint32_t t = path[i].type;
+            const int len = (int)path[i].length;
+            if (pl_seg_match(t)) {
+                for (int j = 0; j < len; ++j) {
+                    const int rp = read_head + j;
+                    if (rp < read_begin || rp >= read_end) continue;
+                    const int refp = ref_head + j;
+                    if (refp < o->report_begin || refp >= o->report_end) continue; /* is_pos_reportable */
+                    const int locus = refp - o->report_begin;
+                    const uint8_t c = code[rp];
+                    const unsigned id = c == 1 ? 0 : c == 2 ? 1 : c == 4 ? 2 : c == 8 ? 3 : 4; /* bam_seq_code_to_id */
+                    int q = qual[rp];
+                    if (is_mapq_adjust) q = sko_mapped_qscore(q, (int)adj_mapq);
+                    int current = 1, tscf = 0, nmm = 0;
+                    if (!is_submapped) {
+                        int is_call_filter = (c == 15) || (q < o->min_basecall_qscore);
+                        int is_t2 = is_call_filter;
+                        if (mdf) {
+                            const int idx0 = ((fs > rp) ? fs : rp) - fs;
+                            const int del = delta[(idx0 < delta_size - 1) ? idx0 : delta_size - 1]; /* ddata::get */
+                            if (!is_call_filter) {
+                                is_call_filter = (o->mismatch_density_max_count < del);
+                                is_t2 = o->use_tier2_evidence ? (o->tier2_mismatch_density_max_count < del) : is_call_filter;
+                            }
+                            nmm = (del - (int)is_mm[rp]) > 0;
+                        }
+                        current = is_tier1 ? is_call_filter : is_t2;
+                        tscf = is_tier1 && is_call_filter && !is_t2;
+                    }
+                    if (is_submapped) {
+                        if (submapped_count) submapped_count[locus]++;
+                        continue;
+                    }
+                    const unsigned qb = (unsigned)(q > 63 ? 63 : q); /* base_call ctor, snp_pos_info.hh:70 */
+                    const uint16_t bc = (uint16_t)(qb | (id << 6) | ((unsigned)fwd << 10) | ((unsigned)nmm << 11) |
+                                                   ((unsigned)current << 12) | ((unsigned)tscf << 13));
+                    if (pl_push(is_tier1 ? &t1[locus] : &t2[locus], bc)) bad = 1;
+                }
+            } else if (t == 3) {
+                const int edge = (i < first_match) || (i > last_match);
+                if (!edge) {
+                    for (int j = 0; j < len; ++j) {
+                        const int refp = ref_head + j;
+                        if (refp < o->report_begin || refp >= o->report_end) continue;
+                        uint32_t* ctr = is_submapped ? submapped_count : spandel_count;
+                        if (ctr) ctr[refp - o->report_begin]++;
+                    }
+                }
+            }
+            if (pl_seg_read_len(t)) read_head += len;
+            if (pl_seg_ref_len(t)) ref_head += len;
+        }
+    }
+
+    if (!bad) {
+        int64_t n = 0;
+        for (int32_t l = 0; l < n_loci && !bad; ++l) {
+            call_off[l] = n;
+#define PL_OUT(x)                                  \
+    do {                                           \
+        if (n >= capacity) { bad = 1; break; }     \
+        calls[n++] = (x);                          \
+    } while (0)
+            if (mode == 0) {
+                for (int i = 0; i < t1[l].n && !bad; ++i) PL_OUT(t1[l].v[i]);
+            } else if (mode == 1) {
+                for (int i = 0; i < t2[l].n && !bad; ++i) PL_OUT(t2[l].v[i]);
+            } else { /* CleanPileupFilter, PileupCleaner.cpp:28-66 */
+                const int inc2 = (mode == 3);
+                for (int i = 0; i < t1[l].n && !bad; ++i) {
+                    const uint16_t bc = t1[l].v[i];
+                    if ((bc >> 12) & 1) {
+                        if (!(inc2 && ((bc >> 13) & 1))) continue;
+                    }
+                    PL_OUT(bc);
+                }
+                if (inc2)
+                    for (int i = 0; i < t2[l].n && !bad; ++i) {
+                        if ((t2[l].v[i] >> 12) & 1) continue;
+                        PL_OUT(t2[l].v[i]);
+                    }
+            }
+        }
+        if (!bad) {
+            call_off[n_loci] = n;
+            result = n;
+        }
+    }
+    for (int32_t l = 0; l < n_loci; ++l) {
+        free(t1[l].v);
+        free(t2[l].v);
+    }
+    free(t1);
+    free(t2);
+    free(delta);
+    free(is_mm);
+    return result;
+}

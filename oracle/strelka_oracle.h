@@ -182,6 +182,35 @@ void sko_somatic_snv_call_batch(const int64_t* n_off, const uint16_t* n_calls, c
                                 const sko_somatic_snv_options* opt, int is_forced_output, sko_somatic_snv_call* out);
 void sko_germline_lnpriors(double theta, float* out /* [2][5][2][10] */);
 
+/* ---- row a8: pileup of aligned reads (restatement of starling_pos_processor_base::pileup_read_segment,
+ * L/starling_common/starling_pos_processor_base.cpp:1127-1421, run read after read as pileup_pos_reads does) ---- */
+int sko_mapped_qscore(int basecall_q, int mapq); /* qphred_cache::get_mapped_qscore, L/blt_util/qscore_cache.hh:123-134 */
+typedef struct sko_pileup_options {
+    int32_t min_basecall_qscore, mismatch_density_flank_size, mismatch_density_max_count, use_tier2_evidence,
+        tier2_mismatch_density_max_count, is_mapq_adjust, min_distance_from_read_edge,
+        largest_total_indel_ref_span_per_read, report_begin, report_end;
+} sko_pileup_options;
+typedef struct sko_read_batch {
+    int32_t n_reads;
+    const int64_t* read_off;
+    const uint8_t* read_code;
+    const uint8_t* read_qual;
+    const int64_t* path_off;
+    const sko_path_seg* path;
+    const int32_t* pos;
+    const uint8_t* is_fwd;
+    const uint8_t* mapq;
+    const uint8_t* map_level; /* MAPLEVEL::index_t */
+    const char* ref_seq;
+    int32_t ref_offset, ref_len;
+    const uint8_t* cand_snv_mask;
+} sko_read_batch;
+/* mode: 0 raw tier1 calls, 1 raw tier2 calls, 2 CleanPileupFilter(pi,false), 3 CleanPileupFilter(pi,true)
+ * (L/starling_common/PileupCleaner.cpp:28-66).  call_off[n_loci+1], calls[capacity]; returns the number of calls or -1
+ * when capacity is too small / a read is malformed. */
+int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* opt, int mode, int64_t* call_off,
+                         uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ HIP_SOURCES = [
     "csrc/germline_fused.hip",
     "csrc/somatic_site.hip",
     "csrc/indel_lhood.hip",
+    "csrc/pileup.hip",
 ]
 HOST_SOURCES = [
     "host/align_flatten.cpp",

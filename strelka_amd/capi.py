@@ -88,6 +88,28 @@ class ReadResult(C.Structure):
                 ("warn_max_toggle_depth", C.c_int32)]
 
 
+class PileupOptions(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("min_basecall_qscore", "mismatch_density_flank_size", "mismatch_density_max_count",
+                                         "use_tier2_evidence", "tier2_mismatch_density_max_count", "is_mapq_adjust",
+                                         "min_distance_from_read_edge", "largest_total_indel_ref_span_per_read",
+                                         "report_begin", "report_end")]
+
+
+class ReadBatchStruct(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("read_off", c_void_p), ("read_code", c_void_p), ("read_qual", c_void_p),
+                ("path_off", c_void_p), ("path", c_void_p), ("pos", c_void_p), ("is_fwd", c_void_p), ("mapq", c_void_p),
+                ("map_level", c_void_p), ("ref_seq", c_void_p), ("ref_offset", C.c_int32), ("ref_len", C.c_int32),
+                ("cand_snv_mask", c_void_p)]
+
+
+class PileupColumns(C.Structure):
+    _fields_ = [("n_loci", C.c_int32), ("capacity", C.c_int64), ("call_off", c_void_p), ("calls", c_void_p),
+                ("spandel_count", c_void_p), ("submapped_count", c_void_p)]
+
+
+PILEUP_RAW_TIER1, PILEUP_RAW_TIER2, PILEUP_CLEAN_TIER1, PILEUP_CLEAN_TIER2 = 0, 1, 2, 3
+
+
 class PileupBatch(C.Structure):
     _fields_ = [("n_loci", C.c_int32), ("call_off", c_void_p), ("calls", c_void_p), ("de", c_void_p),
                 ("ref_base", c_void_p), ("ploidy", c_void_p)]
@@ -150,6 +172,7 @@ EXPORTS = [
     "sk_score_alignments", "sk_score_alignments_dev",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_add_read",
     "sk_align_builder_finish", "sk_align_builder_error",
+    "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_get_batch",
     "sk_realign_job_finish", "sk_realign_job_run", "sk_realign_job_n_reads", "sk_realign_job_read_result",
@@ -187,6 +210,12 @@ def lib():
         L.sk_align_builder_add_read.argtypes = [c_void_p, c_void_p, c_void_p, C.c_int32, C.c_char_p, C.c_int32,
                                                 C.c_int32, C.POINTER(CandidateAlignment), C.c_int32]
         L.sk_align_builder_finish.argtypes = [c_void_p, C.POINTER(AlignBatch)]
+        L.sk_pileup_options_default.argtypes = [C.POINTER(PileupOptions)]
+        L.sk_pileup_reads.argtypes = [C.POINTER(ReadBatchStruct), C.POINTER(PileupOptions), C.c_int, C.POINTER(PileupColumns)]
+        L.sk_pileup_scratch_bytes.restype = C.c_int64
+        L.sk_pileup_scratch_bytes.argtypes = [C.c_int32, C.c_int64, C.c_int32]
+        L.sk_pileup_reads_dev.argtypes = [C.POINTER(ReadBatchStruct), C.c_int64, C.POINTER(PileupOptions), C.c_int,
+                                          C.POINTER(PileupColumns), c_void_p, c_void_p]
         L.sk_realign_options_default.argtypes = [C.POINTER(RealignOptions)]
         L.sk_realign_job_create.restype = c_void_p
         L.sk_realign_job_create.argtypes = [C.POINTER(RealignOptions)]
@@ -669,3 +698,32 @@ class RealignJob:
                     path=[(r.realign_path[i].type, r.realign_path[i].length) for i in range(r.realign_n_seg)],
                     max_score=r.max_score, scores=scores, suboverlap=[r.suboverlap[i] for i in range(r.n_suboverlap)],
                     warn_origin_skip=bool(r.warn_origin_skip), warn_max_toggle_depth=bool(r.warn_max_toggle_depth))
+
+
+# ---------------------------------------------------------------------------------------------------- pileup (a8)
+
+def pileup_options(**kw):
+    o = PileupOptions()
+    lib().sk_pileup_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def pileup_reads(rb, opt, mode):
+    """rb: synth.ReadBatch (host arrays) -> (call_off, calls, spandel_count, submapped_count)"""
+    ref = np.frombuffer(rb.ref_seq.encode(), np.uint8).copy()
+    s = ReadBatchStruct(rb.n_reads, _p(rb.read_off), _p(rb.read_code), _p(rb.read_qual), _p(rb.path_off), _p(rb.path),
+                        _p(rb.pos), _p(rb.is_fwd), _p(rb.mapq), _p(rb.map_level), _p(ref), rb.ref_offset, len(ref),
+                        None if rb.cand_snv_mask is None else _p(rb.cand_snv_mask))
+    n_loci = opt.report_end - opt.report_begin
+    cap = 2 * rb.n_bases + 1
+    call_off = np.zeros(n_loci + 1, np.int64)
+    calls = np.zeros(cap, np.uint16)
+    sd = np.zeros(max(n_loci, 1), np.uint32)
+    sm = np.zeros(max(n_loci, 1), np.uint32)
+    out = PileupColumns(n_loci, cap, _p(call_off), _p(calls), _p(sd), _p(sm))
+    _check(lib().sk_pileup_reads(C.byref(s), C.byref(opt), mode, C.byref(out)))
+    return call_off, calls[:call_off[-1]].copy(), sd[:n_loci], sm[:n_loci]

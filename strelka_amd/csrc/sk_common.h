@@ -37,6 +37,9 @@ struct SkTables
     float t_off_ref[SK_NQ6];                                  // (float) ln_comp_error_prob(q)            (:213)
     float t_off_alt[SK_NQ6];                                  // (float)(ln_error_prob(q) + ln_one_third) (:221)
     float s_ln_one_half;
+
+    // a8: qphred_cache::mappedq[mapq 0..90][q 0..70] (qscore_cache.cpp:46-49, qscore.hh:104-113)
+    uint8_t mappedq[91][SK_NQ + 1];
 };
 
 struct SkContext

@@ -45,6 +45,15 @@ void build_tables(SkTables& t)
         q2lne[i] = static_cast<double>(i) * q2lnp;
         t.q2mis[i] = q2lne[i] + lnthird; // qphred_to_ln_error_prob(qscore)+lnthird (:135)
     }
+    // mappedq[j][i] = error_prob_to_qphred(phred_to_mapped_error_prob(i, j)), qscore_cache.cpp:46-49:
+    //   be = 10^(-i/10), me = 10^(-j/10), p = (1-me)*be + me*0.75 (qscore.hh:104-113); floor(-10*log10(p) + 0.5) (:40-66)
+    for (int i = 0; i < SK_NQ; ++i)
+        for (int j = 0; j <= 90; ++j) {
+            const double be(std::pow(rt(10.), -static_cast<double>(i) / 10.));
+            const double me(std::pow(rt(10.), -static_cast<double>(j) / 10.));
+            const double p(((1. - me) * be) + (me * 0.75));
+            t.mappedq[j][i] = static_cast<uint8_t>(static_cast<int>(std::floor((-10. * std::log10(p)) + 0.5)));
+        }
     t.ln_quarter = std::log(rt(0.25));
     t.ln_noncand = std::log(rt(1e-5));
 

@@ -527,3 +527,128 @@ def realign_scenarios(n, rng, reads_per=6, haplotyping_rate=0.25, max_indels=6):
         out.append(dict(ref_seq=ref, ref_offset=off, indels=indels, reads=reads, is_haplotyping_enabled=int(is_hap),
                         min_read_bp_flank=int(rng.choice([5, 5, 5, 1]))))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# reads with final alignments for the pileup row (a8)
+
+class ReadBatch:
+    """SoA of reads + best alignments in pileup (read-buffer) order; mirrors sk_read_batch"""
+
+    def __init__(self, read_off, read_code, read_qual, path_off, path, pos, is_fwd, mapq, map_level, ref_seq, ref_offset,
+                 cand_snv_mask=None):
+        self.read_off = np.ascontiguousarray(read_off, np.int64)
+        self.read_code = np.ascontiguousarray(read_code, np.uint8)
+        self.read_qual = np.ascontiguousarray(read_qual, np.uint8)
+        self.path_off = np.ascontiguousarray(path_off, np.int64)
+        self.path = np.ascontiguousarray(path, np.uint32).reshape(-1, 2)
+        self.pos = np.ascontiguousarray(pos, np.int32)
+        self.is_fwd = np.ascontiguousarray(is_fwd, np.uint8)
+        self.mapq = np.ascontiguousarray(mapq, np.uint8)
+        self.map_level = np.ascontiguousarray(map_level, np.uint8)
+        self.ref_seq = ref_seq
+        self.ref_offset = int(ref_offset)
+        self.cand_snv_mask = None if cand_snv_mask is None else np.ascontiguousarray(cand_snv_mask, np.uint8)
+        self.n_reads = len(self.pos)
+        self.n_bases = int(self.read_off[-1]) if self.n_reads else 0
+
+    @staticmethod
+    def from_reads(reads, ref_seq, ref_offset, cand_snv_mask=None):
+        """reads: dicts(code, qual, pos, path=[(type,len)], is_fwd, mapq, map_level)"""
+        ro, po = [0], [0]
+        for r in reads:
+            ro.append(ro[-1] + len(r["code"]))
+            po.append(po[-1] + len(r["path"]))
+        cat = lambda k, dt: np.concatenate([np.asarray(r[k], dt) for r in reads]) if reads else np.zeros(0, dt)
+        path = np.array([s for r in reads for s in r["path"]], np.uint32).reshape(-1, 2)
+        return ReadBatch(ro, cat("code", np.uint8), cat("qual", np.uint8), po, path, [r["pos"] for r in reads],
+                         [int(r["is_fwd"]) for r in reads], [r["mapq"] for r in reads], [r["map_level"] for r in reads],
+                         ref_seq, ref_offset, cand_snv_mask)
+
+
+def pileup_reads(n_reads, rng, ref_len=600, ref_offset=5000, read_len=(36, 151), indel_rate=0.25, clip_rate=0.15,
+                 submapped_rate=0.08, tier2_rate=0.1, burst_rate=0.15, sorted_by_pos=True):
+    """reads over a random reference window: mismatches (with bursts that trip the mismatch-density filter), N runs at
+    either end, soft clips, insertions/deletions (also at the edges), assorted MAPQ and mapping tiers"""
+    ref = _random_ref(ref_len, rng)
+    reads = []
+    for _ in range(n_reads):
+        L = int(rng.integers(read_len[0], read_len[1]))
+        start = ref_offset + int(rng.integers(-10, max(1, ref_len - L // 2)))
+        path, seq, p = [], [], start
+        lead_clip = int(rng.integers(1, 12)) if rng.random() < clip_rate else 0
+        trail_clip = int(rng.integers(1, 12)) if rng.random() < clip_rate else 0
+
+        def rbase(pp):
+            i = pp - ref_offset
+            return ref[i] if 0 <= i < ref_len else "N"
+        if lead_clip:
+            path.append((SEG["SOFT_CLIP"], lead_clip))
+            seq += [_BASES[int(x)] for x in rng.integers(0, 4, lead_clip)]
+        body = L - lead_clip - trail_clip
+        n_ind = int(rng.integers(1, 4)) if rng.random() < indel_rate else 0
+        cuts = sorted(int(x) for x in rng.integers(1, max(2, body - 1), n_ind)) if body > 8 else []
+        prev = 0
+        edge_lead_del = rng.random() < 0.03
+        if edge_lead_del:
+            path.append((SEG["DELETE"], int(rng.integers(1, 4))))
+            p += path[-1][1]
+        for c in cuts + [body]:
+            m = c - prev
+            if m > 0:
+                path.append((SEG["MATCH"], m))
+                seq += [rbase(p + j) for j in range(m)]
+                p += m
+            prev = c
+            if c < body:
+                if rng.random() < 0.5:
+                    d = int(rng.choice([1, 2, 3, 8, 20]))
+                    path.append((SEG["DELETE"], d))
+                    p += d
+                else:
+                    k = min(int(rng.choice([1, 2, 5])), body - c)
+                    if k > 0:
+                        path.append((SEG["INSERT"], k))
+                        seq += [_BASES[int(x)] for x in rng.integers(0, 4, k)]
+                        prev = c + k
+        if trail_clip:
+            path.append((SEG["SOFT_CLIP"], trail_clip))
+            seq += [_BASES[int(x)] for x in rng.integers(0, 4, trail_clip)]
+        # merge adjacent equal segment types, fix the length
+        merged = []
+        for t, l in path:
+            if merged and merged[-1][0] == t:
+                merged[-1] = (t, merged[-1][1] + l)
+            else:
+                merged.append((t, l))
+        path = merged
+        seq = seq[:sum(l for t, l in path if t in (SEG["MATCH"], SEG["INSERT"], SEG["SOFT_CLIP"]))]
+        L = len(seq)
+        if L < 10:
+            continue
+        # mismatches: background + an occasional burst
+        for i in range(L):
+            if seq[i] != "N" and rng.random() < 0.01:
+                seq[i] = _BASES[(_BASES.index(seq[i]) + int(rng.integers(1, 4))) % 4]
+        if rng.random() < burst_rate:
+            c0 = int(rng.integers(0, L))
+            for i in range(c0, min(L, c0 + int(rng.integers(3, 25)))):
+                if seq[i] != "N" and rng.random() < 0.4:
+                    seq[i] = _BASES[(_BASES.index(seq[i]) + 1) % 4]
+        if rng.random() < 0.1:
+            for i in range(int(rng.integers(1, 6))):
+                seq[L - 1 - i] = "N"
+        if rng.random() < 0.1:
+            for i in range(int(rng.integers(1, 6))):
+                seq[i] = "N"
+        if rng.random() < 0.05:
+            seq[int(rng.integers(0, L))] = "N"
+        u = rng.random()
+        level = 3 if u < submapped_rate else (2 if u < submapped_rate + tier2_rate else 1)
+        reads.append(dict(code=np.array([_CODE[c] for c in seq], np.uint8), qual=rng.integers(2, 42, L).astype(np.uint8),
+                          pos=int(p - sum(l for t, l in path if t in (SEG["MATCH"], SEG["DELETE"]))), path=path,
+                          is_fwd=bool(rng.random() < 0.5), mapq=int(rng.choice([0, 3, 10, 20, 40, 60, 60, 60, 85, 255])),
+                          map_level=level))
+    if sorted_by_pos:
+        reads.sort(key=lambda r: r["pos"])
+    return reads, ref, ref_offset

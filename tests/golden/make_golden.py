@@ -184,9 +184,67 @@ def realign_golden():
         sum(len(r.get("scores", [])) for e in expect for r in e)))
 
 
+def pileup_golden():
+    """row a8 through the reference's own position processor (oracle/ref/ref_driver_pileup.cpp): reads -> read buffer ->
+    realignment -> pileup_read_segment; the fixture keeps the reads with the alignments the reference piled up and the
+    per-position columns it built"""
+    pyoracle.build(ref=True)
+    rng = np.random.default_rng(20240927)
+    trials = []
+    for t in range(8):
+        reads, ref, off = synth.pileup_reads(110, rng)
+        trim = (t % 3 == 0)
+        kw = dict(report_begin=off + (40 if trim else 0), report_end=off + len(ref) - (55 if trim else 0))
+        if t % 2:
+            kw.update(min_basecall_qscore=0, mismatch_density_max_count=3, use_tier2_evidence=1, tier2_mismatch_density_max_count=10)
+        if t == 6:
+            kw.update(is_mapq_adjust=0, min_distance_from_read_edge=3)
+        if t == 7:
+            kw.update(mismatch_density_flank_size=0)
+        opt = pyoracle.pileup_options(**kw)
+        # externally supplied candidate indels (deletions some reads carry) make the reference realign reads around them
+        cands = []
+        if t in (1, 2, 4, 5):
+            for r in reads:
+                p = r["pos"]
+                for i, (ty, ln) in enumerate(r["path"]):
+                    if ty == synth.SEG["DELETE"] and 0 < i < len(r["path"]) - 1 and len(cands) < 12 and ln <= 20:
+                        if p not in [c["pos"] for c in cands]:
+                            cands.append(dict(pos=p, del_len=ln))
+                    if ty in (synth.SEG["MATCH"], synth.SEG["DELETE"]):
+                        p += ln
+        finals, cols = pyoracle.ref_pileup_pipeline(reads, ref, off, opt, candidate_indels=cands)
+        piled = []
+        for f in finals:
+            if f["skipped"]:
+                continue
+            r = dict(reads[f["read_id"]])
+            r.update(pos=f["pos"], path=capi.cigar_to_path(f["cigar"]), is_fwd=f["is_fwd"], is_realigned=f["is_realigned"])
+            piled.append(r)
+        # columns as CSR over the report range
+        n_loci = opt.report_end - opt.report_begin
+        empty = dict(calls=np.zeros(0, np.uint16), tier2_calls=np.zeros(0, np.uint16), spandel=0, submapped=0)
+        col = [cols.get(opt.report_begin + l, empty) for l in range(n_loci)]
+        csr = lambda k: (np.concatenate([[0], np.cumsum([len(c[k]) for c in col])]).astype(np.int64),
+                         np.concatenate([c[k] for c in col] + [np.zeros(0, np.uint16)]).astype(np.uint16))
+        t1_off, t1 = csr("calls")
+        t2_off, t2 = csr("tier2_calls")
+        trials.append(dict(reads=piled, ref_seq=ref, ref_offset=off, opt=kw, t1_off=t1_off, t1=t1, t2_off=t2_off, t2=t2,
+                           spandel=np.array([c["spandel"] for c in col], np.uint32),
+                           submapped=np.array([c["submapped"] for c in col], np.uint32)))
+        assert all(p in range(opt.report_begin, opt.report_end) for p in cols)
+    import gzip
+    with gzip.open(os.path.join(HERE, "pileup_reference.pkl.gz"), "wb") as f:
+        pickle.dump(trials, f, protocol=4)
+    print("pileup golden: %d trials, %d reads, %d tier1 calls, %d tier2 calls" % (
+        len(trials), sum(len(t["reads"]) for t in trials), sum(len(t["t1"]) for t in trials), sum(len(t["t2"]) for t in trials)))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "realign":
-        realign_golden()
-    else:
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "main"):
         main()
+    if what in ("all", "realign"):
         realign_golden()
+    if what in ("all", "pileup"):
+        pileup_golden()
