@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--loci", type=int, default=1 << 24, help="germline loci per step per GPU (depth ~Poisson(40))")
     ap.add_argument("--unique-reads", type=int, default=1 << 14, help="distinct synthetic reads (tiled on device)")
     ap.add_argument("--unique-loci", type=int, default=1 << 20)
+    ap.add_argument("--pileup-reads", type=int, default=1 << 20, help="reads per step per GPU for the pileup leg (row a8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
     ap.add_argument("--cpu-loci", type=int, default=2000000, help="loci in the CPU-baseline sample")
@@ -154,6 +155,12 @@ def main():
     alg_bytes_b = 6 * db.n_calls + B_BYTES_PER_LOCUS_FIXED * db.n_loci
     ach_b = alg_bytes_b / (kms_b * 1e-3) / 1e9
 
+    # ---- row a8: reads -> pileup columns (feeds hot path B) ----
+    rbatch, rb_loci = synth.pileup_reads_flat(args.pileup_reads, rng)
+    dr = device.DeviceReadBatch(rbatch, rb_loci, dev)
+    dt_p, pbases, kms_p = timed(lambda: dr.pileup(), args.steps, args.warmup, rbatch.n_bases)
+    del dr
+
     traffic = pmc_traffic(args)
     out = {
         "metric": "candidate-alignment scoring cells/s (read bases x candidate alignments; Strelka2 has no pair-HMM, "
@@ -166,6 +173,8 @@ def main():
                                "depth~Poisson(40)" % (da.n_reads, db.n_loci),
                    "reads_per_step_per_gpu": da.n_reads, "candidates_per_read": 64, "read_len": 150,
                    "loci_per_step_per_gpu": db.n_loci, "sharding": "independent segments per GPU, no collective"},
+        "pileup_read_bases_per_s": pbases / dt_p, "pileup_ms_per_step": dt_p / args.steps * 1e3,
+        "pileup_reads_per_step_per_gpu": rbatch.n_reads,
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
         "roofline": {"kernel": "score_wave_per_read", "bound": "hbm", "achieved": ach_a, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach_a / HBM_PEAK_GBS,

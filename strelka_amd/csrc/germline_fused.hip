@@ -7,15 +7,18 @@
 //     which the block copies into LDS with coalesced loads (sub-batched when the span exceeds the LDS budget);
 //   * one THREAD per locus walks its calls in LDS.  Per call the LDS holds 4 bytes: the packed basecall (u16) and one
 //     u16 slot of the per-group sort array -- `de` itself is never stored.
-//   * phase 1 (adjust_joint_eprob): per (strand, base) group the calls' indices are sorted by descending q with the
-//     reference's std::sort (emulated step for step: its tie order decides which calls get the first exponents).  Only
-//     the first few sorted calls of a group (until the exponent reaches min_vexp) have a de that is not a pure function
-//     of q; their RANK (1..7) is written into the three spare bits of the LDS copy of the basecall.
+//   * phase 1 (adjust_joint_eprob): the reference sorts every (strand, base) group by descending q with std::sort and
+//     walks the sorted calls with a decaying exponent.  Only the first few sorted calls (until the exponent reaches
+//     min_vexp) have a de that is not a pure function of q, so only THEIR identity and order are needed: one counting
+//     and one filling pass build all groups' key lists, then per group the leading elements of the std::sort result are
+//     found without sorting (k_top_ranked: the introsort partition steps on the leftmost chain + a stable top-k; the
+//     tie order of libstdc++'s algorithm is reproduced exactly).  Their RANK (1..4) goes into spare bits of the LDS
+//     copy of the basecall.  Groups are visited largest first so that the lanes of a wave stay in step.
 //   * phase 2 (get_diploid_gt_lhood): calls are visited in pileup order; val[0] = logf(de)+ln(1/3) comes from a host-built
 //     table unless the call carries a rank, in which case de is recomputed from (q, group exponent chain).  The ten
 //     genotype sums are sequential float32 adds in pileup order, as in the reference.
-//   Loci deeper than 1023 calls, groups needing more than 7 ranked calls, or spans that do not fit the LDS budget take
-//   the global-memory routines of germline_common.h (same arithmetic).
+//   Loci deeper than 511 calls, groups needing more than 4 ranked calls, or spans that do not fit the LDS budget are
+//   queued on a work-list and redone by the global-memory routines of germline_common.h (same arithmetic, full sort).
 //
 // Roofline: HBM-bound by 2 B/call in + 144 B/locus out (+4 B/call when `de` is requested); SURVEY.md 8d prices the two
 // call sites separately at 6 B/call + 121 B/locus.
@@ -62,76 +65,6 @@ struct FusedArgs
 
 // ---- libstdc++ std::sort on packed u16 keys (q << 10 | idx), comp(a,b) = q(a) > q(b) ----
 __device__ __forceinline__ bool kgt(const uint16_t a, const uint16_t b) { return (a >> 10) > (b >> 10); }
-
-__device__ __forceinline__ void k_unguarded_linear_insert(uint16_t* last)
-{
-    const uint16_t val = *last;
-    uint16_t* next = last - 1;
-    while (kgt(val, *next)) {
-        *last = *next;
-        last = next;
-        --next;
-    }
-    *last = val;
-}
-
-__device__ void k_insertion_sort(uint16_t* first, uint16_t* last)
-{
-    if (first == last) return;
-    for (uint16_t* i = first + 1; i != last; ++i) {
-        if (kgt(*i, *first)) {
-            const uint16_t val = *i;
-            for (uint16_t* p = i; p != first; --p) *p = *(p - 1);
-            *first = val;
-        } else {
-            k_unguarded_linear_insert(i);
-        }
-    }
-}
-
-__device__ void k_adjust_heap(uint16_t* first, int hole, const int len, const uint16_t value)
-{
-    const int top = hole;
-    int child = hole;
-    while (child < (len - 1) / 2) {
-        child = 2 * (child + 1);
-        if (kgt(first[child], first[child - 1])) child--;
-        first[hole] = first[child];
-        hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-        child = 2 * (child + 1);
-        first[hole] = first[child - 1];
-        hole = child - 1;
-    }
-    int parent = (hole - 1) / 2;
-    while (hole > top && kgt(first[parent], value)) {
-        first[hole] = first[parent];
-        hole = parent;
-        parent = (hole - 1) / 2;
-    }
-    first[hole] = value;
-}
-
-__device__ void k_heap_sort(uint16_t* first, uint16_t* last)
-{
-    const int len = int(last - first);
-    if (len >= 2) {
-        int parent = (len - 2) / 2;
-        for (;;) {
-            const uint16_t value = first[parent];
-            k_adjust_heap(first, parent, len, value);
-            if (parent == 0) break;
-            parent--;
-        }
-    }
-    while (last - first > 1) {
-        --last;
-        const uint16_t value = *last;
-        *last = *first;
-        k_adjust_heap(first, 0, int(last - first), value);
-    }
-}
 
 // The first `need` (<= MAX_RANK) elements of std::sort(keys, keys+n, q descending) WITHOUT sorting.
 //

@@ -397,9 +397,9 @@ ScratchLayout layout(const int32_t n_reads, const int64_t n_bases, const int32_t
     int* ip = nullptr;
     uint32_t* up = nullptr;
     int64_t* lp = nullptr;
-    rocprim::inclusive_scan(nullptr, t1, ip, ip, size_t(std::max(n_reads, 1)), MaxOp());
-    rocprim::inclusive_scan(nullptr, t2, std::make_reverse_iterator(ip), std::make_reverse_iterator(ip), size_t(std::max(n_reads, 1)), MinOp());
-    rocprim::exclusive_scan(nullptr, t3, up, lp, int64_t(0), size_t(n_loci) + 1, rocprim::plus<int64_t>());
+    (void)rocprim::inclusive_scan(nullptr, t1, ip, ip, size_t(std::max(n_reads, 1)), MaxOp());
+    (void)rocprim::inclusive_scan(nullptr, t2, std::make_reverse_iterator(ip), std::make_reverse_iterator(ip), size_t(std::max(n_reads, 1)), MinOp());
+    (void)rocprim::exclusive_scan(nullptr, t3, up, lp, int64_t(0), size_t(n_loci) + 1, rocprim::plus<int64_t>());
     s.tmp = o;
     s.tmp_bytes = int64_t(std::max(t1, std::max(t2, t3))) + 256;
     o += align256(s.tmp_bytes);

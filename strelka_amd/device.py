@@ -133,3 +133,34 @@ def somatic_snv_call_dev(normal, tumor, opt=None, is_forced_output=False):
     capi._check(capi.lib().sk_somatic_snv_call_batch_dev(C.byref(sn), C.byref(st), C.byref(opt), int(is_forced_output),
                                                          C.c_void_p(normal.som_out.data_ptr()), _stream_ptr()))
     return normal.som_out
+
+
+class DeviceReadBatch:
+    """synth.ReadBatch resident on the device + output buffers for sk_pileup_reads_dev (row a8)"""
+
+    def __init__(self, rb, n_loci, device="cuda:0", report_begin=0):
+        self.rb, self.n_loci, self.device = rb, n_loci, device
+        ref = np.frombuffer(rb.ref_seq.encode(), np.uint8).copy()
+        self.t = dict(read_off=_t(rb.read_off, device), read_code=_t(rb.read_code, device), read_qual=_t(rb.read_qual, device),
+                      path_off=_t(rb.path_off, device), path=_t(rb.path.view(np.int32), device), pos=_t(rb.pos, device),
+                      is_fwd=_t(rb.is_fwd, device), mapq=_t(rb.mapq, device), map_level=_t(rb.map_level, device),
+                      ref=_t(ref, device))
+        t = self.t
+        self.s = capi.ReadBatchStruct(rb.n_reads, *[t[k].data_ptr() for k in ("read_off", "read_code", "read_qual", "path_off",
+                                                                                "path", "pos", "is_fwd", "mapq", "map_level",
+                                                                                "ref")], rb.ref_offset, len(ref), None)
+        self.opt = capi.pileup_options(report_begin=report_begin, report_end=report_begin + n_loci)
+        self.cap = rb.n_bases + 16
+        self.call_off = torch.empty(n_loci + 1, dtype=torch.int64, device=device)
+        self.calls = torch.empty(self.cap, dtype=torch.int16, device=device)
+        self.spandel = torch.empty(max(n_loci, 1), dtype=torch.int32, device=device)
+        self.submapped = torch.empty(max(n_loci, 1), dtype=torch.int32, device=device)
+        self.scratch = torch.empty(capi.lib().sk_pileup_scratch_bytes(rb.n_reads, rb.n_bases, n_loci), dtype=torch.uint8,
+                                   device=device)
+        self.out = capi.PileupColumns(n_loci, self.cap, self.call_off.data_ptr(), self.calls.data_ptr(),
+                                      self.spandel.data_ptr(), self.submapped.data_ptr())
+
+    def pileup(self, mode=capi.PILEUP_CLEAN_TIER1):
+        capi._check(capi.lib().sk_pileup_reads_dev(C.byref(self.s), self.rb.n_bases, C.byref(self.opt), mode,
+                                                   C.byref(self.out), self.scratch.data_ptr(), _stream_ptr()))
+        return self.call_off, self.calls

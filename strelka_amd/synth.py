@@ -652,3 +652,36 @@ def pileup_reads(n_reads, rng, ref_len=600, ref_offset=5000, read_len=(36, 151),
     if sorted_by_pos:
         reads.sort(key=lambda r: r["pos"])
     return reads, ref, ref_offset
+
+
+def pileup_reads_flat(n_reads, rng, L=150, depth=40.0, del_rate=0.05, mismatch_rate=0.01):
+    """bench-sized ReadBatch, vectorised: position-sorted 150 bp reads at the given depth over a random reference;
+    5% carry one internal deletion; 1% substitutions; Q from a 2..40 mix; MAPQ 60 tier1"""
+    n_loci = int(n_reads * L / depth)
+    ref_codes = rng.integers(0, 4, n_loci + 2 * L + 64).astype(np.uint8)
+    pos = np.sort(rng.integers(0, n_loci, n_reads)).astype(np.int32)
+    has_del = rng.random(n_reads) < del_rate
+    cut = rng.integers(20, L - 20, n_reads)
+    dlen = rng.integers(1, 9, n_reads)
+    idx = np.arange(L)[None, :]
+    shift = np.where(has_del[:, None] & (idx >= cut[:, None]), dlen[:, None], 0)
+    base = ref_codes[pos[:, None] + idx + shift]
+    mm = rng.random((n_reads, L)) < mismatch_rate
+    base = np.where(mm, (base + rng.integers(1, 4, (n_reads, L))) % 4, base).astype(np.uint8)
+    code = (1 << base).astype(np.uint8)
+    qual = rng.choice(np.array([2, 12, 22, 27, 32, 37, 37, 40], np.uint8), (n_reads, L))
+    nseg = np.where(has_del, 3, 1)
+    path_off = np.concatenate([[0], np.cumsum(nseg)]).astype(np.int64)
+    path = np.zeros((int(path_off[-1]), 2), np.uint32)
+    first = path_off[:-1]
+    path[first, 0] = SEG["MATCH"]
+    path[first, 1] = np.where(has_del, cut, L)
+    d = first[has_del]
+    path[d + 1, 0] = SEG["DELETE"]
+    path[d + 1, 1] = dlen[has_del]
+    path[d + 2, 0] = SEG["MATCH"]
+    path[d + 2, 1] = L - cut[has_del]
+    ref = "".join(np.array(list("ACGT"))[ref_codes])
+    return ReadBatch(np.arange(n_reads + 1, dtype=np.int64) * L, code.reshape(-1), qual.reshape(-1), path_off, path, pos,
+                     rng.integers(0, 2, n_reads).astype(np.uint8), np.full(n_reads, 60, np.uint8), np.ones(n_reads, np.uint8),
+                     ref, 0), n_loci
