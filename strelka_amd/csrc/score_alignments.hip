@@ -59,7 +59,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(con
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = threadIdx.x / WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / WAVE); // wave-uniform: L, P, offsets live in SGPRs
     const size_t per_wave = size_t(a.lds_tab_bytes) + a.lds_hap_bytes + OPS_CAP * sizeof(sk_score_op);
     unsigned char* slab = smem + per_wave * wave;
     unsigned char* tabb = slab;
