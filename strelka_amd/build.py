@@ -49,7 +49,7 @@ def build_all(force=False, verbose=True):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            # no FMA contraction on host or device: the reference is plain x86-64 arithmetic, and the order/rounding of
            # every add is part of the result
-           "-ffp-contract=off", "-Wall",
+           "-ffp-contract=off", "-mllvm", "-disable-promote-alloca-to-lds", "-Wall",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")]
     for s in HOST_SOURCES:
         cmd += ["-x", "c++", os.path.join(PKG, s)]

@@ -33,10 +33,12 @@ namespace
 
 constexpr int LOCI_PER_BLOCK = 128;
 constexpr int FUSED_THREADS = 128;
-constexpr int CAP_CALLS = 5312;       // LDS budget: 4 B/call -> 22 KiB (+12 KiB of per-locus ranked-call terms) per block
+constexpr int CAP_CALLS = 5312;       // LDS budget: 4 B/call (call + sort key) = 20.75 KiB; with the 3.5 KiB term pool, offsets and
+                                      // tables a block takes 26.5 KiB: 6 blocks = 12 waves per CU
+constexpr int V0R_POOL = 864;         // LDS floats per block for the ranked calls' val[0] terms, handed out exact-fit
 constexpr int MAX_RANK = 4;           // ranked calls per group on the LDS path (defaults need <= 4: 1, .65, .4225, .2746)
-constexpr int V0R_PER_LOCUS = 12;    // LDS floats per locus for val[0] of ranks 2..MAX_RANK (rank 1 has de == e_q), packed
-                                     // group after group; a locus needing more takes the global pass
+constexpr int V0R_PER_LOCUS = 16;    // most terms one locus may hold (ranks 2..MAX_RANK of each group, packed group after group,
+                                     // 4-bit slot bases); a locus needing more takes the global pass
 constexpr int MAX_PACKED_DEPTH = 511;  // sort key u16 = q << 10 | neighbor-mismatch << 9 | 9-bit call index
 constexpr unsigned RANK_SHIFT = 13;    // bits 13..15 of the LDS basecall copy hold the rank (bit 13 = tscf, unused here)
 constexpr unsigned CALL_MASK = 0x1fffu;
@@ -204,10 +206,11 @@ __device__ __forceinline__ float call_v0(const uint16_t c, const float4 qv, cons
 //   pass B  write every member's sort key into its group's slice of `keys` (pileup order inside a group)
 //   then per present group: mismatch fraction -> exponent chain length -> the first ranked calls -> their val[0] terms
 __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, const SkTables* __restrict__ T,
-                                 const GermlineDerived& D, const QTab& Q, float (&vfrac)[8], float* v0r,
-                                 unsigned& gbase)
+                                 const GermlineDerived& D, const QTab& Q, float (&vfrac)[8], float* pool,
+                                 unsigned* pool_ctr, float*& v0r, unsigned& gbase)
 {
     gbase = 0;
+    v0r = pool;
     unsigned nslots = 0;
 #pragma unroll
     for (int g = 0; g < 8; ++g) vfrac[g] = 0.f;
@@ -221,6 +224,19 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
         const uint64_t inc = valid ? (uint64_t(1) << (16 * (g & 3))) : 0;
         cntA += (g < 4) ? inc : 0;
         cntB += (g >= 4) ? inc : 0;
+    }
+    // term slots: ranks 2..4 of every group, i.e. at most min(count - 1, MAX_RANK - 1) each; taken exact-fit from the block pool
+    unsigned need = 0;
+#pragma unroll
+    for (unsigned g = 0; g < 8; ++g) {
+        const unsigned cg = unsigned(((g < 4) ? cntA : cntB) >> (16 * (g & 3))) & 0xffffu;
+        need += (cg > 1u) ? ((cg - 1u < unsigned(MAX_RANK - 1)) ? cg - 1u : unsigned(MAX_RANK - 1)) : 0u;
+    }
+    if (need > unsigned(V0R_PER_LOCUS)) return false;
+    if (need) {
+        const unsigned at = atomicAdd(pool_ctr, need);
+        if (at + need > unsigned(V0R_POOL)) return false;
+        v0r = pool + at;
     }
     // exclusive prefix sums of the eight counts, same packing (no field overflows: n <= 511)
     const uint64_t inclA = cntA + (cntA << 16) + (cntA << 32) + (cntA << 48);
@@ -305,8 +321,8 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
             ok = false;
             break;
         }
-        gbase |= nslots << (4 * g);
-        if (nslots + unsigned(ntop > 1 ? ntop - 1 : 0) > unsigned(V0R_PER_LOCUS)) {
+        if (ntop > 1) gbase |= nslots << (4 * g); // (a group without ranks >= 2 owns no slots; nslots may be 16 here)
+        if (nslots + unsigned(ntop > 1 ? ntop - 1 : 0) > need) {
             ok = false;
             break;
         }
@@ -395,18 +411,21 @@ __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigne
     }
 }
 
-__global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(const FusedArgs a)
+__global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void germline_site_fused_kernel(const FusedArgs a)
 {
     __shared__ uint16_t s_calls[CAP_CALLS];
     __shared__ uint16_t s_keys[CAP_CALLS];
-    __shared__ int64_t s_off[LOCI_PER_BLOCK + 1];
-    __shared__ float s_v0r[LOCI_PER_BLOCK * V0R_PER_LOCUS];
+    __shared__ int32_t s_off[LOCI_PER_BLOCK + 1]; // call offsets relative to the block's first call
+    __shared__ float s_pool[V0R_POOL];
+    __shared__ unsigned s_pool_ctr;
     __shared__ QTab s_q;
 
     const int tid = threadIdx.x;
     const int l0 = blockIdx.x * LOCI_PER_BLOCK;
     const int nl = min(LOCI_PER_BLOCK, a.b.n_loci - l0);
-    for (int j = tid; j <= nl; j += FUSED_THREADS) s_off[j] = a.b.call_off[l0 + j];
+    const int64_t block_c0 = a.b.call_off[l0];
+    const bool huge = (a.b.call_off[l0 + nl] - block_c0) > int64_t(0x7fff0000); // offsets below are 32-bit
+    for (int j = tid; j <= nl; j += FUSED_THREADS) s_off[j] = huge ? 0 : int32_t(a.b.call_off[l0 + j] - block_c0);
     for (int q = tid; q < SK_NQ6; q += FUSED_THREADS) {
         s_q.v[q] = make_float4(a.d.v0e[q], a.d.v0min[q], a.tab->g_v1[q], a.tab->g_v2[q]);
         s_q.weight[q] = a.tab->g_weight[q];
@@ -414,13 +433,21 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
         s_q.depmin[q] = a.d.depmin[q];
     }
     __syncthreads();
+    if (huge) { // (a block spanning > 2^31 calls: every locus to the global-memory pass)
+        if (tid < nl) {
+            a.out[l0 + tid].is_called = NEEDS_GLOBAL_PASS;
+            a.worklist[atomicAdd(a.work_count, 1u)] = unsigned(l0 + tid);
+        }
+        return;
+    }
 
     const SkTables* __restrict__ T = a.tab;
     int s = 0; // first locus (block-relative) of the current sub-batch
     while (s < nl) {
         // sub-batch = the longest run of loci starting at s whose calls fit the LDS budget (call_off is monotone)
-        const int64_t c0 = s_off[s];
+        const int c0 = s_off[s];
         const bool fits = (tid >= s) && (tid < nl) && (s_off[tid + 1] - c0 <= CAP_CALLS);
+        if (tid == 0) s_pool_ctr = 0;
         const int cnt = __syncthreads_count(fits);
         if (cnt == 0) {
             // a single locus deeper than the LDS budget: left to the global-memory pass
@@ -433,29 +460,29 @@ __global__ __launch_bounds__(FUSED_THREADS) void germline_site_fused_kernel(cons
             continue;
         }
         const int e = s + cnt;
-        const int span = int(s_off[e] - c0);
-        const uint16_t* __restrict__ gcalls = a.b.calls + c0;
+        const int span = s_off[e] - c0;
+        const uint16_t* __restrict__ gcalls = a.b.calls + block_c0 + c0;
         for (int j = tid; j < span; j += FUSED_THREADS) s_calls[j] = gcalls[j] & CALL_MASK;
         __syncthreads();
 
         const int t = s + tid;
         if (t < e) {
             const int l = l0 + t;
-            const int off = int(s_off[t] - c0);
-            const int n = int(s_off[t + 1] - s_off[t]);
+            const int off = s_off[t] - c0;
+            const int n = s_off[t + 1] - s_off[t];
             const unsigned ref = a.b.ref_base[l];
             const int ploidy = a.b.ploidy ? int(a.b.ploidy[l]) : 2;
             float vfrac[8];
             bool ok = (n <= MAX_PACKED_DEPTH);
-            float* v0r = s_v0r + tid * V0R_PER_LOCUS;
+            float* v0r = s_pool;
             unsigned gbase = 0;
-            if (ok) ok = locus_rank_calls(s_calls + off, s_keys + off, n, T, a.d, s_q, vfrac, v0r, gbase);
+            if (ok) ok = locus_rank_calls(s_calls + off, s_keys + off, n, T, a.d, s_q, vfrac, s_pool, &s_pool_ctr, v0r, gbase);
             if (ok) {
                 sk_digt_call res;
                 locus_call_lds(s_calls + off, n, ref, ploidy, v0r, gbase, T, a.d, s_q, res);
                 a.out[l] = res;
                 if (a.want_de) {
-                    float* __restrict__ de = a.de_tmp + s_off[t];
+                    float* __restrict__ de = a.de_tmp + block_c0 + s_off[t];
                     for (int i = 0; i < n; ++i) de[i] = call_de(s_calls[off + i], vfrac, s_q, a.d);
                 }
             } else {
