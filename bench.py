@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--unique-reads", type=int, default=1 << 14, help="distinct synthetic reads (tiled on device)")
     ap.add_argument("--unique-loci", type=int, default=1 << 20)
     ap.add_argument("--pileup-reads", type=int, default=1 << 20, help="reads per step per GPU for the pileup leg (row a8)")
+    ap.add_argument("--somatic-loci", type=int, default=1 << 22, help="somatic loci per step per GPU (40x normal + 110x tumor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
     ap.add_argument("--cpu-loci", type=int, default=2000000, help="loci in the CPU-baseline sample")
@@ -161,7 +162,18 @@ def main():
     dt_p, pbases, kms_p = timed(lambda: dr.pileup(), args.steps, args.warmup, rbatch.n_bases)
     del dr
 
+    # ---- hot path B (somatic SNV): 30-state grid likelihoods + posterior, normal 40x + tumor 110x ----
+    ns, ts = synth.somatic_pileups(min(args.unique_loci, args.somatic_loci), rng)
+    tile_s = max(1, args.somatic_loci // ns.n_loci)
+    dns = device.DevicePileupBatch(ns, dev, tile=tile_s)
+    dts = device.DevicePileupBatch(ts, dev, tile=tile_s)
+    dt_s, sloci, kms_s = timed(lambda: device.somatic_snv_call_dev(dns, dts), args.steps, args.warmup, dns.n_loci)
+    somatic_calls = dns.n_calls + dts.n_calls
+    somatic_loci_n = dns.n_loci
+    del dns, dts
+
     traffic = pmc_traffic(args)
+    traffic_s = traffic
     out = {
         "metric": "candidate-alignment scoring cells/s (read bases x candidate alignments; Strelka2 has no pair-HMM, "
                   "SURVEY.md section 0) + germline loci/s",
@@ -175,6 +187,12 @@ def main():
                    "loci_per_step_per_gpu": db.n_loci, "sharding": "independent segments per GPU, no collective"},
         "pileup_read_bases_per_s": pbases / dt_p, "pileup_ms_per_step": dt_p / args.steps * 1e3,
         "pileup_reads_per_step_per_gpu": rbatch.n_reads,
+        "somatic_loci_per_s": sloci / dt_s, "somatic_ms_per_step": dt_s / args.steps * 1e3,
+        "somatic_loci_per_step_per_gpu": somatic_loci_n,
+        "roofline_somatic": {"kernel": "somatic_snv_kernel", "bound": "hbm", "achieved": (2 * somatic_calls + 273 * somatic_loci_n) / (kms_s * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (2 * somatic_calls + 273 * somatic_loci_n) / (kms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": traffic_s.get("somatic_snv_kernel"), "algorithmic_bytes_per_launch": 2 * somatic_calls + 273 * somatic_loci_n,
+                             "kernel_ms": kms_s},
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
         "roofline": {"kernel": "score_wave_per_read", "bound": "hbm", "achieved": ach_a, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach_a / HBM_PEAK_GBS,
