@@ -6,7 +6,8 @@
 //                                   L/applications/strelka/position_somatic_snv_strand_grid_lhood_cached.cpp:41-234
 //   calculate_result_set_grid       L/applications/strelka/qscore_calculator.cpp:47-209
 //
-// One thread per locus.  The reference memoises every per-call term by (qscore, ratio index); those memo tables are
+// One thread per locus; the calls of a block's loci are staged through LDS with coalesced loads (normal sample, then
+// tumor, through the same buffer) and the memo tables live in LDS as one row per q-score.  The reference memoises every per-call term by (qscore, ratio index); those memo tables are
 // built on the host (SkTables) so each of the 21 (+2x9 strand) accumulators is the same sequential float32 sum over the
 // calls in pileup order as in the reference -- bit-identical.  Only the 9 strand states' final float logsum and the
 // double-precision posterior evaluate device transcendentals.
@@ -42,9 +43,23 @@ __device__ __forceinline__ float log_sum2f(float x1, float x2)
     return __fadd_rn(x1, l);
 }
 
+// per-q row of every memoised term, one LDS row per q-score: the per-call loop indexes it with a data-dependent q
+struct QRow
+{
+    float v0, v1, v2, off_ref;            // simple genotypes (:56-64); off-strand ref term (:213)
+    float c0[HET_RES], c1[HET_RES];        // het grid (:104-110)
+    float t0[HET_RES], t1[HET_RES];        // strand states, on-strand (:197-206)
+    float off_alt, pad[3];                 // off-strand alt term (:221)
+};
+static_assert(sizeof(QRow) % 16 == 0, "rows are read with 128-bit LDS loads");
+
+constexpr int SOM_THREADS = 64;
+constexpr int SOM_CAP = 8192; // calls of one sample staged per sub-batch (16 KiB)
+
+// one sample's 30 likelihoods for the locus whose calls sit at calls[0..n) in LDS
 template <bool WITH_STRAND>
-__device__ void sample_lhood(const uint16_t* __restrict__ calls, const int n, const unsigned ref_gt,
-                             const SkTables* __restrict__ T, float* __restrict__ lhood, bool& allref, unsigned& alt_id)
+__device__ __forceinline__ void sample_lhood(const uint16_t* calls, const int n, const unsigned ref_gt, const QRow* Q,
+                                             const float ln_one_half, float* __restrict__ lhood, bool& allref, unsigned& alt_id)
 {
     float acc[PRESTRAND];
 #pragma unroll
@@ -61,25 +76,27 @@ __device__ void sample_lhood(const uint16_t* __restrict__ calls, const int n, co
         const bool is_ref = (obs == ref_gt);
         if (!is_ref) {
             allref = false;
-            if (obs < 4) ++alt_count[obs];
+#pragma unroll
+            for (unsigned b = 0; b < 4; ++b) alt_count[b] += (obs == b) ? 1u : 0u;
         }
-        const float v0 = T->s_v0[q], v1 = T->s_v1[q], v2 = T->s_v2[q];
+        const QRow& R = Q[q];
+        const float v0 = R.v0, v1 = R.v1, v2 = R.v2;
         acc[SOM_REF] = __fadd_rn(acc[SOM_REF], is_ref ? v2 : v0);
         acc[SOM_HET] = __fadd_rn(acc[SOM_HET], v1);
         acc[SOM_HOM] = __fadd_rn(acc[SOM_HOM], is_ref ? v0 : v2);
 #pragma unroll
         for (int r = 0; r < HET_RES; ++r) {
-            const float c0 = T->s_c0[r][q], c1 = T->s_c1[r][q];
+            const float c0 = R.c0[r], c1 = R.c1[r];
             // lhood_high = grid[2*HET_RES-(r+1)], lhood_low = grid[r]   (…_lhood_cached.cpp:149-151)
             acc[SOM_SIZE + (2 * HET_RES - (r + 1))] = __fadd_rn(acc[SOM_SIZE + (2 * HET_RES - (r + 1))], is_ref ? c0 : c1);
             acc[SOM_SIZE + r] = __fadd_rn(acc[SOM_SIZE + r], is_ref ? c1 : c0);
         }
         if (WITH_STRAND) {
             const bool fwd = SKC_FWD(bc);
-            const float off = is_ref ? T->t_off_ref[q] : T->t_off_alt[q];
+            const float off = is_ref ? R.off_ref : R.off_alt;
 #pragma unroll
             for (int r = 0; r < HET_RES; ++r) {
-                const float on = is_ref ? T->t_c0[r][q] : T->t_c1[r][q];
+                const float on = is_ref ? R.t0[r] : R.t1[r];
                 sf[r] = __fadd_rn(sf[r], fwd ? on : off);
                 sr[r] = __fadd_rn(sr[r], fwd ? off : on);
             }
@@ -89,7 +106,7 @@ __device__ void sample_lhood(const uint16_t* __restrict__ calls, const int n, co
     for (int i = 0; i < PRESTRAND; ++i) lhood[i] = acc[i];
 #pragma unroll
     for (int r = 0; r < HET_RES; ++r)
-        lhood[PRESTRAND + r] = WITH_STRAND ? __fadd_rn(log_sum2f(sf[r], sr[r]), T->s_ln_one_half) : 0.f;
+        lhood[PRESTRAND + r] = WITH_STRAND ? __fadd_rn(log_sum2f(sf[r], sr[r]), ln_one_half) : 0.f;
 
     // snp_pos_info::get_most_frequent_alt_id, L/blt_common/snp_pos_info.hh:164-190
     alt_id = ref_gt;
@@ -103,23 +120,82 @@ __device__ void sample_lhood(const uint16_t* __restrict__ calls, const int n, co
     }
 }
 
-__global__ void somatic_snv_kernel(const SomArgs a)
+// stage the calls of the block's loci [s, e) of one sample into LDS with coalesced loads; sub-batched like the germline
+// kernel when the span exceeds the buffer.  `f(t, calls, n)` runs for every locus t of the block exactly once; a locus
+// deeper than the whole buffer is handed its global pointer instead.
+template <typename F>
+__device__ __forceinline__ void for_each_locus_staged(const sk_pileup_batch& b, const int l0, const int nl, uint16_t* s_calls,
+                                                      int64_t* s_off, F&& f)
 {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= a.n.n_loci) return;
-    const unsigned ref = a.n.ref_base[l];
+    const int tid = threadIdx.x;
+    for (int j = tid; j <= nl; j += SOM_THREADS) s_off[j] = b.call_off[l0 + j];
+    __syncthreads();
+    int s = 0;
+    while (s < nl) {
+        const int64_t c0 = s_off[s];
+        const bool fits = (tid >= s) && (tid < nl) && (s_off[tid + 1] - c0 <= SOM_CAP);
+        const int cnt = __syncthreads_count(fits);
+        if (cnt == 0) { // one locus deeper than the buffer: straight from global memory
+            if (tid == s) f(s, b.calls + c0, int(s_off[s + 1] - c0));
+            s += 1;
+            __syncthreads();
+            continue;
+        }
+        const int e = s + cnt;
+        const int span = int(s_off[e] - c0);
+        const uint16_t* __restrict__ g = b.calls + c0;
+        for (int j = tid; j < span; j += SOM_THREADS) s_calls[j] = g[j];
+        __syncthreads();
+        const int t = s + tid;
+        if (t < e) f(t, s_calls + int(s_off[t] - c0), int(s_off[t + 1] - s_off[t]));
+        s = e;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SOM_THREADS) void somatic_snv_kernel(const SomArgs a)
+{
+    __shared__ uint16_t s_calls[SOM_CAP];
+    __shared__ int64_t s_off[SOM_THREADS + 1];
+    __shared__ __attribute__((aligned(16))) QRow s_q[SK_NQ6];
+
+    const int tid = threadIdx.x;
+    const int l0 = blockIdx.x * SOM_THREADS;
+    const int nl = min(SOM_THREADS, a.n.n_loci - l0);
+    for (int q = tid; q < SK_NQ6; q += SOM_THREADS) {
+        const SkTables* __restrict__ T = a.tab;
+        QRow r;
+        r.v0 = T->s_v0[q];
+        r.v1 = T->s_v1[q];
+        r.v2 = T->s_v2[q];
+        r.off_ref = T->t_off_ref[q];
+        r.off_alt = T->t_off_alt[q];
+        r.pad[0] = r.pad[1] = r.pad[2] = 0.f;
+#pragma unroll
+        for (int k = 0; k < HET_RES; ++k) {
+            r.c0[k] = T->s_c0[k][q];
+            r.c1[k] = T->s_c1[k][q];
+            r.t0[k] = T->t_c0[k][q];
+            r.t1[k] = T->t_c1[k][q];
+        }
+        s_q[q] = r;
+    }
+    const float ln_one_half = a.tab->s_ln_one_half;
+    const int l = l0 + tid;
+    const unsigned ref = (tid < nl) ? a.n.ref_base[l] : 4u;
+
     sk_somatic_snv_call res;
     memset(&res, 0, sizeof(res));
-    if (ref >= 4) {
-        a.out[l] = res;
-        return;
-    }
-    const int64_t no = a.n.call_off[l], to = a.t.call_off[l];
-    const int nn = int(a.n.call_off[l + 1] - no), nt = int(a.t.call_off[l + 1] - to);
-    bool n_allref, t_allref;
-    sample_lhood<false>(a.n.calls + no, nn, ref, a.tab, res.normal_lhood, n_allref, res.normal_alt_id);
-    sample_lhood<true>(a.t.calls + to, nt, ref, a.tab, res.tumor_lhood, t_allref, res.tumor_alt_id);
-    if (!a.d.is_forced_output && n_allref && t_allref) { // early-out (:251-254): nothing is computed by the reference
+    bool n_allref = true, t_allref = true;
+    // (the first __syncthreads inside for_each_locus_staged also publishes s_q)
+    for_each_locus_staged(a.n, l0, nl, s_calls, s_off, [&](const int, const uint16_t* calls, const int n) {
+        if (ref < 4) sample_lhood<false>(calls, n, ref, s_q, ln_one_half, res.normal_lhood, n_allref, res.normal_alt_id);
+    });
+    for_each_locus_staged(a.t, l0, nl, s_calls, s_off, [&](const int, const uint16_t* calls, const int n) {
+        if (ref < 4) sample_lhood<true>(calls, n, ref, s_q, ln_one_half, res.tumor_lhood, t_allref, res.tumor_alt_id);
+    });
+    if (tid >= nl) return;
+    if (ref >= 4 || (!a.d.is_forced_output && n_allref && t_allref)) { // N reference / early-out (:251-254)
         memset(&res, 0, sizeof(res));
         a.out[l] = res;
         return;
@@ -193,7 +269,7 @@ int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* n, const sk_pileup_batc
     a.tab = sk_ctx().dev_tables;
     a.out = dev_out;
     derive(*opt, is_forced_output, a.d);
-    const int threads = 64;
+    const int threads = SOM_THREADS;
     hipLaunchKernelGGL(somatic_snv_kernel, dim3((n->n_loci + threads - 1) / threads), dim3(threads), 0,
                        static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());
