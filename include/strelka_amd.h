@@ -336,6 +336,35 @@ int sk_pileup_reads_dev(const sk_read_batch* dev_reads, int64_t n_bases, const s
                         sk_pileup_columns* dev_out, void* dev_scratch, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Next row: GlobalAligner<int>::align, the haplotype-to-reference affine-gap aligner of the
+ * active-region code (L/alignment/GlobalAlignerImpl.hh:35-228; used at L/starling_common/ActiveRegionProcessor.cpp:591).
+ * Integer DP with match / delete / insert states, off-edge soft clipping, optional edge insertion and required edge
+ * deletion; results (score, begin position, CIGAR in '='/'X' form) are identical to the reference's, including the
+ * max3 tie order (L/alignment/AlignerBase.hh:75-95) and the order in which traceback start points are considered.
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+typedef struct sk_align_scores { /* AlignmentScores<int>, L/alignment/AlignmentScores.hh:27-58 */
+    int32_t match, mismatch, open, extend, off_edge, insert_delete;
+    int32_t is_allow_edge_insertion, is_require_edge_deletion;
+} sk_align_scores;
+/** the active-region detector's scores (L/starling_common/ActiveRegionDetector.hh:59-63, .cpp:41) */
+void sk_align_scores_default(sk_align_scores* s);
+
+typedef struct sk_global_align_batch {
+    int32_t n;               /* problems */
+    const int64_t* query_off;/* [n+1] */
+    const char* query;       /* symbols compared with ==; 'N' never matches in the '='/'X' expansion */
+    const int64_t* ref_off;  /* [n+1] */
+    const char* ref;
+} sk_global_align_batch;
+
+/** out_score[n], out_begin_pos[n]; problem p's path goes to out_path[path_off[p] .. path_off[p] + out_n_seg[p]) with
+ *  path_off[p] = query_off[p] + ref_off[p] + 4*p (capacity query+ref+4 segments: always enough).
+ *  Query and reference lengths must be in 1..1024 (the reference asserts non-empty). */
+int sk_global_align(const sk_global_align_batch* host_batch, const sk_align_scores* scores, int32_t* out_score,
+                    int32_t* out_begin_pos, sk_path_seg* out_path, int32_t* out_n_seg);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (germline SNV): dependent error probabilities + diploid genotype likelihoods
  * ---------------------------------------------------------------------------------------------------------------- */
 

@@ -525,3 +525,49 @@ def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=()):
         return finals, cols
     finally:
         L.refpp_destroy(s)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GlobalAligner<int>
+
+class AlignScores(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("match", "mismatch", "open", "extend", "offEdge", "insertDelete",
+                                         "isAllowEdgeInsertion", "isRequireEdgeDeletion")]
+
+
+def align_scores(match=1, mismatch=-4, open=-5, extend=-1, off_edge=-100, insert_delete=-5, allow_edge_insertion=1,
+                 require_edge_deletion=1):
+    """defaults: the active-region detector's aligner (L/starling_common/ActiveRegionDetector.hh:59-63, .cpp:41)"""
+    return AlignScores(match, mismatch, open, extend, off_edge, insert_delete, allow_edge_insertion, require_edge_deletion)
+
+
+_CIGAR = "?MIDNSHP=X"
+
+
+def global_align(query, ref_seq, sc):
+    """oracle restatement -> (score, begin_pos, cigar)"""
+    L = oracle()
+    L.sko_global_align.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(AlignScores), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32), C.POINTER(PathSeg), C.c_int]
+    q, r = query.encode(), ref_seq.encode()
+    cap = len(q) + len(r) + 4
+    path = (PathSeg * cap)()
+    score, beg = C.c_int32(), C.c_int32()
+    n = L.sko_global_align(q, len(q), r, len(r), C.byref(sc), C.byref(score), C.byref(beg), path, cap)
+    if n < 0:
+        raise RuntimeError("sko_global_align failed")
+    return score.value, beg.value, "".join("%d%s" % (path[i].length, _CIGAR[path[i].type]) for i in range(n))
+
+
+def ref_global_align(query, ref_seq, sc):
+    """the REFERENCE's GlobalAligner<int>::align -> (score, begin_pos, cigar)"""
+    L = ref()
+    L.ref_global_align.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int] + [C.c_int] * 8 + [C.POINTER(C.c_int)] * 2 + [C.c_char_p, C.c_int]
+    q, r = query.encode(), ref_seq.encode()
+    score, beg = C.c_int(), C.c_int()
+    buf = C.create_string_buffer(4 * (len(q) + len(r)) + 64)
+    rc = L.ref_global_align(q, len(q), r, len(r), sc.match, sc.mismatch, sc.open, sc.extend, sc.offEdge, sc.insertDelete,
+                            sc.isAllowEdgeInsertion, sc.isRequireEdgeDeletion, C.byref(score), C.byref(beg), buf, len(buf))
+    if rc:
+        raise RuntimeError("reference GlobalAligner threw")
+    return score.value, beg.value, buf.value.decode()

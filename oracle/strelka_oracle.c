@@ -1461,3 +1461,178 @@ int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* o, i
     free(is_mm);
     return result;
 }
+
+/* ------------------------------------------------------------------------------------- GlobalAligner<int> (next row, rank 2)
+ * Restatement of GlobalAligner<ScoreType>::align (L/alignment/GlobalAlignerImpl.hh:35-228): affine-gap global alignment
+ * of a query to a reference with match/delete/insert states, off-edge soft clipping, optional edge insertion / required
+ * edge deletion; max3 tie order (L/alignment/AlignerBase.hh:75-95); start-point selection (updateBacktrace,
+ * L/alignment/Alignment.hh); traceback and '='/'X' expansion (SingleRefAlignerSharedImpl.hh:96-195,
+ * L/blt_util/align_path_impl.hh:36-86). */
+
+static unsigned char ga_max3(int* mx, int v0, int v1, int v2)
+{
+    unsigned char ptr = 0;
+    *mx = v0;
+    if (v1 > v0) { *mx = v1; ptr = 1; }
+    if (v2 > *mx) { *mx = v2; ptr = 2; }
+    return ptr;
+}
+
+typedef struct ga_bt {
+    int max, state, queryBegin, refBegin, isInit;
+} ga_bt;
+static void ga_update(int thisMax, int refIndex, int queryIndex, ga_bt* bt, int state)
+{
+    if (!bt->isInit || thisMax > bt->max) {
+        bt->max = thisMax;
+        bt->refBegin = refIndex;
+        bt->queryBegin = queryIndex;
+        bt->isInit = 1;
+        bt->state = state;
+    }
+}
+
+int sko_global_align(const char* query, int querySize, const char* ref, int refSize, const sko_align_scores* sc,
+                     int32_t* out_score, int32_t* out_begin_pos, sko_path_seg* out_path, int path_cap)
+{
+    if (querySize <= 0 || refSize <= 0) return -1;
+    enum { ST_MATCH = 0, ST_DELETE = 1, ST_INSERT = 2 };
+    const int badVal = -10000;
+    const size_t W = (size_t)refSize + 1;
+    int* s1 = (int*)malloc(sizeof(int) * 3 * ((size_t)querySize + 1));
+    int* s2 = (int*)malloc(sizeof(int) * 3 * ((size_t)querySize + 1));
+    unsigned char* ptr = (unsigned char*)malloc(3 * ((size_t)querySize + 1) * W); /* [q][r][state] */
+    if (!s1 || !s2 || !ptr) { free(s1); free(s2); free(ptr); return -1; }
+#define PTR(q, r, s) ptr[(((size_t)(q)) * W + (size_t)(r)) * 3 + (s)]
+    int* thisSV = s1;
+    int* prevSV = s2;
+    for (int q = 0; q <= querySize; ++q) {
+        PTR(q, 0, ST_MATCH) = ST_MATCH;
+        thisSV[3 * q + ST_MATCH] = q * sc->offEdge;
+        PTR(q, 0, ST_DELETE) = ST_MATCH;
+        thisSV[3 * q + ST_DELETE] = badVal;
+        if (!sc->isAllowEdgeInsertion) {
+            PTR(q, 0, ST_INSERT) = ST_MATCH;
+            thisSV[3 * q + ST_INSERT] = badVal;
+        } else {
+            PTR(q, 0, ST_INSERT) = ST_INSERT;
+            thisSV[3 * q + ST_INSERT] = sc->open + (q * sc->extend);
+        }
+    }
+    ga_bt bt = { 0, ST_MATCH, 0, 0, 0 };
+    for (int r = 0; r < refSize; ++r) {
+        int* t = thisSV; thisSV = prevSV; prevSV = t;
+        if (!sc->isRequireEdgeDeletion) {
+            PTR(0, r + 1, ST_MATCH) = ST_MATCH;
+            thisSV[ST_MATCH] = 0;
+            PTR(0, r + 1, ST_DELETE) = ST_MATCH;
+            thisSV[ST_DELETE] = badVal;
+        } else {
+            PTR(0, r + 1, ST_MATCH) = ST_MATCH;
+            thisSV[ST_MATCH] = badVal;
+            PTR(0, r + 1, ST_DELETE) = ST_DELETE;
+            thisSV[ST_DELETE] = sc->open + ((r + 1) * sc->extend);
+        }
+        PTR(0, r + 1, ST_INSERT) = ST_MATCH;
+        thisSV[ST_INSERT] = badVal;
+        for (int q = 0; q < querySize; ++q) {
+            int* head = thisSV + 3 * (q + 1);
+            {
+                const int* sv = prevSV + 3 * q;
+                PTR(q + 1, r + 1, ST_MATCH) = ga_max3(&head[ST_MATCH], sv[ST_MATCH], sv[ST_DELETE], sv[ST_INSERT]);
+                head[ST_MATCH] += (query[q] == ref[r]) ? sc->match : sc->mismatch;
+            }
+            {
+                const int* sv = prevSV + 3 * (q + 1);
+                PTR(q + 1, r + 1, ST_DELETE) = ga_max3(&head[ST_DELETE], sv[ST_MATCH] + sc->open, sv[ST_DELETE], sv[ST_INSERT] + sc->insertDelete);
+                head[ST_DELETE] += sc->extend;
+                if (r == 0) head[ST_DELETE] = badVal;
+            }
+            {
+                const int* sv = thisSV + 3 * q;
+                PTR(q + 1, r + 1, ST_INSERT) = ga_max3(&head[ST_INSERT], sv[ST_MATCH] + sc->open, badVal, sv[ST_INSERT]);
+                head[ST_INSERT] += sc->extend;
+                if (q == 0) head[ST_INSERT] = badVal;
+            }
+        }
+        if (!sc->isRequireEdgeDeletion) ga_update(thisSV[3 * querySize + ST_MATCH], r + 1, querySize, &bt, ST_MATCH);
+    }
+    if (sc->isRequireEdgeDeletion) {
+        ga_update(thisSV[3 * querySize + ST_MATCH], refSize, querySize, &bt, ST_MATCH);
+        ga_update(thisSV[3 * querySize + ST_DELETE], refSize, querySize, &bt, ST_DELETE);
+    }
+    if (sc->isAllowEdgeInsertion) ga_update(thisSV[3 * querySize + ST_INSERT], refSize, querySize, &bt, ST_INSERT);
+    for (int q = 0; q < querySize; ++q)
+        ga_update(thisSV[3 * q + ST_MATCH] + (querySize - q) * sc->offEdge, refSize, q, &bt, ST_MATCH);
+
+    /* backTraceAlignment: segments are collected in reverse */
+    *out_score = bt.max;
+    int nseg = 0, bad = 0;
+    sko_path_seg* rev = (sko_path_seg*)malloc(sizeof(sko_path_seg) * ((size_t)querySize + (size_t)refSize + 4));
+    uint32_t ps_type = 0 /* NONE */, ps_len = 0;
+    if (bt.queryBegin < querySize) { ps_type = 5; /* SOFT_CLIP */ ps_len = (uint32_t)(querySize - bt.queryBegin); }
+#define GA_UPDATE_PATH(atype)                                                       \
+    do {                                                                            \
+        if (ps_type != (atype)) {                                                   \
+            if (ps_type != 0) { rev[nseg].type = ps_type; rev[nseg].length = ps_len; ++nseg; } \
+            ps_type = (atype);                                                      \
+            ps_len = 0;                                                             \
+        }                                                                           \
+    } while (0)
+    for (;;) {
+        const int next = PTR(bt.queryBegin, bt.refBegin, bt.state);
+        if (bt.state == ST_MATCH) {
+            if (bt.queryBegin < 1 || bt.refBegin < 1) break;
+            GA_UPDATE_PATH(1u);
+            bt.queryBegin--;
+            bt.refBegin--;
+        } else if (bt.state == ST_DELETE) {
+            if (bt.refBegin < 1) break;
+            GA_UPDATE_PATH(3u);
+            bt.refBegin--;
+        } else {
+            if (bt.queryBegin < 1) break;
+            GA_UPDATE_PATH(2u);
+            bt.queryBegin--;
+        }
+        bt.state = next;
+        ps_len++;
+    }
+    if (ps_type != 0) { rev[nseg].type = ps_type; rev[nseg].length = ps_len; ++nseg; }
+    if (bt.queryBegin != 0) { rev[nseg].type = 5; rev[nseg].length = (uint32_t)bt.queryBegin; ++nseg; }
+    *out_begin_pos = bt.refBegin;
+    /* reverse + apath_add_seqmatch */
+    int n_out = 0;
+    int qi = 0, ri = bt.refBegin;
+    for (int k = nseg - 1; k >= 0 && !bad; --k) {
+        const uint32_t t = rev[k].type, len = rev[k].length;
+        if (t == 1) {
+            for (uint32_t j = 0; j < len; ++j) {
+                int same = (query[qi] == ref[ri]);
+                if (query[qi] == 'N' || ref[ri] == 'N') same = 0;
+                const uint32_t st = same ? 8u : 9u; /* SEQ_MATCH / SEQ_MISMATCH */
+                if (n_out > 0 && out_path[n_out - 1].type == st) out_path[n_out - 1].length++;
+                else {
+                    if (n_out >= path_cap) { bad = 1; break; }
+                    out_path[n_out].type = st;
+                    out_path[n_out].length = 1;
+                    ++n_out;
+                }
+                ++qi;
+                ++ri;
+            }
+        } else {
+            if (n_out >= path_cap) { bad = 1; break; }
+            out_path[n_out].type = t;
+            out_path[n_out].length = len;
+            ++n_out;
+            if (t == 2 || t == 5) qi += (int)len;
+            if (t == 3) ri += (int)len;
+        }
+    }
+    free(rev);
+    free(s1);
+    free(s2);
+    free(ptr);
+    return bad ? -1 : n_out;
+}

@@ -211,6 +211,14 @@ typedef struct sko_read_batch {
 int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* opt, int mode, int64_t* call_off,
                          uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count);
 
+/* ---- GlobalAligner<int>::align (L/alignment/GlobalAlignerImpl.hh:35-228) ---- */
+typedef struct sko_align_scores { /* AlignmentScores<int>, L/alignment/AlignmentScores.hh */
+    int32_t match, mismatch, open, extend, offEdge, insertDelete, isAllowEdgeInsertion, isRequireEdgeDeletion;
+} sko_align_scores;
+/* returns the number of path segments written (SEQ_MATCH/SEQ_MISMATCH form) or -1 */
+int sko_global_align(const char* query, int query_size, const char* ref, int ref_size, const sko_align_scores* scores,
+                     int32_t* out_score, int32_t* out_begin_pos, sko_path_seg* out_path, int path_cap);
+
 #ifdef __cplusplus
 }
 #endif

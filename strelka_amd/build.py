@@ -21,6 +21,7 @@ HIP_SOURCES = [
     "csrc/somatic_site.hip",
     "csrc/indel_lhood.hip",
     "csrc/pileup.hip",
+    "csrc/global_align.hip",
 ]
 HOST_SOURCES = [
     "host/align_flatten.cpp",

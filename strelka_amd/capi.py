@@ -88,6 +88,15 @@ class ReadResult(C.Structure):
                 ("warn_max_toggle_depth", C.c_int32)]
 
 
+class AlignScores(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("match", "mismatch", "open", "extend", "off_edge", "insert_delete",
+                                         "is_allow_edge_insertion", "is_require_edge_deletion")]
+
+
+class GlobalAlignBatch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("query_off", c_void_p), ("query", c_void_p), ("ref_off", c_void_p), ("ref", c_void_p)]
+
+
 class PileupOptions(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("min_basecall_qscore", "mismatch_density_flank_size", "mismatch_density_max_count",
                                          "use_tier2_evidence", "tier2_mismatch_density_max_count", "is_mapq_adjust",
@@ -172,6 +181,7 @@ EXPORTS = [
     "sk_score_alignments", "sk_score_alignments_dev",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_add_read",
     "sk_align_builder_finish", "sk_align_builder_error",
+    "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_get_batch",
@@ -210,6 +220,8 @@ def lib():
         L.sk_align_builder_add_read.argtypes = [c_void_p, c_void_p, c_void_p, C.c_int32, C.c_char_p, C.c_int32,
                                                 C.c_int32, C.POINTER(CandidateAlignment), C.c_int32]
         L.sk_align_builder_finish.argtypes = [c_void_p, C.POINTER(AlignBatch)]
+        L.sk_align_scores_default.argtypes = [C.POINTER(AlignScores)]
+        L.sk_global_align.argtypes = [C.POINTER(GlobalAlignBatch), C.POINTER(AlignScores), c_void_p, c_void_p, c_void_p, c_void_p]
         L.sk_pileup_options_default.argtypes = [C.POINTER(PileupOptions)]
         L.sk_pileup_reads.argtypes = [C.POINTER(ReadBatchStruct), C.POINTER(PileupOptions), C.c_int, C.POINTER(PileupColumns)]
         L.sk_pileup_scratch_bytes.restype = C.c_int64
@@ -727,3 +739,39 @@ def pileup_reads(rb, opt, mode):
     out = PileupColumns(n_loci, cap, _p(call_off), _p(calls), _p(sd), _p(sm))
     _check(lib().sk_pileup_reads(C.byref(s), C.byref(opt), mode, C.byref(out)))
     return call_off, calls[:call_off[-1]].copy(), sd[:n_loci], sm[:n_loci]
+
+
+# ---------------------------------------------------------------------------------------------------- GlobalAligner
+
+def align_scores(**kw):
+    s = AlignScores()
+    lib().sk_align_scores_default(C.byref(s))
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise AttributeError(k)
+        setattr(s, k, v)
+    return s
+
+
+def global_align(pairs, scores=None):
+    """pairs: [(query, ref)] strings -> [(score, begin_pos, cigar)]"""
+    scores = scores or align_scores()
+    n = len(pairs)
+    qo = np.zeros(n + 1, np.int64)
+    ro = np.zeros(n + 1, np.int64)
+    for i, (q, r) in enumerate(pairs):
+        qo[i + 1] = qo[i] + len(q)
+        ro[i + 1] = ro[i] + len(r)
+    qb = np.frombuffer("".join(q for q, _ in pairs).encode(), np.uint8).copy() if n else np.zeros(1, np.uint8)
+    rb = np.frombuffer("".join(r for _, r in pairs).encode(), np.uint8).copy() if n else np.zeros(1, np.uint8)
+    b = GlobalAlignBatch(n, _p(qo), _p(qb), _p(ro), _p(rb))
+    score = np.zeros(max(n, 1), np.int32)
+    beg = np.zeros(max(n, 1), np.int32)
+    nseg = np.zeros(max(n, 1), np.int32)
+    path = np.zeros((int(qo[-1] + ro[-1]) + 4 * n + 1, 2), np.uint32)
+    _check(lib().sk_global_align(C.byref(b), C.byref(scores), _p(score), _p(beg), _p(path), _p(nseg)))
+    out = []
+    for i in range(n):
+        po = int(qo[i] + ro[i]) + 4 * i
+        out.append((int(score[i]), int(beg[i]), "".join("%d%s" % (path[po + k, 1], CIGAR_CHARS[path[po + k, 0]]) for k in range(nseg[i]))))
+    return out
