@@ -43,6 +43,7 @@ constexpr int WAVE = 64;
 constexpr int P1_WAVES = 4;
 constexpr int MAX_READ_LEN = 1024;  // LDS: 4 B delta + 1 B flag per read base
 constexpr unsigned REC_TIER2 = 1u << 14, REC_EMIT = 1u << 15;
+constexpr int COL_STAGE = 3072;     // calls of one wave's 64 columns staged in LDS (6 KiB); deeper spans store directly
 
 struct PileupArgs
 {
@@ -326,35 +327,92 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel(const PileupArgs a)
     unsigned cnt = 0;
     const int64_t base = (a.store && l < a.n_loci) ? a.call_off[l] : 0;
     const int parts = (a.mode == SK_PILEUP_CLEAN_TIER2) ? 2 : 1;
+    const bool live = (l < a.n_loci);
+    // store pass: the wave's 64 columns are one contiguous span of `calls`; it is assembled in LDS and written out with
+    // consecutive stores (a lane storing 2 bytes every ~80 bytes costs a 32-byte memory transaction per call)
+    __shared__ uint16_t s_col[COL_STAGE];
+    int64_t span0 = 0;
+    int span_n = 0;
+    bool staged = false;
+    if (a.store) {
+        span0 = a.call_off[min(l0, a.n_loci)];
+        const int64_t tot = a.call_off[min(l0 + WAVE, a.n_loci)] - span0;
+        staged = (tot <= COL_STAGE);
+        span_n = staged ? int(tot) : 0;
+    }
+    const unsigned lbase = unsigned(base - span0);
+    // a read's contribution to this lane's locus, given the read's geometry in wave-uniform values
+    auto take = [&](const int64_t ro, const int read_head, const int ref_head, const int len, const int part) {
+        if (live && p >= ref_head && p < ref_head + len) {
+            const unsigned rec = a.rec[ro + read_head + (p - ref_head)];
+            if (rec_selected(rec, a.mode, part)) {
+                if (a.store) {
+                    if (staged) s_col[lbase + cnt] = uint16_t(rec & 0x3fffu);
+                    else a.calls[base + cnt] = uint16_t(rec & 0x3fffu);
+                }
+                ++cnt;
+            }
+        }
+    };
     for (int part = 0; part < parts; ++part) {
-        for (int r = lo; r < hi; ++r) {
-            const int2 sp = a.span[r];
-            if (sp.y <= p0 || sp.x >= p0 + WAVE) continue;
-            const int64_t ro = a.b.read_off[r];
-            const int64_t so = a.b.path_off[r];
-            const int nseg = int(a.b.path_off[r + 1] - so);
-            int read_head = 0, ref_head = sp.x;
-            for (int i = 0; i < nseg; ++i) {
-                const uint32_t t = a.b.path[so + i].type;
-                const int len = int(a.b.path[so + i].length);
-                if (seg_match(t)) {
-                    if (ref_head < p0 + WAVE && ref_head + len > p0) {
-                        if (p >= ref_head && p < ref_head + len && l < a.n_loci) {
-                            const unsigned rec = a.rec[ro + read_head + (p - ref_head)];
-                            if (rec_selected(rec, a.mode, part)) {
-                                if (a.store) a.calls[base + cnt] = uint16_t(rec & 0x3fffu);
-                                ++cnt;
-                            }
+        for (int rb = lo; rb < hi; rb += WAVE) {
+            // the lanes fetch the geometry of 64 reads at once (one memory round trip instead of one per read); the
+            // loop below then reads it back lane by lane into scalar registers
+            const int rk = rb + lane;
+            const bool have = (rk < hi);
+            const int2 sp = have ? a.span[rk] : make_int2(INT_MAX, INT_MIN);
+            const int64_t ro_k = have ? a.b.read_off[rk] : 0;
+            const int64_t so_k = have ? a.b.path_off[rk] : 0;
+            const int nseg_k = have ? int(a.b.path_off[rk + 1] - so_k) : 0;
+            sk_path_seg g0 = { 0u, 0u }, g1 = { 0u, 0u }, g2 = { 0u, 0u };
+            if (nseg_k >= 1) g0 = a.b.path[so_k];
+            if (nseg_k >= 2) g1 = a.b.path[so_k + 1];
+            if (nseg_k >= 3) g2 = a.b.path[so_k + 2];
+            const int nk = min(WAVE, hi - rb);
+            for (int k = 0; k < nk; ++k) {
+                const int sx = __builtin_amdgcn_readlane(sp.x, k), sy = __builtin_amdgcn_readlane(sp.y, k);
+                if (sy <= p0 || sx >= p0 + WAVE) continue;
+                const int64_t ro = (int64_t(__builtin_amdgcn_readlane(int(ro_k >> 32), k)) << 32) |
+                                   uint32_t(__builtin_amdgcn_readlane(int(ro_k & 0xffffffff), k));
+                const int nseg = __builtin_amdgcn_readlane(nseg_k, k);
+                int read_head = 0, ref_head = sx;
+                if (nseg <= 3) {
+                    const uint32_t t0 = __builtin_amdgcn_readlane(int(g0.type), k), n0 = __builtin_amdgcn_readlane(int(g0.length), k);
+                    const uint32_t t1 = __builtin_amdgcn_readlane(int(g1.type), k), n1 = __builtin_amdgcn_readlane(int(g1.length), k);
+                    const uint32_t t2 = __builtin_amdgcn_readlane(int(g2.type), k), n2 = __builtin_amdgcn_readlane(int(g2.length), k);
+                    const uint32_t ts[3] = { t0, t1, t2 }, ns[3] = { n0, n1, n2 };
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        if (i < nseg) {
+                            const int len = int(ns[i]);
+                            if (seg_match(ts[i]) && ref_head < p0 + WAVE && ref_head + len > p0) take(ro, read_head, ref_head, len, part);
+                            if (seg_read_len(ts[i])) read_head += len;
+                            if (seg_ref_len(ts[i])) ref_head += len;
                         }
                     }
+                } else {
+                    const int64_t so = (int64_t(__builtin_amdgcn_readlane(int(so_k >> 32), k)) << 32) |
+                                       uint32_t(__builtin_amdgcn_readlane(int(so_k & 0xffffffff), k));
+                    for (int i = 0; i < nseg; ++i) {
+                        const uint32_t t = a.b.path[so + i].type;
+                        const int len = int(a.b.path[so + i].length);
+                        if (seg_match(t) && ref_head < p0 + WAVE && ref_head + len > p0) take(ro, read_head, ref_head, len, part);
+                        if (seg_read_len(t)) read_head += len;
+                        if (seg_ref_len(t)) ref_head += len;
+                        if (ref_head >= p0 + WAVE) break;
+                    }
                 }
-                if (seg_read_len(t)) read_head += len;
-                if (seg_ref_len(t)) ref_head += len;
-                if (ref_head >= p0 + WAVE) break;
             }
         }
     }
     if (!a.store && l <= a.n_loci) a.count[l] = (l < a.n_loci) ? cnt : 0u;
+    if (a.store && staged) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint16_t* __restrict__ dst = a.calls + span0;
+        for (int i = lane; i < span_n; i += WAVE) dst[i] = s_col[i];
+    }
 }
 
 __global__ void span_split_kernel(const int2* span, int* begin, int* end, const int n)
