@@ -5,17 +5,18 @@
 // contraction, no reassociation.
 //
 // Kernel A1 `score_wave_per_read` (the fast path)
-//   * one 64-lane wavefront per read, one LANE per candidate alignment of that read (64 per pass);
-//   * the read is staged once per wave into LDS as a per-position table {M_i, X_i, 0.0} of doubles
-//     (M_i = ln(1-e_q), X_i = ln(e_q)-ln3; both 0.0 for an 'N' read base = the reference's `continue`, X_i = M_i for a
-//     '=' read base = "always matches"), plus the read codes and the read's haplotype source pool (reference window +
-//     insert sequences) as bytes;
-//   * all lanes sweep the read positions i = 0..L-1 together: the read code of position i is wave-uniform (LDS
-//     broadcast), each lane fetches ITS haplotype byte hap[delta+i], selects the LDS address of M_i / X_i / 0.0 with one
-//     v_cndmask, and performs one dependent v_add_f64.  CIGAR/indel structure costs nothing per cell: a lane only
-//     leaves the uniform sweep at an op boundary (soft-clip term, non-candidate-indel penalty, next op's delta).
-//   Adding the table's 0.0 entry is exact (x + 0.0 == x for every x the sum can hold), so clip/idle lanes stay in
-//   lock-step without changing any bit of the result.
+//   * one 64-lane wavefront per read, one LANE per candidate alignment of that read (64 per pass), 4 waves per block;
+//   * the read is expanded once per wave into LDS as a per-position ROW of 6 doubles {term vs hap A, C, G, T, other,
+//     0.0}: M = ln(1-e_q) in the column of the read base, X = ln(e_q)-ln3 elsewhere; all 0.0 for an 'N' read base (the
+//     reference's `continue`), all M for '=' ("always matches").  The read's haplotype source pool (reference window +
+//     insert sequences) is stored as row-column byte offsets;
+//   * all lanes sweep the read positions i = 0..L-1 together: per cell one ds_read_u8 (the lane's haplotype column,
+//     prefetched one position ahead), one ds_read_b64 of row[i][column] -- the row address is wave-uniform, so the 64
+//     reads of a row are LDS broadcasts -- and one dependent v_add_f64 one position behind.  A lane leaves the lock-step
+//     sweep only at its own op boundaries (soft-clip term, non-candidate-indel penalty, next op's hap offset); its ops
+//     are prefetched from global memory one transition ahead;
+//   * soft-clipped and finished lanes read the 0.0 column: x + 0.0 == x for every x the sum can hold, so they stay in
+//     lock-step without changing a bit of the result.
 //
 // Kernel A2 `score_thread_per_cal` (generic fallback: reads/pools too long for LDS, or unknown bounds)
 //   one thread per candidate alignment, straight from global memory.

@@ -287,17 +287,11 @@ int sk_somatic_snv_call_batch(const sk_pileup_batch* hn, const sk_pileup_batch* 
     if (std::memcmp(hn->ref_base, ht->ref_base, n) != 0) return sk_fail("sk_somatic_snv_call_batch: ref_base differs");
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
-    // two uploads share one arena: reserve for both up front
-    const int64_t tn = hn->call_off[n], tt = hn == ht ? 0 : ht->call_off[n];
-    const size_t per = [&](int64_t tc) {
-        return sk_align256(sizeof(int64_t) * (n + 1)) + sk_align256(2 * tc) + sk_align256(n) * 2 + 8 * 256;
-    }(0);
-    (void)per;
+    // the two uploads and the output share one arena
     SkArena ar;
     const size_t need = 2 * (sk_align256(sizeof(int64_t) * (n + 1)) + sk_align256(n) * 2 + 16 * 256) +
-                        sk_align256(2 * tn) + sk_align256(2 * ht->call_off[n]) +
+                        sk_align256(2 * hn->call_off[n]) + sk_align256(2 * ht->call_off[n]) +
                         sk_align256(sizeof(sk_somatic_snv_call) * n) + 4096;
-    (void)tt;
     if (ar.reserve(need)) return 1;
     auto up = [&](const sk_pileup_batch* hb, sk_pileup_batch& d) -> int {
         if (hb->call_off[0] != 0) return sk_fail("pileup batch: call_off must start at 0");
