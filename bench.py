@@ -76,11 +76,27 @@ def cpu_baseline(args):
     de = pyoracle.adjust_joint_eprob(pb)
     pyoracle.site_digt_call(pb, de)
     tb = time.perf_counter() - t0
-    return {"value": cells / ta, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "%d reads x 64 candidate alignments x 150 bp, %d passes through sko_score_cases (%.1f s); loci: %d loci "
-                      "depth~Poisson(40) through sko_adjust_joint_eprob+sko_position_snp_call_pprob_digt (%.1f s)"
-                      % (len(cases), reps, ta, args.cpu_loci, tb),
-            "loci_per_s": args.cpu_loci / tb}
+    out = {"value": cells / ta, "unit": "cells/s", "cores": 1, "kind": "port",
+           "sample": "%d reads x 64 candidate alignments x 150 bp, %d passes through sko_score_cases (%.1f s); loci: %d loci "
+                     "depth~Poisson(40) through sko_adjust_joint_eprob+sko_position_snp_call_pprob_digt (%.1f s)"
+                     % (len(cases), reps, ta, args.cpu_loci, tb),
+           "loci_per_s": args.cpu_loci / tb}
+    # where the reference's own translation units travelled with the repo (oracle/_ref, built from /root/reference by
+    # oracle/Makefile), time the REFERENCE's adjust_joint_eprob + position_snp_call_pprob_digt on part of the same loci
+    try:
+        if pyoracle.ref_available():
+            R = pyoracle.ref()
+            R.ref_time_germline_sites.restype = C.c_double
+            R.ref_time_germline_sites.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_double, C.POINTER(C.c_double)]
+            n = min(pb.n_loci, 300000)
+            chk = C.c_double()
+            secs = R.ref_time_germline_sites(pb.call_off.ctypes.data, pb.calls.ctypes.data, pb.ref_base.ctypes.data, n, 0.001,
+                                             C.byref(chk))
+            out["loci_per_s_reference"] = n / secs
+            out["sample"] += "; reference TUs (oracle/_ref) on %d of those loci: %.1f s" % (n, secs)
+    except Exception as e:  # the reference build is optional test infrastructure
+        out["loci_reference_error"] = str(e)
+    return out
 
 
 def pmc_traffic(args):

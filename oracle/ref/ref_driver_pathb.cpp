@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -149,6 +150,34 @@ void ref_position_snp_call_pprob_digt(const uint16_t* calls, const float* de, in
     out->strand_bias = dgt.strand_bias;
     out->ref_gt = dgt.ref_gt;
     out->is_called = 1;
+}
+
+/// The reference's own per-locus germline chain over a CSR pileup, as starling_pos_processor.cpp:146-266 runs it:
+/// adjust_joint_eprob (PileupCleaner::CleanPileupErrorProb) then position_snp_call_pprob_digt, one locus after the
+/// other.  Returns the seconds spent in those two calls (inputs are materialised in the reference's own structs outside
+/// the timed region); `checksum` defeats dead-code elimination.  Used only as the "reference" CPU baseline of bench.py.
+double ref_time_germline_sites(const int64_t* call_off, const uint16_t* calls, const uint8_t* ref_base, int n_loci, double theta,
+                               double* checksum)
+{
+    pprob_digt_caller caller(theta);
+    driver_blt_options opt;
+    opt.bsnp_diploid_theta = theta;
+    dependent_prob_cache dpc;
+    double secs = 0, acc = 0;
+    std::vector<float> dep;
+    for (int l = 0; l < n_loci; ++l) {
+        snp_pos_info pi;
+        fill_pileup(pi, calls + call_off[l], int(call_off[l + 1] - call_off[l]), ref_base[l] < 4 ? ref_base[l] : 0);
+        diploid_genotype dgt;
+        const auto t0 = std::chrono::steady_clock::now();
+        adjust_joint_eprob(opt, dpc, pi, dep);
+        const extended_pos_info epi(pi, dep);
+        caller.position_snp_call_pprob_digt(opt, epi, dgt, true);
+        secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        acc += dgt.genome.snp_qphred + dgt.phredLoghood[1];
+    }
+    *checksum = acc;
+    return secs;
 }
 
 void ref_germline_lnpriors(double theta, float* out /* [2][5][2][10] */)
