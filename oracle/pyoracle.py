@@ -463,11 +463,13 @@ def mapped_qscore_table():
     return np.array([[L.sko_mapped_qscore(q, m) for q in range(71)] for m in range(91)], np.int32)
 
 
-def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=()):
+def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=(), return_indels=False):
     """The REFERENCE's position processor end to end (oracle/ref/ref_driver_pileup.cpp): reads (dicts as produced by
     synth.pileup_reads, position-sorted) -> read buffer -> realignment -> pileup.
     Returns (finals, columns): finals = per piled read, in pileup order, dict(read_id = index into `reads`, is_realigned,
-    pos, is_fwd, cigar, skipped); columns = {pos: dict(calls, tier2_calls, spandel, submapped)}."""
+    pos, is_fwd, cigar, skipped, input_pos, input_cigar, realign_range); columns = {pos: dict(calls, tier2_calls, spandel,
+    submapped)}.  With return_indels=True a third value lists the IndelBuffer as the realigner saw it:
+    dict(pos, type, del_len, ins_seq, is_candidate, r2i, i2r (log error rates), read_ids = indices into `reads`)."""
     L = ref()
     L.refpp_create.restype = vp
     L.refpp_create.argtypes = [C.c_char_p] + [C.c_int] * 10
@@ -480,6 +482,11 @@ def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=()):
     L.refpp_column_calls.argtypes = [vp, C.c_int, vp, vp]
     L.refpp_n_finals.argtypes = [vp]
     L.refpp_final.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)] + [C.POINTER(C.c_int32)] * 4 + [C.c_char_p, C.c_int]
+    L.refpp_final_input.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int32)] * 3 + [C.c_char_p, C.c_int]
+    L.refpp_n_indels.argtypes = [vp]
+    L.refpp_indel.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_char_p, C.c_int,
+                              C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                              C.POINTER(C.c_double), vp, C.c_int]
     s = L.refpp_create(ref_seq.encode(), ref_offset, opt.report_begin, opt.report_end, opt.min_basecall_qscore,
                        opt.mismatch_density_flank_size, opt.mismatch_density_max_count, opt.use_tier2_evidence,
                        opt.tier2_mismatch_density_max_count, opt.is_mapq_adjust, opt.min_distance_from_read_edge)
@@ -510,8 +517,12 @@ def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=()):
             rid, a, b, c, d = C.c_uint32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
             buf = C.create_string_buffer(1024)
             L.refpp_final(s, i, rid, a, b, c, d, buf, 1024)
+            ip, rb_, re_ = C.c_int32(), C.c_int32(), C.c_int32()
+            buf2 = C.create_string_buffer(1024)
+            L.refpp_final_input(s, i, ip, rb_, re_, buf2, 1024)
             finals.append(dict(read_id=id_of[rid.value], is_realigned=bool(a.value), pos=b.value, is_fwd=bool(c.value),
-                               skipped=bool(d.value), cigar=buf.value.decode()))
+                               skipped=bool(d.value), cigar=buf.value.decode(), input_pos=ip.value,
+                               input_cigar=buf2.value.decode(), realign_range=(rb_.value, re_.value)))
         cols = {}
         for i in range(L.refpp_n_columns(s)):
             pos, n, n2 = C.c_int32(), C.c_int32(), C.c_int32()
@@ -522,7 +533,20 @@ def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=()):
             L.refpp_column_calls(s, i, _p(calls), _p(t2))
             cols[pos.value] = dict(calls=calls[:n.value].copy(), tier2_calls=t2[:n2.value].copy(), spandel=sd.value,
                                    submapped=sm.value)
-        return finals, cols
+        if not return_indels:
+            return finals, cols
+        indels = []
+        for i in range(L.refpp_n_indels(s)):
+            pos, ty, ic, nd, fo = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            dl = C.c_uint32()
+            a1, a2 = C.c_double(), C.c_double()
+            ins = C.create_string_buffer(256)
+            ids = np.zeros(4096, np.uint32)
+            n = L.refpp_indel(s, i, pos, ty, dl, ins, 256, ic, nd, fo, a1, a2, _p(ids), 4096)
+            indels.append(dict(pos=pos.value, type=ty.value, del_len=dl.value, ins_seq=ins.value.decode(),
+                               is_candidate=ic.value, ndfr=nd.value, forced=fo.value, r2i=a1.value, i2r=a2.value,
+                               read_ids=sorted(set(id_of[int(x)] for x in ids[:min(n, 4096)] if int(x) in id_of))))
+        return finals, cols, indels
     finally:
         L.refpp_destroy(s)
 

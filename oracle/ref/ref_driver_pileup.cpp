@@ -12,6 +12,7 @@
 #include "htsapi/align_path_bam_util.hh"
 #include "starling_common/normalizeAlignment.hh"
 #include "starling_common/starling_pos_processor_base.hh"
+#include "starling_common/starling_pos_processor_base_stages.hh"
 #include "starling_common/starling_streams_base.hh"
 #include "test/starling_base_options_test.hh"
 
@@ -40,6 +41,18 @@ struct FinalAlignment
     uint32_t read_id;
     int32_t is_realigned, pos, is_fwd, skipped;
     std::string cigar;
+    int32_t input_pos, realign_begin, realign_end; // what realignAndScoreRead was given for this read
+    std::string input_cigar;
+};
+
+struct DumpIndel
+{
+    int32_t pos, type;
+    uint32_t del_len;
+    std::string ins;
+    int32_t is_candidate, not_discovered_from_reads, is_forced_output;
+    double ref_to_indel_lnp, indel_to_ref_lnp;
+    std::vector<uint32_t> read_ids; // tier1/tier2/submapped/noise observations of sample 0 (is_usable_indel)
 };
 
 struct Streams : public starling_streams_base
@@ -88,12 +101,56 @@ struct PP : public starling_pos_processor_base
     // order pileup_pos_reads visited them
     void post_align_clear_pos(const pos_t pos) override
     {
+        // the realignment range align_pos(pos) used (get_realignment_range, starling_pos_processor_base.cpp:705-727);
+        // valid as long as the stage sizes did not change between the two stages (the test reads keep them fixed)
+        int32_t rb, re;
+        {
+            const stage_data& sd(_stagemanPtr->get_stage_data());
+            const unsigned head_offset(sd.get_stage_id_shift(STAGE::HEAD));
+            const unsigned buffer_offset(sd.get_stage_id_shift(STAGE::READ_BUFFER));
+            const unsigned post_offset(sd.get_stage_id_shift(STAGE::POST_ALIGN));
+            pos_t min_offset(static_cast<pos_t>(post_offset - buffer_offset));
+            pos_t max_offset(static_cast<pos_t>(buffer_offset - head_offset));
+            min_offset = std::max(0, min_offset - 1);
+            max_offset = std::max(0, max_offset - 1);
+            rb = std::max(static_cast<pos_t>(0), pos - min_offset);
+            re = pos + 1 + max_offset;
+        }
+        // the indels keyed at this position, as the realigner saw them
+        {
+            const auto range(getIndelBuffer().rangeIterator(pos, pos + 1));
+            for (auto it(range.first); it != range.second; ++it) {
+                const IndelKey& k(it->first);
+                if (k.pos != pos) continue;
+                const IndelData& d(it->second);
+                DumpIndel di;
+                di.pos = k.pos;
+                di.type = k.type;
+                di.del_len = k.deletionLength;
+                di.ins = k.insertSequence;
+                di.is_candidate = getIndelBuffer().isCandidateIndel(k, d) ? 1 : 0;
+                di.not_discovered_from_reads = d.status.notDiscoveredFromReads ? 1 : 0;
+                di.is_forced_output = d.isForcedOutput ? 1 : 0;
+                const IndelSampleData& sdat(d.getSampleData(0));
+                di.ref_to_indel_lnp = sdat.getErrorRates().refToIndelErrorProb.getLogValue();
+                di.indel_to_ref_lnp = sdat.getErrorRates().indelToRefErrorProb.getLogValue();
+                for (const auto id : sdat.tier1_map_read_ids) di.read_ids.push_back(id);
+                for (const auto id : sdat.tier2_map_read_ids) di.read_ids.push_back(id);
+                for (const auto id : sdat.submap_read_ids) di.read_ids.push_back(id);
+                for (const auto id : sdat.noise_read_ids) di.read_ids.push_back(id);
+                indels.push_back(di);
+            }
+        }
         read_segment_iter ri(sample(0).readBuffer.get_pos_read_segment_iter(pos));
         for (read_segment_iter::ret_val r; true; ri.next()) {
             r = ri.get_ptr();
             if (nullptr == r.first) break;
             const read_segment& rseg(r.first->get_segment(r.second));
             FinalAlignment fa;
+            fa.input_pos = rseg.getInputAlignment().pos;
+            fa.input_cigar = ALIGNPATH::apath_to_cigar(rseg.getInputAlignment().path);
+            fa.realign_begin = rb;
+            fa.realign_end = re;
             fa.read_id = rseg.getReadIndex();
             fa.is_realigned = rseg.is_realigned ? 1 : 0;
             const alignment& al(rseg.is_realigned ? rseg.realignment : rseg.getInputAlignment());
@@ -108,6 +165,7 @@ struct PP : public starling_pos_processor_base
 
     std::vector<Column> columns;
     std::vector<FinalAlignment> finals;
+    std::vector<DumpIndel> indels;
 };
 
 struct Session
@@ -256,6 +314,40 @@ int refpp_final(void* p, int i, uint32_t* read_id, int32_t* is_realigned, int32_
     std::strncpy(cigar, f.cigar.c_str(), cap - 1);
     cigar[cap - 1] = 0;
     return 0;
+}
+
+/// what realignAndScoreRead was given for final i: the (normalised) input alignment and the realignment range
+int refpp_final_input(void* p, int i, int32_t* input_pos, int32_t* realign_begin, int32_t* realign_end, char* cigar, int cap)
+{
+    const FinalAlignment& f(static_cast<Session*>(p)->pp->finals[i]);
+    *input_pos = f.input_pos;
+    *realign_begin = f.realign_begin;
+    *realign_end = f.realign_end;
+    std::strncpy(cigar, f.input_cigar.c_str(), cap - 1);
+    cigar[cap - 1] = 0;
+    return 0;
+}
+
+int refpp_n_indels(void* p) { return int(static_cast<Session*>(p)->pp->indels.size()); }
+
+/// indel i of the buffer as the realigner saw it; returns the number of observing read ids (copied up to id_cap)
+int refpp_indel(void* p, int i, int32_t* pos, int32_t* type, uint32_t* del_len, char* ins, int ins_cap, int32_t* is_candidate,
+                int32_t* not_discovered_from_reads, int32_t* is_forced_output, double* ref_to_indel_lnp, double* indel_to_ref_lnp, uint32_t* read_ids, int id_cap)
+{
+    const DumpIndel& d(static_cast<Session*>(p)->pp->indels[i]);
+    *pos = d.pos;
+    *type = d.type;
+    *del_len = d.del_len;
+    std::strncpy(ins, d.ins.c_str(), ins_cap - 1);
+    ins[ins_cap - 1] = 0;
+    *is_candidate = d.is_candidate;
+    *not_discovered_from_reads = d.not_discovered_from_reads;
+    *is_forced_output = d.is_forced_output;
+    *ref_to_indel_lnp = d.ref_to_indel_lnp;
+    *indel_to_ref_lnp = d.indel_to_ref_lnp;
+    const int n(int(d.read_ids.size()));
+    for (int k = 0; k < n && k < id_cap; ++k) read_ids[k] = d.read_ids[k];
+    return n;
 }
 
 } // extern "C"

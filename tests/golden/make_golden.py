@@ -240,6 +240,53 @@ def pileup_golden():
         len(trials), sum(len(t["reads"]) for t in trials), sum(len(t["t1"]) for t in trials), sum(len(t["t2"]) for t in trials)))
 
 
+def _candidates_from(reads, k=12):
+    cands = []
+    for r in reads:
+        p = r["pos"]
+        for i, (ty, ln) in enumerate(r["path"]):
+            if ty == synth.SEG["DELETE"] and 0 < i < len(r["path"]) - 1 and len(cands) < k and ln <= 20:
+                if p not in [c["pos"] for c in cands]:
+                    cands.append(dict(pos=p, del_len=ln))
+            if ty in (synth.SEG["MATCH"], synth.SEG["DELETE"]):
+                p += ln
+    return cands
+
+
+def pipeline_golden():
+    """rows a1-a8 end to end through the reference's own position processor: reads -> read buffer -> realignAndScoreRead
+    -> pileup_read_segment.  The fixture keeps, per trial, the reads, the IndelBuffer as the realigner saw it, what
+    realignAndScoreRead was given per read (normalised input alignment, realignment range), the alignment the reference
+    piled up, and the columns it built."""
+    pyoracle.build(ref=True)
+    rng = np.random.default_rng(20240928)
+    trials = []
+    for t in range(6):
+        reads, ref, off = synth.pileup_reads(110, rng, read_len=(36, 120))
+        # total indel reference span per read <= maxIndelSize keeps the processor's stage sizes (hence realignment ranges) fixed
+        reads = [r for r in reads if sum(l for ty, l in r["path"] if ty in (synth.SEG["INSERT"], synth.SEG["DELETE"])) <= 49]
+        kw = dict(report_begin=off, report_end=off + len(ref))
+        opt = pyoracle.pileup_options(**kw)
+        finals, cols, indels = pyoracle.ref_pileup_pipeline(reads, ref, off, opt, candidate_indels=_candidates_from(reads),
+                                                            return_indels=True)
+        n_loci = opt.report_end - opt.report_begin
+        empty = dict(calls=np.zeros(0, np.uint16), tier2_calls=np.zeros(0, np.uint16), spandel=0, submapped=0)
+        col = [cols.get(opt.report_begin + l, empty) for l in range(n_loci)]
+        csr = lambda k: (np.concatenate([[0], np.cumsum([len(c[k]) for c in col])]).astype(np.int64),
+                         np.concatenate([c[k] for c in col] + [np.zeros(0, np.uint16)]).astype(np.uint16))
+        t1_off, t1 = csr("calls")
+        t2_off, t2 = csr("tier2_calls")
+        trials.append(dict(reads=reads, ref_seq=ref, ref_offset=off, opt=kw, finals=finals, indels=indels, t1_off=t1_off, t1=t1,
+                           t2_off=t2_off, t2=t2, spandel=np.array([c["spandel"] for c in col], np.uint32),
+                           submapped=np.array([c["submapped"] for c in col], np.uint32)))
+    import gzip
+    with gzip.open(os.path.join(HERE, "pipeline_reference.pkl.gz"), "wb") as f:
+        pickle.dump(trials, f, protocol=4)
+    print("pipeline golden: %d trials, %d reads (%d realigned), %d indels" % (
+        len(trials), sum(len(t["finals"]) for t in trials), sum(f["is_realigned"] for t in trials for f in t["finals"]),
+        sum(len(t["indels"]) for t in trials)))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "main"):
@@ -248,3 +295,5 @@ if __name__ == "__main__":
         realign_golden()
     if what in ("all", "pileup"):
         pileup_golden()
+    if what in ("all", "pipeline"):
+        pipeline_golden()

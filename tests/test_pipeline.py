@@ -1,0 +1,107 @@
+"""Rows a1-a8 end to end against the REFERENCE's own position processor.
+
+tests/golden/pipeline_reference.pkl.gz was produced by driving starling_pos_processor_base itself (oracle/ref/
+ref_driver_pileup.cpp): reads go into its read buffer, it realigns them (realignAndScoreRead) against the candidate indels,
+piles them up (pileup_read_segment) and the fixture records what it did -- per read the alignment it piled up, per
+position the column it built -- together with the IndelBuffer as the realigner saw it.
+
+Here the same reads go through this repository's chain: sk_realign_job (enumeration + scoring + selection) followed by the
+pileup (a8), and both the per-read alignments and the per-position columns must be identical.  The CPU test scores with the
+test-only interpreter and piles up with the C restatement; the GPU test runs everything through the C-ABI / HIP kernels."""
+import gzip
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from strelka_amd import capi, synth
+from tests.flat_interp import score_flat
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold(built):
+    with gzip.open(os.path.join(GOLD, "pipeline_reference.pkl.gz"), "rb") as f:
+        return pickle.load(f)
+
+
+def _run_trial(t, on_gpu):
+    reads, finals, indels = t["reads"], t["finals"], t["indels"]
+    job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=0, min_read_bp_flank=5))
+    job.set_reference(t["ref_seq"], t["ref_offset"])
+    job.set_indels(indels)
+    idx = []
+    for f in finals:
+        r = reads[f["read_id"]]
+        if r["map_level"] not in (capi.MAPLEVEL["TIER1"], capi.MAPLEVEL["TIER2"]):
+            idx.append(None)  # align_pos realigns tier1/tier2 reads only (starling_pos_processor_base.cpp:746)
+            continue
+        observed = [k for k, d in enumerate(indels) if f["read_id"] in d["read_ids"]]
+        idx.append(job.add_read(r["code"], r["qual"], f["input_pos"], capi.cigar_to_path(f["input_cigar"]), r["is_fwd"],
+                                r["map_level"], 0, f["realign_range"], observed))
+    if on_gpu:
+        job.run()
+    else:
+        b = job.batch()
+        _, lnc, lne = capi.qscore_tables()
+        job.finish(score_flat(b, lnc, lne))
+    piled = []
+    for f, i in zip(finals, idx):
+        res = job.result(i) if i is not None else dict(is_realigned=False)
+        mine = (True, res["pos"], capi.path_to_cigar(res["path"])) if res["is_realigned"] else (False, f["input_pos"], f["input_cigar"])
+        assert mine == (f["is_realigned"], f["pos"], f["cigar"]), ("read", f["read_id"])
+        if f["skipped"]:
+            continue
+        r = dict(reads[f["read_id"]])
+        r.update(pos=mine[1], path=capi.cigar_to_path(mine[2]))
+        piled.append(r)
+    rb = synth.ReadBatch.from_reads(piled, t["ref_seq"], t["ref_offset"])
+    fn, mk = (capi.pileup_reads, capi.pileup_options) if on_gpu else (pyoracle.pileup_reads, pyoracle.pileup_options)
+    for mode, off_key, key in ((capi.PILEUP_RAW_TIER1, "t1_off", "t1"), (capi.PILEUP_RAW_TIER2, "t2_off", "t2")):
+        co, calls, sd, sm = fn(rb, mk(**t["opt"]), mode)
+        assert np.array_equal(co, t[off_key]) and np.array_equal(calls, t[key])
+        assert np.array_equal(sd, t["spandel"]) and np.array_equal(sm, t["submapped"])
+    return len(finals)
+
+
+def test_fixture_is_not_trivial(gold):
+    assert sum(len(t["finals"]) for t in gold) > 500
+    assert sum(f["is_realigned"] for t in gold for f in t["finals"]) > 300
+    assert sum(f["is_realigned"] and (f["pos"], f["cigar"]) != (f["input_pos"], f["input_cigar"]) for t in gold for f in t["finals"]) > 50
+    assert sum(d["is_candidate"] for t in gold for d in t["indels"]) > 50
+    assert sum(1 for t in gold for d in t["indels"] if not d["is_candidate"]) > 100
+
+
+def test_realign_then_pileup_equals_reference_pipeline(gold):
+    assert sum(_run_trial(t, on_gpu=False) for t in gold) > 500
+
+
+@pytest.mark.skipif(not pyoracle.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_realign_then_pileup_equals_reference_pipeline_live(built):
+    from tests.golden.make_golden import _candidates_from
+    rng = np.random.default_rng(4242)
+    for _ in range(3):
+        reads, ref, off = synth.pileup_reads(100, rng, read_len=(36, 120))
+        reads = [r for r in reads if sum(l for ty, l in r["path"] if ty in (synth.SEG["INSERT"], synth.SEG["DELETE"])) <= 49]
+        kw = dict(report_begin=off, report_end=off + len(ref))
+        opt = pyoracle.pileup_options(**kw)
+        finals, cols, indels = pyoracle.ref_pileup_pipeline(reads, ref, off, opt, candidate_indels=_candidates_from(reads),
+                                                            return_indels=True)
+        n_loci = opt.report_end - opt.report_begin
+        empty = dict(calls=np.zeros(0, np.uint16), tier2_calls=np.zeros(0, np.uint16), spandel=0, submapped=0)
+        col = [cols.get(opt.report_begin + l, empty) for l in range(n_loci)]
+        csr = lambda k: (np.concatenate([[0], np.cumsum([len(c[k]) for c in col])]).astype(np.int64),
+                         np.concatenate([c[k] for c in col] + [np.zeros(0, np.uint16)]).astype(np.uint16))
+        t1_off, t1 = csr("calls")
+        t2_off, t2 = csr("tier2_calls")
+        _run_trial(dict(reads=reads, ref_seq=ref, ref_offset=off, opt=kw, finals=finals, indels=indels, t1_off=t1_off, t1=t1,
+                        t2_off=t2_off, t2=t2, spandel=np.array([c["spandel"] for c in col], np.uint32),
+                        submapped=np.array([c["submapped"] for c in col], np.uint32)), on_gpu=False)
+
+
+@pytest.mark.gpu
+def test_gpu_realign_then_pileup_equals_reference_pipeline(gpu, gold):
+    assert sum(_run_trial(t, on_gpu=True) for t in gold) > 500
