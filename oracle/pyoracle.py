@@ -484,6 +484,8 @@ def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=(), re
     L.refpp_final.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)] + [C.POINTER(C.c_int32)] * 4 + [C.c_char_p, C.c_int]
     L.refpp_final_input.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int32)] * 3 + [C.c_char_p, C.c_int]
     L.refpp_n_indels.argtypes = [vp]
+    L.refpp_indel_n_scores.argtypes = [vp, C.c_int]
+    L.refpp_indel_score.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_char_p, C.c_int]
     L.refpp_indel.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_char_p, C.c_int,
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
                               C.POINTER(C.c_double), vp, C.c_int]
@@ -543,7 +545,20 @@ def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=(), re
             ins = C.create_string_buffer(256)
             ids = np.zeros(4096, np.uint32)
             n = L.refpp_indel(s, i, pos, ty, dl, ins, 256, ic, nd, fo, a1, a2, _p(ids), 4096)
-            indels.append(dict(pos=pos.value, type=ty.value, del_len=dl.value, ins_seq=ins.value.decode(),
+            scores = []
+            for k in range(L.refpp_indel_n_scores(s, i)):
+                iv = np.zeros(12, np.int32)
+                fv = np.zeros(4, np.float32)
+                ab = C.create_string_buffer(256)
+                L.refpp_indel_score(s, i, k, _p(iv), _p(fv), ab, 256)
+                if int(iv[0]) not in id_of:
+                    continue
+                ai = ab.value.decode().split("|")
+                scores.append(dict(read_id=id_of[int(iv[0])], ref_lnp=float(fv[0]), indel_lnp=float(fv[1]), non_ambig=int(iv[1]),
+                                   read_length=int(iv[2]), is_tier1_read=int(iv[3]), is_fwd_strand=int(iv[4]), read_pos=int(iv[5]),
+                                   edge_dist=int(iv[6]),
+                                   alt=[((int(iv[8 + a]), int(iv[10 + a]), ai[a]), float(fv[2 + a])) for a in range(int(iv[7]))]))
+            indels.append(dict(scores=scores, pos=pos.value, type=ty.value, del_len=dl.value, ins_seq=ins.value.decode(),
                                is_candidate=ic.value, ndfr=nd.value, forced=fo.value, r2i=a1.value, i2r=a2.value,
                                read_ids=sorted(set(id_of[int(x)] for x in ids[:min(n, 4096)] if int(x) in id_of))))
         return finals, cols, indels

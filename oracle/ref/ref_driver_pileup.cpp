@@ -53,6 +53,18 @@ struct DumpIndel
     int32_t is_candidate, not_discovered_from_reads, is_forced_output;
     double ref_to_indel_lnp, indel_to_ref_lnp;
     std::vector<uint32_t> read_ids; // tier1/tier2/submapped/noise observations of sample 0 (is_usable_indel)
+    // read_path_lnp of sample 0 (score_indels output): read id, {ref, indel} lnp, then the alternate indels
+    struct Score
+    {
+        uint32_t read_id;
+        float ref_lnp, indel_lnp;
+        int32_t non_ambig, read_length, is_tier1, is_fwd, read_pos, edge_dist, n_alt;
+        int32_t alt_pos[2];
+        uint32_t alt_del[2];
+        std::string alt_ins[2];
+        float alt_lnp[2];
+    };
+    std::vector<Score> scores;
 };
 
 struct Streams : public starling_streams_base
@@ -138,6 +150,27 @@ struct PP : public starling_pos_processor_base
                 for (const auto id : sdat.tier2_map_read_ids) di.read_ids.push_back(id);
                 for (const auto id : sdat.submap_read_ids) di.read_ids.push_back(id);
                 for (const auto id : sdat.noise_read_ids) di.read_ids.push_back(id);
+                for (const auto& kv : sdat.read_path_lnp) {
+                    const ReadPathScores& r(kv.second);
+                    DumpIndel::Score sc;
+                    sc.read_id = kv.first;
+                    sc.ref_lnp = r.ref;
+                    sc.indel_lnp = r.indel;
+                    sc.non_ambig = r.nonAmbiguousBasesInRead;
+                    sc.read_length = r.read_length;
+                    sc.is_tier1 = r.is_tier1_read;
+                    sc.is_fwd = r.is_fwd_strand;
+                    sc.read_pos = r.read_pos;
+                    sc.edge_dist = r.distanceFromClosestReadEdge;
+                    sc.n_alt = int32_t(r.alt_indel.size());
+                    for (int a = 0; a < 2 && a < sc.n_alt; ++a) {
+                        sc.alt_pos[a] = r.alt_indel[a].first.pos;
+                        sc.alt_del[a] = r.alt_indel[a].first.deletionLength;
+                        sc.alt_ins[a] = r.alt_indel[a].first.insertSequence;
+                        sc.alt_lnp[a] = r.alt_indel[a].second;
+                    }
+                    di.scores.push_back(sc);
+                }
                 indels.push_back(di);
             }
         }
@@ -348,6 +381,34 @@ int refpp_indel(void* p, int i, int32_t* pos, int32_t* type, uint32_t* del_len, 
     const int n(int(d.read_ids.size()));
     for (int k = 0; k < n && k < id_cap; ++k) read_ids[k] = d.read_ids[k];
     return n;
+}
+
+int refpp_indel_n_scores(void* p, int i) { return int(static_cast<Session*>(p)->pp->indels[i].scores.size()); }
+
+/// score k of indel i: ints = {read_id, non_ambig, read_length, is_tier1, is_fwd, read_pos, edge_dist, n_alt, alt_pos[2],
+/// alt_del[2]}; floats = {ref, indel, alt_lnp[2]}; alt insert sequences concatenated with '|'
+int refpp_indel_score(void* p, int i, int k, int32_t* ints, float* floats, char* alt_ins, int cap)
+{
+    const DumpIndel::Score& s(static_cast<Session*>(p)->pp->indels[i].scores[k]);
+    ints[0] = int32_t(s.read_id);
+    ints[1] = s.non_ambig;
+    ints[2] = s.read_length;
+    ints[3] = s.is_tier1;
+    ints[4] = s.is_fwd;
+    ints[5] = s.read_pos;
+    ints[6] = s.edge_dist;
+    ints[7] = s.n_alt;
+    for (int a = 0; a < 2; ++a) {
+        ints[8 + a] = (a < s.n_alt) ? s.alt_pos[a] : 0;
+        ints[10 + a] = (a < s.n_alt) ? int32_t(s.alt_del[a]) : 0;
+        floats[2 + a] = (a < s.n_alt) ? s.alt_lnp[a] : 0.f;
+    }
+    floats[0] = s.ref_lnp;
+    floats[1] = s.indel_lnp;
+    const std::string joined((s.n_alt > 0 ? s.alt_ins[0] : std::string()) + "|" + (s.n_alt > 1 ? s.alt_ins[1] : std::string()));
+    std::strncpy(alt_ins, joined.c_str(), cap - 1);
+    alt_ins[cap - 1] = 0;
+    return 0;
 }
 
 } // extern "C"

@@ -49,8 +49,11 @@ def _run_trial(t, on_gpu):
         _, lnc, lne = capi.qscore_tables()
         job.finish(score_flat(b, lnc, lne))
     piled = []
+    mine_scores = {}  # (indel index, read index) -> ReadPathScores
     for f, i in zip(finals, idx):
-        res = job.result(i) if i is not None else dict(is_realigned=False)
+        res = job.result(i) if i is not None else dict(is_realigned=False, scores=[])
+        for sc in res["scores"]:
+            mine_scores[(sc["indel"], f["read_id"])] = sc
         mine = (True, res["pos"], capi.path_to_cigar(res["path"])) if res["is_realigned"] else (False, f["input_pos"], f["input_cigar"])
         assert mine == (f["is_realigned"], f["pos"], f["cigar"]), ("read", f["read_id"])
         if f["skipped"]:
@@ -58,6 +61,17 @@ def _run_trial(t, on_gpu):
         r = dict(reads[f["read_id"]])
         r.update(pos=mine[1], path=capi.cigar_to_path(mine[2]))
         piled.append(r)
+    # a7: the per-(indel, read) support scores left in the reference's IndelBuffer (read_path_lnp)
+    want_scores = {(k, sc["read_id"]): sc for k, d in enumerate(indels) for sc in d["scores"]}
+    assert set(mine_scores) == set(want_scores)
+    f32 = lambda x: np.float32(x).view(np.uint32)
+    key_of = lambda k: (indels[k]["pos"], indels[k]["del_len"], indels[k]["ins_seq"])
+    for kk, w in want_scores.items():
+        m = mine_scores[kk]
+        for fld in ("non_ambig", "read_length", "is_tier1_read", "is_fwd_strand", "read_pos", "edge_dist"):
+            assert m[fld] == w[fld], (kk, fld)
+        assert f32(m["ref_lnp"]) == f32(w["ref_lnp"]) and f32(m["indel_lnp"]) == f32(w["indel_lnp"]), kk
+        assert [(key_of(a), f32(l)) for a, l in m["alt"]] == [(a, f32(l)) for a, l in w["alt"]], kk
     rb = synth.ReadBatch.from_reads(piled, t["ref_seq"], t["ref_offset"])
     fn, mk = (capi.pileup_reads, capi.pileup_options) if on_gpu else (pyoracle.pileup_reads, pyoracle.pileup_options)
     for mode, off_key, key in ((capi.PILEUP_RAW_TIER1, "t1_off", "t1"), (capi.PILEUP_RAW_TIER2, "t2_off", "t2")):
@@ -73,6 +87,7 @@ def test_fixture_is_not_trivial(gold):
     assert sum(f["is_realigned"] and (f["pos"], f["cigar"]) != (f["input_pos"], f["input_cigar"]) for t in gold for f in t["finals"]) > 50
     assert sum(d["is_candidate"] for t in gold for d in t["indels"]) > 50
     assert sum(1 for t in gold for d in t["indels"] if not d["is_candidate"]) > 100
+    assert sum(len(d["scores"]) for t in gold for d in t["indels"]) > 500
 
 
 def test_realign_then_pileup_equals_reference_pipeline(gold):
