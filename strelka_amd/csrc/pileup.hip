@@ -80,6 +80,237 @@ __device__ __forceinline__ unsigned ref_code_at(const sk_read_batch& b, const in
     }
 }
 
+constexpr int FAST_K = 4; // positions per lane on the short-read path (reads up to 256 bases)
+
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, WAVE));
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, WAVE));
+    return v;
+}
+
+// P1, reads of up to 256 bases: every lane keeps its (at most four) read positions in registers -- base code, quality,
+// reference position -- so the read is loaded once, the alignment path is walked once, and every record is written once.
+// Same arithmetic as the general path below.
+__device__ void pileup_read_short(const PileupArgs& a, const int r, const int lane, int* delta)
+{
+    const int64_t ro = a.b.read_off[r];
+    const int L = int(a.b.read_off[r + 1] - ro);
+    const int64_t so = a.b.path_off[r];
+    const int nseg = int(a.b.path_off[r + 1] - so);
+    const sk_path_seg* __restrict__ path = a.b.path + so;
+    const int pos = a.b.pos[r];
+    const bool fwd = a.b.is_fwd[r] != 0;
+    const unsigned mapq = a.b.mapq[r];
+    const unsigned level = a.b.map_level[r];
+    const sk_pileup_options& o = a.o;
+
+    unsigned code[FAST_K], qual[FAST_K];
+#pragma unroll
+    for (int k = 0; k < FAST_K; ++k) {
+        const int p = lane + WAVE * k;
+        code[k] = (p < L) ? a.b.read_code[ro + p] : unsigned(SK_BAM_ANY);
+        qual[k] = (p < L) ? a.b.read_qual[ro + p] : 0u;
+    }
+    if (lane == 0) a.span[r] = make_int2(INT_MAX, INT_MIN);
+    auto store_none = [&]() {
+#pragma unroll
+        for (int k = 0; k < FAST_K; ++k) {
+            const int p = lane + WAVE * k;
+            if (p < L) a.rec[ro + p] = 0;
+        }
+    };
+
+    // one walk over the path: totals, edge segments, and for each of the lane's positions its segment
+    int ref_len = 0, read_len_path = 0, first_match = nseg, last_match = nseg;
+    int refpos[FAST_K];
+    bool in_match[FAST_K];
+#pragma unroll
+    for (int k = 0; k < FAST_K; ++k) {
+        refpos[k] = 0;
+        in_match[k] = false;
+    }
+    for (int i = 0; i < nseg; ++i) {
+        const uint32_t t = path[i].type;
+        const int len = int(path[i].length);
+        if (seg_match(t)) {
+            if (first_match == nseg) first_match = i;
+            last_match = i;
+#pragma unroll
+            for (int k = 0; k < FAST_K; ++k) {
+                const int p = lane + WAVE * k;
+                if (p >= read_len_path && p < read_len_path + len) {
+                    in_match[k] = true;
+                    refpos[k] = pos + ref_len + (p - read_len_path);
+                }
+            }
+        }
+        if (seg_ref_len(t)) ref_len += len;
+        if (seg_read_len(t)) read_len_path += len;
+    }
+    if (nseg == 0 || read_len_path != L || ref_len > L + o.largest_total_indel_ref_span_per_read || pos >= o.report_end ||
+        pos + ref_len <= o.report_begin) {
+        store_none();
+        return;
+    }
+    // ambiguous read end: trailing Ns of a forward read, leading Ns of a reverse read
+    int amb;
+    {
+        int hi_non_n = -1, lo_non_n = L;
+#pragma unroll
+        for (int k = 0; k < FAST_K; ++k) {
+            const int p = lane + WAVE * k;
+            if (p < L && code[k] != SK_BAM_ANY) {
+                hi_non_n = max(hi_non_n, p);
+                lo_non_n = min(lo_non_n, p);
+            }
+        }
+        amb = fwd ? (L - 1 - wave_max(hi_non_n)) : wave_min(lo_non_n);
+    }
+    int read_begin = 0, read_end = L;
+    if (amb > 0) {
+        if (fwd) read_end -= amb;
+        else read_begin += amb;
+    }
+    if (o.min_distance_from_read_edge > 0) {
+        read_begin += o.min_distance_from_read_edge;
+        if (o.min_distance_from_read_edge <= read_end) read_end -= o.min_distance_from_read_edge;
+        else read_end = 0;
+        if (read_end <= read_begin) {
+            store_none();
+            return;
+        }
+    }
+    const bool is_submapped = !(level == SK_MAPLEVEL_TIER1 || level == SK_MAPLEVEL_TIER2);
+    const bool is_tier1 = (level == SK_MAPLEVEL_TIER1);
+    const bool mdf = (o.mismatch_density_flank_size > 0);
+    const int fs = o.mismatch_density_flank_size, fs2 = 2 * fs;
+    const int delta_size = max(1 + fs2, L) - fs2;
+
+    bool mmk[FAST_K];
+#pragma unroll
+    for (int k = 0; k < FAST_K; ++k) mmk[k] = false;
+    if (!is_submapped && mdf) {
+        for (int i = lane; i < delta_size; i += WAVE) delta[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        auto inc = [&](const int start, const int length) {
+            atomicAdd(&delta[max(fs2, start) - fs2], 1);
+            if (start + length < delta_size) atomicAdd(&delta[start + length], -1);
+        };
+        if (lane == 0) { // internal indels
+            int read_head = 0;
+            for (int i = 0; i < nseg; ++i) {
+                const uint32_t t = path[i].type;
+                const int len = int(path[i].length);
+                const bool edge = (i < first_match) || (i > last_match);
+                if (t == SK_SEG_INSERT && !edge) inc(read_head, len);
+                if (t == SK_SEG_DELETE && !edge) inc(read_head, 0);
+                if (seg_read_len(t)) read_head += len;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FAST_K; ++k) {
+            const int p = lane + WAVE * k;
+            if (in_match[k] && p >= read_begin && p < read_end) {
+                const unsigned fc = ref_code_at(a.b, refpos[k]);
+                if (code[k] != fc) {
+                    bool cand = false;
+                    if (a.b.cand_snv_mask && refpos[k] >= a.b.ref_offset && refpos[k] < a.b.ref_offset + a.b.ref_len) {
+                        const unsigned id = code[k] == SK_BAM_A ? 0u : code[k] == SK_BAM_C ? 1u : code[k] == SK_BAM_G ? 2u : code[k] == SK_BAM_T ? 3u : 4u;
+                        cand = (id < 4u) && ((a.b.cand_snv_mask[refpos[k] - a.b.ref_offset] >> id) & 1u);
+                    }
+                    if (!cand) {
+                        mmk[k] = true;
+                        inc(p, 1);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int carry = 0;
+        for (int base = 0; base < delta_size; base += WAVE) {
+            const int i = base + lane;
+            int v = (i < delta_size) ? delta[i] : 0;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const int up = __shfl_up(v, d, WAVE);
+                if (lane >= d) v += up;
+            }
+            v += carry;
+            if (i < delta_size) delta[i] = v;
+            carry = __shfl(v, WAVE - 1, WAVE);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane == 0) a.span[r] = make_int2(pos, pos + ref_len);
+
+    const unsigned adj_mapq = mapq < 5u ? 5u : mapq;
+    const bool mapq_adjust = o.is_mapq_adjust && (adj_mapq <= 80u);
+#pragma unroll
+    for (int k = 0; k < FAST_K; ++k) {
+        const int p = lane + WAVE * k;
+        if (p >= L) continue;
+        unsigned rec = 0;
+        const bool live = in_match[k] && p >= read_begin && p < read_end && refpos[k] >= o.report_begin && refpos[k] < o.report_end;
+        if (live) {
+            if (is_submapped) {
+                if (a.submapped) atomicAdd(&a.submapped[refpos[k] - o.report_begin], 1u);
+            } else {
+                const unsigned c = code[k];
+                const unsigned id = c == SK_BAM_A ? 0u : c == SK_BAM_C ? 1u : c == SK_BAM_G ? 2u : c == SK_BAM_T ? 3u : 4u;
+                unsigned q = qual[k];
+                if (mapq_adjust) q = a.tab->mappedq[adj_mapq][q > 70u ? 70u : q];
+                bool is_call_filter = (c == SK_BAM_ANY) || (int(q) < o.min_basecall_qscore);
+                bool is_tier2_call_filter = is_call_filter;
+                bool nmm = false;
+                if (mdf) {
+                    const int del = delta[min(delta_size - 1, max(fs, p) - fs)];
+                    if (!is_call_filter) {
+                        is_call_filter = (o.mismatch_density_max_count < del);
+                        is_tier2_call_filter = o.use_tier2_evidence ? (o.tier2_mismatch_density_max_count < del) : is_call_filter;
+                    }
+                    nmm = (del - int(mmk[k])) > 0;
+                }
+                const bool current = is_tier1 ? is_call_filter : is_tier2_call_filter;
+                const bool tscf = is_tier1 && is_call_filter && !is_tier2_call_filter;
+                const unsigned qb = q > 63u ? 63u : q;
+                rec = qb | (id << 6) | (fwd ? 1u << 10 : 0u) | (nmm ? 1u << 11 : 0u) | (current ? 1u << 12 : 0u) |
+                      (tscf ? 1u << 13 : 0u) | (is_tier1 ? 0u : REC_TIER2) | REC_EMIT;
+            }
+        }
+        a.rec[ro + p] = uint16_t(rec);
+    }
+    // spanning deletions (order-free counters)
+    {
+        int ref_head = pos;
+        for (int i = 0; i < nseg; ++i) {
+            const uint32_t t = path[i].type;
+            const int len = int(path[i].length);
+            if (t == SK_SEG_DELETE && !((i < first_match) || (i > last_match))) {
+                for (int j = lane; j < len; j += WAVE) {
+                    const int refp = ref_head + j;
+                    if (refp < o.report_begin || refp >= o.report_end) continue;
+                    uint32_t* ctr = is_submapped ? a.submapped : a.spandel;
+                    if (ctr) atomicAdd(&ctr[refp - o.report_begin], 1u);
+                }
+            }
+            if (seg_ref_len(t)) ref_head += len;
+        }
+    }
+}
+
 // P1: one wave per read
 __global__ __launch_bounds__(P1_WAVES* WAVE) void pileup_read_kernel(const PileupArgs a)
 {
@@ -94,6 +325,10 @@ __global__ __launch_bounds__(P1_WAVES* WAVE) void pileup_read_kernel(const Pileu
 
     const int64_t ro = a.b.read_off[r];
     const int L = int(a.b.read_off[r + 1] - ro);
+    if (L <= FAST_K * WAVE) {
+        pileup_read_short(a, r, lane, delta);
+        return;
+    }
     const int64_t so = a.b.path_off[r];
     const int nseg = int(a.b.path_off[r + 1] - so);
     const sk_path_seg* __restrict__ path = a.b.path + so;

@@ -147,9 +147,11 @@ def test_gpu_pileup_matches_reference_golden(gpu, gold):
 @pytest.mark.gpu
 def test_gpu_pileup_matches_restatement_on_random_batches(gpu):
     rng = np.random.default_rng(2024)
-    for trial in range(6):
-        reads, ref, off = synth.pileup_reads(400 if trial < 5 else 3000, rng, ref_len=900 if trial < 5 else 6000,
-                                             sorted_by_pos=(trial != 3))
+    for trial in range(7):
+        # trial 6: reads longer than 256 bases take the general per-read path of the kernel
+        reads, ref, off = synth.pileup_reads(400 if trial < 5 else 3000 if trial == 5 else 200, rng,
+                                             ref_len=900 if trial < 5 else 6000 if trial == 5 else 1500,
+                                             sorted_by_pos=(trial != 3), read_len=(36, 151) if trial != 6 else (200, 420))
         kw = dict(report_begin=off + 13 * trial, report_end=off + len(ref) - 11 * trial)
         if trial % 2:
             kw.update(min_basecall_qscore=0, mismatch_density_max_count=3, use_tier2_evidence=1)
