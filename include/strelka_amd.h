@@ -90,7 +90,17 @@ typedef struct sk_align_batch {
     const sk_score_op* ops;   /* [n_ops] */
     int32_t max_read_len;     /* upper bound of any read length in the batch, 0 = unknown (selects the generic kernel) */
     int32_t max_hap_len;      /* upper bound of any per-read hap pool size, 0 = unknown */
+    /* Device-ready form of `ops` (sk_align_prepare; sk_align_builder_finish fills it): transition entries and per-read
+     * event masks, layout in strelka_amd/csrc/align_entry.h.  NULL = not prepared: sk_score_alignments prepares on the
+     * fly, sk_score_alignments_dev falls back to the generic thread-per-alignment kernel. */
+    const uint32_t* entries;  /* [n_ops + 2*n_cals] */
+    const uint32_t* evmask;   /* [n_reads * evmask_words] */
+    int32_t evmask_words;     /* sk_align_evmask_words(max_read_len) */
 } sk_align_batch;
+
+/** Prepared form of a host batch (max_read_len must be set): entries[n_ops + 2*n_cals], evmask[n_reads * words]. */
+int32_t sk_align_evmask_words(int32_t max_read_len);
+int sk_align_prepare(const sk_align_batch* host_batch, uint32_t* entries, uint32_t* evmask);
 
 /** out_lnp[n_cals]: ln P(read | alignment), double, bit-identical to the reference's sequential accumulation. */
 int sk_score_alignments(const sk_align_batch* host_batch, double* out_lnp);

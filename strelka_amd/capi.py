@@ -27,7 +27,8 @@ class AlignBatch(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("n_cals", C.c_int32), ("n_ops", C.c_int64),
                 ("read_off", c_void_p), ("read_code", c_void_p), ("read_qual", c_void_p),
                 ("hap_off", c_void_p), ("hap_code", c_void_p), ("cal_off", c_void_p), ("op_off", c_void_p),
-                ("ops", c_void_p), ("max_read_len", C.c_int32), ("max_hap_len", C.c_int32)]
+                ("ops", c_void_p), ("max_read_len", C.c_int32), ("max_hap_len", C.c_int32),
+                ("entries", c_void_p), ("evmask", c_void_p), ("evmask_words", C.c_int32)]
 
 
 class PathSeg(C.Structure):
@@ -178,7 +179,7 @@ assert DIGT_CALL_DTYPE.itemsize == 144 and SOMATIC_CALL_DTYPE.itemsize == 272
 # every symbol include/strelka_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
     "sk_init", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_get_qscore_tables",
-    "sk_score_alignments", "sk_score_alignments_dev",
+    "sk_score_alignments", "sk_score_alignments_dev", "sk_align_evmask_words", "sk_align_prepare",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_add_read",
     "sk_align_builder_finish", "sk_align_builder_error",
     "sk_align_scores_default", "sk_global_align",
@@ -249,6 +250,8 @@ def lib():
         L.sk_get_end_pin_start_pos.argtypes = [C.POINTER(IndelKey), C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.sk_score_alignments.argtypes = [C.POINTER(AlignBatch), c_void_p]
+        L.sk_align_evmask_words.argtypes = [C.c_int32]
+        L.sk_align_prepare.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
         L.sk_score_alignments_dev.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
         L.sk_score_alignments_dev_generic.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
         L.sk_dependent_eprob.argtypes = [C.POINTER(PileupBatch), C.POINTER(GermlineOptions), c_void_p]
@@ -336,10 +339,27 @@ class HostAlignBatch:
         self.max_read_len = int(np.diff(self.read_off).max()) if max_read_len is None and self.n_reads else int(max_read_len or 0)
         self.max_hap_len = int(np.diff(self.hap_off).max()) if max_hap_len is None and self.n_reads else int(max_hap_len or 0)
 
+        self.entries = self.evmask = None
+        self.evmask_words = 0
+
     def struct(self):
         return AlignBatch(self.n_reads, self.n_cals, len(self.ops), _p(self.read_off), _p(self.read_code),
                           _p(self.read_qual), _p(self.hap_off), _p(self.hap_code), _p(self.cal_off), _p(self.op_off),
-                          _p(self.ops), self.max_read_len, self.max_hap_len)
+                          _p(self.ops), self.max_read_len, self.max_hap_len,
+                          None if self.entries is None else _p(self.entries),
+                          None if self.evmask is None else _p(self.evmask), self.evmask_words)
+
+    def prepare(self):
+        """sk_align_prepare: the device-ready transition entries + event masks of this batch"""
+        if self.entries is None:
+            self.evmask_words = lib().sk_align_evmask_words(self.max_read_len)
+            ent = np.zeros(len(self.ops) + 2 * self.n_cals + 1, np.uint32)
+            msk = np.zeros(self.n_reads * self.evmask_words + 1, np.uint32)
+            s = self.struct()
+            if lib().sk_align_prepare(C.byref(s), _p(ent), _p(msk)) != 0:
+                raise StrelkaAmdError("sk_align_prepare failed")
+            self.entries, self.evmask = ent, msk
+        return self
 
 
 def score_alignments(batch):

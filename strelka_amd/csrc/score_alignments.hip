@@ -4,19 +4,22 @@
 // double per pair, terms added in path order, every term taken from the host-built tables (SkTables), no FMA
 // contraction, no reassociation.
 //
-// Kernel A1 `score_wave_per_read` (the fast path)
-//   * one 64-lane wavefront per read, one LANE per candidate alignment of that read (64 per pass), 4 waves per block;
-//   * the read is expanded once per wave into LDS as a per-position ROW of 6 doubles {term vs hap A, C, G, T, other,
-//     0.0}: M = ln(1-e_q) in the column of the read base, X = ln(e_q)-ln3 elsewhere; all 0.0 for an 'N' read base (the
-//     reference's `continue`), all M for '=' ("always matches").  The read's haplotype source pool (reference window +
-//     insert sequences) is stored as row-column byte offsets;
-//   * all lanes sweep the read positions i = 0..L-1 together: per cell one ds_read_u8 (the lane's haplotype column,
-//     prefetched one position ahead), one ds_read_b64 of row[i][column] -- the row address is wave-uniform, so the 64
-//     reads of a row are LDS broadcasts -- and one dependent v_add_f64 one position behind.  A lane leaves the lock-step
-//     sweep only at its own op boundaries (soft-clip term, non-candidate-indel penalty, next op's hap offset); its ops
-//     are prefetched from global memory one transition ahead;
-//   * soft-clipped and finished lanes read the 0.0 column: x + 0.0 == x for every x the sum can hold, so they stay in
-//     lock-step without changing a bit of the result.
+// Kernel A1 `score_wave_per_read` (the fast path; needs the batch's prepared form, csrc/align_entry.h)
+//   * one 64-lane wavefront per read, one LANE per candidate alignment of that read (up to 64 per pass), 4 waves per block;
+//   * per wave, LDS holds (a) the read as a per-position ROW of 6 doubles {term vs hap A, C, G, T, other, 0.0}: M =
+//     ln(1-e_q) in the column of the read base, X = ln(e_q)-ln3 elsewhere; all 0.0 for an 'N' read base (the reference's
+//     `continue`), all M for '='; (b) the read's haplotype pool as row-column byte offsets, followed by a run of "0.0
+//     column" bytes; (c) the pass's TRANSITION ENTRIES, one short list per candidate (read position, hap index base, the
+//     first two columns, penalties / soft-clip term to add first), copied from the prepared batch with coalesced loads;
+//     (d) the read's event mask: the read positions at which ANY candidate has an entry;
+//   * all lanes sweep the read positions together, one uniform scalar loop.  Per cell: one ds_read_b64
+//     (row[position][column]; the row address is wave-uniform, so the reads of a row are LDS broadcasts), one
+//     ds_read_u8 (the lane's haplotype column two positions ahead), one dependent v_add_f64 one position behind.
+//     Soft-clipped and finished lanes read the 0.0 column (x + 0.0 == x exactly): they stay in lock-step without
+//     changing a bit of the result;
+//   * a scalar bit test per position tells whether any lane has a transition there; only then do the lanes whose next
+//     entry starts at that position take the short transition: new hap index base and columns come out of the entry
+//     register, the next entry is fetched from LDS, penalties / the soft-clip term are added in path order.
 //
 // Kernel A2 `score_thread_per_cal` (generic fallback: reads/pools too long for LDS, or unknown bounds)
 //   one thread per candidate alignment, straight from global memory.
@@ -26,6 +29,8 @@
 
 #include "sk_common.h"
 
+#include "align_entry.h"
+
 #include <algorithm>
 #include <vector>
 
@@ -34,9 +39,9 @@ namespace
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int WAVE = 64;
-constexpr int OPS_CAP = 0;     // >0: stage up to this many scoring ops per wave per pass in LDS (0: prefetch from global)
-constexpr int ROW_BYTES = 48;  // per read position: {A, C, G, T, other, 0.0} doubles
-constexpr int ZERO_COL = 40;   // byte offset of the 0.0 column
+constexpr int ROW_BYTES = 48;                 // per read position: {A, C, G, T, other, 0.0} doubles
+constexpr int ZERO_COL = 8 * SK_ENT_ZERO_COL; // byte offset of the 0.0 column
+constexpr int ENT_CAP = 576;                  // transition entries per wave per pass (ops of the pass + 2 per candidate)
 
 __device__ __forceinline__ double dadd(double a, double b) { return __dadd_rn(a, b); }
 
@@ -52,163 +57,19 @@ struct ScoreArgs
     const SkTables* tab;
     double* out;
     int lds_tab_bytes; // per wave: ROW_BYTES * maxL
-    int lds_hap_bytes; // per wave: align16(max(maxPool, maxL))
+    int lds_hap_bytes; // per wave: align16(maxP + maxL + 8)  (pool columns + the 0.0-column run)
 };
 
-// Kernel A1.  LDS slab per wave: [table rows][hap column offsets][staged ops]
-__global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(const ScoreArgs a)
+__device__ __forceinline__ void wave_sync()
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / WAVE); // wave-uniform: L, P, offsets live in SGPRs
-    const size_t per_wave = size_t(a.lds_tab_bytes) + a.lds_hap_bytes + OPS_CAP * sizeof(sk_score_op);
-    unsigned char* slab = smem + per_wave * wave;
-    unsigned char* tabb = slab;
-    unsigned char* hap = slab + a.lds_tab_bytes;
-    sk_score_op* lops = reinterpret_cast<sk_score_op*>(hap + a.lds_hap_bytes);
-
-    const int r = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (r >= a.b.n_reads) return; // whole wave; waves never synchronise with each other
-
-    const int64_t ro = a.b.read_off[r];
-    const int L = int(a.b.read_off[r + 1] - ro);
-    const int64_t ho = a.b.hap_off[r];
-    const int P = int(a.b.hap_off[r + 1] - ho);
-    const int cal_begin = a.b.cal_off[r], cal_end = a.b.cal_off[r + 1];
-    {
-        // per-position table: row[col] = the term added when the haplotype base of that column faces read base i
-        //   'N' read base -> 0.0 everywhere (the reference `continue`s, :125/:158)
-        //   '=' read base -> M everywhere   (always a match, :127/:160)
-        const SkTables* __restrict__ T = a.tab;
-        double* tab = reinterpret_cast<double*>(tabb);
-        for (int j = lane; j < L; j += WAVE) {
-            const unsigned rc = a.b.read_code[ro + j];
-            unsigned q = a.b.read_qual[ro + j];
-            q = q > 70u ? 70u : q;
-            const bool any = (rc == SK_BAM_ANY);
-            const double M = any ? 0.0 : T->q2lncompe[q];
-            const double X = any ? 0.0 : (rc == SK_BAM_REF ? M : T->q2mis[q]);
-            double* row = tab + 6 * j;
-            row[0] = (rc == SK_BAM_A) ? M : X;
-            row[1] = (rc == SK_BAM_C) ? M : X;
-            row[2] = (rc == SK_BAM_G) ? M : X;
-            row[3] = (rc == SK_BAM_T) ? M : X;
-            row[4] = X; // haplotype 'N'/other never equals a non-N read code
-            row[5] = 0.0;
-        }
-        for (int j = lane; j < P; j += WAVE) hap[j] = (unsigned char)hap_col_offset(a.b.hap_code[ho + j]);
-        for (int j = P + lane; j < a.lds_hap_bytes; j += WAVE) hap[j] = 32;
-    }
-
-    const double ln_quarter = a.tab->ln_quarter;
-    const double ln_noncand = a.tab->ln_noncand;
-    const sk_score_op* __restrict__ gops = a.b.ops;
-
-    for (int cbase = cal_begin; cbase < cal_end; cbase += WAVE) {
-        const int c = cbase + lane;
-        const bool has_cal = (c < cal_end);
-        const int clast = (cbase + WAVE < cal_end) ? cbase + WAVE : cal_end;
-        const int64_t kbase = a.b.op_off[cbase];
-        const int nstage = int(a.b.op_off[clast] - kbase);
-        const bool in_lds = (OPS_CAP > 0) && (nstage <= OPS_CAP);
-        __builtin_amdgcn_wave_barrier();
-        if (in_lds) {
-            // consecutive candidates' ops are contiguous: one coalesced copy for the whole wave
-            const uint2* __restrict__ src = reinterpret_cast<const uint2*>(gops + kbase);
-            uint2* dst = reinterpret_cast<uint2*>(lops);
-            for (int j = lane; j < nstage; j += WAVE) dst[j] = src[j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        int k = 0, kend = 0; // op cursor relative to kbase
-        if (has_cal) {
-            k = int(a.b.op_off[c] - kbase);
-            kend = int(a.b.op_off[c + 1] - kbase);
-        }
-        auto load_op = [&](const int kk) -> uint2 {
-            if (kk >= kend) return make_uint2(0u, 0u);
-            return in_lds ? reinterpret_cast<const uint2*>(lops)[kk] : reinterpret_cast<const uint2*>(gops + kbase)[kk];
-        };
-        double lnp = 0.0;
-        double pend = 0.0;  // term of the previous read position, not yet added (software pipeline of depth 1)
-        int op_end = 0;     // read position at which the current op ends
-        int delta = 0;      // hap index = delta + i inside a BASES op
-        unsigned colmin = ZERO_COL; // 0 inside a BASES op, ZERO_COL otherwise (max() forces the 0.0 column)
-        unsigned cur_flags = 0;
-        uint2 nop = load_op(k); // the next op, prefetched one transition ahead
-
-        // advance(): finish the current op (penalty), start following ops until one that spans read bases.
-        // Called by exactly the lanes whose current op ends at read position i.
-        auto advance = [&](const int i) {
-            lnp = dadd(lnp, pend); // the last base term of the finished op precedes its penalty
-            pend = 0.0;
-            for (;;) {
-                if (cur_flags & SK_OPFLAG_NONCANDIDATE_PENALTY) lnp = dadd(lnp, ln_noncand);
-                cur_flags = 0;
-                if (k >= kend) {
-                    op_end = 0x7fffffff;
-                    colmin = ZERO_COL;
-                    delta = -i; // keeps the (ignored) hap read of an idle lane in range
-                    return;
-                }
-                const unsigned w0 = nop.x;
-                const int src = int(nop.y);
-                ++k;
-                nop = load_op(k);
-                cur_flags = (w0 >> 24) & 0xffu;
-                const unsigned kind = (w0 >> 16) & 0xffu;
-                int len = int(w0 & 0xffffu);
-                if (kind == SK_OP_BASES) {
-                    colmin = 0;
-                    delta = src - i;
-                } else {
-                    colmin = ZERO_COL;
-                    delta = -i;
-                    if (kind == SK_OP_SOFT_CLIP) {
-                        lnp = dadd(lnp, __dmul_rn(double(unsigned(len)), ln_quarter));
-                    } else {
-                        len = 0;
-                    }
-                }
-                op_end = i + len;
-                if (len > 0) return;
-            }
-        };
-
-        if (op_end == 0) advance(0);
-        unsigned col_next = (L > 0) ? hap[delta] : 0u;
-#pragma unroll 2
-        for (int i = 0; i < L; ++i) {
-            if (op_end == i && i > 0) { // a lane leaves the lock-step sweep only at its own op boundaries
-                advance(i);
-                col_next = hap[delta + i];
-            }
-            unsigned col = col_next;
-            col = col > colmin ? col : colmin;
-            const double v = *reinterpret_cast<const double*>(tabb + ROW_BYTES * i + col);
-            col_next = hap[delta + i + 1]; // prefetch (hap slab is padded by 16 bytes beyond max(P, L))
-            lnp = dadd(lnp, pend);
-            pend = v;
-        }
-        if (op_end == L && L > 0) advance(L); // trailing penalty / NOBASE ops
-        lnp = dadd(lnp, pend);
-        if (has_cal) a.out[c] = lnp;
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ void score_thread_per_cal(const ScoreArgs a)
+// one candidate alignment straight from global memory (kernel A2; also the per-candidate escape of A1)
+__device__ double score_one_generic(const ScoreArgs& a, const int r, const int c)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.b.n_cals) return;
-    // read index: last r with cal_off[r] <= c
-    int lo = 0, hi = a.b.n_reads;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.b.cal_off[mid] <= c) lo = mid; else hi = mid;
-    }
-    const int r = lo;
     const int64_t ro = a.b.read_off[r];
     const int64_t ho = a.b.hap_off[r];
     const SkTables* __restrict__ T = a.tab;
@@ -232,7 +93,210 @@ __global__ void score_thread_per_cal(const ScoreArgs a)
         }
         if (op.flags & SK_OPFLAG_NONCANDIDATE_PENALTY) lnp = dadd(lnp, T->ln_noncand);
     }
-    a.out[c] = lnp;
+    return lnp;
+}
+
+// Kernel A1.  LDS slab per wave: [rows][hap columns + 0.0 run][entries][event mask]
+__global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(const ScoreArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / WAVE); // wave-uniform: L, P, offsets live in SGPRs
+    constexpr int ENT_BYTES = (ENT_CAP + 4) * 4;
+    const int W = a.b.evmask_words;
+    const size_t per_wave = (size_t(a.lds_tab_bytes) + a.lds_hap_bytes + ENT_BYTES + size_t(W) * 4 + 15) & ~size_t(15); // 16-byte aligned slabs
+    unsigned char* slab = smem + per_wave * wave;
+    unsigned char* tabb = slab;
+    unsigned char* hap = slab + a.lds_tab_bytes;
+    unsigned* ent = reinterpret_cast<unsigned*>(hap + a.lds_hap_bytes);
+    unsigned* mask = ent + (ENT_CAP + 4);
+
+    const int r = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (r >= a.b.n_reads) return; // whole wave; waves never synchronise with each other
+
+    const int64_t ro = a.b.read_off[r];
+    const int L = int(a.b.read_off[r + 1] - ro);
+    const int64_t ho = a.b.hap_off[r];
+    const int P = int(a.b.hap_off[r + 1] - ho);
+    const int cal_begin = a.b.cal_off[r], cal_end = a.b.cal_off[r + 1];
+    {
+        // Global loads are issued in groups, before any of them is consumed, so that their latencies overlap.
+        // haplotype pool as column offsets, then the 0.0-column run (soft-clipped / finished lanes index into it)
+        const uint8_t* __restrict__ gh = a.b.hap_code + ho;
+        for (int j0 = 0; j0 < P; j0 += 8 * WAVE) {
+            unsigned t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * WAVE + lane;
+                t[u] = (j < P) ? gh[j] : unsigned(SK_BAM_ANY);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * WAVE + lane;
+                if (j < P) hap[j] = (unsigned char)hap_col_offset(t[u]);
+            }
+        }
+        for (int j = P + lane; j < a.lds_hap_bytes; j += WAVE) hap[j] = ZERO_COL;
+        const uint32_t* __restrict__ gm = a.b.evmask + int64_t(r) * W;
+        for (int j = lane; j < W; j += WAVE) mask[j] = gm[j];
+        if (lane == 0) { // the entry list of lanes without a candidate: 0.0 column throughout
+            ent[ENT_CAP] = unsigned(SK_ENT_ZERO_COL << 15) | unsigned(SK_ENT_ZERO_COL << 18) | (unsigned(P + SK_ENT_HIDX_BIAS) << 21);
+            ent[ENT_CAP + 1] = SK_ENT_END;
+        }
+        // per-position rows: row[col] = the term added when the haplotype base of that column faces read base i
+        //   'N' read base -> 0.0 everywhere (the reference `continue`s, :125/:158)
+        //   '=' read base -> M everywhere   (always a match, :127/:160)
+        const SkTables* __restrict__ T = a.tab;
+        double* tab = reinterpret_cast<double*>(tabb);
+        for (int j0 = 0; j0 < L; j0 += 4 * WAVE) {
+            unsigned rcv[4], rqv[4];
+            double Mv[4], Xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * WAVE + lane;
+                rcv[u] = (j < L) ? a.b.read_code[ro + j] : unsigned(SK_BAM_ANY);
+                rqv[u] = (j < L) ? a.b.read_qual[ro + j] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned q = rqv[u] > 70u ? 70u : rqv[u];
+                Mv[u] = T->q2lncompe[q];
+                Xv[u] = T->q2mis[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * WAVE + lane;
+                if (j >= L) continue;
+                const unsigned rc = rcv[u];
+                const bool any = (rc == SK_BAM_ANY);
+                const double M = any ? 0.0 : Mv[u];
+                const double X = any ? 0.0 : (rc == SK_BAM_REF ? M : Xv[u]);
+                double* row = tab + 6 * j;
+                row[0] = (rc == SK_BAM_A) ? M : X;
+                row[1] = (rc == SK_BAM_C) ? M : X;
+                row[2] = (rc == SK_BAM_G) ? M : X;
+                row[3] = (rc == SK_BAM_T) ? M : X;
+                row[4] = X; // haplotype 'N'/other never equals a non-N read code
+                row[5] = 0.0;
+            }
+        }
+    }
+
+    const double ln_quarter = a.tab->ln_quarter;
+    const double ln_noncand = a.tab->ln_noncand;
+    const uint32_t* __restrict__ gent = a.b.entries;
+
+    int cbase = cal_begin;
+    while (cbase < cal_end) {
+        // ---- how many candidates this pass takes: their entry slots (ops + 2 each) must fit the LDS table
+        const int c = cbase + lane;
+        const bool has = (c < cal_end);
+        const int64_t sbase = a.b.op_off[cbase] + 2 * int64_t(cbase); // first entry slot of the pass
+        const int s1 = has ? int(a.b.op_off[c + 1] + 2 * int64_t(c + 1) - sbase) : 0x3fffffff; // end slot of the lane's candidate
+        const bool fits = has && (s1 <= ENT_CAP);
+        const int m = __popcll(__ballot(fits)); // `fits` is monotone in the lane index
+        if (m == 0) { // a single candidate with more ops than the table holds
+            if (lane == 0) a.out[cbase] = score_one_generic(a, r, cbase);
+            cbase += 1;
+            continue;
+        }
+        const bool active = lane < m;
+        const int nslots = __builtin_amdgcn_readlane(s1, m - 1);
+        const int ebase = active ? int(a.b.op_off[c] + 2 * int64_t(c) - sbase) : ENT_CAP;
+
+        wave_sync(); // the previous pass is done with the entry table; rows / hap columns / mask are complete
+        for (int j0 = 0; j0 < nslots; j0 += 10 * WAVE) { // the pass's entries are contiguous in the prepared batch
+            unsigned t[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int j = j0 + u * WAVE + lane;
+                t[u] = (j < nslots) ? gent[sbase + j] : SK_ENT_END;
+            }
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int j = j0 + u * WAVE + lane;
+                if (j < nslots) ent[j] = t[u];
+            }
+        }
+        wave_sync();
+
+        // ---- the sweep
+        double lnp = 0.0, pend = 0.0; // pend: the term of the previous position, added one step later
+        unsigned nxt = ent[ebase];
+        const bool complex_cal = (nxt == SK_ENT_COMPLEX);
+        if (complex_cal) nxt = ent[ENT_CAP];
+        int kp = complex_cal ? ENT_CAP + 1 : ebase + 1;
+        int hidx = 0;          // the lane's haplotype column of read position i is hap[hidx + i]
+        unsigned cA = 0, cB = 0; // columns of the next even / odd position
+        // lanes whose next entry starts at read position i; `first` receives the column of position i, `second` of i+1
+        auto transition = [&](const int i, unsigned& first, unsigned& second) {
+            const unsigned e = nxt;
+            nxt = ent[kp++];
+            if (e & SK_ENT_ADD_BITS) {
+                lnp = dadd(lnp, pend); // the last base term precedes the penalties
+                pend = 0.0;
+                const unsigned np = (e >> 10) & 7u;
+                for (unsigned t = 0; t < np; ++t) lnp = dadd(lnp, ln_noncand);
+                if (e & (1u << 13)) lnp = dadd(lnp, __dmul_rn(double(unsigned(int(nxt & SK_ENT_POS_MASK) - i)), ln_quarter));
+            }
+            hidx = int(e >> 21) - SK_ENT_HIDX_BIAS;
+            first = ((e >> 15) & 7u) << 3;
+            second = ((e >> 18) & 7u) << 3;
+        };
+        transition(0, cA, cB); // every list starts with an entry at read position 0
+
+        const unsigned char* rowp = tabb;
+        for (int wb = 0; wb < L; wb += 64) {
+            // 64-position window of the event mask, wave-uniform (bit 0 of the read is handled above)
+            uint64_t win = uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(mask[wb >> 5]))) |
+                           (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(mask[(wb >> 5) + 1]))) << 32);
+            const int wend = (wb + 64 < L) ? wb + 64 : L;
+            for (int i = wb; i < wend; i += 2) {
+                if (win & 1ull) { // scalar branch: some lane has an entry starting here
+                    asm volatile("; event" ::: "memory");
+                    if ((nxt & SK_ENT_POS_MASK) == unsigned(i)) transition(i, cA, cB);
+                }
+                {
+                    const double v = *reinterpret_cast<const double*>(rowp + cA);
+                    cA = hap[hidx + i + 2];
+                    lnp = dadd(lnp, pend);
+                    pend = v;
+                }
+                if (i + 1 < wend) {
+                    if (win & 2ull) {
+                        asm volatile("; event" ::: "memory");
+                        if ((nxt & SK_ENT_POS_MASK) == unsigned(i + 1)) transition(i + 1, cB, cA);
+                    }
+                    const double v = *reinterpret_cast<const double*>(rowp + ROW_BYTES + cB);
+                    cB = hap[hidx + i + 3];
+                    lnp = dadd(lnp, pend);
+                    pend = v;
+                }
+                win >>= 2;
+                rowp += 2 * ROW_BYTES;
+            }
+        }
+        // entries at the end of the read: trailing penalties
+        if ((uint32_t(__builtin_amdgcn_readfirstlane(mask[L >> 5])) >> (L & 31)) & 1u) {
+            if ((nxt & SK_ENT_POS_MASK) == unsigned(L)) transition(L, cA, cB);
+        }
+        lnp = dadd(lnp, pend);
+        if (active) a.out[c] = complex_cal ? score_one_generic(a, r, c) : lnp;
+        cbase += m;
+    }
+}
+
+__global__ void score_thread_per_cal(const ScoreArgs a)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.b.n_cals) return;
+    // read index: last r with cal_off[r] <= c
+    int lo = 0, hi = a.b.n_reads;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.b.cal_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    a.out[c] = score_one_generic(a, lo, c);
 }
 
 inline int align16(int n) { return (n + 15) & ~15; }
@@ -251,12 +315,13 @@ extern "C" int sk_score_alignments_dev(const sk_align_batch* b, double* dev_out_
     a.tab = sk_ctx().dev_tables;
     a.out = dev_out_lnp;
     const int maxL = b->max_read_len, maxP = b->max_hap_len;
-    a.lds_tab_bytes = ROW_BYTES * std::max(maxL, 1);
-    a.lds_hap_bytes = align16(std::max(std::max(maxP, maxL), 1)) + 16; // +16: the sweep prefetches one byte ahead
-    const size_t per_wave = size_t(a.lds_tab_bytes) + a.lds_hap_bytes + OPS_CAP * sizeof(sk_score_op);
+    a.lds_tab_bytes = align16(ROW_BYTES * std::max(maxL, 1));
+    a.lds_hap_bytes = align16(std::max(maxP, 0) + std::max(maxL, 1) + 8);
+    const size_t per_wave = (size_t(a.lds_tab_bytes) + a.lds_hap_bytes + (ENT_CAP + 4) * 4 + size_t(std::max(b->evmask_words, 0)) * 4 + 15) & ~size_t(15);
     const size_t lds = per_wave * WAVES_PER_BLOCK;
-    // fast path when 4 waves' slabs leave room for >= 2 workgroups per CU (160 KiB LDS)
-    if (maxL > 0 && maxP > 0 && lds <= 64 * 1024) {
+    // fast path: prepared batch, bounds known, and 4 waves' slabs leave room for >= 2 workgroups per CU (160 KiB LDS)
+    const bool prepared = b->entries && b->evmask && b->evmask_words == sk_ent_evmask_words(maxL);
+    if (prepared && maxL > 0 && maxL <= SK_ENT_MAX_READ_LEN && maxP > 0 && maxP <= SK_ENT_MAX_POOL && lds <= 64 * 1024) {
         const int blocks = (b->n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
         hipLaunchKernelGGL(score_wave_per_read, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds, st, a);
     } else {
@@ -336,11 +401,25 @@ extern "C" int sk_score_alignments(const sk_align_batch* hb, double* out_lnp)
     SkArena ar;
     const size_t need = sk_align256(sizeof(int64_t) * (n + 1)) * 2 + sk_align256(sizeof(int32_t) * (n + 1)) +
                         sk_align256(sizeof(int64_t) * (n_cals + 1)) + sk_align256(n_bases) * 2 + sk_align256(n_hap) +
-                        sk_align256(sizeof(sk_score_op) * n_ops) + sk_align256(sizeof(double) * n_cals) + 16 * 256;
+                        sk_align256(sizeof(sk_score_op) * n_ops) + sk_align256(sizeof(double) * n_cals) + 16 * 256 +
+                        sk_align256(4 * (size_t(n_ops) + 2 * size_t(n_cals) + 1)) +
+                        sk_align256(4 * (size_t(n) * size_t(sk_ent_evmask_words(maxL)) + 1));
     if (ar.reserve(need)) return 1;
     sk_align_batch d = *hb;
     d.max_read_len = maxL;
     d.max_hap_len = std::max(maxP, 1);
+    // the device-ready form: taken from the caller when it matches these bounds, else prepared here
+    std::vector<uint32_t> h_entries, h_evmask;
+    const uint32_t* src_entries = hb->entries;
+    const uint32_t* src_evmask = hb->evmask;
+    d.evmask_words = sk_ent_evmask_words(maxL);
+    if (!(hb->entries && hb->evmask && hb->evmask_words == d.evmask_words && hb->max_read_len == maxL)) {
+        h_entries.resize(size_t(n_ops) + 2 * size_t(n_cals) + 1);
+        h_evmask.resize(size_t(n) * size_t(d.evmask_words) + 1);
+        if (sk_align_prepare(&d, h_entries.data(), h_evmask.data())) return sk_fail("sk_score_alignments: sk_align_prepare failed");
+        src_entries = h_entries.data();
+        src_evmask = h_evmask.data();
+    }
     hipStream_t st = ctx.stream;
 #define UP(field, T, count)                                                                              \
     {                                                                                                    \
@@ -357,6 +436,15 @@ extern "C" int sk_score_alignments(const sk_align_batch* hb, double* out_lnp)
     UP(op_off, int64_t, size_t(n_cals + 1));
     UP(ops, sk_score_op, size_t(n_ops));
 #undef UP
+    {
+        const size_t ne = size_t(n_ops) + 2 * size_t(n_cals), nm = size_t(n) * size_t(d.evmask_words);
+        uint32_t* pe = ar.take<uint32_t>(ne + 1);
+        uint32_t* pm = ar.take<uint32_t>(nm + 1);
+        if (ne) SK_HIP(hipMemcpyAsync(pe, src_entries, 4 * ne, hipMemcpyHostToDevice, st));
+        if (nm) SK_HIP(hipMemcpyAsync(pm, src_evmask, 4 * nm, hipMemcpyHostToDevice, st));
+        d.entries = pe;
+        d.evmask = pm;
+    }
     double* dout = ar.take<double>(n_cals);
     if (sk_score_alignments_dev(&d, dout, st)) return 1;
     SK_HIP(hipMemcpyAsync(out_lnp, dout, sizeof(double) * n_cals, hipMemcpyDeviceToHost, st));

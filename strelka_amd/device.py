@@ -20,6 +20,7 @@ class DeviceAlignBatch:
     def __init__(self, hb, device="cuda:0", tile=1):
         """Upload a capi.HostAlignBatch; `tile` > 1 replicates it on the device (offsets shifted) to reach bench sizes."""
         self.device = device
+        hb.prepare()
         ops_bytes = hb.ops.view(np.uint8).reshape(-1, 8)
         t = dict(read_off=_t(hb.read_off, device), read_code=_t(hb.read_code, device), read_qual=_t(hb.read_qual, device),
                  hap_off=_t(hb.hap_off, device), hap_code=_t(hb.hap_code, device), cal_off=_t(hb.cal_off, device),
@@ -37,6 +38,12 @@ class DeviceAlignBatch:
             for k in ("read_code", "read_qual", "hap_code"):
                 t[k] = t[k].repeat(tile)
             t["ops"] = t["ops"].repeat(tile, 1)
+        # prepared form: candidate c owns entry slots [op_off[c] + 2c, ...), so tiles simply repeat
+        ent = hb.entries[:len(hb.ops) + 2 * hb.n_cals]
+        msk = hb.evmask[:hb.n_reads * hb.evmask_words]
+        t["entries"] = _t(ent.view(np.int32), device).repeat(tile)
+        t["evmask"] = _t(msk.view(np.int32), device).repeat(tile)
+        self.evmask_words = hb.evmask_words
         self.t = t
         self.n_reads = hb.n_reads * tile
         self.n_cals = hb.n_cals * tile
@@ -51,7 +58,7 @@ class DeviceAlignBatch:
         return capi.AlignBatch(self.n_reads, self.n_cals, self.n_ops, t["read_off"].data_ptr(), t["read_code"].data_ptr(),
                                t["read_qual"].data_ptr(), t["hap_off"].data_ptr(), t["hap_code"].data_ptr(),
                                t["cal_off"].data_ptr(), t["op_off"].data_ptr(), t["ops"].data_ptr(), self.max_read_len,
-                               self.max_hap_len)
+                               self.max_hap_len, t["entries"].data_ptr(), t["evmask"].data_ptr(), self.evmask_words)
 
     def score(self, generic=False):
         """Enqueue the scoring kernel on torch's current stream; returns the device output tensor."""

@@ -7,6 +7,8 @@
 
 #include "strelka_amd.h"
 
+#include "../csrc/align_entry.h"
+
 #include <algorithm>
 #include <climits>
 #include <cstring>
@@ -45,6 +47,7 @@ struct sk_align_builder
     std::vector<int32_t> cal_off{ 0 };
     std::vector<uint8_t> read_code, read_qual, hap_code;
     std::vector<sk_score_op> ops;
+    std::vector<uint32_t> entries, evmask; // prepared form, filled by finish
     int32_t max_read_len = 0, max_hap_len = 0;
     std::string error;
 
@@ -296,6 +299,69 @@ int sk_align_builder_add_read(sk_align_builder* b, const uint8_t* read_code, con
     }
 }
 
+int32_t sk_align_evmask_words(const int32_t max_read_len) { return sk_ent_evmask_words(max_read_len < 0 ? 0 : max_read_len); }
+
+// ops -> transition entries + per-read event masks (layout: csrc/align_entry.h)
+int sk_align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* evmask)
+{
+    if (!b || !entries || !evmask || b->n_reads < 0) return 1;
+    const int W = sk_ent_evmask_words(b->max_read_len);
+    for (int r = 0; r < b->n_reads; ++r) {
+        const int64_t L64 = b->read_off[r + 1] - b->read_off[r], P64 = b->hap_off[r + 1] - b->hap_off[r];
+        uint32_t* mask = evmask + int64_t(r) * W;
+        std::memset(mask, 0, sizeof(uint32_t) * size_t(W));
+        const bool read_ok = (L64 >= 0 && L64 <= SK_ENT_MAX_READ_LEN && L64 <= b->max_read_len && P64 >= 0 && P64 <= SK_ENT_MAX_POOL);
+        const int L = int(L64), P = int(P64);
+        const uint8_t* hap = b->hap_code + b->hap_off[r];
+        auto col_at = [&](const int idx) -> unsigned {
+            return (idx >= 0 && idx < P) ? sk_ent_col_index(hap[idx]) : unsigned(SK_ENT_ZERO_COL);
+        };
+        for (int c = b->cal_off[r]; c < b->cal_off[r + 1]; ++c) {
+            const int64_t k0 = b->op_off[c], k1 = b->op_off[c + 1];
+            uint32_t* ent = entries + k0 + 2 * int64_t(c);
+            const int nslots = int(k1 - k0) + 2;
+            for (int i = 0; i < nslots; ++i) ent[i] = SK_ENT_END;
+            bool complex_cal = !read_ok;
+            int e = 0, pos = 0;
+            unsigned npen = 0;
+            auto emit = [&](const unsigned np, const bool clip, const int hidx) {
+                if (np > 7u || hidx + SK_ENT_HIDX_BIAS < 0 || hidx + SK_ENT_HIDX_BIAS > 2047) complex_cal = true;
+                if (complex_cal) return;
+                ent[e++] = unsigned(pos) | (np << 10) | (clip ? 1u << 13 : 0u) | (col_at(hidx + pos) << 15) |
+                           (col_at(hidx + pos + 1) << 18) | (unsigned(hidx + SK_ENT_HIDX_BIAS) << 21);
+                if (pos > 0 && pos <= L) mask[pos >> 5] |= 1u << (pos & 31);
+            };
+            for (int64_t k = k0; k < k1 && !complex_cal; ++k) {
+                const sk_score_op& op = b->ops[k];
+                const int len = int(op.length);
+                const unsigned pen = op.flags & SK_OPFLAG_NONCANDIDATE_PENALTY;
+                if ((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0) {
+                    if (pos >= int(SK_ENT_END)) {
+                        complex_cal = true;
+                        break;
+                    }
+                    const bool bases = (op.kind == SK_OP_BASES);
+                    if (bases && (op.src < 0 || int64_t(op.src) + len > P)) complex_cal = true;
+                    emit(npen, !bases, bases ? int(op.src) - pos : P - pos);
+                    pos += len;
+                    npen = pen;
+                } else {
+                    npen += pen; // NOBASE / zero-length ops carry only their penalty (0 * ln 1/4 adds exactly nothing)
+                }
+            }
+            if (!complex_cal) {
+                if (pos != L || pos >= int(SK_ENT_END)) complex_cal = true; // does not span the read
+                else emit(npen, false, P - pos);
+            }
+            if (complex_cal) {
+                for (int i = 0; i < nslots; ++i) ent[i] = SK_ENT_END;
+                ent[0] = SK_ENT_COMPLEX;
+            }
+        }
+    }
+    return 0;
+}
+
 int sk_align_builder_finish(sk_align_builder* b, sk_align_batch* out)
 {
     if (!b || !out) return 1;
@@ -312,6 +378,15 @@ int sk_align_builder_finish(sk_align_builder* b, sk_align_batch* out)
     out->ops = b->ops.data();
     out->max_read_len = b->max_read_len;
     out->max_hap_len = b->max_hap_len;
+    // the device-ready form of the ops
+    out->evmask_words = sk_ent_evmask_words(b->max_read_len);
+    b->entries.assign(b->ops.size() + 2 * size_t(out->n_cals) + 1, SK_ENT_END);
+    b->evmask.assign(size_t(out->n_reads) * size_t(out->evmask_words) + 1, 0u);
+    out->entries = nullptr;
+    out->evmask = nullptr;
+    if (sk_align_prepare(out, b->entries.data(), b->evmask.data())) return 1;
+    out->entries = b->entries.data();
+    out->evmask = b->evmask.data();
     return 0;
 }
 

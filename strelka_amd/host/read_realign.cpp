@@ -441,6 +441,7 @@ struct sk_realign_job
     };
     std::vector<Read> reads;
     sk_align_builder* builder = nullptr;
+    int32_t n_cals_total = 0;
     bool finished = false;
 
     // ---- table access
@@ -1690,6 +1691,7 @@ void sk_realign_job_clear_reads(sk_realign_job* j)
 {
     if (!j) return;
     j->reads.clear();
+    j->n_cals_total = 0;
     sk_align_builder_clear(j->builder);
     j->finished = false;
     j->error.clear();
@@ -1748,9 +1750,7 @@ int sk_realign_job_add_read(sk_realign_job* j, const sk_read_input* in)
         rd.cals.assign(cal_set.begin(), cal_set.end());
 
         // flatten this read's candidate alignments into the job's batch
-        sk_align_batch cur;
-        sk_align_builder_finish(j->builder, &cur);
-        rd.cal_begin = cur.n_cals;
+        rd.cal_begin = j->n_cals_total;
         std::vector<std::vector<sk_path_seg>> segs(rd.cals.size());
         std::vector<std::vector<sk_indel_key>> keys(rd.cals.size());
         std::vector<sk_candidate_alignment> cc(rd.cals.size());
@@ -1759,6 +1759,7 @@ int sk_realign_job_add_read(sk_realign_job* j, const sk_read_input* in)
             sk_align_builder_add_read(j->builder, rd.code.data(), rd.qual.data(), in->read_len, j->ref.data(), j->ref_offset,
                                       int32_t(j->ref.size()), cc.data(), int32_t(cc.size())) != 0)
             throw Fail(std::string("flatten: ") + sk_align_builder_error(j->builder));
+        j->n_cals_total += int32_t(rd.cals.size());
         j->reads.push_back(std::move(rd));
         return int(j->reads.size()) - 1;
     } catch (const std::exception& e) {
