@@ -489,9 +489,10 @@ typedef struct sk_somatic_snv_call { /* snv_result_set, L/applications/strelka/s
  *  normal/tumor batches must have the same n_loci and ref_base; `de` is ignored (raw error_prob(q) is used). */
 int sk_somatic_snv_call_batch(const sk_pileup_batch* host_normal, const sk_pileup_batch* host_tumor,
                               const sk_somatic_snv_options* opt, int is_forced_output, sk_somatic_snv_call* out);
+/* dev_scratch: >= 4 * (n_loci + 4) bytes of device memory (the queue of loci that are not skipped) */
 int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* dev_normal, const sk_pileup_batch* dev_tumor,
                                   const sk_somatic_snv_options* opt, int is_forced_output,
-                                  sk_somatic_snv_call* dev_out, void* hip_stream);
+                                  sk_somatic_snv_call* dev_out, void* dev_scratch, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (indels): per-read likelihood reductions over IndelSampleData::read_path_lnp

@@ -52,6 +52,7 @@ def build_all(force=False, verbose=True):
            # every add is part of the result
            "-ffp-contract=off", "-mllvm", "-disable-promote-alloca-to-lds", "-Wall",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")]
+    cmd += os.environ.get("SK_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DSOM_WPE=3)
     for s in HOST_SOURCES:
         cmd += ["-x", "c++", os.path.join(PKG, s)]
     for s in HIP_SOURCES:

@@ -265,7 +265,7 @@ def lib():
         L.sk_somatic_snv_call_batch.argtypes = [C.POINTER(PileupBatch), C.POINTER(PileupBatch),
                                                 C.POINTER(SomaticSnvOptions), C.c_int, c_void_p]
         L.sk_somatic_snv_call_batch_dev.argtypes = [C.POINTER(PileupBatch), C.POINTER(PileupBatch),
-                                                    C.POINTER(SomaticSnvOptions), C.c_int, c_void_p, c_void_p]
+                                                    C.POINTER(SomaticSnvOptions), C.c_int, c_void_p, c_void_p, c_void_p]
         L.sk_indel_grid_lhood.argtypes = [C.POINTER(ReadScoreBatch), C.POINTER(IndelOptions), C.c_int, c_void_p]
         L.sk_indel_grid_lhood_dev.argtypes = [C.POINTER(ReadScoreBatch), C.POINTER(IndelOptions), C.c_int, c_void_p, c_void_p]
         L.sk_somatic_indel_call_batch.argtypes = [C.POINTER(ReadScoreBatch), C.POINTER(ReadScoreBatch),

@@ -44,49 +44,54 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const float* 
     unsigned max_gt = 0;
     const float RATIO_INCREMENT = 0.5f / static_cast<float>(HET_RES + 1);
 
+    // The reference fills log_sum[] for one (ngt,tgt) at a time, Ft outer / Fn inner, then takes the max and sums the
+    // exps in that order (:75-160).  Here Ft is the (unrolled) outer loop for all six (ngt,tgt) at once, so every
+    // likelihood index is a compile-time constant and the arrays stay in registers; each (ngt,tgt) still sees its own
+    // terms in the reference's order.  Two passes (max, then sum) instead of the 441-double buffer.
+    double mx[SOM_SIZE][2], sm[SOM_SIZE][2];
+#pragma unroll
     for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) {
-        for (unsigned tgt = 0; tgt < 2; ++tgt) {
-            // two passes over the allowed (Ft,Fn) pairs instead of the reference's log_sum[] buffer: same max, same
-            // summation order, no 441-double scratch array
-            double max_log_sum = neg_inf;
-            double sum = 0.0;
-            for (int pass = 0; pass < 2; ++pass) {
-                for (unsigned tfi = 0; tfi < PRESTRAND; ++tfi) {
-                    const bool consider_norm_contam = (__fmul_rn(d.contam_tolerance, d.grid_frac[tfi]) >= RATIO_INCREMENT);
-                    for (unsigned nfi = 0; nfi < PRESTRAND; ++nfi) {
-                        double lprior_freq;
-                        if (tgt == 0) {
-                            if (nfi != tfi) continue;
-                            lprior_freq = (nfi == ngt) ? static_cast<double>(d.ln_csse_rate)
-                                                       : static_cast<double>(__fadd_rn(d.ln_sse_rate, d.log_error_mod));
-                        } else {
-                            if (nfi == tfi) continue;
-                            if (ngt != SOM_REF) {
-                                if (nfi != ngt) continue;
-                                lprior_freq = d.log_error_mod;
-                            } else {
-                                if (!consider_norm_contam) {
-                                    if (nfi == 0) lprior_freq = d.log_error_mod;
-                                    else continue;
-                                } else {
-                                    if ((nfi == ngt) || (nfi == SOM_SIZE))
-                                        lprior_freq = static_cast<double>(__fadd_rn(d.log_error_mod, d.ln_one_half));
-                                    else continue;
-                                }
-                            }
-                        }
-                        const double lsum = __dadd_rn(__dadd_rn(lprior_freq, static_cast<double>(normal_lhood[nfi])),
-                                                      static_cast<double>(tumor_lhood[tfi]));
-                        if (pass == 0) {
-                            if (lsum > max_log_sum) max_log_sum = lsum;
-                        } else {
-                            sum = __dadd_rn(sum, exp(__dsub_rn(lsum, max_log_sum)));
-                        }
-                    }
-                }
+        mx[ngt][0] = mx[ngt][1] = neg_inf;
+        sm[ngt][0] = sm[ngt][1] = 0.0;
+    }
+    const double lp_match = static_cast<double>(d.ln_csse_rate);
+    const double lp_mismatch = static_cast<double>(__fadd_rn(d.ln_sse_rate, d.log_error_mod));
+    const double lp_mod = static_cast<double>(d.log_error_mod);
+    const double lp_half = static_cast<double>(__fadd_rn(d.log_error_mod, d.ln_one_half));
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        auto visit = [&](const unsigned ngt, const unsigned tgt, const unsigned nfi, const unsigned tfi, const double lprior_freq) {
+            const double lsum = __dadd_rn(__dadd_rn(lprior_freq, static_cast<double>(normal_lhood[nfi])),
+                                          static_cast<double>(tumor_lhood[tfi]));
+            if (pass == 0) {
+                if (lsum > mx[ngt][tgt]) mx[ngt][tgt] = lsum;
+            } else {
+                // exp() of anything at or below -746 is exactly 0 and adding it changes nothing
+                const double dlt = __dsub_rn(lsum, mx[ngt][tgt]);
+                if (!(dlt <= -746.)) sm[ngt][tgt] = __dadd_rn(sm[ngt][tgt], exp(dlt));
             }
+        };
+#pragma unroll
+        for (unsigned tfi = 0; tfi < PRESTRAND; ++tfi) {
+#pragma unroll
+            for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) visit(ngt, 0, tfi, tfi, (tfi == ngt) ? lp_match : lp_mismatch);
+            // tgt == 1 (:96-137)
+            if (!(__fmul_rn(d.contam_tolerance, d.grid_frac[tfi]) >= RATIO_INCREMENT)) {
+                if (tfi != 0) visit(SOM_REF, 1, 0, tfi, lp_mod);
+            } else {
+                if (tfi != 0) visit(SOM_REF, 1, 0, tfi, lp_half);
+                if (tfi != SOM_SIZE) visit(SOM_REF, 1, SOM_SIZE, tfi, lp_half);
+            }
+            if (tfi != SOM_HOM) visit(SOM_HOM, 1, SOM_HOM, tfi, lp_mod);
+            if (tfi != SOM_HET) visit(SOM_HET, 1, SOM_HET, tfi, lp_mod);
+        }
+    }
+#pragma unroll
+    for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) {
+#pragma unroll
+        for (unsigned tgt = 0; tgt < 2; ++tgt) {
             const double log_genotype_prior = static_cast<double>(__fadd_rn(d.lnprior[ngt], (tgt == 0) ? d.ln_som_match : d.ln_som_mismatch));
-            log_post_prob[ngt][tgt] = __dadd_rn(__dadd_rn(log_genotype_prior, max_log_sum), log(sum));
+            log_post_prob[ngt][tgt] = __dadd_rn(__dadd_rn(log_genotype_prior, mx[ngt][tgt]), log(sm[ngt][tgt]));
             if (log_post_prob[ngt][tgt] > max_log_prob) {
                 max_log_prob = log_post_prob[ngt][tgt];
                 max_gt = ngt * 2 + tgt;

@@ -6,8 +6,10 @@
 //                                   L/applications/strelka/position_somatic_snv_strand_grid_lhood_cached.cpp:41-234
 //   calculate_result_set_grid       L/applications/strelka/qscore_calculator.cpp:47-209
 //
-// One thread per locus; the calls of a block's loci are staged through LDS with coalesced loads (normal sample, then
-// tumor, through the same buffer) and the memo tables live in LDS as one row per q-score.  The reference memoises every per-call term by (qscore, ratio index); those memo tables are
+// Two launches: `somatic_classify_kernel` streams the calls once and queues the loci that are not skipped by the
+// reference's early return (reference base 'N', or both pileups all-reference); `somatic_snv_kernel` evaluates the queued
+// loci, one thread per locus, 64 at a time, their calls staged through LDS with coalesced loads (normal sample, then
+// tumor, through the same buffer) and the memo tables in LDS as one row per q-score.  The reference memoises every per-call term by (qscore, ratio index); those memo tables are
 // built on the host (SkTables) so each of the 21 (+2x9 strand) accumulators is the same sequential float32 sum over the
 // calls in pileup order as in the reference -- bit-identical.  Only the 9 strand states' final float logsum and the
 // double-precision posterior evaluate device transcendentals.
@@ -25,6 +27,7 @@ struct SomArgs
     sk_pileup_batch n, t;
     const SkTables* tab;
     sk_somatic_snv_call* out;
+    unsigned* work; // [0] = number of loci to evaluate, [1..] = their indices (any order)
     SomaticDerived d;
 };
 
@@ -43,163 +46,247 @@ __device__ __forceinline__ float log_sum2f(float x1, float x2)
     return __fadd_rn(x1, l);
 }
 
-// per-q row of every memoised term, one LDS row per q-score: the per-call loop indexes it with a data-dependent q
+// Every memoised term of one call, one LDS row per (q-score, call == reference base): the fields are stored in the order
+// the accumulators use them, so the per-call loop is loads + adds with no selects except the strand one.
 struct QRow
 {
-    float v0, v1, v2, off_ref;            // simple genotypes (:56-64); off-strand ref term (:213)
-    float c0[HET_RES], c1[HET_RES];        // het grid (:104-110)
-    float t0[HET_RES], t1[HET_RES];        // strand states, on-strand (:197-206)
-    float off_alt, pad[3];                 // off-strand alt term (:221)
+    float ref, het, hom;    // simple genotypes: is_ref ? (v2, v1, v0) : (v0, v1, v2)            (:56-64)
+    float off;              // off-strand term: is_ref ? ln_comp_error_prob : ln_error_prob+ln(1/3) (:213,:221)
+    float hi[HET_RES];      // -> grid[2*HET_RES-(r+1)]: is_ref ? c0 : c1                          (:104-110,:149-151)
+    float lo[HET_RES];      // -> grid[r]:               is_ref ? c1 : c0
+    float on[HET_RES];      // on-strand term of the strand states: is_ref ? t0 : t1              (:197-206)
+    float pad[5];           // 144-byte rows: a 128-byte stride would put every row on the same two LDS bank groups
 };
-static_assert(sizeof(QRow) % 16 == 0, "rows are read with 128-bit LDS loads");
+static_assert(sizeof(QRow) == 144, "rows are read with 128-bit LDS loads");
+constexpr int N_QROWS = 2 * SK_NQ6;
 
-constexpr int SOM_THREADS = 64;
-constexpr int SOM_CAP = 8192; // calls of one sample staged per sub-batch (16 KiB)
+__device__ __forceinline__ void fill_qrows(const SkTables* __restrict__ T, QRow* s_q, const int tid, const int nthreads)
+{
+    for (int i = tid; i < N_QROWS; i += nthreads) {
+        const int q = i >> 1;
+        const bool is_ref = (i & 1) != 0;
+        QRow r;
+        r.ref = is_ref ? T->s_v2[q] : T->s_v0[q];
+        r.het = T->s_v1[q];
+        r.hom = is_ref ? T->s_v0[q] : T->s_v2[q];
+        r.off = is_ref ? T->t_off_ref[q] : T->t_off_alt[q];
+        r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = r.pad[4] = 0.f;
+#pragma unroll
+        for (int k = 0; k < HET_RES; ++k) {
+            r.hi[k] = is_ref ? T->s_c0[k][q] : T->s_c1[k][q];
+            r.lo[k] = is_ref ? T->s_c1[k][q] : T->s_c0[k][q];
+            r.on[k] = is_ref ? T->t_c0[k][q] : T->t_c1[k][q];
+        }
+        s_q[i] = r;
+    }
+}
 
-// one sample's 30 likelihoods for the locus whose calls sit at calls[0..n) in LDS
-template <bool WITH_STRAND>
-__device__ __forceinline__ void sample_lhood(const uint16_t* calls, const int n, const unsigned ref_gt, const QRow* Q,
-                                             const float ln_one_half, float* __restrict__ lhood, bool& allref, unsigned& alt_id)
+constexpr int SOM_WPE = 4;                 // waves per SIMD the register allocation is held to (128 VGPRs)
+constexpr int SOM_WAVES = 4;               // waves per block; each works through its own 64 queued loci
+constexpr int SOM_THREADS = 64 * SOM_WAVES;
+constexpr int CHUNK = 32;                  // calls of one locus staged per round
+constexpr int ROW_DW = CHUNK / 2 + 1;      // row stride in dwords: 17 keeps the lanes' row reads on distinct LDS banks
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct LhoodAcc
 {
     float acc[PRESTRAND];
-#pragma unroll
-    for (int i = 0; i < PRESTRAND; ++i) acc[i] = 0.f;
     float sf[HET_RES], sr[HET_RES];
-#pragma unroll
-    for (int r = 0; r < HET_RES; ++r) sf[r] = sr[r] = 0.f;
-    unsigned alt_count[4] = { 0, 0, 0, 0 };
-    allref = true;
+    unsigned alt_count[4];
+};
 
-    for (int i = 0; i < n; ++i) {
-        const uint16_t bc = calls[i];
+// the per-call updates of one sample's accumulators for calls row[0..cnt), in pileup order
+template <bool WITH_STRAND>
+__device__ __forceinline__ void accumulate_calls(const uint16_t* row, const int cnt, const unsigned ref_gt, const QRow* Q, LhoodAcc& A)
+{
+    for (int i = 0; i < cnt; ++i) {
+        const uint16_t bc = row[i];
         const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
         const bool is_ref = (obs == ref_gt);
         if (!is_ref) {
-            allref = false;
 #pragma unroll
-            for (unsigned b = 0; b < 4; ++b) alt_count[b] += (obs == b) ? 1u : 0u;
+            for (unsigned b = 0; b < 4; ++b) A.alt_count[b] += (obs == b) ? 1u : 0u;
         }
-        const QRow& R = Q[q];
-        const float v0 = R.v0, v1 = R.v1, v2 = R.v2;
-        acc[SOM_REF] = __fadd_rn(acc[SOM_REF], is_ref ? v2 : v0);
-        acc[SOM_HET] = __fadd_rn(acc[SOM_HET], v1);
-        acc[SOM_HOM] = __fadd_rn(acc[SOM_HOM], is_ref ? v0 : v2);
+        const QRow& R = Q[2 * q + (is_ref ? 1 : 0)];
+        A.acc[SOM_REF] = __fadd_rn(A.acc[SOM_REF], R.ref);
+        A.acc[SOM_HET] = __fadd_rn(A.acc[SOM_HET], R.het);
+        A.acc[SOM_HOM] = __fadd_rn(A.acc[SOM_HOM], R.hom);
 #pragma unroll
         for (int r = 0; r < HET_RES; ++r) {
-            const float c0 = R.c0[r], c1 = R.c1[r];
-            // lhood_high = grid[2*HET_RES-(r+1)], lhood_low = grid[r]   (…_lhood_cached.cpp:149-151)
-            acc[SOM_SIZE + (2 * HET_RES - (r + 1))] = __fadd_rn(acc[SOM_SIZE + (2 * HET_RES - (r + 1))], is_ref ? c0 : c1);
-            acc[SOM_SIZE + r] = __fadd_rn(acc[SOM_SIZE + r], is_ref ? c1 : c0);
+            A.acc[SOM_SIZE + (2 * HET_RES - (r + 1))] = __fadd_rn(A.acc[SOM_SIZE + (2 * HET_RES - (r + 1))], R.hi[r]);
+            A.acc[SOM_SIZE + r] = __fadd_rn(A.acc[SOM_SIZE + r], R.lo[r]);
         }
         if (WITH_STRAND) {
             const bool fwd = SKC_FWD(bc);
-            const float off = is_ref ? R.off_ref : R.off_alt;
+            const float off = R.off;
 #pragma unroll
             for (int r = 0; r < HET_RES; ++r) {
-                const float on = is_ref ? R.t0[r] : R.t1[r];
-                sf[r] = __fadd_rn(sf[r], fwd ? on : off);
-                sr[r] = __fadd_rn(sr[r], fwd ? off : on);
+                const float on = R.on[r];
+                A.sf[r] = __fadd_rn(A.sf[r], fwd ? on : off);
+                A.sr[r] = __fadd_rn(A.sr[r], fwd ? off : on);
             }
         }
     }
+}
+
+// one sample's 30 likelihoods for the wave's 64 queued loci (lane t owns locus `l`, -1 = none).  The calls are staged
+// CHUNK per locus at a time into the wave's LDS rows: 32 lanes fetch 64 contiguous bytes of one locus, so every global
+// request is a full segment and the buffer stays small enough for the register file to bound the occupancy.
+template <bool WITH_STRAND>
+__device__ __forceinline__ void sample_lhood(const sk_pileup_batch& b, const int l, const unsigned ref_gt, uint32_t* rows,
+                                             const QRow* Q, const float ln_one_half, float* __restrict__ lhood, unsigned& alt_id)
+{
+    const int lane = threadIdx.x & 63;
+    int64_t g0 = 0;
+    int n = 0;
+    if (l >= 0) {
+        g0 = b.call_off[l];
+        n = int(b.call_off[l + 1] - g0);
+    }
+    int maxn = n;
 #pragma unroll
-    for (int i = 0; i < PRESTRAND; ++i) lhood[i] = acc[i];
+    for (int d = 32; d >= 1; d >>= 1) maxn = max(maxn, __shfl_xor(maxn, d));
+    LhoodAcc A;
+#pragma unroll
+    for (int i = 0; i < PRESTRAND; ++i) A.acc[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < HET_RES; ++r) A.sf[r] = A.sr[r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A.alt_count[k] = 0;
+
+    const uint16_t* __restrict__ calls = b.calls;
+    uint16_t* rows16 = reinterpret_cast<uint16_t*>(rows);
+    const uint16_t* own = rows16 + lane * (2 * ROW_DW);
+    const int half = lane >> 5, k = lane & 31;
+    for (int c = 0; c < maxn; c += CHUNK) {
+#pragma unroll 8
+        for (int j2 = 0; j2 < 32; ++j2) {
+            const int j = 2 * j2 + half;
+            const int64_t gj = __shfl(g0, j);
+            const int nj = __shfl(n, j);
+            if (c + k < nj) rows16[j * (2 * ROW_DW) + k] = calls[gj + c + k];
+        }
+        wave_sync();
+        accumulate_calls<WITH_STRAND>(own, min(max(n - c, 0), CHUNK), ref_gt, Q, A);
+        wave_sync();
+    }
+#pragma unroll
+    for (int i = 0; i < PRESTRAND; ++i) lhood[i] = A.acc[i];
 #pragma unroll
     for (int r = 0; r < HET_RES; ++r)
-        lhood[PRESTRAND + r] = WITH_STRAND ? __fadd_rn(log_sum2f(sf[r], sr[r]), ln_one_half) : 0.f;
+        lhood[PRESTRAND + r] = WITH_STRAND ? __fadd_rn(log_sum2f(A.sf[r], A.sr[r]), ln_one_half) : 0.f;
 
     // snp_pos_info::get_most_frequent_alt_id, L/blt_common/snp_pos_info.hh:164-190
     alt_id = ref_gt;
     unsigned max_count = 0;
 #pragma unroll
-    for (unsigned b = 0; b < 4; ++b) {
-        if (alt_count[b] > max_count && b != ref_gt) {
-            max_count = alt_count[b];
-            alt_id = b;
+    for (unsigned bb = 0; bb < 4; ++bb) {
+        if (A.alt_count[bb] > max_count && bb != ref_gt) {
+            max_count = A.alt_count[bb];
+            alt_id = bb;
         }
     }
 }
 
-// stage the calls of the block's loci [s, e) of one sample into LDS with coalesced loads; sub-batched like the germline
-// kernel when the span exceeds the buffer.  `f(t, calls, n)` runs for every locus t of the block exactly once; a locus
-// deeper than the whole buffer is handed its global pointer instead.
-template <typename F>
-__device__ __forceinline__ void for_each_locus_staged(const sk_pileup_batch& b, const int l0, const int nl, uint16_t* s_calls,
-                                                      int64_t* s_off, F&& f)
+constexpr int CLS_THREADS = 256;
+
+// S0: which loci need evaluating at all.  The reference returns before any likelihood is computed when the reference base
+// is 'N' or both pileups show only the reference base (position_somatic_snv_strand_grid.cpp:244-254); on 40x + 110x
+// data that is most loci.  Calls are streamed with 16-byte loads; a locus is queued when any of its calls differs from
+// its reference base (or unconditionally for forced output).  The queue order is arbitrary -- loci are independent.
+__device__ __forceinline__ void flag_nonref_loci(const sk_pileup_batch& b, const int l0, const int nl, int64_t* s_off,
+                                                 const unsigned char* s_ref, unsigned* s_flag)
 {
     const int tid = threadIdx.x;
-    for (int j = tid; j <= nl; j += SOM_THREADS) s_off[j] = b.call_off[l0 + j];
+    for (int j = tid; j <= nl; j += CLS_THREADS) s_off[j] = b.call_off[l0 + j];
     __syncthreads();
-    int s = 0;
-    while (s < nl) {
-        const int64_t c0 = s_off[s];
-        const bool fits = (tid >= s) && (tid < nl) && (s_off[tid + 1] - c0 <= SOM_CAP);
-        const int cnt = __syncthreads_count(fits);
-        if (cnt == 0) { // one locus deeper than the buffer: straight from global memory
-            if (tid == s) f(s, b.calls + c0, int(s_off[s + 1] - c0));
-            s += 1;
-            __syncthreads();
-            continue;
+    const int64_t c0 = s_off[0], c1 = s_off[nl];
+    const uint16_t* __restrict__ g = b.calls;
+    const int64_t a0 = c0 - int64_t((reinterpret_cast<uintptr_t>(g + c0) & 15u) >> 1); // 16-byte aligned start
+    for (int64_t i = a0 + int64_t(tid) * 8; i < c1; i += CLS_THREADS * 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(g + i); // stays inside the 16-byte blocks of valid calls
+        const unsigned w[4] = { v.x, v.y, v.z, v.w };
+        int lo = 0, hi = nl; // locus of call max(i, c0): the last j with s_off[j] <= it
+        const int64_t first = (i < c0) ? c0 : i;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] <= first) lo = mid; else hi = mid;
         }
-        const int e = s + cnt;
-        const int span = int(s_off[e] - c0);
-        const uint16_t* __restrict__ g = b.calls + c0;
-        for (int j = tid; j < span; j += SOM_THREADS) s_calls[j] = g[j];
-        __syncthreads();
-        const int t = s + tid;
-        if (t < e) f(t, s_calls + int(s_off[t] - c0), int(s_off[t + 1] - s_off[t]));
-        s = e;
-        __syncthreads();
+        int loc = lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t idx = i + k;
+            if (idx < c0 || idx >= c1) continue;
+            while (idx >= s_off[loc + 1]) ++loc;
+            const unsigned bc = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            if (SKC_BASE(bc) != unsigned(s_ref[loc])) s_flag[loc] = 1u;
+        }
     }
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(SOM_THREADS) void somatic_snv_kernel(const SomArgs a)
+__global__ __launch_bounds__(CLS_THREADS) void somatic_classify_kernel(const SomArgs a)
 {
-    __shared__ uint16_t s_calls[SOM_CAP];
-    __shared__ int64_t s_off[SOM_THREADS + 1];
-    __shared__ __attribute__((aligned(16))) QRow s_q[SK_NQ6];
+    __shared__ int64_t s_off[CLS_THREADS + 1];
+    __shared__ unsigned char s_ref[CLS_THREADS];
+    __shared__ unsigned s_flag[CLS_THREADS];
+    __shared__ unsigned s_wave_cnt[CLS_THREADS / 64], s_base;
+    const int tid = threadIdx.x;
+    const int l0 = blockIdx.x * CLS_THREADS;
+    const int nl = min(CLS_THREADS, a.n.n_loci - l0);
+    const unsigned ref = (tid < nl) ? a.n.ref_base[l0 + tid] : 4u;
+    s_ref[tid] = (unsigned char)ref;
+    s_flag[tid] = a.d.is_forced_output ? 1u : 0u;
+    __syncthreads();
+    if (!a.d.is_forced_output) {
+        flag_nonref_loci(a.n, l0, nl, s_off, s_ref, s_flag);
+        flag_nonref_loci(a.t, l0, nl, s_off, s_ref, s_flag);
+    }
+    const bool active = (tid < nl) && (ref < 4u) && (s_flag[tid] != 0u);
+    const unsigned long long m = __ballot(active);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) s_wave_cnt[wave] = unsigned(__popcll(m));
+    __syncthreads();
+    if (tid == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < CLS_THREADS / 64; ++w) {
+            const unsigned c = s_wave_cnt[w];
+            s_wave_cnt[w] = tot;
+            tot += c;
+        }
+        s_base = tot ? atomicAdd(a.work, tot) : 0u;
+    }
+    __syncthreads();
+    if (active) a.work[1 + s_base + s_wave_cnt[wave] + unsigned(__popcll(m & ((1ull << lane) - 1ull)))] = unsigned(l0 + tid);
+}
+
+// S1: likelihoods + posterior of the queued loci, one thread per locus, 64 queue entries per wave
+__global__ __launch_bounds__(SOM_THREADS) __attribute__((amdgpu_waves_per_eu(SOM_WPE, SOM_WPE))) void somatic_snv_kernel(const SomArgs a)
+{
+    __shared__ uint32_t s_rows[SOM_WAVES][64 * ROW_DW];
+    __shared__ __attribute__((aligned(16))) QRow s_q[N_QROWS];
 
     const int tid = threadIdx.x;
-    const int l0 = blockIdx.x * SOM_THREADS;
-    const int nl = min(SOM_THREADS, a.n.n_loci - l0);
-    for (int q = tid; q < SK_NQ6; q += SOM_THREADS) {
-        const SkTables* __restrict__ T = a.tab;
-        QRow r;
-        r.v0 = T->s_v0[q];
-        r.v1 = T->s_v1[q];
-        r.v2 = T->s_v2[q];
-        r.off_ref = T->t_off_ref[q];
-        r.off_alt = T->t_off_alt[q];
-        r.pad[0] = r.pad[1] = r.pad[2] = 0.f;
-#pragma unroll
-        for (int k = 0; k < HET_RES; ++k) {
-            r.c0[k] = T->s_c0[k][q];
-            r.c1[k] = T->s_c1[k][q];
-            r.t0[k] = T->t_c0[k][q];
-            r.t1[k] = T->t_c1[k][q];
-        }
-        s_q[q] = r;
-    }
+    const unsigned n_work = a.work[0];
+    if (unsigned(blockIdx.x) * SOM_THREADS >= n_work) return;
+    fill_qrows(a.tab, s_q, tid, SOM_THREADS);
+    __syncthreads();
     const float ln_one_half = a.tab->s_ln_one_half;
-    const int l = l0 + tid;
-    const unsigned ref = (tid < nl) ? a.n.ref_base[l] : 4u;
-
+    const unsigned w = unsigned(blockIdx.x) * SOM_THREADS + unsigned(tid);
+    const int l = (w < n_work) ? int(a.work[1 + w]) : -1;
+    const unsigned ref = (l >= 0) ? a.n.ref_base[l] : 0u;
+    uint32_t* rows = s_rows[tid >> 6];
     sk_somatic_snv_call res;
     memset(&res, 0, sizeof(res));
-    bool n_allref = true, t_allref = true;
-    // (the first __syncthreads inside for_each_locus_staged also publishes s_q)
-    for_each_locus_staged(a.n, l0, nl, s_calls, s_off, [&](const int, const uint16_t* calls, const int n) {
-        if (ref < 4) sample_lhood<false>(calls, n, ref, s_q, ln_one_half, res.normal_lhood, n_allref, res.normal_alt_id);
-    });
-    for_each_locus_staged(a.t, l0, nl, s_calls, s_off, [&](const int, const uint16_t* calls, const int n) {
-        if (ref < 4) sample_lhood<true>(calls, n, ref, s_q, ln_one_half, res.tumor_lhood, t_allref, res.tumor_alt_id);
-    });
-    if (tid >= nl) return;
-    if (ref >= 4 || (!a.d.is_forced_output && n_allref && t_allref)) { // N reference / early-out (:251-254)
-        memset(&res, 0, sizeof(res));
-        a.out[l] = res;
-        return;
-    }
+    sample_lhood<false>(a.n, l, ref, rows, s_q, ln_one_half, res.normal_lhood, res.normal_alt_id);
+    sample_lhood<true>(a.t, l, ref, rows, s_q, ln_one_half, res.tumor_lhood, res.tumor_alt_id);
+    if (l < 0) return;
     res.is_called = 1;
     calculate_result_set_grid(a.d, res.normal_lhood, res.tumor_lhood, res);
     if (a.d.is_forced_output || res.qphred != 0) { // strand bias (:216-225), skipped by the early return at :184
@@ -257,21 +344,27 @@ void derive(const sk_somatic_snv_options& opt, int is_forced_output, SomaticDeri
 extern "C" {
 
 int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* n, const sk_pileup_batch* t, const sk_somatic_snv_options* opt,
-                                  int is_forced_output, sk_somatic_snv_call* dev_out, void* hip_stream)
+                                  int is_forced_output, sk_somatic_snv_call* dev_out, void* dev_scratch, void* hip_stream)
 {
     SK_REQUIRE_INIT();
-    if (!n || !t || !opt || !dev_out) return sk_fail("sk_somatic_snv_call_batch_dev: null argument");
+    if (!n || !t || !opt || !dev_out || !dev_scratch) return sk_fail("sk_somatic_snv_call_batch_dev: null argument");
     if (n->n_loci != t->n_loci) return sk_fail("sk_somatic_snv_call_batch_dev: normal/tumor n_loci differ");
     if (n->n_loci <= 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
     SomArgs a;
     a.n = *n;
     a.t = *t;
     a.tab = sk_ctx().dev_tables;
     a.out = dev_out;
+    a.work = static_cast<unsigned*>(dev_scratch);
     derive(*opt, is_forced_output, a.d);
-    const int threads = SOM_THREADS;
-    hipLaunchKernelGGL(somatic_snv_kernel, dim3((n->n_loci + threads - 1) / threads), dim3(threads), 0,
-                       static_cast<hipStream_t>(hip_stream), a);
+    // skipped loci report an all-zero record (is_called = 0)
+    SK_HIP(hipMemsetAsync(dev_out, 0, sizeof(sk_somatic_snv_call) * size_t(n->n_loci), st));
+    SK_HIP(hipMemsetAsync(a.work, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(somatic_classify_kernel, dim3((n->n_loci + CLS_THREADS - 1) / CLS_THREADS), dim3(CLS_THREADS), 0, st, a);
+    SK_HIP(hipGetLastError());
+    // sized for every locus being queued; blocks past the end of the queue exit at once
+    hipLaunchKernelGGL(somatic_snv_kernel, dim3((n->n_loci + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a);
     SK_HIP(hipGetLastError());
     return 0;
 }
@@ -291,7 +384,7 @@ int sk_somatic_snv_call_batch(const sk_pileup_batch* hn, const sk_pileup_batch* 
     SkArena ar;
     const size_t need = 2 * (sk_align256(sizeof(int64_t) * (n + 1)) + sk_align256(n) * 2 + 16 * 256) +
                         sk_align256(2 * hn->call_off[n]) + sk_align256(2 * ht->call_off[n]) +
-                        sk_align256(sizeof(sk_somatic_snv_call) * n) + 4096;
+                        sk_align256(sizeof(sk_somatic_snv_call) * n) + sk_align256(4 * (size_t(n) + 4)) + 4096;
     if (ar.reserve(need)) return 1;
     auto up = [&](const sk_pileup_batch* hb, sk_pileup_batch& d) -> int {
         if (hb->call_off[0] != 0) return sk_fail("pileup batch: call_off must start at 0");
@@ -315,7 +408,8 @@ int sk_somatic_snv_call_batch(const sk_pileup_batch* hn, const sk_pileup_batch* 
     sk_pileup_batch dn, dt;
     if (up(hn, dn) || up(ht, dt)) return 1;
     sk_somatic_snv_call* dout = ar.take<sk_somatic_snv_call>(n);
-    if (sk_somatic_snv_call_batch_dev(&dn, &dt, opt, is_forced_output, dout, ctx.stream)) return 1;
+    unsigned* work = ar.take<unsigned>(size_t(n) + 4);
+    if (sk_somatic_snv_call_batch_dev(&dn, &dt, opt, is_forced_output, dout, work, ctx.stream)) return 1;
     SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_snv_call) * n, hipMemcpyDeviceToHost, ctx.stream));
     SK_HIP(hipStreamSynchronize(ctx.stream));
     return 0;

@@ -137,8 +137,11 @@ def somatic_snv_call_dev(normal, tumor, opt=None, is_forced_output=False):
         normal.som_out = torch.empty(normal.n_loci * capi.SOMATIC_CALL_DTYPE.itemsize, dtype=torch.uint8,
                                      device=normal.device)
     sn, st = normal.struct(with_de=False), tumor.struct(with_de=False)
+    if getattr(normal, "som_scratch", None) is None:
+        normal.som_scratch = torch.empty(4 * (normal.n_loci + 4), dtype=torch.uint8, device=normal.device)
     capi._check(capi.lib().sk_somatic_snv_call_batch_dev(C.byref(sn), C.byref(st), C.byref(opt), int(is_forced_output),
-                                                         C.c_void_p(normal.som_out.data_ptr()), _stream_ptr()))
+                                                         C.c_void_p(normal.som_out.data_ptr()),
+                                                         C.c_void_p(normal.som_scratch.data_ptr()), _stream_ptr()))
     return normal.som_out
 
 

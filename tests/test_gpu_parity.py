@@ -252,6 +252,49 @@ def test_somatic_snv(gpu):
         assert close_ll(got["strand_bias"], want["strand_bias"])
 
 
+def test_somatic_snv_skipped_deep_and_empty_loci(gpu):
+    """the queue of non-skipped loci: all-reference loci (the reference's early return), 'N' reference, empty pileups,
+    one locus far deeper than the staging chunk, a locus count that is not a multiple of the block size"""
+    from strelka_amd import capi
+    rng = np.random.default_rng(205)
+    n_loci = 777
+    ref = rng.integers(0, 4, n_loci).astype(np.uint8)
+    ref[rng.random(n_loci) < 0.05] = 4
+    kind = rng.integers(0, 4, n_loci)  # 0: all-ref both, 1: noisy, 2: empty normal, 3: all-ref normal / variant tumor
+
+    def sample(depth_mean, is_tumor):
+        depth = rng.poisson(depth_mean, n_loci)
+        depth[kind == 2] = 0 if not is_tumor else depth[kind == 2]
+        depth[5] = 3000 if is_tumor else 1500  # >> CHUNK
+        off = np.zeros(n_loci + 1, np.int64)
+        np.cumsum(depth, out=off[1:])
+        total = int(off[-1])
+        locus = np.repeat(np.arange(n_loci), depth)
+        r = np.minimum(ref[locus], 3)
+        alt = (r + 1 + rng.integers(0, 3, total)) % 4
+        p_alt = np.where(kind[locus] == 1, 0.05, np.where((kind[locus] == 3) & is_tumor, 0.3, 0.0))
+        p_alt = np.where(locus == 5, 0.2, p_alt)
+        base = np.where(rng.random(total) < p_alt, alt, r).astype(np.uint8)
+        q = rng.choice(synth.QUAL_VALUES, total, p=synth.QUAL_PROBS)
+        return capi.HostPileupBatch(off, capi.make_call(q, base, rng.integers(0, 2, total), 0, 0, 0), ref)
+
+    n, t = sample(30, False), sample(60, True)
+    for forced in (False, True):
+        got = gpu.somatic_snv_call(n, t, is_forced_output=forced)
+        want = pyoracle.somatic_snv_call(n, t, is_forced_output=forced)
+        assert np.array_equal(got["is_called"], want["is_called"])
+        assert 0.2 < want["is_called"].mean() < 1.0
+        for f in ("normal_lhood", "tumor_lhood"):
+            assert np.array_equal(got[f][:, :21].view(np.uint32), want[f][:, :21].view(np.uint32)), f
+        assert close_ll(got["tumor_lhood"][:, 21:], want["tumor_lhood"][:, 21:])
+        for f in ("normal_alt_id", "tumor_alt_id", "max_gt", "ntype"):
+            assert np.array_equal(got[f], want[f]), f
+        assert np.abs(got["qphred"] - want["qphred"]).max() <= 1
+        assert np.abs(got["from_ntype_qphred"] - want["from_ntype_qphred"]).max() <= 1
+        skipped = want["is_called"] == 0
+        assert not got["normal_lhood"][skipped].any() and not got["qphred"][skipped].any()
+
+
 def test_pileup_edge_cases(gpu):
     from strelka_amd import capi
     # empty loci, single-call loci, all-filtered loci, N reference

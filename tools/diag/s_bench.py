@@ -13,3 +13,4 @@ for _ in range(5): run()
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / 5 * 1e3
 print("somatic SNV: %d loci, normal calls %d, tumor calls %d: %.2f ms  %.3e loci/s" % (dn.n_loci, dn.n_calls, dt.n_calls, ms, dn.n_loci / ms * 1e3))
+print("queued loci:", int(dn.som_scratch.view(torch.int32)[0].item()), "of", dn.n_loci)
