@@ -189,7 +189,8 @@ def main():
     del dns, dts
 
     traffic = pmc_traffic(args)
-    traffic_s = traffic
+    som_kernels = ("somatic_classify_kernel", "somatic_lhood_kernel", "somatic_posterior_kernel")
+    som_traffic = sum(traffic[k] for k in som_kernels) if all(k in traffic for k in som_kernels) else None
     out = {
         "metric": "candidate-alignment scoring cells/s (read bases x candidate alignments; Strelka2 has no pair-HMM, "
                   "SURVEY.md section 0) + germline loci/s",
@@ -205,9 +206,9 @@ def main():
         "pileup_reads_per_step_per_gpu": rbatch.n_reads,
         "somatic_loci_per_s": sloci / dt_s, "somatic_ms_per_step": dt_s / args.steps * 1e3,
         "somatic_loci_per_step_per_gpu": somatic_loci_n,
-        "roofline_somatic": {"kernel": "somatic_snv_kernel", "bound": "hbm", "achieved": (2 * somatic_calls + 273 * somatic_loci_n) / (kms_s * 1e-3) / 1e9,
+        "roofline_somatic": {"kernel": "somatic_classify_kernel+somatic_lhood_kernel+somatic_posterior_kernel", "bound": "hbm", "achieved": (2 * somatic_calls + 273 * somatic_loci_n) / (kms_s * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (2 * somatic_calls + 273 * somatic_loci_n) / (kms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": traffic_s.get("somatic_snv_kernel"), "algorithmic_bytes_per_launch": 2 * somatic_calls + 273 * somatic_loci_n,
+                             "traffic": som_traffic, "algorithmic_bytes_per_launch": 2 * somatic_calls + 273 * somatic_loci_n,
                              "kernel_ms": kms_s},
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
         "roofline": {"kernel": "score_wave_per_read", "bound": "hbm", "achieved": ach_a, "peak": HBM_PEAK_GBS,

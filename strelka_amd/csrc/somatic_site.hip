@@ -16,6 +16,8 @@
 
 #include "somatic_common.h"
 
+#include <cstddef>
+
 int sk_upload_pileup_internal(const sk_pileup_batch* hb, bool need_de, SkArena& ar, size_t extra_bytes,
                               sk_pileup_batch& d, hipStream_t st, int64_t& total_calls);
 
@@ -81,11 +83,22 @@ __device__ __forceinline__ void fill_qrows(const SkTables* __restrict__ T, QRow*
     }
 }
 
-constexpr int SOM_WPE = 4;                 // waves per SIMD the register allocation is held to (128 VGPRs)
+// measured on the bench input (ms per 2^20 loci, S1 / S2): (4 waves/SIMD, 32-call chunks) 0.78, (4, 16) 0.75,
+// (5, 16) 0.71; S2 at 1 / 2 / 3 waves per SIMD 0.34 / 0.27 / 0.30
+#ifndef SOM_WPE
+#define SOM_WPE 5       // S1: waves per SIMD the register allocation is held to (96 VGPRs; it needs 90)
+#endif
+#ifndef SOM_CHUNK
+#define SOM_CHUNK 16
+#endif
+#ifndef SOM_POST_WPE
+#define SOM_POST_WPE 2  // S2: 256 VGPRs, no spills
+#endif
 constexpr int SOM_WAVES = 4;               // waves per block; each works through its own 64 queued loci
 constexpr int SOM_THREADS = 64 * SOM_WAVES;
-constexpr int CHUNK = 32;                  // calls of one locus staged per round
-constexpr int ROW_DW = CHUNK / 2 + 1;      // row stride in dwords: 17 keeps the lanes' row reads on distinct LDS banks
+constexpr int CHUNK = SOM_CHUNK;           // calls of one locus staged per round
+constexpr int ROW_DW = CHUNK / 2 + 1;      // row stride in dwords: odd, so the lanes' row reads fall on distinct LDS banks
+constexpr int LOCI_PER_TRIP = 64 / CHUNK;  // loci one staging trip of the wave fetches (CHUNK lanes each)
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -163,11 +176,11 @@ __device__ __forceinline__ void sample_lhood(const sk_pileup_batch& b, const int
     const uint16_t* __restrict__ calls = b.calls;
     uint16_t* rows16 = reinterpret_cast<uint16_t*>(rows);
     const uint16_t* own = rows16 + lane * (2 * ROW_DW);
-    const int half = lane >> 5, k = lane & 31;
+    const int part = lane / CHUNK, k = lane % CHUNK;
     for (int c = 0; c < maxn; c += CHUNK) {
 #pragma unroll 8
-        for (int j2 = 0; j2 < 32; ++j2) {
-            const int j = 2 * j2 + half;
+        for (int j2 = 0; j2 < 64 / LOCI_PER_TRIP; ++j2) {
+            const int j = LOCI_PER_TRIP * j2 + part;
             const int64_t gj = __shfl(g0, j);
             const int nj = __shfl(n, j);
             if (c + k < nj) rows16[j * (2 * ROW_DW) + k] = calls[gj + c + k];
@@ -266,10 +279,38 @@ __global__ __launch_bounds__(CLS_THREADS) void somatic_classify_kernel(const Som
     if (active) a.work[1 + s_base + s_wave_cnt[wave] + unsigned(__popcll(m & ((1ull << lane) - 1ull)))] = unsigned(l0 + tid);
 }
 
-// S1: likelihoods + posterior of the queued loci, one thread per locus, 64 queue entries per wave
-__global__ __launch_bounds__(SOM_THREADS) __attribute__((amdgpu_waves_per_eu(SOM_WPE, SOM_WPE))) void somatic_snv_kernel(const SomArgs a)
+// write one 30-float block of the wave's 64 result records (at `dword_off` inside the record) through the wave's LDS rows,
+// so that 15 consecutive lanes store the 120 contiguous bytes of one record instead of every lane scattering dwords
+__device__ __forceinline__ void emit_lhood_block(uint32_t* rows, const int l, const float* v, sk_somatic_snv_call* out,
+                                                 const int dword_off)
 {
-    __shared__ uint32_t s_rows[SOM_WAVES][64 * ROW_DW];
+    constexpr int PER = (64 * ROW_DW) / GRID >= 32 ? 32 : 16; // records per pass that fit the rows buffer
+    static_assert(PER * GRID <= 64 * ROW_DW, "a pass fits the rows buffer");
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int h = 0; h < 64 / PER; ++h) {
+        wave_sync();
+        if (lane / PER == h) {
+#pragma unroll
+            for (int i = 0; i < GRID; ++i) rows[(lane % PER) * GRID + i] = __float_as_uint(v[i]);
+        }
+        wave_sync();
+        for (int i0 = 0; i0 < PER * (GRID / 2); i0 += 64) { // all lanes take every trip: __shfl reads 0 from an idle lane
+            const int idx = i0 + lane;
+            const int j = min(idx / (GRID / 2), PER - 1), c = idx - j * (GRID / 2);
+            const int lj = __shfl(l, PER * h + j);
+            if (idx < PER * (GRID / 2) && lj >= 0) {
+                const uint2 w = *reinterpret_cast<const uint2*>(rows + j * GRID + 2 * c);
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(out + lj) + dword_off + 2 * c) = w;
+            }
+        }
+    }
+}
+
+// S1: the 2 x 30 likelihoods of the queued loci, one thread per locus, 64 queue entries per wave
+__global__ __launch_bounds__(SOM_THREADS) __attribute__((amdgpu_waves_per_eu(SOM_WPE, SOM_WPE))) void somatic_lhood_kernel(const SomArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[SOM_WAVES][64 * ROW_DW];
     __shared__ __attribute__((aligned(16))) QRow s_q[N_QROWS];
 
     const int tid = threadIdx.x;
@@ -282,22 +323,74 @@ __global__ __launch_bounds__(SOM_THREADS) __attribute__((amdgpu_waves_per_eu(SOM
     const int l = (w < n_work) ? int(a.work[1 + w]) : -1;
     const unsigned ref = (l >= 0) ? a.n.ref_base[l] : 0u;
     uint32_t* rows = s_rows[tid >> 6];
-    sk_somatic_snv_call res;
-    memset(&res, 0, sizeof(res));
-    sample_lhood<false>(a.n, l, ref, rows, s_q, ln_one_half, res.normal_lhood, res.normal_alt_id);
-    sample_lhood<true>(a.t, l, ref, rows, s_q, ln_one_half, res.tumor_lhood, res.tumor_alt_id);
-    if (l < 0) return;
-    res.is_called = 1;
-    calculate_result_set_grid(a.d, res.normal_lhood, res.tumor_lhood, res);
-    if (a.d.is_forced_output || res.qphred != 0) { // strand bias (:216-225), skipped by the early return at :184
-        float symm = res.tumor_lhood[SOM_SIZE];
-        for (int i = SOM_SIZE; i < PRESTRAND; ++i) symm = (symm < res.tumor_lhood[i]) ? res.tumor_lhood[i] : symm;
-        float strand = res.tumor_lhood[PRESTRAND];
-        for (int i = PRESTRAND; i < GRID; ++i) strand = (strand < res.tumor_lhood[i]) ? res.tumor_lhood[i] : strand;
-        const float dd = __fsub_rn(strand, symm);
-        res.strand_bias = (0.f < dd) ? dd : 0.f;
+    unsigned alt_n, alt_t;
+    {
+        float lh[GRID];
+        sample_lhood<false>(a.n, l, ref, rows, s_q, ln_one_half, lh, alt_n);
+        emit_lhood_block(rows, l, lh, a.out, 0);
     }
-    a.out[l] = res;
+    {
+        float lh[GRID];
+        sample_lhood<true>(a.t, l, ref, rows, s_q, ln_one_half, lh, alt_t);
+        emit_lhood_block(rows, l, lh, a.out, GRID);
+    }
+    if (l >= 0) {
+        a.out[l].normal_alt_id = alt_n;
+        a.out[l].tumor_alt_id = alt_t;
+    }
+}
+
+// S2: posterior of the queued loci from the likelihoods S1 left in their records (a13)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOM_POST_WPE, SOM_POST_WPE))) void somatic_posterior_kernel(const SomArgs a)
+{
+    const unsigned w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= a.work[0]) return;
+    const int l = int(a.work[1 + w]);
+    sk_somatic_snv_call* o = a.out + l;
+    float nl[PRESTRAND], tl[GRID];
+    {
+        const float4* p = reinterpret_cast<const float4*>(o->normal_lhood); // records are 16-byte aligned (272 = 17 x 16)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float4 v = p[i];
+            nl[4 * i] = v.x;
+            nl[4 * i + 1] = v.y;
+            nl[4 * i + 2] = v.z;
+            nl[4 * i + 3] = v.w;
+        }
+        nl[20] = o->normal_lhood[20];
+        const float2* t = reinterpret_cast<const float2*>(o->tumor_lhood); // 8-byte aligned (offset 120)
+#pragma unroll
+        for (int i = 0; i < GRID / 2; ++i) {
+            const float2 v = t[i];
+            tl[2 * i] = v.x;
+            tl[2 * i + 1] = v.y;
+        }
+    }
+    struct
+    {
+        uint32_t max_gt;
+        int32_t qphred, from_ntype_qphred;
+        uint32_t ntype;
+    } rs;
+    calculate_result_set_grid(a.d, nl, tl, rs);
+    float strand_bias = 0.f;
+    if (a.d.is_forced_output || rs.qphred != 0) { // strand bias (:216-225), skipped by the early return at :184
+        float symm = tl[SOM_SIZE];
+#pragma unroll
+        for (int i = SOM_SIZE; i < PRESTRAND; ++i) symm = (symm < tl[i]) ? tl[i] : symm;
+        float strand = tl[PRESTRAND];
+#pragma unroll
+        for (int i = PRESTRAND; i < GRID; ++i) strand = (strand < tl[i]) ? tl[i] : strand;
+        const float dd = __fsub_rn(strand, symm);
+        strand_bias = (0.f < dd) ? dd : 0.f;
+    }
+    // two wide stores (the tail of the record is 16-byte aligned) instead of six scattered dwords
+    static_assert(offsetof(sk_somatic_snv_call, max_gt) % 16 == 0 && offsetof(sk_somatic_snv_call, strand_bias) == offsetof(sk_somatic_snv_call, max_gt) + 16 &&
+                      offsetof(sk_somatic_snv_call, is_called) == offsetof(sk_somatic_snv_call, strand_bias) + 4,
+                  "record tail layout");
+    *reinterpret_cast<uint4*>(&o->max_gt) = make_uint4(rs.max_gt, uint32_t(rs.qphred), uint32_t(rs.from_ntype_qphred), rs.ntype);
+    *reinterpret_cast<uint2*>(&o->strand_bias) = make_uint2(__float_as_uint(strand_bias), 1u);
 }
 
 double log1p_switch(const double x)
@@ -364,7 +457,9 @@ int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* n, const sk_pileup_batc
     hipLaunchKernelGGL(somatic_classify_kernel, dim3((n->n_loci + CLS_THREADS - 1) / CLS_THREADS), dim3(CLS_THREADS), 0, st, a);
     SK_HIP(hipGetLastError());
     // sized for every locus being queued; blocks past the end of the queue exit at once
-    hipLaunchKernelGGL(somatic_snv_kernel, dim3((n->n_loci + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a);
+    hipLaunchKernelGGL(somatic_lhood_kernel, dim3((n->n_loci + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a);
+    SK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(somatic_posterior_kernel, dim3((n->n_loci + 255) / 256), dim3(256), 0, st, a);
     SK_HIP(hipGetLastError());
     return 0;
 }

@@ -32,4 +32,13 @@ for k in sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"])):
     fk, wk = sum(f) / len(f), sum(w) / len(w)
     out[k] = dict(launches=len(f), fetch_kib=fk, write_kib=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024,
                   hbm_bytes_uncorrected=(fk + wk) * 1024)
-json.dump(out, sys.stdout, indent=1)
+# the per-launch workload these counters belong to: bench.py's defaults (tools/gpu_round.sh runs it without size flags);
+# bench.py only quotes `traffic` from this file when its own run has the same workload
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+argv, sys.argv = sys.argv, [sys.argv[0]]
+a = bench.parse()
+sys.argv = argv
+workload = dict(reads_per_step_per_gpu=a.reads, loci_per_step_per_gpu=a.loci, unique_reads=a.unique_reads,
+                unique_loci=a.unique_loci, pileup_reads=a.pileup_reads, somatic_loci=a.somatic_loci)
+json.dump(dict(workload=workload, kernels=out), sys.stdout, indent=1)
