@@ -9,12 +9,11 @@
 //                                       (L/starling_common/AlleleGroupGenotype.cpp:185-258)
 //
 // Mapping: one 64-lane wavefront per indel / allele group.  The reference adds one double term per read to each state
-// (sequentially, in read-id order); the TERMS are independent, so lanes evaluate them for 64 reads at a time (each costs
-// several exp/log/log1p evaluations) into LDS, then one lane per state performs the adds in read order -- the order
-// and rounding of every add is the reference's.
+// (sequentially, in read-id order); the TERMS are independent, so lanes evaluate them for 64 reads at a time into LDS,
+// then one lane per state performs the adds in read order -- the order and rounding of every add is the reference's.
 //
-// Double exp/log/log1p are the device library's; they differ from glibc's in the last ulp now and then, so likelihoods
-// agree with the oracle to ~1e-15 relative, not bit-for-bit.
+// Double exp/log are the device library's and I1 evaluates each term in an algebraically equal form with one log per
+// state (see mix_term), so likelihoods agree with the oracle to ~1e-15 relative, not bit-for-bit (tests: 1e-12).
 
 #include "somatic_common.h"
 
@@ -81,6 +80,61 @@ struct GridArgs
     double loghalf;
 };
 
+// get_het_observed_allele_ratio as a probability instead of the pair of logs the reference keeps: (1 - p, p) with
+// log(1 - p) == log_ref_prob and log(p) == log_indel_prob.  Returns false when the reference leaves its inputs untouched
+// (total_path_term <= 0), in which case the caller's default ratio applies.
+__device__ __forceinline__ bool het_observed_indel_prob(const unsigned read_length, const unsigned min_overlap, const unsigned del_len,
+                                                        const unsigned ins_len, const double het_allele_ratio, double& ref_prob,
+                                                        double& indel_prob)
+{
+    const unsigned base_expect = ((read_length + 1) < (2 * min_overlap)) ? 0 : (read_length + 1) - (2 * min_overlap);
+    const double ref_path_expect = double(base_expect + min(del_len, base_expect));
+    const double indel_path_expect = double(base_expect + min(ins_len, base_expect));
+    const double ref_path_term = __dmul_rn(__dsub_rn(1., het_allele_ratio), ref_path_expect);
+    const double indel_path_term = __dmul_rn(het_allele_ratio, indel_path_expect);
+    const double total_path_term = __dadd_rn(ref_path_term, indel_path_term);
+    if (!(total_path_term > 0)) return false;
+    indel_prob = __ddiv_rn(indel_path_term, total_path_term);
+    ref_prob = __dsub_rn(1., indel_prob);
+    return true;
+}
+
+// One read's term of a het state, integrateOutMappingStatus(logsum(noindel + log(1-p), hom + log(p))), evaluated as
+//     T + log( (e^(A-T) * ((1-p) e^(a-m) + p e^(b-m))) + e^(M-T) )
+// with a = noindel, b = hom, m = max(a,b), A = m + correct_mapping_log_prior, M = random_base_match_log_prob * nonAmbig,
+// T = max(A, M).  This is the same quantity as the reference's two nested log-sum-exp calls
+// (starling_indel_call_pprob_digt.cpp:126-136, readMappingAdjustmentUtil.hh:44-56) with one log per state instead of two
+// exp + two log1p + two log; the scaled exponentials are shared by all 21 states of the read.  Both forms carry a
+// rounding error of a few ulp of |T| (~1e-13): the results agree to ~1e-15 relative, not bit for bit.
+struct ReadExp
+{
+    double T, wa, wb, wm; // wa = e^(A-T) e^(a-m), wb = e^(A-T) e^(b-m), wm = e^(M-T)
+};
+__device__ __forceinline__ ReadExp read_exponentials(const MapParams& mp, const unsigned non_ambig, const double a, const double b)
+{
+    const bool a_lt_b = (a < b);
+    const double m = a_lt_b ? b : a;
+    const double A = __dadd_rn(m, mp.correct_mapping_log_prior);
+    const double M = __dmul_rn(mp.random_base_match_log_prob, double(non_ambig));
+    const bool A_lt_M = (A < M);
+    ReadExp r;
+    r.T = A_lt_M ? M : A;
+    // of each pair of scaled exponentials one is exp(0): two exp() per read
+    double ex = exp(-fabs(__dsub_rn(a, b)));
+    if (!(ex == ex)) ex = 1.; // a == b == -inf
+    const double eT = exp(-fabs(__dsub_rn(A, M)));
+    const double sA = A_lt_M ? eT : 1.;
+    r.wm = A_lt_M ? 1. : eT;
+    r.wa = __dmul_rn(sA, a_lt_b ? ex : 1.);
+    r.wb = __dmul_rn(sA, a_lt_b ? 1. : ex);
+    return r;
+}
+__device__ __forceinline__ double mix_term(const ReadExp& r, const double ref_prob, const double indel_prob)
+{
+    const double mix = __dadd_rn(__dmul_rn(ref_prob, r.wa), __dmul_rn(indel_prob, r.wb));
+    return __dadd_rn(r.T, log(__dadd_rn(mix, r.wm)));
+}
+
 __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a)
 {
     __shared__ double s_term[N_STATES][WAVE];
@@ -113,26 +167,25 @@ __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a
                 const double hom_lnp = double(a.b.indel_lnp[g]);
                 const unsigned na = a.b.non_ambig[g];
                 const unsigned rl = a.b.read_length[g];
+                const ReadExp e = read_exponentials(a.map, na, noindel_lnp, hom_lnp);
                 // SOMATIC_DIGT / STAR_DIINDEL: 0 = REF/NOINDEL, 1 = HOM, 2 = HET
-                s_term[0][lane] = integrate_out_mapping(a.map, na, noindel_lnp);
-                s_term[1][lane] = integrate_out_mapping(a.map, na, hom_lnp);
+                s_term[0][lane] = mix_term(e, 1., 0.);
+                s_term[1][lane] = mix_term(e, 0., 1.);
                 {
-                    double lr = a.loghalf, li = a.loghalf;
-                    if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, 0.5, lr, li);
-                    s_term[2][lane] = integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li)));
+                    double pr = 0.5, pi = 0.5;
+                    if (!is_breakpoint) het_observed_indel_prob(rl, flank, del_len, ins_len, 0.5, pr, pi);
+                    s_term[2][lane] = mix_term(e, pr, pi);
                 }
                 for (int i = 0; i < SK_HET_RES; ++i) {
                     { // het_lhood_low -> grid[i]
-                        double lr = a.log_chet_ratio[i], li = a.log_het_ratio[i];
-                        if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, a.het_ratio[i], lr, li);
-                        s_term[3 + i][lane] =
-                            integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li)));
+                        double pr = a.chet_ratio[i], pi = a.het_ratio[i];
+                        if (!is_breakpoint) het_observed_indel_prob(rl, flank, del_len, ins_len, a.het_ratio[i], pr, pi);
+                        s_term[3 + i][lane] = mix_term(e, pr, pi);
                     }
                     { // het_lhood_high -> grid[2*HET_RES-(i+1)]
-                        double lr = a.log_het_ratio[i], li = a.log_chet_ratio[i];
-                        if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, a.chet_ratio[i], lr, li);
-                        s_term[3 + (2 * SK_HET_RES - (i + 1))][lane] =
-                            integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li)));
+                        double pr = a.het_ratio[i], pi = a.chet_ratio[i];
+                        if (!is_breakpoint) het_observed_indel_prob(rl, flank, del_len, ins_len, a.chet_ratio[i], pr, pi);
+                        s_term[3 + (2 * SK_HET_RES - (i + 1))][lane] = mix_term(e, pr, pi);
                     }
                 }
             }
