@@ -10,10 +10,12 @@
 // The last lane of a strip leaves its row in LDS for lane 0 of the next strip.  Scores are plain int32 (the reference's
 // ScoreType for this aligner), including its -10000 "bad" value that is added to like any other number; max3 keeps the
 // reference's tie order (first of equals; L/alignment/AlignerBase.hh:75-95).  Back-pointers (3 x 2 bits per cell) are one
-// byte per cell in anti-diagonal-major order -- the 64 lanes write 64 consecutive bytes per step -- in LDS when the
-// matrix fits, else in global scratch.  Lane 0 then picks the traceback start exactly in the order the reference offers
-// candidates (updateBacktrace, L/alignment/Alignment.hh) and walks back (SingleRefAlignerSharedImpl.hh:96-195), and
-// expands matches to '=' / 'X' (L/blt_util/align_path_impl.hh:36-86).
+// byte per cell in anti-diagonal-major order -- the 64 lanes write 64 consecutive bytes per step -- in global scratch
+// (L2-resident): keeping the whole matrix in LDS left one wave per CU, and the sweep is a chain of dependent shuffles
+// that needs several waves per SIMD to hide.  The traceback start is picked exactly in the order the reference offers
+// candidates (updateBacktrace, L/alignment/Alignment.hh); the walk back (SingleRefAlignerSharedImpl.hh:96-195) reads the
+// pointers through a 64-anti-diagonal LDS window that the whole wave refills with coalesced loads (the walk only ever
+// moves to lower anti-diagonals inside a strip); matches are expanded to '=' / 'X' (L/blt_util/align_path_impl.hh:36-86).
 //
 // Roofline: a latency-bound integer DP (~30 instructions per anti-diagonal step); bytes are negligible.
 
@@ -28,7 +30,7 @@ namespace
 constexpr int WAVE = 64;
 constexpr int BAD = -10000;
 constexpr int MAX_LEN = 1024;
-constexpr int LDS_PTR_BUDGET = 96 * 1024;
+constexpr int WIN = 64; // anti-diagonals of one strip held in LDS during the traceback
 enum { ST_MATCH = 0, ST_DELETE = 1, ST_INSERT = 2 };
 
 struct GaArgs
@@ -40,10 +42,10 @@ struct GaArgs
     sk_path_seg* out_path;
     sk_path_seg* tmp_path; // same layout as out_path: reversed raw segments
     int32_t* out_nseg;
-    uint8_t* ptr_scratch;  // back-pointers of problems too large for LDS
+    uint8_t* ptr_scratch;  // back-pointers
     const int64_t* ptr_off;
     int max_ref;           // LDS sizing: boundary rows and the reference copy
-    int lds_ptr_bytes;     // back-pointer bytes available in LDS
+    int max_query;         // LDS sizing: last-column scores
 };
 
 __device__ __forceinline__ unsigned max3(int& mx, const int v0, const int v1, const int v2)
@@ -89,16 +91,15 @@ __global__ __launch_bounds__(WAVE) void global_align_kernel(const GaArgs a)
     const sk_align_scores sc = a.sc;
     const bool allow_ins = sc.is_allow_edge_insertion != 0, req_del = sc.is_require_edge_deletion != 0;
 
-    // LDS: [reference copy][last-column match scores (Q+1)][two boundary rows of (R+1) x {m,d,i}][back-pointers]
+    // LDS: [back-pointer window][reference copy][last-column match scores (Q+1)][two boundary rows of (R+1) x {m,d,i}]
     const int RW = a.max_ref + 1;
-    char* s_ref = reinterpret_cast<char*>(smem);
-    int* s_last = reinterpret_cast<int*>(smem + ((RW + 3) & ~3));
-    int* s_rowA = s_last + (MAX_LEN + 1);
+    uint8_t* s_win = smem;
+    char* s_ref = reinterpret_cast<char*>(smem + WIN * WAVE);
+    int* s_last = reinterpret_cast<int*>(smem + WIN * WAVE + ((RW + 3) & ~3));
+    int* s_rowA = s_last + (a.max_query + 1);
     int* s_rowB = s_rowA + 3 * RW;
-    uint8_t* s_ptr = reinterpret_cast<uint8_t*>(s_rowB + 3 * RW);
     const int strips = (Q + WAVE - 1) / WAVE;
-    const int64_t ptr_bytes = int64_t(strips) * (R + WAVE) * WAVE;
-    uint8_t* ptr = (ptr_bytes <= a.lds_ptr_bytes) ? s_ptr : (a.ptr_scratch + a.ptr_off[p]);
+    uint8_t* ptr = a.ptr_scratch + a.ptr_off[p];
 
     for (int i = lane; i < R; i += WAVE) s_ref[i] = gr[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -185,7 +186,10 @@ __global__ __launch_bounds__(WAVE) void global_align_kernel(const GaArgs a)
     fin_m = __shfl(fin_m, owner, WAVE);
     fin_d = __shfl(fin_d, owner, WAVE);
     fin_i = __shfl(fin_i, owner, WAVE);
-    if (lane != 0) return;
+    // every lane walks the (wave-uniform) traceback so that the wave can refill the pointer window together; lane 0 writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
     Bt bt = { b_max, ST_MATCH, Q, b_r, b_init != 0 };
     if (req_del) { // (:214-220)
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(WAVE) void global_align_kernel(const GaArgs a)
     s_last[0] = req_del ? BAD : 0;                          // row 0 at the last column
     for (int q = 0; q < Q; ++q) bt_update(bt, s_last[q] + (Q - q) * sc.off_edge, R, q, ST_MATCH); // (:229-235)
 
-    a.out_score[p] = bt.max;
+    if (lane == 0) a.out_score[p] = bt.max;
     const int64_t po = qo + ro + 4 * int64_t(p);
     sk_path_seg* rev = a.tmp_path + po;
     int nrev = 0;
@@ -207,15 +211,31 @@ __global__ __launch_bounds__(WAVE) void global_align_kernel(const GaArgs a)
     }
     auto update_path = [&](const uint32_t atype) { // AlignerUtil::updatePath
         if (ps_type == atype) return;
-        if (ps_type != SK_SEG_NONE) rev[nrev++] = sk_path_seg{ ps_type, ps_len };
+        if (ps_type != SK_SEG_NONE) {
+            if (lane == 0) rev[nrev] = sk_path_seg{ ps_type, ps_len };
+            nrev++;
+        }
         ps_type = atype;
         ps_len = 0;
     };
+    int win_s = -1, win_lo = 0; // the window holds anti-diagonals [win_lo, win_lo + WIN) of strip win_s
     auto state_ptr = [&](const int q, const int r, const int state) -> int {
         if (r == 0) return (state == ST_INSERT && allow_ins) ? ST_INSERT : ST_MATCH; // column 0 (:72-83)
         if (q == 0) return (state == ST_DELETE && req_del) ? ST_DELETE : ST_MATCH;   // row 0 (:101-116)
-        const int s = (q - 1) / WAVE, j = (q - 1) % WAVE;
-        const unsigned v = ptr[(int64_t(s) * (R + WAVE) + (r + j)) * WAVE + j];
+        const int s = (q - 1) / WAVE, j = (q - 1) % WAVE, t = r + j;
+        if (s != win_s || t < win_lo || t >= win_lo + WIN) {
+            win_s = s;
+            win_lo = max(0, t - (WIN - 1));
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(ptr + (int64_t(s) * (R + WAVE) + win_lo) * WAVE);
+            uint4* dst = reinterpret_cast<uint4*>(s_win);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < WIN * WAVE / 16 / WAVE; ++k) dst[k * WAVE + lane] = src[k * WAVE + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const unsigned v = s_win[(t - win_lo) * WAVE + j];
         return int((v >> (2 * state)) & 3u);
     };
     for (;;) {
@@ -237,6 +257,7 @@ __global__ __launch_bounds__(WAVE) void global_align_kernel(const GaArgs a)
         bt.state = next;
         ps_len++;
     }
+    if (lane != 0) return;
     if (ps_type != SK_SEG_NONE) rev[nrev++] = sk_path_seg{ ps_type, ps_len };
     if (bt.q != 0) rev[nrev++] = sk_path_seg{ SK_SEG_SOFT_CLIP, uint32_t(bt.q) };
     a.out_begin[p] = bt.r;
@@ -301,19 +322,16 @@ int sk_global_align(const sk_global_align_batch* hb, const sk_align_scores* sc, 
         ptr_off[size_t(p) + 1] = ptr_off[size_t(p)] + ((Q + WAVE - 1) / WAVE) * (R + WAVE) * WAVE;
     }
     const int64_t nq = hb->query_off[n], nr = hb->ref_off[n], npath = nq + nr + 4 * int64_t(n);
-    // LDS: reference copy, last column, two boundary rows, then as many back-pointers as fit
+    // LDS: pointer window, reference copy, last column, two boundary rows
     const int RW = maxR + 1;
-    const size_t fixed = size_t((RW + 3) & ~3) + 4 * size_t(MAX_LEN + 1) + 2 * 12 * size_t(RW);
-    const int64_t need_ptr = int64_t((maxQ + WAVE - 1) / WAVE) * (maxR + WAVE) * WAVE;
-    const int lds_ptr = int(std::min<int64_t>(need_ptr, std::max<int64_t>(0, LDS_PTR_BUDGET - int64_t(fixed))));
-    const bool all_in_lds = need_ptr <= lds_ptr;
+    const size_t lds = size_t(WIN) * WAVE + size_t((RW + 3) & ~3) + 4 * size_t(maxQ + 1) + 2 * 12 * size_t(RW) + 16;
 
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
     SkArena ar;
     const size_t need = 2 * sk_align256(8 * (size_t(n) + 1)) + sk_align256(size_t(nq)) + sk_align256(size_t(nr)) +
                         sk_align256(8 * (size_t(n) + 1)) + 2 * sk_align256(8 * size_t(npath)) + 3 * sk_align256(4 * size_t(n)) +
-                        sk_align256(all_in_lds ? 256 : size_t(ptr_off[size_t(n)])) + 16 * 256;
+                        sk_align256(size_t(ptr_off[size_t(n)]) + 16 * WIN * WAVE) + 16 * 256;
     if (ar.reserve(need)) return 1;
     hipStream_t st = ctx.stream;
     GaArgs a;
@@ -341,10 +359,9 @@ int sk_global_align(const sk_global_align_batch* hb, const sk_align_scores* sc, 
     a.out_score = ar.take<int32_t>(size_t(n));
     a.out_begin = ar.take<int32_t>(size_t(n));
     a.out_nseg = ar.take<int32_t>(size_t(n));
-    a.ptr_scratch = ar.take<uint8_t>(all_in_lds ? 1 : size_t(ptr_off[size_t(n)]));
+    a.ptr_scratch = ar.take<uint8_t>(size_t(ptr_off[size_t(n)]) + size_t(WIN) * WAVE); // + slack: a window read may run past the end
     a.max_ref = maxR;
-    a.lds_ptr_bytes = lds_ptr;
-    const size_t lds = fixed + size_t(lds_ptr) + 16;
+    a.max_query = maxQ;
     SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(global_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     hipLaunchKernelGGL(global_align_kernel, dim3(n), dim3(WAVE), lds, st, a);
     SK_HIP(hipGetLastError());
