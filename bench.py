@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--unique-loci", type=int, default=1 << 20)
     ap.add_argument("--pileup-reads", type=int, default=1 << 20, help="reads per step per GPU for the pileup leg (row a8)")
     ap.add_argument("--somatic-loci", type=int, default=1 << 22, help="somatic loci per step per GPU (40x normal + 110x tumor)")
+    ap.add_argument("--indels", type=int, default=1 << 18, help="indel loci per step per GPU for the indel legs (a11, a14)")
+    ap.add_argument("--align-problems", type=int, default=4096, help="GlobalAligner problems per step (next row f2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
     ap.add_argument("--cpu-loci", type=int, default=2000000, help="loci in the CPU-baseline sample")
@@ -188,6 +190,29 @@ def main():
     somatic_loci_n = dns.n_loci
     del dns, dts
 
+    # ---- hot path B (indels): a14 21-state grid likelihoods of one sample at tumor depth; a11 allele-group genotypes ----
+    hrs = synth.readscore_batch(args.indels, rng, depth_mean=110.0)
+    drs = device.DeviceReadScoreBatch(hrs, dev)
+    dt_i, iloci, kms_i = timed(lambda: drs.grid_lhood(), args.steps, args.warmup, drs.n_indels)
+    indel_alg_bytes = 16 * drs.n_reads + 8 * 21 * drs.n_indels  # 16 B per read + 8 B per state
+    hag = synth.allele_group_batch(args.indels, rng)
+    dag = device.DeviceAlleleGroupBatch(hag, dev)
+    dt_g, gloci, kms_g = timed(lambda: dag.genotype_lhoods(), args.steps, args.warmup, dag.n_groups)
+    group_alg_bytes = (8 * capi.MAX_ALT + 5) * dag.n_reads + 128 * dag.n_groups
+    del drs, dag
+
+    # ---- next row f2: GlobalAligner<int>, haplotype vs reference segment, through the host-buffer entry point (the
+    # rate includes the H2D of the sequences and the D2H of the CIGARs; the kernel alone is in profiles/) ----
+    pairs = synth.align_pairs(args.align_problems, rng)
+    ga_cells = sum(len(q) * len(r) for q, r in pairs)
+    ga_steps = max(1, min(args.steps, 5))
+    capi.global_align(pairs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(ga_steps):
+        capi.global_align(pairs)
+    dt_ga = time.perf_counter() - t0
+
     traffic = pmc_traffic(args)
     som_kernels = ("somatic_classify_kernel", "somatic_lhood_kernel", "somatic_posterior_kernel")
     som_traffic = sum(traffic[k] for k in som_kernels) if all(k in traffic for k in som_kernels) else None
@@ -210,6 +235,17 @@ def main():
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (2 * somatic_calls + 273 * somatic_loci_n) / (kms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "traffic": som_traffic, "algorithmic_bytes_per_launch": 2 * somatic_calls + 273 * somatic_loci_n,
                              "kernel_ms": kms_s},
+        "indel_grid_loci_per_s": iloci / dt_i, "indel_grid_ms_per_step": dt_i / args.steps * 1e3,
+        "roofline_indel_grid": {"kernel": "indel_grid_lhood_kernel", "bound": "hbm", "achieved": indel_alg_bytes / (kms_i * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": indel_alg_bytes / (kms_i * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "traffic": traffic.get("indel_grid_lhood_kernel"), "algorithmic_bytes_per_launch": indel_alg_bytes,
+                                "kernel_ms": kms_i},
+        "allele_group_loci_per_s": gloci / dt_g, "allele_group_ms_per_step": dt_g / args.steps * 1e3,
+        "roofline_allele_group": {"kernel": "allele_group_kernel", "bound": "hbm", "achieved": group_alg_bytes / (kms_g * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": group_alg_bytes / (kms_g * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": traffic.get("allele_group_kernel"), "algorithmic_bytes_per_launch": group_alg_bytes,
+                                  "kernel_ms": kms_g},
+        "global_align_cells_per_s_pcie_inclusive": ga_cells * ga_steps / dt_ga, "global_align_problems_per_step": len(pairs),
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
         "roofline": {"kernel": "score_wave_per_read", "bound": "hbm", "achieved": ach_a, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach_a / HBM_PEAK_GBS,

@@ -174,3 +174,51 @@ class DeviceReadBatch:
         capi._check(capi.lib().sk_pileup_reads_dev(C.byref(self.s), self.rb.n_bases, C.byref(self.opt), mode,
                                                    C.byref(self.out), self.scratch.data_ptr(), _stream_ptr()))
         return self.call_off, self.calls
+
+
+class DeviceReadScoreBatch:
+    """sk_readscore_batch resident on the device (a14 likelihood half)."""
+
+    def __init__(self, hb, device="cuda:0"):
+        self.device, self.n_indels = device, hb.n_indels
+        self.n_reads = int(hb.read_off[-1])
+        names = ("read_off", "ref_lnp", "indel_lnp", "alt_lnp", "non_ambig", "read_length", "read_flags", "del_len",
+                 "ins_len", "is_breakpoint")
+        self.t = {k: (None if getattr(hb, k) is None else _t(getattr(hb, k), device)) for k in names}
+        self.out = torch.empty((hb.n_indels, 21), dtype=torch.float64, device=device)
+
+    def struct(self):
+        p = {k: (None if v is None else C.c_void_p(v.data_ptr())) for k, v in self.t.items()}
+        return capi.ReadScoreBatch(self.n_indels, p["read_off"], p["ref_lnp"], p["indel_lnp"], p["alt_lnp"], p["non_ambig"],
+                                   p["read_length"], p["read_flags"], p["del_len"], p["ins_len"], p["is_breakpoint"])
+
+    def grid_lhood(self, opt=None, is_include_tier2=False):
+        opt = opt or capi.indel_options(True)
+        s = self.struct()
+        capi._check(capi.lib().sk_indel_grid_lhood_dev(C.byref(s), C.byref(opt), int(is_include_tier2),
+                                                       C.c_void_p(self.out.data_ptr()), _stream_ptr()))
+        return self.out
+
+
+class DeviceAlleleGroupBatch:
+    """sk_allele_group_batch resident on the device (a11)."""
+
+    def __init__(self, hb, device="cuda:0"):
+        self.device, self.n_groups = device, hb.n_groups
+        self.n_reads = int(hb.read_off[-1])
+        names = ("read_off", "n_alt", "ploidy", "del_len", "ins_len", "ref_lnp", "allele_lnp", "non_ambig", "read_length",
+                 "read_flags")
+        self.t = {k: _t(getattr(hb, k), device) for k in names}
+        self.out = torch.empty(hb.n_groups * capi.ALLELE_GROUP_CALL_DTYPE.itemsize, dtype=torch.uint8, device=device)
+
+    def struct(self):
+        p = {k: C.c_void_p(v.data_ptr()) for k, v in self.t.items()}
+        return capi.AlleleGroupBatch(self.n_groups, p["read_off"], p["n_alt"], p["ploidy"], p["del_len"], p["ins_len"],
+                                     p["ref_lnp"], p["allele_lnp"], p["non_ambig"], p["read_length"], p["read_flags"])
+
+    def genotype_lhoods(self, opt=None):
+        opt = opt or capi.indel_options(False)
+        s = self.struct()
+        capi._check(capi.lib().sk_allele_group_genotype_lhoods_dev(C.byref(s), C.byref(opt), C.c_void_p(self.out.data_ptr()),
+                                                                   _stream_ptr()))
+        return self.out

@@ -685,3 +685,24 @@ def pileup_reads_flat(n_reads, rng, L=150, depth=40.0, del_rate=0.05, mismatch_r
     return ReadBatch(np.arange(n_reads + 1, dtype=np.int64) * L, code.reshape(-1), qual.reshape(-1), path_off, path, pos,
                      rng.integers(0, 2, n_reads).astype(np.uint8), np.full(n_reads, 60, np.uint8), np.ones(n_reads, np.uint8),
                      ref, 0), n_loci
+
+
+def align_pairs(n, rng, ref_len=(100, 270), max_edits=3):
+    """(haplotype, reference segment) string pairs for GlobalAligner: the reference segment with a few indels applied."""
+    bases = np.array(list("ACGT"))
+
+    def seq(k):
+        return "".join(bases[rng.integers(0, 4, k)])
+
+    pairs = []
+    for _ in range(n):
+        r = seq(int(rng.integers(ref_len[0], ref_len[1])))
+        q = list(r)
+        for _k in range(int(rng.integers(0, max_edits + 1))):
+            p = int(rng.integers(5, len(q) - 5))
+            if rng.random() < 0.5:
+                del q[p:p + int(rng.integers(1, 12))]
+            else:
+                q[p:p] = list(seq(int(rng.integers(1, 12))))
+        pairs.append(("".join(q), r))
+    return pairs
