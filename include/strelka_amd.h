@@ -374,6 +374,26 @@ typedef struct sk_global_align_batch {
 int sk_global_align(const sk_global_align_batch* host_batch, const sk_align_scores* scores, int32_t* out_score,
                     int32_t* out_begin_pos, sk_path_seg* out_path, int32_t* out_n_seg);
 
+typedef struct sk_discovered_allele { /* an IndelKey found in a haplotype */
+    int32_t pos;
+    int32_t type;      /* SK_INDEL_INDEL or SK_INDEL_MISMATCH */
+    uint32_t del_len;
+    uint32_t ins_len;
+    int32_t ins_off;   /* the insert sequence is out_ins_seq[ins_off .. ins_off + ins_len) */
+} sk_discovered_allele;
+
+/** Replaces the part of ActiveRegionProcessor::discoverIndelsAndMismatches after the aligner call
+ *  (L/starling_common/ActiveRegionProcessor.cpp:594-705): walks the path sk_global_align returned for `haplotype` against
+ *  the active region [ar_begin, ar_end) of the reference segment (ref_seq covers [ref_offset, ref_offset + ref_len), 'N'
+ *  outside), left-shifts insertions and deletions as far as the reference sequence allows, drops indels longer than
+ *  max_indel_size, shifted into the previous active region (pos < prev_ar_end), next to an 'N' or past ar_end, and reports
+ *  one MISMATCH key per mismatched base at or after prev_ar_end.  *n_indels = the reference's numIndels. */
+int sk_discover_indels_and_mismatches(const char* ref_seq, int32_t ref_offset, int32_t ref_len, int32_t ar_begin,
+                                      int32_t ar_end, int32_t prev_ar_end, uint32_t max_indel_size, const char* haplotype,
+                                      int32_t hap_len, int32_t align_begin_pos, const sk_path_seg* path, int32_t n_seg,
+                                      sk_discovered_allele* out, int32_t out_cap, char* out_ins_seq, int32_t ins_cap,
+                                      int32_t* n_out, int32_t* n_indels);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (germline SNV): dependent error probabilities + diploid genotype likelihoods
  * ---------------------------------------------------------------------------------------------------------------- */

@@ -610,3 +610,22 @@ def ref_global_align(query, ref_seq, sc):
     if rc:
         raise RuntimeError("reference GlobalAligner threw")
     return score.value, beg.value, buf.value.decode()
+
+
+def ref_discover_indels_and_mismatches(ref_seq, ref_offset, ar_begin, ar_end, prev_ar_end, max_indel_size, haplotype):
+    """the REFERENCE's ActiveRegionProcessor::discoverIndelsAndMismatches -> ([(pos, type, del_len, ins_seq)], numIndels)"""
+    L = ref()
+    L.ref_discover_indels_and_mismatches.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_char_p,
+                                                     C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    buf = C.create_string_buffer(64 * (len(haplotype) + len(ref_seq)) + 64)
+    n = C.c_int()
+    rc = L.ref_discover_indels_and_mismatches(ref_seq.encode(), ref_offset, ar_begin, ar_end, prev_ar_end, max_indel_size,
+                                              haplotype.encode(), buf, len(buf), C.byref(n))
+    if rc:
+        raise RuntimeError("reference discoverIndelsAndMismatches failed (%d)" % rc)
+    out = []
+    for item in buf.value.decode().split(";"):
+        if item:
+            pos, typ, dl, ins = item.split(",")
+            out.append((int(pos), int(typ), int(dl), ins))
+    return out, n.value

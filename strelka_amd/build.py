@@ -26,6 +26,7 @@ HIP_SOURCES = [
 HOST_SOURCES = [
     "host/align_flatten.cpp",
     "host/read_realign.cpp",
+    "host/active_region.cpp",
 ]
 
 

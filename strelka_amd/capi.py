@@ -193,6 +193,7 @@ EXPORTS = [
     "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
     "sk_indel_options_default", "sk_somatic_indel_options_default", "sk_indel_grid_lhood", "sk_indel_grid_lhood_dev",
     "sk_somatic_indel_call_batch", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
+    "sk_discover_indels_and_mismatches",
 ]
 
 _lib = None
@@ -795,3 +796,28 @@ def global_align(pairs, scores=None):
         po = int(qo[i] + ro[i]) + 4 * i
         out.append((int(score[i]), int(beg[i]), "".join("%d%s" % (path[po + k, 1], CIGAR_CHARS[path[po + k, 0]]) for k in range(nseg[i]))))
     return out
+
+
+class DiscoveredAllele(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("type", C.c_int32), ("del_len", C.c_uint32), ("ins_len", C.c_uint32), ("ins_off", C.c_int32)]
+
+
+def discover_indels_and_mismatches(ref_seq, ref_offset, ar_begin, ar_end, prev_ar_end, max_indel_size, haplotype, begin_pos,
+                                   cigar):
+    """-> ([(pos, type, del_len, ins_seq)], n_indels); `cigar` is the '='/'X' CIGAR sk_global_align returned"""
+    path = cigar_to_path(cigar)
+    segs = (PathSeg * max(len(path), 1))(*[PathSeg(t, l) for t, l in path])
+    cap = len(haplotype) + len(path) + 1
+    out = (DiscoveredAllele * cap)()
+    ins = C.create_string_buffer(2 * len(haplotype) + 16)
+    n, ni = C.c_int32(), C.c_int32()
+    f = lib().sk_discover_indels_and_mismatches
+    f.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_char_p, C.c_int32, C.c_int32,
+                  C.POINTER(PathSeg), C.c_int32, C.POINTER(DiscoveredAllele), C.c_int32, C.c_char_p, C.c_int32,
+                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    r, h = ref_seq.encode(), haplotype.encode()
+    _check(f(r, ref_offset, len(r), ar_begin, ar_end, prev_ar_end, max_indel_size, h, len(h), begin_pos, segs, len(path), out, cap,
+             ins, len(ins), C.byref(n), C.byref(ni)))
+    raw = ins.raw
+    return [(out[i].pos, out[i].type, out[i].del_len, raw[out[i].ins_off:out[i].ins_off + out[i].ins_len].decode())
+            for i in range(n.value)], ni.value

@@ -706,3 +706,52 @@ def align_pairs(n, rng, ref_len=(100, 270), max_edits=3):
                 q[p:p] = list(seq(int(rng.integers(1, 12))))
         pairs.append(("".join(q), r))
     return pairs
+
+
+def active_region_scenarios(n, rng):
+    """inputs of ActiveRegionProcessor::discoverIndelsAndMismatches: a repeat-rich reference segment, an active region
+    in it, and a haplotype = the region's sequence with a few SNVs / insertions / deletions (often of repeat units, so
+    that left-shifting has something to do, sometimes up to the region's or the segment's edge)"""
+    out = []
+    while len(out) < n:
+        L = int(rng.integers(120, 400))
+        parts = []
+        while sum(map(len, parts)) < L:
+            r = rng.random()
+            if r < 0.25:
+                parts.append(_BASES[int(rng.integers(0, 4))] * int(rng.integers(3, 15)))
+            elif r < 0.45:
+                unit = "".join(_BASES[int(x)] for x in rng.integers(0, 4, int(rng.integers(2, 5))))
+                parts.append(unit * int(rng.integers(2, 8)))
+            elif r < 0.5:
+                parts.append("N" * int(rng.integers(1, 4)))
+            else:
+                parts.append("".join(_BASES[int(x)] for x in rng.integers(0, 4, int(rng.integers(3, 20)))))
+        ref = "".join(parts)[:L]
+        off = int(rng.choice([0, 0, 1000, 52000]))
+        size = int(rng.integers(20, min(200, L - 4)))
+        b = int(rng.integers(0, L - size + 1))
+        e = b + size
+        seg = ref[b:e]
+        hap = list(seg)
+        for _ in range(int(rng.integers(1, 5))):
+            if len(hap) < 12:
+                break
+            p = int(rng.integers(0, len(hap)))
+            r = rng.random()
+            if r < 0.3:
+                hap[p] = _BASES[(_BASES.find(hap[p]) + int(rng.integers(1, 4))) % 4] if hap[p] in _BASES else "A"
+            elif r < 0.65:
+                k = int(rng.choice([1, 1, 2, 3, 4, 8, 20, 60]))
+                src = hap[max(0, p - k):p] if rng.random() < 0.6 and p >= k else [_BASES[int(x)] for x in rng.integers(0, 4, k)]
+                hap[p:p] = src
+            else:
+                k = int(rng.choice([1, 1, 2, 3, 4, 8, 20, 60]))
+                del hap[p:p + k]
+        hap = "".join(hap)
+        if hap == seg or len(hap) < 1:
+            continue
+        prev = int(rng.choice([off + b, off + b - 5, off + b + 1, off, off + b + 10]))
+        out.append(dict(ref_seq=ref, ref_offset=off, ar_begin=off + b, ar_end=off + e, prev_ar_end=prev,
+                        max_indel_size=int(rng.choice([49, 49, 49, 10])), haplotype=hap))
+    return out

@@ -287,6 +287,19 @@ def pipeline_golden():
         sum(len(t["indels"]) for t in trials)))
 
 
+def active_region_golden():
+    """next row f2 post-processing: the reference's ActiveRegionProcessor::discoverIndelsAndMismatches (with the CIGAR of
+    its own GlobalAligner) on seeded (reference segment, active region, haplotype) scenarios"""
+    pyoracle.build(ref=True)
+    from tests.test_active_region import reference_outputs
+    scenarios = synth.active_region_scenarios(400, np.random.default_rng(4242))
+    expect = reference_outputs(scenarios)
+    with open(os.path.join(HERE, "active_region_reference.pkl"), "wb") as f:
+        pickle.dump(dict(scenarios=scenarios, expect=expect), f, protocol=4)
+    print("active-region golden: %d scenarios, %d keys, %d indels" % (
+        len(scenarios), sum(len(w["keys"]) for w in expect), sum(w["n_indels"] for w in expect)))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "main"):
@@ -297,3 +310,5 @@ if __name__ == "__main__":
         pileup_golden()
     if what in ("all", "pipeline"):
         pipeline_golden()
+    if what in ("all", "active_region"):
+        active_region_golden()
