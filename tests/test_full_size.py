@@ -1,0 +1,95 @@
+"""GPU suite (-m gpu): size-independent properties at BASELINE.json's full sizes (the oracle cannot finish these sizes in
+seconds, so the checks are structural):
+
+  * a bench-size batch is a small batch tiled K times -> every tile's results must equal tile 0's bit for bit
+    (periodicity: catches any dependence on block / queue position, overflow of 32-bit offsets, races), and tile 0 must
+    equal the small batch run on its own, which the parity tests pin against the oracle;
+  * the somatic queue holds exactly the loci the reference would not skip; the pileup columns of 2^20 reads are compared
+    with the C restatement in full (it still finishes that size in seconds).
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from strelka_amd import capi, device, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiles_equal(t, n_tiles):
+    import torch
+    v = t.view(n_tiles, -1)
+    return bool(torch.equal(v, v[0:1].expand_as(v)))
+
+
+def test_alignment_scores_full_size(gpu):
+    import torch
+    rng = np.random.default_rng(901)
+    hb = synth.align_batch_flat(1 << 14, rng)
+    tile = 64                                           # 2^20 reads x 64 candidates x 150 bp = bench.py's step
+    d = device.DeviceAlignBatch(hb, "cuda:0", tile=tile)
+    out = d.score()
+    torch.cuda.synchronize()
+    assert d.n_reads == 1 << 20
+    assert _tiles_equal(out.view(torch.int64), tile)
+    small = gpu.score_alignments(hb)
+    assert np.array_equal(small.view(np.uint64), out[:hb.n_cals].cpu().numpy().view(np.uint64))
+
+
+def test_germline_loci_full_size(gpu):
+    import torch
+    rng = np.random.default_rng(902)
+    hb = synth.pileups(1 << 20, rng)
+    tile = 16                                           # 2^24 loci
+    d = device.DevicePileupBatch(hb, "cuda:0", tile=tile)
+    d.site_digt_call_fused(capi.germline_options())
+    torch.cuda.synchronize()
+    assert d.n_loci == 1 << 24
+    assert _tiles_equal(d.digt_out.view(torch.uint8), tile)
+    got = d.digt_numpy()[:4000]
+    # tile 0's first loci against the oracle (float likelihoods to 1e-5 relative, as in test_gpu_parity)
+    sub = capi.HostPileupBatch(hb.call_off[:4001], hb.calls[:hb.call_off[4000]], hb.ref_base[:4000])
+    oopt = pyoracle.germline_options()
+    want = pyoracle.site_digt_call(sub, pyoracle.adjust_joint_eprob(sub, oopt), oopt)
+    a, b = got["lhood"].astype(np.float64), want["lhood"].astype(np.float64)
+    assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(1.0, np.abs(b)))
+    assert np.mean(got["genome"]["max_gt"] == want["genome"]["max_gt"]) == 1.0
+
+
+def test_somatic_loci_full_size(gpu):
+    import torch
+    rng = np.random.default_rng(903)
+    n, t = synth.somatic_pileups(1 << 18, rng)
+    tile = 16                                           # 2^22 loci
+    dn, dt = device.DevicePileupBatch(n, "cuda:0", tile=tile), device.DevicePileupBatch(t, "cuda:0", tile=tile)
+    out = device.somatic_snv_call_dev(dn, dt)
+    torch.cuda.synchronize()
+    assert _tiles_equal(out, tile)
+    rec = out[: (1 << 18) * capi.SOMATIC_CALL_DTYPE.itemsize].cpu().numpy().view(capi.SOMATIC_CALL_DTYPE)
+    # the queue holds exactly the loci the reference does not skip (:244-254): ref known and some call differs from it
+    nonref = np.zeros(1 << 18, bool)
+    for b in (n, t):
+        locus = np.repeat(np.arange(b.n_loci), np.diff(b.call_off))
+        np.logical_or.at(nonref, locus, ((b.calls >> 6) & 0xf) != b.ref_base[locus])
+    expect_called = nonref & (n.ref_base < 4)
+    assert np.array_equal(rec["is_called"] != 0, expect_called)
+    assert int(dn.som_scratch.view(torch.int32)[0].item()) == int(expect_called.sum()) * tile
+    small = gpu.somatic_snv_call(n, t)
+    assert small.tobytes() == rec.tobytes()
+
+
+def test_pileup_full_size_equals_restatement(gpu):
+    """2^20 reads x 150 bp (bench.py's pileup step): the C restatement still finishes this size in seconds, so the columns
+    are compared in full -- offsets, calls and their order inside every column."""
+    import torch
+    rng = np.random.default_rng(904)
+    rb, n_loci = synth.pileup_reads_flat(1 << 20, rng)
+    d = device.DeviceReadBatch(rb, n_loci, "cuda:0")
+    for mode in (capi.PILEUP_CLEAN_TIER1,):
+        d.pileup(mode)
+        torch.cuda.synchronize()
+        off = d.call_off.cpu().numpy()
+        want_off, want_calls, _, _ = pyoracle.pileup_reads(rb, pyoracle.pileup_options(report_begin=0, report_end=n_loci), mode)
+        assert np.array_equal(off, want_off)
+        got = d.calls[: int(off[-1])].cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, want_calls)
