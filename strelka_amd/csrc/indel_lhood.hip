@@ -25,48 +25,15 @@ namespace
 constexpr int WAVE = 64;
 constexpr int N_STATES = 21;
 
-// log1p_switch / getLogSum, L/blt_util/math_util.hh:33-48, L/blt_util/logSumUtil.hh:33-41 (double)
-__device__ __forceinline__ double log1p_switch_d(const double x) { return (fabs(x) < 0.01) ? log1p(x) : log(__dadd_rn(1., x)); }
-__device__ __forceinline__ double log_sum2(double x1, double x2)
-{
-    if (x1 < x2) {
-        const double t = x1;
-        x1 = x2;
-        x2 = t;
-    }
-    return __dadd_rn(x1, log1p_switch_d(exp(__dsub_rn(x2, x1))));
-}
-
+// The reference's per-read term is built from getLogSum (L/blt_util/logSumUtil.hh:33-41, log1p_switch
+// L/blt_util/math_util.hh:33-48) and integrateOutMappingStatus (L/starling_common/readMappingAdjustmentUtil.hh:29-56):
+//     integrateOutMappingStatus(x) = logsum(x + correct_mapping_log_prior, random_base_match_log_prob * nonAmbiguousBases)
+// The kernels evaluate these nested log-sum-exps in the scaled-exponential form described at mix_term below.
 struct MapParams
 {
     double correct_mapping_log_prior; // log(1.7e-10), starling_base_shared.cpp:64
     double random_base_match_log_prob; // log(randomBaseMatchProb) of the pass (tier2 passes use the tier2 value)
 };
-
-// integrateOutMappingStatus, L/starling_common/readMappingAdjustmentUtil.hh:29-56
-__device__ __forceinline__ double integrate_out_mapping(const MapParams& m, const unsigned non_ambig, const double lnp)
-{
-    return log_sum2(__dadd_rn(lnp, m.correct_mapping_log_prior), __dmul_rn(m.random_base_match_log_prob, double(non_ambig)));
-}
-
-// get_het_observed_allele_ratio, starling_indel_call_pprob_digt.cpp:40-71
-__device__ __forceinline__ void het_observed_allele_ratio(const unsigned read_length, const unsigned min_overlap,
-                                                          const unsigned del_len, const unsigned ins_len,
-                                                          const double het_allele_ratio, double& log_ref_prob,
-                                                          double& log_indel_prob)
-{
-    const unsigned base_expect = ((read_length + 1) < (2 * min_overlap)) ? 0 : (read_length + 1) - (2 * min_overlap);
-    const double ref_path_expect = double(base_expect + min(del_len, base_expect));
-    const double indel_path_expect = double(base_expect + min(ins_len, base_expect));
-    const double ref_path_term = __dmul_rn(__dsub_rn(1., het_allele_ratio), ref_path_expect);
-    const double indel_path_term = __dmul_rn(het_allele_ratio, indel_path_expect);
-    const double total_path_term = __dadd_rn(ref_path_term, indel_path_term);
-    if (total_path_term > 0) {
-        const double indel_prob = __ddiv_rn(indel_path_term, total_path_term);
-        log_ref_prob = log(__dsub_rn(1., indel_prob));
-        log_indel_prob = log(indel_prob);
-    }
-}
 
 struct GridArgs
 {
@@ -295,58 +262,77 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
             } else {
                 const unsigned na = a.b.non_ambig[g];
                 const unsigned rlen = a.b.read_length[g];
+                // Scaled exponentials shared by every genotype of the read (same algebra as mix_term above):
+                //   integrateOutMappingStatus(x) = T + log(e^(A-T) e^(x-m) + e^(M-T)),  m = max_k L[k], A = m + prior, T = max(A, M)
+                double m = L[0];
+#pragma unroll
+                for (int k = 1; k <= SK_MAX_ALT; ++k)
+                    if (k < full && L[k] > m) m = L[k];
+                const double A = __dadd_rn(m, a.map.correct_mapping_log_prior);
+                const double M = __dmul_rn(a.map.random_base_match_log_prob, double(na));
+                const bool A_lt_M = (A < M);
+                const double T = A_lt_M ? M : A;
+                const double eT = exp(-fabs(__dsub_rn(A, M)));
+                const double sA = A_lt_M ? eT : 1., wm = A_lt_M ? 1. : eT;
+                double E[SK_MAX_ALT + 1], W[SK_MAX_ALT + 1]; // W[k] = e^(Lm[k] - T): the read's weight for allele k
+#pragma unroll
+                for (int k = 0; k <= SK_MAX_ALT; ++k) {
+                    E[k] = 0.;
+                    W[k] = 0.;
+                    if (k < full) {
+                        double ex = exp(__dsub_rn(L[k], m));
+                        if (!(ex == ex)) ex = 1.; // L[k] == m == -inf
+                        E[k] = __dmul_rn(sA, ex);
+                        W[k] = __dadd_rn(E[k], wm);
+                    }
+                }
                 // updateGenotypeLogLhoodFromAlleleLogLhood, AlleleGroupGenotype.cpp:36-114
                 if (ploidy == 1) {
 #pragma unroll
                     for (int a0 = 0; a0 <= SK_MAX_ALT; ++a0)
-                        if (a0 < full) s_term[a0][lane] = integrate_out_mapping(a.map, na, L[a0]);
+                        if (a0 < full) s_term[a0][lane] = __dadd_rn(T, log(W[a0]));
                 } else {
+                    // P[k]: the observed-allele ratio of alt allele k at het ratio 0.5 (get_het_observed_allele_ratio)
+                    double Pref[SK_MAX_ALT + 1], Pind[SK_MAX_ALT + 1];
+#pragma unroll
+                    for (int k = 1; k <= SK_MAX_ALT; ++k) {
+                        Pref[k] = 0.5;
+                        Pind[k] = 0.5;
+                        if (k < full) het_observed_indel_prob(rlen, flank, del_len[k - 1], ins_len[k - 1], 0.5, Pref[k], Pind[k]);
+                    }
 #pragma unroll
                     for (int a1 = 0; a1 <= SK_MAX_ALT; ++a1) {
 #pragma unroll
                         for (int a0 = 0; a0 <= a1; ++a0) {
                             if (a1 >= full) continue;
                             const int gi = a0 + (a1 * (a1 + 1) / 2);
-                            double raw;
+                            double w;
                             if (a0 != a1) {
-                                double lp0 = a.loghalf, lp1 = a.loghalf;
-                                het_observed_allele_ratio(rlen, flank, del_len[a1 - 1], ins_len[a1 - 1], 0.5, lp0, lp1);
-                                if (a0 > 0) {
-                                    double log_ref_prior = a.loghalf;
-                                    lp0 = a.loghalf;
-                                    het_observed_allele_ratio(rlen, flank, del_len[a0 - 1], ins_len[a0 - 1], 0.5, log_ref_prior, lp0);
-                                    const double norm = log_sum2(lp0, lp1);
-                                    lp0 = __dsub_rn(lp0, norm);
-                                    lp1 = __dsub_rn(lp1, norm);
+                                double p0 = Pref[a1], p1 = Pind[a1];
+                                if (a0 > 0) { // het-alt: both alleles' indel ratios, renormalised (:83-95)
+                                    p0 = Pind[a0];
+                                    const double norm = __dadd_rn(p0, p1);
+                                    p0 = __ddiv_rn(p0, norm);
+                                    p1 = __ddiv_rn(p1, norm);
                                 }
-                                raw = log_sum2(__dadd_rn(L[a0], lp0), __dadd_rn(L[a1], lp1));
+                                w = __dadd_rn(__dadd_rn(__dmul_rn(p0, E[a0]), __dmul_rn(p1, E[a1])), wm);
                             } else {
-                                raw = L[a0];
+                                w = W[a0];
                             }
-                            s_term[gi][lane] = integrate_out_mapping(a.map, na, raw);
+                            s_term[gi][lane] = __dadd_rn(T, log(w));
                         }
                     }
                 }
-                // updateSupportingReadStats, :125-155 (normalizeLogDistro: first maximum, exp, 1/sum)
-                double Lm[SK_MAX_ALT + 1];
-                double mx = 0.;
-#pragma unroll
-                for (int k = 0; k <= SK_MAX_ALT; ++k) {
-                    Lm[k] = (k < full) ? integrate_out_mapping(a.map, na, L[k]) : 0.;
-                    if (k < full) mx = (k == 0) ? Lm[0] : ((Lm[k] > mx) ? Lm[k] : mx);
-                }
+                // updateSupportingReadStats, :125-155: normalizeLogDistro over Lm[k] = T + log(W[k]) is W[k] / sum(W)
                 double sum = 0.;
 #pragma unroll
                 for (int k = 0; k <= SK_MAX_ALT; ++k)
-                    if (k < full) {
-                        Lm[k] = exp(__dsub_rn(Lm[k], mx));
-                        sum = __dadd_rn(sum, Lm[k]);
-                    }
+                    if (k < full) sum = __dadd_rn(sum, W[k]);
                 sum = __ddiv_rn(1., sum);
                 unsigned which = 15;
 #pragma unroll
                 for (int k = SK_MAX_ALT; k >= 0; --k)
-                    if (k < full && !(__dmul_rn(Lm[k], sum) < a.support_threshold)) which = unsigned(k); // first such allele
+                    if (k < full && !(__dmul_rn(W[k], sum) < a.support_threshold)) which = unsigned(k); // first such allele
                 s_support[lane] = (unsigned char)(((flags & SK_READ_FWD) ? 0x10 : 0) | which);
             }
         }
