@@ -202,7 +202,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(con
         }
         const bool active = lane < m;
         const int nslots = __builtin_amdgcn_readlane(s1, m - 1);
-        const int ebase = active ? int(a.b.op_off[c] + 2 * int64_t(c) - sbase) : ENT_CAP;
+        const int prev_end = __shfl_up(s1, 1); // the lane's first slot is where the previous lane's candidate ends
+        const int ebase = active ? (lane == 0 ? 0 : prev_end) : ENT_CAP;
 
         wave_sync(); // the previous pass is done with the entry table; rows / hap columns / mask are complete
         for (int j0 = 0; j0 < nslots; j0 += 10 * WAVE) { // the pass's entries are contiguous in the prepared batch
