@@ -535,9 +535,8 @@ int sk_site_digt_call_fused_dev(const sk_pileup_batch* b, const sk_germline_opti
     SK_HIP(hipMemsetAsync(a.work_count, 0, sizeof(uint32_t), static_cast<hipStream_t>(hip_stream)));
     hipLaunchKernelGGL(germline_site_fused_kernel, dim3(blocks), dim3(FUSED_THREADS), 0,
                        static_cast<hipStream_t>(hip_stream), a);
-    if (!getenv("SK_DEBUG_SKIP_GLOBAL_PASS")) // debugging aid: leaves the sentinel visible in is_called
-        hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3(std::min(2048, (b->n_loci + 63) / 64)), dim3(64), 0,
-                           static_cast<hipStream_t>(hip_stream), a);
+    hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3(std::min(2048, (b->n_loci + 63) / 64)), dim3(64), 0,
+                       static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());
     return 0;
 }

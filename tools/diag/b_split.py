@@ -18,7 +18,3 @@ for depth in (10.0, 20.0, 40.0, 80.0):
     g0 = capi.germline_options(); g0.bsnp_ssd_no_mismatch = 0.0; g0.bsnp_ssd_one_mismatch = 0.0
     g1 = capi.germline_options(); g1.is_min_vexp = 1; g1.min_vexp = 1.0
     print("depth %5.1f  loci %d  calls %d  fused %.2f ms   sort-but-no-pow/log (min_vexp=1) %.2f ms   no-dependent-eprob %.2f ms" % (depth, db.n_loci, db.n_calls, t(db, g), t(db, g1), t(db, g0)), flush=True)
-os.environ["SK_DEBUG_SKIP_GLOBAL_PASS"] = "1"
-print("depth 80 without the global pass kernel: %.2f ms" % t(db, g))
-out = db.digt_numpy()
-print("loci left to the global pass: %d of %d" % (int((out["is_called"] == 0xffffffff).sum()), db.n_loci))
