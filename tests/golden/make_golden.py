@@ -26,11 +26,10 @@ def _p(a):
     return a.ctypes.data_as(vp)
 
 
-def main():
-    pyoracle.build(ref=True)
+def pathb_vectors(rng):
+    """inputs + the REFERENCE's outputs for the scalar helpers, std::sort tie order and every path-B function"""
     R = pyoracle.ref()
     assert R is not None, "oracle/_ref/libstrelka_ref.so missing"
-    rng = np.random.default_rng(20240925)
     out = {}
 
     # ---- scalar helpers / tables
@@ -159,6 +158,13 @@ def main():
                a_ref=ab.ref_lnp, a_allele=ab.allele_lnp, a_na=ab.non_ambig, a_rl=ab.read_length, a_flags=ab.read_flags,
                a_lhood=glh, a_counts=gcnt)
 
+    return out
+
+
+def main():
+    pyoracle.build(ref=True)
+    rng = np.random.default_rng(20240925)
+    out = pathb_vectors(rng)
     np.savez_compressed(os.path.join(HERE, "pathb_reference.npz"), **out)
 
     # ---- hot path A: scoreCandidateAlignment of the reference on reference-shaped candidate alignments
