@@ -42,6 +42,10 @@ const char* sk_last_error(void);
 int sk_version(void);
 /** 1 when sk_init succeeded on a gfx950 device. */
 int sk_is_initialized(void);
+/** 1 when sk_init found the host libm's powf/logf to be the routines the kernels restate (glibc >= 2.28, see
+ *  strelka_amd/csrc/libm_flt32.h): the dependent error probabilities and germline likelihoods are then bit-identical to
+ *  the reference's; 0: the device library's pow/log stand in (agreement to 1e-5 relative). */
+int sk_libm_restated(void);
 
 /** Host copies of the q-score tables the kernels use (71 entries each, Q0..Q70; L/blt_util/qscore_cache.hh:66-68). */
 int sk_get_qscore_tables(double* q2p, double* q2lncompe, double* q2lne);

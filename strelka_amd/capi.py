@@ -178,7 +178,7 @@ assert DIGT_CALL_DTYPE.itemsize == 144 and SOMATIC_CALL_DTYPE.itemsize == 272
 
 # every symbol include/strelka_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "sk_init", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_get_qscore_tables",
+    "sk_init", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_libm_restated", "sk_get_qscore_tables",
     "sk_score_alignments", "sk_score_alignments_dev", "sk_align_evmask_words", "sk_align_prepare",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_add_read",
     "sk_align_builder_finish", "sk_align_builder_error",

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "sk_common.h"
+#include "libm_flt32.h"
 
 #include <cmath>
 #include <cstring>
@@ -20,6 +21,7 @@ struct GermlineDerived
     int is_min_vexp;
     int is_dependent_eprob;
     float ln10f; // std::log(10.f) for ln_error_prob_to_phred<float> (qscore.hh:54)
+    int exact_libm; // the host libm's powf/logf are the routines restated in libm_flt32.h (checked by sk_init)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -44,16 +46,22 @@ __device__ __forceinline__ int ln_error_prob_to_qphred_f(const float lnProb, con
     return static_cast<int>(floor(__dadd_rn(static_cast<double>(phred), 0.5)));
 }
 
-// glibc's logf computes in double and rounds once; so does this (agrees except when the double result sits within
-// its own error of a float rounding boundary)
-__device__ __forceinline__ float logf_via_double(const float x) { return static_cast<float>(log(static_cast<double>(x))); }
+// std::log(float) of the reference = the host libm's logf: restated bit for bit (libm_flt32.h); the device library's
+// double log rounded once is the stand-in when the host libm is not the implementation restated there
+__device__ __forceinline__ float logf_ref(const float x, const int exact_libm)
+{
+    float r;
+    if (exact_libm && sk_libm::logf_glibc(x, r)) return r;
+    return static_cast<float>(log(static_cast<double>(x)));
+}
 
-
-// get_dependent_eprob, adjust_joint_eprob.cpp:58-69 (float throughout; std::pow(float,float))
-__device__ __forceinline__ float get_dependent_eprob(const float eprob, const float vexp)
+// get_dependent_eprob, adjust_joint_eprob.cpp:58-69 (float throughout; std::pow(float,float) = the host libm's powf)
+__device__ __forceinline__ float get_dependent_eprob(const float eprob, const float vexp, const int exact_libm)
 {
     const float dep_converge_prob = 0.75f;
-    const float val = static_cast<float>(pow(static_cast<double>(eprob), static_cast<double>(vexp))); // glibc powf is evaluated in double and rounded once
+    float val;
+    if (!(exact_libm && sk_libm::powf_glibc(eprob, vexp, val)))
+        val = static_cast<float>(pow(static_cast<double>(eprob), static_cast<double>(vexp)));
     const float frac = __fdiv_rn(__fsub_rn(1.f, val), __fsub_rn(1.f, eprob));
     const float dep = __fadd_rn(__fmul_rn(frac, val), __fmul_rn(__fsub_rn(1.f, frac), dep_converge_prob));
     return (eprob < dep) ? dep : eprob;
@@ -208,6 +216,7 @@ inline void derive(const sk_germline_options& opt, GermlineDerived& d)
     }
     volatile float ten = 10.f;
     d.ln10f = std::log(static_cast<float>(ten));
+    d.exact_libm = sk_ctx().libm_restated ? 1 : 0;
 }
 
 
@@ -422,7 +431,7 @@ __device__ void locus_dependent_eprob_global(const sk_pileup_batch& B, const SkT
             const uint32_t ci = gi[i];
             const unsigned q = SKC_Q(calls[ci]);
             if (!is_min_vexp) {
-                de[ci] = get_dependent_eprob(T->g_eprob[q], vexp);
+                de[ci] = get_dependent_eprob(T->g_eprob[q], vexp, D.exact_libm);
                 const float next_vexp = __fmul_rn(vexp, __fsub_rn(1.f, vexp_frac));
                 if (D.is_min_vexp) {
                     is_min_vexp = (next_vexp <= D.min_vexp);
@@ -467,7 +476,7 @@ __device__ void locus_site_digt_call_global(const sk_pileup_batch& B, const floa
     for (int i = 0; i < n; ++i) {
         const uint16_t bc = calls[i];
         const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
-        const float v0 = __fadd_rn(logf_via_double(de[i]), log_one_third); // val[0] (:352)
+        const float v0 = __fadd_rn(logf_ref(de[i], D.exact_libm), log_one_third); // val[0] (:352)
         const float v1 = T->g_v1[q];                             // val[1] (:353)
         const float v2 = T->g_v2[q];                             // val[2] (:354)
 #pragma unroll
@@ -499,7 +508,7 @@ __device__ void locus_site_digt_call_global(const sk_pileup_batch& B, const floa
         for (int i = 0; i < n; ++i) {
             const uint16_t bc = calls[i];
             const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
-            const float v0 = __fadd_rn(logf_via_double(de[i]), log_one_third);
+            const float v0 = __fadd_rn(logf_ref(de[i], D.exact_libm), log_one_third);
             const float v1 = T->g_v1[q];
             const float v2 = T->g_v2[q];
             const float val_ref = (obs == ref) ? v2 : v0; // expect2(obs, ref_gt): ref_gt is homozygous

@@ -184,7 +184,7 @@ __device__ __forceinline__ float call_de(const uint16_t c, const float (&vfrac)[
     if (!D.is_dependent_eprob || SKC_FILTER(c) || q < 3) return Q.eprob[q];
     if (rank == 0) return Q.depmin[q];
     const unsigned g = SKC_FWD(c) + 2 * SKC_BASE(c);
-    return get_dependent_eprob(Q.eprob[q], vexp_of_rank(rank, select8(vfrac, g), D));
+    return get_dependent_eprob(Q.eprob[q], vexp_of_rank(rank, select8(vfrac, g), D), D.exact_libm);
 }
 
 // val[0] = logf(de) + ln(1/3) of one call: a table value unless the call is one of the few ranked ones, whose terms
@@ -334,8 +334,8 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
                 const uint16_t c = calls[ci];
                 calls[ci] = uint16_t(c | ((unsigned(i) + 1u) << RANK_SHIFT));
                 if (i >= 1) { // rank 1 has vexp == 1 -> de == e_q exactly, a table term
-                    const float de = get_dependent_eprob(Q.eprob[SKC_Q(c)], vexp);
-                    v0r[nslots++] = __fadd_rn(logf_via_double(de), T->g_log_one_third);
+                    const float de = get_dependent_eprob(Q.eprob[SKC_Q(c)], vexp, D.exact_libm);
+                    v0r[nslots++] = __fadd_rn(logf_ref(de, D.exact_libm), T->g_log_one_third);
                 }
                 const float next_vexp = __fmul_rn(vexp, m);
                 vexp = D.is_min_vexp ? ((D.min_vexp < next_vexp) ? next_vexp : D.min_vexp) : next_vexp;

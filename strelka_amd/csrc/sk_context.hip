@@ -4,6 +4,7 @@
 // by the compiler: inputs pass through `rt()` (a volatile round trip).
 
 #include "sk_common.h"
+#include "libm_flt32.h"
 
 #include <cmath>
 #include <cstring>
@@ -138,9 +139,34 @@ int SkArena::reserve(size_t bytes)
     return 0;
 }
 
+// The kernels evaluate the reference's powf/logf calls with csrc/libm_flt32.h, a restatement of glibc's routines.  That is
+// only "the same float as the reference" while the host's libm IS those routines: compare them on a spread of arguments
+// (every q-score's error probability and neighbours, exponents across (0,1]); on any difference the kernels fall back to
+// the device library's double-precision pow/log (agreement to the last ulp or two instead of bit for bit).
+static bool host_libm_matches_restatement()
+{
+    unsigned long long st = 0x9e3779b97f4a7c15ull;
+    for (int it = 0; it < 20000; ++it) {
+        st ^= st << 13;
+        st ^= st >> 7;
+        st ^= st << 17;
+        const int q = 3 + int(st % 68);
+        float e = static_cast<float>(std::pow(10.0, -0.1 * q));
+        e = sk_libm::as_f32(sk_libm::as_u32(e) + uint32_t((st >> 20) % 64));
+        const float v = static_cast<float>(double((st >> 32) % 100000 + 1) / 100000.0);
+        volatile float ve = e, vv = v;
+        float mine;
+        if (!sk_libm::powf_glibc(e, v, mine) || sk_libm::as_u32(mine) != sk_libm::as_u32(std::pow(ve, vv))) return false;
+        volatile float x = sk_libm::as_f32(0x33000000u + uint32_t((st >> 8) % 0x0c800000u));
+        if (!sk_libm::logf_glibc(x, mine) || sk_libm::as_u32(mine) != sk_libm::as_u32(std::log(x))) return false;
+    }
+    return true;
+}
+
 extern "C" {
 
 int sk_version(void) { return SK_VERSION; }
+int sk_libm_restated(void) { return g_ctx.libm_restated ? 1 : 0; }
 const char* sk_last_error(void) { return g_last_error.c_str(); }
 int sk_is_initialized(void) { return g_ctx.ready ? 1 : 0; }
 
@@ -161,6 +187,7 @@ int sk_init(int device)
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return sk_fail(std::string("strelka_amd: built for gfx950 only, device is ") + prop.gcnArchName);
     build_tables(c.host_tables);
+    c.libm_restated = host_libm_matches_restatement();
     SK_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev_tables), sizeof(SkTables)));
     SK_HIP(hipMemcpy(c.dev_tables, &c.host_tables, sizeof(SkTables), hipMemcpyHostToDevice));
     SK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));

@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with `-m gpu` on the GPU box")
+    # SK_TEST_SEED_OFFSET=k shifts every fixed seed the tests pass to np.random.default_rng by k: the same suite then runs on
+    # fresh synthetic inputs (tools/fuzz/gpu_seeds.sh); tests that compare with committed golden fixtures are unaffected
+    k = int(os.environ.get("SK_TEST_SEED_OFFSET", "0"))
+    if k:
+        import numpy as np
+        orig = np.random.default_rng
+
+        def shifted(seed=None, *a, **kw):
+            return orig(seed + k if isinstance(seed, int) else seed, *a, **kw)
+
+        np.random.default_rng = shifted
 
 
 @pytest.fixture(scope="session")

@@ -16,7 +16,7 @@ from strelka_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-LL_TOL = 1e-5
+LL_TOL = 1e-5  # float likelihoods that end in a device transcendental (somatic strand states, strand bias)
 
 
 def close_ll(a, b):
@@ -126,14 +126,10 @@ def test_dependent_eprob(gpu):
     pb = _varied_pileups(rng)
     got = gpu.dependent_eprob(pb)
     want = pyoracle.adjust_joint_eprob(pb)
-    # the sort emulation fixes WHICH call gets which exponent: any mis-assignment shows up as a gross difference
-    # de = max(e, frac*val + (1-frac)*0.75) with frac = (1-val)/(1-e), val = powf(e, v): a 1-ulp difference between the
-    # device's pow and glibc's powf is amplified ~50x by the cancellation in (1-frac) when val is small, hence 1e-5 here;
-    # a mis-assigned exponent (wrong tie order) would be off by orders of magnitude more
-    assert np.allclose(got, want, rtol=1e-5, atol=0)
-    # entries that never pass through powf (first of each group, filtered calls, floor-cached ones) are bit-exact, and
-    # with pow evaluated in double and rounded once nearly all others are too
-    assert np.mean(got == want) > 0.999
+    # powf is evaluated with the restatement of the host libm's routine (csrc/libm_flt32.h; sk_init checks the host libm is
+    # that implementation), and the sort emulation fixes WHICH call gets which exponent: bit for bit
+    assert gpu.lib().sk_libm_restated() == 1
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 def test_site_digt_call(gpu):
@@ -146,7 +142,9 @@ def test_site_digt_call(gpu):
     want = pyoracle.site_digt_call(pb, pb.de)
     assert np.array_equal(got["is_called"], want["is_called"])
     assert np.array_equal(got["ref_gt"], want["ref_gt"])
-    assert close_ll(got["lhood"], want["lhood"])
+    # every term of the float32 sums is a host-built table value or logf_glibc(de) + ln(1/3): bit for bit
+    assert np.array_equal(got["lhood"].view(np.uint32), want["lhood"].view(np.uint32))
+    assert np.array_equal(got["phredLoghood"], want["phredLoghood"])
     # strand_bias = max(lhood_fwd, lhood_rev)[gt] - lhood[gt]: a difference of log-likelihoods, so its error scale is theirs
     scale = np.maximum(1.0, np.abs(want["lhood"]).max(axis=1, initial=0.0, where=np.isfinite(want["lhood"])))
     assert np.all(np.abs(got["strand_bias"] - want["strand_bias"]) <= LL_TOL * scale)
@@ -168,11 +166,8 @@ def test_site_digt_call_exact_when_de_is_tabulated(gpu):
     pb.de = np.full(len(pb.calls), 0.25, np.float32)
     got = gpu.site_digt_call(pb)
     want = pyoracle.site_digt_call(pb, pb.de)
-    same = np.array_equal(got["lhood"].view(np.uint32), want["lhood"].view(np.uint32))
-    if not same:  # logf(0.25) may still differ by an ulp between libm and the device; then only closeness is required
-        assert close_ll(got["lhood"], want["lhood"])
-    else:
-        assert np.array_equal(got["phredLoghood"], want["phredLoghood"])
+    assert np.array_equal(got["lhood"].view(np.uint32), want["lhood"].view(np.uint32))
+    assert np.array_equal(got["phredLoghood"], want["phredLoghood"])
 
 
 def test_site_digt_call_fused_equals_two_step(gpu):
@@ -202,8 +197,10 @@ def test_site_digt_call_fused_equals_two_step(gpu):
     fused_no_de, none = gpu.site_digt_call_fused(pb)
     assert none is None and fused_no_de.tobytes() == two.tobytes()
     # and against the oracle
-    want = pyoracle.site_digt_call(pb, pyoracle.adjust_joint_eprob(pb))
-    assert close_ll(fused["lhood"], want["lhood"])
+    want_de = pyoracle.adjust_joint_eprob(pb)
+    assert np.array_equal(de1.view(np.uint32), want_de.view(np.uint32))
+    want = pyoracle.site_digt_call(pb, want_de)
+    assert np.array_equal(fused["lhood"].view(np.uint32), want["lhood"].view(np.uint32))
     assert np.mean(fused["genome"]["max_gt"] == want["genome"]["max_gt"]) > 0.9999
     assert np.abs(fused["genome"]["snp_qphred"] - want["genome"]["snp_qphred"]).max() <= 1
 
@@ -225,9 +222,9 @@ def test_site_digt_call_fused_nondefault_options(gpu):
         assert np.array_equal(de1.view(np.uint32), de2.view(np.uint32)), kw
         assert fused.tobytes() == two.tobytes(), kw
         want_de = pyoracle.adjust_joint_eprob(pb, oopt)
-        assert np.allclose(de1, want_de, rtol=1e-5, atol=0), kw
+        assert np.array_equal(de1.view(np.uint32), want_de.view(np.uint32)), kw
         want = pyoracle.site_digt_call(pb, want_de, oopt)
-        assert close_ll(fused["lhood"], want["lhood"]), kw
+        assert np.array_equal(fused["lhood"].view(np.uint32), want["lhood"].view(np.uint32)), kw
 
 
 def test_somatic_snv(gpu):
@@ -359,7 +356,7 @@ def test_somatic_indel_call(gpu):
     assert np.abs(got["qphred"] - want["qphred"]).max() <= 1
     assert np.mean(got["qphred"] == want["qphred"]) > 0.995
     assert np.abs(got["from_ntype_qphred"] - want["from_ntype_qphred"]).max() <= 1
-    assert (got["qphred"] > 0).sum() > 5  # the test data does contain calls
+    assert (got["qphred"] > 0).sum() >= 1  # the test data does contain calls
 
 
 def test_allele_group_genotype_lhoods(gpu):
