@@ -1,24 +1,49 @@
-// libm_check.cpp -- TEST INFRASTRUCTURE: compares strelka_amd/csrc/libm_flt32.h (the restatement of glibc's powf / logf that
-// the kernels use for the reference's std::pow(float,float) / std::log(float) calls) with the host libm, bit for bit, on N
-// pseudo-random arguments of the domain the path uses.  Built and run by tests/test_libm_restatement.py.
+// libm_check.cpp -- TEST INFRASTRUCTURE: compares strelka_amd/csrc/libm_flt32.h (the restatement of glibc's powf / logf /
+// expf / log1pf that the kernels use for the reference's std::pow(float,float), std::log(float), std::exp(float) and
+// log1p(float) calls) with the host libm, bit for bit, on N pseudo-random arguments of the domains the path uses.
+// Built and run by tests/test_libm_restatement.py.
 #include "../strelka_amd/csrc/libm_flt32.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-int main(int argc,char**argv){
-  long n=atol(argv[1]); unsigned long long st=88172645463325252ull; long badp=0,badl=0,fall=0;
-  for(long it=0;it<n;++it){
-    st^=st<<13; st^=st>>7; st^=st<<17;
-    int q=3+(st%68);
-    float e=(float)std::pow(10.0,-0.1*q);
-    if(it&1){ uint32_t u=sk_libm::as_u32(e); u+=(st>>20)%2048; e=sk_libm::as_f32(u);}
-    float v=(float)(((st>>32)%1000000)/1000000.0); if(v<=0)v=0.25f;
-    float a=powf(e,v), b=0; if(!sk_libm::powf_glibc(e,v,b)) {fall++; b=a;}
-    if(sk_libm::as_u32(a)!=sk_libm::as_u32(b)) badp++;
-    float x=sk_libm::as_f32(0x33000000u+(uint32_t)((st>>8)%0x0c800000u));
-    float la=logf(x), lb=0; if(!sk_libm::logf_glibc(x,lb)) {fall++; lb=la;}
-    if(sk_libm::as_u32(la)!=sk_libm::as_u32(lb)) badl++;
-  }
-  printf("n=%ld powf mismatches %ld logf mismatches %ld fallbacks %ld\n",n,badp,badl,fall);
-  return badp||badl;
+using namespace sk_libm;
+int main(int argc, char** argv)
+{
+    const long n = (argc > 1) ? atol(argv[1]) : 1000000;
+    unsigned long long st = 88172645463325252ull;
+    long badp = 0, badl = 0, bade = 0, bad1 = 0, fall = 0;
+    for (long it = 0; it < n; ++it) {
+        st ^= st << 13;
+        st ^= st >> 7;
+        st ^= st << 17;
+        // powf: error probabilities of q-scores 3..70 (and neighbouring floats), exponents in (0, 1]
+        const int q = 3 + int(st % 68);
+        float e = float(std::pow(10.0, -0.1 * q));
+        if (it & 1) e = as_f32(as_u32(e) + uint32_t((st >> 20) % 2048));
+        float v = float(double((st >> 32) % 1000000) / 1000000.0);
+        if (v <= 0) v = 0.25f;
+        float a = powf(e, v), b = 0;
+        if (!powf_glibc(e, v, b)) { fall++; b = a; }
+        badp += as_u32(a) != as_u32(b);
+        // logf: 2^-25 .. 1
+        const float x = as_f32(0x33000000u + uint32_t((st >> 8) % 0x0c800000u));
+        a = logf(x);
+        if (!logf_glibc(x, b)) { fall++; b = a; }
+        badl += as_u32(a) != as_u32(b);
+        // expf: (-110, 0], dense near 0
+        float xe = -float(double(st % 11000000) / 100000.0);
+        if (it & 1) xe = -float(double((st >> 8) % 1000000) / 1.0e8);
+        a = expf(xe);
+        if (!expf_glibc(xe, b)) { fall++; b = a; }
+        bade += as_u32(a) != as_u32(b);
+        // log1pf: ~1e-19 .. 0.01 and 0.01 .. 0.41
+        const float x1 = (it & 2) ? as_f32(0x20000000u + uint32_t((st >> 16) % (0x3c23d70au - 0x20000000u)))
+                                  : as_f32(0x3c23d70au + uint32_t((st >> 16) % (0x3ed413d7u - 0x3c23d70au)));
+        a = log1pf(x1);
+        if (!log1pf_glibc(x1, b)) { fall++; b = a; }
+        bad1 += as_u32(a) != as_u32(b);
+    }
+    printf("n=%ld powf mismatches %ld logf mismatches %ld expf mismatches %ld log1pf mismatches %ld fallbacks %ld\n", n, badp, badl,
+           bade, bad1, fall);
+    return (badp || badl || bade || bad1 || fall) ? 1 : 0;
 }

@@ -4,7 +4,8 @@
 // the host C library.  glibc (>= 2.28; this image: 2.35) implements both in sysdeps/ieee754/flt-32/{e_powf,e_logf}.c with
 // the table-driven double-precision algorithms of ARM's optimized-routines: a 16-entry log table + degree-5 (powf) or
 // degree-3 (logf) polynomial, and for powf a 32-entry exp2 table + cubic.  Those few dozen double operations are
-// restated below, so the device produces the SAME float, bit for bit, as the reference's libm call -- the device
+// restated below (with expf and the fdlibm log1pf the somatic strand states' float log-sum needs), so the device
+// produces the SAME float, bit for bit, as the reference's libm call -- the device
 // library's own pow/log are accurate but round differently now and then.  x86-64 glibc runs its FMA build of these
 // routines on every CPU with FMA (ifunc); the multiply-adds below are fused accordingly.
 //
@@ -151,6 +152,67 @@ SK_HD bool powf_glibc(const float x, const float y, float& out)
     v = fma_(zz, rr2, v);
     v = v * s;
     out = float(v);
+    return true;
+}
+
+/// glibc expf (e_expf.c) for x <= 88: the main path plus the underflow cut-off.  Shares the exp2 table with powf.
+SK_HD bool expf_glibc(const float x, float& out)
+{
+    constexpr uint64_t E[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+        0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+        0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+        0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+        0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+        0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull };
+    constexpr double INVLN2_SCALED = 0x1.71547652b82fep+5; // 32 / ln 2
+    constexpr double SHIFT = 0x1.8p+52;
+    constexpr double C[3] = { 0x1.c6af84b912394p-20, 0x1.ebfce50fac4f3p-13, 0x1.62e42ff0c52d6p-6 }; // poly / 32^(3,2,1)
+    if (!(x <= 88.0f)) return false;      // overflow range, nan
+    if (x < -0x1.9fe368p6f) {             // x < log(0x1p-150): underflows to +0 (includes -inf)
+        out = 0.f;
+        return true;
+    }
+    // x*32/ln2 = k + r, r in [-1/2, 1/2]
+    const double xd = double(x);
+    const double z = INVLN2_SCALED * xd;
+    double kd = fma_(INVLN2_SCALED, xd, SHIFT);
+    const uint64_t ki = as_u64(kd);
+    kd -= SHIFT;
+    const double r = fma_(INVLN2_SCALED, xd, -kd); // (z - kd with the product fused, as the FMA build does)
+    (void)z;
+    uint64_t t = E[ki % 32u];
+    t += ki << (52 - 5);
+    const double s = as_f64(t);
+    const double zz = fma_(C[0], r, C[1]);
+    const double r2 = r * r;
+    double y = fma_(C[2], r, 1.0);
+    y = fma_(zz, r2, y);
+    y = y * s;
+    out = float(y);
+    return true;
+}
+
+/// glibc log1pf (s_log1pf.c, the fdlibm float routine) for 0 <= x < 0.41422: single-precision arithmetic, no fused ops
+/// (there is no FMA build of this one).  Callers must compile with -ffp-contract=off.
+SK_HD bool log1pf_glibc(const float x, float& out)
+{
+    const uint32_t hx = as_u32(x);
+    if (hx >= 0x3ed413d7u) return false; // negative, >= 0.41422, inf, nan
+    if (hx < 0x31000000u) {              // x < 2^-29
+        out = (hx < 0x24800000u) ? x : x - x * x * 0.5f;
+        return true;
+    }
+    const float Lp1 = as_f32(0x3F2AAAABu), Lp2 = as_f32(0x3ECCCCCDu), Lp3 = as_f32(0x3E924925u), Lp4 = as_f32(0x3E638E29u),
+                Lp5 = as_f32(0x3E3A3325u), Lp6 = as_f32(0x3E1CD04Fu), Lp7 = as_f32(0x3E178897u);
+    const float f = x;
+    const float hfsq = 0.5f * f * f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+    out = f - (hfsq - s * (hfsq + R));
     return true;
 }
 

@@ -159,6 +159,10 @@ static bool host_libm_matches_restatement()
         if (!sk_libm::powf_glibc(e, v, mine) || sk_libm::as_u32(mine) != sk_libm::as_u32(std::pow(ve, vv))) return false;
         volatile float x = sk_libm::as_f32(0x33000000u + uint32_t((st >> 8) % 0x0c800000u));
         if (!sk_libm::logf_glibc(x, mine) || sk_libm::as_u32(mine) != sk_libm::as_u32(std::log(x))) return false;
+        volatile float xe = -static_cast<float>(double(st % 11000000) / 100000.0);
+        if (!sk_libm::expf_glibc(xe, mine) || sk_libm::as_u32(mine) != sk_libm::as_u32(std::exp(xe))) return false;
+        volatile float x1 = sk_libm::as_f32(0x20000000u + uint32_t((st >> 16) % (0x3ed413d7u - 0x20000000u)));
+        if (!sk_libm::log1pf_glibc(x1, mine) || sk_libm::as_u32(mine) != sk_libm::as_u32(std::log1p(x1))) return false;
     }
     return true;
 }

@@ -21,6 +21,7 @@ struct SomaticDerived
     float ln_one_half;   // (float) std::log(1./2.)
     float grid_frac[PRESTRAND];
     int is_forced_output;
+    int exact_libm; // the host libm's float routines are the ones restated in libm_flt32.h (checked by sk_init)
 };
 
 // error_prob_to_qphred<double>, L/blt_util/qscore.hh:40-47,60-66

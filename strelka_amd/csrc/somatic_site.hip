@@ -15,6 +15,7 @@
 // double-precision posterior evaluate device transcendentals.
 
 #include "somatic_common.h"
+#include "libm_flt32.h"
 
 #include <cstddef>
 
@@ -33,18 +34,25 @@ struct SomArgs
     SomaticDerived d;
 };
 
-// getLogSum<float>, L/blt_util/logSumUtil.hh:33-41 with log1p_switch<float>, L/blt_util/math_util.hh:33-48
-__device__ __forceinline__ float log_sum2f(float x1, float x2)
+// getLogSum<float>, L/blt_util/logSumUtil.hh:33-41 with log1p_switch<float>, L/blt_util/math_util.hh:33-48: the reference's
+// expf / log1pf / logf are the host libm's, restated for the device in libm_flt32.h; the device library's double-precision
+// functions rounded once stand in when the host libm is another implementation (sk_libm_restated() == 0)
+__device__ __forceinline__ float log_sum2f(float x1, float x2, const int exact_libm)
 {
     if (x1 < x2) {
         const float t = x1;
         x1 = x2;
         x2 = t;
     }
-    // expf/log1pf/logf of glibc are evaluated in double and rounded once; so are these
-    const float e = static_cast<float>(exp(static_cast<double>(__fsub_rn(x2, x1))));
-    const float l = (fabsf(e) < 0.01f) ? static_cast<float>(log1p(static_cast<double>(e)))
-                                       : static_cast<float>(log(static_cast<double>(__fadd_rn(1.f, e))));
+    const float d = __fsub_rn(x2, x1);
+    float e, l;
+    if (!(exact_libm && sk_libm::expf_glibc(d, e))) e = static_cast<float>(exp(static_cast<double>(d)));
+    if (fabsf(e) < 0.01f) {
+        if (!(exact_libm && sk_libm::log1pf_glibc(e, l))) l = static_cast<float>(log1p(static_cast<double>(e)));
+    } else {
+        const float one_e = __fadd_rn(1.f, e);
+        if (!(exact_libm && sk_libm::logf_glibc(one_e, l))) l = static_cast<float>(log(static_cast<double>(one_e)));
+    }
     return __fadd_rn(x1, l);
 }
 
@@ -153,7 +161,7 @@ __device__ __forceinline__ void accumulate_calls(const uint16_t* row, const int 
 // request is a full segment and the buffer stays small enough for the register file to bound the occupancy.
 template <bool WITH_STRAND>
 __device__ __forceinline__ void sample_lhood(const sk_pileup_batch& b, const int l, const unsigned ref_gt, uint32_t* rows,
-                                             const QRow* Q, const float ln_one_half, float* __restrict__ lhood, unsigned& alt_id)
+                                             const QRow* Q, const float ln_one_half, const int exact_libm, float* __restrict__ lhood, unsigned& alt_id)
 {
     const int lane = threadIdx.x & 63;
     int64_t g0 = 0;
@@ -193,7 +201,7 @@ __device__ __forceinline__ void sample_lhood(const sk_pileup_batch& b, const int
     for (int i = 0; i < PRESTRAND; ++i) lhood[i] = A.acc[i];
 #pragma unroll
     for (int r = 0; r < HET_RES; ++r)
-        lhood[PRESTRAND + r] = WITH_STRAND ? __fadd_rn(log_sum2f(A.sf[r], A.sr[r]), ln_one_half) : 0.f;
+        lhood[PRESTRAND + r] = WITH_STRAND ? __fadd_rn(log_sum2f(A.sf[r], A.sr[r], exact_libm), ln_one_half) : 0.f;
 
     // snp_pos_info::get_most_frequent_alt_id, L/blt_common/snp_pos_info.hh:164-190
     alt_id = ref_gt;
@@ -326,12 +334,12 @@ __global__ __launch_bounds__(SOM_THREADS) __attribute__((amdgpu_waves_per_eu(SOM
     unsigned alt_n, alt_t;
     {
         float lh[GRID];
-        sample_lhood<false>(a.n, l, ref, rows, s_q, ln_one_half, lh, alt_n);
+        sample_lhood<false>(a.n, l, ref, rows, s_q, ln_one_half, a.d.exact_libm, lh, alt_n);
         emit_lhood_block(rows, l, lh, a.out, 0);
     }
     {
         float lh[GRID];
-        sample_lhood<true>(a.t, l, ref, rows, s_q, ln_one_half, lh, alt_t);
+        sample_lhood<true>(a.t, l, ref, rows, s_q, ln_one_half, a.d.exact_libm, lh, alt_t);
         emit_lhood_block(rows, l, lh, a.out, GRID);
     }
     if (l >= 0) {
@@ -430,6 +438,7 @@ void derive(const sk_somatic_snv_options& opt, int is_forced_output, SomaticDeri
         d.grid_frac[index] = f;
     }
     d.is_forced_output = is_forced_output ? 1 : 0;
+    d.exact_libm = sk_ctx().libm_restated ? 1 : 0;
 }
 
 } // namespace

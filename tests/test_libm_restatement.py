@@ -14,4 +14,4 @@ def test_restatement_matches_host_libm(tmp_path):
                    check=True)
     out = subprocess.run([exe, "10000000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
-    assert "powf mismatches 0 logf mismatches 0 fallbacks 0" in out.stdout
+    assert "powf mismatches 0 logf mismatches 0 expf mismatches 0 log1pf mismatches 0 fallbacks 0" in out.stdout
