@@ -1,8 +1,8 @@
-// libm_check.cpp -- TEST INFRASTRUCTURE: compares strelka_amd/csrc/libm_flt32.h (the restatement of glibc's powf / logf /
-// expf / log1pf that the kernels use for the reference's std::pow(float,float), std::log(float), std::exp(float) and
+// libm_check.cpp -- TEST INFRASTRUCTURE: compares strelka_amd/csrc/libm_flt32.h and libm_dbl64.h (the restatement of glibc's
+// powf / logf / expf / log1pf and double exp / log / log10 that the kernels use for the reference's std::pow(float,float), std::log(float), std::exp(float) and
 // log1p(float) calls) with the host libm, bit for bit, on N pseudo-random arguments of the domains the path uses.
 // Built and run by tests/test_libm_restatement.py.
-#include "../strelka_amd/csrc/libm_flt32.h"
+#include "../strelka_amd/csrc/libm_dbl64.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,7 +11,7 @@ int main(int argc, char** argv)
 {
     const long n = (argc > 1) ? atol(argv[1]) : 1000000;
     unsigned long long st = 88172645463325252ull;
-    long badp = 0, badl = 0, bade = 0, bad1 = 0, fall = 0;
+    long badp = 0, badl = 0, bade = 0, bad1 = 0, fall = 0, badde = 0, baddl = 0, badd10 = 0;
     for (long it = 0; it < n; ++it) {
         st ^= st << 13;
         st ^= st >> 7;
@@ -42,7 +42,25 @@ int main(int argc, char** argv)
         a = log1pf(x1);
         if (!log1pf_glibc(x1, b)) { fall++; b = a; }
         bad1 += as_u32(a) != as_u32(b);
+        // double exp: (-760, 0] incl. the subnormal-result range, dense near 0, tiny, and a few positive
+        double xd = -double(st % 760000000) / 1.0e6;
+        if ((it & 3) == 1) xd = -double((st >> 8) % 1000000) / 1.0e9;
+        if ((it & 3) == 2) xd = double((st >> 8) % 1000000) / 1.0e4;
+        if ((it & 7) == 7) xd = -double((st >> 8) % 1000000) * 0x1p-70;
+        double da = exp(xd), db = 0;
+        if (!exp_glibc(xd, db)) { fall++; db = da; }
+        badde += as_u64(da) != as_u64(db);
+        // double log / log10: the range close to 1, and all positive normal magnitudes
+        double xl = (it & 1) ? 0.9375 + double(st % 12720000) / 1.0e8 : as_f64(0x0010000000000000ull + (st % 0x7fe0000000000000ull));
+        da = log(xl);
+        if (!log_glibc(xl, db)) { fall++; db = da; }
+        baddl += as_u64(da) != as_u64(db);
+        da = log10(xl);
+        if (!log10_glibc(xl, db)) { fall++; db = da; }
+        badd10 += as_u64(da) != as_u64(db);
     }
+    printf("n=%ld exp mismatches %ld log mismatches %ld log10 mismatches %ld\n", n, badde, baddl, badd10);
+    if (badde || baddl || badd10) return 1;
     printf("n=%ld powf mismatches %ld logf mismatches %ld expf mismatches %ld log1pf mismatches %ld fallbacks %ld\n", n, badp, badl,
            bade, bad1, fall);
     return (badp || badl || bade || bad1 || fall) ? 1 : 0;

@@ -2,7 +2,7 @@
 #pragma once
 
 #include "sk_common.h"
-#include "libm_flt32.h"
+#include "libm_dbl64.h"
 
 #include <cmath>
 #include <cstring>
@@ -28,10 +28,10 @@ struct GermlineDerived
 // scalar helpers (device restatements; the oracle has the same functions on the CPU)
 
 // error_prob_to_qphred<double>, L/blt_util/qscore.hh:40-47,60-66
-__device__ __forceinline__ int error_prob_to_qphred_d(const double prob)
+__device__ __forceinline__ int error_prob_to_qphred_d(const double prob, const int exact_libm, const SkLibmTables& lt)
 {
     const double minlog10 = -307.; // std::numeric_limits<double>::min_exponent10
-    const double l = log10(prob);
+    const double l = sk_log10(prob, exact_libm, lt);
     const double m = (minlog10 < l) ? l : minlog10;
     return static_cast<int>(floor(__dadd_rn(__dmul_rn(-10., m), 0.5)));
 }
@@ -81,8 +81,8 @@ __device__ __forceinline__ unsigned digt_a1(const unsigned gt)
 }
 
 // calculate_result_set, position_snp_call_pprob_digt.cpp:412-433 (normalizeLogDistro + prob_comp, prob_util.hh:177-237)
-__device__ void calculate_result_set(const float* lhood, const float* lnprior, const unsigned ref_gt,
-                                     sk_digt_result_set& rs)
+__device__ void calculate_result_set(const float* lhood, const float* lnprior, const unsigned ref_gt, const int exact_libm,
+                                     const SkLibmTables& lt, sk_digt_result_set& rs)
 {
     double pprob[10];
 #pragma unroll
@@ -98,7 +98,7 @@ __device__ void calculate_result_set(const float* lhood, const float* lnprior, c
     double sum = 0.;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        pprob[i] = exp(__dsub_rn(pprob[i], mx));
+        pprob[i] = sk_exp(__dsub_rn(pprob[i], mx), exact_libm, lt);
         sum = __dadd_rn(sum, pprob[i]);
     }
     sum = __ddiv_rn(1., sum);
@@ -111,8 +111,8 @@ __device__ void calculate_result_set(const float* lhood, const float* lnprior, c
     }
     rs.max_gt = max_idx;
     rs.ref_pprob = refp;
-    rs.snp_qphred = error_prob_to_qphred_d(refp);
-    rs.max_gt_qphred = error_prob_to_qphred_d(comp);
+    rs.snp_qphred = error_prob_to_qphred_d(refp, exact_libm, lt);
+    rs.max_gt_qphred = error_prob_to_qphred_d(comp, exact_libm, lt);
     rs._pad = 0;
 }
 
@@ -498,8 +498,9 @@ __device__ void locus_site_digt_call_global(const sk_pileup_batch& B, const floa
     }
     const float* pg = D.lnprior[is_haploid ? 1 : 0][ref][0];
     const float* pp = D.lnprior[is_haploid ? 1 : 0][ref][1];
-    calculate_result_set(lh, pg, ref, res.genome);
-    calculate_result_set(lh, pp, ref, res.poly);
+    const SkLibmTables lt = sk_libm_tables_default();
+    calculate_result_set(lh, pg, ref, D.exact_libm, lt, res.genome);
+    calculate_result_set(lh, pp, ref, D.exact_libm, lt, res.poly);
 
     if (res.genome.snp_qphred != 0) { // strand bias (:520-534): only lhood_{fwd,rev}[max_gt] are consumed
         const unsigned tgt = res.genome.max_gt;

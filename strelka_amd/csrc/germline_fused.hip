@@ -28,6 +28,10 @@
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef G3_LIBM_LDS
+#define G3_LIBM_LDS 1
+#endif
+
 namespace
 {
 
@@ -348,7 +352,7 @@ __device__ bool locus_rank_calls(uint16_t* calls, uint16_t* keys, const int n, c
 // phase 2 for one locus in LDS
 __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigned ref, const int ploidy,
                                const float* v0r, const unsigned gbase, const SkTables* __restrict__ T,
-                               const GermlineDerived& D, const QTab& Q, sk_digt_call& res)
+                               const GermlineDerived& D, const QTab& Q, const SkLibmTables& lt, sk_digt_call& res)
 {
     memset(&res, 0, sizeof(res));
     if (ref >= 4) return;
@@ -383,8 +387,8 @@ __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigne
         for (int gt = 0; gt < 10; ++gt)
             res.phredLoghood[gt] = (gt < gtcount) ? unsigned(ln_error_prob_to_qphred_f(__fsub_rn(lh[gt], best), D.ln10f)) : 0u;
     }
-    calculate_result_set(lh, D.lnprior[is_haploid ? 1 : 0][ref][0], ref, res.genome);
-    calculate_result_set(lh, D.lnprior[is_haploid ? 1 : 0][ref][1], ref, res.poly);
+    calculate_result_set(lh, D.lnprior[is_haploid ? 1 : 0][ref][0], ref, D.exact_libm, lt, res.genome);
+    calculate_result_set(lh, D.lnprior[is_haploid ? 1 : 0][ref][1], ref, D.exact_libm, lt, res.poly);
 
     if (res.genome.snp_qphred != 0) {
         const unsigned tgt = res.genome.max_gt;
@@ -419,6 +423,9 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(3
     __shared__ float s_pool[V0R_POOL];
     __shared__ unsigned s_pool_ctr;
     __shared__ QTab s_q;
+#if G3_LIBM_LDS
+    __shared__ uint64_t s_libm[512];
+#endif
 
     const int tid = threadIdx.x;
     const int l0 = blockIdx.x * LOCI_PER_BLOCK;
@@ -432,6 +439,11 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(3
         s_q.eprob[q] = a.tab->g_eprob[q];
         s_q.depmin[q] = a.d.depmin[q];
     }
+#if G3_LIBM_LDS
+    const SkLibmTables lt = sk_libm_tables_to_lds(s_libm, tid, FUSED_THREADS);
+#else
+    const SkLibmTables lt = sk_libm_tables_default();
+#endif
     __syncthreads();
     if (huge) { // (a block spanning > 2^31 calls: every locus to the global-memory pass)
         if (tid < nl) {
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(3
             if (ok) ok = locus_rank_calls(s_calls + off, s_keys + off, n, T, a.d, s_q, vfrac, s_pool, &s_pool_ctr, v0r, gbase);
             if (ok) {
                 sk_digt_call res;
-                locus_call_lds(s_calls + off, n, ref, ploidy, v0r, gbase, T, a.d, s_q, res);
+                locus_call_lds(s_calls + off, n, ref, ploidy, v0r, gbase, T, a.d, s_q, lt, res);
                 a.out[l] = res;
                 if (a.want_de) {
                     float* __restrict__ de = a.de_tmp + block_c0 + s_off[t];

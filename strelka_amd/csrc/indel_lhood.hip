@@ -178,6 +178,7 @@ struct PostArgs
 
 __global__ void somatic_indel_posterior_kernel(const PostArgs a)
 {
+    const SkLibmTables lt = sk_libm_tables_default();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     sk_somatic_indel_call res;
@@ -192,7 +193,7 @@ __global__ void somatic_indel_posterior_kernel(const PostArgs a)
     SomaticDerived d = a.d;
     d.ln_sse_rate = a.ln_sse[i];
     d.ln_csse_rate = a.ln_csse[i];
-    calculate_result_set_grid(d, nf, tf, res);
+    calculate_result_set_grid(d, lt, nf, tf, res);
     a.out[i] = res;
 }
 
@@ -539,6 +540,7 @@ int sk_somatic_indel_call_batch(const sk_readscore_batch* hn, const sk_readscore
     std::memset(&p.d, 0, sizeof(p.d));
     // somatic_indel_caller_grid ctor, somatic_indel_grid.cpp:58-64
     p.d.contam_tolerance = (float)sopt->indel_contam_tolerance;
+    p.d.exact_libm = sk_ctx().libm_restated ? 1 : 0;
     p.d.ln_som_match = h_log1p_switch(-sopt->somatic_indel_rate);
     p.d.ln_som_mismatch = std::log(sopt->somatic_indel_rate);
     p.d.lnprior[SOM_REF] = (float)h_log1p_switch(-(3. * sopt->bindel_diploid_theta) / 2.);

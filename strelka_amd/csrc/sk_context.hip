@@ -4,7 +4,7 @@
 // by the compiler: inputs pass through `rt()` (a volatile round trip).
 
 #include "sk_common.h"
-#include "libm_flt32.h"
+#include "libm_dbl64.h"
 
 #include <cmath>
 #include <cstring>
@@ -163,6 +163,13 @@ static bool host_libm_matches_restatement()
         if (!sk_libm::expf_glibc(xe, mine) || sk_libm::as_u32(mine) != sk_libm::as_u32(std::exp(xe))) return false;
         volatile float x1 = sk_libm::as_f32(0x20000000u + uint32_t((st >> 16) % (0x3ed413d7u - 0x20000000u)));
         if (!sk_libm::log1pf_glibc(x1, mine) || sk_libm::as_u32(mine) != sk_libm::as_u32(std::log1p(x1))) return false;
+        double dm;
+        volatile double xd = -double(st % 760000000) / 1.0e6;
+        if (!sk_libm::exp_glibc(xd, dm) || sk_libm::as_u64(dm) != sk_libm::as_u64(std::exp(xd))) return false;
+        volatile double xl = (it & 1) ? 0.9375 + double(st % 12720000) / 1.0e8
+                                      : sk_libm::as_f64(0x0010000000000000ull + (st % 0x7fe0000000000000ull));
+        if (!sk_libm::log_glibc(xl, dm) || sk_libm::as_u64(dm) != sk_libm::as_u64(std::log(xl))) return false;
+        if (!sk_libm::log10_glibc(xl, dm) || sk_libm::as_u64(dm) != sk_libm::as_u64(std::log10(xl))) return false;
     }
     return true;
 }

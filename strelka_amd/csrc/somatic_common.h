@@ -2,6 +2,7 @@
 #pragma once
 
 #include "sk_common.h"
+#include "libm_dbl64.h"
 
 #include <cmath>
 #include <cstring>
@@ -25,10 +26,10 @@ struct SomaticDerived
 };
 
 // error_prob_to_qphred<double>, L/blt_util/qscore.hh:40-47,60-66
-__device__ __forceinline__ int error_prob_to_qphred_d(const double prob)
+__device__ __forceinline__ int error_prob_to_qphred_d(const double prob, const int exact_libm, const SkLibmTables& lt)
 {
     const double minlog10 = -307.;
-    const double l = log10(prob);
+    const double l = sk_log10_call(prob, exact_libm, lt);
     const double m = (minlog10 < l) ? l : minlog10;
     return static_cast<int>(floor(__dadd_rn(__dmul_rn(-10., m), 0.5)));
 }
@@ -36,8 +37,8 @@ __device__ __forceinline__ int error_prob_to_qphred_d(const double prob)
 // calculate_result_set_grid, L/applications/strelka/qscore_calculator.cpp:47-209.  The (Fn,Ft) enumeration order of the
 // reference is kept so that the running max / sums see the terms in the same order.
 template <typename ResultT>
-__device__ void calculate_result_set_grid(const SomaticDerived& d, const float* normal_lhood, const float* tumor_lhood,
-                                          ResultT& rs)
+__device__ void calculate_result_set_grid(const SomaticDerived& d, const SkLibmTables& lt, const float* normal_lhood,
+                                          const float* tumor_lhood, ResultT& rs)
 {
     const double neg_inf = -INFINITY;
     double log_post_prob[SOM_SIZE][2];
@@ -69,7 +70,7 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const float* 
             } else {
                 // exp() of anything at or below -746 is exactly 0 and adding it changes nothing
                 const double dlt = __dsub_rn(lsum, mx[ngt][tgt]);
-                if (!(dlt <= -746.)) sm[ngt][tgt] = __dadd_rn(sm[ngt][tgt], exp(dlt));
+                if (!(dlt <= -746.)) sm[ngt][tgt] = __dadd_rn(sm[ngt][tgt], sk_exp_call(dlt, d.exact_libm, lt));
             }
         };
 #pragma unroll
@@ -92,7 +93,7 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const float* 
 #pragma unroll
         for (unsigned tgt = 0; tgt < 2; ++tgt) {
             const double log_genotype_prior = static_cast<double>(__fadd_rn(d.lnprior[ngt], (tgt == 0) ? d.ln_som_match : d.ln_som_mismatch));
-            log_post_prob[ngt][tgt] = __dadd_rn(__dadd_rn(log_genotype_prior, mx[ngt][tgt]), log(sm[ngt][tgt]));
+            log_post_prob[ngt][tgt] = __dadd_rn(__dadd_rn(log_genotype_prior, mx[ngt][tgt]), sk_log_call(sm[ngt][tgt], d.exact_libm, lt));
             if (log_post_prob[ngt][tgt] > max_log_prob) {
                 max_log_prob = log_post_prob[ngt][tgt];
                 max_gt = ngt * 2 + tgt;
@@ -103,8 +104,8 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const float* 
     double sum_prob = 0.0;
     for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt)
         for (unsigned tgt = 0; tgt < 2; ++tgt)
-            sum_prob = __dadd_rn(sum_prob, exp(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob)));
-    const double log_sum_prob = log(sum_prob);
+            sum_prob = __dadd_rn(sum_prob, sk_exp_call(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob), d.exact_libm, lt));
+    const double log_sum_prob = sk_log_call(sum_prob, d.exact_libm, lt);
     double min_not_somfrom_sum = INFINITY;
     double nonsom_prob = 0.0;
     int from_ntype_qphred = 0;
@@ -112,19 +113,19 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const float* 
     for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) {
         double som_prob_given_ngt = 0;
         for (unsigned tgt = 0; tgt < 2; ++tgt) {
-            const double pp = exp(__dsub_rn(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob), log_sum_prob));
+            const double pp = sk_exp_call(__dsub_rn(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob), log_sum_prob), d.exact_libm, lt);
             if (tgt == 0) nonsom_prob = __dadd_rn(nonsom_prob, pp);
             else som_prob_given_ngt = __dadd_rn(som_prob_given_ngt, pp);
         }
         const double err_som_and_ngt = __dsub_rn(1.0, som_prob_given_ngt);
         if (err_som_and_ngt < min_not_somfrom_sum) {
             min_not_somfrom_sum = err_som_and_ngt;
-            from_ntype_qphred = error_prob_to_qphred_d(err_som_and_ngt);
+            from_ntype_qphred = error_prob_to_qphred_d(err_som_and_ngt, d.exact_libm, lt);
             ntype = ngt;
         }
     }
     rs.max_gt = max_gt;
-    rs.qphred = error_prob_to_qphred_d(nonsom_prob);
+    rs.qphred = error_prob_to_qphred_d(nonsom_prob, d.exact_libm, lt);
     rs.from_ntype_qphred = from_ntype_qphred;
     rs.ntype = ntype;
 }

@@ -351,8 +351,10 @@ __global__ __launch_bounds__(SOM_THREADS) __attribute__((amdgpu_waves_per_eu(SOM
 // S2: posterior of the queued loci from the likelihoods S1 left in their records (a13)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOM_POST_WPE, SOM_POST_WPE))) void somatic_posterior_kernel(const SomArgs a)
 {
+    const unsigned n_work = a.work[0];
     const unsigned w = blockIdx.x * 256u + threadIdx.x;
-    if (w >= a.work[0]) return;
+    if (w >= n_work) return;
+    const SkLibmTables lt = sk_libm_tables_default(); // (an LDS copy of the tables measured slower here: flat addressing)
     const int l = int(a.work[1 + w]);
     sk_somatic_snv_call* o = a.out + l;
     float nl[PRESTRAND], tl[GRID];
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOM_POST_WP
         int32_t qphred, from_ntype_qphred;
         uint32_t ntype;
     } rs;
-    calculate_result_set_grid(a.d, nl, tl, rs);
+    calculate_result_set_grid(a.d, lt, nl, tl, rs);
     float strand_bias = 0.f;
     if (a.d.is_forced_output || rs.qphred != 0) { // strand bias (:216-225), skipped by the early return at :184
         float symm = tl[SOM_SIZE];
