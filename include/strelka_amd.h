@@ -20,6 +20,7 @@
 #ifndef STRELKA_AMD_H
 #define STRELKA_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -377,6 +378,15 @@ typedef struct sk_global_align_batch {
  *  Query and reference lengths must be in 1..1024 (the reference asserts non-empty). */
 int sk_global_align(const sk_global_align_batch* host_batch, const sk_align_scores* scores, int32_t* out_score,
                     int32_t* out_begin_pos, sk_path_seg* out_path, int32_t* out_n_seg);
+/** Device-resident twin: the batch arrays and the four outputs are device pointers (out_path: capacity
+ *  total_query_len + total_ref_len + 4n segments, same per-problem offsets).  max_*_len: upper bounds of the problem sizes.
+ *  dev_scratch: sk_global_align_scratch_bytes(...) bytes (reversed paths + one back-pointer byte per DP cell). */
+size_t sk_global_align_scratch_bytes(int32_t n, int64_t total_query_len, int64_t total_ref_len, int32_t max_query_len,
+                                     int32_t max_ref_len);
+int sk_global_align_dev(const sk_global_align_batch* dev_batch, int64_t total_query_len, int64_t total_ref_len,
+                        int32_t max_query_len, int32_t max_ref_len, const sk_align_scores* scores, int32_t* dev_out_score,
+                        int32_t* dev_out_begin_pos, sk_path_seg* dev_out_path, int32_t* dev_out_n_seg, void* dev_scratch,
+                        void* hip_stream);
 
 typedef struct sk_discovered_allele { /* an IndelKey found in a haplotype */
     int32_t pos;

@@ -193,7 +193,7 @@ EXPORTS = [
     "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
     "sk_indel_options_default", "sk_somatic_indel_options_default", "sk_indel_grid_lhood", "sk_indel_grid_lhood_dev",
     "sk_somatic_indel_call_batch", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
-    "sk_discover_indels_and_mismatches",
+    "sk_discover_indels_and_mismatches", "sk_global_align_scratch_bytes", "sk_global_align_dev",
 ]
 
 _lib = None

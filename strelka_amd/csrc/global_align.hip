@@ -43,7 +43,8 @@ struct GaArgs
     sk_path_seg* tmp_path; // same layout as out_path: reversed raw segments
     int32_t* out_nseg;
     uint8_t* ptr_scratch;  // back-pointers
-    const int64_t* ptr_off;
+    const int64_t* ptr_off; // per-problem offsets into ptr_scratch, or NULL: problem p starts at p * ptr_stride
+    int64_t ptr_stride;
     int max_ref;           // LDS sizing: boundary rows and the reference copy
     int max_query;         // LDS sizing: last-column scores
 };
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(WAVE) void global_align_kernel(const GaArgs a)
     int* s_rowA = s_last + (a.max_query + 1);
     int* s_rowB = s_rowA + 3 * RW;
     const int strips = (Q + WAVE - 1) / WAVE;
-    uint8_t* ptr = a.ptr_scratch + a.ptr_off[p];
+    uint8_t* ptr = a.ptr_scratch + (a.ptr_off ? a.ptr_off[p] : int64_t(p) * a.ptr_stride);
 
     for (int i = lane; i < R; i += WAVE) s_ref[i] = gr[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -360,6 +361,7 @@ int sk_global_align(const sk_global_align_batch* hb, const sk_align_scores* sc, 
     a.out_begin = ar.take<int32_t>(size_t(n));
     a.out_nseg = ar.take<int32_t>(size_t(n));
     a.ptr_scratch = ar.take<uint8_t>(size_t(ptr_off[size_t(n)]) + size_t(WIN) * WAVE); // + slack: a window read may run past the end
+    a.ptr_stride = 0;
     a.max_ref = maxR;
     a.max_query = maxQ;
     SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(global_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -370,6 +372,55 @@ int sk_global_align(const sk_global_align_batch* hb, const sk_align_scores* sc, 
     SK_HIP(hipMemcpyAsync(out_n_seg, a.out_nseg, 4 * size_t(n), hipMemcpyDeviceToHost, st));
     SK_HIP(hipMemcpyAsync(out_path, a.out_path, 8 * size_t(npath), hipMemcpyDeviceToHost, st));
     SK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+static int64_t ga_ptr_stride(const int max_query_len, const int max_ref_len)
+{
+    return int64_t((max_query_len + WAVE - 1) / WAVE) * (max_ref_len + WAVE) * WAVE;
+}
+
+size_t sk_global_align_scratch_bytes(int32_t n, int64_t total_query_len, int64_t total_ref_len, int32_t max_query_len,
+                                     int32_t max_ref_len)
+{
+    if (n <= 0) return 256;
+    const int64_t npath = total_query_len + total_ref_len + 4 * int64_t(n);
+    return sk_align256(8 * size_t(npath)) + sk_align256(size_t(n) * size_t(ga_ptr_stride(max_query_len, max_ref_len)) + size_t(WIN) * WAVE) + 512;
+}
+
+int sk_global_align_dev(const sk_global_align_batch* db, int64_t total_query_len, int64_t total_ref_len, int32_t max_query_len,
+                        int32_t max_ref_len, const sk_align_scores* sc, int32_t* dev_out_score, int32_t* dev_out_begin_pos,
+                        sk_path_seg* dev_out_path, int32_t* dev_out_n_seg, void* dev_scratch, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (!db || !sc || !dev_out_score || !dev_out_begin_pos || !dev_out_path || !dev_out_n_seg || !dev_scratch)
+        return sk_fail("sk_global_align_dev: null argument");
+    if (db->n < 0) return sk_fail("sk_global_align_dev: negative n");
+    if (db->n == 0) return 0;
+    if (max_query_len < 1 || max_ref_len < 1 || max_query_len > MAX_LEN || max_ref_len > MAX_LEN)
+        return sk_fail("sk_global_align_dev: query and reference lengths must be in 1..1024");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int64_t npath = total_query_len + total_ref_len + 4 * int64_t(db->n);
+    GaArgs a;
+    a.b = *db;
+    a.sc = *sc;
+    a.out_score = dev_out_score;
+    a.out_begin = dev_out_begin_pos;
+    a.out_path = dev_out_path;
+    a.out_nseg = dev_out_n_seg;
+    char* base = static_cast<char*>(dev_scratch);
+    base += (256 - (reinterpret_cast<uintptr_t>(base) & 255)) & 255;
+    a.tmp_path = reinterpret_cast<sk_path_seg*>(base);
+    a.ptr_scratch = reinterpret_cast<uint8_t*>(base + sk_align256(8 * size_t(npath)));
+    a.ptr_off = nullptr;
+    a.ptr_stride = ga_ptr_stride(max_query_len, max_ref_len);
+    a.max_ref = max_ref_len;
+    a.max_query = max_query_len;
+    const int RW = max_ref_len + 1;
+    const size_t lds = size_t(WIN) * WAVE + size_t((RW + 3) & ~3) + 4 * size_t(max_query_len + 1) + 2 * 12 * size_t(RW) + 16;
+    SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(global_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(global_align_kernel, dim3(db->n), dim3(WAVE), lds, st, a);
+    SK_HIP(hipGetLastError());
     return 0;
 }
 

@@ -222,3 +222,54 @@ class DeviceAlleleGroupBatch:
         capi._check(capi.lib().sk_allele_group_genotype_lhoods_dev(C.byref(s), C.byref(opt), C.c_void_p(self.out.data_ptr()),
                                                                    _stream_ptr()))
         return self.out
+
+
+class DeviceGlobalAlignBatch:
+    """(haplotype, reference segment) pairs resident on the device for sk_global_align_dev (next row f2)."""
+
+    def __init__(self, pairs, device="cuda:0"):
+        self.n = len(pairs)
+        qo = np.zeros(self.n + 1, np.int64)
+        ro = np.zeros(self.n + 1, np.int64)
+        for i, (q, r) in enumerate(pairs):
+            qo[i + 1] = qo[i] + len(q)
+            ro[i + 1] = ro[i] + len(r)
+        self.qo, self.ro = qo, ro
+        self.nq, self.nr = int(qo[-1]), int(ro[-1])
+        self.max_q = max((len(q) for q, _ in pairs), default=1)
+        self.max_r = max((len(r) for _, r in pairs), default=1)
+        self.cells = sum(len(q) * len(r) for q, r in pairs)
+        q = np.frombuffer("".join(q for q, _ in pairs).encode(), np.uint8).copy()
+        r = np.frombuffer("".join(r for _, r in pairs).encode(), np.uint8).copy()
+        self.t = dict(qo=_t(qo, device), q=_t(q, device), ro=_t(ro, device), r=_t(r, device))
+        self.npath = self.nq + self.nr + 4 * self.n
+        self.score = torch.empty(self.n, dtype=torch.int32, device=device)
+        self.begin = torch.empty(self.n, dtype=torch.int32, device=device)
+        self.nseg = torch.empty(self.n, dtype=torch.int32, device=device)
+        self.path = torch.empty((self.npath, 2), dtype=torch.int32, device=device)
+        L = capi.lib()
+        L.sk_global_align_scratch_bytes.restype = C.c_size_t
+        L.sk_global_align_scratch_bytes.argtypes = [C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
+        nbytes = L.sk_global_align_scratch_bytes(self.n, self.nq, self.nr, self.max_q, self.max_r)
+        self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        L.sk_global_align_dev.argtypes = [C.POINTER(capi.GlobalAlignBatch), C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                          C.POINTER(capi.AlignScores)] + [C.c_void_p] * 6
+
+    def align(self, scores=None):
+        scores = scores or capi.align_scores()
+        t = self.t
+        b = capi.GlobalAlignBatch(self.n, t["qo"].data_ptr(), t["q"].data_ptr(), t["ro"].data_ptr(), t["r"].data_ptr())
+        capi._check(capi.lib().sk_global_align_dev(C.byref(b), self.nq, self.nr, self.max_q, self.max_r, C.byref(scores),
+                                                   self.score.data_ptr(), self.begin.data_ptr(), self.path.data_ptr(),
+                                                   self.nseg.data_ptr(), self.scratch.data_ptr(), _stream_ptr()))
+
+    def results(self):
+        """-> [(score, begin_pos, cigar)] like capi.global_align"""
+        score, beg, nseg = self.score.cpu().numpy(), self.begin.cpu().numpy(), self.nseg.cpu().numpy()
+        path = self.path.cpu().numpy()
+        out = []
+        for i in range(self.n):
+            po = int(self.qo[i] + self.ro[i]) + 4 * i
+            out.append((int(score[i]), int(beg[i]),
+                        "".join("%d%s" % (path[po + k, 1], capi.CIGAR_CHARS[path[po + k, 0]]) for k in range(nseg[i]))))
+        return out

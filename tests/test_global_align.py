@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle
-from strelka_amd import capi
+from strelka_amd import capi, synth
 
 
 def _S(off_edge=-4, insert_delete=0, allow=0, require=0):
@@ -138,3 +138,13 @@ def test_gpu_large_problem_uses_global_back_pointers(gpu):
         capi.global_align([("A" * 1025, "ACGT")])
     with pytest.raises(capi.StrelkaAmdError, match="1..1024"):
         capi.global_align([("", "ACGT")])
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_entry_equals_host_entry(gpu):
+    from strelka_amd import device
+    rng = np.random.default_rng(412)
+    pairs = synth.align_pairs(300, rng, ref_len=(20, 330), max_edits=4)
+    d = device.DeviceGlobalAlignBatch(pairs, "cuda:0")
+    d.align()
+    assert d.results() == capi.global_align(pairs)
