@@ -43,8 +43,9 @@ def _stale(target, deps):
 
 def build_all(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
-    deps = _sources() + [os.path.join(ROOT, "include", "strelka_amd.h"), os.path.join(PKG, "csrc", "sk_common.h"), os.path.join(PKG, "csrc", "germline_common.h"), os.path.join(PKG, "csrc", "somatic_common.h"),
-                         os.path.abspath(__file__)]
+    import glob
+    deps = _sources() + glob.glob(os.path.join(PKG, "csrc", "*.h")) + [os.path.join(ROOT, "include", "strelka_amd.h"),
+                                                                       os.path.abspath(__file__)]
     if not force and not _stale(LIB_PATH, deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
