@@ -193,7 +193,7 @@ __global__ void somatic_indel_posterior_kernel(const PostArgs a)
     SomaticDerived d = a.d;
     d.ln_sse_rate = a.ln_sse[i];
     d.ln_csse_rate = a.ln_csse[i];
-    calculate_result_set_grid(d, lt, nf, tf, res);
+    calculate_result_set_grid<false>(d, lt, [&](const unsigned i) { return nf[i]; }, [&](const unsigned i) { return tf[i]; }, res);
     a.out[i] = res;
 }
 

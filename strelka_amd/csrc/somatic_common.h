@@ -36,10 +36,18 @@ __device__ __forceinline__ int error_prob_to_qphred_d(const double prob, const i
 
 // calculate_result_set_grid, L/applications/strelka/qscore_calculator.cpp:47-209.  The (Fn,Ft) enumeration order of the
 // reference is kept so that the running max / sums see the terms in the same order.
-template <typename ResultT>
-__device__ void calculate_result_set_grid(const SomaticDerived& d, const SkLibmTables& lt, const float* normal_lhood,
-                                          const float* tumor_lhood, ResultT& rs)
+//
+// Two shapes of the same arithmetic.  ROLLED = false: Ft is unrolled for all six (ngt,tgt) at once, so every likelihood
+// index is a compile-time constant and plain arrays stay in registers (the transcendental routines are then called out of
+// line: 150 inlined copies defeat the unrolling).  ROLLED = true: the Ft loop stays a loop, `normal_lhood(i)` /
+// `tumor_lhood(i)` are accessors of something indexable at run time (LDS), and the routines are inlined once.
+template <bool ROLLED, typename NL, typename TL, typename ResultT>
+__device__ void calculate_result_set_grid(const SomaticDerived& d, const SkLibmTables& lt, const NL& normal_lhood,
+                                          const TL& tumor_lhood, ResultT& rs)
 {
+    constexpr int UNROLL_FT = ROLLED ? 1 : int(PRESTRAND);
+    auto exp_ = [&](const double x) { return ROLLED ? sk_exp(x, d.exact_libm, lt) : sk_exp_call(x, d.exact_libm, lt); };
+    auto log_ = [&](const double x) { return ROLLED ? sk_log(x, d.exact_libm, lt) : sk_log_call(x, d.exact_libm, lt); };
     const double neg_inf = -INFINITY;
     double log_post_prob[SOM_SIZE][2];
     double max_log_prob = neg_inf;
@@ -47,9 +55,8 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const SkLibmT
     const float RATIO_INCREMENT = 0.5f / static_cast<float>(HET_RES + 1);
 
     // The reference fills log_sum[] for one (ngt,tgt) at a time, Ft outer / Fn inner, then takes the max and sums the
-    // exps in that order (:75-160).  Here Ft is the (unrolled) outer loop for all six (ngt,tgt) at once, so every
-    // likelihood index is a compile-time constant and the arrays stay in registers; each (ngt,tgt) still sees its own
-    // terms in the reference's order.  Two passes (max, then sum) instead of the 441-double buffer.
+    // exps in that order (:75-160).  Here Ft is the outer loop for all six (ngt,tgt) at once; each (ngt,tgt) still sees its
+    // own terms in the reference's order.  Two passes (max, then sum) instead of the 441-double buffer.
     double mx[SOM_SIZE][2], sm[SOM_SIZE][2];
 #pragma unroll
     for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) {
@@ -63,17 +70,17 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const SkLibmT
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         auto visit = [&](const unsigned ngt, const unsigned tgt, const unsigned nfi, const unsigned tfi, const double lprior_freq) {
-            const double lsum = __dadd_rn(__dadd_rn(lprior_freq, static_cast<double>(normal_lhood[nfi])),
-                                          static_cast<double>(tumor_lhood[tfi]));
+            const double lsum = __dadd_rn(__dadd_rn(lprior_freq, static_cast<double>(normal_lhood(nfi))),
+                                          static_cast<double>(tumor_lhood(tfi)));
             if (pass == 0) {
                 if (lsum > mx[ngt][tgt]) mx[ngt][tgt] = lsum;
             } else {
                 // exp() of anything at or below -746 is exactly 0 and adding it changes nothing
                 const double dlt = __dsub_rn(lsum, mx[ngt][tgt]);
-                if (!(dlt <= -746.)) sm[ngt][tgt] = __dadd_rn(sm[ngt][tgt], sk_exp_call(dlt, d.exact_libm, lt));
+                if (!(dlt <= -746.)) sm[ngt][tgt] = __dadd_rn(sm[ngt][tgt], exp_(dlt));
             }
         };
-#pragma unroll
+#pragma unroll UNROLL_FT
         for (unsigned tfi = 0; tfi < PRESTRAND; ++tfi) {
 #pragma unroll
             for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) visit(ngt, 0, tfi, tfi, (tfi == ngt) ? lp_match : lp_mismatch);
@@ -93,7 +100,7 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const SkLibmT
 #pragma unroll
         for (unsigned tgt = 0; tgt < 2; ++tgt) {
             const double log_genotype_prior = static_cast<double>(__fadd_rn(d.lnprior[ngt], (tgt == 0) ? d.ln_som_match : d.ln_som_mismatch));
-            log_post_prob[ngt][tgt] = __dadd_rn(__dadd_rn(log_genotype_prior, mx[ngt][tgt]), sk_log_call(sm[ngt][tgt], d.exact_libm, lt));
+            log_post_prob[ngt][tgt] = __dadd_rn(__dadd_rn(log_genotype_prior, mx[ngt][tgt]), log_(sm[ngt][tgt]));
             if (log_post_prob[ngt][tgt] > max_log_prob) {
                 max_log_prob = log_post_prob[ngt][tgt];
                 max_gt = ngt * 2 + tgt;
@@ -104,8 +111,8 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const SkLibmT
     double sum_prob = 0.0;
     for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt)
         for (unsigned tgt = 0; tgt < 2; ++tgt)
-            sum_prob = __dadd_rn(sum_prob, sk_exp_call(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob), d.exact_libm, lt));
-    const double log_sum_prob = sk_log_call(sum_prob, d.exact_libm, lt);
+            sum_prob = __dadd_rn(sum_prob, exp_(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob)));
+    const double log_sum_prob = log_(sum_prob);
     double min_not_somfrom_sum = INFINITY;
     double nonsom_prob = 0.0;
     int from_ntype_qphred = 0;
@@ -113,7 +120,7 @@ __device__ void calculate_result_set_grid(const SomaticDerived& d, const SkLibmT
     for (unsigned ngt = 0; ngt < SOM_SIZE; ++ngt) {
         double som_prob_given_ngt = 0;
         for (unsigned tgt = 0; tgt < 2; ++tgt) {
-            const double pp = sk_exp_call(__dsub_rn(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob), log_sum_prob), d.exact_libm, lt);
+            const double pp = exp_(__dsub_rn(__dsub_rn(log_post_prob[ngt][tgt], max_log_prob), log_sum_prob));
             if (tgt == 0) nonsom_prob = __dadd_rn(nonsom_prob, pp);
             else som_prob_given_ngt = __dadd_rn(som_prob_given_ngt, pp);
         }

@@ -100,7 +100,7 @@ __device__ __forceinline__ void fill_qrows(const SkTables* __restrict__ T, QRow*
 #define SOM_CHUNK 16
 #endif
 #ifndef SOM_POST_WPE
-#define SOM_POST_WPE 2  // S2: 256 VGPRs, no spills
+#define SOM_POST_WPE 3  // S2: three 256-thread workgroups (44 KB of LDS rows each) per CU
 #endif
 constexpr int SOM_WAVES = 4;               // waves per block; each works through its own 64 queued loci
 constexpr int SOM_THREADS = 64 * SOM_WAVES;
@@ -348,50 +348,60 @@ __global__ __launch_bounds__(SOM_THREADS) __attribute__((amdgpu_waves_per_eu(SOM
     }
 }
 
-// S2: posterior of the queued loci from the likelihoods S1 left in their records (a13)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SOM_POST_WPE, SOM_POST_WPE))) void somatic_posterior_kernel(const SomArgs a)
+// S2: posterior of the queued loci from the likelihoods S1 left in their records (a13).  The 2 x 21 likelihoods of a thread's
+// locus sit in an LDS row (odd stride: conflict-free), so the (Fn,Ft) enumeration can stay a loop over Ft with run-time
+// indices and the table-driven exp is inlined a handful of times instead of called ~150 times.
+constexpr int POST_THREADS = 256;
+constexpr int POST_ROW = 2 * PRESTRAND + 1;
+__global__ __launch_bounds__(POST_THREADS) __attribute__((amdgpu_waves_per_eu(SOM_POST_WPE, SOM_POST_WPE))) void somatic_posterior_kernel(const SomArgs a)
 {
+    __shared__ float s_lh[POST_THREADS * POST_ROW];
     const unsigned n_work = a.work[0];
-    const unsigned w = blockIdx.x * 256u + threadIdx.x;
+    const unsigned w = blockIdx.x * unsigned(POST_THREADS) + threadIdx.x;
     if (w >= n_work) return;
-    const SkLibmTables lt = sk_libm_tables_default(); // (an LDS copy of the tables measured slower here: flat addressing)
+    const SkLibmTables lt = sk_libm_tables_default();
     const int l = int(a.work[1 + w]);
     sk_somatic_snv_call* o = a.out + l;
-    float nl[PRESTRAND], tl[GRID];
+    float* row = s_lh + threadIdx.x * POST_ROW;
     {
         const float4* p = reinterpret_cast<const float4*>(o->normal_lhood); // records are 16-byte aligned (272 = 17 x 16)
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const float4 v = p[i];
-            nl[4 * i] = v.x;
-            nl[4 * i + 1] = v.y;
-            nl[4 * i + 2] = v.z;
-            nl[4 * i + 3] = v.w;
+            row[4 * i] = v.x;
+            row[4 * i + 1] = v.y;
+            row[4 * i + 2] = v.z;
+            row[4 * i + 3] = v.w;
         }
-        nl[20] = o->normal_lhood[20];
+        row[20] = o->normal_lhood[20];
+    }
+    float tl_strand[GRID - PRESTRAND + 1]; // tumor states 20..29 (20 goes to the row, 21..29 are the strand states)
+    {
         const float2* t = reinterpret_cast<const float2*>(o->tumor_lhood); // 8-byte aligned (offset 120)
 #pragma unroll
         for (int i = 0; i < GRID / 2; ++i) {
             const float2 v = t[i];
-            tl[2 * i] = v.x;
-            tl[2 * i + 1] = v.y;
+            if (2 * i < PRESTRAND) row[PRESTRAND + 2 * i] = v.x;
+            else tl_strand[2 * i - (PRESTRAND - 1)] = v.x;
+            if (2 * i + 1 < PRESTRAND) row[PRESTRAND + 2 * i + 1] = v.y;
+            else tl_strand[2 * i + 1 - (PRESTRAND - 1)] = v.y;
         }
     }
+    // (each thread reads back only its own row: no barrier needed)
     struct
     {
         uint32_t max_gt;
         int32_t qphred, from_ntype_qphred;
         uint32_t ntype;
     } rs;
-    calculate_result_set_grid(a.d, lt, nl, tl, rs);
+    calculate_result_set_grid<true>(a.d, lt, [&](const unsigned i) { return row[i]; }, [&](const unsigned i) { return row[PRESTRAND + i]; }, rs);
     float strand_bias = 0.f;
     if (a.d.is_forced_output || rs.qphred != 0) { // strand bias (:216-225), skipped by the early return at :184
-        float symm = tl[SOM_SIZE];
+        float symm = row[PRESTRAND + SOM_SIZE];
+        for (int i = SOM_SIZE; i < PRESTRAND; ++i) symm = (symm < row[PRESTRAND + i]) ? row[PRESTRAND + i] : symm;
+        float strand = tl_strand[1];
 #pragma unroll
-        for (int i = SOM_SIZE; i < PRESTRAND; ++i) symm = (symm < tl[i]) ? tl[i] : symm;
-        float strand = tl[PRESTRAND];
-#pragma unroll
-        for (int i = PRESTRAND; i < GRID; ++i) strand = (strand < tl[i]) ? tl[i] : strand;
+        for (int i = 1; i <= GRID - PRESTRAND; ++i) strand = (strand < tl_strand[i]) ? tl_strand[i] : strand;
         const float dd = __fsub_rn(strand, symm);
         strand_bias = (0.f < dd) ? dd : 0.f;
     }
@@ -470,7 +480,7 @@ int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* n, const sk_pileup_batc
     // sized for every locus being queued; blocks past the end of the queue exit at once
     hipLaunchKernelGGL(somatic_lhood_kernel, dim3((n->n_loci + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a);
     SK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(somatic_posterior_kernel, dim3((n->n_loci + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(somatic_posterior_kernel, dim3((n->n_loci + POST_THREADS - 1) / POST_THREADS), dim3(POST_THREADS), 0, st, a);
     SK_HIP(hipGetLastError());
     return 0;
 }
