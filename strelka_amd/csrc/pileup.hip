@@ -543,22 +543,27 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel(const PileupArgs a)
     const int p = p0 + lane;
     const int n = a.b.n_reads;
     // reads [lo, hi): lo = first read whose prefix-max end exceeds p0; hi = first read from which every begin >= p0+64
-    int lo = 0, hi = n;
-    {
-        int x = 0, y = n;
+    // 64-ary searches: the lanes probe 64 evenly spaced elements per step, so a range of 2^20 reads takes 4 dependent
+    // loads instead of the 20 of a binary search (those 2 x 20 round trips were most of this kernel's time)
+    auto first_true = [&](int x, int y, auto&& pred) { // first index in [x, y) with pred, y if none; pred is monotone
         while (x < y) {
-            const int m = (x + y) >> 1;
-            if (a.maxend[m] > p0) y = m; else x = m + 1;
+            const int span = y - x;
+            const int step = (span + WAVE - 1) / WAVE;
+            const int m = x + lane * step;
+            const bool valid = (m < y);
+            const bool v = valid ? pred(m) : true;
+            const unsigned long long hit = __ballot(v);                 // lanes past the range report true
+            const int f = hit ? __ffsll((long long)hit) - 1 : WAVE;    // first true probe; WAVE: every probe was false
+            const int mf = x + f * step;
+            if (step == 1) return (mf < y) ? mf : y;
+            const int nx = (f == 0) ? x : x + (f - 1) * step + 1;
+            y = (mf < y) ? mf : y;
+            x = nx;
         }
-        lo = x;
-        x = lo;
-        y = n;
-        while (x < y) {
-            const int m = (x + y) >> 1;
-            if (a.minbegin[m] >= p0 + WAVE) y = m; else x = m + 1;
-        }
-        hi = x;
-    }
+        return y;
+    };
+    const int lo = first_true(0, n, [&](const int m) { return a.maxend[m] > p0; });
+    const int hi = first_true(lo, n, [&](const int m) { return a.minbegin[m] >= p0 + WAVE; });
     unsigned cnt = 0;
     const int64_t base = (a.store && l < a.n_loci) ? a.call_off[l] : 0;
     const int parts = (a.mode == SK_PILEUP_CLEAN_TIER2) ? 2 : 1;
@@ -576,23 +581,45 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel(const PileupArgs a)
         span_n = staged ? int(tot) : 0;
     }
     const unsigned lbase = unsigned(base - span0);
-    // a read's contribution to this lane's locus, given the read's geometry in wave-uniform values
-    auto take = [&](const int64_t ro, const int read_head, const int ref_head, const int len, const int part) {
-        if (live && p >= ref_head && p < ref_head + len) {
-            const unsigned rec = a.rec[ro + read_head + (p - ref_head)];
-            if (rec_selected(rec, a.mode, part)) {
-                if (a.store) {
-                    if (staged) s_col[lbase + cnt] = uint16_t(rec & 0x3fffu);
-                    else a.calls[base + cnt] = uint16_t(rec & 0x3fffu);
-                }
-                ++cnt;
+    // Index of the record read k of the batch contributes to this lane's locus (-1: none).  A locus lies in at most one
+    // match segment of a read.  The segments of reads with up to three segments were decoded by the lane that fetched the
+    // read (mb/me/mr: reference begin / end and read begin of its match segments, empty ranges otherwise), so per read
+    // the wave only broadcasts nine integers and does three range tests; longer paths are walked segment by segment.
+    auto locate = [&](const int2 sp, const int64_t ro_k, const int64_t so_k, const int nseg_k, const int (&mb)[3], const int (&me)[3],
+                      const int (&mr)[3], const int k) -> int64_t {
+        const int sx = __builtin_amdgcn_readlane(sp.x, k), sy = __builtin_amdgcn_readlane(sp.y, k);
+        if (sy <= p0 || sx >= p0 + WAVE) return -1;
+        const int64_t ro = (int64_t(__builtin_amdgcn_readlane(int(ro_k >> 32), k)) << 32) |
+                           uint32_t(__builtin_amdgcn_readlane(int(ro_k & 0xffffffff), k));
+        const int nseg = __builtin_amdgcn_readlane(nseg_k, k);
+        int off = -1;
+        if (nseg <= 3) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int b = __builtin_amdgcn_readlane(mb[i], k), e = __builtin_amdgcn_readlane(me[i], k);
+                const int r = __builtin_amdgcn_readlane(mr[i], k);
+                off = (p >= b && p < e) ? r + (p - b) : off;
+            }
+        } else {
+            const int64_t so = (int64_t(__builtin_amdgcn_readlane(int(so_k >> 32), k)) << 32) |
+                               uint32_t(__builtin_amdgcn_readlane(int(so_k & 0xffffffff), k));
+            int read_head = 0, ref_head = sx;
+            for (int i = 0; i < nseg; ++i) {
+                const uint32_t t = a.b.path[so + i].type;
+                const int len = int(a.b.path[so + i].length);
+                if (seg_match(t) && p >= ref_head && p < ref_head + len) off = read_head + (p - ref_head);
+                if (seg_read_len(t)) read_head += len;
+                if (seg_ref_len(t)) ref_head += len;
+                if (ref_head >= p0 + WAVE) break;
             }
         }
+        return (live && off >= 0) ? ro + off : int64_t(-1);
     };
+    constexpr int RU = 8; // reads whose record loads are in flight together
     for (int part = 0; part < parts; ++part) {
         for (int rb = lo; rb < hi; rb += WAVE) {
             // the lanes fetch the geometry of 64 reads at once (one memory round trip instead of one per read); the
-            // loop below then reads it back lane by lane into scalar registers
+            // loops below read it back lane by lane into scalar registers
             const int rk = rb + lane;
             const bool have = (rk < hi);
             const int2 sp = have ? a.span[rk] : make_int2(INT_MAX, INT_MIN);
@@ -603,38 +630,40 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel(const PileupArgs a)
             if (nseg_k >= 1) g0 = a.b.path[so_k];
             if (nseg_k >= 2) g1 = a.b.path[so_k + 1];
             if (nseg_k >= 3) g2 = a.b.path[so_k + 2];
-            const int nk = min(WAVE, hi - rb);
-            for (int k = 0; k < nk; ++k) {
-                const int sx = __builtin_amdgcn_readlane(sp.x, k), sy = __builtin_amdgcn_readlane(sp.y, k);
-                if (sy <= p0 || sx >= p0 + WAVE) continue;
-                const int64_t ro = (int64_t(__builtin_amdgcn_readlane(int(ro_k >> 32), k)) << 32) |
-                                   uint32_t(__builtin_amdgcn_readlane(int(ro_k & 0xffffffff), k));
-                const int nseg = __builtin_amdgcn_readlane(nseg_k, k);
-                int read_head = 0, ref_head = sx;
-                if (nseg <= 3) {
-                    const uint32_t t0 = __builtin_amdgcn_readlane(int(g0.type), k), n0 = __builtin_amdgcn_readlane(int(g0.length), k);
-                    const uint32_t t1 = __builtin_amdgcn_readlane(int(g1.type), k), n1 = __builtin_amdgcn_readlane(int(g1.length), k);
-                    const uint32_t t2 = __builtin_amdgcn_readlane(int(g2.type), k), n2 = __builtin_amdgcn_readlane(int(g2.length), k);
-                    const uint32_t ts[3] = { t0, t1, t2 }, ns[3] = { n0, n1, n2 };
+            int mb[3], me[3], mr[3];
+            {
+                int read_head = 0, ref_head = sp.x;
+                const sk_path_seg gs[3] = { g0, g1, g2 };
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        if (i < nseg) {
-                            const int len = int(ns[i]);
-                            if (seg_match(ts[i]) && ref_head < p0 + WAVE && ref_head + len > p0) take(ro, read_head, ref_head, len, part);
-                            if (seg_read_len(ts[i])) read_head += len;
-                            if (seg_ref_len(ts[i])) ref_head += len;
+                for (int i = 0; i < 3; ++i) {
+                    const uint32_t t = gs[i].type;
+                    const int len = int(gs[i].length);
+                    const bool is_m = (i < nseg_k) && seg_match(t);
+                    mb[i] = is_m ? ref_head : INT_MAX;
+                    me[i] = is_m ? ref_head + len : INT_MIN;
+                    mr[i] = read_head;
+                    if (i < nseg_k && seg_read_len(t)) read_head += len;
+                    if (i < nseg_k && seg_ref_len(t)) ref_head += len;
+                }
+            }
+            const int nk = min(WAVE, hi - rb);
+            // RU reads at a time: all their record loads are issued before the first is consumed (one dependent load per
+            // read was the whole cost of this kernel); the calls are still appended in read order
+            for (int k0 = 0; k0 < nk; k0 += RU) {
+                int64_t idx[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) idx[u] = (k0 + u < nk) ? locate(sp, ro_k, so_k, nseg_k, mb, me, mr, k0 + u) : -1;
+                unsigned rec[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) rec[u] = (idx[u] >= 0) ? unsigned(a.rec[idx[u]]) : 0u;
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    if (idx[u] >= 0 && rec_selected(rec[u], a.mode, part)) {
+                        if (a.store) {
+                            if (staged) s_col[lbase + cnt] = uint16_t(rec[u] & 0x3fffu);
+                            else a.calls[base + cnt] = uint16_t(rec[u] & 0x3fffu);
                         }
-                    }
-                } else {
-                    const int64_t so = (int64_t(__builtin_amdgcn_readlane(int(so_k >> 32), k)) << 32) |
-                                       uint32_t(__builtin_amdgcn_readlane(int(so_k & 0xffffffff), k));
-                    for (int i = 0; i < nseg; ++i) {
-                        const uint32_t t = a.b.path[so + i].type;
-                        const int len = int(a.b.path[so + i].length);
-                        if (seg_match(t) && ref_head < p0 + WAVE && ref_head + len > p0) take(ro, read_head, ref_head, len, part);
-                        if (seg_read_len(t)) read_head += len;
-                        if (seg_ref_len(t)) ref_head += len;
-                        if (ref_head >= p0 + WAVE) break;
+                        ++cnt;
                     }
                 }
             }
