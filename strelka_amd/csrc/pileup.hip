@@ -80,6 +80,21 @@ __device__ __forceinline__ unsigned ref_code_at(const sk_read_batch& b, const in
     }
 }
 
+// the same with an unconditional load (clamped index) and selects: straight-line code for the per-position loops
+__device__ __forceinline__ unsigned ref_code_at_nobranch(const sk_read_batch& b, const int p)
+{
+    const int i = p - b.ref_offset;
+    const bool inside = (i >= 0) && (i < b.ref_len);
+    const int ci = min(max(i, 0), max(b.ref_len - 1, 0));
+    const unsigned c = (b.ref_len > 0) ? unsigned(b.ref_seq[ci]) : unsigned('N');
+    unsigned code = SK_BAM_ANY;
+    code = (c == 'A') ? unsigned(SK_BAM_A) : code;
+    code = (c == 'C') ? unsigned(SK_BAM_C) : code;
+    code = (c == 'G') ? unsigned(SK_BAM_G) : code;
+    code = (c == 'T') ? unsigned(SK_BAM_T) : code;
+    return inside ? code : unsigned(SK_BAM_ANY);
+}
+
 constexpr int FAST_K = 4; // positions per lane on the short-read path (reads up to 256 bases)
 
 __device__ __forceinline__ int wave_max(int v)
@@ -219,8 +234,8 @@ __device__ void pileup_read_short(const PileupArgs& a, const int r, const int la
 #pragma unroll
         for (int k = 0; k < FAST_K; ++k) {
             const int p = lane + WAVE * k;
+            const unsigned fc = ref_code_at_nobranch(a.b, refpos[k]);
             if (in_match[k] && p >= read_begin && p < read_end) {
-                const unsigned fc = ref_code_at(a.b, refpos[k]);
                 if (code[k] != fc) {
                     bool cand = false;
                     if (a.b.cand_snv_mask && refpos[k] >= a.b.ref_offset && refpos[k] < a.b.ref_offset + a.b.ref_len) {
@@ -258,39 +273,40 @@ __device__ void pileup_read_short(const PileupArgs& a, const int r, const int la
 
     const unsigned adj_mapq = mapq < 5u ? 5u : mapq;
     const bool mapq_adjust = o.is_mapq_adjust && (adj_mapq <= 80u);
+    if (is_submapped) { // (per read, hence wave-uniform) no basecalls, only the counter
 #pragma unroll
-    for (int k = 0; k < FAST_K; ++k) {
-        const int p = lane + WAVE * k;
-        if (p >= L) continue;
-        unsigned rec = 0;
-        const bool live = in_match[k] && p >= read_begin && p < read_end && refpos[k] >= o.report_begin && refpos[k] < o.report_end;
-        if (live) {
-            if (is_submapped) {
-                if (a.submapped) atomicAdd(&a.submapped[refpos[k] - o.report_begin], 1u);
-            } else {
-                const unsigned c = code[k];
-                const unsigned id = c == SK_BAM_A ? 0u : c == SK_BAM_C ? 1u : c == SK_BAM_G ? 2u : c == SK_BAM_T ? 3u : 4u;
-                unsigned q = qual[k];
-                if (mapq_adjust) q = a.tab->mappedq[adj_mapq][q > 70u ? 70u : q];
-                bool is_call_filter = (c == SK_BAM_ANY) || (int(q) < o.min_basecall_qscore);
-                bool is_tier2_call_filter = is_call_filter;
-                bool nmm = false;
-                if (mdf) {
-                    const int del = delta[min(delta_size - 1, max(fs, p) - fs)];
-                    if (!is_call_filter) {
-                        is_call_filter = (o.mismatch_density_max_count < del);
-                        is_tier2_call_filter = o.use_tier2_evidence ? (o.tier2_mismatch_density_max_count < del) : is_call_filter;
-                    }
-                    nmm = (del - int(mmk[k])) > 0;
-                }
-                const bool current = is_tier1 ? is_call_filter : is_tier2_call_filter;
-                const bool tscf = is_tier1 && is_call_filter && !is_tier2_call_filter;
-                const unsigned qb = q > 63u ? 63u : q;
-                rec = qb | (id << 6) | (fwd ? 1u << 10 : 0u) | (nmm ? 1u << 11 : 0u) | (current ? 1u << 12 : 0u) |
-                      (tscf ? 1u << 13 : 0u) | (is_tier1 ? 0u : REC_TIER2) | REC_EMIT;
-            }
+        for (int k = 0; k < FAST_K; ++k) {
+            const int p = lane + WAVE * k;
+            const bool live = in_match[k] && p >= read_begin && p < read_end && refpos[k] >= o.report_begin && refpos[k] < o.report_end;
+            if (live && a.submapped) atomicAdd(&a.submapped[refpos[k] - o.report_begin], 1u);
+            if (p < L) a.rec[ro + p] = 0;
         }
-        a.rec[ro + p] = uint16_t(rec);
+    } else {
+        // straight-line per position: table and LDS reads use clamped indices, every flag is a select, and the record of a
+        // position that does not emit a call is 0
+        const uint8_t* __restrict__ mq = a.tab->mappedq[mapq_adjust ? adj_mapq : 0u];
+#pragma unroll
+        for (int k = 0; k < FAST_K; ++k) {
+            const int p = lane + WAVE * k;
+            const bool live = in_match[k] && p >= read_begin && p < read_end && refpos[k] >= o.report_begin && refpos[k] < o.report_end;
+            const unsigned c = code[k];
+            const unsigned id = c == SK_BAM_A ? 0u : c == SK_BAM_C ? 1u : c == SK_BAM_G ? 2u : c == SK_BAM_T ? 3u : 4u;
+            const unsigned q0 = qual[k];
+            const unsigned qm = mq[q0 > 70u ? 70u : q0];
+            const unsigned q = mapq_adjust ? qm : q0;
+            const bool base_filter = (c == SK_BAM_ANY) || (int(q) < o.min_basecall_qscore);
+            const int del = mdf ? delta[min(delta_size - 1, max(fs, p) - fs)] : 0; // (delta_size >= 1)
+            const bool is_call_filter = base_filter || (mdf && o.mismatch_density_max_count < del);
+            const bool is_tier2_call_filter =
+                base_filter || (mdf && (o.use_tier2_evidence ? (o.tier2_mismatch_density_max_count < del) : (o.mismatch_density_max_count < del)));
+            const bool nmm = mdf && (del - int(mmk[k])) > 0;
+            const bool current = is_tier1 ? is_call_filter : is_tier2_call_filter;
+            const bool tscf = is_tier1 && is_call_filter && !is_tier2_call_filter;
+            const unsigned qb = q > 63u ? 63u : q;
+            const unsigned rec = qb | (id << 6) | (fwd ? 1u << 10 : 0u) | (nmm ? 1u << 11 : 0u) | (current ? 1u << 12 : 0u) |
+                                 (tscf ? 1u << 13 : 0u) | (is_tier1 ? 0u : REC_TIER2) | REC_EMIT;
+            if (p < L) a.rec[ro + p] = uint16_t(live ? rec : 0u);
+        }
     }
     // spanning deletions (order-free counters)
     {
