@@ -699,6 +699,8 @@ def align_pairs(n, rng, ref_len=(100, 270), max_edits=3):
         r = seq(int(rng.integers(ref_len[0], ref_len[1])))
         q = list(r)
         for _k in range(int(rng.integers(0, max_edits + 1))):
+            if len(q) < 12:
+                break
             p = int(rng.integers(5, len(q) - 5))
             if rng.random() < 0.5:
                 del q[p:p + int(rng.integers(1, 12))]
