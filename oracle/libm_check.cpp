@@ -11,7 +11,7 @@ int main(int argc, char** argv)
 {
     const long n = (argc > 1) ? atol(argv[1]) : 1000000;
     unsigned long long st = 88172645463325252ull;
-    long badp = 0, badl = 0, bade = 0, bad1 = 0, fall = 0, badde = 0, baddl = 0, badd10 = 0;
+    long badp = 0, badl = 0, bade = 0, bad1 = 0, fall = 0, badde = 0, baddl = 0, badd10 = 0, baddp = 0;
     for (long it = 0; it < n; ++it) {
         st ^= st << 13;
         st ^= st >> 7;
@@ -58,9 +58,14 @@ int main(int argc, char** argv)
         da = log10(xl);
         if (!log10_glibc(xl, db)) { fall++; db = da; }
         badd10 += as_u64(da) != as_u64(db);
+        // double log1p: [0, 0.01) as log1p_switch uses it, and up to 0.41
+        const double xp = (it & 1) ? double(st % 1000000000) / 1.0e11 : as_f64(0x3c00000000000000ull + (st % (0x3fda827a00000000ull - 0x3c00000000000000ull)));
+        da = log1p(xp);
+        if (!log1p_glibc(xp, db)) { fall++; db = da; }
+        baddp += as_u64(da) != as_u64(db);
     }
-    printf("n=%ld exp mismatches %ld log mismatches %ld log10 mismatches %ld\n", n, badde, baddl, badd10);
-    if (badde || baddl || badd10) return 1;
+    printf("n=%ld exp mismatches %ld log mismatches %ld log10 mismatches %ld log1p mismatches %ld\n", n, badde, baddl, badd10, baddp);
+    if (badde || baddl || badd10 || baddp) return 1;
     printf("n=%ld powf mismatches %ld logf mismatches %ld expf mismatches %ld log1pf mismatches %ld fallbacks %ld\n", n, badp, badl,
            bade, bad1, fall);
     return (badp || badl || bade || bad1 || fall) ? 1 : 0;

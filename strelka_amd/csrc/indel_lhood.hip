@@ -12,8 +12,11 @@
 // (sequentially, in read-id order); the TERMS are independent, so lanes evaluate them for 64 reads at a time into LDS,
 // then one lane per state performs the adds in read order -- the order and rounding of every add is the reference's.
 //
-// Double exp/log are the device library's and I1 evaluates each term in an algebraically equal form with one log per
-// state (see mix_term), so likelihoods agree with the oracle to ~1e-15 relative, not bit-for-bit (tests: 1e-12).
+// Every term is evaluated operation for operation as the reference does (getLogSum / log1p_switch / integrateOutMappingStatus
+// / get_het_observed_allele_ratio), and its double exp / log / log1p calls are the host libm's routines restated in
+// libm_dbl64.h: the likelihoods are bit-identical to the reference's.  (An algebraically equal form with one log per state
+// and the read's exponentials shared by its states is 2.5x faster, 2.3 instead of ~6 ms per 2^18 indels, but only agrees to
+// ~1e-15; indel loci are a thousandth of all loci, so the exact form is the one that ships.)
 
 #include "somatic_common.h"
 
@@ -25,10 +28,6 @@ namespace
 constexpr int WAVE = 64;
 constexpr int N_STATES = 21;
 
-// The reference's per-read term is built from getLogSum (L/blt_util/logSumUtil.hh:33-41, log1p_switch
-// L/blt_util/math_util.hh:33-48) and integrateOutMappingStatus (L/starling_common/readMappingAdjustmentUtil.hh:29-56):
-//     integrateOutMappingStatus(x) = logsum(x + correct_mapping_log_prior, random_base_match_log_prob * nonAmbiguousBases)
-// The kernels evaluate these nested log-sum-exps in the scaled-exponential form described at mix_term below.
 struct MapParams
 {
     double correct_mapping_log_prior; // log(1.7e-10), starling_base_shared.cpp:64
@@ -43,16 +42,38 @@ struct GridArgs
     int is_include_tier2;
     int is_use_alt_indel;
     double* out; // [n_indels][21]
+    int exact_libm;
     double het_ratio[SK_HET_RES], chet_ratio[SK_HET_RES], log_het_ratio[SK_HET_RES], log_chet_ratio[SK_HET_RES];
     double loghalf;
 };
 
-// get_het_observed_allele_ratio as a probability instead of the pair of logs the reference keeps: (1 - p, p) with
-// log(1 - p) == log_ref_prob and log(p) == log_indel_prob.  Returns false when the reference leaves its inputs untouched
-// (total_path_term <= 0), in which case the caller's default ratio applies.
-__device__ __forceinline__ bool het_observed_indel_prob(const unsigned read_length, const unsigned min_overlap, const unsigned del_len,
-                                                        const unsigned ins_len, const double het_allele_ratio, double& ref_prob,
-                                                        double& indel_prob)
+// log1p_switch / getLogSum, L/blt_util/math_util.hh:33-48, L/blt_util/logSumUtil.hh:33-41 (double)
+__device__ __forceinline__ double log1p_switch_d(const double x, const int ex, const SkLibmTables& lt)
+{
+    return (fabs(x) < 0.01) ? sk_log1p(x, ex) : sk_log(__dadd_rn(1., x), ex, lt);
+}
+__device__ __forceinline__ double log_sum2(double x1, double x2, const int ex, const SkLibmTables& lt)
+{
+    if (x1 < x2) {
+        const double t = x1;
+        x1 = x2;
+        x2 = t;
+    }
+    return __dadd_rn(x1, log1p_switch_d(sk_exp(__dsub_rn(x2, x1), ex, lt), ex, lt));
+}
+
+// integrateOutMappingStatus, L/starling_common/readMappingAdjustmentUtil.hh:29-56
+__device__ __forceinline__ double integrate_out_mapping(const MapParams& m, const unsigned non_ambig, const double lnp, const int ex,
+                                                        const SkLibmTables& lt)
+{
+    return log_sum2(__dadd_rn(lnp, m.correct_mapping_log_prior), __dmul_rn(m.random_base_match_log_prob, double(non_ambig)), ex, lt);
+}
+
+// get_het_observed_allele_ratio, starling_indel_call_pprob_digt.cpp:40-71
+__device__ __forceinline__ void het_observed_allele_ratio(const unsigned read_length, const unsigned min_overlap,
+                                                          const unsigned del_len, const unsigned ins_len,
+                                                          const double het_allele_ratio, double& log_ref_prob,
+                                                          double& log_indel_prob, const int ex, const SkLibmTables& lt)
 {
     const unsigned base_expect = ((read_length + 1) < (2 * min_overlap)) ? 0 : (read_length + 1) - (2 * min_overlap);
     const double ref_path_expect = double(base_expect + min(del_len, base_expect));
@@ -60,46 +81,11 @@ __device__ __forceinline__ bool het_observed_indel_prob(const unsigned read_leng
     const double ref_path_term = __dmul_rn(__dsub_rn(1., het_allele_ratio), ref_path_expect);
     const double indel_path_term = __dmul_rn(het_allele_ratio, indel_path_expect);
     const double total_path_term = __dadd_rn(ref_path_term, indel_path_term);
-    if (!(total_path_term > 0)) return false;
-    indel_prob = __ddiv_rn(indel_path_term, total_path_term);
-    ref_prob = __dsub_rn(1., indel_prob);
-    return true;
-}
-
-// One read's term of a het state, integrateOutMappingStatus(logsum(noindel + log(1-p), hom + log(p))), evaluated as
-//     T + log( (e^(A-T) * ((1-p) e^(a-m) + p e^(b-m))) + e^(M-T) )
-// with a = noindel, b = hom, m = max(a,b), A = m + correct_mapping_log_prior, M = random_base_match_log_prob * nonAmbig,
-// T = max(A, M).  This is the same quantity as the reference's two nested log-sum-exp calls
-// (starling_indel_call_pprob_digt.cpp:126-136, readMappingAdjustmentUtil.hh:44-56) with one log per state instead of two
-// exp + two log1p + two log; the scaled exponentials are shared by all 21 states of the read.  Both forms carry a
-// rounding error of a few ulp of |T| (~1e-13): the results agree to ~1e-15 relative, not bit for bit.
-struct ReadExp
-{
-    double T, wa, wb, wm; // wa = e^(A-T) e^(a-m), wb = e^(A-T) e^(b-m), wm = e^(M-T)
-};
-__device__ __forceinline__ ReadExp read_exponentials(const MapParams& mp, const unsigned non_ambig, const double a, const double b)
-{
-    const bool a_lt_b = (a < b);
-    const double m = a_lt_b ? b : a;
-    const double A = __dadd_rn(m, mp.correct_mapping_log_prior);
-    const double M = __dmul_rn(mp.random_base_match_log_prob, double(non_ambig));
-    const bool A_lt_M = (A < M);
-    ReadExp r;
-    r.T = A_lt_M ? M : A;
-    // of each pair of scaled exponentials one is exp(0): two exp() per read
-    double ex = exp(-fabs(__dsub_rn(a, b)));
-    if (!(ex == ex)) ex = 1.; // a == b == -inf
-    const double eT = exp(-fabs(__dsub_rn(A, M)));
-    const double sA = A_lt_M ? eT : 1.;
-    r.wm = A_lt_M ? 1. : eT;
-    r.wa = __dmul_rn(sA, a_lt_b ? ex : 1.);
-    r.wb = __dmul_rn(sA, a_lt_b ? 1. : ex);
-    return r;
-}
-__device__ __forceinline__ double mix_term(const ReadExp& r, const double ref_prob, const double indel_prob)
-{
-    const double mix = __dadd_rn(__dmul_rn(ref_prob, r.wa), __dmul_rn(indel_prob, r.wb));
-    return __dadd_rn(r.T, log(__dadd_rn(mix, r.wm)));
+    if (total_path_term > 0) {
+        const double indel_prob = __ddiv_rn(indel_path_term, total_path_term);
+        log_ref_prob = sk_log(__dsub_rn(1., indel_prob), ex, lt);
+        log_indel_prob = sk_log(indel_prob, ex, lt);
+    }
 }
 
 __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a)
@@ -112,6 +98,8 @@ __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a
     const unsigned del_len = a.b.del_len[ind], ins_len = a.b.ins_len[ind];
     const bool is_breakpoint = a.b.is_breakpoint ? (a.b.is_breakpoint[ind] != 0) : false;
     const unsigned flank = unsigned(a.min_read_bp_flank);
+    const int ex = a.exact_libm;
+    const SkLibmTables lt = sk_libm_tables_default();
 
     double acc = 0.; // lanes 0..20: the running sum of state `lane`
     for (int base = 0; base < n; base += WAVE) {
@@ -134,25 +122,26 @@ __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a
                 const double hom_lnp = double(a.b.indel_lnp[g]);
                 const unsigned na = a.b.non_ambig[g];
                 const unsigned rl = a.b.read_length[g];
-                const ReadExp e = read_exponentials(a.map, na, noindel_lnp, hom_lnp);
                 // SOMATIC_DIGT / STAR_DIINDEL: 0 = REF/NOINDEL, 1 = HOM, 2 = HET
-                s_term[0][lane] = mix_term(e, 1., 0.);
-                s_term[1][lane] = mix_term(e, 0., 1.);
+                s_term[0][lane] = integrate_out_mapping(a.map, na, noindel_lnp, ex, lt);
+                s_term[1][lane] = integrate_out_mapping(a.map, na, hom_lnp, ex, lt);
                 {
-                    double pr = 0.5, pi = 0.5;
-                    if (!is_breakpoint) het_observed_indel_prob(rl, flank, del_len, ins_len, 0.5, pr, pi);
-                    s_term[2][lane] = mix_term(e, pr, pi);
+                    double lr = a.loghalf, li = a.loghalf;
+                    if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, 0.5, lr, li, ex, lt);
+                    s_term[2][lane] = integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li), ex, lt), ex, lt);
                 }
                 for (int i = 0; i < SK_HET_RES; ++i) {
                     { // het_lhood_low -> grid[i]
-                        double pr = a.chet_ratio[i], pi = a.het_ratio[i];
-                        if (!is_breakpoint) het_observed_indel_prob(rl, flank, del_len, ins_len, a.het_ratio[i], pr, pi);
-                        s_term[3 + i][lane] = mix_term(e, pr, pi);
+                        double lr = a.log_chet_ratio[i], li = a.log_het_ratio[i];
+                        if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, a.het_ratio[i], lr, li, ex, lt);
+                        s_term[3 + i][lane] =
+                            integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li), ex, lt), ex, lt);
                     }
                     { // het_lhood_high -> grid[2*HET_RES-(i+1)]
-                        double pr = a.het_ratio[i], pi = a.chet_ratio[i];
-                        if (!is_breakpoint) het_observed_indel_prob(rl, flank, del_len, ins_len, a.chet_ratio[i], pr, pi);
-                        s_term[3 + (2 * SK_HET_RES - (i + 1))][lane] = mix_term(e, pr, pi);
+                        double lr = a.log_het_ratio[i], li = a.log_chet_ratio[i];
+                        if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, a.chet_ratio[i], lr, li, ex, lt);
+                        s_term[3 + (2 * SK_HET_RES - (i + 1))][lane] =
+                            integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li), ex, lt), ex, lt);
                     }
                 }
             }
@@ -207,6 +196,7 @@ struct GroupArgs
     double support_threshold;
     double loghalf;
     sk_allele_group_call* out;
+    int exact_libm;
 };
 
 __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
@@ -222,6 +212,8 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
     const int full = n_alt + 1;
     const int gcount = (ploidy == 1) ? full : full * (full + 1) / 2;
     const unsigned flank = unsigned(a.min_read_bp_flank);
+    const int ex = a.exact_libm;
+    const SkLibmTables lt = sk_libm_tables_default();
     unsigned del_len[SK_MAX_ALT], ins_len[SK_MAX_ALT];
 #pragma unroll
     for (int k = 0; k < SK_MAX_ALT; ++k) {
@@ -263,77 +255,58 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
             } else {
                 const unsigned na = a.b.non_ambig[g];
                 const unsigned rlen = a.b.read_length[g];
-                // Scaled exponentials shared by every genotype of the read (same algebra as mix_term above):
-                //   integrateOutMappingStatus(x) = T + log(e^(A-T) e^(x-m) + e^(M-T)),  m = max_k L[k], A = m + prior, T = max(A, M)
-                double m = L[0];
-#pragma unroll
-                for (int k = 1; k <= SK_MAX_ALT; ++k)
-                    if (k < full && L[k] > m) m = L[k];
-                const double A = __dadd_rn(m, a.map.correct_mapping_log_prior);
-                const double M = __dmul_rn(a.map.random_base_match_log_prob, double(na));
-                const bool A_lt_M = (A < M);
-                const double T = A_lt_M ? M : A;
-                const double eT = exp(-fabs(__dsub_rn(A, M)));
-                const double sA = A_lt_M ? eT : 1., wm = A_lt_M ? 1. : eT;
-                double E[SK_MAX_ALT + 1], W[SK_MAX_ALT + 1]; // W[k] = e^(Lm[k] - T): the read's weight for allele k
-#pragma unroll
-                for (int k = 0; k <= SK_MAX_ALT; ++k) {
-                    E[k] = 0.;
-                    W[k] = 0.;
-                    if (k < full) {
-                        double ex = exp(__dsub_rn(L[k], m));
-                        if (!(ex == ex)) ex = 1.; // L[k] == m == -inf
-                        E[k] = __dmul_rn(sA, ex);
-                        W[k] = __dadd_rn(E[k], wm);
-                    }
-                }
                 // updateGenotypeLogLhoodFromAlleleLogLhood, AlleleGroupGenotype.cpp:36-114
                 if (ploidy == 1) {
 #pragma unroll
                     for (int a0 = 0; a0 <= SK_MAX_ALT; ++a0)
-                        if (a0 < full) s_term[a0][lane] = __dadd_rn(T, log(W[a0]));
+                        if (a0 < full) s_term[a0][lane] = integrate_out_mapping(a.map, na, L[a0], ex, lt);
                 } else {
-                    // P[k]: the observed-allele ratio of alt allele k at het ratio 0.5 (get_het_observed_allele_ratio)
-                    double Pref[SK_MAX_ALT + 1], Pind[SK_MAX_ALT + 1];
-#pragma unroll
-                    for (int k = 1; k <= SK_MAX_ALT; ++k) {
-                        Pref[k] = 0.5;
-                        Pind[k] = 0.5;
-                        if (k < full) het_observed_indel_prob(rlen, flank, del_len[k - 1], ins_len[k - 1], 0.5, Pref[k], Pind[k]);
-                    }
 #pragma unroll
                     for (int a1 = 0; a1 <= SK_MAX_ALT; ++a1) {
 #pragma unroll
                         for (int a0 = 0; a0 <= a1; ++a0) {
                             if (a1 >= full) continue;
                             const int gi = a0 + (a1 * (a1 + 1) / 2);
-                            double w;
+                            double raw;
                             if (a0 != a1) {
-                                double p0 = Pref[a1], p1 = Pind[a1];
+                                double lp0 = a.loghalf, lp1 = a.loghalf;
+                                het_observed_allele_ratio(rlen, flank, del_len[a1 - 1], ins_len[a1 - 1], 0.5, lp0, lp1, ex, lt);
                                 if (a0 > 0) { // het-alt: both alleles' indel ratios, renormalised (:83-95)
-                                    p0 = Pind[a0];
-                                    const double norm = __dadd_rn(p0, p1);
-                                    p0 = __ddiv_rn(p0, norm);
-                                    p1 = __ddiv_rn(p1, norm);
+                                    double log_ref_prior = a.loghalf;
+                                    lp0 = a.loghalf;
+                                    het_observed_allele_ratio(rlen, flank, del_len[a0 - 1], ins_len[a0 - 1], 0.5, log_ref_prior, lp0, ex, lt);
+                                    const double norm = log_sum2(lp0, lp1, ex, lt);
+                                    lp0 = __dsub_rn(lp0, norm);
+                                    lp1 = __dsub_rn(lp1, norm);
                                 }
-                                w = __dadd_rn(__dadd_rn(__dmul_rn(p0, E[a0]), __dmul_rn(p1, E[a1])), wm);
+                                raw = log_sum2(__dadd_rn(L[a0], lp0), __dadd_rn(L[a1], lp1), ex, lt);
                             } else {
-                                w = W[a0];
+                                raw = L[a0];
                             }
-                            s_term[gi][lane] = __dadd_rn(T, log(w));
+                            s_term[gi][lane] = integrate_out_mapping(a.map, na, raw, ex, lt);
                         }
                     }
                 }
-                // updateSupportingReadStats, :125-155: normalizeLogDistro over Lm[k] = T + log(W[k]) is W[k] / sum(W)
+                // updateSupportingReadStats, :125-155 (normalizeLogDistro: first maximum, exp, 1/sum)
+                double Lm[SK_MAX_ALT + 1];
+                double mx = 0.;
+#pragma unroll
+                for (int k = 0; k <= SK_MAX_ALT; ++k) {
+                    Lm[k] = (k < full) ? integrate_out_mapping(a.map, na, L[k], ex, lt) : 0.;
+                    if (k < full) mx = (k == 0) ? Lm[0] : ((Lm[k] > mx) ? Lm[k] : mx);
+                }
                 double sum = 0.;
 #pragma unroll
                 for (int k = 0; k <= SK_MAX_ALT; ++k)
-                    if (k < full) sum = __dadd_rn(sum, W[k]);
+                    if (k < full) {
+                        Lm[k] = sk_exp(__dsub_rn(Lm[k], mx), ex, lt);
+                        sum = __dadd_rn(sum, Lm[k]);
+                    }
                 sum = __ddiv_rn(1., sum);
                 unsigned which = 15;
 #pragma unroll
                 for (int k = SK_MAX_ALT; k >= 0; --k)
-                    if (k < full && !(__dmul_rn(W[k], sum) < a.support_threshold)) which = unsigned(k); // first such allele
+                    if (k < full && !(__dmul_rn(Lm[k], sum) < a.support_threshold)) which = unsigned(k); // first such allele
                 s_support[lane] = (unsigned char)(((flags & SK_READ_FWD) ? 0x10 : 0) | which);
             }
         }
@@ -420,6 +393,7 @@ int sk_indel_grid_lhood_dev(const sk_readscore_batch* b, const sk_indel_options*
     a.is_include_tier2 = is_include_tier2 ? 1 : 0;
     a.is_use_alt_indel = opt->is_use_alt_indel ? 1 : 0;
     a.out = dev_out_lhood;
+    a.exact_libm = sk_ctx().libm_restated ? 1 : 0;
     const float RATIO_INCREMENT = 0.5f / static_cast<float>(SK_HET_RES + 1);
     for (unsigned i = 0; i < SK_HET_RES; ++i) {
         // get_indel_het_grid_lhood :79 / get_high_low_het_ratio_lhood :88-91
@@ -582,6 +556,7 @@ int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* b, const sk
     volatile double half = 0.5;
     a.loghalf = std::log(half); // :75
     a.out = dev_out;
+    a.exact_libm = sk_ctx().libm_restated ? 1 : 0;
     hipLaunchKernelGGL(allele_group_kernel, dim3(b->n_groups), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());
     return 0;

@@ -1,4 +1,4 @@
-// libm_dbl64.h -- glibc's double-precision exp / log / log10, restated for the device (see libm_flt32.h for the why).
+// libm_dbl64.h -- glibc's double-precision exp / log / log10 / log1p, restated for the device (see libm_flt32.h for the why).
 //
 // The SNV posteriors (calculate_result_set, calculate_result_set_grid, error_prob_to_qphred) are double-precision
 // exp / log / log10 calls into the host C library.  glibc >= 2.28 (this image: 2.35): sysdeps/ieee754/dbl-64/e_exp.c and
@@ -275,6 +275,32 @@ SK_HD bool log10_glibc(double x, double& out, const double* T = log_table())
     return true;
 }
 
+/// glibc log1p (s_log1p.c: the fdlibm routine with glibc's split polynomial evaluation; no FMA build) for 0 <= x < 0.41422.
+/// Plain double arithmetic: callers compile with -ffp-contract=off.
+SK_HD bool log1p_glibc(const double x, double& out)
+{
+    const int32_t hx = int32_t(as_u64(x) >> 32);
+    if (hx < 0 || hx >= 0x3FDA827A) return false; // negative, >= 0.41422, inf, nan
+    if (hx < 0x3e200000) {                        // x < 2^-29
+        out = (hx < 0x3c900000) ? x : x - x * x * 0.5;
+        return true;
+    }
+    const double Lp1 = as_f64(0x3FE5555555555593ull), Lp2 = as_f64(0x3FD999999997FA04ull), Lp3 = as_f64(0x3FD2492494229359ull),
+                 Lp4 = as_f64(0x3FCC71C51D8E78AFull), Lp5 = as_f64(0x3FC7466496CB03DEull), Lp6 = as_f64(0x3FC39A09D078C69Full),
+                 Lp7 = as_f64(0x3FC2F112DF3E5244ull);
+    const double f = x;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double R1 = z * Lp1, z2 = z * z;
+    const double R2 = Lp2 + z * Lp3, z4 = z2 * z2;
+    const double R3 = Lp4 + z * Lp5, z6 = z4 * z2;
+    const double R4 = Lp6 + z * Lp7;
+    const double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
+    out = f - (hfsq - s * (hfsq + R));
+    return true;
+}
+
 } // namespace sk_libm
 
 #if defined(__HIPCC__)
@@ -311,6 +337,11 @@ __device__ __forceinline__ double sk_log10(const double x, const int exact_libm,
 {
     double r;
     return (exact_libm && sk_libm::log10_glibc(x, r, t.log_t)) ? r : log10(x);
+}
+__device__ __forceinline__ double sk_log1p(const double x, const int exact_libm)
+{
+    double r;
+    return (exact_libm && sk_libm::log1p_glibc(x, r)) ? r : log1p(x);
 }
 // Out-of-line twins for the somatic grid posterior: it unrolls ~150 call sites so that every likelihood index is static,
 // and inlining a table-driven routine into each of them makes the compiler give the unrolling up and index the

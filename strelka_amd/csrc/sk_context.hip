@@ -170,6 +170,8 @@ static bool host_libm_matches_restatement()
                                       : sk_libm::as_f64(0x0010000000000000ull + (st % 0x7fe0000000000000ull));
         if (!sk_libm::log_glibc(xl, dm) || sk_libm::as_u64(dm) != sk_libm::as_u64(std::log(xl))) return false;
         if (!sk_libm::log10_glibc(xl, dm) || sk_libm::as_u64(dm) != sk_libm::as_u64(std::log10(xl))) return false;
+        volatile double xp = double(st % 1000000000) / 1.0e11;
+        if (!sk_libm::log1p_glibc(xp, dm) || sk_libm::as_u64(dm) != sk_libm::as_u64(std::log1p(xp))) return false;
     }
     return true;
 }
