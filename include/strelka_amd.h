@@ -151,6 +151,8 @@ typedef struct sk_align_builder sk_align_builder;
 sk_align_builder* sk_align_builder_create(void);
 void sk_align_builder_destroy(sk_align_builder* b);
 void sk_align_builder_clear(sk_align_builder* b);
+/** append the reads of `src` after those of `dst` (joins batches flattened on different host threads) */
+int sk_align_builder_append(sk_align_builder* dst, const sk_align_builder* src);
 /** Append one read and its candidate alignments.  read_code: BAM 4-bit codes one per byte; ref_seq/ref_offset/ref_len:
  *  the reference_contig_segment (positions outside it read as 'N', L/blt_util/reference_contig_segment.hh:46-51). */
 int sk_align_builder_add_read(sk_align_builder* b, const uint8_t* read_code, const uint8_t* read_qual, int32_t read_len,
@@ -195,6 +197,7 @@ typedef struct sk_realign_options { /* L/starling_common/starling_base_shared.hh
     int32_t is_haplotyping_enabled;       /* germline 1, somatic 0 (:98, starling_shared.hh:52) */
     int32_t min_read_bp_flank;            /* 5; normal sample of a somatic run 1 */
     int32_t sample_count;                 /* 1..SK_MAX_SAMPLES */
+    int32_t host_threads;                 /* host stages of sk_realign_job_add_reads / _finish: 0 = up to 16 hardware threads, 1 = none */
 } sk_realign_options;
 void sk_realign_options_default(sk_realign_options* opt);
 
@@ -260,6 +263,10 @@ int sk_realign_job_set_reference(sk_realign_job* job, const char* ref_seq, int32
 int sk_realign_job_set_indels(sk_realign_job* job, const sk_indel_info* indels, int32_t n_indels);
 /** stage 1 for one read; returns the read's index in the job or -1 */
 int sk_realign_job_add_read(sk_realign_job* job, const sk_read_input* read);
+/** The same for n reads at once: gate, normalisation and enumeration (a1-a4) of the reads run on host threads, their
+ *  candidate alignments enter the batch in input order.  Returns the index of the first read added (the rest follow
+ *  consecutively), or -1 and adds nothing when any read is rejected (sk_realign_job_error names it). */
+int sk_realign_job_add_reads(sk_realign_job* job, const sk_read_input* reads, int32_t n);
 /** the flattened (read, candidate alignment) pairs of all reads added so far (host pointers owned by the job) */
 int sk_realign_job_get_batch(sk_realign_job* job, sk_align_batch* out);
 /** stage 3 from host scores laid out as get_batch's candidate alignments */

@@ -57,7 +57,7 @@ class RealignOptions(C.Structure):
                 ("max_realignment_candidates", C.c_uint32), ("max_indel_size", C.c_uint32),
                 ("is_smoothed_alignments", C.c_int32), ("smoothed_lnp_range", C.c_double),
                 ("upstream_oligo_size", C.c_uint32), ("is_haplotyping_enabled", C.c_int32),
-                ("min_read_bp_flank", C.c_int32), ("sample_count", C.c_int32)]
+                ("min_read_bp_flank", C.c_int32), ("sample_count", C.c_int32), ("host_threads", C.c_int32)]
 
 
 class IndelInfo(C.Structure):
@@ -180,12 +180,12 @@ assert DIGT_CALL_DTYPE.itemsize == 144 and SOMATIC_CALL_DTYPE.itemsize == 272
 EXPORTS = [
     "sk_init", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_libm_restated", "sk_get_qscore_tables",
     "sk_score_alignments", "sk_score_alignments_dev", "sk_align_evmask_words", "sk_align_prepare",
-    "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_add_read",
+    "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_append", "sk_align_builder_add_read",
     "sk_align_builder_finish", "sk_align_builder_error",
     "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
-    "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_get_batch",
+    "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
     "sk_realign_job_finish", "sk_realign_job_run", "sk_realign_job_n_reads", "sk_realign_job_read_result",
     "sk_realign_job_clear_reads", "sk_make_start_pos_alignment", "sk_get_end_pin_start_pos",
     "sk_germline_options_default", "sk_dependent_eprob", "sk_dependent_eprob_dev", "sk_site_digt_call",
@@ -239,6 +239,7 @@ def lib():
         L.sk_realign_job_set_reference.argtypes = [c_void_p, C.c_char_p, C.c_int32, C.c_int32]
         L.sk_realign_job_set_indels.argtypes = [c_void_p, C.POINTER(IndelInfo), C.c_int32]
         L.sk_realign_job_add_read.argtypes = [c_void_p, C.POINTER(ReadInput)]
+        L.sk_realign_job_add_reads.argtypes = [c_void_p, C.POINTER(ReadInput), C.c_int32]
         L.sk_realign_job_get_batch.argtypes = [c_void_p, C.POINTER(AlignBatch)]
         L.sk_realign_job_finish.argtypes = [c_void_p, c_void_p]
         L.sk_realign_job_run.argtypes = [c_void_p]
@@ -694,6 +695,24 @@ class RealignJob:
         if i < 0:
             raise self._err()
         return i
+
+    def add_reads(self, reads):
+        """reads: [(read_code, read_qual, pos, path, is_fwd, map_level, sample, realign_range, observed)] -> first index"""
+        n = len(reads)
+        arr = (ReadInput * max(n, 1))()
+        keep = []
+        for i, (read_code, read_qual, pos, path, is_fwd, map_level, sample, realign_range, observed) in enumerate(reads):
+            code = np.ascontiguousarray(read_code, np.uint8)
+            qual = np.ascontiguousarray(read_qual, np.uint8)
+            segs = (PathSeg * max(len(path), 1))(*[PathSeg(t, l) for t, l in path])
+            obs = (C.c_int32 * max(len(observed), 1))(*observed)
+            keep.append((code, qual, segs, obs))
+            arr[i] = ReadInput(_p(code), _p(qual), len(code), pos, len(path), segs, int(is_fwd), map_level, sample,
+                               realign_range[0], realign_range[1], len(observed), obs)
+        first = lib().sk_realign_job_add_reads(self._j, arr, n)
+        if first < 0:
+            raise self._err()
+        return first
 
     def batch(self):
         s = AlignBatch()

@@ -13,6 +13,7 @@
 #include <climits>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace
@@ -233,6 +234,26 @@ void sk_align_builder_clear(sk_align_builder* b)
     if (b) b->clear();
 }
 
+// append every read of `src` after the reads of `dst` (batches built on several threads are joined this way: op sources are
+// relative to their read's haplotype pool, so only the CSR offsets shift)
+int sk_align_builder_append(sk_align_builder* dst, const sk_align_builder* src)
+{
+    if (!dst || !src) return 1;
+    const int64_t rb = dst->read_off.back(), hb = dst->hap_off.back(), ob = dst->op_off.back();
+    const int32_t cb = dst->cal_off.back();
+    for (size_t i = 1; i < src->read_off.size(); ++i) dst->read_off.push_back(rb + src->read_off[i]);
+    for (size_t i = 1; i < src->hap_off.size(); ++i) dst->hap_off.push_back(hb + src->hap_off[i]);
+    for (size_t i = 1; i < src->cal_off.size(); ++i) dst->cal_off.push_back(cb + src->cal_off[i]);
+    for (size_t i = 1; i < src->op_off.size(); ++i) dst->op_off.push_back(ob + src->op_off[i]);
+    dst->read_code.insert(dst->read_code.end(), src->read_code.begin(), src->read_code.end());
+    dst->read_qual.insert(dst->read_qual.end(), src->read_qual.begin(), src->read_qual.end());
+    dst->hap_code.insert(dst->hap_code.end(), src->hap_code.begin(), src->hap_code.end());
+    dst->ops.insert(dst->ops.end(), src->ops.begin(), src->ops.end());
+    dst->max_read_len = std::max(dst->max_read_len, src->max_read_len);
+    dst->max_hap_len = std::max(dst->max_hap_len, src->max_hap_len);
+    return 0;
+}
+
 // error text of the last failing builder call (the GPU library's sk_last_error covers the device entry points)
 const char* sk_align_builder_error(const sk_align_builder* b) { return b ? b->error.c_str() : "null builder"; }
 
@@ -306,7 +327,11 @@ int sk_align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* evmas
 {
     if (!b || !entries || !evmask || b->n_reads < 0) return 1;
     const int W = sk_ent_evmask_words(b->max_read_len);
-    for (int r = 0; r < b->n_reads; ++r) {
+    // reads are independent (each owns its entry slots and its mask words): large batches are split over host threads
+    const int threads = int(std::max<int64_t>(1, std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
+                                                                    int64_t(b->n_reads) / 4096)));
+    auto slice = [&](const int r_begin, const int r_end) {
+    for (int r = r_begin; r < r_end; ++r) {
         const int64_t L64 = b->read_off[r + 1] - b->read_off[r], P64 = b->hap_off[r + 1] - b->hap_off[r];
         uint32_t* mask = evmask + int64_t(r) * W;
         std::memset(mask, 0, sizeof(uint32_t) * size_t(W));
@@ -358,6 +383,16 @@ int sk_align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* evmas
                 ent[0] = SK_ENT_COMPLEX;
             }
         }
+    }
+    };
+    if (threads <= 1) {
+        slice(0, b->n_reads);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t)
+            pool.emplace_back(slice, int(int64_t(b->n_reads) * t / threads), int(int64_t(b->n_reads) * (t + 1) / threads));
+        slice(0, int(int64_t(b->n_reads) / threads));
+        for (auto& th : pool) th.join();
     }
     return 0;
 }

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <set>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -1618,6 +1619,7 @@ void sk_realign_options_default(sk_realign_options* o)
     o->is_haplotyping_enabled = 0;
     o->min_read_bp_flank = 5;
     o->sample_count = 1;
+    o->host_threads = 0;
 }
 
 sk_realign_job* sk_realign_job_create(const sk_realign_options* opt)
@@ -1699,69 +1701,184 @@ void sk_realign_job_clear_reads(sk_realign_job* j)
 
 int sk_realign_job_n_reads(const sk_realign_job* j) { return j ? int(j->reads.size()) : 0; }
 
+} // extern "C"
+
+namespace
+{
+
+// stage 1 for one read: validation, gate, normalisation, enumeration.  Touches nothing but `rd` (the job is read-only here),
+// so reads can be prepared concurrently.  Throws Fail.
+void prepare_read(const Job& job, const sk_read_input* in, sk_realign_job::Read& rd)
+{
+    if (in->read_len < 0 || in->n_seg < 0) throw Fail("negative read or path length");
+    if (in->sample_index < 0 || in->sample_index >= job.opt.sample_count) throw Fail("sample_index out of range");
+    rd.code.assign(in->read_code, in->read_code + in->read_len);
+    rd.qual.assign(in->read_qual, in->read_qual + in->read_len);
+    rd.map_level = in->map_level;
+    rd.sample = in->sample_index;
+    rd.input.pos = in->pos;
+    rd.input.fwd = in->is_fwd_strand != 0;
+    for (int i = 0; i < in->n_seg; ++i) rd.input.path.push_back(Seg{ in->path[i].type, in->path[i].length });
+    if (rd.input.empty() || path_read_length(rd.input.path) != unsigned(in->read_len))
+        throw Fail("invalid alignment path associated with read segment"); // realignAndScoreRead :2036-2040
+    std::set<int> observed;
+    for (int i = 0; i < in->n_observed; ++i) {
+        const int o = in->observed[i];
+        if (o < 0 || size_t(o) >= job.orig_to_tab.size()) throw Fail("observed indel index out of range");
+        observed.insert(job.orig_to_tab[size_t(o)]);
+    }
+    const Range realign_range(in->realign_begin, in->realign_end);
+
+    std::set<Cal> cal_set;
+    bool gate = !is_overmax(rd.input, job.opt.max_indel_size); // is_realignable :2045
+    if (gate) { // check_for_candidate_indel_overlap :217-270
+        const Range rr = alignment_zone(rd.input, unsigned(in->read_len));
+        gate = false;
+        if (realign_range.superset_of(rr)) {
+            const auto it = job.range_iter(rr.b, rr.e);
+            for (int i = it.first; i < it.second; ++i) {
+                if (!range_intersect_indel_breakpoints(rr, job.key(i))) continue;
+                if (job.tab[size_t(i)].cand) { gate = true; break; }
+            }
+        }
+    }
+    if (gate) {
+        // normalizeInputAlignmentIndels :2001-2021 (no pinned edges on DNA reads)
+        Aln norm = rd.input;
+        if (is_edge_readref_len_segment(norm.path)) norm = matchify_edge_indels(norm, true, true);
+        if (path_is_soft_clipped(norm.path)) norm = matchify_edge_segment_type(norm, SK_SEG_SOFT_CLIP); // :2051-2057
+        if (norm.pos >= 0) {
+            get_candidate_alignments(job, rd, observed, norm, realign_range, cal_set);
+            if (cal_set.empty()) throw Fail("Empty candidate alignment set while realigning normed input alignment");
+        }
+    }
+    rd.incomplete_search = rd.warn_origin || rd.warn_toggle;
+    rd.cals.assign(cal_set.begin(), cal_set.end());
+}
+
+// flatten a prepared read's candidate alignments into `builder`; returns the number of candidate alignments added
+int32_t flatten_read(const Job& j, sk_align_builder* builder, const sk_realign_job::Read& rd)
+{
+    std::vector<std::vector<sk_path_seg>> segs(rd.cals.size());
+    std::vector<std::vector<sk_indel_key>> keys(rd.cals.size());
+    std::vector<sk_candidate_alignment> cc(rd.cals.size());
+    for (size_t i = 0; i < rd.cals.size(); ++i) cal_to_c(j, rd.cals[i], segs[i], keys[i], cc[i]);
+    if (!rd.cals.empty() &&
+        sk_align_builder_add_read(builder, rd.code.data(), rd.qual.data(), int32_t(rd.code.size()), j.ref.data(), j.ref_offset,
+                                  int32_t(j.ref.size()), cc.data(), int32_t(cc.size())) != 0)
+        throw Fail(std::string("flatten: ") + sk_align_builder_error(builder));
+    return int32_t(rd.cals.size());
+}
+
+// flatten into the job's batch and keep the read (sequential: batch order = read order)
+void append_read(Job& j, sk_realign_job::Read&& rd)
+{
+    rd.cal_begin = j.n_cals_total;
+    j.n_cals_total += flatten_read(j, j.builder, rd);
+    j.reads.push_back(std::move(rd));
+}
+
+int host_threads(const Job& j, const size_t n_items)
+{
+    int t = j.opt.host_threads;
+    if (t <= 0) t = int(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+    return int(std::max<size_t>(1, std::min<size_t>(size_t(t), n_items / 64))); // not worth a thread below ~64 reads each
+}
+
+// run f(i) for i in [0, n) on up to `threads` threads (contiguous slices); returns the first exception's message, if any
+template <typename F>
+std::string parallel_for(const size_t n, const int threads, F&& f)
+{
+    const size_t nt = static_cast<size_t>(threads);
+    std::vector<std::string> err(nt);
+    std::vector<size_t> err_at(nt, n);
+    auto work = [&](const int t) {
+        const size_t b = n * size_t(t) / size_t(threads), e = n * size_t(t + 1) / size_t(threads);
+        for (size_t i = b; i < e; ++i) {
+            try {
+                f(i);
+            } catch (const std::exception& ex) {
+                err[size_t(t)] = ex.what();
+                err_at[size_t(t)] = i;
+                return;
+            }
+        }
+    };
+    if (threads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
+    size_t best = n;
+    std::string msg;
+    for (int t = 0; t < threads; ++t)
+        if (err_at[size_t(t)] < best) {
+            best = err_at[size_t(t)];
+            msg = "read " + std::to_string(best) + ": " + err[size_t(t)];
+        }
+    return msg;
+}
+
+} // namespace
+
+extern "C" {
+
 int sk_realign_job_add_read(sk_realign_job* j, const sk_read_input* in)
 {
     if (!j || !in || in->read_len < 0 || in->n_seg < 0) return -1;
     try {
         if (j->finished) throw Fail("job already finished: clear the reads first");
-        if (in->sample_index < 0 || in->sample_index >= j->opt.sample_count) throw Fail("sample_index out of range");
         sk_realign_job::Read rd;
-        rd.code.assign(in->read_code, in->read_code + in->read_len);
-        rd.qual.assign(in->read_qual, in->read_qual + in->read_len);
-        rd.map_level = in->map_level;
-        rd.sample = in->sample_index;
-        rd.input.pos = in->pos;
-        rd.input.fwd = in->is_fwd_strand != 0;
-        for (int i = 0; i < in->n_seg; ++i) rd.input.path.push_back(Seg{ in->path[i].type, in->path[i].length });
-        if (rd.input.empty() || path_read_length(rd.input.path) != unsigned(in->read_len))
-            throw Fail("invalid alignment path associated with read segment"); // realignAndScoreRead :2036-2040
-        std::set<int> observed;
-        for (int i = 0; i < in->n_observed; ++i) {
-            const int o = in->observed[i];
-            if (o < 0 || size_t(o) >= j->orig_to_tab.size()) throw Fail("observed indel index out of range");
-            observed.insert(j->orig_to_tab[size_t(o)]);
-        }
-        const Range realign_range(in->realign_begin, in->realign_end);
+        prepare_read(*j, in, rd);
+        append_read(*j, std::move(rd));
+        return int(j->reads.size()) - 1;
+    } catch (const std::exception& e) {
+        j->error = e.what();
+        return -1;
+    }
+}
 
-        std::set<Cal> cal_set;
-        bool gate = !is_overmax(rd.input, j->opt.max_indel_size); // is_realignable :2045
-        if (gate) { // check_for_candidate_indel_overlap :217-270
-            const Range rr = alignment_zone(rd.input, unsigned(in->read_len));
-            gate = false;
-            if (realign_range.superset_of(rr)) {
-                const auto it = j->range_iter(rr.b, rr.e);
-                for (int i = it.first; i < it.second; ++i) {
-                    if (!range_intersect_indel_breakpoints(rr, j->key(i))) continue;
-                    if (j->tab[size_t(i)].cand) { gate = true; break; }
+int sk_realign_job_add_reads(sk_realign_job* j, const sk_read_input* in, int32_t n)
+{
+    if (!j || (!in && n > 0) || n < 0) return -1;
+    try {
+        if (j->finished) throw Fail("job already finished: clear the reads first");
+        // every thread prepares AND flattens its contiguous slice of the reads into a builder of its own; the slices are then
+        // appended to the job's batch in order, so the batch is byte for byte what read-by-read calls produce
+        std::vector<sk_realign_job::Read> prepared(static_cast<size_t>(n));
+        const int threads = host_threads(*j, size_t(n));
+        struct Slice
+        {
+            sk_align_builder* builder = nullptr;
+            ~Slice() { if (builder) sk_align_builder_destroy(builder); }
+        };
+        std::vector<Slice> slices(static_cast<size_t>(threads));
+        for (auto& sl : slices) sl.builder = sk_align_builder_create();
+        const std::string err = parallel_for(size_t(threads), threads, [&](const size_t t) {
+            const size_t b = size_t(n) * t / size_t(threads), e = size_t(n) * (t + 1) / size_t(threads);
+            for (size_t i = b; i < e; ++i) {
+                try {
+                    prepare_read(*j, in + i, prepared[i]);
+                    prepared[i].cal_begin = flatten_read(*j, slices[t].builder, prepared[i]); // (count for now)
+                } catch (const std::exception& ex) {
+                    throw Fail("read " + std::to_string(i) + ": " + ex.what());
                 }
             }
+        });
+        if (!err.empty()) throw Fail(err.substr(err.find(": ") + 2)); // nothing was added
+        const int first = int(j->reads.size());
+        for (int t = 0; t < threads; ++t)
+            if (sk_align_builder_append(j->builder, slices[size_t(t)].builder)) throw Fail("append");
+        for (auto& rd : prepared) {
+            const int32_t n_cals = rd.cal_begin;
+            rd.cal_begin = j->n_cals_total;
+            j->n_cals_total += n_cals;
+            j->reads.push_back(std::move(rd));
         }
-        if (gate) {
-            // normalizeInputAlignmentIndels :2001-2021 (no pinned edges on DNA reads)
-            Aln norm = rd.input;
-            if (is_edge_readref_len_segment(norm.path)) norm = matchify_edge_indels(norm, true, true);
-            if (path_is_soft_clipped(norm.path)) norm = matchify_edge_segment_type(norm, SK_SEG_SOFT_CLIP); // :2051-2057
-            if (norm.pos >= 0) {
-                get_candidate_alignments(*j, rd, observed, norm, realign_range, cal_set);
-                if (cal_set.empty()) throw Fail("Empty candidate alignment set while realigning normed input alignment");
-            }
-        }
-        rd.incomplete_search = rd.warn_origin || rd.warn_toggle;
-        rd.cals.assign(cal_set.begin(), cal_set.end());
-
-        // flatten this read's candidate alignments into the job's batch
-        rd.cal_begin = j->n_cals_total;
-        std::vector<std::vector<sk_path_seg>> segs(rd.cals.size());
-        std::vector<std::vector<sk_indel_key>> keys(rd.cals.size());
-        std::vector<sk_candidate_alignment> cc(rd.cals.size());
-        for (size_t i = 0; i < rd.cals.size(); ++i) cal_to_c(*j, rd.cals[i], segs[i], keys[i], cc[i]);
-        if (!rd.cals.empty() &&
-            sk_align_builder_add_read(j->builder, rd.code.data(), rd.qual.data(), in->read_len, j->ref.data(), j->ref_offset,
-                                      int32_t(j->ref.size()), cc.data(), int32_t(cc.size())) != 0)
-            throw Fail(std::string("flatten: ") + sk_align_builder_error(j->builder));
-        j->n_cals_total += int32_t(rd.cals.size());
-        j->reads.push_back(std::move(rd));
-        return int(j->reads.size()) - 1;
+        return first;
     } catch (const std::exception& e) {
         j->error = e.what();
         return -1;
@@ -1778,12 +1895,14 @@ int sk_realign_job_finish(sk_realign_job* j, const double* scores)
 {
     if (!j) return 1;
     try {
-        for (auto& rd : j->reads) {
+        // reads are independent in stage 3 as well: each writes only its own results
+        const std::string err = parallel_for(j->reads.size(), host_threads(*j, j->reads.size()), [&](const size_t ri) {
+            auto& rd = j->reads[ri];
             rd.scores.clear();
             rd.suboverlap.clear();
             rd.realigned = false;
             rd.out_path.clear();
-            if (rd.cals.empty()) continue;
+            if (rd.cals.empty()) return;
             if (!scores) throw Fail("sk_realign_job_finish: null scores");
             const double* s = scores + rd.cal_begin;
             const Cal* max_cal = nullptr;
@@ -1791,7 +1910,8 @@ int sk_realign_job_finish(sk_realign_job* j, const double* scores)
             if (rd.map_level == SK_MAPLEVEL_TIER1 || rd.map_level == SK_MAPLEVEL_TIER2) // is_tier1or2_mapping :1800
                 score_indels(*j, rd, s, rd.max_score, max_cal);
             for (const Seg& q : rd.realignment.path) rd.out_path.push_back(sk_path_seg{ q.type, q.length });
-        }
+        });
+        if (!err.empty()) throw Fail(err);
         j->finished = true;
         return 0;
     } catch (const std::exception& e) {

@@ -221,6 +221,50 @@ def test_gpu_whole_read_job_matches_reference_golden(gpu, gold):
     assert n_reads > 400
 
 
+def test_threaded_batch_add_equals_read_by_read(built, gold):
+    """sk_realign_job_add_reads (stage 1 on host threads) and a threaded sk_realign_job_finish give exactly what the
+    read-by-read, single-threaded calls give: same batch bytes, same per-read results; a rejected read adds nothing"""
+    _, lnc, lne = capi.qscore_tables()
+    sc = max(gold["scenarios"], key=lambda s: len(s["reads"]))
+    reads = [(rd["code"], rd["qual"], rd["pos"], rd["path"], rd["is_fwd"], rd["map_level"], 0, rd["realign_range"], rd["observed"])
+             for rd in sc["reads"] if not rd.get("bad")]
+    ok = []
+    probe = _make_job(sc)
+    for r in reads:  # keep the reads the job accepts
+        try:
+            probe.add_read(*r)
+            ok.append(r)
+        except capi.StrelkaAmdError:
+            pass
+    many = ok * (300 // max(len(ok), 1) + 1)  # > 64 reads per thread, so that several threads really run
+    def run(threads, batched):
+        opt = capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"], min_read_bp_flank=sc["min_read_bp_flank"])
+        opt.host_threads = threads
+        job = capi.RealignJob(opt)
+        job.set_reference(sc["ref_seq"], sc["ref_offset"])
+        job.set_indels(sc["indels"])
+        if batched:
+            assert job.add_reads(many) == 0
+        else:
+            for r in many:
+                job.add_read(*r)
+        b = job.batch()
+        job.finish(score_flat(b, lnc, lne))
+        return b, [job.result(i) for i in range(len(many))]
+    b1, r1 = run(1, False)
+    b4, r4 = run(4, True)
+    for f in ("read_off", "read_code", "read_qual", "hap_off", "hap_code", "cal_off", "op_off"):
+        assert np.array_equal(getattr(b1, f), getattr(b4, f)), f
+    assert b1.ops.tobytes() == b4.ops.tobytes()
+    assert r1 == r4
+    # all or nothing
+    job = _make_job(sc)
+    bad = list(many[:70]) + [(many[0][0], many[0][1], many[0][2], [(capi.SEG["MATCH"], 3)]) + tuple(many[0][4:])]
+    with pytest.raises(capi.StrelkaAmdError, match="read 70: invalid alignment path"):
+        job.add_reads(bad)
+    assert job.n_reads() == 0
+
+
 @pytest.mark.gpu
 def test_gpu_one_job_many_reads_matches_per_scenario_jobs(gpu, gold):
     """the batched job (all reads of a scenario scored in ONE launch) gives the same bits as the CPU interpreter"""
