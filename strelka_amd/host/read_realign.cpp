@@ -643,11 +643,62 @@ void get_end_pin_start_pos(const std::vector<Indel>& tab, const ISet& indels, un
 
 // ------------------------------------------------------------------------------------------------ enumeration state
 
+// the subset of std::map the search uses, over a sorted vector: the reference passes its status / haplotype maps by value at
+// every recursion step, and copying a node-based map costs an allocation per entry
+template <typename K, typename V>
+struct FlatMap
+{
+    typedef std::pair<K, V> value_type;
+    typedef typename std::vector<value_type>::iterator iterator;
+    typedef typename std::vector<value_type>::const_iterator const_iterator;
+    std::vector<value_type> v;
+    iterator begin() { return v.begin(); }
+    iterator end() { return v.end(); }
+    const_iterator begin() const { return v.begin(); }
+    const_iterator end() const { return v.end(); }
+    size_t size() const { return v.size(); }
+    iterator lower(const K& k)
+    {
+        return std::lower_bound(v.begin(), v.end(), k, [](const value_type& a, const K& kk) { return a.first < kk; });
+    }
+    const_iterator lower(const K& k) const
+    {
+        return std::lower_bound(v.begin(), v.end(), k, [](const value_type& a, const K& kk) { return a.first < kk; });
+    }
+    iterator find(const K& k)
+    {
+        iterator it = lower(k);
+        return (it != v.end() && it->first == k) ? it : v.end();
+    }
+    const_iterator find(const K& k) const
+    {
+        const_iterator it = lower(k);
+        return (it != v.end() && it->first == k) ? it : v.end();
+    }
+    V& operator[](const K& k)
+    {
+        iterator it = lower(k);
+        if (it == v.end() || !(it->first == k)) it = v.insert(it, value_type(k, V()));
+        return it->second;
+    }
+    V& at(const K& k)
+    {
+        iterator it = find(k);
+        if (it == v.end()) throw std::out_of_range("FlatMap::at");
+        return it->second;
+    }
+    void insert(const value_type& kv)
+    {
+        iterator it = lower(kv.first);
+        if (it == v.end() || !(it->first == kv.first)) v.insert(it, kv);
+    }
+};
+
 struct IndelStatus // starling_align_indel_info :48-53
 {
     bool is_present = false, is_remove_only = false, in_original = false;
 };
-typedef std::map<int, IndelStatus> StatusMap; // ordered by table index == IndelKey order
+typedef FlatMap<int, IndelStatus> StatusMap; // ordered by table index == IndelKey order
 
 // getUpdatedSampleHaplotypeConstraints :63-130
 int updated_haplotype_constraints(int hc, int cur_hap_id, bool cur_on, bool any_on)
@@ -684,7 +735,7 @@ struct HapStatus // HaplotypeStatus :134-179
         return valid;
     }
 };
-typedef std::map<int32_t, HapStatus> HapMap;
+typedef FlatMap<int32_t, HapStatus> HapMap;
 
 struct SearchCtx
 {
