@@ -13,6 +13,7 @@
 #include <climits>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -389,9 +390,16 @@ int sk_align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* evmas
         slice(0, b->n_reads);
     } else {
         std::vector<std::thread> pool;
-        for (int t = 1; t < threads; ++t)
-            pool.emplace_back(slice, int(int64_t(b->n_reads) * t / threads), int(int64_t(b->n_reads) * (t + 1) / threads));
-        slice(0, int(int64_t(b->n_reads) / threads));
+        std::vector<int> inline_slices{ 0 };
+        auto lo = [&](const int t) { return int(int64_t(b->n_reads) * t / threads); };
+        for (int t = 1; t < threads; ++t) {
+            try {
+                pool.emplace_back(slice, lo(t), lo(t + 1));
+            } catch (const std::system_error&) { // no more threads to be had: this slice runs here
+                inline_slices.push_back(t);
+            }
+        }
+        for (const int t : inline_slices) slice(lo(t), lo(t + 1));
         for (auto& th : pool) th.join();
     }
     return 0;

@@ -22,6 +22,7 @@
 #include <thread>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <tuple>
 #include <vector>
 
@@ -1859,8 +1860,15 @@ std::string parallel_for(const size_t n, const int threads, F&& f)
         work(0);
     } else {
         std::vector<std::thread> pool;
-        for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
-        work(0);
+        std::vector<int> inline_slices{ 0 };
+        for (int t = 1; t < threads; ++t) {
+            try {
+                pool.emplace_back(work, t);
+            } catch (const std::system_error&) { // no more threads to be had: this slice runs here
+                inline_slices.push_back(t);
+            }
+        }
+        for (const int t : inline_slices) work(t);
         for (auto& th : pool) th.join();
     }
     size_t best = n;
