@@ -197,7 +197,8 @@ typedef struct sk_realign_options { /* L/starling_common/starling_base_shared.hh
     int32_t is_haplotyping_enabled;       /* germline 1, somatic 0 (:98, starling_shared.hh:52) */
     int32_t min_read_bp_flank;            /* 5; normal sample of a somatic run 1 */
     int32_t sample_count;                 /* 1..SK_MAX_SAMPLES */
-    int32_t host_threads;                 /* host stages of sk_realign_job_add_reads / _finish: 0 = up to 16 hardware threads, 1 = none */
+    int32_t host_threads;                 /* host stages of sk_realign_job_add_reads / _finish: 1 = none (default: the reference runs one
+                                             process per core), n = up to n threads, 0 = up to 16 hardware threads */
 } sk_realign_options;
 void sk_realign_options_default(sk_realign_options* opt);
 

@@ -1671,7 +1671,7 @@ void sk_realign_options_default(sk_realign_options* o)
     o->is_haplotyping_enabled = 0;
     o->min_read_bp_flank = 5;
     o->sample_count = 1;
-    o->host_threads = 0;
+    o->host_threads = 1; // the reference runs one process per core; an adapter that owns more cores raises this
 }
 
 sk_realign_job* sk_realign_job_create(const sk_realign_options* opt)
