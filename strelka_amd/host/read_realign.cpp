@@ -1444,15 +1444,36 @@ void late_indel_normalization_filter(const Job& job, const sk_realign_job::Read&
     }
 }
 
-typedef std::tuple<int, bool, int> IksKey; // (evaluated indel, (is present, which indel)) -- indel_status_t :46-49
-
-void update_scoring_info(std::map<IksKey, double>& m, int call, bool present, int which, double lnp) // :61-77
+// The reference's iks_map_t (:54): best score per (evaluated indel, (is present, which indel)).  Both indels always come from
+// the read's evaluated set, so the map is a dense [evaluated][present][evaluated] table over positions in that (sorted) set.
+struct ScoringInfo
 {
-    const IksKey k(call, present, which);
-    auto it = m.find(k);
-    if (it != m.end() && it->second >= lnp) return;
-    m[k] = lnp;
-}
+    const ISet& eval;
+    int n;
+    std::vector<double> val;
+    std::vector<char> has;
+    explicit ScoringInfo(const ISet& e) : eval(e), n(int(e.size())), val(size_t(2) * e.size() * e.size()), has(val.size(), 0) {}
+    size_t slot(const int call, const bool present, const int which) const
+    {
+        const size_t lc = size_t(std::lower_bound(eval.begin(), eval.end(), call) - eval.begin());
+        const size_t lw = size_t(std::lower_bound(eval.begin(), eval.end(), which) - eval.begin());
+        return (lc * 2 + (present ? 1 : 0)) * size_t(n) + lw;
+    }
+    void update(const int call, const bool present, const int which, const double lnp) // updateIndelScoringInfo :61-77
+    {
+        const size_t k = slot(call, present, which);
+        if (has[k] && val[k] >= lnp) return;
+        has[k] = 1;
+        val[k] = lnp;
+    }
+    bool find(const int call, const bool present, const int which, double& out) const
+    {
+        const size_t k = slot(call, present, which);
+        if (!has[k]) return false;
+        out = val[k];
+        return true;
+    }
+};
 
 // score_indels :454-1079
 void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores, double max_score, const Cal* max_cal)
@@ -1505,7 +1526,7 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
                 iset_insert(ortho[to_eval[j]], to_eval[i]);
             }
 
-    std::map<IksKey, double> info;
+    ScoringInfo info(to_eval);
     for (unsigned ci = 0; ci < n; ++ci) {
         if (is_filtered[ci]) continue;
         const Cal& c = rd.cals[ci];
@@ -1514,13 +1535,13 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
         for (const int e : to_eval) {
             const Indel& ed = job.tab[e];
             if (iset_has(c.indels, e)) {
-                update_scoring_info(info, e, true, e, score);
-                update_scoring_info(info, e, false, e, score + ed.r2i);
+                info.update(e, true, e, score);
+                info.update(e, false, e, score + ed.r2i);
                 auto of = ortho.find(e);
                 if (of == ortho.end()) { ortho[e]; of = ortho.find(e); } // operator[] in the reference creates the entry
                 for (const int o : of->second) {
-                    update_scoring_info(info, o, false, o, score + ed.r2i);
-                    update_scoring_info(info, o, true, e, score);
+                    info.update(o, false, o, score + ed.r2i);
+                    info.update(o, true, e, score);
                 }
             } else {
                 // which_interfering_indel :100-119
@@ -1531,17 +1552,17 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
                 }
                 if (interfering >= 0 && !iset_has(to_eval, interfering)) iset_insert(noncand_ortho, interfering);
                 if (interfering < 0) {
-                    update_scoring_info(info, e, false, e, score);
-                    update_scoring_info(info, e, true, e, score + ed.i2r);
+                    info.update(e, false, e, score);
+                    info.update(e, true, e, score + ed.i2r);
                 } else {
-                    update_scoring_info(info, e, true, e, score + ed.i2r);
+                    info.update(e, true, e, score + ed.i2r);
                 }
             }
         }
         for (const int nc : noncand_ortho) {
             for (const int e : to_eval) {
                 if (!is_indel_conflict(job.key(nc), job.key(e))) continue;
-                update_scoring_info(info, e, false, e, score + job.tab[nc].r2i);
+                info.update(e, false, e, score + job.tab[nc].r2i);
             }
         }
     }
@@ -1554,17 +1575,9 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
         const Key& k = job.key(e);
         const bool in_max = iset_has(mc.indels, e);
         double indel_score = max_score;
-        if (!in_max) {
-            auto it = info.find(IksKey(e, true, e));
-            if (it == info.end()) continue; // incomplete search or "safe mode" warning: the indel is skipped either way
-            indel_score = it->second;
-        }
+        if (!in_max && !info.find(e, true, e, indel_score)) continue; // incomplete search or "safe mode" warning: skipped either way
         double ref_score = 0;
-        {
-            auto it = info.find(IksKey(e, false, e));
-            if (it == info.end()) continue;
-            ref_score = it->second;
-        }
+        if (!info.find(e, false, e, ref_score)) continue;
         const Range rr(k.pos - 1, k.right_pos() + 1);
         const int32_t read_pos = lowest_fwd_read_pos_for_ref_range(mc.al, rr);
         int32_t edge_dist = int32_t(read_length);
@@ -1589,10 +1602,10 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
         auto of = ortho.find(e);
         if (of != ortho.end()) {
             for (const int o : of->second) {
-                auto it = info.find(IksKey(e, true, o));
-                if (it == info.end()) continue;
+                double alt_score;
+                if (!info.find(e, true, o, alt_score)) continue;
                 // ReadPathScores::insertAlt, IndelData.cpp:40-68: keep the two best
-                const float a = static_cast<float>(it->second);
+                const float a = static_cast<float>(alt_score);
                 if (s.n_alt < 2) {
                     s.alt_indel[s.n_alt] = job.tab[o].orig;
                     s.alt_lnp[s.n_alt] = a;
