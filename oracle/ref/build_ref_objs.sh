@@ -8,7 +8,7 @@ REFERENCE=${REFERENCE:-/root/reference}
 L=$REFERENCE/src/c++/lib
 HERE=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$HERE/_ref
-INC="-I$L -I$HERE/boost_shim -I$OUT/redist/htslib-1.7-6-g6d2bfb7 -I$OUT/redist/rapidjson-1.1.0/include -I$HERE/ref"
+INC="-I$L -I$HERE/ref/gen -I$HERE/boost_shim -I$OUT/redist/htslib-1.7-6-g6d2bfb7 -I$OUT/redist/rapidjson-1.1.0/include -I$HERE/ref"
 mkdir -p $OUT/obj
 comp() {
     f=$1; o=$OUT/obj/$(echo ${f%.cpp} | tr '/' '_').o

@@ -22,9 +22,6 @@
 #include <string>
 #include <vector>
 
-// appstats/RunStats.cpp needs Boost.Serialization's XML archives and is not built; its only symbol reached from here is
-// the stats writer, which RunStatsManager calls only when given an output file name (never, in this driver)
-void RunStats::save(std::ostream&) const {}
 
 namespace
 {
