@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Write hooked copies of a few reference translation units into oracle/_ref/adapter_src/ (git-ignored, never committed).
+
+The reference has no plug-in seam for this path: the hot-path calls are ordinary C++ calls inside
+starling_pos_processor_base / starling_pos_processor / strelka_pos_processor.  A maintainer integrating
+libstrelka_amd.so would edit those call sites; this script makes exactly those edits, mechanically, on copies made at
+build time from the sources where they lie under $REFERENCE -- each edit is an anchored substitution that must match
+exactly once, so a reference version with a different call site fails the build instead of silently changing nothing.
+Every inserted line calls a function declared in adapter/sk_adapter.hh; all logic lives in adapter/*.cpp.
+
+usage: apply_hooks.py <reference root> <output dir>
+"""
+import os
+import re
+import sys
+
+L = "src/c++/lib/"
+
+# (file, [(description, anchor regex, replacement)])
+HOOKS = [
+    (L + "starling_common/starling_pos_processor_base.hh", [
+        ("friend + forward declaration",
+         r'struct starling_pos_processor_base : public pos_processor_base, private boost::noncopyable\n\{\n',
+         '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::Access;\n'),
+    ]),
+    (L + "starling_common/starling_pos_processor_base.cpp", [
+        ("include", r'#include "starling_read_align.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # stage geometry: READ_BUFFER and POST_ALIGN pushed further behind HEAD by the batching windows
+        ("READ_BUFFER stage distance", r'\+HAPLOTYPING_PADDING\);', '+HAPLOTYPING_PADDING+sk_adapter::read_buffer_defer());'),
+        ("POST_ALIGN stage distance",
+         r'sdata\.add_stage\(POST_ALIGN,READ_BUFFER,largest_total_indel_ref_span_per_read\);',
+         'sdata.add_stage(POST_ALIGN,READ_BUFFER,largest_total_indel_ref_span_per_read+sk_adapter::post_align_defer());'),
+        # empty-site genotypes of the constructor (site 3 with zero-depth loci)
+        ("empty-site precompute",
+         r'_dopt\.pdcaller\(\)\.position_snp_call_pprob_digt\(_opt,good_epi,\s*\*_empty_dgt\[b\],\s*_opt\.is_all_sites\(\)\);',
+         'sk_adapter::empty_site_genotype(*this, b, *_empty_dgt[b]);'),
+        ("region reset",
+         r'(_stagemanPtr\.reset\(new stage_manager\(STAGE::get_stage_data\(STARLING_INIT_LARGEST_READ_SIZE, get_largest_total_indel_ref_span_per_read\(\), _opt, _dopt\), pr, \*this\)\);\n)',
+         '\\1    sk_adapter::on_reset_region(*this);\n'),
+        # read-buffer occupancy as the reference would see it (its CLEAR_READ_BUFFER stage runs earlier than ours)
+        ("read-buffer capacity test", r'if \(rbuff\.size\(\) >= _opt\.maxBufferedReads\)',
+         'if (sk_adapter::buffered_read_count(*this, sampleIndex, rbuff.size()) >= _opt.maxBufferedReads)'),
+        ("read inserted",
+         r'(        assert\(nullptr!=sread_ptr\);\n)',
+         '\\1        sk_adapter::on_read_inserted(*this, sampleIndex, *sread_ptr);\n'),
+        # site 1
+        ("align_pos",
+         r'(starling_pos_processor_base::\nalign_pos\(const pos_t pos\)\n\{\n)',
+         '\\1    if (sk_adapter::align_pos(*this, pos)) return;\n'),
+        ("set_head_pos",
+         r'(starling_pos_processor_base::\nset_head_pos\(const pos_t pos\)\n\{\n)',
+         '\\1    sk_adapter::on_set_head_pos(*this, pos, get_read_buffer_size(get_largest_read_size(), '
+         'get_largest_total_indel_ref_span_per_read())+HAPLOTYPING_PADDING, get_largest_total_indel_ref_span_per_read());\n'),
+        # sites 2+3: the window's genotypes are computed when POST_ALIGN reaches its first position
+        ("process_pos_variants",
+         r'(starling_pos_processor_base::\nprocess_pos_variants\(\n    const pos_t pos,\n    const bool isPosPrecedingReportableRange\)\n\{\n)',
+         '\\1    sk_adapter::before_process_pos_variants(*this, pos);\n'),
+    ]),
+    (L + "applications/starling/starling_pos_processor.hh", [
+        ("friend", r'(struct starling_pos_processor : public starling_pos_processor_base\n\{\n)',
+         '\\1    friend struct sk_adapter::Access;\n'),
+    ]),
+    (L + "applications/starling/starling_pos_processor.cpp", [
+        ("include", r'#include "starling_pos_processor.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # site 2: the dependent error probabilities are computed inside the fused site kernel
+        ("CleanPileupErrorProb", r'_pileupCleaner\.CleanPileupErrorProb\(sample\(sampleIndex\)\.cleanedPileup\);',
+         '/* strelka_amd: adjust_joint_eprob runs fused with the genotype kernel (sk_site_digt_call_fused) */'),
+        # site 3
+        ("computeSampleDiploidSiteGenotype call",
+         r'computeSampleDiploidSiteGenotype\(\n\s*_opt, _dopt, sample\(sampleIndex\), callerPloidy\[sampleIndex\], allDgt\[sampleIndex\]\);',
+         'sk_adapter::site_diploid_genotype(*this, pos, sampleIndex, callerPloidy[sampleIndex], allDgt[sampleIndex]);'),
+    ]),
+]
+
+
+def main():
+    ref_root, out_dir = sys.argv[1], sys.argv[2]
+    only = set(sys.argv[3:])
+    for rel, hooks in HOOKS:
+        src = os.path.join(ref_root, rel)
+        text = open(src).read()
+        for desc, anchor, repl in hooks:
+            if only and not any(o in desc for o in only) and "include" not in desc and "friend" not in desc:
+                continue
+            n = len(re.findall(anchor, text))
+            if n != 1:
+                sys.exit("apply_hooks: anchor for '%s' matches %d times in %s (expected exactly 1)" % (desc, n, rel))
+            text = re.sub(anchor, repl, text, count=1)
+        dst = os.path.join(out_dir, rel[len(L):])
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        with open(dst, "w") as f:
+            f.write(text)
+        print("hooked", rel, "->", dst)
+
+
+if __name__ == "__main__":
+    main()

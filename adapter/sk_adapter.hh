@@ -1,0 +1,60 @@
+// sk_adapter.hh -- the hook functions the hooked copies of the reference's position-processor sources call
+// (adapter/apply_hooks.py inserts the calls; the hooked copies live under oracle/_ref/adapter_src/, never in the repo).
+//
+// This is the compiled form of INTEGRATION.md: C++ written against the REFERENCE's headers (it only builds where
+// /root/reference is present) that re-routes the hot-path call sites of starling_pos_processor_base / starling_pos_processor /
+// strelka_pos_processor through the C-ABI of include/strelka_amd.h, with stage-window batching.  It is the integration
+// layer a Strelka2 maintainer would add, and the test vehicle for the end-to-end byte-identity tests
+// (tests/test_e2e_adapter.py); the product is libstrelka_amd.so.
+//
+// Batching.  The reference runs every call site once per position as its stage manager
+// advances (L/blt_util/stage_manager.cpp:206-243).  The adapter pushes the READ_BUFFER stage `read_buffer_defer()`
+// positions and the POST_ALIGN stage a further `post_align_defer()` positions behind their reference distances
+// (L/starling_common/starling_pos_processor_base.cpp:141-224), so that when a stage reaches position P every input of
+// positions [P, P+W) is already final: it then runs the kernel-backed work of the whole window in one C-ABI call and serves
+// the per-position calls of the reference's unchanged control flow from the cached results.  Everything the reference
+// derives from the stage geometry itself (realignment range, realignment-validity test, read-buffer occupancy) is
+// reproduced from a shadow of the ORIGINAL geometry (GeometryShadow, sk_adapter_common.cpp).
+#pragma once
+
+#include "sk_adapter_fwd.hh"
+
+#include "blt_util/blt_types.hh"
+
+#include <vector>
+
+struct starling_pos_processor_base;
+struct starling_pos_processor;
+struct strelka_pos_processor;
+struct diploid_genotype;
+struct starling_read;
+
+namespace sk_adapter
+{
+
+/// extra distance of the READ_BUFFER stage behind HEAD / of the POST_ALIGN stage behind READ_BUFFER
+/// ($STRELKA_AMD_READ_WINDOW / $STRELKA_AMD_SITE_WINDOW, default 256 / 512 positions)
+unsigned read_buffer_defer();
+unsigned post_align_defer();
+
+/// select the device ($STRELKA_AMD_DEVICE, default 0) and sk_init(); throws blt_exception on failure.  Idempotent.
+void init();
+
+// ---- geometry shadow (starling_pos_processor_base.cpp: set_head_pos, insert_read, resetRegionBase, reset) ----
+void on_reset_region(starling_pos_processor_base& pp);
+void on_set_head_pos(starling_pos_processor_base& pp, const pos_t pos, const unsigned readBufferShift, const unsigned indelSpan);
+unsigned buffered_read_count(const starling_pos_processor_base& pp, const unsigned sampleIndex, const unsigned actualCount);
+void on_read_inserted(starling_pos_processor_base& pp, const unsigned sampleIndex, const starling_read& sread);
+
+// ---- site 1: realignAndScoreRead at starling_pos_processor_base.cpp:752 (align_pos) ----
+/// replaces the body of align_pos(pos); always returns true
+bool align_pos(starling_pos_processor_base& pp, const pos_t pos);
+
+// ---- sites 2+3: adjust_joint_eprob (PileupCleaner.cpp:73) + position_snp_call_pprob_digt (starling_pos_processor.cpp:265) ----
+void before_process_pos_variants(starling_pos_processor_base& pp, const pos_t pos);
+void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const unsigned sampleIndex, const unsigned ploidy,
+                           diploid_genotype& dgt);
+/// the four zero-depth genotypes of the constructor (starling_pos_processor_base.cpp:259-274)
+void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseId, diploid_genotype& dgt);
+
+}

@@ -1,0 +1,92 @@
+// sk_adapter_access.hh -- the friend through which the adapter reaches the private state of the reference's position
+// processors, and the per-process adapter state.  Included by the adapter's own translation units only.
+#pragma once
+
+#include "sk_adapter.hh"
+#include "strelka_amd.h"
+
+#include "blt_util/blt_exception.hh"
+#include "starling_common/starling_pos_processor_base.hh"
+
+#include <deque>
+#include <map>
+#include <set>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace sk_adapter
+{
+
+struct Access
+{
+    typedef starling_pos_processor_base base_t;
+    static const starling_base_options& opt(const base_t& pp) { return pp._opt; }
+    static const starling_base_deriv_options& dopt(const base_t& pp) { return pp._dopt; }
+    static const reference_contig_segment& ref(const base_t& pp) { return pp._ref; }
+    static unsigned sampleCount(const base_t& pp) { return pp.getSampleCount(); }
+    static IndelBuffer& indelBuffer(base_t& pp) { return pp.getIndelBuffer(); }
+    static const PileupCleaner& pileupCleaner(const base_t& pp) { return pp._pileupCleaner; }
+    static unsigned largestReadSize(const base_t& pp) { return pp.get_largest_read_size(); }
+    static unsigned largestTotalIndelRefSpanPerRead(const base_t& pp) { return pp.get_largest_total_indel_ref_span_per_read(); }
+    static bool isPosReportable(const base_t& pp, const pos_t pos) { return pp.is_pos_reportable(pos); }
+    static unsigned ploidy(const base_t& pp, const pos_t pos, const unsigned sampleIndex) { return pp.get_ploidy(pos, sampleIndex); }
+};
+
+/// C-ABI status -> the reference's exception type (the context chain of starling_pos_processor_base.cpp:755-760 prints it)
+inline void check(const int rc, const char* what)
+{
+    if (rc == 0) return;
+    throw blt_exception((std::string("strelka_amd: ") + what + ": " + sk_last_error()).c_str());
+}
+
+/// Shadow of the stage geometry the UNHOOKED reference would have at each moment (see sk_adapter.hh).
+struct GeometryShadow
+{
+    struct Params
+    {
+        pos_t upto;           ///< last READ_BUFFER position these values apply to
+        pos_t rangeMinOffset; ///< get_realignment_range (starling_pos_processor_base.cpp:705-727)
+        pos_t rangeMaxOffset;
+        pos_t validThreshold; ///< a realignment is valid iff realignment.pos > validThreshold (:764, stage_manager.cpp:190-198)
+    };
+
+    void reset(const unsigned sampleCount);
+    void onSetHeadPos(const pos_t pos, const unsigned readBufferShift, const unsigned indelSpan);
+    /// values the reference's align_pos(pos) would have used
+    Params query(const pos_t pos) const;
+
+    bool isFirstPosSet = false;
+    pos_t maxPos = 0;          ///< stage_manager::_max_pos
+    pos_t lastReadBufferPos = 0;
+    bool isAnyReadBufferPos = false;
+    unsigned curReadBufferShift = 0, curIndelSpan = 0;
+    std::deque<Params> segments;
+    pos_t clearedToPos = 0;    ///< reads at buffer positions <= this have left the reference's read buffer (CLEAR_READ_BUFFER)
+    bool isAnyCleared = false;
+    std::vector<std::multiset<pos_t>> bufferedReadPos; ///< per sample: buffer positions of the reads the reference would still hold
+};
+
+/// germline SNV genotypes of one stage window, computed ahead of the per-position calls of process_pos_snp_digt
+struct SiteCache
+{
+    pos_t begin = 0, end = 0;      ///< positions [begin, end) are cached
+    std::vector<uint8_t> isValid;  ///< [(pos-begin)*sampleCount + sample]
+    std::vector<uint8_t> ploidy;   ///< the ploidy the entry was computed with
+    std::vector<uint32_t> callCount;
+    std::vector<sk_digt_call> calls;
+    void clear() { begin = end = 0; isValid.clear(); ploidy.clear(); callCount.clear(); calls.clear(); }
+};
+
+struct State
+{
+    GeometryShadow geometry;
+    bool isAnyRealigned = false;
+    pos_t realignedTo = 0;         ///< reads buffered at positions < realignedTo went through a realign job already
+    SiteCache sites;
+    // counters reported at exit with $STRELKA_AMD_VERBOSE=1
+    unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0;
+};
+State& state();
+
+}

@@ -1,0 +1,192 @@
+// sk_adapter_common.cpp -- process set-up and the shadow of the reference's original stage geometry.
+#include "sk_adapter_access.hh"
+
+#include "blt_util/log.hh"
+#include "starling_common/starling_read.hh"
+
+#include <cstdlib>
+#include <iostream>
+
+namespace sk_adapter
+{
+
+static unsigned env_unsigned(const char* name, const unsigned def)
+{
+    const char* v(std::getenv(name));
+    if (v == nullptr || *v == 0) return def;
+    return static_cast<unsigned>(std::strtoul(v, nullptr, 10));
+}
+
+unsigned read_buffer_defer()
+{
+    static const unsigned w(env_unsigned("STRELKA_AMD_READ_WINDOW", 256));
+    return w;
+}
+
+unsigned post_align_defer()
+{
+    static const unsigned w(env_unsigned("STRELKA_AMD_SITE_WINDOW", 512));
+    return w;
+}
+
+void init()
+{
+    static bool done(false);
+    if (done) return;
+    // segment process -> device: pyflow starts one process per genome segment; the launcher (or the workflow's task
+    // wrapper) exports STRELKA_AMD_DEVICE = segment index mod number of GPUs.  Many processes may share a device.
+    const int device(static_cast<int>(env_unsigned("STRELKA_AMD_DEVICE", 0)));
+    check(sk_init(device), "sk_init");
+    if (sk_libm_restated() != 1)
+    {
+        // byte-identical VCFs need the kernels' restated libm routines to be the host's
+        if (env_unsigned("STRELKA_AMD_ALLOW_INEXACT_LIBM", 0) == 0)
+        {
+            throw blt_exception("strelka_amd: the host C library is not the one the kernels restate (sk_libm_restated()==0); "
+                                "results would agree with the reference only to 1e-5. Set STRELKA_AMD_ALLOW_INEXACT_LIBM=1 to run anyway.");
+        }
+        log_os << "WARNING: strelka_amd runs with the device math library; outputs may differ from the reference in the last digit\n";
+    }
+    done = true;
+}
+
+State& state()
+{
+    // what went through the C-ABI, on stderr at exit with STRELKA_AMD_VERBOSE=1 (the end-to-end tests read it to make sure
+    // the identical VCF was produced by the routed path and not by an idle adapter)
+    struct Reporter
+    {
+        State s;
+        ~Reporter()
+        {
+            if (env_unsigned("STRELKA_AMD_VERBOSE", 0) == 0) return;
+            std::cerr << "strelka_amd adapter: realign_jobs=" << s.realignBatches << " realign_reads=" << s.realignReads
+                      << " site_batches=" << s.siteBatches << " site_loci=" << s.siteLoci << " site_recomputed=" << s.siteRecomputed
+                      << " indel_groups=" << s.indelGroups << " read_window=" << read_buffer_defer()
+                      << " site_window=" << post_align_defer() << "\n";
+        }
+    };
+    static Reporter r;
+    return r.s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+
+void GeometryShadow::reset(const unsigned sampleCount)
+{
+    isFirstPosSet = false;
+    maxPos = 0;
+    lastReadBufferPos = 0;
+    isAnyReadBufferPos = false;
+    segments.clear();
+    clearedToPos = 0;
+    isAnyCleared = false;
+    bufferedReadPos.assign(sampleCount, std::multiset<pos_t>());
+}
+
+void GeometryShadow::onSetHeadPos(const pos_t pos, const unsigned readBufferShift, const unsigned indelSpan)
+{
+    curReadBufferShift = readBufferShift;
+    curIndelSpan = indelSpan;
+
+    // stage_manager::handle_new_pos_value (L/blt_util/stage_manager.cpp:160-188): on the first call _max_pos is set
+    // before the stages run, afterwards the stages of a head advance run while _max_pos still holds the old value
+    pos_t maxPosDuring;
+    if (!isFirstPosSet)
+    {
+        maxPos = pos;
+        maxPosDuring = pos;
+        isFirstPosSet = true;
+    }
+    else
+    {
+        if (pos <= maxPos) return;
+        maxPosDuring = maxPos;
+        maxPos = pos;
+    }
+
+    const pos_t postAlignShift(static_cast<pos_t>(readBufferShift + indelSpan));
+    const pos_t rb(pos - static_cast<pos_t>(readBufferShift));
+    if ((!isAnyReadBufferPos) || rb > lastReadBufferPos)
+    {
+        Params p;
+        p.upto = rb;
+        p.rangeMinOffset = std::max(0, static_cast<pos_t>(indelSpan) - 1);
+        p.rangeMaxOffset = std::max(0, static_cast<pos_t>(readBufferShift) - 1);
+        p.validThreshold = maxPosDuring - postAlignShift;
+        if ((!segments.empty()) && segments.back().rangeMinOffset == p.rangeMinOffset &&
+            segments.back().rangeMaxOffset == p.rangeMaxOffset && segments.back().validThreshold == p.validThreshold)
+        {
+            segments.back().upto = rb;
+        }
+        else
+        {
+            segments.push_back(p);
+        }
+        lastReadBufferPos = rb;
+        isAnyReadBufferPos = true;
+    }
+
+    // CLEAR_READ_BUFFER sits at the POST_ALIGN distance (starling_pos_processor_base.cpp:198)
+    const pos_t cleared(pos - postAlignShift);
+    if ((!isAnyCleared) || cleared > clearedToPos)
+    {
+        clearedToPos = cleared;
+        isAnyCleared = true;
+        for (auto& held : bufferedReadPos)
+        {
+            held.erase(held.begin(), held.upper_bound(clearedToPos));
+        }
+    }
+}
+
+GeometryShadow::Params GeometryShadow::query(const pos_t pos) const
+{
+    for (const Params& p : segments)
+    {
+        if (pos <= p.upto) return p;
+    }
+    // not reached by a head advance: the position is handled by the final flush (stage_manager::reset), with the
+    // geometry and _max_pos in force at that time
+    Params p;
+    p.upto = pos;
+    p.rangeMinOffset = std::max(0, static_cast<pos_t>(curIndelSpan) - 1);
+    p.rangeMaxOffset = std::max(0, static_cast<pos_t>(curReadBufferShift) - 1);
+    p.validThreshold = maxPos - static_cast<pos_t>(curReadBufferShift + curIndelSpan);
+    return p;
+}
+
+void on_reset_region(starling_pos_processor_base& pp)
+{
+    init();
+    State& s(state());
+    s.geometry.reset(Access::sampleCount(pp));
+    s.isAnyRealigned = false;
+    s.realignedTo = 0;
+    s.sites.clear();
+}
+
+void on_set_head_pos(starling_pos_processor_base& /*pp*/, const pos_t pos, const unsigned readBufferShift, const unsigned indelSpan)
+{
+    GeometryShadow& g(state().geometry);
+    g.onSetHeadPos(pos, readBufferShift, indelSpan);
+    // segments behind the real (deferred) READ_BUFFER stage are no longer needed
+    const pos_t done(pos - static_cast<pos_t>(readBufferShift + read_buffer_defer()) - 1);
+    while (g.segments.size() > 1 && g.segments.front().upto < done) g.segments.pop_front();
+}
+
+unsigned buffered_read_count(const starling_pos_processor_base& /*pp*/, const unsigned sampleIndex, const unsigned /*actualCount*/)
+{
+    return static_cast<unsigned>(state().geometry.bufferedReadPos[sampleIndex].size());
+}
+
+void on_read_inserted(starling_pos_processor_base& /*pp*/, const unsigned sampleIndex, const starling_read& sread)
+{
+    if (sread.isSpliced())
+    {
+        throw blt_exception("strelka_amd adapter: spliced (RNA) reads are not supported on this path");
+    }
+    state().geometry.bufferedReadPos[sampleIndex].insert(sread.get_full_segment().buffer_pos);
+}
+
+}

@@ -1,0 +1,322 @@
+// sk_adapter_realign.cpp -- site 1: realignAndScoreRead (L/starling_common/starling_pos_processor_base.cpp:732-773,
+// align_pos) as one sk_realign_job per sample and stage window.
+//
+// The reference realigns the reads buffered at position P when its READ_BUFFER stage reaches P.  Here that stage runs
+// read_buffer_defer() positions later (sk_adapter.hh), so when it reaches P every read buffered at [P, P+W) is in the
+// read buffer and every indel such a read can reach is as final as it was for the reference: the window's reads go
+// through one job (gate, normalisation, enumeration and flattening on the host, scoring of all their candidate alignments
+// in one kernel launch, selection and score_indels on the host) and the results are written where the reference writes
+// them: rseg.realignment / is_realigned (starling_read_align.cpp:1738-1739), IndelSampleData::read_path_lnp
+// (starling_read_align_score_indels.cpp:1071) and the suboverlap read-id sets (:616-626).
+#include "sk_adapter_access.hh"
+
+#include "blt_util/log.hh"
+#include "starling_common/alignment_util.hh"
+#include "starling_common/starling_read_segment.hh"
+
+#include <algorithm>
+#include <unordered_map>
+
+namespace sk_adapter
+{
+
+namespace
+{
+
+struct WindowRead
+{
+    read_segment* rseg;
+    pos_t bufferPos;
+    GeometryShadow::Params geometry;
+    pos_t rangeBegin, rangeEnd;
+    size_t codeOffset, pathOffset, observedOffset;
+    unsigned observedCount;
+};
+
+void toIndelKey(const IndelKey& k, const bool isCandidate, sk_indel_key& out)
+{
+    out.pos = k.pos;
+    out.type = static_cast<int32_t>(k.type);
+    out.del_len = k.deletionLength;
+    out.ins_len = static_cast<uint32_t>(k.insertSequence.size());
+    out.ins_seq = k.insertSequence.c_str();
+    out.is_candidate = isCandidate ? 1 : 0;
+}
+
+void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampleIndex, const pos_t begin, const pos_t end)
+{
+    State& s(state());
+    const starling_base_options& opt(Access::opt(pp));
+    const unsigned sampleCount(Access::sampleCount(pp));
+    starling_pos_processor_base::sample_info& sif(pp.sample(sampleIndex));
+    IndelBuffer& indelBuffer(Access::indelBuffer(pp));
+    const reference_contig_segment& ref(Access::ref(pp));
+
+    if (sampleCount > SK_MAX_SAMPLES) throw blt_exception("strelka_amd adapter: more samples than SK_MAX_SAMPLES");
+
+    // ---- the window's reads, in read-buffer order ----
+    std::vector<WindowRead> reads;
+    std::vector<uint8_t> codes;
+    std::vector<sk_path_seg> paths;
+    pos_t tableBegin(0), tableEnd(0);
+    // how far past its alignment zone the candidate-alignment search of a read can reach: every toggled indel moves the
+    // far end by at most maxIndelSize (starling_read_align.cpp:859-1277, max_read_indel_toggle)
+    const pos_t reach(static_cast<pos_t>(opt.max_read_indel_toggle * opt.maxIndelSize + 5));
+    for (pos_t pos(begin); pos < end; ++pos)
+    {
+        read_segment_iter ri(sif.readBuffer.get_pos_read_segment_iter(pos));
+        for (read_segment_iter::ret_val r; true; ri.next())
+        {
+            r = ri.get_ptr();
+            if (nullptr == r.first) break;
+            if (r.second != 0) throw blt_exception("strelka_amd adapter: spliced (RNA) read segments are not supported on this path");
+            read_segment& rseg(r.first->get_segment(r.second));
+            if (not (opt.is_realign_submapped_reads || rseg.is_tier1or2_mapping())) continue;
+            if (! rseg.is_valid())
+            {
+                log_os << "ERROR: invalid alignment path associated with read segment:\n" << rseg;
+                exit(EXIT_FAILURE);
+            }
+            WindowRead wr;
+            wr.rseg = &rseg;
+            wr.bufferPos = pos;
+            wr.geometry = s.geometry.query(pos);
+            wr.rangeBegin = std::max(static_cast<pos_t>(0), pos - wr.geometry.rangeMinOffset);
+            wr.rangeEnd = pos + 1 + wr.geometry.rangeMaxOffset;
+            const alignment& al(rseg.getInputAlignment());
+            const known_pos_range zone(get_alignment_zone(al, rseg.read_size()));
+            const pos_t lo(std::max(wr.rangeBegin, std::min(zone.begin_pos, pos) - reach));
+            const pos_t hi(std::min(wr.rangeEnd, zone.end_pos + reach));
+            if (reads.empty())
+            {
+                tableBegin = lo;
+                tableEnd = hi;
+            }
+            else
+            {
+                tableBegin = std::min(tableBegin, lo);
+                tableEnd = std::max(tableEnd, hi);
+            }
+            wr.codeOffset = codes.size();
+            const bam_seq bseq(rseg.get_bam_read());
+            const unsigned readSize(rseg.read_size());
+            for (unsigned i(0); i < readSize; ++i) codes.push_back(bseq.get_code(static_cast<pos_t>(i)));
+            wr.pathOffset = paths.size();
+            for (const auto& ps : al.path)
+            {
+                sk_path_seg seg;
+                seg.type = static_cast<uint32_t>(ps.type);
+                seg.length = ps.length;
+                paths.push_back(seg);
+            }
+            wr.observedOffset = 0;
+            wr.observedCount = 0;
+            reads.push_back(wr);
+        }
+    }
+    if (reads.empty()) return;
+
+    // ---- the IndelBuffer entries those reads can see ----
+    std::vector<sk_indel_info> table;
+    std::vector<const IndelKey*> keys;
+    std::vector<IndelData*> data;
+    std::unordered_map<align_id_t, std::vector<int32_t>> observedBy;
+    {
+        const auto range(indelBuffer.rangeIterator(tableBegin, tableEnd));
+        for (auto it(range.first); it != range.second; ++it)
+        {
+            const IndelKey& k(it->first);
+            IndelData& d(getIndelData(it));
+            if (k.is_breakpoint()) throw blt_exception("strelka_amd adapter: open-ended breakpoint alleles are not supported on this path");
+            sk_indel_info e;
+            std::memset(&e, 0, sizeof(e));
+            toIndelKey(k, indelBuffer.isCandidateIndel(k, d), e.key);
+            const IndelSampleData& isd(d.getSampleData(sampleIndex));
+            e.ref_to_indel_log_prob = isd.getErrorRates().refToIndelErrorProb.getLogValue();
+            e.indel_to_ref_log_prob = isd.getErrorRates().indelToRefErrorProb.getLogValue();
+            e.active_region_id = static_cast<int32_t>(d.activeRegionId);
+            for (unsigned si(0); si < sampleCount; ++si)
+            {
+                e.haplotype_id[si] = static_cast<int8_t>(d.getSampleData(si).haplotypeId);
+                e.is_haplotyping_bypassed[si] = d.getSampleData(si).isHaplotypingBypassed ? 1 : 0;
+            }
+            e.is_forced_output = d.isForcedOutput ? 1 : 0;
+            e.not_discovered_from_reads = d.status.notDiscoveredFromReads ? 1 : 0;
+            const int32_t index(static_cast<int32_t>(table.size()));
+            // is_usable_indel (starling_read_align.cpp:289-305): the reads observed to carry this indel in this sample
+            for (const auto id : isd.tier1_map_read_ids) observedBy[id].push_back(index);
+            for (const auto id : isd.tier2_map_read_ids) observedBy[id].push_back(index);
+            for (const auto id : isd.submap_read_ids) observedBy[id].push_back(index);
+            for (const auto id : isd.noise_read_ids) observedBy[id].push_back(index);
+            table.push_back(e);
+            keys.push_back(&k);
+            data.push_back(&d);
+        }
+    }
+
+    std::vector<int32_t> observed;
+    for (WindowRead& wr : reads)
+    {
+        const auto it(observedBy.find(wr.rseg->getReadIndex()));
+        if (it == observedBy.end()) continue;
+        wr.observedOffset = observed.size();
+        std::vector<int32_t> ids(it->second);
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        wr.observedCount = static_cast<unsigned>(ids.size());
+        observed.insert(observed.end(), ids.begin(), ids.end());
+    }
+
+    // ---- the job ----
+    sk_realign_options ro;
+    sk_realign_options_default(&ro);
+    ro.max_read_indel_toggle = opt.max_read_indel_toggle;
+    ro.max_candidate_indel_density = opt.max_candidate_indel_density;
+    ro.max_realignment_candidates = opt.max_realignment_candidates;
+    ro.max_indel_size = opt.maxIndelSize;
+    ro.is_smoothed_alignments = opt.is_smoothed_alignments ? 1 : 0;
+    ro.smoothed_lnp_range = opt.smoothed_lnp_range;
+    ro.upstream_oligo_size = opt.upstream_oligo_size;
+    ro.is_haplotyping_enabled = opt.isHaplotypingEnabled ? 1 : 0;
+    ro.min_read_bp_flank = sif.sampleOptions.min_read_bp_flank;
+    ro.sample_count = static_cast<int32_t>(sampleCount);
+    if (opt.isRetainOptimalSoftClipping) throw blt_exception("strelka_amd adapter: --retain-optimal-soft-clipping (RNA) is not supported on this path");
+
+    struct JobHolder
+    {
+        sk_realign_job* job;
+        ~JobHolder() { if (job) sk_realign_job_destroy(job); }
+    } holder{sk_realign_job_create(&ro)};
+    sk_realign_job* job(holder.job);
+    if (job == nullptr) throw blt_exception("strelka_amd adapter: sk_realign_job_create failed");
+
+    auto jobCheck = [&](const int rc, const char* what)
+    {
+        if (rc == 0) return;
+        throw blt_exception((std::string("strelka_amd: ") + what + ": " + sk_realign_job_error(job)).c_str());
+    };
+    jobCheck(sk_realign_job_set_reference(job, ref.seq().data(), static_cast<int32_t>(ref.get_offset()),
+                                          static_cast<int32_t>(ref.seq().size())), "sk_realign_job_set_reference");
+    jobCheck(sk_realign_job_set_indels(job, table.data(), static_cast<int32_t>(table.size())), "sk_realign_job_set_indels");
+
+    std::vector<sk_read_input> inputs(reads.size());
+    for (size_t i(0); i < reads.size(); ++i)
+    {
+        const WindowRead& wr(reads[i]);
+        const read_segment& rseg(*wr.rseg);
+        const alignment& al(rseg.getInputAlignment());
+        sk_read_input& in(inputs[i]);
+        std::memset(&in, 0, sizeof(in));
+        in.read_code = codes.data() + wr.codeOffset;
+        in.read_qual = rseg.qual();
+        in.read_len = static_cast<int32_t>(rseg.read_size());
+        in.pos = al.pos;
+        in.n_seg = static_cast<int32_t>(al.path.size());
+        in.path = paths.data() + wr.pathOffset;
+        in.is_fwd_strand = al.is_fwd_strand ? 1 : 0;
+        in.map_level = static_cast<int32_t>(rseg.getInputAlignmentMapLevel());
+        in.sample_index = static_cast<int32_t>(sampleIndex);
+        in.realign_begin = wr.rangeBegin;
+        in.realign_end = wr.rangeEnd;
+        in.n_observed = static_cast<int32_t>(wr.observedCount);
+        in.observed = wr.observedCount ? observed.data() + wr.observedOffset : nullptr;
+    }
+    if (sk_realign_job_add_reads(job, inputs.data(), static_cast<int32_t>(inputs.size())) < 0)
+    {
+        jobCheck(1, "sk_realign_job_add_reads");
+    }
+    jobCheck(sk_realign_job_run(job), "sk_realign_job_run");
+    s.realignBatches++;
+    s.realignReads += reads.size();
+
+    // ---- results, written where the reference writes them ----
+    const bool isMaxToggleWarnEnabled(opt.verbosity >= LOG_LEVEL::ALLWARN);
+    for (size_t i(0); i < reads.size(); ++i)
+    {
+        const WindowRead& wr(reads[i]);
+        read_segment& rseg(*wr.rseg);
+        sk_read_result res;
+        jobCheck(sk_realign_job_read_result(job, static_cast<int32_t>(i), &res), "sk_realign_job_read_result");
+        if (res.n_candidate_alignments == 0) continue;
+
+        if (res.warn_origin_skip || (res.warn_max_toggle_depth && isMaxToggleWarnEnabled))
+        {
+            auto writeSkipWarning = [&rseg](const char* reason)
+            {
+                log_os << "WARNING: re-alignment skipped some alternate alignments for read: " << rseg.key() << "\n"
+                       << "\treason: " << reason << "\n";
+            };
+            if (res.warn_origin_skip) writeSkipWarning("alignments crossed chromosome origin");
+            if (res.warn_max_toggle_depth && isMaxToggleWarnEnabled) writeSkipWarning("exceeded max number of indel switches");
+        }
+
+        if (res.is_realigned)
+        {
+            rseg.is_realigned = true;
+            rseg.realignment.pos = res.realign_pos;
+            rseg.realignment.is_fwd_strand = rseg.getInputAlignment().is_fwd_strand;
+            rseg.realignment.path.clear();
+            for (int32_t k(0); k < res.realign_n_seg; ++k)
+            {
+                rseg.realignment.path.push_back(ALIGNPATH::path_segment(static_cast<ALIGNPATH::align_t>(res.realign_path[k].type),
+                                                                         res.realign_path[k].length));
+            }
+            // align_pos's check that the read was not moved behind the POST_ALIGN stage (:761-770), against the
+            // reference's own geometry
+            if (! (rseg.realignment.pos > wr.geometry.validThreshold))
+            {
+                log_os << "WARNING: read realigned outside bounds of realignment stage buffer. Skipping...\n"
+                       << "\tread: " << rseg.key() << "\n";
+                rseg.is_invalid_realignment = true;
+            }
+        }
+
+        const align_id_t readId(rseg.getReadIndex());
+        for (int32_t k(0); k < res.n_scores; ++k)
+        {
+            const sk_read_path_scores& sc(res.scores[k]);
+            ReadPathScores rps(sc.ref_lnp, sc.indel_lnp, sc.non_ambig, sc.read_length, sc.is_tier1_read != 0,
+                               sc.is_fwd_strand != 0, sc.read_pos, sc.distance_from_closest_read_edge);
+            for (int32_t a(0); a < sc.n_alt; ++a)
+            {
+                rps.alt_indel.push_back(std::make_pair(*keys[sc.alt_indel[a]], sc.alt_lnp[a]));
+            }
+            data[sc.indel]->getSampleData(sampleIndex).read_path_lnp[readId] = rps;
+        }
+        const bool isTier1(rseg.is_tier1_mapping());
+        for (int32_t k(0); k < res.n_suboverlap; ++k)
+        {
+            IndelSampleData& isd(data[res.suboverlap[k]]->getSampleData(sampleIndex));
+            if (isTier1) isd.suboverlap_tier1_read_ids.insert(readId);
+            else isd.suboverlap_tier2_read_ids.insert(readId);
+        }
+    }
+}
+
+}
+
+bool align_pos(starling_pos_processor_base& pp, const pos_t pos)
+{
+    State& s(state());
+    if (s.isAnyRealigned && pos < s.realignedTo) return true;
+    const pos_t end(pos + static_cast<pos_t>(std::max(1u, read_buffer_defer() + 1)));
+    const unsigned sampleCount(Access::sampleCount(pp));
+    for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
+    {
+        try
+        {
+            realign_sample_window(pp, sampleIndex, pos, end);
+        }
+        catch (...)
+        {
+            log_os << "Exception caught in align_pos() while realigning the reads buffered at positions [" << (pos + 1) << ","
+                   << end << "] of sample " << sampleIndex << "\n";
+            throw;
+        }
+    }
+    s.isAnyRealigned = true;
+    s.realignedTo = end;
+    return true;
+}
+
+}

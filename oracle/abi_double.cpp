@@ -1,0 +1,206 @@
+// abi_double.cpp -- a CPU TEST DOUBLE of the C-ABI of include/strelka_amd.h.
+//
+// TEST INFRASTRUCTURE ONLY (built by `make -C oracle double` into oracle/libstrelka_amd_double.so).  It exports the same
+// `sk_*` symbols as the product library, with every kernel-backed entry point answered by the CPU oracle
+// (oracle/strelka_oracle.c) and the product's own host stages (strelka_amd/host/*.cpp) compiled in unchanged.  Its one
+// purpose: let the `-m "not gpu"` suite run the ADAPTER's host logic (adapter/*.cpp: marshalling, stage-window batching,
+// geometry shadow, cache validation) end to end on the demo BAMs without a GPU -- binaries `*_dbl` in oracle/_ref/bin.
+// Nothing in strelka_amd/ loads it, links it or falls back to it; the product library fails in sk_init without a gfx950
+// device.  The `-m gpu` tests run the same adapter against the real library (`*_amd` binaries).
+#include "strelka_amd.h"
+
+extern "C" {
+#include "strelka_oracle.h"
+}
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static std::string g_err;
+static bool g_ready = false;
+
+static int fail(const char* m)
+{
+    g_err = m;
+    return 1;
+}
+
+// the product's host stages report errors through this (strelka_amd/csrc/sk_common.h)
+int sk_fail(const std::string& msg)
+{
+    g_err = msg;
+    return 1;
+}
+
+static void to_sko(const sk_germline_options* o, sko_germline_options* g)
+{
+    g->bsnp_diploid_theta = o->bsnp_diploid_theta;
+    g->bsnp_ssd_no_mismatch = o->bsnp_ssd_no_mismatch;
+    g->bsnp_ssd_one_mismatch = o->bsnp_ssd_one_mismatch;
+    g->is_min_vexp = o->is_min_vexp;
+    g->min_vexp = o->min_vexp;
+}
+
+extern "C" {
+
+int sk_init(int) { g_ready = true; return 0; }
+void sk_shutdown(void) { g_ready = false; }
+const char* sk_last_error(void) { return g_err.c_str(); }
+int sk_version(void) { return SK_VERSION; }
+int sk_is_initialized(void) { return g_ready ? 1 : 0; }
+int sk_libm_restated(void) { return 1; } // the oracle calls the host libm directly
+int sk_abi_double(void) { return 1; }    // marker: lets a test assert which library a binary loaded
+
+int sk_get_qscore_tables(double* q2p, double* q2lncompe, double* q2lne)
+{
+    sko_get_qscore_tables(q2p, q2lncompe, q2lne);
+    return 0;
+}
+
+void sk_germline_options_default(sk_germline_options* opt)
+{
+    opt->bsnp_diploid_theta = 0.001;
+    opt->bsnp_ssd_no_mismatch = 0.35;
+    opt->bsnp_ssd_one_mismatch = 0.6;
+    opt->is_min_vexp = 1;
+    opt->min_vexp = 0.25;
+}
+
+void sk_somatic_snv_options_default(sk_somatic_snv_options* opt)
+{
+    opt->bsnp_diploid_theta = 0.001;
+    opt->somatic_snv_rate = 1e-4;
+    opt->shared_site_error_rate = 5e-10;
+    opt->shared_site_error_strand_bias_fraction = 0.0;
+    opt->ssnv_contam_tolerance = 0.15;
+}
+
+void sk_indel_options_default(sk_indel_options* opt, int is_somatic)
+{
+    opt->min_read_bp_flank = 5;
+    opt->random_base_match_prob = is_somatic ? 0.5 : 0.25;
+    opt->tier2_random_base_match_prob = 0.25;
+    opt->read_confident_support_threshold = 0.51;
+    opt->is_use_alt_indel = 1;
+}
+
+void sk_somatic_indel_options_default(sk_somatic_indel_options* opt)
+{
+    opt->bindel_diploid_theta = 1e-4;
+    opt->somatic_indel_rate = 1e-6;
+    opt->shared_indel_error_factor = 2.2;
+    opt->indel_contam_tolerance = 0.15;
+}
+
+/* the op-level meaning of a flattened batch (include/strelka_amd.h: sk_score_op), sequential double adds */
+int sk_score_alignments(const sk_align_batch* b, double* out_lnp)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    double q2p[71], q2lncompe[71], q2lne[71];
+    sko_get_qscore_tables(q2p, q2lncompe, q2lne);
+    const double lnthird(-std::log(3.0));
+    const double ln_quarter(std::log(0.25));
+    const double ln_noncand(std::log(1e-5));
+    for (int32_t r = 0; r < b->n_reads; ++r) {
+        const uint8_t* code = b->read_code + b->read_off[r];
+        const uint8_t* qual = b->read_qual + b->read_off[r];
+        const uint8_t* hap = b->hap_code + b->hap_off[r];
+        for (int32_t c = b->cal_off[r]; c < b->cal_off[r + 1]; ++c) {
+            double lnp = 0.0;
+            int64_t rp = 0;
+            for (int64_t k = b->op_off[c]; k < b->op_off[c + 1]; ++k) {
+                const sk_score_op& op = b->ops[k];
+                if (op.kind == SK_OP_BASES) {
+                    for (int j = 0; j < op.length; ++j) {
+                        const uint8_t rc = code[rp + j];
+                        if (rc == SK_BAM_ANY) continue;
+                        const uint8_t q = qual[rp + j];
+                        if (q > 70) return fail("basecall quality above 70");
+                        const bool is_ref = (rc == SK_BAM_REF) || (rc == hap[op.src + j]);
+                        lnp += is_ref ? q2lncompe[q] : (q2lne[q] + lnthird);
+                    }
+                    rp += op.length;
+                } else if (op.kind == SK_OP_SOFT_CLIP) {
+                    lnp += op.length * ln_quarter;
+                    rp += op.length;
+                }
+                if (op.flags & SK_OPFLAG_NONCANDIDATE_PENALTY) lnp += ln_noncand;
+            }
+            out_lnp[c] = lnp;
+        }
+    }
+    return 0;
+}
+
+int sk_dependent_eprob(const sk_pileup_batch* b, const sk_germline_options* opt, float* out_de)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    sko_germline_options g;
+    to_sko(opt, &g);
+    sko_adjust_joint_eprob_batch(b->call_off, b->calls, b->n_loci, &g, out_de);
+    return 0;
+}
+
+int sk_site_digt_call(const sk_pileup_batch* b, const sk_germline_options* opt, sk_digt_call* out)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    static_assert(sizeof(sk_digt_call) == sizeof(sko_digt_call), "record layouts must agree");
+    sko_germline_options g;
+    to_sko(opt, &g);
+    sko_site_digt_call_batch(b->call_off, b->calls, b->de, b->ref_base, b->ploidy, b->n_loci, &g,
+                             reinterpret_cast<sko_digt_call*>(out));
+    return 0;
+}
+
+int sk_site_digt_call_fused(const sk_pileup_batch* b, const sk_germline_options* opt, sk_digt_call* out, float* out_de)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    std::vector<float> de(static_cast<size_t>(b->call_off[b->n_loci]) + 1);
+    sko_germline_options g;
+    to_sko(opt, &g);
+    sko_adjust_joint_eprob_batch(b->call_off, b->calls, b->n_loci, &g, de.data());
+    sko_site_digt_call_batch(b->call_off, b->calls, de.data(), b->ref_base, b->ploidy, b->n_loci, &g,
+                             reinterpret_cast<sko_digt_call*>(out));
+    if (out_de) std::memcpy(out_de, de.data(), sizeof(float) * static_cast<size_t>(b->call_off[b->n_loci]));
+    return 0;
+}
+
+int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* b, const sk_indel_options* opt, sk_allele_group_call* out)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    for (int32_t g = 0; g < b->n_groups; ++g) {
+        const int64_t r0 = b->read_off[g];
+        const int32_t n = static_cast<int32_t>(b->read_off[g + 1] - r0);
+        const int32_t n_alt = b->n_alt[g];
+        const int ploidy = b->ploidy[g];
+        if (n_alt < 1 || n_alt > SK_MAX_ALT) return fail("allele group with an unsupported number of alternate alleles");
+        std::vector<float> ref(static_cast<size_t>(n) * n_alt), al(static_cast<size_t>(n) * n_alt);
+        std::vector<uint8_t> t1(n), fwd(n);
+        for (int32_t r = 0; r < n; ++r) {
+            for (int32_t a = 0; a < n_alt; ++a) {
+                ref[static_cast<size_t>(r) * n_alt + a] = b->ref_lnp[(r0 + r) * SK_MAX_ALT + a];
+                al[static_cast<size_t>(r) * n_alt + a] = b->allele_lnp[(r0 + r) * SK_MAX_ALT + a];
+            }
+            t1[r] = (b->read_flags[r0 + r] & SK_READ_TIER1) ? 1 : 0;
+            fwd[r] = (b->read_flags[r0 + r] & SK_READ_FWD) ? 1 : 0;
+        }
+        sk_allele_group_call& o = out[g];
+        std::memset(&o, 0, sizeof(o));
+        uint32_t counts[2 * (SK_MAX_ALT + 2)] = {0};
+        sko_allele_group_genotype_lhoods(n, n_alt, ref.data(), al.data(), b->non_ambig + r0, b->read_length + r0, t1.data(),
+                                         fwd.data(), b->del_len + static_cast<size_t>(g) * SK_MAX_ALT,
+                                         b->ins_len + static_cast<size_t>(g) * SK_MAX_ALT, ploidy, opt->min_read_bp_flank,
+                                         opt->random_base_match_prob, opt->read_confident_support_threshold, o.lhood, counts);
+        for (int s = 0; s < 2; ++s)
+            for (int a = 0; a < n_alt + 2; ++a) o.counts[s][a] = counts[s * (n_alt + 2) + a];
+        o.n_genotypes = ploidy == 1 ? uint32_t(n_alt + 1) : uint32_t((n_alt + 1) * (n_alt + 2) / 2);
+        uint32_t used = 0;
+        for (int32_t r = 0; r < n; ++r) used += t1[r];
+        o.n_reads_used = used;
+    }
+    return 0;
+}
+
+} // extern "C"
