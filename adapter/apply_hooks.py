@@ -70,6 +70,20 @@ HOOKS = [
          r'computeSampleDiploidSiteGenotype\(\n\s*_opt, _dopt, sample\(sampleIndex\), callerPloidy\[sampleIndex\], allDgt\[sampleIndex\]\);',
          'sk_adapter::site_diploid_genotype(*this, pos, sampleIndex, callerPloidy[sampleIndex], allDgt[sampleIndex]);'),
     ]),
+    (L + "starling_common/AlleleGroupGenotype.cpp", [
+        # site 4: the reference's definition steps aside; adapter/sk_adapter_germline_indel.cpp defines the function
+        ("getVariantAlleleGroupGenotypeLhoodsForSample",
+         r'\nvoid\ngetVariantAlleleGroupGenotypeLhoodsForSample\(',
+         '\nvoid\ngetVariantAlleleGroupGenotypeLhoodsForSample_reference('),
+    ]),
+    (L + "starling_common/ActiveRegionProcessor.cpp", [
+        ("include", r'#include "ActiveRegionProcessor.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # site 7: haplotype alignment + allele discovery
+        ("discoverIndelsAndMismatches",
+         r'(    const std::string& haplotypeSeq\(_selectedHaplotypes\[selectedHaplotypeIndex\]\);\n    assert \(haplotypeSeq != _refSegment\);\n)',
+         '\\1    if (sk_adapter::discover_indels_and_mismatches(haplotypeSeq, _refSegment, _ref, _posRange.begin_pos(), '
+         '_posRange.end_pos(), _prevActiveRegionEnd, _maxIndelSize, discoveredIndelsAndMismatches, numIndels)) return;\n'),
+    ]),
 ]
 
 

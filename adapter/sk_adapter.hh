@@ -21,6 +21,7 @@
 
 #include "blt_util/blt_types.hh"
 
+#include <string>
 #include <vector>
 
 struct starling_pos_processor_base;
@@ -28,6 +29,8 @@ struct starling_pos_processor;
 struct strelka_pos_processor;
 struct diploid_genotype;
 struct starling_read;
+struct reference_contig_segment;
+struct IndelKey;
 
 namespace sk_adapter
 {
@@ -56,5 +59,11 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
                            diploid_genotype& dgt);
 /// the four zero-depth genotypes of the constructor (starling_pos_processor_base.cpp:259-274)
 void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseId, diploid_genotype& dgt);
+
+// ---- site 7: ActiveRegionProcessor::discoverIndelsAndMismatches (ActiveRegionProcessor.cpp:572-705) ----
+bool discover_indels_and_mismatches(const std::string& haplotypeSeq, const std::string& refSegment,
+                                    const reference_contig_segment& ref, const pos_t regionBegin, const pos_t regionEnd,
+                                    const pos_t prevActiveRegionEnd, const unsigned maxIndelSize,
+                                    std::vector<IndelKey>& discovered, int& numIndels);
 
 }

@@ -85,7 +85,7 @@ struct State
     pos_t realignedTo = 0;         ///< reads buffered at positions < realignedTo went through a realign job already
     SiteCache sites;
     // counters reported at exit with $STRELKA_AMD_VERBOSE=1
-    unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0;
+    unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0;
 };
 State& state();
 

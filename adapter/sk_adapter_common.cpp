@@ -62,7 +62,7 @@ State& state()
             if (env_unsigned("STRELKA_AMD_VERBOSE", 0) == 0) return;
             std::cerr << "strelka_amd adapter: realign_jobs=" << s.realignBatches << " realign_reads=" << s.realignReads
                       << " site_batches=" << s.siteBatches << " site_loci=" << s.siteLoci << " site_recomputed=" << s.siteRecomputed
-                      << " indel_groups=" << s.indelGroups << " read_window=" << read_buffer_defer()
+                      << " indel_groups=" << s.indelGroups << " haplotypes=" << s.haplotypes << " read_window=" << read_buffer_defer()
                       << " site_window=" << post_align_defer() << "\n";
         }
     };

@@ -1,0 +1,140 @@
+// sk_adapter_germline_indel.cpp -- site 4: getVariantAlleleGroupGenotypeLhoodsForSample
+// (L/starling_common/AlleleGroupGenotype.cpp:185-258, called at L/applications/starling/starling_pos_processor.cpp:1384-1386)
+// through sk_allele_group_genotype_lhoods.
+//
+// apply_hooks.py renames the reference's definition to ..._reference (it stays in the hooked translation unit, uncalled);
+// this file provides the function under the original name, so every caller in the reference reaches the C-ABI.  The
+// allele group's reads are resolved exactly as the reference does (getAlleleGroupSupportingReadIds: tier1 reads scored for
+// every allele of the group, ascending read id; per allele the read's ReadPathScores ref / indel floats) and handed over
+// as one CSR row; genotype likelihoods and the supporting-read counts come back.
+//
+// One group per call: indel loci are ~1e-3 of all loci and each call site sits inside position-ordered host logic whose
+// inputs (which alleles form the group) depend on the calls made at earlier positions (_variantLocusAlreadyOutputToPos,
+// starling_pos_processor.cpp:1618,1797), so the groups of a window are not known ahead of time.
+#include "sk_adapter_access.hh"
+
+#include "starling_common/AlleleGroupGenotype.hh"
+#include "starling_common/OrthogonalVariantAlleleCandidateGroupUtil.hh"
+#include "htsapi/vcf_util.hh"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+void
+getVariantAlleleGroupGenotypeLhoodsForSample(
+    const starling_base_options& opt,
+    const starling_base_deriv_options& /*dopt*/,
+    const starling_sample_options& sampleOptions,
+    const unsigned callerPloidy,
+    const unsigned sampleIndex,
+    const OrthogonalVariantAlleleCandidateGroup& alleleGroup,
+    const OrthogonalVariantAlleleCandidateGroup& contrastGroup,
+    std::vector<double>& genotypeLogLhood,
+    LocusSupportingReadStats& locusReadStats)
+{
+    using namespace sk_adapter;
+    assert(callerPloidy > 0u);
+    assert(callerPloidy < 3u);
+
+    const uint8_t nonRefAlleleCount(alleleGroup.size());
+    const uint8_t fullAlleleCount(nonRefAlleleCount + 1);
+    const unsigned genotypeCount(VcfGenotypeUtil::getGenotypeCount(callerPloidy, fullAlleleCount));
+    genotypeLogLhood.resize(genotypeCount);
+    std::fill(genotypeLogLhood.begin(), genotypeLogLhood.end(), 0.);
+    if (nonRefAlleleCount == 0) return;
+
+    if (contrastGroup.size() != 0)
+    {
+        throw blt_exception("strelka_amd adapter: contrast allele groups are not supported on this path");
+    }
+    if (nonRefAlleleCount > SK_MAX_ALT)
+    {
+        throw blt_exception("strelka_amd adapter: more alternate alleles in one group than SK_MAX_ALT");
+    }
+    init();
+
+    locusReadStats.setAltCount(nonRefAlleleCount);
+
+    static const bool isTier1Only(true);
+    std::set<unsigned> readIds;
+    getAlleleGroupSupportingReadIds(sampleIndex, alleleGroup, readIds, isTier1Only);
+
+    const size_t readCount(readIds.size());
+    const float notScored(std::numeric_limits<float>::quiet_NaN());
+    std::vector<float> refLnp(readCount * SK_MAX_ALT, 0.f), alleleLnp(readCount * SK_MAX_ALT, notScored);
+    std::vector<uint16_t> nonAmbig(readCount), readLength(readCount);
+    std::vector<uint8_t> flags(readCount);
+    size_t r(0);
+    for (const unsigned readId : readIds)
+    {
+        bool isExemplarSet(false);
+        for (unsigned a(0); a < nonRefAlleleCount; ++a)
+        {
+            const IndelSampleData& isd(alleleGroup.data(a).getSampleData(sampleIndex));
+            const auto it(isd.read_path_lnp.find(readId));
+            if (it == isd.read_path_lnp.end()) continue;
+            const ReadPathScores& rps(it->second);
+            refLnp[r * SK_MAX_ALT + a] = rps.ref;
+            alleleLnp[r * SK_MAX_ALT + a] = rps.indel;
+            if (! isExemplarSet)
+            {
+                // getExemplarReadScore (AlleleGroupGenotype.cpp:157-181): the first allele that scored the read
+                nonAmbig[r] = rps.nonAmbiguousBasesInRead;
+                readLength[r] = rps.read_length;
+                flags[r] = static_cast<uint8_t>((rps.is_tier1_read ? SK_READ_TIER1 : 0) | (rps.is_fwd_strand ? SK_READ_FWD : 0));
+                isExemplarSet = true;
+            }
+        }
+        assert(isExemplarSet);
+        ++r;
+    }
+
+    const int64_t readOff[2] = {0, static_cast<int64_t>(readCount)};
+    const uint8_t nAlt(nonRefAlleleCount), ploidy(static_cast<uint8_t>(callerPloidy));
+    uint32_t delLen[SK_MAX_ALT] = {0}, insLen[SK_MAX_ALT] = {0};
+    for (unsigned a(0); a < nonRefAlleleCount; ++a)
+    {
+        const IndelKey& k(alleleGroup.key(a));
+        delLen[a] = k.delete_length();
+        insLen[a] = k.insert_length();
+    }
+    static const float noFloat(0.f);
+    static const uint16_t noU16(0);
+    static const uint8_t noU8(0);
+    sk_allele_group_batch b;
+    std::memset(&b, 0, sizeof(b));
+    b.n_groups = 1;
+    b.read_off = readOff;
+    b.n_alt = &nAlt;
+    b.ploidy = &ploidy;
+    b.del_len = delLen;
+    b.ins_len = insLen;
+    b.ref_lnp = readCount ? refLnp.data() : &noFloat;
+    b.allele_lnp = readCount ? alleleLnp.data() : &noFloat;
+    b.non_ambig = readCount ? nonAmbig.data() : &noU16;
+    b.read_length = readCount ? readLength.data() : &noU16;
+    b.read_flags = readCount ? flags.data() : &noU8;
+
+    sk_indel_options io;
+    sk_indel_options_default(&io, opt.isSomaticCallingMode ? 1 : 0);
+    io.min_read_bp_flank = sampleOptions.min_read_bp_flank;
+    io.random_base_match_prob = opt.randomBaseMatchProb;
+    io.tier2_random_base_match_prob = opt.tier2.randomBaseMatchProb;
+    io.read_confident_support_threshold = opt.readConfidentSupportThreshold.numval();
+
+    sk_allele_group_call out;
+    check(sk_allele_group_genotype_lhoods(&b, &io, &out), "sk_allele_group_genotype_lhoods");
+    if (out.n_genotypes != genotypeCount)
+    {
+        throw blt_exception("strelka_amd adapter: genotype count mismatch in sk_allele_group_genotype_lhoods");
+    }
+    for (unsigned g(0); g < genotypeCount; ++g) genotypeLogLhood[g] = out.lhood[g];
+    for (unsigned s(0); s < 2; ++s)
+    {
+        auto& counts(locusReadStats.getCounts(s == 0));
+        for (unsigned a(0); a < fullAlleleCount; ++a) counts.incrementAlleleCount(a, out.counts[s][a]);
+        counts.nonConfidentCount += out.counts[s][fullAlleleCount];
+    }
+    state().indelGroups++;
+}

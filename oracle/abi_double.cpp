@@ -203,4 +203,30 @@ int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* b, const sk_ind
     return 0;
 }
 
+void sk_align_scores_default(sk_align_scores* s)
+{
+    s->match = 1; s->mismatch = -4; s->open = -5; s->extend = -1; s->off_edge = -100; s->insert_delete = -5;
+    s->is_allow_edge_insertion = 1; s->is_require_edge_deletion = 1;
+}
+
+int sk_global_align(const sk_global_align_batch* b, const sk_align_scores* scores, int32_t* out_score, int32_t* out_begin_pos,
+                    sk_path_seg* out_path, int32_t* out_n_seg)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    sko_align_scores sc;
+    sc.match = scores->match; sc.mismatch = scores->mismatch; sc.open = scores->open; sc.extend = scores->extend;
+    sc.offEdge = scores->off_edge; sc.insertDelete = scores->insert_delete;
+    sc.isAllowEdgeInsertion = scores->is_allow_edge_insertion; sc.isRequireEdgeDeletion = scores->is_require_edge_deletion;
+    static_assert(sizeof(sk_path_seg) == sizeof(sko_path_seg), "path segment layouts must agree");
+    for (int32_t p = 0; p < b->n; ++p) {
+        const int ql = int(b->query_off[p + 1] - b->query_off[p]), rl = int(b->ref_off[p + 1] - b->ref_off[p]);
+        const int64_t off = b->query_off[p] + b->ref_off[p] + 4 * int64_t(p);
+        const int n = sko_global_align(b->query + b->query_off[p], ql, b->ref + b->ref_off[p], rl, &sc, out_score + p,
+                                       out_begin_pos + p, reinterpret_cast<sko_path_seg*>(out_path + off), ql + rl + 4);
+        if (n < 0) return fail("sko_global_align failed");
+        out_n_seg[p] = n;
+    }
+    return 0;
+}
+
 } // extern "C"

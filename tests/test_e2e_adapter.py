@@ -1,0 +1,61 @@
+"""End to end through the drop-in boundary: the reference's own caller programs with the hot-path call sites re-routed
+through the C-ABI (adapter/, built by adapter/Makefile) against the unmodified reference programs (oracle/Makefile),
+same command line, same inputs -- every output file must be byte-identical (only the two header lines that echo the
+command line and the start time are ignored).
+
+  *_ref : the reference's translation units, untouched                                   (baseline)
+  *_amd : the same with adapter/ + strelka_amd/lib/libstrelka_amd.so (gfx950)            -> `-m gpu`
+  *_dbl : the same with adapter/ + oracle/libstrelka_amd_double.so (CPU double of the C-ABI, test infrastructure)
+          -> CPU suite: checks the adapter's host logic (marshalling, stage-window batching, geometry shadow)
+
+Each run also reports what went through the C-ABI (STRELKA_AMD_VERBOSE=1), so an identical VCF cannot come from an adapter
+that routed nothing.
+"""
+import re
+
+import pytest
+
+from tests import e2e_util as E
+
+GERMLINE_BAMS = ["NA12891_demo20.bam", "NA12892_demo20.bam"]
+
+
+def _counters(stderr):
+    m = re.search(r"strelka_amd adapter: (.*)", stderr)
+    assert m, "adapter did not report:\n" + stderr[-2000:]
+    return {k: int(v) for k, v in (kv.split("=") for kv in m.group(1).split())}
+
+
+def _germline(variant, tmp_path, windows=None):
+    ref_out, out = str(tmp_path / "ref") + "/", str(tmp_path / variant) + "/"
+    (tmp_path / "ref").mkdir(exist_ok=True)
+    (tmp_path / variant).mkdir(exist_ok=True)
+    bams = [E.demo(b) for b in GERMLINE_BAMS]
+    E.run(E.germline_argv("starling2_ref", ref_out, bams))
+    env = {"STRELKA_AMD_VERBOSE": "1"}
+    if windows:
+        env["STRELKA_AMD_READ_WINDOW"], env["STRELKA_AMD_SITE_WINDOW"] = str(windows[0]), str(windows[1])
+    p = E.run(E.germline_argv("starling2_" + variant, out, bams), env=env)
+    c = _counters(p.stderr.decode())
+    assert c["realign_reads"] > 1000 and c["realign_jobs"] >= 1 and c["site_loci"] > 5000
+    assert c["indel_groups"] >= 1 and c["haplotypes"] >= 1
+    for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf"):
+        want, got = E.vcf_body(ref_out + f, keep_header=True), E.vcf_body(out + f, keep_header=True)
+        assert len(want) > 50
+        assert got == want, f
+    return c
+
+
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("windows", [None, (0, 0), (1, 1), (7, 13), (1000, 3000)])
+def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
+    c = _germline("dbl", tmp_path, windows)
+    if windows == (1000, 3000):
+        assert c["realign_jobs"] <= 10 and c["site_batches"] <= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("windows", [None, (7, 13)])
+def test_germline_demo_identical_through_adapter_gpu(tmp_path, windows):
+    _germline("amd", tmp_path, windows)
