@@ -70,6 +70,15 @@ HOOKS = [
          r'computeSampleDiploidSiteGenotype\(\n\s*_opt, _dopt, sample\(sampleIndex\), callerPloidy\[sampleIndex\], allDgt\[sampleIndex\]\);',
          'sk_adapter::site_diploid_genotype(*this, pos, sampleIndex, callerPloidy[sampleIndex], allDgt[sampleIndex]);'),
     ]),
+    (L + "applications/strelka/strelka_pos_processor.cpp", [
+        ("include", r'#include "strelka_pos_processor.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # site 5
+        ("position_somatic_snv_call",
+         r'_dopt\.sscaller_strand_grid\(\)\.position_somatic_snv_call\([^;]*;',
+         'sk_adapter::somatic_snv_genotype(*this, pos, *(normal_cpi_ptr[0]), *(tumor_cpi_ptr[0]), '
+         '(_opt.useTier2Evidence ? normal_cpi_ptr[1] : nullptr), (_opt.useTier2Evidence ? tumor_cpi_ptr[1] : nullptr), '
+         'isComputeNonSomatic, sgtg);'),
+    ]),
     (L + "starling_common/AlleleGroupGenotype.cpp", [
         # site 4: the reference's definition steps aside; adapter/sk_adapter_germline_indel.cpp defines the function
         ("getVariantAlleleGroupGenotypeLhoodsForSample",

@@ -29,6 +29,8 @@ struct starling_pos_processor;
 struct strelka_pos_processor;
 struct diploid_genotype;
 struct starling_read;
+struct CleanedPileup;
+struct somatic_snv_genotype_grid;
 struct reference_contig_segment;
 struct IndelKey;
 
@@ -59,6 +61,12 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
                            diploid_genotype& dgt);
 /// the four zero-depth genotypes of the constructor (starling_pos_processor_base.cpp:259-274)
 void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseId, diploid_genotype& dgt);
+
+// ---- site 5: position_somatic_snv_call at strelka_pos_processor.cpp:213-219 ----
+void somatic_window(starling_pos_processor_base& pp, const pos_t pos);
+void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, const CleanedPileup& normal1, const CleanedPileup& tumor1,
+                          const CleanedPileup* normal2, const CleanedPileup* tumor2, const bool isComputeNonSomatic,
+                          somatic_snv_genotype_grid& sgt);
 
 // ---- site 7: ActiveRegionProcessor::discoverIndelsAndMismatches (ActiveRegionProcessor.cpp:572-705) ----
 bool discover_indels_and_mismatches(const std::string& haplotypeSeq, const std::string& refSegment,

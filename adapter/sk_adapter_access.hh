@@ -31,6 +31,7 @@ struct Access
     static unsigned largestTotalIndelRefSpanPerRead(const base_t& pp) { return pp.get_largest_total_indel_ref_span_per_read(); }
     static bool isPosReportable(const base_t& pp, const pos_t pos) { return pp.is_pos_reportable(pos); }
     static unsigned ploidy(const base_t& pp, const pos_t pos, const unsigned sampleIndex) { return pp.get_ploidy(pos, sampleIndex); }
+    static bool isForcedOutputPos(const base_t& pp, const pos_t pos) { return pp.is_forced_output_pos(pos); }
 };
 
 /// C-ABI status -> the reference's exception type (the context chain of starling_pos_processor_base.cpp:755-760 prints it)
@@ -78,12 +79,23 @@ struct SiteCache
     void clear() { begin = end = 0; isValid.clear(); ploidy.clear(); callCount.clear(); calls.clear(); }
 };
 
+/// somatic SNV records of one stage window
+struct SomaticSiteCache
+{
+    pos_t begin = 0, end = 0;
+    std::vector<uint8_t> isValid, forced;
+    std::vector<uint32_t> callCount; ///< [(pos-begin)*4 + {normal t1, tumor t1, normal t2, tumor t2}]
+    std::vector<sk_somatic_snv_genotype> genotypes;
+    void clear() { begin = end = 0; isValid.clear(); forced.clear(); callCount.clear(); genotypes.clear(); }
+};
+
 struct State
 {
     GeometryShadow geometry;
     bool isAnyRealigned = false;
     pos_t realignedTo = 0;         ///< reads buffered at positions < realignedTo went through a realign job already
     SiteCache sites;
+    SomaticSiteCache somaticSites;
     // counters reported at exit with $STRELKA_AMD_VERBOSE=1
     unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0;
 };

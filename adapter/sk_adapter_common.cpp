@@ -164,6 +164,7 @@ void on_reset_region(starling_pos_processor_base& pp)
     s.isAnyRealigned = false;
     s.realignedTo = 0;
     s.sites.clear();
+    s.somaticSites.clear();
 }
 
 void on_set_head_pos(starling_pos_processor_base& /*pp*/, const pos_t pos, const unsigned readBufferShift, const unsigned indelSpan)

@@ -105,7 +105,11 @@ void genotypeLoci(const starling_base_options& opt, const std::vector<int64_t>& 
 void before_process_pos_variants(starling_pos_processor_base& pp, const pos_t pos)
 {
     const starling_base_options& opt(Access::opt(pp));
-    if (opt.isSomaticCallingMode) return;
+    if (opt.isSomaticCallingMode)
+    {
+        somatic_window(pp, pos);
+        return;
+    }
     if (! opt.is_bsnp_diploid()) return; // the continuous-frequency caller stays on the reference's path
 
     State& s(state());

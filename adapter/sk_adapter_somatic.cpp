@@ -1,0 +1,227 @@
+// sk_adapter_somatic.cpp -- site 5 of the somatic caller: somatic_snv_caller_strand_grid::position_somatic_snv_call
+// (L/applications/strelka/strelka_pos_processor.cpp:213-219) for a whole stage window in one sk_somatic_snv_call_tiers call.
+//
+// When the (deferred) POST_ALIGN stage reaches position P the pileup columns of [P, P+W] are complete, so the four cleaned
+// columns per locus -- normal / tumor, CleanPileupFilter(pi,false) and, with tier2 evidence, CleanPileupFilter(pi,true)
+// (L/starling_common/PileupCleaner.cpp:28-66) -- are packed into four sk_pileup_batch and the whole wrapper (early return,
+// both tiers, tier selection, NTYPE conflict, forced output, non-somatic quality) runs in one call.  The reference's
+// per-position control flow is unchanged: process_pos_snp_somatic(P+k) asks for its somatic_snv_genotype_grid and gets the
+// cached record after a check that the columns it was computed from are the ones the reference holds now.
+#include "sk_adapter_access.hh"
+
+#include "applications/strelka/strelka_pos_processor.hh"
+#include "applications/strelka/strelka_shared.hh"
+#include "blt_util/seq_util.hh"
+
+#include <cstring>
+
+namespace sk_adapter
+{
+
+namespace
+{
+
+const strelka_options& strelkaOptions(const starling_pos_processor_base& pp)
+{
+    return dynamic_cast<const strelka_options&>(Access::opt(pp));
+}
+
+void somaticSnvOptions(const strelka_options& opt, sk_somatic_snv_options& so)
+{
+    sk_somatic_snv_options_default(&so);
+    so.bsnp_diploid_theta = opt.bsnp_diploid_theta;
+    so.somatic_snv_rate = opt.somatic_snv_rate;
+    so.shared_site_error_rate = opt.shared_site_error_rate;
+    so.shared_site_error_strand_bias_fraction = opt.shared_site_error_strand_bias_fraction;
+    so.ssnv_contam_tolerance = opt.ssnv_contam_tolerance;
+}
+
+inline uint16_t bits(const base_call& bc)
+{
+    uint16_t v;
+    std::memcpy(&v, &bc, 2);
+    return v;
+}
+
+/// CleanPileupFilter(pi, is_include_tier2) (PileupCleaner.cpp:28-66)
+void appendCleaned(const snp_pos_info& pi, const bool isIncludeTier2, std::vector<uint16_t>& calls)
+{
+    for (const base_call& bc : pi.calls)
+    {
+        if (bc.is_call_filter)
+        {
+            if (! (isIncludeTier2 && bc.is_tier_specific_call_filter)) continue;
+        }
+        calls.push_back(bits(bc));
+    }
+    if (isIncludeTier2)
+    {
+        for (const base_call& bc : pi.tier2_calls)
+        {
+            if (bc.is_call_filter) continue;
+            calls.push_back(bits(bc));
+        }
+    }
+}
+
+struct Columns
+{
+    std::vector<int64_t> off;
+    std::vector<uint16_t> calls;
+    Columns() : off(1, 0) {}
+    void close() { off.push_back(static_cast<int64_t>(calls.size())); }
+    void fill(sk_pileup_batch& b, const std::vector<uint8_t>& refBase) const
+    {
+        static const uint16_t none(0);
+        std::memset(&b, 0, sizeof(b));
+        b.n_loci = static_cast<int32_t>(refBase.size());
+        b.call_off = off.data();
+        b.calls = calls.empty() ? &none : calls.data();
+        b.ref_base = refBase.data();
+    }
+};
+
+void callLoci(const strelka_options& opt, const Columns col[4], const std::vector<uint8_t>& refBase,
+              const std::vector<uint8_t>& forced, const bool isComputeNonSomatic, sk_somatic_snv_genotype* out)
+{
+    sk_somatic_snv_options so;
+    somaticSnvOptions(opt, so);
+    sk_pileup_batch b[4];
+    for (unsigned i(0); i < 4; ++i) col[i].fill(b[i], refBase);
+    const bool isTier2(opt.useTier2Evidence);
+    check(sk_somatic_snv_call_tiers(&b[0], &b[1], isTier2 ? &b[2] : nullptr, isTier2 ? &b[3] : nullptr, &so, forced.data(),
+                                    isComputeNonSomatic ? 1 : 0, out), "sk_somatic_snv_call_tiers");
+}
+
+uint8_t refBaseId(const char refBase)
+{
+    const unsigned id(base_to_id(refBase));
+    return static_cast<uint8_t>(id < 4 ? id : 4);
+}
+
+void toGenotypeGrid(const sk_somatic_snv_genotype& g, somatic_snv_genotype_grid& sgt)
+{
+    sgt.snv_tier = (g.snv_tier != 0);
+    sgt.snv_from_ntype_tier = (g.snv_from_ntype_tier != 0);
+    sgt.ref_gt = g.ref_gt;
+    sgt.is_forced_output = (g.is_forced_output != 0);
+    sgt.rs.ntype = g.ntype;
+    sgt.rs.max_gt = g.max_gt;
+    sgt.rs.qphred = g.qphred;
+    sgt.rs.from_ntype_qphred = g.from_ntype_qphred;
+    sgt.rs.nonsomatic_qphred = g.nonsomatic_qphred;
+    sgt.rs.normal_alt_id = g.normal_alt_id;
+    sgt.rs.tumor_alt_id = g.tumor_alt_id;
+    sgt.rs.strandBias = g.strand_bias;
+}
+
+}
+
+void somatic_window(starling_pos_processor_base& pp, const pos_t pos)
+{
+    const strelka_options& opt(strelkaOptions(pp));
+    if (! opt.is_somatic_snv()) return;
+
+    State& s(state());
+    SomaticSiteCache& cache(s.somaticSites);
+    if (pos >= cache.begin && pos < cache.end) return;
+
+    using namespace STRELKA_SAMPLE_TYPE;
+    const pos_t begin(pos), end(pos + static_cast<pos_t>(post_align_defer()) + 1);
+    const size_t n(static_cast<size_t>(end - begin));
+    cache.begin = begin;
+    cache.end = end;
+    cache.isValid.assign(n, 0);
+    cache.forced.assign(n, 0);
+    cache.callCount.assign(n * 4, 0);
+    cache.genotypes.resize(n);
+
+    Columns col[4]; // normal t1, tumor t1, normal t2, tumor t2
+    std::vector<uint8_t> refBase, forced;
+    std::vector<size_t> slot;
+    const bool isTier2(opt.useTier2Evidence);
+    for (pos_t p(begin); p < end; ++p)
+    {
+        if (! Access::isPosReportable(pp, p)) continue;
+        const snp_pos_info& npi(pp.sample(NORMAL).basecallBuffer.get_pos(p));
+        const snp_pos_info& tpi(pp.sample(TUMOR).basecallBuffer.get_pos(p));
+        const size_t k(static_cast<size_t>(p - begin));
+        const snp_pos_info* pis[2] = {&npi, &tpi};
+        for (unsigned t(0); t < 2; ++t)
+        {
+            if (t == 1 && ! isTier2) continue;
+            for (unsigned si(0); si < 2; ++si)
+            {
+                Columns& c(col[2 * t + si]);
+                const size_t before(c.calls.size());
+                appendCleaned(*pis[si], t == 1, c.calls);
+                c.close();
+                cache.callCount[4 * k + 2 * t + si] = static_cast<uint32_t>(c.calls.size() - before);
+            }
+        }
+        refBase.push_back(refBaseId(npi.get_ref_base()));
+        const uint8_t isForced(Access::isForcedOutputPos(pp, p) ? 1 : 0);
+        forced.push_back(isForced);
+        cache.forced[k] = isForced;
+        slot.push_back(k);
+    }
+    if (slot.empty()) return;
+    if (! isTier2)
+    {
+        col[2] = col[0];
+        col[3] = col[1];
+    }
+    std::vector<sk_somatic_snv_genotype> out(slot.size());
+    callLoci(opt, col, refBase, forced, opt.is_somatic_callable(), out.data());
+    for (size_t i(0); i < slot.size(); ++i)
+    {
+        cache.genotypes[slot[i]] = out[i];
+        cache.isValid[slot[i]] = 1;
+    }
+    s.siteBatches++;
+    s.siteLoci += slot.size();
+}
+
+void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, const CleanedPileup& normal1, const CleanedPileup& tumor1,
+                          const CleanedPileup* normal2, const CleanedPileup* tumor2, const bool isComputeNonSomatic,
+                          somatic_snv_genotype_grid& sgt)
+{
+    State& s(state());
+    SomaticSiteCache& cache(s.somaticSites);
+    const strelka_options& opt(strelkaOptions(pp));
+    const bool isTier2(normal2 != nullptr);
+    const snp_pos_info* cleaned[4] = {&normal1.cleanedPileup(), &tumor1.cleanedPileup(),
+                                      isTier2 ? &normal2->cleanedPileup() : nullptr, isTier2 ? &tumor2->cleanedPileup() : nullptr};
+    const uint8_t isForced(sgt.is_forced_output ? 1 : 0);
+    if (pos >= cache.begin && pos < cache.end)
+    {
+        const size_t k(static_cast<size_t>(pos - cache.begin));
+        bool ok(cache.isValid[k] && cache.forced[k] == isForced);
+        for (unsigned i(0); ok && i < 4; ++i)
+        {
+            if (cleaned[i] == nullptr) continue;
+            ok = (cache.callCount[4 * k + i] == cleaned[i]->calls.size());
+        }
+        if (ok)
+        {
+            toGenotypeGrid(cache.genotypes[k], sgt);
+            return;
+        }
+    }
+    // not covered by the window (or the site changed since): call the locus as the reference holds it now
+    Columns col[4];
+    for (unsigned i(0); i < 4; ++i)
+    {
+        const snp_pos_info* pi(cleaned[i] ? cleaned[i] : cleaned[i - 2]);
+        for (const base_call& bc : pi->calls) col[i].calls.push_back(bits(bc));
+        col[i].close();
+    }
+    const std::vector<uint8_t> refBase(1, refBaseId(cleaned[0]->get_ref_base()));
+    const std::vector<uint8_t> forced(1, isForced);
+    sk_somatic_snv_genotype out;
+    callLoci(opt, col, refBase, forced, isComputeNonSomatic, &out);
+    toGenotypeGrid(out, sgt);
+    s.siteRecomputed++;
+}
+
+}

@@ -536,6 +536,43 @@ int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* dev_normal, const sk_pi
                                   const sk_somatic_snv_options* opt, int is_forced_output,
                                   sk_somatic_snv_call* dev_out, void* dev_scratch, void* hip_stream);
 
+/** The whole of position_somatic_snv_call: somatic_snv_genotype_grid (L/applications/strelka/somatic_result_set.hh:56-79)
+ *  as the reference leaves it -- all-zero result fields on its early returns. */
+typedef struct sk_somatic_snv_genotype {
+    uint32_t ref_gt;              /* 0 when the reference base is 'N' */
+    uint8_t snv_tier;             /* tier of rs.qphred (:324-329) */
+    uint8_t snv_from_ntype_tier;  /* tier of every other rs field (:331-337) */
+    uint8_t is_forced_output;     /* the input flag, cleared when the reference base is 'N' (:246) */
+    uint8_t is_computed;          /* 1 when the locus got past the all-reference early return (:251-254) */
+    uint32_t ntype;               /* NTYPE::REF / HOM / HET / CONFLICT = 0..3 (somatic_call_shared.hh:32-40) */
+    uint32_t max_gt;              /* DDIGT state of the chosen tier */
+    int32_t qphred;               /* QSS */
+    int32_t from_ntype_qphred;    /* QSS_NT */
+    int32_t nonsomatic_qphred;    /* tier1, only with is_compute_nonsomatic */
+    uint32_t normal_alt_id, tumor_alt_id;
+    int32_t _pad;
+    double strand_bias;           /* snv_result_set::strandBias */
+} sk_somatic_snv_genotype;
+
+/** a12+a13 complete: replaces somatic_snv_caller_strand_grid::position_somatic_snv_call at
+ *  L/applications/strelka/strelka_pos_processor.cpp:213-219 for a batch of loci, with the reference's tier logic
+ *  (L/applications/strelka/position_somatic_snv_strand_grid.cpp:268-362): the all-reference early return is decided on the
+ *  tier1 pileups; tier2 is evaluated only where tier1 gave qphred != 0 (otherwise its result is tier1's); snv_tier /
+ *  snv_from_ntype_tier / NTYPE conflict as in :321-359; non-somatic quality (:186-214) with is_compute_nonsomatic.
+ *  normal_t1/tumor_t1: CleanPileupFilter(pi,false) columns; normal_t2/tumor_t2: CleanPileupFilter(pi,true) columns, both
+ *  NULL = no tier2 evidence (opt.useTier2Evidence off).  is_forced_output: [n_loci] or NULL.  All batches share n_loci
+ *  and ref_base. */
+int sk_somatic_snv_call_tiers(const sk_pileup_batch* host_normal_t1, const sk_pileup_batch* host_tumor_t1,
+                              const sk_pileup_batch* host_normal_t2, const sk_pileup_batch* host_tumor_t2,
+                              const sk_somatic_snv_options* opt, const uint8_t* is_forced_output,
+                              int is_compute_nonsomatic, sk_somatic_snv_genotype* out);
+size_t sk_somatic_snv_tiers_scratch_bytes(int32_t n_loci);
+int sk_somatic_snv_call_tiers_dev(const sk_pileup_batch* dev_normal_t1, const sk_pileup_batch* dev_tumor_t1,
+                                  const sk_pileup_batch* dev_normal_t2, const sk_pileup_batch* dev_tumor_t2,
+                                  const sk_somatic_snv_options* opt, const uint8_t* dev_is_forced_output,
+                                  int is_compute_nonsomatic, sk_somatic_snv_genotype* dev_out, void* dev_scratch,
+                                  void* hip_stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (indels): per-read likelihood reductions over IndelSampleData::read_path_lnp
  * ---------------------------------------------------------------------------------------------------------------- */

@@ -203,6 +203,31 @@ int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* b, const sk_ind
     return 0;
 }
 
+int sk_somatic_snv_call_tiers(const sk_pileup_batch* n1, const sk_pileup_batch* t1, const sk_pileup_batch* n2,
+                              const sk_pileup_batch* t2, const sk_somatic_snv_options* opt, const uint8_t* is_forced_output,
+                              int is_compute_nonsomatic, sk_somatic_snv_genotype* out)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    static_assert(sizeof(sk_somatic_snv_genotype) == sizeof(sko_somatic_snv_genotype), "record layouts must agree");
+    sko_somatic_snv_options so;
+    so.bsnp_diploid_theta = opt->bsnp_diploid_theta;
+    so.somatic_snv_rate = opt->somatic_snv_rate;
+    so.shared_site_error_rate = opt->shared_site_error_rate;
+    so.shared_site_error_strand_bias_fraction = opt->shared_site_error_strand_bias_fraction;
+    so.ssnv_contam_tolerance = opt->ssnv_contam_tolerance;
+    const bool is_tier2 = (n2 != nullptr);
+    if (!is_tier2) { n2 = n1; t2 = t1; }
+    for (int32_t l = 0; l < n1->n_loci; ++l) {
+        sko_position_somatic_snv_call_tiers(n1->calls + n1->call_off[l], int32_t(n1->call_off[l + 1] - n1->call_off[l]),
+                                            t1->calls + t1->call_off[l], int32_t(t1->call_off[l + 1] - t1->call_off[l]),
+                                            n2->calls + n2->call_off[l], int32_t(n2->call_off[l + 1] - n2->call_off[l]),
+                                            t2->calls + t2->call_off[l], int32_t(t2->call_off[l + 1] - t2->call_off[l]),
+                                            is_tier2 ? 1 : 0, n1->ref_base[l], &so, is_forced_output ? is_forced_output[l] : 0,
+                                            is_compute_nonsomatic, reinterpret_cast<sko_somatic_snv_genotype*>(out + l));
+    }
+    return 0;
+}
+
 void sk_align_scores_default(sk_align_scores* s)
 {
     s->match = 1; s->mismatch = -4; s->open = -5; s->extend = -1; s->off_edge = -100; s->insert_delete = -5;

@@ -189,6 +189,46 @@ def somatic_snv_call(normal, tumor, opt=None, is_forced_output=False):
 # ----------------------------------------------------------------------------------------------------------------------
 # hot path B, indels
 
+def _genotype_dtype():
+    from strelka_amd import capi
+    return capi.SOMATIC_GENOTYPE_DTYPE
+
+
+def somatic_snv_call_tiers(n1, t1, n2=None, t2=None, opt=None, is_forced_output=None, is_compute_nonsomatic=False,
+                           use_reference=False):
+    """the whole of position_somatic_snv_call per locus: the C restatement (sko_position_somatic_snv_call_tiers) or, with
+    use_reference, the reference's own function through oracle/_ref (ref_position_somatic_snv_call)."""
+    opt = opt or somatic_snv_options()
+    n = n1.n_loci
+    out = np.zeros(n, _genotype_dtype())
+    is_tier2 = n2 is not None
+    if not is_tier2:
+        n2, t2 = n1, t1
+    L = ref() if use_reference else oracle()
+    for l in range(n):
+        def rng_(b):
+            s, e = int(b.call_off[l]), int(b.call_off[l + 1])
+            c = np.ascontiguousarray(b.calls[s:e])
+            return c, e - s
+        c1, k1 = rng_(n1)
+        c2, k2 = rng_(t1)
+        c3, k3 = rng_(n2)
+        c4, k4 = rng_(t2)
+        forced = 0 if is_forced_output is None else int(is_forced_output[l])
+        rec = np.zeros(1, _genotype_dtype())
+        rb = int(n1.ref_base[l])
+        if use_reference:
+            rc = L.ref_position_somatic_snv_call(_p(c1), k1, _p(c2), k2, _p(c3), k3, _p(c4), k4, int(is_tier2),
+                                                 C.c_char(b"ACGTN"[min(rb, 4):min(rb, 4) + 1]), C.byref(opt), forced,
+                                                 int(bool(is_compute_nonsomatic)), _p(rec))
+            assert rc == 0
+        else:
+            L.sko_position_somatic_snv_call_tiers(_p(c1), k1, _p(c2), k2, _p(c3), k3, _p(c4), k4, int(is_tier2), rb,
+                                                  C.byref(opt), forced, int(bool(is_compute_nonsomatic)), _p(rec))
+        out[l] = rec[0]
+    return out
+
+
 def indel_grid_lhood(batch, min_read_bp_flank, random_base_match_prob, is_include_tier2, is_use_alt_indel=True):
     """batch: strelka_amd.capi.HostReadScoreBatch -> float64 [n_indels][21] (pass the EFFECTIVE random-base-match
     probability of the pass: the tier2 value for tier2 passes)."""

@@ -960,6 +960,171 @@ void sko_position_somatic_snv_call(const uint16_t* ncalls, int32_t n_n, const ui
     }
 }
 
+/* ---- the whole of position_somatic_snv_call: both tiers, forced output, non-somatic quality ----
+ * (L/applications/strelka/position_somatic_snv_strand_grid.cpp:230-363 with the wrapper calculate_result_set_grid
+ * :159-226, gvcf_nonsomatic_gvcf_prior :120-155, isValidNonsomaticIndex :93-113) */
+
+typedef struct tier_result { /* snv_result_set, somatic_result_set.hh:32-54 */
+    uint32_t ntype, max_gt;
+    int32_t qphred, from_ntype_qphred;
+    uint32_t normal_alt_id, tumor_alt_id;
+    int32_t nonsomatic_qphred;
+    double strandBias;
+} tier_result;
+
+static int is_valid_nonsomatic_index(unsigned f)
+{
+    static const float nonSomaticMinFrac = 0.1f;
+    const float nonSomaticMinFracComp = (float)(1. - nonSomaticMinFrac); /* blt_float_t(1.-nonSomaticMinFrac) */
+    static const float epsilon = 0.0001f;
+    const float nonSomaticMinFracEps = nonSomaticMinFrac - epsilon;
+    const float nonSomaticMinFracCompEps = nonSomaticMinFracComp + epsilon;
+    if (f == SOM_REF || f == SOM_HOM) return 1;
+    const float frac = get_fraction_from_index((int)f);
+    if (frac < nonSomaticMinFracEps) return 0;
+    if (frac > nonSomaticMinFracCompEps) return 0;
+    return 1;
+}
+
+static float gvcf_nonsomatic_gvcf_prior(unsigned fn, unsigned ft)
+{
+    const float lzero = -INFINITY;
+    if (!is_valid_nonsomatic_index(ft)) return lzero;
+    if (fn == ft) return logf(1.f);
+    if (fn == SOM_REF || fn == SOM_HOM) return logf(0.5f);
+    return lzero;
+}
+
+/* the non-somatic quality block of the wrapper (:186-214), opt_normalize_ln_distro from L/blt_util/prob_util.hh:248-311
+ * (its "opt max" is compared against the running max that has just been updated, so it ends up being the first
+ * predicate-true entry -- restated as written) */
+int sko_nonsomatic_qphred(const float* normal_lhood, const float* tumor_lhood)
+{
+    enum { N = PRESTRAND * PRESTRAND };
+    double pprob[N];
+    unsigned char pred[N];
+    for (unsigned i = 0; i < N; ++i) pred[i] = 0;
+    for (unsigned gt = 0; gt < PRESTRAND; ++gt) pred[gt + PRESTRAND * gt] = 1; /* DDIGT_GRID::is_nonsom, strelka_digt_states.cpp:154-162 */
+    for (unsigned fn = 0; fn < PRESTRAND; ++fn)
+        for (unsigned ft = 0; ft < PRESTRAND; ++ft) {
+            const float v = normal_lhood[fn] + tumor_lhood[ft] + gvcf_nonsomatic_gvcf_prior(fn, ft);
+            pprob[fn + PRESTRAND * ft] = v;
+        }
+    int is_max = 0, is_opt_max = 0;
+    double max = 0, opt_max = 0;
+    for (unsigned i = 0; i < N; ++i) {
+        if ((!is_max) || (pprob[i] > max)) { max = pprob[i]; is_max = 1; }
+        if (((!is_opt_max) || (pprob[i] > max)) && pred[i]) { opt_max = pprob[i]; is_opt_max = 1; }
+    }
+    static const double norm_thresh = 20, opt_thresh = 5;
+    double sum = 0.;
+    for (unsigned i = 0; i < N; ++i) {
+        const double mdiff = max - pprob[i];
+        if (mdiff > norm_thresh) {
+            if (!pred[i]) { pprob[i] = 0; continue; }
+            const double optdiff = opt_max - pprob[i];
+            if (optdiff > opt_thresh) { pprob[i] = 0; continue; }
+        }
+        pprob[i] = exp(-mdiff);
+        sum += pprob[i];
+    }
+    sum = 1. / sum;
+    for (unsigned i = 0; i < N; ++i) pprob[i] *= sum;
+    double nonsomatic_sum = 0;
+    for (unsigned f = 0; f < PRESTRAND; ++f) nonsomatic_sum += pprob[f + PRESTRAND * f];
+    return sko_error_prob_to_qphred(1. - nonsomatic_sum);
+}
+
+void sko_position_somatic_snv_call_tiers(const uint16_t* n1, int32_t n_n1, const uint16_t* t1, int32_t n_t1,
+                                         const uint16_t* n2, int32_t n_n2, const uint16_t* t2, int32_t n_t2, int is_tier2,
+                                         uint32_t ref_base_id, const sko_somatic_snv_options* opt, int is_forced_output,
+                                         int is_compute_nonsomatic, sko_somatic_snv_genotype* sgt)
+{
+    memset(sgt, 0, sizeof(*sgt));
+    sgt->is_forced_output = (uint8_t)(is_forced_output ? 1 : 0);
+    if (ref_base_id >= 4) { /* :244-248 */
+        sgt->is_forced_output = 0;
+        return;
+    }
+    sgt->ref_gt = ref_base_id;
+    if (!(is_forced_output || is_compute_nonsomatic)) { /* :251-254, tier1 pileups */
+        int allref = 1;
+        for (int i = 0; i < n_n1 && allref; ++i) if (C_BASE(n1[i]) != ref_base_id) allref = 0;
+        for (int i = 0; i < n_t1 && allref; ++i) if (C_BASE(t1[i]) != ref_base_id) allref = 0;
+        if (allref) return;
+    }
+    sgt->is_computed = 1;
+
+    const float contam_tolerance = (float)opt->ssnv_contam_tolerance;
+    const float ln_csse_rate = (float)sko_log1p_switch(-opt->shared_site_error_rate);
+    const float ln_som_match = (float)sko_log1p_switch(-opt->somatic_snv_rate);
+    const float ln_som_mismatch = (float)log(opt->somatic_snv_rate);
+    float lnprior[3];
+    lnprior[SOM_REF] = (float)sko_log1p_switch(-(3. * opt->bsnp_diploid_theta) / 2.);
+    lnprior[SOM_HOM] = (float)log(opt->bsnp_diploid_theta / 2.);
+    lnprior[SOM_HET] = (float)log(opt->bsnp_diploid_theta);
+    const float strand_sse_rate = (float)(opt->shared_site_error_rate * opt->shared_site_error_strand_bias_fraction);
+    const float nostrand_sse_rate = (float)(opt->shared_site_error_rate - strand_sse_rate);
+    const float ln_sse_rate = logf(nostrand_sse_rate);
+
+    tier_result tier_rs[2];
+    memset(tier_rs, 0, sizeof(tier_rs));
+    for (unsigned i = 0; i < 2; ++i) {
+        const int is_include_tier2 = (i == 1);
+        if (is_include_tier2) {
+            if (!is_tier2) continue;
+            if (tier_rs[0].qphred == 0) { tier_rs[1] = tier_rs[0]; continue; }
+        }
+        const uint16_t* nc = is_include_tier2 ? n2 : n1;
+        const uint16_t* tc = is_include_tier2 ? t2 : t1;
+        const int32_t nn = is_include_tier2 ? n_n2 : n_n1, nt = is_include_tier2 ? n_t2 : n_t1;
+        float normal_lhood[GRID], tumor_lhood[GRID];
+        sko_somatic_sample_lhood(nc, nn, ref_base_id, 0, normal_lhood);
+        sko_somatic_sample_lhood(tc, nt, ref_base_id, 1, tumor_lhood);
+        tier_result* rs = &tier_rs[i];
+        sko_calculate_result_set_grid(contam_tolerance, ln_sse_rate, ln_csse_rate, normal_lhood, tumor_lhood, lnprior,
+                                      ln_som_match, ln_som_mismatch, &rs->max_gt, &rs->qphred, &rs->from_ntype_qphred,
+                                      &rs->ntype);
+        if ((is_forced_output || is_compute_nonsomatic) || rs->qphred != 0) { /* wrapper :184 */
+            if (is_compute_nonsomatic) rs->nonsomatic_qphred = sko_nonsomatic_qphred(normal_lhood, tumor_lhood);
+            float symm = tumor_lhood[SOM_SIZE];
+            for (int k = SOM_SIZE; k < PRESTRAND; ++k) if (symm < tumor_lhood[k]) symm = tumor_lhood[k];
+            float strand = tumor_lhood[PRESTRAND];
+            for (int k = PRESTRAND; k < GRID; ++k) if (strand < tumor_lhood[k]) strand = tumor_lhood[k];
+            const float d = strand - symm;
+            rs->strandBias = (0.f < d) ? d : 0.f;
+        }
+        rs->normal_alt_id = most_frequent_alt_id(nc, nn, ref_base_id);
+        rs->tumor_alt_id = most_frequent_alt_id(tc, nt, ref_base_id);
+    }
+    if (!(is_forced_output || is_compute_nonsomatic)) { /* :315-319 */
+        if ((tier_rs[0].qphred == 0) || (is_tier2 && (tier_rs[1].qphred == 0))) return;
+    }
+    sgt->snv_tier = 0;
+    sgt->snv_from_ntype_tier = 0;
+    if (is_tier2) {
+        if (tier_rs[0].qphred > tier_rs[1].qphred) sgt->snv_tier = 1;
+        if (tier_rs[0].from_ntype_qphred > tier_rs[1].from_ntype_qphred) sgt->snv_from_ntype_tier = 1;
+    }
+    const tier_result* rs = &tier_rs[sgt->snv_from_ntype_tier];
+    sgt->ntype = rs->ntype;
+    sgt->max_gt = rs->max_gt;
+    sgt->from_ntype_qphred = rs->from_ntype_qphred;
+    sgt->normal_alt_id = rs->normal_alt_id;
+    sgt->tumor_alt_id = rs->tumor_alt_id;
+    sgt->strand_bias = rs->strandBias;
+    if (is_tier2 && (tier_rs[0].ntype != tier_rs[1].ntype)) { /* NTYPE::CONFLICT, somatic_call_shared.hh:32-40 */
+        sgt->ntype = 3;
+        sgt->from_ntype_qphred = 0;
+    } else {
+        if (sgt->ntype == SOM_REF) sgt->ntype = 0;
+        else if (sgt->ntype == SOM_HOM) sgt->ntype = 1;
+        else sgt->ntype = 2;
+    }
+    sgt->qphred = tier_rs[sgt->snv_tier].qphred;
+    sgt->nonsomatic_qphred = tier_rs[0].nonsomatic_qphred;
+}
+
 /* ------------------------------------------------------------------------------------ hot path B: indels */
 
 /* get_het_observed_allele_ratio, L/starling_common/starling_indel_call_pprob_digt.cpp:40-71 */

@@ -125,6 +125,25 @@ void sko_position_somatic_snv_call(const uint16_t* ncalls, int32_t n_n, const ui
                                    uint32_t ref_base_id, const sko_somatic_snv_options* opt, int is_forced_output,
                                    sko_somatic_snv_call* out);
 
+/* the whole of position_somatic_snv_call (both tiers, per-locus forced output, non-somatic quality):
+ * somatic_snv_genotype_grid (L/applications/strelka/somatic_result_set.hh:56-79); same layout as sk_somatic_snv_genotype */
+typedef struct sko_somatic_snv_genotype {
+    uint32_t ref_gt;
+    uint8_t snv_tier, snv_from_ntype_tier, is_forced_output, is_computed;
+    uint32_t ntype; /* NTYPE::REF/HOM/HET/CONFLICT = 0..3 */
+    uint32_t max_gt;
+    int32_t qphred, from_ntype_qphred, nonsomatic_qphred;
+    uint32_t normal_alt_id, tumor_alt_id;
+    int32_t _pad;
+    double strand_bias;
+} sko_somatic_snv_genotype;
+/* n1/t1: CleanPileupFilter(pi,false) of the normal / tumor sample; n2/t2: CleanPileupFilter(pi,true) (used when is_tier2) */
+void sko_position_somatic_snv_call_tiers(const uint16_t* n1, int32_t n_n1, const uint16_t* t1, int32_t n_t1,
+                                         const uint16_t* n2, int32_t n_n2, const uint16_t* t2, int32_t n_t2, int is_tier2,
+                                         uint32_t ref_base_id, const sko_somatic_snv_options* opt, int is_forced_output,
+                                         int is_compute_nonsomatic, sko_somatic_snv_genotype* sgt);
+int sko_nonsomatic_qphred(const float* normal_lhood21, const float* tumor_lhood21);
+
 /* ---- hot path B, indels ---- */
 /* get_het_observed_allele_ratio (L/starling_common/starling_indel_call_pprob_digt.cpp:40-71); outputs untouched when
  * the total path term is 0 */

@@ -191,6 +191,7 @@ EXPORTS = [
     "sk_germline_options_default", "sk_dependent_eprob", "sk_dependent_eprob_dev", "sk_site_digt_call",
     "sk_site_digt_call_dev", "sk_site_digt_call_fused", "sk_site_digt_call_fused_dev",
     "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
+    "sk_somatic_snv_call_tiers", "sk_somatic_snv_call_tiers_dev", "sk_somatic_snv_tiers_scratch_bytes",
     "sk_indel_options_default", "sk_somatic_indel_options_default", "sk_indel_grid_lhood", "sk_indel_grid_lhood_dev",
     "sk_somatic_indel_call_batch", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
     "sk_discover_indels_and_mismatches", "sk_global_align_scratch_bytes", "sk_global_align_dev",
@@ -483,6 +484,36 @@ def somatic_snv_call(normal, tumor, opt=None, is_forced_output=False):
     out = np.zeros(normal.n_loci, SOMATIC_CALL_DTYPE)
     sn, st = normal.struct(), tumor.struct()
     _check(lib().sk_somatic_snv_call_batch(C.byref(sn), C.byref(st), C.byref(opt), int(is_forced_output), _p(out)))
+    return out
+
+
+SOMATIC_GENOTYPE_DTYPE = np.dtype([
+    ("ref_gt", np.uint32), ("snv_tier", np.uint8), ("snv_from_ntype_tier", np.uint8), ("is_forced_output", np.uint8),
+    ("is_computed", np.uint8), ("ntype", np.uint32), ("max_gt", np.uint32), ("qphred", np.int32),
+    ("from_ntype_qphred", np.int32), ("nonsomatic_qphred", np.int32), ("normal_alt_id", np.uint32),
+    ("tumor_alt_id", np.uint32), ("_pad", np.int32), ("strand_bias", np.float64)], align=True)
+assert SOMATIC_GENOTYPE_DTYPE.itemsize == 48
+
+
+def somatic_snv_call_tiers(normal_t1, tumor_t1, normal_t2=None, tumor_t2=None, opt=None, is_forced_output=None,
+                           is_compute_nonsomatic=False):
+    """sk_somatic_snv_call_tiers: the whole of position_somatic_snv_call (both tiers)."""
+    opt = opt or somatic_snv_options()
+    n = normal_t1.n_loci
+    out = np.zeros(n, SOMATIC_GENOTYPE_DTYPE)
+    s1, s2 = normal_t1.struct(), tumor_t1.struct()
+    if normal_t2 is not None:
+        s3, s4 = normal_t2.struct(), tumor_t2.struct()
+        p3, p4 = C.byref(s3), C.byref(s4)
+    else:
+        p3 = p4 = None
+    forced = None if is_forced_output is None else np.ascontiguousarray(is_forced_output, np.uint8)
+    L = lib()
+    L.sk_somatic_snv_call_tiers.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
+    _check(L.sk_somatic_snv_call_tiers(C.cast(C.byref(s1), C.c_void_p), C.cast(C.byref(s2), C.c_void_p),
+                                       C.cast(p3, C.c_void_p) if p3 is not None else None,
+                                       C.cast(p4, C.c_void_p) if p4 is not None else None,
+                                       C.cast(C.byref(opt), C.c_void_p), _p(forced), int(bool(is_compute_nonsomatic)), _p(out)))
     return out
 
 

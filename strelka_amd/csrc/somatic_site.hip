@@ -32,7 +32,16 @@ struct SomArgs
     sk_somatic_snv_call* out;
     unsigned* work; // [0] = number of loci to evaluate, [1..] = their indices (any order)
     SomaticDerived d;
+    // the whole-wrapper entry (sk_somatic_snv_call_tiers): per-locus forced output, non-somatic quality
+    const uint8_t* forced;  // [n_loci] or nullptr
+    int nonsomatic;         // isComputeNonSomatic: acts like forced output on every early return (:251,:184,:315)
+    int* nonsom_q;          // [n_loci] nonsomatic_qphred of this tier's records, or nullptr
 };
+
+__device__ __forceinline__ bool locus_is_forced(const SomArgs& a, const int l)
+{
+    return a.d.is_forced_output || a.nonsomatic || (a.forced != nullptr && a.forced[l] != 0);
+}
 
 // getLogSum<float>, L/blt_util/logSumUtil.hh:33-41 with log1p_switch<float>, L/blt_util/math_util.hh:33-48: the reference's
 // expf / log1pf / logf are the host libm's, restated for the device in libm_flt32.h; the device library's double-precision
@@ -263,9 +272,9 @@ __global__ __launch_bounds__(CLS_THREADS) void somatic_classify_kernel(const Som
     const int nl = min(CLS_THREADS, a.n.n_loci - l0);
     const unsigned ref = (tid < nl) ? a.n.ref_base[l0 + tid] : 4u;
     s_ref[tid] = (unsigned char)ref;
-    s_flag[tid] = a.d.is_forced_output ? 1u : 0u;
+    s_flag[tid] = (tid < nl && locus_is_forced(a, l0 + tid)) ? 1u : 0u;
     __syncthreads();
-    if (!a.d.is_forced_output) {
+    if (!(a.d.is_forced_output || a.nonsomatic)) {
         flag_nonref_loci(a.n, l0, nl, s_off, s_ref, s_flag);
         flag_nonref_loci(a.t, l0, nl, s_off, s_ref, s_flag);
     }
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(POST_THREADS) __attribute__((amdgpu_waves_per_eu(SO
     } rs;
     calculate_result_set_grid<true>(a.d, lt, [&](const unsigned i) { return row[i]; }, [&](const unsigned i) { return row[PRESTRAND + i]; }, rs);
     float strand_bias = 0.f;
-    if (a.d.is_forced_output || rs.qphred != 0) { // strand bias (:216-225), skipped by the early return at :184
+    if (locus_is_forced(a, l) || rs.qphred != 0) { // strand bias (:216-225), skipped by the early return at :184
         float symm = row[PRESTRAND + SOM_SIZE];
         for (int i = SOM_SIZE; i < PRESTRAND; ++i) symm = (symm < row[PRESTRAND + i]) ? row[PRESTRAND + i] : symm;
         float strand = tl_strand[1];
@@ -411,6 +420,158 @@ __global__ __launch_bounds__(POST_THREADS) __attribute__((amdgpu_waves_per_eu(SO
                   "record tail layout");
     *reinterpret_cast<uint4*>(&o->max_gt) = make_uint4(rs.max_gt, uint32_t(rs.qphred), uint32_t(rs.from_ntype_qphred), rs.ntype);
     *reinterpret_cast<uint2*>(&o->strand_bias) = make_uint2(__float_as_uint(strand_bias), 1u);
+}
+
+// ---- the whole wrapper (sk_somatic_snv_call_tiers) ----------------------------------------------------------------------
+
+struct TierArgs
+{
+    const unsigned* work1;            // loci past the early return
+    unsigned* work2;                  // those of them whose tier1 result has qphred != 0: tier2 is evaluated for these
+    const sk_somatic_snv_call* rec1;  // tier records (likelihoods, posterior, alt ids)
+    const sk_somatic_snv_call* rec2;
+    const int* nonsom_q1;
+    const uint8_t* ref_base;
+    const uint8_t* forced;
+    int is_tier2, nonsomatic;
+    int n_loci;
+    sk_somatic_snv_genotype* out;
+};
+
+// every locus: the record the reference leaves on its early returns (:244-254)
+__global__ __launch_bounds__(256) void somatic_prefill_kernel(const TierArgs a)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= a.n_loci) return;
+    const unsigned ref = a.ref_base[l];
+    sk_somatic_snv_genotype g;
+    memset(&g, 0, sizeof(g));
+    if (ref < 4u) {
+        g.ref_gt = ref;
+        g.is_forced_output = (a.forced != nullptr && a.forced[l] != 0) ? 1 : 0;
+    }
+    a.out[l] = g;
+}
+
+// tier2 is evaluated only where tier1 found something (:274-282)
+__global__ __launch_bounds__(256) void somatic_tier2_queue_kernel(const TierArgs a)
+{
+    const unsigned n_work = a.work1[0];
+    const unsigned w = blockIdx.x * 256u + threadIdx.x;
+    const bool active = (w < n_work) && (a.rec1[a.work1[1 + w]].qphred != 0);
+    const unsigned long long m = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0 && m != 0ull) base = atomicAdd(a.work2, unsigned(__popcll(m)));
+    base = __shfl(base, 0);
+    if (active) a.work2[1 + base + unsigned(__popcll(m & ((1ull << lane) - 1ull)))] = a.work1[1 + w];
+}
+
+// the non-somatic quality of the wrapper (:186-214): 21 x 21 joint states with gvcf_nonsomatic_gvcf_prior (:120-155),
+// opt_normalize_ln_distro (L/blt_util/prob_util.hh:248-311; its "opt max" is compared with the running max that has just
+// been updated, so it is the first predicate-true entry, i.e. state (REF,REF)), then the sum over fn == ft
+struct NonsomArgs
+{
+    const unsigned* work;
+    const sk_somatic_snv_call* rec;
+    int* nonsom_q;
+    unsigned valid_mask; // isValidNonsomaticIndex per tumor state (:93-113)
+    float ln_half;       // std::log(0.5f)
+    int exact_libm;
+};
+
+constexpr int NS_THREADS = 256;
+__global__ __launch_bounds__(NS_THREADS) void somatic_nonsomatic_kernel(const NonsomArgs a)
+{
+    __shared__ float s_lh[NS_THREADS * POST_ROW];
+    const unsigned n_work = a.work[0];
+    const unsigned w = blockIdx.x * unsigned(NS_THREADS) + threadIdx.x;
+    if (w >= n_work) return;
+    const SkLibmTables lt = sk_libm_tables_default();
+    const int l = int(a.work[1 + w]);
+    const sk_somatic_snv_call* o = a.rec + l;
+    float* row = s_lh + threadIdx.x * POST_ROW;
+    for (int i = 0; i < PRESTRAND; ++i) {
+        row[i] = o->normal_lhood[i];
+        row[PRESTRAND + i] = o->tumor_lhood[i];
+    }
+    const float neg_inf = -INFINITY;
+    auto value = [&](const unsigned fn, const unsigned ft) -> float {
+        float prior;
+        if (!((a.valid_mask >> ft) & 1u)) prior = neg_inf;
+        else if (fn == ft) prior = 0.f; // std::log(1.f)
+        else if (fn == SOM_REF || fn == SOM_HOM) prior = a.ln_half;
+        else prior = neg_inf;
+        return __fadd_rn(__fadd_rn(row[fn], row[PRESTRAND + ft]), prior);
+    };
+    float maxv = value(0, 0);
+    const double opt_max = double(maxv);
+    for (unsigned ft = 0; ft < PRESTRAND; ++ft)
+        for (unsigned fn = 0; fn < PRESTRAND; ++fn) {
+            const float v = value(fn, ft);
+            if (v > maxv) maxv = v;
+        }
+    const double mx = double(maxv);
+    double sum = 0.;
+    for (unsigned ft = 0; ft < PRESTRAND; ++ft)
+        for (unsigned fn = 0; fn < PRESTRAND; ++fn) {
+            const double p = double(value(fn, ft));
+            const double mdiff = __dsub_rn(mx, p);
+            if (mdiff > 20.) {
+                if (fn != ft) continue;
+                if (__dsub_rn(opt_max, p) > 5.) continue;
+            }
+            sum = __dadd_rn(sum, sk_exp(-mdiff, a.exact_libm, lt));
+        }
+    const double inv = __ddiv_rn(1., sum);
+    double nonsomatic_sum = 0.;
+    for (unsigned f = 0; f < PRESTRAND; ++f) {
+        const double p = double(value(f, f));
+        const double mdiff = __dsub_rn(mx, p);
+        double e = 0.;
+        if (!(mdiff > 20. && __dsub_rn(opt_max, p) > 5.)) e = sk_exp(-mdiff, a.exact_libm, lt);
+        nonsomatic_sum = __dadd_rn(nonsomatic_sum, __dmul_rn(e, inv));
+    }
+    a.nonsom_q[l] = error_prob_to_qphred_d(__dsub_rn(1., nonsomatic_sum), a.exact_libm, lt);
+}
+
+// tier selection, NTYPE conflict and the final record (:315-362)
+__global__ __launch_bounds__(256) void somatic_combine_kernel(const TierArgs a)
+{
+    const unsigned n_work = a.work1[0];
+    const unsigned w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= n_work) return;
+    const int l = int(a.work1[1 + w]);
+    const sk_somatic_snv_call& r0 = a.rec1[l];
+    // tier_rs[1] = tier_rs[0] where tier1 found nothing (:277-281)
+    const sk_somatic_snv_call& r1 = (a.is_tier2 && r0.qphred != 0) ? a.rec2[l] : r0;
+    const bool forced = a.nonsomatic || (a.forced != nullptr && a.forced[l] != 0);
+    sk_somatic_snv_genotype g = a.out[l];
+    g.is_computed = 1;
+    if (forced || !((r0.qphred == 0) || (a.is_tier2 && r1.qphred == 0))) {
+        uint8_t snv_tier = 0, from_tier = 0;
+        if (a.is_tier2) {
+            if (r0.qphred > r1.qphred) snv_tier = 1;
+            if (r0.from_ntype_qphred > r1.from_ntype_qphred) from_tier = 1;
+        }
+        const sk_somatic_snv_call& rs = from_tier ? r1 : r0;
+        g.snv_tier = snv_tier;
+        g.snv_from_ntype_tier = from_tier;
+        g.max_gt = rs.max_gt;
+        g.from_ntype_qphred = rs.from_ntype_qphred;
+        g.normal_alt_id = rs.normal_alt_id;
+        g.tumor_alt_id = rs.tumor_alt_id;
+        g.strand_bias = double(rs.strand_bias);
+        if (a.is_tier2 && r0.ntype != r1.ntype) {
+            g.ntype = 3u; // NTYPE::CONFLICT
+            g.from_ntype_qphred = 0;
+        } else {
+            g.ntype = (rs.ntype == SOM_REF) ? 0u : ((rs.ntype == SOM_HOM) ? 1u : 2u);
+        }
+        g.qphred = (snv_tier ? r1 : r0).qphred;
+        g.nonsomatic_qphred = a.nonsomatic ? a.nonsom_q1[l] : 0;
+    }
+    a.out[l] = g;
 }
 
 double log1p_switch(const double x)
@@ -455,6 +616,34 @@ void derive(const sk_somatic_snv_options& opt, int is_forced_output, SomaticDeri
 
 } // namespace
 
+
+// one sample's cleaned pileup columns to the device (calls validated: base ids 0..3)
+static int upload_somatic_pileup(const sk_pileup_batch* hb, const int n, SkArena& ar, hipStream_t st, sk_pileup_batch& d)
+{
+    if (hb->call_off[0] != 0) return sk_fail("pileup batch: call_off must start at 0");
+    const int64_t tc = hb->call_off[n];
+    for (int64_t i = 0; i < tc; ++i)
+        if (SKC_BASE(hb->calls[i]) > 3) return sk_fail("somatic pileup batch: basecall with base_id > 3");
+    d = *hb;
+    int64_t* off = ar.take<int64_t>(n + 1);
+    SK_HIP(hipMemcpyAsync(off, hb->call_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+    d.call_off = off;
+    uint16_t* calls = ar.take<uint16_t>(tc);
+    if (tc) SK_HIP(hipMemcpyAsync(calls, hb->calls, 2 * tc, hipMemcpyHostToDevice, st));
+    d.calls = calls;
+    d.de = nullptr;
+    d.ploidy = nullptr;
+    uint8_t* rb = ar.take<uint8_t>(n);
+    SK_HIP(hipMemcpyAsync(rb, hb->ref_base, n, hipMemcpyHostToDevice, st));
+    d.ref_base = rb;
+    return 0;
+}
+
+static size_t pileup_upload_bytes(const sk_pileup_batch* hb, const int n)
+{
+    return sk_align256(sizeof(int64_t) * (size_t(n) + 1)) + sk_align256(size_t(n)) + sk_align256(2 * size_t(hb->call_off[n])) + 3 * 256;
+}
+
 extern "C" {
 
 int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* n, const sk_pileup_batch* t, const sk_somatic_snv_options* opt,
@@ -471,6 +660,9 @@ int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* n, const sk_pileup_batc
     a.tab = sk_ctx().dev_tables;
     a.out = dev_out;
     a.work = static_cast<unsigned*>(dev_scratch);
+    a.forced = nullptr;
+    a.nonsomatic = 0;
+    a.nonsom_q = nullptr;
     derive(*opt, is_forced_output, a.d);
     // skipped loci report an all-zero record (is_called = 0)
     SK_HIP(hipMemsetAsync(dev_out, 0, sizeof(sk_somatic_snv_call) * size_t(n->n_loci), st));
@@ -502,31 +694,157 @@ int sk_somatic_snv_call_batch(const sk_pileup_batch* hn, const sk_pileup_batch* 
                         sk_align256(2 * hn->call_off[n]) + sk_align256(2 * ht->call_off[n]) +
                         sk_align256(sizeof(sk_somatic_snv_call) * n) + sk_align256(4 * (size_t(n) + 4)) + 4096;
     if (ar.reserve(need)) return 1;
-    auto up = [&](const sk_pileup_batch* hb, sk_pileup_batch& d) -> int {
-        if (hb->call_off[0] != 0) return sk_fail("pileup batch: call_off must start at 0");
-        const int64_t tc = hb->call_off[n];
-        for (int64_t i = 0; i < tc; ++i)
-            if (SKC_BASE(hb->calls[i]) > 3) return sk_fail("sk_somatic_snv_call_batch: basecall with base_id > 3");
-        d = *hb;
-        int64_t* off = ar.take<int64_t>(n + 1);
-        SK_HIP(hipMemcpyAsync(off, hb->call_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, ctx.stream));
-        d.call_off = off;
-        uint16_t* calls = ar.take<uint16_t>(tc);
-        if (tc) SK_HIP(hipMemcpyAsync(calls, hb->calls, 2 * tc, hipMemcpyHostToDevice, ctx.stream));
-        d.calls = calls;
-        d.de = nullptr;
-        d.ploidy = nullptr;
-        uint8_t* rb = ar.take<uint8_t>(n);
-        SK_HIP(hipMemcpyAsync(rb, hb->ref_base, n, hipMemcpyHostToDevice, ctx.stream));
-        d.ref_base = rb;
-        return 0;
-    };
+    auto up = [&](const sk_pileup_batch* hb, sk_pileup_batch& d) -> int { return upload_somatic_pileup(hb, n, ar, ctx.stream, d); };
     sk_pileup_batch dn, dt;
     if (up(hn, dn) || up(ht, dt)) return 1;
     sk_somatic_snv_call* dout = ar.take<sk_somatic_snv_call>(n);
     unsigned* work = ar.take<unsigned>(size_t(n) + 4);
     if (sk_somatic_snv_call_batch_dev(&dn, &dt, opt, is_forced_output, dout, work, ctx.stream)) return 1;
     SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_snv_call) * n, hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
+// ---- sk_somatic_snv_call_tiers: the whole of position_somatic_snv_call ----------------------------------------------------
+
+size_t sk_somatic_snv_tiers_scratch_bytes(int32_t n_loci)
+{
+    const size_t n = size_t(n_loci > 0 ? n_loci : 0);
+    return 2 * sk_align256(4 * (n + 4)) + 2 * sk_align256(sizeof(sk_somatic_snv_call) * n) + sk_align256(4 * n) + 1024;
+}
+
+int sk_somatic_snv_call_tiers_dev(const sk_pileup_batch* n1, const sk_pileup_batch* t1, const sk_pileup_batch* n2,
+                                  const sk_pileup_batch* t2, const sk_somatic_snv_options* opt, const uint8_t* dev_forced,
+                                  int is_compute_nonsomatic, sk_somatic_snv_genotype* dev_out, void* dev_scratch, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (!n1 || !t1 || !opt || !dev_out || !dev_scratch) return sk_fail("sk_somatic_snv_call_tiers_dev: null argument");
+    if ((n2 == nullptr) != (t2 == nullptr)) return sk_fail("sk_somatic_snv_call_tiers_dev: tier2 needs both samples");
+    const int n = n1->n_loci;
+    if (t1->n_loci != n || (n2 && (n2->n_loci != n || t2->n_loci != n))) return sk_fail("sk_somatic_snv_call_tiers_dev: n_loci differ");
+    if (n <= 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const bool is_tier2 = (n2 != nullptr);
+
+    char* p = static_cast<char*>(dev_scratch);
+    auto take = [&](const size_t bytes) { char* r = p; p += sk_align256(bytes); return r; };
+    unsigned* work1 = reinterpret_cast<unsigned*>(take(4 * (size_t(n) + 4)));
+    unsigned* work2 = reinterpret_cast<unsigned*>(take(4 * (size_t(n) + 4)));
+    sk_somatic_snv_call* rec1 = reinterpret_cast<sk_somatic_snv_call*>(take(sizeof(sk_somatic_snv_call) * size_t(n)));
+    sk_somatic_snv_call* rec2 = reinterpret_cast<sk_somatic_snv_call*>(take(sizeof(sk_somatic_snv_call) * size_t(n)));
+    int* nonsom_q = reinterpret_cast<int*>(take(4 * size_t(n)));
+
+    SomArgs a;
+    a.n = *n1;
+    a.t = *t1;
+    a.tab = sk_ctx().dev_tables;
+    a.out = rec1;
+    a.work = work1;
+    a.forced = dev_forced;
+    a.nonsomatic = is_compute_nonsomatic ? 1 : 0;
+    a.nonsom_q = nonsom_q;
+    derive(*opt, 0, a.d);
+
+    TierArgs ta;
+    ta.work1 = work1;
+    ta.work2 = work2;
+    ta.rec1 = rec1;
+    ta.rec2 = rec2;
+    ta.nonsom_q1 = nonsom_q;
+    ta.ref_base = n1->ref_base;
+    ta.forced = dev_forced;
+    ta.is_tier2 = is_tier2 ? 1 : 0;
+    ta.nonsomatic = a.nonsomatic;
+    ta.n_loci = n;
+    ta.out = dev_out;
+
+    const dim3 g256((n + 255) / 256), b256(256);
+    SK_HIP(hipMemsetAsync(work1, 0, sizeof(unsigned), st));
+    SK_HIP(hipMemsetAsync(work2, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(somatic_prefill_kernel, g256, b256, 0, st, ta);
+    hipLaunchKernelGGL(somatic_classify_kernel, dim3((n + CLS_THREADS - 1) / CLS_THREADS), dim3(CLS_THREADS), 0, st, a);
+    hipLaunchKernelGGL(somatic_lhood_kernel, dim3((n + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a);
+    hipLaunchKernelGGL(somatic_posterior_kernel, dim3((n + POST_THREADS - 1) / POST_THREADS), dim3(POST_THREADS), 0, st, a);
+    SK_HIP(hipGetLastError());
+    if (a.nonsomatic) {
+        NonsomArgs na;
+        na.work = work1;
+        na.rec = rec1;
+        na.nonsom_q = nonsom_q;
+        na.exact_libm = a.d.exact_libm;
+        // isValidNonsomaticIndex (:93-113) and the two finite priors of gvcf_nonsomatic_gvcf_prior (:120-155), host floats
+        {
+            const float nonSomaticMinFrac(0.1f);
+            const float nonSomaticMinFracComp(1. - nonSomaticMinFrac);
+            const float epsilon(0.0001f);
+            const float lo(nonSomaticMinFrac - epsilon), hi(nonSomaticMinFracComp + epsilon);
+            unsigned mask = 0;
+            for (unsigned f = 0; f < PRESTRAND; ++f) {
+                bool ok = true;
+                if (!(f == SOM_REF || f == SOM_HOM)) {
+                    const float frac = a.d.grid_frac[f];
+                    if (frac < lo || frac > hi) ok = false;
+                }
+                if (ok) mask |= (1u << f);
+            }
+            na.valid_mask = mask;
+            volatile float half = 0.5f;
+            na.ln_half = std::log(half);
+        }
+        hipLaunchKernelGGL(somatic_nonsomatic_kernel, dim3((n + NS_THREADS - 1) / NS_THREADS), dim3(NS_THREADS), 0, st, na);
+        SK_HIP(hipGetLastError());
+    }
+    if (is_tier2) {
+        hipLaunchKernelGGL(somatic_tier2_queue_kernel, g256, b256, 0, st, ta);
+        SomArgs a2 = a;
+        a2.n = *n2;
+        a2.t = *t2;
+        a2.out = rec2;
+        a2.work = work2;
+        a2.nonsom_q = nullptr;
+        hipLaunchKernelGGL(somatic_lhood_kernel, dim3((n + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a2);
+        hipLaunchKernelGGL(somatic_posterior_kernel, dim3((n + POST_THREADS - 1) / POST_THREADS), dim3(POST_THREADS), 0, st, a2);
+        SK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(somatic_combine_kernel, g256, b256, 0, st, ta);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sk_somatic_snv_call_tiers(const sk_pileup_batch* hn1, const sk_pileup_batch* ht1, const sk_pileup_batch* hn2,
+                              const sk_pileup_batch* ht2, const sk_somatic_snv_options* opt, const uint8_t* is_forced_output,
+                              int is_compute_nonsomatic, sk_somatic_snv_genotype* out)
+{
+    SK_REQUIRE_INIT();
+    if (!hn1 || !ht1 || !opt || !out) return sk_fail("sk_somatic_snv_call_tiers: null argument");
+    if ((hn2 == nullptr) != (ht2 == nullptr)) return sk_fail("sk_somatic_snv_call_tiers: tier2 needs both samples");
+    const int n = hn1->n_loci;
+    if (ht1->n_loci != n || (hn2 && (hn2->n_loci != n || ht2->n_loci != n))) return sk_fail("sk_somatic_snv_call_tiers: n_loci differ");
+    if (n <= 0) return 0;
+    if (std::memcmp(hn1->ref_base, ht1->ref_base, n) != 0 ||
+        (hn2 && (std::memcmp(hn1->ref_base, hn2->ref_base, n) != 0 || std::memcmp(hn1->ref_base, ht2->ref_base, n) != 0)))
+        return sk_fail("sk_somatic_snv_call_tiers: ref_base differs between the batches");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    SkArena ar;
+    size_t need = pileup_upload_bytes(hn1, n) + pileup_upload_bytes(ht1, n) + sk_align256(size_t(n)) +
+                  sk_align256(sizeof(sk_somatic_snv_genotype) * size_t(n)) + sk_somatic_snv_tiers_scratch_bytes(n) + 4096;
+    if (hn2) need += pileup_upload_bytes(hn2, n) + pileup_upload_bytes(ht2, n);
+    if (ar.reserve(need)) return 1;
+    sk_pileup_batch dn1, dt1, dn2, dt2;
+    if (upload_somatic_pileup(hn1, n, ar, ctx.stream, dn1) || upload_somatic_pileup(ht1, n, ar, ctx.stream, dt1)) return 1;
+    if (hn2 && (upload_somatic_pileup(hn2, n, ar, ctx.stream, dn2) || upload_somatic_pileup(ht2, n, ar, ctx.stream, dt2))) return 1;
+    uint8_t* dforced = nullptr;
+    if (is_forced_output) {
+        dforced = ar.take<uint8_t>(n);
+        SK_HIP(hipMemcpyAsync(dforced, is_forced_output, n, hipMemcpyHostToDevice, ctx.stream));
+    }
+    sk_somatic_snv_genotype* dout = ar.take<sk_somatic_snv_genotype>(n);
+    void* scratch = ar.take<char>(sk_somatic_snv_tiers_scratch_bytes(n));
+    if (sk_somatic_snv_call_tiers_dev(&dn1, &dt1, hn2 ? &dn2 : nullptr, hn2 ? &dt2 : nullptr, opt, dforced, is_compute_nonsomatic,
+                                      dout, scratch, ctx.stream))
+        return 1;
+    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_snv_genotype) * size_t(n), hipMemcpyDeviceToHost, ctx.stream));
     SK_HIP(hipStreamSynchronize(ctx.stream));
     return 0;
 }

@@ -78,6 +78,46 @@ def somatic_pileups(n_loci, rng, normal_depth=40.0, tumor_depth=110.0, somatic_r
     return one(normal_depth, nfrac), one(tumor_depth, tfrac)
 
 
+def somatic_tier_pileups(n_loci, rng, **kw):
+    """Input C with tier2 evidence: (normal_t1, tumor_t1, normal_t2, tumor_t2).  The tier2 columns are what
+    CleanPileupFilter(pi, is_include_tier2=true) gives: the tier1 calls, a few calls that only the tier-specific filter
+    had removed, then the tier2 reads' calls (noisier: lower qualities, more non-reference bases)."""
+    n1, t1 = somatic_pileups(n_loci, rng, **kw)
+
+    def widen(b, extra_mean):
+        ref = b.ref_base
+        depth = np.diff(b.call_off)
+        extra = rng.poisson(extra_mean, n_loci).astype(np.int64)
+        extra[rng.random(n_loci) < 0.5] = 0
+        extra = np.where(rng.random(n_loci) < 0.25, extra + 12, extra)
+        off = np.zeros(n_loci + 1, np.int64)
+        np.cumsum(depth + extra, out=off[1:])
+        calls = np.zeros(int(off[-1]), np.uint16)
+        tot = int(extra.sum())
+        locus = np.repeat(np.arange(n_loci), extra)
+        q = rng.integers(2, 35, tot)
+        base = np.where(rng.random(tot) < 0.85, ref[locus], rng.integers(0, 4, tot)).astype(np.uint8)
+        # at a few loci the tier2 reads carry one alternate allele at ~50 %: the two tiers then disagree on the normal
+        # genotype (NTYPE conflict, position_somatic_snv_strand_grid.cpp:341-346)
+        alt_locus = rng.random(n_loci) < 0.25
+        alt_base = ((ref.astype(np.int64) + 1 + (np.arange(n_loci) % 3)) % 4).astype(np.uint8)
+        flip = alt_locus[locus] & (rng.random(tot) < 0.5)
+        base = np.where(flip, alt_base[locus], base).astype(np.uint8)
+        q = np.where(alt_locus[locus], 30, q)
+        ecalls = capi.make_call(q, base, rng.integers(0, 2, tot), 0, 0, 0)
+        epos = 0
+        for l in range(n_loci):
+            s, e = int(b.call_off[l]), int(b.call_off[l + 1])
+            o = int(off[l])
+            calls[o:o + (e - s)] = b.calls[s:e]
+            k = int(extra[l])
+            calls[o + (e - s):o + (e - s) + k] = ecalls[epos:epos + k]
+            epos += k
+        return capi.HostPileupBatch(off, calls, ref)
+
+    return n1, t1, widen(n1, 4.0), widen(t1, 8.0)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # input A, flattened and vectorised (bench scale)
 

@@ -306,8 +306,23 @@ def active_region_golden():
         len(scenarios), sum(len(w["keys"]) for w in expect), sum(w["n_indels"] for w in expect)))
 
 
+def somatic_tiers_golden():
+    """rows a12/a13 complete: the reference's own position_somatic_snv_call (both tiers, forced output, non-somatic
+    quality) on the seeded scenarios of tests/test_somatic_tiers.py"""
+    pyoracle.build(ref=True)
+    from tests import test_somatic_tiers as T
+    out = {}
+    for ci, case in enumerate(T.CASES):
+        out["case%d" % ci] = T.run(pyoracle.somatic_snv_call_tiers, T.scenario(1000 + ci), case, use_reference=True)
+    np.savez_compressed(T.GOLDEN, **out)
+    print("somatic tiers golden: %s" % ", ".join("%d calls / %d tier2-chosen / %d conflicts" % (
+        (v["qphred"] > 0).sum(), (v["snv_tier"] == 1).sum(), (v["ntype"] == 3).sum()) for v in out.values()))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "somatic_tiers"):
+        somatic_tiers_golden()
     if what in ("all", "main"):
         main()
     if what in ("all", "realign"):
