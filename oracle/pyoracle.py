@@ -229,6 +229,74 @@ def somatic_snv_call_tiers(n1, t1, n2=None, t2=None, opt=None, is_forced_output=
     return out
 
 
+class IndelSampleReads(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("ref_lnp", C.c_void_p), ("indel_lnp", C.c_void_p), ("alt_key", C.c_void_p),
+                ("alt_lnp", C.c_void_p), ("non_ambig", C.c_void_p), ("read_length", C.c_void_p), ("is_tier1", C.c_void_p)]
+
+
+class AltKey(C.Structure):
+    _fields_ = [("begin_pos", C.c_int32), ("end_pos", C.c_int32), ("is_mismatch", C.c_int32)]
+
+
+class SomaticIndelParams(C.Structure):
+    _fields_ = [("normal_min_read_bp_flank", C.c_int32), ("tumor_min_read_bp_flank", C.c_int32),
+                ("random_base_match_prob", C.c_double), ("tier2_random_base_match_prob", C.c_double),
+                ("use_tier2_evidence", C.c_int32), ("is_use_alt_indel", C.c_int32), ("bindel_diploid_theta", C.c_double),
+                ("somatic_indel_rate", C.c_double), ("shared_indel_error_factor", C.c_double),
+                ("indel_contam_tolerance", C.c_double)]
+
+
+def somatic_indel_params(**kw):
+    # strelka_options defaults with the workflow's overrides (configureStrelkaSomaticWorkflow.py.ini)
+    p = SomaticIndelParams(1, 5, 0.5, 0.25, 1, 1, 1e-4, 1e-6, 2.2, 0.15)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+SOMATIC_INDEL_GENOTYPE_DTYPE = np.dtype([("sindel_tier", np.uint8), ("sindel_from_ntype_tier", np.uint8),
+                                         ("is_forced_output", np.uint8), ("is_overlap", np.uint8), ("ntype", np.uint32),
+                                         ("max_gt", np.uint32), ("qphred", np.int32), ("from_ntype_qphred", np.int32)])
+assert SOMATIC_INDEL_GENOTYPE_DTYPE.itemsize == 20
+
+
+def _sample_struct(smp, keep):
+    arrs = [np.ascontiguousarray(smp["ref_lnp"], np.float32), np.ascontiguousarray(smp["indel_lnp"], np.float32),
+            np.ascontiguousarray(smp["alt_key"], np.int32), np.ascontiguousarray(smp["alt_lnp"], np.float32),
+            np.ascontiguousarray(smp["non_ambig"], np.uint16), np.ascontiguousarray(smp["read_length"], np.uint16),
+            np.ascontiguousarray(smp["is_tier1"], np.uint8)]
+    keep.extend(arrs)
+    return IndelSampleReads(len(arrs[0]), *[a.ctypes.data for a in arrs])
+
+
+def get_somatic_indel(cases, params=None, use_reference=False):
+    """cases: list of dicts(normal=sample, tumor=sample, alt_keys=[(begin,end,is_mismatch)], del_len, ins_len, forced,
+    indel_to_ref_error_prob) with sample = dict of per-read arrays.  The whole of get_somatic_indel per case: the C
+    restatement, or with use_reference the reference's own function (which also reports the error rate it used)."""
+    params = params or somatic_indel_params()
+    out = np.zeros(len(cases), SOMATIC_INDEL_GENOTYPE_DTYPE)
+    used = np.zeros(len(cases))
+    L = ref() if use_reference else oracle()
+    for i, c in enumerate(cases):
+        keep = []
+        ns, ts = _sample_struct(c["normal"], keep), _sample_struct(c["tumor"], keep)
+        ak = (AltKey * max(1, len(c["alt_keys"])))(*[AltKey(*k) for k in c["alt_keys"]])
+        rec = np.zeros(1, SOMATIC_INDEL_GENOTYPE_DTYPE)
+        if use_reference:
+            u = C.c_double(0)
+            rc = L.ref_get_somatic_indel(C.byref(ns), C.byref(ts), ak, len(c["alt_keys"]), int(c["del_len"]), int(c["ins_len"]),
+                                         C.byref(params), C.c_double(c["indel_to_ref_error_prob"]), int(c["forced"]), _p(rec),
+                                         C.byref(u))
+            assert rc == 0
+            used[i] = u.value
+        else:
+            L.sko_get_somatic_indel(C.byref(ns), C.byref(ts), ak, len(c["alt_keys"]), int(c["del_len"]), int(c["ins_len"]), 0,
+                                    C.byref(params), C.c_double(c["indel_to_ref_error_prob"]), int(c["forced"]), _p(rec))
+            used[i] = c["indel_to_ref_error_prob"]
+        out[i] = rec[0]
+    return out, used
+
+
 def indel_grid_lhood(batch, min_read_bp_flank, random_base_match_prob, is_include_tier2, is_use_alt_indel=True):
     """batch: strelka_amd.capi.HostReadScoreBatch -> float64 [n_indels][21] (pass the EFFECTIVE random-base-match
     probability of the pass: the tier2 value for tier2 passes)."""

@@ -1358,6 +1358,226 @@ void sko_somatic_snv_call_batch(const int64_t* n_off, const uint16_t* n_calls, c
                                       (int32_t)(t_off[l + 1] - t_off[l]), ref_base[l], opt, is_forced_output, &out[l]);
 }
 
+/* ------------------------------------------------------------------------ the whole of get_somatic_indel (a14) */
+
+/* indel_lnp_to_pprob, L/starling_common/AlleleReportInfoUtil.cpp:220-301.  ReadPathScores::score_t is float: every store
+ * to a pprob field rounds to float, the arithmetic in between is double wherever a double operand takes part. */
+typedef struct read_pprob {
+    float ref, indel;
+    int n_alt;
+    int32_t alt_key[2];
+    float alt[2];
+} read_pprob;
+
+static const double CORRECT_MAPPING_LOG_PRIOR_INIT = 0; /* placeholder, see correct_mapping_log_prior() */
+static double correct_mapping_log_prior(void)
+{
+    (void)CORRECT_MAPPING_LOG_PRIOR_INIT;
+    return log(1.7e-10); /* starling_base_deriv_options: correctMappingLogPrior, starling_base_shared.cpp:64 */
+}
+
+static read_pprob indel_lnp_to_pprob(const sko_indel_sample_reads* s, int r, double random_base_match_log_prob,
+                                     int is_use_alt_indel)
+{
+    read_pprob pp;
+    int n_in = 0;
+    for (int a = 0; a < 2; ++a) if (s->alt_key[2 * r + a] >= 0) ++n_in;
+    unsigned n_alleles = 2;
+    if (is_use_alt_indel) n_alleles += (unsigned)n_in;
+    const double allele_prior = 1. / (double)n_alleles;
+    const double allele_lnprior = log(allele_prior);
+    const double cmlp = correct_mapping_log_prior();
+    float incorrect = (float)(random_base_match_log_prob * s->non_ambig[r]); /* getIncorrectMappingLogLikelihood -> score_t */
+    pp.ref = (float)(s->ref_lnp[r] + cmlp + allele_lnprior);
+    pp.indel = (float)(s->indel_lnp[r] + cmlp + allele_lnprior);
+    pp.n_alt = 0;
+    if (is_use_alt_indel) {
+        for (int a = 0; a < n_in; ++a) {
+            pp.alt_key[pp.n_alt] = s->alt_key[2 * r + a];
+            pp.alt[pp.n_alt] = (float)(s->alt_lnp[2 * r + a] + cmlp + allele_lnprior);
+            ++pp.n_alt;
+        }
+    }
+    const float m1 = (pp.ref < pp.indel) ? pp.indel : pp.ref;           /* std::max(pprob.ref,pprob.indel) */
+    double scale = (incorrect < m1) ? m1 : incorrect;                   /* std::max(incorrect, ...) -> double */
+    for (int a = 0; a < pp.n_alt; ++a) if (scale < pp.alt[a]) scale = pp.alt[a];
+    incorrect = (float)exp(incorrect - scale);
+    pp.ref = (float)exp(pp.ref - scale);
+    pp.indel = (float)exp(pp.indel - scale);
+    for (int a = 0; a < pp.n_alt; ++a) pp.alt[a] = (float)exp(pp.alt[a] - scale);
+    double sum = incorrect + pp.ref + pp.indel; /* three floats added in float, then widened */
+    for (int a = 0; a < pp.n_alt; ++a) sum += pp.alt[a];
+    pp.ref = (float)(pp.ref / sum);
+    pp.indel = (float)(pp.indel / sum);
+    for (int a = 0; a < pp.n_alt; ++a) pp.alt[a] = (float)(pp.alt[a] / sum);
+    return pp;
+}
+
+typedef struct total_pprob {
+    float ref, indel;
+    int n_alt, cap;
+    int32_t* alt_key;
+    float* alt;
+} total_pprob;
+
+/* get_sum_path_pprob, L/starling_common/starling_indel_call_pprob_digt.cpp:187-236: the key -> slot map is local to one
+ * call, so the tumor sample's alternates are appended after the normal sample's even where the key repeats */
+static void sum_path_pprob(const sko_indel_sample_reads* s, double random_base_match_log_prob, int is_tier2_pass,
+                           int is_use_alt_indel, total_pprob* t, int is_init_total)
+{
+    if (is_init_total) { t->ref = 0; t->indel = 0; }
+    const int first_slot = t->n_alt;
+    for (int r = 0; r < s->n_reads; ++r) {
+        if ((!is_tier2_pass) && (!s->is_tier1[r])) continue;
+        const read_pprob pp = indel_lnp_to_pprob(s, r, random_base_match_log_prob, is_use_alt_indel);
+        t->indel += pp.indel;
+        t->ref += pp.ref;
+        if (!is_use_alt_indel) continue;
+        for (int a = 0; a < pp.n_alt; ++a) {
+            int slot = -1;
+            for (int k = first_slot; k < t->n_alt; ++k) if (t->alt_key[k] == pp.alt_key[a]) { slot = k; break; }
+            if (slot < 0) {
+                assert(t->n_alt < t->cap);
+                t->alt_key[t->n_alt] = pp.alt_key[a];
+                t->alt[t->n_alt] = pp.alt[a];
+                ++t->n_alt;
+            } else {
+                t->alt[slot] += pp.alt[a];
+            }
+        }
+    }
+}
+
+static int alt_keys_conflict(const sko_alt_key* a, const sko_alt_key* b) /* is_indel_conflict, indel_util.cpp:27-45 */
+{
+    const int either_mismatch = a->is_mismatch || b->is_mismatch;
+    const int32_t e1 = a->end_pos + (either_mismatch ? 0 : 1), e2 = b->end_pos + (either_mismatch ? 0 : 1);
+    return (e2 > a->begin_pos) && (b->begin_pos < e1); /* pr1.is_range_intersect(pr2), pos_range.hh:102-106 */
+}
+
+typedef struct score_entry { double score; int id; } score_entry;
+static int score_entry_less(const void* x, const void* y)
+{
+    const score_entry* a = (const score_entry*)x; const score_entry* b = (const score_entry*)y;
+    if (a->score < b->score) return -1;
+    if (b->score < a->score) return 1;
+    return (a->id < b->id) ? -1 : ((b->id < a->id) ? 1 : 0); /* std::pair<double,int> operator< */
+}
+
+int sko_is_multi_indel_allele(const sko_indel_sample_reads* normal, const sko_indel_sample_reads* tumor,
+                              const sko_alt_key* alt_keys, const sko_somatic_indel_params* p, int is_include_tier2,
+                              int* is_overlap)
+{
+    enum { INDEL_ID = -2, REF_ID = -1 };
+    const double rbm = is_include_tier2 ? log(p->tier2_random_base_match_prob) : log(p->random_base_match_prob);
+    total_pprob t;
+    const int cap = 2 * (normal->n_reads + tumor->n_reads) + 1;
+    t.alt_key = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+    t.alt = (float*)malloc(sizeof(float) * (size_t)cap);
+    t.n_alt = 0; t.cap = cap; t.ref = 0; t.indel = 0;
+    sum_path_pprob(normal, rbm, is_include_tier2, 1, &t, 1);
+    sum_path_pprob(tumor, rbm, is_include_tier2, 1, &t, 0);
+    int n = 2 + t.n_alt;
+    score_entry* scores = (score_entry*)malloc(sizeof(score_entry) * (size_t)n);
+    scores[0].score = -t.indel; scores[0].id = INDEL_ID;
+    scores[1].score = -t.ref; scores[1].id = REF_ID;
+    for (int i = 0; i < t.n_alt; ++i) { scores[2 + i].score = -t.alt[i]; scores[2 + i].id = i; }
+    qsort(scores, (size_t)n, sizeof(score_entry), score_entry_less); /* total order: equal to std::sort's result */
+    while (scores[0].id >= 0 && scores[1].id >= 0) {
+        if (alt_keys_conflict(&alt_keys[t.alt_key[scores[0].id]], &alt_keys[t.alt_key[scores[1].id]])) break;
+        memmove(scores + 1, scores + 2, sizeof(score_entry) * (size_t)(n - 2));
+        --n;
+    }
+    int result = 0;
+    if ((scores[0].id != INDEL_ID) && (scores[1].id != INDEL_ID)) result = 1;
+    if (!result && n >= 3) {
+        const double top_prob = scores[0].score + scores[1].score;
+        const double top_frac = top_prob / (top_prob + scores[2].score);
+        if (top_frac < .9) result = 1;
+    }
+    if (!result) *is_overlap = ((scores[0].id != REF_ID) && (scores[1].id != REF_ID));
+    free(scores); free(t.alt_key); free(t.alt);
+    return result;
+}
+
+void sko_get_somatic_indel(const sko_indel_sample_reads* normal, const sko_indel_sample_reads* tumor,
+                           const sko_alt_key* alt_keys, int32_t n_alt_keys, unsigned del_len, unsigned ins_len,
+                           int is_breakpoint, const sko_somatic_indel_params* p, double indel_to_ref_error_prob,
+                           int is_forced_output, sko_somatic_indel_genotype* out)
+{
+    (void)n_alt_keys;
+    memset(out, 0, sizeof(*out));
+    out->is_forced_output = (uint8_t)(is_forced_output ? 1 : 0);
+    struct { uint32_t ntype, max_gt; int32_t qphred, from_ntype_qphred; int is_overlap; } tier_rs[2];
+    memset(tier_rs, 0, sizeof(tier_rs)); /* the reference leaves ntype / max_gt of a skipped tier indeterminate: 0 here */
+
+    /* per-read best alternate score for the likelihood functions (get_indel_digt_lhood reads path_lnp.alt_indel's max) */
+    const sko_indel_sample_reads* smp[2] = { normal, tumor };
+    float* alt_max[2];
+    for (int s = 0; s < 2; ++s) {
+        alt_max[s] = (float*)malloc(sizeof(float) * (size_t)(smp[s]->n_reads + 1));
+        for (int r = 0; r < smp[s]->n_reads; ++r) {
+            float m = NAN;
+            for (int a = 0; a < 2; ++a) {
+                if (smp[s]->alt_key[2 * r + a] < 0) continue;
+                const float v = smp[s]->alt_lnp[2 * r + a];
+                if (!(m == m) || m < v) m = v;
+            }
+            alt_max[s][r] = m;
+        }
+    }
+
+    for (unsigned i = 0; i < 2; ++i) {
+        const int is_include_tier2 = (i == 1);
+        if (is_include_tier2) {
+            if (!p->use_tier2_evidence) continue;
+            if (tier_rs[0].qphred == 0) {
+                if (!is_forced_output) { tier_rs[1].qphred = 0; continue; }
+            }
+        }
+        int is_overlap = tier_rs[i].is_overlap;
+        const int is_filter = sko_is_multi_indel_allele(normal, tumor, alt_keys, p, is_include_tier2, &is_overlap);
+        tier_rs[i].is_overlap = is_overlap;
+        if (is_filter && !is_forced_output) { tier_rs[i].qphred = 0; continue; }
+
+        double normal_lhood[PRESTRAND], tumor_lhood[PRESTRAND];
+        const double rbm = is_include_tier2 ? p->tier2_random_base_match_prob : p->random_base_match_prob;
+        sko_indel_grid_lhood(normal->n_reads, normal->ref_lnp, normal->indel_lnp, alt_max[0], normal->non_ambig,
+                             normal->read_length, normal->is_tier1, del_len, ins_len, is_breakpoint,
+                             p->normal_min_read_bp_flank, rbm, is_include_tier2, p->is_use_alt_indel, normal_lhood);
+        sko_indel_grid_lhood(tumor->n_reads, tumor->ref_lnp, tumor->indel_lnp, alt_max[1], tumor->non_ambig,
+                             tumor->read_length, tumor->is_tier1, del_len, ins_len, is_breakpoint,
+                             p->tumor_min_read_bp_flank, rbm, is_include_tier2, p->is_use_alt_indel, tumor_lhood);
+        sko_somatic_indel_result(normal_lhood, tumor_lhood, indel_to_ref_error_prob, p->shared_indel_error_factor,
+                                 p->indel_contam_tolerance, p->somatic_indel_rate, p->bindel_diploid_theta,
+                                 &tier_rs[i].max_gt, &tier_rs[i].qphred, &tier_rs[i].from_ntype_qphred, &tier_rs[i].ntype);
+        if (is_filter) tier_rs[i].qphred = 0;
+    }
+    free(alt_max[0]); free(alt_max[1]);
+
+    if (!is_forced_output) {
+        if (tier_rs[0].qphred == 0 || tier_rs[1].qphred == 0) return;
+    }
+    out->sindel_tier = 0;
+    if (p->use_tier2_evidence && (tier_rs[0].qphred > tier_rs[1].qphred)) out->sindel_tier = 1;
+    out->sindel_from_ntype_tier = 0;
+    if (p->use_tier2_evidence && (tier_rs[0].from_ntype_qphred > tier_rs[1].from_ntype_qphred)) out->sindel_from_ntype_tier = 1;
+    const unsigned ft = out->sindel_from_ntype_tier;
+    out->ntype = tier_rs[ft].ntype;
+    out->max_gt = tier_rs[ft].max_gt;
+    out->from_ntype_qphred = tier_rs[ft].from_ntype_qphred;
+    out->is_overlap = (uint8_t)(tier_rs[ft].is_overlap ? 1 : 0);
+    if (tier_rs[0].ntype != tier_rs[1].ntype) {
+        out->ntype = 3; /* NTYPE::CONFLICT */
+        out->from_ntype_qphred = 0;
+    } else {
+        if (out->ntype == SOM_REF) out->ntype = 0;
+        else if (out->ntype == SOM_HOM) out->ntype = 1;
+        else out->ntype = 2;
+    }
+    out->qphred = tier_rs[out->sindel_tier].qphred;
+}
+
 /* ---------------------------------------------------------------------------------------------------- row a8: pileup */
 
 /* qphred_cache::mappedq, L/blt_util/qscore_cache.cpp:46-49 with phred_to_mapped_error_prob (qscore.hh:104-113) */

@@ -178,6 +178,44 @@ void sko_somatic_indel_result(const double* normal_lhood21, const double* tumor_
                               double bindel_diploid_theta, uint32_t* max_gt, int32_t* qphred, int32_t* from_ntype_qphred,
                               uint32_t* ntype);
 
+/* ---- the whole of somatic_indel_caller_grid::get_somatic_indel (L/applications/strelka/somatic_indel_grid.cpp:181-361):
+ * multi-indel-allele filter (:102-177, get_sum_path_pprob L/starling_common/starling_indel_call_pprob_digt.cpp:187-236,
+ * indel_lnp_to_pprob L/starling_common/AlleleReportInfoUtil.cpp:220-301), both tiers, tier combination ---- */
+typedef struct sko_indel_sample_reads { /* IndelSampleData::read_path_lnp in read-id order */
+    int32_t n_reads;
+    const float* ref_lnp;
+    const float* indel_lnp;
+    const int32_t* alt_key; /* [n_reads][2] index into the indel's alt-key table, -1 = no entry (entries are front-packed) */
+    const float* alt_lnp;   /* [n_reads][2] */
+    const uint16_t* non_ambig;
+    const uint16_t* read_length;
+    const uint8_t* is_tier1;
+} sko_indel_sample_reads;
+typedef struct sko_alt_key { /* what is_indel_conflict (L/starling_common/indel_util.cpp:27-45) reads of an IndelKey */
+    int32_t begin_pos, end_pos; /* pos, right_pos() */
+    int32_t is_mismatch;
+} sko_alt_key;
+typedef struct sko_somatic_indel_params {
+    int32_t normal_min_read_bp_flank, tumor_min_read_bp_flank;
+    double random_base_match_prob, tier2_random_base_match_prob;
+    int32_t use_tier2_evidence, is_use_alt_indel;
+    double bindel_diploid_theta, somatic_indel_rate, shared_indel_error_factor, indel_contam_tolerance;
+} sko_somatic_indel_params;
+typedef struct sko_somatic_indel_genotype { /* somatic_indel_call, somatic_result_set.hh:81-102; same layout as sk_somatic_indel_genotype */
+    uint8_t sindel_tier, sindel_from_ntype_tier, is_forced_output, is_overlap;
+    uint32_t ntype; /* NTYPE */
+    uint32_t max_gt;
+    int32_t qphred, from_ntype_qphred;
+} sko_somatic_indel_genotype;
+void sko_get_somatic_indel(const sko_indel_sample_reads* normal, const sko_indel_sample_reads* tumor,
+                           const sko_alt_key* alt_keys, int32_t n_alt_keys, unsigned del_len, unsigned ins_len,
+                           int is_breakpoint, const sko_somatic_indel_params* p, double indel_to_ref_error_prob,
+                           int is_forced_output, sko_somatic_indel_genotype* out);
+/* is_multi_indel_allele alone: returns 1 when the indel is filtered; *is_overlap as the reference sets it */
+int sko_is_multi_indel_allele(const sko_indel_sample_reads* normal, const sko_indel_sample_reads* tumor,
+                              const sko_alt_key* alt_keys, const sko_somatic_indel_params* p, int is_include_tier2,
+                              int* is_overlap);
+
 /* ---- batch drivers (plain loops over the functions above; used for parity tests and the bench CPU baseline) ---- */
 typedef struct sko_read_case {
     const uint8_t* read_code;

@@ -118,6 +118,62 @@ def somatic_tier_pileups(n_loci, rng, **kw):
     return n1, t1, widen(n1, 4.0), widen(t1, 8.0)
 
 
+def somatic_indel_cases(n_cases, rng, normal_depth=40.0, tumor_depth=110.0):
+    """Input D for the whole of get_somatic_indel: per candidate indel the two samples' ReadPathScores rows (ref / indel
+    scores, up to two alternate-indel scores keyed into a small per-indel table of overlapping alternate alleles, tier flag)
+    for germline-absent / somatic / germline-het / noisy-multi-allele loci."""
+    cases = []
+    for _ in range(n_cases):
+        kind = rng.choice(["somatic", "absent", "het", "multi", "compound"], p=[0.35, 0.15, 0.2, 0.15, 0.15])
+        is_del = rng.random() < 0.5
+        length = int(rng.integers(1, 12))
+        del_len, ins_len = (length, 0) if is_del else (0, length)
+        n_keys = int(rng.integers(0, 4))
+        alt_keys = []
+        for _k in range(n_keys):
+            b = 1000 + int(rng.integers(-6, 8))
+            is_mm = int(rng.random() < 0.2)
+            e = b + (1 if is_mm else int(rng.integers(0, 6)))
+            if (b, e, is_mm) not in alt_keys:  # distinct alleles only: the table is keyed by IndelKey
+                alt_keys.append((b, e, is_mm))
+        n_keys = len(alt_keys)
+
+        def sample(depth, frac, alt_rate):
+            n = int(rng.poisson(depth))
+            has = rng.random(n) < frac
+            ref = np.where(has, rng.normal(-22, 6, n), rng.normal(-3, 2, n)).clip(max=0).astype(np.float32)
+            ind = np.where(has, rng.normal(-3, 2, n), rng.normal(-22, 6, n)).clip(max=0).astype(np.float32)
+            alt_key = np.full((n, 2), -1, np.int32)
+            alt_lnp = np.zeros((n, 2), np.float32)
+            if n_keys:
+                for r in range(n):
+                    k = 0
+                    if rng.random() < alt_rate:
+                        ids = rng.permutation(n_keys)[:int(rng.integers(1, min(2, n_keys) + 1))]
+                        for a in ids:
+                            alt_key[r, k] = a
+                            alt_lnp[r, k] = np.float32(min(0.0, rng.normal(-4, 3) if rng.random() < 0.5 else rng.normal(-25, 5)))
+                            k += 1
+            if kind == "compound" and n_keys:
+                # the reads without the indel carry alternate allele 0 instead of the reference
+                for r in range(n):
+                    if not has[r] and rng.random() < 0.9:
+                        ref[r] = np.float32(min(0.0, rng.normal(-22, 5)))
+                        alt_key[r] = (0, -1)
+                        alt_lnp[r] = (np.float32(min(0.0, rng.normal(-3, 2))), 0)
+            return dict(ref_lnp=ref, indel_lnp=ind, alt_key=alt_key, alt_lnp=alt_lnp,
+                        non_ambig=rng.integers(90, 151, n).astype(np.uint16), read_length=np.full(n, 150, np.uint16),
+                        is_tier1=(rng.random(n) < 0.85).astype(np.uint8))
+
+        nf, tf = dict(somatic=(0.0, 0.25), absent=(0.0, 0.0), het=(0.5, 0.5), multi=(0.05, 0.3),
+                      compound=(0.0 if rng.random() < 0.5 else 0.5, 0.5))[kind]
+        alt_rate = 0.7 if kind == "multi" else 0.15
+        cases.append(dict(normal=sample(normal_depth, nf, alt_rate), tumor=sample(tumor_depth, tf, alt_rate),
+                          alt_keys=alt_keys, del_len=del_len, ins_len=ins_len, forced=int(rng.random() < 0.15),
+                          indel_to_ref_error_prob=float(rng.choice([5e-5, 3e-4, 2e-3]))))
+    return cases
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # input A, flattened and vectorised (bench scale)
 
