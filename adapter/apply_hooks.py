@@ -78,6 +78,10 @@ HOOKS = [
          'sk_adapter::somatic_snv_genotype(*this, pos, *(normal_cpi_ptr[0]), *(tumor_cpi_ptr[0]), '
          '(_opt.useTier2Evidence ? normal_cpi_ptr[1] : nullptr), (_opt.useTier2Evidence ? tumor_cpi_ptr[1] : nullptr), '
          'isComputeNonSomatic, sgtg);'),
+        # site 6
+        ("get_somatic_indel",
+         r'_dopt\.sicaller_grid\(\)\.get_somatic_indel\(_opt,_dopt,',
+         'sk_adapter::somatic_indel(_opt,'),
     ]),
     (L + "starling_common/AlleleGroupGenotype.cpp", [
         # site 4: the reference's definition steps aside; adapter/sk_adapter_germline_indel.cpp defines the function

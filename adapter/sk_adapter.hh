@@ -31,6 +31,10 @@ struct diploid_genotype;
 struct starling_read;
 struct CleanedPileup;
 struct somatic_snv_genotype_grid;
+struct somatic_indel_call;
+struct strelka_options;
+struct starling_sample_options;
+struct IndelData;
 struct reference_contig_segment;
 struct IndelKey;
 
@@ -67,6 +71,11 @@ void somatic_window(starling_pos_processor_base& pp, const pos_t pos);
 void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, const CleanedPileup& normal1, const CleanedPileup& tumor1,
                           const CleanedPileup* normal2, const CleanedPileup* tumor2, const bool isComputeNonSomatic,
                           somatic_snv_genotype_grid& sgt);
+
+// ---- site 6: get_somatic_indel at strelka_pos_processor.cpp:343-349 ----
+void somatic_indel(const strelka_options& opt, const starling_sample_options& normalOpt, const starling_sample_options& tumorOpt,
+                   const IndelKey& indelKey, const IndelData& indelData, const unsigned normalSampleIndex,
+                   const unsigned tumorSampleIndex, const bool isUseAltIndel, somatic_indel_call& sindel);
 
 // ---- site 7: ActiveRegionProcessor::discoverIndelsAndMismatches (ActiveRegionProcessor.cpp:572-705) ----
 bool discover_indels_and_mismatches(const std::string& haplotypeSeq, const std::string& refSegment,

@@ -13,7 +13,10 @@
 #include "applications/strelka/strelka_shared.hh"
 #include "blt_util/seq_util.hh"
 
+#include <cmath>
 #include <cstring>
+#include <limits>
+#include <map>
 
 namespace sk_adapter
 {
@@ -222,6 +225,144 @@ void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, cons
     callLoci(opt, col, refBase, forced, isComputeNonSomatic, &out);
     toGenotypeGrid(out, sgt);
     s.siteRecomputed++;
+}
+
+
+// ---- site 6: somatic_indel_caller_grid::get_somatic_indel at strelka_pos_processor.cpp:343-349 ------------------------------
+//
+// One candidate indel per call, as the reference calls it (candidate indels with read support are ~1e-3 of the loci and the
+// call sits inside position-ordered host logic).  The two samples' IndelSampleData::read_path_lnp rows go over as CSR rows
+// in read-id order, the reads' alternate-indel lists as indices into a table of the distinct alternate IndelKeys.
+void somatic_indel(const strelka_options& opt, const starling_sample_options& normalOpt, const starling_sample_options& tumorOpt,
+                   const IndelKey& indelKey, const IndelData& indelData, const unsigned normalSampleIndex,
+                   const unsigned tumorSampleIndex, const bool isUseAltIndel, somatic_indel_call& sindel)
+{
+    init();
+    if (indelKey.is_breakpoint()) throw blt_exception("strelka_amd adapter: breakpoint alleles are not supported on this path");
+
+    std::map<IndelKey, int32_t> altIndex;
+    std::vector<sk_alt_allele> alleles;
+    struct Rows
+    {
+        std::vector<float> ref, indel, best;
+        std::vector<int32_t> altKey;
+        std::vector<float> altLnp;
+        std::vector<uint16_t> nonAmbig, readLength;
+        std::vector<uint8_t> flags;
+    } rows[2];
+    const unsigned sampleIndex[2] = {normalSampleIndex, tumorSampleIndex};
+    for (unsigned s(0); s < 2; ++s)
+    {
+        Rows& R(rows[s]);
+        for (const auto& val : indelData.getSampleData(sampleIndex[s]).read_path_lnp)
+        {
+            const ReadPathScores& rps(val.second);
+            R.ref.push_back(rps.ref);
+            R.indel.push_back(rps.indel);
+            R.nonAmbig.push_back(rps.nonAmbiguousBasesInRead);
+            R.readLength.push_back(rps.read_length);
+            R.flags.push_back(static_cast<uint8_t>((rps.is_tier1_read ? SK_READ_TIER1 : 0) | (rps.is_fwd_strand ? SK_READ_FWD : 0)));
+            float best(std::numeric_limits<float>::quiet_NaN());
+            if (rps.alt_indel.size() > 2) throw blt_exception("strelka_amd adapter: more than two alternate indels on a read");
+            for (unsigned a(0); a < 2; ++a)
+            {
+                if (a >= rps.alt_indel.size())
+                {
+                    R.altKey.push_back(-1);
+                    R.altLnp.push_back(0.f);
+                    continue;
+                }
+                const IndelKey& ak(rps.alt_indel[a].first);
+                if (ak.is_breakpoint()) throw blt_exception("strelka_amd adapter: breakpoint alleles are not supported on this path");
+                auto it(altIndex.find(ak));
+                if (it == altIndex.end())
+                {
+                    it = altIndex.insert(std::make_pair(ak, static_cast<int32_t>(alleles.size()))).first;
+                    sk_alt_allele al;
+                    al.begin_pos = ak.pos;
+                    al.end_pos = ak.right_pos();
+                    al.is_mismatch = ak.isMismatch() ? 1 : 0;
+                    alleles.push_back(al);
+                }
+                R.altKey.push_back(it->second);
+                R.altLnp.push_back(rps.alt_indel[a].second);
+                const float v(rps.alt_indel[a].second);
+                if (!(best == best) || best < v) best = v;
+            }
+            R.best.push_back(best);
+        }
+    }
+
+    const uint32_t delLen(indelKey.delete_length()), insLen(indelKey.insert_length());
+    static const float noFloat(0.f);
+    static const uint16_t noU16(0);
+    static const uint8_t noU8(0);
+    static const int32_t noI32(-1);
+    int64_t readOff[2][2];
+    auto fill = [&](const unsigned s, sk_readscore_batch& b)
+    {
+        const Rows& R(rows[s]);
+        std::memset(&b, 0, sizeof(b));
+        readOff[s][0] = 0;
+        readOff[s][1] = static_cast<int64_t>(R.ref.size());
+        b.n_indels = 1;
+        b.read_off = readOff[s];
+        const bool any(! R.ref.empty());
+        b.ref_lnp = any ? R.ref.data() : &noFloat;
+        b.indel_lnp = any ? R.indel.data() : &noFloat;
+        b.alt_lnp = any ? R.best.data() : &noFloat;
+        b.non_ambig = any ? R.nonAmbig.data() : &noU16;
+        b.read_length = any ? R.readLength.data() : &noU16;
+        b.read_flags = any ? R.flags.data() : &noU8;
+        b.del_len = &delLen;
+        b.ins_len = &insLen;
+        b.is_breakpoint = nullptr;
+    };
+    sk_somatic_indel_batch sb;
+    std::memset(&sb, 0, sizeof(sb));
+    sb.n_indels = 1;
+    fill(0, sb.normal);
+    fill(1, sb.tumor);
+    sb.normal_alt_key = rows[0].altKey.empty() ? &noI32 : rows[0].altKey.data();
+    sb.normal_alt_lnp = rows[0].altLnp.empty() ? &noFloat : rows[0].altLnp.data();
+    sb.tumor_alt_key = rows[1].altKey.empty() ? &noI32 : rows[1].altKey.data();
+    sb.tumor_alt_lnp = rows[1].altLnp.empty() ? &noFloat : rows[1].altLnp.data();
+    const int64_t altOff[2] = {0, static_cast<int64_t>(alleles.size())};
+    static const sk_alt_allele noAllele = {0, 0, 0};
+    sb.alt_off = altOff;
+    sb.alt_alleles = alleles.empty() ? &noAllele : alleles.data();
+    const double indelToRef(indelData.getSampleData(tumorSampleIndex).getErrorRates().indelToRefErrorProb.getValue());
+    sb.indel_to_ref_error_prob = &indelToRef;
+    const uint8_t forced(indelData.isForcedOutput ? 1 : 0);
+    sb.is_forced_output = &forced;
+
+    sk_indel_options no, to;
+    sk_indel_options_default(&no, 1);
+    no.min_read_bp_flank = normalOpt.min_read_bp_flank;
+    no.random_base_match_prob = opt.randomBaseMatchProb;
+    no.tier2_random_base_match_prob = opt.tier2.randomBaseMatchProb;
+    no.read_confident_support_threshold = opt.readConfidentSupportThreshold.numval();
+    no.is_use_alt_indel = isUseAltIndel ? 1 : 0;
+    to = no;
+    to.min_read_bp_flank = tumorOpt.min_read_bp_flank;
+    sk_somatic_indel_options so;
+    sk_somatic_indel_options_default(&so);
+    so.bindel_diploid_theta = opt.bindel_diploid_theta;
+    so.somatic_indel_rate = opt.somatic_indel_rate;
+    so.shared_indel_error_factor = opt.shared_indel_error_factor;
+    so.indel_contam_tolerance = opt.indel_contam_tolerance;
+
+    sk_somatic_indel_genotype g;
+    check(sk_somatic_indel_call_tiers(&sb, &no, &to, &so, opt.useTier2Evidence ? 1 : 0, &g), "sk_somatic_indel_call_tiers");
+    sindel.is_forced_output = indelData.isForcedOutput;
+    sindel.sindel_tier = (g.sindel_tier != 0);
+    sindel.sindel_from_ntype_tier = (g.sindel_from_ntype_tier != 0);
+    sindel.rs.ntype = g.ntype;
+    sindel.rs.max_gt = g.max_gt;
+    sindel.rs.qphred = g.qphred;
+    sindel.rs.from_ntype_qphred = g.from_ntype_qphred;
+    sindel.rs.is_overlap = (g.is_overlap != 0);
+    state().indelGroups++;
 }
 
 }

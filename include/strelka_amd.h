@@ -640,6 +640,49 @@ int sk_somatic_indel_call_batch(const sk_readscore_batch* host_normal, const sk_
                                 const sk_somatic_indel_options* sopt, const double* indel_to_ref_error_prob,
                                 int is_include_tier2, sk_somatic_indel_call* out);
 
+/* The whole of get_somatic_indel: multi-indel-allele filter, both tiers, tier combination. */
+enum { SK_MAX_ALT_ALLELES = 16 };
+typedef struct sk_alt_allele { /* what is_indel_conflict (L/starling_common/indel_util.cpp:27-45) reads of an alternate IndelKey */
+    int32_t begin_pos, end_pos; /* IndelKey::pos, IndelKey::right_pos() */
+    int32_t is_mismatch;        /* IndelKey::isMismatch() */
+} sk_alt_allele;
+
+typedef struct sk_somatic_indel_batch {
+    int32_t n_indels;
+    sk_readscore_batch normal, tumor;  /* as for sk_indel_grid_lhood: alt_lnp = the read's best alternate score, NaN = none */
+    /* the reads' ReadPathScores::alt_indel lists (<= 2 entries, front-packed) for the multi-indel-allele filter */
+    const int32_t* normal_alt_key;     /* [normal reads][2] index into this indel's alternate-allele table, -1 = no entry */
+    const float* normal_alt_lnp;       /* [normal reads][2] */
+    const int32_t* tumor_alt_key;
+    const float* tumor_alt_lnp;
+    const int64_t* alt_off;            /* [n_indels+1]: alternate-allele table of each indel, <= SK_MAX_ALT_ALLELES entries */
+    const sk_alt_allele* alt_alleles;  /* distinct IndelKeys */
+    const double* indel_to_ref_error_prob; /* [n_indels] tumorIndelSampleData.getErrorRates().indelToRefErrorProb (:273) */
+    const uint8_t* is_forced_output;   /* [n_indels] IndelData::isForcedOutput, or NULL */
+} sk_somatic_indel_batch;
+
+typedef struct sk_somatic_indel_genotype { /* somatic_indel_call, L/applications/strelka/somatic_result_set.hh:81-102 */
+    uint8_t sindel_tier;             /* tier of rs.qphred (:303-310) */
+    uint8_t sindel_from_ntype_tier;  /* tier of the other rs fields (:312-321) */
+    uint8_t is_forced_output;
+    uint8_t is_overlap;              /* indel_result_set::is_overlap of the chosen tier */
+    uint32_t ntype;                  /* NTYPE::REF / HOM / HET / CONFLICT */
+    uint32_t max_gt;
+    int32_t qphred;                  /* QSI */
+    int32_t from_ntype_qphred;       /* QSI_NT */
+} sk_somatic_indel_genotype;
+
+/** a14 complete: replaces somatic_indel_caller_grid::get_somatic_indel at
+ *  L/applications/strelka/strelka_pos_processor.cpp:343-349 for a batch of candidate indels
+ *  (L/applications/strelka/somatic_indel_grid.cpp:181-361): per tier the multi-indel-allele filter (is_multi_indel_allele
+ *  :102-177 over get_sum_path_pprob / indel_lnp_to_pprob), the 2 x 21 likelihoods and the posterior; then the skip rules
+ *  (:220-232, :239-254, :289-293), tier selection and NTYPE conflict (:295-360).  A record the reference returns without
+ *  filling (not forced and a tier with qphred == 0) comes back all-zero.  With use_tier2_evidence == 0 the second tier is
+ *  never evaluated (the reference then reads its never-written ntype at :323; it is taken as 0 here). */
+int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* host_batch, const sk_indel_options* normal_opt,
+                                const sk_indel_options* tumor_opt, const sk_somatic_indel_options* sopt,
+                                int use_tier2_evidence, sk_somatic_indel_genotype* out);
+
 /** allele groups -> reads (CSR): getVariantAlleleGroupGenotypeLhoodsForSample's input after the host adapter resolved
  *  read ids (L/starling_common/AlleleGroupGenotype.cpp:185-258; empty contrast group) */
 typedef struct sk_allele_group_batch {

@@ -228,6 +228,52 @@ int sk_somatic_snv_call_tiers(const sk_pileup_batch* n1, const sk_pileup_batch* 
     return 0;
 }
 
+int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* b, const sk_indel_options* nopt, const sk_indel_options* topt,
+                                const sk_somatic_indel_options* sopt, int use_tier2_evidence, sk_somatic_indel_genotype* out)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    static_assert(sizeof(sk_somatic_indel_genotype) == sizeof(sko_somatic_indel_genotype), "record layouts must agree");
+    static_assert(sizeof(sk_alt_allele) == sizeof(sko_alt_key), "alternate-allele layouts must agree");
+    sko_somatic_indel_params p;
+    p.normal_min_read_bp_flank = nopt->min_read_bp_flank;
+    p.tumor_min_read_bp_flank = topt->min_read_bp_flank;
+    p.random_base_match_prob = topt->random_base_match_prob;
+    p.tier2_random_base_match_prob = topt->tier2_random_base_match_prob;
+    p.use_tier2_evidence = use_tier2_evidence;
+    p.is_use_alt_indel = topt->is_use_alt_indel;
+    p.bindel_diploid_theta = sopt->bindel_diploid_theta;
+    p.somatic_indel_rate = sopt->somatic_indel_rate;
+    p.shared_indel_error_factor = sopt->shared_indel_error_factor;
+    p.indel_contam_tolerance = sopt->indel_contam_tolerance;
+    for (int32_t i = 0; i < b->n_indels; ++i) {
+        if (b->alt_off[i + 1] - b->alt_off[i] > SK_MAX_ALT_ALLELES) return fail("more alternate alleles at one indel than SK_MAX_ALT_ALLELES");
+        sko_indel_sample_reads smp[2];
+        std::vector<uint8_t> t1[2];
+        const sk_readscore_batch* rb[2] = { &b->normal, &b->tumor };
+        const int32_t* ak[2] = { b->normal_alt_key, b->tumor_alt_key };
+        const float* al[2] = { b->normal_alt_lnp, b->tumor_alt_lnp };
+        for (int s = 0; s < 2; ++s) {
+            const int64_t r0 = rb[s]->read_off[i];
+            const int32_t n = int32_t(rb[s]->read_off[i + 1] - r0);
+            t1[s].resize(size_t(n) + 1);
+            for (int32_t r = 0; r < n; ++r) t1[s][r] = (rb[s]->read_flags[r0 + r] & SK_READ_TIER1) ? 1 : 0;
+            smp[s].n_reads = n;
+            smp[s].ref_lnp = rb[s]->ref_lnp + r0;
+            smp[s].indel_lnp = rb[s]->indel_lnp + r0;
+            smp[s].alt_key = ak[s] + 2 * r0;
+            smp[s].alt_lnp = al[s] + 2 * r0;
+            smp[s].non_ambig = rb[s]->non_ambig + r0;
+            smp[s].read_length = rb[s]->read_length + r0;
+            smp[s].is_tier1 = t1[s].data();
+        }
+        sko_get_somatic_indel(&smp[0], &smp[1], reinterpret_cast<const sko_alt_key*>(b->alt_alleles + b->alt_off[i]),
+                              int32_t(b->alt_off[i + 1] - b->alt_off[i]), b->normal.del_len[i], b->normal.ins_len[i],
+                              b->normal.is_breakpoint ? b->normal.is_breakpoint[i] : 0, &p, b->indel_to_ref_error_prob[i],
+                              b->is_forced_output ? b->is_forced_output[i] : 0, reinterpret_cast<sko_somatic_indel_genotype*>(out + i));
+    }
+    return 0;
+}
+
 void sk_align_scores_default(sk_align_scores* s)
 {
     s->match = 1; s->mismatch = -4; s->open = -5; s->extend = -1; s->off_edge = -100; s->insert_delete = -5;

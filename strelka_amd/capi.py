@@ -193,7 +193,7 @@ EXPORTS = [
     "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
     "sk_somatic_snv_call_tiers", "sk_somatic_snv_call_tiers_dev", "sk_somatic_snv_tiers_scratch_bytes",
     "sk_indel_options_default", "sk_somatic_indel_options_default", "sk_indel_grid_lhood", "sk_indel_grid_lhood_dev",
-    "sk_somatic_indel_call_batch", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
+    "sk_somatic_indel_call_batch", "sk_somatic_indel_call_tiers", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
     "sk_discover_indels_and_mismatches", "sk_global_align_scratch_bytes", "sk_global_align_dev",
 ]
 
@@ -558,6 +558,74 @@ class HostReadScoreBatch:
         return ReadScoreBatch(self.n_indels, _p(self.read_off), _p(self.ref_lnp), _p(self.indel_lnp), _p(self.alt_lnp),
                               _p(self.non_ambig), _p(self.read_length), _p(self.read_flags), _p(self.del_len),
                               _p(self.ins_len), _p(self.is_breakpoint))
+
+
+class AltAllele(C.Structure):
+    _fields_ = [("begin_pos", C.c_int32), ("end_pos", C.c_int32), ("is_mismatch", C.c_int32)]
+
+
+class SomaticIndelBatch(C.Structure):
+    _fields_ = [("n_indels", C.c_int32), ("normal", ReadScoreBatch), ("tumor", ReadScoreBatch),
+                ("normal_alt_key", c_void_p), ("normal_alt_lnp", c_void_p), ("tumor_alt_key", c_void_p),
+                ("tumor_alt_lnp", c_void_p), ("alt_off", c_void_p), ("alt_alleles", c_void_p),
+                ("indel_to_ref_error_prob", c_void_p), ("is_forced_output", c_void_p)]
+
+
+SOMATIC_INDEL_GENOTYPE_DTYPE = np.dtype([("sindel_tier", np.uint8), ("sindel_from_ntype_tier", np.uint8),
+                                         ("is_forced_output", np.uint8), ("is_overlap", np.uint8), ("ntype", np.uint32),
+                                         ("max_gt", np.uint32), ("qphred", np.int32), ("from_ntype_qphred", np.int32)])
+assert SOMATIC_INDEL_GENOTYPE_DTYPE.itemsize == 20
+
+
+class HostSomaticIndelBatch:
+    """sk_somatic_indel_batch from per-indel cases (strelka_amd.synth.somatic_indel_cases layout)."""
+
+    def __init__(self, cases):
+        n = len(cases)
+        self.n = n
+
+        def sample(name):
+            off = np.zeros(n + 1, np.int64)
+            np.cumsum([len(c[name]["ref_lnp"]) for c in cases], out=off[1:])
+            cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(c[name][k]).reshape(len(c[name]["ref_lnp"]), -1) for c in cases] or [np.zeros((0, 1))]), dt)
+            alt_key = cat("alt_key", np.int32).reshape(-1, 2)
+            alt_lnp = cat("alt_lnp", np.float32).reshape(-1, 2)
+            best = np.where(alt_key >= 0, alt_lnp, -np.inf).max(axis=1) if len(alt_key) else np.zeros(0)
+            best = np.where((alt_key >= 0).any(axis=1), best, np.nan).astype(np.float32) if len(alt_key) else np.zeros(0, np.float32)
+            t1 = cat("is_tier1", np.uint8).ravel()
+            b = HostReadScoreBatch(off, cat("ref_lnp", np.float32).ravel(), cat("indel_lnp", np.float32).ravel(), best,
+                                   cat("non_ambig", np.uint16).ravel(), cat("read_length", np.uint16).ravel(),
+                                   (t1 & 1) | 2, [c["del_len"] for c in cases], [c["ins_len"] for c in cases])
+            return b, np.ascontiguousarray(alt_key), np.ascontiguousarray(alt_lnp)
+
+        self.normal, self.n_alt_key, self.n_alt_lnp = sample("normal")
+        self.tumor, self.t_alt_key, self.t_alt_lnp = sample("tumor")
+        self.alt_off = np.zeros(n + 1, np.int64)
+        np.cumsum([len(c["alt_keys"]) for c in cases], out=self.alt_off[1:])
+        keys = [k for c in cases for k in c["alt_keys"]]
+        self.alleles = np.ascontiguousarray(np.array(keys, np.int32).reshape(-1, 3))
+        self.err = np.ascontiguousarray([c["indel_to_ref_error_prob"] for c in cases], np.float64)
+        self.forced = np.ascontiguousarray([c["forced"] for c in cases], np.uint8)
+
+    def struct(self):
+        return SomaticIndelBatch(self.n, self.normal.struct(), self.tumor.struct(), _p(self.n_alt_key), _p(self.n_alt_lnp),
+                                 _p(self.t_alt_key), _p(self.t_alt_lnp), _p(self.alt_off), _p(self.alleles), _p(self.err),
+                                 _p(self.forced))
+
+
+def somatic_indel_call_tiers(cases, normal_opt=None, tumor_opt=None, sopt=None, use_tier2_evidence=True):
+    """sk_somatic_indel_call_tiers: the whole of get_somatic_indel per candidate indel."""
+    if normal_opt is None:
+        normal_opt = indel_options(True)
+        normal_opt.min_read_bp_flank = 1
+    tumor_opt = tumor_opt or indel_options(True)
+    sopt = sopt or somatic_indel_options()
+    b = HostSomaticIndelBatch(cases)
+    out = np.zeros(b.n, SOMATIC_INDEL_GENOTYPE_DTYPE)
+    s = b.struct()
+    _check(lib().sk_somatic_indel_call_tiers(C.byref(s), C.byref(normal_opt), C.byref(tumor_opt), C.byref(sopt),
+                                             int(bool(use_tier2_evidence)), _p(out)))
+    return out
 
 
 def indel_grid_lhood(batch, opt=None, is_include_tier2=False):

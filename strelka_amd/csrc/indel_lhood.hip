@@ -343,6 +343,220 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
     }
 }
 
+// ---- the whole of get_somatic_indel (sk_somatic_indel_call_tiers) -------------------------------------------------------
+
+// M1: is_multi_indel_allele (somatic_indel_grid.cpp:102-177) for both tiers of every indel, one wave per indel.
+//   lanes  : indel_lnp_to_pprob (L/starling_common/AlleleReportInfoUtil.cpp:220-301) of 64 reads at a time into LDS --
+//            ReadPathScores::score_t is float, so every store to a pprob field rounds to float while the arithmetic in
+//            between is double wherever a double operand takes part (restated literally);
+//   lane 0 : get_sum_path_pprob (L/starling_common/starling_indel_call_pprob_digt.cpp:187-236) -- float sums in read order,
+//            alternates accumulated per key with a key -> slot map that is local to each of the two calls (so the tumor
+//            sample's alternates follow the normal sample's even where a key repeats) -- then the sort and the decisions.
+struct MultiArgs
+{
+    sk_readscore_batch n, t;
+    const int32_t* alt_key[2]; // [reads][2]
+    const float* alt_lnp[2];
+    const int64_t* alt_off;
+    const sk_alt_allele* alt_alleles;
+    double correct_mapping_log_prior;
+    double random_base_match_log_prob[2]; // per tier
+    double allele_lnprior[3];             // log(1./n_alleles), n_alleles = 2, 3, 4
+    uint8_t* filter;  // [2][n_indels]
+    uint8_t* overlap; // [2][n_indels]
+    int n_indels;
+    int exact_libm;
+};
+
+struct ReadPprob
+{
+    float ref, indel, alt[2];
+    int32_t alt_key[2];
+    int32_t use; // the read takes part in this tier's pass
+};
+
+constexpr int MAX_SLOTS = 2 * SK_MAX_ALT_ALLELES;
+
+__global__ __launch_bounds__(WAVE) void multi_indel_allele_kernel(const MultiArgs a)
+{
+    __shared__ ReadPprob s_pp[WAVE];
+    const int ind = blockIdx.x;
+    const int lane = threadIdx.x;
+    const SkLibmTables lt = sk_libm_tables_default();
+    const int ex = a.exact_libm;
+    const sk_alt_allele* alleles = a.alt_alleles + a.alt_off[ind];
+
+    for (int tier = 0; tier < 2; ++tier) {
+        float tot_ref = 0.f, tot_indel = 0.f;
+        int n_slots = 0;
+        int32_t slot_key[MAX_SLOTS];
+        float slot_val[MAX_SLOTS];
+        for (int smp = 0; smp < 2; ++smp) {
+            const sk_readscore_batch& b = smp ? a.t : a.n;
+            const int64_t r0 = b.read_off[ind];
+            const int n = int(b.read_off[ind + 1] - r0);
+            const int first_slot = n_slots;
+            for (int base = 0; base < n; base += WAVE) {
+                const int r = base + lane;
+                if (r < n) {
+                    const int64_t g = r0 + r;
+                    ReadPprob pp;
+                    pp.use = (tier == 1) || ((b.read_flags[g] & SK_READ_TIER1) != 0);
+                    int n_in = 0;
+                    if (a.alt_key[smp][2 * g] >= 0) ++n_in;
+                    if (a.alt_key[smp][2 * g + 1] >= 0) ++n_in;
+                    const double alp = a.allele_lnprior[n_in];
+                    const double cmlp = a.correct_mapping_log_prior;
+                    float incorrect = float(__dmul_rn(a.random_base_match_log_prob[tier], double(b.non_ambig[g])));
+                    pp.ref = float(__dadd_rn(__dadd_rn(double(b.ref_lnp[g]), cmlp), alp));
+                    pp.indel = float(__dadd_rn(__dadd_rn(double(b.indel_lnp[g]), cmlp), alp));
+                    pp.alt_key[0] = pp.alt_key[1] = -1;
+                    pp.alt[0] = pp.alt[1] = 0.f;
+                    for (int k = 0; k < n_in; ++k) {
+                        pp.alt_key[k] = a.alt_key[smp][2 * g + k];
+                        pp.alt[k] = float(__dadd_rn(__dadd_rn(double(a.alt_lnp[smp][2 * g + k]), cmlp), alp));
+                    }
+                    const float m1 = (pp.ref < pp.indel) ? pp.indel : pp.ref;
+                    double scale = double((incorrect < m1) ? m1 : incorrect);
+                    for (int k = 0; k < n_in; ++k) if (scale < double(pp.alt[k])) scale = double(pp.alt[k]);
+                    incorrect = float(sk_exp(__dsub_rn(double(incorrect), scale), ex, lt));
+                    pp.ref = float(sk_exp(__dsub_rn(double(pp.ref), scale), ex, lt));
+                    pp.indel = float(sk_exp(__dsub_rn(double(pp.indel), scale), ex, lt));
+                    for (int k = 0; k < n_in; ++k) pp.alt[k] = float(sk_exp(__dsub_rn(double(pp.alt[k]), scale), ex, lt));
+                    double sum = double(__fadd_rn(__fadd_rn(incorrect, pp.ref), pp.indel));
+                    for (int k = 0; k < n_in; ++k) sum = __dadd_rn(sum, double(pp.alt[k]));
+                    pp.ref = float(__ddiv_rn(double(pp.ref), sum));
+                    pp.indel = float(__ddiv_rn(double(pp.indel), sum));
+                    for (int k = 0; k < n_in; ++k) pp.alt[k] = float(__ddiv_rn(double(pp.alt[k]), sum));
+                    s_pp[lane] = pp;
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    const int cnt = min(WAVE, n - base);
+                    for (int j = 0; j < cnt; ++j) {
+                        const ReadPprob& pp = s_pp[j];
+                        if (!pp.use) continue;
+                        tot_indel = __fadd_rn(tot_indel, pp.indel);
+                        tot_ref = __fadd_rn(tot_ref, pp.ref);
+                        for (int k = 0; k < 2; ++k) {
+                            if (pp.alt_key[k] < 0) break;
+                            int slot = -1;
+                            for (int q = first_slot; q < n_slots; ++q)
+                                if (slot_key[q] == pp.alt_key[k]) { slot = q; break; }
+                            if (slot < 0) {
+                                if (n_slots < MAX_SLOTS) {
+                                    slot_key[n_slots] = pp.alt_key[k];
+                                    slot_val[n_slots] = pp.alt[k];
+                                    ++n_slots;
+                                }
+                            } else {
+                                slot_val[slot] = __fadd_rn(slot_val[slot], pp.alt[k]);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (lane == 0) {
+            // scores: (-pprob, id) with id -2 = the indel, -1 = the reference, >= 0 = alternate slot; std::sort ascending
+            int n = 2 + n_slots;
+            double sc[MAX_SLOTS + 2];
+            int id[MAX_SLOTS + 2];
+            sc[0] = -double(tot_indel); id[0] = -2;
+            sc[1] = -double(tot_ref); id[1] = -1;
+            for (int i = 0; i < n_slots; ++i) { sc[2 + i] = -double(slot_val[i]); id[2 + i] = i; }
+            for (int i = 1; i < n; ++i) { // insertion sort on the total order of std::pair<double,int>
+                const double v = sc[i];
+                const int vi = id[i];
+                int j = i - 1;
+                while (j >= 0 && (v < sc[j] || (!(sc[j] < v) && vi < id[j]))) {
+                    sc[j + 1] = sc[j];
+                    id[j + 1] = id[j];
+                    --j;
+                }
+                sc[j + 1] = v;
+                id[j + 1] = vi;
+            }
+            while (id[0] >= 0 && id[1] >= 0) {
+                const sk_alt_allele& k1 = alleles[slot_key[id[0]]];
+                const sk_alt_allele& k2 = alleles[slot_key[id[1]]];
+                const bool either_mm = k1.is_mismatch || k2.is_mismatch; // is_indel_conflict, indel_util.cpp:27-45
+                const int e1 = k1.end_pos + (either_mm ? 0 : 1), e2 = k2.end_pos + (either_mm ? 0 : 1);
+                if ((e2 > k1.begin_pos) && (k2.begin_pos < e1)) break;
+                for (int i = 1; i + 1 < n; ++i) { sc[i] = sc[i + 1]; id[i] = id[i + 1]; }
+                --n;
+            }
+            bool filtered = (id[0] != -2) && (id[1] != -2);
+            if (!filtered && n >= 3) {
+                const double top_prob = __dadd_rn(sc[0], sc[1]);
+                const double top_frac = __ddiv_rn(top_prob, __dadd_rn(top_prob, sc[2]));
+                if (top_frac < .9) filtered = true;
+            }
+            a.filter[tier * a.n_indels + ind] = filtered ? 1 : 0;
+            a.overlap[tier * a.n_indels + ind] = (!filtered && (id[0] != -1) && (id[1] != -1)) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+// M2: skip rules, tier selection and NTYPE conflict (somatic_indel_grid.cpp:220-232, 239-254, 289-360)
+struct IndelCombineArgs
+{
+    const sk_somatic_indel_call* call[2]; // per tier: likelihoods + posterior of every indel
+    const uint8_t* filter;
+    const uint8_t* overlap;
+    const uint8_t* forced;
+    int use_tier2;
+    int n_indels;
+    sk_somatic_indel_genotype* out;
+};
+
+__global__ __launch_bounds__(256) void somatic_indel_combine_kernel(const IndelCombineArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_indels) return;
+    const bool forced = (a.forced != nullptr) && (a.forced[i] != 0);
+    struct Rs { uint32_t ntype, max_gt; int32_t qphred, from_ntype_qphred; bool is_overlap; } rs[2];
+    for (int t = 0; t < 2; ++t) { rs[t].ntype = rs[t].max_gt = 0; rs[t].qphred = rs[t].from_ntype_qphred = 0; rs[t].is_overlap = false; }
+    for (int t = 0; t < 2; ++t) {
+        if (t == 1) {
+            if (!a.use_tier2) continue;
+            if (rs[0].qphred == 0 && !forced) continue;
+        }
+        const bool filtered = a.filter[t * a.n_indels + i] != 0;
+        rs[t].is_overlap = a.overlap[t * a.n_indels + i] != 0;
+        if (filtered && !forced) continue; // (qphred stays 0)
+        const sk_somatic_indel_call& c = a.call[t][i];
+        rs[t].ntype = c.ntype;
+        rs[t].max_gt = c.max_gt;
+        rs[t].qphred = filtered ? 0 : c.qphred;
+        rs[t].from_ntype_qphred = c.from_ntype_qphred;
+    }
+    sk_somatic_indel_genotype g;
+    memset(&g, 0, sizeof(g));
+    g.is_forced_output = forced ? 1 : 0;
+    if (forced || !(rs[0].qphred == 0 || rs[1].qphred == 0)) {
+        uint8_t tier = 0, from_tier = 0;
+        if (a.use_tier2 && rs[0].qphred > rs[1].qphred) tier = 1;
+        if (a.use_tier2 && rs[0].from_ntype_qphred > rs[1].from_ntype_qphred) from_tier = 1;
+        g.sindel_tier = tier;
+        g.sindel_from_ntype_tier = from_tier;
+        g.max_gt = rs[from_tier].max_gt;
+        g.from_ntype_qphred = rs[from_tier].from_ntype_qphred;
+        g.is_overlap = rs[from_tier].is_overlap ? 1 : 0;
+        if (rs[0].ntype != rs[1].ntype) {
+            g.ntype = 3u; // NTYPE::CONFLICT
+            g.from_ntype_qphred = 0;
+        } else {
+            const uint32_t nt = rs[from_tier].ntype;
+            g.ntype = (nt == SOM_REF) ? 0u : ((nt == SOM_HOM) ? 1u : 2u);
+        }
+        g.qphred = rs[tier].qphred;
+    }
+    a.out[i] = g;
+}
+
 double h_log1p_switch(const double x)
 {
     if (std::abs(x) < 0.01) return ::log1p(x);
@@ -448,6 +662,58 @@ static size_t readscore_bytes(const sk_readscore_batch* hb)
            2 * sk_align256(4 * hb->n_indels) + sk_align256(hb->n_indels) + 16 * 256;
 }
 
+
+// per-indel shared error rate, host libm (somatic_indel_grid.cpp:273-275)
+static int upload_shared_error_rates(const double* indel_to_ref_error_prob, const int n, const sk_somatic_indel_options& sopt,
+                                     SkArena& ar, hipStream_t st, float*& dsse, float*& dcsse)
+{
+    std::vector<float> ln_sse(n), ln_csse(n);
+    for (int i = 0; i < n; ++i) {
+        const double sharedIndelErrorRate(std::pow(indel_to_ref_error_prob[i], sopt.shared_indel_error_factor));
+        ln_sse[i] = (float)std::log(sharedIndelErrorRate);
+        ln_csse[i] = (float)h_log1p_switch(-sharedIndelErrorRate);
+    }
+    dsse = ar.take<float>(n);
+    dcsse = ar.take<float>(n);
+    SK_HIP(hipMemcpy(dsse, ln_sse.data(), 4 * size_t(n), hipMemcpyHostToDevice));
+    SK_HIP(hipMemcpy(dcsse, ln_csse.data(), 4 * size_t(n), hipMemcpyHostToDevice));
+    (void)st;
+    return 0;
+}
+
+static void fill_post_args(const sk_somatic_indel_options& sopt, const double* dnl, const double* dtl, const float* dsse,
+                           const float* dcsse, sk_somatic_indel_call* dout, const int n, PostArgs& p)
+{
+    p.normal_lhood = dnl;
+    p.tumor_lhood = dtl;
+    p.ln_sse = dsse;
+    p.ln_csse = dcsse;
+    p.out = dout;
+    p.n = n;
+    std::memset(&p.d, 0, sizeof(p.d));
+    // somatic_indel_caller_grid ctor, somatic_indel_grid.cpp:58-64
+    p.d.contam_tolerance = (float)sopt.indel_contam_tolerance;
+    p.d.exact_libm = sk_ctx().libm_restated ? 1 : 0;
+    p.d.ln_som_match = h_log1p_switch(-sopt.somatic_indel_rate);
+    p.d.ln_som_mismatch = std::log(sopt.somatic_indel_rate);
+    p.d.lnprior[SOM_REF] = (float)h_log1p_switch(-(3. * sopt.bindel_diploid_theta) / 2.);
+    p.d.lnprior[SOM_HOM] = (float)std::log(sopt.bindel_diploid_theta / 2.);
+    p.d.lnprior[SOM_HET] = (float)std::log(sopt.bindel_diploid_theta);
+    volatile double half = 1. / 2., pm1 = static_cast<double>(PRESTRAND - 1);
+    p.d.ln_one_half = std::log(half);
+    p.d.log_error_mod = -std::log(pm1);
+    const float RATIO_INCREMENT = 0.5f / static_cast<float>(HET_RES + 1);
+    for (int index = 0; index < PRESTRAND; ++index) {
+        float f;
+        if (index == SOM_REF) f = 0.f;
+        else if (index == SOM_HOM) f = 1.f;
+        else if (index == SOM_HET) f = 0.5f;
+        else if (index < SOM_SIZE + HET_RES) f = RATIO_INCREMENT * (index - SOM_SIZE + 1);
+        else f = RATIO_INCREMENT * (index - SOM_SIZE + 2);
+        p.d.grid_frac[index] = f;
+    }
+}
+
 int sk_indel_grid_lhood(const sk_readscore_batch* hb, const sk_indel_options* opt, int is_include_tier2, double* out_lhood)
 {
     SK_REQUIRE_INIT();
@@ -491,54 +757,120 @@ int sk_somatic_indel_call_batch(const sk_readscore_batch* hn, const sk_readscore
     if (sk_indel_grid_lhood_dev(&dn, nopt, is_include_tier2, dnl, ctx.stream)) return 1;
     if (sk_indel_grid_lhood_dev(&dt, topt, is_include_tier2, dtl, ctx.stream)) return 1;
 
-    // per-indel shared error rate, host libm (somatic_indel_grid.cpp:273-275)
-    std::vector<float> ln_sse(n), ln_csse(n);
-    for (int i = 0; i < n; ++i) {
-        const double sharedIndelErrorRate(std::pow(indel_to_ref_error_prob[i], sopt->shared_indel_error_factor));
-        ln_sse[i] = (float)std::log(sharedIndelErrorRate);
-        ln_csse[i] = (float)h_log1p_switch(-sharedIndelErrorRate);
-    }
-    float* dsse = ar.take<float>(n);
-    float* dcsse = ar.take<float>(n);
-    SK_HIP(hipMemcpyAsync(dsse, ln_sse.data(), 4 * n, hipMemcpyHostToDevice, ctx.stream));
-    SK_HIP(hipMemcpyAsync(dcsse, ln_csse.data(), 4 * n, hipMemcpyHostToDevice, ctx.stream));
+    float *dsse = nullptr, *dcsse = nullptr;
+    if (upload_shared_error_rates(indel_to_ref_error_prob, n, *sopt, ar, ctx.stream, dsse, dcsse)) return 1;
     sk_somatic_indel_call* dout = ar.take<sk_somatic_indel_call>(n);
-
     PostArgs p;
-    p.normal_lhood = dnl;
-    p.tumor_lhood = dtl;
-    p.ln_sse = dsse;
-    p.ln_csse = dcsse;
-    p.out = dout;
-    p.n = n;
-    std::memset(&p.d, 0, sizeof(p.d));
-    // somatic_indel_caller_grid ctor, somatic_indel_grid.cpp:58-64
-    p.d.contam_tolerance = (float)sopt->indel_contam_tolerance;
-    p.d.exact_libm = sk_ctx().libm_restated ? 1 : 0;
-    p.d.ln_som_match = h_log1p_switch(-sopt->somatic_indel_rate);
-    p.d.ln_som_mismatch = std::log(sopt->somatic_indel_rate);
-    p.d.lnprior[SOM_REF] = (float)h_log1p_switch(-(3. * sopt->bindel_diploid_theta) / 2.);
-    p.d.lnprior[SOM_HOM] = (float)std::log(sopt->bindel_diploid_theta / 2.);
-    p.d.lnprior[SOM_HET] = (float)std::log(sopt->bindel_diploid_theta);
-    {
-        volatile double half = 1. / 2., pm1 = static_cast<double>(PRESTRAND - 1);
-        p.d.ln_one_half = std::log(half);
-        p.d.log_error_mod = -std::log(pm1);
-        const float RATIO_INCREMENT = 0.5f / static_cast<float>(HET_RES + 1);
-        for (int index = 0; index < PRESTRAND; ++index) {
-            float f;
-            if (index == SOM_REF) f = 0.f;
-            else if (index == SOM_HOM) f = 1.f;
-            else if (index == SOM_HET) f = 0.5f;
-            else if (index < SOM_SIZE + HET_RES) f = RATIO_INCREMENT * (index - SOM_SIZE + 1);
-            else f = RATIO_INCREMENT * (index - SOM_SIZE + 2);
-            p.d.grid_frac[index] = f;
-        }
-    }
+    fill_post_args(*sopt, dnl, dtl, dsse, dcsse, dout, n, p);
     hipLaunchKernelGGL(somatic_indel_posterior_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx.stream, p);
     SK_HIP(hipGetLastError());
     SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_indel_call) * n, hipMemcpyDeviceToHost, ctx.stream));
     SK_HIP(hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
+int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* hb, const sk_indel_options* nopt, const sk_indel_options* topt,
+                                const sk_somatic_indel_options* sopt, int use_tier2_evidence, sk_somatic_indel_genotype* out)
+{
+    SK_REQUIRE_INIT();
+    if (!hb || !nopt || !topt || !sopt || !out) return sk_fail("sk_somatic_indel_call_tiers: null argument");
+    const int n = hb->n_indels;
+    if (n <= 0) return 0;
+    if (hb->normal.n_indels != n || hb->tumor.n_indels != n) return sk_fail("sk_somatic_indel_call_tiers: n_indels differ");
+    if (!hb->normal_alt_key || !hb->normal_alt_lnp || !hb->tumor_alt_key || !hb->tumor_alt_lnp || !hb->alt_off ||
+        !hb->indel_to_ref_error_prob)
+        return sk_fail("sk_somatic_indel_call_tiers: missing array");
+    const sk_readscore_batch* smp[2] = { &hb->normal, &hb->tumor };
+    const int32_t* h_alt_key[2] = { hb->normal_alt_key, hb->tumor_alt_key };
+    for (int i = 0; i < n; ++i) {
+        const int64_t na = hb->alt_off[i + 1] - hb->alt_off[i];
+        if (na < 0 || na > SK_MAX_ALT_ALLELES) return sk_fail("sk_somatic_indel_call_tiers: more alternate alleles at one indel than SK_MAX_ALT_ALLELES");
+        for (int s = 0; s < 2; ++s)
+            for (int64_t r = smp[s]->read_off[i]; r < smp[s]->read_off[i + 1]; ++r)
+                for (int k = 0; k < 2; ++k) {
+                    const int32_t key = h_alt_key[s][2 * r + k];
+                    if (key >= na) return sk_fail("sk_somatic_indel_call_tiers: alternate-allele index out of range");
+                    if (k == 1 && key >= 0 && h_alt_key[s][2 * r] < 0) return sk_fail("sk_somatic_indel_call_tiers: alt entries must be front-packed");
+                }
+    }
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    SkArena ar;
+    const size_t lh_bytes = sizeof(double) * N_STATES * size_t(n);
+    const int64_t trn = hb->normal.read_off[n], trt = hb->tumor.read_off[n];
+    const int64_t n_alleles = hb->alt_off[n];
+    if (ar.reserve(readscore_bytes(&hb->normal) + readscore_bytes(&hb->tumor) + 2 * sk_align256(lh_bytes) + 2 * sk_align256(4 * n) +
+                   2 * sk_align256(sizeof(sk_somatic_indel_call) * n) + 2 * sk_align256(8 * size_t(trn)) + 2 * sk_align256(8 * size_t(trt)) +
+                   sk_align256(8 * (size_t(n) + 1)) + sk_align256(sizeof(sk_alt_allele) * size_t(n_alleles)) + 3 * sk_align256(2 * size_t(n)) +
+                   sk_align256(sizeof(sk_somatic_indel_genotype) * n) + 8192))
+        return 1;
+    sk_readscore_batch dn, dt;
+    if (upload_readscores(&hb->normal, ar, dn, st) || upload_readscores(&hb->tumor, ar, dt, st)) return 1;
+    double* dnl = ar.take<double>(size_t(n) * N_STATES);
+    double* dtl = ar.take<double>(size_t(n) * N_STATES);
+    float *dsse = nullptr, *dcsse = nullptr;
+    if (upload_shared_error_rates(hb->indel_to_ref_error_prob, n, *sopt, ar, st, dsse, dcsse)) return 1;
+    sk_somatic_indel_call* dcall[2] = { ar.take<sk_somatic_indel_call>(n), ar.take<sk_somatic_indel_call>(n) };
+
+    MultiArgs m;
+    m.n = dn;
+    m.t = dt;
+    auto up = [&](const void* src, const size_t bytes) -> void* {
+        void* p = ar.take<char>(bytes ? bytes : 1);
+        if (bytes) (void)hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st);
+        return p;
+    };
+    m.alt_key[0] = static_cast<const int32_t*>(up(hb->normal_alt_key, 8 * size_t(trn)));
+    m.alt_lnp[0] = static_cast<const float*>(up(hb->normal_alt_lnp, 8 * size_t(trn)));
+    m.alt_key[1] = static_cast<const int32_t*>(up(hb->tumor_alt_key, 8 * size_t(trt)));
+    m.alt_lnp[1] = static_cast<const float*>(up(hb->tumor_alt_lnp, 8 * size_t(trt)));
+    m.alt_off = static_cast<const int64_t*>(up(hb->alt_off, 8 * (size_t(n) + 1)));
+    m.alt_alleles = static_cast<const sk_alt_allele*>(up(hb->alt_alleles, sizeof(sk_alt_allele) * size_t(n_alleles)));
+    SK_HIP(hipGetLastError());
+    {
+        const MapParams m0 = make_map(*topt, false), m1 = make_map(*topt, true);
+        m.correct_mapping_log_prior = m0.correct_mapping_log_prior;
+        m.random_base_match_log_prob[0] = m0.random_base_match_log_prob;
+        m.random_base_match_log_prob[1] = m1.random_base_match_log_prob;
+        for (int k = 0; k < 3; ++k) {
+            volatile double prior = 1. / static_cast<double>(2 + k);
+            m.allele_lnprior[k] = std::log(prior);
+        }
+    }
+    uint8_t* dflags = ar.take<uint8_t>(4 * size_t(n));
+    m.filter = dflags;
+    m.overlap = dflags + 2 * size_t(n);
+    m.n_indels = n;
+    m.exact_libm = sk_ctx().libm_restated ? 1 : 0;
+    hipLaunchKernelGGL(multi_indel_allele_kernel, dim3(n), dim3(WAVE), 0, st, m);
+    SK_HIP(hipGetLastError());
+
+    for (int tier = 0; tier < 2; ++tier) {
+        if (tier == 1 && !use_tier2_evidence) break;
+        if (sk_indel_grid_lhood_dev(&dn, nopt, tier, dnl, st)) return 1;
+        if (sk_indel_grid_lhood_dev(&dt, topt, tier, dtl, st)) return 1;
+        PostArgs p;
+        fill_post_args(*sopt, dnl, dtl, dsse, dcsse, dcall[tier], n, p);
+        hipLaunchKernelGGL(somatic_indel_posterior_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p);
+        SK_HIP(hipGetLastError());
+    }
+    uint8_t* dforced = nullptr;
+    if (hb->is_forced_output) dforced = static_cast<uint8_t*>(up(hb->is_forced_output, size_t(n)));
+    sk_somatic_indel_genotype* dout = ar.take<sk_somatic_indel_genotype>(n);
+    IndelCombineArgs c;
+    c.call[0] = dcall[0];
+    c.call[1] = dcall[1];
+    c.filter = m.filter;
+    c.overlap = m.overlap;
+    c.forced = dforced;
+    c.use_tier2 = use_tier2_evidence ? 1 : 0;
+    c.n_indels = n;
+    c.out = dout;
+    hipLaunchKernelGGL(somatic_indel_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c);
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_indel_genotype) * size_t(n), hipMemcpyDeviceToHost, st));
+    SK_HIP(hipStreamSynchronize(st));
     return 0;
 }
 

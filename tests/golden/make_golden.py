@@ -319,8 +319,27 @@ def somatic_tiers_golden():
         (v["qphred"] > 0).sum(), (v["snv_tier"] == 1).sum(), (v["ntype"] == 3).sum()) for v in out.values()))
 
 
+def somatic_indel_tiers_golden():
+    """row a14 complete: the reference's own get_somatic_indel (multi-indel-allele filter, both tiers, tier combination)
+    on seeded cases; the error rate the reference attached to each key is recorded with its record"""
+    pyoracle.build(ref=True)
+    from tests import test_somatic_tiers as T
+    out = {}
+    for seed in T.INDEL_SEEDS:
+        cases = synth.somatic_indel_cases(500, np.random.default_rng(seed))
+        rec, used = pyoracle.get_somatic_indel(cases, use_reference=True)
+        out["rec%d" % seed] = rec
+        out["err%d" % seed] = used
+        print("somatic indel golden seed %d: %d calls, %d tier2-chosen, %d overlap, %d conflicts, %d forced" % (
+            seed, (rec["qphred"] > 0).sum(), (rec["sindel_tier"] == 1).sum(), (rec["is_overlap"] == 1).sum(),
+            (rec["ntype"] == 3).sum(), (rec["is_forced_output"] == 1).sum()))
+    np.savez_compressed(T.INDEL_GOLDEN, **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "somatic_indel_tiers"):
+        somatic_indel_tiers_golden()
     if what in ("all", "somatic_tiers"):
         somatic_tiers_golden()
     if what in ("all", "main"):

@@ -59,3 +59,41 @@ def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
 @pytest.mark.parametrize("windows", [None, (7, 13)])
 def test_germline_demo_identical_through_adapter_gpu(tmp_path, windows):
     _germline("amd", tmp_path, windows)
+
+
+def _somatic(variant, tmp_path, windows=None, callable_regions=False):
+    ref_out, out = str(tmp_path / "ref") + "/", str(tmp_path / variant) + "/"
+    (tmp_path / "ref").mkdir(exist_ok=True)
+    (tmp_path / variant).mkdir(exist_ok=True)
+    normal, tumor = E.demo("NA12892_demo20.bam"), E.demo("NA12891_demo20.bam")
+    extra = lambda o: (["--somatic-callable-regions-file", o + "somatic.callable.regions.bed"] if callable_regions else [])
+    E.run(E.somatic_argv("strelka2_ref", ref_out, normal, tumor, extra=extra(ref_out)))
+    env = {"STRELKA_AMD_VERBOSE": "1"}
+    if windows:
+        env["STRELKA_AMD_READ_WINDOW"], env["STRELKA_AMD_SITE_WINDOW"] = str(windows[0]), str(windows[1])
+    p = E.run(E.somatic_argv("strelka2_" + variant, out, normal, tumor, extra=extra(out)), env=env)
+    c = _counters(p.stderr.decode())
+    assert c["realign_reads"] > 1000 and c["site_loci"] > 3000 and c["indel_groups"] >= 1
+    files = ["somatic.snvs.vcf", "somatic.indels.vcf"] + (["somatic.callable.regions.bed"] if callable_regions else [])
+    for f in files:
+        want, got = E.vcf_body(ref_out + f, keep_header=True), E.vcf_body(out + f, keep_header=True)
+        assert len(want) > 10
+        assert got == want, f
+    # ... and both equal what the reference ships (src/demo/expectedResults)
+    if not callable_regions:
+        for kind in ("snvs", "indels"):
+            assert E.vcf_body(out + "somatic.%s.vcf" % kind) == E.vcf_body(E.demo("somatic.%s.vcf.gz" % kind))
+    return c
+
+
+@pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("windows,callable_regions", [(None, False), ((0, 0), False), ((5, 9), True), ((1000, 3000), True)])
+def test_somatic_demo_identical_through_adapter_cpu_double(tmp_path, windows, callable_regions):
+    _somatic("dbl", tmp_path, windows, callable_regions)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_amd"), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("windows,callable_regions", [(None, False), ((5, 9), True)])
+def test_somatic_demo_identical_through_adapter_gpu(tmp_path, windows, callable_regions):
+    _somatic("amd", tmp_path, windows, callable_regions)

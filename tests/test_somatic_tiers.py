@@ -88,3 +88,62 @@ def test_gpu_equals_golden_reference():
     g = np.load(GOLDEN)
     for ci, case in enumerate(CASES):
         same(run(capi.somatic_snv_call_tiers, scenario(1000 + ci), case), g["case%d" % ci])
+
+
+# ---- a14 complete: the whole of somatic_indel_caller_grid::get_somatic_indel (somatic_indel_grid.cpp:181-361) -----------------
+
+INDEL_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "somatic_indel_tiers_reference.npz")
+
+
+def indel_cases(seed, n=500):
+    """seeded cases; the tumour sample's indelToRef error rate of every case is the one the reference's own error model
+    attached to the key (recorded in the golden file), so restatement and kernels get the reference's value"""
+    cases = synth.somatic_indel_cases(n, np.random.default_rng(seed))
+    g = np.load(INDEL_GOLDEN)
+    if "err%d" % seed in g:
+        for c, e in zip(cases, g["err%d" % seed]):
+            c["indel_to_ref_error_prob"] = float(e)
+    return cases
+
+
+INDEL_SEEDS = (41, 42)
+
+
+@pytest.mark.parametrize("seed", INDEL_SEEDS)
+def test_indel_restatement_equals_golden(seed):
+    g = np.load(INDEL_GOLDEN)
+    got, _ = pyoracle.get_somatic_indel(indel_cases(seed))
+    want = g["rec%d" % seed]
+    assert got.tobytes() == want.tobytes()
+    assert (want["qphred"] > 0).sum() > 100 and (want["sindel_tier"] == 1).sum() > 5 and (want["is_forced_output"] == 1).sum() > 20
+    assert (want["is_overlap"] == 1).sum() + (g["rec%d" % INDEL_SEEDS[0]]["is_overlap"] == 1).sum() > 0
+
+
+@pytest.mark.skipif(not pyoracle.ref_available(), reason="oracle/_ref not built")
+def test_indel_restatement_equals_live_reference():
+    cases = synth.somatic_indel_cases(300, np.random.default_rng(77))
+    want, used = pyoracle.get_somatic_indel(cases, use_reference=True)
+    for c, e in zip(cases, used):
+        c["indel_to_ref_error_prob"] = float(e)
+    got, _ = pyoracle.get_somatic_indel(cases)
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", INDEL_SEEDS)
+def test_indel_gpu_equals_golden_reference_bytes(seed):
+    capi.init(0)
+    assert capi.lib().sk_libm_restated() == 1
+    g = np.load(INDEL_GOLDEN)
+    got = capi.somatic_indel_call_tiers(indel_cases(seed))
+    assert got.tobytes() == g["rec%d" % seed].tobytes()
+
+
+@pytest.mark.gpu
+def test_indel_gpu_equals_restatement_fresh_seeds():
+    capi.init(0)
+    for seed in (901, 902, 903):
+        cases = synth.somatic_indel_cases(2000, np.random.default_rng(seed))
+        want, _ = pyoracle.get_somatic_indel(cases)
+        got = capi.somatic_indel_call_tiers(cases)
+        assert got.tobytes() == want.tobytes(), seed
