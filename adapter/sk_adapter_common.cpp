@@ -36,16 +36,18 @@ void init()
     // segment process -> device: pyflow starts one process per genome segment; the launcher (or the workflow's task
     // wrapper) exports STRELKA_AMD_DEVICE = segment index mod number of GPUs.  Many processes may share a device.
     const int device(static_cast<int>(env_unsigned("STRELKA_AMD_DEVICE", 0)));
-    check(sk_init(device), "sk_init");
-    if (sk_libm_restated() != 1)
+    // byte-identical VCFs need the kernels' restated libm routines to be the host's: strict by default
+    if (env_unsigned("STRELKA_AMD_ALLOW_INEXACT_LIBM", 0) == 0)
     {
-        // byte-identical VCFs need the kernels' restated libm routines to be the host's
-        if (env_unsigned("STRELKA_AMD_ALLOW_INEXACT_LIBM", 0) == 0)
+        check(sk_init_strict(device), "sk_init_strict");
+    }
+    else
+    {
+        check(sk_init(device), "sk_init");
+        if (sk_libm_restated() != 1)
         {
-            throw blt_exception("strelka_amd: the host C library is not the one the kernels restate (sk_libm_restated()==0); "
-                                "results would agree with the reference only to 1e-5. Set STRELKA_AMD_ALLOW_INEXACT_LIBM=1 to run anyway.");
+            log_os << "WARNING: strelka_amd runs with the device math library; outputs may differ from the reference in the last digit\n";
         }
-        log_os << "WARNING: strelka_amd runs with the device math library; outputs may differ from the reference in the last digit\n";
     }
     done = true;
 }

@@ -38,6 +38,9 @@ extern "C" {
  *  L/applications/strelka/position_somatic_snv_strand_grid_lhood_cached.cpp:41-234) and upload them.
  *  Idempotent for the same device. */
 int sk_init(int device);
+/** sk_init, but fails when the host C library is not the one the kernels restate (sk_libm_restated() would be 0): for
+ *  callers that must guarantee results bit-identical to the reference (the adapter, smoke(), bench.py). */
+int sk_init_strict(int device);
 void sk_shutdown(void);
 const char* sk_last_error(void);
 int sk_version(void);
@@ -47,6 +50,17 @@ int sk_is_initialized(void);
  *  strelka_amd/csrc/libm_flt32.h): the dependent error probabilities and germline likelihoods are then bit-identical to
  *  the reference's; 0: the device library's pow/log stand in (agreement to 1e-5 relative). */
 int sk_libm_restated(void);
+
+/** The `*_dev` entry points only enqueue work and cannot validate device-resident input the way the host-buffer entry
+ *  points do.  Where the reference would throw on such input (a basecall quality above 70, qscore_cache.cpp:53-75), the
+ *  kernel raises a sticky device flag instead of returning a plausible number; this call synchronises the device, returns
+ *  non-zero with the reference's message in sk_last_error() if a flag is up, and clears it. */
+int sk_check_device_errors(void);
+
+/** Test hook: on != 0 makes every kernel take the path it takes on a host whose libm is NOT the restated one (the device
+ *  math library's double routines stand in; sk_libm_restated() then reports 0); on == 0 restores the sk_init outcome.
+ *  Lets the test suite measure the documented 1e-5 bar of that path on a box where the exact path is available. */
+int sk_debug_force_device_libm(int on);
 
 /** Host copies of the q-score tables the kernels use (71 entries each, Q0..Q70; L/blt_util/qscore_cache.hh:66-68). */
 int sk_get_qscore_tables(double* q2p, double* q2lncompe, double* q2lne);
@@ -158,6 +172,9 @@ int sk_align_builder_append(sk_align_builder* dst, const sk_align_builder* src);
 int sk_align_builder_add_read(sk_align_builder* b, const uint8_t* read_code, const uint8_t* read_qual, int32_t read_len,
                               const char* ref_seq, int32_t ref_offset, int32_t ref_len,
                               const sk_candidate_alignment* cals, int32_t n_cals);
+/** Host threads sk_align_builder_finish may use to compile the batch's transition entries: 1 = none (default -- the
+ *  reference runs one process per core), n = up to n, 0 = up to 16 hardware threads. */
+int sk_align_builder_set_host_threads(sk_align_builder* b, int32_t host_threads);
 /** Fill `out` with HOST pointers into the builder (valid until the next clear/add/destroy). */
 int sk_align_builder_finish(sk_align_builder* b, sk_align_batch* out);
 /** error text of the last failing builder call */

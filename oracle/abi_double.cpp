@@ -46,6 +46,9 @@ static void to_sko(const sk_germline_options* o, sko_germline_options* g)
 extern "C" {
 
 int sk_init(int) { g_ready = true; return 0; }
+int sk_init_strict(int) { g_ready = true; return 0; }
+int sk_check_device_errors(void) { return 0; }
+int sk_debug_force_device_libm(int) { return 0; }
 void sk_shutdown(void) { g_ready = false; }
 const char* sk_last_error(void) { return g_err.c_str(); }
 int sk_version(void) { return SK_VERSION; }

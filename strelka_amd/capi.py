@@ -178,10 +178,10 @@ assert DIGT_CALL_DTYPE.itemsize == 144 and SOMATIC_CALL_DTYPE.itemsize == 272
 
 # every symbol include/strelka_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "sk_init", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_libm_restated", "sk_get_qscore_tables",
+    "sk_init", "sk_init_strict", "sk_check_device_errors", "sk_debug_force_device_libm", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_libm_restated", "sk_get_qscore_tables",
     "sk_score_alignments", "sk_score_alignments_dev", "sk_align_evmask_words", "sk_align_prepare",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_append", "sk_align_builder_add_read",
-    "sk_align_builder_finish", "sk_align_builder_error",
+    "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
@@ -292,6 +292,11 @@ def _check(rc):
 
 def init(device=0):
     _check(lib().sk_init(int(device)))
+
+
+def init_strict(device=0):
+    """sk_init_strict: also fails when the host libm is not the one the kernels restate (no bit-exactness otherwise)"""
+    _check(lib().sk_init_strict(int(device)))
 
 
 def shutdown():

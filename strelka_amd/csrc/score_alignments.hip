@@ -58,6 +58,7 @@ struct ScoreArgs
     double* out;
     int lds_tab_bytes; // per wave: ROW_BYTES * maxL
     int lds_hap_bytes; // per wave: align16(maxP + maxL + 8)  (pool columns + the 0.0-column run)
+    unsigned* err;     // SkContext::dev_error_flags
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -82,7 +83,10 @@ __device__ double score_one_generic(const ScoreArgs& a, const int r, const int c
                 const unsigned rc = a.b.read_code[ro + rp + j];
                 if (rc == SK_BAM_ANY) continue;
                 unsigned q = a.b.read_qual[ro + rp + j];
-                q = q > 70u ? 70u : q;
+                if (q > 70u) { // the reference throws (qscore_cache.cpp:53-75): flag it, sk_check_device_errors reports it
+                    atomicOr(a.err, unsigned(SK_DEVERR_QSCORE));
+                    q = 70u;
+                }
                 const bool is_ref = (rc == SK_BAM_REF) || (rc == a.b.hap_code[ho + op.src + j]);
                 lnp = dadd(lnp, is_ref ? T->q2lncompe[q] : T->q2mis[q]);
             }
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(con
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (rqv[u] > 70u) atomicOr(a.err, unsigned(SK_DEVERR_QSCORE)); // see score_one_generic
                 const unsigned q = rqv[u] > 70u ? 70u : rqv[u];
                 Mv[u] = T->q2lncompe[q];
                 Xv[u] = T->q2mis[q];
@@ -315,6 +320,7 @@ extern "C" int sk_score_alignments_dev(const sk_align_batch* b, double* dev_out_
     a.b = *b;
     a.tab = sk_ctx().dev_tables;
     a.out = dev_out_lnp;
+    a.err = sk_ctx().dev_error_flags;
     const int maxL = b->max_read_len, maxP = b->max_hap_len;
     a.lds_tab_bytes = align16(ROW_BYTES * std::max(maxL, 1));
     a.lds_hap_bytes = align16(std::max(maxP, 0) + std::max(maxL, 1) + 8);

@@ -53,7 +53,10 @@ struct SkContext
     // staging arena for the host-buffer entry points (grown on demand, never shrunk)
     void* arena = nullptr;
     size_t arena_bytes = 0;
+    // sticky error bits raised by kernels on input the reference would have thrown on (sk_check_device_errors)
+    unsigned* dev_error_flags = nullptr;
 };
+enum { SK_DEVERR_QSCORE = 1u }; // a basecall quality above 70 reached a scoring kernel (qscore_cache.cpp:53-75 throws)
 
 SkContext& sk_ctx();
 void sk_set_error(const std::string& msg);

@@ -204,6 +204,8 @@ int sk_init(int device)
     SK_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev_tables), sizeof(SkTables)));
     SK_HIP(hipMemcpy(c.dev_tables, &c.host_tables, sizeof(SkTables), hipMemcpyHostToDevice));
     SK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    SK_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev_error_flags), sizeof(unsigned)));
+    SK_HIP(hipMemset(c.dev_error_flags, 0, sizeof(unsigned)));
     c.device = device;
     c.ready = true;
     return 0;
@@ -216,8 +218,42 @@ void sk_shutdown(void)
     (void)hipSetDevice(c.device);
     if (c.stream) (void)hipStreamDestroy(c.stream);
     if (c.dev_tables) (void)hipFree(c.dev_tables);
+    if (c.dev_error_flags) (void)hipFree(c.dev_error_flags);
     if (c.arena) (void)hipFree(c.arena);
     c = SkContext();
+}
+
+int sk_check_device_errors(void)
+{
+    SK_REQUIRE_INIT();
+    SkContext& c = sk_ctx();
+    SK_HIP(hipSetDevice(c.device));
+    unsigned flags = 0;
+    SK_HIP(hipMemcpy(&flags, c.dev_error_flags, sizeof(unsigned), hipMemcpyDeviceToHost)); // synchronises the device
+    if (flags == 0) return 0;
+    SK_HIP(hipMemset(c.dev_error_flags, 0, sizeof(unsigned)));
+    if (flags & SK_DEVERR_QSCORE)
+        return sk_fail("Attempting to lookup basecall quality score which exceeds the maximum cached score of 70 (seen by a *_dev kernel)");
+    return sk_fail("strelka_amd: a kernel reported an error");
+}
+
+int sk_debug_force_device_libm(int on)
+{
+    SK_REQUIRE_INIT();
+    SkContext& c = sk_ctx();
+    c.libm_restated = on ? false : host_libm_matches_restatement();
+    return 0;
+}
+
+int sk_init_strict(int device)
+{
+    if (sk_init(device)) return 1;
+    if (!sk_ctx().libm_restated) {
+        sk_shutdown();
+        return sk_fail("strelka_amd: the host C library is not the one the kernels restate (glibc >= 2.28 x86-64 FMA build "
+                       "expected): results would agree with the reference only to 1e-5, not bit for bit");
+    }
+    return 0;
 }
 
 int sk_get_qscore_tables(double* q2p, double* q2lncompe, double* q2lne)

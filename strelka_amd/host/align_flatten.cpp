@@ -51,6 +51,7 @@ struct sk_align_builder
     std::vector<sk_score_op> ops;
     std::vector<uint32_t> entries, evmask; // prepared form, filled by finish
     int32_t max_read_len = 0, max_hap_len = 0;
+    int32_t host_threads = 1; // budget of finish()'s prepare step (sk_align_builder_set_host_threads)
     std::string error;
 
     void clear()
@@ -323,14 +324,16 @@ int sk_align_builder_add_read(sk_align_builder* b, const uint8_t* read_code, con
 
 int32_t sk_align_evmask_words(const int32_t max_read_len) { return sk_ent_evmask_words(max_read_len < 0 ? 0 : max_read_len); }
 
-// ops -> transition entries + per-read event masks (layout: csrc/align_entry.h)
-int sk_align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* evmask)
+// ops -> transition entries + per-read event masks (layout: csrc/align_entry.h).  `host_threads`: 1 = this thread only
+// (the default everywhere: the reference runs one process per core), n = up to n threads, 0 = up to 16 hardware threads;
+// reads are independent (each owns its entry slots and its mask words), so large batches split by read.
+static int align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* evmask, const int host_threads)
 {
     if (!b || !entries || !evmask || b->n_reads < 0) return 1;
     const int W = sk_ent_evmask_words(b->max_read_len);
-    // reads are independent (each owns its entry slots and its mask words): large batches are split over host threads
-    const int threads = int(std::max<int64_t>(1, std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
-                                                                    int64_t(b->n_reads) / 4096)));
+    const int64_t budget = (host_threads == 0) ? int64_t(std::min(16u, std::max(1u, std::thread::hardware_concurrency())))
+                                               : int64_t(std::max(1, host_threads));
+    const int threads = int(std::max<int64_t>(1, std::min<int64_t>(budget, int64_t(b->n_reads) / 4096)));
     auto slice = [&](const int r_begin, const int r_end) {
     for (int r = r_begin; r < r_end; ++r) {
         const int64_t L64 = b->read_off[r + 1] - b->read_off[r], P64 = b->hap_off[r + 1] - b->hap_off[r];
@@ -405,6 +408,15 @@ int sk_align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* evmas
     return 0;
 }
 
+int sk_align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* evmask) { return align_prepare(b, entries, evmask, 1); }
+
+int sk_align_builder_set_host_threads(sk_align_builder* b, const int32_t host_threads)
+{
+    if (!b || host_threads < 0) return 1;
+    b->host_threads = host_threads;
+    return 0;
+}
+
 int sk_align_builder_finish(sk_align_builder* b, sk_align_batch* out)
 {
     if (!b || !out) return 1;
@@ -427,7 +439,7 @@ int sk_align_builder_finish(sk_align_builder* b, sk_align_batch* out)
     b->evmask.assign(size_t(out->n_reads) * size_t(out->evmask_words) + 1, 0u);
     out->entries = nullptr;
     out->evmask = nullptr;
-    if (sk_align_prepare(out, b->entries.data(), b->evmask.data())) return 1;
+    if (align_prepare(out, b->entries.data(), b->evmask.data(), b->host_threads)) return 1;
     out->entries = b->entries.data();
     out->evmask = b->evmask.data();
     return 0;

@@ -1775,7 +1775,10 @@ namespace
 // so reads can be prepared concurrently.  Throws Fail.
 void prepare_read(const Job& job, const sk_read_input* in, sk_realign_job::Read& rd)
 {
-    if (in->read_len < 0 || in->n_seg < 0) throw Fail("negative read or path length");
+    if (in->read_len < 0 || in->n_seg < 0 || in->n_observed < 0) throw Fail("negative read, path or observed-list length");
+    if ((in->read_len > 0 && (in->read_code == nullptr || in->read_qual == nullptr)) || (in->n_seg > 0 && in->path == nullptr) ||
+        (in->n_observed > 0 && in->observed == nullptr))
+        throw Fail("null read_code / read_qual / path / observed pointer with a positive length");
     if (in->sample_index < 0 || in->sample_index >= job.opt.sample_count) throw Fail("sample_index out of range");
     rd.code.assign(in->read_code, in->read_code + in->read_len);
     rd.qual.assign(in->read_qual, in->read_qual + in->read_len);
@@ -1783,7 +1786,13 @@ void prepare_read(const Job& job, const sk_read_input* in, sk_realign_job::Read&
     rd.sample = in->sample_index;
     rd.input.pos = in->pos;
     rd.input.fwd = in->is_fwd_strand != 0;
-    for (int i = 0; i < in->n_seg; ++i) rd.input.path.push_back(Seg{ in->path[i].type, in->path[i].length });
+    for (int i = 0; i < in->n_seg; ++i) {
+        // the reference cuts a read with SKIP segments into exon segments realigned with pinned edges
+        // (get_segment_edge_pin, starling_read_align.cpp:1711-1737): that RNA path is not built, say so instead of
+        // realigning the read as if it were one DNA segment
+        if (in->path[i].type == SK_SEG_SKIP) throw Fail("spliced (RNA) read: SKIP segments / exon pins are not supported on this path");
+        rd.input.path.push_back(Seg{ in->path[i].type, in->path[i].length });
+    }
     if (rd.input.empty() || path_read_length(rd.input.path) != unsigned(in->read_len))
         throw Fail("invalid alignment path associated with read segment"); // realignAndScoreRead :2036-2040
     std::set<int> observed;
@@ -1957,10 +1966,22 @@ int sk_realign_job_add_reads(sk_realign_job* j, const sk_read_input* in, int32_t
     }
 }
 
+// flatten the job's batch; the prepare step inside gets the job's thread budget and its error text reaches the job
+static int finish_builder(sk_realign_job* j, sk_align_batch* out)
+{
+    sk_align_builder_set_host_threads(j->builder, j->opt.host_threads);
+    if (sk_align_builder_finish(j->builder, out)) {
+        const char* e = sk_align_builder_error(j->builder);
+        j->error = (e && *e) ? e : "sk_align_builder_finish failed";
+        return 1;
+    }
+    return 0;
+}
+
 int sk_realign_job_get_batch(sk_realign_job* j, sk_align_batch* out)
 {
     if (!j || !out) return 1;
-    return sk_align_builder_finish(j->builder, out);
+    return finish_builder(j, out);
 }
 
 int sk_realign_job_finish(sk_realign_job* j, const double* scores)
@@ -1996,7 +2017,7 @@ int sk_realign_job_run(sk_realign_job* j)
 {
     if (!j) return 1;
     sk_align_batch b;
-    if (sk_align_builder_finish(j->builder, &b)) return 1;
+    if (finish_builder(j, &b)) return 1;
     std::vector<double> scores(size_t(b.n_cals));
     if (b.n_cals > 0 && sk_score_alignments(&b, scores.data()) != 0) {
         j->error = sk_last_error();

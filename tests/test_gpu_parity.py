@@ -199,8 +199,7 @@ def test_site_digt_call_fused_equals_two_step(gpu):
     assert np.array_equal(de1.view(np.uint32), want_de.view(np.uint32))
     want = pyoracle.site_digt_call(pb, want_de)
     assert np.array_equal(fused["lhood"].view(np.uint32), want["lhood"].view(np.uint32))
-    assert np.mean(fused["genome"]["max_gt"] == want["genome"]["max_gt"]) > 0.9999
-    assert np.abs(fused["genome"]["snp_qphred"] - want["genome"]["snp_qphred"]).max() <= 1
+    assert fused.tobytes() == want.tobytes()
 
 
 def test_site_digt_call_fused_nondefault_options(gpu):
@@ -298,13 +297,11 @@ def test_pileup_edge_cases(gpu):
     pb = capi.HostPileupBatch(off, calls, np.array([0, 0, 1, 4, 2], np.uint8))
     de = gpu.dependent_eprob(pb)
     want_de = pyoracle.adjust_joint_eprob(pb)
-    assert np.allclose(de, want_de, rtol=1e-5)
+    assert np.array_equal(de.view(np.uint32), want_de.view(np.uint32))
     pb.de = want_de
     got = gpu.site_digt_call(pb)
     want = pyoracle.site_digt_call(pb, want_de)
-    assert np.array_equal(got["is_called"], want["is_called"])
-    assert close_ll(got["lhood"], want["lhood"])
-    assert np.array_equal(got["genome"]["max_gt"], want["genome"]["max_gt"])
+    assert got.tobytes() == want.tobytes()
 
 
 # ---------------------------------------------------------------------------------------------------- hot path B, indels
