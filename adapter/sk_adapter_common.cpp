@@ -173,9 +173,13 @@ void on_set_head_pos(starling_pos_processor_base& /*pp*/, const pos_t pos, const
 {
     GeometryShadow& g(state().geometry);
     g.onSetHeadPos(pos, readBufferShift, indelSpan);
-    // segments behind the real (deferred) READ_BUFFER stage are no longer needed
-    const pos_t done(pos - static_cast<pos_t>(readBufferShift + read_buffer_defer()) - 1);
-    while (g.segments.size() > 1 && g.segments.front().upto < done) g.segments.pop_front();
+    // segments behind the windows already realigned are no longer needed (the deferred READ_BUFFER stage has yet to visit
+    // everything from realignedTo on -- during this very head advance, too)
+    State& s(state());
+    if (s.isAnyRealigned)
+    {
+        while (g.segments.size() > 1 && g.segments.front().upto < s.realignedTo) g.segments.pop_front();
+    }
 }
 
 unsigned buffered_read_count(const starling_pos_processor_base& /*pp*/, const unsigned sampleIndex, const unsigned /*actualCount*/)

@@ -130,7 +130,14 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
             if (k.is_breakpoint()) throw blt_exception("strelka_amd adapter: open-ended breakpoint alleles are not supported on this path");
             sk_indel_info e;
             std::memset(&e, 0, sizeof(e));
-            toIndelKey(k, indelBuffer.isCandidateIndel(k, d), e.key);
+            // candidate status as of now, WITHOUT committing it to the IndelBuffer's cache: the reference computes and caches
+            // an indel's status when a read first asks for it (IndelBuffer.hh:153-164), and most indels of this table are
+            // never asked about by this window's reads -- those keep their status open, as in the reference, until the
+            // window (or the caller stage) that does ask (the commit is after the job, below)
+            const IndelData::status_t savedStatus(d.status);
+            const bool isCandidate(indelBuffer.isCandidateIndel(k, d));
+            d.status = savedStatus;
+            toIndelKey(k, isCandidate, e.key);
             const IndelSampleData& isd(d.getSampleData(sampleIndex));
             e.ref_to_indel_log_prob = isd.getErrorRates().refToIndelErrorProb.getLogValue();
             e.indel_to_ref_log_prob = isd.getErrorRates().indelToRefErrorProb.getLogValue();
@@ -228,6 +235,16 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
     jobCheck(sk_realign_job_run(job), "sk_realign_job_run");
     s.realignBatches++;
     s.realignReads += reads.size();
+
+    // commit the candidate status of the indels the job's reads asked about
+    {
+        std::vector<uint8_t> consulted(table.size() + 1, 0);
+        jobCheck(sk_realign_job_indels_consulted(job, consulted.data(), static_cast<int32_t>(table.size())), "sk_realign_job_indels_consulted");
+        for (size_t i(0); i < table.size(); ++i)
+        {
+            if (consulted[i]) (void)indelBuffer.isCandidateIndel(*keys[i], *data[i]);
+        }
+    }
 
     // ---- results, written where the reference writes them ----
     const bool isMaxToggleWarnEnabled(opt.verbosity >= LOG_LEVEL::ALLWARN);

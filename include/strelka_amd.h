@@ -293,6 +293,12 @@ int sk_realign_job_finish(sk_realign_job* job, const double* scores);
 int sk_realign_job_run(sk_realign_job* job);
 int sk_realign_job_n_reads(const sk_realign_job* job);
 int sk_realign_job_read_result(const sk_realign_job* job, int32_t read_index, sk_read_result* out);
+/** out[i] = 1 when the candidate status (sk_indel_key.is_candidate) of indel i of the table -- as given to set_indels -- was
+ *  consulted by any read of the job so far, at the places where the reference calls IndelBuffer::isCandidateIndel.  The
+ *  reference computes and caches an indel's candidate status at its first such call (L/starling_common/IndelBuffer.hh:
+ *  153-164); an adapter that had to evaluate the status of every indel of the table up front does that without caching and
+ *  commits the cache only for the indels reported here, so that it caches what the reference would have. */
+int sk_realign_job_indels_consulted(const sk_realign_job* job, uint8_t* out, int32_t n_indels);
 /** drop reads and results, keep reference/indels/options */
 void sk_realign_job_clear_reads(sk_realign_job* job);
 

@@ -14,10 +14,12 @@
 #include "strelka_amd.h"
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <thread>
 #include <stdexcept>
@@ -420,6 +422,16 @@ struct sk_realign_job
     int32_t ref_offset = 0;
     std::vector<Indel> tab;       // IndelKey order
     std::vector<int> orig_to_tab; // index as given -> table index
+    // which table entries had their candidate status consulted -- the places below that read it are the places where the
+    // reference calls IndelBuffer::isCandidateIndel, whose first call per indel computes and caches the status
+    // (IndelBuffer.hh:153-164): a caller that evaluated the status of more indels than the reference would have, earlier
+    // than it would have, must only commit the ones the reference would have touched (sk_realign_job_indels_consulted)
+    mutable std::unique_ptr<std::atomic<uint8_t>[]> consulted;
+    bool cand(const int i) const
+    {
+        consulted[size_t(i)].store(1, std::memory_order_relaxed);
+        return tab[size_t(i)].cand;
+    }
     std::vector<unsigned> max_toggle; // starling_align_limit
     std::string error;
 
@@ -752,7 +764,7 @@ struct SearchCtx
 
 bool is_usable_indel(const SearchCtx& c, int i) // :289-305
 {
-    return c.job.tab[i].cand || c.observed.count(i) > 0;
+    return c.job.cand(i) || c.observed.count(i) > 0;
 }
 
 // add_indels_in_range :311-366
@@ -1178,7 +1190,7 @@ PathInfo path_info(const Path& p)
 unsigned candidate_indel_count(const Job& job, const Cal& c) // :1325-1337
 {
     unsigned v = 0;
-    for (int i : c.indels) if (job.tab[i].cand) ++v;
+    for (int i : c.indels) if (job.cand(i)) ++v;
     return v;
 }
 bool first_cal_preferred(const Job& job, const Cal& c1, const Cal& c2) // isFirstCandidateAlignmentPreferred :1351-1376
@@ -1409,7 +1421,7 @@ void late_indel_normalization_filter(const Job& job, const sk_realign_job::Read&
             bool s1_removed = false, removed = false;
             for (const auto& pr : pairs) {
                 // is_first_indel_dominant :276-292
-                const bool c1 = job.tab[pr.first].cand, c2 = job.tab[pr.second].cand;
+                const bool c1 = job.cand(pr.first), c2 = job.cand(pr.second);
                 bool first_dom;
                 if (c2 && !c1) first_dom = false;
                 else if (c2 == c1) first_dom = (job.key(pr.first).pos <= job.key(pr.second).pos);
@@ -1490,7 +1502,7 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
         for (int e = it.first; e < it.second; ++e) {
             const Key& k = job.key(e);
             if (k.is_mismatch()) continue;
-            if (!job.tab[e].cand) continue;
+            if (!job.cand(e)) continue;
             const bool in_max = iset_has(mc.indels, e);
             const Cal* best = nullptr;
             if (in_max) {
@@ -1642,7 +1654,7 @@ void cal_to_c(const Job& job, const Cal& c, std::vector<sk_path_seg>& segs, std:
         k.del_len = d.key.del;
         k.ins_len = d.key.ins_len();
         k.ins_seq = d.key.ins.c_str();
-        k.is_candidate = d.cand ? 1 : 0;
+        k.is_candidate = job.cand(i) ? 1 : 0; // scoreCandidateAlignment asks for every indel of the alignment (:471-487)
         return k;
     };
     for (int i : c.indels) keys.push_back(mk(i));
@@ -1749,8 +1761,18 @@ int sk_realign_job_set_indels(sk_realign_job* j, const sk_indel_info* indels, in
             return 1;
         }
     j->tab.swap(t);
+    j->consulted.reset(new std::atomic<uint8_t>[j->tab.size() + 1]);
+    for (size_t i = 0; i <= j->tab.size(); ++i) j->consulted[i].store(0, std::memory_order_relaxed);
     j->orig_to_tab.assign(size_t(n), -1);
     for (size_t i = 0; i < j->tab.size(); ++i) j->orig_to_tab[size_t(j->tab[i].orig)] = int(i);
+    return 0;
+}
+
+int sk_realign_job_indels_consulted(const sk_realign_job* j, uint8_t* out, int32_t n_indels)
+{
+    if (!j || !out || n_indels != int32_t(j->orig_to_tab.size())) return 1;
+    for (int32_t i = 0; i < n_indels; ++i)
+        out[i] = j->consulted ? j->consulted[size_t(j->orig_to_tab[size_t(i)])].load(std::memory_order_relaxed) : 0;
     return 0;
 }
 
@@ -1812,7 +1834,7 @@ void prepare_read(const Job& job, const sk_read_input* in, sk_realign_job::Read&
             const auto it = job.range_iter(rr.b, rr.e);
             for (int i = it.first; i < it.second; ++i) {
                 if (!range_intersect_indel_breakpoints(rr, job.key(i))) continue;
-                if (job.tab[size_t(i)].cand) { gate = true; break; }
+                if (job.cand(i)) { gate = true; break; }
             }
         }
     }

@@ -97,3 +97,60 @@ def test_somatic_demo_identical_through_adapter_cpu_double(tmp_path, windows, ca
 @pytest.mark.parametrize("windows,callable_regions", [(None, False), ((5, 9), True)])
 def test_somatic_demo_identical_through_adapter_gpu(tmp_path, windows, callable_regions):
     _somatic("amd", tmp_path, windows, callable_regions)
+
+
+# ---- larger synthetic inputs (tools/make_synth_bam.py, built by `make -C oracle ref` into oracle/_ref/synth) ------------------
+# dense indels and SNV/indel clusters, reads with end-of-read indels soft-clipped or run through by the "mapper", MAPQ tiers,
+# a coverage gap and a pile-up; the second set has 250 bp reads, so the position processor grows its stage geometry
+# while running.  (The first version of the geometry shadow failed exactly here: the coverage gap.)
+
+import os
+
+SYNTH = os.path.join(E.REF_DIR, "synth")
+SYNTH_SETS = {"short_reads": (SYNTH, 60000), "long_reads": (os.path.join(SYNTH, "long_reads"), 36000)}
+
+
+def _have_synth():
+    return all(os.path.exists(os.path.join(d, "somatic_tumor.bam")) for d, _ in SYNTH_SETS.values())
+
+
+def _synth(variant, tmp_path, which, windows=None):
+    d, length = SYNTH_SETS[which]
+    region, fa = "chrS:1-%d" % length, os.path.join(d, "synth.fa")
+    env = {"STRELKA_AMD_VERBOSE": "1"}
+    if windows:
+        env["STRELKA_AMD_READ_WINDOW"], env["STRELKA_AMD_SITE_WINDOW"] = str(windows[0]), str(windows[1])
+    outs = {}
+    for v in ("ref", variant):
+        o = str(tmp_path / v) + "/"
+        os.makedirs(o, exist_ok=True)
+        outs[v] = o
+        e = env if v != "ref" else None
+        pg = E.run(E.germline_argv("starling2_" + v, o, [os.path.join(d, "germline_S1.bam"), os.path.join(d, "germline_S2.bam")],
+                                   region=region, ref=fa), env=e)
+        ps = E.run(E.somatic_argv("strelka2_" + v, o, os.path.join(d, "somatic_normal.bam"), os.path.join(d, "somatic_tumor.bam"),
+                                  region=region, ref=fa, extra=["--somatic-callable-regions-file", o + "callable.bed"]), env=e)
+        if v != "ref":
+            cg, cs = _counters(pg.stderr.decode()), _counters(ps.stderr.decode())
+            assert cg["realign_reads"] > 10000 and cg["indel_groups"] > 100 and cg["haplotypes"] > 100 and cg["site_recomputed"] > 100
+            assert cs["realign_reads"] > 15000 and cs["indel_groups"] > 30
+    n_records = 0
+    for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf", "somatic.snvs.vcf", "somatic.indels.vcf", "callable.bed"):
+        want, got = E.vcf_body(outs["ref"] + f, keep_header=True), E.vcf_body(outs[variant] + f, keep_header=True)
+        assert got == want, (which, f)
+        n_records += sum(1 for l in want if not l.startswith("#"))
+    assert n_records > 2000
+
+
+@pytest.mark.skipif(not (E.have("starling2_dbl", "strelka2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic inputs not built")
+@pytest.mark.parametrize("which,windows", [("short_reads", None), ("short_reads", (3, 5)), ("short_reads", (1000, 3000)),
+                                           ("long_reads", None), ("long_reads", (64, 64))])
+def test_synthetic_identical_through_adapter_cpu_double(tmp_path, which, windows):
+    _synth("dbl", tmp_path, which, windows)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (E.have("starling2_amd", "strelka2_amd") and _have_synth()), reason="oracle/_ref binaries / synthetic inputs not built")
+@pytest.mark.parametrize("which", ["short_reads", "long_reads"])
+def test_synthetic_identical_through_adapter_gpu(tmp_path, which):
+    _synth("amd", tmp_path, which)
