@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=1 << 20, help="reads per step per GPU (x64 candidates x150 bp)")
-    ap.add_argument("--loci", type=int, default=1 << 24, help="germline loci per step per GPU (depth ~Poisson(40))")
+    ap.add_argument("--loci", type=int, default=1 << 26, help="germline loci per step per GPU (depth ~Poisson(40)); 2^26 ~ chr20")
+    ap.add_argument("--realign-reads", type=int, default=1 << 16, help="reads per step of the whole-read leg (a1-a7)")
+    ap.add_argument("--cpu-seconds-per-leg", type=float, default=5.0, help="seconds each CPU-baseline leg runs (all cores in parallel)")
     ap.add_argument("--unique-reads", type=int, default=1 << 14, help="distinct synthetic reads (tiled on device)")
     ap.add_argument("--unique-loci", type=int, default=1 << 20)
     ap.add_argument("--pileup-reads", type=int, default=1 << 20, help="reads per step per GPU for the pileup leg (row a8)")
@@ -56,10 +58,30 @@ def parse():
 
 
 def cpu_baseline(args):
-    """The oracle (plain-C restatement of the reference, oracle/strelka_oracle.c) timed on ONE host core over a bounded
-    sample of the same workload.  This is the only place bench.py touches oracle/: as the thing the GPU number is put
-    beside, never as part of the measured product path."""
+    """The CPU number the GPU line is put beside.  Where oracle/_ref travelled with the repo: the REFERENCE's
+    own translation units, one single-threaded process per host core, each pinned, all running at once (oracle/ref_timing.py):
+    kind "reference".  Otherwise the plain-C restatement on one core: kind "port".  This is the only place bench.py touches
+    oracle/: as the thing the GPU number is put beside, never as part of the measured product path."""
     from oracle import pyoracle
+    if pyoracle.ref_available():
+        from oracle import ref_timing
+        r = ref_timing.reference_baseline(args.cpu_seconds_per_leg)
+        return {"value": r["cells_per_s"], "unit": "cells/s", "cores": r["cores"], "kind": "reference",
+                "value_per_core": r["cells_per_s_per_core"],
+                "loci_per_s": r["loci_per_s"], "loci_per_s_per_core": r["loci_per_s_per_core"],
+                "somatic_loci_per_s": r["somatic_loci_per_s"], "somatic_loci_per_s_per_core": r["somatic_loci_per_s_per_core"],
+                "realign_reads_per_s": r["reads_per_s"], "realign_reads_per_s_per_core": r["reads_per_s_per_core"],
+                "one_process_alone": {"cells_per_s": r["cells_per_s_one_process"], "loci_per_s": r["loci_per_s_one_process"],
+                                      "somatic_loci_per_s": r["somatic_loci_per_s_one_process"],
+                                      "realign_reads_per_s": r["reads_per_s_one_process"]},
+                "sample": "the reference's own translation units (oracle/_ref), %d processes pinned to %d cores, %.0f s per leg, "
+                          "inputs pre-materialised in the reference's structs, only its compute calls inside the clock: "
+                          "scoreCandidateAlignment on 48 reads x 64 candidate alignments x 150 bp per process (cells/s); "
+                          "realignAndScoreRead on 144 reads of synth.realign_scenarios per process (reads/s); adjust_joint_eprob + "
+                          "position_snp_call_pprob_digt on 20000 loci depth~Poisson(40) per process (loci/s); "
+                          "position_somatic_snv_call on 20000 loci 40x+110x per process (somatic loci/s); rates summed over the "
+                          "processes, *_per_core = that sum / cores; one_process_alone = the same legs with a single process on the otherwise idle "
+                          "host" % (r["cores"], r["cores"], r["seconds_per_leg"])}
     from strelka_amd import synth
     pyoracle.build(ref=False)
     rng = np.random.default_rng(1)
@@ -78,27 +100,55 @@ def cpu_baseline(args):
     de = pyoracle.adjust_joint_eprob(pb)
     pyoracle.site_digt_call(pb, de)
     tb = time.perf_counter() - t0
-    out = {"value": cells / ta, "unit": "cells/s", "cores": 1, "kind": "port",
-           "sample": "%d reads x 64 candidate alignments x 150 bp, %d passes through sko_score_cases (%.1f s); loci: %d loci "
-                     "depth~Poisson(40) through sko_adjust_joint_eprob+sko_position_snp_call_pprob_digt (%.1f s)"
-                     % (len(cases), reps, ta, args.cpu_loci, tb),
-           "loci_per_s": args.cpu_loci / tb}
-    # where the reference's own translation units travelled with the repo (oracle/_ref, built from /root/reference by
-    # oracle/Makefile), time the REFERENCE's adjust_joint_eprob + position_snp_call_pprob_digt on part of the same loci
-    try:
-        if pyoracle.ref_available():
-            R = pyoracle.ref()
-            R.ref_time_germline_sites.restype = C.c_double
-            R.ref_time_germline_sites.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_double, C.POINTER(C.c_double)]
-            n = min(pb.n_loci, 300000)
-            chk = C.c_double()
-            secs = R.ref_time_germline_sites(pb.call_off.ctypes.data, pb.calls.ctypes.data, pb.ref_base.ctypes.data, n, 0.001,
-                                             C.byref(chk))
-            out["loci_per_s_reference"] = n / secs
-            out["sample"] += "; reference TUs (oracle/_ref) on %d of those loci: %.1f s" % (n, secs)
-    except Exception as e:  # the reference build is optional test infrastructure
-        out["loci_reference_error"] = str(e)
-    return out
+    return {"value": cells / ta, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "oracle/_ref absent: the C restatement on one core; %d reads x 64 candidate alignments x 150 bp, %d passes "
+                      "through sko_score_cases (%.1f s); loci: %d loci depth~Poisson(40) through sko_adjust_joint_eprob+"
+                      "sko_position_snp_call_pprob_digt (%.1f s)" % (len(cases), reps, ta, args.cpu_loci, tb),
+            "loci_per_s": args.cpu_loci / tb}
+
+
+def whole_read_leg(args, capi, synth, rng):
+    """Rows a1-a7 end to end: reads -> sk_realign_job_add_reads (gate, normalisation, enumeration, flattening on the host)
+    -> run (scoring kernel, selection, score_indels) on the same scenario distribution the reference's realignAndScoreRead is
+    timed on (oracle/ref_timing.py).  Host buffers in and out, PCIe included: this is the path the adapter calls."""
+    scenarios = synth.realign_scenarios(24, rng, reads_per=12)
+    jobs = []
+    total = 0
+    rep = max(1, args.realign_reads // (24 * 12))
+    for sc in scenarios:
+        keep, inputs = [], []
+        for rd in sc["reads"]:
+            code = np.ascontiguousarray(rd["code"], np.uint8)
+            qual = np.ascontiguousarray(rd["qual"], np.uint8)
+            segs = (capi.PathSeg * max(len(rd["path"]), 1))(*[capi.PathSeg(t, l) for t, l in rd["path"]])
+            obs = (C.c_int32 * max(len(rd["observed"]), 1))(*rd["observed"])
+            keep.append((code, qual, segs, obs))
+            inputs.append(capi.ReadInput(capi._p(code), capi._p(qual), len(code), rd["pos"], len(rd["path"]), segs, int(rd["is_fwd"]),
+                                         rd["map_level"], 0, rd["realign_range"][0], rd["realign_range"][1], len(rd["observed"]), obs))
+        job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
+                                                   min_read_bp_flank=sc["min_read_bp_flank"]))
+        job.set_reference(sc["ref_seq"], sc["ref_offset"])
+        job.set_indels(sc["indels"])
+        ok = [r for r in inputs if capi.lib().sk_realign_job_add_read(job._j, C.byref(r)) >= 0]
+        job.clear_reads()
+        if not ok:
+            continue
+        n = len(ok) * rep
+        arr = (capi.ReadInput * n)(*[ok[i % len(ok)] for i in range(n)])
+        jobs.append((job, arr, n, keep))
+        total += n
+
+    def step():
+        for job, arr, n, _ in jobs:
+            job.clear_reads()
+            if capi.lib().sk_realign_job_add_reads(job._j, arr, n) < 0:
+                raise RuntimeError("sk_realign_job_add_reads failed")
+            job.run()
+    cals = 0
+    step()
+    for job, _, _, _ in jobs:
+        cals += job.batch().n_cals
+    return step, total, cals
 
 
 def pmc_traffic(args):
@@ -178,6 +228,7 @@ def main():
     rbatch, rb_loci = synth.pileup_reads_flat(args.pileup_reads, rng)
     dr = device.DeviceReadBatch(rbatch, rb_loci, dev)
     dt_p, pbases, kms_p = timed(lambda: dr.pileup(), args.steps, args.warmup, rbatch.n_bases)
+    pileup_alg_bytes = 8 * rbatch.n_bases  # 4 B per read base (P1) + 4 B per call (P2)
     del dr
 
     # ---- hot path B (somatic SNV): 30-state grid likelihoods + posterior, normal 40x + tumor 110x ----
@@ -206,11 +257,31 @@ def main():
     dga = device.DeviceGlobalAlignBatch(pairs, dev)
     dt_ga, ga_cells, kms_ga = timed(lambda: dga.align(), args.steps, args.warmup, dga.cells)
     n_ga = dga.n
+    ga_alg_bytes = dga.nq + dga.nr + 72 * dga.n  # sequences in, score / begin / ~8 path segments out per problem
     del dga
+
+    # ---- rows a1-a7: the whole read path as the adapter drives it (host stages + kernel), one host thread ----
+    wr_step, wr_reads, wr_cals = whole_read_leg(args, capi, synth, rng)
+    dt_wr, wr_done, _ = timed(wr_step, max(2, args.steps // 4), 1, wr_reads)
 
     traffic = pmc_traffic(args)
     som_kernels = ("somatic_classify_kernel", "somatic_lhood_kernel", "somatic_posterior_kernel")
     som_traffic = sum(traffic[k] for k in som_kernels) if all(k in traffic for k in som_kernels) else None
+    pil_kernels = ("pileup_read_kernel", "pileup_column_kernel")
+    pil_traffic = (traffic["pileup_read_kernel"] + 2 * traffic["pileup_column_kernel"]) if all(k in traffic for k in pil_kernels) else None
+
+    def roof(kernel, alg_bytes, kernel_ms, hbm_traffic):
+        """roofline object: `achieved` = algorithmic bytes / kernel time; `measured_hbm_gbs` = counter-measured HBM
+        bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/) / the same kernel time, i.e. what the memory system
+        actually delivered; both as fractions of the 8 TB/s peak"""
+        ach = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        o = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": hbm_traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms}
+        if hbm_traffic:
+            o["measured_hbm_gbs"] = hbm_traffic / (kernel_ms * 1e-3) / 1e9
+            o["frac_measured"] = o["measured_hbm_gbs"] / HBM_PEAK_GBS
+            o["traffic_over_algorithmic"] = hbm_traffic / alg_bytes
+        return o
     out = {
         "metric": "candidate-alignment scoring cells/s (read bases x candidate alignments; Strelka2 has no pair-HMM, "
                   "SURVEY.md section 0) + germline loci/s",
@@ -226,31 +297,21 @@ def main():
         "pileup_reads_per_step_per_gpu": rbatch.n_reads,
         "somatic_loci_per_s": sloci / dt_s, "somatic_ms_per_step": dt_s / args.steps * 1e3,
         "somatic_loci_per_step_per_gpu": somatic_loci_n,
-        "roofline_somatic": {"kernel": "somatic_classify_kernel+somatic_lhood_kernel+somatic_posterior_kernel", "bound": "hbm", "achieved": (2 * somatic_calls + 273 * somatic_loci_n) / (kms_s * 1e-3) / 1e9,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (2 * somatic_calls + 273 * somatic_loci_n) / (kms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": som_traffic, "algorithmic_bytes_per_launch": 2 * somatic_calls + 273 * somatic_loci_n,
-                             "kernel_ms": kms_s},
+        "roofline_somatic": roof("somatic_classify_kernel+somatic_lhood_kernel+somatic_posterior_kernel", 2 * somatic_calls + 273 * somatic_loci_n, kms_s, som_traffic),
         "indel_grid_loci_per_s": iloci / dt_i, "indel_grid_ms_per_step": dt_i / args.steps * 1e3,
-        "roofline_indel_grid": {"kernel": "indel_grid_lhood_kernel", "bound": "hbm", "achieved": indel_alg_bytes / (kms_i * 1e-3) / 1e9,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": indel_alg_bytes / (kms_i * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "traffic": traffic.get("indel_grid_lhood_kernel"), "algorithmic_bytes_per_launch": indel_alg_bytes,
-                                "kernel_ms": kms_i},
+        "roofline_indel_grid": roof("indel_grid_lhood_kernel", indel_alg_bytes, kms_i, traffic.get("indel_grid_lhood_kernel")),
         "allele_group_loci_per_s": gloci / dt_g, "allele_group_ms_per_step": dt_g / args.steps * 1e3,
-        "roofline_allele_group": {"kernel": "allele_group_kernel", "bound": "hbm", "achieved": group_alg_bytes / (kms_g * 1e-3) / 1e9,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": group_alg_bytes / (kms_g * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": traffic.get("allele_group_kernel"), "algorithmic_bytes_per_launch": group_alg_bytes,
-                                  "kernel_ms": kms_g},
+        "roofline_allele_group": roof("allele_group_kernel", group_alg_bytes, kms_g, traffic.get("allele_group_kernel")),
+        "roofline_pileup": roof("pileup_read_kernel+2*pileup_column_kernel", pileup_alg_bytes, kms_p, pil_traffic),
+        "roofline_global_align": roof("global_align_kernel", ga_alg_bytes, kms_ga, traffic.get("global_align_kernel")),
+        "realign_reads_per_s": wr_done / dt_wr, "realign_ms_per_step": dt_wr / max(2, args.steps // 4) * 1e3,
+        "realign_reads_per_step_per_gpu": wr_reads, "realign_candidate_alignments_per_read": wr_cals / max(1, wr_reads),
+        "realign_host_threads": 1,
         "global_align_cells_per_s": ga_cells / dt_ga, "global_align_ms_per_step": dt_ga / args.steps * 1e3,
         "global_align_problems_per_step": n_ga,
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
-        "roofline": {"kernel": "score_wave_per_read", "bound": "hbm", "achieved": ach_a, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": ach_a / HBM_PEAK_GBS,
-                     "traffic": traffic.get("score_wave_per_read"),
-                     "algorithmic_bytes_per_launch": alg_bytes_a, "kernel_ms": kms_a},
-        "roofline_loci": {"kernel": "germline_site_fused_kernel", "bound": "hbm", "achieved": ach_b,
-                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS,
-                          "traffic": traffic.get("germline_site_fused_kernel"),
-                          "algorithmic_bytes_per_launch": alg_bytes_b, "kernel_ms": kms_b},
+        "roofline": roof("score_wave_per_read", alg_bytes_a, kms_a, traffic.get("score_wave_per_read")),
+        "roofline_loci": roof("germline_site_fused_kernel", alg_bytes_b, kms_b, traffic.get("germline_site_fused_kernel")),
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -87,6 +87,7 @@ void sk_indel_options_default(sk_indel_options* opt, int is_somatic)
     opt->tier2_random_base_match_prob = 0.25;
     opt->read_confident_support_threshold = 0.51;
     opt->is_use_alt_indel = 1;
+    opt->fast_form = 0;
 }
 
 void sk_somatic_indel_options_default(sk_somatic_indel_options* opt)

@@ -12,6 +12,7 @@
 #include "starling_common/starling_read_align_score.hh"
 #include "test/starling_base_options_test.hh"
 
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -64,8 +65,22 @@ Mode& mode(const bool is_somatic)
     return is_somatic ? somatic : germline;
 }
 
+struct PreparedScoreRead
+{
+    std::unique_ptr<starling_read> sread;
+    std::vector<CandidateAlignment> cals;
+};
+struct PreparedRealignRead
+{
+    std::unique_ptr<starling_read> sread;
+    known_pos_range range;
+    PreparedRealignRead() : range(0, 0) {}
+};
+
 struct Session
 {
+    std::vector<PreparedScoreRead> scoreReads;     // ref_session_prepare_score_read / ref_session_time_score
+    std::vector<PreparedRealignRead> realignReads; // ref_session_prepare_realign_read / ref_session_time_realign
     Mode& m;
     starling_base_options_test& opt;
     std::unique_ptr<starling_base_deriv_options>& dopt;
@@ -372,6 +387,118 @@ int ref_session_read_scores(void* p, unsigned read_id, RefReadScore* out, int ca
         }
     }
     return n;
+}
+
+
+// ---- timing entry points for bench.py's "reference" CPU baseline: inputs are materialised in the reference's own structs
+// first, only the reference's compute calls are inside the clock ----
+
+/// a read and its candidate alignments, ready for scoreCandidateAlignment
+int ref_session_prepare_score_read(void* p, const char* read_seq, const uint8_t* qual, int read_len, const RefCal* cals, int n_cals)
+{
+    Session* s = static_cast<Session*>(p);
+    try {
+        PreparedScoreRead pr;
+        bam_record bamRead;
+        bamRead.set_qname("R");
+        bamRead.set_readqual(read_seq, qual);
+        alignment bal;
+        bal.pos = n_cals ? cals[0].pos : 0;
+        bal.path.push_back(ALIGNPATH::path_segment(ALIGNPATH::MATCH, unsigned(read_len)));
+        bam1_t& br(*(bamRead.get_data()));
+        br.core.pos = bal.pos;
+        edit_bam_cigar(bal.path, br);
+        pr.sread.reset(new starling_read(bamRead, bal, MAPLEVEL::TIER1_MAPPED, 0));
+        for (int k = 0; k < n_cals; ++k) {
+            const RefCal& c(cals[k]);
+            CandidateAlignment cal;
+            cal.al.pos = c.pos;
+            for (int i = 0; i < c.n_seg; ++i)
+                cal.al.path.push_back(ALIGNPATH::path_segment(static_cast<ALIGNPATH::align_t>(c.path[i].type), c.path[i].length));
+            indel_set_t iset;
+            for (int i = 0; i < c.n_indels; ++i) iset.insert(to_key(c.indels[i]));
+            cal.setIndels(iset);
+            if (c.leading.type != INDEL::NONE) cal.leading_indel_key = to_key(c.leading);
+            if (c.trailing.type != INDEL::NONE) cal.trailing_indel_key = to_key(c.trailing);
+            pr.cals.push_back(cal);
+        }
+        s->scoreReads.push_back(std::move(pr));
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+/// scoreCandidateAlignment over the prepared reads, pass after pass, for about `seconds`; returns the seconds spent and the
+/// number of (read base x candidate alignment) cells scored
+double ref_session_time_score(void* p, double seconds, double* cells, double* checksum)
+{
+    Session* s = static_cast<Session*>(p);
+    double acc = 0, n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    double dt = 0;
+    do {
+        for (auto& pr : s->scoreReads) {
+            read_segment& rseg(pr.sread->get_full_segment());
+            for (const auto& cal : pr.cals) acc += scoreCandidateAlignment(s->opt, *s->buffer, rseg, cal, s->ref);
+            n += double(rseg.read_size()) * double(pr.cals.size());
+        }
+        dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } while (dt < seconds);
+    *cells = n;
+    *checksum = acc;
+    return dt;
+}
+
+/// a read ready for realignAndScoreRead (as ref_session_realign builds it)
+int ref_session_prepare_realign_read(void* p, const char* read_seq, const uint8_t* qual, int pos, int n_seg, const RefPathSeg* path,
+                                     int is_fwd, int map_level, int realign_begin, int realign_end, unsigned read_id)
+{
+    Session* s = static_cast<Session*>(p);
+    try {
+        bam_record bamRead;
+        bamRead.set_qname("R");
+        bamRead.set_readqual(read_seq, qual);
+        alignment al;
+        al.pos = pos;
+        al.is_fwd_strand = (is_fwd != 0);
+        for (int i = 0; i < n_seg; ++i)
+            al.path.push_back(ALIGNPATH::path_segment(static_cast<ALIGNPATH::align_t>(path[i].type), path[i].length));
+        bam1_t& br(*(bamRead.get_data()));
+        br.core.pos = al.pos;
+        if (!is_fwd) br.core.flag |= BAM_FLAG::STRAND;
+        edit_bam_cigar(al.path, br);
+        PreparedRealignRead pr;
+        pr.sread.reset(new starling_read(bamRead, al, static_cast<MAPLEVEL::index_t>(map_level), read_id));
+        pr.range = known_pos_range(realign_begin, realign_end);
+        s->realignReads.push_back(std::move(pr));
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+/// realignAndScoreRead over the prepared reads, pass after pass, for about `seconds`; returns seconds, *reads = reads done
+double ref_session_time_realign(void* p, double seconds, int is_haplotyping_enabled, int min_read_bp_flank, double* reads)
+{
+    Session* s = static_cast<Session*>(p);
+    s->opt.isHaplotypingEnabled = (is_haplotyping_enabled != 0);
+    s->sopt->min_read_bp_flank = min_read_bp_flank;
+    double n = 0, dt = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    do {
+        for (auto& pr : s->realignReads) {
+            read_segment& rseg(pr.sread->get_full_segment());
+            try {
+                realignAndScoreRead(s->opt, *s->dopt, *s->sopt, s->ref, pr.range, 0, rseg, *s->buffer);
+            } catch (...) {
+            }
+            n += 1;
+        }
+        dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } while (dt < seconds && !s->realignReads.empty());
+    *reads = n;
+    return dt;
 }
 
 } // extern "C"

@@ -15,6 +15,7 @@
 #include "blt_util/reference_contig_segment.hh"
 #include "starling_common/IndelData.hh"
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -278,6 +279,37 @@ int ref_is_multi_indel_allele(const IndelSampleReads* normal, const IndelSampleR
     } catch (...) {
         return -1;
     }
+}
+
+/// the reference's position_somatic_snv_call (tier1 columns only, as sk_somatic_snv_call_batch) over n loci; returns the
+/// seconds spent inside the calls (pileups are materialised in snp_pos_info objects outside the clock)
+double ref_time_somatic_sites(const int64_t* n_off, const uint16_t* n_calls, const int64_t* t_off, const uint16_t* t_calls,
+                              const uint8_t* ref_base, int n_loci, const SnvOptions* o, double* checksum)
+{
+    strelka_options opt;
+    opt.bsnp_diploid_theta = o->bsnp_diploid_theta;
+    opt.somatic_snv_rate = o->somatic_snv_rate;
+    opt.shared_site_error_rate = o->shared_site_error_rate;
+    opt.shared_site_error_strand_bias_fraction = o->shared_site_error_strand_bias_fraction;
+    opt.ssnv_contam_tolerance = o->ssnv_contam_tolerance;
+    const somatic_snv_caller_strand_grid caller(opt);
+    static const std::vector<float> no_de;
+    static const char bases[] = "ACGTN";
+    double secs = 0, acc = 0;
+    for (int l = 0; l < n_loci; ++l) {
+        snp_pos_info pn, pt;
+        const char rb(bases[ref_base[l] > 4 ? 4 : ref_base[l]]);
+        fill_pileup(pn, n_calls + n_off[l], int(n_off[l + 1] - n_off[l]), rb);
+        fill_pileup(pt, t_calls + t_off[l], int(t_off[l + 1] - t_off[l]), rb);
+        const extended_pos_info en(pn, no_de), et(pt, no_de);
+        somatic_snv_genotype_grid sgt;
+        const auto t0 = std::chrono::steady_clock::now();
+        caller.position_somatic_snv_call(en, et, nullptr, nullptr, false, sgt);
+        secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        acc += sgt.rs.qphred;
+    }
+    *checksum = acc;
+    return secs;
 }
 
 } // extern "C"

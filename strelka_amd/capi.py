@@ -139,7 +139,7 @@ class SomaticSnvOptions(C.Structure):
 class IndelOptions(C.Structure):
     _fields_ = [("min_read_bp_flank", C.c_int32), ("random_base_match_prob", C.c_double),
                 ("tier2_random_base_match_prob", C.c_double), ("read_confident_support_threshold", C.c_double),
-                ("is_use_alt_indel", C.c_int32)]
+                ("is_use_alt_indel", C.c_int32), ("fast_form", C.c_int32)]
 
 
 class SomaticIndelOptions(C.Structure):

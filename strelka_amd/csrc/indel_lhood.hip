@@ -20,6 +20,7 @@
 
 #include "somatic_common.h"
 
+#include <unordered_map>
 #include <vector>
 
 namespace
@@ -88,6 +89,60 @@ __device__ __forceinline__ void het_observed_allele_ratio(const unsigned read_le
     }
 }
 
+// ---- the "fast form" (sk_indel_options.fast_form): algebraically the same terms with two exp per read shared by its 21
+// states and one log per state.  Not the reference's operation order: likelihoods agree to ~1e-15 relative, not bit for bit
+// (north_star allows 1e-5 on log-likelihoods); the default is the exact form.
+__device__ __forceinline__ bool het_observed_indel_prob(const unsigned read_length, const unsigned min_overlap, const unsigned del_len,
+                                                        const unsigned ins_len, const double het_allele_ratio, double& ref_prob,
+                                                        double& indel_prob)
+{
+    const unsigned base_expect = ((read_length + 1) < (2 * min_overlap)) ? 0 : (read_length + 1) - (2 * min_overlap);
+    const double ref_path_expect = double(base_expect + min(del_len, base_expect));
+    const double indel_path_expect = double(base_expect + min(ins_len, base_expect));
+    const double ref_path_term = __dmul_rn(__dsub_rn(1., het_allele_ratio), ref_path_expect);
+    const double indel_path_term = __dmul_rn(het_allele_ratio, indel_path_expect);
+    const double total_path_term = __dadd_rn(ref_path_term, indel_path_term);
+    if (!(total_path_term > 0)) return false;
+    indel_prob = __ddiv_rn(indel_path_term, total_path_term);
+    ref_prob = __dsub_rn(1., indel_prob);
+    return true;
+}
+
+// One read's term of a het state, integrateOutMappingStatus(logsum(noindel + log(1-p), hom + log(p))), evaluated as
+//     T + log( (e^(A-T) * ((1-p) e^(a-m) + p e^(b-m))) + e^(M-T) )
+// with a = noindel, b = hom, m = max(a,b), A = m + correct_mapping_log_prior, M = random_base_match_log_prob * nonAmbig,
+// T = max(A, M)
+struct ReadExp
+{
+    double T, wa, wb, wm; // wa = e^(A-T) e^(a-m), wb = e^(A-T) e^(b-m), wm = e^(M-T)
+};
+__device__ __forceinline__ ReadExp read_exponentials(const MapParams& mp, const unsigned non_ambig, const double a, const double b,
+                                                     const int ex, const SkLibmTables& lt)
+{
+    const bool a_lt_b = (a < b);
+    const double m = a_lt_b ? b : a;
+    const double A = __dadd_rn(m, mp.correct_mapping_log_prior);
+    const double M = __dmul_rn(mp.random_base_match_log_prob, double(non_ambig));
+    const bool A_lt_M = (A < M);
+    ReadExp r;
+    r.T = A_lt_M ? M : A;
+    double e1 = sk_exp(-fabs(__dsub_rn(a, b)), ex, lt);
+    if (!(e1 == e1)) e1 = 1.; // a == b == -inf
+    const double eT = sk_exp(-fabs(__dsub_rn(A, M)), ex, lt);
+    const double sA = A_lt_M ? eT : 1.;
+    r.wm = A_lt_M ? 1. : eT;
+    r.wa = __dmul_rn(sA, a_lt_b ? e1 : 1.);
+    r.wb = __dmul_rn(sA, a_lt_b ? 1. : e1);
+    return r;
+}
+__device__ __forceinline__ double mix_term(const ReadExp& r, const double ref_prob, const double indel_prob, const int ex,
+                                           const SkLibmTables& lt)
+{
+    const double mix = __dadd_rn(__dmul_rn(ref_prob, r.wa), __dmul_rn(indel_prob, r.wb));
+    return __dadd_rn(r.T, sk_log(__dadd_rn(mix, r.wm), ex, lt));
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a)
 {
     __shared__ double s_term[N_STATES][WAVE];
@@ -122,6 +177,28 @@ __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a
                 const double hom_lnp = double(a.b.indel_lnp[g]);
                 const unsigned na = a.b.non_ambig[g];
                 const unsigned rl = a.b.read_length[g];
+                if (FAST) {
+                    const ReadExp e = read_exponentials(a.map, na, noindel_lnp, hom_lnp, ex, lt);
+                    s_term[0][lane] = mix_term(e, 1., 0., ex, lt);
+                    s_term[1][lane] = mix_term(e, 0., 1., ex, lt);
+                    {
+                        double pr = 0.5, pi = 0.5;
+                        if (!is_breakpoint) het_observed_indel_prob(rl, flank, del_len, ins_len, 0.5, pr, pi);
+                        s_term[2][lane] = mix_term(e, pr, pi, ex, lt);
+                    }
+                    for (int i = 0; i < SK_HET_RES; ++i) {
+                        {
+                            double pr = a.chet_ratio[i], pi = a.het_ratio[i];
+                            if (!is_breakpoint) het_observed_indel_prob(rl, flank, del_len, ins_len, a.het_ratio[i], pr, pi);
+                            s_term[3 + i][lane] = mix_term(e, pr, pi, ex, lt);
+                        }
+                        {
+                            double pr = a.het_ratio[i], pi = a.chet_ratio[i];
+                            if (!is_breakpoint) het_observed_indel_prob(rl, flank, del_len, ins_len, a.chet_ratio[i], pr, pi);
+                            s_term[3 + (2 * SK_HET_RES - (i + 1))][lane] = mix_term(e, pr, pi, ex, lt);
+                        }
+                    }
+                } else {
                 // SOMATIC_DIGT / STAR_DIINDEL: 0 = REF/NOINDEL, 1 = HOM, 2 = HET
                 s_term[0][lane] = integrate_out_mapping(a.map, na, noindel_lnp, ex, lt);
                 s_term[1][lane] = integrate_out_mapping(a.map, na, hom_lnp, ex, lt);
@@ -144,6 +221,7 @@ __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a
                             integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li), ex, lt), ex, lt);
                     }
                 }
+                } // exact form
             }
         }
         __syncthreads();
@@ -584,6 +662,7 @@ void sk_indel_options_default(sk_indel_options* opt, int is_somatic)
     opt->tier2_random_base_match_prob = 0.25;
     opt->read_confident_support_threshold = 0.51;
     opt->is_use_alt_indel = 1;
+    opt->fast_form = 0;
 }
 
 void sk_somatic_indel_options_default(sk_somatic_indel_options* opt)
@@ -622,7 +701,8 @@ int sk_indel_grid_lhood_dev(const sk_readscore_batch* b, const sk_indel_options*
     }
     volatile double two = 2.;
     a.loghalf = -std::log(two); // :251
-    hipLaunchKernelGGL(indel_grid_lhood_kernel, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
+    if (opt->fast_form) hipLaunchKernelGGL(indel_grid_lhood_kernel<true>, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
+    else hipLaunchKernelGGL(indel_grid_lhood_kernel<false>, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());
     return 0;
 }
@@ -667,11 +747,20 @@ static size_t readscore_bytes(const sk_readscore_batch* hb)
 static int upload_shared_error_rates(const double* indel_to_ref_error_prob, const int n, const sk_somatic_indel_options& sopt,
                                      SkArena& ar, hipStream_t st, float*& dsse, float*& dcsse)
 {
+    // the error model hands out a few dozen distinct rates (one per repeat context), so the host libm's pow / log / log1p
+    // run once per distinct rate, not once per indel
     std::vector<float> ln_sse(n), ln_csse(n);
+    std::unordered_map<uint64_t, std::pair<float, float>> memo;
     for (int i = 0; i < n; ++i) {
-        const double sharedIndelErrorRate(std::pow(indel_to_ref_error_prob[i], sopt.shared_indel_error_factor));
-        ln_sse[i] = (float)std::log(sharedIndelErrorRate);
-        ln_csse[i] = (float)h_log1p_switch(-sharedIndelErrorRate);
+        uint64_t key;
+        std::memcpy(&key, &indel_to_ref_error_prob[i], 8);
+        auto it = memo.find(key);
+        if (it == memo.end()) {
+            const double sharedIndelErrorRate(std::pow(indel_to_ref_error_prob[i], sopt.shared_indel_error_factor));
+            it = memo.emplace(key, std::make_pair((float)std::log(sharedIndelErrorRate), (float)h_log1p_switch(-sharedIndelErrorRate))).first;
+        }
+        ln_sse[i] = it->second.first;
+        ln_csse[i] = it->second.second;
     }
     dsse = ar.take<float>(n);
     dcsse = ar.take<float>(n);

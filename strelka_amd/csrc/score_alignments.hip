@@ -101,7 +101,7 @@ __device__ double score_one_generic(const ScoreArgs& a, const int r, const int c
 }
 
 // Kernel A1.  LDS slab per wave: [rows][hap columns + 0.0 run][entries][event mask]
-__global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(const ScoreArgs a)
+__device__ __forceinline__ void score_wave_per_read_body(const ScoreArgs& a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -292,6 +292,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(con
     }
 }
 
+// The same code under two names: `score_wave_per_read` is what the device-resident entry (sk_score_alignments_dev: the
+// adapter's resident pipeline, bench.py's timed leg) launches, `score_wave_per_read_hostbuf` what the host-buffer entry
+// (sk_score_alignments: stage 2 of sk_realign_job_run, small per-window batches) launches -- so that a kernel trace keeps
+// the per-launch statistics of the two apart.
+__global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read(const ScoreArgs a) { score_wave_per_read_body(a); }
+__global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read_hostbuf(const ScoreArgs a) { score_wave_per_read_body(a); }
+
 __global__ void score_thread_per_cal(const ScoreArgs a)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,7 +316,7 @@ inline int align16(int n) { return (n + 15) & ~15; }
 
 } // namespace
 
-extern "C" int sk_score_alignments_dev(const sk_align_batch* b, double* dev_out_lnp, void* hip_stream)
+static int score_alignments_launch(const sk_align_batch* b, double* dev_out_lnp, void* hip_stream, const bool from_host_entry)
 {
     SK_REQUIRE_INIT();
     if (!b || !dev_out_lnp) return sk_fail("sk_score_alignments_dev: null argument");
@@ -330,7 +337,8 @@ extern "C" int sk_score_alignments_dev(const sk_align_batch* b, double* dev_out_
     const bool prepared = b->entries && b->evmask && b->evmask_words == sk_ent_evmask_words(maxL);
     if (prepared && maxL > 0 && maxL <= SK_ENT_MAX_READ_LEN && maxP > 0 && maxP <= SK_ENT_MAX_POOL && lds <= 64 * 1024) {
         const int blocks = (b->n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        hipLaunchKernelGGL(score_wave_per_read, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds, st, a);
+        if (from_host_entry) hipLaunchKernelGGL(score_wave_per_read_hostbuf, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds, st, a);
+        else hipLaunchKernelGGL(score_wave_per_read, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds, st, a);
     } else {
         const int threads = 256;
         const int blocks = (b->n_cals + threads - 1) / threads;
@@ -338,6 +346,11 @@ extern "C" int sk_score_alignments_dev(const sk_align_batch* b, double* dev_out_
     }
     SK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int sk_score_alignments_dev(const sk_align_batch* b, double* dev_out_lnp, void* hip_stream)
+{
+    return score_alignments_launch(b, dev_out_lnp, hip_stream, false);
 }
 
 // test hook: force the generic kernel regardless of the bounds (parity of the two kernels is tested against each other)
@@ -453,7 +466,7 @@ extern "C" int sk_score_alignments(const sk_align_batch* hb, double* out_lnp)
         d.evmask = pm;
     }
     double* dout = ar.take<double>(n_cals);
-    if (sk_score_alignments_dev(&d, dout, st)) return 1;
+    if (score_alignments_launch(&d, dout, st, true)) return 1;
     SK_HIP(hipMemcpyAsync(out_lnp, dout, sizeof(double) * n_cals, hipMemcpyDeviceToHost, st));
     SK_HIP(hipStreamSynchronize(st));
     return 0;

@@ -364,3 +364,38 @@ def test_allele_group_genotype_lhoods(gpu):
     lh2, counts2, _ = pyoracle.allele_group_genotype_lhoods(ab2)
     assert np.array_equal(got2["lhood"].view(np.uint64), lh2.view(np.uint64))
     assert np.array_equal(got2["counts"], counts2)
+
+
+def test_indel_fast_form_keeps_every_integer_output(gpu):
+    """sk_indel_options.fast_form: two exp per read shared by its 21 states instead of the reference's operation order.
+    Likelihoods then agree to ~1e-13 absolute (1e-15 relative to the terms' magnitude) instead of bit for bit; over 10^6 candidate
+    indels the somatic calls derived from them -- QSI, QSI_NT, NTYPE, max_gt of either tier -- are the same."""
+    from strelka_amd import capi
+    rng = np.random.default_rng(811)
+    total = same = 0
+    worst = 0.0
+    for rep in range(8):
+        n = 1 << 17
+        normal = synth.readscore_batch(n, rng, depth_mean=40.0)
+        tumor = synth.readscore_batch(n, rng, depth_mean=110.0)
+        tumor.del_len, tumor.ins_len = normal.del_len, normal.ins_len
+        k = len(tumor.indel_lnp)
+        boost = np.repeat(rng.random(n) < 0.5, np.diff(tumor.read_off))
+        tumor.indel_lnp = np.where(boost & (rng.random(k) < 0.3), 0.0, tumor.indel_lnp).astype(np.float32)
+        tumor.ref_lnp = np.where(boost, np.minimum(tumor.ref_lnp, -1.0), tumor.ref_lnp).astype(np.float32)
+        err = rng.choice([5e-5, 1e-4, 3e-3, 2e-2], n)
+        res = {}
+        for fast in (0, 1):
+            nopt, topt = capi.indel_options(True), capi.indel_options(True)
+            nopt.min_read_bp_flank = 1
+            nopt.fast_form = topt.fast_form = fast
+            res[fast] = [capi.somatic_indel_call(normal, tumor, err, nopt, topt, is_include_tier2=t2) for t2 in (False, True)]
+        for t in range(2):
+            a, b = res[0][t], res[1][t]
+            for f in ("max_gt", "qphred", "from_ntype_qphred", "ntype"):
+                assert np.array_equal(a[f], b[f]), (rep, t, f, int((a[f] != b[f]).sum()))
+            d = np.abs(a["tumor_lhood"] - b["tumor_lhood"]) / np.maximum(1.0, np.abs(a["tumor_lhood"]))
+            worst = max(worst, float(d.max()))
+        total += n
+    assert total >= 1000000
+    assert worst < 1e-12, worst
