@@ -216,6 +216,13 @@ typedef struct sk_realign_options { /* L/starling_common/starling_base_shared.hh
     int32_t sample_count;                 /* 1..SK_MAX_SAMPLES */
     int32_t host_threads;                 /* host stages of sk_realign_job_add_reads / _finish: 1 = none (default: the reference runs one
                                              process per core), n = up to n threads, 0 = up to 16 hardware threads */
+    int32_t enumeration;                  /* where candidate_alignment_search (:859-1277) runs:
+                                             0 = host, container-based statement (the one pinned to the reference);
+                                             1 = host, the container-free core of csrc/realign_core.h (what the device runs);
+                                             2 = device: search, ordering / de-duplication and flattening of every read's
+                                                 candidate alignments in kernels (csrc/read_enumerate.hip), scored where they
+                                                 are; reads beyond the core's fixed capacities take path 0.
+                                             Results are identical in all three. */
 } sk_realign_options;
 void sk_realign_options_default(sk_realign_options* opt);
 
@@ -299,6 +306,9 @@ int sk_realign_job_read_result(const sk_realign_job* job, int32_t read_index, sk
  *  153-164); an adapter that had to evaluate the status of every indel of the table up front does that without caching and
  *  commits the cache only for the indels reported here, so that it caches what the reference would have. */
 int sk_realign_job_indels_consulted(const sk_realign_job* job, uint8_t* out, int32_t n_indels);
+/** How many reads had their candidate alignments enumerated by the container-free core on the host (enumeration == 1), on the
+ *  device (== 2), and by the container-based code although 1 or 2 was asked for (a fixed capacity of the core was exceeded). */
+int sk_realign_job_enumeration_counts(const sk_realign_job* job, int64_t* n_core, int64_t* n_device, int64_t* n_fallback);
 /** drop reads and results, keep reference/indels/options */
 void sk_realign_job_clear_reads(sk_realign_job* job);
 

@@ -57,7 +57,8 @@ class RealignOptions(C.Structure):
                 ("max_realignment_candidates", C.c_uint32), ("max_indel_size", C.c_uint32),
                 ("is_smoothed_alignments", C.c_int32), ("smoothed_lnp_range", C.c_double),
                 ("upstream_oligo_size", C.c_uint32), ("is_haplotyping_enabled", C.c_int32),
-                ("min_read_bp_flank", C.c_int32), ("sample_count", C.c_int32), ("host_threads", C.c_int32)]
+                ("min_read_bp_flank", C.c_int32), ("sample_count", C.c_int32), ("host_threads", C.c_int32),
+                ("enumeration", C.c_int32)]
 
 
 class IndelInfo(C.Structure):
@@ -187,7 +188,7 @@ EXPORTS = [
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
     "sk_realign_job_finish", "sk_realign_job_run", "sk_realign_job_n_reads", "sk_realign_job_read_result",
-    "sk_realign_job_clear_reads", "sk_realign_job_indels_consulted", "sk_make_start_pos_alignment", "sk_get_end_pin_start_pos",
+    "sk_realign_job_clear_reads", "sk_realign_job_indels_consulted", "sk_realign_job_enumeration_counts", "sk_make_start_pos_alignment", "sk_get_end_pin_start_pos",
     "sk_germline_options_default", "sk_dependent_eprob", "sk_dependent_eprob_dev", "sk_site_digt_call",
     "sk_site_digt_call_dev", "sk_site_digt_call_fused", "sk_site_digt_call_fused_dev",
     "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
@@ -235,6 +236,8 @@ def lib():
         L.sk_realign_job_create.restype = c_void_p
         L.sk_realign_job_create.argtypes = [C.POINTER(RealignOptions)]
         L.sk_realign_job_destroy.argtypes = [c_void_p]
+        L.sk_realign_job_enumeration_counts.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+        L.sk_realign_job_indels_consulted.argtypes = [c_void_p, c_void_p, C.c_int32]
         L.sk_realign_job_error.restype = C.c_char_p
         L.sk_realign_job_error.argtypes = [c_void_p]
         L.sk_realign_job_set_reference.argtypes = [c_void_p, C.c_char_p, C.c_int32, C.c_int32]
@@ -835,6 +838,11 @@ class RealignJob:
 
     def n_reads(self):
         return lib().sk_realign_job_n_reads(self._j)
+
+    def enumeration_counts(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        lib().sk_realign_job_enumeration_counts(self._j, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
 
     def clear_reads(self):
         lib().sk_realign_job_clear_reads(self._j)

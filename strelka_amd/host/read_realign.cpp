@@ -12,11 +12,13 @@
 // integer containers.  Each function cites the reference lines it reproduces.
 
 #include "strelka_amd.h"
+#include "../csrc/realign_core.h"
 
 #include <algorithm>
 #include <atomic>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -427,6 +429,8 @@ struct sk_realign_job
     // (IndelBuffer.hh:153-164): a caller that evaluated the status of more indels than the reference would have, earlier
     // than it would have, must only commit the ones the reference would have touched (sk_realign_job_indels_consulted)
     mutable std::unique_ptr<std::atomic<uint8_t>[]> consulted;
+    // reads whose search ran in the container-free core / on the device / in the container-based code although 1 or 2 was asked for
+    mutable std::atomic<int64_t> n_core_reads{ 0 }, n_device_reads{ 0 }, n_fallback_reads{ 0 };
     bool cand(const int i) const
     {
         consulted[size_t(i)].store(1, std::memory_order_relaxed);
@@ -1092,6 +1096,108 @@ void alignment_indel_keys(const Job& job, const Aln& al, const Key* lead, const 
     }
 }
 
+// ---- the container-free enumeration core (csrc/realign_core.h) on the host: sk_realign_options.enumeration == 1 ----
+struct CoreTables
+{
+    std::vector<skcore::PIndel> tab;
+    std::string ins_pool;
+    skcore::PJob pj;
+};
+void build_core_tables(const Job& job, CoreTables& t, uint8_t* consulted)
+{
+    t.tab.resize(job.tab.size());
+    t.ins_pool.clear();
+    for (size_t i = 0; i < job.tab.size(); ++i) {
+        const Indel& d = job.tab[i];
+        skcore::PIndel& p = t.tab[i];
+        p.pos = d.key.pos;
+        p.del = d.key.del;
+        p.ins_len = d.key.ins_len();
+        p.arid = d.arid;
+        p.type = uint8_t(d.key.type);
+        p.cand = d.cand ? 1 : 0;
+        p.forced = d.forced ? 1 : 0;
+        p.ndfr = d.ndfr ? 1 : 0;
+        for (int s = 0; s < SK_MAX_SAMPLES; ++s) {
+            p.hap[s] = d.hap[s];
+            p.bypass[s] = d.bypass[s] ? 1 : 0;
+        }
+        p.ins_off = uint32_t(t.ins_pool.size());
+        t.ins_pool += d.key.ins;
+    }
+    t.pj.tab = t.tab.data();
+    t.pj.n_tab = int32_t(t.tab.size());
+    t.pj.max_toggle = job.max_toggle.data();
+    t.pj.n_max_toggle = int32_t(job.max_toggle.size());
+    t.pj.sample_count = job.opt.sample_count;
+    t.pj.max_read_indel_toggle = job.opt.max_read_indel_toggle;
+    t.pj.max_candidate_indel_density = job.opt.max_candidate_indel_density;
+    t.pj.is_haplotyping_enabled = job.opt.is_haplotyping_enabled;
+    t.pj.max_indel_size = int32_t(job.opt.max_indel_size);
+    t.pj.consulted = consulted;
+}
+bool to_core_cal(const Cal& c, skcore::PCal& p)
+{
+    if (c.al.path.size() > size_t(skcore::Caps::P) || c.indels.size() > size_t(skcore::Caps::K + 2)) return false;
+    p.pos = c.al.pos;
+    p.lead = int16_t(c.lead);
+    p.trail = int16_t(c.trail);
+    p.fwd = c.al.fwd ? 1 : 0;
+    p.n_seg = uint8_t(c.al.path.size());
+    p.n_indels = uint8_t(c.indels.size());
+    p.pad = 0;
+    for (size_t i = 0; i < c.al.path.size(); ++i) {
+        if (c.al.path[i].length > 0xffffu) return false;
+        p.path[i].type = uint16_t(c.al.path[i].type);
+        p.path[i].length = uint16_t(c.al.path[i].length);
+    }
+    for (size_t i = 0; i < c.indels.size(); ++i) p.indels[i] = int16_t(c.indels[i]);
+    return true;
+}
+Cal from_core_cal(const skcore::PCal& p)
+{
+    Cal c;
+    c.al.pos = p.pos;
+    c.al.fwd = p.fwd != 0;
+    c.lead = p.lead;
+    c.trail = p.trail;
+    for (int i = 0; i < p.n_seg; ++i) c.al.path.push_back(Seg{ p.path[i].type, p.path[i].length });
+    for (int i = 0; i < p.n_indels; ++i) c.indels.push_back(p.indels[i]);
+    return c;
+}
+// the state getCandidateAlignments hands to candidate_alignment_search, in the core's form; false = beyond a cap
+bool to_core_read(const Job& job, const std::set<int>& observed, int sample, unsigned read_length, const Range& realign_range,
+                  const Range& exemplar_pr, const StatusMap& sm, const std::vector<int>& order, const Cal& cal, skcore::PRead& r)
+{
+    if (job.tab.size() > 32000 || sm.size() > size_t(skcore::Caps::K) || order.size() > size_t(skcore::Caps::K) ||
+        observed.size() > size_t(skcore::Caps::OBS) || read_length > 0xffffu)
+        return false;
+    std::memset(&r, 0, sizeof(r));
+    r.realign_b = realign_range.b;
+    r.realign_e = realign_range.e;
+    r.read_length = int32_t(read_length);
+    r.sample = sample;
+    r.exemplar_range = skcore::mk_range(exemplar_pr.b, exemplar_pr.e);
+    if (!to_core_cal(cal, r.cal)) return false;
+    r.cal.n_indels = 0;
+    int n = 0;
+    for (const auto& kv : sm) {
+        skcore::PStatus& s = r.sm[n++];
+        s.idx = int16_t(kv.first);
+        s.is_present = kv.second.is_present;
+        s.is_remove_only = kv.second.is_remove_only;
+        s.in_original = kv.second.in_original;
+        s.pad = 0;
+    }
+    r.n_sm = uint8_t(n);
+    for (size_t i = 0; i < order.size(); ++i) r.order[i] = int16_t(order[i]);
+    r.n_order = uint8_t(order.size());
+    n = 0;
+    for (const int o : observed) r.observed[n++] = int16_t(o);
+    r.n_observed = uint8_t(n);
+    return true;
+}
+
 // getCandidateAlignments :1816-1994
 void get_candidate_alignments(const Job& job, sk_realign_job::Read& rd, const std::set<int>& observed, const Aln& input,
                               const Range& realign_range, std::set<Cal>& cal_set)
@@ -1151,7 +1257,37 @@ void get_candidate_alignments(const Job& job, sk_realign_job::Read& rd, const st
         cal_read_length -= (sc_lead + sc_trail);
     }
     ctx.read_length = cal_read_length;
-    candidate_alignment_search(ctx, sm, hm, order, 0, 0, 0, exemplar_pr, job.opt.max_read_indel_toggle, cal);
+    bool searched = false;
+    if (job.opt.enumeration == 1) {
+        // the container-free core, on this thread (enumeration == 2 runs the same code on the device, read_enumerate.hip)
+        std::unique_ptr<skcore::PRead> pr(new skcore::PRead);
+        if (to_core_read(job, observed, rd.sample, cal_read_length, realign_range, exemplar_pr, sm, order, cal, *pr)) {
+            CoreTables tables;
+            std::vector<uint8_t> consulted(job.tab.size() + 1, 0);
+            build_core_tables(job, tables, consulted.data());
+            std::vector<skcore::PFrame> stack(skcore::Caps::K + 2);
+            std::set<Cal> leaves;
+            bool too_many = false;
+            auto sink = [&](const skcore::PCal& leaf) -> bool {
+                leaves.insert(from_core_cal(leaf));
+                if (leaves.size() > 100000) too_many = true;
+                return !too_many;
+            };
+            const skcore::SearchOut so = skcore::candidate_alignment_search(tables.pj, *pr, stack.data(), sink);
+            if (so.status == skcore::ST_FAIL) throw Fail("candidate alignment search failed (inconsistent indel set)");
+            if (so.status == skcore::ST_OK) {
+                for (size_t i = 0; i < job.tab.size(); ++i)
+                    if (consulted[i]) (void)job.cand(int(i));
+                if (so.warn_origin) rd.warn_origin = true;
+                if (so.warn_toggle) rd.warn_toggle = true;
+                cal_set.swap(leaves);
+                searched = true;
+                job.n_core_reads.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
+        if (!searched) job.n_fallback_reads.fetch_add(1, std::memory_order_relaxed);
+    }
+    if (!searched) candidate_alignment_search(ctx, sm, hm, order, 0, 0, 0, exemplar_pr, job.opt.max_read_indel_toggle, cal);
 
     if (clipped) {
         std::set<Cal> s2;
@@ -1697,6 +1833,9 @@ void sk_realign_options_default(sk_realign_options* o)
     o->min_read_bp_flank = 5;
     o->sample_count = 1;
     o->host_threads = 1; // the reference runs one process per core; an adapter that owns more cores raises this
+    // SK_ENUMERATION overrides the default for test runs of whole suites in one mode (tests/conftest.py documents it)
+    o->enumeration = 0;
+    if (const char* e = std::getenv("SK_ENUMERATION")) o->enumeration = std::atoi(e);
 }
 
 sk_realign_job* sk_realign_job_create(const sk_realign_options* opt)
@@ -1765,6 +1904,15 @@ int sk_realign_job_set_indels(sk_realign_job* j, const sk_indel_info* indels, in
     for (size_t i = 0; i <= j->tab.size(); ++i) j->consulted[i].store(0, std::memory_order_relaxed);
     j->orig_to_tab.assign(size_t(n), -1);
     for (size_t i = 0; i < j->tab.size(); ++i) j->orig_to_tab[size_t(j->tab[i].orig)] = int(i);
+    return 0;
+}
+
+int sk_realign_job_enumeration_counts(const sk_realign_job* j, int64_t* n_core, int64_t* n_device, int64_t* n_fallback)
+{
+    if (!j) return 1;
+    if (n_core) *n_core = j->n_core_reads.load();
+    if (n_device) *n_device = j->n_device_reads.load();
+    if (n_fallback) *n_fallback = j->n_fallback_reads.load();
     return 0;
 }
 
