@@ -97,6 +97,7 @@ struct State
     SiteCache sites;
     SomaticSiteCache somaticSites;
     // counters reported at exit with $STRELKA_AMD_VERBOSE=1
+    unsigned long realignDeviceEnumerated = 0, realignHostEnumerated = 0; // reads whose candidate alignments the device / the host listed
     unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0;
 };
 State& state();

@@ -65,7 +65,8 @@ State& state()
             std::cerr << "strelka_amd adapter: realign_jobs=" << s.realignBatches << " realign_reads=" << s.realignReads
                       << " site_batches=" << s.siteBatches << " site_loci=" << s.siteLoci << " site_recomputed=" << s.siteRecomputed
                       << " indel_groups=" << s.indelGroups << " haplotypes=" << s.haplotypes << " read_window=" << read_buffer_defer()
-                      << " site_window=" << post_align_defer() << "\n";
+                      << " site_window=" << post_align_defer() << " enum_device_reads=" << s.realignDeviceEnumerated
+                      << " enum_host_instead=" << s.realignHostEnumerated << "\n";
         }
     };
     static Reporter r;

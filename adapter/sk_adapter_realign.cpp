@@ -235,6 +235,12 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
     jobCheck(sk_realign_job_run(job), "sk_realign_job_run");
     s.realignBatches++;
     s.realignReads += reads.size();
+    {
+        int64_t onCore(0), onDevice(0), onHostInstead(0);
+        (void)sk_realign_job_enumeration_counts(job, &onCore, &onDevice, &onHostInstead);
+        s.realignDeviceEnumerated += static_cast<unsigned long>(onDevice);
+        s.realignHostEnumerated += static_cast<unsigned long>(onHostInstead);
+    }
 
     // commit the candidate status of the indels the job's reads asked about
     {

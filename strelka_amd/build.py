@@ -22,6 +22,7 @@ HIP_SOURCES = [
     "csrc/indel_lhood.hip",
     "csrc/pileup.hip",
     "csrc/global_align.hip",
+    "csrc/read_enumerate.hip",
 ]
 HOST_SOURCES = [
     "host/align_flatten.cpp",

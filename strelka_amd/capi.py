@@ -789,6 +789,7 @@ class RealignJob:
             a.not_discovered_from_reads = int(d.get("ndfr", 0))
         if lib().sk_realign_job_set_indels(self._j, arr, len(indels)):
             raise self._err()
+        self._n_indels = len(indels)
 
     def add_read(self, read_code, read_qual, pos, path, is_fwd=True, map_level=1, sample=0, realign_range=(0, 1 << 30),
                  observed=()):
@@ -838,6 +839,13 @@ class RealignJob:
 
     def n_reads(self):
         return lib().sk_realign_job_n_reads(self._j)
+
+    def indels_consulted(self):
+        """uint8 per indel of the table as given to set_indels: candidate status consulted by any read so far"""
+        out = np.zeros(max(self._n_indels, 1), np.uint8)
+        if lib().sk_realign_job_indels_consulted(self._j, _p(out), self._n_indels):
+            raise self._err()
+        return out[:self._n_indels]
 
     def enumeration_counts(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()

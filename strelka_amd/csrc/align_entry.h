@@ -25,6 +25,9 @@ constexpr int SK_ENT_MAX_READ_LEN = 1022;
 constexpr int SK_ENT_MAX_POOL = 1023; // hap index bases reach the pool size
 constexpr int SK_ENT_ZERO_COL = 5;    // column index of the 0.0 term
 
+#if defined(__HIP__)
+__host__ __device__
+#endif
 static inline unsigned sk_ent_col_index(const unsigned bam_code)
 {
     return bam_code == 1u ? 0u : bam_code == 2u ? 1u : bam_code == 4u ? 2u : bam_code == 8u ? 3u : 4u;

@@ -1,0 +1,42 @@
+// read_enumerate.h -- internal interface between the host stages of the realignment job (host/read_realign.cpp) and the device
+// enumeration pipeline (csrc/read_enumerate.hip): sk_realign_options.enumeration == 2.
+//
+// Only what the reference's getCandidateAlignments hands to candidate_alignment_search crosses PCIe on the way in (PRead: start
+// alignment, indel status map, indel order, observed indels) plus the read bases/qualities, the indel table and the reference
+// segment; on the way out the candidate alignments of every read in std::set<CandidateAlignment> order and their scores.
+#pragma once
+
+#include "realign_core.h"
+
+struct SkEnumInput
+{
+    const skcore::PIndel* tab;
+    int32_t n_tab;
+    const char* ins_pool; // insert sequences (ACGTN characters), PIndel.ins_off / ins_len index it
+    int64_t ins_pool_len;
+    const uint32_t* max_toggle;
+    int32_t n_max_toggle;
+    int32_t sample_count, max_read_indel_toggle, is_haplotyping_enabled, max_indel_size;
+    double max_candidate_indel_density;
+    const char* ref; // the job's reference segment
+    int32_t ref_offset, ref_len;
+    const skcore::PRead* reads; // reads to enumerate, in job order
+    int32_t n_reads;
+    const int64_t* read_off; // [n_reads+1] the full (unclipped) reads, as scored
+    const uint8_t* read_code;
+    const uint8_t* read_qual;
+    int32_t max_read_len;
+    int32_t want_scores; // 0 = enumeration only (sk_realign_job_get_batch flattens on the host)
+};
+
+struct SkEnumOutput // host arrays owned by the pipeline, valid until its next run
+{
+    const int32_t* status;     // [n_reads] skcore::ST_*; anything but ST_OK: the read has no entries below, enumerate it on the host
+    const uint8_t* warn;       // [n_reads] bit 0: origin warning, bit 1: toggle-depth warning
+    const int32_t* cal_off;    // [n_reads+1]
+    const skcore::PCal* cals;  // [cal_off[n_reads]] each read's candidate alignments in set order
+    const double* scores;      // [cal_off[n_reads]] or null
+    const uint8_t* consulted;  // [n_tab] candidate status consulted by the search or the flattening
+};
+
+extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out);

@@ -1,0 +1,1033 @@
+// read_enumerate.hip -- candidate-alignment enumeration, flattening and scoring of a realignment job on the device
+// (sk_realign_options.enumeration == 2).
+//
+//   E1  root_kernel, level_kernel x depth   candidate_alignment_search (csrc/realign_core.h, the statement of
+//                          L/starling_common/starling_read_align.cpp:857-1277 shared with the host), level by level: one thread
+//                          per call of the reference's recursion, all reads of the job at once
+//   E2  group/dedupe/rank  the leaves of each read -> its std::set<CandidateAlignment>: duplicates dropped, set order
+//   L1  pool_bounds/layout  reference window and insert sequences of each read's haplotype pool
+//   L2  op_count_kernel    one thread per candidate alignment: ops it flattens to
+//   F1  pool_fill_kernel   one wave per read: the pool's bytes
+//   F2  flatten_kernel     one thread per candidate alignment: the walk of scoreCandidateAlignment
+//                          (starling_read_align_score.cpp:286-493) emitting scoring ops (host/align_flatten.cpp holds the host form)
+//   F3  entries_kernel     one thread per candidate alignment: the transition entries and event masks kernel A1 reads
+//                          (csrc/align_entry.h) -- so neither sk_align_builder nor sk_align_prepare runs on the host for these reads
+//   A1  score_wave_per_read (score_alignments.hip) on the batch E3 left in HBM
+//
+// All of this is integer/byte work; it has to reproduce the host stages exactly (tests/test_device_enumeration.py).  A read that
+// exceeds a capacity of the core, or that the host code would have thrown on, is reported (status != ST_OK) and redone by the
+// container-based host code, which then produces either the result or the reference's error text -- nothing is truncated.
+
+#include "sk_common.h"
+
+#include "align_entry.h"
+#include "read_enumerate.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace skcore;
+
+int sk_score_alignments_launch_hostleg(const sk_align_batch* b, double* dev_out_lnp, void* hip_stream); // score_alignments.hip
+
+namespace
+{
+
+static_assert(sizeof(PFrame) % 4 == 0 && sizeof(PCal) % 4 == 0, "frames move through LDS as 32-bit words");
+
+// ---------------------------------------------------------------------------------------------------------------------
+// E1: the search, level by level.  The reference's recursion passes its whole state by value, so the calls at one depth are
+// independent of each other (they share the set the leaves go into and two warning flags): level d of ALL reads of the job is
+// one launch, one thread per call, the frames of the level in one array and the children appended to the next level's array.
+// A thread's frame is staged into LDS first (the 64 frames of a workgroup are contiguous in HBM): expanding a call is a long
+// chain of dependent accesses to its frame, and LDS is an order of magnitude closer than HBM.
+
+struct EnumArgs
+{
+    PJob job; // device pointers
+    const PRead* reads;
+    int32_t n_reads;
+    PFrame* level_in;
+    PFrame* level_out;
+    int32_t frame_cap;
+    int32_t* level_count; // [Caps::K + 3]
+    int32_t depth;
+    PCal* pool; // leaves, as found (duplicates included)
+    int32_t* leaf_read;
+    uint32_t* leaf_hash;
+    int32_t pool_cap;
+    int32_t* n_leaves;
+    int32_t* n_raw;  // [n_reads] leaves found
+    int32_t* status; // [n_reads] max over the read's calls
+    int32_t* warn;   // [n_reads] bit 0 origin, bit 1 toggle depth
+    unsigned long long* n_nodes;
+};
+
+__device__ inline uint32_t cal_hash(const PCal& c)
+{
+    uint32_t h = 2166136261u;
+    auto mix = [&](const uint32_t v) { h = (h ^ v) * 16777619u; };
+    mix(uint32_t(c.pos));
+    mix(uint32_t(c.fwd) | (uint32_t(c.n_seg) << 8) | (uint32_t(c.n_indels) << 16));
+    mix(uint32_t(uint16_t(c.lead)) | (uint32_t(uint16_t(c.trail)) << 16));
+    for (int i = 0; i < c.n_seg; ++i) mix(uint32_t(c.path[i].type) | (uint32_t(c.path[i].length) << 16));
+    for (int i = 0; i < c.n_indels; ++i) mix(uint32_t(uint16_t(c.indels[i])));
+    return h;
+}
+
+struct LeafSink // a leaf: the read's clips back on (clip_adder :508-542), dropped when outside the realign range (:1981-1993)
+{
+    const EnumArgs* a;
+    const PRead* r;
+    int32_t read_id;
+    __device__ bool operator()(PCal& leaf)
+    {
+        if (r->clipped && !clip_adder(leaf, r->hc_lead, r->hc_trail, r->sc_lead, r->sc_trail)) return false;
+        if (!superset_of(mk_range(r->realign_b, r->realign_e), strict_range(leaf))) return true;
+        const int slot = atomicAdd(a->n_leaves, 1);
+        if (slot >= a->pool_cap) return false;
+        copy_cal(a->pool[slot], leaf);
+        a->leaf_read[slot] = read_id;
+        a->leaf_hash[slot] = cal_hash(leaf);
+        atomicAdd(&a->n_raw[read_id], 1);
+        return true;
+    }
+};
+
+struct LevelAlloc
+{
+    const EnumArgs* a;
+    __device__ PFrame* operator()()
+    {
+        const int slot = atomicAdd(&a->level_count[a->depth + 1], 1);
+        if (slot >= a->frame_cap) return nullptr;
+        return &a->level_out[slot];
+    }
+};
+
+__global__ __launch_bounds__(64) void root_kernel(const EnumArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    PFrame& f = a.level_out[r];
+    root_frame(a.job, a.reads[r], f);
+    f.read_id = r;
+}
+
+enum { FRAME_WORDS = sizeof(PFrame) / 4 };
+
+__global__ __launch_bounds__(64) void level_kernel(const EnumArgs a)
+{
+    extern __shared__ __align__(16) uint32_t lds_words[];
+    PFrame* frames = reinterpret_cast<PFrame*>(lds_words);
+    const int n_in = min(a.level_count[a.depth], a.frame_cap);
+    for (int base = blockIdx.x * 64; base < n_in; base += gridDim.x * 64) {
+        const int n_here = min(64, n_in - base);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.level_in + base);
+        for (int w = threadIdx.x; w < n_here * FRAME_WORDS; w += 64) lds_words[w] = src[w];
+        __syncthreads();
+        if (int(threadIdx.x) < n_here) {
+            PFrame& f = frames[threadIdx.x];
+            const int r = f.read_id;
+            if (f.stage != 0xffff && a.status[r] == ST_OK) {
+                SearchOut so;
+                so.status = ST_OK;
+                so.warn_origin = so.warn_toggle = 0;
+                so.nodes = 0;
+                LeafSink sink{ &a, &a.reads[r], r };
+                LevelAlloc alloc{ &a };
+                expand_node(a.job, a.reads[r], f, alloc, &f.cal, sink, so); // (a leaf is completed in place: the frame is done with)
+                if (so.status != ST_OK) atomicMax(&a.status[r], so.status);
+                if (so.warn_origin | so.warn_toggle) atomicOr(&a.warn[r], (so.warn_origin ? 1 : 0) | (so.warn_toggle ? 2 : 0));
+            }
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.n_nodes) atomicAdd(a.n_nodes, (unsigned long long)n_in);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// E2: the leaves of each read -> a std::set<CandidateAlignment>: grouped by read, duplicates dropped, ordered
+
+struct SetArgs
+{
+    const PCal* pool;
+    const int32_t* leaf_read;
+    const uint32_t* leaf_hash;
+    const int32_t* status;
+    int32_t n_reads, n_leaves;
+    const int32_t* raw_off; // [n_reads+1] (reads that failed: empty)
+    int32_t* fill;          // [n_reads] zeroed
+    int32_t* grouped;       // [raw_off[n_reads]] leaf slots, read by read
+    uint8_t* dup;           // [raw_off[n_reads]]
+    int32_t* n_uniq;        // [n_reads] zeroed
+    const int32_t* cal_off; // [n_reads+1]
+    int32_t* sorted;        // [cal_off[n_reads]] leaf slots in set order
+};
+
+__device__ inline int group_of(const int32_t* off, const int n, const int g) // last r with off[r] <= g
+{
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void group_kernel(const SetArgs a)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_leaves) return;
+    const int r = a.leaf_read[s];
+    if (a.status[r] != ST_OK) return;
+    a.grouped[a.raw_off[r] + atomicAdd(&a.fill[r], 1)] = s;
+}
+
+// a leaf is a duplicate when an equal leaf stands before it in its read's group (which of the equal ones stands first differs
+// from run to run; they are equal)
+__global__ __launch_bounds__(256) void dedupe_kernel(const SetArgs a)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.raw_off[a.n_reads]) return;
+    const int r = group_of(a.raw_off, a.n_reads, g);
+    const int me = a.grouped[g];
+    const uint32_t h = a.leaf_hash[me];
+    bool dup = false;
+    for (int q = a.raw_off[r]; q < g && !dup; ++q) {
+        const int o = a.grouped[q];
+        if (a.leaf_hash[o] == h && cal_compare(a.pool[o], a.pool[me]) == 0) dup = true;
+    }
+    a.dup[g] = dup ? 1 : 0;
+    if (!dup) atomicAdd(&a.n_uniq[r], 1);
+}
+
+// the rank of a kept leaf in the set order of its read (CandidateAlignment.hh:37-48, alignment.hh:72-90: cal_compare)
+__global__ __launch_bounds__(256) void rank_kernel(const SetArgs a)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.raw_off[a.n_reads]) return;
+    if (a.dup[g]) return;
+    const int r = group_of(a.raw_off, a.n_reads, g);
+    const PCal& mine = a.pool[a.grouped[g]];
+    int rank = 0;
+    for (int q = a.raw_off[r]; q < a.raw_off[r + 1]; ++q)
+        if (q != g && !a.dup[q] && cal_compare(a.pool[a.grouped[q]], mine) < 0) ++rank;
+    a.sorted[a.cal_off[r] + rank] = a.grouped[g];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// flattening
+
+__device__ inline uint8_t code_of(const char c) // get_bam_seq_code, L/htsapi/bam_seq.hh:73-92
+{
+    switch (c) {
+    case '=': return SK_BAM_REF;
+    case 'A': return SK_BAM_A;
+    case 'C': return SK_BAM_C;
+    case 'G': return SK_BAM_G;
+    case 'T': return SK_BAM_T;
+    default: return SK_BAM_ANY;
+    }
+}
+
+struct FlatArgs
+{
+    PJob job;
+    const char* ins_pool;
+    const char* ref;
+    int32_t ref_offset, ref_len;
+    int32_t n_reads, n_cals;
+    const PCal* pool;
+    const int32_t* list; // [n_cals] leaf slots, each read's in set order
+    int32_t* status;
+    const int64_t* read_off;
+    const int32_t* cal_off;
+    // per-read layout of the haplotype pool (L1 out)
+    int32_t* win_begin; // (L1a: min over the read's candidate alignments, cells start at INT_MAX)
+    int32_t* win_end;   // (cells start at INT_MIN)
+    int32_t* ins_lo;    // lowest / highest table index of an indel with an insert sequence
+    int32_t* ins_hi;
+    int32_t* win_len;
+    int32_t* hap_len;
+    int32_t* n_ins;
+    int16_t* ins_idx; // [n_reads][INS_CAP] table indices whose insert sequence is in the pool
+    int32_t* ins_off; // [n_reads][INS_CAP] where
+    // per candidate alignment
+    int32_t* n_ops; // (L2 out)
+    const int64_t* hap_off;
+    PCal* cals;
+    uint8_t* hap_code;
+    const int64_t* op_off; // [n_cals + 1]
+    sk_score_op* ops;
+    uint32_t* entries;
+    uint32_t* evmask;
+    int32_t evmask_words, max_read_len;
+};
+enum { INS_CAP = Caps::K + 2 };
+
+__device__ inline int read_of_cal(const FlatArgs& a, const int c) // last r with cal_off[r] <= c
+{
+    int lo = 0, hi = a.n_reads;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.cal_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// L1: the layout of each read's haplotype pool -- its reference window (the union of the reference spans of the match segments
+// of all its candidate alignments), then the insert sequences of the table indels between the lowest and the highest one any of
+// its candidate alignments holds, in table order.  (The host builder appends the insert sequences its ops use in order of first
+// use and shares equal sequences; the layout is private to the read's batch entry and the scores do not depend on it.)
+//   L1a  one thread per candidate alignment: window and indel-index bounds into the read's cells (atomicMin / atomicMax)
+//   L1b  one thread per read: offsets
+__global__ __launch_bounds__(256) void pool_bounds_kernel(const FlatArgs a)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n_cals) return;
+    const int r = read_of_cal(a, c);
+    const PCal& cal = a.pool[a.list[c]];
+    int32_t wb = INT_MAX, we = INT_MIN, pos = cal.pos;
+    for (int i = 0; i < cal.n_seg; ++i) {
+        const PSeg s = cal.path[i];
+        if (seg_align_match(s.type)) {
+            wb = min(wb, pos);
+            we = max(we, pos + int32_t(s.length));
+            pos += int32_t(s.length);
+        } else if (s.type == SK_SEG_DELETE || s.type == SK_SEG_SKIP) {
+            pos += int32_t(s.length);
+        }
+    }
+    if (wb <= we) {
+        atomicMin(&a.win_begin[r], wb);
+        atomicMax(&a.win_end[r], we);
+    }
+    int lo = INT_MAX, hi = INT_MIN;
+    auto add = [&](const int t) {
+        if (t < 0 || a.job.tab[t].ins_len == 0) return;
+        lo = min(lo, t);
+        hi = max(hi, t);
+    };
+    for (int i = 0; i < cal.n_indels; ++i) add(cal.indels[i]);
+    add(cal.lead);
+    add(cal.trail);
+    if (lo <= hi) {
+        atomicMin(&a.ins_lo[r], lo);
+        atomicMax(&a.ins_hi[r], hi);
+    }
+}
+
+__global__ __launch_bounds__(64) void pool_layout_kernel(const FlatArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const int nc = a.cal_off[r + 1] - a.cal_off[r];
+    a.n_ins[r] = 0;
+    a.win_len[r] = 0;
+    a.hap_len[r] = 0;
+    if (nc == 0) return;
+    int32_t wb = a.win_begin[r], we = a.win_end[r];
+    if (wb > we) wb = we = 0;
+    a.win_begin[r] = wb;
+    int32_t len = we - wb;
+    a.win_len[r] = len;
+    int16_t* idx = a.ins_idx + size_t(r) * INS_CAP;
+    int32_t* off = a.ins_off + size_t(r) * INS_CAP;
+    int n = 0;
+    for (int t = a.ins_lo[r]; t <= a.ins_hi[r]; ++t) {
+        const uint32_t il = a.job.tab[t].ins_len;
+        if (il == 0) continue;
+        if (n >= INS_CAP) { // more insert sequences than this form holds: the host flattens this read
+            a.status[r] = ST_OVERFLOW;
+            n = 0;
+            break;
+        }
+        idx[n] = int16_t(t);
+        off[n] = len;
+        len += int32_t(il);
+        ++n;
+    }
+    a.n_ins[r] = n;
+    a.hap_len[r] = max(len, 1);
+}
+
+// getMatchingIndelKey, starling_read_align_score.cpp:177-228: table index, -1 = no key, -2 = inconsistent
+__device__ int matching_indel(const PJob& j, const PCal& c, const int32_t ref_head_pos, const unsigned del_len, const unsigned ins_len,
+                              const int ends_first, const int ends_second, const int path_index)
+{
+    if (path_index < ends_first) return c.lead;
+    if (path_index > ends_second) return c.trail;
+    int found = -1;
+    for (int k = 0; k < c.n_indels; ++k) {
+        const PIndel& ci = j.tab[c.indels[k]];
+        if (ci.pos == ref_head_pos && (ci.type == SK_INDEL_INDEL || ci.type == SK_INDEL_MISMATCH) && ci.del == del_len &&
+            ci.ins_len == ins_len) {
+            if (found >= 0) return -2;
+            found = c.indels[k];
+        } else if (ci.pos > ref_head_pos) {
+            break;
+        }
+    }
+    return found >= 0 ? found : -2;
+}
+
+// one candidate alignment -> ops (the walk of scoreCandidateAlignment :286-493 as host/align_flatten.cpp states it); returns the
+// op count, -1 = leave this read to the host (it throws the reference's error, or handles what this form does not hold).
+// WRITE = false only counts.
+template <bool WRITE>
+__device__ int flatten_cal(const FlatArgs& a, const int r, const PCal& c, const int32_t read_len, sk_score_op* ops)
+{
+    const int aps = c.n_seg;
+    const int32_t win_begin = a.win_begin[r];
+    const int n_ins = a.n_ins[r];
+    const int16_t* ins_idx = a.ins_idx + size_t(r) * INS_CAP;
+    const int32_t* ins_off = a.ins_off + size_t(r) * INS_CAP;
+    unsigned read_offset = 0;
+    int32_t ref_head_pos = c.pos;
+    int ends_first = aps, ends_second = aps; // get_match_edge_segments, align_path.cpp:735-752
+    {
+        bool is_first_match = false;
+        for (int i = 0; i < aps; ++i)
+            if (seg_align_match(c.path[i].type)) {
+                if (!is_first_match) ends_first = i;
+                is_first_match = true;
+                ends_second = i;
+            }
+    }
+    int n = 0;
+    auto emit = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
+        if (kind == SK_OP_NOBASE && !penalty) return;
+        if (WRITE) {
+            sk_score_op op;
+            op.length = uint16_t(len);
+            op.kind = kind;
+            op.flags = uint8_t(penalty ? SK_OPFLAG_NONCANDIDATE_PENALTY : 0);
+            op.src = src;
+            ops[n] = op;
+        }
+        ++n;
+    };
+    // offset of insert bases [head, head+len) of table indel `idx` in the pool, -1 = not representable here
+    auto insert_src = [&](const int idx, const int32_t head, const uint32_t len) -> int32_t {
+        const PIndel& k = a.job.tab[idx];
+        if (head < 0 || uint32_t(head) + len > k.ins_len) return -1;
+        for (int i = 0; i < n_ins; ++i)
+            if (ins_idx[i] == idx) return ins_off[i] + head;
+        return -1;
+    };
+    auto is_cand = [&](const int idx) -> bool { return job_cand(a.job, idx); };
+
+    int path_index = 0;
+    while (path_index < aps) {
+        bool is_swap_start = false; // is_segment_swap_start, align_path.cpp:868-895
+        {
+            bool is_insert = false, is_delete = false;
+            for (int i = path_index; i < aps; ++i) {
+                if (c.path[i].type == SK_SEG_INSERT) is_insert = true;
+                else if (c.path[i].type == SK_SEG_DELETE) is_delete = true;
+                else break;
+            }
+            is_swap_start = is_insert && is_delete;
+        }
+        unsigned n_seg = 1;
+        const PSeg ps = c.path[path_index];
+        if (is_swap_start || ps.type == SK_SEG_SEQ_MISMATCH) {
+            unsigned del_len, ins_len;
+            if (ps.type == SK_SEG_SEQ_MISMATCH) {
+                del_len = ins_len = ps.length;
+            } else { // swap_info, align_path_util.hh:75-106
+                int k = path_index;
+                del_len = ins_len = 0;
+                for (; k < aps && (c.path[k].type == SK_SEG_INSERT || c.path[k].type == SK_SEG_DELETE); ++k) {
+                    if (c.path[k].type == SK_SEG_INSERT) ins_len += c.path[k].length;
+                    else del_len += c.path[k].length;
+                }
+                n_seg = unsigned(k - path_index);
+            }
+            const int key = matching_indel(a.job, c, ref_head_pos, del_len, ins_len, ends_first, ends_second, path_index);
+            if (key < 0) return -1;
+            int32_t head = 0;
+            if (path_index < ends_first) head = int32_t(a.job.tab[key].ins_len) - int32_t(ps.length);
+            const bool pen = !is_cand(key);
+            if (ins_len > 0) {
+                if (ins_len > 0xffffu) return -1;
+                const int32_t src = insert_src(key, head, ins_len);
+                if (src < 0) return -1;
+                emit(SK_OP_BASES, ins_len, src, pen);
+            } else {
+                emit(SK_OP_NOBASE, 0, 0, pen);
+            }
+        } else if (seg_align_match(ps.type)) {
+            emit(SK_OP_BASES, ps.length, ref_head_pos - win_begin, false);
+        } else if (ps.type == SK_SEG_INSERT) {
+            const int key = matching_indel(a.job, c, ref_head_pos, 0, ps.length, ends_first, ends_second, path_index);
+            if (key < 0) return -1;
+            int32_t head = 0;
+            if (path_index < ends_first) head = int32_t(a.job.tab[key].ins_len) - int32_t(ps.length);
+            const int32_t src = insert_src(key, head, ps.length);
+            if (src < 0) return -1;
+            emit(SK_OP_BASES, ps.length, src, !is_cand(key));
+        } else if (ps.type == SK_SEG_DELETE) {
+            const int key = matching_indel(a.job, c, ref_head_pos, ps.length, 0, ends_first, ends_second, path_index);
+            if (key < 0) return -1;
+            emit(SK_OP_NOBASE, 0, 0, !is_cand(key));
+        } else if (ps.type == SK_SEG_SKIP || ps.type == SK_SEG_HARD_CLIP) {
+            // nothing
+        } else if (ps.type == SK_SEG_SOFT_CLIP) {
+            emit(SK_OP_SOFT_CLIP, ps.length, 0, false);
+        } else {
+            return -1;
+        }
+        for (unsigned i = 0; i < n_seg; ++i) { // increment_path, align_path_util.hh:38-68
+            const PSeg s = c.path[path_index];
+            if (seg_align_match(s.type)) {
+                read_offset += s.length;
+                ref_head_pos += int32_t(s.length);
+            } else if (s.type == SK_SEG_DELETE || s.type == SK_SEG_SKIP) {
+                ref_head_pos += int32_t(s.length);
+            } else if (s.type == SK_SEG_INSERT || s.type == SK_SEG_SOFT_CLIP) {
+                read_offset += s.length;
+            }
+            path_index++;
+        }
+    }
+    if (int64_t(read_offset) != int64_t(read_len)) return -1;
+    return n;
+}
+
+// L2, one thread per candidate alignment: how many ops it flattens to
+__global__ __launch_bounds__(64) void op_count_kernel(const FlatArgs a)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n_cals) return;
+    const int r = read_of_cal(a, c);
+    const PCal& cal = a.pool[a.list[c]];
+    const int n = flatten_cal<false>(a, r, cal, int32_t(a.read_off[r + 1] - a.read_off[r]), nullptr);
+    if (n < 0) a.status[r] = ST_FAIL;
+    a.n_ops[c] = n < 0 ? 0 : n;
+}
+
+// F1, one wave per read: the bytes of its haplotype pool
+__global__ __launch_bounds__(64) void pool_fill_kernel(const FlatArgs a)
+{
+    const int r = blockIdx.x;
+    if (a.cal_off[r + 1] == a.cal_off[r]) return;
+    uint8_t* hap = a.hap_code + a.hap_off[r];
+    const int32_t P = int32_t(a.hap_off[r + 1] - a.hap_off[r]);
+    const int32_t wb = a.win_begin[r];
+    const int n_ins = a.n_ins[r];
+    const int16_t* idx = a.ins_idx + size_t(r) * INS_CAP;
+    const int32_t* off = a.ins_off + size_t(r) * INS_CAP;
+    const int32_t win_len = a.win_len[r];
+    for (int32_t i = threadIdx.x; i < P; i += 64) {
+        uint8_t v = SK_BAM_ANY;
+        if (i < win_len) {
+            const int32_t p = wb + i; // reference_contig_segment::get_base :46-51
+            v = (p < a.ref_offset || p >= a.ref_offset + a.ref_len) ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
+        }
+        for (int k = 0; k < n_ins; ++k) {
+            const PIndel& d = a.job.tab[idx[k]];
+            if (i >= off[k] && i < off[k] + int32_t(d.ins_len)) v = code_of(a.ins_pool[d.ins_off + uint32_t(i - off[k])]);
+        }
+        hap[i] = v;
+    }
+}
+
+// F2, one thread per candidate alignment: the alignment itself (for the host), its ops, and the candidate-status lookups the
+// host form performs for every indel of the alignment (cal_to_c)
+__global__ __launch_bounds__(64) void flatten_kernel(const FlatArgs a)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n_cals) return;
+    const int r = read_of_cal(a, c);
+    const PCal& cal = a.pool[a.list[c]];
+    PCal& d = a.cals[c];
+    d.pos = cal.pos;
+    d.lead = cal.lead;
+    d.trail = cal.trail;
+    d.fwd = cal.fwd;
+    d.n_seg = cal.n_seg;
+    d.n_indels = cal.n_indels;
+    d.pad = 0;
+    for (int i = 0; i < cal.n_seg; ++i) d.path[i] = cal.path[i];
+    for (int i = 0; i < cal.n_indels; ++i) d.indels[i] = cal.indels[i];
+    if (a.status[r] != ST_OK) return; // (its op range is empty)
+    (void)flatten_cal<true>(a, r, cal, int32_t(a.read_off[r + 1] - a.read_off[r]), a.ops + a.op_off[c]);
+    for (int i = 0; i < cal.n_indels; ++i) (void)job_cand(a.job, cal.indels[i]);
+    if (cal.lead >= 0) (void)job_cand(a.job, cal.lead);
+    if (cal.trail >= 0) (void)job_cand(a.job, cal.trail);
+}
+
+// F3, one thread per candidate alignment: ops -> transition entries + the read's event mask (host form: align_prepare in
+// host/align_flatten.cpp; layout csrc/align_entry.h)
+__global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n_cals) return;
+    const int r = read_of_cal(a, c);
+    const int W = a.evmask_words;
+    uint32_t* mask = a.evmask + int64_t(r) * W;
+    const int32_t L = int32_t(a.read_off[r + 1] - a.read_off[r]);
+    const int32_t P = int32_t(a.hap_off[r + 1] - a.hap_off[r]);
+    const uint8_t* hap = a.hap_code + a.hap_off[r];
+    const bool read_ok = (L >= 0 && L <= SK_ENT_MAX_READ_LEN && L <= a.max_read_len && P >= 0 && P <= SK_ENT_MAX_POOL);
+    auto col_at = [&](const int idx) -> unsigned { return (idx >= 0 && idx < P) ? sk_ent_col_index(hap[idx]) : unsigned(SK_ENT_ZERO_COL); };
+    const int64_t k0 = a.op_off[c], k1 = a.op_off[c + 1];
+    uint32_t* ent = a.entries + k0 + 2 * int64_t(c);
+    const int nslots = int(k1 - k0) + 2;
+    for (int i = 0; i < nslots; ++i) ent[i] = SK_ENT_END;
+    bool complex_cal = !read_ok;
+    int e = 0, pos = 0;
+    unsigned npen = 0;
+    auto emit = [&](const unsigned np, const bool clip, const int hidx) {
+        if (np > 7u || hidx + SK_ENT_HIDX_BIAS < 0 || hidx + SK_ENT_HIDX_BIAS > 2047) complex_cal = true;
+        if (complex_cal) return;
+        ent[e++] = unsigned(pos) | (np << 10) | (clip ? 1u << 13 : 0u) | (col_at(hidx + pos) << 15) | (col_at(hidx + pos + 1) << 18) |
+                   (unsigned(hidx + SK_ENT_HIDX_BIAS) << 21);
+        if (pos > 0 && pos <= L) atomicOr(&mask[pos >> 5], 1u << (pos & 31));
+    };
+    for (int64_t kk = k0; kk < k1 && !complex_cal; ++kk) {
+        const sk_score_op op = a.ops[kk];
+        const int len = int(op.length);
+        const unsigned pen = op.flags & SK_OPFLAG_NONCANDIDATE_PENALTY;
+        if ((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0) {
+            if (pos >= int(SK_ENT_END)) {
+                complex_cal = true;
+                break;
+            }
+            const bool bases = (op.kind == SK_OP_BASES);
+            if (bases && (op.src < 0 || int64_t(op.src) + len > P)) complex_cal = true;
+            emit(npen, !bases, bases ? int(op.src) - pos : P - pos);
+            pos += len;
+            npen = pen;
+        } else {
+            npen += pen;
+        }
+    }
+    if (!complex_cal) {
+        if (pos != L || pos >= int(SK_ENT_END)) complex_cal = true;
+        else emit(npen, false, P - pos);
+    }
+    if (complex_cal) {
+        for (int i = 0; i < nslots; ++i) ent[i] = SK_ENT_END;
+        ent[0] = SK_ENT_COMPLEX;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// buffers: grown on demand, kept for the life of the process (one job after the other reuses them)
+
+struct DevBuf
+{
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(const size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        SK_HIP(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+struct HostBuf // pinned
+{
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(const size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        SK_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct EnumBuffers
+{
+    DevBuf tab, ins, toggle, ref, reads, read_off, read_code, read_qual, consulted;
+    DevBuf level_a, level_b, counters, pool, leaf_read, leaf_hash, n_raw, status, warn;
+    DevBuf raw_off, fill, grouped, dup, n_uniq, sorted;
+    DevBuf n_ops, hap_len, win_begin, win_end, ins_lo, ins_hi, win_len, n_ins, ins_idx, ins_off;
+    DevBuf cal_off, hap_off, cals, hap_code, op_off, ops, entries, evmask, scores;
+    HostBuf h_status, h_warn, h_n_raw, h_raw_off, h_n_uniq, h_n_ops, h_hap_len, h_cal_off, h_hap_off, h_op_off, h_cals, h_scores,
+        h_consulted, h_counters;
+};
+EnumBuffers& bufs()
+{
+    static EnumBuffers b;
+    return b;
+}
+
+} // namespace
+
+extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
+{
+    SK_REQUIRE_INIT();
+    if (!in || !out) return sk_fail("sk_enum_device_run: null argument");
+    std::memset(out, 0, sizeof(*out));
+    const int n = in->n_reads;
+    if (n < 0 || in->n_tab < 0) return sk_fail("sk_enum_device_run: negative count");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    EnumBuffers& B = bufs();
+    const bool timing = std::getenv("SK_ENUM_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        std::fprintf(stderr, "[enum-dev] %-28s t=%.3f ms\n", what,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+
+    const int64_t n_bases = n ? in->read_off[n] : 0;
+    // capacities: calls in flight at one depth and leaves found (before duplicates are dropped), for the whole job; a job that
+    // needs more has the reads that did not fit enumerated on the host
+    int64_t frame_cap = std::min<int64_t>(std::max<int64_t>(int64_t(n) * 128, 1 << 18), 1 << 21);
+    int64_t pool_cap = std::min<int64_t>(std::max<int64_t>(int64_t(n) * 512, 1 << 19), int64_t(8) << 20);
+    if (const char* e = std::getenv("SK_ENUM_TEST_CAPS")) { // tests: small capacities, so that the overflow paths run
+        long long fc = 0, pc = 0;
+        if (std::sscanf(e, "%lld,%lld", &fc, &pc) == 2 && fc > 0 && pc > 0) {
+            frame_cap = std::max<int64_t>(fc, n);
+            pool_cap = pc;
+        }
+    }
+    const int n_counters = Caps::K + 8; // level counts [0, K+3), leaves, calls made (64 bit)
+#define RES(buf, bytes) \
+    if (B.buf.reserve(std::max<size_t>(size_t(bytes), 256))) return 1
+#define HRES(buf, bytes) \
+    if (B.buf.reserve(size_t(bytes) + 64)) return 1
+    RES(tab, sizeof(PIndel) * size_t(in->n_tab));
+    RES(ins, size_t(in->ins_pool_len));
+    RES(toggle, sizeof(uint32_t) * size_t(in->n_max_toggle));
+    RES(ref, size_t(std::max(in->ref_len, 0)));
+    RES(reads, sizeof(PRead) * size_t(n));
+    RES(read_off, sizeof(int64_t) * size_t(n + 1));
+    RES(read_code, size_t(n_bases));
+    RES(read_qual, size_t(n_bases));
+    RES(consulted, size_t(in->n_tab) + 1);
+    RES(level_a, sizeof(PFrame) * size_t(frame_cap));
+    RES(level_b, sizeof(PFrame) * size_t(frame_cap));
+    RES(counters, 4 * size_t(n_counters));
+    RES(pool, sizeof(PCal) * size_t(pool_cap));
+    RES(leaf_read, 4 * size_t(pool_cap));
+    RES(leaf_hash, 4 * size_t(pool_cap));
+    RES(n_raw, 4 * size_t(n));
+    RES(status, 4 * size_t(n));
+    RES(warn, 4 * size_t(n));
+    RES(raw_off, 4 * size_t(n + 1));
+    RES(fill, 4 * size_t(n));
+    RES(n_uniq, 4 * size_t(n));
+    RES(hap_len, 4 * size_t(n));
+    RES(win_begin, 4 * size_t(n));
+    RES(win_end, 4 * size_t(n));
+    RES(ins_lo, 4 * size_t(n));
+    RES(ins_hi, 4 * size_t(n));
+    RES(win_len, 4 * size_t(n));
+    RES(n_ins, 4 * size_t(n));
+    RES(ins_idx, 2 * size_t(n) * INS_CAP);
+    RES(ins_off, 4 * size_t(n) * INS_CAP);
+    RES(cal_off, 4 * size_t(n + 1));
+    RES(hap_off, 8 * size_t(n + 1));
+    HRES(h_status, 4 * size_t(n));
+    HRES(h_warn, 4 * size_t(n));
+    HRES(h_n_raw, 4 * size_t(n));
+    HRES(h_raw_off, 4 * size_t(n + 1));
+    HRES(h_n_uniq, 4 * size_t(n));
+    HRES(h_hap_len, 4 * size_t(n));
+    HRES(h_cal_off, 4 * size_t(n + 1));
+    HRES(h_hap_off, 8 * size_t(n + 1));
+    HRES(h_consulted, size_t(in->n_tab));
+    HRES(h_counters, 4 * size_t(n_counters));
+
+#define H2D(buf, src, bytes) \
+    if ((bytes) > 0) SK_HIP(hipMemcpyAsync(B.buf.p, src, size_t(bytes), hipMemcpyHostToDevice, st))
+#define D2H(hbuf, buf, bytes) \
+    if ((bytes) > 0) SK_HIP(hipMemcpyAsync(B.hbuf.p, B.buf.p, size_t(bytes), hipMemcpyDeviceToHost, st))
+    H2D(tab, in->tab, sizeof(PIndel) * size_t(in->n_tab));
+    H2D(ins, in->ins_pool, in->ins_pool_len);
+    H2D(toggle, in->max_toggle, sizeof(uint32_t) * size_t(in->n_max_toggle));
+    H2D(ref, in->ref, std::max(in->ref_len, 0));
+    H2D(reads, in->reads, sizeof(PRead) * size_t(n));
+    H2D(read_off, in->read_off, sizeof(int64_t) * size_t(n + 1));
+    H2D(read_code, in->read_code, n_bases);
+    H2D(read_qual, in->read_qual, n_bases);
+    SK_HIP(hipMemsetAsync(B.consulted.p, 0, size_t(in->n_tab) + 1, st));
+    SK_HIP(hipMemsetAsync(B.counters.p, 0, 4 * size_t(n_counters), st));
+    if (n > 0) {
+        SK_HIP(hipMemsetAsync(B.n_raw.p, 0, 4 * size_t(n), st));
+        SK_HIP(hipMemsetAsync(B.status.p, 0, 4 * size_t(n), st));
+        SK_HIP(hipMemsetAsync(B.warn.p, 0, 4 * size_t(n), st));
+        SK_HIP(hipMemsetAsync(B.fill.p, 0, 4 * size_t(n), st));
+        SK_HIP(hipMemsetAsync(B.n_uniq.p, 0, 4 * size_t(n), st));
+    }
+
+    int32_t* h_cal_off = B.h_cal_off.as<int32_t>();
+    h_cal_off[0] = 0;
+    out->status = B.h_status.as<int32_t>();
+    out->cal_off = h_cal_off;
+    out->consulted = B.h_consulted.as<uint8_t>();
+    if (n == 0) {
+        std::memset(B.h_consulted.p, 0, size_t(in->n_tab));
+        return 0;
+    }
+    if (n > frame_cap) return sk_fail("sk_enum_device_run: more reads in one job than the device pipeline holds");
+
+    PJob dj;
+    dj.tab = B.tab.as<PIndel>();
+    dj.n_tab = in->n_tab;
+    dj.max_toggle = B.toggle.as<uint32_t>();
+    dj.n_max_toggle = in->n_max_toggle;
+    dj.sample_count = in->sample_count;
+    dj.max_read_indel_toggle = in->max_read_indel_toggle;
+    dj.max_candidate_indel_density = in->max_candidate_indel_density;
+    dj.is_haplotyping_enabled = in->is_haplotyping_enabled;
+    dj.max_indel_size = in->max_indel_size;
+    dj.consulted = B.consulted.as<uint8_t>();
+    dj.max_nodes = 0;
+
+    // ---- E1: the search, one launch per depth
+    EnumArgs ea;
+    ea.job = dj;
+    ea.reads = B.reads.as<PRead>();
+    ea.n_reads = n;
+    ea.frame_cap = int32_t(frame_cap);
+    ea.level_count = B.counters.as<int32_t>();
+    ea.pool = B.pool.as<PCal>();
+    ea.leaf_read = B.leaf_read.as<int32_t>();
+    ea.leaf_hash = B.leaf_hash.as<uint32_t>();
+    ea.pool_cap = int32_t(pool_cap);
+    ea.n_leaves = B.counters.as<int32_t>() + (Caps::K + 3);
+    ea.n_nodes = reinterpret_cast<unsigned long long*>(B.counters.as<int32_t>() + (Caps::K + 4) + ((Caps::K + 4) & 1));
+    ea.n_raw = B.n_raw.as<int32_t>();
+    ea.status = B.status.as<int32_t>();
+    ea.warn = B.warn.as<int32_t>();
+    lap("H2D");
+    {
+        PFrame* buf[2] = { B.level_a.as<PFrame>(), B.level_b.as<PFrame>() };
+        ea.level_in = nullptr;
+        ea.level_out = buf[0];
+        ea.depth = -1;
+        hipLaunchKernelGGL(root_kernel, dim3((n + 63) / 64), dim3(64), 0, st, ea);
+        SK_HIP(hipMemcpyAsync(ea.level_count, &in->n_reads, 4, hipMemcpyHostToDevice, st));
+        const size_t lds = 64 * sizeof(PFrame);
+        const int blocks = int(std::min<int64_t>((frame_cap + 63) / 64, 1024));
+        for (int d = 0; d < Caps::K + 2; ++d) { // a call at depth d expands indel order[d]; depth n_order <= K is a leaf
+            ea.level_in = buf[d & 1];
+            ea.level_out = buf[(d + 1) & 1];
+            ea.depth = d;
+            hipLaunchKernelGGL(level_kernel, dim3(blocks), dim3(64), lds, st, ea);
+        }
+        SK_HIP(hipGetLastError());
+    }
+    D2H(h_status, status, 4 * size_t(n));
+    D2H(h_warn, warn, 4 * size_t(n));
+    D2H(h_n_raw, n_raw, 4 * size_t(n));
+    D2H(h_counters, counters, 4 * size_t(n_counters));
+    SK_HIP(hipStreamSynchronize(st));
+    lap("E1 search (all depths)");
+    int32_t* h_status = B.h_status.as<int32_t>();
+    const int32_t* h_counters = B.h_counters.as<int32_t>();
+    const int32_t n_leaves = std::min<int32_t>(h_counters[Caps::K + 3], int32_t(pool_cap));
+    if (timing) {
+        long long calls = 0;
+        int deepest = 0;
+        for (int d = 0; d < Caps::K + 3; ++d) {
+            calls += h_counters[d];
+            if (h_counters[d]) deepest = d;
+        }
+        std::fprintf(stderr, "[enum-dev] search calls %lld, deepest level %d, leaves found %d\n", calls, deepest, n_leaves);
+    }
+    {
+        uint8_t* w8 = reinterpret_cast<uint8_t*>(B.h_warn.p); // (in place: byte r is written after int r was read)
+        const int32_t* w32 = B.h_warn.as<int32_t>();
+        for (int r = 0; r < n; ++r) w8[r] = uint8_t(w32[r]);
+        out->warn = w8;
+    }
+
+    // ---- E2: leaves -> each read's set
+    const int32_t* h_n_raw = B.h_n_raw.as<int32_t>();
+    int32_t* h_raw_off = B.h_raw_off.as<int32_t>();
+    h_raw_off[0] = 0;
+    for (int r = 0; r < n; ++r) h_raw_off[r + 1] = h_raw_off[r] + ((h_status[r] == ST_OK) ? h_n_raw[r] : 0);
+    const int32_t n_grouped = h_raw_off[n];
+    RES(grouped, 4 * size_t(n_grouped));
+    RES(dup, size_t(n_grouped));
+    RES(sorted, 4 * size_t(n_grouped));
+    SetArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.pool = ea.pool;
+    sa.leaf_read = ea.leaf_read;
+    sa.leaf_hash = ea.leaf_hash;
+    sa.status = ea.status;
+    sa.n_reads = n;
+    sa.n_leaves = n_leaves;
+    sa.raw_off = B.raw_off.as<int32_t>();
+    sa.fill = B.fill.as<int32_t>();
+    sa.grouped = B.grouped.as<int32_t>();
+    sa.dup = B.dup.as<uint8_t>();
+    sa.n_uniq = B.n_uniq.as<int32_t>();
+    sa.cal_off = B.cal_off.as<int32_t>();
+    sa.sorted = B.sorted.as<int32_t>();
+    SK_HIP(hipMemcpyAsync(B.raw_off.p, h_raw_off, 4 * size_t(n + 1), hipMemcpyHostToDevice, st));
+    if (n_grouped > 0) {
+        hipLaunchKernelGGL(group_kernel, dim3((n_leaves + 255) / 256), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(dedupe_kernel, dim3((n_grouped + 255) / 256), dim3(256), 0, st, sa);
+        SK_HIP(hipGetLastError());
+    }
+    D2H(h_n_uniq, n_uniq, 4 * size_t(n));
+    SK_HIP(hipStreamSynchronize(st));
+    const int32_t* h_n_uniq = B.h_n_uniq.as<int32_t>();
+    for (int r = 0; r < n; ++r) h_cal_off[r + 1] = h_cal_off[r] + ((h_status[r] == ST_OK) ? h_n_uniq[r] : 0);
+    const int32_t n_cals = h_cal_off[n];
+    SK_HIP(hipMemcpyAsync(B.cal_off.p, h_cal_off, 4 * size_t(n + 1), hipMemcpyHostToDevice, st));
+    if (n_grouped > 0) {
+        hipLaunchKernelGGL(rank_kernel, dim3((n_grouped + 255) / 256), dim3(256), 0, st, sa);
+        SK_HIP(hipGetLastError());
+    }
+    lap("E2 sets");
+
+    // ---- L1, L2: layout of the batch
+    RES(n_ops, 4 * size_t(n_cals));
+    RES(op_off, 8 * size_t(n_cals + 1));
+    HRES(h_n_ops, 4 * size_t(n_cals));
+    HRES(h_op_off, 8 * size_t(n_cals + 1));
+    FlatArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.job = dj;
+    fa.ins_pool = B.ins.as<char>();
+    fa.ref = B.ref.as<char>();
+    fa.ref_offset = in->ref_offset;
+    fa.ref_len = in->ref_len;
+    fa.n_reads = n;
+    fa.n_cals = n_cals;
+    fa.pool = ea.pool;
+    fa.list = B.sorted.as<int32_t>();
+    fa.status = ea.status;
+    fa.read_off = B.read_off.as<int64_t>();
+    fa.cal_off = B.cal_off.as<int32_t>();
+    fa.win_begin = B.win_begin.as<int32_t>();
+    fa.win_len = B.win_len.as<int32_t>();
+    fa.hap_len = B.hap_len.as<int32_t>();
+    fa.n_ins = B.n_ins.as<int32_t>();
+    fa.ins_idx = B.ins_idx.as<int16_t>();
+    fa.ins_off = B.ins_off.as<int32_t>();
+    fa.n_ops = B.n_ops.as<int32_t>();
+    fa.win_end = B.win_end.as<int32_t>();
+    fa.ins_lo = B.ins_lo.as<int32_t>();
+    fa.ins_hi = B.ins_hi.as<int32_t>();
+    // (byte patterns: 0x7f7f7f7f is large enough to stand for "no lower bound yet", 0x80808080 is below any position / index)
+    SK_HIP(hipMemsetAsync(fa.win_begin, 0x7f, 4 * size_t(n), st));
+    SK_HIP(hipMemsetAsync(fa.ins_lo, 0x7f, 4 * size_t(n), st));
+    SK_HIP(hipMemsetAsync(fa.win_end, 0x80, 4 * size_t(n), st));
+    SK_HIP(hipMemsetAsync(fa.ins_hi, 0x80, 4 * size_t(n), st));
+    if (n_cals > 0) hipLaunchKernelGGL(pool_bounds_kernel, dim3((n_cals + 255) / 256), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(pool_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
+    SK_HIP(hipGetLastError());
+    if (n_cals > 0) {
+        hipLaunchKernelGGL(op_count_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+        SK_HIP(hipGetLastError());
+    }
+    D2H(h_status, status, 4 * size_t(n));
+    D2H(h_hap_len, hap_len, 4 * size_t(n));
+    D2H(h_n_ops, n_ops, 4 * size_t(n_cals));
+    SK_HIP(hipStreamSynchronize(st));
+    lap("L1+L2 layout");
+
+    const int32_t* h_hap_len = B.h_hap_len.as<int32_t>();
+    const int32_t* h_n_ops = B.h_n_ops.as<int32_t>();
+    int64_t* h_hap_off = B.h_hap_off.as<int64_t>();
+    int64_t* h_op_off = B.h_op_off.as<int64_t>();
+    h_hap_off[0] = 0;
+    h_op_off[0] = 0;
+    int32_t max_hap = 1;
+    for (int r = 0; r < n; ++r) {
+        const int32_t c0 = h_cal_off[r], c1 = h_cal_off[r + 1];
+        h_hap_off[r + 1] = h_hap_off[r] + ((c1 > c0) ? h_hap_len[r] : 0);
+        if (c1 > c0) max_hap = std::max(max_hap, h_hap_len[r]);
+        const bool ok = (h_status[r] == ST_OK); // (a read turned down by L1/L2 keeps its slots in the batch, with no ops)
+        for (int32_t c = c0; c < c1; ++c) h_op_off[c + 1] = h_op_off[c] + (ok ? h_n_ops[c] : 0);
+    }
+    const int64_t n_hap = h_hap_off[n], ops_total = h_op_off[n_cals];
+    const int W = sk_ent_evmask_words(std::max(in->max_read_len, 0));
+
+    RES(cals, sizeof(PCal) * size_t(n_cals));
+    RES(hap_code, size_t(n_hap) + 16);
+    RES(ops, sizeof(sk_score_op) * size_t(ops_total));
+    RES(entries, 4 * (size_t(ops_total) + 2 * size_t(n_cals) + 1));
+    RES(evmask, 4 * (size_t(n) * size_t(W) + 1));
+    RES(scores, 8 * size_t(n_cals));
+    HRES(h_cals, sizeof(PCal) * size_t(n_cals));
+    HRES(h_scores, 8 * size_t(n_cals));
+    out->cals = B.h_cals.as<PCal>();
+
+    if (n_cals > 0) {
+        SK_HIP(hipMemcpyAsync(B.hap_off.p, h_hap_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
+        SK_HIP(hipMemcpyAsync(B.op_off.p, h_op_off, 8 * size_t(n_cals + 1), hipMemcpyHostToDevice, st));
+        SK_HIP(hipMemsetAsync(B.evmask.p, 0, 4 * size_t(n) * size_t(W), st));
+        fa.hap_off = B.hap_off.as<int64_t>();
+        fa.op_off = B.op_off.as<int64_t>();
+        fa.cals = B.cals.as<PCal>();
+        fa.hap_code = B.hap_code.as<uint8_t>();
+        fa.ops = B.ops.as<sk_score_op>();
+        fa.entries = B.entries.as<uint32_t>();
+        fa.evmask = B.evmask.as<uint32_t>();
+        fa.evmask_words = W;
+        fa.max_read_len = in->max_read_len;
+        hipLaunchKernelGGL(pool_fill_kernel, dim3(n), dim3(64), 0, st, fa);
+        hipLaunchKernelGGL(flatten_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+        SK_HIP(hipGetLastError());
+        D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
+        if (in->want_scores) {
+            hipLaunchKernelGGL(entries_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+            SK_HIP(hipGetLastError());
+            lap("F1-F3 flatten");
+            sk_align_batch d;
+            std::memset(&d, 0, sizeof(d));
+            d.n_reads = n;
+            d.n_cals = n_cals;
+            d.n_ops = ops_total;
+            d.read_off = B.read_off.as<int64_t>();
+            d.read_code = B.read_code.as<uint8_t>();
+            d.read_qual = B.read_qual.as<uint8_t>();
+            d.hap_off = fa.hap_off;
+            d.hap_code = fa.hap_code;
+            d.cal_off = fa.cal_off;
+            d.op_off = fa.op_off;
+            d.ops = fa.ops;
+            d.max_read_len = in->max_read_len;
+            d.max_hap_len = max_hap;
+            d.entries = fa.entries;
+            d.evmask = fa.evmask;
+            d.evmask_words = W;
+            if (sk_score_alignments_launch_hostleg(&d, B.scores.as<double>(), st)) return 1;
+            lap("A1 score");
+            D2H(h_scores, scores, 8 * size_t(n_cals));
+            out->scores = B.h_scores.as<double>();
+        }
+    }
+    D2H(h_consulted, consulted, size_t(in->n_tab));
+    SK_HIP(hipStreamSynchronize(st));
+    lap("done");
+#undef RES
+#undef HRES
+#undef H2D
+#undef D2H
+    return 0;
+}

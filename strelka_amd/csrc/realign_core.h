@@ -233,6 +233,7 @@ struct PFrame // the by-value state of one call of candidate_alignment_search
     uint8_t n_sm, n_order, n_hm, n_nhm;
     uint16_t depth, indel_toggle_depth, total_toggle_depth, stage; // stage: which child comes next
     int32_t max_read_indel_toggle;
+    int32_t read_id; // (level-synchronous expansion on the device: which read the frame belongs to)
     PRange read_range;
     PCal cal;
     int16_t cur; // order[depth] of this call
@@ -267,6 +268,8 @@ struct PJob
     int32_t is_haplotyping_enabled;
     int32_t max_indel_size;
     uint8_t* consulted; // [n_tab] or null: candidate status consulted (see sk_realign_job_indels_consulted)
+    int32_t max_nodes;  // 0 = no limit; else a search longer than this many calls ends with ST_OVERFLOW (the device hands such
+                        // reads to the host instead of keeping one lane busy for long)
 };
 
 SKC_HD inline bool job_cand(const PJob& j, int i)
@@ -302,6 +305,7 @@ struct SearchOut
 {
     int status;
     int warn_origin, warn_toggle;
+    int nodes; // calls of candidate_alignment_search made
 };
 
 // ---- status-map helpers (entries ascending by table index) ----
@@ -368,7 +372,7 @@ SKC_HD inline bool add_indels_in_range(const PJob& j, const PRead& r, const PRan
 template <typename F>
 SKC_HD inline void sort_remove_only_indels_last(F& f, unsigned current_depth)
 {
-    int16_t o2[Caps::K];
+    int16_t* o2 = f.current; // free at this point of the call: `current` is only live between the frame's stages 1 and 2
     int n = 0;
     for (unsigned i = 0; i < current_depth; ++i) o2[n++] = f.order[i];
     for (unsigned i = current_depth; i < f.n_order; ++i) {
@@ -614,243 +618,304 @@ SKC_HD inline unsigned get_max_toggle(const PJob& j, unsigned n_indels) // starl
     return (n_indels >= unsigned(j.n_max_toggle)) ? 1u : j.max_toggle[n_indels];
 }
 
-// The search.  `stack`: Caps::K + 2 frames of scratch.  `sink(const PCal&)` receives every leaf (with its indel set) in
-// the order the reference inserts them into its set; it returns false when it cannot take more (-> ST_OVERFLOW).
-template <typename Sink>
-SKC_HD inline SearchOut candidate_alignment_search(const PJob& j, const PRead& r, PFrame* stack, Sink& sink)
+// the live part of a candidate alignment (the arrays' tails are not read)
+SKC_HD inline void copy_cal(PCal& d, const PCal& q)
 {
-    SearchOut out;
-    out.status = ST_OK;
-    out.warn_origin = out.warn_toggle = 0;
+    d.pos = q.pos;
+    d.lead = q.lead;
+    d.trail = q.trail;
+    d.fwd = q.fwd;
+    d.n_seg = q.n_seg;
+    d.n_indels = q.n_indels;
+    d.pad = 0;
+    for (int i = 0; i < q.n_seg; ++i) d.path[i] = q.path[i];
+    for (int i = 0; i < q.n_indels; ++i) d.indels[i] = q.indels[i];
+}
+
+// The frame of the first call (getCandidateAlignments :1957)
+SKC_HD inline void root_frame(const PJob& j, const PRead& r, PFrame& f)
+{
+    for (int i = 0; i < r.n_sm; ++i) f.sm[i] = r.sm[i];
+    f.n_sm = r.n_sm;
+    for (int i = 0; i < r.n_order; ++i) f.order[i] = r.order[i];
+    f.n_order = r.n_order;
+    f.n_hm = 0;
+    f.n_nhm = 0;
+    f.depth = f.indel_toggle_depth = f.total_toggle_depth = 0;
+    f.stage = 0;
+    f.max_read_indel_toggle = j.max_read_indel_toggle;
+    f.read_range = r.exemplar_range;
+    f.read_id = 0;
+    copy_cal(f.cal, r.cal);
+}
+
+// ONE call of candidate_alignment_search (:857-1277) up to its recursive calls: `f` is the call's by-value state (it is modified,
+// as the reference modifies its by-value arguments); a leaf goes to `sink(PCal&)` (it may modify the leaf, and returns false when
+// it cannot take more), and every recursive call the reference would make becomes a child frame -- `alloc()` hands out the slot
+// (null = none left) -- that the caller expands in turn, in any order: the calls share nothing but the set the leaves go into
+// and the two warning flags.  `tmp`: one PCal of scratch.  Anything but ST_OK in out.status ends the read's search.
+template <typename Alloc, typename Sink>
+SKC_HD inline void expand_node(const PJob& j, const PRead& r, PFrame& f, Alloc& alloc, PCal* tmp, Sink& sink, SearchOut& out)
+{
     const unsigned read_length = unsigned(r.read_length);
     const PRange realign_range = mk_range(r.realign_b, r.realign_e);
+    out.nodes++;
 
-    int sp = 0;
-    {
-        PFrame& f = stack[0];
-        for (int i = 0; i < r.n_sm; ++i) f.sm[i] = r.sm[i];
-        f.n_sm = r.n_sm;
-        for (int i = 0; i < r.n_order; ++i) f.order[i] = r.order[i];
-        f.n_order = r.n_order;
-        f.n_hm = 0;
-        f.n_nhm = 0;
-        f.depth = f.indel_toggle_depth = f.total_toggle_depth = 0;
-        f.stage = 0;
-        f.max_read_indel_toggle = j.max_read_indel_toggle;
-        f.read_range = r.exemplar_range;
-        f.cal = r.cal;
-    }
-
-    // child creation: copy the parent's state by value into the next frame
-    auto spawn = [&](const PFrame& p, const PHap* hm, int n_hm, unsigned depth, unsigned itd, unsigned ttd, const PCal& cal) {
-        PFrame& c = stack[sp + 1];
-        for (int i = 0; i < p.n_sm; ++i) c.sm[i] = p.sm[i];
-        c.n_sm = p.n_sm;
-        for (int i = 0; i < p.n_order; ++i) c.order[i] = p.order[i];
-        c.n_order = p.n_order;
-        for (int i = 0; i < n_hm; ++i) c.hm[i] = hm[i];
+    // the child's by-value copy of this call's state; its haplotype map and alignment are written by the caller of `spawn`
+    auto spawn = [&](PFrame& c, int n_hm, unsigned depth, unsigned itd, unsigned ttd) {
+        for (int i = 0; i < f.n_sm; ++i) c.sm[i] = f.sm[i];
+        c.n_sm = f.n_sm;
+        for (int i = 0; i < f.n_order; ++i) c.order[i] = f.order[i];
+        c.n_order = f.n_order;
         c.n_hm = uint8_t(n_hm);
         c.n_nhm = 0;
         c.depth = uint16_t(depth);
         c.indel_toggle_depth = uint16_t(itd);
         c.total_toggle_depth = uint16_t(ttd);
         c.stage = 0;
-        c.max_read_indel_toggle = p.max_read_indel_toggle;
-        c.read_range = p.read_range;
-        c.cal = cal;
-        ++sp;
+        c.max_read_indel_toggle = f.max_read_indel_toggle;
+        c.read_range = f.read_range;
+        c.read_id = f.read_id;
     };
 
-    while (sp >= 0) {
-        PFrame& f = stack[sp];
-        if (f.stage == 0) {
-            // ---- entry of the call (:873-1005)
-            bool is_new_indels = (f.indel_toggle_depth == 0);
-            {
-                const unsigned start_size = f.n_sm;
-                const PRange pr = soft_clip_range(f.cal);
-                if (!superset_of(realign_range, pr)) {
-                    --sp;
-                    continue;
-                }
-                if (pr.b < f.read_range.b) {
-                    if (!add_indels_in_range(j, r, mk_range(pr.b, f.read_range.b + 1), f)) { out.status = ST_OVERFLOW; return out; }
-                    f.read_range.b = pr.b;
-                }
-                if (pr.e > f.read_range.e) {
-                    if (!add_indels_in_range(j, r, mk_range(f.read_range.e - 1, pr.e), f)) { out.status = ST_OVERFLOW; return out; }
-                    f.read_range.e = pr.e;
-                }
-                if (!is_new_indels) is_new_indels = (start_size != f.n_sm);
-                if (is_new_indels) sort_remove_only_indels_last(f, start_size);
-            }
-            if (f.depth == f.n_order) {
-                PCal leaf = f.cal;
-                add_keys_to_cal(j, f, leaf);
-                if (!sink(leaf)) { out.status = ST_OVERFLOW; return out; }
-                --sp;
-                continue;
-            }
-            if (is_new_indels) {
-                const double max_indels = double(read_length) * j.max_candidate_indel_density;
-                if (double(f.n_sm) > max_indels) f.max_read_indel_toggle = 1;
-                else f.max_read_indel_toggle = j.max_read_indel_toggle;
-                const int mt = int(get_max_toggle(j, f.n_sm));
-                if (mt < f.max_read_indel_toggle) f.max_read_indel_toggle = mt;
-            }
-            if (int(f.indel_toggle_depth) > f.max_read_indel_toggle) {
-                out.warn_toggle = 1;
-                --sp;
-                continue;
-            }
-            if (sp + 1 >= Caps::K + 2) { out.status = ST_OVERFLOW; return out; }
-
-            const int cur = f.order[f.depth];
-            f.cur = int16_t(cur);
-            const PIndel& cur_key = j.tab[cur];
-            bool cur_conflicting = false, contains_ndfr = false;
-            for (unsigned i = 0; i < f.depth; ++i) {
-                const int oi = f.order[i];
-                if (!f.sm[sm_find(f, oi)].is_present) continue;
-                if (is_indel_conflict(j.tab[oi], cur_key)) cur_conflicting = true;
-                if (!contains_ndfr && j.tab[oi].ndfr) contains_ndfr = true;
-            }
-            const int cur_at = sm_find(f, cur);
-            const bool cur_on = f.sm[cur_at].is_present != 0;
-            f.cur_on = cur_on ? 1 : 0;
-            const int32_t arid = cur_key.arid;
-            const bool in_ar = (arid >= 0);
-            if (in_ar && hm_find(f.hm, f.n_hm, arid) < 0) {
-                if (f.n_hm >= Caps::H) { out.status = ST_OVERFLOW; return out; }
-                PHap h;
-                h.arid = arid;
-                for (int s = 0; s < SK_MAX_SAMPLES; ++s) h.hc[s] = 3;
-                h.any_on = 0;
-                h.pad[0] = h.pad[1] = h.pad[2] = 0;
-                f.hm[f.n_hm++] = h;
-            }
-            const bool cur_ndfr = cur_key.ndfr != 0;
-            int hap_ids[SK_MAX_SAMPLES];
-            cur_indel_haplotype_ids(j, r.sample, cur, f.sm[cur_at].in_original != 0, hap_ids);
-
-            // the toggled children's haplotype map and validity are decided from the state as it is now (:1090-1124)
-            bool valid2 = true;
-            for (int i = 0; i < f.n_hm; ++i) f.nhm[i] = f.hm[i];
-            f.n_nhm = f.n_hm;
-            if (!cur_conflicting && in_ar) valid2 = hap_update(f.nhm[hm_find(f.nhm, f.n_nhm, arid)], j.sample_count, hap_ids, !cur_on);
-            else valid2 = !is_mismatch(cur_key) || cur_on;
-            if (!cur_on && contains_ndfr && cur_ndfr) valid2 = false;
-            if (valid2 && !cur_on) {
-                if (f.sm[cur_at].is_remove_only) valid2 = false;
-                if (cur_conflicting) valid2 = false;
-            }
-            f.toggle_inc = is_mismatch(cur_key) ? 0 : 1;
-            bool toggle_warn = false;
-            if (valid2 && int(f.indel_toggle_depth + f.toggle_inc) > f.max_read_indel_toggle) {
-                toggle_warn = true;
-                valid2 = false;
-            }
-            // stage codes: 1 = children 2/3 still to do, 9 = nothing left after child 1; bit 4 (16) = warn on return
-            f.stage = uint16_t((valid2 ? 1 : 9) | (toggle_warn ? 16 : 0));
-
-            { // alignment 1: unchanged (:1051-1088)
-                bool valid = true;
-                PHap hm1[Caps::H];
-                for (int i = 0; i < f.n_hm; ++i) hm1[i] = f.hm[i];
-                if (!cur_conflicting && in_ar) valid = hap_update(hm1[hm_find(hm1, f.n_hm, arid)], j.sample_count, hap_ids, cur_on);
-                else valid = (!is_mismatch(cur_key)) || (!cur_on);
-                if (cur_on && contains_ndfr && cur_ndfr) valid = false;
-                if (!valid && f.total_toggle_depth == 0) valid = true;
-                if (valid) {
-                    spawn(f, hm1, f.n_hm, f.depth + 1, f.indel_toggle_depth, f.total_toggle_depth, f.cal);
-                    continue;
-                }
-            }
-            continue; // re-enter this frame at its next stage
+    // ---- entry of the call (:873-1005)
+    bool is_new_indels = (f.indel_toggle_depth == 0);
+    {
+        const unsigned start_size = f.n_sm;
+        const PRange pr = soft_clip_range(f.cal);
+        if (!superset_of(realign_range, pr)) return;
+        if (pr.b < f.read_range.b) {
+            if (!add_indels_in_range(j, r, mk_range(pr.b, f.read_range.b + 1), f)) { out.status = ST_OVERFLOW; return; }
+            f.read_range.b = pr.b;
         }
+        if (pr.e > f.read_range.e) {
+            if (!add_indels_in_range(j, r, mk_range(f.read_range.e - 1, pr.e), f)) { out.status = ST_OVERFLOW; return; }
+            f.read_range.e = pr.e;
+        }
+        if (!is_new_indels) is_new_indels = (start_size != f.n_sm);
+        if (is_new_indels) sort_remove_only_indels_last(f, start_size);
+    }
+    if (f.depth == f.n_order) {
+        PCal& leaf = *tmp;
+        copy_cal(leaf, f.cal);
+        add_keys_to_cal(j, f, leaf);
+        if (!sink(leaf)) out.status = ST_OVERFLOW;
+        return;
+    }
+    if (is_new_indels) {
+        const double max_indels = double(read_length) * j.max_candidate_indel_density;
+        if (double(f.n_sm) > max_indels) f.max_read_indel_toggle = 1;
+        else f.max_read_indel_toggle = j.max_read_indel_toggle;
+        const int mt = int(get_max_toggle(j, f.n_sm));
+        if (mt < f.max_read_indel_toggle) f.max_read_indel_toggle = mt;
+    }
+    if (int(f.indel_toggle_depth) > f.max_read_indel_toggle) {
+        out.warn_toggle = 1;
+        return;
+    }
 
-        const unsigned stage = f.stage & 15u;
-        if (stage == 9) {
-            if (f.stage & 16u) out.warn_toggle = 1;
-            --sp;
-            continue;
+    const int cur = f.order[f.depth];
+    const PIndel& cur_key = j.tab[cur];
+    bool cur_conflicting = false, contains_ndfr = false;
+    for (unsigned i = 0; i < f.depth; ++i) {
+        const int oi = f.order[i];
+        if (!f.sm[sm_find(f, oi)].is_present) continue;
+        if (is_indel_conflict(j.tab[oi], cur_key)) cur_conflicting = true;
+        if (!contains_ndfr && j.tab[oi].ndfr) contains_ndfr = true;
+    }
+    const int cur_at = sm_find(f, cur);
+    const bool cur_on = f.sm[cur_at].is_present != 0;
+    const int32_t arid = cur_key.arid;
+    const bool in_ar = (arid >= 0);
+    if (in_ar && hm_find(f.hm, f.n_hm, arid) < 0) {
+        if (f.n_hm >= Caps::H) { out.status = ST_OVERFLOW; return; }
+        PHap h;
+        h.arid = arid;
+        for (int s = 0; s < SK_MAX_SAMPLES; ++s) h.hc[s] = 3;
+        h.any_on = 0;
+        h.pad[0] = h.pad[1] = h.pad[2] = 0;
+        f.hm[f.n_hm++] = h;
+    }
+    const bool cur_ndfr = cur_key.ndfr != 0;
+    int hap_ids[SK_MAX_SAMPLES];
+    cur_indel_haplotype_ids(j, r.sample, cur, f.sm[cur_at].in_original != 0, hap_ids);
+
+    // the toggled children's haplotype map and validity are decided from the state as it is now (:1090-1124)
+    bool valid2 = true;
+    for (int i = 0; i < f.n_hm; ++i) f.nhm[i] = f.hm[i];
+    f.n_nhm = f.n_hm;
+    if (!cur_conflicting && in_ar) valid2 = hap_update(f.nhm[hm_find(f.nhm, f.n_nhm, arid)], j.sample_count, hap_ids, !cur_on);
+    else valid2 = !is_mismatch(cur_key) || cur_on;
+    if (!cur_on && contains_ndfr && cur_ndfr) valid2 = false;
+    if (valid2 && !cur_on) {
+        if (f.sm[cur_at].is_remove_only) valid2 = false;
+        if (cur_conflicting) valid2 = false;
+    }
+    const unsigned toggle_inc = is_mismatch(cur_key) ? 0 : 1;
+    if (valid2 && int(f.indel_toggle_depth + toggle_inc) > f.max_read_indel_toggle) {
+        out.warn_toggle = 1;
+        valid2 = false;
+    }
+
+    { // alignment 1: unchanged (:1051-1088)
+        bool valid = true;
+        PHap one;
+        int at = -1;
+        if (!cur_conflicting && in_ar) {
+            at = hm_find(f.hm, f.n_hm, arid);
+            one = f.hm[at];
+            valid = hap_update(one, j.sample_count, hap_ids, cur_on);
+        } else {
+            valid = (!is_mismatch(cur_key)) || (!cur_on);
         }
-        const PIndel& cur_key = j.tab[f.cur];
-        if (stage == 1) {
-            // toggle the indel, collect the present set (:1126-1140)
-            f.sm[sm_find(f, f.cur)].is_present = f.cur_on ? 0 : 1;
-            int n = 0;
-            for (int i = 0; i < f.n_sm; ++i)
-                if (f.sm[i].is_present) f.current[n++] = f.sm[i].idx;
-            f.n_current = uint8_t(n);
-            f.stage = 2;
-            // alignment 2: start pin (:1142-1190)
-            const int32_t ref_start = f.cal.pos;
-            bool start_pin_valid = true;
-            if (!is_mismatch(cur_key)) {
-                const bool del_span = pos_intersect(open_pos_range(cur_key), ref_start);
-                const bool indel_span = f.cur_on && (f.cur == f.cal.lead);
-                start_pin_valid = !(del_span || indel_span);
-            }
-            if (start_pin_valid) {
-                const int32_t read_start = int32_t(unaligned_prefix(f.cal));
-                PCal start_cal;
-                const int rc = make_start_pos_alignment(j, ref_start, read_start, f.cal.fwd != 0, read_length, f.current, f.n_current, start_cal);
-                if (rc != ST_OK) { out.status = rc; return out; }
-                spawn(f, f.nhm, f.n_nhm, f.depth + 1, f.indel_toggle_depth + f.toggle_inc, f.total_toggle_depth + 1, start_cal);
-                continue;
-            }
-            continue;
+        if (cur_on && contains_ndfr && cur_ndfr) valid = false;
+        if (!valid && f.total_toggle_depth == 0) valid = true;
+        if (valid) {
+            PFrame* c = alloc();
+            if (!c) { out.status = ST_OVERFLOW; return; }
+            for (int i = 0; i < f.n_hm; ++i) c->hm[i] = f.hm[i];
+            if (at >= 0) c->hm[at] = one;
+            copy_cal(c->cal, f.cal);
+            spawn(*c, f.n_hm, f.depth + 1, f.indel_toggle_depth, f.total_toggle_depth);
         }
-        if (stage == 2) {
-            f.stage = 9;
-            if (is_mismatch(cur_key)) continue;
-            if (cur_key.type == SK_INDEL_INDEL && cur_key.del == cur_key.ins_len) continue;
-            // alignment 3: end pin (:1198-1270)
-            const int32_t ref_end = f.cal.pos + int32_t(path_ref_length(f.cal));
-            const bool del_span = pos_intersect(open_pos_range(cur_key), ref_end - 1);
-            const bool indel_span = f.cur_on && (f.cur == f.cal.trail);
-            if (!(del_span || indel_span)) {
-                const int32_t read_end = int32_t(read_length) - int32_t(unaligned_suffix(f.cal));
-                int32_t ref_start = 0, read_start = 0;
-                const int rc0 = get_end_pin_start_pos(j, f.current, f.n_current, read_length, ref_end, read_end, ref_start, read_start);
-                if (rc0 != ST_OK) { out.status = rc0; return out; }
-                if (ref_start < 0) {
-                    out.warn_origin = 1;
-                } else {
-                    PCal start_cal;
-                    const int rc = make_start_pos_alignment(j, ref_start, read_start, f.cal.fwd != 0, read_length, f.current, f.n_current, start_cal);
-                    if (rc != ST_OK) { out.status = rc; return out; }
-                    spawn(f, f.nhm, f.n_nhm, f.depth + 1, f.indel_toggle_depth + f.toggle_inc, f.total_toggle_depth + 1, start_cal);
-                    continue;
-                }
-            }
-            continue;
+    }
+    if (!valid2) return;
+
+    // toggle the indel, collect the present set (:1126-1140)
+    f.sm[cur_at].is_present = cur_on ? 0 : 1;
+    {
+        int n = 0;
+        for (int i = 0; i < f.n_sm; ++i)
+            if (f.sm[i].is_present) f.current[n++] = f.sm[i].idx;
+        f.n_current = uint8_t(n);
+    }
+    { // alignment 2: start pin (:1142-1190)
+        const int32_t ref_start = f.cal.pos;
+        bool start_pin_valid = true;
+        if (!is_mismatch(cur_key)) {
+            const bool del_span = pos_intersect(open_pos_range(cur_key), ref_start);
+            const bool indel_span = cur_on && (cur == f.cal.lead);
+            start_pin_valid = !(del_span || indel_span);
         }
-        --sp; // not reached
+        if (start_pin_valid) {
+            const int32_t read_start = int32_t(unaligned_prefix(f.cal));
+            PFrame* c = alloc();
+            if (!c) { out.status = ST_OVERFLOW; return; }
+            c->stage = 0xffff; // (dead unless completed below)
+            const int rc = make_start_pos_alignment(j, ref_start, read_start, f.cal.fwd != 0, read_length, f.current, f.n_current, c->cal);
+            if (rc != ST_OK) { out.status = rc; return; }
+            for (int i = 0; i < f.n_nhm; ++i) c->hm[i] = f.nhm[i];
+            spawn(*c, f.n_nhm, f.depth + 1, f.indel_toggle_depth + toggle_inc, f.total_toggle_depth + 1);
+        }
+    }
+    if (is_mismatch(cur_key)) return;
+    if (cur_key.type == SK_INDEL_INDEL && cur_key.del == cur_key.ins_len) return;
+    { // alignment 3: end pin (:1198-1270)
+        const int32_t ref_end = f.cal.pos + int32_t(path_ref_length(f.cal));
+        const bool del_span = pos_intersect(open_pos_range(cur_key), ref_end - 1);
+        const bool indel_span = cur_on && (cur == f.cal.trail);
+        if (del_span || indel_span) return;
+        const int32_t read_end = int32_t(read_length) - int32_t(unaligned_suffix(f.cal));
+        int32_t ref_start = 0, read_start = 0;
+        const int rc0 = get_end_pin_start_pos(j, f.current, f.n_current, read_length, ref_end, read_end, ref_start, read_start);
+        if (rc0 != ST_OK) { out.status = rc0; return; }
+        if (ref_start < 0) {
+            out.warn_origin = 1;
+            return;
+        }
+        PFrame* c = alloc();
+        if (!c) { out.status = ST_OVERFLOW; return; }
+        c->stage = 0xffff;
+        const int rc = make_start_pos_alignment(j, ref_start, read_start, f.cal.fwd != 0, read_length, f.current, f.n_current, c->cal);
+        if (rc != ST_OK) { out.status = rc; return; }
+        for (int i = 0; i < f.n_nhm; ++i) c->hm[i] = f.nhm[i];
+        spawn(*c, f.n_nhm, f.depth + 1, f.indel_toggle_depth + toggle_inc, f.total_toggle_depth + 1);
+    }
+}
+
+// The whole search of one read, depth first on a stack of frames (`stack`: up to `max_frames`, 2 * Caps::K + 4 always suffice:
+// expanding a frame takes it off the stack and puts at most three on).  Leaves reach the sink in an order that differs from the
+// reference's (children are expanded last-made-first); the set they form is the same.
+template <typename Sink>
+SKC_HD inline SearchOut candidate_alignment_search(const PJob& j, const PRead& r, PFrame* stack, const int max_frames, PFrame* cur,
+                                                   PCal* tmp, Sink& sink)
+{
+    SearchOut out;
+    out.status = ST_OK;
+    out.warn_origin = out.warn_toggle = 0;
+    out.nodes = 0;
+    int sp = 0;
+    root_frame(j, r, stack[0]);
+    sp = 1;
+    struct StackAlloc
+    {
+        PFrame* stack;
+        int* sp;
+        int max_frames;
+        SKC_HD PFrame* operator()()
+        {
+            if (*sp >= max_frames) return nullptr;
+            return &stack[(*sp)++];
+        }
+    } alloc{ stack, &sp, max_frames };
+    while (sp > 0) {
+        // by value: the frame leaves the stack, its children may take its slot
+        {
+            const PFrame& top = stack[sp - 1];
+            for (int i = 0; i < top.n_sm; ++i) cur->sm[i] = top.sm[i];
+            cur->n_sm = top.n_sm;
+            for (int i = 0; i < top.n_order; ++i) cur->order[i] = top.order[i];
+            cur->n_order = top.n_order;
+            for (int i = 0; i < top.n_hm; ++i) cur->hm[i] = top.hm[i];
+            cur->n_hm = top.n_hm;
+            cur->n_nhm = 0;
+            cur->depth = top.depth;
+            cur->indel_toggle_depth = top.indel_toggle_depth;
+            cur->total_toggle_depth = top.total_toggle_depth;
+            cur->stage = top.stage;
+            cur->max_read_indel_toggle = top.max_read_indel_toggle;
+            cur->read_range = top.read_range;
+            cur->read_id = top.read_id;
+            copy_cal(cur->cal, top.cal);
+        }
+        --sp;
+        if (cur->stage == 0xffff) continue;
+        if (j.max_nodes > 0 && out.nodes >= j.max_nodes) {
+            out.status = ST_OVERFLOW;
+            return out;
+        }
+        expand_node(j, r, *cur, alloc, tmp, sink, out);
+        if (out.status != ST_OK) return out;
     }
     return out;
 }
 
-// clip_adder :508-542 on a leaf
+// clip_adder :508-542 on a leaf, in place
 SKC_HD inline bool clip_adder(PCal& c, unsigned hc_lead, unsigned hc_trail, unsigned sc_lead, unsigned sc_trail)
 {
-    PSeg q[Caps::P];
+    const int n_lead = (hc_lead ? 1 : 0) + (sc_lead ? 1 : 0), n_trail = (hc_trail ? 1 : 0) + (sc_trail ? 1 : 0);
+    if (int(c.n_seg) + n_lead + n_trail > Caps::P) return false;
+    if (hc_lead > 0xffffu || hc_trail > 0xffffu || sc_lead > 0xffffu || sc_trail > 0xffffu) return false;
+    if (n_lead)
+        for (int i = int(c.n_seg) - 1; i >= 0; --i) c.path[i + n_lead] = c.path[i];
     int n = 0;
-    auto push = [&](unsigned t, unsigned l) -> bool {
-        if (n >= Caps::P || l > 0xffffu) return false;
-        q[n].type = uint16_t(t);
-        q[n].length = uint16_t(l);
-        ++n;
-        return true;
-    };
-    if (hc_lead && !push(SK_SEG_HARD_CLIP, hc_lead)) return false;
-    if (sc_lead && !push(SK_SEG_SOFT_CLIP, sc_lead)) return false;
-    for (int i = 0; i < c.n_seg; ++i)
-        if (!push(c.path[i].type, c.path[i].length)) return false;
-    if (sc_trail && !push(SK_SEG_SOFT_CLIP, sc_trail)) return false;
-    if (hc_trail && !push(SK_SEG_HARD_CLIP, hc_trail)) return false;
-    for (int i = 0; i < n; ++i) c.path[i] = q[i];
+    if (hc_lead) {
+        c.path[n].type = SK_SEG_HARD_CLIP;
+        c.path[n++].length = uint16_t(hc_lead);
+    }
+    if (sc_lead) {
+        c.path[n].type = SK_SEG_SOFT_CLIP;
+        c.path[n++].length = uint16_t(sc_lead);
+    }
+    n += c.n_seg;
+    if (sc_trail) {
+        c.path[n].type = SK_SEG_SOFT_CLIP;
+        c.path[n++].length = uint16_t(sc_trail);
+    }
+    if (hc_trail) {
+        c.path[n].type = SK_SEG_HARD_CLIP;
+        c.path[n++].length = uint16_t(hc_trail);
+    }
     c.n_seg = uint8_t(n);
     return true;
 }

@@ -348,6 +348,12 @@ static int score_alignments_launch(const sk_align_batch* b, double* dev_out_lnp,
     return 0;
 }
 
+// device batch, but on behalf of a host-buffer entry point (the realignment job's device pipeline, read_enumerate.hip)
+int sk_score_alignments_launch_hostleg(const sk_align_batch* b, double* dev_out_lnp, void* hip_stream)
+{
+    return score_alignments_launch(b, dev_out_lnp, hip_stream, true);
+}
+
 extern "C" int sk_score_alignments_dev(const sk_align_batch* b, double* dev_out_lnp, void* hip_stream)
 {
     return score_alignments_launch(b, dev_out_lnp, hip_stream, false);

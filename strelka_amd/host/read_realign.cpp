@@ -13,9 +13,12 @@
 
 #include "strelka_amd.h"
 #include "../csrc/realign_core.h"
+#include "../csrc/read_enumerate.h"
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -456,7 +459,14 @@ struct sk_realign_job
         std::vector<sk_read_path_scores> scores;
         std::vector<int32_t> suboverlap;
         int32_t cal_begin = 0; // first candidate alignment of this read in the job's batch
+        // enumeration == 2: the search state handed to the device (set until the job resolves it), what a host search needs
+        // should the device turn the read down, and where the read's scores are once the device has scored it
+        std::shared_ptr<skcore::PRead> pending;
+        std::vector<int> observed;
+        int32_t realign_b = 0, realign_e = 0;
+        int64_t dev_score_at = -1;
     };
+    std::vector<double> dev_scores;
     std::vector<Read> reads;
     sk_align_builder* builder = nullptr;
     int32_t n_cals_total = 0;
@@ -1135,6 +1145,7 @@ void build_core_tables(const Job& job, CoreTables& t, uint8_t* consulted)
     t.pj.is_haplotyping_enabled = job.opt.is_haplotyping_enabled;
     t.pj.max_indel_size = int32_t(job.opt.max_indel_size);
     t.pj.consulted = consulted;
+    t.pj.max_nodes = 0;
 }
 bool to_core_cal(const Cal& c, skcore::PCal& p)
 {
@@ -1161,8 +1172,9 @@ Cal from_core_cal(const skcore::PCal& p)
     c.al.fwd = p.fwd != 0;
     c.lead = p.lead;
     c.trail = p.trail;
-    for (int i = 0; i < p.n_seg; ++i) c.al.path.push_back(Seg{ p.path[i].type, p.path[i].length });
-    for (int i = 0; i < p.n_indels; ++i) c.indels.push_back(p.indels[i]);
+    c.al.path.resize(p.n_seg);
+    for (int i = 0; i < p.n_seg; ++i) c.al.path[size_t(i)] = Seg{ p.path[i].type, p.path[i].length };
+    c.indels.assign(p.indels, p.indels + p.n_indels);
     return c;
 }
 // the state getCandidateAlignments hands to candidate_alignment_search, in the core's form; false = beyond a cap
@@ -1200,7 +1212,7 @@ bool to_core_read(const Job& job, const std::set<int>& observed, int sample, uns
 
 // getCandidateAlignments :1816-1994
 void get_candidate_alignments(const Job& job, sk_realign_job::Read& rd, const std::set<int>& observed, const Aln& input,
-                              const Range& realign_range, std::set<Cal>& cal_set)
+                              const Range& realign_range, std::set<Cal>& cal_set, const bool force_host = false)
 {
     const unsigned read_length = unsigned(rd.code.size());
     StatusMap sm;
@@ -1258,6 +1270,19 @@ void get_candidate_alignments(const Job& job, sk_realign_job::Read& rd, const st
     }
     ctx.read_length = cal_read_length;
     bool searched = false;
+    if (job.opt.enumeration == 2 && !force_host) {
+        std::shared_ptr<skcore::PRead> pr(new skcore::PRead);
+        if (to_core_read(job, observed, rd.sample, cal_read_length, realign_range, exemplar_pr, sm, order, cal, *pr)) {
+            pr->clipped = clipped ? 1 : 0;
+            pr->hc_lead = hc_lead;
+            pr->hc_trail = hc_trail;
+            pr->sc_lead = sc_lead;
+            pr->sc_trail = sc_trail;
+            rd.pending = pr;
+            return;
+        }
+        job.n_fallback_reads.fetch_add(1, std::memory_order_relaxed);
+    }
     if (job.opt.enumeration == 1) {
         // the container-free core, on this thread (enumeration == 2 runs the same code on the device, read_enumerate.hip)
         std::unique_ptr<skcore::PRead> pr(new skcore::PRead);
@@ -1265,16 +1290,18 @@ void get_candidate_alignments(const Job& job, sk_realign_job::Read& rd, const st
             CoreTables tables;
             std::vector<uint8_t> consulted(job.tab.size() + 1, 0);
             build_core_tables(job, tables, consulted.data());
-            std::vector<skcore::PFrame> stack(skcore::Caps::K + 2);
+            std::vector<skcore::PFrame> stack(2 * skcore::Caps::K + 5);
             std::set<Cal> leaves;
             bool too_many = false;
-            auto sink = [&](const skcore::PCal& leaf) -> bool {
+            skcore::PCal tmp_cal;
+            auto sink = [&](skcore::PCal& leaf) -> bool {
                 leaves.insert(from_core_cal(leaf));
                 if (leaves.size() > 100000) too_many = true;
                 return !too_many;
             };
-            const skcore::SearchOut so = skcore::candidate_alignment_search(tables.pj, *pr, stack.data(), sink);
-            if (so.status == skcore::ST_FAIL) throw Fail("candidate alignment search failed (inconsistent indel set)");
+            const skcore::SearchOut so =
+                skcore::candidate_alignment_search(tables.pj, *pr, stack.data(), int(stack.size()) - 1, &stack.back(), &tmp_cal, sink);
+            // (anything else: the container-based code below redoes the read and reports what the reference would)
             if (so.status == skcore::ST_OK) {
                 for (size_t i = 0; i < job.tab.size(); ++i)
                     if (consulted[i]) (void)job.cand(int(i));
@@ -1928,6 +1955,7 @@ void sk_realign_job_clear_reads(sk_realign_job* j)
 {
     if (!j) return;
     j->reads.clear();
+    j->dev_scores.clear();
     j->n_cals_total = 0;
     sk_align_builder_clear(j->builder);
     j->finished = false;
@@ -1940,6 +1968,43 @@ int sk_realign_job_n_reads(const sk_realign_job* j) { return j ? int(j->reads.si
 
 namespace
 {
+
+// the gate, input normalisation and enumeration of a validated read (rd.code/input/observed/realign range are set); with
+// enumeration == 2 and `force_host` false the search itself is left pending for the device
+void enumerate_read(const Job& job, sk_realign_job::Read& rd, const bool force_host)
+{
+    const std::set<int> observed(rd.observed.begin(), rd.observed.end());
+    const Range realign_range(rd.realign_b, rd.realign_e);
+    const unsigned read_len = unsigned(rd.code.size());
+    rd.pending.reset();
+    rd.warn_origin = rd.warn_toggle = false;
+
+    std::set<Cal> cal_set;
+    bool gate = !is_overmax(rd.input, job.opt.max_indel_size); // is_realignable :2045
+    if (gate) { // check_for_candidate_indel_overlap :217-270
+        const Range rr = alignment_zone(rd.input, read_len);
+        gate = false;
+        if (realign_range.superset_of(rr)) {
+            const auto it = job.range_iter(rr.b, rr.e);
+            for (int i = it.first; i < it.second; ++i) {
+                if (!range_intersect_indel_breakpoints(rr, job.key(i))) continue;
+                if (job.cand(i)) { gate = true; break; }
+            }
+        }
+    }
+    if (gate) {
+        // normalizeInputAlignmentIndels :2001-2021 (no pinned edges on DNA reads)
+        Aln norm = rd.input;
+        if (is_edge_readref_len_segment(norm.path)) norm = matchify_edge_indels(norm, true, true);
+        if (path_is_soft_clipped(norm.path)) norm = matchify_edge_segment_type(norm, SK_SEG_SOFT_CLIP); // :2051-2057
+        if (norm.pos >= 0) {
+            get_candidate_alignments(job, rd, observed, norm, realign_range, cal_set, force_host);
+            if (cal_set.empty() && !rd.pending) throw Fail("Empty candidate alignment set while realigning normed input alignment");
+        }
+    }
+    rd.incomplete_search = rd.warn_origin || rd.warn_toggle;
+    rd.cals.assign(cal_set.begin(), cal_set.end());
+}
 
 // stage 1 for one read: validation, gate, normalisation, enumeration.  Touches nothing but `rd` (the job is read-only here),
 // so reads can be prepared concurrently.  Throws Fail.
@@ -1965,39 +2030,23 @@ void prepare_read(const Job& job, const sk_read_input* in, sk_realign_job::Read&
     }
     if (rd.input.empty() || path_read_length(rd.input.path) != unsigned(in->read_len))
         throw Fail("invalid alignment path associated with read segment"); // realignAndScoreRead :2036-2040
-    std::set<int> observed;
-    for (int i = 0; i < in->n_observed; ++i) {
-        const int o = in->observed[i];
-        if (o < 0 || size_t(o) >= job.orig_to_tab.size()) throw Fail("observed indel index out of range");
-        observed.insert(job.orig_to_tab[size_t(o)]);
-    }
-    const Range realign_range(in->realign_begin, in->realign_end);
-
-    std::set<Cal> cal_set;
-    bool gate = !is_overmax(rd.input, job.opt.max_indel_size); // is_realignable :2045
-    if (gate) { // check_for_candidate_indel_overlap :217-270
-        const Range rr = alignment_zone(rd.input, unsigned(in->read_len));
-        gate = false;
-        if (realign_range.superset_of(rr)) {
-            const auto it = job.range_iter(rr.b, rr.e);
-            for (int i = it.first; i < it.second; ++i) {
-                if (!range_intersect_indel_breakpoints(rr, job.key(i))) continue;
-                if (job.cand(i)) { gate = true; break; }
-            }
+    {
+        std::set<int> observed;
+        for (int i = 0; i < in->n_observed; ++i) {
+            const int o = in->observed[i];
+            if (o < 0 || size_t(o) >= job.orig_to_tab.size()) throw Fail("observed indel index out of range");
+            observed.insert(job.orig_to_tab[size_t(o)]);
         }
+        rd.observed.assign(observed.begin(), observed.end());
     }
-    if (gate) {
-        // normalizeInputAlignmentIndels :2001-2021 (no pinned edges on DNA reads)
-        Aln norm = rd.input;
-        if (is_edge_readref_len_segment(norm.path)) norm = matchify_edge_indels(norm, true, true);
-        if (path_is_soft_clipped(norm.path)) norm = matchify_edge_segment_type(norm, SK_SEG_SOFT_CLIP); // :2051-2057
-        if (norm.pos >= 0) {
-            get_candidate_alignments(job, rd, observed, norm, realign_range, cal_set);
-            if (cal_set.empty()) throw Fail("Empty candidate alignment set while realigning normed input alignment");
-        }
-    }
-    rd.incomplete_search = rd.warn_origin || rd.warn_toggle;
-    rd.cals.assign(cal_set.begin(), cal_set.end());
+    rd.realign_b = in->realign_begin;
+    rd.realign_e = in->realign_end;
+    enumerate_read(job, rd, false);
+    if (rd.pending) // the device scores these reads without passing the builder, whose check this is
+        for (const uint8_t q : rd.qual)
+            if (q > 70) // qphred_cache::high_qscore_error, L/blt_util/qscore_cache.cpp:66-75
+                throw Fail("flatten: Attempting to lookup basecall quality score " + std::to_string(int(q)) +
+                           " which exceeds the maximum cached basecall quality score of 70");
 }
 
 // flatten a prepared read's candidate alignments into `builder`; returns the number of candidate alignments added
@@ -2018,7 +2067,7 @@ int32_t flatten_read(const Job& j, sk_align_builder* builder, const sk_realign_j
 void append_read(Job& j, sk_realign_job::Read&& rd)
 {
     rd.cal_begin = j.n_cals_total;
-    j.n_cals_total += flatten_read(j, j.builder, rd);
+    if (j.opt.enumeration != 2) j.n_cals_total += flatten_read(j, j.builder, rd); // (2: the batch is assembled by the job's run)
     j.reads.push_back(std::move(rd));
 }
 
@@ -2113,7 +2162,7 @@ int sk_realign_job_add_reads(sk_realign_job* j, const sk_read_input* in, int32_t
             for (size_t i = b; i < e; ++i) {
                 try {
                     prepare_read(*j, in + i, prepared[i]);
-                    prepared[i].cal_begin = flatten_read(*j, slices[t].builder, prepared[i]); // (count for now)
+                    prepared[i].cal_begin = (j->opt.enumeration != 2) ? flatten_read(*j, slices[t].builder, prepared[i]) : 0; // (count for now)
                 } catch (const std::exception& ex) {
                     throw Fail("read " + std::to_string(i) + ": " + ex.what());
                 }
@@ -2148,15 +2197,130 @@ static int finish_builder(sk_realign_job* j, sk_align_batch* out)
     return 0;
 }
 
+} // extern "C"
+
+// enumeration == 2: hand every pending read to the device pipeline (csrc/read_enumerate.hip); afterwards every read of the job
+// has its candidate alignments (and, with `want_scores`, the device reads their scores in j.dev_scores).  Throws Fail.
+static void resolve_pending(sk_realign_job& j, const bool want_scores)
+{
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < j.reads.size(); ++i)
+        if (j.reads[i].pending) idx.push_back(i);
+    if (idx.empty()) return;
+    CoreTables tables;
+    build_core_tables(j, tables, nullptr);
+    std::vector<skcore::PRead> preads(idx.size());
+    std::vector<int64_t> read_off(idx.size() + 1, 0);
+    std::vector<uint8_t> code, qual;
+    int32_t max_read_len = 0;
+    for (size_t k = 0; k < idx.size(); ++k) {
+        const auto& rd = j.reads[idx[k]];
+        preads[k] = *rd.pending;
+        code.insert(code.end(), rd.code.begin(), rd.code.end());
+        qual.insert(qual.end(), rd.qual.begin(), rd.qual.end());
+        read_off[k + 1] = int64_t(code.size());
+        max_read_len = std::max(max_read_len, int32_t(rd.code.size()));
+    }
+    SkEnumInput in;
+    std::memset(&in, 0, sizeof(in));
+    in.tab = tables.tab.data();
+    in.n_tab = int32_t(tables.tab.size());
+    in.ins_pool = tables.ins_pool.data();
+    in.ins_pool_len = int64_t(tables.ins_pool.size());
+    in.max_toggle = j.max_toggle.data();
+    in.n_max_toggle = int32_t(j.max_toggle.size());
+    in.sample_count = j.opt.sample_count;
+    in.max_read_indel_toggle = j.opt.max_read_indel_toggle;
+    in.is_haplotyping_enabled = j.opt.is_haplotyping_enabled;
+    in.max_indel_size = int32_t(j.opt.max_indel_size);
+    in.max_candidate_indel_density = j.opt.max_candidate_indel_density;
+    in.ref = j.ref.data();
+    in.ref_offset = j.ref_offset;
+    in.ref_len = int32_t(j.ref.size());
+    in.reads = preads.data();
+    in.n_reads = int32_t(preads.size());
+    in.read_off = read_off.data();
+    in.read_code = code.data();
+    in.read_qual = qual.data();
+    in.max_read_len = max_read_len;
+    in.want_scores = want_scores ? 1 : 0;
+    SkEnumOutput out;
+    const bool timing = std::getenv("SK_ENUM_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (sk_enum_device_run(&in, &out)) throw Fail(std::string("device enumeration: ") + sk_last_error());
+    const auto t1 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < j.tab.size(); ++i)
+        if (out.consulted[i]) (void)j.cand(int(i));
+    const int32_t n_cals = out.cal_off[idx.size()];
+    j.dev_scores.clear();
+    if (want_scores && n_cals > 0) j.dev_scores.assign(out.scores, out.scores + n_cals);
+    // device results -> the reads' structures (reads are independent: each slice of the loop touches only its own reads)
+    const std::string err = parallel_for(idx.size(), host_threads(j, idx.size()), [&](const size_t k) {
+        auto& rd = j.reads[idx[k]];
+        rd.pending.reset();
+        rd.dev_score_at = -1;
+        if (out.status[k] == skcore::ST_OK) {
+            const int32_t b = out.cal_off[k], e = out.cal_off[k + 1];
+            if (b == e) throw Fail("Empty candidate alignment set while realigning normed input alignment");
+            rd.cals.clear();
+            rd.cals.reserve(size_t(e - b));
+            for (int32_t c = b; c < e; ++c) rd.cals.push_back(from_core_cal(out.cals[c]));
+            rd.warn_origin = (out.warn[k] & 1) != 0;
+            rd.warn_toggle = (out.warn[k] & 2) != 0;
+            rd.incomplete_search = rd.warn_origin || rd.warn_toggle;
+            if (want_scores) rd.dev_score_at = b;
+            j.n_device_reads.fetch_add(1, std::memory_order_relaxed);
+        } else {
+            // beyond a capacity of the device form, or input the host code throws on: the container-based code decides
+            const auto tf = std::chrono::steady_clock::now();
+            enumerate_read(j, rd, true);
+            j.n_fallback_reads.fetch_add(1, std::memory_order_relaxed);
+            if (timing && std::getenv("SK_ENUM_TIMING_READS"))
+                std::fprintf(stderr, "[enum] read %zu: device status %d, host search %.3f ms -> %zu candidate alignments\n", idx[k], out.status[k],
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf).count(), rd.cals.size());
+        }
+    });
+    if (!err.empty()) throw Fail(err);
+    if (timing)
+        std::fprintf(stderr, "[enum] %zu reads %d cals: device pipeline %.2f ms, results -> host structures %.2f ms\n", idx.size(), n_cals,
+                     std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+}
+
+// enumeration == 2: (re)build the job's host batch from the reads' candidate alignments
+static void rebuild_host_batch(sk_realign_job* j)
+{
+    sk_align_builder_clear(j->builder);
+    j->n_cals_total = 0;
+    for (auto& rd : j->reads) {
+        rd.cal_begin = j->n_cals_total;
+        j->n_cals_total += flatten_read(*j, j->builder, rd);
+    }
+}
+
+extern "C" {
+
 int sk_realign_job_get_batch(sk_realign_job* j, sk_align_batch* out)
 {
     if (!j || !out) return 1;
+    if (j->opt.enumeration == 2) {
+        try {
+            resolve_pending(*j, false);
+            rebuild_host_batch(j);
+        } catch (const std::exception& e) {
+            j->error = e.what();
+            return 1;
+        }
+    }
     return finish_builder(j, out);
 }
 
-int sk_realign_job_finish(sk_realign_job* j, const double* scores)
+} // extern "C"
+
+// stage 3 for every read; score_of(read) -> the scores of its candidate alignments
+template <typename ScoreOf>
+static int finish_reads(sk_realign_job* j, ScoreOf&& score_of)
 {
-    if (!j) return 1;
     try {
         // reads are independent in stage 3 as well: each writes only its own results
         const std::string err = parallel_for(j->reads.size(), host_threads(*j, j->reads.size()), [&](const size_t ri) {
@@ -2166,8 +2330,8 @@ int sk_realign_job_finish(sk_realign_job* j, const double* scores)
             rd.realigned = false;
             rd.out_path.clear();
             if (rd.cals.empty()) return;
-            if (!scores) throw Fail("sk_realign_job_finish: null scores");
-            const double* s = scores + rd.cal_begin;
+            const double* s = score_of(rd);
+            if (!s) throw Fail("sk_realign_job_finish: null scores");
             const Cal* max_cal = nullptr;
             select_alignments(*j, rd, s, rd.max_score, max_cal);
             if (rd.map_level == SK_MAPLEVEL_TIER1 || rd.map_level == SK_MAPLEVEL_TIER2) // is_tier1or2_mapping :1800
@@ -2183,9 +2347,61 @@ int sk_realign_job_finish(sk_realign_job* j, const double* scores)
     }
 }
 
+extern "C" int sk_realign_job_finish(sk_realign_job* j, const double* scores)
+{
+    if (!j) return 1;
+    return finish_reads(j, [&](const sk_realign_job::Read& rd) -> const double* { return scores ? scores + rd.cal_begin : nullptr; });
+}
+
+// enumeration == 2: search, flattening and scoring on the device; reads the device turned down go through the host stages and
+// a host batch of their own
+static int run_with_device_enumeration(sk_realign_job* j)
+{
+    std::vector<double> host_scores;
+    const bool timing = std::getenv("SK_ENUM_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [](const std::chrono::steady_clock::time_point& t) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    };
+    try {
+        resolve_pending(*j, true);
+        if (timing) std::fprintf(stderr, "[enum] resolve_pending %.2f ms\n", ms_since(t0));
+        struct Tmp
+        {
+            sk_align_builder* b = sk_align_builder_create();
+            ~Tmp() { sk_align_builder_destroy(b); }
+        } tmp;
+        int32_t n = 0;
+        for (auto& rd : j->reads) {
+            if (rd.dev_score_at >= 0 || rd.cals.empty()) continue;
+            rd.cal_begin = n;
+            n += flatten_read(*j, tmp.b, rd);
+        }
+        if (n > 0) {
+            sk_align_batch b;
+            sk_align_builder_set_host_threads(tmp.b, j->opt.host_threads);
+            if (sk_align_builder_finish(tmp.b, &b)) throw Fail(std::string("flatten: ") + sk_align_builder_error(tmp.b));
+            host_scores.resize(size_t(b.n_cals));
+            if (sk_score_alignments(&b, host_scores.data()) != 0) throw Fail(sk_last_error());
+        }
+    } catch (const std::exception& e) {
+        j->error = e.what();
+        return 1;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const int rc = finish_reads(j, [&](const sk_realign_job::Read& rd) -> const double* {
+        return rd.dev_score_at >= 0 ? j->dev_scores.data() + rd.dev_score_at : host_scores.data() + rd.cal_begin;
+    });
+    if (timing) std::fprintf(stderr, "[enum] host-enumerated reads %.2f ms, stage 3 %.2f ms\n", ms_since(t0) - ms_since(t1), ms_since(t1));
+    return rc;
+}
+
+extern "C" {
+
 int sk_realign_job_run(sk_realign_job* j)
 {
     if (!j) return 1;
+    if (j->opt.enumeration == 2) return run_with_device_enumeration(j);
     sk_align_batch b;
     if (finish_builder(j, &b)) return 1;
     std::vector<double> scores(size_t(b.n_cals));

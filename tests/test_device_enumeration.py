@@ -78,7 +78,7 @@ def test_device_enumeration_equals_host(seed, max_indels, hap):
     rng = np.random.default_rng(91000 + seed)
     scs = synth.realign_scenarios(80, rng, reads_per=12, max_indels=max_indels, haplotyping_rate=hap)
     for sc in scs:
-        res = {}
+        res, cons = {}, {}
         for mode in (0, 2):
             job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
                                                        min_read_bp_flank=sc["min_read_bp_flank"], enumeration=mode))
@@ -87,8 +87,59 @@ def test_device_enumeration_equals_host(seed, max_indels, hap):
             idx = T._add_reads(job, sc)
             job.run()
             res[mode] = [None if i is None else job.result(i) for i in idx]
+            cons[mode] = job.indels_consulted()
         for a, b in zip(res[0], res[2]):
             assert (a is None) == (b is None)
             if a is None:
                 continue
             assert repr(a) == repr(b)
+        # the candidate status of exactly the same indels was looked up (the adapter commits its cache from this)
+        assert np.array_equal(cons[0], cons[2])
+
+
+@pytest.mark.gpu
+def test_device_capacity_overflow_falls_back_to_the_host(monkeypatch):
+    """with capacities far too small for the job the device turns reads down; the host code enumerates those and nothing changes"""
+    capi.init(0)
+    rng = np.random.default_rng(91077)
+    scs = synth.realign_scenarios(30, rng, reads_per=12, max_indels=12, haplotyping_rate=0.3)
+    fallbacks = 0
+    for sc in scs:
+        res = {}
+        for mode, caps in ((0, None), (2, "1,8")):
+            if caps:
+                monkeypatch.setenv("SK_ENUM_TEST_CAPS", caps)
+            else:
+                monkeypatch.delenv("SK_ENUM_TEST_CAPS", raising=False)
+            job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
+                                                       min_read_bp_flank=sc["min_read_bp_flank"], enumeration=mode))
+            job.set_reference(sc["ref_seq"], sc["ref_offset"])
+            job.set_indels(sc["indels"])
+            idx = T._add_reads(job, sc)
+            job.run()
+            res[mode] = [None if i is None else job.result(i) for i in idx]
+            if mode == 2:
+                fallbacks += job.enumeration_counts()[2]
+        assert [repr(x) for x in res[0]] == [repr(x) for x in res[2]]
+    assert fallbacks > 20
+
+
+@pytest.mark.gpu
+def test_device_batch_scores_equal_host_batch_scores():
+    """get_batch after a device run rebuilds the host batch from the device's candidate alignments: same alignments, same order,
+    and the device's scores are the host batch's scores bit for bit"""
+    capi.init(0)
+    rng = np.random.default_rng(91088)
+    for sc in synth.realign_scenarios(20, rng, reads_per=12, max_indels=10):
+        out = {}
+        for mode in (0, 2):
+            job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
+                                                       min_read_bp_flank=sc["min_read_bp_flank"], enumeration=mode))
+            job.set_reference(sc["ref_seq"], sc["ref_offset"])
+            job.set_indels(sc["indels"])
+            T._add_reads(job, sc)
+            job.run()
+            b = job.batch()
+            out[mode] = (np.array(b.cal_off), capi.score_alignments(b))
+        assert np.array_equal(out[0][0], out[2][0])
+        assert np.array_equal(out[0][1].view(np.uint64), out[2][1].view(np.uint64))

@@ -26,13 +26,14 @@ def _counters(stderr):
     return {k: int(v) for k, v in (kv.split("=") for kv in m.group(1).split())}
 
 
-def _germline(variant, tmp_path, windows=None):
+def _germline(variant, tmp_path, windows=None, extra_env=None):
     ref_out, out = str(tmp_path / "ref") + "/", str(tmp_path / variant) + "/"
     (tmp_path / "ref").mkdir(exist_ok=True)
     (tmp_path / variant).mkdir(exist_ok=True)
     bams = [E.demo(b) for b in GERMLINE_BAMS]
     E.run(E.germline_argv("starling2_ref", ref_out, bams))
     env = {"STRELKA_AMD_VERBOSE": "1"}
+    env.update(extra_env or {})
     if windows:
         env["STRELKA_AMD_READ_WINDOW"], env["STRELKA_AMD_SITE_WINDOW"] = str(windows[0]), str(windows[1])
     p = E.run(E.germline_argv("starling2_" + variant, out, bams), env=env)
@@ -59,6 +60,14 @@ def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
 @pytest.mark.parametrize("windows", [None, (7, 13)])
 def test_germline_demo_identical_through_adapter_gpu(tmp_path, windows):
     _germline("amd", tmp_path, windows)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
+def test_germline_demo_identical_with_device_enumeration(tmp_path):
+    """candidate alignments listed, flattened and scored on the device (sk_realign_options.enumeration = 2)"""
+    c = _germline("amd", tmp_path, extra_env={"SK_ENUMERATION": "2"})
+    assert c["enum_device_reads"] > 50 and c["enum_host_instead"] <= c["enum_device_reads"] // 20
 
 
 def _somatic(variant, tmp_path, windows=None, callable_regions=False):
@@ -114,10 +123,11 @@ def _have_synth():
     return all(os.path.exists(os.path.join(d, "somatic_tumor.bam")) for d, _ in SYNTH_SETS.values())
 
 
-def _synth(variant, tmp_path, which, windows=None):
+def _synth(variant, tmp_path, which, windows=None, extra_env=None):
     d, length = SYNTH_SETS[which]
     region, fa = "chrS:1-%d" % length, os.path.join(d, "synth.fa")
     env = {"STRELKA_AMD_VERBOSE": "1"}
+    env.update(extra_env or {})
     if windows:
         env["STRELKA_AMD_READ_WINDOW"], env["STRELKA_AMD_SITE_WINDOW"] = str(windows[0]), str(windows[1])
     outs = {}
@@ -134,6 +144,9 @@ def _synth(variant, tmp_path, which, windows=None):
             cg, cs = _counters(pg.stderr.decode()), _counters(ps.stderr.decode())
             assert cg["realign_reads"] > 10000 and cg["indel_groups"] > 100 and cg["haplotypes"] > 100 and cg["site_recomputed"] > 100
             assert cs["realign_reads"] > 15000 and cs["indel_groups"] > 30
+            if (extra_env or {}).get("SK_ENUMERATION") == "2":
+                for c in (cg, cs):
+                    assert c["enum_device_reads"] > 500 and c["enum_host_instead"] <= c["enum_device_reads"] // 20
     n_records = 0
     for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf", "somatic.snvs.vcf", "somatic.indels.vcf", "callable.bed"):
         want, got = E.vcf_body(outs["ref"] + f, keep_header=True), E.vcf_body(outs[variant] + f, keep_header=True)
@@ -154,3 +167,10 @@ def test_synthetic_identical_through_adapter_cpu_double(tmp_path, which, windows
 @pytest.mark.parametrize("which", ["short_reads", "long_reads"])
 def test_synthetic_identical_through_adapter_gpu(tmp_path, which):
     _synth("amd", tmp_path, which)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (E.have("starling2_amd", "strelka2_amd") and _have_synth()), reason="oracle/_ref binaries / synthetic inputs not built")
+@pytest.mark.parametrize("which", ["short_reads", "long_reads"])
+def test_synthetic_identical_with_device_enumeration(tmp_path, which):
+    _synth("amd", tmp_path, which, extra_env={"SK_ENUMERATION": "2"})
