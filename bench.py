@@ -107,14 +107,15 @@ def cpu_baseline(args):
             "loci_per_s": args.cpu_loci / tb}
 
 
-def whole_read_leg(args, capi, synth, rng):
-    """Rows a1-a7 end to end: reads -> sk_realign_job_add_reads (gate, normalisation, enumeration, flattening on the host)
-    -> run (scoring kernel, selection, score_indels) on the same scenario distribution the reference's realignAndScoreRead is
-    timed on (oracle/ref_timing.py).  Host buffers in and out, PCIe included: this is the path the adapter calls."""
-    scenarios = synth.realign_scenarios(24, rng, reads_per=12)
+def whole_read_leg(args, capi, synth, rng, enumeration=2, max_indels=6, reads=None):
+    """Rows a1-a7 end to end: reads -> sk_realign_job_add_reads (gate, normalisation) -> run (candidate-alignment enumeration,
+    flattening, scoring; then selection and score_indels on the host) on the same scenario distribution the reference's
+    realignAndScoreRead is timed on (oracle/ref_timing.py).  Host buffers in and out, PCIe included: this is the path the adapter
+    calls.  `enumeration`: 2 = search + flattening on the device (csrc/read_enumerate.hip), 0 = on the host (round 1's path)."""
+    scenarios = synth.realign_scenarios(24, rng, reads_per=12, max_indels=max_indels)
     jobs = []
     total = 0
-    rep = max(1, args.realign_reads // (24 * 12))
+    rep = max(1, (reads or args.realign_reads) // (24 * 12))
     for sc in scenarios:
         keep, inputs = [], []
         for rd in sc["reads"]:
@@ -125,14 +126,18 @@ def whole_read_leg(args, capi, synth, rng):
             keep.append((code, qual, segs, obs))
             inputs.append(capi.ReadInput(capi._p(code), capi._p(qual), len(code), rd["pos"], len(rd["path"]), segs, int(rd["is_fwd"]),
                                          rd["map_level"], 0, rd["realign_range"][0], rd["realign_range"][1], len(rd["observed"]), obs))
-        job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
-                                                   min_read_bp_flank=sc["min_read_bp_flank"]))
-        job.set_reference(sc["ref_seq"], sc["ref_offset"])
-        job.set_indels(sc["indels"])
-        ok = [r for r in inputs if capi.lib().sk_realign_job_add_read(job._j, C.byref(r)) >= 0]
-        job.clear_reads()
+        probe = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
+                                                     min_read_bp_flank=sc["min_read_bp_flank"], enumeration=0))
+        probe.set_reference(sc["ref_seq"], sc["ref_offset"])
+        probe.set_indels(sc["indels"])
+        ok = [r for r in inputs if capi.lib().sk_realign_job_add_read(probe._j, C.byref(r)) >= 0]
+        del probe
         if not ok:
             continue
+        job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
+                                                   min_read_bp_flank=sc["min_read_bp_flank"], enumeration=enumeration))
+        job.set_reference(sc["ref_seq"], sc["ref_offset"])
+        job.set_indels(sc["indels"])
         n = len(ok) * rep
         arr = (capi.ReadInput * n)(*[ok[i % len(ok)] for i in range(n)])
         jobs.append((job, arr, n, keep))
@@ -261,8 +266,17 @@ def main():
     del dga
 
     # ---- rows a1-a7: the whole read path as the adapter drives it (host stages + kernel), one host thread ----
-    wr_step, wr_reads, wr_cals = whole_read_leg(args, capi, synth, rng)
-    dt_wr, wr_done, _ = timed(wr_step, max(2, args.steps // 4), 1, wr_reads)
+    wr = {}
+    for name, kw in (("", dict(enumeration=2)), ("_host_enumeration", dict(enumeration=0)),
+                     ("_dense", dict(enumeration=2, max_indels=14, reads=args.realign_reads // 6)),
+                     ("_dense_host_enumeration", dict(enumeration=0, max_indels=14, reads=args.realign_reads // 6))):
+        wr_step, wr_reads, wr_cals = whole_read_leg(args, capi, synth, np.random.default_rng(4242), **kw)
+        n_wr = max(2, args.steps // 4)
+        dt_wr, wr_done, _ = timed(wr_step, n_wr, 1, wr_reads)
+        wr["realign%s_reads_per_s" % name] = wr_done / dt_wr
+        wr["realign%s_ms_per_step" % name] = dt_wr / n_wr * 1e3
+        wr["realign%s_reads_per_step_per_gpu" % name] = wr_reads
+        wr["realign%s_candidate_alignments_per_read" % name] = wr_cals / max(1, wr_reads)
 
     traffic = pmc_traffic(args)
     som_kernels = ("somatic_classify_kernel", "somatic_lhood_kernel", "somatic_posterior_kernel")
@@ -304,15 +318,17 @@ def main():
         "roofline_allele_group": roof("allele_group_kernel", group_alg_bytes, kms_g, traffic.get("allele_group_kernel")),
         "roofline_pileup": roof("pileup_read_kernel+2*pileup_column_kernel", pileup_alg_bytes, kms_p, pil_traffic),
         "roofline_global_align": roof("global_align_kernel", ga_alg_bytes, kms_ga, traffic.get("global_align_kernel")),
-        "realign_reads_per_s": wr_done / dt_wr, "realign_ms_per_step": dt_wr / max(2, args.steps // 4) * 1e3,
-        "realign_reads_per_step_per_gpu": wr_reads, "realign_candidate_alignments_per_read": wr_cals / max(1, wr_reads),
         "realign_host_threads": 1,
+        "realign_note": "whole read path (rows a1-a7) through sk_realign_job_add_reads + _run, one host thread, host buffers in and out; "
+                        "realign_* = candidate alignments listed, flattened and scored on the device (enumeration=2), *_host_enumeration = "
+                        "listed and flattened on the host (round 1's path), *_dense = scenarios with up to 14 indels around a read",
         "global_align_cells_per_s": ga_cells / dt_ga, "global_align_ms_per_step": dt_ga / args.steps * 1e3,
         "global_align_problems_per_step": n_ga,
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
-        "roofline": roof("score_wave_per_read", alg_bytes_a, kms_a, traffic.get("score_wave_per_read")),
+        "roofline": roof("score_wave_per_read_cols", alg_bytes_a, kms_a, traffic.get("score_wave_per_read_cols")),
         "roofline_loci": roof("germline_site_fused_kernel", alg_bytes_b, kms_b, traffic.get("germline_site_fused_kernel")),
     }
+    out.update(wr)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -115,11 +115,27 @@ typedef struct sk_align_batch {
     const uint32_t* entries;  /* [n_ops + 2*n_cals] */
     const uint32_t* evmask;   /* [n_reads * evmask_words] */
     int32_t evmask_words;     /* sk_align_evmask_words(max_read_len) */
+    /* Column form (sk_align_prepare_cols; sk_align_builder_finish fills it; needs `entries`): for every candidate alignment,
+     * per read position, WHICH term its haplotype base selects -- 0: the bases agree, ln(1-e_q); 1: they differ, ln(e_q/3);
+     * 2: nothing is added (read base N, soft-clipped position, position past the read's end) -- so that the kernel streams the
+     * candidate haplotypes instead of following transitions: the bytes SURVEY.md 8d counts (H * L_h per read, here four bits
+     * per base).  Read r owns colmat[colmat_off[r] ..): word [k * n_cals(r) + j] holds read positions 8k..8k+7 of the read's
+     * j-th candidate alignment: position 8k+q in the low nibble of byte q, position 8k+4+q in its high nibble (q = 0..3).
+     * addmask has bit p of read r set when an entry of ANY of its candidates adds penalty / soft-clip terms at read position p
+     * (0 <= p <= read length); its last bit (32 * evmask_words - 1) is set when one of the read's candidates does not fit the
+     * entry format.  NULL = absent: the kernel follows the transition entries. */
+    const uint32_t* colmat;
+    const int64_t* colmat_off; /* [n_reads+1], in words */
+    const uint32_t* addmask;   /* [n_reads * evmask_words] */
 } sk_align_batch;
 
 /** Prepared form of a host batch (max_read_len must be set): entries[n_ops + 2*n_cals], evmask[n_reads * words]. */
 int32_t sk_align_evmask_words(int32_t max_read_len);
 int sk_align_prepare(const sk_align_batch* host_batch, uint32_t* entries, uint32_t* evmask);
+/** Column form of a prepared host batch (`entries` set): colmat[sk_align_colmat_words], colmat_off[n_reads+1],
+ *  addmask[n_reads * evmask_words]. */
+int64_t sk_align_colmat_words(const sk_align_batch* host_batch);
+int sk_align_prepare_cols(const sk_align_batch* host_batch, uint32_t* colmat, int64_t* colmat_off, uint32_t* addmask);
 
 /** out_lnp[n_cals]: ln P(read | alignment), double, bit-identical to the reference's sequential accumulation. */
 int sk_score_alignments(const sk_align_batch* host_batch, double* out_lnp);

@@ -28,7 +28,8 @@ class AlignBatch(C.Structure):
                 ("read_off", c_void_p), ("read_code", c_void_p), ("read_qual", c_void_p),
                 ("hap_off", c_void_p), ("hap_code", c_void_p), ("cal_off", c_void_p), ("op_off", c_void_p),
                 ("ops", c_void_p), ("max_read_len", C.c_int32), ("max_hap_len", C.c_int32),
-                ("entries", c_void_p), ("evmask", c_void_p), ("evmask_words", C.c_int32)]
+                ("entries", c_void_p), ("evmask", c_void_p), ("evmask_words", C.c_int32),
+                ("colmat", c_void_p), ("colmat_off", c_void_p), ("addmask", c_void_p)]
 
 
 class PathSeg(C.Structure):
@@ -180,7 +181,7 @@ assert DIGT_CALL_DTYPE.itemsize == 144 and SOMATIC_CALL_DTYPE.itemsize == 272
 # every symbol include/strelka_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
     "sk_init", "sk_init_strict", "sk_check_device_errors", "sk_debug_force_device_libm", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_libm_restated", "sk_get_qscore_tables",
-    "sk_score_alignments", "sk_score_alignments_dev", "sk_align_evmask_words", "sk_align_prepare",
+    "sk_score_alignments", "sk_score_alignments_dev", "sk_align_evmask_words", "sk_align_prepare", "sk_align_colmat_words", "sk_align_prepare_cols",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_append", "sk_align_builder_add_read",
     "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
@@ -257,6 +258,9 @@ def lib():
                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.sk_score_alignments.argtypes = [C.POINTER(AlignBatch), c_void_p]
         L.sk_align_evmask_words.argtypes = [C.c_int32]
+        L.sk_align_colmat_words.restype = C.c_int64
+        L.sk_align_colmat_words.argtypes = [c_void_p]
+        L.sk_align_prepare_cols.argtypes = [c_void_p] * 4
         L.sk_align_prepare.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
         L.sk_score_alignments_dev.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
         L.sk_score_alignments_dev_generic.argtypes = [C.POINTER(AlignBatch), c_void_p, c_void_p]
@@ -352,16 +356,21 @@ class HostAlignBatch:
 
         self.entries = self.evmask = None
         self.evmask_words = 0
+        self.colmat = self.colmat_off = self.addmask = None
 
     def struct(self):
         return AlignBatch(self.n_reads, self.n_cals, len(self.ops), _p(self.read_off), _p(self.read_code),
                           _p(self.read_qual), _p(self.hap_off), _p(self.hap_code), _p(self.cal_off), _p(self.op_off),
                           _p(self.ops), self.max_read_len, self.max_hap_len,
                           None if self.entries is None else _p(self.entries),
-                          None if self.evmask is None else _p(self.evmask), self.evmask_words)
+                          None if self.evmask is None else _p(self.evmask), self.evmask_words,
+                          None if self.colmat is None else _p(self.colmat),
+                          None if self.colmat_off is None else _p(self.colmat_off),
+                          None if self.addmask is None else _p(self.addmask))
 
-    def prepare(self):
-        """sk_align_prepare: the device-ready transition entries + event masks of this batch"""
+    def prepare(self, columns=True):
+        """sk_align_prepare (+ sk_align_prepare_cols): the device-ready forms of this batch -- transition entries + event masks,
+        and the column form the streaming kernel reads"""
         if self.entries is None:
             self.evmask_words = lib().sk_align_evmask_words(self.max_read_len)
             ent = np.zeros(len(self.ops) + 2 * self.n_cals + 1, np.uint32)
@@ -370,6 +379,15 @@ class HostAlignBatch:
             if lib().sk_align_prepare(C.byref(s), _p(ent), _p(msk)) != 0:
                 raise StrelkaAmdError("sk_align_prepare failed")
             self.entries, self.evmask = ent, msk
+        if self.colmat is None and columns:
+            s = self.struct()
+            words = lib().sk_align_colmat_words(C.byref(s))
+            cm = np.zeros(words + 1, np.uint32)
+            off = np.zeros(self.n_reads + 1, np.int64)
+            am = np.zeros(self.n_reads * self.evmask_words + 1, np.uint32)
+            if lib().sk_align_prepare_cols(C.byref(s), _p(cm), _p(off), _p(am)) != 0:
+                raise StrelkaAmdError("sk_align_prepare_cols failed")
+            self.colmat, self.colmat_off, self.addmask = cm, off, am
         return self
 
 

@@ -33,3 +33,16 @@ static inline unsigned sk_ent_col_index(const unsigned bam_code)
     return bam_code == 1u ? 0u : bam_code == 2u ? 1u : bam_code == 4u ? 2u : bam_code == 8u ? 3u : 4u;
 }
 static inline int sk_ent_evmask_words(const int max_read_len) { return (max_read_len + 1 + 63) / 32 + 1; }
+
+// column form: the term a haplotype base (table column 0..5, above) selects against a read base (BAM code)
+constexpr unsigned SK_SEL_MATCH = 0, SK_SEL_MISMATCH = 1, SK_SEL_NONE = 2;
+#if defined(__HIP__)
+__host__ __device__
+#endif
+static inline unsigned sk_col_selector(const unsigned col, const unsigned read_code)
+{
+    if (col == unsigned(SK_ENT_ZERO_COL) || read_code == 15u) return SK_SEL_NONE; // soft clip / past the end; read base N
+    if (read_code == 0u) return SK_SEL_MATCH;                                      // '=' always agrees
+    const unsigned code_of_col = (col < 4u) ? (1u << col) : 0x100u;
+    return code_of_col == read_code ? SK_SEL_MATCH : SK_SEL_MISMATCH;
+}

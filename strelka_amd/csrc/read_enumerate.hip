@@ -247,6 +247,7 @@ struct FlatArgs
     const int32_t* list; // [n_cals] leaf slots, each read's in set order
     int32_t* status;
     const int64_t* read_off;
+    const uint8_t* read_code;
     const int32_t* cal_off;
     // per-read layout of the haplotype pool (L1 out)
     int32_t* win_begin; // (L1a: min over the read's candidate alignments, cells start at INT_MAX)
@@ -268,6 +269,10 @@ struct FlatArgs
     uint32_t* entries;
     uint32_t* evmask;
     int32_t evmask_words, max_read_len;
+    // the column form (strelka_amd.h, sk_align_batch::colmat)
+    uint8_t* colmat; // (bytes of the words; pre-filled with the 0.0 column)
+    const int64_t* colmat_off;
+    uint32_t* addmask;
 };
 enum { INS_CAP = Caps::K + 2 };
 
@@ -617,6 +622,31 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
     if (complex_cal) {
         for (int i = 0; i < nslots; ++i) ent[i] = SK_ENT_END;
         ent[0] = SK_ENT_COMPLEX;
+        atomicOr(&a.addmask[int64_t(r) * W + (W - 1)], 1u << 31);
+        return;
+    }
+    // the column form: where entries add terms, and the column every read position faces (host form: sk_align_prepare_cols)
+    uint32_t* am = a.addmask + int64_t(r) * W;
+    for (int i = 0; i < e; ++i)
+        if (ent[i] & SK_ENT_ADD_BITS) {
+            const unsigned p = ent[i] & SK_ENT_POS_MASK;
+            atomicOr(&am[p >> 5], 1u << (p & 31));
+        }
+    const int ncr = a.cal_off[r + 1] - a.cal_off[r], j = c - a.cal_off[r];
+    uint8_t* cm = a.colmat + 4 * a.colmat_off[r];
+    pos = 0;
+    for (int64_t kk = k0; kk < k1; ++kk) {
+        const sk_score_op op = a.ops[kk];
+        const int len = int(op.length);
+        if (!((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0)) continue;
+        if (op.kind == SK_OP_BASES)
+            for (int t = 0; t < len && pos + t < L; ++t) { // (only this thread writes this candidate's bytes)
+                const int i = pos + t;
+                const unsigned sel = sk_col_selector(col_at(int(op.src) + t), a.read_code[a.read_off[r] + i]);
+                uint8_t& byte = cm[(size_t(i >> 3) * size_t(ncr) + size_t(j)) * 4 + size_t(i & 3)];
+                byte = (i & 4) ? uint8_t((byte & 0x0fu) | (sel << 4)) : uint8_t((byte & 0xf0u) | sel);
+            }
+        pos += len;
     }
 }
 
@@ -664,9 +694,9 @@ struct EnumBuffers
     DevBuf level_a, level_b, counters, pool, leaf_read, leaf_hash, n_raw, status, warn;
     DevBuf raw_off, fill, grouped, dup, n_uniq, sorted;
     DevBuf n_ops, hap_len, win_begin, win_end, ins_lo, ins_hi, win_len, n_ins, ins_idx, ins_off;
-    DevBuf cal_off, hap_off, cals, hap_code, op_off, ops, entries, evmask, scores;
+    DevBuf cal_off, hap_off, cals, hap_code, op_off, ops, entries, evmask, scores, colmat, colmat_off, addmask;
     HostBuf h_status, h_warn, h_n_raw, h_raw_off, h_n_uniq, h_n_ops, h_hap_len, h_cal_off, h_hap_off, h_op_off, h_cals, h_scores,
-        h_consulted, h_counters;
+        h_consulted, h_counters, h_colmat_off;
 };
 EnumBuffers& bufs()
 {
@@ -921,6 +951,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     fa.list = B.sorted.as<int32_t>();
     fa.status = ea.status;
     fa.read_off = B.read_off.as<int64_t>();
+    fa.read_code = B.read_code.as<uint8_t>();
     fa.cal_off = B.cal_off.as<int32_t>();
     fa.win_begin = B.win_begin.as<int32_t>();
     fa.win_len = B.win_len.as<int32_t>();
@@ -973,6 +1004,15 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     RES(entries, 4 * (size_t(ops_total) + 2 * size_t(n_cals) + 1));
     RES(evmask, 4 * (size_t(n) * size_t(W) + 1));
     RES(scores, 8 * size_t(n_cals));
+    HRES(h_colmat_off, 8 * size_t(n + 1));
+    int64_t* h_colmat_off = B.h_colmat_off.as<int64_t>();
+    h_colmat_off[0] = 0;
+    for (int r = 0; r < n; ++r)
+        h_colmat_off[r + 1] = h_colmat_off[r] + ((in->read_off[r + 1] - in->read_off[r] + 7) / 8) * int64_t(h_cal_off[r + 1] - h_cal_off[r]);
+    const int64_t colmat_words = h_colmat_off[n];
+    RES(colmat, 4 * size_t(colmat_words) + 16);
+    RES(colmat_off, 8 * size_t(n + 1));
+    RES(addmask, 4 * (size_t(n) * size_t(W) + 1));
     HRES(h_cals, sizeof(PCal) * size_t(n_cals));
     HRES(h_scores, 8 * size_t(n_cals));
     out->cals = B.h_cals.as<PCal>();
@@ -981,6 +1021,9 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         SK_HIP(hipMemcpyAsync(B.hap_off.p, h_hap_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
         SK_HIP(hipMemcpyAsync(B.op_off.p, h_op_off, 8 * size_t(n_cals + 1), hipMemcpyHostToDevice, st));
         SK_HIP(hipMemsetAsync(B.evmask.p, 0, 4 * size_t(n) * size_t(W), st));
+        SK_HIP(hipMemsetAsync(B.addmask.p, 0, 4 * size_t(n) * size_t(W), st));
+        SK_HIP(hipMemsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), 4 * size_t(colmat_words) + 16, st));
+        SK_HIP(hipMemcpyAsync(B.colmat_off.p, h_colmat_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
         fa.hap_off = B.hap_off.as<int64_t>();
         fa.op_off = B.op_off.as<int64_t>();
         fa.cals = B.cals.as<PCal>();
@@ -990,6 +1033,9 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         fa.evmask = B.evmask.as<uint32_t>();
         fa.evmask_words = W;
         fa.max_read_len = in->max_read_len;
+        fa.colmat = B.colmat.as<uint8_t>();
+        fa.colmat_off = B.colmat_off.as<int64_t>();
+        fa.addmask = B.addmask.as<uint32_t>();
         hipLaunchKernelGGL(pool_fill_kernel, dim3(n), dim3(64), 0, st, fa);
         hipLaunchKernelGGL(flatten_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
         SK_HIP(hipGetLastError());
@@ -1016,6 +1062,9 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
             d.entries = fa.entries;
             d.evmask = fa.evmask;
             d.evmask_words = W;
+            d.colmat = B.colmat.as<uint32_t>();
+            d.colmat_off = fa.colmat_off;
+            d.addmask = fa.addmask;
             if (sk_score_alignments_launch_hostleg(&d, B.scores.as<double>(), st)) return 1;
             lap("A1 score");
             D2H(h_scores, scores, 8 * size_t(n_cals));

@@ -32,6 +32,7 @@
 #include "align_entry.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace
@@ -59,6 +60,7 @@ struct ScoreArgs
     int lds_tab_bytes; // per wave: ROW_BYTES * maxL
     int lds_hap_bytes; // per wave: align16(maxP + maxL + 8)  (pool columns + the 0.0-column run)
     unsigned* err;     // SkContext::dev_error_flags
+    int dbg;           // (diagnostics: phases to skip, see tools/diag)
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -292,6 +294,266 @@ __device__ __forceinline__ void score_wave_per_read_body(const ScoreArgs& a)
     }
 }
 
+// Kernel A1c `score_wave_per_read_cols`: the column form of the batch (sk_align_batch::colmat).  Same wave-per-read layout, but
+// the lanes do not follow transition entries: every lane streams its candidate alignment from HBM -- per read position which of
+// the position's terms the haplotype base selects (agree: ln(1-e_q), differ: ln(e_q/3), nothing) -- eight read positions per
+// 32-bit word (four bits each), 64 lanes side by side (256-byte
+// coalesced loads).  A 150 bp candidate is 19 words, so a lane holds its WHOLE candidate in registers: every global load
+// of a read (bases, qualities, add mask, all column words) is issued at the top of the kernel, one round trip after the offsets.
+// LDS holds, per wave, the read as one row {ln(1-e_q), ln(e_q/3), 0.0} per position (24 bytes: half of what the six-column rows
+// of score_wave_per_read take, so half again as many waves fit a CU).  Per cell: 1.5 VALU to unpack the selector and form the
+// row address, one ds_read_b64 and the dependent v_add_f64.  The entries
+// are looked at only where the read's add mask says some candidate adds penalty or soft-clip terms -- those words (eight
+// positions) take the ordered, branchy form; all others are branch-free.
+constexpr uint32_t ZERO_WORD = 0x22222222u; // eight positions that add nothing
+constexpr int SEL_ROW_BYTES = 24;             // per read position: {agree, differ, 0.0}
+
+// the eight row-relative byte offsets (8 * selector) of a column word: lo's bytes are positions 0..3, hi's positions 4..7
+__device__ __forceinline__ void unpack_cols(const uint32_t w, uint32_t& lo, uint32_t& hi)
+{
+    lo = (w & 0x0f0f0f0fu) << 3;
+    hi = (w & 0xf0f0f0f0u) >> 1;
+}
+
+template <int NW> // column words a lane holds in registers: reads up to 8 * NW positions are swept without a load in the loop
+__device__ __forceinline__ void score_cols_body(const ScoreArgs& a)
+{
+    static_assert(NW % 2 == 0, "words are swept in pairs");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / WAVE);
+    constexpr int ENT_BYTES = (ENT_CAP + 4) * 4;
+    const int W = a.b.evmask_words;
+    const size_t per_wave = (size_t(a.lds_tab_bytes) + ENT_BYTES + size_t(W) * 4 + 15) & ~size_t(15);
+    unsigned char* tabb = smem + per_wave * wave;
+    unsigned* ent = reinterpret_cast<unsigned*>(tabb + a.lds_tab_bytes);
+    unsigned* mask = ent + (ENT_CAP + 4);
+    // the two quality tables, once per workgroup: a read's row build then depends on one global round trip, not two
+    double* qtab = reinterpret_cast<double*>(smem + per_wave * WAVES_PER_BLOCK);
+    for (int i = threadIdx.x; i < 2 * (SK_NQ + 1); i += WAVES_PER_BLOCK * WAVE)
+        qtab[i] = (i <= SK_NQ) ? a.tab->q2lncompe[i] : a.tab->q2mis[i - (SK_NQ + 1)];
+    if (lane == 0) { // the entry list of lanes without a candidate
+        ent[ENT_CAP] = SK_ENT_END;
+        ent[ENT_CAP + 1] = SK_ENT_END;
+        ent[ENT_CAP + 2] = SK_ENT_END;
+        ent[ENT_CAP + 3] = SK_ENT_END;
+    }
+    __syncthreads(); // (the only workgroup-wide step: from here on the waves run on their own)
+
+    const int n_reads = a.b.n_reads;
+    const uint32_t* __restrict__ gent = a.b.entries;
+    const double ln_quarter = a.tab->ln_quarter;
+    const double ln_noncand = a.tab->ln_noncand;
+
+    struct Head
+    {
+        int64_t ro;
+        int L, cal_begin, cal_end;
+        const uint32_t* cm;
+    };
+    // where read r's data is: the offsets are fetched TWO reads ahead, so that the data fetch below never waits for them
+    auto fetch_head = [&](const int r, Head& h) {
+        h.ro = a.b.read_off[r];
+        h.L = int(a.b.read_off[r + 1] - h.ro);
+        h.cal_begin = a.b.cal_off[r];
+        h.cal_end = a.b.cal_off[r + 1];
+        h.cm = a.b.colmat + a.b.colmat_off[r];
+    };
+    // everything the wave needs of read r, in flight at once
+    auto fetch = [&](const int r, const Head& h, unsigned (&rq)[4], uint32_t (&cw)[NW], unsigned& am) {
+        const int ncr = h.cal_end - h.cal_begin, nch = (h.L + 7) >> 3;
+        const uint32_t* cp = h.cm + ((lane < ncr) ? lane : (ncr > 0 ? ncr - 1 : 0));
+#pragma unroll
+        for (int t = 0; t < NW; ++t) cw[t] = (t < nch && ncr > 0) ? cp[int64_t(t) * ncr] : ZERO_WORD;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = u * WAVE + lane;
+            rq[u] = (j < h.L) ? a.b.read_qual[h.ro + j] : 0u;
+        }
+        am = (lane < W) ? a.b.addmask[int64_t(r) * W + lane] : 0u;
+    };
+
+    const int r = int(blockIdx.x) * WAVES_PER_BLOCK + wave;
+    if (r >= n_reads) return;
+    Head cur;
+    unsigned rq[4], am;
+    uint32_t cw[NW];
+    fetch_head(r, cur);
+    fetch(r, cur, rq, cw, am);
+
+    {
+        const int64_t ro = cur.ro;
+        const int L = cur.L, cal_begin = cur.cal_begin, cal_end = cur.cal_end;
+        const int ncr = cal_end - cal_begin, nch = (L + 7) >> 3;
+        const uint32_t* __restrict__ cm = cur.cm;
+
+        // ---- the read's add mask and rows into LDS
+        const unsigned cx = (lane == W - 1) ? (am >> 31) : 0u;
+        const unsigned amw = (lane == W - 1) ? (am & 0x7fffffffu) : am;
+        if (lane < W) mask[lane] = amw;
+        const bool has_add = __any(amw != 0);
+        const bool has_complex = __any(cx != 0);
+        {
+            // per-position rows {M, X, 0.0}: the terms of a read base of this quality that agrees / differs; which one a
+            // candidate takes (or none: read base N, soft clip, past the end) is in its column word
+            double* tab = reinterpret_cast<double*>(tabb);
+            const int rows = (a.dbg & 1) ? 0 : 8 * nch;
+            for (int j0 = 0; j0 < rows; j0 += 4 * WAVE) {
+                unsigned rqv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * WAVE + lane;
+                    rqv[u] = (j0 == 0) ? rq[u] : ((j < L) ? a.b.read_qual[ro + j] : 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * WAVE + lane;
+                    if (j >= rows) continue;
+                    if (rqv[u] > 70u) atomicOr(a.err, unsigned(SK_DEVERR_QSCORE));
+                    const unsigned q = rqv[u] > 70u ? 70u : rqv[u];
+                    double* row = tab + 3 * j;
+                    row[0] = qtab[q];
+                    row[1] = qtab[SK_NQ + 1 + q];
+                    row[2] = 0.0;
+                }
+            }
+        }
+
+        int cbase = cal_begin;
+        bool first_pass = true;
+        while (cbase < cal_end) {
+            const int c = cbase + lane;
+            const bool has = (c < cal_end);
+            int m, ebase = ENT_CAP;
+            unsigned first_entry = 0;
+            if (has_add) { // the pass's entries go to LDS, as in score_wave_per_read
+                const int64_t sbase = a.b.op_off[cbase] + 2 * int64_t(cbase);
+                const int s1 = has ? int(a.b.op_off[c + 1] + 2 * int64_t(c + 1) - sbase) : 0x3fffffff;
+                const bool fits = has && (s1 <= ENT_CAP);
+                m = __popcll(__ballot(fits));
+                if (m == 0) {
+                    if (lane == 0) a.out[cbase] = score_one_generic(a, r, cbase);
+                    cbase += 1;
+                    first_pass = false;
+                    continue;
+                }
+                const int nslots = __builtin_amdgcn_readlane(s1, m - 1);
+                const int prev_end = __shfl_up(s1, 1);
+                ebase = (lane < m) ? (lane == 0 ? 0 : prev_end) : ENT_CAP;
+                wave_sync();
+                for (int j0 = 0; j0 < nslots; j0 += 10 * WAVE) {
+                    unsigned t[10];
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) {
+                        const int j = j0 + u * WAVE + lane;
+                        t[u] = (j < nslots) ? gent[sbase + j] : SK_ENT_END;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) {
+                        const int j = j0 + u * WAVE + lane;
+                        if (j < nslots) ent[j] = t[u];
+                    }
+                }
+                wave_sync();
+                first_entry = ent[ebase];
+            } else {
+                m = (cal_end - cbase < WAVE) ? cal_end - cbase : WAVE;
+                if (has_complex) first_entry = has ? gent[a.b.op_off[c] + 2 * int64_t(c)] : 0u; // (else no candidate of the read is)
+                wave_sync(); // rows / mask complete
+            }
+            const bool active = lane < m;
+            const bool complex_cal = active && (first_entry == SK_ENT_COMPLEX);
+            int kp = (active && !complex_cal) ? ebase : ENT_CAP;
+            unsigned e1 = SK_ENT_END; // the lane's next entry (looked at only in words the add mask flags)
+            if (has_add) e1 = ent[kp++];
+
+            const int j = (has ? c : cal_end - 1) - cal_begin;
+            const uint32_t* __restrict__ cp = cm + j;
+            if (!first_pass) { // more than 64 candidate alignments: this pass's words were not fetched ahead
+#pragma unroll
+                for (int t = 0; t < NW; ++t) cw[t] = (t < nch) ? cp[int64_t(t) * ncr] : ZERO_WORD;
+            }
+            first_pass = false;
+
+            double lnp = 0.0;
+            // an entry that adds terms, at read position i: the non-candidate penalties, then the soft-clip term (path order)
+            auto at_position = [&](const int i) {
+                if ((e1 & SK_ENT_POS_MASK) == unsigned(i)) {
+                    const unsigned e = e1;
+                    e1 = ent[kp++];
+                    if (e & SK_ENT_ADD_BITS) {
+                        const unsigned np = (e >> 10) & 7u;
+                        for (unsigned t = 0; t < np; ++t) lnp = dadd(lnp, ln_noncand);
+                        if (e & (1u << 13)) lnp = dadd(lnp, __dmul_rn(double(unsigned(int(e1 & SK_ENT_POS_MASK) - i)), ln_quarter));
+                    }
+                }
+            };
+            // word t (read positions 8t..8t+7) the ordered way: entries that add terms are interleaved with the base terms
+            auto ordered_word = [&](const uint32_t w, const int t) {
+                uint32_t lo, hi;
+                unpack_cols(w, lo, hi);
+                const unsigned char* rp = tabb + SEL_ROW_BYTES * 8 * t;
+                const int i0 = 8 * t;
+                while ((e1 & SK_ENT_POS_MASK) < unsigned(i0)) e1 = ent[kp++]; // entries passed without a look
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    at_position(i0 + u);
+                    const uint32_t col8 = (((u < 4) ? lo : hi) >> (8 * (u & 3))) & 0xffu;
+                    lnp = dadd(lnp, *reinterpret_cast<const double*>(rp + SEL_ROW_BYTES * u + col8));
+                }
+            };
+            // words t, t+1 (16 read positions).  A word past the read's end holds eight 0.0 columns and is read against row 0
+            // (the third term of every row is 0.0), so the pair is processed whole and without a branch.
+            auto word_pair = [&](const uint32_t wa, const uint32_t wb, const int t) {
+                uint32_t bits = 0;
+                if (has_add) bits = (uint32_t(__builtin_amdgcn_readfirstlane(mask[t >> 2])) >> (8 * (t & 3))) & 0xffffu; // t is even
+                if (bits == 0) {
+                    uint32_t lo[2], hi[2];
+                    unpack_cols(wa, lo[0], hi[0]);
+                    unpack_cols(wb, lo[1], hi[1]);
+                    const unsigned char* rpa = tabb + SEL_ROW_BYTES * 8 * t;
+                    const unsigned char* rpb = (t + 1 < nch) ? rpa + SEL_ROW_BYTES * 8 : tabb;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned char* rp = h ? rpb : rpa;
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            v[u] = *reinterpret_cast<const double*>(rp + SEL_ROW_BYTES * u + ((lo[h] >> (8 * u)) & 0xffu));
+                            v[4 + u] = *reinterpret_cast<const double*>(rp + SEL_ROW_BYTES * (4 + u) + ((hi[h] >> (8 * u)) & 0xffu));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) lnp = dadd(lnp, v[q]);
+                    }
+                    return;
+                }
+                ordered_word(wa, t);
+                if (t + 1 < nch) ordered_word(wb, t + 1);
+            };
+#pragma unroll
+            for (int t = 0; t < NW; t += 2)
+                if (t < nch && !(a.dbg & 2)) word_pair(cw[t], cw[t + 1], t);
+            for (int t = NW; t < nch; t += 2) { // a read longer than 8 * NW positions: the rest straight from memory
+                const uint32_t wa = cp[int64_t(t) * ncr];
+                const uint32_t wb = (t + 1 < nch) ? cp[int64_t(t + 1) * ncr] : ZERO_WORD;
+                word_pair(wa, wb, t);
+            }
+            // entries at the end of the read (trailing penalties) when the read's length is a multiple of eight
+            if (has_add && (L & 7) == 0 && ((uint32_t(__builtin_amdgcn_readfirstlane(mask[L >> 5])) >> (L & 31)) & 1u)) {
+                while ((e1 & SK_ENT_POS_MASK) < unsigned(L)) e1 = ent[kp++];
+                at_position(L);
+            }
+            if (active) a.out[c] = complex_cal ? score_one_generic(a, r, c) : lnp;
+            cbase += m;
+        }
+
+    }
+}
+
+__global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read_cols(const ScoreArgs a) { score_cols_body<20>(a); }
+__global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read_cols_hostbuf(const ScoreArgs a) { score_cols_body<20>(a); }
+__global__ __launch_bounds__(WAVES_PER_BLOCK* WAVE) void score_wave_per_read_cols_long(const ScoreArgs a) { score_cols_body<32>(a); }
+
 // The same code under two names: `score_wave_per_read` is what the device-resident entry (sk_score_alignments_dev: the
 // adapter's resident pipeline, bench.py's timed leg) launches, `score_wave_per_read_hostbuf` what the host-buffer entry
 // (sk_score_alignments: stage 2 of sk_realign_job_run, small per-window batches) launches -- so that a kernel trace keeps
@@ -328,6 +590,10 @@ static int score_alignments_launch(const sk_align_batch* b, double* dev_out_lnp,
     a.tab = sk_ctx().dev_tables;
     a.out = dev_out_lnp;
     a.err = sk_ctx().dev_error_flags;
+    {
+        static const int dbg = [] { const char* e = std::getenv("SK_A1_DBG"); return e ? std::atoi(e) : 0; }();
+        a.dbg = dbg;
+    }
     const int maxL = b->max_read_len, maxP = b->max_hap_len;
     a.lds_tab_bytes = align16(ROW_BYTES * std::max(maxL, 1));
     a.lds_hap_bytes = align16(std::max(maxP, 0) + std::max(maxL, 1) + 8);
@@ -335,6 +601,22 @@ static int score_alignments_launch(const sk_align_batch* b, double* dev_out_lnp,
     const size_t lds = per_wave * WAVES_PER_BLOCK;
     // fast path: prepared batch, bounds known, and 4 waves' slabs leave room for >= 2 workgroups per CU (160 KiB LDS)
     const bool prepared = b->entries && b->evmask && b->evmask_words == sk_ent_evmask_words(maxL);
+    if (prepared && b->colmat && b->colmat_off && b->addmask && maxL > 0 && maxL <= SK_ENT_MAX_READ_LEN) { // the column form
+        a.lds_tab_bytes = align16(SEL_ROW_BYTES * ((maxL + 7) & ~7));
+        a.lds_hap_bytes = 0;
+        const size_t pw = (size_t(a.lds_tab_bytes) + (ENT_CAP + 4) * 4 + size_t(b->evmask_words) * 4 + 15) & ~size_t(15);
+        const size_t lds_cols = pw * WAVES_PER_BLOCK + 2 * (SK_NQ + 1) * sizeof(double);
+        if (lds_cols <= 64 * 1024) {
+            const int blocks = (b->n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+            if (maxL > 160) hipLaunchKernelGGL(score_wave_per_read_cols_long, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds_cols, st, a);
+            else if (from_host_entry) hipLaunchKernelGGL(score_wave_per_read_cols_hostbuf, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds_cols, st, a);
+            else hipLaunchKernelGGL(score_wave_per_read_cols, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds_cols, st, a);
+            SK_HIP(hipGetLastError());
+            return 0;
+        }
+        a.lds_tab_bytes = align16(ROW_BYTES * std::max(maxL, 1));
+        a.lds_hap_bytes = align16(std::max(maxP, 0) + std::max(maxL, 1) + 8);
+    }
     if (prepared && maxL > 0 && maxL <= SK_ENT_MAX_READ_LEN && maxP > 0 && maxP <= SK_ENT_MAX_POOL && lds <= 64 * 1024) {
         const int blocks = (b->n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
         if (from_host_entry) hipLaunchKernelGGL(score_wave_per_read_hostbuf, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds, st, a);
@@ -470,6 +752,54 @@ extern "C" int sk_score_alignments(const sk_align_batch* hb, double* out_lnp)
         if (nm) SK_HIP(hipMemcpyAsync(pm, src_evmask, 4 * nm, hipMemcpyHostToDevice, st));
         d.entries = pe;
         d.evmask = pm;
+    }
+    { // the column form: the caller's when it comes with the batch, else made here
+        std::vector<uint32_t> h_colmat, h_addmask;
+        std::vector<int64_t> h_colmat_off;
+        const uint32_t* src_colmat = hb->colmat;
+        const int64_t* src_off = hb->colmat_off;
+        const uint32_t* src_addmask = hb->addmask;
+        if (!(src_colmat && src_off && src_addmask && src_entries == hb->entries)) {
+            sk_align_batch tmp = *hb;
+            tmp.max_read_len = maxL;
+            tmp.entries = src_entries;
+            tmp.evmask = src_evmask;
+            tmp.evmask_words = d.evmask_words;
+            h_colmat.resize(size_t(sk_align_colmat_words(&tmp)) + 1);
+            h_colmat_off.resize(size_t(n) + 1);
+            h_addmask.resize(size_t(n) * size_t(d.evmask_words) + 1);
+            if (sk_align_prepare_cols(&tmp, h_colmat.data(), h_colmat_off.data(), h_addmask.data()))
+                return sk_fail("sk_score_alignments: sk_align_prepare_cols failed");
+            src_colmat = h_colmat.data();
+            src_off = h_colmat_off.data();
+            src_addmask = h_addmask.data();
+        }
+        const size_t words = size_t(src_off[n]), nm = size_t(n) * size_t(d.evmask_words);
+        // (outside the arena's first reservation: sized only now)
+        static thread_local struct Extra
+        {
+            void* p = nullptr;
+            size_t cap = 0;
+        } extra;
+        const size_t need_extra = sk_align256(4 * (words + 1)) + sk_align256(8 * size_t(n + 1)) + sk_align256(4 * (nm + 1));
+        if (extra.cap < need_extra) {
+            if (extra.p) (void)hipFree(extra.p);
+            extra.p = nullptr;
+            extra.cap = 0;
+            SK_HIP(hipMalloc(&extra.p, need_extra + need_extra / 4));
+            extra.cap = need_extra + need_extra / 4;
+        }
+        char* base = static_cast<char*>(extra.p);
+        uint32_t* pc = reinterpret_cast<uint32_t*>(base);
+        int64_t* po = reinterpret_cast<int64_t*>(base + sk_align256(4 * (words + 1)));
+        uint32_t* pa = reinterpret_cast<uint32_t*>(base + sk_align256(4 * (words + 1)) + sk_align256(8 * size_t(n + 1)));
+        if (words) SK_HIP(hipMemcpyAsync(pc, src_colmat, 4 * words, hipMemcpyHostToDevice, st));
+        SK_HIP(hipMemcpyAsync(po, src_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
+        if (nm) SK_HIP(hipMemcpyAsync(pa, src_addmask, 4 * nm, hipMemcpyHostToDevice, st));
+        SK_HIP(hipStreamSynchronize(st)); // (the staging vectors above go out of scope)
+        d.colmat = pc;
+        d.colmat_off = po;
+        d.addmask = pa;
     }
     double* dout = ar.take<double>(n_cals);
     if (score_alignments_launch(&d, dout, st, true)) return 1;

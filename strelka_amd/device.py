@@ -17,10 +17,11 @@ def _stream_ptr():
 
 
 class DeviceAlignBatch:
-    def __init__(self, hb, device="cuda:0", tile=1):
-        """Upload a capi.HostAlignBatch; `tile` > 1 replicates it on the device (offsets shifted) to reach bench sizes."""
+    def __init__(self, hb, device="cuda:0", tile=1, columns=True):
+        """Upload a capi.HostAlignBatch; `tile` > 1 replicates it on the device (offsets shifted) to reach bench sizes.
+        `columns` False leaves the column form out: the kernel then follows the transition entries."""
         self.device = device
-        hb.prepare()
+        hb.prepare(columns=columns)
         ops_bytes = hb.ops.view(np.uint8).reshape(-1, 8)
         t = dict(read_off=_t(hb.read_off, device), read_code=_t(hb.read_code, device), read_qual=_t(hb.read_qual, device),
                  hap_off=_t(hb.hap_off, device), hap_code=_t(hb.hap_code, device), cal_off=_t(hb.cal_off, device),
@@ -44,6 +45,16 @@ class DeviceAlignBatch:
         t["entries"] = _t(ent.view(np.int32), device).repeat(tile)
         t["evmask"] = _t(msk.view(np.int32), device).repeat(tile)
         self.evmask_words = hb.evmask_words
+        self.has_columns = bool(columns)
+        if columns:
+            words = int(hb.colmat_off[-1])
+            t["colmat"] = _t(hb.colmat[:words].view(np.int32), device).repeat(tile)
+            off = _t(hb.colmat_off, device)
+            if tile > 1:
+                k = torch.arange(tile, device=device, dtype=torch.int64)[:, None] * words
+                off = torch.cat([(off[None, :-1] + k).reshape(-1), torch.tensor([words * tile], device=device, dtype=torch.int64)])
+            t["colmat_off"] = off
+            t["addmask"] = _t(hb.addmask[:hb.n_reads * hb.evmask_words].view(np.int32), device).repeat(tile)
         self.t = t
         self.n_reads = hb.n_reads * tile
         self.n_cals = hb.n_cals * tile
@@ -58,7 +69,10 @@ class DeviceAlignBatch:
         return capi.AlignBatch(self.n_reads, self.n_cals, self.n_ops, t["read_off"].data_ptr(), t["read_code"].data_ptr(),
                                t["read_qual"].data_ptr(), t["hap_off"].data_ptr(), t["hap_code"].data_ptr(),
                                t["cal_off"].data_ptr(), t["op_off"].data_ptr(), t["ops"].data_ptr(), self.max_read_len,
-                               self.max_hap_len, t["entries"].data_ptr(), t["evmask"].data_ptr(), self.evmask_words)
+                               self.max_hap_len, t["entries"].data_ptr(), t["evmask"].data_ptr(), self.evmask_words,
+                               t["colmat"].data_ptr() if self.has_columns else None,
+                               t["colmat_off"].data_ptr() if self.has_columns else None,
+                               t["addmask"].data_ptr() if self.has_columns else None)
 
     def score(self, generic=False):
         """Enqueue the scoring kernel on torch's current stream; returns the device output tensor."""

@@ -50,6 +50,8 @@ struct sk_align_builder
     std::vector<uint8_t> read_code, read_qual, hap_code;
     std::vector<sk_score_op> ops;
     std::vector<uint32_t> entries, evmask; // prepared form, filled by finish
+    std::vector<uint32_t> colmat, addmask;
+    std::vector<int64_t> colmat_off;
     int32_t max_read_len = 0, max_hap_len = 0;
     int32_t host_threads = 1; // budget of finish()'s prepare step (sk_align_builder_set_host_threads)
     std::string error;
@@ -410,6 +412,69 @@ static int align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* e
 
 int sk_align_prepare(const sk_align_batch* b, uint32_t* entries, uint32_t* evmask) { return align_prepare(b, entries, evmask, 1); }
 
+int64_t sk_align_colmat_words(const sk_align_batch* b)
+{
+    if (!b || b->n_reads < 0) return -1;
+    int64_t n = 0;
+    for (int r = 0; r < b->n_reads; ++r)
+        n += ((b->read_off[r + 1] - b->read_off[r] + 7) / 8) * int64_t(b->cal_off[r + 1] - b->cal_off[r]);
+    return n;
+}
+
+// the column form (layout: strelka_amd.h, sk_align_batch::colmat): which table column each read position of each candidate
+// alignment faces -- the walk of align_prepare above with every position written out
+int sk_align_prepare_cols(const sk_align_batch* b, uint32_t* colmat, int64_t* colmat_off, uint32_t* addmask)
+{
+    if (!b || !colmat || !colmat_off || !addmask || !b->entries || b->n_reads < 0) return 1;
+    const int W = sk_ent_evmask_words(b->max_read_len);
+    colmat_off[0] = 0;
+    for (int r = 0; r < b->n_reads; ++r)
+        colmat_off[r + 1] = colmat_off[r] + ((b->read_off[r + 1] - b->read_off[r] + 7) / 8) * int64_t(b->cal_off[r + 1] - b->cal_off[r]);
+    const uint8_t zero_byte = uint8_t(SK_SEL_NONE | (SK_SEL_NONE << 4)); // two positions that add nothing
+    for (int r = 0; r < b->n_reads; ++r) {
+        const int L = int(b->read_off[r + 1] - b->read_off[r]), P = int(b->hap_off[r + 1] - b->hap_off[r]);
+        const int ncr = b->cal_off[r + 1] - b->cal_off[r], nch = (L + 7) / 8;
+        uint32_t* am = addmask + int64_t(r) * W;
+        std::memset(am, 0, sizeof(uint32_t) * size_t(W));
+        uint8_t* cm = reinterpret_cast<uint8_t*>(colmat + colmat_off[r]);
+        std::memset(cm, zero_byte, size_t(4) * size_t(nch) * size_t(ncr));
+        const uint8_t* hap = b->hap_code + b->hap_off[r];
+        const uint8_t* read = b->read_code + b->read_off[r];
+        for (int j = 0; j < ncr; ++j) {
+            const int c = b->cal_off[r] + j;
+            const uint32_t* ent = b->entries + b->op_off[c] + 2 * int64_t(c);
+            if (ent[0] == SK_ENT_COMPLEX) { // scored by the generic routine; the mask's last bit tells the kernel the read has one
+                am[W - 1] |= 1u << 31;
+                continue;
+            }
+            for (int e = 0; (ent[e] & SK_ENT_POS_MASK) != SK_ENT_END; ++e)
+                if (ent[e] & SK_ENT_ADD_BITS) {
+                    const unsigned p = ent[e] & SK_ENT_POS_MASK;
+                    am[p >> 5] |= 1u << (p & 31);
+                }
+            int pos = 0;
+            for (int64_t k = b->op_off[c]; k < b->op_off[c + 1]; ++k) {
+                const sk_score_op& op = b->ops[k];
+                const int len = int(op.length);
+                if (!((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0)) continue;
+                for (int t = 0; t < len && pos + t < L; ++t) {
+                    unsigned col = SK_ENT_ZERO_COL;
+                    if (op.kind == SK_OP_BASES) {
+                        const int idx = int(op.src) + t;
+                        col = (idx >= 0 && idx < P) ? sk_ent_col_index(hap[idx]) : unsigned(SK_ENT_ZERO_COL);
+                    }
+                    const int i = pos + t;
+                    const unsigned sel = sk_col_selector(col, read[i]);
+                    uint8_t& byte = cm[(size_t(i >> 3) * size_t(ncr) + size_t(j)) * 4 + size_t(i & 3)];
+                    byte = (i & 4) ? uint8_t((byte & 0x0fu) | (sel << 4)) : uint8_t((byte & 0xf0u) | sel);
+                }
+                pos += len;
+            }
+        }
+    }
+    return 0;
+}
+
 int sk_align_builder_set_host_threads(sk_align_builder* b, const int32_t host_threads)
 {
     if (!b || host_threads < 0) return 1;
@@ -439,9 +504,23 @@ int sk_align_builder_finish(sk_align_builder* b, sk_align_batch* out)
     b->evmask.assign(size_t(out->n_reads) * size_t(out->evmask_words) + 1, 0u);
     out->entries = nullptr;
     out->evmask = nullptr;
+    out->colmat = nullptr;
+    out->colmat_off = nullptr;
+    out->addmask = nullptr;
     if (align_prepare(out, b->entries.data(), b->evmask.data(), b->host_threads)) return 1;
     out->entries = b->entries.data();
     out->evmask = b->evmask.data();
+    // the column form
+    out->colmat = nullptr;
+    out->colmat_off = nullptr;
+    out->addmask = nullptr;
+    b->colmat.assign(size_t(sk_align_colmat_words(out)) + 1, 0u);
+    b->colmat_off.assign(size_t(out->n_reads) + 1, 0);
+    b->addmask.assign(size_t(out->n_reads) * size_t(out->evmask_words) + 1, 0u);
+    if (sk_align_prepare_cols(out, b->colmat.data(), b->colmat_off.data(), b->addmask.data())) return 1;
+    out->colmat = b->colmat.data();
+    out->colmat_off = b->colmat_off.data();
+    out->addmask = b->addmask.data();
     return 0;
 }
 

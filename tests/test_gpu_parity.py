@@ -76,6 +76,23 @@ def test_fast_and_generic_kernels_agree_at_scale(gpu):
     assert np.array_equal(small.view(np.uint64), fast[:n].cpu().numpy().view(np.uint64))
 
 
+def test_column_and_entry_kernels_agree(gpu):
+    """the streaming kernel (column form of the batch) and the transition-entry kernel are two implementations of the same sum:
+    identical bits on the h64 workload (dense transitions, non-candidate penalties) and on soft-clipped / clipped random cases"""
+    import torch
+    from strelka_amd import device
+    rng = np.random.default_rng(106)
+    for cases in (synth.align_cases_h64(300, rng), synth.align_cases(400, rng), synth.align_cases(12, rng, L=150, K=7, max_cals=128)):
+        hb = synth.build_align_batch(cases)
+        want = pyoracle.score_cases(cases)
+        for columns in (True, False):
+            hb.colmat = hb.colmat_off = hb.addmask = None
+            d = device.DeviceAlignBatch(hb, "cuda:0", columns=columns)
+            got = d.score().cpu().numpy()
+            torch.cuda.synchronize()
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), columns
+
+
 def test_flat_workload_matches_interpreter(gpu):
     from tests.flat_interp import score_flat
     rng = np.random.default_rng(105)

@@ -101,3 +101,47 @@ def test_empty_read_and_no_candidates(built):
     batch = b.finish()
     assert batch.n_reads == 2 and batch.n_cals == 1
     assert list(batch.cal_off) == [0, 0, 1]
+
+
+def test_column_form_matches_the_ops():
+    """sk_align_prepare_cols: every read position of every candidate alignment selects the term its ops say (agree / differ /
+    nothing: read base N, soft clip, past the end); the add mask has exactly the positions of entries that add terms"""
+    rng = np.random.default_rng(77)
+    cases = synth.align_cases(60, rng) + synth.align_cases_h64(8, rng) + synth.align_cases(5, rng, L=203, K=6, max_cals=70)
+    hb = synth.build_align_batch(cases).prepare()
+    W = hb.evmask_words
+    col_of = {1: 0, 2: 1, 4: 2, 8: 3}
+    for r in range(hb.n_reads):
+        L = int(hb.read_off[r + 1] - hb.read_off[r])
+        hap = hb.hap_code[hb.hap_off[r]:hb.hap_off[r + 1]]
+        c0, c1 = int(hb.cal_off[r]), int(hb.cal_off[r + 1])
+        ncr, nch = c1 - c0, (L + 7) // 8
+        cm = hb.colmat[int(hb.colmat_off[r]):int(hb.colmat_off[r + 1])].view(np.uint8).reshape(nch, ncr, 4)
+        want_mask = np.zeros(W, np.uint32)
+        for j in range(ncr):
+            c = c0 + j
+            ent = hb.entries[int(hb.op_off[c]) + 2 * c: int(hb.op_off[c + 1]) + 2 * (c + 1)]
+            assert ent[0] != 0xffffffff
+            for e in ent:
+                if (e & 1023) == 1023:
+                    break
+                if e & ((7 << 10) | (1 << 13)):
+                    p = int(e & 1023)
+                    want_mask[p >> 5] |= np.uint32(1 << (p & 31))
+            want = np.full(8 * nch, 2, np.uint8)
+            read = hb.read_code[int(hb.read_off[r]):int(hb.read_off[r + 1])]
+            pos = 0
+            for op in hb.ops[int(hb.op_off[c]):int(hb.op_off[c + 1])]:
+                n = int(op["length"])
+                if op["kind"] == capi.OP_BASES:
+                    for t in range(n):
+                        h, rc = int(hap[int(op["src"]) + t]), int(read[pos + t])
+                        want[pos + t] = 2 if rc == 15 else 0 if (rc == 0 or (rc == h and rc in col_of)) else 1
+                    pos += n
+                elif op["kind"] == capi.OP_SOFT_CLIP:
+                    pos += n
+            assert pos == L
+            by = cm[:, j, :]                                                    # [word][byte]
+            got = np.concatenate([by & 15, by >> 4], axis=1).reshape(-1)        # positions 8k..8k+3 low nibbles, 8k+4..8k+7 high
+            assert np.array_equal(got, want), (r, j)
+        assert np.array_equal(hb.addmask[r * W:(r + 1) * W], want_mask), r
