@@ -238,6 +238,8 @@ typedef struct sk_realign_options { /* L/starling_common/starling_base_shared.hh
                                              2 = device: search, ordering / de-duplication and flattening of every read's
                                                  candidate alignments in kernels (csrc/read_enumerate.hip), scored where they
                                                  are; reads beyond the core's fixed capacities take path 0.
+                                             sk_realign_options_default: 2 once sk_init has succeeded, else 0; the
+                                             environment variable SK_ENUMERATION overrides the default.
                                              Results are identical in all three. */
 } sk_realign_options;
 void sk_realign_options_default(sk_realign_options* opt);

@@ -309,6 +309,7 @@ int sk_global_align(const sk_global_align_batch* b, const sk_align_scores* score
 // enumeration == 2 is the device pipeline of the GPU library; the double has no device
 struct SkEnumInput;
 struct SkEnumOutput;
+extern "C" int sk_enum_device_available(void) { return 0; }
 extern "C" int sk_enum_device_run(const SkEnumInput*, SkEnumOutput*)
 {
     return sk_fail("candidate enumeration on the device (sk_realign_options.enumeration = 2) needs the GPU library");

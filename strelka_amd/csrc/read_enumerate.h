@@ -40,3 +40,7 @@ struct SkEnumOutput // host arrays owned by the pipeline, valid until its next r
 };
 
 extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out);
+
+/** whether enumeration == 2 can run (it is the default where it can): 1 in the GPU library once sk_init has succeeded, 0 before
+ *  that and in the CPU double of the ABI */
+extern "C" int sk_enum_device_available(void);

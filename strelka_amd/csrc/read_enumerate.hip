@@ -632,22 +632,36 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
             const unsigned p = ent[i] & SK_ENT_POS_MASK;
             atomicOr(&am[p >> 5], 1u << (p & 31));
         }
+    // one word (eight read positions) at a time: assembled in a register, stored once
     const int ncr = a.cal_off[r + 1] - a.cal_off[r], j = c - a.cal_off[r];
-    uint8_t* cm = a.colmat + 4 * a.colmat_off[r];
+    uint32_t* cm = reinterpret_cast<uint32_t*>(a.colmat) + a.colmat_off[r] + j;
+    const uint8_t* read = a.read_code + a.read_off[r];
+    constexpr uint32_t NONE_WORD = 0x11111111u * SK_SEL_NONE;
+    uint32_t word = NONE_WORD;
+    int wk = 0; // index of the word being assembled
     pos = 0;
+    auto put = [&](const int i, const unsigned sel) {
+        const int k8 = i >> 3;
+        if (k8 != wk) {
+            cm[int64_t(wk) * ncr] = word;
+            for (int q = wk + 1; q < k8; ++q) cm[int64_t(q) * ncr] = NONE_WORD; // (words a soft clip spans)
+            word = NONE_WORD;
+            wk = k8;
+        }
+        const unsigned shift = 8u * (unsigned(i) & 3u) + ((i & 4) ? 4u : 0u);
+        word = (word & ~(0xfu << shift)) | (sel << shift);
+    };
     for (int64_t kk = k0; kk < k1; ++kk) {
         const sk_score_op op = a.ops[kk];
         const int len = int(op.length);
         if (!((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0)) continue;
         if (op.kind == SK_OP_BASES)
-            for (int t = 0; t < len && pos + t < L; ++t) { // (only this thread writes this candidate's bytes)
-                const int i = pos + t;
-                const unsigned sel = sk_col_selector(col_at(int(op.src) + t), a.read_code[a.read_off[r] + i]);
-                uint8_t& byte = cm[(size_t(i >> 3) * size_t(ncr) + size_t(j)) * 4 + size_t(i & 3)];
-                byte = (i & 4) ? uint8_t((byte & 0x0fu) | (sel << 4)) : uint8_t((byte & 0xf0u) | sel);
-            }
+            for (int t = 0; t < len && pos + t < L; ++t) put(pos + t, sk_col_selector(col_at(int(op.src) + t), read[pos + t]));
         pos += len;
     }
+    const int nch = (L + 7) >> 3;
+    if (wk < nch) cm[int64_t(wk) * ncr] = word;
+    for (int q = wk + 1; q < nch; ++q) cm[int64_t(q) * ncr] = NONE_WORD;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -705,6 +719,8 @@ EnumBuffers& bufs()
 }
 
 } // namespace
+
+extern "C" int sk_enum_device_available(void) { return sk_ctx().ready ? 1 : 0; } // (host stages alone run without a device)
 
 extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
 {
@@ -858,13 +874,22 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         SK_HIP(hipMemcpyAsync(ea.level_count, &in->n_reads, 4, hipMemcpyHostToDevice, st));
         const size_t lds = 64 * sizeof(PFrame);
         const int blocks = int(std::min<int64_t>((frame_cap + 63) / 64, 1024));
-        for (int d = 0; d < Caps::K + 2; ++d) { // a call at depth d expands indel order[d]; depth n_order <= K is a leaf
-            ea.level_in = buf[d & 1];
-            ea.level_out = buf[(d + 1) & 1];
-            ea.depth = d;
-            hipLaunchKernelGGL(level_kernel, dim3(blocks), dim3(64), lds, st, ea);
+        // a call at depth d expands indel order[d]; depth n_order <= K is a leaf.  Few searches go deeper than a dozen levels:
+        // the launches go out twelve at a time, and the level counts tell whether another dozen is needed
+        for (int d0 = 0; d0 < Caps::K + 2; d0 += 12) {
+            for (int d = d0; d < std::min(d0 + 12, Caps::K + 2); ++d) {
+                ea.level_in = buf[d & 1];
+                ea.level_out = buf[(d + 1) & 1];
+                ea.depth = d;
+                hipLaunchKernelGGL(level_kernel, dim3(blocks), dim3(64), lds, st, ea);
+            }
+            SK_HIP(hipGetLastError());
+            if (d0 + 12 >= Caps::K + 2) break;
+            int32_t next_count = 0;
+            SK_HIP(hipMemcpyAsync(&next_count, ea.level_count + (d0 + 12), 4, hipMemcpyDeviceToHost, st));
+            SK_HIP(hipStreamSynchronize(st));
+            if (next_count == 0) break;
         }
-        SK_HIP(hipGetLastError());
     }
     D2H(h_status, status, 4 * size_t(n));
     D2H(h_warn, warn, 4 * size_t(n));

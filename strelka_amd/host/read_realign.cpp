@@ -1860,8 +1860,9 @@ void sk_realign_options_default(sk_realign_options* o)
     o->min_read_bp_flank = 5;
     o->sample_count = 1;
     o->host_threads = 1; // the reference runs one process per core; an adapter that owns more cores raises this
-    // SK_ENUMERATION overrides the default for test runs of whole suites in one mode (tests/conftest.py documents it)
-    o->enumeration = 0;
+    // the device pipeline where there is a device (the CPU double of the ABI, oracle/abi_double.cpp, has none);
+    // SK_ENUMERATION overrides the default for runs of whole suites / of the adapter in one mode
+    o->enumeration = sk_enum_device_available() ? 2 : 0;
     if (const char* e = std::getenv("SK_ENUMERATION")) o->enumeration = std::atoi(e);
 }
 
