@@ -121,9 +121,11 @@ typedef struct sk_align_batch {
      * candidate haplotypes instead of following transitions: the bytes SURVEY.md 8d counts (H * L_h per read, here four bits
      * per base).  Read r owns colmat[colmat_off[r] ..): word [k * n_cals(r) + j] holds read positions 8k..8k+7 of the read's
      * j-th candidate alignment: position 8k+q in the low nibble of byte q, position 8k+4+q in its high nibble (q = 0..3).
+     * Bit 2 of a nibble: ONE non-candidate-indel penalty (and nothing else) is added before this position's term.
      * addmask has bit p of read r set when an entry of ANY of its candidates adds penalty / soft-clip terms at read position p
      * (0 <= p <= read length); its last bit (32 * evmask_words - 1) is set when one of the read's candidates does not fit the
-     * entry format.  NULL = absent: the kernel follows the transition entries. */
+     * entry format, the bit before it when some entry adds more than the one penalty a nibble can flag (the kernel then takes
+     * this read's added terms from its entries and ignores the flags).  NULL = absent: the kernel follows the entries. */
     const uint32_t* colmat;
     const int64_t* colmat_off; /* [n_reads+1], in words */
     const uint32_t* addmask;   /* [n_reads * evmask_words] */

@@ -640,6 +640,20 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
     uint32_t word = NONE_WORD;
     int wk = 0; // index of the word being assembled
     pos = 0;
+    const int nch = (L + 7) >> 3;
+    int ei = 0; // next entry that adds terms (entries and positions both ascend)
+    bool needs_entries = false;
+    // an entry adding exactly one penalty at position i becomes bit 2 of that position's nibble; anything else leaves the read to
+    // its entries (host form and rationale: sk_align_prepare_cols)
+    auto flag_at = [&](const int i) -> unsigned {
+        while (ei < e && int(ent[ei] & SK_ENT_POS_MASK) < i) ++ei;
+        if (ei < e && int(ent[ei] & SK_ENT_POS_MASK) == i && (ent[ei] & SK_ENT_ADD_BITS)) {
+            const bool simple = ((ent[ei] >> 10) & 7u) == 1u && !(ent[ei] & (1u << 13)) && i < 8 * nch;
+            if (simple) return 4u;
+            needs_entries = true;
+        }
+        return 0u;
+    };
     auto put = [&](const int i, const unsigned sel) {
         const int k8 = i >> 3;
         if (k8 != wk) {
@@ -655,11 +669,20 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
         const sk_score_op op = a.ops[kk];
         const int len = int(op.length);
         if (!((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0)) continue;
-        if (op.kind == SK_OP_BASES)
-            for (int t = 0; t < len && pos + t < L; ++t) put(pos + t, sk_col_selector(col_at(int(op.src) + t), read[pos + t]));
+        if (op.kind == SK_OP_BASES) {
+            for (int t = 0; t < len && pos + t < L; ++t)
+                put(pos + t, sk_col_selector(col_at(int(op.src) + t), read[pos + t]) | flag_at(pos + t));
+        } else if (flag_at(pos)) { // (a soft clip's entry is never the simple kind; flag_at notes that the entries are needed)
+        }
         pos += len;
     }
-    const int nch = (L + 7) >> 3;
+    {
+        const unsigned f = flag_at(L); // trailing penalties: the nibble after the last base, where the last word has one
+        if (f) put(L, SK_SEL_NONE | f);
+    }
+    for (; ei < e; ++ei) // (entries no position above stood for)
+        if ((ent[ei] & SK_ENT_ADD_BITS) && int(ent[ei] & SK_ENT_POS_MASK) > L) needs_entries = true;
+    if (needs_entries) atomicOr(&a.addmask[int64_t(r) * W + (W - 1)], 1u << 30);
     if (wk < nch) cm[int64_t(wk) * ncr] = word;
     for (int q = wk + 1; q < nch; ++q) cm[int64_t(q) * ncr] = NONE_WORD;
 }

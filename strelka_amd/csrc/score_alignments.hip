@@ -311,8 +311,8 @@ constexpr int SEL_ROW_BYTES = 24;             // per read position: {agree, diff
 // the eight row-relative byte offsets (8 * selector) of a column word: lo's bytes are positions 0..3, hi's positions 4..7
 __device__ __forceinline__ void unpack_cols(const uint32_t w, uint32_t& lo, uint32_t& hi)
 {
-    lo = (w & 0x0f0f0f0fu) << 3;
-    hi = (w & 0xf0f0f0f0u) >> 1;
+    lo = (w & 0x03030303u) << 3; // (bit 2 of a nibble is the penalty flag, bit 3 is unused)
+    hi = (w & 0x30303030u) >> 1;
 }
 
 template <int NW> // column words a lane holds in registers: reads up to 8 * NW positions are swept without a load in the loop
@@ -389,10 +389,15 @@ __device__ __forceinline__ void score_cols_body(const ScoreArgs& a)
 
         // ---- the read's add mask and rows into LDS
         const unsigned cx = (lane == W - 1) ? (am >> 31) : 0u;
-        const unsigned amw = (lane == W - 1) ? (am & 0x7fffffffu) : am;
+        const unsigned ne = (lane == W - 1) ? ((am >> 30) & 1u) : 0u;
+        const unsigned amw = (lane == W - 1) ? (am & 0x3fffffffu) : am;
         if (lane < W) mask[lane] = amw;
-        const bool has_add = __any(amw != 0);
+        const bool any_add = __any(amw != 0);
         const bool has_complex = __any(cx != 0);
+        // added terms come either from the nibbles' penalty flags (every entry of the read that adds anything adds exactly one
+        // penalty) or, for the reads where that does not hold, from the candidates' entry lists
+        const bool has_add = any_add && __any(ne != 0);
+        const bool has_flags = any_add && !has_add;
         {
             // per-position rows {M, X, 0.0}: the terms of a read base of this quality that agrees / differs; which one a
             // candidate takes (or none: read base N, soft clip, past the end) is in its column word
@@ -506,7 +511,31 @@ __device__ __forceinline__ void score_cols_body(const ScoreArgs& a)
             // (the third term of every row is 0.0), so the pair is processed whole and without a branch.
             auto word_pair = [&](const uint32_t wa, const uint32_t wb, const int t) {
                 uint32_t bits = 0;
-                if (has_add) bits = (uint32_t(__builtin_amdgcn_readfirstlane(mask[t >> 2])) >> (8 * (t & 3))) & 0xffffu; // t is even
+                if (has_add || has_flags) bits = (uint32_t(__builtin_amdgcn_readfirstlane(mask[t >> 2])) >> (8 * (t & 3))) & 0xffffu; // t is even
+                if (bits != 0 && has_flags) { // a flagged position: one penalty, then its term (adding 0.0 elsewhere changes nothing)
+                    const uint32_t ww[2] = { wa, wb };
+                    const unsigned char* rpa = tabb + SEL_ROW_BYTES * 8 * t;
+                    const unsigned char* rpb = (t + 1 < nch) ? rpa + SEL_ROW_BYTES * 8 : tabb;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        uint32_t lo, hi;
+                        unpack_cols(ww[h], lo, hi);
+                        const unsigned char* rp = h ? rpb : rpa;
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            v[u] = *reinterpret_cast<const double*>(rp + SEL_ROW_BYTES * u + ((lo >> (8 * u)) & 0xffu));
+                            v[4 + u] = *reinterpret_cast<const double*>(rp + SEL_ROW_BYTES * (4 + u) + ((hi >> (8 * u)) & 0xffu));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const uint32_t flag = ww[h] & ((q < 4) ? (0x4u << (8 * q)) : (0x40u << (8 * (q - 4))));
+                            lnp = dadd(lnp, flag ? ln_noncand : 0.0);
+                            lnp = dadd(lnp, v[q]);
+                        }
+                    }
+                    return;
+                }
                 if (bits == 0) {
                     uint32_t lo[2], hi[2];
                     unpack_cols(wa, lo[0], hi[0]);

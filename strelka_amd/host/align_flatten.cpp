@@ -453,6 +453,7 @@ int sk_align_prepare_cols(const sk_align_batch* b, uint32_t* colmat, int64_t* co
                     am[p >> 5] |= 1u << (p & 31);
                 }
             int pos = 0;
+            // (selectors first, then the penalty flags on top of them)
             for (int64_t k = b->op_off[c]; k < b->op_off[c + 1]; ++k) {
                 const sk_score_op& op = b->ops[k];
                 const int len = int(op.length);
@@ -469,6 +470,21 @@ int sk_align_prepare_cols(const sk_align_batch* b, uint32_t* colmat, int64_t* co
                     byte = (i & 4) ? uint8_t((byte & 0x0fu) | (sel << 4)) : uint8_t((byte & 0xf0u) | sel);
                 }
                 pos += len;
+            }
+            // one non-candidate-indel penalty and nothing else is the common case of an entry that adds terms: it is flagged
+            // in the position's own nibble (bit 2), and a read whose candidates have nothing but such entries is swept without
+            // its entry lists; anything else (several penalties, a soft clip, a penalty after the last word) sets bit
+            // 32 * W - 2 of the read's add mask: that read's entries are consulted, its flags ignored
+            for (int e = 0; (ent[e] & SK_ENT_POS_MASK) != SK_ENT_END; ++e) {
+                if (!(ent[e] & SK_ENT_ADD_BITS)) continue;
+                const int i = int(ent[e] & SK_ENT_POS_MASK);
+                const bool simple = ((ent[e] >> 10) & 7u) == 1u && !(ent[e] & (1u << 13)) && i < 8 * nch;
+                if (!simple) {
+                    am[W - 1] |= 1u << 30;
+                    continue;
+                }
+                uint8_t& byte = cm[(size_t(i >> 3) * size_t(ncr) + size_t(j)) * 4 + size_t(i & 3)];
+                byte |= (i & 4) ? 0x40u : 0x04u;
             }
         }
     }

@@ -142,6 +142,19 @@ def test_column_form_matches_the_ops():
                     pos += n
             assert pos == L
             by = cm[:, j, :]                                                    # [word][byte]
-            got = np.concatenate([by & 15, by >> 4], axis=1).reshape(-1)        # positions 8k..8k+3 low nibbles, 8k+4..8k+7 high
-            assert np.array_equal(got, want), (r, j)
+            nib = np.concatenate([by & 15, by >> 4], axis=1).reshape(-1)        # positions 8k..8k+3 low nibbles, 8k+4..8k+7 high
+            assert np.array_equal(nib & 3, want), (r, j)
+            # bit 2: exactly one non-candidate penalty (no soft clip) is added before the position's term
+            want_flag = np.zeros(8 * nch, np.uint8)
+            for e in ent:
+                if (e & 1023) == 1023:
+                    break
+                if e & ((7 << 10) | (1 << 13)):
+                    p = int(e & 1023)
+                    if ((e >> 10) & 7) == 1 and not (e & (1 << 13)) and p < 8 * nch:
+                        want_flag[p] = 1
+                    else:
+                        want_mask[W - 1] |= np.uint32(1 << 30)
+            assert np.array_equal((nib >> 2) & 1, want_flag), (r, j)
+            assert not np.any(nib >> 3)
         assert np.array_equal(hb.addmask[r * W:(r + 1) * W], want_mask), r
