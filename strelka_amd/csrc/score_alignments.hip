@@ -38,7 +38,10 @@
 namespace
 {
 
-constexpr int WAVES_PER_BLOCK = 4;
+#ifndef SK_A1_WAVES_PER_BLOCK
+#define SK_A1_WAVES_PER_BLOCK 4
+#endif
+constexpr int WAVES_PER_BLOCK = SK_A1_WAVES_PER_BLOCK;
 constexpr int WAVE = 64;
 constexpr int ROW_BYTES = 48;                 // per read position: {A, C, G, T, other, 0.0} doubles
 constexpr int ZERO_COL = 8 * SK_ENT_ZERO_COL; // byte offset of the 0.0 column
