@@ -1556,9 +1556,11 @@ void late_indel_normalization_filter(const Job& job, const sk_realign_job::Read&
     const unsigned n = unsigned(rd.cals.size());
     const double equiv_range = job.opt.is_smoothed_alignments ? job.opt.smoothed_lnp_range : 0.;
     std::vector<std::pair<double, unsigned>> sorted;
+    sorted.reserve(n);
     for (unsigned i = 0; i < n; ++i) sorted.push_back(std::make_pair(scores[i], i));
     std::sort(sorted.rbegin(), sorted.rend());
     std::vector<double> smooth(scores, scores + n);
+    std::vector<std::pair<int, int>> pairs;
     bool any_excluded = false;
     for (unsigned i1 = 0; i1 < n; ++i1) {
         const unsigned s1 = sorted[i1].second;
@@ -1571,14 +1573,15 @@ void late_indel_normalization_filter(const Job& job, const sk_realign_job::Read&
             const ISet& a = rd.cals[s1].indels;
             const ISet& b = rd.cals[s2].indels;
             if (a.size() != b.size()) continue;
-            std::set<std::pair<int, int>> pairs;
+            // (the reference's std::set of key pairs: a is ascending without repeats, so the pairs are in set order as found)
+            pairs.clear();
             bool equiv = true;
             for (size_t q = 0; q < a.size(); ++q) {
                 if (a[q] == b[q]) continue;
                 const Key& k1 = job.key(a[q]);
                 const Key& k2 = job.key(b[q]);
                 if (k1.type != k2.type || k1.del != k2.del || k1.ins != k2.ins) { equiv = false; break; }
-                pairs.insert(std::make_pair(a[q], b[q]));
+                pairs.push_back(std::make_pair(a[q], b[q]));
             }
             if (!equiv || pairs.empty()) continue;
             bool s1_removed = false, removed = false;
@@ -1621,19 +1624,13 @@ void late_indel_normalization_filter(const Job& job, const sk_realign_job::Read&
 
 // The reference's iks_map_t (:54): best score per (evaluated indel, (is present, which indel)).  Both indels always come from
 // the read's evaluated set, so the map is a dense [evaluated][present][evaluated] table over positions in that (sorted) set.
-struct ScoringInfo
+struct ScoringInfo // indexed by POSITION in the evaluated-indel list (call, present?, which)
 {
-    const ISet& eval;
     int n;
     std::vector<double> val;
     std::vector<char> has;
-    explicit ScoringInfo(const ISet& e) : eval(e), n(int(e.size())), val(size_t(2) * e.size() * e.size()), has(val.size(), 0) {}
-    size_t slot(const int call, const bool present, const int which) const
-    {
-        const size_t lc = size_t(std::lower_bound(eval.begin(), eval.end(), call) - eval.begin());
-        const size_t lw = size_t(std::lower_bound(eval.begin(), eval.end(), which) - eval.begin());
-        return (lc * 2 + (present ? 1 : 0)) * size_t(n) + lw;
-    }
+    explicit ScoringInfo(const size_t n_eval) : n(int(n_eval)), val(size_t(2) * n_eval * n_eval), has(val.size(), 0) {}
+    size_t slot(const int call, const bool present, const int which) const { return (size_t(call) * 2 + (present ? 1 : 0)) * size_t(n) + size_t(which); }
     void update(const int call, const bool present, const int which, const double lnp) // updateIndelScoringInfo :61-77
     {
         const size_t k = slot(call, present, which);
@@ -1693,30 +1690,42 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
             to_eval.push_back(e);
         }
     }
-    std::map<int, ISet> ortho;
-    for (size_t i = 0; i < to_eval.size(); ++i)
-        for (size_t j = i + 1; j < to_eval.size(); ++j)
+    // orthogonal (conflicting) evaluated indels of each evaluated indel, as positions in to_eval, ascending -- the reference's
+    // std::map<IndelKey, std::set<IndelKey>>; (its operator[] creating empty entries has no observable effect)
+    const size_t ne = to_eval.size();
+    std::vector<std::vector<int>> ortho(ne);
+    for (size_t i = 0; i < ne; ++i)
+        for (size_t j = i + 1; j < ne; ++j)
             if (is_indel_conflict(job.key(to_eval[i]), job.key(to_eval[j]))) {
-                iset_insert(ortho[to_eval[i]], to_eval[j]);
-                iset_insert(ortho[to_eval[j]], to_eval[i]);
+                ortho[i].push_back(int(j));
+                ortho[j].push_back(int(i));
             }
+    for (auto& o : ortho) std::sort(o.begin(), o.end());
 
-    ScoringInfo info(to_eval);
+    ScoringInfo info(ne);
+    std::vector<char> in_cal(ne);
+    ISet noncand_ortho;
     for (unsigned ci = 0; ci < n; ++ci) {
         if (is_filtered[ci]) continue;
         const Cal& c = rd.cals[ci];
         const double score = scores[ci];
-        ISet noncand_ortho;
-        for (const int e : to_eval) {
+        { // which evaluated indels the alignment holds: one merge over two ascending lists
+            size_t a = 0;
+            for (size_t q = 0; q < ne; ++q) {
+                while (a < c.indels.size() && c.indels[a] < to_eval[q]) ++a;
+                in_cal[q] = (a < c.indels.size() && c.indels[a] == to_eval[q]) ? 1 : 0;
+            }
+        }
+        noncand_ortho.clear();
+        for (size_t q = 0; q < ne; ++q) {
+            const int e = to_eval[q];
             const Indel& ed = job.tab[e];
-            if (iset_has(c.indels, e)) {
-                info.update(e, true, e, score);
-                info.update(e, false, e, score + ed.r2i);
-                auto of = ortho.find(e);
-                if (of == ortho.end()) { ortho[e]; of = ortho.find(e); } // operator[] in the reference creates the entry
-                for (const int o : of->second) {
+            if (in_cal[q]) {
+                info.update(int(q), true, int(q), score);
+                info.update(int(q), false, int(q), score + ed.r2i);
+                for (const int o : ortho[q]) {
                     info.update(o, false, o, score + ed.r2i);
-                    info.update(o, true, e, score);
+                    info.update(o, true, int(q), score);
                 }
             } else {
                 // which_interfering_indel :100-119
@@ -1727,17 +1736,17 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
                 }
                 if (interfering >= 0 && !iset_has(to_eval, interfering)) iset_insert(noncand_ortho, interfering);
                 if (interfering < 0) {
-                    info.update(e, false, e, score);
-                    info.update(e, true, e, score + ed.i2r);
+                    info.update(int(q), false, int(q), score);
+                    info.update(int(q), true, int(q), score + ed.i2r);
                 } else {
-                    info.update(e, true, e, score + ed.i2r);
+                    info.update(int(q), true, int(q), score + ed.i2r);
                 }
             }
         }
         for (const int nc : noncand_ortho) {
-            for (const int e : to_eval) {
-                if (!is_indel_conflict(job.key(nc), job.key(e))) continue;
-                info.update(e, false, e, score + job.tab[nc].r2i);
+            for (size_t q = 0; q < ne; ++q) {
+                if (!is_indel_conflict(job.key(nc), job.key(to_eval[q]))) continue;
+                info.update(int(q), false, int(q), score + job.tab[nc].r2i);
             }
         }
     }
@@ -1746,13 +1755,14 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
     uint16_t non_ambig = 0;
     for (uint8_t c : rd.code) if (c != SK_BAM_ANY) ++non_ambig;
     const bool tier1 = (rd.map_level == SK_MAPLEVEL_TIER1);
-    for (const int e : to_eval) {
+    for (size_t q = 0; q < ne; ++q) {
+        const int e = to_eval[q];
         const Key& k = job.key(e);
         const bool in_max = iset_has(mc.indels, e);
         double indel_score = max_score;
-        if (!in_max && !info.find(e, true, e, indel_score)) continue; // incomplete search or "safe mode" warning: skipped either way
+        if (!in_max && !info.find(int(q), true, int(q), indel_score)) continue; // incomplete search or "safe mode" warning: skipped either way
         double ref_score = 0;
-        if (!info.find(e, false, e, ref_score)) continue;
+        if (!info.find(int(q), false, int(q), ref_score)) continue;
         const Range rr(k.pos - 1, k.right_pos() + 1);
         const int32_t read_pos = lowest_fwd_read_pos_for_ref_range(mc.al, rr);
         int32_t edge_dist = int32_t(read_length);
@@ -1774,26 +1784,24 @@ void score_indels(const Job& job, sk_realign_job::Read& rd, const double* scores
         s.is_fwd_strand = mc.al.fwd;
         s.read_pos = int16_t(read_pos);
         s.distance_from_closest_read_edge = int16_t(edge_dist);
-        auto of = ortho.find(e);
-        if (of != ortho.end()) {
-            for (const int o : of->second) {
-                double alt_score;
-                if (!info.find(e, true, o, alt_score)) continue;
-                // ReadPathScores::insertAlt, IndelData.cpp:40-68: keep the two best
-                const float a = static_cast<float>(alt_score);
-                if (s.n_alt < 2) {
-                    s.alt_indel[s.n_alt] = job.tab[o].orig;
-                    s.alt_lnp[s.n_alt] = a;
-                    s.n_alt++;
-                } else {
-                    int min_index = 2;
-                    float mn = a;
-                    for (int q = 0; q < 2; ++q)
-                        if (s.alt_lnp[q] < mn) { mn = s.alt_lnp[q]; min_index = q; }
-                    if (min_index < 2) {
-                        s.alt_indel[min_index] = job.tab[o].orig;
-                        s.alt_lnp[min_index] = a;
-                    }
+        for (const int oq : ortho[q]) {
+            const int o = to_eval[size_t(oq)];
+            double alt_score;
+            if (!info.find(int(q), true, oq, alt_score)) continue;
+            // ReadPathScores::insertAlt, IndelData.cpp:40-68: keep the two best
+            const float a = static_cast<float>(alt_score);
+            if (s.n_alt < 2) {
+                s.alt_indel[s.n_alt] = job.tab[o].orig;
+                s.alt_lnp[s.n_alt] = a;
+                s.n_alt++;
+            } else {
+                int min_index = 2;
+                float mn = a;
+                for (int qq = 0; qq < 2; ++qq)
+                    if (s.alt_lnp[qq] < mn) { mn = s.alt_lnp[qq]; min_index = qq; }
+                if (min_index < 2) {
+                    s.alt_indel[min_index] = job.tab[o].orig;
+                    s.alt_lnp[min_index] = a;
                 }
             }
         }
