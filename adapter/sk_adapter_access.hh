@@ -2,6 +2,8 @@
 // processors, and the per-process adapter state.  Included by the adapter's own translation units only.
 #pragma once
 
+#include <chrono>
+
 #include "sk_adapter.hh"
 #include "strelka_amd.h"
 
@@ -97,9 +99,19 @@ struct State
     SiteCache sites;
     SomaticSiteCache somaticSites;
     // counters reported at exit with $STRELKA_AMD_VERBOSE=1
+    // wall seconds inside the hooks (whole hook) and inside the C-ABI calls they make; reported with STRELKA_AMD_VERBOSE=1
+    double tRealignHook = 0, tRealignAbi = 0, tSiteHook = 0, tSiteAbi = 0;
     unsigned long realignDeviceEnumerated = 0, realignHostEnumerated = 0; // reads whose candidate alignments the device / the host listed
     unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0;
 };
 State& state();
+
+struct AccumTimer // adds its lifetime to `acc`
+{
+    double& acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit AccumTimer(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~AccumTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 }

@@ -17,9 +17,19 @@ static unsigned env_unsigned(const char* name, const unsigned def)
     return static_cast<unsigned>(std::strtoul(v, nullptr, 10));
 }
 
+// READ_BUFFER deferral.  Output identity with the reference is tested for windows up to 1000 positions on every data set of
+// tests/test_e2e_adapter.py; on the reference's demo BAMs it holds up to 1450 and breaks (three records) from 1500 on, for a
+// reason not yet understood -- so larger requests are refused rather than run in a regime that is known to differ.
+constexpr unsigned MAX_READ_WINDOW = 1024;
+
 unsigned read_buffer_defer()
 {
-    static const unsigned w(env_unsigned("STRELKA_AMD_READ_WINDOW", 256));
+    static const unsigned w([]() {
+        const unsigned v(env_unsigned("STRELKA_AMD_READ_WINDOW", 256));
+        if (v > MAX_READ_WINDOW)
+            throw blt_exception("strelka_amd adapter: STRELKA_AMD_READ_WINDOW above 1024 is not validated against the reference (see adapter/sk_adapter_common.cpp)");
+        return v;
+    }());
     return w;
 }
 
@@ -67,6 +77,8 @@ State& state()
                       << " indel_groups=" << s.indelGroups << " haplotypes=" << s.haplotypes << " read_window=" << read_buffer_defer()
                       << " site_window=" << post_align_defer() << " enum_device_reads=" << s.realignDeviceEnumerated
                       << " enum_host_instead=" << s.realignHostEnumerated << "\n";
+            std::cerr << "strelka_amd adapter seconds: realign_hook=" << s.tRealignHook << " realign_abi=" << s.tRealignAbi
+                      << " site_hook=" << s.tSiteHook << " site_abi=" << s.tSiteAbi << "\n";
         }
     };
     static Reporter r;

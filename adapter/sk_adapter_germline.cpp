@@ -115,6 +115,7 @@ void before_process_pos_variants(starling_pos_processor_base& pp, const pos_t po
     State& s(state());
     SiteCache& cache(s.sites);
     if (pos >= cache.begin && pos < cache.end) return;
+    AccumTimer hookTimer(s.tSiteHook);
 
     const unsigned sampleCount(Access::sampleCount(pp));
     const pos_t begin(pos), end(pos + static_cast<pos_t>(post_align_defer()) + 1);
@@ -150,7 +151,10 @@ void before_process_pos_variants(starling_pos_processor_base& pp, const pos_t po
     }
     if (slot.empty()) return;
     std::vector<sk_digt_call> out(slot.size());
-    genotypeLoci(opt, callOff, calls, refBase, ploidy, out.data());
+    {
+        AccumTimer abiTimer(s.tSiteAbi);
+        genotypeLoci(opt, callOff, calls, refBase, ploidy, out.data());
+    }
     for (size_t i(0); i < slot.size(); ++i)
     {
         cache.calls[slot[i]] = out[i];

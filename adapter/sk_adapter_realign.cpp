@@ -46,6 +46,7 @@ void toIndelKey(const IndelKey& k, const bool isCandidate, sk_indel_key& out)
 void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampleIndex, const pos_t begin, const pos_t end)
 {
     State& s(state());
+    AccumTimer hookTimer(s.tRealignHook);
     const starling_base_options& opt(Access::opt(pp));
     const unsigned sampleCount(Access::sampleCount(pp));
     starling_pos_processor_base::sample_info& sif(pp.sample(sampleIndex));
@@ -228,11 +229,14 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
         in.n_observed = static_cast<int32_t>(wr.observedCount);
         in.observed = wr.observedCount ? observed.data() + wr.observedOffset : nullptr;
     }
-    if (sk_realign_job_add_reads(job, inputs.data(), static_cast<int32_t>(inputs.size())) < 0)
     {
-        jobCheck(1, "sk_realign_job_add_reads");
+        AccumTimer abiTimer(s.tRealignAbi);
+        if (sk_realign_job_add_reads(job, inputs.data(), static_cast<int32_t>(inputs.size())) < 0)
+        {
+            jobCheck(1, "sk_realign_job_add_reads");
+        }
+        jobCheck(sk_realign_job_run(job), "sk_realign_job_run");
     }
-    jobCheck(sk_realign_job_run(job), "sk_realign_job_run");
     s.realignBatches++;
     s.realignReads += reads.size();
     {

@@ -128,6 +128,7 @@ void somatic_window(starling_pos_processor_base& pp, const pos_t pos)
     State& s(state());
     SomaticSiteCache& cache(s.somaticSites);
     if (pos >= cache.begin && pos < cache.end) return;
+    AccumTimer hookTimer(s.tSiteHook);
 
     using namespace STRELKA_SAMPLE_TYPE;
     const pos_t begin(pos), end(pos + static_cast<pos_t>(post_align_defer()) + 1);
@@ -175,7 +176,10 @@ void somatic_window(starling_pos_processor_base& pp, const pos_t pos)
         col[3] = col[1];
     }
     std::vector<sk_somatic_snv_genotype> out(slot.size());
-    callLoci(opt, col, refBase, forced, opt.is_somatic_callable(), out.data());
+    {
+        AccumTimer abiTimer(s.tSiteAbi);
+        callLoci(opt, col, refBase, forced, opt.is_somatic_callable(), out.data());
+    }
     for (size_t i(0); i < slot.size(); ++i)
     {
         cache.genotypes[slot[i]] = out[i];
