@@ -43,6 +43,17 @@ HOOKS = [
         ("read inserted",
          r'(        assert\(nullptr!=sread_ptr\);\n)',
          '\\1        sk_adapter::on_read_inserted(*this, sampleIndex, *sread_ptr);\n'),
+        # the active-region read buffer is a ring of 1000 positions (ActiveRegionReadBuffer.hh:61) that the reference clears as its
+        # READ_BUFFER stage passes; deferred along with that stage the clear would hit slots the head has already refilled
+        # (found as wrong output for read windows of 500 and of >= 1500 positions), so it stays at the undeferred distance:
+        # right after the HEAD stage of position pos, for position pos - (original READ_BUFFER distance), as stage_manager orders it
+        ("active-region read buffer clear, undeferred",
+         r'(            _getActiveRegionDetector\(\)\.updateEndPosition\(pos\);\n)',
+         '\\1            sk_adapter::clear_active_region_read_buffer_undeferred(*this, pos, get_read_buffer_size(get_largest_read_size(), '
+         'get_largest_total_indel_ref_span_per_read())+HAPLOTYPING_PADDING, _stagemanPtr->min_pos());\n'),
+        ("active-region read buffer clear, deferred copy removed",
+         r'(        write_reads\(pos\);\n\n        if \(is_active_region_detector_enabled\(\)\)\n        \{\n)            _getActiveRegionDetector\(\)\.clearReadBuffer\(pos\);\n',
+         '\\1            /* strelka_amd: cleared at the undeferred distance, see the HEAD stage */\n'),
         # site 1
         ("align_pos",
          r'(starling_pos_processor_base::\nalign_pos\(const pos_t pos\)\n\{\n)',

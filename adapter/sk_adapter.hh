@@ -77,6 +77,10 @@ void somatic_indel(const strelka_options& opt, const starling_sample_options& no
                    const IndelKey& indelKey, const IndelData& indelData, const unsigned normalSampleIndex,
                    const unsigned tumorSampleIndex, const bool isUseAltIndel, somatic_indel_call& sindel);
 
+/// ActiveRegionDetector::clearReadBuffer at the position the UNDEFERRED READ_BUFFER stage would be at while HEAD is at `headStagePos`
+void clear_active_region_read_buffer_undeferred(starling_pos_processor_base& pp, const pos_t headStagePos, const unsigned readBufferShift,
+                                                const pos_t minPos);
+
 // ---- site 7: ActiveRegionProcessor::discoverIndelsAndMismatches (ActiveRegionProcessor.cpp:572-705) ----
 bool discover_indels_and_mismatches(const std::string& haplotypeSeq, const std::string& refSegment,
                                     const reference_contig_segment& ref, const pos_t regionBegin, const pos_t regionEnd,

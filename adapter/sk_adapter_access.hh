@@ -34,6 +34,7 @@ struct Access
     static bool isPosReportable(const base_t& pp, const pos_t pos) { return pp.is_pos_reportable(pos); }
     static unsigned ploidy(const base_t& pp, const pos_t pos, const unsigned sampleIndex) { return pp.get_ploidy(pos, sampleIndex); }
     static bool isForcedOutputPos(const base_t& pp, const pos_t pos) { return pp.is_forced_output_pos(pos); }
+    static void clearActiveRegionReadBuffer(base_t& pp, const pos_t pos) { pp._getActiveRegionDetector().clearReadBuffer(pos); }
 };
 
 /// C-ABI status -> the reference's exception type (the context chain of starling_pos_processor_base.cpp:755-760 prints it)
@@ -65,6 +66,8 @@ struct GeometryShadow
     bool isAnyReadBufferPos = false;
     unsigned curReadBufferShift = 0, curIndelSpan = 0;
     std::deque<Params> segments;
+    pos_t activeRegionClearedTo = 0; ///< ActiveRegionDetector::clearReadBuffer has been called up to here (undeferred)
+    bool isAnyActiveRegionCleared = false;
     pos_t clearedToPos = 0;    ///< reads at buffer positions <= this have left the reference's read buffer (CLEAR_READ_BUFFER)
     bool isAnyCleared = false;
     std::vector<std::multiset<pos_t>> bufferedReadPos; ///< per sample: buffer positions of the reads the reference would still hold

@@ -17,25 +17,18 @@ static unsigned env_unsigned(const char* name, const unsigned def)
     return static_cast<unsigned>(std::strtoul(v, nullptr, 10));
 }
 
-// READ_BUFFER deferral.  Output identity with the reference is tested for windows up to 1000 positions on every data set of
-// tests/test_e2e_adapter.py; on the reference's demo BAMs it holds up to 1450 and breaks (three records) from 1500 on, for a
-// reason not yet understood -- so larger requests are refused rather than run in a regime that is known to differ.
-constexpr unsigned MAX_READ_WINDOW = 1024;
-
+// READ_BUFFER deferral in positions.  (What must NOT move with the stage is the clearing of the active-region read buffer, a ring
+// of 1000 positions: clear_active_region_read_buffer_undeferred below.  Before that was kept at its own distance, windows of 500
+// and of >= 1500 positions gave different output on the reference's demo data.)
 unsigned read_buffer_defer()
 {
-    static const unsigned w([]() {
-        const unsigned v(env_unsigned("STRELKA_AMD_READ_WINDOW", 256));
-        if (v > MAX_READ_WINDOW)
-            throw blt_exception("strelka_amd adapter: STRELKA_AMD_READ_WINDOW above 1024 is not validated against the reference (see adapter/sk_adapter_common.cpp)");
-        return v;
-    }());
+    static const unsigned w(env_unsigned("STRELKA_AMD_READ_WINDOW", 2048));
     return w;
 }
 
 unsigned post_align_defer()
 {
-    static const unsigned w(env_unsigned("STRELKA_AMD_SITE_WINDOW", 512));
+    static const unsigned w(env_unsigned("STRELKA_AMD_SITE_WINDOW", 4096));
     return w;
 }
 
@@ -90,6 +83,7 @@ State& state()
 void GeometryShadow::reset(const unsigned sampleCount)
 {
     isFirstPosSet = false;
+    isAnyActiveRegionCleared = false;
     maxPos = 0;
     lastReadBufferPos = 0;
     isAnyReadBufferPos = false;
@@ -193,6 +187,20 @@ void on_set_head_pos(starling_pos_processor_base& /*pp*/, const pos_t pos, const
     {
         while (g.segments.size() > 1 && g.segments.front().upto < s.realignedTo) g.segments.pop_front();
     }
+}
+
+void clear_active_region_read_buffer_undeferred(starling_pos_processor_base& pp, const pos_t headStagePos, const unsigned readBufferShift,
+                                                const pos_t minPos)
+{
+    // stage_manager::process_pos (L/blt_util/stage_manager.cpp:283-316): READ_BUFFER runs for headStagePos - shift unless that is
+    // before the first position; after a revision of the stage distances a stage resumes where it had got to (never twice)
+    GeometryShadow& g(state().geometry);
+    const pos_t p(headStagePos - static_cast<pos_t>(readBufferShift));
+    if (p < minPos) return;
+    if (g.isAnyActiveRegionCleared && p <= g.activeRegionClearedTo) return;
+    Access::clearActiveRegionReadBuffer(pp, p);
+    g.activeRegionClearedTo = p;
+    g.isAnyActiveRegionCleared = true;
 }
 
 unsigned buffered_read_count(const starling_pos_processor_base& /*pp*/, const unsigned sampleIndex, const unsigned /*actualCount*/)

@@ -10,6 +10,8 @@
 // (starling_read_align_score_indels.cpp:1071) and the suboverlap read-id sets (:616-626).
 #include "sk_adapter_access.hh"
 
+#include <cstdlib>
+
 #include "blt_util/log.hh"
 #include "starling_common/alignment_util.hh"
 #include "starling_common/starling_read_segment.hh"

@@ -48,11 +48,13 @@ def _germline(variant, tmp_path, windows=None, extra_env=None):
 
 
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
-@pytest.mark.parametrize("windows", [None, (0, 0), (1, 1), (7, 13), (1000, 3000)])
+@pytest.mark.parametrize("windows", [None, (0, 0), (1, 1), (7, 13), (256, 512), (500, 512), (1000, 3000), (1500, 100), (5000, 8000)])
 def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
     c = _germline("dbl", tmp_path, windows)
     if windows == (1000, 3000):
         assert c["realign_jobs"] <= 10 and c["site_batches"] <= 2
+    if windows is None:
+        assert c["read_window"] == 2048 and c["site_window"] == 4096
 
 
 @pytest.mark.gpu
@@ -96,7 +98,7 @@ def _somatic(variant, tmp_path, windows=None, callable_regions=False):
 
 
 @pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
-@pytest.mark.parametrize("windows,callable_regions", [(None, False), ((0, 0), False), ((5, 9), True), ((1000, 3000), True)])
+@pytest.mark.parametrize("windows,callable_regions", [(None, False), ((0, 0), False), ((5, 9), True), ((256, 512), False), ((500, 700), True), ((1000, 3000), True), ((3000, 5000), True)])
 def test_somatic_demo_identical_through_adapter_cpu_double(tmp_path, windows, callable_regions):
     _somatic("dbl", tmp_path, windows, callable_regions)
 
@@ -156,8 +158,9 @@ def _synth(variant, tmp_path, which, windows=None, extra_env=None):
 
 
 @pytest.mark.skipif(not (E.have("starling2_dbl", "strelka2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic inputs not built")
-@pytest.mark.parametrize("which,windows", [("short_reads", None), ("short_reads", (3, 5)), ("short_reads", (1000, 3000)),
-                                           ("long_reads", None), ("long_reads", (64, 64))])
+@pytest.mark.parametrize("which,windows", [("short_reads", None), ("short_reads", (3, 5)), ("short_reads", (256, 512)), ("short_reads", (500, 500)),
+                                           ("short_reads", (1000, 3000)), ("short_reads", (1500, 2500)), ("short_reads", (6000, 9000)),
+                                           ("long_reads", None), ("long_reads", (64, 64)), ("long_reads", (500, 900)), ("long_reads", (3000, 3000))])
 def test_synthetic_identical_through_adapter_cpu_double(tmp_path, which, windows):
     _synth("dbl", tmp_path, which, windows)
 
