@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=1 << 20, help="reads per step per GPU (x64 candidates x150 bp)")
     ap.add_argument("--loci", type=int, default=1 << 26, help="germline loci per step per GPU (depth ~Poisson(40)); 2^26 ~ chr20")
+    ap.add_argument("--feed-blocks", type=int, default=1 << 17, help="BGZF blocks per step of the feed leg (8f rank 4)")
     ap.add_argument("--realign-reads", type=int, default=1 << 16, help="reads per step of the whole-read leg (a1-a7)")
     ap.add_argument("--cpu-seconds-per-leg", type=float, default=5.0, help="seconds each CPU-baseline leg runs (all cores in parallel)")
     ap.add_argument("--unique-reads", type=int, default=1 << 14, help="distinct synthetic reads (tiled on device)")
@@ -265,6 +266,18 @@ def main():
     ga_alg_bytes = dga.nq + dga.nr + 72 * dga.n  # sequences in, score / begin / ~8 path segments out per problem
     del dga
 
+    # ---- next row f4, the feed: BGZF inflation (the committed fixture BAM tiled on the device) ----
+    fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "feed_tiny.bam")
+    with open(fixture, "rb") as f:
+        bgzf_image = np.frombuffer(f.read(), np.uint8)
+    n_fix_blocks = len(capi.bgzf_scan(bgzf_image)[0]) - 1
+    dfeed = device.DeviceBgzfBatch(bgzf_image, dev, tile=max(1, args.feed_blocks // n_fix_blocks))
+    dt_f, feed_bytes, kms_f = timed(lambda: dfeed.inflate(), max(2, args.steps // 4), 1, dfeed.out_bytes)
+    assert int(dfeed.status.abs().sum().item()) == 0, "BGZF inflation reported a malformed block"
+    feed_alg_bytes = dfeed.in_bytes + dfeed.out_bytes
+    feed_blocks = dfeed.n_blocks
+    del dfeed
+
     # ---- rows a1-a7: the whole read path as the adapter drives it (host stages + kernel), one host thread ----
     wr = {}
     for name, kw in (("", dict(enumeration=2)), ("_host_enumeration", dict(enumeration=0)),
@@ -322,6 +335,8 @@ def main():
         "realign_note": "whole read path (rows a1-a7) through sk_realign_job_add_reads + _run, one host thread, host buffers in and out; "
                         "realign_* = candidate alignments listed, flattened and scored on the device (enumeration=2), *_host_enumeration = "
                         "listed and flattened on the host (round 1's path), *_dense = scenarios with up to 14 indels around a read",
+        "feed_inflated_bytes_per_s": feed_bytes / dt_f, "feed_ms_per_step": dt_f / max(2, args.steps // 4) * 1e3, "feed_bgzf_blocks_per_step": feed_blocks,
+        "roofline_feed": roof("bgzf_inflate_kernel+bgzf_crc32_kernel", feed_alg_bytes, kms_f, None),
         "global_align_cells_per_s": ga_cells / dt_ga, "global_align_ms_per_step": dt_ga / args.steps * 1e3,
         "global_align_problems_per_step": n_ga,
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",

@@ -771,6 +771,53 @@ int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* host_batch, con
 int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* dev_batch, const sk_indel_options* opt,
                                         sk_allele_group_call* dev_out, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * SURVEY.md section 8f rank 4, the feed: BGZF inflation and BAM record decoding.
+ *
+ * Replaces what htslib (redist/htslib-1.7-6-g6d2bfb7: bgzf.c bgzf_read_block :641 / inflate_block :472, sam.c bam_read1) does
+ * behind L/htsapi/bam_streamer.cpp:268 (sam_itr_next) and L/htsapi/bam_record.hh's accessors: a file image goes in, per-record
+ * fields, BAM base codes (one per byte, as sk_read_input.read_code takes them), qualities and ALIGNPATH path segments come out.
+ * Finding the blocks / records is a chain walk on the host (sk_bgzf_scan, sk_bam_scan_records); the bytes are inflated (DEFLATE,
+ * RFC 1951; CRC-32 and ISIZE of every block checked) and decoded by kernels (csrc/bam_feed.hip).
+ * Not built: the index (.bai) lookup, CRAM, normalizeAlignment, the gVCF writer.
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+/** The BGZF blocks of a file image (or of any run of whole blocks): block_off[i] = start of block i, out_off[i] = where its inflated
+ *  bytes belong in the concatenated stream; both arrays hold max_blocks + 1 entries, the last one written is the end.  Returns the
+ *  number of blocks (may exceed max_blocks: call again with larger arrays), -1 on a malformed block header. */
+int64_t sk_bgzf_scan(const uint8_t* data, int64_t n_bytes, int64_t* block_off, int64_t* out_off, int32_t max_blocks);
+/** Inflate blocks [0, n_blocks) (offsets as sk_bgzf_scan gives them) into out[out_off[n_blocks]]. */
+int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks, uint8_t* out);
+/** block_off relative to dev_data; dev_status[n_blocks]: 0 = ok (else the block is malformed, see csrc/bam_feed.hip) */
+int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, const int64_t* dev_out_off, int32_t n_blocks,
+                        uint8_t* dev_out, int32_t* dev_status, void* hip_stream);
+
+typedef struct sk_bam_record { /* bam1_core_t as L/htsapi/bam_record.hh exposes it */
+    int32_t ref_id;        /* target_id() */
+    int32_t pos;           /* pos() - 1 (0-based, as stored) */
+    int32_t mate_ref_id, mate_pos, template_size;
+    int32_t l_seq;         /* read_size() */
+    int32_t n_cigar;       /* n_cigar() */
+    uint16_t flag;
+    uint8_t mapq;          /* map_qual() */
+    uint8_t is_fwd_strand; /* is_fwd_strand() */
+    uint32_t pad;
+} sk_bam_record;
+
+/** Offset of the first record of an inflated BAM stream (after magic, header text and the reference table); -1 = not BAM. */
+int64_t sk_bam_header_end(const uint8_t* stream, int64_t stream_len);
+/** The records of stream[first, stream_len): rec_off[i] = offset of record i, read_off / path_off = CSR offsets of its bases and
+ *  CIGAR operations (arrays of max_records + 1).  A record cut by the end of the stream is not counted.  Returns the number of
+ *  records (may exceed max_records), -1 on a malformed record. */
+int64_t sk_bam_scan_records(const uint8_t* stream, int64_t stream_len, int64_t first, int64_t* rec_off, int64_t* read_off,
+                            int64_t* path_off, int32_t max_records);
+/** Decode n_records records: fixed fields, read_code (BAM 4-bit codes, one per byte), read_qual, path (sk_path_seg, type = BAM op + 1). */
+int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
+                  const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path);
+int sk_bam_decode_dev(const uint8_t* dev_stream, const int64_t* dev_rec_off, int32_t n_records, const int64_t* dev_read_off,
+                      const int64_t* dev_path_off, sk_bam_record* dev_rec, uint8_t* dev_read_code, uint8_t* dev_read_qual,
+                      sk_path_seg* dev_path, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

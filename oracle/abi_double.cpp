@@ -314,3 +314,76 @@ extern "C" int sk_enum_device_run(const SkEnumInput*, SkEnumOutput*)
 {
     return sk_fail("candidate enumeration on the device (sk_realign_options.enumeration = 2) needs the GPU library");
 }
+
+// ---- the feed: zlib and plain loops stand behind the two kernel-backed entries --------------------------------
+#include <zlib.h>
+
+extern "C" int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks, uint8_t* out)
+{
+    if (n_blocks < 0 || (n_blocks > 0 && (!data || !block_off || !out_off || !out))) return sk_fail("sk_bgzf_inflate: bad argument");
+    for (int32_t b = 0; b < n_blocks; ++b) {
+        const uint8_t* blk = data + block_off[b];
+        const int64_t blen = block_off[b + 1] - block_off[b];
+        if (blen < 28 || blk[0] != 31 || blk[1] != 139) return sk_fail("sk_bgzf_inflate: block " + std::to_string(b) + ": not a BGZF block");
+        const int xlen = int(blk[10]) | (int(blk[11]) << 8);
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        zs.next_in = const_cast<Bytef*>(blk + 12 + xlen);
+        zs.avail_in = uInt(blen - 12 - xlen - 8);
+        zs.next_out = out + out_off[b];
+        zs.avail_out = uInt(out_off[b + 1] - out_off[b]);
+        if (inflateInit2(&zs, -15) != Z_OK) return sk_fail("sk_bgzf_inflate: inflateInit2");
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zs.avail_out != 0) return sk_fail("sk_bgzf_inflate: block " + std::to_string(b) + ": invalid deflate data");
+        const uint8_t* t = blk + blen - 8;
+        const uint32_t want = uint32_t(t[0]) | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
+        if (uint32_t(crc32(crc32(0L, nullptr, 0), out + out_off[b], uInt(out_off[b + 1] - out_off[b]))) != want)
+            return sk_fail("sk_bgzf_inflate: block " + std::to_string(b) + ": CRC-32 mismatch");
+    }
+    return 0;
+}
+extern "C" int sk_bgzf_inflate_dev(const uint8_t*, const int64_t*, const int64_t*, int32_t, uint8_t*, int32_t*, void*)
+{
+    return sk_fail("sk_bgzf_inflate_dev needs the GPU library");
+}
+extern "C" int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
+                             const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path)
+{
+    if (n_records < 0 || stream_len < 0 || (n_records > 0 && (!stream || !rec_off || !read_off || !path_off || !rec || !read_code || !read_qual || !path)))
+        return sk_fail("sk_bam_decode: bad argument");
+    auto le32 = [](const uint8_t* p) { return int32_t(uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24)); };
+    for (int32_t r = 0; r < n_records; ++r) {
+        const uint8_t* p = stream + rec_off[r];
+        sk_bam_record o;
+        std::memset(&o, 0, sizeof(o));
+        o.ref_id = le32(p + 4);
+        o.pos = le32(p + 8);
+        const int l_read_name = p[12];
+        o.mapq = p[13];
+        o.n_cigar = int(p[16]) | (int(p[17]) << 8);
+        o.flag = uint16_t(unsigned(p[18]) | (unsigned(p[19]) << 8));
+        o.l_seq = le32(p + 20);
+        o.mate_ref_id = le32(p + 24);
+        o.mate_pos = le32(p + 28);
+        o.template_size = le32(p + 32);
+        o.is_fwd_strand = (o.flag & 0x10u) ? 0 : 1;
+        rec[r] = o;
+        const uint8_t* cig = p + 36 + l_read_name;
+        for (int i = 0; i < o.n_cigar; ++i) {
+            const uint32_t c = uint32_t(le32(cig + 4 * i));
+            path[path_off[r] + i] = sk_path_seg{ (c & 15u) + 1u, c >> 4 };
+        }
+        const uint8_t* seq = cig + 4 * o.n_cigar;
+        const uint8_t* qual = seq + (o.l_seq + 1) / 2;
+        for (int32_t i = 0; i < o.l_seq; ++i) {
+            read_code[read_off[r] + i] = (i & 1) ? uint8_t(seq[i >> 1] & 15u) : uint8_t(seq[i >> 1] >> 4);
+            read_qual[read_off[r] + i] = qual[i];
+        }
+    }
+    return 0;
+}
+extern "C" int sk_bam_decode_dev(const uint8_t*, const int64_t*, int32_t, const int64_t*, const int64_t*, sk_bam_record*, uint8_t*, uint8_t*, sk_path_seg*, void*)
+{
+    return sk_fail("sk_bam_decode_dev needs the GPU library");
+}

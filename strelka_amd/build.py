@@ -23,11 +23,13 @@ HIP_SOURCES = [
     "csrc/pileup.hip",
     "csrc/global_align.hip",
     "csrc/read_enumerate.hip",
+    "csrc/bam_feed.hip",
 ]
 HOST_SOURCES = [
     "host/align_flatten.cpp",
     "host/read_realign.cpp",
     "host/active_region.cpp",
+    "host/bam_feed.cpp",
 ]
 
 

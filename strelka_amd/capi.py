@@ -182,6 +182,7 @@ assert DIGT_CALL_DTYPE.itemsize == 144 and SOMATIC_CALL_DTYPE.itemsize == 272
 EXPORTS = [
     "sk_init", "sk_init_strict", "sk_check_device_errors", "sk_debug_force_device_libm", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_libm_restated", "sk_get_qscore_tables",
     "sk_score_alignments", "sk_score_alignments_dev", "sk_align_evmask_words", "sk_align_prepare", "sk_align_colmat_words", "sk_align_prepare_cols",
+    "sk_bgzf_scan", "sk_bgzf_inflate", "sk_bgzf_inflate_dev", "sk_bam_header_end", "sk_bam_scan_records", "sk_bam_decode", "sk_bam_decode_dev",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_append", "sk_align_builder_add_read",
     "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
@@ -258,6 +259,16 @@ def lib():
                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.sk_score_alignments.argtypes = [C.POINTER(AlignBatch), c_void_p]
         L.sk_align_evmask_words.argtypes = [C.c_int32]
+        L.sk_bgzf_scan.restype = C.c_int64
+        L.sk_bgzf_scan.argtypes = [c_void_p, C.c_int64, c_void_p, c_void_p, C.c_int32]
+        L.sk_bgzf_inflate.argtypes = [c_void_p, c_void_p, c_void_p, C.c_int32, c_void_p]
+        L.sk_bgzf_inflate_dev.argtypes = [c_void_p, c_void_p, c_void_p, C.c_int32, c_void_p, c_void_p, c_void_p]
+        L.sk_bam_header_end.restype = C.c_int64
+        L.sk_bam_header_end.argtypes = [c_void_p, C.c_int64]
+        L.sk_bam_scan_records.restype = C.c_int64
+        L.sk_bam_scan_records.argtypes = [c_void_p, C.c_int64, C.c_int64, c_void_p, c_void_p, c_void_p, C.c_int32]
+        L.sk_bam_decode.argtypes = [c_void_p, C.c_int64, c_void_p, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.sk_bam_decode_dev.argtypes = [c_void_p, c_void_p, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.sk_align_colmat_words.restype = C.c_int64
         L.sk_align_colmat_words.argtypes = [c_void_p]
         L.sk_align_prepare_cols.argtypes = [c_void_p] * 4
@@ -295,6 +306,10 @@ class StrelkaAmdError(RuntimeError):
 def _check(rc):
     if rc != 0:
         raise StrelkaAmdError(lib().sk_last_error().decode("utf-8", "replace"))
+
+
+def last_error():
+    return lib().sk_last_error().decode("utf-8", "replace")
 
 
 def init(device=0):
@@ -978,3 +993,60 @@ def discover_indels_and_mismatches(ref_seq, ref_offset, ar_begin, ar_end, prev_a
     raw = ins.raw
     return [(out[i].pos, out[i].type, out[i].del_len, raw[out[i].ins_off:out[i].ins_off + out[i].ins_len].decode())
             for i in range(n.value)], ni.value
+
+
+# ---- the feed: BGZF inflation and BAM record decoding ------------------------------------------------------------
+
+BAM_RECORD_DTYPE = np.dtype([("ref_id", "<i4"), ("pos", "<i4"), ("mate_ref_id", "<i4"), ("mate_pos", "<i4"), ("template_size", "<i4"),
+                             ("l_seq", "<i4"), ("n_cigar", "<i4"), ("flag", "<u2"), ("mapq", "u1"), ("is_fwd_strand", "u1"), ("pad", "<u4")])
+PATH_SEG_DTYPE = np.dtype([("type", "<u4"), ("length", "<u4")])
+
+
+def bgzf_scan(data):
+    """data: uint8 array of whole BGZF blocks -> (block_off[n+1], out_off[n+1])"""
+    data = np.ascontiguousarray(data, np.uint8)
+    n = lib().sk_bgzf_scan(_p(data), len(data), None, None, 0)
+    if n < 0:
+        raise StrelkaAmdError("sk_bgzf_scan: malformed BGZF block header")
+    block_off, out_off = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+    if lib().sk_bgzf_scan(_p(data), len(data), _p(block_off), _p(out_off), n) != n:
+        raise StrelkaAmdError("sk_bgzf_scan failed")
+    return block_off, out_off
+
+
+def bgzf_inflate(data):
+    """the inflated stream of a BGZF file image (kernel-backed; CRC-32 and ISIZE of every block checked)"""
+    data = np.ascontiguousarray(data, np.uint8)
+    block_off, out_off = bgzf_scan(data)
+    out = np.zeros(int(out_off[-1]), np.uint8)
+    _check(lib().sk_bgzf_inflate(_p(data), _p(block_off), _p(out_off), len(block_off) - 1, _p(out)))
+    return out
+
+
+def bam_scan_records(stream, first=None):
+    stream = np.ascontiguousarray(stream, np.uint8)
+    if first is None:
+        first = lib().sk_bam_header_end(_p(stream), len(stream))
+        if first < 0:
+            raise StrelkaAmdError("sk_bam_header_end: not a BAM stream")
+    n = lib().sk_bam_scan_records(_p(stream), len(stream), first, None, None, None, 0)
+    if n < 0:
+        raise StrelkaAmdError("sk_bam_scan_records: malformed record")
+    rec_off, read_off, path_off = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+    if lib().sk_bam_scan_records(_p(stream), len(stream), first, _p(rec_off), _p(read_off), _p(path_off), n) != n:
+        raise StrelkaAmdError("sk_bam_scan_records failed")
+    return rec_off[:n].copy(), read_off, path_off
+
+
+def bam_decode(stream, first=None):
+    """-> dict(rec[BAM_RECORD_DTYPE], read_off, read_code, read_qual, path_off, path[PATH_SEG_DTYPE]) of every whole record"""
+    stream = np.ascontiguousarray(stream, np.uint8)
+    rec_off, read_off, path_off = bam_scan_records(stream, first)
+    n = len(rec_off)
+    rec = np.zeros(n, BAM_RECORD_DTYPE)
+    code = np.zeros(max(int(read_off[-1]), 1), np.uint8)
+    qual = np.zeros(max(int(read_off[-1]), 1), np.uint8)
+    path = np.zeros(max(int(path_off[-1]), 1), PATH_SEG_DTYPE)
+    _check(lib().sk_bam_decode(_p(stream), len(stream), _p(rec_off), n, _p(read_off), _p(path_off), _p(rec), _p(code), _p(qual), _p(path)))
+    return dict(rec=rec, rec_off=rec_off, read_off=read_off, read_code=code[:int(read_off[-1])], read_qual=qual[:int(read_off[-1])],
+                path_off=path_off, path=path[:int(path_off[-1])])

@@ -1,0 +1,468 @@
+// bam_feed.hip -- SURVEY.md section 8f rank 4, the feed: BGZF block inflation and BAM record decoding on the device.
+//
+// In the reference this work is a third-party dependency: L/htsapi/bam_streamer.cpp:268 calls htslib's sam_itr_next
+// (redist/htslib-1.7-6-g6d2bfb7), which inflates BGZF blocks with zlib (bgzf.c:441-493: raw DEFLATE, window 15, then CRC-32 and
+// ISIZE of the block trailer) and parses BAM records (sam.c bam_read1).  The algorithms restated here are the published ones:
+// DEFLATE (RFC 1951), the BGZF container and the BAM record layout (SAM specification v1, sections 4.1 and 4.2).  Parity is
+// anchored on zlib / samtools output for the reference's own demo BAMs and synthetic ones (tests/test_bam_feed.py).
+//
+//   B1  bgzf_inflate_kernel   one THREAD per BGZF block (blocks are independent DEFLATE streams of at most 64 KiB of output, a BAM
+//                             of a few GB is 10^5 blocks): canonical-Huffman decoding with per-thread code tables, LZ77 copies
+//                             inside the thread's own output range.  A serial bit stream per block is what the format is; the
+//                             parallelism is across blocks.
+//   B2  bgzf_crc32_kernel     one thread per block: CRC-32 (IEEE 802.3, table in LDS) of the inflated bytes against the trailer
+//   B3  bam_decode_kernel     one thread per BAM record: fixed fields, CIGAR -> path segments (ALIGNPATH::align_t = BAM op + 1),
+//                             4-bit packed bases -> one BAM code per byte (what sk_read_input.read_code takes), qualities
+//
+// Byte work, bound by the serial decode per block rather than by HBM; algorithmic bytes = compressed in + inflated out.
+
+#include "sk_common.h"
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace
+{
+
+enum { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3, INF_BAD_DISTANCE = 4, INF_OUT_OVERFLOW = 5,
+       INF_IN_OVERRUN = 6, INF_BAD_LENGTHS = 7, INF_SIZE_MISMATCH = 8, INF_BAD_HEADER = 9, INF_CRC_MISMATCH = 10 };
+
+struct BitReader
+{
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t buf;
+    int cnt;
+    bool overrun;
+    __device__ void fill(const int need)
+    {
+        while (cnt < need) {
+            uint64_t b = 0;
+            if (p < end) b = *p++;
+            else overrun = true;
+            buf |= b << cnt;
+            cnt += 8;
+        }
+    }
+    __device__ unsigned bits(const int n) // n <= 16
+    {
+        if (n == 0) return 0;
+        fill(n);
+        const unsigned v = unsigned(buf & ((1ull << n) - 1ull));
+        buf >>= n;
+        cnt -= n;
+        return v;
+    }
+};
+
+// canonical Huffman code (RFC 1951 3.2.2): count[len] codes of each length, symbols ordered by (length, value).
+// (Tried: a 9-bit first-level lookup table per code, 32-bit refills of the bit buffer and LZ77 copies in 8-byte pieces.  All
+// three put more per-thread state into scratch memory and the kernel got 25 % SLOWER: a thread's time is a chain of dependent
+// accesses to its private tables, its input and its own output, and what pays is more blocks in flight, not fewer bit steps.)
+struct Huffman
+{
+    short* count;  // [16]
+    short* symbol; // [n]
+};
+
+// returns the number of codes left unused (0 = complete, < 0 = over-subscribed), as zlib's / puff's construct
+__device__ int huff_construct(Huffman& h, const short* length, const int n)
+{
+    for (int len = 0; len <= 15; ++len) h.count[len] = 0;
+    for (int s = 0; s < n; ++s) h.count[length[s]]++;
+    if (h.count[0] == n) return 0;
+    int left = 1;
+    for (int len = 1; len <= 15; ++len) {
+        left <<= 1;
+        left -= h.count[len];
+        if (left < 0) return left;
+    }
+    short offs[16];
+    offs[1] = 0;
+    for (int len = 1; len < 15; ++len) offs[len + 1] = short(offs[len] + h.count[len]);
+    for (int s = 0; s < n; ++s)
+        if (length[s] != 0) h.symbol[offs[length[s]]++] = short(s);
+    return left;
+}
+
+__device__ int huff_decode(BitReader& br, const Huffman& h)
+{
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code |= int(br.bits(1));
+        const int count = h.count[len];
+        if (code - count < first) return h.symbol[index + (code - first)];
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+__device__ const short LEN_BASE[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+__device__ const short LEN_EXTRA[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+__device__ const short DIST_BASE[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+__device__ const short DIST_EXTRA[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+__device__ const unsigned char CLEN_ORDER[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+
+struct InflateArgs
+{
+    const uint8_t* data;      // the compressed file bytes (device)
+    const int64_t* block_off; // [n_blocks+1] start of each BGZF block (its 18-byte header)
+    const int64_t* out_off;   // [n_blocks+1] where each block's inflated bytes go
+    uint8_t* out;
+    int32_t* status;          // [n_blocks]
+    int32_t n_blocks;
+};
+
+__device__ int inflate_codes(BitReader& br, uint8_t* out, int64_t& pos, const int64_t cap, const Huffman& lencode, const Huffman& distcode)
+{
+    for (;;) {
+        int sym = huff_decode(br, lencode);
+        if (sym < 0) return INF_BAD_CODE;
+        if (br.overrun) return INF_IN_OVERRUN;
+        if (sym < 256) {
+            if (pos >= cap) return INF_OUT_OVERFLOW;
+            out[pos++] = uint8_t(sym);
+        } else if (sym == 256) {
+            return INF_OK;
+        } else {
+            sym -= 257;
+            if (sym >= 29) return INF_BAD_CODE;
+            const int len = LEN_BASE[sym] + int(br.bits(LEN_EXTRA[sym]));
+            const int ds = huff_decode(br, distcode);
+            if (ds < 0 || ds >= 30) return INF_BAD_CODE;
+            const int64_t dist = DIST_BASE[ds] + int(br.bits(DIST_EXTRA[ds]));
+            if (dist > pos) return INF_BAD_DISTANCE; // (a BGZF block has no preset dictionary)
+            if (pos + len > cap) return INF_OUT_OVERFLOW;
+            for (int i = 0; i < len; ++i, ++pos) out[pos] = out[pos - dist];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void bgzf_inflate_kernel(const InflateArgs a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.n_blocks) return;
+    const uint8_t* blk = a.data + a.block_off[b];
+    const int64_t blen = a.block_off[b + 1] - a.block_off[b];
+    // gzip member header with the BGZF extra field (SAM spec 4.1): ID1 ID2 CM FLG(=4) MTIME XFL OS XLEN(=6) 'B' 'C' 2 BSIZE
+    if (blen < 28 || blk[0] != 31 || blk[1] != 139 || blk[2] != 8 || !(blk[3] & 4)) {
+        a.status[b] = INF_BAD_HEADER;
+        return;
+    }
+    const int xlen = int(blk[10]) | (int(blk[11]) << 8);
+    const uint8_t* cdata = blk + 12 + xlen;
+    const uint8_t* cend = blk + blen - 8;
+    if (cdata > cend) {
+        a.status[b] = INF_BAD_HEADER;
+        return;
+    }
+    const uint32_t isize = uint32_t(cend[4]) | (uint32_t(cend[5]) << 8) | (uint32_t(cend[6]) << 16) | (uint32_t(cend[7]) << 24);
+    uint8_t* out = a.out + a.out_off[b];
+    const int64_t cap = a.out_off[b + 1] - a.out_off[b];
+    int64_t pos = 0;
+
+    BitReader br;
+    br.p = cdata;
+    br.end = cend;
+    br.buf = 0;
+    br.cnt = 0;
+    br.overrun = false;
+    short lencnt[16], lensym[288], distcnt[16], distsym[30];
+    short lengths[320];
+    Huffman lencode{ lencnt, lensym }, distcode{ distcnt, distsym };
+    int err = INF_OK, last = 0;
+    do {
+        last = int(br.bits(1));
+        const int type = int(br.bits(2));
+        if (type == 0) { // stored
+            br.buf = 0;
+            br.cnt = 0; // (discard the rest of the byte: the buffer never holds more than the current one past a read)
+            if (br.p + 4 > br.end) { err = INF_BAD_STORED; break; }
+            const unsigned len = unsigned(br.p[0]) | (unsigned(br.p[1]) << 8);
+            const unsigned nlen = unsigned(br.p[2]) | (unsigned(br.p[3]) << 8);
+            br.p += 4;
+            if (len != (~nlen & 0xffffu) || br.p + len > br.end) { err = INF_BAD_STORED; break; }
+            if (pos + int64_t(len) > cap) { err = INF_OUT_OVERFLOW; break; }
+            for (unsigned i = 0; i < len; ++i) out[pos++] = *br.p++;
+        } else if (type == 1) { // fixed codes (3.2.6)
+            int s = 0;
+            for (; s < 144; ++s) lengths[s] = 8;
+            for (; s < 256; ++s) lengths[s] = 9;
+            for (; s < 280; ++s) lengths[s] = 7;
+            for (; s < 288; ++s) lengths[s] = 8;
+            huff_construct(lencode, lengths, 288);
+            for (s = 0; s < 30; ++s) lengths[s] = 5;
+            huff_construct(distcode, lengths, 30);
+            err = inflate_codes(br, out, pos, cap, lencode, distcode);
+        } else if (type == 2) { // dynamic codes (3.2.7)
+            const int nlen = int(br.bits(5)) + 257, ndist = int(br.bits(5)) + 1, ncode = int(br.bits(4)) + 4;
+            if (nlen > 286 || ndist > 30) { err = INF_BAD_LENGTHS; break; }
+            int idx = 0;
+            for (; idx < ncode; ++idx) lengths[CLEN_ORDER[idx]] = short(br.bits(3));
+            for (; idx < 19; ++idx) lengths[CLEN_ORDER[idx]] = 0;
+            if (huff_construct(lencode, lengths, 19) != 0) { err = INF_BAD_LENGTHS; break; } // (the code-length code must be complete)
+            idx = 0;
+            while (idx < nlen + ndist) {
+                int sym = huff_decode(br, lencode);
+                if (sym < 0) { err = INF_BAD_CODE; break; }
+                if (sym < 16) {
+                    lengths[idx++] = short(sym);
+                } else {
+                    int len = 0, rep;
+                    if (sym == 16) {
+                        if (idx == 0) { err = INF_BAD_LENGTHS; break; }
+                        len = lengths[idx - 1];
+                        rep = 3 + int(br.bits(2));
+                    } else if (sym == 17) {
+                        rep = 3 + int(br.bits(3));
+                    } else {
+                        rep = 11 + int(br.bits(7));
+                    }
+                    if (idx + rep > nlen + ndist) { err = INF_BAD_LENGTHS; break; }
+                    while (rep--) lengths[idx++] = short(len);
+                }
+            }
+            if (err != INF_OK) break;
+            if (lengths[256] == 0) { err = INF_BAD_LENGTHS; break; }
+            int left = huff_construct(lencode, lengths, nlen);
+            if (left != 0 && (left < 0 || nlen != lencode.count[0] + lencode.count[1])) { err = INF_BAD_LENGTHS; break; } // (incomplete only as one 1-bit code)
+            left = huff_construct(distcode, lengths + nlen, ndist);
+            if (left != 0 && (left < 0 || ndist != distcode.count[0] + distcode.count[1])) { err = INF_BAD_LENGTHS; break; }
+            err = inflate_codes(br, out, pos, cap, lencode, distcode);
+        } else {
+            err = INF_BAD_BLOCK_TYPE;
+        }
+        if (br.overrun && err == INF_OK) err = INF_IN_OVERRUN;
+    } while (err == INF_OK && !last);
+    if (err == INF_OK && (pos != cap || uint32_t(pos) != isize)) err = INF_SIZE_MISMATCH;
+    a.status[b] = err;
+}
+
+__global__ __launch_bounds__(64) void bgzf_crc32_kernel(const InflateArgs a)
+{
+    __shared__ uint32_t table[256];
+    for (int i = threadIdx.x; i < 256; i += 64) {
+        uint32_t c = uint32_t(i);
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
+        table[i] = c;
+    }
+    __syncthreads();
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.n_blocks || a.status[b] != INF_OK) return;
+    const uint8_t* out = a.out + a.out_off[b];
+    const int64_t n = a.out_off[b + 1] - a.out_off[b];
+    uint32_t c = 0xffffffffu;
+    for (int64_t i = 0; i < n; ++i) c = table[(c ^ out[i]) & 0xffu] ^ (c >> 8);
+    c ^= 0xffffffffu;
+    const uint8_t* t = a.data + a.block_off[b + 1] - 8;
+    const uint32_t want = uint32_t(t[0]) | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
+    if (c != want) a.status[b] = INF_CRC_MISMATCH;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BAM records (SAM spec 4.2): block_size, refID, pos, l_read_name, mapq, bin, n_cigar_op, flag, l_seq, next_refID, next_pos, tlen,
+// read_name, cigar[n_cigar_op] (len << 4 | op), seq[(l_seq+1)/2] (4 bits per base, high nibble first), qual[l_seq]
+
+struct DecodeArgs
+{
+    const uint8_t* stream;   // inflated BAM bytes (device)
+    const int64_t* rec_off;  // [n_records] offset of each record's block_size field
+    int32_t n_records;
+    const int64_t* read_off; // [n_records+1] into read_code / read_qual
+    const int64_t* path_off; // [n_records+1] into path
+    sk_bam_record* rec;      // [n_records]
+    uint8_t* read_code;
+    uint8_t* read_qual;
+    sk_path_seg* path;
+};
+
+__device__ __forceinline__ int32_t le32(const uint8_t* p) { return int32_t(uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24)); }
+
+__global__ __launch_bounds__(64) void bam_decode_kernel(const DecodeArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_records) return;
+    const uint8_t* p = a.stream + a.rec_off[r];
+    sk_bam_record o;
+    o.ref_id = le32(p + 4);
+    o.pos = le32(p + 8);
+    const int l_read_name = p[12];
+    o.mapq = p[13];
+    const int n_cigar = int(p[16]) | (int(p[17]) << 8);
+    o.flag = uint16_t(unsigned(p[18]) | (unsigned(p[19]) << 8));
+    const int32_t l_seq = le32(p + 20);
+    o.mate_ref_id = le32(p + 24);
+    o.mate_pos = le32(p + 28);
+    o.template_size = le32(p + 32);
+    o.l_seq = l_seq;
+    o.n_cigar = n_cigar;
+    o.is_fwd_strand = (o.flag & 0x10u) ? 0 : 1;
+    o.pad = 0;
+    a.rec[r] = o;
+    const uint8_t* cig = p + 36 + l_read_name;
+    sk_path_seg* path = a.path + a.path_off[r];
+    for (int i = 0; i < n_cigar; ++i) {
+        const uint32_t c = uint32_t(le32(cig + 4 * i));
+        sk_path_seg s;
+        s.type = (c & 15u) + 1u; // BAM_CMATCH.. = 0..8 -> ALIGNPATH::MATCH.. = 1..9 (L/htsapi/align_path_bam_util.cpp)
+        s.length = c >> 4;
+        path[i] = s;
+    }
+    const uint8_t* seq = cig + 4 * n_cigar;
+    const uint8_t* qual = seq + (l_seq + 1) / 2;
+    uint8_t* code = a.read_code + a.read_off[r];
+    uint8_t* q = a.read_qual + a.read_off[r];
+    for (int32_t i = 0; i < l_seq; ++i) {
+        const uint8_t byte = seq[i >> 1];
+        code[i] = (i & 1) ? uint8_t(byte & 15u) : uint8_t(byte >> 4);
+        q[i] = qual[i];
+    }
+}
+
+struct FeedBuffers
+{
+    void* p[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t cap[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int reserve(const int i, const size_t bytes)
+    {
+        if (bytes <= cap[i]) return 0;
+        if (p[i]) (void)hipFree(p[i]);
+        p[i] = nullptr;
+        cap[i] = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        SK_HIP(hipMalloc(&p[i], want));
+        cap[i] = want;
+        return 0;
+    }
+};
+FeedBuffers& feed_bufs()
+{
+    static FeedBuffers b;
+    return b;
+}
+
+} // namespace
+
+extern "C" {
+
+int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, const int64_t* dev_out_off, int32_t n_blocks, uint8_t* dev_out,
+                        int32_t* dev_status, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (n_blocks < 0) return sk_fail("sk_bgzf_inflate_dev: negative block count");
+    if (n_blocks == 0) return 0;
+    if (!dev_data || !dev_block_off || !dev_out_off || !dev_out || !dev_status) return sk_fail("sk_bgzf_inflate_dev: null argument");
+    InflateArgs a;
+    a.data = dev_data;
+    a.block_off = dev_block_off;
+    a.out_off = dev_out_off;
+    a.out = dev_out;
+    a.status = dev_status;
+    a.n_blocks = n_blocks;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks, uint8_t* out)
+{
+    SK_REQUIRE_INIT();
+    if (n_blocks < 0) return sk_fail("sk_bgzf_inflate: negative block count");
+    if (n_blocks == 0) return 0;
+    if (!data || !block_off || !out_off || !out) return sk_fail("sk_bgzf_inflate: null argument");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    const int64_t in_bytes = block_off[n_blocks] - block_off[0], out_bytes = out_off[n_blocks];
+    if (in_bytes < 0 || out_bytes < 0 || out_off[0] != 0) return sk_fail("sk_bgzf_inflate: bad offsets");
+    FeedBuffers& B = feed_bufs();
+    if (B.reserve(0, size_t(in_bytes) + 16) || B.reserve(1, 8 * size_t(n_blocks + 1)) || B.reserve(2, 8 * size_t(n_blocks + 1)) ||
+        B.reserve(3, size_t(out_bytes) + 16) || B.reserve(4, 4 * size_t(n_blocks)))
+        return 1;
+    std::vector<int64_t> rel(size_t(n_blocks) + 1);
+    for (int i = 0; i <= n_blocks; ++i) rel[size_t(i)] = block_off[i] - block_off[0];
+    SK_HIP(hipMemcpyAsync(B.p[0], data + block_off[0], size_t(in_bytes), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(B.p[1], rel.data(), 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(B.p[2], out_off, 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
+    if (sk_bgzf_inflate_dev(static_cast<uint8_t*>(B.p[0]), static_cast<int64_t*>(B.p[1]), static_cast<int64_t*>(B.p[2]), n_blocks,
+                            static_cast<uint8_t*>(B.p[3]), static_cast<int32_t*>(B.p[4]), st))
+        return 1;
+    std::vector<int32_t> status(static_cast<size_t>(n_blocks));
+    SK_HIP(hipMemcpyAsync(out, B.p[3], size_t(out_bytes), hipMemcpyDeviceToHost, st));
+    SK_HIP(hipMemcpyAsync(status.data(), B.p[4], 4 * size_t(n_blocks), hipMemcpyDeviceToHost, st));
+    SK_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < n_blocks; ++i)
+        if (status[size_t(i)] != INF_OK) {
+            static const char* const what[] = { "", "invalid block type", "invalid stored block", "invalid code", "invalid distance", "output exceeds ISIZE",
+                                                "compressed data ends early", "invalid code lengths", "inflated size differs from ISIZE", "not a BGZF block",
+                                                "CRC-32 mismatch" };
+            return sk_fail(std::string("sk_bgzf_inflate: block ") + std::to_string(i) + ": " + what[status[size_t(i)]]);
+        }
+    return 0;
+}
+
+int sk_bam_decode_dev(const uint8_t* dev_stream, const int64_t* dev_rec_off, int32_t n_records, const int64_t* dev_read_off,
+                      const int64_t* dev_path_off, sk_bam_record* dev_rec, uint8_t* dev_read_code, uint8_t* dev_read_qual, sk_path_seg* dev_path,
+                      void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (n_records < 0) return sk_fail("sk_bam_decode_dev: negative record count");
+    if (n_records == 0) return 0;
+    if (!dev_stream || !dev_rec_off || !dev_read_off || !dev_path_off || !dev_rec || !dev_read_code || !dev_read_qual || !dev_path)
+        return sk_fail("sk_bam_decode_dev: null argument");
+    DecodeArgs a;
+    a.stream = dev_stream;
+    a.rec_off = dev_rec_off;
+    a.n_records = n_records;
+    a.read_off = dev_read_off;
+    a.path_off = dev_path_off;
+    a.rec = dev_rec;
+    a.read_code = dev_read_code;
+    a.read_qual = dev_read_qual;
+    a.path = dev_path;
+    hipLaunchKernelGGL(bam_decode_kernel, dim3((n_records + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
+                  const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path)
+{
+    SK_REQUIRE_INIT();
+    if (n_records < 0 || stream_len < 0) return sk_fail("sk_bam_decode: negative count");
+    if (n_records == 0) return 0;
+    if (!stream || !rec_off || !read_off || !path_off || !rec || !read_code || !read_qual || !path) return sk_fail("sk_bam_decode: null argument");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    const int64_t n_bases = read_off[n_records], n_segs = path_off[n_records];
+    FeedBuffers& B = feed_bufs();
+    if (B.reserve(0, size_t(stream_len) + 16) || B.reserve(1, 8 * size_t(n_records)) || B.reserve(2, 8 * size_t(n_records + 1)) ||
+        B.reserve(5, 8 * size_t(n_records + 1)) || B.reserve(3, sizeof(sk_bam_record) * size_t(n_records)) || B.reserve(4, size_t(n_bases) + 16) ||
+        B.reserve(6, size_t(n_bases) + 16) || B.reserve(7, sizeof(sk_path_seg) * size_t(n_segs) + 16))
+        return 1;
+    SK_HIP(hipMemcpyAsync(B.p[0], stream, size_t(stream_len), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(B.p[1], rec_off, 8 * size_t(n_records), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(B.p[2], read_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(B.p[5], path_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
+    if (sk_bam_decode_dev(static_cast<uint8_t*>(B.p[0]), static_cast<int64_t*>(B.p[1]), n_records, static_cast<int64_t*>(B.p[2]),
+                          static_cast<int64_t*>(B.p[5]), static_cast<sk_bam_record*>(B.p[3]), static_cast<uint8_t*>(B.p[4]),
+                          static_cast<uint8_t*>(B.p[6]), static_cast<sk_path_seg*>(B.p[7]), st))
+        return 1;
+    SK_HIP(hipMemcpyAsync(rec, B.p[3], sizeof(sk_bam_record) * size_t(n_records), hipMemcpyDeviceToHost, st));
+    if (n_bases) {
+        SK_HIP(hipMemcpyAsync(read_code, B.p[4], size_t(n_bases), hipMemcpyDeviceToHost, st));
+        SK_HIP(hipMemcpyAsync(read_qual, B.p[6], size_t(n_bases), hipMemcpyDeviceToHost, st));
+    }
+    if (n_segs) SK_HIP(hipMemcpyAsync(path, B.p[7], sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyDeviceToHost, st));
+    SK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+} // extern "C"

@@ -287,3 +287,29 @@ class DeviceGlobalAlignBatch:
             out.append((int(score[i]), int(beg[i]),
                         "".join("%d%s" % (path[po + k, 1], capi.CIGAR_CHARS[path[po + k, 0]]) for k in range(nseg[i]))))
         return out
+
+
+class DeviceBgzfBatch:
+    """a BGZF file image on the device, tiled to `tile` copies (the feed leg of bench.py): sk_bgzf_inflate_dev over all blocks"""
+
+    def __init__(self, data, device="cuda:0", tile=1):
+        data = np.ascontiguousarray(data, np.uint8)
+        block_off, out_off = capi.bgzf_scan(data)
+        nb = len(block_off) - 1
+        self.n_blocks = nb * tile
+        self.in_bytes = len(data) * tile
+        self.out_bytes = int(out_off[-1]) * tile
+        self.data = torch.from_numpy(data.copy()).to(device).repeat(tile)
+        k = torch.arange(tile, dtype=torch.int64)[:, None]
+        self.block_off = torch.cat([(torch.from_numpy(block_off[:-1])[None, :] + k * len(data)).reshape(-1),
+                                    torch.tensor([len(data) * tile])]).to(device)
+        self.out_off = torch.cat([(torch.from_numpy(out_off[:-1])[None, :] + k * int(out_off[-1])).reshape(-1),
+                                  torch.tensor([int(out_off[-1]) * tile])]).to(device)
+        self.out = torch.empty(self.out_bytes, dtype=torch.uint8, device=device)
+        self.status = torch.empty(self.n_blocks, dtype=torch.int32, device=device)
+
+    def inflate(self):
+        capi._check(capi.lib().sk_bgzf_inflate_dev(C.c_void_p(self.data.data_ptr()), C.c_void_p(self.block_off.data_ptr()),
+                                                   C.c_void_p(self.out_off.data_ptr()), self.n_blocks, C.c_void_p(self.out.data_ptr()),
+                                                   C.c_void_p(self.status.data_ptr()), _stream_ptr()))
+        return self.out
