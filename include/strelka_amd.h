@@ -779,7 +779,9 @@ int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* dev_batch, 
  * fields, BAM base codes (one per byte, as sk_read_input.read_code takes them), qualities and ALIGNPATH path segments come out.
  * Finding the blocks / records is a chain walk on the host (sk_bgzf_scan, sk_bam_scan_records); the bytes are inflated (DEFLATE,
  * RFC 1951; CRC-32 and ISIZE of every block checked) and decoded by kernels (csrc/bam_feed.hip).
- * Not built: the index (.bai) lookup, CRAM, normalizeAlignment, the gVCF writer.
+ * normalizeAlignment (L/starling_common/normalizeAlignment.cpp:647-703), which the reference applies to every read as it comes
+ * off the stream (starling_run.cpp / strelka_run.cpp via normalizeBamRecordAlignment :707-727), is the third kernel.
+ * Not built: the index (.bai) lookup, CRAM, the gVCF writer.
  * ---------------------------------------------------------------------------------------------------------------- */
 
 /** The BGZF blocks of a file image (or of any run of whole blocks): block_off[i] = start of block i, out_off[i] = where its inflated
@@ -817,6 +819,17 @@ int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_
 int sk_bam_decode_dev(const uint8_t* dev_stream, const int64_t* dev_rec_off, int32_t n_records, const int64_t* dev_read_off,
                       const int64_t* dev_path_off, sk_bam_record* dev_rec, uint8_t* dev_read_code, uint8_t* dev_read_qual,
                       sk_path_seg* dev_path, void* hip_stream);
+
+/** normalizeAlignment for n_reads alignments against one reference segment, IN PLACE: indels inside the alignment are collapsed
+ *  and left-shifted, edge indels normalised, the path cleaned (apath_cleaner).  Read r: bases read_code[read_off[r]..), alignment
+ *  pos[r] + path[path_off[r] .. path_off[r] + n_seg[r]) (as sk_bam_decode leaves them; n_seg only ever shrinks), changed[r] = the
+ *  function's return value.  ref_seq: the contig segment (positions outside read as 'N', reference_contig_segment::get_base). */
+int sk_normalize_alignments(const char* ref_seq, int32_t ref_offset, int32_t ref_len, int32_t n_reads, const int64_t* read_off,
+                            const uint8_t* read_code, const int64_t* path_off, int32_t* n_seg, sk_path_seg* path, int32_t* pos,
+                            uint8_t* changed);
+int sk_normalize_alignments_dev(const char* dev_ref_seq, int32_t ref_offset, int32_t ref_len, int32_t n_reads, const int64_t* dev_read_off,
+                                const uint8_t* dev_read_code, const int64_t* dev_path_off, int32_t* dev_n_seg, sk_path_seg* dev_path,
+                                int32_t* dev_pos, uint8_t* dev_changed, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -387,3 +387,24 @@ extern "C" int sk_bam_decode_dev(const uint8_t*, const int64_t*, int32_t, const 
 {
     return sk_fail("sk_bam_decode_dev needs the GPU library");
 }
+
+#include "normalize_core.h"
+extern "C" int sk_normalize_alignments(const char* ref_seq, int32_t ref_offset, int32_t ref_len, int32_t n_reads, const int64_t* read_off,
+                                       const uint8_t* read_code, const int64_t* path_off, int32_t* n_seg, sk_path_seg* path, int32_t* pos, uint8_t* changed)
+{
+    if (n_reads < 0 || (n_reads > 0 && (!ref_seq || !read_off || !read_code || !path_off || !n_seg || !path || !pos || !changed)))
+        return sk_fail("sk_normalize_alignments: bad argument");
+    for (int32_t r = 0; r < n_reads; ++r) {
+        sknorm::Seqs s{ ref_seq, ref_offset, ref_len, read_code + read_off[r], int32_t(read_off[r + 1] - read_off[r]) };
+        sknorm::Aln al{ pos[r], path + path_off[r], n_seg[r] };
+        changed[r] = sknorm::normalize_alignment(s, al) ? 1 : 0;
+        pos[r] = al.pos;
+        n_seg[r] = al.n_seg;
+    }
+    return 0;
+}
+extern "C" int sk_normalize_alignments_dev(const char*, int32_t, int32_t, int32_t, const int64_t*, const uint8_t*, const int64_t*, int32_t*, sk_path_seg*,
+                                           int32_t*, uint8_t*, void*)
+{
+    return sk_fail("sk_normalize_alignments_dev needs the GPU library");
+}

@@ -737,3 +737,19 @@ def ref_discover_indels_and_mismatches(ref_seq, ref_offset, ar_begin, ar_end, pr
             pos, typ, dl, ins = item.split(",")
             out.append((int(pos), int(typ), int(dl), ins))
     return out, n.value
+
+
+def ref_normalize_alignment(ref_seq, ref_offset, read_chars, pos, path):
+    """the reference's own normalizeAlignment (oracle/ref/ref_driver_feed.cpp) -> (changed, pos, path)"""
+    L = ref()
+    L.ref_normalize_alignment.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), vp, C.POINTER(C.c_int32), C.c_int32]
+    cap = len(path) + 4
+    buf = np.zeros(2 * cap, np.uint32)
+    for i, (t, l) in enumerate(path):
+        buf[2 * i], buf[2 * i + 1] = t, l
+    p, n = C.c_int32(int(pos)), C.c_int32(len(path))
+    rb, qb = ref_seq.encode(), read_chars.encode()
+    rc = L.ref_normalize_alignment(rb, int(ref_offset), len(rb), qb, len(qb), C.byref(p), buf.ctypes.data, C.byref(n), cap)
+    if rc < 0:
+        raise RuntimeError("ref_normalize_alignment: result does not fit")
+    return rc, p.value, [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n.value)]

@@ -182,7 +182,7 @@ assert DIGT_CALL_DTYPE.itemsize == 144 and SOMATIC_CALL_DTYPE.itemsize == 272
 EXPORTS = [
     "sk_init", "sk_init_strict", "sk_check_device_errors", "sk_debug_force_device_libm", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_libm_restated", "sk_get_qscore_tables",
     "sk_score_alignments", "sk_score_alignments_dev", "sk_align_evmask_words", "sk_align_prepare", "sk_align_colmat_words", "sk_align_prepare_cols",
-    "sk_bgzf_scan", "sk_bgzf_inflate", "sk_bgzf_inflate_dev", "sk_bam_header_end", "sk_bam_scan_records", "sk_bam_decode", "sk_bam_decode_dev",
+    "sk_bgzf_scan", "sk_bgzf_inflate", "sk_bgzf_inflate_dev", "sk_bam_header_end", "sk_bam_scan_records", "sk_bam_decode", "sk_bam_decode_dev", "sk_normalize_alignments", "sk_normalize_alignments_dev",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_append", "sk_align_builder_add_read",
     "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
@@ -269,6 +269,8 @@ def lib():
         L.sk_bam_scan_records.argtypes = [c_void_p, C.c_int64, C.c_int64, c_void_p, c_void_p, c_void_p, C.c_int32]
         L.sk_bam_decode.argtypes = [c_void_p, C.c_int64, c_void_p, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.sk_bam_decode_dev.argtypes = [c_void_p, c_void_p, C.c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.sk_normalize_alignments.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32] + [c_void_p] * 7
+        L.sk_normalize_alignments_dev.argtypes = [c_void_p, C.c_int32, C.c_int32, C.c_int32] + [c_void_p] * 8
         L.sk_align_colmat_words.restype = C.c_int64
         L.sk_align_colmat_words.argtypes = [c_void_p]
         L.sk_align_prepare_cols.argtypes = [c_void_p] * 4
@@ -1050,3 +1052,34 @@ def bam_decode(stream, first=None):
     _check(lib().sk_bam_decode(_p(stream), len(stream), _p(rec_off), n, _p(read_off), _p(path_off), _p(rec), _p(code), _p(qual), _p(path)))
     return dict(rec=rec, rec_off=rec_off, read_off=read_off, read_code=code[:int(read_off[-1])], read_qual=qual[:int(read_off[-1])],
                 path_off=path_off, path=path[:int(path_off[-1])])
+
+
+def normalize_alignments(ref_seq, ref_offset, reads, library=None):
+    """reads: dicts(code uint8[], pos, path [(type, length)]) -> list of (changed, pos, path) through sk_normalize_alignments
+    (`library`: another build of the ABI, e.g. the CPU double, for the no-GPU test tier)"""
+    L = library or lib()
+    n = len(reads)
+    read_off = np.zeros(n + 1, np.int64)
+    path_off = np.zeros(n + 1, np.int64)
+    for i, r in enumerate(reads):
+        read_off[i + 1] = read_off[i] + len(r["code"])
+        path_off[i + 1] = path_off[i] + len(r["path"])
+    code = np.concatenate([np.asarray(r["code"], np.uint8) for r in reads]) if n else np.zeros(1, np.uint8)
+    path = np.zeros(max(int(path_off[-1]), 1), PATH_SEG_DTYPE)
+    k = 0
+    for r in reads:
+        for t, l in r["path"]:
+            path[k] = (t, l)
+            k += 1
+    n_seg = np.array([len(r["path"]) for r in reads], np.int32)
+    pos = np.array([r["pos"] for r in reads], np.int32)
+    changed = np.zeros(max(n, 1), np.uint8)
+    ref_b = ref_seq.encode() if isinstance(ref_seq, str) else bytes(ref_seq)
+    rc = L.sk_normalize_alignments(ref_b, int(ref_offset), len(ref_b), n, _p(read_off), _p(code), _p(path_off), _p(n_seg), _p(path), _p(pos), _p(changed))
+    if rc != 0:
+        raise StrelkaAmdError(L.sk_last_error().decode("utf-8", "replace"))
+    out = []
+    for i in range(n):
+        seg = path[int(path_off[i]):int(path_off[i]) + int(n_seg[i])]
+        out.append((int(changed[i]), int(pos[i]), [(int(t), int(l)) for t, l in seg]))
+    return out

@@ -11,12 +11,16 @@
 //                             inside the thread's own output range.  A serial bit stream per block is what the format is; the
 //                             parallelism is across blocks.
 //   B2  bgzf_crc32_kernel     one thread per block: CRC-32 (IEEE 802.3, table in LDS) of the inflated bytes against the trailer
+//   B4  normalize_kernel      one thread per read: normalizeAlignment (L/starling_common/normalizeAlignment.cpp:647-703; the
+//                             reference applies it to every read as it comes off the BAM stream), csrc/normalize_core.h, in place
 //   B3  bam_decode_kernel     one thread per BAM record: fixed fields, CIGAR -> path segments (ALIGNPATH::align_t = BAM op + 1),
 //                             4-bit packed bases -> one BAM code per byte (what sk_read_input.read_code takes), qualities
 //
 // Byte work, bound by the serial decode per block rather than by HBM; algorithmic bytes = compressed in + inflated out.
 
 #include "sk_common.h"
+
+#include "normalize_core.h"
 
 #include <cstring>
 #include <string>
@@ -323,10 +327,44 @@ __global__ __launch_bounds__(64) void bam_decode_kernel(const DecodeArgs a)
     }
 }
 
+struct NormArgs
+{
+    const char* ref;
+    int32_t ref_offset, ref_len;
+    int32_t n_reads;
+    const int64_t* read_off;
+    const uint8_t* read_code;
+    const int64_t* path_off;
+    int32_t* n_seg;
+    sk_path_seg* path;
+    int32_t* pos;
+    uint8_t* changed;
+};
+
+__global__ __launch_bounds__(64) void normalize_kernel(const NormArgs a)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    sknorm::Seqs s;
+    s.ref = a.ref;
+    s.ref_offset = a.ref_offset;
+    s.ref_len = a.ref_len;
+    s.read_code = a.read_code + a.read_off[r];
+    s.read_len = int32_t(a.read_off[r + 1] - a.read_off[r]);
+    sknorm::Aln al;
+    al.pos = a.pos[r];
+    al.path = a.path + a.path_off[r];
+    al.n_seg = a.n_seg[r];
+    const bool changed = sknorm::normalize_alignment(s, al);
+    a.pos[r] = al.pos;
+    a.n_seg[r] = al.n_seg;
+    a.changed[r] = changed ? 1 : 0;
+}
+
 struct FeedBuffers
 {
-    void* p[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    size_t cap[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    void* p[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t cap[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int reserve(const int i, const size_t bytes)
     {
         if (bytes <= cap[i]) return 0;
@@ -461,6 +499,69 @@ int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_
         SK_HIP(hipMemcpyAsync(read_qual, B.p[6], size_t(n_bases), hipMemcpyDeviceToHost, st));
     }
     if (n_segs) SK_HIP(hipMemcpyAsync(path, B.p[7], sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyDeviceToHost, st));
+    SK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int sk_normalize_alignments_dev(const char* dev_ref_seq, int32_t ref_offset, int32_t ref_len, int32_t n_reads, const int64_t* dev_read_off,
+                                const uint8_t* dev_read_code, const int64_t* dev_path_off, int32_t* dev_n_seg, sk_path_seg* dev_path,
+                                int32_t* dev_pos, uint8_t* dev_changed, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (n_reads < 0 || ref_len < 0) return sk_fail("sk_normalize_alignments_dev: negative count");
+    if (n_reads == 0) return 0;
+    if (!dev_ref_seq || !dev_read_off || !dev_read_code || !dev_path_off || !dev_n_seg || !dev_path || !dev_pos || !dev_changed)
+        return sk_fail("sk_normalize_alignments_dev: null argument");
+    NormArgs a;
+    a.ref = dev_ref_seq;
+    a.ref_offset = ref_offset;
+    a.ref_len = ref_len;
+    a.n_reads = n_reads;
+    a.read_off = dev_read_off;
+    a.read_code = dev_read_code;
+    a.path_off = dev_path_off;
+    a.n_seg = dev_n_seg;
+    a.path = dev_path;
+    a.pos = dev_pos;
+    a.changed = dev_changed;
+    hipLaunchKernelGGL(normalize_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sk_normalize_alignments(const char* ref_seq, int32_t ref_offset, int32_t ref_len, int32_t n_reads, const int64_t* read_off,
+                            const uint8_t* read_code, const int64_t* path_off, int32_t* n_seg, sk_path_seg* path, int32_t* pos, uint8_t* changed)
+{
+    SK_REQUIRE_INIT();
+    if (n_reads < 0 || ref_len < 0) return sk_fail("sk_normalize_alignments: negative count");
+    if (n_reads == 0) return 0;
+    if (!ref_seq || !read_off || !read_code || !path_off || !n_seg || !path || !pos || !changed) return sk_fail("sk_normalize_alignments: null argument");
+    for (int32_t r = 0; r < n_reads; ++r)
+        if (n_seg[r] < 0 || int64_t(n_seg[r]) > path_off[r + 1] - path_off[r]) return sk_fail("sk_normalize_alignments: n_seg beyond the read's path slots");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    const int64_t n_bases = read_off[n_reads], n_segs = path_off[n_reads];
+    FeedBuffers& B = feed_bufs();
+    if (B.reserve(0, size_t(ref_len) + 16) || B.reserve(1, 8 * size_t(n_reads + 1)) || B.reserve(2, size_t(n_bases) + 16) || B.reserve(3, 8 * size_t(n_reads + 1)) ||
+        B.reserve(4, 4 * size_t(n_reads)) || B.reserve(5, sizeof(sk_path_seg) * size_t(n_segs) + 16) || B.reserve(6, 4 * size_t(n_reads)) ||
+        B.reserve(7, size_t(n_reads) + 16))
+        return 1;
+    SK_HIP(hipMemcpyAsync(B.p[0], ref_seq, size_t(ref_len), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(B.p[1], read_off, 8 * size_t(n_reads + 1), hipMemcpyHostToDevice, st));
+    if (n_bases) SK_HIP(hipMemcpyAsync(B.p[2], read_code, size_t(n_bases), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(B.p[3], path_off, 8 * size_t(n_reads + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(B.p[4], n_seg, 4 * size_t(n_reads), hipMemcpyHostToDevice, st));
+    if (n_segs) SK_HIP(hipMemcpyAsync(B.p[5], path, sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(B.p[6], pos, 4 * size_t(n_reads), hipMemcpyHostToDevice, st));
+    if (sk_normalize_alignments_dev(static_cast<char*>(B.p[0]), ref_offset, ref_len, n_reads, static_cast<int64_t*>(B.p[1]), static_cast<uint8_t*>(B.p[2]),
+                                    static_cast<int64_t*>(B.p[3]), static_cast<int32_t*>(B.p[4]), static_cast<sk_path_seg*>(B.p[5]),
+                                    static_cast<int32_t*>(B.p[6]), static_cast<uint8_t*>(B.p[7]), st))
+        return 1;
+    SK_HIP(hipMemcpyAsync(n_seg, B.p[4], 4 * size_t(n_reads), hipMemcpyDeviceToHost, st));
+    if (n_segs) SK_HIP(hipMemcpyAsync(path, B.p[5], sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyDeviceToHost, st));
+    SK_HIP(hipMemcpyAsync(pos, B.p[6], 4 * size_t(n_reads), hipMemcpyDeviceToHost, st));
+    SK_HIP(hipMemcpyAsync(changed, B.p[7], size_t(n_reads), hipMemcpyDeviceToHost, st));
     SK_HIP(hipStreamSynchronize(st));
     return 0;
 }

@@ -853,3 +853,114 @@ def active_region_scenarios(n, rng):
         out.append(dict(ref_seq=ref, ref_offset=off, ar_begin=off + b, ar_end=off + e, prev_ar_end=prev,
                         max_indel_size=int(rng.choice([49, 49, 49, 10])), haplotype=hap))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the feed: alignments for normalizeAlignment -- indels inside repeats placed anywhere in their equivalence range, insert+delete
+# pairs that partly cancel, indels at the alignment's edges, soft / hard clips
+
+def normalize_cases(n, rng):
+    """-> list of dict(ref_seq, ref_offset, read (ACGTN string), code, pos, path)"""
+    out = []
+    seg = dict(M=1, I=2, D=3, N=4, S=5, H=6, P=7, EQ=8, X=9)
+    char2code = {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15}
+    for _ in range(n):
+        # a reference rich in homopolymers and short tandem repeats
+        parts = []
+        while sum(len(p) for p in parts) < 260:
+            r = rng.random()
+            if r < 0.35:
+                parts.append(BASES[int(rng.integers(0, 4))] * int(rng.integers(3, 12)))
+            elif r < 0.6:
+                unit = "".join(BASES[i] for i in rng.integers(0, 4, int(rng.integers(2, 5))))
+                parts.append(unit * int(rng.integers(2, 7)))
+            else:
+                parts.append("".join(BASES[i] for i in rng.integers(0, 4, int(rng.integers(4, 20)))))
+        ref = "".join(parts)
+        off = int(rng.choice([0, 0, 500, 100000]))
+        start = int(rng.integers(0, 40))
+        rp = start          # position in ref (0-based inside ref)
+        read = []
+        path = []
+        if rng.random() < 0.2:
+            path.append((seg["H"], int(rng.integers(1, 9))))
+        if rng.random() < 0.25:
+            k = int(rng.integers(1, 8))
+            read += [BASES[i] for i in rng.integers(0, 4, k)]
+            path.append((seg["S"], k))
+        if rng.random() < 0.15:  # leading edge indel
+            if rng.random() < 0.5:
+                k = int(rng.integers(1, 6))
+                if rng.random() < 0.5 and rp >= k:
+                    read += list(ref[rp - k:rp])      # an edge insertion that is really a match one step to the left
+                else:
+                    read += [BASES[i] for i in rng.integers(0, 4, k)]
+                path.append((seg["I"], k))
+            else:
+                k = int(rng.integers(1, 6))
+                path.append((seg["D"], k))
+                rp += k
+        n_ev = int(rng.integers(0, 5))
+        for e in range(n_ev + 1):
+            m = int(rng.integers(4, 45))
+            m = min(m, len(ref) - rp - 30)
+            if m <= 0:
+                break
+            chunk = list(ref[rp:rp + m])
+            for i in range(len(chunk)):
+                if rng.random() < 0.03:
+                    chunk[i] = BASES[int(rng.integers(0, 4))] if rng.random() < 0.8 else "N"
+            read += chunk
+            t = seg["M"] if rng.random() < 0.85 else (seg["EQ"] if rng.random() < 0.5 else seg["X"])
+            path.append((t, m))
+            rp += m
+            if e == n_ev:
+                break
+            r = rng.random()
+            if r < 0.35:      # deletion (often of a repeat unit -> shiftable)
+                k = int(rng.integers(1, 9))
+                path.append((seg["D"], k))
+                rp += k
+            elif r < 0.7:     # insertion: a copy of the following / preceding reference bases (shiftable) or random
+                k = int(rng.integers(1, 9))
+                q = rng.random()
+                if q < 0.4:
+                    ins = list(ref[rp:rp + k])
+                elif q < 0.7 and rp >= k:
+                    ins = list(ref[rp - k:rp])
+                else:
+                    ins = [BASES[i] for i in rng.integers(0, 4, k)]
+                read += ins
+                path.append((seg["I"], len(ins)))
+            elif r < 0.9:     # insertion and deletion side by side, partly or wholly cancelling
+                kd, ki = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+                ins = list(ref[rp:rp + ki]) if rng.random() < 0.6 else [BASES[i] for i in rng.integers(0, 4, ki)]
+                if rng.random() < 0.5:
+                    path += [(seg["I"], len(ins)), (seg["D"], kd)]
+                else:
+                    path += [(seg["D"], kd), (seg["I"], len(ins))]
+                read += ins
+                rp += kd
+            else:             # two runs of the same kind split in two segments (the cleaner merges them)
+                k1, k2 = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+                path += [(seg["D"], k1), (seg["D"], k2)]
+                rp += k1 + k2
+        if rng.random() < 0.12:  # trailing edge indel
+            if rng.random() < 0.5:
+                k = int(rng.integers(1, 6))
+                ins = list(ref[rp:rp + k]) if rng.random() < 0.5 else [BASES[i] for i in rng.integers(0, 4, k)]
+                read += ins
+                path.append((seg["I"], len(ins)))
+            else:
+                path.append((seg["D"], int(rng.integers(1, 6))))
+        if rng.random() < 0.25:
+            k = int(rng.integers(1, 8))
+            read += [BASES[i] for i in rng.integers(0, 4, k)]
+            path.append((seg["S"], k))
+        if rng.random() < 0.2:
+            path.append((seg["H"], int(rng.integers(1, 9))))
+        if not any(t in (1, 8, 9) for t, _ in path):
+            continue
+        read = "".join(read)
+        out.append(dict(ref_seq=ref, ref_offset=off, read=read, code=np.array([char2code[c] for c in read], np.uint8), pos=off + start, path=path))
+    return out

@@ -336,6 +336,18 @@ def somatic_indel_tiers_golden():
     np.savez_compressed(T.INDEL_GOLDEN, **out)
 
 
+def normalize_golden():
+    """normalizeAlignment (L/starling_common/normalizeAlignment.cpp) of the reference itself on synth.normalize_cases"""
+    import pickle
+    rng = np.random.default_rng(424242)
+    cases = synth.normalize_cases(1500, rng)
+    expect = [pyoracle.ref_normalize_alignment(c["ref_seq"], c["ref_offset"], c["read"], c["pos"], c["path"]) for c in cases]
+    assert sum(e[0] for e in expect) > 800
+    with open(os.path.join(HERE, "normalize_reference.pkl"), "wb") as f:
+        pickle.dump(dict(seed=424242, n=1500, expect=expect), f, protocol=4)
+    print("normalize_reference.pkl:", len(cases), "alignments,", sum(e[0] for e in expect), "changed")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "somatic_indel_tiers"):
@@ -352,3 +364,5 @@ if __name__ == "__main__":
         pipeline_golden()
     if what in ("all", "active_region"):
         active_region_golden()
+    if what in ("all", "normalize"):
+        normalize_golden()

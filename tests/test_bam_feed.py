@@ -118,3 +118,67 @@ def test_malformed_blocks_are_refused():
         assert rc != 0 and "block 0" in capi.last_error(), what
     # and a good run after a bad one is clean
     assert capi.bgzf_inflate(data).tobytes() == bam_oracle.bgzf_inflate(data.tobytes())
+
+
+# ---- normalizeAlignment (L/starling_common/normalizeAlignment.cpp:647-703): csrc/normalize_core.h on the host and as a kernel ---------------
+
+import ctypes as C
+import pickle
+
+from oracle import pyoracle
+from strelka_amd import synth
+
+
+def _normalize_golden():
+    with open(os.path.join(GOLD, "normalize_reference.pkl"), "rb") as f:
+        g = pickle.load(f)
+    cases = synth.normalize_cases(g["n"], np.random.default_rng(g["seed"]))
+    assert len(cases) == len(g["expect"])
+    return cases, [tuple(e) for e in g["expect"]]
+
+
+def _run_batched(cases, library=None):
+    out = []
+    i = 0
+    while i < len(cases):  # one call per run of alignments that share a reference segment
+        j = i
+        while j < len(cases) and cases[j]["ref_seq"] is cases[i]["ref_seq"] and cases[j]["ref_offset"] == cases[i]["ref_offset"]:
+            j += 1
+        out += capi.normalize_alignments(cases[i]["ref_seq"], cases[i]["ref_offset"], cases[i:j], library=library)
+        i = j
+    return out
+
+
+def _double():
+    path = os.path.join(os.path.dirname(GOLD), "..", "oracle", "libstrelka_amd_double.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/libstrelka_amd_double.so not built")
+    L = C.CDLL(os.path.abspath(path))
+    L.sk_last_error.restype = C.c_char_p
+    L.sk_normalize_alignments.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7
+    return L
+
+
+def test_normalize_core_reproduces_the_reference_golden():
+    cases, expect = _normalize_golden()
+    got = _run_batched(cases, library=_double())
+    assert sum(e[0] for e in expect) > 800
+    assert got == expect
+
+
+@pytest.mark.skipif(not pyoracle.ref_available(), reason="oracle/_ref not built")
+def test_normalize_core_reproduces_the_live_reference():
+    cases = synth.normalize_cases(2500, np.random.default_rng(99001))
+    want = [pyoracle.ref_normalize_alignment(c["ref_seq"], c["ref_offset"], c["read"], c["pos"], c["path"]) for c in cases]
+    assert _run_batched(cases, library=_double()) == want
+
+
+@pytest.mark.gpu
+def test_normalize_kernel_reproduces_the_reference_golden():
+    capi.init(0)
+    cases, expect = _normalize_golden()
+    assert _run_batched(cases) == expect
+    # many alignments against one segment in one launch
+    big = [c for c in cases if c["ref_seq"] is cases[0]["ref_seq"]] * 5000
+    got = capi.normalize_alignments(cases[0]["ref_seq"], cases[0]["ref_offset"], big)
+    assert got == [expect[0]] * len(big)
