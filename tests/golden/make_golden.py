@@ -340,11 +340,13 @@ def normalize_golden():
     """normalizeAlignment (L/starling_common/normalizeAlignment.cpp) of the reference itself on synth.normalize_cases"""
     import pickle
     rng = np.random.default_rng(424242)
-    cases = synth.normalize_cases(1500, rng)
+    cases = synth.normalize_cases(700, rng)
     expect = [pyoracle.ref_normalize_alignment(c["ref_seq"], c["ref_offset"], c["read"], c["pos"], c["path"]) for c in cases]
-    assert sum(e[0] for e in expect) > 800
+    assert sum(e[0] for e in expect) > 400
+    # (the inputs travel with the answers: the test suite can be run on shifted seeds, tools/fuzz/gpu_seeds.sh)
+    slim = [dict(ref_seq=c["ref_seq"], ref_offset=c["ref_offset"], read=c["read"], pos=c["pos"], path=c["path"]) for c in cases]
     with open(os.path.join(HERE, "normalize_reference.pkl"), "wb") as f:
-        pickle.dump(dict(seed=424242, n=1500, expect=expect), f, protocol=4)
+        pickle.dump(dict(cases=slim, expect=expect), f, protocol=4)
     print("normalize_reference.pkl:", len(cases), "alignments,", sum(e[0] for e in expect), "changed")
 
 
