@@ -329,6 +329,10 @@ int sk_realign_job_indels_consulted(const sk_realign_job* job, uint8_t* out, int
 /** How many reads had their candidate alignments enumerated by the container-free core on the host (enumeration == 1), on the
  *  device (== 2), and by the container-based code although 1 or 2 was asked for (a fixed capacity of the core was exceeded). */
 int sk_realign_job_enumeration_counts(const sk_realign_job* job, int64_t* n_core, int64_t* n_device, int64_t* n_fallback);
+/** How many reads had stage 3 (scoreCandidateAlignments' selection, finishRealignment and score_indels, L/starling_common/
+ *  starling_read_align.cpp:1534-1741 and starling_read_align_score_indels.cpp:455-1079) run in its container-free form on the
+ *  host (enumeration == 1) and on the device (== 2); the rest went through the container-based code. */
+int sk_realign_job_stage3_counts(const sk_realign_job* job, int64_t* n_core, int64_t* n_device);
 /** drop reads and results, keep reference/indels/options */
 void sk_realign_job_clear_reads(sk_realign_job* job);
 

@@ -7,6 +7,7 @@
 #pragma once
 
 #include "realign_core.h"
+#include "stage3_core.h"
 
 struct SkEnumInput
 {
@@ -27,6 +28,13 @@ struct SkEnumInput
     const uint8_t* read_qual;
     int32_t max_read_len;
     int32_t want_scores; // 0 = enumeration only (sk_realign_job_get_batch flattens on the host)
+    // stage 3 on the device as well (needs want_scores): per-indel error rates and given order, per-read mapping level
+    int32_t want_stage3;
+    const double* r2i;
+    const double* i2r;
+    const int32_t* orig;
+    const int32_t* map_level;
+    sk3::Opt stage3_opt;
 };
 
 struct SkEnumOutput // host arrays owned by the pipeline, valid until its next run
@@ -36,7 +44,8 @@ struct SkEnumOutput // host arrays owned by the pipeline, valid until its next r
     const int32_t* cal_off;    // [n_reads+1]
     const skcore::PCal* cals;  // [cal_off[n_reads]] each read's candidate alignments in set order
     const double* scores;      // [cal_off[n_reads]] or null
-    const uint8_t* consulted;  // [n_tab] candidate status consulted by the search or the flattening
+    const uint8_t* consulted;  // [n_tab] candidate status consulted by the search, the flattening or stage 3
+    const sk3::Out* stage3;    // [n_reads] or null; stage3[r].status != S3_OK (or status[r] != ST_OK): stage 3 of the read is the host's
 };
 
 extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out);

@@ -688,6 +688,107 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// S3: stage 3 (csrc/stage3_core.h) -- the max / smooth candidate alignment, the realigned alignment clipped where the smooth
+// pool disagrees, the late normalisation filter and score_indels -- one wavefront per read over the read's candidate alignments and
+// scores where the scoring kernel left them: the loops over alignments are spread over the 64 lanes, lane 0 takes the decisions the
+// reference defines by iteration order (see the header).  What leaves the device is a fixed-size record per read.
+enum { S3_LIGHT_CALS = 256, S3_LDS_CALS = 1800 }; // (1800 alignments: 53 KB; with the shared state that stays under 64 KB per workgroup)
+
+struct WaveLanes
+{
+    int id, width;
+    __device__ void sync() const { __syncthreads(); } // (the workgroup is this one wavefront)
+    __device__ void max_i64(long long* p, const long long v) const { atomicMax(p, v); }
+};
+
+struct Stage3Args
+{
+    sk3::Tab tab;
+    sk3::Opt opt;
+    int32_t n_reads;
+    const int32_t* status;
+    const int32_t* cal_off;
+    const PCal* cals;
+    const double* scores;
+    const int64_t* read_off;
+    const uint8_t* read_code;
+    const int32_t* map_level;
+    int32_t* order;
+    double* smooth;
+    uint8_t* flag;
+    uint32_t* key;
+    double* sorted_score;
+    uint32_t* sorted_hash;
+    int32_t* next_same;
+    uint8_t* removed;
+    uint8_t* rm_type;
+    int32_t* rm_pos;
+    sk3::Out* out;
+    const int32_t* list; // the reads of this launch
+    int32_t lds_cals;
+};
+
+__global__ __launch_bounds__(64) void stage3_kernel(const Stage3Args a)
+{
+    __shared__ sk3::Shared sh;
+    extern __shared__ double s3_lds[]; // the per-alignment arrays of the selection and the late normalisation filter, for a read with at most a.lds_cals candidate alignments
+    const int r = a.list[blockIdx.x];
+    sk3::Out& o = a.out[r];
+    const int32_t c0 = a.cal_off[r], c1 = a.cal_off[r + 1];
+    if (a.status[r] != ST_OK || c1 == c0) {
+        if (threadIdx.x == 0) o.status = sk3::S3_CAPACITY;
+        return;
+    }
+    const int64_t b0 = a.read_off[r], b1 = a.read_off[r + 1];
+    sk3::Read rd;
+    rd.cals = a.cals + c0;
+    rd.scores = a.scores + c0;
+    rd.scores_select = rd.scores;
+    rd.n_cals = c1 - c0;
+    rd.map_level = a.map_level[r];
+    rd.read_length = int32_t(b1 - b0);
+    int na = 0;
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 64) na += (a.read_code[i] != SK_BAM_ANY) ? 1 : 0;
+    for (int d = 32; d > 0; d >>= 1) na += __shfl_xor(na, d);
+    rd.non_ambig = na;
+    sk3::Scratch w;
+    w.order = a.order + c0;
+    w.smooth = a.smooth + c0;
+    w.flag = a.flag + c0;
+    w.key = a.key + 4 * size_t(c0);
+    w.sorted_score = a.sorted_score + c0;
+    w.sorted_hash = a.sorted_hash + c0;
+    w.next_same = a.next_same + c0;
+    w.removed = a.removed + c0;
+    w.rm_type = a.rm_type + b0;
+    w.rm_pos = a.rm_pos + b0;
+    if (rd.n_cals <= a.lds_cals) {
+        // what lane 0's scans and the ordering walk over and over sits in LDS (the accesses are chains of dependent loads)
+        double* sc = s3_lds; // the scores for the selection, later the smoothed scores by place
+        double* ssc = sc + a.lds_cals;
+        int32_t* ord = reinterpret_cast<int32_t*>(ssc + a.lds_cals);
+        uint32_t* shs = reinterpret_cast<uint32_t*>(ord + a.lds_cals);
+        int32_t* nxt = reinterpret_cast<int32_t*>(shs + a.lds_cals);
+        uint8_t* fl = reinterpret_cast<uint8_t*>(nxt + a.lds_cals);
+        uint8_t* rem = fl + a.lds_cals;
+        for (int i = threadIdx.x; i < rd.n_cals; i += 64) sc[i] = rd.scores[i];
+        __syncthreads();
+        rd.scores_select = sc;
+        w.smooth = sc;
+        w.sorted_score = ssc;
+        w.sorted_hash = shs;
+        w.next_same = nxt;
+        w.order = ord;
+        w.flag = fl;
+        w.removed = rem;
+    }
+    WaveLanes ln;
+    ln.id = int(threadIdx.x);
+    ln.width = 64;
+    sk3::finish_read(ln, a.tab, a.opt, rd, w, sh, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // buffers: grown on demand, kept for the life of the process (one job after the other reuses them)
 
 struct DevBuf
@@ -732,6 +833,8 @@ struct EnumBuffers
     DevBuf raw_off, fill, grouped, dup, n_uniq, sorted;
     DevBuf n_ops, hap_len, win_begin, win_end, ins_lo, ins_hi, win_len, n_ins, ins_idx, ins_off;
     DevBuf cal_off, hap_off, cals, hap_code, op_off, ops, entries, evmask, scores, colmat, colmat_off, addmask;
+    DevBuf r2i, i2r, orig, map_level, s3_order, s3_smooth, s3_flag, s3_rm_type, s3_rm_pos, s3_key, s3_sorted_score, s3_sorted_hash, s3_next_same, s3_removed, s3_out, s3_list;
+    HostBuf h_s3_out, h_s3_list;
     HostBuf h_status, h_warn, h_n_raw, h_raw_off, h_n_uniq, h_n_ops, h_hap_len, h_cal_off, h_hap_off, h_op_off, h_cals, h_scores,
         h_consulted, h_counters, h_colmat_off;
 };
@@ -1117,6 +1220,86 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
             lap("A1 score");
             D2H(h_scores, scores, 8 * size_t(n_cals));
             out->scores = B.h_scores.as<double>();
+            if (in->want_stage3) {
+                RES(r2i, 8 * size_t(in->n_tab));
+                RES(i2r, 8 * size_t(in->n_tab));
+                RES(orig, 4 * size_t(in->n_tab));
+                RES(map_level, 4 * size_t(n));
+                RES(s3_order, 4 * size_t(n_cals));
+                RES(s3_smooth, 8 * size_t(n_cals));
+                RES(s3_flag, size_t(n_cals));
+                RES(s3_rm_type, size_t(n_bases));
+                RES(s3_rm_pos, 4 * size_t(n_bases));
+                RES(s3_key, 16 * size_t(n_cals));
+                RES(s3_sorted_score, 8 * size_t(n_cals));
+                RES(s3_sorted_hash, 4 * size_t(n_cals));
+                RES(s3_next_same, 4 * size_t(n_cals));
+                RES(s3_removed, size_t(n_cals));
+                RES(s3_out, sizeof(sk3::Out) * size_t(n));
+                HRES(h_s3_out, sizeof(sk3::Out) * size_t(n));
+                H2D(r2i, in->r2i, 8 * size_t(in->n_tab));
+                H2D(i2r, in->i2r, 8 * size_t(in->n_tab));
+                H2D(orig, in->orig, 4 * size_t(in->n_tab));
+                H2D(map_level, in->map_level, 4 * size_t(n));
+                Stage3Args s3;
+                s3.tab.tab = dj.tab;
+                s3.tab.r2i = B.r2i.as<double>();
+                s3.tab.i2r = B.i2r.as<double>();
+                s3.tab.orig = B.orig.as<int32_t>();
+                s3.tab.n_tab = in->n_tab;
+                s3.tab.max_indel_size = in->max_indel_size;
+                s3.tab.consulted = dj.consulted;
+                s3.opt = in->stage3_opt;
+                s3.n_reads = n;
+                s3.status = ea.status;
+                s3.cal_off = fa.cal_off;
+                s3.cals = fa.cals;
+                s3.scores = B.scores.as<double>();
+                s3.read_off = fa.read_off;
+                s3.read_code = fa.read_code;
+                s3.map_level = B.map_level.as<int32_t>();
+                s3.order = B.s3_order.as<int32_t>();
+                s3.smooth = B.s3_smooth.as<double>();
+                s3.flag = B.s3_flag.as<uint8_t>();
+                s3.rm_type = B.s3_rm_type.as<uint8_t>();
+                s3.rm_pos = B.s3_rm_pos.as<int32_t>();
+                s3.key = B.s3_key.as<uint32_t>();
+                s3.sorted_score = B.s3_sorted_score.as<double>();
+                s3.sorted_hash = B.s3_sorted_hash.as<uint32_t>();
+                s3.next_same = B.s3_next_same.as<int32_t>();
+                s3.removed = B.s3_removed.as<uint8_t>();
+                s3.out = B.s3_out.as<sk3::Out>();
+                // two launches: reads with few candidate alignments (small LDS, many wavefronts per CU) and the others
+                RES(s3_list, 4 * size_t(n));
+                HRES(h_s3_list, 4 * size_t(n));
+                int32_t* h_list = B.h_s3_list.as<int32_t>();
+                int n_light = 0, n_heavy = 0, max_cals = 0;
+                for (int r = 0; r < n; ++r) {
+                    const int k = h_cal_off[r + 1] - h_cal_off[r];
+                    if (k <= S3_LIGHT_CALS) h_list[n_light++] = r;
+                    else {
+                        h_list[n - 1 - n_heavy++] = r;
+                        max_cals = std::max(max_cals, k);
+                    }
+                }
+                H2D(s3_list, h_list, 4 * size_t(n));
+                auto lds_bytes = [](const int cals) { return size_t(cals) * (8 + 8 + 4 + 4 + 4 + 1 + 1) + 8; };
+                if (n_light > 0) {
+                    s3.list = B.s3_list.as<int32_t>();
+                    s3.lds_cals = S3_LIGHT_CALS;
+                    hipLaunchKernelGGL(stage3_kernel, dim3(n_light), dim3(64), lds_bytes(S3_LIGHT_CALS), st, s3);
+                }
+                if (n_heavy > 0) {
+                    s3.list = B.s3_list.as<int32_t>() + (n - n_heavy);
+                    s3.lds_cals = std::min(max_cals, int(S3_LDS_CALS)); // (a read with more uses the arrays in HBM)
+                    hipLaunchKernelGGL(stage3_kernel, dim3(n_heavy), dim3(64), lds_bytes(s3.lds_cals), st, s3);
+                }
+                if (timing) std::fprintf(stderr, "[enum-dev] stage 3: %d reads with at most %d candidate alignments, %d with more (up to %d)\n", n_light, int(S3_LIGHT_CALS), n_heavy, max_cals);
+                SK_HIP(hipGetLastError());
+                D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
+                out->stage3 = B.h_s3_out.as<sk3::Out>();
+                lap("S3 stage 3");
+            }
         }
     }
     D2H(h_consulted, consulted, size_t(in->n_tab));

@@ -57,6 +57,7 @@ struct PIndel // the fields of an IndelBuffer entry the search reads
     int8_t hap[SK_MAX_SAMPLES];
     uint8_t bypass[SK_MAX_SAMPLES];
     uint32_t ins_off; // insert sequence in the job's character pool (flattening only)
+    uint32_t shape;   // number of the indel's (type, deletion length, insert sequence) among the table's: stage 3's equivalence test
 };
 
 SKC_HD inline int32_t right_pos(const PIndel& k) { return k.pos + int32_t(k.del); }

@@ -14,6 +14,7 @@
 #include "strelka_amd.h"
 #include "../csrc/realign_core.h"
 #include "../csrc/read_enumerate.h"
+#include "../csrc/stage3_core.h"
 
 #include <algorithm>
 #include <atomic>
@@ -434,6 +435,8 @@ struct sk_realign_job
     mutable std::unique_ptr<std::atomic<uint8_t>[]> consulted;
     // reads whose search ran in the container-free core / on the device / in the container-based code although 1 or 2 was asked for
     mutable std::atomic<int64_t> n_core_reads{ 0 }, n_device_reads{ 0 }, n_fallback_reads{ 0 };
+    // reads whose stage 3 ran in the container-free core (host, enumeration == 1) / on the device (== 2)
+    mutable std::atomic<int64_t> n_stage3_core{ 0 }, n_stage3_device{ 0 };
     bool cand(const int i) const
     {
         consulted[size_t(i)].store(1, std::memory_order_relaxed);
@@ -465,8 +468,13 @@ struct sk_realign_job
         std::vector<int> observed;
         int32_t realign_b = 0, realign_e = 0;
         int64_t dev_score_at = -1;
+        bool stage3_done = false; // stage 3 of this read ran on the device: finish_reads leaves its results alone
+        // the read's candidate alignments as the device listed them (job.dev_cals), until something on the host needs `cals`
+        int64_t dev_cal_at = -1;
+        int32_t n_dev_cals = 0;
     };
     std::vector<double> dev_scores;
+    std::vector<skcore::PCal> dev_cals;
     std::vector<Read> reads;
     sk_align_builder* builder = nullptr;
     int32_t n_cals_total = 0;
@@ -1117,6 +1125,7 @@ void build_core_tables(const Job& job, CoreTables& t, uint8_t* consulted)
 {
     t.tab.resize(job.tab.size());
     t.ins_pool.clear();
+    std::map<std::tuple<int, uint32_t, std::string>, uint32_t> shapes;
     for (size_t i = 0; i < job.tab.size(); ++i) {
         const Indel& d = job.tab[i];
         skcore::PIndel& p = t.tab[i];
@@ -1134,6 +1143,8 @@ void build_core_tables(const Job& job, CoreTables& t, uint8_t* consulted)
         }
         p.ins_off = uint32_t(t.ins_pool.size());
         t.ins_pool += d.key.ins;
+        // what is_equiv_candidate compares, as a number: equal shapes <=> equal (type, deletion length, insert sequence)
+        p.shape = shapes.emplace(std::make_tuple(int(d.key.type), d.key.del, d.key.ins), uint32_t(shapes.size())).first->second;
     }
     t.pj.tab = t.tab.data();
     t.pj.n_tab = int32_t(t.tab.size());
@@ -1952,6 +1963,14 @@ int sk_realign_job_enumeration_counts(const sk_realign_job* j, int64_t* n_core, 
     return 0;
 }
 
+int sk_realign_job_stage3_counts(const sk_realign_job* j, int64_t* n_core, int64_t* n_device)
+{
+    if (!j) return 1;
+    if (n_core) *n_core = j->n_stage3_core.load();
+    if (n_device) *n_device = j->n_stage3_device.load();
+    return 0;
+}
+
 int sk_realign_job_indels_consulted(const sk_realign_job* j, uint8_t* out, int32_t n_indels)
 {
     if (!j || !out || n_indels != int32_t(j->orig_to_tab.size())) return 1;
@@ -2208,6 +2227,91 @@ static int finish_builder(sk_realign_job* j, sk_align_batch* out)
 
 } // extern "C"
 
+// ---- stage 3 in its container-free form (csrc/stage3_core.h; the device runs the same code, read_enumerate.hip) ----
+struct Stage3Tables
+{
+    CoreTables core;
+    std::vector<double> r2i, i2r;
+    std::vector<int32_t> orig;
+    std::vector<uint8_t> consulted;
+    sk3::Tab tab;
+    sk3::Opt opt;
+};
+static void build_stage3_tables(const sk_realign_job& j, Stage3Tables& t)
+{
+    build_core_tables(j, t.core, nullptr);
+    const size_t n = j.tab.size();
+    t.r2i.resize(n);
+    t.i2r.resize(n);
+    t.orig.resize(n);
+    t.consulted.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        t.r2i[i] = j.tab[i].r2i;
+        t.i2r[i] = j.tab[i].i2r;
+        t.orig[i] = j.tab[i].orig;
+    }
+    t.tab.tab = t.core.tab.data();
+    t.tab.r2i = t.r2i.data();
+    t.tab.i2r = t.i2r.data();
+    t.tab.orig = t.orig.data();
+    t.tab.n_tab = int32_t(n);
+    t.tab.max_indel_size = int32_t(j.opt.max_indel_size);
+    t.tab.consulted = nullptr;
+    t.opt.is_smoothed_alignments = j.opt.is_smoothed_alignments;
+    t.opt.smoothed_lnp_range = j.opt.smoothed_lnp_range;
+    t.opt.upstream_oligo_size = j.opt.upstream_oligo_size;
+    t.opt.min_read_bp_flank = j.opt.min_read_bp_flank;
+}
+// a read's stage-3 results as the core (host or device) produced them -> the read's structures
+static void take_stage3_result(sk_realign_job::Read& rd, const bool fwd, const sk3::Out& o)
+{
+    rd.realigned = o.is_realigned != 0;
+    rd.realignment = Aln();
+    rd.realignment.pos = o.realign_pos;
+    rd.realignment.fwd = fwd;
+    for (int q = 0; q < o.n_seg; ++q) {
+        rd.realignment.path.push_back(Seg{ o.path[q].type, o.path[q].length });
+        rd.out_path.push_back(sk_path_seg{ o.path[q].type, o.path[q].length });
+    }
+    rd.max_score = o.max_score;
+    rd.scores.assign(o.scores, o.scores + o.n_scores);
+    rd.suboverlap.assign(o.sub, o.sub + o.n_sub);
+}
+// false: beyond a capacity of the core, or input the container-based code throws on -- that code decides
+static bool finish_read_core(const sk_realign_job& j, const Stage3Tables& t, sk_realign_job::Read& rd, const double* scores)
+{
+    const size_t n = rd.cals.size();
+    if (rd.code.size() > size_t(sk3::RL_MAX)) return false;
+    std::vector<skcore::PCal> cals(n);
+    for (size_t i = 0; i < n; ++i)
+        if (!to_core_cal(rd.cals[i], cals[i])) return false;
+    std::vector<int32_t> order(n), next_same(n), rm_pos(rd.code.size());
+    std::vector<double> smooth(n), sorted_score(n);
+    std::vector<uint32_t> key(4 * n), sorted_hash(n);
+    std::vector<uint8_t> flag(n), removed(n), rm_type(rd.code.size()), consulted(j.tab.size(), 0);
+    sk3::Tab tab = t.tab;
+    tab.consulted = consulted.data();
+    sk3::Read r;
+    r.cals = cals.data();
+    r.scores = scores;
+    r.scores_select = scores;
+    r.n_cals = int32_t(n);
+    r.map_level = rd.map_level;
+    r.read_length = int32_t(rd.code.size());
+    r.non_ambig = 0;
+    for (const uint8_t c : rd.code)
+        if (c != SK_BAM_ANY) ++r.non_ambig;
+    sk3::Scratch w{ flag.data(), key.data(), order.data(), sorted_score.data(), smooth.data(), sorted_hash.data(), next_same.data(), removed.data(), rm_type.data(), rm_pos.data() };
+    sk3::Out o;
+    sk3::Shared sh;
+    sk3::finish_read(sk3::HostLanes(), tab, t.opt, r, w, sh, o);
+    if (o.status != sk3::S3_OK) return false;
+    for (size_t i = 0; i < consulted.size(); ++i)
+        if (consulted[i]) (void)j.cand(int(i));
+    take_stage3_result(rd, rd.cals[0].al.fwd, o);
+    return true;
+}
+
 // enumeration == 2: hand every pending read to the device pipeline (csrc/read_enumerate.hip); afterwards every read of the job
 // has its candidate alignments (and, with `want_scores`, the device reads their scores in j.dev_scores).  Throws Fail.
 static void resolve_pending(sk_realign_job& j, const bool want_scores)
@@ -2253,6 +2357,19 @@ static void resolve_pending(sk_realign_job& j, const bool want_scores)
     in.read_qual = qual.data();
     in.max_read_len = max_read_len;
     in.want_scores = want_scores ? 1 : 0;
+    Stage3Tables s3t;
+    std::vector<int32_t> map_level(idx.size());
+    if (want_scores) { // the whole read path: stage 3 on the device as well
+        build_stage3_tables(j, s3t);
+        for (size_t k = 0; k < idx.size(); ++k) map_level[k] = j.reads[idx[k]].map_level;
+        in.want_stage3 = 1;
+        in.r2i = s3t.r2i.data();
+        in.i2r = s3t.i2r.data();
+        in.orig = s3t.orig.data();
+        in.map_level = map_level.data();
+        in.stage3_opt = s3t.opt;
+        if (const char* e = std::getenv("SK_STAGE3_DEVICE")) in.want_stage3 = std::atoi(e) ? 1 : 0;
+    }
     SkEnumOutput out;
     const bool timing = std::getenv("SK_ENUM_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -2263,22 +2380,38 @@ static void resolve_pending(sk_realign_job& j, const bool want_scores)
     const int32_t n_cals = out.cal_off[idx.size()];
     j.dev_scores.clear();
     if (want_scores && n_cals > 0) j.dev_scores.assign(out.scores, out.scores + n_cals);
+    j.dev_cals.clear();
+    if (out.stage3 && n_cals > 0) j.dev_cals.assign(out.cals, out.cals + n_cals);
     // device results -> the reads' structures (reads are independent: each slice of the loop touches only its own reads)
     const std::string err = parallel_for(idx.size(), host_threads(j, idx.size()), [&](const size_t k) {
         auto& rd = j.reads[idx[k]];
         rd.pending.reset();
         rd.dev_score_at = -1;
+        rd.dev_cal_at = -1;
+        rd.stage3_done = false;
         if (out.status[k] == skcore::ST_OK) {
             const int32_t b = out.cal_off[k], e = out.cal_off[k + 1];
             if (b == e) throw Fail("Empty candidate alignment set while realigning normed input alignment");
             rd.cals.clear();
-            rd.cals.reserve(size_t(e - b));
-            for (int32_t c = b; c < e; ++c) rd.cals.push_back(from_core_cal(out.cals[c]));
             rd.warn_origin = (out.warn[k] & 1) != 0;
             rd.warn_toggle = (out.warn[k] & 2) != 0;
             rd.incomplete_search = rd.warn_origin || rd.warn_toggle;
             if (want_scores) rd.dev_score_at = b;
             j.n_device_reads.fetch_add(1, std::memory_order_relaxed);
+            if (out.stage3 && out.stage3[k].status == sk3::S3_OK) {
+                // finished on the device: the candidate alignments stay in the device's form unless the host asks for them
+                rd.dev_cal_at = b;
+                rd.n_dev_cals = e - b;
+                rd.scores.clear();
+                rd.suboverlap.clear();
+                rd.out_path.clear();
+                take_stage3_result(rd, out.cals[b].fwd != 0, out.stage3[k]);
+                rd.stage3_done = true;
+                j.n_stage3_device.fetch_add(1, std::memory_order_relaxed);
+            } else {
+                rd.cals.reserve(size_t(e - b));
+                for (int32_t c = b; c < e; ++c) rd.cals.push_back(from_core_cal(out.cals[c]));
+            }
         } else {
             // beyond a capacity of the device form, or input the host code throws on: the container-based code decides
             const auto tf = std::chrono::steady_clock::now();
@@ -2296,12 +2429,21 @@ static void resolve_pending(sk_realign_job& j, const bool want_scores)
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
 }
 
+// a read finished on the device: its candidate alignments into the host's structures
+static void materialize_cals(const sk_realign_job& j, sk_realign_job::Read& rd)
+{
+    if (rd.dev_cal_at < 0 || !rd.cals.empty()) return;
+    rd.cals.reserve(size_t(rd.n_dev_cals));
+    for (int32_t c = 0; c < rd.n_dev_cals; ++c) rd.cals.push_back(from_core_cal(j.dev_cals[size_t(rd.dev_cal_at + c)]));
+}
+
 // enumeration == 2: (re)build the job's host batch from the reads' candidate alignments
 static void rebuild_host_batch(sk_realign_job* j)
 {
     sk_align_builder_clear(j->builder);
     j->n_cals_total = 0;
     for (auto& rd : j->reads) {
+        materialize_cals(*j, rd);
         rd.cal_begin = j->n_cals_total;
         j->n_cals_total += flatten_read(*j, j->builder, rd);
     }
@@ -2331,9 +2473,15 @@ template <typename ScoreOf>
 static int finish_reads(sk_realign_job* j, ScoreOf&& score_of)
 {
     try {
+        std::unique_ptr<Stage3Tables> core_tables;
+        if (j->opt.enumeration == 1) { // the container-free statement of stage 3, on this host
+            core_tables.reset(new Stage3Tables);
+            build_stage3_tables(*j, *core_tables);
+        }
         // reads are independent in stage 3 as well: each writes only its own results
         const std::string err = parallel_for(j->reads.size(), host_threads(*j, j->reads.size()), [&](const size_t ri) {
             auto& rd = j->reads[ri];
+            if (rd.stage3_done) return; // (the device finished this read)
             rd.scores.clear();
             rd.suboverlap.clear();
             rd.realigned = false;
@@ -2341,6 +2489,13 @@ static int finish_reads(sk_realign_job* j, ScoreOf&& score_of)
             if (rd.cals.empty()) return;
             const double* s = score_of(rd);
             if (!s) throw Fail("sk_realign_job_finish: null scores");
+            if (core_tables) {
+                if (finish_read_core(*j, *core_tables, rd, s)) {
+                    j->n_stage3_core.fetch_add(1, std::memory_order_relaxed);
+                    return;
+                }
+                rd.out_path.clear();
+            }
             const Cal* max_cal = nullptr;
             select_alignments(*j, rd, s, rd.max_score, max_cal);
             if (rd.map_level == SK_MAPLEVEL_TIER1 || rd.map_level == SK_MAPLEVEL_TIER2) // is_tier1or2_mapping :1800
@@ -2359,6 +2514,10 @@ static int finish_reads(sk_realign_job* j, ScoreOf&& score_of)
 extern "C" int sk_realign_job_finish(sk_realign_job* j, const double* scores)
 {
     if (!j) return 1;
+    for (auto& rd : j->reads) { // scores from the caller decide, whatever an earlier sk_realign_job_run left
+        materialize_cals(*j, rd);
+        rd.stage3_done = false;
+    }
     return finish_reads(j, [&](const sk_realign_job::Read& rd) -> const double* { return scores ? scores + rd.cal_begin : nullptr; });
 }
 
@@ -2426,7 +2585,7 @@ int sk_realign_job_read_result(const sk_realign_job* j, int32_t i, sk_read_resul
     if (!j || !out || i < 0 || size_t(i) >= j->reads.size()) return 1;
     const auto& rd = j->reads[size_t(i)];
     std::memset(out, 0, sizeof(*out));
-    out->n_candidate_alignments = int32_t(rd.cals.size());
+    out->n_candidate_alignments = rd.cals.empty() ? (rd.dev_cal_at >= 0 ? rd.n_dev_cals : 0) : int32_t(rd.cals.size());
     out->is_realigned = rd.realigned ? 1 : 0;
     out->realign_pos = rd.realignment.pos;
     out->realign_n_seg = int32_t(rd.out_path.size());

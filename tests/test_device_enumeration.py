@@ -5,7 +5,9 @@ core of strelka_amd/csrc/realign_core.h -- on the host (sk_realign_options.enume
     REFERENCE's realignAndScoreRead results (golden fixture + live reference where oracle/_ref is present) -- the
     std::set<CandidateAlignment> order included (the batch order feeds the tie rules of the selection);
   * the core must actually have run (enumeration counters), not the fallback;
-  * GPU: enumeration = 2 gives the same per-read results as enumeration = 0, on the golden scenarios and on dense ones.
+  * GPU: enumeration = 2 gives the same per-read results as enumeration = 0, on the golden scenarios and on dense ones;
+  * stage 3 (selection, clipping, score_indels) in its container-free form (csrc/stage3_core.h) is covered by the same runs:
+    on the host with enumeration = 1, in stage3_kernel with enumeration = 2 (sk_realign_job_stage3_counts says where it ran).
 """
 import os
 import pickle
@@ -22,6 +24,7 @@ from tests import test_read_realign as T
 def _run(scenarios, expect, mode, on_gpu):
     _, lnc, lne = capi.qscore_tables()
     core = dev = fb = reads = 0
+    _run.stage3 = [0, 0]
     for si, (sc, exp) in enumerate(zip(scenarios, expect)):
         job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
                                                    min_read_bp_flank=sc["min_read_bp_flank"], enumeration=mode))
@@ -38,6 +41,8 @@ def _run(scenarios, expect, mode, on_gpu):
             reads += 1
         a, b_, c = job.enumeration_counts()
         core, dev, fb = core + a, dev + b_, fb + c
+        s3 = job.stage3_counts()
+        _run.stage3 = [_run.stage3[0] + s3[0], _run.stage3[1] + s3[1]]
     return reads, core, dev, fb
 
 
@@ -51,6 +56,7 @@ def test_host_core_reproduces_the_reference_golden(gold):
     reads, core, dev, fb = _run(gold["scenarios"], gold["expect"], mode=1, on_gpu=False)
     assert reads > 400 and core > 200 and dev == 0
     assert fb <= core // 50  # the fixed capacities are rarely exceeded
+    assert _run.stage3[0] >= core * 0.98  # stage 3 ran in its container-free form as well (csrc/stage3_core.h)
 
 
 @pytest.mark.skipif(not pyoracle.ref_available(), reason="oracle/_ref not built")
@@ -61,6 +67,7 @@ def test_host_core_reproduces_the_live_reference(seed, max_indels, hap):
     exp = pyoracle.ref_realign_scenarios(scs)
     reads, core, dev, fb = _run(scs, exp, mode=1, on_gpu=False)
     assert reads >= 500 and core > 100
+    assert _run.stage3[0] >= core * 0.98
 
 
 @pytest.mark.gpu
@@ -69,6 +76,7 @@ def test_device_enumeration_reproduces_the_reference_golden(gold):
     reads, core, dev, fb = _run(gold["scenarios"], gold["expect"], mode=2, on_gpu=True)
     assert reads > 400 and dev > 200 and core == 0
     assert fb <= dev // 50
+    assert _run.stage3[1] >= dev * 0.95  # and stage 3 of those reads ran on the device as well (stage3_kernel)
 
 
 @pytest.mark.gpu
@@ -77,6 +85,7 @@ def test_device_enumeration_equals_host(seed, max_indels, hap):
     capi.init(0)
     rng = np.random.default_rng(91000 + seed)
     scs = synth.realign_scenarios(80, rng, reads_per=12, max_indels=max_indels, haplotyping_rate=hap)
+    n_dev = n_s3 = 0
     for sc in scs:
         res, cons = {}, {}
         for mode in (0, 2):
@@ -88,6 +97,9 @@ def test_device_enumeration_equals_host(seed, max_indels, hap):
             job.run()
             res[mode] = [None if i is None else job.result(i) for i in idx]
             cons[mode] = job.indels_consulted()
+            if mode == 2:
+                n_dev += job.enumeration_counts()[1]
+                n_s3 += job.stage3_counts()[1]
         for a, b in zip(res[0], res[2]):
             assert (a is None) == (b is None)
             if a is None:
@@ -95,6 +107,7 @@ def test_device_enumeration_equals_host(seed, max_indels, hap):
             assert repr(a) == repr(b)
         # the candidate status of exactly the same indels was looked up (the adapter commits its cache from this)
         assert np.array_equal(cons[0], cons[2])
+    assert n_dev > 200 and n_s3 >= n_dev * 0.9  # the whole read path of these reads ran on the device
 
 
 @pytest.mark.gpu

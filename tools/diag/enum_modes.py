@@ -60,15 +60,22 @@ def main():
     for name, kw, rep in (("sparse", dict(max_indels=6), 200), ("dense", dict(max_indels=14), 40)):
         rng = np.random.default_rng(5)
         scs = synth.realign_scenarios(24, rng, reads_per=12, **kw)
-        for mode in (0, 1, 2):
+        for mode, s3 in ((0, None), (1, None), (2, "0"), (2, "1")):  # (2, "0"): device enumeration + scoring, stage 3 on the host
+            import os
+            if s3 is None:
+                os.environ.pop("SK_STAGE3_DEVICE", None)
+            else:
+                os.environ["SK_STAGE3_DEVICE"] = s3
             jobs = build(scs, rep, mode)
             step(jobs)
             ta, tr = step(jobs)
             reads = sum(j[2] for j in jobs)
-            cals = sum(j[0].batch().n_cals for j in jobs)
             cnt = np.sum([j[0].enumeration_counts() for j in jobs], axis=0)
-            print("%s mode %d: %d reads %.1f cals/read  add %.1f ms run %.1f ms  -> %.3g reads/s  (core,dev,fallback)=%s" %
-                  (name, mode, reads, cals / reads, ta * 1e3, tr * 1e3, reads / (ta + tr), cnt.tolist()), flush=True)
+            cnt3 = np.sum([j[0].stage3_counts() for j in jobs], axis=0)
+            cals = sum(j[0].batch().n_cals for j in jobs)
+            print("%s mode %d%s: %d reads %.1f cals/read  add %.1f ms run %.1f ms  -> %.3g reads/s  (core,dev,fallback)=%s stage3(core,dev)=%s" %
+                  (name, mode, "" if s3 is None else " stage3-dev=" + s3, reads, cals / reads, ta * 1e3, tr * 1e3, reads / (ta + tr),
+                   cnt.tolist(), cnt3.tolist()), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """Device enumeration against the host code on fresh seeded scenarios (run on the GPU box): every read's result through
-sk_realign_job with enumeration = 2 (search, ordering, flattening and scoring in kernels) must equal enumeration = 0 (the
+sk_realign_job with enumeration = 2 (search, ordering, flattening, scoring and stage 3 in kernels) must equal enumeration = 0 (the
 container-based host statement, which tools/fuzz/fuzz_realign.py pins to the reference itself) -- the full per-read record, the
 candidate status lookups reported to the adapter, and the batch rebuilt from the device's candidate alignments.
 
@@ -18,7 +18,7 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     capi.init(0)
-    reads = cals = dev = host_instead = 0
+    reads = cals = dev = host_instead = s3_dev = 0
     t0 = time.time()
     for k in range(rounds):
         rng = np.random.default_rng(7_000_000 + first + k)
@@ -40,13 +40,14 @@ def main():
                     c = job.enumeration_counts()
                     dev += c[1]
                     host_instead += c[2]
+                    s3_dev += job.stage3_counts()[1]
             if res[0] != res[2] or not np.array_equal(cons[0], cons[2]) or not np.array_equal(off[0], off[2]):
                 print("MISMATCH: round", k, "seed", 7_000_000 + first + k)
                 sys.exit(1)
             reads += sum(r is not None for r in res[0])
             cals += int(off[0][-1])
-    print("device enumeration == host enumeration: %d reads, %d candidate alignments, %d enumerated on the device, %d handed to the host; "
-          "%.0f s" % (reads, cals, dev, host_instead, time.time() - t0))
+    print("device enumeration == host enumeration: %d reads, %d candidate alignments, %d enumerated on the device (stage 3 on the device: %d), "
+          "%d handed to the host; %.0f s" % (reads, cals, dev, s3_dev, host_instead, time.time() - t0))
 
 
 if __name__ == "__main__":
