@@ -164,6 +164,8 @@ struct SetArgs
     const int32_t* raw_off; // [n_reads+1] (reads that failed: empty)
     int32_t* fill;          // [n_reads] zeroed
     int32_t* grouped;       // [raw_off[n_reads]] leaf slots, read by read
+    uint32_t* ghash;        // [raw_off[n_reads]] their hashes
+    ulonglong2* gkey;       // [raw_off[n_reads]] their keys (leaf_key)
     uint8_t* dup;           // [raw_off[n_reads]]
     int32_t* n_uniq;        // [n_reads] zeroed
     const int32_t* cal_off; // [n_reads+1]
@@ -180,13 +182,37 @@ __device__ inline int group_of(const int32_t* off, const int n, const int g) // 
     return lo;
 }
 
+// The first fields cal_compare looks at (position, strand, number of segments, the first four segments), packed so that comparing
+// the two words as numbers is comparing those fields in cal_compare's order: most pairs of leaves are told apart by the key alone,
+// read from one contiguous array instead of from two 300-byte records
+__device__ inline ulonglong2 leaf_key(const PCal& c)
+{
+    auto seg = [&](const int i) -> unsigned long long { // 20 bits: type, length
+        return i < c.n_seg ? ((unsigned long long)(c.path[i].type & 0xfu) << 16) | c.path[i].length : 0ull;
+    };
+    ulonglong2 k;
+    k.x = ((unsigned long long)(uint32_t(c.pos) ^ 0x80000000u) << 32) | ((unsigned long long)(c.fwd ? 1 : 0) << 31) |
+          ((unsigned long long)(c.n_seg & 0x7fu) << 24) | (seg(0) << 4) | (seg(1) >> 16);
+    k.y = ((seg(1) & 0xffffull) << 48) | (seg(2) << 28) | (seg(3) << 8);
+    return k;
+}
+__device__ inline int key_compare(const ulonglong2& a, const ulonglong2& b)
+{
+    if (a.x != b.x) return a.x < b.x ? -1 : 1;
+    if (a.y != b.y) return a.y < b.y ? -1 : 1;
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void group_kernel(const SetArgs a)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.n_leaves) return;
     const int r = a.leaf_read[s];
     if (a.status[r] != ST_OK) return;
-    a.grouped[a.raw_off[r] + atomicAdd(&a.fill[r], 1)] = s;
+    const int g = a.raw_off[r] + atomicAdd(&a.fill[r], 1);
+    a.grouped[g] = s;
+    a.ghash[g] = a.leaf_hash[s];
+    a.gkey[g] = leaf_key(a.pool[s]);
 }
 
 // a leaf is a duplicate when an equal leaf stands before it in its read's group (which of the equal ones stands first differs
@@ -196,13 +222,10 @@ __global__ __launch_bounds__(256) void dedupe_kernel(const SetArgs a)
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.raw_off[a.n_reads]) return;
     const int r = group_of(a.raw_off, a.n_reads, g);
-    const int me = a.grouped[g];
-    const uint32_t h = a.leaf_hash[me];
+    const uint32_t h = a.ghash[g];
     bool dup = false;
-    for (int q = a.raw_off[r]; q < g && !dup; ++q) {
-        const int o = a.grouped[q];
-        if (a.leaf_hash[o] == h && cal_compare(a.pool[o], a.pool[me]) == 0) dup = true;
-    }
+    for (int q = a.raw_off[r]; q < g && !dup; ++q)
+        if (a.ghash[q] == h && cal_compare(a.pool[a.grouped[q]], a.pool[a.grouped[g]]) == 0) dup = true;
     a.dup[g] = dup ? 1 : 0;
     if (!dup) atomicAdd(&a.n_uniq[r], 1);
 }
@@ -215,9 +238,14 @@ __global__ __launch_bounds__(256) void rank_kernel(const SetArgs a)
     if (a.dup[g]) return;
     const int r = group_of(a.raw_off, a.n_reads, g);
     const PCal& mine = a.pool[a.grouped[g]];
+    const ulonglong2 kmine = a.gkey[g];
     int rank = 0;
-    for (int q = a.raw_off[r]; q < a.raw_off[r + 1]; ++q)
-        if (q != g && !a.dup[q] && cal_compare(a.pool[a.grouped[q]], mine) < 0) ++rank;
+    for (int q = a.raw_off[r]; q < a.raw_off[r + 1]; ++q) {
+        if (q == g || a.dup[q]) continue;
+        int c = key_compare(a.gkey[q], kmine);
+        if (c == 0) c = cal_compare(a.pool[a.grouped[q]], mine);
+        if (c < 0) ++rank;
+    }
     a.sorted[a.cal_off[r] + rank] = a.grouped[g];
 }
 
@@ -692,7 +720,7 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
 // pool disagrees, the late normalisation filter and score_indels -- one wavefront per read over the read's candidate alignments and
 // scores where the scoring kernel left them: the loops over alignments are spread over the 64 lanes, lane 0 takes the decisions the
 // reference defines by iteration order (see the header).  What leaves the device is a fixed-size record per read.
-enum { S3_LIGHT_CALS = 256, S3_LDS_CALS = 1800 }; // (1800 alignments: 53 KB; with the shared state that stays under 64 KB per workgroup)
+enum { S3_LIGHT_CALS = 256, S3_LDS_CALS = 1580 }; // (1580 alignments: 53 KB; with the shared state that stays under 64 KB per workgroup)
 
 struct WaveLanes
 {
@@ -720,6 +748,7 @@ struct Stage3Args
     double* sorted_score;
     uint32_t* sorted_hash;
     int32_t* next_same;
+    int32_t* range_end;
     uint8_t* removed;
     uint8_t* rm_type;
     int32_t* rm_pos;
@@ -759,6 +788,7 @@ __global__ __launch_bounds__(64) void stage3_kernel(const Stage3Args a)
     w.sorted_score = a.sorted_score + c0;
     w.sorted_hash = a.sorted_hash + c0;
     w.next_same = a.next_same + c0;
+    w.range_end = a.range_end + c0;
     w.removed = a.removed + c0;
     w.rm_type = a.rm_type + b0;
     w.rm_pos = a.rm_pos + b0;
@@ -769,7 +799,8 @@ __global__ __launch_bounds__(64) void stage3_kernel(const Stage3Args a)
         int32_t* ord = reinterpret_cast<int32_t*>(ssc + a.lds_cals);
         uint32_t* shs = reinterpret_cast<uint32_t*>(ord + a.lds_cals);
         int32_t* nxt = reinterpret_cast<int32_t*>(shs + a.lds_cals);
-        uint8_t* fl = reinterpret_cast<uint8_t*>(nxt + a.lds_cals);
+        int32_t* rend = nxt + a.lds_cals;
+        uint8_t* fl = reinterpret_cast<uint8_t*>(rend + a.lds_cals);
         uint8_t* rem = fl + a.lds_cals;
         for (int i = threadIdx.x; i < rd.n_cals; i += 64) sc[i] = rd.scores[i];
         __syncthreads();
@@ -778,6 +809,7 @@ __global__ __launch_bounds__(64) void stage3_kernel(const Stage3Args a)
         w.sorted_score = ssc;
         w.sorted_hash = shs;
         w.next_same = nxt;
+        w.range_end = rend;
         w.order = ord;
         w.flag = fl;
         w.removed = rem;
@@ -830,10 +862,10 @@ struct EnumBuffers
 {
     DevBuf tab, ins, toggle, ref, reads, read_off, read_code, read_qual, consulted;
     DevBuf level_a, level_b, counters, pool, leaf_read, leaf_hash, n_raw, status, warn;
-    DevBuf raw_off, fill, grouped, dup, n_uniq, sorted;
+    DevBuf raw_off, fill, grouped, ghash, gkey, dup, n_uniq, sorted;
     DevBuf n_ops, hap_len, win_begin, win_end, ins_lo, ins_hi, win_len, n_ins, ins_idx, ins_off;
     DevBuf cal_off, hap_off, cals, hap_code, op_off, ops, entries, evmask, scores, colmat, colmat_off, addmask;
-    DevBuf r2i, i2r, orig, map_level, s3_order, s3_smooth, s3_flag, s3_rm_type, s3_rm_pos, s3_key, s3_sorted_score, s3_sorted_hash, s3_next_same, s3_removed, s3_out, s3_list;
+    DevBuf r2i, i2r, orig, map_level, s3_order, s3_smooth, s3_flag, s3_rm_type, s3_rm_pos, s3_key, s3_sorted_score, s3_sorted_hash, s3_next_same, s3_range_end, s3_removed, s3_out, s3_list;
     HostBuf h_s3_out, h_s3_list;
     HostBuf h_status, h_warn, h_n_raw, h_raw_off, h_n_uniq, h_n_ops, h_hap_len, h_cal_off, h_hap_off, h_op_off, h_cals, h_scores,
         h_consulted, h_counters, h_colmat_off;
@@ -1049,6 +1081,8 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     for (int r = 0; r < n; ++r) h_raw_off[r + 1] = h_raw_off[r] + ((h_status[r] == ST_OK) ? h_n_raw[r] : 0);
     const int32_t n_grouped = h_raw_off[n];
     RES(grouped, 4 * size_t(n_grouped));
+    RES(ghash, 4 * size_t(n_grouped));
+    RES(gkey, 16 * size_t(n_grouped));
     RES(dup, size_t(n_grouped));
     RES(sorted, 4 * size_t(n_grouped));
     SetArgs sa;
@@ -1062,6 +1096,8 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     sa.raw_off = B.raw_off.as<int32_t>();
     sa.fill = B.fill.as<int32_t>();
     sa.grouped = B.grouped.as<int32_t>();
+    sa.ghash = B.ghash.as<uint32_t>();
+    sa.gkey = B.gkey.as<ulonglong2>();
     sa.dup = B.dup.as<uint8_t>();
     sa.n_uniq = B.n_uniq.as<int32_t>();
     sa.cal_off = B.cal_off.as<int32_t>();
@@ -1235,6 +1271,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
                 RES(s3_sorted_hash, 4 * size_t(n_cals));
                 RES(s3_next_same, 4 * size_t(n_cals));
                 RES(s3_removed, size_t(n_cals));
+                RES(s3_range_end, 4 * size_t(n_cals));
                 RES(s3_out, sizeof(sk3::Out) * size_t(n));
                 HRES(h_s3_out, sizeof(sk3::Out) * size_t(n));
                 H2D(r2i, in->r2i, 8 * size_t(in->n_tab));
@@ -1268,6 +1305,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
                 s3.sorted_hash = B.s3_sorted_hash.as<uint32_t>();
                 s3.next_same = B.s3_next_same.as<int32_t>();
                 s3.removed = B.s3_removed.as<uint8_t>();
+                s3.range_end = B.s3_range_end.as<int32_t>();
                 s3.out = B.s3_out.as<sk3::Out>();
                 // two launches: reads with few candidate alignments (small LDS, many wavefronts per CU) and the others
                 RES(s3_list, 4 * size_t(n));
@@ -1283,7 +1321,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
                     }
                 }
                 H2D(s3_list, h_list, 4 * size_t(n));
-                auto lds_bytes = [](const int cals) { return size_t(cals) * (8 + 8 + 4 + 4 + 4 + 1 + 1) + 8; };
+                auto lds_bytes = [](const int cals) { return size_t(cals) * (8 + 8 + 4 + 4 + 4 + 4 + 1 + 1) + 8; };
                 if (n_light > 0) {
                     s3.list = B.s3_list.as<int32_t>();
                     s3.lds_cals = S3_LIGHT_CALS;

@@ -50,6 +50,7 @@ struct Opt
     double smoothed_lnp_range;
     uint32_t upstream_oligo_size;
     int32_t min_read_bp_flank;
+    int32_t no_tables; // (tests: score_indels without its per-read conflict tables, as for reads whose indels span too much of the table)
 };
 
 struct Read
@@ -73,6 +74,7 @@ struct Scratch // per read, sized by the caller; [n_cals] each unless noted
     double* smooth;        // its smoothed score (may be the memory of Read::scores_select)
     uint32_t* sorted_hash; // cal_shape_hash
     int32_t* next_same;    // see late_indel_normalization_filter
+    int32_t* range_end;    // the first place whose score is out of range of this place's score
     uint8_t* removed;
     uint8_t* rm_type; // [read_length] clipper's per-base map
     int32_t* rm_pos;  // [read_length]
@@ -382,8 +384,8 @@ struct Shared
     int32_t n_raised;
     uint32_t raised_bits[RAISED_WORDS]; // a set of (shape hash mod size) of the places whose smoothed score is no longer their score
     long long idx_hi, idx_nlo; // the largest table index in the read's alignments, the largest negated one
-    int32_t idx_min, use_conf;
-    uint8_t conf[E_MAX][CONF_SPAN]; // conf[q][i - idx_min]: table indel i (not a mismatch) conflicts with evaluated indel q
+    uint16_t conf_mask[CONF_SPAN]; // [i - idx_min]: the evaluated indels table indel i (not a mismatch) conflicts with
+    uint8_t eval_slot[CONF_SPAN];  // [i - idx_min]: which evaluated indel table indel i is, 0xff: none
     int32_t lo, hi, ne, want_best;
     int16_t to_eval[E_MAX];
     uint32_t ortho[E_MAX];
@@ -542,18 +544,37 @@ SKC_HD inline uint32_t cal_shape_hash(const Tab& t, const PCal& c)
     return h;
 }
 
+// which of the two alignments' indels (same count, ascending) differ: bit q = pair q.  Both lists are read whole, with loads that
+// do not wait for each other, instead of entry by entry behind the comparison of the previous entries
+SKC_HD inline uint64_t differing_pairs(const PCal& a, const PCal& b)
+{
+    enum { WORDS = (Caps::K + 2) / 2 };
+    static_assert((Caps::K + 2) % 2 == 0 && Caps::K + 2 <= 64, "indel lists are compared as 32-bit words, one bit per entry");
+    uint32_t wa[WORDS], wb[WORDS];
+    __builtin_memcpy(wa, a.indels, sizeof(wa));
+    __builtin_memcpy(wb, b.indels, sizeof(wb));
+    uint64_t d = 0;
+    for (int w = 0; w < WORDS; ++w) {
+        const uint32_t x = wa[w] ^ wb[w];
+        if (x & 0xffffu) d |= uint64_t(1) << (2 * w);
+        if (x >> 16) d |= uint64_t(1) << (2 * w + 1);
+    }
+    const int n = a.n_indels;
+    return n >= 64 ? d : (d & ((uint64_t(1) << n) - 1)); // (entries past the count are not part of the lists)
+}
+
 // is_equiv_candidate :240-269: the same indels up to position, with at least one pair that differs
 SKC_HD inline bool equiv_with_pairs(const Tab& t, const PCal& a, const PCal& b)
 {
     if (a.n_indels != b.n_indels) return false;
-    int n_pairs = 0;
-    for (int q = 0; q < a.n_indels; ++q) {
-        if (a.indels[q] == b.indels[q]) continue;
+    uint64_t d = differing_pairs(a, b);
+    if (d == 0) return false;
+    for (; d != 0; d &= d - 1) {
+        const int q = __builtin_ctzll(d);
         // same type, deletion length and insert SEQUENCE (equal insert lengths with different sequences are different keys)
         if (t.tab[a.indels[q]].shape != t.tab[b.indels[q]].shape) return false;
-        ++n_pairs;
     }
-    return n_pairs > 0;
+    return true;
 }
 
 // ---- late_indel_normalization_filter :303-450 ----
@@ -586,8 +607,8 @@ SKC_HD inline Applied apply_equivalent(const Tab& t, const Read& rd, const Scrat
     Applied r;
     r.s1_removed = r.x1_raised = false;
     bool removed = false;
-    for (int q = 0; q < a.n_indels; ++q) { // the pairs in set order (a is ascending)
-        if (a.indels[q] == b.indels[q]) continue;
+    for (uint64_t d = differing_pairs(a, b); d != 0; d &= d - 1) { // the pairs in set order (a is ascending)
+        const int q = __builtin_ctzll(d);
         const int p1 = a.indels[q], p2 = b.indels[q];
         const bool c1 = tab_cand(t, p1), c2 = tab_cand(t, p2); // is_first_indel_dominant :276-292
         bool first_dom;
@@ -680,6 +701,12 @@ SKC_HD inline void late_indel_normalization_filter(const L& ln, const Tab& t, co
         }
         w.next_same[i1] = nxt;
         if (nxt >= 0) sh.found = 1;
+        int lo = i1 + 1, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (w.sorted_score[mid] + equiv_range < x1) hi = mid; else lo = mid + 1;
+        }
+        w.range_end[i1] = lo;
     }
     ln.sync();
     if (!sh.found) return; // no two alignments can be equivalent: the reference's loop changes nothing
@@ -696,10 +723,14 @@ SKC_HD inline void late_indel_normalization_filter(const L& ln, const Tab& t, co
             double x1 = w.smooth[i1];
             int last = i1;
             bool s1_removed = false;
-            for (; m >= 0; m = w.next_same[m]) {
+            for (int prev = i1; m >= 0; m = w.next_same[m]) {
                 if (w.sorted_score[m] + equiv_range < x1) break; // past the places in range by score
                 last = m;
-                if (w.removed[m]) continue;
+                if (w.removed[m]) { // (removed for good: later walks need not pass here again)
+                    w.next_same[prev] = w.next_same[m];
+                    continue;
+                }
+                prev = m;
                 if (!equiv_with_pairs(t, rd.cals[w.order[i1]], rd.cals[w.order[m]])) continue;
                 const Applied ap = apply_equivalent(t, rd, w, sh, i1, m);
                 if (ap.s1_removed) {
@@ -709,15 +740,16 @@ SKC_HD inline void late_indel_normalization_filter(const L& ln, const Tab& t, co
                 if (ap.x1_raised) x1 = w.smooth[i1];
             }
             if (s1_removed || !tail) continue;
-            int p;
-            { // the first place out of range by score
-                int lo = i1 + 1, hi = n;
+            int p = w.range_end[i1]; // the first place out of range by score
+            if (x1 != w.sorted_score[i1]) { // (x1 was raised: the range is narrower)
+                int lo = i1 + 1, hi = p;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if (w.sorted_score[mid] + equiv_range < x1) hi = mid; else lo = mid + 1;
                 }
-                p = (lo > last) ? lo : last + 1;
+                p = lo;
             }
+            if (p <= last) p = last + 1;
             const uint32_t h1 = w.sorted_hash[i1];
             for (; p < n; ++p) {
                 if (w.removed[p]) continue;
@@ -855,18 +887,25 @@ SKC_HD inline void score_indels(const L& ln, const Tab& t, const Opt& opt, const
                 }
     }
     for (int k = ln.id; k < 2 * ne * ne; k += ln.width) sh.info[k] = SK3_NO_ENTRY;
-    // conflicts between the evaluated indels and every table indel the alignments can hold, once per read
+    // Once per read, for every table indel the alignments can hold: which evaluated indels it conflicts with (which_interfering_indel
+    // skips mismatches: they get no bits) and which evaluated indel it is -- the per-alignment loop below reads these instead of
+    // comparing table entries
     const int idx_min = int(-sh.idx_nlo), idx_span = int(sh.idx_hi) - idx_min + 1;
-    const bool use_conf = (idx_span > 0 && idx_span <= CONF_SPAN);
-    if (use_conf)
-        for (int k = ln.id; k < ne * idx_span; k += ln.width) {
-            const int q = k / idx_span, d = k - q * idx_span;
+    const bool use_tables = (idx_span > 0 && idx_span <= CONF_SPAN && ne > 0 && !opt.no_tables);
+    if (use_tables)
+        for (int d = ln.id; d < idx_span; d += ln.width) {
             const PIndel& cur = t.tab[idx_min + d];
-            sh.conf[q][d] = (!is_mismatch(cur) && is_indel_conflict(cur, t.tab[sh.to_eval[q]])) ? 1 : 0;
+            uint32_t mask = 0;
+            uint8_t slot = 0xff;
+            for (int q = 0; q < ne; ++q) {
+                if (sh.to_eval[q] == idx_min + d) slot = uint8_t(q);
+                if (!is_mismatch(cur) && is_indel_conflict(cur, t.tab[sh.to_eval[q]])) mask |= 1u << q;
+            }
+            sh.conf_mask[d] = uint16_t(mask);
+            sh.eval_slot[d] = slot;
         }
     ln.sync();
     auto interferes = [&](const int cur, const int q) -> bool { // a non-mismatch indel of the table against evaluated indel q
-        if (use_conf) return sh.conf[q][cur - idx_min] != 0;
         return !is_mismatch(t.tab[cur]) && is_indel_conflict(t.tab[cur], t.tab[sh.to_eval[q]]);
     };
 
@@ -875,6 +914,52 @@ SKC_HD inline void score_indels(const L& ln, const Tab& t, const Opt& opt, const
         if (w.flag[ci] & 1) continue;
         const PCal& c = rd.cals[ci];
         const double score = rd.scores[ci];
+        if (use_tables) {
+            uint32_t in_cal = 0, seen = 0; // evaluated indels the alignment holds / does not hold but interferes with
+            for (int a = 0; a < c.n_indels; ++a) {
+                const uint8_t slot = sh.eval_slot[c.indels[a] - idx_min];
+                if (slot != 0xff) in_cal |= 1u << slot;
+            }
+            // the alignment's non-evaluated indels that are the first to interfere with an evaluated one (ascending, no repeats)
+            int16_t noncand_ortho[E_MAX];
+            int n_nco = 0;
+            for (int a = 0; a < c.n_indels; ++a) {
+                const int d = c.indels[a] - idx_min;
+                const uint32_t first_for = sh.conf_mask[d] & ~in_cal & ~seen;
+                if (first_for == 0) continue;
+                seen |= first_for;
+                if (sh.eval_slot[d] != 0xff) continue;
+                if (n_nco >= E_MAX) {
+                    sh.status = S3_CAPACITY;
+                    break;
+                }
+                noncand_ortho[n_nco++] = c.indels[a];
+            }
+            for (int q = 0; q < ne; ++q) {
+                const int e = sh.to_eval[q];
+                if ((in_cal >> q) & 1u) {
+                    info_update(ln, sh, q, true, q, score);
+                    info_update(ln, sh, q, false, q, score + t.r2i[e]);
+                    for (uint32_t om = sh.ortho[q]; om != 0; om &= om - 1) {
+                        const int o = __builtin_ctz(om);
+                        info_update(ln, sh, o, false, o, score + t.r2i[e]);
+                        info_update(ln, sh, o, true, q, score);
+                    }
+                } else if ((seen >> q) & 1u) {
+                    info_update(ln, sh, q, true, q, score + t.i2r[e]);
+                } else {
+                    info_update(ln, sh, q, false, q, score);
+                    info_update(ln, sh, q, true, q, score + t.i2r[e]);
+                }
+            }
+            for (int z = 0; z < n_nco; ++z) {
+                const int nc = noncand_ortho[z];
+                for (uint32_t qm = sh.conf_mask[nc - idx_min]; qm != 0; qm &= qm - 1)
+                    info_update(ln, sh, __builtin_ctz(qm), false, __builtin_ctz(qm), score + t.r2i[nc]);
+            }
+            continue;
+        }
+        // (alignments whose indels span more of the table than the tables hold: the same from the table entries)
         uint32_t in_cal = 0;
         {
             int a = 0;

@@ -2261,6 +2261,7 @@ static void build_stage3_tables(const sk_realign_job& j, Stage3Tables& t)
     t.opt.smoothed_lnp_range = j.opt.smoothed_lnp_range;
     t.opt.upstream_oligo_size = j.opt.upstream_oligo_size;
     t.opt.min_read_bp_flank = j.opt.min_read_bp_flank;
+    t.opt.no_tables = std::getenv("SK_STAGE3_NO_TABLES") ? 1 : 0;
 }
 // a read's stage-3 results as the core (host or device) produced them -> the read's structures
 static void take_stage3_result(sk_realign_job::Read& rd, const bool fwd, const sk3::Out& o)
@@ -2285,7 +2286,7 @@ static bool finish_read_core(const sk_realign_job& j, const Stage3Tables& t, sk_
     std::vector<skcore::PCal> cals(n);
     for (size_t i = 0; i < n; ++i)
         if (!to_core_cal(rd.cals[i], cals[i])) return false;
-    std::vector<int32_t> order(n), next_same(n), rm_pos(rd.code.size());
+    std::vector<int32_t> order(n), next_same(n), range_end(n), rm_pos(rd.code.size());
     std::vector<double> smooth(n), sorted_score(n);
     std::vector<uint32_t> key(4 * n), sorted_hash(n);
     std::vector<uint8_t> flag(n), removed(n), rm_type(rd.code.size()), consulted(j.tab.size(), 0);
@@ -2301,7 +2302,7 @@ static bool finish_read_core(const sk_realign_job& j, const Stage3Tables& t, sk_
     r.non_ambig = 0;
     for (const uint8_t c : rd.code)
         if (c != SK_BAM_ANY) ++r.non_ambig;
-    sk3::Scratch w{ flag.data(), key.data(), order.data(), sorted_score.data(), smooth.data(), sorted_hash.data(), next_same.data(), removed.data(), rm_type.data(), rm_pos.data() };
+    sk3::Scratch w{ flag.data(), key.data(), order.data(), sorted_score.data(), smooth.data(), sorted_hash.data(), next_same.data(), range_end.data(), removed.data(), rm_type.data(), rm_pos.data() };
     sk3::Out o;
     sk3::Shared sh;
     sk3::finish_read(sk3::HostLanes(), tab, t.opt, r, w, sh, o);
