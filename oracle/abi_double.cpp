@@ -310,6 +310,8 @@ int sk_global_align(const sk_global_align_batch* b, const sk_align_scores* score
 struct SkEnumInput;
 struct SkEnumOutput;
 extern "C" int sk_enum_device_available(void) { return 0; }
+namespace skcore { struct PCal; }
+extern "C" int sk_enum_device_fetch_cals(uint64_t, int32_t, int32_t, skcore::PCal*) { return 1; }
 extern "C" int sk_enum_device_run(const SkEnumInput*, SkEnumOutput*)
 {
     return sk_fail("candidate enumeration on the device (sk_realign_options.enumeration = 2) needs the GPU library");

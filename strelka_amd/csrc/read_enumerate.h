@@ -42,13 +42,18 @@ struct SkEnumOutput // host arrays owned by the pipeline, valid until its next r
     const int32_t* status;     // [n_reads] skcore::ST_*; anything but ST_OK: the read has no entries below, enumerate it on the host
     const uint8_t* warn;       // [n_reads] bit 0: origin warning, bit 1: toggle-depth warning
     const int32_t* cal_off;    // [n_reads+1]
-    const skcore::PCal* cals;  // [cal_off[n_reads]] each read's candidate alignments in set order
+    const skcore::PCal* cals;  // [cal_off[n_reads]] each read's candidate alignments in set order; null with want_stage3: they stay on
+                               // the device (sk_enum_device_fetch_cals) -- 288 bytes per alignment that the host rarely needs
+    uint64_t generation;       // of this run, for sk_enum_device_fetch_cals
     const double* scores;      // [cal_off[n_reads]] or null
     const uint8_t* consulted;  // [n_tab] candidate status consulted by the search, the flattening or stage 3
     const sk3::Out* stage3;    // [n_reads] or null; stage3[r].status != S3_OK (or status[r] != ST_OK): stage 3 of the read is the host's
 };
 
 extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out);
+
+/** candidate alignments [first, first + count) of run `generation`, from the device's buffers; 1 when another run has replaced them */
+extern "C" int sk_enum_device_fetch_cals(uint64_t generation, int32_t first, int32_t count, skcore::PCal* out);
 
 /** whether enumeration == 2 can run (it is the default where it can): 1 in the GPU library once sk_init has succeeded, 0 before
  *  that and in the CPU double of the ABI */

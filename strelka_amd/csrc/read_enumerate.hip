@@ -880,11 +880,30 @@ EnumBuffers& bufs()
 
 extern "C" int sk_enum_device_available(void) { return sk_ctx().ready ? 1 : 0; } // (host stages alone run without a device)
 
+namespace
+{
+uint64_t g_generation = 0; // of the run whose candidate alignments the buffers hold
+int32_t g_n_cals = 0;
+} // namespace
+
+extern "C" int sk_enum_device_fetch_cals(const uint64_t generation, const int32_t first, const int32_t count, PCal* dst)
+{
+    if (generation != g_generation || first < 0 || count < 0 || first + count > g_n_cals) return 1;
+    if (count == 0) return 0;
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(hipMemcpyAsync(dst, bufs().cals.as<PCal>() + first, sizeof(PCal) * size_t(count), hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
 extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
 {
     SK_REQUIRE_INIT();
     if (!in || !out) return sk_fail("sk_enum_device_run: null argument");
     std::memset(out, 0, sizeof(*out));
+    out->generation = ++g_generation;
+    g_n_cals = 0;
     const int n = in->n_reads;
     if (n < 0 || in->n_tab < 0) return sk_fail("sk_enum_device_run: negative count");
     SkContext& ctx = sk_ctx();
@@ -1200,9 +1219,10 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     RES(colmat, 4 * size_t(colmat_words) + 16);
     RES(colmat_off, 8 * size_t(n + 1));
     RES(addmask, 4 * (size_t(n) * size_t(W) + 1));
-    HRES(h_cals, sizeof(PCal) * size_t(n_cals));
+    if (!(in->want_scores && in->want_stage3)) HRES(h_cals, sizeof(PCal) * size_t(n_cals));
     HRES(h_scores, 8 * size_t(n_cals));
     out->cals = B.h_cals.as<PCal>();
+    g_n_cals = n_cals;
 
     if (n_cals > 0) {
         SK_HIP(hipMemcpyAsync(B.hap_off.p, h_hap_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
@@ -1226,7 +1246,8 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         hipLaunchKernelGGL(pool_fill_kernel, dim3(n), dim3(64), 0, st, fa);
         hipLaunchKernelGGL(flatten_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
         SK_HIP(hipGetLastError());
-        D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
+        if (in->want_scores && in->want_stage3) out->cals = nullptr; // (they stay here: sk_enum_device_fetch_cals)
+        else D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
         if (in->want_scores) {
             hipLaunchKernelGGL(entries_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
             SK_HIP(hipGetLastError());

@@ -474,7 +474,7 @@ struct sk_realign_job
         int32_t n_dev_cals = 0;
     };
     std::vector<double> dev_scores;
-    std::vector<skcore::PCal> dev_cals;
+    uint64_t dev_generation = 0; // the device run that holds the candidate alignments of the reads finished there
     std::vector<Read> reads;
     sk_align_builder* builder = nullptr;
     int32_t n_cals_total = 0;
@@ -2381,8 +2381,16 @@ static void resolve_pending(sk_realign_job& j, const bool want_scores)
     const int32_t n_cals = out.cal_off[idx.size()];
     j.dev_scores.clear();
     if (want_scores && n_cals > 0) j.dev_scores.assign(out.scores, out.scores + n_cals);
-    j.dev_cals.clear();
-    if (out.stage3 && n_cals > 0) j.dev_cals.assign(out.cals, out.cals + n_cals);
+    j.dev_generation = out.generation;
+    // reads the device enumerated but did not finish (a capacity of stage 3): their candidate alignments come over now
+    std::vector<std::vector<skcore::PCal>> unfinished(idx.size());
+    if (out.stage3 && !out.cals)
+        for (size_t k = 0; k < idx.size(); ++k)
+            if (out.status[k] == skcore::ST_OK && out.stage3[k].status != sk3::S3_OK) {
+                unfinished[k].resize(size_t(out.cal_off[k + 1] - out.cal_off[k]));
+                if (sk_enum_device_fetch_cals(out.generation, out.cal_off[k], int32_t(unfinished[k].size()), unfinished[k].data()))
+                    throw Fail(std::string("device enumeration: candidate alignments not available: ") + sk_last_error());
+            }
     // device results -> the reads' structures (reads are independent: each slice of the loop touches only its own reads)
     const std::string err = parallel_for(idx.size(), host_threads(j, idx.size()), [&](const size_t k) {
         auto& rd = j.reads[idx[k]];
@@ -2406,12 +2414,12 @@ static void resolve_pending(sk_realign_job& j, const bool want_scores)
                 rd.scores.clear();
                 rd.suboverlap.clear();
                 rd.out_path.clear();
-                take_stage3_result(rd, out.cals[b].fwd != 0, out.stage3[k]);
+                take_stage3_result(rd, rd.input.fwd, out.stage3[k]); // (candidate alignments keep the read's strand)
                 rd.stage3_done = true;
                 j.n_stage3_device.fetch_add(1, std::memory_order_relaxed);
             } else {
                 rd.cals.reserve(size_t(e - b));
-                for (int32_t c = b; c < e; ++c) rd.cals.push_back(from_core_cal(out.cals[c]));
+                for (int32_t c = b; c < e; ++c) rd.cals.push_back(from_core_cal(out.cals ? out.cals[c] : unfinished[k][size_t(c - b)]));
             }
         } else {
             // beyond a capacity of the device form, or input the host code throws on: the container-based code decides
@@ -2434,8 +2442,13 @@ static void resolve_pending(sk_realign_job& j, const bool want_scores)
 static void materialize_cals(const sk_realign_job& j, sk_realign_job::Read& rd)
 {
     if (rd.dev_cal_at < 0 || !rd.cals.empty()) return;
-    rd.cals.reserve(size_t(rd.n_dev_cals));
-    for (int32_t c = 0; c < rd.n_dev_cals; ++c) rd.cals.push_back(from_core_cal(j.dev_cals[size_t(rd.dev_cal_at + c)]));
+    std::vector<skcore::PCal> cals(size_t(rd.n_dev_cals));
+    if (sk_enum_device_fetch_cals(j.dev_generation, int32_t(rd.dev_cal_at), rd.n_dev_cals, cals.data()) == 0) {
+        rd.cals.reserve(cals.size());
+        for (const skcore::PCal& c : cals) rd.cals.push_back(from_core_cal(c));
+    } else {
+        enumerate_read(j, rd, true); // (the device has run another job since: the host lists them again, the same ones)
+    }
 }
 
 // enumeration == 2: (re)build the job's host batch from the reads' candidate alignments

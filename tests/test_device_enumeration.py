@@ -140,19 +140,37 @@ def test_device_capacity_overflow_falls_back_to_the_host(monkeypatch):
 @pytest.mark.gpu
 def test_device_batch_scores_equal_host_batch_scores():
     """get_batch after a device run rebuilds the host batch from the device's candidate alignments: same alignments, same order,
-    and the device's scores are the host batch's scores bit for bit"""
+    and the device's scores are the host batch's scores bit for bit.  The candidate alignments of reads finished on the device
+    stay there: get_batch right after the run fetches them, get_batch after ANOTHER job has run lists them again on the host, and
+    get_batch without a run has the device list them without scoring."""
     capi.init(0)
     rng = np.random.default_rng(91088)
-    for sc in synth.realign_scenarios(20, rng, reads_per=12, max_indels=10):
-        out = {}
-        for mode in (0, 2):
+    later = []
+    for si, sc in enumerate(synth.realign_scenarios(24, rng, reads_per=12, max_indels=10)):
+        def job_of(mode):
             job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
                                                        min_read_bp_flank=sc["min_read_bp_flank"], enumeration=mode))
             job.set_reference(sc["ref_seq"], sc["ref_offset"])
             job.set_indels(sc["indels"])
             T._add_reads(job, sc)
-            job.run()
-            b = job.batch()
-            out[mode] = (np.array(b.cal_off), capi.score_alignments(b))
-        assert np.array_equal(out[0][0], out[2][0])
-        assert np.array_equal(out[0][1].view(np.uint64), out[2][1].view(np.uint64))
+            return job
+        host = job_of(0)
+        host.run()
+        b = host.batch()
+        want = (np.array(b.cal_off), capi.score_alignments(b))
+        dev = job_of(2)
+        if si % 3 == 2:
+            later.append((dev, want))  # no run at all: enumeration only
+            continue
+        dev.run()
+        if si % 3 == 1:
+            later.append((dev, want))  # batch asked for after other jobs have used the device
+            continue
+        b = dev.batch()
+        assert np.array_equal(want[0], np.array(b.cal_off))
+        assert np.array_equal(want[1].view(np.uint64), capi.score_alignments(b).view(np.uint64))
+    assert len(later) >= 12
+    for dev, want in later:
+        b = dev.batch()
+        assert np.array_equal(want[0], np.array(b.cal_off))
+        assert np.array_equal(want[1].view(np.uint64), capi.score_alignments(b).view(np.uint64))
