@@ -333,8 +333,9 @@ def main():
         "roofline_global_align": roof("global_align_kernel", ga_alg_bytes, kms_ga, traffic.get("global_align_kernel")),
         "realign_host_threads": 1,
         "realign_note": "whole read path (rows a1-a7) through sk_realign_job_add_reads + _run, one host thread, host buffers in and out; "
-                        "realign_* = candidate alignments listed, flattened and scored on the device (enumeration=2), *_host_enumeration = "
-                        "listed and flattened on the host (round 1's path), *_dense = scenarios with up to 14 indels around a read",
+                        "realign_* = candidate alignments listed, flattened, scored and selected / indel-scored (stage 3) on the device "
+                        "(enumeration=2), *_host_enumeration = listed, flattened and finished on the host (round 1's path), *_dense = scenarios "
+                        "with up to 14 indels around a read",
         "feed_inflated_bytes_per_s": feed_bytes / dt_f, "feed_ms_per_step": dt_f / max(2, args.steps // 4) * 1e3, "feed_bgzf_blocks_per_step": feed_blocks,
         "roofline_feed": roof("bgzf_inflate_kernel+bgzf_crc32_kernel", feed_alg_bytes, kms_f, None),
         "global_align_cells_per_s": ga_cells / dt_ga, "global_align_ms_per_step": dt_ga / args.steps * 1e3,
