@@ -785,7 +785,9 @@ int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* dev_batch, 
  * RFC 1951; CRC-32 and ISIZE of every block checked) and decoded by kernels (csrc/bam_feed.hip).
  * normalizeAlignment (L/starling_common/normalizeAlignment.cpp:647-703), which the reference applies to every read as it comes
  * off the stream (starling_run.cpp / strelka_run.cpp via normalizeBamRecordAlignment :707-727), is the third kernel.
- * Not built: the index (.bai) lookup, CRAM, the gVCF writer.
+ * The index: sk_bai_query is hts_itr_query over a .bai image, sk_bam_region_filter the record test of hts_itr_next -- together with the
+ * calls above, what sam_itr_queryi / sam_itr_next (bam_streamer.cpp:228, :268) do for a region.
+ * Not built: CRAM, the gVCF writer.
  * ---------------------------------------------------------------------------------------------------------------- */
 
 /** The BGZF blocks of a file image (or of any run of whole blocks): block_off[i] = start of block i, out_off[i] = where its inflated
@@ -823,6 +825,21 @@ int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_
 int sk_bam_decode_dev(const uint8_t* dev_stream, const int64_t* dev_rec_off, int32_t n_records, const int64_t* dev_read_off,
                       const int64_t* dev_path_off, sk_bam_record* dev_rec, uint8_t* dev_read_code, uint8_t* dev_read_qual,
                       sk_path_seg* dev_path, void* hip_stream);
+
+typedef struct sk_bai_chunk { /* hts_pair64_t: BGZF virtual offsets, (offset of the block in the file) << 16 | offset in the inflated block */
+    uint64_t begin, end;
+} sk_bai_chunk;
+/** hts_itr_query (htslib hts.c:2066-2169, what sam_itr_queryi of L/htsapi/bam_streamer.cpp:228 runs) over the image of a .bai file
+ *  (SAM spec 5.2): the chunks of the BAM that can hold records overlapping [begin, end) of reference ref_id -- the bins of reg2bins
+ *  (:1939-1955), bounded below by the linear index (update_loff :1379-1408) and above by the next existing bin, sorted and merged as
+ *  htslib leaves them.  Records are read from chunk.begin on, one after the other, while their start is before chunk.end.
+ *  Returns the number of chunks (may exceed max_chunks: call again), -1 = malformed index, -2 = ref_id not in the index. */
+int32_t sk_bai_query(const uint8_t* bai, int64_t bai_len, int32_t ref_id, int32_t begin, int32_t end, sk_bai_chunk* out, int32_t max_chunks);
+/** The record test of hts_itr_next (hts.c:2621-2631) on decoded records in the order the chunks give them: keep[i] = 1 for a record
+ *  of ref_id that overlaps [begin, end) (its end: bam_endpos, sam.c:359-365).  Returns how many records the iterator reads before it
+ *  finishes -- at the first record of another reference or starting at or after `end`; keep is 0 from there on. */
+int32_t sk_bam_region_filter(const sk_bam_record* rec, const int64_t* path_off, const sk_path_seg* path, int32_t n_records, int32_t ref_id,
+                             int32_t begin, int32_t end, uint8_t* keep);
 
 /** normalizeAlignment for n_reads alignments against one reference segment, IN PLACE: indels inside the alignment are collapsed
  *  and left-shifted, edge indels normalised, the path cleaned (apath_cleaner).  Read r: bases read_code[read_off[r]..), alignment

@@ -197,7 +197,7 @@ EXPORTS = [
     "sk_somatic_snv_call_tiers", "sk_somatic_snv_call_tiers_dev", "sk_somatic_snv_tiers_scratch_bytes",
     "sk_indel_options_default", "sk_somatic_indel_options_default", "sk_indel_grid_lhood", "sk_indel_grid_lhood_dev",
     "sk_somatic_indel_call_batch", "sk_somatic_indel_call_tiers", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
-    "sk_discover_indels_and_mismatches", "sk_global_align_scratch_bytes", "sk_global_align_dev",
+    "sk_discover_indels_and_mismatches", "sk_global_align_scratch_bytes", "sk_global_align_dev", "sk_bai_query", "sk_bam_region_filter",
 ]
 
 _lib = None
@@ -1089,3 +1089,88 @@ def normalize_alignments(ref_seq, ref_offset, reads, library=None):
         seg = path[int(path_off[i]):int(path_off[i]) + int(n_seg[i])]
         out.append((int(changed[i]), int(pos[i]), [(int(t), int(l)) for t, l in seg]))
     return out
+
+
+BAI_CHUNK_DTYPE = np.dtype([("begin", "<u8"), ("end", "<u8")])
+
+
+def bai_query(bai, ref_id, begin, end):
+    """hts_itr_query over a .bai image -> the chunks (BGZF virtual offsets) that can hold records overlapping [begin, end)"""
+    bai = np.ascontiguousarray(bai, np.uint8)
+    L = lib()
+    L.sk_bai_query.restype = C.c_int32
+    L.sk_bai_query.argtypes = [c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_void_p, C.c_int32]
+    n = L.sk_bai_query(_p(bai), len(bai), ref_id, begin, end, None, 0)
+    if n < 0:
+        raise StrelkaAmdError("sk_bai_query: %s" % ("malformed index" if n == -1 else "reference not in the index"))
+    out = np.zeros(max(n, 1), BAI_CHUNK_DTYPE)
+    if n:
+        assert L.sk_bai_query(_p(bai), len(bai), ref_id, begin, end, _p(out), n) == n
+    return out[:n]
+
+
+def bam_region_filter(rec, path_off, path, ref_id, begin, end):
+    """hts_itr_next's record test -> (keep[n] bool, how many records the iterator reads before it finishes)"""
+    rec = np.ascontiguousarray(rec, BAM_RECORD_DTYPE)
+    path_off = np.ascontiguousarray(path_off, np.int64)
+    path = np.ascontiguousarray(path, PATH_SEG_DTYPE)
+    keep = np.zeros(max(len(rec), 1), np.uint8)
+    L = lib()
+    L.sk_bam_region_filter.restype = C.c_int32
+    L.sk_bam_region_filter.argtypes = [c_void_p, c_void_p, c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_void_p]
+    n = L.sk_bam_region_filter(_p(rec), _p(path_off), _p(path), len(rec), ref_id, begin, end, _p(keep))
+    if n < 0:
+        raise StrelkaAmdError("sk_bam_region_filter: bad argument")
+    return keep[:len(rec)].astype(bool), n
+
+
+def _inflate_blocks(data, block_off, out_off):
+    out = np.zeros(max(int(out_off[-1]), 1), np.uint8)
+    _check(lib().sk_bgzf_inflate(_p(np.ascontiguousarray(data, np.uint8)), _p(np.ascontiguousarray(block_off, np.int64)),
+                                 _p(np.ascontiguousarray(out_off, np.int64)), len(block_off) - 1, _p(out)))
+    return out[:int(out_off[-1])]
+
+
+def bam_fetch_region(bam, bai, ref_id, begin, end, inflate=None, decode=None, blocks=None):
+    """What sam_itr_queryi + sam_itr_next hand the reference's bam_streamer for a region, from file images: the index gives the
+    chunks (sk_bai_query), their BGZF blocks are inflated and their records decoded (the kernels behind sk_bgzf_inflate /
+    sk_bam_decode, unless `inflate(data, block_off, out_off) -> bytes` / `decode(stream, first) -> dict` are given), the iterator's
+    record test picks the result (sk_bam_region_filter).
+    -> dict(rec, stream_offset (of each record in the inflated file), read_code, read_qual, path: one entry per record)."""
+    bam = np.ascontiguousarray(bam, np.uint8)
+    block_off, out_off = blocks if blocks is not None else bgzf_scan(bam)
+    n_blocks = len(block_off) - 1
+    starts = {int(o): i for i, o in enumerate(block_off[:-1])}
+    inflate = inflate or _inflate_blocks
+    decode = decode or bam_decode
+    parts, offsets = [], []
+    for ch in bai_query(bai, ref_id, begin, end):
+        cb, ub, ce, ue = int(ch["begin"]) >> 16, int(ch["begin"]) & 0xffff, int(ch["end"]) >> 16, int(ch["end"]) & 0xffff
+        i0 = starts[cb]
+        i1 = starts.get(ce, n_blocks)  # (a chunk may end where the file ends)
+        limit = int(out_off[i1] - out_off[i0]) + ue  # the chunk's records start before this offset of its inflated bytes
+        last = min(i1, n_blocks - 1)
+        while True:  # a record that starts inside the chunk may end in a later block
+            stream = inflate(bam[int(block_off[i0]):int(block_off[last + 1])], block_off[i0:last + 2] - block_off[i0],
+                             out_off[i0:last + 2] - out_off[i0])
+            d = decode(stream, ub)
+            if len(d["rec_off"]):
+                at = int(d["rec_off"][-1])
+                nxt = at + 4 + int(np.frombuffer(np.asarray(stream[at:at + 4], np.uint8).tobytes(), "<i4")[0])
+            else:
+                nxt = ub
+            if nxt >= limit or last == n_blocks - 1:
+                break
+            last += 1
+        n_in = int(np.searchsorted(d["rec_off"], limit))
+        keep, n_read = bam_region_filter(d["rec"][:n_in], d["path_off"][:n_in + 1], d["path"], ref_id, begin, end)
+        for i in np.nonzero(keep)[0]:
+            parts.append((d, int(i)))
+            offsets.append(int(out_off[i0]) + int(d["rec_off"][i]))
+        if n_read < n_in:
+            break  # the iterator has seen a record past the region: finished
+    rec = np.array([d["rec"][i] for d, i in parts], BAM_RECORD_DTYPE) if parts else np.zeros(0, BAM_RECORD_DTYPE)
+    return dict(rec=rec, stream_offset=np.array(offsets, np.int64),
+                read_code=[d["read_code"][int(d["read_off"][i]):int(d["read_off"][i + 1])] for d, i in parts],
+                read_qual=[d["read_qual"][int(d["read_off"][i]):int(d["read_off"][i + 1])] for d, i in parts],
+                path=[d["path"][int(d["path_off"][i]):int(d["path_off"][i + 1])] for d, i in parts])

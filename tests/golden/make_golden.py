@@ -350,6 +350,73 @@ def normalize_golden():
     print("normalize_reference.pkl:", len(cases), "alignments,", sum(e[0] for e in expect), "changed")
 
 
+def feed_regions_golden():
+    """the index: a small coordinate-sorted BAM with its .bai (samtools 1.6 of the reference's redist/) and, for a list of regions,
+    WHICH records `samtools view BAM region` returns (their ordinals in file order) -- what sam_itr_queryi + sam_itr_next give
+    the reference's bam_streamer.  (htslib merges bins whose records take less than 64 KB of the file into their parents, so a file
+    this small has a coarse index; the fine-grained indexes are covered live, tests/test_bam_feed.py, where oracle/_ref exists.)"""
+    import gzip
+    import json
+    import subprocess
+    import tempfile
+    samtools = os.path.join(os.path.dirname(HERE), "..", "oracle", "_ref", "bin", "samtools")
+    rng = np.random.default_rng(777001)
+    contigs = [("chrA", 200000), ("chrB", 50000), ("chrC", 20000), ("chrD", 140000)]  # chrC stays empty
+    lines = ["@HD\tVN:1.5\tSO:unsorted"] + ["@SQ\tSN:%s\tLN:%d" % c for c in contigs]
+    n = 0
+
+    def add(contig, pos1, cigar, seq_len, flag=0):
+        nonlocal n
+        seq = "".join(rng.choice(list("ACGT"), seq_len))
+        lines.append("\t".join(["r%d" % n, str(flag), contig, str(pos1), "40", cigar, "*", "0", "0", seq, "I" * seq_len]))
+        n += 1
+    for contig, length in (contigs[0], contigs[1], contigs[3]):
+        for _ in range(int(length / 130)):
+            add(contig, int(rng.integers(1, length - 60)), "40M", 40, flag=int(rng.choice([0, 16])))
+        for _ in range(25):  # reads that reach far: deletions and skipped regions put them into the higher bins
+            p = int(rng.integers(1, length - 40000))
+            gap = int(rng.choice([300, 5000, 17000, 33000]))
+            add(contig, p, "20M%d%s20M" % (gap, rng.choice(["D", "N"])), 40)
+        for _ in range(15):  # unmapped reads placed at their mate's position: one base long for the index
+            add(contig, int(rng.integers(1, length - 60)), "*", 40, flag=4)
+        for k in range(8):   # reads that straddle the 16 kb / 128 kb bin boundaries, and some with clips and insertions
+            b = 16384 * int(rng.integers(1, length // 16384))
+            add(contig, b - int(rng.integers(1, 39)), "5S30M2I3M", 40)
+        p0 = int(rng.integers(1000, length - 3000))
+        for _ in range(300):  # a deep pile
+            add(contig, p0 + int(rng.integers(0, 200)), "40M", 40)
+    for _ in range(40):  # unplaced
+        seq = "".join(rng.choice(list("ACGT"), 40))
+        lines.append("\t".join(["r%d" % n, "4", "*", "0", "0", "*", "*", "0", "0", seq, "I" * 40]))
+        n += 1
+    with tempfile.TemporaryDirectory() as d:
+        sam = os.path.join(d, "x.sam")
+        with open(sam, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        bam = os.path.join(HERE, "feed_regions.bam")
+        subprocess.run([samtools, "sort", "-o", bam, sam], check=True)
+        subprocess.run([samtools, "index", bam], check=True)
+        names = [l.split("\t")[0] for l in subprocess.run([samtools, "view", bam], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()]
+        ordinal = {q: i for i, q in enumerate(names)}
+        regions = []
+        for ci, (contig, length) in enumerate(contigs):
+            fixed = [(0, length), (0, 1), (length - 1, length), (16383, 16385), (16384, 16384 + 1), (0, 16384), (16384, 32768),
+                     (131071, 131073), (length // 2, length // 2 + 500), (length - 5000, length + 100000)]
+            rnd = []
+            for _ in range(30):
+                b = int(rng.integers(0, length))
+                rnd.append((b, b + int(rng.choice([1, 40, 300, 5000, 20000, 70000]))))
+            for b, e in fixed + rnd:
+                if b >= e or b >= length:
+                    continue
+                out = subprocess.run([samtools, "view", bam, "%s:%d-%d" % (contig, b + 1, e)], stdout=subprocess.PIPE, check=True).stdout.decode()
+                regions.append([ci, b, e, [ordinal[l.split("\t")[0]] for l in out.splitlines()]])
+    with gzip.open(os.path.join(HERE, "feed_regions.json.gz"), "wt") as f:
+        json.dump(dict(n_records=len(names), regions=regions), f)
+    print("feed_regions.bam:", len(names), "records,", os.path.getsize(bam), "bytes;", len(regions), "regions,",
+          sum(len(r[3]) for r in regions), "records in them,", sum(1 for r in regions if not r[3]), "empty")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "somatic_indel_tiers"):
@@ -368,3 +435,5 @@ if __name__ == "__main__":
         active_region_golden()
     if what in ("all", "normalize"):
         normalize_golden()
+    if what in ("all", "feed_regions"):
+        feed_regions_golden()

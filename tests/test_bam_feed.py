@@ -120,6 +120,154 @@ def test_malformed_blocks_are_refused():
     assert capi.bgzf_inflate(data).tobytes() == bam_oracle.bgzf_inflate(data.tobytes())
 
 
+# ---- the index: hts_itr_query + hts_itr_next's record test (sk_bai_query, sk_bam_region_filter) -------------------------------------------
+
+import json
+
+
+def _zlib_inflate(data, block_off, out_off):
+    return np.frombuffer(bam_oracle.bgzf_inflate(np.asarray(data, np.uint8).tobytes()), np.uint8)
+
+
+def _restatement_decode(stream, first):
+    """capi.bam_decode's dict from the Python restatement (the -m "not gpu" runs have no kernels to decode with)"""
+    recs = bam_oracle.bam_records(np.asarray(stream, np.uint8).tobytes(), first)
+    rec = np.zeros(len(recs), capi.BAM_RECORD_DTYPE)
+    for k in ("ref_id", "pos", "mapq", "flag", "l_seq", "mate_ref_id", "mate_pos", "template_size"):
+        rec[k] = [r[k] for r in recs]
+    rec["n_cigar"] = [len(r["cigar"]) for r in recs]
+    rec["is_fwd_strand"] = [0 if r["flag"] & 16 else 1 for r in recs]
+    path = np.array([(op + 1, l) for r in recs for op, l in r["cigar"]], capi.PATH_SEG_DTYPE) if recs else np.zeros(0, capi.PATH_SEG_DTYPE)
+    off = lambda xs: np.concatenate([[0], np.cumsum(xs)]).astype(np.int64)
+    return dict(rec=rec, rec_off=np.array([r["offset"] for r in recs], np.int64), read_off=off([r["l_seq"] for r in recs]),
+                read_code=np.concatenate([r["code"] for r in recs]) if recs else np.zeros(0, np.uint8),
+                read_qual=np.concatenate([r["qual"] for r in recs]) if recs else np.zeros(0, np.uint8),
+                path_off=off([len(r["cigar"]) for r in recs]), path=path)
+
+
+def _check_regions(bam_path, regions, on_gpu):
+    """regions: [(ref_id, begin, end, ordinals of the records samtools view returns)]"""
+    bam = np.frombuffer(_bytes(bam_path), np.uint8)
+    bai = np.frombuffer(_bytes(bam_path + ".bai"), np.uint8)
+    blocks = capi.bgzf_scan(bam)
+    stream = bam_oracle.bgzf_inflate(bam.tobytes())
+    all_recs = bam_oracle.bam_records(stream)
+    ordinal = {r["offset"]: i for i, r in enumerate(all_recs)}
+    kw = {} if on_gpu else dict(inflate=_zlib_inflate, decode=_restatement_decode)
+    n = 0
+    for ref_id, begin, end, want in regions:
+        got = capi.bam_fetch_region(bam, bai, ref_id, begin, end, blocks=blocks, **kw)
+        assert [ordinal[int(o)] for o in got["stream_offset"]] == list(want), (bam_path, ref_id, begin, end)
+        for j, i in enumerate(want[:50]):  # and they are those records
+            r = all_recs[i]
+            assert int(got["rec"]["pos"][j]) == r["pos"] and int(got["rec"]["flag"][j]) == r["flag"]
+            assert np.array_equal(got["read_code"][j], r["code"]) and np.array_equal(got["read_qual"][j], r["qual"])
+            assert [(int(t), int(l)) for t, l in got["path"][j]] == [(op + 1, l) for op, l in r["cigar"]]
+        n += len(want)
+    return n
+
+
+def _golden_regions():
+    with gzip.open(os.path.join(GOLD, "feed_regions.json.gz"), "rt") as f:
+        g = json.load(f)
+    return [tuple(r) for r in g["regions"]]
+
+
+def test_region_fetch_reproduces_samtools_view_on_the_fixture():
+    regions = _golden_regions()
+    assert len(regions) > 100 and sum(1 for r in regions if not r[3]) > 10
+    assert _check_regions(os.path.join(GOLD, "feed_regions.bam"), regions, on_gpu=False) > 10000
+
+
+def test_index_query_edge_cases():
+    bai = np.frombuffer(_bytes(os.path.join(GOLD, "feed_regions.bam.bai")), np.uint8)
+    assert len(capi.bai_query(bai, 2, 0, 20000)) == 0          # a reference without records
+    assert len(capi.bai_query(bai, 0, 500, 500)) == 0          # an empty interval has no bins (reg2bins)
+    assert len(capi.bai_query(bai, 0, 700, 600)) == 0          # end < begin
+    assert np.array_equal(capi.bai_query(bai, 0, -5, 1000), capi.bai_query(bai, 0, 0, 1000))  # hts_itr_query clamps begin
+    with pytest.raises(capi.StrelkaAmdError):
+        capi.bai_query(bai, 4, 0, 10)                          # four references in the index
+    with pytest.raises(capi.StrelkaAmdError):
+        capi.bai_query(bai[:40], 0, 0, 10)                     # cut short
+    ch = capi.bai_query(bai, 0, 0, 1 << 29)
+    assert len(ch) >= 1 and all(int(c["begin"]) < int(c["end"]) for c in ch)
+    assert all(int(a["end"]) <= int(b["begin"]) for a, b in zip(ch[:-1], ch[1:]))  # sorted, disjoint
+
+
+def _samtools_regions(bam, rng, n_regions):
+    """random regions of an indexed BAM with what samtools view returns for them"""
+    head = subprocess.run([SAMTOOLS, "view", "-H", bam], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
+    contigs = [(l.split("\t")[1][3:], int(l.split("\t")[2][3:])) for l in head if l.startswith("@SQ")]
+    names = [l.split("\t")[0] + "/" + l.split("\t")[1] for l in subprocess.run([SAMTOOLS, "view", bam], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()]
+    first = {}
+    for i, q in enumerate(names):
+        first.setdefault(q, []).append(i)
+    regions = []
+    for _ in range(n_regions):
+        ci = int(rng.integers(0, len(contigs)))
+        length = contigs[ci][1]
+        b = int(rng.integers(0, length))
+        e = min(b + int(rng.choice([1, 150, 2000, 16384, 40000, 200000])), 1 << 29)
+        out = subprocess.run([SAMTOOLS, "view", bam, "%s:%d-%d" % (contigs[ci][0], b + 1, e)], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
+        used, want = {}, []
+        for l in out:  # (name/flag pairs may repeat: take their occurrences in order)
+            q = l.split("\t")[0] + "/" + l.split("\t")[1]
+            k = used.get(q, 0)
+            used[q] = k + 1
+            want.append(first[q][k])
+        regions.append((ci, b, e, sorted(want)))
+    return regions
+
+
+@pytest.mark.skipif(not os.path.exists(SAMTOOLS), reason="oracle/_ref samtools not built")
+def test_region_fetch_reproduces_samtools_view_live():
+    """larger BAMs, whose indexes use the fine bins (htslib merges bins with less than 64 KB of records into their parents)"""
+    rng = np.random.default_rng(555)
+    bams = [b for b in _more_bams()[1:] if os.path.exists(b + ".bai")]
+    assert bams
+    n = 0
+    for bam in bams[:3]:
+        n += _check_regions(bam, _samtools_regions(bam, rng, 25), on_gpu=False)
+    assert n > 5000
+
+
+@pytest.mark.skipif(not os.path.exists(SAMTOOLS), reason="oracle/_ref samtools not built")
+def test_region_fetch_on_a_fine_grained_index(tmp_path):
+    """a BAM made on the spot that is large enough for bins on every level: 200 000 short reads on 3 x 3 Mb, with deep piles (a 16 kb
+    bin of its own needs 64 KB of records) and reads spanning tens of kilobases (the higher bins)"""
+    rng = np.random.default_rng(556)
+    contigs = [("c%d" % i, 3_000_000) for i in range(3)]
+    lines = ["@HD\tVN:1.5\tSO:unsorted"] + ["@SQ\tSN:%s\tLN:%d" % c for c in contigs]
+    seq, qual = "ACGTTGCAAC" * 3, "I" * 30
+    k = 0
+    for name, length in contigs:
+        pos = np.concatenate([rng.integers(1, length - 100, 50000), rng.integers(700000, 700000 + 3000, 12000),
+                              rng.integers(2000000, 2000000 + 40000, 5000)])
+        for p in pos:
+            lines.append("r%d\t0\t%s\t%d\t30\t30M\t*\t0\t0\t%s\t%s" % (k, name, p, seq, qual))
+            k += 1
+        for p in rng.integers(1, length - 600000, 300):
+            gap = int(rng.choice([20000, 150000, 500000]))
+            lines.append("r%d\t0\t%s\t%d\t30\t15M%dN15M\t*\t0\t0\t%s\t%s" % (k, name, p, gap, seq, qual))
+            k += 1
+    sam = tmp_path / "big.sam"
+    sam.write_text("\n".join(lines) + "\n")
+    bam = str(tmp_path / "big.bam")
+    subprocess.run([SAMTOOLS, "sort", "-o", bam, str(sam)], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([SAMTOOLS, "index", bam], check=True)
+    bai = np.frombuffer(_bytes(bam + ".bai"), np.uint8)
+    assert len(bai) > 3000                                                          # many bins
+    assert max(len(capi.bai_query(bai, 0, b, b + 600000)) for b in (0, 650000, 1900000)) >= 3  # several chunks for one region
+    regions = _samtools_regions(bam, rng, 60)
+    assert _check_regions(bam, regions, on_gpu=False) > 20000
+
+
+@pytest.mark.gpu
+def test_region_fetch_through_the_kernels():
+    capi.init(0)
+    assert _check_regions(os.path.join(GOLD, "feed_regions.bam"), _golden_regions(), on_gpu=True) > 10000
+
+
 # ---- normalizeAlignment (L/starling_common/normalizeAlignment.cpp:647-703): csrc/normalize_core.h on the host and as a kernel ---------------
 
 import ctypes as C
