@@ -1051,28 +1051,31 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         SK_HIP(hipMemcpyAsync(ea.level_count, &in->n_reads, 4, hipMemcpyHostToDevice, st));
         const size_t lds = 64 * sizeof(PFrame);
         const int blocks = int(std::min<int64_t>((frame_cap + 63) / 64, 1024));
-        // a call at depth d expands indel order[d]; depth n_order <= K is a leaf.  Few searches go deeper than a dozen levels:
-        // the launches go out twelve at a time, and the level counts tell whether another dozen is needed
-        for (int d0 = 0; d0 < Caps::K + 2; d0 += 12) {
-            for (int d = d0; d < std::min(d0 + 12, Caps::K + 2); ++d) {
+        // a call at depth d expands indel order[d]; a call at depth n_order is a leaf.  A read's order as it arrives says how deep its
+        // search goes unless an alignment reaches indels beyond the read's first range (they join the order): the levels up to the
+        // deepest order of the job (+1) go out at once, the level counts that come back with the results say whether more are needed
+        int max_order = 0;
+        for (int r = 0; r < n; ++r) max_order = std::max(max_order, int(in->reads[r].n_order));
+        int done = 0, batch = std::min(std::max(max_order + 2, 3), int(Caps::K) + 2);
+        for (;;) {
+            const int upto = std::min(done + batch, int(Caps::K) + 2);
+            for (int d = done; d < upto; ++d) {
                 ea.level_in = buf[d & 1];
                 ea.level_out = buf[(d + 1) & 1];
                 ea.depth = d;
                 hipLaunchKernelGGL(level_kernel, dim3(blocks), dim3(64), lds, st, ea);
             }
+            done = upto;
             SK_HIP(hipGetLastError());
-            if (d0 + 12 >= Caps::K + 2) break;
-            int32_t next_count = 0;
-            SK_HIP(hipMemcpyAsync(&next_count, ea.level_count + (d0 + 12), 4, hipMemcpyDeviceToHost, st));
+            D2H(h_status, status, 4 * size_t(n));
+            D2H(h_warn, warn, 4 * size_t(n));
+            D2H(h_n_raw, n_raw, 4 * size_t(n));
+            D2H(h_counters, counters, 4 * size_t(n_counters));
             SK_HIP(hipStreamSynchronize(st));
-            if (next_count == 0) break;
+            if (done >= Caps::K + 2 || B.h_counters.as<int32_t>()[done] == 0) break;
+            batch = 4;
         }
     }
-    D2H(h_status, status, 4 * size_t(n));
-    D2H(h_warn, warn, 4 * size_t(n));
-    D2H(h_n_raw, n_raw, 4 * size_t(n));
-    D2H(h_counters, counters, 4 * size_t(n_counters));
-    SK_HIP(hipStreamSynchronize(st));
     lap("E1 search (all depths)");
     int32_t* h_status = B.h_status.as<int32_t>();
     const int32_t* h_counters = B.h_counters.as<int32_t>();
