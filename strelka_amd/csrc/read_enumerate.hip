@@ -1335,10 +1335,18 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
                 RES(s3_list, 4 * size_t(n));
                 HRES(h_s3_list, 4 * size_t(n));
                 int32_t* h_list = B.h_s3_list.as<int32_t>();
+                int light_cals = S3_LIGHT_CALS, lds_cals = S3_LDS_CALS;
+                if (const char* e = std::getenv("SK_STAGE3_TEST_LDS_CALS")) { // tests: small capacities, so that the second launch and the HBM arrays run
+                    int a = 0, b = 0;
+                    if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b >= a && b <= S3_LDS_CALS) {
+                        light_cals = a;
+                        lds_cals = b;
+                    }
+                }
                 int n_light = 0, n_heavy = 0, max_cals = 0;
                 for (int r = 0; r < n; ++r) {
                     const int k = h_cal_off[r + 1] - h_cal_off[r];
-                    if (k <= S3_LIGHT_CALS) h_list[n_light++] = r;
+                    if (k <= light_cals) h_list[n_light++] = r;
                     else {
                         h_list[n - 1 - n_heavy++] = r;
                         max_cals = std::max(max_cals, k);
@@ -1348,15 +1356,15 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
                 auto lds_bytes = [](const int cals) { return size_t(cals) * (8 + 8 + 4 + 4 + 4 + 4 + 1 + 1) + 8; };
                 if (n_light > 0) {
                     s3.list = B.s3_list.as<int32_t>();
-                    s3.lds_cals = S3_LIGHT_CALS;
-                    hipLaunchKernelGGL(stage3_kernel, dim3(n_light), dim3(64), lds_bytes(S3_LIGHT_CALS), st, s3);
+                    s3.lds_cals = light_cals;
+                    hipLaunchKernelGGL(stage3_kernel, dim3(n_light), dim3(64), lds_bytes(light_cals), st, s3);
                 }
                 if (n_heavy > 0) {
                     s3.list = B.s3_list.as<int32_t>() + (n - n_heavy);
-                    s3.lds_cals = std::min(max_cals, int(S3_LDS_CALS)); // (a read with more uses the arrays in HBM)
+                    s3.lds_cals = std::min(max_cals, lds_cals); // (a read with more uses the arrays in HBM)
                     hipLaunchKernelGGL(stage3_kernel, dim3(n_heavy), dim3(64), lds_bytes(s3.lds_cals), st, s3);
                 }
-                if (timing) std::fprintf(stderr, "[enum-dev] stage 3: %d reads with at most %d candidate alignments, %d with more (up to %d)\n", n_light, int(S3_LIGHT_CALS), n_heavy, max_cals);
+                if (timing) std::fprintf(stderr, "[enum-dev] stage 3: %d reads with at most %d candidate alignments, %d with more (up to %d)\n", n_light, light_cals, n_heavy, max_cals);
                 SK_HIP(hipGetLastError());
                 D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
                 out->stage3 = B.h_s3_out.as<sk3::Out>();

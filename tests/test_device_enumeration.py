@@ -59,6 +59,14 @@ def test_host_core_reproduces_the_reference_golden(gold):
     assert _run.stage3[0] >= core * 0.98  # stage 3 ran in its container-free form as well (csrc/stage3_core.h)
 
 
+def test_host_core_without_the_conflict_tables(gold, monkeypatch):
+    """score_indels' per-read tables cover the span of table indices a read's alignments hold (<= 256); beyond that the same is
+    computed from the table entries -- forced here for every read"""
+    monkeypatch.setenv("SK_STAGE3_NO_TABLES", "1")
+    reads, core, dev, fb = _run(gold["scenarios"], gold["expect"], mode=1, on_gpu=False)
+    assert reads > 400 and _run.stage3[0] >= core * 0.98
+
+
 @pytest.mark.skipif(not pyoracle.ref_available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("seed,max_indels,hap", [(31, 6, 0.25), (32, 12, 0.6), (33, 9, 0.0)])
 def test_host_core_reproduces_the_live_reference(seed, max_indels, hap):
@@ -77,6 +85,25 @@ def test_device_enumeration_reproduces_the_reference_golden(gold):
     assert reads > 400 and dev > 200 and core == 0
     assert fb <= dev // 50
     assert _run.stage3[1] >= dev * 0.95  # and stage 3 of those reads ran on the device as well (stage3_kernel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("caps", ["4,12", "16,64"])
+def test_device_stage3_launch_shapes(gold, monkeypatch, caps):
+    """stage3_kernel keeps a read's per-alignment arrays in LDS when they fit (two launches: few / many candidate alignments) and
+    in HBM otherwise; with tiny capacities the golden scenarios go through all three"""
+    capi.init(0)
+    monkeypatch.setenv("SK_STAGE3_TEST_LDS_CALS", caps)
+    reads, core, dev, fb = _run(gold["scenarios"], gold["expect"], mode=2, on_gpu=True)
+    assert reads > 400 and _run.stage3[1] >= dev * 0.95
+
+
+@pytest.mark.gpu
+def test_device_stage3_without_the_conflict_tables(gold, monkeypatch):
+    capi.init(0)
+    monkeypatch.setenv("SK_STAGE3_NO_TABLES", "1")
+    reads, core, dev, fb = _run(gold["scenarios"], gold["expect"], mode=2, on_gpu=True)
+    assert reads > 400 and _run.stage3[1] >= dev * 0.95
 
 
 @pytest.mark.gpu
