@@ -787,7 +787,7 @@ int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* dev_batch, 
  * off the stream (starling_run.cpp / strelka_run.cpp via normalizeBamRecordAlignment :707-727), is the third kernel.
  * The index: sk_bai_query is hts_itr_query over a .bai image, sk_bam_region_filter the record test of hts_itr_next -- together with the
  * calls above, what sam_itr_queryi / sam_itr_next (bam_streamer.cpp:228, :268) do for a region.
- * Not built: CRAM, the gVCF writer.
+ * Not built: CRAM.  (The gVCF writer's block logic is below; its formatting is host work and stays in the reference.)
  * ---------------------------------------------------------------------------------------------------------------- */
 
 /** The BGZF blocks of a file image (or of any run of whole blocks): block_off[i] = start of block i, out_off[i] = where its inflated
@@ -851,6 +851,42 @@ int sk_normalize_alignments(const char* ref_seq, int32_t ref_offset, int32_t ref
 int sk_normalize_alignments_dev(const char* dev_ref_seq, int32_t ref_offset, int32_t ref_len, int32_t n_reads, const int64_t* dev_read_off,
                                 const uint8_t* dev_read_code, const int64_t* dev_path_off, int32_t* dev_n_seg, sk_path_seg* dev_path,
                                 int32_t* dev_pos, uint8_t* dev_changed, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * SURVEY.md section 8f rank 4, the output side: the non-variant blocks of the gVCF.
+ *
+ * gvcf_writer::queue_site_record (L/applications/starling/gvcf_writer.cpp:278-302) asks, site after site and per sample, whether the
+ * site can join the open block (gvcf_block_site_record::testCanSiteJoinSampleBlock, gvcf_block_site_record.cpp:160-182: same
+ * filters, genotype, ploidy and coverage state, depth and GQX within block_percent_tol / block_abs_tol of the block's minimum) and
+ * joins it or starts a new block (joinSiteToSampleBlock :126-157).  Here a run of sites of one sample goes in, and which sites start
+ * a block, which continue one and which are records of their own comes out, with what write_site_record (:749-806) prints of every
+ * block.  Formatting the records stays host work.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct sk_gvcf_site { /* what the block logic reads of a GermlineSiteLocusInfo, for one sample */
+    int32_t pos;
+    uint8_t is_compressible;   /* gvcf_compressor::is_site_compressible (gvcf_compressor.cpp:41-71): the caller's */
+    uint8_t is_gqx;            /* GermlineSiteLocusInfo::is_gqx(sample) */
+    uint8_t ploidy;            /* LocusSampleInfo::getPloidy().getPloidy() */
+    uint8_t flush_before;      /* the writer flushed its blocks between the previous site and this one (writeAllNonVariantBlockRecords) */
+    uint32_t gt;               /* max_gt() as VcfGenotype::operator== compares it: ploidy << 24 | phased << 16 | allele0 << 8 | allele1 */
+    uint32_t locus_filters, sample_filters; /* GermlineFilterKeeper bits */
+    int32_t gqx;
+    uint32_t used_basecalls, unused_basecalls; /* GermlineSiteSampleInfo */
+} sk_gvcf_site;
+typedef struct sk_gvcf_block { /* gvcf_block_site_record as write_site_record reads it */
+    int32_t pos, count;        /* END = pos + count */
+    int32_t is_gqx_defined;    /* isBlockGqxDefined */
+    int32_t gqx_min;           /* block_gqx.min() */
+    int32_t dpu_min;           /* MIN_DP = block_dpu.min() */
+    int32_t pad;
+    double dpu_mean, dpf_mean; /* DP = round(block_dpu.mean()), DPF = round(block_dpf.mean()): stream_stat's running mean */
+} sk_gvcf_block;
+/** kind[i]: 0 = site i continues the block of the site before it, 1 = it starts a block (blocks[i] describes the block), 2 = it is
+ *  not compressible and is written as a record of its own.  blocks: n_sites entries, written where kind is 1. */
+int sk_gvcf_block_sites(const sk_gvcf_site* sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol, uint8_t* kind,
+                        sk_gvcf_block* blocks);
+int sk_gvcf_block_sites_dev(const sk_gvcf_site* dev_sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol,
+                            uint8_t* dev_kind, sk_gvcf_block* dev_blocks, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -410,3 +410,19 @@ extern "C" int sk_normalize_alignments_dev(const char*, int32_t, int32_t, int32_
 {
     return sk_fail("sk_normalize_alignments_dev needs the GPU library");
 }
+
+// ---- the gVCF writer's block logic: the same statement the kernel runs (csrc/gvcf_block_core.h), on this host ----------------------
+#include "gvcf_block_core.h"
+extern "C" int sk_gvcf_block_sites(const sk_gvcf_site* sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol, uint8_t* kind,
+                                   sk_gvcf_block* blocks)
+{
+    if (n_sites < 0 || (n_sites > 0 && (!sites || !kind || !blocks))) return sk_fail("sk_gvcf_block_sites: bad argument");
+    std::memset(blocks, 0, sizeof(sk_gvcf_block) * size_t(n_sites));
+    for (int32_t i = 0; i < n_sites; ++i)
+        if (skgvcf::starts_stretch(sites, i)) skgvcf::walk_stretch(sites, n_sites, i, static_cast<double>(block_percent_tol) / 100., int(block_abs_tol), kind, blocks);
+    return 0;
+}
+extern "C" int sk_gvcf_block_sites_dev(const sk_gvcf_site*, int32_t, uint32_t, uint32_t, uint8_t*, sk_gvcf_block*, void*)
+{
+    return sk_fail("sk_gvcf_block_sites_dev needs the GPU library");
+}

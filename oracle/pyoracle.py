@@ -753,3 +753,29 @@ def ref_normalize_alignment(ref_seq, ref_offset, read_chars, pos, path):
     if rc < 0:
         raise RuntimeError("ref_normalize_alignment: result does not fit")
     return rc, p.value, [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n.value)]
+
+
+REF_GVCF_SITE_DTYPE = np.dtype([("pos", "<i4"), ("is_compressible", "u1"), ("is_ref_unknown", "u1"), ("gt_ploidy", "u1"), ("gt_phased", "u1"),
+                                ("gt_allele0", "u1"), ("gt_allele1", "u1"), ("ploidy", "u1"), ("flush_before", "u1"), ("locus_filters", "<u4"),
+                                ("sample_filters", "<u4"), ("gqx", "<i4"), ("used_basecalls", "<u4"), ("unused_basecalls", "<u4")])
+REF_GVCF_BLOCK_DTYPE = np.dtype([("first_site", "<i4"), ("pos", "<i4"), ("count", "<i4"), ("is_gqx_defined", "<i4"), ("gqx_min", "<f8"),
+                                 ("dpu_mean", "<f8"), ("dpf_mean", "<f8"), ("dpu_min", "<f8")])
+
+
+def ref_gvcf_block_sites(sites, block_percent_tol=30, block_abs_tol=3):
+    """the reference's own gvcf_block_site_record, driven per site as gvcf_writer::queue_site_record drives it
+    (oracle/ref/ref_driver_gvcf_block.cpp).  sites: synth.gvcf_sites records -> (kind[n], blocks[REF_GVCF_BLOCK_DTYPE])"""
+    L = ref()
+    n = len(sites)
+    rs = np.zeros(n, REF_GVCF_SITE_DTYPE)
+    for k in ("pos", "is_compressible", "is_ref_unknown", "ploidy", "flush_before", "locus_filters", "sample_filters", "gqx", "used_basecalls", "unused_basecalls"):
+        rs[k] = sites[k]
+    rs["gt_ploidy"] = sites["gt"] >> 24
+    rs["gt_phased"] = (sites["gt"] >> 16) & 1
+    rs["gt_allele0"] = (sites["gt"] >> 8) & 0xff
+    rs["gt_allele1"] = sites["gt"] & 0xff
+    kind = np.zeros(max(n, 1), np.uint8)
+    blocks = np.zeros(max(n, 1), REF_GVCF_BLOCK_DTYPE)
+    L.ref_gvcf_block_sites.argtypes = [vp, C.c_int32, C.c_uint32, C.c_uint32, vp, vp]
+    nb = L.ref_gvcf_block_sites(rs.ctypes.data, n, block_percent_tol, block_abs_tol, kind.ctypes.data, blocks.ctypes.data)
+    return kind[:n], blocks[:nb]

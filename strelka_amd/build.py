@@ -24,6 +24,7 @@ HIP_SOURCES = [
     "csrc/global_align.hip",
     "csrc/read_enumerate.hip",
     "csrc/bam_feed.hip",
+    "csrc/gvcf_block.hip",
 ]
 HOST_SOURCES = [
     "host/align_flatten.cpp",

@@ -197,7 +197,7 @@ EXPORTS = [
     "sk_somatic_snv_call_tiers", "sk_somatic_snv_call_tiers_dev", "sk_somatic_snv_tiers_scratch_bytes",
     "sk_indel_options_default", "sk_somatic_indel_options_default", "sk_indel_grid_lhood", "sk_indel_grid_lhood_dev",
     "sk_somatic_indel_call_batch", "sk_somatic_indel_call_tiers", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
-    "sk_discover_indels_and_mismatches", "sk_global_align_scratch_bytes", "sk_global_align_dev", "sk_bai_query", "sk_bam_region_filter",
+    "sk_discover_indels_and_mismatches", "sk_global_align_scratch_bytes", "sk_global_align_dev", "sk_bai_query", "sk_bam_region_filter", "sk_gvcf_block_sites", "sk_gvcf_block_sites_dev",
 ]
 
 _lib = None
@@ -1174,3 +1174,21 @@ def bam_fetch_region(bam, bai, ref_id, begin, end, inflate=None, decode=None, bl
                 read_code=[d["read_code"][int(d["read_off"][i]):int(d["read_off"][i + 1])] for d, i in parts],
                 read_qual=[d["read_qual"][int(d["read_off"][i]):int(d["read_off"][i + 1])] for d, i in parts],
                 path=[d["path"][int(d["path_off"][i]):int(d["path_off"][i + 1])] for d, i in parts])
+
+
+GVCF_SITE_DTYPE = np.dtype([("pos", "<i4"), ("is_compressible", "u1"), ("is_gqx", "u1"), ("ploidy", "u1"), ("flush_before", "u1"), ("gt", "<u4"),
+                            ("locus_filters", "<u4"), ("sample_filters", "<u4"), ("gqx", "<i4"), ("used_basecalls", "<u4"), ("unused_basecalls", "<u4")])
+GVCF_BLOCK_DTYPE = np.dtype([("pos", "<i4"), ("count", "<i4"), ("is_gqx_defined", "<i4"), ("gqx_min", "<i4"), ("dpu_min", "<i4"), ("pad", "<i4"),
+                             ("dpu_mean", "<f8"), ("dpf_mean", "<f8")])
+
+
+def gvcf_block_sites(sites, block_percent_tol=30, block_abs_tol=3, library=None):
+    """the gVCF writer's non-variant block logic for one sample's run of sites -> (kind[n], blocks[n]: valid where kind == 1)"""
+    sites = np.ascontiguousarray(sites, GVCF_SITE_DTYPE)
+    kind = np.zeros(max(len(sites), 1), np.uint8)
+    blocks = np.zeros(max(len(sites), 1), GVCF_BLOCK_DTYPE)
+    L = library or lib()
+    L.sk_gvcf_block_sites.argtypes = [c_void_p, C.c_int32, C.c_uint32, C.c_uint32, c_void_p, c_void_p]
+    if L.sk_gvcf_block_sites(_p(sites), len(sites), block_percent_tol, block_abs_tol, _p(kind), _p(blocks)):
+        raise StrelkaAmdError(L.sk_last_error().decode() if library else last_error())
+    return kind[:len(sites)], blocks[:len(sites)]

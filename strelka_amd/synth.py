@@ -964,3 +964,40 @@ def normalize_cases(n, rng):
         read = "".join(read)
         out.append(dict(ref_seq=ref, ref_offset=off, read=read, code=np.array([char2code[c] for c in read], np.uint8), pos=off + start, path=path))
     return out
+
+
+def gvcf_sites(n, rng):
+    """a run of germline sites of one sample as the gVCF writer's block logic sees them (capi.GVCF_SITE_DTYPE): mostly hom-ref
+    sites whose depth and GQX drift, with variant / filtered / uncovered / non-compressible sites, gaps and flushes in between"""
+    s = np.zeros(n, [("pos", "<i4"), ("is_compressible", "u1"), ("is_gqx", "u1"), ("ploidy", "u1"), ("flush_before", "u1"), ("gt", "<u4"),
+                     ("locus_filters", "<u4"), ("sample_filters", "<u4"), ("gqx", "<i4"), ("used_basecalls", "<u4"), ("unused_basecalls", "<u4"),
+                     ("is_ref_unknown", "u1")])
+    pos = int(rng.integers(0, 1000))
+    depth, gqx, unused = float(rng.integers(0, 60)), float(rng.integers(0, 90)), float(rng.integers(0, 6))
+    ploidy, lf, sf, noise = 2, 0, 0, 1.0
+    for i in range(n):
+        pos += 1 if rng.random() > 0.01 else int(rng.integers(2, 50))
+        if rng.random() < 0.03:  # a new regime
+            depth, gqx, unused = float(rng.integers(0, 120)), float(rng.integers(0, 120)), float(rng.integers(0, 12))
+            noise = float(rng.choice([0.05, 0.3, 1.0]))  # quiet regimes give long blocks
+        if rng.random() < 0.01:
+            ploidy = int(rng.choice([1, 2]))
+        if rng.random() < 0.02:
+            lf = int(rng.choice([0, 0, 1 << 3, 1 << 6, (1 << 3) | (1 << 10)]))
+        if rng.random() < 0.02:
+            sf = int(rng.choice([0, 0, 1 << 3, 1 << 2]))
+        depth = max(0.0, depth + rng.normal(0, 1.5 * noise))
+        gqx = max(0.0, gqx + rng.normal(0, 3 * noise))
+        unused = max(0.0, unused + rng.normal(0, 0.5 * noise))
+        used = int(round(depth)) if rng.random() > 0.02 else 0
+        r = rng.random()
+        if ploidy == 2:
+            a0, a1 = (0, 0) if r > 0.04 else ((0, 1) if r > 0.015 else (1, 1))
+            gt = (2 << 24) | (a0 << 8) | a1
+        else:
+            a0 = 0 if r > 0.03 else 1
+            gt = (1 << 24) | (a0 << 8)
+        ref_unknown = rng.random() < 0.01
+        s[i] = (pos, 0 if rng.random() < 0.03 else 1, 0 if (ref_unknown or used == 0) else 1, ploidy, 1 if rng.random() < 0.01 else 0, gt, lf, sf,
+                int(round(gqx)), used, int(round(unused)) if rng.random() > 0.05 else 0, 1 if ref_unknown else 0)
+    return s

@@ -417,6 +417,19 @@ def feed_regions_golden():
           sum(len(r[3]) for r in regions), "records in them,", sum(1 for r in regions if not r[3]), "empty")
 
 
+def gvcf_block_golden():
+    """the gVCF writer's non-variant block logic: the reference's own gvcf_block_site_record (oracle/ref/ref_driver_gvcf_block.cpp) on
+    synth.gvcf_sites; the fixture carries the sites (the suite can run on shifted seeds) and what the reference made of them"""
+    pyoracle.build(ref=True)
+    runs = []
+    for seed, n, tol in ((1, 6000, (30, 3)), (2, 6000, (10, 1)), (3, 4000, (50, 5)), (4, 3000, (0, 0)), (5, 1, (30, 3)), (6, 2, (30, 3))):
+        sites = synth.gvcf_sites(n, np.random.default_rng(880000 + seed))
+        kind, blocks = pyoracle.ref_gvcf_block_sites(sites, *tol)
+        runs.append(dict(sites=sites, tol=tol, kind=kind, blocks=blocks))
+    np.savez_compressed(os.path.join(HERE, "gvcf_block_reference.npz"), **{"%s_%d" % (k, i): np.asarray(r[k]) for i, r in enumerate(runs) for k in r})
+    print("gvcf_block_reference.npz:", sum(len(r["sites"]) for r in runs), "sites,", sum(len(r["blocks"]) for r in runs), "blocks")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "somatic_indel_tiers"):
@@ -437,3 +450,5 @@ if __name__ == "__main__":
         normalize_golden()
     if what in ("all", "feed_regions"):
         feed_regions_golden()
+    if what in ("all", "gvcf_block"):
+        gvcf_block_golden()
