@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64) void root_kernel(const EnumArgs a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_reads) return;
+    if (r == 0) a.level_count[0] = a.n_reads;
     PFrame& f = a.level_out[r];
     root_frame(a.job, a.reads[r], f);
     f.read_id = r;
@@ -858,17 +859,30 @@ struct HostBuf // pinned
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+struct View // a piece of one of the arenas below
+{
+    void* p = nullptr;
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+// The job's small arrays live in a few arenas so that a job is a handful of copies and fills, not dozens (each one costs 4-5 us on
+// the stream whatever its size): everything that goes up before the search in `in_arena` (packed in a pinned mirror, one copy), every
+// array that starts at zero in `zero_arena` (one fill; the parts the host reads come back in one copy per synchronisation point)
 struct EnumBuffers
 {
-    DevBuf tab, ins, toggle, ref, reads, read_off, read_code, read_qual, consulted;
-    DevBuf level_a, level_b, counters, pool, leaf_read, leaf_hash, n_raw, status, warn;
-    DevBuf raw_off, fill, grouped, ghash, gkey, dup, n_uniq, sorted;
-    DevBuf n_ops, hap_len, win_begin, win_end, ins_lo, ins_hi, win_len, n_ins, ins_idx, ins_off;
-    DevBuf cal_off, hap_off, cals, hap_code, op_off, ops, entries, evmask, scores, colmat, colmat_off, addmask;
-    DevBuf r2i, i2r, orig, map_level, s3_order, s3_smooth, s3_flag, s3_rm_type, s3_rm_pos, s3_key, s3_sorted_score, s3_sorted_hash, s3_next_same, s3_range_end, s3_removed, s3_out, s3_list;
+    DevBuf in_arena, zero_arena, minmax_arena, mask_arena;
+    HostBuf h_in_arena, h_zero_arena;
+    View tab, ins, toggle, ref, reads, read_off, read_code, read_qual, r2i, i2r, orig, map_level;
+    View counters, status, warn, n_raw, hap_len, fill, n_uniq, consulted;
+    View win_begin, ins_lo, win_end, ins_hi, evmask, addmask;
+    View h_counters, h_status, h_warn, h_n_raw, h_hap_len, h_n_uniq, h_consulted;
+    DevBuf level_a, level_b, pool, leaf_read, leaf_hash;
+    DevBuf raw_off, grouped, ghash, gkey, dup, sorted;
+    DevBuf n_ops, win_len, n_ins, ins_idx, ins_off;
+    DevBuf cal_off, hap_off, cals, hap_code, op_off, ops, entries, scores, colmat, colmat_off;
+    DevBuf s3_order, s3_smooth, s3_flag, s3_rm_type, s3_rm_pos, s3_key, s3_sorted_score, s3_sorted_hash, s3_next_same, s3_range_end, s3_removed, s3_out, s3_list;
     HostBuf h_s3_out, h_s3_list;
-    HostBuf h_status, h_warn, h_n_raw, h_raw_off, h_n_uniq, h_n_ops, h_hap_len, h_cal_off, h_hap_off, h_op_off, h_cals, h_scores,
-        h_consulted, h_counters, h_colmat_off;
+    HostBuf h_raw_off, h_n_ops, h_cal_off, h_hap_off, h_op_off, h_cals, h_scores, h_colmat_off;
 };
 EnumBuffers& bufs()
 {
@@ -936,70 +950,98 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     if (B.buf.reserve(std::max<size_t>(size_t(bytes), 256))) return 1
 #define HRES(buf, bytes) \
     if (B.buf.reserve(size_t(bytes) + 64)) return 1
-    RES(tab, sizeof(PIndel) * size_t(in->n_tab));
-    RES(ins, size_t(in->ins_pool_len));
-    RES(toggle, sizeof(uint32_t) * size_t(in->n_max_toggle));
-    RES(ref, size_t(std::max(in->ref_len, 0)));
-    RES(reads, sizeof(PRead) * size_t(n));
-    RES(read_off, sizeof(int64_t) * size_t(n + 1));
-    RES(read_code, size_t(n_bases));
-    RES(read_qual, size_t(n_bases));
-    RES(consulted, size_t(in->n_tab) + 1);
     RES(level_a, sizeof(PFrame) * size_t(frame_cap));
     RES(level_b, sizeof(PFrame) * size_t(frame_cap));
-    RES(counters, 4 * size_t(n_counters));
     RES(pool, sizeof(PCal) * size_t(pool_cap));
     RES(leaf_read, 4 * size_t(pool_cap));
     RES(leaf_hash, 4 * size_t(pool_cap));
-    RES(n_raw, 4 * size_t(n));
-    RES(status, 4 * size_t(n));
-    RES(warn, 4 * size_t(n));
     RES(raw_off, 4 * size_t(n + 1));
-    RES(fill, 4 * size_t(n));
-    RES(n_uniq, 4 * size_t(n));
-    RES(hap_len, 4 * size_t(n));
-    RES(win_begin, 4 * size_t(n));
-    RES(win_end, 4 * size_t(n));
-    RES(ins_lo, 4 * size_t(n));
-    RES(ins_hi, 4 * size_t(n));
     RES(win_len, 4 * size_t(n));
     RES(n_ins, 4 * size_t(n));
     RES(ins_idx, 2 * size_t(n) * INS_CAP);
     RES(ins_off, 4 * size_t(n) * INS_CAP);
     RES(cal_off, 4 * size_t(n + 1));
     RES(hap_off, 8 * size_t(n + 1));
-    HRES(h_status, 4 * size_t(n));
-    HRES(h_warn, 4 * size_t(n));
-    HRES(h_n_raw, 4 * size_t(n));
     HRES(h_raw_off, 4 * size_t(n + 1));
-    HRES(h_n_uniq, 4 * size_t(n));
-    HRES(h_hap_len, 4 * size_t(n));
     HRES(h_cal_off, 4 * size_t(n + 1));
     HRES(h_hap_off, 8 * size_t(n + 1));
-    HRES(h_consulted, size_t(in->n_tab));
-    HRES(h_counters, 4 * size_t(n_counters));
+    const bool with_stage3 = in->want_scores && in->want_stage3;
+    const int W = sk_ent_evmask_words(std::max(in->max_read_len, 0));
+    // ---- the arenas: pieces at 256-byte offsets
+    struct Piece
+    {
+        View* view;
+        const void* src; // in_arena: where the bytes come from
+        size_t bytes, off;
+    };
+    auto lay_out = [](Piece* pc, const int n_pieces) {
+        size_t at = 0;
+        for (int i = 0; i < n_pieces; ++i) {
+            pc[i].off = at;
+            at += (pc[i].bytes + 255) & ~size_t(255);
+        }
+        return at;
+    };
+    Piece ins_p[] = {
+        { &B.tab, in->tab, sizeof(PIndel) * size_t(in->n_tab), 0 },
+        { &B.ins, in->ins_pool, size_t(in->ins_pool_len), 0 },
+        { &B.toggle, in->max_toggle, sizeof(uint32_t) * size_t(in->n_max_toggle), 0 },
+        { &B.ref, in->ref, size_t(std::max(in->ref_len, 0)), 0 },
+        { &B.reads, in->reads, sizeof(PRead) * size_t(n), 0 },
+        { &B.read_off, in->read_off, sizeof(int64_t) * size_t(n + 1), 0 },
+        { &B.read_code, in->read_code, size_t(n_bases), 0 },
+        { &B.read_qual, in->read_qual, size_t(n_bases), 0 },
+        { &B.r2i, in->r2i, with_stage3 ? 8 * size_t(in->n_tab) : 0, 0 },
+        { &B.i2r, in->i2r, with_stage3 ? 8 * size_t(in->n_tab) : 0, 0 },
+        { &B.orig, in->orig, with_stage3 ? 4 * size_t(in->n_tab) : 0, 0 },
+        { &B.map_level, in->map_level, with_stage3 ? 4 * size_t(n) : 0, 0 },
+    };
+    const int n_ins_p = int(sizeof(ins_p) / sizeof(ins_p[0]));
+    const size_t in_bytes = lay_out(ins_p, n_ins_p);
+    // (the order matters: what the host reads after the search is one run, what it reads after the layout another)
+    Piece zero_p[] = {
+        { &B.counters, nullptr, 4 * size_t(n_counters), 0 }, { &B.warn, nullptr, 4 * size_t(n), 0 },    { &B.n_raw, nullptr, 4 * size_t(n), 0 },
+        { &B.status, nullptr, 4 * size_t(n), 0 },            { &B.hap_len, nullptr, 4 * size_t(n), 0 }, { &B.fill, nullptr, 4 * size_t(n), 0 },
+        { &B.n_uniq, nullptr, 4 * size_t(n), 0 },            { &B.consulted, nullptr, size_t(in->n_tab) + 1, 0 },
+    };
+    View* zero_host[] = { &B.h_counters, &B.h_warn, &B.h_n_raw, &B.h_status, &B.h_hap_len, nullptr, &B.h_n_uniq, &B.h_consulted };
+    const int n_zero_p = int(sizeof(zero_p) / sizeof(zero_p[0]));
+    const size_t zero_bytes = lay_out(zero_p, n_zero_p);
+    Piece minmax_p[] = { { &B.win_begin, nullptr, 4 * size_t(n), 0 }, { &B.ins_lo, nullptr, 4 * size_t(n), 0 },
+                         { &B.win_end, nullptr, 4 * size_t(n), 0 },   { &B.ins_hi, nullptr, 4 * size_t(n), 0 } };
+    const size_t minmax_bytes = lay_out(minmax_p, 4);
+    Piece mask_p[] = { { &B.evmask, nullptr, 4 * (size_t(n) * size_t(W) + 1), 0 }, { &B.addmask, nullptr, 4 * (size_t(n) * size_t(W) + 1), 0 } };
+    const size_t mask_bytes = lay_out(mask_p, 2);
+    RES(in_arena, in_bytes);
+    RES(zero_arena, zero_bytes);
+    RES(minmax_arena, minmax_bytes);
+    RES(mask_arena, mask_bytes);
+    HRES(h_in_arena, in_bytes);
+    HRES(h_zero_arena, zero_bytes);
+    for (int i = 0; i < n_ins_p; ++i) {
+        ins_p[i].view->p = static_cast<char*>(B.in_arena.p) + ins_p[i].off;
+        if (ins_p[i].bytes) std::memcpy(static_cast<char*>(B.h_in_arena.p) + ins_p[i].off, ins_p[i].src, ins_p[i].bytes);
+    }
+    for (int i = 0; i < n_zero_p; ++i) {
+        zero_p[i].view->p = static_cast<char*>(B.zero_arena.p) + zero_p[i].off;
+        if (zero_host[i]) zero_host[i]->p = static_cast<char*>(B.h_zero_arena.p) + zero_p[i].off;
+    }
+    for (int i = 0; i < 4; ++i) minmax_p[i].view->p = static_cast<char*>(B.minmax_arena.p) + minmax_p[i].off;
+    for (int i = 0; i < 2; ++i) mask_p[i].view->p = static_cast<char*>(B.mask_arena.p) + mask_p[i].off;
+    // a run of the zero arena, device -> its pinned mirror
+    auto fetch_zero = [&](const View& first, const View& last, const size_t last_bytes) -> int {
+        const size_t a0 = size_t(static_cast<char*>(first.p) - static_cast<char*>(B.zero_arena.p));
+        const size_t a1 = size_t(static_cast<char*>(last.p) - static_cast<char*>(B.zero_arena.p)) + last_bytes;
+        SK_HIP(hipMemcpyAsync(static_cast<char*>(B.h_zero_arena.p) + a0, static_cast<char*>(B.zero_arena.p) + a0, a1 - a0, hipMemcpyDeviceToHost, st));
+        return 0;
+    };
 
 #define H2D(buf, src, bytes) \
     if ((bytes) > 0) SK_HIP(hipMemcpyAsync(B.buf.p, src, size_t(bytes), hipMemcpyHostToDevice, st))
 #define D2H(hbuf, buf, bytes) \
     if ((bytes) > 0) SK_HIP(hipMemcpyAsync(B.hbuf.p, B.buf.p, size_t(bytes), hipMemcpyDeviceToHost, st))
-    H2D(tab, in->tab, sizeof(PIndel) * size_t(in->n_tab));
-    H2D(ins, in->ins_pool, in->ins_pool_len);
-    H2D(toggle, in->max_toggle, sizeof(uint32_t) * size_t(in->n_max_toggle));
-    H2D(ref, in->ref, std::max(in->ref_len, 0));
-    H2D(reads, in->reads, sizeof(PRead) * size_t(n));
-    H2D(read_off, in->read_off, sizeof(int64_t) * size_t(n + 1));
-    H2D(read_code, in->read_code, n_bases);
-    H2D(read_qual, in->read_qual, n_bases);
-    SK_HIP(hipMemsetAsync(B.consulted.p, 0, size_t(in->n_tab) + 1, st));
-    SK_HIP(hipMemsetAsync(B.counters.p, 0, 4 * size_t(n_counters), st));
-    if (n > 0) {
-        SK_HIP(hipMemsetAsync(B.n_raw.p, 0, 4 * size_t(n), st));
-        SK_HIP(hipMemsetAsync(B.status.p, 0, 4 * size_t(n), st));
-        SK_HIP(hipMemsetAsync(B.warn.p, 0, 4 * size_t(n), st));
-        SK_HIP(hipMemsetAsync(B.fill.p, 0, 4 * size_t(n), st));
-        SK_HIP(hipMemsetAsync(B.n_uniq.p, 0, 4 * size_t(n), st));
-    }
+    if (in_bytes > 0) SK_HIP(hipMemcpyAsync(B.in_arena.p, B.h_in_arena.p, in_bytes, hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemsetAsync(B.zero_arena.p, 0, zero_bytes, st));
 
     int32_t* h_cal_off = B.h_cal_off.as<int32_t>();
     h_cal_off[0] = 0;
@@ -1048,7 +1090,6 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         ea.level_out = buf[0];
         ea.depth = -1;
         hipLaunchKernelGGL(root_kernel, dim3((n + 63) / 64), dim3(64), 0, st, ea);
-        SK_HIP(hipMemcpyAsync(ea.level_count, &in->n_reads, 4, hipMemcpyHostToDevice, st));
         const size_t lds = 64 * sizeof(PFrame);
         const int blocks = int(std::min<int64_t>((frame_cap + 63) / 64, 1024));
         // a call at depth d expands indel order[d]; a call at depth n_order is a leaf.  A read's order as it arrives says how deep its
@@ -1067,10 +1108,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
             }
             done = upto;
             SK_HIP(hipGetLastError());
-            D2H(h_status, status, 4 * size_t(n));
-            D2H(h_warn, warn, 4 * size_t(n));
-            D2H(h_n_raw, n_raw, 4 * size_t(n));
-            D2H(h_counters, counters, 4 * size_t(n_counters));
+            if (fetch_zero(B.counters, B.status, 4 * size_t(n))) return 1; // counters, warn, n_raw, status
             SK_HIP(hipStreamSynchronize(st));
             if (done >= Caps::K + 2 || B.h_counters.as<int32_t>()[done] == 0) break;
             batch = 4;
@@ -1130,7 +1168,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         hipLaunchKernelGGL(dedupe_kernel, dim3((n_grouped + 255) / 256), dim3(256), 0, st, sa);
         SK_HIP(hipGetLastError());
     }
-    D2H(h_n_uniq, n_uniq, 4 * size_t(n));
+    if (fetch_zero(B.n_uniq, B.n_uniq, 4 * size_t(n))) return 1;
     SK_HIP(hipStreamSynchronize(st));
     const int32_t* h_n_uniq = B.h_n_uniq.as<int32_t>();
     for (int r = 0; r < n; ++r) h_cal_off[r + 1] = h_cal_off[r] + ((h_status[r] == ST_OK) ? h_n_uniq[r] : 0);
@@ -1173,10 +1211,8 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     fa.ins_lo = B.ins_lo.as<int32_t>();
     fa.ins_hi = B.ins_hi.as<int32_t>();
     // (byte patterns: 0x7f7f7f7f is large enough to stand for "no lower bound yet", 0x80808080 is below any position / index)
-    SK_HIP(hipMemsetAsync(fa.win_begin, 0x7f, 4 * size_t(n), st));
-    SK_HIP(hipMemsetAsync(fa.ins_lo, 0x7f, 4 * size_t(n), st));
-    SK_HIP(hipMemsetAsync(fa.win_end, 0x80, 4 * size_t(n), st));
-    SK_HIP(hipMemsetAsync(fa.ins_hi, 0x80, 4 * size_t(n), st));
+    SK_HIP(hipMemsetAsync(B.minmax_arena.p, 0x7f, minmax_p[2].off, st));                               // win_begin, ins_lo
+    SK_HIP(hipMemsetAsync(static_cast<char*>(B.minmax_arena.p) + minmax_p[2].off, 0x80, minmax_bytes - minmax_p[2].off, st)); // win_end, ins_hi
     if (n_cals > 0) hipLaunchKernelGGL(pool_bounds_kernel, dim3((n_cals + 255) / 256), dim3(256), 0, st, fa);
     hipLaunchKernelGGL(pool_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
     SK_HIP(hipGetLastError());
@@ -1184,8 +1220,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         hipLaunchKernelGGL(op_count_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
         SK_HIP(hipGetLastError());
     }
-    D2H(h_status, status, 4 * size_t(n));
-    D2H(h_hap_len, hap_len, 4 * size_t(n));
+    if (fetch_zero(B.status, B.hap_len, 4 * size_t(n))) return 1; // status, hap_len (the host has made bytes of its copy of warn)
     D2H(h_n_ops, n_ops, 4 * size_t(n_cals));
     SK_HIP(hipStreamSynchronize(st));
     lap("L1+L2 layout");
@@ -1205,13 +1240,11 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         for (int32_t c = c0; c < c1; ++c) h_op_off[c + 1] = h_op_off[c] + (ok ? h_n_ops[c] : 0);
     }
     const int64_t n_hap = h_hap_off[n], ops_total = h_op_off[n_cals];
-    const int W = sk_ent_evmask_words(std::max(in->max_read_len, 0));
 
     RES(cals, sizeof(PCal) * size_t(n_cals));
     RES(hap_code, size_t(n_hap) + 16);
     RES(ops, sizeof(sk_score_op) * size_t(ops_total));
     RES(entries, 4 * (size_t(ops_total) + 2 * size_t(n_cals) + 1));
-    RES(evmask, 4 * (size_t(n) * size_t(W) + 1));
     RES(scores, 8 * size_t(n_cals));
     HRES(h_colmat_off, 8 * size_t(n + 1));
     int64_t* h_colmat_off = B.h_colmat_off.as<int64_t>();
@@ -1221,7 +1254,6 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     const int64_t colmat_words = h_colmat_off[n];
     RES(colmat, 4 * size_t(colmat_words) + 16);
     RES(colmat_off, 8 * size_t(n + 1));
-    RES(addmask, 4 * (size_t(n) * size_t(W) + 1));
     if (!(in->want_scores && in->want_stage3)) HRES(h_cals, sizeof(PCal) * size_t(n_cals));
     HRES(h_scores, 8 * size_t(n_cals));
     out->cals = B.h_cals.as<PCal>();
@@ -1230,8 +1262,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     if (n_cals > 0) {
         SK_HIP(hipMemcpyAsync(B.hap_off.p, h_hap_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
         SK_HIP(hipMemcpyAsync(B.op_off.p, h_op_off, 8 * size_t(n_cals + 1), hipMemcpyHostToDevice, st));
-        SK_HIP(hipMemsetAsync(B.evmask.p, 0, 4 * size_t(n) * size_t(W), st));
-        SK_HIP(hipMemsetAsync(B.addmask.p, 0, 4 * size_t(n) * size_t(W), st));
+        SK_HIP(hipMemsetAsync(B.mask_arena.p, 0, mask_bytes, st)); // evmask, addmask
         SK_HIP(hipMemsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), 4 * size_t(colmat_words) + 16, st));
         SK_HIP(hipMemcpyAsync(B.colmat_off.p, h_colmat_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
         fa.hap_off = B.hap_off.as<int64_t>();
@@ -1281,10 +1312,6 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
             D2H(h_scores, scores, 8 * size_t(n_cals));
             out->scores = B.h_scores.as<double>();
             if (in->want_stage3) {
-                RES(r2i, 8 * size_t(in->n_tab));
-                RES(i2r, 8 * size_t(in->n_tab));
-                RES(orig, 4 * size_t(in->n_tab));
-                RES(map_level, 4 * size_t(n));
                 RES(s3_order, 4 * size_t(n_cals));
                 RES(s3_smooth, 8 * size_t(n_cals));
                 RES(s3_flag, size_t(n_cals));
@@ -1298,10 +1325,6 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
                 RES(s3_range_end, 4 * size_t(n_cals));
                 RES(s3_out, sizeof(sk3::Out) * size_t(n));
                 HRES(h_s3_out, sizeof(sk3::Out) * size_t(n));
-                H2D(r2i, in->r2i, 8 * size_t(in->n_tab));
-                H2D(i2r, in->i2r, 8 * size_t(in->n_tab));
-                H2D(orig, in->orig, 4 * size_t(in->n_tab));
-                H2D(map_level, in->map_level, 4 * size_t(n));
                 Stage3Args s3;
                 s3.tab.tab = dj.tab;
                 s3.tab.r2i = B.r2i.as<double>();
@@ -1372,7 +1395,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
             }
         }
     }
-    D2H(h_consulted, consulted, size_t(in->n_tab));
+    if (fetch_zero(B.consulted, B.consulted, size_t(in->n_tab))) return 1;
     SK_HIP(hipStreamSynchronize(st));
     lap("done");
 #undef RES
