@@ -197,13 +197,6 @@ __device__ inline ulonglong2 leaf_key(const PCal& c)
     k.y = ((seg(1) & 0xffffull) << 48) | (seg(2) << 28) | (seg(3) << 8);
     return k;
 }
-__device__ inline int key_compare(const ulonglong2& a, const ulonglong2& b)
-{
-    if (a.x != b.x) return a.x < b.x ? -1 : 1;
-    if (a.y != b.y) return a.y < b.y ? -1 : 1;
-    return 0;
-}
-
 __global__ __launch_bounds__(256) void group_kernel(const SetArgs a)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,35 +210,65 @@ __global__ __launch_bounds__(256) void group_kernel(const SetArgs a)
 }
 
 // a leaf is a duplicate when an equal leaf stands before it in its read's group (which of the equal ones stands first differs
-// from run to run; they are equal)
+// from run to run; they are equal).  The scan over the group is a plain comparison of hashes with nothing in the loop that waits
+// for a load (reads with thousands of leaves make it long); the records are compared only where a hash is met again.
 __global__ __launch_bounds__(256) void dedupe_kernel(const SetArgs a)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.raw_off[a.n_reads]) return;
     const int r = group_of(a.raw_off, a.n_reads, g);
     const uint32_t h = a.ghash[g];
+    const int q0 = a.raw_off[r];
     bool dup = false;
-    for (int q = a.raw_off[r]; q < g && !dup; ++q)
-        if (a.ghash[q] == h && cal_compare(a.pool[a.grouped[q]], a.pool[a.grouped[g]]) == 0) dup = true;
+    for (int from = q0; from < g && !dup;) {
+        int first = g; // the first leaf at or after `from` with this hash
+        int q = from;
+        for (; q + 8 <= g; q += 8) {
+            uint32_t v[8];
+            for (int z = 0; z < 8; ++z) v[z] = a.ghash[q + z];
+            for (int z = 7; z >= 0; --z) first = (v[z] == h && q + z < first) ? q + z : first;
+            if (first < g) break;
+        }
+        if (first == g)
+            for (; q < g; ++q)
+                if (a.ghash[q] == h) {
+                    first = q;
+                    break;
+                }
+        if (first >= g) break;
+        if (cal_compare(a.pool[a.grouped[first]], a.pool[a.grouped[g]]) == 0) dup = true;
+        from = first + 1;
+    }
     a.dup[g] = dup ? 1 : 0;
     if (!dup) atomicAdd(&a.n_uniq[r], 1);
 }
 
-// the rank of a kept leaf in the set order of its read (CandidateAlignment.hh:37-48, alignment.hh:72-90: cal_compare)
+// the rank of a kept leaf in the set order of its read (CandidateAlignment.hh:37-48, alignment.hh:72-90: cal_compare): the keys
+// decide for almost every pair, without a branch; pairs with equal keys (their number is counted on the way) get the full comparison
 __global__ __launch_bounds__(256) void rank_kernel(const SetArgs a)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.raw_off[a.n_reads]) return;
     if (a.dup[g]) return;
     const int r = group_of(a.raw_off, a.n_reads, g);
-    const PCal& mine = a.pool[a.grouped[g]];
     const ulonglong2 kmine = a.gkey[g];
-    int rank = 0;
-    for (int q = a.raw_off[r]; q < a.raw_off[r + 1]; ++q) {
-        if (q == g || a.dup[q]) continue;
-        int c = key_compare(a.gkey[q], kmine);
-        if (c == 0) c = cal_compare(a.pool[a.grouped[q]], mine);
-        if (c < 0) ++rank;
+    const int q0 = a.raw_off[r], q1 = a.raw_off[r + 1];
+    int rank = 0, n_equal = 0;
+    for (int q = q0; q < q1; ++q) {
+        const ulonglong2 k = a.gkey[q];
+        const bool kept = a.dup[q] == 0;
+        const bool lower = (k.x < kmine.x) || (k.x == kmine.x && k.y < kmine.y);
+        const bool equal = (k.x == kmine.x) && (k.y == kmine.y);
+        rank += (kept && lower) ? 1 : 0;
+        n_equal += (kept && equal) ? 1 : 0;
+    }
+    if (n_equal > 1) { // (itself and others)
+        const PCal& mine = a.pool[a.grouped[g]];
+        for (int q = q0; q < q1; ++q) {
+            if (q == g || a.dup[q]) continue;
+            const ulonglong2 k = a.gkey[q];
+            if (k.x == kmine.x && k.y == kmine.y && cal_compare(a.pool[a.grouped[q]], mine) < 0) ++rank;
+        }
     }
     a.sorted[a.cal_off[r] + rank] = a.grouped[g];
 }
@@ -723,10 +746,10 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
 // reference defines by iteration order (see the header).  What leaves the device is a fixed-size record per read.
 enum { S3_LIGHT_CALS = 256, S3_LDS_CALS = 1580 }; // (1580 alignments: 53 KB; with the shared state that stays under 64 KB per workgroup)
 
-struct WaveLanes
+struct WaveLanes // the lanes of a workgroup: one wavefront for most reads, four for reads with many candidate alignments
 {
     int id, width;
-    __device__ void sync() const { __syncthreads(); } // (the workgroup is this one wavefront)
+    __device__ void sync() const { __syncthreads(); }
     __device__ void max_i64(long long* p, const long long v) const { atomicMax(p, v); }
 };
 
@@ -758,8 +781,10 @@ struct Stage3Args
     int32_t lds_cals;
 };
 
-__global__ __launch_bounds__(64) void stage3_kernel(const Stage3Args a)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void stage3_kernel(const Stage3Args a)
 {
+    constexpr int T = 64 * WAVES;
     __shared__ sk3::Shared sh;
     extern __shared__ double s3_lds[]; // the per-alignment arrays of the selection and the late normalisation filter, for a read with at most a.lds_cals candidate alignments
     const int r = a.list[blockIdx.x];
@@ -777,10 +802,17 @@ __global__ __launch_bounds__(64) void stage3_kernel(const Stage3Args a)
     rd.n_cals = c1 - c0;
     rd.map_level = a.map_level[r];
     rd.read_length = int32_t(b1 - b0);
-    int na = 0;
-    for (int64_t i = b0 + threadIdx.x; i < b1; i += 64) na += (a.read_code[i] != SK_BAM_ANY) ? 1 : 0;
-    for (int d = 32; d > 0; d >>= 1) na += __shfl_xor(na, d);
-    rd.non_ambig = na;
+    if (threadIdx.x == 0) sh.ne = 0; // (borrowed as the counter of bases that are not N)
+    __syncthreads();
+    {
+        int na = 0;
+        for (int64_t i = b0 + threadIdx.x; i < b1; i += T) na += (a.read_code[i] != SK_BAM_ANY) ? 1 : 0;
+        for (int d = 32; d > 0; d >>= 1) na += __shfl_xor(na, d);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sh.ne, na);
+    }
+    __syncthreads();
+    rd.non_ambig = sh.ne;
+    __syncthreads();
     sk3::Scratch w;
     w.order = a.order + c0;
     w.smooth = a.smooth + c0;
@@ -803,7 +835,7 @@ __global__ __launch_bounds__(64) void stage3_kernel(const Stage3Args a)
         int32_t* rend = nxt + a.lds_cals;
         uint8_t* fl = reinterpret_cast<uint8_t*>(rend + a.lds_cals);
         uint8_t* rem = fl + a.lds_cals;
-        for (int i = threadIdx.x; i < rd.n_cals; i += 64) sc[i] = rd.scores[i];
+        for (int i = threadIdx.x; i < rd.n_cals; i += T) sc[i] = rd.scores[i];
         __syncthreads();
         rd.scores_select = sc;
         w.smooth = sc;
@@ -817,7 +849,7 @@ __global__ __launch_bounds__(64) void stage3_kernel(const Stage3Args a)
     }
     WaveLanes ln;
     ln.id = int(threadIdx.x);
-    ln.width = 64;
+    ln.width = T;
     sk3::finish_read(ln, a.tab, a.opt, rd, w, sh, o);
 }
 
@@ -1380,12 +1412,15 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
                 if (n_light > 0) {
                     s3.list = B.s3_list.as<int32_t>();
                     s3.lds_cals = light_cals;
-                    hipLaunchKernelGGL(stage3_kernel, dim3(n_light), dim3(64), lds_bytes(light_cals), st, s3);
+                    hipLaunchKernelGGL(stage3_kernel<1>, dim3(n_light), dim3(64), lds_bytes(light_cals), st, s3);
                 }
                 if (n_heavy > 0) {
                     s3.list = B.s3_list.as<int32_t>() + (n - n_heavy);
                     s3.lds_cals = std::min(max_cals, lds_cals); // (a read with more uses the arrays in HBM)
-                    hipLaunchKernelGGL(stage3_kernel, dim3(n_heavy), dim3(64), lds_bytes(s3.lds_cals), st, s3);
+                    // four wavefronts per read: the loops over the read's alignments go four times as wide, lane 0's share stays
+                    static const bool one_wave = std::getenv("SK_STAGE3_ONE_WAVE") != nullptr; // (diagnostics)
+                    if (one_wave) hipLaunchKernelGGL(stage3_kernel<1>, dim3(n_heavy), dim3(64), lds_bytes(s3.lds_cals), st, s3);
+                    else hipLaunchKernelGGL(stage3_kernel<4>, dim3(n_heavy), dim3(256), lds_bytes(s3.lds_cals), st, s3);
                 }
                 if (timing) std::fprintf(stderr, "[enum-dev] stage 3: %d reads with at most %d candidate alignments, %d with more (up to %d)\n", n_light, light_cals, n_heavy, max_cals);
                 SK_HIP(hipGetLastError());

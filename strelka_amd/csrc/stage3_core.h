@@ -24,6 +24,7 @@ enum {
     RL_MAX = 1024, // read length the clipper's per-base map holds
     OUT_SEGS = Caps::P + 4,
     RAISED_WORDS = 64, // 32-bit words of the late normalisation filter's set of raised shape hashes
+    MAX_LANES = 256, // of a lane group
     CONF_SPAN = 256 // table indices one read's alignments span, for the conflict table of score_indels
 };
 enum { S3_OK = 0, S3_CAPACITY = 1, S3_FAIL = 2 };
@@ -335,7 +336,6 @@ SKC_HD inline bool cal_has(const PCal& c, const int idx)
     return a < c.n_indels && c.indels[a] == idx;
 }
 
-SKC_HD inline bool pair_less(const double* sc, const int a, const int b) { return sc[a] < sc[b] || (sc[a] == sc[b] && a < b); }
 
 // ---- cooperative form ------------------------------------------------------------------------------------------------------------
 // Stage 3 of one read is run by a group of lanes: one on the host (HostLanes below), the 64 lanes of a wavefront on the device
@@ -380,17 +380,17 @@ struct Shared
     int32_t status;
     int32_t max_i, smooth_i, n_pool, nmap;
     double max_score;
-    int32_t done, any_excluded, found;
+    int32_t any_excluded, found;
     int32_t n_raised;
     uint32_t raised_bits[RAISED_WORDS]; // a set of (shape hash mod size) of the places whose smoothed score is no longer their score
     long long idx_hi, idx_nlo; // the largest table index in the read's alignments, the largest negated one
     uint16_t conf_mask[CONF_SPAN]; // [i - idx_min]: the evaluated indels table indel i (not a mismatch) conflicts with
     uint8_t eval_slot[CONF_SPAN];  // [i - idx_min]: which evaluated indel table indel i is, 0xff: none
-    int32_t lo, hi, ne, want_best;
+    int32_t lo, hi, ne;
     int16_t to_eval[E_MAX];
     uint32_t ortho[E_MAX];
-    double red_score[64];
-    int32_t red_i[64];
+    double red_score[MAX_LANES]; // per lane: the best alignment holding the indel at hand
+    int32_t red_i[MAX_LANES];
     long long info[2 * E_MAX * E_MAX]; // [evaluated indel][is present][which indel] -> f64_key of the best score
 };
 
