@@ -100,6 +100,19 @@ HOOKS = [
          r'\nvoid\ngetVariantAlleleGroupGenotypeLhoodsForSample\(',
          '\nvoid\ngetVariantAlleleGroupGenotypeLhoodsForSample_reference('),
     ]),
+    (L + "htsapi/bam_streamer.cpp", [
+        ("include", r'#include "htsapi/bam_streamer.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # site 8: the region's reads through the feed
+        ("resetRegion",
+         r'(    _is_region = true;\n    _region\.clear\(\);\n)',
+         '\\1    sk_adapter::feed_reset_region(this, name(), referenceContigId, beginPos, endPos);\n'),
+        ("next",
+         r'        ret = sam_itr_next\(_hfp, _hitr, _brec\._bp\);\n',
+         '        ret = sk_adapter::feed_active(this) ? sk_adapter::feed_next(this, _brec._bp) : sam_itr_next(_hfp, _hitr, _brec._bp);\n'),
+        ("destructor",
+         r'(bam_streamer::\n~bam_streamer\(\)\n\{\n)',
+         '\\1    sk_adapter::feed_drop(this);\n'),
+    ]),
     (L + "starling_common/ActiveRegionProcessor.cpp", [
         ("include", r'#include "ActiveRegionProcessor.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
         # site 7: haplotype alignment + allele discovery

@@ -87,4 +87,13 @@ bool discover_indels_and_mismatches(const std::string& haplotypeSeq, const std::
                                     const pos_t prevActiveRegionEnd, const unsigned maxIndelSize,
                                     std::vector<IndelKey>& discovered, int& numIndels);
 
+// ---- site 8: the reads of a region, bam_streamer::resetRegion / next (L/htsapi/bam_streamer.cpp:211-287) ----
+/// index lookup, block inflation and record selection for [begin, end) of reference `tid` through the feed entry points of the C-ABI;
+/// false: this streamer keeps the reference's own iterator (not a BAM with a .bai, or STRELKA_AMD_FEED=0)
+bool feed_reset_region(const void* streamer, const char* name, const int tid, const int begin, const int end);
+bool feed_active(const void* streamer);
+/// the next record of the region into the streamer's bam1_t, as sam_itr_next returns it (>= 0, -1 at the end, < -1 on a bad record)
+int feed_next(const void* streamer, void* bam1);
+void feed_drop(const void* streamer);
+
 }

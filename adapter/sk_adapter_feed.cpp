@@ -1,0 +1,295 @@
+// sk_adapter_feed.cpp -- site 8: the reads of a region, from the file to bam_record, through the feed entry points of the C-ABI.
+//
+// bam_streamer::resetRegion (L/htsapi/bam_streamer.cpp:211-243) asks htslib for an iterator (sam_itr_queryi) and next() (:246-287)
+// pulls one record at a time through it (sam_itr_next: bgzf seek, zlib inflate block by block, bam_read1).  Here resetRegion has the
+// index answer the region (sk_bai_query), reads the byte ranges of the chunks, inflates all their BGZF blocks in one call
+// (sk_bgzf_inflate: the kernels), finds and decodes the records (sk_bam_scan_records, sk_bam_decode) and applies the iterator's test
+// (sk_bam_region_filter); next() then hands the reference its bam1_t one record after the other, filled from the record's bytes the
+// way bam_read1 (htslib sam.c:435-500) fills it.  Everything after that -- bam_record's accessors, the read filters,
+// normalizeBamRecordAlignment -- is the reference's, untouched.
+//
+// Falls back to the reference's own iterator (returns false from feed_reset_region) for anything that is not a BAM file with a .bai
+// next to it, and with STRELKA_AMD_FEED=0.
+
+#include "sk_adapter.hh"
+#include "sk_adapter_access.hh"
+
+#include "blt_util/blt_exception.hh"
+
+#include "strelka_amd.h"
+
+extern "C" {
+#include "htslib/hts.h"
+#include "htslib/sam.h"
+}
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace sk_adapter
+{
+
+namespace
+{
+
+struct BamFile
+{
+    int fd = -1;
+    int64_t size = 0;
+    std::vector<uint8_t> bai;
+    bool usable = false;
+};
+
+struct Feed
+{
+    std::vector<uint8_t> bytes;  // the region's records, raw (block_size field included), one after the other
+    std::vector<size_t> rec_at;
+    size_t next = 0;
+};
+
+struct FeedState
+{
+    std::map<std::string, BamFile> files;
+    std::map<const void*, Feed> feeds;
+    unsigned long regions = 0, records = 0, blocks = 0, inflated = 0;
+    ~FeedState()
+    {
+        if (std::getenv("STRELKA_AMD_VERBOSE") && std::atoi(std::getenv("STRELKA_AMD_VERBOSE")) != 0)
+            std::cerr << "strelka_amd adapter feed: regions=" << regions << " records=" << records << " bgzf_blocks=" << blocks
+                      << " inflated_bytes=" << inflated << "\n";
+        for (auto& f : files)
+            if (f.second.fd >= 0) ::close(f.second.fd);
+    }
+};
+FeedState& fs()
+{
+    static FeedState s;
+    return s;
+}
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    out.resize(size_t(n));
+    const bool ok = (n == 0) || std::fread(out.data(), 1, size_t(n), f) == size_t(n);
+    std::fclose(f);
+    return ok;
+}
+
+BamFile& bam_file(const std::string& name)
+{
+    auto it = fs().files.find(name);
+    if (it != fs().files.end()) return it->second;
+    BamFile& b = fs().files[name];
+    if (name.size() < 4 || name.compare(name.size() - 4, 4, ".bam") != 0) return b; // (CRAM and the rest: the reference's own path)
+    if (!read_file(name + ".bai", b.bai) && !read_file(name.substr(0, name.size() - 4) + ".bai", b.bai)) return b;
+    b.fd = ::open(name.c_str(), O_RDONLY);
+    struct stat st;
+    if (b.fd < 0 || ::fstat(b.fd, &st) != 0) return b;
+    b.size = int64_t(st.st_size);
+    b.usable = true;
+    return b;
+}
+
+void fail(const std::string& what, const char* name)
+{
+    std::ostringstream oss;
+    oss << "strelka_amd feed: " << what << " (file '" << name << "')";
+    throw blt_exception(oss.str().c_str());
+}
+
+inline uint32_t le32(const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24); }
+
+} // namespace
+
+bool feed_reset_region(const void* streamer, const char* name, const int tid, const int begin, const int end)
+{
+    fs().feeds.erase(streamer);
+    if (const char* e = std::getenv("STRELKA_AMD_FEED"))
+        if (std::atoi(e) == 0) return false;
+    BamFile& bf = bam_file(name);
+    if (!bf.usable) return false;
+    init();
+    Feed feed;
+    const int32_t n_chunks = sk_bai_query(bf.bai.data(), int64_t(bf.bai.size()), tid, begin, end, nullptr, 0);
+    if (n_chunks == -2) return false; // (a reference the index does not know: htslib's iterator decides what that means)
+    if (n_chunks < 0) fail("malformed .bai", name);
+    std::vector<sk_bai_chunk> chunks(size_t(n_chunks) + 1);
+    if (n_chunks > 0 && sk_bai_query(bf.bai.data(), int64_t(bf.bai.size()), tid, begin, end, chunks.data(), n_chunks) != n_chunks) fail("index query", name);
+    bool finished = false;
+    std::vector<uint8_t> raw, stream, keep;
+    std::vector<int64_t> block_off, out_off, rec_off, read_off, path_off;
+    std::vector<sk_bam_record> rec;
+    std::vector<uint8_t> code, qual;
+    std::vector<sk_path_seg> path;
+    for (int32_t c = 0; c < n_chunks && !finished; ++c) {
+        const int64_t cb = int64_t(chunks[size_t(c)].begin >> 16), ce = int64_t(chunks[size_t(c)].end >> 16);
+        const int64_t ub = int64_t(chunks[size_t(c)].begin & 0xffff), ue = int64_t(chunks[size_t(c)].end & 0xffff);
+        // the chunk's blocks: from the one at cb to the one at ce, and further ones while its last record is cut
+        int64_t want_to = std::min<int64_t>(bf.size, ce + 2 * 65536);
+        for (;;) {
+            raw.resize(size_t(want_to - cb));
+            if (::pread(bf.fd, raw.data(), raw.size(), off_t(cb)) != ssize_t(raw.size())) fail("short read", name);
+            // whole blocks of the range (sk_bgzf_scan wants whole blocks: cut the range after the last one that is whole)
+            block_off.assign(1, 0);
+            out_off.assign(1, 0);
+            int64_t at = 0;
+            while (at + 18 <= int64_t(raw.size())) {
+                if (raw[size_t(at)] != 31 || raw[size_t(at) + 1] != 139) fail("not a BGZF block where the index points", name);
+                int64_t bsize = -1;
+                const int64_t xlen = raw[size_t(at) + 10] | (raw[size_t(at) + 11] << 8);
+                for (int64_t x = 0; x + 4 <= xlen && at + 12 + x + 4 <= int64_t(raw.size());) {
+                    const uint8_t* sf = raw.data() + at + 12 + x;
+                    const int64_t slen = sf[2] | (sf[3] << 8);
+                    if (sf[0] == 66 && sf[1] == 67 && slen == 2 && at + 12 + x + 6 <= int64_t(raw.size())) bsize = (sf[4] | (sf[5] << 8)) + 1;
+                    x += 4 + slen;
+                }
+                if (bsize < 0 || at + bsize > int64_t(raw.size())) break;
+                out_off.push_back(out_off.back() + int64_t(le32(raw.data() + at + bsize - 4)));
+                at += bsize;
+                block_off.push_back(at);
+            }
+            const int32_t nb = int32_t(block_off.size()) - 1;
+            if (nb == 0) fail("no whole BGZF block in the chunk", name);
+            stream.resize(size_t(out_off.back()) + 8);
+            if (sk_bgzf_inflate(raw.data(), block_off.data(), out_off.data(), nb, stream.data())) fail(std::string("inflate: ") + sk_last_error(), name);
+            fs().blocks += unsigned(nb);
+            fs().inflated += (unsigned long)out_off.back();
+            // where the chunk ends in the inflated bytes: the block at ce (if it is among these) + ue
+            int64_t limit = out_off.back();
+            bool end_block_here = false;
+            for (int32_t b = 0; b <= nb; ++b)
+                if (cb + block_off[size_t(b)] == ce) {
+                    limit = out_off[size_t(b)] + ue;
+                    end_block_here = true;
+                }
+            const int64_t stream_len = out_off.back();
+            int64_t n_rec = sk_bam_scan_records(stream.data(), stream_len, ub, nullptr, nullptr, nullptr, 0);
+            if (n_rec < 0) fail("malformed BAM record", name);
+            rec_off.assign(size_t(n_rec) + 1, 0);
+            read_off.assign(size_t(n_rec) + 1, 0);
+            path_off.assign(size_t(n_rec) + 1, 0);
+            if (n_rec > 0 && sk_bam_scan_records(stream.data(), stream_len, ub, rec_off.data(), read_off.data(), path_off.data(), int32_t(n_rec)) != n_rec)
+                fail("record scan", name);
+            // is every record that starts inside the chunk whole?
+            int64_t next_at = ub;
+            if (n_rec > 0) next_at = rec_off[size_t(n_rec) - 1] + 4 + int64_t(le32(stream.data() + rec_off[size_t(n_rec) - 1]));
+            const bool at_eof = (cb + int64_t(raw.size()) >= bf.size);
+            if ((end_block_here || at_eof) && (next_at >= limit || at_eof)) {
+                int32_t n_in = 0;
+                while (n_in < n_rec && rec_off[size_t(n_in)] < limit) ++n_in;
+                if (n_in > 0) {
+                    rec.resize(size_t(n_in));
+                    code.resize(size_t(read_off[size_t(n_in)]) + 1);
+                    qual.resize(size_t(read_off[size_t(n_in)]) + 1);
+                    path.resize(size_t(path_off[size_t(n_in)]) + 1);
+                    keep.resize(size_t(n_in));
+                    if (sk_bam_decode(stream.data(), stream_len, rec_off.data(), n_in, read_off.data(), path_off.data(), rec.data(), code.data(), qual.data(),
+                                      path.data()))
+                        fail(std::string("decode: ") + sk_last_error(), name);
+                    const int32_t n_read = sk_bam_region_filter(rec.data(), path_off.data(), path.data(), n_in, tid, begin, end, keep.data());
+                    if (n_read < 0) fail("region filter", name);
+                    for (int32_t i = 0; i < n_in; ++i)
+                        if (keep[size_t(i)]) {
+                            const uint8_t* r = stream.data() + rec_off[size_t(i)];
+                            const size_t len = 4 + size_t(le32(r));
+                            feed.rec_at.push_back(feed.bytes.size());
+                            feed.bytes.insert(feed.bytes.end(), r, r + len);
+                        }
+                    finished = n_read < n_in;
+                }
+                break;
+            }
+            if (at_eof) break;
+            want_to = std::min<int64_t>(bf.size, want_to + 4 * 65536);
+        }
+    }
+    fs().regions++;
+    fs().records += feed.rec_at.size();
+    fs().feeds[streamer] = std::move(feed);
+    return true;
+}
+
+bool feed_active(const void* streamer) { return fs().feeds.count(streamer) != 0; }
+
+void feed_drop(const void* streamer) { fs().feeds.erase(streamer); }
+
+// bam_read1 (htslib sam.c:435-500) from the record's bytes; >= 0: a record, -1: none left, -4: a record htslib refuses
+int feed_next(const void* streamer, void* bam1)
+{
+    Feed& f = fs().feeds[streamer];
+    if (f.next >= f.rec_at.size()) return -1;
+    const uint8_t* r = f.bytes.data() + f.rec_at[f.next++];
+    bam1_t* b = static_cast<bam1_t*>(bam1);
+    bam1_core_t* c = &b->core;
+    const int32_t block_len = int32_t(le32(r));
+    if (block_len < 32) return -4;
+    uint32_t x[8];
+    for (int i = 0; i < 8; ++i) x[i] = le32(r + 4 + 4 * i);
+    c->tid = int32_t(x[0]);
+    c->pos = int32_t(x[1]);
+    c->bin = uint16_t(x[2] >> 16);
+    c->qual = uint8_t(x[2] >> 8 & 0xff);
+    c->l_qname = uint8_t(x[2] & 0xff);
+    c->l_extranul = (c->l_qname % 4 != 0) ? uint8_t(4 - c->l_qname % 4) : 0;
+    if (uint32_t(c->l_qname) + c->l_extranul > 255) return -4;
+    c->flag = uint16_t(x[3] >> 16);
+    c->n_cigar = x[3] & 0xffff;
+    c->l_qseq = int32_t(x[4]);
+    c->mtid = int32_t(x[5]);
+    c->mpos = int32_t(x[6]);
+    c->isize = int32_t(x[7]);
+    b->l_data = block_len - 32 + c->l_extranul;
+    if (b->l_data < 0 || c->l_qseq < 0 || c->l_qname < 1) return -4;
+    if ((uint64_t(c->n_cigar) << 2) + c->l_qname + c->l_extranul + ((uint64_t(c->l_qseq) + 1) >> 1) + uint64_t(c->l_qseq) > uint64_t(b->l_data)) return -4;
+    if (b->m_data < b->l_data) {
+        uint32_t new_m = uint32_t(b->l_data);
+        kroundup32(new_m);
+        uint8_t* new_data = static_cast<uint8_t*>(std::realloc(b->data, new_m));
+        if (!new_data) return -4;
+        b->data = new_data;
+        b->m_data = new_m;
+    }
+    const uint8_t* body = r + 36;
+    std::memcpy(b->data, body, c->l_qname);
+    for (int i = 0; i < c->l_extranul; ++i) b->data[c->l_qname + i] = '\0';
+    const int l_qname_file = c->l_qname;
+    c->l_qname = uint8_t(c->l_qname + c->l_extranul);
+    if (b->l_data < c->l_qname) return -4;
+    std::memcpy(b->data + c->l_qname, body + l_qname_file, size_t(b->l_data - c->l_qname));
+    // bam_tag2cigar (:367-432): a placeholder CIGAR with the real one in a CG:B,I tag (more than 65535 operations) is not handled here
+    if (c->n_cigar > 0 && c->tid >= 0 && c->pos >= 0) {
+        const uint32_t* cigar0 = bam_get_cigar(b);
+        if (bam_cigar_op(cigar0[0]) == BAM_CSOFT_CLIP && int32_t(bam_cigar_oplen(cigar0[0])) == c->l_qseq && bam_aux_get(b, "CG") != nullptr) {
+            std::cerr << "strelka_amd feed: record " << bam_get_qname(b) << " keeps its CIGAR in a CG tag; run with STRELKA_AMD_FEED=0\n";
+            return -4;
+        }
+    }
+    if (c->n_cigar > 0) { // :484-495: "bin" recomputed, CIGAR against the query length
+        int rlen = bam_cigar2rlen(int(c->n_cigar), bam_get_cigar(b));
+        const int qlen = bam_cigar2qlen(int(c->n_cigar), bam_get_cigar(b));
+        if (c->flag & BAM_FUNMAP) rlen = 1;
+        c->bin = uint16_t(hts_reg2bin(c->pos, c->pos + rlen, 14, 5));
+        if (c->l_qseq > 0 && !(c->flag & BAM_FUNMAP) && qlen != c->l_qseq) {
+            std::cerr << "strelka_amd feed: CIGAR and query sequence lengths differ for " << bam_get_qname(b) << "\n";
+            return -4;
+        }
+    }
+    return 4 + block_len;
+}
+
+} // namespace sk_adapter

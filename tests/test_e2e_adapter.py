@@ -23,7 +23,11 @@ GERMLINE_BAMS = ["NA12891_demo20.bam", "NA12892_demo20.bam"]
 def _counters(stderr):
     m = re.search(r"strelka_amd adapter: (.*)", stderr)
     assert m, "adapter did not report:\n" + stderr[-2000:]
-    return {k: int(v) for k, v in (kv.split("=") for kv in m.group(1).split())}
+    c = {k: int(v) for k, v in (kv.split("=") for kv in m.group(1).split())}
+    f = re.search(r"strelka_amd adapter feed: (.*)", stderr)  # site 8: the region's reads came through the feed entry points
+    assert f, "adapter did not report its feed:\n" + stderr[-2000:]
+    c.update({"feed_" + k: int(v) for k, v in (kv.split("=") for kv in f.group(1).split())})
+    return c
 
 
 def _germline(variant, tmp_path, windows=None, extra_env=None):
@@ -39,6 +43,10 @@ def _germline(variant, tmp_path, windows=None, extra_env=None):
     p = E.run(E.germline_argv("starling2_" + variant, out, bams), env=env)
     c = _counters(p.stderr.decode())
     assert c["realign_reads"] > 1000 and c["realign_jobs"] >= 1 and c["site_loci"] > 5000
+    if (extra_env or {}).get("STRELKA_AMD_FEED") == "0":
+        assert c["feed_regions"] == 0
+    else:  # both BAMs' regions, every read the realigner saw and more (the reference filters some after the stream)
+        assert c["feed_regions"] == 2 and c["feed_records"] >= c["realign_reads"] and c["feed_bgzf_blocks"] >= 2
     assert c["indel_groups"] >= 1 and c["haplotypes"] >= 1
     for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf"):
         want, got = E.vcf_body(ref_out + f, keep_header=True), E.vcf_body(out + f, keep_header=True)
@@ -55,6 +63,12 @@ def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
         assert c["realign_jobs"] <= 10 and c["site_batches"] <= 2
     if windows is None:
         assert c["read_window"] == 2048 and c["site_window"] == 4096
+
+
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_germline_demo_identical_with_the_reference_stream(tmp_path):
+    """STRELKA_AMD_FEED=0: the reads come through the reference's own htslib iterator instead of site 8"""
+    _germline("dbl", tmp_path, extra_env={"STRELKA_AMD_FEED": "0"})
 
 
 @pytest.mark.gpu
@@ -146,6 +160,7 @@ def _synth(variant, tmp_path, which, windows=None, extra_env=None):
             cg, cs = _counters(pg.stderr.decode()), _counters(ps.stderr.decode())
             assert cg["realign_reads"] > 10000 and cg["indel_groups"] > 100 and cg["haplotypes"] > 100 and cg["site_recomputed"] > 100
             assert cs["realign_reads"] > 15000 and cs["indel_groups"] > 30
+            assert cg["feed_regions"] == 2 and cs["feed_regions"] == 2 and cg["feed_records"] > 10000 and cs["feed_records"] > 15000
             if (extra_env or {}).get("SK_ENUMERATION") == "2":
                 for c in (cg, cs):
                     assert c["enum_device_reads"] > 500 and c["enum_host_instead"] <= c["enum_device_reads"] // 20
