@@ -447,7 +447,8 @@ struct sk_realign_job
 
     struct Read
     {
-        std::vector<uint8_t> code, qual;
+        std::vector<uint8_t> code, qual; // (empty for a read that did not pass the gate)
+        uint32_t read_len = 0;
         Aln input;
         int map_level = 0, sample = 0;
         int32_t read_id = 0;
@@ -1999,33 +2000,36 @@ namespace
 
 // the gate, input normalisation and enumeration of a validated read (rd.code/input/observed/realign range are set); with
 // enumeration == 2 and `force_host` false the search itself is left pending for the device
+// is_realignable :2045 and check_for_candidate_indel_overlap :217-270: does the read go on to the search at all?
+bool passes_gate(const Job& job, const Aln& input, const unsigned read_len, const Range& realign_range)
+{
+    if (is_overmax(input, job.opt.max_indel_size)) return false;
+    const Range rr = alignment_zone(input, read_len);
+    if (!realign_range.superset_of(rr)) return false;
+    const auto it = job.range_iter(rr.b, rr.e);
+    for (int i = it.first; i < it.second; ++i) {
+        if (!range_intersect_indel_breakpoints(rr, job.key(i))) continue;
+        if (job.cand(i)) return true;
+    }
+    return false;
+}
+
 void enumerate_read(const Job& job, sk_realign_job::Read& rd, const bool force_host)
 {
-    const std::set<int> observed(rd.observed.begin(), rd.observed.end());
     const Range realign_range(rd.realign_b, rd.realign_e);
-    const unsigned read_len = unsigned(rd.code.size());
+    const unsigned read_len = rd.read_len;
     rd.pending.reset();
     rd.warn_origin = rd.warn_toggle = false;
 
     std::set<Cal> cal_set;
-    bool gate = !is_overmax(rd.input, job.opt.max_indel_size); // is_realignable :2045
-    if (gate) { // check_for_candidate_indel_overlap :217-270
-        const Range rr = alignment_zone(rd.input, read_len);
-        gate = false;
-        if (realign_range.superset_of(rr)) {
-            const auto it = job.range_iter(rr.b, rr.e);
-            for (int i = it.first; i < it.second; ++i) {
-                if (!range_intersect_indel_breakpoints(rr, job.key(i))) continue;
-                if (job.cand(i)) { gate = true; break; }
-            }
-        }
-    }
+    const bool gate = passes_gate(job, rd.input, read_len, realign_range);
     if (gate) {
         // normalizeInputAlignmentIndels :2001-2021 (no pinned edges on DNA reads)
         Aln norm = rd.input;
         if (is_edge_readref_len_segment(norm.path)) norm = matchify_edge_indels(norm, true, true);
         if (path_is_soft_clipped(norm.path)) norm = matchify_edge_segment_type(norm, SK_SEG_SOFT_CLIP); // :2051-2057
         if (norm.pos >= 0) {
+            const std::set<int> observed(rd.observed.begin(), rd.observed.end());
             get_candidate_alignments(job, rd, observed, norm, realign_range, cal_set, force_host);
             if (cal_set.empty() && !rd.pending) throw Fail("Empty candidate alignment set while realigning normed input alignment");
         }
@@ -2043,12 +2047,12 @@ void prepare_read(const Job& job, const sk_read_input* in, sk_realign_job::Read&
         (in->n_observed > 0 && in->observed == nullptr))
         throw Fail("null read_code / read_qual / path / observed pointer with a positive length");
     if (in->sample_index < 0 || in->sample_index >= job.opt.sample_count) throw Fail("sample_index out of range");
-    rd.code.assign(in->read_code, in->read_code + in->read_len);
-    rd.qual.assign(in->read_qual, in->read_qual + in->read_len);
+    rd.read_len = uint32_t(in->read_len);
     rd.map_level = in->map_level;
     rd.sample = in->sample_index;
     rd.input.pos = in->pos;
     rd.input.fwd = in->is_fwd_strand != 0;
+    rd.input.path.reserve(size_t(in->n_seg));
     for (int i = 0; i < in->n_seg; ++i) {
         // the reference cuts a read with SKIP segments into exon segments realigned with pinned edges
         // (get_segment_edge_pin, starling_read_align.cpp:1711-1737): that RNA path is not built, say so instead of
@@ -2058,17 +2062,24 @@ void prepare_read(const Job& job, const sk_read_input* in, sk_realign_job::Read&
     }
     if (rd.input.empty() || path_read_length(rd.input.path) != unsigned(in->read_len))
         throw Fail("invalid alignment path associated with read segment"); // realignAndScoreRead :2036-2040
-    {
-        std::set<int> observed;
-        for (int i = 0; i < in->n_observed; ++i) {
-            const int o = in->observed[i];
-            if (o < 0 || size_t(o) >= job.orig_to_tab.size()) throw Fail("observed indel index out of range");
-            observed.insert(job.orig_to_tab[size_t(o)]);
-        }
-        rd.observed.assign(observed.begin(), observed.end());
-    }
+    for (int i = 0; i < in->n_observed; ++i)
+        if (in->observed[i] < 0 || size_t(in->observed[i]) >= job.orig_to_tab.size()) throw Fail("observed indel index out of range");
     rd.realign_b = in->realign_begin;
     rd.realign_e = in->realign_end;
+    // a read that does not pass the gate (most reads of a sample, away from candidate indels) is done: its bases, qualities and
+    // observed indels are never looked at
+    if (!passes_gate(job, rd.input, rd.read_len, Range(rd.realign_b, rd.realign_e))) {
+        rd.pending.reset();
+        rd.warn_origin = rd.warn_toggle = rd.incomplete_search = false;
+        rd.cals.clear();
+        return;
+    }
+    rd.code.assign(in->read_code, in->read_code + in->read_len);
+    rd.qual.assign(in->read_qual, in->read_qual + in->read_len);
+    rd.observed.resize(size_t(in->n_observed));
+    for (int i = 0; i < in->n_observed; ++i) rd.observed[size_t(i)] = job.orig_to_tab[size_t(in->observed[i])];
+    std::sort(rd.observed.begin(), rd.observed.end());
+    rd.observed.erase(std::unique(rd.observed.begin(), rd.observed.end()), rd.observed.end());
     enumerate_read(job, rd, false);
     if (rd.pending) // the device scores these reads without passing the builder, whose check this is
         for (const uint8_t q : rd.qual)
@@ -2176,7 +2187,10 @@ int sk_realign_job_add_reads(sk_realign_job* j, const sk_read_input* in, int32_t
         if (j->finished) throw Fail("job already finished: clear the reads first");
         // every thread prepares AND flattens its contiguous slice of the reads into a builder of its own; the slices are then
         // appended to the job's batch in order, so the batch is byte for byte what read-by-read calls produce
-        std::vector<sk_realign_job::Read> prepared(static_cast<size_t>(n));
+        // (the reads are prepared where they will stay; a rejected call takes them away again)
+        const size_t first_read = j->reads.size();
+        j->reads.resize(first_read + size_t(n));
+        sk_realign_job::Read* const prepared = j->reads.data() + first_read;
         const int threads = host_threads(*j, size_t(n));
         struct Slice
         {
@@ -2184,27 +2198,35 @@ int sk_realign_job_add_reads(sk_realign_job* j, const sk_read_input* in, int32_t
             ~Slice() { if (builder) sk_align_builder_destroy(builder); }
         };
         std::vector<Slice> slices(static_cast<size_t>(threads));
-        for (auto& sl : slices) sl.builder = sk_align_builder_create();
+        const bool flatten_here = (j->opt.enumeration != 2); // (2: the batch is assembled by the job's run)
+        if (flatten_here)
+            for (auto& sl : slices) sl.builder = sk_align_builder_create();
         const std::string err = parallel_for(size_t(threads), threads, [&](const size_t t) {
             const size_t b = size_t(n) * t / size_t(threads), e = size_t(n) * (t + 1) / size_t(threads);
             for (size_t i = b; i < e; ++i) {
                 try {
                     prepare_read(*j, in + i, prepared[i]);
-                    prepared[i].cal_begin = (j->opt.enumeration != 2) ? flatten_read(*j, slices[t].builder, prepared[i]) : 0; // (count for now)
+                    prepared[i].cal_begin = flatten_here ? flatten_read(*j, slices[t].builder, prepared[i]) : 0; // (count for now)
                 } catch (const std::exception& ex) {
                     throw Fail("read " + std::to_string(i) + ": " + ex.what());
                 }
             }
         });
-        if (!err.empty()) throw Fail(err.substr(err.find(": ") + 2)); // nothing was added
-        const int first = int(j->reads.size());
-        for (int t = 0; t < threads; ++t)
-            if (sk_align_builder_append(j->builder, slices[size_t(t)].builder)) throw Fail("append");
-        for (auto& rd : prepared) {
-            const int32_t n_cals = rd.cal_begin;
-            rd.cal_begin = j->n_cals_total;
+        if (!err.empty()) {
+            j->reads.resize(first_read); // nothing was added
+            throw Fail(err.substr(err.find(": ") + 2));
+        }
+        const int first = int(first_read);
+        if (flatten_here)
+            for (int t = 0; t < threads; ++t)
+                if (sk_align_builder_append(j->builder, slices[size_t(t)].builder)) {
+                    j->reads.resize(first_read);
+                    throw Fail("append");
+                }
+        for (int32_t i = 0; i < n; ++i) {
+            const int32_t n_cals = prepared[i].cal_begin;
+            prepared[i].cal_begin = j->n_cals_total;
             j->n_cals_total += n_cals;
-            j->reads.push_back(std::move(rd));
         }
         return first;
     } catch (const std::exception& e) {
