@@ -443,6 +443,7 @@ struct sk_realign_job
         return tab[size_t(i)].cand;
     }
     std::vector<unsigned> max_toggle; // starling_align_limit
+    bool has_mismatch_keys = false;   // any SK_INDEL_MISMATCH entry in the table (haplotyping's mismatch "indels")
     std::string error;
 
     struct Read
@@ -1090,7 +1091,8 @@ void alignment_indel_keys(const Job& job, const Aln& al, const Key* lead, const 
                 out.insert(l);
                 out.insert(r);
             }
-        } else if (include_mismatches && seg_align_match(s.type)) {
+        } else if (include_mismatches && job.has_mismatch_keys && seg_align_match(s.type)) {
+            // (a mismatch that is not in the table is dropped by the caller: without mismatch entries there is nothing to look for)
             for (unsigned i = 0; i < s.length; ++i) {
                 const unsigned rp = read_off + i;
                 const uint8_t sb = rp < code.size() ? code[rp] : uint8_t(SK_BAM_ANY);
@@ -1952,6 +1954,9 @@ int sk_realign_job_set_indels(sk_realign_job* j, const sk_indel_info* indels, in
     for (size_t i = 0; i <= j->tab.size(); ++i) j->consulted[i].store(0, std::memory_order_relaxed);
     j->orig_to_tab.assign(size_t(n), -1);
     for (size_t i = 0; i < j->tab.size(); ++i) j->orig_to_tab[size_t(j->tab[i].orig)] = int(i);
+    j->has_mismatch_keys = false;
+    for (const Indel& d : j->tab)
+        if (d.key.is_mismatch()) j->has_mismatch_keys = true;
     return 0;
 }
 
