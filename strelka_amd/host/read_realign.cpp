@@ -777,7 +777,7 @@ typedef FlatMap<int32_t, HapStatus> HapMap;
 struct SearchCtx
 {
     const Job& job;
-    const std::set<int>& observed; // table indices this read was observed to support
+    const std::vector<int>& observed; // table indices this read was observed to support (ascending, no repeats)
     int sample;
     unsigned read_length;
     Range realign_range;
@@ -788,7 +788,7 @@ struct SearchCtx
 
 bool is_usable_indel(const SearchCtx& c, int i) // :289-305
 {
-    return c.job.cand(i) || c.observed.count(i) > 0;
+    return c.job.cand(i) || std::binary_search(c.observed.begin(), c.observed.end(), i);
 }
 
 // add_indels_in_range :311-366
@@ -1192,7 +1192,7 @@ Cal from_core_cal(const skcore::PCal& p)
     return c;
 }
 // the state getCandidateAlignments hands to candidate_alignment_search, in the core's form; false = beyond a cap
-bool to_core_read(const Job& job, const std::set<int>& observed, int sample, unsigned read_length, const Range& realign_range,
+bool to_core_read(const Job& job, const std::vector<int>& observed, int sample, unsigned read_length, const Range& realign_range,
                   const Range& exemplar_pr, const StatusMap& sm, const std::vector<int>& order, const Cal& cal, skcore::PRead& r)
 {
     if (job.tab.size() > 32000 || sm.size() > size_t(skcore::Caps::K) || order.size() > size_t(skcore::Caps::K) ||
@@ -1225,7 +1225,7 @@ bool to_core_read(const Job& job, const std::set<int>& observed, int sample, uns
 }
 
 // getCandidateAlignments :1816-1994
-void get_candidate_alignments(const Job& job, sk_realign_job::Read& rd, const std::set<int>& observed, const Aln& input,
+void get_candidate_alignments(const Job& job, sk_realign_job::Read& rd, const std::vector<int>& observed, const Aln& input,
                               const Range& realign_range, std::set<Cal>& cal_set, const bool force_host = false)
 {
     const unsigned read_length = unsigned(rd.code.size());
@@ -2034,8 +2034,7 @@ void enumerate_read(const Job& job, sk_realign_job::Read& rd, const bool force_h
         if (is_edge_readref_len_segment(norm.path)) norm = matchify_edge_indels(norm, true, true);
         if (path_is_soft_clipped(norm.path)) norm = matchify_edge_segment_type(norm, SK_SEG_SOFT_CLIP); // :2051-2057
         if (norm.pos >= 0) {
-            const std::set<int> observed(rd.observed.begin(), rd.observed.end());
-            get_candidate_alignments(job, rd, observed, norm, realign_range, cal_set, force_host);
+            get_candidate_alignments(job, rd, rd.observed, norm, realign_range, cal_set, force_host);
             if (cal_set.empty() && !rd.pending) throw Fail("Empty candidate alignment set while realigning normed input alignment");
         }
     }
