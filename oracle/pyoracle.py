@@ -779,3 +779,14 @@ def ref_gvcf_block_sites(sites, block_percent_tol=30, block_abs_tol=3):
     L.ref_gvcf_block_sites.argtypes = [vp, C.c_int32, C.c_uint32, C.c_uint32, vp, vp]
     nb = L.ref_gvcf_block_sites(rs.ctypes.data, n, block_percent_tol, block_abs_tol, kind.ctypes.data, blocks.ctypes.data)
     return kind[:n], blocks[:nb]
+
+
+def ref_bai_query(bam_path, tid, begin, end):
+    """htslib's own sam_itr_queryi on the index of `bam_path` (oracle/ref/ref_driver_bai.cpp) -> [(begin, end)] virtual offsets"""
+    L = ref()
+    L.ref_bai_query.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32]
+    buf = np.zeros(2 * 4096, np.uint64)
+    n = L.ref_bai_query(bam_path.encode(), tid, begin, end, buf.ctypes.data, 4096)
+    if n < 0:
+        raise RuntimeError("ref_bai_query: no index / no iterator")
+    return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]

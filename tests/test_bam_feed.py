@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from oracle import bam_oracle
+from oracle import bam_oracle, pyoracle
 from strelka_amd import capi
 from tests import e2e_util as E
 
@@ -260,6 +260,34 @@ def test_region_fetch_on_a_fine_grained_index(tmp_path):
     assert max(len(capi.bai_query(bai, 0, b, b + 600000)) for b in (0, 650000, 1900000)) >= 3  # several chunks for one region
     regions = _samtools_regions(bam, rng, 60)
     assert _check_regions(bam, regions, on_gpu=False) > 20000
+    # and chunk for chunk what htslib's own iterator holds (oracle/ref/ref_driver_bai.cpp: hts_idx_load + sam_itr_queryi)
+    n_chunks = 0
+    for _ in range(400):
+        tid = int(rng.integers(0, 3))
+        b = int(rng.integers(-10, 3_000_000))
+        e = b + int(rng.choice([0, 1, 100, 16384, 16385, 131072, 500000, 4_000_000]))
+        want = pyoracle.ref_bai_query(bam, tid, b, e)
+        got = [(int(c["begin"]), int(c["end"])) for c in capi.bai_query(bai, tid, b, e)]
+        assert got == want, (tid, b, e)
+        n_chunks += len(want)
+    assert n_chunks > 500
+
+
+@pytest.mark.skipif(not pyoracle.ref_available(), reason="oracle/_ref not built")
+def test_index_query_equals_htslib_on_the_fixture_and_the_demo_bams():
+    rng = np.random.default_rng(557)
+    n = 0
+    for bam in [os.path.join(GOLD, "feed_regions.bam")] + [b for b in _more_bams()[1:] if os.path.exists(b + ".bai")][:4]:
+        bai = np.frombuffer(_bytes(bam + ".bai"), np.uint8)
+        n_ref = int(np.frombuffer(bai[4:8].tobytes(), "<i4")[0])
+        for _ in range(150):
+            tid = int(rng.integers(0, n_ref))
+            b = int(rng.integers(0, 250000))
+            e = b + int(rng.choice([0, 1, 50, 5000, 16384, 70000, 1 << 29]))
+            want = pyoracle.ref_bai_query(bam, tid, b, e)
+            assert [(int(c["begin"]), int(c["end"])) for c in capi.bai_query(bai, tid, b, e)] == want, (bam, tid, b, e)
+            n += len(want)
+    assert n > 150  # (these indexes are coarse: one or two chunks per region; the fine-grained one is above)
 
 
 @pytest.mark.gpu
