@@ -100,6 +100,13 @@ HOOKS = [
          r'\nvoid\ngetVariantAlleleGroupGenotypeLhoodsForSample\(',
          '\nvoid\ngetVariantAlleleGroupGenotypeLhoodsForSample_reference('),
     ]),
+    (L + "starling_common/starling_pos_processor_util.cpp", [
+        ("include", r'#include "starling_common/starling_pos_processor_util.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # site 8, second half: the region's alignments normalised in one batch
+        ("normalizeAlignment",
+         r'        normalizeAlignment\(refBamSeq, readBamSeq, readAlignment\);\n',
+         '        if (! sk_adapter::feed_normalize_current(&read_stream, ref, readAlignment)) normalizeAlignment(refBamSeq, readBamSeq, readAlignment);\n'),
+    ]),
     (L + "htsapi/bam_streamer.cpp", [
         ("include", r'#include "htsapi/bam_streamer.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
         # site 8: the region's reads through the feed

@@ -37,6 +37,7 @@ struct starling_sample_options;
 struct IndelData;
 struct reference_contig_segment;
 struct IndelKey;
+struct alignment;
 
 namespace sk_adapter
 {
@@ -95,5 +96,8 @@ bool feed_active(const void* streamer);
 /// the next record of the region into the streamer's bam1_t, as sam_itr_next returns it (>= 0, -1 at the end, < -1 on a bad record)
 int feed_next(const void* streamer, void* bam1);
 void feed_drop(const void* streamer);
+/// normalizeAlignment at starling_pos_processor_util.cpp:432 for the streamer's current record, from one batched sk_normalize_alignments
+/// call per region; false: the caller runs the reference's function
+bool feed_normalize_current(const void* streamer, const reference_contig_segment& ref, alignment& al);
 
 }

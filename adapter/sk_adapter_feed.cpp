@@ -14,7 +14,10 @@
 #include "sk_adapter.hh"
 #include "sk_adapter_access.hh"
 
+#include "blt_util/align_path.hh"
 #include "blt_util/blt_exception.hh"
+#include "blt_util/reference_contig_segment.hh"
+#include "starling_common/alignment.hh"
 
 #include "strelka_amd.h"
 
@@ -55,18 +58,32 @@ struct Feed
     std::vector<uint8_t> bytes;  // the region's records, raw (block_size field included), one after the other
     std::vector<size_t> rec_at;
     size_t next = 0;
+    // what sk_bam_decode made of them: bases (BAM codes, one per byte), CIGAR as path segments, position
+    std::vector<int64_t> read_off{ 0 }, path_off{ 0 };
+    std::vector<uint8_t> code;
+    std::vector<sk_path_seg> path;
+    std::vector<int32_t> pos;
+    std::vector<uint8_t> mapped;
+    // normalizeAlignment of all of them at once (feed_normalize_current), made when the first record asks
+    bool normalized = false;
+    std::vector<int32_t> in_batch; // record -> its place in the batch, -1: not in it
+    std::vector<int64_t> n_path_off;
+    std::vector<sk_path_seg> n_path_in, n_path;
+    std::vector<int32_t> n_pos_in, n_pos, n_seg_in, n_seg;
+    std::vector<uint8_t> n_changed;
 };
 
 struct FeedState
 {
     std::map<std::string, BamFile> files;
     std::map<const void*, Feed> feeds;
-    unsigned long regions = 0, records = 0, blocks = 0, inflated = 0;
+    unsigned long regions = 0, records = 0, blocks = 0, inflated = 0, norm_batches = 0, norm_reads = 0, norm_changed = 0, norm_declined = 0;
     ~FeedState()
     {
         if (std::getenv("STRELKA_AMD_VERBOSE") && std::atoi(std::getenv("STRELKA_AMD_VERBOSE")) != 0)
             std::cerr << "strelka_amd adapter feed: regions=" << regions << " records=" << records << " bgzf_blocks=" << blocks
-                      << " inflated_bytes=" << inflated << "\n";
+                      << " inflated_bytes=" << inflated << " normalize_batches=" << norm_batches << " normalized=" << norm_reads
+                      << " normalize_changed=" << norm_changed << " normalize_declined=" << norm_declined << "\n";
         for (auto& f : files)
             if (f.second.fd >= 0) ::close(f.second.fd);
     }
@@ -209,6 +226,12 @@ bool feed_reset_region(const void* streamer, const char* name, const int tid, co
                             const size_t len = 4 + size_t(le32(r));
                             feed.rec_at.push_back(feed.bytes.size());
                             feed.bytes.insert(feed.bytes.end(), r, r + len);
+                            feed.code.insert(feed.code.end(), code.begin() + read_off[size_t(i)], code.begin() + read_off[size_t(i) + 1]);
+                            feed.read_off.push_back(int64_t(feed.code.size()));
+                            feed.path.insert(feed.path.end(), path.begin() + path_off[size_t(i)], path.begin() + path_off[size_t(i) + 1]);
+                            feed.path_off.push_back(int64_t(feed.path.size()));
+                            feed.pos.push_back(rec[size_t(i)].pos);
+                            feed.mapped.push_back((rec[size_t(i)].flag & 0x4) ? 0 : 1);
                         }
                     finished = n_read < n_in;
                 }
@@ -290,6 +313,82 @@ int feed_next(const void* streamer, void* bam1)
         }
     }
     return 4 + block_len;
+}
+
+
+// normalizeAlignment (L/starling_common/normalizeAlignment.cpp:647-703) at its call site in processInputReadAlignment
+// (starling_pos_processor_util.cpp:432), for the record the streamer is at: the first call normalises ALL records of the region in one
+// sk_normalize_alignments call (kernel B4) against the region's reference segment -- from the decoded bases and CIGARs the feed kept,
+// each path cleaned by the reference's own apath_cleaner first, as the call site does -- and every call then hands its record's result
+// over.  Declines (the caller runs the reference's function) when the streamer has no feed, with STRELKA_AMD_FEED_NORMALIZE=0, and
+// when `al` is not the alignment the feed holds for the record.
+bool feed_normalize_current(const void* streamer, const reference_contig_segment& ref, alignment& al)
+{
+    auto it = fs().feeds.find(streamer);
+    if (it == fs().feeds.end()) return false;
+    Feed& f = it->second;
+    if (f.next == 0 || f.next > f.rec_at.size()) return false;
+    static const bool enabled = !(std::getenv("STRELKA_AMD_FEED_NORMALIZE") && std::atoi(std::getenv("STRELKA_AMD_FEED_NORMALIZE")) == 0);
+    if (!enabled) return false;
+    const size_t n_rec = f.rec_at.size();
+    if (!f.normalized) {
+        f.normalized = true;
+        f.in_batch.assign(n_rec, -1);
+        std::vector<int64_t> b_read_off{ 0 };
+        std::vector<uint8_t> b_code;
+        f.n_path_off.assign(1, 0);
+        ALIGNPATH::path_t apath;
+        for (size_t r = 0; r < n_rec; ++r) {
+            if (!f.mapped[r] || f.path_off[r + 1] == f.path_off[r]) continue;
+            apath.clear();
+            for (int64_t k = f.path_off[r]; k < f.path_off[r + 1]; ++k)
+                apath.push_back(ALIGNPATH::path_segment(static_cast<ALIGNPATH::align_t>(f.path[size_t(k)].type), f.path[size_t(k)].length));
+            ALIGNPATH::apath_cleaner(apath);
+            if (apath.empty()) continue;
+            f.in_batch[r] = int32_t(f.n_pos_in.size());
+            for (const auto& ps : apath) f.n_path_in.push_back(sk_path_seg{ uint32_t(ps.type), ps.length });
+            f.n_path_off.push_back(int64_t(f.n_path_in.size()));
+            f.n_seg_in.push_back(int32_t(apath.size()));
+            f.n_pos_in.push_back(f.pos[r]);
+            b_code.insert(b_code.end(), f.code.begin() + f.read_off[r], f.code.begin() + f.read_off[r + 1]);
+            b_read_off.push_back(int64_t(b_code.size()));
+        }
+        const int32_t nb = int32_t(f.n_pos_in.size());
+        f.n_path = f.n_path_in;
+        f.n_seg = f.n_seg_in;
+        f.n_pos = f.n_pos_in;
+        f.n_changed.assign(size_t(nb) + 1, 0);
+        if (nb > 0) {
+            const std::string& seq = ref.seq();
+            if (sk_normalize_alignments(seq.data(), int32_t(ref.get_offset()), int32_t(seq.size()), nb, b_read_off.data(), b_code.data(), f.n_path_off.data(),
+                                        f.n_seg.data(), f.n_path.data(), f.n_pos.data(), f.n_changed.data())) {
+                std::ostringstream oss;
+                oss << "strelka_amd feed: sk_normalize_alignments: " << sk_last_error();
+                throw blt_exception(oss.str().c_str());
+            }
+        }
+        fs().norm_batches++;
+        fs().norm_reads += (unsigned long)nb;
+    }
+    const size_t r = f.next - 1;
+    const int32_t b = f.in_batch[r];
+    bool same = (b >= 0) && al.pos == f.n_pos_in[size_t(b)] && int64_t(al.path.size()) == f.n_path_off[size_t(b) + 1] - f.n_path_off[size_t(b)];
+    for (size_t k = 0; same && k < al.path.size(); ++k) {
+        const sk_path_seg& q = f.n_path_in[size_t(f.n_path_off[size_t(b)]) + k];
+        same = (uint32_t(al.path[k].type) == q.type && al.path[k].length == q.length);
+    }
+    if (!same) {
+        fs().norm_declined++;
+        return false;
+    }
+    if (f.n_changed[size_t(b)]) {
+        fs().norm_changed++;
+        al.pos = f.n_pos[size_t(b)];
+        al.path.clear();
+        const sk_path_seg* q = f.n_path.data() + f.n_path_off[size_t(b)];
+        for (int32_t k = 0; k < f.n_seg[size_t(b)]; ++k) al.path.push_back(ALIGNPATH::path_segment(static_cast<ALIGNPATH::align_t>(q[k].type), q[k].length));
+    }
+    return true;
 }
 
 } // namespace sk_adapter

@@ -47,6 +47,8 @@ def _germline(variant, tmp_path, windows=None, extra_env=None):
         assert c["feed_regions"] == 0
     else:  # both BAMs' regions, every read the realigner saw and more (the reference filters some after the stream)
         assert c["feed_regions"] == 2 and c["feed_records"] >= c["realign_reads"] and c["feed_bgzf_blocks"] >= 2
+        # and their alignments were normalised in one batch per region (kernel B4 behind sk_normalize_alignments)
+        assert c["feed_normalize_batches"] == 2 and c["feed_normalized"] >= c["realign_reads"] and c["feed_normalize_declined"] == 0
     assert c["indel_groups"] >= 1 and c["haplotypes"] >= 1
     for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf"):
         want, got = E.vcf_body(ref_out + f, keep_header=True), E.vcf_body(out + f, keep_header=True)
@@ -161,6 +163,9 @@ def _synth(variant, tmp_path, which, windows=None, extra_env=None):
             assert cg["realign_reads"] > 10000 and cg["indel_groups"] > 100 and cg["haplotypes"] > 100 and cg["site_recomputed"] > 100
             assert cs["realign_reads"] > 15000 and cs["indel_groups"] > 30
             assert cg["feed_regions"] == 2 and cs["feed_regions"] == 2 and cg["feed_records"] > 10000 and cs["feed_records"] > 15000
+            for c in (cg, cs):  # normalizeAlignment in batches, with alignments that it changes, none handed back to the reference
+                assert c["feed_normalize_batches"] == 2 and c["feed_normalized"] > 10000 and c["feed_normalize_changed"] > 100
+                assert c["feed_normalize_declined"] == 0
             if (extra_env or {}).get("SK_ENUMERATION") == "2":
                 for c in (cg, cs):
                     assert c["enum_device_reads"] > 500 and c["enum_host_instead"] <= c["enum_device_reads"] // 20
