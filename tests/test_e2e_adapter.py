@@ -45,6 +45,8 @@ def _germline(variant, tmp_path, windows=None, extra_env=None):
     assert c["realign_reads"] > 1000 and c["realign_jobs"] >= 1 and c["site_loci"] > 5000
     if (extra_env or {}).get("STRELKA_AMD_FEED") == "0":
         assert c["feed_regions"] == 0
+    elif (extra_env or {}).get("STRELKA_AMD_FEED_NORMALIZE") == "0":
+        assert c["feed_regions"] == 2 and c["feed_normalize_batches"] == 0
     else:  # both BAMs' regions, every read the realigner saw and more (the reference filters some after the stream)
         assert c["feed_regions"] == 2 and c["feed_records"] >= c["realign_reads"] and c["feed_bgzf_blocks"] >= 2
         # and their alignments were normalised in one batch per region (kernel B4 behind sk_normalize_alignments)
@@ -71,6 +73,12 @@ def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
 def test_germline_demo_identical_with_the_reference_stream(tmp_path):
     """STRELKA_AMD_FEED=0: the reads come through the reference's own htslib iterator instead of site 8"""
     _germline("dbl", tmp_path, extra_env={"STRELKA_AMD_FEED": "0"})
+
+
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_germline_demo_identical_with_the_reference_normalisation(tmp_path):
+    """STRELKA_AMD_FEED_NORMALIZE=0: the reads come through the feed, normalizeAlignment stays the reference's, record by record"""
+    _germline("dbl", tmp_path, extra_env={"STRELKA_AMD_FEED_NORMALIZE": "0"})
 
 
 @pytest.mark.gpu
