@@ -23,6 +23,11 @@ HOOKS = [
          r'struct starling_pos_processor_base : public pos_processor_base, private boost::noncopyable\n\{\n',
          '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::Access;\n'),
     ]),
+    (L + "starling_common/pos_basecall_buffer.hh", [
+        ("friend + forward declaration",
+         r'struct pos_basecall_buffer\n\{\n',
+         '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::Access;\n'),
+    ]),
     (L + "starling_common/starling_pos_processor_base.cpp", [
         ("include", r'#include "starling_read_align.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
         # stage geometry: READ_BUFFER and POST_ALIGN pushed further behind HEAD by the batching windows
@@ -58,6 +63,13 @@ HOOKS = [
         ("align_pos",
          r'(starling_pos_processor_base::\nalign_pos\(const pos_t pos\)\n\{\n)',
          '\\1    if (sk_adapter::align_pos(*this, pos)) return;\n'),
+        # site 9
+        ("pileup_pos_reads",
+         r'(starling_pos_processor_base::\npileup_pos_reads\(const pos_t pos\)\n\{\n)',
+         '\\1    if (sk_adapter::pileup_pos_reads(*this, pos)) return;\n'),
+        ("reset: the final flush",
+         r'(starling_pos_processor_base::\nreset\(\)\n\{\n    if \(_stagemanPtr\)\n    \{\n)        _stagemanPtr->reset\(\);\n',
+         '\\1        sk_adapter::on_flush_begin(*this);\n        _stagemanPtr->reset();\n        sk_adapter::on_flush_end(*this);\n'),
         ("set_head_pos",
          r'(starling_pos_processor_base::\nset_head_pos\(const pos_t pos\)\n\{\n)',
          '\\1    sk_adapter::on_set_head_pos(*this, pos, get_read_buffer_size(get_largest_read_size(), '

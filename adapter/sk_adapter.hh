@@ -67,6 +67,13 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
 /// the four zero-depth genotypes of the constructor (starling_pos_processor_base.cpp:259-274)
 void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseId, diploid_genotype& dgt);
 
+// ---- site 9: pileup_pos_reads at starling_pos_processor_base.cpp:813 (pileup_read_segment :1127-1421), chained into sites 2+3 ----
+/// replaces the body of pileup_pos_reads(pos); false: the reference's own pileup runs (somatic / EVS-metric runs, STRELKA_AMD_PILEUP=0)
+bool pileup_pos_reads(starling_pos_processor_base& pp, const pos_t pos);
+/// starling_pos_processor_base::reset() (:347-356) is about to flush / has flushed its stages: no more reads in this region
+void on_flush_begin(starling_pos_processor_base& pp);
+void on_flush_end(starling_pos_processor_base& pp);
+
 // ---- site 5: position_somatic_snv_call at strelka_pos_processor.cpp:213-219 ----
 void somatic_window(starling_pos_processor_base& pp, const pos_t pos);
 void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, const CleanedPileup& normal1, const CleanedPileup& tumor1,

@@ -35,6 +35,11 @@ struct Access
     static unsigned ploidy(const base_t& pp, const pos_t pos, const unsigned sampleIndex) { return pp.get_ploidy(pos, sampleIndex); }
     static bool isForcedOutputPos(const base_t& pp, const pos_t pos) { return pp.is_forced_output_pos(pos); }
     static void clearActiveRegionReadBuffer(base_t& pp, const pos_t pos) { pp._getActiveRegionDetector().clearReadBuffer(pos); }
+    static const CandidateSnvBuffer& candidateSnvBuffer(const base_t& pp) { return pp._candidateSnvBuffer; }
+    static bool hasPloidyRegions(const base_t& pp, const unsigned sampleIndex) { return ! pp.sample(sampleIndex).ploidyRegions.empty(); }
+    static const known_pos_range2& reportRange(const base_t& pp) { return pp._reportRange; }
+    /// pos_basecall_buffer::_pdata.getRef(pos): the position's pileup record, created (with its reference base) if absent
+    static snp_pos_info& pileupRef(pos_basecall_buffer& buffer, const pos_t pos) { return buffer._pdata.getRef(pos); }
 };
 
 /// C-ABI status -> the reference's exception type (the context chain of starling_pos_processor_base.cpp:755-760 prints it)
@@ -94,6 +99,31 @@ struct SomaticSiteCache
     void clear() { begin = end = 0; isValid.clear(); forced.clear(); callCount.clear(); genotypes.clear(); }
 };
 
+/// genotypes of a run of positions one pileup push finalised (site 9 chained into sites 2+3)
+struct SiteChunk
+{
+    pos_t begin = 0, end = 0;
+    std::vector<sk_digt_call> calls;
+    std::vector<uint32_t> cleanCount; ///< calls of the cleaned column each genotype was computed from
+    std::vector<uint8_t> ploidy;      ///< ... and the ploidy
+};
+
+/// site 9: one pileup stream per sample (sk_adapter_pileup.cpp)
+struct PileupState
+{
+    bool decided = false, enabled = false, isGenotyping = false;
+    std::vector<sk_pileup_stream*> streams;
+    std::vector<std::deque<SiteChunk>> chunks; ///< per sample, ascending
+    std::vector<uint8_t> isRegionOpen;         ///< per sample: sk_pileup_stream_begin_region done for the current region
+    std::vector<pos_t> nextFinal;              ///< per sample: positions below are final (filled into the reference's buffers)
+    std::vector<pos_t> pendingEnd;             ///< per sample: one past the highest position any pushed read reaches
+    std::vector<pos_t> maxBufferPos;           ///< per sample: highest read-buffer position of any read inserted in this region
+    bool isAnyPiled = false;
+    pos_t piledTo = 0;                         ///< reads buffered at positions < piledTo have been pushed
+    bool isFlushing = false;                   ///< inside starling_pos_processor_base::reset(): no more reads will arrive
+    pos_t regionBegin = 0, regionEnd = 0;
+};
+
 struct State
 {
     GeometryShadow geometry;
@@ -101,13 +131,21 @@ struct State
     pos_t realignedTo = 0;         ///< reads buffered at positions < realignedTo went through a realign job already
     SiteCache sites;
     SomaticSiteCache somaticSites;
+    PileupState pileup;
     // counters reported at exit with $STRELKA_AMD_VERBOSE=1
     // wall seconds inside the hooks (whole hook) and inside the C-ABI calls they make; reported with STRELKA_AMD_VERBOSE=1
-    double tRealignHook = 0, tRealignAbi = 0, tSiteHook = 0, tSiteAbi = 0;
+    double tRealignHook = 0, tRealignAbi = 0, tSiteHook = 0, tSiteAbi = 0, tPileupHook = 0, tPileupAbi = 0;
+    unsigned long pileupBatches = 0, pileupReads = 0, pileupLoci = 0;
     unsigned long realignDeviceEnumerated = 0, realignHostEnumerated = 0; // reads whose candidate alignments the device / the host listed
     unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0;
 };
 State& state();
+
+// site 9 internals (sk_adapter_pileup.cpp)
+bool pileup_enabled(starling_pos_processor_base& pp);
+void pileup_reset_region(starling_pos_processor_base& pp);
+void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos);
+void pileup_note_read(const unsigned sampleIndex, const pos_t bufferPos);
 
 struct AccumTimer // adds its lifetime to `acc`
 {

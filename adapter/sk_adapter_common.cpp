@@ -70,8 +70,11 @@ State& state()
                       << " indel_groups=" << s.indelGroups << " haplotypes=" << s.haplotypes << " read_window=" << read_buffer_defer()
                       << " site_window=" << post_align_defer() << " enum_device_reads=" << s.realignDeviceEnumerated
                       << " enum_host_instead=" << s.realignHostEnumerated << "\n";
+            std::cerr << "strelka_amd adapter pileup: pushes=" << s.pileupBatches << " reads=" << s.pileupReads << " loci=" << s.pileupLoci
+                      << " genotyping=" << (s.pileup.isGenotyping ? 1 : 0) << "\n";
             std::cerr << "strelka_amd adapter seconds: realign_hook=" << s.tRealignHook << " realign_abi=" << s.tRealignAbi
-                      << " site_hook=" << s.tSiteHook << " site_abi=" << s.tSiteAbi << "\n";
+                      << " site_hook=" << s.tSiteHook << " site_abi=" << s.tSiteAbi << " pileup_hook=" << s.tPileupHook
+                      << " pileup_abi=" << s.tPileupAbi << "\n";
         }
     };
     static Reporter r;
@@ -174,6 +177,7 @@ void on_reset_region(starling_pos_processor_base& pp)
     s.realignedTo = 0;
     s.sites.clear();
     s.somaticSites.clear();
+    pileup_reset_region(pp);
 }
 
 void on_set_head_pos(starling_pos_processor_base& /*pp*/, const pos_t pos, const unsigned readBufferShift, const unsigned indelSpan)
@@ -215,6 +219,7 @@ void on_read_inserted(starling_pos_processor_base& /*pp*/, const unsigned sample
         throw blt_exception("strelka_amd adapter: spliced (RNA) reads are not supported on this path");
     }
     state().geometry.bufferedReadPos[sampleIndex].insert(sread.get_full_segment().buffer_pos);
+    pileup_note_read(sampleIndex, sread.get_full_segment().buffer_pos);
 }
 
 }

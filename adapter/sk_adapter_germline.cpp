@@ -110,9 +110,11 @@ void before_process_pos_variants(starling_pos_processor_base& pp, const pos_t po
         somatic_window(pp, pos);
         return;
     }
+    pileup_before_variants(pp, pos);
     if (! opt.is_bsnp_diploid()) return; // the continuous-frequency caller stays on the reference's path
 
     State& s(state());
+    if (s.pileup.isGenotyping) return; // the genotypes came with the pileup (site 9)
     SiteCache& cache(s.sites);
     if (pos >= cache.begin && pos < cache.end) return;
     AccumTimer hookTimer(s.tSiteHook);
@@ -172,7 +174,22 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
     const starling_pos_processor_base& base(pp);
     const snp_pos_info& cleaned(base.sample(sampleIndex).cleanedPileup.cleanedPileup());
     const unsigned sampleCount(Access::sampleCount(base));
-    if (pos >= cache.begin && pos < cache.end)
+    if (s.pileup.isGenotyping)
+    {
+        std::deque<SiteChunk>& chunks(s.pileup.chunks[sampleIndex]);
+        while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front(); // POST_ALIGN only moves forward
+        if ((! chunks.empty()) && chunks.front().begin <= pos)
+        {
+            const SiteChunk& c(chunks.front());
+            const size_t k(static_cast<size_t>(pos - c.begin));
+            if (c.ploidy[k] == ploidy && c.cleanCount[k] == cleaned.calls.size())
+            {
+                toDiploidGenotype(c.calls[k], ploidy, dgt);
+                return;
+            }
+        }
+    }
+    else if (pos >= cache.begin && pos < cache.end)
     {
         const size_t k(static_cast<size_t>(pos - cache.begin) * sampleCount + sampleIndex);
         if (cache.isValid[k] && cache.ploidy[k] == ploidy && cache.callCount[k] == cleaned.calls.size())

@@ -1,0 +1,410 @@
+// sk_adapter_pileup.cpp -- site 9: pileup_pos_reads (L/starling_common/starling_pos_processor_base.cpp:1107-1123, called at :813)
+// -> pileup_read_segment (:1127-1421), chained on the device into sites 2+3 (adjust_joint_eprob + position_snp_call_pprob_digt).
+//
+// The reference piles the reads buffered at position P up when its READ_BUFFER stage reaches P, one basecall at a time into the
+// position-keyed pos_basecall_buffer, and genotypes P when POST_ALIGN gets there.  Here, when the (deferred) READ_BUFFER stage
+// reaches the first position of a stage window -- right after the window's realignment job (sk_adapter_realign.cpp) -- the
+// window's reads go, per sample, through one sk_pileup_stream_push with their best alignments: the kernels build the columns,
+// genotype the positions no later read can reach (everything below window end - largest_total_indel_ref_span_per_read, the
+// POST_ALIGN position of the window's end) and hand back, for exactly those positions, what the reference keeps per position:
+// calls, tier2_calls, spanningDeletionReadCount, submappedReadCount, the MapqTracker.  They are written into the reference's own
+// pos_basecall_buffer in bulk, so everything downstream (CleanPileupFilter, site / indel locus info, gVCF) runs unchanged; the
+// genotypes wait in a per-sample cache for process_pos_snp_digt (sk_adapter_germline.cpp).
+//
+// Not routed (the reference's own pileup runs): the somatic processor and runs that compute the EVS feature accumulators
+// (updateGermlineScoringMetrics / updateSomaticScoringMetrics: rank sums over every basecall), and $STRELKA_AMD_PILEUP=0.
+#include "sk_adapter_access.hh"
+
+#include "blt_util/log.hh"
+#include "blt_util/seq_util.hh"
+#include "starling_common/starling_read_segment.hh"
+
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+
+namespace sk_adapter
+{
+
+namespace
+{
+
+bool env_flag(const char* name, const bool def)
+{
+    const char* v(std::getenv(name));
+    if (v == nullptr || *v == 0) return def;
+    return std::strtol(v, nullptr, 10) != 0;
+}
+
+void pileupOptions(const starling_base_options& opt, sk_pileup_options& po)
+{
+    sk_pileup_options_default(&po);
+    po.min_basecall_qscore = opt.minBasecallErrorPhredProb;
+    po.mismatch_density_flank_size = opt.isMismatchDensityFilter() ? static_cast<int32_t>(opt.mismatchDensityFilterFlankSize) : 0;
+    po.mismatch_density_max_count = static_cast<int32_t>(opt.mismatchDensityFilterMaxMismatchCount);
+    po.use_tier2_evidence = opt.useTier2Evidence ? 1 : 0;
+    po.tier2_mismatch_density_max_count = static_cast<int32_t>(opt.tier2.mismatchDensityFilterMaxMismatchCount);
+    po.is_mapq_adjust = opt.isBasecallQualAdjustedForMapq ? 1 : 0;
+    po.min_distance_from_read_edge = static_cast<int32_t>(opt.minDistanceFromReadEdge);
+    // the read-level test against get_largest_total_indel_ref_span_per_read() (:1186-1191) is made here, per read, with the value
+    // the reference had when IT piled the read up (geometry shadow); the kernel's copy of the test never fires
+    po.largest_total_indel_ref_span_per_read = INT_MAX / 4;
+}
+
+void germlineOptionsForStream(const starling_base_options& opt, sk_germline_options& go)
+{
+    sk_germline_options_default(&go);
+    go.bsnp_diploid_theta = opt.bsnp_diploid_theta;
+    go.bsnp_ssd_no_mismatch = opt.bsnp_ssd_no_mismatch;
+    go.bsnp_ssd_one_mismatch = opt.bsnp_ssd_one_mismatch;
+    go.is_min_vexp = opt.is_min_vexp ? 1 : 0;
+    go.min_vexp = opt.min_vexp;
+}
+
+struct WindowBatch
+{
+    std::vector<int64_t> readOff, pathOff;
+    std::vector<uint8_t> code, qual, isFwd, mapq, level;
+    std::vector<sk_path_seg> path;
+    std::vector<int32_t> pos;
+    pos_t lo = INT_MAX, hi = INT_MIN;
+    void clear()
+    {
+        readOff.assign(1, 0);
+        pathOff.assign(1, 0);
+        code.clear(); qual.clear(); isFwd.clear(); mapq.clear(); level.clear(); path.clear(); pos.clear();
+        lo = INT_MAX;
+        hi = INT_MIN;
+    }
+};
+
+/// one sample's window into its stream; the finalised positions into the reference's buffers
+void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sampleIndex, const pos_t begin, const pos_t end,
+                          const bool isFinal)
+{
+    State& s(state());
+    PileupState& ps(s.pileup);
+    const starling_base_options& opt(Access::opt(pp));
+    starling_pos_processor_base::sample_info& sif(pp.sample(sampleIndex));
+    const reference_contig_segment& ref(Access::ref(pp));
+    sk_pileup_stream* stream(ps.streams[sampleIndex]);
+
+    if (! ps.isRegionOpen[sampleIndex])
+    {
+        check(sk_pileup_stream_begin_region(stream, ref.seq().data(), static_cast<int32_t>(ref.get_offset()),
+                                            static_cast<int32_t>(ref.seq().size()), ps.regionBegin, ps.regionEnd,
+                                            static_cast<int32_t>(Access::largestTotalIndelRefSpanPerRead(pp))), "sk_pileup_stream_begin_region");
+        ps.isRegionOpen[sampleIndex] = 1;
+    }
+
+    static WindowBatch wb;
+    wb.clear();
+    for (pos_t pos(begin); pos < end; ++pos)
+    {
+        read_segment_iter ri(sif.readBuffer.get_pos_read_segment_iter(pos));
+        for (read_segment_iter::ret_val r; true; ri.next())
+        {
+            r = ri.get_ptr();
+            if (nullptr == r.first) break;
+            if (r.second != 0) throw blt_exception("strelka_amd adapter: spliced (RNA) read segments are not supported on this path");
+            const read_segment& rseg(r.first->get_segment(r.second));
+
+            // pileup_read_segment's read-level exits (:1132-1165), messages included
+            const alignment* best(&(rseg.getInputAlignment()));
+            if (rseg.is_realigned) best = &(rseg.realignment);
+            else if (! rseg.is_any_nonovermax(opt.maxIndelSize)) continue;
+            if (best->empty())
+            {
+                if (! rseg.is_realigned)
+                {
+                    if (opt.verbosity >= LOG_LEVEL::ALLWARN)
+                    {
+                        log_os << "WARNING: skipping read_segment with no genomic alignment and contig alignment outside of indel.\n";
+                        log_os << "\tread_name: " << rseg.key() << "\n";
+                    }
+                }
+                else
+                {
+                    log_os << "WARNING: skipping read_segment which has multiple equally likely but incompatible alignments: " << rseg.key() << "\n";
+                }
+                continue;
+            }
+            if (rseg.is_realigned && rseg.is_invalid_realignment) continue;
+
+            const unsigned readSize(rseg.read_size());
+            const unsigned refSpan(ALIGNPATH::apath_ref_length(best->path));
+            // :1186-1191 with the reference's value at the time its READ_BUFFER stage was at this read
+            const unsigned spanThen(static_cast<unsigned>(s.geometry.query(pos).rangeMinOffset) + 1);
+            if (refSpan > (readSize + spanThen)) continue;
+
+            const bam_seq bseq(rseg.get_bam_read());
+            const size_t c0(wb.code.size());
+            wb.code.resize(c0 + readSize);
+            for (unsigned i(0); i < readSize; ++i) wb.code[c0 + i] = bseq.get_code(static_cast<pos_t>(i));
+            const uint8_t* q(rseg.qual());
+            wb.qual.insert(wb.qual.end(), q, q + readSize);
+            for (const auto& seg : best->path)
+            {
+                sk_path_seg out;
+                out.type = static_cast<uint32_t>(seg.type);
+                out.length = seg.length;
+                wb.path.push_back(out);
+            }
+            wb.readOff.push_back(static_cast<int64_t>(wb.code.size()));
+            wb.pathOff.push_back(static_cast<int64_t>(wb.path.size()));
+            wb.pos.push_back(best->pos);
+            wb.isFwd.push_back(best->is_fwd_strand ? 1 : 0);
+            wb.mapq.push_back(rseg.map_qual());
+            wb.level.push_back(static_cast<uint8_t>(rseg.getInputAlignmentMapLevel()));
+            wb.lo = std::min(wb.lo, best->pos);
+            wb.hi = std::max(wb.hi, best->pos + static_cast<pos_t>(refSpan));
+        }
+    }
+
+    const pos_t span(static_cast<pos_t>(Access::largestTotalIndelRefSpanPerRead(pp)));
+    const int32_t finalTo(isFinal ? INT32_MAX : static_cast<int32_t>(end - span));
+
+    // CandidateSnvBuffer::isCandidateSnvAnySample over the new reads' span, as of now
+    static std::vector<uint8_t> mask;
+    pos_t maskBegin(0), maskEnd(0);
+    if (! wb.pos.empty())
+    {
+        maskBegin = std::max(wb.lo, static_cast<pos_t>(ref.get_offset()));
+        maskEnd = std::min(wb.hi, static_cast<pos_t>(ref.get_offset()) + static_cast<pos_t>(ref.seq().size()));
+        if (maskEnd < maskBegin) maskEnd = maskBegin;
+        mask.assign(static_cast<size_t>(maskEnd - maskBegin), 0);
+        const CandidateSnvBuffer& csb(Access::candidateSnvBuffer(pp));
+        if (! csb.empty())
+        {
+            const unsigned sampleCount(Access::sampleCount(pp));
+            for (pos_t p(maskBegin); p < maskEnd; ++p)
+            {
+                uint8_t m(0);
+                for (unsigned si(0); si < sampleCount; ++si)
+                {
+                    for (unsigned b(0); b < 4; ++b)
+                    {
+                        if (csb.getHaplotypeId(si, p, static_cast<BASE_ID::index_t>(b)) != 0) m |= static_cast<uint8_t>(1u << b);
+                    }
+                }
+                mask[static_cast<size_t>(p - maskBegin)] = m;
+            }
+        }
+    }
+
+    // caller ploidy of the positions this push can finalise (process_pos_snp_digt "prep step 2", starling_pos_processor.cpp:637-651,
+    // without the indel calls' adjustment, which is not known yet: site_diploid_genotype() checks it when the locus is called)
+    static std::vector<uint8_t> ploidy;
+    pos_t ploidyBegin(0);
+    const uint8_t* ploidyPtr(nullptr);
+    int32_t ploidyLen(0);
+    if (ps.isGenotyping && Access::hasPloidyRegions(pp, sampleIndex))
+    {
+        ploidyBegin = std::max(ps.regionBegin, std::min(ps.nextFinal[sampleIndex], ps.regionEnd));
+        // one past the last position this push can finalise
+        pos_t reach(isFinal ? ps.pendingEnd[sampleIndex] : static_cast<pos_t>(finalTo));
+        if (isFinal && (! wb.pos.empty())) reach = std::max(reach, wb.hi);
+        const pos_t ploidyEnd(std::max(ploidyBegin, std::min(reach, ps.regionEnd)));
+        ploidy.resize(static_cast<size_t>(ploidyEnd - ploidyBegin));
+        for (pos_t p(ploidyBegin); p < ploidyEnd; ++p)
+        {
+            const unsigned pl(Access::ploidy(pp, p, sampleIndex));
+            ploidy[static_cast<size_t>(p - ploidyBegin)] = static_cast<uint8_t>(pl == 0 ? 2 : pl);
+        }
+        ploidyPtr = ploidy.data();
+        ploidyLen = static_cast<int32_t>(ploidy.size());
+    }
+
+    sk_read_batch rb;
+    std::memset(&rb, 0, sizeof(rb));
+    rb.n_reads = static_cast<int32_t>(wb.pos.size());
+    static const uint8_t none8(0);
+    static const sk_path_seg noneSeg = {0u, 0u};
+    static const int32_t none32(0);
+    rb.read_off = wb.readOff.data();
+    rb.read_code = wb.code.empty() ? &none8 : wb.code.data();
+    rb.read_qual = wb.qual.empty() ? &none8 : wb.qual.data();
+    rb.path_off = wb.pathOff.data();
+    rb.path = wb.path.empty() ? &noneSeg : wb.path.data();
+    rb.pos = wb.pos.empty() ? &none32 : wb.pos.data();
+    rb.is_fwd = wb.isFwd.empty() ? &none8 : wb.isFwd.data();
+    rb.mapq = wb.mapq.empty() ? &none8 : wb.mapq.data();
+    rb.map_level = wb.level.empty() ? &none8 : wb.level.data();
+
+    sk_pileup_window w;
+    std::memset(&w, 0, sizeof(w));
+    {
+        AccumTimer abiTimer(s.tPileupAbi);
+        check(sk_pileup_stream_push(stream, &rb, static_cast<int32_t>(span), static_cast<int32_t>(maskBegin),
+                                    static_cast<int32_t>(maskEnd - maskBegin), mask.empty() ? nullptr : mask.data(), finalTo,
+                                    static_cast<int32_t>(ploidyBegin), ploidyLen, ploidyPtr, &w), "sk_pileup_stream_push");
+    }
+    s.pileupBatches++;
+    s.pileupReads += wb.pos.size();
+    if (! wb.pos.empty()) ps.pendingEnd[sampleIndex] = std::max(ps.pendingEnd[sampleIndex], wb.hi);
+
+    // ---- the finalised positions, into the reference's pos_basecall_buffer (what insert_pos_basecall / insert_mapq_count /
+    // insert_pos_spandel_count / insert_pos_submap_count would have left there)
+    const size_t n(static_cast<size_t>(w.end - w.begin));
+    static_assert(sizeof(base_call) == 2, "base_call is the 16-bit record the kernels write");
+    for (size_t i(0); i < n; ++i)
+    {
+        const uint32_t mq(w.mapq_count[i]), sd(w.spandel_count[i]), sm(w.submapped_count[i]);
+        if ((mq | sd | sm) == 0) continue; // untouched: the reference has no entry either
+        snp_pos_info& pi(Access::pileupRef(sif.basecallBuffer, w.begin + static_cast<pos_t>(i)));
+        const size_t n1(static_cast<size_t>(w.tier1_off[i + 1] - w.tier1_off[i]));
+        const size_t n2(static_cast<size_t>(w.tier2_off[i + 1] - w.tier2_off[i]));
+        static const base_call blank(0, 0, false, 0, 0, false, false, false);
+        pi.calls.assign(n1, blank);
+        if (n1) std::memcpy(static_cast<void*>(pi.calls.data()), w.tier1_calls + w.tier1_off[i], 2 * n1);
+        pi.tier2_calls.assign(n2, blank);
+        if (n2) std::memcpy(static_cast<void*>(pi.tier2_calls.data()), w.tier2_calls + w.tier2_off[i], 2 * n2);
+        pi.spanningDeletionReadCount = sd;
+        pi.submappedReadCount = sm;
+        pi.mapqTracker.count = mq;
+        pi.mapqTracker.zeroCount = w.mapq_zero_count[i];
+        pi.mapqTracker.sumSquare = static_cast<double>(w.mapq_sum_square[i]);
+    }
+    s.pileupLoci += n;
+
+    if (ps.isGenotyping && n > 0)
+    {
+        SiteChunk chunk;
+        chunk.begin = w.begin;
+        chunk.end = w.end;
+        chunk.calls.assign(w.genotype, w.genotype + n);
+        chunk.cleanCount.assign(w.clean_count, w.clean_count + n);
+        chunk.ploidy.resize(n);
+        for (size_t i(0); i < n; ++i)
+        {
+            const int64_t k(static_cast<int64_t>(w.begin) + static_cast<int64_t>(i) - ploidyBegin);
+            chunk.ploidy[i] = (ploidyPtr && k >= 0 && k < ploidyLen) ? ploidyPtr[k] : 2;
+        }
+        ps.chunks[sampleIndex].push_back(std::move(chunk));
+        s.siteLoci += n;
+        s.siteBatches++;
+    }
+    ps.nextFinal[sampleIndex] = isFinal ? INT_MAX : std::max(ps.nextFinal[sampleIndex], static_cast<pos_t>(finalTo));
+}
+
+}
+
+bool pileup_enabled(starling_pos_processor_base& pp)
+{
+    PileupState& ps(state().pileup);
+    if (ps.decided) return ps.enabled;
+    const starling_base_options& opt(Access::opt(pp));
+    ps.decided = true;
+    ps.enabled = env_flag("STRELKA_AMD_PILEUP", true) && (! opt.isSomaticCallingMode) && (! opt.is_compute_germline_scoring_metrics()) &&
+                 (! opt.is_compute_somatic_scoring_metrics);
+    // genotypes straight from the device columns: the diploid germline model only
+    ps.isGenotyping = ps.enabled && opt.is_bsnp_diploid() && env_flag("STRELKA_AMD_PILEUP_GENOTYPE", true);
+    return ps.enabled;
+}
+
+void pileup_reset_region(starling_pos_processor_base& pp)
+{
+    State& s(state());
+    PileupState& ps(s.pileup);
+    if (! pileup_enabled(pp)) return;
+    const starling_base_options& opt(Access::opt(pp));
+    const unsigned sampleCount(Access::sampleCount(pp));
+    if (ps.streams.empty())
+    {
+        sk_pileup_options po;
+        pileupOptions(opt, po);
+        sk_germline_options go;
+        germlineOptionsForStream(opt, go);
+        if (ps.isGenotyping && opt.isHetVariantFrequencyExtensionDefined())
+        {
+            throw blt_exception("strelka_amd adapter: --het-variant-frequency-extension (RNA) is not supported on this path");
+        }
+        for (unsigned i(0); i < sampleCount; ++i)
+        {
+            sk_pileup_stream* st(sk_pileup_stream_create(&po, ps.isGenotyping ? &go : nullptr));
+            if (st == nullptr) check(1, "sk_pileup_stream_create");
+            ps.streams.push_back(st);
+        }
+    }
+    // (the reference segment of the region is loaded after resetRegion, starling_run.cpp:117-119: the streams get it with the
+    // region's first push)
+    const known_pos_range2& rr(Access::reportRange(pp));
+    ps.regionBegin = rr.begin_pos();
+    ps.regionEnd = rr.end_pos();
+    ps.isRegionOpen.assign(sampleCount, 0);
+    ps.chunks.assign(sampleCount, std::deque<SiteChunk>());
+    ps.nextFinal.assign(sampleCount, rr.begin_pos());
+    ps.pendingEnd.assign(sampleCount, INT_MIN);
+    ps.maxBufferPos.assign(sampleCount, INT_MIN);
+    ps.isAnyPiled = false;
+    ps.piledTo = 0;
+    ps.isFlushing = false;
+}
+
+bool pileup_pos_reads(starling_pos_processor_base& pp, const pos_t pos)
+{
+    if (! pileup_enabled(pp)) return false;
+    State& s(state());
+    PileupState& ps(s.pileup);
+    if (ps.isAnyPiled && pos < ps.piledTo) return true;
+    AccumTimer hookTimer(s.tPileupHook);
+    // align_pos(pos) has just realigned the window [pos, realignedTo) (process_pos :812-813 calls them back to back)
+    const pos_t end(s.realignedTo);
+    if (! (s.isAnyRealigned && end > pos)) throw blt_exception("strelka_amd adapter: pileup window without its realignment job");
+    const unsigned sampleCount(Access::sampleCount(pp));
+    for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
+    {
+        // the last window of a region: at the final flush, when no read is buffered beyond it
+        const bool isFinal(ps.isFlushing && ps.maxBufferPos[sampleIndex] < end);
+        try
+        {
+            pileup_sample_window(pp, sampleIndex, pos, end, isFinal);
+        }
+        catch (...)
+        {
+            log_os << "Exception caught in pileup_pos_reads() while piling up the reads buffered at positions [" << (pos + 1) << "," << end
+                   << "] of sample " << sampleIndex << "\n";
+            throw;
+        }
+    }
+    ps.isAnyPiled = true;
+    ps.piledTo = end;
+    return true;
+}
+
+void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos)
+{
+    // POST_ALIGN asks for a position that no push has finalised: only at the end of a region, when the READ_BUFFER stage has run
+    // out of positions before the last window's tail was final
+    State& s(state());
+    PileupState& ps(s.pileup);
+    if (! ps.enabled) return;
+    const unsigned sampleCount(Access::sampleCount(pp));
+    for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
+    {
+        if (pos < ps.nextFinal[sampleIndex]) continue;
+        if (! ps.isFlushing) throw blt_exception("strelka_amd adapter: the POST_ALIGN stage reached a position whose pileup is not final");
+        AccumTimer hookTimer(s.tPileupHook);
+        // nothing new to pile up: an empty window that finalises everything
+        pileup_sample_window(pp, sampleIndex, 0, 0, true);
+    }
+}
+
+void on_flush_begin(starling_pos_processor_base& /*pp*/)
+{
+    state().pileup.isFlushing = true;
+}
+
+void on_flush_end(starling_pos_processor_base& /*pp*/)
+{
+    state().pileup.isFlushing = false;
+}
+
+void pileup_note_read(const unsigned sampleIndex, const pos_t bufferPos)
+{
+    PileupState& ps(state().pileup);
+    if (sampleIndex < ps.maxBufferPos.size()) ps.maxBufferPos[sampleIndex] = std::max(ps.maxBufferPos[sampleIndex], bufferPos);
+}
+
+}

@@ -553,6 +553,54 @@ int sk_site_digt_call_fused(const sk_pileup_batch* host_batch, const sk_germline
 int sk_site_digt_call_fused_dev(const sk_pileup_batch* dev_batch, const sk_germline_options* opt, sk_digt_call* dev_out,
                                 float* dev_de_tmp, int want_de, void* dev_scratch, int64_t n_calls, void* hip_stream);
 
+/* ---- row a8 as a stream over a genome segment, chained into a9+a10 (sk_pileup_reads -> sk_site_digt_call_fused) --------
+ * The reference piles the reads of position P up when its READ_BUFFER stage reaches P (pileup_pos_reads,
+ * L/starling_common/starling_pos_processor_base.cpp:1107-1123, called at :813) and genotypes a position when the POST_ALIGN
+ * stage -- largest_total_indel_ref_span_per_read positions behind (:141-224) -- gets there (process_pos_variants :821-890 ->
+ * CleanPileupFilter, PileupCleaner.cpp:28-66; adjust_joint_eprob :73; position_snp_call_pprob_digt,
+ * L/applications/starling/starling_pos_processor.cpp:256-267).  A caller that batches by stage windows pushes one window's reads
+ * at a time, in read-buffer order, and names the position `final_to` below which no later read can add a basecall; the push
+ * returns everything the position processor keeps per position for [begin, end): the raw tier1 / tier2 columns
+ * (snp_pos_info::calls / tier2_calls), spanningDeletionReadCount, submappedReadCount, the MapqTracker sums
+ * (L/blt_common/MapqTracker.hh:36-42, fed by insert_mapq_count at starling_pos_processor_base.cpp:1346) and -- when the stream
+ * was created with germline options -- the diploid genotype of the CleanPileupFilter'ed tier1 column.  The columns never
+ * leave the device between the pileup and the genotype kernels; reads that reach past `final_to` stay on the device for the
+ * next push.  Not produced: the EVS feature accumulators (updateGermlineScoringMetrics / updateSomaticScoringMetrics).
+ * The returned pointers are into a host buffer of the stream, valid until its next call. */
+typedef struct sk_pileup_stream sk_pileup_stream;
+
+typedef struct sk_pileup_window {
+    int32_t begin, end;              /* positions [begin, end); n = end - begin */
+    const int64_t* tier1_off;        /* [n+1] */
+    const uint16_t* tier1_calls;
+    const int64_t* tier2_off;        /* [n+1] */
+    const uint16_t* tier2_calls;
+    const uint32_t* spandel_count;   /* [n] */
+    const uint32_t* submapped_count; /* [n] */
+    const uint32_t* mapq_count;      /* [n] MapqTracker::count */
+    const uint32_t* mapq_zero_count; /* [n] MapqTracker::zeroCount */
+    const uint64_t* mapq_sum_square; /* [n] MapqTracker::sumSquare (a sum of integer squares: exact) */
+    const uint32_t* clean_count;     /* [n] calls in the cleaned tier1 column the genotype was computed from */
+    const sk_digt_call* genotype;    /* [n], NULL when the stream does not genotype */
+} sk_pileup_window;
+
+/** genotype_opt: NULL = columns only.  opt->report_begin / report_end / largest_total_indel_ref_span_per_read are set per
+ *  region and per push. */
+sk_pileup_stream* sk_pileup_stream_create(const sk_pileup_options* opt, const sk_germline_options* genotype_opt);
+void sk_pileup_stream_destroy(sk_pileup_stream* s);
+/** resetRegionBase (starling_pos_processor_base.cpp:361-393): the reference segment of the region and its report range */
+int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, int32_t ref_offset, int32_t ref_len,
+                                  int32_t report_begin, int32_t report_end, int32_t largest_total_indel_ref_span_per_read);
+/** host_reads: the window's reads with their best alignments (ref_seq / ref_offset / ref_len / cand_snv_mask of the batch are
+ *  ignored: the stream holds the region's); cand_snv_mask[mask_len] = CandidateSnvBuffer::isCandidateSnvAnySample for
+ *  positions [mask_begin, mask_begin + mask_len) as of now (it must cover the new reads; may be NULL with mask_len 0);
+ *  final_to: no read of a later push has a basecall or spanning deletion below it (INT32_MAX at the end of a region);
+ *  ploidy[ploidy_len]: caller ploidy (1 or 2) of positions from ploidy_begin on, 2 elsewhere (NULL: all 2).
+ *  Fails if a read reaches below the previous push's final_to. */
+int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* host_reads, int32_t largest_total_indel_ref_span_per_read,
+                          int32_t mask_begin, int32_t mask_len, const uint8_t* cand_snv_mask, int32_t final_to,
+                          int32_t ploidy_begin, int32_t ploidy_len, const uint8_t* ploidy, sk_pileup_window* out);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (somatic SNV): 30-state frequency-grid likelihoods + 3x2 posterior
  * ---------------------------------------------------------------------------------------------------------------- */

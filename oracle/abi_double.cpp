@@ -425,4 +425,260 @@ extern "C" int sk_gvcf_block_sites(const sk_gvcf_site* sites, int32_t n_sites, u
 extern "C" int sk_gvcf_block_sites_dev(const sk_gvcf_site*, int32_t, uint32_t, uint32_t, uint8_t*, sk_gvcf_block*, void*)
 {
     return sk_fail("sk_gvcf_block_sites_dev needs the GPU library");
+
+// ---- row a8 as a stream (sk_pileup_stream_*): read after read into per-position columns, exactly as the reference's
+// pos_basecall_buffer accumulates them (each read meets the candidate-SNV mask of ITS push), finalised range by range ----
+}  // extern "C" (reopened below)
+
+#include <map>
+
+struct sk_pileup_stream
+{
+    sk_pileup_options opt;
+    sk_germline_options gopt;
+    bool genotype = false;
+    bool has_region = false;
+    std::string ref;
+    int32_t ref_offset = 0, region_begin = 0, region_end = 0;
+    std::vector<uint8_t> mask;
+    struct Col
+    {
+        std::vector<uint16_t> t1, t2;
+        uint32_t spandel = 0, submapped = 0, mq_n = 0, mq_zero = 0;
+        uint64_t mq_sq = 0;
+    };
+    std::map<int32_t, Col> cols;
+    int32_t pending_end = INT32_MIN; // one past the highest position any pushed read covers
+    bool has_prev = false;
+    int32_t next_begin = 0;
+    // output storage
+    std::vector<int64_t> o_off1, o_off2;
+    std::vector<uint16_t> o_c1, o_c2;
+    std::vector<uint32_t> o_sd, o_sm, o_mn, o_mz, o_cn;
+    std::vector<uint64_t> o_sq;
+    std::vector<sk_digt_call> o_g;
+};
+
+extern "C" {
+
+void sk_pileup_options_default(sk_pileup_options* o)
+{
+    o->min_basecall_qscore = 17;
+    o->mismatch_density_flank_size = 20;
+    o->mismatch_density_max_count = 2;
+    o->use_tier2_evidence = 0;
+    o->tier2_mismatch_density_max_count = 10;
+    o->is_mapq_adjust = 1;
+    o->min_distance_from_read_edge = 0;
+    o->largest_total_indel_ref_span_per_read = 49;
+    o->report_begin = 0;
+    o->report_end = 0;
+}
+
+sk_pileup_stream* sk_pileup_stream_create(const sk_pileup_options* opt, const sk_germline_options* genotype_opt)
+{
+    if (!g_ready || !opt) {
+        fail("sk_pileup_stream_create: not initialised / null options");
+        return nullptr;
+    }
+    sk_pileup_stream* s = new sk_pileup_stream();
+    s->opt = *opt;
+    if (genotype_opt) {
+        s->gopt = *genotype_opt;
+        s->genotype = true;
+    }
+    return s;
+}
+
+void sk_pileup_stream_destroy(sk_pileup_stream* s) { delete s; }
+
+int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, int32_t ref_offset, int32_t ref_len, int32_t report_begin,
+                                  int32_t report_end, int32_t span)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    if (!s || ref_len < 0 || report_end < report_begin) return fail("sk_pileup_stream_begin_region: bad argument");
+    s->ref.assign(ref_seq ? ref_seq : "", static_cast<size_t>(ref_len));
+    s->ref_offset = ref_offset;
+    s->region_begin = report_begin;
+    s->region_end = report_end;
+    s->opt.report_begin = report_begin;
+    s->opt.report_end = report_end;
+    s->opt.largest_total_indel_ref_span_per_read = span;
+    s->mask.assign(static_cast<size_t>(ref_len) + 1, 0);
+    s->cols.clear();
+    s->pending_end = INT32_MIN;
+    s->has_prev = false;
+    s->next_begin = report_begin;
+    s->has_region = true;
+    return 0;
+}
+
+int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32_t span, int32_t mask_begin, int32_t mask_len,
+                          const uint8_t* cand_snv_mask, int32_t final_to, int32_t ploidy_begin, int32_t ploidy_len, const uint8_t* ploidy,
+                          sk_pileup_window* out)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    if (!s || !reads || !out || !s->has_region) return fail("sk_pileup_stream_push: bad argument / no region");
+    if (mask_len > 0 && (mask_begin < s->ref_offset || mask_begin + mask_len > s->ref_offset + static_cast<int32_t>(s->ref.size())))
+        return fail("sk_pileup_stream_push: candidate-SNV mask window outside the reference segment");
+    if (mask_len > 0) std::memcpy(s->mask.data() + (mask_begin - s->ref_offset), cand_snv_mask, static_cast<size_t>(mask_len));
+    s->opt.largest_total_indel_ref_span_per_read = span;
+    const int n = reads->n_reads;
+    // the new reads' own span
+    int32_t lo = INT32_MAX, hi = INT32_MIN;
+    for (int r = 0; r < n; ++r) {
+        const int64_t a = reads->path_off[r], b = reads->path_off[r + 1];
+        if (a == b) continue;
+        int ref_len = 0;
+        for (int64_t i = a; i < b; ++i) {
+            const uint32_t t = reads->path[i].type;
+            if (t == SK_SEG_MATCH || t == SK_SEG_SEQ_MATCH || t == SK_SEG_SEQ_MISMATCH || t == SK_SEG_DELETE || t == SK_SEG_SKIP) ref_len += static_cast<int>(reads->path[i].length);
+        }
+        lo = std::min(lo, reads->pos[r]);
+        hi = std::max(hi, reads->pos[r] + ref_len);
+    }
+    if (lo != INT32_MAX) {
+        lo = std::max(lo, s->region_begin);
+        hi = std::min(hi, s->region_end);
+    }
+    if (lo != INT32_MAX && lo < hi) {
+        if (s->has_prev && lo < s->next_begin) {
+            // (only an error when a basecall or deletion really lands there; checked after the pileup below)
+        }
+        sko_pileup_options o;
+        o.min_basecall_qscore = s->opt.min_basecall_qscore;
+        o.mismatch_density_flank_size = s->opt.mismatch_density_flank_size;
+        o.mismatch_density_max_count = s->opt.mismatch_density_max_count;
+        o.use_tier2_evidence = s->opt.use_tier2_evidence;
+        o.tier2_mismatch_density_max_count = s->opt.tier2_mismatch_density_max_count;
+        o.is_mapq_adjust = s->opt.is_mapq_adjust;
+        o.min_distance_from_read_edge = s->opt.min_distance_from_read_edge;
+        o.largest_total_indel_ref_span_per_read = span;
+        // the reads see the REGION's report range (is_pos_reportable); columns are collected over [lo, hi)
+        sko_read_batch b;
+        static_assert(sizeof(sko_path_seg) == sizeof(sk_path_seg), "path segment layouts must agree");
+        b.n_reads = n;
+        b.read_off = reads->read_off;
+        b.read_code = reads->read_code;
+        b.read_qual = reads->read_qual;
+        b.path_off = reads->path_off;
+        b.path = reinterpret_cast<const sko_path_seg*>(reads->path);
+        b.pos = reads->pos;
+        b.is_fwd = reads->is_fwd;
+        b.mapq = reads->mapq;
+        b.map_level = reads->map_level;
+        b.ref_seq = s->ref.data();
+        b.ref_offset = s->ref_offset;
+        b.ref_len = static_cast<int32_t>(s->ref.size());
+        b.cand_snv_mask = s->mask.data();
+        o.report_begin = lo;
+        o.report_end = hi;
+        // a read that starts inside [lo, hi) but the region's range is narrower: lo/hi were clipped to the region above, and a
+        // read is dropped as a whole only by the region's bounds (pos >= report_end / end <= report_begin), which clipping
+        // [lo, hi) to the region preserves for every read of this batch
+        const size_t nl = static_cast<size_t>(hi - lo);
+        const int64_t cap = n ? reads->read_off[n] : 0;
+        std::vector<int64_t> off1(nl + 1), off2(nl + 1);
+        std::vector<uint16_t> c1(static_cast<size_t>(cap) + 1), c2(static_cast<size_t>(cap) + 1);
+        std::vector<uint32_t> sd(nl), sm(nl), mn(nl), mz(nl);
+        std::vector<uint64_t> sq(nl);
+        if (sko_pileup_reads_mapq(&b, &o, 0, off1.data(), c1.data(), cap, sd.data(), sm.data(), mn.data(), mz.data(), sq.data()) < 0)
+            return fail("sk_pileup_stream_push: malformed read");
+        if (sko_pileup_reads(&b, &o, 1, off2.data(), c2.data(), cap, nullptr, nullptr) < 0) return fail("sk_pileup_stream_push: malformed read");
+        for (size_t l = 0; l < nl; ++l) {
+            const bool any = (off1[l + 1] > off1[l]) || (off2[l + 1] > off2[l]) || sd[l] || sm[l] || mn[l];
+            if (!any) continue;
+            const int32_t p = lo + static_cast<int32_t>(l);
+            if (s->has_prev && p < s->next_begin) return fail("sk_pileup_stream_push: a read reaches positions that an earlier push declared final");
+            sk_pileup_stream::Col& c = s->cols[p];
+            c.t1.insert(c.t1.end(), c1.begin() + off1[l], c1.begin() + off1[l + 1]);
+            c.t2.insert(c.t2.end(), c2.begin() + off2[l], c2.begin() + off2[l + 1]);
+            c.spandel += sd[l];
+            c.submapped += sm[l];
+            c.mq_n += mn[l];
+            c.mq_zero += mz[l];
+            c.mq_sq += sq[l];
+        }
+        s->pending_end = std::max(s->pending_end, hi);
+    }
+
+    // ---- the range this push finalises: as the product computes it (lowest / highest over the reads it still holds)
+    const int32_t F = std::min(final_to, s->region_end);
+    int32_t begin = s->next_begin, end = s->next_begin;
+    {
+        // "lowest" of the product = min start over carried + new reads; the carried reads start below next_begin whenever there are
+        // any, and the columns present in `cols` tell the same story: use the first pending position or the new reads' start
+        int32_t lowest = (lo != INT32_MAX) ? lo : INT32_MAX;
+        if (!s->cols.empty()) lowest = std::min(lowest, s->cols.begin()->first);
+        int32_t highest = s->pending_end;
+        if (lowest != INT32_MAX && highest != INT32_MIN) {
+            begin = std::max(s->region_begin, s->has_prev ? std::max(s->next_begin, lowest) : lowest);
+            end = std::max(begin, std::min(F, highest));
+        }
+        if (begin > F) begin = end = std::max(s->next_begin, std::min(begin, F));
+    }
+    const size_t nl = static_cast<size_t>(end - begin);
+    s->o_off1.assign(nl + 1, 0); s->o_off2.assign(nl + 1, 0);
+    s->o_c1.clear(); s->o_c2.clear();
+    s->o_sd.assign(nl, 0); s->o_sm.assign(nl, 0); s->o_mn.assign(nl, 0); s->o_mz.assign(nl, 0); s->o_cn.assign(nl + 1, 0);
+    s->o_sq.assign(nl, 0);
+    std::vector<int64_t> coff(nl + 1, 0);
+    std::vector<uint16_t> ccalls;
+    for (size_t l = 0; l < nl; ++l) {
+        s->o_off1[l] = static_cast<int64_t>(s->o_c1.size());
+        s->o_off2[l] = static_cast<int64_t>(s->o_c2.size());
+        coff[l] = static_cast<int64_t>(ccalls.size());
+        const auto it = s->cols.find(begin + static_cast<int32_t>(l));
+        if (it == s->cols.end()) continue;
+        const sk_pileup_stream::Col& c = it->second;
+        s->o_c1.insert(s->o_c1.end(), c.t1.begin(), c.t1.end());
+        s->o_c2.insert(s->o_c2.end(), c.t2.begin(), c.t2.end());
+        for (const uint16_t bc : c.t1) if (!((bc >> 12) & 1)) ccalls.push_back(bc);
+        s->o_cn[l] = static_cast<uint32_t>(ccalls.size() - static_cast<size_t>(coff[l]));
+        s->o_sd[l] = c.spandel; s->o_sm[l] = c.submapped; s->o_mn[l] = c.mq_n; s->o_mz[l] = c.mq_zero; s->o_sq[l] = c.mq_sq;
+    }
+    s->o_off1[nl] = static_cast<int64_t>(s->o_c1.size());
+    s->o_off2[nl] = static_cast<int64_t>(s->o_c2.size());
+    coff[nl] = static_cast<int64_t>(ccalls.size());
+    s->o_c1.push_back(0); s->o_c2.push_back(0); ccalls.push_back(0);
+    s->o_g.assign(nl + 1, sk_digt_call());
+    if (s->genotype && nl) {
+        std::vector<uint8_t> rb(nl), pl(nl);
+        for (size_t l = 0; l < nl; ++l) {
+            const int64_t k = static_cast<int64_t>(begin) + static_cast<int64_t>(l) - s->ref_offset;
+            const char ch = (k >= 0 && k < static_cast<int64_t>(s->ref.size())) ? s->ref[static_cast<size_t>(k)] : 'N';
+            rb[l] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+            const int64_t kp = static_cast<int64_t>(begin) + static_cast<int64_t>(l) - ploidy_begin;
+            pl[l] = (ploidy && kp >= 0 && kp < ploidy_len) ? ploidy[kp] : 2;
+        }
+        sk_pileup_batch pb;
+        std::memset(&pb, 0, sizeof(pb));
+        pb.n_loci = static_cast<int32_t>(nl);
+        pb.call_off = coff.data();
+        pb.calls = ccalls.data();
+        pb.ref_base = rb.data();
+        pb.ploidy = pl.data();
+        if (sk_site_digt_call_fused(&pb, &s->gopt, s->o_g.data(), nullptr)) return 1;
+    }
+    s->cols.erase(s->cols.begin(), s->cols.lower_bound(F));
+    if (s->cols.empty()) s->pending_end = INT32_MIN;
+    s->has_prev = true;
+    s->next_begin = std::max(s->next_begin, F);
+
+    out->begin = begin;
+    out->end = end;
+    out->tier1_off = s->o_off1.data();
+    out->tier1_calls = s->o_c1.data();
+    out->tier2_off = s->o_off2.data();
+    out->tier2_calls = s->o_c2.data();
+    out->spandel_count = s->o_sd.data();
+    out->submapped_count = s->o_sm.data();
+    out->mapq_count = s->o_mn.data();
+    out->mapq_zero_count = s->o_mz.data();
+    out->mapq_sum_square = s->o_sq.data();
+    out->clean_count = s->o_cn.data();
+    out->genotype = s->genotype ? s->o_g.data() : nullptr;
+    return 0;
+}
+
 }

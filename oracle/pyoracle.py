@@ -566,6 +566,25 @@ def pileup_reads(rb, opt, mode):
     return call_off, calls[:n].copy(), sd[:n_loci], sm[:n_loci]
 
 
+def pileup_reads_mapq(rb, opt):
+    """raw tier1 columns + MapqTracker per position -> (call_off, calls, spandel, submapped, mapq_count, mapq_zero, mapq_sumsq)"""
+    L = oracle()
+    L.sko_pileup_reads_mapq.restype = C.c_int64
+    L.sko_pileup_reads_mapq.argtypes = [C.POINTER(ReadBatchStruct), C.POINTER(PileupOptions), C.c_int, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+    n_loci = opt.report_end - opt.report_begin
+    keep = []
+    s = read_batch_struct(rb, keep)
+    cap = 2 * rb.n_bases + 1
+    call_off = np.zeros(n_loci + 1, np.int64)
+    calls = np.zeros(cap, np.uint16)
+    sd, sm, mn, mz = (np.zeros(max(n_loci, 1), np.uint32) for _ in range(4))
+    sq = np.zeros(max(n_loci, 1), np.uint64)
+    n = L.sko_pileup_reads_mapq(C.byref(s), C.byref(opt), 0, _p(call_off), _p(calls), cap, _p(sd), _p(sm), _p(mn), _p(mz), _p(sq))
+    if n < 0:
+        raise RuntimeError("sko_pileup_reads_mapq failed")
+    return call_off, calls[:n].copy(), sd[:n_loci], sm[:n_loci], mn[:n_loci], mz[:n_loci], sq[:n_loci]
+
+
 def mapped_qscore_table():
     L = oracle()
     return np.array([[L.sko_mapped_qscore(q, m) for q in range(71)] for m in range(91)], np.int32)

@@ -1630,6 +1630,16 @@ static int pl_push(pl_col* c, uint16_t x)
 int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* o, int mode, int64_t* call_off,
                          uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count)
 {
+    return sko_pileup_reads_mapq(b, o, mode, call_off, calls, capacity, spandel_count, submapped_count, NULL, NULL, NULL);
+}
+
+/* the same with the MapqTracker of every position (insert_mapq_count, starling_pos_processor_base.cpp:1346:
+ * every match position inside the trimmed read and the report range, submapped reads included;
+ * L/blt_common/MapqTracker.hh:36-42) */
+int64_t sko_pileup_reads_mapq(const sko_read_batch* b, const sko_pileup_options* o, int mode, int64_t* call_off,
+                              uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count,
+                              uint32_t* mapq_count, uint32_t* mapq_zero_count, uint64_t* mapq_sum_square)
+{
     const int32_t n_loci = o->report_end - o->report_begin;
     pl_col* t1 = (pl_col*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col));
     pl_col* t2 = (pl_col*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col));
@@ -1639,6 +1649,9 @@ int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* o, i
     int bad = 0;
     if (spandel_count) memset(spandel_count, 0, sizeof(uint32_t) * (size_t)n_loci);
     if (submapped_count) memset(submapped_count, 0, sizeof(uint32_t) * (size_t)n_loci);
+    if (mapq_count) memset(mapq_count, 0, sizeof(uint32_t) * (size_t)n_loci);
+    if (mapq_zero_count) memset(mapq_zero_count, 0, sizeof(uint32_t) * (size_t)n_loci);
+    if (mapq_sum_square) memset(mapq_sum_square, 0, sizeof(uint64_t) * (size_t)n_loci);
 
     for (int32_t r = 0; r < b->n_reads && !bad; ++r) { /* pileup_pos_reads: read after read, buffer order */
         const int64_t ro = b->read_off[r];
@@ -1777,6 +1790,9 @@ int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* o, i
                         current = is_tier1 ? is_call_filter : is_t2;
                         tscf = is_tier1 && is_call_filter && !is_t2;
                     }
+                    if (mapq_count) mapq_count[locus]++; /* :1346, before the submapped test */
+                    if (mapq_zero_count && mapq == 0) mapq_zero_count[locus]++;
+                    if (mapq_sum_square) mapq_sum_square[locus] += (uint64_t)(mapq * mapq);
                     if (is_submapped) {
                         if (submapped_count) submapped_count[locus]++;
                         continue;

@@ -267,6 +267,10 @@ typedef struct sko_read_batch {
  * when capacity is too small / a read is malformed. */
 int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* opt, int mode, int64_t* call_off,
                          uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count);
+/* + MapqTracker per position (insert_mapq_count :1346; any of the three may be NULL) */
+int64_t sko_pileup_reads_mapq(const sko_read_batch* b, const sko_pileup_options* opt, int mode, int64_t* call_off,
+                              uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count,
+                              uint32_t* mapq_count, uint32_t* mapq_zero_count, uint64_t* mapq_sum_square);
 
 /* ---- GlobalAligner<int>::align (L/alignment/GlobalAlignerImpl.hh:35-228) ---- */
 typedef struct sko_align_scores { /* AlignmentScores<int>, L/alignment/AlignmentScores.hh */

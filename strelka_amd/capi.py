@@ -122,6 +122,13 @@ class PileupColumns(C.Structure):
 PILEUP_RAW_TIER1, PILEUP_RAW_TIER2, PILEUP_CLEAN_TIER1, PILEUP_CLEAN_TIER2 = 0, 1, 2, 3
 
 
+class PileupWindow(C.Structure):
+    _fields_ = [("begin", C.c_int32), ("end", C.c_int32), ("tier1_off", c_void_p), ("tier1_calls", c_void_p),
+                ("tier2_off", c_void_p), ("tier2_calls", c_void_p), ("spandel_count", c_void_p), ("submapped_count", c_void_p),
+                ("mapq_count", c_void_p), ("mapq_zero_count", c_void_p), ("mapq_sum_square", c_void_p),
+                ("clean_count", c_void_p), ("genotype", c_void_p)]
+
+
 class PileupBatch(C.Structure):
     _fields_ = [("n_loci", C.c_int32), ("call_off", c_void_p), ("calls", c_void_p), ("de", c_void_p),
                 ("ref_base", c_void_p), ("ploidy", c_void_p)]
@@ -187,6 +194,7 @@ EXPORTS = [
     "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
+    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
     "sk_realign_job_finish", "sk_realign_job_run", "sk_realign_job_n_reads", "sk_realign_job_read_result",
@@ -940,6 +948,73 @@ def pileup_reads(rb, opt, mode):
     out = PileupColumns(n_loci, cap, _p(call_off), _p(calls), _p(sd), _p(sm))
     _check(lib().sk_pileup_reads(C.byref(s), C.byref(opt), mode, C.byref(out)))
     return call_off, calls[:call_off[-1]].copy(), sd[:n_loci], sm[:n_loci]
+
+
+class PileupStream:
+    """sk_pileup_stream_*: one sample's pileup over a region, pushed window by window (row a8 chained into a9+a10).
+    `library`: the ctypes handle to drive (default: the product library; the tests also drive the CPU double with it)."""
+
+    def __init__(self, opt, germline_opt=None, library=None):
+        self.L = library or lib()
+        L = self.L
+        L.sk_pileup_stream_create.restype = c_void_p
+        L.sk_pileup_stream_create.argtypes = [C.POINTER(PileupOptions), c_void_p]
+        L.sk_pileup_stream_destroy.argtypes = [c_void_p]
+        L.sk_pileup_stream_begin_region.argtypes = [c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.sk_pileup_stream_push.argtypes = [c_void_p, C.POINTER(ReadBatchStruct), C.c_int32, C.c_int32, C.c_int32, c_void_p, C.c_int32,
+                                            C.c_int32, C.c_int32, c_void_p, C.POINTER(PileupWindow)]
+        L.sk_last_error.restype = C.c_char_p
+        self.genotype = germline_opt is not None
+        self.h = L.sk_pileup_stream_create(C.byref(opt), C.byref(germline_opt) if self.genotype else None)
+        if not self.h:
+            raise RuntimeError(L.sk_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.L.sk_pileup_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.sk_last_error().decode())
+
+    def begin_region(self, ref_seq, ref_offset, report_begin, report_end, span=49):
+        ref = ref_seq.encode()
+        self._check(self.L.sk_pileup_stream_begin_region(self.h, ref, ref_offset, len(ref), report_begin, report_end, span))
+
+    def push(self, rb, final_to, mask=None, mask_begin=0, ploidy=None, ploidy_begin=0, span=49):
+        """rb: synth.ReadBatch (its reference / mask fields are ignored) -> dict of numpy copies for [begin, end)"""
+        s = ReadBatchStruct(rb.n_reads, _p(rb.read_off), _p(rb.read_code), _p(rb.read_qual), _p(rb.path_off), _p(rb.path),
+                            _p(rb.pos), _p(rb.is_fwd), _p(rb.mapq), _p(rb.map_level), None, 0, 0, None)
+        w = PileupWindow()
+        mask = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        ploidy = None if ploidy is None else np.ascontiguousarray(ploidy, np.uint8)
+        self._check(self.L.sk_pileup_stream_push(self.h, C.byref(s), span, mask_begin, 0 if mask is None else len(mask), _p(mask),
+                                                  min(final_to, 2**31 - 1), ploidy_begin, 0 if ploidy is None else len(ploidy), _p(ploidy),
+                                                  C.byref(w)))
+        n = w.end - w.begin
+
+        def arr(ptr, dt, k):
+            if k == 0 or not ptr:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(np.dtype(dt)))), shape=(k,)).copy()
+
+        def rec(ptr, dt, k):
+            if k == 0 or not ptr:
+                return np.zeros(0, dt)
+            buf = (C.c_char * (dt.itemsize * k)).from_address(ptr)
+            return np.frombuffer(buf, dt, k).copy()
+        o1 = arr(w.tier1_off, np.int64, n + 1)
+        o2 = arr(w.tier2_off, np.int64, n + 1)
+        return dict(begin=w.begin, end=w.end, tier1_off=o1, tier1_calls=arr(w.tier1_calls, np.uint16, int(o1[-1]) if n else 0),
+                    tier2_off=o2, tier2_calls=arr(w.tier2_calls, np.uint16, int(o2[-1]) if n else 0),
+                    spandel=arr(w.spandel_count, np.uint32, n), submapped=arr(w.submapped_count, np.uint32, n),
+                    mapq_count=arr(w.mapq_count, np.uint32, n), mapq_zero=arr(w.mapq_zero_count, np.uint32, n),
+                    mapq_sumsq=arr(w.mapq_sum_square, np.uint64, n), clean_count=arr(w.clean_count, np.uint32, n),
+                    genotype=rec(w.genotype, DIGT_CALL_DTYPE, n) if self.genotype else None)
 
 
 # ---------------------------------------------------------------------------------------------------- GlobalAligner

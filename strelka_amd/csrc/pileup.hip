@@ -43,6 +43,7 @@ constexpr int WAVE = 64;
 constexpr int P1_WAVES = 4;
 constexpr int MAX_READ_LEN = 1024;  // LDS: 4 B delta + 1 B flag per read base
 constexpr unsigned REC_TIER2 = 1u << 14, REC_EMIT = 1u << 15;
+constexpr unsigned REC_SUBLIVE = 1u; // (REC_EMIT clear) a live position of a submapped read: no basecall, but it counts for the MAPQ tracker
 constexpr int COL_STAGE = 3072;     // calls of one wave's 64 columns staged in LDS (6 KiB); deeper spans store directly
 
 struct PileupArgs
@@ -62,6 +63,15 @@ struct PileupArgs
     int n_loci;
     int mode;
     int store; // 0: count, 1: store
+    int r0;    // P1 handles reads [r0, n_reads): the reads before r0 kept their records from an earlier launch (pileup stream)
+    // the three-column form of P2 (pileup_column3_kernel): raw tier1, raw tier2 and CleanPileupFilter'ed tier1 columns of the
+    // same loci in one pass over the records, plus the MAPQ tracker (insert_mapq_count: every live match position of every read)
+    uint32_t* count3[3];
+    const int64_t* call_off3[3];
+    uint16_t* calls3[3];
+    uint32_t* mapq_count;
+    uint32_t* mapq_zero;
+    unsigned long long* mapq_sumsq;
 };
 
 __device__ __forceinline__ bool seg_match(const uint32_t t) { return t == SK_SEG_MATCH || t == SK_SEG_SEQ_MATCH || t == SK_SEG_SEQ_MISMATCH; }
@@ -279,7 +289,7 @@ __device__ void pileup_read_short(const PileupArgs& a, const int r, const int la
             const int p = lane + WAVE * k;
             const bool live = in_match[k] && p >= read_begin && p < read_end && refpos[k] >= o.report_begin && refpos[k] < o.report_end;
             if (live && a.submapped) atomicAdd(&a.submapped[refpos[k] - o.report_begin], 1u);
-            if (p < L) a.rec[ro + p] = 0;
+            if (p < L) a.rec[ro + p] = uint16_t(live ? REC_SUBLIVE : 0u);
         }
     } else {
         // straight-line per position: table and LDS reads use clamped indices, every flag is a select, and the record of a
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(P1_WAVES* WAVE) void pileup_read_kernel(const Pileu
     __shared__ unsigned char s_mm[P1_WAVES][MAX_READ_LEN];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / WAVE);
-    const int r = blockIdx.x * P1_WAVES + wave;
+    const int r = a.r0 + blockIdx.x * P1_WAVES + wave;
     if (r >= a.b.n_reads) return;
     int* delta = s_delta[wave];
     unsigned char* mm = s_mm[wave];
@@ -496,6 +506,7 @@ __global__ __launch_bounds__(P1_WAVES* WAVE) void pileup_read_kernel(const Pileu
                 if (refp < o.report_begin || refp >= o.report_end) continue;
                 if (is_submapped) {
                     if (a.submapped) atomicAdd(&a.submapped[refp - o.report_begin], 1u);
+                    a.rec[ro + rp] = uint16_t(REC_SUBLIVE);
                     continue;
                 }
                 const unsigned code = a.b.read_code[ro + rp];
@@ -549,8 +560,10 @@ __device__ __forceinline__ bool rec_selected(const unsigned rec, const int mode,
     }
 }
 
-// P2: one wave per 64 loci
-__global__ __launch_bounds__(WAVE) void pileup_column_kernel(const PileupArgs a)
+// P2: one wave per 64 loci.  THREE = false: the column of a.mode; THREE = true: the raw tier1, raw tier2 and cleaned tier1 columns
+// (count3 / call_off3 / calls3, in that order) and the MAPQ tracker in the same walk over the records.
+template <bool THREE>
+__global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs a)
 {
     const int lane = threadIdx.x;
     const int l0 = blockIdx.x * WAVE;
@@ -580,23 +593,35 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel(const PileupArgs a)
     };
     const int lo = first_true(0, n, [&](const int m) { return a.maxend[m] > p0; });
     const int hi = first_true(lo, n, [&](const int m) { return a.minbegin[m] >= p0 + WAVE; });
-    unsigned cnt = 0;
-    const int64_t base = (a.store && l < a.n_loci) ? a.call_off[l] : 0;
-    const int parts = (a.mode == SK_PILEUP_CLEAN_TIER2) ? 2 : 1;
+    unsigned cnt = 0, cnt2 = 0, cnt3 = 0;
+    unsigned mq_n = 0, mq_zero = 0;
+    unsigned long long mq_sq = 0;
+    const int64_t* __restrict__ off_a = THREE ? a.call_off3[0] : a.call_off;
+    uint16_t* __restrict__ calls_a = THREE ? a.calls3[0] : a.calls;
+    const int64_t base = (a.store && l < a.n_loci) ? off_a[l] : 0;
+    const int64_t base2 = (THREE && a.store && l < a.n_loci) ? a.call_off3[1][l] : 0;
+    const int64_t base3 = (THREE && a.store && l < a.n_loci) ? a.call_off3[2][l] : 0;
+    const int parts = (!THREE && a.mode == SK_PILEUP_CLEAN_TIER2) ? 2 : 1;
     const bool live = (l < a.n_loci);
     // store pass: the wave's 64 columns are one contiguous span of `calls`; it is assembled in LDS and written out with
     // consecutive stores (a lane storing 2 bytes every ~80 bytes costs a 32-byte memory transaction per call)
     __shared__ uint16_t s_col[COL_STAGE];
-    int64_t span0 = 0;
-    int span_n = 0;
+    __shared__ uint16_t s_col3[THREE ? COL_STAGE : 1];
+    int64_t span0 = 0, span0c = 0;
+    int span_n = 0, span_nc = 0;
     bool staged = false;
     if (a.store) {
-        span0 = a.call_off[min(l0, a.n_loci)];
-        const int64_t tot = a.call_off[min(l0 + WAVE, a.n_loci)] - span0;
-        staged = (tot <= COL_STAGE);
+        span0 = off_a[min(l0, a.n_loci)];
+        const int64_t tot = off_a[min(l0 + WAVE, a.n_loci)] - span0;
+        staged = (tot <= COL_STAGE); // (the cleaned column is a subset of the raw tier1 one: it fits whenever that does)
         span_n = staged ? int(tot) : 0;
+        if (THREE) {
+            span0c = a.call_off3[2][min(l0, a.n_loci)];
+            span_nc = staged ? int(a.call_off3[2][min(l0 + WAVE, a.n_loci)] - span0c) : 0;
+        }
     }
     const unsigned lbase = unsigned(base - span0);
+    const unsigned lbase3 = unsigned(base3 - span0c);
     // Index of the record read k of the batch contributes to this lane's locus (-1: none).  A locus lies in at most one
     // match segment of a read.  The segments of reads with up to three segments were decoded by the lane that fetched the
     // read (mb/me/mr: reference begin / end and read begin of its match segments, empty ranges otherwise), so per read
@@ -642,6 +667,7 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel(const PileupArgs a)
             const int64_t ro_k = have ? a.b.read_off[rk] : 0;
             const int64_t so_k = have ? a.b.path_off[rk] : 0;
             const int nseg_k = have ? int(a.b.path_off[rk + 1] - so_k) : 0;
+            const int mapq_k = (THREE && have) ? int(a.b.mapq[rk]) : 0;
             sk_path_seg g0 = { 0u, 0u }, g1 = { 0u, 0u }, g2 = { 0u, 0u };
             if (nseg_k >= 1) g0 = a.b.path[so_k];
             if (nseg_k >= 2) g1 = a.b.path[so_k + 1];
@@ -674,10 +700,39 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel(const PileupArgs a)
                 for (int u = 0; u < RU; ++u) rec[u] = (idx[u] >= 0) ? unsigned(a.rec[idx[u]]) : 0u;
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
-                    if (idx[u] >= 0 && rec_selected(rec[u], a.mode, part)) {
+                    if (THREE) {
+                        if (idx[u] < 0) continue;
+                        const unsigned rc = rec[u];
+                        const uint16_t call = uint16_t(rc & 0x3fffu);
+                        if (rc & REC_EMIT) {
+                            if (rc & REC_TIER2) {
+                                if (a.store) a.calls3[1][base2 + cnt2] = call;
+                                ++cnt2;
+                            } else {
+                                if (a.store) {
+                                    if (staged) s_col[lbase + cnt] = call;
+                                    else calls_a[base + cnt] = call;
+                                }
+                                ++cnt;
+                                if (!(rc & (1u << 12))) {
+                                    if (a.store) {
+                                        if (staged) s_col3[lbase3 + cnt3] = call;
+                                        else a.calls3[2][base3 + cnt3] = call;
+                                    }
+                                    ++cnt3;
+                                }
+                            }
+                        }
+                        if (!a.store && ((rc & REC_EMIT) || rc == REC_SUBLIVE)) { // MapqTracker::add (L/blt_common/MapqTracker.hh:36-42)
+                            const unsigned mq = unsigned(__builtin_amdgcn_readlane(mapq_k, k0 + u));
+                            ++mq_n;
+                            mq_sq += (unsigned long long)(mq * mq);
+                            mq_zero += (mq == 0u) ? 1u : 0u;
+                        }
+                    } else if (idx[u] >= 0 && rec_selected(rec[u], a.mode, part)) {
                         if (a.store) {
                             if (staged) s_col[lbase + cnt] = uint16_t(rec[u] & 0x3fffu);
-                            else a.calls[base + cnt] = uint16_t(rec[u] & 0x3fffu);
+                            else calls_a[base + cnt] = uint16_t(rec[u] & 0x3fffu);
                         }
                         ++cnt;
                     }
@@ -685,15 +740,33 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel(const PileupArgs a)
             }
         }
     }
-    if (!a.store && l <= a.n_loci) a.count[l] = (l < a.n_loci) ? cnt : 0u;
+    if (!a.store && l <= a.n_loci) {
+        if (THREE) {
+            a.count3[0][l] = (l < a.n_loci) ? cnt : 0u;
+            a.count3[1][l] = (l < a.n_loci) ? cnt2 : 0u;
+            a.count3[2][l] = (l < a.n_loci) ? cnt3 : 0u;
+            if (l < a.n_loci) {
+                a.mapq_count[l] = mq_n;
+                a.mapq_zero[l] = mq_zero;
+                a.mapq_sumsq[l] = mq_sq;
+            }
+        } else {
+            a.count[l] = (l < a.n_loci) ? cnt : 0u;
+        }
+    }
     if (a.store && staged) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        uint16_t* __restrict__ dst = a.calls + span0;
+        uint16_t* __restrict__ dst = calls_a + span0;
         for (int i = lane; i < span_n; i += WAVE) dst[i] = s_col[i];
+        if (THREE) {
+            uint16_t* __restrict__ dst3 = a.calls3[2] + span0c;
+            for (int i = lane; i < span_nc; i += WAVE) dst3[i] = s_col3[i];
+        }
     }
 }
+
 
 __global__ void span_split_kernel(const int2* span, int* begin, int* end, const int n)
 {
@@ -803,6 +876,7 @@ int sk_pileup_reads_dev(const sk_read_batch* b, const int64_t n_bases, const sk_
     a.n_loci = n_loci;
     a.mode = mode;
     a.store = 0;
+    a.r0 = 0;
     void* tmp = base + L.tmp;
     size_t tmp_bytes = size_t(L.tmp_bytes);
 
@@ -817,7 +891,7 @@ int sk_pileup_reads_dev(const sk_read_batch* b, const int64_t n_bases, const sk_
                                        std::make_reverse_iterator(d_minbegin + b->n_reads), size_t(b->n_reads), MinOp(), st));
     }
     const int blocks = (n_loci + 1 + WAVE - 1) / WAVE; // the extra locus carries the total through the scan
-    hipLaunchKernelGGL(pileup_column_kernel, dim3(blocks), dim3(WAVE), 0, st, a);
+    hipLaunchKernelGGL(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE), 0, st, a);
     tmp_bytes = size_t(L.tmp_bytes);
     SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, a.count, out->call_off, int64_t(0), size_t(n_loci) + 1, rocprim::plus<int64_t>(), st));
     // capacity check needs the total on the host
@@ -826,7 +900,7 @@ int sk_pileup_reads_dev(const sk_read_batch* b, const int64_t n_bases, const sk_
     SK_HIP(hipStreamSynchronize(st));
     if (total > out->capacity) return sk_fail("sk_pileup_reads_dev: calls capacity too small");
     a.store = 1;
-    if (total > 0) hipLaunchKernelGGL(pileup_column_kernel, dim3(blocks), dim3(WAVE), 0, st, a);
+    if (total > 0) hipLaunchKernelGGL(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE), 0, st, a);
     SK_HIP(hipGetLastError());
     return 0;
 }
@@ -918,6 +992,545 @@ int sk_pileup_reads(const sk_read_batch* hb, const sk_pileup_options* opt, const
     if (out->spandel_count && n_loci) SK_HIP(hipMemcpyAsync(out->spandel_count, dc.spandel_count, 4 * size_t(n_loci), hipMemcpyDeviceToHost, ctx.stream));
     if (out->submapped_count && n_loci) SK_HIP(hipMemcpyAsync(out->submapped_count, dc.submapped_count, 4 * size_t(n_loci), hipMemcpyDeviceToHost, ctx.stream));
     SK_HIP(hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
+} // extern "C"
+
+// =====================================================================================================================
+// The pileup of one sample as a stream over a genome segment (sk_pileup_stream_*, include/strelka_amd.h).
+//
+// The reference piles reads up one at a time as its READ_BUFFER stage passes them and genotypes a position when the
+// POST_ALIGN stage, largest_total_indel_ref_span_per_read positions behind, gets there
+// (L/starling_common/starling_pos_processor_base.cpp:141-224, :810-890).  A caller of this stream hands over the reads of
+// one stage window at a time, in read-buffer order, together with the position up to which no later read can add a
+// basecall (`final_to`, the POST_ALIGN position of the window's end).  A push
+//   * runs P1 on the new reads only: their records join, on the device, those of the earlier reads that still reach past
+//     the previous `final_to` (the carried tail -- a few dozen reads: two record buffers used alternately, the tail is copied
+//     across), so every read meets the candidate-SNV mask exactly once, as in the reference;
+//   * runs the three-column P2 over [begin, end) = the not yet finalised positions below `final_to` that the batch covers:
+//     raw tier1 / tier2 columns (snp_pos_info::calls / tier2_calls), the CleanPileupFilter'ed tier1 column, the MAPQ
+//     tracker; spanning-deletion and submapped counters are P1's region-wide atomics;
+//   * chains a9+a10 (germline_site_fused_kernel) on the cleaned columns where they lie in HBM;
+//   * brings everything the host-side position processor keeps per position back in one copy.
+// One host synchronisation per push.
+// =====================================================================================================================
+
+namespace
+{
+
+struct DevBuf
+{
+    void* p = nullptr;
+    size_t cap = 0;
+    int need(const size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) return 1;
+        cap = want;
+        return 0;
+    }
+    void drop()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct PinBuf
+{
+    void* p = nullptr;
+    size_t cap = 0;
+    int need(const size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return 1;
+        cap = want;
+        return 0;
+    }
+    void drop()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+__global__ void ref_base_id_kernel(const char* ref_seq, const int ref_offset, const int ref_len, const int begin, const int n,
+                                   uint8_t* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = begin + i - ref_offset;
+    uint8_t id = 4;
+    if (p >= 0 && p < ref_len) {
+        const char c = ref_seq[p];
+        id = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+    }
+    out[i] = id;
+}
+
+inline int path_ref_length(const sk_path_seg* path, const int nseg)
+{
+    int n = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const uint32_t t = path[i].type;
+        if (t == SK_SEG_MATCH || t == SK_SEG_SEQ_MATCH || t == SK_SEG_SEQ_MISMATCH || t == SK_SEG_DELETE || t == SK_SEG_SKIP) n += int(path[i].length);
+    }
+    return n;
+}
+
+} // namespace
+
+struct sk_pileup_stream
+{
+    sk_pileup_options opt;
+    sk_germline_options gopt;
+    bool genotype = false;
+    // region
+    bool has_region = false;
+    int32_t ref_offset = 0, ref_len = 0;
+    int32_t region_begin = 0, region_end = 0;
+    DevBuf d_ref, d_mask, d_spandel, d_submapped;
+    // carried reads: metadata on the host, records and spans on the device
+    std::vector<int32_t> c_len, c_nseg, c_pos;
+    std::vector<uint8_t> c_mapq;
+    std::vector<sk_path_seg> c_path;
+    int64_t c_bases = 0;
+    int64_t c_tail_base = 0; // where the carried reads' records start in d_rec[cur]
+    int64_t c_tail_read = 0; // ... and their spans in d_span[cur]
+    int cur = 0;
+    DevBuf d_rec[2], d_span[2];
+    bool has_prev = false;
+    int32_t next_begin = 0;
+    DevBuf d_in, d_work, d_out;
+    PinBuf h_in, h_out;
+    int64_t pushes = 0, reads_in = 0;
+};
+
+extern "C" {
+
+sk_pileup_stream* sk_pileup_stream_create(const sk_pileup_options* opt, const sk_germline_options* genotype_opt)
+{
+    if (!sk_ctx().ready) {
+        sk_fail("strelka_amd: sk_init() has not succeeded");
+        return nullptr;
+    }
+    if (!opt) {
+        sk_fail("sk_pileup_stream_create: null options");
+        return nullptr;
+    }
+    sk_pileup_stream* s = new sk_pileup_stream();
+    s->opt = *opt;
+    if (genotype_opt) {
+        s->gopt = *genotype_opt;
+        s->genotype = true;
+    }
+    return s;
+}
+
+void sk_pileup_stream_destroy(sk_pileup_stream* s)
+{
+    if (!s) return;
+    if (sk_ctx().ready) {
+        (void)hipSetDevice(sk_ctx().device);
+        (void)hipStreamSynchronize(sk_ctx().stream);
+    }
+    s->d_ref.drop(); s->d_mask.drop(); s->d_spandel.drop(); s->d_submapped.drop();
+    s->d_rec[0].drop(); s->d_rec[1].drop(); s->d_span[0].drop(); s->d_span[1].drop();
+    s->d_in.drop(); s->d_work.drop(); s->d_out.drop();
+    s->h_in.drop(); s->h_out.drop();
+    delete s;
+}
+
+int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, const int32_t ref_offset, const int32_t ref_len,
+                                  const int32_t report_begin, const int32_t report_end,
+                                  const int32_t largest_total_indel_ref_span_per_read)
+{
+    SK_REQUIRE_INIT();
+    if (!s || (!ref_seq && ref_len > 0)) return sk_fail("sk_pileup_stream_begin_region: null argument");
+    if (ref_len < 0 || report_end < report_begin) return sk_fail("sk_pileup_stream_begin_region: bad range");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    const size_t n_region = size_t(report_end - report_begin);
+    if (s->d_ref.need(size_t(ref_len) + 1) || s->d_mask.need(size_t(ref_len) + 1) || s->d_spandel.need(4 * n_region + 4) ||
+        s->d_submapped.need(4 * n_region + 4))
+        return sk_fail("sk_pileup_stream_begin_region: out of device memory");
+    if (ref_len > 0) SK_HIP(hipMemcpyAsync(s->d_ref.p, ref_seq, size_t(ref_len), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemsetAsync(s->d_mask.p, 0, size_t(ref_len) + 1, st));
+    SK_HIP(hipMemsetAsync(s->d_spandel.p, 0, 4 * n_region + 4, st));
+    SK_HIP(hipMemsetAsync(s->d_submapped.p, 0, 4 * n_region + 4, st));
+    SK_HIP(hipStreamSynchronize(st)); // ref_seq is the caller's
+    s->ref_offset = ref_offset;
+    s->ref_len = ref_len;
+    s->region_begin = report_begin;
+    s->region_end = report_end;
+    s->opt.report_begin = report_begin;
+    s->opt.report_end = report_end;
+    s->opt.largest_total_indel_ref_span_per_read = largest_total_indel_ref_span_per_read;
+    s->c_len.clear(); s->c_nseg.clear(); s->c_pos.clear(); s->c_mapq.clear(); s->c_path.clear();
+    s->c_bases = 0;
+    s->c_tail_base = 0;
+    s->c_tail_read = 0;
+    s->has_prev = false;
+    s->next_begin = report_begin;
+    s->has_region = true;
+    return 0;
+}
+
+int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const int32_t largest_total_indel_ref_span_per_read,
+                          const int32_t mask_begin, const int32_t mask_len, const uint8_t* cand_snv_mask, const int32_t final_to,
+                          const int32_t ploidy_begin, const int32_t ploidy_len, const uint8_t* ploidy, sk_pileup_window* out)
+{
+    SK_REQUIRE_INIT();
+    if (!s || !reads || !out) return sk_fail("sk_pileup_stream_push: null argument");
+    if (!s->has_region) return sk_fail("sk_pileup_stream_push: no region (sk_pileup_stream_begin_region)");
+    if (reads->n_reads < 0) return sk_fail("sk_pileup_stream_push: negative n_reads");
+    const int n_new = reads->n_reads;
+    if (n_new > 0 && (reads->read_off[0] != 0 || reads->path_off[0] != 0)) return sk_fail("sk_pileup_stream_push: CSR offsets must start at 0");
+    const int64_t new_bases = n_new ? reads->read_off[n_new] : 0, new_segs = n_new ? reads->path_off[n_new] : 0;
+    // what the reference rejects by throwing / exiting (as sk_pileup_reads)
+    for (int r = 0; r < n_new; ++r) {
+        const int64_t L = reads->read_off[r + 1] - reads->read_off[r];
+        if (L < 0 || reads->path_off[r + 1] < reads->path_off[r]) return sk_fail("sk_pileup_stream_push: bad CSR offsets");
+        if (L > MAX_READ_LEN) return sk_fail("sk_pileup_stream_push: read longer than 1024 bases");
+        int64_t plen = 0;
+        for (int64_t i = reads->path_off[r]; i < reads->path_off[r + 1]; ++i) {
+            const uint32_t t = reads->path[i].type;
+            if (t == SK_SEG_MATCH || t == SK_SEG_SEQ_MATCH || t == SK_SEG_SEQ_MISMATCH || t == SK_SEG_INSERT || t == SK_SEG_SOFT_CLIP)
+                plen += reads->path[i].length;
+            else if (!(t == SK_SEG_DELETE || t == SK_SEG_HARD_CLIP || t == SK_SEG_SKIP))
+                return sk_fail("sk_pileup_stream_push: Can't handle cigar code"); // starling_read_util.cpp:198-203
+        }
+        if (reads->path_off[r + 1] > reads->path_off[r] && plen != L) return sk_fail("sk_pileup_stream_push: alignment path does not span its read");
+    }
+    {
+        unsigned bad_code = 0, bad_q = 0;
+        for (int64_t i = 0; i < new_bases; ++i) {
+            const uint8_t c = reads->read_code[i];
+            bad_code |= unsigned(!(c == SK_BAM_REF || c == SK_BAM_A || c == SK_BAM_C || c == SK_BAM_G || c == SK_BAM_T || c == SK_BAM_ANY));
+            bad_q |= unsigned(reads->read_qual[i] > 70);
+        }
+        if (bad_code) return sk_fail("sk_pileup_stream_push: unsupported BAM base code"); // bam_seq_code_to_id base_error, bam_seq.hh:145-147
+        if (bad_q && s->opt.is_mapq_adjust)
+            return sk_fail("Attempting to lookup basecall quality score which exceeds the maximum cached basecall quality score of 70");
+    }
+    if (mask_len < 0 || (mask_len > 0 && (!cand_snv_mask || mask_begin < s->ref_offset || mask_begin + mask_len > s->ref_offset + s->ref_len)))
+        return sk_fail("sk_pileup_stream_push: candidate-SNV mask window outside the reference segment");
+
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    s->opt.largest_total_indel_ref_span_per_read = largest_total_indel_ref_span_per_read;
+
+    const int n_c = int(s->c_len.size());
+    const int n = n_c + n_new;
+    const int64_t c_segs = int64_t(s->c_path.size());
+    const int64_t n_bases = s->c_bases + new_bases, n_segs = c_segs + new_segs;
+
+    // ---- the range this push finalises
+    const int32_t F = std::min(final_to, s->region_end);
+    int32_t lowest = INT_MAX, highest = INT_MIN;
+    {
+        int64_t so = 0;
+        for (int i = 0; i < n_c; ++i) {
+            lowest = std::min(lowest, s->c_pos[i]);
+            highest = std::max(highest, s->c_pos[i] + path_ref_length(s->c_path.data() + so, s->c_nseg[i]));
+            so += s->c_nseg[i];
+        }
+    }
+    for (int r = 0; r < n_new; ++r) {
+        const int nseg = int(reads->path_off[r + 1] - reads->path_off[r]);
+        if (nseg == 0) continue;
+        const int e = reads->pos[r] + path_ref_length(reads->path + reads->path_off[r], nseg);
+        if (s->has_prev && reads->pos[r] < s->next_begin && e > s->region_begin) {
+            // (the reference's own guard is validate_new_pos_value, starling_pos_processor_base.cpp:1326: a basecall behind the
+            // POST_ALIGN stage throws)
+            bool any_match_before = false;
+            int ref_head = reads->pos[r];
+            for (int64_t i = reads->path_off[r]; i < reads->path_off[r + 1] && !any_match_before; ++i) {
+                const uint32_t t = reads->path[i].type;
+                const bool m = (t == SK_SEG_MATCH || t == SK_SEG_SEQ_MATCH || t == SK_SEG_SEQ_MISMATCH);
+                if ((m || t == SK_SEG_DELETE) && ref_head < s->next_begin && ref_head >= s->region_begin) any_match_before = true;
+                if (m || t == SK_SEG_DELETE || t == SK_SEG_SKIP) ref_head += int(reads->path[i].length);
+            }
+            if (any_match_before) return sk_fail("sk_pileup_stream_push: a read reaches positions that an earlier push declared final");
+        }
+        lowest = std::min(lowest, reads->pos[r]);
+        highest = std::max(highest, e);
+    }
+    int32_t begin = s->next_begin, end = s->next_begin;
+    if (n > 0 && lowest != INT_MAX) {
+        begin = std::max(s->region_begin, s->has_prev ? std::max(s->next_begin, lowest) : lowest);
+        end = std::max(begin, std::min(F, highest));
+    }
+    if (begin > F) begin = end = std::max(s->next_begin, std::min(begin, F));
+    const int n_loci = end - begin;
+
+    // ---- device input block: carried metadata + the new reads
+    struct Lay { int64_t read_off, path_off, path, pos, is_fwd, mapq, level, code, qual, ploidy, total; } li;
+    {
+        int64_t o = 0;
+        li.read_off = o; o += align256(8 * (int64_t(n) + 1));
+        li.path_off = o; o += align256(8 * (int64_t(n) + 1));
+        li.path = o; o += align256(8 * std::max<int64_t>(n_segs, 1));
+        li.pos = o; o += align256(4 * int64_t(std::max(n, 1)));
+        li.is_fwd = o; o += align256(std::max(n, 1));
+        li.mapq = o; o += align256(std::max(n, 1));
+        li.level = o; o += align256(std::max(n, 1));
+        li.ploidy = o; o += align256(std::max(n_loci, 1));
+        li.code = o; o += align256(std::max<int64_t>(n_bases, 1));
+        li.qual = o; o += align256(std::max<int64_t>(n_bases, 1));
+        li.total = o;
+    }
+    if (s->h_in.need(size_t(li.total)) || s->d_in.need(size_t(li.total))) return sk_fail("sk_pileup_stream_push: out of memory (input block)");
+    char* hi = static_cast<char*>(s->h_in.p);
+    {
+        int64_t* ro = reinterpret_cast<int64_t*>(hi + li.read_off);
+        int64_t* po = reinterpret_cast<int64_t*>(hi + li.path_off);
+        sk_path_seg* pa = reinterpret_cast<sk_path_seg*>(hi + li.path);
+        int32_t* ps = reinterpret_cast<int32_t*>(hi + li.pos);
+        uint8_t* fw = reinterpret_cast<uint8_t*>(hi + li.is_fwd);
+        uint8_t* mq = reinterpret_cast<uint8_t*>(hi + li.mapq);
+        uint8_t* lv = reinterpret_cast<uint8_t*>(hi + li.level);
+        int64_t b = 0, sg = 0;
+        for (int i = 0; i < n_c; ++i) {
+            ro[i] = b; po[i] = sg;
+            b += s->c_len[i]; sg += s->c_nseg[i];
+            ps[i] = s->c_pos[i]; fw[i] = 0; mq[i] = s->c_mapq[i]; lv[i] = 0;
+        }
+        if (c_segs) std::memcpy(pa, s->c_path.data(), size_t(8 * c_segs));
+        for (int r = 0; r < n_new; ++r) {
+            ro[n_c + r] = s->c_bases + reads->read_off[r];
+            po[n_c + r] = c_segs + reads->path_off[r];
+            ps[n_c + r] = reads->pos[r]; fw[n_c + r] = reads->is_fwd[r]; mq[n_c + r] = reads->mapq[r]; lv[n_c + r] = reads->map_level[r];
+        }
+        ro[n] = n_bases; po[n] = n_segs;
+        if (new_segs) std::memcpy(pa + c_segs, reads->path, size_t(8 * new_segs));
+        if (new_bases) {
+            std::memcpy(hi + li.code + s->c_bases, reads->read_code, size_t(new_bases));
+            std::memcpy(hi + li.qual + s->c_bases, reads->read_qual, size_t(new_bases));
+        }
+        uint8_t* pl = reinterpret_cast<uint8_t*>(hi + li.ploidy);
+        for (int i = 0; i < n_loci; ++i) {
+            const int64_t k = int64_t(begin) + i - ploidy_begin;
+            pl[i] = (ploidy && k >= 0 && k < ploidy_len) ? ploidy[k] : uint8_t(2);
+        }
+    }
+    char* di = static_cast<char*>(s->d_in.p);
+    SK_HIP(hipMemcpyAsync(di, hi, size_t(li.total), hipMemcpyHostToDevice, st));
+    if (mask_len > 0)
+        SK_HIP(hipMemcpyAsync(static_cast<char*>(s->d_mask.p) + (mask_begin - s->ref_offset), cand_snv_mask, size_t(mask_len), hipMemcpyHostToDevice, st));
+
+    // ---- records and spans: the carried tail moves to the front of the other buffer
+    const int nxt = s->cur ^ 1;
+    if (s->d_rec[nxt].need(size_t(2 * std::max<int64_t>(n_bases, 1))) || s->d_span[nxt].need(size_t(8 * std::max(n, 1))))
+        return sk_fail("sk_pileup_stream_push: out of device memory (records)");
+    if (s->c_bases > 0)
+        SK_HIP(hipMemcpyAsync(s->d_rec[nxt].p, static_cast<char*>(s->d_rec[s->cur].p) + 2 * s->c_tail_base, size_t(2 * s->c_bases), hipMemcpyDeviceToDevice, st));
+    if (n_c > 0)
+        SK_HIP(hipMemcpyAsync(s->d_span[nxt].p, static_cast<char*>(s->d_span[s->cur].p) + 8 * s->c_tail_read, size_t(8) * size_t(n_c), hipMemcpyDeviceToDevice, st));
+    s->cur = nxt;
+
+    // ---- work and output blocks
+    const ScratchLayout SL = layout(n, n_bases, n_loci); // (its rec / span / count parts are unused here)
+    struct WLay { int64_t begin, end, maxend, minbegin, count0, count1, count2, off2, calls2, refbase, de, gscr, tmp, total; } wl;
+    {
+        int64_t o = 0;
+        wl.begin = o; o += align256(4 * int64_t(std::max(n, 1)));
+        wl.end = o; o += align256(4 * int64_t(std::max(n, 1)));
+        wl.maxend = o; o += align256(4 * int64_t(std::max(n, 1)));
+        wl.minbegin = o; o += align256(4 * int64_t(std::max(n, 1)));
+        wl.count0 = o; o += align256(4 * (int64_t(n_loci) + 1));
+        wl.count1 = o; o += align256(4 * (int64_t(n_loci) + 1));
+        wl.count2 = o; o += align256(4 * (int64_t(n_loci) + 1));
+        wl.off2 = o; o += align256(8 * (int64_t(n_loci) + 1));
+        wl.calls2 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
+        wl.refbase = o; o += align256(std::max(n_loci, 1));
+        wl.de = o; o += align256(4 * std::max<int64_t>(n_bases, 1));
+        wl.gscr = o; o += align256(4 * (n_bases + int64_t(n_loci) + 8));
+        wl.tmp = o; o += align256(SL.tmp_bytes);
+        wl.total = o;
+    }
+    struct OLay { int64_t off0, off1, clean_n, mq_n, mq_zero, mq_sq, spandel, submapped, geno, calls0, calls1, total; } ol;
+    {
+        int64_t o = 0;
+        ol.off0 = o; o += align256(8 * (int64_t(n_loci) + 1));
+        ol.off1 = o; o += align256(8 * (int64_t(n_loci) + 1));
+        ol.clean_n = o; o += align256(4 * (int64_t(n_loci) + 1));
+        ol.mq_n = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
+        ol.mq_zero = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
+        ol.mq_sq = o; o += align256(8 * int64_t(std::max(n_loci, 1)));
+        ol.spandel = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
+        ol.submapped = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
+        ol.geno = o; o += align256(int64_t(sizeof(sk_digt_call)) * std::max(n_loci, 1));
+        ol.calls0 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
+        ol.calls1 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
+        ol.total = o;
+    }
+    if (s->d_work.need(size_t(wl.total)) || s->d_out.need(size_t(ol.total)) || s->h_out.need(size_t(ol.total)))
+        return sk_fail("sk_pileup_stream_push: out of memory (work / output blocks)");
+    char* dw = static_cast<char*>(s->d_work.p);
+    char* dout = static_cast<char*>(s->d_out.p);
+    char* ho = static_cast<char*>(s->h_out.p);
+
+    PileupArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.b.n_reads = n;
+    a.b.read_off = reinterpret_cast<const int64_t*>(di + li.read_off);
+    a.b.read_code = reinterpret_cast<const uint8_t*>(di + li.code);
+    a.b.read_qual = reinterpret_cast<const uint8_t*>(di + li.qual);
+    a.b.path_off = reinterpret_cast<const int64_t*>(di + li.path_off);
+    a.b.path = reinterpret_cast<const sk_path_seg*>(di + li.path);
+    a.b.pos = reinterpret_cast<const int32_t*>(di + li.pos);
+    a.b.is_fwd = reinterpret_cast<const uint8_t*>(di + li.is_fwd);
+    a.b.mapq = reinterpret_cast<const uint8_t*>(di + li.mapq);
+    a.b.map_level = reinterpret_cast<const uint8_t*>(di + li.level);
+    a.b.ref_seq = static_cast<const char*>(s->d_ref.p);
+    a.b.ref_offset = s->ref_offset;
+    a.b.ref_len = s->ref_len;
+    a.b.cand_snv_mask = static_cast<const uint8_t*>(s->d_mask.p);
+    a.o = s->opt; // P1: the region's report range, region-wide counters
+    a.tab = ctx.dev_tables;
+    a.rec = static_cast<uint16_t*>(s->d_rec[s->cur].p);
+    a.span = static_cast<int2*>(s->d_span[s->cur].p);
+    a.spandel = static_cast<uint32_t*>(s->d_spandel.p);
+    a.submapped = static_cast<uint32_t*>(s->d_submapped.p);
+    a.n_loci = s->region_end - s->region_begin;
+    a.r0 = n_c;
+    if (n_new > 0) hipLaunchKernelGGL(pileup_read_kernel, dim3((n_new + P1_WAVES - 1) / P1_WAVES), dim3(P1_WAVES * WAVE), 0, st, a);
+
+    int* d_begin = reinterpret_cast<int*>(dw + wl.begin);
+    int* d_end = reinterpret_cast<int*>(dw + wl.end);
+    int* d_maxend = reinterpret_cast<int*>(dw + wl.maxend);
+    int* d_minbegin = reinterpret_cast<int*>(dw + wl.minbegin);
+    void* tmp = dw + wl.tmp;
+    size_t tmp_bytes = size_t(SL.tmp_bytes);
+    if (n > 0) {
+        hipLaunchKernelGGL(span_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.span, d_begin, d_end, n);
+        SK_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, d_end, d_maxend, size_t(n), MaxOp(), st));
+        tmp_bytes = size_t(SL.tmp_bytes);
+        SK_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, std::make_reverse_iterator(d_begin + n), std::make_reverse_iterator(d_minbegin + n),
+                                       size_t(n), MinOp(), st));
+    }
+    // P2: the window's columns
+    PileupArgs c = a;
+    c.o.report_begin = begin;
+    c.o.report_end = end;
+    c.n_loci = n_loci;
+    c.maxend = d_maxend;
+    c.minbegin = d_minbegin;
+    c.count3[0] = reinterpret_cast<uint32_t*>(dw + wl.count0);
+    c.count3[1] = reinterpret_cast<uint32_t*>(dw + wl.count1);
+    c.count3[2] = reinterpret_cast<uint32_t*>(dw + wl.count2);
+    int64_t* off0 = reinterpret_cast<int64_t*>(dout + ol.off0);
+    int64_t* off1 = reinterpret_cast<int64_t*>(dout + ol.off1);
+    int64_t* off2 = reinterpret_cast<int64_t*>(dw + wl.off2);
+    c.call_off3[0] = off0; c.call_off3[1] = off1; c.call_off3[2] = off2;
+    c.calls3[0] = reinterpret_cast<uint16_t*>(dout + ol.calls0);
+    c.calls3[1] = reinterpret_cast<uint16_t*>(dout + ol.calls1);
+    c.calls3[2] = reinterpret_cast<uint16_t*>(dw + wl.calls2);
+    c.mapq_count = reinterpret_cast<uint32_t*>(dout + ol.mq_n);
+    c.mapq_zero = reinterpret_cast<uint32_t*>(dout + ol.mq_zero);
+    c.mapq_sumsq = reinterpret_cast<unsigned long long*>(dout + ol.mq_sq);
+    c.store = 0;
+    const int blocks = (n_loci + 1 + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL(pileup_column_kernel_t<true>, dim3(blocks), dim3(WAVE), 0, st, c);
+    for (int m = 0; m < 3; ++m) {
+        tmp_bytes = size_t(SL.tmp_bytes);
+        SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, c.count3[m], const_cast<int64_t*>(c.call_off3[m]), int64_t(0), size_t(n_loci) + 1,
+                                       rocprim::plus<int64_t>(), st));
+    }
+    c.store = 1;
+    if (n > 0 && n_loci > 0) hipLaunchKernelGGL(pileup_column_kernel_t<true>, dim3(blocks), dim3(WAVE), 0, st, c);
+    // the cleaned column's sizes for the caller's cache validation; the region-wide counters' slice
+    SK_HIP(hipMemcpyAsync(dout + ol.clean_n, c.count3[2], 4 * (size_t(n_loci) + 1), hipMemcpyDeviceToDevice, st));
+    if (n_loci > 0) {
+        SK_HIP(hipMemcpyAsync(dout + ol.spandel, static_cast<char*>(s->d_spandel.p) + 4 * size_t(begin - s->region_begin), 4 * size_t(n_loci),
+                              hipMemcpyDeviceToDevice, st));
+        SK_HIP(hipMemcpyAsync(dout + ol.submapped, static_cast<char*>(s->d_submapped.p) + 4 * size_t(begin - s->region_begin), 4 * size_t(n_loci),
+                              hipMemcpyDeviceToDevice, st));
+    }
+    // a9 + a10 on the cleaned columns, where they are
+    if (s->genotype && n_loci > 0) {
+        uint8_t* d_refbase = reinterpret_cast<uint8_t*>(dw + wl.refbase);
+        hipLaunchKernelGGL(ref_base_id_kernel, dim3((n_loci + 255) / 256), dim3(256), 0, st, static_cast<const char*>(s->d_ref.p), s->ref_offset,
+                           s->ref_len, begin, n_loci, d_refbase);
+        sk_pileup_batch pb;
+        std::memset(&pb, 0, sizeof(pb));
+        pb.n_loci = n_loci;
+        pb.call_off = off2;
+        pb.calls = c.calls3[2];
+        pb.de = nullptr;
+        pb.ref_base = d_refbase;
+        pb.ploidy = reinterpret_cast<const uint8_t*>(di + li.ploidy);
+        if (sk_site_digt_call_fused_dev(&pb, &s->gopt, reinterpret_cast<sk_digt_call*>(dout + ol.geno), reinterpret_cast<float*>(dw + wl.de), 0,
+                                        dw + wl.gscr, n_bases, st))
+            return 1;
+    }
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipMemcpyAsync(ho, dout, size_t(ol.total), hipMemcpyDeviceToHost, st));
+    SK_HIP(hipStreamSynchronize(st));
+
+    // ---- what the next push carries: the reads from the first one that ends past F on
+    {
+        const int64_t* ro = reinterpret_cast<const int64_t*>(hi + li.read_off);
+        const int64_t* po = reinterpret_cast<const int64_t*>(hi + li.path_off);
+        const sk_path_seg* pa = reinterpret_cast<const sk_path_seg*>(hi + li.path);
+        const int32_t* ps = reinterpret_cast<const int32_t*>(hi + li.pos);
+        const uint8_t* mq = reinterpret_cast<const uint8_t*>(hi + li.mapq);
+        int i0 = n;
+        if (F < s->region_end) {
+            for (int i = 0; i < n; ++i) {
+                const int nseg = int(po[i + 1] - po[i]);
+                if (nseg > 0 && ps[i] + path_ref_length(pa + po[i], nseg) > F) {
+                    i0 = i;
+                    break;
+                }
+            }
+        }
+        std::vector<int32_t> nl, ns, np;
+        std::vector<uint8_t> nm;
+        for (int i = i0; i < n; ++i) {
+            nl.push_back(int32_t(ro[i + 1] - ro[i]));
+            ns.push_back(int32_t(po[i + 1] - po[i]));
+            np.push_back(ps[i]);
+            nm.push_back(mq[i]);
+        }
+        std::vector<sk_path_seg> npath(pa + (i0 < n ? po[i0] : n_segs), pa + n_segs);
+        s->c_tail_base = (i0 < n) ? ro[i0] : n_bases;
+        s->c_tail_read = i0;
+        s->c_bases = n_bases - s->c_tail_base;
+        s->c_len.swap(nl); s->c_nseg.swap(ns); s->c_pos.swap(np); s->c_mapq.swap(nm); s->c_path.swap(npath);
+    }
+    s->has_prev = true;
+    s->next_begin = std::max(s->next_begin, F);
+    s->pushes++;
+    s->reads_in += n_new;
+
+    out->begin = begin;
+    out->end = end;
+    out->tier1_off = reinterpret_cast<const int64_t*>(ho + ol.off0);
+    out->tier1_calls = reinterpret_cast<const uint16_t*>(ho + ol.calls0);
+    out->tier2_off = reinterpret_cast<const int64_t*>(ho + ol.off1);
+    out->tier2_calls = reinterpret_cast<const uint16_t*>(ho + ol.calls1);
+    out->spandel_count = reinterpret_cast<const uint32_t*>(ho + ol.spandel);
+    out->submapped_count = reinterpret_cast<const uint32_t*>(ho + ol.submapped);
+    out->mapq_count = reinterpret_cast<const uint32_t*>(ho + ol.mq_n);
+    out->mapq_zero_count = reinterpret_cast<const uint32_t*>(ho + ol.mq_zero);
+    out->mapq_sum_square = reinterpret_cast<const uint64_t*>(ho + ol.mq_sq);
+    out->clean_count = reinterpret_cast<const uint32_t*>(ho + ol.clean_n);
+    out->genotype = s->genotype ? reinterpret_cast<const sk_digt_call*>(ho + ol.geno) : nullptr;
     return 0;
 }
 

@@ -27,6 +27,9 @@ def _counters(stderr):
     f = re.search(r"strelka_amd adapter feed: (.*)", stderr)  # site 8: the region's reads came through the feed entry points
     assert f, "adapter did not report its feed:\n" + stderr[-2000:]
     c.update({"feed_" + k: int(v) for k, v in (kv.split("=") for kv in f.group(1).split())})
+    g = re.search(r"strelka_amd adapter pileup: (.*)", stderr)  # site 9: the pileup stream (germline)
+    assert g, "adapter did not report its pileup stream:\n" + stderr[-2000:]
+    c.update({"pileup_" + k: int(v) for k, v in (kv.split("=") for kv in g.group(1).split())})
     return c
 
 
@@ -52,6 +55,11 @@ def _germline(variant, tmp_path, windows=None, extra_env=None):
         # and their alignments were normalised in one batch per region (kernel B4 behind sk_normalize_alignments)
         assert c["feed_normalize_batches"] == 2 and c["feed_normalized"] >= c["realign_reads"] and c["feed_normalize_declined"] == 0
     assert c["indel_groups"] >= 1 and c["haplotypes"] >= 1
+    if (extra_env or {}).get("STRELKA_AMD_PILEUP") == "0":
+        assert c["pileup_pushes"] == 0
+    else:  # site 9: every read that piles up went through the stream, and (unless switched off) the genotypes came with the columns
+        assert c["pileup_pushes"] >= 2 and c["pileup_reads"] > 1000 and c["pileup_loci"] > 5000
+        assert c["pileup_genotyping"] == (0 if (extra_env or {}).get("STRELKA_AMD_PILEUP_GENOTYPE") == "0" else 1)
     for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf"):
         want, got = E.vcf_body(ref_out + f, keep_header=True), E.vcf_body(out + f, keep_header=True)
         assert len(want) > 50
@@ -64,7 +72,7 @@ def _germline(variant, tmp_path, windows=None, extra_env=None):
 def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
     c = _germline("dbl", tmp_path, windows)
     if windows == (1000, 3000):
-        assert c["realign_jobs"] <= 10 and c["site_batches"] <= 2
+        assert c["realign_jobs"] <= 10 and c["pileup_pushes"] <= 12
     if windows is None:
         assert c["read_window"] == 2048 and c["site_window"] == 4096
 
@@ -81,11 +89,31 @@ def test_germline_demo_identical_with_the_reference_normalisation(tmp_path):
     _germline("dbl", tmp_path, extra_env={"STRELKA_AMD_FEED_NORMALIZE": "0"})
 
 
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("windows", [None, (700, 900)])
+def test_germline_demo_identical_with_the_reference_pileup(tmp_path, windows):
+    """STRELKA_AMD_PILEUP=0: pileup_read_segment stays the reference's; the window's columns go up for the genotypes (sites 2+3)"""
+    c = _germline("dbl", tmp_path, windows, extra_env={"STRELKA_AMD_PILEUP": "0"})
+    assert c["site_batches"] >= 1
+
+
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_germline_demo_identical_with_columns_only(tmp_path):
+    """STRELKA_AMD_PILEUP_GENOTYPE=0: the stream builds the columns, the genotypes are computed per site window from the host's copy"""
+    _germline("dbl", tmp_path, extra_env={"STRELKA_AMD_PILEUP_GENOTYPE": "0"})
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
 @pytest.mark.parametrize("windows", [None, (7, 13)])
 def test_germline_demo_identical_through_adapter_gpu(tmp_path, windows):
     _germline("amd", tmp_path, windows)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
+def test_germline_demo_identical_with_the_reference_pileup_gpu(tmp_path):
+    _germline("amd", tmp_path, extra_env={"STRELKA_AMD_PILEUP": "0"})
 
 
 @pytest.mark.gpu
@@ -170,6 +198,8 @@ def _synth(variant, tmp_path, which, windows=None, extra_env=None):
             cg, cs = _counters(pg.stderr.decode()), _counters(ps.stderr.decode())
             assert cg["realign_reads"] > 10000 and cg["indel_groups"] > 100 and cg["haplotypes"] > 100 and cg["site_recomputed"] > 100
             assert cs["realign_reads"] > 15000 and cs["indel_groups"] > 30
+            assert cg["pileup_pushes"] >= 2 and cg["pileup_reads"] > 10000 and cg["pileup_genotyping"] == 1
+            assert cs["pileup_pushes"] == 0  # the somatic processor keeps the reference's pileup (EVS feature accumulators)
             assert cg["feed_regions"] == 2 and cs["feed_regions"] == 2 and cg["feed_records"] > 10000 and cs["feed_records"] > 15000
             for c in (cg, cs):  # normalizeAlignment in batches, with alignments that it changes, none handed back to the reference
                 assert c["feed_normalize_batches"] == 2 and c["feed_normalized"] > 10000 and c["feed_normalize_changed"] > 100

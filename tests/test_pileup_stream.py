@@ -1,0 +1,204 @@
+"""Row a8 as a stream (sk_pileup_stream_*): a sample's pileup pushed one stage window at a time, chained into a9+a10.
+
+What is pinned: whatever way the reads of a region are cut into pushes, the finalised ranges put together are the columns
+the one-shot restatement (oracle sko_pileup_reads, itself pinned to the reference's own position processor in
+tests/test_pileup.py) builds from all the reads at once -- raw tier1 / tier2 columns in read order, spanning-deletion and
+submapped counters, the MapqTracker sums -- and the genotypes are the oracle caller's on the CleanPileupFilter'ed columns,
+record for record.  The CPU tier drives the test double of the C-ABI (the adapter's `*_dbl` binaries use it), the GPU tier
+the product library."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from strelka_amd import capi, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _double():
+    path = os.path.join(HERE, "..", "oracle", "libstrelka_amd_double.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/libstrelka_amd_double.so not built")
+    L = C.CDLL(os.path.abspath(path))
+    L.sk_init(0)
+    return L
+
+
+def _sub_batch(reads, lo, hi):
+    return synth.ReadBatch.from_reads(reads[lo:hi], "", 0)
+
+
+def _read_end(r):
+    return r["pos"] + sum(l for t, l in r["path"] if t in (capi.SEG["MATCH"], capi.SEG["DELETE"]))
+
+
+def _run_stream(library, reads, ref, off, kw, cuts, mask=None, genotype=True, ploidy=None, region=None):
+    """push reads[cuts[i]:cuts[i+1]] one after the other; final_to = the lowest start of any later read"""
+    opt = capi.pileup_options(**kw)
+    st = capi.PileupStream(opt, capi.germline_options() if genotype else None, library=library)
+    rb, re = region or (kw["report_begin"], kw["report_end"])
+    st.begin_region(ref, off, rb, re)
+    wins = []
+    for i in range(len(cuts) - 1):
+        later = [r["pos"] for r in reads[cuts[i + 1]:] if r["path"]]
+        final_to = min(later) if later else 2**31 - 1
+        wins.append(st.push(_sub_batch(reads, cuts[i], cuts[i + 1]), final_to, mask=mask, mask_begin=off,
+                            ploidy=ploidy, ploidy_begin=rb))
+    st.close()
+    return wins
+
+
+def _expect(reads, ref, off, kw, mask):
+    rb = synth.ReadBatch.from_reads(reads, ref, off, cand_snv_mask=mask)
+    o = pyoracle.pileup_options(**kw)
+    o1, c1, sd, sm, mn, mz, sq = pyoracle.pileup_reads_mapq(rb, o)
+    o2, c2, _, _ = pyoracle.pileup_reads(rb, o, capi.PILEUP_RAW_TIER2)
+    oc, cc, _, _ = pyoracle.pileup_reads(rb, o, capi.PILEUP_CLEAN_TIER1)
+    return dict(o1=o1, c1=c1, o2=o2, c2=c2, oc=oc, cc=cc, sd=sd, sm=sm, mn=mn, mz=mz, sq=sq)
+
+
+def _compare(wins, want, ref, off, kw, ploidy=None, genotype=True):
+    rb, re = kw["report_begin"], kw["report_end"]
+    covered = np.zeros(re - rb, bool)
+    prev_end = None
+    for w in wins:
+        b, e = w["begin"], w["end"]
+        assert rb <= b <= e <= re
+        if prev_end is not None:
+            assert b >= prev_end
+        prev_end = e
+        n = e - b
+        if n == 0:
+            continue
+        covered[b - rb:e - rb] = True
+        sl = slice(b - rb, e - rb)
+        for off_key, call_key, wo, wc in (("tier1_off", "tier1_calls", "o1", "c1"), ("tier2_off", "tier2_calls", "o2", "c2")):
+            assert np.array_equal(np.diff(w[off_key]), np.diff(want[wo][b - rb:e - rb + 1]))
+            assert np.array_equal(w[call_key], want[wc][want[wo][b - rb]:want[wo][e - rb]])
+        assert np.array_equal(w["spandel"], want["sd"][sl]) and np.array_equal(w["submapped"], want["sm"][sl])
+        assert np.array_equal(w["mapq_count"], want["mn"][sl]) and np.array_equal(w["mapq_zero"], want["mz"][sl])
+        assert np.array_equal(w["mapq_sumsq"], want["sq"][sl])
+        assert np.array_equal(w["clean_count"], np.diff(want["oc"][b - rb:e - rb + 1]))
+        if genotype:
+            co = want["oc"][b - rb:e - rb + 1] - want["oc"][b - rb]
+            cc = want["cc"][want["oc"][b - rb]:want["oc"][e - rb]]
+            ref_base = np.array(["ACGTN".index(ref[p - off]) if 0 <= p - off < len(ref) and ref[p - off] in "ACGT" else 4
+                                 for p in range(b, e)], np.uint8)
+            pl = None if ploidy is None else np.ascontiguousarray(ploidy[b - rb:e - rb], np.uint8)
+            pb = capi.HostPileupBatch(co, cc, ref_base, ploidy=pl)
+            de = pyoracle.adjust_joint_eprob(pb)
+            wg = pyoracle.site_digt_call(pb, de)
+            assert w["genotype"].tobytes() == wg.tobytes()
+    # positions no window reported have nothing in them
+    quiet = ~covered
+    assert not np.diff(want["o1"])[quiet].any() and not np.diff(want["o2"])[quiet].any()
+    assert not want["sd"][quiet].any() and not want["sm"][quiet].any() and not want["mn"][quiet].any()
+
+
+def _scenarios():
+    rng = np.random.default_rng(77)
+    out = []
+    for trial in range(6):
+        n = (300, 900, 60, 500, 1200, 5)[trial]
+        reads, ref, off = synth.pileup_reads(n, rng, ref_len=(900, 2500, 400, 1500, 3000, 300)[trial],
+                                             read_len=(36, 151) if trial != 4 else (120, 300))
+        kw = dict(report_begin=off + 7 * trial, report_end=off + len(ref) - 5 * trial)
+        if trial % 2:
+            kw.update(min_basecall_qscore=0, mismatch_density_max_count=3, use_tier2_evidence=1)
+        mask = rng.integers(0, 16, len(ref)).astype(np.uint8) if trial in (1, 3) else None
+        k = len(reads)
+        if trial == 0:
+            cuts = [0, k]                                   # everything in one push
+        elif trial == 2:
+            cuts = list(range(0, k + 1))                    # one read per push
+        else:
+            cuts = sorted(set([0, k] + [int(x) for x in rng.integers(0, k, (3, 12, 0, 25, 40, 2)[trial])]))
+        if trial == 5:
+            cuts = [0, 0, k, k]                             # empty pushes before and after
+        ploidy = None
+        if trial == 3:
+            ploidy = np.where(rng.random(kw["report_end"] - kw["report_begin"]) < 0.3, 1, 2).astype(np.uint8)
+        out.append((reads, ref, off, kw, cuts, mask, ploidy))
+    return out
+
+
+def _run_all(library):
+    n_windows = n_loci = 0
+    for reads, ref, off, kw, cuts, mask, ploidy in _scenarios():
+        want = _expect(reads, ref, off, kw, mask)
+        wins = _run_stream(library, reads, ref, off, kw, cuts, mask=mask, ploidy=ploidy)
+        _compare(wins, want, ref, off, kw, ploidy=ploidy)
+        n_windows += len(wins)
+        n_loci += sum(w["end"] - w["begin"] for w in wins)
+    assert n_windows > 60 and n_loci > 5000
+
+
+def test_double_stream_equals_one_shot_restatement(built):
+    _run_all(_double())
+
+
+def test_double_stream_rejects_a_read_behind_the_final_position(built):
+    L = _double()
+    ref = "ACGTTGCA" * 40
+    mk = lambda pos: dict(code=np.full(30, 1, np.uint8), qual=np.full(30, 30, np.uint8), pos=pos, path=[(capi.SEG["MATCH"], 30)],
+                          is_fwd=True, mapq=60, map_level=1)
+    st = capi.PileupStream(capi.pileup_options(), None, library=L)
+    st.begin_region(ref, 1000, 1000, 1320)
+    st.push(synth.ReadBatch.from_reads([mk(1010)], "", 0), 1100)
+    with pytest.raises(RuntimeError, match="declared final"):
+        st.push(synth.ReadBatch.from_reads([mk(1090)], "", 0), 1200)
+    st.close()
+
+
+@pytest.mark.gpu
+def test_gpu_stream_equals_one_shot_restatement(gpu):
+    _run_all(None)
+
+
+@pytest.mark.gpu
+def test_gpu_stream_rejects_a_read_behind_the_final_position(gpu):
+    ref = "ACGTTGCA" * 40
+    mk = lambda pos: dict(code=np.full(30, 1, np.uint8), qual=np.full(30, 30, np.uint8), pos=pos, path=[(capi.SEG["MATCH"], 30)],
+                          is_fwd=True, mapq=60, map_level=1)
+    st = capi.PileupStream(capi.pileup_options(), None)
+    st.begin_region(ref, 1000, 1000, 1320)
+    w = st.push(synth.ReadBatch.from_reads([mk(1010)], "", 0), 1100)
+    assert (w["begin"], w["end"]) == (1010, 1040) and int(w["tier1_off"][-1]) == 30
+    with pytest.raises(RuntimeError, match="declared final"):
+        st.push(synth.ReadBatch.from_reads([mk(1090)], "", 0), 1200)
+    st.close()
+
+
+@pytest.mark.gpu
+def test_gpu_stream_at_window_scale(gpu):
+    """a 40x sample pushed in windows of ~4000 reads (what the adapter sends): equal to the one-shot kernels' columns"""
+    rng = np.random.default_rng(5)
+    rb, n_loci = synth.pileup_reads_flat(40000, rng)
+    kw = dict(report_begin=0, report_end=n_loci + 200)
+    o1, c1, sd, sm = capi.pileup_reads(rb, capi.pileup_options(**kw), capi.PILEUP_RAW_TIER1)
+    st = capi.PileupStream(capi.pileup_options(**kw), capi.germline_options())
+    st.begin_region(rb.ref_seq, 0, 0, n_loci + 200)
+    got_off, got_calls = [0], []
+    L = 150
+    for lo in range(0, rb.n_reads, 4000):
+        hi = min(rb.n_reads, lo + 4000)
+        sub = synth.ReadBatch(rb.read_off[lo:hi + 1] - rb.read_off[lo], rb.read_code[rb.read_off[lo]:rb.read_off[hi]],
+                              rb.read_qual[rb.read_off[lo]:rb.read_off[hi]], rb.path_off[lo:hi + 1] - rb.path_off[lo],
+                              rb.path[rb.path_off[lo]:rb.path_off[hi]], rb.pos[lo:hi], rb.is_fwd[lo:hi], rb.mapq[lo:hi],
+                              rb.map_level[lo:hi], "", 0)
+        final_to = int(rb.pos[hi]) if hi < rb.n_reads else 2**31 - 1
+        w = st.push(sub, final_to)
+        if w["end"] > w["begin"]:
+            assert w["begin"] == len(got_off) - 1 or not np.diff(o1[len(got_off) - 1:w["begin"] + 1]).any()
+            while len(got_off) - 1 < w["begin"]:
+                got_off.append(got_off[-1])
+            got_off += list(got_off[-1] + w["tier1_off"][1:])
+            got_calls.append(w["tier1_calls"])
+            assert np.array_equal(w["spandel"], sd[w["begin"]:w["end"]])
+    got_calls = np.concatenate(got_calls)
+    assert np.array_equal(np.array(got_off), o1[:len(got_off)]) and np.array_equal(got_calls, c1[:len(got_calls)])
+    assert len(got_calls) == len(c1)
+    st.close()
