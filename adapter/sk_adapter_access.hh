@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+struct read_segment;
+
 namespace sk_adapter
 {
 
@@ -124,6 +126,13 @@ struct PileupState
     pos_t regionBegin = 0, regionEnd = 0;
 };
 
+/// a read segment of the current stage window (collected by align_pos, used by the realignment job and the pileup push)
+struct WindowSegment
+{
+    read_segment* rseg;
+    pos_t bufferPos;
+};
+
 struct State
 {
     GeometryShadow geometry;
@@ -132,10 +141,12 @@ struct State
     SiteCache sites;
     SomaticSiteCache somaticSites;
     PileupState pileup;
+    std::vector<std::vector<WindowSegment>> windowSegments; ///< per sample: the read segments buffered in [window begin, realignedTo)
     // counters reported at exit with $STRELKA_AMD_VERBOSE=1
     // wall seconds inside the hooks (whole hook) and inside the C-ABI calls they make; reported with STRELKA_AMD_VERBOSE=1
     double tRealignHook = 0, tRealignAbi = 0, tSiteHook = 0, tSiteAbi = 0, tPileupHook = 0, tPileupAbi = 0;
     unsigned long pileupBatches = 0, pileupReads = 0, pileupLoci = 0;
+    unsigned long realignJobReads = 0; ///< reads that went into a realignment job (realignReads counts every read a window looked at)
     unsigned long realignDeviceEnumerated = 0, realignHostEnumerated = 0; // reads whose candidate alignments the device / the host listed
     unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0;
 };

@@ -4,6 +4,7 @@
 #include "blt_util/log.hh"
 #include "starling_common/starling_read.hh"
 
+#include <algorithm>
 #include <cstdlib>
 #include <iostream>
 
@@ -65,7 +66,7 @@ State& state()
         ~Reporter()
         {
             if (env_unsigned("STRELKA_AMD_VERBOSE", 0) == 0) return;
-            std::cerr << "strelka_amd adapter: realign_jobs=" << s.realignBatches << " realign_reads=" << s.realignReads
+            std::cerr << "strelka_amd adapter: realign_jobs=" << s.realignBatches << " realign_reads=" << s.realignReads << " realign_job_reads=" << s.realignJobReads
                       << " site_batches=" << s.siteBatches << " site_loci=" << s.siteLoci << " site_recomputed=" << s.siteRecomputed
                       << " indel_groups=" << s.indelGroups << " haplotypes=" << s.haplotypes << " read_window=" << read_buffer_defer()
                       << " site_window=" << post_align_defer() << " enum_device_reads=" << s.realignDeviceEnumerated
@@ -154,10 +155,9 @@ void GeometryShadow::onSetHeadPos(const pos_t pos, const unsigned readBufferShif
 
 GeometryShadow::Params GeometryShadow::query(const pos_t pos) const
 {
-    for (const Params& p : segments)
-    {
-        if (pos <= p.upto) return p;
-    }
+    // (segments are in ascending order of `upto`; a stage window asks for every read it holds)
+    const auto it(std::lower_bound(segments.begin(), segments.end(), pos, [](const Params& p, const pos_t v) { return p.upto < v; }));
+    if (it != segments.end()) return *it;
     // not reached by a head advance: the position is handled by the final flush (stage_manager::reset), with the
     // geometry and _max_pos in force at that time
     Params p;

@@ -100,15 +100,12 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
 
     static WindowBatch wb;
     wb.clear();
-    for (pos_t pos(begin); pos < end; ++pos)
+    static const std::vector<WindowSegment> noSegments;
+    for (const WindowSegment& ws : (begin < end ? s.windowSegments[sampleIndex] : noSegments))
     {
-        read_segment_iter ri(sif.readBuffer.get_pos_read_segment_iter(pos));
-        for (read_segment_iter::ret_val r; true; ri.next())
         {
-            r = ri.get_ptr();
-            if (nullptr == r.first) break;
-            if (r.second != 0) throw blt_exception("strelka_amd adapter: spliced (RNA) read segments are not supported on this path");
-            const read_segment& rseg(r.first->get_segment(r.second));
+            const read_segment& rseg(*ws.rseg);
+            const pos_t pos(ws.bufferPos);
 
             // pileup_read_segment's read-level exits (:1132-1165), messages included
             const alignment* best(&(rseg.getInputAlignment()));

@@ -31,6 +31,7 @@ struct WindowRead
     pos_t bufferPos;
     GeometryShadow::Params geometry;
     pos_t rangeBegin, rangeEnd;
+    pos_t zoneBegin, zoneEnd;
     size_t codeOffset, pathOffset, observedOffset;
     unsigned observedCount;
 };
@@ -65,58 +66,45 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
     // how far past its alignment zone the candidate-alignment search of a read can reach: every toggled indel moves the
     // far end by at most maxIndelSize (starling_read_align.cpp:859-1277, max_read_indel_toggle)
     const pos_t reach(static_cast<pos_t>(opt.max_read_indel_toggle * opt.maxIndelSize + 5));
-    for (pos_t pos(begin); pos < end; ++pos)
+    for (const WindowSegment& ws : s.windowSegments[sampleIndex])
     {
-        read_segment_iter ri(sif.readBuffer.get_pos_read_segment_iter(pos));
-        for (read_segment_iter::ret_val r; true; ri.next())
+        read_segment& rseg(*ws.rseg);
+        const pos_t pos(ws.bufferPos);
+        if (not (opt.is_realign_submapped_reads || rseg.is_tier1or2_mapping())) continue;
+        if (! rseg.is_valid())
         {
-            r = ri.get_ptr();
-            if (nullptr == r.first) break;
-            if (r.second != 0) throw blt_exception("strelka_amd adapter: spliced (RNA) read segments are not supported on this path");
-            read_segment& rseg(r.first->get_segment(r.second));
-            if (not (opt.is_realign_submapped_reads || rseg.is_tier1or2_mapping())) continue;
-            if (! rseg.is_valid())
-            {
-                log_os << "ERROR: invalid alignment path associated with read segment:\n" << rseg;
-                exit(EXIT_FAILURE);
-            }
-            WindowRead wr;
-            wr.rseg = &rseg;
-            wr.bufferPos = pos;
-            wr.geometry = s.geometry.query(pos);
-            wr.rangeBegin = std::max(static_cast<pos_t>(0), pos - wr.geometry.rangeMinOffset);
-            wr.rangeEnd = pos + 1 + wr.geometry.rangeMaxOffset;
-            const alignment& al(rseg.getInputAlignment());
-            const known_pos_range zone(get_alignment_zone(al, rseg.read_size()));
-            const pos_t lo(std::max(wr.rangeBegin, std::min(zone.begin_pos, pos) - reach));
-            const pos_t hi(std::min(wr.rangeEnd, zone.end_pos + reach));
-            if (reads.empty())
-            {
-                tableBegin = lo;
-                tableEnd = hi;
-            }
-            else
-            {
-                tableBegin = std::min(tableBegin, lo);
-                tableEnd = std::max(tableEnd, hi);
-            }
-            wr.codeOffset = codes.size();
-            const bam_seq bseq(rseg.get_bam_read());
-            const unsigned readSize(rseg.read_size());
-            for (unsigned i(0); i < readSize; ++i) codes.push_back(bseq.get_code(static_cast<pos_t>(i)));
-            wr.pathOffset = paths.size();
-            for (const auto& ps : al.path)
-            {
-                sk_path_seg seg;
-                seg.type = static_cast<uint32_t>(ps.type);
-                seg.length = ps.length;
-                paths.push_back(seg);
-            }
-            wr.observedOffset = 0;
-            wr.observedCount = 0;
-            reads.push_back(wr);
+            log_os << "ERROR: invalid alignment path associated with read segment:\n" << rseg;
+            exit(EXIT_FAILURE);
         }
+        WindowRead wr;
+        wr.rseg = &rseg;
+        wr.bufferPos = pos;
+        wr.geometry = s.geometry.query(pos);
+        wr.rangeBegin = std::max(static_cast<pos_t>(0), pos - wr.geometry.rangeMinOffset);
+        wr.rangeEnd = pos + 1 + wr.geometry.rangeMaxOffset;
+        const alignment& al(rseg.getInputAlignment());
+        const known_pos_range zone(get_alignment_zone(al, rseg.read_size()));
+        wr.zoneBegin = zone.begin_pos;
+        wr.zoneEnd = zone.end_pos;
+        const pos_t lo(std::max(wr.rangeBegin, std::min(zone.begin_pos, pos) - reach));
+        const pos_t hi(std::min(wr.rangeEnd, zone.end_pos + reach));
+        if (reads.empty())
+        {
+            tableBegin = lo;
+            tableEnd = hi;
+        }
+        else
+        {
+            tableBegin = std::min(tableBegin, lo);
+            tableEnd = std::max(tableEnd, hi);
+        }
+        wr.codeOffset = 0;
+        wr.pathOffset = 0;
+        wr.observedOffset = 0;
+        wr.observedCount = 0;
+        reads.push_back(wr);
     }
+    s.realignReads += reads.size();
     if (reads.empty()) return;
 
     // ---- the IndelBuffer entries those reads can see ----
@@ -161,6 +149,41 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
             table.push_back(e);
             keys.push_back(&k);
             data.push_back(&d);
+        }
+    }
+
+    // Most reads of a window meet no indel at all: realignAndScoreRead returns at check_for_candidate_indel_overlap
+    // (starling_read_align.cpp:2047, :219-270), whose range query (IndelBuffer.cpp:76-92) finds nothing -- no candidate status is
+    // asked for, nothing is cached.  Those reads need not travel: a read stays in the job iff some table entry starts inside
+    // [zone begin - maxIndelSize - 1, zone end + 1], a superset of what that query can return for it.
+    {
+        std::vector<pos_t> keyPos;
+        keyPos.reserve(keys.size());
+        for (const IndelKey* k : keys) keyPos.push_back(k->pos); // the IndelBuffer's order: ascending position
+        std::vector<WindowRead> kept;
+        for (const WindowRead& wr : reads)
+        {
+            const pos_t lo(wr.zoneBegin - static_cast<pos_t>(opt.maxIndelSize) - 1), hi(wr.zoneEnd + 1);
+            const auto it(std::lower_bound(keyPos.begin(), keyPos.end(), lo));
+            if (it != keyPos.end() && *it <= hi) kept.push_back(wr);
+        }
+        reads.swap(kept);
+    }
+    if (reads.empty()) return;
+    for (WindowRead& wr : reads)
+    {
+        const read_segment& rseg(*wr.rseg);
+        wr.codeOffset = codes.size();
+        const bam_seq bseq(rseg.get_bam_read());
+        const unsigned readSize(rseg.read_size());
+        for (unsigned i(0); i < readSize; ++i) codes.push_back(bseq.get_code(static_cast<pos_t>(i)));
+        wr.pathOffset = paths.size();
+        for (const auto& ps : rseg.getInputAlignment().path)
+        {
+            sk_path_seg seg;
+            seg.type = static_cast<uint32_t>(ps.type);
+            seg.length = ps.length;
+            paths.push_back(seg);
         }
     }
 
@@ -240,7 +263,7 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
         jobCheck(sk_realign_job_run(job), "sk_realign_job_run");
     }
     s.realignBatches++;
-    s.realignReads += reads.size();
+    s.realignJobReads += reads.size();
     {
         int64_t onCore(0), onDevice(0), onHostInstead(0);
         (void)sk_realign_job_enumeration_counts(job, &onCore, &onDevice, &onHostInstead);
@@ -330,6 +353,28 @@ bool align_pos(starling_pos_processor_base& pp, const pos_t pos)
     if (s.isAnyRealigned && pos < s.realignedTo) return true;
     const pos_t end(pos + static_cast<pos_t>(std::max(1u, read_buffer_defer() + 1)));
     const unsigned sampleCount(Access::sampleCount(pp));
+    // the window's read segments in read-buffer order, once: the realignment job and the pileup push (site 9) both walk them
+    s.windowSegments.resize(sampleCount);
+    for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
+    {
+        std::vector<WindowSegment>& segs(s.windowSegments[sampleIndex]);
+        segs.clear();
+        starling_pos_processor_base::sample_info& sif(pp.sample(sampleIndex));
+        for (pos_t p(pos); p < end; ++p)
+        {
+            read_segment_iter ri(sif.readBuffer.get_pos_read_segment_iter(p));
+            for (read_segment_iter::ret_val r; true; ri.next())
+            {
+                r = ri.get_ptr();
+                if (nullptr == r.first) break;
+                if (r.second != 0) throw blt_exception("strelka_amd adapter: spliced (RNA) read segments are not supported on this path");
+                WindowSegment ws;
+                ws.rseg = &(r.first->get_segment(r.second));
+                ws.bufferPos = p;
+                segs.push_back(ws);
+            }
+        }
+    }
     for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
     {
         try

@@ -249,7 +249,7 @@ def main():
         which = rng.integers(0, 2, n)
         lens = np.where(rng.random(n) < 0.93, RL, rng.integers(70, RL + 1, n))
         q = qualities(n, RL, rng)
-        err = rng.random((n, RL)) < np.power(10.0, -q / 10.0)
+        err = rng.random((n, RL)) < np.power(10.0, -q.astype(np.float64) / 10.0)
         shift = rng.integers(1, 4, (n, RL), dtype=np.uint8)
         r = rng.random(n)
         mapq = np.where(r < 0.93, 60, np.where(r < 0.98, rng.integers(1, 20, n), 0))
