@@ -39,7 +39,9 @@ void init()
     if (done) return;
     // segment process -> device: pyflow starts one process per genome segment; the launcher (or the workflow's task
     // wrapper) exports STRELKA_AMD_DEVICE = segment index mod number of GPUs.  Many processes may share a device.
-    const int device(static_cast<int>(env_unsigned("STRELKA_AMD_DEVICE", 0)));
+    // (a launcher may count more devices than this node has: the index is taken modulo the devices present)
+    const int deviceCount(std::max(1, sk_device_count()));
+    const int device(static_cast<int>(env_unsigned("STRELKA_AMD_DEVICE", 0)) % deviceCount);
     // byte-identical VCFs need the kernels' restated libm routines to be the host's: strict by default
     if (env_unsigned("STRELKA_AMD_ALLOW_INEXACT_LIBM", 0) == 0)
     {

@@ -37,6 +37,9 @@ extern "C" {
  *  L/blt_util/qscore_cache.cpp:34-50 and the memoised tables of
  *  L/applications/strelka/position_somatic_snv_strand_grid_lhood_cached.cpp:41-234) and upload them.
  *  Idempotent for the same device. */
+/** number of gfx950 devices this process can see (0 when there is none); callable before sk_init.  A launcher that hands
+ *  segment process i the device `i mod N` may name more devices than a node has: the adapter takes the index modulo this. */
+int sk_device_count(void);
 int sk_init(int device);
 /** sk_init, but fails when the host C library is not the one the kernels restate (sk_libm_restated() would be 0): for
  *  callers that must guarantee results bit-identical to the reference (the adapter, smoke(), bench.py). */

@@ -45,6 +45,7 @@ static void to_sko(const sk_germline_options* o, sko_germline_options* g)
 
 extern "C" {
 
+int sk_device_count(void) { return 1; }
 int sk_init(int) { g_ready = true; return 0; }
 int sk_init_strict(int) { g_ready = true; return 0; }
 int sk_check_device_errors(void) { return 0; }

@@ -183,6 +183,13 @@ int sk_libm_restated(void) { return g_ctx.libm_restated ? 1 : 0; }
 const char* sk_last_error(void) { return g_last_error.c_str(); }
 int sk_is_initialized(void) { return g_ctx.ready ? 1 : 0; }
 
+int sk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
 int sk_init(int device)
 {
     SkContext& c = g_ctx;

@@ -39,41 +39,15 @@ def germline_argv(binary, out_prefix, bams, region="demo20:1-5000", ref=None, ex
 
 def germline_wgs_argv(binary, out_prefix, bams, regions, ref, chrom_depth, ploidy_vcf=None, nocompress_bed=None, skip_header=False,
                       extra=()):
-    """The segment command of a WGS run (isHighDepthFilter on, no --exome): PY/strelkaGermlineWorkflow.py:81-147 with several
-    --region per process (gsegGroup, PY/strelkaSharedWorkflow.py:174-175), --chrom-depth-file (:125-126), --ploidy-region-vcf
-    (:131-132), --nocompress-bed (:128-129) and --gvcf-skip-header for every segment but the first (:120-121)."""
-    cmd = [os.path.join(BIN_DIR, binary)]
-    for r in regions:
-        cmd += ["--region", r]
-    cmd += ["--ref", ref, "--max-indel-size", "49", "--min-mapping-quality", "20",
-            "--gvcf-output-prefix", out_prefix, "--gvcf-min-gqx", "15", "--gvcf-min-homref-gqx", "15",
-            "--gvcf-max-snv-strand-bias", "10", "--enable-read-backed-phasing",
-            "--stats-file", out_prefix + "runStats.xml"]
-    for b in bams:
-        cmd += ["--align-file", b]
-    if skip_header:
-        cmd.append("--gvcf-skip-header")
-    cmd += ["--chrom-depth-file", chrom_depth]
-    if nocompress_bed:
-        cmd += ["--nocompress-bed", nocompress_bed]
-    if ploidy_vcf:
-        cmd += ["--ploidy-region-vcf", ploidy_vcf]
-    cmd += ["--indel-error-models-file", demo("indelErrorModel.json"), "--theta-file", demo("theta.json")]
-    return cmd + list(extra)
+    """the segment command of a WGS run, as the farm builds it (strelka_amd/farm.py cites the workflow lines)"""
+    from strelka_amd import farm
+    return farm.germline_segment_argv(binary, out_prefix, bams, regions, ref, chrom_depth=chrom_depth, ploidy_vcf=ploidy_vcf,
+                                      nocompress_bed=nocompress_bed, skip_header=skip_header, extra=extra)
 
 
 def wgs_dataset(length=1000000, depth=40.0, seed=20260926):
-    """A WGS-like sample (tools/make_wgs_bam.py), made on the spot under oracle/_ref/synth/ (git-ignored; too large to travel with
-    a snapshot: ~18 MB per Mb) and kept for the next caller.  -> directory with wgs.bam(.bai), wgs.fa(.fai), chrom_depth.txt"""
-    import sys
-    d = os.path.join(REF_DIR, "synth", "wgs_%d_%g_%d" % (length, depth, seed))
-    if not os.path.exists(os.path.join(d, "chrom_depth.txt")):
-        os.makedirs(d, exist_ok=True)
-        subprocess.run([sys.executable, os.path.join(REPO, "tools", "make_wgs_bam.py"), d, os.path.join(BIN_DIR, "samtools"),
-                        "--length", str(length), "--depth", str(depth), "--seed", str(seed)], check=True, stdout=subprocess.DEVNULL)
-        with open(os.path.join(d, "chrom_depth.txt"), "w") as f:  # GetChromDepth's output format: chrom <tab> mean depth
-            f.write("chrW\t%.3f\n" % depth)
-    return d
+    from strelka_amd import farm
+    return farm.wgs_dataset(length, depth, seed)
 
 
 def somatic_argv(binary, out_prefix, normal_bam, tumor_bam, region="demo20:1-5000", ref=None, extra=()):

@@ -1,0 +1,105 @@
+"""The segment farm (strelka_amd/farm.py) and the workflow's WGS flags, end to end.
+
+A WGS-like sample (tools/make_wgs_bam.py) is cut into segments the way the reference's workflow cuts a genome
+(getChromIntervals / getGenomeSegmentGroups), one caller process per group -- some groups with several --region --, with the
+flags a WGS run passes (--chrom-depth-file, --ploidy-region-vcf, --nocompress-bed, --gvcf-skip-header): the farm's joined
+outputs through the adapter must be the unmodified reference's, byte for byte, whatever the number of concurrent processes
+and devices.  CPU tier: the adapter on the test double of the C-ABI; GPU tier: the product library, several processes
+sharing the device."""
+import os
+import subprocess
+
+import pytest
+
+from strelka_amd import farm
+from tests import e2e_util as E
+
+LENGTH = 600000
+OUTPUTS = ("variants.vcf", "genome.S1.vcf")
+
+
+def _have(*names):
+    return E.have(*names) and os.path.exists(os.path.join(E.BIN_DIR, "tabix"))
+
+
+def _dataset(tmp_path_factory):
+    d = E.wgs_dataset(LENGTH)
+    extra = tmp_path_factory.mktemp("wgs_flags")
+    # a haploid stretch and a ploidy-0 stretch (e.g. chrX / chrY of a male sample): ##FORMAT CN per sample, END in INFO
+    # (parsePloidyFromVcf, L/starling_common/ploidy_util.cpp)
+    vcf = extra / "ploidy.vcf"
+    vcf.write_text("##fileformat=VCFv4.1\n##INFO=<ID=END,Number=1,Type=Integer,Description=\"end\">\n"
+                   "##FORMAT=<ID=CN,Number=1,Type=Integer,Description=\"copy number\">\n"
+                   "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tNA_SYNTH\n"
+                   "chrW\t150000\t.\tN\t<CNV>\t.\tPASS\tEND=260000\tCN\t1\n"
+                   "chrW\t400001\t.\tN\t<CNV>\t.\tPASS\tEND=430000\tCN\t0\n")
+    subprocess.run([os.path.join(E.BIN_DIR, "bgzip"), "-f", str(vcf)], check=True)
+    subprocess.run([os.path.join(E.BIN_DIR, "tabix"), "-p", "vcf", str(vcf) + ".gz"], check=True)
+    bed = extra / "nocompress.bed"
+    bed.write_text("chrW\t99000\t101000\nchrW\t505000\t505100\n")
+    subprocess.run([os.path.join(E.BIN_DIR, "bgzip"), "-f", str(bed)], check=True)
+    subprocess.run([os.path.join(E.BIN_DIR, "tabix"), "-p", "bed", str(bed) + ".gz"], check=True)
+    return d, str(vcf) + ".gz", str(bed) + ".gz"
+
+
+def _groups():
+    # 600 kb in 70 kb pieces -> 9 segments; the workflow groups consecutive pieces up to 200 kb: three or so --region per process
+    segs = list(farm.chrom_intervals(["chrW"], {"chrW": LENGTH}, 70000))
+    groups = list(farm.segment_groups(segs, min_group_size=200000))
+    assert len(segs) == 9 and 3 <= len(groups) <= 5 and max(len(g) for g in groups) >= 2
+    assert segs[0][2] == 1 and segs[-1][3] == LENGTH and all(a[3] + 1 == b[2] for a, b in zip(segs, segs[1:]))
+    return groups
+
+
+def _run(binary, tmp, data, jobs, n_gpus=1, env=None):
+    d, ploidy, bed = data
+
+    def argv(index, regions, prefix, skip_header):
+        return farm.germline_segment_argv(binary, prefix, [os.path.join(d, "wgs.bam")], regions, os.path.join(d, "wgs.fa"),
+                                          chrom_depth=os.path.join(d, "chrom_depth.txt"), ploidy_vcf=ploidy, nocompress_bed=bed,
+                                          skip_header=skip_header)
+    return farm.run_farm(_groups(), argv, str(tmp), OUTPUTS, n_gpus=n_gpus, jobs=jobs, env=env)
+
+
+def _body(path):
+    with open(path) as f:
+        return [l for l in f.read().splitlines() if not (l.startswith("##cmdline=") or l.startswith("##startTime=") or l.startswith("##fileDate="))]
+
+
+def test_chrom_intervals_follow_the_workflow():
+    # PY/workflowUtil.py:182-218 on a 30 Mb + 5 Mb genome at 12 Mb: 3 equal pieces, then 1
+    segs = list(farm.chrom_intervals(["a", "b"], {"a": 30000000, "b": 5000000}, 12000000))
+    assert [(s[1], s[2], s[3], s[4]) for s in segs] == [("a", 1, 10000000, 0), ("a", 10000001, 20000000, 1), ("a", 20000001, 30000000, 2),
+                                                        ("b", 1, 5000000, 0)]
+    segs = list(farm.chrom_intervals(["a"], {"a": 25}, 10))
+    assert [(s[2], s[3]) for s in segs] == [(1, 9), (10, 17), (18, 25)]  # 25 = 9 + 8 + 8: the first `size % n` pieces get the extra base
+
+
+@pytest.mark.skipif(not _have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_farm_with_wgs_flags_identical_through_adapter_cpu_double(tmp_path, tmp_path_factory):
+    data = _dataset(tmp_path_factory)
+    ref = _run("starling2_ref", tmp_path / "ref", data, jobs=4)
+    want = {n: _body(ref.outputs[n]) for n in OUTPUTS}
+    assert sum(1 for l in want["variants.vcf"] if not l.startswith("#")) > 400
+    # the ploidy regions reached the records: haploid genotypes inside 150000-260000
+    hap = [l for l in want["variants.vcf"] if not l.startswith("#") and 150000 <= int(l.split("\t")[1]) <= 260000]
+    assert hap and any(l.split("\t")[9].split(":")[0] in ("0", "1") for l in hap)
+    for jobs in (1, 4):
+        got = _run("starling2_dbl", tmp_path / ("dbl%d" % jobs), data, jobs=jobs, env={"STRELKA_AMD_VERBOSE": "1"})
+        for n in OUTPUTS:
+            assert _body(got.outputs[n]) == want[n], (jobs, n)
+        assert len(got.process_s) == len(_groups())
+        assert all("pileup: pushes=" in t and "genotyping=1" in t for t in got.stderr_tails)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
+def test_farm_with_wgs_flags_identical_through_adapter_gpu(tmp_path, tmp_path_factory):
+    data = _dataset(tmp_path_factory)
+    ref = _run("starling2_ref", tmp_path / "ref", data, jobs=4)
+    want = {n: _body(ref.outputs[n]) for n in OUTPUTS}
+    for jobs, n_gpus in ((1, 1), (4, 1), (4, 4)):  # (4 devices named on a 1-GPU box: the adapter takes the index modulo the devices present)
+        env = {"STRELKA_AMD_VERBOSE": "1"}
+        got = _run("starling2_amd", tmp_path / ("amd%d_%d" % (jobs, n_gpus)), data, jobs=jobs, n_gpus=n_gpus, env=env)
+        for n in OUTPUTS:
+            assert _body(got.outputs[n]) == want[n], (jobs, n_gpus, n)

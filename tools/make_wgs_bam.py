@@ -17,7 +17,7 @@ meet a candidate indel, every locus is piled up and genotyped, almost all of the
   * the mapper's habits: an indel within 8 bases of a read end comes out as a soft clip (insertions) or is run through as
     mismatches (deletions) for 70 % of such reads.
 
-usage: make_wgs_bam.py <out dir> <samtools> [--length BP] [--depth X] [--seed N] [--contig NAME] [--sample NAME]
+usage: make_wgs_bam.py <out dir> <samtools> [--length BP] [--depth X] [--seed N] [--procs P] [--contig NAME] [--sample NAME]
 writes <out>/wgs.fa (+ .fai), <out>/wgs.bam (+ .bai), <out>/truth.tsv
 """
 import argparse
@@ -182,6 +182,13 @@ def qualities(n, L, rng):
     return q
 
 
+_WORKER = None
+
+
+def _run_worker(k):
+    return _WORKER(k)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("out")
@@ -195,7 +202,8 @@ def main():
     ap.add_argument("--name", default="wgs")
     ap.add_argument("--snv-every", type=float, default=1000.0)
     ap.add_argument("--indel-every", type=float, default=8000.0)
-    ap.add_argument("--reference-from", default=None, help="reuse <dir>/wgs.fa and its variants' seed (a second sample)")
+    ap.add_argument("--procs", type=int, default=max(1, min(16, len(os.sched_getaffinity(0)))),
+                    help="worker processes (the data set depends on the seed AND this number)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     os.makedirs(a.out, exist_ok=True)
@@ -233,79 +241,109 @@ def main():
 
     n_reads = int(L * a.depth / RL)
     starts = np.sort(rng.integers(0, L - RL - 50, n_reads))
-    sam = os.path.join(a.out, a.name + ".sam")
     bam = os.path.join(a.out, a.name + ".bam")
-    proc = subprocess.Popen([a.samtools, "view", "-b", "-o", bam, "-"], stdin=subprocess.PIPE)
-    w = proc.stdin
-    w.write(("@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n@RG\tID:%s\tSM:%s\n" % (a.contig, L, a.sample, a.sample)).encode())
-    CH = 1 << 16
-    rid = 0
-    carry = []  # (ref_start, line) records whose start moved; flushed in order
+    header = ("@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n@RG\tID:%s\tSM:%s\n" % (a.contig, L, a.sample, a.sample)).encode()
     tail = ("\tRG:Z:%s\n" % a.sample).encode()
     contig = a.contig.encode()
-    for c0 in range(0, n_reads, CH):
-        st = starts[c0:c0 + CH]
-        n = len(st)
-        which = rng.integers(0, 2, n)
-        lens = np.where(rng.random(n) < 0.93, RL, rng.integers(70, RL + 1, n))
-        q = qualities(n, RL, rng)
-        err = rng.random((n, RL)) < np.power(10.0, -q.astype(np.float64) / 10.0)
-        shift = rng.integers(1, 4, (n, RL), dtype=np.uint8)
-        r = rng.random(n)
-        mapq = np.where(r < 0.93, 60, np.where(r < 0.98, rng.integers(1, 20, n), 0))
-        flag = np.where(rng.random(n) < 0.5, 16, 0)
-        seq_err_indel = rng.random(n) < 0.0005
-        lines = []
-        for i in range(n):
-            h = int(which[i])
-            kk = int(np.searchsorted(ref_to_hap[h][0], st[i], side="right")) - 1
-            hs = int(min(max(0, st[i] + ref_to_hap[h][1][kk]), len(haps[h][0]) - RL - 1))
-            Lr = int(lens[i])
-            codes = haps[h][0][hs:hs + Lr]
-            e = err[i, :Lr]
-            if e.any():
-                codes = codes.copy()
-                codes[e] = (codes[e] + shift[i, :Lr][e]) & 3
-            j = int(np.searchsorted(indel_hp[h], hs, side="right"))
-            if j < len(indel_hp[h]) and indel_hp[h][j] < hs + Lr or (j > 0 and indel_hp[h][j - 1] >= hs - 64):
-                ops, ref_start = cigar_for(haps[h][1], bstarts[h], hs, Lr, rng)
-                if ops is None:
-                    continue
-            else:
-                k = int(np.searchsorted(off_pos[h][0], hs, side="right")) - 1
-                ref_start = hs + int(off_pos[h][1][k])
-                ops = [["M", Lr]]
-            seq = BASES[codes].tobytes()
-            if seq_err_indel[i] and len(ops) == 1 and Lr > 60:
-                p = int(rng.integers(20, Lr - 20))
-                if rng.random() < 0.5:      # a base dropped by the instrument
-                    seq = seq[:p] + seq[p + 1:]
-                    ops = [["M", p], ["D", 1], ["M", Lr - p - 1]]
-                    Lr -= 1
+    CH = 1 << 16
+
+    # The reads are made in `procs` stretches of the (sorted) start list, one worker process each writing its own BAM; a worker
+    # keeps the reads whose reference start lies in its stretch [lo, hi) (a soft clip can move a start by a few bases), so the
+    # pieces joined with `samtools cat` are coordinate-sorted.  Worker k draws from its own generator (seed + 1000 + k): the
+    # data set depends on the seed AND the number of stretches.
+    procs = max(1, min(a.procs, n_reads // 1000 or 1))
+    cuts = [int(round(k * n_reads / procs)) for k in range(procs + 1)]
+
+    def worker(k):
+        wrng = np.random.default_rng(a.seed + 1000 + k)
+        lo = int(starts[cuts[k]]) if k > 0 else -(1 << 62)
+        hi = int(starts[cuts[k + 1]]) if k + 1 < procs else 1 << 62
+        part = os.path.join(a.out, "%s.part%03d.bam" % (a.name, k))
+        proc = subprocess.Popen([a.samtools, "view", "-b", "-o", part, "-"], stdin=subprocess.PIPE)
+        w = proc.stdin
+        w.write(header)
+        rid = 0
+        carry = []  # (ref_start, line): flushed in order once no later read can start before them
+        for c0 in range(cuts[k], cuts[k + 1], CH):
+            st = starts[c0:min(c0 + CH, cuts[k + 1])]
+            n = len(st)
+            which = wrng.integers(0, 2, n)
+            lens = np.where(wrng.random(n) < 0.93, RL, wrng.integers(70, RL + 1, n))
+            q = qualities(n, RL, wrng)
+            err = wrng.random((n, RL)) < np.power(10.0, -q.astype(np.float64) / 10.0)
+            shift = wrng.integers(1, 4, (n, RL), dtype=np.uint8)
+            r = wrng.random(n)
+            mapq = np.where(r < 0.93, 60, np.where(r < 0.98, wrng.integers(1, 20, n), 0))
+            flag = np.where(wrng.random(n) < 0.5, 16, 0)
+            seq_err_indel = wrng.random(n) < 0.0005
+            lines = []
+            for i in range(n):
+                h = int(which[i])
+                kk = int(np.searchsorted(ref_to_hap[h][0], st[i], side="right")) - 1
+                hs = int(min(max(0, st[i] + ref_to_hap[h][1][kk]), len(haps[h][0]) - RL - 1))
+                Lr = int(lens[i])
+                codes = haps[h][0][hs:hs + Lr]
+                e = err[i, :Lr]
+                if e.any():
+                    codes = codes.copy()
+                    codes[e] = (codes[e] + shift[i, :Lr][e]) & 3
+                j = int(np.searchsorted(indel_hp[h], hs, side="right"))
+                if j < len(indel_hp[h]) and indel_hp[h][j] < hs + Lr or (j > 0 and indel_hp[h][j - 1] >= hs - 64):
+                    ops, ref_start = cigar_for(haps[h][1], bstarts[h], hs, Lr, wrng)
+                    if ops is None:
+                        continue
                 else:
-                    seq = seq[:p] + b"ACGT"[int(rng.integers(0, 4)):][:1] + seq[p:]
-                    ops = [["M", p], ["I", 1], ["M", Lr - p]]
-                    Lr += 1
-            qs = (q[i, :Lr] + 33).tobytes() if Lr <= RL else (q[i, :RL] + 33).tobytes() + b"F" * (Lr - RL)
-            cigar = "".join("%d%s" % (m, o) for o, m in ops).encode()
-            lines.append((ref_start, b"r%07d\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s%s" % (
-                rid, int(flag[i]), contig, ref_start + 1, int(mapq[i]), cigar, seq, qs, tail)))
-            rid += 1
-        # reads are generated in order of haplotype start; reference starts differ by at most the indel offsets: merge with
-        # the carry and hold back the last stretch
-        carry.extend(lines)
-        carry.sort(key=lambda x: x[0])
-        limit = int(st[-1]) - 2000 if c0 + CH < n_reads else 1 << 62
-        k = 0
-        while k < len(carry) and carry[k][0] <= limit:
-            k += 1
-        w.write(b"".join(l for _, l in carry[:k]))
-        carry = carry[k:]
-    w.close()
-    if proc.wait() != 0:
-        sys.exit("samtools view failed")
+                    kq = int(np.searchsorted(off_pos[h][0], hs, side="right")) - 1
+                    ref_start = hs + int(off_pos[h][1][kq])
+                    ops = [["M", Lr]]
+                if not (lo <= ref_start < hi):
+                    continue
+                seq = BASES[codes].tobytes()
+                if seq_err_indel[i] and len(ops) == 1 and Lr > 60:
+                    p = int(wrng.integers(20, Lr - 20))
+                    if wrng.random() < 0.5:      # a base dropped by the instrument
+                        seq = seq[:p] + seq[p + 1:]
+                        ops = [["M", p], ["D", 1], ["M", Lr - p - 1]]
+                        Lr -= 1
+                    else:
+                        seq = seq[:p] + b"ACGT"[int(wrng.integers(0, 4)):][:1] + seq[p:]
+                        ops = [["M", p], ["I", 1], ["M", Lr - p]]
+                        Lr += 1
+                qs = (q[i, :Lr] + 33).tobytes() if Lr <= RL else (q[i, :RL] + 33).tobytes() + b"F" * (Lr - RL)
+                cigar = "".join("%d%s" % (m, o) for o, m in ops).encode()
+                lines.append((ref_start, b"r%02d_%07d\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s%s" % (
+                    k, rid, int(flag[i]), contig, ref_start + 1, int(mapq[i]), cigar, seq, qs, tail)))
+                rid += 1
+            carry.extend(lines)
+            carry.sort(key=lambda x: x[0])
+            limit = int(st[-1]) - 2000 if c0 + CH < cuts[k + 1] else 1 << 62
+            kc = 0
+            while kc < len(carry) and carry[kc][0] <= limit:
+                kc += 1
+            w.write(b"".join(l for _, l in carry[:kc]))
+            carry = carry[kc:]
+        w.close()
+        if proc.wait() != 0:
+            sys.exit("samtools view failed")
+        return part, rid
+
+    if procs == 1:
+        results = [worker(0)]
+    else:
+        import multiprocessing as mp
+        global _WORKER
+        _WORKER = worker
+        with mp.get_context("fork").Pool(procs) as pool:   # (fork: the workers read the haplotypes where they are)
+            results = pool.map(_run_worker, range(procs))
+    parts = [r[0] for r in results]
+    if len(parts) == 1:
+        os.replace(parts[0], bam)
+    else:
+        subprocess.run([a.samtools, "cat", "-o", bam] + parts, check=True)
+        for pth in parts:
+            os.remove(pth)
     subprocess.run([a.samtools, "index", bam], check=True)
-    print("%s: %d bp, %d reads, %d variants (%d indels)" % (bam, L, rid, len(variants),
+    print("%s: %d bp, %d reads, %d variants (%d indels)" % (bam, L, sum(r[1] for r in results), len(variants),
                                                            sum(1 for v in variants if not (v[1] == 1 and len(v[2]) == 1))))
 
 
