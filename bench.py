@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--somatic-loci", type=int, default=1 << 22, help="somatic loci per step per GPU (40x normal + 110x tumor)")
     ap.add_argument("--indels", type=int, default=1 << 18, help="indel loci per step per GPU for the indel legs (a11, a14)")
     ap.add_argument("--align-problems", type=int, default=4096, help="GlobalAligner problems per step (next row f2)")
+    ap.add_argument("--e2e-bp", type=int, default=8000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
+    ap.add_argument("--e2e-segment-bp", type=int, default=500000, help="segment size of the end-to-end leg (one caller process per segment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
     ap.add_argument("--cpu-loci", type=int, default=2000000, help="loci in the CPU-baseline sample")
@@ -155,6 +157,80 @@ def whole_read_leg(args, capi, synth, rng, enumeration=2, max_indels=6, reads=No
     for job, _, _, _ in jobs:
         cals += job.batch().n_cals
     return step, total, cals
+
+
+E2E_OUTPUTS = ("variants.vcf", "genome.S1.vcf")
+
+
+def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference):
+    """BASELINE.json's second metric, "40x WGS germline wall-clock": a WGS-like 40x sample (tools/make_wgs_bam.py, made before the
+    clock starts) cut into segments as the reference's workflow cuts a genome, one caller process per segment with the command line
+    the workflow builds (strelka_amd/farm.py), as many processes at a time as this rank has host cores: the drop-in
+    (`starling2_amd`: the reference's own program with its hot-path call sites routed through libstrelka_amd.so) on this rank's
+    GPU, and -- rank 0 of a 1-GPU run -- the unmodified reference (`starling2_ref`, kind "reference") on the same cores, outputs
+    compared byte for byte.  Weak scaling: every rank calls the whole sample on its own GPU with cores/N processes."""
+    import re
+    import shutil
+    import tempfile
+    from strelka_amd import farm
+    L = args.e2e_bp
+    drop_in = os.environ.get("SK_E2E_BINARY", "starling2_amd")  # (tests/test_bench_e2e.py runs the leg's plumbing on the CPU double)
+    if not (os.path.exists(os.path.join(farm.BIN_DIR, drop_in)) and os.path.exists(os.path.join(farm.BIN_DIR, "samtools"))):
+        return {"skipped": "oracle/_ref/bin/starling2_amd (adapter/Makefile, needs the reference tree at build time) did not travel"}
+    if rank == 0:
+        farm.wgs_dataset(L)
+    barrier()
+    d = farm.wgs_dataset(L)
+    cores = farm.usable_cores()
+    jobs = max(1, len(cores) // world)
+    groups = [[s] for s in farm.chrom_intervals(["chrW"], {"chrW": L}, args.e2e_segment_bp)]
+    root = tempfile.mkdtemp(prefix="sk_e2e_r%d_" % rank)
+
+    def argv_fn(binary):
+        def fn(index, regions, prefix, skip_header):
+            return farm.germline_segment_argv(binary, prefix, [os.path.join(d, "wgs.bam")], regions, os.path.join(d, "wgs.fa"),
+                                              chrom_depth=os.path.join(d, "chrom_depth.txt"), skip_header=skip_header)
+        return fn
+    try:
+        farm.run_farm(groups[:1], argv_fn(drop_in), os.path.join(root, "warm"), E2E_OUTPUTS, n_gpus=1, jobs=1,
+                      device_offset=local_rank)  # page the binary and the GPU runtime in
+        barrier()
+        t0 = time.perf_counter()
+        amd = farm.run_farm(groups, argv_fn(drop_in), os.path.join(root, "amd"), E2E_OUTPUTS, n_gpus=1, jobs=jobs,
+                            device_offset=local_rank, env={"STRELKA_AMD_VERBOSE": "1"})
+        barrier()
+        amd_wall = max_over_ranks(time.perf_counter() - t0)
+        hooks = {}
+        for tail in amd.stderr_tails:
+            m = re.search(r"strelka_amd adapter seconds: (.*)", tail)
+            if m:
+                for kv in m.group(1).split():
+                    k, v = kv.split("=")
+                    hooks[k] = hooks.get(k, 0.0) + float(v)
+        out = {"workload": "WGS-like synthetic germline sample, %d bp at 40x, 150 bp reads (tools/make_wgs_bam.py), %d segments of %d bp, one "
+                           "caller process per segment with the workflow's WGS command line (--chrom-depth-file, --gvcf-skip-header ...)"
+                           % (L, len(groups), args.e2e_segment_bp),
+               "bp": L * world, "reads": int(L * 40.0 / 150) * world, "segments": len(groups) * world,
+               "amd_wall_s": amd_wall, "amd_procs": jobs * world, "amd_procs_per_gpu": jobs, "host_cores": len(cores),
+               "bp_per_s": L * world / amd_wall, "process_seconds_sum": sum(amd.process_s),
+               "hook_seconds": {k: round(v, 4) for k, v in hooks.items()},
+               "hook_seconds_note": "summed over this rank's segment processes: wall seconds inside the adapter's hooks (*_hook) of which inside "
+                                    "the C-ABI (*_abi); the rest of process_seconds_sum is the reference's own host code (BAM records, read "
+                                    "buffer, active regions, locus objects, gVCF text)"}
+        if with_reference:
+            t0 = time.perf_counter()
+            ref = farm.run_farm(groups, argv_fn("starling2_ref"), os.path.join(root, "ref"), E2E_OUTPUTS, jobs=jobs)
+            ref_wall = time.perf_counter() - t0
+
+            def body(path):
+                with open(path, "rb") as f:
+                    return [l for l in f.read().split(b"\n") if not (l.startswith(b"##cmdline=") or l.startswith(b"##startTime=") or l.startswith(b"##fileDate="))]
+            identical = all(body(amd.outputs[n]) == body(ref.outputs[n]) for n in E2E_OUTPUTS)
+            out.update({"ref_wall_s": ref_wall, "ref_cores": jobs, "ref_process_seconds_sum": sum(ref.process_s), "speedup": ref_wall / amd_wall,
+                        "identical": identical, "variant_records": sum(1 for l in body(ref.outputs["variants.vcf"]) if l and not l.startswith(b"#"))})
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def pmc_traffic(args):
@@ -291,6 +367,21 @@ def main():
         wr["realign%s_reads_per_step_per_gpu" % name] = wr_reads
         wr["realign%s_candidate_alignments_per_read" % name] = wr_cals / max(1, wr_reads)
 
+    # ---- end to end: the drop-in as the workflow runs it, one caller process per genome segment ----
+    e2e = None
+    if args.e2e_bp > 0:
+        def barrier():
+            if world > 1:
+                dist.barrier()
+
+        def max_over_ranks(v):
+            if world == 1:
+                return v
+            t = torch.tensor([v], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        e2e = e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference=(world == 1 and not args.no_cpu_baseline))
+
     traffic = pmc_traffic(args)
     som_kernels = ("somatic_classify_kernel", "somatic_lhood_kernel", "somatic_posterior_kernel")
     som_traffic = sum(traffic[k] for k in som_kernels) if all(k in traffic for k in som_kernels) else None
@@ -345,6 +436,7 @@ def main():
         "roofline_loci": roof("germline_site_fused_kernel", alg_bytes_b, kms_b, traffic.get("germline_site_fused_kernel")),
     }
     out.update(wr)
+    out["e2e"] = e2e
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

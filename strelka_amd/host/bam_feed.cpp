@@ -28,11 +28,15 @@ int64_t sk_bgzf_scan(const uint8_t* data, int64_t n_bytes, int64_t* block_off, i
         const uint8_t* h = data + at;
         if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return -1;
         const uint32_t xlen = le16(h + 10);
+        // the extra field and the 8-byte trailer must lie inside the buffer before a subfield is read (a header that claims
+        // XLEN = 0xFFFF in a 28-byte buffer is malformed input, not a reason to read past the end)
+        if (int64_t(12) + int64_t(xlen) + 8 > n_bytes - at) return -1;
         // the BC subfield (SI1 = 66, SI2 = 67, SLEN = 2) holds BSIZE = total block size - 1
         int64_t bsize = -1;
         for (uint32_t x = 0; x + 4 <= xlen;) {
             const uint8_t* sf = h + 12 + x;
             const uint32_t slen = le16(sf + 2);
+            if (x + 4 + slen > xlen) return -1; // a subfield that runs past XLEN
             if (sf[0] == 66 && sf[1] == 67 && slen == 2) bsize = int64_t(le16(sf + 4)) + 1;
             x += 4 + slen;
         }
@@ -62,7 +66,8 @@ int64_t sk_bam_scan_records(const uint8_t* stream, int64_t stream_len, int64_t f
     int32_t n = 0;
     while (at + 4 <= stream_len) {
         const int64_t block_size = int64_t(le32(stream + at));
-        if (block_size < 32 || at + 4 + block_size > stream_len) break; // (a record cut by the end of the stream is left to the next call)
+        if (block_size < 32) return -1; // shorter than its fixed fields: malformed (htslib's bam_read1 returns -4, the reference throws)
+        if (at + 4 + block_size > stream_len) break; // (a record cut by the end of the stream is left to the next call)
         const uint8_t* p = stream + at;
         const uint32_t l_read_name = p[12], n_cigar = le16(p + 16);
         const int64_t l_seq = int64_t(int32_t(le32(p + 20)));

@@ -1,0 +1,20 @@
+"""bench.py's end-to-end leg (the "40x WGS germline wall-clock" half of BASELINE.json's metric): its plumbing -- data set, segment
+farm, reference leg on the same cores, byte comparison, hook-timer sums -- run here on the CPU double of the C-ABI.  On the GPU box
+bench.py runs the same function with `starling2_amd`."""
+import argparse
+import os
+
+import pytest
+
+from tests import e2e_util as E
+
+
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_e2e_leg_runs_and_compares(monkeypatch):
+    import bench
+    monkeypatch.setenv("SK_E2E_BINARY", "starling2_dbl")
+    args = argparse.Namespace(e2e_bp=400000, e2e_segment_bp=100000)
+    out = bench.e2e_leg(args, 0, 1, 0, lambda: None, lambda v: v, with_reference=True)
+    assert out["identical"] is True and out["segments"] == 4 and out["bp"] == 400000
+    assert out["variant_records"] > 300 and out["ref_wall_s"] > 0 and out["amd_wall_s"] > 0
+    assert out["hook_seconds"]["pileup_abi"] > 0 and out["hook_seconds"]["pileup_hook"] >= out["hook_seconds"]["pileup_abi"]
