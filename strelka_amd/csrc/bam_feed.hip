@@ -22,6 +22,7 @@
 
 #include "normalize_core.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -268,6 +269,421 @@ __global__ __launch_bounds__(64) void bgzf_crc32_kernel(const InflateArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// B1w  bgzf_inflate_wave_kernel: one WAVE per BGZF block, inflation and the CRC-32 / ISIZE check in one kernel.
+//
+// The thread-per-block kernel above wins on throughput only when a launch holds 10^5 blocks; a caller process of the drop-in has
+// a few hundred to a few thousand per region, and there the latency of ONE block is the whole cost (~0.1 s: every Huffman step a
+// round trip to private tables in scratch memory, one bit per step, one dependent byte load per output byte).  Here a block has a
+// wavefront and 78 KB of LDS to itself:
+//   * the block's 64 KiB of output and every table live in LDS; the compressed bytes stream through an 8 KiB LDS ring that the 64
+//     lanes refill 4 KiB at a time with 16-byte loads;
+//   * the serial part of DEFLATE -- the bit buffer, one literal/length or distance symbol after the other -- is executed by all
+//     lanes in lockstep on identical values (uniform control flow, LDS reads of one address are broadcasts): a symbol is ONE
+//     lookup in a 10-bit (distances: 8-bit) first-level table, codes longer than that walk the canonical counts as before;
+//   * what is parallel is done by the lanes: an LZ77 copy of `len` bytes is len lanes (byte k comes from position - dist +
+//     k mod dist, which is the overlap rule), table fills, the CRC (64 slices, combined with x^(8 n) mod P as zlib's
+//     crc32_combine does) and the final store of the block to HBM in consecutive 64-byte rows.
+// Same checks, same status codes as the kernel above.
+// ---------------------------------------------------------------------------------------------------------------------
+
+constexpr int IW_FAST = 10, IW_DFAST = 8;
+constexpr int IW_RING = 8192, IW_HALF = 4096;
+
+struct InflateWaveLds
+{
+    uint8_t out[65536];
+    uint8_t ring[IW_RING];
+    uint32_t crc_table[256];
+    uint16_t lit_fast[1 << IW_FAST];  // symbol | code length << 9; 0: longer than IW_FAST bits (or unused)
+    uint16_t dist_fast[1 << IW_DFAST];
+    uint16_t lit_count[16], dist_count[16];
+    uint16_t lit_sym[288], dist_sym[32];
+    uint16_t len_base[32], dist_base[32];
+    uint8_t len_extra[32], dist_extra[32];
+    uint8_t lengths[320];
+};
+
+struct WaveBits
+{
+    uint64_t buf;
+    int cnt;
+    int64_t next;   // ring-origin-relative offset of the next 4 input bytes to enter `buf` (a multiple of 4)
+    int64_t loaded; // ring-origin-relative offset up to which the ring holds input (a multiple of IW_HALF)
+    int64_t limit;  // ... of the end of the compressed data
+    const uint8_t* g0; // the ring origin in HBM (16-byte aligned)
+};
+
+// 4 KiB of input into the ring half that `from` falls in; past `limit` the ring reads as zero
+__device__ __forceinline__ void iw_load_half(InflateWaveLds& L, const WaveBits& b, const int64_t from, const int lane)
+{
+#pragma unroll
+    for (int it = 0; it < IW_HALF / (64 * 16); ++it) {
+        const int64_t o = from + (it * 64 + lane) * 16;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (o + 16 <= b.limit) {
+            v = *reinterpret_cast<const uint4*>(b.g0 + o);
+        } else if (o < b.limit) {
+            uint8_t t[16];
+            for (int k = 0; k < 16; ++k) t[k] = (o + k < b.limit) ? b.g0[o + k] : uint8_t(0);
+            v.x = uint32_t(t[0]) | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
+            v.y = uint32_t(t[4]) | (uint32_t(t[5]) << 8) | (uint32_t(t[6]) << 16) | (uint32_t(t[7]) << 24);
+            v.z = uint32_t(t[8]) | (uint32_t(t[9]) << 8) | (uint32_t(t[10]) << 16) | (uint32_t(t[11]) << 24);
+            v.w = uint32_t(t[12]) | (uint32_t(t[13]) << 8) | (uint32_t(t[14]) << 16) | (uint32_t(t[15]) << 24);
+        }
+        *reinterpret_cast<uint4*>(&L.ring[size_t(o) & (IW_RING - 1)]) = v;
+    }
+}
+
+// at least 32 bits in the buffer afterwards
+__device__ __forceinline__ void iw_refill(InflateWaveLds& L, WaveBits& b, const int lane)
+{
+    if (b.cnt >= 32) return;
+    if (b.next >= b.loaded - IW_HALF) { // the reader is in the newest half: the other one is spent, refill it
+        __syncthreads();
+        iw_load_half(L, b, b.loaded, lane);
+        b.loaded += IW_HALF;
+        __syncthreads();
+    }
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(&L.ring[size_t(b.next) & (IW_RING - 1)]);
+    b.buf |= uint64_t(w) << b.cnt;
+    b.cnt += 32;
+    b.next += 4;
+}
+
+__device__ __forceinline__ unsigned iw_take(WaveBits& b, const int n) // n <= 16, the buffer holds them
+{
+    const unsigned v = unsigned(b.buf & ((1ull << n) - 1ull));
+    b.buf >>= n;
+    b.cnt -= n;
+    return v;
+}
+
+// puff's canonical walk over the buffered bits (not consumed): symbol and its length, -1 if no code matches
+__device__ __forceinline__ int iw_slow_decode(const WaveBits& b, const uint16_t* count, const uint16_t* symbol, int& len_out)
+{
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code |= int((b.buf >> (len - 1)) & 1ull);
+        const int c = count[len];
+        if (code - c < first) {
+            len_out = len;
+            return symbol[index + (code - first)];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+// counts, sorted symbols (as huff_construct) and the first-level table; returns puff's `left`
+__device__ int iw_construct(InflateWaveLds& L, uint16_t* count, uint16_t* symbol, uint16_t* fast, const int fast_bits, const uint8_t* length,
+                            const int n, const int lane)
+{
+    __syncthreads();
+    if (lane == 0) {
+        for (int len = 0; len <= 15; ++len) count[len] = 0;
+        for (int s = 0; s < n; ++s) count[length[s]]++;
+    }
+    for (int i = lane; i < (1 << fast_bits); i += 64) fast[i] = 0;
+    __syncthreads();
+    if (count[0] == n) return 0;
+    int left = 1;
+    for (int len = 1; len <= 15; ++len) {
+        left <<= 1;
+        left -= int(count[len]);
+        if (left < 0) return left;
+    }
+    if (lane == 0) {
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int len = 1; len < 15; ++len) offs[len + 1] = uint16_t(offs[len] + count[len]);
+        for (int s = 0; s < n; ++s)
+            if (length[s] != 0) symbol[offs[length[s]]++] = uint16_t(s);
+    }
+    __syncthreads();
+    // the k-th sorted symbol: its length from the cumulative counts, its canonical code = first code of that length + its rank
+    const int total = n - int(count[0]);
+    for (int idx = lane; idx < total; idx += 64) {
+        int len = 1, start = 0, code0 = 0;
+        while (len <= 15 && idx >= start + int(count[len])) {
+            start += int(count[len]);
+            code0 = (code0 + int(count[len])) << 1;
+            ++len;
+        }
+        if (len > fast_bits) continue;
+        const unsigned code = unsigned(code0 + (idx - start));
+        const unsigned rev = __brev(code) >> (32 - len); // DEFLATE packs Huffman codes most significant bit first
+        const uint16_t entry = uint16_t(unsigned(symbol[idx]) | (unsigned(len) << 9));
+        for (unsigned e = rev; e < (1u << fast_bits); e += (1u << len)) fast[e] = entry;
+    }
+    __syncthreads();
+    return left;
+}
+
+__device__ int iw_codes(InflateWaveLds& L, WaveBits& b, int& pos, const int cap, const int lane)
+{
+    for (;;) {
+        iw_refill(L, b, lane);
+        unsigned e = L.lit_fast[unsigned(b.buf) & ((1u << IW_FAST) - 1u)];
+        int len = int(e >> 9), sym = int(e & 511u);
+        if (len == 0) {
+            sym = iw_slow_decode(b, L.lit_count, L.lit_sym, len);
+            if (sym < 0) return INF_BAD_CODE;
+        }
+        (void)iw_take(b, len);
+        if (sym < 256) {
+            if (pos >= cap) return INF_OUT_OVERFLOW;
+            if (lane == 0) L.out[pos] = uint8_t(sym);
+            ++pos;
+            continue;
+        }
+        if (sym == 256) return INF_OK;
+        sym -= 257;
+        if (sym >= 29) return INF_BAD_CODE;
+        const int mlen = int(L.len_base[sym]) + int(iw_take(b, L.len_extra[sym]));
+        iw_refill(L, b, lane);
+        e = L.dist_fast[unsigned(b.buf) & ((1u << IW_DFAST) - 1u)];
+        len = int(e >> 9);
+        int ds = int(e & 511u);
+        if (len == 0) {
+            ds = iw_slow_decode(b, L.dist_count, L.dist_sym, len);
+            if (ds < 0) return INF_BAD_CODE;
+        }
+        if (ds >= 30) return INF_BAD_CODE;
+        (void)iw_take(b, len);
+        const int dist = int(L.dist_base[ds]) + int(iw_take(b, L.dist_extra[ds]));
+        if (dist > pos) return INF_BAD_DISTANCE; // (a BGZF block has no preset dictionary)
+        if (pos + mlen > cap) return INF_OUT_OVERFLOW;
+        // the copy: byte k of the match is byte (k mod dist) of the `dist` bytes before it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int src0 = pos - dist;
+        for (int k = lane; k < mlen; k += 64) L.out[pos + k] = L.out[src0 + (dist >= mlen ? k : k % dist)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        pos += mlen;
+    }
+}
+
+// a * b mod P over GF(2), reflected (zlib crc32.c multmodp)
+__device__ __forceinline__ uint32_t iw_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? ((b >> 1) ^ 0xedb88320u) : (b >> 1);
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(64) void bgzf_inflate_wave_kernel(const InflateArgs a)
+{
+    extern __shared__ __align__(16) unsigned char iw_lds_raw[];
+    InflateWaveLds& L = *reinterpret_cast<InflateWaveLds*>(iw_lds_raw);
+    const int lane = threadIdx.x;
+    const int blk_i = blockIdx.x;
+    if (blk_i >= a.n_blocks) return;
+    const uint8_t* blk = a.data + a.block_off[blk_i];
+    const int64_t blen = a.block_off[blk_i + 1] - a.block_off[blk_i];
+    if (blen < 28 || blk[0] != 31 || blk[1] != 139 || blk[2] != 8 || !(blk[3] & 4)) {
+        if (lane == 0) a.status[blk_i] = INF_BAD_HEADER;
+        return;
+    }
+    const int xlen = int(blk[10]) | (int(blk[11]) << 8);
+    const uint8_t* cdata = blk + 12 + xlen;
+    const uint8_t* cend = blk + blen - 8;
+    if (cdata > cend) {
+        if (lane == 0) a.status[blk_i] = INF_BAD_HEADER;
+        return;
+    }
+    const uint32_t isize = uint32_t(cend[4]) | (uint32_t(cend[5]) << 8) | (uint32_t(cend[6]) << 16) | (uint32_t(cend[7]) << 24);
+    const uint32_t want_crc = uint32_t(cend[0]) | (uint32_t(cend[1]) << 8) | (uint32_t(cend[2]) << 16) | (uint32_t(cend[3]) << 24);
+    const int64_t cap64 = a.out_off[blk_i + 1] - a.out_off[blk_i];
+    if (cap64 < 0 || cap64 > 65536) {
+        if (lane == 0) a.status[blk_i] = INF_OUT_OVERFLOW;
+        return;
+    }
+    const int cap = int(cap64);
+
+    // tables every block needs
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = uint32_t(i);
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
+        L.crc_table[i] = c;
+    }
+    if (lane < 29) {
+        L.len_base[lane] = uint16_t(LEN_BASE[lane]);
+        L.len_extra[lane] = uint8_t(LEN_EXTRA[lane]);
+    }
+    if (lane < 30) {
+        L.dist_base[lane] = uint16_t(DIST_BASE[lane]);
+        L.dist_extra[lane] = uint8_t(DIST_EXTRA[lane]);
+    }
+
+    WaveBits b;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(cdata);
+    b.g0 = cdata - (addr & 15u);
+    b.limit = int64_t(cend - b.g0);
+    b.buf = 0;
+    b.cnt = 0;
+    b.next = 0;
+    b.loaded = 0;
+    iw_load_half(L, b, 0, lane);
+    iw_load_half(L, b, IW_HALF, lane);
+    b.loaded = IW_RING;
+    __syncthreads();
+    {   // the bytes between the ring origin and the first compressed byte
+        int drop = int(addr & 15u) * 8;
+        while (drop > 0) {
+            iw_refill(L, b, lane);
+            const int d = drop < 16 ? drop : 16;
+            (void)iw_take(b, d);
+            drop -= d;
+        }
+    }
+    const int64_t total_bits = int64_t(cend - cdata) * 8;
+    const int64_t origin_bits = int64_t(addr & 15u) * 8;
+    auto consumed_bits = [&]() { return b.next * 8 - b.cnt - origin_bits; };
+
+    int pos = 0, err = INF_OK, last = 0;
+    do {
+        iw_refill(L, b, lane);
+        last = int(iw_take(b, 1));
+        const int type = int(iw_take(b, 2));
+        if (type == 0) { // stored: the rest of the byte is dropped, LEN NLEN, then LEN bytes
+            (void)iw_take(b, b.cnt & 7);
+            iw_refill(L, b, lane);
+            const unsigned len = iw_take(b, 16);
+            iw_refill(L, b, lane);
+            const unsigned nlen = iw_take(b, 16);
+            if (len != (~nlen & 0xffffu) || consumed_bits() + int64_t(len) * 8 > total_bits) { err = INF_BAD_STORED; break; }
+            if (pos + int(len) > cap) { err = INF_OUT_OVERFLOW; break; }
+            for (unsigned i = 0; i < len; ++i) {
+                iw_refill(L, b, lane);
+                const unsigned v = iw_take(b, 8);
+                if (lane == 0) L.out[pos] = uint8_t(v);
+                ++pos;
+            }
+        } else if (type == 1 || type == 2) {
+            int nlen = 288, ndist = 30;
+            if (type == 1) { // fixed codes (RFC 1951 3.2.6)
+                __syncthreads();
+                for (int s = lane; s < 288; s += 64) L.lengths[s] = uint8_t(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                if (lane < 30) L.lengths[288 + lane] = 5;
+                __syncthreads();
+            } else { // dynamic codes (3.2.7)
+                nlen = int(iw_take(b, 5)) + 257;
+                ndist = int(iw_take(b, 5)) + 1;
+                const int ncode = int(iw_take(b, 4)) + 4;
+                if (nlen > 286 || ndist > 30) { err = INF_BAD_LENGTHS; break; }
+                __syncthreads();
+                if (lane < 19) L.lengths[lane] = 0;
+                __syncthreads();
+                for (int idx = 0; idx < ncode; ++idx) {
+                    iw_refill(L, b, lane);
+                    const unsigned v = iw_take(b, 3);
+                    if (lane == 0) L.lengths[CLEN_ORDER[idx]] = uint8_t(v);
+                }
+                // the code-length code: at most 7 bits, it uses the distance tables' space
+                if (iw_construct(L, L.dist_count, L.dist_sym, L.dist_fast, 7, L.lengths, 19, lane) != 0) { err = INF_BAD_LENGTHS; break; }
+                int idx = 0, prev = 0;
+                const int want = nlen + ndist;
+                // (the lengths are written after the table that decodes them was built from the same array: they go to a second
+                // array first -- the literal/length table's space is free until iw_construct below)
+                uint8_t* dst = reinterpret_cast<uint8_t*>(L.lit_sym);
+                while (idx < want) {
+                    iw_refill(L, b, lane);
+                    const unsigned e = L.dist_fast[unsigned(b.buf) & 127u];
+                    const int len = int(e >> 9), sym = int(e & 511u);
+                    if (len == 0) { err = INF_BAD_CODE; break; }
+                    (void)iw_take(b, len);
+                    if (sym < 16) {
+                        if (lane == 0) dst[idx] = uint8_t(sym);
+                        prev = sym;
+                        ++idx;
+                    } else {
+                        int fill = 0, rep;
+                        if (sym == 16) {
+                            if (idx == 0) { err = INF_BAD_LENGTHS; break; }
+                            fill = prev;
+                            rep = 3 + int(iw_take(b, 2));
+                        } else if (sym == 17) {
+                            rep = 3 + int(iw_take(b, 3));
+                        } else {
+                            rep = 11 + int(iw_take(b, 7));
+                        }
+                        if (idx + rep > want) { err = INF_BAD_LENGTHS; break; }
+                        for (int k = lane; k < rep; k += 64) dst[idx + k] = uint8_t(fill);
+                        idx += rep;
+                        prev = fill;
+                    }
+                }
+                if (err != INF_OK) break;
+                __syncthreads();
+                for (int s = lane; s < want; s += 64) L.lengths[s] = dst[s];
+                __syncthreads();
+                if (L.lengths[256] == 0) { err = INF_BAD_LENGTHS; break; }
+            }
+            int left = iw_construct(L, L.lit_count, L.lit_sym, L.lit_fast, IW_FAST, L.lengths, nlen, lane);
+            if (type == 2 && left != 0 && (left < 0 || nlen != int(L.lit_count[0]) + int(L.lit_count[1]))) { err = INF_BAD_LENGTHS; break; }
+            left = iw_construct(L, L.dist_count, L.dist_sym, L.dist_fast, IW_DFAST, L.lengths + nlen, ndist, lane);
+            if (type == 2 && left != 0 && (left < 0 || ndist != int(L.dist_count[0]) + int(L.dist_count[1]))) { err = INF_BAD_LENGTHS; break; }
+            err = iw_codes(L, b, pos, cap, lane);
+        } else {
+            err = INF_BAD_BLOCK_TYPE;
+        }
+        if (err == INF_OK && consumed_bits() > total_bits) err = INF_IN_OVERRUN;
+    } while (err == INF_OK && !last);
+    if (err == INF_OK && (pos != cap || uint32_t(pos) != isize)) err = INF_SIZE_MISMATCH;
+    __syncthreads();
+    if (err == INF_OK) {
+        // CRC-32 of the block: 64 slices, slice i shifted by the bytes after it (crc(A || B) = crc(A) * x^(8 |B|) + crc(B))
+        const int n = pos;
+        const int slice = (n + 63) / 64;
+        const int s0 = min(n, lane * slice), s1 = min(n, s0 + slice);
+        uint32_t c = 0;
+        if (s1 > s0) {
+            c = 0xffffffffu;
+            for (int i = s0; i < s1; ++i) c = L.crc_table[(c ^ L.out[i]) & 0xffu] ^ (c >> 8);
+            c ^= 0xffffffffu;
+            // x^(8 (n - s1)) mod P by square and multiply (zlib x2nmodp)
+            uint32_t sq = 1u << 30; // x^1
+            uint32_t pw = 1u << 31; // x^0
+            uint32_t e = uint32_t(n - s1) * 8u;
+            while (e) {
+                if (e & 1u) pw = iw_multmodp(sq, pw);
+                sq = iw_multmodp(sq, sq);
+                e >>= 1;
+            }
+            c = iw_multmodp(pw, c);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
+        if (c != want_crc) err = INF_CRC_MISMATCH;
+        // the block to HBM: consecutive lanes, consecutive bytes (4 per lane where the destination allows)
+        uint8_t* dst = a.out + a.out_off[blk_i];
+        const int head = min(n, int((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
+        if (lane < head) dst[lane] = L.out[lane];
+        const int words = (n - head) / 4;
+        for (int w = lane; w < words; w += 64) {
+            const int o = head + 4 * w;
+            const uint32_t v = uint32_t(L.out[o]) | (uint32_t(L.out[o + 1]) << 8) | (uint32_t(L.out[o + 2]) << 16) | (uint32_t(L.out[o + 3]) << 24);
+            *reinterpret_cast<uint32_t*>(dst + o) = v;
+        }
+        for (int o = head + 4 * words + lane; o < n; o += 64) dst[o] = L.out[o];
+    }
+    if (lane == 0) a.status[blk_i] = err;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // BAM records (SAM spec 4.2): block_size, refID, pos, l_read_name, mapq, bin, n_cigar_op, flag, l_seq, next_refID, next_pos, tlen,
 // read_name, cigar[n_cigar_op] (len << 4 | op), seq[(l_seq+1)/2] (4 bits per base, high nibble first), qual[l_seq]
 
@@ -402,8 +818,22 @@ int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, c
     a.status = dev_status;
     a.n_blocks = n_blocks;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
+    // a wave per block up to the launch size where blocks in flight beat latency per block;
+    // $SK_INFLATE_KERNEL = thread | wave pins one (tests run every input through both)
+    bool wave = n_blocks <= 16384;
+    if (const char* e = std::getenv("SK_INFLATE_KERNEL")) wave = (std::strcmp(e, "wave") == 0) ? true : (std::strcmp(e, "thread") == 0) ? false : wave;
+    if (wave) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bgzf_inflate_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(sizeof(InflateWaveLds))));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(bgzf_inflate_wave_kernel, dim3(n_blocks), dim3(64), sizeof(InflateWaveLds), st, a);
+    } else {
+        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
+    }
     SK_HIP(hipGetLastError());
     return 0;
 }

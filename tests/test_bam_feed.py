@@ -105,6 +105,49 @@ def test_inflate_and_decode_equal_the_restatement(bam):
     assert set(np.unique(d["read_code"])) <= {1, 2, 4, 8, 15}  # what sk_read_input.read_code takes
 
 
+def _python_deflate_blocks(payloads, level):
+    """a BGZF image made here (zlib raw deflate at `level`; level 0 = stored blocks): [(block bytes)] joined"""
+    import struct
+    import zlib
+    out = bytearray()
+    for p in payloads:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(p) + c.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out += bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", bsize - 1) + body
+        out += struct.pack("<II", zlib.crc32(p) & 0xffffffff, len(p))
+    return bytes(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["thread", "wave"])
+def test_both_inflate_kernels_on_every_block_shape(kernel, monkeypatch):
+    """the thread-per-block and the wave-per-block kernels ($SK_INFLATE_KERNEL) on the fixture BAMs and on blocks made here: stored
+    blocks, fixed codes (tiny payloads), dynamic codes with long matches at short distances (runs), 64 KiB blocks, empty blocks, a
+    destination that is not 4-byte aligned, codes longer than the first-level table (skewed alphabets)"""
+    capi.init(0)
+    monkeypatch.setenv("SK_INFLATE_KERNEL", kernel)
+    rng = np.random.default_rng(12)
+    for bam in _more_bams()[:4]:
+        data = np.frombuffer(_bytes(bam), np.uint8)
+        assert capi.bgzf_inflate(data).tobytes() == bam_oracle.bgzf_inflate(data.tobytes())
+    skew = np.minimum(255, rng.geometric(0.02, 60000)).astype(np.uint8).tobytes()  # a long-tailed byte histogram: 14/15-bit codes
+    payloads = [b"", b"a", b"abc" * 5, bytes(65280), bytes([7]) * 3 + bytes(range(256)) * 200, rng.integers(0, 256, 65280, dtype=np.uint8).tobytes(),
+                rng.integers(0, 4, 65281, dtype=np.uint8).tobytes(), b"ACGT" * 16000 + b"N", skew, skew[:33333], b"xyz" * 333]
+    for level in (0, 1, 6, 9):
+        image = np.frombuffer(_python_deflate_blocks(payloads, level), np.uint8)
+        assert capi.bgzf_inflate(image).tobytes() == b"".join(payloads), level
+    # every way of breaking a block is refused by this kernel too
+    data = np.frombuffer(_bytes(TINY), np.uint8).copy()
+    block_off, out_off = capi.bgzf_scan(data)
+    out = np.zeros(int(out_off[-1]), np.uint8)
+    for at in (int(block_off[0]) + 40, int(block_off[0]) + 400, int(block_off[1]) - 7, int(block_off[1]) - 2):
+        bad = data.copy()
+        bad[at] ^= 0x5a
+        rc = capi.lib().sk_bgzf_inflate(capi._p(bad), capi._p(block_off), capi._p(out_off), len(block_off) - 1, capi._p(out))
+        assert rc != 0 and "block 0" in capi.last_error(), at
+
+
 @pytest.mark.gpu
 def test_malformed_blocks_are_refused():
     capi.init(0)
