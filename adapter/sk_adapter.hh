@@ -43,7 +43,7 @@ namespace sk_adapter
 {
 
 /// extra distance of the READ_BUFFER stage behind HEAD / of the POST_ALIGN stage behind READ_BUFFER
-/// ($STRELKA_AMD_READ_WINDOW / $STRELKA_AMD_SITE_WINDOW, default 256 / 512 positions)
+/// ($STRELKA_AMD_READ_WINDOW / $STRELKA_AMD_SITE_WINDOW, default 32768 / 65536 positions)
 unsigned read_buffer_defer();
 unsigned post_align_defer();
 

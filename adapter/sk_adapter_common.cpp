@@ -23,13 +23,15 @@ static unsigned env_unsigned(const char* name, const unsigned def)
 // and of >= 1500 positions gave different output on the reference's demo data.)
 unsigned read_buffer_defer()
 {
-    static const unsigned w(env_unsigned("STRELKA_AMD_READ_WINDOW", 2048));
+    // (32768: a caller process shares its GPU with the other segment processes of the node, and what a window costs there is the
+    // number of times the process waits for the device, not the work in it -- profiles/r03_v2_gpu_sharing.txt)
+    static const unsigned w(env_unsigned("STRELKA_AMD_READ_WINDOW", 32768));
     return w;
 }
 
 unsigned post_align_defer()
 {
-    static const unsigned w(env_unsigned("STRELKA_AMD_SITE_WINDOW", 4096));
+    static const unsigned w(env_unsigned("STRELKA_AMD_SITE_WINDOW", 65536));
     return w;
 }
 
@@ -37,6 +39,7 @@ void init()
 {
     static bool done(false);
     if (done) return;
+    AccumTimer initTimer(state().tInit);
     // segment process -> device: pyflow starts one process per genome segment; the launcher (or the workflow's task
     // wrapper) exports STRELKA_AMD_DEVICE = segment index mod number of GPUs.  Many processes may share a device.
     // (a launcher may count more devices than this node has: the index is taken modulo the devices present)
@@ -77,7 +80,7 @@ State& state()
                       << " genotyping=" << (s.pileup.isGenotyping ? 1 : 0) << "\n";
             std::cerr << "strelka_amd adapter seconds: realign_hook=" << s.tRealignHook << " realign_abi=" << s.tRealignAbi
                       << " site_hook=" << s.tSiteHook << " site_abi=" << s.tSiteAbi << " pileup_hook=" << s.tPileupHook
-                      << " pileup_abi=" << s.tPileupAbi << "\n";
+                      << " pileup_abi=" << s.tPileupAbi << " init=" << s.tInit << "\n";
         }
     };
     static Reporter r;

@@ -51,8 +51,8 @@ def parse():
     ap.add_argument("--somatic-loci", type=int, default=1 << 22, help="somatic loci per step per GPU (40x normal + 110x tumor)")
     ap.add_argument("--indels", type=int, default=1 << 18, help="indel loci per step per GPU for the indel legs (a11, a14)")
     ap.add_argument("--align-problems", type=int, default=4096, help="GlobalAligner problems per step (next row f2)")
-    ap.add_argument("--e2e-bp", type=int, default=8000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
-    ap.add_argument("--e2e-segment-bp", type=int, default=500000, help="segment size of the end-to-end leg (one caller process per segment)")
+    ap.add_argument("--e2e-bp", type=int, default=16000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
+    ap.add_argument("--e2e-segment-bp", type=int, default=1000000, help="segment size of the end-to-end leg (one caller process per segment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
     ap.add_argument("--cpu-loci", type=int, default=2000000, help="loci in the CPU-baseline sample")

@@ -1278,7 +1278,7 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     const int n_loci = end - begin;
 
     // ---- device input block: carried metadata + the new reads
-    struct Lay { int64_t read_off, path_off, path, pos, is_fwd, mapq, level, code, qual, ploidy, total; } li;
+    struct Lay { int64_t read_off, path_off, path, pos, is_fwd, mapq, level, code, qual, ploidy, mask, total; } li;
     {
         int64_t o = 0;
         li.read_off = o; o += align256(8 * (int64_t(n) + 1));
@@ -1291,6 +1291,7 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
         li.ploidy = o; o += align256(std::max(n_loci, 1));
         li.code = o; o += align256(std::max<int64_t>(n_bases, 1));
         li.qual = o; o += align256(std::max<int64_t>(n_bases, 1));
+        li.mask = o; o += align256(std::max(mask_len, 1));
         li.total = o;
     }
     if (s->h_in.need(size_t(li.total)) || s->d_in.need(size_t(li.total))) return sk_fail("sk_pileup_stream_push: out of memory (input block)");
@@ -1327,10 +1328,11 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
             pl[i] = (ploidy && k >= 0 && k < ploidy_len) ? ploidy[k] : uint8_t(2);
         }
     }
+    if (mask_len > 0) std::memcpy(hi + li.mask, cand_snv_mask, size_t(mask_len)); // (through the pinned block: a copy from the caller's pageable memory would wait for the device)
     char* di = static_cast<char*>(s->d_in.p);
     SK_HIP(hipMemcpyAsync(di, hi, size_t(li.total), hipMemcpyHostToDevice, st));
     if (mask_len > 0)
-        SK_HIP(hipMemcpyAsync(static_cast<char*>(s->d_mask.p) + (mask_begin - s->ref_offset), cand_snv_mask, size_t(mask_len), hipMemcpyHostToDevice, st));
+        SK_HIP(hipMemcpyAsync(static_cast<char*>(s->d_mask.p) + (mask_begin - s->ref_offset), di + li.mask, size_t(mask_len), hipMemcpyDeviceToDevice, st));
 
     // ---- records and spans: the carried tail moves to the front of the other buffer
     const int nxt = s->cur ^ 1;

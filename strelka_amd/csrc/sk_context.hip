@@ -7,6 +7,7 @@
 #include "libm_dbl64.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -195,6 +196,11 @@ int sk_init(int device)
     SkContext& c = g_ctx;
     if (c.ready && c.device == device) return 0;
     if (c.ready) sk_shutdown();
+    // One hardware queue per process unless the caller says otherwise: this library runs everything on one stream, and its
+    // processes are many per GPU (one per genome segment) -- with HIP's default of four queues per process, sixteen caller
+    // processes oversubscribe the device's queue slots and every wait turns into a scheduler time slice
+    // (profiles/r03_v2_gpu_sharing.txt).  Read by the HIP runtime when it first touches the device, i.e. below.
+    (void)setenv("GPU_MAX_HW_QUEUES", "1", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)

@@ -46,21 +46,22 @@ def main():
 
     print("%d bp, %d segments of %d bp, %d usable cores" % (L, len(groups), seg, cores), flush=True)
     run("starling2_amd", 1, {})  # warm
-    for jobs in (cores, max(1, cores // 2), max(1, cores // 4)):
+    for jobs in (cores,):
         w, ps, _ = run("starling2_ref", jobs, {})
         print("reference            jobs %2d: wall %.2f s, process seconds %.1f" % (jobs, w, ps), flush=True)
-    configs = [("default", {}), ("1 HW queue", {"GPU_MAX_HW_QUEUES": "1"}), ("2 HW queues", {"GPU_MAX_HW_QUEUES": "2"}),
-               ("windows 32k/64k", {"STRELKA_AMD_READ_WINDOW": "32768", "STRELKA_AMD_SITE_WINDOW": "65536"}),
-               ("windows 32k/64k, 1 queue", {"STRELKA_AMD_READ_WINDOW": "32768", "STRELKA_AMD_SITE_WINDOW": "65536", "GPU_MAX_HW_QUEUES": "1"}),
-               ("windows 128k/128k, 1 queue", {"STRELKA_AMD_READ_WINDOW": "131072", "STRELKA_AMD_SITE_WINDOW": "131072", "GPU_MAX_HW_QUEUES": "1"})]
-    for jobs in (cores, max(1, cores // 2), max(1, cores // 4), 1):
+    configs = [("default (32k/64k, 1 queue)", {}), ("4 HW queues", {"GPU_MAX_HW_QUEUES": "4"}),
+               ("windows 2k/4k", {"STRELKA_AMD_READ_WINDOW": "2048", "STRELKA_AMD_SITE_WINDOW": "4096"}),
+               ("windows 8k/16k", {"STRELKA_AMD_READ_WINDOW": "8192", "STRELKA_AMD_SITE_WINDOW": "16384"}),
+               ("device enumeration always", {"SK_ENUMERATION": "2"}), ("host enumeration always", {"SK_ENUMERATION": "0"}),
+               ("reference pileup", {"STRELKA_AMD_PILEUP": "0"}), ("reference feed", {"STRELKA_AMD_FEED": "0"})]
+    for jobs in (cores, 1):
         for label, env in configs:
-            if jobs != cores and label not in ("default", "windows 32k/64k, 1 queue"):
+            if jobs != cores and not label.startswith("default"):
                 continue
             w, ps, hooks = run("starling2_amd", jobs, env)
-            print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f, abi seconds realign %.2f pileup %.2f (hooks %.2f / %.2f)" %
-                  (label, jobs, w, ps, hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("realign_hook", 0), hooks.get("pileup_hook", 0)),
-                  flush=True)
+            print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f, init %.2f, abi seconds realign %.2f pileup %.2f (hooks %.2f / %.2f)" %
+                  (label, jobs, w, ps, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("realign_hook", 0),
+                   hooks.get("pileup_hook", 0)), flush=True)
 
 
 if __name__ == "__main__":
