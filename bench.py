@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--somatic-loci", type=int, default=1 << 22, help="somatic loci per step per GPU (40x normal + 110x tumor)")
     ap.add_argument("--indels", type=int, default=1 << 18, help="indel loci per step per GPU for the indel legs (a11, a14)")
     ap.add_argument("--align-problems", type=int, default=4096, help="GlobalAligner problems per step (next row f2)")
+    ap.add_argument("--a5-scenarios", type=int, default=12, help="scenarios (jobs) of the flatten + score leg")
+    ap.add_argument("--a5-reads", type=int, default=1 << 12, help="reads per job of the flatten + score leg")
+    ap.add_argument("--a5-reps", type=int, default=3)
     ap.add_argument("--e2e-bp", type=int, default=16000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
     ap.add_argument("--e2e-segment-bp", type=int, default=1000000, help="segment size of the end-to-end leg (one caller process per segment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -233,6 +236,65 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
         shutil.rmtree(root, ignore_errors=True)
 
 
+def a5_leg(args, capi, synth):
+    """Row a5 measured as ONE function, like the reference's (scoreCandidateAlignment, starling_read_align_score.cpp:261-499):
+    from the candidate alignments as the search left them on the device (position, path, indel indices: PCal) to one double each --
+    the haplotype bytes an alignment faces, its ops, every base comparison (kernels F1-F3) AND the table sums (A1c).  150 bp reads
+    over a window with 5-7 candidate indels (the densest of a dozen seeded scenarios); the job is enumerated on the device once,
+    outside the clock; a step = sk_realign_job_rescore(1): flattening + scoring of the resident records, timed by stream events.
+    -> (step function, per-step meta, list the step appends its event milliseconds to)"""
+    rng = np.random.default_rng(4242)
+    scenarios = synth.realign_scenarios(args.a5_scenarios, rng, reads_per=16, max_indels=7, min_indels=5, read_len=(150, 151), window=(330, 420),
+                                        haplotyping_rate=0.0)
+    best = None
+    for sc in scenarios:
+        keep, inputs = [], []
+        for rd in sc["reads"]:
+            code = np.ascontiguousarray(rd["code"], np.uint8)
+            qual = np.ascontiguousarray(rd["qual"], np.uint8)
+            segs = (capi.PathSeg * max(len(rd["path"]), 1))(*[capi.PathSeg(t, l) for t, l in rd["path"]])
+            obs = (C.c_int32 * max(len(rd["observed"]), 1))(*rd["observed"])
+            keep.append((code, qual, segs, obs))
+            inputs.append(capi.ReadInput(capi._p(code), capi._p(qual), len(code), rd["pos"], len(rd["path"]), segs, int(rd["is_fwd"]),
+                                         rd["map_level"], 0, rd["realign_range"][0], rd["realign_range"][1], len(rd["observed"]), obs))
+        probe = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=0, min_read_bp_flank=sc["min_read_bp_flank"], enumeration=0))
+        probe.set_reference(sc["ref_seq"], sc["ref_offset"])
+        probe.set_indels(sc["indels"])
+        ok = [r for r in inputs if capi.lib().sk_realign_job_add_read(probe._j, C.byref(r)) >= 0]
+        if ok:
+            probe.run()
+            cals = probe.batch().n_cals / len(ok)
+            if best is None or cals > best[0]:
+                best = (cals, sc, ok, keep)
+        del probe
+    if best is None:
+        raise RuntimeError("a5 leg: no scenario passed the gate")
+    _, sc, ok, keep = best
+    job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=0, min_read_bp_flank=sc["min_read_bp_flank"], enumeration=2))
+    job.set_reference(sc["ref_seq"], sc["ref_offset"])
+    job.set_indels(sc["indels"])
+    n = max(len(ok), args.a5_reads // len(ok) * len(ok))
+    arr = (capi.ReadInput * n)(*[ok[i % len(ok)] for i in range(n)])
+    if capi.lib().sk_realign_job_add_reads(job._j, arr, n) < 0:
+        raise RuntimeError("sk_realign_job_add_reads failed")
+    job.run()
+    ms, nr, nc, cells = C.c_float(0), C.c_int32(0), C.c_int32(0), C.c_int64(0)
+    event_ms = []
+
+    def step():
+        if capi.lib().sk_realign_job_rescore(1, C.byref(ms), C.byref(nr), C.byref(nc), C.byref(cells)) != 0:
+            raise RuntimeError("sk_realign_job_rescore: " + capi.last_error())
+        event_ms.append(ms.value)
+    step()
+    del event_ms[:]
+    n_core, n_dev, n_fall = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    capi.lib().sk_realign_job_enumeration_counts(job._j, C.byref(n_core), C.byref(n_dev), C.byref(n_fall))
+    meta = {"reads": nr.value, "candidate_alignments": nc.value, "candidate_alignments_per_read": nc.value / max(1, nr.value), "cells": cells.value,
+            "reads_enumerated_on_device": n_dev.value, "reads_handed_back_to_host": n_fall.value,
+            "algorithmic_bytes": 2 * 150 * nr.value + (160 + 8) * nc.value, "_keep": (job, arr, keep)}
+    return step, meta, event_ms
+
+
 def pmc_traffic(args):
     """HBM bytes per launch from the newest committed PMC summary (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes over this same command, tools/gpu_round.sh) -- used only when that run had the same
@@ -297,6 +359,12 @@ def main():
     value = cells / dt_a
     alg_bytes_a = A_BYTES_PER_READ * da.n_reads
     ach_a = alg_bytes_a / (kms_a * 1e-3) / 1e9
+
+    # ---- a5 as one function: flattening + scoring from the resident candidate alignments (the headline) ----
+    a5_step, a5_meta, a5_event_ms = a5_leg(args, capi, synth)
+    dt_a5, a5_cells, _ = timed(a5_step, args.steps, args.warmup, a5_meta["cells"])
+    kms_a5 = float(np.mean(a5_event_ms[-args.steps:]))
+    a5_keep = a5_meta.pop("_keep")
 
     # ---- hot path B (germline): dependent eprob + site genotype call ----
     def step_b():

@@ -338,6 +338,12 @@ int sk_realign_job_enumeration_counts(const sk_realign_job* job, int64_t* n_core
 int sk_realign_job_stage3_counts(const sk_realign_job* job, int64_t* n_core, int64_t* n_device);
 /** drop reads and results, keep reference/indels/options */
 void sk_realign_job_clear_reads(sk_realign_job* job);
+/** Measurement: scoreCandidateAlignment (L/starling_common/starling_read_align_score.cpp:261-499) as the device pipeline performs it for
+ *  the job that ran last with enumeration == 2 -- from the candidate alignments as the search left them (position, path, indels)
+ *  to one double each: the haplotype bytes every alignment faces, its ops, the base comparisons (F1-F3) AND the table sums (A1c),
+ *  `reps` times over the resident records.  out_ms: elapsed time of all repetitions (events on the library's stream);
+ *  cells = read bases x candidate alignments of one repetition. */
+int sk_realign_job_rescore(int32_t reps, float* out_ms, int32_t* out_n_reads, int32_t* out_n_cals, int64_t* out_cells);
 
 /* building blocks, exposed for known-answer tests against the reference's own unit tests
  * (L/starling_common/test/starling_read_align_test.cpp:67-335) */

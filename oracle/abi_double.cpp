@@ -313,6 +313,10 @@ struct SkEnumOutput;
 extern "C" int sk_enum_device_available(void) { return 0; }
 namespace skcore { struct PCal; }
 extern "C" int sk_enum_device_fetch_cals(uint64_t, int32_t, int32_t, skcore::PCal*) { return 1; }
+extern "C" int sk_enum_device_rescore(int32_t, float*, int32_t*, int32_t*, int64_t*)
+{
+    return sk_fail("sk_realign_job_rescore measures the GPU library's kernels");
+}
 extern "C" int sk_enum_device_run(const SkEnumInput*, SkEnumOutput*)
 {
     return sk_fail("candidate enumeration on the device (sk_realign_options.enumeration = 2) needs the GPU library");

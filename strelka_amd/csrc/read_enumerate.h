@@ -58,3 +58,5 @@ extern "C" int sk_enum_device_fetch_cals(uint64_t generation, int32_t first, int
 /** whether enumeration == 2 can run (it is the default where it can): 1 in the GPU library once sk_init has succeeded, 0 before
  *  that and in the CPU double of the ABI */
 extern "C" int sk_enum_device_available(void);
+// bench: F1-F3 + scoring over the last run's resident candidate alignments, `reps` times; elapsed milliseconds (stream events)
+extern "C" int sk_enum_device_rescore(int32_t reps, float* out_ms, int32_t* out_n_reads, int32_t* out_n_cals, int64_t* out_cells);

@@ -930,6 +930,18 @@ namespace
 {
 uint64_t g_generation = 0; // of the run whose candidate alignments the buffers hold
 int32_t g_n_cals = 0;
+
+// what sk_enum_device_rescore needs to run F1-F3 + the scoring kernel again on the candidate alignments of the last run
+struct LastFlat
+{
+    bool valid = false;
+    FlatArgs fa;
+    sk_align_batch d;
+    int32_t n = 0, n_cals = 0;
+    int64_t cells = 0;
+    size_t mask_bytes = 0, colmat_bytes = 0;
+    double* scores = nullptr;
+} g_last;
 } // namespace
 
 extern "C" int sk_enum_device_fetch_cals(const uint64_t generation, const int32_t first, const int32_t count, PCal* dst)
@@ -950,6 +962,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     std::memset(out, 0, sizeof(*out));
     out->generation = ++g_generation;
     g_n_cals = 0;
+    g_last.valid = false;
     const int n = in->n_reads;
     if (n < 0 || in->n_tab < 0) return sk_fail("sk_enum_device_run: negative count");
     SkContext& ctx = sk_ctx();
@@ -1341,6 +1354,16 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
             d.addmask = fa.addmask;
             if (sk_score_alignments_launch_hostleg(&d, B.scores.as<double>(), st)) return 1;
             lap("A1 score");
+            g_last.fa = fa;
+            g_last.d = d;
+            g_last.n = n;
+            g_last.n_cals = n_cals;
+            g_last.mask_bytes = mask_bytes;
+            g_last.colmat_bytes = 4 * size_t(colmat_words) + 16;
+            g_last.scores = B.scores.as<double>();
+            g_last.cells = 0;
+            for (int r = 0; r < n; ++r) g_last.cells += (in->read_off[r + 1] - in->read_off[r]) * int64_t(h_cal_off[r + 1] - h_cal_off[r]);
+            g_last.valid = true;
             D2H(h_scores, scores, 8 * size_t(n_cals));
             out->scores = B.h_scores.as<double>();
             if (in->want_stage3) {
@@ -1437,5 +1460,43 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
 #undef HRES
 #undef H2D
 #undef D2H
+    return 0;
+}
+
+// Measurement entry (bench.py's a5 leg): flattening AND scoring of the candidate alignments the last run left on the device -- pool
+// bytes, ops, transition entries, masks and column words rebuilt from the PCal records (F1-F3), then the scoring kernel over them --
+// `reps` times, timed with events on the library's stream.  This is what sk_enum_device_run does between the sets (E2) and stage 3,
+// minus the layout pass (L1/L2: per-read pool bounds and op counts, whose results -- offsets -- a steady state already has).
+extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t* out_n_reads, int32_t* out_n_cals, int64_t* out_cells)
+{
+    SK_REQUIRE_INIT();
+    if (!g_last.valid) return sk_fail("sk_enum_device_rescore: no device run with scores to repeat");
+    if (reps <= 0 || !out_ms) return sk_fail("sk_enum_device_rescore: bad argument");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    EnumBuffers& B = bufs();
+    const FlatArgs& fa = g_last.fa;
+    hipEvent_t e0, e1;
+    SK_HIP(hipEventCreate(&e0));
+    SK_HIP(hipEventCreate(&e1));
+    SK_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) {
+        SK_HIP(hipMemsetAsync(B.mask_arena.p, 0, g_last.mask_bytes, st));
+        SK_HIP(hipMemsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), g_last.colmat_bytes, st));
+        hipLaunchKernelGGL(pool_fill_kernel, dim3(g_last.n), dim3(64), 0, st, fa);
+        hipLaunchKernelGGL(flatten_kernel, dim3((g_last.n_cals + 63) / 64), dim3(64), 0, st, fa);
+        hipLaunchKernelGGL(entries_kernel, dim3((g_last.n_cals + 63) / 64), dim3(64), 0, st, fa);
+        if (sk_score_alignments_launch_hostleg(&g_last.d, g_last.scores, st)) return 1;
+    }
+    SK_HIP(hipEventRecord(e1, st));
+    SK_HIP(hipEventSynchronize(e1));
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipEventElapsedTime(out_ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (out_n_reads) *out_n_reads = g_last.n;
+    if (out_n_cals) *out_n_cals = g_last.n_cals;
+    if (out_cells) *out_cells = g_last.cells;
     return 0;
 }

@@ -132,6 +132,8 @@ class FarmResult:
     def __init__(self):
         self.wall_s = 0.0
         self.process_s = []     # per process wall time
+        self.user_s = []        # ... user CPU seconds (all its threads)
+        self.sys_s = []         # ... system CPU seconds
         self.outputs = {}       # file name -> joined output path
         self.stderr_tails = []
 
@@ -154,6 +156,7 @@ def run_farm(groups, argv_fn, out_dir, output_names, n_gpus=1, jobs=None, device
     free_slots = list(range(jobs))
     t_start = time.perf_counter()
     done = {}
+    usage = {}
 
     def launch(slot, index, group):
         prefix = os.path.join(out_dir, "seg%04d." % index)
@@ -173,7 +176,19 @@ def run_farm(groups, argv_fn, out_dir, output_names, n_gpus=1, jobs=None, device
             slot = free_slots.pop(0)
             index, group = pending.pop(0)
             launch(slot, index, group)
-        finished = [s for s, (_, p, _, _, _) in running.items() if p.poll() is not None]
+        finished = []
+        for slot_, (_, p_, _, _, _) in list(running.items()):
+            if p_.returncode is not None:
+                finished.append(slot_)
+                continue
+            try:
+                pid, status, ru = os.wait4(p_.pid, os.WNOHANG)
+            except ChildProcessError:
+                pid, status, ru = p_.pid, 0, None
+            if pid == p_.pid:
+                p_.returncode = os.waitstatus_to_exitcode(status) if ru is not None else (p_.poll() or 0)
+                usage[p_.pid] = ru
+                finished.append(slot_)
         if not finished:
             time.sleep(0.002)
             continue
@@ -186,10 +201,13 @@ def run_farm(groups, argv_fn, out_dir, output_names, n_gpus=1, jobs=None, device
                     e2.close()
                 with open(prefix + "stderr.txt", "rb") as f:
                     raise RuntimeError("segment process %d failed (%d):\n%s" % (index, p.returncode, f.read().decode(errors="replace")[-3000:]))
-            done[index] = (time.perf_counter() - t0, prefix)
+            ru = usage.get(p.pid)
+            done[index] = (time.perf_counter() - t0, prefix, ru.ru_utime if ru else 0.0, ru.ru_stime if ru else 0.0)
             free_slots.append(slot)
     res.wall_s = time.perf_counter() - t_start
     res.process_s = [done[i][0] for i in sorted(done)]
+    res.user_s = [done[i][2] for i in sorted(done)]
+    res.sys_s = [done[i][3] for i in sorted(done)]
     for i in sorted(done):
         with open(done[i][1] + "stderr.txt", "rb") as f:
             res.stderr_tails.append(f.read().decode(errors="replace")[-2000:])

@@ -1960,6 +1960,11 @@ int sk_realign_job_set_indels(sk_realign_job* j, const sk_indel_info* indels, in
     return 0;
 }
 
+int sk_realign_job_rescore(const int32_t reps, float* out_ms, int32_t* out_n_reads, int32_t* out_n_cals, int64_t* out_cells)
+{
+    return sk_enum_device_rescore(reps, out_ms, out_n_reads, out_n_cals, out_cells);
+}
+
 int sk_realign_job_enumeration_counts(const sk_realign_job* j, int64_t* n_core, int64_t* n_device, int64_t* n_fallback)
 {
     if (!j) return 1;

@@ -480,13 +480,15 @@ def _conflict(a, b):
     return a["pos"] <= b["pos"] + b["del_len"] and b["pos"] <= a["pos"] + a["del_len"]
 
 
-def realign_scenarios(n, rng, reads_per=6, haplotyping_rate=0.25, max_indels=6):
+def realign_scenarios(n, rng, reads_per=6, haplotyping_rate=0.25, max_indels=6, read_len=(40, 101), window=(160, 360), min_indels=1):
+    """read_len / window: half-open ranges of the read length and of the reference window; min_indels..max_indels candidate
+    indels per scenario (bench.py's a5 leg asks for 150 bp reads over 6 indels: ~64 candidate alignments per read)"""
     out = []
     for _ in range(n):
-        L = int(rng.integers(160, 360))
+        L = int(rng.integers(window[0], window[1]))
         off = int(rng.choice([0, 0, 1000, 25000]))
         ref = _random_ref(L, rng)
-        n_ind = int(rng.integers(1, max_indels + 1))
+        n_ind = int(rng.integers(min_indels, max_indels + 1))
         indels = []
         for _k in range(n_ind * 3):
             if len(indels) >= n_ind:
@@ -536,7 +538,7 @@ def realign_scenarios(n, rng, reads_per=6, haplotyping_rate=0.25, max_indels=6):
                 if rng.random() < 0.5 and not any(_conflict(indels[i], indels[j]) for j in hap):
                     hap.append(int(i))
             hap.sort(key=lambda i: (indels[i]["pos"], indels[i]["del_len"]))
-            rl = int(rng.integers(40, 101))
+            rl = int(rng.integers(read_len[0], read_len[1]))
             start = off + int(rng.integers(0, max(1, L - rl - 35)))
             # walk the haplotype from `start`
             seq, path, used, p, hi = [], [], [], start, 0

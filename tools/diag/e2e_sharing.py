@@ -40,27 +40,26 @@ def main():
                     for kv in m.group(1).split():
                         k, v = kv.split("=")
                         hooks[k] = hooks.get(k, 0.0) + float(v)
-            return r.wall_s, sum(r.process_s), hooks
+            return r.wall_s, sum(r.process_s), hooks, sum(r.user_s), sum(r.sys_s)
         finally:
             shutil.rmtree(root, ignore_errors=True)
 
     print("%d bp, %d segments of %d bp, %d usable cores" % (L, len(groups), seg, cores), flush=True)
-    run("starling2_amd", 1, {})  # warm
+    run("starling2_amd", cores, {})  # warm
     for jobs in (cores,):
-        w, ps, _ = run("starling2_ref", jobs, {})
-        print("reference            jobs %2d: wall %.2f s, process seconds %.1f" % (jobs, w, ps), flush=True)
-    configs = [("default (32k/64k, 1 queue)", {}), ("4 HW queues", {"GPU_MAX_HW_QUEUES": "4"}),
-               ("windows 2k/4k", {"STRELKA_AMD_READ_WINDOW": "2048", "STRELKA_AMD_SITE_WINDOW": "4096"}),
-               ("windows 8k/16k", {"STRELKA_AMD_READ_WINDOW": "8192", "STRELKA_AMD_SITE_WINDOW": "16384"}),
-               ("device enumeration always", {"SK_ENUMERATION": "2"}), ("host enumeration always", {"SK_ENUMERATION": "0"}),
-               ("reference pileup", {"STRELKA_AMD_PILEUP": "0"}), ("reference feed", {"STRELKA_AMD_FEED": "0"})]
+        w, ps, _, us, ss = run("starling2_ref", jobs, {})
+        print("reference            jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f)" % (jobs, w, ps, us, ss), flush=True)
+    malloc_env = {"MALLOC_TRIM_THRESHOLD_": "2147483647", "MALLOC_TOP_PAD_": "268435456", "MALLOC_MMAP_THRESHOLD_": "1073741824"}
+    configs = [("default", {}), ("malloc keeps its memory", malloc_env), ("HSA_XNACK=0", {"HSA_XNACK": "0"}),
+               ("reference feed", {"STRELKA_AMD_FEED": "0"}), ("malloc + reference feed", dict(malloc_env, STRELKA_AMD_FEED="0")),
+               ("no SDMA", {"HSA_ENABLE_SDMA": "0"})]
     for jobs in (cores, 1):
         for label, env in configs:
             if jobs != cores and not label.startswith("default"):
                 continue
-            w, ps, hooks = run("starling2_amd", jobs, env)
-            print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f, init %.2f, abi seconds realign %.2f pileup %.2f (hooks %.2f / %.2f)" %
-                  (label, jobs, w, ps, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("realign_hook", 0),
+            w, ps, hooks, us, ss = run("starling2_amd", jobs, env)
+            print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f (hooks %.2f / %.2f)" %
+                  (label, jobs, w, ps, us, ss, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("realign_hook", 0),
                    hooks.get("pileup_hook", 0)), flush=True)
 
 
