@@ -34,7 +34,7 @@ HOOKS = [
         ("READ_BUFFER stage distance", r'\+HAPLOTYPING_PADDING\);', '+HAPLOTYPING_PADDING+sk_adapter::read_buffer_defer());'),
         ("POST_ALIGN stage distance",
          r'sdata\.add_stage\(POST_ALIGN,READ_BUFFER,largest_total_indel_ref_span_per_read\);',
-         'sdata.add_stage(POST_ALIGN,READ_BUFFER,largest_total_indel_ref_span_per_read+sk_adapter::post_align_defer());'),
+         'sdata.add_stage(POST_ALIGN,READ_BUFFER,largest_total_indel_ref_span_per_read+sk_adapter::post_align_defer(opt));'),
         # empty-site genotypes of the constructor (site 3 with zero-depth loci)
         ("empty-site precompute",
          r'_dopt\.pdcaller\(\)\.position_snp_call_pprob_digt\(_opt,good_epi,\s*\*_empty_dgt\[b\],\s*_opt\.is_all_sites\(\)\);',

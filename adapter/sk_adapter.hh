@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 
+struct starling_base_options;
 struct starling_pos_processor_base;
 struct starling_pos_processor;
 struct strelka_pos_processor;
@@ -43,9 +44,13 @@ namespace sk_adapter
 {
 
 /// extra distance of the READ_BUFFER stage behind HEAD / of the POST_ALIGN stage behind READ_BUFFER
-/// ($STRELKA_AMD_READ_WINDOW / $STRELKA_AMD_SITE_WINDOW, default 32768 / 65536 positions)
+/// ($STRELKA_AMD_READ_WINDOW / $STRELKA_AMD_SITE_WINDOW, default 8192 positions / 0 with the pileup stream, else 4096)
 unsigned read_buffer_defer();
 unsigned post_align_defer();
+/// the same, decided on first use from the options: a run whose genotypes come with the pileup stream (site 9) has nothing to batch at
+/// POST_ALIGN and keeps the reference's distance (0) -- every deferred position is a position's worth of pileup and read buffer kept
+/// alive, and the host code runs out of cache long before the device runs out of work
+unsigned post_align_defer(const starling_base_options& opt);
 
 /// select the device ($STRELKA_AMD_DEVICE, default 0) and sk_init(); throws blt_exception on failure.  Idempotent.
 void init();

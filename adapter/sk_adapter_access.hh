@@ -154,6 +154,7 @@ State& state();
 
 // site 9 internals (sk_adapter_pileup.cpp)
 bool pileup_enabled(starling_pos_processor_base& pp);
+bool pileup_genotypes_with_stream(const starling_base_options& opt);
 void pileup_reset_region(starling_pos_processor_base& pp);
 void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos);
 void pileup_note_read(const unsigned sampleIndex, const pos_t bufferPos);

@@ -23,16 +23,30 @@ static unsigned env_unsigned(const char* name, const unsigned def)
 // and of >= 1500 positions gave different output on the reference's demo data.)
 unsigned read_buffer_defer()
 {
-    // (32768: a caller process shares its GPU with the other segment processes of the node, and what a window costs there is the
-    // number of times the process waits for the device, not the work in it -- profiles/r03_v2_gpu_sharing.txt)
-    static const unsigned w(env_unsigned("STRELKA_AMD_READ_WINDOW", 32768));
+    // (a caller process shares its GPU with the other segment processes of the node: what a window costs there is the number of
+    // times the process waits for the device, not the work in it; what a LARGE window costs is the host's cache -- everything between
+    // the head and the deferred stages is kept alive; profiles/r03_v2..v5_gpu_sharing*.txt)
+    static const unsigned w(env_unsigned("STRELKA_AMD_READ_WINDOW", 8192));
     return w;
 }
 
+static int g_postAlignDefer(-1);
+
 unsigned post_align_defer()
 {
-    static const unsigned w(env_unsigned("STRELKA_AMD_SITE_WINDOW", 65536));
-    return w;
+    if (g_postAlignDefer < 0) g_postAlignDefer = static_cast<int>(env_unsigned("STRELKA_AMD_SITE_WINDOW", 4096));
+    return static_cast<unsigned>(g_postAlignDefer);
+}
+
+unsigned post_align_defer(const starling_base_options& opt)
+{
+    if (g_postAlignDefer < 0)
+    {
+        const char* v(std::getenv("STRELKA_AMD_SITE_WINDOW"));
+        if (v != nullptr && *v != 0) g_postAlignDefer = static_cast<int>(std::strtoul(v, nullptr, 10));
+        else g_postAlignDefer = pileup_genotypes_with_stream(opt) ? 0 : 4096;
+    }
+    return static_cast<unsigned>(g_postAlignDefer);
 }
 
 void init()

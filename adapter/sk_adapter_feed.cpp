@@ -55,7 +55,22 @@ struct BamFile
 
 struct Feed
 {
-    std::vector<uint8_t> bytes;  // the region's records, raw (block_size field included), one after the other
+    // ---- the region as a stream: the reference's iterator holds one record at a time (hts_itr_next); this one holds one SLICE of
+    // at most SLICE_BLOCKS BGZF blocks -- inflated, scanned, decoded, filtered and normalised in one call each -- and refills from
+    // next() when the slice is used up, carrying a record the slice end cut over to the next slice
+    BamFile* file = nullptr;
+    std::string name;
+    int tid = 0, begin = 0, end = 0;
+    std::vector<sk_bai_chunk> chunks;
+    size_t chunk = 0;          // the chunk being read
+    bool chunk_open = false;
+    int64_t file_at = 0;       // file offset of the next BGZF block of the chunk
+    int64_t first_offset = 0;  // where the first record starts in the next slice's stream (the chunk's in-block offset, then 0)
+    int64_t limit = -1;        // the chunk's end in the next slice's stream, once the block holding it has been read; -1: not yet
+    std::vector<uint8_t> carry; // the bytes of the record the last slice ended in
+    bool finished = false;     // the iterator's end: a record past the region was seen, or every chunk is used up
+    // ---- the current slice
+    std::vector<uint8_t> bytes;  // its records, raw (block_size field included), one after the other
     std::vector<size_t> rec_at;
     size_t next = 0;
     // what sk_bam_decode made of them: bases (BAM codes, one per byte), CIGAR as path segments, position
@@ -133,82 +148,109 @@ inline uint32_t le32(const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1])
 
 } // namespace
 
-bool feed_reset_region(const void* streamer, const char* name, const int tid, const int begin, const int end)
+constexpr int32_t SLICE_BLOCKS = 512; // BGZF blocks per slice: at most 32 MiB of inflated bytes in flight per stream
+
+/// the next slice of the region into `feed` (records, decoded fields); false: the region is used up
+bool feed_refill(Feed& feed)
 {
-    fs().feeds.erase(streamer);
-    if (const char* e = std::getenv("STRELKA_AMD_FEED"))
-        if (std::atoi(e) == 0) return false;
-    BamFile& bf = bam_file(name);
-    if (!bf.usable) return false;
-    init();
-    Feed feed;
-    const int32_t n_chunks = sk_bai_query(bf.bai.data(), int64_t(bf.bai.size()), tid, begin, end, nullptr, 0);
-    if (n_chunks == -2) return false; // (a reference the index does not know: htslib's iterator decides what that means)
-    if (n_chunks < 0) fail("malformed .bai", name);
-    std::vector<sk_bai_chunk> chunks(size_t(n_chunks) + 1);
-    if (n_chunks > 0 && sk_bai_query(bf.bai.data(), int64_t(bf.bai.size()), tid, begin, end, chunks.data(), n_chunks) != n_chunks) fail("index query", name);
-    bool finished = false;
-    std::vector<uint8_t> raw, stream, keep;
-    std::vector<int64_t> block_off, out_off, rec_off, read_off, path_off;
-    std::vector<sk_bam_record> rec;
-    std::vector<uint8_t> code, qual;
-    std::vector<sk_path_seg> path;
-    for (int32_t c = 0; c < n_chunks && !finished; ++c) {
-        const int64_t cb = int64_t(chunks[size_t(c)].begin >> 16), ce = int64_t(chunks[size_t(c)].end >> 16);
-        const int64_t ub = int64_t(chunks[size_t(c)].begin & 0xffff), ue = int64_t(chunks[size_t(c)].end & 0xffff);
-        // the chunk's blocks: from the one at cb to the one at ce, and further ones while its last record is cut
-        int64_t want_to = std::min<int64_t>(bf.size, ce + 2 * 65536);
-        for (;;) {
-            raw.resize(size_t(want_to - cb));
-            if (::pread(bf.fd, raw.data(), raw.size(), off_t(cb)) != ssize_t(raw.size())) fail("short read", name);
-            // whole blocks of the range (sk_bgzf_scan wants whole blocks: cut the range after the last one that is whole)
+    static std::vector<uint8_t> raw, stream, keep;
+    static std::vector<int64_t> block_off, out_off, rec_off, read_off, path_off;
+    static std::vector<sk_bam_record> rec;
+    static std::vector<uint8_t> code, qual;
+    static std::vector<sk_path_seg> path;
+    BamFile& bf(*feed.file);
+    const char* name(feed.name.c_str());
+    feed.bytes.clear();
+    feed.rec_at.clear();
+    feed.next = 0;
+    feed.read_off.assign(1, 0);
+    feed.path_off.assign(1, 0);
+    feed.code.clear();
+    feed.path.clear();
+    feed.pos.clear();
+    feed.mapped.clear();
+    feed.normalized = false;
+    feed.n_path_in.clear();
+    feed.n_seg_in.clear();
+    feed.n_pos_in.clear();
+    while (feed.rec_at.empty() && !feed.finished) {
+        if (!feed.chunk_open) {
+            if (feed.chunk >= feed.chunks.size()) {
+                feed.finished = true;
+                break;
+            }
+            feed.file_at = int64_t(feed.chunks[feed.chunk].begin >> 16);
+            feed.first_offset = int64_t(feed.chunks[feed.chunk].begin & 0xffff);
+            feed.limit = -1;
+            feed.carry.clear();
+            feed.chunk_open = true;
+        }
+        const int64_t ce = int64_t(feed.chunks[feed.chunk].end >> 16), ue = int64_t(feed.chunks[feed.chunk].end & 0xffff);
+        // the slice's blocks: whole blocks from file_at on, SLICE_BLOCKS at most; once the chunk's last block is among them, only the
+        // few more a record cut by it can reach into
+        const int64_t want = std::min<int64_t>(bf.size - feed.file_at, int64_t(SLICE_BLOCKS) * 65536);
+        bool chunk_done = false;
+        if (want <= 0) {
+            chunk_done = true;
+        } else {
+            raw.resize(size_t(want));
+            if (::pread(bf.fd, raw.data(), raw.size(), off_t(feed.file_at)) != ssize_t(raw.size())) fail("short read", name);
             block_off.assign(1, 0);
             out_off.assign(1, 0);
             int64_t at = 0;
-            while (at + 18 <= int64_t(raw.size())) {
+            int32_t past_end = 0;
+            while (int32_t(block_off.size()) - 1 < SLICE_BLOCKS && at + 18 <= int64_t(raw.size())) {
                 if (raw[size_t(at)] != 31 || raw[size_t(at) + 1] != 139) fail("not a BGZF block where the index points", name);
                 int64_t bsize = -1;
                 const int64_t xlen = raw[size_t(at) + 10] | (raw[size_t(at) + 11] << 8);
-                for (int64_t x = 0; x + 4 <= xlen && at + 12 + x + 4 <= int64_t(raw.size());) {
+                if (at + 12 + xlen > int64_t(raw.size())) break; // (the header itself is cut: not a whole block)
+                for (int64_t x = 0; x + 4 <= xlen;) {
                     const uint8_t* sf = raw.data() + at + 12 + x;
                     const int64_t slen = sf[2] | (sf[3] << 8);
-                    if (sf[0] == 66 && sf[1] == 67 && slen == 2 && at + 12 + x + 6 <= int64_t(raw.size())) bsize = (sf[4] | (sf[5] << 8)) + 1;
+                    if (x + 4 + slen > xlen) fail("malformed BGZF extra field", name);
+                    if (sf[0] == 66 && sf[1] == 67 && slen == 2) bsize = (sf[4] | (sf[5] << 8)) + 1;
                     x += 4 + slen;
                 }
-                if (bsize < 0 || at + bsize > int64_t(raw.size())) break;
+                if (bsize < 0) fail("BGZF block without its BC subfield", name);
+                if (bsize < 12 + xlen + 8) fail("BGZF block shorter than its header and trailer", name); // (before the trailer is read)
+                if (at + bsize > int64_t(raw.size())) break;
+                if (feed.file_at + at > ce && ++past_end > 2) break;
                 out_off.push_back(out_off.back() + int64_t(le32(raw.data() + at + bsize - 4)));
                 at += bsize;
                 block_off.push_back(at);
             }
             const int32_t nb = int32_t(block_off.size()) - 1;
-            if (nb == 0) fail("no whole BGZF block in the chunk", name);
-            stream.resize(size_t(out_off.back()) + 8);
-            if (sk_bgzf_inflate(raw.data(), block_off.data(), out_off.data(), nb, stream.data())) fail(std::string("inflate: ") + sk_last_error(), name);
-            fs().blocks += unsigned(nb);
-            fs().inflated += (unsigned long)out_off.back();
-            // where the chunk ends in the inflated bytes: the block at ce (if it is among these) + ue
-            int64_t limit = out_off.back();
-            bool end_block_here = false;
-            for (int32_t b = 0; b <= nb; ++b)
-                if (cb + block_off[size_t(b)] == ce) {
-                    limit = out_off[size_t(b)] + ue;
-                    end_block_here = true;
+            if (nb == 0) {
+                chunk_done = true; // (the file ends in a cut block, or the chunk's end was passed: nothing more to read for it)
+            } else {
+                const int64_t carried = int64_t(feed.carry.size());
+                stream.resize(size_t(carried + out_off.back()) + 8);
+                if (carried) std::memcpy(stream.data(), feed.carry.data(), size_t(carried));
+                if (sk_bgzf_inflate(raw.data(), block_off.data(), out_off.data(), nb, stream.data() + carried))
+                    fail(std::string("inflate: ") + sk_last_error(), name);
+                fs().blocks += unsigned(nb);
+                fs().inflated += (unsigned long)out_off.back();
+                const int64_t stream_len = carried + out_off.back();
+                if (feed.limit < 0)
+                    for (int32_t b = 0; b <= nb; ++b)
+                        if (feed.file_at + block_off[size_t(b)] == ce) feed.limit = carried + out_off[size_t(b)] + ue;
+                const bool at_eof = (feed.file_at + block_off[size_t(nb)] >= bf.size);
+                const int64_t start = carried ? 0 : feed.first_offset;
+                int64_t n_rec = sk_bam_scan_records(stream.data(), stream_len, start, nullptr, nullptr, nullptr, 0);
+                if (n_rec < 0) fail("malformed BAM record", name);
+                rec_off.assign(size_t(n_rec) + 1, 0);
+                read_off.assign(size_t(n_rec) + 1, 0);
+                path_off.assign(size_t(n_rec) + 1, 0);
+                if (n_rec > 0 && sk_bam_scan_records(stream.data(), stream_len, start, rec_off.data(), read_off.data(), path_off.data(), int32_t(n_rec)) != n_rec)
+                    fail("record scan", name);
+                int64_t next_at = start;
+                if (n_rec > 0) next_at = rec_off[size_t(n_rec) - 1] + 4 + int64_t(le32(stream.data() + rec_off[size_t(n_rec) - 1]));
+                // the records of this chunk among them: those that start before its end
+                int32_t n_in = int32_t(n_rec);
+                if (feed.limit >= 0) {
+                    n_in = 0;
+                    while (n_in < n_rec && rec_off[size_t(n_in)] < feed.limit) ++n_in;
                 }
-            const int64_t stream_len = out_off.back();
-            int64_t n_rec = sk_bam_scan_records(stream.data(), stream_len, ub, nullptr, nullptr, nullptr, 0);
-            if (n_rec < 0) fail("malformed BAM record", name);
-            rec_off.assign(size_t(n_rec) + 1, 0);
-            read_off.assign(size_t(n_rec) + 1, 0);
-            path_off.assign(size_t(n_rec) + 1, 0);
-            if (n_rec > 0 && sk_bam_scan_records(stream.data(), stream_len, ub, rec_off.data(), read_off.data(), path_off.data(), int32_t(n_rec)) != n_rec)
-                fail("record scan", name);
-            // is every record that starts inside the chunk whole?
-            int64_t next_at = ub;
-            if (n_rec > 0) next_at = rec_off[size_t(n_rec) - 1] + 4 + int64_t(le32(stream.data() + rec_off[size_t(n_rec) - 1]));
-            const bool at_eof = (cb + int64_t(raw.size()) >= bf.size);
-            if ((end_block_here || at_eof) && (next_at >= limit || at_eof)) {
-                int32_t n_in = 0;
-                while (n_in < n_rec && rec_off[size_t(n_in)] < limit) ++n_in;
                 if (n_in > 0) {
                     rec.resize(size_t(n_in));
                     code.resize(size_t(read_off[size_t(n_in)]) + 1);
@@ -218,7 +260,7 @@ bool feed_reset_region(const void* streamer, const char* name, const int tid, co
                     if (sk_bam_decode(stream.data(), stream_len, rec_off.data(), n_in, read_off.data(), path_off.data(), rec.data(), code.data(), qual.data(),
                                       path.data()))
                         fail(std::string("decode: ") + sk_last_error(), name);
-                    const int32_t n_read = sk_bam_region_filter(rec.data(), path_off.data(), path.data(), n_in, tid, begin, end, keep.data());
+                    const int32_t n_read = sk_bam_region_filter(rec.data(), path_off.data(), path.data(), n_in, feed.tid, feed.begin, feed.end, keep.data());
                     if (n_read < 0) fail("region filter", name);
                     for (int32_t i = 0; i < n_in; ++i)
                         if (keep[size_t(i)]) {
@@ -233,16 +275,51 @@ bool feed_reset_region(const void* streamer, const char* name, const int tid, co
                             feed.pos.push_back(rec[size_t(i)].pos);
                             feed.mapped.push_back((rec[size_t(i)].flag & 0x4) ? 0 : 1);
                         }
-                    finished = n_read < n_in;
+                    if (n_read < n_in) feed.finished = true; // a record past the region's end: hts_itr_next stops there
                 }
-                break;
+                // is the chunk used up?  Its end is known and the next record starts at or past it; or the file is
+                if ((feed.limit >= 0 && (next_at >= feed.limit || n_in < n_rec)) || at_eof) {
+                    chunk_done = true;
+                } else {
+                    // the record the slice ended in (if any) opens the next slice's stream
+                    feed.carry.assign(stream.begin() + next_at, stream.begin() + stream_len);
+                    if (feed.limit >= 0) feed.limit -= next_at;
+                    feed.first_offset = 0;
+                    feed.file_at += block_off[size_t(nb)];
+                    if (next_at > stream_len) fail("record scan ran past the slice", name);
+                }
             }
-            if (at_eof) break;
-            want_to = std::min<int64_t>(bf.size, want_to + 4 * 65536);
+        }
+        if (chunk_done) {
+            feed.chunk_open = false;
+            ++feed.chunk;
         }
     }
-    fs().regions++;
     fs().records += feed.rec_at.size();
+    return !feed.rec_at.empty();
+}
+
+bool feed_reset_region(const void* streamer, const char* name, const int tid, const int begin, const int end)
+{
+    fs().feeds.erase(streamer);
+    if (const char* e = std::getenv("STRELKA_AMD_FEED"))
+        if (std::atoi(e) == 0) return false;
+    BamFile& bf = bam_file(name);
+    if (!bf.usable) return false;
+    init();
+    Feed feed;
+    const int32_t n_chunks = sk_bai_query(bf.bai.data(), int64_t(bf.bai.size()), tid, begin, end, nullptr, 0);
+    if (n_chunks == -2) return false; // (a reference the index does not know: htslib's iterator decides what that means)
+    if (n_chunks < 0) fail("malformed .bai", name);
+    feed.chunks.resize(size_t(n_chunks) + 1);
+    if (n_chunks > 0 && sk_bai_query(bf.bai.data(), int64_t(bf.bai.size()), tid, begin, end, feed.chunks.data(), n_chunks) != n_chunks) fail("index query", name);
+    feed.chunks.resize(size_t(n_chunks));
+    feed.file = &bf;
+    feed.name = name;
+    feed.tid = tid;
+    feed.begin = begin;
+    feed.end = end;
+    fs().regions++;
     fs().feeds[streamer] = std::move(feed);
     return true;
 }
@@ -255,7 +332,7 @@ void feed_drop(const void* streamer) { fs().feeds.erase(streamer); }
 int feed_next(const void* streamer, void* bam1)
 {
     Feed& f = fs().feeds[streamer];
-    if (f.next >= f.rec_at.size()) return -1;
+    if (f.next >= f.rec_at.size() && (f.finished || !feed_refill(f))) return -1;
     const uint8_t* r = f.bytes.data() + f.rec_at[f.next++];
     bam1_t* b = static_cast<bam1_t*>(bam1);
     bam1_core_t* c = &b->core;

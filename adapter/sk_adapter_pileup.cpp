@@ -287,16 +287,26 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
 
 }
 
+static bool pileup_routed(const starling_base_options& opt)
+{
+    return env_flag("STRELKA_AMD_PILEUP", true) && (! opt.isSomaticCallingMode) && (! opt.is_compute_germline_scoring_metrics()) &&
+           (! opt.is_compute_somatic_scoring_metrics);
+}
+
+bool pileup_genotypes_with_stream(const starling_base_options& opt)
+{
+    // genotypes straight from the device columns: the diploid germline model only
+    return pileup_routed(opt) && opt.is_bsnp_diploid() && env_flag("STRELKA_AMD_PILEUP_GENOTYPE", true);
+}
+
 bool pileup_enabled(starling_pos_processor_base& pp)
 {
     PileupState& ps(state().pileup);
     if (ps.decided) return ps.enabled;
     const starling_base_options& opt(Access::opt(pp));
     ps.decided = true;
-    ps.enabled = env_flag("STRELKA_AMD_PILEUP", true) && (! opt.isSomaticCallingMode) && (! opt.is_compute_germline_scoring_metrics()) &&
-                 (! opt.is_compute_somatic_scoring_metrics);
-    // genotypes straight from the device columns: the diploid germline model only
-    ps.isGenotyping = ps.enabled && opt.is_bsnp_diploid() && env_flag("STRELKA_AMD_PILEUP_GENOTYPE", true);
+    ps.enabled = pileup_routed(opt);
+    ps.isGenotyping = pileup_genotypes_with_stream(opt);
     return ps.enabled;
 }
 

@@ -621,22 +621,25 @@ __global__ __launch_bounds__(64) void flatten_kernel(const FlatArgs a)
     if (cal.trail >= 0) (void)job_cand(a.job, cal.trail);
 }
 
-// F3, one thread per candidate alignment: ops -> transition entries + the read's event mask (host form: align_prepare in
-// host/align_flatten.cpp; layout csrc/align_entry.h)
-__global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
+// F3: ops -> transition entries + the read's event mask (host form: align_prepare in host/align_flatten.cpp; layout
+// csrc/align_entry.h), then the column form (host form: sk_align_prepare_cols).  Two kernels produce the same bytes:
+//   entries_kernel       one THREAD per candidate alignment walks its ops and then every read position (a dependent byte load of
+//                        the haplotype pool per position);
+//   entries_wave_kernel  one WAVE per read: the lanes emit the entries of their candidate alignments, the base comparisons are
+//                        made once per distinct (haplotype offset, read position) -- a read's candidates face the pool at a
+//                        handful of offsets, one per combination of indels before a position -- as packed 8-position words in
+//                        LDS, and a lane assembles its alignment's column words from those with masks.
+
+// the entries of candidate alignment c (slots ent[0 .. nslots)); returns true if the alignment is left to the generic routine
+// ("complex"), in which case its column words stay as preset.  `hap`: the read's pool (P bytes).  n_ent: entries written.
+__device__ inline bool f3_emit_entries(const FlatArgs& a, const int c, const int r, const uint8_t* hap, const int32_t L, const int32_t P,
+                                       uint32_t* ent, int& n_ent)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.n_cals) return;
-    const int r = read_of_cal(a, c);
     const int W = a.evmask_words;
     uint32_t* mask = a.evmask + int64_t(r) * W;
-    const int32_t L = int32_t(a.read_off[r + 1] - a.read_off[r]);
-    const int32_t P = int32_t(a.hap_off[r + 1] - a.hap_off[r]);
-    const uint8_t* hap = a.hap_code + a.hap_off[r];
     const bool read_ok = (L >= 0 && L <= SK_ENT_MAX_READ_LEN && L <= a.max_read_len && P >= 0 && P <= SK_ENT_MAX_POOL);
     auto col_at = [&](const int idx) -> unsigned { return (idx >= 0 && idx < P) ? sk_ent_col_index(hap[idx]) : unsigned(SK_ENT_ZERO_COL); };
     const int64_t k0 = a.op_off[c], k1 = a.op_off[c + 1];
-    uint32_t* ent = a.entries + k0 + 2 * int64_t(c);
     const int nslots = int(k1 - k0) + 2;
     for (int i = 0; i < nslots; ++i) ent[i] = SK_ENT_END;
     bool complex_cal = !read_ok;
@@ -675,15 +678,27 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
         for (int i = 0; i < nslots; ++i) ent[i] = SK_ENT_END;
         ent[0] = SK_ENT_COMPLEX;
         atomicOr(&a.addmask[int64_t(r) * W + (W - 1)], 1u << 31);
-        return;
+        n_ent = 0;
+        return true;
     }
-    // the column form: where entries add terms, and the column every read position faces (host form: sk_align_prepare_cols)
+    // where entries add terms
     uint32_t* am = a.addmask + int64_t(r) * W;
     for (int i = 0; i < e; ++i)
         if (ent[i] & SK_ENT_ADD_BITS) {
             const unsigned p = ent[i] & SK_ENT_POS_MASK;
             atomicOr(&am[p >> 5], 1u << (p & 31));
         }
+    n_ent = e;
+    return false;
+}
+
+// the column words of candidate alignment c, position by position (the serial form)
+__device__ inline void f3_columns_serial(const FlatArgs& a, const int c, const int r, const uint8_t* hap, const int32_t L, const int32_t P,
+                                         const uint32_t* ent, const int e)
+{
+    const int W = a.evmask_words;
+    auto col_at = [&](const int idx) -> unsigned { return (idx >= 0 && idx < P) ? sk_ent_col_index(hap[idx]) : unsigned(SK_ENT_ZERO_COL); };
+    const int64_t k0 = a.op_off[c], k1 = a.op_off[c + 1];
     // one word (eight read positions) at a time: assembled in a register, stored once
     const int ncr = a.cal_off[r + 1] - a.cal_off[r], j = c - a.cal_off[r];
     uint32_t* cm = reinterpret_cast<uint32_t*>(a.colmat) + a.colmat_off[r] + j;
@@ -691,7 +706,7 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
     constexpr uint32_t NONE_WORD = 0x11111111u * SK_SEL_NONE;
     uint32_t word = NONE_WORD;
     int wk = 0; // index of the word being assembled
-    pos = 0;
+    int pos = 0;
     const int nch = (L + 7) >> 3;
     int ei = 0; // next entry that adds terms (entries and positions both ascend)
     bool needs_entries = false;
@@ -737,6 +752,195 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
     if (needs_entries) atomicOr(&a.addmask[int64_t(r) * W + (W - 1)], 1u << 30);
     if (wk < nch) cm[int64_t(wk) * ncr] = word;
     for (int q = wk + 1; q < nch; ++q) cm[int64_t(q) * ncr] = NONE_WORD;
+}
+
+__global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n_cals) return;
+    const int r = read_of_cal(a, c);
+    const int32_t L = int32_t(a.read_off[r + 1] - a.read_off[r]);
+    const int32_t P = int32_t(a.hap_off[r + 1] - a.hap_off[r]);
+    const uint8_t* hap = a.hap_code + a.hap_off[r];
+    uint32_t* ent = a.entries + a.op_off[c] + 2 * int64_t(c);
+    int e = 0;
+    if (f3_emit_entries(a, c, r, hap, L, P, ent, e)) return;
+    f3_columns_serial(a, c, r, hap, L, P, ent, e);
+}
+
+constexpr int F3W_MAX_D = 64;    // distinct haplotype offsets of a read's candidate alignments the wave form holds
+constexpr int F3W_MAX_NCH = 32;  // reads of up to 256 bases
+constexpr int F3W_MAX_POOL = 1024;
+
+struct F3wLds
+{
+    uint8_t hap[F3W_MAX_POOL];
+    uint8_t read[8 * F3W_MAX_NCH];
+    uint8_t slot_of[2048];           // haplotype offset + SK_ENT_HIDX_BIAS -> its slot in M
+    uint32_t delta_bits[64];         // which of the 2048 offsets occur
+    int32_t n_slots;
+    int16_t delta_of[F3W_MAX_D];     // slot -> haplotype offset
+    uint32_t M[F3W_MAX_D][F3W_MAX_NCH];  // the column word of (offset, 8 read positions)
+    uint32_t tile[F3W_MAX_NCH][64];      // the column words of 64 candidate alignments
+};
+
+// positions [0, x) of an 8-position column word (position i sits at bit 8 (i & 3) + 4 (i >> 2 & 1))
+__device__ __forceinline__ uint32_t f3w_below(const int x)
+{
+    const uint32_t lo = (x >= 4) ? 0x0f0f0f0fu : (uint32_t((1ull << (8 * x)) - 1ull) & 0x0f0f0f0fu);
+    const uint32_t hi = (x <= 4) ? 0u : (x >= 8 ? 0xf0f0f0f0u : (uint32_t((1ull << (8 * (x - 4))) - 1ull) & 0xf0f0f0f0u));
+    return lo | hi;
+}
+
+__global__ __launch_bounds__(64) void entries_wave_kernel(const FlatArgs a)
+{
+    __shared__ F3wLds S;
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int c0 = a.cal_off[r], c1 = a.cal_off[r + 1];
+    const int ncr = c1 - c0;
+    if (ncr == 0) return;
+    const int32_t L = int32_t(a.read_off[r + 1] - a.read_off[r]);
+    const int32_t P = int32_t(a.hap_off[r + 1] - a.hap_off[r]);
+    const uint8_t* ghap = a.hap_code + a.hap_off[r];
+    const uint8_t* gread = a.read_code + a.read_off[r];
+    const int nch = (L + 7) >> 3;
+    const bool fits = (L >= 0 && nch <= F3W_MAX_NCH && P >= 0 && P <= F3W_MAX_POOL);
+    if (fits) {
+        for (int i = lane; i < P; i += 64) S.hap[i] = ghap[i];
+        for (int i = lane; i < 8 * nch; i += 64) S.read[i] = (i < L) ? gread[i] : uint8_t(15);
+    }
+    S.delta_bits[lane] = 0;
+    if (lane == 0) S.n_slots = 0;
+    __syncthreads();
+    const uint8_t* hap = fits ? S.hap : ghap;
+
+    // ---- the entries of every candidate alignment; the haplotype offsets their base ops use
+    for (int c = c0 + lane; c < c1; c += 64) {
+        uint32_t* ent = a.entries + a.op_off[c] + 2 * int64_t(c);
+        int e = 0;
+        const bool complex_cal = f3_emit_entries(a, c, r, hap, L, P, ent, e);
+        if (complex_cal) continue;
+        if (!fits) { // (a read the LDS form does not hold: position by position, as the thread-per-alignment kernel)
+            f3_columns_serial(a, c, r, hap, L, P, ent, e);
+            continue;
+        }
+        int pos = 0;
+        for (int64_t kk = a.op_off[c]; kk < a.op_off[c + 1]; ++kk) {
+            const sk_score_op op = a.ops[kk];
+            const int len = int(op.length);
+            if (!((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0)) continue;
+            if (op.kind == SK_OP_BASES) {
+                const int d = int(op.src) - pos + SK_ENT_HIDX_BIAS; // (0..2047: f3_emit_entries turned anything else down)
+                atomicOr(&S.delta_bits[d >> 5], 1u << (d & 31));
+            }
+            pos += len;
+        }
+    }
+    if (!fits) return;
+    __syncthreads();
+    // ---- a slot per distinct offset (ascending)
+    {
+        const uint32_t w = S.delta_bits[lane];
+        int n = __popc(w), before = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(before, d, 64);
+            if (lane >= d) before += up;
+        }
+        const int total = __shfl(before, 63, 64);
+        before -= n;
+        if (lane == 0) S.n_slots = total;
+        if (total <= F3W_MAX_D) {
+            uint32_t ww = w;
+            int slot = before;
+            while (ww) {
+                const int b = __ffs(int(ww)) - 1;
+                ww &= ww - 1u;
+                S.delta_of[slot] = int16_t(32 * lane + b - SK_ENT_HIDX_BIAS);
+                S.slot_of[32 * lane + b] = uint8_t(slot++);
+            }
+        }
+    }
+    __syncthreads();
+    const int D = S.n_slots;
+    if (D > F3W_MAX_D) { // (more offsets than the table holds: the serial form for this read)
+        for (int c = c0 + lane; c < c1; c += 64) {
+            const uint32_t* ent = a.entries + a.op_off[c] + 2 * int64_t(c);
+            if (ent[0] == SK_ENT_COMPLEX) continue;
+            int e = 0;
+            while ((ent[e] & SK_ENT_POS_MASK) != SK_ENT_END) ++e;
+            f3_columns_serial(a, c, r, hap, L, P, ent, e);
+        }
+        return;
+    }
+    // ---- M: every (offset, 8 positions) once
+    constexpr uint32_t NONE_WORD = 0x11111111u * SK_SEL_NONE;
+    for (int t = lane; t < D * nch; t += 64) {
+        const int slot = t / nch, k = t - slot * nch;
+        const int delta = S.delta_of[slot];
+        uint32_t word = NONE_WORD;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {
+            const int p = 8 * k + t8;
+            if (p < L) {
+                const int idx = p + delta;
+                const unsigned col = (idx >= 0 && idx < P) ? sk_ent_col_index(S.hap[idx]) : unsigned(SK_ENT_ZERO_COL);
+                const unsigned sel = sk_col_selector(col, S.read[p]);
+                const unsigned shift = 8u * (unsigned(t8) & 3u) + ((t8 & 4) ? 4u : 0u);
+                word = (word & ~(0xfu << shift)) | (sel << shift);
+            }
+        }
+        S.M[slot][k] = word;
+    }
+    __syncthreads();
+    // ---- the column words of the candidate alignments, 64 at a time
+    const int W = a.evmask_words;
+    uint32_t* cm_base = reinterpret_cast<uint32_t*>(a.colmat) + a.colmat_off[r];
+    for (int j0 = 0; j0 < ncr; j0 += 64) {
+        const int j = j0 + lane;
+        for (int k = 0; k < nch; ++k) S.tile[k][lane] = NONE_WORD;
+        if (j < ncr) {
+            const int c = c0 + j;
+            const uint32_t* ent = a.entries + a.op_off[c] + 2 * int64_t(c);
+            if (ent[0] != SK_ENT_COMPLEX) {
+                int pos = 0;
+                for (int64_t kk = a.op_off[c]; kk < a.op_off[c + 1]; ++kk) {
+                    const sk_score_op op = a.ops[kk];
+                    const int len = int(op.length);
+                    if (!((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0)) continue;
+                    if (op.kind == SK_OP_BASES) {
+                        const int slot = S.slot_of[int(op.src) - pos + SK_ENT_HIDX_BIAS];
+                        const int p0 = pos, p1 = min(pos + len, int(L));
+                        for (int k = p0 >> 3; p0 < p1 && k <= (p1 - 1) >> 3; ++k) {
+                            const int lo = max(p0, 8 * k) - 8 * k, hi = min(p1, 8 * k + 8) - 8 * k;
+                            const uint32_t m = f3w_below(hi) & ~f3w_below(lo);
+                            S.tile[k][lane] = (S.tile[k][lane] & ~m) | (S.M[slot][k] & m);
+                        }
+                    }
+                    pos += len;
+                }
+                // an entry adding exactly one penalty becomes bit 2 of its position's nibble; anything else leaves the read to its
+                // entries (f3_columns_serial's flag_at: every entry sits at the start of a base op, of a soft clip, or at L)
+                bool needs_entries = false;
+                for (int ei = 0; (ent[ei] & SK_ENT_POS_MASK) != SK_ENT_END; ++ei) {
+                    if (!(ent[ei] & SK_ENT_ADD_BITS)) continue;
+                    const int i = int(ent[ei] & SK_ENT_POS_MASK);
+                    const bool simple = ((ent[ei] >> 10) & 7u) == 1u && !(ent[ei] & (1u << 13)) && i < 8 * nch && i <= L;
+                    if (simple) {
+                        const unsigned shift = 8u * (unsigned(i) & 3u) + ((i & 4) ? 4u : 0u);
+                        S.tile[i >> 3][lane] |= 4u << shift;
+                    } else {
+                        needs_entries = true;
+                    }
+                }
+                if (needs_entries) atomicOr(&a.addmask[int64_t(r) * W + (W - 1)], 1u << 30);
+            }
+        }
+        // (a lane reads and writes only its own column of the tile)
+        if (j < ncr)
+            for (int k = 0; k < nch; ++k) cm_base[int64_t(k) * ncr + j] = S.tile[k][lane];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1328,7 +1532,10 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         if (in->want_scores && in->want_stage3) out->cals = nullptr; // (they stay here: sk_enum_device_fetch_cals)
         else D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
         if (in->want_scores) {
-            hipLaunchKernelGGL(entries_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+            // F3: a wave per read ($SK_F3_KERNEL = thread pins the thread-per-alignment form; the tests run both)
+            const bool f3_thread = (std::getenv("SK_F3_KERNEL") != nullptr && std::strcmp(std::getenv("SK_F3_KERNEL"), "thread") == 0);
+            if (f3_thread) hipLaunchKernelGGL(entries_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+            else hipLaunchKernelGGL(entries_wave_kernel, dim3(n), dim3(64), 0, st, fa);
             SK_HIP(hipGetLastError());
             lap("F1-F3 flatten");
             sk_align_batch d;
@@ -1486,7 +1693,9 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
         SK_HIP(hipMemsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), g_last.colmat_bytes, st));
         hipLaunchKernelGGL(pool_fill_kernel, dim3(g_last.n), dim3(64), 0, st, fa);
         hipLaunchKernelGGL(flatten_kernel, dim3((g_last.n_cals + 63) / 64), dim3(64), 0, st, fa);
-        hipLaunchKernelGGL(entries_kernel, dim3((g_last.n_cals + 63) / 64), dim3(64), 0, st, fa);
+        const bool f3_thread = (std::getenv("SK_F3_KERNEL") != nullptr && std::strcmp(std::getenv("SK_F3_KERNEL"), "thread") == 0);
+        if (f3_thread) hipLaunchKernelGGL(entries_kernel, dim3((g_last.n_cals + 63) / 64), dim3(64), 0, st, fa);
+        else hipLaunchKernelGGL(entries_wave_kernel, dim3(g_last.n), dim3(64), 0, st, fa);
         if (sk_score_alignments_launch_hostleg(&g_last.d, g_last.scores, st)) return 1;
     }
     SK_HIP(hipEventRecord(e1, st));

@@ -138,6 +138,38 @@ def test_device_enumeration_equals_host(seed, max_indels, hap):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["thread", "wave"])
+def test_device_flatten_kernels_on_long_reads(kernel, monkeypatch):
+    """F3 in both forms ($SK_F3_KERNEL: a thread per candidate alignment / a wave per read with the base comparisons made once per
+    haplotype offset) on reads of 120-260 bases over 4-9 indels: more than 64 candidate alignments per read (several passes of the
+    wave's tile), reads past 256 bases (the wave form hands them to the serial walk); results equal to the host path's"""
+    capi.init(0)
+    monkeypatch.setenv("SK_F3_KERNEL", kernel)
+    rng = np.random.default_rng(91333)
+    scs = synth.realign_scenarios(40, rng, reads_per=10, max_indels=9, min_indels=4, read_len=(120, 261), window=(330, 520), haplotyping_rate=0.2)
+    n_dev = n_cals = n_long = 0
+    for sc in scs:
+        res = {}
+        for mode in (0, 2):
+            job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
+                                                       min_read_bp_flank=sc["min_read_bp_flank"], enumeration=mode))
+            job.set_reference(sc["ref_seq"], sc["ref_offset"])
+            job.set_indels(sc["indels"])
+            idx = T._add_reads(job, sc)
+            job.run()
+            res[mode] = [None if i is None else job.result(i) for i in idx]
+            if mode == 2:
+                n_dev += job.enumeration_counts()[1]
+        for rd, a, b in zip(sc["reads"], res[0], res[2]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert repr(a) == repr(b)
+                n_cals += a["n_cals"]
+                n_long += len(rd["code"]) > 256
+    assert n_dev > 150 and n_cals > 64 * n_dev // 4
+
+
+@pytest.mark.gpu
 def test_device_capacity_overflow_falls_back_to_the_host(monkeypatch):
     """with capacities far too small for the job the device turns reads down; the host code enumerates those and nothing changes"""
     capi.init(0)
