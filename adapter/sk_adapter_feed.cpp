@@ -148,7 +148,16 @@ inline uint32_t le32(const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1])
 
 } // namespace
 
-constexpr int32_t SLICE_BLOCKS = 512; // BGZF blocks per slice: at most 32 MiB of inflated bytes in flight per stream
+// BGZF blocks per slice (at most 32 MiB of inflated bytes in flight per stream) and bytes read from the file at a time (the blocks of
+// a BAM are ~15-25 kB: ~400 of them); $STRELKA_AMD_FEED_SLICE_BLOCKS makes slices small enough for the tests' inputs to need many
+static int32_t slice_blocks()
+{
+    static const int32_t v([]() { const char* e(std::getenv("STRELKA_AMD_FEED_SLICE_BLOCKS")); return (e && std::atoi(e) > 0) ? std::atoi(e) : 512; }());
+    return v;
+}
+#define SLICE_BLOCKS slice_blocks()
+static int64_t slice_raw_bytes() { return std::max<int64_t>(int64_t(2) * 65536, std::min<int64_t>(int64_t(8) << 20, int64_t(slice_blocks()) * 65536)); }
+#define SLICE_RAW_BYTES slice_raw_bytes()
 
 /// the next slice of the region into `feed` (records, decoded fields); false: the region is used up
 bool feed_refill(Feed& feed)
@@ -188,7 +197,7 @@ bool feed_refill(Feed& feed)
         const int64_t ce = int64_t(feed.chunks[feed.chunk].end >> 16), ue = int64_t(feed.chunks[feed.chunk].end & 0xffff);
         // the slice's blocks: whole blocks from file_at on, SLICE_BLOCKS at most; once the chunk's last block is among them, only the
         // few more a record cut by it can reach into
-        const int64_t want = std::min<int64_t>(bf.size - feed.file_at, int64_t(SLICE_BLOCKS) * 65536);
+        const int64_t want = std::min<int64_t>(bf.size - feed.file_at, SLICE_RAW_BYTES);
         bool chunk_done = false;
         if (want <= 0) {
             chunk_done = true;

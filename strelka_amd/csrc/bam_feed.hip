@@ -906,6 +906,20 @@ int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_
     if (n_records < 0 || stream_len < 0) return sk_fail("sk_bam_decode: negative count");
     if (n_records == 0) return 0;
     if (!stream || !rec_off || !read_off || !path_off || !rec || !read_code || !read_qual || !path) return sk_fail("sk_bam_decode: null argument");
+    // the offsets are the caller's: a record must lie inside the stream with the size its own fields state (sk_bam_scan_records
+    // delivers such offsets; anything else would send the kernel outside the buffer)
+    for (int32_t i = 0; i < n_records; ++i) {
+        const int64_t at = rec_off[i];
+        if (at < 0 || at + 36 > stream_len) return sk_fail("sk_bam_decode: record offset outside the stream");
+        const uint8_t* p = stream + at;
+        const int64_t block_size = int64_t(uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24));
+        const int64_t l_seq = int64_t(int32_t(uint32_t(p[20]) | (uint32_t(p[21]) << 8) | (uint32_t(p[22]) << 16) | (uint32_t(p[23]) << 24)));
+        const int64_t n_cigar = int64_t(uint32_t(p[16]) | (uint32_t(p[17]) << 8));
+        if (block_size < 32 || at + 4 + block_size > stream_len || l_seq < 0 ||
+            32 + int64_t(p[12]) + 4 * n_cigar + (l_seq + 1) / 2 + l_seq > block_size || read_off[i + 1] - read_off[i] != l_seq ||
+            path_off[i + 1] - path_off[i] != n_cigar)
+            return sk_fail("sk_bam_decode: record does not fit its offsets");
+    }
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
     hipStream_t st = ctx.stream;
