@@ -37,6 +37,7 @@ extern "C" {
 #include <map>
 #include <sstream>
 #include <string>
+#include <chrono>
 #include <vector>
 
 namespace sk_adapter
@@ -93,12 +94,14 @@ struct FeedState
     std::map<std::string, BamFile> files;
     std::map<const void*, Feed> feeds;
     unsigned long regions = 0, records = 0, blocks = 0, inflated = 0, norm_batches = 0, norm_reads = 0, norm_changed = 0, norm_declined = 0;
+    double t_refill = 0, t_abi = 0; // wall seconds in feed_refill / feed_normalize_current's batch, of which inside the C-ABI
     ~FeedState()
     {
         if (std::getenv("STRELKA_AMD_VERBOSE") && std::atoi(std::getenv("STRELKA_AMD_VERBOSE")) != 0)
             std::cerr << "strelka_amd adapter feed: regions=" << regions << " records=" << records << " bgzf_blocks=" << blocks
                       << " inflated_bytes=" << inflated << " normalize_batches=" << norm_batches << " normalized=" << norm_reads
-                      << " normalize_changed=" << norm_changed << " normalize_declined=" << norm_declined << "\n";
+                      << " normalize_changed=" << norm_changed << " normalize_declined=" << norm_declined << " seconds=" << t_refill
+                      << " abi_seconds=" << t_abi << "\n";
         for (auto& f : files)
             if (f.second.fd >= 0) ::close(f.second.fd);
     }
@@ -160,8 +163,17 @@ static int64_t slice_raw_bytes() { return std::max<int64_t>(int64_t(2) * 65536, 
 #define SLICE_RAW_BYTES slice_raw_bytes()
 
 /// the next slice of the region into `feed` (records, decoded fields); false: the region is used up
+struct FeedTimer
+{
+    double& acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit FeedTimer(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~FeedTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 bool feed_refill(Feed& feed)
 {
+    FeedTimer whole(fs().t_refill);
     static std::vector<uint8_t> raw, stream, keep;
     static std::vector<int64_t> block_off, out_off, rec_off, read_off, path_off;
     static std::vector<sk_bam_record> rec;
@@ -235,8 +247,11 @@ bool feed_refill(Feed& feed)
                 const int64_t carried = int64_t(feed.carry.size());
                 stream.resize(size_t(carried + out_off.back()) + 8);
                 if (carried) std::memcpy(stream.data(), feed.carry.data(), size_t(carried));
-                if (sk_bgzf_inflate(raw.data(), block_off.data(), out_off.data(), nb, stream.data() + carried))
-                    fail(std::string("inflate: ") + sk_last_error(), name);
+                {
+                    FeedTimer abi(fs().t_abi);
+                    if (sk_bgzf_inflate(raw.data(), block_off.data(), out_off.data(), nb, stream.data() + carried))
+                        fail(std::string("inflate: ") + sk_last_error(), name);
+                }
                 fs().blocks += unsigned(nb);
                 fs().inflated += (unsigned long)out_off.back();
                 const int64_t stream_len = carried + out_off.back();
@@ -266,9 +281,12 @@ bool feed_refill(Feed& feed)
                     qual.resize(size_t(read_off[size_t(n_in)]) + 1);
                     path.resize(size_t(path_off[size_t(n_in)]) + 1);
                     keep.resize(size_t(n_in));
-                    if (sk_bam_decode(stream.data(), stream_len, rec_off.data(), n_in, read_off.data(), path_off.data(), rec.data(), code.data(), qual.data(),
-                                      path.data()))
-                        fail(std::string("decode: ") + sk_last_error(), name);
+                    {
+                        FeedTimer abi(fs().t_abi);
+                        if (sk_bam_decode(stream.data(), stream_len, rec_off.data(), n_in, read_off.data(), path_off.data(), rec.data(), code.data(),
+                                          qual.data(), path.data()))
+                            fail(std::string("decode: ") + sk_last_error(), name);
+                    }
                     const int32_t n_read = sk_bam_region_filter(rec.data(), path_off.data(), path.data(), n_in, feed.tid, feed.begin, feed.end, keep.data());
                     if (n_read < 0) fail("region filter", name);
                     for (int32_t i = 0; i < n_in; ++i)
@@ -446,6 +464,8 @@ bool feed_normalize_current(const void* streamer, const reference_contig_segment
         f.n_changed.assign(size_t(nb) + 1, 0);
         if (nb > 0) {
             const std::string& seq = ref.seq();
+            FeedTimer whole(fs().t_refill);
+            FeedTimer abi(fs().t_abi);
             if (sk_normalize_alignments(seq.data(), int32_t(ref.get_offset()), int32_t(seq.size()), nb, b_read_off.data(), b_code.data(), f.n_path_off.data(),
                                         f.n_seg.data(), f.n_path.data(), f.n_pos.data(), f.n_changed.data())) {
                 std::ostringstream oss;

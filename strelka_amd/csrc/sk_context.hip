@@ -201,6 +201,10 @@ int sk_init(int device)
     // processes oversubscribe the device's queue slots and every wait turns into a scheduler time slice
     // (profiles/r03_v2_gpu_sharing.txt).  Read by the HIP runtime when it first touches the device, i.e. below.
     (void)setenv("GPU_MAX_HW_QUEUES", "1", 0);
+    // ... and a process that waits for the device SLEEPS: sixteen caller processes share a GPU and a CPU quota, and a wait spent
+    // spinning is a core taken from a process that has host work to do (profiles/r03_v5_thread_cpu_seconds.txt: under contention
+    // the callers' CPU seconds doubled, all of it in their main threads).  Ignored when the process's HIP context exists already.
+    if (std::getenv("STRELKA_AMD_SPIN_WAIT") == nullptr) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)

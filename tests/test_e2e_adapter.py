@@ -26,7 +26,7 @@ def _counters(stderr):
     c = {k: int(v) for k, v in (kv.split("=") for kv in m.group(1).split())}
     f = re.search(r"strelka_amd adapter feed: (.*)", stderr)  # site 8: the region's reads came through the feed entry points
     assert f, "adapter did not report its feed:\n" + stderr[-2000:]
-    c.update({"feed_" + k: int(v) for k, v in (kv.split("=") for kv in f.group(1).split())})
+    c.update({"feed_" + k: (float(v) if "seconds" in k else int(v)) for k, v in (kv.split("=") for kv in f.group(1).split())})
     g = re.search(r"strelka_amd adapter pileup: (.*)", stderr)  # site 9: the pileup stream (germline)
     assert g, "adapter did not report its pileup stream:\n" + stderr[-2000:]
     c.update({"pileup_" + k: int(v) for k, v in (kv.split("=") for kv in g.group(1).split())})

@@ -40,6 +40,10 @@ def main():
                     for kv in m.group(1).split():
                         k, v = kv.split("=")
                         hooks[k] = hooks.get(k, 0.0) + float(v)
+                m = re.search(r"strelka_amd adapter feed: .* seconds=(\S+) abi_seconds=(\S+)", tail)
+                if m:
+                    hooks["feed"] = hooks.get("feed", 0.0) + float(m.group(1))
+                    hooks["feed_abi"] = hooks.get("feed_abi", 0.0) + float(m.group(2))
             return r.wall_s, sum(r.process_s), hooks, sum(r.user_s), sum(r.sys_s)
         finally:
             shutil.rmtree(root, ignore_errors=True)
@@ -50,17 +54,16 @@ def main():
         w, ps, _, us, ss = run("starling2_ref", jobs, {})
         print("reference            jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f)" % (jobs, w, ps, us, ss), flush=True)
     malloc_env = {"MALLOC_TRIM_THRESHOLD_": "2147483647", "MALLOC_TOP_PAD_": "268435456", "MALLOC_MMAP_THRESHOLD_": "1073741824"}
-    configs = [("default", {}), ("malloc keeps its memory", malloc_env), ("HSA_XNACK=0", {"HSA_XNACK": "0"}),
-               ("reference feed", {"STRELKA_AMD_FEED": "0"}), ("malloc + reference feed", dict(malloc_env, STRELKA_AMD_FEED="0")),
-               ("no SDMA", {"HSA_ENABLE_SDMA": "0"})]
+    configs = [("default (blocking waits)", {}), ("spinning waits", {"STRELKA_AMD_SPIN_WAIT": "1"}), ("reference feed", {"STRELKA_AMD_FEED": "0"}),
+               ("read window 16k", {"STRELKA_AMD_READ_WINDOW": "16384"})]
     for jobs in (cores, 1):
         for label, env in configs:
             if jobs != cores and not label.startswith("default"):
                 continue
             w, ps, hooks, us, ss = run("starling2_amd", jobs, env)
-            print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f (hooks %.2f / %.2f)" %
-                  (label, jobs, w, ps, us, ss, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("realign_hook", 0),
-                   hooks.get("pileup_hook", 0)), flush=True)
+            print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f feed %.2f (hooks %.2f / %.2f / %.2f)" %
+                  (label, jobs, w, ps, us, ss, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("feed_abi", 0),
+                   hooks.get("realign_hook", 0), hooks.get("pileup_hook", 0), hooks.get("feed", 0)), flush=True)
 
 
 if __name__ == "__main__":
