@@ -54,16 +54,17 @@ def main():
         w, ps, _, us, ss = run("starling2_ref", jobs, {})
         print("reference            jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f)" % (jobs, w, ps, us, ss), flush=True)
     malloc_env = {"MALLOC_TRIM_THRESHOLD_": "2147483647", "MALLOC_TOP_PAD_": "268435456", "MALLOC_MMAP_THRESHOLD_": "1073741824"}
-    configs = [("default (blocking waits)", {}), ("spinning waits", {"STRELKA_AMD_SPIN_WAIT": "1"}), ("reference feed", {"STRELKA_AMD_FEED": "0"}),
-               ("read window 16k", {"STRELKA_AMD_READ_WINDOW": "16384"})]
-    for jobs in (cores, 1):
+    configs = [("default", {})]
+    job_list = [int(x) for x in os.environ.get("SK_SHARING_JOBS", "%d,%d,%d" % (cores, cores * 3 // 2, cores * 2)).split(",")]
+    for jobs in job_list:
         for label, env in configs:
-            if jobs != cores and not label.startswith("default"):
-                continue
             w, ps, hooks, us, ss = run("starling2_amd", jobs, env)
             print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f feed %.2f (hooks %.2f / %.2f / %.2f)" %
                   (label, jobs, w, ps, us, ss, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("feed_abi", 0),
                    hooks.get("realign_hook", 0), hooks.get("pileup_hook", 0), hooks.get("feed", 0)), flush=True)
+    for jobs in job_list[1:]:
+        w, ps, _, us, ss = run("starling2_ref", jobs, {})
+        print("reference            jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f)" % (jobs, w, ps, us, ss), flush=True)
 
 
 if __name__ == "__main__":
