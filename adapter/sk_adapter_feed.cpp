@@ -163,6 +163,27 @@ static int64_t slice_raw_bytes() { return std::max<int64_t>(int64_t(2) * 65536, 
 #define SLICE_RAW_BYTES slice_raw_bytes()
 
 /// the next slice of the region into `feed` (records, decoded fields); false: the region is used up
+/// a grow-only buffer of page-locked host memory (sk_host_alloc): what crosses the C-ABI again and again
+template <typename T>
+struct Pinned
+{
+    T* p = nullptr;
+    size_t cap = 0, n = 0;
+    T* data() { return p; }
+    size_t size() const { return n; }
+    void resize(const size_t count) // (contents are not kept across a growth: every user refills)
+    {
+        if (count > cap) {
+            if (p) sk_host_free(p);
+            cap = count + count / 2 + 64;
+            p = static_cast<T*>(sk_host_alloc(cap * sizeof(T)));
+            if (p == nullptr) throw blt_exception((std::string("strelka_amd feed: sk_host_alloc: ") + sk_last_error()).c_str());
+        }
+        n = count;
+    }
+    T& operator[](const size_t i) { return p[i]; }
+};
+
 struct FeedTimer
 {
     double& acc;
@@ -174,11 +195,11 @@ struct FeedTimer
 bool feed_refill(Feed& feed)
 {
     FeedTimer whole(fs().t_refill);
-    static std::vector<uint8_t> raw, stream, keep;
+    static Pinned<uint8_t> raw, stream, code, qual;
+    static Pinned<sk_bam_record> rec;
+    static Pinned<sk_path_seg> path;
+    static std::vector<uint8_t> keep;
     static std::vector<int64_t> block_off, out_off, rec_off, read_off, path_off;
-    static std::vector<sk_bam_record> rec;
-    static std::vector<uint8_t> code, qual;
-    static std::vector<sk_path_seg> path;
     BamFile& bf(*feed.file);
     const char* name(feed.name.c_str());
     feed.bytes.clear();
@@ -246,10 +267,9 @@ bool feed_refill(Feed& feed)
             } else {
                 const int64_t carried = int64_t(feed.carry.size());
                 stream.resize(size_t(carried + out_off.back()) + 8);
-                if (carried) std::memcpy(stream.data(), feed.carry.data(), size_t(carried));
                 {
                     FeedTimer abi(fs().t_abi);
-                    if (sk_bgzf_inflate(raw.data(), block_off.data(), out_off.data(), nb, stream.data() + carried))
+                    if (sk_bgzf_inflate_prefixed(raw.data(), block_off.data(), out_off.data(), nb, feed.carry.data(), carried, stream.data()))
                         fail(std::string("inflate: ") + sk_last_error(), name);
                 }
                 fs().blocks += unsigned(nb);
@@ -283,8 +303,8 @@ bool feed_refill(Feed& feed)
                     keep.resize(size_t(n_in));
                     {
                         FeedTimer abi(fs().t_abi);
-                        if (sk_bam_decode(stream.data(), stream_len, rec_off.data(), n_in, read_off.data(), path_off.data(), rec.data(), code.data(),
-                                          qual.data(), path.data()))
+                        if (sk_bam_decode_kept(stream.data(), stream_len, rec_off.data(), n_in, read_off.data(), path_off.data(), rec.data(), code.data(),
+                                               qual.data(), path.data()))
                             fail(std::string("decode: ") + sk_last_error(), name);
                     }
                     const int32_t n_read = sk_bam_region_filter(rec.data(), path_off.data(), path.data(), n_in, feed.tid, feed.begin, feed.end, keep.data());
@@ -295,9 +315,9 @@ bool feed_refill(Feed& feed)
                             const size_t len = 4 + size_t(le32(r));
                             feed.rec_at.push_back(feed.bytes.size());
                             feed.bytes.insert(feed.bytes.end(), r, r + len);
-                            feed.code.insert(feed.code.end(), code.begin() + read_off[size_t(i)], code.begin() + read_off[size_t(i) + 1]);
+                            feed.code.insert(feed.code.end(), code.data() + read_off[size_t(i)], code.data() + read_off[size_t(i) + 1]);
                             feed.read_off.push_back(int64_t(feed.code.size()));
-                            feed.path.insert(feed.path.end(), path.begin() + path_off[size_t(i)], path.begin() + path_off[size_t(i) + 1]);
+                            feed.path.insert(feed.path.end(), path.data() + path_off[size_t(i)], path.data() + path_off[size_t(i) + 1]);
                             feed.path_off.push_back(int64_t(feed.path.size()));
                             feed.pos.push_back(rec[size_t(i)].pos);
                             feed.mapped.push_back((rec[size_t(i)].flag & 0x4) ? 0 : 1);
@@ -309,7 +329,7 @@ bool feed_refill(Feed& feed)
                     chunk_done = true;
                 } else {
                     // the record the slice ended in (if any) opens the next slice's stream
-                    feed.carry.assign(stream.begin() + next_at, stream.begin() + stream_len);
+                    feed.carry.assign(stream.data() + next_at, stream.data() + stream_len);
                     if (feed.limit >= 0) feed.limit -= next_at;
                     feed.first_offset = 0;
                     feed.file_at += block_off[size_t(nb)];
@@ -439,7 +459,9 @@ bool feed_normalize_current(const void* streamer, const reference_contig_segment
         f.normalized = true;
         f.in_batch.assign(n_rec, -1);
         std::vector<int64_t> b_read_off{ 0 };
-        std::vector<uint8_t> b_code;
+        static Pinned<uint8_t> b_code; // (page-locked: the largest array sk_normalize_alignments uploads)
+        b_code.resize(f.code.size() + 1);
+        size_t b_code_n(0);
         f.n_path_off.assign(1, 0);
         ALIGNPATH::path_t apath;
         for (size_t r = 0; r < n_rec; ++r) {
@@ -454,8 +476,9 @@ bool feed_normalize_current(const void* streamer, const reference_contig_segment
             f.n_path_off.push_back(int64_t(f.n_path_in.size()));
             f.n_seg_in.push_back(int32_t(apath.size()));
             f.n_pos_in.push_back(f.pos[r]);
-            b_code.insert(b_code.end(), f.code.begin() + f.read_off[r], f.code.begin() + f.read_off[r + 1]);
-            b_read_off.push_back(int64_t(b_code.size()));
+            std::memcpy(b_code.data() + b_code_n, f.code.data() + f.read_off[r], size_t(f.read_off[r + 1] - f.read_off[r]));
+            b_code_n += size_t(f.read_off[r + 1] - f.read_off[r]);
+            b_read_off.push_back(int64_t(b_code_n));
         }
         const int32_t nb = int32_t(f.n_pos_in.size());
         f.n_path = f.n_path_in;

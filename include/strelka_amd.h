@@ -40,6 +40,12 @@ extern "C" {
 /** number of gfx950 devices this process can see (0 when there is none); callable before sk_init.  A launcher that hands
  *  segment process i the device `i mod N` may name more devices than a node has: the adapter takes the index modulo this. */
 int sk_device_count(void);
+/** Page-locked host memory for buffers that cross this ABI again and again (a region's compressed and inflated bytes, decoded
+ *  reads): the device copies straight from / into it, whereas a copy from ordinary memory has the driver pin and unpin the pages
+ *  every time -- system time that sixteen caller processes sharing a GPU spend contending for the same locks.  Any host pointer is
+ *  accepted everywhere; these are for speed.  NULL on failure (sk_last_error).  Needs sk_init. */
+void* sk_host_alloc(size_t bytes);
+void sk_host_free(void* p);
 int sk_init(int device);
 /** sk_init, but fails when the host C library is not the one the kernels restate (sk_libm_restated() would be 0): for
  *  callers that must guarantee results bit-identical to the reference (the adapter, smoke(), bench.py). */
@@ -853,6 +859,12 @@ int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* dev_batch, 
 int64_t sk_bgzf_scan(const uint8_t* data, int64_t n_bytes, int64_t* block_off, int64_t* out_off, int32_t max_blocks);
 /** Inflate blocks [0, n_blocks) (offsets as sk_bgzf_scan gives them) into out[out_off[n_blocks]]. */
 int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks, uint8_t* out);
+/** The same for a caller that reads a region slice by slice: out receives `prefix_len` bytes the caller already holds (the record
+ *  the previous slice ended in) followed by the inflated blocks, and the DEVICE copy of exactly those bytes is kept until the next
+ *  feed call of this library -- sk_bam_decode_kept decodes from it, so the inflated stream crosses the bus once (down), not three
+ *  times (down, up, and the decoded fields down). */
+int sk_bgzf_inflate_prefixed(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks,
+                             const uint8_t* prefix, int64_t prefix_len, uint8_t* out);
 /** block_off relative to dev_data; dev_status[n_blocks]: 0 = ok (else the block is malformed, see csrc/bam_feed.hip) */
 int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, const int64_t* dev_out_off, int32_t n_blocks,
                         uint8_t* dev_out, int32_t* dev_status, void* hip_stream);
@@ -879,6 +891,10 @@ int64_t sk_bam_scan_records(const uint8_t* stream, int64_t stream_len, int64_t f
 /** Decode n_records records: fixed fields, read_code (BAM 4-bit codes, one per byte), read_qual, path (sk_path_seg, type = BAM op + 1). */
 int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
                   const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path);
+/** sk_bam_decode on the stream the last sk_bgzf_inflate_prefixed left on the device (`stream` = the caller's host copy of it, read
+ *  only to validate the offsets; stream_len must be that call's prefix_len + inflated size). */
+int sk_bam_decode_kept(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
+                       const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path);
 int sk_bam_decode_dev(const uint8_t* dev_stream, const int64_t* dev_rec_off, int32_t n_records, const int64_t* dev_read_off,
                       const int64_t* dev_path_off, sk_bam_record* dev_rec, uint8_t* dev_read_code, uint8_t* dev_read_qual,
                       sk_path_seg* dev_path, void* hip_stream);

@@ -14,6 +14,7 @@ extern "C" {
 }
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -46,6 +47,8 @@ static void to_sko(const sk_germline_options* o, sko_germline_options* g)
 extern "C" {
 
 int sk_device_count(void) { return 1; }
+void* sk_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void sk_host_free(void* p) { std::free(p); }
 int sk_init(int) { g_ready = true; return 0; }
 int sk_init_strict(int) { g_ready = true; return 0; }
 int sk_check_device_errors(void) { return 0; }
@@ -349,6 +352,25 @@ extern "C" int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, co
             return sk_fail("sk_bgzf_inflate: block " + std::to_string(b) + ": CRC-32 mismatch");
     }
     return 0;
+}
+static int64_t g_kept_len = -1;
+extern "C" int sk_bgzf_inflate_prefixed(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks, const uint8_t* prefix,
+                                        int64_t prefix_len, uint8_t* out)
+{
+    g_kept_len = -1;
+    if (prefix_len < 0 || (prefix_len > 0 && !prefix)) return sk_fail("sk_bgzf_inflate: bad prefix");
+    if (prefix_len > 0 && out != prefix) std::memmove(out, prefix, size_t(prefix_len));
+    if (sk_bgzf_inflate(data, block_off, out_off, n_blocks, out + prefix_len)) return 1;
+    g_kept_len = prefix_len + (n_blocks > 0 ? out_off[n_blocks] : 0);
+    return 0;
+}
+extern "C" int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
+                             const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path);
+extern "C" int sk_bam_decode_kept(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
+                                  const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path)
+{
+    if (g_kept_len != stream_len) return sk_fail("sk_bam_decode_kept: no stream of this length was kept by sk_bgzf_inflate_prefixed");
+    return sk_bam_decode(stream, stream_len, rec_off, n_records, read_off, path_off, rec, read_code, read_qual, path);
 }
 extern "C" int sk_bgzf_inflate_dev(const uint8_t*, const int64_t*, const int64_t*, int32_t, uint8_t*, int32_t*, void*)
 {

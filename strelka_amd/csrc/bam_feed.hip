@@ -781,6 +781,7 @@ struct FeedBuffers
 {
     void* p[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     size_t cap[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    int64_t kept_len = -1; // p[3] holds a stream of this many bytes left by sk_bgzf_inflate_prefixed (-1: nothing kept)
     int reserve(const int i, const size_t bytes)
     {
         if (bytes <= cap[i]) return 0;
@@ -838,8 +839,11 @@ int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, c
     return 0;
 }
 
-int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks, uint8_t* out)
+int sk_bgzf_inflate_prefixed(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks,
+                             const uint8_t* prefix, int64_t prefix_len, uint8_t* out)
 {
+    feed_bufs().kept_len = -1;
+    if (prefix_len < 0 || (prefix_len > 0 && !prefix)) return sk_fail("sk_bgzf_inflate: bad prefix");
     SK_REQUIRE_INIT();
     if (n_blocks < 0) return sk_fail("sk_bgzf_inflate: negative block count");
     if (n_blocks == 0) return 0;
@@ -851,18 +855,20 @@ int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, const int64_t
     if (in_bytes < 0 || out_bytes < 0 || out_off[0] != 0) return sk_fail("sk_bgzf_inflate: bad offsets");
     FeedBuffers& B = feed_bufs();
     if (B.reserve(0, size_t(in_bytes) + 16) || B.reserve(1, 8 * size_t(n_blocks + 1)) || B.reserve(2, 8 * size_t(n_blocks + 1)) ||
-        B.reserve(3, size_t(out_bytes) + 16) || B.reserve(4, 4 * size_t(n_blocks)))
+        B.reserve(3, size_t(prefix_len) + size_t(out_bytes) + 16) || B.reserve(4, 4 * size_t(n_blocks)))
         return 1;
     std::vector<int64_t> rel(size_t(n_blocks) + 1);
     for (int i = 0; i <= n_blocks; ++i) rel[size_t(i)] = block_off[i] - block_off[0];
     SK_HIP(hipMemcpyAsync(B.p[0], data + block_off[0], size_t(in_bytes), hipMemcpyHostToDevice, st));
     SK_HIP(hipMemcpyAsync(B.p[1], rel.data(), 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
     SK_HIP(hipMemcpyAsync(B.p[2], out_off, 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
+    if (prefix_len > 0) SK_HIP(hipMemcpyAsync(B.p[3], prefix, size_t(prefix_len), hipMemcpyHostToDevice, st));
     if (sk_bgzf_inflate_dev(static_cast<uint8_t*>(B.p[0]), static_cast<int64_t*>(B.p[1]), static_cast<int64_t*>(B.p[2]), n_blocks,
-                            static_cast<uint8_t*>(B.p[3]), static_cast<int32_t*>(B.p[4]), st))
+                            static_cast<uint8_t*>(B.p[3]) + prefix_len, static_cast<int32_t*>(B.p[4]), st))
         return 1;
     std::vector<int32_t> status(static_cast<size_t>(n_blocks));
-    SK_HIP(hipMemcpyAsync(out, B.p[3], size_t(out_bytes), hipMemcpyDeviceToHost, st));
+    if (prefix_len > 0 && out != prefix) std::memcpy(out, prefix, size_t(prefix_len));
+    SK_HIP(hipMemcpyAsync(out + prefix_len, static_cast<uint8_t*>(B.p[3]) + prefix_len, size_t(out_bytes), hipMemcpyDeviceToHost, st));
     SK_HIP(hipMemcpyAsync(status.data(), B.p[4], 4 * size_t(n_blocks), hipMemcpyDeviceToHost, st));
     SK_HIP(hipStreamSynchronize(st));
     for (int i = 0; i < n_blocks; ++i)
@@ -872,8 +878,17 @@ int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, const int64_t
                                                 "CRC-32 mismatch" };
             return sk_fail(std::string("sk_bgzf_inflate: block ") + std::to_string(i) + ": " + what[status[size_t(i)]]);
         }
+    B.kept_len = prefix_len + out_bytes;
     return 0;
 }
+
+int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks, uint8_t* out)
+{
+    const int rc = sk_bgzf_inflate_prefixed(data, block_off, out_off, n_blocks, nullptr, 0, out);
+    feed_bufs().kept_len = -1; // (only the prefixed form promises a kept stream)
+    return rc;
+}
+
 
 int sk_bam_decode_dev(const uint8_t* dev_stream, const int64_t* dev_rec_off, int32_t n_records, const int64_t* dev_read_off,
                       const int64_t* dev_path_off, sk_bam_record* dev_rec, uint8_t* dev_read_code, uint8_t* dev_read_qual, sk_path_seg* dev_path,
@@ -899,8 +914,8 @@ int sk_bam_decode_dev(const uint8_t* dev_stream, const int64_t* dev_rec_off, int
     return 0;
 }
 
-int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
-                  const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path)
+static int bam_decode_host(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
+                           const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path, const bool kept)
 {
     SK_REQUIRE_INIT();
     if (n_records < 0 || stream_len < 0) return sk_fail("sk_bam_decode: negative count");
@@ -925,15 +940,16 @@ int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_
     hipStream_t st = ctx.stream;
     const int64_t n_bases = read_off[n_records], n_segs = path_off[n_records];
     FeedBuffers& B = feed_bufs();
-    if (B.reserve(0, size_t(stream_len) + 16) || B.reserve(1, 8 * size_t(n_records)) || B.reserve(2, 8 * size_t(n_records + 1)) ||
+    if (kept && B.kept_len != stream_len) return sk_fail("sk_bam_decode_kept: no stream of this length was kept by sk_bgzf_inflate_prefixed");
+    if ((!kept && B.reserve(0, size_t(stream_len) + 16)) || B.reserve(1, 8 * size_t(n_records)) || B.reserve(2, 8 * size_t(n_records + 1)) ||
         B.reserve(5, 8 * size_t(n_records + 1)) || B.reserve(3, sizeof(sk_bam_record) * size_t(n_records)) || B.reserve(4, size_t(n_bases) + 16) ||
         B.reserve(6, size_t(n_bases) + 16) || B.reserve(7, sizeof(sk_path_seg) * size_t(n_segs) + 16))
         return 1;
-    SK_HIP(hipMemcpyAsync(B.p[0], stream, size_t(stream_len), hipMemcpyHostToDevice, st));
+    if (!kept) SK_HIP(hipMemcpyAsync(B.p[0], stream, size_t(stream_len), hipMemcpyHostToDevice, st));
     SK_HIP(hipMemcpyAsync(B.p[1], rec_off, 8 * size_t(n_records), hipMemcpyHostToDevice, st));
     SK_HIP(hipMemcpyAsync(B.p[2], read_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
     SK_HIP(hipMemcpyAsync(B.p[5], path_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
-    if (sk_bam_decode_dev(static_cast<uint8_t*>(B.p[0]), static_cast<int64_t*>(B.p[1]), n_records, static_cast<int64_t*>(B.p[2]),
+    if (sk_bam_decode_dev(static_cast<uint8_t*>(kept ? B.p[3] : B.p[0]), static_cast<int64_t*>(B.p[1]), n_records, static_cast<int64_t*>(B.p[2]),
                           static_cast<int64_t*>(B.p[5]), static_cast<sk_bam_record*>(B.p[3]), static_cast<uint8_t*>(B.p[4]),
                           static_cast<uint8_t*>(B.p[6]), static_cast<sk_path_seg*>(B.p[7]), st))
         return 1;
@@ -945,6 +961,18 @@ int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_
     if (n_segs) SK_HIP(hipMemcpyAsync(path, B.p[7], sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyDeviceToHost, st));
     SK_HIP(hipStreamSynchronize(st));
     return 0;
+}
+
+int sk_bam_decode(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
+                  const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path)
+{
+    return bam_decode_host(stream, stream_len, rec_off, n_records, read_off, path_off, rec, read_code, read_qual, path, false);
+}
+
+int sk_bam_decode_kept(const uint8_t* stream, int64_t stream_len, const int64_t* rec_off, int32_t n_records, const int64_t* read_off,
+                       const int64_t* path_off, sk_bam_record* rec, uint8_t* read_code, uint8_t* read_qual, sk_path_seg* path)
+{
+    return bam_decode_host(stream, stream_len, rec_off, n_records, read_off, path_off, rec, read_code, read_qual, path, true);
 }
 
 int sk_normalize_alignments_dev(const char* dev_ref_seq, int32_t ref_offset, int32_t ref_len, int32_t n_reads, const int64_t* dev_read_off,

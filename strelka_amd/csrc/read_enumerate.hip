@@ -632,14 +632,15 @@ __global__ __launch_bounds__(64) void flatten_kernel(const FlatArgs a)
 
 // the entries of candidate alignment c (slots ent[0 .. nslots)); returns true if the alignment is left to the generic routine
 // ("complex"), in which case its column words stay as preset.  `hap`: the read's pool (P bytes).  n_ent: entries written.
-__device__ inline bool f3_emit_entries(const FlatArgs& a, const int r, const uint8_t* hap, const int32_t L, const int32_t P,
-                                       const sk_score_op* ops, const int n_ops, uint32_t* ent, int& n_ent)
+__device__ inline bool f3_emit_entries(const FlatArgs& a, const int c, const int r, const uint8_t* hap, const int32_t L, const int32_t P,
+                                       uint32_t* ent, int& n_ent)
 {
     const int W = a.evmask_words;
     uint32_t* mask = a.evmask + int64_t(r) * W;
     const bool read_ok = (L >= 0 && L <= SK_ENT_MAX_READ_LEN && L <= a.max_read_len && P >= 0 && P <= SK_ENT_MAX_POOL);
     auto col_at = [&](const int idx) -> unsigned { return (idx >= 0 && idx < P) ? sk_ent_col_index(hap[idx]) : unsigned(SK_ENT_ZERO_COL); };
-    const int nslots = n_ops + 2;
+    const int64_t k0 = a.op_off[c], k1 = a.op_off[c + 1];
+    const int nslots = int(k1 - k0) + 2;
     for (int i = 0; i < nslots; ++i) ent[i] = SK_ENT_END;
     bool complex_cal = !read_ok;
     int e = 0, pos = 0;
@@ -651,8 +652,8 @@ __device__ inline bool f3_emit_entries(const FlatArgs& a, const int r, const uin
                    (unsigned(hidx + SK_ENT_HIDX_BIAS) << 21);
         if (pos > 0 && pos <= L) atomicOr(&mask[pos >> 5], 1u << (pos & 31));
     };
-    for (int kk = 0; kk < n_ops && !complex_cal; ++kk) {
-        const sk_score_op op = ops[kk];
+    for (int64_t kk = k0; kk < k1 && !complex_cal; ++kk) {
+        const sk_score_op op = a.ops[kk];
         const int len = int(op.length);
         const unsigned pen = op.flags & SK_OPFLAG_NONCANDIDATE_PENALTY;
         if ((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0) {
@@ -693,10 +694,11 @@ __device__ inline bool f3_emit_entries(const FlatArgs& a, const int r, const uin
 
 // the column words of candidate alignment c, position by position (the serial form)
 __device__ inline void f3_columns_serial(const FlatArgs& a, const int c, const int r, const uint8_t* hap, const int32_t L, const int32_t P,
-                                         const sk_score_op* ops, const int n_ops, const uint32_t* ent, const int e)
+                                         const uint32_t* ent, const int e)
 {
     const int W = a.evmask_words;
     auto col_at = [&](const int idx) -> unsigned { return (idx >= 0 && idx < P) ? sk_ent_col_index(hap[idx]) : unsigned(SK_ENT_ZERO_COL); };
+    const int64_t k0 = a.op_off[c], k1 = a.op_off[c + 1];
     // one word (eight read positions) at a time: assembled in a register, stored once
     const int ncr = a.cal_off[r + 1] - a.cal_off[r], j = c - a.cal_off[r];
     uint32_t* cm = reinterpret_cast<uint32_t*>(a.colmat) + a.colmat_off[r] + j;
@@ -730,8 +732,8 @@ __device__ inline void f3_columns_serial(const FlatArgs& a, const int c, const i
         const unsigned shift = 8u * (unsigned(i) & 3u) + ((i & 4) ? 4u : 0u);
         word = (word & ~(0xfu << shift)) | (sel << shift);
     };
-    for (int kk = 0; kk < n_ops; ++kk) {
-        const sk_score_op op = ops[kk];
+    for (int64_t kk = k0; kk < k1; ++kk) {
+        const sk_score_op op = a.ops[kk];
         const int len = int(op.length);
         if (!((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0)) continue;
         if (op.kind == SK_OP_BASES) {
@@ -761,17 +763,14 @@ __global__ __launch_bounds__(64) void entries_kernel(const FlatArgs a)
     const int32_t P = int32_t(a.hap_off[r + 1] - a.hap_off[r]);
     const uint8_t* hap = a.hap_code + a.hap_off[r];
     uint32_t* ent = a.entries + a.op_off[c] + 2 * int64_t(c);
-    const sk_score_op* ops = a.ops + a.op_off[c];
-    const int n_ops = int(a.op_off[c + 1] - a.op_off[c]);
     int e = 0;
-    if (f3_emit_entries(a, r, hap, L, P, ops, n_ops, ent, e)) return;
-    f3_columns_serial(a, c, r, hap, L, P, ops, n_ops, ent, e);
+    if (f3_emit_entries(a, c, r, hap, L, P, ent, e)) return;
+    f3_columns_serial(a, c, r, hap, L, P, ent, e);
 }
 
 constexpr int F3W_MAX_D = 64;    // distinct haplotype offsets of a read's candidate alignments the wave form holds
 constexpr int F3W_MAX_NCH = 32;  // reads of up to 256 bases
 constexpr int F3W_MAX_POOL = 1024;
-constexpr int F3W_MAX_CALS = 256, F3W_MAX_OPS = 1024; // a read's candidate alignments / ops staged in LDS (the others: where they lie)
 
 struct F3wLds
 {
@@ -781,10 +780,6 @@ struct F3wLds
     uint32_t delta_bits[64];         // which of the 2048 offsets occur
     int32_t n_slots;
     int16_t delta_of[F3W_MAX_D];     // slot -> haplotype offset
-    // the read's ops, op offsets and entries, when they fit: the lanes' walks over them are chains of dependent accesses
-    int32_t op_at[F3W_MAX_CALS + 1];
-    sk_score_op ops[F3W_MAX_OPS];
-    uint32_t ent[F3W_MAX_OPS + 2 * F3W_MAX_CALS];
     uint32_t M[F3W_MAX_D][F3W_MAX_NCH];  // the column word of (offset, 8 read positions)
     uint32_t tile[F3W_MAX_NCH][64];      // the column words of 64 candidate alignments
 };
@@ -815,46 +810,24 @@ __global__ __launch_bounds__(64) void entries_wave_kernel(const FlatArgs a)
         for (int i = lane; i < P; i += 64) S.hap[i] = ghap[i];
         for (int i = lane; i < 8 * nch; i += 64) S.read[i] = (i < L) ? gread[i] : uint8_t(15);
     }
-    const int64_t o0 = a.op_off[c0], o1 = a.op_off[c1];
-    const bool staged = fits && ncr <= F3W_MAX_CALS && (o1 - o0) <= F3W_MAX_OPS;
-    if (staged) {
-        for (int i = lane; i <= ncr; i += 64) S.op_at[i] = int32_t(a.op_off[c0 + i] - o0);
-        for (int i = lane; i < int(o1 - o0); i += 64) S.ops[i] = a.ops[o0 + i];
-    }
     S.delta_bits[lane] = 0;
     if (lane == 0) S.n_slots = 0;
     __syncthreads();
     const uint8_t* hap = fits ? S.hap : ghap;
-    uint32_t* const gent0 = a.entries + o0 + 2 * int64_t(c0); // the read's entry slots in HBM
-    auto ops_of = [&](const int j, int& n) -> const sk_score_op* {
-        if (staged) {
-            n = S.op_at[j + 1] - S.op_at[j];
-            return S.ops + S.op_at[j];
-        }
-        n = int(a.op_off[c0 + j + 1] - a.op_off[c0 + j]);
-        return a.ops + a.op_off[c0 + j];
-    };
-    auto ent_of = [&](const int j) -> uint32_t* {
-        if (staged) return S.ent + S.op_at[j] + 2 * j;
-        return gent0 + (a.op_off[c0 + j] - o0) + 2 * int64_t(j);
-    };
 
     // ---- the entries of every candidate alignment; the haplotype offsets their base ops use
-    for (int j = lane; j < ncr; j += 64) {
-        const int c = c0 + j;
-        int n_ops = 0;
-        const sk_score_op* ops = ops_of(j, n_ops);
-        uint32_t* ent = ent_of(j);
+    for (int c = c0 + lane; c < c1; c += 64) {
+        uint32_t* ent = a.entries + a.op_off[c] + 2 * int64_t(c);
         int e = 0;
-        const bool complex_cal = f3_emit_entries(a, r, hap, L, P, ops, n_ops, ent, e);
+        const bool complex_cal = f3_emit_entries(a, c, r, hap, L, P, ent, e);
         if (complex_cal) continue;
         if (!fits) { // (a read the LDS form does not hold: position by position, as the thread-per-alignment kernel)
-            f3_columns_serial(a, c, r, hap, L, P, ops, n_ops, ent, e);
+            f3_columns_serial(a, c, r, hap, L, P, ent, e);
             continue;
         }
         int pos = 0;
-        for (int kk = 0; kk < n_ops; ++kk) {
-            const sk_score_op op = ops[kk];
+        for (int64_t kk = a.op_off[c]; kk < a.op_off[c + 1]; ++kk) {
+            const sk_score_op op = a.ops[kk];
             const int len = int(op.length);
             if (!((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0)) continue;
             if (op.kind == SK_OP_BASES) {
@@ -892,18 +865,12 @@ __global__ __launch_bounds__(64) void entries_wave_kernel(const FlatArgs a)
     __syncthreads();
     const int D = S.n_slots;
     if (D > F3W_MAX_D) { // (more offsets than the table holds: the serial form for this read)
-        for (int j = lane; j < ncr; j += 64) {
-            const uint32_t* ent = ent_of(j);
+        for (int c = c0 + lane; c < c1; c += 64) {
+            const uint32_t* ent = a.entries + a.op_off[c] + 2 * int64_t(c);
             if (ent[0] == SK_ENT_COMPLEX) continue;
             int e = 0;
             while ((ent[e] & SK_ENT_POS_MASK) != SK_ENT_END) ++e;
-            int n_ops = 0;
-            const sk_score_op* ops = ops_of(j, n_ops);
-            f3_columns_serial(a, c0 + j, r, hap, L, P, ops, n_ops, ent, e);
-        }
-        if (staged) {
-            __syncthreads();
-            for (int i = lane; i < int(o1 - o0) + 2 * ncr; i += 64) gent0[i] = S.ent[i];
+            f3_columns_serial(a, c, r, hap, L, P, ent, e);
         }
         return;
     }
@@ -934,13 +901,12 @@ __global__ __launch_bounds__(64) void entries_wave_kernel(const FlatArgs a)
         const int j = j0 + lane;
         for (int k = 0; k < nch; ++k) S.tile[k][lane] = NONE_WORD;
         if (j < ncr) {
-            const uint32_t* ent = ent_of(j);
+            const int c = c0 + j;
+            const uint32_t* ent = a.entries + a.op_off[c] + 2 * int64_t(c);
             if (ent[0] != SK_ENT_COMPLEX) {
                 int pos = 0;
-                int n_ops = 0;
-                const sk_score_op* ops = ops_of(j, n_ops);
-                for (int kk = 0; kk < n_ops; ++kk) {
-                    const sk_score_op op = ops[kk];
+                for (int64_t kk = a.op_off[c]; kk < a.op_off[c + 1]; ++kk) {
+                    const sk_score_op op = a.ops[kk];
                     const int len = int(op.length);
                     if (!((op.kind == SK_OP_BASES || op.kind == SK_OP_SOFT_CLIP) && len > 0)) continue;
                     if (op.kind == SK_OP_BASES) {
@@ -974,10 +940,6 @@ __global__ __launch_bounds__(64) void entries_wave_kernel(const FlatArgs a)
         // (a lane reads and writes only its own column of the tile)
         if (j < ncr)
             for (int k = 0; k < nch; ++k) cm_base[int64_t(k) * ncr + j] = S.tile[k][lane];
-    }
-    if (staged) { // the entries to HBM, in rows
-        __syncthreads();
-        for (int i = lane; i < int(o1 - o0) + 2 * ncr; i += 64) gent0[i] = S.ent[i];
     }
 }
 

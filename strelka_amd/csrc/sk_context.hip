@@ -191,6 +191,26 @@ int sk_device_count(void)
     return n;
 }
 
+void* sk_host_alloc(size_t bytes)
+{
+    if (!g_ctx.ready) {
+        sk_fail("strelka_amd: sk_init() has not succeeded");
+        return nullptr;
+    }
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        sk_fail(std::string("sk_host_alloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+void sk_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int sk_init(int device)
 {
     SkContext& c = g_ctx;
