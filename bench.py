@@ -395,10 +395,16 @@ def main():
     hrs = synth.readscore_batch(args.indels, rng, depth_mean=110.0)
     drs = device.DeviceReadScoreBatch(hrs, dev)
     dt_i, iloci, kms_i = timed(lambda: drs.grid_lhood(), args.steps, args.warmup, drs.n_indels)
+    fast_opt_i = capi.indel_options(True)
+    fast_opt_i.fast_form = 1
+    dt_if, iloci_f, kms_if = timed(lambda: drs.grid_lhood(opt=fast_opt_i), args.steps, args.warmup, drs.n_indels)
     indel_alg_bytes = 16 * drs.n_reads + 8 * 21 * drs.n_indels  # 16 B per read + 8 B per state
     hag = synth.allele_group_batch(args.indels, rng)
     dag = device.DeviceAlleleGroupBatch(hag, dev)
     dt_g, gloci, kms_g = timed(lambda: dag.genotype_lhoods(), args.steps, args.warmup, dag.n_groups)
+    fast_opt_g = capi.indel_options(False)
+    fast_opt_g.fast_form = 1
+    dt_gf, gloci_f, kms_gf = timed(lambda: dag.genotype_lhoods(opt=fast_opt_g), args.steps, args.warmup, dag.n_groups)
     group_alg_bytes = (8 * capi.MAX_ALT + 5) * dag.n_reads + 128 * dag.n_groups
     del drs, dag
 
@@ -499,6 +505,11 @@ def main():
         "roofline_somatic": roof("somatic_classify_kernel+somatic_lhood_kernel+somatic_posterior_kernel", 2 * somatic_calls + 273 * somatic_loci_n, kms_s, som_traffic),
         "indel_grid_loci_per_s": iloci / dt_i, "indel_grid_ms_per_step": dt_i / args.steps * 1e3,
         "roofline_indel_grid": roof("indel_grid_lhood_kernel", indel_alg_bytes, kms_i, traffic.get("indel_grid_lhood_kernel")),
+        "indel_grid_fast_form_loci_per_s": iloci_f / dt_if, "indel_grid_fast_form_kernel_ms": kms_if,
+        "allele_group_fast_form_loci_per_s": gloci_f / dt_gf, "allele_group_fast_form_kernel_ms": kms_gf,
+        "fast_form_note": "sk_indel_options.fast_form = 1: the algebraically equal form with two exp per read shared by its states and one "
+                          "log per state (agrees with the reference's operation order to ~1e-15 relative, within north_star's 1e-5; the "
+                          "integer outputs are pinned by tests/test_gpu_parity.py); off by default: the exact form is bit-identical",
         "allele_group_loci_per_s": gloci / dt_g, "allele_group_ms_per_step": dt_g / args.steps * 1e3,
         "roofline_allele_group": roof("allele_group_kernel", group_alg_bytes, kms_g, traffic.get("allele_group_kernel")),
         "roofline_pileup": roof("pileup_read_kernel+2*pileup_column_kernel", pileup_alg_bytes, kms_p, pil_traffic),

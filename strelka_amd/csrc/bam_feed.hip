@@ -17,6 +17,17 @@
 //                             4-bit packed bases -> one BAM code per byte (what sk_read_input.read_code takes), qualities
 //
 // Byte work, bound by the serial decode per block rather than by HBM; algorithmic bytes = compressed in + inflated out.
+//
+// PROVENANCE AND LICENCE.  Nothing here comes from /root/reference's own sources.  The canonical-Huffman construction and decode
+// of the thread-per-block kernel (huff_construct, huff_decode, the LEN_* / DIST_* base and extra-bit tables, the order of the
+// code-length code lengths) follow zlib's contrib/puff/puff.c by Mark Adler (construct(), decode(), lens / lext / dists / dext,
+// order[]), down to its variable names; zlib licence: "Copyright (C) 2002-2013 Mark Adler ... This software is provided 'as-is',
+// without any express or implied warranty ... Permission is granted to anyone to use this software for any purpose, including
+// commercial applications, and to alter it and redistribute it freely, subject to the following restrictions: 1. The origin of this
+// software must not be misrepresented ... 2. Altered source versions must be plainly marked as such ... 3. This notice may not be
+// removed or altered from any source distribution."  This is an altered version (HIP, per-block status codes, no setjmp).  The tables
+// themselves are RFC 1951's.  iw_multmodp / the x^(8n) exponentiation of the wave kernel follow zlib's crc32.c (multmodp, x2nmodp;
+// same licence).  The wave-per-block decoder (first-level tables, lockstep bit buffer, lane-parallel copies) is original.
 
 #include "sk_common.h"
 

@@ -9,6 +9,13 @@
 //
 // Each function returns false outside the restated domain (the caller then uses the device library): exp for nan and
 // x >= 512; log / log10 for anything but positive normal numbers.
+//
+// PROVENANCE AND LICENCE.  Nothing here comes from /root/reference.  exp / log: ARM Optimized Routines (math/exp.c, log.c,
+// exp_data.c, log_data.c; (c) Arm Limited; SPDX: MIT OR Apache-2.0 WITH LLVM-exception) as imported into the GNU C Library
+// (sysdeps/ieee754/dbl-64/e_exp.c, e_log.c, e_exp_data.c, e_log_data.c; LGPL-2.1-or-later).  log10 / log1p: glibc's e_log10.c /
+// s_log1p.c, from fdlibm ("Copyright (C) 1993 by Sun Microsystems, Inc. ... Permission to use, copy, modify, and distribute this
+// software is freely granted, provided that this notice is preserved").  A restatement written for this repository (new code, the
+// same operation sequence and published constants); redistribution should keep this notice and the licences named above.
 #pragma once
 
 #include "libm_flt32.h"

@@ -15,6 +15,14 @@
 // be a different implementation, the kernels keep using the device library's double-precision pow/log instead.
 //
 // Domain: x a positive normal float, |y * log2(x)| < 126 (powf).  Anything else returns `false`: the caller falls back.
+//
+// PROVENANCE AND LICENCE.  Nothing here comes from /root/reference.  The algorithms and constant tables are those of ARM
+// Optimized Routines (math/powf.c, logf.c, expf.c and their *_data.c; (c) Arm Limited; SPDX: MIT OR Apache-2.0 WITH LLVM-exception)
+// as imported into the GNU C Library (sysdeps/ieee754/flt-32/e_powf.c, e_logf.c, e_expf.c, e_exp2f_data.c, e_logf_data.c,
+// e_powf_log2_data.c; LGPL-2.1-or-later); log1pf follows glibc's s_log1pf.c, which descends from FreeBSD msun / fdlibm
+// ("Copyright (C) 1993 by Sun Microsystems, Inc. ... Permission to use, copy, modify, and distribute this software is freely
+// granted, provided that this notice is preserved").  This file is a restatement written for this repository (new code, the same
+// operation sequence and published constants); redistribution should keep this notice and the licences named above.
 #pragma once
 
 #include <cstdint>
