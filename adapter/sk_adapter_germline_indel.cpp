@@ -21,10 +21,23 @@
 #include <cstring>
 #include <limits>
 
+// the reference's own definition, renamed by apply_hooks.py (it stays in the hooked translation unit)
+void
+getVariantAlleleGroupGenotypeLhoodsForSample_reference(
+    const starling_base_options& opt,
+    const starling_base_deriv_options& dopt,
+    const starling_sample_options& sampleOptions,
+    const unsigned callerPloidy,
+    const unsigned sampleIndex,
+    const OrthogonalVariantAlleleCandidateGroup& alleleGroup,
+    const OrthogonalVariantAlleleCandidateGroup& contrastGroup,
+    std::vector<double>& genotypeLogLhood,
+    LocusSupportingReadStats& locusReadStats);
+
 void
 getVariantAlleleGroupGenotypeLhoodsForSample(
     const starling_base_options& opt,
-    const starling_base_deriv_options& /*dopt*/,
+    const starling_base_deriv_options& dopt,
     const starling_sample_options& sampleOptions,
     const unsigned callerPloidy,
     const unsigned sampleIndex,
@@ -50,7 +63,14 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
     }
     if (nonRefAlleleCount > SK_MAX_ALT)
     {
-        throw blt_exception("strelka_amd adapter: more alternate alleles in one group than SK_MAX_ALT");
+        // A multi-sample run can put up to ploidy x sample-count alternate alleles into one group (selectTopOrthogonalAllelesInAllSamples,
+        // L/starling_common/OrthogonalVariantAlleleCandidateGroupUtil.cpp:285-340: the union of every sample's top alleles); the
+        // kernel's records hold SK_MAX_ALT.  Such a group -- several distinct overlapping indels that differ between the samples --
+        // takes the reference's own function; `indel_groups_reference` counts them.
+        state().indelGroupsReference++;
+        getVariantAlleleGroupGenotypeLhoodsForSample_reference(opt, dopt, sampleOptions, callerPloidy, sampleIndex, alleleGroup, contrastGroup,
+                                                               genotypeLogLhood, locusReadStats);
+        return;
     }
     init();
 

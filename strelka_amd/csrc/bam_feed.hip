@@ -792,7 +792,7 @@ struct FeedBuffers
 {
     void* p[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     size_t cap[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    int64_t kept_len = -1; // p[3] holds a stream of this many bytes left by sk_bgzf_inflate_prefixed (-1: nothing kept)
+    int64_t kept_len = -1; // p[8] holds a stream of this many bytes left by sk_bgzf_inflate_prefixed (-1: nothing kept)
     int reserve(const int i, const size_t bytes)
     {
         if (bytes <= cap[i]) return 0;
@@ -866,20 +866,20 @@ int sk_bgzf_inflate_prefixed(const uint8_t* data, const int64_t* block_off, cons
     if (in_bytes < 0 || out_bytes < 0 || out_off[0] != 0) return sk_fail("sk_bgzf_inflate: bad offsets");
     FeedBuffers& B = feed_bufs();
     if (B.reserve(0, size_t(in_bytes) + 16) || B.reserve(1, 8 * size_t(n_blocks + 1)) || B.reserve(2, 8 * size_t(n_blocks + 1)) ||
-        B.reserve(3, size_t(prefix_len) + size_t(out_bytes) + 16) || B.reserve(4, 4 * size_t(n_blocks)))
+        B.reserve(8, size_t(prefix_len) + size_t(out_bytes) + 16) || B.reserve(4, 4 * size_t(n_blocks)))
         return 1;
     std::vector<int64_t> rel(size_t(n_blocks) + 1);
     for (int i = 0; i <= n_blocks; ++i) rel[size_t(i)] = block_off[i] - block_off[0];
     SK_HIP(hipMemcpyAsync(B.p[0], data + block_off[0], size_t(in_bytes), hipMemcpyHostToDevice, st));
     SK_HIP(hipMemcpyAsync(B.p[1], rel.data(), 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
     SK_HIP(hipMemcpyAsync(B.p[2], out_off, 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
-    if (prefix_len > 0) SK_HIP(hipMemcpyAsync(B.p[3], prefix, size_t(prefix_len), hipMemcpyHostToDevice, st));
+    if (prefix_len > 0) SK_HIP(hipMemcpyAsync(B.p[8], prefix, size_t(prefix_len), hipMemcpyHostToDevice, st));
     if (sk_bgzf_inflate_dev(static_cast<uint8_t*>(B.p[0]), static_cast<int64_t*>(B.p[1]), static_cast<int64_t*>(B.p[2]), n_blocks,
-                            static_cast<uint8_t*>(B.p[3]) + prefix_len, static_cast<int32_t*>(B.p[4]), st))
+                            static_cast<uint8_t*>(B.p[8]) + prefix_len, static_cast<int32_t*>(B.p[4]), st))
         return 1;
     std::vector<int32_t> status(static_cast<size_t>(n_blocks));
     if (prefix_len > 0 && out != prefix) std::memcpy(out, prefix, size_t(prefix_len));
-    SK_HIP(hipMemcpyAsync(out + prefix_len, static_cast<uint8_t*>(B.p[3]) + prefix_len, size_t(out_bytes), hipMemcpyDeviceToHost, st));
+    SK_HIP(hipMemcpyAsync(out + prefix_len, static_cast<uint8_t*>(B.p[8]) + prefix_len, size_t(out_bytes), hipMemcpyDeviceToHost, st));
     SK_HIP(hipMemcpyAsync(status.data(), B.p[4], 4 * size_t(n_blocks), hipMemcpyDeviceToHost, st));
     SK_HIP(hipStreamSynchronize(st));
     for (int i = 0; i < n_blocks; ++i)
@@ -960,7 +960,7 @@ static int bam_decode_host(const uint8_t* stream, int64_t stream_len, const int6
     SK_HIP(hipMemcpyAsync(B.p[1], rec_off, 8 * size_t(n_records), hipMemcpyHostToDevice, st));
     SK_HIP(hipMemcpyAsync(B.p[2], read_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
     SK_HIP(hipMemcpyAsync(B.p[5], path_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
-    if (sk_bam_decode_dev(static_cast<uint8_t*>(kept ? B.p[3] : B.p[0]), static_cast<int64_t*>(B.p[1]), n_records, static_cast<int64_t*>(B.p[2]),
+    if (sk_bam_decode_dev(static_cast<uint8_t*>(kept ? B.p[8] : B.p[0]), static_cast<int64_t*>(B.p[1]), n_records, static_cast<int64_t*>(B.p[2]),
                           static_cast<int64_t*>(B.p[5]), static_cast<sk_bam_record*>(B.p[3]), static_cast<uint8_t*>(B.p[4]),
                           static_cast<uint8_t*>(B.p[6]), static_cast<sk_path_seg*>(B.p[7]), st))
         return 1;
