@@ -40,11 +40,11 @@ def test_germline_loci_full_size(gpu):
     import torch
     rng = np.random.default_rng(902)
     hb = synth.pileups(1 << 20, rng)
-    tile = 16                                           # 2^24 loci
+    tile = 64                                           # 2^26 loci ~ chr20: bench.py's step (2.7e9 calls: offsets past 2^31)
     d = device.DevicePileupBatch(hb, "cuda:0", tile=tile)
     d.site_digt_call_fused(capi.germline_options())
     torch.cuda.synchronize()
-    assert d.n_loci == 1 << 24
+    assert d.n_loci == 1 << 26 and d.n_calls > 1 << 31
     assert _tiles_equal(d.digt_out.view(torch.uint8), tile)
     got = d.digt_numpy()[:4000]
     # tile 0's first loci against the oracle (bit for bit, as in test_gpu_parity)
