@@ -34,7 +34,10 @@ bool discover_indels_and_mismatches(const std::string& haplotypeSeq, const std::
     gb.ref = refSegment.data();
     int32_t score(0), beginPos(0), segCount(0);
     std::vector<sk_path_seg> path(haplotypeSeq.size() + refSegment.size() + 4);
-    check(sk_global_align(&gb, &scores, &score, &beginPos, path.data(), &segCount), "sk_global_align");
+    {
+        AccumTimer abiTimer(state().tHaplotypeAbi);
+        check(sk_global_align(&gb, &scores, &score, &beginPos, path.data(), &segCount), "sk_global_align");
+    }
 
     const int32_t cap(static_cast<int32_t>(haplotypeSeq.size() + refSegment.size() + 4));
     std::vector<sk_discovered_allele> found(static_cast<size_t>(cap));

@@ -94,7 +94,8 @@ State& state()
                       << " genotyping=" << (s.pileup.isGenotyping ? 1 : 0) << "\n";
             std::cerr << "strelka_amd adapter seconds: realign_hook=" << s.tRealignHook << " realign_abi=" << s.tRealignAbi
                       << " site_hook=" << s.tSiteHook << " site_abi=" << s.tSiteAbi << " pileup_hook=" << s.tPileupHook
-                      << " pileup_abi=" << s.tPileupAbi << " init=" << s.tInit << "\n";
+                      << " pileup_abi=" << s.tPileupAbi << " init=" << s.tInit << " indel_abi=" << s.tIndelAbi
+                      << " haplotype_abi=" << s.tHaplotypeAbi << "\n";
         }
     };
     static Reporter r;

@@ -144,7 +144,10 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
     io.read_confident_support_threshold = opt.readConfidentSupportThreshold.numval();
 
     sk_allele_group_call out;
-    check(sk_allele_group_genotype_lhoods(&b, &io, &out), "sk_allele_group_genotype_lhoods");
+    {
+        AccumTimer abiTimer(state().tIndelAbi);
+        check(sk_allele_group_genotype_lhoods(&b, &io, &out), "sk_allele_group_genotype_lhoods");
+    }
     if (out.n_genotypes != genotypeCount)
     {
         throw blt_exception("strelka_amd adapter: genotype count mismatch in sk_allele_group_genotype_lhoods");

@@ -50,7 +50,7 @@ def main():
 
     print("%d bp, %d segments of %d bp, %d usable cores" % (L, len(groups), seg, cores), flush=True)
     run("starling2_amd", cores, {})  # warm
-    for jobs in (cores,):
+    for jobs in [int(x) for x in os.environ.get("SK_SHARING_REF_JOBS", str(cores)).split(",")]:
         w, ps, _, us, ss = run("starling2_ref", jobs, {})
         print("reference            jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f)" % (jobs, w, ps, us, ss), flush=True)
     malloc_env = {"MALLOC_TRIM_THRESHOLD_": "2147483647", "MALLOC_TOP_PAD_": "268435456", "MALLOC_MMAP_THRESHOLD_": "1073741824"}
@@ -59,12 +59,9 @@ def main():
     for jobs in job_list:
         for label, env in configs:
             w, ps, hooks, us, ss = run("starling2_amd", jobs, env)
-            print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f feed %.2f (hooks %.2f / %.2f / %.2f)" %
+            print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f feed %.2f indel %.2f haplotype %.2f (hooks %.2f / %.2f / %.2f)" %
                   (label, jobs, w, ps, us, ss, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("feed_abi", 0),
-                   hooks.get("realign_hook", 0), hooks.get("pileup_hook", 0), hooks.get("feed", 0)), flush=True)
-    for jobs in job_list[1:]:
-        w, ps, _, us, ss = run("starling2_ref", jobs, {})
-        print("reference            jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f)" % (jobs, w, ps, us, ss), flush=True)
+                   hooks.get("indel_abi", 0), hooks.get("haplotype_abi", 0), hooks.get("realign_hook", 0), hooks.get("pileup_hook", 0), hooks.get("feed", 0)), flush=True)
 
 
 if __name__ == "__main__":
