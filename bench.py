@@ -55,7 +55,10 @@ def parse():
     ap.add_argument("--a5-reads", type=int, default=1 << 12, help="reads per job of the flatten + score leg")
     ap.add_argument("--a5-reps", type=int, default=3)
     ap.add_argument("--e2e-bp", type=int, default=16000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
-    ap.add_argument("--e2e-segment-bp", type=int, default=1000000, help="segment size of the end-to-end leg (one caller process per segment)")
+    ap.add_argument("--e2e-segment-bp", type=int, default=2000000, help="segment size of the end-to-end leg (one caller process per segment)")
+    ap.add_argument("--e2e-max-procs-per-gpu", type=int, default=8,
+                    help="caller processes that share one GPU in the end-to-end leg (beyond ~8 the device's scheduler time-slices them: "
+                         "profiles/r03_v10_processes_per_gpu.txt, r03_v11_gpu_sharing_sdma.txt); the reference gets the same number of cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
     ap.add_argument("--cpu-loci", type=int, default=2000000, help="loci in the CPU-baseline sample")
@@ -185,7 +188,7 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
     barrier()
     d = farm.wgs_dataset(L)
     cores = farm.usable_cores()
-    jobs = max(1, len(cores) // world)
+    jobs = max(1, min(len(cores) // world, args.e2e_max_procs_per_gpu))
     groups = [[s] for s in farm.chrom_intervals(["chrW"], {"chrW": L}, args.e2e_segment_bp)]
     root = tempfile.mkdtemp(prefix="sk_e2e_r%d_" % rank)
 
@@ -195,7 +198,8 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                                               chrom_depth=os.path.join(d, "chrom_depth.txt"), skip_header=skip_header)
         return fn
     try:
-        farm.run_farm(groups[:1], argv_fn(drop_in), os.path.join(root, "warm"), E2E_OUTPUTS, n_gpus=1, jobs=1,
+        warm = [[(0, "chrW", 1, min(L, 50000), 0)]]
+        farm.run_farm(warm, argv_fn(drop_in), os.path.join(root, "warm"), E2E_OUTPUTS, n_gpus=1, jobs=1,
                       device_offset=local_rank)  # page the binary and the GPU runtime in
         barrier()
         t0 = time.perf_counter()
@@ -215,6 +219,11 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                            % (L, len(groups), args.e2e_segment_bp),
                "bp": L * world, "reads": int(L * 40.0 / 150) * world, "segments": len(groups) * world,
                "amd_wall_s": amd_wall, "amd_procs": jobs * world, "amd_procs_per_gpu": jobs, "host_cores": len(cores),
+               "cores_used": jobs * world,
+               "procs_note": "one caller process per core, at most --e2e-max-procs-per-gpu (8) per GPU: one MI355X serves up to ~8 "
+                             "caller processes at full speed-up (1.6-1.8x the reference per process); with 12-16 sharing it the "
+                             "device's scheduler time-slices them and the gain is gone (profiles/r03_v10, r03_v11).  The reference "
+                             "leg runs on the same number of cores.",
                "bp_per_s": L * world / amd_wall, "process_seconds_sum": sum(amd.process_s),
                "hook_seconds": {k: round(v, 4) for k, v in hooks.items()},
                "hook_seconds_note": "summed over this rank's segment processes: wall seconds inside the adapter's hooks (*_hook) of which inside "
@@ -381,6 +390,27 @@ def main():
     pileup_alg_bytes = 8 * rbatch.n_bases  # 4 B per read base (P1) + 4 B per call (P2)
     del dr
 
+    # ---- row a8 as the adapter drives it: sk_pileup_stream_push, one stage window (2 200 reads at 40x) at a time, host buffers in,
+    # columns + counters + genotypes out, one host thread (site 9; P1 + three-column P2 + G3 chained on the device)
+    sb, sb_loci = synth.pileup_reads_flat(1 << 16, np.random.default_rng(77))
+    stream = capi.PileupStream(capi.pileup_options(report_begin=0, report_end=sb_loci + 200), capi.germline_options())
+    win_reads = 2200
+    subs = []
+    for lo in range(0, sb.n_reads, win_reads):
+        hi = min(sb.n_reads, lo + win_reads)
+        subs.append((synth.ReadBatch(sb.read_off[lo:hi + 1] - sb.read_off[lo], sb.read_code[sb.read_off[lo]:sb.read_off[hi]],
+                                     sb.read_qual[sb.read_off[lo]:sb.read_off[hi]], sb.path_off[lo:hi + 1] - sb.path_off[lo],
+                                     sb.path[sb.path_off[lo]:sb.path_off[hi]], sb.pos[lo:hi], sb.is_fwd[lo:hi], sb.mapq[lo:hi],
+                                     sb.map_level[lo:hi], "", 0), int(sb.pos[hi]) if hi < sb.n_reads else 2**31 - 1))
+
+    def stream_step():
+        stream.begin_region(sb.ref_seq, 0, 0, sb_loci + 200)
+        for sub, final_to in subs:
+            stream.push_raw(sub, final_to)
+    dt_ps, ps_bases, _ = timed(stream_step, max(2, args.steps // 4), 1, sb.n_bases)
+    stream_windows = len(subs)
+    stream.close()
+
     # ---- hot path B (somatic SNV): 30-state grid likelihoods + posterior, normal 40x + tumor 110x ----
     ns, ts = synth.somatic_pileups(min(args.unique_loci, args.somatic_loci), rng)
     tile_s = max(1, args.somatic_loci // ns.n_loci)
@@ -427,6 +457,17 @@ def main():
     feed_alg_bytes = dfeed.in_bytes + dfeed.out_bytes
     feed_blocks = dfeed.n_blocks
     del dfeed
+    # ... and at the launch size a caller process has (one slice of a region: a few hundred blocks), where the latency of one block is
+    # the whole cost: the wave-per-block kernel (the default up to 16 384 blocks) against the thread-per-block one
+    feed_small = {}
+    for kern in ("wave", "thread"):
+        os.environ["SK_INFLATE_KERNEL"] = kern
+        dsm = device.DeviceBgzfBatch(bgzf_image, dev, tile=max(1, 512 // n_fix_blocks))
+        dt_fs, fs_bytes, kms_fs = timed(lambda: dsm.inflate(), max(2, args.steps // 4), 1, dsm.out_bytes)
+        assert int(dsm.status.abs().sum().item()) == 0, "BGZF inflation reported a malformed block"
+        feed_small[kern] = {"blocks": dsm.n_blocks, "inflated_bytes": dsm.out_bytes, "kernel_ms": kms_fs, "inflated_bytes_per_s": fs_bytes / dt_fs}
+        del dsm
+    del os.environ["SK_INFLATE_KERNEL"]
 
     # ---- rows a1-a7: the whole read path as the adapter drives it (host stages + kernel), one host thread ----
     wr = {}
@@ -459,8 +500,8 @@ def main():
     traffic = pmc_traffic(args)
     som_kernels = ("somatic_classify_kernel", "somatic_lhood_kernel", "somatic_posterior_kernel")
     som_traffic = sum(traffic[k] for k in som_kernels) if all(k in traffic for k in som_kernels) else None
-    pil_kernels = ("pileup_read_kernel", "pileup_column_kernel")
-    pil_traffic = (traffic["pileup_read_kernel"] + 2 * traffic["pileup_column_kernel"]) if all(k in traffic for k in pil_kernels) else None
+    pil_kernels = ("pileup_read_kernel", "pileup_column_kernel_t")
+    pil_traffic = (traffic["pileup_read_kernel"] + 2 * traffic["pileup_column_kernel_t"]) if all(k in traffic for k in pil_kernels) else None
 
     def roof(kernel, alg_bytes, kernel_ms, hbm_traffic):
         """roofline object: `achieved` = algorithmic bytes / kernel time; `measured_hbm_gbs` = counter-measured HBM
@@ -500,6 +541,10 @@ def main():
         "sum_only_cells_per_s": value, "sum_only_ms_per_step": dt_a / args.steps * 1e3, "sum_only_reads_per_step_per_gpu": da.n_reads,
         "pileup_read_bases_per_s": pbases / dt_p, "pileup_ms_per_step": dt_p / args.steps * 1e3,
         "pileup_reads_per_step_per_gpu": rbatch.n_reads,
+        "pileup_stream_read_bases_per_s": ps_bases / dt_ps, "pileup_stream_windows_per_step": stream_windows,
+        "pileup_stream_ms_per_window": dt_ps / max(2, args.steps // 4) / stream_windows * 1e3,
+        "pileup_stream_note": "sk_pileup_stream_push as the adapter calls it (site 9): windows of 2 200 reads, host buffers in, raw columns + "
+                              "MAPQ tracker + genotypes of the finalised positions out, one host thread, one device round trip per window",
         "somatic_loci_per_s": sloci / dt_s, "somatic_ms_per_step": dt_s / args.steps * 1e3,
         "somatic_loci_per_step_per_gpu": somatic_loci_n,
         "roofline_somatic": roof("somatic_classify_kernel+somatic_lhood_kernel+somatic_posterior_kernel", 2 * somatic_calls + 273 * somatic_loci_n, kms_s, som_traffic),
@@ -512,7 +557,7 @@ def main():
                           "integer outputs are pinned by tests/test_gpu_parity.py); off by default: the exact form is bit-identical",
         "allele_group_loci_per_s": gloci / dt_g, "allele_group_ms_per_step": dt_g / args.steps * 1e3,
         "roofline_allele_group": roof("allele_group_kernel", group_alg_bytes, kms_g, traffic.get("allele_group_kernel")),
-        "roofline_pileup": roof("pileup_read_kernel+2*pileup_column_kernel", pileup_alg_bytes, kms_p, pil_traffic),
+        "roofline_pileup": roof("pileup_read_kernel+2*pileup_column_kernel_t", pileup_alg_bytes, kms_p, pil_traffic),
         "roofline_global_align": roof("global_align_kernel", ga_alg_bytes, kms_ga, traffic.get("global_align_kernel")),
         "realign_host_threads": 1,
         "realign_note": "whole read path (rows a1-a7) through sk_realign_job_add_reads + _run, one host thread, host buffers in and out; "
@@ -520,7 +565,9 @@ def main():
                         "(enumeration=2), *_host_enumeration = listed, flattened and finished on the host (round 1's path), *_dense = scenarios "
                         "with up to 14 indels around a read",
         "feed_inflated_bytes_per_s": feed_bytes / dt_f, "feed_ms_per_step": dt_f / max(2, args.steps // 4) * 1e3, "feed_bgzf_blocks_per_step": feed_blocks,
-        "roofline_feed": roof("bgzf_inflate_kernel+bgzf_crc32_kernel", feed_alg_bytes, kms_f, None),
+        "roofline_feed": roof("bgzf_inflate_kernel+bgzf_crc32_kernel", feed_alg_bytes, kms_f,
+                              (traffic["bgzf_inflate_kernel"] + traffic["bgzf_crc32_kernel"]) if all(k in traffic for k in ("bgzf_inflate_kernel", "bgzf_crc32_kernel")) else None),
+        "feed_slice_sized_launch": feed_small,
         "global_align_cells_per_s": ga_cells / dt_ga, "global_align_ms_per_step": dt_ga / args.steps * 1e3,
         "global_align_problems_per_step": n_ga,
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",

@@ -985,6 +985,14 @@ class PileupStream:
         ref = ref_seq.encode()
         self._check(self.L.sk_pileup_stream_begin_region(self.h, ref, ref_offset, len(ref), report_begin, report_end, span))
 
+    def push_raw(self, rb, final_to, span=49):
+        """push without copying the window out (bench): -> (begin, end)"""
+        s = ReadBatchStruct(rb.n_reads, _p(rb.read_off), _p(rb.read_code), _p(rb.read_qual), _p(rb.path_off), _p(rb.path),
+                            _p(rb.pos), _p(rb.is_fwd), _p(rb.mapq), _p(rb.map_level), None, 0, 0, None)
+        w = PileupWindow()
+        self._check(self.L.sk_pileup_stream_push(self.h, C.byref(s), span, 0, 0, None, min(final_to, 2**31 - 1), 0, 0, None, C.byref(w)))
+        return w.begin, w.end
+
     def push(self, rb, final_to, mask=None, mask_begin=0, ploidy=None, ploidy_begin=0, span=49):
         """rb: synth.ReadBatch (its reference / mask fields are ignored) -> dict of numpy copies for [begin, end)"""
         s = ReadBatchStruct(rb.n_reads, _p(rb.read_off), _p(rb.read_code), _p(rb.read_qual), _p(rb.path_off), _p(rb.path),

@@ -13,7 +13,7 @@ from tests import e2e_util as E
 def test_e2e_leg_runs_and_compares(monkeypatch):
     import bench
     monkeypatch.setenv("SK_E2E_BINARY", "starling2_dbl")
-    args = argparse.Namespace(e2e_bp=400000, e2e_segment_bp=100000)
+    args = argparse.Namespace(e2e_bp=400000, e2e_segment_bp=100000, e2e_max_procs_per_gpu=8)
     out = bench.e2e_leg(args, 0, 1, 0, lambda: None, lambda v: v, with_reference=True)
     assert out["identical"] is True and out["segments"] == 4 and out["bp"] == 400000
     assert out["variant_records"] > 300 and out["ref_wall_s"] > 0 and out["amd_wall_s"] > 0
