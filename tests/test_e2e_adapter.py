@@ -250,3 +250,71 @@ def test_synthetic_identical_through_adapter_gpu(tmp_path, which):
 @pytest.mark.parametrize("which", ["short_reads", "long_reads"])
 def test_synthetic_identical_with_device_enumeration(tmp_path, which):
     _synth("amd", tmp_path, which, extra_env={"SK_ENUMERATION": "2"})
+
+
+# ---- the workflow's variant inputs: --candidate-indel-input-vcf (Manta's candidates in a somatic run, PY/strelkaSharedWorkflow.py:189) and
+# --force-output-vcf (forced genotyping, :190).  Candidates arrive as observations that no read made (IndelData::status.notDiscoveredFromReads,
+# the external-candidate flag of the realignment job's table), forced positions switch off the zero-coverage / all-reference exits of the
+# site callers and make every window's cached result answer for isForcedOutput.
+def _variant_inputs(tmp_path, d, length):
+    import subprocess
+    region, fa = "chrS:1-%d" % length, os.path.join(d, "synth.fa")
+    o = str(tmp_path / "probe") + "/"
+    os.makedirs(o, exist_ok=True)
+    E.run(E.germline_argv("starling2_ref", o, [os.path.join(d, "germline_S1.bam"), os.path.join(d, "germline_S2.bam")], region=region, ref=fa))
+    recs = [l.split("\t") for l in E.vcf_body(o + "variants.vcf") if not l.startswith("#")]
+    indels = [r for r in recs if len(r[3]) != len(r[4].split(",")[0])]
+    snvs = [r for r in recs if len(r[3]) == 1 and len(r[4].split(",")[0]) == 1]
+    assert len(indels) > 60 and len(snvs) > 60
+    head = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    line = lambda r: "%s\t%s\t.\t%s\t%s\t.\tPASS\t.\n" % (r[0], r[1], r[3], r[4].split(",")[0])
+    with open(fa) as f:
+        seq = "".join(l.strip() for l in f if not l.startswith(">"))
+    cand = tmp_path / "candidates.vcf"
+    cand.write_text(head + "".join(line(r) for r in indels[::3]))
+    forced_recs = sorted([(int(r[1]), line(r)) for r in snvs[::5] + indels[1::7]] +
+                         [(p, "chrS\t%d\t.\t%s\t%s\t.\tPASS\t.\n" % (p, seq[p - 1], "ACGT"[("ACGT".index(seq[p - 1]) + 1) % 4])) for p in range(997, length - 500, 4001)])
+    forced = tmp_path / "forced.vcf"
+    forced.write_text(head + "".join(l for _, l in forced_recs))
+    for v in (cand, forced):
+        subprocess.run([os.path.join(E.BIN_DIR, "bgzip"), "-f", str(v)], check=True)
+        subprocess.run([os.path.join(E.BIN_DIR, "tabix"), "-p", "vcf", str(v) + ".gz"], check=True)
+    return ["--candidate-indel-input-vcf", str(cand) + ".gz", "--force-output-vcf", str(forced) + ".gz"]
+
+
+def _synth_with_variant_inputs(variant, tmp_path, env=None):
+    d, length = SYNTH_SETS["short_reads"]
+    region, fa = "chrS:1-%d" % length, os.path.join(d, "synth.fa")
+    extra = _variant_inputs(tmp_path, d, length)
+    outs = {}
+    for v in ("ref", variant):
+        o = str(tmp_path / v) + "/"
+        os.makedirs(o, exist_ok=True)
+        outs[v] = o
+        e = dict({"STRELKA_AMD_VERBOSE": "1"}, **(env or {})) if v != "ref" else None
+        E.run(E.germline_argv("starling2_" + v, o, [os.path.join(d, "germline_S1.bam"), os.path.join(d, "germline_S2.bam")], region=region, ref=fa,
+                              extra=extra), env=e)
+        E.run(E.somatic_argv("strelka2_" + v, o, os.path.join(d, "somatic_normal.bam"), os.path.join(d, "somatic_tumor.bam"), region=region, ref=fa,
+                             extra=extra), env=e)
+    n_forced = 0
+    for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf", "somatic.snvs.vcf", "somatic.indels.vcf"):
+        want, got = E.vcf_body(outs["ref"] + f, keep_header=True), E.vcf_body(outs[variant] + f, keep_header=True)
+        assert got == want, f
+        n_forced += sum(1 for l in want if not l.startswith("#"))
+    # forced positions reached the outputs: the somatic SNV file reports every forced site, called or not
+    assert sum(1 for l in E.vcf_body(outs["ref"] + "somatic.snvs.vcf") if not l.startswith("#")) > 20 and n_forced > 1000
+
+
+@pytest.mark.skipif(not (E.have("starling2_dbl", "strelka2_dbl") and _have_synth() and os.path.exists(os.path.join(E.BIN_DIR, "tabix"))),
+                    reason="oracle/_ref binaries / synthetic inputs / tabix not built")
+@pytest.mark.parametrize("windows", [None, (700, 900)])
+def test_candidate_indel_and_forced_output_vcfs_identical_cpu_double(tmp_path, windows):
+    env = {} if windows is None else {"STRELKA_AMD_READ_WINDOW": str(windows[0]), "STRELKA_AMD_SITE_WINDOW": str(windows[1])}
+    _synth_with_variant_inputs("dbl", tmp_path, env)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (E.have("starling2_amd", "strelka2_amd") and _have_synth() and os.path.exists(os.path.join(E.BIN_DIR, "tabix"))),
+                    reason="oracle/_ref binaries / synthetic inputs / tabix not built")
+def test_candidate_indel_and_forced_output_vcfs_identical_gpu(tmp_path):
+    _synth_with_variant_inputs("amd", tmp_path)
