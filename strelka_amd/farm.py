@@ -74,6 +74,51 @@ def germline_segment_argv(binary, out_prefix, bams, regions, ref, chrom_depth=No
     return cmd + list(extra)
 
 
+def somatic_segment_argv(binary, out_prefix, normal_bam, tumor_bam, regions, ref, chrom_depth=None, callable_regions=False, skip_header=False,
+                         extra=()):
+    """One somatic segment process as the workflow builds it: PY/strelkaSomaticWorkflow.py:74-146 with the defaults of
+    src/python/bin/configureStrelkaSomaticWorkflow.py.ini, EVS models on (they ship with the reference), --strelka-chrom-depth-file /
+    --strelka-max-depth-factor when the high-depth filter is on (WGS; :140-142), --strelka-skip-header for every segment but the first."""
+    cmd = [os.path.join(BIN_DIR, binary)]
+    for r in regions:
+        cmd += ["--region", r]
+    cmd += ["--ref", ref, "--max-indel-size", "49", "--min-mapping-quality", "20",
+            "--somatic-snv-rate", "0.0001", "--shared-site-error-rate", "0.0000000005",
+            "--shared-site-error-strand-bias-fraction", "0.0", "--somatic-indel-rate", "0.000001",
+            "--shared-indel-error-factor", "2.2", "--tier2-min-mapping-quality", "0",
+            "--strelka-snv-max-filtered-basecall-frac", "0.4", "--strelka-snv-max-spanning-deletion-frac", "0.75",
+            "--strelka-snv-min-qss-ref", "15", "--strelka-indel-max-window-filtered-basecall-frac", "0.3",
+            "--strelka-indel-min-qsi-ref", "40", "--ssnv-contam-tolerance", "0.15", "--indel-contam-tolerance", "0.15",
+            "--somatic-snv-scoring-model-file", os.path.join(MODEL_DIR, "somaticSNVScoringModels.json"),
+            "--somatic-indel-scoring-model-file", os.path.join(MODEL_DIR, "somaticIndelScoringModels.json"),
+            "--normal-align-file", normal_bam, "--tumor-align-file", tumor_bam,
+            "--somatic-snv-file", out_prefix + "somatic.snvs.vcf", "--somatic-indel-file", out_prefix + "somatic.indels.vcf"]
+    if callable_regions:
+        cmd += ["--somatic-callable-regions-file", out_prefix + "somatic.callable.regions.bed"]
+    cmd += ["--stats-file", out_prefix + "runStats.xml"]
+    if skip_header:
+        cmd.append("--strelka-skip-header")
+    if chrom_depth:
+        cmd += ["--strelka-chrom-depth-file", chrom_depth, "--strelka-max-depth-factor", "3.0"]
+    return cmd + list(extra)
+
+
+def wgs_somatic_dataset(length=1000000, normal_depth=40.0, tumor_depth=110.0, seed=20260926, procs=16):
+    """A WGS-like tumour / normal pair (BASELINE.json configs[2]: 110x / 40x): the same reference and germline variants, the tumour with
+    two clone haplotypes carrying somatic SNVs and indels.  -> directory with normal.bam, tumor.bam, normal.fa (the pair's reference),
+    chrom_depth.txt"""
+    d = os.path.join(REPO, "oracle", "_ref", "synth", "wgs_somatic_%d_%g_%g_%d_p%d" % (length, normal_depth, tumor_depth, seed, procs))
+    if not os.path.exists(os.path.join(d, "chrom_depth.txt")):
+        os.makedirs(d, exist_ok=True)
+        for role, depth, name in (("normal", normal_depth, "normal"), ("tumor", tumor_depth, "tumor")):
+            subprocess.run([sys.executable, os.path.join(REPO, "tools", "make_wgs_bam.py"), d, os.path.join(BIN_DIR, "samtools"),
+                            "--length", str(length), "--depth", str(depth), "--seed", str(seed), "--procs", str(procs), "--role", role,
+                            "--name", name, "--sample", name.upper()], check=True, stdout=subprocess.DEVNULL)
+        with open(os.path.join(d, "chrom_depth.txt"), "w") as f:
+            f.write("chrW\t%.3f\n" % normal_depth)
+    return d
+
+
 def wgs_dataset(length=1000000, depth=40.0, seed=20260926, procs=16):
     """A WGS-like synthetic sample (tools/make_wgs_bam.py: 150 bp reads, human variant density), made on the spot under
     oracle/_ref/synth/ (git-ignored) and kept.  -> directory with wgs.bam(.bai), wgs.fa(.fai), chrom_depth.txt"""

@@ -202,6 +202,11 @@ def main():
     ap.add_argument("--name", default="wgs")
     ap.add_argument("--snv-every", type=float, default=1000.0)
     ap.add_argument("--indel-every", type=float, default=8000.0)
+    ap.add_argument("--role", choices=["germline", "normal", "tumor"], default="germline",
+                    help="tumor: reads also come from two clone haplotypes carrying somatic variants (--clone-fraction of the reads); normal / "
+                         "tumor of one seed share the reference and the germline variants")
+    ap.add_argument("--somatic-every", type=float, default=40000.0, help="mean distance between somatic variants (tumor)")
+    ap.add_argument("--clone-fraction", type=float, default=0.6)
     ap.add_argument("--procs", type=int, default=max(1, min(16, len(os.sched_getaffinity(0)))),
                     help="worker processes (the data set depends on the seed AND this number)")
     a = ap.parse_args()
@@ -221,6 +226,25 @@ def main():
         for pos, ref_len, alt, zyg in variants:
             f.write("%d\t%d\t%s\t%d\n" % (pos + 1, ref_len, alt.decode(), zyg))
     haps = [haplotype(ref, variants, w) for w in (0, 1)]
+    hap_probs = [0.5, 0.5]
+    if a.role == "tumor":
+        # somatic variants: their own generator stream (the germline draw above is the pair's common part), kept clear of the germline ones
+        srng = np.random.default_rng(a.seed + 7)
+        taken = np.array([v[0] for v in variants], np.int64)
+        som = []
+        for v in plant(ref, repeats, srng, a.somatic_every * 1.25, a.somatic_every * 5.0):
+            j = int(np.searchsorted(taken, v[0]))
+            near = min(abs(int(taken[k]) - v[0]) for k in (j - 1, j) if 0 <= k < len(taken)) if len(taken) else 1 << 30
+            if near > 60:
+                som.append((v[0], v[1], v[2], int(srng.integers(0, 2))))  # on one clone haplotype
+        with open(os.path.join(a.out, a.name + ".somatic_truth.tsv"), "w") as f:
+            for pos, ref_len, alt, zyg in som:
+                f.write("%d\t%d\t%s\t%d\n" % (pos + 1, ref_len, alt.decode(), zyg))
+        merged = sorted(variants + som)
+        haps += [haplotype(ref, [v for v in merged], w) for w in (0, 1)]
+        cf = a.clone_fraction
+        hap_probs = [(1 - cf) / 2, (1 - cf) / 2, cf / 2, cf / 2]
+    hap_cum = np.cumsum(hap_probs)
     hap_text = [BASES[h[0]] for h in haps]
     bstarts = [np.array([b[2] for b in h[1]], np.int64) for h in haps]
     # hap position of every "structural" block (I or D) for the fast path test
@@ -240,7 +264,7 @@ def main():
         ref_to_hap.append((np.array(rp_list, np.int64), np.array(roff_list, np.int64)))
 
     n_reads = int(L * a.depth / RL)
-    starts = np.sort(rng.integers(0, L - RL - 50, n_reads))
+    starts = np.sort((rng if a.role != "tumor" else np.random.default_rng(a.seed + 11)).integers(0, L - RL - 50, n_reads))
     bam = os.path.join(a.out, a.name + ".bam")
     header = ("@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n@RG\tID:%s\tSM:%s\n" % (a.contig, L, a.sample, a.sample)).encode()
     tail = ("\tRG:Z:%s\n" % a.sample).encode()
@@ -255,7 +279,7 @@ def main():
     cuts = [int(round(k * n_reads / procs)) for k in range(procs + 1)]
 
     def worker(k):
-        wrng = np.random.default_rng(a.seed + 1000 + k)
+        wrng = np.random.default_rng(a.seed + 1000 + k + {"germline": 0, "normal": 0, "tumor": 500000}[a.role])
         lo = int(starts[cuts[k]]) if k > 0 else -(1 << 62)
         hi = int(starts[cuts[k + 1]]) if k + 1 < procs else 1 << 62
         part = os.path.join(a.out, "%s.part%03d.bam" % (a.name, k))
@@ -267,7 +291,7 @@ def main():
         for c0 in range(cuts[k], cuts[k + 1], CH):
             st = starts[c0:min(c0 + CH, cuts[k + 1])]
             n = len(st)
-            which = wrng.integers(0, 2, n)
+            which = np.minimum(np.searchsorted(hap_cum, wrng.random(n), side="right"), len(haps) - 1)
             lens = np.where(wrng.random(n) < 0.93, RL, wrng.integers(70, RL + 1, n))
             q = qualities(n, RL, wrng)
             err = wrng.random((n, RL)) < np.power(10.0, -q.astype(np.float64) / 10.0)
