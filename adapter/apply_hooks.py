@@ -101,6 +101,10 @@ HOOKS = [
          'sk_adapter::somatic_snv_genotype(*this, pos, *(normal_cpi_ptr[0]), *(tumor_cpi_ptr[0]), '
          '(_opt.useTier2Evidence ? normal_cpi_ptr[1] : nullptr), (_opt.useTier2Evidence ? tumor_cpi_ptr[1] : nullptr), '
          'isComputeNonSomatic, sgtg);'),
+        # site 9 (somatic): the tumor sample's EVS accumulators of a position, just before its record is written
+        ("write_vcf_somatic_snv_genotype_strand_grid",
+         r'(\n)(        write_vcf_somatic_snv_genotype_strand_grid\(_opt, _dopt, sgtg,)',
+         '\\1        sk_adapter::somatic_fill_scoring_metrics(*this, pos);\n\\2'),
         # site 6
         ("get_somatic_indel",
          r'_dopt\.sicaller_grid\(\)\.get_somatic_indel\(_opt,_dopt,',

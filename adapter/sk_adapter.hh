@@ -85,6 +85,11 @@ void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, cons
                           const CleanedPileup* normal2, const CleanedPileup* tumor2, const bool isComputeNonSomatic,
                           somatic_snv_genotype_grid& sgt);
 
+/// the tumor sample's readPositionRankSum / altAlleleReadPositionInfo of `pos` (updateSomaticScoringMetrics,
+/// starling_pos_processor_base.cpp:984-1000), rebuilt from the pileup stream's window before the position's record is written
+/// (strelka_pos_processor.cpp:255); nothing to do when the reference's own pileup ran
+void somatic_fill_scoring_metrics(starling_pos_processor_base& pp, const pos_t pos);
+
 // ---- site 6: get_somatic_indel at strelka_pos_processor.cpp:343-349 ----
 void somatic_indel(const strelka_options& opt, const starling_sample_options& normalOpt, const starling_sample_options& tumorOpt,
                    const IndelKey& indelKey, const IndelData& indelData, const unsigned normalSampleIndex,

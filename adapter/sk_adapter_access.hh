@@ -110,11 +110,27 @@ struct SiteChunk
     std::vector<uint8_t> ploidy;      ///< ... and the ploidy
 };
 
-/// site 9: one pileup stream per sample (sk_adapter_pileup.cpp)
+/// somatic SNV records of a run of positions one push of the two samples' pileups finalised (site 9 chained into site 5)
+struct SomaticChunk
+{
+    pos_t begin = 0, end = 0;
+    std::vector<sk_somatic_snv_genotype> genotypes; ///< empty when the stream does not genotype
+    std::vector<uint32_t> count[4];                 ///< cleaned column sizes: normal t1, tumor t1, normal t2, tumor t2
+    std::vector<uint8_t> forced;
+    // what updateSomaticScoringMetrics would have accumulated for the tumor sample, kept until a record is written
+    std::vector<int64_t> tumorTier1Off;             ///< [n+1]
+    std::vector<uint32_t> tumorReadPos;             ///< parallel to the tumor's tier1 calls: read_pos | read_size << 16
+    std::vector<uint8_t> isMetricsFilled;
+};
+
+/// site 9: one pileup stream per sample (sk_adapter_pileup.cpp); the somatic caller's two samples share one
 struct PileupState
 {
     bool decided = false, enabled = false, isGenotyping = false;
+    bool isSomatic = false, isSomaticMetrics = false;
     std::vector<sk_pileup_stream*> streams;
+    sk_somatic_pileup_stream* somaticStream = nullptr;
+    std::deque<SomaticChunk> somaticChunks;
     std::vector<std::deque<SiteChunk>> chunks; ///< per sample, ascending
     std::vector<uint8_t> isRegionOpen;         ///< per sample: sk_pileup_stream_begin_region done for the current region
     std::vector<pos_t> nextFinal;              ///< per sample: positions below are final (filled into the reference's buffers)
@@ -159,6 +175,8 @@ bool pileup_genotypes_with_stream(const starling_base_options& opt);
 void pileup_reset_region(starling_pos_processor_base& pp);
 void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos);
 void pileup_note_read(const unsigned sampleIndex, const pos_t bufferPos);
+/// (sk_adapter_somatic.cpp) the somatic SNV model's options for the chained stream; false: the run does not call somatic SNVs
+bool somatic_stream_options(const starling_pos_processor_base& pp, sk_somatic_snv_options& so, bool& isComputeNonSomatic);
 
 struct AccumTimer // adds its lifetime to `acc`
 {

@@ -11,8 +11,15 @@
 // pos_basecall_buffer in bulk, so everything downstream (CleanPileupFilter, site / indel locus info, gVCF) runs unchanged; the
 // genotypes wait in a per-sample cache for process_pos_snp_digt (sk_adapter_germline.cpp).
 //
-// Not routed (the reference's own pileup runs): the somatic processor and runs that compute the EVS feature accumulators
-// (updateGermlineScoringMetrics / updateSomaticScoringMetrics: rank sums over every basecall), and $STRELKA_AMD_PILEUP=0.
+// The somatic caller's two samples go through ONE stream (sk_somatic_pileup_stream_*): both are pushed together, share the finalised
+// range, and their four cleaned columns go on the device straight into position_somatic_snv_call's kernels (site 5); the records
+// wait for process_pos_snp_somatic (sk_adapter_somatic.cpp).  With the somatic EVS models loaded the reference also feeds, for
+// every tumor basecall, a rank-sum and a list of alternate-allele read positions (updateSomaticScoringMetrics) that only the
+// writer of a somatic record ever reads: the stream returns each tumor call's read position and read length, and
+// somatic_fill_scoring_metrics() rebuilds the two accumulators for a position just before its record is written.
+//
+// Not routed (the reference's own pileup runs): runs that compute the GERMLINE EVS accumulators (updateGermlineScoringMetrics:
+// three rank sums over every basecall), and $STRELKA_AMD_PILEUP=0.
 #include "sk_adapter_access.hh"
 
 #include "blt_util/log.hh"
@@ -79,13 +86,148 @@ struct WindowBatch
     }
 };
 
+/// the reads buffered in [begin, end) of one sample with their best alignments, as pileup_read_segment would take them
+void gatherWindow(starling_pos_processor_base& pp, const unsigned sampleIndex, const pos_t begin, const pos_t end, WindowBatch& wb)
+{
+    State& s(state());
+    const starling_base_options& opt(Access::opt(pp));
+    wb.clear();
+    static const std::vector<WindowSegment> noSegments;
+    for (const WindowSegment& ws : (begin < end ? s.windowSegments[sampleIndex] : noSegments))
+    {
+        const read_segment& rseg(*ws.rseg);
+        const pos_t pos(ws.bufferPos);
+
+        // pileup_read_segment's read-level exits (:1132-1165), messages included
+        const alignment* best(&(rseg.getInputAlignment()));
+        if (rseg.is_realigned) best = &(rseg.realignment);
+        else if (! rseg.is_any_nonovermax(opt.maxIndelSize)) continue;
+        if (best->empty())
+        {
+            if (! rseg.is_realigned)
+            {
+                if (opt.verbosity >= LOG_LEVEL::ALLWARN)
+                {
+                    log_os << "WARNING: skipping read_segment with no genomic alignment and contig alignment outside of indel.\n";
+                    log_os << "\tread_name: " << rseg.key() << "\n";
+                }
+            }
+            else
+            {
+                log_os << "WARNING: skipping read_segment which has multiple equally likely but incompatible alignments: " << rseg.key() << "\n";
+            }
+            continue;
+        }
+        if (rseg.is_realigned && rseg.is_invalid_realignment) continue;
+
+        const unsigned readSize(rseg.read_size());
+        const unsigned refSpan(ALIGNPATH::apath_ref_length(best->path));
+        // :1186-1191 with the reference's value at the time its READ_BUFFER stage was at this read
+        const unsigned spanThen(static_cast<unsigned>(s.geometry.query(pos).rangeMinOffset) + 1);
+        if (refSpan > (readSize + spanThen)) continue;
+
+        const bam_seq bseq(rseg.get_bam_read());
+        const size_t c0(wb.code.size());
+        wb.code.resize(c0 + readSize);
+        for (unsigned i(0); i < readSize; ++i) wb.code[c0 + i] = bseq.get_code(static_cast<pos_t>(i));
+        const uint8_t* q(rseg.qual());
+        wb.qual.insert(wb.qual.end(), q, q + readSize);
+        for (const auto& seg : best->path)
+        {
+            sk_path_seg out;
+            out.type = static_cast<uint32_t>(seg.type);
+            out.length = seg.length;
+            wb.path.push_back(out);
+        }
+        wb.readOff.push_back(static_cast<int64_t>(wb.code.size()));
+        wb.pathOff.push_back(static_cast<int64_t>(wb.path.size()));
+        wb.pos.push_back(best->pos);
+        wb.isFwd.push_back(best->is_fwd_strand ? 1 : 0);
+        wb.mapq.push_back(rseg.map_qual());
+        wb.level.push_back(static_cast<uint8_t>(rseg.getInputAlignmentMapLevel()));
+        wb.lo = std::min(wb.lo, best->pos);
+        wb.hi = std::max(wb.hi, best->pos + static_cast<pos_t>(refSpan));
+    }
+}
+
+void fillReadBatch(const WindowBatch& wb, sk_read_batch& rb)
+{
+    std::memset(&rb, 0, sizeof(rb));
+    rb.n_reads = static_cast<int32_t>(wb.pos.size());
+    static const uint8_t none8(0);
+    static const sk_path_seg noneSeg = {0u, 0u};
+    static const int32_t none32(0);
+    rb.read_off = wb.readOff.data();
+    rb.read_code = wb.code.empty() ? &none8 : wb.code.data();
+    rb.read_qual = wb.qual.empty() ? &none8 : wb.qual.data();
+    rb.path_off = wb.pathOff.data();
+    rb.path = wb.path.empty() ? &noneSeg : wb.path.data();
+    rb.pos = wb.pos.empty() ? &none32 : wb.pos.data();
+    rb.is_fwd = wb.isFwd.empty() ? &none8 : wb.isFwd.data();
+    rb.mapq = wb.mapq.empty() ? &none8 : wb.mapq.data();
+    rb.map_level = wb.level.empty() ? &none8 : wb.level.data();
+}
+
+/// CandidateSnvBuffer::isCandidateSnvAnySample over [lo, hi) clipped to the reference segment, as of now
+void candidateMask(starling_pos_processor_base& pp, const pos_t lo, const pos_t hi, std::vector<uint8_t>& mask, pos_t& maskBegin,
+                   pos_t& maskEnd)
+{
+    const reference_contig_segment& ref(Access::ref(pp));
+    maskBegin = std::max(lo, static_cast<pos_t>(ref.get_offset()));
+    maskEnd = std::min(hi, static_cast<pos_t>(ref.get_offset()) + static_cast<pos_t>(ref.seq().size()));
+    if (maskEnd < maskBegin) maskEnd = maskBegin;
+    mask.assign(static_cast<size_t>(maskEnd - maskBegin), 0);
+    const CandidateSnvBuffer& csb(Access::candidateSnvBuffer(pp));
+    if (! csb.empty())
+    {
+        const unsigned sampleCount(Access::sampleCount(pp));
+        for (pos_t p(maskBegin); p < maskEnd; ++p)
+        {
+            uint8_t m(0);
+            for (unsigned si(0); si < sampleCount; ++si)
+            {
+                for (unsigned b(0); b < 4; ++b)
+                {
+                    if (csb.getHaplotypeId(si, p, static_cast<BASE_ID::index_t>(b)) != 0) m |= static_cast<uint8_t>(1u << b);
+                }
+            }
+            mask[static_cast<size_t>(p - maskBegin)] = m;
+        }
+    }
+}
+
+/// the finalised positions of a window into the reference's pos_basecall_buffer (what insert_pos_basecall / insert_mapq_count /
+/// insert_pos_spandel_count / insert_pos_submap_count would have left there)
+void assignWindow(starling_pos_processor_base::sample_info& sif, const sk_pileup_window& w)
+{
+    const size_t n(static_cast<size_t>(w.end - w.begin));
+    static_assert(sizeof(base_call) == 2, "base_call is the 16-bit record the kernels write");
+    for (size_t i(0); i < n; ++i)
+    {
+        const uint32_t mq(w.mapq_count[i]), sd(w.spandel_count[i]), sm(w.submapped_count[i]);
+        if ((mq | sd | sm) == 0) continue; // untouched: the reference has no entry either
+        snp_pos_info& pi(Access::pileupRef(sif.basecallBuffer, w.begin + static_cast<pos_t>(i)));
+        const size_t n1(static_cast<size_t>(w.tier1_off[i + 1] - w.tier1_off[i]));
+        const size_t n2(static_cast<size_t>(w.tier2_off[i + 1] - w.tier2_off[i]));
+        static const base_call blank(0, 0, false, 0, 0, false, false, false);
+        pi.calls.assign(n1, blank);
+        if (n1) std::memcpy(static_cast<void*>(pi.calls.data()), w.tier1_calls + w.tier1_off[i], 2 * n1);
+        pi.tier2_calls.assign(n2, blank);
+        if (n2) std::memcpy(static_cast<void*>(pi.tier2_calls.data()), w.tier2_calls + w.tier2_off[i], 2 * n2);
+        pi.spanningDeletionReadCount = sd;
+        pi.submappedReadCount = sm;
+        pi.mapqTracker.count = mq;
+        pi.mapqTracker.zeroCount = w.mapq_zero_count[i];
+        pi.mapqTracker.sumSquare = static_cast<double>(w.mapq_sum_square[i]);
+    }
+}
+
 /// one sample's window into its stream; the finalised positions into the reference's buffers
 void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sampleIndex, const pos_t begin, const pos_t end,
                           const bool isFinal)
 {
     State& s(state());
     PileupState& ps(s.pileup);
-    const starling_base_options& opt(Access::opt(pp));
     starling_pos_processor_base::sample_info& sif(pp.sample(sampleIndex));
     const reference_contig_segment& ref(Access::ref(pp));
     sk_pileup_stream* stream(ps.streams[sampleIndex]);
@@ -99,96 +241,15 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
     }
 
     static WindowBatch wb;
-    wb.clear();
-    static const std::vector<WindowSegment> noSegments;
-    for (const WindowSegment& ws : (begin < end ? s.windowSegments[sampleIndex] : noSegments))
-    {
-        {
-            const read_segment& rseg(*ws.rseg);
-            const pos_t pos(ws.bufferPos);
-
-            // pileup_read_segment's read-level exits (:1132-1165), messages included
-            const alignment* best(&(rseg.getInputAlignment()));
-            if (rseg.is_realigned) best = &(rseg.realignment);
-            else if (! rseg.is_any_nonovermax(opt.maxIndelSize)) continue;
-            if (best->empty())
-            {
-                if (! rseg.is_realigned)
-                {
-                    if (opt.verbosity >= LOG_LEVEL::ALLWARN)
-                    {
-                        log_os << "WARNING: skipping read_segment with no genomic alignment and contig alignment outside of indel.\n";
-                        log_os << "\tread_name: " << rseg.key() << "\n";
-                    }
-                }
-                else
-                {
-                    log_os << "WARNING: skipping read_segment which has multiple equally likely but incompatible alignments: " << rseg.key() << "\n";
-                }
-                continue;
-            }
-            if (rseg.is_realigned && rseg.is_invalid_realignment) continue;
-
-            const unsigned readSize(rseg.read_size());
-            const unsigned refSpan(ALIGNPATH::apath_ref_length(best->path));
-            // :1186-1191 with the reference's value at the time its READ_BUFFER stage was at this read
-            const unsigned spanThen(static_cast<unsigned>(s.geometry.query(pos).rangeMinOffset) + 1);
-            if (refSpan > (readSize + spanThen)) continue;
-
-            const bam_seq bseq(rseg.get_bam_read());
-            const size_t c0(wb.code.size());
-            wb.code.resize(c0 + readSize);
-            for (unsigned i(0); i < readSize; ++i) wb.code[c0 + i] = bseq.get_code(static_cast<pos_t>(i));
-            const uint8_t* q(rseg.qual());
-            wb.qual.insert(wb.qual.end(), q, q + readSize);
-            for (const auto& seg : best->path)
-            {
-                sk_path_seg out;
-                out.type = static_cast<uint32_t>(seg.type);
-                out.length = seg.length;
-                wb.path.push_back(out);
-            }
-            wb.readOff.push_back(static_cast<int64_t>(wb.code.size()));
-            wb.pathOff.push_back(static_cast<int64_t>(wb.path.size()));
-            wb.pos.push_back(best->pos);
-            wb.isFwd.push_back(best->is_fwd_strand ? 1 : 0);
-            wb.mapq.push_back(rseg.map_qual());
-            wb.level.push_back(static_cast<uint8_t>(rseg.getInputAlignmentMapLevel()));
-            wb.lo = std::min(wb.lo, best->pos);
-            wb.hi = std::max(wb.hi, best->pos + static_cast<pos_t>(refSpan));
-        }
-    }
+    gatherWindow(pp, sampleIndex, begin, end, wb);
 
     const pos_t span(static_cast<pos_t>(Access::largestTotalIndelRefSpanPerRead(pp)));
     const int32_t finalTo(isFinal ? INT32_MAX : static_cast<int32_t>(end - span));
 
-    // CandidateSnvBuffer::isCandidateSnvAnySample over the new reads' span, as of now
     static std::vector<uint8_t> mask;
     pos_t maskBegin(0), maskEnd(0);
-    if (! wb.pos.empty())
-    {
-        maskBegin = std::max(wb.lo, static_cast<pos_t>(ref.get_offset()));
-        maskEnd = std::min(wb.hi, static_cast<pos_t>(ref.get_offset()) + static_cast<pos_t>(ref.seq().size()));
-        if (maskEnd < maskBegin) maskEnd = maskBegin;
-        mask.assign(static_cast<size_t>(maskEnd - maskBegin), 0);
-        const CandidateSnvBuffer& csb(Access::candidateSnvBuffer(pp));
-        if (! csb.empty())
-        {
-            const unsigned sampleCount(Access::sampleCount(pp));
-            for (pos_t p(maskBegin); p < maskEnd; ++p)
-            {
-                uint8_t m(0);
-                for (unsigned si(0); si < sampleCount; ++si)
-                {
-                    for (unsigned b(0); b < 4; ++b)
-                    {
-                        if (csb.getHaplotypeId(si, p, static_cast<BASE_ID::index_t>(b)) != 0) m |= static_cast<uint8_t>(1u << b);
-                    }
-                }
-                mask[static_cast<size_t>(p - maskBegin)] = m;
-            }
-        }
-    }
+    mask.clear();
+    if (! wb.pos.empty()) candidateMask(pp, wb.lo, wb.hi, mask, maskBegin, maskEnd);
 
     // caller ploidy of the positions this push can finalise (process_pos_snp_digt "prep step 2", starling_pos_processor.cpp:637-651,
     // without the indel calls' adjustment, which is not known yet: site_diploid_genotype() checks it when the locus is called)
@@ -214,20 +275,7 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
     }
 
     sk_read_batch rb;
-    std::memset(&rb, 0, sizeof(rb));
-    rb.n_reads = static_cast<int32_t>(wb.pos.size());
-    static const uint8_t none8(0);
-    static const sk_path_seg noneSeg = {0u, 0u};
-    static const int32_t none32(0);
-    rb.read_off = wb.readOff.data();
-    rb.read_code = wb.code.empty() ? &none8 : wb.code.data();
-    rb.read_qual = wb.qual.empty() ? &none8 : wb.qual.data();
-    rb.path_off = wb.pathOff.data();
-    rb.path = wb.path.empty() ? &noneSeg : wb.path.data();
-    rb.pos = wb.pos.empty() ? &none32 : wb.pos.data();
-    rb.is_fwd = wb.isFwd.empty() ? &none8 : wb.isFwd.data();
-    rb.mapq = wb.mapq.empty() ? &none8 : wb.mapq.data();
-    rb.map_level = wb.level.empty() ? &none8 : wb.level.data();
+    fillReadBatch(wb, rb);
 
     sk_pileup_window w;
     std::memset(&w, 0, sizeof(w));
@@ -241,28 +289,8 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
     s.pileupReads += wb.pos.size();
     if (! wb.pos.empty()) ps.pendingEnd[sampleIndex] = std::max(ps.pendingEnd[sampleIndex], wb.hi);
 
-    // ---- the finalised positions, into the reference's pos_basecall_buffer (what insert_pos_basecall / insert_mapq_count /
-    // insert_pos_spandel_count / insert_pos_submap_count would have left there)
+    assignWindow(sif, w);
     const size_t n(static_cast<size_t>(w.end - w.begin));
-    static_assert(sizeof(base_call) == 2, "base_call is the 16-bit record the kernels write");
-    for (size_t i(0); i < n; ++i)
-    {
-        const uint32_t mq(w.mapq_count[i]), sd(w.spandel_count[i]), sm(w.submapped_count[i]);
-        if ((mq | sd | sm) == 0) continue; // untouched: the reference has no entry either
-        snp_pos_info& pi(Access::pileupRef(sif.basecallBuffer, w.begin + static_cast<pos_t>(i)));
-        const size_t n1(static_cast<size_t>(w.tier1_off[i + 1] - w.tier1_off[i]));
-        const size_t n2(static_cast<size_t>(w.tier2_off[i + 1] - w.tier2_off[i]));
-        static const base_call blank(0, 0, false, 0, 0, false, false, false);
-        pi.calls.assign(n1, blank);
-        if (n1) std::memcpy(static_cast<void*>(pi.calls.data()), w.tier1_calls + w.tier1_off[i], 2 * n1);
-        pi.tier2_calls.assign(n2, blank);
-        if (n2) std::memcpy(static_cast<void*>(pi.tier2_calls.data()), w.tier2_calls + w.tier2_off[i], 2 * n2);
-        pi.spanningDeletionReadCount = sd;
-        pi.submappedReadCount = sm;
-        pi.mapqTracker.count = mq;
-        pi.mapqTracker.zeroCount = w.mapq_zero_count[i];
-        pi.mapqTracker.sumSquare = static_cast<double>(w.mapq_sum_square[i]);
-    }
     s.pileupLoci += n;
 
     if (ps.isGenotyping && n > 0)
@@ -285,18 +313,123 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
     ps.nextFinal[sampleIndex] = isFinal ? INT_MAX : std::max(ps.nextFinal[sampleIndex], static_cast<pos_t>(finalTo));
 }
 
+/// the somatic caller: the normal and the tumor sample's windows into the one stream that holds both, chained into site 5
+void pileup_somatic_window(starling_pos_processor_base& pp, const pos_t begin, const pos_t end, const bool isFinal)
+{
+    State& s(state());
+    PileupState& ps(s.pileup);
+    const reference_contig_segment& ref(Access::ref(pp));
+    if (! ps.isRegionOpen[0])
+    {
+        check(sk_somatic_pileup_stream_begin_region(ps.somaticStream, ref.seq().data(), static_cast<int32_t>(ref.get_offset()),
+                                                    static_cast<int32_t>(ref.seq().size()), ps.regionBegin, ps.regionEnd,
+                                                    static_cast<int32_t>(Access::largestTotalIndelRefSpanPerRead(pp))),
+              "sk_somatic_pileup_stream_begin_region");
+        ps.isRegionOpen[0] = ps.isRegionOpen[1] = 1;
+    }
+    static WindowBatch wb[2];
+    sk_read_batch rb[2];
+    pos_t lo(INT_MAX), hi(INT_MIN);
+    for (unsigned si(0); si < 2; ++si)
+    {
+        gatherWindow(pp, si, begin, end, wb[si]);
+        fillReadBatch(wb[si], rb[si]);
+        if (! wb[si].pos.empty())
+        {
+            lo = std::min(lo, wb[si].lo);
+            hi = std::max(hi, wb[si].hi);
+            ps.pendingEnd[si] = std::max(ps.pendingEnd[si], wb[si].hi);
+        }
+        s.pileupReads += wb[si].pos.size();
+    }
+    const pos_t span(static_cast<pos_t>(Access::largestTotalIndelRefSpanPerRead(pp)));
+    const int32_t finalTo(isFinal ? INT32_MAX : static_cast<int32_t>(end - span));
+
+    static std::vector<uint8_t> mask;
+    pos_t maskBegin(0), maskEnd(0);
+    mask.clear();
+    if (lo != INT_MAX) candidateMask(pp, lo, hi, mask, maskBegin, maskEnd);
+
+    // is_forced_output_pos of the positions this push can finalise
+    static std::vector<uint8_t> forced;
+    forced.clear();
+    pos_t forcedBegin(0);
+    if (ps.isGenotyping)
+    {
+        forcedBegin = std::max(ps.regionBegin, std::min(ps.nextFinal[0], ps.regionEnd));
+        pos_t reach(isFinal ? std::max(ps.pendingEnd[0], ps.pendingEnd[1]) : static_cast<pos_t>(finalTo));
+        const pos_t forcedEnd(std::max(forcedBegin, std::min(reach, ps.regionEnd)));
+        forced.resize(static_cast<size_t>(forcedEnd - forcedBegin));
+        for (pos_t p(forcedBegin); p < forcedEnd; ++p)
+        {
+            forced[static_cast<size_t>(p - forcedBegin)] = Access::isForcedOutputPos(pp, p) ? 1 : 0;
+        }
+    }
+
+    sk_somatic_snv_options so;
+    bool isComputeNonSomatic(false);
+    (void)somatic_stream_options(pp, so, isComputeNonSomatic);
+
+    sk_somatic_pileup_window w;
+    std::memset(&w, 0, sizeof(w));
+    {
+        AccumTimer abiTimer(s.tPileupAbi);
+        check(sk_somatic_pileup_stream_push(ps.somaticStream, &rb[0], &rb[1], static_cast<int32_t>(span), static_cast<int32_t>(maskBegin),
+                                            static_cast<int32_t>(maskEnd - maskBegin), mask.empty() ? nullptr : mask.data(), finalTo,
+                                            static_cast<int32_t>(forcedBegin), static_cast<int32_t>(forced.size()),
+                                            forced.empty() ? nullptr : forced.data(), isComputeNonSomatic ? 1 : 0, &w),
+              "sk_somatic_pileup_stream_push");
+    }
+    s.pileupBatches++;
+    assignWindow(pp.sample(0), w.normal);
+    assignWindow(pp.sample(1), w.tumor);
+    const size_t n(static_cast<size_t>(w.normal.end - w.normal.begin));
+    s.pileupLoci += n;
+    if (n > 0 && (ps.isGenotyping || ps.isSomaticMetrics))
+    {
+        SomaticChunk chunk;
+        chunk.begin = w.normal.begin;
+        chunk.end = w.normal.end;
+        if (ps.isGenotyping)
+        {
+            chunk.genotypes.assign(w.genotype, w.genotype + n);
+            chunk.count[0].assign(w.normal.clean_count, w.normal.clean_count + n);
+            chunk.count[1].assign(w.tumor.clean_count, w.tumor.clean_count + n);
+            chunk.count[2].assign(w.normal_clean_tier2_count, w.normal_clean_tier2_count + n);
+            chunk.count[3].assign(w.tumor_clean_tier2_count, w.tumor_clean_tier2_count + n);
+            chunk.forced.resize(n);
+            for (size_t i(0); i < n; ++i)
+            {
+                const int64_t k(static_cast<int64_t>(chunk.begin) + static_cast<int64_t>(i) - forcedBegin);
+                chunk.forced[i] = (k >= 0 && k < static_cast<int64_t>(forced.size())) ? forced[static_cast<size_t>(k)] : 0;
+            }
+            s.siteLoci += n;
+            s.siteBatches++;
+        }
+        if (ps.isSomaticMetrics)
+        {
+            chunk.tumorTier1Off.assign(w.tumor.tier1_off, w.tumor.tier1_off + n + 1);
+            chunk.tumorReadPos.assign(w.tumor_tier1_read_pos, w.tumor_tier1_read_pos + w.tumor.tier1_off[n]);
+            chunk.isMetricsFilled.assign(n, 0);
+        }
+        ps.somaticChunks.push_back(std::move(chunk));
+    }
+    const pos_t next(isFinal ? INT_MAX : static_cast<pos_t>(finalTo));
+    for (unsigned si(0); si < 2; ++si) ps.nextFinal[si] = isFinal ? INT_MAX : std::max(ps.nextFinal[si], next);
+}
+
 }
 
 static bool pileup_routed(const starling_base_options& opt)
 {
-    return env_flag("STRELKA_AMD_PILEUP", true) && (! opt.isSomaticCallingMode) && (! opt.is_compute_germline_scoring_metrics()) &&
-           (! opt.is_compute_somatic_scoring_metrics);
+    // (the germline EVS accumulators -- three rank sums over every basecall, updateGermlineScoringMetrics -- are not produced)
+    return env_flag("STRELKA_AMD_PILEUP", true) && (! opt.is_compute_germline_scoring_metrics());
 }
 
 bool pileup_genotypes_with_stream(const starling_base_options& opt)
 {
-    // genotypes straight from the device columns: the diploid germline model only
-    return pileup_routed(opt) && opt.is_bsnp_diploid() && env_flag("STRELKA_AMD_PILEUP_GENOTYPE", true);
+    // genotypes straight from the device columns: the diploid germline model, the somatic SNV model
+    return pileup_routed(opt) && (opt.isSomaticCallingMode || opt.is_bsnp_diploid()) && env_flag("STRELKA_AMD_PILEUP_GENOTYPE", true);
 }
 
 bool pileup_enabled(starling_pos_processor_base& pp)
@@ -306,7 +439,16 @@ bool pileup_enabled(starling_pos_processor_base& pp)
     const starling_base_options& opt(Access::opt(pp));
     ps.decided = true;
     ps.enabled = pileup_routed(opt);
+    ps.isSomatic = ps.enabled && opt.isSomaticCallingMode;
+    if (ps.isSomatic && Access::sampleCount(pp) != 2) throw blt_exception("strelka_amd adapter: the somatic pileup stream takes a normal and a tumor sample");
+    ps.isSomaticMetrics = ps.isSomatic && opt.is_compute_somatic_scoring_metrics;
     ps.isGenotyping = pileup_genotypes_with_stream(opt);
+    if (ps.isSomatic && ps.isGenotyping)
+    {
+        sk_somatic_snv_options so;
+        bool isComputeNonSomatic(false);
+        ps.isGenotyping = somatic_stream_options(pp, so, isComputeNonSomatic);
+    }
     return ps.enabled;
 }
 
@@ -317,7 +459,17 @@ void pileup_reset_region(starling_pos_processor_base& pp)
     if (! pileup_enabled(pp)) return;
     const starling_base_options& opt(Access::opt(pp));
     const unsigned sampleCount(Access::sampleCount(pp));
-    if (ps.streams.empty())
+    if (ps.isSomatic && ps.somaticStream == nullptr)
+    {
+        sk_pileup_options po;
+        pileupOptions(opt, po);
+        sk_somatic_snv_options so;
+        bool isComputeNonSomatic(false);
+        const bool isCalling(somatic_stream_options(pp, so, isComputeNonSomatic) && ps.isGenotyping);
+        ps.somaticStream = sk_somatic_pileup_stream_create(&po, isCalling ? &so : nullptr, ps.isSomaticMetrics ? 1 : 0);
+        if (ps.somaticStream == nullptr) check(1, "sk_somatic_pileup_stream_create");
+    }
+    if ((! ps.isSomatic) && ps.streams.empty())
     {
         sk_pileup_options po;
         pileupOptions(opt, po);
@@ -341,6 +493,7 @@ void pileup_reset_region(starling_pos_processor_base& pp)
     ps.regionEnd = rr.end_pos();
     ps.isRegionOpen.assign(sampleCount, 0);
     ps.chunks.assign(sampleCount, std::deque<SiteChunk>());
+    ps.somaticChunks.clear();
     ps.nextFinal.assign(sampleCount, rr.begin_pos());
     ps.pendingEnd.assign(sampleCount, INT_MIN);
     ps.maxBufferPos.assign(sampleCount, INT_MIN);
@@ -360,19 +513,37 @@ bool pileup_pos_reads(starling_pos_processor_base& pp, const pos_t pos)
     const pos_t end(s.realignedTo);
     if (! (s.isAnyRealigned && end > pos)) throw blt_exception("strelka_amd adapter: pileup window without its realignment job");
     const unsigned sampleCount(Access::sampleCount(pp));
-    for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
+    if (ps.isSomatic)
     {
-        // the last window of a region: at the final flush, when no read is buffered beyond it
-        const bool isFinal(ps.isFlushing && ps.maxBufferPos[sampleIndex] < end);
+        // the last window of a region: at the final flush, when no read of either sample is buffered beyond it
+        const bool isFinal(ps.isFlushing && ps.maxBufferPos[0] < end && ps.maxBufferPos[1] < end);
         try
         {
-            pileup_sample_window(pp, sampleIndex, pos, end, isFinal);
+            pileup_somatic_window(pp, pos, end, isFinal);
         }
         catch (...)
         {
             log_os << "Exception caught in pileup_pos_reads() while piling up the reads buffered at positions [" << (pos + 1) << "," << end
-                   << "] of sample " << sampleIndex << "\n";
+                   << "] of the normal and the tumor sample\n";
             throw;
+        }
+    }
+    else
+    {
+        for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
+        {
+            // the last window of a region: at the final flush, when no read is buffered beyond it
+            const bool isFinal(ps.isFlushing && ps.maxBufferPos[sampleIndex] < end);
+            try
+            {
+                pileup_sample_window(pp, sampleIndex, pos, end, isFinal);
+            }
+            catch (...)
+            {
+                log_os << "Exception caught in pileup_pos_reads() while piling up the reads buffered at positions [" << (pos + 1) << "," << end
+                       << "] of sample " << sampleIndex << "\n";
+                throw;
+            }
         }
     }
     ps.isAnyPiled = true;
@@ -387,6 +558,14 @@ void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos)
     State& s(state());
     PileupState& ps(s.pileup);
     if (! ps.enabled) return;
+    if (ps.isSomatic)
+    {
+        if (pos < ps.nextFinal[0]) return;
+        if (! ps.isFlushing) throw blt_exception("strelka_amd adapter: the POST_ALIGN stage reached a position whose pileup is not final");
+        AccumTimer hookTimer(s.tPileupHook);
+        pileup_somatic_window(pp, 0, 0, true);
+        return;
+    }
     const unsigned sampleCount(Access::sampleCount(pp));
     for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
     {
@@ -395,6 +574,36 @@ void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos)
         AccumTimer hookTimer(s.tPileupHook);
         // nothing new to pile up: an empty window that finalises everything
         pileup_sample_window(pp, sampleIndex, 0, 0, true);
+    }
+}
+
+void somatic_fill_scoring_metrics(starling_pos_processor_base& pp, const pos_t pos)
+{
+    PileupState& ps(state().pileup);
+    if (! (ps.enabled && ps.isSomaticMetrics)) return;
+    for (SomaticChunk& c : ps.somaticChunks)
+    {
+        if (pos < c.begin || pos >= c.end) continue;
+        const size_t k(static_cast<size_t>(pos - c.begin));
+        if (c.isMetricsFilled[k]) return;
+        c.isMetricsFilled[k] = 1;
+        snp_pos_info& pi(Access::pileupRef(pp.sample(1).basecallBuffer, pos));
+        const int64_t o(c.tumorTier1Off[k]);
+        const size_t n(static_cast<size_t>(c.tumorTier1Off[k + 1] - o));
+        if (n != pi.calls.size()) throw blt_exception("strelka_amd adapter: the tumor pileup of a written position is not the stream's");
+        const char refBase(pi.get_ref_base());
+        for (size_t i(0); i < n; ++i)
+        {
+            // updateSomaticScoringMetrics (:984-1000): tier1 reads of sample != 0, calls that pass the tier1 filter
+            const base_call& bc(pi.calls[i]);
+            if (bc.is_call_filter) continue;
+            const uint32_t v(c.tumorReadPos[static_cast<size_t>(o) + i]);
+            const uint16_t readPos(static_cast<uint16_t>(v & 0xffffu)), readLength(static_cast<uint16_t>(v >> 16));
+            const bool isReference(refBase == id_to_base(bc.base_id));
+            pi.readPositionRankSum.add_observation(isReference, readPos); // update_read_pos_ranksum, pos_basecall_buffer.cpp:75-85
+            if (! isReference) pi.altAlleleReadPositionInfo.push_back({readPos, readLength}); // insert_alt_read_pos, .hh:84-95
+        }
+        return;
     }
 }
 

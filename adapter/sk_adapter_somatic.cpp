@@ -120,12 +120,22 @@ void toGenotypeGrid(const sk_somatic_snv_genotype& g, somatic_snv_genotype_grid&
 
 }
 
+bool somatic_stream_options(const starling_pos_processor_base& pp, sk_somatic_snv_options& so, bool& isComputeNonSomatic)
+{
+    const strelka_options& opt(strelkaOptions(pp));
+    somaticSnvOptions(opt, so);
+    isComputeNonSomatic = opt.is_somatic_callable();
+    return opt.is_somatic_snv();
+}
+
 void somatic_window(starling_pos_processor_base& pp, const pos_t pos)
 {
     const strelka_options& opt(strelkaOptions(pp));
+    pileup_before_variants(pp, pos);
     if (! opt.is_somatic_snv()) return;
 
     State& s(state());
+    if (s.pileup.isGenotyping) return; // the records came with the pileup (site 9)
     SomaticSiteCache& cache(s.somaticSites);
     if (pos >= cache.begin && pos < cache.end) return;
     AccumTimer hookTimer(s.tSiteHook);
@@ -200,7 +210,28 @@ void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, cons
     const snp_pos_info* cleaned[4] = {&normal1.cleanedPileup(), &tumor1.cleanedPileup(),
                                       isTier2 ? &normal2->cleanedPileup() : nullptr, isTier2 ? &tumor2->cleanedPileup() : nullptr};
     const uint8_t isForced(sgt.is_forced_output ? 1 : 0);
-    if (pos >= cache.begin && pos < cache.end)
+    if (s.pileup.isGenotyping)
+    {
+        std::deque<SomaticChunk>& chunks(s.pileup.somaticChunks);
+        while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front(); // POST_ALIGN only moves forward
+        if ((! chunks.empty()) && chunks.front().begin <= pos)
+        {
+            const SomaticChunk& c(chunks.front());
+            const size_t k(static_cast<size_t>(pos - c.begin));
+            bool ok(c.forced[k] == isForced);
+            for (unsigned i(0); ok && i < 4; ++i)
+            {
+                if (cleaned[i] == nullptr) continue;
+                ok = (c.count[i][k] == cleaned[i]->calls.size());
+            }
+            if (ok)
+            {
+                toGenotypeGrid(c.genotypes[k], sgt);
+                return;
+            }
+        }
+    }
+    else if (pos >= cache.begin && pos < cache.end)
     {
         const size_t k(static_cast<size_t>(pos - cache.begin));
         bool ok(cache.isValid[k] && cache.forced[k] == isForced);

@@ -693,6 +693,42 @@ int sk_somatic_snv_call_tiers_dev(const sk_pileup_batch* dev_normal_t1, const sk
                                   int is_compute_nonsomatic, sk_somatic_snv_genotype* dev_out, void* dev_scratch,
                                   void* hip_stream);
 
+/* ---- row a8 for the two samples of a somatic run, chained into a12+a13 (sk_pileup_stream_* x 2 -> sk_somatic_snv_call_tiers) ----
+ * strelka_pos_processor::process_pos_snp_somatic (L/applications/strelka/strelka_pos_processor.cpp:166-260) cleans the normal and
+ * the tumor sample's pileup of a position twice (CleanPileupFilter(pi, false) and, with tier2 evidence, (pi, true),
+ * PileupCleaner.cpp:28-66) and hands the four columns to position_somatic_snv_call (:213-219).  This stream takes one stage
+ * window's reads of BOTH samples per push; the two samples share the finalised range [begin, end), each gets its raw tier1 /
+ * tier2 columns and counters back as in sk_pileup_stream_push, the four cleaned columns stay on the device and go straight
+ * into the somatic kernels (created with options: `genotype`, one record per position of the range).
+ * with_read_pos: the tumor window also carries, parallel to its tier1 calls, each call's position in its read and the read's
+ * length -- what updateSomaticScoringMetrics (starling_pos_processor_base.cpp:984-1000, called at :1360 for every basecall
+ * when the somatic EVS models are loaded) feeds into snp_pos_info::readPositionRankSum and altAlleleReadPositionInfo for the
+ * calls of sample != 0 that pass the tier1 filter: the caller rebuilds both accumulators from it for the few positions whose
+ * record is written (position_somatic_snv_strand_grid_vcf.cpp:161-208). */
+typedef struct sk_somatic_pileup_stream sk_somatic_pileup_stream;
+
+typedef struct sk_somatic_pileup_window {
+    sk_pileup_window normal, tumor;             /* same begin / end; clean_count = the CleanPileupFilter(pi,false) column's sizes */
+    const uint32_t* normal_clean_tier2_count;   /* [n] sizes of the CleanPileupFilter(pi,true) columns */
+    const uint32_t* tumor_clean_tier2_count;
+    const uint32_t* tumor_tier1_read_pos;       /* [tumor.tier1_off[n]] read_pos | read_size << 16; NULL without with_read_pos */
+    const sk_somatic_snv_genotype* genotype;    /* [n]; NULL when the stream does not genotype or n = 0 */
+} sk_somatic_pileup_window;
+
+/** genotype_opt: NULL = columns only.  Tier2 evidence as opt->use_tier2_evidence says. */
+sk_somatic_pileup_stream* sk_somatic_pileup_stream_create(const sk_pileup_options* opt, const sk_somatic_snv_options* genotype_opt,
+                                                          int with_read_pos);
+void sk_somatic_pileup_stream_destroy(sk_somatic_pileup_stream* s);
+int sk_somatic_pileup_stream_begin_region(sk_somatic_pileup_stream* s, const char* ref_seq, int32_t ref_offset, int32_t ref_len,
+                                          int32_t report_begin, int32_t report_end, int32_t largest_total_indel_ref_span_per_read);
+/** as sk_pileup_stream_push for both samples at once; is_forced_output[forced_len]: is_forced_output_pos() of positions from
+ *  forced_begin on (0 elsewhere; NULL with forced_len 0); is_compute_nonsomatic: opt.is_somatic_callable(). */
+int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* s, const sk_read_batch* host_normal_reads,
+                                  const sk_read_batch* host_tumor_reads, int32_t largest_total_indel_ref_span_per_read,
+                                  int32_t mask_begin, int32_t mask_len, const uint8_t* cand_snv_mask, int32_t final_to,
+                                  int32_t forced_begin, int32_t forced_len, const uint8_t* is_forced_output,
+                                  int is_compute_nonsomatic, sk_somatic_pileup_window* out);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (indels): per-read likelihood reductions over IndelSampleData::read_path_lnp
  * ---------------------------------------------------------------------------------------------------------------- */

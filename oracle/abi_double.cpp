@@ -464,6 +464,7 @@ struct sk_pileup_stream
     sk_pileup_options opt;
     sk_germline_options gopt;
     bool genotype = false;
+    bool somatic = false, want_read_pos = false;
     bool has_region = false;
     std::string ref;
     int32_t ref_offset = 0, region_begin = 0, region_end = 0;
@@ -471,6 +472,7 @@ struct sk_pileup_stream
     struct Col
     {
         std::vector<uint16_t> t1, t2;
+        std::vector<uint32_t> rp; // parallel to t1 (want_read_pos)
         uint32_t spandel = 0, submapped = 0, mq_n = 0, mq_zero = 0;
         uint64_t mq_sq = 0;
     };
@@ -481,9 +483,21 @@ struct sk_pileup_stream
     // output storage
     std::vector<int64_t> o_off1, o_off2;
     std::vector<uint16_t> o_c1, o_c2;
-    std::vector<uint32_t> o_sd, o_sm, o_mn, o_mz, o_cn;
+    std::vector<uint32_t> o_sd, o_sm, o_mn, o_mz, o_cn, o_cn4, o_rp;
     std::vector<uint64_t> o_sq;
     std::vector<sk_digt_call> o_g;
+    // the cleaned columns of the last emitted range (CleanPileupFilter(pi,false) / (pi,true))
+    std::vector<int64_t> k_off, k_off4;
+    std::vector<uint16_t> k_calls, k_calls4;
+    std::vector<uint8_t> k_ref;
+};
+
+struct sk_somatic_pileup_stream
+{
+    sk_pileup_stream* sample[2] = { nullptr, nullptr };
+    sk_somatic_snv_options sopt;
+    bool genotype = false, tier2 = false;
+    std::vector<sk_somatic_snv_genotype> o_g;
 };
 
 extern "C" {
@@ -540,12 +554,13 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, int3
     return 0;
 }
 
-int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32_t span, int32_t mask_begin, int32_t mask_len,
-                          const uint8_t* cand_snv_mask, int32_t final_to, int32_t ploidy_begin, int32_t ploidy_len, const uint8_t* ploidy,
-                          sk_pileup_window* out)
+namespace
 {
-    if (!g_ready) return fail("sk_init() has not succeeded");
-    if (!s || !reads || !out || !s->has_region) return fail("sk_pileup_stream_push: bad argument / no region");
+
+// the new reads into the per-position columns; lo_out = the lowest position they cover (INT32_MAX: none)
+int double_ingest(sk_pileup_stream* s, const sk_read_batch* reads, int32_t span, int32_t mask_begin, int32_t mask_len,
+                  const uint8_t* cand_snv_mask, int32_t* lo_out)
+{
     if (mask_len > 0 && (mask_begin < s->ref_offset || mask_begin + mask_len > s->ref_offset + static_cast<int32_t>(s->ref.size())))
         return fail("sk_pileup_stream_push: candidate-SNV mask window outside the reference segment");
     if (mask_len > 0) std::memcpy(s->mask.data() + (mask_begin - s->ref_offset), cand_snv_mask, static_cast<size_t>(mask_len));
@@ -568,10 +583,8 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32
         lo = std::max(lo, s->region_begin);
         hi = std::min(hi, s->region_end);
     }
+    *lo_out = lo;
     if (lo != INT32_MAX && lo < hi) {
-        if (s->has_prev && lo < s->next_begin) {
-            // (only an error when a basecall or deletion really lands there; checked after the pileup below)
-        }
         sko_pileup_options o;
         o.min_basecall_qscore = s->opt.min_basecall_qscore;
         o.mismatch_density_flank_size = s->opt.mismatch_density_flank_size;
@@ -607,11 +620,16 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32
         const int64_t cap = n ? reads->read_off[n] : 0;
         std::vector<int64_t> off1(nl + 1), off2(nl + 1);
         std::vector<uint16_t> c1(static_cast<size_t>(cap) + 1), c2(static_cast<size_t>(cap) + 1);
-        std::vector<uint32_t> sd(nl), sm(nl), mn(nl), mz(nl);
+        std::vector<uint32_t> sd(nl), sm(nl), mn(nl), mz(nl), rp(static_cast<size_t>(cap) + 1);
         std::vector<uint64_t> sq(nl);
         if (sko_pileup_reads_mapq(&b, &o, 0, off1.data(), c1.data(), cap, sd.data(), sm.data(), mn.data(), mz.data(), sq.data()) < 0)
             return fail("sk_pileup_stream_push: malformed read");
         if (sko_pileup_reads(&b, &o, 1, off2.data(), c2.data(), cap, nullptr, nullptr) < 0) return fail("sk_pileup_stream_push: malformed read");
+        if (s->want_read_pos) {
+            std::vector<int64_t> offr(nl + 1);
+            std::vector<uint16_t> cr(static_cast<size_t>(cap) + 1);
+            if (sko_pileup_reads_readpos(&b, &o, offr.data(), cr.data(), cap, rp.data()) < 0) return fail("sk_pileup_stream_push: malformed read");
+        }
         for (size_t l = 0; l < nl; ++l) {
             const bool any = (off1[l + 1] > off1[l]) || (off2[l + 1] > off2[l]) || sd[l] || sm[l] || mn[l];
             if (!any) continue;
@@ -620,6 +638,7 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32
             sk_pileup_stream::Col& c = s->cols[p];
             c.t1.insert(c.t1.end(), c1.begin() + off1[l], c1.begin() + off1[l + 1]);
             c.t2.insert(c.t2.end(), c2.begin() + off2[l], c2.begin() + off2[l + 1]);
+            if (s->want_read_pos) c.rp.insert(c.rp.end(), rp.begin() + off1[l], rp.begin() + off1[l + 1]);
             c.spandel += sd[l];
             c.submapped += sm[l];
             c.mq_n += mn[l];
@@ -628,53 +647,81 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32
         }
         s->pending_end = std::max(s->pending_end, hi);
     }
+    return 0;
+}
 
-    // ---- the range this push finalises: as the product computes it (lowest / highest over the reads it still holds)
-    const int32_t F = std::min(final_to, s->region_end);
+// the range a push finalises: as the product computes it (lowest / highest over the reads it still holds).  "lowest" of the
+// product = min start over carried + new reads; the carried reads start below next_begin whenever there are any, and the columns
+// present in `cols` tell the same story: the first pending position or the new reads' start
+void double_extent(const sk_pileup_stream* s, const int32_t lo, int32_t* lowest, int32_t* highest)
+{
+    *lowest = (lo != INT32_MAX) ? lo : INT32_MAX;
+    if (!s->cols.empty()) *lowest = std::min(*lowest, s->cols.begin()->first);
+    *highest = s->pending_end;
+}
+
+void double_range(const sk_pileup_stream* s, const int32_t lowest, const int32_t highest, const int32_t F, int32_t* begin_out, int32_t* end_out)
+{
     int32_t begin = s->next_begin, end = s->next_begin;
-    {
-        // "lowest" of the product = min start over carried + new reads; the carried reads start below next_begin whenever there are
-        // any, and the columns present in `cols` tell the same story: use the first pending position or the new reads' start
-        int32_t lowest = (lo != INT32_MAX) ? lo : INT32_MAX;
-        if (!s->cols.empty()) lowest = std::min(lowest, s->cols.begin()->first);
-        int32_t highest = s->pending_end;
-        if (lowest != INT32_MAX && highest != INT32_MIN) {
-            begin = std::max(s->region_begin, s->has_prev ? std::max(s->next_begin, lowest) : lowest);
-            end = std::max(begin, std::min(F, highest));
-        }
-        if (begin > F) begin = end = std::max(s->next_begin, std::min(begin, F));
+    if (lowest != INT32_MAX && highest != INT32_MIN) {
+        begin = std::max(s->region_begin, s->has_prev ? std::max(s->next_begin, lowest) : lowest);
+        end = std::max(begin, std::min(F, highest));
     }
+    if (begin > F) begin = end = std::max(s->next_begin, std::min(begin, F));
+    *begin_out = begin;
+    *end_out = end;
+}
+
+int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, const int32_t F, int32_t ploidy_begin, int32_t ploidy_len,
+                const uint8_t* ploidy, sk_pileup_window* out)
+{
     const size_t nl = static_cast<size_t>(end - begin);
     s->o_off1.assign(nl + 1, 0); s->o_off2.assign(nl + 1, 0);
-    s->o_c1.clear(); s->o_c2.clear();
+    s->o_c1.clear(); s->o_c2.clear(); s->o_rp.clear();
     s->o_sd.assign(nl, 0); s->o_sm.assign(nl, 0); s->o_mn.assign(nl, 0); s->o_mz.assign(nl, 0); s->o_cn.assign(nl + 1, 0);
+    s->o_cn4.assign(nl + 1, 0);
     s->o_sq.assign(nl, 0);
-    std::vector<int64_t> coff(nl + 1, 0);
-    std::vector<uint16_t> ccalls;
+    std::vector<int64_t>& coff = s->k_off;
+    std::vector<int64_t>& coff4 = s->k_off4;
+    std::vector<uint16_t>& ccalls = s->k_calls;
+    std::vector<uint16_t>& ccalls4 = s->k_calls4;
+    coff.assign(nl + 1, 0); coff4.assign(nl + 1, 0);
+    ccalls.clear(); ccalls4.clear();
     for (size_t l = 0; l < nl; ++l) {
         s->o_off1[l] = static_cast<int64_t>(s->o_c1.size());
         s->o_off2[l] = static_cast<int64_t>(s->o_c2.size());
         coff[l] = static_cast<int64_t>(ccalls.size());
+        coff4[l] = static_cast<int64_t>(ccalls4.size());
         const auto it = s->cols.find(begin + static_cast<int32_t>(l));
         if (it == s->cols.end()) continue;
         const sk_pileup_stream::Col& c = it->second;
         s->o_c1.insert(s->o_c1.end(), c.t1.begin(), c.t1.end());
         s->o_c2.insert(s->o_c2.end(), c.t2.begin(), c.t2.end());
+        if (s->want_read_pos) s->o_rp.insert(s->o_rp.end(), c.rp.begin(), c.rp.end());
         for (const uint16_t bc : c.t1) if (!((bc >> 12) & 1)) ccalls.push_back(bc);
         s->o_cn[l] = static_cast<uint32_t>(ccalls.size() - static_cast<size_t>(coff[l]));
+        if (s->somatic) { // CleanPileupFilter(pi, true), PileupCleaner.cpp:43-64
+            for (const uint16_t bc : c.t1) if (!((bc >> 12) & 1) || ((bc >> 13) & 1)) ccalls4.push_back(bc);
+            for (const uint16_t bc : c.t2) if (!((bc >> 12) & 1)) ccalls4.push_back(bc);
+            s->o_cn4[l] = static_cast<uint32_t>(ccalls4.size() - static_cast<size_t>(coff4[l]));
+        }
         s->o_sd[l] = c.spandel; s->o_sm[l] = c.submapped; s->o_mn[l] = c.mq_n; s->o_mz[l] = c.mq_zero; s->o_sq[l] = c.mq_sq;
     }
     s->o_off1[nl] = static_cast<int64_t>(s->o_c1.size());
     s->o_off2[nl] = static_cast<int64_t>(s->o_c2.size());
     coff[nl] = static_cast<int64_t>(ccalls.size());
-    s->o_c1.push_back(0); s->o_c2.push_back(0); ccalls.push_back(0);
+    coff4[nl] = static_cast<int64_t>(ccalls4.size());
+    s->o_c1.push_back(0); s->o_c2.push_back(0); ccalls.push_back(0); ccalls4.push_back(0); s->o_rp.push_back(0);
     s->o_g.assign(nl + 1, sk_digt_call());
+    s->k_ref.assign(nl + 1, 4);
+    for (size_t l = 0; l < nl; ++l) {
+        const int64_t k = static_cast<int64_t>(begin) + static_cast<int64_t>(l) - s->ref_offset;
+        const char ch = (k >= 0 && k < static_cast<int64_t>(s->ref.size())) ? s->ref[static_cast<size_t>(k)] : 'N';
+        s->k_ref[l] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+    }
     if (s->genotype && nl) {
-        std::vector<uint8_t> rb(nl), pl(nl);
+        std::vector<uint8_t> pl(nl);
         for (size_t l = 0; l < nl; ++l) {
-            const int64_t k = static_cast<int64_t>(begin) + static_cast<int64_t>(l) - s->ref_offset;
-            const char ch = (k >= 0 && k < static_cast<int64_t>(s->ref.size())) ? s->ref[static_cast<size_t>(k)] : 'N';
-            rb[l] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
             const int64_t kp = static_cast<int64_t>(begin) + static_cast<int64_t>(l) - ploidy_begin;
             pl[l] = (ploidy && kp >= 0 && kp < ploidy_len) ? ploidy[kp] : 2;
         }
@@ -683,7 +730,7 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32
         pb.n_loci = static_cast<int32_t>(nl);
         pb.call_off = coff.data();
         pb.calls = ccalls.data();
-        pb.ref_base = rb.data();
+        pb.ref_base = s->k_ref.data();
         pb.ploidy = pl.data();
         if (sk_site_digt_call_fused(&pb, &s->gopt, s->o_g.data(), nullptr)) return 1;
     }
@@ -705,6 +752,113 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32
     out->mapq_sum_square = s->o_sq.data();
     out->clean_count = s->o_cn.data();
     out->genotype = s->genotype ? s->o_g.data() : nullptr;
+    return 0;
+}
+
+}
+
+int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32_t span, int32_t mask_begin, int32_t mask_len,
+                          const uint8_t* cand_snv_mask, int32_t final_to, int32_t ploidy_begin, int32_t ploidy_len, const uint8_t* ploidy,
+                          sk_pileup_window* out)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    if (!s || !reads || !out || !s->has_region) return fail("sk_pileup_stream_push: bad argument / no region");
+    int32_t lo, lowest, highest, begin, end;
+    if (double_ingest(s, reads, span, mask_begin, mask_len, cand_snv_mask, &lo)) return 1;
+    const int32_t F = std::min(final_to, s->region_end);
+    double_extent(s, lo, &lowest, &highest);
+    double_range(s, lowest, highest, F, &begin, &end);
+    return double_emit(s, begin, end, F, ploidy_begin, ploidy_len, ploidy, out);
+}
+
+sk_somatic_pileup_stream* sk_somatic_pileup_stream_create(const sk_pileup_options* opt, const sk_somatic_snv_options* genotype_opt,
+                                                          int with_read_pos)
+{
+    if (!g_ready || !opt) {
+        fail("sk_somatic_pileup_stream_create: not initialised / null options");
+        return nullptr;
+    }
+    sk_somatic_pileup_stream* p = new sk_somatic_pileup_stream();
+    for (int i = 0; i < 2; ++i) {
+        p->sample[i] = new sk_pileup_stream();
+        p->sample[i]->opt = *opt;
+        p->sample[i]->somatic = true;
+    }
+    p->sample[1]->want_read_pos = (with_read_pos != 0);
+    p->tier2 = (opt->use_tier2_evidence != 0);
+    if (genotype_opt) {
+        p->sopt = *genotype_opt;
+        p->genotype = true;
+    }
+    return p;
+}
+
+void sk_somatic_pileup_stream_destroy(sk_somatic_pileup_stream* p)
+{
+    if (!p) return;
+    delete p->sample[0];
+    delete p->sample[1];
+    delete p;
+}
+
+int sk_somatic_pileup_stream_begin_region(sk_somatic_pileup_stream* p, const char* ref_seq, int32_t ref_offset, int32_t ref_len,
+                                          int32_t report_begin, int32_t report_end, int32_t span)
+{
+    if (!p) return fail("sk_somatic_pileup_stream_begin_region: null argument");
+    for (int i = 0; i < 2; ++i) {
+        if (sk_pileup_stream_begin_region(p->sample[i], ref_seq, ref_offset, ref_len, report_begin, report_end, span)) return 1;
+    }
+    return 0;
+}
+
+int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_batch* normal_reads, const sk_read_batch* tumor_reads,
+                                  int32_t span, int32_t mask_begin, int32_t mask_len, const uint8_t* cand_snv_mask, int32_t final_to,
+                                  int32_t forced_begin, int32_t forced_len, const uint8_t* is_forced_output, int is_compute_nonsomatic,
+                                  sk_somatic_pileup_window* out)
+{
+    if (!g_ready) return fail("sk_init() has not succeeded");
+    if (!p || !normal_reads || !tumor_reads || !out || !p->sample[0]->has_region) return fail("sk_somatic_pileup_stream_push: bad argument / no region");
+    const sk_read_batch* reads[2] = { normal_reads, tumor_reads };
+    int32_t lowest = INT32_MAX, highest = INT32_MIN, begin, end;
+    for (int i = 0; i < 2; ++i) {
+        int32_t lo, l, h;
+        if (double_ingest(p->sample[i], reads[i], span, mask_begin, mask_len, cand_snv_mask, &lo)) return 1;
+        double_extent(p->sample[i], lo, &l, &h);
+        lowest = std::min(lowest, l);
+        highest = std::max(highest, h);
+    }
+    const int32_t F = std::min(final_to, p->sample[0]->region_end);
+    double_range(p->sample[0], lowest, highest, F, &begin, &end);
+    if (double_emit(p->sample[0], begin, end, F, 0, 0, nullptr, &out->normal)) return 1;
+    if (double_emit(p->sample[1], begin, end, F, 0, 0, nullptr, &out->tumor)) return 1;
+    const size_t nl = static_cast<size_t>(end - begin);
+    p->o_g.assign(nl + 1, sk_somatic_snv_genotype());
+    if (p->genotype && nl) {
+        std::vector<uint8_t> forced(nl, 0);
+        for (size_t l = 0; l < nl; ++l) {
+            const int64_t k = static_cast<int64_t>(begin) + static_cast<int64_t>(l) - forced_begin;
+            forced[l] = (is_forced_output && k >= 0 && k < forced_len) ? is_forced_output[k] : 0;
+        }
+        sk_pileup_batch b[4];
+        for (int i = 0; i < 2; ++i) {
+            sk_pileup_stream* s = p->sample[i];
+            std::memset(&b[i], 0, sizeof(sk_pileup_batch));
+            b[i].n_loci = static_cast<int32_t>(nl);
+            b[i].call_off = s->k_off.data();
+            b[i].calls = s->k_calls.data();
+            b[i].ref_base = p->sample[0]->k_ref.data();
+            b[2 + i] = b[i];
+            b[2 + i].call_off = s->k_off4.data();
+            b[2 + i].calls = s->k_calls4.data();
+        }
+        if (sk_somatic_snv_call_tiers(&b[0], &b[1], p->tier2 ? &b[2] : nullptr, p->tier2 ? &b[3] : nullptr, &p->sopt, forced.data(),
+                                      is_compute_nonsomatic, p->o_g.data()))
+            return 1;
+    }
+    out->normal_clean_tier2_count = p->sample[0]->o_cn4.data();
+    out->tumor_clean_tier2_count = p->sample[1]->o_cn4.data();
+    out->tumor_tier1_read_pos = p->sample[1]->want_read_pos ? p->sample[1]->o_rp.data() : nullptr;
+    out->genotype = (p->genotype && nl) ? p->o_g.data() : nullptr;
     return 0;
 }
 

@@ -585,6 +585,24 @@ def pileup_reads_mapq(rb, opt):
     return call_off, calls[:n].copy(), sd[:n_loci], sm[:n_loci], mn[:n_loci], mz[:n_loci], sq[:n_loci]
 
 
+def pileup_reads_readpos(rb, opt):
+    """raw tier1 columns + (read_pos | read_size << 16) of every call -> (call_off, calls, read_pos)"""
+    L = oracle()
+    L.sko_pileup_reads_readpos.restype = C.c_int64
+    L.sko_pileup_reads_readpos.argtypes = [C.POINTER(ReadBatchStruct), C.POINTER(PileupOptions), vp, vp, C.c_int64, vp]
+    n_loci = opt.report_end - opt.report_begin
+    keep = []
+    s = read_batch_struct(rb, keep)
+    cap = 2 * rb.n_bases + 1
+    call_off = np.zeros(n_loci + 1, np.int64)
+    calls = np.zeros(cap, np.uint16)
+    rp = np.zeros(cap, np.uint32)
+    n = L.sko_pileup_reads_readpos(C.byref(s), C.byref(opt), _p(call_off), _p(calls), cap, _p(rp))
+    if n < 0:
+        raise RuntimeError("sko_pileup_reads_readpos failed")
+    return call_off, calls[:n].copy(), rp[:n].copy()
+
+
 def mapped_qscore_table():
     L = oracle()
     return np.array([[L.sko_mapped_qscore(q, m) for q in range(71)] for m in range(91)], np.int32)

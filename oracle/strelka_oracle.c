@@ -1636,13 +1636,51 @@ int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* o, i
 /* the same with the MapqTracker of every position (insert_mapq_count, starling_pos_processor_base.cpp:1346:
  * every match position inside the trimmed read and the report range, submapped reads included;
  * L/blt_common/MapqTracker.hh:36-42) */
+static int64_t pileup_reads_impl(const sko_read_batch* b, const sko_pileup_options* o, int mode, int64_t* call_off,
+                                 uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count,
+                                 uint32_t* mapq_count, uint32_t* mapq_zero_count, uint64_t* mapq_sum_square, uint32_t* read_pos);
+
 int64_t sko_pileup_reads_mapq(const sko_read_batch* b, const sko_pileup_options* o, int mode, int64_t* call_off,
                               uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count,
                               uint32_t* mapq_count, uint32_t* mapq_zero_count, uint64_t* mapq_sum_square)
 {
+    return pileup_reads_impl(b, o, mode, call_off, calls, capacity, spandel_count, submapped_count, mapq_count, mapq_zero_count,
+                             mapq_sum_square, NULL);
+}
+
+/* the raw tier1 column (mode 0) and, parallel to its calls, what updateSomaticScoringMetrics gets for each of them
+ * (starling_pos_processor_base.cpp:1360: readPos = read_pos, readLength = read_size): read_pos | read_size << 16 */
+int64_t sko_pileup_reads_readpos(const sko_read_batch* b, const sko_pileup_options* o, int64_t* call_off, uint16_t* calls,
+                                 int64_t capacity, uint32_t* read_pos)
+{
+    return pileup_reads_impl(b, o, 0, call_off, calls, capacity, NULL, NULL, NULL, NULL, NULL, read_pos);
+}
+
+typedef struct pl_col32 {
+    uint32_t* v;
+    int32_t n, cap;
+} pl_col32;
+static int pl_push32(pl_col32* c, uint32_t x)
+{
+    if (c->n == c->cap) {
+        const int32_t nc = c->cap ? 2 * c->cap : 16;
+        uint32_t* nv = (uint32_t*)realloc(c->v, sizeof(uint32_t) * (size_t)nc);
+        if (!nv) return 1;
+        c->v = nv;
+        c->cap = nc;
+    }
+    c->v[c->n++] = x;
+    return 0;
+}
+
+static int64_t pileup_reads_impl(const sko_read_batch* b, const sko_pileup_options* o, int mode, int64_t* call_off,
+                                 uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count,
+                                 uint32_t* mapq_count, uint32_t* mapq_zero_count, uint64_t* mapq_sum_square, uint32_t* read_pos)
+{
     const int32_t n_loci = o->report_end - o->report_begin;
     pl_col* t1 = (pl_col*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col));
     pl_col* t2 = (pl_col*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col));
+    pl_col32* rp1 = (pl_col32*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col32));
     int* delta = NULL;
     unsigned char* is_mm = NULL;
     int64_t result = -1;
@@ -1801,6 +1839,7 @@ int64_t sko_pileup_reads_mapq(const sko_read_batch* b, const sko_pileup_options*
                     const uint16_t bc = (uint16_t)(qb | (id << 6) | ((unsigned)fwd << 10) | ((unsigned)nmm << 11) |
                                                    ((unsigned)current << 12) | ((unsigned)tscf << 13));
                     if (pl_push(is_tier1 ? &t1[locus] : &t2[locus], bc)) bad = 1;
+                    if (read_pos && is_tier1 && pl_push32(&rp1[locus], (uint32_t)rp | ((uint32_t)L << 16))) bad = 1;
                 }
             } else if (t == 3) {
                 const int edge = (i < first_match) || (i > last_match);
@@ -1828,7 +1867,10 @@ int64_t sko_pileup_reads_mapq(const sko_read_batch* b, const sko_pileup_options*
         calls[n++] = (x);                          \
     } while (0)
             if (mode == 0) {
-                for (int i = 0; i < t1[l].n && !bad; ++i) PL_OUT(t1[l].v[i]);
+                for (int i = 0; i < t1[l].n && !bad; ++i) {
+                    if (read_pos && n < capacity) read_pos[n] = rp1[l].v[i];
+                    PL_OUT(t1[l].v[i]);
+                }
             } else if (mode == 1) {
                 for (int i = 0; i < t2[l].n && !bad; ++i) PL_OUT(t2[l].v[i]);
             } else { /* CleanPileupFilter, PileupCleaner.cpp:28-66 */
@@ -1855,9 +1897,11 @@ int64_t sko_pileup_reads_mapq(const sko_read_batch* b, const sko_pileup_options*
     for (int32_t l = 0; l < n_loci; ++l) {
         free(t1[l].v);
         free(t2[l].v);
+        free(rp1[l].v);
     }
     free(t1);
     free(t2);
+    free(rp1);
     free(delta);
     free(is_mm);
     return result;

@@ -271,6 +271,10 @@ int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* opt,
 int64_t sko_pileup_reads_mapq(const sko_read_batch* b, const sko_pileup_options* opt, int mode, int64_t* call_off,
                               uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count,
                               uint32_t* mapq_count, uint32_t* mapq_zero_count, uint64_t* mapq_sum_square);
+/* the raw tier1 column and, parallel to it, read_pos | read_size << 16 of every call (updateSomaticScoringMetrics' arguments,
+ * L/starling_common/starling_pos_processor_base.cpp:984-1000, :1360) */
+int64_t sko_pileup_reads_readpos(const sko_read_batch* b, const sko_pileup_options* opt, int64_t* call_off, uint16_t* calls,
+                                 int64_t capacity, uint32_t* read_pos);
 
 /* ---- GlobalAligner<int>::align (L/alignment/GlobalAlignerImpl.hh:35-228) ---- */
 typedef struct sko_align_scores { /* AlignmentScores<int>, L/alignment/AlignmentScores.hh */

@@ -129,6 +129,11 @@ class PileupWindow(C.Structure):
                 ("clean_count", c_void_p), ("genotype", c_void_p)]
 
 
+class SomaticPileupWindow(C.Structure):
+    _fields_ = [("normal", PileupWindow), ("tumor", PileupWindow), ("normal_clean_tier2_count", c_void_p),
+                ("tumor_clean_tier2_count", c_void_p), ("tumor_tier1_read_pos", c_void_p), ("genotype", c_void_p)]
+
+
 class PileupBatch(C.Structure):
     _fields_ = [("n_loci", C.c_int32), ("call_off", c_void_p), ("calls", c_void_p), ("de", c_void_p),
                 ("ref_base", c_void_p), ("ploidy", c_void_p)]
@@ -195,6 +200,7 @@ EXPORTS = [
     "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
     "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push",
+    "sk_somatic_pileup_stream_create", "sk_somatic_pileup_stream_destroy", "sk_somatic_pileup_stream_begin_region", "sk_somatic_pileup_stream_push",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
     "sk_realign_job_finish", "sk_realign_job_run", "sk_realign_job_n_reads", "sk_realign_job_read_result",
@@ -1023,6 +1029,87 @@ class PileupStream:
                     mapq_count=arr(w.mapq_count, np.uint32, n), mapq_zero=arr(w.mapq_zero_count, np.uint32, n),
                     mapq_sumsq=arr(w.mapq_sum_square, np.uint64, n), clean_count=arr(w.clean_count, np.uint32, n),
                     genotype=rec(w.genotype, DIGT_CALL_DTYPE, n) if self.genotype else None)
+
+
+def _window_arrays(w, genotype_dtype=None):
+    n = w.end - w.begin
+
+    def arr(ptr, dt, k):
+        if k == 0 or not ptr:
+            return np.zeros(0, dt)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(np.dtype(dt)))), shape=(k,)).copy()
+    o1 = arr(w.tier1_off, np.int64, n + 1)
+    o2 = arr(w.tier2_off, np.int64, n + 1)
+    return dict(begin=w.begin, end=w.end, tier1_off=o1, tier1_calls=arr(w.tier1_calls, np.uint16, int(o1[-1]) if n else 0),
+                tier2_off=o2, tier2_calls=arr(w.tier2_calls, np.uint16, int(o2[-1]) if n else 0),
+                spandel=arr(w.spandel_count, np.uint32, n), submapped=arr(w.submapped_count, np.uint32, n),
+                mapq_count=arr(w.mapq_count, np.uint32, n), mapq_zero=arr(w.mapq_zero_count, np.uint32, n),
+                mapq_sumsq=arr(w.mapq_sum_square, np.uint64, n), clean_count=arr(w.clean_count, np.uint32, n)), arr
+
+
+class SomaticPileupStream:
+    """sk_somatic_pileup_stream_*: the normal and the tumor sample's pileups over a region, pushed window by window together and
+    chained into a12+a13.  `library` as for PileupStream."""
+
+    def __init__(self, opt, somatic_opt=None, with_read_pos=False, library=None):
+        self.L = library or lib()
+        L = self.L
+        L.sk_somatic_pileup_stream_create.restype = c_void_p
+        L.sk_somatic_pileup_stream_create.argtypes = [C.POINTER(PileupOptions), c_void_p, C.c_int]
+        L.sk_somatic_pileup_stream_destroy.argtypes = [c_void_p]
+        L.sk_somatic_pileup_stream_begin_region.argtypes = [c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.sk_somatic_pileup_stream_push.argtypes = [c_void_p, C.POINTER(ReadBatchStruct), C.POINTER(ReadBatchStruct), C.c_int32, C.c_int32,
+                                                    C.c_int32, c_void_p, C.c_int32, C.c_int32, C.c_int32, c_void_p, C.c_int,
+                                                    C.POINTER(SomaticPileupWindow)]
+        L.sk_last_error.restype = C.c_char_p
+        self.genotype = somatic_opt is not None
+        self.with_read_pos = with_read_pos
+        self.h = L.sk_somatic_pileup_stream_create(C.byref(opt), C.byref(somatic_opt) if self.genotype else None, 1 if with_read_pos else 0)
+        if not self.h:
+            raise RuntimeError(L.sk_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.L.sk_somatic_pileup_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.sk_last_error().decode())
+
+    def begin_region(self, ref_seq, ref_offset, report_begin, report_end, span=49):
+        ref = ref_seq.encode()
+        self._check(self.L.sk_somatic_pileup_stream_begin_region(self.h, ref, ref_offset, len(ref), report_begin, report_end, span))
+
+    def push(self, normal_rb, tumor_rb, final_to, mask=None, mask_begin=0, forced=None, forced_begin=0, is_compute_nonsomatic=False,
+             span=49):
+        """-> dict(normal=..., tumor=... (as PileupStream.push), clean2_count per sample, read_pos, genotype)"""
+        st = [ReadBatchStruct(rb.n_reads, _p(rb.read_off), _p(rb.read_code), _p(rb.read_qual), _p(rb.path_off), _p(rb.path),
+                              _p(rb.pos), _p(rb.is_fwd), _p(rb.mapq), _p(rb.map_level), None, 0, 0, None) for rb in (normal_rb, tumor_rb)]
+        w = SomaticPileupWindow()
+        mask = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        forced = None if forced is None else np.ascontiguousarray(forced, np.uint8)
+        self._check(self.L.sk_somatic_pileup_stream_push(self.h, C.byref(st[0]), C.byref(st[1]), span, mask_begin,
+                                                          0 if mask is None else len(mask), _p(mask), min(final_to, 2**31 - 1), forced_begin,
+                                                          0 if forced is None else len(forced), _p(forced), 1 if is_compute_nonsomatic else 0,
+                                                          C.byref(w)))
+        normal, arr = _window_arrays(w.normal)
+        tumor, _ = _window_arrays(w.tumor)
+        n = w.normal.end - w.normal.begin
+        normal["clean2_count"] = arr(w.normal_clean_tier2_count, np.uint32, n)
+        tumor["clean2_count"] = arr(w.tumor_clean_tier2_count, np.uint32, n)
+        geno = None
+        if self.genotype:
+            if n and w.genotype:
+                buf = (C.c_char * (SOMATIC_GENOTYPE_DTYPE.itemsize * n)).from_address(w.genotype)
+                geno = np.frombuffer(buf, SOMATIC_GENOTYPE_DTYPE, n).copy()
+            else:
+                geno = np.zeros(0, SOMATIC_GENOTYPE_DTYPE)
+        read_pos = arr(w.tumor_tier1_read_pos, np.uint32, len(tumor["tier1_calls"])) if self.with_read_pos else None
+        return dict(begin=w.normal.begin, end=w.normal.end, normal=normal, tumor=tumor, read_pos=read_pos, genotype=geno)
 
 
 # ---------------------------------------------------------------------------------------------------- GlobalAligner

@@ -72,6 +72,15 @@ struct PileupArgs
     uint32_t* mapq_count;
     uint32_t* mapq_zero;
     unsigned long long* mapq_sumsq;
+    // the somatic extension of the three-column form (template flag SOM): a fourth column, CleanPileupFilter(pi, true)
+    // (PileupCleaner.cpp:43-64: the tier1 calls that pass or fail only the tier1-specific filter, then the passing tier2 calls),
+    // and, parallel to the raw tier1 column, each call's position in its read and the read's length
+    // (updateSomaticScoringMetrics' readPos / readLength, starling_pos_processor_base.cpp:1360)
+    uint32_t* count4;       // [n_loci + 1] size of the fourth column
+    uint32_t* count4a;      // [n_loci + 1] ... of its tier1 part
+    const int64_t* call_off4;
+    uint16_t* calls4;
+    uint32_t* read_pos;     // [tier1 calls] read_pos | read_size << 16, or nullptr
 };
 
 __device__ __forceinline__ bool seg_match(const uint32_t t) { return t == SK_SEG_MATCH || t == SK_SEG_SEQ_MATCH || t == SK_SEG_SEQ_MISMATCH; }
@@ -562,9 +571,10 @@ __device__ __forceinline__ bool rec_selected(const unsigned rec, const int mode,
 
 // P2: one wave per 64 loci.  THREE = false: the column of a.mode; THREE = true: the raw tier1, raw tier2 and cleaned tier1 columns
 // (count3 / call_off3 / calls3, in that order) and the MAPQ tracker in the same walk over the records.
-template <bool THREE>
+template <bool THREE, bool SOM = false>
 __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs a)
 {
+    static_assert(THREE || !SOM, "the somatic columns extend the three-column form");
     const int lane = threadIdx.x;
     const int l0 = blockIdx.x * WAVE;
     const int l = l0 + lane;
@@ -593,7 +603,7 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
     };
     const int lo = first_true(0, n, [&](const int m) { return a.maxend[m] > p0; });
     const int hi = first_true(lo, n, [&](const int m) { return a.minbegin[m] >= p0 + WAVE; });
-    unsigned cnt = 0, cnt2 = 0, cnt3 = 0;
+    unsigned cnt = 0, cnt2 = 0, cnt3 = 0, cnt4a = 0, cnt4b = 0;
     unsigned mq_n = 0, mq_zero = 0;
     unsigned long long mq_sq = 0;
     const int64_t* __restrict__ off_a = THREE ? a.call_off3[0] : a.call_off;
@@ -601,6 +611,8 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
     const int64_t base = (a.store && l < a.n_loci) ? off_a[l] : 0;
     const int64_t base2 = (THREE && a.store && l < a.n_loci) ? a.call_off3[1][l] : 0;
     const int64_t base3 = (THREE && a.store && l < a.n_loci) ? a.call_off3[2][l] : 0;
+    const int64_t base4a = (SOM && a.store && l < a.n_loci) ? a.call_off4[l] : 0;
+    const int64_t base4b = (SOM && a.store && l < a.n_loci) ? base4a + int64_t(a.count4a[l]) : 0;
     const int parts = (!THREE && a.mode == SK_PILEUP_CLEAN_TIER2) ? 2 : 1;
     const bool live = (l < a.n_loci);
     // store pass: the wave's 64 columns are one contiguous span of `calls`; it is assembled in LDS and written out with
@@ -668,6 +680,7 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
             const int64_t so_k = have ? a.b.path_off[rk] : 0;
             const int nseg_k = have ? int(a.b.path_off[rk + 1] - so_k) : 0;
             const int mapq_k = (THREE && have) ? int(a.b.mapq[rk]) : 0;
+            const int len_k = (SOM && have) ? int(a.b.read_off[rk + 1] - ro_k) : 0;
             sk_path_seg g0 = { 0u, 0u }, g1 = { 0u, 0u }, g2 = { 0u, 0u };
             if (nseg_k >= 1) g0 = a.b.path[so_k];
             if (nseg_k >= 2) g1 = a.b.path[so_k + 1];
@@ -712,6 +725,12 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
                                 if (a.store) {
                                     if (staged) s_col[lbase + cnt] = call;
                                     else calls_a[base + cnt] = call;
+                                    if (SOM && a.read_pos) {
+                                        const int64_t ro_u = (int64_t(__builtin_amdgcn_readlane(int(ro_k >> 32), k0 + u)) << 32) |
+                                                             uint32_t(__builtin_amdgcn_readlane(int(ro_k & 0xffffffff), k0 + u));
+                                        const unsigned len_u = unsigned(__builtin_amdgcn_readlane(len_k, k0 + u));
+                                        a.read_pos[base + cnt] = unsigned(idx[u] - ro_u) | (len_u << 16);
+                                    }
                                 }
                                 ++cnt;
                                 if (!(rc & (1u << 12))) {
@@ -720,6 +739,16 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
                                         else a.calls3[2][base3 + cnt3] = call;
                                     }
                                     ++cnt3;
+                                }
+                            }
+                            if (SOM) { // the fourth column's two parts
+                                const bool t2 = rc & REC_TIER2, filt = rc & (1u << 12), tscf = rc & (1u << 13);
+                                if (!t2 && (!filt || tscf)) {
+                                    if (a.store) a.calls4[base4a + cnt4a] = call;
+                                    ++cnt4a;
+                                } else if (t2 && !filt) {
+                                    if (a.store) a.calls4[base4b + cnt4b] = call;
+                                    ++cnt4b;
                                 }
                             }
                         }
@@ -745,6 +774,10 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
             a.count3[0][l] = (l < a.n_loci) ? cnt : 0u;
             a.count3[1][l] = (l < a.n_loci) ? cnt2 : 0u;
             a.count3[2][l] = (l < a.n_loci) ? cnt3 : 0u;
+            if (SOM) {
+                a.count4[l] = (l < a.n_loci) ? cnt4a + cnt4b : 0u;
+                a.count4a[l] = (l < a.n_loci) ? cnt4a : 0u;
+            }
             if (l < a.n_loci) {
                 a.mapq_count[l] = mq_n;
                 a.mapq_zero[l] = mq_zero;
@@ -1091,11 +1124,22 @@ inline int path_ref_length(const sk_path_seg* path, const int nseg)
 
 } // namespace
 
+namespace
+{
+
+struct InLay { int64_t read_off, path_off, path, pos, is_fwd, mapq, level, code, qual, ploidy, mask, total; };
+struct WorkLay { int64_t begin, end, maxend, minbegin, count0, count1, count2, count4, count4a, off2, off4, calls2, calls4, refbase, de, gscr, tmp, total; };
+struct OutLay { int64_t off0, off1, clean_n, clean4_n, mq_n, mq_zero, mq_sq, spandel, submapped, geno, calls0, calls1, read_pos, total; };
+
+} // namespace
+
 struct sk_pileup_stream
 {
     sk_pileup_options opt;
     sk_germline_options gopt;
     bool genotype = false;
+    bool somatic = false;      // also build the CleanPileupFilter(pi, true) column (kept on the device)
+    bool want_read_pos = false; // ... and return each tier1 call's read position / read length
     // region
     bool has_region = false;
     int32_t ref_offset = 0, ref_len = 0;
@@ -1115,91 +1159,37 @@ struct sk_pileup_stream
     DevBuf d_in, d_work, d_out;
     PinBuf h_in, h_out;
     int64_t pushes = 0, reads_in = 0;
+    // the push in flight (stream_enqueue -> stream_finish)
+    InLay li;
+    WorkLay wl;
+    OutLay ol;
+    int p_n = 0, p_new = 0, p_loci = 0;
+    int64_t p_bases = 0, p_segs = 0;
+    int32_t p_begin = 0, p_end = 0, p_F = 0;
 };
 
-extern "C" {
-
-sk_pileup_stream* sk_pileup_stream_create(const sk_pileup_options* opt, const sk_germline_options* genotype_opt)
+struct sk_somatic_pileup_stream
 {
-    if (!sk_ctx().ready) {
-        sk_fail("strelka_amd: sk_init() has not succeeded");
-        return nullptr;
-    }
-    if (!opt) {
-        sk_fail("sk_pileup_stream_create: null options");
-        return nullptr;
-    }
-    sk_pileup_stream* s = new sk_pileup_stream();
-    s->opt = *opt;
-    if (genotype_opt) {
-        s->gopt = *genotype_opt;
-        s->genotype = true;
-    }
-    return s;
-}
+    sk_pileup_stream* sample[2] = { nullptr, nullptr }; // normal, tumor
+    sk_somatic_snv_options sopt;
+    bool genotype = false;
+    bool tier2 = false;
+    DevBuf d_call; // forced flags, somatic records, the wrapper's scratch
+    PinBuf h_forced, h_geno;
+};
 
-void sk_pileup_stream_destroy(sk_pileup_stream* s)
+namespace
 {
-    if (!s) return;
-    if (sk_ctx().ready) {
-        (void)hipSetDevice(sk_ctx().device);
-        (void)hipStreamSynchronize(sk_ctx().stream);
-    }
-    s->d_ref.drop(); s->d_mask.drop(); s->d_spandel.drop(); s->d_submapped.drop();
-    s->d_rec[0].drop(); s->d_rec[1].drop(); s->d_span[0].drop(); s->d_span[1].drop();
-    s->d_in.drop(); s->d_work.drop(); s->d_out.drop();
-    s->h_in.drop(); s->h_out.drop();
-    delete s;
-}
 
-int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, const int32_t ref_offset, const int32_t ref_len,
-                                  const int32_t report_begin, const int32_t report_end,
-                                  const int32_t largest_total_indel_ref_span_per_read)
+// what the reference rejects by throwing / exiting (as sk_pileup_reads)
+int stream_check_reads(const sk_pileup_stream* s, const sk_read_batch* reads, const int32_t mask_begin, const int32_t mask_len,
+                       const uint8_t* cand_snv_mask)
 {
-    SK_REQUIRE_INIT();
-    if (!s || (!ref_seq && ref_len > 0)) return sk_fail("sk_pileup_stream_begin_region: null argument");
-    if (ref_len < 0 || report_end < report_begin) return sk_fail("sk_pileup_stream_begin_region: bad range");
-    SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
-    hipStream_t st = ctx.stream;
-    const size_t n_region = size_t(report_end - report_begin);
-    if (s->d_ref.need(size_t(ref_len) + 1) || s->d_mask.need(size_t(ref_len) + 1) || s->d_spandel.need(4 * n_region + 4) ||
-        s->d_submapped.need(4 * n_region + 4))
-        return sk_fail("sk_pileup_stream_begin_region: out of device memory");
-    if (ref_len > 0) SK_HIP(hipMemcpyAsync(s->d_ref.p, ref_seq, size_t(ref_len), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemsetAsync(s->d_mask.p, 0, size_t(ref_len) + 1, st));
-    SK_HIP(hipMemsetAsync(s->d_spandel.p, 0, 4 * n_region + 4, st));
-    SK_HIP(hipMemsetAsync(s->d_submapped.p, 0, 4 * n_region + 4, st));
-    SK_HIP(hipStreamSynchronize(st)); // ref_seq is the caller's
-    s->ref_offset = ref_offset;
-    s->ref_len = ref_len;
-    s->region_begin = report_begin;
-    s->region_end = report_end;
-    s->opt.report_begin = report_begin;
-    s->opt.report_end = report_end;
-    s->opt.largest_total_indel_ref_span_per_read = largest_total_indel_ref_span_per_read;
-    s->c_len.clear(); s->c_nseg.clear(); s->c_pos.clear(); s->c_mapq.clear(); s->c_path.clear();
-    s->c_bases = 0;
-    s->c_tail_base = 0;
-    s->c_tail_read = 0;
-    s->has_prev = false;
-    s->next_begin = report_begin;
-    s->has_region = true;
-    return 0;
-}
-
-int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const int32_t largest_total_indel_ref_span_per_read,
-                          const int32_t mask_begin, const int32_t mask_len, const uint8_t* cand_snv_mask, const int32_t final_to,
-                          const int32_t ploidy_begin, const int32_t ploidy_len, const uint8_t* ploidy, sk_pileup_window* out)
-{
-    SK_REQUIRE_INIT();
-    if (!s || !reads || !out) return sk_fail("sk_pileup_stream_push: null argument");
     if (!s->has_region) return sk_fail("sk_pileup_stream_push: no region (sk_pileup_stream_begin_region)");
     if (reads->n_reads < 0) return sk_fail("sk_pileup_stream_push: negative n_reads");
     const int n_new = reads->n_reads;
     if (n_new > 0 && (reads->read_off[0] != 0 || reads->path_off[0] != 0)) return sk_fail("sk_pileup_stream_push: CSR offsets must start at 0");
-    const int64_t new_bases = n_new ? reads->read_off[n_new] : 0, new_segs = n_new ? reads->path_off[n_new] : 0;
-    // what the reference rejects by throwing / exiting (as sk_pileup_reads)
+    const int64_t new_bases = n_new ? reads->read_off[n_new] : 0;
     for (int r = 0; r < n_new; ++r) {
         const int64_t L = reads->read_off[r + 1] - reads->read_off[r];
         if (L < 0 || reads->path_off[r + 1] < reads->path_off[r]) return sk_fail("sk_pileup_stream_push: bad CSR offsets");
@@ -1227,29 +1217,23 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     }
     if (mask_len < 0 || (mask_len > 0 && (!cand_snv_mask || mask_begin < s->ref_offset || mask_begin + mask_len > s->ref_offset + s->ref_len)))
         return sk_fail("sk_pileup_stream_push: candidate-SNV mask window outside the reference segment");
+    return 0;
+}
 
-    SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
-    hipStream_t st = ctx.stream;
-    s->opt.largest_total_indel_ref_span_per_read = largest_total_indel_ref_span_per_read;
-
-    const int n_c = int(s->c_len.size());
-    const int n = n_c + n_new;
-    const int64_t c_segs = int64_t(s->c_path.size());
-    const int64_t n_bases = s->c_bases + new_bases, n_segs = c_segs + new_segs;
-
-    // ---- the range this push finalises
-    const int32_t F = std::min(final_to, s->region_end);
+// lowest start / highest end of the carried and the new reads (INT_MAX / INT_MIN when there are none); fails when a new read
+// reaches positions an earlier push declared final
+int stream_extent(const sk_pileup_stream* s, const sk_read_batch* reads, int32_t* lowest_out, int32_t* highest_out)
+{
     int32_t lowest = INT_MAX, highest = INT_MIN;
     {
         int64_t so = 0;
-        for (int i = 0; i < n_c; ++i) {
+        for (size_t i = 0; i < s->c_len.size(); ++i) {
             lowest = std::min(lowest, s->c_pos[i]);
             highest = std::max(highest, s->c_pos[i] + path_ref_length(s->c_path.data() + so, s->c_nseg[i]));
             so += s->c_nseg[i];
         }
     }
-    for (int r = 0; r < n_new; ++r) {
+    for (int r = 0; r < reads->n_reads; ++r) {
         const int nseg = int(reads->path_off[r + 1] - reads->path_off[r]);
         if (nseg == 0) continue;
         const int e = reads->pos[r] + path_ref_length(reads->path + reads->path_off[r], nseg);
@@ -1269,16 +1253,44 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
         lowest = std::min(lowest, reads->pos[r]);
         highest = std::max(highest, e);
     }
+    *lowest_out = lowest;
+    *highest_out = highest;
+    return 0;
+}
+
+// the range a push finalises: the not yet final positions below F that the reads (extent lowest..highest) cover
+void stream_range(const sk_pileup_stream* s, const int32_t lowest, const int32_t highest, const int32_t F, int32_t* begin_out, int32_t* end_out)
+{
     int32_t begin = s->next_begin, end = s->next_begin;
-    if (n > 0 && lowest != INT_MAX) {
+    if (lowest != INT_MAX) {
         begin = std::max(s->region_begin, s->has_prev ? std::max(s->next_begin, lowest) : lowest);
         end = std::max(begin, std::min(F, highest));
     }
     if (begin > F) begin = end = std::max(s->next_begin, std::min(begin, F));
+    *begin_out = begin;
+    *end_out = end;
+}
+
+// everything of a push up to and including the copy of its output block to the host, on the context's stream, no wait
+int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_t largest_total_indel_ref_span_per_read,
+                   const int32_t mask_begin, const int32_t mask_len, const uint8_t* cand_snv_mask, const int32_t F, const int32_t begin,
+                   const int32_t end, const int32_t ploidy_begin, const int32_t ploidy_len, const uint8_t* ploidy)
+{
+    SkContext& ctx = sk_ctx();
+    hipStream_t st = ctx.stream;
+    s->opt.largest_total_indel_ref_span_per_read = largest_total_indel_ref_span_per_read;
+    const int n_new = reads->n_reads;
+    const int64_t new_bases = n_new ? reads->read_off[n_new] : 0, new_segs = n_new ? reads->path_off[n_new] : 0;
+    const int n_c = int(s->c_len.size());
+    const int n = n_c + n_new;
+    const int64_t c_segs = int64_t(s->c_path.size());
+    const int64_t n_bases = s->c_bases + new_bases, n_segs = c_segs + new_segs;
     const int n_loci = end - begin;
+    s->p_n = n; s->p_new = n_new; s->p_loci = n_loci; s->p_bases = n_bases; s->p_segs = n_segs;
+    s->p_begin = begin; s->p_end = end; s->p_F = F;
 
     // ---- device input block: carried metadata + the new reads
-    struct Lay { int64_t read_off, path_off, path, pos, is_fwd, mapq, level, code, qual, ploidy, mask, total; } li;
+    InLay& li = s->li;
     {
         int64_t o = 0;
         li.read_off = o; o += align256(8 * (int64_t(n) + 1));
@@ -1346,7 +1358,8 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
 
     // ---- work and output blocks
     const ScratchLayout SL = layout(n, n_bases, n_loci); // (its rec / span / count parts are unused here)
-    struct WLay { int64_t begin, end, maxend, minbegin, count0, count1, count2, off2, calls2, refbase, de, gscr, tmp, total; } wl;
+    const bool som = s->somatic;
+    WorkLay& wl = s->wl;
     {
         int64_t o = 0;
         wl.begin = o; o += align256(4 * int64_t(std::max(n, 1)));
@@ -1356,28 +1369,34 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
         wl.count0 = o; o += align256(4 * (int64_t(n_loci) + 1));
         wl.count1 = o; o += align256(4 * (int64_t(n_loci) + 1));
         wl.count2 = o; o += align256(4 * (int64_t(n_loci) + 1));
+        wl.count4 = o; o += align256(som ? 4 * (int64_t(n_loci) + 1) : 0);
+        wl.count4a = o; o += align256(som ? 4 * (int64_t(n_loci) + 1) : 0);
         wl.off2 = o; o += align256(8 * (int64_t(n_loci) + 1));
+        wl.off4 = o; o += align256(som ? 8 * (int64_t(n_loci) + 1) : 0);
         wl.calls2 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
+        wl.calls4 = o; o += align256(som ? 2 * std::max<int64_t>(n_bases, 1) : 0);
         wl.refbase = o; o += align256(std::max(n_loci, 1));
-        wl.de = o; o += align256(4 * std::max<int64_t>(n_bases, 1));
-        wl.gscr = o; o += align256(4 * (n_bases + int64_t(n_loci) + 8));
+        wl.de = o; o += align256(s->genotype ? 4 * std::max<int64_t>(n_bases, 1) : 0);
+        wl.gscr = o; o += align256(s->genotype ? 4 * (n_bases + int64_t(n_loci) + 8) : 0);
         wl.tmp = o; o += align256(SL.tmp_bytes);
         wl.total = o;
     }
-    struct OLay { int64_t off0, off1, clean_n, mq_n, mq_zero, mq_sq, spandel, submapped, geno, calls0, calls1, total; } ol;
+    OutLay& ol = s->ol;
     {
         int64_t o = 0;
         ol.off0 = o; o += align256(8 * (int64_t(n_loci) + 1));
         ol.off1 = o; o += align256(8 * (int64_t(n_loci) + 1));
         ol.clean_n = o; o += align256(4 * (int64_t(n_loci) + 1));
+        ol.clean4_n = o; o += align256(som ? 4 * (int64_t(n_loci) + 1) : 0);
         ol.mq_n = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
         ol.mq_zero = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
         ol.mq_sq = o; o += align256(8 * int64_t(std::max(n_loci, 1)));
         ol.spandel = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
         ol.submapped = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
-        ol.geno = o; o += align256(int64_t(sizeof(sk_digt_call)) * std::max(n_loci, 1));
+        ol.geno = o; o += align256(s->genotype ? int64_t(sizeof(sk_digt_call)) * std::max(n_loci, 1) : 0);
         ol.calls0 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
         ol.calls1 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
+        ol.read_pos = o; o += align256(s->want_read_pos ? 4 * std::max<int64_t>(n_bases, 1) : 0);
         ol.total = o;
     }
     if (s->d_work.need(size_t(wl.total)) || s->d_out.need(size_t(ol.total)) || s->h_out.need(size_t(ol.total)))
@@ -1445,36 +1464,52 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     c.mapq_count = reinterpret_cast<uint32_t*>(dout + ol.mq_n);
     c.mapq_zero = reinterpret_cast<uint32_t*>(dout + ol.mq_zero);
     c.mapq_sumsq = reinterpret_cast<unsigned long long*>(dout + ol.mq_sq);
+    if (som) {
+        c.count4 = reinterpret_cast<uint32_t*>(dw + wl.count4);
+        c.count4a = reinterpret_cast<uint32_t*>(dw + wl.count4a);
+        c.call_off4 = reinterpret_cast<int64_t*>(dw + wl.off4);
+        c.calls4 = reinterpret_cast<uint16_t*>(dw + wl.calls4);
+        c.read_pos = s->want_read_pos ? reinterpret_cast<uint32_t*>(dout + ol.read_pos) : nullptr;
+    }
     c.store = 0;
     const int blocks = (n_loci + 1 + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL(pileup_column_kernel_t<true>, dim3(blocks), dim3(WAVE), 0, st, c);
+    void (*const p2)(const PileupArgs) = som ? pileup_column_kernel_t<true, true> : pileup_column_kernel_t<true, false>;
+    hipLaunchKernelGGL(p2, dim3(blocks), dim3(WAVE), 0, st, c);
     for (int m = 0; m < 3; ++m) {
         tmp_bytes = size_t(SL.tmp_bytes);
         SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, c.count3[m], const_cast<int64_t*>(c.call_off3[m]), int64_t(0), size_t(n_loci) + 1,
                                        rocprim::plus<int64_t>(), st));
     }
+    if (som) {
+        tmp_bytes = size_t(SL.tmp_bytes);
+        SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, c.count4, const_cast<int64_t*>(c.call_off4), int64_t(0), size_t(n_loci) + 1,
+                                       rocprim::plus<int64_t>(), st));
+    }
     c.store = 1;
-    if (n > 0 && n_loci > 0) hipLaunchKernelGGL(pileup_column_kernel_t<true>, dim3(blocks), dim3(WAVE), 0, st, c);
-    // the cleaned column's sizes for the caller's cache validation; the region-wide counters' slice
+    if (n > 0 && n_loci > 0) hipLaunchKernelGGL(p2, dim3(blocks), dim3(WAVE), 0, st, c);
+    // the cleaned columns' sizes for the caller's cache validation; the region-wide counters' slice
     SK_HIP(hipMemcpyAsync(dout + ol.clean_n, c.count3[2], 4 * (size_t(n_loci) + 1), hipMemcpyDeviceToDevice, st));
+    if (som) SK_HIP(hipMemcpyAsync(dout + ol.clean4_n, c.count4, 4 * (size_t(n_loci) + 1), hipMemcpyDeviceToDevice, st));
     if (n_loci > 0) {
         SK_HIP(hipMemcpyAsync(dout + ol.spandel, static_cast<char*>(s->d_spandel.p) + 4 * size_t(begin - s->region_begin), 4 * size_t(n_loci),
                               hipMemcpyDeviceToDevice, st));
         SK_HIP(hipMemcpyAsync(dout + ol.submapped, static_cast<char*>(s->d_submapped.p) + 4 * size_t(begin - s->region_begin), 4 * size_t(n_loci),
                               hipMemcpyDeviceToDevice, st));
     }
-    // a9 + a10 on the cleaned columns, where they are
-    if (s->genotype && n_loci > 0) {
+    if (n_loci > 0 && (s->genotype || som)) {
         uint8_t* d_refbase = reinterpret_cast<uint8_t*>(dw + wl.refbase);
         hipLaunchKernelGGL(ref_base_id_kernel, dim3((n_loci + 255) / 256), dim3(256), 0, st, static_cast<const char*>(s->d_ref.p), s->ref_offset,
                            s->ref_len, begin, n_loci, d_refbase);
+    }
+    // a9 + a10 on the cleaned columns, where they are
+    if (s->genotype && n_loci > 0) {
         sk_pileup_batch pb;
         std::memset(&pb, 0, sizeof(pb));
         pb.n_loci = n_loci;
         pb.call_off = off2;
         pb.calls = c.calls3[2];
         pb.de = nullptr;
-        pb.ref_base = d_refbase;
+        pb.ref_base = reinterpret_cast<const uint8_t*>(dw + wl.refbase);
         pb.ploidy = reinterpret_cast<const uint8_t*>(di + li.ploidy);
         if (sk_site_digt_call_fused_dev(&pb, &s->gopt, reinterpret_cast<sk_digt_call*>(dout + ol.geno), reinterpret_cast<float*>(dw + wl.de), 0,
                                         dw + wl.gscr, n_bases, st))
@@ -1482,9 +1517,19 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     }
     SK_HIP(hipGetLastError());
     SK_HIP(hipMemcpyAsync(ho, dout, size_t(ol.total), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
 
-    // ---- what the next push carries: the reads from the first one that ends past F on
+// after the stream has been waited for: what the next push carries, and the window's pointers
+void stream_finish(sk_pileup_stream* s, sk_pileup_window* out)
+{
+    const InLay& li = s->li;
+    const OutLay& ol = s->ol;
+    const char* hi = static_cast<const char*>(s->h_in.p);
+    const char* ho = static_cast<const char*>(s->h_out.p);
+    const int n = s->p_n;
+    const int32_t F = s->p_F;
+    // the reads from the first one that ends past F on
     {
         const int64_t* ro = reinterpret_cast<const int64_t*>(hi + li.read_off);
         const int64_t* po = reinterpret_cast<const int64_t*>(hi + li.path_off);
@@ -1509,19 +1554,19 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
             np.push_back(ps[i]);
             nm.push_back(mq[i]);
         }
-        std::vector<sk_path_seg> npath(pa + (i0 < n ? po[i0] : n_segs), pa + n_segs);
-        s->c_tail_base = (i0 < n) ? ro[i0] : n_bases;
+        std::vector<sk_path_seg> npath(pa + (i0 < n ? po[i0] : s->p_segs), pa + s->p_segs);
+        s->c_tail_base = (i0 < n) ? ro[i0] : s->p_bases;
         s->c_tail_read = i0;
-        s->c_bases = n_bases - s->c_tail_base;
+        s->c_bases = s->p_bases - s->c_tail_base;
         s->c_len.swap(nl); s->c_nseg.swap(ns); s->c_pos.swap(np); s->c_mapq.swap(nm); s->c_path.swap(npath);
     }
     s->has_prev = true;
     s->next_begin = std::max(s->next_begin, F);
     s->pushes++;
-    s->reads_in += n_new;
+    s->reads_in += s->p_new;
 
-    out->begin = begin;
-    out->end = end;
+    out->begin = s->p_begin;
+    out->end = s->p_end;
     out->tier1_off = reinterpret_cast<const int64_t*>(ho + ol.off0);
     out->tier1_calls = reinterpret_cast<const uint16_t*>(ho + ol.calls0);
     out->tier2_off = reinterpret_cast<const int64_t*>(ho + ol.off1);
@@ -1533,6 +1578,241 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     out->mapq_sum_square = reinterpret_cast<const uint64_t*>(ho + ol.mq_sq);
     out->clean_count = reinterpret_cast<const uint32_t*>(ho + ol.clean_n);
     out->genotype = s->genotype ? reinterpret_cast<const sk_digt_call*>(ho + ol.geno) : nullptr;
+}
+
+void stream_drop(sk_pileup_stream* s)
+{
+    s->d_ref.drop(); s->d_mask.drop(); s->d_spandel.drop(); s->d_submapped.drop();
+    s->d_rec[0].drop(); s->d_rec[1].drop(); s->d_span[0].drop(); s->d_span[1].drop();
+    s->d_in.drop(); s->d_work.drop(); s->d_out.drop();
+    s->h_in.drop(); s->h_out.drop();
+}
+
+} // namespace
+
+extern "C" {
+
+sk_pileup_stream* sk_pileup_stream_create(const sk_pileup_options* opt, const sk_germline_options* genotype_opt)
+{
+    if (!sk_ctx().ready) {
+        sk_fail("strelka_amd: sk_init() has not succeeded");
+        return nullptr;
+    }
+    if (!opt) {
+        sk_fail("sk_pileup_stream_create: null options");
+        return nullptr;
+    }
+    sk_pileup_stream* s = new sk_pileup_stream();
+    s->opt = *opt;
+    if (genotype_opt) {
+        s->gopt = *genotype_opt;
+        s->genotype = true;
+    }
+    return s;
+}
+
+void sk_pileup_stream_destroy(sk_pileup_stream* s)
+{
+    if (!s) return;
+    if (sk_ctx().ready) {
+        (void)hipSetDevice(sk_ctx().device);
+        (void)hipStreamSynchronize(sk_ctx().stream);
+    }
+    stream_drop(s);
+    delete s;
+}
+
+int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, const int32_t ref_offset, const int32_t ref_len,
+                                  const int32_t report_begin, const int32_t report_end,
+                                  const int32_t largest_total_indel_ref_span_per_read)
+{
+    SK_REQUIRE_INIT();
+    if (!s || (!ref_seq && ref_len > 0)) return sk_fail("sk_pileup_stream_begin_region: null argument");
+    if (ref_len < 0 || report_end < report_begin) return sk_fail("sk_pileup_stream_begin_region: bad range");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    const size_t n_region = size_t(report_end - report_begin);
+    if (s->d_ref.need(size_t(ref_len) + 1) || s->d_mask.need(size_t(ref_len) + 1) || s->d_spandel.need(4 * n_region + 4) ||
+        s->d_submapped.need(4 * n_region + 4))
+        return sk_fail("sk_pileup_stream_begin_region: out of device memory");
+    if (ref_len > 0) SK_HIP(hipMemcpyAsync(s->d_ref.p, ref_seq, size_t(ref_len), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemsetAsync(s->d_mask.p, 0, size_t(ref_len) + 1, st));
+    SK_HIP(hipMemsetAsync(s->d_spandel.p, 0, 4 * n_region + 4, st));
+    SK_HIP(hipMemsetAsync(s->d_submapped.p, 0, 4 * n_region + 4, st));
+    SK_HIP(hipStreamSynchronize(st)); // ref_seq is the caller's
+    s->ref_offset = ref_offset;
+    s->ref_len = ref_len;
+    s->region_begin = report_begin;
+    s->region_end = report_end;
+    s->opt.report_begin = report_begin;
+    s->opt.report_end = report_end;
+    s->opt.largest_total_indel_ref_span_per_read = largest_total_indel_ref_span_per_read;
+    s->c_len.clear(); s->c_nseg.clear(); s->c_pos.clear(); s->c_mapq.clear(); s->c_path.clear();
+    s->c_bases = 0;
+    s->c_tail_base = 0;
+    s->c_tail_read = 0;
+    s->has_prev = false;
+    s->next_begin = report_begin;
+    s->has_region = true;
+    return 0;
+}
+
+int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const int32_t largest_total_indel_ref_span_per_read,
+                          const int32_t mask_begin, const int32_t mask_len, const uint8_t* cand_snv_mask, const int32_t final_to,
+                          const int32_t ploidy_begin, const int32_t ploidy_len, const uint8_t* ploidy, sk_pileup_window* out)
+{
+    SK_REQUIRE_INIT();
+    if (!s || !reads || !out) return sk_fail("sk_pileup_stream_push: null argument");
+    if (stream_check_reads(s, reads, mask_begin, mask_len, cand_snv_mask)) return 1;
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    const int32_t F = std::min(final_to, s->region_end);
+    int32_t lowest, highest, begin, end;
+    if (stream_extent(s, reads, &lowest, &highest)) return 1;
+    stream_range(s, lowest, highest, F, &begin, &end);
+    if (stream_enqueue(s, reads, largest_total_indel_ref_span_per_read, mask_begin, mask_len, cand_snv_mask, F, begin, end, ploidy_begin,
+                       ploidy_len, ploidy))
+        return 1;
+    SK_HIP(hipStreamSynchronize(ctx.stream));
+    stream_finish(s, out);
+    return 0;
+}
+
+// ---- the two samples of a somatic run, pushed together and chained into a12+a13 ----------------------------------------------
+
+sk_somatic_pileup_stream* sk_somatic_pileup_stream_create(const sk_pileup_options* opt, const sk_somatic_snv_options* genotype_opt,
+                                                          const int with_read_pos)
+{
+    if (!sk_ctx().ready) {
+        sk_fail("strelka_amd: sk_init() has not succeeded");
+        return nullptr;
+    }
+    if (!opt) {
+        sk_fail("sk_somatic_pileup_stream_create: null options");
+        return nullptr;
+    }
+    sk_somatic_pileup_stream* p = new sk_somatic_pileup_stream();
+    for (int i = 0; i < 2; ++i) {
+        p->sample[i] = new sk_pileup_stream();
+        p->sample[i]->opt = *opt;
+        p->sample[i]->somatic = true;
+    }
+    p->sample[1]->want_read_pos = (with_read_pos != 0);
+    p->tier2 = (opt->use_tier2_evidence != 0);
+    if (genotype_opt) {
+        p->sopt = *genotype_opt;
+        p->genotype = true;
+    }
+    return p;
+}
+
+void sk_somatic_pileup_stream_destroy(sk_somatic_pileup_stream* p)
+{
+    if (!p) return;
+    if (sk_ctx().ready) {
+        (void)hipSetDevice(sk_ctx().device);
+        (void)hipStreamSynchronize(sk_ctx().stream);
+    }
+    for (int i = 0; i < 2; ++i) {
+        stream_drop(p->sample[i]);
+        delete p->sample[i];
+    }
+    p->d_call.drop();
+    p->h_forced.drop();
+    p->h_geno.drop();
+    delete p;
+}
+
+int sk_somatic_pileup_stream_begin_region(sk_somatic_pileup_stream* p, const char* ref_seq, const int32_t ref_offset, const int32_t ref_len,
+                                          const int32_t report_begin, const int32_t report_end,
+                                          const int32_t largest_total_indel_ref_span_per_read)
+{
+    if (!p) return sk_fail("sk_somatic_pileup_stream_begin_region: null argument");
+    for (int i = 0; i < 2; ++i) {
+        if (sk_pileup_stream_begin_region(p->sample[i], ref_seq, ref_offset, ref_len, report_begin, report_end, largest_total_indel_ref_span_per_read))
+            return 1;
+    }
+    return 0;
+}
+
+int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_batch* normal_reads, const sk_read_batch* tumor_reads,
+                                  const int32_t largest_total_indel_ref_span_per_read, const int32_t mask_begin, const int32_t mask_len,
+                                  const uint8_t* cand_snv_mask, const int32_t final_to, const int32_t forced_begin, const int32_t forced_len,
+                                  const uint8_t* is_forced_output, const int is_compute_nonsomatic, sk_somatic_pileup_window* out)
+{
+    SK_REQUIRE_INIT();
+    if (!p || !normal_reads || !tumor_reads || !out) return sk_fail("sk_somatic_pileup_stream_push: null argument");
+    const sk_read_batch* reads[2] = { normal_reads, tumor_reads };
+    for (int i = 0; i < 2; ++i) {
+        if (stream_check_reads(p->sample[i], reads[i], mask_begin, mask_len, cand_snv_mask)) return 1;
+    }
+    if (forced_len < 0 || (forced_len > 0 && !is_forced_output)) return sk_fail("sk_somatic_pileup_stream_push: bad forced-output window");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    sk_pileup_stream* sn = p->sample[0];
+    sk_pileup_stream* stu = p->sample[1];
+    const int32_t F = std::min(final_to, sn->region_end);
+    // one range for both samples: the positions either sample's reads cover
+    int32_t lowest = INT_MAX, highest = INT_MIN, begin, end;
+    for (int i = 0; i < 2; ++i) {
+        int32_t lo, hi;
+        if (stream_extent(p->sample[i], reads[i], &lo, &hi)) return 1;
+        lowest = std::min(lowest, lo);
+        highest = std::max(highest, hi);
+    }
+    stream_range(sn, lowest, highest, F, &begin, &end);
+    for (int i = 0; i < 2; ++i) {
+        if (stream_enqueue(p->sample[i], reads[i], largest_total_indel_ref_span_per_read, mask_begin, mask_len, cand_snv_mask, F, begin, end, 0,
+                           0, nullptr))
+            return 1;
+    }
+    const int n_loci = end - begin;
+    // a12 + a13 on the four cleaned columns, where they are
+    const size_t geno_bytes = sizeof(sk_somatic_snv_genotype) * size_t(std::max(n_loci, 1));
+    if (p->genotype && n_loci > 0) {
+        const size_t forced_bytes = size_t(align256(n_loci));
+        const size_t scratch_bytes = sk_somatic_snv_tiers_scratch_bytes(n_loci);
+        if (p->d_call.need(forced_bytes + size_t(align256(int64_t(geno_bytes))) + scratch_bytes) || p->h_forced.need(forced_bytes) ||
+            p->h_geno.need(geno_bytes))
+            return sk_fail("sk_somatic_pileup_stream_push: out of memory (somatic records)");
+        uint8_t* hf = static_cast<uint8_t*>(p->h_forced.p);
+        for (int i = 0; i < n_loci; ++i) {
+            const int64_t k = int64_t(begin) + i - forced_begin;
+            hf[i] = (is_forced_output && k >= 0 && k < forced_len) ? is_forced_output[k] : uint8_t(0);
+        }
+        char* dc = static_cast<char*>(p->d_call.p);
+        uint8_t* d_forced = reinterpret_cast<uint8_t*>(dc);
+        sk_somatic_snv_genotype* d_geno = reinterpret_cast<sk_somatic_snv_genotype*>(dc + forced_bytes);
+        void* d_scratch = dc + forced_bytes + size_t(align256(int64_t(geno_bytes)));
+        SK_HIP(hipMemcpyAsync(d_forced, hf, size_t(n_loci), hipMemcpyHostToDevice, st));
+        sk_pileup_batch b[4]; // normal t1, tumor t1, normal t2, tumor t2
+        for (int i = 0; i < 2; ++i) {
+            sk_pileup_stream* s = p->sample[i];
+            char* dw = static_cast<char*>(s->d_work.p);
+            std::memset(&b[i], 0, sizeof(sk_pileup_batch));
+            b[i].n_loci = n_loci;
+            b[i].call_off = reinterpret_cast<const int64_t*>(dw + s->wl.off2);
+            b[i].calls = reinterpret_cast<const uint16_t*>(dw + s->wl.calls2);
+            b[i].ref_base = reinterpret_cast<const uint8_t*>(static_cast<char*>(sn->d_work.p) + sn->wl.refbase);
+            b[2 + i] = b[i];
+            b[2 + i].call_off = reinterpret_cast<const int64_t*>(dw + s->wl.off4);
+            b[2 + i].calls = reinterpret_cast<const uint16_t*>(dw + s->wl.calls4);
+        }
+        if (sk_somatic_snv_call_tiers_dev(&b[0], &b[1], p->tier2 ? &b[2] : nullptr, p->tier2 ? &b[3] : nullptr, &p->sopt, d_forced,
+                                          is_compute_nonsomatic, d_geno, d_scratch, st))
+            return 1;
+        SK_HIP(hipMemcpyAsync(p->h_geno.p, d_geno, sizeof(sk_somatic_snv_genotype) * size_t(n_loci), hipMemcpyDeviceToHost, st));
+    }
+    SK_HIP(hipStreamSynchronize(st));
+    stream_finish(sn, &out->normal);
+    stream_finish(stu, &out->tumor);
+    out->tumor_tier1_read_pos =
+        stu->want_read_pos ? reinterpret_cast<const uint32_t*>(static_cast<const char*>(stu->h_out.p) + stu->ol.read_pos) : nullptr;
+    out->normal_clean_tier2_count = reinterpret_cast<const uint32_t*>(static_cast<const char*>(sn->h_out.p) + sn->ol.clean4_n);
+    out->tumor_clean_tier2_count = reinterpret_cast<const uint32_t*>(static_cast<const char*>(stu->h_out.p) + stu->ol.clean4_n);
+    out->genotype = (p->genotype && n_loci > 0) ? static_cast<const sk_somatic_snv_genotype*>(p->h_geno.p) : nullptr;
     return 0;
 }
 

@@ -133,7 +133,7 @@ def test_germline_demo_identical_with_device_enumeration(tmp_path):
     assert c["enum_device_reads"] > 50 and c["enum_host_instead"] <= c["enum_device_reads"] // 20
 
 
-def _somatic(variant, tmp_path, windows=None, callable_regions=False):
+def _somatic(variant, tmp_path, windows=None, callable_regions=False, extra_env=None):
     ref_out, out = str(tmp_path / "ref") + "/", str(tmp_path / variant) + "/"
     (tmp_path / "ref").mkdir(exist_ok=True)
     (tmp_path / variant).mkdir(exist_ok=True)
@@ -143,9 +143,17 @@ def _somatic(variant, tmp_path, windows=None, callable_regions=False):
     env = {"STRELKA_AMD_VERBOSE": "1"}
     if windows:
         env["STRELKA_AMD_READ_WINDOW"], env["STRELKA_AMD_SITE_WINDOW"] = str(windows[0]), str(windows[1])
+    env.update(extra_env or {})
     p = E.run(E.somatic_argv("strelka2_" + variant, out, normal, tumor, extra=extra(out)), env=env)
     c = _counters(p.stderr.decode())
     assert c["realign_reads"] > 1000 and c["site_loci"] > 3000 and c["indel_groups"] >= 1
+    # site 9: both samples through the one somatic stream, its records serving site 5 (the somatic EVS models are loaded:
+    # the tumor sample's read-position accumulators are rebuilt from the stream's window when a record is written)
+    if (extra_env or {}).get("STRELKA_AMD_PILEUP") == "0":
+        assert c["pileup_pushes"] == 0
+    else:
+        assert c["pileup_pushes"] >= 1 and c["pileup_reads"] > 1000 and c["pileup_loci"] > 3000
+        assert c["pileup_genotyping"] == (0 if (extra_env or {}).get("STRELKA_AMD_PILEUP_GENOTYPE") == "0" else 1)
     files = ["somatic.snvs.vcf", "somatic.indels.vcf"] + (["somatic.callable.regions.bed"] if callable_regions else [])
     for f in files:
         want, got = E.vcf_body(ref_out + f, keep_header=True), E.vcf_body(out + f, keep_header=True)
@@ -164,11 +172,26 @@ def test_somatic_demo_identical_through_adapter_cpu_double(tmp_path, windows, ca
     _somatic("dbl", tmp_path, windows, callable_regions)
 
 
+@pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("env", [{"STRELKA_AMD_PILEUP": "0"}, {"STRELKA_AMD_PILEUP_GENOTYPE": "0"}])
+def test_somatic_demo_identical_with_reference_pileup_or_columns_only(tmp_path, env):
+    """STRELKA_AMD_PILEUP=0: the reference's pileup_read_segment, site 5 per site window from the host's copy of the columns;
+    STRELKA_AMD_PILEUP_GENOTYPE=0: the stream builds the columns (and the EVS read positions), site 5 as before"""
+    _somatic("dbl", tmp_path, callable_regions=True, extra_env=env)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_amd"), reason="oracle/_ref binaries not built")
 @pytest.mark.parametrize("windows,callable_regions", [(None, False), ((5, 9), True)])
 def test_somatic_demo_identical_through_adapter_gpu(tmp_path, windows, callable_regions):
     _somatic("amd", tmp_path, windows, callable_regions)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_amd"), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("env", [{"STRELKA_AMD_PILEUP": "0"}, {"STRELKA_AMD_PILEUP_GENOTYPE": "0"}])
+def test_somatic_demo_identical_with_reference_pileup_or_columns_only_gpu(tmp_path, env):
+    _somatic("amd", tmp_path, callable_regions=True, extra_env=env)
 
 
 # ---- larger synthetic inputs (tools/make_synth_bam.py, built by `make -C oracle ref` into oracle/_ref/synth) ------------------
@@ -208,7 +231,7 @@ def _synth(variant, tmp_path, which, windows=None, extra_env=None):
             assert cg["realign_reads"] > 10000 and cg["indel_groups"] > 100 and cg["haplotypes"] > 100 and cg["site_recomputed"] > 100
             assert cs["realign_reads"] > 15000 and cs["indel_groups"] > 30
             assert cg["pileup_pushes"] >= 2 and cg["pileup_reads"] > 10000 and cg["pileup_genotyping"] == 1
-            assert cs["pileup_pushes"] == 0  # the somatic processor keeps the reference's pileup (EVS feature accumulators)
+            assert cs["pileup_pushes"] >= 2 and cs["pileup_reads"] > 10000 and cs["pileup_genotyping"] == 1
             assert cg["feed_regions"] == 2 and cs["feed_regions"] == 2 and cg["feed_records"] > 10000 and cs["feed_records"] > 15000
             for c in (cg, cs):  # normalizeAlignment in batches, with alignments that it changes, none handed back to the reference
                 assert c["feed_normalize_batches"] >= 2 and c["feed_normalized"] > 10000 and c["feed_normalize_changed"] > 100

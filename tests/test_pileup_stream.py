@@ -202,3 +202,135 @@ def test_gpu_stream_at_window_scale(gpu):
     assert np.array_equal(np.array(got_off), o1[:len(got_off)]) and np.array_equal(got_calls, c1[:len(got_calls)])
     assert len(got_calls) == len(c1)
     st.close()
+
+
+# ---- the two samples of a somatic run through one stream (sk_somatic_pileup_stream_*), chained into a12+a13 --------------------
+
+def _expect_somatic_sample(reads, ref, off, kw, mask):
+    want = _expect(reads, ref, off, kw, mask)
+    rb = synth.ReadBatch.from_reads(reads, ref, off, cand_snv_mask=mask)
+    o = pyoracle.pileup_options(**kw)
+    want["o4"], want["c4"], _, _ = pyoracle.pileup_reads(rb, o, capi.PILEUP_CLEAN_TIER2)
+    orp, crp, rp = pyoracle.pileup_reads_readpos(rb, o)
+    assert np.array_equal(orp, want["o1"]) and np.array_equal(crp, want["c1"])
+    want["rp"] = rp
+    return want
+
+
+def _somatic_scenarios():
+    rng = np.random.default_rng(1234)
+    out = []
+    for trial in range(4):
+        ref_len = (700, 1800, 300, 1200)[trial]
+        off = 5000
+        ref = synth._random_ref(ref_len, rng)
+        samples = []
+        for depth_reads in ((120, 300), (400, 900), (20, 70), (250, 0))[trial]:
+            reads, _, _ = synth.pileup_reads(depth_reads, rng, ref_len=ref_len, ref_offset=off, read_len=(36, 151)) if depth_reads else ([], None, None)
+            # pileup_reads draws its own reference: re-draw the bases of the reads against the shared one, keeping geometry
+            for r in reads:
+                p, rp = r["pos"], 0
+                code = r["code"].copy()
+                for t, l in r["path"]:
+                    if t == capi.SEG["MATCH"]:
+                        for j in range(l):
+                            i = p + j - off
+                            if 0 <= i < ref_len and rng.random() > 0.04 and code[rp + j] != 15:
+                                code[rp + j] = 1 << "ACGT".index(ref[i])
+                        p += l
+                        rp += l
+                    elif t == capi.SEG["DELETE"]:
+                        p += l
+                    elif t in (capi.SEG["INSERT"], capi.SEG["SOFT_CLIP"]):
+                        rp += l
+                r["code"] = code
+            samples.append(reads)
+        kw = dict(report_begin=off + 5 * trial, report_end=off + ref_len - 3 * trial, min_basecall_qscore=0, mismatch_density_max_count=3,
+                  use_tier2_evidence=1)
+        if trial == 2:
+            kw["use_tier2_evidence"] = 0
+        mask = rng.integers(0, 16, ref_len).astype(np.uint8) if trial == 1 else None
+        n_cuts = (0, 9, 30, 4)[trial]
+        cuts = sorted(set(int(x) for x in rng.integers(off - 10, off + ref_len, n_cuts)))
+        forced = (rng.random(ref_len) < 0.05).astype(np.uint8) if trial in (1, 3) else None
+        out.append((samples, ref, off, kw, cuts, mask, forced, trial % 2 == 1))
+    return out
+
+
+def _run_somatic(library, genotype=True):
+    n_windows = n_loci = n_computed = 0
+    for samples, ref, off, kw, cuts, mask, forced, nonsom in _somatic_scenarios():
+        want = [_expect_somatic_sample(reads, ref, off, kw, mask) for reads in samples]
+        opt = capi.pileup_options(**kw)
+        sopt = capi.somatic_snv_options()
+        st = capi.SomaticPileupStream(opt, sopt if genotype else None, with_read_pos=True, library=library)
+        st.begin_region(ref, off, kw["report_begin"], kw["report_end"])
+        bounds = [-(2**31)] + cuts + [2**31 - 1]
+        rb, re = kw["report_begin"], kw["report_end"]
+        covered = np.zeros(re - rb, bool)
+        for i in range(len(bounds) - 1):
+            lo, hi = bounds[i], bounds[i + 1]
+            subs, later = [], []
+            for reads in samples:
+                subs.append(synth.ReadBatch.from_reads([r for r in reads if lo <= r["pos"] < hi], "", 0))
+                later += [r["pos"] for r in reads if r["pos"] >= hi and r["path"]]
+            final_to = min(later) if later else 2**31 - 1
+            w = st.push(subs[0], subs[1], final_to, mask=mask, mask_begin=off, forced=forced, forced_begin=off, is_compute_nonsomatic=nonsom)
+            b, e = w["begin"], w["end"]
+            assert rb <= b <= e <= re and w["normal"]["begin"] == b and w["tumor"]["end"] == e
+            n = e - b
+            n_windows += 1
+            if n == 0:
+                continue
+            assert not covered[b - rb:e - rb].any()
+            covered[b - rb:e - rb] = True
+            n_loci += n
+            cols = []
+            for si, name in enumerate(("normal", "tumor")):
+                ws, wa = w[name], want[si]
+                for off_key, call_key, wo, wc in (("tier1_off", "tier1_calls", "o1", "c1"), ("tier2_off", "tier2_calls", "o2", "c2")):
+                    assert np.array_equal(np.diff(ws[off_key]), np.diff(wa[wo][b - rb:e - rb + 1]))
+                    assert np.array_equal(ws[call_key], wa[wc][wa[wo][b - rb]:wa[wo][e - rb]])
+                sl = slice(b - rb, e - rb)
+                assert np.array_equal(ws["spandel"], wa["sd"][sl]) and np.array_equal(ws["submapped"], wa["sm"][sl])
+                assert np.array_equal(ws["mapq_count"], wa["mn"][sl]) and np.array_equal(ws["mapq_sumsq"], wa["sq"][sl])
+                assert np.array_equal(ws["clean_count"], np.diff(wa["oc"][b - rb:e - rb + 1]))
+                assert np.array_equal(ws["clean2_count"], np.diff(wa["o4"][b - rb:e - rb + 1]))
+                for o_key, c_key in (("oc", "cc"), ("o4", "c4")):
+                    cols.append((wa[o_key][b - rb:e - rb + 1] - wa[o_key][b - rb], wa[c_key][wa[o_key][b - rb]:wa[o_key][e - rb]]))
+            assert np.array_equal(w["read_pos"], want[1]["rp"][want[1]["o1"][b - rb]:want[1]["o1"][e - rb]])
+            if genotype:
+                ref_base = np.array(["ACGTN".index(ref[p - off]) if 0 <= p - off < len(ref) and ref[p - off] in "ACGT" else 4
+                                     for p in range(b, e)], np.uint8)
+                n1, n2, t1, t2 = (capi.HostPileupBatch(co, cc, ref_base) for co, cc in cols)
+                fo = None if forced is None else np.ascontiguousarray(forced[b - off:e - off])
+                tier2 = bool(kw["use_tier2_evidence"])
+                wg = pyoracle.somatic_snv_call_tiers(n1, t1, n2 if tier2 else None, t2 if tier2 else None, sopt, is_forced_output=fo,
+                                                     is_compute_nonsomatic=nonsom)
+                assert w["genotype"].tobytes() == wg.tobytes()
+                n_computed += int(w["genotype"]["is_computed"].sum())
+            else:
+                assert w["genotype"] is None
+        st.close()
+        quiet = ~covered
+        for wa in want:
+            assert not np.diff(wa["o1"])[quiet].any() and not np.diff(wa["o2"])[quiet].any() and not wa["mn"][quiet].any()
+    assert n_windows > 40 and n_loci > 3000 and (n_computed > 1000 or not genotype)
+
+
+def test_double_somatic_stream_equals_one_shot_restatement(built):
+    _run_somatic(_double())
+
+
+def test_double_somatic_stream_columns_only(built):
+    _run_somatic(_double(), genotype=False)
+
+
+@pytest.mark.gpu
+def test_gpu_somatic_stream_equals_one_shot_restatement(gpu):
+    _run_somatic(None)
+
+
+@pytest.mark.gpu
+def test_gpu_somatic_stream_columns_only(gpu):
+    _run_somatic(None, genotype=False)
