@@ -74,6 +74,17 @@ HOOKS = [
          r'(starling_pos_processor_base::\nset_head_pos\(const pos_t pos\)\n\{\n)',
          '\\1    sk_adapter::on_set_head_pos(*this, pos, get_read_buffer_size(get_largest_read_size(), '
          'get_largest_total_indel_ref_span_per_read())+HAPLOTYPING_PADDING, get_largest_total_indel_ref_span_per_read());\n'),
+        # the somatic caller's per-sample depth statistics from the stream's column sizes (its cleaned pileups are built on demand)
+        ("process_pos_sample_stats",
+         r'    _pileupCleaner\.CleanPileupFilter\(pi,is_include_tier2,sif\.cleanedPileup\);\n\n'
+         r'(    const unsigned n_spandel\(pi\.spanningDeletionReadCount\);\n    const unsigned n_submapped\(pi\.submappedReadCount\);\n\n'
+         r'    if \(pi\.get_ref_base\(\) != \'N\'\)\n    \{\n)'
+         r'        sif\.localRegionStatsCollection\.insert\(pos, sif\.cleanedPileup\.usedBasecallCount\(\), sif\.cleanedPileup\.unusedBasecallCount\(\),n_spandel,n_submapped\);\n',
+         '    unsigned skUsed(0), skUnused(0);\n'
+         '    if (! sk_adapter::sample_stats_counts(*this, pos, sample_no, skUsed, skUnused))\n    {\n'
+         '        _pileupCleaner.CleanPileupFilter(pi,is_include_tier2,sif.cleanedPileup);\n'
+         '        skUsed = sif.cleanedPileup.usedBasecallCount();\n        skUnused = sif.cleanedPileup.unusedBasecallCount();\n    }\n\n'
+         '\\1        sif.localRegionStatsCollection.insert(pos, skUsed, skUnused,n_spandel,n_submapped);\n'),
         # sites 2+3: the window's genotypes are computed when POST_ALIGN reaches its first position
         ("process_pos_variants",
          r'(starling_pos_processor_base::\nprocess_pos_variants\(\n    const pos_t pos,\n    const bool isPosPrecedingReportableRange\)\n\{\n)',
@@ -95,16 +106,20 @@ HOOKS = [
     ]),
     (L + "applications/strelka/strelka_pos_processor.cpp", [
         ("include", r'#include "strelka_pos_processor.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # site 9 (somatic): the four cleaned pileups of a position are built when something reads them -- the writer of a somatic
+        # record, or site 5 for a position the stream's records do not cover -- not for every position
+        ("CleanPileup loop",
+         r'    for \(unsigned t\(0\); t<n_tier; \+\+t\)\n(    \{\n        const bool is_include_tier2\(t!=0\);\n        if \(is_include_tier2 && \(! _opt\.useTier2Evidence\)\) continue;\n        _pileupCleaner\.CleanPileup\(normal_sif)',
+         '    bool skIsCleanDeferred(sk_adapter::somatic_defer_clean(*this, pos));\n    for (unsigned t(0); (! skIsCleanDeferred) && t<n_tier; ++t)\n\\1'),
         # site 5
         ("position_somatic_snv_call",
          r'_dopt\.sscaller_strand_grid\(\)\.position_somatic_snv_call\([^;]*;',
-         'sk_adapter::somatic_snv_genotype(*this, pos, *(normal_cpi_ptr[0]), *(tumor_cpi_ptr[0]), '
-         '(_opt.useTier2Evidence ? normal_cpi_ptr[1] : nullptr), (_opt.useTier2Evidence ? tumor_cpi_ptr[1] : nullptr), '
-         'isComputeNonSomatic, sgtg);'),
-        # site 9 (somatic): the tumor sample's EVS accumulators of a position, just before its record is written
+         'sk_adapter::somatic_snv_genotype(*this, pos, normal_cpi_ptr, tumor_cpi_ptr, skIsCleanDeferred, isComputeNonSomatic, sgtg);'),
+        # site 9 (somatic): the cleaned pileups and the tumor sample's EVS accumulators of a position, just before its record is written
         ("write_vcf_somatic_snv_genotype_strand_grid",
          r'(\n)(        write_vcf_somatic_snv_genotype_strand_grid\(_opt, _dopt, sgtg,)',
-         '\\1        sk_adapter::somatic_fill_scoring_metrics(*this, pos);\n\\2'),
+         '\\1        if (skIsCleanDeferred) sk_adapter::somatic_clean_now(*this, pos, normal_cpi_ptr, tumor_cpi_ptr);\n'
+         '        sk_adapter::somatic_fill_scoring_metrics(*this, pos);\n\\2'),
         # site 6
         ("get_somatic_indel",
          r'_dopt\.sicaller_grid\(\)\.get_somatic_indel\(_opt,_dopt,',

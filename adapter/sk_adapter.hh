@@ -81,9 +81,17 @@ void on_flush_end(starling_pos_processor_base& pp);
 
 // ---- site 5: position_somatic_snv_call at strelka_pos_processor.cpp:213-219 ----
 void somatic_window(starling_pos_processor_base& pp, const pos_t pos);
-void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, const CleanedPileup& normal1, const CleanedPileup& tumor1,
-                          const CleanedPileup* normal2, const CleanedPileup* tumor2, const bool isComputeNonSomatic,
-                          somatic_snv_genotype_grid& sgt);
+/// the position's record; normalCpi / tumorCpi: the processor's cleaned pileups {tier1, tier2}; isCleanDeferred: they have not been
+/// built for this position (somatic_defer_clean) -- cleared when this call had to build them
+void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, CleanedPileup* const* normalCpi, CleanedPileup* const* tumorCpi,
+                          bool& isCleanDeferred, const bool isComputeNonSomatic, somatic_snv_genotype_grid& sgt);
+/// true: process_pos_snp_somatic skips its four CleanPileup calls for this position (the stream's records serve site 5)
+bool somatic_defer_clean(starling_pos_processor_base& pp, const pos_t pos);
+/// the skipped CleanPileup calls (strelka_pos_processor.cpp:180-186), now
+void somatic_clean_now(starling_pos_processor_base& pp, const pos_t pos, CleanedPileup* const* normalCpi, CleanedPileup* const* tumorCpi);
+/// process_pos_sample_stats (starling_pos_processor_base.cpp:1473-1495): used / unused basecall counts of the position from the
+/// stream's column sizes; false: the caller cleans the pileup itself (always, outside the somatic stream)
+bool sample_stats_counts(starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex, unsigned& used, unsigned& unused);
 
 /// the tumor sample's readPositionRankSum / altAlleleReadPositionInfo of `pos` (updateSomaticScoringMetrics,
 /// starling_pos_processor_base.cpp:984-1000), rebuilt from the pileup stream's window before the position's record is written

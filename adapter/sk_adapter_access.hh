@@ -116,6 +116,7 @@ struct SomaticChunk
     pos_t begin = 0, end = 0;
     std::vector<sk_somatic_snv_genotype> genotypes; ///< empty when the stream does not genotype
     std::vector<uint32_t> count[4];                 ///< cleaned column sizes: normal t1, tumor t1, normal t2, tumor t2
+    std::vector<uint32_t> rawCount[4];              ///< raw column sizes: normal tier1, tumor tier1, normal tier2, tumor tier2
     std::vector<uint8_t> forced;
     // what updateSomaticScoringMetrics would have accumulated for the tumor sample, kept until a record is written
     std::vector<int64_t> tumorTier1Off;             ///< [n+1]

@@ -397,6 +397,17 @@ void pileup_somatic_window(starling_pos_processor_base& pp, const pos_t begin, c
             chunk.count[1].assign(w.tumor.clean_count, w.tumor.clean_count + n);
             chunk.count[2].assign(w.normal_clean_tier2_count, w.normal_clean_tier2_count + n);
             chunk.count[3].assign(w.tumor_clean_tier2_count, w.tumor_clean_tier2_count + n);
+            const sk_pileup_window* ws[2] = {&w.normal, &w.tumor};
+            for (unsigned si(0); si < 2; ++si)
+            {
+                chunk.rawCount[si].resize(n);
+                chunk.rawCount[2 + si].resize(n);
+                for (size_t i(0); i < n; ++i)
+                {
+                    chunk.rawCount[si][i] = static_cast<uint32_t>(ws[si]->tier1_off[i + 1] - ws[si]->tier1_off[i]);
+                    chunk.rawCount[2 + si][i] = static_cast<uint32_t>(ws[si]->tier2_off[i + 1] - ws[si]->tier2_off[i]);
+                }
+            }
             chunk.forced.resize(n);
             for (size_t i(0); i < n; ++i)
             {

@@ -14,6 +14,7 @@
 #include "blt_util/seq_util.hh"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -23,6 +24,13 @@ namespace sk_adapter
 
 namespace
 {
+
+unsigned env_unsigned(const char* name, const unsigned def)
+{
+    const char* v(std::getenv(name));
+    if (v == nullptr || *v == 0) return def;
+    return static_cast<unsigned>(std::strtoul(v, nullptr, 10));
+}
 
 const strelka_options& strelkaOptions(const starling_pos_processor_base& pp)
 {
@@ -199,39 +207,109 @@ void somatic_window(starling_pos_processor_base& pp, const pos_t pos)
     s.siteLoci += slot.size();
 }
 
-void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, const CleanedPileup& normal1, const CleanedPileup& tumor1,
-                          const CleanedPileup* normal2, const CleanedPileup* tumor2, const bool isComputeNonSomatic,
-                          somatic_snv_genotype_grid& sgt)
+namespace
 {
+
+/// the chunk of the pileup stream that covers pos (POST_ALIGN only moves forward: chunks behind it are dropped)
+SomaticChunk* somaticChunkFor(const pos_t pos)
+{
+    std::deque<SomaticChunk>& chunks(state().pileup.somaticChunks);
+    while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front();
+    if ((! chunks.empty()) && chunks.front().begin <= pos) return &chunks.front();
+    return nullptr;
+}
+
+}
+
+bool somatic_defer_clean(starling_pos_processor_base& /*pp*/, const pos_t /*pos*/)
+{
+    static const bool isLazy(env_unsigned("STRELKA_AMD_LAZY_CLEAN", 1) != 0);
+    const PileupState& ps(state().pileup);
+    return isLazy && ps.enabled && ps.isSomatic && ps.isGenotyping;
+}
+
+void somatic_clean_now(starling_pos_processor_base& pp, const pos_t pos, CleanedPileup* const* normalCpi, CleanedPileup* const* tumorCpi)
+{
+    using namespace STRELKA_SAMPLE_TYPE;
+    const starling_base_options& opt(Access::opt(pp));
+    const PileupCleaner& cleaner(Access::pileupCleaner(pp));
+    for (unsigned t(0); t < 2; ++t) // strelka_pos_processor.cpp:180-186
+    {
+        const bool isIncludeTier2(t != 0);
+        if (isIncludeTier2 && (! opt.useTier2Evidence)) continue;
+        cleaner.CleanPileup(pp.sample(NORMAL).basecallBuffer.get_pos(pos), isIncludeTier2, *(normalCpi[t]));
+        cleaner.CleanPileup(pp.sample(TUMOR).basecallBuffer.get_pos(pos), isIncludeTier2, *(tumorCpi[t]));
+    }
+}
+
+bool sample_stats_counts(starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex, unsigned& used, unsigned& unused)
+{
+    if (! somatic_defer_clean(pp, pos)) return false;
+    const snp_pos_info& pi(pp.sample(sampleIndex).basecallBuffer.get_pos(pos));
+    if (pi.calls.empty())
+    {
+        used = unused = 0;
+        return true;
+    }
+    const SomaticChunk* c(somaticChunkFor(pos));
+    if (c == nullptr) return false;
+    const size_t k(static_cast<size_t>(pos - c->begin));
+    if (sampleIndex > 1 || c->rawCount[sampleIndex][k] != pi.calls.size()) return false;
+    // CleanedPileup::usedBasecallCount / unusedBasecallCount of CleanPileupFilter(pi, false) (PileupCleaner.hh:48-58)
+    used = c->count[sampleIndex][k];
+    unused = static_cast<unsigned>(pi.calls.size()) - used;
+    return true;
+}
+
+void somatic_snv_genotype(starling_pos_processor_base& pp, const pos_t pos, CleanedPileup* const* normalCpi, CleanedPileup* const* tumorCpi,
+                          bool& isCleanDeferred, const bool isComputeNonSomatic, somatic_snv_genotype_grid& sgt)
+{
+    using namespace STRELKA_SAMPLE_TYPE;
     State& s(state());
     SomaticSiteCache& cache(s.somaticSites);
     const strelka_options& opt(strelkaOptions(pp));
-    const bool isTier2(normal2 != nullptr);
-    const snp_pos_info* cleaned[4] = {&normal1.cleanedPileup(), &tumor1.cleanedPileup(),
-                                      isTier2 ? &normal2->cleanedPileup() : nullptr, isTier2 ? &tumor2->cleanedPileup() : nullptr};
+    const bool isTier2(opt.useTier2Evidence);
     const uint8_t isForced(sgt.is_forced_output ? 1 : 0);
     if (s.pileup.isGenotyping)
     {
-        std::deque<SomaticChunk>& chunks(s.pileup.somaticChunks);
-        while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front(); // POST_ALIGN only moves forward
-        if ((! chunks.empty()) && chunks.front().begin <= pos)
+        const SomaticChunk* c(somaticChunkFor(pos));
+        if (c != nullptr)
         {
-            const SomaticChunk& c(chunks.front());
-            const size_t k(static_cast<size_t>(pos - c.begin));
-            bool ok(c.forced[k] == isForced);
-            for (unsigned i(0); ok && i < 4; ++i)
+            const size_t k(static_cast<size_t>(pos - c->begin));
+            bool ok(c->forced[k] == isForced);
+            if (isCleanDeferred)
             {
-                if (cleaned[i] == nullptr) continue;
-                ok = (c.count[i][k] == cleaned[i]->calls.size());
+                // the record was computed from the columns the stream wrote into the reference's buffers: still those?
+                const snp_pos_info& npi(pp.sample(NORMAL).basecallBuffer.get_pos(pos));
+                const snp_pos_info& tpi(pp.sample(TUMOR).basecallBuffer.get_pos(pos));
+                ok = ok && c->rawCount[0][k] == npi.calls.size() && c->rawCount[1][k] == tpi.calls.size() &&
+                     c->rawCount[2][k] == npi.tier2_calls.size() && c->rawCount[3][k] == tpi.tier2_calls.size();
+            }
+            else
+            {
+                const CleanedPileup* cpis[4] = {normalCpi[0], tumorCpi[0], isTier2 ? normalCpi[1] : nullptr, isTier2 ? tumorCpi[1] : nullptr};
+                for (unsigned i(0); ok && i < 4; ++i)
+                {
+                    if (cpis[i] == nullptr) continue;
+                    ok = (c->count[i][k] == cpis[i]->cleanedPileup().calls.size());
+                }
             }
             if (ok)
             {
-                toGenotypeGrid(c.genotypes[k], sgt);
+                toGenotypeGrid(c->genotypes[k], sgt);
                 return;
             }
         }
     }
-    else if (pos >= cache.begin && pos < cache.end)
+    if (isCleanDeferred)
+    {
+        somatic_clean_now(pp, pos, normalCpi, tumorCpi);
+        isCleanDeferred = false;
+    }
+    const CleanedPileup* const cpis[4] = {normalCpi[0], tumorCpi[0], normalCpi[1], tumorCpi[1]};
+    const snp_pos_info* cleaned[4] = {&cpis[0]->cleanedPileup(), &cpis[1]->cleanedPileup(),
+                                      isTier2 ? &cpis[2]->cleanedPileup() : nullptr, isTier2 ? &cpis[3]->cleanedPileup() : nullptr};
+    if ((! s.pileup.isGenotyping) && pos >= cache.begin && pos < cache.end)
     {
         const size_t k(static_cast<size_t>(pos - cache.begin));
         bool ok(cache.isValid[k] && cache.forced[k] == isForced);

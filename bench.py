@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--a5-reps", type=int, default=3)
     ap.add_argument("--e2e-bp", type=int, default=16000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
     ap.add_argument("--e2e-segment-bp", type=int, default=2000000, help="segment size of the end-to-end leg (one caller process per segment)")
+    ap.add_argument("--e2e-somatic-bp", type=int, default=3200000,
+                    help="length of the WGS-like 110x / 40x tumour-normal pair of the somatic end-to-end leg per GPU (0: skip the leg)")
+    ap.add_argument("--e2e-somatic-segment-bp", type=int, default=400000, help="segment size of the somatic end-to-end leg")
     ap.add_argument("--e2e-max-procs-per-gpu", type=int, default=8,
                     help="caller processes that share one GPU in the end-to-end leg (beyond ~8 the device's scheduler time-slices them: "
                          "profiles/r03_v10_processes_per_gpu.txt, r03_v11_gpu_sharing_sdma.txt); the reference gets the same number of cores")
@@ -168,42 +171,56 @@ def whole_read_leg(args, capi, synth, rng, enumeration=2, max_indels=6, reads=No
 E2E_OUTPUTS = ("variants.vcf", "genome.S1.vcf")
 
 
-def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference):
-    """BASELINE.json's second metric, "40x WGS germline wall-clock": a WGS-like 40x sample (tools/make_wgs_bam.py, made before the
-    clock starts) cut into segments as the reference's workflow cuts a genome, one caller process per segment with the command line
-    the workflow builds (strelka_amd/farm.py), as many processes at a time as this rank has host cores: the drop-in
-    (`starling2_amd`: the reference's own program with its hot-path call sites routed through libstrelka_amd.so) on this rank's
-    GPU, and -- rank 0 of a 1-GPU run -- the unmodified reference (`starling2_ref`, kind "reference") on the same cores, outputs
+E2E_SOMATIC_OUTPUTS = ("somatic.snvs.vcf", "somatic.indels.vcf", "somatic.callable.regions.bed")
+
+
+def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference, mode="germline"):
+    """BASELINE.json's second metric, "40x WGS germline wall-clock" (mode "germline", configs[1]) and its somatic counterpart (mode
+    "somatic", configs[2]: tumour 110x / normal 40x): a WGS-like sample (tools/make_wgs_bam.py, made before the clock starts) cut
+    into segments as the reference's workflow cuts a genome, one caller process per segment with the command line the workflow builds
+    (strelka_amd/farm.py), as many processes at a time as this rank has host cores (at most --e2e-max-procs-per-gpu): the drop-in
+    (`starling2_amd` / `strelka2_amd`: the reference's own program with its hot-path call sites routed through libstrelka_amd.so) on
+    this rank's GPU, and -- rank 0 of a 1-GPU run -- the unmodified reference (`*_ref`, kind "reference") on the same cores, outputs
     compared byte for byte.  Weak scaling: every rank calls the whole sample on its own GPU with cores/N processes."""
     import re
     import shutil
     import tempfile
     from strelka_amd import farm
-    L = args.e2e_bp
-    drop_in = os.environ.get("SK_E2E_BINARY", "starling2_amd")  # (tests/test_bench_e2e.py runs the leg's plumbing on the CPU double)
+    somatic = (mode == "somatic")
+    L = args.e2e_somatic_bp if somatic else args.e2e_bp
+    seg_bp = args.e2e_somatic_segment_bp if somatic else args.e2e_segment_bp
+    outputs = E2E_SOMATIC_OUTPUTS if somatic else E2E_OUTPUTS
+    program = "strelka2" if somatic else "starling2"
+    # (tests/test_bench_e2e.py runs the leg's plumbing on the CPU double)
+    drop_in = program + "_" + os.environ.get("SK_E2E_VARIANT", "amd")
     if not (os.path.exists(os.path.join(farm.BIN_DIR, drop_in)) and os.path.exists(os.path.join(farm.BIN_DIR, "samtools"))):
-        return {"skipped": "oracle/_ref/bin/starling2_amd (adapter/Makefile, needs the reference tree at build time) did not travel"}
+        return {"skipped": "oracle/_ref/bin/%s (adapter/Makefile, needs the reference tree at build time) did not travel" % drop_in}
+    dataset = farm.wgs_somatic_dataset if somatic else farm.wgs_dataset
     if rank == 0:
-        farm.wgs_dataset(L)
+        dataset(L)
     barrier()
-    d = farm.wgs_dataset(L)
+    d = dataset(L)
     cores = farm.usable_cores()
     jobs = max(1, min(len(cores) // world, args.e2e_max_procs_per_gpu))
-    groups = [[s] for s in farm.chrom_intervals(["chrW"], {"chrW": L}, args.e2e_segment_bp)]
+    groups = [[s] for s in farm.chrom_intervals(["chrW"], {"chrW": L}, seg_bp)]
     root = tempfile.mkdtemp(prefix="sk_e2e_r%d_" % rank)
 
     def argv_fn(binary):
         def fn(index, regions, prefix, skip_header):
+            if somatic:
+                return farm.somatic_segment_argv(binary, prefix, os.path.join(d, "normal.bam"), os.path.join(d, "tumor.bam"), regions,
+                                                 os.path.join(d, "normal.fa"), chrom_depth=os.path.join(d, "chrom_depth.txt"),
+                                                 callable_regions=True, skip_header=skip_header)
             return farm.germline_segment_argv(binary, prefix, [os.path.join(d, "wgs.bam")], regions, os.path.join(d, "wgs.fa"),
                                               chrom_depth=os.path.join(d, "chrom_depth.txt"), skip_header=skip_header)
         return fn
     try:
         warm = [[(0, "chrW", 1, min(L, 50000), 0)]]
-        farm.run_farm(warm, argv_fn(drop_in), os.path.join(root, "warm"), E2E_OUTPUTS, n_gpus=1, jobs=1,
+        farm.run_farm(warm, argv_fn(drop_in), os.path.join(root, "warm"), outputs, n_gpus=1, jobs=1,
                       device_offset=local_rank)  # page the binary and the GPU runtime in
         barrier()
         t0 = time.perf_counter()
-        amd = farm.run_farm(groups, argv_fn(drop_in), os.path.join(root, "amd"), E2E_OUTPUTS, n_gpus=1, jobs=jobs,
+        amd = farm.run_farm(groups, argv_fn(drop_in), os.path.join(root, "amd"), outputs, n_gpus=1, jobs=jobs,
                             device_offset=local_rank, env={"STRELKA_AMD_VERBOSE": "1"})
         barrier()
         amd_wall = max_over_ranks(time.perf_counter() - t0)
@@ -214,32 +231,36 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                 for kv in m.group(1).split():
                     k, v = kv.split("=")
                     hooks[k] = hooks.get(k, 0.0) + float(v)
-        out = {"workload": "WGS-like synthetic germline sample, %d bp at 40x, 150 bp reads (tools/make_wgs_bam.py), %d segments of %d bp, one "
-                           "caller process per segment with the workflow's WGS command line (--chrom-depth-file, --gvcf-skip-header ...)"
-                           % (L, len(groups), args.e2e_segment_bp),
-               "bp": L * world, "reads": int(L * 40.0 / 150) * world, "segments": len(groups) * world,
+        depth = 150.0 if somatic else 40.0
+        what = ("tumour / normal pair, %d bp at 110x / 40x" if somatic else "germline sample, %d bp at 40x") % L
+        flags = ("somatic workflow's command line (EVS scoring models, --somatic-callable-regions-file, --strelka-chrom-depth-file ...)"
+                 if somatic else "workflow's WGS command line (--chrom-depth-file, --gvcf-skip-header ...)")
+        out = {"workload": "WGS-like synthetic %s, 150 bp reads (tools/make_wgs_bam.py), %d segments of %d bp, one caller process per segment "
+                           "with the %s" % (what, len(groups), seg_bp, flags),
+               "bp": L * world, "reads": int(L * depth / 150) * world, "segments": len(groups) * world,
                "amd_wall_s": amd_wall, "amd_procs": jobs * world, "amd_procs_per_gpu": jobs, "host_cores": len(cores),
                "cores_used": jobs * world,
                "procs_note": "one caller process per core, at most --e2e-max-procs-per-gpu (8) per GPU: one MI355X serves up to ~8 "
-                             "caller processes at full speed-up (1.6-1.8x the reference per process); with 12-16 sharing it the "
-                             "device's scheduler time-slices them and the gain is gone (profiles/r03_v10, r03_v11).  The reference "
-                             "leg runs on the same number of cores.",
+                             "caller processes at full speed-up; with 12-16 sharing it the device's scheduler time-slices them and the "
+                             "gain is gone (profiles/r03_v10, r03_v11).  The reference leg runs on the same number of cores.",
                "bp_per_s": L * world / amd_wall, "process_seconds_sum": sum(amd.process_s),
                "hook_seconds": {k: round(v, 4) for k, v in hooks.items()},
                "hook_seconds_note": "summed over this rank's segment processes: wall seconds inside the adapter's hooks (*_hook) of which inside "
                                     "the C-ABI (*_abi); the rest of process_seconds_sum is the reference's own host code (BAM records, read "
-                                    "buffer, active regions, locus objects, gVCF text)"}
+                                    "buffer, active regions, locus objects, VCF text)"}
         if with_reference:
             t0 = time.perf_counter()
-            ref = farm.run_farm(groups, argv_fn("starling2_ref"), os.path.join(root, "ref"), E2E_OUTPUTS, jobs=jobs)
+            ref = farm.run_farm(groups, argv_fn(program + "_ref"), os.path.join(root, "ref"), outputs, jobs=jobs)
             ref_wall = time.perf_counter() - t0
 
             def body(path):
                 with open(path, "rb") as f:
                     return [l for l in f.read().split(b"\n") if not (l.startswith(b"##cmdline=") or l.startswith(b"##startTime=") or l.startswith(b"##fileDate="))]
-            identical = all(body(amd.outputs[n]) == body(ref.outputs[n]) for n in E2E_OUTPUTS)
+            identical = all(body(amd.outputs[n]) == body(ref.outputs[n]) for n in outputs)
             out.update({"ref_wall_s": ref_wall, "ref_cores": jobs, "ref_process_seconds_sum": sum(ref.process_s), "speedup": ref_wall / amd_wall,
-                        "identical": identical, "variant_records": sum(1 for l in body(ref.outputs["variants.vcf"]) if l and not l.startswith(b"#"))})
+                        "identical": identical,
+                        "variant_records": sum(1 for n in outputs if n.endswith(".vcf") and not n.startswith("genome")
+                                               for l in body(ref.outputs[n]) if l and not l.startswith(b"#"))})
         return out
     finally:
         shutil.rmtree(root, ignore_errors=True)
@@ -483,19 +504,23 @@ def main():
         wr["realign%s_candidate_alignments_per_read" % name] = wr_cals / max(1, wr_reads)
 
     # ---- end to end: the drop-in as the workflow runs it, one caller process per genome segment ----
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
     e2e = None
     if args.e2e_bp > 0:
-        def barrier():
-            if world > 1:
-                dist.barrier()
-
-        def max_over_ranks(v):
-            if world == 1:
-                return v
-            t = torch.tensor([v], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
         e2e = e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference=(world == 1 and not args.no_cpu_baseline))
+    e2e_somatic = None
+    if args.e2e_somatic_bp > 0:
+        e2e_somatic = e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference=(world == 1 and not args.no_cpu_baseline),
+                              mode="somatic")
 
     traffic = pmc_traffic(args)
     som_kernels = ("somatic_classify_kernel", "somatic_lhood_kernel", "somatic_posterior_kernel")
@@ -578,6 +603,7 @@ def main():
     }
     out.update(wr)
     out["e2e"] = e2e
+    out["e2e_somatic"] = e2e_somatic
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

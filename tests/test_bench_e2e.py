@@ -12,9 +12,21 @@ from tests import e2e_util as E
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
 def test_e2e_leg_runs_and_compares(monkeypatch):
     import bench
-    monkeypatch.setenv("SK_E2E_BINARY", "starling2_dbl")
+    monkeypatch.setenv("SK_E2E_VARIANT", "dbl")
     args = argparse.Namespace(e2e_bp=400000, e2e_segment_bp=100000, e2e_max_procs_per_gpu=8)
     out = bench.e2e_leg(args, 0, 1, 0, lambda: None, lambda v: v, with_reference=True)
     assert out["identical"] is True and out["segments"] == 4 and out["bp"] == 400000
     assert out["variant_records"] > 300 and out["ref_wall_s"] > 0 and out["amd_wall_s"] > 0
     assert out["hook_seconds"]["pileup_abi"] > 0 and out["hook_seconds"]["pileup_hook"] >= out["hook_seconds"]["pileup_abi"]
+
+
+@pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
+def test_e2e_somatic_leg_runs_and_compares(monkeypatch):
+    """the somatic leg (configs[2]): a 110x / 40x tumour-normal pair with the somatic workflow's flags, EVS models on"""
+    import bench
+    monkeypatch.setenv("SK_E2E_VARIANT", "dbl")
+    args = argparse.Namespace(e2e_somatic_bp=200000, e2e_somatic_segment_bp=50000, e2e_max_procs_per_gpu=8)
+    out = bench.e2e_leg(args, 0, 1, 0, lambda: None, lambda v: v, with_reference=True, mode="somatic")
+    assert out["identical"] is True and out["segments"] == 4 and out["bp"] == 200000
+    assert out["variant_records"] >= 10 and out["ref_wall_s"] > 0 and out["amd_wall_s"] > 0
+    assert out["hook_seconds"]["pileup_abi"] > 0 and out["hook_seconds"]["site_abi"] == 0  # site 5 served by the stream's records

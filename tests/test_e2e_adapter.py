@@ -173,10 +173,11 @@ def test_somatic_demo_identical_through_adapter_cpu_double(tmp_path, windows, ca
 
 
 @pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
-@pytest.mark.parametrize("env", [{"STRELKA_AMD_PILEUP": "0"}, {"STRELKA_AMD_PILEUP_GENOTYPE": "0"}])
+@pytest.mark.parametrize("env", [{"STRELKA_AMD_PILEUP": "0"}, {"STRELKA_AMD_PILEUP_GENOTYPE": "0"}, {"STRELKA_AMD_LAZY_CLEAN": "0"}])
 def test_somatic_demo_identical_with_reference_pileup_or_columns_only(tmp_path, env):
     """STRELKA_AMD_PILEUP=0: the reference's pileup_read_segment, site 5 per site window from the host's copy of the columns;
-    STRELKA_AMD_PILEUP_GENOTYPE=0: the stream builds the columns (and the EVS read positions), site 5 as before"""
+    STRELKA_AMD_PILEUP_GENOTYPE=0: the stream builds the columns (and the EVS read positions), site 5 as before;
+    STRELKA_AMD_LAZY_CLEAN=0: process_pos_snp_somatic builds its four cleaned pileups for every position, as the reference does"""
     _somatic("dbl", tmp_path, callable_regions=True, extra_env=env)
 
 
