@@ -138,6 +138,13 @@ HOOKS = [
          r'        normalizeAlignment\(refBamSeq, readBamSeq, readAlignment\);\n',
          '        if (! sk_adapter::feed_normalize_current(&read_stream, ref, readAlignment)) normalizeAlignment(refBamSeq, readBamSeq, readAlignment);\n'),
     ]),
+    (L + "starling_common/starling_pos_processor_indel_util.cpp", [
+        ("include", r'#include "starling_pos_processor_indel_util.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # the active-region detector's per-base bookkeeping of an aligned segment, in one call
+        ("active-region match/mismatch loop",
+         r'(            // detect active regions \(match/mismatch\)\n)            for \(unsigned j\(0\); j < ps\.length; \+\+j\)\n            \{\n(?:.*\n)*?            \}\n(        \}\n\n        for \(unsigned i\(0\); i<n_seg; \+\+i\))',
+         '\\1            sk_adapter::active_region_insert_aligned_segment(activeRegionReadBuffer, id, ref, read_seq, read_offset, ref_head_pos, ps.length);\n\\2'),
+    ]),
     (L + "htsapi/bam_streamer.cpp", [
         ("include", r'#include "htsapi/bam_streamer.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
         # site 8: the region's reads through the feed

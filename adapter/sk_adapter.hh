@@ -39,6 +39,8 @@ struct IndelData;
 struct reference_contig_segment;
 struct IndelKey;
 struct alignment;
+class ActiveRegionReadBuffer;
+struct bam_seq_base;
 
 namespace sk_adapter
 {
@@ -106,6 +108,10 @@ void somatic_indel(const strelka_options& opt, const starling_sample_options& no
 /// ActiveRegionDetector::clearReadBuffer at the position the UNDEFERRED READ_BUFFER stage would be at while HEAD is at `headStagePos`
 void clear_active_region_read_buffer_undeferred(starling_pos_processor_base& pp, const pos_t headStagePos, const unsigned readBufferShift,
                                                 const pos_t minPos);
+
+/// the match / mismatch bookkeeping of one aligned segment of an input read (starling_pos_processor_indel_util.cpp:463-483), in one call
+void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const unsigned alignId, const reference_contig_segment& ref,
+                                          const bam_seq_base& readSeq, const unsigned readOffset, const pos_t refHeadPos, const unsigned length);
 
 // ---- site 7: ActiveRegionProcessor::discoverIndelsAndMismatches (ActiveRegionProcessor.cpp:572-705) ----
 bool discover_indels_and_mismatches(const std::string& haplotypeSeq, const std::string& refSegment,

@@ -1,0 +1,99 @@
+// sk_adapter_active_region_buffer.cpp -- the active-region detector's per-basecall bookkeeping for one aligned segment of a read
+// (addAlignmentIndelsToPosProcessor, L/starling_common/starling_pos_processor_indel_util.cpp:463-483) in one call.
+//
+// The reference walks every match segment of every input read base by base and calls ActiveRegionReadBuffer::insertMatch or
+// insertMismatch (ActiveRegionReadBuffer.cpp:26-50) -- an out-of-line call that takes three ring-buffer slots by `%` and two vector
+// rows by double indirection for each base.  This is host work the device path does not touch (the detector's ring buffers feed
+// the reference's own haplotype assembly), but once the pileup and the likelihoods are off the host it is the largest single item
+// of what remains (profiles/r03_v15_host_remainder.txt), so the segment is entered here with the same stores in the same order,
+// the row pointers and the ring index taken once.  A maintainer would add this as a member function
+// (ActiveRegionReadBuffer::insertAlignedSegment); the adapter cannot edit the class (its header is included by unhooked headers of
+// the reference through relative paths), so this one translation unit sees the class with its private section opened.
+#include <algorithm>
+#include <cassert>
+#include <iosfwd>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "blt_util/known_pos_range2.hh"
+#include "blt_util/reference_contig_segment.hh"
+#include "htsapi/bam_seq.hh"
+#include "starling_common/IndelBuffer.hh"
+#include "starling_common/ReferenceRepeatFinder.hh"
+#include "starling_common/indel.hh"
+#include "starling_common/starling_types.hh"
+
+#define private public
+#include "starling_common/ActiveRegionReadBuffer.hh"
+#undef private
+
+#include "sk_adapter.hh"
+
+namespace sk_adapter
+{
+
+void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const unsigned alignId, const reference_contig_segment& ref,
+                                          const bam_seq_base& readSeq, const unsigned readOffset, const pos_t refHeadPos, const unsigned length)
+{
+    const bam_seq* packed(dynamic_cast<const bam_seq*>(&readSeq));
+    if (refHeadPos < 0 || packed == nullptr)
+    {
+        // (a segment that starts before position 0 wraps the ring index through the unsigned conversion: the reference's own loop)
+        for (unsigned j(0); j < length; ++j)
+        {
+            const pos_t refPos(refHeadPos + static_cast<pos_t>(j));
+            const char baseChar(readSeq.get_char(static_cast<pos_t>(readOffset + j)));
+            if (ref.get_base(refPos) != baseChar) buffer.insertMismatch(alignId, refPos, baseChar);
+            else buffer.insertMatch(alignId, refPos);
+        }
+        return;
+    }
+    static const unsigned ringSize(ActiveRegionReadBuffer::MaxBufferSize);
+    const unsigned idIndex(alignId % ActiveRegionReadBuffer::MaxDepth);
+    ActiveRegionReadBuffer::VariantType* const variantRow(buffer._variantInfo[idIndex].data());
+    char* const snvRow(buffer._snvBuffer[idIndex]);
+    unsigned* const variantCounter(buffer._variantCounter.data());
+    unsigned* const depth(buffer._depth.data());
+    std::vector<align_id_t>* const alignIds(buffer._positionToAlignIds.data());
+    // the segment in runs that do not wrap the ring: per run the bases are unpacked and compared first, then each of the buffer's
+    // arrays gets its stores in one pass over consecutive slots (the per-position result is the same whatever the order between arrays)
+    static const unsigned maxRun(512);
+    char baseChar[maxRun];
+    unsigned char isMismatch[maxRun];
+    unsigned done(0);
+    while (done < length)
+    {
+        const unsigned index0(static_cast<unsigned>(refHeadPos + static_cast<pos_t>(done)) % ringSize);
+        const unsigned run(std::min(std::min(length - done, ringSize - index0), maxRun));
+        const pos_t refPos0(refHeadPos + static_cast<pos_t>(done));
+        for (unsigned j(0); j < run; ++j)
+        {
+            baseChar[j] = packed->bam_seq::get_char(static_cast<pos_t>(readOffset + done + j));
+            isMismatch[j] = (ref.get_base(refPos0 + static_cast<pos_t>(j)) != baseChar[j]) ? 1 : 0;
+        }
+        // insertMismatch / insertMatch: addVariantCount ...
+        for (unsigned j(0); j < run; ++j)
+        {
+            variantCounter[index0 + j] += isMismatch[j] * static_cast<unsigned>(ActiveRegionReadBuffer::MismatchWeight);
+            ++depth[index0 + j];
+        }
+        // ... setMismatch / setMatch ...
+        for (unsigned j(0); j < run; ++j)
+        {
+            variantRow[index0 + j] = isMismatch[j] ? ActiveRegionReadBuffer::MISMATCH : ActiveRegionReadBuffer::MATCH;
+            if (isMismatch[j]) snvRow[index0 + j] = baseChar[j];
+        }
+        // ... addAlignIdToPos
+        for (unsigned j(0); j < run; ++j)
+        {
+            std::vector<align_id_t>& ids(alignIds[index0 + j]);
+            if (ids.empty() || ids.back() != alignId) ids.push_back(alignId);
+        }
+        done += run;
+    }
+}
+
+}

@@ -129,7 +129,7 @@ void gatherWindow(starling_pos_processor_base& pp, const unsigned sampleIndex, c
         const bam_seq bseq(rseg.get_bam_read());
         const size_t c0(wb.code.size());
         wb.code.resize(c0 + readSize);
-        for (unsigned i(0); i < readSize; ++i) wb.code[c0 + i] = bseq.get_code(static_cast<pos_t>(i));
+        for (unsigned i(0); i < readSize; ++i) wb.code[c0 + i] = bseq.bam_seq::get_code(static_cast<pos_t>(i)); // (qualified: no virtual dispatch)
         const uint8_t* q(rseg.qual());
         wb.qual.insert(wb.qual.end(), q, q + readSize);
         for (const auto& seg : best->path)
