@@ -7,9 +7,11 @@
 // anchored on zlib / samtools output for the reference's own demo BAMs and synthetic ones (tests/test_bam_feed.py).
 //
 //   B1  bgzf_inflate_kernel   one THREAD per BGZF block (blocks are independent DEFLATE streams of at most 64 KiB of output, a BAM
-//                             of a few GB is 10^5 blocks): canonical-Huffman decoding with per-thread code tables, LZ77 copies
-//                             inside the thread's own output range.  A serial bit stream per block is what the format is; the
-//                             parallelism is across blocks.
+//                             of a few GB is 10^5 blocks): canonical-Huffman decoding (per-length counts in registers, symbols in a
+//                             private array), LZ77 copies inside the thread's own output range in unaligned 8/4/2/1-byte pieces.
+//                             A serial bit stream per block is what the format is; the parallelism is across blocks.
+//   B1w bgzf_inflate_wave_kernel  one WAVE per block, output assembled in LDS: a third of the latency per block, for the few
+//                             hundred blocks a caller process inflates at a time
 //   B2  bgzf_crc32_kernel     one thread per block: CRC-32 (IEEE 802.3, table in LDS) of the inflated bytes against the trailer
 //   B4  normalize_kernel      one thread per read: normalizeAlignment (L/starling_common/normalizeAlignment.cpp:647-703; the
 //                             reference applies it to every read as it comes off the BAM stream), csrc/normalize_core.h, in place
@@ -44,6 +46,77 @@ namespace
 enum { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3, INF_BAD_DISTANCE = 4, INF_OUT_OVERFLOW = 5,
        INF_IN_OVERRUN = 6, INF_BAD_LENGTHS = 7, INF_SIZE_MISMATCH = 8, INF_BAD_HEADER = 9, INF_CRC_MISMATCH = 10 };
 
+// byte-addressed data at any alignment in one memory instruction (the global address space takes unaligned dword accesses; a packed
+// struct tells the compiler so).  What a lane of the thread-per-block kernel costs is the NUMBER of its memory instructions -- its
+// 64 lanes are 64 different streams, every access is 64 separate cache lines -- so bytes are moved 8 / 4 / 2 / 1 at a time.
+struct __attribute__((packed)) U64u { uint64_t v; };
+struct __attribute__((packed)) U32u { uint32_t v; };
+struct __attribute__((packed)) U16u { uint16_t v; };
+__device__ __forceinline__ uint64_t ld_u64(const uint8_t* p) { return reinterpret_cast<const U64u*>(p)->v; }
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { return reinterpret_cast<const U32u*>(p)->v; }
+__device__ __forceinline__ uint16_t ld_u16(const uint8_t* p) { return reinterpret_cast<const U16u*>(p)->v; }
+__device__ __forceinline__ void st_u64(uint8_t* p, const uint64_t v) { reinterpret_cast<U64u*>(p)->v = v; }
+__device__ __forceinline__ void st_u32(uint8_t* p, const uint32_t v) { reinterpret_cast<U32u*>(p)->v = v; }
+__device__ __forceinline__ void st_u16(uint8_t* p, const uint16_t v) { reinterpret_cast<U16u*>(p)->v = v; }
+
+// up to 16 bytes from src into two registers / out of them to dst: 8 + 4 + 2 + 1 pieces, at most four instructions each way
+__device__ __forceinline__ void ld_upto16(const uint8_t* src, const int k, uint64_t& lo, uint64_t& hi)
+{
+    lo = 0;
+    hi = 0;
+    if (k >= 16) {
+        lo = ld_u64(src);
+        hi = ld_u64(src + 8);
+        return;
+    }
+    int at = 0;
+    if (k & 8) {
+        lo = ld_u64(src);
+        at = 8;
+    }
+    uint64_t rest = 0;
+    int sh = 0;
+    if (k & 4) {
+        rest |= uint64_t(ld_u32(src + at)) << sh;
+        at += 4;
+        sh += 32;
+    }
+    if (k & 2) {
+        rest |= uint64_t(ld_u16(src + at)) << sh;
+        at += 2;
+        sh += 16;
+    }
+    if (k & 1) rest |= uint64_t(src[at]) << sh;
+    if (k & 8) hi = rest;
+    else lo = rest;
+}
+__device__ __forceinline__ void st_upto16(uint8_t* dst, const int k, const uint64_t lo, const uint64_t hi)
+{
+    if (k >= 16) {
+        st_u64(dst, lo);
+        st_u64(dst + 8, hi);
+        return;
+    }
+    int at = 0;
+    uint64_t rest = lo;
+    if (k & 8) {
+        st_u64(dst, lo);
+        at = 8;
+        rest = hi;
+    }
+    if (k & 4) {
+        st_u32(dst + at, uint32_t(rest));
+        at += 4;
+        rest >>= 32;
+    }
+    if (k & 2) {
+        st_u16(dst + at, uint16_t(rest));
+        at += 2;
+        rest >>= 16;
+    }
+    if (k & 1) dst[at] = uint8_t(rest);
+}
+
 struct BitReader
 {
     const uint8_t* p;
@@ -51,70 +124,147 @@ struct BitReader
     uint64_t buf;
     int cnt;
     bool overrun;
-    __device__ void fill(const int need)
+    // top the buffer up to at least 25 bits where the input has them (four independent byte loads and one wait when there is room
+    // for four bytes); bits past the end of the input read as 0 and are only an error when a code or a field consumes them
+    __device__ void refill()
     {
-        while (cnt < need) {
-            uint64_t b = 0;
-            if (p < end) b = *p++;
-            else overrun = true;
-            buf |= b << cnt;
+        if (cnt <= 32 && p + 4 <= end) {
+            buf |= uint64_t(ld_u32(p)) << cnt;
+            cnt += 32;
+            p += 4;
+            return;
+        }
+        while (cnt <= 24 && p < end) {
+            buf |= uint64_t(*p++) << cnt;
             cnt += 8;
         }
+    }
+    __device__ void consume(const int n)
+    {
+        if (n > cnt) overrun = true;
+        buf >>= n;
+        cnt = (n > cnt) ? 0 : cnt - n;
     }
     __device__ unsigned bits(const int n) // n <= 16
     {
         if (n == 0) return 0;
-        fill(n);
+        if (cnt < n) refill();
         const unsigned v = unsigned(buf & ((1ull << n) - 1ull));
-        buf >>= n;
-        cnt -= n;
+        consume(n);
         return v;
+    }
+    // the bytes of a stored block follow the bit buffer's byte boundary: hand the whole bytes still buffered back
+    __device__ void align_to_byte()
+    {
+        cnt -= (cnt & 7);
+        p -= cnt / 8;
+        buf = 0;
+        cnt = 0;
     }
 };
 
 // canonical Huffman code (RFC 1951 3.2.2): count[len] codes of each length, symbols ordered by (length, value).
-// (Tried: a 9-bit first-level lookup table per code, 32-bit refills of the bit buffer and LZ77 copies in 8-byte pieces.  All
-// three put more per-thread state into scratch memory and the kernel got 25 % SLOWER: a thread's time is a chain of dependent
-// accesses to its private tables, its input and its own output, and what pays is more blocks in flight, not fewer bit steps.)
+//
+// What a lane of the thread-per-block kernel costs (round 3, profiles/r03_v16_inflate_kernels.txt; 510 blocks = one block's
+// latency, 1.3e5 blocks = the bench's launch).  Its 64 lanes decode 64 unrelated streams, so EVERY memory instruction is a
+// wave-wide scatter of 64 cache lines, and the lane's time is the number of such instructions it issues:
+//   * the code tables in LDS instead of private arrays: same latency per block, a third of the blocks in flight (156 ms vs 89 ms);
+//   * 4 byte loads in flight per refill, copies as 16 byte loads then 16 byte stores, literals stored 8 at a time: 89 -> 76 ms
+//     (fewer waits, the same number of instructions);
+//   * the per-length counts in registers and the decode loop unrolled over a 16-bit peek: no change (the nine scratch loads per
+//     symbol it removed were hits in the lane's own line);
+//   * the same bytes moved with ONE unaligned 8 / 4 / 2 / 1 byte instruction per piece (refill = one dword load, a 15-byte match
+//     = 4 loads + 4 stores instead of 15 + 15, pending literals = at most 4 stores): 76 -> 63 ms, 46 -> 33 ms per block;
+//   * length / distance bases in closed form instead of four table loads per match: 63 -> 61 ms.
+// The sixteen per-length counts (and the running offsets while a table is built) are packed 16 bits each into four 64-bit
+// registers, and a code is decoded from a 16-bit peek of the bit buffer by a fully unrolled loop over the lengths.
+struct Packed16
+{
+    uint64_t w[4];
+    __device__ void clear() { w[0] = w[1] = w[2] = w[3] = 0; }
+    __device__ unsigned get(const int i) const // dynamic index
+    {
+        const uint64_t v = (i < 8) ? ((i < 4) ? w[0] : w[1]) : ((i < 12) ? w[2] : w[3]);
+        return unsigned(v >> (16 * (i & 3))) & 0xffffu;
+    }
+    template <int I>
+    __device__ unsigned at() const { return unsigned(w[I >> 2] >> (16 * (I & 3))) & 0xffffu; } // constant index
+    __device__ void add(const int i, const unsigned d)
+    {
+        const uint64_t v = uint64_t(d) << (16 * (i & 3));
+        w[0] += (i < 4) ? v : 0;
+        w[1] += (i >= 4 && i < 8) ? v : 0;
+        w[2] += (i >= 8 && i < 12) ? v : 0;
+        w[3] += (i >= 12) ? v : 0;
+    }
+};
+
 struct Huffman
 {
-    short* count;  // [16]
-    short* symbol; // [n]
+    Packed16 count; // [16] codes of each length
+    short* symbol;  // [n] symbols ordered by (length, value)
 };
 
 // returns the number of codes left unused (0 = complete, < 0 = over-subscribed), as zlib's / puff's construct
 __device__ int huff_construct(Huffman& h, const short* length, const int n)
 {
-    for (int len = 0; len <= 15; ++len) h.count[len] = 0;
-    for (int s = 0; s < n; ++s) h.count[length[s]]++;
-    if (h.count[0] == n) return 0;
+    h.count.clear();
+    for (int s = 0; s < n; ++s) h.count.add(length[s], 1u);
+    if (int(h.count.get(0)) == n) return 0;
     int left = 1;
     for (int len = 1; len <= 15; ++len) {
         left <<= 1;
-        left -= h.count[len];
+        left -= int(h.count.get(len));
         if (left < 0) return left;
     }
-    short offs[16];
-    offs[1] = 0;
-    for (int len = 1; len < 15; ++len) offs[len + 1] = short(offs[len] + h.count[len]);
-    for (int s = 0; s < n; ++s)
-        if (length[s] != 0) h.symbol[offs[length[s]]++] = short(s);
+    Packed16 offs;
+    offs.clear();
+    {
+        unsigned o = 0;
+        for (int len = 1; len < 15; ++len) {
+            o += h.count.get(len);
+            offs.add(len + 1, o);
+        }
+    }
+    for (int s = 0; s < n; ++s) {
+        const int len = length[s];
+        if (len != 0) {
+            h.symbol[offs.get(len)] = short(s);
+            offs.add(len, 1u);
+        }
+    }
     return left;
+}
+
+template <int LEN>
+__device__ __forceinline__ bool huff_step(const Huffman& h, unsigned& w, int& code, int& first, int& index, int& sym_index)
+{
+    code |= int(w & 1u);
+    w >>= 1;
+    const int count = int(h.count.at<LEN>());
+    if (code - count < first) {
+        sym_index = index + (code - first);
+        return true;
+    }
+    index += count;
+    first += count;
+    first <<= 1;
+    code <<= 1;
+    return false;
 }
 
 __device__ int huff_decode(BitReader& br, const Huffman& h)
 {
-    int code = 0, first = 0, index = 0;
-    for (int len = 1; len <= 15; ++len) {
-        code |= int(br.bits(1));
-        const int count = h.count[len];
-        if (code - count < first) return h.symbol[index + (code - first)];
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
-    }
-    return -1;
+    if (br.cnt < 15) br.refill();
+    unsigned w = unsigned(br.buf) & 0xffffu;
+    int code = 0, first = 0, index = 0, si = 0, len = 0;
+#define SK_HUFF_STEP(L) if (len == 0 && huff_step<L>(h, w, code, first, index, si)) len = L;
+    SK_HUFF_STEP(1) SK_HUFF_STEP(2) SK_HUFF_STEP(3) SK_HUFF_STEP(4) SK_HUFF_STEP(5) SK_HUFF_STEP(6) SK_HUFF_STEP(7) SK_HUFF_STEP(8)
+    SK_HUFF_STEP(9) SK_HUFF_STEP(10) SK_HUFF_STEP(11) SK_HUFF_STEP(12) SK_HUFF_STEP(13) SK_HUFF_STEP(14) SK_HUFF_STEP(15)
+#undef SK_HUFF_STEP
+    if (len == 0) return -1;
+    br.consume(len);
+    return h.symbol[si];
 }
 
 __device__ const short LEN_BASE[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
@@ -135,25 +285,62 @@ struct InflateArgs
 
 __device__ int inflate_codes(BitReader& br, uint8_t* out, int64_t& pos, const int64_t cap, const Huffman& lencode, const Huffman& distcode)
 {
+    // On this hardware a wave's loads and stores retire through ONE in-order counter: a load issued after a store cannot be waited
+    // for without waiting for the store's acknowledgement too.  A literal stored straight away therefore puts a full write round
+    // trip into the lane's dependent chain (the next table / input load waits for it).  Literals are collected in a register and
+    // written eight at a time -- before a match (which may read them), when the register is full, and at the end of the block.
+    uint64_t lit = 0;
+    int nlit = 0; // pending literals: out[pos - nlit, pos)
+    auto flush = [&]() {
+        if (nlit) st_upto16(out + (pos - nlit), nlit, lit, 0);
+        lit = 0;
+        nlit = 0;
+    };
     for (;;) {
         int sym = huff_decode(br, lencode);
-        if (sym < 0) return INF_BAD_CODE;
-        if (br.overrun) return INF_IN_OVERRUN;
+        if (sym < 0 || br.overrun) {
+            flush();
+            return (sym < 0) ? INF_BAD_CODE : INF_IN_OVERRUN;
+        }
         if (sym < 256) {
-            if (pos >= cap) return INF_OUT_OVERFLOW;
-            out[pos++] = uint8_t(sym);
+            if (pos >= cap) {
+                flush();
+                return INF_OUT_OVERFLOW;
+            }
+            lit |= uint64_t(unsigned(sym)) << (8 * nlit);
+            ++nlit;
+            ++pos;
+            if (nlit == 8) flush();
         } else if (sym == 256) {
+            flush();
             return INF_OK;
         } else {
+            flush();
             sym -= 257;
             if (sym >= 29) return INF_BAD_CODE;
-            const int len = LEN_BASE[sym] + int(br.bits(LEN_EXTRA[sym]));
+            // RFC 1951 3.2.5 in closed form (the four 30-entry tables were four more scattered loads per match): length codes 8..27
+            // and distance codes 4..29 come in groups of four / two with one more extra bit per group
+            const int le = (sym < 8 || sym == 28) ? 0 : ((sym - 4) >> 2);
+            const int lbase = (sym < 8) ? (3 + sym) : (sym == 28) ? 258 : (3 + ((4 + (sym & 3)) << le));
+            const int len = lbase + int(br.bits(le));
             const int ds = huff_decode(br, distcode);
             if (ds < 0 || ds >= 30) return INF_BAD_CODE;
-            const int64_t dist = DIST_BASE[ds] + int(br.bits(DIST_EXTRA[ds]));
+            const int de = (ds < 4) ? 0 : ((ds - 2) >> 1);
+            const int64_t dist = ((ds < 4) ? (1 + ds) : (1 + ((2 + (ds & 1)) << de))) + int(br.bits(de));
             if (dist > pos) return INF_BAD_DISTANCE; // (a BGZF block has no preset dictionary)
             if (pos + len > cap) return INF_OUT_OVERFLOW;
-            for (int i = 0; i < len; ++i, ++pos) out[pos] = out[pos - dist];
+            // The copy reads this lane's own earlier output.  In pieces of k = min(left, dist, 16) bytes the loads of a piece do not
+            // depend on its stores, and a piece moves as 8 + 4 + 2 + 1 byte accesses: at most four loads and four stores for 15
+            // bytes where the byte loop issued fifteen of each, every one a wave-wide scatter.
+            int left = len;
+            while (left > 0) {
+                const int k = min(left, int(min(dist, int64_t(16))));
+                uint64_t lo, hi;
+                ld_upto16(out + (pos - dist), k, lo, hi);
+                st_upto16(out + pos, k, lo, hi);
+                pos += k;
+                left -= k;
+            }
         }
     }
 }
@@ -187,23 +374,31 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const InflateArgs a)
     br.buf = 0;
     br.cnt = 0;
     br.overrun = false;
-    short lencnt[16], lensym[288], distcnt[16], distsym[30];
+    short lensym[288], distsym[30];
     short lengths[320];
-    Huffman lencode{ lencnt, lensym }, distcode{ distcnt, distsym };
+    Huffman lencode, distcode;
+    lencode.symbol = lensym;
+    distcode.symbol = distsym;
     int err = INF_OK, last = 0;
     do {
         last = int(br.bits(1));
         const int type = int(br.bits(2));
         if (type == 0) { // stored
-            br.buf = 0;
-            br.cnt = 0; // (discard the rest of the byte: the buffer never holds more than the current one past a read)
+            br.align_to_byte(); // (discard the rest of the current byte; whole bytes read ahead go back to the input)
             if (br.p + 4 > br.end) { err = INF_BAD_STORED; break; }
             const unsigned len = unsigned(br.p[0]) | (unsigned(br.p[1]) << 8);
             const unsigned nlen = unsigned(br.p[2]) | (unsigned(br.p[3]) << 8);
             br.p += 4;
             if (len != (~nlen & 0xffffu) || br.p + len > br.end) { err = INF_BAD_STORED; break; }
             if (pos + int64_t(len) > cap) { err = INF_OUT_OVERFLOW; break; }
-            for (unsigned i = 0; i < len; ++i) out[pos++] = *br.p++;
+            for (unsigned i = 0; i < len; i += 16) {
+                const int k = int(min(16u, len - i));
+                uint64_t lo, hi;
+                ld_upto16(br.p + i, k, lo, hi);
+                st_upto16(out + pos + i, k, lo, hi);
+            }
+            pos += len;
+            br.p += len;
         } else if (type == 1) { // fixed codes (3.2.6)
             int s = 0;
             for (; s < 144; ++s) lengths[s] = 8;
@@ -245,9 +440,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const InflateArgs a)
             if (err != INF_OK) break;
             if (lengths[256] == 0) { err = INF_BAD_LENGTHS; break; }
             int left = huff_construct(lencode, lengths, nlen);
-            if (left != 0 && (left < 0 || nlen != lencode.count[0] + lencode.count[1])) { err = INF_BAD_LENGTHS; break; } // (incomplete only as one 1-bit code)
+            if (left != 0 && (left < 0 || nlen != int(lencode.count.get(0) + lencode.count.get(1)))) { err = INF_BAD_LENGTHS; break; } // (incomplete only as one 1-bit code)
             left = huff_construct(distcode, lengths + nlen, ndist);
-            if (left != 0 && (left < 0 || ndist != distcode.count[0] + distcode.count[1])) { err = INF_BAD_LENGTHS; break; }
+            if (left != 0 && (left < 0 || ndist != int(distcode.count.get(0) + distcode.count.get(1)))) { err = INF_BAD_LENGTHS; break; }
             err = inflate_codes(br, out, pos, cap, lencode, distcode);
         } else {
             err = INF_BAD_BLOCK_TYPE;
@@ -833,7 +1028,7 @@ int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, c
     // a wave per block up to the launch size where blocks in flight beat latency per block;
     // $SK_INFLATE_KERNEL = thread | wave pins one (tests run every input through both)
     bool wave = n_blocks <= 16384;
-    if (const char* e = std::getenv("SK_INFLATE_KERNEL")) wave = (std::strcmp(e, "wave") == 0) ? true : (std::strcmp(e, "thread") == 0) ? false : wave;
+    if (const char* e = std::getenv("SK_INFLATE_KERNEL")) wave = (std::strcmp(e, "wave") == 0) ? true : (std::strncmp(e, "thread", 6) == 0) ? false : wave;
     if (wave) {
         static bool attr_set = false;
         if (!attr_set) {
