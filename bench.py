@@ -504,6 +504,12 @@ def main():
         wr["realign%s_candidate_alignments_per_read" % name] = wr_cals / max(1, wr_reads)
 
     # ---- end to end: the drop-in as the workflow runs it, one caller process per genome segment ----
+    # (this process steps aside: its cached device memory goes back and its stream is idle while the caller processes share the GPU)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -549,7 +555,7 @@ def main():
         return o
     out = {
         "metric": "candidate-alignment scoring cells/s (read bases x candidate alignments; Strelka2 has no pair-HMM, "
-                  "SURVEY.md section 0) + germline loci/s + 40x WGS-like germline wall-clock (e2e)",
+                  "SURVEY.md section 0) + germline loci/s + 40x WGS-like germline wall-clock (e2e) + 110x/40x somatic wall-clock (e2e_somatic)",
         "value": a5_cells / dt_a5, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_a5 / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",

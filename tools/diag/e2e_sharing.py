@@ -54,7 +54,10 @@ def main():
         w, ps, _, us, ss = run("starling2_ref", jobs, {})
         print("reference            jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f)" % (jobs, w, ps, us, ss), flush=True)
     malloc_env = {"MALLOC_TRIM_THRESHOLD_": "2147483647", "MALLOC_TOP_PAD_": "268435456", "MALLOC_MMAP_THRESHOLD_": "1073741824"}
-    configs = [("default", {})] + ([("no SDMA", {"HSA_ENABLE_SDMA": "0"}), ("no SDMA, 2 HW queues", {"HSA_ENABLE_SDMA": "0", "GPU_MAX_HW_QUEUES": "2"})] if os.environ.get("SK_SHARING_SDMA") else [])
+    extra = []
+    if os.environ.get("SK_SHARING_SPIN"):
+        extra = [("spin wait", {"STRELKA_AMD_SPIN_WAIT": "1"}), ("spin wait, no SDMA", {"STRELKA_AMD_SPIN_WAIT": "1", "HSA_ENABLE_SDMA": "0"})]
+    configs = [("default", {})] + extra + ([("no SDMA", {"HSA_ENABLE_SDMA": "0"}), ("no SDMA, 2 HW queues", {"HSA_ENABLE_SDMA": "0", "GPU_MAX_HW_QUEUES": "2"})] if os.environ.get("SK_SHARING_SDMA") else [])
     job_list = [int(x) for x in os.environ.get("SK_SHARING_JOBS", "%d,%d,%d" % (cores, cores * 3 // 2, cores * 2)).split(",")]
     for jobs in job_list:
         for label, env in configs:
