@@ -103,3 +103,48 @@ def test_farm_with_wgs_flags_identical_through_adapter_gpu(tmp_path, tmp_path_fa
         got = _run("starling2_amd", tmp_path / ("amd%d_%d" % (jobs, n_gpus)), data, jobs=jobs, n_gpus=n_gpus, env=env)
         for n in OUTPUTS:
             assert _body(got.outputs[n]) == want[n], (jobs, n_gpus, n)
+
+
+# ---- the somatic caller through the farm: several --region per process (the stream's region reset), EVS models, callable regions ----
+
+SOMATIC_LENGTH = 200000
+SOMATIC_OUTPUTS = ("somatic.snvs.vcf", "somatic.indels.vcf", "somatic.callable.regions.bed")
+
+
+def _somatic_groups():
+    segs = list(farm.chrom_intervals(["chrW"], {"chrW": SOMATIC_LENGTH}, 30000))
+    groups = list(farm.segment_groups(segs, min_group_size=70000))
+    assert len(segs) == 7 and 2 <= len(groups) <= 4 and max(len(g) for g in groups) >= 2
+    return groups
+
+
+def _run_somatic(binary, tmp, jobs, env=None):
+    d = farm.wgs_somatic_dataset(SOMATIC_LENGTH)
+
+    def argv(index, regions, prefix, skip_header):
+        return farm.somatic_segment_argv(binary, prefix, os.path.join(d, "normal.bam"), os.path.join(d, "tumor.bam"), regions,
+                                         os.path.join(d, "normal.fa"), chrom_depth=os.path.join(d, "chrom_depth.txt"), callable_regions=True,
+                                         skip_header=skip_header)
+    return farm.run_farm(_somatic_groups(), argv, str(tmp), SOMATIC_OUTPUTS, jobs=jobs, env=env)
+
+
+@pytest.mark.skipif(not _have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
+def test_somatic_farm_identical_through_adapter_cpu_double(tmp_path):
+    ref = _run_somatic("strelka2_ref", tmp_path / "ref", jobs=4)
+    want = {n: _body(ref.outputs[n]) for n in SOMATIC_OUTPUTS}
+    assert sum(1 for l in want["somatic.snvs.vcf"] if not l.startswith("#")) >= 5
+    got = _run_somatic("strelka2_dbl", tmp_path / "dbl", jobs=4, env={"STRELKA_AMD_VERBOSE": "1"})
+    for n in SOMATIC_OUTPUTS:
+        assert _body(got.outputs[n]) == want[n], n
+    assert all("pileup: pushes=" in t and "genotyping=1" in t for t in got.stderr_tails)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _have("strelka2_ref", "strelka2_amd"), reason="oracle/_ref binaries not built")
+def test_somatic_farm_identical_through_adapter_gpu(tmp_path):
+    ref = _run_somatic("strelka2_ref", tmp_path / "ref", jobs=4)
+    want = {n: _body(ref.outputs[n]) for n in SOMATIC_OUTPUTS}
+    for jobs in (1, 4):
+        got = _run_somatic("strelka2_amd", tmp_path / ("amd%d" % jobs), jobs=jobs, env={"STRELKA_AMD_VERBOSE": "1"})
+        for n in SOMATIC_OUTPUTS:
+            assert _body(got.outputs[n]) == want[n], (jobs, n)

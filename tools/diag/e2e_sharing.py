@@ -57,6 +57,8 @@ def main():
     extra = []
     if os.environ.get("SK_SHARING_SPIN"):
         extra = [("spin wait", {"STRELKA_AMD_SPIN_WAIT": "1"}), ("spin wait, no SDMA", {"STRELKA_AMD_SPIN_WAIT": "1", "HSA_ENABLE_SDMA": "0"})]
+    for w in [x for x in os.environ.get("SK_SHARING_WINDOWS", "").split(",") if x]:
+        extra.append(("read window %s" % w, {"STRELKA_AMD_READ_WINDOW": w}))
     configs = [("default", {})] + extra + ([("no SDMA", {"HSA_ENABLE_SDMA": "0"}), ("no SDMA, 2 HW queues", {"HSA_ENABLE_SDMA": "0", "GPU_MAX_HW_QUEUES": "2"})] if os.environ.get("SK_SHARING_SDMA") else [])
     job_list = [int(x) for x in os.environ.get("SK_SHARING_JOBS", "%d,%d,%d" % (cores, cores * 3 // 2, cores * 2)).split(",")]
     for jobs in job_list:
