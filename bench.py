@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--a5-reps", type=int, default=3)
     ap.add_argument("--e2e-bp", type=int, default=16000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
     ap.add_argument("--e2e-segment-bp", type=int, default=2000000, help="segment size of the end-to-end leg (one caller process per segment)")
+    ap.add_argument("--only", default="", help="'a5': run the headline leg alone (the counter passes of tools/gpu_round.sh use it: per-kernel "
+                                               "averages then belong to that leg's launches) and print a short line")
     ap.add_argument("--e2e-somatic-bp", type=int, default=3200000,
                     help="length of the WGS-like 110x / 40x tumour-normal pair of the somatic end-to-end leg per GPU (0: skip the leg)")
     ap.add_argument("--e2e-somatic-segment-bp", type=int, default=400000, help="segment size of the somatic end-to-end leg")
@@ -338,7 +340,11 @@ def pmc_traffic(args):
     if (w.get("reads_per_step_per_gpu"), w.get("loci_per_step_per_gpu"), w.get("unique_reads"), w.get("unique_loci")) != \
             (args.reads, args.loci, args.unique_reads, args.unique_loci):
         return {}
-    return {k: v["hbm_bytes_per_launch"] for k, v in d.get("kernels", {}).items()}
+    out = {k: v["hbm_bytes_per_launch"] for k, v in d.get("kernels", {}).items()}
+    a5 = d.get("a5_only")
+    if a5 and a5.get("workload", {}).get("a5_scenarios") == args.a5_scenarios:
+        out["__a5_step__"] = a5["hbm_bytes_per_step"]
+    return out
 
 
 def main():
@@ -359,6 +365,16 @@ def main():
 
     from strelka_amd import capi, device, shard, synth
     capi.init(local_rank)
+
+    if args.only == "a5":
+        a5_step, a5_meta, a5_event_ms = a5_leg(args, capi, synth)
+        for _ in range(args.warmup + args.steps):
+            a5_step()
+        torch.cuda.synchronize()
+        a5_meta.pop("_keep")
+        print(json.dumps({"only": "a5", "steps": args.steps, "warmup": args.warmup, "a5": a5_meta,
+                          "kernel_ms": float(np.mean(a5_event_ms[-args.steps:]))}))
+        return
 
     # ---- resident inputs (per rank: an independent batch, seeded by rank = an independent genome segment) ----
     rng = np.random.default_rng(1000 + rank)
@@ -602,8 +618,8 @@ def main():
         "global_align_cells_per_s": ga_cells / dt_ga, "global_align_ms_per_step": dt_ga / args.steps * 1e3,
         "global_align_problems_per_step": n_ga,
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
-        "roofline": roof("pool_fill_kernel+flatten_kernel+entries_kernel+score_wave_per_read_cols (flattening + scoring)",
-                         a5_meta["algorithmic_bytes"], kms_a5, None),
+        "roofline": roof("pool_fill_kernel+flatten_kernel+entries_wave_kernel+score_wave_per_read_cols (flattening + scoring)",
+                         a5_meta["algorithmic_bytes"], kms_a5, traffic.get("__a5_step__")),
         "roofline_sum_only": roof("score_wave_per_read_cols", alg_bytes_a, kms_a, traffic.get("score_wave_per_read_cols")),
         "roofline_loci": roof("germline_site_fused_kernel", alg_bytes_b, kms_b, traffic.get("germline_site_fused_kernel")),
     }

@@ -10,6 +10,34 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+
+
+def collect(prefix):
+    acc = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        per = defaultdict(list)
+        for f in glob.glob(os.path.join(root, prefix + counter, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    name = row["Kernel_Name"].replace("(anonymous namespace)::", "")
+                    if name.startswith("void "):
+                        name = name[5:]
+                    per[name.split("(")[0].split("<")[0]].append(float(row["Counter_Value"]))
+        acc[counter] = per
+    res = {}
+    for k in sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"])):
+        f = acc["FETCH_SIZE"].get(k, [])
+        w = acc["WRITE_SIZE"].get(k, [])
+        if not f or not w:
+            continue
+        fk, wk = sum(f) / len(f), sum(w) / len(w)
+        res[k] = dict(launches=len(f), fetch_kib=fk, write_kib=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024,
+                      hbm_bytes_uncorrected=(fk + wk) * 1024)
+    return res
+
+
 acc = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     per = defaultdict(list)
@@ -41,4 +69,12 @@ a = bench.parse()
 sys.argv = argv
 workload = dict(reads_per_step_per_gpu=a.reads, loci_per_step_per_gpu=a.loci, unique_reads=a.unique_reads,
                 unique_loci=a.unique_loci, pileup_reads=a.pileup_reads, somatic_loci=a.somatic_loci)
-json.dump(dict(workload=workload, kernels=out), sys.stdout, indent=1)
+# the headline leg alone (bench.py --only a5): a step launches each of these kernels once, all launches of a kernel have one size
+a5 = collect("pmc_a5_")
+a5_only = None
+step_kernels = ("pool_fill_kernel", "flatten_kernel", "entries_wave_kernel", "score_wave_per_read_cols_hostbuf", "score_wave_per_read_cols")
+if a5:
+    per_step = sum(a5[k]["hbm_bytes_per_launch"] for k in step_kernels if k in a5)
+    a5_only = dict(workload=dict(a5_scenarios=a.a5_scenarios), hbm_bytes_per_step=per_step,
+                   kernels={k: a5[k] for k in step_kernels if k in a5})
+json.dump(dict(workload=workload, kernels=out, a5_only=a5_only), sys.stdout, indent=1)
