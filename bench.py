@@ -263,6 +263,43 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                         "identical": identical,
                         "variant_records": sum(1 for n in outputs if n.endswith(".vcf") and not n.startswith("genome")
                                                for l in body(ref.outputs[n]) if l and not l.startswith(b"#"))})
+            # ---- the whole host: every usable core busy in both legs.  A GPU serves ~8 caller processes, so the drop-in's leg is a
+            # MIXED farm: `jobs` processes of the drop-in on the GPU plus one process of the unmodified reference on each remaining
+            # core (same bytes out), the sample cut so that both kinds of slot finish together; the reference's leg is one process
+            # per core.
+            fill = len(cores) // world - jobs
+            if fill > 0:
+                # the mixed leg's segments are sized for its two kinds of slot (a GPU slot's `ratio` times a fill slot's, the ratio
+                # of the two programs' speeds measured above), the reference's leg gets equal segments -- each leg the cut that suits
+                # it.  Outputs depend on where a genome is cut (blocks end at segment ends), so the mixed leg's bytes are compared
+                # with a third run: the reference alone on the mixed leg's segments.
+                ratio = min(4.0, max(1.0, ref_wall / amd_wall))
+                n_proc = jobs + fill
+                b = int(L / (jobs * ratio + fill))
+                a = int(b * ratio)
+                mixed_groups, pos = [], 1
+                for k in range(n_proc):
+                    end = L if k == n_proc - 1 else pos + (a if k < jobs else b) - 1
+                    mixed_groups.append([(k, "chrW", pos, end, k)])
+                    pos = end + 1
+                t0 = time.perf_counter()
+                mixed = farm.run_farm(mixed_groups, argv_fn(drop_in), os.path.join(root, "mixed"), outputs, n_gpus=1, jobs=jobs,
+                                      device_offset=local_rank, fill_jobs=fill, fill_argv_fn=argv_fn(program + "_ref"), fill_min_pending=0)
+                mixed_wall = time.perf_counter() - t0
+                all_groups = [[sg] for sg in farm.chrom_intervals(["chrW"], {"chrW": L}, -(-L // n_proc))]
+                t0 = time.perf_counter()
+                ref_all = farm.run_farm(all_groups, argv_fn(program + "_ref"), os.path.join(root, "ref_all"), outputs, jobs=n_proc)
+                ref_all_wall = time.perf_counter() - t0
+                ref_same_cut = farm.run_farm(mixed_groups, argv_fn(program + "_ref"), os.path.join(root, "ref_mixed_cut"), outputs, jobs=n_proc)
+                out["all_cores"] = {
+                    "cores": jobs + fill, "ref_procs": jobs + fill, "ref_wall_s": ref_all_wall,
+                    "amd_gpu_procs": jobs, "amd_fill_procs_running_the_reference": fill, "fill_segments": mixed.fill_segments,
+                    "gpu_segment_bp": a, "fill_segment_bp": b, "amd_wall_s": mixed_wall, "speedup": ref_all_wall / mixed_wall,
+                    "identical": all(body(mixed.outputs[n]) == body(ref_same_cut.outputs[n]) for n in outputs),
+                    "identical_note": "the mixed leg's joined outputs against the reference alone on the same segments (a third, untimed run)",
+                    "note": "node level: every usable core calls segments in both legs; the drop-in's leg = %d drop-in processes sharing the "
+                            "GPU + %d processes of the unmodified reference on the other cores (a GPU gives ~8 caller processes the "
+                            "one-process speed-up and time-slices beyond that)" % (jobs, fill)}
         return out
     finally:
         shutil.rmtree(root, ignore_errors=True)

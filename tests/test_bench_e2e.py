@@ -13,9 +13,13 @@ from tests import e2e_util as E
 def test_e2e_leg_runs_and_compares(monkeypatch):
     import bench
     monkeypatch.setenv("SK_E2E_VARIANT", "dbl")
-    args = argparse.Namespace(e2e_bp=400000, e2e_segment_bp=100000, e2e_max_procs_per_gpu=8)
+    args = argparse.Namespace(e2e_bp=400000, e2e_segment_bp=100000, e2e_max_procs_per_gpu=2)
     out = bench.e2e_leg(args, 0, 1, 0, lambda: None, lambda v: v, with_reference=True)
     assert out["identical"] is True and out["segments"] == 4 and out["bp"] == 400000
+    # the node-level pair of legs: a mixed farm (2 drop-in processes + the reference on the other cores) against the reference on all
+    ac = out["all_cores"]
+    assert ac["identical"] is True and ac["amd_gpu_procs"] == 2 and ac["amd_fill_procs_running_the_reference"] >= 1
+    assert ac["fill_segments"] == ac["amd_fill_procs_running_the_reference"] and ac["ref_procs"] == ac["cores"]
     assert out["variant_records"] > 300 and out["ref_wall_s"] > 0 and out["amd_wall_s"] > 0
     assert out["hook_seconds"]["pileup_abi"] > 0 and out["hook_seconds"]["pileup_hook"] >= out["hook_seconds"]["pileup_abi"]
 
