@@ -395,6 +395,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # ---- end to end FIRST when this is the only rank: the caller processes of these legs share the GPU eight at a time, and eight is
+    # all the device runs side by side -- a ninth process with a queue on it (this one, once it has initialised HIP) puts all of them
+    # under the driver's time-slicing (1.46x instead of 1.6x on the germline leg, profiles/r03_v20_bench.json vs r03_v19).  So the
+    # legs run before this process creates its context.
+    e2e = e2e_somatic = None
+    if world == 1 and not args.only:
+        if args.e2e_bp > 0:
+            e2e = e2e_leg(args, 0, 1, local_rank, lambda: None, lambda v: v, with_reference=not args.no_cpu_baseline)
+        if args.e2e_somatic_bp > 0:
+            e2e_somatic = e2e_leg(args, 0, 1, local_rank, lambda: None, lambda v: v, with_reference=not args.no_cpu_baseline, mode="somatic")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -556,30 +566,27 @@ def main():
         wr["realign%s_reads_per_step_per_gpu" % name] = wr_reads
         wr["realign%s_candidate_alignments_per_read" % name] = wr_cals / max(1, wr_reads)
 
-    # ---- end to end: the drop-in as the workflow runs it, one caller process per genome segment ----
-    # (this process steps aside: its cached device memory goes back and its stream is idle while the caller processes share the GPU)
-    import gc
-    gc.collect()
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()
+    # ---- end to end (N > 1; a single rank ran these legs before it touched the GPU, see the top of main) ----
+    if world > 1:
+        # (this process steps aside as far as it can: its cached device memory goes back and its stream is idle -- but it keeps its
+        # queue on the device, one of the eight the caller processes want: a rank runs at most 7 of them)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        args.e2e_max_procs_per_gpu = min(args.e2e_max_procs_per_gpu, 7)
 
-    def barrier():
-        if world > 1:
+        def barrier():
             dist.barrier()
 
-    def max_over_ranks(v):
-        if world == 1:
-            return v
-        t = torch.tensor([v], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-    e2e = None
-    if args.e2e_bp > 0:
-        e2e = e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference=(world == 1 and not args.no_cpu_baseline))
-    e2e_somatic = None
-    if args.e2e_somatic_bp > 0:
-        e2e_somatic = e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference=(world == 1 and not args.no_cpu_baseline),
-                              mode="somatic")
+        def max_over_ranks(v):
+            t = torch.tensor([v], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        if args.e2e_bp > 0:
+            e2e = e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference=False)
+        if args.e2e_somatic_bp > 0:
+            e2e_somatic = e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference=False, mode="somatic")
 
     traffic = pmc_traffic(args)
     som_kernels = ("somatic_classify_kernel", "somatic_lhood_kernel", "somatic_posterior_kernel")

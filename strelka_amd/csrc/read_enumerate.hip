@@ -600,20 +600,30 @@ __global__ __launch_bounds__(64) void pool_fill_kernel(const FlatArgs a)
 // host form performs for every indel of the alignment (cal_to_c)
 __global__ __launch_bounds__(64) void flatten_kernel(const FlatArgs a)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // The wave's 64 records travel pool -> LDS -> cals as rows of consecutive dwords: a lane copying its own 288-byte record field
+    // by field made every load and store a scatter over 64 records (1.4 GB of traffic for 360 000 candidate alignments,
+    // profiles/r03_v20_pmc_traffic.json); the lanes then read their record from LDS (stride 73 dwords: odd, conflict-free).
+    constexpr int REC_DW = int(sizeof(PCal) / 4), REC_STRIDE = REC_DW | 1;
+    static_assert(sizeof(PCal) % 4 == 0 && REC_DW <= 128, "a record is at most two dwords per lane");
+    __shared__ uint32_t s_cal[64 * REC_STRIDE];
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * blockDim.x;
+    const int c = c0 + lane;
+    const int nc = min(64, a.n_cals - c0);
+    const int src_k = (lane < nc) ? a.list[c0 + lane] : 0;
+    for (int k = 0; k < nc; ++k) {
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(a.pool + __shfl(src_k, k));
+        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.cals + (c0 + k));
+        for (int j = lane; j < REC_DW; j += 64) {
+            const uint32_t v = src[j];
+            s_cal[k * REC_STRIDE + j] = v;
+            dst[j] = v;
+        }
+    }
+    __syncthreads();
     if (c >= a.n_cals) return;
     const int r = read_of_cal(a, c);
-    const PCal& cal = a.pool[a.list[c]];
-    PCal& d = a.cals[c];
-    d.pos = cal.pos;
-    d.lead = cal.lead;
-    d.trail = cal.trail;
-    d.fwd = cal.fwd;
-    d.n_seg = cal.n_seg;
-    d.n_indels = cal.n_indels;
-    d.pad = 0;
-    for (int i = 0; i < cal.n_seg; ++i) d.path[i] = cal.path[i];
-    for (int i = 0; i < cal.n_indels; ++i) d.indels[i] = cal.indels[i];
+    const PCal& cal = *reinterpret_cast<const PCal*>(s_cal + lane * REC_STRIDE);
     if (a.status[r] != ST_OK) return; // (its op range is empty)
     (void)flatten_cal<true>(a, r, cal, int32_t(a.read_off[r + 1] - a.read_off[r]), a.ops + a.op_off[c]);
     for (int i = 0; i < cal.n_indels; ++i) (void)job_cand(a.job, cal.indels[i]);
