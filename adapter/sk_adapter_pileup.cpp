@@ -209,11 +209,11 @@ void assignWindow(starling_pos_processor_base::sample_info& sif, const sk_pileup
         snp_pos_info& pi(Access::pileupRef(sif.basecallBuffer, w.begin + static_cast<pos_t>(i)));
         const size_t n1(static_cast<size_t>(w.tier1_off[i + 1] - w.tier1_off[i]));
         const size_t n2(static_cast<size_t>(w.tier2_off[i + 1] - w.tier2_off[i]));
-        static const base_call blank(0, 0, false, 0, 0, false, false, false);
-        pi.calls.assign(n1, blank);
-        if (n1) std::memcpy(static_cast<void*>(pi.calls.data()), w.tier1_calls + w.tier1_off[i], 2 * n1);
-        pi.tier2_calls.assign(n2, blank);
-        if (n2) std::memcpy(static_cast<void*>(pi.tier2_calls.data()), w.tier2_calls + w.tier2_off[i], 2 * n2);
+        // (base_call is the 16-bit record itself: the column is a run of them; one pass, no fill before the copy)
+        const base_call* const t1(reinterpret_cast<const base_call*>(w.tier1_calls + w.tier1_off[i]));
+        const base_call* const t2(reinterpret_cast<const base_call*>(w.tier2_calls + w.tier2_off[i]));
+        pi.calls.assign(t1, t1 + n1);
+        pi.tier2_calls.assign(t2, t2 + n2);
         pi.spanningDeletionReadCount = sd;
         pi.submappedReadCount = sm;
         pi.mapqTracker.count = mq;
