@@ -99,6 +99,10 @@ HOOKS = [
         # site 2: the dependent error probabilities are computed inside the fused site kernel
         ("CleanPileupErrorProb", r'_pileupCleaner\.CleanPileupErrorProb\(sample\(sampleIndex\)\.cleanedPileup\);',
          '/* strelka_amd: adjust_joint_eprob runs fused with the genotype kernel (sk_site_digt_call_fused) */'),
+        # site 9 (germline EVS): the position's rank sums, rebuilt from the stream's window just before they are read
+        ("germline EVS accumulators",
+         r'(            siteSampleInfo\.ReadPosRankSum = pi\.get_read_pos_ranksum\(\);\n)',
+         '            sk_adapter::germline_fill_scoring_metrics(sampleIndex, locus.pos, pi);\n\\1'),
         # site 3
         ("computeSampleDiploidSiteGenotype call",
          r'computeSampleDiploidSiteGenotype\(\n\s*_opt, _dopt, sample\(sampleIndex\), callerPloidy\[sampleIndex\], allDgt\[sampleIndex\]\);',

@@ -31,6 +31,7 @@ struct strelka_pos_processor;
 struct diploid_genotype;
 struct starling_read;
 struct CleanedPileup;
+struct snp_pos_info;
 struct somatic_snv_genotype_grid;
 struct somatic_indel_call;
 struct strelka_options;
@@ -99,6 +100,11 @@ bool sample_stats_counts(starling_pos_processor_base& pp, const pos_t pos, const
 /// starling_pos_processor_base.cpp:984-1000), rebuilt from the pileup stream's window before the position's record is written
 /// (strelka_pos_processor.cpp:255); nothing to do when the reference's own pileup ran
 void somatic_fill_scoring_metrics(starling_pos_processor_base& pp, const pos_t pos);
+
+/// the germline EVS accumulators of one sample's pileup at `pos` (mq_ranksum, baseq_ranksum, readPositionRankSum, distanceFromReadEdge:
+/// updateGermlineScoringMetrics, starling_pos_processor_base.cpp:1346-1357), rebuilt from the pileup stream's window just before
+/// updateSiteSampleInfo reads them (starling_pos_processor.cpp:235-246); nothing to do when the reference's own pileup ran
+void germline_fill_scoring_metrics(const unsigned sampleIndex, const pos_t pos, const snp_pos_info& pi);
 
 // ---- site 6: get_somatic_indel at strelka_pos_processor.cpp:343-349 ----
 void somatic_indel(const strelka_options& opt, const starling_sample_options& normalOpt, const starling_sample_options& tumorOpt,

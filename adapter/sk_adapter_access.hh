@@ -108,6 +108,10 @@ struct SiteChunk
     std::vector<sk_digt_call> calls;
     std::vector<uint32_t> cleanCount; ///< calls of the cleaned column each genotype was computed from
     std::vector<uint8_t> ploidy;      ///< ... and the ploidy
+    // germline EVS: the per-call arguments of updateGermlineScoringMetrics, kept until POST_ALIGN has passed the chunk
+    std::vector<int64_t> evsOff;      ///< [n+1]
+    std::vector<uint64_t> evsWords;
+    std::vector<uint8_t> isMetricsFilled;
 };
 
 /// somatic SNV records of a run of positions one push of the two samples' pileups finalised (site 9 chained into site 5)
@@ -128,7 +132,7 @@ struct SomaticChunk
 struct PileupState
 {
     bool decided = false, enabled = false, isGenotyping = false;
-    bool isSomatic = false, isSomaticMetrics = false;
+    bool isSomatic = false, isSomaticMetrics = false, isGermlineMetrics = false;
     std::vector<sk_pileup_stream*> streams;
     sk_somatic_pileup_stream* somaticStream = nullptr;
     std::deque<SomaticChunk> somaticChunks;

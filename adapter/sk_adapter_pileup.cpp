@@ -293,22 +293,31 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
     const size_t n(static_cast<size_t>(w.end - w.begin));
     s.pileupLoci += n;
 
-    if (ps.isGenotyping && n > 0)
+    if ((ps.isGenotyping || ps.isGermlineMetrics) && n > 0)
     {
         SiteChunk chunk;
         chunk.begin = w.begin;
         chunk.end = w.end;
-        chunk.calls.assign(w.genotype, w.genotype + n);
-        chunk.cleanCount.assign(w.clean_count, w.clean_count + n);
-        chunk.ploidy.resize(n);
-        for (size_t i(0); i < n; ++i)
+        if (ps.isGenotyping)
         {
-            const int64_t k(static_cast<int64_t>(w.begin) + static_cast<int64_t>(i) - ploidyBegin);
-            chunk.ploidy[i] = (ploidyPtr && k >= 0 && k < ploidyLen) ? ploidyPtr[k] : 2;
+            chunk.calls.assign(w.genotype, w.genotype + n);
+            chunk.cleanCount.assign(w.clean_count, w.clean_count + n);
+            chunk.ploidy.resize(n);
+            for (size_t i(0); i < n; ++i)
+            {
+                const int64_t k(static_cast<int64_t>(w.begin) + static_cast<int64_t>(i) - ploidyBegin);
+                chunk.ploidy[i] = (ploidyPtr && k >= 0 && k < ploidyLen) ? ploidyPtr[k] : 2;
+            }
+            s.siteLoci += n;
+            s.siteBatches++;
+        }
+        if (ps.isGermlineMetrics)
+        {
+            chunk.evsOff.assign(w.evs_off, w.evs_off + n + 1);
+            chunk.evsWords.assign(w.evs_words, w.evs_words + w.evs_off[n]);
+            chunk.isMetricsFilled.assign(n, 0);
         }
         ps.chunks[sampleIndex].push_back(std::move(chunk));
-        s.siteLoci += n;
-        s.siteBatches++;
     }
     ps.nextFinal[sampleIndex] = isFinal ? INT_MAX : std::max(ps.nextFinal[sampleIndex], static_cast<pos_t>(finalTo));
 }
@@ -431,10 +440,9 @@ void pileup_somatic_window(starling_pos_processor_base& pp, const pos_t begin, c
 
 }
 
-static bool pileup_routed(const starling_base_options& opt)
+static bool pileup_routed(const starling_base_options& /*opt*/)
 {
-    // (the germline EVS accumulators -- three rank sums over every basecall, updateGermlineScoringMetrics -- are not produced)
-    return env_flag("STRELKA_AMD_PILEUP", true) && (! opt.is_compute_germline_scoring_metrics());
+    return env_flag("STRELKA_AMD_PILEUP", true);
 }
 
 bool pileup_genotypes_with_stream(const starling_base_options& opt)
@@ -453,6 +461,7 @@ bool pileup_enabled(starling_pos_processor_base& pp)
     ps.isSomatic = ps.enabled && opt.isSomaticCallingMode;
     if (ps.isSomatic && Access::sampleCount(pp) != 2) throw blt_exception("strelka_amd adapter: the somatic pileup stream takes a normal and a tumor sample");
     ps.isSomaticMetrics = ps.isSomatic && opt.is_compute_somatic_scoring_metrics;
+    ps.isGermlineMetrics = ps.enabled && (! ps.isSomatic) && opt.is_compute_germline_scoring_metrics();
     ps.isGenotyping = pileup_genotypes_with_stream(opt);
     if (ps.isSomatic && ps.isGenotyping)
     {
@@ -494,6 +503,7 @@ void pileup_reset_region(starling_pos_processor_base& pp)
         {
             sk_pileup_stream* st(sk_pileup_stream_create(&po, ps.isGenotyping ? &go : nullptr));
             if (st == nullptr) check(1, "sk_pileup_stream_create");
+            if (ps.isGermlineMetrics) check(sk_pileup_stream_enable_evs_words(st, 1), "sk_pileup_stream_enable_evs_words");
             ps.streams.push_back(st);
         }
     }
@@ -578,6 +588,15 @@ void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos)
         return;
     }
     const unsigned sampleCount(Access::sampleCount(pp));
+    if (! ps.isGenotyping)
+    {
+        // (chunks kept for the EVS accumulators only: POST_ALIGN only moves forward)
+        for (unsigned sampleIndex(0); sampleIndex < sampleCount && sampleIndex < ps.chunks.size(); ++sampleIndex)
+        {
+            std::deque<SiteChunk>& chunks(ps.chunks[sampleIndex]);
+            while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front();
+        }
+    }
     for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
     {
         if (pos < ps.nextFinal[sampleIndex]) continue;
@@ -585,6 +604,42 @@ void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos)
         AccumTimer hookTimer(s.tPileupHook);
         // nothing new to pile up: an empty window that finalises everything
         pileup_sample_window(pp, sampleIndex, 0, 0, true);
+    }
+}
+
+void germline_fill_scoring_metrics(const unsigned sampleIndex, const pos_t pos, const snp_pos_info& pi)
+{
+    PileupState& ps(state().pileup);
+    if (! (ps.enabled && ps.isGermlineMetrics) || sampleIndex >= ps.chunks.size()) return;
+    for (SiteChunk& c : ps.chunks[sampleIndex])
+    {
+        if (pos < c.begin || pos >= c.end) continue;
+        const size_t k(static_cast<size_t>(pos - c.begin));
+        if (c.isMetricsFilled[k]) return;
+        c.isMetricsFilled[k] = 1;
+        const int64_t o(c.evsOff[k]);
+        const size_t n(static_cast<size_t>(c.evsOff[k + 1] - o));
+        if (n != pi.mapqTracker.count) throw blt_exception("strelka_amd adapter: the pileup of a scored position is not the stream's");
+        snp_pos_info& acc(const_cast<snp_pos_info&>(pi));
+        const char refBase(pi.get_ref_base());
+        for (size_t i(0); i < n; ++i)
+        {
+            // pos_basecall_buffer::updateGermlineScoringMetrics (pos_basecall_buffer.cpp:43-70), in pileup order
+            const uint64_t w(c.evsWords[static_cast<size_t>(o) + i]);
+            const uint8_t callId(static_cast<uint8_t>(w & 7u));
+            const unsigned mapq(static_cast<unsigned>((w >> 3) & 0xffu)), qscore(static_cast<unsigned>((w >> 11) & 0x7fu));
+            const unsigned cycle(static_cast<unsigned>((w >> 18) & 0x7ffu)), edge(static_cast<unsigned>((w >> 29) & 0x1fu));
+            const bool isSubmapped((w >> 34) & 1u);
+            const bool isReference(refBase == id_to_base(callId));
+            acc.mq_ranksum.add_observation(isReference, mapq);
+            if (! isSubmapped)
+            {
+                acc.baseq_ranksum.add_observation(isReference, qscore);
+                acc.readPositionRankSum.add_observation(isReference, cycle);
+                if (! isReference) acc.distanceFromReadEdge.addObservation(edge); // (already min(20, .))
+            }
+        }
+        return;
     }
 }
 

@@ -214,8 +214,17 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                                                  os.path.join(d, "normal.fa"), chrom_depth=os.path.join(d, "chrom_depth.txt"),
                                                  callable_regions=True, skip_header=skip_header)
             return farm.germline_segment_argv(binary, prefix, [os.path.join(d, "wgs.bam")], regions, os.path.join(d, "wgs.fa"),
-                                              chrom_depth=os.path.join(d, "chrom_depth.txt"), skip_header=skip_header)
+                                              chrom_depth=os.path.join(d, "chrom_depth.txt"), skip_header=skip_header, evs_models=evs_models)
         return fn
+    evs_models = None
+    if not somatic:
+        # the germline workflow runs with EVS on by default (strelkaSharedOptions.py:173): scoring models on the command line, the EVS
+        # accumulators in the pileup.  The reference tree does not carry its germline models; small stand-ins are written here.
+        import subprocess
+        import sys
+        subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "make_dummy_germline_models.py"),
+                        os.path.join(root, "models")], check=True)
+        evs_models = (os.path.join(root, "models", "germlineSNVScoringModels.json"), os.path.join(root, "models", "germlineIndelScoringModels.json"))
     try:
         warm = [[(0, "chrW", 1, min(L, 50000), 0)]]
         farm.run_farm(warm, argv_fn(drop_in), os.path.join(root, "warm"), outputs, n_gpus=1, jobs=1,
@@ -236,7 +245,9 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
         depth = 150.0 if somatic else 40.0
         what = ("tumour / normal pair, %d bp at 110x / 40x" if somatic else "germline sample, %d bp at 40x") % L
         flags = ("somatic workflow's command line (EVS scoring models, --somatic-callable-regions-file, --strelka-chrom-depth-file ...)"
-                 if somatic else "workflow's WGS command line (--chrom-depth-file, --gvcf-skip-header ...)")
+                 if somatic else "workflow's WGS command line (--chrom-depth-file, --gvcf-skip-header, EVS on as by default: "
+                                 "--snv-scoring-model-file / --indel-scoring-model-file with stand-in models, "
+                                 "tools/make_dummy_germline_models.py ...)")
         out = {"workload": "WGS-like synthetic %s, 150 bp reads (tools/make_wgs_bam.py), %d segments of %d bp, one caller process per segment "
                            "with the %s" % (what, len(groups), seg_bp, flags),
                "bp": L * world, "reads": int(L * depth / 150) * world, "segments": len(groups) * world,

@@ -597,12 +597,24 @@ typedef struct sk_pileup_window {
     const uint64_t* mapq_sum_square; /* [n] MapqTracker::sumSquare (a sum of integer squares: exact) */
     const uint32_t* clean_count;     /* [n] calls in the cleaned tier1 column the genotype was computed from */
     const sk_digt_call* genotype;    /* [n], NULL when the stream does not genotype */
+    const int64_t* evs_off;          /* [n+1], NULL unless sk_pileup_stream_enable_evs_words: a position has mapq_count words */
+    const uint64_t* evs_words;       /* one per live match position of every read, submapped reads included, in pileup order:
+                                        base id (bits 0-2) | mapq << 3 | qscore << 11 (MAPQ-adjusted, not capped) | cycle << 18
+                                        (align_strand_read_pos) | min(20, distance from the read edge) << 29 | is_submapped << 34
+                                        (a submapped position carries base id, mapq and the flag only) */
 } sk_pileup_window;
 
 /** genotype_opt: NULL = columns only.  opt->report_begin / report_end / largest_total_indel_ref_span_per_read are set per
  *  region and per push. */
 sk_pileup_stream* sk_pileup_stream_create(const sk_pileup_options* opt, const sk_germline_options* genotype_opt);
 void sk_pileup_stream_destroy(sk_pileup_stream* s);
+/** The germline EVS accumulators (updateGermlineScoringMetrics, starling_pos_processor_base.cpp:1346-1357 ->
+ *  pos_basecall_buffer.cpp:43-70: mq_ranksum, baseq_ranksum, readPositionRankSum, distanceFromReadEdge) are fed for every basecall
+ *  of every read when the germline EVS models are loaded, and read only where a variant record is scored
+ *  (L/applications/starling/starling_pos_processor.cpp:235-246).  With this switched on (before the first region) a window also
+ *  returns the per-call arguments of that function, evs_off / evs_words, from which the caller rebuilds the four accumulators of the
+ *  positions it needs them for. */
+int sk_pileup_stream_enable_evs_words(sk_pileup_stream* s, int enable);
 /** resetRegionBase (starling_pos_processor_base.cpp:361-393): the reference segment of the region and its report range */
 int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, int32_t ref_offset, int32_t ref_len,
                                   int32_t report_begin, int32_t report_end, int32_t largest_total_indel_ref_span_per_read);

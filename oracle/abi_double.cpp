@@ -464,7 +464,7 @@ struct sk_pileup_stream
     sk_pileup_options opt;
     sk_germline_options gopt;
     bool genotype = false;
-    bool somatic = false, want_read_pos = false;
+    bool somatic = false, want_read_pos = false, want_evs = false;
     bool has_region = false;
     std::string ref;
     int32_t ref_offset = 0, region_begin = 0, region_end = 0;
@@ -473,6 +473,7 @@ struct sk_pileup_stream
     {
         std::vector<uint16_t> t1, t2;
         std::vector<uint32_t> rp; // parallel to t1 (want_read_pos)
+        std::vector<uint64_t> ev; // one per live match position (want_evs)
         uint32_t spandel = 0, submapped = 0, mq_n = 0, mq_zero = 0;
         uint64_t mq_sq = 0;
     };
@@ -484,7 +485,8 @@ struct sk_pileup_stream
     std::vector<int64_t> o_off1, o_off2;
     std::vector<uint16_t> o_c1, o_c2;
     std::vector<uint32_t> o_sd, o_sm, o_mn, o_mz, o_cn, o_cn4, o_rp;
-    std::vector<uint64_t> o_sq;
+    std::vector<uint64_t> o_sq, o_ev;
+    std::vector<int64_t> o_evoff;
     std::vector<sk_digt_call> o_g;
     // the cleaned columns of the last emitted range (CleanPileupFilter(pi,false) / (pi,true))
     std::vector<int64_t> k_off, k_off4;
@@ -630,6 +632,12 @@ int double_ingest(sk_pileup_stream* s, const sk_read_batch* reads, int32_t span,
             std::vector<uint16_t> cr(static_cast<size_t>(cap) + 1);
             if (sko_pileup_reads_readpos(&b, &o, offr.data(), cr.data(), cap, rp.data()) < 0) return fail("sk_pileup_stream_push: malformed read");
         }
+        std::vector<int64_t> offe(nl + 1);
+        std::vector<uint64_t> ew;
+        if (s->want_evs) {
+            ew.resize(static_cast<size_t>(cap) + 1);
+            if (sko_pileup_reads_evs(&b, &o, offe.data(), ew.data(), cap) < 0) return fail("sk_pileup_stream_push: malformed read");
+        }
         for (size_t l = 0; l < nl; ++l) {
             const bool any = (off1[l + 1] > off1[l]) || (off2[l + 1] > off2[l]) || sd[l] || sm[l] || mn[l];
             if (!any) continue;
@@ -639,6 +647,7 @@ int double_ingest(sk_pileup_stream* s, const sk_read_batch* reads, int32_t span,
             c.t1.insert(c.t1.end(), c1.begin() + off1[l], c1.begin() + off1[l + 1]);
             c.t2.insert(c.t2.end(), c2.begin() + off2[l], c2.begin() + off2[l + 1]);
             if (s->want_read_pos) c.rp.insert(c.rp.end(), rp.begin() + off1[l], rp.begin() + off1[l + 1]);
+            if (s->want_evs) c.ev.insert(c.ev.end(), ew.begin() + offe[l], ew.begin() + offe[l + 1]);
             c.spandel += sd[l];
             c.submapped += sm[l];
             c.mq_n += mn[l];
@@ -677,7 +686,8 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
 {
     const size_t nl = static_cast<size_t>(end - begin);
     s->o_off1.assign(nl + 1, 0); s->o_off2.assign(nl + 1, 0);
-    s->o_c1.clear(); s->o_c2.clear(); s->o_rp.clear();
+    s->o_c1.clear(); s->o_c2.clear(); s->o_rp.clear(); s->o_ev.clear();
+    s->o_evoff.assign(nl + 1, 0);
     s->o_sd.assign(nl, 0); s->o_sm.assign(nl, 0); s->o_mn.assign(nl, 0); s->o_mz.assign(nl, 0); s->o_cn.assign(nl + 1, 0);
     s->o_cn4.assign(nl + 1, 0);
     s->o_sq.assign(nl, 0);
@@ -690,6 +700,7 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
     for (size_t l = 0; l < nl; ++l) {
         s->o_off1[l] = static_cast<int64_t>(s->o_c1.size());
         s->o_off2[l] = static_cast<int64_t>(s->o_c2.size());
+        s->o_evoff[l] = static_cast<int64_t>(s->o_ev.size());
         coff[l] = static_cast<int64_t>(ccalls.size());
         coff4[l] = static_cast<int64_t>(ccalls4.size());
         const auto it = s->cols.find(begin + static_cast<int32_t>(l));
@@ -698,6 +709,7 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
         s->o_c1.insert(s->o_c1.end(), c.t1.begin(), c.t1.end());
         s->o_c2.insert(s->o_c2.end(), c.t2.begin(), c.t2.end());
         if (s->want_read_pos) s->o_rp.insert(s->o_rp.end(), c.rp.begin(), c.rp.end());
+        if (s->want_evs) s->o_ev.insert(s->o_ev.end(), c.ev.begin(), c.ev.end());
         for (const uint16_t bc : c.t1) if (!((bc >> 12) & 1)) ccalls.push_back(bc);
         s->o_cn[l] = static_cast<uint32_t>(ccalls.size() - static_cast<size_t>(coff[l]));
         if (s->somatic) { // CleanPileupFilter(pi, true), PileupCleaner.cpp:43-64
@@ -709,6 +721,8 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
     }
     s->o_off1[nl] = static_cast<int64_t>(s->o_c1.size());
     s->o_off2[nl] = static_cast<int64_t>(s->o_c2.size());
+    s->o_evoff[nl] = static_cast<int64_t>(s->o_ev.size());
+    s->o_ev.push_back(0);
     coff[nl] = static_cast<int64_t>(ccalls.size());
     coff4[nl] = static_cast<int64_t>(ccalls4.size());
     s->o_c1.push_back(0); s->o_c2.push_back(0); ccalls.push_back(0); ccalls4.push_back(0); s->o_rp.push_back(0);
@@ -752,9 +766,18 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
     out->mapq_sum_square = s->o_sq.data();
     out->clean_count = s->o_cn.data();
     out->genotype = s->genotype ? s->o_g.data() : nullptr;
+    out->evs_off = s->want_evs ? s->o_evoff.data() : nullptr;
+    out->evs_words = s->want_evs ? s->o_ev.data() : nullptr;
     return 0;
 }
 
+}
+
+int sk_pileup_stream_enable_evs_words(sk_pileup_stream* s, int enable)
+{
+    if (!s || s->somatic) return fail("sk_pileup_stream_enable_evs_words: bad argument");
+    s->want_evs = (enable != 0);
+    return 0;
 }
 
 int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32_t span, int32_t mask_begin, int32_t mask_len,

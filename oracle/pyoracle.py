@@ -603,6 +603,23 @@ def pileup_reads_readpos(rb, opt):
     return call_off, calls[:n].copy(), rp[:n].copy()
 
 
+def pileup_reads_evs(rb, opt):
+    """the germline EVS words of every live match position (updateGermlineScoringMetrics' arguments) -> (evs_off, evs_words)"""
+    L = oracle()
+    L.sko_pileup_reads_evs.restype = C.c_int64
+    L.sko_pileup_reads_evs.argtypes = [C.POINTER(ReadBatchStruct), C.POINTER(PileupOptions), vp, vp, C.c_int64]
+    n_loci = opt.report_end - opt.report_begin
+    keep = []
+    s = read_batch_struct(rb, keep)
+    cap = 2 * rb.n_bases + 1
+    off = np.zeros(n_loci + 1, np.int64)
+    words = np.zeros(cap, np.uint64)
+    n = L.sko_pileup_reads_evs(C.byref(s), C.byref(opt), _p(off), _p(words), cap)
+    if n < 0:
+        raise RuntimeError("sko_pileup_reads_evs failed")
+    return off, words[:n].copy()
+
+
 def mapped_qscore_table():
     L = oracle()
     return np.array([[L.sko_mapped_qscore(q, m) for q in range(71)] for m in range(91)], np.int32)

@@ -1639,6 +1639,29 @@ int64_t sko_pileup_reads(const sko_read_batch* b, const sko_pileup_options* o, i
 static int64_t pileup_reads_impl(const sko_read_batch* b, const sko_pileup_options* o, int mode, int64_t* call_off,
                                  uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count,
                                  uint32_t* mapq_count, uint32_t* mapq_zero_count, uint64_t* mapq_sum_square, uint32_t* read_pos);
+static int64_t g_evs_capacity = 0; /* sko_pileup_reads_evs's side outputs (test infrastructure: single-threaded) */
+static int64_t* g_evs_off = NULL;
+static uint64_t* g_evs_words = NULL;
+
+/* What updateGermlineScoringMetrics gets (L/starling_common/starling_pos_processor_base.cpp:1346-1357 ->
+ * pos_basecall_buffer.cpp:43-70) for every live match position of every read, submapped reads included, in pileup order, one
+ * word each: base id (bits 0-2) | mapq << 3 | qscore << 11 (after the MAPQ adjustment, not capped) | cycle << 18
+ * (align_strand_read_pos) | min(20, distance from the read edge) << 29 | is_submapped << 34.  evs_off[n_loci + 1]. */
+int64_t sko_pileup_reads_evs(const sko_read_batch* b, const sko_pileup_options* o, int64_t* evs_off, uint64_t* evs_words, int64_t capacity)
+{
+    const int32_t n_loci = o->report_end - o->report_begin;
+    int64_t* off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_loci + 1));
+    uint16_t* calls = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)(capacity + 1));
+    g_evs_capacity = capacity;
+    g_evs_off = evs_off;
+    g_evs_words = evs_words;
+    const int64_t rc = pileup_reads_impl(b, o, 0, off, calls, capacity, NULL, NULL, NULL, NULL, NULL, NULL);
+    g_evs_off = NULL;
+    g_evs_words = NULL;
+    free(off);
+    free(calls);
+    return rc < 0 ? rc : evs_off[n_loci];
+}
 
 int64_t sko_pileup_reads_mapq(const sko_read_batch* b, const sko_pileup_options* o, int mode, int64_t* call_off,
                               uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count,
@@ -1673,11 +1696,29 @@ static int pl_push32(pl_col32* c, uint32_t x)
     return 0;
 }
 
+typedef struct pl_col64 {
+    uint64_t* v;
+    int32_t n, cap;
+} pl_col64;
+static int pl_push64(pl_col64* c, uint64_t x)
+{
+    if (c->n == c->cap) {
+        const int32_t nc = c->cap ? 2 * c->cap : 16;
+        uint64_t* nv = (uint64_t*)realloc(c->v, sizeof(uint64_t) * (size_t)nc);
+        if (!nv) return 1;
+        c->v = nv;
+        c->cap = nc;
+    }
+    c->v[c->n++] = x;
+    return 0;
+}
+
 static int64_t pileup_reads_impl(const sko_read_batch* b, const sko_pileup_options* o, int mode, int64_t* call_off,
                                  uint16_t* calls, int64_t capacity, uint32_t* spandel_count, uint32_t* submapped_count,
                                  uint32_t* mapq_count, uint32_t* mapq_zero_count, uint64_t* mapq_sum_square, uint32_t* read_pos)
 {
     const int32_t n_loci = o->report_end - o->report_begin;
+    pl_col64* ev = g_evs_words ? (pl_col64*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col64)) : NULL;
     pl_col* t1 = (pl_col*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col));
     pl_col* t2 = (pl_col*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col));
     pl_col32* rp1 = (pl_col32*)calloc((size_t)(n_loci > 0 ? n_loci : 1), sizeof(pl_col32));
@@ -1831,6 +1872,15 @@ static int64_t pileup_reads_impl(const sko_read_batch* b, const sko_pileup_optio
                     if (mapq_count) mapq_count[locus]++; /* :1346, before the submapped test */
                     if (mapq_zero_count && mapq == 0) mapq_zero_count[locus]++;
                     if (mapq_sum_square) mapq_sum_square[locus] += (uint64_t)(mapq * mapq);
+                    if (ev) { /* updateGermlineScoringMetrics :1348-1357 */
+                        const unsigned cycle = fwd ? (unsigned)rp : (unsigned)(L - (rp + 1));
+                        const unsigned edge = (unsigned)((rp < L - (rp + 1)) ? rp : L - (rp + 1));
+                        /* (a submapped position only feeds the MAPQ rank sum: its other fields are left 0) */
+                        const uint64_t w = is_submapped ? ((uint64_t)id | ((uint64_t)mapq << 3) | ((uint64_t)1 << 34))
+                                                        : ((uint64_t)id | ((uint64_t)mapq << 3) | ((uint64_t)(unsigned)q << 11) |
+                                                           ((uint64_t)cycle << 18) | ((uint64_t)(edge < 20 ? edge : 20) << 29));
+                        if (pl_push64(&ev[locus], w)) bad = 1;
+                    }
                     if (is_submapped) {
                         if (submapped_count) submapped_count[locus]++;
                         continue;
@@ -1893,6 +1943,21 @@ static int64_t pileup_reads_impl(const sko_read_batch* b, const sko_pileup_optio
             call_off[n_loci] = n;
             result = n;
         }
+        if (!bad && ev) {
+            int64_t m = 0;
+            for (int32_t l = 0; l < n_loci && !bad; ++l) {
+                g_evs_off[l] = m;
+                for (int i = 0; i < ev[l].n; ++i) {
+                    if (m >= g_evs_capacity) { bad = 1; result = -1; break; }
+                    g_evs_words[m++] = ev[l].v[i];
+                }
+            }
+            if (!bad) g_evs_off[n_loci] = m;
+        }
+    }
+    if (ev) {
+        for (int32_t l = 0; l < n_loci; ++l) free(ev[l].v);
+        free(ev);
     }
     for (int32_t l = 0; l < n_loci; ++l) {
         free(t1[l].v);

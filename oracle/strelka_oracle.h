@@ -275,6 +275,10 @@ int64_t sko_pileup_reads_mapq(const sko_read_batch* b, const sko_pileup_options*
  * L/starling_common/starling_pos_processor_base.cpp:984-1000, :1360) */
 int64_t sko_pileup_reads_readpos(const sko_read_batch* b, const sko_pileup_options* opt, int64_t* call_off, uint16_t* calls,
                                  int64_t capacity, uint32_t* read_pos);
+/* one word per live match position of every read (submapped reads included), in pileup order: what updateGermlineScoringMetrics
+ * accumulates (L/starling_common/starling_pos_processor_base.cpp:1346-1357, pos_basecall_buffer.cpp:43-70):
+ * base id | mapq << 3 | qscore << 11 | cycle << 18 | min(20, distance from read edge) << 29 | is_submapped << 34 */
+int64_t sko_pileup_reads_evs(const sko_read_batch* b, const sko_pileup_options* opt, int64_t* evs_off, uint64_t* evs_words, int64_t capacity);
 
 /* ---- GlobalAligner<int>::align (L/alignment/GlobalAlignerImpl.hh:35-228) ---- */
 typedef struct sko_align_scores { /* AlignmentScores<int>, L/alignment/AlignmentScores.hh */

@@ -126,7 +126,7 @@ class PileupWindow(C.Structure):
     _fields_ = [("begin", C.c_int32), ("end", C.c_int32), ("tier1_off", c_void_p), ("tier1_calls", c_void_p),
                 ("tier2_off", c_void_p), ("tier2_calls", c_void_p), ("spandel_count", c_void_p), ("submapped_count", c_void_p),
                 ("mapq_count", c_void_p), ("mapq_zero_count", c_void_p), ("mapq_sum_square", c_void_p),
-                ("clean_count", c_void_p), ("genotype", c_void_p)]
+                ("clean_count", c_void_p), ("genotype", c_void_p), ("evs_off", c_void_p), ("evs_words", c_void_p)]
 
 
 class SomaticPileupWindow(C.Structure):
@@ -199,7 +199,7 @@ EXPORTS = [
     "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
-    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push",
+    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push", "sk_pileup_stream_enable_evs_words",
     "sk_somatic_pileup_stream_create", "sk_somatic_pileup_stream_destroy", "sk_somatic_pileup_stream_begin_region", "sk_somatic_pileup_stream_push",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
@@ -960,9 +960,11 @@ class PileupStream:
     """sk_pileup_stream_*: one sample's pileup over a region, pushed window by window (row a8 chained into a9+a10).
     `library`: the ctypes handle to drive (default: the product library; the tests also drive the CPU double with it)."""
 
-    def __init__(self, opt, germline_opt=None, library=None):
+    def __init__(self, opt, germline_opt=None, library=None, evs_words=False):
         self.L = library or lib()
         L = self.L
+        self.evs_words = evs_words
+        L.sk_pileup_stream_enable_evs_words.argtypes = [c_void_p, C.c_int]
         L.sk_pileup_stream_create.restype = c_void_p
         L.sk_pileup_stream_create.argtypes = [C.POINTER(PileupOptions), c_void_p]
         L.sk_pileup_stream_destroy.argtypes = [c_void_p]
@@ -973,6 +975,8 @@ class PileupStream:
         self.genotype = germline_opt is not None
         self.h = L.sk_pileup_stream_create(C.byref(opt), C.byref(germline_opt) if self.genotype else None)
         if not self.h:
+            raise RuntimeError(L.sk_last_error().decode())
+        if evs_words and L.sk_pileup_stream_enable_evs_words(self.h, 1) != 0:
             raise RuntimeError(L.sk_last_error().decode())
 
     def close(self):
@@ -1028,7 +1032,9 @@ class PileupStream:
                     spandel=arr(w.spandel_count, np.uint32, n), submapped=arr(w.submapped_count, np.uint32, n),
                     mapq_count=arr(w.mapq_count, np.uint32, n), mapq_zero=arr(w.mapq_zero_count, np.uint32, n),
                     mapq_sumsq=arr(w.mapq_sum_square, np.uint64, n), clean_count=arr(w.clean_count, np.uint32, n),
-                    genotype=rec(w.genotype, DIGT_CALL_DTYPE, n) if self.genotype else None)
+                    genotype=rec(w.genotype, DIGT_CALL_DTYPE, n) if self.genotype else None,
+                    evs_off=arr(w.evs_off, np.int64, n + 1) if self.evs_words else None,
+                    evs_words=(arr(w.evs_words, np.uint64, int(arr(w.evs_off, np.int64, n + 1)[-1]) if n else 0) if self.evs_words else None))
 
 
 def _window_arrays(w, genotype_dtype=None):

@@ -81,6 +81,11 @@ struct PileupArgs
     const int64_t* call_off4;
     uint16_t* calls4;
     uint32_t* read_pos;     // [tier1 calls] read_pos | read_size << 16, or nullptr
+    // the germline EVS extension (template flag EVS): one word per live match position of every read -- submapped reads included --
+    // with what updateGermlineScoringMetrics accumulates (starling_pos_processor_base.cpp:1346-1357): base id | mapq << 3 |
+    // qscore << 11 | cycle << 18 | min(20, distance from the read edge) << 29 | is_submapped << 34; a locus has mapq_count of them
+    const int64_t* evs_off;
+    unsigned long long* evs_words;
 };
 
 __device__ __forceinline__ bool seg_match(const uint32_t t) { return t == SK_SEG_MATCH || t == SK_SEG_SEQ_MATCH || t == SK_SEG_SEQ_MISMATCH; }
@@ -571,10 +576,10 @@ __device__ __forceinline__ bool rec_selected(const unsigned rec, const int mode,
 
 // P2: one wave per 64 loci.  THREE = false: the column of a.mode; THREE = true: the raw tier1, raw tier2 and cleaned tier1 columns
 // (count3 / call_off3 / calls3, in that order) and the MAPQ tracker in the same walk over the records.
-template <bool THREE, bool SOM = false>
+template <bool THREE, bool SOM = false, bool EVS = false>
 __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs a)
 {
-    static_assert(THREE || !SOM, "the somatic columns extend the three-column form");
+    static_assert(THREE || !(SOM || EVS), "the somatic / EVS columns extend the three-column form");
     const int lane = threadIdx.x;
     const int l0 = blockIdx.x * WAVE;
     const int l = l0 + lane;
@@ -613,6 +618,8 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
     const int64_t base3 = (THREE && a.store && l < a.n_loci) ? a.call_off3[2][l] : 0;
     const int64_t base4a = (SOM && a.store && l < a.n_loci) ? a.call_off4[l] : 0;
     const int64_t base4b = (SOM && a.store && l < a.n_loci) ? base4a + int64_t(a.count4a[l]) : 0;
+    const int64_t base_e = (EVS && a.store && l < a.n_loci) ? a.evs_off[l] : 0;
+    unsigned cnt_e = 0;
     const int parts = (!THREE && a.mode == SK_PILEUP_CLEAN_TIER2) ? 2 : 1;
     const bool live = (l < a.n_loci);
     // store pass: the wave's 64 columns are one contiguous span of `calls`; it is assembled in LDS and written out with
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
             const int64_t so_k = have ? a.b.path_off[rk] : 0;
             const int nseg_k = have ? int(a.b.path_off[rk + 1] - so_k) : 0;
             const int mapq_k = (THREE && have) ? int(a.b.mapq[rk]) : 0;
-            const int len_k = (SOM && have) ? int(a.b.read_off[rk + 1] - ro_k) : 0;
+            const int len_k = ((SOM || EVS) && have) ? int(a.b.read_off[rk + 1] - ro_k) : 0;
             sk_path_seg g0 = { 0u, 0u }, g1 = { 0u, 0u }, g2 = { 0u, 0u };
             if (nseg_k >= 1) g0 = a.b.path[so_k];
             if (nseg_k >= 2) g1 = a.b.path[so_k + 1];
@@ -751,6 +758,29 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
                                     ++cnt4b;
                                 }
                             }
+                        }
+                        if (EVS && a.store && ((rc & REC_EMIT) || rc == REC_SUBLIVE)) {
+                            const int64_t ro_u = (int64_t(__builtin_amdgcn_readlane(int(ro_k >> 32), k0 + u)) << 32) |
+                                                 uint32_t(__builtin_amdgcn_readlane(int(ro_k & 0xffffffff), k0 + u));
+                            const unsigned len_u = unsigned(__builtin_amdgcn_readlane(len_k, k0 + u));
+                            const unsigned mq = unsigned(__builtin_amdgcn_readlane(mapq_k, k0 + u));
+                            const unsigned rp = unsigned(idx[u] - ro_u);
+                            const unsigned code = a.b.read_code[idx[u]];
+                            const unsigned id = code == SK_BAM_A ? 0u : code == SK_BAM_C ? 1u : code == SK_BAM_G ? 2u : code == SK_BAM_T ? 3u : 4u;
+                            const unsigned q0 = a.b.read_qual[idx[u]];
+                            const unsigned adj = mq < 5u ? 5u : mq; // pileup_read_segment :1181-1184
+                            const bool mapq_adjust = a.o.is_mapq_adjust && (adj <= 80u);
+                            const unsigned q = mapq_adjust ? unsigned(a.tab->mappedq[adj][q0 > 70u ? 70u : q0]) : q0;
+                            const bool sub = (rc == REC_SUBLIVE);
+                            const bool fwd = (rc >> 10) & 1u; // (a submapped position has no strand in its record; its cycle is never read)
+                            const unsigned cycle = fwd ? rp : (len_u - (rp + 1u));
+                            const unsigned edge = min(min(rp, len_u - (rp + 1u)), 20u);
+                            // (a submapped position only feeds the MAPQ rank sum: its other fields are left 0)
+                            a.evs_words[base_e + cnt_e] =
+                                sub ? ((unsigned long long)id | ((unsigned long long)mq << 3) | (1ull << 34))
+                                    : ((unsigned long long)id | ((unsigned long long)mq << 3) | ((unsigned long long)q << 11) |
+                                       ((unsigned long long)cycle << 18) | ((unsigned long long)edge << 29));
+                            ++cnt_e;
                         }
                         if (!a.store && ((rc & REC_EMIT) || rc == REC_SUBLIVE)) { // MapqTracker::add (L/blt_common/MapqTracker.hh:36-42)
                             const unsigned mq = unsigned(__builtin_amdgcn_readlane(mapq_k, k0 + u));
@@ -1129,7 +1159,7 @@ namespace
 
 struct InLay { int64_t read_off, path_off, path, pos, is_fwd, mapq, level, code, qual, ploidy, mask, total; };
 struct WorkLay { int64_t begin, end, maxend, minbegin, count0, count1, count2, count4, count4a, off2, off4, calls2, calls4, refbase, de, gscr, tmp, total; };
-struct OutLay { int64_t off0, off1, clean_n, clean4_n, mq_n, mq_zero, mq_sq, spandel, submapped, geno, calls0, calls1, read_pos, total; };
+struct OutLay { int64_t off0, off1, clean_n, clean4_n, mq_n, mq_zero, mq_sq, spandel, submapped, geno, calls0, calls1, read_pos, evs_off, evs, total; };
 
 } // namespace
 
@@ -1140,6 +1170,7 @@ struct sk_pileup_stream
     bool genotype = false;
     bool somatic = false;      // also build the CleanPileupFilter(pi, true) column (kept on the device)
     bool want_read_pos = false; // ... and return each tier1 call's read position / read length
+    bool want_evs = false;      // return the germline EVS words of every live call (sk_pileup_stream_enable_evs_words)
     // region
     bool has_region = false;
     int32_t ref_offset = 0, ref_len = 0;
@@ -1388,7 +1419,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         ol.off1 = o; o += align256(8 * (int64_t(n_loci) + 1));
         ol.clean_n = o; o += align256(4 * (int64_t(n_loci) + 1));
         ol.clean4_n = o; o += align256(som ? 4 * (int64_t(n_loci) + 1) : 0);
-        ol.mq_n = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
+        ol.mq_n = o; o += align256(4 * (int64_t(n_loci) + 1));
         ol.mq_zero = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
         ol.mq_sq = o; o += align256(8 * int64_t(std::max(n_loci, 1)));
         ol.spandel = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
@@ -1397,6 +1428,8 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         ol.calls0 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
         ol.calls1 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
         ol.read_pos = o; o += align256(s->want_read_pos ? 4 * std::max<int64_t>(n_bases, 1) : 0);
+        ol.evs_off = o; o += align256(s->want_evs ? 8 * (int64_t(n_loci) + 1) : 0);
+        ol.evs = o; o += align256(s->want_evs ? 8 * std::max<int64_t>(n_bases, 1) : 0);
         ol.total = o;
     }
     if (s->d_work.need(size_t(wl.total)) || s->d_out.need(size_t(ol.total)) || s->h_out.need(size_t(ol.total)))
@@ -1471,9 +1504,15 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         c.calls4 = reinterpret_cast<uint16_t*>(dw + wl.calls4);
         c.read_pos = s->want_read_pos ? reinterpret_cast<uint32_t*>(dout + ol.read_pos) : nullptr;
     }
+    if (s->want_evs) {
+        c.evs_off = reinterpret_cast<const int64_t*>(dout + ol.evs_off);
+        c.evs_words = reinterpret_cast<unsigned long long*>(dout + ol.evs);
+    }
     c.store = 0;
     const int blocks = (n_loci + 1 + WAVE - 1) / WAVE;
-    void (*const p2)(const PileupArgs) = som ? pileup_column_kernel_t<true, true> : pileup_column_kernel_t<true, false>;
+    void (*const p2)(const PileupArgs) = som ? pileup_column_kernel_t<true, true, false>
+                                             : (s->want_evs ? pileup_column_kernel_t<true, false, true> : pileup_column_kernel_t<true, false, false>);
+    if (s->want_evs) SK_HIP(hipMemsetAsync(c.mapq_count + n_loci, 0, 4, st)); // (the scan below reads n_loci + 1 counts)
     hipLaunchKernelGGL(p2, dim3(blocks), dim3(WAVE), 0, st, c);
     for (int m = 0; m < 3; ++m) {
         tmp_bytes = size_t(SL.tmp_bytes);
@@ -1483,6 +1522,11 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     if (som) {
         tmp_bytes = size_t(SL.tmp_bytes);
         SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, c.count4, const_cast<int64_t*>(c.call_off4), int64_t(0), size_t(n_loci) + 1,
+                                       rocprim::plus<int64_t>(), st));
+    }
+    if (s->want_evs) { // a locus has mapq_count words
+        tmp_bytes = size_t(SL.tmp_bytes);
+        SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, c.mapq_count, const_cast<int64_t*>(c.evs_off), int64_t(0), size_t(n_loci) + 1,
                                        rocprim::plus<int64_t>(), st));
     }
     c.store = 1;
@@ -1578,6 +1622,8 @@ void stream_finish(sk_pileup_stream* s, sk_pileup_window* out)
     out->mapq_sum_square = reinterpret_cast<const uint64_t*>(ho + ol.mq_sq);
     out->clean_count = reinterpret_cast<const uint32_t*>(ho + ol.clean_n);
     out->genotype = s->genotype ? reinterpret_cast<const sk_digt_call*>(ho + ol.geno) : nullptr;
+    out->evs_off = s->want_evs ? reinterpret_cast<const int64_t*>(ho + ol.evs_off) : nullptr;
+    out->evs_words = s->want_evs ? reinterpret_cast<const uint64_t*>(ho + ol.evs) : nullptr;
 }
 
 void stream_drop(sk_pileup_stream* s)
@@ -1609,6 +1655,14 @@ sk_pileup_stream* sk_pileup_stream_create(const sk_pileup_options* opt, const sk
         s->genotype = true;
     }
     return s;
+}
+
+int sk_pileup_stream_enable_evs_words(sk_pileup_stream* s, const int enable)
+{
+    if (!s) return sk_fail("sk_pileup_stream_enable_evs_words: null argument");
+    if (s->somatic) return sk_fail("sk_pileup_stream_enable_evs_words: a sample of a somatic stream (it returns read positions instead)");
+    s->want_evs = (enable != 0);
+    return 0;
 }
 
 void sk_pileup_stream_destroy(sk_pileup_stream* s)

@@ -47,12 +47,13 @@ def usable_cores():
 
 
 def germline_segment_argv(binary, out_prefix, bams, regions, ref, chrom_depth=None, ploidy_vcf=None, nocompress_bed=None,
-                          skip_header=False, extra=()):
+                          skip_header=False, extra=(), evs_models=None, report_evs_features=False):
     """The command line of one germline segment process as the workflow builds it: PY/strelkaGermlineWorkflow.py:81-147 +
     appendCommonGenomeSegmentCommandOptions (PY/strelkaSharedWorkflow.py:164-200): several --region per process (gsegGroup),
     --chrom-depth-file when the high-depth filter is on (WGS; :125-126), --ploidy-region-vcf (:131-132), --nocompress-bed
-    (:128-129), --gvcf-skip-header for every segment but the first (:120-121).  (No EVS model files: the reference tree lacks its
-    germline models, .MISSING_LARGE_BLOBS.)"""
+    (:128-129), --gvcf-skip-header for every segment but the first (:120-121).  evs_models = (SNV model, indel model): the
+    workflow's default passes --snv-scoring-model-file / --indel-scoring-model-file (:111-115); the reference tree does not carry
+    its germline models (they ship with the release packages), tools/make_dummy_germline_models.py writes small stand-ins."""
     cmd = [os.path.join(BIN_DIR, binary)]
     for r in regions:
         cmd += ["--region", r]
@@ -71,6 +72,10 @@ def germline_segment_argv(binary, out_prefix, bams, regions, ref, chrom_depth=No
     if ploidy_vcf:
         cmd += ["--ploidy-region-vcf", ploidy_vcf]
     cmd += ["--indel-error-models-file", os.path.join(MODEL_DIR, "indelErrorModel.json"), "--theta-file", os.path.join(MODEL_DIR, "theta.json")]
+    if evs_models:
+        cmd += ["--snv-scoring-model-file", evs_models[0], "--indel-scoring-model-file", evs_models[1]]
+    if report_evs_features:
+        cmd.append("--report-evs-features")
     return cmd + list(extra)
 
 

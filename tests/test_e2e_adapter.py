@@ -342,3 +342,58 @@ def test_candidate_indel_and_forced_output_vcfs_identical_cpu_double(tmp_path, w
                     reason="oracle/_ref binaries / synthetic inputs / tabix not built")
 def test_candidate_indel_and_forced_output_vcfs_identical_gpu(tmp_path):
     _synth_with_variant_inputs("amd", tmp_path)
+
+
+# ---- germline with EVS models (the workflow's default): the pileup's rank-sum accumulators rebuilt from the stream ------------------
+# The reference tree does not carry its germline models; tools/make_dummy_germline_models.py writes small ones whose trees split on
+# the read-position and mapping-quality rank sums.  With --report-evs-features every feature value is printed into the VCF.
+
+def _evs_models(tmp_path):
+    import subprocess
+    import sys
+    d = tmp_path / "models"
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "make_dummy_germline_models.py"), str(d)], check=True)
+    return str(d / "germlineSNVScoringModels.json"), str(d / "germlineIndelScoringModels.json")
+
+
+def _germline_evs(variant, tmp_path, extra_env=None, length=300000):
+    from strelka_amd import farm
+    d = E.wgs_dataset(length)
+    models = _evs_models(tmp_path)
+    outs = {}
+    for v in ("ref", variant):
+        o = tmp_path / v
+        o.mkdir()
+        argv = farm.germline_segment_argv("starling2_" + v, str(o) + "/", [os.path.join(d, "wgs.bam")], ["chrW:1-%d" % length],
+                                          os.path.join(d, "wgs.fa"), chrom_depth=os.path.join(d, "chrom_depth.txt"), evs_models=models,
+                                          report_evs_features=True)
+        env = {"STRELKA_AMD_VERBOSE": "1"}
+        env.update(extra_env or {})
+        p = E.run(argv, env=env if v != "ref" else None, timeout=1800)
+        outs[v] = ({f: E.vcf_body(str(o / f), keep_header=True) for f in ("variants.vcf", "genome.S1.vcf")}, p.stderr.decode())
+    want, got = outs["ref"][0], outs[variant][0]
+    records = [l for l in want["variants.vcf"] if not l.startswith("#")]
+    assert len(records) > 200 and all("EVSF=" in l for l in records if "\tPASS\t" in l or "LowGQX" in l)
+    # the rank-sum features are really there: not all zero
+    evsf = [l.split("EVSF=")[1].split(";")[0].split("\t")[0].split(",") for l in records if "EVSF=" in l and len(l.split("\t")[3]) == 1 and len(l.split("\t")[4]) == 1]
+    assert sum(1 for f in evsf if float(f[4]) != 0.0) > 50 and sum(1 for f in evsf if float(f[5]) != 0.0) > 50
+    for f in want:
+        assert got[f] == want[f], f
+    return _counters(outs[variant][1])
+
+
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("env", [None, {"STRELKA_AMD_PILEUP": "0"}, {"STRELKA_AMD_PILEUP_GENOTYPE": "0"}])
+def test_germline_with_evs_models_identical_through_adapter_cpu_double(tmp_path, env):
+    c = _germline_evs("dbl", tmp_path, extra_env=env)
+    if env and env.get("STRELKA_AMD_PILEUP") == "0":
+        assert c["pileup_pushes"] == 0
+    else:
+        assert c["pileup_pushes"] >= 10 and c["pileup_loci"] > 250000  # the stream ran although the EVS accumulators are wanted
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
+def test_germline_with_evs_models_identical_through_adapter_gpu(tmp_path):
+    c = _germline_evs("amd", tmp_path)
+    assert c["pileup_pushes"] >= 10 and c["pileup_genotyping"] == 1

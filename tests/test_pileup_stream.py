@@ -35,10 +35,10 @@ def _read_end(r):
     return r["pos"] + sum(l for t, l in r["path"] if t in (capi.SEG["MATCH"], capi.SEG["DELETE"]))
 
 
-def _run_stream(library, reads, ref, off, kw, cuts, mask=None, genotype=True, ploidy=None, region=None):
+def _run_stream(library, reads, ref, off, kw, cuts, mask=None, genotype=True, ploidy=None, region=None, evs_words=False):
     """push reads[cuts[i]:cuts[i+1]] one after the other; final_to = the lowest start of any later read"""
     opt = capi.pileup_options(**kw)
-    st = capi.PileupStream(opt, capi.germline_options() if genotype else None, library=library)
+    st = capi.PileupStream(opt, capi.germline_options() if genotype else None, library=library, evs_words=evs_words)
     rb, re = region or (kw["report_begin"], kw["report_end"])
     st.begin_region(ref, off, rb, re)
     wins = []
@@ -125,19 +125,34 @@ def _scenarios():
     return out
 
 
-def _run_all(library):
-    n_windows = n_loci = 0
+def _run_all(library, evs_words=False):
+    n_windows = n_loci = n_words = 0
     for reads, ref, off, kw, cuts, mask, ploidy in _scenarios():
         want = _expect(reads, ref, off, kw, mask)
-        wins = _run_stream(library, reads, ref, off, kw, cuts, mask=mask, ploidy=ploidy)
+        wins = _run_stream(library, reads, ref, off, kw, cuts, mask=mask, ploidy=ploidy, evs_words=evs_words)
         _compare(wins, want, ref, off, kw, ploidy=ploidy)
+        if evs_words:
+            # the germline EVS words: the one-shot restatement's, window by window; a position has mapq_count of them
+            rb = synth.ReadBatch.from_reads(reads, ref, off, cand_snv_mask=mask)
+            eo, ew = pyoracle.pileup_reads_evs(rb, pyoracle.pileup_options(**kw))
+            assert np.array_equal(np.diff(eo), want["mn"])
+            b0 = kw["report_begin"]
+            for w in wins:
+                b, e = w["begin"], w["end"]
+                assert np.array_equal(np.diff(w["evs_off"]), np.diff(eo[b - b0:e - b0 + 1])) and int(w["evs_off"][0]) == 0 if e > b else True
+                assert np.array_equal(w["evs_words"], ew[eo[b - b0]:eo[e - b0]])
+                n_words += len(w["evs_words"])
         n_windows += len(wins)
         n_loci += sum(w["end"] - w["begin"] for w in wins)
-    assert n_windows > 60 and n_loci > 5000
+    assert n_windows > 60 and n_loci > 5000 and (n_words > 100000 or not evs_words)
 
 
 def test_double_stream_equals_one_shot_restatement(built):
     _run_all(_double())
+
+
+def test_double_stream_with_evs_words(built):
+    _run_all(_double(), evs_words=True)
 
 
 def test_double_stream_rejects_a_read_behind_the_final_position(built):
@@ -156,6 +171,11 @@ def test_double_stream_rejects_a_read_behind_the_final_position(built):
 @pytest.mark.gpu
 def test_gpu_stream_equals_one_shot_restatement(gpu):
     _run_all(None)
+
+
+@pytest.mark.gpu
+def test_gpu_stream_with_evs_words(gpu):
+    _run_all(None, evs_words=True)
 
 
 @pytest.mark.gpu
