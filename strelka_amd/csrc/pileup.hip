@@ -1187,7 +1187,8 @@ struct sk_pileup_stream
     DevBuf d_rec[2], d_span[2];
     bool has_prev = false;
     int32_t next_begin = 0;
-    DevBuf d_in, d_work, d_out;
+    DevBuf d_in2[2], d_work, d_out; // (two input blocks used alternately: with want_evs the carried reads' bases and qualities are copied across)
+    int cur_in = 0;
     PinBuf h_in, h_out;
     int64_t pushes = 0, reads_in = 0;
     // the push in flight (stream_enqueue -> stream_finish)
@@ -1321,6 +1322,10 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     s->p_begin = begin; s->p_end = end; s->p_F = F;
 
     // ---- device input block: carried metadata + the new reads
+    const InLay prev_li = s->li;
+    const int prev_in = s->cur_in;
+    s->cur_in ^= 1;
+    DevBuf& d_in = s->d_in2[s->cur_in];
     InLay& li = s->li;
     {
         int64_t o = 0;
@@ -1337,7 +1342,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         li.mask = o; o += align256(std::max(mask_len, 1));
         li.total = o;
     }
-    if (s->h_in.need(size_t(li.total)) || s->d_in.need(size_t(li.total))) return sk_fail("sk_pileup_stream_push: out of memory (input block)");
+    if (s->h_in.need(size_t(li.total)) || d_in.need(size_t(li.total))) return sk_fail("sk_pileup_stream_push: out of memory (input block)");
     char* hi = static_cast<char*>(s->h_in.p);
     {
         int64_t* ro = reinterpret_cast<int64_t*>(hi + li.read_off);
@@ -1372,8 +1377,14 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         }
     }
     if (mask_len > 0) std::memcpy(hi + li.mask, cand_snv_mask, size_t(mask_len)); // (through the pinned block: a copy from the caller's pageable memory would wait for the device)
-    char* di = static_cast<char*>(s->d_in.p);
+    char* di = static_cast<char*>(d_in.p);
     SK_HIP(hipMemcpyAsync(di, hi, size_t(li.total), hipMemcpyHostToDevice, st));
+    if (s->want_evs && s->c_bases > 0) {
+        // the EVS words are made in P2 from the reads' bases and qualities: the carried reads' come over from the previous block
+        const char* dp = static_cast<const char*>(s->d_in2[prev_in].p);
+        SK_HIP(hipMemcpyAsync(di + li.code, dp + prev_li.code + s->c_tail_base, size_t(s->c_bases), hipMemcpyDeviceToDevice, st));
+        SK_HIP(hipMemcpyAsync(di + li.qual, dp + prev_li.qual + s->c_tail_base, size_t(s->c_bases), hipMemcpyDeviceToDevice, st));
+    }
     if (mask_len > 0)
         SK_HIP(hipMemcpyAsync(static_cast<char*>(s->d_mask.p) + (mask_begin - s->ref_offset), di + li.mask, size_t(mask_len), hipMemcpyDeviceToDevice, st));
 
@@ -1630,7 +1641,7 @@ void stream_drop(sk_pileup_stream* s)
 {
     s->d_ref.drop(); s->d_mask.drop(); s->d_spandel.drop(); s->d_submapped.drop();
     s->d_rec[0].drop(); s->d_rec[1].drop(); s->d_span[0].drop(); s->d_span[1].drop();
-    s->d_in.drop(); s->d_work.drop(); s->d_out.drop();
+    s->d_in2[0].drop(); s->d_in2[1].drop(); s->d_work.drop(); s->d_out.drop();
     s->h_in.drop(); s->h_out.drop();
 }
 

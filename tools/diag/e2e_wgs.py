@@ -19,17 +19,17 @@ def main():
     windows = [tuple(int(x) for x in w.split(":")) for w in (sys.argv[3] if len(sys.argv) > 3 else "2048:4096,16384:32768").split(",")]
     d = E.wgs_dataset(length)
     region = "chrW:1-%d" % length
-    extra = ()
+    evs_args = ()
     if os.environ.get("SK_E2E_EVS"):  # the workflow's default: EVS on (stand-in models, tools/make_dummy_germline_models.py)
         md = tempfile.mkdtemp(prefix="sk_models_")
         subprocess.run([sys.executable, "tools/make_dummy_germline_models.py", md], check=True)
-        extra = ("--snv-scoring-model-file", md + "/germlineSNVScoringModels.json", "--indel-scoring-model-file", md + "/germlineIndelScoringModels.json")
+        evs_args = ("--snv-scoring-model-file", md + "/germlineSNVScoringModels.json", "--indel-scoring-model-file", md + "/germlineIndelScoringModels.json")
 
     def run(binary, env=None):
         with tempfile.TemporaryDirectory() as o:
             t0 = time.perf_counter()
             p = E.run(E.germline_wgs_argv(binary, o + "/", [os.path.join(d, "wgs.bam")], [region], os.path.join(d, "wgs.fa"),
-                                          os.path.join(d, "chrom_depth.txt"), extra=extra), env=env, timeout=3600)
+                                          os.path.join(d, "chrom_depth.txt"), extra=evs_args), env=env, timeout=3600)
             dt = time.perf_counter() - t0
             body = {f: E.vcf_body(os.path.join(o, f), keep_header=True) for f in ("variants.vcf", "genome.S1.vcf")}
             return dt, body, [l for l in p.stderr.decode().splitlines() if "strelka_amd adapter" in l]
