@@ -38,7 +38,10 @@ def main():
     print("reference: %.2f s (%d variant records, %d gVCF lines)" % (t_ref, sum(1 for l in want["variants.vcf"] if l[0] != "#"),
                                                                      len(want["genome.S1.vcf"])), flush=True)
     for rw, sw in windows:
-        for label, extra in (("default", {}), ("device enumeration", {"SK_ENUMERATION": "2"}), ("reference pileup", {"STRELKA_AMD_PILEUP": "0"})):
+        legs = [("default", {}), ("device enumeration", {"SK_ENUMERATION": "2"})]
+        if sw > 0:  # (with the reference's pileup the genotypes are batched per site window: a window of 0 is one ABI call per position)
+            legs.append(("reference pileup", {"STRELKA_AMD_PILEUP": "0"}))
+        for label, extra in legs:
             env = {"STRELKA_AMD_VERBOSE": "1", "STRELKA_AMD_READ_WINDOW": str(rw), "STRELKA_AMD_SITE_WINDOW": str(sw)}
             env.update(extra)
             best = min((run("starling2_" + variant, env) for _ in range(2)), key=lambda x: x[0])
