@@ -12,6 +12,13 @@ from collections import defaultdict
 root = sys.argv[1]
 
 
+def full_size(values):
+    """the launches of a kernel's full-size leg: bench.py also launches several kernels at window size (the pileup stream, the
+    slice-sized feed, the whole-read jobs); a kernel's traffic per launch is quoted for its largest launches only"""
+    top = max(values)
+    return [v for v in values if v >= 0.5 * top] if top > 0 else values
+
+
 def collect(prefix):
     acc = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -32,6 +39,7 @@ def collect(prefix):
         w = acc["WRITE_SIZE"].get(k, [])
         if not f or not w:
             continue
+        f, w = full_size(f), full_size(w)
         fk, wk = sum(f) / len(f), sum(w) / len(w)
         res[k] = dict(launches=len(f), fetch_kib=fk, write_kib=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024,
                       hbm_bytes_uncorrected=(fk + wk) * 1024)
@@ -57,8 +65,10 @@ for k in sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"])):
     w = acc["WRITE_SIZE"].get(k, [])
     if not f or not w:
         continue
+    n_all = len(f)
+    f, w = full_size(f), full_size(w)
     fk, wk = sum(f) / len(f), sum(w) / len(w)
-    out[k] = dict(launches=len(f), fetch_kib=fk, write_kib=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024,
+    out[k] = dict(launches=len(f), launches_of_any_size=n_all, fetch_kib=fk, write_kib=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024,
                   hbm_bytes_uncorrected=(fk + wk) * 1024)
 # the per-launch workload these counters belong to: bench.py's defaults (tools/gpu_round.sh runs it without size flags);
 # bench.py only quotes `traffic` from this file when its own run has the same workload
