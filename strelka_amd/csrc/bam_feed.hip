@@ -199,16 +199,64 @@ struct Packed16
     }
 };
 
+// The symbols of a code, ordered by (length, value), in LDS: the 64 lanes' tables interleaved byte by byte (element i of lane l at
+// byte i * 64 + l: whatever the lanes' indices, consecutive lanes hit consecutive bytes), the low eight bits of a symbol in `lo`,
+// the ninth (literal/length symbols reach 285) as a bit of `hi`.  In private arrays these tables were 1.3 KB of scratch memory per
+// lane, 170 MB for a launch of 1.3e5 blocks -- far more than the L2 holds -- and every symbol look-up went to HBM for a whole line:
+// 138 GB of traffic for 6.3 GB of algorithmic bytes (profiles/r03_v23_pmc_traffic.json).
+struct SymTab
+{
+    uint8_t* lo;     // literal/length code: &lo_base[lane], element i at lo[i * 64]; nullptr = the distance code (registers only)
+    uint64_t hi[5];  // literal/length code: the symbols' ninth bits (LDS room for them would cost the eighth resident wave of a CU:
+                     // 288 x 64 bytes is 18 KB per wave, 8 waves = 144 of the CU's 160 KB); distance code: its 30 symbols, five
+                     // bits each, twelve to a register
+    __device__ void set(const int i, const int sym)
+    {
+        if (lo) {
+            lo[i * 64] = uint8_t(sym);
+            if (sym & 0x100) {
+                const uint64_t bit = 1ull << (i & 63);
+                const int j = i >> 6;
+                hi[0] |= (j == 0) ? bit : 0;
+                hi[1] |= (j == 1) ? bit : 0;
+                hi[2] |= (j == 2) ? bit : 0;
+                hi[3] |= (j == 3) ? bit : 0;
+                hi[4] |= (j == 4) ? bit : 0;
+            }
+        } else {
+            const int j = (i >= 24) ? 2 : (i >= 12) ? 1 : 0;
+            const uint64_t v = uint64_t(unsigned(sym) & 31u) << (5 * (i - 12 * j));
+            hi[0] |= (j == 0) ? v : 0;
+            hi[1] |= (j == 1) ? v : 0;
+            hi[2] |= (j == 2) ? v : 0;
+        }
+    }
+    __device__ int get(const int i) const
+    {
+        if (lo) {
+            const int v = lo[i * 64];
+            const int j = i >> 6;
+            const uint64_t word = (j == 0) ? hi[0] : (j == 1) ? hi[1] : (j == 2) ? hi[2] : (j == 3) ? hi[3] : hi[4];
+            return ((word >> (i & 63)) & 1ull) ? (v | 0x100) : v;
+        }
+        const int j = (i >= 24) ? 2 : (i >= 12) ? 1 : 0;
+        const uint64_t word = (j == 0) ? hi[0] : (j == 1) ? hi[1] : hi[2];
+        return int((word >> (5 * (i - 12 * j))) & 31ull);
+    }
+    __device__ void clear_hi(const int /*n*/) { hi[0] = hi[1] = hi[2] = hi[3] = hi[4] = 0; }
+};
+
 struct Huffman
 {
     Packed16 count; // [16] codes of each length
-    short* symbol;  // [n] symbols ordered by (length, value)
+    SymTab symbol;  // [n] symbols ordered by (length, value)
 };
 
 // returns the number of codes left unused (0 = complete, < 0 = over-subscribed), as zlib's / puff's construct
 __device__ int huff_construct(Huffman& h, const short* length, const int n)
 {
     h.count.clear();
+    h.symbol.clear_hi(n);
     for (int s = 0; s < n; ++s) h.count.add(length[s], 1u);
     if (int(h.count.get(0)) == n) return 0;
     int left = 1;
@@ -229,7 +277,7 @@ __device__ int huff_construct(Huffman& h, const short* length, const int n)
     for (int s = 0; s < n; ++s) {
         const int len = length[s];
         if (len != 0) {
-            h.symbol[offs.get(len)] = short(s);
+            h.symbol.set(int(offs.get(len)), s);
             offs.add(len, 1u);
         }
     }
@@ -264,7 +312,7 @@ __device__ int huff_decode(BitReader& br, const Huffman& h)
 #undef SK_HUFF_STEP
     if (len == 0) return -1;
     br.consume(len);
-    return h.symbol[si];
+    return h.symbol.get(si);
 }
 
 __device__ const short LEN_BASE[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
@@ -374,11 +422,13 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const InflateArgs a)
     br.buf = 0;
     br.cnt = 0;
     br.overrun = false;
-    short lensym[288], distsym[30];
+    __shared__ uint8_t s_len_lo[288 * 64];
     short lengths[320];
     Huffman lencode, distcode;
-    lencode.symbol = lensym;
-    distcode.symbol = distsym;
+    lencode.symbol.lo = s_len_lo + threadIdx.x;
+    lencode.symbol.clear_hi(0);
+    distcode.symbol.lo = nullptr;
+    distcode.symbol.clear_hi(0);
     int err = INF_OK, last = 0;
     do {
         last = int(br.bits(1));
