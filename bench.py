@@ -434,6 +434,20 @@ def main():
                           "kernel_ms": float(np.mean(a5_event_ms[-args.steps:]))}))
         return
 
+    if args.only == "feed":
+        fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "feed_tiny.bam")
+        with open(fixture, "rb") as f:
+            bgzf_image = np.frombuffer(f.read(), np.uint8)
+        n_fix_blocks = len(capi.bgzf_scan(bgzf_image)[0]) - 1
+        os.environ["SK_INFLATE_KERNEL"] = "thread"
+        dfeed = device.DeviceBgzfBatch(bgzf_image, dev, tile=max(1, args.feed_blocks // n_fix_blocks))
+        for _ in range(args.warmup + args.steps):
+            dfeed.inflate()
+        torch.cuda.synchronize()
+        assert int(dfeed.status.abs().sum().item()) == 0
+        print(json.dumps({"only": "feed", "blocks": dfeed.n_blocks, "algorithmic_bytes": dfeed.in_bytes + dfeed.out_bytes}))
+        return
+
     # ---- resident inputs (per rank: an independent batch, seeded by rank = an independent genome segment) ----
     rng = np.random.default_rng(1000 + rank)
     ua = min(args.unique_reads, args.reads)

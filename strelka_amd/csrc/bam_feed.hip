@@ -49,6 +49,7 @@ enum { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3,
 // byte-addressed data at any alignment in one memory instruction (the global address space takes unaligned dword accesses; a packed
 // struct tells the compiler so).  What a lane of the thread-per-block kernel costs is the NUMBER of its memory instructions -- its
 // 64 lanes are 64 different streams, every access is 64 separate cache lines -- so bytes are moved 8 / 4 / 2 / 1 at a time.
+struct __attribute__((packed)) U128u { uint32_t a, b, c, d; };
 struct __attribute__((packed)) U64u { uint64_t v; };
 struct __attribute__((packed)) U32u { uint32_t v; };
 struct __attribute__((packed)) U16u { uint16_t v; };
@@ -124,12 +125,32 @@ struct BitReader
     uint64_t buf;
     int cnt;
     bool overrun;
+    // Sixteen input bytes at a time in registers.  A lane's input line does not survive in the L2 between two of its refills (1.3e5
+    // lanes each walk their own line), so every 4-byte refill from memory fetched a whole line again: 24 GB of fetches per 1.3e5
+    // blocks whose compressed bytes are 1.4 GB (profiles/r03_v24_pmc_traffic.json).  One unaligned 16-byte load feeds four refills.
+    uint32_t res[4];
+    const uint8_t* res_at; // the address res[] was loaded from, or nullptr
+    __device__ uint32_t next_dword()
+    {
+        if (!(res_at && p >= res_at && p + 4 <= res_at + 16 && ((p - res_at) & 3) == 0)) {
+            if (p + 16 <= end) {
+                const U128u v = *reinterpret_cast<const U128u*>(p);
+                res[0] = v.a; res[1] = v.b; res[2] = v.c; res[3] = v.d;
+                res_at = p;
+            } else {
+                res_at = nullptr;
+                return ld_u32(p);
+            }
+        }
+        const int j = int(p - res_at) >> 2;
+        return (j == 0) ? res[0] : (j == 1) ? res[1] : (j == 2) ? res[2] : res[3];
+    }
     // top the buffer up to at least 25 bits where the input has them (four independent byte loads and one wait when there is room
     // for four bytes); bits past the end of the input read as 0 and are only an error when a code or a field consumes them
     __device__ void refill()
     {
         if (cnt <= 32 && p + 4 <= end) {
-            buf |= uint64_t(ld_u32(p)) << cnt;
+            buf |= uint64_t(next_dword()) << cnt;
             cnt += 32;
             p += 4;
             return;
@@ -422,6 +443,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const InflateArgs a)
     br.buf = 0;
     br.cnt = 0;
     br.overrun = false;
+    br.res_at = nullptr;
     __shared__ uint8_t s_len_lo[288 * 64];
     short lengths[320];
     Huffman lencode, distcode;
