@@ -397,3 +397,37 @@ def test_germline_with_evs_models_identical_through_adapter_cpu_double(tmp_path,
 def test_germline_with_evs_models_identical_through_adapter_gpu(tmp_path):
     c = _germline_evs("amd", tmp_path)
     assert c["pileup_pushes"] >= 10 and c["pileup_genotyping"] == 1
+
+
+def _two_sample_evs(variant, tmp_path, which):
+    """two germline samples called jointly with EVS models (no feature report: the reference allows that for one sample only); the dense
+    synthetic sets: indel clusters, MAPQ tiers, a coverage gap, long reads"""
+    d, length = SYNTH_SETS[which]
+    models = _evs_models(tmp_path)
+    outs = {}
+    for v in ("ref", variant):
+        o = str(tmp_path / v) + "/"
+        os.makedirs(o, exist_ok=True)
+        p = E.run(E.germline_argv("starling2_" + v, o, [os.path.join(d, "germline_S1.bam"), os.path.join(d, "germline_S2.bam")],
+                                  region="chrS:1-%d" % length, ref=os.path.join(d, "synth.fa"),
+                                  extra=["--snv-scoring-model-file", models[0], "--indel-scoring-model-file", models[1]]),
+                  env={"STRELKA_AMD_VERBOSE": "1"} if v != "ref" else None)
+        outs[v] = ({f: E.vcf_body(o + f, keep_header=True) for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf")}, p.stderr.decode())
+    assert len(outs["ref"][0]["variants.vcf"]) > 100
+    for f in outs["ref"][0]:
+        assert outs[variant][0][f] == outs["ref"][0][f], f
+    c = _counters(outs[variant][1])
+    assert c["pileup_pushes"] >= 4 and c["pileup_genotyping"] == 1
+
+
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
+@pytest.mark.parametrize("which", ["short_reads", "long_reads"])
+def test_two_sample_germline_with_evs_models_cpu_double(tmp_path, which):
+    _two_sample_evs("dbl", tmp_path, which)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_amd") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
+@pytest.mark.parametrize("which", ["short_reads", "long_reads"])
+def test_two_sample_germline_with_evs_models_gpu(tmp_path, which):
+    _two_sample_evs("amd", tmp_path, which)

@@ -51,13 +51,13 @@ def _groups():
     return groups
 
 
-def _run(binary, tmp, data, jobs, n_gpus=1, env=None):
+def _run(binary, tmp, data, jobs, n_gpus=1, env=None, evs_models=None):
     d, ploidy, bed = data
 
     def argv(index, regions, prefix, skip_header):
         return farm.germline_segment_argv(binary, prefix, [os.path.join(d, "wgs.bam")], regions, os.path.join(d, "wgs.fa"),
                                           chrom_depth=os.path.join(d, "chrom_depth.txt"), ploidy_vcf=ploidy, nocompress_bed=bed,
-                                          skip_header=skip_header)
+                                          skip_header=skip_header, evs_models=evs_models, report_evs_features=bool(evs_models))
     return farm.run_farm(_groups(), argv, str(tmp), OUTPUTS, n_gpus=n_gpus, jobs=jobs, env=env)
 
 
@@ -90,6 +90,26 @@ def test_farm_with_wgs_flags_identical_through_adapter_cpu_double(tmp_path, tmp_
             assert _body(got.outputs[n]) == want[n], (jobs, n)
         assert len(got.process_s) == len(_groups())
         assert all("pileup: pushes=" in t and "genotyping=1" in t for t in got.stderr_tails)
+
+
+@pytest.mark.skipif(not _have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_farm_with_wgs_flags_and_evs_models_identical_cpu_double(tmp_path, tmp_path_factory):
+    """the same farm with the workflow's default scoring (EVS models on the command line; stand-in models, every feature printed):
+    several regions per process, haploid and ploidy-0 stretches, the rank sums rebuilt from the stream per region"""
+    import subprocess
+    import sys
+    data = _dataset(tmp_path_factory)
+    md = tmp_path / "models"
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "make_dummy_germline_models.py"),
+                    str(md)], check=True)
+    models = (str(md / "germlineSNVScoringModels.json"), str(md / "germlineIndelScoringModels.json"))
+    ref = _run("starling2_ref", tmp_path / "ref", data, jobs=4, evs_models=models)
+    want = {n: _body(ref.outputs[n]) for n in OUTPUTS}
+    assert sum(1 for l in want["variants.vcf"] if "EVSF=" in l) > 300
+    got = _run("starling2_dbl", tmp_path / "dbl", data, jobs=4, env={"STRELKA_AMD_VERBOSE": "1"}, evs_models=models)
+    for n in OUTPUTS:
+        assert _body(got.outputs[n]) == want[n], n
+    assert all("pileup: pushes=" in t and "genotyping=1" in t for t in got.stderr_tails)
 
 
 @pytest.mark.gpu
