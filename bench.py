@@ -85,13 +85,17 @@ def cpu_baseline(args):
                 "loci_per_s": r["loci_per_s"], "loci_per_s_per_core": r["loci_per_s_per_core"],
                 "somatic_loci_per_s": r["somatic_loci_per_s"], "somatic_loci_per_s_per_core": r["somatic_loci_per_s_per_core"],
                 "realign_reads_per_s": r["reads_per_s"], "realign_reads_per_s_per_core": r["reads_per_s_per_core"],
+                "realign_dense_reads_per_s": r["reads_dense_per_s"], "realign_dense_reads_per_s_per_core": r["reads_dense_per_s_per_core"],
                 "one_process_alone": {"cells_per_s": r["cells_per_s_one_process"], "loci_per_s": r["loci_per_s_one_process"],
                                       "somatic_loci_per_s": r["somatic_loci_per_s_one_process"],
-                                      "realign_reads_per_s": r["reads_per_s_one_process"]},
+                                      "realign_reads_per_s": r["reads_per_s_one_process"],
+                                      "realign_dense_reads_per_s": r["reads_dense_per_s_one_process"]},
                 "sample": "the reference's own translation units (oracle/_ref), %d processes pinned to %d cores, %.0f s per leg, "
                           "inputs pre-materialised in the reference's structs, only its compute calls inside the clock: "
                           "scoreCandidateAlignment on 48 reads x 64 candidate alignments x 150 bp per process (cells/s); "
-                          "realignAndScoreRead on 144 reads of synth.realign_scenarios per process (reads/s); adjust_joint_eprob + "
+                          "realignAndScoreRead on the scenarios of the whole-read legs themselves (default_rng(4242), 24 scenarios x 12 "
+                          "reads, up to 6 candidate indels around a read; realign_dense_*: up to 14), every process the same ones "
+                          "(reads/s); adjust_joint_eprob + "
                           "position_snp_call_pprob_digt on 20000 loci depth~Poisson(40) per process (loci/s); "
                           "position_somatic_snv_call on 20000 loci 40x+110x per process (somatic loci/s); rates summed over the "
                           "processes, *_per_core = that sum / cores; one_process_alone = the same legs with a single process on the otherwise idle "

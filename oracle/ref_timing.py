@@ -91,10 +91,10 @@ def _time_scoring(L, seconds, rng, n_reads):
     return cells, secs
 
 
-def _time_realign(L, seconds, rng, n_scenarios):
+def _time_realign(L, seconds, rng, n_scenarios, max_indels=6):
     from oracle import pyoracle
     from strelka_amd import synth
-    scenarios = synth.realign_scenarios(n_scenarios, rng, reads_per=12)
+    scenarios = synth.realign_scenarios(n_scenarios, rng, reads_per=12, max_indels=max_indels)
     sessions = []
     for sc in scenarios:
         s = L.ref_session_create(sc["ref_seq"].encode(), int(sc["ref_offset"]), 0)
@@ -177,7 +177,10 @@ def _worker(job):
     rng = np.random.default_rng(seed)
     out = {}
     out["cells"] = _time_scoring(L, seconds, rng, 48)
-    out["reads"] = _time_realign(L, seconds, rng, 12)
+    # the scenarios of bench.py's whole-read legs themselves (whole_read_leg: default_rng(4242), 24 scenarios x 12 reads, up to 6
+    # candidate indels around a read; "dense": up to 14), the same in every process
+    out["reads"] = _time_realign(L, seconds, np.random.default_rng(4242), 24, max_indels=6)
+    out["reads_dense"] = _time_realign(L, seconds, np.random.default_rng(4242), 24, max_indels=14)
     out["loci"] = _time_loci(L, seconds, rng, 20000)
     out["somatic_loci"] = _time_somatic(L, seconds, rng, 20000)
     return out
@@ -213,7 +216,7 @@ def _run(cores, seconds):
         return pool.map(_worker, [(c, seconds, 7000 + i) for i, c in enumerate(cores)])
 
 
-LEGS = ("cells", "reads", "loci", "somatic_loci")
+LEGS = ("cells", "reads", "reads_dense", "loci", "somatic_loci")
 
 
 def reference_baseline(seconds_per_leg=5.0, processes=None):
