@@ -697,6 +697,13 @@ def main():
         "roofline_loci": roof("germline_site_fused_kernel", alg_bytes_b, kms_b, traffic.get("germline_site_fused_kernel")),
     }
     out.update(wr)
+    out["roofline_global_align"]["note"] = ("latency-bound integer DP; its traffic is the back-pointer matrix (one byte per cell in global "
+                                            "scratch, written by the sweep and read back by the traceback), not the sequences the formula "
+                                            "prices: frac says nothing here")
+    out["roofline_feed"]["note"] = ("a serial bit stream per block: the traffic is the matches' sources (a lane's 32 KB window, 1.3e5 lanes) "
+                                    "and its partial-line stores, DESIGN.md section 3 B1")
+    out["roofline"]["note"] = ("flattening + scoring of one job; `traffic` from the --only a5 counter passes (tools/gpu_round.sh); the table sums "
+                               "alone are roofline_sum_only")
     out["e2e"] = e2e
     out["e2e_somatic"] = e2e_somatic
     if rank == 0:
