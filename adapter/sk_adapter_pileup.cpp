@@ -581,6 +581,12 @@ void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos)
     if (! ps.enabled) return;
     if (ps.isSomatic)
     {
+        // (chunks kept only for the EVS read positions -- the records are computed per site window -- are dropped here; when the
+        // records come with the stream, site 5 drops them as it passes)
+        if (! ps.isGenotyping)
+        {
+            while ((! ps.somaticChunks.empty()) && ps.somaticChunks.front().end <= pos) ps.somaticChunks.pop_front();
+        }
         if (pos < ps.nextFinal[0]) return;
         if (! ps.isFlushing) throw blt_exception("strelka_amd adapter: the POST_ALIGN stage reached a position whose pileup is not final");
         AccumTimer hookTimer(s.tPileupHook);
