@@ -126,11 +126,31 @@ void gatherWindow(starling_pos_processor_base& pp, const unsigned sampleIndex, c
         const unsigned spanThen(static_cast<unsigned>(s.geometry.query(pos).rangeMinOffset) + 1);
         if (refSpan > (readSize + spanThen)) continue;
 
-        const bam_seq bseq(rseg.get_bam_read());
         const size_t c0(wb.code.size());
         wb.code.resize(c0 + readSize);
-        for (unsigned i(0); i < readSize; ++i) wb.code[c0 + i] = bseq.bam_seq::get_code(static_cast<pos_t>(i)); // (qualified: no virtual dispatch)
         const uint8_t* q(rseg.qual());
+        if (rseg.full_read_offset() == 0)
+        {
+            // the BAM record's packed bases sit right before its qualities (bam_get_qual = bam_get_seq + (l_qseq + 1) / 2): two codes per
+            // byte, unpacked a byte at a time (bam_seq::get_code: high nibble first)
+            static uint16_t pairOf[256];
+            static bool isPairTable(false);
+            if (! isPairTable)
+            {
+                for (unsigned b(0); b < 256; ++b) pairOf[b] = static_cast<uint16_t>((b >> 4) | ((b & 15u) << 8));
+                isPairTable = true;
+            }
+            const uint8_t* packed(q - ((rseg.full_read_size() + 1) >> 1));
+            uint8_t* dst(wb.code.data() + c0);
+            unsigned i(0);
+            for (; i + 2 <= readSize; i += 2) std::memcpy(dst + i, &pairOf[packed[i >> 1]], 2);
+            if (i < readSize) dst[i] = static_cast<uint8_t>(packed[i >> 1] >> 4);
+        }
+        else
+        {
+            const bam_seq bseq(rseg.get_bam_read());
+            for (unsigned i(0); i < readSize; ++i) wb.code[c0 + i] = bseq.bam_seq::get_code(static_cast<pos_t>(i)); // (qualified: no virtual dispatch)
+        }
         wb.qual.insert(wb.qual.end(), q, q + readSize);
         for (const auto& seg : best->path)
         {
