@@ -144,6 +144,8 @@ HOOKS = [
     ]),
     (L + "starling_common/starling_pos_processor_indel_util.cpp", [
         ("include", r'#include "starling_pos_processor_indel_util.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        ("get_valid_alignment_range", r'    get_valid_alignment_range\(al,ref_bseq,read_seq,valid_pr\);\n',
+         '    sk_adapter::valid_alignment_range(al, ref, read_seq, valid_pr);\n'),
         # the active-region detector's per-base bookkeeping of an aligned segment, in one call
         ("active-region match/mismatch loop",
          r'(            // detect active regions \(match/mismatch\)\n)            for \(unsigned j\(0\); j < ps\.length; \+\+j\)\n            \{\n(?:.*\n)*?            \}\n(        \}\n\n        for \(unsigned i\(0\); i<n_seg; \+\+i\))',

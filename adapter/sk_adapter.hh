@@ -42,6 +42,7 @@ struct IndelKey;
 struct alignment;
 class ActiveRegionReadBuffer;
 struct bam_seq_base;
+struct pos_range;
 
 namespace sk_adapter
 {
@@ -114,6 +115,10 @@ void somatic_indel(const strelka_options& opt, const starling_sample_options& no
 /// ActiveRegionDetector::clearReadBuffer at the position the UNDEFERRED READ_BUFFER stage would be at while HEAD is at `headStagePos`
 void clear_active_region_read_buffer_undeferred(starling_pos_processor_base& pp, const pos_t headStagePos, const unsigned readBufferShift,
                                                 const pos_t minPos);
+
+/// get_valid_alignment_range (starling_read_util.cpp:218-329) at starling_pos_processor_indel_util.cpp:335, without its per-read
+/// allocations and virtual base look-ups (host work, the same arithmetic)
+void valid_alignment_range(const alignment& al, const reference_contig_segment& ref, const bam_seq_base& readSeq, pos_range& validRange);
 
 /// the match / mismatch bookkeeping of one aligned segment of an input read (starling_pos_processor_indel_util.cpp:463-483), in one call
 void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const unsigned alignId, const reference_contig_segment& ref,

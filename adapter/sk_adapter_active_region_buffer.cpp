@@ -32,8 +32,97 @@
 
 #include "sk_adapter.hh"
 
+#include "blt_util/blt_exception.hh"
+#include "blt_util/pos_range.hh"
+#include "starling_common/alignment.hh"
+
+#include <sstream>
+
 namespace sk_adapter
 {
+
+// get_valid_alignment_range (L/starling_common/starling_read_util.cpp:218-329), called for every input read at
+// starling_pos_processor_indel_util.cpp:335: the same scores, sums and tie rules, with the two per-read vectors kept between calls
+// and the base look-ups made without virtual dispatch (the read is a bam_seq, the reference the contig segment itself).
+void valid_alignment_range(const alignment& al, const reference_contig_segment& ref, const bam_seq_base& readSeq, pos_range& validRange)
+{
+    static const int matchScore(2), mismatchScore(-5), minSegmentScore(-11);
+    const bam_seq* packed(dynamic_cast<const bam_seq*>(&readSeq));
+    const unsigned readSize(readSeq.size());
+    static std::vector<int> fwdScore, revScore;
+    fwdScore.assign(readSize, 0);
+    revScore.assign(readSize, 0);
+    pos_t refHeadPos(al.pos);
+    unsigned readHeadPos(0);
+    using namespace ALIGNPATH;
+    for (const path_segment& ps : al.path)
+    {
+        if ((ps.type == INSERT) || (ps.type == SOFT_CLIP))
+        {
+            if (ps.type == INSERT)
+            {
+                fwdScore[readHeadPos] += mismatchScore;
+                revScore[readHeadPos + ps.length - 1] += mismatchScore;
+            }
+            readHeadPos += ps.length;
+        }
+        else if (ps.type == DELETE)
+        {
+            if (readHeadPos > 0) fwdScore[readHeadPos - 1] += mismatchScore;       // (leading deletions do not count)
+            if (readHeadPos < readSize) revScore[readHeadPos] += mismatchScore;    // (nor trailing ones)
+            refHeadPos += ps.length;
+        }
+        else if (is_segment_align_match(ps.type))
+        {
+            for (unsigned j(0); j < ps.length; ++j)
+            {
+                const unsigned readPos(readHeadPos + j);
+                const char readChar(packed ? packed->bam_seq::get_char(static_cast<pos_t>(readPos)) : readSeq.get_char(static_cast<pos_t>(readPos)));
+                const char refChar(ref.get_base(refHeadPos + static_cast<pos_t>(j)));
+                if ((readChar != 'N') && (refChar != 'N'))
+                {
+                    const int v((readChar != refChar) ? mismatchScore : matchScore);
+                    fwdScore[readPos] += v;
+                    revScore[readPos] += v;
+                }
+            }
+            readHeadPos += ps.length;
+            refHeadPos += ps.length;
+        }
+        else if (ps.type == HARD_CLIP)
+        {
+        }
+        else
+        {
+            std::ostringstream oss;
+            oss << "Can't handle cigar code: " << segment_type_to_cigar_code(ps.type) << "\n";
+            throw blt_exception(oss.str().c_str());
+        }
+    }
+    validRange.set_begin_pos(0);
+    validRange.set_end_pos(readSize);
+    int fwdSum(0), fwdMin(minSegmentScore), revSum(0), revMin(minSegmentScore);
+    for (unsigned i(0); i < readSize; ++i)
+    {
+        fwdSum += fwdScore[i];
+        if (fwdSum <= fwdMin)
+        {
+            validRange.begin_pos = i + 1;
+            fwdMin = fwdSum;
+        }
+        revSum += revScore[readSize - i - 1];
+        if (revSum <= revMin)
+        {
+            validRange.end_pos = readSize - i - 1;
+            revMin = revSum;
+        }
+    }
+    if (validRange.end_pos <= validRange.begin_pos)
+    {
+        validRange.begin_pos = 0;
+        validRange.end_pos = 0;
+    }
+}
 
 void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const unsigned alignId, const reference_contig_segment& ref,
                                           const bam_seq_base& readSeq, const unsigned readOffset, const pos_t refHeadPos, const unsigned length)
