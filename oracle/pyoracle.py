@@ -620,19 +620,41 @@ def pileup_reads_evs(rb, opt):
     return off, words[:n].copy()
 
 
+def ref_germline_metrics(words, ref_base_id):
+    """The REFERENCE's rank-sum / mean accumulators (snp_pos_info) fed with the observations one position's EVS words spell out
+    (the unpacking of adapter/sk_adapter_pileup.cpp germline_fill_scoring_metrics) -> the six numbers of
+    ref_pileup_pipeline(germline_metrics=True)'s `evs`."""
+    L = ref()
+    L.ref_germline_metrics_from_observations.argtypes = [C.c_int] + [vp] * 7
+    w = np.ascontiguousarray(words, np.uint64)
+    is_ref = ((w & 7) == ref_base_id).astype(np.uint8)
+    mapq = ((w >> 3) & 0xff).astype(np.uint8)
+    q = ((w >> 11) & 0x7f).astype(np.uint8)
+    cycle = ((w >> 18) & 0x7ff).astype(np.uint16)
+    edge = ((w >> 29) & 0x1f).astype(np.uint8)
+    sub = ((w >> 34) & 1).astype(np.uint8)
+    out = np.zeros(6, np.float64)
+    L.ref_germline_metrics_from_observations(len(w), _p(is_ref), _p(mapq), _p(q), _p(cycle), _p(edge), _p(sub), _p(out))
+    return out
+
+
 def mapped_qscore_table():
     L = oracle()
     return np.array([[L.sko_mapped_qscore(q, m) for q in range(71)] for m in range(91)], np.int32)
 
 
-def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=(), return_indels=False):
+def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=(), return_indels=False, germline_metrics=False):
     """The REFERENCE's position processor end to end (oracle/ref/ref_driver_pileup.cpp): reads (dicts as produced by
     synth.pileup_reads, position-sorted) -> read buffer -> realignment -> pileup.
     Returns (finals, columns): finals = per piled read, in pileup order, dict(read_id = index into `reads`, is_realigned,
     pos, is_fwd, cigar, skipped, input_pos, input_cigar, realign_range); columns = {pos: dict(calls, tier2_calls, spandel,
     submapped)}.  With return_indels=True a third value lists the IndelBuffer as the realigner saw it:
-    dict(pos, type, del_len, ins_seq, is_candidate, r2i, i2r (log error rates), read_ids = indices into `reads`)."""
+    dict(pos, type, del_len, ins_seq, is_candidate, r2i, i2r (log error rates), read_ids = indices into `reads`).
+    With germline_metrics=True the session accumulates the germline EVS metrics (updateGermlineScoringMetrics) and every column
+    also holds evs = (MQRankSum, BaseQRankSum, ReadPosRankSum, rawPos, avgBaseQ, meanDistanceFromReadEdge) and mapq_count."""
     L = ref()
+    L.refpp_set_germline_metrics.argtypes = [C.c_int]
+    L.refpp_column_evs.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_uint32)]
     L.refpp_create.restype = vp
     L.refpp_create.argtypes = [C.c_char_p] + [C.c_int] * 10
     L.refpp_destroy.argtypes = [vp]
@@ -651,9 +673,13 @@ def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=(), re
     L.refpp_indel.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_char_p, C.c_int,
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
                               C.POINTER(C.c_double), vp, C.c_int]
-    s = L.refpp_create(ref_seq.encode(), ref_offset, opt.report_begin, opt.report_end, opt.min_basecall_qscore,
-                       opt.mismatch_density_flank_size, opt.mismatch_density_max_count, opt.use_tier2_evidence,
-                       opt.tier2_mismatch_density_max_count, opt.is_mapq_adjust, opt.min_distance_from_read_edge)
+    L.refpp_set_germline_metrics(int(germline_metrics))
+    try:
+        s = L.refpp_create(ref_seq.encode(), ref_offset, opt.report_begin, opt.report_end, opt.min_basecall_qscore,
+                           opt.mismatch_density_flank_size, opt.mismatch_density_max_count, opt.use_tier2_evidence,
+                           opt.tier2_mismatch_density_max_count, opt.is_mapq_adjust, opt.min_distance_from_read_edge)
+    finally:
+        L.refpp_set_germline_metrics(0)
     if not s:
         raise RuntimeError("refpp_create failed")
     try:
@@ -697,6 +723,10 @@ def ref_pileup_pipeline(reads, ref_seq, ref_offset, opt, candidate_indels=(), re
             L.refpp_column_calls(s, i, _p(calls), _p(t2))
             cols[pos.value] = dict(calls=calls[:n.value].copy(), tier2_calls=t2[:n2.value].copy(), spandel=sd.value,
                                    submapped=sm.value)
+            if germline_metrics:
+                evs, mc = np.zeros(6, np.float64), C.c_uint32()
+                L.refpp_column_evs(s, i, _p(evs), mc)
+                cols[pos.value].update(evs=evs, mapq_count=mc.value)
         if not return_indels:
             return finals, cols
         indels = []

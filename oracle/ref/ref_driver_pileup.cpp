@@ -14,7 +14,8 @@
 #include "starling_common/starling_pos_processor_base.hh"
 #include "starling_common/starling_pos_processor_base_stages.hh"
 #include "starling_common/starling_streams_base.hh"
-#include "test/starling_base_options_test.hh"
+#include "options/AlignmentFileOptions.hh"
+#include "starling_common/starling_base_shared.hh"
 
 #include <cstring>
 #include <map>
@@ -31,6 +32,10 @@ struct Column
     int32_t pos;
     std::vector<uint16_t> calls, tier2_calls;
     uint32_t spandel, submapped;
+    // with the germline EVS accumulators switched on (updateGermlineScoringMetrics): what the reference derives from them
+    // (snp_pos_info::get_mq_ranksum / get_baseq_ranksum / get_read_pos_ranksum / get_raw_pos / get_raw_baseQ, distanceFromReadEdge)
+    double evs[6];
+    uint32_t mapq_count;
 };
 
 struct FinalAlignment
@@ -101,6 +106,13 @@ struct PP : public starling_pos_processor_base
         }
         c.spandel = pi.spanningDeletionReadCount;
         c.submapped = pi.submappedReadCount;
+        c.evs[0] = pi.get_mq_ranksum();
+        c.evs[1] = pi.get_baseq_ranksum();
+        c.evs[2] = pi.get_read_pos_ranksum();
+        c.evs[3] = pi.get_raw_pos();
+        c.evs[4] = pi.get_raw_baseQ();
+        c.evs[5] = pi.distanceFromReadEdge.mean();
+        c.mapq_count = pi.mapqTracker.count;
         if (!(c.calls.empty() && c.tier2_calls.empty() && c.spandel == 0 && c.submapped == 0)) columns.push_back(c);
 
     }
@@ -198,9 +210,25 @@ struct PP : public starling_pos_processor_base
     std::vector<DumpIndel> indels;
 };
 
+/// the test options with the germline EVS accumulators on demand (starling_options::is_compute_germline_scoring_metrics is true when
+/// scoring models are loaded or --report-evs-features is given, L/applications/starling/starling_shared.hh:70)
+struct DriverOptions : public starling_base_options
+{
+    bool isGermlineMetrics = false;
+    bool is_compute_germline_scoring_metrics() const override { return isGermlineMetrics; }
+    const AlignmentFileOptions& getAlignmentFileOptions() const override // (as L/test/starling_base_options_test.hh, which is final)
+    {
+        static AlignmentFileOptions alignFileOpt;
+        if (alignFileOpt.alignmentFilenames.empty()) alignFileOpt.alignmentFilenames.push_back("sample.bam");
+        return alignFileOpt;
+    }
+};
+
+bool g_germline_metrics = false;
+
 struct Session
 {
-    starling_base_options_test opt;
+    DriverOptions opt;
     std::unique_ptr<starling_base_deriv_options> dopt;
     reference_contig_segment ref;
     std::unique_ptr<Streams> streams;
@@ -224,6 +252,7 @@ void* refpp_create(const char* ref_seq, int ref_offset, int report_begin, int re
 {
     try {
         Session* s = new Session();
+        s->opt.isGermlineMetrics = g_germline_metrics;
         s->opt.isHaplotypingEnabled = false;
         s->opt.minBasecallErrorPhredProb = min_basecall_qscore;
         s->opt.mismatchDensityFilterFlankSize = mdf_flank;
@@ -327,6 +356,43 @@ int refpp_column_calls(void* p, int i, uint16_t* calls, uint16_t* tier2_calls)
     const Column& c(static_cast<Session*>(p)->pp->columns[i]);
     if (!c.calls.empty()) std::memcpy(calls, c.calls.data(), 2 * c.calls.size());
     if (!c.tier2_calls.empty()) std::memcpy(tier2_calls, c.tier2_calls.data(), 2 * c.tier2_calls.size());
+    return 0;
+}
+
+/// sessions created from now on accumulate the germline EVS metrics in their pileups (0 / 1)
+void refpp_set_germline_metrics(int on) { g_germline_metrics = (on != 0); }
+
+/// column i: {MQRankSum, BaseQRankSum, ReadPosRankSum, rawPos, avgBaseQ, meanDistanceFromReadEdge} as the reference derives them, and
+/// the MapqTracker's count
+int refpp_column_evs(void* p, int i, double* evs6, uint32_t* mapq_count)
+{
+    const Column& c(static_cast<Session*>(p)->pp->columns[i]);
+    for (int k = 0; k < 6; ++k) evs6[k] = c.evs[k];
+    *mapq_count = c.mapq_count;
+    return 0;
+}
+
+/// the reference's own accumulators fed from a list of observations: the same six numbers from what updateGermlineScoringMetrics got
+/// per basecall (is_reference, mapq, qscore, cycle, distance from read edge (already capped), is_submapped)
+int ref_germline_metrics_from_observations(int n, const uint8_t* is_reference, const uint8_t* mapq, const uint8_t* qscore,
+                                           const uint16_t* cycle, const uint8_t* edge, const uint8_t* is_submapped, double* evs6)
+{
+    snp_pos_info pi;
+    for (int i = 0; i < n; ++i) { // pos_basecall_buffer::updateGermlineScoringMetrics, pos_basecall_buffer.cpp:43-70
+        const bool isRef(is_reference[i] != 0);
+        pi.mq_ranksum.add_observation(isRef, static_cast<unsigned>(mapq[i]));
+        if (!is_submapped[i]) {
+            pi.baseq_ranksum.add_observation(isRef, static_cast<unsigned>(qscore[i]));
+            pi.readPositionRankSum.add_observation(isRef, cycle[i]);
+            if (!isRef) pi.distanceFromReadEdge.addObservation(edge[i]);
+        }
+    }
+    evs6[0] = pi.get_mq_ranksum();
+    evs6[1] = pi.get_baseq_ranksum();
+    evs6[2] = pi.get_read_pos_ranksum();
+    evs6[3] = pi.get_raw_pos();
+    evs6[4] = pi.get_raw_baseQ();
+    evs6[5] = pi.distanceFromReadEdge.mean();
     return 0;
 }
 

@@ -113,6 +113,46 @@ def test_restatement_matches_reference_live(built):
                     assert np.array_equal(got, want[key]) and sd[l] == want["spandel"] and sm[l] == want["submapped"]
 
 
+@pytest.mark.skipif(not pyoracle.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_evs_words_match_reference_live(built):
+    """The germline EVS words (one per live match position: base id, mapq, qscore, cycle, capped edge distance, submapped) against the
+    reference's position processor run with its germline scoring metrics on: per position the number of words is the MapqTracker's
+    count, and the reference's own rank-sum / mean accumulators fed from the words give the six numbers its pileup holds."""
+    rng = np.random.default_rng(1234)
+    n_checked = n_informative = 0
+    for trial in range(4):
+        reads, ref, off = synth.pileup_reads(120, rng)
+        kw = dict(report_begin=off + 5 * trial, report_end=off + len(ref) - 3 * trial)
+        if trial % 2:
+            kw.update(min_basecall_qscore=0, mismatch_density_max_count=3)
+        if trial == 3:
+            kw.update(is_mapq_adjust=0, min_distance_from_read_edge=3)
+        opt = pyoracle.pileup_options(**kw)
+        finals, cols = pyoracle.ref_pileup_pipeline(reads, ref, off, opt, germline_metrics=True)
+        piled = []
+        for f in finals:
+            if f["skipped"]:
+                continue
+            r = dict(reads[f["read_id"]])
+            r.update(pos=f["pos"], path=capi.cigar_to_path(f["cigar"]), is_fwd=f["is_fwd"])
+            piled.append(r)
+        rb = synth.ReadBatch.from_reads(piled, ref, off)
+        eo, ew = pyoracle.pileup_reads_evs(rb, opt)
+        for l in range(opt.report_end - opt.report_begin):
+            pos = opt.report_begin + l
+            words = ew[eo[l]:eo[l + 1]]
+            want = cols.get(pos)
+            if want is None:
+                assert len(words) == 0
+                continue
+            assert len(words) == want["mapq_count"]
+            got = pyoracle.ref_germline_metrics(words, "ACGTN".index(ref[pos - off]) if ref[pos - off] in "ACGT" else 4)
+            assert np.array_equal(got, want["evs"], equal_nan=True), (pos, got, want["evs"])
+            n_checked += 1
+            n_informative += int(np.any(got[:3] != 0))
+    assert n_checked > 800 and n_informative > 100
+
+
 def test_candidate_snv_mask_and_edge_cases_restatement(built):
     # a read whose three mismatches sit within the flank: filtered; marking them candidate SNVs lifts the filter
     ref = "ACGT" * 30
