@@ -151,6 +151,13 @@ HOOKS = [
          r'(            // detect active regions \(match/mismatch\)\n)            for \(unsigned j\(0\); j < ps\.length; \+\+j\)\n            \{\n(?:.*\n)*?            \}\n(        \}\n\n        for \(unsigned i\(0\); i<n_seg; \+\+i\))',
          '\\1            sk_adapter::active_region_insert_aligned_segment(activeRegionReadBuffer, id, ref, read_seq, read_offset, ref_head_pos, ps.length);\n\\2'),
     ]),
+    (L + "starling_common/ReferenceRepeatFinder.cpp", [
+        ("include", r'#include "ReferenceRepeatFinder.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # the anchor finder's per-position table update (host work: 50 unit lengths per position)
+        ("updateRepeatSpan",
+         r'(void ReferenceRepeatFinder::updateRepeatSpan\(pos_t pos\)\n\{\n)',
+         '\\1    if (sk_adapter::repeat_span_update(_ref, pos, _maxRepeatUnitLength, _maxBufferSize, _minRepeatSpan, _repeatSpan, _isAnchor)) return;\n'),
+    ]),
     (L + "htsapi/bam_streamer.cpp", [
         ("include", r'#include "htsapi/bam_streamer.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
         # site 8: the region's reads through the feed

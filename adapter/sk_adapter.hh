@@ -124,6 +124,11 @@ void valid_alignment_range(const alignment& al, const reference_contig_segment& 
 void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const unsigned alignId, const reference_contig_segment& ref,
                                           const bam_seq_base& readSeq, const unsigned readOffset, const pos_t refHeadPos, const unsigned length);
 
+/// ReferenceRepeatFinder::updateRepeatSpan (ReferenceRepeatFinder.cpp:26-59) for a position whose look-back lies inside the reference
+/// segment: the same table rows and anchor flags, the ring indices taken once (false = not handled, run the reference's loop)
+bool repeat_span_update(const reference_contig_segment& ref, const pos_t pos, const unsigned maxRepeatUnitLength, const unsigned ringSize,
+                        const unsigned minRepeatSpan, std::vector<std::vector<unsigned>>& repeatSpan, std::vector<bool>& isAnchor);
+
 // ---- site 7: ActiveRegionProcessor::discoverIndelsAndMismatches (ActiveRegionProcessor.cpp:572-705) ----
 bool discover_indels_and_mismatches(const std::string& haplotypeSeq, const std::string& refSegment,
                                     const reference_contig_segment& ref, const pos_t regionBegin, const pos_t regionEnd,

@@ -18,9 +18,19 @@
 #include <string>
 #include <vector>
 
+#include <cstdint>
+#include <cstring>
+#include <ostream>
+#include <sstream>
+
+#include "blt_util/blt_types.hh"
+#include "blt_util/PolymorphicObject.hh"
 #include "blt_util/known_pos_range2.hh"
 #include "blt_util/reference_contig_segment.hh"
+#include "blt_util/seq_util.hh"
+#define private public
 #include "htsapi/bam_seq.hh"
+#undef private
 #include "starling_common/IndelBuffer.hh"
 #include "starling_common/ReferenceRepeatFinder.hh"
 #include "starling_common/indel.hh"
@@ -41,6 +51,48 @@
 namespace sk_adapter
 {
 
+namespace
+{
+
+/// bam_seq::get_char for positions [from, from + n) of a packed read (bam_seq.hh:193-206: high nibble first, 'N' past the end), two
+/// bases per table look-up instead of a virtual size() and a switch per base
+void unpackReadChars(const bam_seq& seq, const unsigned from, const unsigned n, char* dst)
+{
+    static char pairChar[256][2];
+    static bool isTable(false);
+    if (! isTable)
+    {
+        for (unsigned b(0); b < 256; ++b)
+        {
+            pairChar[b][0] = get_bam_seq_char(static_cast<uint8_t>(b >> 4));
+            pairChar[b][1] = get_bam_seq_char(static_cast<uint8_t>(b & 15u));
+        }
+        isTable = true;
+    }
+    const unsigned size(seq._size);
+    const unsigned live((from < size) ? std::min(n, size - from) : 0u);
+    const uint8_t* packed(seq._s);
+    unsigned i(static_cast<unsigned>(seq._offset) + from), k(0);
+    if ((i & 1u) && k < live)
+    {
+        dst[k++] = pairChar[packed[i >> 1]][1];
+        ++i;
+    }
+    for (; k + 2 <= live; k += 2, i += 2) std::memcpy(dst + k, pairChar[packed[i >> 1]], 2);
+    if (k < live) dst[k++] = pairChar[packed[i >> 1]][0];
+    for (; k < n; ++k) dst[k] = 'N';
+}
+
+/// reference_contig_segment::get_base for [pos, pos + n): the segment's own characters where the range lies inside it
+const char* referenceChars(const reference_contig_segment& ref, const pos_t pos, const unsigned n, char* buffer)
+{
+    if (pos >= ref.get_offset() && pos + static_cast<pos_t>(n) <= ref.end()) return ref.seq().data() + (pos - ref.get_offset());
+    for (unsigned j(0); j < n; ++j) buffer[j] = ref.get_base(pos + static_cast<pos_t>(j));
+    return buffer;
+}
+
+}
+
 // get_valid_alignment_range (L/starling_common/starling_read_util.cpp:218-329), called for every input read at
 // starling_pos_processor_indel_util.cpp:335: the same scores, sums and tie rules, with the two per-read vectors kept between calls
 // and the base look-ups made without virtual dispatch (the read is a bam_seq, the reference the contig segment itself).
@@ -50,6 +102,7 @@ void valid_alignment_range(const alignment& al, const reference_contig_segment& 
     const bam_seq* packed(dynamic_cast<const bam_seq*>(&readSeq));
     const unsigned readSize(readSeq.size());
     static std::vector<int> fwdScore, revScore;
+    static std::vector<char> readChars, refChars;
     fwdScore.assign(readSize, 0);
     revScore.assign(readSize, 0);
     pos_t refHeadPos(al.pos);
@@ -74,16 +127,36 @@ void valid_alignment_range(const alignment& al, const reference_contig_segment& 
         }
         else if (is_segment_align_match(ps.type))
         {
-            for (unsigned j(0); j < ps.length; ++j)
+            if (packed != nullptr && readHeadPos + ps.length <= readSize)
             {
-                const unsigned readPos(readHeadPos + j);
-                const char readChar(packed ? packed->bam_seq::get_char(static_cast<pos_t>(readPos)) : readSeq.get_char(static_cast<pos_t>(readPos)));
-                const char refChar(ref.get_base(refHeadPos + static_cast<pos_t>(j)));
-                if ((readChar != 'N') && (refChar != 'N'))
+                readChars.resize(ps.length);
+                refChars.resize(ps.length);
+                unpackReadChars(*packed, readHeadPos, ps.length, readChars.data());
+                const char* const refChar(referenceChars(ref, refHeadPos, ps.length, refChars.data()));
+                const char* const readChar(readChars.data());
+                int* const fwd(fwdScore.data() + readHeadPos);
+                int* const rev(revScore.data() + readHeadPos);
+                for (unsigned j(0); j < ps.length; ++j)
                 {
-                    const int v((readChar != refChar) ? mismatchScore : matchScore);
-                    fwdScore[readPos] += v;
-                    revScore[readPos] += v;
+                    const int v((readChar[j] != refChar[j]) ? mismatchScore : matchScore);
+                    const int w(((readChar[j] != 'N') && (refChar[j] != 'N')) ? v : 0);
+                    fwd[j] += w;
+                    rev[j] += w;
+                }
+            }
+            else
+            {
+                for (unsigned j(0); j < ps.length; ++j)
+                {
+                    const unsigned readPos(readHeadPos + j);
+                    const char readChar(readSeq.get_char(static_cast<pos_t>(readPos)));
+                    const char refChar(ref.get_base(refHeadPos + static_cast<pos_t>(j)));
+                    if ((readChar != 'N') && (refChar != 'N'))
+                    {
+                        const int v((readChar != refChar) ? mismatchScore : matchScore);
+                        fwdScore[readPos] += v;
+                        revScore[readPos] += v;
+                    }
                 }
             }
             readHeadPos += ps.length;
@@ -150,7 +223,7 @@ void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const 
     // the segment in runs that do not wrap the ring: per run the bases are unpacked and compared first, then each of the buffer's
     // arrays gets its stores in one pass over consecutive slots (the per-position result is the same whatever the order between arrays)
     static const unsigned maxRun(512);
-    char baseChar[maxRun];
+    char baseChar[maxRun], refBuffer[maxRun];
     unsigned char isMismatch[maxRun];
     unsigned done(0);
     while (done < length)
@@ -158,11 +231,9 @@ void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const 
         const unsigned index0(static_cast<unsigned>(refHeadPos + static_cast<pos_t>(done)) % ringSize);
         const unsigned run(std::min(std::min(length - done, ringSize - index0), maxRun));
         const pos_t refPos0(refHeadPos + static_cast<pos_t>(done));
-        for (unsigned j(0); j < run; ++j)
-        {
-            baseChar[j] = packed->bam_seq::get_char(static_cast<pos_t>(readOffset + done + j));
-            isMismatch[j] = (ref.get_base(refPos0 + static_cast<pos_t>(j)) != baseChar[j]) ? 1 : 0;
-        }
+        unpackReadChars(*packed, readOffset + done, run, baseChar);
+        const char* const refChar(referenceChars(ref, refPos0, run, refBuffer));
+        for (unsigned j(0); j < run; ++j) isMismatch[j] = (refChar[j] != baseChar[j]) ? 1 : 0;
         // insertMismatch / insertMatch: addVariantCount ...
         for (unsigned j(0); j < run; ++j)
         {
@@ -173,6 +244,9 @@ void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const 
         for (unsigned j(0); j < run; ++j)
         {
             variantRow[index0 + j] = isMismatch[j] ? ActiveRegionReadBuffer::MISMATCH : ActiveRegionReadBuffer::MATCH;
+        }
+        for (unsigned j(0); j < run; ++j)
+        {
             if (isMismatch[j]) snvRow[index0 + j] = baseChar[j];
         }
         // ... addAlignIdToPos
@@ -183,6 +257,60 @@ void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const 
         }
         done += run;
     }
+}
+
+bool repeat_span_update(const reference_contig_segment& ref, const pos_t pos, const unsigned maxRepeatUnitLength, const unsigned ringSize,
+                        const unsigned minRepeatSpan, std::vector<std::vector<unsigned>>& repeatSpan, std::vector<bool>& isAnchor)
+{
+    // the reference evaluates, for each of the 50 unit lengths, two bounds-checked base look-ups and two ring indices by division;
+    // here: the segment's characters directly (so only where [pos - maxRepeatUnitLength, pos] lies inside it), the two rows once
+    static const unsigned maxUnits(64);
+    const unsigned lookBack((maxRepeatUnitLength + 7u) & ~7u);
+    if (pos < 0 || ringSize < 2 || lookBack > maxUnits || pos - static_cast<pos_t>(lookBack) < ref.get_offset() || pos >= ref.end()) return false;
+    const char* const refChar(ref.seq().data() + (pos - ref.get_offset()));
+    const char base(refChar[0]);
+    // prevBase[unit - 1] = the base `unit` positions back: eight at a time, byte-swapped, so that the loop below runs forward over
+    // three plain arrays and the compiler can vectorise it
+    unsigned char prevBase[maxUnits];
+    for (unsigned k(0); k < lookBack; k += 8)
+    {
+        uint64_t v;
+        std::memcpy(&v, refChar - static_cast<int>(k) - 8, 8);
+        v = __builtin_bswap64(v);
+        std::memcpy(prevBase + k, &v, 8);
+    }
+    const unsigned posIndex(static_cast<unsigned>(pos) % ringSize);
+    const unsigned* __restrict const prevRow(repeatSpan[static_cast<unsigned>(pos - 1) % ringSize].data());
+    unsigned* __restrict const row(repeatSpan[posIndex].data());
+    isAnchor[posIndex] = true;
+    // (the comparison outcome is as good as random: selected by mask, not by branch)
+    unsigned isAnyRepeat(0);
+    for (unsigned k(0); k < maxRepeatUnitLength; ++k)
+    {
+        const unsigned unit(k + 1u);
+        const unsigned isSame(static_cast<unsigned>(prevBase[k] == static_cast<unsigned char>(base)) & static_cast<unsigned>(prevBase[k] != 'N'));
+        const unsigned mask(0u - isSame);
+        const unsigned span((mask & (prevRow[k] + 1u)) | (~mask & unit));
+        row[k] = span;
+        isAnyRepeat |= static_cast<unsigned>(span >= unit * 2u) & static_cast<unsigned>(span >= minRepeatSpan);
+    }
+    if (! isAnyRepeat) return true;
+    for (unsigned unit(1); unit <= maxRepeatUnitLength; ++unit)
+    {
+        const unsigned span(row[unit - 1]);
+        if (! (span >= unit * 2u && span >= minRepeatSpan)) continue;
+        if (span == unit * 2u || span == minRepeatSpan)
+        {
+            // (the flags only ever go to false here: the order between unit lengths does not matter)
+            for (pos_t prevPos(pos - 1u); prevPos > static_cast<pos_t>(pos - span); --prevPos)
+            {
+                const pos_t prevPosIndex(prevPos % ringSize);
+                isAnchor[prevPosIndex] = false;
+            }
+        }
+        isAnchor[posIndex] = false;
+    }
+    return true;
 }
 
 }
