@@ -59,6 +59,11 @@ HOOKS = [
         ("active-region read buffer clear, deferred copy removed",
          r'(        write_reads\(pos\);\n\n        if \(is_active_region_detector_enabled\(\)\)\n        \{\n)            _getActiveRegionDetector\(\)\.clearReadBuffer\(pos\);\n',
          '\\1            /* strelka_amd: cleared at the undeferred distance, see the HEAD stage */\n'),
+        # second and later exons of spliced reads are initialised position by position (a read-buffer look-up per position and per
+        # read); the adapter refuses spliced reads when they are inserted (on_read_inserted), so there is never one to find
+        ("initializeSplicedReadSegmentsAtPos",
+         r'(    if        \(stage_no==STAGE::HEAD\)\n    \{\n)        initializeSplicedReadSegmentsAtPos\(pos\);\n',
+         '\\1        if (sk_adapter::spliced_reads_possible()) initializeSplicedReadSegmentsAtPos(pos);\n'),
         # site 1
         ("align_pos",
          r'(starling_pos_processor_base::\nalign_pos\(const pos_t pos\)\n\{\n)',
@@ -82,8 +87,10 @@ HOOKS = [
          r'        sif\.localRegionStatsCollection\.insert\(pos, sif\.cleanedPileup\.usedBasecallCount\(\), sif\.cleanedPileup\.unusedBasecallCount\(\),n_spandel,n_submapped\);\n',
          '    unsigned skUsed(0), skUnused(0);\n'
          '    if (! sk_adapter::sample_stats_counts(*this, pos, sample_no, skUsed, skUnused))\n    {\n'
+         '        sk_adapter::germline_arm_clean_summary(*this, pos, sample_no);\n'
          '        _pileupCleaner.CleanPileupFilter(pi,is_include_tier2,sif.cleanedPileup);\n'
-         '        skUsed = sif.cleanedPileup.usedBasecallCount();\n        skUnused = sif.cleanedPileup.unusedBasecallCount();\n    }\n\n'
+         '        skUsed = sk_adapter::used_basecall_count(sample_no, sif.cleanedPileup);\n'
+         '        skUnused = sk_adapter::unused_basecall_count(sample_no, sif.cleanedPileup);\n    }\n\n'
          '\\1        sif.localRegionStatsCollection.insert(pos, skUsed, skUnused,n_spandel,n_submapped);\n'),
         # sites 2+3: the window's genotypes are computed when POST_ALIGN reaches its first position
         ("process_pos_variants",
@@ -103,6 +110,23 @@ HOOKS = [
         ("germline EVS accumulators",
          r'(            siteSampleInfo\.ReadPosRankSum = pi\.get_read_pos_ranksum\(\);\n)',
          '            sk_adapter::germline_fill_scoring_metrics(sampleIndex, locus.pos, pi);\n\\1'),
+        # the cleaned pileup's counts from the summary (sk_adapter.hh, clean_pileup_summary)
+        ("getSiteAltAlleles: getBasecallCounts",
+         r'        good_pi\.getBasecallCounts\(sampleBaseCounts\);\n',
+         '        if (! sk_adapter::summary_basecall_counts(sampleIndex, cpi, sampleBaseCounts.data())) good_pi.getBasecallCounts(sampleBaseCounts);\n'),
+        ("updateSnvLocusWithSampleInfo: used count, ploidy conflict",
+         r'    if \(cpi\.usedBasecallCount\(\) != 0\)\n(    \{\n        // the principle of this filter)',
+         '    if (sk_adapter::used_basecall_count(sampleIndex, cpi) != 0)\n\\1'),
+        ("updateSnvLocusWithSampleInfo: used count, genotype",
+         r'    if     \(locus\.isRefUnknown\(\) or \(cpi\.usedBasecallCount\(\) == 0\) or isOverlappingHomAltDeletion\)\n(    \{\n        sampleInfo\.genotypeQuality = 0;\n        sampleInfo\.maxGenotypeIndex\.setGenotypeFromAlleleIndices\(\);\n\n        sampleInfo\.genotypeQualityPolymorphic=0;)',
+         '    if     (locus.isRefUnknown() or (sk_adapter::used_basecall_count(sampleIndex, cpi) == 0) or isOverlappingHomAltDeletion)\n\\1'),
+        ("updateSnvLocusWithSampleInfo: AD counts",
+         r'(            sampleInfo\.supportCounts\.setAltCount\(altAlleleCount\);\n\n            const snp_pos_info& good_pi\(cpi\.cleanedPileup\(\)\);\n)(            for \(const auto& call : good_pi\.calls\)\n            \{\n                if \(call\.base_id == BASE_ID::ANY\) continue;\n)',
+         '\\1            if (! sk_adapter::summary_allele_counts(sampleIndex, cpi, baseIndexToAlleleIndex, fullAlleleCount, sampleInfo.supportCounts))\n\\2'),
+        ("updateSiteSampleInfo: used and unused counts",
+         r'    siteSampleInfo\.usedBasecallCount = cpi\.usedBasecallCount\(\);\n    siteSampleInfo\.unusedBasecallCount = cpi\.unusedBasecallCount\(\);\n',
+         '    siteSampleInfo.usedBasecallCount = sk_adapter::used_basecall_count(sampleIndex, cpi);\n'
+         '    siteSampleInfo.unusedBasecallCount = sk_adapter::unused_basecall_count(sampleIndex, cpi);\n'),
         # site 3
         ("computeSampleDiploidSiteGenotype call",
          r'computeSampleDiploidSiteGenotype\(\n\s*_opt, _dopt, sample\(sampleIndex\), callerPloidy\[sampleIndex\], allDgt\[sampleIndex\]\);',
@@ -150,6 +174,12 @@ HOOKS = [
         ("active-region match/mismatch loop",
          r'(            // detect active regions \(match/mismatch\)\n)            for \(unsigned j\(0\); j < ps\.length; \+\+j\)\n            \{\n(?:.*\n)*?            \}\n(        \}\n\n        for \(unsigned i\(0\); i<n_seg; \+\+i\))',
          '\\1            sk_adapter::active_region_insert_aligned_segment(activeRegionReadBuffer, id, ref, read_seq, read_offset, ref_head_pos, ps.length);\n\\2'),
+    ]),
+    (L + "starling_common/PileupCleaner.cpp", [
+        ("include", r'#include "PileupCleaner.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        ("CleanPileupFilter: counted instead of copied",
+         r'(    cpi\._n_raw_calls = pi\.calls\.size\(\);\n)(    for \(const auto& bc : pi\.calls\)\n    \{\n        if \(bc\.is_call_filter\)\n        \{\n            if \(! \(is_include_tier2 &&)',
+         '\\1    if (sk_adapter::clean_pileup_summary(pi, is_include_tier2)) return;\n\\2'),
     ]),
     (L + "starling_common/ReferenceRepeatFinder.cpp", [
         ("include", r'#include "ReferenceRepeatFinder.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),

@@ -43,6 +43,7 @@ struct alignment;
 class ActiveRegionReadBuffer;
 struct bam_seq_base;
 struct pos_range;
+struct LocusSupportingReadStats;
 
 namespace sk_adapter
 {
@@ -73,6 +74,24 @@ bool align_pos(starling_pos_processor_base& pp, const pos_t pos);
 void before_process_pos_variants(starling_pos_processor_base& pp, const pos_t pos);
 void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const unsigned sampleIndex, const unsigned ploidy,
                            diploid_genotype& dgt);
+// The germline caller reads a position's cleaned tier1 pileup (CleanPileupFilter, PileupCleaner.cpp:28-66) three times and only for
+// counts: how many calls it holds (process_pos_sample_stats, updateSnvLocusWithSampleInfo, updateSiteSampleInfo), how many per base
+// (getSiteAltAlleles) and how many per allele and strand (the AD counts) -- the genotype itself comes from the kernels.  So the copy is
+// not made: one pass over the raw calls counts the unfiltered ones per strand and base, and the five places read the counts.
+/// process_pos_sample_stats, before its CleanPileupFilter call: arms the summary for this sample's next CleanPileupFilter (germline
+/// diploid caller only)
+void germline_arm_clean_summary(const starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex);
+/// inside CleanPileupFilter, after the raw pointer, reference base and raw count are set: true = the summary was taken instead of
+/// the copy (armed, tier1 only)
+bool clean_pileup_summary(const snp_pos_info& pi, const bool isIncludeTier2);
+/// CleanedPileup::usedBasecallCount() / unusedBasecallCount() of a sample's current position, whichever way it was cleaned
+unsigned used_basecall_count(const unsigned sampleIndex, const CleanedPileup& cpi);
+unsigned unused_basecall_count(const unsigned sampleIndex, const CleanedPileup& cpi);
+/// snp_pos_info::getBasecallCounts of the cleaned pileup (false = not summarised, the caller counts)
+bool summary_basecall_counts(const unsigned sampleIndex, const CleanedPileup& cpi, double* baseCount);
+/// the AD counting loop of updateSnvLocusWithSampleInfo (starling_pos_processor.cpp:446-469; false = not summarised)
+bool summary_allele_counts(const unsigned sampleIndex, const CleanedPileup& cpi, const uint8_t* baseIndexToAlleleIndex, const uint8_t fullAlleleCount,
+                           LocusSupportingReadStats& supportCounts);
 /// the four zero-depth genotypes of the constructor (starling_pos_processor_base.cpp:259-274)
 void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseId, diploid_genotype& dgt);
 
@@ -115,6 +134,9 @@ void somatic_indel(const strelka_options& opt, const starling_sample_options& no
 /// ActiveRegionDetector::clearReadBuffer at the position the UNDEFERRED READ_BUFFER stage would be at while HEAD is at `headStagePos`
 void clear_active_region_read_buffer_undeferred(starling_pos_processor_base& pp, const pos_t headStagePos, const unsigned readBufferShift,
                                                 const pos_t minPos);
+
+/// false: on_read_inserted throws for a spliced read, so the read buffer never holds second or later exons
+bool spliced_reads_possible();
 
 /// get_valid_alignment_range (starling_read_util.cpp:218-329) at starling_pos_processor_indel_util.cpp:335, without its per-read
 /// allocations and virtual base look-ups (host work, the same arithmetic)

@@ -217,6 +217,9 @@ void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const 
     const unsigned idIndex(alignId % ActiveRegionReadBuffer::MaxDepth);
     ActiveRegionReadBuffer::VariantType* const variantRow(buffer._variantInfo[idIndex].data());
     char* const snvRow(buffer._snvBuffer[idIndex]);
+    // the rows are 4 kB apart and come round once per thousand reads: ask for the next read's slots (the next id, about here) while
+    // this read's are written
+    const ActiveRegionReadBuffer::VariantType* const nextRow(buffer._variantInfo[(idIndex + 1u) % ActiveRegionReadBuffer::MaxDepth].data());
     unsigned* const variantCounter(buffer._variantCounter.data());
     unsigned* const depth(buffer._depth.data());
     std::vector<align_id_t>* const alignIds(buffer._positionToAlignIds.data());
@@ -231,6 +234,7 @@ void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const 
         const unsigned index0(static_cast<unsigned>(refHeadPos + static_cast<pos_t>(done)) % ringSize);
         const unsigned run(std::min(std::min(length - done, ringSize - index0), maxRun));
         const pos_t refPos0(refHeadPos + static_cast<pos_t>(done));
+        for (unsigned j(0); j < run; j += 16) __builtin_prefetch(nextRow + index0 + j, 1);
         unpackReadChars(*packed, readOffset + done, run, baseChar);
         const char* const refChar(referenceChars(ref, refPos0, run, refBuffer));
         for (unsigned j(0); j < run; ++j) isMismatch[j] = (refChar[j] != baseChar[j]) ? 1 : 0;

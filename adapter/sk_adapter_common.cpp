@@ -232,6 +232,11 @@ unsigned buffered_read_count(const starling_pos_processor_base& /*pp*/, const un
     return static_cast<unsigned>(state().geometry.bufferedReadPos[sampleIndex].size());
 }
 
+bool spliced_reads_possible()
+{
+    return false;
+}
+
 void on_read_inserted(starling_pos_processor_base& /*pp*/, const unsigned sampleIndex, const starling_read& sread)
 {
     if (sread.isSpliced())
