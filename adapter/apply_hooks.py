@@ -64,6 +64,13 @@ HOOKS = [
         ("initializeSplicedReadSegmentsAtPos",
          r'(    if        \(stage_no==STAGE::HEAD\)\n    \{\n)        initializeSplicedReadSegmentsAtPos\(pos\);\n',
          '\\1        if (sk_adapter::spliced_reads_possible()) initializeSplicedReadSegmentsAtPos(pos);\n'),
+        # the estimated-depth buffers: an input read's matched positions a run at a time
+        ("load_read_in_depth_buffer, tier1",
+         r'        add_alignment_to_depth_buffer\(al\.pos,al\.path,sample\(sample_no\)\.estdepth_buff\);\n',
+         '        sk_adapter::depth_buffer_add_alignment(al.pos,al.path,sample(sample_no).estdepth_buff);\n'),
+        ("load_read_in_depth_buffer, tier2",
+         r'        add_alignment_to_depth_buffer\(al\.pos,al\.path,sample\(sample_no\)\.estdepth_buff_tier2\);\n',
+         '        sk_adapter::depth_buffer_add_alignment(al.pos,al.path,sample(sample_no).estdepth_buff_tier2);\n'),
         # site 1
         ("align_pos",
          r'(starling_pos_processor_base::\nalign_pos\(const pos_t pos\)\n\{\n)',

@@ -43,6 +43,8 @@ struct alignment;
 class ActiveRegionReadBuffer;
 struct bam_seq_base;
 struct pos_range;
+struct depth_buffer;
+namespace ALIGNPATH { struct path_segment; }
 struct LocusSupportingReadStats;
 
 namespace sk_adapter
@@ -134,6 +136,10 @@ void somatic_indel(const strelka_options& opt, const starling_sample_options& no
 /// ActiveRegionDetector::clearReadBuffer at the position the UNDEFERRED READ_BUFFER stage would be at while HEAD is at `headStagePos`
 void clear_active_region_read_buffer_undeferred(starling_pos_processor_base& pp, const pos_t headStagePos, const unsigned readBufferShift,
                                                 const pos_t minPos);
+
+/// add_alignment_to_depth_buffer (depth_buffer_util.cpp:29-48) with the positions inside the buffer's present range taken a run at a
+/// time (sk_adapter_depth_buffer.cpp)
+void depth_buffer_add_alignment(const pos_t pos, const std::vector<ALIGNPATH::path_segment>& path, depth_buffer& buffer);
 
 /// false: on_read_inserted throws for a spliced read, so the read buffer never holds second or later exons
 bool spliced_reads_possible();

@@ -186,7 +186,13 @@ struct State
     unsigned long realignDeviceEnumerated = 0, realignHostEnumerated = 0; // reads whose candidate alignments the device / the host listed
     unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0;
 };
-State& state();
+/// the adapter's state (one per process); the hooks ask for it at every position and every read, so after the first call it is a load
+State& make_state();
+extern State* g_state;
+inline State& state()
+{
+    return (g_state != nullptr) ? *g_state : make_state();
+}
 
 // site 9 internals (sk_adapter_pileup.cpp)
 bool pileup_enabled(starling_pos_processor_base& pp);

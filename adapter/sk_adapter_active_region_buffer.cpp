@@ -103,11 +103,73 @@ void valid_alignment_range(const alignment& al, const reference_contig_segment& 
     const unsigned readSize(readSeq.size());
     static std::vector<int> fwdScore, revScore;
     static std::vector<char> readChars, refChars;
+    using namespace ALIGNPATH;
+    if (packed != nullptr)
+    {
+        // Each mismatch, insertion or deletion takes 5 from the running sums below and nothing else lowers them, so with at most two
+        // such events no prefix (or suffix) sum reaches minSegmentScore = -11 and the whole read is valid -- most reads.  Counting the
+        // events needs neither the score arrays nor the scan.
+        unsigned eventCount(0);
+        bool isCountable(true);
+        pos_t refPos(al.pos);
+        unsigned readPos(0);
+        for (const path_segment& ps : al.path)
+        {
+            if (ps.type == INSERT || ps.type == SOFT_CLIP)
+            {
+                if (ps.type == INSERT) ++eventCount;
+                readPos += ps.length;
+            }
+            else if (ps.type == DELETE)
+            {
+                ++eventCount;
+                refPos += ps.length;
+            }
+            else if (is_segment_align_match(ps.type))
+            {
+                if (readPos + ps.length > readSize)
+                {
+                    isCountable = false;
+                    break;
+                }
+                readChars.resize(ps.length);
+                refChars.resize(ps.length);
+                unpackReadChars(*packed, readPos, ps.length, readChars.data());
+                const char* const refChar(referenceChars(ref, refPos, ps.length, refChars.data()));
+                const char* const readChar(readChars.data());
+                unsigned mismatchCount(0);
+                for (unsigned j(0); j < ps.length; ++j)
+                {
+                    mismatchCount += static_cast<unsigned>(readChar[j] != refChar[j]) & static_cast<unsigned>(readChar[j] != 'N') &
+                                     static_cast<unsigned>(refChar[j] != 'N');
+                }
+                eventCount += mismatchCount;
+                readPos += ps.length;
+                refPos += ps.length;
+            }
+            else if (ps.type != HARD_CLIP)
+            {
+                isCountable = false; // (the full pass below reports it)
+                break;
+            }
+            if (eventCount > 2) break;
+        }
+        if (isCountable && eventCount <= 2)
+        {
+            validRange.set_begin_pos(0);
+            validRange.set_end_pos(readSize);
+            if (validRange.end_pos <= validRange.begin_pos)
+            {
+                validRange.begin_pos = 0;
+                validRange.end_pos = 0;
+            }
+            return;
+        }
+    }
     fwdScore.assign(readSize, 0);
     revScore.assign(readSize, 0);
     pos_t refHeadPos(al.pos);
     unsigned readHeadPos(0);
-    using namespace ALIGNPATH;
     for (const path_segment& ps : al.path)
     {
         if ((ps.type == INSERT) || (ps.type == SOFT_CLIP))

@@ -29,7 +29,7 @@ def link_profiled(program):
                               L + "/applications/strelka", ROOT + "/oracle/ref/gen", ROOT + "/oracle/boost_shim", hts,
                               OUT + "/redist/rapidjson-1.1.0/include")]
     binary = os.path.join(OUT, "bin", program + "_prof")
-    subprocess.run(["g++", "-std=c++11", "-O2", "-w", "-fPIC", "-ffp-contract=off", "-pg"] + inc + [REF + "/src/c++/bin/%s.cpp" % program] + objs +
+    subprocess.run(["g++", "-std=c++11", "-O3", "-w", "-fPIC", "-ffp-contract=off", "-pg"] + inc + [REF + "/src/c++/bin/%s.cpp" % program] + objs +
                    [OUT + "/libreftus.a", hts + "/libhts.a", "-lm", "-lz", "-lpthread", "-L" + ROOT + "/oracle", "-lstrelka_amd_double",
                     "-Wl,-rpath," + ROOT + "/oracle", "-o", binary], check=True)
     return binary
@@ -57,7 +57,7 @@ def main():
                                              os.path.join(d, "normal.fa"), chrom_depth=os.path.join(d, "chrom_depth.txt"), callable_regions=True)
         env = dict(os.environ, GMON_OUT_PREFIX=os.path.join(o, "gmon"))
         for _ in range(runs):
-            subprocess.run(argv, check=True, cwd=o, stdout=subprocess.DEVNULL, env=env)
+            subprocess.run(argv, check=True, cwd=o, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
         text = subprocess.run(["gprof", "-b", "-p", binary] + sorted(glob.glob(os.path.join(o, "gmon.*"))), check=True, stdout=subprocess.PIPE).stdout.decode()
     head = ("# %s drop-in over the CPU double of the C-ABI, %d bp WGS-like segment, build container: sampling profile of the main\n"
             "# program text (the double and libz are shared objects and are not sampled) = the host code that remains\n" % (mode, length))
