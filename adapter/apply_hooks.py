@@ -168,6 +168,10 @@ HOOKS = [
     ]),
     (L + "starling_common/starling_pos_processor_util.cpp", [
         ("include", r'#include "starling_common/starling_pos_processor_util.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
+        # the two per-base validity loops of checkBamRecord, decided by table for the common case
+        ("checkBamRecord",
+         r'    const bool isKeepRecord\(checkBamRecord\(read_stream, read\)\);\n',
+         '    const bool isKeepRecord(sk_adapter::is_plain_bam_record(read.qual(), read.read_size()) || checkBamRecord(read_stream, read));\n'),
         # site 8, second half: the region's alignments normalised in one batch
         ("normalizeAlignment",
          r'        normalizeAlignment\(refBamSeq, readBamSeq, readAlignment\);\n',

@@ -141,6 +141,11 @@ void clear_active_region_read_buffer_undeferred(starling_pos_processor_base& pp,
 /// time (sk_adapter_depth_buffer.cpp)
 void depth_buffer_add_alignment(const pos_t pos, const std::vector<ALIGNPATH::path_segment>& path, depth_buffer& buffer);
 
+/// checkBamRecord's two per-base loops (starling_pos_processor_util.cpp:203-240) for the common case: true = every base code is one of
+/// A, C, G, T, N and every quality is at most 70, so the record is kept; false = undecided, checkBamRecord itself runs (and reports).
+/// `qual` is bam_record::qual() of a record of `readSize` bases: the packed bases sit right before it.
+bool is_plain_bam_record(const uint8_t* qual, const unsigned readSize);
+
 /// false: on_read_inserted throws for a spliced read, so the read buffer never holds second or later exons
 bool spliced_reads_possible();
 

@@ -30,6 +30,7 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace sk_adapter
 {
@@ -218,6 +219,31 @@ void candidateMask(starling_pos_processor_base& pp, const pos_t lo, const pos_t 
 
 /// the finalised positions of a window into the reference's pos_basecall_buffer (what insert_pos_basecall / insert_mapq_count /
 /// insert_pos_spandel_count / insert_pos_submap_count would have left there)
+/// column := the n records at `from`.  vector::assign (and resize with a fill value) handle base_call one element at a time: the type
+/// has a constructor with arguments and no default one, so the library does not take it for plain data, although it is a 16-bit
+/// record with a trivial copy and destructor.  A maintainer would give it `base_call() = default;` and assign would be a memmove; from
+/// outside the class the same effect needs the vector's end pointer: storage by reserve(), the records by memcpy, the end set through
+/// the implementation's own member (libstdc++'s _Vector_base::_M_impl, reached through a derived type).
+struct ColumnOpener : public std::vector<base_call>
+{
+    static void setSize(std::vector<base_call>& v, const size_t n)
+    {
+        ColumnOpener& o(static_cast<ColumnOpener&>(v));
+        o._M_impl._M_finish = o._M_impl._M_start + n;
+    }
+};
+static_assert(std::is_trivially_copyable<base_call>::value && std::is_trivially_destructible<base_call>::value,
+              "the column is filled by memcpy");
+
+inline void assignColumn(std::vector<base_call>& column, const base_call* const from, const size_t n)
+{
+    column.clear();
+    if (n == 0) return;
+    column.reserve(n);
+    std::memcpy(static_cast<void*>(column.data()), from, n * sizeof(base_call));
+    ColumnOpener::setSize(column, n);
+}
+
 void assignWindow(starling_pos_processor_base::sample_info& sif, const sk_pileup_window& w)
 {
     const size_t n(static_cast<size_t>(w.end - w.begin));
@@ -229,11 +255,11 @@ void assignWindow(starling_pos_processor_base::sample_info& sif, const sk_pileup
         snp_pos_info& pi(Access::pileupRef(sif.basecallBuffer, w.begin + static_cast<pos_t>(i)));
         const size_t n1(static_cast<size_t>(w.tier1_off[i + 1] - w.tier1_off[i]));
         const size_t n2(static_cast<size_t>(w.tier2_off[i + 1] - w.tier2_off[i]));
-        // (base_call is the 16-bit record itself: the column is a run of them; one pass, no fill before the copy)
+        // (base_call is the 16-bit record itself: the column is a run of them)
         const base_call* const t1(reinterpret_cast<const base_call*>(w.tier1_calls + w.tier1_off[i]));
         const base_call* const t2(reinterpret_cast<const base_call*>(w.tier2_calls + w.tier2_off[i]));
-        pi.calls.assign(t1, t1 + n1);
-        pi.tier2_calls.assign(t2, t2 + n2);
+        assignColumn(pi.calls, t1, n1);
+        assignColumn(pi.tier2_calls, t2, n2);
         pi.spanningDeletionReadCount = sd;
         pi.submappedReadCount = sm;
         pi.mapqTracker.count = mq;
