@@ -28,7 +28,7 @@ def link_profiled(program):
     inc = ["-I" + p for p in (OUT + "/adapter_src", ROOT + "/adapter", ROOT + "/include", L, L + "/starling_common", L + "/applications/starling",
                               L + "/applications/strelka", ROOT + "/oracle/ref/gen", ROOT + "/oracle/boost_shim", hts,
                               OUT + "/redist/rapidjson-1.1.0/include")]
-    binary = os.path.join(OUT, "bin", program + "_prof")
+    binary = os.path.join(tempfile.gettempdir(), program + "_prof")  # (not beside the product binaries: oracle/_ref/ travels to the GPU box)
     subprocess.run(["g++", "-std=c++11", "-O3", "-w", "-fPIC", "-ffp-contract=off", "-pg"] + inc + [REF + "/src/c++/bin/%s.cpp" % program] + objs +
                    [OUT + "/libreftus.a", hts + "/libhts.a", "-lm", "-lz", "-lpthread", "-L" + ROOT + "/oracle", "-lstrelka_amd_double",
                     "-Wl,-rpath," + ROOT + "/oracle", "-o", binary], check=True)
