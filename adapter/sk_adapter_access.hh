@@ -11,6 +11,8 @@
 #include "starling_common/starling_pos_processor_base.hh"
 
 #include <deque>
+#include <functional>
+#include <queue>
 #include <map>
 #include <set>
 #include <memory>
@@ -77,7 +79,10 @@ struct GeometryShadow
     bool isAnyActiveRegionCleared = false;
     pos_t clearedToPos = 0;    ///< reads at buffer positions <= this have left the reference's read buffer (CLEAR_READ_BUFFER)
     bool isAnyCleared = false;
-    std::vector<std::multiset<pos_t>> bufferedReadPos; ///< per sample: buffer positions of the reads the reference would still hold
+    /// per sample: buffer positions of the reads the reference would still hold (a min-heap: inserted per read, dropped from the low end
+    /// as the reference's CLEAR_READ_BUFFER stage would pass them, counted -- no node per read)
+    typedef std::priority_queue<pos_t, std::vector<pos_t>, std::greater<pos_t>> PosHeap;
+    std::vector<PosHeap> bufferedReadPos;
 };
 
 /// germline SNV genotypes of one stage window, computed ahead of the per-position calls of process_pos_snp_digt

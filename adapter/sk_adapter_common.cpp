@@ -117,7 +117,7 @@ void GeometryShadow::reset(const unsigned sampleCount)
     segments.clear();
     clearedToPos = 0;
     isAnyCleared = false;
-    bufferedReadPos.assign(sampleCount, std::multiset<pos_t>());
+    bufferedReadPos.assign(sampleCount, PosHeap());
 }
 
 void GeometryShadow::onSetHeadPos(const pos_t pos, const unsigned readBufferShift, const unsigned indelSpan)
@@ -171,7 +171,7 @@ void GeometryShadow::onSetHeadPos(const pos_t pos, const unsigned readBufferShif
         isAnyCleared = true;
         for (auto& held : bufferedReadPos)
         {
-            held.erase(held.begin(), held.upper_bound(clearedToPos));
+            while ((! held.empty()) && held.top() <= clearedToPos) held.pop();
         }
     }
 }
@@ -269,7 +269,7 @@ void on_read_inserted(starling_pos_processor_base& /*pp*/, const unsigned sample
     {
         throw blt_exception("strelka_amd adapter: spliced (RNA) reads are not supported on this path");
     }
-    state().geometry.bufferedReadPos[sampleIndex].insert(sread.get_full_segment().buffer_pos);
+    state().geometry.bufferedReadPos[sampleIndex].push(sread.get_full_segment().buffer_pos);
     pileup_note_read(sampleIndex, sread.get_full_segment().buffer_pos);
 }
 
