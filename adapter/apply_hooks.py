@@ -134,6 +134,13 @@ HOOKS = [
          r'    siteSampleInfo\.usedBasecallCount = cpi\.usedBasecallCount\(\);\n    siteSampleInfo\.unusedBasecallCount = cpi\.unusedBasecallCount\(\);\n',
          '    siteSampleInfo.usedBasecallCount = sk_adapter::used_basecall_count(sampleIndex, cpi);\n'
          '    siteSampleInfo.unusedBasecallCount = sk_adapter::unused_basecall_count(sampleIndex, cpi);\n'),
+        # the per-position work vectors of process_pos_snp_digt, kept between positions
+        ("process_pos_snp_digt: ploidy arrays",
+         r'    std::vector<int> groupLocusPloidy;\n    std::vector<int> callerPloidy;\n(    for \(unsigned sampleIndex\(0\); sampleIndex < sampleCount; \+\+sampleIndex\)\n    \{\n        // groupLocusPloidy of 0 is treated as a special case)',
+         '    std::vector<int>& groupLocusPloidy(sk_adapter::scratch_ploidy_vector(0));\n    std::vector<int>& callerPloidy(sk_adapter::scratch_ploidy_vector(1));\n\\1'),
+        ("process_pos_snp_digt: genotype array",
+         r'    std::vector<diploid_genotype> allDgt\(sampleCount\);\n(    for \(unsigned sampleIndex\(0\); sampleIndex < sampleCount; \+\+sampleIndex\)\n    \{\n        sk_adapter::site_diploid_genotype|    for \(unsigned sampleIndex\(0\); sampleIndex < sampleCount; \+\+sampleIndex\)\n    \{\n        computeSampleDiploidSiteGenotype)',
+         '    std::vector<diploid_genotype>& allDgt(sk_adapter::scratch_site_genotypes(sampleCount));\n\\1'),
         # site 3
         ("computeSampleDiploidSiteGenotype call",
          r'computeSampleDiploidSiteGenotype\(\n\s*_opt, _dopt, sample\(sampleIndex\), callerPloidy\[sampleIndex\], allDgt\[sampleIndex\]\);',

@@ -94,6 +94,11 @@ bool summary_basecall_counts(const unsigned sampleIndex, const CleanedPileup& cp
 /// the AD counting loop of updateSnvLocusWithSampleInfo (starling_pos_processor.cpp:446-469; false = not summarised)
 bool summary_allele_counts(const unsigned sampleIndex, const CleanedPileup& cpi, const uint8_t* baseIndexToAlleleIndex, const uint8_t fullAlleleCount,
                            LocusSupportingReadStats& supportCounts);
+/// process_pos_snp_digt's per-position work vectors (starling_pos_processor.cpp:637-655), kept between positions: the two ploidy
+/// arrays come back empty, the genotype array with `sampleCount` objects in their constructed state (diploid_genotype::reset) -- four
+/// heap allocations per position less
+std::vector<int>& scratch_ploidy_vector(const unsigned which);
+std::vector<diploid_genotype>& scratch_site_genotypes(const unsigned sampleCount);
 /// the four zero-depth genotypes of the constructor (starling_pos_processor_base.cpp:259-274)
 void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseId, diploid_genotype& dgt);
 

@@ -341,6 +341,24 @@ bool summary_allele_counts(const unsigned sampleIndex, const CleanedPileup& cpi,
     return true;
 }
 
+std::vector<int>& scratch_ploidy_vector(const unsigned which)
+{
+    static std::vector<int> v[2];
+    v[which & 1u].clear();
+    return v[which & 1u];
+}
+
+std::vector<diploid_genotype>& scratch_site_genotypes(const unsigned sampleCount)
+{
+    static std::vector<diploid_genotype> v;
+    if (v.size() != sampleCount) v.assign(sampleCount, diploid_genotype());
+    else
+    {
+        for (diploid_genotype& dgt : v) dgt.reset();
+    }
+    return v;
+}
+
 void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseIndex, diploid_genotype& dgt)
 {
     init();
