@@ -75,6 +75,8 @@ def main():
                 w = os.path.join(o, "%s_%d" % (tag, r))
                 os.makedirs(w)
                 env = dict(os.environ, GMON_OUT_PREFIX=os.path.join(o, "gmon_" + tag))
+                if tag == "other":  # ($OTHER_ENV="NAME=V,NAME=V": the same build under another setting, e.g. a stage window size)
+                    env.update(dict(kv.split("=") for kv in os.environ.get("OTHER_ENV", "").split(",") if kv))
                 subprocess.run(argv(binary, w + "/"), check=True, cwd=w, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
                 body = {f: E.vcf_body(os.path.join(w, f), keep_header=True) for f in sorted(os.listdir(w)) if f.endswith(".vcf") or f.endswith(".bed")}
                 outputs.setdefault(tag, body)
