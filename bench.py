@@ -264,7 +264,11 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                "hook_seconds": {k: round(v, 4) for k, v in hooks.items()},
                "hook_seconds_note": "summed over this rank's segment processes: wall seconds inside the adapter's hooks (*_hook) of which inside "
                                     "the C-ABI (*_abi); the rest of process_seconds_sum is the reference's own host code (BAM records, read "
-                                    "buffer, active regions, locus objects, VCF text)"}
+                                    "buffer, active regions, locus objects, VCF text)",
+               "host_note": "the drop-in's leg includes the adapter's host-side edits beside the routed sites (same bytes out: the germline "
+                            "caller's cleaned pileups counted instead of copied, the active-region / repeat-finder / depth-buffer / "
+                            "alignment-range loops restated; DESIGN.md section 6, profiles/r03_v26_host_remainder_ab.txt); both programs "
+                            "are built with the reference's release flags (-O3)"}
         if with_reference:
             t0 = time.perf_counter()
             ref = farm.run_farm(groups, argv_fn(program + "_ref"), os.path.join(root, "ref"), outputs, jobs=jobs)
