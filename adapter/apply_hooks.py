@@ -224,7 +224,7 @@ HOOKS = [
         # site 7: haplotype alignment + allele discovery
         ("discoverIndelsAndMismatches",
          r'(    const std::string& haplotypeSeq\(_selectedHaplotypes\[selectedHaplotypeIndex\]\);\n    assert \(haplotypeSeq != _refSegment\);\n)',
-         '\\1    if (sk_adapter::discover_indels_and_mismatches(haplotypeSeq, _refSegment, _ref, _posRange.begin_pos(), '
+         '\\1    if (sk_adapter::discover_indels_and_mismatches(_selectedHaplotypes, selectedHaplotypeIndex, _refSegment, _ref, _posRange.begin_pos(), '
          '_posRange.end_pos(), _prevActiveRegionEnd, _maxIndelSize, discoveredIndelsAndMismatches, numIndels)) return;\n'),
     ]),
 ]

@@ -168,8 +168,11 @@ bool repeat_span_update(const reference_contig_segment& ref, const pos_t pos, co
                         const unsigned minRepeatSpan, std::vector<std::vector<unsigned>>& repeatSpan, std::vector<bool>& isAnchor);
 
 // ---- site 7: ActiveRegionProcessor::discoverIndelsAndMismatches (ActiveRegionProcessor.cpp:572-705) ----
-bool discover_indels_and_mismatches(const std::string& haplotypeSeq, const std::string& refSegment,
-                                    const reference_contig_segment& ref, const pos_t regionBegin, const pos_t regionEnd,
+/// `selectedHaplotypes` / `selectedHaplotypeIndex`: the region's selected haplotypes and the one asked for -- the first call of a
+/// region aligns all of its alternate haplotypes in ONE sk_global_align batch, the later calls of processSelectedHaplotypes' loop
+/// (:528-551) take their path from it
+bool discover_indels_and_mismatches(const std::vector<std::string>& selectedHaplotypes, const unsigned selectedHaplotypeIndex,
+                                    const std::string& refSegment, const reference_contig_segment& ref, const pos_t regionBegin, const pos_t regionEnd,
                                     const pos_t prevActiveRegionEnd, const unsigned maxIndelSize,
                                     std::vector<IndelKey>& discovered, int& numIndels);
 

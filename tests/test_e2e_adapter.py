@@ -239,6 +239,8 @@ def _synth(variant, tmp_path, which, windows=None, extra_env=None):
         if v != "ref":
             cg, cs = _counters(pg.stderr.decode()), _counters(ps.stderr.decode())
             assert cg["realign_reads"] > 10000 and cg["indel_groups"] > 100 and cg["haplotypes"] > 100 and cg["site_recomputed"] > 100
+            # site 7: a region's alternate haplotypes go through sk_global_align in one batch
+            assert 0 < cg["haplotype_batches"] < cg["haplotypes"]
             assert cs["realign_reads"] > 15000 and cs["indel_groups"] > 30
             assert cg["pileup_pushes"] >= 2 and cg["pileup_reads"] > 10000 and cg["pileup_genotyping"] == 1
             assert cs["pileup_pushes"] >= 2 and cs["pileup_reads"] > 10000 and cs["pileup_genotyping"] == 1
