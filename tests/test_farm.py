@@ -112,6 +112,49 @@ def test_farm_with_wgs_flags_and_evs_models_identical_cpu_double(tmp_path, tmp_p
     assert all("pileup: pushes=" in t and "genotyping=1" in t for t in got.stderr_tails)
 
 
+@pytest.mark.skipif(not _have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_reference_with_n_runs_identical_cpu_double(tmp_path):
+    """A genome has runs of N (gaps, masked repeats) and contigs start at position 1; the synthetic reference has neither.  The same
+    reads against a copy of the reference with N runs written over it -- short ones inside homopolymers and tandem repeats, a long
+    one, one that begins the contig -- from position 1: every base comparison of the host code beside the routed sites
+    (active-region bookkeeping, repeat finder, valid alignment range) and of the routed sites themselves now meets N on the
+    reference side, and the reads over the runs are all mismatch there."""
+    import subprocess
+    import sys
+    import numpy as np
+    d = E.wgs_dataset(LENGTH)
+    lines = open(os.path.join(d, "wgs.fa")).read().split("\n")
+    seq = bytearray("".join(lines[1:]).encode())
+    rng = np.random.default_rng(77)
+    seq[0:180] = b"N" * 180                      # the contig begins with a gap
+    seq[60000:63000] = b"N" * 3000               # longer than any read and than the detector's ring of 1000 positions
+    for p in rng.integers(1000, 250000, 120):    # short runs, some of them inside the planted repeats
+        n = int(rng.integers(1, 60))
+        seq[int(p):int(p) + n] = b"N" * n
+    fa = tmp_path / "masked.fa"
+    with open(fa, "w") as f:
+        f.write(lines[0] + "\n")
+        for i in range(0, len(seq), 60):
+            f.write(seq[i:i + 60].decode() + "\n")
+    subprocess.run([os.path.join(E.BIN_DIR, "samtools"), "faidx", str(fa)], check=True)
+    md = tmp_path / "models"
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "make_dummy_germline_models.py"),
+                    str(md)], check=True)
+    models = (str(md / "germlineSNVScoringModels.json"), str(md / "germlineIndelScoringModels.json"))
+    out = {}
+    for variant in ("ref", "dbl"):
+        o = tmp_path / variant
+        o.mkdir()
+        argv = farm.germline_segment_argv("starling2_" + variant, str(o) + "/", [os.path.join(d, "wgs.bam")], ["chrW:1-100000", "chrW:100001-260000"],
+                                          str(fa), chrom_depth=os.path.join(d, "chrom_depth.txt"), evs_models=models, report_evs_features=True)
+        E.run(argv, env={"STRELKA_AMD_VERBOSE": "1"} if variant == "dbl" else None, timeout=1800)
+        out[variant] = {n: _body(str(o / n)) for n in OUTPUTS}
+    assert sum(1 for l in out["ref"]["variants.vcf"] if l and l[0] != "#") > 100
+    assert sum(1 for l in out["ref"]["genome.S1.vcf"] if "\tN\t" in l) > 50  # (records whose reference base is N)
+    for n in OUTPUTS:
+        assert out["dbl"][n] == out["ref"][n], n
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not _have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
 def test_farm_with_wgs_flags_identical_through_adapter_gpu(tmp_path, tmp_path_factory):
@@ -157,6 +200,41 @@ def test_somatic_farm_identical_through_adapter_cpu_double(tmp_path):
     for n in SOMATIC_OUTPUTS:
         assert _body(got.outputs[n]) == want[n], n
     assert all("pileup: pushes=" in t and "genotyping=1" in t for t in got.stderr_tails)
+
+
+@pytest.mark.skipif(not _have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
+def test_somatic_reference_with_n_runs_identical_cpu_double(tmp_path):
+    """the somatic caller on the tumour / normal pair against the reference with N runs written over it, from position 1 (see
+    test_reference_with_n_runs_identical_cpu_double)"""
+    import subprocess
+    import numpy as np
+    d = farm.wgs_somatic_dataset(SOMATIC_LENGTH)
+    lines = open(os.path.join(d, "normal.fa")).read().split("\n")
+    seq = bytearray("".join(lines[1:]).encode())
+    rng = np.random.default_rng(78)
+    seq[0:150] = b"N" * 150
+    seq[40000:41500] = b"N" * 1500
+    for p in rng.integers(1000, 110000, 60):
+        n = int(rng.integers(1, 50))
+        seq[int(p):int(p) + n] = b"N" * n
+    fa = tmp_path / "masked.fa"
+    with open(fa, "w") as f:
+        f.write(lines[0] + "\n")
+        for i in range(0, len(seq), 60):
+            f.write(seq[i:i + 60].decode() + "\n")
+    subprocess.run([os.path.join(E.BIN_DIR, "samtools"), "faidx", str(fa)], check=True)
+    names = ("somatic.snvs.vcf", "somatic.indels.vcf", "somatic.callable.regions.bed")
+    out = {}
+    for variant in ("ref", "dbl"):
+        o = tmp_path / variant
+        o.mkdir()
+        argv = farm.somatic_segment_argv("strelka2_" + variant, str(o) + "/", os.path.join(d, "normal.bam"), os.path.join(d, "tumor.bam"),
+                                         ["chrW:1-120000"], str(fa), chrom_depth=os.path.join(d, "chrom_depth.txt"), callable_regions=True)
+        E.run(argv, env={"STRELKA_AMD_VERBOSE": "1"} if variant == "dbl" else None, timeout=1800)
+        out[variant] = {n: _body(str(o / n)) for n in names}
+    assert sum(1 for l in out["ref"]["somatic.snvs.vcf"] if l and l[0] != "#") > 5
+    for n in names:
+        assert out["dbl"][n] == out["ref"][n], n
 
 
 @pytest.mark.gpu
