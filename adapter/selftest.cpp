@@ -14,6 +14,7 @@
 #include <cassert>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iosfwd>
 #include <iostream>
@@ -471,9 +472,10 @@ void testPlainRecord(Rng& rng)
 
 }
 
-int main()
+int main(int argc, char** argv)
 {
-    Rng rng(20260926);
+    // (the test suite runs the default seed; `adapter_selftest SEED` for other inputs)
+    Rng rng(argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 20260926ull);
     testValidAlignmentRange(rng);
     testRepeatSpan(rng);
     testDepthBuffer(rng);
