@@ -224,6 +224,9 @@ void candidateMask(starling_pos_processor_base& pp, const pos_t lo, const pos_t 
 /// record with a trivial copy and destructor.  A maintainer would give it `base_call() = default;` and assign would be a memmove; from
 /// outside the class the same effect needs the vector's end pointer: storage by reserve(), the records by memcpy, the end set through
 /// the implementation's own member (libstdc++'s _Vector_base::_M_impl, reached through a derived type).
+#ifndef __GLIBCXX__
+#error "assignColumn sets std::vector's end pointer through libstdc++'s _Vector_base::_M_impl; with another library use vector::assign"
+#endif
 struct ColumnOpener : public std::vector<base_call>
 {
     static void setSize(std::vector<base_call>& v, const size_t n)
