@@ -19,3 +19,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 find $OUT -name "*.csv" | head -20
 python tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json 2>$OUT/pmc_traffic.err; cat $OUT/pmc_traffic.json
+# one caller process, reference vs drop-in, with the adapter's hook timers: germline 1 Mb with the EVS models on, the tumour-normal pair
+SK_E2E_EVS=1 timeout 600 python tools/diag/e2e_wgs.py 1000000 amd 8192:0 > $OUT/e2e_wgs_evs.txt 2>&1; tail -4 $OUT/e2e_wgs_evs.txt
+timeout 600 python tools/diag/e2e_wgs_somatic.py 400000 amd "default=" > $OUT/e2e_wgs_somatic.txt 2>&1; tail -4 $OUT/e2e_wgs_somatic.txt
