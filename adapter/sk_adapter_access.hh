@@ -121,6 +121,8 @@ struct SiteChunk
     std::vector<sk_digt_call> calls;
     std::vector<uint32_t> cleanCount; ///< calls of the cleaned column each genotype was computed from
     std::vector<uint8_t> ploidy;      ///< ... and the ploidy
+    std::vector<uint32_t> rawCount;   ///< calls of the raw tier1 column
+    std::vector<uint32_t> strandBase; ///< [n][10]: the unfiltered tier1 calls per strand (reverse, forward) and base id (0-3, 4 = any)
     // germline EVS: the per-call arguments of updateGermlineScoringMetrics, kept until POST_ALIGN has passed the chunk
     std::vector<int64_t> evsOff;      ///< [n+1]
     std::vector<uint64_t> evsWords;
@@ -175,6 +177,7 @@ struct State
 {
     std::vector<CleanSummary> cleanSummary; ///< per sample
     int cleanSummaryArmed = -1;             ///< the sample whose next CleanPileupFilter call takes the summary, or -1
+    pos_t cleanSummaryArmedPos = 0;         ///< ... and the position it is called for
     GeometryShadow geometry;
     bool isAnyRealigned = false;
     pos_t realignedTo = 0;         ///< reads buffered at positions < realignedTo went through a realign job already

@@ -244,6 +244,7 @@ void germline_arm_clean_summary(const starling_pos_processor_base& pp, const pos
     State& s(state());
     if (s.cleanSummary.size() <= sampleIndex) s.cleanSummary.resize(sampleIndex + 1);
     s.cleanSummaryArmed = static_cast<int>(sampleIndex);
+    s.cleanSummaryArmedPos = pos;
     // the columns were written a window ago and each is a small block of its own: ask for the one two positions on
     __builtin_prefetch(&(pp.sample(sampleIndex).basecallBuffer.get_pos(pos + 6).calls));
     const snp_pos_info& ahead(pp.sample(sampleIndex).basecallBuffer.get_pos(pos + 2));
@@ -274,6 +275,32 @@ bool clean_pileup_summary(const snp_pos_info& pi, const bool isIncludeTier2)
         if (other.pi == &pi) other.pi = nullptr;
     }
     cs.pi = &pi;
+    if (s.pileup.isGenotyping && static_cast<size_t>(armed) < s.pileup.chunks.size())
+    {
+        // the counts were taken when the stream delivered the window (sk_adapter_pileup.cpp), if this is still that column
+        const pos_t pos(s.cleanSummaryArmedPos);
+        std::deque<SiteChunk>& chunks(s.pileup.chunks[static_cast<size_t>(armed)]);
+        while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front(); // (as site_diploid_genotype: POST_ALIGN only moves forward)
+        if ((! chunks.empty()) && chunks.front().begin <= pos)
+        {
+            const SiteChunk& c(chunks.front());
+            const size_t k(static_cast<size_t>(pos - c.begin));
+            if ((! c.rawCount.empty()) && c.rawCount[k] == pi.calls.size())
+            {
+                const uint32_t* const count(c.strandBase.data() + k * 10);
+                cs.used = 0;
+                for (unsigned strand(0); strand < 2; ++strand)
+                {
+                    for (unsigned b(0); b < 5; ++b)
+                    {
+                        cs.count[strand][b] = count[strand * 5 + b];
+                        cs.used += count[strand * 5 + b];
+                    }
+                }
+                return true;
+            }
+        }
+    }
     // CleanPileupFilter's tier1 test (PileupCleaner.cpp:40-50): what it would have copied, counted.  Most calls of a position land
     // on the same counter (the reference base of one strand or the other): two sets of counters, alternating, halve that chain.
     uint32_t count[2][2][8] = {};

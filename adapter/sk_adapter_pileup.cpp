@@ -357,6 +357,23 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
                 const int64_t k(static_cast<int64_t>(w.begin) + static_cast<int64_t>(i) - ploidyBegin);
                 chunk.ploidy[i] = (ploidyPtr && k >= 0 && k < ploidyLen) ? ploidyPtr[k] : 2;
             }
+            // what the germline caller reads of a position's cleaned tier1 column besides the genotype -- how many calls per strand
+            // and base (sk_adapter_germline.cpp, clean_pileup_summary) -- counted here, where the window's calls lie in one block,
+            // instead of position by position when POST_CALL comes back to them
+            chunk.rawCount.resize(n);
+            chunk.strandBase.assign(n * 10, 0);
+            for (size_t i(0); i < n; ++i)
+            {
+                const base_call* const calls(reinterpret_cast<const base_call*>(w.tier1_calls + w.tier1_off[i]));
+                const size_t callCount(static_cast<size_t>(w.tier1_off[i + 1] - w.tier1_off[i]));
+                chunk.rawCount[i] = static_cast<uint32_t>(callCount);
+                uint32_t* const count(chunk.strandBase.data() + i * 10);
+                for (size_t j(0); j < callCount; ++j)
+                {
+                    const base_call& bc(calls[j]);
+                    count[(bc.is_fwd_strand ? 5u : 0u) + std::min<unsigned>(bc.base_id, 4u)] += bc.is_call_filter ? 0u : 1u;
+                }
+            }
             s.siteLoci += n;
             s.siteBatches++;
         }
