@@ -245,6 +245,7 @@ void germline_arm_clean_summary(const starling_pos_processor_base& pp, const pos
     if (s.cleanSummary.size() <= sampleIndex) s.cleanSummary.resize(sampleIndex + 1);
     s.cleanSummaryArmed = static_cast<int>(sampleIndex);
     s.cleanSummaryArmedPos = pos;
+    if (s.pileup.isGenotyping) return; // (the counts come with the stream's windows: the column itself is not read)
     // the columns were written a window ago and each is a small block of its own: ask for the one two positions on
     __builtin_prefetch(&(pp.sample(sampleIndex).basecallBuffer.get_pos(pos + 6).calls));
     const snp_pos_info& ahead(pp.sample(sampleIndex).basecallBuffer.get_pos(pos + 2));

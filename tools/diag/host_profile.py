@@ -22,7 +22,7 @@ OUT = os.path.join(ROOT, "oracle", "_ref")
 def link_profiled(program):
     """the `make -C adapter double` link line with -pg; returns the binary's path"""
     subprocess.run(["make", "-C", os.path.join(ROOT, "adapter"), "double"], check=True, stdout=subprocess.DEVNULL)
-    objs = sorted(glob.glob(OUT + "/obj/adapter/hooked/*/*.o") + glob.glob(OUT + "/obj/adapter/hooked/*/*/*.o") + glob.glob(OUT + "/obj/adapter/*.o"))
+    objs = sorted(glob.glob(OUT + "/obj/adapter/hooked/*/*.o") + glob.glob(OUT + "/obj/adapter/hooked/*/*/*.o") + glob.glob(OUT + "/obj/adapter/sk_adapter_*.o"))
     L = REF + "/src/c++/lib"
     hts = OUT + "/redist/htslib-1.7-6-g6d2bfb7"
     inc = ["-I" + p for p in (OUT + "/adapter_src", ROOT + "/adapter", ROOT + "/include", L, L + "/starling_common", L + "/applications/starling",
