@@ -367,11 +367,21 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
                 const base_call* const calls(reinterpret_cast<const base_call*>(w.tier1_calls + w.tier1_off[i]));
                 const size_t callCount(static_cast<size_t>(w.tier1_off[i + 1] - w.tier1_off[i]));
                 chunk.rawCount[i] = static_cast<uint32_t>(callCount);
-                uint32_t* const count(chunk.strandBase.data() + i * 10);
-                for (size_t j(0); j < callCount; ++j)
+                // (most calls of a position land on one counter: two sets, alternating, halve that chain; base ids are 0..4)
+                uint32_t partial[2][16] = {};
+                size_t j(0);
+                for (; j + 2 <= callCount; j += 2)
                 {
-                    const base_call& bc(calls[j]);
-                    count[(bc.is_fwd_strand ? 5u : 0u) + std::min<unsigned>(bc.base_id, 4u)] += bc.is_call_filter ? 0u : 1u;
+                    const base_call& a(calls[j]);
+                    const base_call& b(calls[j + 1]);
+                    partial[0][(a.is_fwd_strand ? 8u : 0u) + (a.base_id & 7u)] += a.is_call_filter ? 0u : 1u;
+                    partial[1][(b.is_fwd_strand ? 8u : 0u) + (b.base_id & 7u)] += b.is_call_filter ? 0u : 1u;
+                }
+                if (j < callCount) partial[0][(calls[j].is_fwd_strand ? 8u : 0u) + (calls[j].base_id & 7u)] += calls[j].is_call_filter ? 0u : 1u;
+                uint32_t* const count(chunk.strandBase.data() + i * 10);
+                for (unsigned strand(0); strand < 2; ++strand)
+                {
+                    for (unsigned b(0); b < 8; ++b) count[strand * 5 + std::min(b, 4u)] += partial[0][strand * 8 + b] + partial[1][strand * 8 + b];
                 }
             }
             s.siteLoci += n;
