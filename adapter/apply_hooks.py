@@ -59,18 +59,6 @@ HOOKS = [
         ("active-region read buffer clear, deferred copy removed",
          r'(        write_reads\(pos\);\n\n        if \(is_active_region_detector_enabled\(\)\)\n        \{\n)            _getActiveRegionDetector\(\)\.clearReadBuffer\(pos\);\n',
          '\\1            /* strelka_amd: cleared at the undeferred distance, see the HEAD stage */\n'),
-        # second and later exons of spliced reads are initialised position by position (a read-buffer look-up per position and per
-        # read); the adapter refuses spliced reads when they are inserted (on_read_inserted), so there is never one to find
-        ("initializeSplicedReadSegmentsAtPos",
-         r'(    if        \(stage_no==STAGE::HEAD\)\n    \{\n)        initializeSplicedReadSegmentsAtPos\(pos\);\n',
-         '\\1        if (sk_adapter::spliced_reads_possible()) initializeSplicedReadSegmentsAtPos(pos);\n'),
-        # the estimated-depth buffers: an input read's matched positions a run at a time
-        ("load_read_in_depth_buffer, tier1",
-         r'        add_alignment_to_depth_buffer\(al\.pos,al\.path,sample\(sample_no\)\.estdepth_buff\);\n',
-         '        sk_adapter::depth_buffer_add_alignment(al.pos,al.path,sample(sample_no).estdepth_buff);\n'),
-        ("load_read_in_depth_buffer, tier2",
-         r'        add_alignment_to_depth_buffer\(al\.pos,al\.path,sample\(sample_no\)\.estdepth_buff_tier2\);\n',
-         '        sk_adapter::depth_buffer_add_alignment(al.pos,al.path,sample(sample_no).estdepth_buff_tier2);\n'),
         # site 1
         ("align_pos",
          r'(starling_pos_processor_base::\nalign_pos\(const pos_t pos\)\n\{\n)',
@@ -94,10 +82,8 @@ HOOKS = [
          r'        sif\.localRegionStatsCollection\.insert\(pos, sif\.cleanedPileup\.usedBasecallCount\(\), sif\.cleanedPileup\.unusedBasecallCount\(\),n_spandel,n_submapped\);\n',
          '    unsigned skUsed(0), skUnused(0);\n'
          '    if (! sk_adapter::sample_stats_counts(*this, pos, sample_no, skUsed, skUnused))\n    {\n'
-         '        sk_adapter::germline_arm_clean_summary(*this, pos, sample_no);\n'
          '        _pileupCleaner.CleanPileupFilter(pi,is_include_tier2,sif.cleanedPileup);\n'
-         '        skUsed = sk_adapter::used_basecall_count(sample_no, sif.cleanedPileup);\n'
-         '        skUnused = sk_adapter::unused_basecall_count(sample_no, sif.cleanedPileup);\n    }\n\n'
+         '        skUsed = sif.cleanedPileup.usedBasecallCount();\n        skUnused = sif.cleanedPileup.unusedBasecallCount();\n    }\n\n'
          '\\1        sif.localRegionStatsCollection.insert(pos, skUsed, skUnused,n_spandel,n_submapped);\n'),
         # sites 2+3: the window's genotypes are computed when POST_ALIGN reaches its first position
         ("process_pos_variants",
@@ -117,30 +103,6 @@ HOOKS = [
         ("germline EVS accumulators",
          r'(            siteSampleInfo\.ReadPosRankSum = pi\.get_read_pos_ranksum\(\);\n)',
          '            sk_adapter::germline_fill_scoring_metrics(sampleIndex, locus.pos, pi);\n\\1'),
-        # the cleaned pileup's counts from the summary (sk_adapter.hh, clean_pileup_summary)
-        ("getSiteAltAlleles: getBasecallCounts",
-         r'        good_pi\.getBasecallCounts\(sampleBaseCounts\);\n',
-         '        if (! sk_adapter::summary_basecall_counts(sampleIndex, cpi, sampleBaseCounts.data())) good_pi.getBasecallCounts(sampleBaseCounts);\n'),
-        ("updateSnvLocusWithSampleInfo: used count, ploidy conflict",
-         r'    if \(cpi\.usedBasecallCount\(\) != 0\)\n(    \{\n        // the principle of this filter)',
-         '    if (sk_adapter::used_basecall_count(sampleIndex, cpi) != 0)\n\\1'),
-        ("updateSnvLocusWithSampleInfo: used count, genotype",
-         r'    if     \(locus\.isRefUnknown\(\) or \(cpi\.usedBasecallCount\(\) == 0\) or isOverlappingHomAltDeletion\)\n(    \{\n        sampleInfo\.genotypeQuality = 0;\n        sampleInfo\.maxGenotypeIndex\.setGenotypeFromAlleleIndices\(\);\n\n        sampleInfo\.genotypeQualityPolymorphic=0;)',
-         '    if     (locus.isRefUnknown() or (sk_adapter::used_basecall_count(sampleIndex, cpi) == 0) or isOverlappingHomAltDeletion)\n\\1'),
-        ("updateSnvLocusWithSampleInfo: AD counts",
-         r'(            sampleInfo\.supportCounts\.setAltCount\(altAlleleCount\);\n\n            const snp_pos_info& good_pi\(cpi\.cleanedPileup\(\)\);\n)(            for \(const auto& call : good_pi\.calls\)\n            \{\n                if \(call\.base_id == BASE_ID::ANY\) continue;\n)',
-         '\\1            if (! sk_adapter::summary_allele_counts(sampleIndex, cpi, baseIndexToAlleleIndex, fullAlleleCount, sampleInfo.supportCounts))\n\\2'),
-        ("updateSiteSampleInfo: used and unused counts",
-         r'    siteSampleInfo\.usedBasecallCount = cpi\.usedBasecallCount\(\);\n    siteSampleInfo\.unusedBasecallCount = cpi\.unusedBasecallCount\(\);\n',
-         '    siteSampleInfo.usedBasecallCount = sk_adapter::used_basecall_count(sampleIndex, cpi);\n'
-         '    siteSampleInfo.unusedBasecallCount = sk_adapter::unused_basecall_count(sampleIndex, cpi);\n'),
-        # the per-position work vectors of process_pos_snp_digt, kept between positions
-        ("process_pos_snp_digt: ploidy arrays",
-         r'    std::vector<int> groupLocusPloidy;\n    std::vector<int> callerPloidy;\n(    for \(unsigned sampleIndex\(0\); sampleIndex < sampleCount; \+\+sampleIndex\)\n    \{\n        // groupLocusPloidy of 0 is treated as a special case)',
-         '    std::vector<int>& groupLocusPloidy(sk_adapter::scratch_ploidy_vector(0));\n    std::vector<int>& callerPloidy(sk_adapter::scratch_ploidy_vector(1));\n\\1'),
-        ("process_pos_snp_digt: genotype array",
-         r'    std::vector<diploid_genotype> allDgt\(sampleCount\);\n(    for \(unsigned sampleIndex\(0\); sampleIndex < sampleCount; \+\+sampleIndex\)\n    \{\n        sk_adapter::site_diploid_genotype|    for \(unsigned sampleIndex\(0\); sampleIndex < sampleCount; \+\+sampleIndex\)\n    \{\n        computeSampleDiploidSiteGenotype)',
-         '    std::vector<diploid_genotype>& allDgt(sk_adapter::scratch_site_genotypes(sampleCount));\n\\1'),
         # site 3
         ("computeSampleDiploidSiteGenotype call",
          r'computeSampleDiploidSiteGenotype\(\n\s*_opt, _dopt, sample\(sampleIndex\), callerPloidy\[sampleIndex\], allDgt\[sampleIndex\]\);',
@@ -175,36 +137,10 @@ HOOKS = [
     ]),
     (L + "starling_common/starling_pos_processor_util.cpp", [
         ("include", r'#include "starling_common/starling_pos_processor_util.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
-        # the two per-base validity loops of checkBamRecord, decided by table for the common case
-        ("checkBamRecord",
-         r'    const bool isKeepRecord\(checkBamRecord\(read_stream, read\)\);\n',
-         '    const bool isKeepRecord(sk_adapter::is_plain_bam_record(read.qual(), read.read_size()) || checkBamRecord(read_stream, read));\n'),
         # site 8, second half: the region's alignments normalised in one batch
         ("normalizeAlignment",
          r'        normalizeAlignment\(refBamSeq, readBamSeq, readAlignment\);\n',
          '        if (! sk_adapter::feed_normalize_current(&read_stream, ref, readAlignment)) normalizeAlignment(refBamSeq, readBamSeq, readAlignment);\n'),
-    ]),
-    (L + "starling_common/starling_pos_processor_indel_util.cpp", [
-        ("include", r'#include "starling_pos_processor_indel_util.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
-        ("get_valid_alignment_range", r'    get_valid_alignment_range\(al,ref_bseq,read_seq,valid_pr\);\n',
-         '    sk_adapter::valid_alignment_range(al, ref, read_seq, valid_pr);\n'),
-        # the active-region detector's per-base bookkeeping of an aligned segment, in one call
-        ("active-region match/mismatch loop",
-         r'(            // detect active regions \(match/mismatch\)\n)            for \(unsigned j\(0\); j < ps\.length; \+\+j\)\n            \{\n(?:.*\n)*?            \}\n(        \}\n\n        for \(unsigned i\(0\); i<n_seg; \+\+i\))',
-         '\\1            sk_adapter::active_region_insert_aligned_segment(activeRegionReadBuffer, id, ref, read_seq, read_offset, ref_head_pos, ps.length);\n\\2'),
-    ]),
-    (L + "starling_common/PileupCleaner.cpp", [
-        ("include", r'#include "PileupCleaner.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
-        ("CleanPileupFilter: counted instead of copied",
-         r'(    cpi\._n_raw_calls = pi\.calls\.size\(\);\n)(    for \(const auto& bc : pi\.calls\)\n    \{\n        if \(bc\.is_call_filter\)\n        \{\n            if \(! \(is_include_tier2 &&)',
-         '\\1    if (sk_adapter::clean_pileup_summary(pi, is_include_tier2)) return;\n\\2'),
-    ]),
-    (L + "starling_common/ReferenceRepeatFinder.cpp", [
-        ("include", r'#include "ReferenceRepeatFinder.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
-        # the anchor finder's per-position table update (host work: 50 unit lengths per position)
-        ("updateRepeatSpan",
-         r'(void ReferenceRepeatFinder::updateRepeatSpan\(pos_t pos\)\n\{\n)',
-         '\\1    if (sk_adapter::repeat_span_update(_ref, pos, _maxRepeatUnitLength, _maxBufferSize, _minRepeatSpan, _repeatSpan, _isAnchor)) return;\n'),
     ]),
     (L + "htsapi/bam_streamer.cpp", [
         ("include", r'#include "htsapi/bam_streamer.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),

@@ -42,10 +42,6 @@ struct IndelKey;
 struct alignment;
 class ActiveRegionReadBuffer;
 struct bam_seq_base;
-struct pos_range;
-struct depth_buffer;
-namespace ALIGNPATH { struct path_segment; }
-struct LocusSupportingReadStats;
 
 namespace sk_adapter
 {
@@ -76,29 +72,6 @@ bool align_pos(starling_pos_processor_base& pp, const pos_t pos);
 void before_process_pos_variants(starling_pos_processor_base& pp, const pos_t pos);
 void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const unsigned sampleIndex, const unsigned ploidy,
                            diploid_genotype& dgt);
-// The germline caller reads a position's cleaned tier1 pileup (CleanPileupFilter, PileupCleaner.cpp:28-66) three times and only for
-// counts: how many calls it holds (process_pos_sample_stats, updateSnvLocusWithSampleInfo, updateSiteSampleInfo), how many per base
-// (getSiteAltAlleles) and how many per allele and strand (the AD counts) -- the genotype itself comes from the kernels.  So the copy is
-// not made: one pass over the raw calls counts the unfiltered ones per strand and base, and the five places read the counts.
-/// process_pos_sample_stats, before its CleanPileupFilter call: arms the summary for this sample's next CleanPileupFilter (germline
-/// diploid caller only)
-void germline_arm_clean_summary(const starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex);
-/// inside CleanPileupFilter, after the raw pointer, reference base and raw count are set: true = the summary was taken instead of
-/// the copy (armed, tier1 only)
-bool clean_pileup_summary(const snp_pos_info& pi, const bool isIncludeTier2);
-/// CleanedPileup::usedBasecallCount() / unusedBasecallCount() of a sample's current position, whichever way it was cleaned
-unsigned used_basecall_count(const unsigned sampleIndex, const CleanedPileup& cpi);
-unsigned unused_basecall_count(const unsigned sampleIndex, const CleanedPileup& cpi);
-/// snp_pos_info::getBasecallCounts of the cleaned pileup (false = not summarised, the caller counts)
-bool summary_basecall_counts(const unsigned sampleIndex, const CleanedPileup& cpi, double* baseCount);
-/// the AD counting loop of updateSnvLocusWithSampleInfo (starling_pos_processor.cpp:446-469; false = not summarised)
-bool summary_allele_counts(const unsigned sampleIndex, const CleanedPileup& cpi, const uint8_t* baseIndexToAlleleIndex, const uint8_t fullAlleleCount,
-                           LocusSupportingReadStats& supportCounts);
-/// process_pos_snp_digt's per-position work vectors (starling_pos_processor.cpp:637-655), kept between positions: the two ploidy
-/// arrays come back empty, the genotype array with `sampleCount` objects in their constructed state (diploid_genotype::reset) -- four
-/// heap allocations per position less
-std::vector<int>& scratch_ploidy_vector(const unsigned which);
-std::vector<diploid_genotype>& scratch_site_genotypes(const unsigned sampleCount);
 /// the four zero-depth genotypes of the constructor (starling_pos_processor_base.cpp:259-274)
 void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseId, diploid_genotype& dgt);
 
@@ -141,31 +114,6 @@ void somatic_indel(const strelka_options& opt, const starling_sample_options& no
 /// ActiveRegionDetector::clearReadBuffer at the position the UNDEFERRED READ_BUFFER stage would be at while HEAD is at `headStagePos`
 void clear_active_region_read_buffer_undeferred(starling_pos_processor_base& pp, const pos_t headStagePos, const unsigned readBufferShift,
                                                 const pos_t minPos);
-
-/// add_alignment_to_depth_buffer (depth_buffer_util.cpp:29-48) with the positions inside the buffer's present range taken a run at a
-/// time (sk_adapter_depth_buffer.cpp)
-void depth_buffer_add_alignment(const pos_t pos, const std::vector<ALIGNPATH::path_segment>& path, depth_buffer& buffer);
-
-/// checkBamRecord's two per-base loops (starling_pos_processor_util.cpp:203-240) for the common case: true = every base code is one of
-/// A, C, G, T, N and every quality is at most 70, so the record is kept; false = undecided, checkBamRecord itself runs (and reports).
-/// `qual` is bam_record::qual() of a record of `readSize` bases: the packed bases sit right before it.
-bool is_plain_bam_record(const uint8_t* qual, const unsigned readSize);
-
-/// false: on_read_inserted throws for a spliced read, so the read buffer never holds second or later exons
-bool spliced_reads_possible();
-
-/// get_valid_alignment_range (starling_read_util.cpp:218-329) at starling_pos_processor_indel_util.cpp:335, without its per-read
-/// allocations and virtual base look-ups (host work, the same arithmetic)
-void valid_alignment_range(const alignment& al, const reference_contig_segment& ref, const bam_seq_base& readSeq, pos_range& validRange);
-
-/// the match / mismatch bookkeeping of one aligned segment of an input read (starling_pos_processor_indel_util.cpp:463-483), in one call
-void active_region_insert_aligned_segment(ActiveRegionReadBuffer& buffer, const unsigned alignId, const reference_contig_segment& ref,
-                                          const bam_seq_base& readSeq, const unsigned readOffset, const pos_t refHeadPos, const unsigned length);
-
-/// ReferenceRepeatFinder::updateRepeatSpan (ReferenceRepeatFinder.cpp:26-59) for a position whose look-back lies inside the reference
-/// segment: the same table rows and anchor flags, the ring indices taken once (false = not handled, run the reference's loop)
-bool repeat_span_update(const reference_contig_segment& ref, const pos_t pos, const unsigned maxRepeatUnitLength, const unsigned ringSize,
-                        const unsigned minRepeatSpan, std::vector<std::vector<unsigned>>& repeatSpan, std::vector<bool>& isAnchor);
 
 // ---- site 7: ActiveRegionProcessor::discoverIndelsAndMismatches (ActiveRegionProcessor.cpp:572-705) ----
 /// `selectedHaplotypes` / `selectedHaplotypeIndex`: the region's selected haplotypes and the one asked for -- the first call of a

@@ -96,14 +96,6 @@ struct SiteCache
     void clear() { begin = end = 0; isValid.clear(); ploidy.clear(); callCount.clear(); calls.clear(); }
 };
 
-/// the unfiltered tier1 calls of one sample's current position, counted instead of copied (clean_pileup_summary)
-struct CleanSummary
-{
-    const snp_pos_info* pi = nullptr; ///< the raw pileup the counts were taken from; null = this position was cleaned by copy
-    uint32_t used = 0;
-    uint32_t count[2][5] = {};        ///< [is_fwd_strand][base id, 4 = any]
-};
-
 /// somatic SNV records of one stage window
 struct SomaticSiteCache
 {
@@ -121,8 +113,6 @@ struct SiteChunk
     std::vector<sk_digt_call> calls;
     std::vector<uint32_t> cleanCount; ///< calls of the cleaned column each genotype was computed from
     std::vector<uint8_t> ploidy;      ///< ... and the ploidy
-    std::vector<uint32_t> rawCount;   ///< calls of the raw tier1 column
-    std::vector<uint32_t> strandBase; ///< [n][10]: the unfiltered tier1 calls per strand (reverse, forward) and base id (0-3, 4 = any)
     // germline EVS: the per-call arguments of updateGermlineScoringMetrics, kept until POST_ALIGN has passed the chunk
     std::vector<int64_t> evsOff;      ///< [n+1]
     std::vector<uint64_t> evsWords;
@@ -169,15 +159,8 @@ struct WindowSegment
     pos_t bufferPos;
 };
 
-/// the read segments buffered at positions [begin, end), appended in the order position by position iteration gives
-/// (sk_adapter_read_buffer.cpp)
-void collect_window_segments(starling_read_buffer& buffer, const pos_t begin, const pos_t end, std::vector<WindowSegment>& segments);
-
 struct State
 {
-    std::vector<CleanSummary> cleanSummary; ///< per sample
-    int cleanSummaryArmed = -1;             ///< the sample whose next CleanPileupFilter call takes the summary, or -1
-    pos_t cleanSummaryArmedPos = 0;         ///< ... and the position it is called for
     GeometryShadow geometry;
     bool isAnyRealigned = false;
     pos_t realignedTo = 0;         ///< reads buffered at positions < realignedTo went through a realign job already

@@ -235,34 +235,6 @@ unsigned buffered_read_count(const starling_pos_processor_base& /*pp*/, const un
     return static_cast<unsigned>(state().geometry.bufferedReadPos[sampleIndex].size());
 }
 
-bool is_plain_bam_record(const uint8_t* qual, const unsigned readSize)
-{
-    static uint8_t isBadPair[256];
-    static bool isTable(false);
-    if (! isTable)
-    {
-        // is_valid_bam_code (starling_pos_processor_util.cpp:141-156): A = 1, C = 2, G = 4, T = 8, ANY = 15
-        bool isValidCode[16] = {};
-        isValidCode[1] = isValidCode[2] = isValidCode[4] = isValidCode[8] = isValidCode[15] = true;
-        for (unsigned b(0); b < 256; ++b) isBadPair[b] = (isValidCode[b >> 4] && isValidCode[b & 15u]) ? 0 : 1;
-        isTable = true;
-    }
-    if (readSize == 0 || readSize > 25000u) return false; // (STRELKA_MAX_READ_SIZE, starling_base_shared.hh:37: the reference's error exits)
-    const uint8_t* const packed(qual - ((readSize + 1u) >> 1));
-    unsigned bad(0);
-    const unsigned fullBytes(readSize >> 1);
-    for (unsigned i(0); i < fullBytes; ++i) bad |= isBadPair[packed[i]];
-    if (readSize & 1u) bad |= isBadPair[(packed[fullBytes] & 0xf0u) | 1u]; // (the last base is the high nibble; the pad is not looked at)
-    uint8_t maxQual(0);
-    for (unsigned i(0); i < readSize; ++i) maxQual = std::max(maxQual, qual[i]);
-    return (bad == 0) && (maxQual <= 70); // (qphred_cache::MAX_QSCORE; a quality of 255 is the reference's filter case)
-}
-
-bool spliced_reads_possible()
-{
-    return false;
-}
-
 void on_read_inserted(starling_pos_processor_base& /*pp*/, const unsigned sampleIndex, const starling_read& sread)
 {
     if (sread.isSpliced())

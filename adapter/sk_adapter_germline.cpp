@@ -15,10 +15,7 @@
 #include "applications/starling/starling_pos_processor.hh"
 #include "blt_common/position_snp_call_pprob_digt.hh"
 #include "blt_util/seq_util.hh"
-#include "starling_common/LocusSupportingReadStats.hh"
-#include "starling_common/PileupCleaner.hh"
 
-#include <cstdlib>
 #include <cstring>
 
 namespace sk_adapter
@@ -175,8 +172,7 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
     State& s(state());
     SiteCache& cache(s.sites);
     const starling_pos_processor_base& base(pp);
-    const CleanedPileup& cpi(base.sample(sampleIndex).cleanedPileup);
-    const size_t cleanedCount(used_basecall_count(sampleIndex, cpi));
+    const snp_pos_info& cleaned(base.sample(sampleIndex).cleanedPileup.cleanedPileup());
     const unsigned sampleCount(Access::sampleCount(base));
     if (s.pileup.isGenotyping)
     {
@@ -186,7 +182,7 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
         {
             const SiteChunk& c(chunks.front());
             const size_t k(static_cast<size_t>(pos - c.begin));
-            if (c.ploidy[k] == ploidy && c.cleanCount[k] == cleanedCount)
+            if (c.ploidy[k] == ploidy && c.cleanCount[k] == cleaned.calls.size())
             {
                 toDiploidGenotype(c.calls[k], ploidy, dgt);
                 return;
@@ -196,7 +192,7 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
     else if (pos >= cache.begin && pos < cache.end)
     {
         const size_t k(static_cast<size_t>(pos - cache.begin) * sampleCount + sampleIndex);
-        if (cache.isValid[k] && cache.ploidy[k] == ploidy && cache.callCount[k] == cleanedCount)
+        if (cache.isValid[k] && cache.ploidy[k] == ploidy && cache.callCount[k] == cleaned.calls.size())
         {
             toDiploidGenotype(cache.calls[k], ploidy, dgt);
             return;
@@ -206,185 +202,19 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
     // genotype the locus as it is now
     std::vector<int64_t> callOff(1, 0);
     std::vector<uint16_t> calls;
-    appendCleanedCalls(cpi.rawPileup(), calls); // (the cleaned tier1 column, whether or not the copy was made)
+    for (const base_call& bc : cleaned.calls)
+    {
+        uint16_t v;
+        std::memcpy(&v, &bc, 2);
+        calls.push_back(v);
+    }
     callOff.push_back(static_cast<int64_t>(calls.size()));
-    const std::vector<uint8_t> refBase(1, refBaseId(cpi.rawPileup().get_ref_base()));
+    const std::vector<uint8_t> refBase(1, refBaseId(cleaned.get_ref_base()));
     const std::vector<uint8_t> pl(1, static_cast<uint8_t>(ploidy));
     sk_digt_call out;
     genotypeLoci(Access::opt(base), callOff, calls, refBase, pl, &out);
     toDiploidGenotype(out, ploidy, dgt);
     s.siteRecomputed++;
-}
-
-namespace
-{
-
-bool isCleanSummaryEnabled()
-{
-    static const char* const v(std::getenv("STRELKA_AMD_CLEAN_SUMMARY"));
-    static const bool isEnabled(v == nullptr || *v == 0 || std::strtoul(v, nullptr, 10) != 0);
-    return isEnabled;
-}
-
-/// the sample's summary if it was taken from the pileup this CleanedPileup points at
-const CleanSummary* summaryOf(const unsigned sampleIndex, const CleanedPileup& cpi)
-{
-    const State& s(state());
-    if (sampleIndex >= s.cleanSummary.size()) return nullptr;
-    const CleanSummary& cs(s.cleanSummary[sampleIndex]);
-    return (cs.pi != nullptr && cs.pi == &(cpi.rawPileup())) ? &cs : nullptr;
-}
-
-}
-
-void germline_arm_clean_summary(const starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex)
-{
-    const starling_base_options& opt(Access::opt(pp));
-    if (opt.isSomaticCallingMode || (! opt.is_bsnp_diploid()) || (! isCleanSummaryEnabled())) return;
-    State& s(state());
-    if (s.cleanSummary.size() <= sampleIndex) s.cleanSummary.resize(sampleIndex + 1);
-    s.cleanSummaryArmed = static_cast<int>(sampleIndex);
-    s.cleanSummaryArmedPos = pos;
-    if (s.pileup.isGenotyping) return; // (the counts come with the stream's windows: the column itself is not read)
-    // the columns were written a window ago and each is a small block of its own: ask for the one two positions on
-    __builtin_prefetch(&(pp.sample(sampleIndex).basecallBuffer.get_pos(pos + 6).calls));
-    const snp_pos_info& ahead(pp.sample(sampleIndex).basecallBuffer.get_pos(pos + 2));
-    if (! ahead.calls.empty())
-    {
-        __builtin_prefetch(ahead.calls.data());
-        __builtin_prefetch(reinterpret_cast<const char*>(ahead.calls.data()) + 64);
-    }
-}
-
-bool clean_pileup_summary(const snp_pos_info& pi, const bool isIncludeTier2)
-{
-    State& s(state());
-    const int armed(s.cleanSummaryArmed);
-    s.cleanSummaryArmed = -1;
-    if (armed < 0 || isIncludeTier2)
-    {
-        // cleaned by copy: no summary may go on describing this pileup object (the basecall buffer reuses its entries)
-        for (CleanSummary& cs : s.cleanSummary)
-        {
-            if (cs.pi == &pi) cs.pi = nullptr;
-        }
-        return false;
-    }
-    CleanSummary& cs(s.cleanSummary[static_cast<size_t>(armed)]);
-    for (CleanSummary& other : s.cleanSummary)
-    {
-        if (other.pi == &pi) other.pi = nullptr;
-    }
-    cs.pi = &pi;
-    if (s.pileup.isGenotyping && static_cast<size_t>(armed) < s.pileup.chunks.size())
-    {
-        // the counts were taken when the stream delivered the window (sk_adapter_pileup.cpp), if this is still that column
-        const pos_t pos(s.cleanSummaryArmedPos);
-        std::deque<SiteChunk>& chunks(s.pileup.chunks[static_cast<size_t>(armed)]);
-        while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front(); // (as site_diploid_genotype: POST_ALIGN only moves forward)
-        if ((! chunks.empty()) && chunks.front().begin <= pos)
-        {
-            const SiteChunk& c(chunks.front());
-            const size_t k(static_cast<size_t>(pos - c.begin));
-            if ((! c.rawCount.empty()) && c.rawCount[k] == pi.calls.size())
-            {
-                const uint32_t* const count(c.strandBase.data() + k * 10);
-                cs.used = 0;
-                for (unsigned strand(0); strand < 2; ++strand)
-                {
-                    for (unsigned b(0); b < 5; ++b)
-                    {
-                        cs.count[strand][b] = count[strand * 5 + b];
-                        cs.used += count[strand * 5 + b];
-                    }
-                }
-                return true;
-            }
-        }
-    }
-    // CleanPileupFilter's tier1 test (PileupCleaner.cpp:40-50): what it would have copied, counted.  Most calls of a position land
-    // on the same counter (the reference base of one strand or the other): two sets of counters, alternating, halve that chain.
-    uint32_t count[2][2][8] = {};
-    const base_call* const calls(pi.calls.data());
-    const size_t n(pi.calls.size());
-    size_t i(0);
-    for (; i + 2 <= n; i += 2)
-    {
-        const base_call& a(calls[i]);
-        const base_call& b(calls[i + 1]);
-        count[0][a.is_fwd_strand ? 1 : 0][a.base_id & 7u] += a.is_call_filter ? 0u : 1u;
-        count[1][b.is_fwd_strand ? 1 : 0][b.base_id & 7u] += b.is_call_filter ? 0u : 1u;
-    }
-    if (i < n) count[0][calls[i].is_fwd_strand ? 1 : 0][calls[i].base_id & 7u] += calls[i].is_call_filter ? 0u : 1u;
-    cs.used = 0;
-    for (unsigned strand(0); strand < 2; ++strand)
-    {
-        for (unsigned b(0); b < 5; ++b) cs.count[strand][b] = 0;
-        for (unsigned b(0); b < 8; ++b)
-        {
-            // (base ids are 0..4, BASE_ID::ANY = 4)
-            const uint32_t c(count[0][strand][b] + count[1][strand][b]);
-            cs.count[strand][std::min(b, 4u)] += c;
-            cs.used += c;
-        }
-    }
-    return true;
-}
-
-unsigned used_basecall_count(const unsigned sampleIndex, const CleanedPileup& cpi)
-{
-    const CleanSummary* cs(summaryOf(sampleIndex, cpi));
-    return (cs != nullptr) ? cs->used : cpi.usedBasecallCount();
-}
-
-unsigned unused_basecall_count(const unsigned sampleIndex, const CleanedPileup& cpi)
-{
-    const CleanSummary* cs(summaryOf(sampleIndex, cpi));
-    return (cs != nullptr) ? (cpi.totalBasecallCount() - cs->used) : cpi.unusedBasecallCount();
-}
-
-bool summary_basecall_counts(const unsigned sampleIndex, const CleanedPileup& cpi, double* baseCount)
-{
-    const CleanSummary* cs(summaryOf(sampleIndex, cpi));
-    if (cs == nullptr) return false;
-    // snp_pos_info::getBasecallCounts (snp_pos_info.hh:162-174): unknown bases are not counted
-    for (unsigned b(0); b < 4; ++b) baseCount[b] = static_cast<double>(cs->count[0][b] + cs->count[1][b]);
-    return true;
-}
-
-bool summary_allele_counts(const unsigned sampleIndex, const CleanedPileup& cpi, const uint8_t* baseIndexToAlleleIndex, const uint8_t fullAlleleCount,
-                           LocusSupportingReadStats& supportCounts)
-{
-    const CleanSummary* cs(summaryOf(sampleIndex, cpi));
-    if (cs == nullptr) return false;
-    for (unsigned b(0); b < 4; ++b)
-    {
-        const uint8_t alleleIndex(baseIndexToAlleleIndex[b]);
-        if (alleleIndex == fullAlleleCount) continue;
-        for (unsigned strand(0); strand < 2; ++strand)
-        {
-            if (cs->count[strand][b] != 0) supportCounts.getCounts(strand != 0).incrementAlleleCount(alleleIndex, cs->count[strand][b]);
-        }
-    }
-    return true;
-}
-
-std::vector<int>& scratch_ploidy_vector(const unsigned which)
-{
-    static std::vector<int> v[2];
-    v[which & 1u].clear();
-    return v[which & 1u];
-}
-
-std::vector<diploid_genotype>& scratch_site_genotypes(const unsigned sampleCount)
-{
-    static std::vector<diploid_genotype> v;
-    if (v.size() != sampleCount) v.assign(sampleCount, diploid_genotype());
-    else
-    {
-        for (diploid_genotype& dgt : v) dgt.reset();
-    }
-    return v;
 }
 
 void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseIndex, diploid_genotype& dgt)

@@ -18,8 +18,9 @@
 // writer of a somatic record ever reads: the stream returns each tumor call's read position and read length, and
 // somatic_fill_scoring_metrics() rebuilds the two accumulators for a position just before its record is written.
 //
-// Not routed (the reference's own pileup runs): runs that compute the GERMLINE EVS accumulators (updateGermlineScoringMetrics:
-// three rank sums over every basecall), and $STRELKA_AMD_PILEUP=0.
+// The germline EVS accumulators (updateGermlineScoringMetrics: three rank sums and a mean over every basecall) are only read where a
+// variant record is scored: the stream returns the per-call arguments (P2's EVS column) and germline_fill_scoring_metrics() rebuilds
+// a position's accumulators just before they are read.  Not routed (the reference's own pileup runs): $STRELKA_AMD_PILEUP=0.
 #include "sk_adapter_access.hh"
 
 #include "blt_util/log.hh"
@@ -30,7 +31,6 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
-#include <type_traits>
 
 namespace sk_adapter
 {
@@ -219,34 +219,6 @@ void candidateMask(starling_pos_processor_base& pp, const pos_t lo, const pos_t 
 
 /// the finalised positions of a window into the reference's pos_basecall_buffer (what insert_pos_basecall / insert_mapq_count /
 /// insert_pos_spandel_count / insert_pos_submap_count would have left there)
-/// column := the n records at `from`.  vector::assign (and resize with a fill value) handle base_call one element at a time: the type
-/// has a constructor with arguments and no default one, so the library does not take it for plain data, although it is a 16-bit
-/// record with a trivial copy and destructor.  A maintainer would give it `base_call() = default;` and assign would be a memmove; from
-/// outside the class the same effect needs the vector's end pointer: storage by reserve(), the records by memcpy, the end set through
-/// the implementation's own member (libstdc++'s _Vector_base::_M_impl, reached through a derived type).
-#ifndef __GLIBCXX__
-#error "assignColumn sets std::vector's end pointer through libstdc++'s _Vector_base::_M_impl; with another library use vector::assign"
-#endif
-struct ColumnOpener : public std::vector<base_call>
-{
-    static void setSize(std::vector<base_call>& v, const size_t n)
-    {
-        ColumnOpener& o(static_cast<ColumnOpener&>(v));
-        o._M_impl._M_finish = o._M_impl._M_start + n;
-    }
-};
-static_assert(std::is_trivially_copyable<base_call>::value && std::is_trivially_destructible<base_call>::value,
-              "the column is filled by memcpy");
-
-inline void assignColumn(std::vector<base_call>& column, const base_call* const from, const size_t n)
-{
-    column.clear();
-    if (n == 0) return;
-    column.reserve(n);
-    std::memcpy(static_cast<void*>(column.data()), from, n * sizeof(base_call));
-    ColumnOpener::setSize(column, n);
-}
-
 void assignWindow(starling_pos_processor_base::sample_info& sif, const sk_pileup_window& w)
 {
     const size_t n(static_cast<size_t>(w.end - w.begin));
@@ -261,8 +233,8 @@ void assignWindow(starling_pos_processor_base::sample_info& sif, const sk_pileup
         // (base_call is the 16-bit record itself: the column is a run of them)
         const base_call* const t1(reinterpret_cast<const base_call*>(w.tier1_calls + w.tier1_off[i]));
         const base_call* const t2(reinterpret_cast<const base_call*>(w.tier2_calls + w.tier2_off[i]));
-        assignColumn(pi.calls, t1, n1);
-        assignColumn(pi.tier2_calls, t2, n2);
+        pi.calls.assign(t1, t1 + n1);
+        pi.tier2_calls.assign(t2, t2 + n2);
         pi.spanningDeletionReadCount = sd;
         pi.submappedReadCount = sm;
         pi.mapqTracker.count = mq;
@@ -356,33 +328,6 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
             {
                 const int64_t k(static_cast<int64_t>(w.begin) + static_cast<int64_t>(i) - ploidyBegin);
                 chunk.ploidy[i] = (ploidyPtr && k >= 0 && k < ploidyLen) ? ploidyPtr[k] : 2;
-            }
-            // what the germline caller reads of a position's cleaned tier1 column besides the genotype -- how many calls per strand
-            // and base (sk_adapter_germline.cpp, clean_pileup_summary) -- counted here, where the window's calls lie in one block,
-            // instead of position by position when POST_CALL comes back to them
-            chunk.rawCount.resize(n);
-            chunk.strandBase.assign(n * 10, 0);
-            for (size_t i(0); i < n; ++i)
-            {
-                const base_call* const calls(reinterpret_cast<const base_call*>(w.tier1_calls + w.tier1_off[i]));
-                const size_t callCount(static_cast<size_t>(w.tier1_off[i + 1] - w.tier1_off[i]));
-                chunk.rawCount[i] = static_cast<uint32_t>(callCount);
-                // (most calls of a position land on one counter: two sets, alternating, halve that chain; base ids are 0..4)
-                uint32_t partial[2][16] = {};
-                size_t j(0);
-                for (; j + 2 <= callCount; j += 2)
-                {
-                    const base_call& a(calls[j]);
-                    const base_call& b(calls[j + 1]);
-                    partial[0][(a.is_fwd_strand ? 8u : 0u) + (a.base_id & 7u)] += a.is_call_filter ? 0u : 1u;
-                    partial[1][(b.is_fwd_strand ? 8u : 0u) + (b.base_id & 7u)] += b.is_call_filter ? 0u : 1u;
-                }
-                if (j < callCount) partial[0][(calls[j].is_fwd_strand ? 8u : 0u) + (calls[j].base_id & 7u)] += calls[j].is_call_filter ? 0u : 1u;
-                uint32_t* const count(chunk.strandBase.data() + i * 10);
-                for (unsigned strand(0); strand < 2; ++strand)
-                {
-                    for (unsigned b(0); b < 8; ++b) count[strand * 5 + std::min(b, 4u)] += partial[0][strand * 8 + b] + partial[1][strand * 8 + b];
-                }
             }
             s.siteLoci += n;
             s.siteBatches++;

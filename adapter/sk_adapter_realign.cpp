@@ -368,7 +368,20 @@ bool align_pos(starling_pos_processor_base& pp, const pos_t pos)
         std::vector<WindowSegment>& segs(s.windowSegments[sampleIndex]);
         segs.clear();
         starling_pos_processor_base::sample_info& sif(pp.sample(sampleIndex));
-        collect_window_segments(sif.readBuffer, pos, end, segs);
+        for (pos_t p(pos); p < end; ++p)
+        {
+            read_segment_iter ri(sif.readBuffer.get_pos_read_segment_iter(p));
+            for (read_segment_iter::ret_val r; true; ri.next())
+            {
+                r = ri.get_ptr();
+                if (nullptr == r.first) break;
+                if (r.second != 0) throw blt_exception("strelka_amd adapter: spliced (RNA) read segments are not supported on this path");
+                WindowSegment ws;
+                ws.rseg = &(r.first->get_segment(r.second));
+                ws.bufferPos = p;
+                segs.push_back(ws);
+            }
+        }
     }
     for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
     {

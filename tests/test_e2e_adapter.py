@@ -112,15 +112,6 @@ def test_germline_demo_identical_with_columns_only(tmp_path):
     _germline("dbl", tmp_path, extra_env={"STRELKA_AMD_PILEUP_GENOTYPE": "0"})
 
 
-@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
-@pytest.mark.parametrize("env", [{}, {"STRELKA_AMD_PILEUP": "0"}])
-def test_germline_demo_identical_with_cleaned_pileups_copied(tmp_path, env):
-    """STRELKA_AMD_CLEAN_SUMMARY=0: CleanPileupFilter copies the cleaned tier1 column of every position as the reference does (by
-    default the germline caller's readers of that column take per-strand / per-base counts made in one pass over the raw calls,
-    adapter/sk_adapter_germline.cpp clean_pileup_summary) -- with the stream's pileup and with the reference's"""
-    _germline("dbl", tmp_path, extra_env=dict(env, STRELKA_AMD_CLEAN_SUMMARY="0"))
-
-
 @pytest.mark.gpu
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
 @pytest.mark.parametrize("windows", [None, (7, 13)])
