@@ -5,6 +5,8 @@
 // region's alternate haplotypes in one sk_global_align batch.
 #include "sk_adapter_access.hh"
 
+#include <cstdlib>
+
 #include "blt_util/reference_contig_segment.hh"
 #include "starling_common/IndelKey.hh"
 
@@ -96,11 +98,22 @@ bool discover_indels_and_mismatches(const std::vector<std::string>& selectedHapl
 {
     init();
     static RegionAlignments ra;
-    if (! ra.matches(selectedHaplotypes, refSegment, regionBegin, regionEnd)) alignRegion(selectedHaplotypes, refSegment, regionBegin, regionEnd, ra);
+    // $STRELKA_AMD_HAPLOTYPE_BATCH=0: one sk_global_align problem per call, as the reference calls its aligner (diagnosis)
+    static const bool isBatched([]() { const char* v(std::getenv("STRELKA_AMD_HAPLOTYPE_BATCH")); return ! (v && *v == '0'); }());
     const std::string& haplotypeSeq(selectedHaplotypes[selectedHaplotypeIndex]);
-    if (ra.segCount[selectedHaplotypeIndex] < 0) throw blt_exception("strelka_amd adapter: haplotype equal to the reference segment");
-    const int32_t beginPos(ra.beginPos[selectedHaplotypeIndex]), segCount(ra.segCount[selectedHaplotypeIndex]);
-    const std::vector<sk_path_seg>& path(ra.path[selectedHaplotypeIndex]);
+    unsigned at(selectedHaplotypeIndex);
+    if (isBatched)
+    {
+        if (! ra.matches(selectedHaplotypes, refSegment, regionBegin, regionEnd)) alignRegion(selectedHaplotypes, refSegment, regionBegin, regionEnd, ra);
+    }
+    else
+    {
+        alignRegion(std::vector<std::string>(1, haplotypeSeq), refSegment, regionBegin, regionEnd, ra);
+        at = 0;
+    }
+    if (ra.segCount[at] < 0) throw blt_exception("strelka_amd adapter: haplotype equal to the reference segment");
+    const int32_t beginPos(ra.beginPos[at]), segCount(ra.segCount[at]);
+    const std::vector<sk_path_seg>& path(ra.path[at]);
 
     const int32_t cap(static_cast<int32_t>(haplotypeSeq.size() + refSegment.size() + 4));
     std::vector<sk_discovered_allele> found(static_cast<size_t>(cap));

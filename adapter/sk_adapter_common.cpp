@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <iostream>
+#include <sstream>
 
 namespace sk_adapter
 {
@@ -235,13 +236,23 @@ unsigned buffered_read_count(const starling_pos_processor_base& /*pp*/, const un
     return static_cast<unsigned>(state().geometry.bufferedReadPos[sampleIndex].size());
 }
 
-void on_read_inserted(starling_pos_processor_base& /*pp*/, const unsigned sampleIndex, const starling_read& sread)
+void on_read_inserted(starling_pos_processor_base& pp, const unsigned sampleIndex, const starling_read& sread)
 {
     if (sread.isSpliced())
     {
         throw blt_exception("strelka_amd adapter: spliced (RNA) reads are not supported on this path");
     }
     state().geometry.bufferedReadPos[sampleIndex].push(sread.get_full_segment().buffer_pos);
+    // The device pileup holds a read's per-base state in LDS: 1024 bases (SK_PILEUP_MAX_READ_LEN); the reference takes reads up to
+    // STRELKA_MAX_READ_SIZE = 25000.  Said here, when the read arrives, with the way out -- not as a failed push a window later.
+    if (sread.get_full_segment().read_size() > SK_PILEUP_MAX_READ_LEN && pileup_enabled(pp))
+    {
+        std::ostringstream oss;
+        oss << "strelka_amd adapter: read of " << sread.get_full_segment().read_size() << " bases (sample " << sampleIndex << ", position "
+            << (sread.get_full_segment().buffer_pos + 1) << "): the device pileup (site 9) takes reads of at most " << SK_PILEUP_MAX_READ_LEN
+            << " bases; rerun with STRELKA_AMD_PILEUP=0 (the reference's own pileup_read_segment, every other site still routed)";
+        throw blt_exception(oss.str().c_str());
+    }
     pileup_note_read(sampleIndex, sread.get_full_segment().buffer_pos);
 }
 

@@ -56,8 +56,10 @@ def parse():
     ap.add_argument("--a5-reps", type=int, default=3)
     ap.add_argument("--e2e-bp", type=int, default=16000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
     ap.add_argument("--e2e-segment-bp", type=int, default=2000000, help="segment size of the end-to-end leg (one caller process per segment)")
-    ap.add_argument("--only", default="", help="'a5': run the headline leg alone (the counter passes of tools/gpu_round.sh use it: per-kernel "
-                                               "averages then belong to that leg's launches) and print a short line")
+    ap.add_argument("--only", default="", help="'a5' / 'feed' / 'loci': run one kernel leg alone (the counter passes of tools/gpu_round.sh use it: "
+                                               "per-kernel averages then belong to that leg's launches) and print a short line; 'e2e', "
+                                               "'e2e_germline', 'e2e_somatic': the end-to-end legs alone (exit code 1 when the drop-in's outputs "
+                                               "differ from the reference's)")
     ap.add_argument("--e2e-somatic-bp", type=int, default=3200000,
                     help="length of the WGS-like 110x / 40x tumour-normal pair of the somatic end-to-end leg per GPU (0: skip the leg)")
     ap.add_argument("--e2e-somatic-segment-bp", type=int, default=400000, help="segment size of the somatic end-to-end leg")
@@ -265,10 +267,8 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                "hook_seconds_note": "summed over this rank's segment processes: wall seconds inside the adapter's hooks (*_hook) of which inside "
                                     "the C-ABI (*_abi); the rest of process_seconds_sum is the reference's own host code (BAM records, read "
                                     "buffer, active regions, locus objects, VCF text)",
-               "host_note": "the drop-in's leg includes the adapter's host-side edits beside the routed sites (same bytes out: the germline "
-                            "caller's cleaned pileups counted instead of copied, the active-region / repeat-finder / depth-buffer / "
-                            "alignment-range loops restated; DESIGN.md section 6, profiles/r03_v26_host_remainder_ab.txt); both programs "
-                            "are built with the reference's release flags (-O3)"}
+               "host_note": "the drop-in is the reference's own program with the routed call sites (adapter/apply_hooks.py) and nothing else "
+                            "changed: the host code beside those sites is the reference's, built with the same release flags (-O3)"}
         if with_reference:
             t0 = time.perf_counter()
             ref = farm.run_farm(groups, argv_fn(program + "_ref"), os.path.join(root, "ref"), outputs, jobs=jobs)
@@ -277,48 +277,25 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
             def body(path):
                 with open(path, "rb") as f:
                     return [l for l in f.read().split(b"\n") if not (l.startswith(b"##cmdline=") or l.startswith(b"##startTime=") or l.startswith(b"##fileDate="))]
-            identical = all(body(amd.outputs[n]) == body(ref.outputs[n]) for n in outputs)
+            identical, first_difference = True, None
+            for n in outputs:
+                got, want = body(amd.outputs[n]), body(ref.outputs[n])
+                if got != want:
+                    identical = False
+                    k = next((i for i, (x, y) in enumerate(zip(got, want)) if x != y), min(len(got), len(want)))
+                    first_difference = {"file": n, "line": k + 1, "lines_drop_in": len(got), "lines_reference": len(want),
+                                        "drop_in": got[k].decode(errors="replace")[:400] if k < len(got) else None,
+                                        "reference": want[k].decode(errors="replace")[:400] if k < len(want) else None}
+                    keep = os.environ.get("SK_E2E_KEEP_DIR")
+                    if keep:  # (diagnosis: the two joined files, for a diff after the run)
+                        os.makedirs(keep, exist_ok=True)
+                        shutil.copy(amd.outputs[n], os.path.join(keep, mode + "_drop_in_" + n))
+                        shutil.copy(ref.outputs[n], os.path.join(keep, mode + "_reference_" + n))
+                    break
             out.update({"ref_wall_s": ref_wall, "ref_cores": jobs, "ref_process_seconds_sum": sum(ref.process_s), "speedup": ref_wall / amd_wall,
-                        "identical": identical,
+                        "identical": identical, "first_difference": first_difference,
                         "variant_records": sum(1 for n in outputs if n.endswith(".vcf") and not n.startswith("genome")
                                                for l in body(ref.outputs[n]) if l and not l.startswith(b"#"))})
-            # ---- the whole host: every usable core busy in both legs.  A GPU serves ~8 caller processes, so the drop-in's leg is a
-            # MIXED farm: `jobs` processes of the drop-in on the GPU plus one process of the unmodified reference on each remaining
-            # core (same bytes out), the sample cut so that both kinds of slot finish together; the reference's leg is one process
-            # per core.
-            fill = len(cores) // world - jobs
-            if fill > 0:
-                # the mixed leg's segments are sized for its two kinds of slot (a GPU slot's `ratio` times a fill slot's, the ratio
-                # of the two programs' speeds measured above), the reference's leg gets equal segments -- each leg the cut that suits
-                # it.  Outputs depend on where a genome is cut (blocks end at segment ends), so the mixed leg's bytes are compared
-                # with a third run: the reference alone on the mixed leg's segments.
-                ratio = min(4.0, max(1.0, ref_wall / amd_wall))
-                n_proc = jobs + fill
-                b = int(L / (jobs * ratio + fill))
-                a = int(b * ratio)
-                mixed_groups, pos = [], 1
-                for k in range(n_proc):
-                    end = L if k == n_proc - 1 else pos + (a if k < jobs else b) - 1
-                    mixed_groups.append([(k, "chrW", pos, end, k)])
-                    pos = end + 1
-                t0 = time.perf_counter()
-                mixed = farm.run_farm(mixed_groups, argv_fn(drop_in), os.path.join(root, "mixed"), outputs, n_gpus=1, jobs=jobs,
-                                      device_offset=local_rank, fill_jobs=fill, fill_argv_fn=argv_fn(program + "_ref"), fill_min_pending=0)
-                mixed_wall = time.perf_counter() - t0
-                all_groups = [[sg] for sg in farm.chrom_intervals(["chrW"], {"chrW": L}, -(-L // n_proc))]
-                t0 = time.perf_counter()
-                ref_all = farm.run_farm(all_groups, argv_fn(program + "_ref"), os.path.join(root, "ref_all"), outputs, jobs=n_proc)
-                ref_all_wall = time.perf_counter() - t0
-                ref_same_cut = farm.run_farm(mixed_groups, argv_fn(program + "_ref"), os.path.join(root, "ref_mixed_cut"), outputs, jobs=n_proc)
-                out["all_cores"] = {
-                    "cores": jobs + fill, "ref_procs": jobs + fill, "ref_wall_s": ref_all_wall,
-                    "amd_gpu_procs": jobs, "amd_fill_procs_running_the_reference": fill, "fill_segments": mixed.fill_segments,
-                    "gpu_segment_bp": a, "fill_segment_bp": b, "amd_wall_s": mixed_wall, "speedup": ref_all_wall / mixed_wall,
-                    "identical": all(body(mixed.outputs[n]) == body(ref_same_cut.outputs[n]) for n in outputs),
-                    "identical_note": "the mixed leg's joined outputs against the reference alone on the same segments (a third, untimed run)",
-                    "note": "node level: every usable core calls segments in both legs; the drop-in's leg = %d drop-in processes sharing the "
-                            "GPU + %d processes of the unmodified reference on the other cores (a GPU gives ~8 caller processes the "
-                            "one-process speed-up and time-slices beyond that)" % (jobs, fill)}
         return out
     finally:
         shutil.rmtree(root, ignore_errors=True)
@@ -419,11 +396,18 @@ def main():
     # under the driver's time-slicing (1.46x instead of 1.6x on the germline leg, profiles/r03_v20_bench.json vs r03_v19).  So the
     # legs run before this process creates its context.
     e2e = e2e_somatic = None
-    if world == 1 and not args.only:
-        if args.e2e_bp > 0:
+    if world == 1 and (not args.only or args.only.startswith("e2e")):
+        if args.e2e_bp > 0 and args.only in ("", "e2e", "e2e_germline"):
             e2e = e2e_leg(args, 0, 1, local_rank, lambda: None, lambda v: v, with_reference=not args.no_cpu_baseline)
-        if args.e2e_somatic_bp > 0:
+        if args.e2e_somatic_bp > 0 and args.only in ("", "e2e", "e2e_somatic"):
             e2e_somatic = e2e_leg(args, 0, 1, local_rank, lambda: None, lambda v: v, with_reference=not args.no_cpu_baseline, mode="somatic")
+    e2e_failed = [name for name, leg in (("e2e", e2e), ("e2e_somatic", e2e_somatic)) if leg and leg.get("identical") is False]
+    for name in e2e_failed:
+        print("bench.py: the %s leg's outputs are NOT identical to the reference's: %s" % (name, json.dumps(locals()[name]["first_difference"])),
+              file=sys.stderr, flush=True)
+    if args.only.startswith("e2e"):
+        print(json.dumps({"only": args.only, "e2e": e2e, "e2e_somatic": e2e_somatic}), flush=True)
+        sys.exit(1 if e2e_failed else 0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -440,6 +424,25 @@ def main():
         a5_meta.pop("_keep")
         print(json.dumps({"only": "a5", "steps": args.steps, "warmup": args.warmup, "a5": a5_meta,
                           "kernel_ms": float(np.mean(a5_event_ms[-args.steps:]))}))
+        return
+
+    if args.only == "loci":
+        # the germline site kernel alone (G3: adjust_joint_eprob + position_snp_call_pprob_digt fused), for counter passes
+        hb = synth.pileups(min(args.unique_loci, args.loci), np.random.default_rng(1000 + rank))
+        db = device.DevicePileupBatch(hb, dev, tile=max(1, args.loci // hb.n_loci))
+        gopt = capi.germline_options()
+        evs = []
+        for i in range(args.warmup + args.steps):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            db.site_digt_call_fused(gopt)
+            e.record()
+            evs.append((s, e))
+        torch.cuda.synchronize()
+        ms = float(np.mean([s.elapsed_time(e) for s, e in evs[args.warmup:]]))
+        alg = 6 * db.n_calls + B_BYTES_PER_LOCUS_FIXED * db.n_loci
+        print(json.dumps({"only": "loci", "loci": db.n_loci, "calls": db.n_calls, "kernel_ms": ms, "loci_per_s": db.n_loci / (ms * 1e-3),
+                          "algorithmic_bytes": alg, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}))
         return
 
     if args.only == "feed":
@@ -719,6 +722,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if e2e_failed:
+        sys.exit(1)  # a drop-in whose bytes differ is not a result: the line above carries first_difference, the exit code says so
 
 
 if __name__ == "__main__":

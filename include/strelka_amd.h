@@ -55,6 +55,10 @@ const char* sk_last_error(void);
 int sk_version(void);
 /** 1 when sk_init succeeded on a gfx950 device. */
 int sk_is_initialized(void);
+/** How this process waits for its device: 1 = blocking (it sleeps: the default, many caller processes share a GPU and a CPU quota),
+ *  0 = spinning ($STRELKA_AMD_SPIN_WAIT, or the runtime refused the flag), -1 = not initialised.  The flag is per device: it is set
+ *  after the device is chosen (a farm process on device 3 gets it as one on device 0 does). */
+int sk_sync_mode(void);
 /** 1 when sk_init found the host libm's powf/logf to be the routines the kernels restate (glibc >= 2.28, see
  *  strelka_amd/csrc/libm_flt32.h): the dependent error probabilities and germline likelihoods are then bit-identical to
  *  the reference's; 0: the device library's pow/log stand in (agreement to 1e-5 relative). */
@@ -376,6 +380,11 @@ int sk_get_end_pin_start_pos(const sk_indel_key* indels, int32_t n_indels, uint3
  * Not produced: the EVS feature accumulators (updateGermlineScoringMetrics / updateSomaticScoringMetrics) and the MAPQ
  * tracker -- scoring-model inputs, outside the likelihood path.
  * ---------------------------------------------------------------------------------------------------------------- */
+
+/** Longest read the pileup kernels take (a read's per-base state lives in LDS); the reference's own limit is
+ *  STRELKA_MAX_READ_SIZE = 25000 (L/starling_common/starling_base_shared.hh:37).  sk_pileup_reads and the stream pushes fail on a longer
+ *  read; the adapter says so when such a read arrives and points at STRELKA_AMD_PILEUP=0 (limits). */
+#define SK_PILEUP_MAX_READ_LEN 1024
 
 typedef struct sk_pileup_options {
     int32_t min_basecall_qscore;              /* blt_options::minBasecallErrorPhredProb: 17 germline (blt_shared.hh:107), 0 somatic */

@@ -45,28 +45,50 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _compile_flags():
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+            # no FMA contraction on host or device: the reference is plain x86-64 arithmetic, and the order/rounding of
+            # every add is part of the result
+            "-ffp-contract=off", "-mllvm", "-disable-promote-alloca-to-lds", "-Wall",
+            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")] + \
+        os.environ.get("SK_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DSOM_WPE=3)
+
+
 def build_all(force=False, verbose=True):
-    os.makedirs(LIB_DIR, exist_ok=True)
+    """One object per source under strelka_amd/_build/ (compiled in parallel, recompiled only when the source, a header or the flags
+    changed), linked into the one shared library."""
     import glob
-    deps = _sources() + glob.glob(os.path.join(PKG, "csrc", "*.h")) + [os.path.join(ROOT, "include", "strelka_amd.h"),
-                                                                       os.path.abspath(__file__)]
-    if not force and not _stale(LIB_PATH, deps):
-        return LIB_PATH
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(PKG, "_build")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           # no FMA contraction on host or device: the reference is plain x86-64 arithmetic, and the order/rounding of
-           # every add is part of the result
-           "-ffp-contract=off", "-mllvm", "-disable-promote-alloca-to-lds", "-Wall",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")]
-    cmd += os.environ.get("SK_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DSOM_WPE=3)
-    for s in HOST_SOURCES:
-        cmd += ["-x", "c++", os.path.join(PKG, s)]
-    for s in HIP_SOURCES:
-        cmd += ["-x", "hip", os.path.join(PKG, s)]
-    cmd += ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print("[strelka_amd.build]", " ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    flags = _compile_flags()
+    headers = glob.glob(os.path.join(PKG, "csrc", "*.h")) + [os.path.join(ROOT, "include", "strelka_amd.h"), os.path.abspath(__file__)]
+    stamp = hashlib.sha256(" ".join([hipcc] + flags).encode()).hexdigest()[:12]
+    jobs = []
+    objs = []
+    for s in HOST_SOURCES + HIP_SOURCES:
+        src = os.path.join(PKG, s)
+        obj = os.path.join(obj_dir, os.path.basename(s).replace(".", "_") + "." + stamp + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            lang = "hip" if s.endswith(".hip") else "c++"
+            jobs.append([hipcc] + flags + ["-x", lang, "-c", src, "-o", obj])
+    if not jobs and not force and not _stale(LIB_PATH, objs):
+        return LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print("[strelka_amd.build]", " ".join(cmd[-4:]), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, jobs))
+    for old in glob.glob(os.path.join(obj_dir, "*.o")):
+        if old not in objs:
+            os.remove(old)
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"])
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

@@ -41,7 +41,7 @@ namespace
 
 constexpr int WAVE = 64;
 constexpr int P1_WAVES = 4;
-constexpr int MAX_READ_LEN = 1024;  // LDS: 4 B delta + 1 B flag per read base
+constexpr int MAX_READ_LEN = SK_PILEUP_MAX_READ_LEN;  // LDS: 4 B delta + 1 B flag per read base
 constexpr unsigned REC_TIER2 = 1u << 14, REC_EMIT = 1u << 15;
 constexpr unsigned REC_SUBLIVE = 1u; // (REC_EMIT clear) a live position of a submapped read: no basecall, but it counts for the MAPQ tracker
 constexpr int COL_STAGE = 3072;     // calls of one wave's 64 columns staged in LDS (6 KiB); deeper spans store directly

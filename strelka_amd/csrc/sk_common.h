@@ -47,6 +47,7 @@ struct SkContext
     int device = -1;
     bool ready = false;
     bool libm_restated = false; // the host libm's powf/logf match csrc/libm_flt32.h (checked at sk_init)
+    bool blocking_sync = false; // hipDeviceScheduleBlockingSync took effect on this process's device (sk_sync_mode)
     SkTables host_tables;
     SkTables* dev_tables = nullptr;
     hipStream_t stream = nullptr; // used by the host-buffer entry points

@@ -183,9 +183,21 @@ int sk_version(void) { return SK_VERSION; }
 int sk_libm_restated(void) { return g_ctx.libm_restated ? 1 : 0; }
 const char* sk_last_error(void) { return g_last_error.c_str(); }
 int sk_is_initialized(void) { return g_ctx.ready ? 1 : 0; }
+int sk_sync_mode(void) { return g_ctx.ready ? (g_ctx.blocking_sync ? 1 : 0) : -1; }
+
+// One hardware queue per process unless the caller says otherwise: this library runs everything on one stream, and its
+// processes are many per GPU (one per genome segment) -- with HIP's default of four queues per process, sixteen caller
+// processes oversubscribe the device's queue slots and every wait turns into a scheduler time slice
+// (profiles/r03_v2_gpu_sharing.txt).  The HIP runtime reads the variable when it is first touched, so every entry point that
+// can be a process's first HIP call (sk_device_count, sk_init) comes through here first.
+static void sk_pre_runtime_env()
+{
+    (void)setenv("GPU_MAX_HW_QUEUES", "1", 0);
+}
 
 int sk_device_count(void)
 {
+    sk_pre_runtime_env();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
@@ -216,15 +228,7 @@ int sk_init(int device)
     SkContext& c = g_ctx;
     if (c.ready && c.device == device) return 0;
     if (c.ready) sk_shutdown();
-    // One hardware queue per process unless the caller says otherwise: this library runs everything on one stream, and its
-    // processes are many per GPU (one per genome segment) -- with HIP's default of four queues per process, sixteen caller
-    // processes oversubscribe the device's queue slots and every wait turns into a scheduler time slice
-    // (profiles/r03_v2_gpu_sharing.txt).  Read by the HIP runtime when it first touches the device, i.e. below.
-    (void)setenv("GPU_MAX_HW_QUEUES", "1", 0);
-    // ... and a process that waits for the device SLEEPS: sixteen caller processes share a GPU and a CPU quota, and a wait spent
-    // spinning is a core taken from a process that has host work to do (profiles/r03_v5_thread_cpu_seconds.txt: under contention
-    // the callers' CPU seconds doubled, all of it in their main threads).  Ignored when the process's HIP context exists already.
-    if (std::getenv("STRELKA_AMD_SPIN_WAIT") == nullptr) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    sk_pre_runtime_env();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -232,6 +236,15 @@ int sk_init(int device)
                        "); this library has no CPU fallback");
     if (device < 0 || device >= n) return sk_fail("strelka_amd: device index out of range");
     SK_HIP(hipSetDevice(device));
+    // A process that waits for the device SLEEPS: sixteen caller processes share a GPU and a CPU quota, and a wait spent
+    // spinning is a core taken from a process that has host work to do (profiles/r03_v5_thread_cpu_seconds.txt: under contention
+    // the callers' CPU seconds doubled, all of it in their main threads).  The flags belong to the CURRENT device: set after
+    // hipSetDevice, so that farm processes on devices 1..N-1 get them too.
+    if (std::getenv("STRELKA_AMD_SPIN_WAIT") == nullptr) {
+        (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+        unsigned flags = 0;
+        if (hipGetDeviceFlags(&flags) == hipSuccess) c.blocking_sync = (flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync;
+    }
     hipDeviceProp_t prop;
     SK_HIP(hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)

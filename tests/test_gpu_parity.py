@@ -416,3 +416,10 @@ def test_indel_fast_form_keeps_every_integer_output(gpu):
         total += n
     assert total >= 1000000
     assert worst < 1e-12, worst
+
+
+def test_process_waits_blocking_on_its_device(gpu):
+    """the blocking-wait flag is per device and must be set after the device is chosen; sk_sync_mode reports what the
+    runtime holds for this process's device"""
+    from strelka_amd import capi
+    assert capi.lib().sk_sync_mode() == 1

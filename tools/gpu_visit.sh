@@ -1,0 +1,62 @@
+#!/bin/bash
+# one GPU-box visit of round 4: the steps named on the command line, outputs under gpurun_out/$TAG.
+#   tools/gpu_visit.sh TAG step [step ...]
+# steps: e2e (bench's germline leg; on a mismatch the parity hunt), e2e_somatic, tests (pytest -m gpu without the two bench-configuration
+#        tests), tests_all, bench, smoke, ktrace, pmc_traffic, pmc_g3 (SQ counters of the germline site kernel), pmc_a5
+TAG=$1; shift
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+for step in "$@"; do
+  t0=$(date +%s)
+  case $step in
+    e2e)
+      SK_E2E_KEEP_DIR=$OUT/kept timeout 900 python bench.py --only e2e_germline > $OUT/e2e_germline.json 2> $OUT/e2e_germline.err
+      rc=$?; echo "e2e_germline rc=$rc"; tail -c 600 $OUT/e2e_germline.err
+      if [ $rc -ne 0 ]; then
+        timeout 1500 python tools/diag/e2e_parity_hunt.py $OUT/hunt > $OUT/hunt.log 2>&1; tail -12 $OUT/hunt.log
+        rm -rf $OUT/hunt/ref $OUT/hunt/*_tmp; find $OUT/hunt -name "genome.S1.vcf" -size +2M -delete
+      fi ;;
+    e2e_somatic)
+      SK_E2E_KEEP_DIR=$OUT/kept timeout 900 python bench.py --only e2e_somatic > $OUT/e2e_somatic.json 2> $OUT/e2e_somatic.err
+      echo "e2e_somatic rc=$?"; tail -c 400 $OUT/e2e_somatic.err ;;
+    tests)
+      timeout 1200 python -m pytest tests -m gpu -x -q -k "not at_bench_configuration" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+      tail -5 $OUT/pytest_gpu.log ;;
+    tests_all)
+      timeout 1800 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+      tail -5 $OUT/pytest_gpu.log ;;
+    bench)
+      timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.json ;;
+    bench_kernels)
+      timeout 600 python bench.py --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 > $OUT/bench_kernels.json 2> $OUT/bench_kernels.err; echo "bench_kernels rc=$?" ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log ;;
+    ktrace)
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 > $OUT/ktrace.log 2>&1
+      find $OUT/ktrace -name "*kernel_stats.csv" | head -2 ;;
+    pmc_traffic)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 > $OUT/pmc_$c.log 2>&1
+        timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_a5_$c -o pmc -- python bench.py --only a5 --steps 10 --warmup 2 > $OUT/pmc_a5_$c.log 2>&1
+      done
+      python tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json 2>$OUT/pmc_traffic.err; head -c 600 $OUT/pmc_traffic.json ;;
+    pmc_g3)
+      i=0
+      for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+                 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" \
+                 "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL"; do
+        i=$((i+1))
+        timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_g3_$i -o pmc -- python bench.py --only loci --loci 16777216 --steps 3 --warmup 1 > $OUT/pmc_g3_$i.log 2>&1
+        tail -1 $OUT/pmc_g3_$i.log | head -c 300
+      done
+      python tools/diag/pmc_kernel_sums.py $OUT/pmc_g3_* > $OUT/pmc_g3.txt 2>&1; cat $OUT/pmc_g3.txt ;;
+    loci)
+      timeout 300 python bench.py --only loci --steps 5 --warmup 2 > $OUT/loci.json 2>$OUT/loci.err; cat $OUT/loci.json ;;
+    *) echo "unknown step $step" ;;
+  esac
+  echo "[$step: $(( $(date +%s) - t0 )) s]"
+done
+# keep the merge-back small: counter CSVs are large, the summaries are what is read
+find $OUT -name "*counter_collection.csv" -size +20M -delete
+du -sh $OUT
