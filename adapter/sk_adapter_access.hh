@@ -172,7 +172,7 @@ struct State
     // wall seconds inside the hooks (whole hook) and inside the C-ABI calls they make; reported with STRELKA_AMD_VERBOSE=1
     double tRealignHook = 0, tRealignAbi = 0, tSiteHook = 0, tSiteAbi = 0, tPileupHook = 0, tPileupAbi = 0, tInit = 0, tIndelAbi = 0, tHaplotypeAbi = 0;
     unsigned long pileupBatches = 0, pileupReads = 0, pileupLoci = 0;
-    unsigned long indelGroupsReference = 0; ///< allele groups with more alternate alleles than SK_MAX_ALT: the reference's function ran
+    unsigned long indelGroupsWide = 0; ///< allele groups with more alternate alleles than SK_MAX_ALT (sk_allele_group_genotype_lhoods_wide)
     unsigned long realignJobReads = 0; ///< reads that went into a realignment job (realignReads counts every read a window looked at)
     unsigned long realignDeviceEnumerated = 0, realignHostEnumerated = 0; // reads whose candidate alignments the device / the host listed
     unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0, haplotypeBatches = 0;

@@ -2,7 +2,7 @@
 // (L/starling_common/AlleleGroupGenotype.cpp:185-258, called at L/applications/starling/starling_pos_processor.cpp:1384-1386)
 // through sk_allele_group_genotype_lhoods.
 //
-// apply_hooks.py renames the reference's definition to ..._reference (it stays in the hooked translation unit, uncalled);
+// apply_hooks.py renames the reference's definition to ..._reference (it stays in the hooked translation unit, never called);
 // this file provides the function under the original name, so every caller in the reference reaches the C-ABI.  The
 // allele group's reads are resolved exactly as the reference does (getAlleleGroupSupportingReadIds: tier1 reads scored for
 // every allele of the group, ascending read id; per allele the read's ReadPathScores ref / indel floats) and handed over
@@ -20,19 +20,6 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
-
-// the reference's own definition, renamed by apply_hooks.py (it stays in the hooked translation unit)
-void
-getVariantAlleleGroupGenotypeLhoodsForSample_reference(
-    const starling_base_options& opt,
-    const starling_base_deriv_options& dopt,
-    const starling_sample_options& sampleOptions,
-    const unsigned callerPloidy,
-    const unsigned sampleIndex,
-    const OrthogonalVariantAlleleCandidateGroup& alleleGroup,
-    const OrthogonalVariantAlleleCandidateGroup& contrastGroup,
-    std::vector<double>& genotypeLogLhood,
-    LocusSupportingReadStats& locusReadStats);
 
 void
 getVariantAlleleGroupGenotypeLhoodsForSample(
@@ -61,17 +48,16 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
     {
         throw blt_exception("strelka_amd adapter: contrast allele groups are not supported on this path");
     }
-    if (nonRefAlleleCount > SK_MAX_ALT)
+    // A multi-sample run can put up to ploidy x sample-count alternate alleles into one group (selectTopOrthogonalAllelesInAllSamples,
+    // L/starling_common/OrthogonalVariantAlleleCandidateGroupUtil.cpp:285-340: the union of every sample's top alleles).  Groups of up to
+    // SK_MAX_ALT alleles go through the narrow record, wider ones (several distinct overlapping indels that differ between the
+    // samples) through sk_allele_group_genotype_lhoods_wide: the same kernel with rows of SK_MAX_ALT_WIDE.
+    if (nonRefAlleleCount > SK_MAX_ALT_WIDE)
     {
-        // A multi-sample run can put up to ploidy x sample-count alternate alleles into one group (selectTopOrthogonalAllelesInAllSamples,
-        // L/starling_common/OrthogonalVariantAlleleCandidateGroupUtil.cpp:285-340: the union of every sample's top alleles); the
-        // kernel's records hold SK_MAX_ALT.  Such a group -- several distinct overlapping indels that differ between the samples --
-        // takes the reference's own function; `indel_groups_reference` counts them.
-        state().indelGroupsReference++;
-        getVariantAlleleGroupGenotypeLhoodsForSample_reference(opt, dopt, sampleOptions, callerPloidy, sampleIndex, alleleGroup, contrastGroup,
-                                                               genotypeLogLhood, locusReadStats);
-        return;
+        throw blt_exception("strelka_amd adapter: allele group with more than SK_MAX_ALT_WIDE (8 = ploidy x 4 samples) alternate alleles");
     }
+    const bool isWide(nonRefAlleleCount > SK_MAX_ALT);
+    const size_t width(isWide ? SK_MAX_ALT_WIDE : SK_MAX_ALT);
     init();
 
     locusReadStats.setAltCount(nonRefAlleleCount);
@@ -82,7 +68,7 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
 
     const size_t readCount(readIds.size());
     const float notScored(std::numeric_limits<float>::quiet_NaN());
-    std::vector<float> refLnp(readCount * SK_MAX_ALT, 0.f), alleleLnp(readCount * SK_MAX_ALT, notScored);
+    std::vector<float> refLnp(readCount * width, 0.f), alleleLnp(readCount * width, notScored);
     std::vector<uint16_t> nonAmbig(readCount), readLength(readCount);
     std::vector<uint8_t> flags(readCount);
     size_t r(0);
@@ -95,8 +81,8 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
             const auto it(isd.read_path_lnp.find(readId));
             if (it == isd.read_path_lnp.end()) continue;
             const ReadPathScores& rps(it->second);
-            refLnp[r * SK_MAX_ALT + a] = rps.ref;
-            alleleLnp[r * SK_MAX_ALT + a] = rps.indel;
+            refLnp[r * width + a] = rps.ref;
+            alleleLnp[r * width + a] = rps.indel;
             if (! isExemplarSet)
             {
                 // getExemplarReadScore (AlleleGroupGenotype.cpp:157-181): the first allele that scored the read
@@ -112,7 +98,7 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
 
     const int64_t readOff[2] = {0, static_cast<int64_t>(readCount)};
     const uint8_t nAlt(nonRefAlleleCount), ploidy(static_cast<uint8_t>(callerPloidy));
-    uint32_t delLen[SK_MAX_ALT] = {0}, insLen[SK_MAX_ALT] = {0};
+    uint32_t delLen[SK_MAX_ALT_WIDE] = {0}, insLen[SK_MAX_ALT_WIDE] = {0};
     for (unsigned a(0); a < nonRefAlleleCount; ++a)
     {
         const IndelKey& k(alleleGroup.key(a));
@@ -143,21 +129,28 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
     io.tier2_random_base_match_prob = opt.tier2.randomBaseMatchProb;
     io.read_confident_support_threshold = opt.readConfidentSupportThreshold.numval();
 
-    sk_allele_group_call out;
+    // (the two records differ in their array sizes only: read through one view)
+    sk_allele_group_call narrow;
+    sk_allele_group_call_wide wide;
     {
         AccumTimer abiTimer(state().tIndelAbi);
-        check(sk_allele_group_genotype_lhoods(&b, &io, &out), "sk_allele_group_genotype_lhoods");
+        if (isWide) check(sk_allele_group_genotype_lhoods_wide(&b, &io, &wide), "sk_allele_group_genotype_lhoods_wide");
+        else check(sk_allele_group_genotype_lhoods(&b, &io, &narrow), "sk_allele_group_genotype_lhoods");
     }
-    if (out.n_genotypes != genotypeCount)
+    const unsigned outGenotypes(isWide ? wide.n_genotypes : narrow.n_genotypes);
+    const double* const outLhood(isWide ? wide.lhood : narrow.lhood);
+    if (outGenotypes != genotypeCount)
     {
         throw blt_exception("strelka_amd adapter: genotype count mismatch in sk_allele_group_genotype_lhoods");
     }
-    for (unsigned g(0); g < genotypeCount; ++g) genotypeLogLhood[g] = out.lhood[g];
+    for (unsigned g(0); g < genotypeCount; ++g) genotypeLogLhood[g] = outLhood[g];
     for (unsigned s(0); s < 2; ++s)
     {
         auto& counts(locusReadStats.getCounts(s == 0));
-        for (unsigned a(0); a < fullAlleleCount; ++a) counts.incrementAlleleCount(a, out.counts[s][a]);
-        counts.nonConfidentCount += out.counts[s][fullAlleleCount];
+        const uint32_t* const outCounts(isWide ? wide.counts[s] : narrow.counts[s]);
+        for (unsigned a(0); a < fullAlleleCount; ++a) counts.incrementAlleleCount(a, outCounts[a]);
+        counts.nonConfidentCount += outCounts[fullAlleleCount];
     }
+    if (isWide) state().indelGroupsWide++;
     state().indelGroups++;
 }

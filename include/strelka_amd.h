@@ -895,6 +895,23 @@ int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* host_batch, con
 int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* dev_batch, const sk_indel_options* opt,
                                         sk_allele_group_call* dev_out, void* hip_stream);
 
+/** The same for allele groups of a multi-sample run: selectTopOrthogonalAllelesInAllSamples
+ *  (L/starling_common/OrthogonalVariantAlleleCandidateGroupUtil.cpp:285-340) forms the union of every sample's top alleles, up to
+ *  ploidy x sample_count = 8 alternate alleles (9 alleles, 45 diploid genotypes).  Same batch struct with every
+ *  `[..][SK_MAX_ALT]` row SK_MAX_ALT_WIDE wide, n_alt 1..SK_MAX_ALT_WIDE; same arithmetic, same kernel (instantiated for the wider
+ *  record).  The adapter takes this entry for groups of more than SK_MAX_ALT alternate alleles: no group goes back to the reference. */
+enum { SK_MAX_ALT_WIDE = 8, SK_MAX_INDEL_GT_WIDE = 45 };
+typedef struct sk_allele_group_call_wide {
+    double lhood[SK_MAX_INDEL_GT_WIDE];
+    uint32_t counts[2][SK_MAX_ALT_WIDE + 2];
+    uint32_t n_genotypes;
+    uint32_t n_reads_used;
+} sk_allele_group_call_wide;
+int sk_allele_group_genotype_lhoods_wide(const sk_allele_group_batch* host_batch, const sk_indel_options* opt,
+                                         sk_allele_group_call_wide* out);
+int sk_allele_group_genotype_lhoods_wide_dev(const sk_allele_group_batch* dev_batch, const sk_indel_options* opt,
+                                             sk_allele_group_call_wide* dev_out, void* hip_stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * SURVEY.md section 8f rank 4, the feed: BGZF inflation and BAM record decoding.
  *

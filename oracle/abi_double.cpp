@@ -176,7 +176,10 @@ int sk_site_digt_call_fused(const sk_pileup_batch* b, const sk_germline_options*
     return 0;
 }
 
-int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* b, const sk_indel_options* opt, sk_allele_group_call* out)
+} // extern "C"
+
+template <int MAXA, typename CallT>
+static int allele_groups_t(const sk_allele_group_batch* b, const sk_indel_options* opt, CallT* out)
 {
     if (!g_ready) return fail("sk_init() has not succeeded");
     for (int32_t g = 0; g < b->n_groups; ++g) {
@@ -184,23 +187,23 @@ int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* b, const sk_ind
         const int32_t n = static_cast<int32_t>(b->read_off[g + 1] - r0);
         const int32_t n_alt = b->n_alt[g];
         const int ploidy = b->ploidy[g];
-        if (n_alt < 1 || n_alt > SK_MAX_ALT) return fail("allele group with an unsupported number of alternate alleles");
+        if (n_alt < 1 || n_alt > MAXA) return fail("allele group with an unsupported number of alternate alleles");
         std::vector<float> ref(static_cast<size_t>(n) * n_alt), al(static_cast<size_t>(n) * n_alt);
         std::vector<uint8_t> t1(n), fwd(n);
         for (int32_t r = 0; r < n; ++r) {
             for (int32_t a = 0; a < n_alt; ++a) {
-                ref[static_cast<size_t>(r) * n_alt + a] = b->ref_lnp[(r0 + r) * SK_MAX_ALT + a];
-                al[static_cast<size_t>(r) * n_alt + a] = b->allele_lnp[(r0 + r) * SK_MAX_ALT + a];
+                ref[static_cast<size_t>(r) * n_alt + a] = b->ref_lnp[(r0 + r) * MAXA + a];
+                al[static_cast<size_t>(r) * n_alt + a] = b->allele_lnp[(r0 + r) * MAXA + a];
             }
             t1[r] = (b->read_flags[r0 + r] & SK_READ_TIER1) ? 1 : 0;
             fwd[r] = (b->read_flags[r0 + r] & SK_READ_FWD) ? 1 : 0;
         }
-        sk_allele_group_call& o = out[g];
+        CallT& o = out[g];
         std::memset(&o, 0, sizeof(o));
-        uint32_t counts[2 * (SK_MAX_ALT + 2)] = {0};
+        uint32_t counts[2 * (MAXA + 2)] = {0};
         sko_allele_group_genotype_lhoods(n, n_alt, ref.data(), al.data(), b->non_ambig + r0, b->read_length + r0, t1.data(),
-                                         fwd.data(), b->del_len + static_cast<size_t>(g) * SK_MAX_ALT,
-                                         b->ins_len + static_cast<size_t>(g) * SK_MAX_ALT, ploidy, opt->min_read_bp_flank,
+                                         fwd.data(), b->del_len + static_cast<size_t>(g) * MAXA,
+                                         b->ins_len + static_cast<size_t>(g) * MAXA, ploidy, opt->min_read_bp_flank,
                                          opt->random_base_match_prob, opt->read_confident_support_threshold, o.lhood, counts);
         for (int s = 0; s < 2; ++s)
             for (int a = 0; a < n_alt + 2; ++a) o.counts[s][a] = counts[s * (n_alt + 2) + a];
@@ -210,6 +213,19 @@ int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* b, const sk_ind
         o.n_reads_used = used;
     }
     return 0;
+}
+
+
+extern "C" {
+
+int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* b, const sk_indel_options* opt, sk_allele_group_call* out)
+{
+    return allele_groups_t<SK_MAX_ALT, sk_allele_group_call>(b, opt, out);
+}
+
+int sk_allele_group_genotype_lhoods_wide(const sk_allele_group_batch* b, const sk_indel_options* opt, sk_allele_group_call_wide* out)
+{
+    return allele_groups_t<SK_MAX_ALT_WIDE, sk_allele_group_call_wide>(b, opt, out);
 }
 
 int sk_somatic_snv_call_tiers(const sk_pileup_batch* n1, const sk_pileup_batch* t1, const sk_pileup_batch* n2,

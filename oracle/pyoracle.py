@@ -332,10 +332,12 @@ def somatic_indel_result(normal_lhood, tumor_lhood, indel_to_ref_error_prob, sha
 
 
 def allele_group_genotype_lhoods(batch, min_read_bp_flank=5, random_base_match_prob=0.25, threshold=0.51):
-    """batch: strelka_amd.capi.HostAlleleGroupBatch -> (lhood [n][10], counts [n][2][5], n_genotypes [n])"""
+    """batch: strelka_amd.capi.HostAlleleGroupBatch -> (lhood [n][10], counts [n][2][5], n_genotypes [n]); for a wide batch (rows of 8
+    alternate alleles) [n][45] and [n][2][10]"""
     n = batch.n_groups
-    lh = np.zeros((n, 10))
-    counts = np.zeros((n, 2, 5), np.uint32)
+    width = getattr(batch, "width", 3)
+    lh = np.zeros((n, (width + 1) * (width + 2) // 2))
+    counts = np.zeros((n, 2, width + 2), np.uint32)
     ng = np.zeros(n, np.uint32)
     for g in range(n):
         s, e = int(batch.read_off[g]), int(batch.read_off[g + 1])

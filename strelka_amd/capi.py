@@ -179,6 +179,11 @@ SOMATIC_INDEL_CALL_DTYPE = np.dtype([("normal_lhood", "<f8", (21,)), ("tumor_lho
 ALLELE_GROUP_CALL_DTYPE = np.dtype([("lhood", "<f8", (MAX_INDEL_GT,)), ("counts", "<u4", (2, MAX_ALT + 2)),
                                     ("n_genotypes", "<u4"), ("n_reads_used", "<u4")])
 assert SOMATIC_INDEL_CALL_DTYPE.itemsize == 352 and ALLELE_GROUP_CALL_DTYPE.itemsize == 128
+# multi-sample allele groups (up to ploidy x sample_count alternate alleles): sk_allele_group_call_wide
+MAX_ALT_WIDE, MAX_INDEL_GT_WIDE = 8, 45
+ALLELE_GROUP_CALL_WIDE_DTYPE = np.dtype([("lhood", "<f8", (MAX_INDEL_GT_WIDE,)), ("counts", "<u4", (2, MAX_ALT_WIDE + 2)),
+                                         ("n_genotypes", "<u4"), ("n_reads_used", "<u4")])
+assert ALLELE_GROUP_CALL_WIDE_DTYPE.itemsize == 448
 
 DIGT_RS_DTYPE = np.dtype([("ref_pprob", "<f8"), ("max_gt", "<u4"), ("snp_qphred", "<i4"), ("max_gt_qphred", "<i4"),
                           ("_pad", "<i4")])
@@ -211,6 +216,7 @@ EXPORTS = [
     "sk_somatic_snv_call_tiers", "sk_somatic_snv_call_tiers_dev", "sk_somatic_snv_tiers_scratch_bytes",
     "sk_indel_options_default", "sk_somatic_indel_options_default", "sk_indel_grid_lhood", "sk_indel_grid_lhood_dev",
     "sk_somatic_indel_call_batch", "sk_somatic_indel_call_tiers", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
+    "sk_allele_group_genotype_lhoods_wide", "sk_allele_group_genotype_lhoods_wide_dev",
     "sk_discover_indels_and_mismatches", "sk_global_align_scratch_bytes", "sk_global_align_dev", "sk_bai_query", "sk_bam_region_filter", "sk_gvcf_block_sites", "sk_gvcf_block_sites_dev",
 ]
 
@@ -312,6 +318,9 @@ def lib():
         L.sk_allele_group_genotype_lhoods.argtypes = [C.POINTER(AlleleGroupBatch), C.POINTER(IndelOptions), c_void_p]
         L.sk_allele_group_genotype_lhoods_dev.argtypes = [C.POINTER(AlleleGroupBatch), C.POINTER(IndelOptions), c_void_p,
                                                           c_void_p]
+        L.sk_allele_group_genotype_lhoods_wide_dev.argtypes = [C.POINTER(AlleleGroupBatch), C.POINTER(IndelOptions), c_void_p,
+                                                          c_void_p]
+        L.sk_allele_group_genotype_lhoods_wide.argtypes = [C.POINTER(AlleleGroupBatch), C.POINTER(IndelOptions), c_void_p]
         _lib = L
     return _lib
 
@@ -710,14 +719,16 @@ def somatic_indel_call(normal, tumor, indel_to_ref_error_prob, normal_opt=None, 
 
 
 class HostAlleleGroupBatch:
-    def __init__(self, read_off, n_alt, ploidy, del_len, ins_len, ref_lnp, allele_lnp, non_ambig, read_length, read_flags):
+    def __init__(self, read_off, n_alt, ploidy, del_len, ins_len, ref_lnp, allele_lnp, non_ambig, read_length, read_flags, width=MAX_ALT):
+        assert width in (MAX_ALT, MAX_ALT_WIDE)
+        self.width = width  # columns of the per-allele arrays: MAX_ALT, or MAX_ALT_WIDE for the wide entry points
         self.read_off = np.ascontiguousarray(read_off, np.int64)
         self.n_alt = np.ascontiguousarray(n_alt, np.uint8)
         self.ploidy = np.ascontiguousarray(ploidy, np.uint8)
-        self.del_len = np.ascontiguousarray(del_len, np.uint32).reshape(-1, MAX_ALT)
-        self.ins_len = np.ascontiguousarray(ins_len, np.uint32).reshape(-1, MAX_ALT)
-        self.ref_lnp = np.ascontiguousarray(ref_lnp, np.float32).reshape(-1, MAX_ALT)
-        self.allele_lnp = np.ascontiguousarray(allele_lnp, np.float32).reshape(-1, MAX_ALT)
+        self.del_len = np.ascontiguousarray(del_len, np.uint32).reshape(-1, width)
+        self.ins_len = np.ascontiguousarray(ins_len, np.uint32).reshape(-1, width)
+        self.ref_lnp = np.ascontiguousarray(ref_lnp, np.float32).reshape(-1, width)
+        self.allele_lnp = np.ascontiguousarray(allele_lnp, np.float32).reshape(-1, width)
         self.non_ambig = np.ascontiguousarray(non_ambig, np.uint16)
         self.read_length = np.ascontiguousarray(read_length, np.uint16)
         self.read_flags = np.ascontiguousarray(read_flags, np.uint8)
@@ -731,9 +742,11 @@ class HostAlleleGroupBatch:
 
 def allele_group_genotype_lhoods(batch, opt=None):
     opt = opt or indel_options(False)
-    out = np.zeros(batch.n_groups, ALLELE_GROUP_CALL_DTYPE)
+    wide = getattr(batch, "width", MAX_ALT) == MAX_ALT_WIDE
+    out = np.zeros(batch.n_groups, ALLELE_GROUP_CALL_WIDE_DTYPE if wide else ALLELE_GROUP_CALL_DTYPE)
     s = batch.struct()
-    _check(lib().sk_allele_group_genotype_lhoods(C.byref(s), C.byref(opt), _p(out)))
+    fn = lib().sk_allele_group_genotype_lhoods_wide if wide else lib().sk_allele_group_genotype_lhoods
+    _check(fn(C.byref(s), C.byref(opt), _p(out)))
     return out
 
 

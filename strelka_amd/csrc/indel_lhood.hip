@@ -273,13 +273,17 @@ struct GroupArgs
     int min_read_bp_flank;
     double support_threshold;
     double loghalf;
-    sk_allele_group_call* out;
+    void* out; // sk_allele_group_call or sk_allele_group_call_wide records
     int exact_libm;
 };
 
+// MAXA = alternate alleles a record holds: MAXA (3) or MAXA_WIDE (8: a multi-sample group, ploidy x samples).  Rows of
+// del_len / ins_len / ref_lnp / allele_lnp are MAXA wide.
+template <int MAXA, typename CallT>
 __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
 {
-    __shared__ double s_term[SK_MAX_INDEL_GT][WAVE];
+    constexpr int MAXGT = (MAXA + 1) * (MAXA + 2) / 2;
+    __shared__ double s_term[MAXGT][WAVE];
     __shared__ unsigned char s_support[WAVE]; // 0xff = read not used; else fwd<<4 | (allele index, or 15 = non-confident)
     const int grp = blockIdx.x;
     const int lane = threadIdx.x;
@@ -292,17 +296,17 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
     const unsigned flank = unsigned(a.min_read_bp_flank);
     const int ex = a.exact_libm;
     const SkLibmTables lt = sk_libm_tables_default();
-    unsigned del_len[SK_MAX_ALT], ins_len[SK_MAX_ALT];
+    unsigned del_len[MAXA], ins_len[MAXA];
 #pragma unroll
-    for (int k = 0; k < SK_MAX_ALT; ++k) {
-        del_len[k] = a.b.del_len[size_t(grp) * SK_MAX_ALT + k];
-        ins_len[k] = a.b.ins_len[size_t(grp) * SK_MAX_ALT + k];
+    for (int k = 0; k < MAXA; ++k) {
+        del_len[k] = a.b.del_len[size_t(grp) * MAXA + k];
+        ins_len[k] = a.b.ins_len[size_t(grp) * MAXA + k];
     }
 
     double acc = 0.;
-    unsigned cnt_f[SK_MAX_ALT + 2], cnt_r[SK_MAX_ALT + 2]; // lane 0 only
+    unsigned cnt_f[MAXA + 2], cnt_r[MAXA + 2]; // lane 0 only
 #pragma unroll
-    for (int k = 0; k < SK_MAX_ALT + 2; ++k) cnt_f[k] = cnt_r[k] = 0;
+    for (int k = 0; k < MAXA + 2; ++k) cnt_f[k] = cnt_r[k] = 0;
     unsigned used = 0;
 
     for (int base = 0; base < n; base += WAVE) {
@@ -313,22 +317,22 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
             const unsigned flags = a.b.read_flags[g];
             // intersection of the tier1 reads scored for every allele (OrthogonalVariantAlleleCandidateGroupUtil.cpp:64-113)
             bool use = (flags & SK_READ_TIER1) != 0;
-            double L[SK_MAX_ALT + 1];
+            double L[MAXA + 1];
             L[0] = 0.;
 #pragma unroll
-            for (int k = 0; k < SK_MAX_ALT; ++k) {
+            for (int k = 0; k < MAXA; ++k) {
                 L[k + 1] = 0.;
                 if (k < n_alt) {
-                    const float s = a.b.allele_lnp[g * SK_MAX_ALT + k];
+                    const float s = a.b.allele_lnp[g * MAXA + k];
                     if (!(s == s)) use = false;
-                    const double rl = double(a.b.ref_lnp[g * SK_MAX_ALT + k]);
+                    const double rl = double(a.b.ref_lnp[g * MAXA + k]);
                     L[0] = (k == 0) ? rl : ((L[0] < rl) ? rl : L[0]); // getAlleleLogLhoodFromRead :159-167
                     L[k + 1] = double(s);
                 }
             }
             if (!use) {
 #pragma unroll
-                for (int gi = 0; gi < SK_MAX_INDEL_GT; ++gi) s_term[gi][lane] = 0.;
+                for (int gi = 0; gi < MAXGT; ++gi) s_term[gi][lane] = 0.;
                 s_support[lane] = 0xff;
             } else {
                 const unsigned na = a.b.non_ambig[g];
@@ -336,11 +340,11 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
                 // updateGenotypeLogLhoodFromAlleleLogLhood, AlleleGroupGenotype.cpp:36-114
                 if (ploidy == 1) {
 #pragma unroll
-                    for (int a0 = 0; a0 <= SK_MAX_ALT; ++a0)
+                    for (int a0 = 0; a0 <= MAXA; ++a0)
                         if (a0 < full) s_term[a0][lane] = integrate_out_mapping(a.map, na, L[a0], ex, lt);
                 } else {
 #pragma unroll
-                    for (int a1 = 0; a1 <= SK_MAX_ALT; ++a1) {
+                    for (int a1 = 0; a1 <= MAXA; ++a1) {
 #pragma unroll
                         for (int a0 = 0; a0 <= a1; ++a0) {
                             if (a1 >= full) continue;
@@ -366,16 +370,16 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
                     }
                 }
                 // updateSupportingReadStats, :125-155 (normalizeLogDistro: first maximum, exp, 1/sum)
-                double Lm[SK_MAX_ALT + 1];
+                double Lm[MAXA + 1];
                 double mx = 0.;
 #pragma unroll
-                for (int k = 0; k <= SK_MAX_ALT; ++k) {
+                for (int k = 0; k <= MAXA; ++k) {
                     Lm[k] = (k < full) ? integrate_out_mapping(a.map, na, L[k], ex, lt) : 0.;
                     if (k < full) mx = (k == 0) ? Lm[0] : ((Lm[k] > mx) ? Lm[k] : mx);
                 }
                 double sum = 0.;
 #pragma unroll
-                for (int k = 0; k <= SK_MAX_ALT; ++k)
+                for (int k = 0; k <= MAXA; ++k)
                     if (k < full) {
                         Lm[k] = sk_exp(__dsub_rn(Lm[k], mx), ex, lt);
                         sum = __dadd_rn(sum, Lm[k]);
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
                 sum = __ddiv_rn(1., sum);
                 unsigned which = 15;
 #pragma unroll
-                for (int k = SK_MAX_ALT; k >= 0; --k)
+                for (int k = MAXA; k >= 0; --k)
                     if (k < full && !(__dmul_rn(Lm[k], sum) < a.support_threshold)) which = unsigned(k); // first such allele
                 s_support[lane] = (unsigned char)(((flags & SK_READ_FWD) ? 0x10 : 0) | which);
             }
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
                 const unsigned which = s & 15u;
                 const unsigned slot = (which == 15u) ? unsigned(n_alt + 1) : which;
 #pragma unroll
-                for (unsigned k = 0; k < SK_MAX_ALT + 2; ++k) {
+                for (unsigned k = 0; k < MAXA + 2; ++k) {
                     if (k == slot) {
                         if (s & 0x10) ++cnt_f[k]; else ++cnt_r[k];
                     }
@@ -408,11 +412,11 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
         }
         __syncthreads();
     }
-    sk_allele_group_call* o = a.out + grp;
-    if (lane < SK_MAX_INDEL_GT) o->lhood[lane] = (lane < gcount) ? acc : 0.;
+    CallT* o = static_cast<CallT*>(a.out) + grp;
+    if (lane < MAXGT) o->lhood[lane] = (lane < gcount) ? acc : 0.;
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < SK_MAX_ALT + 2; ++k) {
+        for (int k = 0; k < MAXA + 2; ++k) {
             o->counts[0][k] = cnt_f[k];
             o->counts[1][k] = cnt_r[k];
         }
@@ -652,6 +656,73 @@ MapParams make_map(const sk_indel_options& opt, const bool tier2_pass)
 }
 
 } // namespace
+
+template <int MAXA, typename CallT>
+static int allele_group_dev_t(const sk_allele_group_batch* b, const sk_indel_options* opt, CallT* dev_out, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (!b || !opt || !dev_out) return sk_fail("sk_allele_group_genotype_lhoods_dev: null argument");
+    if (b->n_groups <= 0) return 0;
+    GroupArgs a;
+    a.b = *b;
+    a.map = make_map(*opt, false); // isTier2Pass(false), AlleleGroupGenotype.cpp:46
+    a.min_read_bp_flank = opt->min_read_bp_flank;
+    a.support_threshold = opt->read_confident_support_threshold;
+    volatile double half = 0.5;
+    a.loghalf = std::log(half); // :75
+    a.out = dev_out;
+    a.exact_libm = sk_ctx().libm_restated ? 1 : 0;
+    hipLaunchKernelGGL((allele_group_kernel<MAXA, CallT>), dim3(b->n_groups), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int MAXA, typename CallT>
+static int allele_group_host_t(const sk_allele_group_batch* hb, const sk_indel_options* opt, CallT* out)
+{
+    SK_REQUIRE_INIT();
+    if (!hb || !opt || !out) return sk_fail("sk_allele_group_genotype_lhoods: null argument");
+    const int n = hb->n_groups;
+    if (n <= 0) return 0;
+    if (hb->read_off[0] != 0) return sk_fail("allele group batch: read_off must start at 0");
+    for (int g = 0; g < n; ++g) {
+        if (hb->n_alt[g] < 1 || hb->n_alt[g] > MAXA) return sk_fail("allele group batch: n_alt outside 1..SK_MAX_ALT (SK_MAX_ALT_WIDE for the wide entry)");
+        if (hb->ploidy[g] != 1 && hb->ploidy[g] != 2) return sk_fail("Unexpected ploidy value"); // AlleleGroupGenotype.cpp:112
+    }
+    const int64_t tr = hb->read_off[n];
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    SkArena ar;
+    if (ar.reserve(sk_align256(8 * (n + 1)) + 2 * sk_align256(n) + 2 * sk_align256(4 * MAXA * n) +
+                   2 * sk_align256(4 * MAXA * tr) + 2 * sk_align256(2 * tr) + sk_align256(tr) +
+                   sk_align256(sizeof(CallT) * n) + 16 * 256))
+        return 1;
+    sk_allele_group_batch d = *hb;
+    hipStream_t st = ctx.stream;
+#define UPG(field, T, count)                                                                            \
+    {                                                                                                   \
+        T* p = ar.take<T>(count);                                                                       \
+        if (count) SK_HIP(hipMemcpyAsync(p, hb->field, sizeof(T) * (count), hipMemcpyHostToDevice, st)); \
+        d.field = p;                                                                                    \
+    }
+    UPG(read_off, int64_t, size_t(n + 1));
+    UPG(n_alt, uint8_t, size_t(n));
+    UPG(ploidy, uint8_t, size_t(n));
+    UPG(del_len, uint32_t, size_t(n) * MAXA);
+    UPG(ins_len, uint32_t, size_t(n) * MAXA);
+    UPG(ref_lnp, float, size_t(tr) * MAXA);
+    UPG(allele_lnp, float, size_t(tr) * MAXA);
+    UPG(non_ambig, uint16_t, size_t(tr));
+    UPG(read_length, uint16_t, size_t(tr));
+    UPG(read_flags, uint8_t, size_t(tr));
+#undef UPG
+    CallT* dout = ar.take<CallT>(n);
+    if (allele_group_dev_t<MAXA, CallT>(&d, opt, dout, st)) return 1;
+    SK_HIP(hipMemcpyAsync(out, dout, sizeof(CallT) * n, hipMemcpyDeviceToHost, st));
+    SK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 
 extern "C" {
 
@@ -966,66 +1037,23 @@ int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* hb, const sk_indel
 int sk_allele_group_genotype_lhoods_dev(const sk_allele_group_batch* b, const sk_indel_options* opt,
                                         sk_allele_group_call* dev_out, void* hip_stream)
 {
-    SK_REQUIRE_INIT();
-    if (!b || !opt || !dev_out) return sk_fail("sk_allele_group_genotype_lhoods_dev: null argument");
-    if (b->n_groups <= 0) return 0;
-    GroupArgs a;
-    a.b = *b;
-    a.map = make_map(*opt, false); // isTier2Pass(false), AlleleGroupGenotype.cpp:46
-    a.min_read_bp_flank = opt->min_read_bp_flank;
-    a.support_threshold = opt->read_confident_support_threshold;
-    volatile double half = 0.5;
-    a.loghalf = std::log(half); // :75
-    a.out = dev_out;
-    a.exact_libm = sk_ctx().libm_restated ? 1 : 0;
-    hipLaunchKernelGGL(allele_group_kernel, dim3(b->n_groups), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
-    return 0;
+    return allele_group_dev_t<SK_MAX_ALT, sk_allele_group_call>(b, opt, dev_out, hip_stream);
+}
+
+int sk_allele_group_genotype_lhoods_wide_dev(const sk_allele_group_batch* b, const sk_indel_options* opt,
+                                             sk_allele_group_call_wide* dev_out, void* hip_stream)
+{
+    return allele_group_dev_t<SK_MAX_ALT_WIDE, sk_allele_group_call_wide>(b, opt, dev_out, hip_stream);
 }
 
 int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* hb, const sk_indel_options* opt, sk_allele_group_call* out)
 {
-    SK_REQUIRE_INIT();
-    if (!hb || !opt || !out) return sk_fail("sk_allele_group_genotype_lhoods: null argument");
-    const int n = hb->n_groups;
-    if (n <= 0) return 0;
-    if (hb->read_off[0] != 0) return sk_fail("allele group batch: read_off must start at 0");
-    for (int g = 0; g < n; ++g) {
-        if (hb->n_alt[g] < 1 || hb->n_alt[g] > SK_MAX_ALT) return sk_fail("allele group batch: n_alt must be 1..SK_MAX_ALT");
-        if (hb->ploidy[g] != 1 && hb->ploidy[g] != 2) return sk_fail("Unexpected ploidy value"); // AlleleGroupGenotype.cpp:112
-    }
-    const int64_t tr = hb->read_off[n];
-    SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
-    SkArena ar;
-    if (ar.reserve(sk_align256(8 * (n + 1)) + 2 * sk_align256(n) + 2 * sk_align256(4 * SK_MAX_ALT * n) +
-                   2 * sk_align256(4 * SK_MAX_ALT * tr) + 2 * sk_align256(2 * tr) + sk_align256(tr) +
-                   sk_align256(sizeof(sk_allele_group_call) * n) + 16 * 256))
-        return 1;
-    sk_allele_group_batch d = *hb;
-    hipStream_t st = ctx.stream;
-#define UPG(field, T, count)                                                                            \
-    {                                                                                                   \
-        T* p = ar.take<T>(count);                                                                       \
-        if (count) SK_HIP(hipMemcpyAsync(p, hb->field, sizeof(T) * (count), hipMemcpyHostToDevice, st)); \
-        d.field = p;                                                                                    \
-    }
-    UPG(read_off, int64_t, size_t(n + 1));
-    UPG(n_alt, uint8_t, size_t(n));
-    UPG(ploidy, uint8_t, size_t(n));
-    UPG(del_len, uint32_t, size_t(n) * SK_MAX_ALT);
-    UPG(ins_len, uint32_t, size_t(n) * SK_MAX_ALT);
-    UPG(ref_lnp, float, size_t(tr) * SK_MAX_ALT);
-    UPG(allele_lnp, float, size_t(tr) * SK_MAX_ALT);
-    UPG(non_ambig, uint16_t, size_t(tr));
-    UPG(read_length, uint16_t, size_t(tr));
-    UPG(read_flags, uint8_t, size_t(tr));
-#undef UPG
-    sk_allele_group_call* dout = ar.take<sk_allele_group_call>(n);
-    if (sk_allele_group_genotype_lhoods_dev(&d, opt, dout, st)) return 1;
-    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_allele_group_call) * n, hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
-    return 0;
+    return allele_group_host_t<SK_MAX_ALT, sk_allele_group_call>(hb, opt, out);
+}
+
+int sk_allele_group_genotype_lhoods_wide(const sk_allele_group_batch* hb, const sk_indel_options* opt, sk_allele_group_call_wide* out)
+{
+    return allele_group_host_t<SK_MAX_ALT_WIDE, sk_allele_group_call_wide>(hb, opt, out);
 }
 
 } // extern "C"

@@ -434,22 +434,25 @@ def readscore_batch(n_indels, rng, depth_mean=40.0, alt_rate=0.2, breakpoint_rat
     return capi.HostReadScoreBatch(off, ref, ind, alt, na, rl, fl, del_len, ins_len, bp)
 
 
-def allele_group_batch(n_groups, rng, depth_mean=40.0, missing_rate=0.05):
+def allele_group_batch(n_groups, rng, depth_mean=40.0, missing_rate=0.05, min_alt=1, max_alt=None):
+    """max_alt > capi.MAX_ALT: a batch for the wide entry points (multi-sample allele groups, rows of capi.MAX_ALT_WIDE)"""
+    max_alt = max_alt or capi.MAX_ALT
+    width = capi.MAX_ALT if max_alt <= capi.MAX_ALT else capi.MAX_ALT_WIDE
     depth = rng.poisson(depth_mean, n_groups).astype(np.int64)
     off = np.zeros(n_groups + 1, np.int64)
     np.cumsum(depth, out=off[1:])
     total = int(off[-1])
-    n_alt = rng.integers(1, capi.MAX_ALT + 1, n_groups).astype(np.uint8)
+    n_alt = rng.integers(min_alt, max_alt + 1, n_groups).astype(np.uint8)
     ploidy = rng.choice(np.array([1, 2, 2, 2], np.uint8), n_groups)
-    is_del = rng.random((n_groups, capi.MAX_ALT)) < 0.5
-    ln = rng.integers(1, 30, (n_groups, capi.MAX_ALT))
+    is_del = rng.random((n_groups, width)) < 0.5
+    ln = rng.integers(1, 30, (n_groups, width))
     del_len = np.where(is_del, ln, 0).astype(np.uint32)
     ins_len = np.where(is_del, 0, ln).astype(np.uint32)
-    refl = np.minimum(0, rng.normal(-5, 3, (total, capi.MAX_ALT))).astype(np.float32)
-    al = np.minimum(0, rng.normal(-5, 3, (total, capi.MAX_ALT))).astype(np.float32)
-    al = np.where(rng.random((total, capi.MAX_ALT)) < missing_rate, np.nan, al).astype(np.float32)
+    refl = np.minimum(0, rng.normal(-5, 3, (total, width))).astype(np.float32)
+    al = np.minimum(0, rng.normal(-5, 3, (total, width))).astype(np.float32)
+    al = np.where(rng.random((total, width)) < missing_rate, np.nan, al).astype(np.float32)
     na, rl, fl = _read_fields(total, rng)
-    return capi.HostAlleleGroupBatch(off, n_alt, ploidy, del_len, ins_len, refl, al, na, rl, fl)
+    return capi.HostAlleleGroupBatch(off, n_alt, ploidy, del_len, ins_len, refl, al, na, rl, fl, width=width)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

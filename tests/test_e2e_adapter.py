@@ -433,3 +433,42 @@ def test_two_sample_germline_with_evs_models_cpu_double(tmp_path, which):
 @pytest.mark.parametrize("which", ["short_reads", "long_reads"])
 def test_two_sample_germline_with_evs_models_gpu(tmp_path, which):
     _two_sample_evs("amd", tmp_path, which)
+
+
+# ---- allele groups of a multi-sample run (tools/make_multiallelic_bam.py): four samples, each heterozygous for its own pair of
+# overlapping indels at the same loci -> groups of up to ploidy x samples alternate alleles (selectTopOrthogonalAllelesInAllSamples).
+# Round 3's adapter handed groups of more than SK_MAX_ALT alleles back to the reference's own function; now they go through
+# sk_allele_group_genotype_lhoods_wide and nothing on this path runs the reference's likelihood code.
+MULTI = os.path.join(SYNTH, "multi")
+
+
+def _multi_sample_wide_groups(variant, tmp_path):
+    outs = {}
+    bams = [os.path.join(MULTI, "multi_M%d.bam" % k) for k in (1, 2, 3, 4)]
+    for v in ("ref", variant):
+        o = str(tmp_path / v) + "/"
+        os.makedirs(o, exist_ok=True)
+        p = E.run(E.germline_argv("starling2_" + v, o, bams, region="chrS:1-24000", ref=os.path.join(MULTI, "multi.fa")),
+                  env={"STRELKA_AMD_VERBOSE": "1"} if v != "ref" else None)
+        outs[v] = ({f: E.vcf_body(o + f, keep_header=True) for f in ["variants.vcf"] + ["genome.S%d.vcf" % k for k in (1, 2, 3, 4)]},
+                   p.stderr.decode())
+    records = [l for l in outs["ref"][0]["variants.vcf"] if not l.startswith("#")]
+    assert max(len(l.split("\t")[4].split(",")) for l in records) >= 6  # records with six and more alternate alleles
+    for f in outs["ref"][0]:
+        assert outs[variant][0][f] == outs["ref"][0][f], f
+    c = _counters(outs[variant][1])
+    assert c["indel_groups_wide"] >= 40 and c["indel_groups"] > c["indel_groups_wide"]
+    assert "indel_groups_reference" not in c  # (the fall-back to the reference's function is gone, and its counter with it)
+
+
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and os.path.exists(os.path.join(MULTI, "multi_M4.bam"))),
+                    reason="oracle/_ref binaries / synthetic sets not built")
+def test_multi_sample_wide_allele_groups_cpu_double(tmp_path):
+    _multi_sample_wide_groups("dbl", tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_amd") and os.path.exists(os.path.join(MULTI, "multi_M4.bam"))),
+                    reason="oracle/_ref binaries / synthetic sets not built")
+def test_multi_sample_wide_allele_groups_gpu(tmp_path):
+    _multi_sample_wide_groups("amd", tmp_path)

@@ -383,6 +383,32 @@ def test_allele_group_genotype_lhoods(gpu):
     assert np.array_equal(got2["counts"], counts2)
 
 
+def test_allele_group_genotype_lhoods_wide(gpu):
+    """groups of 4..8 alternate alleles (a multi-sample run's): sk_allele_group_genotype_lhoods_wide against the oracle on fresh
+    groups and against the REFERENCE's own function on the committed fixture (tests/golden/make_golden_wide_groups.py)"""
+    import os
+    from strelka_amd import capi
+    rng = np.random.default_rng(304)
+    ab = synth.allele_group_batch(300, rng, depth_mean=45.0, min_alt=1, max_alt=capi.MAX_ALT_WIDE, missing_rate=0.01)
+    assert ab.width == capi.MAX_ALT_WIDE
+    got = gpu.allele_group_genotype_lhoods(ab)
+    lh, counts, ng = pyoracle.allele_group_genotype_lhoods(ab)
+    assert got["lhood"].shape[1] == 45 and np.array_equal(got["n_genotypes"], ng) and ng.max() == 45
+    assert np.array_equal(got["lhood"].view(np.uint64), lh.view(np.uint64))
+    assert np.array_equal(got["counts"], counts)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "allele_group_wide_reference.npz"))
+    gb = capi.HostAlleleGroupBatch(g["a_read_off"], g["a_n_alt"], g["a_ploidy"], g["a_del"], g["a_ins"], g["a_ref"], g["a_allele"],
+                                   g["a_na"], g["a_rl"], g["a_flags"], width=capi.MAX_ALT_WIDE)
+    got = gpu.allele_group_genotype_lhoods(gb)
+    assert np.array_equal(got["lhood"].view(np.uint64), g["a_lhood"].view(np.uint64))
+    assert np.array_equal(got["counts"], g["a_counts"])
+    # deep groups (more than one 64-read chunk)
+    ab2 = synth.allele_group_batch(6, rng, depth_mean=200.0, min_alt=5, max_alt=capi.MAX_ALT_WIDE, missing_rate=0.0)
+    got2 = gpu.allele_group_genotype_lhoods(ab2)
+    lh2, counts2, _ = pyoracle.allele_group_genotype_lhoods(ab2)
+    assert np.array_equal(got2["lhood"].view(np.uint64), lh2.view(np.uint64)) and np.array_equal(got2["counts"], counts2)
+
+
 def test_indel_fast_form_keeps_every_integer_output(gpu):
     """sk_indel_options.fast_form: two exp per read shared by its 21 states instead of the reference's operation order.
     Likelihoods then agree to ~1e-13 absolute (1e-15 relative to the terms' magnitude) instead of bit for bit; over 10^6 candidate

@@ -39,6 +39,12 @@ def test_more_alt_alleles_than_supported_is_refused():
     b.n_alt[:] = 4
     with pytest.raises(RuntimeError, match="n_alt"):
         capi.allele_group_genotype_lhoods(b)
+    # ... and the wide entry (a multi-sample run's groups) holds ploidy x 4 samples = 8, no more
+    w = synth.allele_group_batch(4, rng, max_alt=capi.MAX_ALT_WIDE)
+    capi.allele_group_genotype_lhoods(w)
+    w.n_alt[:] = 9
+    with pytest.raises(RuntimeError, match="n_alt"):
+        capi.allele_group_genotype_lhoods(w)
 
 
 @pytest.mark.gpu

@@ -131,6 +131,24 @@ def test_indel_likelihoods_match_reference(gold):
     assert np.array_equal(counts, gold["a_counts"])
 
 
+def test_wide_allele_groups_match_reference(built):
+    """allele groups of 4..8 alternate alleles (multi-sample runs): the restatement against the reference's own
+    getVariantAlleleGroupGenotypeLhoodsForSample -- the committed fixture, and live on fresh groups where oracle/_ref is built"""
+    g = np.load(os.path.join(GOLD, "allele_group_wide_reference.npz"))
+    ab = capi.HostAlleleGroupBatch(g["a_read_off"], g["a_n_alt"], g["a_ploidy"], g["a_del"], g["a_ins"], g["a_ref"], g["a_allele"],
+                                   g["a_na"], g["a_rl"], g["a_flags"], width=capi.MAX_ALT_WIDE)
+    assert ab.n_alt.min() == 4 and ab.n_alt.max() == 8
+    lh, counts, ng = pyoracle.allele_group_genotype_lhoods(ab)
+    assert ng.max() == 45 and np.array_equal(lh.view(np.uint64), g["a_lhood"].view(np.uint64)) and np.array_equal(counts, g["a_counts"])
+    assert int(counts.sum()) > 2000  # reads were used
+    if pyoracle.ref_available():
+        from tests.golden import make_golden_wide_groups as W
+        fresh = synth.allele_group_batch(40, np.random.default_rng(99), depth_mean=30.0, min_alt=4, max_alt=capi.MAX_ALT_WIDE, missing_rate=0.02)
+        want_lh, want_counts = W.reference_lhoods(fresh)
+        lh, counts, _ = pyoracle.allele_group_genotype_lhoods(fresh)
+        assert np.array_equal(lh.view(np.uint64), want_lh.view(np.uint64)) and np.array_equal(counts, want_counts)
+
+
 def test_alignment_scores_match_reference(built):
     with open(os.path.join(GOLD, "patha_scores_reference.pkl"), "rb") as f:
         g = pickle.load(f)
