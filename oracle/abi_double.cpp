@@ -58,6 +58,7 @@ const char* sk_last_error(void) { return g_err.c_str(); }
 int sk_version(void) { return SK_VERSION; }
 int sk_is_initialized(void) { return g_ready ? 1 : 0; }
 int sk_sync_mode(void) { return g_ready ? 1 : -1; }
+int sk_debug_set_g3_variant(int) { return 0; }
 int sk_libm_restated(void) { return 1; } // the oracle calls the host libm directly
 int sk_abi_double(void) { return 1; }    // marker: lets a test assert which library a binary loaded
 

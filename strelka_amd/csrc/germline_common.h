@@ -16,6 +16,8 @@ struct GermlineDerived
     float depmin[SK_NQ6];       // get_dependent_eprob(q, (float)min_vexp)  (dependent_prob_cache, adjust_joint_eprob.cpp:73-86)
     float v0min[SK_NQ6];        // logf(depmin[q]) + log_one_third : val[0] of a call whose de is the cached floor value
     float v0e[SK_NQ6];          // logf((float)error_prob(q)) + log_one_third : val[0] of a call left at its raw error prob
+    float v0r0[SK_NQ6][3];      // val[0] of the call ranked 2, 3, 4 in a (strand, base) group WITHOUT a neighbouring mismatch: there
+                                // mismatch_frac is exactly 0, the exponent chain of adjust_icalls_eprob (:146-178) a constant of the options
     double ssd_no_mismatch, ssd_one_mismatch;
     float min_vexp;
     int is_min_vexp;
@@ -213,6 +215,23 @@ inline void derive(const sk_germline_options& opt, GermlineDerived& d)
         d.depmin[q] = host_dependent_eprob(t.g_eprob[q], d.min_vexp);
         d.v0min[q] = std::log(d.depmin[q]) + t.g_log_one_third; // position_snp_call_pprob_digt.cpp:352, float logf + float add
         d.v0e[q] = std::log(t.g_eprob[q]) + t.g_log_one_third;
+    }
+    {
+        // a group none of whose calls has a neighbouring mismatch: mismatch_frac = 0 / den = 0 exactly (adjust_joint_eprob.cpp:128-133),
+        // so vexp_frac and the exponents of its sorted calls (:146-178) do not depend on the data; the same expressions as the kernels'
+        const float mismatch_frac(0.f);
+        const float vexp_frac(static_cast<float>(static_cast<double>(1.f - mismatch_frac) * d.ssd_no_mismatch +
+                                                 static_cast<double>(mismatch_frac) * d.ssd_one_mismatch));
+        const float m(1.f - vexp_frac);
+        float vexp(1.f);
+        for (int rank = 1; rank <= 4; ++rank) {
+            if (rank >= 2) {
+                for (int q = 0; q < SK_NQ6; ++q)
+                    d.v0r0[q][rank - 2] = std::log(host_dependent_eprob(t.g_eprob[q], vexp)) + t.g_log_one_third;
+            }
+            const float next_vexp(vexp * m);
+            vexp = d.is_min_vexp ? ((d.min_vexp < next_vexp) ? next_vexp : d.min_vexp) : next_vexp;
+        }
     }
     volatile float ten = 10.f;
     d.ln10f = std::log(static_cast<float>(ten));

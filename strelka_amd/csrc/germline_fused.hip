@@ -26,10 +26,14 @@
 #include "germline_common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #ifndef G3_LIBM_LDS
 #define G3_LIBM_LDS 1
+#endif
+#ifndef G3_DEFAULT_VARIANT
+#define G3_DEFAULT_VARIANT 1
 #endif
 
 namespace
@@ -507,6 +511,335 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(3
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// G3 v2.  Counters of the kernel above on 2^24 loci at 40x (profiles/r04_v1_g3_sq_counters.txt): it is bound by VALU issue --
+// 11 900 vector instructions per wave of 64 loci, the vector ALUs busy 60-70 % of the time with three waves per SIMD -- not by LDS
+// (21 % busy) or memory.  A third of those instructions are the powf + logf of the ranked calls' terms: three per big group, inside
+// the per-group loop, where a wave pays for them whenever ANY of its lanes has a ranked call in that round.  Here
+//   * a group none of whose calls has a neighbouring mismatch has mismatch_frac == 0 exactly, hence a constant exponent chain: its
+//     ranked terms are a host-built table of (q, rank) (GermlineDerived::v0r0) -- two groups in three at human mismatch densities;
+//   * the others leave (slot, q) on a block-wide list and their exponent in the slot; after a barrier the whole block works the list
+//     off, one entry per lane: the transcendentals are evaluated once per entry instead of once per (wave, round, rank);
+//   * FLAG_SORT: lanes take the loci of a sub-batch in order of depth, so that the lanes of a wave run loops of similar length;
+//   * the log table of the restated double-precision libm stays in global memory (L1-resident): six blocks per CU instead of five.
+// Same arithmetic, same records; loci the fast path declines take the global-memory pass as before.
+enum { G3_FLAG_SORT = 1 };
+
+template <int LOCI>
+struct G3Cfg
+{
+    static constexpr int CAP = (CAP_CALLS * LOCI) / 128;
+    static constexpr int POOL = (V0R_POOL * LOCI) / 128;
+    static constexpr int PEND = 4 * LOCI;
+    // a list entry = pool slot | q << QSHIFT: 16 bits while the pool has at most 1024 slots
+    static constexpr int QSHIFT = (POOL <= 1024) ? 10 : 16;
+    typedef typename std::conditional<(POOL <= 1024), uint16_t, uint32_t>::type pend_t;
+};
+
+// phase 1 of a locus, as locus_rank_calls, except that a ranked call's term is either taken from the table (group without a
+// neighbouring mismatch) or left pending: its exponent in the slot, (slot | q << 16) on the block's list
+template <typename PendT, int QSHIFT>
+__device__ bool locus_rank_calls_v2(uint16_t* calls, uint16_t* keys, const int n, const GermlineDerived& D, const QTab& Q, const float* tab,
+                                    float (&vfrac)[8], float* pool, unsigned* pool_ctr, const unsigned pool_cap, PendT* pend,
+                                    unsigned* pend_ctr, const unsigned pend_cap, float*& v0r, unsigned& gbase)
+{
+    gbase = 0;
+    v0r = pool;
+    unsigned nslots = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) vfrac[g] = 0.f;
+    if (!D.is_dependent_eprob) return true;
+
+    uint64_t cntA = 0, cntB = 0; // groups 0-3 / 4-7
+    for (int i = 0; i < n; ++i) {
+        const uint16_t b = calls[i];
+        const bool valid = !(SKC_FILTER(b) || SKC_Q(b) < 3);
+        const unsigned g = SKC_FWD(b) + 2 * SKC_BASE(b);
+        const uint64_t inc = valid ? (uint64_t(1) << (16 * (g & 3))) : 0;
+        cntA += (g < 4) ? inc : 0;
+        cntB += (g >= 4) ? inc : 0;
+    }
+    unsigned need = 0;
+#pragma unroll
+    for (unsigned g = 0; g < 8; ++g) {
+        const unsigned cg = unsigned(((g < 4) ? cntA : cntB) >> (16 * (g & 3))) & 0xffffu;
+        need += (cg > 1u) ? ((cg - 1u < unsigned(MAX_RANK - 1)) ? cg - 1u : unsigned(MAX_RANK - 1)) : 0u;
+    }
+    if (need > unsigned(V0R_PER_LOCUS)) return false;
+    if (need) {
+        const unsigned at = atomicAdd(pool_ctr, need);
+        if (at + need > pool_cap) return false;
+        v0r = pool + at;
+    }
+    const uint64_t inclA = cntA + (cntA << 16) + (cntA << 32) + (cntA << 48);
+    const uint64_t inclB = cntB + (cntB << 16) + (cntB << 32) + (cntB << 48);
+    const uint64_t totalA = inclA >> 48;
+    uint64_t posA = inclA << 16, posB = (inclB << 16) + totalA * 0x0001000100010001ull;
+    for (int i = 0; i < n; ++i) {
+        const uint16_t b = calls[i];
+        const bool valid = !(SKC_FILTER(b) || SKC_Q(b) < 3);
+        const unsigned g = SKC_FWD(b) + 2 * SKC_BASE(b);
+        const unsigned sh = 16 * (g & 3);
+        const unsigned off = unsigned(((g < 4) ? posA : posB) >> sh) & 0xffffu;
+        if (valid) keys[off] = uint16_t((SKC_Q(b) << 10) | (SKC_NMM(b) << 9) | unsigned(i));
+        const uint64_t inc = valid ? (uint64_t(1) << sh) : 0;
+        posA += (g < 4) ? inc : 0;
+        posB += (g >= 4) ? inc : 0;
+    }
+
+    bool ok = true;
+    unsigned present = 0;
+#pragma unroll
+    for (unsigned g = 0; g < 8; ++g)
+        if ((((g < 4) ? cntA : cntB) >> (16 * (g & 3))) & 0xffffu) present |= 1u << g;
+    while (present) {
+        unsigned g = 0, best = 0;
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k) {
+            const unsigned ck = unsigned(((k < 4) ? cntA : cntB) >> (16 * (k & 3))) & 0xffffu;
+            const bool take = ((present >> k) & 1u) && ck > best;
+            g = take ? k : g;
+            best = take ? ck : best;
+        }
+        present &= ~(1u << g);
+        const unsigned sh = 16 * (g & 3);
+        const int gs = int(((g < 4) ? cntA : cntB) >> sh) & 0xffff;
+        uint16_t* gk = keys + ((int(((g < 4) ? posA : posB) >> sh) & 0xffff) - gs);
+
+        float num = 0.f, den = 0.f; // adjust_icalls_eprob :110-127, pileup order
+        unsigned any_nmm = 0;
+        for (int i = 0; i < gs; ++i) {
+            const unsigned k = gk[i];
+            const float weight = Q.weight[k >> 10];
+            den = __fadd_rn(den, weight);
+            if (k & 0x200u) num = __fadd_rn(num, weight);
+            any_nmm |= k & 0x200u;
+        }
+        float mismatch_frac = 0.f;
+        if (den > 0.) mismatch_frac = __fdiv_rn(num, den);
+        const float vexp_frac = static_cast<float>(
+            __dadd_rn(__dmul_rn(static_cast<double>(__fsub_rn(1.f, mismatch_frac)), D.ssd_no_mismatch),
+                      __dmul_rn(static_cast<double>(mismatch_frac), D.ssd_one_mismatch)));
+#pragma unroll
+        for (unsigned k = 0; k < 8; ++k)
+            if (k == g) vfrac[k] = vexp_frac;
+
+        const float m = __fsub_rn(1.f, vexp_frac);
+        int nrank = 0;
+        {
+            float vexp = 1.f;
+            bool is_min = false;
+            while (!is_min && nrank < gs && nrank <= MAX_RANK) {
+                ++nrank;
+                const float next_vexp = __fmul_rn(vexp, m);
+                if (D.is_min_vexp) {
+                    is_min = (next_vexp <= D.min_vexp);
+                    vexp = (D.min_vexp < next_vexp) ? next_vexp : D.min_vexp;
+                } else {
+                    vexp = next_vexp;
+                }
+            }
+        }
+        if (nrank > MAX_RANK) {
+            ok = false;
+            break;
+        }
+        uint16_t top[MAX_RANK];
+        int ntop = 0;
+        if (!k_top_ranked(gk, gs, nrank, top, ntop)) {
+            ok = false;
+            break;
+        }
+        if (ntop > 1) gbase |= nslots << (4 * g);
+        if (nslots + unsigned(ntop > 1 ? ntop - 1 : 0) > need) {
+            ok = false;
+            break;
+        }
+        // a group whose calls carry no neighbouring mismatch has the constant chain the table was built for -- unless the weights'
+        // sum is not positive (then mismatch_frac is 0 as well, :128-133)
+        const bool tabled = (any_nmm == 0u);
+        float vexp = 1.f;
+#pragma unroll
+        for (int i = 0; i < MAX_RANK; ++i) {
+            if (i < ntop) {
+                const unsigned ci = top[i] & 0x1ffu;
+                const uint16_t c = calls[ci];
+                calls[ci] = uint16_t(c | ((unsigned(i) + 1u) << RANK_SHIFT));
+                if (i >= 1) { // rank 1 has vexp == 1 -> de == e_q exactly, a table term
+                    const unsigned q = SKC_Q(c);
+                    if (tabled) {
+                        v0r[nslots] = tab[q * 3u + unsigned(i - 1)];
+                    } else {
+                        v0r[nslots] = vexp;
+                        const unsigned at = atomicAdd(pend_ctr, 1u);
+                        if (at < pend_cap) pend[at] = PendT((unsigned(v0r - pool) + nslots) | (q << QSHIFT));
+                        else ok = false; // (list full: this locus takes the global-memory pass)
+                    }
+                    ++nslots;
+                }
+                const float next_vexp = __fmul_rn(vexp, m);
+                vexp = D.is_min_vexp ? ((D.min_vexp < next_vexp) ? next_vexp : D.min_vexp) : next_vexp;
+            }
+        }
+    }
+    return ok;
+}
+
+template <int LOCI, int FLAGS>
+__global__ __launch_bounds__(LOCI) __attribute__((amdgpu_waves_per_eu(3, 3))) void germline_site_fused_v2_kernel(const FusedArgs a)
+{
+    typedef G3Cfg<LOCI> C;
+    __shared__ __attribute__((aligned(16))) uint16_t s_calls[C::CAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_keys[C::CAP]; // (also the scratch of the depth sort: needs 4 * 256 + 2 * LOCI bytes)
+    __shared__ int32_t s_off[LOCI + 1];
+    __shared__ float s_pool[C::POOL];
+    __shared__ typename C::pend_t s_pend[C::PEND];
+    __shared__ unsigned s_pool_ctr, s_pend_ctr;
+    __shared__ QTab s_q;
+    __shared__ float s_tab[SK_NQ6 * 3];
+    __shared__ uint64_t s_exp[256];
+    static_assert(C::CAP * 2 >= 4 * 256 + 2 * LOCI, "depth-sort scratch");
+
+    const int tid = threadIdx.x;
+    const int l0 = blockIdx.x * LOCI;
+    const int nl = min(LOCI, a.b.n_loci - l0);
+    const int64_t block_c0 = a.b.call_off[l0];
+    const bool huge = (a.b.call_off[l0 + nl] - block_c0) > int64_t(0x7fff0000);
+    for (int j = tid; j <= nl; j += LOCI) s_off[j] = huge ? 0 : int32_t(a.b.call_off[l0 + j] - block_c0);
+    for (int q = tid; q < SK_NQ6; q += LOCI) {
+        s_q.v[q] = make_float4(a.d.v0e[q], a.d.v0min[q], a.tab->g_v1[q], a.tab->g_v2[q]);
+        s_q.weight[q] = a.tab->g_weight[q];
+        s_q.eprob[q] = a.tab->g_eprob[q];
+        s_q.depmin[q] = a.d.depmin[q];
+    }
+    for (int j = tid; j < SK_NQ6 * 3; j += LOCI) s_tab[j] = a.d.v0r0[j / 3][j % 3];
+    {
+        const uint64_t* e = sk_libm::exp_table();
+        for (int j = tid; j < 256; j += LOCI) s_exp[j] = e[j];
+    }
+    const SkLibmTables lt = SkLibmTables{ s_exp, sk_libm::log_table() };
+    __syncthreads();
+    if (huge) {
+        if (tid < nl) {
+            a.out[l0 + tid].is_called = NEEDS_GLOBAL_PASS;
+            a.worklist[atomicAdd(a.work_count, 1u)] = unsigned(l0 + tid);
+        }
+        return;
+    }
+
+    const SkTables* __restrict__ T = a.tab;
+    int s = 0;
+    while (s < nl) {
+        const int c0 = s_off[s];
+        const bool fits = (tid >= s) && (tid < nl) && (s_off[tid + 1] - c0 <= C::CAP);
+        if (tid == 0) {
+            s_pool_ctr = 0;
+            s_pend_ctr = 0;
+        }
+        const int cnt = __syncthreads_count(fits);
+        if (cnt == 0) {
+            if (tid == 0) {
+                a.out[l0 + s].is_called = NEEDS_GLOBAL_PASS;
+                a.worklist[atomicAdd(a.work_count, 1u)] = unsigned(l0 + s);
+            }
+            s += 1;
+            __syncthreads();
+            continue;
+        }
+        const int e = s + cnt;
+        const int span = s_off[e] - c0;
+        const uint16_t* __restrict__ gcalls = a.b.calls + block_c0 + c0;
+        for (int j = tid; j < span; j += LOCI) s_calls[j] = gcalls[j] & CALL_MASK;
+
+        // which locus of the sub-batch this thread takes: its own, or (FLAG_SORT) the tid-th in order of depth -- a counting sort over
+        // min(depth, 255) with the key array as scratch; the order inside a bin is whatever the atomics give, which changes nothing:
+        // every locus is computed by exactly one thread, from its own calls
+        int t = s + tid;
+        if (FLAGS & G3_FLAG_SORT) {
+            int* hist = reinterpret_cast<int*>(s_keys);
+            uint16_t* order = s_keys + 512;
+            for (int j = tid; j < 256; j += LOCI) hist[j] = 0;
+            __syncthreads();
+            int bin = 0;
+            if (t < e) {
+                bin = min(s_off[t + 1] - s_off[t], 255);
+                atomicAdd(&hist[bin], 1);
+            }
+            __syncthreads();
+            if (tid < 64) { // exclusive prefix sums of the 256 bins: four per lane, then across the wave
+                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const int mine = h0 + h1 + h2 + h3;
+                int incl = mine;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int up = __shfl_up(incl, d, 64);
+                    if (tid >= d) incl += up;
+                }
+                const int excl = incl - mine;
+                hist[4 * tid] = excl;
+                hist[4 * tid + 1] = excl + h0;
+                hist[4 * tid + 2] = excl + h0 + h1;
+                hist[4 * tid + 3] = excl + h0 + h1 + h2;
+            }
+            __syncthreads();
+            if (t < e) order[atomicAdd(&hist[bin], 1)] = uint16_t(t);
+            __syncthreads();
+            const int mine = (tid < cnt) ? int(order[tid]) : e;
+            __syncthreads(); // (the scratch becomes the key array again)
+            t = mine;
+        } else {
+            __syncthreads();
+        }
+
+        const bool active = (t < e);
+        int off = 0, n = 0;
+        float vfrac[8];
+        float* v0r = s_pool;
+        unsigned gbase = 0;
+        bool ok = false;
+        if (active) {
+            off = s_off[t] - c0;
+            n = s_off[t + 1] - s_off[t];
+            ok = (n <= MAX_PACKED_DEPTH);
+            if (ok)
+                ok = locus_rank_calls_v2<typename C::pend_t, C::QSHIFT>(s_calls + off, s_keys + off, n, a.d, s_q, s_tab, vfrac, s_pool, &s_pool_ctr, unsigned(C::POOL), s_pend,
+                                         &s_pend_ctr, unsigned(C::PEND), v0r, gbase);
+        }
+        __syncthreads();
+        {
+            // the pending terms, one per lane: val[0] = logf(de) + ln(1/3) with de from (e_q, exponent) -- position_snp_call_pprob_digt.cpp:352,
+            // adjust_joint_eprob.cpp:58-69
+            const unsigned np = min(s_pend_ctr, unsigned(C::PEND));
+            for (unsigned i = unsigned(tid); i < np; i += unsigned(LOCI)) {
+                const unsigned ent = s_pend[i];
+                const unsigned slot = ent & ((1u << C::QSHIFT) - 1u), q = ent >> C::QSHIFT;
+                const float de = get_dependent_eprob(s_q.eprob[q], s_pool[slot], a.d.exact_libm);
+                s_pool[slot] = __fadd_rn(logf_ref(de, a.d.exact_libm), T->g_log_one_third);
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const int l = l0 + t;
+            if (ok) {
+                const unsigned ref = a.b.ref_base[l];
+                const int ploidy = a.b.ploidy ? int(a.b.ploidy[l]) : 2;
+                sk_digt_call res;
+                locus_call_lds(s_calls + off, n, ref, ploidy, v0r, gbase, T, a.d, s_q, lt, res);
+                a.out[l] = res;
+                if (a.want_de) {
+                    float* __restrict__ de = a.de_tmp + block_c0 + s_off[t];
+                    for (int i = 0; i < n; ++i) de[i] = call_de(s_calls[off + i], vfrac, s_q, a.d);
+                }
+            } else {
+                a.out[l].is_called = NEEDS_GLOBAL_PASS;
+                a.worklist[atomicAdd(a.work_count, 1u)] = unsigned(l);
+            }
+        }
+        s = e;
+        __syncthreads();
+    }
+}
+
 // second pass: the few loci the LDS kernel declined (deeper than 1022 calls / the LDS budget, or needing more ranked
 // calls / sort stack than the fast path holds) through the global-memory routines -- same arithmetic
 __global__ void germline_site_global_pass_kernel(const FusedArgs a)
@@ -524,7 +857,15 @@ __global__ void germline_site_global_pass_kernel(const FusedArgs a)
 int sk_upload_pileup_internal(const sk_pileup_batch* hb, bool need_de, SkArena& ar, size_t extra_bytes,
                               sk_pileup_batch& d, hipStream_t st, int64_t& total_calls);
 
+static int g_g3_variant_override = -1;
+
 extern "C" {
+
+int sk_debug_set_g3_variant(int variant)
+{
+    g_g3_variant_override = variant;
+    return 0;
+}
 
 int sk_site_digt_call_fused_dev(const sk_pileup_batch* b, const sk_germline_options* opt, sk_digt_call* dev_out,
                                 float* dev_de_tmp, int want_de, void* dev_scratch, int64_t n_calls, void* hip_stream)
@@ -543,10 +884,20 @@ int sk_site_digt_call_fused_dev(const sk_pileup_batch* b, const sk_germline_opti
     a.worklist = a.work_count + 4;
     a.want_de = want_de ? 1 : 0;
     derive(*opt, a.d);
-    const int blocks = (b->n_loci + LOCI_PER_BLOCK - 1) / LOCI_PER_BLOCK;
     SK_HIP(hipMemsetAsync(a.work_count, 0, sizeof(uint32_t), static_cast<hipStream_t>(hip_stream)));
-    hipLaunchKernelGGL(germline_site_fused_kernel, dim3(blocks), dim3(FUSED_THREADS), 0,
-                       static_cast<hipStream_t>(hip_stream), a);
+    // $SK_G3_VARIANT (experiments / A-B runs): 0 = round 1's kernel; 1 = v2 (tabled + pending terms), 128 loci per block;
+    // 2 = v2 with the depth sort; 3 / 4 = the same two with 256 loci per block.  Same records from all of them.
+    static const int env_variant = []() { const char* v = std::getenv("SK_G3_VARIANT"); return (v && *v) ? std::atoi(v) : G3_DEFAULT_VARIANT; }();
+    const int variant = (g_g3_variant_override >= 0) ? g_g3_variant_override : env_variant;
+    const hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int n = b->n_loci;
+    switch (variant) {
+    case 0: hipLaunchKernelGGL(germline_site_fused_kernel, dim3((n + LOCI_PER_BLOCK - 1) / LOCI_PER_BLOCK), dim3(FUSED_THREADS), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((germline_site_fused_v2_kernel<128, G3_FLAG_SORT>), dim3((n + 127) / 128), dim3(128), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((germline_site_fused_v2_kernel<256, 0>), dim3((n + 255) / 256), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((germline_site_fused_v2_kernel<256, G3_FLAG_SORT>), dim3((n + 255) / 256), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((germline_site_fused_v2_kernel<128, 0>), dim3((n + 127) / 128), dim3(128), 0, st, a); break;
+    }
     hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3(std::min(2048, (b->n_loci + 63) / 64)), dim3(64), 0,
                        static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());

@@ -437,8 +437,15 @@ __device__ int matching_indel(const PJob& j, const PCal& c, const int32_t ref_he
 // one candidate alignment -> ops (the walk of scoreCandidateAlignment :286-493 as host/align_flatten.cpp states it); returns the
 // op count, -1 = leave this read to the host (it throws the reference's error, or handles what this form does not hold).
 // WRITE = false only counts.
-template <bool WRITE>
-__device__ int flatten_cal(const FlatArgs& a, const int r, const PCal& c, const int32_t read_len, sk_score_op* ops)
+struct NoOpSink
+{
+    __device__ __forceinline__ void operator()(uint8_t, uint32_t, int32_t, bool) const {}
+};
+
+// SINK: called for every op in path order (kind, length, source offset, non-candidate penalty) -- the fused flatten + score kernel
+// (F5) scores the op on the spot instead of storing it
+template <bool WRITE, typename SINK = NoOpSink>
+__device__ int flatten_cal(const FlatArgs& a, const int r, const PCal& c, const int32_t read_len, sk_score_op* ops, SINK&& sink = SINK())
 {
     const int aps = c.n_seg;
     const int32_t win_begin = a.win_begin[r];
@@ -460,6 +467,7 @@ __device__ int flatten_cal(const FlatArgs& a, const int r, const PCal& c, const 
     int n = 0;
     auto emit = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
         if (kind == SK_OP_NOBASE && !penalty) return;
+        sink(kind, len, src, penalty);
         if (WRITE) {
             sk_score_op op;
             op.length = uint16_t(len);
@@ -629,6 +637,154 @@ __global__ __launch_bounds__(64) void flatten_kernel(const FlatArgs a)
     for (int i = 0; i < cal.n_indels; ++i) (void)job_cand(a.job, cal.indels[i]);
     if (cal.lead >= 0) (void)job_cand(a.job, cal.lead);
     if (cal.trail >= 0) (void)job_cand(a.job, cal.trail);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// F5, one wave per read: flattening AND scoring in one kernel -- scoreCandidateAlignment (starling_read_align_score.cpp:261-499) as the
+// reference has it, one function from the alignment to its double.  F1-F3 + A1c stage the same work through HBM (the pool's bytes, 8-byte
+// ops, transition entries, masks, column words: 6.8 x the algorithmic bytes, profiles/r03_v24_pmc_traffic.json) and wait on dependent
+// global loads lane by lane (a wave of entries_wave_kernel took ~200 us per read); here the read (codes, the two terms of every position),
+// its haplotype pool and the wave's 64 candidate-alignment records sit in LDS, every lane walks its alignment's path with flatten_cal and
+// adds each op's terms as they come -- bases in read order, then the op's penalty, a soft clip's length x ln 0.25: the order of
+// score_one_generic (score_alignments.hip), which A1 / A1c reproduce.  Nothing but the scores (and, while stage 3 reads them there, the
+// records' copy in set order) goes back to HBM.
+// A read this form does not hold (longer than F5_MAX_READ bases, pool over F5_MAX_POOL bytes) is counted in *n_unhandled: the caller
+// then runs F1-F3 + A1c over the job.
+constexpr int F5_MAX_READ = 256;  // (as F3's wave form; longer reads and larger pools take the staged chain)
+constexpr int F5_MAX_POOL = 1024;
+
+struct FusedScoreArgs
+{
+    FlatArgs f;
+    const uint8_t* read_qual;
+    const SkTables* tab;
+    double* scores;
+    unsigned* err;         // SkContext::dev_error_flags (a quality above 70)
+    int32_t* n_unhandled;  // reads left to the staged kernels
+    int32_t write_cals;    // the records' copy in set order (stage 3 and sk_enum_device_fetch_cals read it)
+};
+
+struct F5Lds
+{
+    double agree[F5_MAX_READ], differ[F5_MAX_READ]; // ln(1-e_q), ln(e_q/3) of the read's positions
+    uint8_t read[F5_MAX_READ];
+    uint8_t hap[F5_MAX_POOL];
+    uint32_t cal[64 * ((sizeof(PCal) / 4) | 1)];    // the wave's records, rows of dwords (stride odd: conflict-free)
+};
+
+__global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs fa)
+{
+    constexpr int REC_DW = int(sizeof(PCal) / 4), REC_STRIDE = REC_DW | 1;
+    __shared__ F5Lds S;
+    const FlatArgs& a = fa.f;
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int c0 = a.cal_off[r], c1 = a.cal_off[r + 1];
+    const int ncr = c1 - c0;
+    if (ncr == 0 || a.status[r] != ST_OK) return;
+    const int64_t ro = a.read_off[r];
+    const int32_t L = int32_t(a.read_off[r + 1] - ro);
+    const int32_t P = a.hap_len[r];
+    if (L > F5_MAX_READ || P > F5_MAX_POOL) {
+        if (lane == 0) atomicAdd(fa.n_unhandled, 1);
+        return;
+    }
+    // ---- the pool's bytes (as pool_fill_kernel) and the read
+    {
+        const int32_t wb = a.win_begin[r];
+        const int n_ins = a.n_ins[r];
+        const int16_t* idx = a.ins_idx + size_t(r) * INS_CAP;
+        const int32_t* off = a.ins_off + size_t(r) * INS_CAP;
+        const int32_t win_len = a.win_len[r];
+        for (int32_t i = lane; i < P; i += 64) {
+            uint8_t v = SK_BAM_ANY;
+            if (i < win_len) {
+                const int32_t p = wb + i; // reference_contig_segment::get_base :46-51
+                v = (p < a.ref_offset || p >= a.ref_offset + a.ref_len) ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
+            }
+            for (int k = 0; k < n_ins; ++k) {
+                const PIndel& d = a.job.tab[idx[k]];
+                if (i >= off[k] && i < off[k] + int32_t(d.ins_len)) v = code_of(a.ins_pool[d.ins_off + uint32_t(i - off[k])]);
+            }
+            S.hap[i] = v;
+        }
+        const SkTables* __restrict__ T = fa.tab;
+        for (int32_t i = lane; i < L; i += 64) {
+            S.read[i] = a.read_code[ro + i];
+            unsigned q = fa.read_qual[ro + i];
+            if (q > 70u) { // the reference throws (qscore_cache.cpp:53-75): flagged, sk_check_device_errors reports it
+                atomicOr(fa.err, unsigned(SK_DEVERR_QSCORE));
+                q = 70u;
+            }
+            S.agree[i] = T->q2lncompe[q];
+            S.differ[i] = T->q2mis[q];
+        }
+    }
+    const double ln_quarter = fa.tab->ln_quarter, ln_noncand = fa.tab->ln_noncand;
+
+    for (int j0 = 0; j0 < ncr; j0 += 64) {
+        const int nc = min(64, ncr - j0);
+        __syncthreads(); // (pool and read complete; the previous round's records read)
+        // ---- the round's records: pool -> LDS (-> cals) as rows of consecutive dwords, eight records' loads in flight at a time
+        const int src_k = (lane < nc) ? a.list[c0 + j0 + lane] : 0;
+        for (int k0 = 0; k0 < nc; k0 += 8) {
+            uint32_t v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(a.pool + __shfl(src_k, (k < nc) ? k : 0));
+                v0[u] = (k < nc) ? src[lane] : 0u;
+                v1[u] = (k < nc && lane + 64 < REC_DW) ? src[lane + 64] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                if (k < nc) {
+                    S.cal[k * REC_STRIDE + lane] = v0[u];
+                    if (lane + 64 < REC_DW) S.cal[k * REC_STRIDE + lane + 64] = v1[u];
+                    if (fa.write_cals) {
+                        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.cals + (c0 + j0 + k));
+                        dst[lane] = v0[u];
+                        if (lane + 64 < REC_DW) dst[lane + 64] = v1[u];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (lane < nc) {
+            const int c = c0 + j0 + lane;
+            const PCal& cal = *reinterpret_cast<const PCal*>(S.cal + lane * REC_STRIDE);
+            double lnp = 0.0;
+            int rp = 0;
+            bool bad = false;
+            auto score_op = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
+                if (kind == SK_OP_BASES) {
+                    if (rp + int(len) > L || src < 0 || int64_t(src) + int64_t(len) > int64_t(P)) {
+                        bad = true; // (a path longer than the read, a source outside the pool: the host states what the reference does)
+                    } else {
+                        for (int j = 0; j < int(len); ++j) {
+                            const unsigned rc = S.read[rp + j];
+                            if (rc == SK_BAM_ANY) continue;
+                            const bool is_ref = (rc == SK_BAM_REF) || (rc == S.hap[src + j]);
+                            lnp = __dadd_rn(lnp, is_ref ? S.agree[rp + j] : S.differ[rp + j]);
+                        }
+                    }
+                    rp += int(len);
+                } else if (kind == SK_OP_SOFT_CLIP) {
+                    lnp = __dadd_rn(lnp, __dmul_rn(double(unsigned(len)), ln_quarter));
+                    rp += int(len);
+                }
+                if (penalty) lnp = __dadd_rn(lnp, ln_noncand);
+            };
+            const int n = flatten_cal<false>(a, r, cal, L, nullptr, score_op);
+            if (n < 0 || bad) a.status[r] = ST_FAIL;
+            else fa.scores[c] = lnp;
+            // the candidate-status lookups the host form performs for every indel of the alignment (cal_to_c)
+            for (int i = 0; i < cal.n_indels; ++i) (void)job_cand(a.job, cal.indels[i]);
+            if (cal.lead >= 0) (void)job_cand(a.job, cal.lead);
+            if (cal.trail >= 0) (void)job_cand(a.job, cal.trail);
+        }
+    }
 }
 
 // F3: ops -> transition entries + the read's event mask (host form: align_prepare in host/align_flatten.cpp; layout
@@ -1149,6 +1305,8 @@ int32_t g_n_cals = 0;
 struct LastFlat
 {
     bool valid = false;
+    bool fused = false; // the last run scored with F5 (fs), else with the staged chain (fa, d)
+    FusedScoreArgs fs;
     FlatArgs fa;
     sk_align_batch d;
     int32_t n = 0, n_cals = 0;
@@ -1475,198 +1633,242 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     if (n_cals > 0) hipLaunchKernelGGL(pool_bounds_kernel, dim3((n_cals + 255) / 256), dim3(256), 0, st, fa);
     hipLaunchKernelGGL(pool_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
     SK_HIP(hipGetLastError());
-    if (n_cals > 0) {
-        hipLaunchKernelGGL(op_count_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
-        SK_HIP(hipGetLastError());
-    }
-    if (fetch_zero(B.status, B.hap_len, 4 * size_t(n))) return 1; // status, hap_len (the host has made bytes of its copy of warn)
-    D2H(h_n_ops, n_ops, 4 * size_t(n_cals));
-    SK_HIP(hipStreamSynchronize(st));
-    lap("L1+L2 layout");
-
-    const int32_t* h_hap_len = B.h_hap_len.as<int32_t>();
-    const int32_t* h_n_ops = B.h_n_ops.as<int32_t>();
-    int64_t* h_hap_off = B.h_hap_off.as<int64_t>();
-    int64_t* h_op_off = B.h_op_off.as<int64_t>();
-    h_hap_off[0] = 0;
-    h_op_off[0] = 0;
-    int32_t max_hap = 1;
-    for (int r = 0; r < n; ++r) {
-        const int32_t c0 = h_cal_off[r], c1 = h_cal_off[r + 1];
-        h_hap_off[r + 1] = h_hap_off[r] + ((c1 > c0) ? h_hap_len[r] : 0);
-        if (c1 > c0) max_hap = std::max(max_hap, h_hap_len[r]);
-        const bool ok = (h_status[r] == ST_OK); // (a read turned down by L1/L2 keeps its slots in the batch, with no ops)
-        for (int32_t c = c0; c < c1; ++c) h_op_off[c + 1] = h_op_off[c] + (ok ? h_n_ops[c] : 0);
-    }
-    const int64_t n_hap = h_hap_off[n], ops_total = h_op_off[n_cals];
-
+    // ---- flattening + scoring.  The default is F5 (flatten_score_kernel): one launch from the records to the scores, no layout pass
+    // and no host wait before stage 3.  F1-F3 + A1c (the staged chain: ops, entries, column words through HBM) run when the job
+    // holds a read F5 turns down, when the host wants the alignments without scores, and with $SK_A5_FUSED=0 (tests: both chains).
+    const bool fused_enabled = !(std::getenv("SK_A5_FUSED") != nullptr && std::strcmp(std::getenv("SK_A5_FUSED"), "0") == 0);
+    const bool try_fused = fused_enabled && in->want_scores && n_cals > 0;
     RES(cals, sizeof(PCal) * size_t(n_cals));
-    RES(hap_code, size_t(n_hap) + 16);
-    RES(ops, sizeof(sk_score_op) * size_t(ops_total));
-    RES(entries, 4 * (size_t(ops_total) + 2 * size_t(n_cals) + 1));
     RES(scores, 8 * size_t(n_cals));
-    HRES(h_colmat_off, 8 * size_t(n + 1));
-    int64_t* h_colmat_off = B.h_colmat_off.as<int64_t>();
-    h_colmat_off[0] = 0;
-    for (int r = 0; r < n; ++r)
-        h_colmat_off[r + 1] = h_colmat_off[r] + ((in->read_off[r + 1] - in->read_off[r] + 7) / 8) * int64_t(h_cal_off[r + 1] - h_cal_off[r]);
-    const int64_t colmat_words = h_colmat_off[n];
-    RES(colmat, 4 * size_t(colmat_words) + 16);
-    RES(colmat_off, 8 * size_t(n + 1));
     if (!(in->want_scores && in->want_stage3)) HRES(h_cals, sizeof(PCal) * size_t(n_cals));
     HRES(h_scores, 8 * size_t(n_cals));
     out->cals = B.h_cals.as<PCal>();
     g_n_cals = n_cals;
+    fa.cals = B.cals.as<PCal>();
+    fa.max_read_len = in->max_read_len;
 
-    if (n_cals > 0) {
-        SK_HIP(hipMemcpyAsync(B.hap_off.p, h_hap_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
-        SK_HIP(hipMemcpyAsync(B.op_off.p, h_op_off, 8 * size_t(n_cals + 1), hipMemcpyHostToDevice, st));
-        SK_HIP(hipMemsetAsync(B.mask_arena.p, 0, mask_bytes, st)); // evmask, addmask
-        SK_HIP(hipMemsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), 4 * size_t(colmat_words) + 16, st));
-        SK_HIP(hipMemcpyAsync(B.colmat_off.p, h_colmat_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
-        fa.hap_off = B.hap_off.as<int64_t>();
-        fa.op_off = B.op_off.as<int64_t>();
-        fa.cals = B.cals.as<PCal>();
-        fa.hap_code = B.hap_code.as<uint8_t>();
-        fa.ops = B.ops.as<sk_score_op>();
-        fa.entries = B.entries.as<uint32_t>();
-        fa.evmask = B.evmask.as<uint32_t>();
-        fa.evmask_words = W;
-        fa.max_read_len = in->max_read_len;
-        fa.colmat = B.colmat.as<uint8_t>();
-        fa.colmat_off = B.colmat_off.as<int64_t>();
-        fa.addmask = B.addmask.as<uint32_t>();
-        hipLaunchKernelGGL(pool_fill_kernel, dim3(n), dim3(64), 0, st, fa);
-        hipLaunchKernelGGL(flatten_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
-        SK_HIP(hipGetLastError());
-        if (in->want_scores && in->want_stage3) out->cals = nullptr; // (they stay here: sk_enum_device_fetch_cals)
-        else D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
-        if (in->want_scores) {
-            // F3: a wave per read ($SK_F3_KERNEL = thread pins the thread-per-alignment form; the tests run both)
-            const bool f3_thread = (std::getenv("SK_F3_KERNEL") != nullptr && std::strcmp(std::getenv("SK_F3_KERNEL"), "thread") == 0);
-            if (f3_thread) hipLaunchKernelGGL(entries_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
-            else hipLaunchKernelGGL(entries_wave_kernel, dim3(n), dim3(64), 0, st, fa);
+    // what follows the scores in either chain: bookkeeping for sk_enum_device_rescore, the scores' way back, stage 3
+    auto after_scores = [&]() -> int {
+        D2H(h_scores, scores, 8 * size_t(n_cals));
+        out->scores = B.h_scores.as<double>();
+        if (in->want_stage3) {
+            RES(s3_order, 4 * size_t(n_cals));
+            RES(s3_smooth, 8 * size_t(n_cals));
+            RES(s3_flag, size_t(n_cals));
+            RES(s3_rm_type, size_t(n_bases));
+            RES(s3_rm_pos, 4 * size_t(n_bases));
+            RES(s3_key, 16 * size_t(n_cals));
+            RES(s3_sorted_score, 8 * size_t(n_cals));
+            RES(s3_sorted_hash, 4 * size_t(n_cals));
+            RES(s3_next_same, 4 * size_t(n_cals));
+            RES(s3_removed, size_t(n_cals));
+            RES(s3_range_end, 4 * size_t(n_cals));
+            RES(s3_out, sizeof(sk3::Out) * size_t(n));
+            HRES(h_s3_out, sizeof(sk3::Out) * size_t(n));
+            Stage3Args s3;
+            s3.tab.tab = dj.tab;
+            s3.tab.r2i = B.r2i.as<double>();
+            s3.tab.i2r = B.i2r.as<double>();
+            s3.tab.orig = B.orig.as<int32_t>();
+            s3.tab.n_tab = in->n_tab;
+            s3.tab.max_indel_size = in->max_indel_size;
+            s3.tab.consulted = dj.consulted;
+            s3.opt = in->stage3_opt;
+            s3.n_reads = n;
+            s3.status = ea.status;
+            s3.cal_off = fa.cal_off;
+            s3.cals = fa.cals;
+            s3.scores = B.scores.as<double>();
+            s3.read_off = fa.read_off;
+            s3.read_code = fa.read_code;
+            s3.map_level = B.map_level.as<int32_t>();
+            s3.order = B.s3_order.as<int32_t>();
+            s3.smooth = B.s3_smooth.as<double>();
+            s3.flag = B.s3_flag.as<uint8_t>();
+            s3.rm_type = B.s3_rm_type.as<uint8_t>();
+            s3.rm_pos = B.s3_rm_pos.as<int32_t>();
+            s3.key = B.s3_key.as<uint32_t>();
+            s3.sorted_score = B.s3_sorted_score.as<double>();
+            s3.sorted_hash = B.s3_sorted_hash.as<uint32_t>();
+            s3.next_same = B.s3_next_same.as<int32_t>();
+            s3.removed = B.s3_removed.as<uint8_t>();
+            s3.range_end = B.s3_range_end.as<int32_t>();
+            s3.out = B.s3_out.as<sk3::Out>();
+            // two launches: reads with few candidate alignments (small LDS, many wavefronts per CU) and the others
+            RES(s3_list, 4 * size_t(n));
+            HRES(h_s3_list, 4 * size_t(n));
+            int32_t* h_list = B.h_s3_list.as<int32_t>();
+            int light_cals = S3_LIGHT_CALS, lds_cals = S3_LDS_CALS;
+            if (const char* e = std::getenv("SK_STAGE3_TEST_LDS_CALS")) { // tests: small capacities, so that the second launch and the HBM arrays run
+                int a = 0, b = 0;
+                if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b >= a && b <= S3_LDS_CALS) {
+                    light_cals = a;
+                    lds_cals = b;
+                }
+            }
+            int n_light = 0, n_heavy = 0, max_cals = 0;
+            for (int r = 0; r < n; ++r) {
+                const int k = h_cal_off[r + 1] - h_cal_off[r];
+                if (k <= light_cals) h_list[n_light++] = r;
+                else {
+                    h_list[n - 1 - n_heavy++] = r;
+                    max_cals = std::max(max_cals, k);
+                }
+            }
+            H2D(s3_list, h_list, 4 * size_t(n));
+            auto lds_bytes = [](const int cals) { return size_t(cals) * (8 + 8 + 4 + 4 + 4 + 4 + 1 + 1) + 8; };
+            if (n_light > 0) {
+                s3.list = B.s3_list.as<int32_t>();
+                s3.lds_cals = light_cals;
+                hipLaunchKernelGGL(stage3_kernel<1>, dim3(n_light), dim3(64), lds_bytes(light_cals), st, s3);
+            }
+            if (n_heavy > 0) {
+                s3.list = B.s3_list.as<int32_t>() + (n - n_heavy);
+                s3.lds_cals = std::min(max_cals, lds_cals); // (a read with more uses the arrays in HBM)
+                // four wavefronts per read: the loops over the read's alignments go four times as wide, lane 0's share stays
+                static const bool one_wave = std::getenv("SK_STAGE3_ONE_WAVE") != nullptr; // (diagnostics)
+                if (one_wave) hipLaunchKernelGGL(stage3_kernel<1>, dim3(n_heavy), dim3(64), lds_bytes(s3.lds_cals), st, s3);
+                else hipLaunchKernelGGL(stage3_kernel<4>, dim3(n_heavy), dim3(256), lds_bytes(s3.lds_cals), st, s3);
+            }
+            if (timing) std::fprintf(stderr, "[enum-dev] stage 3: %d reads with at most %d candidate alignments, %d with more (up to %d)\n", n_light, light_cals, n_heavy, max_cals);
             SK_HIP(hipGetLastError());
-            lap("F1-F3 flatten");
-            sk_align_batch d;
-            std::memset(&d, 0, sizeof(d));
-            d.n_reads = n;
-            d.n_cals = n_cals;
-            d.n_ops = ops_total;
-            d.read_off = B.read_off.as<int64_t>();
-            d.read_code = B.read_code.as<uint8_t>();
-            d.read_qual = B.read_qual.as<uint8_t>();
-            d.hap_off = fa.hap_off;
-            d.hap_code = fa.hap_code;
-            d.cal_off = fa.cal_off;
-            d.op_off = fa.op_off;
-            d.ops = fa.ops;
-            d.max_read_len = in->max_read_len;
-            d.max_hap_len = max_hap;
-            d.entries = fa.entries;
-            d.evmask = fa.evmask;
-            d.evmask_words = W;
-            d.colmat = B.colmat.as<uint32_t>();
-            d.colmat_off = fa.colmat_off;
-            d.addmask = fa.addmask;
-            if (sk_score_alignments_launch_hostleg(&d, B.scores.as<double>(), st)) return 1;
-            lap("A1 score");
-            g_last.fa = fa;
-            g_last.d = d;
-            g_last.n = n;
-            g_last.n_cals = n_cals;
-            g_last.mask_bytes = mask_bytes;
-            g_last.colmat_bytes = 4 * size_t(colmat_words) + 16;
-            g_last.scores = B.scores.as<double>();
-            g_last.cells = 0;
-            for (int r = 0; r < n; ++r) g_last.cells += (in->read_off[r + 1] - in->read_off[r]) * int64_t(h_cal_off[r + 1] - h_cal_off[r]);
-            g_last.valid = true;
-            D2H(h_scores, scores, 8 * size_t(n_cals));
-            out->scores = B.h_scores.as<double>();
-            if (in->want_stage3) {
-                RES(s3_order, 4 * size_t(n_cals));
-                RES(s3_smooth, 8 * size_t(n_cals));
-                RES(s3_flag, size_t(n_cals));
-                RES(s3_rm_type, size_t(n_bases));
-                RES(s3_rm_pos, 4 * size_t(n_bases));
-                RES(s3_key, 16 * size_t(n_cals));
-                RES(s3_sorted_score, 8 * size_t(n_cals));
-                RES(s3_sorted_hash, 4 * size_t(n_cals));
-                RES(s3_next_same, 4 * size_t(n_cals));
-                RES(s3_removed, size_t(n_cals));
-                RES(s3_range_end, 4 * size_t(n_cals));
-                RES(s3_out, sizeof(sk3::Out) * size_t(n));
-                HRES(h_s3_out, sizeof(sk3::Out) * size_t(n));
-                Stage3Args s3;
-                s3.tab.tab = dj.tab;
-                s3.tab.r2i = B.r2i.as<double>();
-                s3.tab.i2r = B.i2r.as<double>();
-                s3.tab.orig = B.orig.as<int32_t>();
-                s3.tab.n_tab = in->n_tab;
-                s3.tab.max_indel_size = in->max_indel_size;
-                s3.tab.consulted = dj.consulted;
-                s3.opt = in->stage3_opt;
-                s3.n_reads = n;
-                s3.status = ea.status;
-                s3.cal_off = fa.cal_off;
-                s3.cals = fa.cals;
-                s3.scores = B.scores.as<double>();
-                s3.read_off = fa.read_off;
-                s3.read_code = fa.read_code;
-                s3.map_level = B.map_level.as<int32_t>();
-                s3.order = B.s3_order.as<int32_t>();
-                s3.smooth = B.s3_smooth.as<double>();
-                s3.flag = B.s3_flag.as<uint8_t>();
-                s3.rm_type = B.s3_rm_type.as<uint8_t>();
-                s3.rm_pos = B.s3_rm_pos.as<int32_t>();
-                s3.key = B.s3_key.as<uint32_t>();
-                s3.sorted_score = B.s3_sorted_score.as<double>();
-                s3.sorted_hash = B.s3_sorted_hash.as<uint32_t>();
-                s3.next_same = B.s3_next_same.as<int32_t>();
-                s3.removed = B.s3_removed.as<uint8_t>();
-                s3.range_end = B.s3_range_end.as<int32_t>();
-                s3.out = B.s3_out.as<sk3::Out>();
-                // two launches: reads with few candidate alignments (small LDS, many wavefronts per CU) and the others
-                RES(s3_list, 4 * size_t(n));
-                HRES(h_s3_list, 4 * size_t(n));
-                int32_t* h_list = B.h_s3_list.as<int32_t>();
-                int light_cals = S3_LIGHT_CALS, lds_cals = S3_LDS_CALS;
-                if (const char* e = std::getenv("SK_STAGE3_TEST_LDS_CALS")) { // tests: small capacities, so that the second launch and the HBM arrays run
-                    int a = 0, b = 0;
-                    if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b >= a && b <= S3_LDS_CALS) {
-                        light_cals = a;
-                        lds_cals = b;
-                    }
-                }
-                int n_light = 0, n_heavy = 0, max_cals = 0;
-                for (int r = 0; r < n; ++r) {
-                    const int k = h_cal_off[r + 1] - h_cal_off[r];
-                    if (k <= light_cals) h_list[n_light++] = r;
-                    else {
-                        h_list[n - 1 - n_heavy++] = r;
-                        max_cals = std::max(max_cals, k);
-                    }
-                }
-                H2D(s3_list, h_list, 4 * size_t(n));
-                auto lds_bytes = [](const int cals) { return size_t(cals) * (8 + 8 + 4 + 4 + 4 + 4 + 1 + 1) + 8; };
-                if (n_light > 0) {
-                    s3.list = B.s3_list.as<int32_t>();
-                    s3.lds_cals = light_cals;
-                    hipLaunchKernelGGL(stage3_kernel<1>, dim3(n_light), dim3(64), lds_bytes(light_cals), st, s3);
-                }
-                if (n_heavy > 0) {
-                    s3.list = B.s3_list.as<int32_t>() + (n - n_heavy);
-                    s3.lds_cals = std::min(max_cals, lds_cals); // (a read with more uses the arrays in HBM)
-                    // four wavefronts per read: the loops over the read's alignments go four times as wide, lane 0's share stays
-                    static const bool one_wave = std::getenv("SK_STAGE3_ONE_WAVE") != nullptr; // (diagnostics)
-                    if (one_wave) hipLaunchKernelGGL(stage3_kernel<1>, dim3(n_heavy), dim3(64), lds_bytes(s3.lds_cals), st, s3);
-                    else hipLaunchKernelGGL(stage3_kernel<4>, dim3(n_heavy), dim3(256), lds_bytes(s3.lds_cals), st, s3);
-                }
-                if (timing) std::fprintf(stderr, "[enum-dev] stage 3: %d reads with at most %d candidate alignments, %d with more (up to %d)\n", n_light, light_cals, n_heavy, max_cals);
+            D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
+            out->stage3 = B.h_s3_out.as<sk3::Out>();
+            lap("S3 stage 3");
+        }
+        return 0;
+    };
+
+    bool staged = !try_fused;
+    if (try_fused) {
+        FusedScoreArgs fs;
+        fs.f = fa;
+        fs.read_qual = B.read_qual.as<uint8_t>();
+        fs.tab = ctx.dev_tables;
+        fs.scores = B.scores.as<double>();
+        fs.err = ctx.dev_error_flags;
+        fs.n_unhandled = B.counters.as<int32_t>() + (Caps::K + 7);
+        fs.write_cals = 1;
+        hipLaunchKernelGGL(flatten_score_kernel, dim3(n), dim3(64), 0, st, fs);
+        SK_HIP(hipGetLastError());
+        lap("F5 flatten + score");
+        if (in->want_stage3) out->cals = nullptr; // (they stay here: sk_enum_device_fetch_cals)
+        else D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
+        g_last.fused = true;
+        g_last.fs = fs;
+        g_last.n = n;
+        g_last.n_cals = n_cals;
+        g_last.scores = B.scores.as<double>();
+        g_last.cells = 0;
+        for (int r = 0; r < n; ++r) g_last.cells += (in->read_off[r + 1] - in->read_off[r]) * int64_t(h_cal_off[r + 1] - h_cal_off[r]);
+        g_last.valid = true;
+        if (after_scores()) return 1;
+        if (fetch_zero(B.counters, B.counters, 4 * size_t(n_counters))) return 1; // (n_unhandled)
+        if (fetch_zero(B.status, B.status, 4 * size_t(n))) return 1;               // (F5 may have turned reads down: ST_FAIL)
+        SK_HIP(hipStreamSynchronize(st));
+        if (B.h_counters.as<int32_t>()[Caps::K + 7] > 0) staged = true; // a read outside F5's form: the staged chain over the job
+    }
+    if (staged) {
+        if (n_cals > 0) {
+            hipLaunchKernelGGL(op_count_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+            SK_HIP(hipGetLastError());
+        }
+        if (fetch_zero(B.status, B.hap_len, 4 * size_t(n))) return 1; // status, hap_len (the host has made bytes of its copy of warn)
+        D2H(h_n_ops, n_ops, 4 * size_t(n_cals));
+        SK_HIP(hipStreamSynchronize(st));
+        lap("L1+L2 layout");
+
+        const int32_t* h_hap_len = B.h_hap_len.as<int32_t>();
+        const int32_t* h_n_ops = B.h_n_ops.as<int32_t>();
+        int64_t* h_hap_off = B.h_hap_off.as<int64_t>();
+        int64_t* h_op_off = B.h_op_off.as<int64_t>();
+        h_hap_off[0] = 0;
+        h_op_off[0] = 0;
+        int32_t max_hap = 1;
+        for (int r = 0; r < n; ++r) {
+            const int32_t c0 = h_cal_off[r], c1 = h_cal_off[r + 1];
+            h_hap_off[r + 1] = h_hap_off[r] + ((c1 > c0) ? h_hap_len[r] : 0);
+            if (c1 > c0) max_hap = std::max(max_hap, h_hap_len[r]);
+            const bool ok = (h_status[r] == ST_OK); // (a read turned down by L1/L2 keeps its slots in the batch, with no ops)
+            for (int32_t c = c0; c < c1; ++c) h_op_off[c + 1] = h_op_off[c] + (ok ? h_n_ops[c] : 0);
+        }
+        const int64_t n_hap = h_hap_off[n], ops_total = h_op_off[n_cals];
+
+        RES(hap_code, size_t(n_hap) + 16);
+        RES(ops, sizeof(sk_score_op) * size_t(ops_total));
+        RES(entries, 4 * (size_t(ops_total) + 2 * size_t(n_cals) + 1));
+        HRES(h_colmat_off, 8 * size_t(n + 1));
+        int64_t* h_colmat_off = B.h_colmat_off.as<int64_t>();
+        h_colmat_off[0] = 0;
+        for (int r = 0; r < n; ++r)
+            h_colmat_off[r + 1] = h_colmat_off[r] + ((in->read_off[r + 1] - in->read_off[r] + 7) / 8) * int64_t(h_cal_off[r + 1] - h_cal_off[r]);
+        const int64_t colmat_words = h_colmat_off[n];
+        RES(colmat, 4 * size_t(colmat_words) + 16);
+        RES(colmat_off, 8 * size_t(n + 1));
+
+        if (n_cals > 0) {
+            SK_HIP(hipMemcpyAsync(B.hap_off.p, h_hap_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
+            SK_HIP(hipMemcpyAsync(B.op_off.p, h_op_off, 8 * size_t(n_cals + 1), hipMemcpyHostToDevice, st));
+            SK_HIP(hipMemsetAsync(B.mask_arena.p, 0, mask_bytes, st)); // evmask, addmask
+            SK_HIP(hipMemsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), 4 * size_t(colmat_words) + 16, st));
+            SK_HIP(hipMemcpyAsync(B.colmat_off.p, h_colmat_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
+            fa.hap_off = B.hap_off.as<int64_t>();
+            fa.op_off = B.op_off.as<int64_t>();
+            fa.hap_code = B.hap_code.as<uint8_t>();
+            fa.ops = B.ops.as<sk_score_op>();
+            fa.entries = B.entries.as<uint32_t>();
+            fa.evmask = B.evmask.as<uint32_t>();
+            fa.evmask_words = W;
+            fa.colmat = B.colmat.as<uint8_t>();
+            fa.colmat_off = B.colmat_off.as<int64_t>();
+            fa.addmask = B.addmask.as<uint32_t>();
+            hipLaunchKernelGGL(pool_fill_kernel, dim3(n), dim3(64), 0, st, fa);
+            hipLaunchKernelGGL(flatten_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+            SK_HIP(hipGetLastError());
+            if (in->want_scores && in->want_stage3) out->cals = nullptr; // (they stay here: sk_enum_device_fetch_cals)
+            else D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
+            if (in->want_scores) {
+                // F3: a wave per read ($SK_F3_KERNEL = thread pins the thread-per-alignment form; the tests run both)
+                const bool f3_thread = (std::getenv("SK_F3_KERNEL") != nullptr && std::strcmp(std::getenv("SK_F3_KERNEL"), "thread") == 0);
+                if (f3_thread) hipLaunchKernelGGL(entries_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+                else hipLaunchKernelGGL(entries_wave_kernel, dim3(n), dim3(64), 0, st, fa);
                 SK_HIP(hipGetLastError());
-                D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
-                out->stage3 = B.h_s3_out.as<sk3::Out>();
-                lap("S3 stage 3");
+                lap("F1-F3 flatten");
+                sk_align_batch d;
+                std::memset(&d, 0, sizeof(d));
+                d.n_reads = n;
+                d.n_cals = n_cals;
+                d.n_ops = ops_total;
+                d.read_off = B.read_off.as<int64_t>();
+                d.read_code = B.read_code.as<uint8_t>();
+                d.read_qual = B.read_qual.as<uint8_t>();
+                d.hap_off = fa.hap_off;
+                d.hap_code = fa.hap_code;
+                d.cal_off = fa.cal_off;
+                d.op_off = fa.op_off;
+                d.ops = fa.ops;
+                d.max_read_len = in->max_read_len;
+                d.max_hap_len = max_hap;
+                d.entries = fa.entries;
+                d.evmask = fa.evmask;
+                d.evmask_words = W;
+                d.colmat = B.colmat.as<uint32_t>();
+                d.colmat_off = fa.colmat_off;
+                d.addmask = fa.addmask;
+                if (sk_score_alignments_launch_hostleg(&d, B.scores.as<double>(), st)) return 1;
+                lap("A1 score");
+                g_last.fused = false;
+                g_last.fa = fa;
+                g_last.d = d;
+                g_last.n = n;
+                g_last.n_cals = n_cals;
+                g_last.mask_bytes = mask_bytes;
+                g_last.colmat_bytes = 4 * size_t(colmat_words) + 16;
+                g_last.scores = B.scores.as<double>();
+                g_last.cells = 0;
+                for (int r = 0; r < n; ++r) g_last.cells += (in->read_off[r + 1] - in->read_off[r]) * int64_t(h_cal_off[r + 1] - h_cal_off[r]);
+                g_last.valid = true;
+                if (after_scores()) return 1;
             }
         }
     }
@@ -1680,8 +1882,9 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     return 0;
 }
 
-// Measurement entry (bench.py's a5 leg): flattening AND scoring of the candidate alignments the last run left on the device -- pool
-// bytes, ops, transition entries, masks and column words rebuilt from the PCal records (F1-F3), then the scoring kernel over them --
+// Measurement entry (bench.py's a5 leg): flattening AND scoring of the candidate alignments the last run left on the device, the way
+// that run did it -- F5 (one launch from the records to the scores), or, for a job scored by the staged chain, pool bytes, ops,
+// transition entries, masks and column words rebuilt from the PCal records (F1-F3), then the scoring kernel over them --
 // `reps` times, timed with events on the library's stream.  This is what sk_enum_device_run does between the sets (E2) and stage 3,
 // minus the layout pass (L1/L2: per-read pool bounds and op counts, whose results -- offsets -- a steady state already has).
 extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t* out_n_reads, int32_t* out_n_cals, int64_t* out_cells)
@@ -1699,6 +1902,10 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
     SK_HIP(hipEventCreate(&e1));
     SK_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < reps; ++i) {
+        if (g_last.fused) { // F5: the records -> the scores in one launch
+            hipLaunchKernelGGL(flatten_score_kernel, dim3(g_last.n), dim3(64), 0, st, g_last.fs);
+            continue;
+        }
         SK_HIP(hipMemsetAsync(B.mask_arena.p, 0, g_last.mask_bytes, st));
         SK_HIP(hipMemsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), g_last.colmat_bytes, st));
         hipLaunchKernelGGL(pool_fill_kernel, dim3(g_last.n), dim3(64), 0, st, fa);

@@ -79,8 +79,12 @@ def test_host_core_reproduces_the_live_reference(seed, max_indels, hap):
 
 
 @pytest.mark.gpu
-def test_device_enumeration_reproduces_the_reference_golden(gold):
+@pytest.mark.parametrize("chain", ["fused", "staged"])
+def test_device_enumeration_reproduces_the_reference_golden(gold, monkeypatch, chain):
+    """chain: flattening + scoring as F5 (flatten_score_kernel: the records -> the scores in one launch, the default) or as the staged
+    chain F1-F3 + A1c ($SK_A5_FUSED=0; also what a job with a read outside F5's form takes)"""
     capi.init(0)
+    monkeypatch.setenv("SK_A5_FUSED", "1" if chain == "fused" else "0")
     reads, core, dev, fb = _run(gold["scenarios"], gold["expect"], mode=2, on_gpu=True)
     assert reads > 400 and dev > 200 and core == 0
     assert fb <= dev // 50
@@ -107,9 +111,10 @@ def test_device_stage3_without_the_conflict_tables(gold, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,max_indels,hap", [(41, 6, 0.25), (42, 12, 0.6), (43, 12, 0.0)])
-def test_device_enumeration_equals_host(seed, max_indels, hap):
+@pytest.mark.parametrize("seed,max_indels,hap,chain", [(41, 6, 0.25, "fused"), (42, 12, 0.6, "fused"), (43, 12, 0.0, "fused"), (42, 12, 0.6, "staged")])
+def test_device_enumeration_equals_host(seed, max_indels, hap, chain, monkeypatch):
     capi.init(0)
+    monkeypatch.setenv("SK_A5_FUSED", "1" if chain == "fused" else "0")
     rng = np.random.default_rng(91000 + seed)
     scs = synth.realign_scenarios(80, rng, reads_per=12, max_indels=max_indels, haplotyping_rate=hap)
     n_dev = n_s3 = 0
@@ -145,6 +150,7 @@ def test_device_flatten_kernels_on_long_reads(kernel, monkeypatch):
     wave's tile), reads past 256 bases (the wave form hands them to the serial walk); results equal to the host path's"""
     capi.init(0)
     monkeypatch.setenv("SK_F3_KERNEL", kernel)
+    monkeypatch.setenv("SK_A5_FUSED", "0")  # (F3 belongs to the staged chain)
     rng = np.random.default_rng(91333)
     scs = synth.realign_scenarios(40, rng, reads_per=10, max_indels=9, min_indels=4, read_len=(120, 261), window=(330, 520), haplotyping_rate=0.2)
     n_dev = n_cals = n_long = 0
@@ -167,6 +173,35 @@ def test_device_flatten_kernels_on_long_reads(kernel, monkeypatch):
                 n_cals += a["n_cals"]
                 n_long += len(rd["code"]) > 256
     assert n_dev > 150 and n_cals > 64 * n_dev // 4
+
+
+@pytest.mark.gpu
+def test_fused_flatten_score_on_long_reads_and_mixed_jobs():
+    """F5 on reads of 120-260 bases over 4-9 indels (more than 64 candidate alignments per read: several rounds of the wave); a job
+    holding a read past 256 bases takes the staged chain whole -- either way the host path's results"""
+    capi.init(0)
+    rng = np.random.default_rng(91444)
+    scs = synth.realign_scenarios(40, rng, reads_per=10, max_indels=9, min_indels=4, read_len=(120, 261), window=(330, 520), haplotyping_rate=0.2)
+    n_dev = n_cals = n_long_jobs = 0
+    for sc in scs:
+        res = {}
+        for mode in (0, 2):
+            job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
+                                                       min_read_bp_flank=sc["min_read_bp_flank"], enumeration=mode))
+            job.set_reference(sc["ref_seq"], sc["ref_offset"])
+            job.set_indels(sc["indels"])
+            idx = T._add_reads(job, sc)
+            job.run()
+            res[mode] = [None if i is None else job.result(i) for i in idx]
+            if mode == 2:
+                n_dev += job.enumeration_counts()[1]
+        n_long_jobs += any(len(rd["code"]) > 256 for rd in sc["reads"])
+        for a, b in zip(res[0], res[2]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert repr(a) == repr(b)
+                n_cals += a["n_cals"]
+    assert n_dev > 150 and n_cals > 64 * n_dev // 4 and 0 < n_long_jobs < len(scs)
 
 
 @pytest.mark.gpu

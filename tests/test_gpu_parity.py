@@ -241,6 +241,49 @@ def test_site_digt_call_fused_nondefault_options(gpu):
         assert np.array_equal(fused["lhood"].view(np.uint32), want["lhood"].view(np.uint32)), kw
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_site_digt_call_fused_every_kernel_variant(gpu, variant):
+    """csrc/germline_fused.hip holds round 1's kernel (0) and the second statement (tabled + pending ranked terms) with 128 / 256 loci
+    per block, without / with the depth sort (1..4): every one of them against the oracle, byte for byte -- ordinary 40x loci with and
+    without neighbouring mismatches, dense mismatch flags (every group pending: the list overflows into the global-memory pass), low
+    quality calls, deep loci, loci beyond the LDS path, haploid and N-reference loci, non-default options"""
+    from strelka_amd import capi
+    rng = np.random.default_rng(2090 + variant)
+    capi.lib().sk_debug_set_g3_variant(variant)
+    try:
+        parts = [synth.pileups(3000, rng, het_rate=0.05, hom_rate=0.02), synth.pileups(1500, rng, het_rate=0.1, nmm_rate=0.6),
+                 synth.pileups(700, rng, nmm_rate=0.0), _varied_pileups(rng), synth.pileups(30, rng, depth_mean=1500.0, het_rate=0.2),
+                 synth.pileups(300, rng, depth_mean=150.0, het_rate=0.1), synth.pileups(600, rng, depth_mean=3.0),
+                 synth.pileups(1, rng, depth_mean=9000.0), synth.pileups(513, rng, depth_mean=70.0, nmm_rate=0.1)]
+        off = [np.zeros(1, np.int64)]
+        calls, ref = [], []
+        base = 0
+        for p in parts:
+            off.append(p.call_off[1:] + base)
+            base += p.call_off[-1]
+            calls.append(p.calls)
+            ref.append(p.ref_base)
+        pb = gpu.HostPileupBatch(np.concatenate(off), np.concatenate(calls), np.concatenate(ref))
+        pb.ploidy = rng.choice(np.array([1, 2, 2], np.uint8), pb.n_loci)
+        pb.ref_base[::53] = 4
+        for kw in ({}, dict(bsnp_ssd_no_mismatch=0.05, bsnp_ssd_one_mismatch=0.1), dict(is_min_vexp=0), dict(min_vexp=0.6, bsnp_diploid_theta=0.01)):
+            opt = gpu.germline_options()
+            oopt = pyoracle.germline_options()
+            for k, v in kw.items():
+                setattr(opt, k, v)
+                setattr(oopt, k, v)
+            fused, de1 = gpu.site_digt_call_fused(pb, opt, want_de=True)
+            want_de = pyoracle.adjust_joint_eprob(pb, oopt)
+            assert np.array_equal(de1.view(np.uint32), want_de.view(np.uint32)), (variant, kw)
+            want = pyoracle.site_digt_call(pb, want_de, oopt)
+            assert np.array_equal(fused["lhood"].view(np.uint32), want["lhood"].view(np.uint32)), (variant, kw)
+            assert fused.tobytes() == want.tobytes(), (variant, kw)
+            again, none = gpu.site_digt_call_fused(pb, opt)
+            assert none is None and again.tobytes() == want.tobytes(), (variant, kw)
+    finally:
+        capi.lib().sk_debug_set_g3_variant(-1)
+
+
 def test_somatic_snv(gpu):
     rng = np.random.default_rng(204)
     n, t = synth.somatic_pileups(6000, rng, somatic_rate=0.03, het_rate=0.03)
