@@ -51,6 +51,15 @@ for step in "$@"; do
         tail -1 $OUT/pmc_g3_$i.log | head -c 300
       done
       python tools/diag/pmc_kernel_sums.py $OUT/pmc_g3_* > $OUT/pmc_g3.txt 2>&1; cat $OUT/pmc_g3.txt ;;
+    g3_variants)
+      for v in 0 1 2 3 4; do
+        SK_G3_VARIANT=$v timeout 300 python bench.py --only loci --steps 5 --warmup 2 > $OUT/loci_v$v.json 2>$OUT/loci_v$v.err; echo "variant $v: $(cat $OUT/loci_v$v.json | head -c 400)"
+      done ;;
+    a5_ab)
+      for f in 1 0; do
+        SK_A5_FUSED=$f timeout 300 python bench.py --only a5 --steps 20 --warmup 3 > $OUT/a5_fused$f.json 2>$OUT/a5_fused$f.err; echo "fused=$f: $(cat $OUT/a5_fused$f.json | head -c 600)"
+        SK_A5_FUSED=$f timeout 300 python bench.py --only a5 --a5-reads 65536 --steps 10 --warmup 2 > $OUT/a5_65536_fused$f.json 2>$OUT/a5_65536_fused$f.err; echo "fused=$f 2^16 reads: $(cat $OUT/a5_65536_fused$f.json | head -c 600)"
+      done ;;
     loci)
       timeout 300 python bench.py --only loci --steps 5 --warmup 2 > $OUT/loci.json 2>$OUT/loci.err; cat $OUT/loci.json ;;
     *) echo "unknown step $step" ;;
