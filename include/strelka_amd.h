@@ -940,7 +940,8 @@ int sk_bgzf_inflate(const uint8_t* data, const int64_t* block_off, const int64_t
 /** The same for a caller that reads a region slice by slice: out receives `prefix_len` bytes the caller already holds (the record
  *  the previous slice ended in) followed by the inflated blocks, and the DEVICE copy of exactly those bytes is kept until the next
  *  feed call of this library -- sk_bam_decode_kept decodes from it, so the inflated stream crosses the bus once (down), not three
- *  times (down, up, and the decoded fields down). */
+ *  times (down, up, and the decoded fields down).  n_blocks == 0 with a prefix (a slice that is only the carried record) is valid:
+ *  out and the kept stream are the prefix. */
 int sk_bgzf_inflate_prefixed(const uint8_t* data, const int64_t* block_off, const int64_t* out_off, int32_t n_blocks,
                              const uint8_t* prefix, int64_t prefix_len, uint8_t* out);
 /** block_off relative to dev_data; dev_status[n_blocks]: 0 = ok (else the block is malformed, see csrc/bam_feed.hip) */

@@ -1145,11 +1145,22 @@ int sk_bgzf_inflate_prefixed(const uint8_t* data, const int64_t* block_off, cons
     if (prefix_len < 0 || (prefix_len > 0 && !prefix)) return sk_fail("sk_bgzf_inflate: bad prefix");
     SK_REQUIRE_INIT();
     if (n_blocks < 0) return sk_fail("sk_bgzf_inflate: negative block count");
-    if (n_blocks == 0) return 0;
-    if (!data || !block_off || !out_off || !out) return sk_fail("sk_bgzf_inflate: null argument");
+    if (n_blocks == 0 && prefix_len == 0) return 0;
+    if ((n_blocks > 0 && (!data || !block_off || !out_off)) || !out) return sk_fail("sk_bgzf_inflate: null argument");
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
     hipStream_t st = ctx.stream;
+    if (n_blocks == 0) {
+        // a slice that is only the carried record: `out` and the kept stream are the prefix (the header's contract: out receives
+        // prefix_len bytes, then the inflated blocks, and sk_bam_decode_kept decodes from the kept stream)
+        FeedBuffers& B0 = feed_bufs();
+        if (B0.reserve(8, size_t(prefix_len) + 16)) return 1;
+        SK_HIP(hipMemcpyAsync(B0.p[8], prefix, size_t(prefix_len), hipMemcpyHostToDevice, st));
+        if (out != prefix) std::memcpy(out, prefix, size_t(prefix_len));
+        SK_HIP(hipStreamSynchronize(st));
+        B0.kept_len = prefix_len;
+        return 0;
+    }
     const int64_t in_bytes = block_off[n_blocks] - block_off[0], out_bytes = out_off[n_blocks];
     if (in_bytes < 0 || out_bytes < 0 || out_off[0] != 0) return sk_fail("sk_bgzf_inflate: bad offsets");
     FeedBuffers& B = feed_bufs();

@@ -419,6 +419,87 @@ __device__ void locus_call_lds(const uint16_t* calls, const int n, const unsigne
     }
 }
 
+// phase 2 for one locus in LDS, four calls read ahead (see locus_rank_calls_v2)
+__device__ void locus_call_lds_v2(const uint16_t* calls, const int n, const unsigned ref, const int ploidy,
+                               const float* v0r, const unsigned gbase, const SkTables* __restrict__ T,
+                               const GermlineDerived& D, const QTab& Q, const SkLibmTables& lt, sk_digt_call& res)
+{
+    memset(&res, 0, sizeof(res));
+    if (ref >= 4) return;
+    res.is_called = 1;
+    res.ref_gt = ref;
+    const bool is_haploid = (ploidy == 1);
+
+    float lh[10];
+#pragma unroll
+    for (int gt = 0; gt < 10; ++gt) lh[gt] = 0.f;
+    auto add_call = [&](const uint16_t bc, const float4 qv, const float v0) {
+        const unsigned obs = SKC_BASE(bc);
+        const float v1 = qv.z;
+        const float v2 = qv.w;
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) lh[gt] = __fadd_rn(lh[gt], (obs == unsigned(gt)) ? v2 : v0);
+#pragma unroll
+        for (int gt = 4; gt < 10; ++gt) lh[gt] = __fadd_rn(lh[gt], (obs == digt_a0(gt) || obs == digt_a1(gt)) ? v1 : v0);
+    };
+    {
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const uint16_t b0 = calls[i], b1 = calls[i + 1], b2 = calls[i + 2], b3 = calls[i + 3];
+            const float4 q0 = Q.v[SKC_Q(b0)], q1 = Q.v[SKC_Q(b1)], q2 = Q.v[SKC_Q(b2)], q3 = Q.v[SKC_Q(b3)];
+            const float t0 = call_v0(b0, q0, v0r, gbase, D), t1 = call_v0(b1, q1, v0r, gbase, D), t2 = call_v0(b2, q2, v0r, gbase, D),
+                        t3 = call_v0(b3, q3, v0r, gbase, D);
+            add_call(b0, q0, t0);
+            add_call(b1, q1, t1);
+            add_call(b2, q2, t2);
+            add_call(b3, q3, t3);
+        }
+        for (; i < n; ++i) {
+            const uint16_t bc = calls[i];
+            const float4 qv = Q.v[SKC_Q(bc)];
+            add_call(bc, qv, call_v0(bc, qv, v0r, gbase, D));
+        }
+    }
+#pragma unroll
+    for (int gt = 0; gt < 10; ++gt) res.lhood[gt] = lh[gt];
+    {
+        const int gtcount = is_haploid ? 4 : 10;
+        float best = lh[0]; // lhood[maxIndex]: first maximum, strict > as in the reference
+#pragma unroll
+        for (int gt = 1; gt < 10; ++gt)
+            if (gt < gtcount && lh[gt] > best) best = lh[gt];
+#pragma unroll
+        for (int gt = 0; gt < 10; ++gt)
+            res.phredLoghood[gt] = (gt < gtcount) ? unsigned(ln_error_prob_to_qphred_f(__fsub_rn(lh[gt], best), D.ln10f)) : 0u;
+    }
+    calculate_result_set(lh, D.lnprior[is_haploid ? 1 : 0][ref][0], ref, D.exact_libm, lt, res.genome);
+    calculate_result_set(lh, D.lnprior[is_haploid ? 1 : 0][ref][1], ref, D.exact_libm, lt, res.poly);
+
+    if (res.genome.snp_qphred != 0) {
+        const unsigned tgt = res.genome.max_gt;
+        const unsigned t0 = digt_a0(tgt), t1 = digt_a1(tgt);
+        float lf = 0.f, lr = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const uint16_t bc = calls[i];
+            const unsigned q = SKC_Q(bc), obs = SKC_BASE(bc);
+            const float4 qv = Q.v[q];
+            const float v0 = call_v0(bc, qv, v0r, gbase, D);
+            const float v1 = qv.z;
+            const float v2 = qv.w;
+            const float val_ref = (obs == ref) ? v2 : v0;
+            const float val_tgt = (tgt < 4) ? ((obs == tgt) ? v2 : v0) : ((obs == t0 || obs == t1) ? v1 : v0);
+            const bool fwd = SKC_FWD(bc);
+            lf = __fadd_rn(lf, fwd ? val_tgt : val_ref);
+            lr = __fadd_rn(lr, fwd ? val_ref : val_tgt);
+        }
+        const float m = (lf < lr) ? lr : lf;
+        float lht = lh[0];
+#pragma unroll
+        for (int gt = 1; gt < 10; ++gt) lht = (tgt == unsigned(gt)) ? lh[gt] : lht;
+        res.strand_bias = static_cast<double>(__fsub_rn(m, lht));
+    }
+}
+
 __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void germline_site_fused_kernel(const FusedArgs a)
 {
     __shared__ uint16_t s_calls[CAP_CALLS];
@@ -550,14 +631,27 @@ __device__ bool locus_rank_calls_v2(uint16_t* calls, uint16_t* keys, const int n
     for (int g = 0; g < 8; ++g) vfrac[g] = 0.f;
     if (!D.is_dependent_eprob) return true;
 
+    // (the per-call loops of this kernel are latency chains -- an LDS read, a table read that depends on it, an accumulator -- and a
+    // SIMD holds only two or three waves of it: four calls are read ahead of their use in every loop, so that a loop waits for LDS once
+    // per four calls instead of once or twice per call)
     uint64_t cntA = 0, cntB = 0; // groups 0-3 / 4-7
-    for (int i = 0; i < n; ++i) {
-        const uint16_t b = calls[i];
+    auto count_call = [&](const uint16_t b) {
         const bool valid = !(SKC_FILTER(b) || SKC_Q(b) < 3);
         const unsigned g = SKC_FWD(b) + 2 * SKC_BASE(b);
         const uint64_t inc = valid ? (uint64_t(1) << (16 * (g & 3))) : 0;
         cntA += (g < 4) ? inc : 0;
         cntB += (g >= 4) ? inc : 0;
+    };
+    {
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const uint16_t b0 = calls[i], b1 = calls[i + 1], b2 = calls[i + 2], b3 = calls[i + 3];
+            count_call(b0);
+            count_call(b1);
+            count_call(b2);
+            count_call(b3);
+        }
+        for (; i < n; ++i) count_call(calls[i]);
     }
     unsigned need = 0;
 #pragma unroll
@@ -575,8 +669,7 @@ __device__ bool locus_rank_calls_v2(uint16_t* calls, uint16_t* keys, const int n
     const uint64_t inclB = cntB + (cntB << 16) + (cntB << 32) + (cntB << 48);
     const uint64_t totalA = inclA >> 48;
     uint64_t posA = inclA << 16, posB = (inclB << 16) + totalA * 0x0001000100010001ull;
-    for (int i = 0; i < n; ++i) {
-        const uint16_t b = calls[i];
+    auto place_call = [&](const uint16_t b, const int i) {
         const bool valid = !(SKC_FILTER(b) || SKC_Q(b) < 3);
         const unsigned g = SKC_FWD(b) + 2 * SKC_BASE(b);
         const unsigned sh = 16 * (g & 3);
@@ -585,6 +678,17 @@ __device__ bool locus_rank_calls_v2(uint16_t* calls, uint16_t* keys, const int n
         const uint64_t inc = valid ? (uint64_t(1) << sh) : 0;
         posA += (g < 4) ? inc : 0;
         posB += (g >= 4) ? inc : 0;
+    };
+    {
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const uint16_t b0 = calls[i], b1 = calls[i + 1], b2 = calls[i + 2], b3 = calls[i + 3];
+            place_call(b0, i);
+            place_call(b1, i + 1);
+            place_call(b2, i + 2);
+            place_call(b3, i + 3);
+        }
+        for (; i < n; ++i) place_call(calls[i], i);
     }
 
     bool ok = true;
@@ -608,12 +712,25 @@ __device__ bool locus_rank_calls_v2(uint16_t* calls, uint16_t* keys, const int n
 
         float num = 0.f, den = 0.f; // adjust_icalls_eprob :110-127, pileup order
         unsigned any_nmm = 0;
-        for (int i = 0; i < gs; ++i) {
-            const unsigned k = gk[i];
-            const float weight = Q.weight[k >> 10];
+        auto weigh = [&](const unsigned k, const float weight) {
             den = __fadd_rn(den, weight);
             if (k & 0x200u) num = __fadd_rn(num, weight);
             any_nmm |= k & 0x200u;
+        };
+        {
+            int i = 0;
+            for (; i + 4 <= gs; i += 4) {
+                const unsigned k0 = gk[i], k1 = gk[i + 1], k2 = gk[i + 2], k3 = gk[i + 3];
+                const float w0 = Q.weight[k0 >> 10], w1 = Q.weight[k1 >> 10], w2 = Q.weight[k2 >> 10], w3 = Q.weight[k3 >> 10];
+                weigh(k0, w0);
+                weigh(k1, w1);
+                weigh(k2, w2);
+                weigh(k3, w3);
+            }
+            for (; i < gs; ++i) {
+                const unsigned k = gk[i];
+                weigh(k, Q.weight[k >> 10]);
+            }
         }
         float mismatch_frac = 0.f;
         if (den > 0.) mismatch_frac = __fdiv_rn(num, den);
@@ -824,7 +941,7 @@ __global__ __launch_bounds__(LOCI) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
                 const unsigned ref = a.b.ref_base[l];
                 const int ploidy = a.b.ploidy ? int(a.b.ploidy[l]) : 2;
                 sk_digt_call res;
-                locus_call_lds(s_calls + off, n, ref, ploidy, v0r, gbase, T, a.d, s_q, lt, res);
+                locus_call_lds_v2(s_calls + off, n, ref, ploidy, v0r, gbase, T, a.d, s_q, lt, res);
                 a.out[l] = res;
                 if (a.want_de) {
                     float* __restrict__ de = a.de_tmp + block_c0 + s_off[t];

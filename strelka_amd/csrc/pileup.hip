@@ -1171,6 +1171,7 @@ struct sk_pileup_stream
     bool somatic = false;      // also build the CleanPileupFilter(pi, true) column (kept on the device)
     bool want_read_pos = false; // ... and return each tier1 call's read position / read length
     bool want_evs = false;      // return the germline EVS words of every live call (sk_pileup_stream_enable_evs_words)
+    bool poisoned = false;      // a push failed after it had begun to change the stream's state: only begin_region is accepted
     // region
     bool has_region = false;
     int32_t ref_offset = 0, ref_len = 0;
@@ -1246,6 +1247,9 @@ int stream_check_reads(const sk_pileup_stream* s, const sk_read_batch* reads, co
         if (bad_code) return sk_fail("sk_pileup_stream_push: unsupported BAM base code"); // bam_seq_code_to_id base_error, bam_seq.hh:145-147
         if (bad_q && s->opt.is_mapq_adjust)
             return sk_fail("Attempting to lookup basecall quality score which exceeds the maximum cached basecall quality score of 70");
+        // (without the MAPQ adjustment the raw quality goes into the calls as it is; the EVS word has seven bits for it, the
+        // basecall record six: a quality the reference's own caches would throw on further down the path is refused here)
+        if (bad_q && s->want_evs) return sk_fail("sk_pileup_stream_push: basecall quality above 70 with the EVS column on");
     }
     if (mask_len < 0 || (mask_len > 0 && (!cand_snv_mask || mask_begin < s->ref_offset || mask_begin + mask_len > s->ref_offset + s->ref_len)))
         return sk_fail("sk_pileup_stream_push: candidate-SNV mask window outside the reference segment");
@@ -1706,6 +1710,7 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, cons
     SK_HIP(hipMemsetAsync(s->d_spandel.p, 0, 4 * n_region + 4, st));
     SK_HIP(hipMemsetAsync(s->d_submapped.p, 0, 4 * n_region + 4, st));
     SK_HIP(hipStreamSynchronize(st)); // ref_seq is the caller's
+    s->poisoned = false;
     s->ref_offset = ref_offset;
     s->ref_len = ref_len;
     s->region_begin = report_begin;
@@ -1729,6 +1734,7 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
 {
     SK_REQUIRE_INIT();
     if (!s || !reads || !out) return sk_fail("sk_pileup_stream_push: null argument");
+    if (s->poisoned) return sk_fail("sk_pileup_stream_push: an earlier push of this stream failed; begin the region again");
     if (stream_check_reads(s, reads, mask_begin, mask_len, cand_snv_mask)) return 1;
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
@@ -1736,10 +1742,18 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     int32_t lowest, highest, begin, end;
     if (stream_extent(s, reads, &lowest, &highest)) return 1;
     stream_range(s, lowest, highest, F, &begin, &end);
+    // (stream_enqueue flips the record buffers and moves the carried tail as it goes: a failure from here on leaves work in flight and
+    // the stream's bookkeeping half done -- the stream is drained and refuses further pushes until begin_region resets it)
     if (stream_enqueue(s, reads, largest_total_indel_ref_span_per_read, mask_begin, mask_len, cand_snv_mask, F, begin, end, ploidy_begin,
-                       ploidy_len, ploidy))
+                       ploidy_len, ploidy)) {
+        (void)hipStreamSynchronize(ctx.stream);
+        s->poisoned = true;
         return 1;
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    }
+    if (hipStreamSynchronize(ctx.stream) != hipSuccess) {
+        s->poisoned = true;
+        return sk_fail("sk_pileup_stream_push: the device reported an error");
+    }
     stream_finish(s, out);
     return 0;
 }
@@ -1810,6 +1824,7 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
     if (!p || !normal_reads || !tumor_reads || !out) return sk_fail("sk_somatic_pileup_stream_push: null argument");
     const sk_read_batch* reads[2] = { normal_reads, tumor_reads };
     for (int i = 0; i < 2; ++i) {
+        if (p->sample[i]->poisoned) return sk_fail("sk_somatic_pileup_stream_push: an earlier push of this stream failed; begin the region again");
         if (stream_check_reads(p->sample[i], reads[i], mask_begin, mask_len, cand_snv_mask)) return 1;
     }
     if (forced_len < 0 || (forced_len > 0 && !is_forced_output)) return sk_fail("sk_somatic_pileup_stream_push: bad forced-output window");
@@ -1830,8 +1845,12 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
     stream_range(sn, lowest, highest, F, &begin, &end);
     for (int i = 0; i < 2; ++i) {
         if (stream_enqueue(p->sample[i], reads[i], largest_total_indel_ref_span_per_read, mask_begin, mask_len, cand_snv_mask, F, begin, end, 0,
-                           0, nullptr))
+                           0, nullptr)) {
+            // (the other sample may be enqueued already: drain, and both streams refuse pushes until begin_region)
+            (void)hipStreamSynchronize(st);
+            p->sample[0]->poisoned = p->sample[1]->poisoned = true;
             return 1;
+        }
     }
     const int n_loci = end - begin;
     // a12 + a13 on the four cleaned columns, where they are

@@ -725,19 +725,19 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
     for (int j0 = 0; j0 < ncr; j0 += 64) {
         const int nc = min(64, ncr - j0);
         __syncthreads(); // (pool and read complete; the previous round's records read)
-        // ---- the round's records: pool -> LDS (-> cals) as rows of consecutive dwords, eight records' loads in flight at a time
+        // ---- the round's records: pool -> LDS (-> cals) as rows of consecutive dwords, sixteen records' loads in flight at a time
         const int src_k = (lane < nc) ? a.list[c0 + j0 + lane] : 0;
-        for (int k0 = 0; k0 < nc; k0 += 8) {
-            uint32_t v0[8], v1[8];
+        for (int k0 = 0; k0 < nc; k0 += 16) {
+            uint32_t v0[16], v1[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int k = k0 + u;
                 const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(a.pool + __shfl(src_k, (k < nc) ? k : 0));
                 v0[u] = (k < nc) ? src[lane] : 0u;
                 v1[u] = (k < nc && lane + 64 < REC_DW) ? src[lane + 64] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int k = k0 + u;
                 if (k < nc) {
                     S.cal[k * REC_STRIDE + lane] = v0[u];
@@ -751,38 +751,80 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
             }
         }
         __syncthreads();
-        if (lane < nc) {
-            const int c = c0 + j0 + lane;
-            const PCal& cal = *reinterpret_cast<const PCal*>(S.cal + lane * REC_STRIDE);
-            double lnp = 0.0;
-            int rp = 0;
-            bool bad = false;
-            auto score_op = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
-                if (kind == SK_OP_BASES) {
-                    if (rp + int(len) > L || src < 0 || int64_t(src) + int64_t(len) > int64_t(P)) {
-                        bad = true; // (a path longer than the read, a source outside the pool: the host states what the reference does)
-                    } else {
-                        for (int j = 0; j < int(len); ++j) {
-                            const unsigned rc = S.read[rp + j];
-                            if (rc == SK_BAM_ANY) continue;
-                            const bool is_ref = (rc == SK_BAM_REF) || (rc == S.hap[src + j]);
-                            lnp = __dadd_rn(lnp, is_ref ? S.agree[rp + j] : S.differ[rp + j]);
-                        }
-                    }
-                    rp += int(len);
-                } else if (kind == SK_OP_SOFT_CLIP) {
-                    lnp = __dadd_rn(lnp, __dmul_rn(double(unsigned(len)), ln_quarter));
-                    rp += int(len);
+        // ---- phase A, a lane per candidate alignment: the walk of its path (flatten_cal) leaves, instead of ops, the alignment's
+        // TRANSITIONS in the free tail of its own record's path array: one word per op that covers read positions (and one for the
+        // read's end) = start position | penalties that precede its terms << 9 | soft clip << 15 | (pool offset - position + 256) << 16
+        const bool has = lane < nc;
+        uint32_t* const myrec = S.cal + lane * REC_STRIDE;
+        int n_ent = 0;
+        bool bad = false;
+        if (has) {
+            const PCal& cal = *reinterpret_cast<const PCal*>(myrec);
+            uint32_t* const ent = myrec + 3 + cal.n_seg; // (path[n_seg ..]: unused by this alignment)
+            const int ent_cap = int(Caps::P) - int(cal.n_seg);
+            int pos = 0;
+            unsigned npen = 0;
+            auto put = [&](const unsigned at, const unsigned np, const bool clip, const int hidx) {
+                if (n_ent >= ent_cap || np > 63u || hidx < -256 || hidx > 3839) {
+                    bad = true; // (more transitions than the record's tail holds: the host form takes the read)
+                    return;
                 }
-                if (penalty) lnp = __dadd_rn(lnp, ln_noncand);
+                ent[n_ent++] = at | (np << 9) | (clip ? 1u << 15 : 0u) | (unsigned(hidx + 256) << 16);
             };
-            const int n = flatten_cal<false>(a, r, cal, L, nullptr, score_op);
-            if (n < 0 || bad) a.status[r] = ST_FAIL;
-            else fa.scores[c] = lnp;
+            auto on_op = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
+                if ((kind == SK_OP_BASES || kind == SK_OP_SOFT_CLIP) && len > 0) {
+                    const bool bases = (kind == SK_OP_BASES);
+                    if (pos + int(len) > L || (bases && (src < 0 || int64_t(src) + int64_t(len) > int64_t(P)))) bad = true;
+                    else put(unsigned(pos), npen, !bases, bases ? int(src) - pos : 0);
+                    pos += int(len);
+                    npen = penalty ? 1u : 0u;
+                } else {
+                    npen += penalty ? 1u : 0u;
+                }
+            };
+            const int n = flatten_cal<false>(a, r, cal, L, nullptr, on_op);
+            if (n < 0 || pos != L) bad = true;
+            else put(unsigned(L), npen, false, 0); // trailing penalties
             // the candidate-status lookups the host form performs for every indel of the alignment (cal_to_c)
             for (int i = 0; i < cal.n_indels; ++i) (void)job_cand(a.job, cal.indels[i]);
             if (cal.lead >= 0) (void)job_cand(a.job, cal.lead);
             if (cal.trail >= 0) (void)job_cand(a.job, cal.trail);
+            if (bad) a.status[r] = ST_FAIL;
+        }
+        // ---- phase B, the wave in step over the read's positions: at a position where a lane's next transition starts it adds the
+        // transition's penalties, then a soft clip's length x ln 0.25 (path order, as score_one_generic); elsewhere the position's term
+        // -- agree or differ, by the pool byte the lane's current offset faces -- unless the read base is N or the lane is inside a clip
+        {
+            const uint32_t* const ent = myrec + 3 + (has ? int(reinterpret_cast<const PCal*>(myrec)->n_seg) : 0);
+            const bool live = has && !bad;
+            int e = 0;
+            uint32_t next = live ? ent[0] : 0x1ffu;           // (0x1ff: a position no read has)
+            int hidx = 0;
+            bool in_bases = false;
+            double lnp = 0.0;
+            for (int p = 0; p <= L; ++p) {
+                if (int(next & 0x1ffu) == p) {
+                    const uint32_t cur = next;
+                    ++e;
+                    next = (e < n_ent) ? ent[e] : 0x1ffu;
+                    const unsigned np = (cur >> 9) & 63u;
+                    for (unsigned k = 0; k < np; ++k) lnp = __dadd_rn(lnp, ln_noncand);
+                    if (cur & (1u << 15)) {
+                        lnp = __dadd_rn(lnp, __dmul_rn(double(unsigned(int(next & 0x1ffu) - p)), ln_quarter));
+                        in_bases = false;
+                    } else {
+                        hidx = int(cur >> 16) - 256;
+                        in_bases = true;
+                    }
+                }
+                if (p < L) {
+                    const unsigned rc = S.read[p];
+                    const unsigned hc = S.hap[in_bases ? p + hidx : 0];
+                    const double term = ((rc == SK_BAM_REF) || (rc == hc)) ? S.agree[p] : S.differ[p];
+                    if (in_bases && rc != SK_BAM_ANY) lnp = __dadd_rn(lnp, term);
+                }
+            }
+            if (live) fa.scores[c0 + j0 + lane] = lnp;
         }
     }
 }

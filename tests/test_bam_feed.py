@@ -335,6 +335,33 @@ def test_index_query_equals_htslib_on_the_fixture_and_the_demo_bams():
 
 
 @pytest.mark.gpu
+def test_prefix_only_slice_keeps_the_stream():
+    """a slice that is only the carried record (no blocks): out receives the prefix and sk_bam_decode_kept decodes from the
+    kept stream, as the header promises"""
+    capi.init(0)
+    stream = np.frombuffer(bam_oracle.bgzf_inflate(_bytes(TINY)), np.uint8)
+    rec_off, read_off, path_off = capi.bam_scan_records(stream)
+    a, b = int(rec_off[3]), int(rec_off[5])  # two whole records
+    prefix = np.ascontiguousarray(stream[a:b])
+    out = np.zeros(len(prefix), np.uint8)
+    none = np.zeros(1, np.int64)
+    rc = capi.lib().sk_bgzf_inflate_prefixed(capi._p(none.view(np.uint8)), capi._p(none), capi._p(none), 0, capi._p(prefix), len(prefix), capi._p(out))
+    assert rc == 0, capi.last_error()
+    assert out.tobytes() == prefix.tobytes()
+    want = capi.bam_decode(prefix, first=0)
+    ro, rd, po = capi.bam_scan_records(prefix, 0)
+    n = len(ro)
+    assert n == 2
+    rec = np.zeros(n, capi.BAM_RECORD_DTYPE)
+    code = np.zeros(int(rd[-1]), np.uint8)
+    qual = np.zeros(int(rd[-1]), np.uint8)
+    path = np.zeros(int(po[-1]), capi.PATH_SEG_DTYPE)
+    rc = capi.lib().sk_bam_decode_kept(capi._p(prefix), len(prefix), capi._p(ro), n, capi._p(rd), capi._p(po), capi._p(rec), capi._p(code), capi._p(qual), capi._p(path))
+    assert rc == 0, capi.last_error()
+    assert rec.tobytes() == want["rec"].tobytes() and code.tobytes() == want["read_code"].tobytes() and qual.tobytes() == want["read_qual"].tobytes()
+
+
+@pytest.mark.gpu
 def test_region_fetch_through_the_kernels():
     capi.init(0)
     assert _check_regions(os.path.join(GOLD, "feed_regions.bam"), _golden_regions(), on_gpu=True) > 10000

@@ -12,7 +12,7 @@ for d in sys.argv[1:]:
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                k = row.get("Kernel_Name", "?").split("(")[0][:60]
+                k = row.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").split("(")[0][:60]
                 sums[k][row["Counter_Name"]] += float(row["Counter_Value"])
                 launches[k].add(row.get("Dispatch_Id"))
     print("==", d)

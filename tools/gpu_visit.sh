@@ -20,6 +20,9 @@ for step in "$@"; do
     e2e_somatic)
       SK_E2E_KEEP_DIR=$OUT/kept timeout 900 python bench.py --only e2e_somatic > $OUT/e2e_somatic.json 2> $OUT/e2e_somatic.err
       echo "e2e_somatic rc=$?"; tail -c 400 $OUT/e2e_somatic.err ;;
+    tests_kernels)
+      timeout 900 python -m pytest tests/test_device_enumeration.py tests/test_gpu_parity.py tests/test_read_realign.py tests/test_pipeline.py tests/test_bam_feed.py tests/test_limits.py tests/test_pileup_stream.py -m gpu -x -q > $OUT/pytest_gpu_kernels.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu_kernels.log
+      tail -4 $OUT/pytest_gpu_kernels.log ;;
     tests)
       timeout 1200 python -m pytest tests -m gpu -x -q -k "not at_bench_configuration" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
       tail -5 $OUT/pytest_gpu.log ;;
@@ -52,7 +55,7 @@ for step in "$@"; do
       done
       python tools/diag/pmc_kernel_sums.py $OUT/pmc_g3_* > $OUT/pmc_g3.txt 2>&1; cat $OUT/pmc_g3.txt ;;
     g3_variants)
-      for v in 0 1 2 3 4; do
+      for v in ${G3_VARIANTS:-0 1 2 3 4}; do
         SK_G3_VARIANT=$v timeout 300 python bench.py --only loci --steps 5 --warmup 2 > $OUT/loci_v$v.json 2>$OUT/loci_v$v.err; echo "variant $v: $(cat $OUT/loci_v$v.json | head -c 400)"
       done ;;
     a5_ab)
