@@ -70,8 +70,8 @@ int sk_libm_restated(void);
  *  non-zero with the reference's message in sk_last_error() if a flag is up, and clears it. */
 int sk_check_device_errors(void);
 
-/** Test hook: which statement of the fused germline site kernel sk_site_digt_call_fused[_dev] launches (0 = round 1's, 1..4 = the
- *  second one with 128 / 256 loci per block, without / with the depth sort: csrc/germline_fused.hip); < 0 = $SK_G3_VARIANT or the
+/** Test hook: which statement of the fused germline site kernel sk_site_digt_call_fused[_dev] launches (0 = round 1's, 1 = the second one:
+ *  csrc/germline_fused.hip); < 0 = $SK_G3_VARIANT or the
  *  default.  Every variant writes the same records (tests/test_gpu_parity.py runs them all against the oracle). */
 int sk_debug_set_g3_variant(int variant);
 /** Test hook: on != 0 makes every kernel take the path it takes on a host whose libm is NOT the restated one (the device

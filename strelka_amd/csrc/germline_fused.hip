@@ -601,11 +601,9 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(3
 //     ranked terms are a host-built table of (q, rank) (GermlineDerived::v0r0) -- two groups in three at human mismatch densities;
 //   * the others leave (slot, q) on a block-wide list and their exponent in the slot; after a barrier the whole block works the list
 //     off, one entry per lane: the transcendentals are evaluated once per entry instead of once per (wave, round, rank);
-//   * FLAG_SORT: lanes take the loci of a sub-batch in order of depth, so that the lanes of a wave run loops of similar length;
+//   * every per-call loop reads four calls ahead of their use (one LDS wait per four calls instead of one or two per call);
 //   * the log table of the restated double-precision libm stays in global memory (L1-resident): six blocks per CU instead of five.
 // Same arithmetic, same records; loci the fast path declines take the global-memory pass as before.
-enum { G3_FLAG_SORT = 1 };
-
 template <int LOCI>
 struct G3Cfg
 {
@@ -802,12 +800,12 @@ __device__ bool locus_rank_calls_v2(uint16_t* calls, uint16_t* keys, const int n
     return ok;
 }
 
-template <int LOCI, int FLAGS>
+template <int LOCI>
 __global__ __launch_bounds__(LOCI) __attribute__((amdgpu_waves_per_eu(3, 3))) void germline_site_fused_v2_kernel(const FusedArgs a)
 {
     typedef G3Cfg<LOCI> C;
     __shared__ __attribute__((aligned(16))) uint16_t s_calls[C::CAP];
-    __shared__ __attribute__((aligned(16))) uint16_t s_keys[C::CAP]; // (also the scratch of the depth sort: needs 4 * 256 + 2 * LOCI bytes)
+    __shared__ __attribute__((aligned(16))) uint16_t s_keys[C::CAP];
     __shared__ int32_t s_off[LOCI + 1];
     __shared__ float s_pool[C::POOL];
     __shared__ typename C::pend_t s_pend[C::PEND];
@@ -815,7 +813,6 @@ __global__ __launch_bounds__(LOCI) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     __shared__ QTab s_q;
     __shared__ float s_tab[SK_NQ6 * 3];
     __shared__ uint64_t s_exp[256];
-    static_assert(C::CAP * 2 >= 4 * 256 + 2 * LOCI, "depth-sort scratch");
 
     const int tid = threadIdx.x;
     const int l0 = blockIdx.x * LOCI;
@@ -868,45 +865,8 @@ __global__ __launch_bounds__(LOCI) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         const uint16_t* __restrict__ gcalls = a.b.calls + block_c0 + c0;
         for (int j = tid; j < span; j += LOCI) s_calls[j] = gcalls[j] & CALL_MASK;
 
-        // which locus of the sub-batch this thread takes: its own, or (FLAG_SORT) the tid-th in order of depth -- a counting sort over
-        // min(depth, 255) with the key array as scratch; the order inside a bin is whatever the atomics give, which changes nothing:
-        // every locus is computed by exactly one thread, from its own calls
-        int t = s + tid;
-        if (FLAGS & G3_FLAG_SORT) {
-            int* hist = reinterpret_cast<int*>(s_keys);
-            uint16_t* order = s_keys + 512;
-            for (int j = tid; j < 256; j += LOCI) hist[j] = 0;
-            __syncthreads();
-            int bin = 0;
-            if (t < e) {
-                bin = min(s_off[t + 1] - s_off[t], 255);
-                atomicAdd(&hist[bin], 1);
-            }
-            __syncthreads();
-            if (tid < 64) { // exclusive prefix sums of the 256 bins: four per lane, then across the wave
-                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-                const int mine = h0 + h1 + h2 + h3;
-                int incl = mine;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int up = __shfl_up(incl, d, 64);
-                    if (tid >= d) incl += up;
-                }
-                const int excl = incl - mine;
-                hist[4 * tid] = excl;
-                hist[4 * tid + 1] = excl + h0;
-                hist[4 * tid + 2] = excl + h0 + h1;
-                hist[4 * tid + 3] = excl + h0 + h1 + h2;
-            }
-            __syncthreads();
-            if (t < e) order[atomicAdd(&hist[bin], 1)] = uint16_t(t);
-            __syncthreads();
-            const int mine = (tid < cnt) ? int(order[tid]) : e;
-            __syncthreads(); // (the scratch becomes the key array again)
-            t = mine;
-        } else {
-            __syncthreads();
-        }
+        const int t = s + tid;
+        __syncthreads();
 
         const bool active = (t < e);
         int off = 0, n = 0;
@@ -1002,19 +962,13 @@ int sk_site_digt_call_fused_dev(const sk_pileup_batch* b, const sk_germline_opti
     a.want_de = want_de ? 1 : 0;
     derive(*opt, a.d);
     SK_HIP(hipMemsetAsync(a.work_count, 0, sizeof(uint32_t), static_cast<hipStream_t>(hip_stream)));
-    // $SK_G3_VARIANT (experiments / A-B runs): 0 = round 1's kernel; 1 = v2 (tabled + pending terms), 128 loci per block;
-    // 2 = v2 with the depth sort; 3 / 4 = the same two with 256 loci per block.  Same records from all of them.
+    // $SK_G3_VARIANT = 0 (A-B runs, tests): round 1's kernel; otherwise the second statement.  Same records from both.
     static const int env_variant = []() { const char* v = std::getenv("SK_G3_VARIANT"); return (v && *v) ? std::atoi(v) : G3_DEFAULT_VARIANT; }();
     const int variant = (g_g3_variant_override >= 0) ? g_g3_variant_override : env_variant;
     const hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const int n = b->n_loci;
-    switch (variant) {
-    case 0: hipLaunchKernelGGL(germline_site_fused_kernel, dim3((n + LOCI_PER_BLOCK - 1) / LOCI_PER_BLOCK), dim3(FUSED_THREADS), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((germline_site_fused_v2_kernel<128, G3_FLAG_SORT>), dim3((n + 127) / 128), dim3(128), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((germline_site_fused_v2_kernel<256, 0>), dim3((n + 255) / 256), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((germline_site_fused_v2_kernel<256, G3_FLAG_SORT>), dim3((n + 255) / 256), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((germline_site_fused_v2_kernel<128, 0>), dim3((n + 127) / 128), dim3(128), 0, st, a); break;
-    }
+    if (variant == 0) hipLaunchKernelGGL(germline_site_fused_kernel, dim3((n + LOCI_PER_BLOCK - 1) / LOCI_PER_BLOCK), dim3(FUSED_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((germline_site_fused_v2_kernel<128>), dim3((n + 127) / 128), dim3(128), 0, st, a);
     hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3(std::min(2048, (b->n_loci + 63) / 64)), dim3(64), 0,
                        static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());

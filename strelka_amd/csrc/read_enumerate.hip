@@ -652,6 +652,9 @@ __global__ __launch_bounds__(64) void flatten_kernel(const FlatArgs a)
 // then runs F1-F3 + A1c over the job.
 constexpr int F5_MAX_READ = 256;  // (as F3's wave form; longer reads and larger pools take the staged chain)
 constexpr int F5_MAX_POOL = 1024;
+constexpr int F5_TAB = 48;       // span of table indices the indels of one round's candidate alignments may cover
+
+static_assert(sizeof(PIndel) % 4 == 0, "table entries move as 32-bit words");
 
 struct FusedScoreArgs
 {
@@ -670,6 +673,12 @@ struct F5Lds
     uint8_t read[F5_MAX_READ];
     uint8_t hap[F5_MAX_POOL];
     uint32_t cal[64 * ((sizeof(PCal) / 4) | 1)];    // the wave's records, rows of dwords (stride odd: conflict-free)
+    // what flatten_cal looks up per path segment, close by (a walk is a chain of dependent look-ups: from HBM / L2 they cost a wave of
+    // this kernel ~100 us per round): the table entries of the round's indels and the read's pool layout
+    uint32_t tab[F5_TAB * (sizeof(PIndel) / 4)];
+    int32_t ins_off[INS_CAP];
+    int16_t ins_idx[INS_CAP];
+    int32_t win_begin, n_ins;
 };
 
 __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs fa)
@@ -721,6 +730,24 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         }
     }
     const double ln_quarter = fa.tab->ln_quarter, ln_noncand = fa.tab->ln_noncand;
+    {
+        const int n_ins = a.n_ins[r];
+        if (lane < n_ins) {
+            S.ins_idx[lane] = a.ins_idx[size_t(r) * INS_CAP + lane];
+            S.ins_off[lane] = a.ins_off[size_t(r) * INS_CAP + lane];
+        }
+        if (lane == 0) {
+            S.win_begin = a.win_begin[r];
+            S.n_ins = n_ins;
+        }
+    }
+    // flatten_cal and job_cand read `la`: the same arguments with the per-read and per-indel arrays rebased onto their LDS copies
+    // (element r of win_begin / n_ins / ins_idx / ins_off, elements [tab_lo, tab_lo + F5_TAB) of the indel table)
+    FlatArgs la = a;
+    la.win_begin = &S.win_begin - r;
+    la.n_ins = &S.n_ins - r;
+    la.ins_idx = S.ins_idx - size_t(r) * INS_CAP;
+    la.ins_off = S.ins_off - size_t(r) * INS_CAP;
 
     for (int j0 = 0; j0 < ncr; j0 += 64) {
         const int nc = min(64, ncr - j0);
@@ -756,6 +783,35 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         // read's end) = start position | penalties that precede its terms << 9 | soft clip << 15 | (pool offset - position + 256) << 16
         const bool has = lane < nc;
         uint32_t* const myrec = S.cal + lane * REC_STRIDE;
+        {
+            // the table entries this round's alignments name
+            int lo = INT_MAX, hi = INT_MIN;
+            if (has) {
+                const PCal& cal = *reinterpret_cast<const PCal*>(myrec);
+                auto add = [&](const int i) {
+                    lo = min(lo, i);
+                    hi = max(hi, i);
+                };
+                for (int i = 0; i < cal.n_indels; ++i) add(cal.indels[i]);
+                if (cal.lead >= 0) add(cal.lead);
+                if (cal.trail >= 0) add(cal.trail);
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                lo = min(lo, __shfl_xor(lo, d));
+                hi = max(hi, __shfl_xor(hi, d));
+            }
+            const int n_tab = (lo <= hi) ? hi - lo + 1 : 0;
+            if (lo < 0 || n_tab > F5_TAB) { // (indices further apart than the copy holds: the staged chain takes the job)
+                if (lane == 0) atomicAdd(fa.n_unhandled, 1);
+                return;
+            }
+            constexpr int ENT_DW = int(sizeof(PIndel) / 4);
+            const uint32_t* __restrict__ gt = reinterpret_cast<const uint32_t*>(a.job.tab + (n_tab ? lo : 0));
+            for (int j = lane; j < n_tab * ENT_DW; j += 64) S.tab[j] = gt[j];
+            la.job.tab = reinterpret_cast<const PIndel*>(S.tab) - (n_tab ? lo : 0);
+            __syncthreads();
+        }
         int n_ent = 0;
         bool bad = false;
         if (has) {
@@ -782,13 +838,13 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                     npen += penalty ? 1u : 0u;
                 }
             };
-            const int n = flatten_cal<false>(a, r, cal, L, nullptr, on_op);
+            const int n = flatten_cal<false>(la, r, cal, L, nullptr, on_op);
             if (n < 0 || pos != L) bad = true;
             else put(unsigned(L), npen, false, 0); // trailing penalties
             // the candidate-status lookups the host form performs for every indel of the alignment (cal_to_c)
-            for (int i = 0; i < cal.n_indels; ++i) (void)job_cand(a.job, cal.indels[i]);
-            if (cal.lead >= 0) (void)job_cand(a.job, cal.lead);
-            if (cal.trail >= 0) (void)job_cand(a.job, cal.trail);
+            for (int i = 0; i < cal.n_indels; ++i) (void)job_cand(la.job, cal.indels[i]);
+            if (cal.lead >= 0) (void)job_cand(la.job, cal.lead);
+            if (cal.trail >= 0) (void)job_cand(la.job, cal.trail);
             if (bad) a.status[r] = ST_FAIL;
         }
         // ---- phase B, the wave in step over the read's positions: at a position where a lane's next transition starts it adds the
@@ -825,6 +881,37 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                 }
             }
             if (live) fa.scores[c0 + j0 + lane] = lnp;
+        }
+    }
+}
+
+// the records in set order, for the host (sk_enum_device_fetch_cals; a job whose stage 3 runs on the host): pool[list[c]] -> cals[c], a wave
+// per 64 records, rows of consecutive dwords
+__global__ __launch_bounds__(64) void gather_cals_kernel(const PCal* __restrict__ pool, const int32_t* __restrict__ list, const int32_t n_cals,
+                                                         PCal* __restrict__ cals)
+{
+    constexpr int REC_DW = int(sizeof(PCal) / 4);
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x * 64;
+    const int nc = min(64, n_cals - c0);
+    const int src_k = (lane < nc) ? list[c0 + lane] : 0;
+    for (int k0 = 0; k0 < nc; k0 += 16) {
+        uint32_t v0[16], v1[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = k0 + u;
+            const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(pool + __shfl(src_k, (k < nc) ? k : 0));
+            v0[u] = (k < nc) ? src[lane] : 0u;
+            v1[u] = (k < nc && lane + 64 < REC_DW) ? src[lane + 64] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = k0 + u;
+            if (k < nc) {
+                uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(cals + (c0 + k));
+                dst[lane] = v0[u];
+                if (lane + 64 < REC_DW) dst[lane + 64] = v1[u];
+            }
         }
     }
 }
@@ -1172,7 +1259,8 @@ struct Stage3Args
     int32_t n_reads;
     const int32_t* status;
     const int32_t* cal_off;
-    const PCal* cals;
+    const PCal* cals;    // the records in set order -- or, with `slot`, the pool the search left its leaves in
+    const int32_t* slot; // null, or [n_cals] the pool slot of every alignment in set order
     const double* scores;
     const int64_t* read_off;
     const uint8_t* read_code;
@@ -1208,7 +1296,7 @@ __global__ __launch_bounds__(64 * WAVES) void stage3_kernel(const Stage3Args a)
     }
     const int64_t b0 = a.read_off[r], b1 = a.read_off[r + 1];
     sk3::Read rd;
-    rd.cals = a.cals + c0;
+    rd.cals = a.slot ? sk3::CalView{ a.cals, a.slot + c0 } : sk3::CalView{ a.cals + c0, nullptr };
     rd.scores = a.scores + c0;
     rd.scores_select = rd.scores;
     rd.n_cals = c1 - c0;
@@ -1342,6 +1430,9 @@ namespace
 {
 uint64_t g_generation = 0; // of the run whose candidate alignments the buffers hold
 int32_t g_n_cals = 0;
+bool g_cals_gathered = false; // bufs().cals holds the run's records in set order (else: pool + list, gathered when the host asks)
+const PCal* g_cals_pool = nullptr;
+const int32_t* g_cals_list = nullptr;
 
 // what sk_enum_device_rescore needs to run F1-F3 + the scoring kernel again on the candidate alignments of the last run
 struct LastFlat
@@ -1364,6 +1455,12 @@ extern "C" int sk_enum_device_fetch_cals(const uint64_t generation, const int32_
     if (count == 0) return 0;
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
+    if (!g_cals_gathered) { // (F5 left the records where the search put them: in set order on demand, once per run)
+        if (bufs().cals.reserve(sizeof(PCal) * size_t(g_n_cals))) return 1;
+        hipLaunchKernelGGL(gather_cals_kernel, dim3((g_n_cals + 63) / 64), dim3(64), 0, ctx.stream, g_cals_pool, g_cals_list, g_n_cals, bufs().cals.as<PCal>());
+        SK_HIP(hipGetLastError());
+        g_cals_gathered = true;
+    }
     SK_HIP(hipMemcpyAsync(dst, bufs().cals.as<PCal>() + first, sizeof(PCal) * size_t(count), hipMemcpyDeviceToHost, ctx.stream));
     SK_HIP(hipStreamSynchronize(ctx.stream));
     return 0;
@@ -1376,6 +1473,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     std::memset(out, 0, sizeof(*out));
     out->generation = ++g_generation;
     g_n_cals = 0;
+    g_cals_gathered = false;
     g_last.valid = false;
     const int n = in->n_reads;
     if (n < 0 || in->n_tab < 0) return sk_fail("sk_enum_device_run: negative count");
@@ -1680,14 +1778,15 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     // holds a read F5 turns down, when the host wants the alignments without scores, and with $SK_A5_FUSED=0 (tests: both chains).
     const bool fused_enabled = !(std::getenv("SK_A5_FUSED") != nullptr && std::strcmp(std::getenv("SK_A5_FUSED"), "0") == 0);
     const bool try_fused = fused_enabled && in->want_scores && n_cals > 0;
-    RES(cals, sizeof(PCal) * size_t(n_cals));
     RES(scores, 8 * size_t(n_cals));
     if (!(in->want_scores && in->want_stage3)) HRES(h_cals, sizeof(PCal) * size_t(n_cals));
     HRES(h_scores, 8 * size_t(n_cals));
     out->cals = B.h_cals.as<PCal>();
     g_n_cals = n_cals;
-    fa.cals = B.cals.as<PCal>();
     fa.max_read_len = in->max_read_len;
+    g_cals_pool = fa.pool;
+    g_cals_list = fa.list;
+    bool cals_in_set_order = false; // F5 reads the records where the search left them; the staged chain copies them (flatten_kernel)
 
     // what follows the scores in either chain: bookkeeping for sk_enum_device_rescore, the scores' way back, stage 3
     auto after_scores = [&]() -> int {
@@ -1719,7 +1818,8 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
             s3.n_reads = n;
             s3.status = ea.status;
             s3.cal_off = fa.cal_off;
-            s3.cals = fa.cals;
+            s3.cals = cals_in_set_order ? fa.cals : fa.pool;
+        s3.slot = cals_in_set_order ? nullptr : fa.list;
             s3.scores = B.scores.as<double>();
             s3.read_off = fa.read_off;
             s3.read_code = fa.read_code;
@@ -1790,12 +1890,19 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         fs.scores = B.scores.as<double>();
         fs.err = ctx.dev_error_flags;
         fs.n_unhandled = B.counters.as<int32_t>() + (Caps::K + 7);
-        fs.write_cals = 1;
+        fs.write_cals = 0;
         hipLaunchKernelGGL(flatten_score_kernel, dim3(n), dim3(64), 0, st, fs);
         SK_HIP(hipGetLastError());
         lap("F5 flatten + score");
-        if (in->want_stage3) out->cals = nullptr; // (they stay here: sk_enum_device_fetch_cals)
-        else D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
+        if (in->want_stage3) {
+            out->cals = nullptr; // (they stay here, in the pool: sk_enum_device_fetch_cals gathers them when the host asks)
+        } else {
+            RES(cals, sizeof(PCal) * size_t(n_cals));
+            hipLaunchKernelGGL(gather_cals_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa.pool, fa.list, n_cals, B.cals.as<PCal>());
+            SK_HIP(hipGetLastError());
+            g_cals_gathered = true;
+            D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
+        }
         g_last.fused = true;
         g_last.fs = fs;
         g_last.n = n;
@@ -1811,6 +1918,10 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         if (B.h_counters.as<int32_t>()[Caps::K + 7] > 0) staged = true; // a read outside F5's form: the staged chain over the job
     }
     if (staged) {
+        RES(cals, sizeof(PCal) * size_t(n_cals));
+        fa.cals = B.cals.as<PCal>();
+        cals_in_set_order = true;
+        g_cals_gathered = true; // (flatten_kernel below writes them)
         if (n_cals > 0) {
             hipLaunchKernelGGL(op_count_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
             SK_HIP(hipGetLastError());

@@ -54,9 +54,18 @@ struct Opt
     int32_t no_tables; // (tests: score_indels without its per-read conflict tables, as for reads whose indels span too much of the table)
 };
 
+// A read's candidate alignments in std::set order: an array of records, or -- on the device, where the search leaves its leaves in
+// one pool and the set order is a list of slots -- the pool and the read's part of that list (no copy of the records in set order)
+struct CalView
+{
+    const PCal* base;
+    const int32_t* slot; // null: base[i] is alignment i
+    SKC_HD const PCal& operator[](const int i) const { return slot ? base[slot[i]] : base[i]; }
+};
+
 struct Read
 {
-    const PCal* cals; // std::set order
+    CalView cals; // std::set order
     const double* scores;        // of the candidate alignments
     const double* scores_select; // the same values, maybe in closer memory; read until the late normalisation filter has sorted
     int32_t n_cals;

@@ -2324,7 +2324,7 @@ static bool finish_read_core(const sk_realign_job& j, const Stage3Tables& t, sk_
     sk3::Tab tab = t.tab;
     tab.consulted = consulted.data();
     sk3::Read r;
-    r.cals = cals.data();
+    r.cals = sk3::CalView{ cals.data(), nullptr };
     r.scores = scores;
     r.scores_select = scores;
     r.n_cals = int32_t(n);

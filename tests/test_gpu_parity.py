@@ -241,10 +241,10 @@ def test_site_digt_call_fused_nondefault_options(gpu):
         assert np.array_equal(fused["lhood"].view(np.uint32), want["lhood"].view(np.uint32)), kw
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1])
 def test_site_digt_call_fused_every_kernel_variant(gpu, variant):
-    """csrc/germline_fused.hip holds round 1's kernel (0) and the second statement (tabled + pending ranked terms) with 128 / 256 loci
-    per block, without / with the depth sort (1..4): every one of them against the oracle, byte for byte -- ordinary 40x loci with and
+    """csrc/germline_fused.hip holds round 1's kernel (0) and the second statement (1: tabled + pending ranked terms, calls read
+    ahead): both against the oracle, byte for byte -- ordinary 40x loci with and
     without neighbouring mismatches, dense mismatch flags (every group pending: the list overflows into the global-memory pass), low
     quality calls, deep loci, loci beyond the LDS path, haploid and N-reference loci, non-default options"""
     from strelka_amd import capi

@@ -55,7 +55,7 @@ for step in "$@"; do
       done
       python tools/diag/pmc_kernel_sums.py $OUT/pmc_g3_* > $OUT/pmc_g3.txt 2>&1; cat $OUT/pmc_g3.txt ;;
     g3_variants)
-      for v in ${G3_VARIANTS:-0 1 2 3 4}; do
+      for v in ${G3_VARIANTS:-0 1}; do
         SK_G3_VARIANT=$v timeout 300 python bench.py --only loci --steps 5 --warmup 2 > $OUT/loci_v$v.json 2>$OUT/loci_v$v.err; echo "variant $v: $(cat $OUT/loci_v$v.json | head -c 400)"
       done ;;
     a5_ab)
