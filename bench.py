@@ -54,8 +54,10 @@ def parse():
     ap.add_argument("--a5-scenarios", type=int, default=12, help="scenarios (jobs) of the flatten + score leg")
     ap.add_argument("--a5-reads", type=int, default=1 << 12, help="reads per job of the flatten + score leg")
     ap.add_argument("--a5-reps", type=int, default=3)
-    ap.add_argument("--e2e-bp", type=int, default=16000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
-    ap.add_argument("--e2e-segment-bp", type=int, default=2000000, help="segment size of the end-to-end leg (one caller process per segment)")
+    ap.add_argument("--e2e-bp", type=int, default=32000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
+    ap.add_argument("--e2e-segment-bp", type=int, default=4000000,
+                    help="segment size of the end-to-end leg (one caller process per segment; the workflow cuts a genome into 12 Mb pieces: "
+                         "profiles/ holds a run at --e2e-bp 64000000 --e2e-segment-bp 12000000, chr20's size)")
     ap.add_argument("--only", default="", help="'a5' / 'feed' / 'loci': run one kernel leg alone (the counter passes of tools/gpu_round.sh use it: "
                                                "per-kernel averages then belong to that leg's launches) and print a short line; 'e2e', "
                                                "'e2e_germline', 'e2e_somatic': the end-to-end legs alone (exit code 1 when the drop-in's outputs "

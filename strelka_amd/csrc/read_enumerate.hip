@@ -665,32 +665,185 @@ struct FusedScoreArgs
     unsigned* err;         // SkContext::dev_error_flags (a quality above 70)
     int32_t* n_unhandled;  // reads left to the staged kernels
     int32_t write_cals;    // the records' copy in set order (stage 3 and sk_enum_device_fetch_cals read it)
+    unsigned long long* dbg; // diagnostics ($SK_F5_TIMING): per block 8 cycle stamps, or null
 };
+
+// a candidate alignment as F5 keeps it in LDS: the used part of the PCal record, then the walk's transitions
+//   [0] pos   [1] lead | trail << 16   [2] fwd | n_seg << 8 | n_indels << 16   [3 .. 3+F5_SEGS) path   [.. +F5_INDELS/2) indels
+//   [F5_ENT0 ..) transitions: start position | penalties that precede the op's terms << 9 | soft clip << 15 | (pool offset - position + 256) << 16
+constexpr int F5_SEGS = 16, F5_INDELS = 8, F5_ENTS = 20;
+constexpr int F5_IND0 = 3 + F5_SEGS, F5_ENT0 = F5_IND0 + F5_INDELS / 2, F5_SLOT = (F5_ENT0 + F5_ENTS) | 1; // (odd stride: conflict-free)
+constexpr int F5_ROW = 3; // doubles per read position: agree, differ, 0.0 (a selector's byte offset picks one: score_cols_body's rows)
 
 struct F5Lds
 {
-    double agree[F5_MAX_READ], differ[F5_MAX_READ]; // ln(1-e_q), ln(e_q/3) of the read's positions
-    uint8_t read[F5_MAX_READ];
-    uint8_t hap[F5_MAX_POOL];
-    uint32_t cal[64 * ((sizeof(PCal) / 4) | 1)];    // the wave's records, rows of dwords (stride odd: conflict-free)
-    // what flatten_cal looks up per path segment, close by (a walk is a chain of dependent look-ups: from HBM / L2 they cost a wave of
-    // this kernel ~100 us per round): the table entries of the round's indels and the read's pool layout
+    double row[(F5_MAX_READ + 8) * F5_ROW];
+    uint8_t read[F5_MAX_READ + 8];
+    uint8_t hap[F5_MAX_POOL + 8];
+    uint32_t slot[64 * F5_SLOT];
+    // what the walk looks up per path segment (a chain of dependent look-ups: from HBM / L2 they cost a wave ~100 us per round)
     uint32_t tab[F5_TAB * (sizeof(PIndel) / 4)];
     int32_t ins_off[INS_CAP];
     int16_t ins_idx[INS_CAP];
-    int32_t win_begin, n_ins;
 };
+
+struct F5Rec // accessors of a compact record
+{
+    const uint32_t* w;
+    __device__ __forceinline__ int32_t pos() const { return int32_t(w[0]); }
+    __device__ __forceinline__ int lead() const { return int(int16_t(w[1] & 0xffffu)); }
+    __device__ __forceinline__ int trail() const { return int(int16_t(w[1] >> 16)); }
+    __device__ __forceinline__ int n_seg() const { return int((w[2] >> 8) & 0xffu); }
+    __device__ __forceinline__ int n_indels() const { return int((w[2] >> 16) & 0xffu); }
+    __device__ __forceinline__ unsigned seg_type(const int i) const { return w[3 + i] & 0xffffu; }
+    __device__ __forceinline__ unsigned seg_len(const int i) const { return w[3 + i] >> 16; }
+    __device__ __forceinline__ int indel(const int k) const { return int(int16_t((w[F5_IND0 + (k >> 1)] >> (16 * (k & 1))) & 0xffffu)); }
+};
+
+// flatten_cal over a compact record, every look-up from the block's LDS copies (S is the kernel's __shared__ object: the accesses stay
+// LDS accesses).  The same walk, statement for statement (scoreCandidateAlignment :286-493 as host/align_flatten.cpp states it); `sink`
+// receives the ops.  Returns false: leave the read to the host form.
+template <typename SINK>
+__device__ __forceinline__ bool f5_walk(F5Lds& S, const F5Rec c, const int tab_lo, const int n_ins, const int32_t win_begin, uint8_t* consulted,
+                                        const int32_t read_len, SINK&& sink)
+{
+    auto tab = [&](const int i) -> const PIndel& { return reinterpret_cast<const PIndel*>(S.tab)[i - tab_lo]; };
+    auto is_cand = [&](const int i) -> bool { // job_cand
+        if (consulted) consulted[i] = 1;
+        return tab(i).cand != 0;
+    };
+    const int aps = c.n_seg();
+    unsigned read_offset = 0;
+    int32_t ref_head_pos = c.pos();
+    int ends_first = aps, ends_second = aps; // get_match_edge_segments, align_path.cpp:735-752
+    {
+        bool is_first_match = false;
+        for (int i = 0; i < aps; ++i)
+            if (seg_align_match(c.seg_type(i))) {
+                if (!is_first_match) ends_first = i;
+                is_first_match = true;
+                ends_second = i;
+            }
+    }
+    // getMatchingIndelKey, starling_read_align_score.cpp:177-228: table index, -1 = no key, -2 = inconsistent
+    auto matching = [&](const unsigned del_len, const unsigned ins_len, const int path_index) -> int {
+        if (path_index < ends_first) return c.lead();
+        if (path_index > ends_second) return c.trail();
+        int found = -1;
+        const int ni = c.n_indels();
+        for (int k = 0; k < ni; ++k) {
+            const int idx = c.indel(k);
+            const PIndel& ci = tab(idx);
+            if (ci.pos == ref_head_pos && (ci.type == SK_INDEL_INDEL || ci.type == SK_INDEL_MISMATCH) && ci.del == del_len && ci.ins_len == ins_len) {
+                if (found >= 0) return -2;
+                found = idx;
+            } else if (ci.pos > ref_head_pos) {
+                break;
+            }
+        }
+        return found >= 0 ? found : -2;
+    };
+    auto emit = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
+        if (kind == SK_OP_NOBASE && !penalty) return;
+        sink(kind, len, src, penalty);
+    };
+    // offset of insert bases [head, head+len) of table indel `idx` in the pool, -1 = not representable here
+    auto insert_src = [&](const int idx, const int32_t head, const uint32_t len) -> int32_t {
+        if (head < 0 || uint32_t(head) + len > tab(idx).ins_len) return -1;
+        for (int i = 0; i < n_ins; ++i)
+            if (S.ins_idx[i] == idx) return S.ins_off[i] + head;
+        return -1;
+    };
+    int path_index = 0;
+    while (path_index < aps) {
+        bool is_swap_start = false; // is_segment_swap_start, align_path.cpp:868-895
+        {
+            bool is_insert = false, is_delete = false;
+            for (int i = path_index; i < aps; ++i) {
+                const unsigned ty = c.seg_type(i);
+                if (ty == SK_SEG_INSERT) is_insert = true;
+                else if (ty == SK_SEG_DELETE) is_delete = true;
+                else break;
+            }
+            is_swap_start = is_insert && is_delete;
+        }
+        unsigned n_seg = 1;
+        const unsigned ps_type = c.seg_type(path_index), ps_len = c.seg_len(path_index);
+        if (is_swap_start || ps_type == SK_SEG_SEQ_MISMATCH) {
+            unsigned del_len, ins_len;
+            if (ps_type == SK_SEG_SEQ_MISMATCH) {
+                del_len = ins_len = ps_len;
+            } else { // swap_info, align_path_util.hh:75-106
+                int k = path_index;
+                del_len = ins_len = 0;
+                for (; k < aps && (c.seg_type(k) == SK_SEG_INSERT || c.seg_type(k) == SK_SEG_DELETE); ++k) {
+                    if (c.seg_type(k) == SK_SEG_INSERT) ins_len += c.seg_len(k);
+                    else del_len += c.seg_len(k);
+                }
+                n_seg = unsigned(k - path_index);
+            }
+            const int key = matching(del_len, ins_len, path_index);
+            if (key < 0) return false;
+            int32_t head = 0;
+            if (path_index < ends_first) head = int32_t(tab(key).ins_len) - int32_t(ps_len);
+            const bool pen = !is_cand(key);
+            if (ins_len > 0) {
+                if (ins_len > 0xffffu) return false;
+                const int32_t src = insert_src(key, head, ins_len);
+                if (src < 0) return false;
+                emit(SK_OP_BASES, ins_len, src, pen);
+            } else {
+                emit(SK_OP_NOBASE, 0, 0, pen);
+            }
+        } else if (seg_align_match(ps_type)) {
+            emit(SK_OP_BASES, ps_len, ref_head_pos - win_begin, false);
+        } else if (ps_type == SK_SEG_INSERT) {
+            const int key = matching(0, ps_len, path_index);
+            if (key < 0) return false;
+            int32_t head = 0;
+            if (path_index < ends_first) head = int32_t(tab(key).ins_len) - int32_t(ps_len);
+            const int32_t src = insert_src(key, head, ps_len);
+            if (src < 0) return false;
+            emit(SK_OP_BASES, ps_len, src, !is_cand(key));
+        } else if (ps_type == SK_SEG_DELETE) {
+            const int key = matching(ps_len, 0, path_index);
+            if (key < 0) return false;
+            emit(SK_OP_NOBASE, 0, 0, !is_cand(key));
+        } else if (ps_type == SK_SEG_SKIP || ps_type == SK_SEG_HARD_CLIP) {
+            // nothing
+        } else if (ps_type == SK_SEG_SOFT_CLIP) {
+            emit(SK_OP_SOFT_CLIP, ps_len, 0, false);
+        } else {
+            return false;
+        }
+        for (unsigned i = 0; i < n_seg; ++i) { // increment_path, align_path_util.hh:38-68
+            const unsigned ty = c.seg_type(path_index), ln = c.seg_len(path_index);
+            if (seg_align_match(ty)) {
+                read_offset += ln;
+                ref_head_pos += int32_t(ln);
+            } else if (ty == SK_SEG_DELETE || ty == SK_SEG_SKIP) {
+                ref_head_pos += int32_t(ln);
+            } else if (ty == SK_SEG_INSERT || ty == SK_SEG_SOFT_CLIP) {
+                read_offset += ln;
+            }
+            path_index++;
+        }
+    }
+    return int64_t(read_offset) == int64_t(read_len);
+}
 
 __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs fa)
 {
-    constexpr int REC_DW = int(sizeof(PCal) / 4), REC_STRIDE = REC_DW | 1;
-    __shared__ F5Lds S;
+    __shared__ __attribute__((aligned(16))) F5Lds S;
     const FlatArgs& a = fa.f;
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
     const int c0 = a.cal_off[r], c1 = a.cal_off[r + 1];
     const int ncr = c1 - c0;
     if (ncr == 0 || a.status[r] != ST_OK) return;
+    unsigned long long stamp[8];
+    stamp[0] = clock64();
+    for (int i = 1; i < 8; ++i) stamp[i] = 0;
     const int64_t ro = a.read_off[r];
     const int32_t L = int32_t(a.read_off[r + 1] - ro);
     const int32_t P = a.hap_len[r];
@@ -698,103 +851,90 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         if (lane == 0) atomicAdd(fa.n_unhandled, 1);
         return;
     }
-    // ---- the pool's bytes (as pool_fill_kernel) and the read
+    const int32_t win_begin = a.win_begin[r];
+    const int n_ins = a.n_ins[r];
+    // ---- the pool's bytes (as pool_fill_kernel), the read, its rows of terms, the pool's layout
     {
-        const int32_t wb = a.win_begin[r];
-        const int n_ins = a.n_ins[r];
         const int16_t* idx = a.ins_idx + size_t(r) * INS_CAP;
         const int32_t* off = a.ins_off + size_t(r) * INS_CAP;
+        if (lane < n_ins) {
+            S.ins_idx[lane] = idx[lane];
+            S.ins_off[lane] = off[lane];
+        }
         const int32_t win_len = a.win_len[r];
-        for (int32_t i = lane; i < P; i += 64) {
+        for (int32_t i = lane; i < P + 8; i += 64) {
             uint8_t v = SK_BAM_ANY;
-            if (i < win_len) {
-                const int32_t p = wb + i; // reference_contig_segment::get_base :46-51
-                v = (p < a.ref_offset || p >= a.ref_offset + a.ref_len) ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
-            }
-            for (int k = 0; k < n_ins; ++k) {
-                const PIndel& d = a.job.tab[idx[k]];
-                if (i >= off[k] && i < off[k] + int32_t(d.ins_len)) v = code_of(a.ins_pool[d.ins_off + uint32_t(i - off[k])]);
+            if (i < P) {
+                if (i < win_len) {
+                    const int32_t p = win_begin + i; // reference_contig_segment::get_base :46-51
+                    v = (p < a.ref_offset || p >= a.ref_offset + a.ref_len) ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
+                }
+                for (int k = 0; k < n_ins; ++k) {
+                    const PIndel& d = a.job.tab[idx[k]];
+                    if (i >= off[k] && i < off[k] + int32_t(d.ins_len)) v = code_of(a.ins_pool[d.ins_off + uint32_t(i - off[k])]);
+                }
             }
             S.hap[i] = v;
         }
         const SkTables* __restrict__ T = fa.tab;
-        for (int32_t i = lane; i < L; i += 64) {
-            S.read[i] = a.read_code[ro + i];
-            unsigned q = fa.read_qual[ro + i];
-            if (q > 70u) { // the reference throws (qscore_cache.cpp:53-75): flagged, sk_check_device_errors reports it
-                atomicOr(fa.err, unsigned(SK_DEVERR_QSCORE));
-                q = 70u;
+        for (int32_t i = lane; i < L + 8; i += 64) {
+            unsigned q = 0;
+            uint8_t code = SK_BAM_ANY;
+            if (i < L) {
+                code = a.read_code[ro + i];
+                q = fa.read_qual[ro + i];
+                if (q > 70u) { // the reference throws (qscore_cache.cpp:53-75): flagged, sk_check_device_errors reports it
+                    atomicOr(fa.err, unsigned(SK_DEVERR_QSCORE));
+                    q = 70u;
+                }
             }
-            S.agree[i] = T->q2lncompe[q];
-            S.differ[i] = T->q2mis[q];
+            S.read[i] = code;
+            S.row[F5_ROW * i] = T->q2lncompe[q];
+            S.row[F5_ROW * i + 1] = T->q2mis[q];
+            S.row[F5_ROW * i + 2] = 0.0;
         }
     }
     const double ln_quarter = fa.tab->ln_quarter, ln_noncand = fa.tab->ln_noncand;
-    {
-        const int n_ins = a.n_ins[r];
-        if (lane < n_ins) {
-            S.ins_idx[lane] = a.ins_idx[size_t(r) * INS_CAP + lane];
-            S.ins_off[lane] = a.ins_off[size_t(r) * INS_CAP + lane];
-        }
-        if (lane == 0) {
-            S.win_begin = a.win_begin[r];
-            S.n_ins = n_ins;
-        }
-    }
-    // flatten_cal and job_cand read `la`: the same arguments with the per-read and per-indel arrays rebased onto their LDS copies
-    // (element r of win_begin / n_ins / ins_idx / ins_off, elements [tab_lo, tab_lo + F5_TAB) of the indel table)
-    FlatArgs la = a;
-    la.win_begin = &S.win_begin - r;
-    la.n_ins = &S.n_ins - r;
-    la.ins_idx = S.ins_idx - size_t(r) * INS_CAP;
-    la.ins_off = S.ins_off - size_t(r) * INS_CAP;
 
     for (int j0 = 0; j0 < ncr; j0 += 64) {
         const int nc = min(64, ncr - j0);
-        __syncthreads(); // (pool and read complete; the previous round's records read)
-        // ---- the round's records: pool -> LDS (-> cals) as rows of consecutive dwords, sixteen records' loads in flight at a time
-        const int src_k = (lane < nc) ? a.list[c0 + j0 + lane] : 0;
-        for (int k0 = 0; k0 < nc; k0 += 16) {
-            uint32_t v0[16], v1[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = k0 + u;
-                const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(a.pool + __shfl(src_k, (k < nc) ? k : 0));
-                v0[u] = (k < nc) ? src[lane] : 0u;
-                v1[u] = (k < nc && lane + 64 < REC_DW) ? src[lane + 64] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = k0 + u;
-                if (k < nc) {
-                    S.cal[k * REC_STRIDE + lane] = v0[u];
-                    if (lane + 64 < REC_DW) S.cal[k * REC_STRIDE + lane + 64] = v1[u];
-                    if (fa.write_cals) {
-                        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.cals + (c0 + j0 + k));
-                        dst[lane] = v0[u];
-                        if (lane + 64 < REC_DW) dst[lane + 64] = v1[u];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- phase A, a lane per candidate alignment: the walk of its path (flatten_cal) leaves, instead of ops, the alignment's
-        // TRANSITIONS in the free tail of its own record's path array: one word per op that covers read positions (and one for the
-        // read's end) = start position | penalties that precede its terms << 9 | soft clip << 15 | (pool offset - position + 256) << 16
+        __syncthreads(); // (pool and read complete; the previous round's slots read)
+        const unsigned long long ta = clock64();
+        if (j0 == 0) stamp[1] = ta; // prologue done
+        // ---- the round's records, a lane its own: header + F5_SEGS path segments (five 16-byte loads) + F5_INDELS indel indices, all in
+        // flight at once; a record with more of either is left to the staged chain
         const bool has = lane < nc;
-        uint32_t* const myrec = S.cal + lane * REC_STRIDE;
+        uint32_t* const myslot = S.slot + lane * F5_SLOT;
+        bool fits = true;
+        if (has) {
+            const PCal* src = a.pool + a.list[c0 + j0 + lane];
+            const uint4* s4 = reinterpret_cast<const uint4*>(src);
+            const uint4 q0 = s4[0], q1 = s4[1], q2 = s4[2], q3 = s4[3], q4 = s4[4];
+            const uint32_t* si = reinterpret_cast<const uint32_t*>(src->indels);
+            const uint32_t i0 = si[0], i1 = si[1], i2 = si[2], i3 = si[3];
+            myslot[0] = q0.x; myslot[1] = q0.y; myslot[2] = q0.z; myslot[3] = q0.w;
+            myslot[4] = q1.x; myslot[5] = q1.y; myslot[6] = q1.z; myslot[7] = q1.w;
+            myslot[8] = q2.x; myslot[9] = q2.y; myslot[10] = q2.z; myslot[11] = q2.w;
+            myslot[12] = q3.x; myslot[13] = q3.y; myslot[14] = q3.z; myslot[15] = q3.w;
+            myslot[16] = q4.x; myslot[17] = q4.y; myslot[18] = q4.z;
+            myslot[F5_IND0] = i0; myslot[F5_IND0 + 1] = i1; myslot[F5_IND0 + 2] = i2; myslot[F5_IND0 + 3] = i3;
+            const unsigned nseg = (q0.z >> 8) & 0xffu, nind = (q0.z >> 16) & 0xffu;
+            fits = (nseg <= unsigned(F5_SEGS) && nind <= unsigned(F5_INDELS));
+        }
+        const F5Rec rec{ myslot };
+        // the table entries this round's alignments name
+        int tab_lo = 0;
         {
-            // the table entries this round's alignments name
             int lo = INT_MAX, hi = INT_MIN;
-            if (has) {
-                const PCal& cal = *reinterpret_cast<const PCal*>(myrec);
+            if (has && fits) {
                 auto add = [&](const int i) {
                     lo = min(lo, i);
                     hi = max(hi, i);
                 };
-                for (int i = 0; i < cal.n_indels; ++i) add(cal.indels[i]);
-                if (cal.lead >= 0) add(cal.lead);
-                if (cal.trail >= 0) add(cal.trail);
+                const int ni = rec.n_indels();
+                for (int i = 0; i < ni; ++i) add(rec.indel(i));
+                if (rec.lead() >= 0) add(rec.lead());
+                if (rec.trail() >= 0) add(rec.trail());
             }
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) {
@@ -802,27 +942,30 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                 hi = max(hi, __shfl_xor(hi, d));
             }
             const int n_tab = (lo <= hi) ? hi - lo + 1 : 0;
-            if (lo < 0 || n_tab > F5_TAB) { // (indices further apart than the copy holds: the staged chain takes the job)
+            // (a record beyond the compact form, indices further apart than the copy holds: the staged chain takes the job)
+            if (__any(has && !fits) || (n_tab > 0 && lo < 0) || n_tab > F5_TAB) {
                 if (lane == 0) atomicAdd(fa.n_unhandled, 1);
                 return;
             }
             constexpr int ENT_DW = int(sizeof(PIndel) / 4);
-            const uint32_t* __restrict__ gt = reinterpret_cast<const uint32_t*>(a.job.tab + (n_tab ? lo : 0));
+            tab_lo = n_tab ? lo : 0;
+            const uint32_t* __restrict__ gt = reinterpret_cast<const uint32_t*>(a.job.tab + tab_lo);
             for (int j = lane; j < n_tab * ENT_DW; j += 64) S.tab[j] = gt[j];
-            la.job.tab = reinterpret_cast<const PIndel*>(S.tab) - (n_tab ? lo : 0);
-            __syncthreads();
         }
+        __syncthreads();
+        const unsigned long long tc = clock64();
+        stamp[2] += tc - ta; // staging + table copy
+        // ---- phase A, a lane per candidate alignment: the walk of its path leaves the alignment's TRANSITIONS in its slot: one word per
+        // op that covers read positions, and one for the read's end
+        uint32_t* const ent = myslot + F5_ENT0;
         int n_ent = 0;
         bool bad = false;
         if (has) {
-            const PCal& cal = *reinterpret_cast<const PCal*>(myrec);
-            uint32_t* const ent = myrec + 3 + cal.n_seg; // (path[n_seg ..]: unused by this alignment)
-            const int ent_cap = int(Caps::P) - int(cal.n_seg);
             int pos = 0;
             unsigned npen = 0;
             auto put = [&](const unsigned at, const unsigned np, const bool clip, const int hidx) {
-                if (n_ent >= ent_cap || np > 63u || hidx < -256 || hidx > 3839) {
-                    bad = true; // (more transitions than the record's tail holds: the host form takes the read)
+                if (n_ent >= F5_ENTS || np > 63u || hidx < -256 || hidx > 3839) {
+                    bad = true; // (more transitions than the slot holds: the host form takes the read)
                     return;
                 }
                 ent[n_ent++] = at | (np << 9) | (clip ? 1u << 15 : 0u) | (unsigned(hidx + 256) << 16);
@@ -838,50 +981,68 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                     npen += penalty ? 1u : 0u;
                 }
             };
-            const int n = flatten_cal<false>(la, r, cal, L, nullptr, on_op);
-            if (n < 0 || pos != L) bad = true;
+            const bool ok = f5_walk(S, rec, tab_lo, n_ins, win_begin, a.job.consulted, L, on_op);
+            if (!ok || pos != L) bad = true;
             else put(unsigned(L), npen, false, 0); // trailing penalties
             // the candidate-status lookups the host form performs for every indel of the alignment (cal_to_c)
-            for (int i = 0; i < cal.n_indels; ++i) (void)job_cand(la.job, cal.indels[i]);
-            if (cal.lead >= 0) (void)job_cand(la.job, cal.lead);
-            if (cal.trail >= 0) (void)job_cand(la.job, cal.trail);
+            if (a.job.consulted) {
+                const int ni = rec.n_indels();
+                for (int i = 0; i < ni; ++i) a.job.consulted[rec.indel(i)] = 1;
+                if (rec.lead() >= 0) a.job.consulted[rec.lead()] = 1;
+                if (rec.trail() >= 0) a.job.consulted[rec.trail()] = 1;
+            }
             if (bad) a.status[r] = ST_FAIL;
         }
-        // ---- phase B, the wave in step over the read's positions: at a position where a lane's next transition starts it adds the
-        // transition's penalties, then a soft clip's length x ln 0.25 (path order, as score_one_generic); elsewhere the position's term
-        // -- agree or differ, by the pool byte the lane's current offset faces -- unless the read base is N or the lane is inside a clip
-        {
-            const uint32_t* const ent = myrec + 3 + (has ? int(reinterpret_cast<const PCal*>(myrec)->n_seg) : 0);
-            const bool live = has && !bad;
-            int e = 0;
-            uint32_t next = live ? ent[0] : 0x1ffu;           // (0x1ff: a position no read has)
-            int hidx = 0;
-            bool in_bases = false;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long td = clock64();
+        stamp[4] += td - tc; // phase A
+        // ---- phase B, a lane its alignment, op by op in path order (the order of score_one_generic): the penalties that precede the op,
+        // then a soft clip's length x ln 0.25, or the op's bases eight at a time -- eight read codes against the eight pool bytes they
+        // face (SWAR), each position's byte offset into its row {agree, differ, 0.0} (N, or past the op: 0.0), eight row reads, eight adds
+        if (has && !bad) {
             double lnp = 0.0;
-            for (int p = 0; p <= L; ++p) {
-                if (int(next & 0x1ffu) == p) {
-                    const uint32_t cur = next;
-                    ++e;
-                    next = (e < n_ent) ? ent[e] : 0x1ffu;
-                    const unsigned np = (cur >> 9) & 63u;
-                    for (unsigned k = 0; k < np; ++k) lnp = __dadd_rn(lnp, ln_noncand);
-                    if (cur & (1u << 15)) {
-                        lnp = __dadd_rn(lnp, __dmul_rn(double(unsigned(int(next & 0x1ffu) - p)), ln_quarter));
-                        in_bases = false;
-                    } else {
-                        hidx = int(cur >> 16) - 256;
-                        in_bases = true;
-                    }
+            constexpr uint64_t K01 = 0x0101010101010101ull, K0F = 0x0f0f0f0f0f0f0f0full, K7F = 0x7f7f7f7f7f7f7f7full, K71 = 0x7171717171717171ull;
+            for (int e = 0; e < n_ent; ++e) {
+                const uint32_t cur = ent[e];
+                const int start = int(cur & 0x1ffu);
+                const unsigned np = (cur >> 9) & 63u;
+                for (unsigned k = 0; k < np; ++k) lnp = __dadd_rn(lnp, ln_noncand);
+                if (e + 1 >= n_ent) break; // (the read's end)
+                const int stop = int(ent[e + 1] & 0x1ffu);
+                if (cur & (1u << 15)) {
+                    lnp = __dadd_rn(lnp, __dmul_rn(double(unsigned(stop - start)), ln_quarter));
+                    continue;
                 }
-                if (p < L) {
-                    const unsigned rc = S.read[p];
-                    const unsigned hc = S.hap[in_bases ? p + hidx : 0];
-                    const double term = ((rc == SK_BAM_REF) || (rc == hc)) ? S.agree[p] : S.differ[p];
-                    if (in_bases && rc != SK_BAM_ANY) lnp = __dadd_rn(lnp, term);
+                const int hidx = int(cur >> 16) - 256;
+                for (int p = start; p < stop; p += 8) {
+                    const int m = stop - p; // (>= 1; positions u >= m belong to the next op)
+                    uint64_t R, H;
+                    __builtin_memcpy(&R, S.read + p, 8);
+                    __builtin_memcpy(&H, S.hap + (p + hidx), 8);
+                    R &= K0F;
+                    H &= K0F;
+                    const uint64_t ne = (((R ^ H) + K7F) >> 7) & K01;  // 1: the bytes differ
+                    const uint64_t nz = ((R + K7F) >> 7) & K01;        // 1: the read base is not '='
+                    const uint64_t any = ((R + K71) >> 7) & K01;       // 1: the read base is N (code 15)
+                    const uint64_t live = (m >= 8) ? K01 : (K01 & ((uint64_t(1) << (8 * m)) - 1ull));
+                    const uint64_t none = any | (live ^ K01);
+                    const uint64_t differ = ne & nz & (none ^ K01);
+                    const uint64_t off = (none << 4) | (differ << 3); // byte u: 0 agree, 8 differ, 16 nothing
+                    const unsigned char* rb = reinterpret_cast<const unsigned char*>(S.row + F5_ROW * p);
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double*>(rb + 8 * F5_ROW * u + unsigned((off >> (8 * u)) & 0xffu));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) lnp = __dadd_rn(lnp, v[u]);
                 }
             }
-            if (live) fa.scores[c0 + j0 + lane] = lnp;
+            fa.scores[c0 + j0 + lane] = lnp;
         }
+        stamp[5] += clock64() - td; // phase B
+    }
+    if (fa.dbg && lane == 0) {
+        stamp[6] = clock64();
+        for (int i = 0; i < 8; ++i) fa.dbg[size_t(r) * 8 + i] = stamp[i];
     }
 }
 
@@ -1891,6 +2052,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         fs.err = ctx.dev_error_flags;
         fs.n_unhandled = B.counters.as<int32_t>() + (Caps::K + 7);
         fs.write_cals = 0;
+        fs.dbg = nullptr;
         hipLaunchKernelGGL(flatten_score_kernel, dim3(n), dim3(64), 0, st, fs);
         SK_HIP(hipGetLastError());
         lap("F5 flatten + score");
@@ -2054,6 +2216,36 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
     SK_HIP(hipEventCreate(&e0));
     SK_HIP(hipEventCreate(&e1));
     SK_HIP(hipEventRecord(e0, st));
+    if (g_last.fused && std::getenv("SK_F5_TIMING")) { // diagnostics: where a wave of F5 spends its cycles
+        FusedScoreArgs fs = g_last.fs;
+        const size_t nb = size_t(g_last.n) * 8;
+        unsigned long long* d = nullptr;
+        SK_HIP(hipMalloc(reinterpret_cast<void**>(&d), nb * 8));
+        SK_HIP(hipMemsetAsync(d, 0, nb * 8, st));
+        fs.dbg = d;
+        hipLaunchKernelGGL(flatten_score_kernel, dim3(g_last.n), dim3(64), 0, st, fs);
+        std::vector<unsigned long long> h(nb);
+        SK_HIP(hipMemcpyAsync(h.data(), d, nb * 8, hipMemcpyDeviceToHost, st));
+        SK_HIP(hipStreamSynchronize(st));
+        (void)hipFree(d);
+        double sum[8] = { 0 };
+        unsigned long long first = ~0ull, last = 0;
+        int nblk = 0;
+        for (int r = 0; r < g_last.n; ++r) {
+            const unsigned long long* s = &h[size_t(r) * 8];
+            if (s[6] == 0) continue;
+            ++nblk;
+            first = std::min(first, s[0]);
+            last = std::max(last, s[6]);
+            sum[0] += double(s[1] - s[0]);
+            for (int i = 2; i <= 5; ++i) sum[i] += double(s[i]);
+            sum[6] += double(s[6] - s[0]);
+        }
+        if (nblk)
+            std::fprintf(stderr, "[f5-timing] blocks %d: cycles per block: prologue %.0f staging %.0f table %.0f phaseA %.0f phaseB %.0f total %.0f; kernel span %llu cycles => %.1f blocks in flight\n",
+                         nblk, sum[0] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[5] / nblk, sum[6] / nblk, last - first,
+                         sum[6] / double(last - first));
+    }
     for (int i = 0; i < reps; ++i) {
         if (g_last.fused) { // F5: the records -> the scores in one launch
             hipLaunchKernelGGL(flatten_score_kernel, dim3(g_last.n), dim3(64), 0, st, g_last.fs);

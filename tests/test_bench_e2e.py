@@ -57,13 +57,13 @@ def test_e2e_leg_reports_the_first_difference(monkeypatch, tmp_path):
     assert os.path.exists(str(tmp_path / "kept" / ("germline_drop_in_" + fd["file"])))
 
 
-# ---- the legs at the configuration the metric is quoted on (what the driver's bench run does): 8 caller processes sharing one GPU, 2 Mb
+# ---- the legs at the configuration the metric is quoted on (what the driver's bench run does): 8 caller processes sharing one GPU, 4 Mb
 # segments, the workflow's command line with the EVS models on; BENCH_r03's germline leg failed exactly here while every smaller test passed
 @pytest.mark.gpu
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
 def test_e2e_germline_at_bench_configuration_identical_gpu():
     import bench
-    args = argparse.Namespace(e2e_bp=16000000, e2e_segment_bp=2000000, e2e_max_procs_per_gpu=8)
+    args = argparse.Namespace(e2e_bp=32000000, e2e_segment_bp=4000000, e2e_max_procs_per_gpu=8)
     out = bench.e2e_leg(args, 0, 1, 0, lambda: None, lambda v: v, with_reference=True)
     assert out["identical"] is True, out["first_difference"]
     assert out["segments"] == 8 and out["variant_records"] > 5000
