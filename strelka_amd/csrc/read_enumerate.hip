@@ -671,13 +671,14 @@ struct FusedScoreArgs
 // a candidate alignment as F5 keeps it in LDS: the used part of the PCal record, then the walk's transitions
 //   [0] pos   [1] lead | trail << 16   [2] fwd | n_seg << 8 | n_indels << 16   [3 .. 3+F5_SEGS) path   [.. +F5_INDELS/2) indels
 //   [F5_ENT0 ..) transitions: start position | penalties that precede the op's terms << 9 | soft clip << 15 | (pool offset - position + 256) << 16
-constexpr int F5_SEGS = 16, F5_INDELS = 8, F5_ENTS = 20;
+constexpr int F5_SEGS = 16, F5_INDELS = 8, F5_ENTS = 16;
 constexpr int F5_IND0 = 3 + F5_SEGS, F5_ENT0 = F5_IND0 + F5_INDELS / 2, F5_SLOT = (F5_ENT0 + F5_ENTS) | 1; // (odd stride: conflict-free)
-constexpr int F5_ROW = 3; // doubles per read position: agree, differ, 0.0 (a selector's byte offset picks one: score_cols_body's rows)
+constexpr int F5_ROW = 2; // doubles per read position: agree, differ (a position that adds nothing reads the shared 0.0 instead)
 
 struct F5Lds
 {
     double row[(F5_MAX_READ + 8) * F5_ROW];
+    double zero; // 0.0
     uint8_t read[F5_MAX_READ + 8];
     uint8_t hap[F5_MAX_POOL + 8];
     uint32_t slot[64 * F5_SLOT];
@@ -725,23 +726,39 @@ __device__ __forceinline__ bool f5_walk(F5Lds& S, const F5Rec c, const int tab_l
                 ends_second = i;
             }
     }
+    // the alignment's indels, read once (all at a time: two LDS round trips) -- getMatchingIndelKey below compares against registers
+    const int ni = c.n_indels();
+    int k_idx[F5_INDELS];
+    int32_t k_pos[F5_INDELS];
+    uint32_t k_del[F5_INDELS], k_ins[F5_INDELS];
+    bool k_kind[F5_INDELS];
+#pragma unroll
+    for (int k = 0; k < F5_INDELS; ++k) {
+        k_idx[k] = (k < ni) ? c.indel(k) : tab_lo;
+        const PIndel& ci = tab(k_idx[k]);
+        k_pos[k] = ci.pos;
+        k_del[k] = ci.del;
+        k_ins[k] = ci.ins_len;
+        k_kind[k] = (ci.type == SK_INDEL_INDEL || ci.type == SK_INDEL_MISMATCH);
+    }
     // getMatchingIndelKey, starling_read_align_score.cpp:177-228: table index, -1 = no key, -2 = inconsistent
     auto matching = [&](const unsigned del_len, const unsigned ins_len, const int path_index) -> int {
         if (path_index < ends_first) return c.lead();
         if (path_index > ends_second) return c.trail();
         int found = -1;
-        const int ni = c.n_indels();
-        for (int k = 0; k < ni; ++k) {
-            const int idx = c.indel(k);
-            const PIndel& ci = tab(idx);
-            if (ci.pos == ref_head_pos && (ci.type == SK_INDEL_INDEL || ci.type == SK_INDEL_MISMATCH) && ci.del == del_len && ci.ins_len == ins_len) {
-                if (found >= 0) return -2;
-                found = idx;
-            } else if (ci.pos > ref_head_pos) {
-                break;
+        bool twice = false, past = false; // (the reference returns at the second match and stops at the first later position)
+#pragma unroll
+        for (int k = 0; k < F5_INDELS; ++k) {
+            if (k < ni && !past && !twice) {
+                if (k_pos[k] == ref_head_pos && k_kind[k] && k_del[k] == del_len && k_ins[k] == ins_len) {
+                    if (found >= 0) twice = true;
+                    found = k_idx[k];
+                } else if (k_pos[k] > ref_head_pos) {
+                    past = true;
+                }
             }
         }
-        return found >= 0 ? found : -2;
+        return (twice || found < 0) ? -2 : found;
     };
     auto emit = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
         if (kind == SK_OP_NOBASE && !penalty) return;
@@ -877,6 +894,7 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
             S.hap[i] = v;
         }
         const SkTables* __restrict__ T = fa.tab;
+        if (lane == 0) S.zero = 0.0;
         for (int32_t i = lane; i < L + 8; i += 64) {
             unsigned q = 0;
             uint8_t code = SK_BAM_ANY;
@@ -891,7 +909,6 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
             S.read[i] = code;
             S.row[F5_ROW * i] = T->q2lncompe[q];
             S.row[F5_ROW * i + 1] = T->q2mis[q];
-            S.row[F5_ROW * i + 2] = 0.0;
         }
     }
     const double ln_quarter = fa.tab->ln_quarter, ln_noncand = fa.tab->ln_noncand;
@@ -996,25 +1013,34 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         __builtin_amdgcn_wave_barrier();
         const unsigned long long td = clock64();
         stamp[4] += td - tc; // phase A
-        // ---- phase B, a lane its alignment, op by op in path order (the order of score_one_generic): the penalties that precede the op,
-        // then a soft clip's length x ln 0.25, or the op's bases eight at a time -- eight read codes against the eight pool bytes they
-        // face (SWAR), each position's byte offset into its row {agree, differ, 0.0} (N, or past the op: 0.0), eight row reads, eight adds
+        // ---- phase B, a lane its alignment, in path order (the order of score_one_generic): entering an op, the penalties that precede
+        // its terms, then a soft clip's length x ln 0.25; inside an op of bases, eight positions per turn -- eight read codes against the
+        // eight pool bytes they face (SWAR), each position's address: its row's agree or differ term, or the shared 0.0 (N, or past the
+        // op's end) -- eight reads, eight adds.  ONE loop per lane (an op's start, eight bases and the step to the next op in the same
+        // turn), so that the turns a wave makes are the longest lane's, not the sum over ops of the longest op
         if (has && !bad) {
             double lnp = 0.0;
             constexpr uint64_t K01 = 0x0101010101010101ull, K0F = 0x0f0f0f0f0f0f0f0full, K7F = 0x7f7f7f7f7f7f7f7full, K71 = 0x7171717171717171ull;
-            for (int e = 0; e < n_ent; ++e) {
-                const uint32_t cur = ent[e];
-                const int start = int(cur & 0x1ffu);
-                const unsigned np = (cur >> 9) & 63u;
-                for (unsigned k = 0; k < np; ++k) lnp = __dadd_rn(lnp, ln_noncand);
-                if (e + 1 >= n_ent) break; // (the read's end)
-                const int stop = int(ent[e + 1] & 0x1ffu);
-                if (cur & (1u << 15)) {
-                    lnp = __dadd_rn(lnp, __dmul_rn(double(unsigned(stop - start)), ln_quarter));
-                    continue;
+            const unsigned zero_at = unsigned(reinterpret_cast<const unsigned char*>(&S.zero) - reinterpret_cast<const unsigned char*>(S.row));
+            int e = 0;
+            uint32_t cur = ent[0], nxt = ent[(n_ent > 1) ? 1 : 0];
+            int p = 0, stop = 0, hidx = 0;
+            bool entering = true;
+            for (;;) {
+                if (entering) {
+                    const unsigned np = (cur >> 9) & 63u;
+                    for (unsigned k = 0; k < np; ++k) lnp = __dadd_rn(lnp, ln_noncand);
+                    if (e + 1 >= n_ent) break; // (the read's end)
+                    p = int(cur & 0x1ffu);
+                    stop = int(nxt & 0x1ffu);
+                    if (cur & (1u << 15)) {
+                        lnp = __dadd_rn(lnp, __dmul_rn(double(unsigned(stop - p)), ln_quarter));
+                        p = stop;
+                    }
+                    hidx = int(cur >> 16) - 256;
+                    entering = false;
                 }
-                const int hidx = int(cur >> 16) - 256;
-                for (int p = start; p < stop; p += 8) {
+                if (p < stop) {
                     const int m = stop - p; // (>= 1; positions u >= m belong to the next op)
                     uint64_t R, H;
                     __builtin_memcpy(&R, S.read + p, 8);
@@ -1026,14 +1052,24 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                     const uint64_t any = ((R + K71) >> 7) & K01;       // 1: the read base is N (code 15)
                     const uint64_t live = (m >= 8) ? K01 : (K01 & ((uint64_t(1) << (8 * m)) - 1ull));
                     const uint64_t none = any | (live ^ K01);
-                    const uint64_t differ = ne & nz & (none ^ K01);
-                    const uint64_t off = (none << 4) | (differ << 3); // byte u: 0 agree, 8 differ, 16 nothing
-                    const unsigned char* rb = reinterpret_cast<const unsigned char*>(S.row + F5_ROW * p);
+                    const uint64_t differ = ne & nz;
+                    const unsigned char* rows = reinterpret_cast<const unsigned char*>(S.row);
+                    const unsigned base = unsigned(8 * F5_ROW * p);
                     double v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double*>(rb + 8 * F5_ROW * u + unsigned((off >> (8 * u)) & 0xffu));
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned at = ((none >> (8 * u)) & 1u) ? zero_at : base + unsigned(8 * F5_ROW * u) + (unsigned((differ >> (8 * u)) & 1u) << 3);
+                        v[u] = *reinterpret_cast<const double*>(rows + at);
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) lnp = __dadd_rn(lnp, v[u]);
+                    p += 8;
+                }
+                if (p >= stop) { // on to the next op (its entry was read a whole op ago)
+                    ++e;
+                    cur = nxt;
+                    nxt = ent[(e + 1 < n_ent) ? e + 1 : e];
+                    entering = true;
                 }
             }
             fa.scores[c0 + j0 + lane] = lnp;
@@ -2240,6 +2276,23 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
             sum[0] += double(s[1] - s[0]);
             for (int i = 2; i <= 5; ++i) sum[i] += double(s[i]);
             sum[6] += double(s[6] - s[0]);
+        }
+        for (const int grid : { 64, 256, 512, 1024, 1792, 2048, 4096 }) { // how the kernel's time grows with the blocks in flight
+            if (grid > g_last.n) break;
+            hipEvent_t a0, a1;
+            SK_HIP(hipEventCreate(&a0));
+            SK_HIP(hipEventCreate(&a1));
+            FusedScoreArgs f2 = g_last.fs;
+            hipLaunchKernelGGL(flatten_score_kernel, dim3(grid), dim3(64), 0, st, f2);
+            SK_HIP(hipEventRecord(a0, st));
+            for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(flatten_score_kernel, dim3(grid), dim3(64), 0, st, f2);
+            SK_HIP(hipEventRecord(a1, st));
+            SK_HIP(hipEventSynchronize(a1));
+            float ms = 0;
+            SK_HIP(hipEventElapsedTime(&ms, a0, a1));
+            std::fprintf(stderr, "[f5-timing] grid %d blocks: %.1f us per launch\n", grid, ms * 1000.f / 5.f);
+            (void)hipEventDestroy(a0);
+            (void)hipEventDestroy(a1);
         }
         if (nblk)
             std::fprintf(stderr, "[f5-timing] blocks %d: cycles per block: prologue %.0f staging %.0f table %.0f phaseA %.0f phaseB %.0f total %.0f; kernel span %llu cycles => %.1f blocks in flight\n",
