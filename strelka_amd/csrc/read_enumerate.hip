@@ -981,7 +981,7 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
             int pos = 0;
             unsigned npen = 0;
             auto put = [&](const unsigned at, const unsigned np, const bool clip, const int hidx) {
-                if (n_ent >= F5_ENTS || np > 63u || hidx < -256 || hidx > 3839) {
+                if (n_ent >= F5_ENTS || np > 4u || hidx < -256 || hidx > 3839) {
                     bad = true; // (more transitions than the slot holds: the host form takes the read)
                     return;
                 }
@@ -1022,26 +1022,13 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
             double lnp = 0.0;
             constexpr uint64_t K01 = 0x0101010101010101ull, K0F = 0x0f0f0f0f0f0f0f0full, K7F = 0x7f7f7f7f7f7f7f7full, K71 = 0x7171717171717171ull;
             const unsigned zero_at = unsigned(reinterpret_cast<const unsigned char*>(&S.zero) - reinterpret_cast<const unsigned char*>(S.row));
-            int e = 0;
-            uint32_t cur = ent[0], nxt = ent[(n_ent > 1) ? 1 : 0];
-            int p = 0, stop = 0, hidx = 0;
-            bool entering = true;
+            // (the eight-base step comes first and unconditionally -- a lane between ops steps over zero bases, eight times + 0.0 --
+            // so that the loop stays ONE loop: with the step behind a test the compiler nests a loop over an op's steps inside a
+            // loop over ops, and a wave then makes, per op, the steps of the lane with the longest op)
+            int e = 0, p = 0, stop = 0, hidx = 0;
             for (;;) {
-                if (entering) {
-                    const unsigned np = (cur >> 9) & 63u;
-                    for (unsigned k = 0; k < np; ++k) lnp = __dadd_rn(lnp, ln_noncand);
-                    if (e + 1 >= n_ent) break; // (the read's end)
-                    p = int(cur & 0x1ffu);
-                    stop = int(nxt & 0x1ffu);
-                    if (cur & (1u << 15)) {
-                        lnp = __dadd_rn(lnp, __dmul_rn(double(unsigned(stop - p)), ln_quarter));
-                        p = stop;
-                    }
-                    hidx = int(cur >> 16) - 256;
-                    entering = false;
-                }
-                if (p < stop) {
-                    const int m = stop - p; // (>= 1; positions u >= m belong to the next op)
+                {
+                    const int m = stop - p; // bases of the current op still to add (0: between ops)
                     uint64_t R, H;
                     __builtin_memcpy(&R, S.read + p, 8);
                     __builtin_memcpy(&H, S.hap + (p + hidx), 8);
@@ -1063,14 +1050,31 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) lnp = __dadd_rn(lnp, v[u]);
-                    p += 8;
+                    p += (m > 8) ? 8 : m;
                 }
-                if (p >= stop) { // on to the next op (its entry was read a whole op ago)
-                    ++e;
-                    cur = nxt;
-                    nxt = ent[(e + 1 < n_ent) ? e + 1 : e];
-                    entering = true;
-                }
+                // the op is done (or none begun yet): enter the next one -- by selects, not branches: the loop has one back edge
+                const bool adv = (p >= stop);
+                const uint32_t cur = ent[e];
+                const int e1 = (e + 1 < n_ent) ? e + 1 : e;
+                const int next_start = int(ent[e1] & 0x1ffu);
+                const unsigned np = adv ? ((cur >> 9) & 63u) : 0u; // (at most 4: put() hands anything longer to the host form)
+                const double l1 = __dadd_rn(lnp, ln_noncand);
+                lnp = (np >= 1u) ? l1 : lnp;
+                const double l2 = __dadd_rn(lnp, ln_noncand);
+                lnp = (np >= 2u) ? l2 : lnp;
+                const double l3 = __dadd_rn(lnp, ln_noncand);
+                lnp = (np >= 3u) ? l3 : lnp;
+                const double l4 = __dadd_rn(lnp, ln_noncand);
+                lnp = (np >= 4u) ? l4 : lnp;
+                if (adv && e + 1 >= n_ent) break; // (the read's end)
+                const int start = int(cur & 0x1ffu);
+                const bool clip = adv && (cur & (1u << 15)) != 0u;
+                const double lc = __dadd_rn(lnp, __dmul_rn(double(unsigned(next_start - start)), ln_quarter));
+                lnp = clip ? lc : lnp;
+                p = adv ? (clip ? next_start : start) : p;
+                stop = adv ? next_start : stop;
+                hidx = adv ? int(cur >> 16) - 256 : hidx;
+                e = adv ? e1 : e;
             }
             fa.scores[c0 + j0 + lane] = lnp;
         }
