@@ -684,7 +684,8 @@ struct F5Lds
     uint32_t slot[64 * F5_SLOT];
     // what the walk looks up per path segment (a chain of dependent look-ups: from HBM / L2 they cost a wave ~100 us per round)
     uint32_t tab[F5_TAB * (sizeof(PIndel) / 4)];
-    int32_t ins_off[INS_CAP];
+    int32_t ins_off[INS_CAP], ins_len[INS_CAP];
+    uint32_t ins_src[INS_CAP];
     int16_t ins_idx[INS_CAP];
 };
 
@@ -786,53 +787,51 @@ __device__ __forceinline__ bool f5_walk(F5Lds& S, const F5Rec c, const int tab_l
         }
         unsigned n_seg = 1;
         const unsigned ps_type = c.seg_type(path_index), ps_len = c.seg_len(path_index);
-        if (is_swap_start || ps_type == SK_SEG_SEQ_MISMATCH) {
-            unsigned del_len, ins_len;
-            if (ps_type == SK_SEG_SEQ_MISMATCH) {
-                del_len = ins_len = ps_len;
-            } else { // swap_info, align_path_util.hh:75-106
+        // The four kinds of segment that stand for a table indel -- a swap (insert + delete run), a sequence mismatch, an insert, a
+        // delete -- differ in the two lengths the key is looked up with and in nothing else (:296-420 treat them in four branches
+        // with the same steps); ONE code site for them: lanes at different kinds of indel segment then run it together
+        const bool is_indel_seg = is_swap_start || ps_type == SK_SEG_SEQ_MISMATCH || ps_type == SK_SEG_INSERT || ps_type == SK_SEG_DELETE;
+        // (... and one site where the segment's op leaves for the sink)
+        uint8_t op_kind = SK_OP_NOBASE;
+        uint32_t op_len = 0;
+        int32_t op_src = 0;
+        bool op_pen = false;
+        if (is_indel_seg) {
+            unsigned del_len = 0, ins_len = 0;
+            if (is_swap_start) { // swap_info, align_path_util.hh:75-106
                 int k = path_index;
-                del_len = ins_len = 0;
                 for (; k < aps && (c.seg_type(k) == SK_SEG_INSERT || c.seg_type(k) == SK_SEG_DELETE); ++k) {
                     if (c.seg_type(k) == SK_SEG_INSERT) ins_len += c.seg_len(k);
                     else del_len += c.seg_len(k);
                 }
                 n_seg = unsigned(k - path_index);
+            } else {
+                del_len = (ps_type == SK_SEG_INSERT) ? 0u : ps_len;
+                ins_len = (ps_type == SK_SEG_DELETE) ? 0u : ps_len;
             }
             const int key = matching(del_len, ins_len, path_index);
             if (key < 0) return false;
             int32_t head = 0;
             if (path_index < ends_first) head = int32_t(tab(key).ins_len) - int32_t(ps_len);
-            const bool pen = !is_cand(key);
+            op_pen = !is_cand(key);
             if (ins_len > 0) {
                 if (ins_len > 0xffffu) return false;
-                const int32_t src = insert_src(key, head, ins_len);
-                if (src < 0) return false;
-                emit(SK_OP_BASES, ins_len, src, pen);
-            } else {
-                emit(SK_OP_NOBASE, 0, 0, pen);
+                op_src = insert_src(key, head, ins_len);
+                if (op_src < 0) return false;
+                op_kind = SK_OP_BASES;
+                op_len = ins_len;
             }
         } else if (seg_align_match(ps_type)) {
-            emit(SK_OP_BASES, ps_len, ref_head_pos - win_begin, false);
-        } else if (ps_type == SK_SEG_INSERT) {
-            const int key = matching(0, ps_len, path_index);
-            if (key < 0) return false;
-            int32_t head = 0;
-            if (path_index < ends_first) head = int32_t(tab(key).ins_len) - int32_t(ps_len);
-            const int32_t src = insert_src(key, head, ps_len);
-            if (src < 0) return false;
-            emit(SK_OP_BASES, ps_len, src, !is_cand(key));
-        } else if (ps_type == SK_SEG_DELETE) {
-            const int key = matching(ps_len, 0, path_index);
-            if (key < 0) return false;
-            emit(SK_OP_NOBASE, 0, 0, !is_cand(key));
-        } else if (ps_type == SK_SEG_SKIP || ps_type == SK_SEG_HARD_CLIP) {
-            // nothing
+            op_kind = SK_OP_BASES;
+            op_len = ps_len;
+            op_src = ref_head_pos - win_begin;
         } else if (ps_type == SK_SEG_SOFT_CLIP) {
-            emit(SK_OP_SOFT_CLIP, ps_len, 0, false);
-        } else {
+            op_kind = SK_OP_SOFT_CLIP;
+            op_len = ps_len;
+        } else if (!(ps_type == SK_SEG_SKIP || ps_type == SK_SEG_HARD_CLIP)) {
             return false;
         }
+        emit(op_kind, op_len, op_src, op_pen); // (a NOBASE op without a penalty is dropped there: skips, hard clips)
         for (unsigned i = 0; i < n_seg; ++i) { // increment_path, align_path_util.hh:38-68
             const unsigned ty = c.seg_type(path_index), ln = c.seg_len(path_index);
             if (seg_align_match(ty)) {
@@ -875,23 +874,28 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         const int16_t* idx = a.ins_idx + size_t(r) * INS_CAP;
         const int32_t* off = a.ins_off + size_t(r) * INS_CAP;
         if (lane < n_ins) {
-            S.ins_idx[lane] = idx[lane];
+            const int t_idx = idx[lane];
+            S.ins_idx[lane] = int16_t(t_idx);
             S.ins_off[lane] = off[lane];
+            S.ins_len[lane] = int32_t(a.job.tab[t_idx].ins_len);
+            S.ins_src[lane] = a.job.tab[t_idx].ins_off;
         }
         const int32_t win_len = a.win_len[r];
+        // (the window's bytes first: they do not depend on the insert table just written)
         for (int32_t i = lane; i < P + 8; i += 64) {
             uint8_t v = SK_BAM_ANY;
-            if (i < P) {
-                if (i < win_len) {
-                    const int32_t p = win_begin + i; // reference_contig_segment::get_base :46-51
-                    v = (p < a.ref_offset || p >= a.ref_offset + a.ref_len) ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
-                }
-                for (int k = 0; k < n_ins; ++k) {
-                    const PIndel& d = a.job.tab[idx[k]];
-                    if (i >= off[k] && i < off[k] + int32_t(d.ins_len)) v = code_of(a.ins_pool[d.ins_off + uint32_t(i - off[k])]);
-                }
+            if (i < win_len) {
+                const int32_t p = win_begin + i; // reference_contig_segment::get_base :46-51
+                v = (p < a.ref_offset || p >= a.ref_offset + a.ref_len) ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
             }
             S.hap[i] = v;
+        }
+        __syncthreads();
+        for (int k = 0; k < n_ins; ++k) { // the insert sequences, in table order (a later one overwrites an earlier one, as pool_fill_kernel)
+            const int32_t o = S.ins_off[k], n = S.ins_len[k];
+            const uint32_t src = S.ins_src[k];
+            for (int32_t i = lane; i < n; i += 64)
+                if (o + i < P) S.hap[o + i] = code_of(a.ins_pool[src + uint32_t(i)]);
         }
         const SkTables* __restrict__ T = fa.tab;
         if (lane == 0) S.zero = 0.0;
