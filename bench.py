@@ -306,7 +306,8 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
 def a5_leg(args, capi, synth):
     """Row a5 measured as ONE function, like the reference's (scoreCandidateAlignment, starling_read_align_score.cpp:261-499):
     from the candidate alignments as the search left them on the device (position, path, indel indices: PCal) to one double each --
-    the haplotype bytes an alignment faces, its ops, every base comparison (kernels F1-F3) AND the table sums (A1c).  150 bp reads
+    the haplotype bytes an alignment faces, the walk of its path, every base comparison and the sums: kernel F5 (flatten_score_kernel;
+    with $SK_A5_FUSED=0 the staged chain F1-F3 + A1c it replaced).  150 bp reads
     over a window with 5-7 candidate indels (the densest of a dozen seeded scenarios); the job is enumerated on the device once,
     outside the clock; a step = sk_realign_job_rescore(1): flattening + scoring of the resident records, timed by stream events.
     -> (step function, per-step meta, list the step appends its event milliseconds to)"""
@@ -377,7 +378,7 @@ def pmc_traffic(args):
         return {}
     out = {k: v["hbm_bytes_per_launch"] for k, v in d.get("kernels", {}).items()}
     a5 = d.get("a5_only")
-    if a5 and a5.get("workload", {}).get("a5_scenarios") == args.a5_scenarios:
+    if a5 and a5.get("workload", {}).get("a5_scenarios") == args.a5_scenarios and a5.get("workload", {}).get("a5_reads") == args.a5_reads:
         out["__a5_step__"] = a5["hbm_bytes_per_step"]
     return out
 
@@ -660,7 +661,7 @@ def main():
         "config": {"workload": "germline chr20-style synthetic (BASELINE.json configs[1]).  Headline: scoreCandidateAlignment as one "
                                "function -- per GPU per step %d reads of 150 bp x %.1f candidate alignments each (5-7 candidate indels "
                                "around them), from the candidate alignments the device search left (PCal) to one double each: "
-                               "flattening (F1-F3: haplotype bytes, ops, base comparisons) + table sums (A1c).  sum_only: the table "
+                               "one kernel (F5: the walk of each alignment's path + the terms of its bases, penalties and clips).  sum_only: the table "
                                "sums alone over %d reads x 64 candidate alignments whose base comparisons were made before the clock "
                                "started (round 2's headline).  loci leg: %d loci, depth~Poisson(40).  e2e: see e2e.workload"
                                % (a5_meta["reads"], a5_meta["candidate_alignments_per_read"], da.n_reads, db.n_loci),
@@ -700,7 +701,7 @@ def main():
         "global_align_cells_per_s": ga_cells / dt_ga, "global_align_ms_per_step": dt_ga / args.steps * 1e3,
         "global_align_problems_per_step": n_ga,
         "loci_per_s": loci_per_s, "loci_ms_per_step": dt_b / args.steps * 1e3, "loci_dtype": "f32",
-        "roofline": roof("pool_fill_kernel+flatten_kernel+entries_wave_kernel+score_wave_per_read_cols (flattening + scoring)",
+        "roofline": roof("flatten_score_kernel (F5: flattening + scoring of a read's candidate alignments in one launch)",
                          a5_meta["algorithmic_bytes"], kms_a5, traffic.get("__a5_step__")),
         "roofline_sum_only": roof("score_wave_per_read_cols", alg_bytes_a, kms_a, traffic.get("score_wave_per_read_cols")),
         "roofline_loci": roof("germline_site_fused_kernel", alg_bytes_b, kms_b, traffic.get("germline_site_fused_kernel")),
@@ -711,8 +712,9 @@ def main():
                                             "prices: frac says nothing here")
     out["roofline_feed"]["note"] = ("a serial bit stream per block: the traffic is the matches' sources (a lane's 32 KB window, 1.3e5 lanes) "
                                     "and its partial-line stores, DESIGN.md section 3 B1")
-    out["roofline"]["note"] = ("flattening + scoring of one job; `traffic` from the --only a5 counter passes (tools/gpu_round.sh); the table sums "
-                               "alone are roofline_sum_only")
+    out["roofline"]["note"] = ("scoreCandidateAlignment as one kernel, from the records the device search left to one double each; `traffic` from the "
+                               "--only a5 counter passes (tools/gpu_visit.sh pmc_traffic); the table sums alone over a prepared batch are roofline_sum_only; "
+                               "the staged chain it replaced (F1-F3 + A1c, $SK_A5_FUSED=0) is 2.8x slower on this job (profiles/r04_*)")
     out["e2e"] = e2e
     out["e2e_somatic"] = e2e_somatic
     if rank == 0:

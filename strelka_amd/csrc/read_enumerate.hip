@@ -1002,7 +1002,10 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                     npen += penalty ? 1u : 0u;
                 }
             };
+            const unsigned long long tA0 = clock64();
             const bool ok = f5_walk(S, rec, tab_lo, n_ins, win_begin, a.job.consulted, L, on_op);
+            const unsigned long long tA1 = clock64();
+            stamp[7] += tA1 - tA0; // the walk
             if (!ok || pos != L) bad = true;
             else put(unsigned(L), npen, false, 0); // trailing penalties
             // the candidate-status lookups the host form performs for every indel of the alignment (cal_to_c)
@@ -1013,6 +1016,7 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                 if (rec.trail() >= 0) a.job.consulted[rec.trail()] = 1;
             }
             if (bad) a.status[r] = ST_FAIL;
+            stamp[3] += clock64() - tA1; // candidate-status marks
         }
         __builtin_amdgcn_wave_barrier();
         const unsigned long long td = clock64();
@@ -1024,7 +1028,6 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         // turn), so that the turns a wave makes are the longest lane's, not the sum over ops of the longest op
         if (has && !bad) {
             double lnp = 0.0;
-            constexpr uint64_t K01 = 0x0101010101010101ull, K0F = 0x0f0f0f0f0f0f0f0full, K7F = 0x7f7f7f7f7f7f7f7full, K71 = 0x7171717171717171ull;
             const unsigned zero_at = unsigned(reinterpret_cast<const unsigned char*>(&S.zero) - reinterpret_cast<const unsigned char*>(S.row));
             // (the eight-base step comes first and unconditionally -- a lane between ops steps over zero bases, eight times + 0.0 --
             // so that the loop stays ONE loop: with the step behind a test the compiler nests a loop over an op's steps inside a
@@ -1033,23 +1036,31 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
             for (;;) {
                 {
                     const int m = stop - p; // bases of the current op still to add (0: between ops)
-                    uint64_t R, H;
-                    __builtin_memcpy(&R, S.read + p, 8);
-                    __builtin_memcpy(&H, S.hap + (p + hidx), 8);
-                    R &= K0F;
-                    H &= K0F;
-                    const uint64_t ne = (((R ^ H) + K7F) >> 7) & K01;  // 1: the bytes differ
-                    const uint64_t nz = ((R + K7F) >> 7) & K01;        // 1: the read base is not '='
-                    const uint64_t any = ((R + K71) >> 7) & K01;       // 1: the read base is N (code 15)
-                    const uint64_t live = (m >= 8) ? K01 : (K01 & ((uint64_t(1) << (8 * m)) - 1ull));
-                    const uint64_t none = any | (live ^ K01);
-                    const uint64_t differ = ne & nz;
-                    const unsigned char* rows = reinterpret_cast<const unsigned char*>(S.row);
+                    // (32-bit halves: positions 0-3, 4-7; every byte holds a 4-bit code, so a byte-wise add never carries across bytes)
+                    uint32_t R[2], H[2];
+                    __builtin_memcpy(R, S.read + p, 8);
+                    __builtin_memcpy(H, S.hap + (p + hidx), 8);
+                    constexpr uint32_t B01 = 0x01010101u, B0F = 0x0f0f0f0fu, B7F = 0x7f7f7f7fu, B71 = 0x71717171u;
+                    const int mh = m - 4;
+                    const uint32_t live[2] = { (m >= 4) ? B01 : (B01 & ((1u << (8 * (m > 0 ? m : 0))) - 1u)),
+                                               (mh >= 4) ? B01 : ((mh > 0) ? (B01 & ((1u << (8 * mh)) - 1u)) : 0u) };
+                    uint32_t none[2], dif8[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t r = R[h] & B0F, q = H[h] & B0F;
+                        const uint32_t ne = (((r ^ q) + B7F) >> 7) & B01; // 1: the bytes differ
+                        const uint32_t nz = ((r + B7F) >> 7) & B01;       // 1: the read base is not '='
+                        const uint32_t any = ((r + B71) >> 7) & B01;      // 1: the read base is N (code 15)
+                        none[h] = any | (live[h] ^ B01);
+                        dif8[h] = (ne & nz) << 3;                         // per byte: 8 = the differ term, 0 = the agree term
+                    }
                     const unsigned base = unsigned(8 * F5_ROW * p);
+                    const unsigned char* rows = reinterpret_cast<const unsigned char*>(S.row);
                     double v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const unsigned at = ((none >> (8 * u)) & 1u) ? zero_at : base + unsigned(8 * F5_ROW * u) + (unsigned((differ >> (8 * u)) & 1u) << 3);
+                        const unsigned nb = (none[u >> 2] >> (8 * (u & 3))) & 0xffu, db = (dif8[u >> 2] >> (8 * (u & 3))) & 0xffu;
+                        const unsigned at = nb ? zero_at : base + unsigned(8 * F5_ROW * u) + db;
                         v[u] = *reinterpret_cast<const double*>(rows + at);
                     }
 #pragma unroll
@@ -2283,6 +2294,7 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
             last = std::max(last, s[6]);
             sum[0] += double(s[1] - s[0]);
             for (int i = 2; i <= 5; ++i) sum[i] += double(s[i]);
+            sum[7] += double(s[7]);
             sum[6] += double(s[6] - s[0]);
         }
         for (const int grid : { 64, 256, 512, 1024, 1792, 2048, 4096 }) { // how the kernel's time grows with the blocks in flight
@@ -2303,8 +2315,8 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
             (void)hipEventDestroy(a1);
         }
         if (nblk)
-            std::fprintf(stderr, "[f5-timing] blocks %d: cycles per block: prologue %.0f staging %.0f table %.0f phaseA %.0f phaseB %.0f total %.0f; kernel span %llu cycles => %.1f blocks in flight\n",
-                         nblk, sum[0] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[5] / nblk, sum[6] / nblk, last - first,
+            std::fprintf(stderr, "[f5-timing] blocks %d: cycles per block: prologue %.0f staging %.0f marks %.0f phaseA %.0f (walk %.0f) phaseB %.0f total %.0f; kernel span %llu cycles => %.1f blocks in flight\n",
+                         nblk, sum[0] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[7] / nblk, sum[5] / nblk, sum[6] / nblk, last - first,
                          sum[6] / double(last - first));
     }
     for (int i = 0; i < reps; ++i) {

@@ -84,7 +84,9 @@ a5 = collect("pmc_a5_")
 a5_only = None
 step_kernels = ("pool_fill_kernel", "flatten_kernel", "entries_wave_kernel", "score_wave_per_read_cols_hostbuf", "score_wave_per_read_cols")
 if a5:
+    if "flatten_score_kernel" in a5:  # F5: a step is one launch of the fused kernel
+        step_kernels = ("flatten_score_kernel",)
     per_step = sum(a5[k]["hbm_bytes_per_launch"] for k in step_kernels if k in a5)
-    a5_only = dict(workload=dict(a5_scenarios=a.a5_scenarios), hbm_bytes_per_step=per_step,
+    a5_only = dict(workload=dict(a5_scenarios=a.a5_scenarios, a5_reads=a.a5_reads), hbm_bytes_per_step=per_step,
                    kernels={k: a5[k] for k in step_kernels if k in a5})
 json.dump(dict(workload=workload, kernels=out, a5_only=a5_only), sys.stdout, indent=1)
