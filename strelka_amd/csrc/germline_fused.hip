@@ -609,7 +609,7 @@ struct G3Cfg
 {
     static constexpr int CAP = (CAP_CALLS * LOCI) / 128;
     static constexpr int POOL = (V0R_POOL * LOCI) / 128;
-    static constexpr int PEND = 4 * LOCI;
+    static constexpr int PEND = POOL; // (every pooled term may be pending -- pileups made of reads carry the neighbouring-mismatch flag in runs)
     // a list entry = pool slot | q << QSHIFT: 16 bits while the pool has at most 1024 slots
     static constexpr int QSHIFT = (POOL <= 1024) ? 10 : 16;
     typedef typename std::conditional<(POOL <= 1024), uint16_t, uint32_t>::type pend_t;

@@ -1709,8 +1709,10 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     const int64_t n_bases = n ? in->read_off[n] : 0;
     // capacities: calls in flight at one depth and leaves found (before duplicates are dropped), for the whole job; a job that
     // needs more has the reads that did not fit enumerated on the host
-    int64_t frame_cap = std::min<int64_t>(std::max<int64_t>(int64_t(n) * 128, 1 << 18), 1 << 21);
-    int64_t pool_cap = std::min<int64_t>(std::max<int64_t>(int64_t(n) * 512, 1 << 19), int64_t(8) << 20);
+    // (sized by the job; the ceilings -- two level buffers of 2^23 frames, 2^25 leaves: ~21 GB in all -- are a fraction of 288 GB of HBM
+    // and let a job of 2^16 reads with ~90 candidate alignments each run whole)
+    int64_t frame_cap = std::min<int64_t>(std::max<int64_t>(int64_t(n) * 128, 1 << 18), 1 << 23);
+    int64_t pool_cap = std::min<int64_t>(std::max<int64_t>(int64_t(n) * 512, 1 << 19), int64_t(32) << 20);
     if (const char* e = std::getenv("SK_ENUM_TEST_CAPS")) { // tests: small capacities, so that the overflow paths run
         long long fc = 0, pc = 0;
         if (std::sscanf(e, "%lld,%lld", &fc, &pc) == 2 && fc > 0 && pc > 0) {
