@@ -52,7 +52,9 @@ def parse():
     ap.add_argument("--indels", type=int, default=1 << 18, help="indel loci per step per GPU for the indel legs (a11, a14)")
     ap.add_argument("--align-problems", type=int, default=4096, help="GlobalAligner problems per step (next row f2)")
     ap.add_argument("--a5-scenarios", type=int, default=12, help="scenarios (jobs) of the flatten + score leg")
-    ap.add_argument("--a5-reads", type=int, default=1 << 14, help="reads per job of the flatten + score leg (2^14 reads x ~88 candidate alignments: the\n                    largest job the device search's frame and leaf pools hold; SURVEY 8d's smallest batch)")
+    ap.add_argument("--a5-reads", type=int, default=1 << 16,
+                    help="reads per job of the flatten + score leg (2^16 reads x ~88 candidate alignments = 5.8e6 alignments in one job; "
+                         "SURVEY 8d asks for 2^14 .. 2^20 reads)")
     ap.add_argument("--a5-reps", type=int, default=3)
     ap.add_argument("--e2e-bp", type=int, default=32000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
     ap.add_argument("--e2e-segment-bp", type=int, default=4000000,
