@@ -214,12 +214,14 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
     ro.min_read_bp_flank = sif.sampleOptions.min_read_bp_flank;
     ro.sample_count = static_cast<int32_t>(sampleCount);
     // Small jobs stay with the host statement of the search (one device round trip: the scoring launch); the device pipeline -- three
-    // waits per job: level counts, set sizes, results -- is for jobs that have the reads to fill it: alone on a GPU it overtakes the host
-    // search at ~100 reads per job on WGS-like indel densities, ~50 on dense ones (tools/diag/enum_threshold.py, profiles/r04_*).  An explicit
+    // waits per job: level counts, set sizes, results -- is for jobs that have the reads to fill it.  Alone on a GPU it overtakes the host
+    // search at ~100 reads per job on WGS-like indel densities and ~50 on dense ones (tools/diag/enum_threshold.py); with eight caller
+    // processes sharing the GPU every wait costs ~0.6 ms and a device job ~5 ms, and a threshold of 160 made the realignment hook of
+    // the germline leg slower (0.92 -> 1.72 s per 16 Mb, profiles/r04_v17_e2e_sweep.json): 512 stays.  An explicit
     // $SK_ENUMERATION decides for every job (the tests run whole suites in one mode).
     {
         static const bool isModePinned(std::getenv("SK_ENUMERATION") != nullptr);
-        static const size_t minDeviceReads([]() { const char* v(std::getenv("STRELKA_AMD_DEVICE_ENUM_MIN_READS")); return (v && *v) ? static_cast<size_t>(std::strtoul(v, nullptr, 10)) : size_t(160); }());
+        static const size_t minDeviceReads([]() { const char* v(std::getenv("STRELKA_AMD_DEVICE_ENUM_MIN_READS")); return (v && *v) ? static_cast<size_t>(std::strtoul(v, nullptr, 10)) : size_t(512); }());
         if ((! isModePinned) && ro.enumeration == 2 && reads.size() < minDeviceReads) ro.enumeration = 0;
     }
     if (opt.isRetainOptimalSoftClipping) throw blt_exception("strelka_amd adapter: --retain-optimal-soft-clipping (RNA) is not supported on this path");

@@ -6,7 +6,9 @@
 #include "sk_common.h"
 #include "libm_dbl64.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -229,12 +231,18 @@ int sk_init(int device)
     if (c.ready && c.device == device) return 0;
     if (c.ready) sk_shutdown();
     sk_pre_runtime_env();
+    const bool timing = std::getenv("SK_INIT_TIMING") != nullptr; // diagnostics: where a caller process's start-up goes
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) std::fprintf(stderr, "[sk_init] %-34s t=%.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         return sk_fail(std::string("strelka_amd: no HIP device available (") + hipGetErrorString(e) +
                        "); this library has no CPU fallback");
     if (device < 0 || device >= n) return sk_fail("strelka_amd: device index out of range");
+    lap("hipGetDeviceCount (runtime start)");
     SK_HIP(hipSetDevice(device));
     // A process that waits for the device SLEEPS: sixteen caller processes share a GPU and a CPU quota, and a wait spent
     // spinning is a core taken from a process that has host work to do (profiles/r03_v5_thread_cpu_seconds.txt: under contention
@@ -249,13 +257,18 @@ int sk_init(int device)
     SK_HIP(hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return sk_fail(std::string("strelka_amd: built for gfx950 only, device is ") + prop.gcnArchName);
+    lap("device properties");
     build_tables(c.host_tables);
+    lap("host tables");
     c.libm_restated = host_libm_matches_restatement();
+    lap("libm comparison");
     SK_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev_tables), sizeof(SkTables)));
+    lap("first hipMalloc (context)");
     SK_HIP(hipMemcpy(c.dev_tables, &c.host_tables, sizeof(SkTables), hipMemcpyHostToDevice));
     SK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     SK_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev_error_flags), sizeof(unsigned)));
     SK_HIP(hipMemset(c.dev_error_flags, 0, sizeof(unsigned)));
+    lap("tables up, stream, flags");
     c.device = device;
     c.ready = true;
     return 0;
