@@ -472,3 +472,28 @@ def test_multi_sample_wide_allele_groups_cpu_double(tmp_path):
                     reason="oracle/_ref binaries / synthetic sets not built")
 def test_multi_sample_wide_allele_groups_gpu(tmp_path):
     _multi_sample_wide_groups("amd", tmp_path)
+
+
+# ---- reads longer than the device pileup takes: refused when they arrive, with the way out in the message
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_reads_over_the_pileup_limit_are_refused_with_the_way_out(tmp_path):
+    import subprocess
+    import sys
+    d = str(tmp_path / "long")
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "make_synth_bam.py"), d,
+                    os.path.join(E.BIN_DIR, "samtools"), "--seed", "5", "--length", "9000", "--read-length", "1200", "--spacing", "600"],
+                   check=True, stdout=subprocess.DEVNULL)
+    outs = {}
+    for v in ("ref", "dbl"):
+        o = str(tmp_path / v) + "/"
+        os.makedirs(o, exist_ok=True)
+        argv = E.germline_argv("starling2_" + v, o, [os.path.join(d, "germline_S1.bam")], region="chrS:1-9000", ref=os.path.join(d, "synth.fa"))
+        if v == "dbl":
+            with pytest.raises(RuntimeError, match="at most 1024 bases; rerun with STRELKA_AMD_PILEUP=0"):
+                E.run(argv)
+            E.run(argv, env={"STRELKA_AMD_PILEUP": "0"})
+        else:
+            E.run(argv)
+        outs[v] = E.vcf_body(o + "variants.vcf", keep_header=True)
+    assert sum(1 for l in outs["ref"] if not l.startswith("#")) >= 5
+    assert outs["dbl"] == outs["ref"]
