@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--e2e-segment-bp", type=int, default=4000000,
                     help="segment size of the end-to-end leg (one caller process per segment; the workflow cuts a genome into 12 Mb pieces: "
                          "profiles/ holds a run at --e2e-bp 64000000 --e2e-segment-bp 12000000, chr20's size)")
-    ap.add_argument("--only", default="", help="'a5' / 'feed' / 'loci': run one kernel leg alone (the counter passes of tools/gpu_round.sh use it: "
+    ap.add_argument("--only", default="", help="'a5' / 'feed' / 'feed_slice' / 'loci': run one kernel leg alone (the counter passes of tools/gpu_round.sh use it: "
                                                "per-kernel averages then belong to that leg's launches) and print a short line; 'e2e', "
                                                "'e2e_germline', 'e2e_somatic': the end-to-end legs alone (exit code 1 when the drop-in's outputs "
                                                "differ from the reference's)")
@@ -464,6 +464,33 @@ def main():
         print(json.dumps({"only": "feed", "blocks": dfeed.n_blocks, "algorithmic_bytes": dfeed.in_bytes + dfeed.out_bytes}))
         return
 
+    if args.only == "feed_slice":  # the launch a caller process makes: one slice of a region's BGZF blocks, every inflate kernel
+        fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "feed_tiny.bam")
+        with open(fixture, "rb") as f:
+            bgzf_image = np.frombuffer(f.read(), np.uint8)
+        n_fix_blocks = len(capi.bgzf_scan(bgzf_image)[0]) - 1
+        res = {}
+        for kern in ("wave", "wave_lockstep", "thread"):
+            os.environ["SK_INFLATE_KERNEL"] = kern
+            dsm = device.DeviceBgzfBatch(bgzf_image, dev, tile=max(1, 512 // n_fix_blocks))
+            for _ in range(args.warmup):
+                dsm.inflate()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(args.steps):
+                dsm.inflate()
+            ev1.record()
+            torch.cuda.synchronize()
+            assert int(dsm.status.abs().sum().item()) == 0, "BGZF inflation reported a malformed block"
+            ms = ev0.elapsed_time(ev1) / args.steps
+            res[kern] = {"blocks": dsm.n_blocks, "inflated_bytes": dsm.out_bytes, "compressed_bytes": dsm.in_bytes, "ms": ms,
+                         "inflated_bytes_per_s": dsm.out_bytes / (ms * 1e-3)}
+            del dsm
+        del os.environ["SK_INFLATE_KERNEL"]
+        print(json.dumps({"only": "feed_slice", "kernels": res}))
+        return
+
     # ---- resident inputs (per rank: an independent batch, seeded by rank = an independent genome segment) ----
     rng = np.random.default_rng(1000 + rank)
     ua = min(args.unique_reads, args.reads)
@@ -585,7 +612,7 @@ def main():
     # ... and at the launch size a caller process has (one slice of a region: a few hundred blocks), where the latency of one block is
     # the whole cost: the wave-per-block kernel (the default up to 16 384 blocks) against the thread-per-block one
     feed_small = {}
-    for kern in ("wave", "thread"):
+    for kern in ("wave", "wave_lockstep", "thread"):
         os.environ["SK_INFLATE_KERNEL"] = kern
         dsm = device.DeviceBgzfBatch(bgzf_image, dev, tile=max(1, 512 // n_fix_blocks))
         dt_fs, fs_bytes, kms_fs = timed(lambda: dsm.inflate(), max(2, args.steps // 4), 1, dsm.out_bytes)

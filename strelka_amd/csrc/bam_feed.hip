@@ -968,6 +968,538 @@ __global__ __launch_bounds__(64) void bgzf_inflate_wave_kernel(const InflateArgs
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// B1s  bgzf_inflate_scalar_kernel: the wave-per-block decoder with its serial part on the SCALAR unit.
+//
+// What a slice of a few hundred blocks costs is the latency of ONE block: ~3e4 symbols, one after the other.  In B1w above a symbol is
+// two to six dependent LDS round trips (the ring word, the table entry, the base / extra tables, the copy) of ~100 cycles each, plus
+// the waits the fences put around every copy: ~800 cycles per symbol, 11 ms per block.  Here nothing on the symbol-to-symbol chain
+// goes to memory:
+//   * the compressed bytes sit in two VGPRs (lane l holds dword l of the current 256 bytes, and of the next 256, loaded ahead straight
+//     from HBM); the next word enters the bit buffer through v_readlane with a scalar index;
+//   * the first-level tables sit in VGPRs too -- 2 048 literal/length entries in sixteen registers, 256 distance entries in two: an entry
+//     is a register picked by the high index bits (s_set_gpr_idx) and v_readlane by the low ones, ~8 scalar instructions and no wait;
+//   * the bit buffer, its count, the output position, match length and distance are wave-uniform values the compiler keeps in SGPRs:
+//     shifts, masks and the closed-form base / extra-bit arithmetic (RFC 1951 3.2.5) issue on the scalar unit;
+//   * LDS is written, never waited for, on that chain: a literal is one predicated byte store; a match's bytes are read into a register
+//     and stored when the NEXT match is decoded (LDS executes a wave's accesses in order, so a later read sees them), which takes the
+//     read's latency off the chain as well;
+//   * the tables are built by the lanes: per-length counts and every symbol's rank among its length by ballots (no serial pass over the
+//     code lengths), the canonical code of a symbol = first code of its length + rank.
+// Same checks and status codes as B1 / B1w.
+// ---------------------------------------------------------------------------------------------------------------------
+
+constexpr int IS_FAST = 11, IS_DFAST = 10, IS_CFAST = 7;
+typedef uint32_t is_v32u __attribute__((ext_vector_type(32)));
+typedef uint32_t is_v16u __attribute__((ext_vector_type(16)));
+
+// A first-level entry is 32 bits, everything a symbol needs without a further look-up:
+//   bits 0-3  the code's length (0: no code this short ends here -- longer than the table, or not a code at all)
+//   bits 4-7  the number of extra bits that follow
+//   bits 8-23 a literal's byte / a match length's base (3..258) / a distance's base (1..24 577) / a code-length symbol (0..18)
+//   bit 31    set on everything of the literal/length alphabet that is not a literal with a valid length (so that ONE sign test picks
+//             the literal path), bit 30: end of block, bit 29: a symbol that may not occur (286, 287; distances 30, 31)
+constexpr uint32_t IS_NOT_LITERAL = 1u << 31, IS_END = 1u << 30, IS_BAD = 1u << 29;
+
+__device__ __forceinline__ uint32_t is_pack_litlen(const int sym, const int len)
+{
+    if (sym < 256) return uint32_t(len) | (uint32_t(sym) << 8);
+    if (sym == 256) return uint32_t(len) | IS_NOT_LITERAL | IS_END;
+    const int s = sym - 257;
+    if (s >= 29) return uint32_t(len) | IS_NOT_LITERAL | IS_BAD;
+    // RFC 1951 3.2.5 in closed form: length codes 8..27 come in groups of four with one more extra bit per group
+    const int le = (s < 8 || s == 28) ? 0 : ((s - 4) >> 2);
+    const int base = (s < 8) ? (3 + s) : (s == 28) ? 258 : (3 + ((4 + (s & 3)) << le));
+    return uint32_t(len) | (uint32_t(le) << 4) | (uint32_t(base) << 8) | IS_NOT_LITERAL;
+}
+__device__ __forceinline__ uint32_t is_pack_dist(const int ds, const int len)
+{
+    if (ds >= 30) return uint32_t(len) | IS_BAD;
+    const int de = (ds < 4) ? 0 : ((ds - 2) >> 1); // distance codes 4..29: groups of two
+    const int base = (ds < 4) ? (1 + ds) : (1 + ((2 + (ds & 1)) << de));
+    return uint32_t(len) | (uint32_t(de) << 4) | (uint32_t(base) << 8);
+}
+__device__ __forceinline__ uint32_t is_pack_plain(const int sym, const int len) { return uint32_t(len) | (uint32_t(sym) << 8); }
+enum { IS_KIND_LITLEN = 0, IS_KIND_DIST = 1, IS_KIND_PLAIN = 2 };
+__device__ __forceinline__ uint32_t is_pack(const int kind, const int sym, const int len)
+{
+    return kind == IS_KIND_LITLEN ? is_pack_litlen(sym, len) : kind == IS_KIND_DIST ? is_pack_dist(sym, len) : is_pack_plain(sym, len);
+}
+
+struct InflateScalarLds
+{
+    uint8_t out[65536];
+    uint32_t crc_table[256];
+    uint32_t fast[1 << IS_FAST];           // the first-level table being built (literal/length codes; code-length codes): copied to registers
+    uint32_t fast_dist[1 << IS_DFAST];     // ... of the distance codes
+    uint16_t lit_sym[288], dist_sym[32];   // symbols sorted by code (the walk for codes longer than the first-level table)
+    uint16_t lit_count[16], dist_count[16];
+    uint16_t offs[16], first[16];
+    uint8_t lengths[320], lengths2[320];
+    uint8_t sink[64];                      // where a lane with nothing to store stores
+};
+
+struct ScalarBits
+{
+    uint64_t buf;        // wave-uniform
+    int cnt;             // bits in buf
+    int widx;            // next dword of `cur` to enter buf, 0..64 (64: the next refill moves on to `nxt` first)
+    int base;            // offset of `cur`'s 256 bytes from g0
+    uint32_t cur, nxt;   // per lane: dword `lane` of the 256 bytes at base / base + 256 (nxt: as loaded, see is_chunk_seen)
+    const uint8_t* g0;   // 4-byte aligned origin
+    int limit;           // readable bytes from g0 (the block's end, trailer included)
+};
+
+// dword `lane` of the 256 bytes at `off`, as loaded / as the reader may see it (zero past the end).  Two steps so that the load can be
+// issued one chunk ahead and waited for only when its chunk becomes the current one; no per-lane branch: a lane past the end loads the
+// last whole dword and drops it.
+__device__ __forceinline__ uint32_t is_load_chunk_raw(const ScalarBits& b, const int off, const int lane)
+{
+    // (said to be global memory: a flat load -- the pointer came through the by-reference argument of is_codes -- is waited for on the
+    // LDS counter too, and then every symbol waits for the byte it stored)
+    typedef const __attribute__((address_space(1))) uint32_t* global_u32;
+    return *(global_u32)(b.g0 + min(off + lane * 4, (b.limit - 4) & ~3));
+}
+__device__ __forceinline__ uint32_t is_chunk_seen(const ScalarBits& b, const uint32_t raw, const int off, const int lane)
+{
+    return (off + lane * 4 + 4 <= b.limit) ? raw : 0u;
+}
+
+__device__ __forceinline__ void is_roll(ScalarBits& b, const int lane)
+{
+    b.base += 256;
+    b.cur = is_chunk_seen(b, b.nxt, b.base, lane);
+    b.nxt = is_load_chunk_raw(b, b.base + 256, lane);
+    b.widx = 0;
+}
+
+__device__ __forceinline__ uint64_t is_uniform64(const uint64_t v)
+{
+    return uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))))) |
+           (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))))) << 32);
+}
+// The bit reader's state is the same in every lane; said to the compiler after code whose per-lane branches (table fills, run fills)
+// make it keep the state in vector registers -- the symbol loops run on the scalar unit only if it knows.
+__device__ __forceinline__ void is_pin(ScalarBits& b)
+{
+    b.buf = is_uniform64(b.buf);
+    b.cnt = __builtin_amdgcn_readfirstlane(b.cnt);
+    b.widx = __builtin_amdgcn_readfirstlane(b.widx);
+    b.base = __builtin_amdgcn_readfirstlane(b.base);
+    b.limit = __builtin_amdgcn_readfirstlane(b.limit);
+    b.g0 = reinterpret_cast<const uint8_t*>(is_uniform64(reinterpret_cast<uint64_t>(b.g0)));
+}
+
+// at least 32 bits in the buffer afterwards
+__device__ __forceinline__ void is_refill(ScalarBits& b, const int lane)
+{
+    if (b.cnt < 32) {
+        if (b.widx == 64) is_roll(b, lane);
+        const uint32_t w = uint32_t(__builtin_amdgcn_readlane(int(b.cur), b.widx));
+        b.buf |= uint64_t(w) << b.cnt;
+        b.cnt += 32;
+        ++b.widx;
+    }
+}
+
+__device__ __forceinline__ unsigned is_take(ScalarBits& b, const int n) // n <= 16, the buffer holds them
+{
+    const unsigned v = unsigned(b.buf) & ((1u << n) - 1u);
+    b.buf >>= n;
+    b.cnt -= n;
+    return v;
+}
+
+__device__ __forceinline__ void is_seek(ScalarBits& b, const int off, const int lane)
+{
+    b.base = off & ~3;
+    b.cur = is_chunk_seen(b, is_load_chunk_raw(b, b.base, lane), b.base, lane);
+    b.nxt = is_load_chunk_raw(b, b.base + 256, lane);
+    b.widx = 0;
+    b.buf = 0;
+    b.cnt = 0;
+    is_refill(b, lane);
+    (void)is_take(b, (off & 3) * 8);
+}
+
+__device__ __forceinline__ int is_byte_offset(const ScalarBits& b) { return b.base + b.widx * 4 - (b.cnt >> 3); }
+
+// the canonical walk over the buffered bits for a code longer than the first-level table: symbol | length << 9, -1 if no code matches
+// (One exit, no early return: with an exit per length in the caller's loop the compiler threads flags through all of that loop.)
+__device__ __forceinline__ int is_slow_decode(const uint64_t buf, const uint16_t* count, const uint16_t* symbol)
+{
+    int code = 0, first = 0, index = 0, at = -1, len_hit = 0;
+#pragma nounroll
+    for (int len = 1; len <= 15; ++len) {
+        code |= int((buf >> (len - 1)) & 1ull);
+        const int c = __builtin_amdgcn_readfirstlane(int(count[len])); // (uniform to the compiler too: no per-lane branch in the caller's loop)
+        const bool hit = at < 0 && code - c < first;
+        at = hit ? index + (code - first) : at;
+        len_hit = hit ? len : len_hit;
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    const int sym = __builtin_amdgcn_readfirstlane(int(symbol[max(at, 0)]));
+    return at < 0 ? -1 : (sym | (len_hit << 9));
+}
+
+// Per-length counts, the symbols sorted by code and the first-level table of a canonical code, all by the lanes; returns puff's `left`
+// (0: complete, > 0: incomplete, < 0: over-subscribed; nothing is built then).  `length` is an LDS array of n <= 320 code lengths.
+__device__ __noinline__ int is_construct(InflateScalarLds& L, uint16_t* count, uint16_t* symbol, uint32_t* fast, const int fast_bits, const int kind,
+                                         const uint8_t* length, const int n, const int lane)
+{
+    __syncthreads();
+    const uint64_t below = (1ull << lane) - 1ull;
+    int cnt[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) cnt[l] = 0;
+    int my_len[5], my_rank[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int s = c * 64 + lane;
+        const int l = (s < n) ? int(length[s]) : 16;
+        my_len[c] = l;
+        my_rank[c] = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const uint64_t m = __ballot(l == v);
+            if (l == v) my_rank[c] = cnt[v] + __popcll(m & below);
+            cnt[v] += __popcll(m);
+        }
+    }
+    for (int i = lane; i < (1 << fast_bits); i += 64) fast[i] = 0;
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < 16; ++l) count[l] = uint16_t(cnt[l]);
+    }
+    int left = 1;
+    bool over = false;
+#pragma unroll
+    for (int l = 1; l <= 15; ++l) {
+        left <<= 1;
+        left -= cnt[l];
+        over = over || (left < 0);
+        if (over) left = left < 0 ? left : -1;
+    }
+    if (cnt[0] == n) left = 0;
+    if (cnt[0] == n || over) {
+        __syncthreads();
+        return left;
+    }
+    if (lane == 0) {
+        int start = 0, code0 = 0;
+#pragma unroll
+        for (int l = 1; l <= 15; ++l) {
+            L.offs[l] = uint16_t(start);
+            L.first[l] = uint16_t(code0);
+            start += cnt[l];
+            code0 = (code0 + cnt[l]) << 1;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int l = my_len[c];
+        if (l >= 1 && l <= 15) {
+            const int s = c * 64 + lane;
+            symbol[int(L.offs[l]) + my_rank[c]] = uint16_t(s);
+            if (l <= fast_bits) {
+                const unsigned code = unsigned(L.first[l]) + unsigned(my_rank[c]);
+                const unsigned rev = __brev(code) >> (32 - l); // DEFLATE packs Huffman codes most significant bit first
+                const uint32_t entry = is_pack(kind, s, l);
+                for (unsigned e = rev; e < (1u << fast_bits); e += (1u << l)) fast[e] = entry;
+            }
+        }
+    }
+    __syncthreads();
+    return left;
+}
+
+// entry i of a table in registers: lane (i & 63) of register (i >> 6).  (The registers are passed by value: a table inside a struct
+// taken by reference stays in scratch memory.)
+__device__ __forceinline__ uint32_t is_lit_entry(const is_v32u lit, const unsigned idx)
+{
+    return uint32_t(__builtin_amdgcn_readlane(int(lit[idx >> 6]), int(idx & 63u)));
+}
+__device__ __forceinline__ uint32_t is_dist_entry(const is_v16u dist, const unsigned idx)
+{
+    return uint32_t(__builtin_amdgcn_readlane(int(dist[idx >> 6]), int(idx & 63u)));
+}
+
+// The symbols of one deflate block.  Nothing in this loop branches on a per-lane value: a byte is stored by every lane (the same byte to
+// the same address), a match of up to 64 bytes is read by lane min(lane, length - 1) and stored the same way, longer ones in uniform
+// rounds of 64.  A function of its own, not inlined: inside the kernel the compiler merges this loop with the loop over deflate blocks
+// around it, whose per-lane branches (table fills) put the whole region through the structuriser -- every exit of the symbol loop
+// becomes a flag tested on the way round -- and whose hoisted lane masks take the scalar registers this loop lives in.
+extern __shared__ __align__(16) unsigned char is_lds_raw[];
+
+__device__ __noinline__ int is_codes(ScalarBits* bits, int* pos_io, const int cap_arg, const int lane)
+{
+    const int cap = __builtin_amdgcn_readfirstlane(cap_arg); // (arguments arrive in vector registers)
+    InflateScalarLds& L = *reinterpret_cast<InflateScalarLds*>(is_lds_raw);
+    ScalarBits b = *bits;
+    is_pin(b);
+    is_v32u lit;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) lit[r] = L.fast[r * 64 + lane];
+    is_v16u dist;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dist[r] = L.fast_dist[r * 64 + lane];
+    int pos = __builtin_amdgcn_readfirstlane(*pos_io);
+    uint32_t pend_v = 0;                                                   // the bytes of the last match, read and not yet stored
+    uint32_t pend_at = uint32_t(offsetof(InflateScalarLds, sink)) + lane;  // where they go (offset into L)
+    uint8_t* const lds = reinterpret_cast<uint8_t*>(&L);
+    int err = INF_OK;
+    for (;;) {
+        is_refill(b, lane);
+        uint32_t e = is_lit_entry(lit, unsigned(b.buf) & ((1u << IS_FAST) - 1u));
+        if ((e & 15u) == 0) {
+            const int r = is_slow_decode(b.buf, L.lit_count, L.lit_sym);
+            e = r < 0 ? (IS_NOT_LITERAL | IS_BAD) : is_pack_litlen(r & 511, r >> 9);
+        }
+        (void)is_take(b, int(e & 15u));
+        if (int32_t(e) >= 0) { // a literal
+            L.out[pos & 0xffff] = uint8_t(e >> 8); // (pos <= cap <= 65 536 here: at pos == cap the store lands on byte 0 of a block that fails)
+            ++pos;
+            if (pos > cap) { err = INF_OUT_OVERFLOW; break; }
+            continue;
+        }
+        if (e & (IS_END | IS_BAD)) {
+            if (e & IS_BAD) err = INF_BAD_CODE;
+            break;
+        }
+        const int mlen = int((e >> 8) & 0xffffu) + int(is_take(b, int((e >> 4) & 15u)));
+        is_refill(b, lane);
+        uint32_t d = is_dist_entry(dist, unsigned(b.buf) & ((1u << IS_DFAST) - 1u));
+        if ((d & 15u) == 0) {
+            const int r = is_slow_decode(b.buf, L.dist_count, L.dist_sym);
+            d = r < 0 ? IS_BAD : is_pack_dist(r & 511, r >> 9);
+        }
+        if (d & IS_BAD) { err = INF_BAD_CODE; break; }
+        (void)is_take(b, int(d & 15u));
+        const int dst = int((d >> 8) & 0xffffu) + int(is_take(b, int((d >> 4) & 15u)));
+        if (dst > pos) { err = INF_BAD_DISTANCE; break; } // (a BGZF block has no preset dictionary)
+        if (pos + mlen > cap) { err = INF_OUT_OVERFLOW; break; }
+        // the bytes of the match before: this one may read them (LDS executes a wave's accesses in order)
+        lds[pend_at] = uint8_t(pend_v);
+        asm volatile("" ::: "memory");
+        const int src0 = pos - dst;
+        if (mlen <= 64) {
+            const int k = min(lane, mlen - 1);
+            int r = k;
+            if (dst < mlen) { // overlapping: byte k of the match is byte (k mod dist) of the `dist` bytes before it; k < 64: exact in float
+                const int q = int(float(k) / float(dst));
+                r = k - q * dst;
+            }
+            pend_v = L.out[src0 + r];
+            pend_at = uint32_t(pos + k);
+        } else {
+            const float inv = 1.0f / float(dst);
+            for (int base = 0; base < mlen; base += 64) {
+                const int k = min(base + lane, mlen - 1);
+                int r = k;
+                if (dst < mlen) { // k < 258 and dist < 258: the quotient from a float reciprocal is off by at most one
+                    const int q = int(float(k) * inv);
+                    r = k - q * dst;
+                    r += (r < 0) ? dst : 0;
+                    r -= (r >= dst) ? dst : 0;
+                }
+                L.out[pos + k] = L.out[src0 + r];
+            }
+            asm volatile("" ::: "memory");
+            pend_at = uint32_t(offsetof(InflateScalarLds, sink)) + lane;
+        }
+        pos += mlen;
+    }
+    lds[pend_at] = uint8_t(pend_v);
+    asm volatile("" ::: "memory");
+    *pos_io = pos;
+    *bits = b;
+    return err;
+}
+
+__global__ __launch_bounds__(64) void bgzf_inflate_scalar_kernel(const InflateArgs a)
+{
+    InflateScalarLds& L = *reinterpret_cast<InflateScalarLds*>(is_lds_raw);
+    const int lane = threadIdx.x;
+    const int blk_i = blockIdx.x;
+    if (blk_i >= a.n_blocks) return;
+    const uint8_t* blk = a.data + a.block_off[blk_i];
+    const int64_t blen = a.block_off[blk_i + 1] - a.block_off[blk_i];
+    if (blen < 28 || blen > (1 << 20) || blk[0] != 31 || blk[1] != 139 || blk[2] != 8 || !(blk[3] & 4)) {
+        if (lane == 0) a.status[blk_i] = INF_BAD_HEADER;
+        return;
+    }
+    const int xlen = int(blk[10]) | (int(blk[11]) << 8);
+    const uint8_t* cdata = blk + 12 + xlen;
+    const uint8_t* cend = blk + blen - 8;
+    if (cdata > cend) {
+        if (lane == 0) a.status[blk_i] = INF_BAD_HEADER;
+        return;
+    }
+    const uint32_t isize = uint32_t(cend[4]) | (uint32_t(cend[5]) << 8) | (uint32_t(cend[6]) << 16) | (uint32_t(cend[7]) << 24);
+    const uint32_t want_crc = uint32_t(cend[0]) | (uint32_t(cend[1]) << 8) | (uint32_t(cend[2]) << 16) | (uint32_t(cend[3]) << 24);
+    const int64_t cap64 = a.out_off[blk_i + 1] - a.out_off[blk_i];
+    if (cap64 < 0 || cap64 > 65536) {
+        if (lane == 0) a.status[blk_i] = INF_OUT_OVERFLOW;
+        return;
+    }
+    const int cap = __builtin_amdgcn_readfirstlane(int(cap64));
+
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = uint32_t(i);
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
+        L.crc_table[i] = c;
+    }
+
+    ScalarBits b;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(cdata);
+    b.g0 = cdata - (addr & 3u);
+    b.limit = int((blk + blen) - b.g0);
+    const int origin = int(addr & 3u);
+    is_seek(b, origin, lane);
+    const int total_bits = int(cend - cdata) * 8;
+    auto consumed_bits = [&]() { return (b.base + b.widx * 4 - origin) * 8 - b.cnt; };
+
+    int pos = 0, err = INF_OK, last = 0;
+    do {
+        is_pin(b);
+        pos = __builtin_amdgcn_readfirstlane(pos);
+        is_refill(b, lane);
+        last = int(is_take(b, 1));
+        const int type = int(is_take(b, 2));
+        if (type == 0) { // stored: the rest of the byte is dropped, LEN NLEN, then LEN bytes straight from the input
+            (void)is_take(b, b.cnt & 7);
+            is_refill(b, lane);
+            const unsigned len = is_take(b, 16);
+            is_refill(b, lane);
+            const unsigned nlen = is_take(b, 16);
+            if (len != (~nlen & 0xffffu) || consumed_bits() + int(len) * 8 > total_bits) { err = INF_BAD_STORED; break; }
+            if (pos + int(len) > cap) { err = INF_OUT_OVERFLOW; break; }
+            const int from = is_byte_offset(b);
+            for (int k = lane; k < int(len); k += 64) L.out[pos + k] = b.g0[from + k];
+            pos += int(len);
+            is_seek(b, from + int(len), lane);
+        } else if (type == 1 || type == 2) {
+            int nlen = 288, ndist = 30;
+            if (type == 1) { // fixed codes (RFC 1951 3.2.6)
+                __syncthreads();
+                for (int s = lane; s < 288; s += 64) L.lengths[s] = uint8_t(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                if (lane < 30) L.lengths[288 + lane] = 5;
+                __syncthreads();
+            } else { // dynamic codes (3.2.7)
+                nlen = int(is_take(b, 5)) + 257;
+                ndist = int(is_take(b, 5)) + 1;
+                const int ncode = int(is_take(b, 4)) + 4;
+                if (nlen > 286 || ndist > 30) { err = INF_BAD_LENGTHS; break; }
+                __syncthreads();
+                if (lane < 19) L.lengths2[lane] = 0;
+                __syncthreads();
+                for (int idx = 0; idx < ncode; ++idx) {
+                    is_refill(b, lane);
+                    const unsigned v = is_take(b, 3);
+                    L.lengths2[CLEN_ORDER[idx]] = uint8_t(v);
+                }
+                // the code-length code: at most 7 bits, one register of entries
+                if (is_construct(L, L.dist_count, L.dist_sym, L.fast, IS_CFAST, IS_KIND_PLAIN, L.lengths2, 19, lane) != 0) { err = INF_BAD_LENGTHS; break; }
+                const uint32_t ct0 = L.fast[lane], ct1 = L.fast[64 + lane];
+                int idx = 0, prev = 0;
+                const int want = nlen + ndist;
+                __syncthreads();
+                is_pin(b);
+                while (idx < want) {
+                    is_refill(b, lane);
+                    const unsigned at = unsigned(b.buf) & 127u;
+                    const uint32_t e = uint32_t(__builtin_amdgcn_readlane(int((at & 64u) ? ct1 : ct0), int(at & 63u)));
+                    const int len = int(e & 15u), sym = int(e >> 8);
+                    if (len == 0) { err = INF_BAD_CODE; break; }
+                    (void)is_take(b, len);
+                    if (sym < 16) {
+                        L.lengths[idx] = uint8_t(sym);
+                        prev = sym;
+                        ++idx;
+                    } else {
+                        int fill = 0, rep;
+                        if (sym == 16) {
+                            if (idx == 0) { err = INF_BAD_LENGTHS; break; }
+                            fill = prev;
+                            rep = 3 + int(is_take(b, 2));
+                        } else if (sym == 17) {
+                            rep = 3 + int(is_take(b, 3));
+                        } else {
+                            rep = 11 + int(is_take(b, 7));
+                        }
+                        if (idx + rep > want) { err = INF_BAD_LENGTHS; break; }
+                        for (int k = lane; k < rep; k += 64) L.lengths[idx + k] = uint8_t(fill);
+                        idx += rep;
+                        prev = fill;
+                    }
+                }
+                if (err != INF_OK) break;
+                __syncthreads();
+                if (__builtin_amdgcn_readfirstlane(int(L.lengths[256])) == 0) { err = INF_BAD_LENGTHS; break; }
+            }
+            int left = is_construct(L, L.lit_count, L.lit_sym, L.fast, IS_FAST, IS_KIND_LITLEN, L.lengths, nlen, lane);
+            if (type == 2 && left != 0 && (left < 0 || nlen != __builtin_amdgcn_readfirstlane(int(L.lit_count[0]) + int(L.lit_count[1])))) { err = INF_BAD_LENGTHS; break; }
+            left = is_construct(L, L.dist_count, L.dist_sym, L.fast_dist, IS_DFAST, IS_KIND_DIST, L.lengths + nlen, ndist, lane);
+            if (type == 2 && left != 0 && (left < 0 || ndist != __builtin_amdgcn_readfirstlane(int(L.dist_count[0]) + int(L.dist_count[1])))) { err = INF_BAD_LENGTHS; break; }
+            err = __builtin_amdgcn_readfirstlane(is_codes(&b, &pos, cap, lane));
+        } else {
+            err = INF_BAD_BLOCK_TYPE;
+        }
+        if (err == INF_OK && consumed_bits() > total_bits) err = INF_IN_OVERRUN;
+    } while (err == INF_OK && !last);
+    if (err == INF_OK && (pos != cap || uint32_t(pos) != isize)) err = INF_SIZE_MISMATCH;
+    __syncthreads();
+    if (err == INF_OK) {
+        // CRC-32 of the block: 64 slices of whole dwords, slice i shifted by the bytes after it (crc(A || B) = crc(A) * x^(8 |B|) + crc(B))
+        const int n = pos;
+        const int slice = (((n + 63) / 64) + 3) & ~3;
+        const int s0 = min(n, lane * slice), s1 = min(n, s0 + slice);
+        uint32_t c = 0;
+        if (s1 > s0) {
+            c = 0xffffffffu;
+            int i = s0;
+            for (; i + 4 <= s1; i += 4) {
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(&L.out[i]);
+                c = L.crc_table[(c ^ w) & 0xffu] ^ (c >> 8);
+                c = L.crc_table[(c ^ (w >> 8)) & 0xffu] ^ (c >> 8);
+                c = L.crc_table[(c ^ (w >> 16)) & 0xffu] ^ (c >> 8);
+                c = L.crc_table[(c ^ (w >> 24)) & 0xffu] ^ (c >> 8);
+            }
+            for (; i < s1; ++i) c = L.crc_table[(c ^ L.out[i]) & 0xffu] ^ (c >> 8);
+            c ^= 0xffffffffu;
+            // x^(8 (n - s1)) mod P by square and multiply (zlib x2nmodp)
+            uint32_t sq = 1u << 30; // x^1
+            uint32_t pw = 1u << 31; // x^0
+            uint32_t e = uint32_t(n - s1) * 8u;
+            while (e) {
+                if (e & 1u) pw = iw_multmodp(sq, pw);
+                sq = iw_multmodp(sq, sq);
+                e >>= 1;
+            }
+            c = iw_multmodp(pw, c);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
+        if (c != want_crc) err = INF_CRC_MISMATCH;
+        // the block to HBM: consecutive lanes, consecutive bytes (4 per lane where the destination allows)
+        uint8_t* dst = a.out + a.out_off[blk_i];
+        const int head = min(n, int((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
+        if (lane < head) dst[lane] = L.out[lane];
+        const int words = (n - head) / 4;
+        for (int w = lane; w < words; w += 64) {
+            const int o = head + 4 * w;
+            const uint32_t v = uint32_t(L.out[o]) | (uint32_t(L.out[o + 1]) << 8) | (uint32_t(L.out[o + 2]) << 16) | (uint32_t(L.out[o + 3]) << 24);
+            *reinterpret_cast<uint32_t*>(dst + o) = v;
+        }
+        for (int o = head + 4 * words + lane; o < n; o += 64) dst[o] = L.out[o];
+    }
+    if (lane == 0) a.status[blk_i] = err;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // BAM records (SAM spec 4.2): block_size, refID, pos, l_read_name, mapq, bin, n_cigar_op, flag, l_seq, next_refID, next_pos, tlen,
 // read_name, cigar[n_cigar_op] (len << 4 | op), seq[(l_seq+1)/2] (4 bits per base, high nibble first), qual[l_seq]
 
@@ -1120,9 +1652,20 @@ int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, c
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     // a wave per block up to the launch size where blocks in flight beat latency per block;
     // $SK_INFLATE_KERNEL = thread | wave pins one (tests run every input through both)
-    bool wave = n_blocks <= 16384;
-    if (const char* e = std::getenv("SK_INFLATE_KERNEL")) wave = (std::strcmp(e, "wave") == 0) ? true : (std::strncmp(e, "thread", 6) == 0) ? false : wave;
-    if (wave) {
+    bool wave = n_blocks <= 16384, lockstep = false;
+    if (const char* e = std::getenv("SK_INFLATE_KERNEL")) {
+        wave = (std::strncmp(e, "wave", 4) == 0) ? true : (std::strncmp(e, "thread", 6) == 0) ? false : wave;
+        lockstep = std::strcmp(e, "wave_lockstep") == 0; // B1w, round 3's wave kernel
+    }
+    if (wave && !lockstep) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bgzf_inflate_scalar_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(sizeof(InflateScalarLds))));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(bgzf_inflate_scalar_kernel, dim3(n_blocks), dim3(64), sizeof(InflateScalarLds), st, a);
+    } else if (wave) {
         static bool attr_set = false;
         if (!attr_set) {
             SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bgzf_inflate_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

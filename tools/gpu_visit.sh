@@ -63,6 +63,9 @@ for step in "$@"; do
         SK_A5_FUSED=$f timeout 300 python bench.py --only a5 --steps 20 --warmup 3 > $OUT/a5_fused$f.json 2>$OUT/a5_fused$f.err; echo "fused=$f: $(cat $OUT/a5_fused$f.json | head -c 600)"
         SK_A5_FUSED=$f timeout 300 python bench.py --only a5 --a5-reads 65536 --steps 10 --warmup 2 > $OUT/a5_65536_fused$f.json 2>$OUT/a5_65536_fused$f.err; echo "fused=$f 2^16 reads: $(cat $OUT/a5_65536_fused$f.json | head -c 600)"
       done ;;
+    feed)
+      timeout 600 python -m pytest tests/test_bam_feed.py -m gpu -x -q > $OUT/pytest_feed.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_feed.log; tail -4 $OUT/pytest_feed.log
+      timeout 300 python bench.py --only feed_slice --steps 8 --warmup 2 > $OUT/feed_slice.json 2>$OUT/feed_slice.err; echo "feed_slice rc=$?"; cat $OUT/feed_slice.json; tail -3 $OUT/feed_slice.err ;;
     loci)
       timeout 300 python bench.py --only loci --steps 5 --warmup 2 > $OUT/loci.json 2>$OUT/loci.err; cat $OUT/loci.json ;;
     *) echo "unknown step $step" ;;
