@@ -470,7 +470,7 @@ def main():
             bgzf_image = np.frombuffer(f.read(), np.uint8)
         n_fix_blocks = len(capi.bgzf_scan(bgzf_image)[0]) - 1
         res = {}
-        for kern in ("wave", "wave_lockstep", "thread"):
+        for kern in ("wave", "thread"):
             os.environ["SK_INFLATE_KERNEL"] = kern
             dsm = device.DeviceBgzfBatch(bgzf_image, dev, tile=max(1, 512 // n_fix_blocks))
             for _ in range(args.warmup):
@@ -612,7 +612,7 @@ def main():
     # ... and at the launch size a caller process has (one slice of a region: a few hundred blocks), where the latency of one block is
     # the whole cost: the wave-per-block kernel (the default up to 16 384 blocks) against the thread-per-block one
     feed_small = {}
-    for kern in ("wave", "wave_lockstep", "thread"):
+    for kern in ("wave", "thread"):
         os.environ["SK_INFLATE_KERNEL"] = kern
         dsm = device.DeviceBgzfBatch(bgzf_image, dev, tile=max(1, 512 // n_fix_blocks))
         dt_fs, fs_bytes, kms_fs = timed(lambda: dsm.inflate(), max(2, args.steps // 4), 1, dsm.out_bytes)

@@ -10,8 +10,9 @@
 //                             of a few GB is 10^5 blocks): canonical-Huffman decoding (per-length counts in registers, symbols in a
 //                             private array), LZ77 copies inside the thread's own output range in unaligned 8/4/2/1-byte pieces.
 //                             A serial bit stream per block is what the format is; the parallelism is across blocks.
-//   B1w bgzf_inflate_wave_kernel  one WAVE per block, output assembled in LDS: a third of the latency per block, for the few
-//                             hundred blocks a caller process inflates at a time
+//   B1s bgzf_inflate_scalar_kernel  one WAVE per block, output assembled in LDS, the symbol loop on the scalar unit with the input and
+//                             the first-level tables in vector registers: a twelfth of B1's latency per block, for the few hundred
+//                             blocks a caller process inflates at a time
 //   B2  bgzf_crc32_kernel     one thread per block: CRC-32 (IEEE 802.3, table in LDS) of the inflated bytes against the trailer
 //   B4  normalize_kernel      one thread per read: normalizeAlignment (L/starling_common/normalizeAlignment.cpp:647-703; the
 //                             reference applies it to every read as it comes off the BAM stream), csrc/normalize_core.h, in place
@@ -28,8 +29,9 @@
 // commercial applications, and to alter it and redistribute it freely, subject to the following restrictions: 1. The origin of this
 // software must not be misrepresented ... 2. Altered source versions must be plainly marked as such ... 3. This notice may not be
 // removed or altered from any source distribution."  This is an altered version (HIP, per-block status codes, no setjmp).  The tables
-// themselves are RFC 1951's.  iw_multmodp / the x^(8n) exponentiation of the wave kernel follow zlib's crc32.c (multmodp, x2nmodp;
-// same licence).  The wave-per-block decoder (first-level tables, lockstep bit buffer, lane-parallel copies) is original.
+// themselves are RFC 1951's.  is_multmodp / the x^(8n) exponentiation of the wave kernel follow zlib's crc32.c (multmodp, x2nmodp;
+// same licence).  The wave-per-block decoder (first-level tables in registers, scalar bit buffer, lane-parallel table construction and
+// copies) is original.
 
 #include "sk_common.h"
 
@@ -553,439 +555,27 @@ __global__ __launch_bounds__(64) void bgzf_crc32_kernel(const InflateArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// B1w  bgzf_inflate_wave_kernel: one WAVE per BGZF block, inflation and the CRC-32 / ISIZE check in one kernel.
-//
-// The thread-per-block kernel above wins on throughput only when a launch holds 10^5 blocks; a caller process of the drop-in has
-// a few hundred to a few thousand per region, and there the latency of ONE block is the whole cost (~0.1 s: every Huffman step a
-// round trip to private tables in scratch memory, one bit per step, one dependent byte load per output byte).  Here a block has a
-// wavefront and 78 KB of LDS to itself:
-//   * the block's 64 KiB of output and every table live in LDS; the compressed bytes stream through an 8 KiB LDS ring that the 64
-//     lanes refill 4 KiB at a time with 16-byte loads;
-//   * the serial part of DEFLATE -- the bit buffer, one literal/length or distance symbol after the other -- is executed by all
-//     lanes in lockstep on identical values (uniform control flow, LDS reads of one address are broadcasts): a symbol is ONE
-//     lookup in a 10-bit (distances: 8-bit) first-level table, codes longer than that walk the canonical counts as before;
-//   * what is parallel is done by the lanes: an LZ77 copy of `len` bytes is len lanes (byte k comes from position - dist +
-//     k mod dist, which is the overlap rule), table fills, the CRC (64 slices, combined with x^(8 n) mod P as zlib's
-//     crc32_combine does) and the final store of the block to HBM in consecutive 64-byte rows.
-// Same checks, same status codes as the kernel above.
-// ---------------------------------------------------------------------------------------------------------------------
-
-constexpr int IW_FAST = 10, IW_DFAST = 8;
-constexpr int IW_RING = 8192, IW_HALF = 4096;
-
-struct InflateWaveLds
-{
-    uint8_t out[65536];
-    uint8_t ring[IW_RING];
-    uint32_t crc_table[256];
-    uint16_t lit_fast[1 << IW_FAST];  // symbol | code length << 9; 0: longer than IW_FAST bits (or unused)
-    uint16_t dist_fast[1 << IW_DFAST];
-    uint16_t lit_count[16], dist_count[16];
-    uint16_t lit_sym[288], dist_sym[32];
-    uint16_t len_base[32], dist_base[32];
-    uint8_t len_extra[32], dist_extra[32];
-    uint8_t lengths[320];
-};
-
-struct WaveBits
-{
-    uint64_t buf;
-    int cnt;
-    int64_t next;   // ring-origin-relative offset of the next 4 input bytes to enter `buf` (a multiple of 4)
-    int64_t loaded; // ring-origin-relative offset up to which the ring holds input (a multiple of IW_HALF)
-    int64_t limit;  // ... of the end of the compressed data
-    const uint8_t* g0; // the ring origin in HBM (16-byte aligned)
-};
-
-// 4 KiB of input into the ring half that `from` falls in; past `limit` the ring reads as zero
-__device__ __forceinline__ void iw_load_half(InflateWaveLds& L, const WaveBits& b, const int64_t from, const int lane)
-{
-#pragma unroll
-    for (int it = 0; it < IW_HALF / (64 * 16); ++it) {
-        const int64_t o = from + (it * 64 + lane) * 16;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (o + 16 <= b.limit) {
-            v = *reinterpret_cast<const uint4*>(b.g0 + o);
-        } else if (o < b.limit) {
-            uint8_t t[16];
-            for (int k = 0; k < 16; ++k) t[k] = (o + k < b.limit) ? b.g0[o + k] : uint8_t(0);
-            v.x = uint32_t(t[0]) | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
-            v.y = uint32_t(t[4]) | (uint32_t(t[5]) << 8) | (uint32_t(t[6]) << 16) | (uint32_t(t[7]) << 24);
-            v.z = uint32_t(t[8]) | (uint32_t(t[9]) << 8) | (uint32_t(t[10]) << 16) | (uint32_t(t[11]) << 24);
-            v.w = uint32_t(t[12]) | (uint32_t(t[13]) << 8) | (uint32_t(t[14]) << 16) | (uint32_t(t[15]) << 24);
-        }
-        *reinterpret_cast<uint4*>(&L.ring[size_t(o) & (IW_RING - 1)]) = v;
-    }
-}
-
-// at least 32 bits in the buffer afterwards
-__device__ __forceinline__ void iw_refill(InflateWaveLds& L, WaveBits& b, const int lane)
-{
-    if (b.cnt >= 32) return;
-    if (b.next >= b.loaded - IW_HALF) { // the reader is in the newest half: the other one is spent, refill it
-        __syncthreads();
-        iw_load_half(L, b, b.loaded, lane);
-        b.loaded += IW_HALF;
-        __syncthreads();
-    }
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(&L.ring[size_t(b.next) & (IW_RING - 1)]);
-    b.buf |= uint64_t(w) << b.cnt;
-    b.cnt += 32;
-    b.next += 4;
-}
-
-__device__ __forceinline__ unsigned iw_take(WaveBits& b, const int n) // n <= 16, the buffer holds them
-{
-    const unsigned v = unsigned(b.buf & ((1ull << n) - 1ull));
-    b.buf >>= n;
-    b.cnt -= n;
-    return v;
-}
-
-// puff's canonical walk over the buffered bits (not consumed): symbol and its length, -1 if no code matches
-__device__ __forceinline__ int iw_slow_decode(const WaveBits& b, const uint16_t* count, const uint16_t* symbol, int& len_out)
-{
-    int code = 0, first = 0, index = 0;
-    for (int len = 1; len <= 15; ++len) {
-        code |= int((b.buf >> (len - 1)) & 1ull);
-        const int c = count[len];
-        if (code - c < first) {
-            len_out = len;
-            return symbol[index + (code - first)];
-        }
-        index += c;
-        first += c;
-        first <<= 1;
-        code <<= 1;
-    }
-    return -1;
-}
-
-// counts, sorted symbols (as huff_construct) and the first-level table; returns puff's `left`
-__device__ int iw_construct(InflateWaveLds& L, uint16_t* count, uint16_t* symbol, uint16_t* fast, const int fast_bits, const uint8_t* length,
-                            const int n, const int lane)
-{
-    __syncthreads();
-    if (lane == 0) {
-        for (int len = 0; len <= 15; ++len) count[len] = 0;
-        for (int s = 0; s < n; ++s) count[length[s]]++;
-    }
-    for (int i = lane; i < (1 << fast_bits); i += 64) fast[i] = 0;
-    __syncthreads();
-    if (count[0] == n) return 0;
-    int left = 1;
-    for (int len = 1; len <= 15; ++len) {
-        left <<= 1;
-        left -= int(count[len]);
-        if (left < 0) return left;
-    }
-    if (lane == 0) {
-        uint16_t offs[16];
-        offs[1] = 0;
-        for (int len = 1; len < 15; ++len) offs[len + 1] = uint16_t(offs[len] + count[len]);
-        for (int s = 0; s < n; ++s)
-            if (length[s] != 0) symbol[offs[length[s]]++] = uint16_t(s);
-    }
-    __syncthreads();
-    // the k-th sorted symbol: its length from the cumulative counts, its canonical code = first code of that length + its rank
-    const int total = n - int(count[0]);
-    for (int idx = lane; idx < total; idx += 64) {
-        int len = 1, start = 0, code0 = 0;
-        while (len <= 15 && idx >= start + int(count[len])) {
-            start += int(count[len]);
-            code0 = (code0 + int(count[len])) << 1;
-            ++len;
-        }
-        if (len > fast_bits) continue;
-        const unsigned code = unsigned(code0 + (idx - start));
-        const unsigned rev = __brev(code) >> (32 - len); // DEFLATE packs Huffman codes most significant bit first
-        const uint16_t entry = uint16_t(unsigned(symbol[idx]) | (unsigned(len) << 9));
-        for (unsigned e = rev; e < (1u << fast_bits); e += (1u << len)) fast[e] = entry;
-    }
-    __syncthreads();
-    return left;
-}
-
-__device__ int iw_codes(InflateWaveLds& L, WaveBits& b, int& pos, const int cap, const int lane)
-{
-    for (;;) {
-        iw_refill(L, b, lane);
-        unsigned e = L.lit_fast[unsigned(b.buf) & ((1u << IW_FAST) - 1u)];
-        int len = int(e >> 9), sym = int(e & 511u);
-        if (len == 0) {
-            sym = iw_slow_decode(b, L.lit_count, L.lit_sym, len);
-            if (sym < 0) return INF_BAD_CODE;
-        }
-        (void)iw_take(b, len);
-        if (sym < 256) {
-            if (pos >= cap) return INF_OUT_OVERFLOW;
-            if (lane == 0) L.out[pos] = uint8_t(sym);
-            ++pos;
-            continue;
-        }
-        if (sym == 256) return INF_OK;
-        sym -= 257;
-        if (sym >= 29) return INF_BAD_CODE;
-        const int mlen = int(L.len_base[sym]) + int(iw_take(b, L.len_extra[sym]));
-        iw_refill(L, b, lane);
-        e = L.dist_fast[unsigned(b.buf) & ((1u << IW_DFAST) - 1u)];
-        len = int(e >> 9);
-        int ds = int(e & 511u);
-        if (len == 0) {
-            ds = iw_slow_decode(b, L.dist_count, L.dist_sym, len);
-            if (ds < 0) return INF_BAD_CODE;
-        }
-        if (ds >= 30) return INF_BAD_CODE;
-        (void)iw_take(b, len);
-        const int dist = int(L.dist_base[ds]) + int(iw_take(b, L.dist_extra[ds]));
-        if (dist > pos) return INF_BAD_DISTANCE; // (a BGZF block has no preset dictionary)
-        if (pos + mlen > cap) return INF_OUT_OVERFLOW;
-        // the copy: byte k of the match is byte (k mod dist) of the `dist` bytes before it
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int src0 = pos - dist;
-        for (int k = lane; k < mlen; k += 64) L.out[pos + k] = L.out[src0 + (dist >= mlen ? k : k % dist)];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        pos += mlen;
-    }
-}
-
-// a * b mod P over GF(2), reflected (zlib crc32.c multmodp)
-__device__ __forceinline__ uint32_t iw_multmodp(uint32_t a, uint32_t b)
-{
-    uint32_t m = 1u << 31, p = 0;
-    for (;;) {
-        if (a & m) {
-            p ^= b;
-            if ((a & (m - 1u)) == 0) break;
-        }
-        m >>= 1;
-        b = (b & 1u) ? ((b >> 1) ^ 0xedb88320u) : (b >> 1);
-    }
-    return p;
-}
-
-__global__ __launch_bounds__(64) void bgzf_inflate_wave_kernel(const InflateArgs a)
-{
-    extern __shared__ __align__(16) unsigned char iw_lds_raw[];
-    InflateWaveLds& L = *reinterpret_cast<InflateWaveLds*>(iw_lds_raw);
-    const int lane = threadIdx.x;
-    const int blk_i = blockIdx.x;
-    if (blk_i >= a.n_blocks) return;
-    const uint8_t* blk = a.data + a.block_off[blk_i];
-    const int64_t blen = a.block_off[blk_i + 1] - a.block_off[blk_i];
-    if (blen < 28 || blk[0] != 31 || blk[1] != 139 || blk[2] != 8 || !(blk[3] & 4)) {
-        if (lane == 0) a.status[blk_i] = INF_BAD_HEADER;
-        return;
-    }
-    const int xlen = int(blk[10]) | (int(blk[11]) << 8);
-    const uint8_t* cdata = blk + 12 + xlen;
-    const uint8_t* cend = blk + blen - 8;
-    if (cdata > cend) {
-        if (lane == 0) a.status[blk_i] = INF_BAD_HEADER;
-        return;
-    }
-    const uint32_t isize = uint32_t(cend[4]) | (uint32_t(cend[5]) << 8) | (uint32_t(cend[6]) << 16) | (uint32_t(cend[7]) << 24);
-    const uint32_t want_crc = uint32_t(cend[0]) | (uint32_t(cend[1]) << 8) | (uint32_t(cend[2]) << 16) | (uint32_t(cend[3]) << 24);
-    const int64_t cap64 = a.out_off[blk_i + 1] - a.out_off[blk_i];
-    if (cap64 < 0 || cap64 > 65536) {
-        if (lane == 0) a.status[blk_i] = INF_OUT_OVERFLOW;
-        return;
-    }
-    const int cap = int(cap64);
-
-    // tables every block needs
-    for (int i = lane; i < 256; i += 64) {
-        uint32_t c = uint32_t(i);
-        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
-        L.crc_table[i] = c;
-    }
-    if (lane < 29) {
-        L.len_base[lane] = uint16_t(LEN_BASE[lane]);
-        L.len_extra[lane] = uint8_t(LEN_EXTRA[lane]);
-    }
-    if (lane < 30) {
-        L.dist_base[lane] = uint16_t(DIST_BASE[lane]);
-        L.dist_extra[lane] = uint8_t(DIST_EXTRA[lane]);
-    }
-
-    WaveBits b;
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(cdata);
-    b.g0 = cdata - (addr & 15u);
-    b.limit = int64_t(cend - b.g0);
-    b.buf = 0;
-    b.cnt = 0;
-    b.next = 0;
-    b.loaded = 0;
-    iw_load_half(L, b, 0, lane);
-    iw_load_half(L, b, IW_HALF, lane);
-    b.loaded = IW_RING;
-    __syncthreads();
-    {   // the bytes between the ring origin and the first compressed byte
-        int drop = int(addr & 15u) * 8;
-        while (drop > 0) {
-            iw_refill(L, b, lane);
-            const int d = drop < 16 ? drop : 16;
-            (void)iw_take(b, d);
-            drop -= d;
-        }
-    }
-    const int64_t total_bits = int64_t(cend - cdata) * 8;
-    const int64_t origin_bits = int64_t(addr & 15u) * 8;
-    auto consumed_bits = [&]() { return b.next * 8 - b.cnt - origin_bits; };
-
-    int pos = 0, err = INF_OK, last = 0;
-    do {
-        iw_refill(L, b, lane);
-        last = int(iw_take(b, 1));
-        const int type = int(iw_take(b, 2));
-        if (type == 0) { // stored: the rest of the byte is dropped, LEN NLEN, then LEN bytes
-            (void)iw_take(b, b.cnt & 7);
-            iw_refill(L, b, lane);
-            const unsigned len = iw_take(b, 16);
-            iw_refill(L, b, lane);
-            const unsigned nlen = iw_take(b, 16);
-            if (len != (~nlen & 0xffffu) || consumed_bits() + int64_t(len) * 8 > total_bits) { err = INF_BAD_STORED; break; }
-            if (pos + int(len) > cap) { err = INF_OUT_OVERFLOW; break; }
-            for (unsigned i = 0; i < len; ++i) {
-                iw_refill(L, b, lane);
-                const unsigned v = iw_take(b, 8);
-                if (lane == 0) L.out[pos] = uint8_t(v);
-                ++pos;
-            }
-        } else if (type == 1 || type == 2) {
-            int nlen = 288, ndist = 30;
-            if (type == 1) { // fixed codes (RFC 1951 3.2.6)
-                __syncthreads();
-                for (int s = lane; s < 288; s += 64) L.lengths[s] = uint8_t(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
-                if (lane < 30) L.lengths[288 + lane] = 5;
-                __syncthreads();
-            } else { // dynamic codes (3.2.7)
-                nlen = int(iw_take(b, 5)) + 257;
-                ndist = int(iw_take(b, 5)) + 1;
-                const int ncode = int(iw_take(b, 4)) + 4;
-                if (nlen > 286 || ndist > 30) { err = INF_BAD_LENGTHS; break; }
-                __syncthreads();
-                if (lane < 19) L.lengths[lane] = 0;
-                __syncthreads();
-                for (int idx = 0; idx < ncode; ++idx) {
-                    iw_refill(L, b, lane);
-                    const unsigned v = iw_take(b, 3);
-                    if (lane == 0) L.lengths[CLEN_ORDER[idx]] = uint8_t(v);
-                }
-                // the code-length code: at most 7 bits, it uses the distance tables' space
-                if (iw_construct(L, L.dist_count, L.dist_sym, L.dist_fast, 7, L.lengths, 19, lane) != 0) { err = INF_BAD_LENGTHS; break; }
-                int idx = 0, prev = 0;
-                const int want = nlen + ndist;
-                // (the lengths are written after the table that decodes them was built from the same array: they go to a second
-                // array first -- the literal/length table's space is free until iw_construct below)
-                uint8_t* dst = reinterpret_cast<uint8_t*>(L.lit_sym);
-                while (idx < want) {
-                    iw_refill(L, b, lane);
-                    const unsigned e = L.dist_fast[unsigned(b.buf) & 127u];
-                    const int len = int(e >> 9), sym = int(e & 511u);
-                    if (len == 0) { err = INF_BAD_CODE; break; }
-                    (void)iw_take(b, len);
-                    if (sym < 16) {
-                        if (lane == 0) dst[idx] = uint8_t(sym);
-                        prev = sym;
-                        ++idx;
-                    } else {
-                        int fill = 0, rep;
-                        if (sym == 16) {
-                            if (idx == 0) { err = INF_BAD_LENGTHS; break; }
-                            fill = prev;
-                            rep = 3 + int(iw_take(b, 2));
-                        } else if (sym == 17) {
-                            rep = 3 + int(iw_take(b, 3));
-                        } else {
-                            rep = 11 + int(iw_take(b, 7));
-                        }
-                        if (idx + rep > want) { err = INF_BAD_LENGTHS; break; }
-                        for (int k = lane; k < rep; k += 64) dst[idx + k] = uint8_t(fill);
-                        idx += rep;
-                        prev = fill;
-                    }
-                }
-                if (err != INF_OK) break;
-                __syncthreads();
-                for (int s = lane; s < want; s += 64) L.lengths[s] = dst[s];
-                __syncthreads();
-                if (L.lengths[256] == 0) { err = INF_BAD_LENGTHS; break; }
-            }
-            int left = iw_construct(L, L.lit_count, L.lit_sym, L.lit_fast, IW_FAST, L.lengths, nlen, lane);
-            if (type == 2 && left != 0 && (left < 0 || nlen != int(L.lit_count[0]) + int(L.lit_count[1]))) { err = INF_BAD_LENGTHS; break; }
-            left = iw_construct(L, L.dist_count, L.dist_sym, L.dist_fast, IW_DFAST, L.lengths + nlen, ndist, lane);
-            if (type == 2 && left != 0 && (left < 0 || ndist != int(L.dist_count[0]) + int(L.dist_count[1]))) { err = INF_BAD_LENGTHS; break; }
-            err = iw_codes(L, b, pos, cap, lane);
-        } else {
-            err = INF_BAD_BLOCK_TYPE;
-        }
-        if (err == INF_OK && consumed_bits() > total_bits) err = INF_IN_OVERRUN;
-    } while (err == INF_OK && !last);
-    if (err == INF_OK && (pos != cap || uint32_t(pos) != isize)) err = INF_SIZE_MISMATCH;
-    __syncthreads();
-    if (err == INF_OK) {
-        // CRC-32 of the block: 64 slices, slice i shifted by the bytes after it (crc(A || B) = crc(A) * x^(8 |B|) + crc(B))
-        const int n = pos;
-        const int slice = (n + 63) / 64;
-        const int s0 = min(n, lane * slice), s1 = min(n, s0 + slice);
-        uint32_t c = 0;
-        if (s1 > s0) {
-            c = 0xffffffffu;
-            for (int i = s0; i < s1; ++i) c = L.crc_table[(c ^ L.out[i]) & 0xffu] ^ (c >> 8);
-            c ^= 0xffffffffu;
-            // x^(8 (n - s1)) mod P by square and multiply (zlib x2nmodp)
-            uint32_t sq = 1u << 30; // x^1
-            uint32_t pw = 1u << 31; // x^0
-            uint32_t e = uint32_t(n - s1) * 8u;
-            while (e) {
-                if (e & 1u) pw = iw_multmodp(sq, pw);
-                sq = iw_multmodp(sq, sq);
-                e >>= 1;
-            }
-            c = iw_multmodp(pw, c);
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
-        if (c != want_crc) err = INF_CRC_MISMATCH;
-        // the block to HBM: consecutive lanes, consecutive bytes (4 per lane where the destination allows)
-        uint8_t* dst = a.out + a.out_off[blk_i];
-        const int head = min(n, int((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
-        if (lane < head) dst[lane] = L.out[lane];
-        const int words = (n - head) / 4;
-        for (int w = lane; w < words; w += 64) {
-            const int o = head + 4 * w;
-            const uint32_t v = uint32_t(L.out[o]) | (uint32_t(L.out[o + 1]) << 8) | (uint32_t(L.out[o + 2]) << 16) | (uint32_t(L.out[o + 3]) << 24);
-            *reinterpret_cast<uint32_t*>(dst + o) = v;
-        }
-        for (int o = head + 4 * words + lane; o < n; o += 64) dst[o] = L.out[o];
-    }
-    if (lane == 0) a.status[blk_i] = err;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // B1s  bgzf_inflate_scalar_kernel: the wave-per-block decoder with its serial part on the SCALAR unit.
 //
-// What a slice of a few hundred blocks costs is the latency of ONE block: ~3e4 symbols, one after the other.  In B1w above a symbol is
-// two to six dependent LDS round trips (the ring word, the table entry, the base / extra tables, the copy) of ~100 cycles each, plus
-// the waits the fences put around every copy: ~800 cycles per symbol, 11 ms per block.  Here nothing on the symbol-to-symbol chain
-// goes to memory:
+// What a slice of a few hundred blocks costs is the latency of ONE block: ~1e4 symbols (BAM data: two thirds of them matches of ~9
+// bytes), one after the other.  Round 3's wave-per-block kernel ran every symbol on all lanes in lockstep through LDS: two to six
+// dependent LDS round trips of ~100 cycles each (the input ring word, the table entry, the base / extra tables, the copy) plus the
+// waits the fences put around every copy -- 11.4 ms per slice of 510 blocks (profiles/r04_inflate_history.txt).  A wave alone on its
+// SIMD issues one instruction every ~6 cycles, so what counts is the number of instructions and waits on the symbol-to-symbol chain.
+// Here nothing on that chain goes to memory:
 //   * the compressed bytes sit in two VGPRs (lane l holds dword l of the current 256 bytes, and of the next 256, loaded ahead straight
 //     from HBM); the next word enters the bit buffer through v_readlane with a scalar index;
-//   * the first-level tables sit in VGPRs too -- 2 048 literal/length entries in sixteen registers, 256 distance entries in two: an entry
-//     is a register picked by the high index bits (s_set_gpr_idx) and v_readlane by the low ones, ~8 scalar instructions and no wait;
+//   * the first-level tables sit in VGPRs too -- 2 048 literal/length entries in 32 registers, 1 024 distance entries in 16, an entry
+//     32 bits with everything the symbol needs (code length, extra-bit count, base value, kind): an entry is a register picked by the
+//     high index bits (s_set_gpr_idx) and v_readlane by the low ones, five instructions and no wait;
 //   * the bit buffer, its count, the output position, match length and distance are wave-uniform values the compiler keeps in SGPRs:
-//     shifts, masks and the closed-form base / extra-bit arithmetic (RFC 1951 3.2.5) issue on the scalar unit;
-//   * LDS is written, never waited for, on that chain: a literal is one predicated byte store; a match's bytes are read into a register
-//     and stored when the NEXT match is decoded (LDS executes a wave's accesses in order, so a later read sees them), which takes the
-//     read's latency off the chain as well;
+//     shifts and masks issue on the scalar unit;
+//   * LDS is written, never waited for, by a literal (one byte store; the other lanes store into a sink of their own, an address select
+//     instead of a branch); a match's copy is the one wait: read, then store, in rounds of 64 bytes (LDS executes a wave's accesses in
+//     order, so the read sees every byte stored before);
 //   * the tables are built by the lanes: per-length counts and every symbol's rank among its length by ballots (no serial pass over the
 //     code lengths), the canonical code of a symbol = first code of its length + rank.
-// Same checks and status codes as B1 / B1w.
+// Same checks and status codes as B1.
 // ---------------------------------------------------------------------------------------------------------------------
 
 constexpr int IS_FAST = 11, IS_DFAST = 10, IS_CFAST = 7;
@@ -1035,7 +625,7 @@ struct InflateScalarLds
     uint16_t lit_count[16], dist_count[16];
     uint16_t offs[16], first[16];
     uint8_t lengths[320], lengths2[320];
-    uint8_t sink[64];                      // where a lane with nothing to store stores
+    uint32_t sink[64];                     // where a lane with nothing to store stores (a bank each)
 };
 
 struct ScalarBits
@@ -1125,7 +715,8 @@ __device__ __forceinline__ int is_byte_offset(const ScalarBits& b) { return b.ba
 
 // the canonical walk over the buffered bits for a code longer than the first-level table: symbol | length << 9, -1 if no code matches
 // (One exit, no early return: with an exit per length in the caller's loop the compiler threads flags through all of that loop.)
-__device__ __forceinline__ int is_slow_decode(const uint64_t buf, const uint16_t* count, const uint16_t* symbol)
+template <typename CountPtr>
+__device__ __forceinline__ int is_slow_decode(const uint64_t buf, const CountPtr count, const CountPtr symbol)
 {
     int code = 0, first = 0, index = 0, at = -1, len_hit = 0;
 #pragma nounroll
@@ -1227,53 +818,81 @@ __device__ __forceinline__ uint32_t is_dist_entry(const is_v16u dist, const unsi
     return uint32_t(__builtin_amdgcn_readlane(int(dist[idx >> 6]), int(idx & 63u)));
 }
 
-// The symbols of one deflate block.  Nothing in this loop branches on a per-lane value: a byte is stored by every lane (the same byte to
-// the same address), a match of up to 64 bytes is read by lane min(lane, length - 1) and stored the same way, longer ones in uniform
-// rounds of 64.  A function of its own, not inlined: inside the kernel the compiler merges this loop with the loop over deflate blocks
+// The symbols of one deflate block.  Nothing in this loop branches on a per-lane value: a lane with nothing to store stores into a
+// sink of its own (an address select, not a branch); a match of up to 64 bytes is read by lane min(lane, length - 1), longer ones in
+// uniform rounds of 64.  A function of its own, not inlined: inside the kernel the compiler merges this loop with the loop over deflate blocks
 // around it, whose per-lane branches (table fills) put the whole region through the structuriser -- every exit of the symbol loop
 // becomes a flag tested on the way round -- and whose hoisted lane masks take the scalar registers this loop lives in.
 extern __shared__ __align__(16) unsigned char is_lds_raw[];
 
-__device__ __noinline__ int is_codes(ScalarBits* bits, int* pos_io, const int cap_arg, const int lane)
+#ifdef SK_IS_TIMING  // experiments: where a block's time goes (build with SK_EXTRA_HIPCC_FLAGS=-DSK_IS_TIMING, run with $SK_INFLATE_TIMING=1)
+__device__ unsigned long long is_dbg[16384 * 8];
+#define IS_DBG_ADD(i, v) do { if (lane == 0) is_dbg[size_t(blockIdx.x) * 8 + (i)] += (unsigned long long)(v); } while (0)
+#else
+#define IS_DBG_ADD(i, v) do { } while (0)
+#endif
+
+__device__ __noinline__ int is_codes(ScalarBits* bits, int* pos_io, const int cap_arg, const unsigned lds_base_arg, const int lane)
 {
-    const int cap = __builtin_amdgcn_readfirstlane(cap_arg); // (arguments arrive in vector registers)
-    InflateScalarLds& L = *reinterpret_cast<InflateScalarLds*>(is_lds_raw);
+    // (arguments arrive in vector registers; the LDS base as a number: a function that names the dynamic LDS array itself loads its
+    // address from a table at every use -- a scalar load and a wait for it per symbol)
+    const int cap = __builtin_amdgcn_readfirstlane(cap_arg);
+    typedef __attribute__((address_space(3))) uint8_t* lds_u8;
+    typedef __attribute__((address_space(3))) uint16_t* lds_u16;
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+    const lds_u8 lds = (lds_u8)(uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane(int(lds_base_arg));
+    const lds_u32 fast = (lds_u32)(lds + offsetof(InflateScalarLds, fast)), fast_dist = (lds_u32)(lds + offsetof(InflateScalarLds, fast_dist));
+    const lds_u16 lit_count = (lds_u16)(lds + offsetof(InflateScalarLds, lit_count)), lit_sym = (lds_u16)(lds + offsetof(InflateScalarLds, lit_sym));
+    const lds_u16 dist_count = (lds_u16)(lds + offsetof(InflateScalarLds, dist_count)), dist_sym = (lds_u16)(lds + offsetof(InflateScalarLds, dist_sym));
     ScalarBits b = *bits;
     is_pin(b);
     is_v32u lit;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) lit[r] = L.fast[r * 64 + lane];
+    for (int r = 0; r < 32; ++r) lit[r] = fast[r * 64 + lane];
     is_v16u dist;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dist[r] = L.fast_dist[r * 64 + lane];
+    for (int r = 0; r < 16; ++r) dist[r] = fast_dist[r * 64 + lane];
     int pos = __builtin_amdgcn_readfirstlane(*pos_io);
-    uint32_t pend_v = 0;                                                   // the bytes of the last match, read and not yet stored
-    uint32_t pend_at = uint32_t(offsetof(InflateScalarLds, sink)) + lane;  // where they go (offset into L)
-    uint8_t* const lds = reinterpret_cast<uint8_t*>(&L);
+    const uint32_t my_sink = uint32_t(offsetof(InflateScalarLds, sink)) + 4u * lane; // (offsets into the LDS struct; `out` is at 0)
     int err = INF_OK;
+#ifdef SK_IS_TIMING
+    const long long t_in = clock64();
+    int n_lit = 0, n_match = 0;
+    long long t_lit = 0, t_match = 0, t_mdec = 0;
+#endif
     for (;;) {
+#ifdef SK_IS_TIMING
+        const long long t_it = clock64();
+#endif
         is_refill(b, lane);
         uint32_t e = is_lit_entry(lit, unsigned(b.buf) & ((1u << IS_FAST) - 1u));
-        if ((e & 15u) == 0) {
-            const int r = is_slow_decode(b.buf, L.lit_count, L.lit_sym);
+        if (__builtin_expect((e & 15u) == 0, 0)) {
+            const int r = is_slow_decode(b.buf, lit_count, lit_sym);
             e = r < 0 ? (IS_NOT_LITERAL | IS_BAD) : is_pack_litlen(r & 511, r >> 9);
         }
         (void)is_take(b, int(e & 15u));
         if (int32_t(e) >= 0) { // a literal
-            L.out[pos & 0xffff] = uint8_t(e >> 8); // (pos <= cap <= 65 536 here: at pos == cap the store lands on byte 0 of a block that fails)
+            // lane 0 stores the byte, the others into their sink: an address select, not a branch (and not 64 stores to one address).  No
+            // wait: nothing on the way to the next symbol reads LDS.
+            // (pos <= cap <= 65 536 here: at pos == cap the store lands on byte 0 of a block that fails)
+            lds[lane == 0 ? uint32_t(pos & 0xffff) : my_sink] = uint8_t(e >> 8);
             ++pos;
-            if (pos > cap) { err = INF_OUT_OVERFLOW; break; }
+#ifdef SK_IS_TIMING
+            ++n_lit;
+            t_lit += clock64() - t_it;
+#endif
+            if (__builtin_expect(pos > cap, 0)) { err = INF_OUT_OVERFLOW; break; }
             continue;
         }
-        if (e & (IS_END | IS_BAD)) {
+        if (__builtin_expect((e & (IS_END | IS_BAD)) != 0, 0)) {
             if (e & IS_BAD) err = INF_BAD_CODE;
             break;
         }
         const int mlen = int((e >> 8) & 0xffffu) + int(is_take(b, int((e >> 4) & 15u)));
         is_refill(b, lane);
         uint32_t d = is_dist_entry(dist, unsigned(b.buf) & ((1u << IS_DFAST) - 1u));
-        if ((d & 15u) == 0) {
-            const int r = is_slow_decode(b.buf, L.dist_count, L.dist_sym);
+        if (__builtin_expect((d & 15u) == 0, 0)) {
+            const int r = is_slow_decode(b.buf, dist_count, dist_sym);
             d = r < 0 ? IS_BAD : is_pack_dist(r & 511, r >> 9);
         }
         if (d & IS_BAD) { err = INF_BAD_CODE; break; }
@@ -1281,42 +900,61 @@ __device__ __noinline__ int is_codes(ScalarBits* bits, int* pos_io, const int ca
         const int dst = int((d >> 8) & 0xffffu) + int(is_take(b, int((d >> 4) & 15u)));
         if (dst > pos) { err = INF_BAD_DISTANCE; break; } // (a BGZF block has no preset dictionary)
         if (pos + mlen > cap) { err = INF_OUT_OVERFLOW; break; }
-        // the bytes of the match before: this one may read them (LDS executes a wave's accesses in order)
-        lds[pend_at] = uint8_t(pend_v);
-        asm volatile("" ::: "memory");
+        // The copy, in uniform rounds of 64 bytes (one round for all but the longest matches): LDS executes a wave's accesses in order, so
+        // the reads see every byte stored before, and byte k of an overlapping match (distance < length) is byte (k mod distance) of the
+        // `distance` bytes before it -- never a byte of this match.  The read's round trip is the one wait of the symbol loop.
+#ifdef SK_IS_TIMING
+        t_mdec += clock64() - t_it;
+#endif
         const int src0 = pos - dst;
-        if (mlen <= 64) {
-            const int k = min(lane, mlen - 1);
-            int r = k;
-            if (dst < mlen) { // overlapping: byte k of the match is byte (k mod dist) of the `dist` bytes before it; k < 64: exact in float
-                const int q = int(float(k) / float(dst));
-                r = k - q * dst;
-            }
-            pend_v = L.out[src0 + r];
-            pend_at = uint32_t(pos + k);
+        if (__builtin_expect(dst >= mlen && mlen <= 64, 1)) {
+            lds[lane < mlen ? uint32_t(pos + lane) : my_sink] = lds[src0 + min(lane, mlen - 1)];
         } else {
             const float inv = 1.0f / float(dst);
             for (int base = 0; base < mlen; base += 64) {
                 const int k = min(base + lane, mlen - 1);
                 int r = k;
-                if (dst < mlen) { // k < 258 and dist < 258: the quotient from a float reciprocal is off by at most one
+                if (dst < mlen) { // k < 258 and distance < 258: the quotient from a float reciprocal is off by at most one
                     const int q = int(float(k) * inv);
                     r = k - q * dst;
                     r += (r < 0) ? dst : 0;
                     r -= (r >= dst) ? dst : 0;
                 }
-                L.out[pos + k] = L.out[src0 + r];
+                lds[base + lane < mlen ? uint32_t(pos + k) : my_sink] = lds[src0 + r];
             }
-            asm volatile("" ::: "memory");
-            pend_at = uint32_t(offsetof(InflateScalarLds, sink)) + lane;
         }
         pos += mlen;
+#ifdef SK_IS_TIMING
+        ++n_match;
+        t_match += clock64() - t_it;
+#endif
     }
-    lds[pend_at] = uint8_t(pend_v);
-    asm volatile("" ::: "memory");
+#ifdef SK_IS_TIMING
+    IS_DBG_ADD(2, clock64() - t_in);
+    IS_DBG_ADD(3, n_lit);
+    IS_DBG_ADD(4, n_match);
+    IS_DBG_ADD(1, t_lit);
+    IS_DBG_ADD(7, t_match);
+    IS_DBG_ADD(6, t_mdec);
+#endif
     *pos_io = pos;
     *bits = b;
     return err;
+}
+
+// a * b mod P over GF(2), reflected (zlib crc32.c multmodp)
+__device__ __forceinline__ uint32_t is_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? ((b >> 1) ^ 0xedb88320u) : (b >> 1);
+    }
+    return p;
 }
 
 __global__ __launch_bounds__(64) void bgzf_inflate_scalar_kernel(const InflateArgs a)
@@ -1352,6 +990,10 @@ __global__ __launch_bounds__(64) void bgzf_inflate_scalar_kernel(const InflateAr
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
         L.crc_table[i] = c;
     }
+#ifdef SK_IS_TIMING
+    const long long t_start = clock64();
+    if (lane < 8) is_dbg[size_t(blockIdx.x) * 8 + lane] = 0;
+#endif
 
     ScalarBits b;
     const uintptr_t addr = reinterpret_cast<uintptr_t>(cdata);
@@ -1444,7 +1086,11 @@ __global__ __launch_bounds__(64) void bgzf_inflate_scalar_kernel(const InflateAr
             if (type == 2 && left != 0 && (left < 0 || nlen != __builtin_amdgcn_readfirstlane(int(L.lit_count[0]) + int(L.lit_count[1])))) { err = INF_BAD_LENGTHS; break; }
             left = is_construct(L, L.dist_count, L.dist_sym, L.fast_dist, IS_DFAST, IS_KIND_DIST, L.lengths + nlen, ndist, lane);
             if (type == 2 && left != 0 && (left < 0 || ndist != __builtin_amdgcn_readfirstlane(int(L.dist_count[0]) + int(L.dist_count[1])))) { err = INF_BAD_LENGTHS; break; }
-            err = __builtin_amdgcn_readfirstlane(is_codes(&b, &pos, cap, lane));
+            // (the base through an empty asm: handed over as a constant expression the compiler propagates it into is_codes and the table
+            // loads are back)
+            unsigned lds_base = unsigned(uintptr_t((__attribute__((address_space(3))) unsigned char*)is_lds_raw));
+            asm volatile("" : "+v"(lds_base));
+            err = __builtin_amdgcn_readfirstlane(is_codes(&b, &pos, cap, lds_base, lane));
         } else {
             err = INF_BAD_BLOCK_TYPE;
         }
@@ -1452,6 +1098,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate_scalar_kernel(const InflateAr
     } while (err == INF_OK && !last);
     if (err == INF_OK && (pos != cap || uint32_t(pos) != isize)) err = INF_SIZE_MISMATCH;
     __syncthreads();
+#ifdef SK_IS_TIMING
+    const long long t_decoded = clock64();
+#endif
     if (err == INF_OK) {
         // CRC-32 of the block: 64 slices of whole dwords, slice i shifted by the bytes after it (crc(A || B) = crc(A) * x^(8 |B|) + crc(B))
         const int n = pos;
@@ -1475,11 +1124,11 @@ __global__ __launch_bounds__(64) void bgzf_inflate_scalar_kernel(const InflateAr
             uint32_t pw = 1u << 31; // x^0
             uint32_t e = uint32_t(n - s1) * 8u;
             while (e) {
-                if (e & 1u) pw = iw_multmodp(sq, pw);
-                sq = iw_multmodp(sq, sq);
+                if (e & 1u) pw = is_multmodp(sq, pw);
+                sq = is_multmodp(sq, sq);
                 e >>= 1;
             }
-            c = iw_multmodp(pw, c);
+            c = is_multmodp(pw, c);
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
@@ -1496,6 +1145,11 @@ __global__ __launch_bounds__(64) void bgzf_inflate_scalar_kernel(const InflateAr
         }
         for (int o = head + 4 * words + lane; o < n; o += 64) dst[o] = L.out[o];
     }
+#ifdef SK_IS_TIMING
+    __syncthreads();
+    IS_DBG_ADD(0, clock64() - t_start);
+    IS_DBG_ADD(5, clock64() - t_decoded);
+#endif
     if (lane == 0) a.status[blk_i] = err;
 }
 
@@ -1652,12 +1306,9 @@ int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, c
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     // a wave per block up to the launch size where blocks in flight beat latency per block;
     // $SK_INFLATE_KERNEL = thread | wave pins one (tests run every input through both)
-    bool wave = n_blocks <= 16384, lockstep = false;
-    if (const char* e = std::getenv("SK_INFLATE_KERNEL")) {
-        wave = (std::strncmp(e, "wave", 4) == 0) ? true : (std::strncmp(e, "thread", 6) == 0) ? false : wave;
-        lockstep = std::strcmp(e, "wave_lockstep") == 0; // B1w, round 3's wave kernel
-    }
-    if (wave && !lockstep) {
+    bool wave = n_blocks <= 16384;
+    if (const char* e = std::getenv("SK_INFLATE_KERNEL")) wave = (std::strcmp(e, "wave") == 0) ? true : (std::strncmp(e, "thread", 6) == 0) ? false : wave;
+    if (wave) {
         static bool attr_set = false;
         if (!attr_set) {
             SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bgzf_inflate_scalar_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1665,14 +1316,25 @@ int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, c
             attr_set = true;
         }
         hipLaunchKernelGGL(bgzf_inflate_scalar_kernel, dim3(n_blocks), dim3(64), sizeof(InflateScalarLds), st, a);
-    } else if (wave) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bgzf_inflate_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       int(sizeof(InflateWaveLds))));
-            attr_set = true;
+#ifdef SK_IS_TIMING
+        if (std::getenv("SK_INFLATE_TIMING") && n_blocks <= 16384) {
+            SK_HIP(hipStreamSynchronize(st));
+            std::vector<unsigned long long> d(size_t(n_blocks) * 8);
+            SK_HIP(hipMemcpyFromSymbol(d.data(), HIP_SYMBOL(is_dbg), d.size() * 8));
+            size_t worst = 0;
+            unsigned long long sum[8] = {0};
+            for (size_t i = 0; i < size_t(n_blocks); ++i) {
+                if (d[i * 8] > d[worst * 8]) worst = i;
+                for (int k = 0; k < 8; ++k) sum[k] += d[i * 8 + k];
+            }
+            std::fprintf(stderr, "[inflate timing] slowest block %zu: in literal iterations %llu ticks, in match iterations %llu (up to the copy: %llu)\n", worst,
+                         d[worst * 8 + 1], d[worst * 8 + 7], d[worst * 8 + 6]);
+            std::fprintf(stderr, "[inflate timing] slowest block %zu: total %llu ticks, symbol loops %llu, crc+store %llu; %llu literals %llu matches -> %llu bytes; "
+                         "all %d blocks: total %llu, symbol loops %llu, crc+store %llu, %llu literals %llu matches %llu bytes\n", worst, d[worst * 8],
+                         d[worst * 8 + 2], d[worst * 8 + 5], d[worst * 8 + 3], d[worst * 8 + 4], d[worst * 8 + 6], n_blocks, sum[0], sum[2], sum[5], sum[3],
+                         sum[4], sum[6]);
         }
-        hipLaunchKernelGGL(bgzf_inflate_wave_kernel, dim3(n_blocks), dim3(64), sizeof(InflateWaveLds), st, a);
+#endif
     } else {
         hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
         hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);

@@ -120,9 +120,9 @@ def _python_deflate_blocks(payloads, level):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["thread", "wave", "wave_lockstep"])
+@pytest.mark.parametrize("kernel", ["thread", "wave"])
 def test_both_inflate_kernels_on_every_block_shape(kernel, monkeypatch):
-    """the thread-per-block and the two wave-per-block kernels ($SK_INFLATE_KERNEL: `wave` is the scalar-unit decoder B1s) on the fixture BAMs and on blocks made here: stored
+    """the thread-per-block and the wave-per-block kernels ($SK_INFLATE_KERNEL) on the fixture BAMs and on blocks made here: stored
     blocks, fixed codes (tiny payloads), dynamic codes with long matches at short distances (runs), 64 KiB blocks, empty blocks, a
     destination that is not 4-byte aligned, codes longer than the first-level table (skewed alphabets)"""
     capi.init(0)
