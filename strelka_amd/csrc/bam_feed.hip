@@ -1304,9 +1304,10 @@ int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, c
     a.status = dev_status;
     a.n_blocks = n_blocks;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    // a wave per block up to the launch size where blocks in flight beat latency per block;
-    // $SK_INFLATE_KERNEL = thread | wave pins one (tests run every input through both)
-    bool wave = n_blocks <= 16384;
+    // a wave per block up to the launch size where blocks in flight beat latency per block: B1s holds two blocks per CU (LDS), 512 at a
+    // time at ~2.9 ms a round; B1 takes ~35 ms for anything up to 1.6e4 blocks (a lane each) and 59 ms for 1.3e5 -- the curves cross near
+    // 6 000 blocks (profiles/r04_inflate_history.txt).  $SK_INFLATE_KERNEL = thread | wave pins one (tests run every input through both)
+    bool wave = n_blocks <= 6144;
     if (const char* e = std::getenv("SK_INFLATE_KERNEL")) wave = (std::strcmp(e, "wave") == 0) ? true : (std::strncmp(e, "thread", 6) == 0) ? false : wave;
     if (wave) {
         static bool attr_set = false;

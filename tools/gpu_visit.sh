@@ -54,6 +54,19 @@ for step in "$@"; do
         tail -1 $OUT/pmc_g3_$i.log | head -c 300
       done
       python tools/diag/pmc_kernel_sums.py $OUT/pmc_g3_* > $OUT/pmc_g3.txt 2>&1; cat $OUT/pmc_g3.txt ;;
+    pmc_som)
+      i=0
+      for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+                 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" \
+                 "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL"; do
+        i=$((i+1))
+        timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_som_$i -o pmc -- python bench.py --only somatic --steps 3 --warmup 1 > $OUT/pmc_som_$i.log 2>&1
+        tail -1 $OUT/pmc_som_$i.log | head -c 300
+      done
+      python tools/diag/pmc_kernel_sums.py $OUT/pmc_som_* > $OUT/pmc_som.txt 2>&1; cat $OUT/pmc_som.txt ;;
+    som)
+      timeout 300 python bench.py --only somatic --steps 5 --warmup 2 > $OUT/som.json 2>$OUT/som.err; cat $OUT/som.json; tail -2 $OUT/som.err
+      timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_somatic_tiers.py -m gpu -x -q -k "somatic or tier" 2>&1 | tail -2 ;;
     g3_variants)
       for v in ${G3_VARIANTS:-0 1}; do
         SK_G3_VARIANT=$v timeout 300 python bench.py --only loci --steps 5 --warmup 2 > $OUT/loci_v$v.json 2>$OUT/loci_v$v.err; echo "variant $v: $(cat $OUT/loci_v$v.json | head -c 400)"
