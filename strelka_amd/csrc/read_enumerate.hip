@@ -654,7 +654,7 @@ constexpr int F5_MAX_READ = 256;  // (as F3's wave form; longer reads and larger
 constexpr int F5_MAX_POOL = 1024;
 constexpr int F5_TAB = 48;       // span of table indices the indels of one round's candidate alignments may cover
 
-static_assert(sizeof(PIndel) % 4 == 0, "table entries move as 32-bit words");
+static_assert(F5_TAB <= 64, "the table copy is a lane an entry");
 
 struct FusedScoreArgs
 {
@@ -668,22 +668,38 @@ struct FusedScoreArgs
     unsigned long long* dbg; // diagnostics ($SK_F5_TIMING): per block 8 cycle stamps, or null
 };
 
-// a candidate alignment as F5 keeps it in LDS: the used part of the PCal record, then the walk's transitions
+// a candidate alignment as F5 keeps it in LDS: the used part of the PCal record
 //   [0] pos   [1] lead | trail << 16   [2] fwd | n_seg << 8 | n_indels << 16   [3 .. 3+F5_SEGS) path   [.. +F5_INDELS/2) indels
-//   [F5_ENT0 ..) transitions: start position | penalties that precede the op's terms << 9 | soft clip << 15 | (pool offset - position + 256) << 16
-constexpr int F5_SEGS = 16, F5_INDELS = 8, F5_ENTS = 16;
-constexpr int F5_IND0 = 3 + F5_SEGS, F5_ENT0 = F5_IND0 + F5_INDELS / 2, F5_SLOT = (F5_ENT0 + F5_ENTS) | 1; // (odd stride: conflict-free)
+// and, written over it by the walk, the alignment's transitions (start position | penalties that precede the op's terms << 9 | soft clip
+// << 15 | (pool offset - position + 256) << 16): transition 0 in word 0, transition k in word 2 + k = the place of path segment k - 1.  The
+// walk reads the position once, at its start, and only ever looks at path segments from the current one on; an op is emitted per turn of
+// its loop, each turn consumes at least one segment, so transition k (k - 1 ops before it, at least k - 1 segments consumed, and the
+// current segment is still read after the emit) lands on a segment the walk is done with; the last one, the read's end, is number
+// n_seg at most.  A slot of 23 words instead of 39: with the table entries cut to the four words the walk reads and the rows of terms
+// sized for the job's longest read, a wave's LDS goes from 17.8 KB to ~10 KB and a CU holds 15 of them instead of 9 -- the kernel is a
+// latency chain per lane (profiles/r04_a5_history.txt: a wave alone on a CU takes as long as nine sharing it).
+constexpr int F5_SEGS = 16, F5_INDELS = 8;
+constexpr int F5_IND0 = 3 + F5_SEGS, F5_SLOT = (F5_IND0 + F5_INDELS / 2) | 1; // (odd stride: conflict-free)
+__device__ __forceinline__ int f5_ent_word(const int k) { return k ? 2 + k : 0; }
 constexpr int F5_ROW = 2; // doubles per read position: agree, differ (a position that adds nothing reads the shared 0.0 instead)
 
+struct F5Tab // what the walk reads of a table entry
+{
+    int32_t pos;
+    uint32_t del, ins_len;
+    uint32_t type_cand; // type | cand << 8
+};
+
+template <int MAXR>
 struct F5Lds
 {
-    double row[(F5_MAX_READ + 8) * F5_ROW];
+    double row[(MAXR + 8) * F5_ROW];
     double zero; // 0.0
-    uint8_t read[F5_MAX_READ + 8];
+    uint8_t read[MAXR + 8];
     uint8_t hap[F5_MAX_POOL + 8];
     uint32_t slot[64 * F5_SLOT];
     // what the walk looks up per path segment (a chain of dependent look-ups: from HBM / L2 they cost a wave ~100 us per round)
-    uint32_t tab[F5_TAB * (sizeof(PIndel) / 4)];
+    F5Tab tab[F5_TAB];
     int32_t ins_off[INS_CAP], ins_len[INS_CAP];
     uint32_t ins_src[INS_CAP];
     int16_t ins_idx[INS_CAP];
@@ -705,14 +721,14 @@ struct F5Rec // accessors of a compact record
 // flatten_cal over a compact record, every look-up from the block's LDS copies (S is the kernel's __shared__ object: the accesses stay
 // LDS accesses).  The same walk, statement for statement (scoreCandidateAlignment :286-493 as host/align_flatten.cpp states it); `sink`
 // receives the ops.  Returns false: leave the read to the host form.
-template <typename SINK>
-__device__ __forceinline__ bool f5_walk(F5Lds& S, const F5Rec c, const int tab_lo, const int n_ins, const int32_t win_begin, uint8_t* consulted,
+template <typename LDS, typename SINK>
+__device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo, const int n_ins, const int32_t win_begin, uint8_t* consulted,
                                         const int32_t read_len, SINK&& sink)
 {
-    auto tab = [&](const int i) -> const PIndel& { return reinterpret_cast<const PIndel*>(S.tab)[i - tab_lo]; };
+    auto tab = [&](const int i) -> const F5Tab& { return S.tab[i - tab_lo]; };
     auto is_cand = [&](const int i) -> bool { // job_cand
         if (consulted) consulted[i] = 1;
-        return tab(i).cand != 0;
+        return (tab(i).type_cand >> 8) != 0;
     };
     const int aps = c.n_seg();
     unsigned read_offset = 0;
@@ -736,11 +752,12 @@ __device__ __forceinline__ bool f5_walk(F5Lds& S, const F5Rec c, const int tab_l
 #pragma unroll
     for (int k = 0; k < F5_INDELS; ++k) {
         k_idx[k] = (k < ni) ? c.indel(k) : tab_lo;
-        const PIndel& ci = tab(k_idx[k]);
+        const F5Tab& ci = tab(k_idx[k]);
         k_pos[k] = ci.pos;
         k_del[k] = ci.del;
         k_ins[k] = ci.ins_len;
-        k_kind[k] = (ci.type == SK_INDEL_INDEL || ci.type == SK_INDEL_MISMATCH);
+        const unsigned ty = ci.type_cand & 0xffu;
+        k_kind[k] = (ty == SK_INDEL_INDEL || ty == SK_INDEL_MISMATCH);
     }
     // getMatchingIndelKey, starling_read_align_score.cpp:177-228: table index, -1 = no key, -2 = inconsistent
     auto matching = [&](const unsigned del_len, const unsigned ins_len, const int path_index) -> int {
@@ -848,9 +865,10 @@ __device__ __forceinline__ bool f5_walk(F5Lds& S, const F5Rec c, const int tab_l
     return int64_t(read_offset) == int64_t(read_len);
 }
 
+template <int MAXR>
 __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs fa)
 {
-    __shared__ __attribute__((aligned(16))) F5Lds S;
+    __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S;
     const FlatArgs& a = fa.f;
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
@@ -863,7 +881,7 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
     const int64_t ro = a.read_off[r];
     const int32_t L = int32_t(a.read_off[r + 1] - ro);
     const int32_t P = a.hap_len[r];
-    if (L > F5_MAX_READ || P > F5_MAX_POOL) {
+    if (L > MAXR || P > F5_MAX_POOL) {
         if (lane == 0) atomicAdd(fa.n_unhandled, 1);
         return;
     }
@@ -968,28 +986,34 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                 if (lane == 0) atomicAdd(fa.n_unhandled, 1);
                 return;
             }
-            constexpr int ENT_DW = int(sizeof(PIndel) / 4);
             tab_lo = n_tab ? lo : 0;
-            const uint32_t* __restrict__ gt = reinterpret_cast<const uint32_t*>(a.job.tab + tab_lo);
-            for (int j = lane; j < n_tab * ENT_DW; j += 64) S.tab[j] = gt[j];
+            if (lane < n_tab) { // (n_tab <= F5_TAB <= 64: a lane an entry)
+                const PIndel& g = a.job.tab[tab_lo + lane];
+                F5Tab e;
+                e.pos = g.pos;
+                e.del = g.del;
+                e.ins_len = g.ins_len;
+                e.type_cand = unsigned(g.type) | (unsigned(g.cand) << 8);
+                S.tab[lane] = e;
+            }
         }
         __syncthreads();
         const unsigned long long tc = clock64();
         stamp[2] += tc - ta; // staging + table copy
         // ---- phase A, a lane per candidate alignment: the walk of its path leaves the alignment's TRANSITIONS in its slot: one word per
         // op that covers read positions, and one for the read's end
-        uint32_t* const ent = myslot + F5_ENT0;
         int n_ent = 0;
         bool bad = false;
         if (has) {
             int pos = 0;
             unsigned npen = 0;
             auto put = [&](const unsigned at, const unsigned np, const bool clip, const int hidx) {
-                if (n_ent >= F5_ENTS || np > 4u || hidx < -256 || hidx > 3839) {
-                    bad = true; // (more transitions than the slot holds: the host form takes the read)
+                if (n_ent > F5_SEGS || np > 4u || hidx < -256 || hidx > 3839) { // (n_ent <= n_seg by construction; the test guards the slot)
+                    bad = true; // (the host form takes the read)
                     return;
                 }
-                ent[n_ent++] = at | (np << 9) | (clip ? 1u << 15 : 0u) | (unsigned(hidx + 256) << 16);
+                myslot[f5_ent_word(n_ent)] = at | (np << 9) | (clip ? 1u << 15 : 0u) | (unsigned(hidx + 256) << 16);
+                ++n_ent;
             };
             auto on_op = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
                 if ((kind == SK_OP_BASES || kind == SK_OP_SOFT_CLIP) && len > 0) {
@@ -1069,9 +1093,9 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                 }
                 // the op is done (or none begun yet): enter the next one -- by selects, not branches: the loop has one back edge
                 const bool adv = (p >= stop);
-                const uint32_t cur = ent[e];
+                const uint32_t cur = myslot[f5_ent_word(e)];
                 const int e1 = (e + 1 < n_ent) ? e + 1 : e;
-                const int next_start = int(ent[e1] & 0x1ffu);
+                const int next_start = int(myslot[f5_ent_word(e1)] & 0x1ffu);
                 const unsigned np = adv ? ((cur >> 9) & 63u) : 0u; // (at most 4: put() hands anything longer to the host form)
                 const double l1 = __dadd_rn(lnp, ln_noncand);
                 lnp = (np >= 1u) ? l1 : lnp;
@@ -1099,6 +1123,13 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         stamp[6] = clock64();
         for (int i = 0; i < 8; ++i) fa.dbg[size_t(r) * 8 + i] = stamp[i];
     }
+}
+
+// the rows of terms sized for the job's longest read: 150-base reads leave room for one more wave per CU than the 256-base form
+static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
+{
+    if (fs.f.max_read_len <= 160) hipLaunchKernelGGL(flatten_score_kernel<160>, dim3(n_reads), dim3(64), 0, st, fs);
+    else hipLaunchKernelGGL(flatten_score_kernel<F5_MAX_READ>, dim3(n_reads), dim3(64), 0, st, fs);
 }
 
 // the records in set order, for the host (sk_enum_device_fetch_cals; a job whose stage 3 runs on the host): pool[list[c]] -> cals[c], a wave
@@ -2110,7 +2141,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         fs.n_unhandled = B.counters.as<int32_t>() + (Caps::K + 7);
         fs.write_cals = 0;
         fs.dbg = nullptr;
-        hipLaunchKernelGGL(flatten_score_kernel, dim3(n), dim3(64), 0, st, fs);
+        launch_flatten_score(n, st, fs);
         SK_HIP(hipGetLastError());
         lap("F5 flatten + score");
         if (in->want_stage3) {
@@ -2280,7 +2311,7 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
         SK_HIP(hipMalloc(reinterpret_cast<void**>(&d), nb * 8));
         SK_HIP(hipMemsetAsync(d, 0, nb * 8, st));
         fs.dbg = d;
-        hipLaunchKernelGGL(flatten_score_kernel, dim3(g_last.n), dim3(64), 0, st, fs);
+        launch_flatten_score(g_last.n, st, fs);
         std::vector<unsigned long long> h(nb);
         SK_HIP(hipMemcpyAsync(h.data(), d, nb * 8, hipMemcpyDeviceToHost, st));
         SK_HIP(hipStreamSynchronize(st));
@@ -2305,9 +2336,9 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
             SK_HIP(hipEventCreate(&a0));
             SK_HIP(hipEventCreate(&a1));
             FusedScoreArgs f2 = g_last.fs;
-            hipLaunchKernelGGL(flatten_score_kernel, dim3(grid), dim3(64), 0, st, f2);
+            launch_flatten_score(grid, st, f2);
             SK_HIP(hipEventRecord(a0, st));
-            for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(flatten_score_kernel, dim3(grid), dim3(64), 0, st, f2);
+            for (int k = 0; k < 5; ++k) launch_flatten_score(grid, st, f2);
             SK_HIP(hipEventRecord(a1, st));
             SK_HIP(hipEventSynchronize(a1));
             float ms = 0;
@@ -2323,7 +2354,7 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
     }
     for (int i = 0; i < reps; ++i) {
         if (g_last.fused) { // F5: the records -> the scores in one launch
-            hipLaunchKernelGGL(flatten_score_kernel, dim3(g_last.n), dim3(64), 0, st, g_last.fs);
+            launch_flatten_score(g_last.n, st, g_last.fs);
             continue;
         }
         SK_HIP(hipMemsetAsync(B.mask_arena.p, 0, g_last.mask_bytes, st));

@@ -76,6 +76,10 @@ for step in "$@"; do
         SK_A5_FUSED=$f timeout 300 python bench.py --only a5 --steps 20 --warmup 3 > $OUT/a5_fused$f.json 2>$OUT/a5_fused$f.err; echo "fused=$f: $(cat $OUT/a5_fused$f.json | head -c 600)"
         SK_A5_FUSED=$f timeout 300 python bench.py --only a5 --a5-reads 65536 --steps 10 --warmup 2 > $OUT/a5_65536_fused$f.json 2>$OUT/a5_65536_fused$f.err; echo "fused=$f 2^16 reads: $(cat $OUT/a5_65536_fused$f.json | head -c 600)"
       done ;;
+    a5)
+      timeout 600 python -m pytest tests/test_device_enumeration.py -m gpu -x -q > $OUT/pytest_a5.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_a5.log; tail -3 $OUT/pytest_a5.log
+      timeout 300 python bench.py --only a5 --steps 10 --warmup 2 > $OUT/a5.json 2>$OUT/a5.err; echo "a5: $(cat $OUT/a5.json | head -c 500)"
+      SK_F5_TIMING=1 timeout 300 python bench.py --only a5 --a5-reads 4096 --steps 10 --warmup 2 > $OUT/a5_4096.json 2>$OUT/a5_4096.err; echo "a5 4096: $(cat $OUT/a5_4096.json | head -c 300)"; grep "f5-timing" $OUT/a5_4096.err | tail -9 ;;
     feed)
       timeout 600 python -m pytest tests/test_bam_feed.py -m gpu -x -q > $OUT/pytest_feed.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_feed.log; tail -4 $OUT/pytest_feed.log
       timeout 300 python bench.py --only feed_slice --steps 8 --warmup 2 > $OUT/feed_slice.json 2>$OUT/feed_slice.err; echo "feed_slice rc=$?"; cat $OUT/feed_slice.json; tail -3 $OUT/feed_slice.err ;;
