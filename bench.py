@@ -600,6 +600,12 @@ def main():
     fast_opt_i.fast_form = 1
     dt_if, iloci_f, kms_if = timed(lambda: drs.grid_lhood(opt=fast_opt_i), args.steps, args.warmup, drs.n_indels)
     indel_alg_bytes = 16 * drs.n_reads + 8 * 21 * drs.n_indels  # 16 B per read + 8 B per state
+    # ... and on the same reads with ONE read length, what a WGS sample has (the batch above mixes lengths 8..200 into 15 % of the reads, a
+    # test input): the two logs of get_het_observed_allele_ratio are then 19 pairs per indel, not per read
+    hrs.read_length[:] = 150
+    drs1 = device.DeviceReadScoreBatch(hrs, dev)
+    dt_i1, iloci_1, kms_i1 = timed(lambda: drs1.grid_lhood(), args.steps, args.warmup, drs1.n_indels)
+    del drs1
     hag = synth.allele_group_batch(args.indels, rng)
     dag = device.DeviceAlleleGroupBatch(hag, dev)
     dt_g, gloci, kms_g = timed(lambda: dag.genotype_lhoods(), args.steps, args.warmup, dag.n_groups)
@@ -607,6 +613,10 @@ def main():
     fast_opt_g.fast_form = 1
     dt_gf, gloci_f, kms_gf = timed(lambda: dag.genotype_lhoods(opt=fast_opt_g), args.steps, args.warmup, dag.n_groups)
     group_alg_bytes = (8 * capi.MAX_ALT + 5) * dag.n_reads + 128 * dag.n_groups
+    hag.read_length[:] = 150  # ... and with one read length, as for the grid kernel
+    dag1 = device.DeviceAlleleGroupBatch(hag, dev)
+    dt_g1, gloci_1, kms_g1 = timed(lambda: dag1.genotype_lhoods(), args.steps, args.warmup, dag1.n_groups)
+    del dag1
     del drs, dag
 
     # ---- next row f2: GlobalAligner<int>, haplotype vs reference segment (device-resident entry point) ----
@@ -729,6 +739,8 @@ def main():
         "indel_grid_loci_per_s": iloci / dt_i, "indel_grid_ms_per_step": dt_i / args.steps * 1e3,
         "roofline_indel_grid": roof("indel_grid_lhood_kernel", indel_alg_bytes, kms_i, traffic.get("indel_grid_lhood_kernel")),
         "indel_grid_fast_form_loci_per_s": iloci_f / dt_if, "indel_grid_fast_form_kernel_ms": kms_if,
+        "indel_grid_one_read_length_loci_per_s": iloci_1 / dt_i1, "indel_grid_one_read_length_kernel_ms": kms_i1,
+        "allele_group_one_read_length_loci_per_s": gloci_1 / dt_g1, "allele_group_one_read_length_kernel_ms": kms_g1,
         "allele_group_fast_form_loci_per_s": gloci_f / dt_gf, "allele_group_fast_form_kernel_ms": kms_gf,
         "fast_form_note": "sk_indel_options.fast_form = 1: the algebraically equal form with two exp per read shared by its states and one "
                           "log per state (agrees with the reference's operation order to ~1e-15 relative, within north_star's 1e-5; the "

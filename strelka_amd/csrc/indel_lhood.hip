@@ -156,6 +156,41 @@ __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a
     const int ex = a.exact_libm;
     const SkLibmTables lt = sk_libm_tables_default();
 
+    // The two logs of get_het_observed_allele_ratio depend on (read length, the indel's lengths, the state's ratio) and on nothing else
+    // of the read: when all reads of the indel have one length -- every WGS sample -- they are 19 pairs per indel, evaluated once, by
+    // the operations the per-read form performs (the same values bit for bit), instead of 19 pairs per read: two of the six
+    // transcendentals of a (read, het state).
+    __shared__ double s_lr[N_STATES], s_li[N_STATES];
+    bool one_length = false;
+    if (!FAST) {
+        unsigned lo = 0xffffffffu, hi = 0;
+        for (int r = lane; r < n; r += WAVE) {
+            const unsigned rl = a.b.read_length[r0 + r];
+            lo = min(lo, rl);
+            hi = max(hi, rl);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, unsigned(__shfl_xor(int(lo), d)));
+            hi = max(hi, unsigned(__shfl_xor(int(hi), d)));
+        }
+        one_length = (n > 0 && lo == hi);
+        if (one_length && lane < 2 * SK_HET_RES + 1) {
+            // lane 0: the 0.5 state (2); lanes 1..HET_RES: het_lhood_low of i = lane - 1 (state 3 + i); the rest: het_lhood_high of i
+            // (state 3 + 2*HET_RES - (i + 1))
+            const bool mid = (lane == 0), low = (lane >= 1 && lane <= SK_HET_RES);
+            const int i = mid ? 0 : low ? lane - 1 : lane - 1 - SK_HET_RES;
+            double lr = mid ? a.loghalf : low ? a.log_chet_ratio[i] : a.log_het_ratio[i];
+            double li = mid ? a.loghalf : low ? a.log_het_ratio[i] : a.log_chet_ratio[i];
+            const double ratio = mid ? 0.5 : low ? a.het_ratio[i] : a.chet_ratio[i];
+            if (!is_breakpoint) het_observed_allele_ratio(lo, flank, del_len, ins_len, ratio, lr, li, ex, lt);
+            const int state = mid ? 2 : low ? 3 + i : 3 + (2 * SK_HET_RES - (i + 1));
+            s_lr[state] = lr;
+            s_li[state] = li;
+        }
+        __syncthreads();
+    }
+
     double acc = 0.; // lanes 0..20: the running sum of state `lane`
     for (int base = 0; base < n; base += WAVE) {
         const int r = base + lane;
@@ -202,6 +237,11 @@ __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a
                 // SOMATIC_DIGT / STAR_DIINDEL: 0 = REF/NOINDEL, 1 = HOM, 2 = HET
                 s_term[0][lane] = integrate_out_mapping(a.map, na, noindel_lnp, ex, lt);
                 s_term[1][lane] = integrate_out_mapping(a.map, na, hom_lnp, ex, lt);
+                if (one_length) { // (wave-uniform)
+                    for (int s = 2; s < N_STATES; ++s)
+                        s_term[s][lane] =
+                            integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, s_lr[s]), __dadd_rn(hom_lnp, s_li[s]), ex, lt), ex, lt);
+                } else {
                 {
                     double lr = a.loghalf, li = a.loghalf;
                     if (!is_breakpoint) het_observed_allele_ratio(rl, flank, del_len, ins_len, 0.5, lr, li, ex, lt);
@@ -220,6 +260,7 @@ __global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a
                         s_term[3 + (2 * SK_HET_RES - (i + 1))][lane] =
                             integrate_out_mapping(a.map, na, log_sum2(__dadd_rn(noindel_lnp, lr), __dadd_rn(hom_lnp, li), ex, lt), ex, lt);
                     }
+                }
                 }
                 } // exact form
             }
@@ -303,6 +344,52 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
         ins_len[k] = a.b.ins_len[size_t(grp) * MAXA + k];
     }
 
+    // The allele-ratio priors of a het genotype (get_het_observed_allele_ratio once or twice and, for two alternate alleles, their
+    // renormalisation) depend on (read length, the alleles' lengths) only: with one read length in the group -- every WGS sample -- a
+    // pair per genotype and group, evaluated once by the per-read form's own operations, not per read (as I1 does).
+    __shared__ double s_lp0[MAXGT], s_lp1[MAXGT];
+    bool one_length = false;
+    {
+        unsigned lo = 0xffffffffu, hi = 0;
+        for (int r = lane; r < n; r += WAVE) {
+            const unsigned rl = a.b.read_length[r0 + r];
+            lo = min(lo, rl);
+            hi = max(hi, rl);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, unsigned(__shfl_xor(int(lo), d)));
+            hi = max(hi, unsigned(__shfl_xor(int(hi), d)));
+        }
+        one_length = (n > 0 && lo == hi && ploidy != 1);
+        if (one_length && lane < gcount) {
+            int a1 = 0;
+            while ((a1 + 1) * (a1 + 2) / 2 <= lane) ++a1;
+            const int a0 = lane - a1 * (a1 + 1) / 2;
+            double lp0 = a.loghalf, lp1 = a.loghalf;
+            if (a0 != a1) {
+                unsigned d1 = 0, i1 = 0, d0 = 0, i0 = 0; // (run-time allele indices: selected, not indexed, so that the arrays stay in registers)
+#pragma unroll
+                for (int k = 0; k < MAXA; ++k) {
+                    if (k == a1 - 1) { d1 = del_len[k]; i1 = ins_len[k]; }
+                    if (k == a0 - 1) { d0 = del_len[k]; i0 = ins_len[k]; }
+                }
+                het_observed_allele_ratio(lo, flank, d1, i1, 0.5, lp0, lp1, ex, lt);
+                if (a0 > 0) {
+                    double log_ref_prior = a.loghalf;
+                    lp0 = a.loghalf;
+                    het_observed_allele_ratio(lo, flank, d0, i0, 0.5, log_ref_prior, lp0, ex, lt);
+                    const double norm = log_sum2(lp0, lp1, ex, lt);
+                    lp0 = __dsub_rn(lp0, norm);
+                    lp1 = __dsub_rn(lp1, norm);
+                }
+            }
+            s_lp0[lane] = lp0;
+            s_lp1[lane] = lp1;
+        }
+        __syncthreads();
+    }
+
     double acc = 0.;
     unsigned cnt_f[MAXA + 2], cnt_r[MAXA + 2]; // lane 0 only
 #pragma unroll
@@ -350,7 +437,9 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
                             if (a1 >= full) continue;
                             const int gi = a0 + (a1 * (a1 + 1) / 2);
                             double raw;
-                            if (a0 != a1) {
+                            if (a0 != a1 && one_length) { // (wave-uniform)
+                                raw = log_sum2(__dadd_rn(L[a0], s_lp0[gi]), __dadd_rn(L[a1], s_lp1[gi]), ex, lt);
+                            } else if (a0 != a1) {
                                 double lp0 = a.loghalf, lp1 = a.loghalf;
                                 het_observed_allele_ratio(rlen, flank, del_len[a1 - 1], ins_len[a1 - 1], 0.5, lp0, lp1, ex, lt);
                                 if (a0 > 0) { // het-alt: both alleles' indel ratios, renormalised (:83-95)

@@ -426,6 +426,31 @@ def test_allele_group_genotype_lhoods(gpu):
     assert np.array_equal(got2["counts"], counts2)
 
 
+def test_indel_kernels_with_one_read_length(gpu):
+    """every read of an indel / allele group as long as the others (a WGS sample): the kernels evaluate the allele-ratio priors once per
+    indel / genotype then, not per read -- the same bits; groups where a few reads differ take the per-read form"""
+    from strelka_amd import capi
+    rng = np.random.default_rng(305)
+    rb = synth.readscore_batch(300, rng, depth_mean=110.0, breakpoint_rate=0.05)
+    for length in (150, 36, 251):
+        rb.read_length[:] = length
+        rb.read_length[rb.read_off[7]:rb.read_off[9]] = rng.integers(8, 200, int(rb.read_off[9] - rb.read_off[7]))  # two mixed indels among them
+        opt = gpu.indel_options(True)
+        got = gpu.indel_grid_lhood(rb, opt, False)
+        want = pyoracle.indel_grid_lhood(rb, opt.min_read_bp_flank, 0.5, False)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), length
+    for max_alt in (capi.MAX_ALT, capi.MAX_ALT_WIDE):
+        ab = synth.allele_group_batch(250, rng, depth_mean=45.0, min_alt=1, max_alt=max_alt)
+        for length in (150, 40):
+            ab.read_length[:] = length
+            ab.read_length[ab.read_off[3]:ab.read_off[5]] = rng.integers(8, 200, int(ab.read_off[5] - ab.read_off[3]))
+            got = gpu.allele_group_genotype_lhoods(ab)
+            lh, counts, ng = pyoracle.allele_group_genotype_lhoods(ab)
+            assert np.array_equal(got["n_genotypes"], ng)
+            assert np.array_equal(got["lhood"].view(np.uint64), lh.view(np.uint64)), (max_alt, length)
+            assert np.array_equal(got["counts"], counts)
+
+
 def test_allele_group_genotype_lhoods_wide(gpu):
     """groups of 4..8 alternate alleles (a multi-sample run's): sk_allele_group_genotype_lhoods_wide against the oracle on fresh
     groups and against the REFERENCE's own function on the committed fixture (tests/golden/make_golden_wide_groups.py)"""
