@@ -65,45 +65,50 @@ __device__ __forceinline__ float log_sum2f(float x1, float x2, const int exact_l
     return __fadd_rn(x1, l);
 }
 
-// Every memoised term of one call, one LDS row per (q-score, call == reference base): the fields are stored in the order
-// the accumulators use them, so the per-call loop is loads + adds with no selects except the strand one.
-struct QRow
+// Every memoised term of one call, one LDS row per (q-score, call == reference base): 31 floats in the order the accumulators use
+// them -- ref, het, hom (is_ref ? (v2, v1, v0) : (v0, v1, v2), :56-64), the off-strand term (is_ref ? ln_comp_error_prob :
+// ln_error_prob + ln(1/3), :213,:221), hi[HET_RES] (-> grid[2*HET_RES-(r+1)]: is_ref ? c0 : c1, :104-110,:149-151), lo[HET_RES]
+// (-> grid[r]: is_ref ? c1 : c0), on[HET_RES] (the on-strand term of the strand states: is_ref ? t0 : t1, :197-206) -- so that the
+// per-call loop is loads + adds with no selects except the strand one.  The loop reads a row as six (with the strand terms: eight)
+// `ds_read_b128`, written out: from source the compiler reads the same bytes in 16 pieces of 8 and 12, and the LDS pipe is what bounds
+// the kernel (busy 80 % of its time, profiles/r04_v26_som_sq_counters.txt).
+constexpr int QROW_HI = 4, QROW_LO = 4 + HET_RES, QROW_ON = 4 + 2 * HET_RES;
+struct alignas(16) QRow
 {
-    float ref, het, hom;    // simple genotypes: is_ref ? (v2, v1, v0) : (v0, v1, v2)            (:56-64)
-    float off;              // off-strand term: is_ref ? ln_comp_error_prob : ln_error_prob+ln(1/3) (:213,:221)
-    float hi[HET_RES];      // -> grid[2*HET_RES-(r+1)]: is_ref ? c0 : c1                          (:104-110,:149-151)
-    float lo[HET_RES];      // -> grid[r]:               is_ref ? c1 : c0
-    float on[HET_RES];      // on-strand term of the strand states: is_ref ? t0 : t1              (:197-206)
-    float pad[5];           // 144-byte rows: a 128-byte stride would put every row on the same two LDS bank groups
+    float f[32];
+    float pad[4]; // 144-byte rows = 36 banks: sixteen consecutive rows tile the 64 banks
 };
-static_assert(sizeof(QRow) == 144, "rows are read with 128-bit LDS loads");
-constexpr int N_QROWS = 2 * SK_NQ6;
+static_assert(sizeof(QRow) == 144 && 4 + 3 * HET_RES <= 32 && 4 + 2 * HET_RES <= 24, "eight / six 128-bit loads hold the fields");
+// row of (q, is_ref): one further row per eight q-scores, so that q and q + 8 (binned qualities: 32 / 40) do not share banks
+__device__ __forceinline__ int qrow_index(const unsigned q, const bool is_ref) { return int(2u * q + (is_ref ? 1u : 0u) + (q >> 3)); }
+constexpr int N_QROWS = 2 * SK_NQ6 + SK_NQ6 / 8;
 
 __device__ __forceinline__ void fill_qrows(const SkTables* __restrict__ T, QRow* s_q, const int tid, const int nthreads)
 {
-    for (int i = tid; i < N_QROWS; i += nthreads) {
+    for (int i = tid; i < 2 * SK_NQ6; i += nthreads) {
         const int q = i >> 1;
         const bool is_ref = (i & 1) != 0;
         QRow r;
-        r.ref = is_ref ? T->s_v2[q] : T->s_v0[q];
-        r.het = T->s_v1[q];
-        r.hom = is_ref ? T->s_v0[q] : T->s_v2[q];
-        r.off = is_ref ? T->t_off_ref[q] : T->t_off_alt[q];
-        r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = r.pad[4] = 0.f;
+        r.f[0] = is_ref ? T->s_v2[q] : T->s_v0[q];
+        r.f[1] = T->s_v1[q];
+        r.f[2] = is_ref ? T->s_v0[q] : T->s_v2[q];
+        r.f[3] = is_ref ? T->t_off_ref[q] : T->t_off_alt[q];
 #pragma unroll
         for (int k = 0; k < HET_RES; ++k) {
-            r.hi[k] = is_ref ? T->s_c0[k][q] : T->s_c1[k][q];
-            r.lo[k] = is_ref ? T->s_c1[k][q] : T->s_c0[k][q];
-            r.on[k] = is_ref ? T->t_c0[k][q] : T->t_c1[k][q];
+            r.f[QROW_HI + k] = is_ref ? T->s_c0[k][q] : T->s_c1[k][q];
+            r.f[QROW_LO + k] = is_ref ? T->s_c1[k][q] : T->s_c0[k][q];
+            r.f[QROW_ON + k] = is_ref ? T->t_c0[k][q] : T->t_c1[k][q];
         }
-        s_q[i] = r;
+        for (int k = 4 + 3 * HET_RES; k < 32; ++k) r.f[k] = 0.f;
+        r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0.f;
+        s_q[qrow_index(unsigned(q), is_ref)] = r;
     }
 }
 
 // measured on the bench input (ms per 2^20 loci, S1 / S2): (4 waves/SIMD, 32-call chunks) 0.78, (4, 16) 0.75,
 // (5, 16) 0.71; S2 at 1 / 2 / 3 waves per SIMD 0.34 / 0.27 / 0.30
 #ifndef SOM_WPE
-#define SOM_WPE 5       // S1: waves per SIMD the register allocation is held to (96 VGPRs; it needs 90)
+#define SOM_WPE 4       // S1: waves per SIMD the register allocation is held to (128 VGPRs: a row of ten float4s + 39 accumulators)
 #endif
 #ifndef SOM_CHUNK
 #define SOM_CHUNK 16
@@ -131,6 +136,28 @@ struct LhoodAcc
     unsigned alt_count[4];
 };
 
+// a row as 128-bit LDS reads, issued together and waited for once
+typedef float som_v4f __attribute__((ext_vector_type(4)));
+template <bool WITH_STRAND>
+__device__ __forceinline__ void read_qrow(const QRow* row, som_v4f (&v)[8])
+{
+    const unsigned at = unsigned(uintptr_t((const __attribute__((address_space(3))) QRow*)row)); // (the LDS address: the low half of the generic one)
+    if (WITH_STRAND) {
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                     "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\t"
+                     "ds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                     : "v"(at)
+                     : "memory");
+    } else {
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\tds_read_b128 %3, %6 offset:48\n\t"
+                     "ds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                     : "v"(at)
+                     : "memory");
+    }
+}
+
 // the per-call updates of one sample's accumulators for calls row[0..cnt), in pileup order
 template <bool WITH_STRAND>
 __device__ __forceinline__ void accumulate_calls(const uint16_t* row, const int cnt, const unsigned ref_gt, const QRow* Q, LhoodAcc& A)
@@ -143,21 +170,23 @@ __device__ __forceinline__ void accumulate_calls(const uint16_t* row, const int 
 #pragma unroll
             for (unsigned b = 0; b < 4; ++b) A.alt_count[b] += (obs == b) ? 1u : 0u;
         }
-        const QRow& R = Q[2 * q + (is_ref ? 1 : 0)];
-        A.acc[SOM_REF] = __fadd_rn(A.acc[SOM_REF], R.ref);
-        A.acc[SOM_HET] = __fadd_rn(A.acc[SOM_HET], R.het);
-        A.acc[SOM_HOM] = __fadd_rn(A.acc[SOM_HOM], R.hom);
+        som_v4f R4[8];
+        read_qrow<WITH_STRAND>(Q + qrow_index(q, is_ref), R4);
+        auto f = [&](const int k) -> float { return R4[k >> 2][k & 3]; }; // (constant k after unrolling)
+        A.acc[SOM_REF] = __fadd_rn(A.acc[SOM_REF], f(0));
+        A.acc[SOM_HET] = __fadd_rn(A.acc[SOM_HET], f(1));
+        A.acc[SOM_HOM] = __fadd_rn(A.acc[SOM_HOM], f(2));
 #pragma unroll
         for (int r = 0; r < HET_RES; ++r) {
-            A.acc[SOM_SIZE + (2 * HET_RES - (r + 1))] = __fadd_rn(A.acc[SOM_SIZE + (2 * HET_RES - (r + 1))], R.hi[r]);
-            A.acc[SOM_SIZE + r] = __fadd_rn(A.acc[SOM_SIZE + r], R.lo[r]);
+            A.acc[SOM_SIZE + (2 * HET_RES - (r + 1))] = __fadd_rn(A.acc[SOM_SIZE + (2 * HET_RES - (r + 1))], f(QROW_HI + r));
+            A.acc[SOM_SIZE + r] = __fadd_rn(A.acc[SOM_SIZE + r], f(QROW_LO + r));
         }
         if (WITH_STRAND) {
             const bool fwd = SKC_FWD(bc);
-            const float off = R.off;
+            const float off = f(3);
 #pragma unroll
             for (int r = 0; r < HET_RES; ++r) {
-                const float on = R.on[r];
+                const float on = f(QROW_ON + r);
                 A.sf[r] = __fadd_rn(A.sf[r], fwd ? on : off);
                 A.sr[r] = __fadd_rn(A.sr[r], fwd ? off : on);
             }
