@@ -651,8 +651,8 @@ __global__ __launch_bounds__(64) void flatten_kernel(const FlatArgs a)
 // A read this form does not hold (longer than F5_MAX_READ bases, pool over F5_MAX_POOL bytes) is counted in *n_unhandled: the caller
 // then runs F1-F3 + A1c over the job.
 constexpr int F5_MAX_READ = 256;  // (as F3's wave form; longer reads and larger pools take the staged chain)
-constexpr int F5_MAX_POOL = 1024;
-constexpr int F5_TAB = 48;       // span of table indices the indels of one round's candidate alignments may cover
+constexpr int F5_MAX_POOL = 768;
+constexpr int F5_TAB = 32;       // span of table indices the indels of one round's candidate alignments may cover
 
 static_assert(F5_TAB <= 64, "the table copy is a lane an entry");
 
@@ -700,10 +700,12 @@ struct F5Lds
     uint32_t slot[64 * F5_SLOT];
     // what the walk looks up per path segment (a chain of dependent look-ups: from HBM / L2 they cost a wave ~100 us per round)
     F5Tab tab[F5_TAB];
-    int32_t ins_off[INS_CAP], ins_len[INS_CAP];
-    uint32_t ins_src[INS_CAP];
+    int32_t ins_off[INS_CAP];
     int16_t ins_idx[INS_CAP];
 };
+// (the CU hands LDS out in 1 280-byte pieces: 10 240 bytes are sixteen waves to a CU, one byte more fourteen)
+static_assert(sizeof(F5Lds<152>) <= 10240, "sixteen waves of the short-read form to a CU");
+static_assert(INS_CAP <= 64, "a lane an insert");
 
 struct F5Rec // accessors of a compact record
 {
@@ -891,12 +893,17 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
     {
         const int16_t* idx = a.ins_idx + size_t(r) * INS_CAP;
         const int32_t* off = a.ins_off + size_t(r) * INS_CAP;
+        // (insert k's length and source stay in lane k's registers -- the fill below takes them by readlane; the walk looks up
+        // index and offset, which go to LDS)
+        int32_t my_ins_off = 0, my_ins_len = 0;
+        uint32_t my_ins_src = 0;
         if (lane < n_ins) {
             const int t_idx = idx[lane];
             S.ins_idx[lane] = int16_t(t_idx);
-            S.ins_off[lane] = off[lane];
-            S.ins_len[lane] = int32_t(a.job.tab[t_idx].ins_len);
-            S.ins_src[lane] = a.job.tab[t_idx].ins_off;
+            my_ins_off = off[lane];
+            S.ins_off[lane] = my_ins_off;
+            my_ins_len = int32_t(a.job.tab[t_idx].ins_len);
+            my_ins_src = a.job.tab[t_idx].ins_off;
         }
         const int32_t win_len = a.win_len[r];
         // (the window's bytes first: they do not depend on the insert table just written)
@@ -910,8 +917,8 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         }
         __syncthreads();
         for (int k = 0; k < n_ins; ++k) { // the insert sequences, in table order (a later one overwrites an earlier one, as pool_fill_kernel)
-            const int32_t o = S.ins_off[k], n = S.ins_len[k];
-            const uint32_t src = S.ins_src[k];
+            const int32_t o = __builtin_amdgcn_readlane(my_ins_off, k), n = __builtin_amdgcn_readlane(my_ins_len, k);
+            const uint32_t src = uint32_t(__builtin_amdgcn_readlane(int(my_ins_src), k));
             for (int32_t i = lane; i < n; i += 64)
                 if (o + i < P) S.hap[o + i] = code_of(a.ins_pool[src + uint32_t(i)]);
         }
@@ -1125,10 +1132,11 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
     }
 }
 
-// the rows of terms sized for the job's longest read: 150-base reads leave room for one more wave per CU than the 256-base form
+// the rows of terms sized for the job's longest read: with 150-base reads a wave's LDS is 10 KB, sixteen waves to a CU (the 256-base
+// form: twelve)
 static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
 {
-    if (fs.f.max_read_len <= 160) hipLaunchKernelGGL(flatten_score_kernel<160>, dim3(n_reads), dim3(64), 0, st, fs);
+    if (fs.f.max_read_len <= 152) hipLaunchKernelGGL(flatten_score_kernel<152>, dim3(n_reads), dim3(64), 0, st, fs);
     else hipLaunchKernelGGL(flatten_score_kernel<F5_MAX_READ>, dim3(n_reads), dim3(64), 0, st, fs);
 }
 
