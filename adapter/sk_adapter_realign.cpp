@@ -216,8 +216,9 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
     // Small jobs stay with the host statement of the search (one device round trip: the scoring launch); the device pipeline -- three
     // waits per job: level counts, set sizes, results -- is for jobs that have the reads to fill it.  Alone on a GPU it overtakes the host
     // search at ~100 reads per job on WGS-like indel densities and ~50 on dense ones (tools/diag/enum_threshold.py); with eight caller
-    // processes sharing the GPU every wait costs ~0.6 ms and a device job ~5 ms, and a threshold of 160 made the realignment hook of
-    // the germline leg slower (0.92 -> 1.72 s per 16 Mb, profiles/r04_v17_e2e_sweep.json): 512 stays.  An explicit
+    // processes sharing the GPU a device job costs 0.56 ms inside the C-ABI against 0.30 ms for the host search + one scoring launch
+    // (profiles/r04_v43_e2e_device_enumeration.json: every job on the device, 32 Mb: +0.9 s over the eight processes, +0.2 s of wall
+    // time, identical output; the enumerated reads are 36 % of the jobs' reads, the gate settles the rest): 512 stays.  An explicit
     // $SK_ENUMERATION decides for every job (the tests run whole suites in one mode).
     {
         static const bool isModePinned(std::getenv("SK_ENUMERATION") != nullptr);

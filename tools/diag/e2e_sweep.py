@@ -22,7 +22,11 @@ ENV_SETS = [
     ("window_16384", {"STRELKA_AMD_READ_WINDOW": "16384"}),
     ("window_32768", {"STRELKA_AMD_READ_WINDOW": "32768"}),
     ("staged_chain", {"SK_A5_FUSED": "0"}),
+    ("min_reads_1", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1"}),
+    ("min_reads_32", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "32"}),
 ]
+if os.environ.get("SK_SWEEP_ONLY"):  # a comma-separated choice of the settings above
+    ENV_SETS = [s for s in ENV_SETS if s[0] in os.environ["SK_SWEEP_ONLY"].split(",")]
 
 
 def body(path):
