@@ -812,6 +812,8 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
                 a.mapq_count[l] = mq_n;
                 a.mapq_zero[l] = mq_zero;
                 a.mapq_sumsq[l] = mq_sq;
+            } else {
+                a.mapq_count[l] = 0; // (entry n_loci of the counts, as the columns' have)
             }
         } else {
             a.count[l] = (l < a.n_loci) ? cnt : 0u;
@@ -850,6 +852,120 @@ struct MinOp
 };
 
 inline int64_t align256(const int64_t x) { return (x + 255) & ~int64_t(255); }
+
+// ---- the stream's small steps as three launches.  A window's push used to be ~30 submissions -- five device-to-device copies of the
+// carried tail, the span split, two rocPRIM scans over the reads and three to five over the loci (two launches each), four copies of
+// counters into the output block -- around the four kernels that do the work.  Here: one launch copies every carried piece, one makes
+// both running bounds of the reads' spans, one makes every column's offsets and moves the counters: ~12 submissions per push.  (It
+// is 4 % of a window's 0.45 ms, not more: what a push waits for is P1's latency on 2 200 reads -- 0.11 ms, a chain of dependent loads
+// per read -- and the 2.5 MB of columns and records going back to the host.)
+struct CopySeg
+{
+    const char* src;
+    char* dst;
+    int64_t bytes;
+};
+struct CopyArgs
+{
+    CopySeg seg[6];
+    int n;
+};
+// blockIdx.y = the piece, grid-stride over it in 16-byte words where both ends allow
+__global__ __launch_bounds__(256) void copy_segments_kernel(const CopyArgs a)
+{
+    const CopySeg s = a.seg[blockIdx.y];
+    const int64_t tid = int64_t(blockIdx.x) * 256 + threadIdx.x, stride = int64_t(gridDim.x) * 256;
+    if (((reinterpret_cast<uintptr_t>(s.src) | reinterpret_cast<uintptr_t>(s.dst)) & 15u) == 0) {
+        const int64_t words = s.bytes / 16;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(s.src);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(s.dst);
+        for (int64_t i = tid; i < words; i += stride) dst[i] = src[i];
+        for (int64_t i = words * 16 + tid; i < s.bytes; i += stride) s.dst[i] = s.src[i];
+    } else {
+        for (int64_t i = tid; i < s.bytes; i += stride) s.dst[i] = s.src[i];
+    }
+}
+
+// a block's inclusive scan of one value per thread (1 024 threads), `op` associative; `carry` joins from the chunk before
+template <typename T, typename OP>
+__device__ __forceinline__ T block_scan_1024(T v, const OP op, T* s_wave /*[16]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const T up = __shfl_up(v, d, 64);
+        if (lane >= d) v = op(up, v);
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    if (wave > 0) {
+        T pre = s_wave[0];
+        for (int w = 1; w < wave; ++w) pre = op(pre, s_wave[w]);
+        v = op(pre, v);
+    }
+    __syncthreads();
+    return v;
+}
+
+// block 0: maxend[i] = max of the spans' ends up to read i; block 1: minbegin[i] = min of the spans' begins from read i on
+__global__ __launch_bounds__(1024) void span_bounds_kernel(const int2* __restrict__ span, int* __restrict__ maxend, int* __restrict__ minbegin, const int n)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const bool fwd = (blockIdx.x == 0);
+    if (threadIdx.x == 0) s_carry = fwd ? INT_MIN : INT_MAX;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + int(threadIdx.x);           // position in scan order
+        const int i = fwd ? k : n - 1 - k;               // the read
+        int v = fwd ? INT_MIN : INT_MAX;
+        if (k < n) v = fwd ? span[i].y : span[i].x;
+        v = fwd ? block_scan_1024(v, MaxOp(), s_wave) : block_scan_1024(v, MinOp(), s_wave);
+        const int carry = s_carry;
+        v = fwd ? max(v, carry) : min(v, carry);
+        if (k < n) (fwd ? maxend : minbegin)[i] = v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = v;
+        __syncthreads();
+    }
+}
+
+struct OffsetsArgs
+{
+    const uint32_t* count[5]; // per-locus counts, n + 1 entries each (the last is not read)
+    int64_t* off[5];          // exclusive sums, n + 1 entries: off[n] = the total
+    int n_scans;
+    int n;                    // loci
+    CopySeg copy[4];          // counters to move into the output block, a block each
+    int n_copies;
+};
+struct PlusOp
+{
+    __device__ int64_t operator()(const int64_t a, const int64_t b) const { return a + b; }
+};
+__global__ __launch_bounds__(1024) void column_offsets_kernel(const OffsetsArgs a)
+{
+    __shared__ int64_t s_wave[16];
+    __shared__ int64_t s_carry;
+    if (int(blockIdx.x) >= a.n_scans) {
+        const CopySeg s = a.copy[int(blockIdx.x) - a.n_scans];
+        for (int64_t i = threadIdx.x; i < s.bytes; i += 1024) s.dst[i] = s.src[i];
+        return;
+    }
+    const uint32_t* __restrict__ cnt = a.count[blockIdx.x];
+    int64_t* __restrict__ off = a.off[blockIdx.x];
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base <= a.n; base += 1024) {
+        const int i = base + int(threadIdx.x);
+        const int64_t c = (i < a.n) ? int64_t(cnt[i]) : 0;
+        const int64_t incl = block_scan_1024(c, PlusOp(), s_wave) + s_carry;
+        if (i <= a.n) off[i] = incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = incl;
+        __syncthreads();
+    }
+}
 
 struct ScratchLayout
 {
@@ -1383,24 +1499,36 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     if (mask_len > 0) std::memcpy(hi + li.mask, cand_snv_mask, size_t(mask_len)); // (through the pinned block: a copy from the caller's pageable memory would wait for the device)
     char* di = static_cast<char*>(d_in.p);
     SK_HIP(hipMemcpyAsync(di, hi, size_t(li.total), hipMemcpyHostToDevice, st));
+    CopyArgs carry; // every device-to-device piece of this push, one launch
+    carry.n = 0;
+    int64_t carry_max = 0;
+    auto add_copy = [&](const void* src, void* dst, const int64_t bytes) {
+        if (bytes <= 0) return;
+        carry.seg[carry.n].src = static_cast<const char*>(src);
+        carry.seg[carry.n].dst = static_cast<char*>(dst);
+        carry.seg[carry.n].bytes = bytes;
+        ++carry.n;
+        carry_max = std::max(carry_max, bytes);
+    };
     if (s->want_evs && s->c_bases > 0) {
         // the EVS words are made in P2 from the reads' bases and qualities: the carried reads' come over from the previous block
         const char* dp = static_cast<const char*>(s->d_in2[prev_in].p);
-        SK_HIP(hipMemcpyAsync(di + li.code, dp + prev_li.code + s->c_tail_base, size_t(s->c_bases), hipMemcpyDeviceToDevice, st));
-        SK_HIP(hipMemcpyAsync(di + li.qual, dp + prev_li.qual + s->c_tail_base, size_t(s->c_bases), hipMemcpyDeviceToDevice, st));
+        add_copy(dp + prev_li.code + s->c_tail_base, di + li.code, s->c_bases);
+        add_copy(dp + prev_li.qual + s->c_tail_base, di + li.qual, s->c_bases);
     }
-    if (mask_len > 0)
-        SK_HIP(hipMemcpyAsync(static_cast<char*>(s->d_mask.p) + (mask_begin - s->ref_offset), di + li.mask, size_t(mask_len), hipMemcpyDeviceToDevice, st));
+    if (mask_len > 0) add_copy(di + li.mask, static_cast<char*>(s->d_mask.p) + (mask_begin - s->ref_offset), mask_len);
 
     // ---- records and spans: the carried tail moves to the front of the other buffer
     const int nxt = s->cur ^ 1;
     if (s->d_rec[nxt].need(size_t(2 * std::max<int64_t>(n_bases, 1))) || s->d_span[nxt].need(size_t(8 * std::max(n, 1))))
         return sk_fail("sk_pileup_stream_push: out of device memory (records)");
-    if (s->c_bases > 0)
-        SK_HIP(hipMemcpyAsync(s->d_rec[nxt].p, static_cast<char*>(s->d_rec[s->cur].p) + 2 * s->c_tail_base, size_t(2 * s->c_bases), hipMemcpyDeviceToDevice, st));
-    if (n_c > 0)
-        SK_HIP(hipMemcpyAsync(s->d_span[nxt].p, static_cast<char*>(s->d_span[s->cur].p) + 8 * s->c_tail_read, size_t(8) * size_t(n_c), hipMemcpyDeviceToDevice, st));
+    if (s->c_bases > 0) add_copy(static_cast<char*>(s->d_rec[s->cur].p) + 2 * s->c_tail_base, s->d_rec[nxt].p, 2 * s->c_bases);
+    if (n_c > 0) add_copy(static_cast<char*>(s->d_span[s->cur].p) + 8 * s->c_tail_read, s->d_span[nxt].p, int64_t(8) * n_c);
     s->cur = nxt;
+    if (carry.n > 0) {
+        const int bx = int(std::min<int64_t>((carry_max / 16 + 255) / 256 + 1, 64));
+        hipLaunchKernelGGL(copy_segments_kernel, dim3(bx, carry.n), dim3(256), 0, st, carry);
+    }
 
     // ---- work and output blocks
     const ScratchLayout SL = layout(n, n_bases, n_loci); // (its rec / span / count parts are unused here)
@@ -1479,19 +1607,9 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     a.r0 = n_c;
     if (n_new > 0) hipLaunchKernelGGL(pileup_read_kernel, dim3((n_new + P1_WAVES - 1) / P1_WAVES), dim3(P1_WAVES * WAVE), 0, st, a);
 
-    int* d_begin = reinterpret_cast<int*>(dw + wl.begin);
-    int* d_end = reinterpret_cast<int*>(dw + wl.end);
     int* d_maxend = reinterpret_cast<int*>(dw + wl.maxend);
     int* d_minbegin = reinterpret_cast<int*>(dw + wl.minbegin);
-    void* tmp = dw + wl.tmp;
-    size_t tmp_bytes = size_t(SL.tmp_bytes);
-    if (n > 0) {
-        hipLaunchKernelGGL(span_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.span, d_begin, d_end, n);
-        SK_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, d_end, d_maxend, size_t(n), MaxOp(), st));
-        tmp_bytes = size_t(SL.tmp_bytes);
-        SK_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, std::make_reverse_iterator(d_begin + n), std::make_reverse_iterator(d_minbegin + n),
-                                       size_t(n), MinOp(), st));
-    }
+    if (n > 0) hipLaunchKernelGGL(span_bounds_kernel, dim3(2), dim3(1024), 0, st, a.span, d_maxend, d_minbegin, n);
     // P2: the window's columns
     PileupArgs c = a;
     c.o.report_begin = begin;
@@ -1527,34 +1645,41 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     const int blocks = (n_loci + 1 + WAVE - 1) / WAVE;
     void (*const p2)(const PileupArgs) = som ? pileup_column_kernel_t<true, true, false>
                                              : (s->want_evs ? pileup_column_kernel_t<true, false, true> : pileup_column_kernel_t<true, false, false>);
-    if (s->want_evs) SK_HIP(hipMemsetAsync(c.mapq_count + n_loci, 0, 4, st)); // (the scan below reads n_loci + 1 counts)
     hipLaunchKernelGGL(p2, dim3(blocks), dim3(WAVE), 0, st, c);
-    for (int m = 0; m < 3; ++m) {
-        tmp_bytes = size_t(SL.tmp_bytes);
-        SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, c.count3[m], const_cast<int64_t*>(c.call_off3[m]), int64_t(0), size_t(n_loci) + 1,
-                                       rocprim::plus<int64_t>(), st));
-    }
-    if (som) {
-        tmp_bytes = size_t(SL.tmp_bytes);
-        SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, c.count4, const_cast<int64_t*>(c.call_off4), int64_t(0), size_t(n_loci) + 1,
-                                       rocprim::plus<int64_t>(), st));
-    }
-    if (s->want_evs) { // a locus has mapq_count words
-        tmp_bytes = size_t(SL.tmp_bytes);
-        SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, c.mapq_count, const_cast<int64_t*>(c.evs_off), int64_t(0), size_t(n_loci) + 1,
-                                       rocprim::plus<int64_t>(), st));
+    {
+        // every column's offsets (exclusive sums of n_loci + 1 counts: the last entry is the total) and, in the same launch, the cleaned
+        // columns' sizes for the caller's cache validation and the region-wide counters' slice
+        OffsetsArgs oa;
+        std::memset(&oa, 0, sizeof(oa));
+        oa.n = n_loci;
+        for (int m = 0; m < 3; ++m) {
+            oa.count[oa.n_scans] = c.count3[m];
+            oa.off[oa.n_scans++] = const_cast<int64_t*>(c.call_off3[m]);
+        }
+        if (som) {
+            oa.count[oa.n_scans] = c.count4;
+            oa.off[oa.n_scans++] = const_cast<int64_t*>(c.call_off4);
+        }
+        if (s->want_evs) { // a locus has mapq_count words
+            oa.count[oa.n_scans] = c.mapq_count;
+            oa.off[oa.n_scans++] = const_cast<int64_t*>(c.evs_off);
+        }
+        auto add = [&](const void* src, void* dst, const int64_t bytes) {
+            oa.copy[oa.n_copies].src = static_cast<const char*>(src);
+            oa.copy[oa.n_copies].dst = static_cast<char*>(dst);
+            oa.copy[oa.n_copies].bytes = bytes;
+            ++oa.n_copies;
+        };
+        add(c.count3[2], dout + ol.clean_n, 4 * (int64_t(n_loci) + 1));
+        if (som) add(c.count4, dout + ol.clean4_n, 4 * (int64_t(n_loci) + 1));
+        if (n_loci > 0) {
+            add(static_cast<char*>(s->d_spandel.p) + 4 * size_t(begin - s->region_begin), dout + ol.spandel, 4 * int64_t(n_loci));
+            add(static_cast<char*>(s->d_submapped.p) + 4 * size_t(begin - s->region_begin), dout + ol.submapped, 4 * int64_t(n_loci));
+        }
+        hipLaunchKernelGGL(column_offsets_kernel, dim3(oa.n_scans + oa.n_copies), dim3(1024), 0, st, oa);
     }
     c.store = 1;
     if (n > 0 && n_loci > 0) hipLaunchKernelGGL(p2, dim3(blocks), dim3(WAVE), 0, st, c);
-    // the cleaned columns' sizes for the caller's cache validation; the region-wide counters' slice
-    SK_HIP(hipMemcpyAsync(dout + ol.clean_n, c.count3[2], 4 * (size_t(n_loci) + 1), hipMemcpyDeviceToDevice, st));
-    if (som) SK_HIP(hipMemcpyAsync(dout + ol.clean4_n, c.count4, 4 * (size_t(n_loci) + 1), hipMemcpyDeviceToDevice, st));
-    if (n_loci > 0) {
-        SK_HIP(hipMemcpyAsync(dout + ol.spandel, static_cast<char*>(s->d_spandel.p) + 4 * size_t(begin - s->region_begin), 4 * size_t(n_loci),
-                              hipMemcpyDeviceToDevice, st));
-        SK_HIP(hipMemcpyAsync(dout + ol.submapped, static_cast<char*>(s->d_submapped.p) + 4 * size_t(begin - s->region_begin), 4 * size_t(n_loci),
-                              hipMemcpyDeviceToDevice, st));
-    }
     if (n_loci > 0 && (s->genotype || som)) {
         uint8_t* d_refbase = reinterpret_cast<uint8_t*>(dw + wl.refbase);
         hipLaunchKernelGGL(ref_base_id_kernel, dim3((n_loci + 255) / 256), dim3(256), 0, st, static_cast<const char*>(s->d_ref.p), s->ref_offset,
