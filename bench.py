@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--e2e-segment-bp", type=int, default=4000000,
                     help="segment size of the end-to-end leg (one caller process per segment; the workflow cuts a genome into 12 Mb pieces: "
                          "profiles/ holds a run at --e2e-bp 64000000 --e2e-segment-bp 12000000, chr20's size)")
-    ap.add_argument("--only", default="", help="'a5' / 'feed' / 'feed_slice' / 'loci' / 'somatic': run one kernel leg alone (the counter passes of tools/gpu_round.sh use it: "
+    ap.add_argument("--only", default="", help="'a5' / 'feed' / 'feed_slice' / 'loci' / 'pileup' / 'somatic': run one kernel leg alone (the counter passes of tools/gpu_round.sh use it: "
                                                "per-kernel averages then belong to that leg's launches) and print a short line; 'e2e', "
                                                "'e2e_germline', 'e2e_somatic': the end-to-end legs alone (exit code 1 when the drop-in's outputs "
                                                "differ from the reference's)")
@@ -448,6 +448,22 @@ def main():
         alg = 6 * db.n_calls + B_BYTES_PER_LOCUS_FIXED * db.n_loci
         print(json.dumps({"only": "loci", "loci": db.n_loci, "calls": db.n_calls, "kernel_ms": ms, "loci_per_s": db.n_loci / (ms * 1e-3),
                           "algorithmic_bytes": alg, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}))
+        return
+
+    if args.only == "pileup":
+        # the one-shot pileup leg alone (P1 + two P2 launches + the scan), for counter passes
+        rbatch, rb_loci = synth.pileup_reads_flat(args.pileup_reads, np.random.default_rng(1000 + rank))
+        dr = device.DeviceReadBatch(rbatch, rb_loci, dev)
+        evs = []
+        for i in range(args.warmup + args.steps):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            dr.pileup()
+            e.record()
+            evs.append((s, e))
+        torch.cuda.synchronize()
+        ms = float(np.mean([s.elapsed_time(e) for s, e in evs[args.warmup:]]))
+        print(json.dumps({"only": "pileup", "reads": rbatch.n_reads, "bases": rbatch.n_bases, "kernel_ms": ms, "bases_per_s": rbatch.n_bases / (ms * 1e-3)}))
         return
 
     if args.only == "somatic":

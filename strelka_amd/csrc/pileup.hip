@@ -168,6 +168,7 @@ __device__ void pileup_read_short(const PileupArgs& a, const int r, const int la
 
     // one walk over the path: totals, edge segments, and for each of the lane's positions its segment
     int ref_len = 0, read_len_path = 0, first_match = nseg, last_match = nseg;
+    bool indel_since_match = false, has_internal_indel = false; // an insertion / deletion with match segments on both sides
     int refpos[FAST_K];
     bool in_match[FAST_K];
 #pragma unroll
@@ -181,6 +182,7 @@ __device__ void pileup_read_short(const PileupArgs& a, const int r, const int la
         if (seg_match(t)) {
             if (first_match == nseg) first_match = i;
             last_match = i;
+            has_internal_indel = has_internal_indel || indel_since_match;
 #pragma unroll
             for (int k = 0; k < FAST_K; ++k) {
                 const int p = lane + WAVE * k;
@@ -189,6 +191,8 @@ __device__ void pileup_read_short(const PileupArgs& a, const int r, const int la
                     refpos[k] = pos + ref_len + (p - read_len_path);
                 }
             }
+        } else if ((t == SK_SEG_INSERT || t == SK_SEG_DELETE) && first_match != nseg) {
+            indel_since_match = true;
         }
         if (seg_ref_len(t)) ref_len += len;
         if (seg_read_len(t)) read_len_path += len;
@@ -235,26 +239,13 @@ __device__ void pileup_read_short(const PileupArgs& a, const int r, const int la
     bool mmk[FAST_K];
 #pragma unroll
     for (int k = 0; k < FAST_K; ++k) mmk[k] = false;
+    // The mismatch-density counts: +1 / -1 marks per mismatch and internal indel in the difference array, then its running sum.  Most
+    // reads have neither -- every count is 0 then, and the array, its atomics and the scan (three LDS round trips and 18 shuffles) are
+    // skipped for the wave.  (No measurable change on the bench's reads, 2.35 ms per 2^20 either way: P1 spends its time in the ~500
+    // vector and ~470 scalar instructions per read around this, profiles/r04_v46_pileup_sq_counters.txt.)
+    bool have_delta = false;
     if (!is_submapped && mdf) {
-        for (int i = lane; i < delta_size; i += WAVE) delta[i] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        auto inc = [&](const int start, const int length) {
-            atomicAdd(&delta[max(fs2, start) - fs2], 1);
-            if (start + length < delta_size) atomicAdd(&delta[start + length], -1);
-        };
-        if (lane == 0) { // internal indels
-            int read_head = 0;
-            for (int i = 0; i < nseg; ++i) {
-                const uint32_t t = path[i].type;
-                const int len = int(path[i].length);
-                const bool edge = (i < first_match) || (i > last_match);
-                if (t == SK_SEG_INSERT && !edge) inc(read_head, len);
-                if (t == SK_SEG_DELETE && !edge) inc(read_head, 0);
-                if (seg_read_len(t)) read_head += len;
-            }
-        }
+        bool any_mm = false;
 #pragma unroll
         for (int k = 0; k < FAST_K; ++k) {
             const int p = lane + WAVE * k;
@@ -266,13 +257,36 @@ __device__ void pileup_read_short(const PileupArgs& a, const int r, const int la
                         const unsigned id = code[k] == SK_BAM_A ? 0u : code[k] == SK_BAM_C ? 1u : code[k] == SK_BAM_G ? 2u : code[k] == SK_BAM_T ? 3u : 4u;
                         cand = (id < 4u) && ((a.b.cand_snv_mask[refpos[k] - a.b.ref_offset] >> id) & 1u);
                     }
-                    if (!cand) {
-                        mmk[k] = true;
-                        inc(p, 1);
-                    }
+                    mmk[k] = !cand;
+                    any_mm = any_mm || !cand;
                 }
             }
         }
+        have_delta = has_internal_indel || (__ballot(any_mm) != 0ull); // (wave-uniform)
+    }
+    if (have_delta) {
+        for (int i = lane; i < delta_size; i += WAVE) delta[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        auto inc = [&](const int start, const int length) {
+            atomicAdd(&delta[max(fs2, start) - fs2], 1);
+            if (start + length < delta_size) atomicAdd(&delta[start + length], -1);
+        };
+        if (lane == 0 && has_internal_indel) { // internal indels
+            int read_head = 0;
+            for (int i = 0; i < nseg; ++i) {
+                const uint32_t t = path[i].type;
+                const int len = int(path[i].length);
+                const bool edge = (i < first_match) || (i > last_match);
+                if (t == SK_SEG_INSERT && !edge) inc(read_head, len);
+                if (t == SK_SEG_DELETE && !edge) inc(read_head, 0);
+                if (seg_read_len(t)) read_head += len;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FAST_K; ++k)
+            if (mmk[k]) inc(lane + WAVE * k, 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -319,7 +333,7 @@ __device__ void pileup_read_short(const PileupArgs& a, const int r, const int la
             const unsigned qm = mq[q0 > 70u ? 70u : q0];
             const unsigned q = mapq_adjust ? qm : q0;
             const bool base_filter = (c == SK_BAM_ANY) || (int(q) < o.min_basecall_qscore);
-            const int del = mdf ? delta[min(delta_size - 1, max(fs, p) - fs)] : 0; // (delta_size >= 1)
+            const int del = have_delta ? delta[min(delta_size - 1, max(fs, p) - fs)] : 0; // (delta_size >= 1; no marks: every count is 0)
             const bool is_call_filter = base_filter || (mdf && o.mismatch_density_max_count < del);
             const bool is_tier2_call_filter =
                 base_filter || (mdf && (o.use_tier2_evidence ? (o.tier2_mismatch_density_max_count < del) : (o.mismatch_density_max_count < del)));

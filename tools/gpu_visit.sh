@@ -54,6 +54,15 @@ for step in "$@"; do
         tail -1 $OUT/pmc_g3_$i.log | head -c 300
       done
       python tools/diag/pmc_kernel_sums.py $OUT/pmc_g3_* > $OUT/pmc_g3.txt 2>&1; cat $OUT/pmc_g3.txt ;;
+    pmc_pileup)
+      i=0
+      for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+                 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES"; do
+        i=$((i+1))
+        timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_pileup_$i -o pmc -- python bench.py --only pileup --steps 3 --warmup 1 > $OUT/pmc_pileup_$i.log 2>&1
+        tail -1 $OUT/pmc_pileup_$i.log | head -c 300
+      done
+      python tools/diag/pmc_kernel_sums.py $OUT/pmc_pileup_* 2>&1 | grep -A10 "^pileup_\|^void pileup" > $OUT/pmc_pileup.txt; cat $OUT/pmc_pileup.txt ;;
     pmc_som)
       i=0
       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
