@@ -652,6 +652,9 @@ __global__ __launch_bounds__(64) void flatten_kernel(const FlatArgs a)
 // then runs F1-F3 + A1c over the job.
 constexpr int F5_MAX_READ = 256;  // (as F3's wave form; longer reads and larger pools take the staged chain)
 constexpr int F5_MAX_POOL = 768;
+#ifndef F5_SORT
+#define F5_SORT 1 // experiments: 0 = the set's order
+#endif
 constexpr int F5_TAB = 32;       // span of table indices the indels of one round's candidate alignments may cover
 
 static_assert(F5_TAB <= 64, "the table copy is a lane an entry");
@@ -942,9 +945,33 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
     }
     const double ln_quarter = fa.tab->ln_quarter, ln_noncand = fa.tab->ln_noncand;
 
+    // The read's candidate alignments in order of path length, longest first (a counting sort over the segment counts, the order in the
+    // unused tail of the pool's bytes): a wave's walk lasts as long as its longest path, so a round of like paths wastes fewer turns
+    // and the last, partly filled round gets the short ones.  Reads with more than 256 candidate alignments keep the set's order.
+    uint8_t* const order = S.hap + ((P + 8 + 3) & ~3);
+    const bool sorted_order = (F5_SORT != 0) && ncr > 64 && ncr <= 256 && ((P + 8 + 3) & ~3) + ncr <= int(sizeof(S.hap));
+    if (sorted_order) {
+        int seg_of[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = lane + 64 * k;
+            seg_of[k] = (j < ncr) ? int((reinterpret_cast<const uint32_t*>(a.pool + a.list[c0 + j])[2] >> 8) & 0xffu) : -1;
+            seg_of[k] = min(seg_of[k], F5_SEGS + 1);
+        }
+        int at = 0; // alignments placed so far
+        for (int v = F5_SEGS + 1; v >= 0; --v) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t m = __ballot(seg_of[k] == v);
+                if (seg_of[k] == v) order[at + __popcll(m & ((1ull << lane) - 1ull))] = uint8_t(lane + 64 * k);
+                at += __popcll(m);
+            }
+        }
+    }
+
     for (int j0 = 0; j0 < ncr; j0 += 64) {
         const int nc = min(64, ncr - j0);
-        __syncthreads(); // (pool and read complete; the previous round's slots read)
+        __syncthreads(); // (pool and read complete; the previous round's slots read; the order written)
         const unsigned long long ta = clock64();
         if (j0 == 0) stamp[1] = ta; // prologue done
         // ---- the round's records, a lane its own: header + F5_SEGS path segments (five 16-byte loads) + F5_INDELS indel indices, all in
@@ -952,8 +979,9 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         const bool has = lane < nc;
         uint32_t* const myslot = S.slot + lane * F5_SLOT;
         bool fits = true;
+        const int my_j = has ? (sorted_order ? int(order[j0 + lane]) : j0 + lane) : 0; // the lane's alignment among the read's
         if (has) {
-            const PCal* src = a.pool + a.list[c0 + j0 + lane];
+            const PCal* src = a.pool + a.list[c0 + my_j];
             const uint4* s4 = reinterpret_cast<const uint4*>(src);
             const uint4 q0 = s4[0], q1 = s4[1], q2 = s4[2], q3 = s4[3], q4 = s4[4];
             const uint32_t* si = reinterpret_cast<const uint32_t*>(src->indels);
@@ -1122,7 +1150,7 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                 hidx = adv ? int(cur >> 16) - 256 : hidx;
                 e = adv ? e1 : e;
             }
-            fa.scores[c0 + j0 + lane] = lnp;
+            fa.scores[c0 + my_j] = lnp;
         }
         stamp[5] += clock64() - td; // phase B
     }
