@@ -306,6 +306,7 @@ struct FlatArgs
     int32_t* win_end;   // (cells start at INT_MIN)
     int32_t* ins_lo;    // lowest / highest table index of an indel with an insert sequence
     int32_t* ins_hi;
+    uint8_t* n_seg8;    // [n_cals] path segments of each candidate alignment (capped at 255), set order: F5 orders a read's alignments by it
     int32_t* win_len;
     int32_t* hap_len;
     int32_t* n_ins;
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256) void pool_bounds_kernel(const FlatArgs a)
     if (c >= a.n_cals) return;
     const int r = read_of_cal(a, c);
     const PCal& cal = a.pool[a.list[c]];
+    a.n_seg8[c] = uint8_t(min(int(cal.n_seg), 255));
     int32_t wb = INT_MAX, we = INT_MIN, pos = cal.pos;
     for (int i = 0; i < cal.n_seg; ++i) {
         const PSeg s = cal.path[i];
@@ -955,7 +957,7 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int j = lane + 64 * k;
-            seg_of[k] = (j < ncr) ? int((reinterpret_cast<const uint32_t*>(a.pool + a.list[c0 + j])[2] >> 8) & 0xffu) : -1;
+            seg_of[k] = (j < ncr) ? int(a.n_seg8[c0 + j]) : -1; // (left by pool_bounds_kernel, which reads every record anyway)
             seg_of[k] = min(seg_of[k], F5_SEGS + 1);
         }
         int at = 0; // alignments placed so far
@@ -1693,7 +1695,7 @@ struct EnumBuffers
     View h_counters, h_status, h_warn, h_n_raw, h_hap_len, h_n_uniq, h_consulted;
     DevBuf level_a, level_b, pool, leaf_read, leaf_hash;
     DevBuf raw_off, grouped, ghash, gkey, dup, sorted;
-    DevBuf n_ops, win_len, n_ins, ins_idx, ins_off;
+    DevBuf n_ops, win_len, n_ins, ins_idx, ins_off, n_seg8;
     DevBuf cal_off, hap_off, cals, hap_code, op_off, ops, entries, scores, colmat, colmat_off;
     DevBuf s3_order, s3_smooth, s3_flag, s3_rm_type, s3_rm_pos, s3_key, s3_sorted_score, s3_sorted_hash, s3_next_same, s3_range_end, s3_removed, s3_out, s3_list;
     HostBuf h_s3_out, h_s3_list;
@@ -2052,6 +2054,8 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     fa.win_end = B.win_end.as<int32_t>();
     fa.ins_lo = B.ins_lo.as<int32_t>();
     fa.ins_hi = B.ins_hi.as<int32_t>();
+    RES(n_seg8, size_t(n_cals));
+    fa.n_seg8 = B.n_seg8.as<uint8_t>();
     // (byte patterns: 0x7f7f7f7f is large enough to stand for "no lower bound yet", 0x80808080 is below any position / index)
     SK_HIP(hipMemsetAsync(B.minmax_arena.p, 0x7f, minmax_p[2].off, st));                               // win_begin, ins_lo
     SK_HIP(hipMemsetAsync(static_cast<char*>(B.minmax_arena.p) + minmax_p[2].off, 0x80, minmax_bytes - minmax_p[2].off, st)); // win_end, ins_hi
