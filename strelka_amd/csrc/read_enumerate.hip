@@ -872,9 +872,11 @@ __device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo,
     return int64_t(read_offset) == int64_t(read_len);
 }
 
-template <int MAXR>
+// TIMING: the cycle stamps of $SK_F5_TIMING (fa.dbg); without it the stamps are constants and their s_memtime + waits are gone
+template <int MAXR, bool TIMING>
 __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs fa)
 {
+    auto now = [&]() -> unsigned long long { return TIMING ? (unsigned long long)clock64() : 0ull; };
     __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S;
     const FlatArgs& a = fa.f;
     const int r = blockIdx.x;
@@ -883,7 +885,7 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
     const int ncr = c1 - c0;
     if (ncr == 0 || a.status[r] != ST_OK) return;
     unsigned long long stamp[8];
-    stamp[0] = clock64();
+    stamp[0] = now();
     for (int i = 1; i < 8; ++i) stamp[i] = 0;
     const int64_t ro = a.read_off[r];
     const int32_t L = int32_t(a.read_off[r + 1] - ro);
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
     for (int j0 = 0; j0 < ncr; j0 += 64) {
         const int nc = min(64, ncr - j0);
         __syncthreads(); // (pool and read complete; the previous round's slots read; the order written)
-        const unsigned long long ta = clock64();
+        const unsigned long long ta = now();
         if (j0 == 0) stamp[1] = ta; // prologue done
         // ---- the round's records, a lane its own: header + F5_SEGS path segments (five 16-byte loads) + F5_INDELS indel indices, all in
         // flight at once; a record with more of either is left to the staged chain
@@ -1035,7 +1037,7 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
             }
         }
         __syncthreads();
-        const unsigned long long tc = clock64();
+        const unsigned long long tc = now();
         stamp[2] += tc - ta; // staging + table copy
         // ---- phase A, a lane per candidate alignment: the walk of its path leaves the alignment's TRANSITIONS in its slot: one word per
         // op that covers read positions, and one for the read's end
@@ -1063,9 +1065,9 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                     npen += penalty ? 1u : 0u;
                 }
             };
-            const unsigned long long tA0 = clock64();
+            const unsigned long long tA0 = now();
             const bool ok = f5_walk(S, rec, tab_lo, n_ins, win_begin, a.job.consulted, L, on_op);
-            const unsigned long long tA1 = clock64();
+            const unsigned long long tA1 = now();
             stamp[7] += tA1 - tA0; // the walk
             if (!ok || pos != L) bad = true;
             else put(unsigned(L), npen, false, 0); // trailing penalties
@@ -1077,10 +1079,10 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
                 if (rec.trail() >= 0) a.job.consulted[rec.trail()] = 1;
             }
             if (bad) a.status[r] = ST_FAIL;
-            stamp[3] += clock64() - tA1; // candidate-status marks
+            stamp[3] += now() - tA1; // candidate-status marks
         }
         __builtin_amdgcn_wave_barrier();
-        const unsigned long long td = clock64();
+        const unsigned long long td = now();
         stamp[4] += td - tc; // phase A
         // ---- phase B, a lane its alignment, in path order (the order of score_one_generic): entering an op, the penalties that precede
         // its terms, then a soft clip's length x ln 0.25; inside an op of bases, eight positions per turn -- eight read codes against the
@@ -1154,10 +1156,10 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
             }
             fa.scores[c0 + my_j] = lnp;
         }
-        stamp[5] += clock64() - td; // phase B
+        stamp[5] += now() - td; // phase B
     }
     if (fa.dbg && lane == 0) {
-        stamp[6] = clock64();
+        stamp[6] = now();
         for (int i = 0; i < 8; ++i) fa.dbg[size_t(r) * 8 + i] = stamp[i];
     }
 }
@@ -1166,8 +1168,11 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
 // form: twelve)
 static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
 {
-    if (fs.f.max_read_len <= 152) hipLaunchKernelGGL(flatten_score_kernel<152>, dim3(n_reads), dim3(64), 0, st, fs);
-    else hipLaunchKernelGGL(flatten_score_kernel<F5_MAX_READ>, dim3(n_reads), dim3(64), 0, st, fs);
+    const bool short_reads = fs.f.max_read_len <= 152, timing = fs.dbg != nullptr;
+    if (short_reads && !timing) hipLaunchKernelGGL((flatten_score_kernel<152, false>), dim3(n_reads), dim3(64), 0, st, fs);
+    else if (short_reads) hipLaunchKernelGGL((flatten_score_kernel<152, true>), dim3(n_reads), dim3(64), 0, st, fs);
+    else if (!timing) hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, false>), dim3(n_reads), dim3(64), 0, st, fs);
+    else hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, true>), dim3(n_reads), dim3(64), 0, st, fs);
 }
 
 // the records in set order, for the host (sk_enum_device_fetch_cals; a job whose stage 3 runs on the host): pool[list[c]] -> cals[c], a wave
