@@ -105,14 +105,21 @@ def test_inflate_and_decode_equal_the_restatement(bam):
     assert set(np.unique(d["read_code"])) <= {1, 2, 4, 8, 15}  # what sk_read_input.read_code takes
 
 
-def _python_deflate_blocks(payloads, level):
-    """a BGZF image made here (zlib raw deflate at `level`; level 0 = stored blocks): [(block bytes)] joined"""
+def _python_deflate_blocks(payloads, level, mem_level=8, strategy=0, flush_every=0):
+    """a BGZF image made here (zlib raw deflate at `level`; level 0 = stored blocks): [(block bytes)] joined.  `mem_level` 1 makes
+    zlib end a deflate block every few hundred symbols, `strategy` picks fixed codes / Huffman only / run lengths, `flush_every` > 0
+    puts a full flush (an empty stored block, byte alignment) after every so many input bytes"""
     import struct
     import zlib
     out = bytearray()
     for p in payloads:
-        c = zlib.compressobj(level, zlib.DEFLATED, -15)
-        body = c.compress(p) + c.flush()
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, mem_level, strategy)
+        if flush_every:
+            body = b"".join(c.compress(p[i:i + flush_every]) + c.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(p), flush_every)) + c.flush()
+        else:
+            body = c.compress(p) + c.flush()
+        if len(body) + 26 > 65536:
+            continue  # (does not fit a BGZF block)
         bsize = 12 + 6 + len(body) + 8
         out += bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", bsize - 1) + body
         out += struct.pack("<II", zlib.crc32(p) & 0xffffffff, len(p))
@@ -147,6 +154,36 @@ def test_both_inflate_kernels_on_every_block_shape(kernel, monkeypatch):
         bad[at] ^= 0x5a
         rc = capi.lib().sk_bgzf_inflate(capi._p(bad), capi._p(block_off), capi._p(out_off), len(block_off) - 1, capi._p(out))
         assert rc != 0 and ("block %d:" % b) in capi.last_error(), (at, capi.last_error())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["thread", "wave"])
+def test_inflate_kernels_on_many_deflate_streams(kernel, monkeypatch):
+    """streams zlib writes under other settings than bgzip's: many deflate blocks per BGZF block (memLevel 1: tables rebuilt every
+    few hundred symbols), fixed codes throughout, Huffman only (no matches), run lengths (distance 1 only), stored pieces and empty
+    stored blocks between compressed ones (full flushes), on text-like, BAM-like, run-heavy and random payloads of every size class"""
+    import zlib
+    capi.init(0)
+    monkeypatch.setenv("SK_INFLATE_KERNEL", kernel)
+    rng = np.random.default_rng(13)
+    bam_like = _bytes(TINY)
+    raw = bam_oracle.bgzf_inflate(bam_like)
+    payloads = []
+    for n in (1, 2, 63, 64, 65, 257, 258, 259, 1000, 4095, 32768, 32769, 50000, 65280):
+        payloads.append(raw[7:7 + n] if len(raw) >= 7 + n else (raw * (1 + (7 + n) // max(1, len(raw))))[7:7 + n])
+        payloads.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+        payloads.append(bytes(rng.choice(np.frombuffer(b"ACGTN=\x00\xff", np.uint8), n, p=[0.24, 0.24, 0.24, 0.24, 0.01, 0.01, 0.01, 0.01]).astype(np.uint8)))
+        payloads.append((bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 300)) + rng.integers(0, 256, 5, dtype=np.uint8).tobytes()) * (1 + n // 150))
+    payloads = [p[:65280] for p in payloads]
+    want = b"".join
+    settings = [(6, 1, zlib.Z_DEFAULT_STRATEGY, 0), (9, 1, zlib.Z_DEFAULT_STRATEGY, 0), (6, 8, zlib.Z_FIXED, 0), (6, 8, zlib.Z_HUFFMAN_ONLY, 0),
+                (6, 8, zlib.Z_RLE, 0), (1, 9, zlib.Z_FILTERED, 0), (6, 8, zlib.Z_DEFAULT_STRATEGY, 777), (0, 8, zlib.Z_DEFAULT_STRATEGY, 1000),
+                (6, 1, zlib.Z_FIXED, 333)]
+    for level, mem_level, strategy, flush_every in settings:
+        kept = [p for p in payloads if len(_python_deflate_blocks([p], level, mem_level, strategy, flush_every)) > 0]
+        image = np.frombuffer(_python_deflate_blocks(kept, level, mem_level, strategy, flush_every), np.uint8)
+        assert len(kept) > len(payloads) // 2
+        assert capi.bgzf_inflate(image).tobytes() == want(kept), (level, mem_level, strategy, flush_every)
 
 
 @pytest.mark.gpu
