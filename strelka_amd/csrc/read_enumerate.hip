@@ -673,19 +673,15 @@ struct FusedScoreArgs
     unsigned long long* dbg; // diagnostics ($SK_F5_TIMING): per block 8 cycle stamps, or null
 };
 
-// a candidate alignment as F5 keeps it in LDS: the used part of the PCal record
-//   [0] pos   [1] lead | trail << 16   [2] fwd | n_seg << 8 | n_indels << 16   [3 .. 3+F5_SEGS) path   [.. +F5_INDELS/2) indels
-// and, written over it by the walk, the alignment's transitions (start position | penalties that precede the op's terms << 9 | soft clip
-// << 15 | (pool offset - position + 256) << 16): transition 0 in word 0, transition k in word 2 + k = the place of path segment k - 1.  The
-// walk reads the position once, at its start, and only ever looks at path segments from the current one on; an op is emitted per turn of
-// its loop, each turn consumes at least one segment, so transition k (k - 1 ops before it, at least k - 1 segments consumed, and the
-// current segment is still read after the emit) lands on a segment the walk is done with; the last one, the read's end, is number
-// n_seg at most.  A slot of 23 words instead of 39: with the table entries cut to the four words the walk reads and the rows of terms
-// sized for the job's longest read, a wave's LDS goes from 17.8 KB to ~10 KB and a CU holds 15 of them instead of 9 -- the kernel is a
-// latency chain per lane (profiles/r04_a5_history.txt: a wave alone on a CU takes as long as nine sharing it).
+// a candidate alignment's slot in LDS: the walk's output -- up to F5_SEGS + 1 transitions, one per op that covers read positions and
+// one for the read's end (start position | penalties that precede the op's terms << 9 | soft clip << 15 | (pool offset - position + 256)
+// << 16) -- then the record's indel indices.  The record's header and path are in the lane's registers (F5Rec).  21 words a lane
+// instead of round 3's 39: with the table entries cut to the four words the walk reads and the rows of terms sized for the job's
+// longest read, a wave's LDS goes from 17.8 KB to under 10 KB and a CU holds 16 of them instead of 9 -- the kernel is a latency chain per
+// lane (profiles/r04_a5_history.txt: a wave alone on a CU takes as long as nine sharing it).
 constexpr int F5_SEGS = 16, F5_INDELS = 8;
-constexpr int F5_IND0 = 3 + F5_SEGS, F5_SLOT = (F5_IND0 + F5_INDELS / 2) | 1; // (odd stride: conflict-free)
-__device__ __forceinline__ int f5_ent_word(const int k) { return k ? 2 + k : 0; }
+constexpr int F5_IND0 = F5_SEGS + 1, F5_SLOT = (F5_IND0 + F5_INDELS / 2) | 1; // (odd stride: conflict-free)
+__device__ __forceinline__ int f5_ent_word(const int k) { return k; }
 constexpr int F5_ROW = 2; // doubles per read position: agree, differ (a position that adds nothing reads the shared 0.0 instead)
 
 struct F5Tab // what the walk reads of a table entry
@@ -712,17 +708,23 @@ struct F5Lds
 static_assert(sizeof(F5Lds<152>) <= 10240, "sixteen waves of the short-read form to a CU");
 static_assert(INS_CAP <= 64, "a lane an insert");
 
-struct F5Rec // accessors of a compact record
+// A compact record's path in the lane's registers: the walk looks at a segment's type up to a dozen times per turn (the edge
+// segments, the look-ahead for swaps, the step to the next segment) and every look from LDS is a round trip on the lane's chain.  The
+// sixteen types are 4 bits each in one 64-bit value, the sixteen lengths 16 bits each in four; segment i is a shift by i (the lengths:
+// a select among the four values first).  The indel indices stay in the slot (read once, at the walk's start).
+struct F5Rec
 {
-    const uint32_t* w;
-    __device__ __forceinline__ int32_t pos() const { return int32_t(w[0]); }
-    __device__ __forceinline__ int lead() const { return int(int16_t(w[1] & 0xffffu)); }
-    __device__ __forceinline__ int trail() const { return int(int16_t(w[1] >> 16)); }
-    __device__ __forceinline__ int n_seg() const { return int((w[2] >> 8) & 0xffu); }
-    __device__ __forceinline__ int n_indels() const { return int((w[2] >> 16) & 0xffu); }
-    __device__ __forceinline__ unsigned seg_type(const int i) const { return w[3 + i] & 0xffffu; }
-    __device__ __forceinline__ unsigned seg_len(const int i) const { return w[3 + i] >> 16; }
-    __device__ __forceinline__ int indel(const int k) const { return int(int16_t((w[F5_IND0 + (k >> 1)] >> (16 * (k & 1))) & 0xffffu)); }
+    uint32_t w0, w1, w2;  // pos; lead | trail << 16; fwd | n_seg << 8 | n_indels << 16
+    uint64_t types;       // segment i: bits [4i, 4i + 4)
+    uint64_t l0, l1, l2, l3; // segment i: bits [16 (i & 3), + 16) of l(i >> 2)  (four values, not an array: an array indexed per lane
+                          // goes to scratch memory)
+    const uint32_t* slot; // the lane's slot: indel indices at F5_IND0
+    __device__ __forceinline__ int32_t pos() const { return int32_t(w0); }
+    __device__ __forceinline__ int lead() const { return int(int16_t(w1 & 0xffffu)); }
+    __device__ __forceinline__ int trail() const { return int(int16_t(w1 >> 16)); }
+    __device__ __forceinline__ int n_seg() const { return int((w2 >> 8) & 0xffu); }
+    __device__ __forceinline__ int n_indels() const { return int((w2 >> 16) & 0xffu); }
+    __device__ __forceinline__ int indel(const int k) const { return int(int16_t((slot[F5_IND0 + (k >> 1)] >> (16 * (k & 1))) & 0xffffu)); }
 };
 
 // flatten_cal over a compact record, every look-up from the block's LDS copies (S is the kernel's __shared__ object: the accesses stay
@@ -737,6 +739,14 @@ __device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo,
         if (consulted) consulted[i] = 1;
         return (tab(i).type_cand >> 8) != 0;
     };
+    // (the path as values of this function: fields of a struct selected per lane become an indexed load from the struct's copy in scratch
+    // memory)
+    const uint64_t p_types = c.types, p_l0 = c.l0, p_l1 = c.l1, p_l2 = c.l2, p_l3 = c.l3;
+    auto seg_type = [=](const int i) -> unsigned { return unsigned(p_types >> (4 * i)) & 15u; };
+    auto seg_len = [=](const int i) -> unsigned {
+        const uint64_t lo = (i & 4) ? p_l1 : p_l0, hi = (i & 4) ? p_l3 : p_l2;
+        return unsigned(((i & 8) ? hi : lo) >> (16 * (i & 3))) & 0xffffu;
+    };
     const int aps = c.n_seg();
     unsigned read_offset = 0;
     int32_t ref_head_pos = c.pos();
@@ -744,7 +754,7 @@ __device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo,
     {
         bool is_first_match = false;
         for (int i = 0; i < aps; ++i)
-            if (seg_align_match(c.seg_type(i))) {
+            if (seg_align_match(seg_type(i))) {
                 if (!is_first_match) ends_first = i;
                 is_first_match = true;
                 ends_second = i;
@@ -802,7 +812,7 @@ __device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo,
         {
             bool is_insert = false, is_delete = false;
             for (int i = path_index; i < aps; ++i) {
-                const unsigned ty = c.seg_type(i);
+                const unsigned ty = seg_type(i);
                 if (ty == SK_SEG_INSERT) is_insert = true;
                 else if (ty == SK_SEG_DELETE) is_delete = true;
                 else break;
@@ -810,7 +820,7 @@ __device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo,
             is_swap_start = is_insert && is_delete;
         }
         unsigned n_seg = 1;
-        const unsigned ps_type = c.seg_type(path_index), ps_len = c.seg_len(path_index);
+        const unsigned ps_type = seg_type(path_index), ps_len = seg_len(path_index);
         // The four kinds of segment that stand for a table indel -- a swap (insert + delete run), a sequence mismatch, an insert, a
         // delete -- differ in the two lengths the key is looked up with and in nothing else (:296-420 treat them in four branches
         // with the same steps); ONE code site for them: lanes at different kinds of indel segment then run it together
@@ -824,9 +834,9 @@ __device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo,
             unsigned del_len = 0, ins_len = 0;
             if (is_swap_start) { // swap_info, align_path_util.hh:75-106
                 int k = path_index;
-                for (; k < aps && (c.seg_type(k) == SK_SEG_INSERT || c.seg_type(k) == SK_SEG_DELETE); ++k) {
-                    if (c.seg_type(k) == SK_SEG_INSERT) ins_len += c.seg_len(k);
-                    else del_len += c.seg_len(k);
+                for (; k < aps && (seg_type(k) == SK_SEG_INSERT || seg_type(k) == SK_SEG_DELETE); ++k) {
+                    if (seg_type(k) == SK_SEG_INSERT) ins_len += seg_len(k);
+                    else del_len += seg_len(k);
                 }
                 n_seg = unsigned(k - path_index);
             } else {
@@ -857,7 +867,7 @@ __device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo,
         }
         emit(op_kind, op_len, op_src, op_pen); // (a NOBASE op without a penalty is dropped there: skips, hard clips)
         for (unsigned i = 0; i < n_seg; ++i) { // increment_path, align_path_util.hh:38-68
-            const unsigned ty = c.seg_type(path_index), ln = c.seg_len(path_index);
+            const unsigned ty = seg_type(path_index), ln = seg_len(path_index);
             if (seg_align_match(ty)) {
                 read_offset += ln;
                 ref_head_pos += int32_t(ln);
@@ -874,7 +884,7 @@ __device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo,
 
 // TIMING: the cycle stamps of $SK_F5_TIMING (fa.dbg); without it the stamps are constants and their s_memtime + waits are gone
 template <int MAXR, bool TIMING>
-__global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs fa)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void flatten_score_kernel(const FusedScoreArgs fa)
 {
     auto now = [&]() -> unsigned long long { return TIMING ? (unsigned long long)clock64() : 0ull; };
     __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S;
@@ -984,22 +994,38 @@ __global__ __launch_bounds__(64) void flatten_score_kernel(const FusedScoreArgs 
         uint32_t* const myslot = S.slot + lane * F5_SLOT;
         bool fits = true;
         const int my_j = has ? (sorted_order ? int(order[j0 + lane]) : j0 + lane) : 0; // the lane's alignment among the read's
+        F5Rec rec;
+        rec.w0 = rec.w1 = rec.w2 = 0;
+        rec.types = 0;
+        rec.l0 = rec.l1 = rec.l2 = rec.l3 = 0;
+        rec.slot = myslot;
         if (has) {
             const PCal* src = a.pool + a.list[c0 + my_j];
             const uint4* s4 = reinterpret_cast<const uint4*>(src);
             const uint4 q0 = s4[0], q1 = s4[1], q2 = s4[2], q3 = s4[3], q4 = s4[4];
             const uint32_t* si = reinterpret_cast<const uint32_t*>(src->indels);
             const uint32_t i0 = si[0], i1 = si[1], i2 = si[2], i3 = si[3];
-            myslot[0] = q0.x; myslot[1] = q0.y; myslot[2] = q0.z; myslot[3] = q0.w;
-            myslot[4] = q1.x; myslot[5] = q1.y; myslot[6] = q1.z; myslot[7] = q1.w;
-            myslot[8] = q2.x; myslot[9] = q2.y; myslot[10] = q2.z; myslot[11] = q2.w;
-            myslot[12] = q3.x; myslot[13] = q3.y; myslot[14] = q3.z; myslot[15] = q3.w;
-            myslot[16] = q4.x; myslot[17] = q4.y; myslot[18] = q4.z;
             myslot[F5_IND0] = i0; myslot[F5_IND0 + 1] = i1; myslot[F5_IND0 + 2] = i2; myslot[F5_IND0 + 3] = i3;
+            rec.w0 = q0.x;
+            rec.w1 = q0.y;
+            rec.w2 = q0.z;
             const unsigned nseg = (q0.z >> 8) & 0xffu, nind = (q0.z >> 16) & 0xffu;
             fits = (nseg <= unsigned(F5_SEGS) && nind <= unsigned(F5_INDELS));
+            uint64_t types = 0;
+            bool odd_type = false; // (not a segment type: the staged chain reports it)
+            auto pack4 = [&](const uint32_t a0, const uint32_t a1, const uint32_t a2, const uint32_t a3, const int first) -> uint64_t {
+                types |= (uint64_t(a0 & 15u) | (uint64_t(a1 & 15u) << 4) | (uint64_t(a2 & 15u) << 8) | (uint64_t(a3 & 15u) << 12)) << (4 * first);
+                odd_type = odd_type || (unsigned(first) < nseg && (a0 & 0xffffu) > 15u) || (unsigned(first + 1) < nseg && (a1 & 0xffffu) > 15u) ||
+                           (unsigned(first + 2) < nseg && (a2 & 0xffffu) > 15u) || (unsigned(first + 3) < nseg && (a3 & 0xffffu) > 15u);
+                return uint64_t(a0 >> 16) | (uint64_t(a1 >> 16) << 16) | (uint64_t(a2 >> 16) << 32) | (uint64_t(a3 >> 16) << 48);
+            };
+            rec.l0 = pack4(q0.w, q1.x, q1.y, q1.z, 0);
+            rec.l1 = pack4(q1.w, q2.x, q2.y, q2.z, 4);
+            rec.l2 = pack4(q2.w, q3.x, q3.y, q3.z, 8);
+            rec.l3 = pack4(q3.w, q4.x, q4.y, q4.z, 12);
+            rec.types = types;
+            fits = fits && !odd_type;
         }
-        const F5Rec rec{ myslot };
         // the table entries this round's alignments name
         int tab_lo = 0;
         {
