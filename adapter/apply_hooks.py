@@ -9,6 +9,9 @@ exactly once, so a reference version with a different call site fails the build 
 Every inserted line calls a function declared in adapter/sk_adapter.hh; all logic lives in adapter/*.cpp.
 
 usage: apply_hooks.py <reference root> <output dir>
+       apply_hooks.py --doc [INTEGRATION.md]     print the table of edits made from HOOKS (markdown), or rewrite the section of the
+                                                 named file between the `hooks:begin` / `hooks:end` markers with it -- the document's
+                                                 table is GENERATED from this list (tests/test_abi.py compares them), it cannot drift
 """
 import os
 import re
@@ -166,7 +169,47 @@ HOOKS = [
 ]
 
 
+DOC_BEGIN, DOC_END = "<!-- hooks:begin (generated by adapter/apply_hooks.py --doc; do not edit) -->", "<!-- hooks:end -->"
+
+
+def doc_table():
+    """the edits as a markdown table: reference file, what the edit is for (the description the build prints when an anchor fails), the
+    adapter functions the inserted text calls"""
+    rows = ["| reference file | edit | calls inserted (`sk_adapter::`) |", "|---|---|---|"]
+    for rel, hooks in HOOKS:
+        for desc, _anchor, repl in hooks:
+            calls = []
+            for name in re.findall(r"sk_adapter::([A-Za-z_0-9]+)", repl):
+                if name not in calls:
+                    calls.append(name)
+            if "friend" in desc and calls == ["Access"]:
+                what = "`friend struct sk_adapter::Access;` (no data member: the class layout is unchanged)"
+            elif desc == "include":
+                what = '`#include "sk_adapter.hh"`'
+            elif calls:
+                what = ", ".join("`%s`" % c for c in calls)
+            elif "_reference(" in repl:
+                what = "the reference's definition renamed `..._reference` (never called): `adapter/sk_adapter_germline_indel.cpp` defines the function"
+            else:
+                what = "(text removed: the work is done by a routed site)"
+            rows.append("| `L/%s` | %s | %s |" % (rel[len(L):], desc, what))
+    return "\n".join(rows)
+
+
+def doc_section():
+    return DOC_BEGIN + "\n" + doc_table() + "\n" + DOC_END
+
+
 def main():
+    if len(sys.argv) >= 2 and sys.argv[1] == "--doc":
+        if len(sys.argv) == 2:
+            print(doc_table())
+            return
+        text = open(sys.argv[2]).read()
+        a, b = text.index(DOC_BEGIN), text.index(DOC_END) + len(DOC_END)
+        with open(sys.argv[2], "w") as f:
+            f.write(text[:a] + doc_section() + text[b:])
+        return
     ref_root, out_dir = sys.argv[1], sys.argv[2]
     only = set(sys.argv[3:])
     for rel, hooks in HOOKS:

@@ -195,6 +195,19 @@ GeometryShadow::Params GeometryShadow::query(const pos_t pos) const
 void on_reset_region(starling_pos_processor_base& pp)
 {
     init();
+    // Said before the first read, not by a throw in the middle of a genome: a realignment job and the pileup streams hold per-sample
+    // fields for SK_MAX_SAMPLES samples, and an allele group of a multi-sample run can hold ploidy x samples alternate alleles
+    // (selectTopOrthogonalAllelesInAllSamples, OrthogonalVariantAlleleCandidateGroupUtil.cpp:285-340) -- the wide record takes
+    // SK_MAX_ALT_WIDE = 2 x SK_MAX_SAMPLES, so with this bound no group can outgrow it.
+    static_assert(SK_MAX_ALT_WIDE >= 2 * SK_MAX_SAMPLES, "the wide allele-group record holds ploidy x samples alternate alleles");
+    if (Access::sampleCount(pp) > SK_MAX_SAMPLES)
+    {
+        std::ostringstream oss;
+        oss << "strelka_amd adapter: " << Access::sampleCount(pp) << " samples in one run; this path takes at most SK_MAX_SAMPLES = "
+            << SK_MAX_SAMPLES << " (per-sample fields of a realignment job, allele groups of up to " << SK_MAX_ALT_WIDE
+            << " alternate alleles)";
+        throw blt_exception(oss.str().c_str());
+    }
     State& s(state());
     s.geometry.reset(Access::sampleCount(pp));
     s.isAnyRealigned = false;

@@ -56,17 +56,20 @@ def parse():
                     help="reads per job of the flatten + score leg (2^16 reads x ~88 candidate alignments = 5.8e6 alignments in one job; "
                          "SURVEY 8d asks for 2^14 .. 2^20 reads)")
     ap.add_argument("--a5-reps", type=int, default=3)
-    ap.add_argument("--e2e-bp", type=int, default=32000000, help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg)")
-    ap.add_argument("--e2e-segment-bp", type=int, default=4000000,
-                    help="segment size of the end-to-end leg (one caller process per segment; the workflow cuts a genome into 12 Mb pieces: "
-                         "profiles/ holds a run at --e2e-bp 64000000 --e2e-segment-bp 12000000, chr20's size)")
+    ap.add_argument("--e2e-bp", type=int, default=64000000,
+                    help="length of the WGS-like 40x sample of the end-to-end leg per GPU (0: skip the leg); the default is chr20's size "
+                         "(BASELINE.json configs[1])")
+    ap.add_argument("--e2e-segment-bp", type=int, default=12000000,
+                    help="segment size of the end-to-end leg (one caller process per segment); the default is the workflow's: a genome is cut "
+                         "into equal pieces no longer than scanSizeMb = 12 Mb (PY/strelkaSharedOptions.py:161), chr20 -> 6 segments")
     ap.add_argument("--only", default="", help="'a5' / 'feed' / 'feed_slice' / 'loci' / 'pileup' / 'somatic': run one kernel leg alone (the counter passes of tools/gpu_round.sh use it: "
                                                "per-kernel averages then belong to that leg's launches) and print a short line; 'e2e', "
                                                "'e2e_germline', 'e2e_somatic': the end-to-end legs alone (exit code 1 when the drop-in's outputs "
                                                "differ from the reference's)")
-    ap.add_argument("--e2e-somatic-bp", type=int, default=3200000,
-                    help="length of the WGS-like 110x / 40x tumour-normal pair of the somatic end-to-end leg per GPU (0: skip the leg)")
-    ap.add_argument("--e2e-somatic-segment-bp", type=int, default=400000, help="segment size of the somatic end-to-end leg")
+    ap.add_argument("--e2e-somatic-bp", type=int, default=16000000,
+                    help="length of the WGS-like 110x / 40x tumour-normal pair of the somatic end-to-end leg per GPU (0: skip the leg); "
+                         "a quarter of chr20 (BASELINE.json configs[2]) at 150x in all")
+    ap.add_argument("--e2e-somatic-segment-bp", type=int, default=2000000, help="segment size of the somatic end-to-end leg")
     ap.add_argument("--e2e-max-procs-per-gpu", type=int, default=8,
                     help="caller processes that share one GPU in the end-to-end leg (beyond ~8 the device's scheduler time-slices them: "
                          "profiles/r03_v10_processes_per_gpu.txt, r03_v11_gpu_sharing_sdma.txt); the reference gets the same number of cores")
@@ -246,12 +249,23 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
         barrier()
         amd_wall = max_over_ranks(time.perf_counter() - t0)
         hooks = {}
+        counters = {}
         for tail in amd.stderr_tails:
             m = re.search(r"strelka_amd adapter seconds: (.*)", tail)
             if m:
                 for kv in m.group(1).split():
                     k, v = kv.split("=")
                     hooks[k] = hooks.get(k, 0.0) + float(v)
+            # what went through the C-ABI (adapter/sk_adapter_common.cpp, sk_adapter_feed.cpp: STRELKA_AMD_VERBOSE=1), summed over the
+            # segment processes: the identical bytes below are the routed path's only if these say so
+            for pat in (r"strelka_amd adapter: (.*)", r"strelka_amd adapter pileup: (.*)", r"strelka_amd adapter feed: (.*)"):
+                m = re.search(pat, tail)
+                if m:
+                    for kv in m.group(1).split():
+                        if "=" in kv:
+                            k, v = kv.split("=", 1)
+                            if re.fullmatch(r"-?\d+", v) and k not in ("read_window", "site_window"):
+                                counters[k] = counters.get(k, 0) + int(v)
         depth = 150.0 if somatic else 40.0
         what = ("tumour / normal pair, %d bp at 110x / 40x" if somatic else "germline sample, %d bp at 40x") % L
         flags = ("somatic workflow's command line (EVS scoring models, --somatic-callable-regions-file, --strelka-chrom-depth-file ...)"
@@ -268,6 +282,10 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                              "gain is gone (profiles/r03_v10, r03_v11).  The reference leg runs on the same number of cores.",
                "bp_per_s": L * world / amd_wall, "process_seconds_sum": sum(amd.process_s),
                "hook_seconds": {k: round(v, 4) for k, v in hooks.items()},
+               "counters": counters,
+               "counters_note": "summed over the segment processes: enum_device_reads / enum_host_instead = reads whose candidate alignments the "
+                                "device search listed / reads the device turned down and the host statement listed instead; "
+                                "normalize_declined = alignments handed back to the reference's own normalizeAlignment (must be 0)",
                "hook_seconds_note": "summed over this rank's segment processes: wall seconds inside the adapter's hooks (*_hook) of which inside "
                                     "the C-ABI (*_abi); the rest of process_seconds_sum is the reference's own host code (BAM records, read "
                                     "buffer, active regions, locus objects, VCF text)",
@@ -382,6 +400,9 @@ def pmc_traffic(args):
     a5 = d.get("a5_only")
     if a5 and a5.get("workload", {}).get("a5_scenarios") == args.a5_scenarios and a5.get("workload", {}).get("a5_reads") == args.a5_reads:
         out["__a5_step__"] = a5["hbm_bytes_per_step"]
+    # where the numbers come from: every roofline object names the file, and the commit the counter passes ran at (tools/pmc_traffic.py
+    # records it; older files only carry their visit tags in `note`)
+    out["__source__"] = {"file": "profiles/" + os.path.basename(files[-1]), "commit": d.get("commit"), "note": d.get("note")}
     return out
 
 
@@ -702,6 +723,8 @@ def main():
             e2e_somatic = e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_reference=False, mode="somatic")
 
     traffic = pmc_traffic(args)
+    # the germline site kernel this run launched: variant 0 is round 1's statement, every other value the v2 kernel (the default)
+    g3_kernel = "germline_site_fused_kernel" if os.environ.get("SK_G3_VARIANT", "") == "0" else "germline_site_fused_v2_kernel"
     som_kernels = ("somatic_classify_kernel", "somatic_lhood_kernel", "somatic_posterior_kernel")
     som_traffic = sum(traffic[k] for k in som_kernels) if all(k in traffic for k in som_kernels) else None
     pil_kernels = ("pileup_read_kernel", "pileup_column_kernel_t")
@@ -715,6 +738,7 @@ def main():
         o = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": hbm_traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms}
         if hbm_traffic:
+            o["traffic_source"] = traffic.get("__source__")
             o["measured_hbm_gbs"] = hbm_traffic / (kernel_ms * 1e-3) / 1e9
             o["frac_measured"] = o["measured_hbm_gbs"] / HBM_PEAK_GBS
             o["traffic_over_algorithmic"] = hbm_traffic / alg_bytes
@@ -780,7 +804,7 @@ def main():
         "roofline": roof("flatten_score_kernel (F5: flattening + scoring of a read's candidate alignments in one launch)",
                          a5_meta["algorithmic_bytes"], kms_a5, traffic.get("__a5_step__")),
         "roofline_sum_only": roof("score_wave_per_read_cols", alg_bytes_a, kms_a, traffic.get("score_wave_per_read_cols")),
-        "roofline_loci": roof("germline_site_fused_kernel", alg_bytes_b, kms_b, traffic.get("germline_site_fused_kernel")),
+        "roofline_loci": roof(g3_kernel, alg_bytes_b, kms_b, traffic.get(g3_kernel)),
     }
     out.update(wr)
     out["roofline_global_align"]["note"] = ("latency-bound integer DP; its traffic is the back-pointer matrix (one byte per cell in global "

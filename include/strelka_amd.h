@@ -72,7 +72,10 @@ int sk_check_device_errors(void);
 
 /** Test hook: which statement of the fused germline site kernel sk_site_digt_call_fused[_dev] launches (0 = round 1's, 1 = the second one:
  *  csrc/germline_fused.hip); < 0 = $SK_G3_VARIANT or the
- *  default.  Every variant writes the same records (tests/test_gpu_parity.py runs them all against the oracle). */
+ *  default.  Every variant writes the same records (tests/test_gpu_parity.py runs them all against the oracle) WHEN
+ *  sk_libm_restated() == 1: variant 1 takes the ranked-call terms of groups without a neighbouring mismatch from a table built with
+ *  the host libm (csrc/germline_common.h, v0r0), its pending terms and all of variant 0's from the device routines; on a host whose
+ *  libm is not the restated one (STRELKA_AMD_ALLOW_INEXACT_LIBM) the two agree to the documented 1e-5, not bit for bit. */
 int sk_debug_set_g3_variant(int variant);
 /** Test hook: on != 0 makes every kernel take the path it takes on a host whose libm is NOT the restated one (the device
  *  math library's double routines stand in; sk_libm_restated() then reports 0); on == 0 restores the sk_init outcome.

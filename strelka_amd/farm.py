@@ -186,20 +186,10 @@ class FarmResult:
         self.sys_s = []         # ... system CPU seconds
         self.outputs = {}       # file name -> joined output path
         self.stderr_tails = []
-        self.fill_segments = 0  # segments called by the fill program of a mixed farm
 
 
-def run_farm(groups, argv_fn, out_dir, output_names, n_gpus=1, jobs=None, device_offset=0, env=None, pin_cores=None, join=True,
-             fill_jobs=0, fill_argv_fn=None, fill_min_pending=None):
+def run_farm(groups, argv_fn, out_dir, output_names, n_gpus=1, jobs=None, device_offset=0, env=None, pin_cores=None, join=True):
     """Run one process per segment group, `jobs` at a time.
-
-    fill_jobs / fill_argv_fn: a MIXED farm -- `fill_jobs` more process slots whose segments are called by another program
-    (fill_argv_fn, same signature as argv_fn: the unmodified reference).  A GPU serves about eight caller processes at the
-    one-process speed-up and no more (the driver gives compute processes eight hardware address spaces per device and time-slices
-    beyond that), so a node with more cores than 8 x GPUs lets the remaining cores call segments with the
-    reference's own program: both write the same bytes, the segments come from one queue, a faster slot simply takes more of them.
-    fill_min_pending: a fill slot takes a segment only while more than this many are waiting (default 2 x jobs; 0 when the caller has
-    sized the segments for the two kinds of slot itself).
 
     groups: [[segment, ...], ...] in genome order; argv_fn(group_index, regions, out_prefix, skip_header) -> argv;
     output_names: the files each process writes under its prefix (e.g. "variants.vcf", "genome.S1.vcf"), joined in group order
@@ -213,17 +203,14 @@ def run_farm(groups, argv_fn, out_dir, output_names, n_gpus=1, jobs=None, device
     res = FarmResult()
     pending = list(enumerate(groups))
     running = {}  # slot -> (index, Popen, t0, err path)
-    free_slots = list(range(jobs + (fill_jobs if fill_argv_fn else 0)))
+    free_slots = list(range(jobs))
     t_start = time.perf_counter()
     done = {}
     usage = {}
 
     def launch(slot, index, group):
         prefix = os.path.join(out_dir, "seg%04d." % index)
-        fn = argv_fn if slot < jobs else fill_argv_fn
-        argv = fn(index, [region_arg(s) for s in group], prefix, index != 0)
-        if slot >= jobs:
-            res.fill_segments += 1
+        argv = argv_fn(index, [region_arg(s) for s in group], prefix, index != 0)
         e = dict(base_env)
         e["STRELKA_AMD_DEVICE"] = str(device_offset + index % max(1, n_gpus))
         err = open(prefix + "stderr.txt", "wb")
@@ -237,10 +224,6 @@ def run_farm(groups, argv_fn, out_dir, output_names, n_gpus=1, jobs=None, device
     while pending or running:
         free_slots.sort()
         while pending and free_slots:
-            # (a fill slot is the slower kind: near the end of the queue it would be the straggler, so it only takes a segment
-            # while the primary slots have more than two rounds of work left)
-            if free_slots[0] >= jobs and len(pending) <= (2 * jobs if fill_min_pending is None else fill_min_pending):
-                break
             slot = free_slots.pop(0)
             index, group = pending.pop(0)
             launch(slot, index, group)
@@ -278,7 +261,7 @@ def run_farm(groups, argv_fn, out_dir, output_names, n_gpus=1, jobs=None, device
     res.sys_s = [done[i][3] for i in sorted(done)]
     for i in sorted(done):
         with open(done[i][1] + "stderr.txt", "rb") as f:
-            res.stderr_tails.append(f.read().decode(errors="replace")[-2000:])
+            res.stderr_tails.append(f.read().decode(errors="replace")[-6000:])
     if join:
         # the workflow's concatenation (bgzip'd pieces joined with bgzf_cat there; the raw text here)
         for name in output_names:

@@ -64,3 +64,22 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "strelka_oracle" not in txt and "libstrelka_ref" not in txt, f
+
+
+def test_integration_doc_lists_the_hooks_the_build_applies():
+    """INTEGRATION.md's table of edits is generated from adapter/apply_hooks.py's HOOKS (the list the build applies): the document
+    cannot describe a binding that no longer exists"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("apply_hooks", os.path.join(root, "adapter", "apply_hooks.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert m.doc_section() in text, "run `python adapter/apply_hooks.py --doc INTEGRATION.md`"
+    # every adapter source the document names exists, and every adapter source is named
+    import glob
+    import re
+    named = set(re.findall(r"sk_adapter_[a-z_]+\.(?:cpp|hh)", text))
+    present = {os.path.basename(p) for p in glob.glob(os.path.join(root, "adapter", "sk_adapter*"))}
+    assert named <= present, sorted(named - present)
+    assert {p for p in present if p.endswith(".cpp")} <= named, sorted(present - named)

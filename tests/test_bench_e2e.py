@@ -19,6 +19,8 @@ def test_e2e_leg_runs_and_compares(monkeypatch):
     assert out["first_difference"] is None and "all_cores" not in out
     assert out["variant_records"] > 300 and out["ref_wall_s"] > 0 and out["amd_wall_s"] > 0
     assert out["hook_seconds"]["pileup_abi"] > 0 and out["hook_seconds"]["pileup_hook"] >= out["hook_seconds"]["pileup_abi"]
+    c = out["counters"]
+    assert c["normalize_declined"] == 0 and c["realign_jobs"] > 0 and c["pushes"] > 0 and c["loci"] > 300000, c
 
 
 @pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
@@ -57,23 +59,53 @@ def test_e2e_leg_reports_the_first_difference(monkeypatch, tmp_path):
     assert os.path.exists(str(tmp_path / "kept" / ("germline_drop_in_" + fd["file"])))
 
 
-# ---- the legs at the configuration the metric is quoted on (what the driver's bench run does): 8 caller processes sharing one GPU, 4 Mb
-# segments, the workflow's command line with the EVS models on; BENCH_r03's germline leg failed exactly here while every smaller test passed
+# ---- the legs at the configuration the metric is quoted on (what the driver's bench run does; bench.py's defaults): chr20's 64 Mb cut
+# into 12 Mb segments as the workflow cuts it (configs[1]) / a 16 Mb tumour-normal pair in 2 Mb segments (configs[2]), caller processes
+# sharing one GPU, the workflow's command line with the EVS models on.  BENCH_r03's germline leg failed at its bench configuration while
+# every smaller test passed: the sizes here ARE the bench's (read from its argument parser, so they cannot drift apart).
+def _bench_defaults():
+    import sys
+    import bench
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        return bench.parse()
+    finally:
+        sys.argv = argv
+
+
+def _assert_routed(out, somatic=False):
+    """identical bytes are the routed path's only if the counters say the work went through the C-ABI"""
+    c = out["counters"]
+    assert c["normalize_declined"] == 0, c          # no alignment went back to the reference's own normalizeAlignment
+    assert c["enum_host_instead"] == 0, c           # no read of a device job was turned down and listed by the host statement
+    assert c["realign_jobs"] > 0 and c["enum_device_reads"] > 0, c
+    assert c["pushes"] > 0 and c["loci"] >= out["bp"] * 0.9, c
+    if not somatic:
+        assert c.get("gvcf_block_loci", 0) >= 0
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
 def test_e2e_germline_at_bench_configuration_identical_gpu():
     import bench
-    args = argparse.Namespace(e2e_bp=32000000, e2e_segment_bp=4000000, e2e_max_procs_per_gpu=8)
+    d = _bench_defaults()
+    assert d.e2e_bp == 64000000 and d.e2e_segment_bp == 12000000
+    args = argparse.Namespace(e2e_bp=d.e2e_bp, e2e_segment_bp=d.e2e_segment_bp, e2e_max_procs_per_gpu=d.e2e_max_procs_per_gpu)
     out = bench.e2e_leg(args, 0, 1, 0, lambda: None, lambda v: v, with_reference=True)
     assert out["identical"] is True, out["first_difference"]
-    assert out["segments"] == 8 and out["variant_records"] > 5000
+    assert out["segments"] == 6 and out["bp"] == 64000000 and out["variant_records"] > 50000
+    _assert_routed(out)
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_amd"), reason="oracle/_ref binaries not built")
 def test_e2e_somatic_at_bench_configuration_identical_gpu():
     import bench
-    args = argparse.Namespace(e2e_somatic_bp=3200000, e2e_somatic_segment_bp=400000, e2e_max_procs_per_gpu=8)
+    d = _bench_defaults()
+    assert d.e2e_somatic_bp >= 16000000 and d.e2e_somatic_segment_bp >= 2000000
+    args = argparse.Namespace(e2e_somatic_bp=d.e2e_somatic_bp, e2e_somatic_segment_bp=d.e2e_somatic_segment_bp,
+                              e2e_max_procs_per_gpu=d.e2e_max_procs_per_gpu)
     out = bench.e2e_leg(args, 0, 1, 0, lambda: None, lambda v: v, with_reference=True, mode="somatic")
     assert out["identical"] is True, out["first_difference"]
     assert out["segments"] == 8
+    _assert_routed(out, somatic=True)

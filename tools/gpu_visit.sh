@@ -1,12 +1,13 @@
 #!/bin/bash
-# one GPU-box visit of round 4: the steps named on the command line, outputs under gpurun_out/$TAG.
-#   tools/gpu_visit.sh TAG step [step ...]
+# one GPU-box visit: the steps named on the command line, outputs under gpurun_out/$TAG.
+#   tools/gpurun.sh --timeout S -- tools/gpu_visit.sh TAG step [step ...]
 # steps: e2e (bench's germline leg; on a mismatch the parity hunt), e2e_somatic, tests (pytest -m gpu without the two bench-configuration
 #        tests), tests_all, bench, smoke, ktrace, pmc_traffic, pmc_g3 (SQ counters of the germline site kernel), pmc_a5
 TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
+[ -f gpurun_commit.txt ] && cp gpurun_commit.txt $OUT/commit.txt
 for step in "$@"; do
   t0=$(date +%s)
   case $step in

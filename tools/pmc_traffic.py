@@ -89,4 +89,11 @@ if a5:
     per_step = sum(a5[k]["hbm_bytes_per_launch"] for k in step_kernels if k in a5)
     a5_only = dict(workload=dict(a5_scenarios=a.a5_scenarios, a5_reads=a.a5_reads), hbm_bytes_per_step=per_step,
                    kernels={k: a5[k] for k in step_kernels if k in a5})
-json.dump(dict(workload=workload, kernels=out, a5_only=a5_only), sys.stdout, indent=1)
+# the commit the counter passes ran at: tools/gpu_visit.sh writes `git rev-parse HEAD` of the pushing container into the visit's
+# directory before the snapshot leaves (the GPU box has no .git)
+commit = None
+for cand in (os.path.join(root, "commit.txt"), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_commit.txt")):
+    if os.path.exists(cand):
+        commit = open(cand).read().strip() or None
+        break
+json.dump(dict(workload=workload, kernels=out, a5_only=a5_only, commit=commit), sys.stdout, indent=1)
