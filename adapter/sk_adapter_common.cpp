@@ -92,7 +92,14 @@ State& make_state()
                       << " site_batches=" << s.siteBatches << " site_loci=" << s.siteLoci << " site_recomputed=" << s.siteRecomputed
                       << " indel_groups=" << s.indelGroups << " indel_groups_wide=" << s.indelGroupsWide << " haplotypes=" << s.haplotypes << " haplotype_batches=" << s.haplotypeBatches << " read_window=" << read_buffer_defer()
                       << " site_window=" << post_align_defer() << " enum_device_reads=" << s.realignDeviceEnumerated
-                      << " enum_host_instead=" << s.realignHostEnumerated << "\n";
+                      << " enum_host_instead=" << s.realignHostEnumerated;
+            {
+                // the device jobs of this process: run as one fixed sequence with one wait / of those run again the staged way / staged
+                int64_t oneWait(0), redone(0), staged(0);
+                sk_realign_device_job_counts(&oneWait, &redone, &staged);
+                std::cerr << " enum_jobs_one_wait=" << oneWait << " enum_jobs_redone=" << redone << " enum_jobs_staged=" << staged
+                          << " enum_jobs_host=" << s.realignHostJobs << "\n";
+            }
             std::cerr << "strelka_amd adapter pileup: pushes=" << s.pileupBatches << " reads=" << s.pileupReads << " loci=" << s.pileupLoci
                       << " genotyping=" << (s.pileup.isGenotyping ? 1 : 0) << "\n";
             std::cerr << "strelka_amd adapter seconds: realign_hook=" << s.tRealignHook << " realign_abi=" << s.tRealignAbi

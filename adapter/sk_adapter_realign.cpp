@@ -224,6 +224,7 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
         static const bool isModePinned(std::getenv("SK_ENUMERATION") != nullptr);
         static const size_t minDeviceReads([]() { const char* v(std::getenv("STRELKA_AMD_DEVICE_ENUM_MIN_READS")); return (v && *v) ? static_cast<size_t>(std::strtoul(v, nullptr, 10)) : size_t(512); }());
         if ((! isModePinned) && ro.enumeration == 2 && reads.size() < minDeviceReads) ro.enumeration = 0;
+        if (ro.enumeration != 2) s.realignHostJobs++;
     }
     if (opt.isRetainOptimalSoftClipping) throw blt_exception("strelka_amd adapter: --retain-optimal-soft-clipping (RNA) is not supported on this path");
 

@@ -349,6 +349,12 @@ int sk_realign_job_indels_consulted(const sk_realign_job* job, uint8_t* out, int
 /** How many reads had their candidate alignments enumerated by the container-free core on the host (enumeration == 1), on the
  *  device (== 2), and by the container-based code although 1 or 2 was asked for (a fixed capacity of the core was exceeded). */
 int sk_realign_job_enumeration_counts(const sk_realign_job* job, int64_t* n_core, int64_t* n_device, int64_t* n_fallback);
+/** Device jobs of this process so far (enumeration == 2; L/starling_common/starling_read_align.cpp:859-1277, :1536-1741 and
+ *  starling_read_align_score.cpp:261-499 for every read of a job): run as ONE fixed sequence of launches with one host wait (search levels,
+ *  sets, layout, F5 and stage 3 back to back, the prefix sums between them made on the device); of those, run again the staged way
+ *  because the device reported that an assumption of the sequence did not hold (deeper search levels than launched, a full leaf pool, a
+ *  read outside F5's form); run the staged way (three waits) from the start. */
+void sk_realign_device_job_counts(int64_t* n_one_wait, int64_t* n_one_wait_redone, int64_t* n_staged);
 /** How many reads had stage 3 (scoreCandidateAlignments' selection, finishRealignment and score_indels, L/starling_common/
  *  starling_read_align.cpp:1534-1741 and starling_read_align_score_indels.cpp:455-1079) run in its container-free form on the
  *  host (enumeration == 1) and on the device (== 2); the rest went through the container-based code. */

@@ -334,6 +334,13 @@ struct SkEnumOutput;
 extern "C" int sk_enum_device_available(void) { return 0; }
 namespace skcore { struct PCal; }
 extern "C" int sk_enum_device_fetch_cals(uint64_t, int32_t, int32_t, skcore::PCal*) { return 1; }
+extern "C" int sk_enum_device_fetch_scores(uint64_t, int32_t, int32_t, double*) { return 1; }
+extern "C" void sk_enum_device_job_counts(int64_t* a, int64_t* b, int64_t* c)
+{
+    if (a) *a = 0;
+    if (b) *b = 0;
+    if (c) *c = 0;
+}
 extern "C" int sk_enum_device_rescore(int32_t, float*, int32_t*, int32_t*, int64_t*)
 {
     return sk_fail("sk_realign_job_rescore measures the GPU library's kernels");

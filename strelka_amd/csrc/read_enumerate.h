@@ -45,7 +45,8 @@ struct SkEnumOutput // host arrays owned by the pipeline, valid until its next r
     const skcore::PCal* cals;  // [cal_off[n_reads]] each read's candidate alignments in set order; null with want_stage3: they stay on
                                // the device (sk_enum_device_fetch_cals) -- 288 bytes per alignment that the host rarely needs
     uint64_t generation;       // of this run, for sk_enum_device_fetch_cals
-    const double* scores;      // [cal_off[n_reads]] or null
+    const double* scores;      // [cal_off[n_reads]]; null without want_scores, and null when the job ran as one fixed sequence: the scores stay on
+                               // the device (sk_enum_device_fetch_scores) -- the host reads them only for a read stage 3 turned down
     const uint8_t* consulted;  // [n_tab] candidate status consulted by the search, the flattening or stage 3
     const sk3::Out* stage3;    // [n_reads] or null; stage3[r].status != S3_OK (or status[r] != ST_OK): stage 3 of the read is the host's
 };
@@ -54,6 +55,11 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out);
 
 /** candidate alignments [first, first + count) of run `generation`, from the device's buffers; 1 when another run has replaced them */
 extern "C" int sk_enum_device_fetch_cals(uint64_t generation, int32_t first, int32_t count, skcore::PCal* out);
+
+/** scores [first, first + count) of run `generation`; 1 when another run has replaced them */
+extern "C" int sk_enum_device_fetch_scores(uint64_t generation, int32_t first, int32_t count, double* out);
+/** jobs of this process: run as one fixed sequence with one wait, of those run again the staged way, run the staged way from the start */
+extern "C" void sk_enum_device_job_counts(int64_t* one_wait, int64_t* one_wait_redone, int64_t* staged);
 
 /** whether enumeration == 2 can run (it is the default where it can): 1 in the GPU library once sk_init has succeeded, 0 before
  *  that and in the CPU double of the ABI */

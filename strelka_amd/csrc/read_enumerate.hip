@@ -66,6 +66,12 @@ struct EnumArgs
     int32_t* status; // [n_reads] max over the read's calls
     int32_t* warn;   // [n_reads] bit 0 origin, bit 1 toggle depth
     unsigned long long* n_nodes;
+    // null, or per read cells that start at INT_MAX (win_begin, ins_lo) / INT_MIN (win_end, ins_hi): the root launch sets them when the
+    // job runs as one fixed sequence (no fills of their own)
+    int32_t* min_cells_a;
+    int32_t* min_cells_b;
+    int32_t* max_cells_a;
+    int32_t* max_cells_b;
 };
 
 __device__ inline uint32_t cal_hash(const PCal& c)
@@ -115,6 +121,10 @@ __global__ __launch_bounds__(64) void root_kernel(const EnumArgs a)
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_reads) return;
     if (r == 0) a.level_count[0] = a.n_reads;
+    if (a.min_cells_a) {
+        a.min_cells_a[r] = a.min_cells_b[r] = INT_MAX;
+        a.max_cells_a[r] = a.max_cells_b[r] = INT_MIN;
+    }
     PFrame& f = a.level_out[r];
     root_frame(a.job, a.reads[r], f);
     f.read_id = r;
@@ -171,6 +181,8 @@ struct SetArgs
     int32_t* n_uniq;        // [n_reads] zeroed
     const int32_t* cal_off; // [n_reads+1]
     int32_t* sorted;        // [cal_off[n_reads]] leaf slots in set order
+    const int32_t* n_leaves_dev; // null, or where the search counted its leaves: the job runs as one fixed sequence, the host has not
+                                 // seen the count (n_leaves is then the pool's capacity)
 };
 
 __device__ inline int group_of(const int32_t* off, const int n, const int g) // last r with off[r] <= g
@@ -199,14 +211,15 @@ __device__ inline ulonglong2 leaf_key(const PCal& c)
 }
 __global__ __launch_bounds__(256) void group_kernel(const SetArgs a)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.n_leaves) return;
-    const int r = a.leaf_read[s];
-    if (a.status[r] != ST_OK) return;
-    const int g = a.raw_off[r] + atomicAdd(&a.fill[r], 1);
-    a.grouped[g] = s;
-    a.ghash[g] = a.leaf_hash[s];
-    a.gkey[g] = leaf_key(a.pool[s]);
+    const int n_leaves = a.n_leaves_dev ? min(*a.n_leaves_dev, a.n_leaves) : a.n_leaves;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n_leaves; s += gridDim.x * blockDim.x) {
+        const int r = a.leaf_read[s];
+        if (a.status[r] != ST_OK) continue;
+        const int g = a.raw_off[r] + atomicAdd(&a.fill[r], 1);
+        a.grouped[g] = s;
+        a.ghash[g] = a.leaf_hash[s];
+        a.gkey[g] = leaf_key(a.pool[s]);
+    }
 }
 
 // a leaf is a duplicate when an equal leaf stands before it in its read's group (which of the equal ones stands first differs
@@ -214,8 +227,8 @@ __global__ __launch_bounds__(256) void group_kernel(const SetArgs a)
 // for a load (reads with thousands of leaves make it long); the records are compared only where a hash is met again.
 __global__ __launch_bounds__(256) void dedupe_kernel(const SetArgs a)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.raw_off[a.n_reads]) return;
+    const int n_grouped = a.raw_off[a.n_reads];
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_grouped; g += gridDim.x * blockDim.x) {
     const int r = group_of(a.raw_off, a.n_reads, g);
     const uint32_t h = a.ghash[g];
     const int q0 = a.raw_off[r];
@@ -241,15 +254,16 @@ __global__ __launch_bounds__(256) void dedupe_kernel(const SetArgs a)
     }
     a.dup[g] = dup ? 1 : 0;
     if (!dup) atomicAdd(&a.n_uniq[r], 1);
+    }
 }
 
 // the rank of a kept leaf in the set order of its read (CandidateAlignment.hh:37-48, alignment.hh:72-90: cal_compare): the keys
 // decide for almost every pair, without a branch; pairs with equal keys (their number is counted on the way) get the full comparison
 __global__ __launch_bounds__(256) void rank_kernel(const SetArgs a)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.raw_off[a.n_reads]) return;
-    if (a.dup[g]) return;
+    const int n_grouped = a.raw_off[a.n_reads];
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_grouped; g += gridDim.x * blockDim.x) {
+    if (a.dup[g]) continue;
     const int r = group_of(a.raw_off, a.n_reads, g);
     const ulonglong2 kmine = a.gkey[g];
     const int q0 = a.raw_off[r], q1 = a.raw_off[r + 1];
@@ -271,6 +285,108 @@ __global__ __launch_bounds__(256) void rank_kernel(const SetArgs a)
         }
     }
     a.sorted[a.cal_off[r] + rank] = a.grouped[g];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The job as ONE fixed sequence of launches (no host decision between the upload and the results): the two prefix sums the host used to
+// make between waits -- leaves per read -> raw_off, unique alignments per read -> cal_off -- are made here, by one workgroup (a job has at
+// most a few ten thousand reads: a thread a run of consecutive reads, one block-wide scan of the runs' sums), together with what else
+// the host derived from them: the totals, stage 3's two read lists, and the conditions under which the sequence's assumptions do not
+// hold (then the host runs the job again the staged way: sk_enum_device_run).
+
+enum { DYN_N_GROUPED = 0, DYN_N_CALS, DYN_N_LIGHT, DYN_N_HEAVY, DYN_FLAGS, DYN_MAX_CALS, DYN_COUNT = 8 };
+enum { DYNF_DEEPER = 1,    // calls were left at the first level the sequence did not launch
+       DYNF_POOL_FULL = 2 }; // more leaves than the sequence's pool holds
+
+__device__ inline int block_exclusive_scan(const int v, int* wave_sums /* LDS [blockDim.x / 64 + 1] */, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    int x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads(); // (wave_sums may still be read from a previous scan)
+    if (lane == 63) wave_sums[wave] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < n_waves; ++w) {
+            const int t = wave_sums[w];
+            wave_sums[w] = run;
+            run += t;
+        }
+        wave_sums[n_waves] = run;
+    }
+    __syncthreads();
+    *total = wave_sums[n_waves];
+    return wave_sums[wave] + x - v;
+}
+
+struct ScanArgs
+{
+    int32_t n_reads;
+    const int32_t* status;
+    const int32_t* count;   // [n_reads] n_raw (scan 1) / n_uniq (scan 2)
+    int32_t* off;           // [n_reads + 1] raw_off / cal_off
+    int32_t* dyn;           // [DYN_COUNT]
+    // scan 1
+    const int32_t* level_count;
+    int32_t first_level_not_launched; // (or -1: every level went out)
+    const int32_t* n_leaves;
+    int32_t pool_cap;
+    // scan 2
+    int32_t* list;          // [n_reads] stage 3: reads with at most light_cals alignments from the front, the others from the back
+    int32_t light_cals;
+};
+
+template <bool SECOND>
+__global__ __launch_bounds__(1024) void job_scan_kernel(const ScanArgs a)
+{
+    __shared__ int wave_sums[17];
+    const int n = a.n_reads, t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int r0 = min(n, t * per), r1 = min(n, r0 + per);
+    int sum = 0, n_light = 0, n_heavy = 0, max_cals = 0;
+    for (int r = r0; r < r1; ++r) {
+        const int k = (a.status[r] == ST_OK) ? a.count[r] : 0;
+        sum += k;
+        if (SECOND) {
+            if (k <= a.light_cals) ++n_light; else ++n_heavy;
+            max_cals = max(max_cals, k);
+        }
+    }
+    int total = 0;
+    int at = block_exclusive_scan(sum, wave_sums, &total);
+    for (int r = r0; r < r1; ++r) {
+        a.off[r] = at;
+        at += (a.status[r] == ST_OK) ? a.count[r] : 0;
+    }
+    if (t == 0) a.off[n] = total;
+    if (!SECOND) {
+        if (t == 0) {
+            a.dyn[DYN_N_GROUPED] = total;
+            int flags = 0;
+            if (a.first_level_not_launched >= 0 && a.level_count[a.first_level_not_launched] != 0) flags |= DYNF_DEEPER;
+            if (*a.n_leaves >= a.pool_cap) flags |= DYNF_POOL_FULL;
+            a.dyn[DYN_FLAGS] = flags;
+        }
+    } else {
+        int tot_light = 0, tot_heavy = 0;
+        int lat = block_exclusive_scan(n_light, wave_sums, &tot_light);
+        int hat = block_exclusive_scan(n_heavy, wave_sums, &tot_heavy);
+        for (int r = r0; r < r1; ++r) {
+            const int k = (a.status[r] == ST_OK) ? a.count[r] : 0;
+            if (k <= a.light_cals) a.list[lat++] = r; else a.list[n - 1 - hat++] = r;
+        }
+        atomicMax(&a.dyn[DYN_MAX_CALS], max_cals);
+        if (t == 0) {
+            a.dyn[DYN_N_CALS] = total;
+            a.dyn[DYN_N_LIGHT] = tot_light;
+            a.dyn[DYN_N_HEAVY] = tot_heavy;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -326,6 +442,7 @@ struct FlatArgs
     uint8_t* colmat; // (bytes of the words; pre-filled with the 0.0 column)
     const int64_t* colmat_off;
     uint32_t* addmask;
+    int32_t n_cals_on_device; // the job runs as one fixed sequence: the number of candidate alignments is cal_off[n_reads], the host has not seen it
 };
 enum { INS_CAP = Caps::K + 2 };
 
@@ -347,8 +464,8 @@ __device__ inline int read_of_cal(const FlatArgs& a, const int c) // last r with
 //   L1b  one thread per read: offsets
 __global__ __launch_bounds__(256) void pool_bounds_kernel(const FlatArgs a)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.n_cals) return;
+    const int n_cals = a.n_cals_on_device ? a.cal_off[a.n_reads] : a.n_cals;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cals; c += gridDim.x * blockDim.x) {
     const int r = read_of_cal(a, c);
     const PCal& cal = a.pool[a.list[c]];
     a.n_seg8[c] = uint8_t(min(int(cal.n_seg), 255));
@@ -379,6 +496,7 @@ __global__ __launch_bounds__(256) void pool_bounds_kernel(const FlatArgs a)
     if (lo <= hi) {
         atomicMin(&a.ins_lo[r], lo);
         atomicMax(&a.ins_hi[r], hi);
+    }
     }
 }
 
@@ -653,6 +771,7 @@ __global__ __launch_bounds__(64) void flatten_kernel(const FlatArgs a)
 // A read this form does not hold (longer than F5_MAX_READ bases, pool over F5_MAX_POOL bytes) is counted in *n_unhandled: the caller
 // then runs F1-F3 + A1c over the job.
 constexpr int F5_MAX_READ = 256;  // (as F3's wave form; longer reads and larger pools take the staged chain)
+constexpr int ONE_WAIT_MAX_READS = 16384; // reads of a job that runs as one fixed sequence (its buffers are sized by capacities: 256 leaves per read)
 constexpr int F5_MAX_POOL = 768;
 #ifndef F5_SORT
 #define F5_SORT 1 // experiments: 0 = the set's order
@@ -1595,6 +1714,12 @@ struct Stage3Args
     sk3::Out* out;
     const int32_t* list; // the reads of this launch
     int32_t lds_cals;
+    // the job as one fixed sequence: the launch has a block per read of the JOB, the number of reads on this launch's list is on the
+    // device (n_list; the heavy list is filled from the back: list_step = -1), and nothing runs when F5 turned a read down (skip_if:
+    // the scores are then incomplete -- the host runs the job again through the staged chain)
+    const int32_t* n_list;
+    int32_t list_step;
+    const int32_t* skip_if;
 };
 
 template <int WAVES>
@@ -1603,7 +1728,9 @@ __global__ __launch_bounds__(64 * WAVES) void stage3_kernel(const Stage3Args a)
     constexpr int T = 64 * WAVES;
     __shared__ sk3::Shared sh;
     extern __shared__ double s3_lds[]; // the per-alignment arrays of the selection and the late normalisation filter, for a read with at most a.lds_cals candidate alignments
-    const int r = a.list[blockIdx.x];
+    if (a.skip_if && *a.skip_if > 0) return;
+    if (a.n_list && int(blockIdx.x) >= *a.n_list) return;
+    const int r = a.list[int(blockIdx.x) * (a.n_list ? a.list_step : 1)];
     sk3::Out& o = a.out[r];
     const int32_t c0 = a.cal_off[r], c1 = a.cal_off[r + 1];
     if (a.status[r] != ST_OK || c1 == c0) {
@@ -1724,6 +1851,7 @@ struct EnumBuffers
     View counters, status, warn, n_raw, hap_len, fill, n_uniq, consulted;
     View win_begin, ins_lo, win_end, ins_hi, evmask, addmask;
     View h_counters, h_status, h_warn, h_n_raw, h_hap_len, h_n_uniq, h_consulted;
+    View cal_off_z, h_cal_off_z;
     DevBuf level_a, level_b, pool, leaf_read, leaf_hash;
     DevBuf raw_off, grouped, ghash, gkey, dup, sorted;
     DevBuf n_ops, win_len, n_ins, ins_idx, ins_off, n_seg8;
@@ -1749,6 +1877,7 @@ int32_t g_n_cals = 0;
 bool g_cals_gathered = false; // bufs().cals holds the run's records in set order (else: pool + list, gathered when the host asks)
 const PCal* g_cals_pool = nullptr;
 const int32_t* g_cals_list = nullptr;
+const double* g_scores = nullptr; // the run's scores, where the scoring kernel left them
 
 // what sk_enum_device_rescore needs to run F1-F3 + the scoring kernel again on the candidate alignments of the last run
 struct LastFlat
@@ -1764,6 +1893,17 @@ struct LastFlat
     double* scores = nullptr;
 } g_last;
 } // namespace
+
+extern "C" int sk_enum_device_fetch_scores(const uint64_t generation, const int32_t first, const int32_t count, double* dst)
+{
+    if (generation != g_generation || first < 0 || count < 0 || first + count > g_n_cals || !g_scores) return 1;
+    if (count == 0) return 0;
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(hipMemcpyAsync(dst, g_scores + first, 8 * size_t(count), hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(hipStreamSynchronize(ctx.stream));
+    return 0;
+}
 
 extern "C" int sk_enum_device_fetch_cals(const uint64_t generation, const int32_t first, const int32_t count, PCal* dst)
 {
@@ -1782,13 +1922,29 @@ extern "C" int sk_enum_device_fetch_cals(const uint64_t generation, const int32_
     return 0;
 }
 
-extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
+namespace
+{
+// statistics of the process: jobs run as one fixed sequence (one wait), and those of them the host ran again the staged way because
+// an assumption of the sequence did not hold (deeper levels than launched, a full leaf pool, a read outside F5's form)
+int64_t g_jobs_one_wait = 0, g_jobs_one_wait_redone = 0, g_jobs_staged = 0;
+}
+extern "C" void sk_enum_device_job_counts(int64_t* one_wait, int64_t* one_wait_redone, int64_t* staged)
+{
+    if (one_wait) *one_wait = g_jobs_one_wait;
+    if (one_wait_redone) *one_wait_redone = g_jobs_one_wait_redone;
+    if (staged) *staged = g_jobs_staged;
+}
+
+// one_wait: the job as ONE fixed sequence of submissions and one host wait (see job_scan_kernel); *redo is set when the sequence's
+// assumptions did not hold for this job and nothing of `out` is valid: the caller runs it again with one_wait = false
+static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const bool one_wait, bool* redo)
 {
     SK_REQUIRE_INIT();
     if (!in || !out) return sk_fail("sk_enum_device_run: null argument");
     std::memset(out, 0, sizeof(*out));
     out->generation = ++g_generation;
     g_n_cals = 0;
+    g_scores = nullptr;
     g_cals_gathered = false;
     g_last.valid = false;
     const int n = in->n_reads;
@@ -1820,7 +1976,12 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
             pool_cap = pc;
         }
     }
-    const int n_counters = Caps::K + 8; // level counts [0, K+3), leaves, calls made (64 bit)
+    bool test_caps = false;
+    if (const char* e = std::getenv("SK_ENUM_TEST_CAPS")) test_caps = (e[0] != 0);
+    // one sequence: the buffers between the search and stage 3 are sized by the pool's capacity instead of by counts the host would have
+    // to wait for -- 256 leaves per read (at least 2^17) cover every WGS-like job; one that needs more is run again the staged way
+    if (one_wait && !test_caps) pool_cap = std::min<int64_t>(pool_cap, std::max<int64_t>(int64_t(n) * 256, 1 << 17));
+    const int n_counters = Caps::K + 8 + DYN_COUNT; // level counts [0, K+3), leaves, calls made (64 bit), F5's unhandled reads; the scans' results
 #define RES(buf, bytes) \
     if (B.buf.reserve(std::max<size_t>(size_t(bytes), 256))) return 1
 #define HRES(buf, bytes) \
@@ -1878,8 +2039,9 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
         { &B.counters, nullptr, 4 * size_t(n_counters), 0 }, { &B.warn, nullptr, 4 * size_t(n), 0 },    { &B.n_raw, nullptr, 4 * size_t(n), 0 },
         { &B.status, nullptr, 4 * size_t(n), 0 },            { &B.hap_len, nullptr, 4 * size_t(n), 0 }, { &B.fill, nullptr, 4 * size_t(n), 0 },
         { &B.n_uniq, nullptr, 4 * size_t(n), 0 },            { &B.consulted, nullptr, size_t(in->n_tab) + 1, 0 },
+        { &B.cal_off_z, nullptr, one_wait ? 4 * size_t(n + 1) : 0, 0 }, // (one sequence: cal_off is made on the device and comes back with the arena)
     };
-    View* zero_host[] = { &B.h_counters, &B.h_warn, &B.h_n_raw, &B.h_status, &B.h_hap_len, nullptr, &B.h_n_uniq, &B.h_consulted };
+    View* zero_host[] = { &B.h_counters, &B.h_warn, &B.h_n_raw, &B.h_status, &B.h_hap_len, nullptr, &B.h_n_uniq, &B.h_consulted, &B.h_cal_off_z };
     const int n_zero_p = int(sizeof(zero_p) / sizeof(zero_p[0]));
     const size_t zero_bytes = lay_out(zero_p, n_zero_p);
     Piece minmax_p[] = { { &B.win_begin, nullptr, 4 * size_t(n), 0 }, { &B.ins_lo, nullptr, 4 * size_t(n), 0 },
@@ -1958,7 +2120,242 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     ea.n_raw = B.n_raw.as<int32_t>();
     ea.status = B.status.as<int32_t>();
     ea.warn = B.warn.as<int32_t>();
+    ea.min_cells_a = ea.min_cells_b = ea.max_cells_a = ea.max_cells_b = nullptr;
     lap("H2D");
+    if (one_wait) {
+        // ---- the job as one fixed sequence: ~20 submissions, no host decision between them, ONE wait.  Everything the host used to
+        // compute between waits is computed by job_scan_kernel; every buffer is sized by a capacity known now; launches whose size the
+        // host does not know cover the capacity with a grid-stride loop (or a block per read of the job that leaves at once).
+        const int32_t n_cap = int32_t(pool_cap); // leaves, grouped leaves and candidate alignments are all at most this many
+        RES(grouped, 4 * size_t(n_cap));
+        RES(ghash, 4 * size_t(n_cap));
+        RES(gkey, 16 * size_t(n_cap));
+        RES(dup, size_t(n_cap));
+        RES(sorted, 4 * size_t(n_cap));
+        RES(n_seg8, size_t(n_cap));
+        RES(scores, 8 * size_t(n_cap));
+        RES(s3_order, 4 * size_t(n_cap));
+        RES(s3_smooth, 8 * size_t(n_cap));
+        RES(s3_flag, size_t(n_cap));
+        RES(s3_rm_type, size_t(n_bases));
+        RES(s3_rm_pos, 4 * size_t(n_bases));
+        RES(s3_key, 16 * size_t(n_cap));
+        RES(s3_sorted_score, 8 * size_t(n_cap));
+        RES(s3_sorted_hash, 4 * size_t(n_cap));
+        RES(s3_next_same, 4 * size_t(n_cap));
+        RES(s3_removed, size_t(n_cap));
+        RES(s3_range_end, 4 * size_t(n_cap));
+        RES(s3_out, sizeof(sk3::Out) * size_t(n));
+        RES(s3_list, 4 * size_t(n));
+        HRES(h_s3_out, sizeof(sk3::Out) * size_t(n));
+        int32_t* const dyn = B.counters.as<int32_t>() + (Caps::K + 8);
+        const int32_t* const h_dyn = B.h_counters.as<int32_t>() + (Caps::K + 8);
+        int32_t* const n_unhandled = B.counters.as<int32_t>() + (Caps::K + 7);
+
+        // E1: root + the levels up to the deepest order of the job (+ 2: indels that join an order on the way); whether calls were left
+        // for a deeper level is looked at on the device (scan 1) and reported with the results
+        PFrame* buf[2] = { B.level_a.as<PFrame>(), B.level_b.as<PFrame>() };
+        ea.min_cells_a = B.win_begin.as<int32_t>();
+        ea.min_cells_b = B.ins_lo.as<int32_t>();
+        ea.max_cells_a = B.win_end.as<int32_t>();
+        ea.max_cells_b = B.ins_hi.as<int32_t>();
+        ea.level_in = nullptr;
+        ea.level_out = buf[0];
+        ea.depth = -1;
+        hipLaunchKernelGGL(root_kernel, dim3((n + 63) / 64), dim3(64), 0, st, ea);
+        int max_order = 0;
+        for (int r = 0; r < n; ++r) max_order = std::max(max_order, int(in->reads[r].n_order));
+        int n_levels = std::min(max_order + 3, int(Caps::K) + 2);
+        if (const char* e = std::getenv("SK_ENUM_TEST_LEVELS")) // tests: too few levels, so that the device reports it and the job runs again
+            if (std::atoi(e) > 0) n_levels = std::min(n_levels, std::atoi(e));
+        {
+            const size_t lds = 64 * sizeof(PFrame);
+            // (a level of this job has at most a few frames per read: blocks beyond that would only read the count and leave)
+            const int blocks = int(std::min<int64_t>(std::min<int64_t>((frame_cap + 63) / 64, 1024), std::max<int64_t>(n, 16)));
+            for (int d = 0; d < n_levels; ++d) {
+                ea.level_in = buf[d & 1];
+                ea.level_out = buf[(d + 1) & 1];
+                ea.depth = d;
+                hipLaunchKernelGGL(level_kernel, dim3(blocks), dim3(64), lds, st, ea);
+            }
+        }
+        // scan 1: raw_off
+        ScanArgs sc;
+        std::memset(&sc, 0, sizeof(sc));
+        sc.n_reads = n;
+        sc.status = ea.status;
+        sc.count = ea.n_raw;
+        sc.off = B.raw_off.as<int32_t>();
+        sc.dyn = dyn;
+        sc.level_count = ea.level_count;
+        sc.first_level_not_launched = (n_levels >= int(Caps::K) + 2) ? -1 : n_levels;
+        sc.n_leaves = ea.n_leaves;
+        sc.pool_cap = n_cap;
+        hipLaunchKernelGGL(job_scan_kernel<false>, dim3(1), dim3(1024), 0, st, sc);
+        // E2
+        SetArgs sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.pool = ea.pool;
+        sa.leaf_read = ea.leaf_read;
+        sa.leaf_hash = ea.leaf_hash;
+        sa.status = ea.status;
+        sa.n_reads = n;
+        sa.n_leaves = n_cap;
+        sa.n_leaves_dev = ea.n_leaves;
+        sa.raw_off = B.raw_off.as<int32_t>();
+        sa.fill = B.fill.as<int32_t>();
+        sa.grouped = B.grouped.as<int32_t>();
+        sa.ghash = B.ghash.as<uint32_t>();
+        sa.gkey = B.gkey.as<ulonglong2>();
+        sa.dup = B.dup.as<uint8_t>();
+        sa.n_uniq = B.n_uniq.as<int32_t>();
+        sa.cal_off = B.cal_off_z.as<int32_t>();
+        sa.sorted = B.sorted.as<int32_t>();
+        // (grids for counts the host has not seen: enough blocks for ~64 leaves per read, the loops cover the rest)
+        const int e2_blocks = int(std::min<int64_t>(std::max<int64_t>((int64_t(n) * 64 + 255) / 256, 8), 2048));
+        hipLaunchKernelGGL(group_kernel, dim3(e2_blocks), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(dedupe_kernel, dim3(e2_blocks), dim3(256), 0, st, sa);
+        // scan 2: cal_off, stage 3's lists
+        int light_cals = S3_LIGHT_CALS, lds_cals = S3_LDS_CALS;
+        if (const char* e = std::getenv("SK_STAGE3_TEST_LDS_CALS")) {
+            int a = 0, b = 0;
+            if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b >= a && b <= S3_LDS_CALS) {
+                light_cals = a;
+                lds_cals = b;
+            }
+        }
+        sc.count = B.n_uniq.as<int32_t>();
+        sc.off = B.cal_off_z.as<int32_t>();
+        sc.list = B.s3_list.as<int32_t>();
+        sc.light_cals = light_cals;
+        hipLaunchKernelGGL(job_scan_kernel<true>, dim3(1), dim3(1024), 0, st, sc);
+        hipLaunchKernelGGL(rank_kernel, dim3(e2_blocks), dim3(256), 0, st, sa);
+        // L1
+        FlatArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.job = dj;
+        fa.ins_pool = B.ins.as<char>();
+        fa.ref = B.ref.as<char>();
+        fa.ref_offset = in->ref_offset;
+        fa.ref_len = in->ref_len;
+        fa.n_reads = n;
+        fa.n_cals = n_cap;
+        fa.n_cals_on_device = 1;
+        fa.pool = ea.pool;
+        fa.list = B.sorted.as<int32_t>();
+        fa.status = ea.status;
+        fa.read_off = B.read_off.as<int64_t>();
+        fa.read_code = B.read_code.as<uint8_t>();
+        fa.cal_off = B.cal_off_z.as<int32_t>();
+        fa.win_begin = B.win_begin.as<int32_t>();
+        fa.win_len = B.win_len.as<int32_t>();
+        fa.hap_len = B.hap_len.as<int32_t>();
+        fa.n_ins = B.n_ins.as<int32_t>();
+        fa.ins_idx = B.ins_idx.as<int16_t>();
+        fa.ins_off = B.ins_off.as<int32_t>();
+        fa.win_end = B.win_end.as<int32_t>();
+        fa.ins_lo = B.ins_lo.as<int32_t>();
+        fa.ins_hi = B.ins_hi.as<int32_t>();
+        fa.n_seg8 = B.n_seg8.as<uint8_t>();
+        fa.max_read_len = in->max_read_len;
+        hipLaunchKernelGGL(pool_bounds_kernel, dim3(e2_blocks), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL(pool_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
+        // F5
+        FusedScoreArgs fs;
+        fs.f = fa;
+        fs.read_qual = B.read_qual.as<uint8_t>();
+        fs.tab = ctx.dev_tables;
+        fs.scores = B.scores.as<double>();
+        fs.err = ctx.dev_error_flags;
+        fs.n_unhandled = n_unhandled;
+        fs.write_cals = 0;
+        fs.dbg = nullptr;
+        launch_flatten_score(n, st, fs);
+        // S3: a block per read of the job in either launch; the blocks past a list's length leave at once
+        Stage3Args s3;
+        s3.tab.tab = dj.tab;
+        s3.tab.r2i = B.r2i.as<double>();
+        s3.tab.i2r = B.i2r.as<double>();
+        s3.tab.orig = B.orig.as<int32_t>();
+        s3.tab.n_tab = in->n_tab;
+        s3.tab.max_indel_size = in->max_indel_size;
+        s3.tab.consulted = dj.consulted;
+        s3.opt = in->stage3_opt;
+        s3.n_reads = n;
+        s3.status = ea.status;
+        s3.cal_off = fa.cal_off;
+        s3.cals = fa.pool;
+        s3.slot = fa.list;
+        s3.scores = B.scores.as<double>();
+        s3.read_off = fa.read_off;
+        s3.read_code = fa.read_code;
+        s3.map_level = B.map_level.as<int32_t>();
+        s3.order = B.s3_order.as<int32_t>();
+        s3.smooth = B.s3_smooth.as<double>();
+        s3.flag = B.s3_flag.as<uint8_t>();
+        s3.rm_type = B.s3_rm_type.as<uint8_t>();
+        s3.rm_pos = B.s3_rm_pos.as<int32_t>();
+        s3.key = B.s3_key.as<uint32_t>();
+        s3.sorted_score = B.s3_sorted_score.as<double>();
+        s3.sorted_hash = B.s3_sorted_hash.as<uint32_t>();
+        s3.next_same = B.s3_next_same.as<int32_t>();
+        s3.removed = B.s3_removed.as<uint8_t>();
+        s3.range_end = B.s3_range_end.as<int32_t>();
+        s3.out = B.s3_out.as<sk3::Out>();
+        s3.skip_if = n_unhandled;
+        auto lds_bytes = [](const int cals) { return size_t(cals) * (8 + 8 + 4 + 4 + 4 + 4 + 1 + 1) + 8; };
+        s3.list = B.s3_list.as<int32_t>();
+        s3.n_list = dyn + DYN_N_LIGHT;
+        s3.list_step = 1;
+        s3.lds_cals = light_cals;
+        hipLaunchKernelGGL(stage3_kernel<1>, dim3(n), dim3(64), lds_bytes(light_cals), st, s3);
+        s3.list = B.s3_list.as<int32_t>() + (n - 1);
+        s3.n_list = dyn + DYN_N_HEAVY;
+        s3.list_step = -1;
+        s3.lds_cals = lds_cals; // (the largest read of the list is not known here: LDS for the most a block holds)
+        hipLaunchKernelGGL(stage3_kernel<4>, dim3(n), dim3(256), lds_bytes(lds_cals), st, s3);
+        SK_HIP(hipGetLastError());
+        // the results: the zero arena whole (counters + the scans' numbers, warn, n_raw, status, ..., consulted, cal_off) and stage 3's records
+        SK_HIP(hipMemcpyAsync(B.h_zero_arena.p, B.zero_arena.p, zero_bytes, hipMemcpyDeviceToHost, st));
+        D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
+        SK_HIP(hipStreamSynchronize(st));
+        lap("one sequence");
+        const int32_t* h_counters = B.h_counters.as<int32_t>();
+        if (h_dyn[DYN_FLAGS] != 0 || h_counters[Caps::K + 7] > 0) {
+            if (timing) std::fprintf(stderr, "[enum-dev] one sequence: flags %d, reads outside F5's form %d -> the staged chain\n", h_dyn[DYN_FLAGS], h_counters[Caps::K + 7]);
+            *redo = true;
+            return 0;
+        }
+        ++g_jobs_one_wait;
+        {
+            uint8_t* w8 = reinterpret_cast<uint8_t*>(B.h_warn.p);
+            const int32_t* w32 = B.h_warn.as<int32_t>();
+            for (int r = 0; r < n; ++r) w8[r] = uint8_t(w32[r]);
+            out->warn = w8;
+        }
+        std::memcpy(h_cal_off, B.h_cal_off_z.p, 4 * size_t(n + 1));
+        const int32_t n_cals = h_cal_off[n];
+        g_n_cals = n_cals;
+        g_cals_pool = fa.pool;
+        g_cals_list = fa.list;
+        g_scores = B.scores.as<double>();
+        out->cals = nullptr;   // (in the pool: sk_enum_device_fetch_cals)
+        out->scores = nullptr; // (on the device: sk_enum_device_fetch_scores -- the host needs them only for a read stage 3 turned down)
+        out->stage3 = B.h_s3_out.as<sk3::Out>();
+        g_last.fused = true;
+        g_last.fs = fs;
+        g_last.fs.f.n_cals = n_cals;
+        g_last.n = n;
+        g_last.n_cals = n_cals;
+        g_last.scores = B.scores.as<double>();
+        g_last.cells = 0;
+        for (int r = 0; r < n; ++r) g_last.cells += (in->read_off[r + 1] - in->read_off[r]) * int64_t(h_cal_off[r + 1] - h_cal_off[r]);
+        g_last.valid = true;
+        if (timing) std::fprintf(stderr, "[enum-dev] one sequence: %d reads, %d levels launched, %d leaves, %d candidate alignments, stage 3 lists %d + %d\n", n, n_levels,
+                                 h_counters[Caps::K + 3], n_cals, h_dyn[DYN_N_LIGHT], h_dyn[DYN_N_HEAVY]);
+        return 0;
+    }
+    ++g_jobs_staged;
     {
         PFrame* buf[2] = { B.level_a.as<PFrame>(), B.level_b.as<PFrame>() };
         ea.level_in = nullptr;
@@ -2037,6 +2434,7 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
     sa.n_uniq = B.n_uniq.as<int32_t>();
     sa.cal_off = B.cal_off.as<int32_t>();
     sa.sorted = B.sorted.as<int32_t>();
+    sa.n_leaves_dev = nullptr;
     SK_HIP(hipMemcpyAsync(B.raw_off.p, h_raw_off, 4 * size_t(n + 1), hipMemcpyHostToDevice, st));
     if (n_grouped > 0) {
         hipLaunchKernelGGL(group_kernel, dim3((n_leaves + 255) / 256), dim3(256), 0, st, sa);
@@ -2156,6 +2554,10 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
             s3.removed = B.s3_removed.as<uint8_t>();
             s3.range_end = B.s3_range_end.as<int32_t>();
             s3.out = B.s3_out.as<sk3::Out>();
+            s3.n_list = nullptr;
+            s3.list_step = 1;
+            // (F5 counts the reads it turns down: stage 3 then has nothing to work on -- the staged chain scores the job and calls this again)
+            s3.skip_if = cals_in_set_order ? nullptr : (B.counters.as<int32_t>() + (Caps::K + 7));
             // two launches: reads with few candidate alignments (small LDS, many wavefronts per CU) and the others
             RES(s3_list, 4 * size_t(n));
             HRES(h_s3_list, 4 * size_t(n));
@@ -2354,6 +2756,24 @@ extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
 #undef H2D
 #undef D2H
     return 0;
+}
+
+// A job with the whole read path on the device (scores + stage 3) and F5 enabled runs as one fixed sequence with one wait; a job for
+// which the sequence's assumptions do not hold (reported by the device with the results), one too large for capacity-sized buffers, and
+// a caller that wants the alignments or the scores on the host run the staged way (a wait after the search, one after the sets, one at
+// the end).  $SK_ENUM_ONE_WAIT = 0 pins the staged way (tests run both).
+extern "C" int sk_enum_device_run(const SkEnumInput* in, SkEnumOutput* out)
+{
+    const bool enabled = !(std::getenv("SK_ENUM_ONE_WAIT") != nullptr && std::strcmp(std::getenv("SK_ENUM_ONE_WAIT"), "0") == 0);
+    const bool fused_enabled = !(std::getenv("SK_A5_FUSED") != nullptr && std::strcmp(std::getenv("SK_A5_FUSED"), "0") == 0);
+    bool redo = false;
+    if (enabled && fused_enabled && in && in->want_scores && in->want_stage3 && in->n_reads > 0 && in->n_reads <= ONE_WAIT_MAX_READS &&
+        in->max_read_len <= F5_MAX_READ) {
+        const int rc = enum_device_run_impl(in, out, true, &redo);
+        if (rc != 0 || !redo) return rc;
+        ++g_jobs_one_wait_redone;
+    }
+    return enum_device_run_impl(in, out, false, &redo);
 }
 
 // Measurement entry (bench.py's a5 leg): flattening AND scoring of the candidate alignments the last run left on the device, the way

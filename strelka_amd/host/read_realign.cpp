@@ -1965,6 +1965,11 @@ int sk_realign_job_rescore(const int32_t reps, float* out_ms, int32_t* out_n_rea
     return sk_enum_device_rescore(reps, out_ms, out_n_reads, out_n_cals, out_cells);
 }
 
+void sk_realign_device_job_counts(int64_t* n_one_wait, int64_t* n_one_wait_redone, int64_t* n_staged)
+{
+    sk_enum_device_job_counts(n_one_wait, n_one_wait_redone, n_staged);
+}
+
 int sk_realign_job_enumeration_counts(const sk_realign_job* j, int64_t* n_core, int64_t* n_device, int64_t* n_fallback)
 {
     if (!j) return 1;
@@ -2411,7 +2416,10 @@ static void resolve_pending(sk_realign_job& j, const bool want_scores)
         if (out.consulted[i]) (void)j.cand(int(i));
     const int32_t n_cals = out.cal_off[idx.size()];
     j.dev_scores.clear();
-    if (want_scores && n_cals > 0) j.dev_scores.assign(out.scores, out.scores + n_cals);
+    if (want_scores && n_cals > 0) {
+        if (out.scores) j.dev_scores.assign(out.scores, out.scores + n_cals);
+        else j.dev_scores.assign(size_t(n_cals), 0.0); // (the job ran as one sequence: a read's scores are fetched below if the host needs them)
+    }
     j.dev_generation = out.generation;
     // reads the device enumerated but did not finish (a capacity of stage 3): their candidate alignments come over now
     std::vector<std::vector<skcore::PCal>> unfinished(idx.size());
@@ -2421,6 +2429,9 @@ static void resolve_pending(sk_realign_job& j, const bool want_scores)
                 unfinished[k].resize(size_t(out.cal_off[k + 1] - out.cal_off[k]));
                 if (sk_enum_device_fetch_cals(out.generation, out.cal_off[k], int32_t(unfinished[k].size()), unfinished[k].data()))
                     throw Fail(std::string("device enumeration: candidate alignments not available: ") + sk_last_error());
+                if (want_scores && !out.scores &&
+                    sk_enum_device_fetch_scores(out.generation, out.cal_off[k], int32_t(unfinished[k].size()), j.dev_scores.data() + out.cal_off[k]))
+                    throw Fail(std::string("device enumeration: scores not available: ") + sk_last_error());
             }
     // device results -> the reads' structures (reads are independent: each slice of the loop touches only its own reads)
     const std::string err = parallel_for(idx.size(), host_threads(j, idx.size()), [&](const size_t k) {

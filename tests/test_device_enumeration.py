@@ -79,24 +79,41 @@ def test_host_core_reproduces_the_live_reference(seed, max_indels, hap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chain", ["fused", "staged"])
+@pytest.mark.parametrize("chain", ["fused", "fused_three_waits", "staged", "fused_too_few_levels"])
 def test_device_enumeration_reproduces_the_reference_golden(gold, monkeypatch, chain):
     """chain: flattening + scoring as F5 (flatten_score_kernel: the records -> the scores in one launch, the default) or as the staged
-    chain F1-F3 + A1c ($SK_A5_FUSED=0; also what a job with a read outside F5's form takes)"""
+    chain F1-F3 + A1c ($SK_A5_FUSED=0; also what a job with a read outside F5's form takes).  With F5 a job is ONE fixed sequence of
+    launches and one host wait (the default; job_scan_kernel makes the prefix sums between the stages on the device) or the sequence with
+    a wait after the search, the sets and stage 3 ($SK_ENUM_ONE_WAIT=0); with too few search levels launched the device reports it and
+    the job runs again the other way -- the same records from all of them."""
     capi.init(0)
-    monkeypatch.setenv("SK_A5_FUSED", "1" if chain == "fused" else "0")
+    monkeypatch.setenv("SK_A5_FUSED", "0" if chain == "staged" else "1")
+    monkeypatch.setenv("SK_ENUM_ONE_WAIT", "0" if chain == "fused_three_waits" else "1")
+    if chain == "fused_too_few_levels":
+        monkeypatch.setenv("SK_ENUM_TEST_LEVELS", "2")
+    before = capi.RealignJob.device_job_counts()
     reads, core, dev, fb = _run(gold["scenarios"], gold["expect"], mode=2, on_gpu=True)
+    one_wait, redone, staged = (b - a for a, b in zip(before, capi.RealignJob.device_job_counts()))
     assert reads > 400 and dev > 200 and core == 0
     assert fb <= dev // 50
     assert _run.stage3[1] >= dev * 0.95  # and stage 3 of those reads ran on the device as well (stage3_kernel)
+    if chain == "fused":
+        assert one_wait > 0 and redone <= one_wait // 10 and staged == redone
+    elif chain == "fused_too_few_levels":
+        assert redone > 0 and staged == redone
+    else:
+        assert one_wait == 0 and redone == 0 and staged > 0
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("one_wait", ["1", "0"])
 @pytest.mark.parametrize("caps", ["4,12", "16,64"])
-def test_device_stage3_launch_shapes(gold, monkeypatch, caps):
+def test_device_stage3_launch_shapes(gold, monkeypatch, caps, one_wait):
     """stage3_kernel keeps a read's per-alignment arrays in LDS when they fit (two launches: few / many candidate alignments) and
-    in HBM otherwise; with tiny capacities the golden scenarios go through all three"""
+    in HBM otherwise; with tiny capacities the golden scenarios go through all three -- the lists of the two launches made by the host
+    (three waits) and by the device (one sequence)"""
     capi.init(0)
+    monkeypatch.setenv("SK_ENUM_ONE_WAIT", one_wait)
     monkeypatch.setenv("SK_STAGE3_TEST_LDS_CALS", caps)
     reads, core, dev, fb = _run(gold["scenarios"], gold["expect"], mode=2, on_gpu=True)
     assert reads > 400 and _run.stage3[1] >= dev * 0.95
@@ -111,10 +128,12 @@ def test_device_stage3_without_the_conflict_tables(gold, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,max_indels,hap,chain", [(41, 6, 0.25, "fused"), (42, 12, 0.6, "fused"), (43, 12, 0.0, "fused"), (42, 12, 0.6, "staged")])
+@pytest.mark.parametrize("seed,max_indels,hap,chain", [(41, 6, 0.25, "fused"), (42, 12, 0.6, "fused"), (43, 12, 0.0, "fused"), (42, 12, 0.6, "staged"),
+                                                       (44, 12, 0.4, "fused_three_waits")])
 def test_device_enumeration_equals_host(seed, max_indels, hap, chain, monkeypatch):
     capi.init(0)
-    monkeypatch.setenv("SK_A5_FUSED", "1" if chain == "fused" else "0")
+    monkeypatch.setenv("SK_A5_FUSED", "0" if chain == "staged" else "1")
+    monkeypatch.setenv("SK_ENUM_ONE_WAIT", "0" if chain == "fused_three_waits" else "1")
     rng = np.random.default_rng(91000 + seed)
     scs = synth.realign_scenarios(80, rng, reads_per=12, max_indels=max_indels, haplotyping_rate=hap)
     n_dev = n_s3 = 0
@@ -183,6 +202,7 @@ def test_fused_flatten_score_on_long_reads_and_mixed_jobs():
     rng = np.random.default_rng(91444)
     scs = synth.realign_scenarios(40, rng, reads_per=10, max_indels=9, min_indels=4, read_len=(120, 261), window=(330, 520), haplotyping_rate=0.2)
     n_dev = n_cals = n_long_jobs = 0
+    before = capi.RealignJob.device_job_counts()
     for sc in scs:
         res = {}
         for mode in (0, 2):
@@ -202,6 +222,9 @@ def test_fused_flatten_score_on_long_reads_and_mixed_jobs():
                 assert repr(a) == repr(b)
                 n_cals += a["n_cals"]
     assert n_dev > 150 and n_cals > 64 * n_dev // 4 and 0 < n_long_jobs < len(scs)
+    # the jobs without a long read ran as one sequence; those with one went the staged way at once (the host knows the read lengths)
+    one_wait, redone, staged = (b - a for a, b in zip(before, capi.RealignJob.device_job_counts()))
+    assert one_wait > 0 and staged >= n_long_jobs
 
 
 @pytest.mark.gpu

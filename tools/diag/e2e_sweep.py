@@ -24,6 +24,7 @@ ENV_SETS = [
     ("staged_chain", {"SK_A5_FUSED": "0"}),
     ("min_reads_1", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1"}),
     ("min_reads_32", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "32"}),
+    ("min_reads_1_three_waits", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1", "SK_ENUM_ONE_WAIT": "0"}),
 ]
 if os.environ.get("SK_SWEEP_ONLY"):  # a comma-separated choice of the settings above
     ENV_SETS = [s for s in ENV_SETS if s[0] in os.environ["SK_SWEEP_ONLY"].split(",")]
@@ -72,6 +73,7 @@ def main():
         row = {"name": name, "env": env, "wall_s": res.wall_s, "process_seconds_sum": sum(res.process_s), "identical": same,
                "speedup": ref.wall_s / res.wall_s, "realign_jobs": counters.get("realign_jobs"), "realign_job_reads": counters.get("realign_job_reads"),
                "enum_device_reads": counters.get("enum_device_reads"), "enum_host_instead": counters.get("enum_host_instead"),
+               "enum_jobs": {k[len("enum_jobs_"):]: v for k, v in counters.items() if k.startswith("enum_jobs_")},
                "device_share": (counters.get("enum_device_reads", 0) / max(1, counters.get("realign_job_reads", 1))), "hook_seconds": hooks}
         report["runs"].append(row)
         print(json.dumps(row), flush=True)

@@ -93,6 +93,8 @@ for step in "$@"; do
     feed)
       timeout 600 python -m pytest tests/test_bam_feed.py -m gpu -x -q > $OUT/pytest_feed.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_feed.log; tail -4 $OUT/pytest_feed.log
       timeout 300 python bench.py --only feed_slice --steps 8 --warmup 2 > $OUT/feed_slice.json 2>$OUT/feed_slice.err; echo "feed_slice rc=$?"; cat $OUT/feed_slice.json; tail -3 $OUT/feed_slice.err ;;
+    sweep)  # $SK_SWEEP_ONLY = names of tools/diag/e2e_sweep.py's settings, $SWEEP_ARGS = "bp segment_bp procs"
+      timeout 1500 python tools/diag/e2e_sweep.py $OUT/e2e_sweep.json ${SWEEP_ARGS:-32000000 4000000 8} > $OUT/e2e_sweep.log 2>&1; echo "sweep rc=$?"; tail -c 3000 $OUT/e2e_sweep.log ;;
     loci)
       timeout 300 python bench.py --only loci --steps 5 --warmup 2 > $OUT/loci.json 2>$OUT/loci.err; cat $OUT/loci.json ;;
     *) echo "unknown step $step" ;;
