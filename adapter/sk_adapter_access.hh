@@ -175,6 +175,7 @@ struct State
     unsigned long indelGroupsWide = 0; ///< allele groups with more alternate alleles than SK_MAX_ALT (sk_allele_group_genotype_lhoods_wide)
     unsigned long realignJobReads = 0; ///< reads that went into a realignment job (realignReads counts every read a window looked at)
     unsigned long realignDeviceEnumerated = 0, realignHostEnumerated = 0; // reads whose candidate alignments the device / the host listed
+    unsigned long realignRefWindowMisses = 0; // jobs run a second time with the whole contig segment as their reference
     unsigned long realignHostJobs = 0; // jobs whose search ran as the host statement (below the device threshold, or $SK_ENUMERATION)
     unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0, haplotypeBatches = 0;
 };

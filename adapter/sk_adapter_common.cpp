@@ -98,7 +98,7 @@ State& make_state()
                 int64_t oneWait(0), redone(0), staged(0);
                 sk_realign_device_job_counts(&oneWait, &redone, &staged);
                 std::cerr << " enum_jobs_one_wait=" << oneWait << " enum_jobs_redone=" << redone << " enum_jobs_staged=" << staged
-                          << " enum_jobs_host=" << s.realignHostJobs << "\n";
+                          << " enum_jobs_host=" << s.realignHostJobs << " realign_ref_window_misses=" << s.realignRefWindowMisses << "\n";
             }
             std::cerr << "strelka_amd adapter pileup: pushes=" << s.pileupBatches << " reads=" << s.pileupReads << " loci=" << s.pileupLoci
                       << " genotyping=" << (s.pileup.isGenotyping ? 1 : 0) << "\n";

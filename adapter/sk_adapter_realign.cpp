@@ -232,20 +232,48 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
     {
         sk_realign_job* job;
         ~JobHolder() { if (job) sk_realign_job_destroy(job); }
-    } holder{sk_realign_job_create(&ro)};
-    sk_realign_job* job(holder.job);
-    if (job == nullptr) throw blt_exception("strelka_amd adapter: sk_realign_job_create failed");
+        void reset(sk_realign_job* j) { if (job) sk_realign_job_destroy(job); job = j; }
+    } holder{nullptr};
+    sk_realign_job* job(nullptr);
 
     auto jobCheck = [&](const int rc, const char* what)
     {
         if (rc == 0) return;
         throw blt_exception((std::string("strelka_amd: ") + what + ": " + sk_realign_job_error(job)).c_str());
     };
-    jobCheck(sk_realign_job_set_reference(job, ref.seq().data(), static_cast<int32_t>(ref.get_offset()),
-                                          static_cast<int32_t>(ref.seq().size())), "sk_realign_job_set_reference");
+    // The job keeps a copy of its reference (and uploads it): of the contig segment -- megabases -- it gets the WINDOW its reads can
+    // reach, the union of their realignment ranges and alignment zones plus a margin.  Whether that was enough is not argued but
+    // counted: the library counts every reference base a job reads outside what it was given (such a base reads as 'N'); if the count
+    // moved with a window narrower than the segment, the job runs again with the whole segment (realign_ref_window_misses).
+    const pos_t segBegin(static_cast<pos_t>(ref.get_offset())), segEnd(segBegin + static_cast<pos_t>(ref.seq().size()));
+    pos_t winBegin(segBegin), winEnd(segEnd);
+    {
+        static const bool isWholeSegment([]() { const char* v(std::getenv("STRELKA_AMD_REALIGN_WHOLE_REFERENCE")); return v && *v && *v != '0'; }());
+        if (! isWholeSegment)
+        {
+            pos_t lo(reads.front().rangeBegin), hi(reads.front().rangeEnd);
+            for (const WindowRead& wr : reads)
+            {
+                lo = std::min(lo, std::min(wr.rangeBegin, wr.zoneBegin));
+                hi = std::max(hi, std::max(wr.rangeEnd, wr.zoneEnd));
+            }
+            const pos_t margin(static_cast<pos_t>(opt.maxIndelSize) + 64);
+            winBegin = std::max(segBegin, lo - margin);
+            winEnd = std::min(segEnd, hi + margin);
+            if (winEnd < winBegin) winEnd = winBegin;
+        }
+    }
+    std::vector<sk_read_input> inputs(reads.size());
+    for (int attempt(0); attempt < 2; ++attempt)
+    {
+    holder.reset(sk_realign_job_create(&ro));
+    job = holder.job;
+    if (job == nullptr) throw blt_exception("strelka_amd adapter: sk_realign_job_create failed");
+    const int64_t outsideBefore(sk_realign_reference_reads_outside());
+    jobCheck(sk_realign_job_set_reference(job, ref.seq().data() + (winBegin - segBegin), static_cast<int32_t>(winBegin),
+                                          static_cast<int32_t>(winEnd - winBegin)), "sk_realign_job_set_reference");
     jobCheck(sk_realign_job_set_indels(job, table.data(), static_cast<int32_t>(table.size())), "sk_realign_job_set_indels");
 
-    std::vector<sk_read_input> inputs(reads.size());
     for (size_t i(0); i < reads.size(); ++i)
     {
         const WindowRead& wr(reads[i]);
@@ -274,6 +302,12 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
             jobCheck(1, "sk_realign_job_add_reads");
         }
         jobCheck(sk_realign_job_run(job), "sk_realign_job_run");
+    }
+    if (sk_realign_reference_reads_outside() == outsideBefore || (winBegin == segBegin && winEnd == segEnd)) break;
+    // a read reached past the window (or past the segment's own end, where the reference reads 'N' as well): once more, whole segment
+    s.realignRefWindowMisses++;
+    winBegin = segBegin;
+    winEnd = segEnd;
     }
     s.realignBatches++;
     s.realignJobReads += reads.size();

@@ -355,6 +355,12 @@ int sk_realign_job_enumeration_counts(const sk_realign_job* job, int64_t* n_core
  *  because the device reported that an assumption of the sequence did not hold (deeper search levels than launched, a full leaf pool, a
  *  read outside F5's form); run the staged way (three waits) from the start. */
 void sk_realign_device_job_counts(int64_t* n_one_wait, int64_t* n_one_wait_redone, int64_t* n_staged);
+/** How many reference bases the realignment jobs of this process have read OUTSIDE the segment given to sk_realign_job_set_reference
+ *  (such a position reads as 'N', reference_contig_segment::get_base, L/blt_util/reference_contig_segment.hh:46-51), host stages and
+ *  kernels together, since the process started.  A caller whose contig segment is megabases long hands a job the WINDOW of it that the
+ *  job's reads can reach (the job copies its reference: 12 MB per job otherwise) and takes the difference of this number around the job: if
+ *  it moved and the window was not the whole segment, the window was too narrow and the job is run again with the whole segment. */
+int64_t sk_realign_reference_reads_outside(void);
 /** How many reads had stage 3 (scoreCandidateAlignments' selection, finishRealignment and score_indels, L/starling_common/
  *  starling_read_align.cpp:1534-1741 and starling_read_align_score_indels.cpp:455-1079) run in its container-free form on the
  *  host (enumeration == 1) and on the device (== 2); the rest went through the container-based code. */

@@ -209,7 +209,7 @@ EXPORTS = [
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
     "sk_realign_job_finish", "sk_realign_job_run", "sk_realign_job_n_reads", "sk_realign_job_read_result",
-    "sk_realign_job_clear_reads", "sk_realign_job_rescore", "sk_realign_job_indels_consulted", "sk_realign_job_enumeration_counts", "sk_realign_device_job_counts", "sk_realign_job_stage3_counts", "sk_make_start_pos_alignment", "sk_get_end_pin_start_pos",
+    "sk_realign_job_clear_reads", "sk_realign_job_rescore", "sk_realign_job_indels_consulted", "sk_realign_job_enumeration_counts", "sk_realign_device_job_counts", "sk_realign_reference_reads_outside", "sk_realign_job_stage3_counts", "sk_make_start_pos_alignment", "sk_get_end_pin_start_pos",
     "sk_germline_options_default", "sk_dependent_eprob", "sk_dependent_eprob_dev", "sk_site_digt_call",
     "sk_site_digt_call_dev", "sk_site_digt_call_fused", "sk_site_digt_call_fused_dev",
     "sk_somatic_snv_options_default", "sk_somatic_snv_call_batch", "sk_somatic_snv_call_batch_dev",
@@ -261,6 +261,8 @@ def lib():
         L.sk_realign_job_enumeration_counts.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
         L.sk_realign_device_job_counts.argtypes = [c_void_p, c_void_p, c_void_p]
         L.sk_realign_device_job_counts.restype = None
+        L.sk_realign_reference_reads_outside.argtypes = []
+        L.sk_realign_reference_reads_outside.restype = C.c_int64
         L.sk_realign_job_stage3_counts.argtypes = [c_void_p, c_void_p, c_void_p]
         L.sk_realign_job_indels_consulted.argtypes = [c_void_p, c_void_p, C.c_int32]
         L.sk_realign_job_error.restype = C.c_char_p

@@ -48,6 +48,7 @@ struct SkEnumOutput // host arrays owned by the pipeline, valid until its next r
     const double* scores;      // [cal_off[n_reads]]; null without want_scores, and null when the job ran as one fixed sequence: the scores stay on
                                // the device (sk_enum_device_fetch_scores) -- the host reads them only for a read stage 3 turned down
     const uint8_t* consulted;  // [n_tab] candidate status consulted by the search, the flattening or stage 3
+    int64_t ref_reads_outside; // reference reads of the flattening that fell outside [ref_offset, ref_offset + ref_len) (read as 'N')
     const sk3::Out* stage3;    // [n_reads] or null; stage3[r].status != S3_OK (or status[r] != ST_OK): stage 3 of the read is the host's
 };
 

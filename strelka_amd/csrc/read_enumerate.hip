@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void rank_kernel(const SetArgs a)
 // the host derived from them: the totals, stage 3's two read lists, and the conditions under which the sequence's assumptions do not
 // hold (then the host runs the job again the staged way: sk_enum_device_run).
 
-enum { DYN_N_GROUPED = 0, DYN_N_CALS, DYN_N_LIGHT, DYN_N_HEAVY, DYN_FLAGS, DYN_MAX_CALS, DYN_COUNT = 8 };
+enum { DYN_N_GROUPED = 0, DYN_N_CALS, DYN_N_LIGHT, DYN_N_HEAVY, DYN_FLAGS, DYN_MAX_CALS, DYN_REF_OUTSIDE, DYN_COUNT = 8 };
 enum { DYNF_DEEPER = 1,    // calls were left at the first level the sequence did not launch
        DYNF_POOL_FULL = 2 }; // more leaves than the sequence's pool holds
 
@@ -442,6 +442,7 @@ struct FlatArgs
     uint8_t* colmat; // (bytes of the words; pre-filled with the 0.0 column)
     const int64_t* colmat_off;
     uint32_t* addmask;
+    int32_t* ref_outside;     // counts the window bytes that lie outside the job's reference segment (they read as N)
     int32_t n_cals_on_device; // the job runs as one fixed sequence: the number of candidate alignments is cal_off[n_reads], the host has not seen it
 };
 enum { INS_CAP = Caps::K + 2 };
@@ -714,7 +715,9 @@ __global__ __launch_bounds__(64) void pool_fill_kernel(const FlatArgs a)
         uint8_t v = SK_BAM_ANY;
         if (i < win_len) {
             const int32_t p = wb + i; // reference_contig_segment::get_base :46-51
-            v = (p < a.ref_offset || p >= a.ref_offset + a.ref_len) ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
+            const bool outside = (p < a.ref_offset || p >= a.ref_offset + a.ref_len);
+            if (outside && a.ref_outside) atomicAdd(a.ref_outside, 1);
+            v = outside ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
         }
         for (int k = 0; k < n_ins; ++k) {
             const PIndel& d = a.job.tab[idx[k]];
@@ -1047,7 +1050,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             uint8_t v = SK_BAM_ANY;
             if (i < win_len) {
                 const int32_t p = win_begin + i; // reference_contig_segment::get_base :46-51
-                v = (p < a.ref_offset || p >= a.ref_offset + a.ref_len) ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
+                const bool outside = (p < a.ref_offset || p >= a.ref_offset + a.ref_len);
+                if (outside && a.ref_outside) atomicAdd(a.ref_outside, 1);
+                v = outside ? uint8_t(SK_BAM_ANY) : code_of(a.ref[p - a.ref_offset]);
             }
             S.hap[i] = v;
         }
@@ -1927,6 +1932,17 @@ namespace
 // statistics of the process: jobs run as one fixed sequence (one wait), and those of them the host ran again the staged way because
 // an assumption of the sequence did not hold (deeper levels than launched, a full leaf pool, a read outside F5's form)
 int64_t g_jobs_one_wait = 0, g_jobs_one_wait_redone = 0, g_jobs_staged = 0;
+// diagnostics ($SK_ENUM_JOB_SECONDS): where a one-sequence job's wall time goes -- buffers + packing, submissions, the wait -- on stderr at exit
+struct JobSeconds
+{
+    double setup = 0, submit = 0, wait = 0, after = 0;
+    ~JobSeconds()
+    {
+        if (std::getenv("SK_ENUM_JOB_SECONDS"))
+            std::fprintf(stderr, "strelka_amd enum job seconds: jobs=%lld setup=%.4f submit=%.4f wait=%.4f after=%.4f\n", (long long)g_jobs_one_wait, setup, submit,
+                         wait, after);
+    }
+} g_job_seconds;
 }
 extern "C" void sk_enum_device_job_counts(int64_t* one_wait, int64_t* one_wait_redone, int64_t* staged)
 {
@@ -2122,6 +2138,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
     ea.warn = B.warn.as<int32_t>();
     ea.min_cells_a = ea.min_cells_b = ea.max_cells_a = ea.max_cells_b = nullptr;
     lap("H2D");
+    const auto t_setup = std::chrono::steady_clock::now();
     if (one_wait) {
         // ---- the job as one fixed sequence: ~20 submissions, no host decision between them, ONE wait.  Everything the host used to
         // compute between waits is computed by job_scan_kernel; every buffer is sized by a capacity known now; launches whose size the
@@ -2258,6 +2275,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         fa.ins_hi = B.ins_hi.as<int32_t>();
         fa.n_seg8 = B.n_seg8.as<uint8_t>();
         fa.max_read_len = in->max_read_len;
+        fa.ref_outside = dyn + DYN_REF_OUTSIDE;
         hipLaunchKernelGGL(pool_bounds_kernel, dim3(e2_blocks), dim3(256), 0, st, fa);
         hipLaunchKernelGGL(pool_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
         // F5
@@ -2318,7 +2336,12 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         // the results: the zero arena whole (counters + the scans' numbers, warn, n_raw, status, ..., consulted, cal_off) and stage 3's records
         SK_HIP(hipMemcpyAsync(B.h_zero_arena.p, B.zero_arena.p, zero_bytes, hipMemcpyDeviceToHost, st));
         D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
+        const auto t_submitted = std::chrono::steady_clock::now();
         SK_HIP(hipStreamSynchronize(st));
+        const auto t_waited = std::chrono::steady_clock::now();
+        g_job_seconds.setup += std::chrono::duration<double>(t_setup - t_begin).count();
+        g_job_seconds.submit += std::chrono::duration<double>(t_submitted - t_setup).count();
+        g_job_seconds.wait += std::chrono::duration<double>(t_waited - t_submitted).count();
         lap("one sequence");
         const int32_t* h_counters = B.h_counters.as<int32_t>();
         if (h_dyn[DYN_FLAGS] != 0 || h_counters[Caps::K + 7] > 0) {
@@ -2342,9 +2365,11 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         out->cals = nullptr;   // (in the pool: sk_enum_device_fetch_cals)
         out->scores = nullptr; // (on the device: sk_enum_device_fetch_scores -- the host needs them only for a read stage 3 turned down)
         out->stage3 = B.h_s3_out.as<sk3::Out>();
+        out->ref_reads_outside = h_dyn[DYN_REF_OUTSIDE];
         g_last.fused = true;
         g_last.fs = fs;
         g_last.fs.f.n_cals = n_cals;
+        g_last.fs.f.ref_outside = nullptr; // (a repeat for the clock counts nothing)
         g_last.n = n;
         g_last.n_cals = n_cals;
         g_last.scores = B.scores.as<double>();
@@ -2485,6 +2510,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
     fa.ins_hi = B.ins_hi.as<int32_t>();
     RES(n_seg8, size_t(n_cals));
     fa.n_seg8 = B.n_seg8.as<uint8_t>();
+    fa.ref_outside = B.counters.as<int32_t>() + (Caps::K + 8 + DYN_REF_OUTSIDE);
     // (byte patterns: 0x7f7f7f7f is large enough to stand for "no lower bound yet", 0x80808080 is below any position / index)
     SK_HIP(hipMemsetAsync(B.minmax_arena.p, 0x7f, minmax_p[2].off, st));                               // win_begin, ins_lo
     SK_HIP(hipMemsetAsync(static_cast<char*>(B.minmax_arena.p) + minmax_p[2].off, 0x80, minmax_bytes - minmax_p[2].off, st)); // win_end, ins_hi
@@ -2628,6 +2654,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         }
         g_last.fused = true;
         g_last.fs = fs;
+        g_last.fs.f.ref_outside = nullptr; // (a repeat for the clock counts nothing)
         g_last.n = n;
         g_last.n_cals = n_cals;
         g_last.scores = B.scores.as<double>();
@@ -2735,6 +2762,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
                 lap("A1 score");
                 g_last.fused = false;
                 g_last.fa = fa;
+                g_last.fa.ref_outside = nullptr;
                 g_last.d = d;
                 g_last.n = n;
                 g_last.n_cals = n_cals;
@@ -2749,7 +2777,10 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         }
     }
     if (fetch_zero(B.consulted, B.consulted, size_t(in->n_tab))) return 1;
+    if (fetch_zero(B.counters, B.counters, 4 * size_t(n_counters))) return 1;
     SK_HIP(hipStreamSynchronize(st));
+    // (when F5 turned a read down both chains filled the pools: the count may be double -- what matters to the caller is zero or not)
+    out->ref_reads_outside = B.h_counters.as<int32_t>()[Caps::K + 8 + DYN_REF_OUTSIDE];
     lap("done");
 #undef RES
 #undef HRES

@@ -10,6 +10,7 @@
 #include "../csrc/align_entry.h"
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstring>
 #include <string>
@@ -42,6 +43,11 @@ struct Error
 };
 
 } // namespace
+
+// reference reads of the read path that fell outside the segment the caller gave (they read as 'N', reference_contig_segment::get_base):
+// a caller that hands a job a WINDOW of its contig segment learns from this whether the window was wide enough
+// (sk_realign_reference_reads_outside, strelka_amd.h)
+std::atomic<int64_t> g_sk_ref_reads_outside{ 0 };
 
 struct sk_align_builder
 {
@@ -291,8 +297,15 @@ int sk_align_builder_add_read(sk_align_builder* b, const uint8_t* read_code, con
         pool.win_begin = wb;
         pool.win_end = we;
         pool.bytes.resize(size_t(we - wb));
-        for (int32_t p = wb; p < we; ++p) // reference_contig_segment::get_base, :46-51
-            pool.bytes[size_t(p - wb)] = (p < ref_offset || p >= ref_offset + ref_len) ? uint8_t(SK_BAM_ANY) : code_of(ref_seq[p - ref_offset]);
+        {
+            int64_t outside = 0;
+            for (int32_t p = wb; p < we; ++p) { // reference_contig_segment::get_base, :46-51
+                const bool out = (p < ref_offset || p >= ref_offset + ref_len);
+                outside += out ? 1 : 0;
+                pool.bytes[size_t(p - wb)] = out ? uint8_t(SK_BAM_ANY) : code_of(ref_seq[p - ref_offset]);
+            }
+            if (outside) g_sk_ref_reads_outside.fetch_add(outside, std::memory_order_relaxed);
+        }
 
         const size_t ops_mark = b->ops.size(), off_mark = b->op_off.size();
         try {

@@ -421,6 +421,8 @@ struct Cal // CandidateAlignment, L/starling_common/CandidateAlignment.hh:35-78
 
 // =====================================================================================================================
 
+extern std::atomic<int64_t> g_sk_ref_reads_outside; // host/align_flatten.cpp
+
 struct sk_realign_job
 {
     sk_realign_options opt;
@@ -486,7 +488,10 @@ struct sk_realign_job
     const Key& key(int i) const { return tab[i].key; }
     char ref_base(int32_t p) const // reference_contig_segment::get_base :46-51
     {
-        if (p < ref_offset || p >= ref_offset + int32_t(ref.size())) return 'N';
+        if (p < ref_offset || p >= ref_offset + int32_t(ref.size())) {
+            g_sk_ref_reads_outside.fetch_add(1, std::memory_order_relaxed);
+            return 'N';
+        }
         return ref[size_t(p - ref_offset)];
     }
     // IndelBuffer::rangeIterator, IndelBuffer.cpp:76-92
@@ -1965,6 +1970,8 @@ int sk_realign_job_rescore(const int32_t reps, float* out_ms, int32_t* out_n_rea
     return sk_enum_device_rescore(reps, out_ms, out_n_reads, out_n_cals, out_cells);
 }
 
+int64_t sk_realign_reference_reads_outside(void) { return g_sk_ref_reads_outside.load(std::memory_order_relaxed); }
+
 void sk_realign_device_job_counts(int64_t* n_one_wait, int64_t* n_one_wait_redone, int64_t* n_staged)
 {
     sk_enum_device_job_counts(n_one_wait, n_one_wait_redone, n_staged);
@@ -2411,6 +2418,7 @@ static void resolve_pending(sk_realign_job& j, const bool want_scores)
     const bool timing = std::getenv("SK_ENUM_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     if (sk_enum_device_run(&in, &out)) throw Fail(std::string("device enumeration: ") + sk_last_error());
+    if (out.ref_reads_outside > 0) g_sk_ref_reads_outside.fetch_add(out.ref_reads_outside, std::memory_order_relaxed);
     const auto t1 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < j.tab.size(); ++i)
         if (out.consulted[i]) (void)j.cand(int(i));

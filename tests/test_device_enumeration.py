@@ -222,9 +222,10 @@ def test_fused_flatten_score_on_long_reads_and_mixed_jobs():
                 assert repr(a) == repr(b)
                 n_cals += a["n_cals"]
     assert n_dev > 150 and n_cals > 64 * n_dev // 4 and 0 < n_long_jobs < len(scs)
-    # the jobs without a long read ran as one sequence; those with one went the staged way at once (the host knows the read lengths)
+    # the jobs without a long read among those that pass the gate ran as one sequence; those with one went the staged way at once (the host
+    # knows the read lengths), and a pool over F5's 768 bytes is reported by the device: that job runs again (redone)
     one_wait, redone, staged = (b - a for a, b in zip(before, capi.RealignJob.device_job_counts()))
-    assert one_wait > 0 and staged >= n_long_jobs
+    assert one_wait > 0 and 0 < staged <= n_long_jobs + redone and one_wait + staged - redone == len(scs)
 
 
 @pytest.mark.gpu

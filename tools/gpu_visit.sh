@@ -95,6 +95,8 @@ for step in "$@"; do
       timeout 300 python bench.py --only feed_slice --steps 8 --warmup 2 > $OUT/feed_slice.json 2>$OUT/feed_slice.err; echo "feed_slice rc=$?"; cat $OUT/feed_slice.json; tail -3 $OUT/feed_slice.err ;;
     sweep)  # $SK_SWEEP_ONLY = names of tools/diag/e2e_sweep.py's settings, $SWEEP_ARGS = "bp segment_bp procs"
       timeout 1500 python tools/diag/e2e_sweep.py $OUT/e2e_sweep.json ${SWEEP_ARGS:-32000000 4000000 8} > $OUT/e2e_sweep.log 2>&1; echo "sweep rc=$?"; tail -c 3000 $OUT/e2e_sweep.log ;;
+    enum_profile)
+      timeout 900 python tools/diag/enum_job_profile.py $OUT/enum_profile > $OUT/enum_profile.log 2>&1; echo "enum_profile rc=$?"; tail -c 6000 $OUT/enum_profile.log ;;
     loci)
       timeout 300 python bench.py --only loci --steps 5 --warmup 2 > $OUT/loci.json 2>$OUT/loci.err; cat $OUT/loci.json ;;
     *) echo "unknown step $step" ;;
