@@ -341,6 +341,27 @@ struct ScanArgs
     int32_t light_cals;
 };
 
+// The job's way in and out as kernels: the packed input arena is read from the caller's page-locked mirror and the zero arena filled by
+// one launch, the results (the zero arena, stage 3's records) are written to their page-locked mirrors by another.  The copy and fill
+// calls they replace go through the runtime's copy engines, which eight caller processes sharing a GPU queue up for (a job's two copies
+// in cost 0.16 ms of host time there against 0.015 ms alone: profiles/r05_enum_job_history.txt); a launch is a packet in the process's
+// own queue.
+__global__ __launch_bounds__(256) void job_stage_in_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const uint32_t n_in, uint4* __restrict__ zero,
+                                                          const uint32_t n_zero)
+{
+    const uint32_t i0 = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
+    for (uint32_t i = i0; i < n_in; i += step) dst[i] = src[i];
+    const uint4 z = { 0, 0, 0, 0 };
+    for (uint32_t i = i0; i < n_zero; i += step) zero[i] = z;
+}
+__global__ __launch_bounds__(256) void job_stage_out_kernel(const uint4* __restrict__ a, uint4* __restrict__ host_a, const uint32_t n_a, const uint4* __restrict__ b,
+                                                           uint4* __restrict__ host_b, const uint32_t n_b)
+{
+    const uint32_t i0 = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
+    for (uint32_t i = i0; i < n_a; i += step) host_a[i] = a[i];
+    for (uint32_t i = i0; i < n_b; i += step) host_b[i] = b[i];
+}
+
 template <bool SECOND>
 __global__ __launch_bounds__(1024) void job_scan_kernel(const ScanArgs a)
 {
@@ -2093,8 +2114,16 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
     if ((bytes) > 0) SK_HIP(hipMemcpyAsync(B.buf.p, src, size_t(bytes), hipMemcpyHostToDevice, st))
 #define D2H(hbuf, buf, bytes) \
     if ((bytes) > 0) SK_HIP(hipMemcpyAsync(B.hbuf.p, B.buf.p, size_t(bytes), hipMemcpyDeviceToHost, st))
-    if (in_bytes > 0) SK_HIP(hipMemcpyAsync(B.in_arena.p, B.h_in_arena.p, in_bytes, hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemsetAsync(B.zero_arena.p, 0, zero_bytes, st));
+    static const bool stage_by_kernel = !(std::getenv("SK_ENUM_STAGE_COPIES") != nullptr); // ($SK_ENUM_STAGE_COPIES: the copy / fill calls, for A-B runs)
+    if (one_wait && stage_by_kernel) {
+        const uint32_t n_in16 = uint32_t(in_bytes / 16), n_zero16 = uint32_t(zero_bytes / 16); // (pieces sit at 256-byte offsets)
+        const int blocks = int(std::min<size_t>(std::max<size_t>((std::max(in_bytes, zero_bytes) / 16 + 255) / 256, 1), 256));
+        hipLaunchKernelGGL(job_stage_in_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint4*>(B.h_in_arena.p), static_cast<uint4*>(B.in_arena.p), n_in16,
+                           static_cast<uint4*>(B.zero_arena.p), n_zero16);
+    } else {
+        if (in_bytes > 0) SK_HIP(hipMemcpyAsync(B.in_arena.p, B.h_in_arena.p, in_bytes, hipMemcpyHostToDevice, st));
+        SK_HIP(hipMemsetAsync(B.zero_arena.p, 0, zero_bytes, st));
+    }
 
     int32_t* h_cal_off = B.h_cal_off.as<int32_t>();
     h_cal_off[0] = 0;
@@ -2334,8 +2363,17 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         hipLaunchKernelGGL(stage3_kernel<4>, dim3(n), dim3(256), lds_bytes(lds_cals), st, s3);
         SK_HIP(hipGetLastError());
         // the results: the zero arena whole (counters + the scans' numbers, warn, n_raw, status, ..., consulted, cal_off) and stage 3's records
-        SK_HIP(hipMemcpyAsync(B.h_zero_arena.p, B.zero_arena.p, zero_bytes, hipMemcpyDeviceToHost, st));
-        D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
+        if (stage_by_kernel) {
+            const size_t out_bytes = sizeof(sk3::Out) * size_t(n);
+            const uint32_t n_a = uint32_t(zero_bytes / 16), n_b = uint32_t((out_bytes + 15) / 16); // (buffers are reserved with slack)
+            const int blocks = int(std::min<size_t>(std::max<size_t>((std::max(zero_bytes, out_bytes) / 16 + 255) / 256, 1), 256));
+            hipLaunchKernelGGL(job_stage_out_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint4*>(B.zero_arena.p), static_cast<uint4*>(B.h_zero_arena.p), n_a,
+                               static_cast<const uint4*>(B.s3_out.p), static_cast<uint4*>(B.h_s3_out.p), n_b);
+            SK_HIP(hipGetLastError());
+        } else {
+            SK_HIP(hipMemcpyAsync(B.h_zero_arena.p, B.zero_arena.p, zero_bytes, hipMemcpyDeviceToHost, st));
+            D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
+        }
         const auto t_submitted = std::chrono::steady_clock::now();
         SK_HIP(hipStreamSynchronize(st));
         const auto t_waited = std::chrono::steady_clock::now();

@@ -39,6 +39,7 @@ def main():
     report = {}
     for name, grp, jobs in (("eight_processes", groups, 8), ("one_process", groups[:1], 1)):
         for mode, extra in (("device_one_wait", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1"}), ("host", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1000000"}),
+                            ("device_one_wait_copy_calls", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1", "SK_ENUM_STAGE_COPIES": "1"}),
                             ("device_three_waits", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1", "SK_ENUM_ONE_WAIT": "0"})):
             env = dict(extra, STRELKA_AMD_VERBOSE="1", SK_ENUM_JOB_SECONDS="1")
             res = farm.run_farm(grp, argv_fn, os.path.join(root, name + mode), OUTPUTS, jobs=jobs, env=env)
