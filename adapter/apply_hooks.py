@@ -95,7 +95,25 @@ HOOKS = [
     ]),
     (L + "applications/starling/starling_pos_processor.hh", [
         ("friend", r'(struct starling_pos_processor : public starling_pos_processor_base\n\{\n)',
-         '\\1    friend struct sk_adapter::Access;\n'),
+         '\\1    friend struct sk_adapter::Access;\n    friend struct sk_adapter::GvcfAccess;\n'),
+    ]),
+    # site 10: the writer's pipe as the gVCF fast path has to see it (is anything buffered between the caller and the writer?) and
+    # the writer's own skip_to_pos / add_site_internal
+    (L + "applications/starling/gvcf_aggregator.hh", [
+        ("friend + forward declaration", r'class gvcf_aggregator\n\{\n',
+         '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::GvcfAccess;\n'),
+    ]),
+    (L + "applications/starling/gvcf_writer.hh", [
+        ("friend + forward declaration", r'struct gvcf_writer : public variant_pipe_stage_base\n\{\n',
+         '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::GvcfAccess;\n'),
+    ]),
+    (L + "applications/starling/VariantPhaser.hh", [
+        ("friend + forward declaration", r'struct VariantPhaser : public variant_pipe_stage_base\n\{\n',
+         '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::GvcfAccess;\n'),
+    ]),
+    (L + "applications/starling/VariantOverlapResolver.hh", [
+        ("friend + forward declaration", r'struct VariantOverlapResolver : public variant_pipe_stage_base\n\{\n',
+         '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::GvcfAccess;\n'),
     ]),
     (L + "applications/starling/starling_pos_processor.cpp", [
         ("include", r'#include "starling_pos_processor.hh"\n', '\\g<0>#include "sk_adapter.hh"\n'),
@@ -106,6 +124,10 @@ HOOKS = [
         ("germline EVS accumulators",
          r'(            siteSampleInfo\.ReadPosRankSum = pi\.get_read_pos_ranksum\(\);\n)',
          '            sk_adapter::germline_fill_scoring_metrics(sampleIndex, locus.pos, pi);\n\\1'),
+        # site 10: a plain homozygous-reference position goes from the stream's window straight into the writer's open block
+        ("process_pos_snp",
+         r'(starling_pos_processor::\nprocess_pos_snp\(const pos_t pos\)\n\{\n    try\n    \{\n)',
+         '\\1        if (sk_adapter::gvcf_plain_site(*this, pos)) return;\n'),
         # site 3
         ("computeSampleDiploidSiteGenotype call",
          r'computeSampleDiploidSiteGenotype\(\n\s*_opt, _dopt, sample\(sampleIndex\), callerPloidy\[sampleIndex\], allDgt\[sampleIndex\]\);',
@@ -182,8 +204,8 @@ def doc_table():
             for name in re.findall(r"sk_adapter::([A-Za-z_0-9]+)", repl):
                 if name not in calls:
                     calls.append(name)
-            if "friend" in desc and calls == ["Access"]:
-                what = "`friend struct sk_adapter::Access;` (no data member: the class layout is unchanged)"
+            if "friend" in desc and set(calls) <= {"Access", "GvcfAccess"}:
+                what = " ".join("`friend struct sk_adapter::%s;`" % c for c in calls) + " (no data member: the class layout is unchanged)"
             elif desc == "include":
                 what = '`#include "sk_adapter.hh"`'
             elif calls:

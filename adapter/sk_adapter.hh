@@ -96,6 +96,14 @@ void somatic_clean_now(starling_pos_processor_base& pp, const pos_t pos, Cleaned
 /// stream's column sizes; false: the caller cleans the pileup itself (always, outside the somatic stream)
 bool sample_stats_counts(starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex, unsigned& used, unsigned& unused);
 
+// ---- site 10 (sk_adapter_gvcf.cpp): the gVCF writer's non-variant blocks fed from the pileup stream's window
+/// the germline half of sample_stats_counts: the counts of a position the window calls a plain site (its pileup is then not cleaned)
+bool germline_sample_stats_counts(starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex, unsigned& used, unsigned& unused);
+/// process_pos_snp (L/applications/starling/starling_pos_processor.cpp:143-197), first thing: true = the position was a plain
+/// homozygous-reference site and has gone into the writer's open block (gvcf_writer::skip_to_pos + add_site_internal on a kept
+/// locus); false = the reference's process_pos_snp runs (its cleaned pileup is made first if process_pos_sample_stats left it out)
+bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos);
+
 /// the tumor sample's readPositionRankSum / altAlleleReadPositionInfo of `pos` (updateSomaticScoringMetrics,
 /// starling_pos_processor_base.cpp:984-1000), rebuilt from the pileup stream's window before the position's record is written
 /// (strelka_pos_processor.cpp:255); nothing to do when the reference's own pileup ran

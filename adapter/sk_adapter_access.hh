@@ -42,6 +42,7 @@ struct Access
     static const CandidateSnvBuffer& candidateSnvBuffer(const base_t& pp) { return pp._candidateSnvBuffer; }
     static bool hasPloidyRegions(const base_t& pp, const unsigned sampleIndex) { return ! pp.sample(sampleIndex).ploidyRegions.empty(); }
     static const known_pos_range2& reportRange(const base_t& pp) { return pp._reportRange; }
+    static ActiveRegionId activeRegionId(const base_t& pp, const pos_t pos) { return pp.getActiveRegionDetector().getActiveRegionId(pos); }
     /// pos_basecall_buffer::_pdata.getRef(pos): the position's pileup record, created (with its reference base) if absent
     static snp_pos_info& pileupRef(pos_basecall_buffer& buffer, const pos_t pos) { return buffer._pdata.getRef(pos); }
 };
@@ -113,6 +114,8 @@ struct SiteChunk
     std::vector<sk_digt_call> calls;
     std::vector<uint32_t> cleanCount; ///< calls of the cleaned column each genotype was computed from
     std::vector<uint8_t> ploidy;      ///< ... and the ploidy
+    std::vector<uint32_t> rawCount;   ///< calls of the raw tier1 column the window wrote into the reference's buffer
+    std::vector<sk_gvcf_site_summary> summary; ///< what the gVCF writer's block logic reads of each position (site 10)
     // germline EVS: the per-call arguments of updateGermlineScoringMetrics, kept until POST_ALIGN has passed the chunk
     std::vector<int64_t> evsOff;      ///< [n+1]
     std::vector<uint64_t> evsWords;

@@ -5,4 +5,5 @@
 namespace sk_adapter
 {
 struct Access;
+struct GvcfAccess; // (sk_adapter_gvcf.cpp: the gVCF writer's pipe)
 }

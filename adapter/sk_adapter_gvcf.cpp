@@ -1,0 +1,253 @@
+// sk_adapter_gvcf.cpp -- site 10: the gVCF writer's non-variant blocks fed from the pileup stream's window (SURVEY.md section 8f rank 4,
+// the output side).
+//
+// For every covered position the reference builds a GermlineDiploidSiteLocusInfo (process_pos_snp_digt, L/applications/starling/
+// starling_pos_processor.cpp:619-701: candidate alternate alleles, translated genotype, PLs, AD counts, per-sample site info), sends it
+// through the variant pipe (prefilter -> phaser -> overlap resolver) and, for almost every position of a genome, the writer then reads
+// five numbers of it and joins it to the sample's open non-variant block (gvcf_writer::queue_site_record, gvcf_writer.cpp:278-302).
+// The device has already said which positions are such PLAIN sites (sk_gvcf_site_summary, made beside the genotype record from the same
+// cleaned column: csrc/gvcf_site_core.h) and holds their numbers.  For a plain position whose state at call time is the window's --
+// ploidy not lowered by an indel call made since, not forced, no active region open in the phaser, no variant indel buffered in the
+// resolver or still overlapping in the writer -- the adapter
+//
+//   * does not clean the pileup (process_pos_sample_stats takes the two depth counts from the window: sample_stats_counts),
+//   * does not build a locus: it patches ONE kept GermlineDiploidSiteLocusInfo with the position's numbers, lets the reference's own
+//     ScoringModelManager set its filters (applyDepthFilter, classify_site: the calls variant_prefilter_stage makes) and hands it to the
+//     reference's own gvcf_writer::skip_to_pos / add_site_internal -- the block joining, the block records and their text are the
+//     reference's code on a locus that holds, field for field, what the writer reads of the one process_pos_snp_digt would have built.
+//
+// Anything else (a variant or filtered-looking site, an alternate allele in the column, ploidy 1 or 0, reference N, an empty cleaned
+// column, a forced position, any buffered locus in the pipe, several samples, call regions) takes the reference's path as before.
+// $STRELKA_AMD_GVCF_FAST=0 switches the site off.
+#include "sk_adapter_access.hh"
+
+#include "applications/starling/VariantOverlapResolver.hh"
+#include "applications/starling/VariantPhaser.hh"
+#include "applications/starling/gvcf_aggregator.hh"
+#include "applications/starling/gvcf_writer.hh"
+#include "applications/starling/starling_pos_processor.hh"
+#include "blt_util/seq_util.hh"
+
+#include <algorithm>
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+
+namespace sk_adapter
+{
+
+struct GvcfAccess
+{
+    static gvcf_aggregator* aggregator(starling_pos_processor& pp) { return pp._gvcfer.get(); }
+    static const starling_options& opt(const starling_pos_processor& pp) { return pp._opt; }
+    static const starling_deriv_options& dopt(const starling_pos_processor& pp) { return pp._dopt; }
+    static const ScoringModelManager& models(const gvcf_aggregator& a) { return a._scoringModels; }
+    static gvcf_writer* writer(gvcf_aggregator& a) { return a._gvcfWriterPtr.get(); }
+    static VariantPhaser* phaser(gvcf_aggregator& a) { return a._variantPhaserPtr.get(); }
+    static bool isPhaserEmpty(const VariantPhaser& p) { return p._locusBuffer.empty(); }
+    static VariantOverlapResolver* resolverBehind(VariantPhaser& p) { return dynamic_cast<VariantOverlapResolver*>(p._sink.get()); }
+    static bool isResolverEmpty(const VariantOverlapResolver& r)
+    {
+        return r._variantIndelBuffer.empty() && r._nonvariantIndelBuffer.empty() && r._siteBuffer.empty();
+    }
+    /// the writer's last variant indel still reaches this position (modifySiteForConsistencyWithUpstreamIndels would change the site)
+    static bool isUnderLastVariantIndel(const gvcf_writer& w, const pos_t pos)
+    {
+        return w._lastVariantIndelWritten && pos < w._lastVariantIndelWritten->end();
+    }
+    static bool isCompressible(const gvcf_writer& w, const GermlineSiteLocusInfo& locus) { return w._gvcf_comp.is_site_compressible(locus); }
+    /// gvcf_writer::process(site) without the ownership (gvcf_writer.cpp:180-197)
+    static void writerProcessSite(gvcf_writer& w, GermlineSiteLocusInfo& locus)
+    {
+        w.skip_to_pos(locus.pos);
+        w.add_site_internal(locus);
+    }
+};
+
+namespace
+{
+
+struct GvcfFast
+{
+    bool decided = false, enabled = false;
+    bool isCleanSkipped = false; ///< process_pos_sample_stats took the counts of cleanSkippedPos from the window and did not clean its pileup
+    pos_t cleanSkippedPos = 0;
+    std::unique_ptr<GermlineDiploidSiteLocusInfo> scratch;
+    unsigned long plainSites = 0, referenceSites = 0, declinedByState = 0;
+    ~GvcfFast()
+    {
+        const char* v(std::getenv("STRELKA_AMD_VERBOSE"));
+        if (v && std::atoi(v) != 0)
+        {
+            std::cerr << "strelka_amd adapter gvcf: gvcf_plain_sites=" << plainSites << " gvcf_reference_sites=" << referenceSites
+                      << " gvcf_plain_declined_by_state=" << declinedByState << "\n";
+        }
+    }
+};
+
+GvcfFast& gf()
+{
+    static GvcfFast g;
+    return g;
+}
+
+bool decide(starling_pos_processor& pp)
+{
+    GvcfFast& g(gf());
+    if (g.decided) return g.enabled;
+    g.decided = true;
+    const starling_options& opt(GvcfAccess::opt(pp));
+    const char* v(std::getenv("STRELKA_AMD_GVCF_FAST"));
+    const bool isOn(! (v && *v == '0'));
+    State& s(state());
+    g.enabled = isOn && s.pileup.enabled && s.pileup.isGenotyping && (Access::sampleCount(pp) == 1) && opt.is_bsnp_diploid() &&
+                opt.gvcf.is_gvcf_output() && (! opt.isUseCallRegions()) && (GvcfAccess::aggregator(pp) != nullptr);
+    if (g.enabled)
+    {
+        // the one locus that stands for every plain site: what never changes is set here (updateSnvLocusWithSampleInfo :344-500 for
+        // a diploid sample whose most likely genotype is 0/0 under both priors and whose locus has no alternate allele)
+        g.scratch.reset(new GermlineDiploidSiteLocusInfo(GvcfAccess::dopt(pp).gvcf, 1));
+        LocusSampleInfo& sampleInfo(g.scratch->getSample(0));
+        sampleInfo.setPloidy(2);
+        sampleInfo.setActiveRegionId(-1);
+        sampleInfo.maxGenotypeIndex.setGenotypeFromAlleleIndices(0, 0);
+        sampleInfo.maxGenotypeIndexPolymorphic.setGenotypeFromAlleleIndices(0, 0);
+        sampleInfo.supportCounts.setAltCount(0);
+    }
+    return g.enabled;
+}
+
+/// the chunk of sample 0 that holds pos (chunks leave from the front as POST_ALIGN moves forward, as in site_diploid_genotype)
+const SiteChunk* chunkAt(const pos_t pos)
+{
+    State& s(state());
+    if (s.pileup.chunks.empty()) return nullptr;
+    std::deque<SiteChunk>& chunks(s.pileup.chunks[0]);
+    while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front();
+    if (chunks.empty() || chunks.front().begin > pos) return nullptr;
+    return &chunks.front();
+}
+
+/// plain by the window's account, with the column the window wrote still in place
+bool isPlainInWindow(const SiteChunk& c, const size_t k, const snp_pos_info& pi)
+{
+    if (c.summary.empty()) return false;
+    return (c.summary[k].flags & 1u) != 0 && c.ploidy[k] == 2 && c.rawCount[k] == pi.calls.size();
+}
+
+}
+
+bool germline_sample_stats_counts(starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex, unsigned& used, unsigned& unused)
+{
+    GvcfFast& g(gf());
+    g.isCleanSkipped = false;
+    if (! (g.decided && g.enabled) || sampleIndex != 0) return false;
+    const SiteChunk* c(chunkAt(pos));
+    if (c == nullptr) return false;
+    const snp_pos_info& pi(pp.sample(0).basecallBuffer.get_pos(pos));
+    const size_t k(static_cast<size_t>(pos - c->begin));
+    if (! isPlainInWindow(*c, k, pi)) return false;
+    // CleanedPileup::usedBasecallCount / unusedBasecallCount of CleanPileupFilter(pi, false) (PileupCleaner.hh:48-58)
+    used = c->cleanCount[k];
+    unused = static_cast<unsigned>(pi.calls.size()) - used;
+    g.isCleanSkipped = true;
+    g.cleanSkippedPos = pos;
+    return true;
+}
+
+bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
+{
+    if (! decide(pp)) return false;
+    GvcfFast& g(gf());
+    const bool isCleanSkipped(g.isCleanSkipped && g.cleanSkippedPos == pos);
+    g.isCleanSkipped = false;
+    starling_pos_processor_base& base(pp);
+    starling_pos_processor_base::sample_info& sif(base.sample(0));
+    const snp_pos_info& pi(sif.basecallBuffer.get_pos(pos));
+
+    auto referencePath = [&]() -> bool
+    {
+        // the reference's process_pos_snp takes it from here; its cleaned pileup is made now if process_pos_sample_stats left it out
+        if (isCleanSkipped) Access::pileupCleaner(base).CleanPileupFilter(pi, false, sif.cleanedPileup);
+        if (! pi.calls.empty()) g.referenceSites++;
+        return false;
+    };
+    if (! isCleanSkipped) return referencePath(); // (not plain in the window, or the counts did not come from it)
+
+    const SiteChunk* c(chunkAt(pos));
+    if (c == nullptr) return referencePath();
+    const size_t k(static_cast<size_t>(pos - c->begin));
+    if (! isPlainInWindow(*c, k, pi)) return referencePath();
+
+    // ---- the state at call time (process_pos_snp_digt "prep step 2" :637-651; is_forced_output_pos :152)
+    const int regionPloidy(static_cast<int>(Access::ploidy(base, pos, 0)));
+    if (regionPloidy != 2 || pi.spanningIndelPloidyModification != 0 || Access::isForcedOutputPos(base, pos))
+    {
+        g.declinedByState++;
+        return referencePath();
+    }
+    const reference_contig_segment& ref(Access::ref(base));
+    const uint8_t refBaseIndex(base_to_id(ref.get_base(pos)));
+    if (refBaseIndex == BASE_ID::ANY) return referencePath();
+
+    // ---- the pipe between process_pos_snp_digt and the writer must be empty: a locus waiting there would be overtaken
+    gvcf_aggregator& agg(*GvcfAccess::aggregator(pp));
+    gvcf_writer* writer(GvcfAccess::writer(agg));
+    VariantPhaser* phaser(GvcfAccess::phaser(agg));
+    if (writer == nullptr) return referencePath();
+    if (phaser != nullptr)
+    {
+        VariantOverlapResolver* resolver(GvcfAccess::resolverBehind(*phaser));
+        const bool isInActiveRegion(GvcfAccess::opt(pp).isUseVariantPhaser && (Access::activeRegionId(base, pos) >= 0));
+        if ((! GvcfAccess::isPhaserEmpty(*phaser)) || isInActiveRegion || resolver == nullptr || (! GvcfAccess::isResolverEmpty(*resolver)))
+        {
+            g.declinedByState++;
+            return referencePath();
+        }
+    }
+    if (GvcfAccess::isUnderLastVariantIndel(*writer, pos))
+    {
+        g.declinedByState++;
+        return referencePath();
+    }
+
+    // ---- the locus process_pos_snp_digt would have built, as far as anything downstream reads it
+    const sk_digt_call& dgt(c->calls[k]);
+    const sk_gvcf_site_summary& sm(c->summary[k]);
+    GermlineDiploidSiteLocusInfo& locus(*g.scratch);
+    locus.pos = pos;
+    locus.refBaseIndex = refBaseIndex;
+    locus.isForcedOutput = false;
+    locus.filters.clear();
+    LocusSampleInfo& sampleInfo(locus.getSample(0));
+    sampleInfo.filters.clear();
+    sampleInfo.genotypeQuality = dgt.genome.max_gt_qphred;           // :388
+    sampleInfo.genotypeQualityPolymorphic = dgt.poly.max_gt_qphred;   // :391
+    sampleInfo.setGqx();                                              // :394
+    sampleInfo.supportCounts.setAltCount(0);                          // :452 (clears the counts)
+    sampleInfo.supportCounts.getCounts(true).incrementAlleleCount(0, sm.ref_fwd);  // :455-465
+    sampleInfo.supportCounts.getCounts(false).incrementAlleleCount(0, sm.ref_rev);
+    {
+        // updateSiteSampleInfo :200-250 (the EVS metrics belong to variant or forced sites only)
+        GermlineSiteSampleInfo siteSampleInfo;
+        siteSampleInfo.isOverlappingHomAltDeletion = false;
+        siteSampleInfo.spanningDeletionReadCount = pi.spanningDeletionReadCount;
+        siteSampleInfo.usedBasecallCount = c->cleanCount[k];
+        siteSampleInfo.unusedBasecallCount = static_cast<unsigned>(pi.calls.size()) - c->cleanCount[k];
+        siteSampleInfo.mapqTracker = pi.mapqTracker;
+        const double maxBias(GvcfAccess::opt(pp).maxAbsSampleVariantStrandBias);
+        siteSampleInfo.strandBias = std::min(maxBias, std::max(-maxBias, dgt.strand_bias));
+        locus.setSiteSampleInfo(0, siteSampleInfo);
+    }
+    // variant_prefilter_stage::process (variant_prefilter_stage.cpp:52-71): no ploidy conflict; the depth filter; the site's filters
+    const ScoringModelManager& models(GvcfAccess::models(agg));
+    models.applyDepthFilter(locus);
+    models.classify_site(locus);
+    if (! GvcfAccess::isCompressible(*writer, locus)) return referencePath(); // (a no-compress region: the writer would print the site)
+
+    GvcfAccess::writerProcessSite(*writer, locus);
+    g.plainSites++;
+    return true;
+}
+
+}

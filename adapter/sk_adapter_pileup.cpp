@@ -323,6 +323,12 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
         {
             chunk.calls.assign(w.genotype, w.genotype + n);
             chunk.cleanCount.assign(w.clean_count, w.clean_count + n);
+            if (w.site_summary != nullptr)
+            {
+                chunk.summary.assign(w.site_summary, w.site_summary + n);
+                chunk.rawCount.resize(n);
+                for (size_t i(0); i < n; ++i) chunk.rawCount[i] = static_cast<uint32_t>(w.tier1_off[i + 1] - w.tier1_off[i]);
+            }
             chunk.ploidy.resize(n);
             for (size_t i(0); i < n; ++i)
             {

@@ -244,6 +244,8 @@ void somatic_clean_now(starling_pos_processor_base& pp, const pos_t pos, Cleaned
 
 bool sample_stats_counts(starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex, unsigned& used, unsigned& unused)
 {
+    // the germline caller: a plain site's counts come from the window (site 10, sk_adapter_gvcf.cpp)
+    if (! Access::opt(pp).isSomaticCallingMode) return germline_sample_stats_counts(pp, pos, sampleIndex, used, unused);
     if (! somatic_defer_clean(pp, pos)) return false;
     const snp_pos_info& pi(pp.sample(sampleIndex).basecallBuffer.get_pos(pos));
     if (pi.calls.empty())

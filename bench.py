@@ -258,7 +258,7 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                     hooks[k] = hooks.get(k, 0.0) + float(v)
             # what went through the C-ABI (adapter/sk_adapter_common.cpp, sk_adapter_feed.cpp: STRELKA_AMD_VERBOSE=1), summed over the
             # segment processes: the identical bytes below are the routed path's only if these say so
-            for pat in (r"strelka_amd adapter: (.*)", r"strelka_amd adapter pileup: (.*)", r"strelka_amd adapter feed: (.*)"):
+            for pat in (r"strelka_amd adapter: (.*)", r"strelka_amd adapter pileup: (.*)", r"strelka_amd adapter feed: (.*)", r"strelka_amd adapter gvcf: (.*)"):
                 m = re.search(pat, tail)
                 if m:
                     for kv in m.group(1).split():

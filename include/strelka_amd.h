@@ -612,6 +612,18 @@ int sk_site_digt_call_fused_dev(const sk_pileup_batch* dev_batch, const sk_germl
  * The returned pointers are into a host buffer of the stream, valid until its next call. */
 typedef struct sk_pileup_stream sk_pileup_stream;
 
+/** What the gVCF writer's non-variant block logic reads of a position (gvcf_writer::queue_site_record, L/applications/starling/
+ *  gvcf_writer.cpp:278-302; gvcf_block_site_record.cpp:30-184), made on the device from the position's cleaned column and genotype record
+ *  (csrc/gvcf_site_core.h): whether process_pos_snp_digt (L/applications/starling/starling_pos_processor.cpp:619-701) would build a
+ *  homozygous-reference site locus with no alternate allele for it -- flags bit 0, "plain" -- and, for such a site, its GQX
+ *  (LocusSampleInfo::setGqx) and the reference allele's AD counts by strand.  The depth numbers (used / unused basecalls) are
+ *  clean_count and the tier1 column's length. */
+typedef struct sk_gvcf_site_summary {
+    uint32_t flags;            /* bit 0: plain site (see above); valid for the ploidy the window was genotyped with */
+    int32_t gqx;               /* min(genome.max_gt_qphred, poly.max_gt_qphred) */
+    uint32_t ref_fwd, ref_rev; /* cleaned basecalls equal to the reference base, forward / reverse strand */
+} sk_gvcf_site_summary;
+
 typedef struct sk_pileup_window {
     int32_t begin, end;              /* positions [begin, end); n = end - begin */
     const int64_t* tier1_off;        /* [n+1] */
@@ -630,6 +642,7 @@ typedef struct sk_pileup_window {
                                         base id (bits 0-2) | mapq << 3 | qscore << 11 (MAPQ-adjusted, not capped) | cycle << 18
                                         (align_strand_read_pos) | min(20, distance from the read edge) << 29 | is_submapped << 34
                                         (a submapped position carries base id, mapq and the flag only) */
+    const sk_gvcf_site_summary* site_summary; /* [n], NULL when the stream does not genotype */
 } sk_pileup_window;
 
 /** genotype_opt: NULL = columns only.  opt->report_begin / report_end / largest_total_indel_ref_span_per_read are set per
@@ -1050,6 +1063,11 @@ typedef struct sk_gvcf_block { /* gvcf_block_site_record as write_site_record re
 } sk_gvcf_block;
 /** kind[i]: 0 = site i continues the block of the site before it, 1 = it starts a block (blocks[i] describes the block), 2 = it is
  *  not compressible and is written as a record of its own.  blocks: n_sites entries, written where kind is 1. */
+/** sk_gvcf_site_summary of every locus of a device-resident batch (the cleaned columns as sk_site_digt_call_fused_dev takes them) from
+ *  the genotype records that call left: what the pileup stream appends to a window (sk_pileup_window.site_summary). */
+int sk_gvcf_site_summaries_dev(const sk_pileup_batch* dev_batch, const sk_digt_call* dev_genotypes, sk_gvcf_site_summary* dev_out, void* hip_stream);
+/** the same for host arrays (one upload, one launch, one copy back): tests, and callers without a stream */
+int sk_gvcf_site_summaries(const sk_pileup_batch* host_batch, const sk_digt_call* genotypes, sk_gvcf_site_summary* out);
 int sk_gvcf_block_sites(const sk_gvcf_site* sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol, uint8_t* kind,
                         sk_gvcf_block* blocks);
 int sk_gvcf_block_sites_dev(const sk_gvcf_site* dev_sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol,

@@ -465,6 +465,19 @@ extern "C" int sk_normalize_alignments_dev(const char*, int32_t, int32_t, int32_
 
 // ---- the gVCF writer's block logic: the same statement the kernel runs (csrc/gvcf_block_core.h), on this host ----------------------
 #include "gvcf_block_core.h"
+#include "gvcf_site_core.h"
+extern "C" int sk_gvcf_site_summaries(const sk_pileup_batch* hb, const sk_digt_call* genotypes, sk_gvcf_site_summary* out)
+{
+    if (!g_ready) return sk_fail("sk_init() has not succeeded");
+    if (!hb || hb->n_loci < 0 || (hb->n_loci > 0 && (!genotypes || !out))) return sk_fail("sk_gvcf_site_summaries: bad argument");
+    for (int32_t i = 0; i < hb->n_loci; ++i)
+        out[i] = skgvcf::site_summary(hb->calls + hb->call_off[i], hb->call_off[i + 1] - hb->call_off[i], hb->ref_base[i], hb->ploidy ? hb->ploidy[i] : 2u, genotypes[i]);
+    return 0;
+}
+extern "C" int sk_gvcf_site_summaries_dev(const sk_pileup_batch*, const sk_digt_call*, sk_gvcf_site_summary*, void*)
+{
+    return sk_fail("sk_gvcf_site_summaries_dev needs the GPU library");
+}
 extern "C" int sk_gvcf_block_sites(const sk_gvcf_site* sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol, uint8_t* kind,
                                    sk_gvcf_block* blocks)
 {
@@ -513,6 +526,7 @@ struct sk_pileup_stream
     std::vector<uint64_t> o_sq, o_ev;
     std::vector<int64_t> o_evoff;
     std::vector<sk_digt_call> o_g;
+    std::vector<sk_gvcf_site_summary> o_sum;
     // the cleaned columns of the last emitted range (CleanPileupFilter(pi,false) / (pi,true))
     std::vector<int64_t> k_off, k_off4;
     std::vector<uint16_t> k_calls, k_calls4;
@@ -791,6 +805,15 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
     out->mapq_sum_square = s->o_sq.data();
     out->clean_count = s->o_cn.data();
     out->genotype = s->genotype ? s->o_g.data() : nullptr;
+    s->o_sum.assign(nl + 1, sk_gvcf_site_summary());
+    if (s->genotype) {
+        for (size_t l = 0; l < nl; ++l) {
+            const int64_t kp = static_cast<int64_t>(begin) + static_cast<int64_t>(l) - ploidy_begin;
+            const unsigned pl = (ploidy && kp >= 0 && kp < ploidy_len) ? ploidy[kp] : 2;
+            s->o_sum[l] = skgvcf::site_summary(ccalls.data() + coff[l], coff[l + 1] - coff[l], s->k_ref[l], pl, s->o_g[l]);
+        }
+    }
+    out->site_summary = s->genotype ? s->o_sum.data() : nullptr;
     out->evs_off = s->want_evs ? s->o_evoff.data() : nullptr;
     out->evs_words = s->want_evs ? s->o_ev.data() : nullptr;
     return 0;

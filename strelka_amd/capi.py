@@ -122,11 +122,15 @@ class PileupColumns(C.Structure):
 PILEUP_RAW_TIER1, PILEUP_RAW_TIER2, PILEUP_CLEAN_TIER1, PILEUP_CLEAN_TIER2 = 0, 1, 2, 3
 
 
+GVCF_SITE_SUMMARY_DTYPE = np.dtype([("flags", np.uint32), ("gqx", np.int32), ("ref_fwd", np.uint32), ("ref_rev", np.uint32)])
+
+
 class PileupWindow(C.Structure):
     _fields_ = [("begin", C.c_int32), ("end", C.c_int32), ("tier1_off", c_void_p), ("tier1_calls", c_void_p),
                 ("tier2_off", c_void_p), ("tier2_calls", c_void_p), ("spandel_count", c_void_p), ("submapped_count", c_void_p),
                 ("mapq_count", c_void_p), ("mapq_zero_count", c_void_p), ("mapq_sum_square", c_void_p),
-                ("clean_count", c_void_p), ("genotype", c_void_p), ("evs_off", c_void_p), ("evs_words", c_void_p)]
+                ("clean_count", c_void_p), ("genotype", c_void_p), ("evs_off", c_void_p), ("evs_words", c_void_p),
+                ("site_summary", c_void_p)]
 
 
 class SomaticPileupWindow(C.Structure):
@@ -204,7 +208,7 @@ EXPORTS = [
     "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
-    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push", "sk_pileup_stream_enable_evs_words",
+    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push", "sk_pileup_stream_enable_evs_words", "sk_gvcf_site_summaries", "sk_gvcf_site_summaries_dev",
     "sk_somatic_pileup_stream_create", "sk_somatic_pileup_stream_destroy", "sk_somatic_pileup_stream_begin_region", "sk_somatic_pileup_stream_push",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
@@ -1057,6 +1061,7 @@ class PileupStream:
                     mapq_count=arr(w.mapq_count, np.uint32, n), mapq_zero=arr(w.mapq_zero_count, np.uint32, n),
                     mapq_sumsq=arr(w.mapq_sum_square, np.uint64, n), clean_count=arr(w.clean_count, np.uint32, n),
                     genotype=rec(w.genotype, DIGT_CALL_DTYPE, n) if self.genotype else None,
+                    site_summary=rec(w.site_summary, GVCF_SITE_SUMMARY_DTYPE, n) if self.genotype else None,
                     evs_off=arr(w.evs_off, np.int64, n + 1) if self.evs_words else None,
                     evs_words=(arr(w.evs_words, np.uint64, int(arr(w.evs_off, np.int64, n + 1)[-1]) if n else 0) if self.evs_words else None))
 

@@ -3,7 +3,10 @@
 
 #include "sk_common.h"
 
+#include <cstring>
+
 #include "gvcf_block_core.h"
+#include "gvcf_site_core.h"
 
 namespace
 {
@@ -25,6 +28,15 @@ __global__ __launch_bounds__(256) void gvcf_block_kernel(const GvcfArgs a)
     if (i >= a.n) return;
     if (!skgvcf::starts_stretch(a.sites, i)) return;
     skgvcf::walk_stretch(a.sites, a.n, i, a.frac_tol, a.abs_tol, a.kind, a.blocks);
+}
+
+// one lane per position of a stream window: its cleaned column (a few dozen 16-bit calls) and its genotype record -> sk_gvcf_site_summary
+__global__ __launch_bounds__(256) void gvcf_site_summary_kernel(const sk_pileup_batch b, const sk_digt_call* __restrict__ geno, sk_gvcf_site_summary* __restrict__ out)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n_loci) return;
+    const int64_t c0 = b.call_off[i], c1 = b.call_off[i + 1];
+    out[i] = skgvcf::site_summary(b.calls + c0, c1 - c0, b.ref_base[i], b.ploidy ? b.ploidy[i] : 2u, geno[i]);
 }
 
 struct GvcfBuffers
@@ -51,6 +63,53 @@ GvcfBuffers& gvcf_bufs()
 } // namespace
 
 extern "C" {
+
+int sk_gvcf_site_summaries_dev(const sk_pileup_batch* dev_batch, const sk_digt_call* dev_genotypes, sk_gvcf_site_summary* dev_out, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (!dev_batch || dev_batch->n_loci < 0) return sk_fail("sk_gvcf_site_summaries_dev: bad batch");
+    if (dev_batch->n_loci == 0) return 0;
+    if (!dev_genotypes || !dev_out) return sk_fail("sk_gvcf_site_summaries_dev: null argument");
+    hipLaunchKernelGGL(gvcf_site_summary_kernel, dim3((dev_batch->n_loci + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), *dev_batch, dev_genotypes,
+                       dev_out);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sk_gvcf_site_summaries(const sk_pileup_batch* hb, const sk_digt_call* genotypes, sk_gvcf_site_summary* out)
+{
+    SK_REQUIRE_INIT();
+    if (!hb || hb->n_loci < 0) return sk_fail("sk_gvcf_site_summaries: bad batch");
+    if (hb->n_loci == 0) return 0;
+    if (!genotypes || !out || !hb->call_off || !hb->calls || !hb->ref_base) return sk_fail("sk_gvcf_site_summaries: null argument");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    const size_t n = size_t(hb->n_loci);
+    const size_t n_calls = size_t(hb->call_off[n]);
+    auto up = [](const size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t o_off = 0, o_calls = o_off + up(8 * (n + 1)), o_ref = o_calls + up(2 * n_calls + 2), o_pl = o_ref + up(n), o_g = o_pl + up(n),
+                 o_out = o_g + up(sizeof(sk_digt_call) * n), total = o_out + up(sizeof(sk_gvcf_site_summary) * n);
+    GvcfBuffers& B = gvcf_bufs();
+    if (B.reserve(0, total)) return 1;
+    char* d = static_cast<char*>(B.p[0]);
+    SK_HIP(hipMemcpyAsync(d + o_off, hb->call_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
+    if (n_calls) SK_HIP(hipMemcpyAsync(d + o_calls, hb->calls, 2 * n_calls, hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(d + o_ref, hb->ref_base, n, hipMemcpyHostToDevice, st));
+    if (hb->ploidy) SK_HIP(hipMemcpyAsync(d + o_pl, hb->ploidy, n, hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(d + o_g, genotypes, sizeof(sk_digt_call) * n, hipMemcpyHostToDevice, st));
+    sk_pileup_batch db;
+    std::memset(&db, 0, sizeof(db));
+    db.n_loci = hb->n_loci;
+    db.call_off = reinterpret_cast<const int64_t*>(d + o_off);
+    db.calls = reinterpret_cast<const uint16_t*>(d + o_calls);
+    db.ref_base = reinterpret_cast<const uint8_t*>(d + o_ref);
+    db.ploidy = hb->ploidy ? reinterpret_cast<const uint8_t*>(d + o_pl) : nullptr;
+    if (sk_gvcf_site_summaries_dev(&db, reinterpret_cast<const sk_digt_call*>(d + o_g), reinterpret_cast<sk_gvcf_site_summary*>(d + o_out), st)) return 1;
+    SK_HIP(hipMemcpyAsync(out, d + o_out, sizeof(sk_gvcf_site_summary) * n, hipMemcpyDeviceToHost, st));
+    SK_HIP(hipStreamSynchronize(st));
+    return 0;
+}
 
 int sk_gvcf_block_sites_dev(const sk_gvcf_site* dev_sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol, uint8_t* dev_kind,
                             sk_gvcf_block* dev_blocks, void* hip_stream)

@@ -1,0 +1,76 @@
+// gvcf_site_core.h -- what the gVCF writer's non-variant block logic needs of a position, made from the position's cleaned pileup column
+// and its genotype record where they lie (the stream's window), for the device and the host (the output side).
+//
+// For a position of one diploid sample the reference builds a GermlineDiploidSiteLocusInfo (process_pos_snp_digt,
+// L/applications/starling/starling_pos_processor.cpp:619-701): the candidate alternate alleles (getSiteAltAlleles :508-612), the genotype
+// translated to them, PLs, AD counts (updateSnvLocusWithSampleInfo :344-500) -- and, for almost every position of a genome, finds a
+// homozygous-reference site with no alternate allele, which the writer joins to the open block of the sample
+// (gvcf_writer::queue_site_record, gvcf_writer.cpp:278-302) after reading five numbers of it.  This header says, per position, whether it
+// is such a PLAIN site and gives the numbers:
+//
+//   plain  <=>  the reference base is known, the caller ploidy is 2, the cleaned column is not empty, getSiteAltAlleles would list no
+//               alternate allele (the rank pass :527-560 gives no rank to a base other than the reference's; both most likely genotypes
+//               -- genomic and polymorphic prior -- are the homozygous-reference one, so the pass over them :578-611 adds none)
+//   gqx            LocusSampleInfo::setGqx (gvcf_locus_info.hh:356-369) with maxGenotypeIndex == maxGenotypeIndexPolymorphic == 0/0:
+//                  min(genome.max_gt_qphred, poly.max_gt_qphred)
+//   ref_fwd/rev    the AD counts of the reference allele by strand (:452-466; with no alternate allele every other base is skipped)
+//
+// Everything that depends on state the window cannot know (the ploidy as indel calls have lowered it since, forced output, an open
+// active region or overlapping indel in the writer's pipe) is the caller's to check when the position is reached.
+#pragma once
+
+#include "strelka_amd.h"
+
+#ifdef __HIPCC__
+#define SKGS_HD __host__ __device__
+#else
+#define SKGS_HD
+#endif
+
+namespace skgvcf
+{
+
+enum { SITE_PLAIN = 1 };
+
+// calls: the cleaned tier1 column (CleanPileupFilter(pi, false)) in the reference's base_call bit layout (q:6, base:4, fwd, ...)
+SKGS_HD inline sk_gvcf_site_summary site_summary(const uint16_t* calls, const int64_t n, const unsigned ref_base, const unsigned ploidy, const sk_digt_call& g)
+{
+    sk_gvcf_site_summary s;
+    s.flags = 0;
+    s.gqx = 0;
+    s.ref_fwd = s.ref_rev = 0;
+    if (ref_base > 3 || !g.is_called) return s;
+    uint32_t cnt[4][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+    for (int64_t i = 0; i < n; ++i) {
+        const unsigned b = (unsigned(calls[i]) >> 6) & 0xfu;
+        if (b > 3) continue; // snp_pos_info::getBasecallCounts :166-174: unknown bases are not counted
+        ++cnt[b][(unsigned(calls[i]) >> 10) & 1u];
+    }
+    s.ref_fwd = cnt[ref_base][1];
+    s.ref_rev = cnt[ref_base][0];
+    // getSiteAltAlleles :527-560 for one sample
+    double c[4];
+    unsigned min_count = 0;
+    for (int b = 0; b < 4; ++b) {
+        c[b] = double(cnt[b][0] + cnt[b][1]);
+        min_count = unsigned(double(min_count) + c[b]); // (minCount += sampleBaseCounts[baseIndex])
+    }
+    min_count = unsigned(double(min_count) * 0.10);      // (minCount *= minAlleleFraction)
+    if (min_count < 1u) min_count = 1u;
+    bool alt = false;
+    for (unsigned k = 0; k < ploidy && k < 2; ++k) {
+        unsigned mb = 0;
+        for (unsigned b = 1; b < 4; ++b)
+            if (c[b] > c[mb]) mb = b;
+        if (c[mb] >= double(min_count) && mb != ref_base) alt = true;
+        c[mb] = 0;
+    }
+    // the pass over the most likely genotypes :578-611: hom-ref under both priors adds nothing (DIGT: genotypes 0..3 are AA,CC,GG,TT)
+    const bool hom_ref = (g.poly.max_gt == ref_base) && (g.genome.max_gt == ref_base);
+    const int32_t gq = int32_t(g.genome.max_gt_qphred), gqp = int32_t(g.poly.max_gt_qphred);
+    s.gqx = gq < gqp ? gq : gqp;
+    if (ploidy == 2 && n > 0 && !alt && hom_ref) s.flags |= SITE_PLAIN;
+    return s;
+}
+
+} // namespace skgvcf

@@ -1289,7 +1289,7 @@ namespace
 
 struct InLay { int64_t read_off, path_off, path, pos, is_fwd, mapq, level, code, qual, ploidy, mask, total; };
 struct WorkLay { int64_t begin, end, maxend, minbegin, count0, count1, count2, count4, count4a, off2, off4, calls2, calls4, refbase, de, gscr, tmp, total; };
-struct OutLay { int64_t off0, off1, clean_n, clean4_n, mq_n, mq_zero, mq_sq, spandel, submapped, geno, calls0, calls1, read_pos, evs_off, evs, total; };
+struct OutLay { int64_t off0, off1, clean_n, clean4_n, mq_n, mq_zero, mq_sq, spandel, submapped, geno, summary, calls0, calls1, read_pos, evs_off, evs, total; };
 
 } // namespace
 
@@ -1582,6 +1582,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         ol.spandel = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
         ol.submapped = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
         ol.geno = o; o += align256(s->genotype ? int64_t(sizeof(sk_digt_call)) * std::max(n_loci, 1) : 0);
+        ol.summary = o; o += align256(s->genotype ? int64_t(sizeof(sk_gvcf_site_summary)) * std::max(n_loci, 1) : 0);
         ol.calls0 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
         ol.calls1 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
         ol.read_pos = o; o += align256(s->want_read_pos ? 4 * std::max<int64_t>(n_bases, 1) : 0);
@@ -1712,6 +1713,9 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         if (sk_site_digt_call_fused_dev(&pb, &s->gopt, reinterpret_cast<sk_digt_call*>(dout + ol.geno), reinterpret_cast<float*>(dw + wl.de), 0,
                                         dw + wl.gscr, n_bases, st))
             return 1;
+        // ... and what the gVCF writer's block logic reads of each position, from the same column and the record just written
+        if (sk_gvcf_site_summaries_dev(&pb, reinterpret_cast<const sk_digt_call*>(dout + ol.geno), reinterpret_cast<sk_gvcf_site_summary*>(dout + ol.summary), st))
+            return 1;
     }
     SK_HIP(hipGetLastError());
     SK_HIP(hipMemcpyAsync(ho, dout, size_t(ol.total), hipMemcpyDeviceToHost, st));
@@ -1776,6 +1780,7 @@ void stream_finish(sk_pileup_stream* s, sk_pileup_window* out)
     out->mapq_sum_square = reinterpret_cast<const uint64_t*>(ho + ol.mq_sq);
     out->clean_count = reinterpret_cast<const uint32_t*>(ho + ol.clean_n);
     out->genotype = s->genotype ? reinterpret_cast<const sk_digt_call*>(ho + ol.geno) : nullptr;
+    out->site_summary = s->genotype ? reinterpret_cast<const sk_gvcf_site_summary*>(ho + ol.summary) : nullptr;
     out->evs_off = s->want_evs ? reinterpret_cast<const int64_t*>(ho + ol.evs_off) : nullptr;
     out->evs_words = s->want_evs ? reinterpret_cast<const uint64_t*>(ho + ol.evs) : nullptr;
 }
