@@ -180,7 +180,7 @@ struct State
     unsigned long realignDeviceEnumerated = 0, realignHostEnumerated = 0; // reads whose candidate alignments the device / the host listed
     unsigned long realignRefWindowMisses = 0; // jobs run a second time with the whole contig segment as their reference
     unsigned long realignHostJobs = 0; // jobs whose search ran as the host statement (below the device threshold, or $SK_ENUMERATION)
-    unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, indelGroups = 0, haplotypes = 0, haplotypeBatches = 0;
+    unsigned long realignBatches = 0, realignReads = 0, siteBatches = 0, siteLoci = 0, siteRecomputed = 0, siteRecomputeCalls = 0, indelGroups = 0, haplotypes = 0, haplotypeBatches = 0;
 };
 /// the adapter's state (one per process); the hooks ask for it at every position and every read, so after the first call it is a load
 State& make_state();

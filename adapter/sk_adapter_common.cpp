@@ -89,7 +89,7 @@ State& make_state()
         {
             if (env_unsigned("STRELKA_AMD_VERBOSE", 0) == 0) return;
             std::cerr << "strelka_amd adapter: realign_jobs=" << s.realignBatches << " realign_reads=" << s.realignReads << " realign_job_reads=" << s.realignJobReads
-                      << " site_batches=" << s.siteBatches << " site_loci=" << s.siteLoci << " site_recomputed=" << s.siteRecomputed
+                      << " site_batches=" << s.siteBatches << " site_loci=" << s.siteLoci << " site_recomputed=" << s.siteRecomputed << " site_recompute_calls=" << s.siteRecomputeCalls
                       << " indel_groups=" << s.indelGroups << " indel_groups_wide=" << s.indelGroupsWide << " haplotypes=" << s.haplotypes << " haplotype_batches=" << s.haplotypeBatches << " read_window=" << read_buffer_defer()
                       << " site_window=" << post_align_defer() << " enum_device_reads=" << s.realignDeviceEnumerated
                       << " enum_host_instead=" << s.realignHostEnumerated;

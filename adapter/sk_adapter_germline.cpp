@@ -180,12 +180,56 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
         while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front(); // POST_ALIGN only moves forward
         if ((! chunks.empty()) && chunks.front().begin <= pos)
         {
-            const SiteChunk& c(chunks.front());
+            SiteChunk& c(chunks.front());
             const size_t k(static_cast<size_t>(pos - c.begin));
             if (c.ploidy[k] == ploidy && c.cleanCount[k] == cleaned.calls.size())
             {
                 toDiploidGenotype(c.calls[k], ploidy, dgt);
                 return;
+            }
+            // An indel call made since the window was genotyped has lowered the ploidy here -- and, as a rule, over the whole span of
+            // the deletion (updateDiploidIndelLocusWithSampleInfo, starling_pos_processor.cpp:1215-1226, decrements every position of
+            // it at once): the run of following positions of this chunk whose ploidy no longer is the window's is genotyped again in
+            // ONE call and the chunk's records replaced, instead of one device round trip per position.
+            if (c.cleanCount[k] == cleaned.calls.size())
+            {
+                std::vector<int64_t> callOff(1, 0);
+                std::vector<uint16_t> calls;
+                std::vector<uint8_t> refBase, pl;
+                std::vector<size_t> slot;
+                const size_t kEnd(std::min(c.calls.size(), k + 512));
+                for (size_t kk(k); kk < kEnd; ++kk)
+                {
+                    const pos_t p(c.begin + static_cast<pos_t>(kk));
+                    const snp_pos_info& pi(base.sample(sampleIndex).basecallBuffer.get_pos(p));
+                    const unsigned nowPloidy((kk == k) ? ploidy : callerPloidy(base, p, sampleIndex, pi));
+                    if (nowPloidy == c.ploidy[kk]) break;
+                    const size_t before(calls.size());
+                    appendCleanedCalls(pi, calls);
+                    if ((calls.size() - before) != c.cleanCount[kk]) // (the column is not the window's: left to its own call)
+                    {
+                        calls.resize(before);
+                        break;
+                    }
+                    callOff.push_back(static_cast<int64_t>(calls.size()));
+                    refBase.push_back(refBaseId(pi.get_ref_base()));
+                    pl.push_back(static_cast<uint8_t>(nowPloidy));
+                    slot.push_back(kk);
+                }
+                if (! slot.empty())
+                {
+                    std::vector<sk_digt_call> out(slot.size());
+                    genotypeLoci(Access::opt(base), callOff, calls, refBase, pl, out.data());
+                    for (size_t i(0); i < slot.size(); ++i)
+                    {
+                        c.calls[slot[i]] = out[i];
+                        c.ploidy[slot[i]] = pl[i];
+                    }
+                    s.siteRecomputed += slot.size();
+                    s.siteRecomputeCalls++;
+                    toDiploidGenotype(c.calls[k], ploidy, dgt);
+                    return;
+                }
             }
         }
     }
@@ -215,6 +259,7 @@ void site_diploid_genotype(starling_pos_processor& pp, const pos_t pos, const un
     genotypeLoci(Access::opt(base), callOff, calls, refBase, pl, &out);
     toDiploidGenotype(out, ploidy, dgt);
     s.siteRecomputed++;
+    s.siteRecomputeCalls++;
 }
 
 void empty_site_genotype(const starling_pos_processor_base& pp, const unsigned refBaseIndex, diploid_genotype& dgt)

@@ -213,16 +213,16 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
     ro.is_haplotyping_enabled = opt.isHaplotypingEnabled ? 1 : 0;
     ro.min_read_bp_flank = sif.sampleOptions.min_read_bp_flank;
     ro.sample_count = static_cast<int32_t>(sampleCount);
-    // Small jobs stay with the host statement of the search (one device round trip: the scoring launch); the device pipeline -- three
-    // waits per job: level counts, set sizes, results -- is for jobs that have the reads to fill it.  Alone on a GPU it overtakes the host
-    // search at ~100 reads per job on WGS-like indel densities and ~50 on dense ones (tools/diag/enum_threshold.py); with eight caller
-    // processes sharing the GPU a device job costs 0.56 ms inside the C-ABI against 0.30 ms for the host search + one scoring launch
-    // (profiles/r04_v43_e2e_device_enumeration.json: every job on the device, 32 Mb: +0.9 s over the eight processes, +0.2 s of wall
-    // time, identical output; the enumerated reads are 36 % of the jobs' reads, the gate settles the rest): 512 stays.  An explicit
-    // $SK_ENUMERATION decides for every job (the tests run whole suites in one mode).
+    // Every job's search, flattening, scoring and stage 3 run on the device (enumeration 2): as ONE fixed sequence of launches with one
+    // host wait (csrc/read_enumerate.hip, job_scan_kernel), staged in and out by kernels, with the window of the reference its reads can
+    // reach.  In that form a job costs less inside the C-ABI than the host statement of the search + one scoring launch did, alone on a
+    // GPU (0.25 against 0.33 ms) and with eight caller processes sharing it (0.35 against 0.39 ms; profiles/r05_enum_job_history.txt) --
+    // round 4's three-wait form, with the whole contig segment copied and uploaded per job, cost 0.56 ms and the adapter kept jobs under
+    // 512 reads on the host.  $STRELKA_AMD_DEVICE_ENUM_MIN_READS brings a threshold back; an explicit $SK_ENUMERATION decides for every
+    // job (the tests run whole suites in one mode).
     {
         static const bool isModePinned(std::getenv("SK_ENUMERATION") != nullptr);
-        static const size_t minDeviceReads([]() { const char* v(std::getenv("STRELKA_AMD_DEVICE_ENUM_MIN_READS")); return (v && *v) ? static_cast<size_t>(std::strtoul(v, nullptr, 10)) : size_t(512); }());
+        static const size_t minDeviceReads([]() { const char* v(std::getenv("STRELKA_AMD_DEVICE_ENUM_MIN_READS")); return (v && *v) ? static_cast<size_t>(std::strtoul(v, nullptr, 10)) : size_t(1); }());
         if ((! isModePinned) && ro.enumeration == 2 && reads.size() < minDeviceReads) ro.enumeration = 0;
         if (ro.enumeration != 2) s.realignHostJobs++;
     }

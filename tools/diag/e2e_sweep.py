@@ -24,6 +24,7 @@ ENV_SETS = [
     ("staged_chain", {"SK_A5_FUSED": "0"}),
     ("min_reads_1", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1"}),
     ("min_reads_32", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "32"}),
+    ("gvcf_fast_off", {"STRELKA_AMD_GVCF_FAST": "0"}),
     ("min_reads_1_three_waits", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1", "SK_ENUM_ONE_WAIT": "0"}),
 ]
 if os.environ.get("SK_SWEEP_ONLY"):  # a comma-separated choice of the settings above
@@ -57,13 +58,18 @@ def main():
     farm.run_farm([[(0, "chrW", 1, min(L, 50000), 0)]], argv_fn(drop_in), os.path.join(root, "warm"), OUTPUTS, jobs=1)
     for name, env in ENV_SETS:
         res = farm.run_farm(groups, argv_fn(drop_in), os.path.join(root, name), OUTPUTS, jobs=procs, env=dict(env, STRELKA_AMD_VERBOSE="1"))
-        counters, hooks = {}, {}
+        counters, hooks, gvcf = {}, {}, {}
         for tail in res.stderr_tails:
             m = re.search(r"strelka_amd adapter: (.*)", tail)
             if m:
                 for kv in m.group(1).split():
                     k, v = kv.split("=")
                     counters[k] = counters.get(k, 0) + int(v)
+            m = re.search(r"strelka_amd adapter gvcf: (.*)", tail)
+            if m:
+                for kv in m.group(1).split():
+                    k, v = kv.split("=")
+                    gvcf[k] = gvcf.get(k, 0) + int(v)
             m = re.search(r"strelka_amd adapter seconds: (.*)", tail)
             if m:
                 for kv in m.group(1).split():
@@ -74,6 +80,7 @@ def main():
                "speedup": ref.wall_s / res.wall_s, "realign_jobs": counters.get("realign_jobs"), "realign_job_reads": counters.get("realign_job_reads"),
                "enum_device_reads": counters.get("enum_device_reads"), "enum_host_instead": counters.get("enum_host_instead"),
                "enum_jobs": {k[len("enum_jobs_"):]: v for k, v in counters.items() if k.startswith("enum_jobs_")},
+               "gvcf": gvcf,
                "device_share": (counters.get("enum_device_reads", 0) / max(1, counters.get("realign_job_reads", 1))), "hook_seconds": hooks}
         report["runs"].append(row)
         print(json.dumps(row), flush=True)
