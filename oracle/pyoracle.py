@@ -876,3 +876,45 @@ def ref_bai_query(bam_path, tid, begin, end):
     if n < 0:
         raise RuntimeError("ref_bai_query: no index / no iterator")
     return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n)]
+
+
+def gvcf_site_summaries(batch, genotypes):
+    """What the gVCF writer's block logic reads of a position (sk_gvcf_site_summary), in numpy / plain Python, from the reference's
+    statements: getSiteAltAlleles' rank pass (L/applications/starling/starling_pos_processor.cpp:527-560: per sample the `ploidy` most
+    frequent bases, a base ranked only with at least max(1, unsigned(0.10 * depth)) calls; ties go to the lower base index), its pass over
+    the two most likely genotypes (:578-611), LocusSampleInfo::setGqx (gvcf_locus_info.hh:356-369) and the AD counts
+    (updateSnvLocusWithSampleInfo :452-466).  A position is PLAIN when the reference base is known, the caller ploidy is 2, the cleaned
+    column is not empty and no alternate allele would be listed.  -> array of (flags, gqx, ref_fwd, ref_rev)"""
+    out = np.zeros(batch.n_loci, np.dtype([("flags", np.uint32), ("gqx", np.int32), ("ref_fwd", np.uint32), ("ref_rev", np.uint32)]))
+    off = np.asarray(batch.call_off)
+    for i in range(batch.n_loci):
+        ref = int(batch.ref_base[i])
+        g = genotypes[i]
+        if ref > 3 or not int(g["is_called"]):
+            continue
+        calls = np.asarray(batch.calls[off[i]:off[i + 1]]).astype(np.int64)
+        base = (calls >> 6) & 0xf
+        fwd = (calls >> 10) & 1
+        cnt = np.zeros((4, 2), np.int64)
+        for b, f in zip(base, fwd):
+            if b <= 3:
+                cnt[b, f] += 1
+        c = cnt.sum(axis=1).astype(np.float64)
+        min_count = max(1, int(float(int(c.sum())) * 0.10))
+        ploidy = int(batch.ploidy[i]) if batch.ploidy is not None else 2
+        alt = False
+        for _ in range(min(ploidy, 2)):
+            mb = 0
+            for b in range(1, 4):
+                if c[b] > c[mb]:
+                    mb = b
+            if c[mb] >= min_count and mb != ref:
+                alt = True
+            c[mb] = 0
+        hom_ref = int(g["poly"]["max_gt"]) == ref and int(g["genome"]["max_gt"]) == ref
+        out["gqx"][i] = min(int(g["genome"]["max_gt_qphred"]), int(g["poly"]["max_gt_qphred"]))
+        out["ref_fwd"][i] = cnt[ref, 1]
+        out["ref_rev"][i] = cnt[ref, 0]
+        if ploidy == 2 and len(calls) > 0 and not alt and hom_ref:
+            out["flags"][i] = 1
+    return out

@@ -554,6 +554,15 @@ def site_digt_call_fused(batch, opt=None, want_de=False):
     return out, de
 
 
+def gvcf_site_summaries(batch, genotypes):
+    """sk_gvcf_site_summary of every locus of `batch` (its cleaned columns) given the genotype records sk_site_digt_call_fused left"""
+    out = np.zeros(batch.n_loci, GVCF_SITE_SUMMARY_DTYPE)
+    s = batch.struct()
+    g = np.ascontiguousarray(genotypes)
+    _check(lib().sk_gvcf_site_summaries(C.byref(s), _p(g), _p(out)))
+    return out
+
+
 def somatic_snv_call(normal, tumor, opt=None, is_forced_output=False):
     opt = opt or somatic_snv_options()
     out = np.zeros(normal.n_loci, SOMATIC_CALL_DTYPE)

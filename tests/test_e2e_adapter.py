@@ -497,3 +497,96 @@ def test_reads_over_the_pileup_limit_are_refused_with_the_way_out(tmp_path):
         outs[v] = E.vcf_body(o + "variants.vcf", keep_header=True)
     assert sum(1 for l in outs["ref"] if not l.startswith("#")) >= 5
     assert outs["dbl"] == outs["ref"]
+
+
+# ---- site 10: the gVCF writer's non-variant blocks fed from the stream's window (adapter/sk_adapter_gvcf.cpp) ---------------------
+# The fast path is taken for ONE sample (several samples keep the reference's path), so the two-sample runs above never reach it.  One
+# sample of each dense synthetic set -- indel clusters (positions inside a called deletion have their ploidy lowered: declined by
+# state; variant indels buffered in the overlap resolver; the phaser's open active regions), a coverage gap (the writer's skip_to_pos
+# fills it between two injected sites), soft clips, MAPQ tiers, 250 bp reads -- alone and with what changes the writer's decisions
+# from outside: forced-output positions, external candidate indels, a ploidy VCF with haploid and zero-ploidy stretches, a
+# no-compress BED.  Everything the reference writes must come out the same; the counters say the path was the routed one.
+def _gvcf_counters(stderr):
+    m = re.search(r"strelka_amd adapter gvcf: (.*)", stderr)
+    return {k: int(v) for k, v in (kv.split("=") for kv in m.group(1).split())} if m else {}
+
+
+def _single_sample(variant, tmp_path, which, sample="germline_S1.bam", extra=(), env=None, min_plain=0.7):
+    d, length = SYNTH_SETS[which]
+    region, fa = "chrS:1-%d" % length, os.path.join(d, "synth.fa")
+    outs, err = {}, None
+    for v in ("ref", variant):
+        o = str(tmp_path / v) + "/"
+        os.makedirs(o, exist_ok=True)
+        outs[v] = o
+        e = dict({"STRELKA_AMD_VERBOSE": "1"}, **(env or {})) if v != "ref" else None
+        p = E.run(E.germline_argv("starling2_" + v, o, [os.path.join(d, sample)], region=region, ref=fa, extra=list(extra)), env=e)
+        if v != "ref":
+            err = p.stderr.decode()
+    for f in ("variants.vcf", "genome.S1.vcf"):
+        want, got = E.vcf_body(outs["ref"] + f, keep_header=True), E.vcf_body(outs[variant] + f, keep_header=True)
+        assert len(want) > 100
+        assert got == want, (which, sample, f)
+    g = _gvcf_counters(err)
+    if (env or {}).get("STRELKA_AMD_GVCF_FAST") == "0":
+        assert g.get("gvcf_plain_sites", 0) == 0
+    else:
+        covered = g["gvcf_plain_sites"] + g["gvcf_reference_sites"]
+        assert covered > 0.5 * length and g["gvcf_plain_sites"] >= min_plain * covered, g
+    return g, outs
+
+
+def _ploidy_and_nocompress(tmp_path, length):
+    """a ploidy VCF (haploid and zero-ploidy stretches, PY/strelkaGermlineWorkflow.py:131-132) and a no-compress BED (:128-129)"""
+    import subprocess
+    pv = tmp_path / "ploidy.vcf"
+    rows = [(3001, 5000, 1), (9001, 9500, 0), (20001, 26000, 1), (length - 4000, length - 3000, 0)]
+    pv.write_text("##fileformat=VCFv4.1\n##FORMAT=<ID=CN,Number=1,Type=Integer,Description=\"copy number\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n" +
+                  "".join("chrS\t%d\t.\tN\t<CNV>\t.\tPASS\tEND=%d\tCN\t%d\n" % (b, e, cn) for b, e, cn in rows))
+    bed = tmp_path / "nocompress.bed"
+    bed.write_text("chrS\t1500\t1700\nchrS\t12000\t12040\nchrS\t30000\t30900\n")
+    for v, preset in ((pv, "vcf"), (bed, "bed")):
+        subprocess.run([os.path.join(E.BIN_DIR, "bgzip"), "-f", str(v)], check=True)
+        subprocess.run([os.path.join(E.BIN_DIR, "tabix"), "-p", preset, str(v) + ".gz"], check=True)
+    return ["--ploidy-region-vcf", str(pv) + ".gz", "--nocompress-bed", str(bed) + ".gz"]
+
+
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
+@pytest.mark.parametrize("which,sample,windows", [("short_reads", "germline_S1.bam", None), ("short_reads", "germline_S2.bam", (500, 0)),
+                                                  ("short_reads", "germline_S1.bam", (1500, 100)), ("long_reads", "germline_S1.bam", None),
+                                                  ("long_reads", "germline_S2.bam", (64, 0))])
+def test_single_sample_gvcf_blocks_from_the_window_cpu_double(tmp_path, which, sample, windows):
+    env = {} if windows is None else {"STRELKA_AMD_READ_WINDOW": str(windows[0]), "STRELKA_AMD_SITE_WINDOW": str(windows[1])}
+    g, _ = _single_sample("dbl", tmp_path, which, sample, env=env)
+    assert g["gvcf_plain_declined_by_state"] > 50  # positions under called deletions / beside buffered variant indels took the reference's path
+
+
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
+def test_single_sample_gvcf_fast_path_switched_off(tmp_path):
+    _single_sample("dbl", tmp_path, "short_reads", env={"STRELKA_AMD_GVCF_FAST": "0"})
+
+
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth() and os.path.exists(os.path.join(E.BIN_DIR, "tabix"))),
+                    reason="oracle/_ref binaries / synthetic inputs / tabix not built")
+@pytest.mark.parametrize("inputs", ["forced_and_candidates", "ploidy_and_nocompress", "all"])
+def test_single_sample_gvcf_blocks_with_outside_inputs_cpu_double(tmp_path, inputs):
+    d, length = SYNTH_SETS["short_reads"]
+    extra = []
+    if inputs in ("forced_and_candidates", "all"):
+        extra += _variant_inputs(tmp_path, d, length)
+    if inputs in ("ploidy_and_nocompress", "all"):
+        extra += _ploidy_and_nocompress(tmp_path, length)
+    g, outs = _single_sample("dbl", tmp_path, "short_reads", extra=extra, min_plain=0.5)
+    if inputs != "forced_and_candidates":
+        body = "\n".join(E.vcf_body(outs["ref"] + "genome.S1.vcf"))
+        assert "PloidyConflict" in body or "\t.:" in body or "\t0:" in body  # (the haploid / zero-ploidy stretches reached the output)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_amd") and _have_synth() and os.path.exists(os.path.join(E.BIN_DIR, "tabix"))),
+                    reason="oracle/_ref binaries / synthetic inputs / tabix not built")
+@pytest.mark.parametrize("which,inputs", [("short_reads", None), ("long_reads", None), ("short_reads", "all")])
+def test_single_sample_gvcf_blocks_from_the_window_gpu(tmp_path, which, inputs):
+    d, length = SYNTH_SETS[which]
+    extra = (_variant_inputs(tmp_path, d, length) + _ploidy_and_nocompress(tmp_path, length)) if inputs else []
+    _single_sample("amd", tmp_path, which, extra=extra, min_plain=0.5)

@@ -241,6 +241,31 @@ def test_site_digt_call_fused_nondefault_options(gpu):
         assert np.array_equal(fused["lhood"].view(np.uint32), want["lhood"].view(np.uint32)), kw
 
 
+def test_gvcf_site_summaries(gpu):
+    """gvcf_site_summary_kernel (csrc/gvcf_site_core.h: would process_pos_snp_digt build a homozygous-reference locus with no alternate
+    allele here?  its GQX, its reference AD counts) against the numpy statement of the reference's getSiteAltAlleles / setGqx / AD loop
+    (oracle/pyoracle.py), on ordinary 40x loci, het and hom-alt sites, noisy and shallow columns, haploid and N-reference loci"""
+    rng = np.random.default_rng(2290)
+    pb = _varied_pileups(rng)
+    pb.ploidy = rng.choice(np.array([1, 2, 2, 2], np.uint8), pb.n_loci)
+    pb.ref_base[::41] = 4
+    calls, _ = gpu.site_digt_call_fused(pb)
+    got = gpu.gvcf_site_summaries(pb, calls)
+    want = pyoracle.gvcf_site_summaries(pb, calls)
+    assert got.tobytes() == want.tobytes()
+    plain = (got["flags"] & 1) != 0
+    assert 0.3 < plain.mean() < 0.95 and (~plain).sum() > 500  # (the batch holds plenty of both kinds)
+    # a plain site: diploid, reference known, covered, both most likely genotypes the homozygous-reference one
+    assert (pb.ploidy[plain] == 2).all() and (pb.ref_base[plain] < 4).all()
+    assert (calls["poly"]["max_gt"][plain] == pb.ref_base[plain]).all() and (calls["genome"]["max_gt"][plain] == pb.ref_base[plain]).all()
+    # ... and on a 40x batch with human variant density nearly every position is one
+    pw = synth.pileups(20000, rng)
+    cw, _ = gpu.site_digt_call_fused(pw)
+    sw = gpu.gvcf_site_summaries(pw, cw)
+    assert sw.tobytes() == pyoracle.gvcf_site_summaries(pw, cw).tobytes()
+    assert ((sw["flags"] & 1) != 0).mean() > 0.97
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_site_digt_call_fused_every_kernel_variant(gpu, variant):
     """csrc/germline_fused.hip holds round 1's kernel (0) and the second statement (1: tabled + pending ranked terms, calls read

@@ -92,6 +92,9 @@ def _compare(wins, want, ref, off, kw, ploidy=None, genotype=True):
             de = pyoracle.adjust_joint_eprob(pb)
             wg = pyoracle.site_digt_call(pb, de)
             assert w["genotype"].tobytes() == wg.tobytes()
+            # ... and what the gVCF writer's block logic reads of each position (site 10): plain site?, GQX, reference AD counts
+            ws = pyoracle.gvcf_site_summaries(pb, wg)
+            assert w["site_summary"].tobytes() == ws.tobytes()
     # positions no window reported have nothing in them
     quiet = ~covered
     assert not np.diff(want["o1"])[quiet].any() and not np.diff(want["o2"])[quiet].any()
