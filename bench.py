@@ -134,7 +134,7 @@ def cpu_baseline(args):
             "loci_per_s": args.cpu_loci / tb}
 
 
-def whole_read_leg(args, capi, synth, rng, enumeration=2, max_indels=6, reads=None):
+def whole_read_leg(args, capi, synth, rng, enumeration=2, max_indels=6, reads=None, host_threads=1):
     """Rows a1-a7 end to end: reads -> sk_realign_job_add_reads (gate, normalisation) -> run (candidate-alignment enumeration,
     flattening, scoring; then selection and score_indels on the host) on the same scenario distribution the reference's
     realignAndScoreRead is timed on (oracle/ref_timing.py).  Host buffers in and out, PCIe included: this is the path the adapter
@@ -162,7 +162,7 @@ def whole_read_leg(args, capi, synth, rng, enumeration=2, max_indels=6, reads=No
         if not ok:
             continue
         job = capi.RealignJob(capi.realign_options(is_haplotyping_enabled=sc["is_haplotyping_enabled"],
-                                                   min_read_bp_flank=sc["min_read_bp_flank"], enumeration=enumeration))
+                                                   min_read_bp_flank=sc["min_read_bp_flank"], enumeration=enumeration, host_threads=host_threads))
         job.set_reference(sc["ref_seq"], sc["ref_offset"])
         job.set_indels(sc["indels"])
         n = len(ok) * rep
@@ -689,9 +689,15 @@ def main():
 
     # ---- rows a1-a7: the whole read path as the adapter drives it (host stages + kernel), one host thread ----
     wr = {}
+    from strelka_amd import farm as _farm
+    n_cores = len(_farm.usable_cores())
     for name, kw in (("", dict(enumeration=2)), ("_host_enumeration", dict(enumeration=0)),
                      ("_dense", dict(enumeration=2, max_indels=14, reads=args.realign_reads // 6)),
-                     ("_dense_host_enumeration", dict(enumeration=0, max_indels=14, reads=args.realign_reads // 6))):
+                     ("_dense_host_enumeration", dict(enumeration=0, max_indels=14, reads=args.realign_reads // 6)),
+                     # the same jobs with the host stages (gate, normalisation, packing; results into the reads' structures) spread
+                     # over the cores cpu_baseline's realign legs use: sk_realign_options.host_threads
+                     ("_all_cores", dict(enumeration=2, host_threads=n_cores)),
+                     ("_dense_all_cores", dict(enumeration=2, max_indels=14, reads=args.realign_reads // 6, host_threads=n_cores))):
         wr_step, wr_reads, wr_cals = whole_read_leg(args, capi, synth, np.random.default_rng(4242), **kw)
         n_wr = max(2, args.steps // 4)
         dt_wr, wr_done, _ = timed(wr_step, n_wr, 1, wr_reads)
@@ -789,11 +795,12 @@ def main():
         "roofline_allele_group": roof("allele_group_kernel", group_alg_bytes, kms_g, traffic.get("allele_group_kernel")),
         "roofline_pileup": roof("pileup_read_kernel+2*pileup_column_kernel_t", pileup_alg_bytes, kms_p, pil_traffic),
         "roofline_global_align": roof("global_align_kernel", ga_alg_bytes, kms_ga, traffic.get("global_align_kernel")),
-        "realign_host_threads": 1,
+        "realign_host_threads": 1, "realign_all_cores_host_threads": n_cores,
         "realign_note": "whole read path (rows a1-a7) through sk_realign_job_add_reads + _run, one host thread, host buffers in and out; "
                         "realign_* = candidate alignments listed, flattened, scored and selected / indel-scored (stage 3) on the device "
                         "(enumeration=2), *_host_enumeration = listed, flattened and finished on the host (round 1's path), *_dense = scenarios "
-                        "with up to 14 indels around a read",
+                        "with up to 14 indels around a read, *_all_cores = the device path with the job's host stages on as many host threads as "
+                        "cpu_baseline's realign legs have cores (sk_realign_options.host_threads)",
         "feed_inflated_bytes_per_s": feed_bytes / dt_f, "feed_ms_per_step": dt_f / max(2, args.steps // 4) * 1e3, "feed_bgzf_blocks_per_step": feed_blocks,
         "roofline_feed": roof("bgzf_inflate_kernel+bgzf_crc32_kernel", feed_alg_bytes, kms_f,
                               (traffic["bgzf_inflate_kernel"] + traffic["bgzf_crc32_kernel"]) if all(k in traffic for k in ("bgzf_inflate_kernel", "bgzf_crc32_kernel")) else None),
