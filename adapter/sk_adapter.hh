@@ -43,6 +43,8 @@ struct alignment;
 class ActiveRegionReadBuffer;
 struct bam_seq_base;
 
+struct sk_pileup_stream; // (include/strelka_amd.h)
+
 namespace sk_adapter
 {
 
@@ -103,6 +105,9 @@ bool germline_sample_stats_counts(starling_pos_processor_base& pp, const pos_t p
 /// homozygous-reference site and has gone into the writer's open block (gvcf_writer::skip_to_pos + add_site_internal on a kept
 /// locus); false = the reference's process_pos_snp runs (its cleaned pileup is made first if process_pos_sample_stats left it out)
 bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos);
+/// at the start of a region: the options that decide a plain site's filters and block membership (gvcf_options, the chromosome's depth
+/// ceiling) to the sample's pileup stream, which then returns the block that would start at every plain site (sk_gvcf_run)
+void gvcf_configure_stream(starling_pos_processor_base& pp, const unsigned sampleIndex, ::sk_pileup_stream* stream);
 
 /// the tumor sample's readPositionRankSum / altAlleleReadPositionInfo of `pos` (updateSomaticScoringMetrics,
 /// starling_pos_processor_base.cpp:984-1000), rebuilt from the pileup stream's window before the position's record is written

@@ -38,6 +38,11 @@ struct Access
     static bool isPosReportable(const base_t& pp, const pos_t pos) { return pp.is_pos_reportable(pos); }
     static unsigned ploidy(const base_t& pp, const pos_t pos, const unsigned sampleIndex) { return pp.get_ploidy(pos, sampleIndex); }
     static bool isForcedOutputPos(const base_t& pp, const pos_t pos) { return pp.is_forced_output_pos(pos); }
+    static bool isAnyForcedOutputPos(const base_t& pp, const pos_t begin, const pos_t end)
+    {
+        const auto it(pp._forced_output_pos.lower_bound(begin));
+        return it != pp._forced_output_pos.end() && *it < end;
+    }
     static void clearActiveRegionReadBuffer(base_t& pp, const pos_t pos) { pp._getActiveRegionDetector().clearReadBuffer(pos); }
     static const CandidateSnvBuffer& candidateSnvBuffer(const base_t& pp) { return pp._candidateSnvBuffer; }
     static bool hasPloidyRegions(const base_t& pp, const unsigned sampleIndex) { return ! pp.sample(sampleIndex).ploidyRegions.empty(); }
@@ -116,6 +121,7 @@ struct SiteChunk
     std::vector<uint8_t> ploidy;      ///< ... and the ploidy
     std::vector<uint32_t> rawCount;   ///< calls of the raw tier1 column the window wrote into the reference's buffer
     std::vector<sk_gvcf_site_summary> summary; ///< what the gVCF writer's block logic reads of each position (site 10)
+    std::vector<sk_gvcf_run> runs;    ///< ... and the non-variant block that would start at each plain position
     // germline EVS: the per-call arguments of updateGermlineScoringMetrics, kept until POST_ALIGN has passed the chunk
     std::vector<int64_t> evsOff;      ///< [n+1]
     std::vector<uint64_t> evsWords;

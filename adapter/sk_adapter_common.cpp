@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <iostream>
 #include <sstream>
+#include <string>
+#include <thread>
 
 namespace sk_adapter
 {
@@ -50,11 +52,20 @@ unsigned post_align_defer(const starling_base_options& opt)
     return static_cast<unsigned>(g_postAlignDefer);
 }
 
-void init()
+namespace
 {
-    static bool done(false);
-    if (done) return;
-    AccumTimer initTimer(state().tInit);
+
+/// sk_init as it has always been made here: the device of this segment process, strict unless told otherwise
+struct InitOutcome
+{
+    int rc = 0;
+    bool isInexactLibm = false;
+    std::string what, error;
+};
+
+InitOutcome run_sk_init()
+{
+    InitOutcome o;
     // segment process -> device: pyflow starts one process per genome segment; the launcher (or the workflow's task
     // wrapper) exports STRELKA_AMD_DEVICE = segment index mod number of GPUs.  Many processes may share a device.
     // (a launcher may count more devices than this node has: the index is taken modulo the devices present)
@@ -63,15 +74,62 @@ void init()
     // byte-identical VCFs need the kernels' restated libm routines to be the host's: strict by default
     if (env_unsigned("STRELKA_AMD_ALLOW_INEXACT_LIBM", 0) == 0)
     {
-        check(sk_init_strict(device), "sk_init_strict");
+        o.what = "sk_init_strict";
+        o.rc = sk_init_strict(device);
     }
     else
     {
-        check(sk_init(device), "sk_init");
-        if (sk_libm_restated() != 1)
-        {
-            log_os << "WARNING: strelka_amd runs with the device math library; outputs may differ from the reference in the last digit\n";
-        }
+        o.what = "sk_init";
+        o.rc = sk_init(device);
+        if (o.rc == 0) o.isInexactLibm = (sk_libm_restated() != 1);
+    }
+    if (o.rc != 0) o.error = sk_last_error();
+    return o;
+}
+
+/// The GPU runtime's start-up (0.2-0.4 s: context, first allocation, tables) on a thread of its own from the moment the program is
+/// loaded, beside the caller's own start-up (options, the reference segment, the alignment files' indices, the scoring models):
+/// init() -- the first hook to run -- waits for it.  $STRELKA_AMD_EARLY_INIT=0: sk_init where it always was.
+struct EarlyInit
+{
+    std::thread worker;
+    InitOutcome outcome;
+    bool isStarted = false;
+    EarlyInit()
+    {
+        if (env_unsigned("STRELKA_AMD_EARLY_INIT", 1) == 0) return;
+        isStarted = true;
+        worker = std::thread([this]() { outcome = run_sk_init(); });
+    }
+    ~EarlyInit()
+    {
+        if (worker.joinable()) worker.join();
+    }
+};
+EarlyInit g_earlyInit;
+
+}
+
+void init()
+{
+    static bool done(false);
+    if (done) return;
+    AccumTimer initTimer(state().tInit);
+    InitOutcome o;
+    if (g_earlyInit.isStarted)
+    {
+        if (g_earlyInit.worker.joinable()) g_earlyInit.worker.join();
+        o = g_earlyInit.outcome;
+        if (o.rc == 0) o = run_sk_init(); // (returns at once: the library is up; the current device is set for THIS thread)
+    }
+    else
+    {
+        o = run_sk_init();
+    }
+    if (o.rc != 0) throw blt_exception((std::string("strelka_amd: ") + o.what + ": " + o.error).c_str());
+    if (o.isInexactLibm)
+    {
+        log_os << "WARNING: strelka_amd runs with the device math library; outputs may differ from the reference in the last digit\n";
     }
     done = true;
 }

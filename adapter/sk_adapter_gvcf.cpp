@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <memory>
 
@@ -56,6 +57,20 @@ struct GvcfAccess
         return w._lastVariantIndelWritten && pos < w._lastVariantIndelWritten->end();
     }
     static bool isCompressible(const gvcf_writer& w, const GermlineSiteLocusInfo& locus) { return w._gvcf_comp.is_site_compressible(locus); }
+    static gvcf_block_site_record& sampleBlock(gvcf_writer& w, const unsigned sampleIndex) { return w._blockPerSample[sampleIndex]; }
+    static bool isRangeCompressible(const gvcf_writer& w, const pos_t begin, const pos_t end)
+    {
+        return w._gvcf_comp.is_range_compressible(known_pos_range2(begin, end));
+    }
+    static void setHeadPos(gvcf_writer& w, const pos_t pos) { w._headPos = pos; }
+    /// a stream_stat as `count` calls of add() left it: running mean, maximum, minimum (Q, the variance's sum, is read by nothing here)
+    static void setStat(stream_stat& ss, const double mean, const double max, const double min, const unsigned count)
+    {
+        ss.M_ = mean;
+        ss.max_ = max;
+        ss.min_ = min;
+        ss.k_ = count;
+    }
     /// gvcf_writer::process(site) without the ownership (gvcf_writer.cpp:180-197)
     static void writerProcessSite(gvcf_writer& w, GermlineSiteLocusInfo& locus)
     {
@@ -73,14 +88,19 @@ struct GvcfFast
     bool isCleanSkipped = false; ///< process_pos_sample_stats took the counts of cleanSkippedPos from the window and did not clean its pileup
     pos_t cleanSkippedPos = 0;
     std::unique_ptr<GermlineDiploidSiteLocusInfo> scratch;
+    bool isBlocks = false; ///< the window brings the block that would start at every plain site (sk_gvcf_run): whole blocks are installed
+    pos_t blockTo = 0;     ///< positions below are members of the block installed last (their process_pos_snp has nothing left to do)
     unsigned long plainSites = 0, referenceSites = 0, declinedByState = 0;
+    unsigned long blocksInstalled = 0, blockSites = 0, blocksDeclined = 0, filterKeyMismatches = 0;
     ~GvcfFast()
     {
         const char* v(std::getenv("STRELKA_AMD_VERBOSE"));
         if (v && std::atoi(v) != 0)
         {
             std::cerr << "strelka_amd adapter gvcf: gvcf_plain_sites=" << plainSites << " gvcf_reference_sites=" << referenceSites
-                      << " gvcf_plain_declined_by_state=" << declinedByState << "\n";
+                      << " gvcf_plain_declined_by_state=" << declinedByState << " gvcf_blocks_installed=" << blocksInstalled
+                      << " gvcf_block_sites=" << blockSites << " gvcf_blocks_declined=" << blocksDeclined
+                      << " gvcf_filter_key_mismatches=" << filterKeyMismatches << "\n";
         }
     }
 };
@@ -100,6 +120,10 @@ bool decide(starling_pos_processor& pp)
     const char* v(std::getenv("STRELKA_AMD_GVCF_FAST"));
     const bool isOn(! (v && *v == '0'));
     State& s(state());
+    {
+        const char* b(std::getenv("STRELKA_AMD_GVCF_BLOCKS"));
+        g.isBlocks = ! (b && *b == '0');
+    }
     g.enabled = isOn && s.pileup.enabled && s.pileup.isGenotyping && (Access::sampleCount(pp) == 1) && opt.is_bsnp_diploid() &&
                 opt.gvcf.is_gvcf_output() && (! opt.isUseCallRegions()) && (GvcfAccess::aggregator(pp) != nullptr);
     if (g.enabled)
@@ -137,6 +161,35 @@ bool isPlainInWindow(const SiteChunk& c, const size_t k, const snp_pos_info& pi)
 
 }
 
+void gvcf_configure_stream(starling_pos_processor_base& pp, const unsigned sampleIndex, sk_pileup_stream* stream)
+{
+    // (before the first position of the region is called: the decision of decide() is not made yet -- a stream that turns out not to
+    // feed the writer only carries the runs along)
+    starling_pos_processor* spp(dynamic_cast<starling_pos_processor*>(&pp));
+    if (spp == nullptr || sampleIndex != 0 || stream == nullptr) return;
+    const starling_options& opt(GvcfAccess::opt(*spp));
+    gvcf_aggregator* agg(GvcfAccess::aggregator(*spp));
+    {
+        const char* b(std::getenv("STRELKA_AMD_GVCF_BLOCKS"));
+        const char* f(std::getenv("STRELKA_AMD_GVCF_FAST"));
+        if ((b && *b == '0') || (f && *f == '0') || agg == nullptr || (! opt.gvcf.is_gvcf_output()) || Access::sampleCount(pp) != 1) return;
+    }
+    sk_gvcf_block_options bo;
+    std::memset(&bo, 0, sizeof(bo));
+    bo.min_passed_call_depth = opt.gvcf.minPassedCallDepth;
+    bo.is_min_homref_gqx = opt.gvcf.is_min_homref_gqx ? 1 : 0;
+    bo.min_homref_gqx = opt.gvcf.min_homref_gqx;
+    bo.is_max_base_filt = opt.gvcf.is_max_base_filt ? 1 : 0;
+    bo.max_base_filt = opt.gvcf.max_base_filt;
+    // ScoringModelManager::default_classify_site :293-302: the depth ceiling of the chromosome the region lies on (resetChrom :80-97,
+    // called by gvcf_aggregator::resetRegion before the region's first read)
+    bo.is_max_depth = GvcfAccess::dopt(*spp).gvcf.is_max_depth() ? 1 : 0;
+    bo.max_chrom_depth = bo.is_max_depth ? agg->getMaxDepth() : 0.;
+    bo.block_percent_tol = opt.gvcf.block_percent_tol;
+    bo.block_abs_tol = opt.gvcf.block_abs_tol;
+    check(sk_pileup_stream_set_gvcf_block_options(stream, &bo), "sk_pileup_stream_set_gvcf_block_options");
+}
+
 bool germline_sample_stats_counts(starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex, unsigned& used, unsigned& unused)
 {
     GvcfFast& g(gf());
@@ -172,6 +225,12 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
         if (! pi.calls.empty()) g.referenceSites++;
         return false;
     };
+    if (pos < g.blockTo)
+    {
+        // a member of the block installed at its first site: joined already
+        if (! isCleanSkipped) throw blt_exception("strelka_amd adapter: a position of an installed gVCF block is no longer a plain site of the window");
+        return true;
+    }
     if (! isCleanSkipped) return referencePath(); // (not plain in the window, or the counts did not come from it)
 
     const SiteChunk* c(chunkAt(pos));
@@ -247,6 +306,76 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
 
     GvcfAccess::writerProcessSite(*writer, locus);
     g.plainSites++;
+
+    // ---- whole blocks: when this site has just STARTED the sample's block, the device has already walked the writer's greedy joining
+    // from it over the plain sites that follow (sk_gvcf_run, gvcf_plain_run_kernel: testCanSiteJoinSampleBlock / joinSiteToSampleBlock
+    // site after site).  If nothing can happen at those positions that the window did not know -- no indel key, no forced position, no
+    // active region, the ploidy and the columns the window's -- the block is brought to the state those joins leave (count, the three
+    // running statistics, the writer's head) and the positions have nothing left to do when process_pos_snp reaches them.  The site
+    // that ends the block, plain or not, meets that block through the reference's own test.
+    if (g.isBlocks && (! c->runs.empty()))
+    {
+        gvcf_block_site_record& block(GvcfAccess::sampleBlock(*writer, 0));
+        const sk_gvcf_run& run(c->runs[k]);
+        const pos_t end(std::min(pos + static_cast<pos_t>(run.len), std::min(c->end, Access::reportRange(base).end_pos())));
+        if (block.count == 1 && block.pos == pos && end > pos + 1)
+        {
+            bool isSafe(true);
+            // the filters the device gave the block's sites are the ones the reference has just given this one
+            {
+                const GermlineFilterKeeper& f(sampleInfo.filters);
+                GermlineFilterKeeper known;
+                uint32_t key(0);
+                if (f.test(GERMLINE_VARIANT_VCF_FILTERS::LowDepth)) { key |= 1u; known.set(GERMLINE_VARIANT_VCF_FILTERS::LowDepth); }
+                if (f.test(GERMLINE_VARIANT_VCF_FILTERS::LowGQX)) { key |= 2u; known.set(GERMLINE_VARIANT_VCF_FILTERS::LowGQX); }
+                if (f.test(GERMLINE_VARIANT_VCF_FILTERS::HighDepth)) { key |= 4u; known.set(GERMLINE_VARIANT_VCF_FILTERS::HighDepth); }
+                if (f.test(GERMLINE_VARIANT_VCF_FILTERS::HighBaseFilt)) { key |= 8u; known.set(GERMLINE_VARIANT_VCF_FILTERS::HighBaseFilt); }
+                if (key != run.filter_key || (! (known == f)) || (! locus.filters.none()))
+                {
+                    g.filterKeyMismatches++;
+                    isSafe = false;
+                }
+            }
+            if (isSafe)
+            {
+                IndelBuffer& indelBuffer(Access::indelBuffer(base));
+                isSafe = (indelBuffer.positionIterator(pos + 1) == indelBuffer.positionIterator(end)) &&
+                         (! Access::isAnyForcedOutputPos(base, pos + 1, end)) && GvcfAccess::isRangeCompressible(*writer, pos, end);
+            }
+            const bool isPloidyRegions(Access::hasPloidyRegions(base, 0));
+            const bool isPhasing(phaser != nullptr && GvcfAccess::opt(pp).isUseVariantPhaser);
+            for (pos_t p(pos + 1); isSafe && p < end; ++p)
+            {
+                const snp_pos_info& ppi(sif.basecallBuffer.get_pos(p));
+                isSafe = isPlainInWindow(*c, static_cast<size_t>(p - c->begin), ppi) && ppi.spanningIndelPloidyModification == 0 &&
+                         ((! isPloidyRegions) || Access::ploidy(base, p, 0) == 2) && ((! isPhasing) || Access::activeRegionId(base, p) < 0);
+            }
+            if (isSafe)
+            {
+                const unsigned n(static_cast<unsigned>(end - pos));
+                if (n == static_cast<unsigned>(run.len))
+                {
+                    // joinSiteToSampleBlock x (n - 1): count and the three accumulators (gvcf_block_site_record.cpp:149-156)
+                    block.count = static_cast<int>(n);
+                    GvcfAccess::setStat(block.block_dpu, run.dpu_mean, static_cast<double>(run.dpu_max), static_cast<double>(run.dpu_min), n);
+                    GvcfAccess::setStat(block.block_dpf, run.dpf_mean, static_cast<double>(run.dpf_max), static_cast<double>(run.dpf_min), n);
+                    GvcfAccess::setStat(block.block_gqx, run.gqx_mean, static_cast<double>(run.gqx_max), static_cast<double>(run.gqx_min), n);
+                    GvcfAccess::setHeadPos(*writer, end); // add_site_internal's _headPos = locus.pos + 1 of the last member
+                    g.blockTo = end;
+                    g.blocksInstalled++;
+                    g.blockSites += (n - 1);
+                }
+                else
+                {
+                    g.blocksDeclined++; // (the window or the report range ends inside the block: its sites go one by one)
+                }
+            }
+            else
+            {
+                g.blocksDeclined++;
+            }
+        }
+    }
     return true;
 }
 

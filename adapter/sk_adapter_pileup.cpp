@@ -258,6 +258,7 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
         check(sk_pileup_stream_begin_region(stream, ref.seq().data(), static_cast<int32_t>(ref.get_offset()),
                                             static_cast<int32_t>(ref.seq().size()), ps.regionBegin, ps.regionEnd,
                                             static_cast<int32_t>(Access::largestTotalIndelRefSpanPerRead(pp))), "sk_pileup_stream_begin_region");
+        gvcf_configure_stream(pp, sampleIndex, stream); // (site 10: the chromosome's depth ceiling with the other block options)
         ps.isRegionOpen[sampleIndex] = 1;
     }
 
@@ -326,6 +327,7 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
             if (w.site_summary != nullptr)
             {
                 chunk.summary.assign(w.site_summary, w.site_summary + n);
+                if (w.gvcf_runs != nullptr) chunk.runs.assign(w.gvcf_runs, w.gvcf_runs + n);
                 chunk.rawCount.resize(n);
                 for (size_t i(0); i < n; ++i) chunk.rawCount[i] = static_cast<uint32_t>(w.tier1_off[i + 1] - w.tier1_off[i]);
             }

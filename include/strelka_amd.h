@@ -624,6 +624,33 @@ typedef struct sk_gvcf_site_summary {
     uint32_t ref_fwd, ref_rev; /* cleaned basecalls equal to the reference base, forward / reverse strand */
 } sk_gvcf_site_summary;
 
+/** What decides a plain site's FILTERs and whether it joins the sample's open block: the options ScoringModelManager::applyDepthFilter /
+ *  default_classify_site (L/applications/starling/ScoringModelManager.cpp:234-249, :270-311) and gvcf_block_site_record (tolerances,
+ *  gvcf_block_site_record.hh:38-44) read.  max_chrom_depth belongs to the chromosome (ScoringModelManager::resetChrom :80-97). */
+typedef struct sk_gvcf_block_options {
+    uint32_t min_passed_call_depth;  /* gvcf_options::minPassedCallDepth (LowDepth) */
+    int32_t is_min_homref_gqx;       /* LowGQX of a homozygous-reference site: gqx < min_homref_gqx */
+    double min_homref_gqx;
+    int32_t is_max_depth;            /* HighDepth: the chromosome's depth is known and MapqTracker::count > max_chrom_depth */
+    int32_t is_max_base_filt;        /* HighBaseFilt: unused / (used + unused) > max_base_filt */
+    double max_chrom_depth;
+    double max_base_filt;
+    uint32_t block_percent_tol, block_abs_tol;
+} sk_gvcf_block_options;
+
+/** For a plain site i: the non-variant block that STARTS at it -- gvcf_writer::queue_site_record's greedy joining
+ *  (testCanSiteJoinSampleBlock / joinSiteToSampleBlock, gvcf_block_site_record.cpp:77-182) from an empty block over the plain sites
+ *  that follow it in the window: how many sites it takes in and the block's three stream_stat accumulators (minimum, maximum, running
+ *  mean; stream_stat.hh:56-66) after the last of them.  len = 0: not a plain site.  The block ends where a site cannot join, at a
+ *  site that is not plain, and at the window's end (where it may well go on: the caller lets the next site decide). */
+typedef struct sk_gvcf_run {
+    int32_t len;
+    uint32_t filter_key;           /* which of LowDepth / LowGQX / HighDepth / HighBaseFilt the block's sites carry (bits 0-3) */
+    int32_t gqx_min, gqx_max;
+    uint32_t dpu_min, dpu_max, dpf_min, dpf_max;
+    double gqx_mean, dpu_mean, dpf_mean;
+} sk_gvcf_run;
+
 typedef struct sk_pileup_window {
     int32_t begin, end;              /* positions [begin, end); n = end - begin */
     const int64_t* tier1_off;        /* [n+1] */
@@ -643,6 +670,7 @@ typedef struct sk_pileup_window {
                                         (align_strand_read_pos) | min(20, distance from the read edge) << 29 | is_submapped << 34
                                         (a submapped position carries base id, mapq and the flag only) */
     const sk_gvcf_site_summary* site_summary; /* [n], NULL when the stream does not genotype */
+    const sk_gvcf_run* gvcf_runs;             /* [n], NULL unless sk_pileup_stream_set_gvcf_block_options gave the stream options */
 } sk_pileup_window;
 
 /** genotype_opt: NULL = columns only.  opt->report_begin / report_end / largest_total_indel_ref_span_per_read are set per
@@ -656,6 +684,10 @@ void sk_pileup_stream_destroy(sk_pileup_stream* s);
  *  returns the per-call arguments of that function, evs_off / evs_words, from which the caller rebuilds the four accumulators of the
  *  positions it needs them for. */
 int sk_pileup_stream_enable_evs_words(sk_pileup_stream* s, int enable);
+/** With options (before or at the start of a region; NULL: off) a genotyping stream also returns, for every plain site of a window, the
+ *  non-variant block that would start at it (sk_pileup_window.gvcf_runs): gvcf_block_kernel's walk (csrc/gvcf_block_core.h) made from
+ *  every plain site, on the device, behind the site summaries. */
+int sk_pileup_stream_set_gvcf_block_options(sk_pileup_stream* s, const sk_gvcf_block_options* opt);
 /** resetRegionBase (starling_pos_processor_base.cpp:361-393): the reference segment of the region and its report range */
 int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, int32_t ref_offset, int32_t ref_len,
                                   int32_t report_begin, int32_t report_end, int32_t largest_total_indel_ref_span_per_read);
@@ -1066,6 +1098,10 @@ typedef struct sk_gvcf_block { /* gvcf_block_site_record as write_site_record re
 /** sk_gvcf_site_summary of every locus of a device-resident batch (the cleaned columns as sk_site_digt_call_fused_dev takes them) from
  *  the genotype records that call left: what the pileup stream appends to a window (sk_pileup_window.site_summary). */
 int sk_gvcf_site_summaries_dev(const sk_pileup_batch* dev_batch, const sk_digt_call* dev_genotypes, sk_gvcf_site_summary* dev_out, void* hip_stream);
+/** sk_gvcf_run of every site of a window from its summaries and column sizes (clean_off / raw_off: CSR offsets of the cleaned and the
+ *  raw tier1 columns; dev_pod_scratch: 16 bytes per site): what the pileup stream appends to a window when it has block options. */
+int sk_gvcf_plain_runs_dev(const sk_gvcf_site_summary* dev_summary, const int64_t* dev_clean_off, const int64_t* dev_raw_off, const uint32_t* dev_mapq_count,
+                           const sk_gvcf_block_options* opt, int32_t n, void* dev_pod_scratch, sk_gvcf_run* dev_runs, void* hip_stream);
 /** the same for host arrays (one upload, one launch, one copy back): tests, and callers without a stream */
 int sk_gvcf_site_summaries(const sk_pileup_batch* host_batch, const sk_digt_call* genotypes, sk_gvcf_site_summary* out);
 int sk_gvcf_block_sites(const sk_gvcf_site* sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol, uint8_t* kind,

@@ -478,6 +478,11 @@ extern "C" int sk_gvcf_site_summaries_dev(const sk_pileup_batch*, const sk_digt_
 {
     return sk_fail("sk_gvcf_site_summaries_dev needs the GPU library");
 }
+extern "C" int sk_gvcf_plain_runs_dev(const sk_gvcf_site_summary*, const int64_t*, const int64_t*, const uint32_t*, const sk_gvcf_block_options*, int32_t, void*,
+                                      sk_gvcf_run*, void*)
+{
+    return sk_fail("sk_gvcf_plain_runs_dev needs the GPU library");
+}
 extern "C" int sk_gvcf_block_sites(const sk_gvcf_site* sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol, uint8_t* kind,
                                    sk_gvcf_block* blocks)
 {
@@ -527,6 +532,9 @@ struct sk_pileup_stream
     std::vector<int64_t> o_evoff;
     std::vector<sk_digt_call> o_g;
     std::vector<sk_gvcf_site_summary> o_sum;
+    std::vector<sk_gvcf_run> o_runs;
+    bool want_runs = false;
+    sk_gvcf_block_options gvcf_opt;
     // the cleaned columns of the last emitted range (CleanPileupFilter(pi,false) / (pi,true))
     std::vector<int64_t> k_off, k_off4;
     std::vector<uint16_t> k_calls, k_calls4;
@@ -814,11 +822,36 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
         }
     }
     out->site_summary = s->genotype ? s->o_sum.data() : nullptr;
+    s->o_runs.assign(nl + 1, sk_gvcf_run());
+    if (s->genotype && s->want_runs) {
+        std::vector<skgvcf::SitePod> pod(nl + 1);
+        for (size_t l = 0; l < nl; ++l) {
+            const sk_gvcf_site_summary& sm = s->o_sum[l];
+            skgvcf::SitePod p;
+            p.gqx = sm.gqx;
+            p.used = s->o_cn[l];
+            p.unused = static_cast<uint32_t>(s->o_off1[l + 1] - s->o_off1[l]) - p.used;
+            p.key_plain = (sm.flags & skgvcf::SITE_PLAIN) ? (uint32_t(skgvcf::POD_PLAIN) | skgvcf::site_filter_key(s->gvcf_opt, sm.gqx, p.used, p.unused, sm.ref_fwd + sm.ref_rev, s->o_mn[l])) : 0u;
+            pod[l] = p;
+        }
+        for (size_t l = 0; l < nl; ++l)
+            s->o_runs[l] = skgvcf::plain_run(pod.data(), static_cast<int64_t>(nl), static_cast<int64_t>(l), static_cast<double>(s->gvcf_opt.block_percent_tol) / 100.,
+                                             static_cast<int>(s->gvcf_opt.block_abs_tol));
+    }
+    out->gvcf_runs = (s->genotype && s->want_runs) ? s->o_runs.data() : nullptr;
     out->evs_off = s->want_evs ? s->o_evoff.data() : nullptr;
     out->evs_words = s->want_evs ? s->o_ev.data() : nullptr;
     return 0;
 }
 
+}
+
+int sk_pileup_stream_set_gvcf_block_options(sk_pileup_stream* s, const sk_gvcf_block_options* opt)
+{
+    if (!s || s->somatic) return fail("sk_pileup_stream_set_gvcf_block_options: bad argument");
+    s->want_runs = (opt != nullptr);
+    if (opt) s->gvcf_opt = *opt;
+    return 0;
 }
 
 int sk_pileup_stream_enable_evs_words(sk_pileup_stream* s, int enable)

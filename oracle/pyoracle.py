@@ -918,3 +918,88 @@ def gvcf_site_summaries(batch, genotypes):
         if ploidy == 2 and len(calls) > 0 and not alt and hom_ref:
             out["flags"][i] = 1
     return out
+
+
+def gvcf_plain_runs(summary, clean_count, raw_count, mapq_count, opt):
+    """sk_gvcf_run of every site of a window in plain Python: from each plain site the greedy joining of gvcf_writer::queue_site_record
+    (L/applications/starling/gvcf_writer.cpp:278-302) over the plain sites that follow -- testCanSiteJoinSampleBlockShared /
+    testCanSiteJoinSampleBlock (gvcf_block_site_record.cpp:77-122, :163-182: equal filters; used / unused depth and GQX each within
+    tolerance of the block, check_block_tolerance :41-55 on the stream_stat with the new value added) and joinSiteToSampleBlock
+    (:126-157); the filters by ScoringModelManager::applyDepthFilter (ScoringModelManager.cpp:234-249) and default_classify_site
+    (:270-311) for a homozygous-reference site.  `opt`: an object with sk_gvcf_block_options' fields.  -> structured array as
+    capi.GVCF_RUN_DTYPE"""
+    import math
+    n = len(summary)
+    dt = np.dtype([("len", np.int32), ("filter_key", np.uint32), ("gqx_min", np.int32), ("gqx_max", np.int32), ("dpu_min", np.uint32),
+                   ("dpu_max", np.uint32), ("dpf_min", np.uint32), ("dpf_max", np.uint32), ("gqx_mean", np.float64), ("dpu_mean", np.float64),
+                   ("dpf_mean", np.float64)])
+    out = np.zeros(n, dt)
+    frac_tol, abs_tol = float(opt.block_percent_tol) / 100., int(opt.block_abs_tol)
+
+    class Stat:  # stream_stat.hh:43-66 without Q
+        def __init__(self):
+            self.M = self.max = self.min = 0.0
+            self.k = 0
+
+        def add(self, x):
+            self.k += 1
+            if self.k == 1 or x > self.max:
+                self.max = x
+            if self.k == 1 or x < self.min:
+                self.min = x
+            self.M += (x - self.M) / float(self.k)
+
+        def with_value(self, x):
+            s = Stat()
+            s.M, s.max, s.min, s.k = self.M, self.max, self.min, self.k
+            s.add(float(x))
+            return s
+
+    def compat_round(x):
+        return math.floor(x + 0.5) if x >= 0 else math.ceil(x - 0.5)
+
+    def tolerable(ss):
+        mn = int(compat_round(ss.min))
+        if (mn + abs_tol) >= ss.max / 2.0:
+            return True
+        ftol = int(math.floor(mn * frac_tol))
+        if ftol <= abs_tol:
+            return False
+        return (mn + ftol) >= ss.max / 2.0
+    used = np.asarray(clean_count, np.int64)
+    unused = np.asarray(raw_count, np.int64) - used
+    key = np.zeros(n, np.int64)
+    plain = (np.asarray(summary["flags"]) & 1) != 0
+    for i in range(n):
+        if not plain[i]:
+            continue
+        k = 0
+        ref_count = int(summary["ref_fwd"][i]) + int(summary["ref_rev"][i])
+        if ref_count < opt.min_passed_call_depth or used[i] < opt.min_passed_call_depth:
+            k |= 1
+        if opt.is_min_homref_gqx and float(summary["gqx"][i]) < opt.min_homref_gqx:
+            k |= 2
+        if opt.is_max_depth and float(mapq_count[i]) > opt.max_chrom_depth:
+            k |= 4
+        if opt.is_max_base_filt:
+            total = float(used[i] + unused[i])
+            if (0.0 if total == 0.0 else float(unused[i]) / total) > opt.max_base_filt:
+                k |= 8
+        key[i] = k
+    for i in range(n):
+        if not plain[i]:
+            continue
+        g, du, df = Stat(), Stat(), Stat()
+        j = i
+        while j < n:
+            if j > i:
+                if not plain[j] or key[j] != key[i]:
+                    break
+                if not tolerable(du.with_value(used[j])) or not tolerable(df.with_value(unused[j])) or not tolerable(g.with_value(int(summary["gqx"][j]))):
+                    break
+            du.add(float(used[j]))
+            df.add(float(unused[j]))
+            g.add(float(int(summary["gqx"][j])))
+            j += 1
+        out[i] = (j - i, key[i], int(g.min), int(g.max), int(du.min), int(du.max), int(df.min), int(df.max), g.M, du.M, df.M)
+    return out

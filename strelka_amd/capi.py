@@ -125,12 +125,32 @@ PILEUP_RAW_TIER1, PILEUP_RAW_TIER2, PILEUP_CLEAN_TIER1, PILEUP_CLEAN_TIER2 = 0, 
 GVCF_SITE_SUMMARY_DTYPE = np.dtype([("flags", np.uint32), ("gqx", np.int32), ("ref_fwd", np.uint32), ("ref_rev", np.uint32)])
 
 
+GVCF_RUN_DTYPE = np.dtype([("len", np.int32), ("filter_key", np.uint32), ("gqx_min", np.int32), ("gqx_max", np.int32), ("dpu_min", np.uint32),
+                           ("dpu_max", np.uint32), ("dpf_min", np.uint32), ("dpf_max", np.uint32), ("gqx_mean", np.float64), ("dpu_mean", np.float64),
+                           ("dpf_mean", np.float64)])
+assert GVCF_RUN_DTYPE.itemsize == 56
+
+
+class GvcfBlockOptions(C.Structure):
+    _fields_ = [("min_passed_call_depth", C.c_uint32), ("is_min_homref_gqx", C.c_int32), ("min_homref_gqx", C.c_double), ("is_max_depth", C.c_int32),
+                ("is_max_base_filt", C.c_int32), ("max_chrom_depth", C.c_double), ("max_base_filt", C.c_double), ("block_percent_tol", C.c_uint32),
+                ("block_abs_tol", C.c_uint32)]
+
+
+def gvcf_block_options(**kw):
+    """the reference's defaults (gvcf_options.hh:57-77); max depth filter off unless max_chrom_depth is given"""
+    o = GvcfBlockOptions(3, 1, 30.0, 0, 1, 0.0, 0.4, 30, 3)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 class PileupWindow(C.Structure):
     _fields_ = [("begin", C.c_int32), ("end", C.c_int32), ("tier1_off", c_void_p), ("tier1_calls", c_void_p),
                 ("tier2_off", c_void_p), ("tier2_calls", c_void_p), ("spandel_count", c_void_p), ("submapped_count", c_void_p),
                 ("mapq_count", c_void_p), ("mapq_zero_count", c_void_p), ("mapq_sum_square", c_void_p),
                 ("clean_count", c_void_p), ("genotype", c_void_p), ("evs_off", c_void_p), ("evs_words", c_void_p),
-                ("site_summary", c_void_p)]
+                ("site_summary", c_void_p), ("gvcf_runs", c_void_p)]
 
 
 class SomaticPileupWindow(C.Structure):
@@ -208,7 +228,7 @@ EXPORTS = [
     "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
-    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push", "sk_pileup_stream_enable_evs_words", "sk_gvcf_site_summaries", "sk_gvcf_site_summaries_dev",
+    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push", "sk_pileup_stream_enable_evs_words", "sk_gvcf_site_summaries", "sk_gvcf_site_summaries_dev", "sk_gvcf_plain_runs_dev", "sk_pileup_stream_set_gvcf_block_options",
     "sk_somatic_pileup_stream_create", "sk_somatic_pileup_stream_destroy", "sk_somatic_pileup_stream_begin_region", "sk_somatic_pileup_stream_push",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
@@ -997,10 +1017,11 @@ class PileupStream:
     """sk_pileup_stream_*: one sample's pileup over a region, pushed window by window (row a8 chained into a9+a10).
     `library`: the ctypes handle to drive (default: the product library; the tests also drive the CPU double with it)."""
 
-    def __init__(self, opt, germline_opt=None, library=None, evs_words=False):
+    def __init__(self, opt, germline_opt=None, library=None, evs_words=False, gvcf_block_opt=None):
         self.L = library or lib()
         L = self.L
         self.evs_words = evs_words
+        self.gvcf_block_opt = gvcf_block_opt
         L.sk_pileup_stream_enable_evs_words.argtypes = [c_void_p, C.c_int]
         L.sk_pileup_stream_create.restype = c_void_p
         L.sk_pileup_stream_create.argtypes = [C.POINTER(PileupOptions), c_void_p]
@@ -1013,6 +1034,10 @@ class PileupStream:
         self.h = L.sk_pileup_stream_create(C.byref(opt), C.byref(germline_opt) if self.genotype else None)
         if not self.h:
             raise RuntimeError(L.sk_last_error().decode())
+        if gvcf_block_opt is not None:
+            L.sk_pileup_stream_set_gvcf_block_options.argtypes = [c_void_p, c_void_p]
+            if L.sk_pileup_stream_set_gvcf_block_options(self.h, C.byref(gvcf_block_opt)) != 0:
+                raise RuntimeError(L.sk_last_error().decode())
         if evs_words and L.sk_pileup_stream_enable_evs_words(self.h, 1) != 0:
             raise RuntimeError(L.sk_last_error().decode())
 
@@ -1071,6 +1096,7 @@ class PileupStream:
                     mapq_sumsq=arr(w.mapq_sum_square, np.uint64, n), clean_count=arr(w.clean_count, np.uint32, n),
                     genotype=rec(w.genotype, DIGT_CALL_DTYPE, n) if self.genotype else None,
                     site_summary=rec(w.site_summary, GVCF_SITE_SUMMARY_DTYPE, n) if self.genotype else None,
+                    gvcf_runs=rec(w.gvcf_runs, GVCF_RUN_DTYPE, n) if (self.genotype and self.gvcf_block_opt is not None) else None,
                     evs_off=arr(w.evs_off, np.int64, n + 1) if self.evs_words else None,
                     evs_words=(arr(w.evs_words, np.uint64, int(arr(w.evs_off, np.int64, n + 1)[-1]) if n else 0) if self.evs_words else None))
 

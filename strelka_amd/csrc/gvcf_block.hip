@@ -39,6 +39,39 @@ __global__ __launch_bounds__(256) void gvcf_site_summary_kernel(const sk_pileup_
     out[i] = skgvcf::site_summary(b.calls + c0, c1 - c0, b.ref_base[i], b.ploidy ? b.ploidy[i] : 2u, geno[i]);
 }
 
+// what the join test reads of every site of a window (skgvcf::SitePod), from the summaries and the window's column sizes
+struct PodArgs
+{
+    const sk_gvcf_site_summary* summary;
+    const int64_t* clean_off; // [n + 1] the cleaned tier1 columns
+    const int64_t* raw_off;   // [n + 1] the raw tier1 columns
+    const uint32_t* mapq_count;
+    sk_gvcf_block_options opt;
+    int32_t n;
+    skgvcf::SitePod* pod;
+};
+__global__ __launch_bounds__(256) void gvcf_site_pod_kernel(const PodArgs a)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const sk_gvcf_site_summary s = a.summary[i];
+    skgvcf::SitePod p;
+    p.gqx = s.gqx;
+    p.used = uint32_t(a.clean_off[i + 1] - a.clean_off[i]);
+    p.unused = uint32_t(a.raw_off[i + 1] - a.raw_off[i]) - p.used;
+    p.key_plain = (s.flags & skgvcf::SITE_PLAIN) ? (uint32_t(skgvcf::POD_PLAIN) | skgvcf::site_filter_key(a.opt, s.gqx, p.used, p.unused, s.ref_fwd + s.ref_rev, a.mapq_count[i])) : 0u;
+    a.pod[i] = p;
+}
+// a lane per site: the block that would start at it (a few dozen sites as a rule; the lanes of a wave walk neighbouring sites, whose
+// blocks mostly end at the same place)
+__global__ __launch_bounds__(64) void gvcf_plain_run_kernel(const skgvcf::SitePod* __restrict__ pod, const int32_t n, const double frac_tol, const int abs_tol,
+                                                            sk_gvcf_run* __restrict__ runs)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    runs[i] = skgvcf::plain_run(pod, n, i, frac_tol, abs_tol);
+}
+
 struct GvcfBuffers
 {
     void* p[3] = { nullptr, nullptr, nullptr };
@@ -72,6 +105,29 @@ int sk_gvcf_site_summaries_dev(const sk_pileup_batch* dev_batch, const sk_digt_c
     if (!dev_genotypes || !dev_out) return sk_fail("sk_gvcf_site_summaries_dev: null argument");
     hipLaunchKernelGGL(gvcf_site_summary_kernel, dim3((dev_batch->n_loci + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), *dev_batch, dev_genotypes,
                        dev_out);
+    SK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sk_gvcf_plain_runs_dev(const sk_gvcf_site_summary* dev_summary, const int64_t* dev_clean_off, const int64_t* dev_raw_off, const uint32_t* dev_mapq_count,
+                           const sk_gvcf_block_options* opt, int32_t n, void* dev_pod_scratch, sk_gvcf_run* dev_runs, void* hip_stream)
+{
+    SK_REQUIRE_INIT();
+    if (n < 0 || !opt) return sk_fail("sk_gvcf_plain_runs_dev: bad argument");
+    if (n == 0) return 0;
+    if (!dev_summary || !dev_clean_off || !dev_raw_off || !dev_mapq_count || !dev_pod_scratch || !dev_runs) return sk_fail("sk_gvcf_plain_runs_dev: null argument");
+    PodArgs a;
+    a.summary = dev_summary;
+    a.clean_off = dev_clean_off;
+    a.raw_off = dev_raw_off;
+    a.mapq_count = dev_mapq_count;
+    a.opt = *opt;
+    a.n = n;
+    a.pod = static_cast<skgvcf::SitePod*>(dev_pod_scratch);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(gvcf_site_pod_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gvcf_plain_run_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a.pod, n, static_cast<double>(opt->block_percent_tol) / 100.,
+                       int(opt->block_abs_tol), dev_runs);
     SK_HIP(hipGetLastError());
     return 0;
 }

@@ -21,6 +21,8 @@
 
 #include "strelka_amd.h"
 
+#include "gvcf_block_core.h"
+
 #ifdef __HIPCC__
 #define SKGS_HD __host__ __device__
 #else
@@ -71,6 +73,77 @@ SKGS_HD inline sk_gvcf_site_summary site_summary(const uint16_t* calls, const in
     s.gqx = gq < gqp ? gq : gqp;
     if (ploidy == 2 && n > 0 && !alt && hom_ref) s.flags |= SITE_PLAIN;
     return s;
+}
+
+// ---- the block that starts at a plain site (sk_gvcf_run) -------------------------------------------------------------------------
+// what the join test reads of a plain site: its filters (as a key: equal filters <=> equal keys), GQX and the two depth counts
+struct SitePod
+{
+    uint32_t key_plain; // bit 31: plain site; bits 0-3: LowDepth, LowGQX, HighDepth, HighBaseFilt
+    int32_t gqx;
+    uint32_t used, unused;
+};
+enum { POD_PLAIN = 0x80000000u };
+
+// ScoringModelManager::applyDepthFilter :234-249 and default_classify_site :270-311 for a homozygous-reference site of one sample whose
+// locus has no alternate allele (totalConfidentCounts = the reference allele's AD; allSampleLocusDepth = the sample's MapqTracker count)
+SKGS_HD inline uint32_t site_filter_key(const sk_gvcf_block_options& o, const int32_t gqx, const uint32_t used, const uint32_t unused, const uint32_t ref_count,
+                                        const uint32_t total_read_depth)
+{
+    uint32_t key = 0;
+    if (ref_count < o.min_passed_call_depth || used < o.min_passed_call_depth) key |= 1u;                  // LowDepth
+    if (o.is_min_homref_gqx && double(gqx) < o.min_homref_gqx) key |= 2u;                                  // LowGQX
+    if (o.is_max_depth && double(total_read_depth) > o.max_chrom_depth) key |= 4u;                         // HighDepth
+    if (o.is_max_base_filt) {                                                                              // HighBaseFilt
+        const double total = double(used + unused);                                                        // (safeFrac, math_util.hh:108-113)
+        const double frac = (total <= 0. && total >= 0.) ? 0. : double(unused) / total;
+        if (frac > o.max_base_filt) key |= 8u;
+    }
+    return key;
+}
+
+// gvcf_writer::queue_site_record's joining from an empty block at site i (testCanSiteJoinSampleBlockShared :77-122 for two plain
+// sites: equal filters; depth and filtered depth within tolerance of the block; both covered; both 0/0, diploid; GQX within tolerance
+// :163-182; joinSiteToSampleBlock :126-157)
+SKGS_HD inline sk_gvcf_run plain_run(const SitePod* pod, const int64_t n, const int64_t i, const double frac_tol, const int abs_tol)
+{
+    sk_gvcf_run r;
+    r.len = 0;
+    r.filter_key = 0;
+    r.gqx_min = r.gqx_max = 0;
+    r.dpu_min = r.dpu_max = r.dpf_min = r.dpf_max = 0;
+    r.gqx_mean = r.dpu_mean = r.dpf_mean = 0.;
+    if (!(pod[i].key_plain & POD_PLAIN)) return r;
+    Stat gqx, dpu, dpf;
+    gqx.reset();
+    dpu.reset();
+    dpf.reset();
+    const uint32_t key = pod[i].key_plain;
+    int64_t j = i;
+    for (; j < n; ++j) {
+        const SitePod s = pod[j];
+        if (j > i) {
+            if (s.key_plain != key) break; // (not plain, or other filters)
+            if (!new_value_blockable(int(s.used), dpu, frac_tol, abs_tol)) break;
+            if (!new_value_blockable(int(s.unused), dpf, frac_tol, abs_tol)) break;
+            if (!new_value_blockable(s.gqx, gqx, frac_tol, abs_tol)) break;
+        }
+        dpu.add(double(s.used));
+        dpf.add(double(s.unused));
+        gqx.add(double(s.gqx));
+    }
+    r.len = int32_t(j - i);
+    r.filter_key = key & 0xfu;
+    r.gqx_min = int32_t(gqx.min);
+    r.gqx_max = int32_t(gqx.max);
+    r.dpu_min = uint32_t(dpu.min);
+    r.dpu_max = uint32_t(dpu.max);
+    r.dpf_min = uint32_t(dpf.min);
+    r.dpf_max = uint32_t(dpf.max);
+    r.gqx_mean = gqx.M;
+    r.dpu_mean = dpu.M;
+    r.dpf_mean = dpf.M;
+    return r;
 }
 
 } // namespace skgvcf

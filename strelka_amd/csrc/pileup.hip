@@ -1288,8 +1288,8 @@ namespace
 {
 
 struct InLay { int64_t read_off, path_off, path, pos, is_fwd, mapq, level, code, qual, ploidy, mask, total; };
-struct WorkLay { int64_t begin, end, maxend, minbegin, count0, count1, count2, count4, count4a, off2, off4, calls2, calls4, refbase, de, gscr, tmp, total; };
-struct OutLay { int64_t off0, off1, clean_n, clean4_n, mq_n, mq_zero, mq_sq, spandel, submapped, geno, summary, calls0, calls1, read_pos, evs_off, evs, total; };
+struct WorkLay { int64_t begin, end, maxend, minbegin, count0, count1, count2, count4, count4a, off2, off4, calls2, calls4, refbase, de, gscr, pods, tmp, total; };
+struct OutLay { int64_t off0, off1, clean_n, clean4_n, mq_n, mq_zero, mq_sq, spandel, submapped, geno, summary, runs, calls0, calls1, read_pos, evs_off, evs, total; };
 
 } // namespace
 
@@ -1301,6 +1301,8 @@ struct sk_pileup_stream
     bool somatic = false;      // also build the CleanPileupFilter(pi, true) column (kept on the device)
     bool want_read_pos = false; // ... and return each tier1 call's read position / read length
     bool want_evs = false;      // return the germline EVS words of every live call (sk_pileup_stream_enable_evs_words)
+    bool want_runs = false;     // return the non-variant block that would start at every plain site (sk_pileup_stream_set_gvcf_block_options)
+    sk_gvcf_block_options gvcf_opt;
     bool poisoned = false;      // a push failed after it had begun to change the stream's state: only begin_region is accepted
     // region
     bool has_region = false;
@@ -1566,6 +1568,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         wl.refbase = o; o += align256(std::max(n_loci, 1));
         wl.de = o; o += align256(s->genotype ? 4 * std::max<int64_t>(n_bases, 1) : 0);
         wl.gscr = o; o += align256(s->genotype ? 4 * (n_bases + int64_t(n_loci) + 8) : 0);
+        wl.pods = o; o += align256((s->genotype && s->want_runs) ? 16 * int64_t(std::max(n_loci, 1)) : 0);
         wl.tmp = o; o += align256(SL.tmp_bytes);
         wl.total = o;
     }
@@ -1583,6 +1586,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         ol.submapped = o; o += align256(4 * int64_t(std::max(n_loci, 1)));
         ol.geno = o; o += align256(s->genotype ? int64_t(sizeof(sk_digt_call)) * std::max(n_loci, 1) : 0);
         ol.summary = o; o += align256(s->genotype ? int64_t(sizeof(sk_gvcf_site_summary)) * std::max(n_loci, 1) : 0);
+        ol.runs = o; o += align256((s->genotype && s->want_runs) ? int64_t(sizeof(sk_gvcf_run)) * std::max(n_loci, 1) : 0);
         ol.calls0 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
         ol.calls1 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
         ol.read_pos = o; o += align256(s->want_read_pos ? 4 * std::max<int64_t>(n_bases, 1) : 0);
@@ -1716,6 +1720,11 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         // ... and what the gVCF writer's block logic reads of each position, from the same column and the record just written
         if (sk_gvcf_site_summaries_dev(&pb, reinterpret_cast<const sk_digt_call*>(dout + ol.geno), reinterpret_cast<sk_gvcf_site_summary*>(dout + ol.summary), st))
             return 1;
+        // ... and, from every plain site, the non-variant block the writer would start there
+        if (s->want_runs &&
+            sk_gvcf_plain_runs_dev(reinterpret_cast<const sk_gvcf_site_summary*>(dout + ol.summary), off2, off0, reinterpret_cast<const uint32_t*>(dout + ol.mq_n),
+                                   &s->gvcf_opt, n_loci, dw + wl.pods, reinterpret_cast<sk_gvcf_run*>(dout + ol.runs), st))
+            return 1;
     }
     SK_HIP(hipGetLastError());
     SK_HIP(hipMemcpyAsync(ho, dout, size_t(ol.total), hipMemcpyDeviceToHost, st));
@@ -1781,6 +1790,7 @@ void stream_finish(sk_pileup_stream* s, sk_pileup_window* out)
     out->clean_count = reinterpret_cast<const uint32_t*>(ho + ol.clean_n);
     out->genotype = s->genotype ? reinterpret_cast<const sk_digt_call*>(ho + ol.geno) : nullptr;
     out->site_summary = s->genotype ? reinterpret_cast<const sk_gvcf_site_summary*>(ho + ol.summary) : nullptr;
+    out->gvcf_runs = (s->genotype && s->want_runs) ? reinterpret_cast<const sk_gvcf_run*>(ho + ol.runs) : nullptr;
     out->evs_off = s->want_evs ? reinterpret_cast<const int64_t*>(ho + ol.evs_off) : nullptr;
     out->evs_words = s->want_evs ? reinterpret_cast<const uint64_t*>(ho + ol.evs) : nullptr;
 }
@@ -1814,6 +1824,15 @@ sk_pileup_stream* sk_pileup_stream_create(const sk_pileup_options* opt, const sk
         s->genotype = true;
     }
     return s;
+}
+
+int sk_pileup_stream_set_gvcf_block_options(sk_pileup_stream* s, const sk_gvcf_block_options* opt)
+{
+    if (!s) return sk_fail("sk_pileup_stream_set_gvcf_block_options: null stream");
+    if (s->somatic) return sk_fail("sk_pileup_stream_set_gvcf_block_options: a germline stream's");
+    s->want_runs = (opt != nullptr);
+    if (opt) s->gvcf_opt = *opt;
+    return 0;
 }
 
 int sk_pileup_stream_enable_evs_words(sk_pileup_stream* s, const int enable)

@@ -228,7 +228,12 @@ void sk_host_free(void* p)
 int sk_init(int device)
 {
     SkContext& c = g_ctx;
-    if (c.ready && c.device == device) return 0;
+    if (c.ready && c.device == device) {
+        // (the current device is a property of the calling THREAD: a caller that initialised on a worker thread calls again from the
+        // thread that will make the calls)
+        SK_HIP(hipSetDevice(device));
+        return 0;
+    }
     if (c.ready) sk_shutdown();
     sk_pre_runtime_env();
     const bool timing = std::getenv("SK_INIT_TIMING") != nullptr; // diagnostics: where a caller process's start-up goes

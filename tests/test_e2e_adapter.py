@@ -531,8 +531,13 @@ def _single_sample(variant, tmp_path, which, sample="germline_S1.bam", extra=(),
     if (env or {}).get("STRELKA_AMD_GVCF_FAST") == "0":
         assert g.get("gvcf_plain_sites", 0) == 0
     else:
-        covered = g["gvcf_plain_sites"] + g["gvcf_reference_sites"]
-        assert covered > 0.5 * length and g["gvcf_plain_sites"] >= min_plain * covered, g
+        routed = g["gvcf_plain_sites"] + g["gvcf_block_sites"]
+        covered = routed + g["gvcf_reference_sites"]
+        assert covered > 0.5 * length and routed >= min_plain * covered and g["gvcf_filter_key_mismatches"] == 0, g
+        if (env or {}).get("STRELKA_AMD_GVCF_BLOCKS") == "0":
+            assert g["gvcf_blocks_installed"] == 0
+        else:
+            assert g["gvcf_blocks_installed"] > 100 and g["gvcf_block_sites"] > g["gvcf_blocks_installed"], g
     return g, outs
 
 
@@ -562,8 +567,10 @@ def test_single_sample_gvcf_blocks_from_the_window_cpu_double(tmp_path, which, s
 
 
 @pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
-def test_single_sample_gvcf_fast_path_switched_off(tmp_path):
-    _single_sample("dbl", tmp_path, "short_reads", env={"STRELKA_AMD_GVCF_FAST": "0"})
+@pytest.mark.parametrize("env", [{"STRELKA_AMD_GVCF_FAST": "0"}, {"STRELKA_AMD_GVCF_BLOCKS": "0"}])
+def test_single_sample_gvcf_fast_path_switched_off(tmp_path, env):
+    """without site 10 altogether, and with its plain sites going into the writer one by one (no whole blocks)"""
+    _single_sample("dbl", tmp_path, "short_reads", env=env)
 
 
 @pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth() and os.path.exists(os.path.join(E.BIN_DIR, "tabix"))),

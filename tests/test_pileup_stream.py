@@ -35,10 +35,15 @@ def _read_end(r):
     return r["pos"] + sum(l for t, l in r["path"] if t in (capi.SEG["MATCH"], capi.SEG["DELETE"]))
 
 
+# the gVCF block options of the streams under test: the reference's defaults with a depth ceiling low enough to set HighDepth somewhere
+GVCF_OPT = capi.gvcf_block_options(is_max_depth=1, max_chrom_depth=30.0, min_homref_gqx=15.0)
+
+
 def _run_stream(library, reads, ref, off, kw, cuts, mask=None, genotype=True, ploidy=None, region=None, evs_words=False):
     """push reads[cuts[i]:cuts[i+1]] one after the other; final_to = the lowest start of any later read"""
     opt = capi.pileup_options(**kw)
-    st = capi.PileupStream(opt, capi.germline_options() if genotype else None, library=library, evs_words=evs_words)
+    st = capi.PileupStream(opt, capi.germline_options() if genotype else None, library=library, evs_words=evs_words,
+                           gvcf_block_opt=GVCF_OPT if genotype else None)
     rb, re = region or (kw["report_begin"], kw["report_end"])
     st.begin_region(ref, off, rb, re)
     wins = []
@@ -95,6 +100,10 @@ def _compare(wins, want, ref, off, kw, ploidy=None, genotype=True):
             # ... and what the gVCF writer's block logic reads of each position (site 10): plain site?, GQX, reference AD counts
             ws = pyoracle.gvcf_site_summaries(pb, wg)
             assert w["site_summary"].tobytes() == ws.tobytes()
+            if w.get("gvcf_runs") is not None:
+                # ... and, from every plain site, the non-variant block the writer would start there (gvcf_plain_run_kernel)
+                wr = pyoracle.gvcf_plain_runs(ws, np.diff(co), np.diff(w["tier1_off"]), w["mapq_count"], GVCF_OPT)
+                assert w["gvcf_runs"].tobytes() == wr.tobytes()
     # positions no window reported have nothing in them
     quiet = ~covered
     assert not np.diff(want["o1"])[quiet].any() and not np.diff(want["o2"])[quiet].any()

@@ -25,6 +25,8 @@ ENV_SETS = [
     ("min_reads_1", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1"}),
     ("min_reads_32", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "32"}),
     ("gvcf_fast_off", {"STRELKA_AMD_GVCF_FAST": "0"}),
+    ("gvcf_blocks_off", {"STRELKA_AMD_GVCF_BLOCKS": "0"}),
+    ("early_init_off", {"STRELKA_AMD_EARLY_INIT": "0"}),
     ("min_reads_1_three_waits", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1", "SK_ENUM_ONE_WAIT": "0"}),
 ]
 if os.environ.get("SK_SWEEP_ONLY"):  # a comma-separated choice of the settings above
