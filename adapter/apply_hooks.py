@@ -111,11 +111,6 @@ HOOKS = [
         ("friend + forward declaration", r'struct VariantPhaser : public variant_pipe_stage_base\n\{\n',
          '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::GvcfAccess;\n'),
     ]),
-    (L + "blt_util/stream_stat.hh", [
-        # site 10: a block's three running statistics are set to what the joins of its members leave (no data member added)
-        ("friend + forward declaration", r'struct stream_stat\n\{\n',
-         '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::GvcfAccess;\n'),
-    ]),
     (L + "applications/starling/VariantOverlapResolver.hh", [
         ("friend + forward declaration", r'struct VariantOverlapResolver : public variant_pipe_stage_base\n\{\n',
          '#include "sk_adapter_fwd.hh"\n\\g<0>    friend struct sk_adapter::GvcfAccess;\n'),

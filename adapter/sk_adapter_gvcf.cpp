@@ -63,14 +63,6 @@ struct GvcfAccess
         return w._gvcf_comp.is_range_compressible(known_pos_range2(begin, end));
     }
     static void setHeadPos(gvcf_writer& w, const pos_t pos) { w._headPos = pos; }
-    /// a stream_stat as `count` calls of add() left it: running mean, maximum, minimum (Q, the variance's sum, is read by nothing here)
-    static void setStat(stream_stat& ss, const double mean, const double max, const double min, const unsigned count)
-    {
-        ss.M_ = mean;
-        ss.max_ = max;
-        ss.min_ = min;
-        ss.k_ = count;
-    }
     /// gvcf_writer::process(site) without the ownership (gvcf_writer.cpp:180-197)
     static void writerProcessSite(gvcf_writer& w, GermlineSiteLocusInfo& locus)
     {
@@ -312,7 +304,8 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
     // site after site).  If nothing can happen at those positions that the window did not know -- no indel key, no forced position, no
     // active region, the ploidy and the columns the window's -- the block is brought to the state those joins leave (count, the three
     // running statistics, the writer's head) and the positions have nothing left to do when process_pos_snp reaches them.  The site
-    // that ends the block, plain or not, meets that block through the reference's own test.
+    // that ends the block, plain or not, meets that block through the reference's own test.  (What the device has done is the join
+    // TESTS, one after the other from the block's first site; the joins themselves are three additions per member.)
     if (g.isBlocks && (! c->runs.empty()))
     {
         gvcf_block_site_record& block(GvcfAccess::sampleBlock(*writer, 0));
@@ -355,11 +348,16 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
                 const unsigned n(static_cast<unsigned>(end - pos));
                 if (n == static_cast<unsigned>(run.len))
                 {
-                    // joinSiteToSampleBlock x (n - 1): count and the three accumulators (gvcf_block_site_record.cpp:149-156)
+                    // joinSiteToSampleBlock (gvcf_block_site_record.cpp:149-156) for every member after the first: the three
+                    // accumulators take the member's numbers through the reference's own stream_stat::add, the count goes up
+                    for (pos_t p(pos + 1); p < end; ++p)
+                    {
+                        const size_t kk(static_cast<size_t>(p - c->begin));
+                        block.block_dpu.add(c->cleanCount[kk]);
+                        block.block_dpf.add(c->rawCount[kk] - c->cleanCount[kk]);
+                        block.block_gqx.add(c->summary[kk].gqx);
+                    }
                     block.count = static_cast<int>(n);
-                    GvcfAccess::setStat(block.block_dpu, run.dpu_mean, static_cast<double>(run.dpu_max), static_cast<double>(run.dpu_min), n);
-                    GvcfAccess::setStat(block.block_dpf, run.dpf_mean, static_cast<double>(run.dpf_max), static_cast<double>(run.dpf_min), n);
-                    GvcfAccess::setStat(block.block_gqx, run.gqx_mean, static_cast<double>(run.gqx_max), static_cast<double>(run.gqx_min), n);
                     GvcfAccess::setHeadPos(*writer, end); // add_site_internal's _headPos = locus.pos + 1 of the last member
                     g.blockTo = end;
                     g.blocksInstalled++;

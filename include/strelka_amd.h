@@ -640,15 +640,16 @@ typedef struct sk_gvcf_block_options {
 
 /** For a plain site i: the non-variant block that STARTS at it -- gvcf_writer::queue_site_record's greedy joining
  *  (testCanSiteJoinSampleBlock / joinSiteToSampleBlock, gvcf_block_site_record.cpp:77-182) from an empty block over the plain sites
- *  that follow it in the window: how many sites it takes in and the block's three stream_stat accumulators (minimum, maximum, running
- *  mean; stream_stat.hh:56-66) after the last of them.  len = 0: not a plain site.  The block ends where a site cannot join, at a
- *  site that is not plain, and at the window's end (where it may well go on: the caller lets the next site decide). */
+ *  that follow it in the window: how many sites it takes in, and the minimum and maximum of the block's three stream_stat accumulators
+ *  after the last of them (the join test reads nothing else of them: check_block_tolerance :41-55; their running means -- a division per
+ *  member, read only when a block is written -- are the caller's to make for the blocks it uses).  len = 0: not a plain site.  The block
+ *  ends where a site cannot join, at a site that is not plain, and at the window's end (where it may well go on: the caller lets the
+ *  next site decide). */
 typedef struct sk_gvcf_run {
     int32_t len;
     uint32_t filter_key;           /* which of LowDepth / LowGQX / HighDepth / HighBaseFilt the block's sites carry (bits 0-3) */
     int32_t gqx_min, gqx_max;
     uint32_t dpu_min, dpu_max, dpf_min, dpf_max;
-    double gqx_mean, dpu_mean, dpf_mean;
 } sk_gvcf_run;
 
 typedef struct sk_pileup_window {

@@ -931,8 +931,7 @@ def gvcf_plain_runs(summary, clean_count, raw_count, mapq_count, opt):
     import math
     n = len(summary)
     dt = np.dtype([("len", np.int32), ("filter_key", np.uint32), ("gqx_min", np.int32), ("gqx_max", np.int32), ("dpu_min", np.uint32),
-                   ("dpu_max", np.uint32), ("dpf_min", np.uint32), ("dpf_max", np.uint32), ("gqx_mean", np.float64), ("dpu_mean", np.float64),
-                   ("dpf_mean", np.float64)])
+                   ("dpu_max", np.uint32), ("dpf_min", np.uint32), ("dpf_max", np.uint32)])
     out = np.zeros(n, dt)
     frac_tol, abs_tol = float(opt.block_percent_tol) / 100., int(opt.block_abs_tol)
 
@@ -1001,5 +1000,5 @@ def gvcf_plain_runs(summary, clean_count, raw_count, mapq_count, opt):
             df.add(float(unused[j]))
             g.add(float(int(summary["gqx"][j])))
             j += 1
-        out[i] = (j - i, key[i], int(g.min), int(g.max), int(du.min), int(du.max), int(df.min), int(df.max), g.M, du.M, df.M)
+        out[i] = (j - i, key[i], int(g.min), int(g.max), int(du.min), int(du.max), int(df.min), int(df.max))
     return out

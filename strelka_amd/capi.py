@@ -126,9 +126,8 @@ GVCF_SITE_SUMMARY_DTYPE = np.dtype([("flags", np.uint32), ("gqx", np.int32), ("r
 
 
 GVCF_RUN_DTYPE = np.dtype([("len", np.int32), ("filter_key", np.uint32), ("gqx_min", np.int32), ("gqx_max", np.int32), ("dpu_min", np.uint32),
-                           ("dpu_max", np.uint32), ("dpf_min", np.uint32), ("dpf_max", np.uint32), ("gqx_mean", np.float64), ("dpu_mean", np.float64),
-                           ("dpf_mean", np.float64)])
-assert GVCF_RUN_DTYPE.itemsize == 56
+                           ("dpu_max", np.uint32), ("dpf_min", np.uint32), ("dpf_max", np.uint32)])
+assert GVCF_RUN_DTYPE.itemsize == 32
 
 
 class GvcfBlockOptions(C.Structure):

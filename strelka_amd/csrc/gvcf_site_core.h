@@ -102,6 +102,19 @@ SKGS_HD inline uint32_t site_filter_key(const sk_gvcf_block_options& o, const in
     return key;
 }
 
+// is_new_value_blockable :59-73 on a stream_stat of which only the extremes matter: the statistic with the new value added has
+// min' = min(min, v), max' = max(max, v), and check_block_tolerance :41-55 reads nothing else (compat_round of an integer-valued
+// minimum is the minimum)
+SKGS_HD inline bool extremes_blockable(const int v, const int mn, const int mx, const double frac_tol, const int abs_tol)
+{
+    const int lo = v < mn ? v : mn, hi = v > mx ? v : mx;
+    const double half_max = double(hi) / 2.0;
+    if (double(lo + abs_tol) >= half_max) return true;
+    const int ftol = int(__builtin_floor(double(lo) * frac_tol));
+    if (ftol <= abs_tol) return false;
+    return double(lo + ftol) >= half_max;
+}
+
 // gvcf_writer::queue_site_record's joining from an empty block at site i (testCanSiteJoinSampleBlockShared :77-122 for two plain
 // sites: equal filters; depth and filtered depth within tolerance of the block; both covered; both 0/0, diploid; GQX within tolerance
 // :163-182; joinSiteToSampleBlock :126-157)
@@ -112,37 +125,32 @@ SKGS_HD inline sk_gvcf_run plain_run(const SitePod* pod, const int64_t n, const 
     r.filter_key = 0;
     r.gqx_min = r.gqx_max = 0;
     r.dpu_min = r.dpu_max = r.dpf_min = r.dpf_max = 0;
-    r.gqx_mean = r.dpu_mean = r.dpf_mean = 0.;
-    if (!(pod[i].key_plain & POD_PLAIN)) return r;
-    Stat gqx, dpu, dpf;
-    gqx.reset();
-    dpu.reset();
-    dpf.reset();
-    const uint32_t key = pod[i].key_plain;
-    int64_t j = i;
+    const SitePod first = pod[i];
+    if (!(first.key_plain & POD_PLAIN)) return r;
+    const uint32_t key = first.key_plain;
+    int g0 = first.gqx, g1 = first.gqx, u0 = int(first.used), u1 = int(first.used), f0 = int(first.unused), f1 = int(first.unused);
+    int64_t j = i + 1;
     for (; j < n; ++j) {
         const SitePod s = pod[j];
-        if (j > i) {
-            if (s.key_plain != key) break; // (not plain, or other filters)
-            if (!new_value_blockable(int(s.used), dpu, frac_tol, abs_tol)) break;
-            if (!new_value_blockable(int(s.unused), dpf, frac_tol, abs_tol)) break;
-            if (!new_value_blockable(s.gqx, gqx, frac_tol, abs_tol)) break;
-        }
-        dpu.add(double(s.used));
-        dpf.add(double(s.unused));
-        gqx.add(double(s.gqx));
+        if (s.key_plain != key) break; // (not plain, or other filters)
+        if (!extremes_blockable(int(s.used), u0, u1, frac_tol, abs_tol)) break;
+        if (!extremes_blockable(int(s.unused), f0, f1, frac_tol, abs_tol)) break;
+        if (!extremes_blockable(s.gqx, g0, g1, frac_tol, abs_tol)) break;
+        u0 = int(s.used) < u0 ? int(s.used) : u0;
+        u1 = int(s.used) > u1 ? int(s.used) : u1;
+        f0 = int(s.unused) < f0 ? int(s.unused) : f0;
+        f1 = int(s.unused) > f1 ? int(s.unused) : f1;
+        g0 = s.gqx < g0 ? s.gqx : g0;
+        g1 = s.gqx > g1 ? s.gqx : g1;
     }
     r.len = int32_t(j - i);
     r.filter_key = key & 0xfu;
-    r.gqx_min = int32_t(gqx.min);
-    r.gqx_max = int32_t(gqx.max);
-    r.dpu_min = uint32_t(dpu.min);
-    r.dpu_max = uint32_t(dpu.max);
-    r.dpf_min = uint32_t(dpf.min);
-    r.dpf_max = uint32_t(dpf.max);
-    r.gqx_mean = gqx.M;
-    r.dpu_mean = dpu.M;
-    r.dpf_mean = dpf.M;
+    r.gqx_min = g0;
+    r.gqx_max = g1;
+    r.dpu_min = uint32_t(u0);
+    r.dpu_max = uint32_t(u1);
+    r.dpf_min = uint32_t(f0);
+    r.dpf_max = uint32_t(f1);
     return r;
 }
 
