@@ -1100,9 +1100,12 @@ typedef struct sk_gvcf_block { /* gvcf_block_site_record as write_site_record re
  *  the genotype records that call left: what the pileup stream appends to a window (sk_pileup_window.site_summary). */
 int sk_gvcf_site_summaries_dev(const sk_pileup_batch* dev_batch, const sk_digt_call* dev_genotypes, sk_gvcf_site_summary* dev_out, void* hip_stream);
 /** sk_gvcf_run of every site of a window from its summaries and column sizes (clean_off / raw_off: CSR offsets of the cleaned and the
- *  raw tier1 columns; dev_pod_scratch: 16 bytes per site): what the pileup stream appends to a window when it has block options. */
+ *  raw tier1 columns; dev_pod_scratch: 256 + 17 bytes per site): what the pileup stream appends to a window when it has block options. */
 int sk_gvcf_plain_runs_dev(const sk_gvcf_site_summary* dev_summary, const int64_t* dev_clean_off, const int64_t* dev_raw_off, const uint32_t* dev_mapq_count,
                            const sk_gvcf_block_options* opt, int32_t n, void* dev_pod_scratch, sk_gvcf_run* dev_runs, void* hip_stream);
+/** ... for host arrays (one upload, the launches, one copy back; clean_count / raw_count: the columns' sizes): tests */
+int sk_gvcf_plain_runs(const sk_gvcf_site_summary* summary, const uint32_t* clean_count, const uint32_t* raw_count, const uint32_t* mapq_count,
+                       const sk_gvcf_block_options* opt, int32_t n, sk_gvcf_run* runs);
 /** the same for host arrays (one upload, one launch, one copy back): tests, and callers without a stream */
 int sk_gvcf_site_summaries(const sk_pileup_batch* host_batch, const sk_digt_call* genotypes, sk_gvcf_site_summary* out);
 int sk_gvcf_block_sites(const sk_gvcf_site* sites, int32_t n_sites, uint32_t block_percent_tol, uint32_t block_abs_tol, uint8_t* kind,

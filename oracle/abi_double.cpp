@@ -478,6 +478,27 @@ extern "C" int sk_gvcf_site_summaries_dev(const sk_pileup_batch*, const sk_digt_
 {
     return sk_fail("sk_gvcf_site_summaries_dev needs the GPU library");
 }
+extern "C" int sk_gvcf_plain_runs(const sk_gvcf_site_summary* summary, const uint32_t* clean_count, const uint32_t* raw_count, const uint32_t* mapq_count,
+                                  const sk_gvcf_block_options* opt, int32_t n, sk_gvcf_run* runs)
+{
+    if (!g_ready) return sk_fail("sk_init() has not succeeded");
+    if (n < 0 || !opt || (n > 0 && (!summary || !clean_count || !raw_count || !mapq_count || !runs))) return sk_fail("sk_gvcf_plain_runs: bad argument");
+    std::vector<skgvcf::SitePod> pod(static_cast<size_t>(n) + 1);
+    for (int32_t l = 0; l < n; ++l) {
+        const sk_gvcf_site_summary& sm = summary[l];
+        skgvcf::SitePod p;
+        p.gqx = sm.gqx;
+        p.used = clean_count[l];
+        p.unused = raw_count[l] - p.used;
+        p.key_plain = (sm.flags & skgvcf::SITE_PLAIN) ? (uint32_t(skgvcf::POD_PLAIN) | skgvcf::site_filter_key(*opt, sm.gqx, p.used, p.unused, sm.ref_fwd + sm.ref_rev, mapq_count[l])) : 0u;
+        pod[static_cast<size_t>(l)] = p;
+    }
+    std::vector<skgvcf::SiteTile> tiles(static_cast<size_t>(n) / skgvcf::TILE_SITES + 2);
+    for (int64_t t = 0; t * skgvcf::TILE_SITES < n; ++t) tiles[static_cast<size_t>(t)] = skgvcf::make_tile(pod.data(), n, t);
+    for (int32_t l = 0; l < n; ++l)
+        runs[l] = skgvcf::plain_run(pod.data(), tiles.data(), n, l, static_cast<double>(opt->block_percent_tol) / 100., static_cast<int>(opt->block_abs_tol));
+    return 0;
+}
 extern "C" int sk_gvcf_plain_runs_dev(const sk_gvcf_site_summary*, const int64_t*, const int64_t*, const uint32_t*, const sk_gvcf_block_options*, int32_t, void*,
                                       sk_gvcf_run*, void*)
 {
@@ -834,9 +855,11 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
             p.key_plain = (sm.flags & skgvcf::SITE_PLAIN) ? (uint32_t(skgvcf::POD_PLAIN) | skgvcf::site_filter_key(s->gvcf_opt, sm.gqx, p.used, p.unused, sm.ref_fwd + sm.ref_rev, s->o_mn[l])) : 0u;
             pod[l] = p;
         }
+        std::vector<skgvcf::SiteTile> tiles((nl + skgvcf::TILE_SITES - 1) / skgvcf::TILE_SITES + 1);
+        for (size_t t = 0; t * skgvcf::TILE_SITES < nl; ++t) tiles[t] = skgvcf::make_tile(pod.data(), static_cast<int64_t>(nl), static_cast<int64_t>(t));
         for (size_t l = 0; l < nl; ++l)
-            s->o_runs[l] = skgvcf::plain_run(pod.data(), static_cast<int64_t>(nl), static_cast<int64_t>(l), static_cast<double>(s->gvcf_opt.block_percent_tol) / 100.,
-                                             static_cast<int>(s->gvcf_opt.block_abs_tol));
+            s->o_runs[l] = skgvcf::plain_run(pod.data(), tiles.data(), static_cast<int64_t>(nl), static_cast<int64_t>(l),
+                                             static_cast<double>(s->gvcf_opt.block_percent_tol) / 100., static_cast<int>(s->gvcf_opt.block_abs_tol));
     }
     out->gvcf_runs = (s->genotype && s->want_runs) ? s->o_runs.data() : nullptr;
     out->evs_off = s->want_evs ? s->o_evoff.data() : nullptr;

@@ -227,7 +227,7 @@ EXPORTS = [
     "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
-    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push", "sk_pileup_stream_enable_evs_words", "sk_gvcf_site_summaries", "sk_gvcf_site_summaries_dev", "sk_gvcf_plain_runs_dev", "sk_pileup_stream_set_gvcf_block_options",
+    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push", "sk_pileup_stream_enable_evs_words", "sk_gvcf_site_summaries", "sk_gvcf_site_summaries_dev", "sk_gvcf_plain_runs_dev", "sk_gvcf_plain_runs", "sk_pileup_stream_set_gvcf_block_options",
     "sk_somatic_pileup_stream_create", "sk_somatic_pileup_stream_destroy", "sk_somatic_pileup_stream_begin_region", "sk_somatic_pileup_stream_push",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
@@ -579,6 +579,20 @@ def gvcf_site_summaries(batch, genotypes):
     s = batch.struct()
     g = np.ascontiguousarray(genotypes)
     _check(lib().sk_gvcf_site_summaries(C.byref(s), _p(g), _p(out)))
+    return out
+
+
+def gvcf_plain_runs(summary, clean_count, raw_count, mapq_count, opt, library=None):
+    """sk_gvcf_run of every site (library: the ctypes handle to drive -- default the product library; the tests also drive the CPU double)"""
+    L = library or lib()
+    n = len(summary)
+    out = np.zeros(n, GVCF_RUN_DTYPE)
+    sm, cc, rc, mq = (np.ascontiguousarray(a, dt) for a, dt in ((summary, GVCF_SITE_SUMMARY_DTYPE), (clean_count, np.uint32), (raw_count, np.uint32),
+                                                                (mapq_count, np.uint32)))
+    L.sk_gvcf_plain_runs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int32, c_void_p]
+    L.sk_last_error.restype = C.c_char_p
+    if L.sk_gvcf_plain_runs(_p(sm), _p(cc), _p(rc), _p(mq), C.byref(opt), n, _p(out)) != 0:
+        raise RuntimeError(L.sk_last_error().decode())
     return out
 
 

@@ -4,6 +4,7 @@
 #include "sk_common.h"
 
 #include <cstring>
+#include <vector>
 
 #include "gvcf_block_core.h"
 #include "gvcf_site_core.h"
@@ -62,14 +63,21 @@ __global__ __launch_bounds__(256) void gvcf_site_pod_kernel(const PodArgs a)
     p.key_plain = (s.flags & skgvcf::SITE_PLAIN) ? (uint32_t(skgvcf::POD_PLAIN) | skgvcf::site_filter_key(a.opt, s.gqx, p.used, p.unused, s.ref_fwd + s.ref_rev, a.mapq_count[i])) : 0u;
     a.pod[i] = p;
 }
-// a lane per site: the block that would start at it (a few dozen sites as a rule; the lanes of a wave walk neighbouring sites, whose
-// blocks mostly end at the same place)
-__global__ __launch_bounds__(64) void gvcf_plain_run_kernel(const skgvcf::SitePod* __restrict__ pod, const int32_t n, const double frac_tol, const int abs_tol,
-                                                            sk_gvcf_run* __restrict__ runs)
+// a lane per tile of 32 sites: the tile's common key and extremes
+__global__ __launch_bounds__(64) void gvcf_site_tile_kernel(const skgvcf::SitePod* __restrict__ pod, const int32_t n, skgvcf::SiteTile* __restrict__ tiles)
+{
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * skgvcf::TILE_SITES >= n) return;
+    tiles[t] = skgvcf::make_tile(pod, n, t);
+}
+// a lane per site: the block that would start at it -- to the next tile boundary site by site, over whole tiles while they join, then
+// site by site to its end (~len / 32 + 32 steps; the lanes of a wave walk neighbouring sites, whose blocks mostly end at the same place)
+__global__ __launch_bounds__(64) void gvcf_plain_run_kernel(const skgvcf::SitePod* __restrict__ pod, const skgvcf::SiteTile* __restrict__ tiles, const int32_t n,
+                                                            const double frac_tol, const int abs_tol, sk_gvcf_run* __restrict__ runs)
 {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    runs[i] = skgvcf::plain_run(pod, n, i, frac_tol, abs_tol);
+    runs[i] = skgvcf::plain_run(pod, tiles, n, i, frac_tol, abs_tol);
 }
 
 struct GvcfBuffers
@@ -126,9 +134,49 @@ int sk_gvcf_plain_runs_dev(const sk_gvcf_site_summary* dev_summary, const int64_
     a.pod = static_cast<skgvcf::SitePod*>(dev_pod_scratch);
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     hipLaunchKernelGGL(gvcf_site_pod_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(gvcf_plain_run_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a.pod, n, static_cast<double>(opt->block_percent_tol) / 100.,
+    // (the scratch holds the pods and, behind them, the tiles: 16 bytes per site + 32 per 32 sites)
+    skgvcf::SiteTile* tiles = reinterpret_cast<skgvcf::SiteTile*>(static_cast<char*>(dev_pod_scratch) + ((size_t(n) * sizeof(skgvcf::SitePod) + 255) & ~size_t(255)));
+    const int n_tiles = (n + skgvcf::TILE_SITES - 1) / skgvcf::TILE_SITES;
+    hipLaunchKernelGGL(gvcf_site_tile_kernel, dim3((n_tiles + 63) / 64), dim3(64), 0, st, a.pod, n, tiles);
+    hipLaunchKernelGGL(gvcf_plain_run_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a.pod, tiles, n, static_cast<double>(opt->block_percent_tol) / 100.,
                        int(opt->block_abs_tol), dev_runs);
     SK_HIP(hipGetLastError());
+    return 0;
+}
+
+int sk_gvcf_plain_runs(const sk_gvcf_site_summary* summary, const uint32_t* clean_count, const uint32_t* raw_count, const uint32_t* mapq_count,
+                       const sk_gvcf_block_options* opt, int32_t n, sk_gvcf_run* runs)
+{
+    SK_REQUIRE_INIT();
+    if (n < 0 || !opt) return sk_fail("sk_gvcf_plain_runs: bad argument");
+    if (n == 0) return 0;
+    if (!summary || !clean_count || !raw_count || !mapq_count || !runs) return sk_fail("sk_gvcf_plain_runs: null argument");
+    SkContext& ctx = sk_ctx();
+    SK_HIP(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    std::vector<int64_t> off(2 * (size_t(n) + 1), 0);
+    int64_t* clean_off = off.data();
+    int64_t* raw_off = off.data() + n + 1;
+    for (int32_t i = 0; i < n; ++i) {
+        clean_off[i + 1] = clean_off[i] + clean_count[i];
+        raw_off[i + 1] = raw_off[i] + raw_count[i];
+    }
+    auto up = [](const size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t N = size_t(n);
+    const size_t o_sum = 0, o_off = o_sum + up(sizeof(sk_gvcf_site_summary) * N), o_mq = o_off + up(16 * (N + 1)), o_pod = o_mq + up(4 * N),
+                 o_runs = o_pod + up(17 * N + 512), total = o_runs + up(sizeof(sk_gvcf_run) * N);
+    GvcfBuffers& B = gvcf_bufs();
+    if (B.reserve(0, total)) return 1;
+    char* d = static_cast<char*>(B.p[0]);
+    SK_HIP(hipMemcpyAsync(d + o_sum, summary, sizeof(sk_gvcf_site_summary) * N, hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(d + o_off, off.data(), 16 * (N + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(hipMemcpyAsync(d + o_mq, mapq_count, 4 * N, hipMemcpyHostToDevice, st));
+    if (sk_gvcf_plain_runs_dev(reinterpret_cast<const sk_gvcf_site_summary*>(d + o_sum), reinterpret_cast<const int64_t*>(d + o_off),
+                               reinterpret_cast<const int64_t*>(d + o_off) + n + 1, reinterpret_cast<const uint32_t*>(d + o_mq), opt, n, d + o_pod,
+                               reinterpret_cast<sk_gvcf_run*>(d + o_runs), st))
+        return 1;
+    SK_HIP(hipMemcpyAsync(runs, d + o_runs, sizeof(sk_gvcf_run) * N, hipMemcpyDeviceToHost, st));
+    SK_HIP(hipStreamSynchronize(st)); // (`off` is pageable: the copies above have finished by now)
     return 0;
 }
 

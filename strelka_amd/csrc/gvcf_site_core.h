@@ -102,23 +102,79 @@ SKGS_HD inline uint32_t site_filter_key(const sk_gvcf_block_options& o, const in
     return key;
 }
 
-// is_new_value_blockable :59-73 on a stream_stat of which only the extremes matter: the statistic with the new value added has
-// min' = min(min, v), max' = max(max, v), and check_block_tolerance :41-55 reads nothing else (compat_round of an integer-valued
-// minimum is the minimum)
-SKGS_HD inline bool extremes_blockable(const int v, const int mn, const int mx, const double frac_tol, const int abs_tol)
+// is_new_value_blockable :59-73 reads of a stream_stat only its extremes: the statistic with the new value added has min' = min(min, v),
+// max' = max(max, v), and check_block_tolerance :41-55 reads nothing else (compat_round of an integer-valued minimum is the minimum).
+// the extremes of a block's three accumulators (all the join test reads of them)
+struct Extremes
 {
-    const int lo = v < mn ? v : mn, hi = v > mx ? v : mx;
-    const double half_max = double(hi) / 2.0;
-    if (double(lo + abs_tol) >= half_max) return true;
-    const int ftol = int(__builtin_floor(double(lo) * frac_tol));
-    if (ftol <= abs_tol) return false;
-    return double(lo + ftol) >= half_max;
+    int g0, g1, u0, u1, f0, f1; // GQX, used depth, unused depth: minimum, maximum
+    SKGS_HD void start(const SitePod& s)
+    {
+        g0 = g1 = s.gqx;
+        u0 = u1 = int(s.used);
+        f0 = f1 = int(s.unused);
+    }
+    SKGS_HD void take(const int g_lo, const int g_hi, const int u_lo, const int u_hi, const int f_lo, const int f_hi)
+    {
+        g0 = g_lo < g0 ? g_lo : g0;
+        g1 = g_hi > g1 ? g_hi : g1;
+        u0 = u_lo < u0 ? u_lo : u0;
+        u1 = u_hi > u1 ? u_hi : u1;
+        f0 = f_lo < f0 ? f_lo : f0;
+        f1 = f_hi > f1 ? f_hi : f1;
+    }
+};
+// would the three accumulators, with values between these bounds added, still pass check_block_tolerance?  (For one site the bounds are
+// its values.  The test is monotone: lowering a minimum or raising a maximum can only make it fail -- so if it passes for the extremes
+// of a whole run of sites it passes for every prefix of the run.)
+SKGS_HD inline bool extremes_join(const Extremes& e, const int g_lo, const int g_hi, const int u_lo, const int u_hi, const int f_lo, const int f_hi, const double frac_tol,
+                                  const int abs_tol)
+{
+    auto ok = [&](const int lo_new, const int hi_new, const int lo, const int hi) {
+        const int mn = lo_new < lo ? lo_new : lo, mx = hi_new > hi ? hi_new : hi;
+        const double half_max = double(mx) / 2.0;
+        if (double(mn + abs_tol) >= half_max) return true;
+        const int ftol = int(__builtin_floor(double(mn) * frac_tol));
+        if (ftol <= abs_tol) return false;
+        return double(mn + ftol) >= half_max;
+    };
+    return ok(u_lo, u_hi, e.u0, e.u1) && ok(f_lo, f_hi, e.f0, e.f1) && ok(g_lo, g_hi, e.g0, e.g1);
+}
+
+// 32 consecutive sites at once: their common key (TILE_MIXED when they are not all plain with one key) and the extremes of their values
+struct SiteTile
+{
+    uint32_t key;
+    int g0, g1, u0, u1, f0, f1;
+    uint32_t pad;
+};
+enum { TILE_SITES = 32, TILE_MIXED = 0x7fffffffu };
+SKGS_HD inline SiteTile make_tile(const SitePod* pod, const int64_t n, const int64_t t)
+{
+    SiteTile T;
+    T.pad = 0;
+    const int64_t b = t * TILE_SITES;
+    T.key = TILE_MIXED;
+    T.g0 = T.g1 = T.u0 = T.u1 = T.f0 = T.f1 = 0;
+    if (b + TILE_SITES > n) return T; // (a partial tile at the window's end is walked site by site)
+    Extremes e;
+    e.start(pod[b]);
+    uint32_t key = pod[b].key_plain;
+    if (!(key & POD_PLAIN)) return T;
+    for (int64_t j = b + 1; j < b + TILE_SITES; ++j) {
+        if (pod[j].key_plain != key) return T;
+        e.take(pod[j].gqx, pod[j].gqx, int(pod[j].used), int(pod[j].used), int(pod[j].unused), int(pod[j].unused));
+    }
+    T.key = key;
+    T.g0 = e.g0; T.g1 = e.g1; T.u0 = e.u0; T.u1 = e.u1; T.f0 = e.f0; T.f1 = e.f1;
+    return T;
 }
 
 // gvcf_writer::queue_site_record's joining from an empty block at site i (testCanSiteJoinSampleBlockShared :77-122 for two plain
 // sites: equal filters; depth and filtered depth within tolerance of the block; both covered; both 0/0, diploid; GQX within tolerance
-// :163-182; joinSiteToSampleBlock :126-157)
-SKGS_HD inline sk_gvcf_run plain_run(const SitePod* pod, const int64_t n, const int64_t i, const double frac_tol, const int abs_tol)
+// :163-182; joinSiteToSampleBlock :126-157).  Site by site to the next tile boundary, then whole tiles while every site of a tile joins
+// (see extremes_join: the test passes for the tile's extremes), then site by site to the block's end.  tiles: null = site by site.
+SKGS_HD inline sk_gvcf_run plain_run(const SitePod* pod, const SiteTile* tiles, const int64_t n, const int64_t i, const double frac_tol, const int abs_tol)
 {
     sk_gvcf_run r;
     r.len = 0;
@@ -128,29 +184,39 @@ SKGS_HD inline sk_gvcf_run plain_run(const SitePod* pod, const int64_t n, const 
     const SitePod first = pod[i];
     if (!(first.key_plain & POD_PLAIN)) return r;
     const uint32_t key = first.key_plain;
-    int g0 = first.gqx, g1 = first.gqx, u0 = int(first.used), u1 = int(first.used), f0 = int(first.unused), f1 = int(first.unused);
+    Extremes e;
+    e.start(first);
     int64_t j = i + 1;
-    for (; j < n; ++j) {
+    bool open = true;
+    auto site = [&]() { // site j: joins (true) or ends the block
         const SitePod s = pod[j];
-        if (s.key_plain != key) break; // (not plain, or other filters)
-        if (!extremes_blockable(int(s.used), u0, u1, frac_tol, abs_tol)) break;
-        if (!extremes_blockable(int(s.unused), f0, f1, frac_tol, abs_tol)) break;
-        if (!extremes_blockable(s.gqx, g0, g1, frac_tol, abs_tol)) break;
-        u0 = int(s.used) < u0 ? int(s.used) : u0;
-        u1 = int(s.used) > u1 ? int(s.used) : u1;
-        f0 = int(s.unused) < f0 ? int(s.unused) : f0;
-        f1 = int(s.unused) > f1 ? int(s.unused) : f1;
-        g0 = s.gqx < g0 ? s.gqx : g0;
-        g1 = s.gqx > g1 ? s.gqx : g1;
+        if (s.key_plain != key) return false; // (not plain, or other filters)
+        if (!extremes_join(e, s.gqx, s.gqx, int(s.used), int(s.used), int(s.unused), int(s.unused), frac_tol, abs_tol)) return false;
+        e.take(s.gqx, s.gqx, int(s.used), int(s.used), int(s.unused), int(s.unused));
+        return true;
+    };
+    if (tiles) {
+        while (open && j < n && (j % TILE_SITES) != 0) {
+            if (site()) ++j; else open = false;
+        }
+        while (open && j + TILE_SITES <= n) {
+            const SiteTile T = tiles[j / TILE_SITES];
+            if (T.key != key || !extremes_join(e, T.g0, T.g1, T.u0, T.u1, T.f0, T.f1, frac_tol, abs_tol)) break;
+            e.take(T.g0, T.g1, T.u0, T.u1, T.f0, T.f1);
+            j += TILE_SITES;
+        }
+    }
+    while (open && j < n) {
+        if (site()) ++j; else open = false;
     }
     r.len = int32_t(j - i);
     r.filter_key = key & 0xfu;
-    r.gqx_min = g0;
-    r.gqx_max = g1;
-    r.dpu_min = uint32_t(u0);
-    r.dpu_max = uint32_t(u1);
-    r.dpf_min = uint32_t(f0);
-    r.dpf_max = uint32_t(f1);
+    r.gqx_min = e.g0;
+    r.gqx_max = e.g1;
+    r.dpu_min = uint32_t(e.u0);
+    r.dpu_max = uint32_t(e.u1);
+    r.dpf_min = uint32_t(e.f0);
+    r.dpf_max = uint32_t(e.f1);
     return r;
 }
 

@@ -1568,7 +1568,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         wl.refbase = o; o += align256(std::max(n_loci, 1));
         wl.de = o; o += align256(s->genotype ? 4 * std::max<int64_t>(n_bases, 1) : 0);
         wl.gscr = o; o += align256(s->genotype ? 4 * (n_bases + int64_t(n_loci) + 8) : 0);
-        wl.pods = o; o += align256((s->genotype && s->want_runs) ? 16 * int64_t(std::max(n_loci, 1)) : 0);
+        wl.pods = o; o += align256((s->genotype && s->want_runs) ? 17 * int64_t(std::max(n_loci, 1)) + 512 : 0); // (pods, then a tile per 32 of them)
         wl.tmp = o; o += align256(SL.tmp_bytes);
         wl.total = o;
     }

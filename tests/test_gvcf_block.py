@@ -116,3 +116,52 @@ def test_kernel_equals_the_host_statement_at_size():
     assert np.array_equal(blocks[st].tobytes(), hb[st].tobytes()) and int(st.sum()) > 100000
     # every compressible site belongs to exactly one block, blocks tile their stretches
     assert int(blocks["count"][st].sum()) == int(np.sum(kind != 2))
+
+
+# ---- the block that would start at every plain site (sk_gvcf_run: site 10's whole blocks) ------------------------------------------
+def _run_inputs(rng, n, depth=40.0, wobble=0.08, holes=0.01):
+    """sites of a sample at slowly varying depth: long runs of plain sites with a few filters changing along the way, holes (sites
+    that are not plain) and depth steps"""
+    base = depth * (1.0 + 0.6 * np.sin(np.arange(n) / 300.0)) * np.where((np.arange(n) // 900) % 3 == 1, 2.2, 1.0)
+    used = np.maximum(0, rng.normal(base, wobble * base)).astype(np.uint32)
+    unused = rng.poisson(0.05 * used + 0.2).astype(np.uint32)
+    sm = np.zeros(n, capi.GVCF_SITE_SUMMARY_DTYPE)
+    sm["flags"] = (rng.random(n) >= holes) & (used > 0)
+    sm["gqx"] = np.minimum(99, (2.5 * used + rng.integers(0, 4, n))).astype(np.int32)
+    sm["ref_fwd"] = used // 2
+    sm["ref_rev"] = used - used // 2
+    return sm, used, used + unused, (used + unused + rng.integers(0, 3, n)).astype(np.uint32)
+
+
+def test_plain_runs_statement_equals_the_site_by_site_statement():
+    """the walk that steps over whole tiles of 32 sites (csrc/gvcf_site_core.h plain_run, run on the host through the CPU double) against
+    the numpy statement that joins site by site with the reference's stream_stat and check_block_tolerance: blocks of hundreds of sites"""
+    L = _double()
+    L.sk_init(0)
+    rng = np.random.default_rng(5100 + SEED)
+    keys, n_long = set(), 0
+    for opt in (capi.gvcf_block_options(), capi.gvcf_block_options(is_max_depth=1, max_chrom_depth=95.0, block_percent_tol=10, block_abs_tol=1),
+                capi.gvcf_block_options(block_percent_tol=50, block_abs_tol=8, min_homref_gqx=60.0)):
+        sm, cc, rc, mq = _run_inputs(rng, 3000)
+        got = capi.gvcf_plain_runs(sm, cc, rc, mq, opt, library=L)
+        want = pyoracle.gvcf_plain_runs(sm, cc, rc, mq, opt)
+        assert got.tobytes() == want.tobytes()
+        assert (got["len"] == 0).sum() > 5
+        n_long += int((got["len"] > 64).sum())
+        keys |= set(got["filter_key"][got["len"] > 0].tolist())
+    assert len(keys) >= 3 and n_long > 500
+
+
+@pytest.mark.gpu
+def test_plain_runs_kernel_equals_the_host_statement_at_size():
+    """gvcf_site_pod_kernel + gvcf_site_tile_kernel + gvcf_plain_run_kernel against the same statement on the host, 400 000 sites"""
+    capi.init(0)
+    L = _double()
+    L.sk_init(0)
+    rng = np.random.default_rng(5200 + SEED)
+    for opt, n in ((capi.gvcf_block_options(), 400000), (capi.gvcf_block_options(is_max_depth=1, max_chrom_depth=95.0, block_percent_tol=10, block_abs_tol=1), 50000)):
+        sm, cc, rc, mq = _run_inputs(rng, n)
+        got = capi.gvcf_plain_runs(sm, cc, rc, mq, opt)
+        want = capi.gvcf_plain_runs(sm, cc, rc, mq, opt, library=L)
+        assert got.tobytes() == want.tobytes()
+        assert (got["len"] > 256).sum() > 1000
