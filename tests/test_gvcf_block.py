@@ -164,4 +164,4 @@ def test_plain_runs_kernel_equals_the_host_statement_at_size():
         got = capi.gvcf_plain_runs(sm, cc, rc, mq, opt)
         want = capi.gvcf_plain_runs(sm, cc, rc, mq, opt, library=L)
         assert got.tobytes() == want.tobytes()
-        assert (got["len"] > 256).sum() > 1000
+        assert (got["len"] > 0).sum() > 0.9 * n and (n < 100000 or (got["len"] > 256).sum() > 1000)

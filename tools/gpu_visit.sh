@@ -96,7 +96,7 @@ for step in "$@"; do
     sweep)  # $SK_SWEEP_ONLY = names of tools/diag/e2e_sweep.py's settings, $SWEEP_ARGS = "bp segment_bp procs"
       timeout 1500 python tools/diag/e2e_sweep.py $OUT/e2e_sweep.json ${SWEEP_ARGS:-32000000 4000000 8} > $OUT/e2e_sweep.log 2>&1; echo "sweep rc=$?"; tail -c 3000 $OUT/e2e_sweep.log ;;
     tests_gvcf)
-      timeout 900 python -m pytest tests/test_pileup_stream.py tests/test_gpu_parity.py tests/test_e2e_adapter.py -m gpu -x -q -k "stream or gvcf or single_sample or germline_demo" > $OUT/pytest_gvcf.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gvcf.log
+      timeout 900 python -m pytest tests/test_pileup_stream.py tests/test_gpu_parity.py tests/test_e2e_adapter.py tests/test_gvcf_block.py -m gpu -x -q -k "stream or gvcf or single_sample or germline_demo or plain_runs or kernel" > $OUT/pytest_gvcf.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gvcf.log
       tail -4 $OUT/pytest_gvcf.log ;;
     enum_profile)
       timeout 900 python tools/diag/enum_job_profile.py $OUT/enum_profile > $OUT/enum_profile.log 2>&1; echo "enum_profile rc=$?"; tail -c 6000 $OUT/enum_profile.log ;;
