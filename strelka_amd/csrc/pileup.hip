@@ -1311,7 +1311,7 @@ struct sk_pileup_stream
     DevBuf d_ref, d_mask, d_spandel, d_submapped;
     // carried reads: metadata on the host, records and spans on the device
     std::vector<int32_t> c_len, c_nseg, c_pos;
-    std::vector<uint8_t> c_mapq;
+    std::vector<uint8_t> c_mapq, c_level;
     std::vector<sk_path_seg> c_path;
     int64_t c_bases = 0;
     int64_t c_tail_base = 0; // where the carried reads' records start in d_rec[cur]
@@ -1492,7 +1492,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         for (int i = 0; i < n_c; ++i) {
             ro[i] = b; po[i] = sg;
             b += s->c_len[i]; sg += s->c_nseg[i];
-            ps[i] = s->c_pos[i]; fw[i] = 0; mq[i] = s->c_mapq[i]; lv[i] = 0;
+            ps[i] = s->c_pos[i]; fw[i] = 0; mq[i] = s->c_mapq[i]; lv[i] = s->c_level[i]; // (P1 runs over the new reads only: r0)
         }
         if (c_segs) std::memcpy(pa, s->c_path.data(), size_t(8 * c_segs));
         for (int r = 0; r < n_new; ++r) {
@@ -1572,6 +1572,13 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         wl.tmp = o; o += align256(SL.tmp_bytes);
         wl.total = o;
     }
+    // the tier2 columns' room: the bases of the reads that are not tier1-mapped (P1 marks a record REC_TIER2 when its read is not; a
+    // germline run has few such reads: the block that goes back to the host is that much smaller)
+    int64_t n_bases_tier2 = 0;
+    for (int i = 0; i < n_c; ++i)
+        if (s->c_level[i] != SK_MAPLEVEL_TIER1) n_bases_tier2 += s->c_len[i];
+    for (int r = 0; r < n_new; ++r)
+        if (reads->map_level[r] != SK_MAPLEVEL_TIER1) n_bases_tier2 += reads->read_off[r + 1] - reads->read_off[r];
     OutLay& ol = s->ol;
     {
         int64_t o = 0;
@@ -1588,7 +1595,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         ol.summary = o; o += align256(s->genotype ? int64_t(sizeof(sk_gvcf_site_summary)) * std::max(n_loci, 1) : 0);
         ol.runs = o; o += align256((s->genotype && s->want_runs) ? int64_t(sizeof(sk_gvcf_run)) * std::max(n_loci, 1) : 0);
         ol.calls0 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
-        ol.calls1 = o; o += align256(2 * std::max<int64_t>(n_bases, 1));
+        ol.calls1 = o; o += align256(2 * std::max<int64_t>(n_bases_tier2, 1)); // (the tier2 column holds the basecalls of tier2-mapped reads only)
         ol.read_pos = o; o += align256(s->want_read_pos ? 4 * std::max<int64_t>(n_bases, 1) : 0);
         ol.evs_off = o; o += align256(s->want_evs ? 8 * (int64_t(n_loci) + 1) : 0);
         ol.evs = o; o += align256(s->want_evs ? 8 * std::max<int64_t>(n_bases, 1) : 0);
@@ -1758,18 +1765,20 @@ void stream_finish(sk_pileup_stream* s, sk_pileup_window* out)
             }
         }
         std::vector<int32_t> nl, ns, np;
-        std::vector<uint8_t> nm;
+        std::vector<uint8_t> nm, nv;
+        const uint8_t* lv = reinterpret_cast<const uint8_t*>(hi + li.level);
         for (int i = i0; i < n; ++i) {
             nl.push_back(int32_t(ro[i + 1] - ro[i]));
             ns.push_back(int32_t(po[i + 1] - po[i]));
             np.push_back(ps[i]);
             nm.push_back(mq[i]);
+            nv.push_back(lv[i]);
         }
         std::vector<sk_path_seg> npath(pa + (i0 < n ? po[i0] : s->p_segs), pa + s->p_segs);
         s->c_tail_base = (i0 < n) ? ro[i0] : s->p_bases;
         s->c_tail_read = i0;
         s->c_bases = s->p_bases - s->c_tail_base;
-        s->c_len.swap(nl); s->c_nseg.swap(ns); s->c_pos.swap(np); s->c_mapq.swap(nm); s->c_path.swap(npath);
+        s->c_len.swap(nl); s->c_nseg.swap(ns); s->c_pos.swap(np); s->c_mapq.swap(nm); s->c_level.swap(nv); s->c_path.swap(npath);
     }
     s->has_prev = true;
     s->next_begin = std::max(s->next_begin, F);
@@ -1881,7 +1890,7 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, cons
     s->opt.report_begin = report_begin;
     s->opt.report_end = report_end;
     s->opt.largest_total_indel_ref_span_per_read = largest_total_indel_ref_span_per_read;
-    s->c_len.clear(); s->c_nseg.clear(); s->c_pos.clear(); s->c_mapq.clear(); s->c_path.clear();
+    s->c_len.clear(); s->c_nseg.clear(); s->c_pos.clear(); s->c_mapq.clear(); s->c_level.clear(); s->c_path.clear();
     s->c_bases = 0;
     s->c_tail_base = 0;
     s->c_tail_read = 0;

@@ -98,6 +98,8 @@ for step in "$@"; do
     tests_gvcf)
       timeout 900 python -m pytest tests/test_pileup_stream.py tests/test_gpu_parity.py tests/test_e2e_adapter.py tests/test_gvcf_block.py -m gpu -x -q -k "stream or gvcf or single_sample or germline_demo or plain_runs or kernel" > $OUT/pytest_gvcf.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gvcf.log
       tail -4 $OUT/pytest_gvcf.log ;;
+    sharing)  # caller processes per GPU: $SK_SHARING_JOBS (default 8,12,16), ${SHARING_ARGS:-32000000 2000000}
+      SK_SHARING_REF_JOBS=${SK_SHARING_REF_JOBS:-8,16} SK_SHARING_JOBS=${SK_SHARING_JOBS:-8,12,16} timeout 1200 python tools/diag/e2e_sharing.py ${SHARING_ARGS:-32000000 2000000} > $OUT/sharing.txt 2>&1; echo "sharing rc=$?"; cat $OUT/sharing.txt | tail -12 ;;
     enum_profile)
       timeout 900 python tools/diag/enum_job_profile.py $OUT/enum_profile > $OUT/enum_profile.log 2>&1; echo "enum_profile rc=$?"; tail -c 6000 $OUT/enum_profile.log ;;
     loci)
