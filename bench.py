@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--e2e-max-procs-per-gpu", type=int, default=8,
                     help="caller processes that share one GPU in the end-to-end leg (beyond ~8 the device's scheduler time-slices them: "
                          "profiles/r03_v10_processes_per_gpu.txt, r03_v11_gpu_sharing_sdma.txt); the reference gets the same number of cores")
+    ap.add_argument("--realign-processes", type=int, default=8, help="caller processes of the multi-process whole-read leg (0: skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
     ap.add_argument("--cpu-loci", type=int, default=2000000, help="loci in the CPU-baseline sample")
@@ -323,6 +324,47 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
         shutil.rmtree(root, ignore_errors=True)
 
 
+def realign_processes_leg(args, n_procs):
+    """The whole read path (rows a1-a7, device legs) driven the way the reference is driven for cpu_baseline: one single-threaded caller
+    process per core, all at once -- here n_procs processes sharing the one GPU (at most 8: beyond that the driver time-slices them).
+    Every process runs `bench.py --only realign` (the same scenarios, the same jobs as the one-process legs); the timed regions are
+    started together through ready / go files; rate = all reads / (last end - first start).  Runs before this process has a GPU
+    context of its own (see the end-to-end legs)."""
+    import shutil
+    import subprocess
+    import tempfile
+    sync = tempfile.mkdtemp(prefix="sk_bench_sync_")
+    try:
+        env = dict(os.environ, SK_BENCH_SYNC_DIR=sync)
+        steps = max(3, args.steps // 4)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--only", "realign", "--steps", str(steps), "--realign-reads", str(args.realign_reads)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for _ in range(n_procs)]
+        for name in ("sparse", "dense"):
+            deadline = time.time() + 600
+            while len(glob.glob(os.path.join(sync, "ready_%s_*" % name))) < n_procs:
+                if time.time() > deadline or any(p.poll() not in (None, 0) for p in procs):
+                    for p in procs:
+                        p.kill()
+                    return {"skipped": "a worker of the multi-process whole-read leg failed: " + b" ".join(p.stderr.read()[-300:] for p in procs if p.poll()).decode(errors="replace")}
+                time.sleep(0.01)
+            open(os.path.join(sync, "go_" + name), "w").close()
+        outs = []
+        for p in procs:
+            o, e = p.communicate(timeout=900)
+            if p.returncode != 0:
+                return {"skipped": "worker exit %d: %s" % (p.returncode, e.decode(errors="replace")[-300:])}
+            outs.append(json.loads(o.decode().strip().splitlines()[-1])["legs"])
+        res = {"processes": n_procs, "steps": steps}
+        for name in ("sparse", "dense"):
+            reads = sum(o[name]["reads"] for o in outs)
+            span = max(o[name]["t1"] for o in outs) - min(o[name]["t0"] for o in outs)
+            res["realign%s_reads_per_s" % ("" if name == "sparse" else "_dense")] = reads / span
+            res["%s_overlap" % name] = min(o[name]["t1"] for o in outs) - max(o[name]["t0"] for o in outs) > 0
+        return res
+    finally:
+        shutil.rmtree(sync, ignore_errors=True)
+
+
 def a5_leg(args, capi, synth):
     """Row a5 measured as ONE function, like the reference's (scoreCandidateAlignment, starling_read_align_score.cpp:261-499):
     from the candidate alignments as the search left them on the device (position, path, indel indices: PCal) to one double each --
@@ -427,6 +469,10 @@ def main():
             e2e = e2e_leg(args, 0, 1, local_rank, lambda: None, lambda v: v, with_reference=not args.no_cpu_baseline)
         if args.e2e_somatic_bp > 0 and args.only in ("", "e2e", "e2e_somatic"):
             e2e_somatic = e2e_leg(args, 0, 1, local_rank, lambda: None, lambda v: v, with_reference=not args.no_cpu_baseline, mode="somatic")
+    realign_processes = None
+    if world == 1 and not args.only and args.realign_processes > 0:
+        from strelka_amd import farm as _farm
+        realign_processes = realign_processes_leg(args, max(1, min(args.realign_processes, len(_farm.usable_cores()), args.e2e_max_procs_per_gpu)))
     e2e_failed = [name for name, leg in (("e2e", e2e), ("e2e_somatic", e2e_somatic)) if leg and leg.get("identical") is False]
     for name in e2e_failed:
         print("bench.py: the %s leg's outputs are NOT identical to the reference's: %s" % (name, json.dumps(locals()[name]["first_difference"])),
@@ -469,6 +515,28 @@ def main():
         alg = 6 * db.n_calls + B_BYTES_PER_LOCUS_FIXED * db.n_loci
         print(json.dumps({"only": "loci", "loci": db.n_loci, "calls": db.n_calls, "kernel_ms": ms, "loci_per_s": db.n_loci / (ms * 1e-3),
                           "algorithmic_bytes": alg, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}))
+        return
+
+    if args.only == "realign":
+        # one caller process of the multi-process whole-read leg (realign_processes_leg): the sparse and the dense scenarios through
+        # sk_realign_job_add_reads + _run on the device; ready / go files keep the processes' timed regions together
+        res = {}
+        legs = {}
+        for name, kw in (("sparse", dict(enumeration=2)), ("dense", dict(enumeration=2, max_indels=14, reads=args.realign_reads // 6))):
+            step, n_reads, _ = whole_read_leg(args, capi, synth, np.random.default_rng(4242), **kw)
+            legs[name] = (step, n_reads)
+        sync = os.environ.get("SK_BENCH_SYNC_DIR")
+        for name, (step, n_reads) in legs.items():
+            if sync:
+                open(os.path.join(sync, "ready_%s_%d" % (name, os.getpid())), "w").close()
+                while not os.path.exists(os.path.join(sync, "go_" + name)):
+                    time.sleep(0.001)
+            t0 = time.time()
+            for _ in range(args.steps):
+                step()
+            t1 = time.time()
+            res[name] = {"reads": n_reads * args.steps, "t0": t0, "t1": t1}
+        print(json.dumps({"only": "realign", "legs": res}))
         return
 
     if args.only == "pileup":
@@ -689,15 +757,9 @@ def main():
 
     # ---- rows a1-a7: the whole read path as the adapter drives it (host stages + kernel), one host thread ----
     wr = {}
-    from strelka_amd import farm as _farm
-    n_cores = len(_farm.usable_cores())
     for name, kw in (("", dict(enumeration=2)), ("_host_enumeration", dict(enumeration=0)),
                      ("_dense", dict(enumeration=2, max_indels=14, reads=args.realign_reads // 6)),
-                     ("_dense_host_enumeration", dict(enumeration=0, max_indels=14, reads=args.realign_reads // 6)),
-                     # the same jobs with the host stages (gate, normalisation, packing; results into the reads' structures) spread
-                     # over the cores cpu_baseline's realign legs use: sk_realign_options.host_threads
-                     ("_all_cores", dict(enumeration=2, host_threads=n_cores)),
-                     ("_dense_all_cores", dict(enumeration=2, max_indels=14, reads=args.realign_reads // 6, host_threads=n_cores))):
+                     ("_dense_host_enumeration", dict(enumeration=0, max_indels=14, reads=args.realign_reads // 6))):
         wr_step, wr_reads, wr_cals = whole_read_leg(args, capi, synth, np.random.default_rng(4242), **kw)
         n_wr = max(2, args.steps // 4)
         dt_wr, wr_done, _ = timed(wr_step, n_wr, 1, wr_reads)
@@ -795,12 +857,12 @@ def main():
         "roofline_allele_group": roof("allele_group_kernel", group_alg_bytes, kms_g, traffic.get("allele_group_kernel")),
         "roofline_pileup": roof("pileup_read_kernel+2*pileup_column_kernel_t", pileup_alg_bytes, kms_p, pil_traffic),
         "roofline_global_align": roof("global_align_kernel", ga_alg_bytes, kms_ga, traffic.get("global_align_kernel")),
-        "realign_host_threads": 1, "realign_all_cores_host_threads": n_cores,
+        "realign_host_threads": 1,
         "realign_note": "whole read path (rows a1-a7) through sk_realign_job_add_reads + _run, one host thread, host buffers in and out; "
                         "realign_* = candidate alignments listed, flattened, scored and selected / indel-scored (stage 3) on the device "
                         "(enumeration=2), *_host_enumeration = listed, flattened and finished on the host (round 1's path), *_dense = scenarios "
-                        "with up to 14 indels around a read, *_all_cores = the device path with the job's host stages on as many host threads as "
-                        "cpu_baseline's realign legs have cores (sk_realign_options.host_threads)",
+                        "with up to 14 indels around a read, realign_processes = the device legs driven by several caller processes at "
+                        "once on the one GPU, as the reference is run for cpu_baseline (one process per core): rates summed",
         "feed_inflated_bytes_per_s": feed_bytes / dt_f, "feed_ms_per_step": dt_f / max(2, args.steps // 4) * 1e3, "feed_bgzf_blocks_per_step": feed_blocks,
         "roofline_feed": roof("bgzf_inflate_kernel+bgzf_crc32_kernel", feed_alg_bytes, kms_f,
                               (traffic["bgzf_inflate_kernel"] + traffic["bgzf_crc32_kernel"]) if all(k in traffic for k in ("bgzf_inflate_kernel", "bgzf_crc32_kernel")) else None),
@@ -822,6 +884,7 @@ def main():
     out["roofline"]["note"] = ("scoreCandidateAlignment as one kernel, from the records the device search left to one double each; `traffic` from the "
                                "--only a5 counter passes (tools/gpu_visit.sh pmc_traffic); the table sums alone over a prepared batch are roofline_sum_only; "
                                "the staged chain it replaced (F1-F3 + A1c, $SK_A5_FUSED=0) is 2.8x slower on this job (profiles/r04_*)")
+    out["realign_processes"] = realign_processes
     out["e2e"] = e2e
     out["e2e_somatic"] = e2e_somatic
     if rank == 0:

@@ -33,15 +33,15 @@ for step in "$@"; do
     bench)
       timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.json ;;
     bench_kernels)
-      timeout 600 python bench.py --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 > $OUT/bench_kernels.json 2> $OUT/bench_kernels.err; echo "bench_kernels rc=$?" ;;
+      timeout 600 python bench.py --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 --realign-processes 0 > $OUT/bench_kernels.json 2> $OUT/bench_kernels.err; echo "bench_kernels rc=$?" ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log ;;
     ktrace)
-      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 > $OUT/ktrace.log 2>&1
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 --realign-processes 0 > $OUT/ktrace.log 2>&1
       find $OUT/ktrace -name "*kernel_stats.csv" | head -2 ;;
     pmc_traffic)
       for c in FETCH_SIZE WRITE_SIZE; do
-        timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 > $OUT/pmc_$c.log 2>&1
+        timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 --realign-processes 0 > $OUT/pmc_$c.log 2>&1
         timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_a5_$c -o pmc -- python bench.py --only a5 --steps 10 --warmup 2 > $OUT/pmc_a5_$c.log 2>&1
       done
       python tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json 2>$OUT/pmc_traffic.err; head -c 600 $OUT/pmc_traffic.json ;;
