@@ -46,8 +46,10 @@ def main():
                 sys.exit(1)
             reads += sum(r is not None for r in res[0])
             cals += int(off[0][-1])
+    one_wait, redone, staged = capi.RealignJob.device_job_counts()
     print("device enumeration == host enumeration: %d reads, %d candidate alignments, %d enumerated on the device (stage 3 on the device: %d), "
-          "%d handed to the host; %.0f s" % (reads, cals, dev, s3_dev, host_instead, time.time() - t0))
+          "%d handed to the host; device jobs: %d as one sequence with one wait, %d of them run again the staged way, %d staged in all; %.0f s"
+          % (reads, cals, dev, s3_dev, host_instead, one_wait, redone, staged, time.time() - t0))
 
 
 if __name__ == "__main__":
