@@ -105,6 +105,8 @@ bool germline_sample_stats_counts(starling_pos_processor_base& pp, const pos_t p
 /// homozygous-reference site and has gone into the writer's open block (gvcf_writer::skip_to_pos + add_site_internal on a kept
 /// locus); false = the reference's process_pos_snp runs (its cleaned pileup is made first if process_pos_sample_stats left it out)
 bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos);
+/// a new region begins (starling_pos_processor_base::resetRegionBase): no block installed by site 10 reaches into it
+void gvcf_reset_region();
 /// at the start of a region: the options that decide a plain site's filters and block membership (gvcf_options, the chromosome's depth
 /// ceiling) to the sample's pileup stream, which then returns the block that would start at every plain site (sk_gvcf_run)
 void gvcf_configure_stream(starling_pos_processor_base& pp, const unsigned sampleIndex, ::sk_pileup_stream* stream);

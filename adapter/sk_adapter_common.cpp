@@ -280,6 +280,7 @@ void on_reset_region(starling_pos_processor_base& pp)
     s.sites.clear();
     s.somaticSites.clear();
     pileup_reset_region(pp);
+    gvcf_reset_region();
 }
 
 void on_set_head_pos(starling_pos_processor_base& /*pp*/, const pos_t pos, const unsigned readBufferShift, const unsigned indelSpan)

@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <limits>
 #include <memory>
 
 namespace sk_adapter
@@ -81,7 +82,7 @@ struct GvcfFast
     pos_t cleanSkippedPos = 0;
     std::unique_ptr<GermlineDiploidSiteLocusInfo> scratch;
     bool isBlocks = false; ///< the window brings the block that would start at every plain site (sk_gvcf_run): whole blocks are installed
-    pos_t blockTo = 0;     ///< positions below are members of the block installed last (their process_pos_snp has nothing left to do)
+    pos_t blockTo = std::numeric_limits<pos_t>::min(); ///< positions below are members of the block installed last (their process_pos_snp has nothing left to do)
     unsigned long plainSites = 0, referenceSites = 0, declinedByState = 0;
     unsigned long blocksInstalled = 0, blockSites = 0, blocksDeclined = 0, filterKeyMismatches = 0;
     ~GvcfFast()
@@ -151,6 +152,14 @@ bool isPlainInWindow(const SiteChunk& c, const size_t k, const snp_pos_info& pi)
     return (c.summary[k].flags & 1u) != 0 && c.ploidy[k] == 2 && c.rawCount[k] == pi.calls.size();
 }
 
+}
+
+void gvcf_reset_region()
+{
+    // (a process may call several regions, on any chromosome: nothing of the last one's installed block carries over)
+    GvcfFast& g(gf());
+    g.blockTo = std::numeric_limits<pos_t>::min();
+    g.isCleanSkipped = false;
 }
 
 void gvcf_configure_stream(starling_pos_processor_base& pp, const unsigned sampleIndex, sk_pileup_stream* stream)

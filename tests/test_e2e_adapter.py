@@ -597,3 +597,26 @@ def test_single_sample_gvcf_blocks_from_the_window_gpu(tmp_path, which, inputs):
     d, length = SYNTH_SETS[which]
     extra = (_variant_inputs(tmp_path, d, length) + _ploidy_and_nocompress(tmp_path, length)) if inputs else []
     _single_sample("amd", tmp_path, which, extra=extra, min_plain=0.5)
+
+
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_single_sample_gvcf_blocks_with_regions_out_of_order(tmp_path):
+    """several --region of one process, the later one LOWER on the chromosome than the earlier one (as a second chromosome's would be):
+    nothing of a block installed in one region may carry into the next"""
+    from strelka_amd import farm
+    d = E.wgs_dataset(400000)
+    outs, err = {}, None
+    for v in ("ref", "dbl"):
+        o = str(tmp_path / v) + "/"
+        os.makedirs(o, exist_ok=True)
+        outs[v] = o
+        argv = farm.germline_segment_argv("starling2_" + v, o, [os.path.join(d, "wgs.bam")], ["chrW:250001-400000", "chrW:1-120000"], os.path.join(d, "wgs.fa"),
+                                          chrom_depth=os.path.join(d, "chrom_depth.txt"))
+        p = E.run(argv, env={"STRELKA_AMD_VERBOSE": "1"} if v != "ref" else None, timeout=1800)
+        if v != "ref":
+            err = p.stderr.decode()
+    for f in ("variants.vcf", "genome.S1.vcf"):
+        want, got = E.vcf_body(outs["ref"] + f, keep_header=True), E.vcf_body(outs["dbl"] + f, keep_header=True)
+        assert len(want) > 100 and got == want, f
+    g = _gvcf_counters(err)
+    assert g["gvcf_blocks_installed"] > 1000 and g["gvcf_block_sites"] > 150000, g
