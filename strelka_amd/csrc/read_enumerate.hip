@@ -800,6 +800,9 @@ constexpr int F5_MAX_POOL = 768;
 #ifndef F5_SORT
 #define F5_SORT 1 // experiments: 0 = the set's order
 #endif
+#ifndef F5_WALK
+#define F5_WALK 1 // experiments: 0 = the walk as branches (f5_walk), 1 = as one loop of selects (f5_walk_selects)
+#endif
 constexpr int F5_TAB = 32;       // span of table indices the indels of one round's candidate alignments may cover
 
 static_assert(F5_TAB <= 64, "the table copy is a lane an entry");
@@ -832,6 +835,7 @@ struct F5Tab // what the walk reads of a table entry
     int32_t pos;
     uint32_t del, ins_len;
     uint32_t type_cand; // type | cand << 8
+    int32_t ins_at;     // where the entry's insert sequence starts in the read's pool, -1 = it is not there (ins_idx / ins_off by entry)
 };
 
 template <int MAXR>
@@ -1025,6 +1029,133 @@ __device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo,
     return int64_t(read_offset) == int64_t(read_len);
 }
 
+// The same walk as ONE loop of selects (F5_WALK 1): f5_walk's body is four branches the lanes of a wave take in turn -- ~1 000 instructions
+// a turn, two thirds of them the scalar unit's mask bookkeeping (profiles/r05_f5_history.txt) -- and a wave makes the turns of its longest
+// path.  Here what the branches have in common is computed once for every lane and selected: the segment kinds as bit sets over the
+// path (one bit per 4-bit type: a run of insert / delete segments, the first and last match segment are shifts and bit counts, not
+// loops), getMatchingIndelKey as two 8-bit sets (the entries that match, the entries past the position) and a bit count, the insert's
+// place in the pool from the table copy (F5Tab::ins_at).  Only a swap (insert + delete run: rare) keeps a branch of its own.  The walk
+// writes the alignment's transitions into its slot itself (what `put` / `on_op` of the caller do for f5_walk); returns the number of
+// transitions, -1 = leave the read to the host form.
+template <typename LDS>
+__device__ __forceinline__ int f5_walk_selects(LDS& S, const F5Rec c, const bool has, const int tab_lo, const int32_t win_begin, uint8_t* consulted,
+                                               const int32_t L, const int32_t P, uint32_t* const myslot)
+{
+    constexpr uint64_t N1 = 0x1111111111111111ull;
+    const uint64_t types = c.types, p_l0 = c.l0, p_l1 = c.l1, p_l2 = c.l2, p_l3 = c.l3;
+    const int aps = has ? c.n_seg() : 0;
+    auto eq4 = [=](const unsigned v) -> uint64_t { // bit 4 i: segment i is of type v
+        uint64_t x = types ^ (N1 * v);
+        x |= x >> 1;
+        x |= x >> 2;
+        return ~x & N1;
+    };
+    auto seg_len = [=](const int i) -> unsigned {
+        const uint64_t lo = (i & 4) ? p_l1 : p_l0, hi = (i & 4) ? p_l3 : p_l2;
+        return unsigned(((i & 8) ? hi : lo) >> (16 * (i & 3))) & 0xffffu;
+    };
+    const uint64_t in_path = (aps >= 16) ? N1 : (((1ull << (4 * aps)) - 1ull) & N1);
+    const uint64_t M4 = (eq4(SK_SEG_MATCH) | eq4(SK_SEG_SEQ_MATCH) | eq4(SK_SEG_SEQ_MISMATCH)) & in_path;
+    const uint64_t I4 = eq4(SK_SEG_INSERT) & in_path, D4 = eq4(SK_SEG_DELETE) & in_path;
+    // get_match_edge_segments, align_path.cpp:735-752
+    const int ends_first = M4 ? (__builtin_ctzll(M4) >> 2) : aps, ends_second = M4 ? ((63 - __builtin_clzll(M4)) >> 2) : aps;
+    // the alignment's indels, read once
+    const int ni = c.n_indels();
+    int32_t k_pos[F5_INDELS];
+    uint32_t k_del[F5_INDELS], k_ins[F5_INDELS];
+    unsigned kind_set = 0; // bit k: entry k is an indel or a sequence mismatch (not a breakpoint)
+#pragma unroll
+    for (int k = 0; k < F5_INDELS; ++k) {
+        const F5Tab& ci = S.tab[((k < ni) ? c.indel(k) : tab_lo) - tab_lo];
+        k_pos[k] = ci.pos;
+        k_del[k] = ci.del;
+        k_ins[k] = ci.ins_len;
+        const unsigned ty = ci.type_cand & 0xffu;
+        kind_set |= (k < ni && (ty == SK_INDEL_INDEL || ty == SK_INDEL_MISMATCH)) ? (1u << k) : 0u;
+    }
+    const unsigned ni_set = (1u << ni) - 1u;
+    int pi = 0, n_ent = 0;
+    int32_t pos = 0, ref_head_pos = c.pos(); // (read_offset of the reference's walk)
+    unsigned npen = 0;
+    bool bad = false;
+    for (;;) {
+        const bool live = pi < aps && !bad;
+        if (!__any(live)) break;
+        const int sh = 4 * (pi & 15);
+        const unsigned ty = unsigned(types >> sh) & 15u, ln = seg_len(pi & 15);
+        // the run of insert / delete segments that starts here (is_segment_swap_start, align_path.cpp:868-895: a swap = both kinds in it)
+        const uint64_t not_run = ~((I4 | D4) >> sh) & N1;
+        const int run4 = not_run ? __builtin_ctzll(not_run) : 64;
+        const uint64_t run_set = (run4 >= 64) ? ~0ull : ((1ull << run4) - 1ull);
+        const bool is_swap = live && ((I4 >> sh) & run_set) != 0ull && ((D4 >> sh) & run_set) != 0ull;
+        const bool is_match = (ty == SK_SEG_MATCH || ty == SK_SEG_SEQ_MATCH), is_clip = (ty == SK_SEG_SOFT_CLIP);
+        const bool is_indel_seg = is_swap || ty == SK_SEG_SEQ_MISMATCH || ty == SK_SEG_INSERT || ty == SK_SEG_DELETE;
+        unsigned del_len = (ty == SK_SEG_INSERT) ? 0u : ln, ins_len = (ty == SK_SEG_DELETE) ? 0u : ln;
+        int n_seg = 1;
+        unsigned read_step = (is_match || ty == SK_SEG_SEQ_MISMATCH || ty == SK_SEG_INSERT || is_clip) ? ln : 0u; // increment_path, align_path_util.hh:38-68
+        unsigned ref_step = (is_match || ty == SK_SEG_SEQ_MISMATCH || ty == SK_SEG_DELETE || ty == SK_SEG_SKIP) ? ln : 0u;
+        if (is_swap) { // swap_info, align_path_util.hh:75-106
+            n_seg = run4 >> 2;
+            del_len = ins_len = 0;
+            for (int k = 0; k < n_seg; ++k) {
+                const unsigned l = seg_len((pi + k) & 15);
+                if ((I4 >> (4 * ((pi + k) & 15))) & 1ull) ins_len += l;
+                else del_len += l;
+            }
+            read_step = ins_len;
+            ref_step = del_len;
+        }
+        // getMatchingIndelKey, starling_read_align_score.cpp:177-228: the edge indels outside the match segments; between them the one
+        // entry of the alignment's that is this indel -- the reference stops at a second match and at the first entry past the position
+        unsigned match_set = 0, past_set = 0;
+#pragma unroll
+        for (int k = 0; k < F5_INDELS; ++k) {
+            const bool m = (k_pos[k] == ref_head_pos) && (k_del[k] == del_len) && (k_ins[k] == ins_len);
+            match_set |= m ? (1u << k) : 0u;
+            past_set |= (k_pos[k] > ref_head_pos) ? (1u << k) : 0u;
+        }
+        match_set &= kind_set;
+        past_set &= ni_set & ~match_set;
+        const unsigned before_past = match_set & ((past_set & (0u - past_set)) - 1u); // (no entry past: every bit)
+        const int k_found = int(__builtin_ctz(before_past | 0x100u)) & 7;
+        int key = (__builtin_popcount(before_past) == 1) ? c.indel(k_found) : -2;
+        key = (pi < ends_first) ? c.lead() : (pi > ends_second) ? c.trail() : key;
+        const bool key_ok = key >= 0;
+        const F5Tab te = S.tab[(key_ok ? key : tab_lo) - tab_lo];
+        const bool indel_ok = live && is_indel_seg && key_ok;
+        if (indel_ok && consulted) consulted[key] = 1; // job_cand
+        const bool pen = is_indel_seg && (te.type_cand >> 8) == 0u;
+        const int32_t head = (pi < ends_first) ? int32_t(te.ins_len) - int32_t(ln) : 0;
+        // the op: bases of the pool (a match segment's window bytes, an indel's insert sequence), a soft clip, or a penalty alone
+        const bool ins_bases = is_indel_seg && ins_len > 0u;
+        const bool ins_ok = ins_len <= 0xffffu && head >= 0 && uint32_t(head) + ins_len <= te.ins_len && te.ins_at >= 0;
+        const bool bases = ins_bases || is_match;
+        const int32_t src = ins_bases ? te.ins_at + head : ref_head_pos - win_begin;
+        const unsigned len = ins_bases ? ins_len : ln;
+        const bool known = is_indel_seg || is_match || is_clip || ty == SK_SEG_SKIP || ty == SK_SEG_HARD_CLIP;
+        bool fail = !known || (is_indel_seg && !key_ok) || (ins_bases && !ins_ok);
+        const bool entry = (bases || (is_clip && !is_indel_seg)) && len > 0u;
+        if (entry) {
+            fail = fail || pos + int32_t(len) > L || (bases && (src < 0 || int64_t(src) + int64_t(len) > int64_t(P)));
+            const int hidx = bases ? int(src) - pos : 0;
+            fail = fail || n_ent > F5_SEGS || npen > 4u || hidx < -256 || hidx > 3839;
+            if (live && !fail) myslot[f5_ent_word(n_ent)] = unsigned(pos) | (npen << 9) | (bases ? 0u : 1u << 15) | (unsigned(hidx + 256) << 16);
+        }
+        if (live) {
+            bad = fail;
+            n_ent += entry ? 1 : 0;
+            npen = entry ? (pen ? 1u : 0u) : npen + (pen ? 1u : 0u);
+            pos += int32_t(read_step);
+            ref_head_pos += int32_t(ref_step);
+            pi += n_seg;
+        }
+    }
+    if (!has) return 0;
+    if (bad || pos != L || n_ent > F5_SEGS || npen > 4u) return -1;
+    myslot[f5_ent_word(n_ent)] = unsigned(L) | (npen << 9) | (256u << 16); // trailing penalties
+    return n_ent + 1;
+}
+
 // TIMING: the cycle stamps of $SK_F5_TIMING (fa.dbg); without it the stamps are constants and their s_memtime + waits are gone
 template <int MAXR, bool TIMING>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void flatten_score_kernel(const FusedScoreArgs fa)
@@ -1204,6 +1335,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 e.del = g.del;
                 e.ins_len = g.ins_len;
                 e.type_cand = unsigned(g.type) | (unsigned(g.cand) << 8);
+                e.ins_at = -1;
+                for (int i = n_ins - 1; i >= 0; --i) // (the first of the read's inserts with this index, as the look-up below)
+                    if (S.ins_idx[i] == tab_lo + lane) e.ins_at = S.ins_off[i];
                 S.tab[lane] = e;
             }
         }
@@ -1214,6 +1348,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // op that covers read positions, and one for the read's end
         int n_ent = 0;
         bool bad = false;
+#if F5_WALK
+        {
+            const unsigned long long tA0 = now();
+            n_ent = f5_walk_selects(S, rec, has, tab_lo, win_begin, a.job.consulted, L, P, myslot);
+            const unsigned long long tA1 = now();
+            stamp[7] += tA1 - tA0; // the walk
+            bad = n_ent < 0;
+            if (has) {
+                // the candidate-status lookups the host form performs for every indel of the alignment (cal_to_c)
+                if (a.job.consulted) {
+                    const int ni = rec.n_indels();
+                    for (int i = 0; i < ni; ++i) a.job.consulted[rec.indel(i)] = 1;
+                    if (rec.lead() >= 0) a.job.consulted[rec.lead()] = 1;
+                    if (rec.trail() >= 0) a.job.consulted[rec.trail()] = 1;
+                }
+                if (bad) a.status[r] = ST_FAIL;
+            }
+            stamp[3] += now() - tA1; // candidate-status marks
+        }
+#else
         if (has) {
             int pos = 0;
             unsigned npen = 0;
@@ -1252,6 +1406,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (bad) a.status[r] = ST_FAIL;
             stamp[3] += now() - tA1; // candidate-status marks
         }
+#endif
         __builtin_amdgcn_wave_barrier();
         const unsigned long long td = now();
         stamp[4] += td - tc; // phase A
