@@ -800,6 +800,9 @@ constexpr int F5_MAX_POOL = 768;
 #ifndef F5_SORT
 #define F5_SORT 1 // experiments: 0 = the set's order
 #endif
+#ifndef F5_SUM
+#define F5_SUM 1 // experiments: 0 = phase B as round 4 left it
+#endif
 #ifndef F5_WALK
 #define F5_WALK 1 // experiments: 0 = the walk as branches (f5_walk), 1 = as one loop of selects (f5_walk_selects)
 #endif
@@ -843,6 +846,7 @@ struct F5Lds
 {
     double row[(MAXR + 8) * F5_ROW];
     double zero; // 0.0
+    uint64_t live[9]; // entry m: 0x01 in the m low bytes (the positions of an eight-base step that belong to the op)
     uint8_t read[MAXR + 8];
     uint8_t hap[F5_MAX_POOL + 8];
     uint32_t slot[64 * F5_SLOT];
@@ -1059,25 +1063,35 @@ __device__ __forceinline__ int f5_walk_selects(LDS& S, const F5Rec c, const bool
     const uint64_t I4 = eq4(SK_SEG_INSERT) & in_path, D4 = eq4(SK_SEG_DELETE) & in_path;
     // get_match_edge_segments, align_path.cpp:735-752
     const int ends_first = M4 ? (__builtin_ctzll(M4) >> 2) : aps, ends_second = M4 ? ((63 - __builtin_clzll(M4)) >> 2) : aps;
-    // the alignment's indels, read once
+    // the alignment's indels, read once: position and the two lengths as one word (del << 16 | ins; an entry that is a breakpoint, or no
+    // entry, holds a word no segment asks for); lengths of 0xffff and more are left to the host form
     const int ni = c.n_indels();
+    int ni_wave = 0; // (the most indels any of the wave's alignments holds: the entries past it are not looked at)
+#pragma unroll
+    for (int k = 1; k <= F5_INDELS; ++k) ni_wave = __any(ni >= k) ? k : ni_wave;
     int32_t k_pos[F5_INDELS];
-    uint32_t k_del[F5_INDELS], k_ins[F5_INDELS];
-    unsigned kind_set = 0; // bit k: entry k is an indel or a sequence mismatch (not a breakpoint)
+    uint32_t k_pack[F5_INDELS];
+    bool bad = false;
 #pragma unroll
     for (int k = 0; k < F5_INDELS; ++k) {
-        const F5Tab& ci = S.tab[((k < ni) ? c.indel(k) : tab_lo) - tab_lo];
-        k_pos[k] = ci.pos;
-        k_del[k] = ci.del;
-        k_ins[k] = ci.ins_len;
-        const unsigned ty = ci.type_cand & 0xffu;
-        kind_set |= (k < ni && (ty == SK_INDEL_INDEL || ty == SK_INDEL_MISMATCH)) ? (1u << k) : 0u;
+        k_pos[k] = INT_MIN;
+        k_pack[k] = 0xffffffffu;
+        if (k < ni_wave) {
+            const F5Tab& ci = S.tab[((k < ni) ? c.indel(k) : tab_lo) - tab_lo];
+            const unsigned ty = ci.type_cand & 0xffu;
+            const bool kind = (ty == SK_INDEL_INDEL || ty == SK_INDEL_MISMATCH);
+            if (k < ni) {
+                k_pos[k] = ci.pos;
+                if (kind) {
+                    k_pack[k] = (ci.del << 16) | ci.ins_len;
+                    bad = bad || ci.del >= 0xffffu || ci.ins_len >= 0xffffu;
+                }
+            }
+        }
     }
-    const unsigned ni_set = (1u << ni) - 1u;
     int pi = 0, n_ent = 0;
     int32_t pos = 0, ref_head_pos = c.pos(); // (read_offset of the reference's walk)
     unsigned npen = 0;
-    bool bad = false;
     for (;;) {
         const bool live = pi < aps && !bad;
         if (!__any(live)) break;
@@ -1107,18 +1121,20 @@ __device__ __forceinline__ int f5_walk_selects(LDS& S, const F5Rec c, const bool
         }
         // getMatchingIndelKey, starling_read_align_score.cpp:177-228: the edge indels outside the match segments; between them the one
         // entry of the alignment's that is this indel -- the reference stops at a second match and at the first entry past the position
-        unsigned match_set = 0, past_set = 0;
+        const unsigned asked = (del_len << 16) | ins_len;
+        const bool askable = del_len < 0xffffu && ins_len < 0xffffu;
+        int k_found = 0, n_found = 0;
+        bool open = true;
 #pragma unroll
         for (int k = 0; k < F5_INDELS; ++k) {
-            const bool m = (k_pos[k] == ref_head_pos) && (k_del[k] == del_len) && (k_ins[k] == ins_len);
-            match_set |= m ? (1u << k) : 0u;
-            past_set |= (k_pos[k] > ref_head_pos) ? (1u << k) : 0u;
+            if (k < ni_wave) {
+                const bool m = open && k_pos[k] == ref_head_pos && k_pack[k] == asked;
+                k_found = m ? k : k_found;
+                n_found += m ? 1 : 0;
+                open = open && (m || k_pos[k] <= ref_head_pos);
+            }
         }
-        match_set &= kind_set;
-        past_set &= ni_set & ~match_set;
-        const unsigned before_past = match_set & ((past_set & (0u - past_set)) - 1u); // (no entry past: every bit)
-        const int k_found = int(__builtin_ctz(before_past | 0x100u)) & 7;
-        int key = (__builtin_popcount(before_past) == 1) ? c.indel(k_found) : -2;
+        int key = (n_found == 1) ? c.indel(k_found) : -2;
         key = (pi < ends_first) ? c.lead() : (pi > ends_second) ? c.trail() : key;
         const bool key_ok = key >= 0;
         const F5Tab te = S.tab[(key_ok ? key : tab_lo) - tab_lo];
@@ -1133,7 +1149,7 @@ __device__ __forceinline__ int f5_walk_selects(LDS& S, const F5Rec c, const bool
         const int32_t src = ins_bases ? te.ins_at + head : ref_head_pos - win_begin;
         const unsigned len = ins_bases ? ins_len : ln;
         const bool known = is_indel_seg || is_match || is_clip || ty == SK_SEG_SKIP || ty == SK_SEG_HARD_CLIP;
-        bool fail = !known || (is_indel_seg && !key_ok) || (ins_bases && !ins_ok);
+        bool fail = !known || (is_indel_seg && (!key_ok || !askable)) || (ins_bases && !ins_ok);
         const bool entry = (bases || (is_clip && !is_indel_seg)) && len > 0u;
         if (entry) {
             fail = fail || pos + int32_t(len) > L || (bases && (src < 0 || int64_t(src) + int64_t(len) > int64_t(P)));
@@ -1154,6 +1170,90 @@ __device__ __forceinline__ int f5_walk_selects(LDS& S, const F5Rec c, const bool
     if (bad || pos != L || n_ent > F5_SEGS || npen > 4u) return -1;
     myslot[f5_ent_word(n_ent)] = unsigned(L) | (npen << 9) | (256u << 16); // trailing penalties
     return n_ent + 1;
+}
+
+// Phase B of F5, a lane its alignment, in path order (the order of score_one_generic): entering an op, the penalties that precede its
+// terms, then a soft clip's length x ln 0.25; inside an op of bases, eight positions per turn -- eight read codes against the eight pool
+// bytes they face (SWAR), each position's address: its row's agree or differ term, or the shared 0.0 (N, or past the op's end) -- eight
+// reads, eight adds.  ONE loop per lane (eight bases and the step to the next op in the same turn), so that the turns a wave makes are the
+// longest lane's, not the sum over ops of the longest op.  PLAIN: the read holds no '=' and no N (the block's lanes share the read: the
+// kernel asks once), the two tests are left out.  What is rare for a whole wave -- a penalty, a soft clip -- sits behind a vote.
+template <bool PLAIN, typename LDS>
+__device__ __forceinline__ double f5_sum(LDS& S, const uint32_t* const myslot, const int n_ent, const double ln_noncand, const double ln_quarter)
+{
+    double lnp = 0.0;
+    const unsigned zero_at = unsigned(reinterpret_cast<const unsigned char*>(&S.zero) - reinterpret_cast<const unsigned char*>(S.row));
+    const unsigned char* rows = reinterpret_cast<const unsigned char*>(S.row);
+    int e = 0, p = 0, stop = 0, hidx = 0;
+    // the step to the next op, by selects (the loop has one back edge); true: the read's end
+    auto next_op = [&]() -> bool {
+        const bool adv = (p >= stop);
+        const uint32_t cur = myslot[f5_ent_word(e)];
+        const int e1 = (e + 1 < n_ent) ? e + 1 : e;
+        const int next_start = int(myslot[f5_ent_word(e1)] & 0x1ffu);
+        const unsigned np = adv ? ((cur >> 9) & 63u) : 0u; // (at most 4: the walk hands anything longer to the host form)
+        if (__any(np != 0u)) {
+            const double l1 = __dadd_rn(lnp, ln_noncand);
+            lnp = (np >= 1u) ? l1 : lnp;
+            const double l2 = __dadd_rn(lnp, ln_noncand);
+            lnp = (np >= 2u) ? l2 : lnp;
+            const double l3 = __dadd_rn(lnp, ln_noncand);
+            lnp = (np >= 3u) ? l3 : lnp;
+            const double l4 = __dadd_rn(lnp, ln_noncand);
+            lnp = (np >= 4u) ? l4 : lnp;
+        }
+        if (adv && e + 1 >= n_ent) return true;
+        const int start = int(cur & 0x1ffu);
+        const bool clip = adv && (cur & (1u << 15)) != 0u;
+        if (__any(clip)) {
+            const double lc = __dadd_rn(lnp, __dmul_rn(double(unsigned(next_start - start)), ln_quarter));
+            lnp = clip ? lc : lnp;
+        }
+        p = adv ? (clip ? next_start : start) : p;
+        stop = adv ? next_start : stop;
+        hidx = adv ? int(cur >> 16) - 256 : hidx;
+        e = adv ? e1 : e;
+        return false;
+    };
+    if (next_op()) return lnp; // (the first op: no bases before it)
+    for (;;) {
+        {
+            const int m = stop - p; // bases of the current op still to add (0: a soft clip just stepped over)
+            // (32-bit halves: positions 0-3, 4-7; every byte holds a 4-bit code, so a byte-wise add never carries across bytes)
+            uint32_t R[2], H[2], live[2];
+            __builtin_memcpy(R, S.read + p, 8);
+            __builtin_memcpy(H, S.hap + (p + hidx), 8);
+            __builtin_memcpy(live, &S.live[m > 8 ? 8 : m], 8);
+            constexpr uint32_t B01 = 0x01010101u, B7F = 0x7f7f7f7fu, B71 = 0x71717171u;
+            uint32_t none[2], dif8[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t ne = (((R[h] ^ H[h]) + B7F) >> 7) & B01; // 1: the bytes differ
+                if (PLAIN) {
+                    none[h] = live[h] ^ B01;
+                    dif8[h] = ne << 3;                                  // per byte: 8 = the differ term, 0 = the agree term
+                } else {
+                    const uint32_t nz = ((R[h] + B7F) >> 7) & B01;      // 1: the read base is not '='
+                    const uint32_t any = ((R[h] + B71) >> 7) & B01;     // 1: the read base is N (code 15)
+                    none[h] = any | (live[h] ^ B01);
+                    dif8[h] = (ne & nz) << 3;
+                }
+            }
+            const unsigned base = unsigned(8 * F5_ROW * p);
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned nb = (none[u >> 2] >> (8 * (u & 3))) & 0xffu, db = (dif8[u >> 2] >> (8 * (u & 3))) & 0xffu;
+                const unsigned at = nb ? zero_at : base + unsigned(8 * F5_ROW * u) + db;
+                v[u] = *reinterpret_cast<const double*>(rows + at);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lnp = __dadd_rn(lnp, v[u]);
+            p += (m > 8) ? 8 : m;
+        }
+        if (next_op()) break;
+    }
+    return lnp;
 }
 
 // TIMING: the cycle stamps of $SK_F5_TIMING (fa.dbg); without it the stamps are constants and their s_memtime + waits are gone
@@ -1180,16 +1280,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     const int32_t win_begin = a.win_begin[r];
     const int n_ins = a.n_ins[r];
+    int my_ins_idx = -1;    // lane k < n_ins: the table index of the read's insert k and where its sequence starts in the pool
+    int32_t my_ins_off = 0;
+    bool odd_code = false;  // the read holds a '=' or an N somewhere (phase B's plain form leaves those two tests out)
     // ---- the pool's bytes (as pool_fill_kernel), the read, its rows of terms, the pool's layout
     {
         const int16_t* idx = a.ins_idx + size_t(r) * INS_CAP;
         const int32_t* off = a.ins_off + size_t(r) * INS_CAP;
         // (insert k's length and source stay in lane k's registers -- the fill below takes them by readlane; the walk looks up
         // index and offset, which go to LDS)
-        int32_t my_ins_off = 0, my_ins_len = 0;
+        int32_t my_ins_len = 0;
         uint32_t my_ins_src = 0;
         if (lane < n_ins) {
             const int t_idx = idx[lane];
+            my_ins_idx = t_idx;
             S.ins_idx[lane] = int16_t(t_idx);
             my_ins_off = off[lane];
             S.ins_off[lane] = my_ins_off;
@@ -1217,6 +1321,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         const SkTables* __restrict__ T = fa.tab;
         if (lane == 0) S.zero = 0.0;
+        if (lane < 9) S.live[lane] = (lane >= 8) ? 0x0101010101010101ull : (0x0101010101010101ull & ((1ull << (8 * lane)) - 1ull));
         for (int32_t i = lane; i < L + 8; i += 64) {
             unsigned q = 0;
             uint8_t code = SK_BAM_ANY;
@@ -1228,12 +1333,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     q = 70u;
                 }
             }
-            S.read[i] = code;
+            odd_code = odd_code || (i < L && ((code & 15u) == 0u || (code & 15u) == 15u));
+            S.read[i] = code & 15u;
             S.row[F5_ROW * i] = T->q2lncompe[q];
             S.row[F5_ROW * i + 1] = T->q2mis[q];
         }
     }
     const double ln_quarter = fa.tab->ln_quarter, ln_noncand = fa.tab->ln_noncand;
+    const bool plain_codes = !__any(odd_code);
 
     // The read's candidate alignments in order of path length, longest first (a counting sort over the segment counts, the order in the
     // unused tail of the pool's bytes): a wave's walk lasts as long as its longest path, so a round of like paths wastes fewer turns
@@ -1336,10 +1443,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 e.ins_len = g.ins_len;
                 e.type_cand = unsigned(g.type) | (unsigned(g.cand) << 8);
                 e.ins_at = -1;
-                for (int i = n_ins - 1; i >= 0; --i) // (the first of the read's inserts with this index, as the look-up below)
-                    if (S.ins_idx[i] == tab_lo + lane) e.ins_at = S.ins_off[i];
                 S.tab[lane] = e;
             }
+            __syncthreads();
+            // (the read's inserts are distinct table indices, pool_layout_kernel: a lane an insert, no two write the same entry)
+            if (my_ins_idx >= tab_lo && my_ins_idx < tab_lo + n_tab) S.tab[my_ins_idx - tab_lo].ins_at = my_ins_off;
         }
         __syncthreads();
         const unsigned long long tc = now();
@@ -1415,6 +1523,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // eight pool bytes they face (SWAR), each position's address: its row's agree or differ term, or the shared 0.0 (N, or past the
         // op's end) -- eight reads, eight adds.  ONE loop per lane (an op's start, eight bases and the step to the next op in the same
         // turn), so that the turns a wave makes are the longest lane's, not the sum over ops of the longest op
+#if F5_SUM
+        if (has && !bad) {
+            const double lnp = plain_codes ? f5_sum<true>(S, myslot, n_ent, ln_noncand, ln_quarter) : f5_sum<false>(S, myslot, n_ent, ln_noncand, ln_quarter);
+            fa.scores[c0 + my_j] = lnp;
+        }
+#else
         if (has && !bad) {
             double lnp = 0.0;
             const unsigned zero_at = unsigned(reinterpret_cast<const unsigned char*>(&S.zero) - reinterpret_cast<const unsigned char*>(S.row));
@@ -1482,6 +1596,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             fa.scores[c0 + my_j] = lnp;
         }
+#endif
         stamp[5] += now() - td; // phase B
     }
     if (fa.dbg && lane == 0) {
