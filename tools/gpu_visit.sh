@@ -55,6 +55,16 @@ for step in "$@"; do
         tail -1 $OUT/pmc_g3_$i.log | head -c 300
       done
       python tools/diag/pmc_kernel_sums.py $OUT/pmc_g3_* > $OUT/pmc_g3.txt 2>&1; cat $OUT/pmc_g3.txt ;;
+    pmc_a5)  # SQ counters of F5 (flatten_score_kernel) over bench.py --only a5
+      i=0
+      for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+                 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" \
+                 "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU"; do
+        i=$((i+1))
+        timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_a5_$i -o pmc -- python bench.py --only a5 --steps 3 --warmup 1 > $OUT/pmc_a5_$i.log 2>&1
+        tail -1 $OUT/pmc_a5_$i.log | head -c 300
+      done
+      python tools/diag/pmc_kernel_sums.py $OUT/pmc_a5_* > $OUT/pmc_a5.txt 2>&1; awk '/^==/{print} /launches=/{p=0} /flatten_score/{p=1} p' $OUT/pmc_a5.txt ;;
     pmc_pileup)
       i=0
       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
