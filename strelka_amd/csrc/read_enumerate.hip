@@ -820,6 +820,7 @@ struct FusedScoreArgs
     int32_t* n_unhandled;  // reads left to the staged kernels
     int32_t write_cals;    // the records' copy in set order (stage 3 and sk_enum_device_fetch_cals read it)
     unsigned long long* dbg; // diagnostics ($SK_F5_TIMING): per block 8 cycle stamps, or null
+    int32_t n_run;         // reads [0, n_run) (set by launch_flatten_score)
 };
 
 // a candidate alignment's slot in LDS: the walk's output -- up to F5_SEGS + 1 transitions, one per op that covers read positions and
@@ -1258,12 +1259,10 @@ __device__ __forceinline__ double f5_sum(LDS& S, const uint32_t* const myslot, c
 
 // TIMING: the cycle stamps of $SK_F5_TIMING (fa.dbg); without it the stamps are constants and their s_memtime + waits are gone
 template <int MAXR, bool TIMING>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void flatten_score_kernel(const FusedScoreArgs fa)
+__device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F5Lds<MAXR>& S)
 {
     auto now = [&]() -> unsigned long long { return TIMING ? (unsigned long long)clock64() : 0ull; };
-    __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S;
     const FlatArgs& a = fa.f;
-    const int r = blockIdx.x;
     const int lane = threadIdx.x;
     const int c0 = a.cal_off[r], c1 = a.cal_off[r + 1];
     const int ncr = c1 - c0;
@@ -1605,15 +1604,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
+// The grid is the blocks a device holds at a time (sixteen to a CU), each taking reads r, r + grid, ...: a block per read is 65 536
+// workgroups of one short-lived wave, and what the dispatcher needs to place one (its LDS, 128 registers a lane) is time the CU's
+// slot stands empty (profiles/r05_f5_history.txt)
+template <int MAXR, bool TIMING>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void flatten_score_kernel(const FusedScoreArgs fa)
+{
+    __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S;
+    for (int r = blockIdx.x; r < fa.n_run; r += gridDim.x) {
+        f5_read<MAXR, TIMING>(fa, r, S);
+        __syncthreads(); // (the next read's bytes go where this one's are)
+    }
+}
+
 // the rows of terms sized for the job's longest read: with 150-base reads a wave's LDS is 10 KB, sixteen waves to a CU (the 256-base
 // form: twelve)
-static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
+static int f5_grid_blocks() // the blocks the device holds at a time: sixteen per CU ($SK_F5_GRID: experiments; 0 = a block per read)
 {
+    static const int v = [] {
+        if (const char* e = std::getenv("SK_F5_GRID")) return std::atoi(e);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 16 * cus;
+    }();
+    return v;
+}
+
+static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs_in)
+{
+    FusedScoreArgs fs = fs_in;
+    fs.n_run = n_reads;
+    const int cap = f5_grid_blocks(), grid = (cap > 0 && cap < n_reads) ? cap : n_reads;
     const bool short_reads = fs.f.max_read_len <= 152, timing = fs.dbg != nullptr;
-    if (short_reads && !timing) hipLaunchKernelGGL((flatten_score_kernel<152, false>), dim3(n_reads), dim3(64), 0, st, fs);
-    else if (short_reads) hipLaunchKernelGGL((flatten_score_kernel<152, true>), dim3(n_reads), dim3(64), 0, st, fs);
-    else if (!timing) hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, false>), dim3(n_reads), dim3(64), 0, st, fs);
-    else hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, true>), dim3(n_reads), dim3(64), 0, st, fs);
+    if (short_reads && !timing) hipLaunchKernelGGL((flatten_score_kernel<152, false>), dim3(grid), dim3(64), 0, st, fs);
+    else if (short_reads) hipLaunchKernelGGL((flatten_score_kernel<152, true>), dim3(grid), dim3(64), 0, st, fs);
+    else if (!timing) hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, false>), dim3(grid), dim3(64), 0, st, fs);
+    else hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, true>), dim3(grid), dim3(64), 0, st, fs);
 }
 
 // the records in set order, for the host (sk_enum_device_fetch_cals; a job whose stage 3 runs on the host): pool[list[c]] -> cals[c], a wave

@@ -55,6 +55,11 @@ for step in "$@"; do
         tail -1 $OUT/pmc_g3_$i.log | head -c 300
       done
       python tools/diag/pmc_kernel_sums.py $OUT/pmc_g3_* > $OUT/pmc_g3.txt 2>&1; cat $OUT/pmc_g3.txt ;;
+    a5_grid)  # F5's time against the blocks of its grid ($SK_F5_GRID; 0 = a block per read)
+      timeout 600 python -m pytest tests/test_device_enumeration.py -m gpu -x -q > $OUT/pytest_a5.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_a5.log; tail -3 $OUT/pytest_a5.log
+      for g in ${A5_GRIDS:-0 4096 3072 2048}; do
+        SK_F5_GRID=$g timeout 300 python bench.py --only a5 --steps 10 --warmup 2 > $OUT/a5_grid$g.json 2>$OUT/a5_grid$g.err; echo "grid=$g: $(grep -o '"kernel_ms": [0-9.]*' $OUT/a5_grid$g.json)"
+      done ;;
     pmc_a5)  # SQ counters of F5 (flatten_score_kernel) over bench.py --only a5
       i=0
       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
