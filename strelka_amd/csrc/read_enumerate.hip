@@ -800,12 +800,6 @@ constexpr int F5_MAX_POOL = 768;
 #ifndef F5_SORT
 #define F5_SORT 1 // experiments: 0 = the set's order
 #endif
-#ifndef F5_SUM
-#define F5_SUM 1 // experiments: 0 = phase B as round 4 left it
-#endif
-#ifndef F5_WALK
-#define F5_WALK 1 // experiments: 0 = the walk as branches (f5_walk), 1 = as one loop of selects (f5_walk_selects)
-#endif
 constexpr int F5_TAB = 32;       // span of table indices the indels of one round's candidate alignments may cover
 
 static_assert(F5_TAB <= 64, "the table copy is a lane an entry");
@@ -820,15 +814,14 @@ struct FusedScoreArgs
     int32_t* n_unhandled;  // reads left to the staged kernels
     int32_t write_cals;    // the records' copy in set order (stage 3 and sk_enum_device_fetch_cals read it)
     unsigned long long* dbg; // diagnostics ($SK_F5_TIMING): per block 8 cycle stamps, or null
-    int32_t n_run;         // reads [0, n_run) (set by launch_flatten_score)
 };
 
 // a candidate alignment's slot in LDS: the walk's output -- up to F5_SEGS + 1 transitions, one per op that covers read positions and
 // one for the read's end (start position | penalties that precede the op's terms << 9 | soft clip << 15 | (pool offset - position + 256)
 // << 16) -- then the record's indel indices.  The record's header and path are in the lane's registers (F5Rec).  21 words a lane
-// instead of round 3's 39: with the table entries cut to the four words the walk reads and the rows of terms sized for the job's
-// longest read, a wave's LDS goes from 17.8 KB to under 10 KB and a CU holds 16 of them instead of 9 -- the kernel is a latency chain per
-// lane (profiles/r04_a5_history.txt: a wave alone on a CU takes as long as nine sharing it).
+// instead of round 3's 39: with the table entries cut to the five words the walk reads and the rows of terms sized for the job's
+// longest read, a wave's LDS goes from 17.8 KB to under 10 KB and a CU holds 16 of them instead of 9 (profiles/r04_a5_history.txt: a
+// wave alone on a CU takes as long as nine sharing it; with sixteen the vector unit is ~85 % busy, profiles/r05_f5_history.txt).
 constexpr int F5_SEGS = 16, F5_INDELS = 8;
 constexpr int F5_IND0 = F5_SEGS + 1, F5_SLOT = (F5_IND0 + F5_INDELS / 2) | 1; // (odd stride: conflict-free)
 __device__ __forceinline__ int f5_ent_word(const int k) { return k; }
@@ -853,8 +846,6 @@ struct F5Lds
     uint32_t slot[64 * F5_SLOT];
     // what the walk looks up per path segment (a chain of dependent look-ups: from HBM / L2 they cost a wave ~100 us per round)
     F5Tab tab[F5_TAB];
-    int32_t ins_off[INS_CAP];
-    int16_t ins_idx[INS_CAP];
 };
 // (the CU hands LDS out in 1 280-byte pieces: 10 240 bytes are sixteen waves to a CU, one byte more fourteen)
 static_assert(sizeof(F5Lds<152>) <= 10240, "sixteen waves of the short-read form to a CU");
@@ -879,169 +870,15 @@ struct F5Rec
     __device__ __forceinline__ int indel(const int k) const { return int(int16_t((slot[F5_IND0 + (k >> 1)] >> (16 * (k & 1))) & 0xffffu)); }
 };
 
-// flatten_cal over a compact record, every look-up from the block's LDS copies (S is the kernel's __shared__ object: the accesses stay
-// LDS accesses).  The same walk, statement for statement (scoreCandidateAlignment :286-493 as host/align_flatten.cpp states it); `sink`
-// receives the ops.  Returns false: leave the read to the host form.
-template <typename LDS, typename SINK>
-__device__ __forceinline__ bool f5_walk(LDS& S, const F5Rec c, const int tab_lo, const int n_ins, const int32_t win_begin, uint8_t* consulted,
-                                        const int32_t read_len, SINK&& sink)
-{
-    auto tab = [&](const int i) -> const F5Tab& { return S.tab[i - tab_lo]; };
-    auto is_cand = [&](const int i) -> bool { // job_cand
-        if (consulted) consulted[i] = 1;
-        return (tab(i).type_cand >> 8) != 0;
-    };
-    // (the path as values of this function: fields of a struct selected per lane become an indexed load from the struct's copy in scratch
-    // memory)
-    const uint64_t p_types = c.types, p_l0 = c.l0, p_l1 = c.l1, p_l2 = c.l2, p_l3 = c.l3;
-    auto seg_type = [=](const int i) -> unsigned { return unsigned(p_types >> (4 * i)) & 15u; };
-    auto seg_len = [=](const int i) -> unsigned {
-        const uint64_t lo = (i & 4) ? p_l1 : p_l0, hi = (i & 4) ? p_l3 : p_l2;
-        return unsigned(((i & 8) ? hi : lo) >> (16 * (i & 3))) & 0xffffu;
-    };
-    const int aps = c.n_seg();
-    unsigned read_offset = 0;
-    int32_t ref_head_pos = c.pos();
-    int ends_first = aps, ends_second = aps; // get_match_edge_segments, align_path.cpp:735-752
-    {
-        bool is_first_match = false;
-        for (int i = 0; i < aps; ++i)
-            if (seg_align_match(seg_type(i))) {
-                if (!is_first_match) ends_first = i;
-                is_first_match = true;
-                ends_second = i;
-            }
-    }
-    // the alignment's indels, read once (all at a time: two LDS round trips) -- getMatchingIndelKey below compares against registers
-    const int ni = c.n_indels();
-    int k_idx[F5_INDELS];
-    int32_t k_pos[F5_INDELS];
-    uint32_t k_del[F5_INDELS], k_ins[F5_INDELS];
-    bool k_kind[F5_INDELS];
-#pragma unroll
-    for (int k = 0; k < F5_INDELS; ++k) {
-        k_idx[k] = (k < ni) ? c.indel(k) : tab_lo;
-        const F5Tab& ci = tab(k_idx[k]);
-        k_pos[k] = ci.pos;
-        k_del[k] = ci.del;
-        k_ins[k] = ci.ins_len;
-        const unsigned ty = ci.type_cand & 0xffu;
-        k_kind[k] = (ty == SK_INDEL_INDEL || ty == SK_INDEL_MISMATCH);
-    }
-    // getMatchingIndelKey, starling_read_align_score.cpp:177-228: table index, -1 = no key, -2 = inconsistent
-    auto matching = [&](const unsigned del_len, const unsigned ins_len, const int path_index) -> int {
-        if (path_index < ends_first) return c.lead();
-        if (path_index > ends_second) return c.trail();
-        int found = -1;
-        bool twice = false, past = false; // (the reference returns at the second match and stops at the first later position)
-#pragma unroll
-        for (int k = 0; k < F5_INDELS; ++k) {
-            if (k < ni && !past && !twice) {
-                if (k_pos[k] == ref_head_pos && k_kind[k] && k_del[k] == del_len && k_ins[k] == ins_len) {
-                    if (found >= 0) twice = true;
-                    found = k_idx[k];
-                } else if (k_pos[k] > ref_head_pos) {
-                    past = true;
-                }
-            }
-        }
-        return (twice || found < 0) ? -2 : found;
-    };
-    auto emit = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
-        if (kind == SK_OP_NOBASE && !penalty) return;
-        sink(kind, len, src, penalty);
-    };
-    // offset of insert bases [head, head+len) of table indel `idx` in the pool, -1 = not representable here
-    auto insert_src = [&](const int idx, const int32_t head, const uint32_t len) -> int32_t {
-        if (head < 0 || uint32_t(head) + len > tab(idx).ins_len) return -1;
-        for (int i = 0; i < n_ins; ++i)
-            if (S.ins_idx[i] == idx) return S.ins_off[i] + head;
-        return -1;
-    };
-    int path_index = 0;
-    while (path_index < aps) {
-        bool is_swap_start = false; // is_segment_swap_start, align_path.cpp:868-895
-        {
-            bool is_insert = false, is_delete = false;
-            for (int i = path_index; i < aps; ++i) {
-                const unsigned ty = seg_type(i);
-                if (ty == SK_SEG_INSERT) is_insert = true;
-                else if (ty == SK_SEG_DELETE) is_delete = true;
-                else break;
-            }
-            is_swap_start = is_insert && is_delete;
-        }
-        unsigned n_seg = 1;
-        const unsigned ps_type = seg_type(path_index), ps_len = seg_len(path_index);
-        // The four kinds of segment that stand for a table indel -- a swap (insert + delete run), a sequence mismatch, an insert, a
-        // delete -- differ in the two lengths the key is looked up with and in nothing else (:296-420 treat them in four branches
-        // with the same steps); ONE code site for them: lanes at different kinds of indel segment then run it together
-        const bool is_indel_seg = is_swap_start || ps_type == SK_SEG_SEQ_MISMATCH || ps_type == SK_SEG_INSERT || ps_type == SK_SEG_DELETE;
-        // (... and one site where the segment's op leaves for the sink)
-        uint8_t op_kind = SK_OP_NOBASE;
-        uint32_t op_len = 0;
-        int32_t op_src = 0;
-        bool op_pen = false;
-        if (is_indel_seg) {
-            unsigned del_len = 0, ins_len = 0;
-            if (is_swap_start) { // swap_info, align_path_util.hh:75-106
-                int k = path_index;
-                for (; k < aps && (seg_type(k) == SK_SEG_INSERT || seg_type(k) == SK_SEG_DELETE); ++k) {
-                    if (seg_type(k) == SK_SEG_INSERT) ins_len += seg_len(k);
-                    else del_len += seg_len(k);
-                }
-                n_seg = unsigned(k - path_index);
-            } else {
-                del_len = (ps_type == SK_SEG_INSERT) ? 0u : ps_len;
-                ins_len = (ps_type == SK_SEG_DELETE) ? 0u : ps_len;
-            }
-            const int key = matching(del_len, ins_len, path_index);
-            if (key < 0) return false;
-            int32_t head = 0;
-            if (path_index < ends_first) head = int32_t(tab(key).ins_len) - int32_t(ps_len);
-            op_pen = !is_cand(key);
-            if (ins_len > 0) {
-                if (ins_len > 0xffffu) return false;
-                op_src = insert_src(key, head, ins_len);
-                if (op_src < 0) return false;
-                op_kind = SK_OP_BASES;
-                op_len = ins_len;
-            }
-        } else if (seg_align_match(ps_type)) {
-            op_kind = SK_OP_BASES;
-            op_len = ps_len;
-            op_src = ref_head_pos - win_begin;
-        } else if (ps_type == SK_SEG_SOFT_CLIP) {
-            op_kind = SK_OP_SOFT_CLIP;
-            op_len = ps_len;
-        } else if (!(ps_type == SK_SEG_SKIP || ps_type == SK_SEG_HARD_CLIP)) {
-            return false;
-        }
-        emit(op_kind, op_len, op_src, op_pen); // (a NOBASE op without a penalty is dropped there: skips, hard clips)
-        for (unsigned i = 0; i < n_seg; ++i) { // increment_path, align_path_util.hh:38-68
-            const unsigned ty = seg_type(path_index), ln = seg_len(path_index);
-            if (seg_align_match(ty)) {
-                read_offset += ln;
-                ref_head_pos += int32_t(ln);
-            } else if (ty == SK_SEG_DELETE || ty == SK_SEG_SKIP) {
-                ref_head_pos += int32_t(ln);
-            } else if (ty == SK_SEG_INSERT || ty == SK_SEG_SOFT_CLIP) {
-                read_offset += ln;
-            }
-            path_index++;
-        }
-    }
-    return int64_t(read_offset) == int64_t(read_len);
-}
-
-// The same walk as ONE loop of selects (F5_WALK 1): f5_walk's body is four branches the lanes of a wave take in turn -- ~1 000 instructions
-// a turn, two thirds of them the scalar unit's mask bookkeeping (profiles/r05_f5_history.txt) -- and a wave makes the turns of its longest
-// path.  Here what the branches have in common is computed once for every lane and selected: the segment kinds as bit sets over the
-// path (one bit per 4-bit type: a run of insert / delete segments, the first and last match segment are shifts and bit counts, not
-// loops), getMatchingIndelKey as two 8-bit sets (the entries that match, the entries past the position) and a bit count, the insert's
-// place in the pool from the table copy (F5Tab::ins_at).  Only a swap (insert + delete run: rare) keeps a branch of its own.  The walk
-// writes the alignment's transitions into its slot itself (what `put` / `on_op` of the caller do for f5_walk); returns the number of
-// transitions, -1 = leave the read to the host form.
+// flatten_cal over a compact record, every look-up from the block's LDS copies: the walk of scoreCandidateAlignment :286-493 as
+// host/align_flatten.cpp states it, as ONE loop of selects.  Written with the reference's four branches (swap, sequence mismatch, insert,
+// delete; match; soft clip; skip / hard clip) a turn is ~1 000 instructions, two thirds of them the scalar unit's mask bookkeeping, and
+// the lanes of a wave take the branches in turn (round 4's form, profiles/r05_f5_history.txt).  Here what the branches have in common is
+// computed once for every lane and selected: the segment kinds as bit sets over the path (one bit per 4-bit type: a run of insert /
+// delete segments, the first and last match segment are shifts and bit counts, not loops), getMatchingIndelKey over packed entries
+// (position; del << 16 | ins) up to the largest count in the wave, the insert's place in the pool from the table copy (F5Tab::ins_at).
+// Only a swap (insert + delete run: rare) keeps a branch of its own.  The walk writes the alignment's transitions into its slot:
+// one word per op that covers read positions and one for the read's end; returns their number, -1 = leave the read to the host form.
 template <typename LDS>
 __device__ __forceinline__ int f5_walk_selects(LDS& S, const F5Rec c, const bool has, const int tab_lo, const int32_t win_begin, uint8_t* consulted,
                                                const int32_t L, const int32_t P, uint32_t* const myslot)
@@ -1286,16 +1123,14 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
     {
         const int16_t* idx = a.ins_idx + size_t(r) * INS_CAP;
         const int32_t* off = a.ins_off + size_t(r) * INS_CAP;
-        // (insert k's length and source stay in lane k's registers -- the fill below takes them by readlane; the walk looks up
-        // index and offset, which go to LDS)
+        // (insert k's length and source stay in lane k's registers -- the fill below takes them by readlane; its table index and
+        // offset go into the round's table copy, F5Tab::ins_at)
         int32_t my_ins_len = 0;
         uint32_t my_ins_src = 0;
         if (lane < n_ins) {
             const int t_idx = idx[lane];
             my_ins_idx = t_idx;
-            S.ins_idx[lane] = int16_t(t_idx);
             my_ins_off = off[lane];
-            S.ins_off[lane] = my_ins_off;
             my_ins_len = int32_t(a.job.tab[t_idx].ins_len);
             my_ins_src = a.job.tab[t_idx].ins_off;
         }
@@ -1455,7 +1290,6 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
         // op that covers read positions, and one for the read's end
         int n_ent = 0;
         bool bad = false;
-#if F5_WALK
         {
             const unsigned long long tA0 = now();
             n_ent = f5_walk_selects(S, rec, has, tab_lo, win_begin, a.job.consulted, L, P, myslot);
@@ -1474,128 +1308,14 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
             }
             stamp[3] += now() - tA1; // candidate-status marks
         }
-#else
-        if (has) {
-            int pos = 0;
-            unsigned npen = 0;
-            auto put = [&](const unsigned at, const unsigned np, const bool clip, const int hidx) {
-                if (n_ent > F5_SEGS || np > 4u || hidx < -256 || hidx > 3839) { // (n_ent <= n_seg by construction; the test guards the slot)
-                    bad = true; // (the host form takes the read)
-                    return;
-                }
-                myslot[f5_ent_word(n_ent)] = at | (np << 9) | (clip ? 1u << 15 : 0u) | (unsigned(hidx + 256) << 16);
-                ++n_ent;
-            };
-            auto on_op = [&](const uint8_t kind, const uint32_t len, const int32_t src, const bool penalty) {
-                if ((kind == SK_OP_BASES || kind == SK_OP_SOFT_CLIP) && len > 0) {
-                    const bool bases = (kind == SK_OP_BASES);
-                    if (pos + int(len) > L || (bases && (src < 0 || int64_t(src) + int64_t(len) > int64_t(P)))) bad = true;
-                    else put(unsigned(pos), npen, !bases, bases ? int(src) - pos : 0);
-                    pos += int(len);
-                    npen = penalty ? 1u : 0u;
-                } else {
-                    npen += penalty ? 1u : 0u;
-                }
-            };
-            const unsigned long long tA0 = now();
-            const bool ok = f5_walk(S, rec, tab_lo, n_ins, win_begin, a.job.consulted, L, on_op);
-            const unsigned long long tA1 = now();
-            stamp[7] += tA1 - tA0; // the walk
-            if (!ok || pos != L) bad = true;
-            else put(unsigned(L), npen, false, 0); // trailing penalties
-            // the candidate-status lookups the host form performs for every indel of the alignment (cal_to_c)
-            if (a.job.consulted) {
-                const int ni = rec.n_indels();
-                for (int i = 0; i < ni; ++i) a.job.consulted[rec.indel(i)] = 1;
-                if (rec.lead() >= 0) a.job.consulted[rec.lead()] = 1;
-                if (rec.trail() >= 0) a.job.consulted[rec.trail()] = 1;
-            }
-            if (bad) a.status[r] = ST_FAIL;
-            stamp[3] += now() - tA1; // candidate-status marks
-        }
-#endif
         __builtin_amdgcn_wave_barrier();
         const unsigned long long td = now();
         stamp[4] += td - tc; // phase A
-        // ---- phase B, a lane its alignment, in path order (the order of score_one_generic): entering an op, the penalties that precede
-        // its terms, then a soft clip's length x ln 0.25; inside an op of bases, eight positions per turn -- eight read codes against the
-        // eight pool bytes they face (SWAR), each position's address: its row's agree or differ term, or the shared 0.0 (N, or past the
-        // op's end) -- eight reads, eight adds.  ONE loop per lane (an op's start, eight bases and the step to the next op in the same
-        // turn), so that the turns a wave makes are the longest lane's, not the sum over ops of the longest op
-#if F5_SUM
+        // ---- phase B, a lane its alignment: the terms in path order (f5_sum)
         if (has && !bad) {
             const double lnp = plain_codes ? f5_sum<true>(S, myslot, n_ent, ln_noncand, ln_quarter) : f5_sum<false>(S, myslot, n_ent, ln_noncand, ln_quarter);
             fa.scores[c0 + my_j] = lnp;
         }
-#else
-        if (has && !bad) {
-            double lnp = 0.0;
-            const unsigned zero_at = unsigned(reinterpret_cast<const unsigned char*>(&S.zero) - reinterpret_cast<const unsigned char*>(S.row));
-            // (the eight-base step comes first and unconditionally -- a lane between ops steps over zero bases, eight times + 0.0 --
-            // so that the loop stays ONE loop: with the step behind a test the compiler nests a loop over an op's steps inside a
-            // loop over ops, and a wave then makes, per op, the steps of the lane with the longest op)
-            int e = 0, p = 0, stop = 0, hidx = 0;
-            for (;;) {
-                {
-                    const int m = stop - p; // bases of the current op still to add (0: between ops)
-                    // (32-bit halves: positions 0-3, 4-7; every byte holds a 4-bit code, so a byte-wise add never carries across bytes)
-                    uint32_t R[2], H[2];
-                    __builtin_memcpy(R, S.read + p, 8);
-                    __builtin_memcpy(H, S.hap + (p + hidx), 8);
-                    constexpr uint32_t B01 = 0x01010101u, B0F = 0x0f0f0f0fu, B7F = 0x7f7f7f7fu, B71 = 0x71717171u;
-                    const int mh = m - 4;
-                    const uint32_t live[2] = { (m >= 4) ? B01 : (B01 & ((1u << (8 * (m > 0 ? m : 0))) - 1u)),
-                                               (mh >= 4) ? B01 : ((mh > 0) ? (B01 & ((1u << (8 * mh)) - 1u)) : 0u) };
-                    uint32_t none[2], dif8[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t r = R[h] & B0F, q = H[h] & B0F;
-                        const uint32_t ne = (((r ^ q) + B7F) >> 7) & B01; // 1: the bytes differ
-                        const uint32_t nz = ((r + B7F) >> 7) & B01;       // 1: the read base is not '='
-                        const uint32_t any = ((r + B71) >> 7) & B01;      // 1: the read base is N (code 15)
-                        none[h] = any | (live[h] ^ B01);
-                        dif8[h] = (ne & nz) << 3;                         // per byte: 8 = the differ term, 0 = the agree term
-                    }
-                    const unsigned base = unsigned(8 * F5_ROW * p);
-                    const unsigned char* rows = reinterpret_cast<const unsigned char*>(S.row);
-                    double v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const unsigned nb = (none[u >> 2] >> (8 * (u & 3))) & 0xffu, db = (dif8[u >> 2] >> (8 * (u & 3))) & 0xffu;
-                        const unsigned at = nb ? zero_at : base + unsigned(8 * F5_ROW * u) + db;
-                        v[u] = *reinterpret_cast<const double*>(rows + at);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) lnp = __dadd_rn(lnp, v[u]);
-                    p += (m > 8) ? 8 : m;
-                }
-                // the op is done (or none begun yet): enter the next one -- by selects, not branches: the loop has one back edge
-                const bool adv = (p >= stop);
-                const uint32_t cur = myslot[f5_ent_word(e)];
-                const int e1 = (e + 1 < n_ent) ? e + 1 : e;
-                const int next_start = int(myslot[f5_ent_word(e1)] & 0x1ffu);
-                const unsigned np = adv ? ((cur >> 9) & 63u) : 0u; // (at most 4: put() hands anything longer to the host form)
-                const double l1 = __dadd_rn(lnp, ln_noncand);
-                lnp = (np >= 1u) ? l1 : lnp;
-                const double l2 = __dadd_rn(lnp, ln_noncand);
-                lnp = (np >= 2u) ? l2 : lnp;
-                const double l3 = __dadd_rn(lnp, ln_noncand);
-                lnp = (np >= 3u) ? l3 : lnp;
-                const double l4 = __dadd_rn(lnp, ln_noncand);
-                lnp = (np >= 4u) ? l4 : lnp;
-                if (adv && e + 1 >= n_ent) break; // (the read's end)
-                const int start = int(cur & 0x1ffu);
-                const bool clip = adv && (cur & (1u << 15)) != 0u;
-                const double lc = __dadd_rn(lnp, __dmul_rn(double(unsigned(next_start - start)), ln_quarter));
-                lnp = clip ? lc : lnp;
-                p = adv ? (clip ? next_start : start) : p;
-                stop = adv ? next_start : stop;
-                hidx = adv ? int(cur >> 16) - 256 : hidx;
-                e = adv ? e1 : e;
-            }
-            fa.scores[c0 + my_j] = lnp;
-        }
-#endif
         stamp[5] += now() - td; // phase B
     }
     if (fa.dbg && lane == 0) {
@@ -1604,42 +1324,24 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
     }
 }
 
-// The grid is the blocks a device holds at a time (sixteen to a CU), each taking reads r, r + grid, ...: a block per read is 65 536
-// workgroups of one short-lived wave, and what the dispatcher needs to place one (its LDS, 128 registers a lane) is time the CU's
-// slot stands empty (profiles/r05_f5_history.txt)
 template <int MAXR, bool TIMING>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void flatten_score_kernel(const FusedScoreArgs fa)
 {
+    // (a block per read: a grid of the 4 096 blocks the device holds at a time, each taking reads r, r + 4 096, ..., is 12 % slower --
+    // the dispatcher's placing of the next block on whichever CU has room is the load balance, profiles/r05_f5_history.txt)
     __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S;
-    for (int r = blockIdx.x; r < fa.n_run; r += gridDim.x) {
-        f5_read<MAXR, TIMING>(fa, r, S);
-        __syncthreads(); // (the next read's bytes go where this one's are)
-    }
+    f5_read<MAXR, TIMING>(fa, blockIdx.x, S);
 }
 
 // the rows of terms sized for the job's longest read: with 150-base reads a wave's LDS is 10 KB, sixteen waves to a CU (the 256-base
 // form: twelve)
-static int f5_grid_blocks() // the blocks the device holds at a time: sixteen per CU ($SK_F5_GRID: experiments; 0 = a block per read)
+static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
 {
-    static const int v = [] {
-        if (const char* e = std::getenv("SK_F5_GRID")) return std::atoi(e);
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return 16 * cus;
-    }();
-    return v;
-}
-
-static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs_in)
-{
-    FusedScoreArgs fs = fs_in;
-    fs.n_run = n_reads;
-    const int cap = f5_grid_blocks(), grid = (cap > 0 && cap < n_reads) ? cap : n_reads;
     const bool short_reads = fs.f.max_read_len <= 152, timing = fs.dbg != nullptr;
-    if (short_reads && !timing) hipLaunchKernelGGL((flatten_score_kernel<152, false>), dim3(grid), dim3(64), 0, st, fs);
-    else if (short_reads) hipLaunchKernelGGL((flatten_score_kernel<152, true>), dim3(grid), dim3(64), 0, st, fs);
-    else if (!timing) hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, false>), dim3(grid), dim3(64), 0, st, fs);
-    else hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, true>), dim3(grid), dim3(64), 0, st, fs);
+    if (short_reads && !timing) hipLaunchKernelGGL((flatten_score_kernel<152, false>), dim3(n_reads), dim3(64), 0, st, fs);
+    else if (short_reads) hipLaunchKernelGGL((flatten_score_kernel<152, true>), dim3(n_reads), dim3(64), 0, st, fs);
+    else if (!timing) hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, false>), dim3(n_reads), dim3(64), 0, st, fs);
+    else hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, true>), dim3(n_reads), dim3(64), 0, st, fs);
 }
 
 // the records in set order, for the host (sk_enum_device_fetch_cals; a job whose stage 3 runs on the host): pool[list[c]] -> cals[c], a wave
