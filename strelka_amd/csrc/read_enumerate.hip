@@ -1061,15 +1061,14 @@ __device__ __forceinline__ double f5_sum(LDS& S, const uint32_t* const myslot, c
             uint32_t R[2], H[2], live[2];
             __builtin_memcpy(R, S.read + p, 8);
             __builtin_memcpy(H, S.hap + (p + hidx), 8);
-            if (!PLAIN) __builtin_memcpy(live, &S.live[m > 8 ? 8 : m], 8);
-            else live[0] = live[1] = 0u;
+            __builtin_memcpy(live, &S.live[m > 8 ? 8 : m], 8);
             constexpr uint32_t B01 = 0x01010101u, B7F = 0x7f7f7f7fu, B71 = 0x71717171u;
             uint32_t none[2], dif8[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const uint32_t ne = (((R[h] ^ H[h]) + B7F) >> 7) & B01; // 1: the bytes differ
                 if (PLAIN) {
-                    none[h] = 0u;
+                    none[h] = live[h] ^ B01;
                     dif8[h] = ne << 3;                                  // per byte: 8 = the differ term, 0 = the agree term
                 } else {
                     const uint32_t nz = ((R[h] + B7F) >> 7) & B01;      // 1: the read base is not '='
@@ -1080,38 +1079,14 @@ __device__ __forceinline__ double f5_sum(LDS& S, const uint32_t* const myslot, c
             }
             const unsigned base = unsigned(8 * F5_ROW * p);
             double v[8];
-            if (PLAIN) {
-                // every position reads its row (past the op's end: a row of the padding or of the next op, not added); the adds stop at the
-                // op's end by the lanes' execution mask -- the scalar unit's work, the vector unit is what this kernel waits for
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const unsigned db = (dif8[u >> 2] >> (8 * (u & 3))) & 8u;
-                    v[u] = *reinterpret_cast<const double*>(rows + (base | db) + unsigned(8 * F5_ROW * u)); // (base: a multiple of 16)
-                }
-                // (the eight reads in flight together, then the adds: left alone the compiler moves each read behind its test -- a
-                // chain of eight LDS round trips -- and turns the last four tests into selects)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
-#define F5_ADD(u) asm volatile(""); lnp = __dadd_rn(lnp, v[u]);
-                if (m > 0) { F5_ADD(0)
-                if (m > 1) { F5_ADD(1)
-                if (m > 2) { F5_ADD(2)
-                if (m > 3) { F5_ADD(3)
-                if (m > 4) { F5_ADD(4)
-                if (m > 5) { F5_ADD(5)
-                if (m > 6) { F5_ADD(6)
-                if (m > 7) { F5_ADD(7) } } } } } } } }
-#undef F5_ADD
-            } else {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const unsigned nb = (none[u >> 2] >> (8 * (u & 3))) & 0xffu, db = (dif8[u >> 2] >> (8 * (u & 3))) & 0xffu;
-                    const unsigned at = nb ? zero_at : base + unsigned(8 * F5_ROW * u) + db;
-                    v[u] = *reinterpret_cast<const double*>(rows + at);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) lnp = __dadd_rn(lnp, v[u]);
+            for (int u = 0; u < 8; ++u) {
+                const unsigned nb = (none[u >> 2] >> (8 * (u & 3))) & 0xffu, db = (dif8[u >> 2] >> (8 * (u & 3))) & 0xffu;
+                const unsigned at = nb ? zero_at : base + unsigned(8 * F5_ROW * u) + db;
+                v[u] = *reinterpret_cast<const double*>(rows + at);
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lnp = __dadd_rn(lnp, v[u]);
             p += (m > 8) ? 8 : m;
         }
         if (next_op()) break;
