@@ -1,0 +1,117 @@
+"""The drop-in against the reference on fresh seeded WGS-like samples (build container: the CPU double of the C-ABI, `starling2_dbl`; on the
+GPU box pass variant=amd): depth, variant density, the way the run is cut into regions and their order vary with the seed; both VCFs must
+be the reference's byte for byte.  The routed gVCF path (site 10: plain sites and whole blocks from the device's window) sees shallow and
+deep samples, regions that start inside blocks, regions called out of order.
+
+usage: python tools/fuzz/e2e_seeds.py [n_seeds=16] [first_seed=1] [variant=dbl] [workers=8]"""
+import os
+import random
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, ".")
+from tests import e2e_util as E
+
+
+def one(seed, variant, models):
+    rng = random.Random(9000 + seed)
+    length = rng.choice([120000, 200000, 300000])
+    depth = rng.choice([4.0, 12.0, 25.0, 40.0, 70.0])
+    snv_every = rng.choice([150, 1000, 4000])
+    indel_every = rng.choice([400, 3000, 20000])
+    d = os.path.join(E.REPO, "oracle", "_ref", "synth", "fuzz_%d" % seed)
+    if not os.path.exists(os.path.join(d, "chrom_depth.txt")):
+        os.makedirs(d, exist_ok=True)
+        subprocess.run([sys.executable, "tools/make_wgs_bam.py", d, os.path.join(E.BIN_DIR, "samtools"), "--length", str(length),
+                        "--depth", str(depth), "--seed", str(seed), "--snv-every", str(snv_every), "--indel-every", str(indel_every),
+                        "--procs", "1"], check=True, stdout=subprocess.DEVNULL)
+        with open(os.path.join(d, "chrom_depth.txt"), "w") as f:
+            f.write("chrW\t%.3f\n" % depth)
+    # the process's regions: one to four pieces of the sample, sometimes with a gap, sometimes out of order
+    cuts = sorted(rng.sample(range(1000, length - 1000), rng.choice([0, 1, 2, 3])))
+    edges = [1] + cuts + [length + 1]
+    regions = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        gap = rng.choice([0, 0, 37, 1500])
+        if b - gap > a:
+            regions.append("chrW:%d-%d" % (a, b - 1 - gap))
+    if rng.random() < 0.3:
+        rng.shuffle(regions)
+    extra = list(models) if rng.random() < 0.7 else []
+    # inputs from outside, at random places: a ploidy VCF with haploid and zero-ploidy stretches, a no-compress BED, forced-output positions
+    if rng.random() < 0.5:
+        rows, at = [], 2000
+        while at < length - 5000 and len(rows) < 6:
+            at += rng.randrange(3000, 60000)
+            n = rng.choice([1, 40, 700, 5000])
+            if at + n < length:
+                rows.append((at, at + n, rng.choice([0, 1, 1])))
+            at += n
+        pv = os.path.join(d, "ploidy_%d.vcf" % seed)
+        with open(pv, "w") as f:
+            f.write("##fileformat=VCFv4.1\n##FORMAT=<ID=CN,Number=1,Type=Integer,Description=\"copy number\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tNA_SYNTH\n" +
+                    "".join("chrW\t%d\t.\tN\t<CNV>\t.\tPASS\tEND=%d\tCN\t%d\n" % r for r in rows))
+        bed = os.path.join(d, "nocompress_%d.bed" % seed)
+        with open(bed, "w") as f:
+            at = 500
+            for _ in range(rng.choice([1, 3, 8])):
+                at += rng.randrange(1000, 40000)
+                n = rng.choice([1, 30, 400, 3000])
+                if at + n < length:
+                    f.write("chrW\t%d\t%d\n" % (at, at + n))
+                at += n
+        for v, preset in ((pv, "vcf"), (bed, "bed")):
+            subprocess.run([os.path.join(E.BIN_DIR, "bgzip"), "-f", v], check=True)
+            subprocess.run([os.path.join(E.BIN_DIR, "tabix"), "-f", "-p", preset, v + ".gz"], check=True)
+        extra += ["--ploidy-region-vcf", pv + ".gz", "--nocompress-bed", bed + ".gz"]
+    if rng.random() < 0.4:
+        fa = open(os.path.join(d, "wgs.fa")).read().split("\n", 1)[1].replace("\n", "")
+        fv = os.path.join(d, "forced_%d.vcf" % seed)
+        with open(fv, "w") as f:
+            f.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+            for pos in sorted(rng.sample(range(100, length - 100), rng.choice([3, 40, 400]))):
+                ref = fa[pos - 1].upper()
+                if ref in "ACGT":
+                    f.write("chrW\t%d\t.\t%s\t%s\t.\t.\t.\n" % (pos, ref, rng.choice([b for b in "ACGT" if b != ref])))
+        subprocess.run([os.path.join(E.BIN_DIR, "bgzip"), "-f", fv], check=True)
+        subprocess.run([os.path.join(E.BIN_DIR, "tabix"), "-f", "-p", "vcf", fv + ".gz"], check=True)
+        extra += ["--force-output-vcf", fv + ".gz"]
+    out = {}
+    for binary in ("starling2_ref", "starling2_" + variant):
+        with tempfile.TemporaryDirectory() as o:
+            E.run(E.germline_wgs_argv(os.path.basename(binary), o + "/", [os.path.join(d, "wgs.bam")], regions, os.path.join(d, "wgs.fa"),
+                                      os.path.join(d, "chrom_depth.txt"), extra=extra), timeout=3600)
+            out[binary] = {f: E.vcf_body(os.path.join(o, f), keep_header=True) for f in ("variants.vcf", "genome.S1.vcf")}
+    want, got = out["starling2_ref"], out["starling2_" + variant]
+    what = "seed %d: %d bp at %gx, snv/%d indel/%d, regions %s%s" % (seed, length, depth, snv_every, indel_every, ",".join(regions),
+                                                                     "".join(" " + x for x in extra if x.startswith("--")))
+    for f in want:
+        if want[f] != got[f]:
+            k = next((i for i, (x, y) in enumerate(zip(want[f], got[f])) if x != y), min(len(want[f]), len(got[f])))
+            return False, "%s: %s differs at line %d\n  reference: %s\n  drop-in:   %s" % (
+                what, f, k + 1, want[f][k] if k < len(want[f]) else "<end>", got[f][k] if k < len(got[f]) else "<end>")
+    return True, "%s: identical (%d variant records, %d gVCF lines)" % (
+        what, sum(1 for l in want["variants.vcf"] if l[0] != "#"), len(want["genome.S1.vcf"]))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    variant = sys.argv[3] if len(sys.argv) > 3 else "dbl"
+    workers = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+    md = tempfile.mkdtemp(prefix="sk_models_")
+    subprocess.run([sys.executable, "tools/make_dummy_germline_models.py", md], check=True)
+    models = ("--snv-scoring-model-file", md + "/germlineSNVScoringModels.json", "--indel-scoring-model-file", md + "/germlineIndelScoringModels.json")
+    bad = 0
+    with ThreadPoolExecutor(workers) as ex:
+        for ok, msg in ex.map(lambda s: one(s, variant, models), range(first, first + n)):
+            print(msg, flush=True)
+            bad += 0 if ok else 1
+    print("%d of %d seeds identical" % (n - bad, n))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
