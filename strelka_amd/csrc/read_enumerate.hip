@@ -268,14 +268,26 @@ __global__ __launch_bounds__(256) void rank_kernel(const SetArgs a)
     const ulonglong2 kmine = a.gkey[g];
     const int q0 = a.raw_off[r], q1 = a.raw_off[r + 1];
     int rank = 0, n_equal = 0;
-    for (int q = q0; q < q1; ++q) {
-        const ulonglong2 k = a.gkey[q];
-        const bool kept = a.dup[q] == 0;
+    auto count = [&](const ulonglong2 k, const uint8_t dup) {
+        const bool kept = dup == 0;
         const bool lower = (k.x < kmine.x) || (k.x == kmine.x && k.y < kmine.y);
         const bool equal = (k.x == kmine.x) && (k.y == kmine.y);
         rank += (kept && lower) ? 1 : 0;
         n_equal += (kept && equal) ? 1 : 0;
+    };
+    int q = q0;
+    for (; q + 8 <= q1; q += 8) { // (eight keys in flight: one at a time the loop is a chain of load latencies, 120 us per 4 096 reads x 88)
+        ulonglong2 k[8];
+        uint8_t d[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) {
+            k[z] = a.gkey[q + z];
+            d[z] = a.dup[q + z];
+        }
+#pragma unroll
+        for (int z = 0; z < 8; ++z) count(k[z], d[z]);
     }
+    for (; q < q1; ++q) count(a.gkey[q], a.dup[q]);
     if (n_equal > 1) { // (itself and others)
         const PCal& mine = a.pool[a.grouped[g]];
         for (int q = q0; q < q1; ++q) {

@@ -6,6 +6,7 @@ deep samples, regions that start inside blocks, regions called out of order.
 usage: python tools/fuzz/e2e_seeds.py [n_seeds=16] [first_seed=1] [variant=dbl] [workers=8]"""
 import os
 import random
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -85,6 +86,8 @@ def one(seed, variant, models):
                                       os.path.join(d, "chrom_depth.txt"), extra=extra), timeout=3600)
             out[binary] = {f: E.vcf_body(os.path.join(o, f), keep_header=True) for f in ("variants.vcf", "genome.S1.vcf")}
     want, got = out["starling2_ref"], out["starling2_" + variant]
+    if not os.environ.get("SK_FUZZ_KEEP"):
+        shutil.rmtree(d, ignore_errors=True)  # (a sample is 5-20 MB; oracle/_ref travels to the GPU box)
     what = "seed %d: %d bp at %gx, snv/%d indel/%d, regions %s%s" % (seed, length, depth, snv_every, indel_every, ",".join(regions),
                                                                      "".join(" " + x for x in extra if x.startswith("--")))
     for f in want:

@@ -55,6 +55,11 @@ for step in "$@"; do
         tail -1 $OUT/pmc_g3_$i.log | head -c 300
       done
       python tools/diag/pmc_kernel_sums.py $OUT/pmc_g3_* > $OUT/pmc_g3.txt 2>&1; cat $OUT/pmc_g3.txt ;;
+    realign)  # the whole-read legs of one process (sparse / dense scenarios): reads per second
+      timeout 600 python bench.py --only realign --steps 5 > $OUT/realign.json 2>$OUT/realign.err
+      python -c "import json;d=json.load(open('$OUT/realign.json'))['legs'];print({k:'%.3e reads/s' % (v['reads']/(v['t1']-v['t0'])) for k,v in d.items()})" ;;
+    seeds)  # the drop-in (this box's GPU) against the reference on fresh seeded samples: $SEEDS_ARGS = "n first variant workers"
+      timeout 900 python tools/fuzz/e2e_seeds.py ${SEEDS_ARGS:-8 201 amd 8} > $OUT/fuzz_e2e_seeds.txt 2>&1; tail -3 $OUT/fuzz_e2e_seeds.txt | cut -c1-300 ;;
     a5_grid)  # F5's time against the blocks of its grid ($SK_F5_GRID; 0 = a block per read)
       timeout 600 python -m pytest tests/test_device_enumeration.py -m gpu -x -q > $OUT/pytest_a5.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_a5.log; tail -3 $OUT/pytest_a5.log
       for g in ${A5_GRIDS:-0 4096 3072 2048}; do
