@@ -44,7 +44,9 @@ for step in "$@"; do
         timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 --realign-processes 0 > $OUT/pmc_$c.log 2>&1
         timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_a5_$c -o pmc -- python bench.py --only a5 --steps 10 --warmup 2 > $OUT/pmc_a5_$c.log 2>&1
       done
-      python tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json 2>$OUT/pmc_traffic.err; head -c 600 $OUT/pmc_traffic.json ;;
+      python tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json 2>$OUT/pmc_traffic.err; head -c 600 $OUT/pmc_traffic.json
+      # (a bench step later in this visit quotes these passes: bench.py reads the newest profiles/*_pmc_traffic.json)
+      [ -s $OUT/pmc_traffic.json ] && cp $OUT/pmc_traffic.json profiles/${TAG}_pmc_traffic.json ;;
     pmc_g3)
       i=0
       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
