@@ -2,7 +2,7 @@
 """The germline end-to-end leg under several adapter settings: wall seconds of the drop-in's farm, the share of the realignment jobs'
 reads whose candidate alignments the device listed, the hook timers -- each run compared byte for byte with the reference's output.
 
-usage: e2e_sweep.py <out.json> [bp] [segment bp] [procs] -- settings are the ENV_SETS below"""
+usage: e2e_sweep.py <out.json> [bp] [segment bp] [procs] -- settings are the ENV_SETS below; $SK_SWEEP_DEPTH / $SK_SWEEP_SEED: the sample"""
 import json
 import os
 import re
@@ -43,7 +43,8 @@ def main():
     L = int(sys.argv[2]) if len(sys.argv) > 2 else 16000000
     seg_bp = int(sys.argv[3]) if len(sys.argv) > 3 else 2000000
     procs = int(sys.argv[4]) if len(sys.argv) > 4 else 8
-    d = farm.wgs_dataset(L)
+    depth, seed = float(os.environ.get("SK_SWEEP_DEPTH", "40")), int(os.environ.get("SK_SWEEP_SEED", "20260926"))  # (another sample than the bench's)
+    d = farm.wgs_dataset(L, depth, seed)
     root = tempfile.mkdtemp(prefix="sk_sweep_")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_dummy_germline_models.py"), os.path.join(root, "models")], check=True)
     evs = (os.path.join(root, "models", "germlineSNVScoringModels.json"), os.path.join(root, "models", "germlineIndelScoringModels.json"))
@@ -56,7 +57,7 @@ def main():
                                               chrom_depth=os.path.join(d, "chrom_depth.txt"), skip_header=skip_header, evs_models=evs)
         return fn
     ref = farm.run_farm(groups, argv_fn("starling2_ref"), os.path.join(root, "ref"), OUTPUTS, jobs=procs)
-    report = {"bp": L, "segment_bp": seg_bp, "procs": procs, "ref_wall_s": ref.wall_s, "ref_process_seconds_sum": sum(ref.process_s), "runs": []}
+    report = {"bp": L, "segment_bp": seg_bp, "procs": procs, "depth": depth, "seed": seed, "ref_wall_s": ref.wall_s, "ref_process_seconds_sum": sum(ref.process_s), "runs": []}
     farm.run_farm([[(0, "chrW", 1, min(L, 50000), 0)]], argv_fn(drop_in), os.path.join(root, "warm"), OUTPUTS, jobs=1)
     for name, env in ENV_SETS:
         res = farm.run_farm(groups, argv_fn(drop_in), os.path.join(root, name), OUTPUTS, jobs=procs, env=dict(env, STRELKA_AMD_VERBOSE="1"))
