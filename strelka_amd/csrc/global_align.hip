@@ -303,6 +303,18 @@ void sk_align_scores_default(sk_align_scores* s)
     s->is_require_edge_deletion = 1;
 }
 
+// the dynamic LDS a launch may ask for is an attribute of the kernel, not of the launch: raised when a call needs more than any before
+// (the adapter calls once per haplotype: the driver call every time was a tenth of the call)
+static int ga_allow_lds(const size_t lds)
+{
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(global_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        allowed = lds;
+    }
+    return 0;
+}
+
 int sk_global_align(const sk_global_align_batch* hb, const sk_align_scores* sc, int32_t* out_score, int32_t* out_begin_pos,
                     sk_path_seg* out_path, int32_t* out_n_seg)
 {
@@ -329,49 +341,38 @@ int sk_global_align(const sk_global_align_batch* hb, const sk_align_scores* sc, 
 
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
-    SkArena ar;
-    const size_t need = 2 * sk_align256(8 * (size_t(n) + 1)) + sk_align256(size_t(nq)) + sk_align256(size_t(nr)) +
-                        sk_align256(8 * (size_t(n) + 1)) + 2 * sk_align256(8 * size_t(npath)) + 3 * sk_align256(4 * size_t(n)) +
-                        sk_align256(size_t(ptr_off[size_t(n)]) + 16 * WIN * WAVE) + 16 * 256;
-    if (ar.reserve(need)) return 1;
+    // one block in, one block out, moved by launches (SkStage, sk_common.h): the adapter calls this once per haplotype
+    SkStage sg;
+    const size_t in_bytes = 3 * 8 * (size_t(n) + 1) + size_t(nq) + size_t(nr);
+    const size_t out_bytes = 8 * size_t(npath) + 3 * 4 * size_t(n);
+    const size_t extra = sk_align256(8 * size_t(npath)) + sk_align256(size_t(ptr_off[size_t(n)]) + 16 * WIN * WAVE) + 8 * 256;
+    if (sg.begin(in_bytes, out_bytes, extra, 9)) return 1;
     hipStream_t st = ctx.stream;
     GaArgs a;
     a.b.n = n;
-    {
-        int64_t* p1 = ar.take<int64_t>(size_t(n) + 1);
-        SK_HIP(hipMemcpyAsync(p1, hb->query_off, 8 * (size_t(n) + 1), hipMemcpyHostToDevice, st));
-        a.b.query_off = p1;
-        char* p2 = ar.take<char>(size_t(nq));
-        SK_HIP(hipMemcpyAsync(p2, hb->query, size_t(nq), hipMemcpyHostToDevice, st));
-        a.b.query = p2;
-        int64_t* p3 = ar.take<int64_t>(size_t(n) + 1);
-        SK_HIP(hipMemcpyAsync(p3, hb->ref_off, 8 * (size_t(n) + 1), hipMemcpyHostToDevice, st));
-        a.b.ref_off = p3;
-        char* p4 = ar.take<char>(size_t(nr));
-        SK_HIP(hipMemcpyAsync(p4, hb->ref, size_t(nr), hipMemcpyHostToDevice, st));
-        a.b.ref = p4;
-        int64_t* p5 = ar.take<int64_t>(size_t(n) + 1);
-        SK_HIP(hipMemcpyAsync(p5, ptr_off.data(), 8 * (size_t(n) + 1), hipMemcpyHostToDevice, st));
-        a.ptr_off = p5;
-    }
+    a.b.query_off = sg.put(hb->query_off, size_t(n) + 1);
+    a.b.query = sg.put(hb->query, size_t(nq));
+    a.b.ref_off = sg.put(hb->ref_off, size_t(n) + 1);
+    a.b.ref = sg.put(hb->ref, size_t(nr));
+    a.ptr_off = sg.put(ptr_off.data(), size_t(n) + 1);
     a.sc = *sc;
-    a.out_path = ar.take<sk_path_seg>(size_t(npath));
-    a.tmp_path = ar.take<sk_path_seg>(size_t(npath));
-    a.out_score = ar.take<int32_t>(size_t(n));
-    a.out_begin = ar.take<int32_t>(size_t(n));
-    a.out_nseg = ar.take<int32_t>(size_t(n));
-    a.ptr_scratch = ar.take<uint8_t>(size_t(ptr_off[size_t(n)]) + size_t(WIN) * WAVE); // + slack: a window read may run past the end
+    a.out_path = sg.out<sk_path_seg>(size_t(npath));
+    a.out_score = sg.out<int32_t>(size_t(n));
+    a.out_begin = sg.out<int32_t>(size_t(n));
+    a.out_nseg = sg.out<int32_t>(size_t(n));
+    a.tmp_path = sg.ar.take<sk_path_seg>(size_t(npath));
+    a.ptr_scratch = sg.ar.take<uint8_t>(size_t(ptr_off[size_t(n)]) + size_t(WIN) * WAVE); // + slack: a window read may run past the end
     a.ptr_stride = 0;
     a.max_ref = maxR;
     a.max_query = maxQ;
-    SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(global_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    if (ga_allow_lds(lds)) return 1;
+    if (sg.upload(st)) return 1;
     hipLaunchKernelGGL(global_align_kernel, dim3(n), dim3(WAVE), lds, st, a);
-    SK_HIP(hipGetLastError());
-    SK_HIP(hipMemcpyAsync(out_score, a.out_score, 4 * size_t(n), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipMemcpyAsync(out_begin_pos, a.out_begin, 4 * size_t(n), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipMemcpyAsync(out_n_seg, a.out_nseg, 4 * size_t(n), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipMemcpyAsync(out_path, a.out_path, 8 * size_t(npath), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    if (sg.download_and_wait(st)) return 1;
+    sg.fetch(out_score, a.out_score, size_t(n));
+    sg.fetch(out_begin_pos, a.out_begin, size_t(n));
+    sg.fetch(out_n_seg, a.out_nseg, size_t(n));
+    sg.fetch(out_path, a.out_path, size_t(npath));
     return 0;
 }
 
@@ -418,7 +419,7 @@ int sk_global_align_dev(const sk_global_align_batch* db, int64_t total_query_len
     a.max_query = max_query_len;
     const int RW = max_ref_len + 1;
     const size_t lds = size_t(WIN) * WAVE + size_t((RW + 3) & ~3) + 4 * size_t(max_query_len + 1) + 2 * 12 * size_t(RW) + 16;
-    SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(global_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    if (ga_allow_lds(lds)) return 1;
     hipLaunchKernelGGL(global_align_kernel, dim3(db->n), dim3(WAVE), lds, st, a);
     SK_HIP(hipGetLastError());
     return 0;

@@ -781,34 +781,27 @@ static int allele_group_host_t(const sk_allele_group_batch* hb, const sk_indel_o
     const int64_t tr = hb->read_off[n];
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
-    SkArena ar;
-    if (ar.reserve(sk_align256(8 * (n + 1)) + 2 * sk_align256(n) + 2 * sk_align256(4 * MAXA * n) +
-                   2 * sk_align256(4 * MAXA * tr) + 2 * sk_align256(2 * tr) + sk_align256(tr) +
-                   sk_align256(sizeof(CallT) * n) + 16 * 256))
-        return 1;
+    // one block in, one block out, moved by launches (SkStage, sk_common.h): the adapter calls this once per indel locus
+    SkStage sg;
+    const size_t in_bytes = 8 * size_t(n + 1) + 2 * size_t(n) + 2 * 4 * size_t(MAXA) * size_t(n) + 2 * 4 * size_t(MAXA) * size_t(tr) + 2 * 2 * size_t(tr) + size_t(tr);
+    if (sg.begin(in_bytes, sizeof(CallT) * size_t(n), 0, 11)) return 1;
     sk_allele_group_batch d = *hb;
     hipStream_t st = ctx.stream;
-#define UPG(field, T, count)                                                                            \
-    {                                                                                                   \
-        T* p = ar.take<T>(count);                                                                       \
-        if (count) SK_HIP(hipMemcpyAsync(p, hb->field, sizeof(T) * (count), hipMemcpyHostToDevice, st)); \
-        d.field = p;                                                                                    \
-    }
-    UPG(read_off, int64_t, size_t(n + 1));
-    UPG(n_alt, uint8_t, size_t(n));
-    UPG(ploidy, uint8_t, size_t(n));
-    UPG(del_len, uint32_t, size_t(n) * MAXA);
-    UPG(ins_len, uint32_t, size_t(n) * MAXA);
-    UPG(ref_lnp, float, size_t(tr) * MAXA);
-    UPG(allele_lnp, float, size_t(tr) * MAXA);
-    UPG(non_ambig, uint16_t, size_t(tr));
-    UPG(read_length, uint16_t, size_t(tr));
-    UPG(read_flags, uint8_t, size_t(tr));
-#undef UPG
-    CallT* dout = ar.take<CallT>(n);
+    d.read_off = sg.put(hb->read_off, size_t(n + 1));
+    d.n_alt = sg.put(hb->n_alt, size_t(n));
+    d.ploidy = sg.put(hb->ploidy, size_t(n));
+    d.del_len = sg.put(hb->del_len, size_t(n) * MAXA);
+    d.ins_len = sg.put(hb->ins_len, size_t(n) * MAXA);
+    d.ref_lnp = sg.put(hb->ref_lnp, size_t(tr) * MAXA);
+    d.allele_lnp = sg.put(hb->allele_lnp, size_t(tr) * MAXA);
+    d.non_ambig = sg.put(hb->non_ambig, size_t(tr));
+    d.read_length = sg.put(hb->read_length, size_t(tr));
+    d.read_flags = sg.put(hb->read_flags, size_t(tr));
+    CallT* dout = sg.out<CallT>(size_t(n));
+    if (sg.upload(st)) return 1;
     if (allele_group_dev_t<MAXA, CallT>(&d, opt, dout, st)) return 1;
-    SK_HIP(hipMemcpyAsync(out, dout, sizeof(CallT) * n, hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    if (sg.download_and_wait(st)) return 1;
+    sg.fetch(out, dout, size_t(n));
     return 0;
 }
 
@@ -867,30 +860,28 @@ int sk_indel_grid_lhood_dev(const sk_readscore_batch* b, const sk_indel_options*
     return 0;
 }
 
-static int upload_readscores(const sk_readscore_batch* hb, SkArena& ar, sk_readscore_batch& d, hipStream_t st)
+static int upload_readscores(const sk_readscore_batch* hb, SkStage& sg, sk_readscore_batch& d)
 {
     const int n = hb->n_indels;
     if (hb->read_off[0] != 0) return sk_fail("readscore batch: read_off must start at 0");
     const int64_t tr = hb->read_off[n];
     d = *hb;
-#define UPA(field, T, count, optional)                                                                  \
-    if (hb->field) {                                                                                    \
-        T* p = ar.take<T>(count);                                                                       \
-        if (count) SK_HIP(hipMemcpyAsync(p, hb->field, sizeof(T) * (count), hipMemcpyHostToDevice, st)); \
-        d.field = p;                                                                                    \
-    } else if (!(optional)) {                                                                           \
-        return sk_fail("readscore batch: missing array " #field);                                      \
+#define UPA(field, count, optional)                                \
+    if (hb->field) {                                               \
+        d.field = sg.put(hb->field, count);                        \
+    } else if (!(optional)) {                                      \
+        return sk_fail("readscore batch: missing array " #field); \
     }
-    UPA(read_off, int64_t, size_t(n + 1), false);
-    UPA(ref_lnp, float, size_t(tr), false);
-    UPA(indel_lnp, float, size_t(tr), false);
-    UPA(alt_lnp, float, size_t(tr), true);
-    UPA(non_ambig, uint16_t, size_t(tr), false);
-    UPA(read_length, uint16_t, size_t(tr), false);
-    UPA(read_flags, uint8_t, size_t(tr), false);
-    UPA(del_len, uint32_t, size_t(n), false);
-    UPA(ins_len, uint32_t, size_t(n), false);
-    UPA(is_breakpoint, uint8_t, size_t(n), true);
+    UPA(read_off, size_t(n + 1), false);
+    UPA(ref_lnp, size_t(tr), false);
+    UPA(indel_lnp, size_t(tr), false);
+    UPA(alt_lnp, size_t(tr), true);
+    UPA(non_ambig, size_t(tr), false);
+    UPA(read_length, size_t(tr), false);
+    UPA(read_flags, size_t(tr), false);
+    UPA(del_len, size_t(n), false);
+    UPA(ins_len, size_t(n), false);
+    UPA(is_breakpoint, size_t(n), true);
 #undef UPA
     return 0;
 }
@@ -905,7 +896,7 @@ static size_t readscore_bytes(const sk_readscore_batch* hb)
 
 // per-indel shared error rate, host libm (somatic_indel_grid.cpp:273-275)
 static int upload_shared_error_rates(const double* indel_to_ref_error_prob, const int n, const sk_somatic_indel_options& sopt,
-                                     SkArena& ar, hipStream_t st, float*& dsse, float*& dcsse)
+                                     SkStage& sg, float*& dsse, float*& dcsse)
 {
     // the error model hands out a few dozen distinct rates (one per repeat context), so the host libm's pow / log / log1p
     // run once per distinct rate, not once per indel
@@ -922,11 +913,8 @@ static int upload_shared_error_rates(const double* indel_to_ref_error_prob, cons
         ln_sse[i] = it->second.first;
         ln_csse[i] = it->second.second;
     }
-    dsse = ar.take<float>(n);
-    dcsse = ar.take<float>(n);
-    SK_HIP(hipMemcpy(dsse, ln_sse.data(), 4 * size_t(n), hipMemcpyHostToDevice));
-    SK_HIP(hipMemcpy(dcsse, ln_csse.data(), 4 * size_t(n), hipMemcpyHostToDevice));
-    (void)st;
+    dsse = sg.put(ln_sse.data(), size_t(n));
+    dcsse = sg.put(ln_csse.data(), size_t(n));
     return 0;
 }
 
@@ -970,15 +958,17 @@ int sk_indel_grid_lhood(const sk_readscore_batch* hb, const sk_indel_options* op
     if (hb->n_indels <= 0) return 0;
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
-    SkArena ar;
+    // (one block in, one block out, moved by launches: SkStage, sk_common.h)
+    SkStage sg;
     const size_t out_bytes = sizeof(double) * N_STATES * size_t(hb->n_indels);
-    if (ar.reserve(readscore_bytes(hb) + sk_align256(out_bytes) + 1024)) return 1;
+    if (sg.begin(readscore_bytes(hb), out_bytes, 0, 12)) return 1;
     sk_readscore_batch d;
-    if (upload_readscores(hb, ar, d, ctx.stream)) return 1;
-    double* dout = ar.take<double>(size_t(hb->n_indels) * N_STATES);
+    if (upload_readscores(hb, sg, d)) return 1;
+    double* dout = sg.out<double>(size_t(hb->n_indels) * N_STATES);
+    if (sg.upload(ctx.stream)) return 1;
     if (sk_indel_grid_lhood_dev(&d, opt, is_include_tier2, dout, ctx.stream)) return 1;
-    SK_HIP(hipMemcpyAsync(out_lhood, dout, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    if (sg.download_and_wait(ctx.stream)) return 1;
+    sg.fetch(out_lhood, dout, size_t(hb->n_indels) * N_STATES);
     return 0;
 }
 
@@ -994,27 +984,25 @@ int sk_somatic_indel_call_batch(const sk_readscore_batch* hn, const sk_readscore
     if (n <= 0) return 0;
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
-    SkArena ar;
+    SkStage sg;
     const size_t lh_bytes = sizeof(double) * N_STATES * size_t(n);
-    if (ar.reserve(readscore_bytes(hn) + readscore_bytes(ht) + 2 * sk_align256(lh_bytes) + 2 * sk_align256(4 * n) +
-                   sk_align256(sizeof(sk_somatic_indel_call) * n) + 4096))
+    if (sg.begin(readscore_bytes(hn) + readscore_bytes(ht) + 2 * 4 * size_t(n), sizeof(sk_somatic_indel_call) * size_t(n), 2 * sk_align256(lh_bytes) + 1024, 26))
         return 1;
     sk_readscore_batch dn, dt;
-    if (upload_readscores(hn, ar, dn, ctx.stream) || upload_readscores(ht, ar, dt, ctx.stream)) return 1;
-    double* dnl = ar.take<double>(size_t(n) * N_STATES);
-    double* dtl = ar.take<double>(size_t(n) * N_STATES);
+    if (upload_readscores(hn, sg, dn) || upload_readscores(ht, sg, dt)) return 1;
+    float *dsse = nullptr, *dcsse = nullptr;
+    if (upload_shared_error_rates(indel_to_ref_error_prob, n, *sopt, sg, dsse, dcsse)) return 1;
+    sk_somatic_indel_call* dout = sg.out<sk_somatic_indel_call>(size_t(n));
+    double* dnl = sg.ar.take<double>(size_t(n) * N_STATES);
+    double* dtl = sg.ar.take<double>(size_t(n) * N_STATES);
+    if (sg.upload(ctx.stream)) return 1;
     if (sk_indel_grid_lhood_dev(&dn, nopt, is_include_tier2, dnl, ctx.stream)) return 1;
     if (sk_indel_grid_lhood_dev(&dt, topt, is_include_tier2, dtl, ctx.stream)) return 1;
-
-    float *dsse = nullptr, *dcsse = nullptr;
-    if (upload_shared_error_rates(indel_to_ref_error_prob, n, *sopt, ar, ctx.stream, dsse, dcsse)) return 1;
-    sk_somatic_indel_call* dout = ar.take<sk_somatic_indel_call>(n);
     PostArgs p;
     fill_post_args(*sopt, dnl, dtl, dsse, dcsse, dout, n, p);
     hipLaunchKernelGGL(somatic_indel_posterior_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx.stream, p);
-    SK_HIP(hipGetLastError());
-    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_indel_call) * n, hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    if (sg.download_and_wait(ctx.stream)) return 1;
+    sg.fetch(out, dout, size_t(n));
     return 0;
 }
 
@@ -1045,38 +1033,38 @@ int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* hb, const sk_indel
     SkContext& ctx = sk_ctx();
     SK_HIP(hipSetDevice(ctx.device));
     hipStream_t st = ctx.stream;
-    SkArena ar;
+    // one block in, one block out, moved by launches (SkStage, sk_common.h): the adapter calls this once per indel locus
+    SkStage sg;
     const size_t lh_bytes = sizeof(double) * N_STATES * size_t(n);
     const int64_t trn = hb->normal.read_off[n], trt = hb->tumor.read_off[n];
     const int64_t n_alleles = hb->alt_off[n];
-    if (ar.reserve(readscore_bytes(&hb->normal) + readscore_bytes(&hb->tumor) + 2 * sk_align256(lh_bytes) + 2 * sk_align256(4 * n) +
-                   2 * sk_align256(sizeof(sk_somatic_indel_call) * n) + 2 * sk_align256(8 * size_t(trn)) + 2 * sk_align256(8 * size_t(trt)) +
-                   sk_align256(8 * (size_t(n) + 1)) + sk_align256(sizeof(sk_alt_allele) * size_t(n_alleles)) + 3 * sk_align256(2 * size_t(n)) +
-                   sk_align256(sizeof(sk_somatic_indel_genotype) * n) + 8192))
-        return 1;
+    const size_t in_bytes = readscore_bytes(&hb->normal) + readscore_bytes(&hb->tumor) + 2 * 4 * size_t(n) + 2 * 8 * size_t(trn) + 2 * 8 * size_t(trt) +
+                            8 * (size_t(n) + 1) + sizeof(sk_alt_allele) * size_t(n_alleles) + size_t(n);
+    const size_t extra = 2 * sk_align256(lh_bytes) + 2 * sk_align256(sizeof(sk_somatic_indel_call) * n) + sk_align256(4 * size_t(n)) + 8 * 256;
+    if (sg.begin(in_bytes, sizeof(sk_somatic_indel_genotype) * size_t(n), extra, 34)) return 1;
+    SkArena& ar = sg.ar;
     sk_readscore_batch dn, dt;
-    if (upload_readscores(&hb->normal, ar, dn, st) || upload_readscores(&hb->tumor, ar, dt, st)) return 1;
-    double* dnl = ar.take<double>(size_t(n) * N_STATES);
-    double* dtl = ar.take<double>(size_t(n) * N_STATES);
+    if (upload_readscores(&hb->normal, sg, dn) || upload_readscores(&hb->tumor, sg, dt)) return 1;
     float *dsse = nullptr, *dcsse = nullptr;
-    if (upload_shared_error_rates(hb->indel_to_ref_error_prob, n, *sopt, ar, st, dsse, dcsse)) return 1;
-    sk_somatic_indel_call* dcall[2] = { ar.take<sk_somatic_indel_call>(n), ar.take<sk_somatic_indel_call>(n) };
+    if (upload_shared_error_rates(hb->indel_to_ref_error_prob, n, *sopt, sg, dsse, dcsse)) return 1;
 
     MultiArgs m;
     m.n = dn;
     m.t = dt;
-    auto up = [&](const void* src, const size_t bytes) -> void* {
-        void* p = ar.take<char>(bytes ? bytes : 1);
-        if (bytes) (void)hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st);
-        return p;
-    };
+    auto up = [&](const void* src, const size_t bytes) -> void* { return sg.put(static_cast<const char*>(src), bytes); };
     m.alt_key[0] = static_cast<const int32_t*>(up(hb->normal_alt_key, 8 * size_t(trn)));
     m.alt_lnp[0] = static_cast<const float*>(up(hb->normal_alt_lnp, 8 * size_t(trn)));
     m.alt_key[1] = static_cast<const int32_t*>(up(hb->tumor_alt_key, 8 * size_t(trt)));
     m.alt_lnp[1] = static_cast<const float*>(up(hb->tumor_alt_lnp, 8 * size_t(trt)));
     m.alt_off = static_cast<const int64_t*>(up(hb->alt_off, 8 * (size_t(n) + 1)));
     m.alt_alleles = static_cast<const sk_alt_allele*>(up(hb->alt_alleles, sizeof(sk_alt_allele) * size_t(n_alleles)));
-    SK_HIP(hipGetLastError());
+    uint8_t* dforced = nullptr;
+    if (hb->is_forced_output) dforced = static_cast<uint8_t*>(up(hb->is_forced_output, size_t(n)));
+    sk_somatic_indel_genotype* dout = sg.out<sk_somatic_indel_genotype>(size_t(n));
+    double* dnl = ar.take<double>(size_t(n) * N_STATES);
+    double* dtl = ar.take<double>(size_t(n) * N_STATES);
+    sk_somatic_indel_call* dcall[2] = { ar.take<sk_somatic_indel_call>(n), ar.take<sk_somatic_indel_call>(n) };
+    if (sg.upload(st)) return 1;
     {
         const MapParams m0 = make_map(*topt, false), m1 = make_map(*topt, true);
         m.correct_mapping_log_prior = m0.correct_mapping_log_prior;
@@ -1104,9 +1092,6 @@ int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* hb, const sk_indel
         hipLaunchKernelGGL(somatic_indel_posterior_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p);
         SK_HIP(hipGetLastError());
     }
-    uint8_t* dforced = nullptr;
-    if (hb->is_forced_output) dforced = static_cast<uint8_t*>(up(hb->is_forced_output, size_t(n)));
-    sk_somatic_indel_genotype* dout = ar.take<sk_somatic_indel_genotype>(n);
     IndelCombineArgs c;
     c.call[0] = dcall[0];
     c.call[1] = dcall[1];
@@ -1117,9 +1102,8 @@ int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* hb, const sk_indel
     c.n_indels = n;
     c.out = dout;
     hipLaunchKernelGGL(somatic_indel_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c);
-    SK_HIP(hipGetLastError());
-    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_indel_genotype) * size_t(n), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    if (sg.download_and_wait(st)) return 1;
+    sg.fetch(out, dout, size_t(n));
     return 0;
 }
 

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 #include <string>
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -89,6 +90,44 @@ struct SkArena
 };
 
 static inline size_t sk_align256(size_t n) { return (n + 255) & ~size_t(255); }
+
+// The small host-buffer entry points (one indel group, one haplotype, a few loci per call: the adapter's per-unit sites) move their
+// arrays as ONE page-locked block in and ONE out, carried by two launches in the process's own queue.  A copy call per array from the
+// caller's pageable memory is a synchronous staged copy each (~10 us, ten of them per call), and with several caller processes on a
+// device every copy call queues behind the others' (profiles/r05_enum_job_history.txt: the realignment job's way in and out).
+//   SkStage st; st.begin(in_bytes, out_bytes);  T* d = st.put(host_array, n); ... U* dout = st.out<U>(n);
+//   st.upload(stream); <launch kernels on d..., dout>; st.download_and_wait(stream); st.fetch(host_dst, dout, n);
+struct SkStage
+{
+    SkArena ar;                 // device side: [in block | out block | whatever the caller takes after begin()]
+    char* h_in = nullptr;       // page-locked mirrors (the context's, grown on demand)
+    char* h_out = nullptr;
+    size_t in_cap = 0, out_cap = 0, in_used = 0, out_used = 0;
+    char* d_in = nullptr;
+    char* d_out = nullptr;
+    /// room for `in_bytes` of inputs and `out_bytes` of outputs (sums of the arrays' sizes; alignment padding is added here) plus
+    /// `extra_bytes` of device scratch the caller takes from `ar` afterwards
+    int begin(size_t in_bytes, size_t out_bytes, size_t extra_bytes, int n_arrays);
+    template <typename T> T* put(const T* src, const size_t n)
+    {
+        const size_t off = (in_used + 255) & ~size_t(255);
+        in_used = off + n * sizeof(T);
+        if (n && in_used <= in_cap) std::memcpy(h_in + off, src, n * sizeof(T)); // (past the room asked for: upload() reports it)
+        return reinterpret_cast<T*>(d_in + off);
+    }
+    template <typename T> T* out(const size_t n)
+    {
+        const size_t off = (out_used + 255) & ~size_t(255);
+        out_used = off + n * sizeof(T);
+        return reinterpret_cast<T*>(d_out + off);
+    }
+    int upload(hipStream_t st);            // in block: page-locked mirror -> device (one launch)
+    int download_and_wait(hipStream_t st); // out block: device -> page-locked mirror (one launch), then the wait
+    template <typename T> void fetch(T* dst, const T* dev, const size_t n) const
+    {
+        if (n) std::memcpy(dst, h_out + (reinterpret_cast<const char*>(dev) - d_out), n * sizeof(T));
+    }
+};
 
 // packed base_call accessors (device + host)
 #define SKC_Q(c) ((unsigned)((c) & 0x3f))

@@ -4,6 +4,8 @@
 // by the compiler: inputs pass through `rt()` (a volatile round trip).
 
 #include "sk_common.h"
+
+#include <algorithm>
 #include "libm_dbl64.h"
 
 #include <chrono>
@@ -139,6 +141,73 @@ int SkArena::reserve(size_t bytes)
     base = static_cast<char*>(c.arena);
     cap = c.arena_bytes;
     used = 0;
+    return 0;
+}
+
+namespace
+{
+// (16-byte pieces, a grid-stride loop: the blocks are a few KB to a few hundred KB)
+__global__ __launch_bounds__(256) void stage_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const uint32_t n16)
+{
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+struct StageMirrors // the context's page-locked mirrors of SkStage's two blocks
+{
+    void* in = nullptr;
+    void* out = nullptr;
+    size_t in_cap = 0, out_cap = 0;
+};
+StageMirrors& stage_mirrors()
+{
+    static StageMirrors m;
+    return m;
+}
+int grow_pinned(void*& p, size_t& cap, const size_t bytes)
+{
+    if (bytes <= cap) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    SK_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return 0;
+}
+}
+
+int SkStage::begin(const size_t in_bytes, const size_t out_bytes, const size_t extra_bytes, const int n_arrays)
+{
+    const size_t pad = 256 * size_t(n_arrays + 2);
+    const size_t in_room = sk_align256(in_bytes + pad), out_room = sk_align256(out_bytes + pad);
+    StageMirrors& m = stage_mirrors();
+    if (grow_pinned(m.in, m.in_cap, in_room) || grow_pinned(m.out, m.out_cap, out_room)) return 1;
+    if (ar.reserve(in_room + out_room + extra_bytes + 256 * size_t(n_arrays + 2))) return 1;
+    h_in = static_cast<char*>(m.in);
+    h_out = static_cast<char*>(m.out);
+    in_cap = in_room;
+    out_cap = out_room;
+    in_used = out_used = 0;
+    d_in = ar.take<char>(in_room);
+    d_out = ar.take<char>(out_room);
+    return 0;
+}
+
+int SkStage::upload(hipStream_t st)
+{
+    if (in_used > in_cap || out_used > out_cap) return sk_fail("strelka_amd: a staged call's arrays outgrew the room asked for");
+    const uint32_t n16 = uint32_t((in_used + 15) / 16);
+    if (n16) hipLaunchKernelGGL(stage_copy_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 256u)), dim3(256), 0, st, reinterpret_cast<const uint4*>(h_in),
+                                reinterpret_cast<uint4*>(d_in), n16);
+    return 0;
+}
+
+int SkStage::download_and_wait(hipStream_t st)
+{
+    const uint32_t n16 = uint32_t((out_used + 15) / 16);
+    if (n16) hipLaunchKernelGGL(stage_copy_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 256u)), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_out),
+                                reinterpret_cast<uint4*>(h_out), n16);
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipStreamSynchronize(st));
     return 0;
 }
 
