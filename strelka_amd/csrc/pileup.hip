@@ -1514,11 +1514,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     }
     if (mask_len > 0) std::memcpy(hi + li.mask, cand_snv_mask, size_t(mask_len)); // (through the pinned block: a copy from the caller's pageable memory would wait for the device)
     char* di = static_cast<char*>(d_in.p);
-    // (the window's way in and out as launches, not copy calls: with several caller processes on a device every copy call queues behind
-    // the others', profiles/r05_enum_job_history.txt -- $SK_PILEUP_STAGE_COPIES: the copy calls, for A-B runs)
-    static const bool copy_calls = std::getenv("SK_PILEUP_STAGE_COPIES") != nullptr;
-    if (copy_calls) SK_HIP(hipMemcpyAsync(di, hi, size_t(li.total), hipMemcpyHostToDevice, st));
-    else if (sk_stage_copy(di, hi, size_t(li.total), st)) return 1;
+    SK_HIP(hipMemcpyAsync(di, hi, size_t(li.total), hipMemcpyHostToDevice, st));
     CopyArgs carry; // every device-to-device piece of this push, one launch
     carry.n = 0;
     int64_t carry_max = 0;
@@ -1738,8 +1734,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
             return 1;
     }
     SK_HIP(hipGetLastError());
-    if (copy_calls) SK_HIP(hipMemcpyAsync(ho, dout, size_t(ol.total), hipMemcpyDeviceToHost, st));
-    else if (sk_stage_copy(ho, dout, size_t(ol.total), st)) return 1;
+    SK_HIP(hipMemcpyAsync(ho, dout, size_t(ol.total), hipMemcpyDeviceToHost, st));
     return 0;
 }
 

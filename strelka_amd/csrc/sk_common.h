@@ -91,9 +91,6 @@ struct SkArena
 
 static inline size_t sk_align256(size_t n) { return (n + 255) & ~size_t(255); }
 
-// a block between page-locked host memory and the device, either way, as ONE launch in the process's own queue (no copy-engine call)
-int sk_stage_copy(void* dst, const void* src, size_t bytes, hipStream_t st);
-
 // The small host-buffer entry points (one indel group, one haplotype, a few loci per call: the adapter's per-unit sites) move their
 // arrays as ONE page-locked block in and ONE out, carried by two launches in the process's own queue.  A copy call per array from the
 // caller's pageable memory is a synchronous staged copy each (~10 us, ten of them per call), and with several caller processes on a

@@ -175,17 +175,6 @@ int grow_pinned(void*& p, size_t& cap, const size_t bytes)
 }
 }
 
-int sk_stage_copy(void* dst, const void* src, const size_t bytes, hipStream_t st)
-{
-    // (both ends 16-byte aligned and the room a multiple of 16: the callers' blocks are 256-byte aligned pieces of larger buffers)
-    const size_t n16 = (bytes + 15) / 16;
-    if (n16 == 0) return 0;
-    if (n16 > 0xffffffffull) return sk_fail("sk_stage_copy: block too large");
-    hipLaunchKernelGGL(stage_copy_kernel, dim3(unsigned(std::min<size_t>((n16 + 255) / 256, 1024))), dim3(256), 0, st, static_cast<const uint4*>(src),
-                       static_cast<uint4*>(dst), uint32_t(n16));
-    return 0;
-}
-
 int SkStage::begin(const size_t in_bytes, const size_t out_bytes, const size_t extra_bytes, const int n_arrays)
 {
     const size_t pad = 256 * size_t(n_arrays + 2);
