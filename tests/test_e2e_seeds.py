@@ -37,3 +37,26 @@ def test_seeded_samples_identical_over_the_cpu_double():
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd", "samtools", "bgzip", "tabix"), reason="oracle/_ref binaries not built")
 def test_seeded_samples_identical_gpu():
     _run((119, 126, 128, 207, 363), "amd")
+
+
+def _run_somatic(seeds, variant):
+    import e2e_seeds
+    cwd = os.getcwd()
+    os.chdir(E.REPO)
+    try:
+        for seed in seeds:
+            ok, msg = e2e_seeds.one_somatic(seed, variant)
+            assert ok, msg
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_dbl", "samtools"), reason="oracle/_ref binaries not built")
+def test_seeded_tumour_normal_pairs_identical_over_the_cpu_double():
+    _run_somatic((8,), "dbl")  # (8x / 25x, three regions out of order, callable regions and the depth filter on)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_amd", "samtools"), reason="oracle/_ref binaries not built")
+def test_seeded_tumour_normal_pairs_identical_gpu():
+    _run_somatic((8, 14, 16), "amd")

@@ -3,7 +3,7 @@ GPU box pass variant=amd): depth, variant density, the way the run is cut into r
 be the reference's byte for byte.  The routed gVCF path (site 10: plain sites and whole blocks from the device's window) sees shallow and
 deep samples, regions that start inside blocks, regions called out of order.
 
-usage: python tools/fuzz/e2e_seeds.py [n_seeds=16] [first_seed=1] [variant=dbl] [workers=8]"""
+usage: python tools/fuzz/e2e_seeds.py [n_seeds=16] [first_seed=1] [variant=dbl] [workers=8] [somatic]"""
 import os
 import random
 import shutil
@@ -99,6 +99,58 @@ def one(seed, variant, models):
         what, sum(1 for l in want["variants.vcf"] if l[0] != "#"), len(want["genome.S1.vcf"]))
 
 
+def one_somatic(seed, variant):
+    """a tumour / normal pair: depths, variant densities, the tumour clones' share and the region cuts from the seed; the somatic workflow's
+    command line (EVS models, callable regions, the chromosome depth filter on or off)"""
+    from strelka_amd import farm
+    rng = random.Random(19000 + seed)
+    length = rng.choice([100000, 160000, 240000])
+    nd, td = rng.choice([(20.0, 40.0), (40.0, 110.0), (30.0, 60.0), (60.0, 60.0), (8.0, 25.0)])
+    snv_every, indel_every, som_every = rng.choice([150, 1000]), rng.choice([400, 3000]), rng.choice([2000, 20000])
+    clone = rng.choice([0.1, 0.3, 0.6])
+    d = os.path.join(E.REPO, "oracle", "_ref", "synth", "fuzz_som_%d" % seed)
+    if not os.path.exists(os.path.join(d, "chrom_depth.txt")):
+        os.makedirs(d, exist_ok=True)
+        for role, depth, name in (("normal", nd, "normal"), ("tumor", td, "tumor")):
+            subprocess.run([sys.executable, "tools/make_wgs_bam.py", d, os.path.join(E.BIN_DIR, "samtools"), "--length", str(length), "--depth", str(depth),
+                            "--seed", str(seed), "--procs", "1", "--role", role, "--name", name, "--sample", name.upper(), "--snv-every", str(snv_every),
+                            "--indel-every", str(indel_every), "--somatic-every", str(som_every), "--clone-fraction", str(clone)],
+                           check=True, stdout=subprocess.DEVNULL)
+        with open(os.path.join(d, "chrom_depth.txt"), "w") as f:
+            f.write("chrW\t%.3f\n" % nd)
+    cuts = sorted(rng.sample(range(1000, length - 1000), rng.choice([0, 1, 2])))
+    edges = [1] + cuts + [length + 1]
+    regions = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        gap = rng.choice([0, 0, 37, 1500])
+        if b - gap > a:
+            regions.append("chrW:%d-%d" % (a, b - 1 - gap))
+    if rng.random() < 0.3:
+        rng.shuffle(regions)
+    callable_regions, depth_filter = rng.random() < 0.5, rng.random() < 0.7
+    outputs = ["somatic.snvs.vcf", "somatic.indels.vcf"] + (["somatic.callable.regions.bed"] if callable_regions else [])
+    out = {}
+    for binary in ("strelka2_ref", "strelka2_" + variant):
+        with tempfile.TemporaryDirectory() as o:
+            E.run(farm.somatic_segment_argv(binary, o + "/", os.path.join(d, "normal.bam"), os.path.join(d, "tumor.bam"), regions, os.path.join(d, "normal.fa"),
+                                            chrom_depth=os.path.join(d, "chrom_depth.txt") if depth_filter else None, callable_regions=callable_regions),
+                  timeout=3600)
+            out[binary] = {f: E.vcf_body(os.path.join(o, f), keep_header=True) for f in outputs}
+    want, got = out["strelka2_ref"], out["strelka2_" + variant]
+    if not os.environ.get("SK_FUZZ_KEEP"):
+        shutil.rmtree(d, ignore_errors=True)
+    what = "somatic seed %d: %d bp at %gx / %gx, snv/%d indel/%d somatic/%d clones %g, regions %s%s%s" % (
+        seed, length, nd, td, snv_every, indel_every, som_every, clone, ",".join(regions), " callable-regions" if callable_regions else "",
+        " depth-filter" if depth_filter else "")
+    for f in want:
+        if want[f] != got[f]:
+            k = next((i for i, (x, y) in enumerate(zip(want[f], got[f])) if x != y), min(len(want[f]), len(got[f])))
+            return False, "%s: %s differs at line %d\n  reference: %s\n  drop-in:   %s" % (
+                what, f, k + 1, want[f][k] if k < len(want[f]) else "<end>", got[f][k] if k < len(got[f]) else "<end>")
+    return True, "%s: identical (%d + %d records)" % (what, sum(1 for l in want["somatic.snvs.vcf"] if l[0] != "#"),
+                                                     sum(1 for l in want["somatic.indels.vcf"] if l[0] != "#"))
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -108,8 +160,9 @@ def main():
     subprocess.run([sys.executable, "tools/make_dummy_germline_models.py", md], check=True)
     models = ("--snv-scoring-model-file", md + "/germlineSNVScoringModels.json", "--indel-scoring-model-file", md + "/germlineIndelScoringModels.json")
     bad = 0
+    somatic = len(sys.argv) > 5 and sys.argv[5] == "somatic"
     with ThreadPoolExecutor(workers) as ex:
-        for ok, msg in ex.map(lambda s: one(s, variant, models), range(first, first + n)):
+        for ok, msg in ex.map((lambda s: one_somatic(s, variant)) if somatic else (lambda s: one(s, variant, models)), range(first, first + n)):
             print(msg, flush=True)
             bad += 0 if ok else 1
     print("%d of %d seeds identical" % (n - bad, n))
