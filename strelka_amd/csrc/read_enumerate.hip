@@ -1118,6 +1118,7 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
     if (ncr == 0 || a.status[r] != ST_OK) return;
     unsigned long long stamp[8];
     stamp[0] = now();
+    const unsigned long long wall0 = TIMING ? (unsigned long long)wall_clock64() : 0ull; // (the constant 100 MHz counter: the block's life in time)
     for (int i = 1; i < 8; ++i) stamp[i] = 0;
     const int64_t ro = a.read_off[r];
     const int32_t L = int32_t(a.read_off[r + 1] - ro);
@@ -1318,7 +1319,7 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
                 }
                 if (bad) a.status[r] = ST_FAIL;
             }
-            stamp[3] += now() - tA1; // candidate-status marks
+            (void)tA1;
         }
         __builtin_amdgcn_wave_barrier();
         const unsigned long long td = now();
@@ -1332,6 +1333,7 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
     }
     if (fa.dbg && lane == 0) {
         stamp[6] = now();
+        stamp[3] = TIMING ? (unsigned long long)wall_clock64() - wall0 : 0ull;
         for (int i = 0; i < 8; ++i) fa.dbg[size_t(r) * 8 + i] = stamp[i];
     }
 }
@@ -2918,8 +2920,9 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
             (void)hipEventDestroy(a1);
         }
         if (nblk)
-            std::fprintf(stderr, "[f5-timing] blocks %d: cycles per block: prologue %.0f staging %.0f marks %.0f phaseA %.0f (walk %.0f) phaseB %.0f total %.0f; kernel span %llu cycles => %.1f blocks in flight\n",
-                         nblk, sum[0] / nblk, sum[2] / nblk, sum[3] / nblk, sum[4] / nblk, sum[7] / nblk, sum[5] / nblk, sum[6] / nblk, last - first,
+            std::fprintf(stderr, "[f5-timing] blocks %d: cycles per block: prologue %.0f staging %.0f phaseA %.0f (walk %.0f) phaseB %.0f total %.0f = %.1f us by the 100 MHz counter (%.0f MHz); kernel span %llu cycles => %.1f blocks in flight\n",
+                         nblk, sum[0] / nblk, sum[2] / nblk, sum[4] / nblk, sum[7] / nblk, sum[5] / nblk, sum[6] / nblk, sum[3] / nblk / 100.0,
+                         sum[6] / std::max(1.0, sum[3]) * 100.0, last - first,
                          sum[6] / double(last - first));
     }
     for (int i = 0; i < reps; ++i) {
