@@ -1107,12 +1107,22 @@ __device__ __forceinline__ double f5_sum(LDS& S, const uint32_t* const myslot, c
 }
 
 // TIMING: the cycle stamps of $SK_F5_TIMING (fa.dbg); without it the stamps are constants and their s_memtime + waits are gone
+// a block is F5_WAVES waves, each with a read and an LDS object of its own: what orders a wave's LDS accesses is the wave (its LDS
+// instructions complete in order), so the points where the lanes exchange data through LDS need the compiler's and the counters'
+// attention, not a workgroup barrier
+__device__ __forceinline__ void f5_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <int MAXR, bool TIMING>
 __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F5Lds<MAXR>& S)
 {
     auto now = [&]() -> unsigned long long { return TIMING ? (unsigned long long)clock64() : 0ull; };
     const FlatArgs& a = fa.f;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int c0 = a.cal_off[r], c1 = a.cal_off[r + 1];
     const int ncr = c1 - c0;
     if (ncr == 0 || a.status[r] != ST_OK) return;
@@ -1159,7 +1169,7 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
             }
             S.hap[i] = v;
         }
-        __syncthreads();
+        f5_wave_sync();
         for (int k = 0; k < n_ins; ++k) { // the insert sequences, in table order (a later one overwrites an earlier one, as pool_fill_kernel)
             const int32_t o = __builtin_amdgcn_readlane(my_ins_off, k), n = __builtin_amdgcn_readlane(my_ins_len, k);
             const uint32_t src = uint32_t(__builtin_amdgcn_readlane(int(my_ins_src), k));
@@ -1215,7 +1225,7 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
 
     for (int j0 = 0; j0 < ncr; j0 += 64) {
         const int nc = min(64, ncr - j0);
-        __syncthreads(); // (pool and read complete; the previous round's slots read; the order written)
+        f5_wave_sync(); // (pool and read complete; the previous round's slots read; the order written)
         const unsigned long long ta = now();
         if (j0 == 0) stamp[1] = ta; // prologue done
         // ---- the round's records, a lane its own: header + F5_SEGS path segments (five 16-byte loads) + F5_INDELS indel indices, all in
@@ -1292,11 +1302,11 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
                 e.ins_at = -1;
                 S.tab[lane] = e;
             }
-            __syncthreads();
+            f5_wave_sync();
             // (the read's inserts are distinct table indices, pool_layout_kernel: a lane an insert, no two write the same entry)
             if (my_ins_idx >= tab_lo && my_ins_idx < tab_lo + n_tab) S.tab[my_ins_idx - tab_lo].ins_at = my_ins_off;
         }
-        __syncthreads();
+        f5_wave_sync();
         const unsigned long long tc = now();
         stamp[2] += tc - ta; // staging + table copy
         // ---- phase A, a lane per candidate alignment: the walk of its path leaves the alignment's TRANSITIONS in its slot: one word per
@@ -1338,24 +1348,34 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
     }
 }
 
-template <int MAXR, bool TIMING>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void flatten_score_kernel(const FusedScoreArgs fa)
+template <int MAXR, bool TIMING, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void flatten_score_kernel(const FusedScoreArgs fa, const int n_reads)
 {
-    // (a block per read: a grid of the 4 096 blocks the device holds at a time, each taking reads r, r + 4 096, ..., is 12 % slower --
-    // the dispatcher's placing of the next block on whichever CU has room is the load balance, profiles/r05_f5_history.txt)
-    __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S;
-    f5_read<MAXR, TIMING>(fa, blockIdx.x, S);
+    // (a wave per read, WAVES reads to a block.  A grid of the 4 096 waves the device holds at a time, each taking reads r, r + 4 096, ...,
+    // is 12 % slower: the dispatcher's placing of the next block where there is room is the load balance -- profiles/r05_f5_history.txt)
+    __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S[WAVES];
+    const int wave = threadIdx.x >> 6, r = blockIdx.x * WAVES + wave;
+    if (r < n_reads) f5_read<MAXR, TIMING>(fa, r, S[wave]);
 }
 
 // the rows of terms sized for the job's longest read: with 150-base reads a wave's LDS is 10 KB, sixteen waves to a CU (the 256-base
 // form: twelve)
+template <int MAXR, bool TIMING>
+static void launch_flatten_score_t(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
+{
+    static const int waves = [] { const char* e = std::getenv("SK_F5_WAVES"); return e ? std::atoi(e) : 1; }(); // (experiments: 1, 2, 4)
+    if (waves == 4) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 4>), dim3((n_reads + 3) / 4), dim3(256), 0, st, fs, n_reads);
+    else if (waves == 2) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 2>), dim3((n_reads + 1) / 2), dim3(128), 0, st, fs, n_reads);
+    else hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 1>), dim3(n_reads), dim3(64), 0, st, fs, n_reads);
+}
+
 static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
 {
     const bool short_reads = fs.f.max_read_len <= 152, timing = fs.dbg != nullptr;
-    if (short_reads && !timing) hipLaunchKernelGGL((flatten_score_kernel<152, false>), dim3(n_reads), dim3(64), 0, st, fs);
-    else if (short_reads) hipLaunchKernelGGL((flatten_score_kernel<152, true>), dim3(n_reads), dim3(64), 0, st, fs);
-    else if (!timing) hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, false>), dim3(n_reads), dim3(64), 0, st, fs);
-    else hipLaunchKernelGGL((flatten_score_kernel<F5_MAX_READ, true>), dim3(n_reads), dim3(64), 0, st, fs);
+    if (short_reads && !timing) launch_flatten_score_t<152, false>(n_reads, st, fs);
+    else if (short_reads) launch_flatten_score_t<152, true>(n_reads, st, fs);
+    else if (!timing) launch_flatten_score_t<F5_MAX_READ, false>(n_reads, st, fs);
+    else launch_flatten_score_t<F5_MAX_READ, true>(n_reads, st, fs);
 }
 
 // the records in set order, for the host (sk_enum_device_fetch_cals; a job whose stage 3 runs on the host): pool[list[c]] -> cals[c], a wave

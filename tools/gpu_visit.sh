@@ -62,6 +62,12 @@ for step in "$@"; do
       python -c "import json;d=json.load(open('$OUT/realign.json'))['legs'];print({k:'%.3e reads/s' % (v['reads']/(v['t1']-v['t0'])) for k,v in d.items()})" ;;
     seeds)  # the drop-in (this box's GPU) against the reference on fresh seeded samples: $SEEDS_ARGS = "n first variant workers"
       timeout 900 python tools/fuzz/e2e_seeds.py ${SEEDS_ARGS:-8 201 amd 8} > $OUT/fuzz_e2e_seeds.txt 2>&1; tail -3 $OUT/fuzz_e2e_seeds.txt | cut -c1-300 ;;
+    a5_waves)  # F5 with 1, 2, 4 waves (reads) to a block ($SK_F5_WAVES)
+      for w in ${A5_WAVES:-1 2 4}; do
+        SK_F5_WAVES=$w timeout 600 python -m pytest tests/test_device_enumeration.py -m gpu -x -q > $OUT/pytest_a5_w$w.log 2>&1; echo "waves=$w pytest rc=$? $(tail -1 $OUT/pytest_a5_w$w.log)"
+        SK_F5_WAVES=$w timeout 300 python bench.py --only a5 --steps 10 --warmup 2 > $OUT/a5_w$w.json 2>$OUT/a5_w$w.err; echo "waves=$w: $(grep -o '"kernel_ms": [0-9.]*' $OUT/a5_w$w.json)"
+        SK_F5_WAVES=$w SK_F5_TIMING=1 timeout 300 python bench.py --only a5 --a5-reads 4096 --steps 3 --warmup 1 > $OUT/a5_4096_w$w.json 2>$OUT/a5_4096_w$w.err; grep "f5-timing" $OUT/a5_4096_w$w.err | tail -4 | cut -c1-260
+      done ;;
     a5_grid)  # F5's time against the blocks of its grid ($SK_F5_GRID; 0 = a block per read)
       timeout 600 python -m pytest tests/test_device_enumeration.py -m gpu -x -q > $OUT/pytest_a5.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_a5.log; tail -3 $OUT/pytest_a5.log
       for g in ${A5_GRIDS:-0 4096 3072 2048}; do
