@@ -1364,7 +1364,9 @@ template <int MAXR, bool TIMING>
 static void launch_flatten_score_t(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
 {
     static const int waves = [] { const char* e = std::getenv("SK_F5_WAVES"); return e ? std::atoi(e) : 1; }(); // (experiments: 1, 2, 4)
-    if (waves == 4) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 4>), dim3((n_reads + 3) / 4), dim3(256), 0, st, fs, n_reads);
+    if (waves == 16 && MAXR <= 152) hipLaunchKernelGGL((flatten_score_kernel<152, TIMING, 16>), dim3((n_reads + 15) / 16), dim3(1024), 0, st, fs, n_reads);
+    else if (waves >= 8) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 8>), dim3((n_reads + 7) / 8), dim3(512), 0, st, fs, n_reads);
+    else if (waves == 4) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 4>), dim3((n_reads + 3) / 4), dim3(256), 0, st, fs, n_reads);
     else if (waves == 2) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 2>), dim3((n_reads + 1) / 2), dim3(128), 0, st, fs, n_reads);
     else hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 1>), dim3(n_reads), dim3(64), 0, st, fs, n_reads);
 }
