@@ -1348,11 +1348,16 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
     }
 }
 
+// A wave per read, WAVES reads to a block (each wave with an LDS object of its own; nothing is shared between them).  With a block per
+// read the kernel was bound by the rate at which the dispatcher places workgroups: 65 536 one-wave blocks went out at ~30 per us, a
+// block lives ~58 us, so ~7 of a CU's 16 slots were filled however many were free (SQ_WAVE_CYCLES says the same); eight waves to a
+// block is an eighth of the placements, its waves spread over the CU's four SIMDs at once: 2.23 -> 1.67 ms per 65 536 reads (2 waves
+// to a block: no change, 4: 1.73, 16: 1.67 -- profiles/r05_f5_history.txt).  A grid of the 4 096 waves the device holds at a time, each
+// taking reads r, r + 4 096, ..., had been the other way round that limit and is slower (2.49 ms: waves that start together stay in step,
+// all in the walk or all in the sums).
 template <int MAXR, bool TIMING, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void flatten_score_kernel(const FusedScoreArgs fa, const int n_reads)
 {
-    // (a wave per read, WAVES reads to a block.  A grid of the 4 096 waves the device holds at a time, each taking reads r, r + 4 096, ...,
-    // is 12 % slower: the dispatcher's placing of the next block where there is room is the load balance -- profiles/r05_f5_history.txt)
     __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S[WAVES];
     const int wave = threadIdx.x >> 6, r = blockIdx.x * WAVES + wave;
     if (r < n_reads) f5_read<MAXR, TIMING>(fa, r, S[wave]);
@@ -1360,14 +1365,17 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
 
 // the rows of terms sized for the job's longest read: with 150-base reads a wave's LDS is 10 KB, sixteen waves to a CU (the 256-base
 // form: twelve)
+// eight waves to a block where their LDS leaves room for two blocks to a CU (the short-read form: 76.7 KB), four with the long form
 template <int MAXR, bool TIMING>
 static void launch_flatten_score_t(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
 {
-    static const int waves = [] { const char* e = std::getenv("SK_F5_WAVES"); return e ? std::atoi(e) : 1; }(); // (experiments: 1, 2, 4)
-    if (waves == 16 && MAXR <= 152) hipLaunchKernelGGL((flatten_score_kernel<152, TIMING, 16>), dim3((n_reads + 15) / 16), dim3(1024), 0, st, fs, n_reads);
-    else if (waves >= 8) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 8>), dim3((n_reads + 7) / 8), dim3(512), 0, st, fs, n_reads);
-    else if (waves == 4) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 4>), dim3((n_reads + 3) / 4), dim3(256), 0, st, fs, n_reads);
-    else if (waves == 2) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 2>), dim3((n_reads + 1) / 2), dim3(128), 0, st, fs, n_reads);
+    static const int waves = [] { const char* e = std::getenv("SK_F5_WAVES"); return e ? std::atoi(e) : 0; }(); // (experiments: 1, 2, 4, 8, 16; 0 = the default)
+    constexpr int DEFAULT_WAVES = (sizeof(F5Lds<MAXR>) * 16 <= 160 * 1024) ? 8 : 4;
+    const int w = waves > 0 ? waves : DEFAULT_WAVES;
+    if (w == 16 && MAXR <= 152) hipLaunchKernelGGL((flatten_score_kernel<152, TIMING, 16>), dim3((n_reads + 15) / 16), dim3(1024), 0, st, fs, n_reads);
+    else if (w >= 8) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 8>), dim3((n_reads + 7) / 8), dim3(512), 0, st, fs, n_reads);
+    else if (w == 4) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 4>), dim3((n_reads + 3) / 4), dim3(256), 0, st, fs, n_reads);
+    else if (w == 2) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 2>), dim3((n_reads + 1) / 2), dim3(128), 0, st, fs, n_reads);
     else hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 1>), dim3(n_reads), dim3(64), 0, st, fs, n_reads);
 }
 
