@@ -142,32 +142,12 @@ __device__ __forceinline__ double mix_term(const ReadExp& r, const double ref_pr
     return __dadd_rn(r.T, sk_log(__dadd_rn(mix, r.wm), ex, lt));
 }
 
-// (the lanes of ONE wave exchange data through LDS here: the wave's LDS instructions complete in order, a workgroup barrier is not needed
-// -- and with several independent waves to a block must not be used)
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// A wave per indel, I1_WAVES indels to a block: with a block per indel the dispatcher places ~36 one-wave blocks per us and a block lives
-// ~20 us -- three waves to a CU whatever room there is (csrc/read_enumerate.hip, flatten_score_kernel: the same finding)
-#ifndef I1_WAVES
-#define I1_WAVES 4
-#endif
 template <bool FAST>
-__global__ __launch_bounds__(WAVE * I1_WAVES) void indel_grid_lhood_kernel(const GridArgs a)
+__global__ __launch_bounds__(WAVE) void indel_grid_lhood_kernel(const GridArgs a)
 {
-    __shared__ double s_term_all[I1_WAVES][N_STATES][WAVE];
-    __shared__ double s_lr_all[I1_WAVES][N_STATES], s_li_all[I1_WAVES][N_STATES];
-    const int wave_in_block = threadIdx.x / WAVE;
-    const int ind = blockIdx.x * I1_WAVES + wave_in_block;
-    if (ind >= a.b.n_indels) return;
-    double (*s_term)[WAVE] = s_term_all[wave_in_block];
-    double* s_lr = s_lr_all[wave_in_block];
-    double* s_li = s_li_all[wave_in_block];
-    const int lane = threadIdx.x % WAVE;
+    __shared__ double s_term[N_STATES][WAVE];
+    const int ind = blockIdx.x;
+    const int lane = threadIdx.x;
     const int64_t r0 = a.b.read_off[ind];
     const int n = int(a.b.read_off[ind + 1] - r0);
     const unsigned del_len = a.b.del_len[ind], ins_len = a.b.ins_len[ind];
@@ -180,6 +160,7 @@ __global__ __launch_bounds__(WAVE * I1_WAVES) void indel_grid_lhood_kernel(const
     // of the read: when all reads of the indel have one length -- every WGS sample -- they are 19 pairs per indel, evaluated once, by
     // the operations the per-read form performs (the same values bit for bit), instead of 19 pairs per read: two of the six
     // transcendentals of a (read, het state).
+    __shared__ double s_lr[N_STATES], s_li[N_STATES];
     bool one_length = false;
     if (!FAST) {
         unsigned lo = 0xffffffffu, hi = 0;
@@ -207,7 +188,7 @@ __global__ __launch_bounds__(WAVE * I1_WAVES) void indel_grid_lhood_kernel(const
             s_lr[state] = lr;
             s_li[state] = li;
         }
-        wave_lds_sync();
+        __syncthreads();
     }
 
     double acc = 0.; // lanes 0..20: the running sum of state `lane`
@@ -284,10 +265,10 @@ __global__ __launch_bounds__(WAVE * I1_WAVES) void indel_grid_lhood_kernel(const
                 } // exact form
             }
         }
-        wave_lds_sync();
+        __syncthreads();
         if (lane < N_STATES)
             for (int j = 0; j < cnt; ++j) acc = __dadd_rn(acc, s_term[lane][j]);
-        wave_lds_sync();
+        __syncthreads();
     }
     if (lane < N_STATES) a.out[size_t(ind) * N_STATES + lane] = acc;
 }
@@ -873,9 +854,8 @@ int sk_indel_grid_lhood_dev(const sk_readscore_batch* b, const sk_indel_options*
     }
     volatile double two = 2.;
     a.loghalf = -std::log(two); // :251
-    const dim3 grid((b->n_indels + I1_WAVES - 1) / I1_WAVES), block(WAVE * I1_WAVES);
-    if (opt->fast_form) hipLaunchKernelGGL(indel_grid_lhood_kernel<true>, grid, block, 0, static_cast<hipStream_t>(hip_stream), a);
-    else hipLaunchKernelGGL(indel_grid_lhood_kernel<false>, grid, block, 0, static_cast<hipStream_t>(hip_stream), a);
+    if (opt->fast_form) hipLaunchKernelGGL(indel_grid_lhood_kernel<true>, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
+    else hipLaunchKernelGGL(indel_grid_lhood_kernel<false>, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
     SK_HIP(hipGetLastError());
     return 0;
 }
