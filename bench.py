@@ -883,7 +883,7 @@ def main():
                                     "and its partial-line stores, DESIGN.md section 3 B1")
     out["roofline"]["note"] = ("scoreCandidateAlignment as one kernel, from the records the device search left to one double each; `traffic` from the "
                                "--only a5 counter passes (tools/gpu_visit.sh pmc_traffic); the table sums alone over a prepared batch are roofline_sum_only; "
-                               "the staged chain it replaced (F1-F3 + A1c, $SK_A5_FUSED=0) is 2.8x slower on this job (profiles/r04_*)")
+                               "the staged chain it replaced (F1-F3 + A1c, $SK_A5_FUSED=0) was 2.8x slower than round 4's F5 on this job (profiles/r04_*) and is ~4x slower than this one (profiles/r05_f5_history.txt)")
     out["realign_processes"] = realign_processes
     out["e2e"] = e2e
     out["e2e_somatic"] = e2e_somatic
