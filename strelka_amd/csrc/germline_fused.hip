@@ -919,7 +919,7 @@ __global__ __launch_bounds__(LOCI) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
 
 // second pass: the few loci the LDS kernel declined (deeper than 1022 calls / the LDS budget, or needing more ranked
 // calls / sort stack than the fast path holds) through the global-memory routines -- same arithmetic
-__global__ void germline_site_global_pass_kernel(const FusedArgs a)
+__global__ __launch_bounds__(64) void germline_site_global_pass_kernel(const FusedArgs a) // (launched 64 lanes to a block: no register cap of 128, no spills)
 {
     const unsigned n = *a.work_count;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

@@ -24,7 +24,7 @@ struct DepArgs
     GermlineDerived d;
 };
 
-__global__ void dependent_eprob_kernel(const DepArgs a)
+__global__ __launch_bounds__(64) void dependent_eprob_kernel(const DepArgs a)
 {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= a.b.n_loci) return;
@@ -41,7 +41,7 @@ struct SiteArgs
     GermlineDerived d;
 };
 
-__global__ void site_digt_call_kernel(const SiteArgs a)
+__global__ __launch_bounds__(64) void site_digt_call_kernel(const SiteArgs a)
 {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= a.b.n_loci) return;

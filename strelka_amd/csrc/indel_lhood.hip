@@ -284,7 +284,9 @@ struct PostArgs
     SomaticDerived d;
 };
 
-__global__ void somatic_indel_posterior_kernel(const PostArgs a)
+// (launched 64 lanes to a block: the bound lets a lane keep its two rows of 21 likelihoods and the posterior's working set in registers -- with the
+// default bound of 1 024 the compiler capped it at 128 and spilled 254 of them to 1 KB of scratch a lane)
+__global__ __launch_bounds__(64) void somatic_indel_posterior_kernel(const PostArgs a)
 {
     const SkLibmTables lt = sk_libm_tables_default();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
