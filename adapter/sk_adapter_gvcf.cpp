@@ -17,7 +17,10 @@
 //     reference's code on a locus that holds, field for field, what the writer reads of the one process_pos_snp_digt would have built.
 //
 // Anything else (a variant or filtered-looking site, an alternate allele in the column, ploidy 1 or 0, reference N, an empty cleaned
-// column, a forced position, any buffered locus in the pipe, several samples, call regions) takes the reference's path as before.
+// column, a forced position, any buffered locus in the pipe, call regions) takes the reference's path as before.  With several samples a
+// position is routed when it is a plain site of EVERY sample's window (the locus then has no alternate allele: getSiteAltAlleles ranks
+// the samples' columns one by one and adds the bases of their most likely genotypes); the writer's own loop joins it to each sample's
+// block.  Whole blocks (below) are installed in single-sample runs only.
 // $STRELKA_AMD_GVCF_FAST=0 switches the site off.
 #include "sk_adapter_access.hh"
 
@@ -34,6 +37,7 @@
 #include <iostream>
 #include <limits>
 #include <memory>
+#include <vector>
 
 namespace sk_adapter
 {
@@ -78,9 +82,11 @@ namespace
 struct GvcfFast
 {
     bool decided = false, enabled = false;
-    bool isCleanSkipped = false; ///< process_pos_sample_stats took the counts of cleanSkippedPos from the window and did not clean its pileup
+    unsigned sampleCount = 1;
+    uint32_t cleanSkipped = 0; ///< bit s: process_pos_sample_stats took sample s's counts of cleanSkippedPos from the window and did not clean its pileup
     pos_t cleanSkippedPos = 0;
     std::unique_ptr<GermlineDiploidSiteLocusInfo> scratch;
+    std::vector<const SiteChunk*> sampleChunks; ///< (scratch of gvcf_plain_site)
     bool isBlocks = false; ///< the window brings the block that would start at every plain site (sk_gvcf_run): whole blocks are installed
     pos_t blockTo = std::numeric_limits<pos_t>::min(); ///< positions below are members of the block installed last (their process_pos_snp has nothing left to do)
     unsigned long plainSites = 0, referenceSites = 0, declinedByState = 0;
@@ -117,29 +123,34 @@ bool decide(starling_pos_processor& pp)
         const char* b(std::getenv("STRELKA_AMD_GVCF_BLOCKS"));
         g.isBlocks = ! (b && *b == '0');
     }
-    g.enabled = isOn && s.pileup.enabled && s.pileup.isGenotyping && (Access::sampleCount(pp) == 1) && opt.is_bsnp_diploid() &&
+    g.sampleCount = Access::sampleCount(pp);
+    g.enabled = isOn && s.pileup.enabled && s.pileup.isGenotyping && (g.sampleCount >= 1) && (g.sampleCount <= 32) && opt.is_bsnp_diploid() &&
                 opt.gvcf.is_gvcf_output() && (! opt.isUseCallRegions()) && (GvcfAccess::aggregator(pp) != nullptr);
+    if (g.sampleCount != 1) g.isBlocks = false;
     if (g.enabled)
     {
         // the one locus that stands for every plain site: what never changes is set here (updateSnvLocusWithSampleInfo :344-500 for
-        // a diploid sample whose most likely genotype is 0/0 under both priors and whose locus has no alternate allele)
-        g.scratch.reset(new GermlineDiploidSiteLocusInfo(GvcfAccess::dopt(pp).gvcf, 1));
-        LocusSampleInfo& sampleInfo(g.scratch->getSample(0));
-        sampleInfo.setPloidy(2);
-        sampleInfo.setActiveRegionId(-1);
-        sampleInfo.maxGenotypeIndex.setGenotypeFromAlleleIndices(0, 0);
-        sampleInfo.maxGenotypeIndexPolymorphic.setGenotypeFromAlleleIndices(0, 0);
-        sampleInfo.supportCounts.setAltCount(0);
+        // diploid samples whose most likely genotype is 0/0 under both priors and whose locus has no alternate allele)
+        g.scratch.reset(new GermlineDiploidSiteLocusInfo(GvcfAccess::dopt(pp).gvcf, g.sampleCount));
+        for (unsigned sampleIndex(0); sampleIndex < g.sampleCount; ++sampleIndex)
+        {
+            LocusSampleInfo& sampleInfo(g.scratch->getSample(sampleIndex));
+            sampleInfo.setPloidy(2);
+            sampleInfo.setActiveRegionId(-1);
+            sampleInfo.maxGenotypeIndex.setGenotypeFromAlleleIndices(0, 0);
+            sampleInfo.maxGenotypeIndexPolymorphic.setGenotypeFromAlleleIndices(0, 0);
+            sampleInfo.supportCounts.setAltCount(0);
+        }
     }
     return g.enabled;
 }
 
-/// the chunk of sample 0 that holds pos (chunks leave from the front as POST_ALIGN moves forward, as in site_diploid_genotype)
-const SiteChunk* chunkAt(const pos_t pos)
+/// the chunk of a sample that holds pos (chunks leave from the front as POST_ALIGN moves forward, as in site_diploid_genotype)
+const SiteChunk* chunkAt(const pos_t pos, const unsigned sampleIndex = 0)
 {
     State& s(state());
-    if (s.pileup.chunks.empty()) return nullptr;
-    std::deque<SiteChunk>& chunks(s.pileup.chunks[0]);
+    if (s.pileup.chunks.size() <= sampleIndex) return nullptr;
+    std::deque<SiteChunk>& chunks(s.pileup.chunks[sampleIndex]);
     while ((! chunks.empty()) && chunks.front().end <= pos) chunks.pop_front();
     if (chunks.empty() || chunks.front().begin > pos) return nullptr;
     return &chunks.front();
@@ -159,7 +170,7 @@ void gvcf_reset_region()
     // (a process may call several regions, on any chromosome: nothing of the last one's installed block carries over)
     GvcfFast& g(gf());
     g.blockTo = std::numeric_limits<pos_t>::min();
-    g.isCleanSkipped = false;
+    g.cleanSkipped = 0;
 }
 
 void gvcf_configure_stream(starling_pos_processor_base& pp, const unsigned sampleIndex, sk_pileup_stream* stream)
@@ -194,18 +205,19 @@ void gvcf_configure_stream(starling_pos_processor_base& pp, const unsigned sampl
 bool germline_sample_stats_counts(starling_pos_processor_base& pp, const pos_t pos, const unsigned sampleIndex, unsigned& used, unsigned& unused)
 {
     GvcfFast& g(gf());
-    g.isCleanSkipped = false;
-    if (! (g.decided && g.enabled) || sampleIndex != 0) return false;
-    const SiteChunk* c(chunkAt(pos));
+    if (g.cleanSkippedPos != pos) g.cleanSkipped = 0; // (the samples of one position are asked one after the other)
+    g.cleanSkippedPos = pos;
+    g.cleanSkipped &= ~(1u << (sampleIndex & 31u));
+    if (! (g.decided && g.enabled) || sampleIndex >= g.sampleCount) return false;
+    const SiteChunk* c(chunkAt(pos, sampleIndex));
     if (c == nullptr) return false;
-    const snp_pos_info& pi(pp.sample(0).basecallBuffer.get_pos(pos));
+    const snp_pos_info& pi(pp.sample(sampleIndex).basecallBuffer.get_pos(pos));
     const size_t k(static_cast<size_t>(pos - c->begin));
     if (! isPlainInWindow(*c, k, pi)) return false;
     // CleanedPileup::usedBasecallCount / unusedBasecallCount of CleanPileupFilter(pi, false) (PileupCleaner.hh:48-58)
     used = c->cleanCount[k];
     unused = static_cast<unsigned>(pi.calls.size()) - used;
-    g.isCleanSkipped = true;
-    g.cleanSkippedPos = pos;
+    g.cleanSkipped |= (1u << sampleIndex);
     return true;
 }
 
@@ -213,16 +225,26 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
 {
     if (! decide(pp)) return false;
     GvcfFast& g(gf());
-    const bool isCleanSkipped(g.isCleanSkipped && g.cleanSkippedPos == pos);
-    g.isCleanSkipped = false;
+    const unsigned sampleCount(g.sampleCount);
+    const uint32_t allSamples((sampleCount >= 32) ? 0xffffffffu : ((1u << sampleCount) - 1u));
+    const uint32_t cleanSkipped((g.cleanSkippedPos == pos) ? g.cleanSkipped : 0u);
+    const bool isCleanSkipped(cleanSkipped == allSamples); // (every sample's counts came from its window: plain in all of them)
+    g.cleanSkipped = 0;
     starling_pos_processor_base& base(pp);
     starling_pos_processor_base::sample_info& sif(base.sample(0));
     const snp_pos_info& pi(sif.basecallBuffer.get_pos(pos));
 
     auto referencePath = [&]() -> bool
     {
-        // the reference's process_pos_snp takes it from here; its cleaned pileup is made now if process_pos_sample_stats left it out
-        if (isCleanSkipped) Access::pileupCleaner(base).CleanPileupFilter(pi, false, sif.cleanedPileup);
+        // the reference's process_pos_snp takes it from here; a sample's cleaned pileup is made now if process_pos_sample_stats left it out
+        for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
+        {
+            if ((cleanSkipped >> sampleIndex) & 1u)
+            {
+                starling_pos_processor_base::sample_info& ssif(base.sample(sampleIndex));
+                Access::pileupCleaner(base).CleanPileupFilter(ssif.basecallBuffer.get_pos(pos), false, ssif.cleanedPileup);
+            }
+        }
         if (! pi.calls.empty()) g.referenceSites++;
         return false;
     };
@@ -232,16 +254,32 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
         if (! isCleanSkipped) throw blt_exception("strelka_amd adapter: a position of an installed gVCF block is no longer a plain site of the window");
         return true;
     }
-    if (! isCleanSkipped) return referencePath(); // (not plain in the window, or the counts did not come from it)
+    if (! isCleanSkipped) return referencePath(); // (not plain in every window, or the counts did not come from them)
 
     const SiteChunk* c(chunkAt(pos));
     if (c == nullptr) return referencePath();
     const size_t k(static_cast<size_t>(pos - c->begin));
     if (! isPlainInWindow(*c, k, pi)) return referencePath();
+    std::vector<const SiteChunk*>& sampleChunks(g.sampleChunks);
+    sampleChunks.assign(sampleCount, c);
+    for (unsigned sampleIndex(1); sampleIndex < sampleCount; ++sampleIndex)
+    {
+        const SiteChunk* sc(chunkAt(pos, sampleIndex));
+        if (sc == nullptr || (! isPlainInWindow(*sc, static_cast<size_t>(pos - sc->begin), base.sample(sampleIndex).basecallBuffer.get_pos(pos))))
+        {
+            return referencePath();
+        }
+        sampleChunks[sampleIndex] = sc;
+    }
 
     // ---- the state at call time (process_pos_snp_digt "prep step 2" :637-651; is_forced_output_pos :152)
-    const int regionPloidy(static_cast<int>(Access::ploidy(base, pos, 0)));
-    if (regionPloidy != 2 || pi.spanningIndelPloidyModification != 0 || Access::isForcedOutputPos(base, pos))
+    bool isStateTheWindows(! Access::isForcedOutputPos(base, pos));
+    for (unsigned sampleIndex(0); isStateTheWindows && sampleIndex < sampleCount; ++sampleIndex)
+    {
+        isStateTheWindows = (static_cast<int>(Access::ploidy(base, pos, sampleIndex)) == 2) &&
+                            (base.sample(sampleIndex).basecallBuffer.get_pos(pos).spanningIndelPloidyModification == 0);
+    }
+    if (! isStateTheWindows)
     {
         g.declinedByState++;
         return referencePath();
@@ -272,33 +310,38 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
     }
 
     // ---- the locus process_pos_snp_digt would have built, as far as anything downstream reads it
-    const sk_digt_call& dgt(c->calls[k]);
-    const sk_gvcf_site_summary& sm(c->summary[k]);
     GermlineDiploidSiteLocusInfo& locus(*g.scratch);
     locus.pos = pos;
     locus.refBaseIndex = refBaseIndex;
     locus.isForcedOutput = false;
     locus.filters.clear();
-    LocusSampleInfo& sampleInfo(locus.getSample(0));
-    sampleInfo.filters.clear();
-    sampleInfo.genotypeQuality = dgt.genome.max_gt_qphred;           // :388
-    sampleInfo.genotypeQualityPolymorphic = dgt.poly.max_gt_qphred;   // :391
-    sampleInfo.setGqx();                                              // :394
-    sampleInfo.supportCounts.setAltCount(0);                          // :452 (clears the counts)
-    sampleInfo.supportCounts.getCounts(true).incrementAlleleCount(0, sm.ref_fwd);  // :455-465
-    sampleInfo.supportCounts.getCounts(false).incrementAlleleCount(0, sm.ref_rev);
+    for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
     {
+        const SiteChunk& sc(*sampleChunks[sampleIndex]);
+        const size_t sk(static_cast<size_t>(pos - sc.begin));
+        const sk_digt_call& sdgt(sc.calls[sk]);
+        const sk_gvcf_site_summary& ssm(sc.summary[sk]);
+        const snp_pos_info& spi(base.sample(sampleIndex).basecallBuffer.get_pos(pos));
+        LocusSampleInfo& sampleInfo(locus.getSample(sampleIndex));
+        sampleInfo.filters.clear();
+        sampleInfo.genotypeQuality = sdgt.genome.max_gt_qphred;           // :388
+        sampleInfo.genotypeQualityPolymorphic = sdgt.poly.max_gt_qphred;   // :391
+        sampleInfo.setGqx();                                               // :394
+        sampleInfo.supportCounts.setAltCount(0);                           // :452 (clears the counts)
+        sampleInfo.supportCounts.getCounts(true).incrementAlleleCount(0, ssm.ref_fwd);  // :455-465
+        sampleInfo.supportCounts.getCounts(false).incrementAlleleCount(0, ssm.ref_rev);
         // updateSiteSampleInfo :200-250 (the EVS metrics belong to variant or forced sites only)
         GermlineSiteSampleInfo siteSampleInfo;
         siteSampleInfo.isOverlappingHomAltDeletion = false;
-        siteSampleInfo.spanningDeletionReadCount = pi.spanningDeletionReadCount;
-        siteSampleInfo.usedBasecallCount = c->cleanCount[k];
-        siteSampleInfo.unusedBasecallCount = static_cast<unsigned>(pi.calls.size()) - c->cleanCount[k];
-        siteSampleInfo.mapqTracker = pi.mapqTracker;
+        siteSampleInfo.spanningDeletionReadCount = spi.spanningDeletionReadCount;
+        siteSampleInfo.usedBasecallCount = sc.cleanCount[sk];
+        siteSampleInfo.unusedBasecallCount = static_cast<unsigned>(spi.calls.size()) - sc.cleanCount[sk];
+        siteSampleInfo.mapqTracker = spi.mapqTracker;
         const double maxBias(GvcfAccess::opt(pp).maxAbsSampleVariantStrandBias);
-        siteSampleInfo.strandBias = std::min(maxBias, std::max(-maxBias, dgt.strand_bias));
-        locus.setSiteSampleInfo(0, siteSampleInfo);
+        siteSampleInfo.strandBias = std::min(maxBias, std::max(-maxBias, sdgt.strand_bias));
+        locus.setSiteSampleInfo(sampleIndex, siteSampleInfo);
     }
+    LocusSampleInfo& sampleInfo(locus.getSample(0)); // (the whole-block step below: single-sample runs)
     // variant_prefilter_stage::process (variant_prefilter_stage.cpp:52-71): no ploidy conflict; the depth filter; the site's filters
     const ScoringModelManager& models(GvcfAccess::models(agg));
     models.applyDepthFilter(locus);

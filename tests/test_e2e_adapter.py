@@ -474,6 +474,37 @@ def test_multi_sample_wide_allele_groups_gpu(tmp_path):
     _multi_sample_wide_groups("amd", tmp_path)
 
 
+# ---- site 10 with several samples: a position that is a plain site of EVERY sample's window goes from the windows into each sample's
+# open block (the writer's own loop over the samples); the variants VCF and every sample's gVCF byte for byte
+def _two_sample_gvcf(variant, tmp_path):
+    d, length = SYNTH_SETS["short_reads"]
+    bams = [os.path.join(d, "germline_S1.bam"), os.path.join(d, "germline_S2.bam")]
+    outs, err = {}, None
+    for v in ("ref", variant):
+        o = str(tmp_path / v) + "/"
+        os.makedirs(o, exist_ok=True)
+        p = E.run(E.germline_argv("starling2_" + v, o, bams, region="chrS:1-%d" % length, ref=os.path.join(d, "synth.fa")),
+                  env={"STRELKA_AMD_VERBOSE": "1"} if v != "ref" else None)
+        outs[v] = {f: E.vcf_body(o + f, keep_header=True) for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf")}
+        if v != "ref":
+            err = p.stderr.decode()
+    for f in outs["ref"]:
+        assert len(outs["ref"][f]) > 100 and outs[variant][f] == outs["ref"][f], f
+    g = _gvcf_counters(err)
+    assert g["gvcf_plain_sites"] > 0.9 * length and g["gvcf_reference_sites"] < 0.05 * length and g["gvcf_blocks_installed"] == 0, g
+
+
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
+def test_two_sample_gvcf_sites_come_from_the_streams_cpu_double(tmp_path):
+    _two_sample_gvcf("dbl", tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_amd") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
+def test_two_sample_gvcf_sites_come_from_the_streams_gpu(tmp_path):
+    _two_sample_gvcf("amd", tmp_path)
+
+
 # ---- reads longer than the device pileup takes: refused when they arrive, with the way out in the message
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
 def test_reads_over_the_pileup_limit_are_refused_with_the_way_out(tmp_path):

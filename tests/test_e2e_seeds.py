@@ -60,3 +60,29 @@ def test_seeded_tumour_normal_pairs_identical_over_the_cpu_double():
 @pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_amd", "samtools"), reason="oracle/_ref binaries not built")
 def test_seeded_tumour_normal_pairs_identical_gpu():
     _run_somatic((8, 14, 16), "amd")
+
+
+def _run_multi(seeds, variant):
+    import e2e_seeds
+    md = tempfile.mkdtemp(prefix="sk_models_")
+    subprocess.run([sys.executable, os.path.join(E.REPO, "tools", "make_dummy_germline_models.py"), md], check=True)
+    models = ("--snv-scoring-model-file", md + "/germlineSNVScoringModels.json", "--indel-scoring-model-file", md + "/germlineIndelScoringModels.json")
+    cwd = os.getcwd()
+    os.chdir(E.REPO)
+    try:
+        for seed in seeds:
+            ok, msg = e2e_seeds.one_multi(seed, variant, models)
+            assert ok, msg
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl", "samtools"), reason="oracle/_ref binaries not built")
+def test_seeded_two_sample_runs_identical_over_the_cpu_double():
+    _run_multi((4,), "dbl")  # (40x + 15x, two regions out of order, EVS on: the variants VCF and both samples' gVCFs)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd", "samtools"), reason="oracle/_ref binaries not built")
+def test_seeded_two_sample_runs_identical_gpu():
+    _run_multi((4, 9, 15), "amd")

@@ -3,7 +3,7 @@ GPU box pass variant=amd): depth, variant density, the way the run is cut into r
 be the reference's byte for byte.  The routed gVCF path (site 10: plain sites and whole blocks from the device's window) sees shallow and
 deep samples, regions that start inside blocks, regions called out of order.
 
-usage: python tools/fuzz/e2e_seeds.py [n_seeds=16] [first_seed=1] [variant=dbl] [workers=8] [somatic]"""
+usage: python tools/fuzz/e2e_seeds.py [n_seeds=16] [first_seed=1] [variant=dbl] [workers=8] [somatic|multi]"""
 import os
 import random
 import shutil
@@ -151,6 +151,56 @@ def one_somatic(seed, variant):
                                                      sum(1 for l in want["somatic.indels.vcf"] if l[0] != "#"))
 
 
+def one_multi(seed, variant, models):
+    """a joint germline run over two samples that share the reference and the germline variants (the pair generator's normal and tumour:
+    the second sample carries extra variants of its own at a clone's share of its reads), depths and region cuts from the seed: the
+    variants VCF and both samples' gVCFs"""
+    rng = random.Random(29000 + seed)
+    length = rng.choice([100000, 160000, 240000])
+    d1, d2 = rng.choice([(30.0, 30.0), (40.0, 15.0), (8.0, 50.0), (20.0, 70.0)])
+    snv_every, indel_every, som_every = rng.choice([150, 1000]), rng.choice([400, 3000]), rng.choice([500, 5000])
+    clone = rng.choice([0.3, 0.5, 0.9])
+    d = os.path.join(E.REPO, "oracle", "_ref", "synth", "fuzz_multi_%d" % seed)
+    if not os.path.exists(os.path.join(d, "chrom_depth.txt")):
+        os.makedirs(d, exist_ok=True)
+        for role, depth, name in (("normal", d1, "normal"), ("tumor", d2, "tumor")):
+            subprocess.run([sys.executable, "tools/make_wgs_bam.py", d, os.path.join(E.BIN_DIR, "samtools"), "--length", str(length), "--depth", str(depth),
+                            "--seed", str(seed), "--procs", "1", "--role", role, "--name", name, "--sample", name.upper(), "--snv-every", str(snv_every),
+                            "--indel-every", str(indel_every), "--somatic-every", str(som_every), "--clone-fraction", str(clone)],
+                           check=True, stdout=subprocess.DEVNULL)
+        with open(os.path.join(d, "chrom_depth.txt"), "w") as f:
+            f.write("chrW\t%.3f\n" % max(d1, d2))
+    cuts = sorted(rng.sample(range(1000, length - 1000), rng.choice([0, 1, 2])))
+    edges = [1] + cuts + [length + 1]
+    regions = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        gap = rng.choice([0, 0, 37, 1500])
+        if b - gap > a:
+            regions.append("chrW:%d-%d" % (a, b - 1 - gap))
+    if rng.random() < 0.3:
+        rng.shuffle(regions)
+    extra = list(models) if rng.random() < 0.7 else []
+    outputs = ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf")
+    out = {}
+    for binary in ("starling2_ref", "starling2_" + variant):
+        with tempfile.TemporaryDirectory() as o:
+            E.run(E.germline_wgs_argv(binary, o + "/", [os.path.join(d, "normal.bam"), os.path.join(d, "tumor.bam")], regions, os.path.join(d, "normal.fa"),
+                                      os.path.join(d, "chrom_depth.txt"), extra=extra), timeout=3600)
+            out[binary] = {f: E.vcf_body(os.path.join(o, f), keep_header=True) for f in outputs}
+    want, got = out["starling2_ref"], out["starling2_" + variant]
+    if not os.environ.get("SK_FUZZ_KEEP"):
+        shutil.rmtree(d, ignore_errors=True)
+    what = "two-sample seed %d: %d bp at %gx + %gx, snv/%d indel/%d second sample's own/%d at %g, regions %s%s" % (
+        seed, length, d1, d2, snv_every, indel_every, som_every, clone, ",".join(regions), " EVS" if extra else "")
+    for f in want:
+        if want[f] != got[f]:
+            k = next((i for i, (x, y) in enumerate(zip(want[f], got[f])) if x != y), min(len(want[f]), len(got[f])))
+            return False, "%s: %s differs at line %d\n  reference: %s\n  drop-in:   %s" % (
+                what, f, k + 1, want[f][k] if k < len(want[f]) else "<end>", got[f][k] if k < len(got[f]) else "<end>")
+    return True, "%s: identical (%d variant records, %d + %d gVCF lines)" % (
+        what, sum(1 for l in want["variants.vcf"] if l[0] != "#"), len(want["genome.S1.vcf"]), len(want["genome.S2.vcf"]))
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -160,9 +210,10 @@ def main():
     subprocess.run([sys.executable, "tools/make_dummy_germline_models.py", md], check=True)
     models = ("--snv-scoring-model-file", md + "/germlineSNVScoringModels.json", "--indel-scoring-model-file", md + "/germlineIndelScoringModels.json")
     bad = 0
-    somatic = len(sys.argv) > 5 and sys.argv[5] == "somatic"
+    mode = sys.argv[5] if len(sys.argv) > 5 else "germline"
+    fn = {"somatic": lambda s: one_somatic(s, variant), "multi": lambda s: one_multi(s, variant, models)}.get(mode, lambda s: one(s, variant, models))
     with ThreadPoolExecutor(workers) as ex:
-        for ok, msg in ex.map((lambda s: one_somatic(s, variant)) if somatic else (lambda s: one(s, variant, models)), range(first, first + n)):
+        for ok, msg in ex.map(fn, range(first, first + n)):
             print(msg, flush=True)
             bad += 0 if ok else 1
     print("%d of %d seeds identical" % (n - bad, n))
