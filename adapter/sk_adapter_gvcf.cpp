@@ -230,6 +230,12 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
     const uint32_t cleanSkipped((g.cleanSkippedPos == pos) ? g.cleanSkipped : 0u);
     const bool isCleanSkipped(cleanSkipped == allSamples); // (every sample's counts came from its window: plain in all of them)
     g.cleanSkipped = 0;
+    if (pos < g.blockTo)
+    {
+        // a member of the block installed at its first site: joined already (nine positions in ten end here)
+        if (! isCleanSkipped) throw blt_exception("strelka_amd adapter: a position of an installed gVCF block is no longer a plain site of the window");
+        return true;
+    }
     starling_pos_processor_base& base(pp);
     starling_pos_processor_base::sample_info& sif(base.sample(0));
     const snp_pos_info& pi(sif.basecallBuffer.get_pos(pos));
@@ -248,12 +254,6 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
         if (! pi.calls.empty()) g.referenceSites++;
         return false;
     };
-    if (pos < g.blockTo)
-    {
-        // a member of the block installed at its first site: joined already
-        if (! isCleanSkipped) throw blt_exception("strelka_amd adapter: a position of an installed gVCF block is no longer a plain site of the window");
-        return true;
-    }
     if (! isCleanSkipped) return referencePath(); // (not plain in every window, or the counts did not come from them)
 
     const SiteChunk* c(chunkAt(pos));

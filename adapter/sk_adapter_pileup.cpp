@@ -27,6 +27,9 @@
 #include "blt_util/seq_util.hh"
 #include "starling_common/starling_read_segment.hh"
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
@@ -144,6 +147,19 @@ void gatherWindow(starling_pos_processor_base& pp, const unsigned sampleIndex, c
             const uint8_t* packed(q - ((rseg.full_read_size() + 1) >> 1));
             uint8_t* dst(wb.code.data() + c0);
             unsigned i(0);
+#if defined(__SSE2__)
+            // sixteen packed bytes -> thirty-two codes per step (high nibble first): a read's 75 bytes are five steps instead of 75 look-ups
+            {
+                const __m128i low4(_mm_set1_epi8(0x0f));
+                for (; i + 32 <= readSize; i += 32)
+                {
+                    const __m128i v(_mm_loadu_si128(reinterpret_cast<const __m128i*>(packed + (i >> 1))));
+                    const __m128i hi(_mm_and_si128(_mm_srli_epi16(v, 4), low4)), lo(_mm_and_si128(v, low4));
+                    _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i), _mm_unpacklo_epi8(hi, lo));
+                    _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i + 16), _mm_unpackhi_epi8(hi, lo));
+                }
+            }
+#endif
             for (; i + 2 <= readSize; i += 2) std::memcpy(dst + i, &pairOf[packed[i >> 1]], 2);
             if (i < readSize) dst[i] = static_cast<uint8_t>(packed[i >> 1] >> 4);
         }
@@ -234,7 +250,7 @@ void assignWindow(starling_pos_processor_base::sample_info& sif, const sk_pileup
         const base_call* const t1(reinterpret_cast<const base_call*>(w.tier1_calls + w.tier1_off[i]));
         const base_call* const t2(reinterpret_cast<const base_call*>(w.tier2_calls + w.tier2_off[i]));
         pi.calls.assign(t1, t1 + n1);
-        pi.tier2_calls.assign(t2, t2 + n2);
+        if (n2 != 0 || (! pi.tier2_calls.empty())) pi.tier2_calls.assign(t2, t2 + n2); // (a germline column has next to no tier2 calls: no call for nothing)
         pi.spanningDeletionReadCount = sd;
         pi.submappedReadCount = sm;
         pi.mapqTracker.count = mq;
