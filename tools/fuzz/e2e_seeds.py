@@ -22,12 +22,19 @@ def one(seed, variant, models):
     depth = rng.choice([4.0, 12.0, 25.0, 40.0, 70.0])
     snv_every = rng.choice([150, 1000, 4000])
     indel_every = rng.choice([400, 3000, 20000])
+    read_length = 150
+    if os.environ.get("SK_FUZZ_HARD"):  # other read lengths, indels every hundred-odd bases, deeper samples
+        hard = random.Random(39000 + seed)
+        read_length = hard.choice([100, 150, 250])
+        indel_every = hard.choice([120, 250, indel_every])
+        depth = hard.choice([depth, 100.0])
+        length = min(length, 160000)
     d = os.path.join(E.REPO, "oracle", "_ref", "synth", "fuzz_%d" % seed)
     if not os.path.exists(os.path.join(d, "chrom_depth.txt")):
         os.makedirs(d, exist_ok=True)
         subprocess.run([sys.executable, "tools/make_wgs_bam.py", d, os.path.join(E.BIN_DIR, "samtools"), "--length", str(length),
                         "--depth", str(depth), "--seed", str(seed), "--snv-every", str(snv_every), "--indel-every", str(indel_every),
-                        "--procs", "1"], check=True, stdout=subprocess.DEVNULL)
+                        "--read-length", str(read_length), "--procs", "1"], check=True, stdout=subprocess.DEVNULL)
         with open(os.path.join(d, "chrom_depth.txt"), "w") as f:
             f.write("chrW\t%.3f\n" % depth)
     # the process's regions: one to four pieces of the sample, sometimes with a gap, sometimes out of order
@@ -88,7 +95,7 @@ def one(seed, variant, models):
     want, got = out["starling2_ref"], out["starling2_" + variant]
     if not os.environ.get("SK_FUZZ_KEEP"):
         shutil.rmtree(d, ignore_errors=True)  # (a sample is 5-20 MB; oracle/_ref travels to the GPU box)
-    what = "seed %d: %d bp at %gx, snv/%d indel/%d, regions %s%s" % (seed, length, depth, snv_every, indel_every, ",".join(regions),
+    what = "seed %d: %d bp at %gx, %d bp reads, snv/%d indel/%d, regions %s%s" % (seed, length, depth, read_length, snv_every, indel_every, ",".join(regions),
                                                                      "".join(" " + x for x in extra if x.startswith("--")))
     for f in want:
         if want[f] != got[f]:
