@@ -4,6 +4,9 @@
 #include "blt_util/log.hh"
 #include "starling_common/starling_read.hh"
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cstdlib>
 #include <iostream>
@@ -110,6 +113,34 @@ EarlyInit g_earlyInit;
 
 }
 
+/// The driver runs eight compute processes side by side on a device and time-slices the processes beyond that ("How
+/// many caller processes per GPU"): a call into the C-ABI then waits for its process's slice, and the run is slower than with eight.
+/// Every caller process of a device holds one of eight advisory file locks for its lifetime (released by the kernel when it exits,
+/// however it exits); the ninth finds none free and says so once.  Nothing else depends on the locks.  $STRELKA_AMD_PROCESS_SLOTS: the
+/// number of slots (0: no check), $STRELKA_AMD_SLOT_DIR: where the lock files live (default /tmp).
+void note_process_slot()
+{
+    const unsigned slots(env_unsigned("STRELKA_AMD_PROCESS_SLOTS", 8));
+    if (slots == 0) return;
+    const char* dir(std::getenv("STRELKA_AMD_SLOT_DIR"));
+    const int deviceCount(std::max(1, sk_device_count()));
+    const int device(static_cast<int>(env_unsigned("STRELKA_AMD_DEVICE", 0)) % deviceCount);
+    bool isAnyOpened(false);
+    for (unsigned i(0); i < slots; ++i)
+    {
+        const std::string path(std::string((dir && *dir) ? dir : "/tmp") + "/strelka_amd_device" + std::to_string(device) + "_slot" + std::to_string(i) + ".lock");
+        const int fd(::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666));
+        if (fd < 0) continue;
+        isAnyOpened = true;
+        if (::flock(fd, LOCK_EX | LOCK_NB) == 0) return; // (held until the process exits: the descriptor is left open on purpose)
+        ::close(fd);
+    }
+    if (! isAnyOpened) return; // (no place for lock files: no check)
+    log_os << "WARNING: strelka_amd: more than " << slots << " caller processes on device " << device
+           << ": the driver runs eight side by side and time-slices the rest -- expect every process of this device to slow down "
+              "(INTEGRATION.md, \"How many caller processes per GPU\")\n";
+}
+
 void init()
 {
     static bool done(false);
@@ -131,6 +162,7 @@ void init()
     {
         log_os << "WARNING: strelka_amd runs with the device math library; outputs may differ from the reference in the last digit\n";
     }
+    note_process_slot();
     done = true;
 }
 

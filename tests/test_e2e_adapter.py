@@ -505,6 +505,32 @@ def test_two_sample_gvcf_sites_come_from_the_streams_gpu(tmp_path):
     _two_sample_gvcf("amd", tmp_path)
 
 
+# ---- the ninth caller process of a device says so (the driver runs eight compute processes side by side and time-slices the rest:
+# INTEGRATION.md "How many caller processes per GPU"): every process holds one of eight advisory file locks for its lifetime
+@pytest.mark.skipif(not E.have("starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_a_ninth_caller_process_on_a_device_is_told(tmp_path):
+    import fcntl
+    slot_dir = tmp_path / "slots"
+    slot_dir.mkdir()
+    env = {"STRELKA_AMD_SLOT_DIR": str(slot_dir)}
+
+    def run():
+        o = str(tmp_path / "o") + "/"
+        os.makedirs(o, exist_ok=True)
+        return E.run(E.germline_argv("starling2_dbl", o, [E.demo("NA12891_demo20.bam")]), env=env).stderr.decode()
+    assert "caller processes on device" not in run()
+    held = []
+    for i in range(8):  # (eight other processes' slots)
+        f = open(str(slot_dir / ("strelka_amd_device0_slot%d.lock" % i)), "a+")
+        fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
+        held.append(f)
+    assert "more than 8 caller processes on device 0" in run()
+    held[3].close()  # (one of them exits)
+    assert "caller processes on device" not in run()
+    for f in held:
+        f.close()
+
+
 # ---- reads longer than the device pileup takes: refused when they arrive, with the way out in the message
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
 def test_reads_over_the_pileup_limit_are_refused_with_the_way_out(tmp_path):
