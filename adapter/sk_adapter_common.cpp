@@ -102,6 +102,9 @@ struct EarlyInit
     {
         if (env_unsigned("STRELKA_AMD_EARLY_INIT", 1) == 0) return;
         isStarted = true;
+        // the library exports this variable (if unset) before its first runtime call; done HERE, on the main thread and before the worker
+        // exists, so that no setenv can run beside another thread's getenv (static constructors, option parsing, htslib)
+        (void)::setenv("GPU_MAX_HW_QUEUES", "1", 0);
         worker = std::thread([this]() { outcome = run_sk_init(); });
     }
     ~EarlyInit()

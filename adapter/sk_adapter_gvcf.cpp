@@ -333,7 +333,9 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
         // updateSiteSampleInfo :200-250 (the EVS metrics belong to variant or forced sites only)
         GermlineSiteSampleInfo siteSampleInfo;
         siteSampleInfo.isOverlappingHomAltDeletion = false;
-        siteSampleInfo.spanningDeletionReadCount = spi.spanningDeletionReadCount;
+        // (updateSiteSampleInfo reads the count from the CLEANED pileup, and CleanPileupFilter does not copy it: it is always 0 there.
+        //  Nothing of the diploid writer reads the field; the locus holds what the reference's would.)
+        siteSampleInfo.spanningDeletionReadCount = 0;
         siteSampleInfo.usedBasecallCount = sc.cleanCount[sk];
         siteSampleInfo.unusedBasecallCount = static_cast<unsigned>(spi.calls.size()) - sc.cleanCount[sk];
         siteSampleInfo.mapqTracker = spi.mapqTracker;

@@ -64,6 +64,26 @@ int sk_sync_mode(void);
  *  the reference's; 0: the device library's pow/log stand in (agreement to 1e-5 relative). */
 int sk_libm_restated(void);
 
+/* ---- many caller processes per GPU: the broker ------------------------------------------------------------------------------
+ * SURVEY.md 8(b) "Threading": the ABI is called by one thread per process and by MANY processes per GPU -- the workflow starts one
+ * caller process per core (PY/strelkaSharedOptions.py:153-161, PY/strelkaGermlineWorkflow.py:81-150).  The device runs eight
+ * processes' compute work side by side; a ninth is time-sliced.  With $STRELKA_AMD_BROKER=1 in a caller process's environment this
+ * library creates no GPU context there: every allocation, copy, launch and wait behind the SAME entry points is carried (records in a
+ * shared-memory ring; page-locked buffers mapped at one address in both processes) to `sk_broker`, the one process per device that
+ * holds its context, started on demand by the first client and gone 20 s after the last
+ * (strelka_amd/csrc/sk_rt.h; $STRELKA_AMD_BROKER_IDLE_S, _QUEUES, _LOG, _SOCKET, _NO_SPAWN).  Host stages (a realignment job's gate and
+ * packing, a pileup stream's carry bookkeeping) stay in the caller.  Not available to a client: the `*_dev` entry points on a stream
+ * of the caller's, and the event-timed diagnostics. */
+/** 1 when this process is a broker client ($STRELKA_AMD_BROKER). */
+int sk_broker_client(void);
+/** The server's main loop (what `sk_broker --device D [--socket NAME] [--idle-exit S]` runs): serves `device` on the abstract unix
+ *  socket `socket_name` (NULL / "": the default name -- user, library build, device) until it has had no client for `idle_seconds`.
+ *  Returns 0 after an idle exit, 2 when the device is unusable, 3 when another broker already serves the name. */
+int sk_broker_serve(int device, const char* socket_name, int idle_seconds);
+/** Round trip of every kind of call a client makes (device memory, copies from / to pageable and page-locked memory, a launch, the
+ *  wait) over n 32-bit words; 0 when the results are right.  Works in a process with its own context too.  Needs sk_init. */
+int sk_broker_selftest(int n, uint32_t mul);
+
 /** The `*_dev` entry points only enqueue work and cannot validate device-resident input the way the host-buffer entry
  *  points do.  Where the reference would throw on such input (a basecall quality above 70, qscore_cache.cpp:53-75), the
  *  kernel raises a sticky device flag instead of returning a plausible number; this call synchronises the device, returns

@@ -12,9 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "strelka_amd")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libstrelka_amd.so")
+BROKER_PATH = os.path.join(LIB_DIR, "sk_broker")  # the per-GPU server of the broker mode (csrc/sk_rt.h), beside the library
 
 HIP_SOURCES = [
     "csrc/sk_context.hip",
+    "csrc/sk_rt.hip",
     "csrc/score_alignments.hip",
     "csrc/germline_site.hip",
     "csrc/germline_fused.hip",
@@ -76,13 +78,21 @@ def build_all(force=False, verbose=True):
         if force or _stale(obj, [src] + headers):
             lang = "hip" if s.endswith(".hip") else "c++"
             jobs.append([hipcc] + flags + ["-x", lang, "-c", src, "-o", obj])
-    if not jobs and not force and not _stale(LIB_PATH, objs):
-        return LIB_PATH
+    broker_src = os.path.join(PKG, "host", "sk_broker_main.cpp")
+
+    def link_broker():
+        if force or _stale(BROKER_PATH, [broker_src, LIB_PATH]):
+            run([hipcc, "-O2", "-std=c++17", broker_src, "-L" + LIB_DIR, "-lstrelka_amd", "-Wl,-rpath,$ORIGIN", "-lpthread", "-o", BROKER_PATH + ".tmp"])
+            os.replace(BROKER_PATH + ".tmp", BROKER_PATH)
 
     def run(cmd):
         if verbose:
             print("[strelka_amd.build]", " ".join(cmd[-4:]), file=sys.stderr)
         subprocess.run(cmd, check=True)
+    if not jobs and not force and not _stale(LIB_PATH, objs):
+        link_broker()
+        return LIB_PATH
+
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(run, jobs))
     for old in glob.glob(os.path.join(obj_dir, "*.o")):
@@ -90,6 +100,7 @@ def build_all(force=False, verbose=True):
             os.remove(old)
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"])
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    link_broker()
     return LIB_PATH
 
 

@@ -1270,11 +1270,11 @@ struct FeedBuffers
     int reserve(const int i, const size_t bytes)
     {
         if (bytes <= cap[i]) return 0;
-        if (p[i]) (void)hipFree(p[i]);
+        if (p[i]) (void)skrt::free_(p[i]);
         p[i] = nullptr;
         cap[i] = 0;
         const size_t want = bytes + bytes / 4 + 4096;
-        SK_HIP(hipMalloc(&p[i], want));
+        SK_HIP(skrt::malloc_(&p[i], want));
         cap[i] = want;
         return 0;
     }
@@ -1310,16 +1310,16 @@ int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, c
     bool wave = n_blocks <= 6144;
     if (const char* e = std::getenv("SK_INFLATE_KERNEL")) wave = (std::strcmp(e, "wave") == 0) ? true : (std::strncmp(e, "thread", 6) == 0) ? false : wave;
     if (wave) {
-        static bool attr_set = false;
+        bool& attr_set = sk_ctx().inflate_scalar_lds_allowed;
         if (!attr_set) {
-            SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bgzf_inflate_scalar_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            SK_HIP(skrt::funcSetAttribute(reinterpret_cast<const void*>(bgzf_inflate_scalar_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        int(sizeof(InflateScalarLds))));
             attr_set = true;
         }
-        hipLaunchKernelGGL(bgzf_inflate_scalar_kernel, dim3(n_blocks), dim3(64), sizeof(InflateScalarLds), st, a);
+        SK_LAUNCH(bgzf_inflate_scalar_kernel, dim3(n_blocks), dim3(64), sizeof(InflateScalarLds), st, a);
 #ifdef SK_IS_TIMING
-        if (std::getenv("SK_INFLATE_TIMING") && n_blocks <= 16384) {
-            SK_HIP(hipStreamSynchronize(st));
+        if (std::getenv("SK_INFLATE_TIMING") && n_blocks <= 16384 && !skrt::remote()) {
+            SK_HIP(skrt::streamSynchronize(st));
             std::vector<unsigned long long> d(size_t(n_blocks) * 8);
             SK_HIP(hipMemcpyFromSymbol(d.data(), HIP_SYMBOL(is_dbg), d.size() * 8));
             size_t worst = 0;
@@ -1337,10 +1337,10 @@ int sk_bgzf_inflate_dev(const uint8_t* dev_data, const int64_t* dev_block_off, c
         }
 #endif
     } else {
-        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
+        SK_LAUNCH(bgzf_inflate_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
+        SK_LAUNCH(bgzf_crc32_kernel, dim3((n_blocks + 63) / 64), dim3(64), 0, st, a);
     }
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -1354,16 +1354,16 @@ int sk_bgzf_inflate_prefixed(const uint8_t* data, const int64_t* block_off, cons
     if (n_blocks == 0 && prefix_len == 0) return 0;
     if ((n_blocks > 0 && (!data || !block_off || !out_off)) || !out) return sk_fail("sk_bgzf_inflate: null argument");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     if (n_blocks == 0) {
         // a slice that is only the carried record: `out` and the kept stream are the prefix (the header's contract: out receives
         // prefix_len bytes, then the inflated blocks, and sk_bam_decode_kept decodes from the kept stream)
         FeedBuffers& B0 = feed_bufs();
         if (B0.reserve(8, size_t(prefix_len) + 16)) return 1;
-        SK_HIP(hipMemcpyAsync(B0.p[8], prefix, size_t(prefix_len), hipMemcpyHostToDevice, st));
+        SK_HIP(skrt::memcpyAsync(B0.p[8], prefix, size_t(prefix_len), hipMemcpyHostToDevice, st));
         if (out != prefix) std::memcpy(out, prefix, size_t(prefix_len));
-        SK_HIP(hipStreamSynchronize(st));
+        SK_HIP(skrt::streamSynchronize(st));
         B0.kept_len = prefix_len;
         return 0;
     }
@@ -1375,18 +1375,18 @@ int sk_bgzf_inflate_prefixed(const uint8_t* data, const int64_t* block_off, cons
         return 1;
     std::vector<int64_t> rel(size_t(n_blocks) + 1);
     for (int i = 0; i <= n_blocks; ++i) rel[size_t(i)] = block_off[i] - block_off[0];
-    SK_HIP(hipMemcpyAsync(B.p[0], data + block_off[0], size_t(in_bytes), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(B.p[1], rel.data(), 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(B.p[2], out_off, 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
-    if (prefix_len > 0) SK_HIP(hipMemcpyAsync(B.p[8], prefix, size_t(prefix_len), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[0], data + block_off[0], size_t(in_bytes), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[1], rel.data(), 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[2], out_off, 8 * size_t(n_blocks + 1), hipMemcpyHostToDevice, st));
+    if (prefix_len > 0) SK_HIP(skrt::memcpyAsync(B.p[8], prefix, size_t(prefix_len), hipMemcpyHostToDevice, st));
     if (sk_bgzf_inflate_dev(static_cast<uint8_t*>(B.p[0]), static_cast<int64_t*>(B.p[1]), static_cast<int64_t*>(B.p[2]), n_blocks,
                             static_cast<uint8_t*>(B.p[8]) + prefix_len, static_cast<int32_t*>(B.p[4]), st))
         return 1;
     std::vector<int32_t> status(static_cast<size_t>(n_blocks));
     if (prefix_len > 0 && out != prefix) std::memcpy(out, prefix, size_t(prefix_len));
-    SK_HIP(hipMemcpyAsync(out + prefix_len, static_cast<uint8_t*>(B.p[8]) + prefix_len, size_t(out_bytes), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipMemcpyAsync(status.data(), B.p[4], 4 * size_t(n_blocks), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    SK_HIP(skrt::memcpyAsync(out + prefix_len, static_cast<uint8_t*>(B.p[8]) + prefix_len, size_t(out_bytes), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::memcpyAsync(status.data(), B.p[4], 4 * size_t(n_blocks), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::streamSynchronize(st));
     for (int i = 0; i < n_blocks; ++i)
         if (status[size_t(i)] != INF_OK) {
             static const char* const what[] = { "", "invalid block type", "invalid stored block", "invalid code", "invalid distance", "output exceeds ISIZE",
@@ -1425,8 +1425,8 @@ int sk_bam_decode_dev(const uint8_t* dev_stream, const int64_t* dev_rec_off, int
     a.read_code = dev_read_code;
     a.read_qual = dev_read_qual;
     a.path = dev_path;
-    hipLaunchKernelGGL(bam_decode_kernel, dim3((n_records + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
+    SK_LAUNCH(bam_decode_kernel, dim3((n_records + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -1452,7 +1452,7 @@ static int bam_decode_host(const uint8_t* stream, int64_t stream_len, const int6
             return sk_fail("sk_bam_decode: record does not fit its offsets");
     }
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     const int64_t n_bases = read_off[n_records], n_segs = path_off[n_records];
     FeedBuffers& B = feed_bufs();
@@ -1461,21 +1461,21 @@ static int bam_decode_host(const uint8_t* stream, int64_t stream_len, const int6
         B.reserve(5, 8 * size_t(n_records + 1)) || B.reserve(3, sizeof(sk_bam_record) * size_t(n_records)) || B.reserve(4, size_t(n_bases) + 16) ||
         B.reserve(6, size_t(n_bases) + 16) || B.reserve(7, sizeof(sk_path_seg) * size_t(n_segs) + 16))
         return 1;
-    if (!kept) SK_HIP(hipMemcpyAsync(B.p[0], stream, size_t(stream_len), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(B.p[1], rec_off, 8 * size_t(n_records), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(B.p[2], read_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(B.p[5], path_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
+    if (!kept) SK_HIP(skrt::memcpyAsync(B.p[0], stream, size_t(stream_len), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[1], rec_off, 8 * size_t(n_records), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[2], read_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[5], path_off, 8 * size_t(n_records + 1), hipMemcpyHostToDevice, st));
     if (sk_bam_decode_dev(static_cast<uint8_t*>(kept ? B.p[8] : B.p[0]), static_cast<int64_t*>(B.p[1]), n_records, static_cast<int64_t*>(B.p[2]),
                           static_cast<int64_t*>(B.p[5]), static_cast<sk_bam_record*>(B.p[3]), static_cast<uint8_t*>(B.p[4]),
                           static_cast<uint8_t*>(B.p[6]), static_cast<sk_path_seg*>(B.p[7]), st))
         return 1;
-    SK_HIP(hipMemcpyAsync(rec, B.p[3], sizeof(sk_bam_record) * size_t(n_records), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::memcpyAsync(rec, B.p[3], sizeof(sk_bam_record) * size_t(n_records), hipMemcpyDeviceToHost, st));
     if (n_bases) {
-        SK_HIP(hipMemcpyAsync(read_code, B.p[4], size_t(n_bases), hipMemcpyDeviceToHost, st));
-        SK_HIP(hipMemcpyAsync(read_qual, B.p[6], size_t(n_bases), hipMemcpyDeviceToHost, st));
+        SK_HIP(skrt::memcpyAsync(read_code, B.p[4], size_t(n_bases), hipMemcpyDeviceToHost, st));
+        SK_HIP(skrt::memcpyAsync(read_qual, B.p[6], size_t(n_bases), hipMemcpyDeviceToHost, st));
     }
-    if (n_segs) SK_HIP(hipMemcpyAsync(path, B.p[7], sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    if (n_segs) SK_HIP(skrt::memcpyAsync(path, B.p[7], sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::streamSynchronize(st));
     return 0;
 }
 
@@ -1512,8 +1512,8 @@ int sk_normalize_alignments_dev(const char* dev_ref_seq, int32_t ref_offset, int
     a.path = dev_path;
     a.pos = dev_pos;
     a.changed = dev_changed;
-    hipLaunchKernelGGL(normalize_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
+    SK_LAUNCH(normalize_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -1527,7 +1527,7 @@ int sk_normalize_alignments(const char* ref_seq, int32_t ref_offset, int32_t ref
     for (int32_t r = 0; r < n_reads; ++r)
         if (n_seg[r] < 0 || int64_t(n_seg[r]) > path_off[r + 1] - path_off[r]) return sk_fail("sk_normalize_alignments: n_seg beyond the read's path slots");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     const int64_t n_bases = read_off[n_reads], n_segs = path_off[n_reads];
     FeedBuffers& B = feed_bufs();
@@ -1535,22 +1535,22 @@ int sk_normalize_alignments(const char* ref_seq, int32_t ref_offset, int32_t ref
         B.reserve(4, 4 * size_t(n_reads)) || B.reserve(5, sizeof(sk_path_seg) * size_t(n_segs) + 16) || B.reserve(6, 4 * size_t(n_reads)) ||
         B.reserve(7, size_t(n_reads) + 16))
         return 1;
-    SK_HIP(hipMemcpyAsync(B.p[0], ref_seq, size_t(ref_len), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(B.p[1], read_off, 8 * size_t(n_reads + 1), hipMemcpyHostToDevice, st));
-    if (n_bases) SK_HIP(hipMemcpyAsync(B.p[2], read_code, size_t(n_bases), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(B.p[3], path_off, 8 * size_t(n_reads + 1), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(B.p[4], n_seg, 4 * size_t(n_reads), hipMemcpyHostToDevice, st));
-    if (n_segs) SK_HIP(hipMemcpyAsync(B.p[5], path, sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(B.p[6], pos, 4 * size_t(n_reads), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[0], ref_seq, size_t(ref_len), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[1], read_off, 8 * size_t(n_reads + 1), hipMemcpyHostToDevice, st));
+    if (n_bases) SK_HIP(skrt::memcpyAsync(B.p[2], read_code, size_t(n_bases), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[3], path_off, 8 * size_t(n_reads + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[4], n_seg, 4 * size_t(n_reads), hipMemcpyHostToDevice, st));
+    if (n_segs) SK_HIP(skrt::memcpyAsync(B.p[5], path, sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.p[6], pos, 4 * size_t(n_reads), hipMemcpyHostToDevice, st));
     if (sk_normalize_alignments_dev(static_cast<char*>(B.p[0]), ref_offset, ref_len, n_reads, static_cast<int64_t*>(B.p[1]), static_cast<uint8_t*>(B.p[2]),
                                     static_cast<int64_t*>(B.p[3]), static_cast<int32_t*>(B.p[4]), static_cast<sk_path_seg*>(B.p[5]),
                                     static_cast<int32_t*>(B.p[6]), static_cast<uint8_t*>(B.p[7]), st))
         return 1;
-    SK_HIP(hipMemcpyAsync(n_seg, B.p[4], 4 * size_t(n_reads), hipMemcpyDeviceToHost, st));
-    if (n_segs) SK_HIP(hipMemcpyAsync(path, B.p[5], sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipMemcpyAsync(pos, B.p[6], 4 * size_t(n_reads), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipMemcpyAsync(changed, B.p[7], size_t(n_reads), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    SK_HIP(skrt::memcpyAsync(n_seg, B.p[4], 4 * size_t(n_reads), hipMemcpyDeviceToHost, st));
+    if (n_segs) SK_HIP(skrt::memcpyAsync(path, B.p[5], sizeof(sk_path_seg) * size_t(n_segs), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::memcpyAsync(pos, B.p[6], 4 * size_t(n_reads), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::memcpyAsync(changed, B.p[7], size_t(n_reads), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::streamSynchronize(st));
     return 0;
 }
 

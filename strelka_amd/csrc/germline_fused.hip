@@ -961,17 +961,17 @@ int sk_site_digt_call_fused_dev(const sk_pileup_batch* b, const sk_germline_opti
     a.worklist = a.work_count + 4;
     a.want_de = want_de ? 1 : 0;
     derive(*opt, a.d);
-    SK_HIP(hipMemsetAsync(a.work_count, 0, sizeof(uint32_t), static_cast<hipStream_t>(hip_stream)));
+    SK_HIP(skrt::memsetAsync(a.work_count, 0, sizeof(uint32_t), static_cast<hipStream_t>(hip_stream)));
     // $SK_G3_VARIANT = 0 (A-B runs, tests): round 1's kernel; otherwise the second statement.  Same records from both.
     static const int env_variant = []() { const char* v = std::getenv("SK_G3_VARIANT"); return (v && *v) ? std::atoi(v) : G3_DEFAULT_VARIANT; }();
     const int variant = (g_g3_variant_override >= 0) ? g_g3_variant_override : env_variant;
     const hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const int n = b->n_loci;
-    if (variant == 0) hipLaunchKernelGGL(germline_site_fused_kernel, dim3((n + LOCI_PER_BLOCK - 1) / LOCI_PER_BLOCK), dim3(FUSED_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((germline_site_fused_v2_kernel<128>), dim3((n + 127) / 128), dim3(128), 0, st, a);
-    hipLaunchKernelGGL(germline_site_global_pass_kernel, dim3(std::min(2048, (b->n_loci + 63) / 64)), dim3(64), 0,
+    if (variant == 0) SK_LAUNCH(germline_site_fused_kernel, dim3((n + LOCI_PER_BLOCK - 1) / LOCI_PER_BLOCK), dim3(FUSED_THREADS), 0, st, a);
+    else SK_LAUNCH((germline_site_fused_v2_kernel<128>), dim3((n + 127) / 128), dim3(128), 0, st, a);
+    SK_LAUNCH(germline_site_global_pass_kernel, dim3(std::min(2048, (b->n_loci + 63) / 64)), dim3(64), 0,
                        static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -981,7 +981,7 @@ int sk_site_digt_call_fused(const sk_pileup_batch* hb, const sk_germline_options
     if (!hb || !opt || !out) return sk_fail("sk_site_digt_call_fused: null argument");
     if (hb->n_loci <= 0) return 0;
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     const int64_t tc = hb->call_off[hb->n_loci];
     for (int64_t i = 0; i < tc; ++i)
         if (SKC_BASE(hb->calls[i]) > 3) return sk_fail("sk_site_digt_call_fused: basecall with base_id > 3 in cleaned pileup");
@@ -995,9 +995,9 @@ int sk_site_digt_call_fused(const sk_pileup_batch* hb, const sk_germline_options
     float* dde = ar.take<float>(total);
     uint32_t* scratch = ar.take<uint32_t>(total + hb->n_loci + 4);
     if (sk_site_digt_call_fused_dev(&d, opt, dout, dde, out_de ? 1 : 0, scratch, total, ctx.stream)) return 1;
-    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_digt_call) * hb->n_loci, hipMemcpyDeviceToHost, ctx.stream));
-    if (out_de && total) SK_HIP(hipMemcpyAsync(out_de, dde, 4 * total, hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    SK_HIP(skrt::memcpyAsync(out, dout, sizeof(sk_digt_call) * hb->n_loci, hipMemcpyDeviceToHost, ctx.stream));
+    if (out_de && total) SK_HIP(skrt::memcpyAsync(out_de, dde, 4 * total, hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(skrt::streamSynchronize(ctx.stream));
     return 0;
 }
 

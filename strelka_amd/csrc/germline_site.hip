@@ -61,25 +61,25 @@ int upload_pileup(const sk_pileup_batch* hb, bool need_de, SkArena& ar, size_t e
     if (ar.reserve(need)) return 1;
     d = *hb;
     int64_t* off = ar.take<int64_t>(n + 1);
-    SK_HIP(hipMemcpyAsync(off, hb->call_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(off, hb->call_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
     d.call_off = off;
     uint16_t* calls = ar.take<uint16_t>(total_calls);
-    if (total_calls) SK_HIP(hipMemcpyAsync(calls, hb->calls, 2 * total_calls, hipMemcpyHostToDevice, st));
+    if (total_calls) SK_HIP(skrt::memcpyAsync(calls, hb->calls, 2 * total_calls, hipMemcpyHostToDevice, st));
     d.calls = calls;
     d.de = nullptr;
     if (need_de) {
         if (!hb->de) return sk_fail("pileup batch: de is required");
         float* de = ar.take<float>(total_calls);
-        if (total_calls) SK_HIP(hipMemcpyAsync(de, hb->de, 4 * total_calls, hipMemcpyHostToDevice, st));
+        if (total_calls) SK_HIP(skrt::memcpyAsync(de, hb->de, 4 * total_calls, hipMemcpyHostToDevice, st));
         d.de = de;
     }
     uint8_t* rb = ar.take<uint8_t>(n);
-    SK_HIP(hipMemcpyAsync(rb, hb->ref_base, n, hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(rb, hb->ref_base, n, hipMemcpyHostToDevice, st));
     d.ref_base = rb;
     d.ploidy = nullptr;
     if (hb->ploidy) {
         uint8_t* pl = ar.take<uint8_t>(n);
-        SK_HIP(hipMemcpyAsync(pl, hb->ploidy, n, hipMemcpyHostToDevice, st));
+        SK_HIP(skrt::memcpyAsync(pl, hb->ploidy, n, hipMemcpyHostToDevice, st));
         d.ploidy = pl;
     }
     return 0;
@@ -108,9 +108,9 @@ int sk_dependent_eprob_dev(const sk_pileup_batch* b, const sk_germline_options* 
     a.scratch = static_cast<uint32_t*>(dev_scratch);
     derive(*opt, a.d);
     const int threads = 64;
-    hipLaunchKernelGGL(dependent_eprob_kernel, dim3((b->n_loci + threads - 1) / threads), dim3(threads), 0,
+    SK_LAUNCH(dependent_eprob_kernel, dim3((b->n_loci + threads - 1) / threads), dim3(threads), 0,
                        static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -120,7 +120,7 @@ int sk_dependent_eprob(const sk_pileup_batch* hb, const sk_germline_options* opt
     if (!hb || !opt || !out_de) return sk_fail("sk_dependent_eprob: null argument");
     if (hb->n_loci <= 0) return 0;
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     for (int64_t i = 0, e = hb->call_off[hb->n_loci]; i < e; ++i)
         if (SKC_BASE(hb->calls[i]) > 3) return sk_fail("sk_dependent_eprob: basecall with base_id > 3 in cleaned pileup");
     SkArena ar;
@@ -131,8 +131,8 @@ int sk_dependent_eprob(const sk_pileup_batch* hb, const sk_germline_options* opt
     float* dde = ar.take<float>(total);
     uint32_t* scratch = ar.take<uint32_t>(total);
     if (sk_dependent_eprob_dev(&d, opt, dde, scratch, ctx.stream)) return 1;
-    if (total) SK_HIP(hipMemcpyAsync(out_de, dde, 4 * total, hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    if (total) SK_HIP(skrt::memcpyAsync(out_de, dde, 4 * total, hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(skrt::streamSynchronize(ctx.stream));
     return 0;
 }
 
@@ -149,9 +149,9 @@ int sk_site_digt_call_dev(const sk_pileup_batch* b, const sk_germline_options* o
     a.out = dev_out;
     derive(*opt, a.d);
     const int threads = 64;
-    hipLaunchKernelGGL(site_digt_call_kernel, dim3((b->n_loci + threads - 1) / threads), dim3(threads), 0,
+    SK_LAUNCH(site_digt_call_kernel, dim3((b->n_loci + threads - 1) / threads), dim3(threads), 0,
                        static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -161,7 +161,7 @@ int sk_site_digt_call(const sk_pileup_batch* hb, const sk_germline_options* opt,
     if (!hb || !opt || !out) return sk_fail("sk_site_digt_call: null argument");
     if (hb->n_loci <= 0) return 0;
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     for (int64_t i = 0, e = hb->call_off[hb->n_loci]; i < e; ++i)
         if (SKC_BASE(hb->calls[i]) > 3) return sk_fail("sk_site_digt_call: basecall with base_id > 3 in cleaned pileup");
     SkArena ar;
@@ -170,8 +170,8 @@ int sk_site_digt_call(const sk_pileup_batch* hb, const sk_germline_options* opt,
     if (upload_pileup(hb, true, ar, sk_align256(sizeof(sk_digt_call) * hb->n_loci) + 512, d, ctx.stream, total)) return 1;
     sk_digt_call* dout = ar.take<sk_digt_call>(hb->n_loci);
     if (sk_site_digt_call_dev(&d, opt, dout, ctx.stream)) return 1;
-    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_digt_call) * hb->n_loci, hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    SK_HIP(skrt::memcpyAsync(out, dout, sizeof(sk_digt_call) * hb->n_loci, hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(skrt::streamSynchronize(ctx.stream));
     return 0;
 }
 

@@ -307,9 +307,9 @@ void sk_align_scores_default(sk_align_scores* s)
 // (the adapter calls once per haplotype: the driver call every time was a tenth of the call)
 static int ga_allow_lds(const size_t lds)
 {
-    static size_t allowed = 0;
+    size_t& allowed = sk_ctx().global_align_lds_allowed; // (of the context: the attribute belongs to the device sk_init chose)
     if (lds > allowed) {
-        SK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(global_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        SK_HIP(skrt::funcSetAttribute(reinterpret_cast<const void*>(global_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         allowed = lds;
     }
     return 0;
@@ -340,7 +340,7 @@ int sk_global_align(const sk_global_align_batch* hb, const sk_align_scores* sc, 
     const size_t lds = size_t(WIN) * WAVE + size_t((RW + 3) & ~3) + 4 * size_t(maxQ + 1) + 2 * 12 * size_t(RW) + 16;
 
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     // one block in, one block out, moved by launches (SkStage, sk_common.h): the adapter calls this once per haplotype
     SkStage sg;
     const size_t in_bytes = 3 * 8 * (size_t(n) + 1) + size_t(nq) + size_t(nr);
@@ -367,7 +367,7 @@ int sk_global_align(const sk_global_align_batch* hb, const sk_align_scores* sc, 
     a.max_query = maxQ;
     if (ga_allow_lds(lds)) return 1;
     if (sg.upload(st)) return 1;
-    hipLaunchKernelGGL(global_align_kernel, dim3(n), dim3(WAVE), lds, st, a);
+    SK_LAUNCH(global_align_kernel, dim3(n), dim3(WAVE), lds, st, a);
     if (sg.download_and_wait(st)) return 1;
     sg.fetch(out_score, a.out_score, size_t(n));
     sg.fetch(out_begin_pos, a.out_begin, size_t(n));
@@ -420,8 +420,8 @@ int sk_global_align_dev(const sk_global_align_batch* db, int64_t total_query_len
     const int RW = max_ref_len + 1;
     const size_t lds = size_t(WIN) * WAVE + size_t((RW + 3) & ~3) + 4 * size_t(max_query_len + 1) + 2 * 12 * size_t(RW) + 16;
     if (ga_allow_lds(lds)) return 1;
-    hipLaunchKernelGGL(global_align_kernel, dim3(db->n), dim3(WAVE), lds, st, a);
-    SK_HIP(hipGetLastError());
+    SK_LAUNCH(global_align_kernel, dim3(db->n), dim3(WAVE), lds, st, a);
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 

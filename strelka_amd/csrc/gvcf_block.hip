@@ -87,10 +87,10 @@ struct GvcfBuffers
     int reserve(const int i, const size_t bytes)
     {
         if (bytes <= cap[i]) return 0;
-        if (p[i]) (void)hipFree(p[i]);
+        if (p[i]) (void)skrt::free_(p[i]);
         p[i] = nullptr;
         cap[i] = 0;
-        SK_HIP(hipMalloc(&p[i], bytes + bytes / 4 + 256));
+        SK_HIP(skrt::malloc_(&p[i], bytes + bytes / 4 + 256));
         cap[i] = bytes + bytes / 4 + 256;
         return 0;
     }
@@ -111,9 +111,9 @@ int sk_gvcf_site_summaries_dev(const sk_pileup_batch* dev_batch, const sk_digt_c
     if (!dev_batch || dev_batch->n_loci < 0) return sk_fail("sk_gvcf_site_summaries_dev: bad batch");
     if (dev_batch->n_loci == 0) return 0;
     if (!dev_genotypes || !dev_out) return sk_fail("sk_gvcf_site_summaries_dev: null argument");
-    hipLaunchKernelGGL(gvcf_site_summary_kernel, dim3((dev_batch->n_loci + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), *dev_batch, dev_genotypes,
+    SK_LAUNCH(gvcf_site_summary_kernel, dim3((dev_batch->n_loci + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), *dev_batch, dev_genotypes,
                        dev_out);
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -133,14 +133,14 @@ int sk_gvcf_plain_runs_dev(const sk_gvcf_site_summary* dev_summary, const int64_
     a.n = n;
     a.pod = static_cast<skgvcf::SitePod*>(dev_pod_scratch);
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipLaunchKernelGGL(gvcf_site_pod_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    SK_LAUNCH(gvcf_site_pod_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a);
     // (the scratch holds the pods and, behind them, the tiles: 16 bytes per site + 32 per 32 sites)
     skgvcf::SiteTile* tiles = reinterpret_cast<skgvcf::SiteTile*>(static_cast<char*>(dev_pod_scratch) + ((size_t(n) * sizeof(skgvcf::SitePod) + 255) & ~size_t(255)));
     const int n_tiles = (n + skgvcf::TILE_SITES - 1) / skgvcf::TILE_SITES;
-    hipLaunchKernelGGL(gvcf_site_tile_kernel, dim3((n_tiles + 63) / 64), dim3(64), 0, st, a.pod, n, tiles);
-    hipLaunchKernelGGL(gvcf_plain_run_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a.pod, tiles, n, static_cast<double>(opt->block_percent_tol) / 100.,
+    SK_LAUNCH(gvcf_site_tile_kernel, dim3((n_tiles + 63) / 64), dim3(64), 0, st, a.pod, n, tiles);
+    SK_LAUNCH(gvcf_plain_run_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a.pod, tiles, n, static_cast<double>(opt->block_percent_tol) / 100.,
                        int(opt->block_abs_tol), dev_runs);
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -152,7 +152,7 @@ int sk_gvcf_plain_runs(const sk_gvcf_site_summary* summary, const uint32_t* clea
     if (n == 0) return 0;
     if (!summary || !clean_count || !raw_count || !mapq_count || !runs) return sk_fail("sk_gvcf_plain_runs: null argument");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     std::vector<int64_t> off(2 * (size_t(n) + 1), 0);
     int64_t* clean_off = off.data();
@@ -168,15 +168,15 @@ int sk_gvcf_plain_runs(const sk_gvcf_site_summary* summary, const uint32_t* clea
     GvcfBuffers& B = gvcf_bufs();
     if (B.reserve(0, total)) return 1;
     char* d = static_cast<char*>(B.p[0]);
-    SK_HIP(hipMemcpyAsync(d + o_sum, summary, sizeof(sk_gvcf_site_summary) * N, hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(d + o_off, off.data(), 16 * (N + 1), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(d + o_mq, mapq_count, 4 * N, hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(d + o_sum, summary, sizeof(sk_gvcf_site_summary) * N, hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(d + o_off, off.data(), 16 * (N + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(d + o_mq, mapq_count, 4 * N, hipMemcpyHostToDevice, st));
     if (sk_gvcf_plain_runs_dev(reinterpret_cast<const sk_gvcf_site_summary*>(d + o_sum), reinterpret_cast<const int64_t*>(d + o_off),
                                reinterpret_cast<const int64_t*>(d + o_off) + n + 1, reinterpret_cast<const uint32_t*>(d + o_mq), opt, n, d + o_pod,
                                reinterpret_cast<sk_gvcf_run*>(d + o_runs), st))
         return 1;
-    SK_HIP(hipMemcpyAsync(runs, d + o_runs, sizeof(sk_gvcf_run) * N, hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st)); // (`off` is pageable: the copies above have finished by now)
+    SK_HIP(skrt::memcpyAsync(runs, d + o_runs, sizeof(sk_gvcf_run) * N, hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::streamSynchronize(st)); // (`off` is pageable: the copies above have finished by now)
     return 0;
 }
 
@@ -187,7 +187,7 @@ int sk_gvcf_site_summaries(const sk_pileup_batch* hb, const sk_digt_call* genoty
     if (hb->n_loci == 0) return 0;
     if (!genotypes || !out || !hb->call_off || !hb->calls || !hb->ref_base) return sk_fail("sk_gvcf_site_summaries: null argument");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     const size_t n = size_t(hb->n_loci);
     const size_t n_calls = size_t(hb->call_off[n]);
@@ -197,11 +197,11 @@ int sk_gvcf_site_summaries(const sk_pileup_batch* hb, const sk_digt_call* genoty
     GvcfBuffers& B = gvcf_bufs();
     if (B.reserve(0, total)) return 1;
     char* d = static_cast<char*>(B.p[0]);
-    SK_HIP(hipMemcpyAsync(d + o_off, hb->call_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
-    if (n_calls) SK_HIP(hipMemcpyAsync(d + o_calls, hb->calls, 2 * n_calls, hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(d + o_ref, hb->ref_base, n, hipMemcpyHostToDevice, st));
-    if (hb->ploidy) SK_HIP(hipMemcpyAsync(d + o_pl, hb->ploidy, n, hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemcpyAsync(d + o_g, genotypes, sizeof(sk_digt_call) * n, hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(d + o_off, hb->call_off, 8 * (n + 1), hipMemcpyHostToDevice, st));
+    if (n_calls) SK_HIP(skrt::memcpyAsync(d + o_calls, hb->calls, 2 * n_calls, hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(d + o_ref, hb->ref_base, n, hipMemcpyHostToDevice, st));
+    if (hb->ploidy) SK_HIP(skrt::memcpyAsync(d + o_pl, hb->ploidy, n, hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(d + o_g, genotypes, sizeof(sk_digt_call) * n, hipMemcpyHostToDevice, st));
     sk_pileup_batch db;
     std::memset(&db, 0, sizeof(db));
     db.n_loci = hb->n_loci;
@@ -210,8 +210,8 @@ int sk_gvcf_site_summaries(const sk_pileup_batch* hb, const sk_digt_call* genoty
     db.ref_base = reinterpret_cast<const uint8_t*>(d + o_ref);
     db.ploidy = hb->ploidy ? reinterpret_cast<const uint8_t*>(d + o_pl) : nullptr;
     if (sk_gvcf_site_summaries_dev(&db, reinterpret_cast<const sk_digt_call*>(d + o_g), reinterpret_cast<sk_gvcf_site_summary*>(d + o_out), st)) return 1;
-    SK_HIP(hipMemcpyAsync(out, d + o_out, sizeof(sk_gvcf_site_summary) * n, hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    SK_HIP(skrt::memcpyAsync(out, d + o_out, sizeof(sk_gvcf_site_summary) * n, hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::streamSynchronize(st));
     return 0;
 }
 
@@ -229,8 +229,8 @@ int sk_gvcf_block_sites_dev(const sk_gvcf_site* dev_sites, int32_t n_sites, uint
     a.abs_tol = int32_t(block_abs_tol);
     a.kind = dev_kind;
     a.blocks = dev_blocks;
-    hipLaunchKernelGGL(gvcf_block_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
+    SK_LAUNCH(gvcf_block_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -242,18 +242,18 @@ int sk_gvcf_block_sites(const sk_gvcf_site* sites, int32_t n_sites, uint32_t blo
     if (n_sites == 0) return 0;
     if (!sites || !kind || !blocks) return sk_fail("sk_gvcf_block_sites: null argument");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     GvcfBuffers& B = gvcf_bufs();
     if (B.reserve(0, sizeof(sk_gvcf_site) * size_t(n_sites)) || B.reserve(1, size_t(n_sites)) || B.reserve(2, sizeof(sk_gvcf_block) * size_t(n_sites))) return 1;
-    SK_HIP(hipMemcpyAsync(B.p[0], sites, sizeof(sk_gvcf_site) * size_t(n_sites), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemsetAsync(B.p[2], 0, sizeof(sk_gvcf_block) * size_t(n_sites), st));
+    SK_HIP(skrt::memcpyAsync(B.p[0], sites, sizeof(sk_gvcf_site) * size_t(n_sites), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memsetAsync(B.p[2], 0, sizeof(sk_gvcf_block) * size_t(n_sites), st));
     if (sk_gvcf_block_sites_dev(static_cast<sk_gvcf_site*>(B.p[0]), n_sites, block_percent_tol, block_abs_tol, static_cast<uint8_t*>(B.p[1]),
                                 static_cast<sk_gvcf_block*>(B.p[2]), st))
         return 1;
-    SK_HIP(hipMemcpyAsync(kind, B.p[1], size_t(n_sites), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipMemcpyAsync(blocks, B.p[2], sizeof(sk_gvcf_block) * size_t(n_sites), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    SK_HIP(skrt::memcpyAsync(kind, B.p[1], size_t(n_sites), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::memcpyAsync(blocks, B.p[2], sizeof(sk_gvcf_block) * size_t(n_sites), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::streamSynchronize(st));
     return 0;
 }
 

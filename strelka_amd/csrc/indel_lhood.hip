@@ -763,8 +763,8 @@ static int allele_group_dev_t(const sk_allele_group_batch* b, const sk_indel_opt
     a.loghalf = std::log(half); // :75
     a.out = dev_out;
     a.exact_libm = sk_ctx().libm_restated ? 1 : 0;
-    hipLaunchKernelGGL((allele_group_kernel<MAXA, CallT>), dim3(b->n_groups), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
+    SK_LAUNCH((allele_group_kernel<MAXA, CallT>), dim3(b->n_groups), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -782,7 +782,7 @@ static int allele_group_host_t(const sk_allele_group_batch* hb, const sk_indel_o
     }
     const int64_t tr = hb->read_off[n];
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     // one block in, one block out, moved by launches (SkStage, sk_common.h): the adapter calls this once per indel locus
     SkStage sg;
     const size_t in_bytes = 8 * size_t(n + 1) + 2 * size_t(n) + 2 * 4 * size_t(MAXA) * size_t(n) + 2 * 4 * size_t(MAXA) * size_t(tr) + 2 * 2 * size_t(tr) + size_t(tr);
@@ -856,9 +856,9 @@ int sk_indel_grid_lhood_dev(const sk_readscore_batch* b, const sk_indel_options*
     }
     volatile double two = 2.;
     a.loghalf = -std::log(two); // :251
-    if (opt->fast_form) hipLaunchKernelGGL(indel_grid_lhood_kernel<true>, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
-    else hipLaunchKernelGGL(indel_grid_lhood_kernel<false>, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
+    if (opt->fast_form) SK_LAUNCH(indel_grid_lhood_kernel<true>, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
+    else SK_LAUNCH(indel_grid_lhood_kernel<false>, dim3(b->n_indels), dim3(WAVE), 0, static_cast<hipStream_t>(hip_stream), a);
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -959,7 +959,7 @@ int sk_indel_grid_lhood(const sk_readscore_batch* hb, const sk_indel_options* op
     if (!hb || !opt || !out_lhood) return sk_fail("sk_indel_grid_lhood: null argument");
     if (hb->n_indels <= 0) return 0;
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     // (one block in, one block out, moved by launches: SkStage, sk_common.h)
     SkStage sg;
     const size_t out_bytes = sizeof(double) * N_STATES * size_t(hb->n_indels);
@@ -985,7 +985,7 @@ int sk_somatic_indel_call_batch(const sk_readscore_batch* hn, const sk_readscore
     const int n = hn->n_indels;
     if (n <= 0) return 0;
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     SkStage sg;
     const size_t lh_bytes = sizeof(double) * N_STATES * size_t(n);
     if (sg.begin(readscore_bytes(hn) + readscore_bytes(ht) + 2 * 4 * size_t(n), sizeof(sk_somatic_indel_call) * size_t(n), 2 * sk_align256(lh_bytes) + 1024, 26))
@@ -1002,7 +1002,7 @@ int sk_somatic_indel_call_batch(const sk_readscore_batch* hn, const sk_readscore
     if (sk_indel_grid_lhood_dev(&dt, topt, is_include_tier2, dtl, ctx.stream)) return 1;
     PostArgs p;
     fill_post_args(*sopt, dnl, dtl, dsse, dcsse, dout, n, p);
-    hipLaunchKernelGGL(somatic_indel_posterior_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx.stream, p);
+    SK_LAUNCH(somatic_indel_posterior_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx.stream, p);
     if (sg.download_and_wait(ctx.stream)) return 1;
     sg.fetch(out, dout, size_t(n));
     return 0;
@@ -1033,7 +1033,7 @@ int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* hb, const sk_indel
                 }
     }
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     // one block in, one block out, moved by launches (SkStage, sk_common.h): the adapter calls this once per indel locus
     SkStage sg;
@@ -1082,8 +1082,8 @@ int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* hb, const sk_indel
     m.overlap = dflags + 2 * size_t(n);
     m.n_indels = n;
     m.exact_libm = sk_ctx().libm_restated ? 1 : 0;
-    hipLaunchKernelGGL(multi_indel_allele_kernel, dim3(n), dim3(WAVE), 0, st, m);
-    SK_HIP(hipGetLastError());
+    SK_LAUNCH(multi_indel_allele_kernel, dim3(n), dim3(WAVE), 0, st, m);
+    SK_HIP(skrt::getLastError());
 
     for (int tier = 0; tier < 2; ++tier) {
         if (tier == 1 && !use_tier2_evidence) break;
@@ -1091,8 +1091,8 @@ int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* hb, const sk_indel
         if (sk_indel_grid_lhood_dev(&dt, topt, tier, dtl, st)) return 1;
         PostArgs p;
         fill_post_args(*sopt, dnl, dtl, dsse, dcsse, dcall[tier], n, p);
-        hipLaunchKernelGGL(somatic_indel_posterior_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p);
-        SK_HIP(hipGetLastError());
+        SK_LAUNCH(somatic_indel_posterior_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p);
+        SK_HIP(skrt::getLastError());
     }
     IndelCombineArgs c;
     c.call[0] = dcall[0];
@@ -1103,7 +1103,7 @@ int sk_somatic_indel_call_tiers(const sk_somatic_indel_batch* hb, const sk_indel
     c.use_tier2 = use_tier2_evidence ? 1 : 0;
     c.n_indels = n;
     c.out = dout;
-    hipLaunchKernelGGL(somatic_indel_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c);
+    SK_LAUNCH(somatic_indel_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c);
     if (sg.download_and_wait(st)) return 1;
     sg.fetch(out, dout, size_t(n));
     return 0;

@@ -1039,6 +1039,9 @@ int sk_pileup_reads_dev(const sk_read_batch* b, const int64_t n_bases, const sk_
                         sk_pileup_columns* out, void* dev_scratch, void* hip_stream)
 {
     SK_REQUIRE_INIT();
+    if (skrt::remote())
+        return sk_fail("sk_pileup_reads: the one-shot pileup uses the device library's scans, which a broker client cannot call; a broker client piles up through "
+                       "sk_pileup_stream_* (unset STRELKA_AMD_BROKER for this entry point)");
     if (!b || !opt || !out || !dev_scratch) return sk_fail("sk_pileup_reads_dev: null argument");
     if (mode < SK_PILEUP_RAW_TIER1 || mode > SK_PILEUP_CLEAN_TIER2) return sk_fail("sk_pileup_reads_dev: unknown mode");
     if (opt->report_end < opt->report_begin || out->n_loci != opt->report_end - opt->report_begin)
@@ -1073,28 +1076,28 @@ int sk_pileup_reads_dev(const sk_read_batch* b, const int64_t n_bases, const sk_
     void* tmp = base + L.tmp;
     size_t tmp_bytes = size_t(L.tmp_bytes);
 
-    if (a.spandel && n_loci) SK_HIP(hipMemsetAsync(a.spandel, 0, 4 * size_t(n_loci), st));
-    if (a.submapped && n_loci) SK_HIP(hipMemsetAsync(a.submapped, 0, 4 * size_t(n_loci), st));
+    if (a.spandel && n_loci) SK_HIP(skrt::memsetAsync(a.spandel, 0, 4 * size_t(n_loci), st));
+    if (a.submapped && n_loci) SK_HIP(skrt::memsetAsync(a.submapped, 0, 4 * size_t(n_loci), st));
     if (b->n_reads > 0) {
-        hipLaunchKernelGGL(pileup_read_kernel, dim3((b->n_reads + P1_WAVES - 1) / P1_WAVES), dim3(P1_WAVES * WAVE), 0, st, a);
-        hipLaunchKernelGGL(span_split_kernel, dim3((b->n_reads + 255) / 256), dim3(256), 0, st, a.span, d_begin, d_end, b->n_reads);
+        SK_LAUNCH(pileup_read_kernel, dim3((b->n_reads + P1_WAVES - 1) / P1_WAVES), dim3(P1_WAVES * WAVE), 0, st, a);
+        SK_LAUNCH(span_split_kernel, dim3((b->n_reads + 255) / 256), dim3(256), 0, st, a.span, d_begin, d_end, b->n_reads);
         SK_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, d_end, d_maxend, size_t(b->n_reads), MaxOp(), st));
         tmp_bytes = size_t(L.tmp_bytes);
         SK_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, std::make_reverse_iterator(d_begin + b->n_reads),
                                        std::make_reverse_iterator(d_minbegin + b->n_reads), size_t(b->n_reads), MinOp(), st));
     }
     const int blocks = (n_loci + 1 + WAVE - 1) / WAVE; // the extra locus carries the total through the scan
-    hipLaunchKernelGGL(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE), 0, st, a);
+    SK_LAUNCH(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE), 0, st, a);
     tmp_bytes = size_t(L.tmp_bytes);
     SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, a.count, out->call_off, int64_t(0), size_t(n_loci) + 1, rocprim::plus<int64_t>(), st));
     // capacity check needs the total on the host
     int64_t total = 0;
-    SK_HIP(hipMemcpyAsync(&total, out->call_off + n_loci, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    SK_HIP(skrt::memcpyAsync(&total, out->call_off + n_loci, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::streamSynchronize(st));
     if (total > out->capacity) return sk_fail("sk_pileup_reads_dev: calls capacity too small");
     a.store = 1;
-    if (total > 0) hipLaunchKernelGGL(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE), 0, st, a);
-    SK_HIP(hipGetLastError());
+    if (total > 0) SK_LAUNCH(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE), 0, st, a);
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -1135,7 +1138,7 @@ int sk_pileup_reads(const sk_read_batch* hb, const sk_pileup_options* opt, const
     }
 
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     const int64_t scratch = sk_pileup_scratch_bytes(n, n_bases, n_loci);
     const int64_t cap = out->capacity;
     struct Item { const void* src; int64_t bytes; int64_t off; };
@@ -1159,7 +1162,7 @@ int sk_pileup_reads(const sk_read_batch* hb, const sk_pileup_options* opt, const
     if (ar.reserve(size_t(bytes) + 256)) return 1;
     char* d = ar.take<char>(size_t(bytes));
     for (const Item& it : items)
-        if (it.src && it.bytes > 0) SK_HIP(hipMemcpyAsync(d + it.off, it.src, size_t(it.bytes), hipMemcpyHostToDevice, ctx.stream));
+        if (it.src && it.bytes > 0) SK_HIP(skrt::memcpyAsync(d + it.off, it.src, size_t(it.bytes), hipMemcpyHostToDevice, ctx.stream));
     sk_read_batch db = *hb;
     db.read_off = reinterpret_cast<const int64_t*>(d + items[0].off);
     db.read_code = reinterpret_cast<const uint8_t*>(d + items[1].off);
@@ -1178,13 +1181,13 @@ int sk_pileup_reads(const sk_read_batch* hb, const sk_pileup_options* opt, const
     dc.spandel_count = reinterpret_cast<uint32_t*>(d + o_sd);
     dc.submapped_count = reinterpret_cast<uint32_t*>(d + o_sm);
     if (sk_pileup_reads_dev(&db, n_bases, opt, mode, &dc, d + o_scr, ctx.stream)) return 1;
-    SK_HIP(hipMemcpyAsync(out->call_off, dc.call_off, 8 * (size_t(n_loci) + 1), hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    SK_HIP(skrt::memcpyAsync(out->call_off, dc.call_off, 8 * (size_t(n_loci) + 1), hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(skrt::streamSynchronize(ctx.stream));
     const int64_t total = out->call_off[n_loci];
-    if (total > 0) SK_HIP(hipMemcpyAsync(out->calls, dc.calls, 2 * size_t(total), hipMemcpyDeviceToHost, ctx.stream));
-    if (out->spandel_count && n_loci) SK_HIP(hipMemcpyAsync(out->spandel_count, dc.spandel_count, 4 * size_t(n_loci), hipMemcpyDeviceToHost, ctx.stream));
-    if (out->submapped_count && n_loci) SK_HIP(hipMemcpyAsync(out->submapped_count, dc.submapped_count, 4 * size_t(n_loci), hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    if (total > 0) SK_HIP(skrt::memcpyAsync(out->calls, dc.calls, 2 * size_t(total), hipMemcpyDeviceToHost, ctx.stream));
+    if (out->spandel_count && n_loci) SK_HIP(skrt::memcpyAsync(out->spandel_count, dc.spandel_count, 4 * size_t(n_loci), hipMemcpyDeviceToHost, ctx.stream));
+    if (out->submapped_count && n_loci) SK_HIP(skrt::memcpyAsync(out->submapped_count, dc.submapped_count, 4 * size_t(n_loci), hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(skrt::streamSynchronize(ctx.stream));
     return 0;
 }
 
@@ -1219,17 +1222,17 @@ struct DevBuf
     int need(const size_t bytes)
     {
         if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
+        if (p) (void)skrt::free_(p);
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 2 + 4096;
-        if (hipMalloc(&p, want) != hipSuccess) return 1;
+        if (skrt::malloc_(&p, want) != hipSuccess) return 1;
         cap = want;
         return 0;
     }
     void drop()
     {
-        if (p) (void)hipFree(p);
+        if (p) (void)skrt::free_(p);
         p = nullptr;
         cap = 0;
     }
@@ -1242,17 +1245,17 @@ struct PinBuf
     int need(const size_t bytes)
     {
         if (bytes <= cap) return 0;
-        if (p) (void)hipHostFree(p);
+        if (p) (void)skrt::hostFree(p);
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 2 + 4096;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return 1;
+        if (skrt::hostMalloc(&p, want) != hipSuccess) return 1;
         cap = want;
         return 0;
     }
     void drop()
     {
-        if (p) (void)hipHostFree(p);
+        if (p) (void)skrt::hostFree(p);
         p = nullptr;
         cap = 0;
     }
@@ -1514,7 +1517,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     }
     if (mask_len > 0) std::memcpy(hi + li.mask, cand_snv_mask, size_t(mask_len)); // (through the pinned block: a copy from the caller's pageable memory would wait for the device)
     char* di = static_cast<char*>(d_in.p);
-    SK_HIP(hipMemcpyAsync(di, hi, size_t(li.total), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(di, hi, size_t(li.total), hipMemcpyHostToDevice, st));
     CopyArgs carry; // every device-to-device piece of this push, one launch
     carry.n = 0;
     int64_t carry_max = 0;
@@ -1543,7 +1546,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     s->cur = nxt;
     if (carry.n > 0) {
         const int bx = int(std::min<int64_t>((carry_max / 16 + 255) / 256 + 1, 64));
-        hipLaunchKernelGGL(copy_segments_kernel, dim3(bx, carry.n), dim3(256), 0, st, carry);
+        SK_LAUNCH(copy_segments_kernel, dim3(bx, carry.n), dim3(256), 0, st, carry);
     }
 
     // ---- work and output blocks
@@ -1631,11 +1634,11 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     a.submapped = static_cast<uint32_t*>(s->d_submapped.p);
     a.n_loci = s->region_end - s->region_begin;
     a.r0 = n_c;
-    if (n_new > 0) hipLaunchKernelGGL(pileup_read_kernel, dim3((n_new + P1_WAVES - 1) / P1_WAVES), dim3(P1_WAVES * WAVE), 0, st, a);
+    if (n_new > 0) SK_LAUNCH(pileup_read_kernel, dim3((n_new + P1_WAVES - 1) / P1_WAVES), dim3(P1_WAVES * WAVE), 0, st, a);
 
     int* d_maxend = reinterpret_cast<int*>(dw + wl.maxend);
     int* d_minbegin = reinterpret_cast<int*>(dw + wl.minbegin);
-    if (n > 0) hipLaunchKernelGGL(span_bounds_kernel, dim3(2), dim3(1024), 0, st, a.span, d_maxend, d_minbegin, n);
+    if (n > 0) SK_LAUNCH(span_bounds_kernel, dim3(2), dim3(1024), 0, st, a.span, d_maxend, d_minbegin, n);
     // P2: the window's columns
     PileupArgs c = a;
     c.o.report_begin = begin;
@@ -1671,7 +1674,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     const int blocks = (n_loci + 1 + WAVE - 1) / WAVE;
     void (*const p2)(const PileupArgs) = som ? pileup_column_kernel_t<true, true, false>
                                              : (s->want_evs ? pileup_column_kernel_t<true, false, true> : pileup_column_kernel_t<true, false, false>);
-    hipLaunchKernelGGL(p2, dim3(blocks), dim3(WAVE), 0, st, c);
+    SK_LAUNCH(p2, dim3(blocks), dim3(WAVE), 0, st, c);
     {
         // every column's offsets (exclusive sums of n_loci + 1 counts: the last entry is the total) and, in the same launch, the cleaned
         // columns' sizes for the caller's cache validation and the region-wide counters' slice
@@ -1702,13 +1705,13 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
             add(static_cast<char*>(s->d_spandel.p) + 4 * size_t(begin - s->region_begin), dout + ol.spandel, 4 * int64_t(n_loci));
             add(static_cast<char*>(s->d_submapped.p) + 4 * size_t(begin - s->region_begin), dout + ol.submapped, 4 * int64_t(n_loci));
         }
-        hipLaunchKernelGGL(column_offsets_kernel, dim3(oa.n_scans + oa.n_copies), dim3(1024), 0, st, oa);
+        SK_LAUNCH(column_offsets_kernel, dim3(oa.n_scans + oa.n_copies), dim3(1024), 0, st, oa);
     }
     c.store = 1;
-    if (n > 0 && n_loci > 0) hipLaunchKernelGGL(p2, dim3(blocks), dim3(WAVE), 0, st, c);
+    if (n > 0 && n_loci > 0) SK_LAUNCH(p2, dim3(blocks), dim3(WAVE), 0, st, c);
     if (n_loci > 0 && (s->genotype || som)) {
         uint8_t* d_refbase = reinterpret_cast<uint8_t*>(dw + wl.refbase);
-        hipLaunchKernelGGL(ref_base_id_kernel, dim3((n_loci + 255) / 256), dim3(256), 0, st, static_cast<const char*>(s->d_ref.p), s->ref_offset,
+        SK_LAUNCH(ref_base_id_kernel, dim3((n_loci + 255) / 256), dim3(256), 0, st, static_cast<const char*>(s->d_ref.p), s->ref_offset,
                            s->ref_len, begin, n_loci, d_refbase);
     }
     // a9 + a10 on the cleaned columns, where they are
@@ -1733,8 +1736,8 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
                                    &s->gvcf_opt, n_loci, dw + wl.pods, reinterpret_cast<sk_gvcf_run*>(dout + ol.runs), st))
             return 1;
     }
-    SK_HIP(hipGetLastError());
-    SK_HIP(hipMemcpyAsync(ho, dout, size_t(ol.total), hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::getLastError());
+    SK_HIP(skrt::memcpyAsync(ho, dout, size_t(ol.total), hipMemcpyDeviceToHost, st));
     return 0;
 }
 
@@ -1856,8 +1859,8 @@ void sk_pileup_stream_destroy(sk_pileup_stream* s)
 {
     if (!s) return;
     if (sk_ctx().ready) {
-        (void)hipSetDevice(sk_ctx().device);
-        (void)hipStreamSynchronize(sk_ctx().stream);
+        (void)skrt::setDevice(sk_ctx().device);
+        (void)skrt::streamSynchronize(sk_ctx().stream);
     }
     stream_drop(s);
     delete s;
@@ -1871,17 +1874,17 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, cons
     if (!s || (!ref_seq && ref_len > 0)) return sk_fail("sk_pileup_stream_begin_region: null argument");
     if (ref_len < 0 || report_end < report_begin) return sk_fail("sk_pileup_stream_begin_region: bad range");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     const size_t n_region = size_t(report_end - report_begin);
     if (s->d_ref.need(size_t(ref_len) + 1) || s->d_mask.need(size_t(ref_len) + 1) || s->d_spandel.need(4 * n_region + 4) ||
         s->d_submapped.need(4 * n_region + 4))
         return sk_fail("sk_pileup_stream_begin_region: out of device memory");
-    if (ref_len > 0) SK_HIP(hipMemcpyAsync(s->d_ref.p, ref_seq, size_t(ref_len), hipMemcpyHostToDevice, st));
-    SK_HIP(hipMemsetAsync(s->d_mask.p, 0, size_t(ref_len) + 1, st));
-    SK_HIP(hipMemsetAsync(s->d_spandel.p, 0, 4 * n_region + 4, st));
-    SK_HIP(hipMemsetAsync(s->d_submapped.p, 0, 4 * n_region + 4, st));
-    SK_HIP(hipStreamSynchronize(st)); // ref_seq is the caller's
+    if (ref_len > 0) SK_HIP(skrt::memcpyAsync(s->d_ref.p, ref_seq, size_t(ref_len), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memsetAsync(s->d_mask.p, 0, size_t(ref_len) + 1, st));
+    SK_HIP(skrt::memsetAsync(s->d_spandel.p, 0, 4 * n_region + 4, st));
+    SK_HIP(skrt::memsetAsync(s->d_submapped.p, 0, 4 * n_region + 4, st));
+    SK_HIP(skrt::streamSynchronize(st)); // ref_seq is the caller's
     s->poisoned = false;
     s->ref_offset = ref_offset;
     s->ref_len = ref_len;
@@ -1909,7 +1912,7 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     if (s->poisoned) return sk_fail("sk_pileup_stream_push: an earlier push of this stream failed; begin the region again");
     if (stream_check_reads(s, reads, mask_begin, mask_len, cand_snv_mask)) return 1;
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     const int32_t F = std::min(final_to, s->region_end);
     int32_t lowest, highest, begin, end;
     if (stream_extent(s, reads, &lowest, &highest)) return 1;
@@ -1918,11 +1921,11 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     // the stream's bookkeeping half done -- the stream is drained and refuses further pushes until begin_region resets it)
     if (stream_enqueue(s, reads, largest_total_indel_ref_span_per_read, mask_begin, mask_len, cand_snv_mask, F, begin, end, ploidy_begin,
                        ploidy_len, ploidy)) {
-        (void)hipStreamSynchronize(ctx.stream);
+        (void)skrt::streamSynchronize(ctx.stream);
         s->poisoned = true;
         return 1;
     }
-    if (hipStreamSynchronize(ctx.stream) != hipSuccess) {
+    if (skrt::streamSynchronize(ctx.stream) != hipSuccess) {
         s->poisoned = true;
         return sk_fail("sk_pileup_stream_push: the device reported an error");
     }
@@ -1962,8 +1965,8 @@ void sk_somatic_pileup_stream_destroy(sk_somatic_pileup_stream* p)
 {
     if (!p) return;
     if (sk_ctx().ready) {
-        (void)hipSetDevice(sk_ctx().device);
-        (void)hipStreamSynchronize(sk_ctx().stream);
+        (void)skrt::setDevice(sk_ctx().device);
+        (void)skrt::streamSynchronize(sk_ctx().stream);
     }
     for (int i = 0; i < 2; ++i) {
         stream_drop(p->sample[i]);
@@ -2001,7 +2004,7 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
     }
     if (forced_len < 0 || (forced_len > 0 && !is_forced_output)) return sk_fail("sk_somatic_pileup_stream_push: bad forced-output window");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     sk_pileup_stream* sn = p->sample[0];
     sk_pileup_stream* stu = p->sample[1];
@@ -2019,7 +2022,7 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
         if (stream_enqueue(p->sample[i], reads[i], largest_total_indel_ref_span_per_read, mask_begin, mask_len, cand_snv_mask, F, begin, end, 0,
                            0, nullptr)) {
             // (the other sample may be enqueued already: drain, and both streams refuse pushes until begin_region)
-            (void)hipStreamSynchronize(st);
+            (void)skrt::streamSynchronize(st);
             p->sample[0]->poisoned = p->sample[1]->poisoned = true;
             return 1;
         }
@@ -2042,7 +2045,7 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
         uint8_t* d_forced = reinterpret_cast<uint8_t*>(dc);
         sk_somatic_snv_genotype* d_geno = reinterpret_cast<sk_somatic_snv_genotype*>(dc + forced_bytes);
         void* d_scratch = dc + forced_bytes + size_t(align256(int64_t(geno_bytes)));
-        SK_HIP(hipMemcpyAsync(d_forced, hf, size_t(n_loci), hipMemcpyHostToDevice, st));
+        SK_HIP(skrt::memcpyAsync(d_forced, hf, size_t(n_loci), hipMemcpyHostToDevice, st));
         sk_pileup_batch b[4]; // normal t1, tumor t1, normal t2, tumor t2
         for (int i = 0; i < 2; ++i) {
             sk_pileup_stream* s = p->sample[i];
@@ -2059,9 +2062,9 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
         if (sk_somatic_snv_call_tiers_dev(&b[0], &b[1], p->tier2 ? &b[2] : nullptr, p->tier2 ? &b[3] : nullptr, &p->sopt, d_forced,
                                           is_compute_nonsomatic, d_geno, d_scratch, st))
             return 1;
-        SK_HIP(hipMemcpyAsync(p->h_geno.p, d_geno, sizeof(sk_somatic_snv_genotype) * size_t(n_loci), hipMemcpyDeviceToHost, st));
+        SK_HIP(skrt::memcpyAsync(p->h_geno.p, d_geno, sizeof(sk_somatic_snv_genotype) * size_t(n_loci), hipMemcpyDeviceToHost, st));
     }
-    SK_HIP(hipStreamSynchronize(st));
+    SK_HIP(skrt::streamSynchronize(st));
     stream_finish(sn, &out->normal);
     stream_finish(stu, &out->tumor);
     out->tumor_tier1_read_pos =

@@ -1372,11 +1372,11 @@ static void launch_flatten_score_t(const int n_reads, hipStream_t st, const Fuse
     static const int waves = [] { const char* e = std::getenv("SK_F5_WAVES"); return e ? std::atoi(e) : 0; }(); // (experiments: 1, 2, 4, 8, 16; 0 = the default)
     constexpr int DEFAULT_WAVES = (sizeof(F5Lds<MAXR>) * 16 <= 160 * 1024) ? 8 : 4;
     const int w = waves > 0 ? waves : DEFAULT_WAVES;
-    if (w == 16 && MAXR <= 152) hipLaunchKernelGGL((flatten_score_kernel<152, TIMING, 16>), dim3((n_reads + 15) / 16), dim3(1024), 0, st, fs, n_reads);
-    else if (w >= 8) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 8>), dim3((n_reads + 7) / 8), dim3(512), 0, st, fs, n_reads);
-    else if (w == 4) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 4>), dim3((n_reads + 3) / 4), dim3(256), 0, st, fs, n_reads);
-    else if (w == 2) hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 2>), dim3((n_reads + 1) / 2), dim3(128), 0, st, fs, n_reads);
-    else hipLaunchKernelGGL((flatten_score_kernel<MAXR, TIMING, 1>), dim3(n_reads), dim3(64), 0, st, fs, n_reads);
+    if (w == 16 && MAXR <= 152) SK_LAUNCH((flatten_score_kernel<152, TIMING, 16>), dim3((n_reads + 15) / 16), dim3(1024), 0, st, fs, n_reads);
+    else if (w >= 8) SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 8>), dim3((n_reads + 7) / 8), dim3(512), 0, st, fs, n_reads);
+    else if (w == 4) SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 4>), dim3((n_reads + 3) / 4), dim3(256), 0, st, fs, n_reads);
+    else if (w == 2) SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 2>), dim3((n_reads + 1) / 2), dim3(128), 0, st, fs, n_reads);
+    else SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 1>), dim3(n_reads), dim3(64), 0, st, fs, n_reads);
 }
 
 static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
@@ -1874,11 +1874,11 @@ struct DevBuf
     int reserve(const size_t bytes)
     {
         if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
+        if (p) (void)skrt::free_(p);
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 4 + 4096;
-        SK_HIP(hipMalloc(&p, want));
+        SK_HIP(skrt::malloc_(&p, want));
         cap = want;
         return 0;
     }
@@ -1891,11 +1891,11 @@ struct HostBuf // pinned
     int reserve(const size_t bytes)
     {
         if (bytes <= cap) return 0;
-        if (p) (void)hipHostFree(p);
+        if (p) (void)skrt::hostFree(p);
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 4 + 4096;
-        SK_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        SK_HIP(skrt::hostMalloc(&p, want));
         cap = want;
         return 0;
     }
@@ -1967,9 +1967,9 @@ extern "C" int sk_enum_device_fetch_scores(const uint64_t generation, const int3
     if (generation != g_generation || first < 0 || count < 0 || first + count > g_n_cals || !g_scores) return 1;
     if (count == 0) return 0;
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
-    SK_HIP(hipMemcpyAsync(dst, g_scores + first, 8 * size_t(count), hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    SK_HIP(skrt::setDevice(ctx.device));
+    SK_HIP(skrt::memcpyAsync(dst, g_scores + first, 8 * size_t(count), hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(skrt::streamSynchronize(ctx.stream));
     return 0;
 }
 
@@ -1978,15 +1978,15 @@ extern "C" int sk_enum_device_fetch_cals(const uint64_t generation, const int32_
     if (generation != g_generation || first < 0 || count < 0 || first + count > g_n_cals) return 1;
     if (count == 0) return 0;
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     if (!g_cals_gathered) { // (F5 left the records where the search put them: in set order on demand, once per run)
         if (bufs().cals.reserve(sizeof(PCal) * size_t(g_n_cals))) return 1;
-        hipLaunchKernelGGL(gather_cals_kernel, dim3((g_n_cals + 63) / 64), dim3(64), 0, ctx.stream, g_cals_pool, g_cals_list, g_n_cals, bufs().cals.as<PCal>());
-        SK_HIP(hipGetLastError());
+        SK_LAUNCH(gather_cals_kernel, dim3((g_n_cals + 63) / 64), dim3(64), 0, ctx.stream, g_cals_pool, g_cals_list, g_n_cals, bufs().cals.as<PCal>());
+        SK_HIP(skrt::getLastError());
         g_cals_gathered = true;
     }
-    SK_HIP(hipMemcpyAsync(dst, bufs().cals.as<PCal>() + first, sizeof(PCal) * size_t(count), hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    SK_HIP(skrt::memcpyAsync(dst, bufs().cals.as<PCal>() + first, sizeof(PCal) * size_t(count), hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(skrt::streamSynchronize(ctx.stream));
     return 0;
 }
 
@@ -2029,14 +2029,14 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
     const int n = in->n_reads;
     if (n < 0 || in->n_tab < 0) return sk_fail("sk_enum_device_run: negative count");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     EnumBuffers& B = bufs();
     const bool timing = std::getenv("SK_ENUM_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing) return;
-        (void)hipStreamSynchronize(st);
+        (void)skrt::streamSynchronize(st);
         std::fprintf(stderr, "[enum-dev] %-28s t=%.3f ms\n", what,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
@@ -2148,23 +2148,23 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
     auto fetch_zero = [&](const View& first, const View& last, const size_t last_bytes) -> int {
         const size_t a0 = size_t(static_cast<char*>(first.p) - static_cast<char*>(B.zero_arena.p));
         const size_t a1 = size_t(static_cast<char*>(last.p) - static_cast<char*>(B.zero_arena.p)) + last_bytes;
-        SK_HIP(hipMemcpyAsync(static_cast<char*>(B.h_zero_arena.p) + a0, static_cast<char*>(B.zero_arena.p) + a0, a1 - a0, hipMemcpyDeviceToHost, st));
+        SK_HIP(skrt::memcpyAsync(static_cast<char*>(B.h_zero_arena.p) + a0, static_cast<char*>(B.zero_arena.p) + a0, a1 - a0, hipMemcpyDeviceToHost, st));
         return 0;
     };
 
 #define H2D(buf, src, bytes) \
-    if ((bytes) > 0) SK_HIP(hipMemcpyAsync(B.buf.p, src, size_t(bytes), hipMemcpyHostToDevice, st))
+    if ((bytes) > 0) SK_HIP(skrt::memcpyAsync(B.buf.p, src, size_t(bytes), hipMemcpyHostToDevice, st))
 #define D2H(hbuf, buf, bytes) \
-    if ((bytes) > 0) SK_HIP(hipMemcpyAsync(B.hbuf.p, B.buf.p, size_t(bytes), hipMemcpyDeviceToHost, st))
+    if ((bytes) > 0) SK_HIP(skrt::memcpyAsync(B.hbuf.p, B.buf.p, size_t(bytes), hipMemcpyDeviceToHost, st))
     static const bool stage_by_kernel = !(std::getenv("SK_ENUM_STAGE_COPIES") != nullptr); // ($SK_ENUM_STAGE_COPIES: the copy / fill calls, for A-B runs)
     if (one_wait && stage_by_kernel) {
         const uint32_t n_in16 = uint32_t(in_bytes / 16), n_zero16 = uint32_t(zero_bytes / 16); // (pieces sit at 256-byte offsets)
         const int blocks = int(std::min<size_t>(std::max<size_t>((std::max(in_bytes, zero_bytes) / 16 + 255) / 256, 1), 256));
-        hipLaunchKernelGGL(job_stage_in_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint4*>(B.h_in_arena.p), static_cast<uint4*>(B.in_arena.p), n_in16,
+        SK_LAUNCH(job_stage_in_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint4*>(B.h_in_arena.p), static_cast<uint4*>(B.in_arena.p), n_in16,
                            static_cast<uint4*>(B.zero_arena.p), n_zero16);
     } else {
-        if (in_bytes > 0) SK_HIP(hipMemcpyAsync(B.in_arena.p, B.h_in_arena.p, in_bytes, hipMemcpyHostToDevice, st));
-        SK_HIP(hipMemsetAsync(B.zero_arena.p, 0, zero_bytes, st));
+        if (in_bytes > 0) SK_HIP(skrt::memcpyAsync(B.in_arena.p, B.h_in_arena.p, in_bytes, hipMemcpyHostToDevice, st));
+        SK_HIP(skrt::memsetAsync(B.zero_arena.p, 0, zero_bytes, st));
     }
 
     int32_t* h_cal_off = B.h_cal_off.as<int32_t>();
@@ -2250,7 +2250,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         ea.level_in = nullptr;
         ea.level_out = buf[0];
         ea.depth = -1;
-        hipLaunchKernelGGL(root_kernel, dim3((n + 63) / 64), dim3(64), 0, st, ea);
+        SK_LAUNCH(root_kernel, dim3((n + 63) / 64), dim3(64), 0, st, ea);
         int max_order = 0;
         for (int r = 0; r < n; ++r) max_order = std::max(max_order, int(in->reads[r].n_order));
         int n_levels = std::min(max_order + 3, int(Caps::K) + 2);
@@ -2264,7 +2264,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
                 ea.level_in = buf[d & 1];
                 ea.level_out = buf[(d + 1) & 1];
                 ea.depth = d;
-                hipLaunchKernelGGL(level_kernel, dim3(blocks), dim3(64), lds, st, ea);
+                SK_LAUNCH(level_kernel, dim3(blocks), dim3(64), lds, st, ea);
             }
         }
         // scan 1: raw_off
@@ -2279,7 +2279,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         sc.first_level_not_launched = (n_levels >= int(Caps::K) + 2) ? -1 : n_levels;
         sc.n_leaves = ea.n_leaves;
         sc.pool_cap = n_cap;
-        hipLaunchKernelGGL(job_scan_kernel<false>, dim3(1), dim3(1024), 0, st, sc);
+        SK_LAUNCH(job_scan_kernel<false>, dim3(1), dim3(1024), 0, st, sc);
         // E2
         SetArgs sa;
         std::memset(&sa, 0, sizeof(sa));
@@ -2301,8 +2301,8 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         sa.sorted = B.sorted.as<int32_t>();
         // (grids for counts the host has not seen: enough blocks for ~64 leaves per read, the loops cover the rest)
         const int e2_blocks = int(std::min<int64_t>(std::max<int64_t>((int64_t(n) * 64 + 255) / 256, 8), 2048));
-        hipLaunchKernelGGL(group_kernel, dim3(e2_blocks), dim3(256), 0, st, sa);
-        hipLaunchKernelGGL(dedupe_kernel, dim3(e2_blocks), dim3(256), 0, st, sa);
+        SK_LAUNCH(group_kernel, dim3(e2_blocks), dim3(256), 0, st, sa);
+        SK_LAUNCH(dedupe_kernel, dim3(e2_blocks), dim3(256), 0, st, sa);
         // scan 2: cal_off, stage 3's lists
         int light_cals = S3_LIGHT_CALS, lds_cals = S3_LDS_CALS;
         if (const char* e = std::getenv("SK_STAGE3_TEST_LDS_CALS")) {
@@ -2316,8 +2316,8 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         sc.off = B.cal_off_z.as<int32_t>();
         sc.list = B.s3_list.as<int32_t>();
         sc.light_cals = light_cals;
-        hipLaunchKernelGGL(job_scan_kernel<true>, dim3(1), dim3(1024), 0, st, sc);
-        hipLaunchKernelGGL(rank_kernel, dim3(e2_blocks), dim3(256), 0, st, sa);
+        SK_LAUNCH(job_scan_kernel<true>, dim3(1), dim3(1024), 0, st, sc);
+        SK_LAUNCH(rank_kernel, dim3(e2_blocks), dim3(256), 0, st, sa);
         // L1
         FlatArgs fa;
         std::memset(&fa, 0, sizeof(fa));
@@ -2347,8 +2347,8 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         fa.n_seg8 = B.n_seg8.as<uint8_t>();
         fa.max_read_len = in->max_read_len;
         fa.ref_outside = dyn + DYN_REF_OUTSIDE;
-        hipLaunchKernelGGL(pool_bounds_kernel, dim3(e2_blocks), dim3(256), 0, st, fa);
-        hipLaunchKernelGGL(pool_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
+        SK_LAUNCH(pool_bounds_kernel, dim3(e2_blocks), dim3(256), 0, st, fa);
+        SK_LAUNCH(pool_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
         // F5
         FusedScoreArgs fs;
         fs.f = fa;
@@ -2397,27 +2397,27 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         s3.n_list = dyn + DYN_N_LIGHT;
         s3.list_step = 1;
         s3.lds_cals = light_cals;
-        hipLaunchKernelGGL(stage3_kernel<1>, dim3(n), dim3(64), lds_bytes(light_cals), st, s3);
+        SK_LAUNCH(stage3_kernel<1>, dim3(n), dim3(64), lds_bytes(light_cals), st, s3);
         s3.list = B.s3_list.as<int32_t>() + (n - 1);
         s3.n_list = dyn + DYN_N_HEAVY;
         s3.list_step = -1;
         s3.lds_cals = lds_cals; // (the largest read of the list is not known here: LDS for the most a block holds)
-        hipLaunchKernelGGL(stage3_kernel<4>, dim3(n), dim3(256), lds_bytes(lds_cals), st, s3);
-        SK_HIP(hipGetLastError());
+        SK_LAUNCH(stage3_kernel<4>, dim3(n), dim3(256), lds_bytes(lds_cals), st, s3);
+        SK_HIP(skrt::getLastError());
         // the results: the zero arena whole (counters + the scans' numbers, warn, n_raw, status, ..., consulted, cal_off) and stage 3's records
         if (stage_by_kernel) {
             const size_t out_bytes = sizeof(sk3::Out) * size_t(n);
             const uint32_t n_a = uint32_t(zero_bytes / 16), n_b = uint32_t((out_bytes + 15) / 16); // (buffers are reserved with slack)
             const int blocks = int(std::min<size_t>(std::max<size_t>((std::max(zero_bytes, out_bytes) / 16 + 255) / 256, 1), 256));
-            hipLaunchKernelGGL(job_stage_out_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint4*>(B.zero_arena.p), static_cast<uint4*>(B.h_zero_arena.p), n_a,
+            SK_LAUNCH(job_stage_out_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint4*>(B.zero_arena.p), static_cast<uint4*>(B.h_zero_arena.p), n_a,
                                static_cast<const uint4*>(B.s3_out.p), static_cast<uint4*>(B.h_s3_out.p), n_b);
-            SK_HIP(hipGetLastError());
+            SK_HIP(skrt::getLastError());
         } else {
-            SK_HIP(hipMemcpyAsync(B.h_zero_arena.p, B.zero_arena.p, zero_bytes, hipMemcpyDeviceToHost, st));
+            SK_HIP(skrt::memcpyAsync(B.h_zero_arena.p, B.zero_arena.p, zero_bytes, hipMemcpyDeviceToHost, st));
             D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
         }
         const auto t_submitted = std::chrono::steady_clock::now();
-        SK_HIP(hipStreamSynchronize(st));
+        SK_HIP(skrt::streamSynchronize(st));
         const auto t_waited = std::chrono::steady_clock::now();
         g_job_seconds.setup += std::chrono::duration<double>(t_setup - t_begin).count();
         g_job_seconds.submit += std::chrono::duration<double>(t_submitted - t_setup).count();
@@ -2466,7 +2466,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         ea.level_in = nullptr;
         ea.level_out = buf[0];
         ea.depth = -1;
-        hipLaunchKernelGGL(root_kernel, dim3((n + 63) / 64), dim3(64), 0, st, ea);
+        SK_LAUNCH(root_kernel, dim3((n + 63) / 64), dim3(64), 0, st, ea);
         const size_t lds = 64 * sizeof(PFrame);
         const int blocks = int(std::min<int64_t>((frame_cap + 63) / 64, 1024));
         // a call at depth d expands indel order[d]; a call at depth n_order is a leaf.  A read's order as it arrives says how deep its
@@ -2481,12 +2481,12 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
                 ea.level_in = buf[d & 1];
                 ea.level_out = buf[(d + 1) & 1];
                 ea.depth = d;
-                hipLaunchKernelGGL(level_kernel, dim3(blocks), dim3(64), lds, st, ea);
+                SK_LAUNCH(level_kernel, dim3(blocks), dim3(64), lds, st, ea);
             }
             done = upto;
-            SK_HIP(hipGetLastError());
+            SK_HIP(skrt::getLastError());
             if (fetch_zero(B.counters, B.status, 4 * size_t(n))) return 1; // counters, warn, n_raw, status
-            SK_HIP(hipStreamSynchronize(st));
+            SK_HIP(skrt::streamSynchronize(st));
             if (done >= Caps::K + 2 || B.h_counters.as<int32_t>()[done] == 0) break;
             batch = 4;
         }
@@ -2540,21 +2540,21 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
     sa.cal_off = B.cal_off.as<int32_t>();
     sa.sorted = B.sorted.as<int32_t>();
     sa.n_leaves_dev = nullptr;
-    SK_HIP(hipMemcpyAsync(B.raw_off.p, h_raw_off, 4 * size_t(n + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.raw_off.p, h_raw_off, 4 * size_t(n + 1), hipMemcpyHostToDevice, st));
     if (n_grouped > 0) {
-        hipLaunchKernelGGL(group_kernel, dim3((n_leaves + 255) / 256), dim3(256), 0, st, sa);
-        hipLaunchKernelGGL(dedupe_kernel, dim3((n_grouped + 255) / 256), dim3(256), 0, st, sa);
-        SK_HIP(hipGetLastError());
+        SK_LAUNCH(group_kernel, dim3((n_leaves + 255) / 256), dim3(256), 0, st, sa);
+        SK_LAUNCH(dedupe_kernel, dim3((n_grouped + 255) / 256), dim3(256), 0, st, sa);
+        SK_HIP(skrt::getLastError());
     }
     if (fetch_zero(B.n_uniq, B.n_uniq, 4 * size_t(n))) return 1;
-    SK_HIP(hipStreamSynchronize(st));
+    SK_HIP(skrt::streamSynchronize(st));
     const int32_t* h_n_uniq = B.h_n_uniq.as<int32_t>();
     for (int r = 0; r < n; ++r) h_cal_off[r + 1] = h_cal_off[r] + ((h_status[r] == ST_OK) ? h_n_uniq[r] : 0);
     const int32_t n_cals = h_cal_off[n];
-    SK_HIP(hipMemcpyAsync(B.cal_off.p, h_cal_off, 4 * size_t(n + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(B.cal_off.p, h_cal_off, 4 * size_t(n + 1), hipMemcpyHostToDevice, st));
     if (n_grouped > 0) {
-        hipLaunchKernelGGL(rank_kernel, dim3((n_grouped + 255) / 256), dim3(256), 0, st, sa);
-        SK_HIP(hipGetLastError());
+        SK_LAUNCH(rank_kernel, dim3((n_grouped + 255) / 256), dim3(256), 0, st, sa);
+        SK_HIP(skrt::getLastError());
     }
     lap("E2 sets");
 
@@ -2592,11 +2592,11 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
     fa.n_seg8 = B.n_seg8.as<uint8_t>();
     fa.ref_outside = B.counters.as<int32_t>() + (Caps::K + 8 + DYN_REF_OUTSIDE);
     // (byte patterns: 0x7f7f7f7f is large enough to stand for "no lower bound yet", 0x80808080 is below any position / index)
-    SK_HIP(hipMemsetAsync(B.minmax_arena.p, 0x7f, minmax_p[2].off, st));                               // win_begin, ins_lo
-    SK_HIP(hipMemsetAsync(static_cast<char*>(B.minmax_arena.p) + minmax_p[2].off, 0x80, minmax_bytes - minmax_p[2].off, st)); // win_end, ins_hi
-    if (n_cals > 0) hipLaunchKernelGGL(pool_bounds_kernel, dim3((n_cals + 255) / 256), dim3(256), 0, st, fa);
-    hipLaunchKernelGGL(pool_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::memsetAsync(B.minmax_arena.p, 0x7f, minmax_p[2].off, st));                               // win_begin, ins_lo
+    SK_HIP(skrt::memsetAsync(static_cast<char*>(B.minmax_arena.p) + minmax_p[2].off, 0x80, minmax_bytes - minmax_p[2].off, st)); // win_end, ins_hi
+    if (n_cals > 0) SK_LAUNCH(pool_bounds_kernel, dim3((n_cals + 255) / 256), dim3(256), 0, st, fa);
+    SK_LAUNCH(pool_layout_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
+    SK_HIP(skrt::getLastError());
     // ---- flattening + scoring.  The default is F5 (flatten_score_kernel): one launch from the records to the scores, no layout pass
     // and no host wait before stage 3.  F1-F3 + A1c (the staged chain: ops, entries, column words through HBM) run when the job
     // holds a read F5 turns down, when the host wants the alignments without scores, and with $SK_A5_FUSED=0 (tests: both chains).
@@ -2690,18 +2690,18 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
             if (n_light > 0) {
                 s3.list = B.s3_list.as<int32_t>();
                 s3.lds_cals = light_cals;
-                hipLaunchKernelGGL(stage3_kernel<1>, dim3(n_light), dim3(64), lds_bytes(light_cals), st, s3);
+                SK_LAUNCH(stage3_kernel<1>, dim3(n_light), dim3(64), lds_bytes(light_cals), st, s3);
             }
             if (n_heavy > 0) {
                 s3.list = B.s3_list.as<int32_t>() + (n - n_heavy);
                 s3.lds_cals = std::min(max_cals, lds_cals); // (a read with more uses the arrays in HBM)
                 // four wavefronts per read: the loops over the read's alignments go four times as wide, lane 0's share stays
                 static const bool one_wave = std::getenv("SK_STAGE3_ONE_WAVE") != nullptr; // (diagnostics)
-                if (one_wave) hipLaunchKernelGGL(stage3_kernel<1>, dim3(n_heavy), dim3(64), lds_bytes(s3.lds_cals), st, s3);
-                else hipLaunchKernelGGL(stage3_kernel<4>, dim3(n_heavy), dim3(256), lds_bytes(s3.lds_cals), st, s3);
+                if (one_wave) SK_LAUNCH(stage3_kernel<1>, dim3(n_heavy), dim3(64), lds_bytes(s3.lds_cals), st, s3);
+                else SK_LAUNCH(stage3_kernel<4>, dim3(n_heavy), dim3(256), lds_bytes(s3.lds_cals), st, s3);
             }
             if (timing) std::fprintf(stderr, "[enum-dev] stage 3: %d reads with at most %d candidate alignments, %d with more (up to %d)\n", n_light, light_cals, n_heavy, max_cals);
-            SK_HIP(hipGetLastError());
+            SK_HIP(skrt::getLastError());
             D2H(h_s3_out, s3_out, sizeof(sk3::Out) * size_t(n));
             out->stage3 = B.h_s3_out.as<sk3::Out>();
             lap("S3 stage 3");
@@ -2721,14 +2721,14 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         fs.write_cals = 0;
         fs.dbg = nullptr;
         launch_flatten_score(n, st, fs);
-        SK_HIP(hipGetLastError());
+        SK_HIP(skrt::getLastError());
         lap("F5 flatten + score");
         if (in->want_stage3) {
             out->cals = nullptr; // (they stay here, in the pool: sk_enum_device_fetch_cals gathers them when the host asks)
         } else {
             RES(cals, sizeof(PCal) * size_t(n_cals));
-            hipLaunchKernelGGL(gather_cals_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa.pool, fa.list, n_cals, B.cals.as<PCal>());
-            SK_HIP(hipGetLastError());
+            SK_LAUNCH(gather_cals_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa.pool, fa.list, n_cals, B.cals.as<PCal>());
+            SK_HIP(skrt::getLastError());
             g_cals_gathered = true;
             D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
         }
@@ -2744,7 +2744,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         if (after_scores()) return 1;
         if (fetch_zero(B.counters, B.counters, 4 * size_t(n_counters))) return 1; // (n_unhandled)
         if (fetch_zero(B.status, B.status, 4 * size_t(n))) return 1;               // (F5 may have turned reads down: ST_FAIL)
-        SK_HIP(hipStreamSynchronize(st));
+        SK_HIP(skrt::streamSynchronize(st));
         if (B.h_counters.as<int32_t>()[Caps::K + 7] > 0) staged = true; // a read outside F5's form: the staged chain over the job
     }
     if (staged) {
@@ -2753,12 +2753,12 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         cals_in_set_order = true;
         g_cals_gathered = true; // (flatten_kernel below writes them)
         if (n_cals > 0) {
-            hipLaunchKernelGGL(op_count_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
-            SK_HIP(hipGetLastError());
+            SK_LAUNCH(op_count_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+            SK_HIP(skrt::getLastError());
         }
         if (fetch_zero(B.status, B.hap_len, 4 * size_t(n))) return 1; // status, hap_len (the host has made bytes of its copy of warn)
         D2H(h_n_ops, n_ops, 4 * size_t(n_cals));
-        SK_HIP(hipStreamSynchronize(st));
+        SK_HIP(skrt::streamSynchronize(st));
         lap("L1+L2 layout");
 
         const int32_t* h_hap_len = B.h_hap_len.as<int32_t>();
@@ -2790,11 +2790,11 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         RES(colmat_off, 8 * size_t(n + 1));
 
         if (n_cals > 0) {
-            SK_HIP(hipMemcpyAsync(B.hap_off.p, h_hap_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
-            SK_HIP(hipMemcpyAsync(B.op_off.p, h_op_off, 8 * size_t(n_cals + 1), hipMemcpyHostToDevice, st));
-            SK_HIP(hipMemsetAsync(B.mask_arena.p, 0, mask_bytes, st)); // evmask, addmask
-            SK_HIP(hipMemsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), 4 * size_t(colmat_words) + 16, st));
-            SK_HIP(hipMemcpyAsync(B.colmat_off.p, h_colmat_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
+            SK_HIP(skrt::memcpyAsync(B.hap_off.p, h_hap_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
+            SK_HIP(skrt::memcpyAsync(B.op_off.p, h_op_off, 8 * size_t(n_cals + 1), hipMemcpyHostToDevice, st));
+            SK_HIP(skrt::memsetAsync(B.mask_arena.p, 0, mask_bytes, st)); // evmask, addmask
+            SK_HIP(skrt::memsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), 4 * size_t(colmat_words) + 16, st));
+            SK_HIP(skrt::memcpyAsync(B.colmat_off.p, h_colmat_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
             fa.hap_off = B.hap_off.as<int64_t>();
             fa.op_off = B.op_off.as<int64_t>();
             fa.hap_code = B.hap_code.as<uint8_t>();
@@ -2805,17 +2805,17 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
             fa.colmat = B.colmat.as<uint8_t>();
             fa.colmat_off = B.colmat_off.as<int64_t>();
             fa.addmask = B.addmask.as<uint32_t>();
-            hipLaunchKernelGGL(pool_fill_kernel, dim3(n), dim3(64), 0, st, fa);
-            hipLaunchKernelGGL(flatten_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
-            SK_HIP(hipGetLastError());
+            SK_LAUNCH(pool_fill_kernel, dim3(n), dim3(64), 0, st, fa);
+            SK_LAUNCH(flatten_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+            SK_HIP(skrt::getLastError());
             if (in->want_scores && in->want_stage3) out->cals = nullptr; // (they stay here: sk_enum_device_fetch_cals)
             else D2H(h_cals, cals, sizeof(PCal) * size_t(n_cals));
             if (in->want_scores) {
                 // F3: a wave per read ($SK_F3_KERNEL = thread pins the thread-per-alignment form; the tests run both)
                 const bool f3_thread = (std::getenv("SK_F3_KERNEL") != nullptr && std::strcmp(std::getenv("SK_F3_KERNEL"), "thread") == 0);
-                if (f3_thread) hipLaunchKernelGGL(entries_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
-                else hipLaunchKernelGGL(entries_wave_kernel, dim3(n), dim3(64), 0, st, fa);
-                SK_HIP(hipGetLastError());
+                if (f3_thread) SK_LAUNCH(entries_kernel, dim3((n_cals + 63) / 64), dim3(64), 0, st, fa);
+                else SK_LAUNCH(entries_wave_kernel, dim3(n), dim3(64), 0, st, fa);
+                SK_HIP(skrt::getLastError());
                 lap("F1-F3 flatten");
                 sk_align_batch d;
                 std::memset(&d, 0, sizeof(d));
@@ -2858,7 +2858,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
     }
     if (fetch_zero(B.consulted, B.consulted, size_t(in->n_tab))) return 1;
     if (fetch_zero(B.counters, B.counters, 4 * size_t(n_counters))) return 1;
-    SK_HIP(hipStreamSynchronize(st));
+    SK_HIP(skrt::streamSynchronize(st));
     // (when F5 turned a read down both chains filled the pools: the count may be double -- what matters to the caller is zero or not)
     out->ref_reads_outside = B.h_counters.as<int32_t>()[Caps::K + 8 + DYN_REF_OUTSIDE];
     lap("done");
@@ -2897,8 +2897,9 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
     SK_REQUIRE_INIT();
     if (!g_last.valid) return sk_fail("sk_enum_device_rescore: no device run with scores to repeat");
     if (reps <= 0 || !out_ms) return sk_fail("sk_enum_device_rescore: bad argument");
+    if (skrt::remote()) return sk_fail("sk_enum_device_rescore: a timing entry point (events); not carried by the broker -- unset STRELKA_AMD_BROKER");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
     EnumBuffers& B = bufs();
     const FlatArgs& fa = g_last.fa;
@@ -2910,14 +2911,14 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
         FusedScoreArgs fs = g_last.fs;
         const size_t nb = size_t(g_last.n) * 8;
         unsigned long long* d = nullptr;
-        SK_HIP(hipMalloc(reinterpret_cast<void**>(&d), nb * 8));
-        SK_HIP(hipMemsetAsync(d, 0, nb * 8, st));
+        SK_HIP(skrt::malloc_(reinterpret_cast<void**>(&d), nb * 8));
+        SK_HIP(skrt::memsetAsync(d, 0, nb * 8, st));
         fs.dbg = d;
         launch_flatten_score(g_last.n, st, fs);
         std::vector<unsigned long long> h(nb);
-        SK_HIP(hipMemcpyAsync(h.data(), d, nb * 8, hipMemcpyDeviceToHost, st));
-        SK_HIP(hipStreamSynchronize(st));
-        (void)hipFree(d);
+        SK_HIP(skrt::memcpyAsync(h.data(), d, nb * 8, hipMemcpyDeviceToHost, st));
+        SK_HIP(skrt::streamSynchronize(st));
+        (void)skrt::free_(d);
         double sum[8] = { 0 };
         unsigned long long first = ~0ull, last = 0;
         int nblk = 0;
@@ -2960,18 +2961,18 @@ extern "C" int sk_enum_device_rescore(const int32_t reps, float* out_ms, int32_t
             launch_flatten_score(g_last.n, st, g_last.fs);
             continue;
         }
-        SK_HIP(hipMemsetAsync(B.mask_arena.p, 0, g_last.mask_bytes, st));
-        SK_HIP(hipMemsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), g_last.colmat_bytes, st));
-        hipLaunchKernelGGL(pool_fill_kernel, dim3(g_last.n), dim3(64), 0, st, fa);
-        hipLaunchKernelGGL(flatten_kernel, dim3((g_last.n_cals + 63) / 64), dim3(64), 0, st, fa);
+        SK_HIP(skrt::memsetAsync(B.mask_arena.p, 0, g_last.mask_bytes, st));
+        SK_HIP(skrt::memsetAsync(B.colmat.p, SK_SEL_NONE | (SK_SEL_NONE << 4), g_last.colmat_bytes, st));
+        SK_LAUNCH(pool_fill_kernel, dim3(g_last.n), dim3(64), 0, st, fa);
+        SK_LAUNCH(flatten_kernel, dim3((g_last.n_cals + 63) / 64), dim3(64), 0, st, fa);
         const bool f3_thread = (std::getenv("SK_F3_KERNEL") != nullptr && std::strcmp(std::getenv("SK_F3_KERNEL"), "thread") == 0);
-        if (f3_thread) hipLaunchKernelGGL(entries_kernel, dim3((g_last.n_cals + 63) / 64), dim3(64), 0, st, fa);
-        else hipLaunchKernelGGL(entries_wave_kernel, dim3(g_last.n), dim3(64), 0, st, fa);
+        if (f3_thread) SK_LAUNCH(entries_kernel, dim3((g_last.n_cals + 63) / 64), dim3(64), 0, st, fa);
+        else SK_LAUNCH(entries_wave_kernel, dim3(g_last.n), dim3(64), 0, st, fa);
         if (sk_score_alignments_launch_hostleg(&g_last.d, g_last.scores, st)) return 1;
     }
     SK_HIP(hipEventRecord(e1, st));
     SK_HIP(hipEventSynchronize(e1));
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::getLastError());
     SK_HIP(hipEventElapsedTime(out_ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

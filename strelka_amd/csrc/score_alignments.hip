@@ -640,10 +640,10 @@ static int score_alignments_launch(const sk_align_batch* b, double* dev_out_lnp,
         const size_t lds_cols = pw * WAVES_PER_BLOCK + 2 * (SK_NQ + 1) * sizeof(double);
         if (lds_cols <= 64 * 1024) {
             const int blocks = (b->n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-            if (maxL > 160) hipLaunchKernelGGL(score_wave_per_read_cols_long, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds_cols, st, a);
-            else if (from_host_entry) hipLaunchKernelGGL(score_wave_per_read_cols_hostbuf, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds_cols, st, a);
-            else hipLaunchKernelGGL(score_wave_per_read_cols, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds_cols, st, a);
-            SK_HIP(hipGetLastError());
+            if (maxL > 160) SK_LAUNCH(score_wave_per_read_cols_long, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds_cols, st, a);
+            else if (from_host_entry) SK_LAUNCH(score_wave_per_read_cols_hostbuf, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds_cols, st, a);
+            else SK_LAUNCH(score_wave_per_read_cols, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds_cols, st, a);
+            SK_HIP(skrt::getLastError());
             return 0;
         }
         a.lds_tab_bytes = align16(ROW_BYTES * std::max(maxL, 1));
@@ -651,14 +651,14 @@ static int score_alignments_launch(const sk_align_batch* b, double* dev_out_lnp,
     }
     if (prepared && maxL > 0 && maxL <= SK_ENT_MAX_READ_LEN && maxP > 0 && maxP <= SK_ENT_MAX_POOL && lds <= 64 * 1024) {
         const int blocks = (b->n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        if (from_host_entry) hipLaunchKernelGGL(score_wave_per_read_hostbuf, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds, st, a);
-        else hipLaunchKernelGGL(score_wave_per_read, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds, st, a);
+        if (from_host_entry) SK_LAUNCH(score_wave_per_read_hostbuf, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds, st, a);
+        else SK_LAUNCH(score_wave_per_read, dim3(blocks), dim3(WAVES_PER_BLOCK * WAVE), lds, st, a);
     } else {
         const int threads = 256;
         const int blocks = (b->n_cals + threads - 1) / threads;
-        hipLaunchKernelGGL(score_thread_per_cal, dim3(blocks), dim3(threads), 0, st, a);
+        SK_LAUNCH(score_thread_per_cal, dim3(blocks), dim3(threads), 0, st, a);
     }
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -685,9 +685,9 @@ extern "C" int sk_score_alignments_dev_generic(const sk_align_batch* b, double* 
     a.out = dev_out_lnp;
     a.lds_tab_bytes = a.lds_hap_bytes = 0;
     const int threads = 256;
-    hipLaunchKernelGGL(score_thread_per_cal, dim3((b->n_cals + threads - 1) / threads), dim3(threads), 0,
+    SK_LAUNCH(score_thread_per_cal, dim3((b->n_cals + threads - 1) / threads), dim3(threads), 0,
                        static_cast<hipStream_t>(hip_stream), a);
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -737,7 +737,7 @@ extern "C" int sk_score_alignments(const sk_align_batch* hb, double* out_lnp)
         if (hb->read_qual[i] > 70) return sk_fail("Attempting to lookup basecall quality score which exceeds the maximum cached score of 70");
 
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     SkArena ar;
     const size_t need = sk_align256(sizeof(int64_t) * (n + 1)) * 2 + sk_align256(sizeof(int32_t) * (n + 1)) +
                         sk_align256(sizeof(int64_t) * (n_cals + 1)) + sk_align256(n_bases) * 2 + sk_align256(n_hap) +
@@ -764,7 +764,7 @@ extern "C" int sk_score_alignments(const sk_align_batch* hb, double* out_lnp)
 #define UP(field, T, count)                                                                              \
     {                                                                                                    \
         T* p = ar.take<T>(count);                                                                        \
-        if (count) SK_HIP(hipMemcpyAsync(p, hb->field, sizeof(T) * (count), hipMemcpyHostToDevice, st)); \
+        if (count) SK_HIP(skrt::memcpyAsync(p, hb->field, sizeof(T) * (count), hipMemcpyHostToDevice, st)); \
         d.field = p;                                                                                     \
     }
     UP(read_off, int64_t, size_t(n + 1));
@@ -780,8 +780,8 @@ extern "C" int sk_score_alignments(const sk_align_batch* hb, double* out_lnp)
         const size_t ne = size_t(n_ops) + 2 * size_t(n_cals), nm = size_t(n) * size_t(d.evmask_words);
         uint32_t* pe = ar.take<uint32_t>(ne + 1);
         uint32_t* pm = ar.take<uint32_t>(nm + 1);
-        if (ne) SK_HIP(hipMemcpyAsync(pe, src_entries, 4 * ne, hipMemcpyHostToDevice, st));
-        if (nm) SK_HIP(hipMemcpyAsync(pm, src_evmask, 4 * nm, hipMemcpyHostToDevice, st));
+        if (ne) SK_HIP(skrt::memcpyAsync(pe, src_entries, 4 * ne, hipMemcpyHostToDevice, st));
+        if (nm) SK_HIP(skrt::memcpyAsync(pm, src_evmask, 4 * nm, hipMemcpyHostToDevice, st));
         d.entries = pe;
         d.evmask = pm;
     }
@@ -815,27 +815,27 @@ extern "C" int sk_score_alignments(const sk_align_batch* hb, double* out_lnp)
         } extra;
         const size_t need_extra = sk_align256(4 * (words + 1)) + sk_align256(8 * size_t(n + 1)) + sk_align256(4 * (nm + 1));
         if (extra.cap < need_extra) {
-            if (extra.p) (void)hipFree(extra.p);
+            if (extra.p) (void)skrt::free_(extra.p);
             extra.p = nullptr;
             extra.cap = 0;
-            SK_HIP(hipMalloc(&extra.p, need_extra + need_extra / 4));
+            SK_HIP(skrt::malloc_(&extra.p, need_extra + need_extra / 4));
             extra.cap = need_extra + need_extra / 4;
         }
         char* base = static_cast<char*>(extra.p);
         uint32_t* pc = reinterpret_cast<uint32_t*>(base);
         int64_t* po = reinterpret_cast<int64_t*>(base + sk_align256(4 * (words + 1)));
         uint32_t* pa = reinterpret_cast<uint32_t*>(base + sk_align256(4 * (words + 1)) + sk_align256(8 * size_t(n + 1)));
-        if (words) SK_HIP(hipMemcpyAsync(pc, src_colmat, 4 * words, hipMemcpyHostToDevice, st));
-        SK_HIP(hipMemcpyAsync(po, src_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
-        if (nm) SK_HIP(hipMemcpyAsync(pa, src_addmask, 4 * nm, hipMemcpyHostToDevice, st));
-        SK_HIP(hipStreamSynchronize(st)); // (the staging vectors above go out of scope)
+        if (words) SK_HIP(skrt::memcpyAsync(pc, src_colmat, 4 * words, hipMemcpyHostToDevice, st));
+        SK_HIP(skrt::memcpyAsync(po, src_off, 8 * size_t(n + 1), hipMemcpyHostToDevice, st));
+        if (nm) SK_HIP(skrt::memcpyAsync(pa, src_addmask, 4 * nm, hipMemcpyHostToDevice, st));
+        SK_HIP(skrt::streamSynchronize(st)); // (the staging vectors above go out of scope)
         d.colmat = pc;
         d.colmat_off = po;
         d.addmask = pa;
     }
     double* dout = ar.take<double>(n_cals);
     if (score_alignments_launch(&d, dout, st, true)) return 1;
-    SK_HIP(hipMemcpyAsync(out_lnp, dout, sizeof(double) * n_cals, hipMemcpyDeviceToHost, st));
-    SK_HIP(hipStreamSynchronize(st));
+    SK_HIP(skrt::memcpyAsync(out_lnp, dout, sizeof(double) * n_cals, hipMemcpyDeviceToHost, st));
+    SK_HIP(skrt::streamSynchronize(st));
     return 0;
 }

@@ -3,7 +3,7 @@
 
 #include "strelka_amd.h"
 
-#include <hip/hip_runtime.h>
+#include "sk_rt.h"
 
 #include <cstdint>
 #include <cstring>
@@ -57,6 +57,9 @@ struct SkContext
     size_t arena_bytes = 0;
     // sticky error bits raised by kernels on input the reference would have thrown on (sk_check_device_errors)
     unsigned* dev_error_flags = nullptr;
+    // per-kernel attributes raised on this context's device (cleared with the context: another device starts from the defaults)
+    size_t global_align_lds_allowed = 0;
+    bool inflate_scalar_lds_allowed = false;
 };
 enum { SK_DEVERR_QSCORE = 1u }; // a basecall quality above 70 reached a scoring kernel (qscore_cache.cpp:53-75 throws)
 
@@ -67,7 +70,7 @@ int sk_fail(const std::string& msg);
 #define SK_HIP(expr)                                                                                          \
     do {                                                                                                      \
         hipError_t _e = (expr);                                                                               \
-        if (_e != hipSuccess) return sk_fail(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+        if (_e != hipSuccess) return sk_fail(std::string(#expr) + ": " + skrt::errorString(_e));              \
     } while (0)
 
 #define SK_REQUIRE_INIT()                                                                    \
@@ -105,6 +108,13 @@ struct SkStage
     size_t in_cap = 0, out_cap = 0, in_used = 0, out_used = 0;
     char* d_in = nullptr;
     char* d_out = nullptr;
+    hipStream_t in_flight = nullptr; // the stream of an upload() that no download_and_wait() has followed yet
+    /// An entry point that fails between upload() and download_and_wait() leaves kernels running over the page-locked mirrors, which
+    /// the next call refills or frees: the stage waits for them before it goes.
+    ~SkStage()
+    {
+        if (in_flight) (void)skrt::streamSynchronize(in_flight);
+    }
     /// room for `in_bytes` of inputs and `out_bytes` of outputs (sums of the arrays' sizes; alignment padding is added here) plus
     /// `extra_bytes` of device scratch the caller takes from `ar` afterwards
     int begin(size_t in_bytes, size_t out_bytes, size_t extra_bytes, int n_arrays);

@@ -131,11 +131,11 @@ int SkArena::reserve(size_t bytes)
     SkContext& c = sk_ctx();
     bytes = sk_align256(bytes) + 4096;
     if (c.arena_bytes < bytes) {
-        if (c.arena) (void)hipFree(c.arena);
+        if (c.arena) (void)skrt::free_(c.arena);
         c.arena = nullptr;
         c.arena_bytes = 0;
         size_t want = bytes + bytes / 4;
-        SK_HIP(hipMalloc(&c.arena, want));
+        SK_HIP(skrt::malloc_(&c.arena, want));
         c.arena_bytes = want;
     }
     base = static_cast<char*>(c.arena);
@@ -165,11 +165,11 @@ StageMirrors& stage_mirrors()
 int grow_pinned(void*& p, size_t& cap, const size_t bytes)
 {
     if (bytes <= cap) return 0;
-    if (p) (void)hipHostFree(p);
+    if (p) (void)skrt::hostFree(p);
     p = nullptr;
     cap = 0;
     const size_t want = bytes + bytes / 4 + 4096;
-    SK_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    SK_HIP(skrt::hostMalloc(&p, want));
     cap = want;
     return 0;
 }
@@ -196,18 +196,20 @@ int SkStage::upload(hipStream_t st)
 {
     if (in_used > in_cap || out_used > out_cap) return sk_fail("strelka_amd: a staged call's arrays outgrew the room asked for");
     const uint32_t n16 = uint32_t((in_used + 15) / 16);
-    if (n16) hipLaunchKernelGGL(stage_copy_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 256u)), dim3(256), 0, st, reinterpret_cast<const uint4*>(h_in),
+    if (n16) SK_LAUNCH(stage_copy_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 256u)), dim3(256), 0, st, reinterpret_cast<const uint4*>(h_in),
                                 reinterpret_cast<uint4*>(d_in), n16);
+    in_flight = st;
     return 0;
 }
 
 int SkStage::download_and_wait(hipStream_t st)
 {
     const uint32_t n16 = uint32_t((out_used + 15) / 16);
-    if (n16) hipLaunchKernelGGL(stage_copy_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 256u)), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_out),
+    if (n16) SK_LAUNCH(stage_copy_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 256u)), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_out),
                                 reinterpret_cast<uint4*>(h_out), n16);
-    SK_HIP(hipGetLastError());
-    SK_HIP(hipStreamSynchronize(st));
+    in_flight = nullptr;
+    SK_HIP(skrt::getLastError());
+    SK_HIP(skrt::streamSynchronize(st));
     return 0;
 }
 
@@ -268,11 +270,19 @@ static void sk_pre_runtime_env()
 
 int sk_device_count(void)
 {
+    if (skrt::remote()) { // a broker client asks the broker of device 0 (started on demand)
+        std::string why;
+        const int n = skrt::r_device_count(&why);
+        if (n <= 0) sk_set_error(why);
+        return n;
+    }
     sk_pre_runtime_env();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+int sk_broker_client(void) { return skrt::remote() ? 1 : 0; }
 
 void* sk_host_alloc(size_t bytes)
 {
@@ -281,9 +291,9 @@ void* sk_host_alloc(size_t bytes)
         return nullptr;
     }
     void* p = nullptr;
-    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    const hipError_t e = skrt::hostMalloc(&p, bytes ? bytes : 1);
     if (e != hipSuccess) {
-        sk_fail(std::string("sk_host_alloc: ") + hipGetErrorString(e));
+        sk_fail(std::string("sk_host_alloc: ") + skrt::errorString(e));
         return nullptr;
     }
     return p;
@@ -291,7 +301,7 @@ void* sk_host_alloc(size_t bytes)
 
 void sk_host_free(void* p)
 {
-    if (p) (void)hipHostFree(p);
+    if (p) (void)skrt::hostFree(p);
 }
 
 int sk_init(int device)
@@ -300,7 +310,7 @@ int sk_init(int device)
     if (c.ready && c.device == device) {
         // (the current device is a property of the calling THREAD: a caller that initialised on a worker thread calls again from the
         // thread that will make the calls)
-        SK_HIP(hipSetDevice(device));
+        SK_HIP(skrt::setDevice(device));
         return 0;
     }
     if (c.ready) sk_shutdown();
@@ -310,6 +320,13 @@ int sk_init(int device)
     auto lap = [&](const char* what) {
         if (timing) std::fprintf(stderr, "[sk_init] %-34s t=%.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
+    if (skrt::remote()) {
+        // a client of the device's broker: no GPU context in this process (sk_rt.h); the broker has checked the device
+        std::string why;
+        if (skrt::r_connect(device, &why)) return sk_fail(why);
+        c.blocking_sync = true; // (a client's wait is a futex wait)
+        lap("broker connection");
+    } else {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -317,7 +334,7 @@ int sk_init(int device)
                        "); this library has no CPU fallback");
     if (device < 0 || device >= n) return sk_fail("strelka_amd: device index out of range");
     lap("hipGetDeviceCount (runtime start)");
-    SK_HIP(hipSetDevice(device));
+    SK_HIP(skrt::setDevice(device));
     // A process that waits for the device SLEEPS: sixteen caller processes share a GPU and a CPU quota, and a wait spent
     // spinning is a core taken from a process that has host work to do (profiles/r03_v5_thread_cpu_seconds.txt: under contention
     // the callers' CPU seconds doubled, all of it in their main threads).  The flags belong to the CURRENT device: set after
@@ -332,16 +349,18 @@ int sk_init(int device)
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return sk_fail(std::string("strelka_amd: built for gfx950 only, device is ") + prop.gcnArchName);
     lap("device properties");
+    }
     build_tables(c.host_tables);
     lap("host tables");
     c.libm_restated = host_libm_matches_restatement();
     lap("libm comparison");
-    SK_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev_tables), sizeof(SkTables)));
+    SK_HIP(skrt::malloc_(reinterpret_cast<void**>(&c.dev_tables), sizeof(SkTables)));
     lap("first hipMalloc (context)");
-    SK_HIP(hipMemcpy(c.dev_tables, &c.host_tables, sizeof(SkTables), hipMemcpyHostToDevice));
-    SK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    SK_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev_error_flags), sizeof(unsigned)));
-    SK_HIP(hipMemset(c.dev_error_flags, 0, sizeof(unsigned)));
+    SK_HIP(skrt::memcpy_(c.dev_tables, &c.host_tables, sizeof(SkTables), hipMemcpyHostToDevice));
+    if (skrt::remote()) c.stream = skrt::r_stream();
+    else SK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    SK_HIP(skrt::malloc_(reinterpret_cast<void**>(&c.dev_error_flags), sizeof(unsigned)));
+    SK_HIP(skrt::memset_(c.dev_error_flags, 0, sizeof(unsigned)));
     lap("tables up, stream, flags");
     c.device = device;
     c.ready = true;
@@ -352,11 +371,13 @@ void sk_shutdown(void)
 {
     SkContext& c = g_ctx;
     if (!c.ready) return;
-    (void)hipSetDevice(c.device);
-    if (c.stream) (void)hipStreamDestroy(c.stream);
-    if (c.dev_tables) (void)hipFree(c.dev_tables);
-    if (c.dev_error_flags) (void)hipFree(c.dev_error_flags);
-    if (c.arena) (void)hipFree(c.arena);
+    (void)skrt::setDevice(c.device);
+    if (c.stream && !skrt::remote()) (void)hipStreamDestroy(c.stream);
+    if (c.dev_tables) (void)skrt::free_(c.dev_tables);
+    if (c.dev_error_flags) (void)skrt::free_(c.dev_error_flags);
+    if (c.arena) (void)skrt::free_(c.arena);
+    // (a broker client keeps its connection: the process's grown buffers -- the job's, the streams', the staged calls' -- stay valid
+    // across sk_shutdown / sk_init as they do in a process with a context of its own; the broker frees them when the process ends)
     c = SkContext();
 }
 
@@ -364,11 +385,11 @@ int sk_check_device_errors(void)
 {
     SK_REQUIRE_INIT();
     SkContext& c = sk_ctx();
-    SK_HIP(hipSetDevice(c.device));
+    SK_HIP(skrt::setDevice(c.device));
     unsigned flags = 0;
-    SK_HIP(hipMemcpy(&flags, c.dev_error_flags, sizeof(unsigned), hipMemcpyDeviceToHost)); // synchronises the device
+    SK_HIP(skrt::memcpy_(&flags, c.dev_error_flags, sizeof(unsigned), hipMemcpyDeviceToHost)); // synchronises the device
     if (flags == 0) return 0;
-    SK_HIP(hipMemset(c.dev_error_flags, 0, sizeof(unsigned)));
+    SK_HIP(skrt::memset_(c.dev_error_flags, 0, sizeof(unsigned)));
     if (flags & SK_DEVERR_QSCORE)
         return sk_fail("Attempting to lookup basecall quality score which exceeds the maximum cached score of 70 (seen by a *_dev kernel)");
     return sk_fail("strelka_amd: a kernel reported an error");

@@ -655,15 +655,15 @@ static int upload_somatic_pileup(const sk_pileup_batch* hb, const int n, SkArena
         if (SKC_BASE(hb->calls[i]) > 3) return sk_fail("somatic pileup batch: basecall with base_id > 3");
     d = *hb;
     int64_t* off = ar.take<int64_t>(n + 1);
-    SK_HIP(hipMemcpyAsync(off, hb->call_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(off, hb->call_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
     d.call_off = off;
     uint16_t* calls = ar.take<uint16_t>(tc);
-    if (tc) SK_HIP(hipMemcpyAsync(calls, hb->calls, 2 * tc, hipMemcpyHostToDevice, st));
+    if (tc) SK_HIP(skrt::memcpyAsync(calls, hb->calls, 2 * tc, hipMemcpyHostToDevice, st));
     d.calls = calls;
     d.de = nullptr;
     d.ploidy = nullptr;
     uint8_t* rb = ar.take<uint8_t>(n);
-    SK_HIP(hipMemcpyAsync(rb, hb->ref_base, n, hipMemcpyHostToDevice, st));
+    SK_HIP(skrt::memcpyAsync(rb, hb->ref_base, n, hipMemcpyHostToDevice, st));
     d.ref_base = rb;
     return 0;
 }
@@ -694,15 +694,15 @@ int sk_somatic_snv_call_batch_dev(const sk_pileup_batch* n, const sk_pileup_batc
     a.nonsom_q = nullptr;
     derive(*opt, is_forced_output, a.d);
     // skipped loci report an all-zero record (is_called = 0)
-    SK_HIP(hipMemsetAsync(dev_out, 0, sizeof(sk_somatic_snv_call) * size_t(n->n_loci), st));
-    SK_HIP(hipMemsetAsync(a.work, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(somatic_classify_kernel, dim3((n->n_loci + CLS_THREADS - 1) / CLS_THREADS), dim3(CLS_THREADS), 0, st, a);
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::memsetAsync(dev_out, 0, sizeof(sk_somatic_snv_call) * size_t(n->n_loci), st));
+    SK_HIP(skrt::memsetAsync(a.work, 0, sizeof(unsigned), st));
+    SK_LAUNCH(somatic_classify_kernel, dim3((n->n_loci + CLS_THREADS - 1) / CLS_THREADS), dim3(CLS_THREADS), 0, st, a);
+    SK_HIP(skrt::getLastError());
     // sized for every locus being queued; blocks past the end of the queue exit at once
-    hipLaunchKernelGGL(somatic_lhood_kernel, dim3((n->n_loci + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a);
-    SK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(somatic_posterior_kernel, dim3((n->n_loci + POST_THREADS - 1) / POST_THREADS), dim3(POST_THREADS), 0, st, a);
-    SK_HIP(hipGetLastError());
+    SK_LAUNCH(somatic_lhood_kernel, dim3((n->n_loci + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a);
+    SK_HIP(skrt::getLastError());
+    SK_LAUNCH(somatic_posterior_kernel, dim3((n->n_loci + POST_THREADS - 1) / POST_THREADS), dim3(POST_THREADS), 0, st, a);
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -716,7 +716,7 @@ int sk_somatic_snv_call_batch(const sk_pileup_batch* hn, const sk_pileup_batch* 
     if (n <= 0) return 0;
     if (std::memcmp(hn->ref_base, ht->ref_base, n) != 0) return sk_fail("sk_somatic_snv_call_batch: ref_base differs");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     // the two uploads and the output share one arena
     SkArena ar;
     const size_t need = 2 * (sk_align256(sizeof(int64_t) * (n + 1)) + sk_align256(n) * 2 + 16 * 256) +
@@ -729,8 +729,8 @@ int sk_somatic_snv_call_batch(const sk_pileup_batch* hn, const sk_pileup_batch* 
     sk_somatic_snv_call* dout = ar.take<sk_somatic_snv_call>(n);
     unsigned* work = ar.take<unsigned>(size_t(n) + 4);
     if (sk_somatic_snv_call_batch_dev(&dn, &dt, opt, is_forced_output, dout, work, ctx.stream)) return 1;
-    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_snv_call) * n, hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    SK_HIP(skrt::memcpyAsync(out, dout, sizeof(sk_somatic_snv_call) * n, hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(skrt::streamSynchronize(ctx.stream));
     return 0;
 }
 
@@ -788,13 +788,13 @@ int sk_somatic_snv_call_tiers_dev(const sk_pileup_batch* n1, const sk_pileup_bat
     ta.out = dev_out;
 
     const dim3 g256((n + 255) / 256), b256(256);
-    SK_HIP(hipMemsetAsync(work1, 0, sizeof(unsigned), st));
-    SK_HIP(hipMemsetAsync(work2, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(somatic_prefill_kernel, g256, b256, 0, st, ta);
-    hipLaunchKernelGGL(somatic_classify_kernel, dim3((n + CLS_THREADS - 1) / CLS_THREADS), dim3(CLS_THREADS), 0, st, a);
-    hipLaunchKernelGGL(somatic_lhood_kernel, dim3((n + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a);
-    hipLaunchKernelGGL(somatic_posterior_kernel, dim3((n + POST_THREADS - 1) / POST_THREADS), dim3(POST_THREADS), 0, st, a);
-    SK_HIP(hipGetLastError());
+    SK_HIP(skrt::memsetAsync(work1, 0, sizeof(unsigned), st));
+    SK_HIP(skrt::memsetAsync(work2, 0, sizeof(unsigned), st));
+    SK_LAUNCH(somatic_prefill_kernel, g256, b256, 0, st, ta);
+    SK_LAUNCH(somatic_classify_kernel, dim3((n + CLS_THREADS - 1) / CLS_THREADS), dim3(CLS_THREADS), 0, st, a);
+    SK_LAUNCH(somatic_lhood_kernel, dim3((n + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a);
+    SK_LAUNCH(somatic_posterior_kernel, dim3((n + POST_THREADS - 1) / POST_THREADS), dim3(POST_THREADS), 0, st, a);
+    SK_HIP(skrt::getLastError());
     if (a.nonsomatic) {
         NonsomArgs na;
         na.work = work1;
@@ -820,23 +820,23 @@ int sk_somatic_snv_call_tiers_dev(const sk_pileup_batch* n1, const sk_pileup_bat
             volatile float half = 0.5f;
             na.ln_half = std::log(half);
         }
-        hipLaunchKernelGGL(somatic_nonsomatic_kernel, dim3((n + NS_THREADS - 1) / NS_THREADS), dim3(NS_THREADS), 0, st, na);
-        SK_HIP(hipGetLastError());
+        SK_LAUNCH(somatic_nonsomatic_kernel, dim3((n + NS_THREADS - 1) / NS_THREADS), dim3(NS_THREADS), 0, st, na);
+        SK_HIP(skrt::getLastError());
     }
     if (is_tier2) {
-        hipLaunchKernelGGL(somatic_tier2_queue_kernel, g256, b256, 0, st, ta);
+        SK_LAUNCH(somatic_tier2_queue_kernel, g256, b256, 0, st, ta);
         SomArgs a2 = a;
         a2.n = *n2;
         a2.t = *t2;
         a2.out = rec2;
         a2.work = work2;
         a2.nonsom_q = nullptr;
-        hipLaunchKernelGGL(somatic_lhood_kernel, dim3((n + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a2);
-        hipLaunchKernelGGL(somatic_posterior_kernel, dim3((n + POST_THREADS - 1) / POST_THREADS), dim3(POST_THREADS), 0, st, a2);
-        SK_HIP(hipGetLastError());
+        SK_LAUNCH(somatic_lhood_kernel, dim3((n + SOM_THREADS - 1) / SOM_THREADS), dim3(SOM_THREADS), 0, st, a2);
+        SK_LAUNCH(somatic_posterior_kernel, dim3((n + POST_THREADS - 1) / POST_THREADS), dim3(POST_THREADS), 0, st, a2);
+        SK_HIP(skrt::getLastError());
     }
-    hipLaunchKernelGGL(somatic_combine_kernel, g256, b256, 0, st, ta);
-    SK_HIP(hipGetLastError());
+    SK_LAUNCH(somatic_combine_kernel, g256, b256, 0, st, ta);
+    SK_HIP(skrt::getLastError());
     return 0;
 }
 
@@ -854,7 +854,7 @@ int sk_somatic_snv_call_tiers(const sk_pileup_batch* hn1, const sk_pileup_batch*
         (hn2 && (std::memcmp(hn1->ref_base, hn2->ref_base, n) != 0 || std::memcmp(hn1->ref_base, ht2->ref_base, n) != 0)))
         return sk_fail("sk_somatic_snv_call_tiers: ref_base differs between the batches");
     SkContext& ctx = sk_ctx();
-    SK_HIP(hipSetDevice(ctx.device));
+    SK_HIP(skrt::setDevice(ctx.device));
     SkArena ar;
     size_t need = pileup_upload_bytes(hn1, n) + pileup_upload_bytes(ht1, n) + sk_align256(size_t(n)) +
                   sk_align256(sizeof(sk_somatic_snv_genotype) * size_t(n)) + sk_somatic_snv_tiers_scratch_bytes(n) + 4096;
@@ -866,15 +866,15 @@ int sk_somatic_snv_call_tiers(const sk_pileup_batch* hn1, const sk_pileup_batch*
     uint8_t* dforced = nullptr;
     if (is_forced_output) {
         dforced = ar.take<uint8_t>(n);
-        SK_HIP(hipMemcpyAsync(dforced, is_forced_output, n, hipMemcpyHostToDevice, ctx.stream));
+        SK_HIP(skrt::memcpyAsync(dforced, is_forced_output, n, hipMemcpyHostToDevice, ctx.stream));
     }
     sk_somatic_snv_genotype* dout = ar.take<sk_somatic_snv_genotype>(n);
     void* scratch = ar.take<char>(sk_somatic_snv_tiers_scratch_bytes(n));
     if (sk_somatic_snv_call_tiers_dev(&dn1, &dt1, hn2 ? &dn2 : nullptr, hn2 ? &dt2 : nullptr, opt, dforced, is_compute_nonsomatic,
                                       dout, scratch, ctx.stream))
         return 1;
-    SK_HIP(hipMemcpyAsync(out, dout, sizeof(sk_somatic_snv_genotype) * size_t(n), hipMemcpyDeviceToHost, ctx.stream));
-    SK_HIP(hipStreamSynchronize(ctx.stream));
+    SK_HIP(skrt::memcpyAsync(out, dout, sizeof(sk_somatic_snv_genotype) * size_t(n), hipMemcpyDeviceToHost, ctx.stream));
+    SK_HIP(skrt::streamSynchronize(ctx.stream));
     return 0;
 }
 

@@ -40,3 +40,16 @@ def gpu(built):
     capi.init(0)  # raises with the library's own message when no gfx950 device is present
     yield capi
     capi.shutdown()
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    """With $STRELKA_AMD_BROKER=1 the suite runs as a CLIENT of the per-GPU broker (strelka_amd/csrc/sk_rt.h): what a client cannot
+    do by design -- `*_dev` entry points on a stream / on memory of the caller's own GPU context, the one-shot pileup over the device
+    library's scans, event-timed diagnostics -- is refused by the library with a message naming the broker; those tests are skipped
+    under the broker, everything else has to pass."""
+    outcome = yield
+    if os.environ.get("STRELKA_AMD_BROKER", "0") not in ("", "0") and outcome.excinfo is not None:
+        text = str(outcome.excinfo[1])
+        if "broker client" in text or "carried by the broker" in text:
+            outcome.force_exception(pytest.skip.Exception("not available to a broker client: " + text[:160]))

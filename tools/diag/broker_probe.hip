@@ -1,0 +1,182 @@
+// broker_probe.hip -- two facts the per-GPU broker (csrc/sk_rt.h) stands on, measured on the box:
+//   (1) a shared-memory segment mapped at the SAME virtual address in a client and in the server, page-locked in the server with
+//       hipHostRegister, is read and written by the server's kernels through that very address (no pointer translation in kernel arguments);
+//   (2) N caller threads of ONE process, a stream each, run "jobs" (20 short launches + one wait) side by side, where N caller PROCESSES
+//       beyond the device's eight compute slots are time-sliced.
+//   hipcc --offload-arch=gfx950 -O2 tools/diag/broker_probe.hip -o tools/diag/_broker_probe -lpthread
+//   _broker_probe map | procs N [jobs] | threads N [jobs]        ($GPU_MAX_HW_QUEUES as exported)
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#define CK(x)                                                                                      \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            std::fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__);       \
+            std::exit(2);                                                                          \
+        }                                                                                          \
+    } while (0)
+
+__global__ void touch_kernel(const uint32_t* in, uint32_t* out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * 3u + 1u;
+}
+
+// ~`ticks` of the 100 MHz constant clock (a job's kernels last a few microseconds)
+__global__ void short_kernel(uint32_t* sink, int ticks)
+{
+    const uint64_t t0 = wall_clock64();
+    uint32_t acc = threadIdx.x;
+    while (wall_clock64() - t0 < (uint64_t)ticks) acc = acc * 1664525u + 1013904223u;
+    if (acc == 0x12345u) sink[0] = acc;
+}
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int probe_map()
+{
+    const size_t bytes = 1 << 20;
+    void* const want = reinterpret_cast<void*>(0x600000000000ull);
+    const int fd = memfd_create("sk_probe", 0);
+    if (fd < 0 || ftruncate(fd, bytes)) return std::perror("memfd"), 1;
+    int pfd[2];
+    if (pipe(pfd)) return 1;
+    const pid_t child = fork(); // the "client": no HIP in this process
+    if (child == 0) {
+        void* p = mmap(want, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED_NOREPLACE, fd, 0);
+        if (p != want) _exit(3);
+        uint32_t* w = static_cast<uint32_t*>(p);
+        for (int i = 0; i < 1024; ++i) w[i] = 1000u + i;
+        char c = 1;
+        if (write(pfd[1], &c, 1) != 1) _exit(4);
+        sleep(3);
+        _exit(0);
+    }
+    char c;
+    if (read(pfd[0], &c, 1) != 1) return 1;
+    CK(hipSetDevice(0));
+    void* p = mmap(want, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED_NOREPLACE, fd, 0);
+    std::printf("map: server mapping at %p (wanted %p)\n", p, want);
+    if (p != want) return 1;
+    const double t0 = now_s();
+    CK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    const double t1 = now_s();
+    void* dp = nullptr;
+    CK(hipHostGetDevicePointer(&dp, p, 0));
+    std::printf("map: hipHostRegister %.3f ms; device pointer %p %s host pointer\n", (t1 - t0) * 1e3, dp, dp == p ? "==" : "!=");
+    uint32_t* w = static_cast<uint32_t*>(p);
+    hipLaunchKernelGGL(touch_kernel, dim3(4), dim3(256), 0, 0, w, w + 4096, 1024); // through the HOST address
+    CK(hipDeviceSynchronize());
+    int bad = 0;
+    for (int i = 0; i < 1024; ++i) bad += (w[4096 + i] != (1000u + i) * 3u + 1u);
+    std::printf("map: kernel through the shared address: %d of 1024 wrong\n", bad);
+    CK(hipHostUnregister(p));
+    int st;
+    waitpid(child, &st, 0);
+    return bad != 0 || dp != p;
+}
+
+struct Shared
+{
+    std::atomic<int> ready, go;
+    double t_begin[64], t_end[64], wait_s[64];
+};
+
+static void worker(int id, int jobs, hipStream_t st, uint32_t* sink, Shared* sh, int n)
+{
+    for (int w = 0; w < 20; ++w) hipLaunchKernelGGL(short_kernel, dim3(8), dim3(64), 0, st, sink, 300);
+    CK(hipStreamSynchronize(st));
+    sh->ready.fetch_add(1);
+    while (sh->go.load() == 0) usleep(100);
+    sh->t_begin[id] = now_s();
+    double waited = 0;
+    for (int j = 0; j < jobs; ++j) {
+        for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(short_kernel, dim3(8), dim3(64), 0, st, sink, 300);
+        const double w0 = now_s();
+        CK(hipStreamSynchronize(st));
+        waited += now_s() - w0;
+        // the caller's host work between two jobs (a segment process uses the device a few per cent of its time)
+        const double h0 = now_s();
+        while (now_s() - h0 < 200e-6) {}
+    }
+    sh->t_end[id] = now_s();
+    sh->wait_s[id] = waited;
+}
+
+static void report(const char* what, int n, int jobs, Shared* sh)
+{
+    double b = 1e300, e = 0, w = 0;
+    for (int i = 0; i < n; ++i) {
+        b = std::min(b, sh->t_begin[i]);
+        e = std::max(e, sh->t_end[i]);
+        w += sh->wait_s[i];
+    }
+    const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+    std::printf("%s n=%d queues=%s jobs=%d: wall %.3f s, %.1f us per job per caller (200 us of it host work), wait %.1f us per job, %.0f jobs/s in all\n", what, n,
+                q ? q : "default", jobs, e - b, (e - b) / jobs * 1e6, w / (double(n) * jobs) * 1e6, double(n) * jobs / (e - b));
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) return 1;
+    if (!std::strcmp(argv[1], "map")) return probe_map();
+    const int n = argc > 2 ? std::atoi(argv[2]) : 8;
+    const int jobs = argc > 3 ? std::atoi(argv[3]) : 2000;
+    if (n < 1 || n > 64) return 1;
+    Shared* sh = static_cast<Shared*>(mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0));
+    new (sh) Shared();
+    if (!std::strcmp(argv[1], "procs")) {
+        std::vector<pid_t> kids;
+        for (int i = 0; i < n; ++i) {
+            const pid_t c = fork();
+            if (c == 0) {
+                CK(hipSetDevice(0));
+                (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+                hipStream_t st;
+                CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                uint32_t* sink;
+                CK(hipMalloc(reinterpret_cast<void**>(&sink), 256));
+                worker(i, jobs, st, sink, sh, n);
+                _exit(0);
+            }
+            kids.push_back(c);
+        }
+        while (sh->ready.load() < n) usleep(1000);
+        sh->go.store(1);
+        for (pid_t c : kids) {
+            int st;
+            waitpid(c, &st, 0);
+        }
+        report("procs", n, jobs, sh);
+    } else {
+        CK(hipSetDevice(0));
+        (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+        uint32_t* sink;
+        CK(hipMalloc(reinterpret_cast<void**>(&sink), 256));
+        std::vector<std::thread> th;
+        std::vector<hipStream_t> sts(n);
+        for (int i = 0; i < n; ++i) CK(hipStreamCreateWithFlags(&sts[i], hipStreamNonBlocking));
+        for (int i = 0; i < n; ++i)
+            th.emplace_back([=] {
+                CK(hipSetDevice(0));
+                worker(i, jobs, sts[i], sink, sh, n);
+            });
+        while (sh->ready.load() < n) usleep(1000);
+        sh->go.store(1);
+        for (auto& t : th) t.join();
+        report("threads", n, jobs, sh);
+    }
+    return 0;
+}

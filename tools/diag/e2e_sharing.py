@@ -30,7 +30,7 @@ def main():
     def run(binary, jobs, env):
         root = tempfile.mkdtemp(prefix="sk_share_")
         try:
-            e = {"STRELKA_AMD_VERBOSE": "1"}
+            e = {"STRELKA_AMD_VERBOSE": "1", "STRELKA_AMD_BROKER_TIMING": "1"}
             e.update(env)
             r = farm.run_farm(groups, argv_fn(binary), root, OUTPUTS, jobs=jobs, env=e)
             hooks = {}
@@ -40,6 +40,11 @@ def main():
                     for kv in m.group(1).split():
                         k, v = kv.split("=")
                         hooks[k] = hooks.get(k, 0.0) + float(v)
+                m = re.search(r"strelka_amd broker client: (.*)", tail)
+                if m:
+                    for kv in m.group(1).split():
+                        k, v = kv.split("=")
+                        hooks["broker_" + k] = hooks.get("broker_" + k, 0.0) + float(v)
                 m = re.search(r"strelka_amd adapter feed: .* seconds=(\S+) abi_seconds=(\S+)", tail)
                 if m:
                     hooks["feed"] = hooks.get("feed", 0.0) + float(m.group(1))
@@ -60,6 +65,12 @@ def main():
     for w in [x for x in os.environ.get("SK_SHARING_WINDOWS", "").split(",") if x]:
         extra.append(("read window %s" % w, {"STRELKA_AMD_READ_WINDOW": w}))
     configs = [("default", {})] + extra + ([("no SDMA", {"HSA_ENABLE_SDMA": "0"}), ("no SDMA, 2 HW queues", {"HSA_ENABLE_SDMA": "0", "GPU_MAX_HW_QUEUES": "2"})] if os.environ.get("SK_SHARING_SDMA") else [])
+    if os.environ.get("SK_SHARING_BROKER"):  # the per-GPU broker (csrc/sk_rt.h) with 4 / 8 / 2 hardware queues
+        configs += [("broker", {"STRELKA_AMD_BROKER": "1"})]
+        if os.environ.get("SK_SHARING_BROKER_DMA"):
+            configs.append(("broker, dma copies", {"STRELKA_AMD_BROKER": "1", "STRELKA_AMD_BROKER_COPY": "dma", "STRELKA_AMD_BROKER_SOCKET": "sk_share_dma"}))
+        for q in [x for x in os.environ.get("SK_SHARING_BROKER_QUEUES", "").split(",") if x]:
+            configs.append(("broker, %s queues" % q, {"STRELKA_AMD_BROKER": "1", "STRELKA_AMD_BROKER_QUEUES": q, "STRELKA_AMD_BROKER_SOCKET": "sk_share_q" + q}))
     job_list = [int(x) for x in os.environ.get("SK_SHARING_JOBS", "%d,%d,%d" % (cores, cores * 3 // 2, cores * 2)).split(",")]
     for jobs in job_list:
         for label, env in configs:
@@ -67,6 +78,8 @@ def main():
             print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f feed %.2f indel %.2f haplotype %.2f (hooks %.2f / %.2f / %.2f)" %
                   (label, jobs, w, ps, us, ss, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("feed_abi", 0),
                    hooks.get("indel_abi", 0), hooks.get("haplotype_abi", 0), hooks.get("realign_hook", 0), hooks.get("pileup_hook", 0), hooks.get("feed", 0)), flush=True)
+            if "broker_waits" in hooks:
+                print("        broker clients: " + " ".join("%s=%.6g" % (k[7:], v) for k, v in sorted(hooks.items()) if k.startswith("broker_")), flush=True)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,7 @@ ENV_SETS = [
     ("gvcf_fast_off", {"STRELKA_AMD_GVCF_FAST": "0"}),
     ("gvcf_blocks_off", {"STRELKA_AMD_GVCF_BLOCKS": "0"}),
     ("early_init_off", {"STRELKA_AMD_EARLY_INIT": "0"}),
+    ("broker", {"STRELKA_AMD_BROKER": "1"}),
     ("min_reads_1_three_waits", {"STRELKA_AMD_DEVICE_ENUM_MIN_READS": "1", "SK_ENUM_ONE_WAIT": "0"}),
 ]
 if os.environ.get("SK_SWEEP_ONLY"):  # a comma-separated choice of the settings above
