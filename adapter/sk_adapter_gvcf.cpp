@@ -89,6 +89,11 @@ struct GvcfFast
     std::vector<const SiteChunk*> sampleChunks; ///< (scratch of gvcf_plain_site)
     bool isBlocks = false; ///< the window brings the block that would start at every plain site (sk_gvcf_run): whole blocks are installed
     pos_t blockTo = std::numeric_limits<pos_t>::min(); ///< positions below are members of the block installed last (their process_pos_snp has nothing left to do)
+    /// What a member of the installed block still owes the reference when its turn comes -- the two depth counts of process_pos_sample_stats
+    /// -- is written down HERE when the block is installed, member by member from blockFrom on: from then on a member depends on nothing
+    /// that can change or go away (its window's chunk, the position's pileup), so there is no state left to find broken mid-genome.
+    pos_t blockFrom = std::numeric_limits<pos_t>::min();
+    std::vector<uint32_t> blockUsed, blockUnused;
     unsigned long plainSites = 0, referenceSites = 0, declinedByState = 0;
     unsigned long blocksInstalled = 0, blockSites = 0, blocksDeclined = 0, filterKeyMismatches = 0;
     ~GvcfFast()
@@ -169,7 +174,7 @@ void gvcf_reset_region()
 {
     // (a process may call several regions, on any chromosome: nothing of the last one's installed block carries over)
     GvcfFast& g(gf());
-    g.blockTo = std::numeric_limits<pos_t>::min();
+    g.blockTo = g.blockFrom = std::numeric_limits<pos_t>::min();
     g.cleanSkipped = 0;
 }
 
@@ -209,6 +214,14 @@ bool germline_sample_stats_counts(starling_pos_processor_base& pp, const pos_t p
     g.cleanSkippedPos = pos;
     g.cleanSkipped &= ~(1u << (sampleIndex & 31u));
     if (! (g.decided && g.enabled) || sampleIndex >= g.sampleCount) return false;
+    if (pos < g.blockTo && pos >= g.blockFrom && sampleIndex == 0)
+    {
+        // a member of the installed block (single-sample runs): the counts noted at the install
+        used = g.blockUsed[static_cast<size_t>(pos - g.blockFrom)];
+        unused = g.blockUnused[static_cast<size_t>(pos - g.blockFrom)];
+        g.cleanSkipped |= 1u;
+        return true;
+    }
     const SiteChunk* c(chunkAt(pos, sampleIndex));
     if (c == nullptr) return false;
     const snp_pos_info& pi(pp.sample(sampleIndex).basecallBuffer.get_pos(pos));
@@ -232,8 +245,8 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
     g.cleanSkipped = 0;
     if (pos < g.blockTo)
     {
-        // a member of the block installed at its first site: joined already (nine positions in ten end here)
-        if (! isCleanSkipped) throw blt_exception("strelka_amd adapter: a position of an installed gVCF block is no longer a plain site of the window");
+        // a member of the block installed at its first site: joined already (nine positions in ten end here).  Everything this position
+        // needed was checked and noted when the block was installed (blockUsed / blockUnused); nothing is looked up again.
         return true;
     }
     starling_pos_processor_base& base(pp);
@@ -404,13 +417,19 @@ bool gvcf_plain_site(starling_pos_processor& pp, const pos_t pos)
                 {
                     // joinSiteToSampleBlock (gvcf_block_site_record.cpp:149-156) for every member after the first: the three
                     // accumulators take the member's numbers through the reference's own stream_stat::add, the count goes up
+                    g.blockUsed.resize(n);
+                    g.blockUnused.resize(n);
                     for (pos_t p(pos + 1); p < end; ++p)
                     {
                         const size_t kk(static_cast<size_t>(p - c->begin));
                         block.block_dpu.add(c->cleanCount[kk]);
                         block.block_dpf.add(c->rawCount[kk] - c->cleanCount[kk]);
                         block.block_gqx.add(c->summary[kk].gqx);
+                        // (rawCount == the position's pileup size: isPlainInWindow above)
+                        g.blockUsed[static_cast<size_t>(p - pos)] = c->cleanCount[kk];
+                        g.blockUnused[static_cast<size_t>(p - pos)] = c->rawCount[kk] - c->cleanCount[kk];
                     }
+                    g.blockFrom = pos;
                     block.count = static_cast<int>(n);
                     GvcfAccess::setHeadPos(*writer, end); // add_site_internal's _headPos = locus.pos + 1 of the last member
                     g.blockTo = end;

@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--e2e-max-procs-per-gpu", type=int, default=8,
                     help="caller processes that share one GPU in the end-to-end leg (beyond ~8 the device's scheduler time-slices them: "
                          "profiles/r03_v10_processes_per_gpu.txt, r03_v11_gpu_sharing_sdma.txt); the reference gets the same number of cores")
+    ap.add_argument("--no-e2e-box", action="store_true", help="skip the e2e_box legs (the reference on all cores against the drop-in's best process count)")
     ap.add_argument("--realign-processes", type=int, default=8, help="caller processes of the multi-process whole-read leg (0: skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1500, help="reads in the CPU-baseline sample (x64 candidates)")
@@ -324,6 +325,99 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
         shutil.rmtree(root, ignore_errors=True)
 
 
+def _vcf_body(path):
+    with open(path, "rb") as f:
+        return [l for l in f.read().split(b"\n") if not (l.startswith(b"##cmdline=") or l.startswith(b"##startTime=") or l.startswith(b"##fileDate="))]
+
+
+def e2e_box_leg(args, local_rank, mode="germline"):
+    """SURVEY.md 8(d)'s end-to-end figure as it is defined there: the reference with `-j P`, P = the box's usable cores (the workflow runs
+    one caller process per core, PY/strelkaSharedOptions.py:153-161), against the drop-in at the process count that suits IT -- the same
+    sample as the `e2e` leg, cut into max(P, 16) segments so that every core has one.  The drop-in runs with 8, 12 and 16 (at most P)
+    caller processes as clients of the GPU's broker ($STRELKA_AMD_BROKER=1: one GPU context however many callers, strelka_amd/csrc/sk_rt.h)
+    and, for comparison, with 8 processes that each hold a context of their own (what `e2e` measures; the device runs eight such processes
+    side by side).  Every run is compared byte for byte with the reference's output; `speedup` = reference at -j P / the fastest drop-in run."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from strelka_amd import farm
+    somatic = (mode == "somatic")
+    L = args.e2e_somatic_bp if somatic else args.e2e_bp
+    outputs = E2E_SOMATIC_OUTPUTS if somatic else E2E_OUTPUTS
+    program = "strelka2" if somatic else "starling2"
+    drop_in = program + "_" + os.environ.get("SK_E2E_VARIANT", "amd")
+    if not (os.path.exists(os.path.join(farm.BIN_DIR, drop_in)) and os.path.exists(os.path.join(farm.BIN_DIR, "samtools"))):
+        return {"skipped": "oracle/_ref/bin/%s (adapter/Makefile, needs the reference tree at build time) did not travel" % drop_in}
+    d = (farm.wgs_somatic_dataset if somatic else farm.wgs_dataset)(L)
+    cores = farm.usable_cores()
+    P = len(cores)
+    n_seg = max(P, 16)
+    seg_bp = -(-L // n_seg)
+    groups = [[s] for s in farm.chrom_intervals(["chrW"], {"chrW": L}, seg_bp)]
+    root = tempfile.mkdtemp(prefix="sk_e2e_box_")
+    evs_models = None
+    if not somatic:
+        subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "make_dummy_germline_models.py"),
+                        os.path.join(root, "models")], check=True)
+        evs_models = (os.path.join(root, "models", "germlineSNVScoringModels.json"), os.path.join(root, "models", "germlineIndelScoringModels.json"))
+
+    def argv_fn(binary):
+        def fn(index, regions, prefix, skip_header):
+            if somatic:
+                return farm.somatic_segment_argv(binary, prefix, os.path.join(d, "normal.bam"), os.path.join(d, "tumor.bam"), regions,
+                                                 os.path.join(d, "normal.fa"), chrom_depth=os.path.join(d, "chrom_depth.txt"),
+                                                 callable_regions=True, skip_header=skip_header)
+            return farm.germline_segment_argv(binary, prefix, [os.path.join(d, "wgs.bam")], regions, os.path.join(d, "wgs.fa"),
+                                              chrom_depth=os.path.join(d, "chrom_depth.txt"), skip_header=skip_header, evs_models=evs_models)
+        return fn
+    broker_env = {"STRELKA_AMD_BROKER": "1", "STRELKA_AMD_BROKER_SOCKET": "sk_bench_%d" % os.getpid(), "STRELKA_AMD_BROKER_IDLE_S": "60"}
+    try:
+        ref = farm.run_farm(groups, argv_fn(program + "_ref"), os.path.join(root, "ref"), outputs, jobs=P)
+        want = {n: _vcf_body(ref.outputs[n]) for n in outputs}
+        # The broker is a service: in a whole-genome run (~260 segments) every caller process but the first wave's finds it running, with
+        # the buffers of the callers that have left in its pool.  The clock starts in that state: one wave of P short callers first (50 kb
+        # each; not timed).  What the very first wave pays instead is measured once and reported (`first_wave_wall_s`: the server's
+        # start-up and ~0.7 GB of fresh device memory per caller, all callers at once).
+        cold_env = dict(broker_env, STRELKA_AMD_BROKER_SOCKET=broker_env["STRELKA_AMD_BROKER_SOCKET"] + "_cold")
+        first_wave = farm.run_farm(groups, argv_fn(drop_in), os.path.join(root, "first_wave"), outputs, n_gpus=1, jobs=min(16, P), device_offset=local_rank, env=cold_env)
+        first_wave_same = all(_vcf_body(first_wave.outputs[n]) == want[n] for n in outputs)
+        shutil.rmtree(os.path.join(root, "first_wave"), ignore_errors=True)
+        warm = [[(0, "chrW", 1 + i * 50000, min(L, (i + 1) * 50000), 0)] for i in range(P) if i * 50000 < L]
+        farm.run_farm(warm, argv_fn(drop_in), os.path.join(root, "warm"), outputs, n_gpus=1, jobs=P, device_offset=local_rank, env=broker_env)
+        runs = []
+        plan = [("broker", j, broker_env) for j in sorted({min(8, P), min(12, P), min(16, P)}, reverse=True)] + [("own_context", min(8, P), {})]
+        for kind, jobs, env in plan:
+            res = farm.run_farm(groups, argv_fn(drop_in), os.path.join(root, "%s_%d" % (kind, jobs)), outputs, n_gpus=1, jobs=jobs,
+                                device_offset=local_rank, env=dict(env, STRELKA_AMD_VERBOSE="1"))
+            hooks = {}
+            for tail in res.stderr_tails:
+                m = re.search(r"strelka_amd adapter seconds: (.*)", tail)
+                if m:
+                    for kv in m.group(1).split():
+                        k, v = kv.split("=")
+                        hooks[k] = hooks.get(k, 0.0) + float(v)
+            same = all(_vcf_body(res.outputs[n]) == want[n] for n in outputs)
+            runs.append({"callers": kind, "procs": jobs, "wall_s": res.wall_s, "process_seconds_sum": sum(res.process_s), "identical": same,
+                         "speedup_vs_reference_all_cores": ref.wall_s / res.wall_s,
+                         "abi_seconds": round(sum(v for k, v in hooks.items() if k.endswith("_abi")), 3), "init_seconds": round(hooks.get("init", 0.0), 3)})
+            shutil.rmtree(os.path.join(root, "%s_%d" % (kind, jobs)), ignore_errors=True)
+        best = min(runs, key=lambda r: r["wall_s"])
+        return {"workload": "the %s sample of the e2e leg (%d bp), cut into %d segments of %d bp: one per usable core" % (mode, L, len(groups), seg_bp),
+                "bp": L, "segments": len(groups), "host_cores": P,
+                "ref_cores": P, "ref_wall_s": ref.wall_s, "ref_process_seconds_sum": sum(ref.process_s),
+                "runs": runs, "best": {"callers": best["callers"], "procs": best["procs"]}, "amd_wall_s": best["wall_s"],
+                "first_wave_wall_s": first_wave.wall_s, "first_wave_procs": min(16, P), "first_wave_identical": first_wave_same,
+                "first_wave_speedup": ref.wall_s / first_wave.wall_s,
+                "speedup": ref.wall_s / best["wall_s"], "identical": all(r["identical"] for r in runs) and first_wave_same,
+                "note": "reference: the unmodified program at -j P (P = usable cores), SURVEY.md 8(d); drop-in: the fastest of `runs`, each "
+                        "byte-compared with the reference's output, with the GPU's broker already serving (as every wave of a whole-genome run but the "
+                        "first finds it); first_wave_*: the same farm against a broker that has to be started and has nothing in its pool.  "
+                        "`e2e.speedup` beside this is the equal-process-count ratio."}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def realign_processes_leg(args, n_procs):
     """The whole read path (rows a1-a7, device legs) driven the way the reference is driven for cpu_baseline: one single-threaded caller
     process per core, all at once -- here n_procs processes sharing the one GPU (at most 8: beyond that the driver time-slices them).
@@ -463,22 +557,29 @@ def main():
     # all the device runs side by side -- a ninth process with a queue on it (this one, once it has initialised HIP) puts all of them
     # under the driver's time-slicing (1.46x instead of 1.6x on the germline leg, profiles/r03_v20_bench.json vs r03_v19).  So the
     # legs run before this process creates its context.
-    e2e = e2e_somatic = None
+    e2e = e2e_somatic = e2e_box = e2e_somatic_box = None
     if world == 1 and (not args.only or args.only.startswith("e2e")):
         if args.e2e_bp > 0 and args.only in ("", "e2e", "e2e_germline"):
             e2e = e2e_leg(args, 0, 1, local_rank, lambda: None, lambda v: v, with_reference=not args.no_cpu_baseline)
         if args.e2e_somatic_bp > 0 and args.only in ("", "e2e", "e2e_somatic"):
             e2e_somatic = e2e_leg(args, 0, 1, local_rank, lambda: None, lambda v: v, with_reference=not args.no_cpu_baseline, mode="somatic")
+        # the box ratio: the reference on ALL cores against the drop-in's best process count
+        if not args.no_cpu_baseline and not args.no_e2e_box:
+            if args.e2e_bp > 0 and args.only in ("", "e2e", "e2e_box", "e2e_germline_box"):
+                e2e_box = e2e_box_leg(args, local_rank)
+            if args.e2e_somatic_bp > 0 and args.only in ("", "e2e", "e2e_box", "e2e_somatic_box"):
+                e2e_somatic_box = e2e_box_leg(args, local_rank, mode="somatic")
     realign_processes = None
     if world == 1 and not args.only and args.realign_processes > 0:
         from strelka_amd import farm as _farm
         realign_processes = realign_processes_leg(args, max(1, min(args.realign_processes, len(_farm.usable_cores()), args.e2e_max_procs_per_gpu)))
-    e2e_failed = [name for name, leg in (("e2e", e2e), ("e2e_somatic", e2e_somatic)) if leg and leg.get("identical") is False]
+    e2e_legs = {"e2e": e2e, "e2e_somatic": e2e_somatic, "e2e_box": e2e_box, "e2e_somatic_box": e2e_somatic_box}
+    e2e_failed = [name for name, leg in e2e_legs.items() if leg and leg.get("identical") is False]
     for name in e2e_failed:
-        print("bench.py: the %s leg's outputs are NOT identical to the reference's: %s" % (name, json.dumps(locals()[name]["first_difference"])),
+        print("bench.py: the %s leg's outputs are NOT identical to the reference's: %s" % (name, json.dumps(e2e_legs[name].get("first_difference") or e2e_legs[name].get("runs"))),
               file=sys.stderr, flush=True)
     if args.only.startswith("e2e"):
-        print(json.dumps({"only": args.only, "e2e": e2e, "e2e_somatic": e2e_somatic}), flush=True)
+        print(json.dumps(dict(e2e_legs, only=args.only)), flush=True)
         sys.exit(1 if e2e_failed else 0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
@@ -887,6 +988,8 @@ def main():
     out["realign_processes"] = realign_processes
     out["e2e"] = e2e
     out["e2e_somatic"] = e2e_somatic
+    out["e2e_box"] = e2e_box
+    out["e2e_somatic_box"] = e2e_somatic_box
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -1350,6 +1350,7 @@ int sk_bgzf_inflate_prefixed(const uint8_t* data, const int64_t* block_off, cons
     feed_bufs().kept_len = -1;
     if (prefix_len < 0 || (prefix_len > 0 && !prefix)) return sk_fail("sk_bgzf_inflate: bad prefix");
     SK_REQUIRE_INIT();
+    skrt::wakeHint();
     if (n_blocks < 0) return sk_fail("sk_bgzf_inflate: negative block count");
     if (n_blocks == 0 && prefix_len == 0) return 0;
     if ((n_blocks > 0 && (!data || !block_off || !out_off)) || !out) return sk_fail("sk_bgzf_inflate: null argument");
@@ -1496,6 +1497,7 @@ int sk_normalize_alignments_dev(const char* dev_ref_seq, int32_t ref_offset, int
                                 int32_t* dev_pos, uint8_t* dev_changed, void* hip_stream)
 {
     SK_REQUIRE_INIT();
+    skrt::wakeHint();
     if (n_reads < 0 || ref_len < 0) return sk_fail("sk_normalize_alignments_dev: negative count");
     if (n_reads == 0) return 0;
     if (!dev_ref_seq || !dev_read_off || !dev_read_code || !dev_path_off || !dev_n_seg || !dev_path || !dev_pos || !dev_changed)

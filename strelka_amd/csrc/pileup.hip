@@ -1908,6 +1908,7 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
                           const int32_t ploidy_begin, const int32_t ploidy_len, const uint8_t* ploidy, sk_pileup_window* out)
 {
     SK_REQUIRE_INIT();
+    skrt::wakeHint();
     if (!s || !reads || !out) return sk_fail("sk_pileup_stream_push: null argument");
     if (s->poisoned) return sk_fail("sk_pileup_stream_push: an earlier push of this stream failed; begin the region again");
     if (stream_check_reads(s, reads, mask_begin, mask_len, cand_snv_mask)) return 1;
@@ -1996,6 +1997,7 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
                                   const uint8_t* is_forced_output, const int is_compute_nonsomatic, sk_somatic_pileup_window* out)
 {
     SK_REQUIRE_INIT();
+    skrt::wakeHint();
     if (!p || !normal_reads || !tumor_reads || !out) return sk_fail("sk_somatic_pileup_stream_push: null argument");
     const sk_read_batch* reads[2] = { normal_reads, tumor_reads };
     for (int i = 0; i < 2; ++i) {

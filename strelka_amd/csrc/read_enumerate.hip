@@ -2019,6 +2019,7 @@ extern "C" void sk_enum_device_job_counts(int64_t* one_wait, int64_t* one_wait_r
 static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const bool one_wait, bool* redo)
 {
     SK_REQUIRE_INIT();
+    skrt::wakeHint();
     if (!in || !out) return sk_fail("sk_enum_device_run: null argument");
     std::memset(out, 0, sizeof(*out));
     out->generation = ++g_generation;

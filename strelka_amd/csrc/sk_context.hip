@@ -177,6 +177,7 @@ int grow_pinned(void*& p, size_t& cap, const size_t bytes)
 
 int SkStage::begin(const size_t in_bytes, const size_t out_bytes, const size_t extra_bytes, const int n_arrays)
 {
+    skrt::wakeHint(); // (the caller fills the in block next)
     const size_t pad = 256 * size_t(n_arrays + 2);
     const size_t in_room = sk_align256(in_bytes + pad), out_room = sk_align256(out_bytes + pad);
     StageMirrors& m = stage_mirrors();

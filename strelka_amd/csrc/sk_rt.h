@@ -52,6 +52,7 @@ int r_connect(int device, std::string* why); // to the device's broker, starting
 void r_disconnect();
 int r_device_count(std::string* why);
 bool r_host_backend(); // the broker runs the no-GPU test backend
+void r_wake_hint();
 
 inline hipError_t malloc_(void** p, const size_t bytes) { return g_remote ? r_malloc(p, bytes) : hipMalloc(p, bytes); }
 template <typename T> inline hipError_t malloc_(T** p, const size_t bytes) { return malloc_(reinterpret_cast<void**>(p), bytes); }
@@ -85,6 +86,11 @@ inline hipError_t setDevice(const int device) { return g_remote ? hipSuccess : h
 inline hipError_t funcSetAttribute(const void* fn, const hipFuncAttribute attr, const int value)
 {
     return g_remote ? r_func_set_attribute(fn, attr, value) : hipFuncSetAttribute(fn, attr, value);
+}
+/// "work is coming": lets a broker client's server thread wake up beside the caller's packing instead of after it (nothing otherwise)
+inline void wakeHint()
+{
+    if (g_remote) r_wake_hint();
 }
 inline const char* errorString(const hipError_t e) { return (g_remote && r_error_text(e)[0]) ? r_error_text(e) : hipGetErrorString(e); }
 

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -108,7 +109,9 @@ struct Ctl
     std::atomic<uint32_t> client_waiting;
     std::atomic<int32_t> status; // the first error since the client last asked (a hipError_t)
     uint64_t result;             // of the last MALLOC
-    char error_text[232];
+    uint64_t gpu_flag;           // address (the same in both processes) of the word a one-lane kernel stores a SYNC's sequence number to
+    double t_first, t_reached, t_done; // ($STRELKA_AMD_BROKER_TIMING) of the last batch: first record seen, SYNC reached, stream waited for (CLOCK_MONOTONIC)
+    char error_text[200];
     alignas(64) char ring[RING_BYTES];
 };
 
@@ -257,8 +260,23 @@ struct Pending
     const char* src;
     size_t bytes;
 };
+unsigned env_us(const char* name, const unsigned def)
+{
+    const char* e = std::getenv(name);
+    return (e && e[0]) ? unsigned(std::strtoul(e, nullptr, 10)) : def;
+}
+
 struct Client
 {
+    // How a client waits: it sleeps on a futex the server thread wakes -- at once by default: with a caller process per core the
+    // server thread needs the very core the client would poll on (profiles/r06_v5: every polling variant is slower at 16 callers on 16
+    // cores).  For a box with idle cores: $STRELKA_AMD_BROKER_CLIENT_SPIN_US polls first, and with $STRELKA_AMD_BROKER_GPU_FLAG=1 the poll
+    // also ends on a word that a one-lane kernel at the end of the client's stream stores into page-locked memory (the device says
+    // "done" itself, no wake-up of a server thread on the way).
+    unsigned spin_us = env_us("STRELKA_AMD_BROKER_CLIENT_SPIN_US", 0);
+    bool use_gpu_flag = env_us("STRELKA_AMD_BROKER_GPU_FLAG", 0) != 0;
+    bool eager_wake = env_us("STRELKA_AMD_BROKER_EAGER_WAKE", 0) != 0;
+    volatile uint32_t* gpu_flag = nullptr;
     int sock = -1;
     int device = -1, device_count = 0;
     bool host_backend = false;
@@ -282,14 +300,17 @@ Client g_cl;
 struct ClientTiming
 {
     bool on = std::getenv("STRELKA_AMD_BROKER_TIMING") != nullptr;
-    double wait_s = 0, connect_s = 0, stage_copy_s = 0;
-    uint64_t waits = 0, launches = 0, copies = 0, staged_bytes = 0, futex_sleeps = 0;
+    double wait_other_s = 0, wait_max = 0, wait_long_s = 0;
+    uint64_t waits_other = 0, waits_long = 0;
+    double wait_s = 0, connect_s = 0, stage_copy_s = 0, leg_wake = 0, leg_submit = 0, leg_device = 0, leg_back = 0;
+    uint64_t waits = 0, launches = 0, copies = 0, staged_bytes = 0, futex_sleeps = 0, flag_hits = 0;
     ~ClientTiming()
     {
         if (on && (waits || launches))
-            std::fprintf(stderr, "strelka_amd broker client: connect=%.4f wait=%.4f waits=%llu futex_sleeps=%llu launches=%llu copies=%llu staged_bytes=%llu stage_copy=%.4f\n", connect_s,
-                         wait_s, (unsigned long long)waits, (unsigned long long)futex_sleeps, (unsigned long long)launches, (unsigned long long)copies,
-                         (unsigned long long)staged_bytes, stage_copy_s);
+            std::fprintf(stderr, "strelka_amd broker client: connect=%.4f wait=%.4f waits=%llu futex_sleeps=%llu flag_hits=%llu launches=%llu copies=%llu staged_bytes=%llu stage_copy=%.4f leg_server_wake=%.4f leg_submit=%.4f leg_device=%.4f leg_client_wake=%.4f wait_not_sync=%.4f waits_not_sync=%llu wait_over_5ms=%.4f waits_over_5ms=%llu wait_max=%.4f\n", connect_s,
+                         wait_s, (unsigned long long)waits, (unsigned long long)futex_sleeps, (unsigned long long)flag_hits, (unsigned long long)launches, (unsigned long long)copies,
+                         (unsigned long long)staged_bytes, stage_copy_s, leg_wake, leg_submit, leg_device, leg_back, wait_other_s, (unsigned long long)waits_other, wait_long_s,
+                         (unsigned long long)waits_long, wait_max);
     }
 } g_tm;
 inline double tm_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -341,12 +362,17 @@ char* ring_reserve(const uint32_t bytes)
         }
     }
 }
-void ring_commit(const uint32_t bytes)
+// Publishes a record.  The server thread is woken when the client is about to WAIT (`wake`), not when work merely exists: caller
+// processes fill the box's cores, so a server thread woken early runs on the very core its client is still writing records from --
+// the two take turns on it and the batch's submission takes ten times as long (profiles/r06_v6: "ring empty inside a batch" 0.55 s
+// of a client's 1.1 s).  Woken at the wait, the server thread gets the core the client has just left.  $STRELKA_AMD_BROKER_EAGER_WAKE=1
+// (a box with idle cores): wake at the first record, the device then starts while the client is still writing.
+void ring_commit(const uint32_t bytes, const bool wake = false)
 {
     Client& cl = g_cl;
     cl.head += bytes;
     cl.ctl->head.store(cl.head, std::memory_order_seq_cst);
-    wake_server(cl.ctl);
+    if (wake || cl.eager_wake || cl.head - cl.ctl->tail.load(std::memory_order_relaxed) > RING_BYTES / 2) wake_server(cl.ctl);
 }
 
 hipError_t take_status()
@@ -361,7 +387,7 @@ hipError_t take_status()
     return hipError_t(s);
 }
 
-hipError_t wait_seq(const uint32_t seq)
+hipError_t wait_seq(const uint32_t seq, const bool sync = false)
 {
     Client& cl = g_cl;
     Ctl* c = cl.ctl;
@@ -371,17 +397,38 @@ hipError_t wait_seq(const uint32_t seq)
     struct Lap
     {
         double t0;
+        bool sync;
         ~Lap()
         {
-            if (g_tm.on) g_tm.wait_s += tm_now() - t0, ++g_tm.waits;
+            if (!g_tm.on) return;
+            const double dt = tm_now() - t0;
+            g_tm.wait_s += dt, ++g_tm.waits;
+            if (!sync) g_tm.wait_other_s += dt, ++g_tm.waits_other;
+            if (dt > g_tm.wait_max) g_tm.wait_max = dt;
+            if (dt > 0.005) g_tm.wait_long_s += dt, ++g_tm.waits_long;
         }
-    } lap{ t_begin };
+    } lap{ t_begin, sync };
+    const bool flag_counts = sync && cl.gpu_flag != nullptr;
+    double spin_until = 0;
     for (;;) {
         const uint32_t d = c->done_seq.load(std::memory_order_acquire);
         if (int32_t(d - seq) >= 0) break;
+        if (flag_counts && int32_t(*cl.gpu_flag - seq) >= 0) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            ++g_tm.flag_hits;
+            break;
+        }
         if (++spins < 64) {
             __builtin_ia32_pause();
             continue;
+        }
+        if (cl.spin_us) {
+            const double now = tm_now();
+            if (spin_until == 0) spin_until = now + 1e-6 * cl.spin_us;
+            if (now < spin_until) {
+                for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
+                continue;
+            }
         }
         c->client_waiting.store(1, std::memory_order_seq_cst);
         ++g_tm.futex_sleeps;
@@ -422,8 +469,19 @@ hipError_t cl_sync()
     RecMem* r = new_rec<RecMem>(OP_SYNC, uint32_t(up16(sizeof(RecMem))));
     if (!r) return cl_fail("strelka_amd: no broker connection");
     const uint32_t seq = r->r.seq = ++cl.seq;
-    ring_commit(r->r.bytes);
-    const hipError_t e = wait_seq(seq);
+    const double t_commit = g_tm.on ? tm_now() : 0.0;
+    ring_commit(r->r.bytes, true);
+    const hipError_t e = wait_seq(seq, true);
+    if (g_tm.on && !cl.host_backend) {
+        // the four legs of a wait: the server thread's wake-up, its submissions, the device, this process's wake-up
+        const double t_back = tm_now(), tf = cl.ctl->t_first, tr = cl.ctl->t_reached, td = cl.ctl->t_done;
+        if (tf > 0 && td >= tr && tr >= tf) {
+            g_tm.leg_wake += std::max(0.0, tf - std::min(tf, t_commit)) ;
+            g_tm.leg_submit += tr - std::max(tf, t_commit);
+            g_tm.leg_device += td - tr;
+            g_tm.leg_back += std::max(0.0, t_back - td);
+        }
+    }
     // copies to the caller's pageable arrays are complete now
     if (!cl.pending.empty()) {
         const double t0 = g_tm.on ? tm_now() : 0.0;
@@ -463,7 +521,7 @@ hipError_t cl_host_map(Seg* out, const size_t want)
     r->a = uint64_t(reinterpret_cast<uintptr_t>(va));
     r->b = bytes;
     const uint32_t seq = r->r.seq = ++cl.seq;
-    ring_commit(r->r.bytes);
+    ring_commit(r->r.bytes, true);
     const hipError_t e = wait_seq(seq);
     if (e != hipSuccess) {
         (void)mmap(va, bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0);
@@ -489,7 +547,7 @@ hipError_t cl_host_unmap(const Seg s)
     r->a = uint64_t(reinterpret_cast<uintptr_t>(s.va));
     r->b = s.bytes;
     const uint32_t seq = r->r.seq = ++cl.seq;
-    ring_commit(r->r.bytes);
+    ring_commit(r->r.bytes, true);
     const hipError_t e = wait_seq(seq); // (the server has waited for the stream before it let go of the pages)
     (void)mmap(s.va, s.bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0);
     return e;
@@ -604,13 +662,16 @@ int connect_or_spawn(const int device, std::string* why)
     return s;
 }
 
+void reset_suballocators(); // (below, with the allocators)
 void cl_close()
 {
     Client& cl = g_cl;
+    const Client knobs = Client();
+    reset_suballocators();
     if (cl.sock >= 0) close(cl.sock); // (the server thread sees the socket close and frees what this client held)
     if (cl.ctl) munmap(cl.ctl, sizeof(Ctl));
     if (cl.slot) munmap(cl.slot, SLOT_BYTES);
-    cl = Client();
+    cl = knobs;
 }
 } // namespace
 
@@ -695,7 +756,22 @@ int r_connect(const int device, std::string* why)
     cl.slot = slot;
     cl.head = 0;
     cl.seq = 0;
+    if (cl.use_gpu_flag && !cl.host_backend) { // a page-locked word of this client's for the device to say "done" in
+        Seg fs;
+        if (cl_host_map(&fs, 4096) == hipSuccess) {
+            cl.gpu_flag = reinterpret_cast<volatile uint32_t*>(fs.va);
+            *cl.gpu_flag = 0;
+            c->gpu_flag = uint64_t(reinterpret_cast<uintptr_t>(fs.va));
+        }
+    }
     return 0;
+}
+
+// An entry point that is about to fill its input block and then submit calls this first: the server thread's wake-up (tens of
+// microseconds from a sleep) then runs beside the packing instead of after it.
+void r_wake_hint()
+{
+    if (g_cl.eager_wake && g_cl.ctl && !g_cl.dead) wake_server(g_cl.ctl);
 }
 void r_disconnect() { cl_close(); }
 int r_device_count(std::string* why)
@@ -718,22 +794,109 @@ static hipError_t foreign_stream()
                    hipErrorNotSupported);
 }
 
-hipError_t r_malloc(void** p, const size_t bytes)
+// ---- allocation.  Every request that reaches the server is a round trip, and the server's own call (hipMalloc; for page-locked memory
+// mmap + hipHostRegister) runs under locks that all of its client threads share: sixteen caller processes starting together spent
+// ~0.45 s each waiting for their ~60 grow-only buffers (profiles/r06_v8: 7.5 of 13 s of waits were not waits for the device).  A client
+// therefore asks for memory by the SLAB -- device memory 256 MB, page-locked memory 32 MB at a time, from the server's pool of
+// departed clients' blocks when there is one -- and hands pieces out itself; a freed piece goes on the client's own list (its buffers
+// only grow: a freed piece is followed by a larger request).  Requests of half a slab or more go to the server as they are.
+namespace
+{
+struct SubAllocator
+{
+    struct Slab
+    {
+        char* base;
+        size_t size, used;
+    };
+    struct Piece
+    {
+        char* p;
+        size_t size;
+    };
+    size_t slab_bytes;
+    std::vector<Slab> slabs;
+    std::vector<Piece> live, spare;
+    explicit SubAllocator(const size_t slab) : slab_bytes(slab) {}
+    static size_t round(const size_t n) { return (n + 4095) & ~size_t(4095); }
+    bool direct(const size_t need) const { return need >= slab_bytes / 2; }
+    /// a piece from the spare list or from a slab with room; nullptr: the caller adds a slab (add_slab) and asks again
+    char* take(const size_t need)
+    {
+        for (size_t i = 0; i < spare.size(); ++i)
+            if (spare[i].size >= need && spare[i].size <= need + need / 2 + 65536) {
+                const Piece pc = spare[i];
+                spare.erase(spare.begin() + long(i));
+                live.push_back(pc);
+                return pc.p;
+            }
+        for (Slab& sl : slabs)
+            if (sl.used + need <= sl.size) {
+                char* p = sl.base + sl.used;
+                sl.used += need;
+                live.push_back(Piece{ p, need });
+                return p;
+            }
+        return nullptr;
+    }
+    void add_slab(void* base, const size_t size) { slabs.push_back(Slab{ static_cast<char*>(base), size, 0 }); }
+    bool give_back(void* p)
+    {
+        for (size_t i = 0; i < live.size(); ++i)
+            if (live[i].p == p) {
+                spare.push_back(live[i]);
+                live.erase(live.begin() + long(i));
+                return true;
+            }
+        return false;
+    }
+};
+SubAllocator g_dev_alloc(size_t(env_us("STRELKA_AMD_BROKER_DEVICE_SLAB_MB", 256)) << 20);
+SubAllocator g_pin_alloc(size_t(env_us("STRELKA_AMD_BROKER_PINNED_SLAB_MB", 32)) << 20);
+
+void reset_suballocators() // (the connection is gone: so is everything its slabs were carved from)
+{
+    for (SubAllocator* a : { &g_dev_alloc, &g_pin_alloc }) {
+        a->slabs.clear();
+        a->live.clear();
+        a->spare.clear();
+    }
+}
+hipError_t server_malloc(void** p, const size_t bytes)
 {
     *p = nullptr;
     RecMem* r = new_rec<RecMem>(OP_MALLOC, uint32_t(up16(sizeof(RecMem))));
     if (!r) return cl_fail("strelka_amd: no broker connection");
     r->a = bytes;
     const uint32_t seq = r->r.seq = ++g_cl.seq;
-    ring_commit(r->r.bytes);
+    ring_commit(r->r.bytes, true);
     const hipError_t e = wait_seq(seq);
     if (e != hipSuccess) return e;
     *p = reinterpret_cast<void*>(uintptr_t(g_cl.ctl->result));
     return *p ? hipSuccess : cl_fail("strelka_amd: the broker could not allocate device memory", hipErrorOutOfMemory);
 }
+}
+
+hipError_t r_malloc(void** p, const size_t bytes)
+{
+    *p = nullptr;
+    const size_t need = SubAllocator::round(bytes ? bytes : 1);
+    if (g_dev_alloc.direct(need)) return server_malloc(p, need);
+    char* q = g_dev_alloc.take(need);
+    if (!q) {
+        void* slab = nullptr;
+        const hipError_t e = server_malloc(&slab, g_dev_alloc.slab_bytes);
+        if (e != hipSuccess) return e;
+        g_dev_alloc.add_slab(slab, g_dev_alloc.slab_bytes);
+        q = g_dev_alloc.take(need);
+    }
+    *p = q;
+    return q ? hipSuccess : cl_fail("strelka_amd: device slab allocation failed", hipErrorOutOfMemory);
+}
 hipError_t r_free(void* p)
 {
     if (!p) return hipSuccess;
+    if (g_dev_alloc.give_back(p)) return hipSuccess; // (a piece of a slab: kept for this client's next request; the stream's order protects it)
     RecMem* r = new_rec<RecMem>(OP_FREE, uint32_t(up16(sizeof(RecMem))));
     if (!r) return cl_fail("strelka_amd: no broker connection");
     r->a = uint64_t(reinterpret_cast<uintptr_t>(p));
@@ -743,14 +906,29 @@ hipError_t r_free(void* p)
 hipError_t r_host_malloc(void** p, const size_t bytes)
 {
     *p = nullptr;
+    const size_t need = SubAllocator::round(bytes ? bytes : 1);
     Seg s;
-    const hipError_t e = cl_host_map(&s, bytes ? bytes : 1);
-    if (e == hipSuccess) *p = s.va;
-    return e;
+    if (g_pin_alloc.direct(need)) {
+        const hipError_t e = cl_host_map(&s, need);
+        if (e == hipSuccess) *p = s.va;
+        return e;
+    }
+    char* q = g_pin_alloc.take(need);
+    if (!q) {
+        const hipError_t e = cl_host_map(&s, g_pin_alloc.slab_bytes);
+        if (e != hipSuccess) return e;
+        g_pin_alloc.add_slab(s.va, s.bytes);
+        q = g_pin_alloc.take(need);
+    }
+    *p = q;
+    return q ? hipSuccess : cl_fail("strelka_amd: page-locked slab allocation failed", hipErrorOutOfMemory);
 }
 hipError_t r_host_free(void* p)
 {
     if (!p) return hipSuccess;
+    // A piece that is handed out again may still be read or written by kernels of the stream the old owner queued: the runtime's own
+    // hipHostFree waits for the device, so does this one (frees of page-locked memory happen when a buffer grows: a handful per process).
+    if (g_pin_alloc.give_back(p)) return cl_sync();
     for (const Seg& s : g_cl.segs)
         if (s.va == p) return cl_host_unmap(s);
     return cl_fail("strelka_amd: hostFree of a pointer that is not page-locked memory of this client", hipErrorInvalidValue);
@@ -823,7 +1001,7 @@ hipError_t r_func_set_attribute(const void* fn, const hipFuncAttribute attr, con
     r->c = uint32_t(attr);
     r->d = uint32_t(value);
     const uint32_t seq = r->r.seq = ++g_cl.seq;
-    ring_commit(r->r.bytes);
+    ring_commit(r->r.bytes, true);
     return wait_seq(seq);
 }
 void r_launch(const void* fn, const dim3 grid, const dim3 block, const size_t lds_bytes, hipStream_t st, void** args, const uint32_t* sizes, const int n_args)
@@ -877,6 +1055,48 @@ struct Server
 };
 Server g_srv;
 
+// Device memory of clients that have left, kept for the clients to come: a workflow's caller processes come and go by the hundred
+// (a genome is ~260 segments), each asking for the same buffers -- from the pool a block costs a map look-up instead of the driver's
+// allocation (and hipFree, which waits for every stream of the device, is not called while clients run).  $STRELKA_AMD_BROKER_POOL_GB (64).
+struct BlockPool
+{
+    std::mutex mu;
+    std::multimap<size_t, void*> blocks;
+    size_t bytes = 0, cap = size_t(env_us("STRELKA_AMD_BROKER_POOL_GB", 64)) << 30;
+    uint64_t hits = 0, misses = 0;
+    /// a block of at least `need` bytes and at most half as much again; *size: what it really holds
+    void* take(const size_t need, size_t* size)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = blocks.lower_bound(need);
+        if (it == blocks.end() || it->first > need + need / 2 + 65536) {
+            ++misses;
+            return nullptr;
+        }
+        void* p = it->second;
+        *size = it->first;
+        bytes -= it->first;
+        blocks.erase(it);
+        ++hits;
+        return p;
+    }
+    bool give(void* p, const size_t size)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (bytes + size > cap) return false;
+        blocks.emplace(size, p);
+        bytes += size;
+        return true;
+    }
+};
+BlockPool g_pool;
+
+struct Block
+{
+    void* p;
+    size_t size, pool_size; // what the client asked for; what the block really holds (larger when it came from the pool)
+};
+
 struct Conn
 {
     int sock = -1;
@@ -884,10 +1104,18 @@ struct Conn
     int slot = -1;
     char* slot_va = nullptr;
     hipStream_t stream = nullptr;
-    std::vector<void*> allocs;
+    std::vector<Block> allocs, freed; // in use; freed by the client (reused by its own later allocations: same stream, in order)
+    double alloc_s = 0;
     std::vector<Seg> segs;
-    uint64_t n_launch = 0, n_sync = 0;
+    uint64_t n_launch = 0, n_sync = 0, n_sleeps = 0;
     unsigned pid = 0;
+    // ($STRELKA_AMD_BROKER_VERBOSE) from the first record after a wait to the SYNC record; inside hipStreamSynchronize
+    bool timing = std::getenv("STRELKA_AMD_BROKER_VERBOSE") != nullptr;
+    bool batch_open = false;
+    double batch_begin = 0, submit_s = 0, sync_s = 0;
+    double batch_first = 0; // when the server thread saw the first record since the last SYNC
+    double in_launch_s = 0, in_copy_s = 0, in_fill_s = 0, idle_in_batch_s = 0; // inside the runtime's calls; with a batch open and the ring empty
+    uint64_t n_copy = 0, n_fill = 0;
 };
 
 void srv_error(Conn& c, const int32_t code, const char* what, const char* detail)
@@ -928,6 +1156,10 @@ __global__ __launch_bounds__(256) void broker_copy16_kernel(const uint4* __restr
 __global__ __launch_bounds__(256) void broker_copy1_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint64_t n)
 {
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) dst[i] = src[i];
+}
+__global__ void broker_flag_kernel(uint32_t* flag, const uint32_t seq)
+{
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 bool copy_by_kernel()
 {
@@ -979,8 +1211,10 @@ void srv_execute(Conn& c, const Rec* rec)
         }
         const void* fn = reinterpret_cast<const void*>(lib_info().base + uintptr_t(r->fn_off));
         ++c.n_launch;
+        const double t0 = c.timing ? tm_now() : 0.0;
         if (host) reinterpret_cast<void (*)(void**)>(const_cast<void*>(fn))(argv);
         else SRV_HIP(c, hipLaunchKernel(fn, dim3(r->grid[0], r->grid[1], r->grid[2]), dim3(r->block[0], r->block[1], r->block[2]), argv, r->lds, c.stream));
+        if (c.timing) c.in_launch_s += tm_now() - t0;
         break;
     }
     case OP_MEMCPY: {
@@ -991,34 +1225,75 @@ void srv_execute(Conn& c, const Rec* rec)
             break;
         }
         if (host) std::memcpy(reinterpret_cast<void*>(uintptr_t(r->dst)), reinterpret_cast<const void*>(uintptr_t(r->src)), r->bytes);
-        else srv_copy(c, r->dst, r->src, r->bytes, hipMemcpyKind(r->kind));
+        else {
+            const double t0 = c.timing ? tm_now() : 0.0;
+            srv_copy(c, r->dst, r->src, r->bytes, hipMemcpyKind(r->kind));
+            if (c.timing) c.in_copy_s += tm_now() - t0, ++c.n_copy;
+        }
         break;
     }
     case OP_MEMSET: {
         const RecCopy* r = reinterpret_cast<const RecCopy*>(rec);
         if (host) std::memset(reinterpret_cast<void*>(uintptr_t(r->dst)), int(r->value), r->bytes);
-        else SRV_HIP(c, hipMemsetAsync(reinterpret_cast<void*>(uintptr_t(r->dst)), int(r->value), r->bytes, c.stream));
+        else {
+            const double t0 = c.timing ? tm_now() : 0.0;
+            SRV_HIP(c, hipMemsetAsync(reinterpret_cast<void*>(uintptr_t(r->dst)), int(r->value), r->bytes, c.stream));
+            if (c.timing) c.in_fill_s += tm_now() - t0, ++c.n_fill;
+        }
         break;
     }
     case OP_SYNC: {
         ++c.n_sync;
-        if (!host) SRV_HIP(c, hipStreamSynchronize(c.stream));
+        if (!host) {
+            const uint64_t f = c.ctl->gpu_flag;
+            if (f && in_segs(c, f, 4)) hipLaunchKernelGGL(broker_flag_kernel, dim3(1), dim3(1), 0, c.stream, reinterpret_cast<uint32_t*>(uintptr_t(f)), rec->seq);
+            const double t0 = tm_now();
+            if (c.timing) c.submit_s += t0 - c.batch_begin;
+            SRV_HIP(c, hipStreamSynchronize(c.stream));
+            const double t1 = tm_now();
+            if (c.timing) c.sync_s += t1 - t0;
+            c.ctl->t_first = c.batch_first;
+            c.ctl->t_reached = t0;
+            c.ctl->t_done = t1;
+        }
         srv_done(c, rec->seq);
+        c.batch_open = false;
+        c.batch_first = 0;
         break;
     }
     case OP_MALLOC: {
         const RecMem* r = reinterpret_cast<const RecMem*>(rec);
-        void* p = nullptr;
-        if (host) p = std::malloc(r->a ? r->a : 1);
-        else SRV_HIP(c, hipMalloc(&p, r->a ? r->a : 1));
-        if (p) c.allocs.push_back(p);
-        c.ctl->result = uint64_t(reinterpret_cast<uintptr_t>(p));
+        const double t0 = c.timing ? tm_now() : 0.0;
+        const size_t need = r->a ? r->a : 1;
+        Block b{ nullptr, need, need };
+        for (size_t i = 0; i < c.freed.size() && !b.p; ++i)
+            if (c.freed[i].pool_size >= need && c.freed[i].pool_size <= need + need / 2 + 65536) {
+                b = c.freed[i];
+                b.size = need;
+                c.freed.erase(c.freed.begin() + long(i));
+            }
+        if (!b.p && !host) b.p = g_pool.take(need, &b.pool_size); // a block a departed client left
+        if (!b.p) {
+            if (host) b.p = std::malloc(need);
+            else SRV_HIP(c, hipMalloc(&b.p, need));
+        }
+        if (b.p) c.allocs.push_back(b);
+        c.ctl->result = uint64_t(reinterpret_cast<uintptr_t>(b.p));
+        if (c.timing) c.alloc_s += tm_now() - t0;
         srv_done(c, rec->seq);
         break;
     }
     case OP_FREE: {
         // hipFree waits for the whole device -- every other client's stream too.  A caller's buffers only grow (a free is followed by a
-        // larger allocation), so what a client frees is kept until it leaves; nothing else may use it meanwhile.
+        // larger allocation): what a client frees stays its own (a later allocation of its may take it: same stream, in order) until
+        // it leaves, when everything goes to the pool.
+        const RecMem* r = reinterpret_cast<const RecMem*>(rec);
+        for (size_t i = 0; i < c.allocs.size(); ++i)
+            if (uint64_t(reinterpret_cast<uintptr_t>(c.allocs[i].p)) == r->a) {
+                c.freed.push_back(c.allocs[i]);
+                c.allocs.erase(c.allocs.begin() + long(i));
+                break;
+            }
         break;
     }
     case OP_FUNC_ATTR: {
@@ -1151,12 +1426,27 @@ void serve_client(const int sock)
     for (;;) {
         uint64_t head = ctl->head.load(std::memory_order_acquire);
         if (head == tail) {
+            const double idle_t0 = (c.timing && c.batch_open) ? tm_now() : 0.0;
+            struct IdleLap
+            {
+                Conn& c;
+                double t0;
+                ~IdleLap()
+                {
+                    if (t0 != 0.0) c.idle_in_batch_s += tm_now() - t0;
+                }
+            } idle_lap{ c, idle_t0 };
             bool got = false;
-            for (int i = 0; i < 256 && !got; ++i) {
-                __builtin_ia32_pause();
-                got = (ctl->head.load(std::memory_order_acquire) != tail);
-            }
+            static const unsigned spin_us = env_us("STRELKA_AMD_BROKER_SERVER_SPIN_US", 2);
+            const double until = tm_now() + 1e-6 * spin_us;
+            do {
+                for (int i = 0; i < 64 && !got; ++i) {
+                    __builtin_ia32_pause();
+                    got = (ctl->head.load(std::memory_order_acquire) != tail);
+                }
+            } while (!got && tm_now() < until);
             if (got) continue;
+            ++c.n_sleeps;
             ctl->server_idle.store(1, std::memory_order_seq_cst);
             if (ctl->head.load(std::memory_order_seq_cst) != tail) {
                 ctl->server_idle.store(0, std::memory_order_seq_cst);
@@ -1176,6 +1466,11 @@ void serve_client(const int sock)
                 shutdown(sock, SHUT_RDWR);
                 break;
             }
+            if (c.batch_first == 0) c.batch_first = tm_now();
+            if (c.timing && !c.batch_open) {
+                c.batch_open = true;
+                c.batch_begin = c.batch_first;
+            }
             srv_execute(c, rec);
             tail += bytes;
             ctl->tail.store(tail, std::memory_order_release);
@@ -1185,10 +1480,13 @@ void serve_client(const int sock)
     if (!g_srv.host_backend) {
         (void)hipStreamSynchronize(c.stream);
         for (const Seg& s : c.segs) (void)hipHostUnregister(s.va);
-        for (void* a : c.allocs) (void)hipFree(a);
+        for (const std::vector<Block>* v : { &c.allocs, &c.freed })
+            for (const Block& b : *v)
+                if (!g_pool.give(b.p, b.pool_size)) (void)hipFree(b.p);
         (void)hipStreamDestroy(c.stream);
     } else {
-        for (void* a : c.allocs) std::free(a);
+        for (const std::vector<Block>* v : { &c.allocs, &c.freed })
+            for (const Block& b : *v) std::free(b.p);
     }
     munmap(c.slot_va, SLOT_BYTES); // (the segments inside go with it)
     munmap(ctl, sizeof(Ctl));
@@ -1199,7 +1497,10 @@ void serve_client(const int sock)
         g_srv.last_client = std::chrono::steady_clock::now();
     }
     if (std::getenv("STRELKA_AMD_BROKER_VERBOSE"))
-        std::fprintf(stderr, "[sk_broker] client pid %u left: %llu launches, %llu waits\n", c.pid, (unsigned long long)c.n_launch, (unsigned long long)c.n_sync);
+        std::fprintf(stderr, "[sk_broker] client pid %u left: %llu launches, %llu waits, %llu sleeps, submit %.4f s, in hipStreamSynchronize %.4f s, in hipLaunchKernel %.4f s, "
+                             "%llu copies %.4f s, %llu fills %.4f s, ring empty inside a batch %.4f s, allocations %.4f s\n", c.pid,
+                     (unsigned long long)c.n_launch, (unsigned long long)c.n_sync, (unsigned long long)c.n_sleeps, c.submit_s, c.sync_s, c.in_launch_s,
+                     (unsigned long long)c.n_copy, c.in_copy_s, (unsigned long long)c.n_fill, c.in_fill_s, c.idle_in_batch_s, c.alloc_s);
     g_srv.clients.fetch_sub(1);
 }
 } // namespace
@@ -1264,7 +1565,8 @@ extern "C" int sk_broker_serve(const int device, const char* socket_name_arg, co
             if (std::chrono::steady_clock::now() - g_srv.last_client > std::chrono::seconds(idle_seconds)) break;
         }
     }
-    std::fprintf(stderr, "[sk_broker] pid %d: no client for %d s after %lld served, leaving\n", int(getpid()), idle_seconds, (long long)g_srv.served.load());
+    std::fprintf(stderr, "[sk_broker] pid %d: no client for %d s after %lld served, leaving (device blocks from the pool / from the driver: %llu / %llu)\n", int(getpid()),
+                 idle_seconds, (long long)g_srv.served.load(), (unsigned long long)g_pool.hits, (unsigned long long)g_pool.misses);
     close(ls);
     return 0;
 }

@@ -64,6 +64,23 @@ def test_e2e_leg_reports_the_first_difference(monkeypatch, tmp_path):
     assert os.path.exists(str(tmp_path / "kept" / ("germline_drop_in_" + fd["file"])))
 
 
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+def test_e2e_box_leg_runs_and_compares(monkeypatch):
+    """the box ratio's plumbing (the reference at -j P, P = usable cores, against the drop-in's best process count; every
+    run byte-compared), on the CPU double -- which has no broker: the runs differ in process count only"""
+    import bench
+    from strelka_amd import farm
+    monkeypatch.setenv("SK_E2E_VARIANT", "dbl")
+    args = argparse.Namespace(e2e_bp=480000, e2e_somatic_bp=0)
+    out = bench.e2e_box_leg(args, 0)
+    P = len(farm.usable_cores())
+    assert out["identical"] is True and out["segments"] == max(P, 16) and out["ref_cores"] == P and out["host_cores"] == P
+    assert [r["callers"] for r in out["runs"]][-1] == "own_context" and {r["callers"] for r in out["runs"][:-1]} == {"broker"}
+    assert out["first_wave_identical"] is True and out["first_wave_wall_s"] > 0
+    assert all(r["identical"] and r["wall_s"] > 0 for r in out["runs"])
+    assert out["amd_wall_s"] == min(r["wall_s"] for r in out["runs"]) and abs(out["speedup"] - out["ref_wall_s"] / out["amd_wall_s"]) < 1e-9
+
+
 # ---- the legs at the configuration the metric is quoted on (what the driver's bench run does; bench.py's defaults): chr20's 64 Mb cut
 # into 12 Mb segments as the workflow cuts it (configs[1]) / a 16 Mb tumour-normal pair in 2 Mb segments (configs[2]), caller processes
 # sharing one GPU, the workflow's command line with the EVS models on.  BENCH_r03's germline leg failed at its bench configuration while
@@ -118,3 +135,30 @@ def test_e2e_somatic_at_bench_configuration_identical_gpu():
     assert out["identical"] is True, out["first_difference"]
     assert out["segments"] == 8
     _assert_routed(out, somatic=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_amd"), reason="oracle/_ref binaries not built")
+def test_e2e_box_germline_at_bench_configuration_identical_gpu():
+    """chr20's 64 Mb with a segment per core: the reference on all cores against 8 own-context callers and 8 / 12 / 16 broker clients on
+    the one GPU -- every run identical to the reference, and more than eight callers FASTER than eight (the broker's point)"""
+    import bench
+    d = _bench_defaults()
+    args = argparse.Namespace(e2e_bp=d.e2e_bp, e2e_somatic_bp=0)
+    out = bench.e2e_box_leg(args, 0)
+    assert out["identical"] is True, out["runs"]
+    by = {(r["callers"], r["procs"]): r for r in out["runs"]}
+    if out["host_cores"] >= 16:
+        assert by[("broker", 16)]["wall_s"] < by[("own_context", 8)]["wall_s"], out["runs"]
+    print("\ne2e_box germline: reference -j%d %.1f s; %s; speedup %.2fx" % (out["ref_cores"], out["ref_wall_s"],
+          ", ".join("%s x%d %.1f s" % (r["callers"], r["procs"], r["wall_s"]) for r in out["runs"]), out["speedup"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_amd"), reason="oracle/_ref binaries not built")
+def test_e2e_box_somatic_at_bench_configuration_identical_gpu():
+    import bench
+    d = _bench_defaults()
+    args = argparse.Namespace(e2e_bp=0, e2e_somatic_bp=d.e2e_somatic_bp)
+    out = bench.e2e_box_leg(args, 0, mode="somatic")
+    assert out["identical"] is True, out["runs"]

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -128,10 +129,113 @@ static void report(const char* what, int n, int jobs, Shared* sh)
                 q ? q : "default", jobs, e - b, (e - b) / jobs * 1e6, w / (double(n) * jobs) * 1e6, double(n) * jobs / (e - b));
 }
 
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const uint64_t n16)
+{
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n16; i += uint64_t(gridDim.x) * 256) dst[i] = src[i];
+}
+
+// (3) what a kernel / a copy call gets out of host memory of three kinds: hipHostMalloc, a memfd segment page-locked with hipHostRegister
+//     (4 KB pages: what the broker's clients share), anonymous memory with MADV_HUGEPAGE page-locked the same way
+static int probe_mem()
+{
+    CK(hipSetDevice(0));
+    const size_t cap = 32u << 20;
+    void* dev;
+    CK(hipMalloc(&dev, cap));
+    void* kinds[3];
+    const char* names[3] = { "hipHostMalloc", "memfd + hipHostRegister", "anonymous huge pages + hipHostRegister" };
+    CK(hipHostMalloc(&kinds[0], cap, hipHostMallocDefault));
+    const int fd = memfd_create("sk_probe_mem", 0);
+    if (fd < 0 || ftruncate(fd, cap)) return 1;
+    kinds[1] = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    kinds[2] = mmap(nullptr, cap + (2u << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    kinds[2] = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(kinds[2]) + (2u << 20) - 1) & ~uintptr_t((2u << 20) - 1));
+    (void)madvise(kinds[2], cap, MADV_HUGEPAGE);
+    for (int k = 1; k < 3; ++k) {
+        std::memset(kinds[k], 1, cap);
+        CK(hipHostRegister(kinds[k], cap, hipHostRegisterDefault));
+    }
+    std::memset(kinds[0], 1, cap);
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (size_t bytes : { size_t(64) << 10, size_t(1) << 20, size_t(8) << 20, size_t(32) << 20 })
+        for (int k = 0; k < 3; ++k)
+            for (int dir = 0; dir < 2; ++dir)
+                for (int how = 0; how < 2; ++how) {
+                    const void* src = dir == 0 ? kinds[k] : dev;
+                    void* dst = dir == 0 ? dev : kinds[k];
+                    const int reps = 20;
+                    double best = 1e300;
+                    for (int rep = 0; rep < reps; ++rep) {
+                        const double t0 = now_s();
+                        if (how == 0) hipLaunchKernelGGL(copy16_kernel, dim3(unsigned(std::min<size_t>((bytes / 16 + 255) / 256, 1024))), dim3(256), 0, st, static_cast<const uint4*>(src),
+                                                         static_cast<uint4*>(dst), uint64_t(bytes / 16));
+                        else CK(hipMemcpyAsync(dst, src, bytes, dir == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+                        CK(hipStreamSynchronize(st));
+                        best = std::min(best, now_s() - t0);
+                    }
+                    std::printf("mem: %8zu KB %-40s %s by %-14s best %.1f us = %.2f GB/s\n", bytes >> 10, names[k], dir == 0 ? "host->device" : "device->host",
+                                how == 0 ? "kernel" : "hipMemcpyAsync", best * 1e6, double(bytes) / best / 1e9);
+                }
+    return 0;
+}
+
+// (4) what an allocation costs the server: hipMalloc / hipHostRegister of several sizes from one thread and from 16 at once
+static int probe_alloc()
+{
+    CK(hipSetDevice(0));
+    void* warm;
+    CK(hipMalloc(&warm, 1 << 20));
+    static std::mutex one_at_a_time;
+    for (int threads : { 1, 16, -16 }) // (-16: sixteen threads, the calls one at a time under a mutex)
+        for (size_t mb : { size_t(8), size_t(32), size_t(256), size_t(1024) }) {
+            const bool serial = threads < 0;
+            if (serial) threads = -threads;
+            std::vector<std::thread> th;
+            std::vector<double> dev_s(threads), pin_s(threads), free_s(threads);
+            for (int t = 0; t < threads; ++t)
+                th.emplace_back([&, t] {
+                    CK(hipSetDevice(0));
+                    const size_t bytes = mb << 20;
+                    void* d[3];
+                    double t0 = now_s();
+                    for (int i = 0; i < 3; ++i) {
+                        std::unique_lock<std::mutex> g(one_at_a_time, std::defer_lock);
+                        if (serial) g.lock();
+                        CK(hipMalloc(&d[i], bytes));
+                    }
+                    dev_s[t] = (now_s() - t0) / 3;
+                    t0 = now_s();
+                    for (int i = 0; i < 3; ++i) CK(hipFree(d[i]));
+                    free_s[t] = (now_s() - t0) / 3;
+                    if (mb <= 256) {
+                        void* h = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+                        t0 = now_s();
+                        {
+                            std::unique_lock<std::mutex> g(one_at_a_time, std::defer_lock);
+                            if (serial) g.lock();
+                            CK(hipHostRegister(h, bytes, hipHostRegisterDefault));
+                        }
+                        pin_s[t] = now_s() - t0;
+                        CK(hipHostUnregister(h));
+                        munmap(h, bytes);
+                    }
+                });
+            for (auto& x : th) x.join();
+            double a = 0, b = 0, c = 0;
+            for (int t = 0; t < threads; ++t) a += dev_s[t], b += pin_s[t], c += free_s[t];
+            std::printf("alloc: %2d threads%s, %4zu MB: hipMalloc %.2f ms, hipFree %.2f ms, hipHostRegister (fresh shared pages) %.2f ms  (mean per call, waiting for the mutex included)\n", threads, serial ? " one call at a time" : "", mb,
+                        a / threads * 1e3, c / threads * 1e3, b / threads * 1e3);
+        }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 1;
     if (!std::strcmp(argv[1], "map")) return probe_map();
+    if (!std::strcmp(argv[1], "alloc")) return probe_alloc();
+    if (!std::strcmp(argv[1], "mem")) return probe_mem();
     const int n = argc > 2 ? std::atoi(argv[2]) : 8;
     const int jobs = argc > 3 ? std::atoi(argv[3]) : 2000;
     if (n < 1 || n > 64) return 1;

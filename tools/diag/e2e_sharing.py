@@ -44,7 +44,7 @@ def main():
                 if m:
                     for kv in m.group(1).split():
                         k, v = kv.split("=")
-                        hooks["broker_" + k] = hooks.get("broker_" + k, 0.0) + float(v)
+                        hooks["broker_" + k] = max(hooks.get("broker_" + k, 0.0), float(v)) if k == "wait_max" else hooks.get("broker_" + k, 0.0) + float(v)
                 m = re.search(r"strelka_amd adapter feed: .* seconds=(\S+) abi_seconds=(\S+)", tail)
                 if m:
                     hooks["feed"] = hooks.get("feed", 0.0) + float(m.group(1))
@@ -71,11 +71,17 @@ def main():
             configs.append(("broker, dma copies", {"STRELKA_AMD_BROKER": "1", "STRELKA_AMD_BROKER_COPY": "dma", "STRELKA_AMD_BROKER_SOCKET": "sk_share_dma"}))
         for q in [x for x in os.environ.get("SK_SHARING_BROKER_QUEUES", "").split(",") if x]:
             configs.append(("broker, %s queues" % q, {"STRELKA_AMD_BROKER": "1", "STRELKA_AMD_BROKER_QUEUES": q, "STRELKA_AMD_BROKER_SOCKET": "sk_share_q" + q}))
+    # "name:K=V,K=V;name:..." -- broker variants, each with a server of its own (server-side knobs are read when the server starts)
+    for i, spec in enumerate([x for x in os.environ.get("SK_SHARING_BROKER_VARIANTS", "").split(";") if x]):
+        name, _, kvs = spec.partition(":")
+        env = {"STRELKA_AMD_BROKER": "1", "STRELKA_AMD_BROKER_SOCKET": "sk_share_v%d" % i}
+        env.update(dict(kv.split("=", 1) for kv in kvs.split(",") if kv))
+        configs.append(("broker " + name, env))
     job_list = [int(x) for x in os.environ.get("SK_SHARING_JOBS", "%d,%d,%d" % (cores, cores * 3 // 2, cores * 2)).split(",")]
     for jobs in job_list:
         for label, env in configs:
             w, ps, hooks, us, ss = run("starling2_amd", jobs, env)
-            print("adapter %-28s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f feed %.2f indel %.2f haplotype %.2f (hooks %.2f / %.2f / %.2f)" %
+            print("adapter %-34s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f feed %.2f indel %.2f haplotype %.2f (hooks %.2f / %.2f / %.2f)" %
                   (label, jobs, w, ps, us, ss, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("feed_abi", 0),
                    hooks.get("indel_abi", 0), hooks.get("haplotype_abi", 0), hooks.get("realign_hook", 0), hooks.get("pileup_hook", 0), hooks.get("feed", 0)), flush=True)
             if "broker_waits" in hooks:
