@@ -44,10 +44,13 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
     std::fill(genotypeLogLhood.begin(), genotypeLogLhood.end(), 0.);
     if (nonRefAlleleCount == 0) return;
 
-    if (contrastGroup.size() != 0)
-    {
-        throw blt_exception("strelka_amd adapter: contrast allele groups are not supported on this path");
-    }
+    // A contrast group (AlleleGroupGenotype.cpp:225-252: alleles "intended for an 'other' category", e.g. a forced-output indel that
+    // overlaps the called group) only ever raises a read's REFERENCE likelihood: the read's allele likelihoods are taken over the
+    // extended group (getAlleleLogLhoodFromRead: the reference entry is the largest ReadPathScores::ref of every allele, contrast
+    // ones included, that scored the read), then every contrast allele's own score is "maxed down into the reference" and dropped.
+    // The reads are those scored for EVERY allele of the group proper (getAlleleGroupIntersectionReadIds), so none of its alleles is
+    // ever missing for a read and the whole step is one more candidate for the maximum the kernel takes over the row's ref entries:
+    // it is folded, as the float it is, into the first allele's ref entry below.
     // A multi-sample run can put up to ploidy x sample-count alternate alleles into one group (selectTopOrthogonalAllelesInAllSamples,
     // L/starling_common/OrthogonalVariantAlleleCandidateGroupUtil.cpp:285-340: the union of every sample's top alleles).  Groups of up to
     // SK_MAX_ALT alleles go through the narrow record, wider ones (several distinct overlapping indels that differ between the
@@ -93,6 +96,24 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
             }
         }
         assert(isExemplarSet);
+        if (contrastGroup.size() != 0)
+        {
+            float best(refLnp[r * width]);
+            for (unsigned a(0); a < nonRefAlleleCount; ++a)
+            {
+                // (with the intersection of the alleles' reads every entry is set; were one missing, the reference's two-step maximum
+                // could not be written as one: that read set is a compile-time choice of the reference, USE_GERMLINE_SUPPORTING_READ_UNION)
+                if (std::isnan(alleleLnp[r * width + a])) throw blt_exception("strelka_amd adapter: a read of an allele group's intersection is missing from one of its alleles");
+            }
+            for (unsigned c(0); c < contrastGroup.size(); ++c)
+            {
+                const IndelSampleData& isd(contrastGroup.data(c).getSampleData(sampleIndex));
+                const auto it(isd.read_path_lnp.find(readId));
+                if (it == isd.read_path_lnp.end()) continue; // (an allele that did not score the read takes the reference entry: no new candidate)
+                best = std::max(best, std::max(it->second.ref, it->second.indel));
+            }
+            refLnp[r * width] = best;
+        }
         ++r;
     }
 

@@ -17,6 +17,7 @@
 #include "starling_common/starling_read_segment.hh"
 
 #include <algorithm>
+#include <iostream>
 #include <unordered_map>
 
 namespace sk_adapter
@@ -127,6 +128,11 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
             // window (or the caller stage) that does ask (the commit is after the job, below)
             const IndelData::status_t savedStatus(d.status);
             const bool isCandidate(indelBuffer.isCandidateIndel(k, d));
+            // (isCandidateIndelImpl also notes, in the same cached status, that an externally specified indel is a candidate WITHOUT read
+            // support -- IndelBuffer.cpp:279-289; the search reads that note, starling_read_align.cpp:1003, :1026, of indels whose status a
+            // read of the reference has always just computed.  It is taken from the evaluation made here, not from the restored cache:
+            // found by tools/fuzz/e2e_seeds.py adversarial -- a forced-output indel no read carries, first asked about by a later window)
+            const bool isNotDiscoveredFromReads(d.status.notDiscoveredFromReads);
             d.status = savedStatus;
             toIndelKey(k, isCandidate, e.key);
             const IndelSampleData& isd(d.getSampleData(sampleIndex));
@@ -139,7 +145,7 @@ void realign_sample_window(starling_pos_processor_base& pp, const unsigned sampl
                 e.is_haplotyping_bypassed[si] = d.getSampleData(si).isHaplotypingBypassed ? 1 : 0;
             }
             e.is_forced_output = d.isForcedOutput ? 1 : 0;
-            e.not_discovered_from_reads = d.status.notDiscoveredFromReads ? 1 : 0;
+            e.not_discovered_from_reads = isNotDiscoveredFromReads ? 1 : 0;
             const int32_t index(static_cast<int32_t>(table.size()));
             // is_usable_indel (starling_read_align.cpp:289-305): the reads observed to carry this indel in this sample
             for (const auto id : isd.tier1_map_read_ids) observedBy[id].push_back(index);

@@ -458,6 +458,12 @@ void somatic_indel(const strelka_options& opt, const starling_sample_options& no
     no.tier2_random_base_match_prob = opt.tier2.randomBaseMatchProb;
     no.read_confident_support_threshold = opt.readConfidentSupportThreshold.numval();
     no.is_use_alt_indel = isUseAltIndel ? 1 : 0;
+    {
+        // the library's default is the fast form of the 21-state likelihoods (include/strelka_amd.h, sk_indel_options.fast_form);
+        // $STRELKA_AMD_INDEL_EXACT=1: the reference's operation order, bit-identical doubles
+        static const bool isExact([]() { const char* v(std::getenv("STRELKA_AMD_INDEL_EXACT")); return v && *v && *v != '0'; }());
+        if (isExact) no.fast_form = 0;
+    }
     to = no;
     to.min_read_bp_flank = tumorOpt.min_read_bp_flank;
     sk_somatic_indel_options so;

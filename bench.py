@@ -539,6 +539,7 @@ def pmc_traffic(args):
     # where the numbers come from: every roofline object names the file, and the commit the counter passes ran at (tools/pmc_traffic.py
     # records it; older files only carry their visit tags in `note`)
     out["__source__"] = {"file": "profiles/" + os.path.basename(files[-1]), "commit": d.get("commit"), "note": d.get("note")}
+    out["__bound__"] = d.get("bound") or {}   # per kernel: which unit binds it (SQ counter passes of the same visit, tools/pmc_traffic.py)
     return out
 
 
@@ -801,16 +802,18 @@ def main():
     # ---- hot path B (indels): a14 21-state grid likelihoods of one sample at tumor depth; a11 allele-group genotypes ----
     hrs = synth.readscore_batch(args.indels, rng, depth_mean=110.0)
     drs = device.DeviceReadScoreBatch(hrs, dev)
-    dt_i, iloci, kms_i = timed(lambda: drs.grid_lhood(), args.steps, args.warmup, drs.n_indels)
-    fast_opt_i = capi.indel_options(True)
-    fast_opt_i.fast_form = 1
-    dt_if, iloci_f, kms_if = timed(lambda: drs.grid_lhood(opt=fast_opt_i), args.steps, args.warmup, drs.n_indels)
+    # (the library's default -- the fast form, what the drop-in runs -- is the leg's figure; the exact form beside it)
+    fast_opt_i = capi.indel_options(True, exact=False)
+    assert fast_opt_i.fast_form == 1
+    dt_i, iloci, kms_i = timed(lambda: drs.grid_lhood(opt=fast_opt_i), args.steps, args.warmup, drs.n_indels)
+    dt_if, iloci_f, kms_if = dt_i, iloci, kms_i
+    dt_ix, iloci_x, kms_ix = timed(lambda: drs.grid_lhood(opt=capi.indel_options(True, exact=True)), args.steps, args.warmup, drs.n_indels)
     indel_alg_bytes = 16 * drs.n_reads + 8 * 21 * drs.n_indels  # 16 B per read + 8 B per state
     # ... and on the same reads with ONE read length, what a WGS sample has (the batch above mixes lengths 8..200 into 15 % of the reads, a
     # test input): the two logs of get_het_observed_allele_ratio are then 19 pairs per indel, not per read
     hrs.read_length[:] = 150
     drs1 = device.DeviceReadScoreBatch(hrs, dev)
-    dt_i1, iloci_1, kms_i1 = timed(lambda: drs1.grid_lhood(), args.steps, args.warmup, drs1.n_indels)
+    dt_i1, iloci_1, kms_i1 = timed(lambda: drs1.grid_lhood(opt=capi.indel_options(True, exact=True)), args.steps, args.warmup, drs1.n_indels)
     del drs1
     hag = synth.allele_group_batch(args.indels, rng)
     dag = device.DeviceAlleleGroupBatch(hag, dev)
@@ -906,6 +909,17 @@ def main():
         ach = alg_bytes / (kernel_ms * 1e-3) / 1e9
         o = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": hbm_traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms}
+        # the binding resource beside the HBM fraction: busy cycles of the busiest unit / kernel cycles, from the SQ counter passes of the
+        # visit the traffic came from (VALU issue, LDS arrays, scalar unit, vector-memory issue; "hbm" when the measured HBM fraction is
+        # the largest; "latency" when no unit is busy 30 % of the time)
+        names = [n.split(" ")[0] for n in kernel.replace("2*", "").split("+")]
+        bounds = [traffic.get("__bound__", {}).get(n) for n in names]
+        bounds = [b for b in bounds if b and "bound_by" in b]
+        if bounds:
+            worst = max(bounds, key=lambda b: b.get("kernel_cycles", 0))  # (several kernels: the one that takes the longest)
+            o["bound_by"], o["frac_bound"] = worst["bound_by"], worst["frac_bound"]
+            o["bound_units"] = {u: worst.get(u) for u in ("valu_busy", "lds_busy", "salu_busy", "vmem_busy", "wave_issue", "wave_wait", "waves_per_cu", "hbm_frac_measured") if worst.get(u) is not None}
+            o["bound_source"] = traffic.get("__source__")
         if hbm_traffic:
             o["traffic_source"] = traffic.get("__source__")
             o["measured_hbm_gbs"] = hbm_traffic / (kernel_ms * 1e-3) / 1e9
@@ -948,12 +962,15 @@ def main():
         "indel_grid_loci_per_s": iloci / dt_i, "indel_grid_ms_per_step": dt_i / args.steps * 1e3,
         "roofline_indel_grid": roof("indel_grid_lhood_kernel", indel_alg_bytes, kms_i, traffic.get("indel_grid_lhood_kernel")),
         "indel_grid_fast_form_loci_per_s": iloci_f / dt_if, "indel_grid_fast_form_kernel_ms": kms_if,
+        "indel_grid_exact_form_loci_per_s": iloci_x / dt_ix, "indel_grid_exact_form_kernel_ms": kms_ix,
         "indel_grid_one_read_length_loci_per_s": iloci_1 / dt_i1, "indel_grid_one_read_length_kernel_ms": kms_i1,
         "allele_group_one_read_length_loci_per_s": gloci_1 / dt_g1, "allele_group_one_read_length_kernel_ms": kms_g1,
         "allele_group_fast_form_loci_per_s": gloci_f / dt_gf, "allele_group_fast_form_kernel_ms": kms_gf,
-        "fast_form_note": "sk_indel_options.fast_form = 1: the algebraically equal form with two exp per read shared by its states and one "
-                          "log per state (agrees with the reference's operation order to ~1e-15 relative, within north_star's 1e-5; the "
-                          "integer outputs are pinned by tests/test_gpu_parity.py); off by default: the exact form is bit-identical",
+        "fast_form_note": "sk_indel_options.fast_form = 1, the library's default and what indel_grid_* / roofline_indel_grid measure: the "
+                          "algebraically equal form with two exp per read shared by its states and one log per state (agrees with the "
+                          "reference's operation order to ~1e-13 relative, within north_star's 1e-5; the integer outputs are pinned by "
+                          "tests/test_gpu_parity.py, the somatic end-to-end outputs stay byte-identical); *_exact_form_*: fast_form = 0, "
+                          "bit-identical doubles; *_one_read_length_*: the exact form on reads of one length",
         "allele_group_loci_per_s": gloci / dt_g, "allele_group_ms_per_step": dt_g / args.steps * 1e3,
         "roofline_allele_group": roof("allele_group_kernel", group_alg_bytes, kms_g, traffic.get("allele_group_kernel")),
         "roofline_pileup": roof("pileup_read_kernel+2*pileup_column_kernel_t", pileup_alg_bytes, kms_p, pil_traffic),

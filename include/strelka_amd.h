@@ -850,12 +850,12 @@ typedef struct sk_indel_options { /* starling_base_options / starling_sample_opt
     double tier2_random_base_match_prob; /* 0.25 (L/starling_common/Tier2Options.hh:50): used for every read of a tier2 pass */
     double read_confident_support_threshold; /* 0.51 (starling_base_shared.hh:245) */
     int32_t is_use_alt_indel;         /* 1 */
-    int32_t fast_form;                /* 0 (default): every term in the reference's operation order, likelihoods bit-identical.
-                                         1: sk_indel_grid_lhood* evaluate the same terms with two exp per read shared by its 21
-                                         states and one log per state (~2.8x faster); likelihoods then agree with the reference
-                                         to ~1e-15 relative instead of bit for bit (north_star's bar is 1e-5), the Q-scores
-                                         and genotypes derived from them are the same in every case tested
-                                         (tests/test_gpu_parity.py) */
+    int32_t fast_form;                /* 1 (default): sk_indel_grid_lhood* evaluate the 21 states' terms with two exp per read shared by
+                                         the states and one log per state (3x faster); likelihoods agree with the reference's
+                                         operation order to ~1e-13 relative (north_star's bar is 1e-5), the Q-scores, genotypes and
+                                         tier decisions derived from them are the reference's in every case tested
+                                         (tests/test_gpu_parity.py: 10^6 indels; the somatic end-to-end outputs byte for byte).
+                                         0: every term in the reference's operation order, likelihoods bit-identical. */
 } sk_indel_options;
 void sk_indel_options_default(sk_indel_options* opt, int is_somatic);
 

@@ -644,9 +644,13 @@ def make_call(q, base, fwd=1, nmm=0, filt=0, tscf=0):
 # ----------------------------------------------------------------------------------------------------------------------
 # indels
 
-def indel_options(is_somatic=False):
+def indel_options(is_somatic=False, exact=True):
+    """sk_indel_options_default; `exact` (the default HERE: these helpers serve tests that compare doubles bit for bit with the oracle)
+    asks for the reference's operation order -- the library's own default is the fast form (sk_indel_options.fast_form)."""
     o = IndelOptions()
     lib().sk_indel_options_default(C.byref(o), int(is_somatic))
+    if exact:
+        o.fast_form = 0
     return o
 
 

@@ -817,7 +817,12 @@ void sk_indel_options_default(sk_indel_options* opt, int is_somatic)
     opt->tier2_random_base_match_prob = 0.25;
     opt->read_confident_support_threshold = 0.51;
     opt->is_use_alt_indel = 1;
-    opt->fast_form = 0;
+    // The 21-state grid likelihoods in the fast form (two exp per read shared by its states, one log per state: 3x).  north_star's
+    // bar for log-likelihoods is 1e-5; this form agrees with the reference's operation order to ~1e-13, every integer the path derives
+    // from them (QSI, QSI_NT, NT, the tier decisions) is the reference's on 10^6 fuzzed indels (tests/test_gpu_parity.py) and the
+    // somatic end-to-end outputs stay byte-identical (tests/test_bench_e2e.py, tools/fuzz/e2e_seeds.py somatic).  fast_form = 0 is the
+    // exact form: bit-identical doubles ($STRELKA_AMD_INDEL_EXACT=1 in the adapter).  DESIGN.md section 5.
+    opt->fast_form = 1;
 }
 
 void sk_somatic_indel_options_default(sk_somatic_indel_options* opt)

@@ -502,8 +502,16 @@ def test_allele_group_genotype_lhoods_wide(gpu):
     assert np.array_equal(got2["lhood"].view(np.uint64), lh2.view(np.uint64)) and np.array_equal(got2["counts"], counts2)
 
 
+def test_the_librarys_default_is_the_fast_form_and_the_helpers_ask_for_the_exact_one():
+    """sk_indel_options_default sets fast_form = 1 (what the drop-in runs; $STRELKA_AMD_INDEL_EXACT=1 in the adapter
+    for the other); the test helpers (capi.indel_options) ask for the exact form, because they compare doubles bit for bit"""
+    from strelka_amd import capi
+    assert capi.indel_options(True, exact=False).fast_form == 1 and capi.indel_options(False, exact=False).fast_form == 1
+    assert capi.indel_options(True).fast_form == 0
+
+
 def test_indel_fast_form_keeps_every_integer_output(gpu):
-    """sk_indel_options.fast_form: two exp per read shared by its 21 states instead of the reference's operation order.
+    """sk_indel_options.fast_form (the library's default): two exp per read shared by its 21 states instead of the reference's operation order.
     Likelihoods then agree to ~1e-13 absolute (1e-15 relative to the terms' magnitude) instead of bit for bit; over 10^6 candidate
     indels the somatic calls derived from them -- QSI, QSI_NT, NTYPE, max_gt of either tier -- are the same."""
     from strelka_amd import capi

@@ -3,7 +3,13 @@ GPU box pass variant=amd): depth, variant density, the way the run is cut into r
 be the reference's byte for byte.  The routed gVCF path (site 10: plain sites and whole blocks from the device's window) sees shallow and
 deep samples, regions that start inside blocks, regions called out of order.
 
-usage: python tools/fuzz/e2e_seeds.py [n_seeds=16] [first_seed=1] [variant=dbl] [workers=8] [somatic|multi]"""
+usage: python tools/fuzz/e2e_seeds.py [n_seeds=16] [first_seed=1] [variant=dbl] [workers=8] [somatic|multi|adversarial]
+
+`adversarial` aims at site 10 (whole gVCF blocks installed from the device's runs, adapter/sk_adapter_gvcf.cpp): quiet samples -- long runs
+of plain sites, many installed blocks -- with everything that must break a block placed INSIDE such runs: candidate indels from a VCF that
+no read supports (--candidate-indel-input-vcf), forced-output SNV and indel records (--force-output-vcf), ploidy regions and no-compress
+regions that begin and end mid-run, a read buffer small enough to drop reads (--max-sample-read-buffer), regions cut inside runs and called
+out of order.  A run counts only if blocks were installed (the drop-in's own counter, STRELKA_AMD_VERBOSE)."""
 import os
 import random
 import shutil
@@ -104,6 +110,130 @@ def one(seed, variant, models):
                 what, f, k + 1, want[f][k] if k < len(want[f]) else "<end>", got[f][k] if k < len(got[f]) else "<end>")
     return True, "%s: identical (%d variant records, %d gVCF lines)" % (
         what, sum(1 for l in want["variants.vcf"] if l[0] != "#"), len(want["genome.S1.vcf"]))
+
+
+def one_adversarial(seed, variant, models):
+    import re
+    rng = random.Random(49000 + seed)
+    length = rng.choice([100000, 160000, 240000])
+    depth = rng.choice([12.0, 25.0, 40.0])
+    snv_every, indel_every = rng.choice([2000, 8000]), rng.choice([8000, 40000])
+    d = os.path.join(E.REPO, "oracle", "_ref", "synth", "fuzz_adv_%d" % seed)
+    if not os.path.exists(os.path.join(d, "chrom_depth.txt")):
+        os.makedirs(d, exist_ok=True)
+        subprocess.run([sys.executable, "tools/make_wgs_bam.py", d, os.path.join(E.BIN_DIR, "samtools"), "--length", str(length), "--depth", str(depth),
+                        "--seed", str(70000 + seed), "--snv-every", str(snv_every), "--indel-every", str(indel_every), "--procs", "1"],
+                       check=True, stdout=subprocess.DEVNULL)
+        with open(os.path.join(d, "chrom_depth.txt"), "w") as f:
+            f.write("chrW\t%.3f\n" % depth)
+    fa = open(os.path.join(d, "wgs.fa")).read().split("\n", 1)[1].replace("\n", "").upper()
+
+    def vcf(path, rows, header_extra=""):
+        with open(path, "w") as f:
+            f.write("##fileformat=VCFv4.1\n" + header_extra + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+            for pos, ref, alt in sorted(rows):
+                f.write("chrW\t%d\t.\t%s\t%s\t.\t.\t.\n" % (pos, ref, alt))
+        subprocess.run([os.path.join(E.BIN_DIR, "bgzip"), "-f", path], check=True)
+        subprocess.run([os.path.join(E.BIN_DIR, "tabix"), "-f", "-p", "vcf", path + ".gz"], check=True)
+        return path + ".gz"
+
+    def indel_row(pos):
+        # a left-anchored deletion or insertion of 1-12 bases at `pos` (1-based anchor), or None where the reference has an N
+        n = rng.choice([1, 1, 2, 3, 5, 8, 12])
+        seg = fa[pos - 1:pos + n]
+        if len(seg) < n + 1 or any(c not in "ACGT" for c in seg):
+            return None
+        # (normalised records only -- the reference rejects a forced record that could be shifted left: the last base of the deleted /
+        # inserted sequence differs from the anchor base)
+        if rng.random() < 0.5:
+            return (pos, seg, seg[0]) if seg[-1] != seg[0] else None
+        ins = "".join(rng.choice("ACGT") for _ in range(n - 1)) + rng.choice([b for b in "ACGT" if b != seg[0]])
+        return (pos, seg[0], seg[0] + ins)
+    extra = list(models) if rng.random() < 0.7 else []
+    what = []
+    if rng.random() < 0.8:
+        rows = [r for r in (indel_row(p) for p in rng.sample(range(200, length - 200), rng.choice([20, 120, 400]))) if r]
+        extra += ["--candidate-indel-input-vcf", vcf(os.path.join(d, "cand_%d.vcf" % seed), rows)]
+        what.append("%d candidate indels" % len(rows))
+    if rng.random() < 0.8:
+        rows = []
+        for p in rng.sample(range(200, length - 200), rng.choice([30, 200, 800])):
+            if rng.random() < 0.3:
+                r = indel_row(p)
+                if r:
+                    rows.append(r)
+            elif fa[p - 1] in "ACGT":
+                rows.append((p, fa[p - 1], rng.choice([b for b in "ACGT" if b != fa[p - 1]])))
+        extra += ["--force-output-vcf", vcf(os.path.join(d, "forced_%d.vcf" % seed), rows)]
+        what.append("%d forced records" % len(rows))
+    if rng.random() < 0.7:
+        rows, at = [], 500
+        while at < length - 3000:
+            at += rng.randrange(400, 12000)
+            n = rng.choice([1, 2, 17, 120, 900])
+            if at + n < length:
+                rows.append((at, at + n, rng.choice([0, 1, 1])))
+            at += n
+        pv = os.path.join(d, "ploidy_%d.vcf" % seed)
+        with open(pv, "w") as f:
+            f.write("##fileformat=VCFv4.1\n##FORMAT=<ID=CN,Number=1,Type=Integer,Description=\"copy number\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tNA_SYNTH\n" +
+                    "".join("chrW\t%d\t.\tN\t<CNV>\t.\tPASS\tEND=%d\tCN\t%d\n" % r for r in rows))
+        subprocess.run([os.path.join(E.BIN_DIR, "bgzip"), "-f", pv], check=True)
+        subprocess.run([os.path.join(E.BIN_DIR, "tabix"), "-f", "-p", "vcf", pv + ".gz"], check=True)
+        extra += ["--ploidy-region-vcf", pv + ".gz"]
+        what.append("%d ploidy regions" % len(rows))
+    if rng.random() < 0.7:
+        bed, n_bed = os.path.join(d, "nocompress_%d.bed" % seed), 0
+        with open(bed, "w") as f:
+            at = 300
+            while at < length - 2000:
+                at += rng.randrange(300, 9000)
+                n = rng.choice([1, 3, 40, 500])
+                if at + n < length:
+                    f.write("chrW\t%d\t%d\n" % (at, at + n))
+                    n_bed += 1
+                at += n
+        subprocess.run([os.path.join(E.BIN_DIR, "bgzip"), "-f", bed], check=True)
+        subprocess.run([os.path.join(E.BIN_DIR, "tabix"), "-f", "-p", "bed", bed + ".gz"], check=True)
+        extra += ["--nocompress-bed", bed + ".gz"]
+        what.append("%d no-compress regions" % n_bed)
+    if rng.random() < 0.4:
+        cap = rng.choice([150, 400, 1500])
+        extra += ["--max-sample-read-buffer", str(cap)]
+        what.append("read buffer %d" % cap)
+    cuts = sorted(rng.sample(range(1000, length - 1000), rng.choice([0, 1, 2, 4])))
+    edges = [1] + cuts + [length + 1]
+    regions = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        gap = rng.choice([0, 0, 1, 37])
+        if b - gap > a:
+            regions.append("chrW:%d-%d" % (a, b - 1 - gap))
+    if rng.random() < 0.4:
+        rng.shuffle(regions)
+    out, installed = {}, -1
+    for binary in ("starling2_ref", "starling2_" + variant):
+        with tempfile.TemporaryDirectory() as o:
+            p = subprocess.run(E.germline_wgs_argv(os.path.basename(binary), o + "/", [os.path.join(d, "wgs.bam")], regions, os.path.join(d, "wgs.fa"),
+                                                   os.path.join(d, "chrom_depth.txt"), extra=extra), env=dict(os.environ, STRELKA_AMD_VERBOSE="1"),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=3600)
+            if p.returncode != 0:
+                return False, "adversarial seed %d: %s failed (%d): %s" % (seed, binary, p.returncode, p.stderr.decode(errors="replace")[-600:])
+            m = re.search(r"gvcf_blocks_installed=(\d+)", p.stderr.decode(errors="replace"))
+            if m and not binary.endswith("_ref"):
+                installed = int(m.group(1))
+            out[binary] = {f: E.vcf_body(os.path.join(o, f), keep_header=True) for f in ("variants.vcf", "genome.S1.vcf")}
+    want, got = out["starling2_ref"], out["starling2_" + variant]
+    if not os.environ.get("SK_FUZZ_KEEP"):
+        shutil.rmtree(d, ignore_errors=True)
+    desc = "adversarial seed %d: %d bp at %gx, %s, regions %s, %d blocks installed" % (seed, length, depth, ", ".join(what) or "nothing from outside", ",".join(regions), installed)
+    for f in want:
+        if want[f] != got[f]:
+            k = next((i for i, (x, y) in enumerate(zip(want[f], got[f])) if x != y), min(len(want[f]), len(got[f])))
+            return False, "%s: %s differs at line %d\n  reference: %s\n  drop-in:   %s" % (
+                desc, f, k + 1, want[f][k] if k < len(want[f]) else "<end>", got[f][k] if k < len(got[f]) else "<end>")
+    if installed <= 0:
+        return False, desc + ": identical, but NO block was installed (the run does not count)"
+    return True, desc + ": identical (%d variant records, %d gVCF lines)" % (sum(1 for l in want["variants.vcf"] if l[0] != "#"), len(want["genome.S1.vcf"]))
 
 
 def one_somatic(seed, variant):
@@ -218,7 +348,8 @@ def main():
     models = ("--snv-scoring-model-file", md + "/germlineSNVScoringModels.json", "--indel-scoring-model-file", md + "/germlineIndelScoringModels.json")
     bad = 0
     mode = sys.argv[5] if len(sys.argv) > 5 else "germline"
-    fn = {"somatic": lambda s: one_somatic(s, variant), "multi": lambda s: one_multi(s, variant, models)}.get(mode, lambda s: one(s, variant, models))
+    fn = {"somatic": lambda s: one_somatic(s, variant), "multi": lambda s: one_multi(s, variant, models),
+          "adversarial": lambda s: one_adversarial(s, variant, models)}.get(mode, lambda s: one(s, variant, models))
     with ThreadPoolExecutor(workers) as ex:
         for ok, msg in ex.map(fn, range(first, first + n)):
             print(msg, flush=True)

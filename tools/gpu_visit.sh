@@ -47,6 +47,15 @@ for step in "$@"; do
       python tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.json 2>$OUT/pmc_traffic.err; head -c 600 $OUT/pmc_traffic.json
       # (a bench step later in this visit quotes these passes: bench.py reads the newest profiles/*_pmc_traffic.json)
       [ -s $OUT/pmc_traffic.json ] && cp $OUT/pmc_traffic.json profiles/${TAG}_pmc_traffic.json ;;
+    pmc_bound)  # SQ counters of every bench kernel (which unit binds it: tools/pmc_traffic.py `bound`); run BEFORE pmc_traffic in a visit
+      i=0
+      for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+                 "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
+        i=$((i+1))
+        timeout 600 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_sq$i -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 --realign-processes 0 > $OUT/pmc_sq$i.log 2>&1
+        timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_a5_sq$i -o pmc -- python bench.py --only a5 --steps 10 --warmup 2 > $OUT/pmc_a5_sq$i.log 2>&1
+        tail -c 200 $OUT/pmc_sq$i.log
+      done ;;
     pmc_g3)
       i=0
       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \

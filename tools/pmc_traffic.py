@@ -96,4 +96,104 @@ for cand in (os.path.join(root, "commit.txt"), os.path.join(os.path.dirname(os.p
     if os.path.exists(cand):
         commit = open(cand).read().strip() or None
         break
-json.dump(dict(workload=workload, kernels=out, a5_only=a5_only, commit=commit), sys.stdout, indent=1)
+
+
+# ---- which unit binds a kernel: SQ counter passes of the same commands (tools/gpu_visit.sh pmc_bound ->
+# pmc_sq1 / pmc_sq2, pmc_a5_sq1 / pmc_a5_sq2).  Per kernel, over its full-size launches:
+#   valu_busy  = SQ_ACTIVE_INST_VALU * 4 / (SIMDs * kernel cycles)     the vector units' issue cycles (the counter is in quad-cycles,
+#                                                                       MI355X_MICROARCH.md "s_memtime tick vs SQ PMC units")
+#   salu_busy  = SQ_ACTIVE_INST_SCA * 4 / (SIMDs * kernel cycles)
+#   lds_busy   = SQ_LDS_IDX_ACTIVE / (CUs * kernel cycles)             cycles the LDS arrays were active
+#   vmem_busy  = SQ_ACTIVE_INST_VMEM * 4 / (SIMDs * kernel cycles)     vector-memory instruction issue
+#   wave_issue = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, wave_wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES   how a resident wave spends its life
+#   waves_per_cu = SQ_WAVE_CYCLES * 4 / (CUs * kernel cycles)          waves in flight per CU, averaged over the kernel
+# kernel cycles = GRBM_GUI_ACTIVE of the launch (one XCD's count; divided by the 8 XCDs when the tool reports their sum: decided by
+# comparing with the launch's duration at the 2.4 GHz peak clock).  `bound_by`: the busiest of valu / lds / salu / vmem, "hbm" when the
+# counter-measured HBM fraction (FETCH/WRITE passes) is larger than all of them, "latency" when nothing is busier than 30 % (the
+# kernel's waves wait: launch- or dependency-bound).
+N_SIMD, N_CU, PEAK_HZ = 1024.0, 256.0, 2.4e9
+
+
+def collect_sq(prefixes):
+    per = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values per launch (in dispatch order)
+    dur = defaultdict(list)
+    for prefix in prefixes:
+        for f in glob.glob(os.path.join(root, prefix, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    name = row["Kernel_Name"].replace("(anonymous namespace)::", "")
+                    if name.startswith("void "):
+                        name = name[5:]
+                    k = name.split("(")[0].split("<")[0]
+                    per[k][row["Counter_Name"]].append((row.get("Dispatch_Id"), float(row["Counter_Value"])))
+                    try:
+                        if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                            dur[k].append((row.get("Dispatch_Id"), float(row["End_Timestamp"]) - float(row["Start_Timestamp"])))
+                    except (KeyError, TypeError, ValueError):
+                        pass
+    res = {}
+    for k, counters in per.items():
+        if "GRBM_GUI_ACTIVE" not in counters or "SQ_WAVE_CYCLES" not in counters:
+            continue
+        gui = [v for _, v in counters["GRBM_GUI_ACTIVE"]]
+        top = max(gui)
+        if top <= 0:
+            continue
+        keep = {d for d, v in counters["GRBM_GUI_ACTIVE"] if v >= 0.5 * top}   # the full-size launches (as full_size above)
+        mean = {}
+        for c, vals in counters.items():
+            # (the passes are separate runs of one deterministic command: the n-th launch of a kernel is the same work in each;
+            # counters of the pass that also took GRBM_GUI_ACTIVE are matched by dispatch id, the others by size)
+            sel = [v for d, v in vals if d in keep] or full_size([v for _, v in vals])
+            mean[c] = sum(sel) / len(sel)
+        cycles = mean["GRBM_GUI_ACTIVE"]
+        durs = [v for d, v in dur.get(k, []) if d in keep]
+        xcd_sum = None
+        if durs:
+            ratio = cycles / (sum(durs) / len(durs) * 1e-9 * PEAK_HZ)
+            xcd_sum = ratio > 2.5   # (a sum over the 8 XCDs reads ~8x the launch's duration in cycles)
+            if xcd_sum:
+                cycles /= 8.0
+
+        def g(name):
+            return mean.get(name)
+        o = {"kernel_cycles": cycles, "cycles_were_a_sum_over_xcds": xcd_sum, "launches": len(keep)}
+        if g("SQ_ACTIVE_INST_VALU") is not None:
+            o["valu_busy"] = g("SQ_ACTIVE_INST_VALU") * 4 / (N_SIMD * cycles)
+        if g("SQ_ACTIVE_INST_SCA") is not None:
+            o["salu_busy"] = g("SQ_ACTIVE_INST_SCA") * 4 / (N_SIMD * cycles)
+        if g("SQ_ACTIVE_INST_VMEM") is not None:
+            o["vmem_busy"] = g("SQ_ACTIVE_INST_VMEM") * 4 / (N_SIMD * cycles)
+        if g("SQ_LDS_IDX_ACTIVE") is not None:
+            o["lds_busy"] = g("SQ_LDS_IDX_ACTIVE") / (N_CU * cycles)
+        wc = g("SQ_WAVE_CYCLES")
+        if wc:
+            if g("SQ_ACTIVE_INST_ANY") is not None:
+                o["wave_issue"] = g("SQ_ACTIVE_INST_ANY") / wc
+            if g("SQ_WAIT_ANY") is not None:
+                o["wave_wait"] = g("SQ_WAIT_ANY") / wc
+            o["waves_per_cu"] = wc * 4 / (N_CU * cycles)
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT"):
+            if g(c) is not None:
+                o[c.lower()] = g(c)
+        units = {u: o[u + "_busy"] for u in ("valu", "lds", "salu", "vmem") if (u + "_busy") in o}
+        if units:
+            best = max(units, key=units.get)
+            o["bound_by"] = best if units[best] >= 0.30 else "latency"
+            o["frac_bound"] = units[best]
+        res[k] = o
+    return res
+
+
+bound = collect_sq(("pmc_sq1", "pmc_sq2"))
+bound_a5 = collect_sq(("pmc_a5_sq1", "pmc_a5_sq2"))
+for k, o in bound_a5.items():
+    if k == "flatten_score_kernel":
+        bound[k] = o    # (the headline's kernel at the headline's size)
+for k, o in bound.items():
+    if k in out and "bound_by" in o:
+        hbm = out[k]["hbm_bytes_per_launch"] / max(o["kernel_cycles"] / PEAK_HZ, 1e-12) / 8.0e12
+        o["hbm_frac_measured"] = hbm
+        if hbm > o["frac_bound"]:
+            o["bound_by"], o["frac_bound"] = "hbm", hbm
+json.dump(dict(workload=workload, kernels=out, a5_only=a5_only, bound=bound or None, commit=commit), sys.stdout, indent=1)
