@@ -32,6 +32,7 @@
 #endif
 #include <algorithm>
 #include <climits>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -346,6 +347,23 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
                 if (w.gvcf_runs != nullptr) chunk.runs.assign(w.gvcf_runs, w.gvcf_runs + n);
                 chunk.rawCount.resize(n);
                 for (size_t i(0); i < n; ++i) chunk.rawCount[i] = static_cast<uint32_t>(w.tier1_off[i + 1] - w.tier1_off[i]);
+                // test switch: every position's site summary as the window brought it (the kernel's, or over the CPU double the shared
+                // statement's), one text line each -- tests/test_gvcf_site_reference.py sets them beside what the REFERENCE printed for
+                // the same positions of the same sample (tests/golden/gvcf_site_reference.npz)
+                static const char* const dumpPath(std::getenv("STRELKA_AMD_GVCF_SITE_DUMP"));
+                if (dumpPath != nullptr && sampleIndex == 0)
+                {
+                    static FILE* dump(std::fopen(dumpPath, "w"));
+                    if (dump != nullptr)
+                    {
+                        for (size_t i(0); i < n; ++i)
+                        {
+                            std::fprintf(dump, "%d %u %d %u %u %u %u\n", static_cast<int>(w.begin + static_cast<pos_t>(i)), w.site_summary[i].flags, w.site_summary[i].gqx,
+                                         w.site_summary[i].ref_fwd, w.site_summary[i].ref_rev, w.clean_count[i], chunk.rawCount[i]);
+                        }
+                        std::fflush(dump);
+                    }
+                }
             }
             chunk.ploidy.resize(n);
             for (size_t i(0); i < n; ++i)
