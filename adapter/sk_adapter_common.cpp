@@ -69,6 +69,13 @@ struct InitOutcome
 InitOutcome run_sk_init()
 {
     InitOutcome o;
+    // A workflow runs one caller process per core (PY/strelkaSharedOptions.py:153-161) and the device runs eight processes' work side by
+    // side: unless told otherwise ($STRELKA_AMD_BROKER=0) a caller process is a client of its device's broker (one GPU context however
+    // many callers, started by the first of them: include/strelka_amd.h "the broker").
+    {
+        const char* v(std::getenv("STRELKA_AMD_BROKER"));
+        if (v == nullptr || *v == 0) (void)sk_broker_enable(1);
+    }
     // segment process -> device: pyflow starts one process per genome segment; the launcher (or the workflow's task
     // wrapper) exports STRELKA_AMD_DEVICE = segment index mod number of GPUs.  Many processes may share a device.
     // (a launcher may count more devices than this node has: the index is taken modulo the devices present)
@@ -165,7 +172,7 @@ void init()
     {
         log_os << "WARNING: strelka_amd runs with the device math library; outputs may differ from the reference in the last digit\n";
     }
-    note_process_slot();
+    if (sk_broker_client() == 0) note_process_slot(); // (clients of the broker share ONE context: the eight-process ceiling is not theirs)
     done = true;
 }
 

@@ -242,12 +242,20 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
         evs_models = (os.path.join(root, "models", "germlineSNVScoringModels.json"), os.path.join(root, "models", "germlineIndelScoringModels.json"))
     try:
         warm = [[(0, "chrW", 1, min(L, 50000), 0)]]
-        farm.run_farm(warm, argv_fn(drop_in), os.path.join(root, "warm"), outputs, n_gpus=1, jobs=1,
-                      device_offset=local_rank)  # page the binary and the GPU runtime in
+        farm.run_farm(warm, argv_fn(drop_in), os.path.join(root, "warm"), outputs, n_gpus=1, jobs=1, device_offset=local_rank,
+                      env=({"STRELKA_AMD_BROKER": "1", "STRELKA_AMD_BROKER_SOCKET": "sk_bench_rank_%d" % os.getpid(), "STRELKA_AMD_BROKER_IDLE_S": "60"}
+                           if world > 1 else {"STRELKA_AMD_BROKER": "0"}))  # page the binary and the GPU runtime in (N > 1: start the device's broker)
         barrier()
         t0 = time.perf_counter()
+        # (one rank: every caller process holds a GPU context of its own -- at most eight, the leg's equal-process-count comparison; the
+        # adapter's own default is the broker, measured by e2e_box)
+        amd_env = {"STRELKA_AMD_VERBOSE": "1", "STRELKA_AMD_BROKER": "0"}
+        if world > 1:
+            # N > 1: this rank's own process holds a GPU context (torch, RCCL); its caller processes are clients of the device's broker
+            # (one more context per device, however many callers: strelka_amd/csrc/sk_rt.h) instead of a context each
+            amd_env.update({"STRELKA_AMD_BROKER": "1", "STRELKA_AMD_BROKER_SOCKET": "sk_bench_rank_%d" % os.getpid(), "STRELKA_AMD_BROKER_IDLE_S": "60"})
         amd = farm.run_farm(groups, argv_fn(drop_in), os.path.join(root, "amd"), outputs, n_gpus=1, jobs=jobs,
-                            device_offset=local_rank, env={"STRELKA_AMD_VERBOSE": "1"})
+                            device_offset=local_rank, env=amd_env)
         barrier()
         amd_wall = max_over_ranks(time.perf_counter() - t0)
         hooks = {}
@@ -279,9 +287,9 @@ def e2e_leg(args, rank, world, local_rank, barrier, max_over_ranks, with_referen
                "bp": L * world, "reads": int(L * depth / 150) * world, "segments": len(groups) * world,
                "amd_wall_s": amd_wall, "amd_procs": jobs * world, "amd_procs_per_gpu": jobs, "host_cores": len(cores),
                "cores_used": jobs * world,
-               "procs_note": "one caller process per core, at most --e2e-max-procs-per-gpu (8) per GPU: one MI355X serves up to ~8 "
-                             "caller processes at full speed-up; with 12-16 sharing it the device's scheduler time-slices them and the "
-                             "gain is gone (profiles/r03_v10, r03_v11).  The reference leg runs on the same number of cores.",
+               "procs_note": "one caller process per segment and core, each with a GPU context of its own (at most --e2e-max-procs-per-gpu, 8: the "
+                             "device runs eight processes side by side); the reference leg runs with the same number of processes.  More "
+                             "callers than eight go through the device's broker: the e2e_box leg (and this leg when --gpus > 1).",
                "bp_per_s": L * world / amd_wall, "process_seconds_sum": sum(amd.process_s),
                "hook_seconds": {k: round(v, 4) for k, v in hooks.items()},
                "counters": counters,
@@ -386,7 +394,7 @@ def e2e_box_leg(args, local_rank, mode="germline"):
         warm = [[(0, "chrW", 1 + i * 50000, min(L, (i + 1) * 50000), 0)] for i in range(P) if i * 50000 < L]
         farm.run_farm(warm, argv_fn(drop_in), os.path.join(root, "warm"), outputs, n_gpus=1, jobs=P, device_offset=local_rank, env=broker_env)
         runs = []
-        plan = [("broker", j, broker_env) for j in sorted({min(8, P), min(12, P), min(16, P)}, reverse=True)] + [("own_context", min(8, P), {})]
+        plan = [("broker", j, broker_env) for j in sorted({min(8, P), min(12, P), min(16, P)}, reverse=True)] + [("own_context", min(8, P), {"STRELKA_AMD_BROKER": "0"})]
         for kind, jobs, env in plan:
             res = farm.run_farm(groups, argv_fn(drop_in), os.path.join(root, "%s_%d" % (kind, jobs)), outputs, n_gpus=1, jobs=jobs,
                                 device_offset=local_rank, env=dict(env, STRELKA_AMD_VERBOSE="1"))
@@ -874,13 +882,14 @@ def main():
 
     # ---- end to end (N > 1; a single rank ran these legs before it touched the GPU, see the top of main) ----
     if world > 1:
-        # (this process steps aside as far as it can: its cached device memory goes back and its stream is idle -- but it keeps its
-        # queue on the device, one of the eight the caller processes want: a rank runs at most 7 of them)
+        # (this process steps aside as far as it can: its cached device memory goes back and its stream is idle; the caller processes of
+        # the legs are clients of the device's broker, so this process's own context costs them one of the device's eight process slots
+        # and nothing else)
         import gc
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        args.e2e_max_procs_per_gpu = min(args.e2e_max_procs_per_gpu, 7)
+        args.e2e_max_procs_per_gpu = max(args.e2e_max_procs_per_gpu, 16)  # (broker clients: no process-slot ceiling, see e2e_leg)
 
         def barrier():
             dist.barrier()

@@ -74,8 +74,11 @@ int sk_libm_restated(void);
  * (strelka_amd/csrc/sk_rt.h; $STRELKA_AMD_BROKER_IDLE_S, _QUEUES, _LOG, _SOCKET, _NO_SPAWN).  Host stages (a realignment job's gate and
  * packing, a pileup stream's carry bookkeeping) stay in the caller.  Not available to a client: the `*_dev` entry points on a stream
  * of the caller's, and the event-timed diagnostics. */
-/** 1 when this process is a broker client ($STRELKA_AMD_BROKER). */
+/** 1 when this process is a broker client ($STRELKA_AMD_BROKER, sk_broker_enable). */
 int sk_broker_client(void);
+/** Turn the broker mode of this process on or off without the environment variable; before sk_init (fails afterwards).  The adapter
+ *  turns it on by default -- a workflow's caller processes are one per core -- and leaves it off with $STRELKA_AMD_BROKER=0. */
+int sk_broker_enable(int on);
 /** The server's main loop (what `sk_broker --device D [--socket NAME] [--idle-exit S]` runs): serves `device` on the abstract unix
  *  socket `socket_name` (NULL / "": the default name -- user, library build, device) until it has had no client for `idle_seconds`.
  *  Returns 0 after an idle exit, 2 when the device is unusable, 3 when another broker already serves the name. */

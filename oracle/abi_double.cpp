@@ -49,6 +49,8 @@ extern "C" {
 int sk_device_count(void) { return 1; }
 void* sk_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 void sk_host_free(void* p) { std::free(p); }
+int sk_broker_enable(int) { return 0; } // (the CPU double has no device side to share)
+int sk_broker_client(void) { return 0; }
 int sk_init(int) { g_ready = true; return 0; }
 int sk_init_strict(int) { g_ready = true; return 0; }
 int sk_check_device_errors(void) { return 0; }

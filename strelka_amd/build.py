@@ -78,7 +78,7 @@ def build_all(force=False, verbose=True):
         if force or _stale(obj, [src] + headers):
             lang = "hip" if s.endswith(".hip") else "c++"
             jobs.append([hipcc] + flags + ["-x", lang, "-c", src, "-o", obj])
-    broker_src = os.path.join(PKG, "host", "sk_broker_main.cpp")
+    broker_src = os.path.join(PKG, "broker", "sk_broker_main.cpp")
 
     def link_broker():
         if force or _stale(BROKER_PATH, [broker_src, LIB_PATH]):

@@ -220,7 +220,7 @@ assert DIGT_CALL_DTYPE.itemsize == 144 and SOMATIC_CALL_DTYPE.itemsize == 272
 
 # every symbol include/strelka_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "sk_device_count", "sk_host_alloc", "sk_host_free", "sk_init", "sk_init_strict", "sk_check_device_errors", "sk_debug_force_device_libm", "sk_debug_set_g3_variant", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_sync_mode", "sk_libm_restated", "sk_broker_client", "sk_broker_serve", "sk_broker_selftest", "sk_get_qscore_tables",
+    "sk_device_count", "sk_host_alloc", "sk_host_free", "sk_init", "sk_init_strict", "sk_check_device_errors", "sk_debug_force_device_libm", "sk_debug_set_g3_variant", "sk_shutdown", "sk_last_error", "sk_version", "sk_is_initialized", "sk_sync_mode", "sk_libm_restated", "sk_broker_client", "sk_broker_enable", "sk_broker_serve", "sk_broker_selftest", "sk_get_qscore_tables",
     "sk_score_alignments", "sk_score_alignments_dev", "sk_align_evmask_words", "sk_align_prepare", "sk_align_colmat_words", "sk_align_prepare_cols",
     "sk_bgzf_scan", "sk_bgzf_inflate", "sk_bgzf_inflate_prefixed", "sk_bgzf_inflate_dev", "sk_bam_header_end", "sk_bam_scan_records", "sk_bam_decode", "sk_bam_decode_kept", "sk_bam_decode_dev", "sk_normalize_alignments", "sk_normalize_alignments_dev",
     "sk_align_builder_create", "sk_align_builder_destroy", "sk_align_builder_clear", "sk_align_builder_append", "sk_align_builder_add_read",

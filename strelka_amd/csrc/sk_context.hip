@@ -285,6 +285,13 @@ int sk_device_count(void)
 
 int sk_broker_client(void) { return skrt::remote() ? 1 : 0; }
 
+int sk_broker_enable(const int on)
+{
+    if (g_ctx.ready) return sk_fail("sk_broker_enable: decided before sk_init (this process already has its device side)");
+    skrt::set_remote(on != 0);
+    return 0;
+}
+
 void* sk_host_alloc(size_t bytes)
 {
     if (!g_ctx.ready) {

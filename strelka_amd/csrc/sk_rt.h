@@ -34,6 +34,7 @@ namespace skrt
 // true in a broker client (decided once, at the library's first use: $STRELKA_AMD_BROKER)
 extern bool g_remote;
 inline bool remote() { return g_remote; }
+void set_remote(bool on);
 
 // the remote halves (sk_rt.hip)
 hipError_t r_malloc(void** p, size_t bytes);

@@ -55,6 +55,8 @@ bool env_remote()
 }
 }
 bool g_remote = env_remote();
+// (sk_broker_enable: a caller that wants the broker without exporting the variable -- the adapter, by default -- before sk_init)
+void set_remote(const bool on) { g_remote = on; }
 
 namespace
 {
@@ -678,6 +680,8 @@ void cl_close()
 // ---------------------------------------------------------------------------------------------------------------------
 // client entry points (sk_rt.h, sk_context.hip)
 
+static int r_connect_once(int device, std::string* why, bool* refused);
+
 int r_connect(const int device, std::string* why)
 {
     Client& cl = g_cl;
@@ -689,6 +693,21 @@ int r_connect(const int device, std::string* why)
         double t0;
         ~Lap() { g_tm.connect_s += tm_now() - t0; }
     } lap{ t_begin };
+    // (a server that was just leaving -- idle for its 20 s -- may accept the connection and be gone before the handshake: the next
+    // attempt finds nobody listening and starts a new one)
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        bool refused = false;
+        why->clear();
+        if (r_connect_once(device, why, &refused) == 0) return 0;
+        if (refused) return 1;
+        usleep(50000);
+    }
+    return 1;
+}
+
+static int r_connect_once(const int device, std::string* why, bool* refused)
+{
+    Client& cl = g_cl;
     const int s = connect_or_spawn(device, why);
     if (s < 0) {
         if (why->empty()) *why = "strelka_amd: cannot reach the broker";
@@ -723,6 +742,7 @@ int r_connect(const int device, std::string* why)
         if (r.type == MSG_REFUSED) {
             *why = std::string("strelka_amd: the broker refused this client: ") + std::string(r.text, strnlen(r.text, sizeof(r.text)));
             rc = 2;
+            *refused = true;
             break;
         }
         if (r.type != MSG_SLOT) {
@@ -1507,7 +1527,7 @@ void serve_client(const int sock)
 } // namespace skrt
 
 // ---------------------------------------------------------------------------------------------------------------------
-// the server's main loop (called by `sk_broker`, host/sk_broker_main.cpp)
+// the server's main loop (called by `sk_broker`, broker/sk_broker_main.cpp)
 
 extern "C" int sk_broker_serve(const int device, const char* socket_name_arg, const int idle_seconds)
 {

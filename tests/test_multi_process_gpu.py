@@ -30,7 +30,8 @@ def test_four_caller_processes_share_one_gpu(tmp_path):
     E.run(E.germline_argv("starling2_ref", gref, bams))
     E.run(E.somatic_argv("strelka2_ref", sref, bams[1], bams[0]))
     procs = []
-    env = dict(os.environ, STRELKA_AMD_DEVICE="0", STRELKA_AMD_VERBOSE="1")
+    # (a context per process, which is this file's subject; the adapter's default -- clients of the device's broker -- is tests/test_broker.py's)
+    env = dict(os.environ, STRELKA_AMD_DEVICE="0", STRELKA_AMD_VERBOSE="1", STRELKA_AMD_BROKER="0")
     for i in range(4):
         out = str(tmp_path / ("p%d" % i)) + "/"
         os.makedirs(out)

@@ -54,7 +54,7 @@ def main():
             shutil.rmtree(root, ignore_errors=True)
 
     print("%d bp, %d segments of %d bp, %d usable cores" % (L, len(groups), seg, cores), flush=True)
-    run("starling2_amd", cores, {})  # warm
+    run("starling2_amd", cores, {"STRELKA_AMD_BROKER": "0"})  # warm
     for jobs in [int(x) for x in os.environ.get("SK_SHARING_REF_JOBS", str(cores)).split(",")]:
         w, ps, _, us, ss = run("starling2_ref", jobs, {})
         print("reference            jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f)" % (jobs, w, ps, us, ss), flush=True)
@@ -64,7 +64,7 @@ def main():
         extra = [("spin wait", {"STRELKA_AMD_SPIN_WAIT": "1"}), ("spin wait, no SDMA", {"STRELKA_AMD_SPIN_WAIT": "1", "HSA_ENABLE_SDMA": "0"})]
     for w in [x for x in os.environ.get("SK_SHARING_WINDOWS", "").split(",") if x]:
         extra.append(("read window %s" % w, {"STRELKA_AMD_READ_WINDOW": w}))
-    configs = [("default", {})] + extra + ([("no SDMA", {"HSA_ENABLE_SDMA": "0"}), ("no SDMA, 2 HW queues", {"HSA_ENABLE_SDMA": "0", "GPU_MAX_HW_QUEUES": "2"})] if os.environ.get("SK_SHARING_SDMA") else [])
+    configs = [("own contexts", {"STRELKA_AMD_BROKER": "0"})] + extra + ([("no SDMA", {"HSA_ENABLE_SDMA": "0"}), ("no SDMA, 2 HW queues", {"HSA_ENABLE_SDMA": "0", "GPU_MAX_HW_QUEUES": "2"})] if os.environ.get("SK_SHARING_SDMA") else [])
     if os.environ.get("SK_SHARING_BROKER"):  # the per-GPU broker (csrc/sk_rt.h) with 4 / 8 / 2 hardware queues
         configs += [("broker", {"STRELKA_AMD_BROKER": "1"})]
         if os.environ.get("SK_SHARING_BROKER_DMA"):
