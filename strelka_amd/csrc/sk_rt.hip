@@ -1111,6 +1111,35 @@ struct BlockPool
 };
 BlockPool g_pool;
 
+// ... and their streams: creating one costs the runtime ~10 ms alone and ~100-200 ms when sixteen clients connect at once
+// (profiles/r06_v14_init_laps.txt: a warm server's clients waited 120 ms each for "their first allocation" -- for the server thread's
+// hipStreamCreate, in fact).  A departed client's stream has been waited for and is as good as new; a few are made ahead at start-up.
+struct StreamPool
+{
+    std::mutex mu;
+    std::vector<hipStream_t> idle;
+    hipStream_t take()
+    {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (!idle.empty()) {
+                hipStream_t st = idle.back();
+                idle.pop_back();
+                return st;
+            }
+        }
+        hipStream_t st = nullptr;
+        (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        return st;
+    }
+    void give(hipStream_t st)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        idle.push_back(st);
+    }
+};
+StreamPool g_streams;
+
 struct Block
 {
     void* p;
@@ -1436,7 +1465,8 @@ void serve_client(const int sock)
     }
     if (!g_srv.host_backend) {
         (void)hipSetDevice(g_srv.device);
-        SRV_HIP(c, hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        c.stream = g_streams.take();
+        if (!c.stream) srv_error(c, int32_t(hipErrorUnknown), "hipStreamCreateWithFlags", "no stream for this client");
     }
     g_srv.clients.fetch_add(1);
     g_srv.served.fetch_add(1);
@@ -1503,7 +1533,7 @@ void serve_client(const int sock)
         for (const std::vector<Block>* v : { &c.allocs, &c.freed })
             for (const Block& b : *v)
                 if (!g_pool.give(b.p, b.pool_size)) (void)hipFree(b.p);
-        (void)hipStreamDestroy(c.stream);
+        if (c.stream) g_streams.give(c.stream);
     } else {
         for (const std::vector<Block>* v : { &c.allocs, &c.freed })
             for (const Block& b : *v) std::free(b.p);
@@ -1566,6 +1596,13 @@ extern "C" int sk_broker_serve(const int device, const char* socket_name_arg, co
         }
         void* warm = nullptr; // the context, before the first client waits for it
         if (hipMalloc(&warm, 256) == hipSuccess) (void)hipFree(warm);
+        std::thread([] { // streams for the first wave of clients, made while the first of them is still shaking hands
+            (void)hipSetDevice(g_srv.device);
+            for (int i = 0; i < int(env_us("STRELKA_AMD_BROKER_STREAMS_AHEAD", 16)); ++i) {
+                hipStream_t st = nullptr;
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) g_streams.give(st);
+            }
+        }).detach();
     } else if (const char* dc = std::getenv("STRELKA_AMD_BROKER_HOST_DEVICES")) g_srv.device_count = std::max(1, std::atoi(dc));
     if (listen(ls, 256) != 0) return 1;
     std::fprintf(stderr, "[sk_broker] pid %d serving device %d on @%s (%s backend)\n", int(getpid()), device, name.c_str(), g_srv.host_backend ? "host" : "hip");

@@ -70,7 +70,7 @@ def _wait_for_exit_line(log, timeout=30):
 
 def test_library_exports_the_broker_and_the_server_is_built(built):
     L = ctypes.CDLL(sk_build.LIB_PATH)
-    for s in ("sk_broker_serve", "sk_broker_selftest", "sk_broker_client"):
+    for s in ("sk_broker_serve", "sk_broker_selftest", "sk_broker_client", "sk_broker_enable"):
         assert hasattr(L, s), s
     assert os.access(sk_build.BROKER_PATH, os.X_OK)
     assert L.sk_broker_client() == (1 if os.environ.get("STRELKA_AMD_BROKER", "0") not in ("", "0") else 0)
@@ -179,6 +179,18 @@ def test_gpu_selftest_through_the_broker(built, tmp_path):
     assert p.returncode == 0, (out, err)
     log = _wait_for_exit_line(str(tmp_path / "broker.log"))
     assert "hip backend" in log
+
+
+@pytest.mark.gpu
+def test_thirty_two_clients_of_one_broker(built, tmp_path):
+    """four times the device's eight process slots, all at once, through ONE GPU context"""
+    env = _env(tmp_path, STRELKA_AMD_BROKER_IDLE_S="5")
+    procs = [_client(env, reps=2) for _ in range(32)]
+    for i, p in enumerate(procs):
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, (i, out, err)
+    log = _wait_for_exit_line(str(tmp_path / "broker.log"))
+    assert log.count("serving device 0") == 1 and log.count(" left: ") == 32, log
 
 
 @pytest.mark.gpu
