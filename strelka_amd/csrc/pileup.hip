@@ -32,6 +32,7 @@
 #include "sk_common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <iterator>
 #include <vector>
@@ -1903,12 +1904,31 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, cons
     return 0;
 }
 
+namespace
+{
+// diagnostics ($SK_PILEUP_PUSH_SECONDS): where a push's wall time goes -- checks, packing + submissions, the wait, the carry bookkeeping
+struct PushSeconds
+{
+    bool on = std::getenv("SK_PILEUP_PUSH_SECONDS") != nullptr;
+    double check = 0, enqueue = 0, wait = 0, finish = 0;
+    long pushes = 0;
+    ~PushSeconds()
+    {
+        if (on && pushes)
+            std::fprintf(stderr, "strelka_amd pileup push seconds: pushes=%ld check=%.4f enqueue=%.4f wait=%.4f finish=%.4f\n", pushes, check, enqueue, wait, finish);
+    }
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} g_push_seconds;
+}
+
 int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const int32_t largest_total_indel_ref_span_per_read,
                           const int32_t mask_begin, const int32_t mask_len, const uint8_t* cand_snv_mask, const int32_t final_to,
                           const int32_t ploidy_begin, const int32_t ploidy_len, const uint8_t* ploidy, sk_pileup_window* out)
 {
     SK_REQUIRE_INIT();
     skrt::wakeHint();
+    const bool tm = g_push_seconds.on;
+    const double t0 = tm ? PushSeconds::now() : 0.0;
     if (!s || !reads || !out) return sk_fail("sk_pileup_stream_push: null argument");
     if (s->poisoned) return sk_fail("sk_pileup_stream_push: an earlier push of this stream failed; begin the region again");
     if (stream_check_reads(s, reads, mask_begin, mask_len, cand_snv_mask)) return 1;
@@ -1918,6 +1938,7 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     int32_t lowest, highest, begin, end;
     if (stream_extent(s, reads, &lowest, &highest)) return 1;
     stream_range(s, lowest, highest, F, &begin, &end);
+    const double t1 = tm ? PushSeconds::now() : 0.0;
     // (stream_enqueue flips the record buffers and moves the carried tail as it goes: a failure from here on leaves work in flight and
     // the stream's bookkeeping half done -- the stream is drained and refuses further pushes until begin_region resets it)
     if (stream_enqueue(s, reads, largest_total_indel_ref_span_per_read, mask_begin, mask_len, cand_snv_mask, F, begin, end, ploidy_begin,
@@ -1926,11 +1947,18 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
         s->poisoned = true;
         return 1;
     }
+    const double t2 = tm ? PushSeconds::now() : 0.0;
     if (skrt::streamSynchronize(ctx.stream) != hipSuccess) {
         s->poisoned = true;
         return sk_fail("sk_pileup_stream_push: the device reported an error");
     }
+    const double t3 = tm ? PushSeconds::now() : 0.0;
     stream_finish(s, out);
+    if (tm) {
+        const double t4 = PushSeconds::now();
+        g_push_seconds.check += t1 - t0, g_push_seconds.enqueue += t2 - t1, g_push_seconds.wait += t3 - t2, g_push_seconds.finish += t4 - t3;
+        ++g_push_seconds.pushes;
+    }
     return 0;
 }
 

@@ -64,15 +64,15 @@ namespace
 // what both sides share
 
 constexpr uint32_t MAGIC = 0x534b4252u; // "SKBR"
-constexpr uint32_t PROTO = 3;
+constexpr uint32_t PROTO = 4;
 constexpr uint32_t RING_BYTES = 1u << 20;
 constexpr uint64_t SLOT_BASE = 0x600000000000ull; // client i's page-locked segments live at SLOT_BASE + i * SLOT_BYTES in BOTH processes
 constexpr uint64_t SLOT_BYTES = 1ull << 36;       // 64 GB of address space per client
 constexpr int MAX_SLOTS = 1024;
 constexpr uintptr_t STREAM_HANDLE = 0x534b0001u;  // what a client's hipStream_t is
 
-enum : uint32_t { OP_PAD = 0, OP_LAUNCH, OP_MEMCPY, OP_MEMSET, OP_SYNC, OP_MALLOC, OP_FREE, OP_FUNC_ATTR, OP_HOST_MAP, OP_HOST_UNMAP };
-enum : uint32_t { MSG_HELLO = 1, MSG_SLOT, MSG_SLOT_OK, MSG_SLOT_RETRY, MSG_MAP, MSG_REFUSED };
+enum : uint32_t { OP_PAD = 0, OP_LAUNCH, OP_MEMCPY, OP_MEMSET, OP_SYNC, OP_MALLOC, OP_FREE, OP_FUNC_ATTR, OP_HOST_MAP, OP_HOST_UNMAP, OP_BYE };
+enum : uint32_t { MSG_HELLO = 1, MSG_SLOT, MSG_SLOT_OK, MSG_SLOT_RETRY, MSG_MAP, MSG_REFUSED, MSG_SEGS, MSG_SEG };
 
 struct Rec
 {
@@ -255,6 +255,7 @@ struct Seg
 {
     char* va = nullptr;
     size_t bytes = 0;
+    int fd = -1; // (server: the segment's memfd, kept so that the next client of the slot can map the same pages)
 };
 struct Pending
 {
@@ -664,7 +665,67 @@ int connect_or_spawn(const int device, std::string* why)
     return s;
 }
 
-void reset_suballocators(); // (below, with the allocators)
+struct SubAllocator
+{
+    struct Slab
+    {
+        char* base;
+        size_t size, used;
+    };
+    struct Piece
+    {
+        char* p;
+        size_t size;
+    };
+    size_t slab_bytes;
+    std::vector<Slab> slabs;
+    std::vector<Piece> live, spare;
+    explicit SubAllocator(const size_t slab) : slab_bytes(slab) {}
+    static size_t round(const size_t n) { return (n + 4095) & ~size_t(4095); }
+    bool direct(const size_t need) const { return need >= slab_bytes / 2; }
+    /// a piece from the spare list or from a slab with room; nullptr: the caller adds a slab (add_slab) and asks again
+    char* take(const size_t need)
+    {
+        for (size_t i = 0; i < spare.size(); ++i)
+            if (spare[i].size >= need && spare[i].size <= need + need / 2 + 65536) {
+                const Piece pc = spare[i];
+                spare.erase(spare.begin() + long(i));
+                live.push_back(pc);
+                return pc.p;
+            }
+        for (Slab& sl : slabs)
+            if (sl.used + need <= sl.size) {
+                char* p = sl.base + sl.used;
+                sl.used += need;
+                live.push_back(Piece{ p, need });
+                return p;
+            }
+        return nullptr;
+    }
+    void add_slab(void* base, const size_t size) { slabs.push_back(Slab{ static_cast<char*>(base), size, 0 }); }
+    bool give_back(void* p)
+    {
+        for (size_t i = 0; i < live.size(); ++i)
+            if (live[i].p == p) {
+                spare.push_back(live[i]);
+                live.erase(live.begin() + long(i));
+                return true;
+            }
+        return false;
+    }
+};
+SubAllocator g_dev_alloc(size_t(env_us("STRELKA_AMD_BROKER_DEVICE_SLAB_MB", 256)) << 20);
+SubAllocator g_pin_alloc(size_t(env_us("STRELKA_AMD_BROKER_PINNED_SLAB_MB", 32)) << 20);
+
+void reset_suballocators() // (the connection is gone: so is everything its slabs were carved from)
+{
+    for (SubAllocator* a : { &g_dev_alloc, &g_pin_alloc }) {
+        a->slabs.clear();
+        a->live.clear();
+        a->spare.clear();
+    }
+}
+
 void cl_close()
 {
     Client& cl = g_cl;
@@ -733,6 +794,8 @@ static int r_connect_once(const int device, std::string* why, bool* refused)
     int rc = send_msg(s, m, fd);
     close(fd);
     char* slot = nullptr;
+    std::vector<Seg> recycled;
+    size_t recycled_used = 0;
     for (int attempt = 0; !rc && attempt < 64; ++attempt) {
         Msg r;
         if (recv_msg(s, r, nullptr, 120000)) {
@@ -757,6 +820,27 @@ static int r_connect_once(const int device, std::string* why, bool* refused)
             cl.host_backend = r.c != 0;
             Msg ok{ MAGIC, MSG_SLOT_OK, 0, 0, 0, {} };
             rc = send_msg(s, ok, -1);
+            // the slot's page-locked segments as the client before this one left them: still mapped and page-locked in the server, so
+            // this client maps the same pages at the same addresses and has its slabs without a registration (hipHostRegister costs
+            // ~4 ms per 32 MB and serialises in the server: profiles/r06_v17, 17 allocation round trips per caller = 0.1-0.5 s)
+            Msg sg;
+            if (!rc && (recv_msg(s, sg, nullptr, 120000) || sg.type != MSG_SEGS)) rc = 1;
+            if (!rc) {
+                recycled_used = size_t(sg.b);
+                for (uint64_t i = 0; i < sg.a && !rc; ++i) {
+                    Msg one;
+                    int sfd = -1;
+                    if (recv_msg(s, one, &sfd, 120000) || one.type != MSG_SEG || sfd < 0) {
+                        rc = 1;
+                    } else {
+                        void* va = reinterpret_cast<void*>(uintptr_t(one.a));
+                        void* mp = mmap(va, size_t(one.b), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, sfd, 0);
+                        if (mp != va) rc = 1;
+                        else recycled.push_back(Seg{ static_cast<char*>(va), size_t(one.b), -1 });
+                    }
+                    if (sfd >= 0) close(sfd);
+                }
+            }
             break;
         }
         if (got != MAP_FAILED) munmap(got, SLOT_BYTES);
@@ -774,8 +858,14 @@ static int r_connect_once(const int device, std::string* why, bool* refused)
     cl.device = device;
     cl.ctl = c;
     cl.slot = slot;
+    cl.slot_used = recycled_used;
     cl.head = 0;
     cl.seq = 0;
+    for (const Seg& sg : recycled) {
+        cl.segs.push_back(sg);
+        if (!cl.staging.va && sg.bytes >= (size_t(8) << 20) && sg.bytes != g_pin_alloc.slab_bytes) cl.staging = sg; // (the staging segment of the client before)
+        else g_pin_alloc.add_slab(sg.va, sg.bytes);
+    }
     if (cl.use_gpu_flag && !cl.host_backend) { // a page-locked word of this client's for the device to say "done" in
         Seg fs;
         if (cl_host_map(&fs, 4096) == hipSuccess) {
@@ -794,6 +884,21 @@ void r_wake_hint()
     if (g_cl.eager_wake && g_cl.ctl && !g_cl.dead) wake_server(g_cl.ctl);
 }
 void r_disconnect() { cl_close(); }
+
+namespace
+{
+// A client that ends normally says so: its server thread then returns its stream and its device memory to the server's pools at
+// once, for the caller processes that start next (without the word the thread notices the closed socket at its next 50 ms look).
+struct ByeAtExit
+{
+    ~ByeAtExit()
+    {
+        if (!g_remote || !g_cl.ctl || g_cl.dead) return;
+        if (RecMem* r = new_rec<RecMem>(OP_BYE, uint32_t(up16(sizeof(RecMem))))) ring_commit(r->r.bytes, true);
+        g_cl.dead = true; // (whatever a later static destructor asks for fails at once instead of waiting for a thread that is gone)
+    }
+} g_bye_at_exit;
+}
 int r_device_count(std::string* why)
 {
     if (g_cl.sock < 0 && r_connect(0, why)) return 0;
@@ -822,66 +927,7 @@ static hipError_t foreign_stream()
 // only grow: a freed piece is followed by a larger request).  Requests of half a slab or more go to the server as they are.
 namespace
 {
-struct SubAllocator
-{
-    struct Slab
-    {
-        char* base;
-        size_t size, used;
-    };
-    struct Piece
-    {
-        char* p;
-        size_t size;
-    };
-    size_t slab_bytes;
-    std::vector<Slab> slabs;
-    std::vector<Piece> live, spare;
-    explicit SubAllocator(const size_t slab) : slab_bytes(slab) {}
-    static size_t round(const size_t n) { return (n + 4095) & ~size_t(4095); }
-    bool direct(const size_t need) const { return need >= slab_bytes / 2; }
-    /// a piece from the spare list or from a slab with room; nullptr: the caller adds a slab (add_slab) and asks again
-    char* take(const size_t need)
-    {
-        for (size_t i = 0; i < spare.size(); ++i)
-            if (spare[i].size >= need && spare[i].size <= need + need / 2 + 65536) {
-                const Piece pc = spare[i];
-                spare.erase(spare.begin() + long(i));
-                live.push_back(pc);
-                return pc.p;
-            }
-        for (Slab& sl : slabs)
-            if (sl.used + need <= sl.size) {
-                char* p = sl.base + sl.used;
-                sl.used += need;
-                live.push_back(Piece{ p, need });
-                return p;
-            }
-        return nullptr;
-    }
-    void add_slab(void* base, const size_t size) { slabs.push_back(Slab{ static_cast<char*>(base), size, 0 }); }
-    bool give_back(void* p)
-    {
-        for (size_t i = 0; i < live.size(); ++i)
-            if (live[i].p == p) {
-                spare.push_back(live[i]);
-                live.erase(live.begin() + long(i));
-                return true;
-            }
-        return false;
-    }
-};
-SubAllocator g_dev_alloc(size_t(env_us("STRELKA_AMD_BROKER_DEVICE_SLAB_MB", 256)) << 20);
-SubAllocator g_pin_alloc(size_t(env_us("STRELKA_AMD_BROKER_PINNED_SLAB_MB", 32)) << 20);
 
-void reset_suballocators() // (the connection is gone: so is everything its slabs were carved from)
-{
-    for (SubAllocator* a : { &g_dev_alloc, &g_pin_alloc }) {
-        a->slabs.clear();
-        a->live.clear();
-        a->spare.clear();
-    }
-}
 hipError_t server_malloc(void** p, const size_t bytes)
 {
     *p = nullptr;
@@ -929,6 +975,10 @@ hipError_t r_host_malloc(void** p, const size_t bytes)
     const size_t need = SubAllocator::round(bytes ? bytes : 1);
     Seg s;
     if (g_pin_alloc.direct(need)) {
+        if (char* big = g_pin_alloc.take(need)) { // (a large segment the slot's last client left)
+            *p = big;
+            return hipSuccess;
+        }
         const hipError_t e = cl_host_map(&s, need);
         if (e == hipSuccess) *p = s.va;
         return e;
@@ -1069,6 +1119,15 @@ struct Server
     int device_count = 1;
     std::mutex mu;
     std::vector<bool> slot_taken = std::vector<bool>(MAX_SLOTS, false);
+    // slots of departed clients whose page-locked segments are still mapped and registered here, for the next client
+    struct Recycled
+    {
+        int slot;
+        std::vector<Seg> segs;
+        size_t used; // bytes of the slot's address range handed out so far
+    };
+    std::vector<Recycled> recycled;
+    uint64_t recycled_given = 0;
     std::atomic<int> clients{ 0 };
     std::atomic<int64_t> served{ 0 };
     std::chrono::steady_clock::time_point last_client = std::chrono::steady_clock::now();
@@ -1158,6 +1217,8 @@ struct Conn
     std::vector<Seg> segs;
     uint64_t n_launch = 0, n_sync = 0, n_sleeps = 0;
     unsigned pid = 0;
+    bool bye = false; // the client has said it is leaving
+    size_t slot_used = 0; // the end of the highest segment mapped in the slot (recycling)
     // ($STRELKA_AMD_BROKER_VERBOSE) from the first record after a wait to the SYNC record; inside hipStreamSynchronize
     bool timing = std::getenv("STRELKA_AMD_BROKER_VERBOSE") != nullptr;
     bool batch_open = false;
@@ -1368,7 +1429,11 @@ void srv_execute(Conn& c, const Rec* rec)
                 if (e != hipSuccess) {
                     srv_error(c, int32_t(e), "hipHostRegister", hipGetErrorString(e));
                     (void)mmap(want, r->b, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0);
-                } else c.segs.push_back(Seg{ static_cast<char*>(p), size_t(r->b) });
+                } else {
+                    c.segs.push_back(Seg{ static_cast<char*>(p), size_t(r->b), fd });
+                    fd = -1; // (kept: the slot's next client maps the same pages)
+                    c.slot_used = std::max(c.slot_used, size_t(r->a + r->b - lo));
+                }
             }
         }
         if (fd >= 0) close(fd);
@@ -1384,12 +1449,14 @@ void srv_execute(Conn& c, const Rec* rec)
                     SRV_HIP(c, hipHostUnregister(c.segs[i].va));
                 }
                 (void)mmap(c.segs[i].va, c.segs[i].bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0);
+                if (c.segs[i].fd >= 0) close(c.segs[i].fd);
                 c.segs.erase(c.segs.begin() + long(i));
                 break;
             }
         srv_done(c, rec->seq);
         break;
     }
+    case OP_BYE: c.bye = true; break;
     default: srv_error(c, int32_t(hipErrorInvalidValue), "record", "unknown op"); break;
     }
 }
@@ -1420,12 +1487,21 @@ void serve_client(const int sock)
         munmap(p, sizeof(Ctl));
         return refuse("bad ring");
     }
-    // an address range for the client's page-locked segments that is free in both processes
+    // an address range for the client's page-locked segments that is free in both processes; first choice: the slot of a client that
+    // has left, with its segments still mapped and page-locked here
     std::vector<int> tried;
+    Server::Recycled inherited{ -1, {}, 0 };
     for (;;) {
         int slot = -1;
+        bool is_recycled = false;
         {
             std::lock_guard<std::mutex> g(g_srv.mu);
+            if (inherited.slot < 0 && !g_srv.recycled.empty()) {
+                inherited = g_srv.recycled.back();
+                g_srv.recycled.pop_back();
+                slot = inherited.slot; // (slot_taken stays true: it was never released)
+                is_recycled = true;
+            }
             for (int i = 0; i < MAX_SLOTS && slot < 0; ++i) {
                 bool was_tried = false;
                 for (int t : tried) was_tried |= (t == i);
@@ -1439,13 +1515,21 @@ void serve_client(const int sock)
         }
         tried.push_back(slot);
         void* want = reinterpret_cast<void*>(uintptr_t(SLOT_BASE + uint64_t(slot) * SLOT_BYTES));
-        void* got = mmap(want, SLOT_BYTES, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE, -1, 0);
-        bool ok = (got == want);
-        if (!ok && got != MAP_FAILED) munmap(got, SLOT_BYTES);
+        bool ok = true;
+        if (!is_recycled) { // (a recycled slot's range is still reserved here, its segments mapped inside)
+            void* got = mmap(want, SLOT_BYTES, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE, -1, 0);
+            ok = (got == want);
+            if (!ok && got != MAP_FAILED) munmap(got, SLOT_BYTES);
+        }
         if (ok) {
             Msg m{ MAGIC, MSG_SLOT, uint64_t(reinterpret_cast<uintptr_t>(want)), uint64_t(g_srv.device_count), uint64_t(g_srv.host_backend ? 1 : 0), {} };
             Msg r;
             if (send_msg(sock, m, -1) || recv_msg(sock, r, nullptr, 10000) || (r.type != MSG_SLOT_OK && r.type != MSG_SLOT_RETRY)) {
+                if (is_recycled)
+                    for (const Seg& sgm : inherited.segs) {
+                        if (!g_srv.host_backend) (void)hipHostUnregister(sgm.va);
+                        if (sgm.fd >= 0) close(sgm.fd);
+                    }
                 munmap(want, SLOT_BYTES);
                 std::lock_guard<std::mutex> g(g_srv.mu);
                 g_srv.slot_taken[size_t(slot)] = false;
@@ -1456,7 +1540,30 @@ void serve_client(const int sock)
             if (r.type == MSG_SLOT_OK) {
                 c.slot = slot;
                 c.slot_va = static_cast<char*>(want);
+                // the segments that come with the slot
+                const bool give = is_recycled;
+                Msg sg{ MAGIC, MSG_SEGS, uint64_t(give ? inherited.segs.size() : 0), uint64_t(give ? inherited.used : 0), 0, {} };
+                bool sent = (send_msg(sock, sg, -1) == 0);
+                for (size_t i = 0; sent && give && i < inherited.segs.size(); ++i) {
+                    Msg one{ MAGIC, MSG_SEG, uint64_t(reinterpret_cast<uintptr_t>(inherited.segs[i].va)), uint64_t(inherited.segs[i].bytes), 0, {} };
+                    sent = (send_msg(sock, one, inherited.segs[i].fd) == 0);
+                }
+                if (give) {
+                    c.segs = inherited.segs;
+                    c.slot_used = inherited.used;
+                    std::lock_guard<std::mutex> g(g_srv.mu);
+                    ++g_srv.recycled_given;
+                }
+                (void)sent; // (a client that went away mid-handshake is noticed by the loop below)
                 break;
+            }
+            // the client cannot have this range: a recycled slot is let go of for good
+            if (is_recycled) {
+                for (const Seg& sgm : inherited.segs) {
+                    if (!g_srv.host_backend) (void)hipHostUnregister(sgm.va);
+                    if (sgm.fd >= 0) close(sgm.fd);
+                }
+                inherited.segs.clear();
             }
             munmap(want, SLOT_BYTES);
         }
@@ -1502,7 +1609,7 @@ void serve_client(const int sock)
                 ctl->server_idle.store(0, std::memory_order_seq_cst);
                 continue;
             }
-            futex_wait(&ctl->server_idle, 1, 250);
+            futex_wait(&ctl->server_idle, 1, 50);
             ctl->server_idle.store(0, std::memory_order_seq_cst);
             if (ctl->head.load(std::memory_order_acquire) == tail && peer_gone(sock)) break;
             continue;
@@ -1524,12 +1631,13 @@ void serve_client(const int sock)
             srv_execute(c, rec);
             tail += bytes;
             ctl->tail.store(tail, std::memory_order_release);
+            if (c.bye) break;
         }
+        if (c.bye) break;
     }
     // the client is gone: wait for its work, give back what it held
     if (!g_srv.host_backend) {
         (void)hipStreamSynchronize(c.stream);
-        for (const Seg& s : c.segs) (void)hipHostUnregister(s.va);
         for (const std::vector<Block>* v : { &c.allocs, &c.freed })
             for (const Block& b : *v)
                 if (!g_pool.give(b.p, b.pool_size)) (void)hipFree(b.p);
@@ -1538,12 +1646,29 @@ void serve_client(const int sock)
         for (const std::vector<Block>* v : { &c.allocs, &c.freed })
             for (const Block& b : *v) std::free(b.p);
     }
-    munmap(c.slot_va, SLOT_BYTES); // (the segments inside go with it)
+    // the slot: kept whole -- range reserved, segments mapped and page-locked -- for the next client, unless enough are kept already
+    bool kept = false;
+    if (!c.segs.empty()) {
+        size_t bytes = 0;
+        for (const Seg& sg : c.segs) bytes += sg.bytes;
+        std::lock_guard<std::mutex> g(g_srv.mu);
+        if (g_srv.recycled.size() < 64 && bytes <= (size_t(1) << 30)) {
+            g_srv.recycled.push_back(Server::Recycled{ c.slot, c.segs, c.slot_used });
+            kept = true;
+        }
+    }
+    if (!kept) {
+        for (const Seg& sg : c.segs) {
+            if (!g_srv.host_backend) (void)hipHostUnregister(sg.va);
+            if (sg.fd >= 0) close(sg.fd);
+        }
+        munmap(c.slot_va, SLOT_BYTES); // (the segments inside go with it)
+    }
     munmap(ctl, sizeof(Ctl));
     close(sock);
     {
         std::lock_guard<std::mutex> g(g_srv.mu);
-        g_srv.slot_taken[size_t(c.slot)] = false;
+        if (!kept) g_srv.slot_taken[size_t(c.slot)] = false;
         g_srv.last_client = std::chrono::steady_clock::now();
     }
     if (std::getenv("STRELKA_AMD_BROKER_VERBOSE"))
@@ -1622,8 +1747,8 @@ extern "C" int sk_broker_serve(const int device, const char* socket_name_arg, co
             if (std::chrono::steady_clock::now() - g_srv.last_client > std::chrono::seconds(idle_seconds)) break;
         }
     }
-    std::fprintf(stderr, "[sk_broker] pid %d: no client for %d s after %lld served, leaving (device blocks from the pool / from the driver: %llu / %llu)\n", int(getpid()),
-                 idle_seconds, (long long)g_srv.served.load(), (unsigned long long)g_pool.hits, (unsigned long long)g_pool.misses);
+    std::fprintf(stderr, "[sk_broker] pid %d: no client for %d s after %lld served, leaving (device blocks from the pool / from the driver: %llu / %llu; clients that inherited a slot's page-locked segments: %llu)\n", int(getpid()),
+                 idle_seconds, (long long)g_srv.served.load(), (unsigned long long)g_pool.hits, (unsigned long long)g_pool.misses, (unsigned long long)g_srv.recycled_given);
     close(ls);
     return 0;
 }

@@ -30,7 +30,7 @@ def main():
     def run(binary, jobs, env):
         root = tempfile.mkdtemp(prefix="sk_share_")
         try:
-            e = {"STRELKA_AMD_VERBOSE": "1", "STRELKA_AMD_BROKER_TIMING": "1"}
+            e = {"STRELKA_AMD_VERBOSE": "1", "STRELKA_AMD_BROKER_TIMING": "1", "SK_PILEUP_PUSH_SECONDS": "1"}
             e.update(env)
             r = farm.run_farm(groups, argv_fn(binary), root, OUTPUTS, jobs=jobs, env=e)
             hooks = {}
@@ -40,6 +40,11 @@ def main():
                     for kv in m.group(1).split():
                         k, v = kv.split("=")
                         hooks[k] = hooks.get(k, 0.0) + float(v)
+                m = re.search(r"strelka_amd pileup push seconds: (.*)", tail)
+                if m:
+                    for kv in m.group(1).split():
+                        k, v = kv.split("=")
+                        hooks["push_" + k] = hooks.get("push_" + k, 0.0) + float(v)
                 m = re.search(r"strelka_amd broker client: (.*)", tail)
                 if m:
                     for kv in m.group(1).split():
@@ -84,6 +89,8 @@ def main():
             print("adapter %-34s jobs %2d: wall %.2f s, process seconds %.1f (user %.1f, sys %.1f), init %.2f, abi seconds realign %.2f pileup %.2f feed %.2f indel %.2f haplotype %.2f (hooks %.2f / %.2f / %.2f)" %
                   (label, jobs, w, ps, us, ss, hooks.get("init", 0), hooks.get("realign_abi", 0), hooks.get("pileup_abi", 0), hooks.get("feed_abi", 0),
                    hooks.get("indel_abi", 0), hooks.get("haplotype_abi", 0), hooks.get("realign_hook", 0), hooks.get("pileup_hook", 0), hooks.get("feed", 0)), flush=True)
+            if "push_pushes" in hooks:
+                print("        pileup pushes: " + " ".join("%s=%.6g" % (k[5:], v) for k, v in sorted(hooks.items()) if k.startswith("push_")), flush=True)
             if "broker_waits" in hooks:
                 print("        broker clients: " + " ".join("%s=%.6g" % (k[7:], v) for k, v in sorted(hooks.items()) if k.startswith("broker_")), flush=True)
 
