@@ -987,7 +987,11 @@ struct ScratchLayout
     int64_t rec, span, begin, end, maxend, minbegin, count, tmp, tmp_bytes, total;
 };
 
-ScratchLayout layout(const int32_t n_reads, const int64_t n_bases, const int32_t n_loci)
+// with_scans: the one-shot pileup's three device-library scans need temporary storage, sized by asking the library -- which asks the HIP
+// runtime about the device.  The STREAM does not use those scans (column_offsets_kernel) and must not ask: in a client of the broker
+// the question costs ~1 ms per push and wakes a runtime the process is not supposed to have (profiles/r06_v22: 3.8 of a farm's 5.4
+// pileup ABI seconds were this line).
+ScratchLayout layout(const int32_t n_reads, const int64_t n_bases, const int32_t n_loci, const bool with_scans = true)
 {
     ScratchLayout s;
     int64_t o = 0;
@@ -999,12 +1003,14 @@ ScratchLayout layout(const int32_t n_reads, const int64_t n_bases, const int32_t
     s.minbegin = o; o += align256(4 * int64_t(std::max(n_reads, 1)));
     s.count = o; o += align256(4 * (int64_t(n_loci) + 1));
     size_t t1 = 0, t2 = 0, t3 = 0;
-    int* ip = nullptr;
-    uint32_t* up = nullptr;
-    int64_t* lp = nullptr;
-    (void)rocprim::inclusive_scan(nullptr, t1, ip, ip, size_t(std::max(n_reads, 1)), MaxOp());
-    (void)rocprim::inclusive_scan(nullptr, t2, std::make_reverse_iterator(ip), std::make_reverse_iterator(ip), size_t(std::max(n_reads, 1)), MinOp());
-    (void)rocprim::exclusive_scan(nullptr, t3, up, lp, int64_t(0), size_t(n_loci) + 1, rocprim::plus<int64_t>());
+    if (with_scans) {
+        int* ip = nullptr;
+        uint32_t* up = nullptr;
+        int64_t* lp = nullptr;
+        (void)rocprim::inclusive_scan(nullptr, t1, ip, ip, size_t(std::max(n_reads, 1)), MaxOp());
+        (void)rocprim::inclusive_scan(nullptr, t2, std::make_reverse_iterator(ip), std::make_reverse_iterator(ip), size_t(std::max(n_reads, 1)), MinOp());
+        (void)rocprim::exclusive_scan(nullptr, t3, up, lp, int64_t(0), size_t(n_loci) + 1, rocprim::plus<int64_t>());
+    }
     s.tmp = o;
     s.tmp_bytes = int64_t(std::max(t1, std::max(t2, t3))) + 256;
     o += align256(s.tmp_bytes);
@@ -1290,6 +1296,30 @@ inline int path_ref_length(const sk_path_seg* path, const int nseg)
 
 namespace
 {
+// diagnostics ($SK_PILEUP_PUSH_SECONDS): where a push's wall time goes -- checks, packing + submissions, the wait, the carry bookkeeping
+struct PushSeconds
+{
+    bool on = std::getenv("SK_PILEUP_PUSH_SECONDS") != nullptr;
+    double check = 0, enqueue = 0, wait = 0, finish = 0, enq_buffers = 0, enq_pack = 0, enq_submit = 0;
+    double lap[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    long pushes = 0;
+    ~PushSeconds()
+    {
+        if (on && pushes)
+            std::fprintf(stderr, "strelka_amd pileup push seconds: pushes=%ld check=%.4f enqueue=%.4f wait=%.4f finish=%.4f enq_buffers=%.4f enq_pack=%.4f enq_submit=%.4f\n", pushes, check, enqueue, wait, finish,
+                         enq_buffers, enq_pack, enq_submit);
+        if (on && pushes) {
+            std::fprintf(stderr, "strelka_amd pileup push laps:");
+            for (int i = 0; i < 10; ++i) std::fprintf(stderr, " %.4f", lap[i]);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} g_push_seconds;
+}
+
+namespace
+{
 
 struct InLay { int64_t read_off, path_off, path, pos, is_fwd, mapq, level, code, qual, ploidy, mask, total; };
 struct WorkLay { int64_t begin, end, maxend, minbegin, count0, count1, count2, count4, count4a, off2, off4, calls2, calls4, refbase, de, gscr, pods, tmp, total; };
@@ -1482,7 +1512,9 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         li.mask = o; o += align256(std::max(mask_len, 1));
         li.total = o;
     }
+    const double tq0 = g_push_seconds.on ? PushSeconds::now() : 0.0;
     if (s->h_in.need(size_t(li.total)) || d_in.need(size_t(li.total))) return sk_fail("sk_pileup_stream_push: out of memory (input block)");
+    const double tq1 = g_push_seconds.on ? PushSeconds::now() : 0.0;
     char* hi = static_cast<char*>(s->h_in.p);
     {
         int64_t* ro = reinterpret_cast<int64_t*>(hi + li.read_off);
@@ -1518,7 +1550,25 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     }
     if (mask_len > 0) std::memcpy(hi + li.mask, cand_snv_mask, size_t(mask_len)); // (through the pinned block: a copy from the caller's pageable memory would wait for the device)
     char* di = static_cast<char*>(d_in.p);
+    const double tq2 = g_push_seconds.on ? PushSeconds::now() : 0.0;
     SK_HIP(skrt::memcpyAsync(di, hi, size_t(li.total), hipMemcpyHostToDevice, st));
+    struct SubmitLap
+    {
+        double t0;
+        ~SubmitLap()
+        {
+            if (g_push_seconds.on) g_push_seconds.enq_submit += PushSeconds::now() - t0;
+        }
+    } submit_lap{ tq2 };
+    if (g_push_seconds.on) g_push_seconds.enq_buffers += tq1 - tq0, g_push_seconds.enq_pack += tq2 - tq1;
+    double lap_t = tq2;
+    auto lap = [&](const int i) {
+        if (!g_push_seconds.on) return;
+        const double t = PushSeconds::now();
+        g_push_seconds.lap[i] += t - lap_t;
+        lap_t = t;
+    };
+    lap(0); // the H2D copy
     CopyArgs carry; // every device-to-device piece of this push, one launch
     carry.n = 0;
     int64_t carry_max = 0;
@@ -1550,8 +1600,9 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         SK_LAUNCH(copy_segments_kernel, dim3(bx, carry.n), dim3(256), 0, st, carry);
     }
 
+    lap(1); // record buffers + carry copies
     // ---- work and output blocks
-    const ScratchLayout SL = layout(n, n_bases, n_loci); // (its rec / span / count parts are unused here)
+    const ScratchLayout SL = layout(n, n_bases, n_loci, false); // (its rec / span / count parts and the scans' storage are unused here)
     const bool som = s->somatic;
     WorkLay& wl = s->wl;
     {
@@ -1610,6 +1661,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     char* dw = static_cast<char*>(s->d_work.p);
     char* dout = static_cast<char*>(s->d_out.p);
     char* ho = static_cast<char*>(s->h_out.p);
+    lap(2); // layouts + work / out buffers
 
     PileupArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -1640,6 +1692,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     int* d_maxend = reinterpret_cast<int*>(dw + wl.maxend);
     int* d_minbegin = reinterpret_cast<int*>(dw + wl.minbegin);
     if (n > 0) SK_LAUNCH(span_bounds_kernel, dim3(2), dim3(1024), 0, st, a.span, d_maxend, d_minbegin, n);
+    lap(3); // P1 + span bounds
     // P2: the window's columns
     PileupArgs c = a;
     c.o.report_begin = begin;
@@ -1710,6 +1763,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     }
     c.store = 1;
     if (n > 0 && n_loci > 0) SK_LAUNCH(p2, dim3(blocks), dim3(WAVE), 0, st, c);
+    lap(4); // P2 count, offsets, P2 store
     if (n_loci > 0 && (s->genotype || som)) {
         uint8_t* d_refbase = reinterpret_cast<uint8_t*>(dw + wl.refbase);
         SK_LAUNCH(ref_base_id_kernel, dim3((n_loci + 255) / 256), dim3(256), 0, st, static_cast<const char*>(s->d_ref.p), s->ref_offset,
@@ -1737,8 +1791,10 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
                                    &s->gvcf_opt, n_loci, dw + wl.pods, reinterpret_cast<sk_gvcf_run*>(dout + ol.runs), st))
             return 1;
     }
+    lap(5); // genotypes, summaries, runs
     SK_HIP(skrt::getLastError());
     SK_HIP(skrt::memcpyAsync(ho, dout, size_t(ol.total), hipMemcpyDeviceToHost, st));
+    lap(6); // D2H
     return 0;
 }
 
@@ -1904,22 +1960,6 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, cons
     return 0;
 }
 
-namespace
-{
-// diagnostics ($SK_PILEUP_PUSH_SECONDS): where a push's wall time goes -- checks, packing + submissions, the wait, the carry bookkeeping
-struct PushSeconds
-{
-    bool on = std::getenv("SK_PILEUP_PUSH_SECONDS") != nullptr;
-    double check = 0, enqueue = 0, wait = 0, finish = 0;
-    long pushes = 0;
-    ~PushSeconds()
-    {
-        if (on && pushes)
-            std::fprintf(stderr, "strelka_amd pileup push seconds: pushes=%ld check=%.4f enqueue=%.4f wait=%.4f finish=%.4f\n", pushes, check, enqueue, wait, finish);
-    }
-    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-} g_push_seconds;
-}
 
 int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const int32_t largest_total_indel_ref_span_per_read,
                           const int32_t mask_begin, const int32_t mask_len, const uint8_t* cand_snv_mask, const int32_t final_to,

@@ -306,13 +306,16 @@ struct ClientTiming
     double wait_other_s = 0, wait_max = 0, wait_long_s = 0;
     uint64_t waits_other = 0, waits_long = 0;
     double wait_s = 0, connect_s = 0, stage_copy_s = 0, leg_wake = 0, leg_submit = 0, leg_device = 0, leg_back = 0;
-    uint64_t waits = 0, launches = 0, copies = 0, staged_bytes = 0, futex_sleeps = 0, flag_hits = 0;
+    uint64_t waits = 0, launches = 0, copies = 0, staged_bytes = 0, futex_sleeps = 0, flag_hits = 0, ring_full_spins = 0;
+    double in_launch_s = 0, in_copy_s = 0, in_alloc_s = 0, in_status_s = 0;
+    uint64_t allocs = 0, host_frees = 0, status_reads = 0;
     ~ClientTiming()
     {
         if (on && (waits || launches))
-            std::fprintf(stderr, "strelka_amd broker client: connect=%.4f wait=%.4f waits=%llu futex_sleeps=%llu flag_hits=%llu launches=%llu copies=%llu staged_bytes=%llu stage_copy=%.4f leg_server_wake=%.4f leg_submit=%.4f leg_device=%.4f leg_client_wake=%.4f wait_not_sync=%.4f waits_not_sync=%llu wait_over_5ms=%.4f waits_over_5ms=%llu wait_max=%.4f\n", connect_s,
+            std::fprintf(stderr, "strelka_amd broker client: connect=%.4f wait=%.4f waits=%llu futex_sleeps=%llu flag_hits=%llu launches=%llu copies=%llu staged_bytes=%llu stage_copy=%.4f in_launch=%.4f in_copy=%.4f in_alloc=%.4f allocs=%llu host_frees=%llu in_status=%.4f status_reads=%llu ring_full_spins=%llu leg_server_wake=%.4f leg_submit=%.4f leg_device=%.4f leg_client_wake=%.4f wait_not_sync=%.4f waits_not_sync=%llu wait_over_5ms=%.4f waits_over_5ms=%llu wait_max=%.4f\n", connect_s,
                          wait_s, (unsigned long long)waits, (unsigned long long)futex_sleeps, (unsigned long long)flag_hits, (unsigned long long)launches, (unsigned long long)copies,
-                         (unsigned long long)staged_bytes, stage_copy_s, leg_wake, leg_submit, leg_device, leg_back, wait_other_s, (unsigned long long)waits_other, wait_long_s,
+                         (unsigned long long)staged_bytes, stage_copy_s, in_launch_s, in_copy_s, in_alloc_s, (unsigned long long)allocs, (unsigned long long)host_frees, in_status_s, (unsigned long long)status_reads,
+                         (unsigned long long)ring_full_spins, leg_wake, leg_submit, leg_device, leg_back, wait_other_s, (unsigned long long)waits_other, wait_long_s,
                          (unsigned long long)waits_long, wait_max);
     }
 } g_tm;
@@ -356,6 +359,7 @@ char* ring_reserve(const uint32_t bytes)
         }
         c->head.store(cl.head, std::memory_order_seq_cst);
         wake_server(c);
+        ++g_tm.ring_full_spins;
         if (++spins > 200) {
             if (peer_gone(cl.sock)) {
                 cl.dead = true;
@@ -945,6 +949,14 @@ hipError_t server_malloc(void** p, const size_t bytes)
 
 hipError_t r_malloc(void** p, const size_t bytes)
 {
+    struct Lap
+    {
+        double t0 = g_tm.on ? tm_now() : 0.0;
+        ~Lap()
+        {
+            if (g_tm.on) g_tm.in_alloc_s += tm_now() - t0, ++g_tm.allocs;
+        }
+    } lap;
     *p = nullptr;
     const size_t need = SubAllocator::round(bytes ? bytes : 1);
     if (g_dev_alloc.direct(need)) return server_malloc(p, need);
@@ -961,6 +973,14 @@ hipError_t r_malloc(void** p, const size_t bytes)
 }
 hipError_t r_free(void* p)
 {
+    struct Lap
+    {
+        double t0 = g_tm.on ? tm_now() : 0.0;
+        ~Lap()
+        {
+            if (g_tm.on) g_tm.in_alloc_s += tm_now() - t0, ++g_tm.allocs;
+        }
+    } lap;
     if (!p) return hipSuccess;
     if (g_dev_alloc.give_back(p)) return hipSuccess; // (a piece of a slab: kept for this client's next request; the stream's order protects it)
     RecMem* r = new_rec<RecMem>(OP_FREE, uint32_t(up16(sizeof(RecMem))));
@@ -971,6 +991,14 @@ hipError_t r_free(void* p)
 }
 hipError_t r_host_malloc(void** p, const size_t bytes)
 {
+    struct Lap
+    {
+        double t0 = g_tm.on ? tm_now() : 0.0;
+        ~Lap()
+        {
+            if (g_tm.on) g_tm.in_alloc_s += tm_now() - t0, ++g_tm.allocs;
+        }
+    } lap;
     *p = nullptr;
     const size_t need = SubAllocator::round(bytes ? bytes : 1);
     Seg s;
@@ -995,9 +1023,18 @@ hipError_t r_host_malloc(void** p, const size_t bytes)
 }
 hipError_t r_host_free(void* p)
 {
+    struct Lap
+    {
+        double t0 = g_tm.on ? tm_now() : 0.0;
+        ~Lap()
+        {
+            if (g_tm.on) g_tm.in_alloc_s += tm_now() - t0, ++g_tm.allocs;
+        }
+    } lap;
     if (!p) return hipSuccess;
     // A piece that is handed out again may still be read or written by kernels of the stream the old owner queued: the runtime's own
     // hipHostFree waits for the device, so does this one (frees of page-locked memory happen when a buffer grows: a handful per process).
+    ++g_tm.host_frees;
     if (g_pin_alloc.give_back(p)) return cl_sync();
     for (const Seg& s : g_cl.segs)
         if (s.va == p) return cl_host_unmap(s);
@@ -1005,6 +1042,14 @@ hipError_t r_host_free(void* p)
 }
 hipError_t r_memcpy_async(void* dst, const void* src, const size_t bytes, const hipMemcpyKind kind, hipStream_t st)
 {
+    struct Lap
+    {
+        double t0 = g_tm.on ? tm_now() : 0.0;
+        ~Lap()
+        {
+            if (g_tm.on) g_tm.in_copy_s += tm_now() - t0;
+        }
+    } lap;
     if (!own_stream(st)) return foreign_stream();
     if (bytes == 0) return hipSuccess;
     Client& cl = g_cl;
@@ -1055,6 +1100,14 @@ hipError_t r_stream_synchronize(hipStream_t st)
 }
 hipError_t r_get_last_error()
 {
+    struct Lap
+    {
+        double t0 = g_tm.on ? tm_now() : 0.0;
+        ~Lap()
+        {
+            if (g_tm.on) g_tm.in_status_s += tm_now() - t0, ++g_tm.status_reads;
+        }
+    } lap;
     Client& cl = g_cl;
     if (cl.last != hipSuccess) { // an error of a call made here (a refused stream, a lost connection): reported once, like the runtime's
         const hipError_t e = cl.last;
@@ -1076,6 +1129,14 @@ hipError_t r_func_set_attribute(const void* fn, const hipFuncAttribute attr, con
 }
 void r_launch(const void* fn, const dim3 grid, const dim3 block, const size_t lds_bytes, hipStream_t st, void** args, const uint32_t* sizes, const int n_args)
 {
+    struct Lap
+    {
+        double t0 = g_tm.on ? tm_now() : 0.0;
+        ~Lap()
+        {
+            if (g_tm.on) g_tm.in_launch_s += tm_now() - t0;
+        }
+    } lap;
     if (!own_stream(st)) {
         (void)foreign_stream();
         return;

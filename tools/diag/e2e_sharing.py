@@ -40,6 +40,10 @@ def main():
                     for kv in m.group(1).split():
                         k, v = kv.split("=")
                         hooks[k] = hooks.get(k, 0.0) + float(v)
+                m = re.search(r"strelka_amd pileup push laps: (.*)", tail)
+                if m:
+                    for i, v in enumerate(m.group(1).split()):
+                        hooks["push_lap%d" % i] = hooks.get("push_lap%d" % i, 0.0) + float(v)
                 m = re.search(r"strelka_amd pileup push seconds: (.*)", tail)
                 if m:
                     for kv in m.group(1).split():
