@@ -1039,7 +1039,7 @@ void sk_pileup_options_default(sk_pileup_options* o)
 int64_t sk_pileup_scratch_bytes(const int32_t n_reads, const int64_t n_bases, const int32_t n_loci)
 {
     if (n_reads < 0 || n_bases < 0 || n_loci < 0) return -1;
-    return layout(n_reads, n_bases, n_loci).total;
+    return layout(n_reads, n_bases, n_loci, !skrt::remote()).total; // (a broker client never asks the device library: the one-shot pileup is not its to run)
 }
 
 int sk_pileup_reads_dev(const sk_read_batch* b, const int64_t n_bases, const sk_pileup_options* opt, const int mode,

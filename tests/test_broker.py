@@ -164,7 +164,16 @@ for rep in range(reps):
     if rep == 0:
         h.update(out.tobytes())
         h.update(som.tobytes())
-print(json.dumps(dict(digest=h.hexdigest(), abi_seconds=abi, client=capi.lib().sk_broker_client())))
+import os
+def _kfd_open():  # has this process opened the GPU driver's compute device?  (a broker client must not: no context, no process slot)
+    for f in os.listdir("/proc/self/fd"):
+        try:
+            if "kfd" in os.readlink("/proc/self/fd/" + f):
+                return True
+        except OSError:
+            pass
+    return False
+print(json.dumps(dict(digest=h.hexdigest(), abi_seconds=abi, client=capi.lib().sk_broker_client(), kfd_open=_kfd_open())))
 '''
 
 
@@ -211,6 +220,9 @@ def test_sixteen_client_processes_equal_a_process_with_its_own_context(built, tm
         res.append(json.loads(out.decode().strip().splitlines()[-1]))
     assert all(r["client"] == 1 for r in res)
     assert all(r["digest"] == ref["digest"] for r in res)
+    # a client never touches the GPU driver: no runtime, no context, none of the device's eight process slots (a device-library size
+    # query on the pileup push path once did, profiles/r06_v22)
+    assert ref["kfd_open"] is True and not any(r["kfd_open"] for r in res)
     log = _wait_for_exit_line(str(tmp_path / "broker.log"))
     assert log.count("serving device 0") == 1 and log.count(" left: ") == 16, log
     print("\n16 broker clients: ABI seconds per process %.2f .. %.2f (3 repetitions); a process with its own context, alone: %.2f (1 repetition)" % (
