@@ -322,12 +322,15 @@ struct GroupArgs
 
 // MAXA = alternate alleles a record holds: MAXA (3) or MAXA_WIDE (8: a multi-sample group, ploidy x samples).  Rows of
 // del_len / ins_len / ref_lnp / allele_lnp are MAXA wide.
+// Round 6 (1.85 -> 1.08 ms per 2^18 groups, bit-identical): every allele's integrateOutMappingStatus is evaluated once for the hom
+// genotypes AND the supporting-read statistics (it was evaluated twice: a third of the kernel's transcendentals); the statistics are
+// counted by ballots over the chunk's lanes instead of a walk by lane 0 over the chunk (~1 000 instructions with one lane active, as
+// many as the parallel part); four waves per SIMD for the narrow record (111 VGPRs; five spill and are slower: 1.36 ms).
 template <int MAXA, typename CallT>
-__global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 ? 4 : 2, MAXA <= 3 ? 4 : 2))) void allele_group_kernel(const GroupArgs a)
 {
     constexpr int MAXGT = (MAXA + 1) * (MAXA + 2) / 2;
     __shared__ double s_term[MAXGT][WAVE];
-    __shared__ unsigned char s_support[WAVE]; // 0xff = read not used; else fwd<<4 | (allele index, or 15 = non-confident)
     const int grp = blockIdx.x;
     const int lane = threadIdx.x;
     const int64_t r0 = a.b.read_off[grp];
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
     }
 
     double acc = 0.;
-    unsigned cnt_f[MAXA + 2], cnt_r[MAXA + 2]; // lane 0 only
+    unsigned cnt_f[MAXA + 2], cnt_r[MAXA + 2]; // (wave-uniform: counted by ballots over the chunk's lanes)
 #pragma unroll
     for (int k = 0; k < MAXA + 2; ++k) cnt_f[k] = cnt_r[k] = 0;
     unsigned used = 0;
@@ -401,6 +404,8 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
     for (int base = 0; base < n; base += WAVE) {
         const int r = base + lane;
         const int cnt = min(WAVE, n - base);
+        unsigned slot = 0xffu; // this lane's read supports allele `slot` (n_alt + 1: none with confidence); 0xff: the read is not used
+        bool fwd = false;
         if (r < n) {
             const int64_t g = r0 + r;
             const unsigned flags = a.b.read_flags[g];
@@ -422,15 +427,19 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
             if (!use) {
 #pragma unroll
                 for (int gi = 0; gi < MAXGT; ++gi) s_term[gi][lane] = 0.;
-                s_support[lane] = 0xff;
             } else {
                 const unsigned na = a.b.non_ambig[g];
                 const unsigned rlen = a.b.read_length[g];
+                // integrateOutMappingStatus of every allele's own likelihood: the hom genotypes' terms (AlleleGroupGenotype.cpp:97-104) AND
+                // what updateSupportingReadStats starts from (:125-131) -- the same function of the same arguments, evaluated once
+                double H[MAXA + 1];
+#pragma unroll
+                for (int k = 0; k <= MAXA; ++k) H[k] = (k < full) ? integrate_out_mapping(a.map, na, L[k], ex, lt) : 0.;
                 // updateGenotypeLogLhoodFromAlleleLogLhood, AlleleGroupGenotype.cpp:36-114
                 if (ploidy == 1) {
 #pragma unroll
                     for (int a0 = 0; a0 <= MAXA; ++a0)
-                        if (a0 < full) s_term[a0][lane] = integrate_out_mapping(a.map, na, L[a0], ex, lt);
+                        if (a0 < full) s_term[a0][lane] = H[a0];
                 } else {
 #pragma unroll
                     for (int a1 = 0; a1 <= MAXA; ++a1) {
@@ -454,7 +463,8 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
                                 }
                                 raw = log_sum2(__dadd_rn(L[a0], lp0), __dadd_rn(L[a1], lp1), ex, lt);
                             } else {
-                                raw = L[a0];
+                                s_term[gi][lane] = H[a0];
+                                continue;
                             }
                             s_term[gi][lane] = integrate_out_mapping(a.map, na, raw, ex, lt);
                         }
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
                 double mx = 0.;
 #pragma unroll
                 for (int k = 0; k <= MAXA; ++k) {
-                    Lm[k] = (k < full) ? integrate_out_mapping(a.map, na, L[k], ex, lt) : 0.;
+                    Lm[k] = H[k];
                     if (k < full) mx = (k == 0) ? Lm[0] : ((Lm[k] > mx) ? Lm[k] : mx);
                 }
                 double sum = 0.;
@@ -480,27 +490,22 @@ __global__ __launch_bounds__(WAVE) void allele_group_kernel(const GroupArgs a)
 #pragma unroll
                 for (int k = MAXA; k >= 0; --k)
                     if (k < full && !(__dmul_rn(Lm[k], sum) < a.support_threshold)) which = unsigned(k); // first such allele
-                s_support[lane] = (unsigned char)(((flags & SK_READ_FWD) ? 0x10 : 0) | which);
+                slot = (which == 15u) ? unsigned(n_alt + 1) : which;
+                fwd = (flags & SK_READ_FWD) != 0;
             }
+        }
+        // LocusSupportingReadStats: the chunk's reads counted per (allele, strand) by ballots -- every lane of the wave, no serial walk
+        // (counts do not depend on the order of the reads)
+        used += unsigned(__popcll(__ballot(slot != 0xffu)));
+#pragma unroll
+        for (unsigned k = 0; k < MAXA + 2; ++k) {
+            const unsigned long long all = __ballot(slot == k), f = __ballot(slot == k && fwd);
+            cnt_f[k] += unsigned(__popcll(f));
+            cnt_r[k] += unsigned(__popcll(all)) - unsigned(__popcll(f));
         }
         __syncthreads();
         if (lane < gcount)
             for (int j = 0; j < cnt; ++j) acc = __dadd_rn(acc, s_term[lane][j]);
-        if (lane == 0) {
-            for (int j = 0; j < cnt; ++j) {
-                const unsigned s = s_support[j];
-                if (s == 0xff) continue;
-                ++used;
-                const unsigned which = s & 15u;
-                const unsigned slot = (which == 15u) ? unsigned(n_alt + 1) : which;
-#pragma unroll
-                for (unsigned k = 0; k < MAXA + 2; ++k) {
-                    if (k == slot) {
-                        if (s & 0x10) ++cnt_f[k]; else ++cnt_r[k];
-                    }
-                }
-            }
-        }
         __syncthreads();
     }
     CallT* o = static_cast<CallT*>(a.out) + grp;
