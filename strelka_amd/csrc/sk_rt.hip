@@ -298,6 +298,10 @@ struct Client
     bool dead = false;
 };
 Client g_cl;
+// The C-ABI is called by one thread per process and so is this layer; the lock is for the caller that is not: two threads
+// writing one ring would interleave records.  (Held across a wait: a client has one stream, its calls are serial by nature.)
+std::recursive_mutex g_cl_mu;
+#define SKRT_CLIENT_LOCK() std::lock_guard<std::recursive_mutex> skrt_client_lock_(g_cl_mu)
 
 // $STRELKA_AMD_BROKER_TIMING: where a client's time inside this layer goes, on stderr when the process ends
 struct ClientTiming
@@ -949,6 +953,7 @@ hipError_t server_malloc(void** p, const size_t bytes)
 
 hipError_t r_malloc(void** p, const size_t bytes)
 {
+    SKRT_CLIENT_LOCK();
     struct Lap
     {
         double t0 = g_tm.on ? tm_now() : 0.0;
@@ -973,6 +978,7 @@ hipError_t r_malloc(void** p, const size_t bytes)
 }
 hipError_t r_free(void* p)
 {
+    SKRT_CLIENT_LOCK();
     struct Lap
     {
         double t0 = g_tm.on ? tm_now() : 0.0;
@@ -991,6 +997,7 @@ hipError_t r_free(void* p)
 }
 hipError_t r_host_malloc(void** p, const size_t bytes)
 {
+    SKRT_CLIENT_LOCK();
     struct Lap
     {
         double t0 = g_tm.on ? tm_now() : 0.0;
@@ -1023,6 +1030,7 @@ hipError_t r_host_malloc(void** p, const size_t bytes)
 }
 hipError_t r_host_free(void* p)
 {
+    SKRT_CLIENT_LOCK();
     struct Lap
     {
         double t0 = g_tm.on ? tm_now() : 0.0;
@@ -1042,6 +1050,7 @@ hipError_t r_host_free(void* p)
 }
 hipError_t r_memcpy_async(void* dst, const void* src, const size_t bytes, const hipMemcpyKind kind, hipStream_t st)
 {
+    SKRT_CLIENT_LOCK();
     struct Lap
     {
         double t0 = g_tm.on ? tm_now() : 0.0;
@@ -1083,6 +1092,7 @@ hipError_t r_memcpy_async(void* dst, const void* src, const size_t bytes, const 
 }
 hipError_t r_memset_async(void* dst, const int value, const size_t bytes, hipStream_t st)
 {
+    SKRT_CLIENT_LOCK();
     if (!own_stream(st)) return foreign_stream();
     if (bytes == 0) return hipSuccess;
     RecCopy* r = new_rec<RecCopy>(OP_MEMSET, uint32_t(up16(sizeof(RecCopy))));
@@ -1095,11 +1105,13 @@ hipError_t r_memset_async(void* dst, const int value, const size_t bytes, hipStr
 }
 hipError_t r_stream_synchronize(hipStream_t st)
 {
+    SKRT_CLIENT_LOCK();
     if (!own_stream(st)) return foreign_stream();
     return cl_sync();
 }
 hipError_t r_get_last_error()
 {
+    SKRT_CLIENT_LOCK();
     struct Lap
     {
         double t0 = g_tm.on ? tm_now() : 0.0;
@@ -1118,6 +1130,7 @@ hipError_t r_get_last_error()
 }
 hipError_t r_func_set_attribute(const void* fn, const hipFuncAttribute attr, const int value)
 {
+    SKRT_CLIENT_LOCK();
     RecMem* r = new_rec<RecMem>(OP_FUNC_ATTR, uint32_t(up16(sizeof(RecMem))));
     if (!r) return cl_fail("strelka_amd: no broker connection");
     r->a = uint64_t(reinterpret_cast<uintptr_t>(fn) - lib_info().base);
@@ -1129,6 +1142,7 @@ hipError_t r_func_set_attribute(const void* fn, const hipFuncAttribute attr, con
 }
 void r_launch(const void* fn, const dim3 grid, const dim3 block, const size_t lds_bytes, hipStream_t st, void** args, const uint32_t* sizes, const int n_args)
 {
+    SKRT_CLIENT_LOCK();
     struct Lap
     {
         double t0 = g_tm.on ? tm_now() : 0.0;
@@ -1380,6 +1394,10 @@ void srv_execute(Conn& c, const Rec* rec)
             argv[i] = const_cast<char*>(p);
             p += up16(sizes[i]);
         }
+        if (r->fn_off >= lib_info().size) { // (a kernel is a host stub of THIS library: an offset inside the file both sides loaded)
+            srv_error(c, int32_t(hipErrorInvalidValue), "launch", "kernel offset outside libstrelka_amd.so");
+            break;
+        }
         const void* fn = reinterpret_cast<const void*>(lib_info().base + uintptr_t(r->fn_off));
         ++c.n_launch;
         const double t0 = c.timing ? tm_now() : 0.0;
@@ -1535,6 +1553,12 @@ void serve_client(const int sock)
         if (fd >= 0) close(fd);
         close(sock);
     };
+    {
+        // (the rendezvous name is per user; a client of another user has no business here whatever name it knows)
+        ucred cred{};
+        socklen_t cl = sizeof(cred);
+        if (getsockopt(sock, SOL_SOCKET, SO_PEERCRED, &cred, &cl) != 0 || cred.uid != getuid()) return refuse("another user's process");
+    }
     if (recv_msg(sock, hello, &fd, 10000) || hello.type != MSG_HELLO || fd < 0) return refuse("bad hello");
     if (uint32_t(hello.c >> 32) != PROTO || hello.a != lib_info().size || hello.b != lib_info().mtime)
         return refuse("the client has loaded another build of libstrelka_amd.so than this broker");
