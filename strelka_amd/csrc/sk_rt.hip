@@ -1305,9 +1305,10 @@ struct Conn
 
 void srv_error(Conn& c, const int32_t code, const char* what, const char* detail)
 {
-    int32_t zero = 0;
-    if (c.ctl->status.compare_exchange_strong(zero, code ? code : int32_t(hipErrorUnknown)))
-        std::snprintf(c.ctl->error_text, sizeof(c.ctl->error_text), "%s: %s (broker)", what, detail ? detail : "");
+    // (one writer -- this client's server thread; the client takes the status with acquire: the text is complete before the code shows)
+    if (c.ctl->status.load(std::memory_order_acquire) != 0) return; // the first error since the client last asked stays
+    std::snprintf(c.ctl->error_text, sizeof(c.ctl->error_text), "%s: %s (broker)", what, detail ? detail : "");
+    c.ctl->status.store(code ? code : int32_t(hipErrorUnknown), std::memory_order_release);
 }
 #define SRV_HIP(c, expr)                                                                  \
     do {                                                                                  \
