@@ -201,7 +201,7 @@ def test_fused_flatten_score_on_long_reads_and_mixed_jobs():
     capi.init(0)
     rng = np.random.default_rng(91444)
     scs = synth.realign_scenarios(40, rng, reads_per=10, max_indels=9, min_indels=4, read_len=(120, 261), window=(330, 520), haplotyping_rate=0.2)
-    n_dev = n_cals = n_long_jobs = 0
+    n_dev = n_cals = n_long_jobs = n_jobs_on_device = 0
     before = capi.RealignJob.device_job_counts()
     for sc in scs:
         res = {}
@@ -214,7 +214,9 @@ def test_fused_flatten_score_on_long_reads_and_mixed_jobs():
             job.run()
             res[mode] = [None if i is None else job.result(i) for i in idx]
             if mode == 2:
-                n_dev += job.enumeration_counts()[1]
+                counts = job.enumeration_counts()
+                n_dev += counts[1]
+                n_jobs_on_device += (counts[1] + counts[2]) > 0  # (a job all of whose reads leave at the gate never reaches the device)
         n_long_jobs += any(len(rd["code"]) > 256 for rd in sc["reads"])
         for a, b in zip(res[0], res[2]):
             assert (a is None) == (b is None)
@@ -225,7 +227,8 @@ def test_fused_flatten_score_on_long_reads_and_mixed_jobs():
     # the jobs without a long read among those that pass the gate ran as one sequence; those with one went the staged way at once (the host
     # knows the read lengths), and a pool over F5's 768 bytes is reported by the device: that job runs again (redone)
     one_wait, redone, staged = (b - a for a, b in zip(before, capi.RealignJob.device_job_counts()))
-    assert one_wait > 0 and 0 < staged <= n_long_jobs + redone and one_wait + staged - redone == len(scs)
+    assert one_wait > 0 and 0 < staged <= n_long_jobs + redone and one_wait + staged - redone == n_jobs_on_device
+    assert n_jobs_on_device >= len(scs) - 2
 
 
 @pytest.mark.gpu
