@@ -227,7 +227,8 @@ def test_fused_flatten_score_on_long_reads_and_mixed_jobs():
     # the jobs without a long read among those that pass the gate ran as one sequence; those with one went the staged way at once (the host
     # knows the read lengths), and a pool over F5's 768 bytes is reported by the device: that job runs again (redone)
     one_wait, redone, staged = (b - a for a, b in zip(before, capi.RealignJob.device_job_counts()))
-    assert one_wait > 0 and 0 < staged <= n_long_jobs + redone and one_wait + staged - redone == n_jobs_on_device
+    # (one_wait counts the jobs that COMPLETED as one sequence: a job that is run again is counted as redone and as staged, not as one_wait)
+    assert one_wait > 0 and 0 < staged <= n_long_jobs + redone and one_wait + staged == n_jobs_on_device
     assert n_jobs_on_device >= len(scs) - 2
 
 
