@@ -826,6 +826,7 @@ struct FusedScoreArgs
     int32_t* n_unhandled;  // reads left to the staged kernels
     int32_t write_cals;    // the records' copy in set order (stage 3 and sk_enum_device_fetch_cals read it)
     unsigned long long* dbg; // diagnostics ($SK_F5_TIMING): per block 8 cycle stamps, or null
+    unsigned* queue;       // [2] the launch's read queue: next read, waves that have left (both 0 between launches: the last wave out zeroes them)
 };
 
 // a candidate alignment's slot in LDS: the walk's output -- up to F5_SEGS + 1 transitions, one per op that covers read positions and
@@ -1348,19 +1349,38 @@ __device__ __forceinline__ void f5_read(const FusedScoreArgs& fa, const int r, F
     }
 }
 
-// A wave per read, WAVES reads to a block (each wave with an LDS object of its own; nothing is shared between them).  With a block per
-// read the kernel was bound by the rate at which the dispatcher places workgroups: 65 536 one-wave blocks went out at ~30 per us, a
-// block lives ~58 us, so ~7 of a CU's 16 slots were filled however many were free (SQ_WAVE_CYCLES says the same); eight waves to a
-// block is an eighth of the placements, its waves spread over the CU's four SIMDs at once: 2.23 -> 1.67 ms per 65 536 reads (2 waves
-// to a block: no change, 4: 1.73, 16: 1.67 -- profiles/r05_f5_history.txt).  A grid of the 4 096 waves the device holds at a time, each
-// taking reads r, r + 4 096, ..., had been the other way round that limit and is slower (2.49 ms: waves that start together stay in step,
-// all in the walk or all in the sums).
+// A wave per read, WAVES waves to a block (each wave with an LDS object of its own; nothing is shared between them).  With a block per
+// read the kernel was bound by the rate at which the dispatcher places workgroups (65 536 one-wave blocks went out at ~30 per us, a block
+// lives ~58 us: ~7 of a CU's 16 slots filled); eight waves to a block: 2.23 -> 1.67 ms per 65 536 reads (profiles/r05_f5_history.txt).
+// The waves TAKE their reads from a queue (one counter, one atomic per read; a grid of the blocks the device holds at a time).  With read r
+// bound to wave r a block lived as long as its heaviest read -- a read's work goes with its candidate alignments, a round of the wave per
+// 64 -- and its other seven slots stood empty meanwhile: 7.5 waves to a CU on average (SQ_WAVE_CYCLES, profiles/r06_v28_pmc_traffic.json)
+// where two such blocks, 16 waves, are resident (tools/diag/lds_residency.hip).  1.67 -> 1.23 ms.  Round 5's persistent grid (reads r, r + 4 096, ... to wave r: slower) had the
+// same binding, only longer.  The queue's order is the job's: taking the heavy reads first, or the light ones last (lists by rounds of 64
+// candidate alignments, filled by pool_layout_kernel), was tried against the launch's tail and is SLOWER (1.33-1.37 ms: reads of one kind
+// side by side keep their waves in step -- all in their prologues, all in their walks -- where the job's own order mixes them;
+// profiles/r06_f5_history.txt).  The last wave to leave puts the queue back to zero, so that the next launch -- the same buffers, the same
+// stream -- finds it as this one did.
 template <int MAXR, bool TIMING, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void flatten_score_kernel(const FusedScoreArgs fa, const int n_reads)
 {
     __shared__ __attribute__((aligned(16))) F5Lds<MAXR> S[WAVES];
-    const int wave = threadIdx.x >> 6, r = blockIdx.x * WAVES + wave;
-    if (r < n_reads) f5_read<MAXR, TIMING>(fa, r, S[wave]);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (;;) {
+        int r = 0;
+        if (lane == 0) r = int(atomicAdd(&fa.queue[0], 1u));
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r >= n_reads) break;
+        f5_read<MAXR, TIMING>(fa, r, S[wave]);
+        f5_wave_sync(); // (the wave's LDS object is the next read's)
+    }
+    if (lane == 0) {
+        __threadfence();
+        if (atomicAdd(&fa.queue[1], 1u) == gridDim.x * unsigned(WAVES) - 1u) { // (every wave has made its last draw)
+            fa.queue[0] = 0u;
+            fa.queue[1] = 0u;
+        }
+    }
 }
 
 // the rows of terms sized for the job's longest read: with 150-base reads a wave's LDS is 10 KB, sixteen waves to a CU (the 256-base
@@ -1372,11 +1392,19 @@ static void launch_flatten_score_t(const int n_reads, hipStream_t st, const Fuse
     static const int waves = [] { const char* e = std::getenv("SK_F5_WAVES"); return e ? std::atoi(e) : 0; }(); // (experiments: 1, 2, 4, 8, 16; 0 = the default)
     constexpr int DEFAULT_WAVES = (sizeof(F5Lds<MAXR>) * 16 <= 160 * 1024) ? 8 : 4;
     const int w = waves > 0 ? waves : DEFAULT_WAVES;
-    if (w == 16 && MAXR <= 152) SK_LAUNCH((flatten_score_kernel<152, TIMING, 16>), dim3((n_reads + 15) / 16), dim3(1024), 0, st, fs, n_reads);
-    else if (w >= 8) SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 8>), dim3((n_reads + 7) / 8), dim3(512), 0, st, fs, n_reads);
-    else if (w == 4) SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 4>), dim3((n_reads + 3) / 4), dim3(256), 0, st, fs, n_reads);
-    else if (w == 2) SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 2>), dim3((n_reads + 1) / 2), dim3(128), 0, st, fs, n_reads);
-    else SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 1>), dim3(n_reads), dim3(64), 0, st, fs, n_reads);
+    // the blocks the device holds at a time (256 CUs; by LDS: 16 waves of the short-read form to a CU, 14 of the long one; a grid larger
+    // than that only queues blocks that find the read queue empty, a smaller one leaves slots unused): $SK_F5_GRID = blocks, experiments
+    static const int grid_env = [] { const char* e = std::getenv("SK_F5_GRID"); return e ? std::atoi(e) : 0; }();
+    constexpr int WAVES_PER_CU = int((160 * 1024) / sizeof(F5Lds<MAXR>)) >= 16 ? 16 : int((160 * 1024) / sizeof(F5Lds<MAXR>));
+    auto grid = [&](const int wpb) {
+        const int resident = grid_env > 0 ? grid_env : 256 * std::max(1, WAVES_PER_CU / wpb);
+        return dim3(unsigned(std::max(1, std::min(resident, (n_reads + wpb - 1) / wpb))));
+    };
+    if (w == 16 && MAXR <= 152) SK_LAUNCH((flatten_score_kernel<152, TIMING, 16>), grid(16), dim3(1024), 0, st, fs, n_reads);
+    else if (w >= 8) SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 8>), grid(8), dim3(512), 0, st, fs, n_reads);
+    else if (w == 4) SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 4>), grid(4), dim3(256), 0, st, fs, n_reads);
+    else if (w == 2) SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 2>), grid(2), dim3(128), 0, st, fs, n_reads);
+    else SK_LAUNCH((flatten_score_kernel<MAXR, TIMING, 1>), grid(1), dim3(64), 0, st, fs, n_reads);
 }
 
 static void launch_flatten_score(const int n_reads, hipStream_t st, const FusedScoreArgs& fs)
@@ -2061,7 +2089,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
     // one sequence: the buffers between the search and stage 3 are sized by the pool's capacity instead of by counts the host would have
     // to wait for -- 256 leaves per read (at least 2^17) cover every WGS-like job; one that needs more is run again the staged way
     if (one_wait && !test_caps) pool_cap = std::min<int64_t>(pool_cap, std::max<int64_t>(int64_t(n) * 256, 1 << 17));
-    const int n_counters = Caps::K + 8 + DYN_COUNT; // level counts [0, K+3), leaves, calls made (64 bit), F5's unhandled reads; the scans' results
+    const int n_counters = Caps::K + 8 + DYN_COUNT + 2; // (+ 2: F5's read queue, FusedScoreArgs::queue)  // level counts [0, K+3), leaves, calls made (64 bit), F5's unhandled reads; the scans' results
 #define RES(buf, bytes) \
     if (B.buf.reserve(std::max<size_t>(size_t(bytes), 256))) return 1
 #define HRES(buf, bytes) \
@@ -2358,6 +2386,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         fs.scores = B.scores.as<double>();
         fs.err = ctx.dev_error_flags;
         fs.n_unhandled = n_unhandled;
+        fs.queue = B.counters.as<unsigned>() + (Caps::K + 8 + DYN_COUNT);
         fs.write_cals = 0;
         fs.dbg = nullptr;
         launch_flatten_score(n, st, fs);
@@ -2719,6 +2748,7 @@ static int enum_device_run_impl(const SkEnumInput* in, SkEnumOutput* out, const 
         fs.scores = B.scores.as<double>();
         fs.err = ctx.dev_error_flags;
         fs.n_unhandled = B.counters.as<int32_t>() + (Caps::K + 7);
+        fs.queue = B.counters.as<unsigned>() + (Caps::K + 8 + DYN_COUNT);
         fs.write_cals = 0;
         fs.dbg = nullptr;
         launch_flatten_score(n, st, fs);
