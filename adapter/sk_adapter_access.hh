@@ -10,6 +10,7 @@
 #include "blt_util/blt_exception.hh"
 #include "starling_common/starling_pos_processor_base.hh"
 
+#include <climits>
 #include <deque>
 #include <functional>
 #include <queue>
@@ -125,7 +126,22 @@ struct SiteChunk
     // germline EVS: the per-call arguments of updateGermlineScoringMetrics, kept until POST_ALIGN has passed the chunk
     std::vector<int64_t> evsOff;      ///< [n+1]
     std::vector<uint64_t> evsWords;
+    /// The words where the push left them -- one of the stream's output blocks, valid through its next SK_PILEUP_WINDOW_LIFETIME pushes
+    /// (strelka_amd.h) -- instead of a copy: 2.6 MB a window (0.3 ms), read at one position in a few hundred (updateSiteSampleInfo asks at
+    /// forced and variant sites only, starling_pos_processor.cpp:232-241).  By the time the block comes round again POST_ALIGN has as a
+    /// rule passed the chunk's positions and nobody will ask; a chunk it has not passed -- the stage machine caught up over a coverage
+    /// gap, pushes in quick succession -- takes its copy then (pileup_push, evsWordsCopied counts them).
+    const uint64_t* evsLive = nullptr;
+    unsigned long evsPush = 0;        ///< the sample stream's push that brought the chunk
+    bool isEvsGone = false;           ///< the words were left in the stream's block when it came round again (nobody asks: germline_fill_scoring_metrics checks)
     std::vector<uint8_t> isMetricsFilled;
+    const uint64_t* evsWordsPtr() const { return evsLive != nullptr ? evsLive : evsWords.data(); }
+    void materializeEvsWords()
+    {
+        if (evsLive == nullptr) return;
+        evsWords.assign(evsLive, evsLive + (evsOff.empty() ? 0 : evsOff.back()));
+        evsLive = nullptr;
+    }
 };
 
 /// somatic SNV records of a run of positions one push of the two samples' pileups finalised (site 9 chained into site 5)
@@ -159,6 +175,9 @@ struct PileupState
     pos_t piledTo = 0;                         ///< reads buffered at positions < piledTo have been pushed
     bool isFlushing = false;                   ///< inside starling_pos_processor_base::reset(): no more reads will arrive
     pos_t regionBegin = 0, regionEnd = 0;
+    pos_t lastVariantsPos = INT_MIN;           ///< the last position POST_ALIGN has been through (pileup_before_variants)
+    std::vector<unsigned long> pushCount;      ///< per sample: pushes of its stream so far
+    unsigned long evsWordsCopied = 0, evsWordsLeft = 0; ///< chunks whose EVS words were copied after all / never were (SiteChunk::evsLive)
 };
 
 /// a read segment of the current stage window (collected by align_pos, used by the realignment job and the pileup push)

@@ -201,7 +201,8 @@ State& make_state()
                           << " enum_jobs_host=" << s.realignHostJobs << " realign_ref_window_misses=" << s.realignRefWindowMisses << "\n";
             }
             std::cerr << "strelka_amd adapter pileup: pushes=" << s.pileupBatches << " reads=" << s.pileupReads << " loci=" << s.pileupLoci
-                      << " genotyping=" << (s.pileup.isGenotyping ? 1 : 0) << "\n";
+                      << " genotyping=" << (s.pileup.isGenotyping ? 1 : 0) << " evs_words_copied=" << s.pileup.evsWordsCopied
+                      << " evs_words_left=" << s.pileup.evsWordsLeft << "\n";
             std::cerr << "strelka_amd adapter seconds: realign_hook=" << s.tRealignHook << " realign_abi=" << s.tRealignAbi
                       << " site_hook=" << s.tSiteHook << " site_abi=" << s.tSiteAbi << " pileup_hook=" << s.tPileupHook
                       << " pileup_abi=" << s.tPileupAbi << " init=" << s.tInit << " indel_abi=" << s.tIndelAbi

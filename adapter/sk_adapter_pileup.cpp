@@ -316,6 +316,28 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
     sk_read_batch rb;
     fillReadBatch(wb, rb);
 
+    // this push writes the output block that the push SK_PILEUP_WINDOW_LIFETIME + 1 before it wrote: a chunk that still reads its EVS
+    // words there takes its copy now -- unless POST_ALIGN is through with its positions
+    if (sampleIndex >= ps.pushCount.size()) ps.pushCount.resize(sampleIndex + 1, 0);
+    ps.pushCount[sampleIndex]++;
+    if (ps.isGermlineMetrics && sampleIndex < ps.chunks.size())
+    {
+        for (SiteChunk& c : ps.chunks[sampleIndex])
+        {
+            if (c.evsLive == nullptr || c.evsPush + SK_PILEUP_WINDOW_LIFETIME >= ps.pushCount[sampleIndex]) continue;
+            if (c.end - 1 <= ps.lastVariantsPos)
+            {
+                c.evsLive = nullptr; // (POST_ALIGN is through with every position of the chunk)
+                c.isEvsGone = true;
+                ps.evsWordsLeft++;
+            }
+            else
+            {
+                c.materializeEvsWords();
+                ps.evsWordsCopied++;
+            }
+        }
+    }
     sk_pileup_window w;
     std::memset(&w, 0, sizeof(w));
     {
@@ -377,7 +399,8 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
         if (ps.isGermlineMetrics)
         {
             chunk.evsOff.assign(w.evs_off, w.evs_off + n + 1);
-            chunk.evsWords.assign(w.evs_words, w.evs_words + w.evs_off[n]);
+            chunk.evsLive = w.evs_words; // (no copy: SiteChunk::evsLive)
+            chunk.evsPush = ps.pushCount[sampleIndex];
             chunk.isMetricsFilled.assign(n, 0);
         }
         ps.chunks[sampleIndex].push_back(std::move(chunk));
@@ -584,6 +607,7 @@ void pileup_reset_region(starling_pos_processor_base& pp)
     ps.isAnyPiled = false;
     ps.piledTo = 0;
     ps.isFlushing = false;
+    ps.lastVariantsPos = INT_MIN;
 }
 
 bool pileup_pos_reads(starling_pos_processor_base& pp, const pos_t pos)
@@ -642,6 +666,7 @@ void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos)
     State& s(state());
     PileupState& ps(s.pileup);
     if (! ps.enabled) return;
+    ps.lastVariantsPos = std::max(ps.lastVariantsPos, pos - 1); // (POST_ALIGN is through with the positions below `pos`)
     if (ps.isSomatic)
     {
         // (chunks kept only for the EVS read positions -- the records are computed per site window -- are dropped here; when the
@@ -686,6 +711,7 @@ void germline_fill_scoring_metrics(const unsigned sampleIndex, const pos_t pos, 
         const size_t k(static_cast<size_t>(pos - c.begin));
         if (c.isMetricsFilled[k]) return;
         c.isMetricsFilled[k] = 1;
+        if (c.isEvsGone) throw blt_exception("strelka_amd adapter: a position is scored after the POST_ALIGN stage has been through its window");
         const int64_t o(c.evsOff[k]);
         const size_t n(static_cast<size_t>(c.evsOff[k + 1] - o));
         if (n != pi.mapqTracker.count) throw blt_exception("strelka_amd adapter: the pileup of a scored position is not the stream's");
@@ -694,7 +720,7 @@ void germline_fill_scoring_metrics(const unsigned sampleIndex, const pos_t pos, 
         for (size_t i(0); i < n; ++i)
         {
             // pos_basecall_buffer::updateGermlineScoringMetrics (pos_basecall_buffer.cpp:43-70), in pileup order
-            const uint64_t w(c.evsWords[static_cast<size_t>(o) + i]);
+            const uint64_t w(c.evsWordsPtr()[static_cast<size_t>(o) + i]);
             const uint8_t callId(static_cast<uint8_t>(w & 7u));
             const unsigned mapq(static_cast<unsigned>((w >> 3) & 0xffu)), qscore(static_cast<unsigned>((w >> 11) & 0x7fu));
             const unsigned cycle(static_cast<unsigned>((w >> 18) & 0x7ffu)), edge(static_cast<unsigned>((w >> 29) & 0x1fu));

@@ -632,7 +632,12 @@ int sk_site_digt_call_fused_dev(const sk_pileup_batch* dev_batch, const sk_germl
  * was created with germline options -- the diploid genotype of the CleanPileupFilter'ed tier1 column.  The columns never
  * leave the device between the pileup and the genotype kernels; reads that reach past `final_to` stay on the device for the
  * next push.  Not produced: the EVS feature accumulators (updateGermlineScoringMetrics / updateSomaticScoringMetrics).
- * The returned pointers are into a host buffer of the stream, valid until its next call. */
+ * The returned pointers are into a host buffer of the stream (page-locked: the device writes it).  A stream keeps
+ * SK_PILEUP_WINDOW_LIFETIME + 1 such buffers in rotation: a window's arrays stay valid through the stream's next
+ * SK_PILEUP_WINDOW_LIFETIME pushes and are overwritten by the one after -- long enough for a caller whose POST_ALIGN stage runs a
+ * window or two behind its pushes to read the bulk of a window (the EVS words: 8 bytes a basecall, asked for at one position in a
+ * few hundred) where the push left it instead of copying it out (adapter/sk_adapter_pileup.cpp, SiteChunk::evsLive). */
+#define SK_PILEUP_WINDOW_LIFETIME 2
 typedef struct sk_pileup_stream sk_pileup_stream;
 
 /** What the gVCF writer's non-variant block logic reads of a position (gvcf_writer::queue_site_record, L/applications/starling/

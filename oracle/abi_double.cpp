@@ -551,7 +551,11 @@ struct sk_pileup_stream
     std::vector<int64_t> o_off1, o_off2;
     std::vector<uint16_t> o_c1, o_c2;
     std::vector<uint32_t> o_sd, o_sm, o_mn, o_mz, o_cn, o_cn4, o_rp;
-    std::vector<uint64_t> o_sq, o_ev;
+    std::vector<uint64_t> o_sq;
+    // (as the library's output blocks: SK_PILEUP_WINDOW_LIFETIME + 1 in rotation; here for the one array whose longer life the adapter
+    // uses -- the window's other arrays live until the next push, the weaker promise)
+    std::vector<uint64_t> o_ev_blocks[SK_PILEUP_WINDOW_LIFETIME + 1];
+    int o_ev_block = 0;
     std::vector<int64_t> o_evoff;
     std::vector<sk_digt_call> o_g;
     std::vector<sk_gvcf_site_summary> o_sum;
@@ -756,7 +760,12 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
 {
     const size_t nl = static_cast<size_t>(end - begin);
     s->o_off1.assign(nl + 1, 0); s->o_off2.assign(nl + 1, 0);
-    s->o_c1.clear(); s->o_c2.clear(); s->o_rp.clear(); s->o_ev.clear();
+    s->o_ev_block = (s->o_ev_block + 1) % (SK_PILEUP_WINDOW_LIFETIME + 1);
+    std::vector<uint64_t>& o_ev = s->o_ev_blocks[s->o_ev_block];
+    // (a block that comes round again is given up and made anew, so that a reader of a window past its life is a use after free for the
+    // sanitizer runs -- tools/diag/sanitize_e2e.sh -- instead of a silent read of newer words)
+    std::vector<uint64_t>().swap(o_ev);
+    s->o_c1.clear(); s->o_c2.clear(); s->o_rp.clear();
     s->o_evoff.assign(nl + 1, 0);
     s->o_sd.assign(nl, 0); s->o_sm.assign(nl, 0); s->o_mn.assign(nl, 0); s->o_mz.assign(nl, 0); s->o_cn.assign(nl + 1, 0);
     s->o_cn4.assign(nl + 1, 0);
@@ -770,7 +779,7 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
     for (size_t l = 0; l < nl; ++l) {
         s->o_off1[l] = static_cast<int64_t>(s->o_c1.size());
         s->o_off2[l] = static_cast<int64_t>(s->o_c2.size());
-        s->o_evoff[l] = static_cast<int64_t>(s->o_ev.size());
+        s->o_evoff[l] = static_cast<int64_t>(o_ev.size());
         coff[l] = static_cast<int64_t>(ccalls.size());
         coff4[l] = static_cast<int64_t>(ccalls4.size());
         const auto it = s->cols.find(begin + static_cast<int32_t>(l));
@@ -779,7 +788,7 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
         s->o_c1.insert(s->o_c1.end(), c.t1.begin(), c.t1.end());
         s->o_c2.insert(s->o_c2.end(), c.t2.begin(), c.t2.end());
         if (s->want_read_pos) s->o_rp.insert(s->o_rp.end(), c.rp.begin(), c.rp.end());
-        if (s->want_evs) s->o_ev.insert(s->o_ev.end(), c.ev.begin(), c.ev.end());
+        if (s->want_evs) o_ev.insert(o_ev.end(), c.ev.begin(), c.ev.end());
         for (const uint16_t bc : c.t1) if (!((bc >> 12) & 1)) ccalls.push_back(bc);
         s->o_cn[l] = static_cast<uint32_t>(ccalls.size() - static_cast<size_t>(coff[l]));
         if (s->somatic) { // CleanPileupFilter(pi, true), PileupCleaner.cpp:43-64
@@ -791,8 +800,8 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
     }
     s->o_off1[nl] = static_cast<int64_t>(s->o_c1.size());
     s->o_off2[nl] = static_cast<int64_t>(s->o_c2.size());
-    s->o_evoff[nl] = static_cast<int64_t>(s->o_ev.size());
-    s->o_ev.push_back(0);
+    s->o_evoff[nl] = static_cast<int64_t>(o_ev.size());
+    o_ev.push_back(0);
     coff[nl] = static_cast<int64_t>(ccalls.size());
     coff4[nl] = static_cast<int64_t>(ccalls4.size());
     s->o_c1.push_back(0); s->o_c2.push_back(0); ccalls.push_back(0); ccalls4.push_back(0); s->o_rp.push_back(0);
@@ -865,7 +874,7 @@ int double_emit(sk_pileup_stream* s, const int32_t begin, const int32_t end, con
     }
     out->gvcf_runs = (s->genotype && s->want_runs) ? s->o_runs.data() : nullptr;
     out->evs_off = s->want_evs ? s->o_evoff.data() : nullptr;
-    out->evs_words = s->want_evs ? s->o_ev.data() : nullptr;
+    out->evs_words = s->want_evs ? s->o_ev_blocks[s->o_ev_block].data() : nullptr;
     return 0;
 }
 

@@ -1356,7 +1356,11 @@ struct sk_pileup_stream
     int32_t next_begin = 0;
     DevBuf d_in2[2], d_work, d_out; // (two input blocks used alternately: with want_evs the carried reads' bases and qualities are copied across)
     int cur_in = 0;
-    PinBuf h_in, h_out;
+    // the output block of a push: OUT_BLOCKS of them in rotation, so that a window's arrays outlive the next pushes (strelka_amd.h,
+    // sk_pileup_window: the caller reads the bulk of a window -- the EVS words -- where the push left it, or not at all)
+    PinBuf h_in, h_out_blocks[SK_PILEUP_WINDOW_LIFETIME + 1];
+    int out_block = 0;
+    PinBuf& h_out_cur() { return h_out_blocks[out_block]; }
     int64_t pushes = 0, reads_in = 0;
     // the push in flight (stream_enqueue -> stream_finish)
     InLay li;
@@ -1656,11 +1660,12 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         ol.evs = o; o += align256(s->want_evs ? 8 * std::max<int64_t>(n_bases, 1) : 0);
         ol.total = o;
     }
-    if (s->d_work.need(size_t(wl.total)) || s->d_out.need(size_t(ol.total)) || s->h_out.need(size_t(ol.total)))
+    s->out_block = (s->out_block + 1) % (SK_PILEUP_WINDOW_LIFETIME + 1);
+    if (s->d_work.need(size_t(wl.total)) || s->d_out.need(size_t(ol.total)) || s->h_out_cur().need(size_t(ol.total)))
         return sk_fail("sk_pileup_stream_push: out of memory (work / output blocks)");
     char* dw = static_cast<char*>(s->d_work.p);
     char* dout = static_cast<char*>(s->d_out.p);
-    char* ho = static_cast<char*>(s->h_out.p);
+    char* ho = static_cast<char*>(s->h_out_cur().p);
     lap(2); // layouts + work / out buffers
 
     PileupArgs a;
@@ -1804,7 +1809,7 @@ void stream_finish(sk_pileup_stream* s, sk_pileup_window* out)
     const InLay& li = s->li;
     const OutLay& ol = s->ol;
     const char* hi = static_cast<const char*>(s->h_in.p);
-    const char* ho = static_cast<const char*>(s->h_out.p);
+    const char* ho = static_cast<const char*>(s->h_out_cur().p);
     const int n = s->p_n;
     const int32_t F = s->p_F;
     // the reads from the first one that ends past F on
@@ -1869,7 +1874,8 @@ void stream_drop(sk_pileup_stream* s)
     s->d_ref.drop(); s->d_mask.drop(); s->d_spandel.drop(); s->d_submapped.drop();
     s->d_rec[0].drop(); s->d_rec[1].drop(); s->d_span[0].drop(); s->d_span[1].drop();
     s->d_in2[0].drop(); s->d_in2[1].drop(); s->d_work.drop(); s->d_out.drop();
-    s->h_in.drop(); s->h_out.drop();
+    s->h_in.drop();
+    for (PinBuf& b : s->h_out_blocks) b.drop();
 }
 
 } // namespace
@@ -2138,9 +2144,9 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
     stream_finish(sn, &out->normal);
     stream_finish(stu, &out->tumor);
     out->tumor_tier1_read_pos =
-        stu->want_read_pos ? reinterpret_cast<const uint32_t*>(static_cast<const char*>(stu->h_out.p) + stu->ol.read_pos) : nullptr;
-    out->normal_clean_tier2_count = reinterpret_cast<const uint32_t*>(static_cast<const char*>(sn->h_out.p) + sn->ol.clean4_n);
-    out->tumor_clean_tier2_count = reinterpret_cast<const uint32_t*>(static_cast<const char*>(stu->h_out.p) + stu->ol.clean4_n);
+        stu->want_read_pos ? reinterpret_cast<const uint32_t*>(static_cast<const char*>(stu->h_out_cur().p) + stu->ol.read_pos) : nullptr;
+    out->normal_clean_tier2_count = reinterpret_cast<const uint32_t*>(static_cast<const char*>(sn->h_out_cur().p) + sn->ol.clean4_n);
+    out->tumor_clean_tier2_count = reinterpret_cast<const uint32_t*>(static_cast<const char*>(stu->h_out_cur().p) + stu->ol.clean4_n);
     out->genotype = (p->genotype && n_loci > 0) ? static_cast<const sk_somatic_snv_genotype*>(p->h_geno.p) : nullptr;
     return 0;
 }
