@@ -158,9 +158,27 @@ struct SomaticChunk
     std::vector<uint8_t> isMetricsFilled;
 };
 
+/// a window whose push has been begun and not finished (sk_pileup_stream_push_begin / _finish): what its completion still needs
+struct PendingPush
+{
+    bool active = false;
+    bool isFinal = false;
+    int32_t finalTo = 0;
+    pos_t ploidyBegin = 0;
+    bool hasPloidy = false;
+    std::vector<uint8_t> ploidy;
+    pos_t forcedBegin = 0;            ///< (the somatic stream's window: is_forced_output_pos of the positions it can finalise)
+    std::vector<uint8_t> forced;
+};
+
 /// site 9: one pileup stream per sample (sk_adapter_pileup.cpp); the somatic caller's two samples share one
 struct PileupState
 {
+    /// The device works on a sample's window while the stage machine goes through the positions POST_ALIGN still has before it:
+    /// the push is finished when POST_ALIGN reaches the first position no finished window covers (pileup_before_variants), before the
+    /// sample's next push, and at a region's end.  $STRELKA_AMD_PUSH_ASYNC=0: begun and finished in one call.
+    std::vector<PendingPush> pending;
+    PendingPush somaticPending;                ///< the two samples of the somatic caller are one push
     bool decided = false, enabled = false, isGenotyping = false;
     bool isSomatic = false, isSomaticMetrics = false, isGermlineMetrics = false;
     std::vector<sk_pileup_stream*> streams;

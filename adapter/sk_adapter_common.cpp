@@ -50,7 +50,15 @@ unsigned post_align_defer(const starling_base_options& opt)
     {
         const char* v(std::getenv("STRELKA_AMD_SITE_WINDOW"));
         if (v != nullptr && *v != 0) g_postAlignDefer = static_cast<int>(std::strtoul(v, nullptr, 10));
-        else g_postAlignDefer = pileup_genotypes_with_stream(opt) ? 0 : 4096;
+        else if (! pileup_genotypes_with_stream(opt)) g_postAlignDefer = 4096;
+        else
+        {
+            // the genotypes come with the pileup stream's windows: POST_ALIGN is held back only by what hides a window's time on the
+            // device -- ~0.45 ms, ~400 head positions of read intake at 40x -- behind the stage machine's own work (the push is begun
+            // when READ_BUFFER reaches the window and finished when POST_ALIGN does: sk_adapter_pileup.cpp, pileup_complete_push)
+            const char* a(std::getenv("STRELKA_AMD_PUSH_ASYNC"));
+            g_postAlignDefer = (a == nullptr || *a == 0 || std::atoi(a) != 0) ? 512 : 0;
+        }
     }
     return static_cast<unsigned>(g_postAlignDefer);
 }

@@ -260,13 +260,23 @@ void assignWindow(starling_pos_processor_base::sample_info& sif, const sk_pileup
     }
 }
 
-/// one sample's window into its stream; the finalised positions into the reference's buffers
+void pileup_complete_push(starling_pos_processor_base& pp, const unsigned sampleIndex);
+void pileup_complete_somatic_push(starling_pos_processor_base& pp);
+
+static bool isPushAsync()
+{
+    static const bool on([] { const char* v(std::getenv("STRELKA_AMD_PUSH_ASYNC")); return v == nullptr || *v == 0 || std::atoi(v) != 0; }());
+    return on;
+}
+
+/// one sample's window into its stream (the push is begun here and finished by pileup_complete_push)
 void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sampleIndex, const pos_t begin, const pos_t end,
                           const bool isFinal)
 {
     State& s(state());
     PileupState& ps(s.pileup);
-    starling_pos_processor_base::sample_info& sif(pp.sample(sampleIndex));
+    if (sampleIndex >= ps.pending.size()) ps.pending.resize(sampleIndex + 1);
+    pileup_complete_push(pp, sampleIndex); // (the sample's last window, if POST_ALIGN has not asked for it yet)
     const reference_contig_segment& ref(Access::ref(pp));
     sk_pileup_stream* stream(ps.streams[sampleIndex]);
 
@@ -338,17 +348,48 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
             }
         }
     }
-    sk_pileup_window w;
-    std::memset(&w, 0, sizeof(w));
     {
         AccumTimer abiTimer(s.tPileupAbi);
-        check(sk_pileup_stream_push(stream, &rb, static_cast<int32_t>(span), static_cast<int32_t>(maskBegin),
-                                    static_cast<int32_t>(maskEnd - maskBegin), mask.empty() ? nullptr : mask.data(), finalTo,
-                                    static_cast<int32_t>(ploidyBegin), ploidyLen, ploidyPtr, &w), "sk_pileup_stream_push");
+        check(sk_pileup_stream_push_begin(stream, &rb, static_cast<int32_t>(span), static_cast<int32_t>(maskBegin),
+                                          static_cast<int32_t>(maskEnd - maskBegin), mask.empty() ? nullptr : mask.data(), finalTo,
+                                          static_cast<int32_t>(ploidyBegin), ploidyLen, ploidyPtr), "sk_pileup_stream_push_begin");
     }
     s.pileupBatches++;
     s.pileupReads += wb.pos.size();
     if (! wb.pos.empty()) ps.pendingEnd[sampleIndex] = std::max(ps.pendingEnd[sampleIndex], wb.hi);
+    PendingPush& pend(ps.pending[sampleIndex]);
+    pend.active = true;
+    pend.isFinal = isFinal;
+    pend.finalTo = finalTo;
+    pend.ploidyBegin = ploidyBegin;
+    pend.hasPloidy = (ploidyPtr != nullptr);
+    if (pend.hasPloidy) pend.ploidy.assign(ploidyPtr, ploidyPtr + ploidyLen);
+    else pend.ploidy.clear();
+    if (! isPushAsync()) pileup_complete_push(pp, sampleIndex);
+}
+
+/// the window of a sample's push in flight, once the device is through with it: the finalised positions into the reference's buffers,
+/// the records the later sites read into the sample's chunks
+void pileup_complete_push(starling_pos_processor_base& pp, const unsigned sampleIndex)
+{
+    State& s(state());
+    PileupState& ps(s.pileup);
+    if (sampleIndex >= ps.pending.size() || ! ps.pending[sampleIndex].active) return;
+    PendingPush& pend(ps.pending[sampleIndex]);
+    pend.active = false;
+    starling_pos_processor_base::sample_info& sif(pp.sample(sampleIndex));
+    sk_pileup_stream* stream(ps.streams[sampleIndex]);
+    const bool isFinal(pend.isFinal);
+    const int32_t finalTo(pend.finalTo);
+    const pos_t ploidyBegin(pend.ploidyBegin);
+    const uint8_t* const ploidyPtr(pend.hasPloidy ? pend.ploidy.data() : nullptr);
+    const int32_t ploidyLen(static_cast<int32_t>(pend.ploidy.size()));
+    sk_pileup_window w;
+    std::memset(&w, 0, sizeof(w));
+    {
+        AccumTimer abiTimer(s.tPileupAbi);
+        check(sk_pileup_stream_push_finish(stream, &w), "sk_pileup_stream_push_finish");
+    }
 
     assignWindow(sif, w);
     const size_t n(static_cast<size_t>(w.end - w.begin));
@@ -413,6 +454,7 @@ void pileup_somatic_window(starling_pos_processor_base& pp, const pos_t begin, c
 {
     State& s(state());
     PileupState& ps(s.pileup);
+    pileup_complete_somatic_push(pp); // (the last window, if POST_ALIGN has not asked for it yet)
     const reference_contig_segment& ref(Access::ref(pp));
     if (! ps.isRegionOpen[0])
     {
@@ -465,17 +507,42 @@ void pileup_somatic_window(starling_pos_processor_base& pp, const pos_t begin, c
     bool isComputeNonSomatic(false);
     (void)somatic_stream_options(pp, so, isComputeNonSomatic);
 
+    {
+        AccumTimer abiTimer(s.tPileupAbi);
+        check(sk_somatic_pileup_stream_push_begin(ps.somaticStream, &rb[0], &rb[1], static_cast<int32_t>(span), static_cast<int32_t>(maskBegin),
+                                                  static_cast<int32_t>(maskEnd - maskBegin), mask.empty() ? nullptr : mask.data(), finalTo,
+                                                  static_cast<int32_t>(forcedBegin), static_cast<int32_t>(forced.size()),
+                                                  forced.empty() ? nullptr : forced.data(), isComputeNonSomatic ? 1 : 0),
+              "sk_somatic_pileup_stream_push_begin");
+    }
+    s.pileupBatches++;
+    PendingPush& pend(ps.somaticPending);
+    pend.active = true;
+    pend.isFinal = isFinal;
+    pend.finalTo = finalTo;
+    pend.forcedBegin = forcedBegin;
+    pend.forced = forced;
+    if (! isPushAsync()) pileup_complete_somatic_push(pp);
+}
+
+/// the somatic stream's window in flight, once the device is through with it
+void pileup_complete_somatic_push(starling_pos_processor_base& pp)
+{
+    State& s(state());
+    PileupState& ps(s.pileup);
+    if (! ps.somaticPending.active) return;
+    PendingPush& pend(ps.somaticPending);
+    pend.active = false;
+    const bool isFinal(pend.isFinal);
+    const int32_t finalTo(pend.finalTo);
+    const pos_t forcedBegin(pend.forcedBegin);
+    const std::vector<uint8_t>& forced(pend.forced);
     sk_somatic_pileup_window w;
     std::memset(&w, 0, sizeof(w));
     {
         AccumTimer abiTimer(s.tPileupAbi);
-        check(sk_somatic_pileup_stream_push(ps.somaticStream, &rb[0], &rb[1], static_cast<int32_t>(span), static_cast<int32_t>(maskBegin),
-                                            static_cast<int32_t>(maskEnd - maskBegin), mask.empty() ? nullptr : mask.data(), finalTo,
-                                            static_cast<int32_t>(forcedBegin), static_cast<int32_t>(forced.size()),
-                                            forced.empty() ? nullptr : forced.data(), isComputeNonSomatic ? 1 : 0, &w),
-              "sk_somatic_pileup_stream_push");
+        check(sk_somatic_pileup_stream_push_finish(ps.somaticStream, &w), "sk_somatic_pileup_stream_push_finish");
     }
-    s.pileupBatches++;
     assignWindow(pp.sample(0), w.normal);
     assignWindow(pp.sample(1), w.tumor);
     const size_t n(static_cast<size_t>(w.normal.end - w.normal.begin));
@@ -593,6 +660,9 @@ void pileup_reset_region(starling_pos_processor_base& pp)
             ps.streams.push_back(st);
         }
     }
+    // (a window still in flight -- POST_ALIGN never asked for a position it covers -- is finished before its stream starts over)
+    for (unsigned i(0); i < ps.pending.size(); ++i) pileup_complete_push(pp, i);
+    pileup_complete_somatic_push(pp);
     // (the reference segment of the region is loaded after resetRegion, starling_run.cpp:117-119: the streams get it with the
     // region's first push)
     const known_pos_range2& rr(Access::reportRange(pp));
@@ -676,9 +746,16 @@ void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos)
             while ((! ps.somaticChunks.empty()) && ps.somaticChunks.front().end <= pos) ps.somaticChunks.pop_front();
         }
         if (pos < ps.nextFinal[0]) return;
+        if (ps.somaticPending.active)
+        {
+            AccumTimer hookTimer(s.tPileupHook);
+            pileup_complete_somatic_push(pp); // (the window in flight is the one that covers it)
+            if (pos < ps.nextFinal[0]) return;
+        }
         if (! ps.isFlushing) throw blt_exception("strelka_amd adapter: the POST_ALIGN stage reached a position whose pileup is not final");
         AccumTimer hookTimer(s.tPileupHook);
         pileup_somatic_window(pp, 0, 0, true);
+        pileup_complete_somatic_push(pp);
         return;
     }
     const unsigned sampleCount(Access::sampleCount(pp));
@@ -694,10 +771,18 @@ void pileup_before_variants(starling_pos_processor_base& pp, const pos_t pos)
     for (unsigned sampleIndex(0); sampleIndex < sampleCount; ++sampleIndex)
     {
         if (pos < ps.nextFinal[sampleIndex]) continue;
+        if (sampleIndex < ps.pending.size() && ps.pending[sampleIndex].active)
+        {
+            // the window in flight is the one that covers it
+            AccumTimer hookTimer(s.tPileupHook);
+            pileup_complete_push(pp, sampleIndex);
+            if (pos < ps.nextFinal[sampleIndex]) continue;
+        }
         if (! ps.isFlushing) throw blt_exception("strelka_amd adapter: the POST_ALIGN stage reached a position whose pileup is not final");
         AccumTimer hookTimer(s.tPileupHook);
         // nothing new to pile up: an empty window that finalises everything
         pileup_sample_window(pp, sampleIndex, 0, 0, true);
+        pileup_complete_push(pp, sampleIndex);
     }
 }
 

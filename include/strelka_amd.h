@@ -729,6 +729,16 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, int3
 int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* host_reads, int32_t largest_total_indel_ref_span_per_read,
                           int32_t mask_begin, int32_t mask_len, const uint8_t* cand_snv_mask, int32_t final_to,
                           int32_t ploidy_begin, int32_t ploidy_len, const uint8_t* ploidy, sk_pileup_window* out);
+/** The same push in two halves.  _begin checks the reads, packs them (the caller's arrays are free again when it returns) and enqueues
+ *  the window's work; _finish waits for the device and hands out the window.  Between the two the stream takes no other call
+ *  (_begin_region and a second _begin fail); other entry points of the library may be called -- they run behind the window's work on the
+ *  process's stream.  For a caller with host work of its own before it needs the window: the reference's POST_ALIGN stage trails the
+ *  READ_BUFFER stage by largest_total_indel_ref_span_per_read positions (starling_pos_processor_base.cpp:141-224) plus what the
+ *  adapter defers it by, and every head position in between is read intake the device's ~0.4 ms can hide behind. */
+int sk_pileup_stream_push_begin(sk_pileup_stream* s, const sk_read_batch* host_reads, int32_t largest_total_indel_ref_span_per_read,
+                                int32_t mask_begin, int32_t mask_len, const uint8_t* cand_snv_mask, int32_t final_to,
+                                int32_t ploidy_begin, int32_t ploidy_len, const uint8_t* ploidy);
+int sk_pileup_stream_push_finish(sk_pileup_stream* s, sk_pileup_window* out);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (somatic SNV): 30-state frequency-grid likelihoods + 3x2 posterior
@@ -842,6 +852,13 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* s, const sk_read_bat
                                   int32_t mask_begin, int32_t mask_len, const uint8_t* cand_snv_mask, int32_t final_to,
                                   int32_t forced_begin, int32_t forced_len, const uint8_t* is_forced_output,
                                   int is_compute_nonsomatic, sk_somatic_pileup_window* out);
+/** the two halves, as sk_pileup_stream_push_begin / _finish */
+int sk_somatic_pileup_stream_push_begin(sk_somatic_pileup_stream* s, const sk_read_batch* host_normal_reads,
+                                        const sk_read_batch* host_tumor_reads, int32_t largest_total_indel_ref_span_per_read,
+                                        int32_t mask_begin, int32_t mask_len, const uint8_t* cand_snv_mask, int32_t final_to,
+                                        int32_t forced_begin, int32_t forced_len, const uint8_t* is_forced_output,
+                                        int is_compute_nonsomatic);
+int sk_somatic_pileup_stream_push_finish(sk_somatic_pileup_stream* s, sk_somatic_pileup_window* out);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Hot path B (indels): per-read likelihood reductions over IndelSampleData::read_path_lnp

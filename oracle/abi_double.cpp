@@ -566,6 +566,8 @@ struct sk_pileup_stream
     std::vector<int64_t> k_off, k_off4;
     std::vector<uint16_t> k_calls, k_calls4;
     std::vector<uint8_t> k_ref;
+    bool in_flight = false; // between sk_pileup_stream_push_begin and _finish
+    sk_pileup_window pending;
 };
 
 struct sk_somatic_pileup_stream
@@ -574,6 +576,8 @@ struct sk_somatic_pileup_stream
     sk_somatic_snv_options sopt;
     bool genotype = false, tier2 = false;
     std::vector<sk_somatic_snv_genotype> o_g;
+    bool in_flight = false; // between sk_somatic_pileup_stream_push_begin and _finish
+    sk_somatic_pileup_window pending;
 };
 
 extern "C" {
@@ -614,6 +618,7 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, int3
 {
     if (!g_ready) return fail("sk_init() has not succeeded");
     if (!s || ref_len < 0 || report_end < report_begin) return fail("sk_pileup_stream_begin_region: bad argument");
+    if (s->in_flight) return fail("sk_pileup_stream_begin_region: the stream's last push has not been finished");
     s->ref.assign(ref_seq ? ref_seq : "", static_cast<size_t>(ref_len));
     s->ref_offset = ref_offset;
     s->region_begin = report_begin;
@@ -895,12 +900,33 @@ int sk_pileup_stream_enable_evs_words(sk_pileup_stream* s, int enable)
     return 0;
 }
 
+// (the two halves of a push: the double computes the window in _begin and hands it out in _finish -- the same contract, nothing in flight)
+int sk_pileup_stream_push_begin(sk_pileup_stream* s, const sk_read_batch* reads, int32_t span, int32_t mask_begin, int32_t mask_len,
+                                const uint8_t* cand_snv_mask, int32_t final_to, int32_t ploidy_begin, int32_t ploidy_len, const uint8_t* ploidy)
+{
+    if (!s) return fail("sk_pileup_stream_push_begin: null argument");
+    if (s->in_flight) return fail("sk_pileup_stream_push_begin: the stream's last push has not been finished");
+    if (sk_pileup_stream_push(s, reads, span, mask_begin, mask_len, cand_snv_mask, final_to, ploidy_begin, ploidy_len, ploidy, &s->pending)) return 1;
+    s->in_flight = true;
+    return 0;
+}
+
+int sk_pileup_stream_push_finish(sk_pileup_stream* s, sk_pileup_window* out)
+{
+    if (!s || !out) return fail("sk_pileup_stream_push_finish: null argument");
+    if (!s->in_flight) return fail("sk_pileup_stream_push_finish: no push of this stream has been begun");
+    s->in_flight = false;
+    *out = s->pending;
+    return 0;
+}
+
 int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, int32_t span, int32_t mask_begin, int32_t mask_len,
                           const uint8_t* cand_snv_mask, int32_t final_to, int32_t ploidy_begin, int32_t ploidy_len, const uint8_t* ploidy,
                           sk_pileup_window* out)
 {
     if (!g_ready) return fail("sk_init() has not succeeded");
     if (!s || !reads || !out || !s->has_region) return fail("sk_pileup_stream_push: bad argument / no region");
+    if (s->in_flight) return fail("sk_pileup_stream_push: the stream's last push has not been finished");
     int32_t lo, lowest, highest, begin, end;
     if (double_ingest(s, reads, span, mask_begin, mask_len, cand_snv_mask, &lo)) return 1;
     const int32_t F = std::min(final_to, s->region_end);
@@ -949,12 +975,35 @@ int sk_somatic_pileup_stream_begin_region(sk_somatic_pileup_stream* p, const cha
     return 0;
 }
 
+int sk_somatic_pileup_stream_push_begin(sk_somatic_pileup_stream* p, const sk_read_batch* normal_reads, const sk_read_batch* tumor_reads,
+                                        int32_t span, int32_t mask_begin, int32_t mask_len, const uint8_t* cand_snv_mask, int32_t final_to,
+                                        int32_t forced_begin, int32_t forced_len, const uint8_t* is_forced_output, int is_compute_nonsomatic)
+{
+    if (!p) return fail("sk_somatic_pileup_stream_push_begin: null argument");
+    if (p->in_flight) return fail("sk_somatic_pileup_stream_push_begin: the stream's last push has not been finished");
+    if (sk_somatic_pileup_stream_push(p, normal_reads, tumor_reads, span, mask_begin, mask_len, cand_snv_mask, final_to, forced_begin, forced_len,
+                                      is_forced_output, is_compute_nonsomatic, &p->pending))
+        return 1;
+    p->in_flight = true;
+    return 0;
+}
+
+int sk_somatic_pileup_stream_push_finish(sk_somatic_pileup_stream* p, sk_somatic_pileup_window* out)
+{
+    if (!p || !out) return fail("sk_somatic_pileup_stream_push_finish: null argument");
+    if (!p->in_flight) return fail("sk_somatic_pileup_stream_push_finish: no push of this stream has been begun");
+    p->in_flight = false;
+    *out = p->pending;
+    return 0;
+}
+
 int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_batch* normal_reads, const sk_read_batch* tumor_reads,
                                   int32_t span, int32_t mask_begin, int32_t mask_len, const uint8_t* cand_snv_mask, int32_t final_to,
                                   int32_t forced_begin, int32_t forced_len, const uint8_t* is_forced_output, int is_compute_nonsomatic,
                                   sk_somatic_pileup_window* out)
 {
     if (!g_ready) return fail("sk_init() has not succeeded");
+    if (p && p->in_flight) return fail("sk_somatic_pileup_stream_push: the stream's last push has not been finished");
     if (!p || !normal_reads || !tumor_reads || !out || !p->sample[0]->has_region) return fail("sk_somatic_pileup_stream_push: bad argument / no region");
     const sk_read_batch* reads[2] = { normal_reads, tumor_reads };
     int32_t lowest = INT32_MAX, highest = INT32_MIN, begin, end;

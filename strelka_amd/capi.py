@@ -227,8 +227,8 @@ EXPORTS = [
     "sk_align_builder_finish", "sk_align_builder_error", "sk_align_builder_set_host_threads",
     "sk_align_scores_default", "sk_global_align",
     "sk_pileup_options_default", "sk_pileup_reads", "sk_pileup_reads_dev", "sk_pileup_scratch_bytes",
-    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push", "sk_pileup_stream_enable_evs_words", "sk_gvcf_site_summaries", "sk_gvcf_site_summaries_dev", "sk_gvcf_plain_runs_dev", "sk_gvcf_plain_runs", "sk_pileup_stream_set_gvcf_block_options",
-    "sk_somatic_pileup_stream_create", "sk_somatic_pileup_stream_destroy", "sk_somatic_pileup_stream_begin_region", "sk_somatic_pileup_stream_push",
+    "sk_pileup_stream_create", "sk_pileup_stream_destroy", "sk_pileup_stream_begin_region", "sk_pileup_stream_push", "sk_pileup_stream_push_begin", "sk_pileup_stream_push_finish", "sk_pileup_stream_enable_evs_words", "sk_gvcf_site_summaries", "sk_gvcf_site_summaries_dev", "sk_gvcf_plain_runs_dev", "sk_gvcf_plain_runs", "sk_pileup_stream_set_gvcf_block_options",
+    "sk_somatic_pileup_stream_create", "sk_somatic_pileup_stream_destroy", "sk_somatic_pileup_stream_begin_region", "sk_somatic_pileup_stream_push", "sk_somatic_pileup_stream_push_begin", "sk_somatic_pileup_stream_push_finish",
     "sk_realign_options_default", "sk_realign_job_create", "sk_realign_job_destroy", "sk_realign_job_error",
     "sk_realign_job_set_reference", "sk_realign_job_set_indels", "sk_realign_job_add_read", "sk_realign_job_add_reads", "sk_realign_job_get_batch",
     "sk_realign_job_finish", "sk_realign_job_run", "sk_realign_job_n_reads", "sk_realign_job_read_result",
@@ -1082,16 +1082,27 @@ class PileupStream:
         self._check(self.L.sk_pileup_stream_push(self.h, C.byref(s), span, 0, 0, None, min(final_to, 2**31 - 1), 0, 0, None, C.byref(w)))
         return w.begin, w.end
 
-    def push(self, rb, final_to, mask=None, mask_begin=0, ploidy=None, ploidy_begin=0, span=49):
-        """rb: synth.ReadBatch (its reference / mask fields are ignored) -> dict of numpy copies for [begin, end)"""
+    def push(self, rb, final_to, mask=None, mask_begin=0, ploidy=None, ploidy_begin=0, span=49, halves=False, between=None):
+        """rb: synth.ReadBatch (its reference / mask fields are ignored) -> dict of numpy copies for [begin, end).
+        halves: as sk_pileup_stream_push_begin + _finish, `between()` called while the window is in flight"""
         s = ReadBatchStruct(rb.n_reads, _p(rb.read_off), _p(rb.read_code), _p(rb.read_qual), _p(rb.path_off), _p(rb.path),
                             _p(rb.pos), _p(rb.is_fwd), _p(rb.mapq), _p(rb.map_level), None, 0, 0, None)
         w = PileupWindow()
         mask = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         ploidy = None if ploidy is None else np.ascontiguousarray(ploidy, np.uint8)
-        self._check(self.L.sk_pileup_stream_push(self.h, C.byref(s), span, mask_begin, 0 if mask is None else len(mask), _p(mask),
-                                                  min(final_to, 2**31 - 1), ploidy_begin, 0 if ploidy is None else len(ploidy), _p(ploidy),
-                                                  C.byref(w)))
+        if halves:
+            self.L.sk_pileup_stream_push_begin.argtypes = self.L.sk_pileup_stream_push.argtypes[:-1]
+            self.L.sk_pileup_stream_push_finish.argtypes = [c_void_p, C.POINTER(PileupWindow)]
+            self._check(self.L.sk_pileup_stream_push_begin(self.h, C.byref(s), span, mask_begin, 0 if mask is None else len(mask), _p(mask),
+                                                            min(final_to, 2**31 - 1), ploidy_begin, 0 if ploidy is None else len(ploidy),
+                                                            _p(ploidy)))
+            if between is not None:
+                between()
+            self._check(self.L.sk_pileup_stream_push_finish(self.h, C.byref(w)))
+        else:
+            self._check(self.L.sk_pileup_stream_push(self.h, C.byref(s), span, mask_begin, 0 if mask is None else len(mask), _p(mask),
+                                                      min(final_to, 2**31 - 1), ploidy_begin, 0 if ploidy is None else len(ploidy), _p(ploidy),
+                                                      C.byref(w)))
         n = w.end - w.begin
 
         def arr(ptr, dt, k):

@@ -1338,6 +1338,7 @@ struct sk_pileup_stream
     bool want_runs = false;     // return the non-variant block that would start at every plain site (sk_pileup_stream_set_gvcf_block_options)
     sk_gvcf_block_options gvcf_opt;
     bool poisoned = false;      // a push failed after it had begun to change the stream's state: only begin_region is accepted
+    bool in_flight = false;     // between sk_pileup_stream_push_begin and _finish: the device is working on the window
     // region
     bool has_region = false;
     int32_t ref_offset = 0, ref_len = 0;
@@ -1379,6 +1380,8 @@ struct sk_somatic_pileup_stream
     bool tier2 = false;
     DevBuf d_call; // forced flags, somatic records, the wrapper's scratch
     PinBuf h_forced, h_geno;
+    bool in_flight = false; // between sk_somatic_pileup_stream_push_begin and _finish
+    int p_loci = 0;         // ... the positions of the window in flight
 };
 
 namespace
@@ -1936,6 +1939,7 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, cons
     SK_REQUIRE_INIT();
     if (!s || (!ref_seq && ref_len > 0)) return sk_fail("sk_pileup_stream_begin_region: null argument");
     if (ref_len < 0 || report_end < report_begin) return sk_fail("sk_pileup_stream_begin_region: bad range");
+    if (s->in_flight) return sk_fail("sk_pileup_stream_begin_region: the stream's last push has not been finished");
     SkContext& ctx = sk_ctx();
     SK_HIP(skrt::setDevice(ctx.device));
     hipStream_t st = ctx.stream;
@@ -1967,16 +1971,21 @@ int sk_pileup_stream_begin_region(sk_pileup_stream* s, const char* ref_seq, cons
 }
 
 
-int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const int32_t largest_total_indel_ref_span_per_read,
-                          const int32_t mask_begin, const int32_t mask_len, const uint8_t* cand_snv_mask, const int32_t final_to,
-                          const int32_t ploidy_begin, const int32_t ploidy_len, const uint8_t* ploidy, sk_pileup_window* out)
+// A push in two halves: _begin checks, packs and enqueues everything up to the copy of the window's output block and returns while the
+// device works; _finish waits and hands out the window.  A caller with host work between the two (the adapter: the positions POST_ALIGN
+// still has to go through before it needs this window) spends the device's ~0.4 ms there instead of asleep.  Between the two the stream
+// object takes no other call.
+int sk_pileup_stream_push_begin(sk_pileup_stream* s, const sk_read_batch* reads, const int32_t largest_total_indel_ref_span_per_read,
+                                const int32_t mask_begin, const int32_t mask_len, const uint8_t* cand_snv_mask, const int32_t final_to,
+                                const int32_t ploidy_begin, const int32_t ploidy_len, const uint8_t* ploidy)
 {
     SK_REQUIRE_INIT();
     skrt::wakeHint();
     const bool tm = g_push_seconds.on;
     const double t0 = tm ? PushSeconds::now() : 0.0;
-    if (!s || !reads || !out) return sk_fail("sk_pileup_stream_push: null argument");
+    if (!s || !reads) return sk_fail("sk_pileup_stream_push: null argument");
     if (s->poisoned) return sk_fail("sk_pileup_stream_push: an earlier push of this stream failed; begin the region again");
+    if (s->in_flight) return sk_fail("sk_pileup_stream_push_begin: the stream's last push has not been finished");
     if (stream_check_reads(s, reads, mask_begin, mask_len, cand_snv_mask)) return 1;
     SkContext& ctx = sk_ctx();
     SK_HIP(skrt::setDevice(ctx.device));
@@ -1993,7 +2002,24 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
         s->poisoned = true;
         return 1;
     }
+    skrt::kick(); // (a broker client's records start running now, not at the wait)
+    s->in_flight = true;
+    if (tm) {
+        const double t2 = PushSeconds::now();
+        g_push_seconds.check += t1 - t0, g_push_seconds.enqueue += t2 - t1;
+    }
+    return 0;
+}
+
+int sk_pileup_stream_push_finish(sk_pileup_stream* s, sk_pileup_window* out)
+{
+    SK_REQUIRE_INIT();
+    if (!s || !out) return sk_fail("sk_pileup_stream_push_finish: null argument");
+    if (!s->in_flight) return sk_fail("sk_pileup_stream_push_finish: no push of this stream has been begun");
+    const bool tm = g_push_seconds.on;
     const double t2 = tm ? PushSeconds::now() : 0.0;
+    SkContext& ctx = sk_ctx();
+    s->in_flight = false;
     if (skrt::streamSynchronize(ctx.stream) != hipSuccess) {
         s->poisoned = true;
         return sk_fail("sk_pileup_stream_push: the device reported an error");
@@ -2002,10 +2028,21 @@ int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const
     stream_finish(s, out);
     if (tm) {
         const double t4 = PushSeconds::now();
-        g_push_seconds.check += t1 - t0, g_push_seconds.enqueue += t2 - t1, g_push_seconds.wait += t3 - t2, g_push_seconds.finish += t4 - t3;
+        g_push_seconds.wait += t3 - t2, g_push_seconds.finish += t4 - t3;
         ++g_push_seconds.pushes;
     }
     return 0;
+}
+
+int sk_pileup_stream_push(sk_pileup_stream* s, const sk_read_batch* reads, const int32_t largest_total_indel_ref_span_per_read,
+                          const int32_t mask_begin, const int32_t mask_len, const uint8_t* cand_snv_mask, const int32_t final_to,
+                          const int32_t ploidy_begin, const int32_t ploidy_len, const uint8_t* ploidy, sk_pileup_window* out)
+{
+    if (!out) return sk_fail("sk_pileup_stream_push: null argument");
+    if (sk_pileup_stream_push_begin(s, reads, largest_total_indel_ref_span_per_read, mask_begin, mask_len, cand_snv_mask, final_to, ploidy_begin,
+                                    ploidy_len, ploidy))
+        return 1;
+    return sk_pileup_stream_push_finish(s, out);
 }
 
 // ---- the two samples of a somatic run, pushed together and chained into a12+a13 ----------------------------------------------
@@ -2065,14 +2102,15 @@ int sk_somatic_pileup_stream_begin_region(sk_somatic_pileup_stream* p, const cha
     return 0;
 }
 
-int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_batch* normal_reads, const sk_read_batch* tumor_reads,
-                                  const int32_t largest_total_indel_ref_span_per_read, const int32_t mask_begin, const int32_t mask_len,
-                                  const uint8_t* cand_snv_mask, const int32_t final_to, const int32_t forced_begin, const int32_t forced_len,
-                                  const uint8_t* is_forced_output, const int is_compute_nonsomatic, sk_somatic_pileup_window* out)
+int sk_somatic_pileup_stream_push_begin(sk_somatic_pileup_stream* p, const sk_read_batch* normal_reads, const sk_read_batch* tumor_reads,
+                                        const int32_t largest_total_indel_ref_span_per_read, const int32_t mask_begin, const int32_t mask_len,
+                                        const uint8_t* cand_snv_mask, const int32_t final_to, const int32_t forced_begin, const int32_t forced_len,
+                                        const uint8_t* is_forced_output, const int is_compute_nonsomatic)
 {
     SK_REQUIRE_INIT();
     skrt::wakeHint();
-    if (!p || !normal_reads || !tumor_reads || !out) return sk_fail("sk_somatic_pileup_stream_push: null argument");
+    if (!p || !normal_reads || !tumor_reads) return sk_fail("sk_somatic_pileup_stream_push: null argument");
+    if (p->in_flight) return sk_fail("sk_somatic_pileup_stream_push_begin: the stream's last push has not been finished");
     const sk_read_batch* reads[2] = { normal_reads, tumor_reads };
     for (int i = 0; i < 2; ++i) {
         if (p->sample[i]->poisoned) return sk_fail("sk_somatic_pileup_stream_push: an earlier push of this stream failed; begin the region again");
@@ -2140,7 +2178,25 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
             return 1;
         SK_HIP(skrt::memcpyAsync(p->h_geno.p, d_geno, sizeof(sk_somatic_snv_genotype) * size_t(n_loci), hipMemcpyDeviceToHost, st));
     }
-    SK_HIP(skrt::streamSynchronize(st));
+    skrt::kick(); // (a broker client's records start running now, not at the wait)
+    p->in_flight = true;
+    p->p_loci = n_loci;
+    return 0;
+}
+
+int sk_somatic_pileup_stream_push_finish(sk_somatic_pileup_stream* p, sk_somatic_pileup_window* out)
+{
+    SK_REQUIRE_INIT();
+    if (!p || !out) return sk_fail("sk_somatic_pileup_stream_push_finish: null argument");
+    if (!p->in_flight) return sk_fail("sk_somatic_pileup_stream_push_finish: no push of this stream has been begun");
+    p->in_flight = false;
+    sk_pileup_stream* sn = p->sample[0];
+    sk_pileup_stream* stu = p->sample[1];
+    const int n_loci = p->p_loci;
+    if (skrt::streamSynchronize(sk_ctx().stream) != hipSuccess) {
+        sn->poisoned = stu->poisoned = true;
+        return sk_fail("sk_somatic_pileup_stream_push: the device reported an error");
+    }
     stream_finish(sn, &out->normal);
     stream_finish(stu, &out->tumor);
     out->tumor_tier1_read_pos =
@@ -2149,6 +2205,19 @@ int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_bat
     out->tumor_clean_tier2_count = reinterpret_cast<const uint32_t*>(static_cast<const char*>(stu->h_out_cur().p) + stu->ol.clean4_n);
     out->genotype = (p->genotype && n_loci > 0) ? static_cast<const sk_somatic_snv_genotype*>(p->h_geno.p) : nullptr;
     return 0;
+}
+
+
+int sk_somatic_pileup_stream_push(sk_somatic_pileup_stream* p, const sk_read_batch* normal_reads, const sk_read_batch* tumor_reads,
+                                  const int32_t largest_total_indel_ref_span_per_read, const int32_t mask_begin, const int32_t mask_len,
+                                  const uint8_t* cand_snv_mask, const int32_t final_to, const int32_t forced_begin, const int32_t forced_len,
+                                  const uint8_t* is_forced_output, const int is_compute_nonsomatic, sk_somatic_pileup_window* out)
+{
+    if (!out) return sk_fail("sk_somatic_pileup_stream_push: null argument");
+    if (sk_somatic_pileup_stream_push_begin(p, normal_reads, tumor_reads, largest_total_indel_ref_span_per_read, mask_begin, mask_len, cand_snv_mask,
+                                            final_to, forced_begin, forced_len, is_forced_output, is_compute_nonsomatic))
+        return 1;
+    return sk_somatic_pileup_stream_push_finish(p, out);
 }
 
 } // extern "C"

@@ -54,6 +54,7 @@ void r_disconnect();
 int r_device_count(std::string* why);
 bool r_host_backend(); // the broker runs the no-GPU test backend
 void r_wake_hint();
+void r_kick();
 
 inline hipError_t malloc_(void** p, const size_t bytes) { return g_remote ? r_malloc(p, bytes) : hipMalloc(p, bytes); }
 template <typename T> inline hipError_t malloc_(T** p, const size_t bytes) { return malloc_(reinterpret_cast<void**>(p), bytes); }
@@ -92,6 +93,13 @@ inline hipError_t funcSetAttribute(const void* fn, const hipFuncAttribute attr, 
 inline void wakeHint()
 {
     if (g_remote) r_wake_hint();
+}
+/// "run what has been submitted": an entry point that returns to its caller with work in flight (sk_pileup_stream_push_begin) says so --
+/// a broker client's server thread is otherwise woken when the client waits (sk_rt.hip, ring_commit); a process with a context of its own
+/// has rung the device's doorbell with every launch already
+inline void kick()
+{
+    if (g_remote) r_kick();
 }
 inline const char* errorString(const hipError_t e) { return (g_remote && r_error_text(e)[0]) ? r_error_text(e) : hipGetErrorString(e); }
 

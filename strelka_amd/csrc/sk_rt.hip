@@ -891,6 +891,14 @@ void r_wake_hint()
 {
     if (g_cl.eager_wake && g_cl.ctl && !g_cl.dead) wake_server(g_cl.ctl);
 }
+// Work was submitted and the caller goes on with host work of its own: the server thread starts on the records now.  ($STRELKA_AMD_BROKER_
+// LAZY_KICK=1: not before the client waits -- on a box whose cores are all taken by callers the server thread otherwise runs beside its
+// client instead of in its place.)
+void r_kick()
+{
+    static const bool lazy = env_us("STRELKA_AMD_BROKER_LAZY_KICK", 0) != 0;
+    if (!lazy && g_cl.ctl && !g_cl.dead) wake_server(g_cl.ctl);
+}
 void r_disconnect() { cl_close(); }
 
 namespace

@@ -73,8 +73,17 @@ def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
     c = _germline("dbl", tmp_path, windows)
     if windows == (1000, 3000):
         assert c["realign_jobs"] <= 10 and c["pileup_pushes"] <= 12
+    if windows is None:  # (the site window that hides a pileup window's device time behind the stage machine: the push in two halves)
+        assert c["read_window"] == 8192 and c["site_window"] == 512
+
+
+@pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("windows", [None, (0, 0), (300, 7), (8192, 2000)])
+def test_germline_demo_identical_with_pushes_finished_at_once(tmp_path, windows):
+    """STRELKA_AMD_PUSH_ASYNC=0: every pileup window begun and finished in one call (no site window by default)"""
+    c = _germline("dbl", tmp_path, windows, extra_env={"STRELKA_AMD_PUSH_ASYNC": "0"})
     if windows is None:
-        assert c["read_window"] == 8192 and c["site_window"] == 0
+        assert c["site_window"] == 0
 
 
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
@@ -173,9 +182,11 @@ def test_somatic_demo_identical_through_adapter_cpu_double(tmp_path, windows, ca
 
 
 @pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
-@pytest.mark.parametrize("env", [{"STRELKA_AMD_PILEUP": "0"}, {"STRELKA_AMD_PILEUP_GENOTYPE": "0"}, {"STRELKA_AMD_LAZY_CLEAN": "0"}])
+@pytest.mark.parametrize("env", [{"STRELKA_AMD_PILEUP": "0"}, {"STRELKA_AMD_PILEUP_GENOTYPE": "0"}, {"STRELKA_AMD_LAZY_CLEAN": "0"},
+                                 {"STRELKA_AMD_PUSH_ASYNC": "0"}, {"STRELKA_AMD_PUSH_ASYNC": "0", "STRELKA_AMD_SITE_WINDOW": "900"}])
 def test_somatic_demo_identical_with_reference_pileup_or_columns_only(tmp_path, env):
-    """STRELKA_AMD_PILEUP=0: the reference's pileup_read_segment, site 5 per site window from the host's copy of the columns;
+    """STRELKA_AMD_PUSH_ASYNC=0: the stream's pushes begun and finished in one call;
+    STRELKA_AMD_PILEUP=0: the reference's pileup_read_segment, site 5 per site window from the host's copy of the columns;
     STRELKA_AMD_PILEUP_GENOTYPE=0: the stream builds the columns (and the EVS read positions), site 5 as before;
     STRELKA_AMD_LAZY_CLEAN=0: process_pos_snp_somatic builds its four cleaned pileups for every position, as the reference does"""
     _somatic("dbl", tmp_path, callable_regions=True, extra_env=env)

@@ -39,6 +39,9 @@ def _read_end(r):
 GVCF_OPT = capi.gvcf_block_options(is_max_depth=1, max_chrom_depth=30.0, min_homref_gqx=15.0)
 
 
+HALVES = {"on": False}  # the pushes as sk_pileup_stream_push_begin + _finish (set by the *_in_two_halves tests)
+
+
 def _run_stream(library, reads, ref, off, kw, cuts, mask=None, genotype=True, ploidy=None, region=None, evs_words=False):
     """push reads[cuts[i]:cuts[i+1]] one after the other; final_to = the lowest start of any later read"""
     opt = capi.pileup_options(**kw)
@@ -50,8 +53,18 @@ def _run_stream(library, reads, ref, off, kw, cuts, mask=None, genotype=True, pl
     for i in range(len(cuts) - 1):
         later = [r["pos"] for r in reads[cuts[i + 1]:] if r["path"]]
         final_to = min(later) if later else 2**31 - 1
-        wins.append(st.push(_sub_batch(reads, cuts[i], cuts[i + 1]), final_to, mask=mask, mask_begin=off,
-                            ploidy=ploidy, ploidy_begin=rb))
+        sub = _sub_batch(reads, cuts[i], cuts[i + 1])
+        between = None
+        if HALVES["on"]:
+            def between(sub=sub):
+                # with the window in flight: the caller's arrays are its own again, and the stream takes no other call
+                sub.read_code[:] = 0
+                sub.read_qual[:] = 0
+                with pytest.raises(RuntimeError, match="has not been finished"):
+                    st.begin_region(ref, off, rb, re)
+                with pytest.raises(RuntimeError, match="has not been finished"):
+                    st.push(sub, final_to)
+        wins.append(st.push(sub, final_to, mask=mask, mask_begin=off, ploidy=ploidy, ploidy_begin=rb, halves=HALVES["on"], between=between))
     st.close()
     return wins
 
@@ -167,6 +180,16 @@ def test_double_stream_with_evs_words(built):
     _run_all(_double(), evs_words=True)
 
 
+def test_double_stream_in_two_halves(built):
+    """sk_pileup_stream_push_begin + _finish: the same windows; between the two the reads' arrays are the caller's again and the stream
+    refuses other calls"""
+    HALVES["on"] = True
+    try:
+        _run_all(_double(), evs_words=True)
+    finally:
+        HALVES["on"] = False
+
+
 def test_double_stream_rejects_a_read_behind_the_final_position(built):
     L = _double()
     ref = "ACGTTGCA" * 40
@@ -188,6 +211,15 @@ def test_gpu_stream_equals_one_shot_restatement(gpu):
 @pytest.mark.gpu
 def test_gpu_stream_with_evs_words(gpu):
     _run_all(None, evs_words=True)
+
+
+@pytest.mark.gpu
+def test_gpu_stream_in_two_halves(gpu):
+    HALVES["on"] = True
+    try:
+        _run_all(None, evs_words=True)
+    finally:
+        HALVES["on"] = False
 
 
 @pytest.mark.gpu
