@@ -39,6 +39,10 @@ for step in "$@"; do
     ktrace)
       timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace -o kt -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 --realign-processes 0 > $OUT/ktrace.log 2>&1
       find $OUT/ktrace -name "*kernel_stats.csv" | head -2 ;;
+    ktrace_a5)  # the headline leg alone: every flatten_score_kernel launch of this trace is the full-size one (the whole bench also
+                # launches it from the realignment legs, at their jobs' sizes -- its average there is over all of them)
+      timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace_a5 -o kt -- python bench.py --only a5 --steps 20 --warmup 3 > $OUT/ktrace_a5.log 2>&1
+      find $OUT/ktrace_a5 -name "*kernel_stats.csv" | head -1 | xargs grep -i flatten_score | cut -c1-200 ;;
     pmc_traffic)
       for c in FETCH_SIZE WRITE_SIZE; do
         timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-bp 0 --e2e-somatic-bp 0 --realign-processes 0 > $OUT/pmc_$c.log 2>&1
