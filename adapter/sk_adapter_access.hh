@@ -216,7 +216,7 @@ struct State
     std::vector<std::vector<WindowSegment>> windowSegments; ///< per sample: the read segments buffered in [window begin, realignedTo)
     // counters reported at exit with $STRELKA_AMD_VERBOSE=1
     // wall seconds inside the hooks (whole hook) and inside the C-ABI calls they make; reported with STRELKA_AMD_VERBOSE=1
-    double tRealignHook = 0, tRealignAbi = 0, tSiteHook = 0, tSiteAbi = 0, tPileupHook = 0, tPileupAbi = 0, tInit = 0, tIndelAbi = 0, tHaplotypeAbi = 0;
+    double tRealignHook = 0, tRealignAbi = 0, tSiteHook = 0, tSiteAbi = 0, tPileupHook = 0, tPileupAbi = 0, tPileupGather = 0, tPileupAssign = 0, tPileupChunk = 0, tInit = 0, tIndelAbi = 0, tHaplotypeAbi = 0;
     unsigned long pileupBatches = 0, pileupReads = 0, pileupLoci = 0;
     unsigned long indelGroupsWide = 0; ///< allele groups with more alternate alleles than SK_MAX_ALT (sk_allele_group_genotype_lhoods_wide)
     unsigned long realignJobReads = 0; ///< reads that went into a realignment job (realignReads counts every read a window looked at)

@@ -213,7 +213,8 @@ State& make_state()
                       << " evs_words_left=" << s.pileup.evsWordsLeft << "\n";
             std::cerr << "strelka_amd adapter seconds: realign_hook=" << s.tRealignHook << " realign_abi=" << s.tRealignAbi
                       << " site_hook=" << s.tSiteHook << " site_abi=" << s.tSiteAbi << " pileup_hook=" << s.tPileupHook
-                      << " pileup_abi=" << s.tPileupAbi << " init=" << s.tInit << " indel_abi=" << s.tIndelAbi
+                      << " pileup_abi=" << s.tPileupAbi << " pileup_gather=" << s.tPileupGather << " pileup_assign=" << s.tPileupAssign
+                      << " pileup_chunk=" << s.tPileupChunk << " init=" << s.tInit << " indel_abi=" << s.tIndelAbi
                       << " haplotype_abi=" << s.tHaplotypeAbi << "\n";
         }
     };

@@ -290,7 +290,10 @@ void pileup_sample_window(starling_pos_processor_base& pp, const unsigned sample
     }
 
     static WindowBatch wb;
-    gatherWindow(pp, sampleIndex, begin, end, wb);
+    {
+        AccumTimer gatherTimer(s.tPileupGather);
+        gatherWindow(pp, sampleIndex, begin, end, wb);
+    }
 
     const pos_t span(static_cast<pos_t>(Access::largestTotalIndelRefSpanPerRead(pp)));
     const int32_t finalTo(isFinal ? INT32_MAX : static_cast<int32_t>(end - span));
@@ -391,10 +394,14 @@ void pileup_complete_push(starling_pos_processor_base& pp, const unsigned sample
         check(sk_pileup_stream_push_finish(stream, &w), "sk_pileup_stream_push_finish");
     }
 
-    assignWindow(sif, w);
+    {
+        AccumTimer assignTimer(s.tPileupAssign);
+        assignWindow(sif, w);
+    }
     const size_t n(static_cast<size_t>(w.end - w.begin));
     s.pileupLoci += n;
 
+    AccumTimer chunkTimer(s.tPileupChunk);
     if ((ps.isGenotyping || ps.isGermlineMetrics) && n > 0)
     {
         SiteChunk chunk;
