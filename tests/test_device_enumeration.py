@@ -106,6 +106,23 @@ def test_device_enumeration_reproduces_the_reference_golden(gold, monkeypatch, c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("grid,waves", [("1", "1"), ("3", "16"), ("7", "4"), ("100000", "2")])
+def test_flatten_score_read_queue_under_any_grid(grid, waves):
+    """F5's waves take their reads from a queue (one counter; the last wave out puts it back to zero): the same records from a grid of ONE
+    wave (every read in turn), from grids that do not divide the job, and from one with far more blocks than reads -- $SK_F5_GRID /
+    $SK_F5_WAVES are read once per process, so each shape runs the golden and the long-read tests in a process of its own"""
+    import subprocess
+    import sys
+    env = dict(os.environ, SK_F5_GRID=grid, SK_F5_WAVES=waves)
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_device_enumeration.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "reproduces_the_reference_golden and fused or long_reads_and_mixed_jobs", "-p", "no:cacheprovider"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = p.stdout.decode(errors="replace")[-1500:]
+    assert p.returncode == 0 and " passed" in tail, tail
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("one_wait", ["1", "0"])
 @pytest.mark.parametrize("caps", ["4,12", "16,64"])
 def test_device_stage3_launch_shapes(gold, monkeypatch, caps, one_wait):
