@@ -219,6 +219,7 @@ struct State
     double tRealignHook = 0, tRealignAbi = 0, tSiteHook = 0, tSiteAbi = 0, tPileupHook = 0, tPileupAbi = 0, tPileupGather = 0, tPileupAssign = 0, tPileupChunk = 0, tInit = 0, tIndelAbi = 0, tHaplotypeAbi = 0;
     unsigned long pileupBatches = 0, pileupReads = 0, pileupLoci = 0;
     unsigned long indelGroupsWide = 0; ///< allele groups with more alternate alleles than SK_MAX_ALT (sk_allele_group_genotype_lhoods_wide)
+    unsigned long indelGroupsXWide = 0; ///< ... of those, with more than SK_MAX_ALT_WIDE (sk_allele_group_genotype_lhoods_xwide: runs of five to eight samples)
     unsigned long realignJobReads = 0; ///< reads that went into a realignment job (realignReads counts every read a window looked at)
     unsigned long realignDeviceEnumerated = 0, realignHostEnumerated = 0; // reads whose candidate alignments the device / the host listed
     unsigned long realignRefWindowMisses = 0; // jobs run a second time with the whole contig segment as their reference

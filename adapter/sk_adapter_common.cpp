@@ -198,7 +198,7 @@ State& make_state()
             if (env_unsigned("STRELKA_AMD_VERBOSE", 0) == 0) return;
             std::cerr << "strelka_amd adapter: realign_jobs=" << s.realignBatches << " realign_reads=" << s.realignReads << " realign_job_reads=" << s.realignJobReads
                       << " site_batches=" << s.siteBatches << " site_loci=" << s.siteLoci << " site_recomputed=" << s.siteRecomputed << " site_recompute_calls=" << s.siteRecomputeCalls
-                      << " indel_groups=" << s.indelGroups << " indel_groups_wide=" << s.indelGroupsWide << " haplotypes=" << s.haplotypes << " haplotype_batches=" << s.haplotypeBatches << " read_window=" << read_buffer_defer()
+                      << " indel_groups=" << s.indelGroups << " indel_groups_wide=" << s.indelGroupsWide << " indel_groups_xwide=" << s.indelGroupsXWide << " haplotypes=" << s.haplotypes << " haplotype_batches=" << s.haplotypeBatches << " read_window=" << read_buffer_defer()
                       << " site_window=" << post_align_defer() << " enum_device_reads=" << s.realignDeviceEnumerated
                       << " enum_host_instead=" << s.realignHostEnumerated;
             {
@@ -314,14 +314,14 @@ void on_reset_region(starling_pos_processor_base& pp)
     init();
     // Said before the first read, not by a throw in the middle of a genome: a realignment job and the pileup streams hold per-sample
     // fields for SK_MAX_SAMPLES samples, and an allele group of a multi-sample run can hold ploidy x samples alternate alleles
-    // (selectTopOrthogonalAllelesInAllSamples, OrthogonalVariantAlleleCandidateGroupUtil.cpp:285-340) -- the wide record takes
-    // SK_MAX_ALT_WIDE = 2 x SK_MAX_SAMPLES, so with this bound no group can outgrow it.
-    static_assert(SK_MAX_ALT_WIDE >= 2 * SK_MAX_SAMPLES, "the wide allele-group record holds ploidy x samples alternate alleles");
+    // (selectTopOrthogonalAllelesInAllSamples, OrthogonalVariantAlleleCandidateGroupUtil.cpp:285-340) -- the widest record takes
+    // SK_MAX_ALT_XWIDE = 2 x SK_MAX_SAMPLES, so with this bound no group can outgrow it.
+    static_assert(SK_MAX_ALT_XWIDE >= 2 * SK_MAX_SAMPLES, "the widest allele-group record holds ploidy x samples alternate alleles");
     if (Access::sampleCount(pp) > SK_MAX_SAMPLES)
     {
         std::ostringstream oss;
         oss << "strelka_amd adapter: " << Access::sampleCount(pp) << " samples in one run; this path takes at most SK_MAX_SAMPLES = "
-            << SK_MAX_SAMPLES << " (per-sample fields of a realignment job, allele groups of up to " << SK_MAX_ALT_WIDE
+            << SK_MAX_SAMPLES << " (per-sample fields of a realignment job, allele groups of up to " << SK_MAX_ALT_XWIDE
             << " alternate alleles)";
         throw blt_exception(oss.str().c_str());
     }

@@ -55,12 +55,15 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
     // L/starling_common/OrthogonalVariantAlleleCandidateGroupUtil.cpp:285-340: the union of every sample's top alleles).  Groups of up to
     // SK_MAX_ALT alleles go through the narrow record, wider ones (several distinct overlapping indels that differ between the
     // samples) through sk_allele_group_genotype_lhoods_wide: the same kernel with rows of SK_MAX_ALT_WIDE.
-    if (nonRefAlleleCount > SK_MAX_ALT_WIDE)
+    // Runs of five to eight samples can go on to SK_MAX_ALT_XWIDE = 16 (sk_allele_group_genotype_lhoods_xwide: 153 genotypes, three to a
+    // lane); a group wider still -- nine or more samples whose top alleles at one locus are all distinct -- is the one refusal left here.
+    if (nonRefAlleleCount > SK_MAX_ALT_XWIDE)
     {
-        throw blt_exception("strelka_amd adapter: allele group with more than SK_MAX_ALT_WIDE (8 = ploidy x 4 samples) alternate alleles");
+        throw blt_exception("strelka_amd adapter: allele group with more than SK_MAX_ALT_XWIDE (16 = ploidy x 8 samples) alternate alleles");
     }
     const bool isWide(nonRefAlleleCount > SK_MAX_ALT);
-    const size_t width(isWide ? SK_MAX_ALT_WIDE : SK_MAX_ALT);
+    const bool isXWide(nonRefAlleleCount > SK_MAX_ALT_WIDE);
+    const size_t width(isXWide ? SK_MAX_ALT_XWIDE : (isWide ? SK_MAX_ALT_WIDE : SK_MAX_ALT));
     init();
 
     locusReadStats.setAltCount(nonRefAlleleCount);
@@ -119,7 +122,7 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
 
     const int64_t readOff[2] = {0, static_cast<int64_t>(readCount)};
     const uint8_t nAlt(nonRefAlleleCount), ploidy(static_cast<uint8_t>(callerPloidy));
-    uint32_t delLen[SK_MAX_ALT_WIDE] = {0}, insLen[SK_MAX_ALT_WIDE] = {0};
+    uint32_t delLen[SK_MAX_ALT_XWIDE] = {0}, insLen[SK_MAX_ALT_XWIDE] = {0};
     for (unsigned a(0); a < nonRefAlleleCount; ++a)
     {
         const IndelKey& k(alleleGroup.key(a));
@@ -150,16 +153,18 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
     io.tier2_random_base_match_prob = opt.tier2.randomBaseMatchProb;
     io.read_confident_support_threshold = opt.readConfidentSupportThreshold.numval();
 
-    // (the two records differ in their array sizes only: read through one view)
+    // (the three records differ in their array sizes only: read through one view)
     sk_allele_group_call narrow;
     sk_allele_group_call_wide wide;
+    static sk_allele_group_call_xwide xwide; // (1.4 KB: not on the stack of a function called per indel locus)
     {
         AccumTimer abiTimer(state().tIndelAbi);
-        if (isWide) check(sk_allele_group_genotype_lhoods_wide(&b, &io, &wide), "sk_allele_group_genotype_lhoods_wide");
+        if (isXWide) check(sk_allele_group_genotype_lhoods_xwide(&b, &io, &xwide), "sk_allele_group_genotype_lhoods_xwide");
+        else if (isWide) check(sk_allele_group_genotype_lhoods_wide(&b, &io, &wide), "sk_allele_group_genotype_lhoods_wide");
         else check(sk_allele_group_genotype_lhoods(&b, &io, &narrow), "sk_allele_group_genotype_lhoods");
     }
-    const unsigned outGenotypes(isWide ? wide.n_genotypes : narrow.n_genotypes);
-    const double* const outLhood(isWide ? wide.lhood : narrow.lhood);
+    const unsigned outGenotypes(isXWide ? xwide.n_genotypes : (isWide ? wide.n_genotypes : narrow.n_genotypes));
+    const double* const outLhood(isXWide ? xwide.lhood : (isWide ? wide.lhood : narrow.lhood));
     if (outGenotypes != genotypeCount)
     {
         throw blt_exception("strelka_amd adapter: genotype count mismatch in sk_allele_group_genotype_lhoods");
@@ -168,10 +173,11 @@ getVariantAlleleGroupGenotypeLhoodsForSample(
     for (unsigned s(0); s < 2; ++s)
     {
         auto& counts(locusReadStats.getCounts(s == 0));
-        const uint32_t* const outCounts(isWide ? wide.counts[s] : narrow.counts[s]);
+        const uint32_t* const outCounts(isXWide ? xwide.counts[s] : (isWide ? wide.counts[s] : narrow.counts[s]));
         for (unsigned a(0); a < fullAlleleCount; ++a) counts.incrementAlleleCount(a, outCounts[a]);
         counts.nonConfidentCount += outCounts[fullAlleleCount];
     }
     if (isWide) state().indelGroupsWide++;
+    if (isXWide) state().indelGroupsXWide++;
     state().indelGroups++;
 }

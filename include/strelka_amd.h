@@ -260,7 +260,7 @@ const char* sk_align_builder_error(const sk_align_builder* b);
  * DNA reads only: spliced (RNA) read segments with pinned exon edges are not handled (north_star: germline/somatic DNA).
  * ---------------------------------------------------------------------------------------------------------------- */
 
-enum { SK_MAX_SAMPLES = 4 };
+enum { SK_MAX_SAMPLES = 8 }; /* (round 6: was 4; allele groups of such runs: sk_allele_group_genotype_lhoods_xwide) */
 /** MAPLEVEL::index_t (L/blt_common/map_level.hh:32-39) */
 enum { SK_MAPLEVEL_UNKNOWN = 0, SK_MAPLEVEL_TIER1 = 1, SK_MAPLEVEL_TIER2 = 2, SK_MAPLEVEL_SUB = 3, SK_MAPLEVEL_UNMAPPED = 4 };
 
@@ -1021,6 +1021,21 @@ int sk_allele_group_genotype_lhoods_wide(const sk_allele_group_batch* host_batch
                                          sk_allele_group_call_wide* out);
 int sk_allele_group_genotype_lhoods_wide_dev(const sk_allele_group_batch* dev_batch, const sk_indel_options* opt,
                                              sk_allele_group_call_wide* dev_out, void* hip_stream);
+
+/** ... and for runs of up to eight samples: rows SK_MAX_ALT_XWIDE wide, up to 16 alternate alleles (17 alleles, 153 diploid genotypes).
+ *  The same arithmetic and the same kernel once more; a lane of the wave sums three genotypes.  Wider groups (more than eight samples whose
+ *  top alleles at one locus are all distinct) are the adapter's one remaining refusal on this site. */
+enum { SK_MAX_ALT_XWIDE = 16, SK_MAX_INDEL_GT_XWIDE = 153 };
+typedef struct sk_allele_group_call_xwide {
+    double lhood[SK_MAX_INDEL_GT_XWIDE];
+    uint32_t counts[2][SK_MAX_ALT_XWIDE + 2];
+    uint32_t n_genotypes;
+    uint32_t n_reads_used;
+} sk_allele_group_call_xwide;
+int sk_allele_group_genotype_lhoods_xwide(const sk_allele_group_batch* host_batch, const sk_indel_options* opt,
+                                          sk_allele_group_call_xwide* out);
+int sk_allele_group_genotype_lhoods_xwide_dev(const sk_allele_group_batch* dev_batch, const sk_indel_options* opt,
+                                              sk_allele_group_call_xwide* dev_out, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * SURVEY.md section 8f rank 4, the feed: BGZF inflation and BAM record decoding.

@@ -231,6 +231,11 @@ int sk_allele_group_genotype_lhoods_wide(const sk_allele_group_batch* b, const s
     return allele_groups_t<SK_MAX_ALT_WIDE, sk_allele_group_call_wide>(b, opt, out);
 }
 
+int sk_allele_group_genotype_lhoods_xwide(const sk_allele_group_batch* b, const sk_indel_options* opt, sk_allele_group_call_xwide* out)
+{
+    return allele_groups_t<SK_MAX_ALT_XWIDE, sk_allele_group_call_xwide>(b, opt, out);
+}
+
 int sk_somatic_snv_call_tiers(const sk_pileup_batch* n1, const sk_pileup_batch* t1, const sk_pileup_batch* n2,
                               const sk_pileup_batch* t2, const sk_somatic_snv_options* opt, const uint8_t* is_forced_output,
                               int is_compute_nonsomatic, sk_somatic_snv_genotype* out)

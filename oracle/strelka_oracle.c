@@ -1227,8 +1227,8 @@ void sko_allele_group_genotype_lhoods(int32_t n_reads, int32_t n_alt, const floa
     for (int g = 0; g < gcount; ++g) out_lhood[g] = 0.;
     memset(out_counts, 0, sizeof(uint32_t) * 2 * (size_t)(n_alt + 2));
     if (n_alt <= 0) return;
-    double L[10], Lm[10];
-    assert(full <= 10);
+    double L[18], Lm[18]; /* (up to SK_MAX_ALT_XWIDE = 16 alternate alleles + the reference) */
+    assert(full <= 18);
     for (int r = 0; r < n_reads; ++r) {
         /* getAlleleGroupIntersectionReadIds (OrthogonalVariantAlleleCandidateGroupUtil.cpp:64-113), tier1 only:
          * the read must be scored for every allele of the group */

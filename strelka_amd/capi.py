@@ -46,7 +46,7 @@ class CandidateAlignment(C.Structure):
                 ("indels", C.POINTER(IndelKey)), ("leading", IndelKey), ("trailing", IndelKey)]
 
 
-MAX_SAMPLES = 4
+MAX_SAMPLES = 8
 SEG = dict(NONE=0, MATCH=1, INSERT=2, DELETE=3, SKIP=4, SOFT_CLIP=5, HARD_CLIP=6, PAD=7, SEQ_MATCH=8, SEQ_MISMATCH=9)
 CIGAR_CHARS = "?MIDNSHP=X"
 INDEL = dict(NONE=0, INDEL=1, MISMATCH=2, BP_LEFT=3, BP_RIGHT=4)
@@ -207,6 +207,11 @@ MAX_ALT_WIDE, MAX_INDEL_GT_WIDE = 8, 45
 ALLELE_GROUP_CALL_WIDE_DTYPE = np.dtype([("lhood", "<f8", (MAX_INDEL_GT_WIDE,)), ("counts", "<u4", (2, MAX_ALT_WIDE + 2)),
                                          ("n_genotypes", "<u4"), ("n_reads_used", "<u4")])
 assert ALLELE_GROUP_CALL_WIDE_DTYPE.itemsize == 448
+# ... of runs of up to eight samples: sk_allele_group_call_xwide
+MAX_ALT_XWIDE, MAX_INDEL_GT_XWIDE = 16, 153
+ALLELE_GROUP_CALL_XWIDE_DTYPE = np.dtype([("lhood", "<f8", (MAX_INDEL_GT_XWIDE,)), ("counts", "<u4", (2, MAX_ALT_XWIDE + 2)),
+                                          ("n_genotypes", "<u4"), ("n_reads_used", "<u4")])
+assert ALLELE_GROUP_CALL_XWIDE_DTYPE.itemsize == 1376
 
 DIGT_RS_DTYPE = np.dtype([("ref_pprob", "<f8"), ("max_gt", "<u4"), ("snp_qphred", "<i4"), ("max_gt_qphred", "<i4"),
                           ("_pad", "<i4")])
@@ -240,6 +245,7 @@ EXPORTS = [
     "sk_indel_options_default", "sk_somatic_indel_options_default", "sk_indel_grid_lhood", "sk_indel_grid_lhood_dev",
     "sk_somatic_indel_call_batch", "sk_somatic_indel_call_tiers", "sk_allele_group_genotype_lhoods", "sk_allele_group_genotype_lhoods_dev",
     "sk_allele_group_genotype_lhoods_wide", "sk_allele_group_genotype_lhoods_wide_dev",
+    "sk_allele_group_genotype_lhoods_xwide", "sk_allele_group_genotype_lhoods_xwide_dev",
     "sk_discover_indels_and_mismatches", "sk_global_align_scratch_bytes", "sk_global_align_dev", "sk_bai_query", "sk_bam_region_filter", "sk_gvcf_block_sites", "sk_gvcf_block_sites_dev",
 ]
 
@@ -774,8 +780,8 @@ def somatic_indel_call(normal, tumor, indel_to_ref_error_prob, normal_opt=None, 
 
 class HostAlleleGroupBatch:
     def __init__(self, read_off, n_alt, ploidy, del_len, ins_len, ref_lnp, allele_lnp, non_ambig, read_length, read_flags, width=MAX_ALT):
-        assert width in (MAX_ALT, MAX_ALT_WIDE)
-        self.width = width  # columns of the per-allele arrays: MAX_ALT, or MAX_ALT_WIDE for the wide entry points
+        assert width in (MAX_ALT, MAX_ALT_WIDE, MAX_ALT_XWIDE)
+        self.width = width  # columns of the per-allele arrays: MAX_ALT, or MAX_ALT_WIDE / MAX_ALT_XWIDE for the wide entry points
         self.read_off = np.ascontiguousarray(read_off, np.int64)
         self.n_alt = np.ascontiguousarray(n_alt, np.uint8)
         self.ploidy = np.ascontiguousarray(ploidy, np.uint8)
@@ -796,11 +802,15 @@ class HostAlleleGroupBatch:
 
 def allele_group_genotype_lhoods(batch, opt=None):
     opt = opt or indel_options(False)
-    wide = getattr(batch, "width", MAX_ALT) == MAX_ALT_WIDE
-    out = np.zeros(batch.n_groups, ALLELE_GROUP_CALL_WIDE_DTYPE if wide else ALLELE_GROUP_CALL_DTYPE)
+    width = getattr(batch, "width", MAX_ALT)
+    dtype, fn = {MAX_ALT: (ALLELE_GROUP_CALL_DTYPE, "sk_allele_group_genotype_lhoods"),
+                 MAX_ALT_WIDE: (ALLELE_GROUP_CALL_WIDE_DTYPE, "sk_allele_group_genotype_lhoods_wide"),
+                 MAX_ALT_XWIDE: (ALLELE_GROUP_CALL_XWIDE_DTYPE, "sk_allele_group_genotype_lhoods_xwide")}[width]
+    out = np.zeros(batch.n_groups, dtype)
     s = batch.struct()
-    fn = lib().sk_allele_group_genotype_lhoods_wide if wide else lib().sk_allele_group_genotype_lhoods
-    _check(fn(C.byref(s), C.byref(opt), _p(out)))
+    f = getattr(lib(), fn)
+    f.argtypes = [C.POINTER(AlleleGroupBatch), C.POINTER(IndelOptions), c_void_p]
+    _check(f(C.byref(s), C.byref(opt), _p(out)))
     return out
 
 
@@ -900,8 +910,8 @@ class RealignJob:
             hap = d.get("hap", 0)
             byp = d.get("bypass", 0)
             for s in range(MAX_SAMPLES):
-                a.haplotype_id[s] = hap[s] if isinstance(hap, (list, tuple)) else hap
-                a.is_haplotyping_bypassed[s] = byp[s] if isinstance(byp, (list, tuple)) else byp
+                a.haplotype_id[s] = (hap[s] if s < len(hap) else 0) if isinstance(hap, (list, tuple)) else hap
+                a.is_haplotyping_bypassed[s] = (byp[s] if s < len(byp) else 0) if isinstance(byp, (list, tuple)) else byp
             a.is_forced_output = int(d.get("forced", 0))
             a.not_discovered_from_reads = int(d.get("ndfr", 0))
         if lib().sk_realign_job_set_indels(self._j, arr, len(indels)):

@@ -326,10 +326,15 @@ struct GroupArgs
 // genotypes AND the supporting-read statistics (it was evaluated twice: a third of the kernel's transcendentals); the statistics are
 // counted by ballots over the chunk's lanes instead of a walk by lane 0 over the chunk (~1 000 instructions with one lane active, as
 // many as the parallel part); four waves per SIMD for the narrow record (111 VGPRs; five spill and are slower: 1.36 ms).
+// MAXA = 16 (SK_MAX_ALT_XWIDE: ploidy x 8 samples, 153 genotypes -- more than a wave has lanes): a lane holds the sums of genotypes
+// lane, lane + 64, lane + 128; the loops over alleles and genotypes are left rolled (run-time indices into the per-lane arrays: they live in
+// scratch memory -- a group this wide is a rarity of multi-sample runs, what matters is that it is computed here and not refused).
 template <int MAXA, typename CallT>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 ? 4 : 2, MAXA <= 3 ? 4 : 2))) void allele_group_kernel(const GroupArgs a)
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 ? 4 : (MAXA <= 8 ? 2 : 1), MAXA <= 3 ? 4 : (MAXA <= 8 ? 2 : 1)))) void allele_group_kernel(const GroupArgs a)
 {
     constexpr int MAXGT = (MAXA + 1) * (MAXA + 2) / 2;
+    constexpr int NACC = (MAXGT + WAVE - 1) / WAVE; // genotypes a lane sums
+    constexpr int UNROLL_A = (MAXA <= 8) ? MAXA + 2 : 1; // (the narrow and the wide record: fully unrolled, as before)
     __shared__ double s_term[MAXGT][WAVE];
     const int grp = blockIdx.x;
     const int lane = threadIdx.x;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 
     const int ex = a.exact_libm;
     const SkLibmTables lt = sk_libm_tables_default();
     unsigned del_len[MAXA], ins_len[MAXA];
-#pragma unroll
+#pragma unroll UNROLL_A
     for (int k = 0; k < MAXA; ++k) {
         del_len[k] = a.b.del_len[size_t(grp) * MAXA + k];
         ins_len[k] = a.b.ins_len[size_t(grp) * MAXA + k];
@@ -367,14 +372,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 
             hi = max(hi, unsigned(__shfl_xor(int(hi), d)));
         }
         one_length = (n > 0 && lo == hi && ploidy != 1);
-        if (one_length && lane < gcount) {
+        for (int gl = lane; one_length && gl < gcount; gl += WAVE) {
             int a1 = 0;
-            while ((a1 + 1) * (a1 + 2) / 2 <= lane) ++a1;
-            const int a0 = lane - a1 * (a1 + 1) / 2;
+            while ((a1 + 1) * (a1 + 2) / 2 <= gl) ++a1;
+            const int a0 = gl - a1 * (a1 + 1) / 2;
             double lp0 = a.loghalf, lp1 = a.loghalf;
             if (a0 != a1) {
                 unsigned d1 = 0, i1 = 0, d0 = 0, i0 = 0; // (run-time allele indices: selected, not indexed, so that the arrays stay in registers)
-#pragma unroll
+#pragma unroll UNROLL_A
                 for (int k = 0; k < MAXA; ++k) {
                     if (k == a1 - 1) { d1 = del_len[k]; i1 = ins_len[k]; }
                     if (k == a0 - 1) { d0 = del_len[k]; i0 = ins_len[k]; }
@@ -389,15 +394,17 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 
                     lp1 = __dsub_rn(lp1, norm);
                 }
             }
-            s_lp0[lane] = lp0;
-            s_lp1[lane] = lp1;
+            s_lp0[gl] = lp0;
+            s_lp1[gl] = lp1;
         }
         __syncthreads();
     }
 
-    double acc = 0.;
-    unsigned cnt_f[MAXA + 2], cnt_r[MAXA + 2]; // (wave-uniform: counted by ballots over the chunk's lanes)
+    double acc[NACC];
 #pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = 0.;
+    unsigned cnt_f[MAXA + 2], cnt_r[MAXA + 2]; // (wave-uniform: counted by ballots over the chunk's lanes)
+#pragma unroll UNROLL_A
     for (int k = 0; k < MAXA + 2; ++k) cnt_f[k] = cnt_r[k] = 0;
     unsigned used = 0;
 
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 
             bool use = (flags & SK_READ_TIER1) != 0;
             double L[MAXA + 1];
             L[0] = 0.;
-#pragma unroll
+#pragma unroll UNROLL_A
             for (int k = 0; k < MAXA; ++k) {
                 L[k + 1] = 0.;
                 if (k < n_alt) {
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 
                 }
             }
             if (!use) {
-#pragma unroll
+#pragma unroll (MAXA <= 8 ? MAXGT : 1)
                 for (int gi = 0; gi < MAXGT; ++gi) s_term[gi][lane] = 0.;
             } else {
                 const unsigned na = a.b.non_ambig[g];
@@ -433,17 +440,17 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 
                 // integrateOutMappingStatus of every allele's own likelihood: the hom genotypes' terms (AlleleGroupGenotype.cpp:97-104) AND
                 // what updateSupportingReadStats starts from (:125-131) -- the same function of the same arguments, evaluated once
                 double H[MAXA + 1];
-#pragma unroll
+#pragma unroll UNROLL_A
                 for (int k = 0; k <= MAXA; ++k) H[k] = (k < full) ? integrate_out_mapping(a.map, na, L[k], ex, lt) : 0.;
                 // updateGenotypeLogLhoodFromAlleleLogLhood, AlleleGroupGenotype.cpp:36-114
                 if (ploidy == 1) {
-#pragma unroll
+#pragma unroll UNROLL_A
                     for (int a0 = 0; a0 <= MAXA; ++a0)
                         if (a0 < full) s_term[a0][lane] = H[a0];
                 } else {
-#pragma unroll
+#pragma unroll UNROLL_A
                     for (int a1 = 0; a1 <= MAXA; ++a1) {
-#pragma unroll
+#pragma unroll UNROLL_A
                         for (int a0 = 0; a0 <= a1; ++a0) {
                             if (a1 >= full) continue;
                             const int gi = a0 + (a1 * (a1 + 1) / 2);
@@ -473,45 +480,53 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(MAXA <= 3 
                 // updateSupportingReadStats, :125-155 (normalizeLogDistro: first maximum, exp, 1/sum)
                 double Lm[MAXA + 1];
                 double mx = 0.;
-#pragma unroll
+#pragma unroll UNROLL_A
                 for (int k = 0; k <= MAXA; ++k) {
                     Lm[k] = H[k];
                     if (k < full) mx = (k == 0) ? Lm[0] : ((Lm[k] > mx) ? Lm[k] : mx);
                 }
                 double sum = 0.;
-#pragma unroll
+#pragma unroll UNROLL_A
                 for (int k = 0; k <= MAXA; ++k)
                     if (k < full) {
                         Lm[k] = sk_exp(__dsub_rn(Lm[k], mx), ex, lt);
                         sum = __dadd_rn(sum, Lm[k]);
                     }
                 sum = __ddiv_rn(1., sum);
-                unsigned which = 15;
-#pragma unroll
+                unsigned which = 0xfeu;
+#pragma unroll UNROLL_A
                 for (int k = MAXA; k >= 0; --k)
                     if (k < full && !(__dmul_rn(Lm[k], sum) < a.support_threshold)) which = unsigned(k); // first such allele
-                slot = (which == 15u) ? unsigned(n_alt + 1) : which;
+                slot = (which == 0xfeu) ? unsigned(n_alt + 1) : which;
                 fwd = (flags & SK_READ_FWD) != 0;
             }
         }
         // LocusSupportingReadStats: the chunk's reads counted per (allele, strand) by ballots -- every lane of the wave, no serial walk
         // (counts do not depend on the order of the reads)
         used += unsigned(__popcll(__ballot(slot != 0xffu)));
-#pragma unroll
+#pragma unroll UNROLL_A
         for (unsigned k = 0; k < MAXA + 2; ++k) {
             const unsigned long long all = __ballot(slot == k), f = __ballot(slot == k && fwd);
             cnt_f[k] += unsigned(__popcll(f));
             cnt_r[k] += unsigned(__popcll(all)) - unsigned(__popcll(f));
         }
         __syncthreads();
-        if (lane < gcount)
-            for (int j = 0; j < cnt; ++j) acc = __dadd_rn(acc, s_term[lane][j]);
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) {
+            const int gl = lane + t * WAVE;
+            if (gl < gcount)
+                for (int j = 0; j < cnt; ++j) acc[t] = __dadd_rn(acc[t], s_term[gl][j]);
+        }
         __syncthreads();
     }
     CallT* o = static_cast<CallT*>(a.out) + grp;
-    if (lane < MAXGT) o->lhood[lane] = (lane < gcount) ? acc : 0.;
-    if (lane == 0) {
 #pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+        const int gl = lane + t * WAVE;
+        if (gl < MAXGT) o->lhood[gl] = (gl < gcount) ? acc[t] : 0.;
+    }
+    if (lane == 0) {
+#pragma unroll UNROLL_A
         for (int k = 0; k < MAXA + 2; ++k) {
             o->counts[0][k] = cnt_f[k];
             o->counts[1][k] = cnt_r[k];
@@ -782,7 +797,7 @@ static int allele_group_host_t(const sk_allele_group_batch* hb, const sk_indel_o
     if (n <= 0) return 0;
     if (hb->read_off[0] != 0) return sk_fail("allele group batch: read_off must start at 0");
     for (int g = 0; g < n; ++g) {
-        if (hb->n_alt[g] < 1 || hb->n_alt[g] > MAXA) return sk_fail("allele group batch: n_alt outside 1..SK_MAX_ALT (SK_MAX_ALT_WIDE for the wide entry)");
+        if (hb->n_alt[g] < 1 || hb->n_alt[g] > MAXA) return sk_fail("allele group batch: n_alt outside 1..SK_MAX_ALT (SK_MAX_ALT_WIDE / SK_MAX_ALT_XWIDE for the wide entries)");
         if (hb->ploidy[g] != 1 && hb->ploidy[g] != 2) return sk_fail("Unexpected ploidy value"); // AlleleGroupGenotype.cpp:112
     }
     const int64_t tr = hb->read_off[n];
@@ -1129,6 +1144,17 @@ int sk_allele_group_genotype_lhoods_wide_dev(const sk_allele_group_batch* b, con
                                              sk_allele_group_call_wide* dev_out, void* hip_stream)
 {
     return allele_group_dev_t<SK_MAX_ALT_WIDE, sk_allele_group_call_wide>(b, opt, dev_out, hip_stream);
+}
+
+int sk_allele_group_genotype_lhoods_xwide_dev(const sk_allele_group_batch* b, const sk_indel_options* opt,
+                                              sk_allele_group_call_xwide* dev_out, void* hip_stream)
+{
+    return allele_group_dev_t<SK_MAX_ALT_XWIDE, sk_allele_group_call_xwide>(b, opt, dev_out, hip_stream);
+}
+
+int sk_allele_group_genotype_lhoods_xwide(const sk_allele_group_batch* hb, const sk_indel_options* opt, sk_allele_group_call_xwide* out)
+{
+    return allele_group_host_t<SK_MAX_ALT_XWIDE, sk_allele_group_call_xwide>(hb, opt, out);
 }
 
 int sk_allele_group_genotype_lhoods(const sk_allele_group_batch* hb, const sk_indel_options* opt, sk_allele_group_call* out)

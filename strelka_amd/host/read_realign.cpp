@@ -387,8 +387,8 @@ struct Indel
     bool cand = false;
     double r2i = 0, i2r = 0;
     int32_t arid = -1;
-    int8_t hap[SK_MAX_SAMPLES] = { 0, 0, 0, 0 };
-    bool bypass[SK_MAX_SAMPLES] = { false, false, false, false };
+    int8_t hap[SK_MAX_SAMPLES] = {};
+    bool bypass[SK_MAX_SAMPLES] = {};
     bool forced = false, ndfr = false;
     int32_t orig = -1;
 };

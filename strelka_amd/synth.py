@@ -435,9 +435,10 @@ def readscore_batch(n_indels, rng, depth_mean=40.0, alt_rate=0.2, breakpoint_rat
 
 
 def allele_group_batch(n_groups, rng, depth_mean=40.0, missing_rate=0.05, min_alt=1, max_alt=None):
-    """max_alt > capi.MAX_ALT: a batch for the wide entry points (multi-sample allele groups, rows of capi.MAX_ALT_WIDE)"""
+    """max_alt > capi.MAX_ALT: a batch for the wide entry points (multi-sample allele groups, rows of capi.MAX_ALT_WIDE, or of
+    capi.MAX_ALT_XWIDE when max_alt > capi.MAX_ALT_WIDE)"""
     max_alt = max_alt or capi.MAX_ALT
-    width = capi.MAX_ALT if max_alt <= capi.MAX_ALT else capi.MAX_ALT_WIDE
+    width = capi.MAX_ALT if max_alt <= capi.MAX_ALT else (capi.MAX_ALT_WIDE if max_alt <= capi.MAX_ALT_WIDE else capi.MAX_ALT_XWIDE)
     depth = rng.poisson(depth_mean, n_groups).astype(np.int64)
     off = np.zeros(n_groups + 1, np.int64)
     np.cumsum(depth, out=off[1:])

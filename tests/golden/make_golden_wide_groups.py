@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Generate tests/golden/allele_group_wide_reference.npz: the REFERENCE's own getVariantAlleleGroupGenotypeLhoodsForSample
 (oracle/_ref/libstrelka_ref.so, ref_allele_group_genotype_lhoods) on seeded allele groups of 4..8 alternate alleles -- the groups a
-multi-sample run forms (selectTopOrthogonalAllelesInAllSamples).  Run in the build container: python tests/golden/make_golden_wide_groups.py"""
+multi-sample run forms (selectTopOrthogonalAllelesInAllSamples) -- and, with the argument `xwide`, allele_group_xwide_reference.npz: groups of
+9..16 (runs of five to eight samples).  Run in the build container: python tests/golden/make_golden_wide_groups.py [xwide]"""
 import ctypes as C
 import os
 import sys
@@ -51,14 +52,21 @@ def reference_lhoods(ab):
 
 def main():
     pyoracle.build(ref=True)
-    rng = np.random.default_rng(20260927)
-    ab = synth.allele_group_batch(90, rng, depth_mean=45.0, min_alt=4, max_alt=capi.MAX_ALT_WIDE, missing_rate=0.01)
+    # "xwide": groups of 9..16 alternate alleles (runs of five to eight samples), fewer and shallower (153 genotypes a group)
+    which = sys.argv[1] if len(sys.argv) > 1 else "wide"
+    if which == "xwide":
+        rng = np.random.default_rng(20261001)
+        ab = synth.allele_group_batch(40, rng, depth_mean=35.0, min_alt=9, max_alt=capi.MAX_ALT_XWIDE, missing_rate=0.01)
+    else:
+        rng = np.random.default_rng(20260927)
+        ab = synth.allele_group_batch(90, rng, depth_mean=45.0, min_alt=4, max_alt=capi.MAX_ALT_WIDE, missing_rate=0.01)
     glh, gcnt = reference_lhoods(ab)
-    np.savez_compressed(os.path.join(HERE, "allele_group_wide_reference.npz"), a_read_off=ab.read_off, a_n_alt=ab.n_alt, a_ploidy=ab.ploidy,
+    name = "allele_group_%s_reference.npz" % which
+    np.savez_compressed(os.path.join(HERE, name), a_read_off=ab.read_off, a_n_alt=ab.n_alt, a_ploidy=ab.ploidy,
                         a_del=ab.del_len, a_ins=ab.ins_len, a_ref=ab.ref_lnp, a_allele=ab.allele_lnp, a_na=ab.non_ambig, a_rl=ab.read_length,
                         a_flags=ab.read_flags, a_lhood=glh, a_counts=gcnt)
-    print("wrote allele_group_wide_reference.npz: %d groups, n_alt %d..%d, reads used in some group: %s" % (
-        ab.n_groups, ab.n_alt.min(), ab.n_alt.max(), bool(np.any(glh != 0))))
+    print("wrote %s: %d groups, n_alt %d..%d, reads used in some group: %s" % (
+        name, ab.n_groups, ab.n_alt.min(), ab.n_alt.max(), bool(np.any(glh != 0))))
 
 
 if __name__ == "__main__":

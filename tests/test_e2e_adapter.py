@@ -485,6 +485,47 @@ def test_multi_sample_wide_allele_groups_gpu(tmp_path):
     _multi_sample_wide_groups("amd", tmp_path)
 
 
+# ---- six samples (SK_MAX_SAMPLES = 8 since round 6): groups of more than eight alternate alleles go through
+# sk_allele_group_genotype_lhoods_xwide (153 genotypes); every sample's gVCF and the variants VCF byte for byte
+MULTI6 = os.path.join(SYNTH, "multi6")
+
+
+def _six_samples(variant, tmp_path):
+    if not os.path.exists(os.path.join(MULTI6, "multi_M6.bam")):  # (a tree whose synthetic sets were made before round 6)
+        import subprocess
+        import sys
+        subprocess.run([sys.executable, os.path.join(E.REPO, "tools", "make_multiallelic_bam.py"), MULTI6, os.path.join(E.BIN_DIR, "samtools"),
+                        "--samples", "6"], check=True, stdout=subprocess.DEVNULL)
+    outs = {}
+    bams = [os.path.join(MULTI6, "multi_M%d.bam" % k) for k in range(1, 7)]
+    files = ["variants.vcf"] + ["genome.S%d.vcf" % k for k in range(1, 7)]
+    for v in ("ref", variant):
+        o = str(tmp_path / v) + "/"
+        os.makedirs(o, exist_ok=True)
+        p = E.run(E.germline_argv("starling2_" + v, o, bams, region="chrS:1-24000", ref=os.path.join(MULTI6, "multi.fa")),
+                  env={"STRELKA_AMD_VERBOSE": "1"} if v != "ref" else None)
+        outs[v] = ({f: E.vcf_body(o + f, keep_header=True) for f in files}, p.stderr.decode())
+    records = [l for l in outs["ref"][0]["variants.vcf"] if not l.startswith("#")]
+    assert max(len(l.split("\t")[4].split(",")) for l in records) >= 10  # records with ten and more alternate alleles
+    for f in files:
+        assert outs[variant][0][f] == outs["ref"][0][f], f
+    c = _counters(outs[variant][1])
+    assert c["indel_groups_xwide"] >= 10 and c["indel_groups_wide"] > c["indel_groups_xwide"]
+
+
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and os.path.exists(os.path.join(E.BIN_DIR, "samtools"))),
+                    reason="oracle/_ref binaries not built")
+def test_six_samples_and_their_allele_groups_cpu_double(tmp_path):
+    _six_samples("dbl", tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_amd") and os.path.exists(os.path.join(MULTI6, "multi_M6.bam"))),
+                    reason="oracle/_ref binaries / synthetic sets not built")
+def test_six_samples_and_their_allele_groups_gpu(tmp_path):
+    _six_samples("amd", tmp_path)
+
+
 # ---- site 10 with several samples: a position that is a plain site of EVERY sample's window goes from the windows into each sample's
 # open block (the writer's own loop over the samples); the variants VCF and every sample's gVCF byte for byte
 def _two_sample_gvcf(variant, tmp_path):

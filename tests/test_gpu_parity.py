@@ -502,6 +502,36 @@ def test_allele_group_genotype_lhoods_wide(gpu):
     assert np.array_equal(got2["lhood"].view(np.uint64), lh2.view(np.uint64)) and np.array_equal(got2["counts"], counts2)
 
 
+def test_allele_group_genotype_lhoods_xwide(gpu):
+    """groups of up to 16 alternate alleles (runs of up to eight samples; 153 genotypes, three to a lane): sk_allele_group_genotype_lhoods_xwide
+    against the oracle on fresh groups of 1..16 and against the REFERENCE's own function on the committed fixture"""
+    import os
+    from strelka_amd import capi
+    rng = np.random.default_rng(305)
+    ab = synth.allele_group_batch(120, rng, depth_mean=40.0, min_alt=1, max_alt=capi.MAX_ALT_XWIDE, missing_rate=0.01)
+    assert ab.width == capi.MAX_ALT_XWIDE
+    got = gpu.allele_group_genotype_lhoods(ab)
+    lh, counts, ng = pyoracle.allele_group_genotype_lhoods(ab)
+    assert got["lhood"].shape[1] == 153 and np.array_equal(got["n_genotypes"], ng) and ng.max() == 153
+    assert np.array_equal(got["lhood"].view(np.uint64), lh.view(np.uint64))
+    assert np.array_equal(got["counts"], counts)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "allele_group_xwide_reference.npz"))
+    gb = capi.HostAlleleGroupBatch(g["a_read_off"], g["a_n_alt"], g["a_ploidy"], g["a_del"], g["a_ins"], g["a_ref"], g["a_allele"],
+                                   g["a_na"], g["a_rl"], g["a_flags"], width=capi.MAX_ALT_XWIDE)
+    got = gpu.allele_group_genotype_lhoods(gb)
+    assert np.array_equal(got["lhood"].view(np.uint64), g["a_lhood"].view(np.uint64))
+    assert np.array_equal(got["counts"], g["a_counts"])
+    # deep groups (more than one 64-read chunk), reads of several lengths and of one length (the priors once per group)
+    for one_length in (False, True):
+        ab2 = synth.allele_group_batch(5, rng, depth_mean=180.0, min_alt=10, max_alt=capi.MAX_ALT_XWIDE, missing_rate=0.0)
+        if one_length:
+            ab2.read_length[:] = 150
+            ab2.non_ambig[:] = np.minimum(ab2.non_ambig, 150)
+        got2 = gpu.allele_group_genotype_lhoods(ab2)
+        lh2, counts2, _ = pyoracle.allele_group_genotype_lhoods(ab2)
+        assert np.array_equal(got2["lhood"].view(np.uint64), lh2.view(np.uint64)) and np.array_equal(got2["counts"], counts2)
+
+
 def test_the_librarys_default_is_the_fast_form_and_the_helpers_ask_for_the_exact_one():
     """sk_indel_options_default sets fast_form = 1 (what the drop-in runs; $STRELKA_AMD_INDEL_EXACT=1 in the adapter
     for the other); the test helpers (capi.indel_options) ask for the exact form, because they compare doubles bit for bit"""

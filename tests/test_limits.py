@@ -14,7 +14,7 @@ from strelka_amd import capi, synth
 def test_more_samples_than_supported_is_refused():
     o = capi.RealignOptions()
     capi.lib().sk_realign_options_default(C.byref(o))
-    o.sample_count = 5
+    o.sample_count = 9  # (SK_MAX_SAMPLES = 8)
     capi.lib().sk_realign_job_create.restype = C.c_void_p
     assert not capi.lib().sk_realign_job_create(C.byref(o))
 
@@ -45,6 +45,12 @@ def test_more_alt_alleles_than_supported_is_refused():
     w.n_alt[:] = 9
     with pytest.raises(RuntimeError, match="n_alt"):
         capi.allele_group_genotype_lhoods(w)
+    # ... and the widest one ploidy x 8 samples = 16
+    x = synth.allele_group_batch(3, rng, max_alt=capi.MAX_ALT_XWIDE)
+    capi.allele_group_genotype_lhoods(x)
+    x.n_alt[:] = 17
+    with pytest.raises(RuntimeError, match="n_alt"):
+        capi.allele_group_genotype_lhoods(x)
 
 
 @pytest.mark.gpu

@@ -149,6 +149,24 @@ def test_wide_allele_groups_match_reference(built):
         assert np.array_equal(lh.view(np.uint64), want_lh.view(np.uint64)) and np.array_equal(counts, want_counts)
 
 
+def test_xwide_allele_groups_match_reference(built):
+    """... and of 9..16 alternate alleles (runs of five to eight samples, up to 153 genotypes): the restatement against the reference's own
+    function -- the committed fixture (tests/golden/make_golden_wide_groups.py xwide), and live on fresh groups where oracle/_ref is built"""
+    g = np.load(os.path.join(GOLD, "allele_group_xwide_reference.npz"))
+    ab = capi.HostAlleleGroupBatch(g["a_read_off"], g["a_n_alt"], g["a_ploidy"], g["a_del"], g["a_ins"], g["a_ref"], g["a_allele"],
+                                   g["a_na"], g["a_rl"], g["a_flags"], width=capi.MAX_ALT_XWIDE)
+    assert ab.n_alt.min() == 9 and ab.n_alt.max() == 16
+    lh, counts, ng = pyoracle.allele_group_genotype_lhoods(ab)
+    assert ng.max() == 153 and np.array_equal(lh.view(np.uint64), g["a_lhood"].view(np.uint64)) and np.array_equal(counts, g["a_counts"])
+    assert int(counts.sum()) > 500  # reads were used
+    if pyoracle.ref_available():
+        from tests.golden import make_golden_wide_groups as W
+        fresh = synth.allele_group_batch(12, np.random.default_rng(98), depth_mean=30.0, min_alt=9, max_alt=capi.MAX_ALT_XWIDE, missing_rate=0.02)
+        want_lh, want_counts = W.reference_lhoods(fresh)
+        lh, counts, _ = pyoracle.allele_group_genotype_lhoods(fresh)
+        assert np.array_equal(lh.view(np.uint64), want_lh.view(np.uint64)) and np.array_equal(counts, want_counts)
+
+
 def test_alignment_scores_match_reference(built):
     with open(os.path.join(GOLD, "patha_scores_reference.pkl"), "rb") as f:
         g = pickle.load(f)
