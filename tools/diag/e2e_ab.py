@@ -26,7 +26,8 @@ def main():
     L = 16000000 if somatic else 64000000
     d = (farm.wgs_somatic_dataset if somatic else farm.wgs_dataset)(L, *((40.0, 110.0) if somatic else (40.0,)))
     cores = farm.usable_cores()
-    P = len(cores)
+    P = int(os.environ.get("E2E_AB_PROCS", len(cores)))  # ($E2E_AB_PROCS=8 $E2E_AB_BROKER=0: eight callers with a GPU context each)
+    cores = cores[:P]
     groups = [[s] for s in farm.chrom_intervals(["chrW"], {"chrW": L}, L // P)]
     drop_in = "strelka2_amd" if somatic else "starling2_amd"
     outputs = ["somatic.snvs.vcf", "somatic.indels.vcf"] if somatic else ["variants.vcf", "genome.S1.vcf"]
@@ -47,7 +48,7 @@ def main():
                                           chrom_depth=os.path.join(d, "chrom_depth.txt"), skip_header=skip_header, evs_models=evs_models)
 
     root = tempfile.mkdtemp(prefix="e2e_ab_")
-    base = {"STRELKA_AMD_BROKER": "1"}
+    base = {"STRELKA_AMD_BROKER": os.environ.get("E2E_AB_BROKER", "1")}
     farm.run_farm(groups, argv_fn, os.path.join(root, "warm"), outputs, n_gpus=1, jobs=P, env=base, pin_cores=cores)  # page cache, broker up
     shutil.rmtree(os.path.join(root, "warm"))
     res = {name: [] for name, _ in settings}
