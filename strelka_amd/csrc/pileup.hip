@@ -589,13 +589,26 @@ __device__ __forceinline__ bool rec_selected(const unsigned rec, const int mode,
     }
 }
 
-// P2: one wave per 64 loci.  THREE = false: the column of a.mode; THREE = true: the raw tier1, raw tier2 and cleaned tier1 columns
-// (count3 / call_off3 / calls3, in that order) and the MAPQ tracker in the same walk over the records.
-template <bool THREE, bool SOM = false, bool EVS = false>
-__global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs a)
+// P2: 64 loci to a block, a lane a locus.  THREE = false: the column of a.mode; THREE = true: the raw tier1, raw tier2 and cleaned tier1
+// columns (count3 / call_off3 / calls3, in that order) and the MAPQ tracker in the same walk over the records.
+// A block is P2_WAVES waves that SHARE the walk: a wave takes one run of the reads that reach the block's loci (the reads [lo, hi) in
+// P2_WAVES consecutive pieces), so a locus' column is its lanes' pieces one after the other -- the count pass adds the waves' counts up,
+// the store pass counts its piece first (the same walk, nothing stored), starts its cursors behind the earlier waves' pieces and walks
+// again.  With one wave a window's two passes took 2 x 64 us of a push's 310 us on the device: a wave per 64 loci is 128 waves for a
+// window, each a chain of ~60 dependent record loads (profiles/r06_v49_stream_window_kernel_stats.csv).
+// A launch that fills the device anyway (the one-shot entry point at bench size: 61 000 blocks) keeps one wave to a block: the pieces'
+// extra quarter walk and the four searches are then work the device has no idle waves for (2.34 -> 2.90 ms with four).
+#ifndef SK_P2_WAVES
+#define SK_P2_WAVES 4 // (experiments: 2, 8)
+#endif
+constexpr int P2_WAVES_MAX = SK_P2_WAVES;
+constexpr int P2_SPLIT_BELOW_BLOCKS = 2048; // (8 waves to each of 256 CUs)
+template <bool THREE, bool SOM = false, bool EVS = false, int P2_WAVES = P2_WAVES_MAX>
+__global__ __launch_bounds__(WAVE* P2_WAVES) void pileup_column_kernel_t(const PileupArgs a)
 {
     static_assert(THREE || !(SOM || EVS), "the somatic / EVS columns extend the three-column form");
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int sub = __builtin_amdgcn_readfirstlane(int(threadIdx.x) / WAVE); // the wave's piece of the reads
     const int l0 = blockIdx.x * WAVE;
     const int l = l0 + lane;
     const int p0 = a.o.report_begin + l0;
@@ -621,8 +634,8 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
         }
         return y;
     };
-    const int lo = first_true(0, n, [&](const int m) { return a.maxend[m] > p0; });
-    const int hi = first_true(lo, n, [&](const int m) { return a.minbegin[m] >= p0 + WAVE; });
+    const int lo_all = first_true(0, n, [&](const int m) { return a.maxend[m] > p0; });
+    const int hi_all = first_true(lo_all, n, [&](const int m) { return a.minbegin[m] >= p0 + WAVE; });
     unsigned cnt = 0, cnt2 = 0, cnt3 = 0, cnt4a = 0, cnt4b = 0;
     unsigned mq_n = 0, mq_zero = 0;
     unsigned long long mq_sq = 0;
@@ -636,6 +649,10 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
     const int64_t base_e = (EVS && a.store && l < a.n_loci) ? a.evs_off[l] : 0;
     unsigned cnt_e = 0;
     const int parts = (!THREE && a.mode == SK_PILEUP_CLEAN_TIER2) ? 2 : 1;
+    // (the two-part column -- every read's first-part calls, then every read's second-part calls -- stays one wave's walk)
+    const int piece = (parts == 2) ? (hi_all - lo_all) : (hi_all - lo_all + P2_WAVES - 1) / P2_WAVES;
+    const int lo = (parts == 2) ? (sub == 0 ? lo_all : hi_all) : min(hi_all, lo_all + sub * piece);
+    const int hi = (parts == 2) ? hi_all : min(hi_all, lo + piece);
     const bool live = (l < a.n_loci);
     // store pass: the wave's 64 columns are one contiguous span of `calls`; it is assembled in LDS and written out with
     // consecutive stores (a lane storing 2 bytes every ~80 bytes costs a 32-byte memory transaction per call)
@@ -691,6 +708,8 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
         return (live && off >= 0) ? ro + off : int64_t(-1);
     };
     constexpr int RU = 8; // reads whose record loads are in flight together
+    // the wave's walk over its piece of the reads; store = false: only the counters move
+    auto walk = [&](const bool store) {
     for (int part = 0; part < parts; ++part) {
         for (int rb = lo; rb < hi; rb += WAVE) {
             // the lanes fetch the geometry of 64 reads at once (one memory round trip instead of one per read); the
@@ -741,10 +760,10 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
                         const uint16_t call = uint16_t(rc & 0x3fffu);
                         if (rc & REC_EMIT) {
                             if (rc & REC_TIER2) {
-                                if (a.store) a.calls3[1][base2 + cnt2] = call;
+                                if (store) a.calls3[1][base2 + cnt2] = call;
                                 ++cnt2;
                             } else {
-                                if (a.store) {
+                                if (store) {
                                     if (staged) s_col[lbase + cnt] = call;
                                     else calls_a[base + cnt] = call;
                                     if (SOM && a.read_pos) {
@@ -756,7 +775,7 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
                                 }
                                 ++cnt;
                                 if (!(rc & (1u << 12))) {
-                                    if (a.store) {
+                                    if (store) {
                                         if (staged) s_col3[lbase3 + cnt3] = call;
                                         else a.calls3[2][base3 + cnt3] = call;
                                     }
@@ -766,15 +785,15 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
                             if (SOM) { // the fourth column's two parts
                                 const bool t2 = rc & REC_TIER2, filt = rc & (1u << 12), tscf = rc & (1u << 13);
                                 if (!t2 && (!filt || tscf)) {
-                                    if (a.store) a.calls4[base4a + cnt4a] = call;
+                                    if (store) a.calls4[base4a + cnt4a] = call;
                                     ++cnt4a;
                                 } else if (t2 && !filt) {
-                                    if (a.store) a.calls4[base4b + cnt4b] = call;
+                                    if (store) a.calls4[base4b + cnt4b] = call;
                                     ++cnt4b;
                                 }
                             }
                         }
-                        if (EVS && a.store && ((rc & REC_EMIT) || rc == REC_SUBLIVE)) {
+                        if (EVS && store && ((rc & REC_EMIT) || rc == REC_SUBLIVE)) {
                             const int64_t ro_u = (int64_t(__builtin_amdgcn_readlane(int(ro_k >> 32), k0 + u)) << 32) |
                                                  uint32_t(__builtin_amdgcn_readlane(int(ro_k & 0xffffffff), k0 + u));
                             const unsigned len_u = unsigned(__builtin_amdgcn_readlane(len_k, k0 + u));
@@ -797,14 +816,14 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
                                        ((unsigned long long)cycle << 18) | ((unsigned long long)edge << 29));
                             ++cnt_e;
                         }
-                        if (!a.store && ((rc & REC_EMIT) || rc == REC_SUBLIVE)) { // MapqTracker::add (L/blt_common/MapqTracker.hh:36-42)
+                        if (!store && ((rc & REC_EMIT) || rc == REC_SUBLIVE)) { // MapqTracker::add (L/blt_common/MapqTracker.hh:36-42)
                             const unsigned mq = unsigned(__builtin_amdgcn_readlane(mapq_k, k0 + u));
                             ++mq_n;
                             mq_sq += (unsigned long long)(mq * mq);
                             mq_zero += (mq == 0u) ? 1u : 0u;
                         }
                     } else if (idx[u] >= 0 && rec_selected(rec[u], a.mode, part)) {
-                        if (a.store) {
+                        if (store) {
                             if (staged) s_col[lbase + cnt] = uint16_t(rec[u] & 0x3fffu);
                             else calls_a[base + cnt] = uint16_t(rec[u] & 0x3fffu);
                         }
@@ -813,6 +832,45 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
                 }
             }
         }
+    }
+    };
+    // the waves' counts meet in LDS: [counter][wave][lane]
+    __shared__ unsigned s_part[8][P2_WAVES][WAVE];
+    __shared__ unsigned long long s_part_sq[P2_WAVES][WAVE];
+    auto publish = [&]() {
+        s_part[0][sub][lane] = cnt; s_part[1][sub][lane] = cnt2; s_part[2][sub][lane] = cnt3; s_part[3][sub][lane] = cnt4a;
+        s_part[4][sub][lane] = cnt4b; s_part[5][sub][lane] = cnt_e; s_part[6][sub][lane] = mq_n; s_part[7][sub][lane] = mq_zero;
+        s_part_sq[sub][lane] = mq_sq;
+        __syncthreads();
+    };
+    if (P2_WAVES == 1) {
+        walk(a.store != 0);
+    } else if (!a.store) {
+        walk(false);
+        publish();
+        if (sub != 0) return;
+        cnt = cnt2 = cnt3 = cnt4a = cnt4b = cnt_e = mq_n = mq_zero = 0;
+        mq_sq = 0;
+#pragma unroll
+        for (int w = 0; w < P2_WAVES; ++w) {
+            cnt += s_part[0][w][lane]; cnt2 += s_part[1][w][lane]; cnt3 += s_part[2][w][lane]; cnt4a += s_part[3][w][lane];
+            cnt4b += s_part[4][w][lane]; cnt_e += s_part[5][w][lane]; mq_n += s_part[6][w][lane]; mq_zero += s_part[7][w][lane];
+            mq_sq += s_part_sq[w][lane];
+        }
+    } else {
+        // where this wave's piece of every column starts: behind the pieces of the waves before it
+        walk(false);
+        publish();
+        cnt = cnt2 = cnt3 = cnt4a = cnt4b = cnt_e = 0;
+#pragma unroll
+        for (int w = 0; w < P2_WAVES; ++w) {
+            if (w < sub) {
+                cnt += s_part[0][w][lane]; cnt2 += s_part[1][w][lane]; cnt3 += s_part[2][w][lane]; cnt4a += s_part[3][w][lane];
+                cnt4b += s_part[4][w][lane];
+                cnt_e += s_part[6][w][lane]; // (a locus has one EVS word per MAPQ-tracker entry: counted as mq_n when nothing is stored)
+            }
+        }
+        walk(true);
     }
     if (!a.store && l <= a.n_loci) {
         if (THREE) {
@@ -834,15 +892,13 @@ __global__ __launch_bounds__(WAVE) void pileup_column_kernel_t(const PileupArgs 
             a.count[l] = (l < a.n_loci) ? cnt : 0u;
         }
     }
-    if (a.store && staged) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (a.store && staged) { // (`staged` is the block's: every wave comes here)
+        __syncthreads();
         uint16_t* __restrict__ dst = calls_a + span0;
-        for (int i = lane; i < span_n; i += WAVE) dst[i] = s_col[i];
+        for (int i = int(threadIdx.x); i < span_n; i += WAVE * P2_WAVES) dst[i] = s_col[i];
         if (THREE) {
             uint16_t* __restrict__ dst3 = a.calls3[2] + span0c;
-            for (int i = lane; i < span_nc; i += WAVE) dst3[i] = s_col3[i];
+            for (int i = int(threadIdx.x); i < span_nc; i += WAVE * P2_WAVES) dst3[i] = s_col3[i];
         }
     }
 }
@@ -1094,7 +1150,8 @@ int sk_pileup_reads_dev(const sk_read_batch* b, const int64_t n_bases, const sk_
                                        std::make_reverse_iterator(d_minbegin + b->n_reads), size_t(b->n_reads), MinOp(), st));
     }
     const int blocks = (n_loci + 1 + WAVE - 1) / WAVE; // the extra locus carries the total through the scan
-    SK_LAUNCH(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE), 0, st, a);
+    if (blocks >= P2_SPLIT_BELOW_BLOCKS) SK_LAUNCH((pileup_column_kernel_t<false, false, false, 1>), dim3(blocks), dim3(WAVE), 0, st, a);
+    else SK_LAUNCH(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE * P2_WAVES_MAX), 0, st, a);
     tmp_bytes = size_t(L.tmp_bytes);
     SK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, a.count, out->call_off, int64_t(0), size_t(n_loci) + 1, rocprim::plus<int64_t>(), st));
     // capacity check needs the total on the host
@@ -1103,7 +1160,10 @@ int sk_pileup_reads_dev(const sk_read_batch* b, const int64_t n_bases, const sk_
     SK_HIP(skrt::streamSynchronize(st));
     if (total > out->capacity) return sk_fail("sk_pileup_reads_dev: calls capacity too small");
     a.store = 1;
-    if (total > 0) SK_LAUNCH(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE), 0, st, a);
+    if (total > 0) {
+        if (blocks >= P2_SPLIT_BELOW_BLOCKS) SK_LAUNCH((pileup_column_kernel_t<false, false, false, 1>), dim3(blocks), dim3(WAVE), 0, st, a);
+        else SK_LAUNCH(pileup_column_kernel_t<false>, dim3(blocks), dim3(WAVE * P2_WAVES_MAX), 0, st, a);
+    }
     SK_HIP(skrt::getLastError());
     return 0;
 }
@@ -1734,9 +1794,14 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
     }
     c.store = 0;
     const int blocks = (n_loci + 1 + WAVE - 1) / WAVE;
-    void (*const p2)(const PileupArgs) = som ? pileup_column_kernel_t<true, true, false>
-                                             : (s->want_evs ? pileup_column_kernel_t<true, false, true> : pileup_column_kernel_t<true, false, false>);
-    SK_LAUNCH(p2, dim3(blocks), dim3(WAVE), 0, st, c);
+    // (a stream's windows are a few thousand loci: the split form; a caller that pushes a whole region at once gets the one-wave form)
+    const bool split = blocks < P2_SPLIT_BELOW_BLOCKS;
+    const int p2_threads = split ? WAVE * P2_WAVES_MAX : WAVE;
+    void (*const p2)(const PileupArgs) =
+        split ? (som ? pileup_column_kernel_t<true, true, false> : (s->want_evs ? pileup_column_kernel_t<true, false, true> : pileup_column_kernel_t<true, false, false>))
+              : (som ? pileup_column_kernel_t<true, true, false, 1>
+                     : (s->want_evs ? pileup_column_kernel_t<true, false, true, 1> : pileup_column_kernel_t<true, false, false, 1>));
+    SK_LAUNCH(p2, dim3(blocks), dim3(p2_threads), 0, st, c);
     {
         // every column's offsets (exclusive sums of n_loci + 1 counts: the last entry is the total) and, in the same launch, the cleaned
         // columns' sizes for the caller's cache validation and the region-wide counters' slice
@@ -1770,7 +1835,7 @@ int stream_enqueue(sk_pileup_stream* s, const sk_read_batch* reads, const int32_
         SK_LAUNCH(column_offsets_kernel, dim3(oa.n_scans + oa.n_copies), dim3(1024), 0, st, oa);
     }
     c.store = 1;
-    if (n > 0 && n_loci > 0) SK_LAUNCH(p2, dim3(blocks), dim3(WAVE), 0, st, c);
+    if (n > 0 && n_loci > 0) SK_LAUNCH(p2, dim3(blocks), dim3(p2_threads), 0, st, c);
     lap(4); // P2 count, offsets, P2 store
     if (n_loci > 0 && (s->genotype || som)) {
         uint8_t* d_refbase = reinterpret_cast<uint8_t*>(dw + wl.refbase);
