@@ -49,7 +49,7 @@ namespace sk_adapter
 {
 
 /// extra distance of the READ_BUFFER stage behind HEAD / of the POST_ALIGN stage behind READ_BUFFER
-/// ($STRELKA_AMD_READ_WINDOW / $STRELKA_AMD_SITE_WINDOW, default 8192 positions / 512 with the pileup stream, else 4096)
+/// ($STRELKA_AMD_READ_WINDOW / $STRELKA_AMD_SITE_WINDOW, default 8192 positions / 1024 with the pileup stream, else 4096)
 unsigned read_buffer_defer();
 unsigned post_align_defer();
 /// the same, decided on first use from the options: a run whose genotypes come with the pileup stream (site 9) has nothing to batch at

@@ -54,10 +54,12 @@ unsigned post_align_defer(const starling_base_options& opt)
         else
         {
             // the genotypes come with the pileup stream's windows: POST_ALIGN is held back only by what hides a window's time on the
-            // device -- ~0.45 ms, ~400 head positions of read intake at 40x -- behind the stage machine's own work (the push is begun
-            // when READ_BUFFER reaches the window and finished when POST_ALIGN does: sk_adapter_pileup.cpp, pileup_complete_push)
+            // device -- ~0.45 ms alone, ~400 head positions of read intake at 40x; two to three times that when sixteen callers share
+            // the device -- behind the stage machine's own work (the push is begun when READ_BUFFER reaches the window and finished
+            // when POST_ALIGN does: sk_adapter_pileup.cpp, pileup_complete_push).  16 callers, interleaved: 256 / 512 / 1024 / 2048
+            // positions 9.67 / 9.31 / 9.12 / 9.01 s (profiles/r06_v54).
             const char* a(std::getenv("STRELKA_AMD_PUSH_ASYNC"));
-            g_postAlignDefer = (a == nullptr || *a == 0 || std::atoi(a) != 0) ? 512 : 0;
+            g_postAlignDefer = (a == nullptr || *a == 0 || std::atoi(a) != 0) ? 1024 : 0;
         }
     }
     return static_cast<unsigned>(g_postAlignDefer);

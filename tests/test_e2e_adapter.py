@@ -74,7 +74,7 @@ def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
     if windows == (1000, 3000):
         assert c["realign_jobs"] <= 10 and c["pileup_pushes"] <= 12
     if windows is None:  # (the site window that hides a pileup window's device time behind the stage machine: the push in two halves)
-        assert c["read_window"] == 8192 and c["site_window"] == 512
+        assert c["read_window"] == 8192 and c["site_window"] == 1024
 
 
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")

@@ -58,7 +58,8 @@ def main():
         for name, env in order:
             out = os.path.join(root, "%s_%d" % (name, r))
             fr = farm.run_farm(groups, argv_fn, out, outputs, n_gpus=1, jobs=P, env=dict(base, **env), pin_cores=cores)
-            body = b"".join(open(os.path.join(out, o), "rb").read() for o in outputs)
+            # (without the header lines that name the run: command line, start time, paths)
+            body = b"".join(b"\n".join(l for l in open(os.path.join(out, o), "rb").read().split(b"\n") if not l.startswith(b"##")) for o in outputs)
             digest.setdefault(name, set()).add(hash(body))
             rec = {"wall_s": fr.wall_s, "process_s": sum(fr.process_s), "user_s": sum(fr.user_s), "sys_s": sum(getattr(fr, "sys_s", []) or [0.0])}
             res[name].append(rec)
