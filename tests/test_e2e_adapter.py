@@ -412,10 +412,13 @@ def test_germline_with_evs_models_identical_through_adapter_gpu(tmp_path):
     assert c["pileup_pushes"] >= 10 and c["pileup_genotyping"] == 1
 
 
-def _two_sample_evs(variant, tmp_path, which):
+def _two_sample_evs(variant, tmp_path, which, windows=None):
     """two germline samples called jointly with EVS models (no feature report: the reference allows that for one sample only); the dense
     synthetic sets: indel clusters, MAPQ tiers, a coverage gap, long reads"""
     d, length = SYNTH_SETS[which]
+    env = {"STRELKA_AMD_VERBOSE": "1"}
+    if windows:
+        env["STRELKA_AMD_READ_WINDOW"], env["STRELKA_AMD_SITE_WINDOW"] = str(windows[0]), str(windows[1])
     models = _evs_models(tmp_path)
     outs = {}
     for v in ("ref", variant):
@@ -424,13 +427,14 @@ def _two_sample_evs(variant, tmp_path, which):
         p = E.run(E.germline_argv("starling2_" + v, o, [os.path.join(d, "germline_S1.bam"), os.path.join(d, "germline_S2.bam")],
                                   region="chrS:1-%d" % length, ref=os.path.join(d, "synth.fa"),
                                   extra=["--snv-scoring-model-file", models[0], "--indel-scoring-model-file", models[1]]),
-                  env={"STRELKA_AMD_VERBOSE": "1"} if v != "ref" else None)
+                  env=env if v != "ref" else None)
         outs[v] = ({f: E.vcf_body(o + f, keep_header=True) for f in ("variants.vcf", "genome.S1.vcf", "genome.S2.vcf")}, p.stderr.decode())
     assert len(outs["ref"][0]["variants.vcf"]) > 100
     for f in outs["ref"][0]:
         assert outs[variant][0][f] == outs["ref"][0][f], f
     c = _counters(outs[variant][1])
     assert c["pileup_pushes"] >= 4 and c["pileup_genotyping"] == 1
+    return c
 
 
 @pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
@@ -439,11 +443,28 @@ def test_two_sample_germline_with_evs_models_cpu_double(tmp_path, which):
     _two_sample_evs("dbl", tmp_path, which)
 
 
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
+@pytest.mark.parametrize("windows", [(300, 2500), (500, 4000)])
+def test_evs_words_outlive_their_output_block(tmp_path, windows):
+    """POST_ALIGN several pileup windows behind READ_BUFFER: a window's EVS words are still unread when the stream's output block comes
+    round again (three in rotation, strelka_amd.h SK_PILEUP_WINDOW_LIFETIME) -- the chunk takes its copy then, and the records are the
+    reference's all the same"""
+    c = _two_sample_evs("dbl", tmp_path, "short_reads", windows)
+    assert c["pileup_evs_words_copied"] > 0
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not (E.have("starling2_ref", "starling2_amd") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
 @pytest.mark.parametrize("which", ["short_reads", "long_reads"])
 def test_two_sample_germline_with_evs_models_gpu(tmp_path, which):
     _two_sample_evs("amd", tmp_path, which)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (E.have("starling2_ref", "starling2_amd") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
+def test_evs_words_outlive_their_output_block_gpu(tmp_path):
+    c = _two_sample_evs("amd", tmp_path, "short_reads", (300, 2500))
+    assert c["pileup_evs_words_copied"] > 0
 
 
 # ---- allele groups of a multi-sample run (tools/make_multiallelic_bam.py): four samples, each heterozygous for its own pair of
