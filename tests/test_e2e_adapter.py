@@ -78,7 +78,7 @@ def test_germline_demo_identical_through_adapter_cpu_double(tmp_path, windows):
 
 
 @pytest.mark.skipif(not E.have("starling2_ref", "starling2_dbl"), reason="oracle/_ref binaries not built")
-@pytest.mark.parametrize("windows", [None, (0, 0), (300, 7), (8192, 2000)])
+@pytest.mark.parametrize("windows", [None, (300, 7)])
 def test_germline_demo_identical_with_pushes_finished_at_once(tmp_path, windows):
     """STRELKA_AMD_PUSH_ASYNC=0: every pileup window begun and finished in one call (no site window by default)"""
     c = _germline("dbl", tmp_path, windows, extra_env={"STRELKA_AMD_PUSH_ASYNC": "0"})
@@ -183,7 +183,7 @@ def test_somatic_demo_identical_through_adapter_cpu_double(tmp_path, windows, ca
 
 @pytest.mark.skipif(not E.have("strelka2_ref", "strelka2_dbl"), reason="oracle/_ref binaries not built")
 @pytest.mark.parametrize("env", [{"STRELKA_AMD_PILEUP": "0"}, {"STRELKA_AMD_PILEUP_GENOTYPE": "0"}, {"STRELKA_AMD_LAZY_CLEAN": "0"},
-                                 {"STRELKA_AMD_PUSH_ASYNC": "0"}, {"STRELKA_AMD_PUSH_ASYNC": "0", "STRELKA_AMD_SITE_WINDOW": "900"}])
+                                 {"STRELKA_AMD_PUSH_ASYNC": "0", "STRELKA_AMD_SITE_WINDOW": "900"}])
 def test_somatic_demo_identical_with_reference_pileup_or_columns_only(tmp_path, env):
     """STRELKA_AMD_PUSH_ASYNC=0: the stream's pushes begun and finished in one call;
     STRELKA_AMD_PILEUP=0: the reference's pileup_read_segment, site 5 per site window from the host's copy of the columns;
@@ -444,7 +444,7 @@ def test_two_sample_germline_with_evs_models_cpu_double(tmp_path, which):
 
 
 @pytest.mark.skipif(not (E.have("starling2_ref", "starling2_dbl") and _have_synth()), reason="oracle/_ref binaries / synthetic sets not built")
-@pytest.mark.parametrize("windows", [(300, 2500), (500, 4000)])
+@pytest.mark.parametrize("windows", [(300, 2500)])
 def test_evs_words_outlive_their_output_block(tmp_path, windows):
     """POST_ALIGN several pileup windows behind READ_BUFFER: a window's EVS words are still unread when the stream's output block comes
     round again (three in rotation, strelka_amd.h SK_PILEUP_WINDOW_LIFETIME) -- the chunk takes its copy then, and the records are the
